@@ -1,0 +1,226 @@
+/*
+ * tf_fusion.h -- C ABI of the MI355X-native voxel-fusion + texture-atlas hot path.
+ *
+ * This is the drop-in boundary: the reference (THU-luvision/TextureFusion) has no FFI of its
+ * own; the "operator API" of the path is the public C++ surface of chisel::Chisel /
+ * ChunkManager / Atlas / Patch as called from GCFusion/MobileFusion.{h,cpp}.
+ * Each entry point below names the reference interface it stands in for (paths relative to
+ * the reference root).  The host-side C++ classes in texturefusion_amd/host/ keep the
+ * reference's class/method names and forward to these functions; INTEGRATION.md shows the
+ * binding a maintainer adds to the reference tree.
+ *
+ * Conventions
+ *   - plain C, opaque handle, POD arguments only; no exceptions cross the boundary.
+ *   - every function returns TF_OK (0) or a negative TF_ERR_* code; tf_last_error() gives the
+ *     text of the most recent failure on the calling thread.
+ *   - host pointers are borrowed for the duration of the call; outputs are caller-allocated
+ *     with a capacity and a count-out.
+ *   - one handle = one HIP stream; calls on a handle are serialised by the caller (the
+ *     reference drives the path from a single map thread, GCFusion/MobileFusion.cpp:99-112).
+ *   - poses are Eigen::Affine3f as 12 floats, row-major 3x4 [R | t] (camera-to-world).
+ *   - chunk ids are int32[3]; lists are int32[3*n], order = the reference's list order.
+ *   - there is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     TF_ERR_NO_DEVICE.
+ */
+#ifndef TF_FUSION_H_
+#define TF_FUSION_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define TF_API __attribute__((visibility("default")))
+#else
+#define TF_API
+#endif
+
+#define TF_OK 0
+#define TF_ERR_ATLAS_FULL (-1)    /* == Chisel::GeneratePatches' -1 (Structure/Chisel.cpp:170-173) */
+#define TF_ERR_INVALID (-2)       /* bad argument / call order */
+#define TF_ERR_CAPACITY (-3)      /* chunk pool, list or scratch capacity exceeded */
+#define TF_ERR_HIP (-4)           /* HIP runtime error */
+#define TF_ERR_NO_DEVICE (-5)     /* no gfx950 device visible */
+#define TF_ERR_MISSING_CHUNK (-6) /* list names a chunk that does not exist (chunks.at() would throw) */
+
+typedef struct tf_volume tf_volume;
+
+/* Sizing of the device-resident state (all allocated once, at create). 0 = default. */
+typedef struct {
+  int32_t device;        /* HIP device ordinal */
+  int64_t max_chunks;    /* chunk pool capacity (8 KiB of HBM each); default 1<<20 */
+  int64_t max_list;      /* max chunks in one visible-chunk list; default 1<<19 */
+  int64_t max_coarse;    /* max 4x4x4 candidate blocks per frame; default 1<<20 */
+  int32_t atlas_w;       /* default 13824 (Structure/Atlas.h:29) */
+  int32_t atlas_h;       /* default 13824 (Structure/Atlas.h:30) */
+  int32_t max_keyframes; /* keyframe image cache slots for the atlas; default 64 */
+  int32_t reserved;
+} tf_config;
+
+/* Counters of the most recent frame / list (device-side integers, read back on request). */
+typedef struct {
+  int64_t n_coarse;       /* candidate 4x4x4 blocks tested */
+  int64_t n_selected;     /* chunks in the visible list */
+  int64_t n_updated;      /* list entries whose needsUpdate flag is set */
+  int64_t rows_tsdf;      /* 8-voxel rows whose sdf/weight were rewritten by the last integrate */
+  int64_t rows_color;     /* 8-voxel rows whose colour was rewritten by the last integrate */
+  int64_t n_chunks;       /* chunks alive in the volume */
+  int64_t n_slots;        /* pool slots in use (alive + parked) */
+  int64_t n_dirty;        /* entries of meshesToUpdate */
+  int32_t min_id[3];      /* Chisel::minChunkID */
+  int32_t max_id[3];      /* Chisel::maxChunkID */
+} tf_stats;
+
+/* Per-kernel timings collected with HIP events on the handle's stream (tf_profile_*). */
+#define TF_PROF_BBOX 0
+#define TF_PROF_SELECT 1
+#define TF_PROF_SCAN 2
+#define TF_PROF_EMIT 3
+#define TF_PROF_INTEGRATE 4
+#define TF_PROF_FINALIZE 5
+#define TF_PROF_PATCH_PROJECT 6
+#define TF_PROF_ATLAS_BLIT 7
+#define TF_PROF_COUNT 8
+typedef struct {
+  double ms[TF_PROF_COUNT];       /* summed elapsed time per kernel */
+  int64_t launches[TF_PROF_COUNT];
+} tf_profile;
+
+TF_API const char* tf_last_error(void);
+TF_API int tf_device_count(void);
+
+/* ---- lifetime / parameters ---------------------------------------------------------
+ * Chisel::Chisel(chunkSize, voxelResolution, useColor)   Structure/Chisel.cpp:38-41
+ *   (+ ChunkManager ctor, Atlas ctor Structure/Atlas.cpp:32-41).  chunk_dim must be 8x8x8:
+ *   the reference kernel hard-codes 512-voxel chunks (ColorVoxel.h:31, Chisel.cpp:81-109). */
+TF_API int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color,
+                            const tf_config* cfg, tf_volume** out);
+TF_API int tf_volume_destroy(tf_volume* v);
+/* Chisel::Reset   Structure/Chisel.cpp:47-50 */
+TF_API int tf_volume_reset(tf_volume* v);
+/* Run on an externally owned hipStream_t (e.g. the caller framework's current stream). */
+TF_API int tf_set_stream(tf_volume* v, void* hip_stream);
+/* PinholeCamera::SetIntrinsics/SetWidth/SetHeight/SetNearPlane/SetFarPlane
+ *   3rd_party/open_chisel/camera/PinholeCamera.h:43-57; floats are stored as given and
+ *   truncated to int where the reference's int-returning getters do (:46-49). */
+TF_API int tf_set_camera(tf_volume* v, float fx, float fy, float cx, float cy, int width,
+                         int height, float near_plane, float far_plane);
+/* QuadraticTruncator(quadratic, linear, constant, scale)  truncation/QuadraticTruncator.h:33 */
+TF_API int tf_set_truncation(tf_volume* v, float quadratic, float linear, float constant,
+                             float scale);
+/* ConstantWeighter(weight)  weighting/ConstantWeighter.h:34 */
+TF_API int tf_set_weight(tf_volume* v, float weight);
+
+/* ---- frame images ------------------------------------------------------------------
+ * The reference passes raw cv::Mat data pointers into the path (MobileFusion.cpp:147-149).
+ * tf_frame_upload copies host images to HBM; tf_frame_bind_device borrows images that are
+ * already device-resident (valid until the next upload/bind).  rgba / quality may be NULL. */
+TF_API int tf_frame_upload(tf_volume* v, const float* depth, const uint8_t* rgba,
+                           const float* quality);
+TF_API int tf_frame_bind_device(tf_volume* v, const float* d_depth, const uint8_t* d_rgba,
+                                const float* d_quality);
+
+/* ---- the path, call by call (the reference's 10-argument flow) ----------------------
+ * Chisel::PrepareIntersectChunks   Structure/Chisel.h:103-140
+ *   -> chunksIntersecting (out_ids), newChunkFlag (out_new); needsUpdateFlag is all false. */
+TF_API int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint8_t* out_new,
+                      int64_t cap, int64_t* n);
+/* Chisel::IntegrateDepthScanColor (10-arg)   Structure/Chisel.h:218-249
+ *   integrate_flag 1 = integrate, 0 = de-integrate; keyframe_id / out_quality carry
+ *   chunk->observations[keyframeID] (host keeps the map; out_quality may be NULL).
+ *   use_color 0 = the call passes colorImage == NULL (depth-only local frames). */
+TF_API int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t n,
+                        int integrate_flag, int use_color, int use_quality,
+                        uint8_t* inout_needs_update, float* out_quality);
+/* Chisel::FinalizeIntegrateChunks + GarbageCollect   Structure/Chisel.h:184-216,472-477
+ *   out_valid receives validChunks (may be NULL). */
+TF_API int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update,
+                       const uint8_t* is_new, int64_t n, int32_t* out_valid, int64_t* n_valid);
+
+/* ---- the path, fused (the per-frame benchmark unit) ---------------------------------
+ * Chisel::IntegrateDepthScanColor (5-arg)   Structure/Chisel.h:453-468, as driven by
+ * MobileFusion::IntegrateFrame (GCFusion/MobileFusion.cpp:223-250): prepare -> integrate
+ * (flag 1, no keyframe id, no quality) -> finalize on the bound frame.  Asynchronous: no
+ * host synchronisation, nothing is copied back.  use_color 0 = rgb.empty() branch. */
+TF_API int tf_integrate_frame(tf_volume* v, const float pose[12], int use_color);
+/* Same, for a batch of device-resident frames (arrays of n device pointers / n poses). */
+TF_API int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* const* d_depth,
+                                      const uint8_t* const* d_rgba, const float* poses12);
+TF_API int tf_sync(tf_volume* v);
+
+/* ---- state access (host mirrors of Chunk::voxels / colors, ChunkManager queries) -----
+ * ChunkManager::HasChunk   Structure/ChunkManager.h:133-135 */
+TF_API int tf_has_chunk(tf_volume* v, const int32_t id[3], int* out);
+/* Chunk::voxels.sdf / .weight (DistVoxel.h:102-103), Chunk::colors.colorData
+ *   (ColorVoxel.h:66) in the reference's layouts: sdf[512], weight[512], color[512*4]. */
+TF_API int tf_chunk_download(tf_volume* v, const int32_t id[3], float* sdf, float* weight,
+                             uint16_t* color);
+TF_API int tf_chunks_download(tf_volume* v, const int32_t* ids, int64_t n, float* sdf,
+                              float* weight, uint16_t* color);
+/* creates the chunk if needed (ChunkManager::CreateChunk, ChunkManager.cpp:266-270) */
+TF_API int tf_chunk_upload(tf_volume* v, const int32_t id[3], const float* sdf,
+                           const float* weight, const uint16_t* color);
+/* ChunkManager::GetChunks() keys */
+TF_API int tf_list_chunks(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n);
+/* Chisel::meshesToUpdate (Structure/Chisel.h:489): keys with value true */
+TF_API int tf_list_dirty(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n);
+TF_API int tf_clear_dirty(tf_volume* v);
+TF_API int tf_get_stats(tf_volume* v, tf_stats* out);
+
+/* ---- measurement ------------------------------------------------------------------- */
+TF_API int tf_profile_enable(tf_volume* v, int on);
+TF_API int tf_profile_get(tf_volume* v, tf_profile* out, int reset);
+
+/* ---- multi-GPU chunk-range partition --------------------------------
+ * A rank owns chunks with lo <= id.x < hi; selection runs in full on every rank, integrate /
+ * finalize touch only owned chunks.  Boundary chunks (x == lo or x == hi-1, updated by the
+ * last integrate) are packed into / unpacked from a device buffer the caller all-gathers over
+ * RCCL.  Record = 16 B header {x,y,z,0} + 4 KiB {sdf,weight}[512] + 4 KiB colour[512][4]. */
+#define TF_BOUNDARY_RECORD_BYTES (16 + 4096 + 4096)
+TF_API int tf_set_partition(tf_volume* v, int32_t x_lo, int32_t x_hi);
+TF_API int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t* n);
+TF_API int tf_boundary_unpack(tf_volume* v, const void* d_records, int64_t n_records);
+
+/* ---- texture atlas ------------------------------------------------------------------
+ * Atlas / Patch (Structure/Atlas.{h,cpp}, Structure/Patch.{h,cpp}) as driven by
+ * Chisel::GeneratePatches / UpdateAtlas (Structure/Chisel.cpp:149-196).
+ *
+ * tf_keyframe_cache: the reference keeps Frame::rgb / refined_depth alive and Patch::SetImage
+ *   holds a non-owning ROI into it (Patch.cpp:172-175); here the keyframe's images are cached
+ *   in HBM under kf_id. rgb = u8[H][W][3], depth = f32[H][W]. */
+TF_API int tf_keyframe_cache(tf_volume* v, int32_t kf_id, const uint8_t* rgb, const float* depth);
+TF_API int tf_keyframe_cache_device(tf_volume* v, int32_t kf_id, const uint8_t* d_rgb,
+                                    const float* d_depth);
+TF_API int tf_keyframe_release(tf_volume* v, int32_t kf_id);
+/* Atlas::SetResolution  Structure/Atlas.h:62-65 */
+TF_API int tf_atlas_patch_size(tf_volume* v, int32_t* patch_w, int32_t* patch_h);
+/* Atlas::AddPatch  Structure/Atlas.cpp:43-64: first call for a chunk hands out the next slot
+ *   (TF_ERR_ATLAS_FULL = std::overflow_error); later calls keep the slot (Patch::clear). */
+TF_API int tf_atlas_add_patch(tf_volume* v, const int32_t id[3], uint64_t* texloc);
+/* Atlas::GetTexLoc / loc_next */
+TF_API int tf_atlas_loc_next(tf_volume* v, uint64_t* loc_next);
+/* Chisel::GeneratePatches + Chisel::UpdateAtlas for a batch of chunks
+ *   (Structure/Chisel.cpp:149-196): for patch p with vertices [voff[p], voff[p+1]):
+ *   AddPatch -> Patch::CalculateTexCoords(frame kf_ids[p]) (Patch.cpp:40-108) ->
+ *   Atlas::UpdateBuffer (Atlas.cpp:71-91).  pose_inv = f32(SE3d.inverse().matrix()), 16
+ *   floats row-major per patch.  Outputs (caller-allocated, may be NULL):
+ *   texcoord f32[2*nv], texcolor f32[3*nv], bbox i32[4*np] (x,y,w,h), flags i32[np]
+ *   (bit0 = CalculateTexCoords returned -1, bit1 = wrong_mapping), ratio f32[2*np],
+ *   texloc u64[np]; hot[2] = atlas.hot_start / hot_end.
+ *   Returns TF_ERR_ATLAS_FULL when the atlas overflows (GeneratePatches' -1). */
+TF_API int tf_patches_update(tf_volume* v, int64_t n_patches, const int32_t* ids,
+                             const int32_t* kf_ids, const float* pose_inv16,
+                             const int64_t* vert_offsets, const float* verts, const float* colors,
+                             float* out_texcoord, float* out_texcolor, int32_t* out_bbox,
+                             int32_t* out_flags, float* out_ratio, uint64_t* out_texloc,
+                             uint64_t out_hot[2]);
+/* Atlas::texture_buffer rows [row0,row1) (MobileFusion.h:406-421 uploads the hot rows) */
+TF_API int tf_atlas_download_rows(tf_volume* v, int64_t row0, int64_t row1, uint8_t* dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TF_FUSION_H_ */

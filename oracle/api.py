@@ -1,0 +1,392 @@
+"""ctypes binding of the CPU oracle (oracle/libtf_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never from texturefusion_amd/.  See oracle/tf_oracle.h for the parity
+status of the oracle itself.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtf_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = [os.path.join(_HERE, f) for f in ("tf_oracle.c", "tf_oracle.h", "Makefile")]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+class Camera(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("near_plane", C.c_float),
+                ("far_plane", C.c_float)]
+
+
+class Integrator(C.Structure):
+    _fields_ = [("quad", C.c_float), ("lin", C.c_float), ("cons", C.c_float),
+                ("scale", C.c_float), ("weight", C.c_float)]
+
+
+class RowStats(C.Structure):
+    _fields_ = [("rows_tsdf", C.c_int64), ("rows_color", C.c_int64),
+                ("chunks_updated", C.c_int64)]
+
+
+def default_integrator() -> Integrator:
+    # MobileFusion::initChiselMap, GCFusion/MobileFusion.h:215-228
+    return Integrator(np.float32(0.0019), np.float32(0.00152), np.float32(0.001504),
+                      np.float32(6.0), np.float32(1.0))
+
+
+def camera_from(cam) -> Camera:
+    return Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.near, cam.far)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    u8p = C.POINTER(C.c_uint8)
+    u16p = C.POINTER(C.c_uint16)
+    i32p = C.POINTER(C.c_int32)
+    i64p = C.POINTER(C.c_int64)
+    u64p = C.POINTER(C.c_uint64)
+    vp = C.c_void_p
+    L.tfo_truncation.restype = C.c_float
+    L.tfo_truncation.argtypes = [C.POINTER(Integrator), C.c_float]
+    L.tfo_centroids.argtypes = [fp, C.c_float, fp]
+    L.tfo_chunk_scalars.argtypes = [C.POINTER(Integrator), fp, i32p, C.c_float, fp, fp, fp]
+    L.tfo_voxel_update.restype = C.c_int
+    L.tfo_voxel_update.argtypes = [fp, u8p, fp, C.POINTER(Camera), C.POINTER(Integrator), fp,
+                                   C.c_int, i32p, C.c_float, fp, fp, fp, u16p, fp,
+                                   C.POINTER(RowStats)]
+    L.tfo_bbox.argtypes = [fp, C.POINTER(Camera), fp, C.c_float, i32p, i32p]
+    L.tfo_select.restype = C.c_int64
+    L.tfo_select.argtypes = [fp, C.POINTER(Camera), C.POINTER(Integrator), fp, C.c_float, i32p,
+                             C.c_int64, i64p]
+    L.tfo_volume_create.restype = vp
+    L.tfo_volume_create.argtypes = [C.c_float, C.c_int]
+    L.tfo_volume_destroy.argtypes = [vp]
+    L.tfo_volume_reset.argtypes = [vp]
+    L.tfo_volume_set_camera.argtypes = [vp, C.POINTER(Camera)]
+    L.tfo_volume_set_integrator.argtypes = [vp, C.POINTER(Integrator)]
+    L.tfo_volume_set_threads.argtypes = [vp, C.c_int]
+    L.tfo_volume_num_chunks.restype = C.c_int64
+    L.tfo_volume_num_chunks.argtypes = [vp]
+    L.tfo_volume_list_chunks.restype = C.c_int64
+    L.tfo_volume_list_chunks.argtypes = [vp, i32p, C.c_int64]
+    L.tfo_volume_has_chunk.argtypes = [vp, i32p]
+    L.tfo_volume_get_chunk.argtypes = [vp, i32p, fp, fp, u16p]
+    L.tfo_volume_set_chunk.argtypes = [vp, i32p, fp, fp, u16p]
+    L.tfo_volume_get_observations.restype = C.c_int64
+    L.tfo_volume_get_observations.argtypes = [vp, i32p, i32p, fp, C.c_int64]
+    L.tfo_volume_num_dirty.restype = C.c_int64
+    L.tfo_volume_num_dirty.argtypes = [vp]
+    L.tfo_volume_list_dirty.restype = C.c_int64
+    L.tfo_volume_list_dirty.argtypes = [vp, i32p, C.c_int64]
+    L.tfo_volume_clear_dirty.argtypes = [vp]
+    L.tfo_volume_get_rowstats.argtypes = [vp, C.POINTER(RowStats)]
+    L.tfo_volume_clear_rowstats.argtypes = [vp]
+    L.tfo_prepare.restype = C.c_int64
+    L.tfo_prepare.argtypes = [vp, fp, fp, i32p, u8p, C.c_int64]
+    L.tfo_integrate.restype = C.c_int
+    L.tfo_integrate.argtypes = [vp, fp, u8p, fp, fp, i32p, C.c_int64, C.c_int, C.c_int, u8p, fp]
+    L.tfo_finalize.restype = C.c_int64
+    L.tfo_finalize.argtypes = [vp, i32p, u8p, u8p, C.c_int64, i32p]
+    L.tfo_integrate_frame.restype = C.c_int64
+    L.tfo_integrate_frame.argtypes = [vp, fp, u8p, fp, i64p]
+    L.tfo_atlas_create.restype = vp
+    L.tfo_atlas_create.argtypes = [C.c_float, C.c_int, C.c_int]
+    L.tfo_atlas_destroy.argtypes = [vp]
+    L.tfo_atlas_patch_w.argtypes = [vp]
+    L.tfo_atlas_patch_h.argtypes = [vp]
+    L.tfo_atlas_alloc.argtypes = [vp, u64p]
+    L.tfo_atlas_loc_next.restype = C.c_uint64
+    L.tfo_atlas_loc_next.argtypes = [vp]
+    L.tfo_atlas_buffer.restype = C.POINTER(C.c_uint8)
+    L.tfo_atlas_buffer.argtypes = [vp]
+    L.tfo_patch_project.argtypes = [fp, fp, C.c_int64, fp, u8p, fp, C.POINTER(Camera), fp, fp,
+                                    i32p, C.POINTER(C.c_int), i64p]
+    L.tfo_atlas_blit.argtypes = [vp, C.c_uint64, u8p, C.c_int, C.c_int, i32p, fp]
+    L.tfo_atlas_hot_range.argtypes = [vp, u64p, C.c_int64, u64p, u64p]
+    _lib = L
+    return L
+
+
+def _p(a, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+def f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def truncation(ig: Integrator, z: float) -> float:
+    return float(lib().tfo_truncation(C.byref(ig), np.float32(z)))
+
+
+def centroids(pose, res) -> np.ndarray:
+    pose = f32(pose).reshape(12)
+    out = np.empty(3 * 512, np.float32)
+    lib().tfo_centroids(_p(pose, C.c_float), np.float32(res), _p(out, C.c_float))
+    return out.reshape(3, 512)
+
+
+def fresh_chunk():
+    return (np.full(512, 999.0, np.float32), np.zeros(512, np.float32), np.zeros(2048, np.uint16))
+
+
+def voxel_update(depth, rgba, quality, cam: Camera, ig: Integrator, pose, flag, cid, res,
+                 sdf, weight, color, cen=None):
+    """In-place update of (sdf, weight, color).  Returns (updated, quality, RowStats)."""
+    pose = f32(pose).reshape(12)
+    depth = f32(depth)
+    if cen is None:
+        cen = centroids(pose, res)
+    cen = f32(cen).reshape(-1)
+    cid = np.ascontiguousarray(cid, np.int32)
+    q = C.c_float(0)
+    st = RowStats()
+    upd = lib().tfo_voxel_update(_p(depth, C.c_float), _p(rgba, C.c_uint8), _p(quality, C.c_float),
+                                 C.byref(cam), C.byref(ig), _p(pose, C.c_float), int(flag),
+                                 _p(cid, C.c_int32), np.float32(res), _p(cen, C.c_float),
+                                 _p(sdf, C.c_float), _p(weight, C.c_float), _p(color, C.c_uint16),
+                                 C.byref(q), C.byref(st))
+    return bool(upd), q.value, st
+
+
+def bbox(depth, cam: Camera, pose, res):
+    pose = f32(pose).reshape(12)
+    depth = f32(depth)
+    mn = np.zeros(3, np.int32)
+    mx = np.zeros(3, np.int32)
+    lib().tfo_bbox(_p(depth, C.c_float), C.byref(cam), _p(pose, C.c_float), np.float32(res),
+                   _p(mn, C.c_int32), _p(mx, C.c_int32))
+    return mn, mx
+
+
+def select(depth, cam: Camera, ig: Integrator, pose, res, cap=1 << 18):
+    pose = f32(pose).reshape(12)
+    depth = f32(depth)
+    ids = np.zeros((cap, 3), np.int32)
+    nc = C.c_int64(0)
+    n = lib().tfo_select(_p(depth, C.c_float), C.byref(cam), C.byref(ig), _p(pose, C.c_float),
+                         np.float32(res), _p(ids, C.c_int32), cap, C.byref(nc))
+    if n > cap:
+        return select(depth, cam, ig, pose, res, cap=int(n))
+    return ids[:n].copy(), nc.value
+
+
+class Volume:
+    """Chisel + ChunkManager state of the oracle."""
+
+    def __init__(self, res, cam=None, ig=None, use_color=True):
+        self.L = lib()
+        self.res = np.float32(res)
+        self.h = self.L.tfo_volume_create(self.res, int(use_color))
+        if cam is not None:
+            self.set_camera(cam)
+        if ig is not None:
+            self.set_integrator(ig)
+
+    def close(self):
+        if self.h:
+            self.L.tfo_volume_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.L.tfo_volume_reset(self.h)
+
+    def set_camera(self, cam):
+        self.cam = cam if isinstance(cam, Camera) else camera_from(cam)
+        self.L.tfo_volume_set_camera(self.h, C.byref(self.cam))
+
+    def set_integrator(self, ig):
+        self.L.tfo_volume_set_integrator(self.h, C.byref(ig))
+
+    def set_threads(self, n):
+        self.L.tfo_volume_set_threads(self.h, int(n))
+
+    def num_chunks(self):
+        return int(self.L.tfo_volume_num_chunks(self.h))
+
+    def list_chunks(self):
+        n = self.num_chunks()
+        ids = np.zeros((max(n, 1), 3), np.int32)
+        self.L.tfo_volume_list_chunks(self.h, _p(ids, C.c_int32), n)
+        return ids[:n]
+
+    def has_chunk(self, cid):
+        cid = np.ascontiguousarray(cid, np.int32)
+        return bool(self.L.tfo_volume_has_chunk(self.h, _p(cid, C.c_int32)))
+
+    def get_chunk(self, cid):
+        cid = np.ascontiguousarray(cid, np.int32)
+        sdf, w, col = fresh_chunk()
+        r = self.L.tfo_volume_get_chunk(self.h, _p(cid, C.c_int32), _p(sdf, C.c_float),
+                                        _p(w, C.c_float), _p(col, C.c_uint16))
+        if r != 0:
+            raise KeyError(tuple(cid))
+        return sdf, w, col
+
+    def set_chunk(self, cid, sdf, w, col):
+        cid = np.ascontiguousarray(cid, np.int32)
+        self.L.tfo_volume_set_chunk(self.h, _p(cid, C.c_int32), _p(f32(sdf), C.c_float),
+                                    _p(f32(w), C.c_float),
+                                    _p(np.ascontiguousarray(col, np.uint16), C.c_uint16))
+
+    def observations(self, cid):
+        cid = np.ascontiguousarray(cid, np.int32)
+        kf = np.zeros(256, np.int32)
+        q = np.zeros(256, np.float32)
+        n = self.L.tfo_volume_get_observations(self.h, _p(cid, C.c_int32), _p(kf, C.c_int32),
+                                               _p(q, C.c_float), 256)
+        if n < 0:
+            raise KeyError(tuple(cid))
+        return {int(kf[i]): float(q[i]) for i in range(n)}
+
+    def dirty(self):
+        n = int(self.L.tfo_volume_num_dirty(self.h))
+        ids = np.zeros((max(n, 1), 3), np.int32)
+        self.L.tfo_volume_list_dirty(self.h, _p(ids, C.c_int32), n)
+        return ids[:n]
+
+    def clear_dirty(self):
+        self.L.tfo_volume_clear_dirty(self.h)
+
+    def rowstats(self, clear=False):
+        st = RowStats()
+        self.L.tfo_volume_get_rowstats(self.h, C.byref(st))
+        if clear:
+            self.L.tfo_volume_clear_rowstats(self.h)
+        return st
+
+    def prepare(self, depth, pose, cap=1 << 18):
+        depth = f32(depth)
+        pose = f32(pose).reshape(12)
+        ids = np.zeros((cap, 3), np.int32)
+        new = np.zeros(cap, np.uint8)
+        n = self.L.tfo_prepare(self.h, _p(depth, C.c_float), _p(pose, C.c_float),
+                               _p(ids, C.c_int32), _p(new, C.c_uint8), cap)
+        if n < 0:
+            raise RuntimeError("oracle prepare: list capacity exceeded (%d)" % -n)
+        return ids[:n].copy(), new[:n].copy()
+
+    def integrate(self, depth, rgba, quality, pose, ids, needs, flag=1, kf_id=-1):
+        depth = f32(depth)
+        pose = f32(pose).reshape(12)
+        ids = np.ascontiguousarray(ids, np.int32)
+        n = len(ids)
+        qout = np.zeros(max(n, 1), np.float32)
+        r = self.L.tfo_integrate(self.h, _p(depth, C.c_float), _p(rgba, C.c_uint8),
+                                 _p(quality, C.c_float), _p(pose, C.c_float), _p(ids, C.c_int32), n,
+                                 int(flag), int(kf_id), _p(needs, C.c_uint8), _p(qout, C.c_float))
+        if r != 0:
+            raise RuntimeError("oracle integrate: %d chunks missing" % -r)
+        return qout[:n]
+
+    def finalize(self, ids, needs, new):
+        ids = np.ascontiguousarray(ids, np.int32)
+        n = len(ids)
+        valid = np.zeros((max(n, 1), 3), np.int32)
+        nv = self.L.tfo_finalize(self.h, _p(ids, C.c_int32), _p(needs, C.c_uint8),
+                                 _p(new, C.c_uint8), n, _p(valid, C.c_int32))
+        return valid[:nv].copy()
+
+    def integrate_frame(self, depth, rgba, pose):
+        depth = f32(depth)
+        pose = f32(pose).reshape(12)
+        ns = C.c_int64(0)
+        nv = self.L.tfo_integrate_frame(self.h, _p(depth, C.c_float), _p(rgba, C.c_uint8),
+                                        _p(pose, C.c_float), C.byref(ns))
+        return int(nv), int(ns.value)
+
+
+class Atlas:
+    def __init__(self, res, w=0, h=0):
+        self.L = lib()
+        self.h = self.L.tfo_atlas_create(np.float32(res), w, h)
+        self.w = w or 13824
+        self.hh = h or 13824
+        self.pw = self.L.tfo_atlas_patch_w(self.h)
+        self.ph = self.L.tfo_atlas_patch_h(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.tfo_atlas_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def alloc(self):
+        t = C.c_uint64(0)
+        r = self.L.tfo_atlas_alloc(self.h, C.byref(t))
+        return r, int(t.value)
+
+    def loc_next(self):
+        return int(self.L.tfo_atlas_loc_next(self.h))
+
+    def buffer(self):
+        p = self.L.tfo_atlas_buffer(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.hh, self.w, 3))
+
+    def blit(self, texloc, rgb, bbox, ratio=None):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        bbox = np.ascontiguousarray(bbox, np.int32)
+        ratio = np.ones(2, np.float32) if ratio is None else f32(ratio)
+        r = self.L.tfo_atlas_blit(self.h, texloc, _p(rgb, C.c_uint8), rgb.shape[1], rgb.shape[0],
+                                  _p(bbox, C.c_int32), _p(ratio, C.c_float))
+        return r, ratio
+
+    def hot_range(self, texlocs):
+        t = np.ascontiguousarray(texlocs, np.uint64)
+        a = C.c_uint64(0)
+        b = C.c_uint64(0)
+        self.L.tfo_atlas_hot_range(self.h, _p(t, C.c_uint64), len(t), C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
+
+def patch_project(verts, colors, T, rgb, depth, cam: Camera):
+    verts = f32(verts).reshape(-1, 3)
+    colors = f32(colors).reshape(-1, 3)
+    n = len(verts)
+    T = f32(T).reshape(16)
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    depth = f32(depth)
+    tc = np.zeros((max(n, 1), 2), np.float32)
+    tcol = np.zeros((max(n, 1), 3), np.float32)
+    bb = np.zeros(4, np.int32)
+    wm = C.c_int(0)
+    nc = C.c_int64(0)
+    flag = lib().tfo_patch_project(_p(verts, C.c_float), _p(colors, C.c_float), n, _p(T, C.c_float),
+                                   _p(rgb, C.c_uint8), _p(depth, C.c_float), C.byref(cam),
+                                   _p(tc, C.c_float), _p(tcol, C.c_float), _p(bb, C.c_int32),
+                                   C.byref(wm), C.byref(nc))
+    return dict(flag=flag, texcoord=tc[:n], texcolor=tcol[:n], bbox=bb, wrong_mapping=bool(wm.value),
+                n_caution=int(nc.value))

@@ -1,0 +1,931 @@
+/*
+ * tf_oracle.c -- CPU restatement of the TextureFusion voxel-fusion + atlas-update hot path.
+ * TEST INFRASTRUCTURE ONLY; see tf_oracle.h for the parity status ("parity unpinned" apart
+ * from the SURVEY.md App. A.1-9 known answers and analytic KATs).
+ *
+ * Build: see oracle/Makefile (-O2 -ffp-contract=off, no fast-math, scalar SSE2 float).
+ */
+#include "tf_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------ */
+/* helpers                                                                              */
+/* ------------------------------------------------------------------------------------ */
+
+/* _mm256_cvtps_epi32 under default MXCSR: round-to-nearest-even; NaN / out of range ->
+ * 0x80000000 ("integer indefinite"). */
+static inline int32_t cvt_rne(float x) {
+  if (!(x >= -2147483648.0f && x < 2147483648.0f)) return INT32_MIN;
+  return (int32_t)lrintf(x);
+}
+
+#define R_(p, i, j) ((p)[4 * (i) + (j)])
+#define T_(p, i) ((p)[4 * (i) + 3])
+
+/* Fixed-size Eigen 3-vector dot in redux order a0*b0 + (a1*b1 + a2*b2) (Eigen's unrolled
+ * redux halves the range; order itself is unpinned). */
+static inline float dot3_tree(float a0, float a1, float a2, float b0, float b1, float b2) {
+  float p0 = a0 * b0, p1 = a1 * b1, p2 = a2 * b2;
+  float s = p1 + p2;
+  return p0 + s;
+}
+/* Dynamic (MatrixXf) product: sequential accumulation. */
+static inline float dot3_seq(float a0, float a1, float a2, float b0, float b1, float b2) {
+  float s = a0 * b0;
+  s = s + a1 * b1;
+  s = s + a2 * b2;
+  return s;
+}
+
+/* QuadraticTruncator::GetTruncationDistance (truncation/QuadraticTruncator.h:45-48):
+ * std::abs(q * pow(z, 2) + l * z + c) * s  with pow(float,int) -> double, l*z in float. */
+float tfo_truncation(const tfo_integrator* ig, float z) {
+  double zz = (double)z * (double)z;
+  float lz = ig->lin * z;
+  double v = (double)ig->quad * zz + (double)lz + (double)ig->cons;
+  return (float)(fabs(v) * (double)ig->scale);
+}
+
+/* Chisel::bufferIntegratorSIMDCentroids (Structure/Chisel.cpp:52-110):
+ * c[i] = (R^T * (x,y,z)) * res + res/2, i = (z*8+y)*8+x; half voxel added un-rotated. */
+void tfo_centroids(const float pose[12], float res, float cen[3 * TFO_CHUNK_VOXELS]) {
+  float half = res * 0.5f;
+  int i = 0;
+  for (int z = 0; z < 8; z++)
+    for (int y = 0; y < 8; y++)
+      for (int x = 0; x < 8; x++, i++) {
+        float fx = (float)x, fy = (float)y, fz = (float)z;
+        for (int a = 0; a < 3; a++) {
+          /* row a of R^T = column a of R */
+          float d = dot3_tree(R_(pose, 0, a), R_(pose, 1, a), R_(pose, 2, a), fx, fy, fz);
+          cen[a * TFO_CHUNK_VOXELS + i] = d * res + half;
+        }
+      }
+}
+
+/* Per-chunk scalars of voxelUpdateSIMD (utils/ProjectionIntegrator.cpp:74-101) and
+ * Chunk origin (geometry/Chunk.cpp:52). */
+void tfo_chunk_scalars(const tfo_integrator* ig, const float pose[12], const int id[3], float res,
+                       float origin_cam[3], float* truncation, float* weight) {
+  float o[3], d[3];
+  for (int a = 0; a < 3; a++) {
+    o[a] = (float)(8 * id[a]) * res;
+    d[a] = o[a] - T_(pose, a);
+  }
+  for (int a = 0; a < 3; a++)
+    origin_cam[a] = dot3_tree(R_(pose, 0, a), R_(pose, 1, a), R_(pose, 2, a), d[0], d[1], d[2]);
+  float tr = tfo_truncation(ig, origin_cam[2]);
+  *truncation = tr;
+  *weight = ig->weight / (2.0f * tr); /* ConstantWeighter.h:43-46 */
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K-A  ProjectionIntegrator::voxelUpdateSIMD (utils/ProjectionIntegrator.cpp:67-426)   */
+/* ------------------------------------------------------------------------------------ */
+int tfo_voxel_update(const float* depth, const uint8_t* rgba, const float* quality,
+                     const tfo_camera* cam, const tfo_integrator* ig, const float pose[12],
+                     int integrate_flag, const int id[3], float res,
+                     const float cen[3 * TFO_CHUNK_VOXELS], float* sdf, float* weight,
+                     uint16_t* color, float* quality_out, tfo_rowstats* stats) {
+  const float* c0 = cen;
+  const float* c1 = cen + TFO_CHUNK_VOXELS;
+  const float* c2 = cen + 2 * TFO_CHUNK_VOXELS;
+  float qsum = 0.0f;
+  int updated = 0;
+
+  const float resDiag = (float)(sqrt(3.0) * (double)res); /* :77 (double sqrt) */
+  const float fxi = (float)(int)cam->fx, fyi = (float)(int)cam->fy; /* :79-82, int getters */
+  const float cxi = (float)(int)cam->cx, cyi = (float)(int)cam->cy;
+  const int W = cam->width, H = cam->height;
+  float o[3], trunc, wD;
+  tfo_chunk_scalars(ig, pose, id, res, o, &trunc, &wD); /* :88-92 */
+  if (!integrate_flag) wD *= -1.0f;                      /* :95-99 */
+  const float thrCol = (float)((double)(resDiag / 2.0f) + 0.01); /* :101 */
+  const float nthrCol = -thrCol;
+  const float cxs = (float)((double)cxi + 0.5), cys = (float)((double)cyi + 0.5); /* :114-115 */
+  const float lower = (float)(-0.03);   /* :314 */
+  const float upper = trunc + resDiag;  /* :315 */
+  const float nearP = cam->near_plane, farP = cam->far_plane;
+  const float sigma = (float)1e-4;      /* :126 */
+
+  int pos = 0;
+  for (int it = 0; it < 64; it++) { /* z,y loops; x advances by 8 (:145-147) */
+    float pz[8], sd[8], dval[8];
+    int32_t X[8], Y[8], idx[8];
+    int valid[8], anyvalid = 0;
+    for (int l = 0; l < 8; l++) {
+      int k = 8 * pos + l;
+      float px = o[0] + c0[k];
+      float py = o[1] + c1[k];
+      pz[l] = o[2] + c2[k];
+      float u = (px / pz[l]) * fxi + cxs; /* :155-164: div, mul, add each rounded */
+      float v = (py / pz[l]) * fyi + cys;
+      X[l] = cvt_rne(u);
+      Y[l] = cvt_rne(v);
+      valid[l] = (X[l] > 0) && (W - 1 > X[l]) && (Y[l] > 0) && (H - 1 > Y[l]); /* :167-173 */
+      anyvalid |= valid[l];
+    }
+    if (!anyvalid) continue; /* :176-178: `continue` skips pos++ -> this row is re-tested forever */
+
+    for (int l = 0; l < 8; l++) {
+      idx[l] = (int32_t)((uint32_t)Y[l] * (uint32_t)W + (uint32_t)X[l]); /* :180-181 */
+      dval[l] = valid[l] ? depth[idx[l]] : 0.0f;                          /* :182-183 */
+      sd[l] = dval[l] - pz[l];                                            /* :191-192 */
+    }
+
+    if (rgba != NULL) { /* :201-306 */
+      int upd[8], anyupd = 0, oob = 0;
+      for (int l = 0; l < 8; l++) {
+        upd[l] = valid[l] && (sd[l] > nthrCol) && (thrCol > sd[l]); /* :202-208 */
+        anyupd |= upd[l];
+        oob |= (0 > X[l]) || (X[l] > W - 1) || (0 > Y[l]) || (Y[l] > H - 1); /* :212-220 */
+      }
+      if (oob) qsum = (float)(-99999999999.0); /* :221-222 (assignment, not accumulation) */
+      if (anyupd) {
+        if (quality != NULL) { /* :227-238 */
+          float sum = 0.0f;
+          for (int l = 0; l < 8; l++) sum += (upd[l] ? quality[idx[l]] : 0.0f);
+          qsum += sum;
+        }
+        for (int l = 0; l < 8; l++) { /* :250-304, all 8 voxels of the row are rewritten */
+          uint16_t* c = color + (size_t)(8 * pos + l) * 4;
+          uint16_t in[4] = {0, 0, 0, 0};
+          if (upd[l]) {
+            const uint8_t* p = rgba + (size_t)idx[l] * 4;
+            in[0] = p[0]; in[1] = p[1]; in[2] = p[2]; in[3] = p[3];
+          }
+          if (integrate_flag) {
+            uint16_t n[4];
+            for (int k = 0; k < 4; k++) n[k] = (uint16_t)(c[k] + in[k]);
+            if ((int16_t)n[3] > 120) /* :281-287: signed compare on the count channel */
+              for (int k = 0; k < 4; k++) n[k] = (uint16_t)(n[k] >> 2);
+            for (int k = 0; k < 4; k++) c[k] = n[k];
+          } else {
+            for (int k = 0; k < 4; k++) c[k] = (uint16_t)(c[k] - in[k]);
+          }
+        }
+        if (stats) stats->rows_color++;
+      }
+    }
+
+    int F[8], anyF = 0; /* :310-317 */
+    for (int l = 0; l < 8; l++) {
+      int dv = (dval[l] > nearP) && (farP > dval[l]);
+      int inside = (sd[l] > lower) && (upper > sd[l]);
+      F[l] = dv && inside;
+      anyF |= F[l];
+    }
+    if (anyF) { /* :319-341: all 8 lanes of the row are rewritten */
+      updated = 1;
+      for (int l = 0; l < 8; l++) {
+        int k = 8 * pos + l;
+        float w = weight[k], s = sdf[k];
+        float nw = F[l] ? wD : 0.0f;
+        float num = s * w + sd[l] * nw;
+        float den = (w + nw) + sigma;
+        float ns = num / den;
+        float nwt = w + nw;
+        if (nwt > 0.5f) { sdf[k] = ns; weight[k] = nwt; }
+        else { sdf[k] = 999.0f; weight[k] = 0.0f; }
+      }
+      if (stats) stats->rows_tsdf++;
+    }
+    pos++; /* :420 */
+  }
+  if (stats && updated) stats->chunks_updated++;
+  *quality_out = qsum; /* :424 */
+  return updated;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K-B  ChunkManager::findCubeCornerByMat / GetBoundaryChunkID / GetIDAt                */
+/*      (Structure/ChunkManager.h:303-378, 197-207)                                     */
+/* ------------------------------------------------------------------------------------ */
+void tfo_bbox(const float* depth, const tfo_camera* cam, const float pose[12], float res,
+              int min_id[3], int max_id[3]) {
+  const int W = cam->width, H = cam->height;
+  const float fx = (float)(int)cam->fx, fy = (float)(int)cam->fy;
+  const float cx = (float)(int)cam->cx, cy = (float)(int)cam->cy;
+  float mx[3] = {-1e8f, -1e8f, -1e8f}, mn[3] = {1e8f, 1e8f, 1e8f};
+  const float off = (float)0.2;
+  for (int i = 0; i < H; i++) {
+    float ly = ((float)i - cy) / fy;
+    for (int j = 0; j < W; j++) {
+      float dz = depth[(size_t)i * W + j] + off;
+      float lx = ((float)j - cx) / fx;
+      float vx = lx * dz, vy = ly * dz;
+      for (int a = 0; a < 3; a++) {
+        float p = R_(pose, a, 0) * vx;
+        p = p + R_(pose, a, 1) * vy;
+        p = p + R_(pose, a, 2) * dz;
+        p = p + T_(pose, a);
+        mx[a] = (p > mx[a]) ? p : mx[a]; /* _mm256_max_ps(p, max) */
+        mn[a] = (p < mn[a]) ? p : mn[a];
+      }
+    }
+  }
+  /* GetIDAt: floor(pos * (1.0f / (chunkSize * res))) */
+  const float f = 1.0f / (8.0f * res);
+  for (int a = 0; a < 3; a++) {
+    max_id[a] = (int)floorf(mx[a] * f);
+    min_id[a] = (int)floorf(mn[a] * f);
+  }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* K-C  ChunkManager::GetChunkIDsObservedByCamera + CheckCornerIntersectingSIMD         */
+/*      (Structure/ChunkManager.h:380-559, 561-636)                                     */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+  float fx, fy, cx, cy;
+  int W, H;
+  float nearP, farP;
+  const float* depth;
+} probe_ctx;
+
+static int probe8(const probe_ctx* pc, const float oc[3], float dtp, float dtn,
+                  const float off[3][8]) {
+  int valid[8], anyvalid = 0;
+  float pz[8];
+  int32_t idx[8];
+  const int depthValid = (oc[2] > pc->nearP) && (pc->farP > oc[2]); /* :598-602 */
+  for (int l = 0; l < 8; l++) {
+    float px = oc[0] + off[0][l];
+    float py = oc[1] + off[1][l];
+    pz[l] = oc[2] + off[2][l];
+    float u = (px / pz[l]) * pc->fx + pc->cx; /* :584-593, no +0.5 here */
+    float v = (py / pz[l]) * pc->fy + pc->cy;
+    int32_t X = cvt_rne(u), Y = cvt_rne(v);
+    valid[l] = (X > 1) && (pc->W - 1 > X) && (Y > 1) && (pc->H - 1 > Y); /* :603-609 */
+    anyvalid |= valid[l];
+    idx[l] = (int32_t)((uint32_t)Y * (uint32_t)pc->W + (uint32_t)X);
+  }
+  if (!anyvalid) return 0; /* :611-613 */
+  const float ndtn = -dtn;
+  int hit = 0;
+  for (int l = 0; l < 8; l++) {
+    float d = valid[l] ? pc->depth[idx[l]] : 0.0f;
+    float sd = d - pz[l];
+    int inside = (sd > ndtn) && (dtp > sd);
+    hit |= (valid[l] && inside && depthValid);
+  }
+  return hit;
+}
+
+int64_t tfo_select(const float* depth, const tfo_camera* cam, const tfo_integrator* ig,
+                   const float pose[12], float res, int32_t* ids, int64_t cap,
+                   int64_t* n_coarse_tested) {
+  int minID[3], maxID[3];
+  tfo_bbox(depth, cam, pose, res, minID, maxID); /* :395-396 (second full-image pass) */
+
+  float diag = 8.0f * res / 2.0f; /* :398 */
+  int step = 4;
+  float negTrunc = (float)0.03;
+  if ((double)res > 0.01) { /* :401-405 (float vs double literal) */
+    diag = (float)((double)(8.0f * res) * sqrt(3.0));
+    step = 1;
+    negTrunc = (float)(0.05 * (double)res / 0.005);
+  }
+  probe_ctx pc;
+  pc.fx = (float)(int)cam->fx; pc.fy = (float)(int)cam->fy;
+  pc.cx = (float)(int)cam->cx; pc.cy = (float)(int)cam->cy;
+  pc.W = cam->width; pc.H = cam->height;
+  pc.nearP = cam->near_plane; pc.farP = cam->far_plane;
+  pc.depth = depth;
+
+  /* rotation = R^T (MatrixXf), translation = rotation * t (:429-430) */
+  float rot[3][3], tc[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) rot[i][j] = R_(pose, j, i);
+  for (int i = 0; i < 3; i++)
+    tc[i] = dot3_seq(rot[i][0], rot[i][1], rot[i][2], T_(pose, 0), T_(pose, 1), T_(pose, 2));
+  float r0[3], r1[3], r2[3]; /* :431-436: columns scaled by 8 then res */
+  for (int i = 0; i < 3; i++) {
+    r0[i] = (rot[i][0] * 8.0f) * res;
+    r1[i] = (rot[i][1] * 8.0f) * res;
+    r2[i] = (rot[i][2] * 8.0f) * res;
+  }
+  const float half = res * 0.5f;
+  float coarse[3][8], fine[3][8]; /* :444-470 */
+  for (int x = 0; x < 2; x++)
+    for (int y = 0; y < 2; y++)
+      for (int z = 0; z < 2; z++) {
+        float cur[3] = {(float)(x * 8), (float)(y * 8), (float)(z * 8)};
+        int k = x + y * 2 + z * 4;
+        for (int a = 0; a < 3; a++) {
+          float d = dot3_seq(rot[a][0], rot[a][1], rot[a][2], cur[0], cur[1], cur[2]);
+          coarse[a][k] = (d * res) * (float)step + half;
+          fine[a][k] = (d * res) * 1.0f + half;
+        }
+      }
+
+  int64_t n = 0, ncoarse = 0;
+  for (int x = minID[0] - 1; x <= maxID[0] + 1; x += step) {
+    float ox[3];
+    for (int a = 0; a < 3; a++) ox[a] = r0[a] * (float)x - tc[a]; /* :473 */
+    for (int y = minID[1] - 1; y <= maxID[1] + 1; y += step) {
+      float oy[3];
+      for (int a = 0; a < 3; a++) oy[a] = ox[a] + r1[a] * (float)y; /* :475 */
+      for (int z = minID[2] - 1; z <= maxID[2] + 1; z += step) {
+        ncoarse++;
+        float oc[3];
+        for (int a = 0; a < 3; a++) oc[a] = oy[a] + (float)z * r2[a]; /* :479 */
+        float trunc = tfo_truncation(ig, oc[2]);
+        float dtp = trunc + diag * (float)step; /* :489-490 */
+        float dtn = negTrunc + diag * (float)step;
+        if (!probe8(&pc, oc, dtp, dtn, coarse)) continue;
+        for (int i = x; i < x + step; i++)
+          for (int j = y; j < y + step; j++)
+            for (int k = z; k < z + step; k++) {
+              float org[3] = {(float)(i * 8) * res, (float)(j * 8) * res, (float)(k * 8) * res};
+              float of[3];
+              for (int a = 0; a < 3; a++) /* :521-524 */
+                of[a] = dot3_seq(rot[a][0], rot[a][1], rot[a][2], org[0], org[1], org[2]) - tc[a];
+              float tr = tfo_truncation(ig, of[2]);
+              float fdtp = tr + diag;
+              float fdtn = negTrunc + diag;
+              if (probe8(&pc, of, fdtp, fdtn, fine)) {
+                if (n < cap) { ids[3 * n] = i; ids[3 * n + 1] = j; ids[3 * n + 2] = k; }
+                n++;
+              }
+            }
+      }
+    }
+  }
+  if (n_coarse_tested) *n_coarse_tested = ncoarse;
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* volume: ChunkManager's ChunkMap + Chisel::meshesToUpdate                              */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t kf;
+  float q;
+} tfo_obs;
+
+typedef struct {
+  int32_t id[3];
+  float* sdf;      /* [512]  DistVoxel.h:102-103, init 999 (Chunk.cpp:64) */
+  float* weight;   /* [512]  init 0 (Chunk.cpp:65) */
+  uint16_t* color; /* [2048] ColorVoxel.cpp:26-33, init 0 */
+  tfo_obs* obs;    /* Chunk::observations (std::map<int,float>), kept sorted by kf */
+  int n_obs, cap_obs;
+  int alive;
+} tfo_chunk;
+
+typedef struct {
+  int32_t* keys;  /* 3 per entry */
+  int64_t* vals;  /* -1 empty, -2 tombstone, else payload */
+  int64_t cap, used, live;
+} tfo_map;
+
+struct tfo_volume {
+  float res;
+  int use_color;
+  int nthreads;
+  tfo_camera cam;
+  tfo_integrator ig;
+  tfo_chunk* chunks;
+  int64_t n_chunks, cap_chunks;
+  int64_t* free_list;
+  int64_t n_free, cap_free;
+  tfo_map map;   /* ChunkID -> index in chunks[] */
+  tfo_map dirty; /* meshesToUpdate: ChunkID -> 1 */
+  tfo_rowstats stats;
+};
+
+static uint64_t hash3(const int32_t* k) { /* Teschner hash, ChunkManager.h:44-53 */
+  return ((uint64_t)(int64_t)k[0] * 73856093ull) ^ ((uint64_t)(int64_t)k[1] * 19349663ull) ^
+         ((uint64_t)(int64_t)k[2] * 83492791ull);
+}
+static void map_init(tfo_map* m, int64_t cap) {
+  m->cap = cap; m->used = 0; m->live = 0;
+  m->keys = (int32_t*)malloc(sizeof(int32_t) * 3 * cap);
+  m->vals = (int64_t*)malloc(sizeof(int64_t) * cap);
+  for (int64_t i = 0; i < cap; i++) m->vals[i] = -1;
+}
+static void map_free(tfo_map* m) { free(m->keys); free(m->vals); m->keys = NULL; m->vals = NULL; }
+static int64_t map_find(const tfo_map* m, const int32_t* k) {
+  uint64_t h = hash3(k) * 0x9E3779B97F4A7C15ull;
+  int64_t i = (int64_t)(h >> 17) & (m->cap - 1);
+  for (;;) {
+    if (m->vals[i] == -1) return -1;
+    if (m->vals[i] != -2 && m->keys[3 * i] == k[0] && m->keys[3 * i + 1] == k[1] &&
+        m->keys[3 * i + 2] == k[2])
+      return i;
+    i = (i + 1) & (m->cap - 1);
+  }
+}
+static void map_put_raw(tfo_map* m, const int32_t* k, int64_t v) {
+  uint64_t h = hash3(k) * 0x9E3779B97F4A7C15ull;
+  int64_t i = (int64_t)(h >> 17) & (m->cap - 1);
+  while (m->vals[i] >= 0) i = (i + 1) & (m->cap - 1);
+  if (m->vals[i] == -1) m->used++;
+  m->keys[3 * i] = k[0]; m->keys[3 * i + 1] = k[1]; m->keys[3 * i + 2] = k[2];
+  m->vals[i] = v;
+  m->live++;
+}
+static void map_grow(tfo_map* m) {
+  tfo_map n;
+  map_init(&n, (m->live * 4 > m->cap) ? m->cap * 2 : m->cap);
+  for (int64_t i = 0; i < m->cap; i++)
+    if (m->vals[i] >= 0) map_put_raw(&n, m->keys + 3 * i, m->vals[i]);
+  map_free(m);
+  *m = n;
+}
+static void map_put(tfo_map* m, const int32_t* k, int64_t v) {
+  int64_t i = map_find(m, k);
+  if (i >= 0) { m->vals[i] = v; return; }
+  if ((m->used + 1) * 2 > m->cap) map_grow(m);
+  map_put_raw(m, k, v);
+}
+static void map_erase(tfo_map* m, const int32_t* k) {
+  int64_t i = map_find(m, k);
+  if (i >= 0) { m->vals[i] = -2; m->live--; }
+}
+
+tfo_volume* tfo_volume_create(float res, int use_color) {
+  tfo_volume* v = (tfo_volume*)calloc(1, sizeof(tfo_volume));
+  v->res = res;
+  v->use_color = use_color;
+  v->nthreads = 1;
+  map_init(&v->map, 1 << 12);
+  map_init(&v->dirty, 1 << 12);
+  /* defaults of MobileFusion::initChiselMap (GCFusion/MobileFusion.h:205-258) */
+  v->ig.quad = 0.0019f; v->ig.lin = 0.00152f; v->ig.cons = 0.001504f; v->ig.scale = 6.0f;
+  v->ig.weight = 1.0f;
+  v->cam.width = 640; v->cam.height = 480;
+  v->cam.fx = 525.0f; v->cam.fy = 525.0f; v->cam.cx = 319.5f; v->cam.cy = 239.5f;
+  v->cam.near_plane = 0.01f; v->cam.far_plane = 5.0f;
+  return v;
+}
+static void chunk_release(tfo_chunk* c) {
+  free(c->sdf); free(c->weight); free(c->color); free(c->obs);
+  memset(c, 0, sizeof(*c));
+}
+void tfo_volume_reset(tfo_volume* v) { /* Chisel::Reset (Chisel.cpp:47-50) */
+  for (int64_t i = 0; i < v->n_chunks; i++)
+    if (v->chunks[i].alive) chunk_release(&v->chunks[i]);
+  v->n_chunks = 0; v->n_free = 0;
+  map_free(&v->map); map_free(&v->dirty);
+  map_init(&v->map, 1 << 12); map_init(&v->dirty, 1 << 12);
+  memset(&v->stats, 0, sizeof(v->stats));
+}
+void tfo_volume_destroy(tfo_volume* v) {
+  if (!v) return;
+  tfo_volume_reset(v);
+  map_free(&v->map); map_free(&v->dirty);
+  free(v->chunks); free(v->free_list);
+  free(v);
+}
+void tfo_volume_set_camera(tfo_volume* v, const tfo_camera* cam) { v->cam = *cam; }
+void tfo_volume_set_integrator(tfo_volume* v, const tfo_integrator* ig) { v->ig = *ig; }
+void tfo_volume_set_threads(tfo_volume* v, int n) { v->nthreads = n < 1 ? 1 : n; }
+int64_t tfo_volume_num_chunks(const tfo_volume* v) { return v->map.live; }
+int64_t tfo_volume_list_chunks(const tfo_volume* v, int32_t* ids, int64_t cap) {
+  int64_t n = 0;
+  for (int64_t i = 0; i < v->n_chunks; i++)
+    if (v->chunks[i].alive) {
+      if (n < cap) memcpy(ids + 3 * n, v->chunks[i].id, 12);
+      n++;
+    }
+  return n;
+}
+static tfo_chunk* vol_get(const tfo_volume* v, const int32_t* id) {
+  int64_t i = map_find(&v->map, id);
+  return i < 0 ? NULL : &v->chunks[v->map.vals[i]];
+}
+int tfo_volume_has_chunk(const tfo_volume* v, const int id[3]) { return vol_get(v, id) != NULL; }
+
+/* ChunkManager::CreateChunk (ChunkManager.cpp:266-270) + Chunk ctor (Chunk.cpp:38-76) */
+static tfo_chunk* vol_create_chunk(tfo_volume* v, const int32_t* id) {
+  int64_t slot;
+  if (v->n_free > 0) slot = v->free_list[--v->n_free];
+  else {
+    if (v->n_chunks == v->cap_chunks) {
+      v->cap_chunks = v->cap_chunks ? v->cap_chunks * 2 : 4096;
+      v->chunks = (tfo_chunk*)realloc(v->chunks, sizeof(tfo_chunk) * v->cap_chunks);
+    }
+    slot = v->n_chunks++;
+  }
+  tfo_chunk* c = &v->chunks[slot];
+  memset(c, 0, sizeof(*c));
+  memcpy(c->id, id, 12);
+  c->sdf = (float*)malloc(sizeof(float) * 512);
+  c->weight = (float*)malloc(sizeof(float) * 512);
+  c->color = (uint16_t*)calloc(2048, sizeof(uint16_t));
+  for (int i = 0; i < 512; i++) { c->sdf[i] = 999.0f; c->weight[i] = 0.0f; }
+  c->alive = 1;
+  map_put(&v->map, id, slot);
+  return c;
+}
+/* ChunkManager::RemoveChunk (ChunkManager.h:151-161) */
+static void vol_remove_chunk(tfo_volume* v, const int32_t* id) {
+  int64_t i = map_find(&v->map, id);
+  if (i < 0) return;
+  int64_t slot = v->map.vals[i];
+  chunk_release(&v->chunks[slot]);
+  map_erase(&v->map, id);
+  if (v->n_free == v->cap_free) {
+    v->cap_free = v->cap_free ? v->cap_free * 2 : 1024;
+    v->free_list = (int64_t*)realloc(v->free_list, sizeof(int64_t) * v->cap_free);
+  }
+  v->free_list[v->n_free++] = slot;
+}
+int tfo_volume_get_chunk(const tfo_volume* v, const int id[3], float* sdf, float* weight,
+                         uint16_t* color) {
+  tfo_chunk* c = vol_get(v, id);
+  if (!c) return -1;
+  if (sdf) memcpy(sdf, c->sdf, 512 * 4);
+  if (weight) memcpy(weight, c->weight, 512 * 4);
+  if (color) memcpy(color, c->color, 2048 * 2);
+  return 0;
+}
+int tfo_volume_set_chunk(tfo_volume* v, const int id[3], const float* sdf, const float* weight,
+                         const uint16_t* color) {
+  tfo_chunk* c = vol_get(v, id);
+  if (!c) c = vol_create_chunk(v, id);
+  if (sdf) memcpy(c->sdf, sdf, 512 * 4);
+  if (weight) memcpy(c->weight, weight, 512 * 4);
+  if (color) memcpy(c->color, color, 2048 * 2);
+  return 0;
+}
+static void chunk_set_obs(tfo_chunk* c, int kf, float q) { /* observations[kf] = q */
+  int i = 0;
+  while (i < c->n_obs && c->obs[i].kf < kf) i++;
+  if (i < c->n_obs && c->obs[i].kf == kf) { c->obs[i].q = q; return; }
+  if (c->n_obs == c->cap_obs) {
+    c->cap_obs = c->cap_obs ? c->cap_obs * 2 : 4;
+    c->obs = (tfo_obs*)realloc(c->obs, sizeof(tfo_obs) * c->cap_obs);
+  }
+  memmove(c->obs + i + 1, c->obs + i, sizeof(tfo_obs) * (c->n_obs - i));
+  c->obs[i].kf = kf; c->obs[i].q = q;
+  c->n_obs++;
+}
+int64_t tfo_volume_get_observations(const tfo_volume* v, const int id[3], int32_t* kf, float* q,
+                                    int64_t cap) {
+  tfo_chunk* c = vol_get(v, id);
+  if (!c) return -1;
+  for (int i = 0; i < c->n_obs && i < cap; i++) { kf[i] = c->obs[i].kf; q[i] = c->obs[i].q; }
+  return c->n_obs;
+}
+int64_t tfo_volume_num_dirty(const tfo_volume* v) { return v->dirty.live; }
+int64_t tfo_volume_list_dirty(const tfo_volume* v, int32_t* ids, int64_t cap) {
+  int64_t n = 0;
+  for (int64_t i = 0; i < v->dirty.cap; i++)
+    if (v->dirty.vals[i] >= 0) {
+      if (n < cap) memcpy(ids + 3 * n, v->dirty.keys + 3 * i, 12);
+      n++;
+    }
+  return n;
+}
+void tfo_volume_clear_dirty(tfo_volume* v) {
+  map_free(&v->dirty);
+  map_init(&v->dirty, 1 << 12);
+}
+void tfo_volume_get_rowstats(const tfo_volume* v, tfo_rowstats* out) { *out = v->stats; }
+void tfo_volume_clear_rowstats(tfo_volume* v) { memset(&v->stats, 0, sizeof(v->stats)); }
+
+/* Chisel::PrepareIntersectChunks (Structure/Chisel.h:103-140). */
+int64_t tfo_prepare(tfo_volume* v, const float* depth, const float pose[12], int32_t* ids,
+                    uint8_t* is_new, int64_t cap) {
+  /* :116 GetBoundaryChunkID fills min/maxChunkID; :124 selection recomputes the same bbox */
+  int64_t n = tfo_select(depth, &v->cam, &v->ig, pose, v->res, ids, cap, NULL);
+  if (n > cap) return -n;
+  for (int64_t i = 0; i < n; i++) { /* :130-138 */
+    int nw = 0;
+    if (!vol_get(v, ids + 3 * i)) { nw = 1; vol_create_chunk(v, ids + 3 * i); }
+    is_new[i] = (uint8_t)nw;
+  }
+  return n;
+}
+
+/* Chisel::IntegrateDepthScanColor 10-arg (Structure/Chisel.h:218-249).  The reference
+ * runs the chunk loop through chisel::parallel_for (threading/Threading.h:36-54); chunks are
+ * independent, so the thread count only affects timing (used for the CPU baseline). */
+int tfo_integrate(tfo_volume* v, const float* depth, const uint8_t* rgba, const float* quality,
+                  const float pose[12], const int32_t* ids, int64_t n, int integrate_flag,
+                  int keyframe_id, uint8_t* needs_update, float* quality_out) {
+  float cen[3 * TFO_CHUNK_VOXELS];
+  tfo_centroids(pose, v->res, cen); /* :226 */
+  if (n < 1) return 0;               /* :228 */
+  int missing = 0;
+  int64_t rt = 0, rc = 0, cu = 0;
+#pragma omp parallel for schedule(static) num_threads(v->nthreads) reduction(+ : missing, rt, rc, cu)
+  for (int64_t i = 0; i < n; i++) {
+    tfo_chunk* c = vol_get(v, ids + 3 * i);
+    if (!c) { missing++; continue; } /* reference: chunks.at() would throw */
+    float q = 0.0f;
+    tfo_rowstats st = {0, 0, 0};
+    int id[3] = {ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]};
+    int upd = tfo_voxel_update(depth, rgba, quality, &v->cam, &v->ig, pose, integrate_flag, id,
+                               v->res, cen, c->sdf, c->weight, c->color, &q, &st);
+    needs_update[i] = (uint8_t)(needs_update[i] || upd); /* :241 */
+    if (quality_out) quality_out[i] = q;
+    if (keyframe_id >= 0 && q > 0.0f && needs_update[i]) chunk_set_obs(c, keyframe_id, q); /* :244-247 */
+    rt += st.rows_tsdf; rc += st.rows_color; cu += st.chunks_updated;
+  }
+  v->stats.rows_tsdf += rt;
+  v->stats.rows_color += rc;
+  v->stats.chunks_updated += cu;
+  return missing ? -missing : 0;
+}
+
+/* Chisel::FinalizeIntegrateChunks + GarbageCollect (Structure/Chisel.h:184-216, 472-477) */
+int64_t tfo_finalize(tfo_volume* v, const int32_t* ids, const uint8_t* needs_update,
+                     const uint8_t* is_new, int64_t n, int32_t* valid_ids) {
+  static const int nb[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, -1, 0},
+                               {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+  int64_t nv = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (needs_update[i]) {
+      for (int k = 0; k < 7; k++) {
+        int32_t id[3] = {ids[3 * i] + nb[k][0], ids[3 * i + 1] + nb[k][1], ids[3 * i + 2] + nb[k][2]};
+        map_put(&v->dirty, id, 1);
+      }
+      if (valid_ids) memcpy(valid_ids + 3 * nv, ids + 3 * i, 12);
+      nv++;
+    }
+  }
+  for (int64_t i = 0; i < n; i++) /* garbage = new and not updated; erased after all marks */
+    if (!needs_update[i] && is_new[i]) {
+      vol_remove_chunk(v, ids + 3 * i);
+      map_erase(&v->dirty, ids + 3 * i);
+    }
+  return nv;
+}
+
+/* Chisel::IntegrateDepthScanColor 5-arg (Structure/Chisel.h:453-468) */
+int64_t tfo_integrate_frame(tfo_volume* v, const float* depth, const uint8_t* rgba,
+                            const float pose[12], int64_t* n_selected) {
+  int64_t cap = 1 << 16, n;
+  int32_t* ids = NULL;
+  uint8_t* is_new = NULL;
+  for (;;) {
+    ids = (int32_t*)malloc(sizeof(int32_t) * 3 * cap);
+    is_new = (uint8_t*)malloc(cap);
+    n = tfo_prepare(v, depth, pose, ids, is_new, cap);
+    if (n >= 0) break;
+    free(ids); free(is_new);
+    cap = -n + 16;
+  }
+  uint8_t* needs = (uint8_t*)calloc(n ? n : 1, 1);
+  tfo_integrate(v, depth, rgba, NULL, pose, ids, n, 1, -1, needs, NULL);
+  int64_t nv = tfo_finalize(v, ids, needs, is_new, n, NULL);
+  if (n_selected) *n_selected = n;
+  free(ids); free(is_new); free(needs);
+  return nv;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* atlas                                                                                */
+/* ------------------------------------------------------------------------------------ */
+struct tfo_atlas {
+  int aw, ah;
+  uint64_t pw, ph;
+  uint64_t loc_next;
+  uint8_t* buf;
+};
+
+tfo_atlas* tfo_atlas_create(float res, int atlas_w, int atlas_h) {
+  tfo_atlas* a = (tfo_atlas*)calloc(1, sizeof(tfo_atlas));
+  a->aw = atlas_w > 0 ? atlas_w : TFO_ATLAS_DIM;
+  a->ah = atlas_h > 0 ? atlas_h : TFO_ATLAS_DIM;
+  a->pw = (uint64_t)floor((double)(4800.0f * res)); /* Atlas.h:62-65: int*float, std::floor */
+  a->ph = (uint64_t)floor((double)(3600.0f * res));
+  a->buf = (uint8_t*)calloc((size_t)a->aw * a->ah, 3); /* Atlas.cpp:34-36 */
+  return a;
+}
+void tfo_atlas_destroy(tfo_atlas* a) { if (a) { free(a->buf); free(a); } }
+int tfo_atlas_patch_w(const tfo_atlas* a) { return (int)a->pw; }
+int tfo_atlas_patch_h(const tfo_atlas* a) { return (int)a->ph; }
+uint64_t tfo_atlas_loc_next(const tfo_atlas* a) { return a->loc_next; }
+uint8_t* tfo_atlas_buffer(tfo_atlas* a) { return a->buf; }
+
+/* Atlas::AddPatch, new-patch branch (Atlas.cpp:44-59).  texloc is assigned before the
+ * overflow test; on overflow the reference throws and loc_next is unchanged. */
+int tfo_atlas_alloc(tfo_atlas* a, uint64_t* texloc) {
+  *texloc = a->loc_next;
+  uint64_t x = a->loc_next % (uint64_t)a->aw;
+  uint64_t y = a->loc_next / (uint64_t)a->aw;
+  if (x >= (uint64_t)a->aw || y >= (uint64_t)a->ah) return -1;
+  if (x + a->pw >= (uint64_t)a->aw) { x = 0; y += a->ph; }
+  else x += a->pw;
+  a->loc_next = x + y * (uint64_t)a->aw;
+  return 0;
+}
+
+/* Patch::bilinear (Patch.cpp:110-145): note c2 reused where c4 belongs (:125-128). */
+static void rgb_at(const uint8_t* rgb, int W, int H, int y, int x, float c[3]) {
+  /* cv::Mat::at is unchecked pointer arithmetic; x==W reads the next row's first pixel.
+   * Reads past the allocation (undefined in the reference) return 0 here. */
+  int64_t i = (int64_t)y * W + x;
+  if (i < 0 || i >= (int64_t)W * H) { c[0] = c[1] = c[2] = 0.0f; return; }
+  c[0] = (float)rgb[3 * i]; c[1] = (float)rgb[3 * i + 1]; c[2] = (float)rgb[3 * i + 2];
+}
+static void bilinear_rgb(const uint8_t* rgb, int W, int H, float lx, float ly, float out[3]) {
+  int x = (int)floorf(lx), y = (int)floorf(ly);
+  float c1[3], c2[3], c3[3];
+  if (x < W - 1 && y < H - 1) {
+    rgb_at(rgb, W, H, y, x, c1); rgb_at(rgb, W, H, y, x + 1, c2); rgb_at(rgb, W, H, y + 1, x, c3);
+    float ax = (float)(x + 1) - lx, bx = lx - (float)x;
+    float ay = (float)(y + 1) - ly, by = ly - (float)y;
+    for (int k = 0; k < 3; k++) {
+      float t = (c1[k] * ax) * ay;
+      t = t + (c2[k] * bx) * ay;
+      t = t + (c3[k] * ax) * by;
+      t = t + (c2[k] * bx) * by;
+      out[k] = t;
+    }
+  } else if (x < W - 1 && y == H - 1) {
+    rgb_at(rgb, W, H, y, x, c1); rgb_at(rgb, W, H, y, x + 1, c2);
+    float ax = (float)(x + 1) - lx, bx = lx - (float)x;
+    for (int k = 0; k < 3; k++) out[k] = c1[k] * ax + c2[k] * bx;
+  } else if (x == W - 1 && y < H - 1) {
+    rgb_at(rgb, W, H, y, x, c1); rgb_at(rgb, W, H, y + 1, x, c2);
+    float ay = (float)(y + 1) - ly, by = ly - (float)y;
+    for (int k = 0; k < 3; k++) out[k] = c1[k] * ay + c2[k] * by;
+  } else {
+    rgb_at(rgb, W, H, y, x, out);
+  }
+}
+static float f_at(const float* img, int W, int H, int y, int x) {
+  int64_t i = (int64_t)y * W + x;
+  if (i < 0 || i >= (int64_t)W * H) return 0.0f;
+  return img[i];
+}
+/* Patch::bilinear_depth (Patch.cpp:147-170) */
+static float bilinear_f(const float* img, int W, int H, float lx, float ly) {
+  int x = (int)floorf(lx), y = (int)floorf(ly);
+  if (x < W - 1 && y < H - 1) {
+    float c1 = f_at(img, W, H, y, x), c2 = f_at(img, W, H, y, x + 1), c3 = f_at(img, W, H, y + 1, x);
+    float ax = (float)(x + 1) - lx, bx = lx - (float)x;
+    float ay = (float)(y + 1) - ly, by = ly - (float)y;
+    float t = (c1 * ax) * ay;
+    t = t + (c2 * bx) * ay;
+    t = t + (c3 * ax) * by;
+    t = t + (c2 * bx) * by;
+    return t;
+  } else if (x < W - 1 && y == H - 1) {
+    float c1 = f_at(img, W, H, y, x), c2 = f_at(img, W, H, y, x + 1);
+    return c1 * ((float)(x + 1) - lx) + c2 * (lx - (float)x);
+  } else if (x == W - 1 && y < H - 1) {
+    float c1 = f_at(img, W, H, y, x), c2 = f_at(img, W, H, y + 1, x);
+    return c1 * ((float)(y + 1) - ly) + c2 * (ly - (float)y);
+  }
+  return f_at(img, W, H, y, x);
+}
+
+/* Patch::CalculateTexCoords (Patch.cpp:40-108).  T = f32(SE3d inverse) row-major 4x4. */
+int tfo_patch_project(const float* verts, const float* colors, int64_t n_v, const float T[16],
+                      const uint8_t* rgb, const float* depth, const tfo_camera* cam,
+                      float* texcoord, float* texcolor, int32_t bbox[4], int* wrong_mapping,
+                      int64_t* n_caution) {
+  int flag = 0;
+  const int W = cam->width, H = cam->height;
+  const int fxi = (int)cam->fx, fyi = (int)cam->fy, cxi = (int)cam->cx, cyi = (int)cam->cy;
+  float minX = (float)W, maxX = 0.0f, minY = (float)H, maxY = 0.0f;
+  int64_t depth_cmp = 0, color_cmp = 0, ncau = 0;
+  for (int64_t i = 0; i < n_v; i++) {
+    const float* v = verts + 3 * i;
+    float vl[3];
+    for (int r = 0; r < 3; r++) { /* T * (v,1): column-sequential accumulation */
+      float s = T[4 * r] * v[0];
+      s = s + T[4 * r + 1] * v[1];
+      s = s + T[4 * r + 2] * v[2];
+      s = s + T[4 * r + 3] * 1.0f;
+      vl[r] = s;
+    }
+    float dist = vl[2];
+    float x = vl[0] / vl[2], y = vl[1] / vl[2];
+    float cX = (float)((double)(x * (float)fxi + (float)cxi) + 0.5); /* :55-56 */
+    float cY = (float)((double)(y * (float)fyi + (float)cyi) + 0.5);
+    if (cX < 0 || cX >= (float)W || cY < 0 || cY >= (float)H) { flag = -1; ncau++; }
+    if (cX < 0) cX = 0;
+    if (cX >= (float)W) cX = (float)W;
+    if (cY < 0) cY = 0;
+    if (cY >= (float)H) cY = (float)H;
+    texcoord[2 * i] = cX; texcoord[2 * i + 1] = cY;
+    minX = minX < cX ? minX : cX; maxX = maxX > cX ? maxX : cX;
+    minY = minY < cY ? minY : cY; maxY = maxY > cY ? maxY : cY;
+    float tc[3];
+    bilinear_rgb(rgb, W, H, cX, cY, tc);
+    for (int k = 0; k < 3; k++) { tc[k] = tc[k] / 255.0f; texcolor[3 * i + k] = tc[k]; }
+    float dpt = bilinear_f(depth, W, H, cX, cY);
+    float d0 = tc[0] - colors[3 * i], d1 = tc[1] - colors[3 * i + 1], d2 = tc[2] - colors[3 * i + 2];
+    float nrm = sqrtf(d0 * d0 + (d1 * d1 + d2 * d2));
+    if ((double)nrm > 0.6) color_cmp++;
+    if ((double)fabsf(dist - dpt) > 0.7) depth_cmp++;
+  }
+  *wrong_mapping = ((double)depth_cmp > 0.3 * (double)n_v) || ((double)color_cmp > 0.3 * (double)n_v);
+  if (maxX >= minX && maxY >= minY) {
+    /* cv::Rect(float...) truncates each argument; (a & b) intersection (:98-99) */
+    int ax = (int)(minX - 2.0f), ay = (int)(minY - 2.0f);
+    int aw = (int)(maxX - minX + 5.0f), ah = (int)(maxY - minY + 5.0f);
+    int x1 = ax > 0 ? ax : 0, y1 = ay > 0 ? ay : 0;
+    int x2 = (ax + aw) < (W - 1) ? (ax + aw) : (W - 1);
+    int y2 = (ay + ah) < (H - 1) ? (ay + ah) : (H - 1);
+    int w = x2 - x1, h = y2 - y1;
+    if (w <= 0 || h <= 0) { x1 = y1 = w = h = 0; }
+    bbox[0] = x1; bbox[1] = y1; bbox[2] = w; bbox[3] = h;
+    for (int64_t i = 0; i < n_v; i++) {
+      texcoord[2 * i] -= (float)x1;
+      texcoord[2 * i + 1] -= (float)y1;
+    }
+  } else {
+    bbox[0] = bbox[1] = bbox[2] = bbox[3] = 0;
+  }
+  if (n_caution) *n_caution = ncau;
+  return flag;
+}
+
+/* cv::resize(src, dst, dst.size()) for CV_8UC3, INTER_LINEAR (third-party arithmetic, not in
+ * the reference tree: OpenCV, README.md:87; restated from its published algorithm --
+ * PARITY UNPINNED): coordinates (dx+0.5)*scale-0.5, 11-bit coefficients, horizontal pass in
+ * int32, vertical pass ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2) >> 2. */
+static int cv_round(double v) { return (int)lrint(v); }
+static void resize_linear_8uc3(const uint8_t* src, int sstep, int sw, int sh, uint8_t* dst,
+                               int dstep, int dw, int dh) {
+  double inv_sx = (double)dw / sw, inv_sy = (double)dh / sh;
+  double scale_x = 1.0 / inv_sx, scale_y = 1.0 / inv_sy;
+  int* xofs = (int*)malloc(sizeof(int) * dw);
+  short* ialpha = (short*)malloc(sizeof(short) * 2 * dw);
+  int* rows0 = (int*)malloc(sizeof(int) * dw * 3);
+  int* rows1 = (int*)malloc(sizeof(int) * dw * 3);
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    xofs[dx] = sx;
+    ialpha[2 * dx] = (short)cv_round((double)((1.f - fx) * 2048.f));
+    ialpha[2 * dx + 1] = (short)cv_round((double)(fx * 2048.f));
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    int sy0 = sy, sy1 = sy + 1;
+    /* vertical border: indices clamped into the source, coefficients kept */
+    if (sy0 < 0) sy0 = 0; if (sy0 > sh - 1) sy0 = sh - 1;
+    if (sy1 < 0) sy1 = 0; if (sy1 > sh - 1) sy1 = sh - 1;
+    short b0 = (short)cv_round((double)((1.f - fy) * 2048.f));
+    short b1 = (short)cv_round((double)(fy * 2048.f));
+    const uint8_t* S0 = src + (size_t)sy0 * sstep;
+    const uint8_t* S1 = src + (size_t)sy1 * sstep;
+    for (int dx = 0; dx < dw; dx++) {
+      int sx = xofs[dx];
+      int sx1 = sx + 1 < sw ? sx + 1 : sx;
+      for (int k = 0; k < 3; k++) {
+        rows0[3 * dx + k] = S0[3 * sx + k] * ialpha[2 * dx] + S0[3 * sx1 + k] * ialpha[2 * dx + 1];
+        rows1[3 * dx + k] = S1[3 * sx + k] * ialpha[2 * dx] + S1[3 * sx1 + k] * ialpha[2 * dx + 1];
+      }
+    }
+    uint8_t* D = dst + (size_t)dy * dstep;
+    for (int x = 0; x < dw * 3; x++) {
+      int val = (((b0 * (rows0[x] >> 4)) >> 16) + ((b1 * (rows1[x] >> 4)) >> 16) + 2) >> 2;
+      D[x] = (uint8_t)(val < 0 ? 0 : (val > 255 ? 255 : val));
+    }
+  }
+  free(xofs); free(ialpha); free(rows0); free(rows1);
+}
+
+/* Atlas::UpdateBuffer (Atlas.cpp:71-91) with Patch::SetImage's ROI (Patch.cpp:172-175). */
+int tfo_atlas_blit(tfo_atlas* a, uint64_t texloc, const uint8_t* rgb, int img_w, int img_h,
+                   const int32_t bbox[4], float ratio[2]) {
+  (void)img_h;
+  int cols = bbox[2], rows = bbox[3];
+  uint64_t ox = texloc % (uint64_t)a->aw, oy = texloc / (uint64_t)a->aw;
+  if ((uint64_t)cols > a->pw) ratio[0] = (float)a->pw / (float)cols;
+  if ((uint64_t)rows > a->ph) ratio[1] = (float)a->ph / (float)rows;
+  size_t astep = (size_t)a->aw * 3;
+  const uint8_t* src = rgb + ((size_t)bbox[1] * img_w + bbox[0]) * 3;
+  if (cols <= 0 || rows <= 0) return 0;
+  if (ratio[0] < 1 || ratio[1] < 1) {
+    if (ox + a->pw > (uint64_t)a->aw || oy + a->ph > (uint64_t)a->ah) return -1;
+    resize_linear_8uc3(src, img_w * 3, cols, rows, a->buf + oy * astep + ox * 3, (int)astep,
+                       (int)a->pw, (int)a->ph);
+  } else {
+    if (ox + cols > (uint64_t)a->aw || oy + rows > (uint64_t)a->ah) return -1;
+    for (int r = 0; r < rows; r++)
+      memcpy(a->buf + (oy + r) * astep + ox * 3, src + (size_t)r * img_w * 3, (size_t)cols * 3);
+  }
+  return 0;
+}
+
+/* Chisel::GeneratePatches hot range (Chisel.cpp:153-186) */
+void tfo_atlas_hot_range(const tfo_atlas* a, const uint64_t* texlocs, int64_t n,
+                         uint64_t* hot_start, uint64_t* hot_end) {
+  uint64_t lo = (uint64_t)a->aw * (uint64_t)a->ah, hi = 0;
+  for (int64_t i = 0; i < n; i++) {
+    if (texlocs[i] < lo) lo = texlocs[i];
+    if (texlocs[i] > hi) hi = texlocs[i];
+  }
+  *hot_start = (lo / (uint64_t)a->aw) * (uint64_t)a->aw;
+  *hot_end = (hi / (uint64_t)a->aw + a->ph) * (uint64_t)a->aw;
+}

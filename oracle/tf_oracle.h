@@ -1,0 +1,146 @@
+/*
+ * tf_oracle.h -- CPU restatement ("oracle") of TextureFusion's per-frame voxel-fusion +
+ * texture-atlas-update hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load it.  The product path (texturefusion_amd/, include/)
+ * never links, imports or calls anything in oracle/.
+ *
+ * PARITY STATUS: "parity unpinned" except for the known-answer values recorded in
+ * SURVEY.md App. A.1-9 (outputs the survey observed from the reference's own translation
+ * unit) and analytic known-answer tests.  The reference has no tests / golden vectors of its
+ * own and cannot be built in this image: every file on the path needs Eigen,
+ * and the facade/atlas files also need OpenCV and Sophus, none of which are installed.  The
+ * rules of this build forbid making a reference build out of stand-in headers, so no
+ * oracle/_ref exists and no fixture in tests/golden/ was produced by reference code.
+ * Every function cites the reference file:line it restates (paths relative to the reference
+ * root).
+ *
+ * All arithmetic is scalar IEEE binary32/binary64 with every operation rounded separately
+ * (built with -ffp-contract=off, no fast-math), in the operation order of the reference
+ * build (-O3 -mavx2, no -mfma, no -ffast-math; CMakeLists.txt:57-58).
+ */
+#ifndef TF_ORACLE_H_
+#define TF_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFO_CHUNK_DIM 8
+#define TFO_CHUNK_VOXELS 512
+#define TFO_ATLAS_DIM 13824 /* Structure/Atlas.h:29-30: 96*72*2 */
+
+/* PinholeCamera (3rd_party/open_chisel/camera/PinholeCamera.h:36-77).  The float intrinsics
+ * are stored as given; every consumer sees them through the int-returning getters
+ * (PinholeCamera.h:46-49), i.e. truncated toward zero. */
+typedef struct {
+  int width, height;
+  float fx, fy, cx, cy;
+  float near_plane, far_plane;
+} tfo_camera;
+
+/* QuadraticTruncator (truncation/QuadraticTruncator.h:33-48) + ConstantWeighter weight
+ * (weighting/ConstantWeighter.h:34-46). */
+typedef struct {
+  float quad, lin, cons, scale;
+  float weight;
+} tfo_integrator;
+
+/* Row statistics of one voxel-update call: the integers SURVEY.md s.8(d) builds the
+ * algorithmic byte count from. */
+typedef struct {
+  int64_t rows_tsdf;  /* 8-voxel rows whose sdf/weight were rewritten */
+  int64_t rows_color; /* 8-voxel rows whose colour was rewritten */
+  int64_t chunks_updated;
+} tfo_rowstats;
+
+/* Pose = Eigen::Affine3f as 12 floats, row-major 3x4 [R | t]: R(i,j)=p[4*i+j], t(i)=p[4*i+3]. */
+
+/* ---- scalar pieces ---------------------------------------------------------------- */
+float tfo_truncation(const tfo_integrator* ig, float z);
+void tfo_centroids(const float pose[12], float res, float cen[3 * TFO_CHUNK_VOXELS]);
+void tfo_chunk_scalars(const tfo_integrator* ig, const float pose[12], const int id[3], float res,
+                       float origin_cam[3], float* truncation, float* weight);
+
+/* ---- K-A: one chunk, one frame ---------------------------------------------------- */
+int tfo_voxel_update(const float* depth, const uint8_t* rgba, const float* quality,
+                     const tfo_camera* cam, const tfo_integrator* ig, const float pose[12],
+                     int integrate_flag, const int id[3], float res,
+                     const float cen[3 * TFO_CHUNK_VOXELS], float* sdf, float* weight,
+                     uint16_t* color, float* quality_out, tfo_rowstats* stats);
+
+/* ---- K-B / K-C: visible-chunk selection ------------------------------------------- */
+void tfo_bbox(const float* depth, const tfo_camera* cam, const float pose[12], float res,
+              int min_id[3], int max_id[3]);
+/* returns the number of selected chunks (may exceed cap; only the first cap are written) */
+int64_t tfo_select(const float* depth, const tfo_camera* cam, const tfo_integrator* ig,
+                   const float pose[12], float res, int32_t* ids, int64_t cap,
+                   int64_t* n_coarse_tested);
+
+/* ---- volume (Chisel + ChunkManager state) ------------------------------------------ */
+typedef struct tfo_volume tfo_volume;
+tfo_volume* tfo_volume_create(float res, int use_color);
+void tfo_volume_destroy(tfo_volume* v);
+void tfo_volume_reset(tfo_volume* v);
+void tfo_volume_set_camera(tfo_volume* v, const tfo_camera* cam);
+void tfo_volume_set_integrator(tfo_volume* v, const tfo_integrator* ig);
+void tfo_volume_set_threads(tfo_volume* v, int nthreads);
+int64_t tfo_volume_num_chunks(const tfo_volume* v);
+int64_t tfo_volume_list_chunks(const tfo_volume* v, int32_t* ids, int64_t cap);
+int tfo_volume_has_chunk(const tfo_volume* v, const int id[3]);
+int tfo_volume_get_chunk(const tfo_volume* v, const int id[3], float* sdf, float* weight,
+                         uint16_t* color);
+int tfo_volume_set_chunk(tfo_volume* v, const int id[3], const float* sdf, const float* weight,
+                         const uint16_t* color);
+int64_t tfo_volume_get_observations(const tfo_volume* v, const int id[3], int32_t* kf,
+                                    float* q, int64_t cap);
+int64_t tfo_volume_num_dirty(const tfo_volume* v);
+int64_t tfo_volume_list_dirty(const tfo_volume* v, int32_t* ids, int64_t cap);
+void tfo_volume_clear_dirty(tfo_volume* v);
+void tfo_volume_get_rowstats(const tfo_volume* v, tfo_rowstats* out);
+void tfo_volume_clear_rowstats(tfo_volume* v);
+
+/* Chisel::PrepareIntersectChunks (Structure/Chisel.h:103-140) */
+int64_t tfo_prepare(tfo_volume* v, const float* depth, const float pose[12], int32_t* ids,
+                    uint8_t* is_new, int64_t cap);
+/* Chisel::IntegrateDepthScanColor, 10-arg (Structure/Chisel.h:218-249) */
+int tfo_integrate(tfo_volume* v, const float* depth, const uint8_t* rgba, const float* quality,
+                  const float pose[12], const int32_t* ids, int64_t n, int integrate_flag,
+                  int keyframe_id, uint8_t* needs_update, float* quality_out);
+/* Chisel::FinalizeIntegrateChunks (Structure/Chisel.h:184-216) */
+int64_t tfo_finalize(tfo_volume* v, const int32_t* ids, const uint8_t* needs_update,
+                     const uint8_t* is_new, int64_t n, int32_t* valid_ids);
+/* Chisel::IntegrateDepthScanColor, 5-arg (Structure/Chisel.h:453-468): the per-frame unit */
+int64_t tfo_integrate_frame(tfo_volume* v, const float* depth, const uint8_t* rgba,
+                            const float pose[12], int64_t* n_selected);
+
+/* ---- atlas (Structure/Atlas.{h,cpp}, Structure/Patch.cpp) -------------------------- */
+typedef struct tfo_atlas tfo_atlas;
+tfo_atlas* tfo_atlas_create(float res, int atlas_w, int atlas_h);
+void tfo_atlas_destroy(tfo_atlas* a);
+int tfo_atlas_patch_w(const tfo_atlas* a);
+int tfo_atlas_patch_h(const tfo_atlas* a);
+/* Atlas::AddPatch slot logic (Atlas.cpp:43-64): returns 0 and the texloc, or -1 on overflow */
+int tfo_atlas_alloc(tfo_atlas* a, uint64_t* texloc);
+uint64_t tfo_atlas_loc_next(const tfo_atlas* a);
+uint8_t* tfo_atlas_buffer(tfo_atlas* a);
+/* Patch::CalculateTexCoords (Patch.cpp:40-108) */
+int tfo_patch_project(const float* verts, const float* colors, int64_t n_v, const float T[16],
+                      const uint8_t* rgb, const float* depth, const tfo_camera* cam,
+                      float* texcoord, float* texcolor, int32_t bbox[4], int* wrong_mapping,
+                      int64_t* n_caution);
+/* Atlas::UpdateBuffer (Atlas.cpp:71-91); ratio[2] in/out */
+int tfo_atlas_blit(tfo_atlas* a, uint64_t texloc, const uint8_t* rgb, int img_w, int img_h,
+                   const int32_t bbox[4], float ratio[2]);
+/* hot row range, Chisel.cpp:153-186 */
+void tfo_atlas_hot_range(const tfo_atlas* a, const uint64_t* texlocs, int64_t n,
+                         uint64_t* hot_start, uint64_t* hot_end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TF_ORACLE_H_ */

@@ -1,0 +1,203 @@
+"""HIP path vs CPU oracle, through the C ABI, on identical seeded inputs.
+
+Bar (north_star): chunk / voxel indices, list order, flags and colour accumulators bit-exact; TSDF
+values within a stated float tolerance -- the tolerance used here is ZERO (bit-exact): the kernels
+round every operation exactly as the oracle does.
+"""
+import numpy as np
+import pytest
+
+from oracle import api as O
+from texturefusion_amd import synth
+from tests.util import RES5, RES10, assert_chunks_equal, make_pair, sorted_ids
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame_flow(ov, gv, depth, rgba, quality, pose, kf_id=-1, use_quality=False):
+    """prepare -> integrate -> finalize on both sides, compared after every call."""
+    oids, onew = ov.prepare(depth, pose)
+    gv.frame_upload(depth, rgba, quality)
+    gids, gnew = gv.prepare(pose)
+    assert np.array_equal(oids, gids), "visible-chunk list (ids or order) differs"
+    assert np.array_equal(onew, gnew), "newChunkFlag differs"
+    oneeds = np.zeros(len(oids), np.uint8)
+    gneeds = np.zeros(len(gids), np.uint8)
+    oq = ov.integrate(depth, rgba, quality if use_quality else None, pose, oids, oneeds, 1, kf_id)
+    gq = gv.integrate(pose, gids, gneeds, 1, rgba is not None, use_quality)
+    assert np.array_equal(oneeds, gneeds), "needsUpdateFlag differs"
+    if rgba is not None:
+        assert np.array_equal(oq.view(np.uint32), gq.view(np.uint32)), "chunkObservationQuality differs"
+    assert_chunks_equal(ov, gv, oids, "after integrate")
+    ovalid = ov.finalize(oids, oneeds, onew)
+    gvalid = gv.finalize(gids, gneeds, gnew)
+    assert np.array_equal(ovalid, gvalid), "validChunks differs"
+    return oids, oneeds, onew
+
+
+def test_wall_known_answer_chunk(gpu_required):
+    """SURVEY.md A.1-9 probe: chunk (0,0,24), wall at 1 m -- w = 17.676939, sdf = 0.0024999836, q = 48."""
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 12)
+    depth, rgba, quality, pose = synth.wall_frame(1.0, cam, hole_stride=0)
+    ids = np.array([[0, 0, 24], [0, -12, 24]], np.int32)
+    for cid in ids:
+        ov.set_chunk(cid, *O.fresh_chunk())
+        gv.set_chunk(cid, *O.fresh_chunk())
+    gv.frame_upload(depth, rgba, quality)
+    oneeds = np.zeros(2, np.uint8)
+    gneeds = np.zeros(2, np.uint8)
+    oq = ov.integrate(depth, rgba, quality, pose, ids, oneeds, 1, 3)
+    gq = gv.integrate(pose, ids, gneeds, 1, True, True)
+    assert list(gneeds) == [1, 0] and list(oneeds) == [1, 0]
+    assert gq[0] == np.float32(48.0) and oq[0] == np.float32(48.0)
+    s, w, c = gv.get_chunk(ids[0])
+    assert w.max() == np.float32(17.676939)
+    assert np.float32(0.0024999836) in s
+    assert_chunks_equal(ov, gv, ids)
+
+
+@pytest.mark.parametrize("res", [RES5, RES10])
+def test_wall_frames_full_flow(gpu_required, res):
+    ov, gv, cam, ig = make_pair(res, max_chunks=1 << 15)
+    depth, rgba, quality, pose = synth.wall_frame(1.5, cam)
+    for it in range(3):
+        _frame_flow(ov, gv, depth, rgba, quality, pose, kf_id=it, use_quality=True)
+    assert ov.num_chunks() == gv.stats().n_chunks
+    assert np.array_equal(sorted_ids(ov.list_chunks()), sorted_ids(gv.list_chunks()))
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+
+
+def test_room_stream_full_flow(gpu_required):
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 16)
+    for k in (0, 1, 2, 50):
+        depth, rgba, quality, pose = synth.room_frame(k, cam)
+        _frame_flow(ov, gv, depth, rgba, quality, pose, kf_id=k, use_quality=True)
+    assert np.array_equal(sorted_ids(ov.list_chunks()), sorted_ids(gv.list_chunks()))
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+    st = gv.stats()
+    ost = ov.rowstats()
+    assert st.n_chunks == ov.num_chunks()
+
+
+def test_fused_frame_matches_call_by_call(gpu_required):
+    """tf_integrate_frame (5-arg unit, asynchronous, device-resident list) == oracle's 5-arg unit."""
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 16)
+    for k in (0, 3, 6):
+        depth, rgba, quality, pose = synth.room_frame(k, cam)
+        ov.rowstats(clear=True)
+        nv, ns = ov.integrate_frame(depth, rgba, pose)
+        gv.frame_upload(depth, rgba, None)
+        gv.integrate_frame(pose, True)
+        gv.sync()
+        st = gv.stats()
+        ost = ov.rowstats()
+        assert st.n_selected == ns
+        assert st.n_updated == nv
+        assert st.rows_tsdf == ost.rows_tsdf and st.rows_color == ost.rows_color
+        assert st.n_chunks == ov.num_chunks()
+    ids = ov.list_chunks()
+    assert np.array_equal(sorted_ids(ids), sorted_ids(gv.list_chunks()))
+    assert_chunks_equal(ov, gv, ids, "fused")
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+
+
+def test_depth_only_and_deintegrate(gpu_required):
+    """Keyframe group: colour frame + depth-only local frames on one list, then de-integration (flag 0)."""
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 16)
+    depth, rgba, quality, pose = synth.room_frame(10, cam)
+    oids, onew = ov.prepare(depth, pose)
+    gv.frame_upload(depth, rgba, quality)
+    gids, gnew = gv.prepare(pose)
+    assert np.array_equal(oids, gids)
+    on = np.zeros(len(oids), np.uint8)
+    gn = np.zeros(len(oids), np.uint8)
+    ov.integrate(depth, rgba, quality, pose, oids, on, 1, 10)
+    gv.integrate(pose, gids, gn, 1, True, True)
+    for k in (11, 12):  # local frames: depth only, their own pose, same list (MobileFusion.cpp:187-203)
+        d2, _, _, p2 = synth.room_frame(k, cam)
+        ov.integrate(d2, None, None, p2, oids, on, 1, -1)
+        gv.frame_upload(d2, None, None)
+        gv.integrate(p2, gids, gn, 1, False, False)
+        assert np.array_equal(on, gn)
+    assert_chunks_equal(ov, gv, oids, "keyframe group")
+    ovalid = ov.finalize(oids, on, onew)
+    gvalid = gv.finalize(gids, gn, gnew)
+    assert np.array_equal(ovalid, gvalid)
+    # de-integrate the colour frame over its validChunks (MobileFusion.cpp:135-143)
+    on2 = np.ones(len(ovalid), np.uint8)
+    gn2 = np.ones(len(ovalid), np.uint8)
+    oq = ov.integrate(depth, rgba, quality, pose, ovalid, on2, 0, 10)
+    gv.frame_upload(depth, rgba, quality)
+    gq = gv.integrate(pose, gvalid, gn2, 0, True, True)
+    assert np.array_equal(oq.view(np.uint32), gq.view(np.uint32))
+    assert_chunks_equal(ov, gv, ovalid, "de-integrated")
+
+
+def test_colour_saturation_cap(gpu_required):
+    """Colour count never exceeds 120: 121 -> all four channels >> 2 (ProjectionIntegrator.cpp:281-287)."""
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 12)
+    depth, rgba, quality, pose = synth.wall_frame(1.0, cam, hole_stride=0, rgba_value=(255, 128, 7, 1))
+    cid = np.array([[0, 0, 24]], np.int32)
+    sdf, w, col = O.fresh_chunk()
+    col[:] = np.tile(np.array([119 * 255, 119 * 128, 119 * 7, 119], np.uint16), 512)
+    ov.set_chunk(cid[0], sdf, w, col)
+    gv.set_chunk(cid[0], sdf, w, col)
+    gv.frame_upload(depth, rgba, None)
+    for it in range(3):
+        on = np.zeros(1, np.uint8)
+        gn = np.zeros(1, np.uint8)
+        ov.integrate(depth, rgba, None, pose, cid, on, 1, -1)
+        gv.integrate(pose, cid, gn, 1, True, False)
+        assert_chunks_equal(ov, gv, cid, "saturation pass %d" % it)
+    _, _, c = gv.get_chunk(cid[0])
+    assert c.reshape(-1, 4)[:, 3].max() <= 120
+
+
+def test_rotated_poses_and_borders(gpu_required):
+    """Tilted cameras exercise off-image rows (the pos-stall quirk) and the out-of-observation quality."""
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 16)
+    for j, (yaw, pitch, roll) in enumerate([(0.35, 0.2, 0.1), (-0.6, -0.15, 0.3), (1.2, 0.05, -0.2)]):
+        depth, rgba, quality, _ = synth.room_frame(7 * j, cam)
+        pose = synth.pose_euler(yaw, pitch, roll, (0.1 * j, -0.05, 0.2))
+        _frame_flow(ov, gv, depth, rgba, quality, pose, kf_id=j, use_quality=True)
+
+
+def test_empty_depth_selects_nothing(gpu_required):
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 12)
+    depth = np.zeros((cam.height, cam.width), np.float32)
+    pose = synth.pose_identity()
+    oids, _ = ov.prepare(depth, pose)
+    gv.frame_upload(depth, None, None)
+    gids, _ = gv.prepare(pose)
+    assert len(oids) == 0 and len(gids) == 0
+    gv.integrate_frame(pose, False)
+    gv.sync()
+    assert gv.stats().n_chunks == 0
+
+
+def test_hires_camera(gpu_required):
+    cam = synth.Camera.hires()
+    ov, gv, cam, ig = make_pair(cam=cam, max_chunks=1 << 16)
+    depth, rgba, quality, pose = synth.room_frame(5, cam)
+    _frame_flow(ov, gv, depth, rgba, quality, pose, kf_id=5, use_quality=True)
+
+
+def test_missing_chunk_is_an_error(gpu_required):
+    from texturefusion_amd import capi
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 12)
+    depth, rgba, quality, pose = synth.wall_frame(1.0, cam)
+    gv.frame_upload(depth, rgba, None)
+    ids = np.array([[1000, 1000, 1000]], np.int32)
+    with pytest.raises(capi.TFError) as e:
+        gv.integrate(pose, ids, np.zeros(1, np.uint8), 1, True, False)
+    assert e.value.code == capi.TF_ERR_MISSING_CHUNK
+
+
+def test_pool_capacity_is_reported(gpu_required):
+    from texturefusion_amd import capi
+    ov, gv, cam, ig = make_pair(max_chunks=256)
+    depth, rgba, quality, pose = synth.wall_frame(1.5, cam)
+    gv.frame_upload(depth, rgba, None)
+    with pytest.raises(capi.TFError) as e:
+        gv.prepare(pose)
+    assert e.value.code == capi.TF_ERR_CAPACITY

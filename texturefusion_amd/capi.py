@@ -1,0 +1,368 @@
+"""ctypes binding of include/tf_fusion.h (texturefusion_amd/libtexfusion_hip.so).
+
+Plumbing only: every compute call goes through the C ABI into the hand-written gfx950 kernels.
+There is no fallback path -- a missing library raises ImportError, a missing GPU makes
+``Volume()`` raise :class:`TFError` (TF_ERR_NO_DEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtexfusion_hip.so")
+
+TF_OK = 0
+TF_ERR_ATLAS_FULL = -1
+TF_ERR_INVALID = -2
+TF_ERR_CAPACITY = -3
+TF_ERR_HIP = -4
+TF_ERR_NO_DEVICE = -5
+TF_ERR_MISSING_CHUNK = -6
+TF_BOUNDARY_RECORD_BYTES = 16 + 4096 + 4096
+
+PROF_NAMES = ("bbox", "select", "scan", "emit", "integrate", "finalize", "patch_project",
+              "atlas_blit")
+
+# every symbol include/tf_fusion.h declares (checked by tests/test_abi.py)
+SYMBOLS = (
+    "tf_last_error", "tf_device_count", "tf_volume_create", "tf_volume_destroy", "tf_volume_reset",
+    "tf_set_stream", "tf_set_camera", "tf_set_truncation", "tf_set_weight", "tf_frame_upload",
+    "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
+    "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
+    "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
+    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_set_partition", "tf_boundary_pack",
+    "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_release",
+    "tf_atlas_patch_size", "tf_atlas_add_patch", "tf_atlas_loc_next", "tf_patches_update",
+    "tf_atlas_download_rows",
+)
+
+
+class TFError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("tf error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_chunks", C.c_int64), ("max_list", C.c_int64),
+                ("max_coarse", C.c_int64), ("atlas_w", C.c_int32), ("atlas_h", C.c_int32),
+                ("max_keyframes", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_coarse", C.c_int64), ("n_selected", C.c_int64), ("n_updated", C.c_int64),
+                ("rows_tsdf", C.c_int64), ("rows_color", C.c_int64), ("n_chunks", C.c_int64),
+                ("n_slots", C.c_int64), ("n_dirty", C.c_int64), ("min_id", C.c_int32 * 3),
+                ("max_id", C.c_int32 * 3)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_int64 * 8)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (ImportError if it has not been built: run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "texturefusion_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, fp, u8p, u16p = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint16)
+    i32p, i64p, u64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
+    L.tf_last_error.restype = C.c_char_p
+    L.tf_device_count.restype = C.c_int
+    L.tf_volume_create.argtypes = [i32p, C.c_float, C.c_int, C.POINTER(Config), C.POINTER(vp)]
+    L.tf_volume_destroy.argtypes = [vp]
+    L.tf_volume_reset.argtypes = [vp]
+    L.tf_set_stream.argtypes = [vp, vp]
+    L.tf_set_camera.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int,
+                                C.c_float, C.c_float]
+    L.tf_set_truncation.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.tf_set_weight.argtypes = [vp, C.c_float]
+    L.tf_frame_upload.argtypes = [vp, fp, u8p, fp]
+    L.tf_frame_bind_device.argtypes = [vp, vp, vp, vp]
+    L.tf_prepare.argtypes = [vp, fp, i32p, u8p, C.c_int64, i64p]
+    L.tf_integrate.argtypes = [vp, fp, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, u8p, fp]
+    L.tf_finalize.argtypes = [vp, i32p, u8p, u8p, C.c_int64, i32p, i64p]
+    L.tf_integrate_frame.argtypes = [vp, fp, C.c_int]
+    L.tf_integrate_frames_device.argtypes = [vp, C.c_int64, C.POINTER(vp), C.POINTER(vp), fp]
+    L.tf_sync.argtypes = [vp]
+    L.tf_has_chunk.argtypes = [vp, i32p, C.POINTER(C.c_int)]
+    L.tf_chunk_download.argtypes = [vp, i32p, fp, fp, u16p]
+    L.tf_chunks_download.argtypes = [vp, i32p, C.c_int64, fp, fp, u16p]
+    L.tf_chunk_upload.argtypes = [vp, i32p, fp, fp, u16p]
+    L.tf_list_chunks.argtypes = [vp, i32p, C.c_int64, i64p]
+    L.tf_list_dirty.argtypes = [vp, i32p, C.c_int64, i64p]
+    L.tf_clear_dirty.argtypes = [vp]
+    L.tf_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.tf_profile_enable.argtypes = [vp, C.c_int]
+    L.tf_profile_get.argtypes = [vp, C.POINTER(Profile), C.c_int]
+    L.tf_set_partition.argtypes = [vp, C.c_int32, C.c_int32]
+    L.tf_boundary_pack.argtypes = [vp, vp, C.c_int64, i64p]
+    L.tf_boundary_unpack.argtypes = [vp, vp, C.c_int64]
+    L.tf_keyframe_cache.argtypes = [vp, C.c_int32, u8p, fp]
+    L.tf_keyframe_cache_device.argtypes = [vp, C.c_int32, vp, vp]
+    L.tf_keyframe_release.argtypes = [vp, C.c_int32]
+    L.tf_atlas_patch_size.argtypes = [vp, i32p, i32p]
+    L.tf_atlas_add_patch.argtypes = [vp, i32p, u64p]
+    L.tf_atlas_loc_next.argtypes = [vp, u64p]
+    L.tf_patches_update.argtypes = [vp, C.c_int64, i32p, i32p, fp, i64p, fp, fp, fp, fp, i32p, i32p,
+                                    fp, u64p, u64p]
+    L.tf_atlas_download_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p]
+    _lib = L
+    return L
+
+
+def _p(a, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+class Volume:
+    """Device-resident chunk volume + atlas behind one tf_volume handle."""
+
+    def __init__(self, res, cam=None, max_chunks=1 << 17, max_list=1 << 18, max_coarse=1 << 20,
+                 atlas_w=0, atlas_h=0, device=0, use_color=True, stream=None):
+        self.L = lib()
+        self.h = C.c_void_p()
+        cfg = Config(device, max_chunks, max_list, max_coarse, atlas_w, atlas_h, 0, 0)
+        dims = (C.c_int32 * 3)(8, 8, 8)
+        rc = self.L.tf_volume_create(dims, np.float32(res), int(use_color), C.byref(cfg), C.byref(self.h))
+        if rc != TF_OK:
+            self.h = None
+            raise TFError(rc, self.L.tf_last_error().decode())
+        self.res = np.float32(res)
+        if stream is not None:
+            self._ck(self.L.tf_set_stream(self.h, C.c_void_p(stream)))
+        if cam is not None:
+            self.set_camera(cam)
+
+    def _ck(self, rc):
+        if rc != TF_OK:
+            raise TFError(rc, self.L.tf_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.tf_volume_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters
+    def set_camera(self, cam):
+        self.cam = cam
+        self._ck(self.L.tf_set_camera(self.h, cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height,
+                                      cam.near, cam.far))
+
+    def set_truncation(self, q, l, c, s):
+        self._ck(self.L.tf_set_truncation(self.h, q, l, c, s))
+
+    def set_weight(self, w):
+        self._ck(self.L.tf_set_weight(self.h, w))
+
+    def reset(self):
+        self._ck(self.L.tf_volume_reset(self.h))
+
+    def set_partition(self, lo, hi):
+        self._ck(self.L.tf_set_partition(self.h, lo, hi))
+
+    # -- frames
+    def frame_upload(self, depth, rgba=None, quality=None):
+        depth = _f32(depth)
+        rgba = None if rgba is None else np.ascontiguousarray(rgba, np.uint8)
+        quality = None if quality is None else _f32(quality)
+        self._keep = (depth, rgba, quality)
+        self._ck(self.L.tf_frame_upload(self.h, _p(depth, C.c_float), _p(rgba, C.c_uint8),
+                                        _p(quality, C.c_float)))
+
+    def frame_bind_device(self, d_depth, d_rgba=0, d_quality=0):
+        self._ck(self.L.tf_frame_bind_device(self.h, C.c_void_p(d_depth), C.c_void_p(d_rgba or None),
+                                             C.c_void_p(d_quality or None)))
+
+    # -- the reference's call-by-call flow
+    def prepare(self, pose, cap=1 << 18):
+        pose = _f32(pose).reshape(12)
+        ids = np.zeros((cap, 3), np.int32)
+        new = np.zeros(cap, np.uint8)
+        n = C.c_int64(0)
+        self._ck(self.L.tf_prepare(self.h, _p(pose, C.c_float), _p(ids, C.c_int32), _p(new, C.c_uint8),
+                                   cap, C.byref(n)))
+        return ids[:n.value].copy(), new[:n.value].copy()
+
+    def integrate(self, pose, ids, needs, flag=1, use_color=True, use_quality=False):
+        pose = _f32(pose).reshape(12)
+        ids = np.ascontiguousarray(ids, np.int32)
+        n = len(ids)
+        q = np.zeros(max(n, 1), np.float32)
+        self._ck(self.L.tf_integrate(self.h, _p(pose, C.c_float), _p(ids, C.c_int32), n, int(flag),
+                                     int(use_color), int(use_quality), _p(needs, C.c_uint8),
+                                     _p(q, C.c_float)))
+        return q[:n]
+
+    def finalize(self, ids, needs, new):
+        ids = np.ascontiguousarray(ids, np.int32)
+        n = len(ids)
+        valid = np.zeros((max(n, 1), 3), np.int32)
+        nv = C.c_int64(0)
+        self._ck(self.L.tf_finalize(self.h, _p(ids, C.c_int32), _p(needs, C.c_uint8), _p(new, C.c_uint8),
+                                    n, _p(valid, C.c_int32), C.byref(nv)))
+        return valid[:nv.value].copy()
+
+    # -- fused per-frame unit
+    def integrate_frame(self, pose, use_color=True):
+        pose = _f32(pose).reshape(12)
+        self._ck(self.L.tf_integrate_frame(self.h, _p(pose, C.c_float), int(use_color)))
+
+    def integrate_frames_device(self, d_depths, d_rgbas, poses):
+        n = len(d_depths)
+        poses = _f32(poses).reshape(n, 12)
+        dd = (C.c_void_p * n)(*d_depths)
+        dr = None if d_rgbas is None else (C.c_void_p * n)(*d_rgbas)
+        self._ck(self.L.tf_integrate_frames_device(self.h, n, dd, dr, _p(poses, C.c_float)))
+
+    def sync(self):
+        self._ck(self.L.tf_sync(self.h))
+
+    # -- state access
+    def has_chunk(self, cid):
+        cid = np.ascontiguousarray(cid, np.int32)
+        out = C.c_int(0)
+        self._ck(self.L.tf_has_chunk(self.h, _p(cid, C.c_int32), C.byref(out)))
+        return bool(out.value)
+
+    def get_chunks(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        n = len(ids)
+        sdf = np.zeros((n, 512), np.float32)
+        w = np.zeros((n, 512), np.float32)
+        col = np.zeros((n, 2048), np.uint16)
+        self._ck(self.L.tf_chunks_download(self.h, _p(ids, C.c_int32), n, _p(sdf, C.c_float),
+                                           _p(w, C.c_float), _p(col, C.c_uint16)))
+        return sdf, w, col
+
+    def get_chunk(self, cid):
+        s, w, c = self.get_chunks(np.asarray(cid, np.int32).reshape(1, 3))
+        return s[0], w[0], c[0]
+
+    def set_chunk(self, cid, sdf, w, col):
+        cid = np.ascontiguousarray(cid, np.int32)
+        col = None if col is None else np.ascontiguousarray(col, np.uint16)
+        sdf = None if sdf is None else _f32(sdf)
+        w = None if w is None else _f32(w)
+        self._ck(self.L.tf_chunk_upload(self.h, _p(cid, C.c_int32), _p(sdf, C.c_float),
+                                        _p(w, C.c_float), _p(col, C.c_uint16)))
+
+    def _list(self, fn):
+        n = C.c_int64(0)
+        self._ck(fn(self.h, None, 0, C.byref(n)))
+        ids = np.zeros((max(n.value, 1), 3), np.int32)
+        self._ck(fn(self.h, _p(ids, C.c_int32), n.value, C.byref(n)))
+        return ids[:n.value]
+
+    def list_chunks(self):
+        return self._list(self.L.tf_list_chunks)
+
+    def dirty(self):
+        return self._list(self.L.tf_list_dirty)
+
+    def clear_dirty(self):
+        self._ck(self.L.tf_clear_dirty(self.h))
+
+    def stats(self):
+        st = Stats()
+        self._ck(self.L.tf_get_stats(self.h, C.byref(st)))
+        return st
+
+    # -- measurement
+    def profile_enable(self, on=True):
+        self._ck(self.L.tf_profile_enable(self.h, int(on)))
+
+    def profile_get(self, reset=True):
+        p = Profile()
+        self._ck(self.L.tf_profile_get(self.h, C.byref(p), int(reset)))
+        return {PROF_NAMES[i]: (p.ms[i], p.launches[i]) for i in range(len(PROF_NAMES))}
+
+    # -- multi-GPU boundary exchange
+    def boundary_pack(self, d_buf, cap):
+        n = C.c_int64(0)
+        self._ck(self.L.tf_boundary_pack(self.h, C.c_void_p(d_buf), cap, C.byref(n)))
+        return n.value
+
+    def boundary_unpack(self, d_buf, n):
+        self._ck(self.L.tf_boundary_unpack(self.h, C.c_void_p(d_buf), n))
+
+    # -- atlas
+    def keyframe_cache(self, kf_id, rgb, depth):
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        depth = _f32(depth)
+        self._ck(self.L.tf_keyframe_cache(self.h, kf_id, _p(rgb, C.c_uint8), _p(depth, C.c_float)))
+
+    def keyframe_cache_device(self, kf_id, d_rgb, d_depth):
+        self._ck(self.L.tf_keyframe_cache_device(self.h, kf_id, C.c_void_p(d_rgb), C.c_void_p(d_depth)))
+
+    def keyframe_release(self, kf_id):
+        self._ck(self.L.tf_keyframe_release(self.h, kf_id))
+
+    def atlas_patch_size(self):
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._ck(self.L.tf_atlas_patch_size(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def atlas_add_patch(self, cid):
+        cid = np.ascontiguousarray(cid, np.int32)
+        t = C.c_uint64(0)
+        rc = self.L.tf_atlas_add_patch(self.h, _p(cid, C.c_int32), C.byref(t))
+        return rc, t.value
+
+    def atlas_loc_next(self):
+        t = C.c_uint64(0)
+        self._ck(self.L.tf_atlas_loc_next(self.h, C.byref(t)))
+        return t.value
+
+    def patches_update(self, ids, kf_ids, pose_inv, voff, verts, colors):
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        np_ = len(ids)
+        kf_ids = np.ascontiguousarray(kf_ids, np.int32)
+        pose_inv = _f32(pose_inv).reshape(np_, 16)
+        voff = np.ascontiguousarray(voff, np.int64)
+        verts = _f32(verts).reshape(-1, 3)
+        colors = _f32(colors).reshape(-1, 3)
+        nv = len(verts)
+        tc = np.zeros((max(nv, 1), 2), np.float32)
+        tcol = np.zeros((max(nv, 1), 3), np.float32)
+        bbox = np.zeros((max(np_, 1), 4), np.int32)
+        flags = np.zeros(max(np_, 1), np.int32)
+        ratio = np.zeros((max(np_, 1), 2), np.float32)
+        texloc = np.zeros(max(np_, 1), np.uint64)
+        hot = np.zeros(2, np.uint64)
+        rc = self.L.tf_patches_update(self.h, np_, _p(ids, C.c_int32), _p(kf_ids, C.c_int32),
+                                      _p(pose_inv, C.c_float), _p(voff, C.c_int64), _p(verts, C.c_float),
+                                      _p(colors, C.c_float), _p(tc, C.c_float), _p(tcol, C.c_float),
+                                      _p(bbox, C.c_int32), _p(flags, C.c_int32), _p(ratio, C.c_float),
+                                      _p(texloc, C.c_uint64), _p(hot, C.c_uint64))
+        if rc == TF_ERR_ATLAS_FULL:
+            return dict(rc=rc)
+        self._ck(rc)
+        return dict(rc=rc, texcoord=tc[:nv], texcolor=tcol[:nv], bbox=bbox[:np_], flags=flags[:np_],
+                    ratio=ratio[:np_], texloc=texloc[:np_], hot=(int(hot[0]), int(hot[1])))
+
+    def atlas_rows(self, row0, row1, width):
+        out = np.zeros((row1 - row0, width, 3), np.uint8)
+        self._ck(self.L.tf_atlas_download_rows(self.h, row0, row1, _p(out, C.c_uint8)))
+        return out

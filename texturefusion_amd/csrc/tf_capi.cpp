@@ -1,0 +1,751 @@
+// tf_capi.cpp -- C ABI (include/tf_fusion.h) over the gfx950 kernels: volume lifetime, the
+// reference's prepare / integrate / finalize flow, the fused per-frame unit, state access.
+// Host code only; compiled with hipcc for the runtime API.  No CPU compute fallback exists.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <limits>
+
+#include "tf_host_math.h"
+#include "tf_volume.h"
+
+namespace tf {
+
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+
+static size_t pow2_at_least(size_t x) {
+  size_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+template <typename T>
+static int dev_alloc(tf_volume* v, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  if (e != hipSuccess) {
+    set_error(std::string("hipMalloc(") + std::to_string(count * sizeof(T)) + " B): " + hipGetErrorString(e));
+    return TF_ERR_HIP;
+  }
+  v->allocs.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return TF_OK;
+}
+
+int ensure_tmp(tf_volume* v, size_t bytes) {
+  if (bytes <= v->d_tmp_bytes) return TF_OK;
+  if (v->d_tmp) {
+    TF_HIP(hipStreamSynchronize(v->stream));
+    TF_HIP(hipFree(v->d_tmp));
+    v->d_tmp = nullptr;
+    v->d_tmp_bytes = 0;
+  }
+  size_t want = pow2_at_least(bytes);
+  TF_HIP(hipMalloc(&v->d_tmp, want));
+  v->d_tmp_bytes = want;
+  return TF_OK;
+}
+
+int ensure_pinned(tf_volume* v, size_t bytes) {
+  if (bytes <= v->h_pinned_bytes) return TF_OK;
+  if (v->h_pinned) {
+    TF_HIP(hipStreamSynchronize(v->stream));
+    TF_HIP(hipHostFree(v->h_pinned));
+    v->h_pinned = nullptr;
+    v->h_pinned_bytes = 0;
+  }
+  size_t want = pow2_at_least(bytes);
+  TF_HIP(hipHostMalloc(&v->h_pinned, want, hipHostMallocDefault));
+  v->h_pinned_bytes = want;
+  return TF_OK;
+}
+
+void prof_begin(tf_volume* v, int kind) {
+  if (!v->prof_on) return;
+  ProfEvent pe;
+  pe.kind = kind;
+  auto get = [&](hipEvent_t* e) {
+    if (!v->prof_pool.empty()) { *e = v->prof_pool.back(); v->prof_pool.pop_back(); }
+    else hipEventCreate(e);
+  };
+  get(&pe.a);
+  get(&pe.b);
+  hipEventRecord(pe.a, v->stream);
+  v->prof_events.push_back(pe);
+}
+void prof_end(tf_volume* v) {
+  if (!v->prof_on) return;
+  hipEventRecord(v->prof_events.back().b, v->stream);
+}
+
+static void prof_collect(tf_volume* v) {
+  for (auto& pe : v->prof_events) {
+    hipEventSynchronize(pe.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) {
+      v->prof_acc.ms[pe.kind] += ms;
+      v->prof_acc.launches[pe.kind] += 1;
+    }
+    v->prof_pool.push_back(pe.a);
+    v->prof_pool.push_back(pe.b);
+  }
+  v->prof_events.clear();
+}
+
+static void refresh_cam(tf_volume* v, int w, int h, float nearP, float farP) {
+  v->cam.W = w;
+  v->cam.H = h;
+  v->cam.fxi = (float)(int)v->fx;  // PinholeCamera::GetFx() returns int (PinholeCamera.h:46-49)
+  v->cam.fyi = (float)(int)v->fy;
+  v->cam.cxi = (float)(int)v->cx;
+  v->cam.cyi = (float)(int)v->cy;
+  v->cam.nearP = nearP;
+  v->cam.farP = farP;
+}
+
+static int status_to_error(uint32_t st) {
+  if (!st) return TF_OK;
+  std::string m = "device status:";
+  if (st & kStPoolFull) m += " chunk pool full (raise tf_config.max_chunks)";
+  if (st & kStListFull) m += " visible list full (raise tf_config.max_list)";
+  if (st & kStCoarseFull) m += " candidate grid full (raise tf_config.max_coarse)";
+  if (st & kStMissing) m += " list names a chunk that does not exist";
+  if (st & kStHashFull) m += " hash table full";
+  set_error(m);
+  if (st & kStMissing) return TF_ERR_MISSING_CHUNK;
+  return TF_ERR_CAPACITY;
+}
+
+// D2H of the control block (synchronises the stream), status -> error code, status cleared.
+static int fetch_ctl(tf_volume* v, FrameCtl* out) {
+  TF_HIP(hipMemcpyAsync(out, v->dev.ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  if (out->status) {
+    TF_HIP(hipMemsetAsync(&v->dev.ctl->status, 0, sizeof(uint32_t), v->stream));
+    return status_to_error(out->status);
+  }
+  return TF_OK;
+}
+
+static int init_device_state(tf_volume* v) {
+  VolumeDev& d = v->dev;
+  hipStream_t s = v->stream;
+  TF_HIP(hipMemsetAsync(d.hkeys, 0xFF, ((size_t)d.hmask + 1) * 8, s));
+  TF_HIP(hipMemsetAsync(d.hvals, 0xFF, ((size_t)d.hmask + 1) * 4, s));
+  TF_HIP(hipMemsetAsync(d.dkeys, 0xFF, ((size_t)d.dmask + 1) * 8, s));
+  TF_HIP(hipMemsetAsync(d.dstamp, 0, ((size_t)d.dmask + 1) * 4, s));
+  TF_HIP(hipMemsetAsync(d.alive, 0, d.max_chunks, s));
+  launch_reset_ctl(d, s);
+  launch_fill_pool(d, 0, d.max_chunks, s);
+  TF_HIP(hipGetLastError());
+  v->host_list_n = -1;
+  v->epoch = 0;
+  return TF_OK;
+}
+
+// The four kernels of Chisel::PrepareIntersectChunks (Structure/Chisel.h:103-140).
+static int launch_prepare(tf_volume* v, const Pose& pose) {
+  const SelectConsts sc = make_select_consts(pose.p, v->res);
+  prof_begin(v, TF_PROF_BBOX);
+  launch_bbox(v->dev, v->frame.depth, v->cam, pose, v->stream);
+  prof_end(v);
+  prof_begin(v, TF_PROF_SELECT);
+  launch_select(v->dev, v->frame.depth, v->cam, v->ig, pose, v->res, v->stream);
+  prof_end(v);
+  prof_begin(v, TF_PROF_SCAN);
+  launch_scan(v->dev, v->stream);
+  prof_end(v);
+  prof_begin(v, TF_PROF_EMIT);
+  launch_emit(v->dev, sc.step, v->stream);
+  prof_end(v);
+  return TF_OK;
+}
+
+// Make the device-resident list equal to the caller's list (upload + slot lookup if it is not
+// the list the last tf_prepare produced).
+static int sync_list(tf_volume* v, const int32_t* ids, int64_t n) {
+  if (n > (int64_t)v->dev.max_list) {
+    set_error("list longer than tf_config.max_list");
+    return TF_ERR_CAPACITY;
+  }
+  if (v->host_list_n == n && (n == 0 || memcmp(v->host_list.data(), ids, (size_t)n * 12) == 0))
+    return TF_OK;
+  int rc = ensure_pinned(v, (size_t)n * 16 + 16);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));  // pinned staging may still be in flight
+  int32_t* st = reinterpret_cast<int32_t*>(v->h_pinned);
+  for (int64_t i = 0; i < n; ++i) {
+    st[4 * i] = ids[3 * i];
+    st[4 * i + 1] = ids[3 * i + 1];
+    st[4 * i + 2] = ids[3 * i + 2];
+    st[4 * i + 3] = 0;
+  }
+  uint32_t* cnt = reinterpret_cast<uint32_t*>(st + 4 * n);
+  *cnt = (uint32_t)n;
+  if (n) TF_HIP(hipMemcpyAsync(v->dev.list_id, st, (size_t)n * 16, hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipMemcpyAsync(&v->dev.ctl->n_list, cnt, 4, hipMemcpyHostToDevice, v->stream));
+  if (n) {
+    TF_HIP(hipMemsetAsync(v->dev.list_new, 0, (size_t)n, v->stream));
+    TF_HIP(hipMemsetAsync(v->dev.list_needs, 0, (size_t)n, v->stream));
+  }
+  launch_lookup(v->dev, (uint32_t)n, v->stream);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipStreamSynchronize(v->stream));
+  v->host_list.assign(ids, ids + 3 * n);
+  v->host_list_n = n;
+  return TF_OK;
+}
+
+}  // namespace tf
+
+using namespace tf;
+
+extern "C" {
+
+const char* tf_last_error(void) { return g_err.c_str(); }
+
+int tf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color,
+                     const tf_config* cfg, tf_volume** out) {
+  if (!out || !chunk_dim) { set_error("null argument"); return TF_ERR_INVALID; }
+  *out = nullptr;
+  if (chunk_dim[0] != 8 || chunk_dim[1] != 8 || chunk_dim[2] != 8) {
+    set_error("chunk size must be 8x8x8 (the reference kernel hard-codes 512-voxel chunks)");
+    return TF_ERR_INVALID;
+  }
+  if (!(resolution > 0.f)) { set_error("resolution must be positive"); return TF_ERR_INVALID; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device visible: this library has no CPU fallback");
+    return TF_ERR_NO_DEVICE;
+  }
+  tf_volume* v = new tf_volume();
+  memset(&v->cfg, 0, sizeof(v->cfg));
+  if (cfg) v->cfg = *cfg;
+  if (v->cfg.max_chunks <= 0) v->cfg.max_chunks = 1ll << 20;
+  if (v->cfg.max_list <= 0) v->cfg.max_list = 1ll << 19;
+  if (v->cfg.max_coarse <= 0) v->cfg.max_coarse = 1ll << 20;
+  if (v->cfg.atlas_w <= 0) v->cfg.atlas_w = 13824;
+  if (v->cfg.atlas_h <= 0) v->cfg.atlas_h = 13824;
+  if (v->cfg.max_keyframes <= 0) v->cfg.max_keyframes = 64;
+  if (v->cfg.device < 0 || v->cfg.device >= ndev) {
+    set_error("tf_config.device out of range");
+    delete v;
+    return TF_ERR_INVALID;
+  }
+  v->device = v->cfg.device;
+  v->res = resolution;
+  v->use_color = use_color;
+  // defaults of MobileFusion::initChiselMap (GCFusion/MobileFusion.h:205-258)
+  v->ig = Integ{0.0019f, 0.00152f, 0.001504f, 6.0f, 1.0f};
+  refresh_cam(v, 640, 480, 0.01f, 5.0f);
+
+  auto fail = [&](int rc) { tf_volume_destroy(v); return rc; };
+  if (hipSetDevice(v->device) != hipSuccess) { set_error("hipSetDevice failed"); return fail(TF_ERR_HIP); }
+  if (hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("hipStreamCreate failed");
+    return fail(TF_ERR_HIP);
+  }
+  v->own_stream = true;
+
+  VolumeDev& d = v->dev;
+  memset(&d, 0, sizeof(d));
+  d.max_chunks = (uint32_t)v->cfg.max_chunks;
+  d.max_list = (uint32_t)v->cfg.max_list;
+  d.max_coarse = (uint32_t)v->cfg.max_coarse;
+  d.part_lo = std::numeric_limits<int32_t>::min();
+  d.part_hi = std::numeric_limits<int32_t>::max();
+  const size_t hcap = pow2_at_least((size_t)d.max_chunks * 2);
+  const size_t dcap = pow2_at_least((size_t)d.max_chunks * 4);
+  d.hmask = (uint32_t)(hcap - 1);
+  d.dmask = (uint32_t)(dcap - 1);
+  int rc;
+  if ((rc = dev_alloc(v, &d.tsdf, (size_t)d.max_chunks * kChunkVoxels))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.color, (size_t)d.max_chunks * kChunkVoxels))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.slot_id, (size_t)d.max_chunks))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.alive, (size_t)d.max_chunks))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.hkeys, hcap))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.hvals, hcap))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.dkeys, dcap))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.dstamp, dcap))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.masks, (size_t)d.max_coarse))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.offsets, (size_t)d.max_coarse))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.list_id, (size_t)d.max_list))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.list_slot, (size_t)d.max_list))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.list_new, (size_t)d.max_list))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.list_needs, (size_t)d.max_list))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.list_quality, (size_t)d.max_list))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.list_rows, (size_t)d.max_list))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.ctl, (size_t)1))) return fail(rc);
+  if ((rc = init_device_state(v))) return fail(rc);
+  if ((rc = atlas_init(v))) return fail(rc);
+  if (hipStreamSynchronize(v->stream) != hipSuccess) { set_error("device init failed"); return fail(TF_ERR_HIP); }
+  *out = v;
+  return TF_OK;
+}
+
+int tf_volume_destroy(tf_volume* v) {
+  if (!v) return TF_OK;
+  hipSetDevice(v->device);
+  if (v->stream) hipStreamSynchronize(v->stream);
+  prof_collect(v);
+  for (hipEvent_t e : v->prof_pool) hipEventDestroy(e);
+  atlas_destroy(v);
+  for (void* p : v->allocs) hipFree(p);
+  if (v->d_depth) hipFree(v->d_depth);
+  if (v->d_rgba) hipFree(v->d_rgba);
+  if (v->d_quality) hipFree(v->d_quality);
+  if (v->d_tmp) hipFree(v->d_tmp);
+  if (v->h_pinned) hipHostFree(v->h_pinned);
+  if (v->own_stream && v->stream) hipStreamDestroy(v->stream);
+  delete v;
+  return TF_OK;
+}
+
+int tf_volume_reset(tf_volume* v) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  int rc = init_device_state(v);
+  if (rc) return rc;
+  return atlas_reset(v);
+}
+
+int tf_set_stream(tf_volume* v, void* hip_stream) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_HIP(hipStreamSynchronize(v->stream));
+  if (v->own_stream && v->stream) hipStreamDestroy(v->stream);
+  v->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  v->own_stream = false;
+  return TF_OK;
+}
+
+int tf_set_camera(tf_volume* v, float fx, float fy, float cx, float cy, int width, int height,
+                  float near_plane, float far_plane) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  if (width <= 0 || height <= 0 || (width & 7)) {
+    set_error("image width must be a positive multiple of 8 (the reference reads 8 pixels per step, ChunkManager.h:326)");
+    return TF_ERR_INVALID;
+  }
+  v->fx = fx; v->fy = fy; v->cx = cx; v->cy = cy;
+  refresh_cam(v, width, height, near_plane, far_plane);
+  v->frame_bound = false;
+  return TF_OK;
+}
+
+int tf_set_truncation(tf_volume* v, float q, float l, float c, float s) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  v->ig.quad = q; v->ig.lin = l; v->ig.cons = c; v->ig.scale = s;
+  return TF_OK;
+}
+
+int tf_set_weight(tf_volume* v, float w) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  v->ig.weight = w;
+  return TF_OK;
+}
+
+int tf_frame_upload(tf_volume* v, const float* depth, const uint8_t* rgba, const float* quality) {
+  if (!v || !depth) { set_error("null argument"); return TF_ERR_INVALID; }
+  const size_t npix = (size_t)v->cam.W * v->cam.H;
+  if (v->img_pixels != npix) {
+    TF_HIP(hipStreamSynchronize(v->stream));
+    if (v->d_depth) hipFree(v->d_depth);
+    if (v->d_rgba) hipFree(v->d_rgba);
+    if (v->d_quality) hipFree(v->d_quality);
+    v->d_depth = nullptr; v->d_rgba = nullptr; v->d_quality = nullptr;
+    TF_HIP(hipMalloc((void**)&v->d_depth, npix * 4));
+    TF_HIP(hipMalloc((void**)&v->d_rgba, npix * 4));
+    TF_HIP(hipMalloc((void**)&v->d_quality, npix * 4));
+    v->img_pixels = npix;
+  }
+  int rc = ensure_pinned(v, npix * 12);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));  // previous use of the staging buffer
+  uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);
+  memcpy(st, depth, npix * 4);
+  TF_HIP(hipMemcpyAsync(v->d_depth, st, npix * 4, hipMemcpyHostToDevice, v->stream));
+  if (rgba) {
+    memcpy(st + npix * 4, rgba, npix * 4);
+    TF_HIP(hipMemcpyAsync(v->d_rgba, st + npix * 4, npix * 4, hipMemcpyHostToDevice, v->stream));
+  }
+  if (quality) {
+    memcpy(st + npix * 8, quality, npix * 4);
+    TF_HIP(hipMemcpyAsync(v->d_quality, st + npix * 8, npix * 4, hipMemcpyHostToDevice, v->stream));
+  }
+  v->frame.depth = v->d_depth;
+  v->frame.rgba = rgba ? reinterpret_cast<const uchar4*>(v->d_rgba) : nullptr;
+  v->frame.quality = quality ? v->d_quality : nullptr;
+  v->frame_bound = true;
+  return TF_OK;
+}
+
+int tf_frame_bind_device(tf_volume* v, const float* d_depth, const uint8_t* d_rgba,
+                         const float* d_quality) {
+  if (!v || !d_depth) { set_error("null argument"); return TF_ERR_INVALID; }
+  if ((reinterpret_cast<uintptr_t>(d_depth) & 15) || (reinterpret_cast<uintptr_t>(d_rgba) & 3) ||
+      (reinterpret_cast<uintptr_t>(d_quality) & 3)) {
+    set_error("device images must be aligned (depth 16 B, rgba/quality 4 B)");
+    return TF_ERR_INVALID;
+  }
+  v->frame.depth = d_depth;
+  v->frame.rgba = reinterpret_cast<const uchar4*>(d_rgba);
+  v->frame.quality = d_quality;
+  v->frame_bound = true;
+  return TF_OK;
+}
+
+int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint8_t* out_new, int64_t cap,
+               int64_t* n) {
+  if (!v || !pose || !n) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (!v->frame_bound) { set_error("no frame bound (tf_frame_upload / tf_frame_bind_device)"); return TF_ERR_INVALID; }
+  Pose P;
+  memcpy(P.p, pose, sizeof(P.p));
+  v->host_list_n = -1;
+  int rc = launch_prepare(v, P);
+  if (rc) return rc;
+  TF_HIP(hipGetLastError());
+  FrameCtl ctl;
+  rc = fetch_ctl(v, &ctl);
+  if (rc) return rc;
+  const int64_t cnt = ctl.n_list;
+  *n = cnt;
+  if (cnt > cap) { set_error("output capacity too small for the visible list"); return TF_ERR_CAPACITY; }
+  if (cnt == 0) { v->host_list.clear(); v->host_list_n = 0; return TF_OK; }
+  rc = ensure_pinned(v, (size_t)cnt * 17);
+  if (rc) return rc;
+  int32_t* st = reinterpret_cast<int32_t*>(v->h_pinned);
+  uint8_t* stn = reinterpret_cast<uint8_t*>(st + 4 * cnt);
+  TF_HIP(hipMemcpyAsync(st, v->dev.list_id, (size_t)cnt * 16, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipMemcpyAsync(stn, v->dev.list_new, (size_t)cnt, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  v->host_list.resize((size_t)cnt * 3);
+  for (int64_t i = 0; i < cnt; ++i) {
+    v->host_list[3 * i] = st[4 * i];
+    v->host_list[3 * i + 1] = st[4 * i + 1];
+    v->host_list[3 * i + 2] = st[4 * i + 2];
+  }
+  v->host_list_n = cnt;
+  if (out_ids) memcpy(out_ids, v->host_list.data(), (size_t)cnt * 12);
+  if (out_new) memcpy(out_new, stn, (size_t)cnt);
+  return TF_OK;
+}
+
+int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t n,
+                 int integrate_flag, int use_color, int use_quality, uint8_t* inout_needs_update,
+                 float* out_quality) {
+  if (!v || !pose || (n > 0 && (!ids || !inout_needs_update))) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (!v->frame_bound) { set_error("no frame bound"); return TF_ERR_INVALID; }
+  if (n < 1) return TF_OK;  // Chisel.h:228
+  if (use_color && !v->frame.rgba) { set_error("use_color set but the bound frame has no colour image"); return TF_ERR_INVALID; }
+  if (use_quality && (!use_color || !v->frame.quality)) { set_error("use_quality needs colour and a quality image"); return TF_ERR_INVALID; }
+  int rc = sync_list(v, ids, n);
+  if (rc) return rc;
+  const size_t npad = (size_t)((n + 3) & ~(int64_t)3);
+  rc = ensure_pinned(v, npad + (size_t)n * 4);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);
+  float* stq = reinterpret_cast<float*>(st + npad);
+  memcpy(st, inout_needs_update, (size_t)n);
+  TF_HIP(hipMemcpyAsync(v->dev.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
+  Pose P;
+  memcpy(P.p, pose, sizeof(P.p));
+  prof_begin(v, TF_PROF_INTEGRATE);
+  launch_integrate(v->dev, v->frame, v->cam, v->ig, P, v->res, integrate_flag, use_color != 0,
+                   use_quality != 0, &v->dev.ctl->n_list, v->stream);
+  prof_end(v);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(st, v->dev.list_needs, (size_t)n, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipMemcpyAsync(stq, v->dev.list_quality, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream));
+  FrameCtl ctl;
+  rc = fetch_ctl(v, &ctl);
+  if (rc) return rc;
+  memcpy(inout_needs_update, st, (size_t)n);
+  if (out_quality) memcpy(out_quality, stq, (size_t)n * 4);
+  return TF_OK;
+}
+
+int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, const uint8_t* is_new,
+                int64_t n, int32_t* out_valid, int64_t* n_valid) {
+  if (!v || (n > 0 && (!ids || !needs_update || !is_new))) { set_error("null argument"); return TF_ERR_INVALID; }
+  int64_t nv = 0;
+  if (n > 0) {
+    int rc = sync_list(v, ids, n);
+    if (rc) return rc;
+    rc = ensure_pinned(v, (size_t)n * 2);
+    if (rc) return rc;
+    TF_HIP(hipStreamSynchronize(v->stream));
+    uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);
+    memcpy(st, needs_update, (size_t)n);
+    memcpy(st + n, is_new, (size_t)n);
+    TF_HIP(hipMemcpyAsync(v->dev.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
+    TF_HIP(hipMemcpyAsync(v->dev.list_new, st + n, (size_t)n, hipMemcpyHostToDevice, v->stream));
+    prof_begin(v, TF_PROF_FINALIZE);
+    launch_finalize(v->dev, &v->dev.ctl->n_list, v->epoch++, v->stream);
+    prof_end(v);
+    TF_HIP(hipGetLastError());
+    // validChunks in list order (Chisel.h:204); pure host bookkeeping on the caller's flags
+    for (int64_t i = 0; i < n; ++i)
+      if (needs_update[i]) {
+        if (out_valid) memcpy(out_valid + 3 * nv, ids + 3 * i, 12);
+        ++nv;
+      }
+    FrameCtl ctl;
+    rc = fetch_ctl(v, &ctl);
+    if (rc == TF_ERR_MISSING_CHUNK) rc = TF_OK;  // finalize only flags/parks; absent chunks are skipped
+    if (rc) return rc;
+  }
+  if (n_valid) *n_valid = nv;
+  return TF_OK;
+}
+
+static int enqueue_frame(tf_volume* v, const Pose& P, int use_color) {
+  int rc = launch_prepare(v, P);
+  if (rc) return rc;
+  const bool col = use_color && v->frame.rgba;
+  prof_begin(v, TF_PROF_INTEGRATE);
+  launch_integrate(v->dev, v->frame, v->cam, v->ig, P, v->res, 1, col, false, &v->dev.ctl->n_list,
+                   v->stream);
+  prof_end(v);
+  prof_begin(v, TF_PROF_FINALIZE);
+  launch_finalize(v->dev, &v->dev.ctl->n_list, v->epoch++, v->stream);
+  prof_end(v);
+  return TF_OK;
+}
+
+int tf_integrate_frame(tf_volume* v, const float pose[12], int use_color) {
+  if (!v || !pose) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (!v->frame_bound) { set_error("no frame bound"); return TF_ERR_INVALID; }
+  Pose P;
+  memcpy(P.p, pose, sizeof(P.p));
+  v->host_list_n = -1;
+  int rc = enqueue_frame(v, P, use_color);
+  if (rc) return rc;
+  TF_HIP(hipGetLastError());
+  return TF_OK;
+}
+
+int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* const* d_depth,
+                               const uint8_t* const* d_rgba, const float* poses12) {
+  if (!v || !d_depth || !poses12) { set_error("null argument"); return TF_ERR_INVALID; }
+  v->host_list_n = -1;
+  for (int64_t f = 0; f < n_frames; ++f) {
+    int rc = tf_frame_bind_device(v, d_depth[f], d_rgba ? d_rgba[f] : nullptr, nullptr);
+    if (rc) return rc;
+    Pose P;
+    memcpy(P.p, poses12 + 12 * f, sizeof(P.p));
+    rc = enqueue_frame(v, P, d_rgba && d_rgba[f]);
+    if (rc) return rc;
+  }
+  TF_HIP(hipGetLastError());
+  return TF_OK;
+}
+
+int tf_sync(tf_volume* v) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  FrameCtl ctl;
+  return fetch_ctl(v, &ctl);
+}
+
+// ---- state access -------------------------------------------------------------------
+int tf_chunks_download(tf_volume* v, const int32_t* ids, int64_t n, float* sdf, float* weight,
+                       uint16_t* color) {
+  if (!v || (n > 0 && !ids)) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (n <= 0) return TF_OK;
+  const size_t per = 16 + 2048 + 2048 + 4096 + 4;  // id, sdf, weight, colour, found
+  int rc = ensure_tmp(v, (size_t)n * per);
+  if (rc) return rc;
+  rc = ensure_pinned(v, (size_t)n * per);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  uint8_t* hb = reinterpret_cast<uint8_t*>(v->h_pinned);
+  uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
+  int32_t* hid = reinterpret_cast<int32_t*>(hb);
+  for (int64_t i = 0; i < n; ++i) {
+    hid[4 * i] = ids[3 * i]; hid[4 * i + 1] = ids[3 * i + 1]; hid[4 * i + 2] = ids[3 * i + 2]; hid[4 * i + 3] = 0;
+  }
+  const size_t o_sdf = (size_t)n * 16, o_w = o_sdf + (size_t)n * 2048, o_c = o_w + (size_t)n * 2048,
+               o_f = o_c + (size_t)n * 4096;
+  TF_HIP(hipMemcpyAsync(db, hb, (size_t)n * 16, hipMemcpyHostToDevice, v->stream));
+  launch_gather_chunks(v->dev, reinterpret_cast<const int4*>(db), (uint32_t)n,
+                       reinterpret_cast<float*>(db + o_sdf), reinterpret_cast<float*>(db + o_w),
+                       reinterpret_cast<uint16_t*>(db + o_c), reinterpret_cast<uint32_t*>(db + o_f),
+                       v->stream);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(hb + o_sdf, db + o_sdf, (size_t)n * (per - 16), hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  const uint32_t* found = reinterpret_cast<const uint32_t*>(hb + o_f);
+  for (int64_t i = 0; i < n; ++i)
+    if (!found[i]) {
+      set_error("chunk (" + std::to_string(ids[3 * i]) + "," + std::to_string(ids[3 * i + 1]) + "," +
+                std::to_string(ids[3 * i + 2]) + ") does not exist");
+      return TF_ERR_MISSING_CHUNK;
+    }
+  if (sdf) memcpy(sdf, hb + o_sdf, (size_t)n * 2048);
+  if (weight) memcpy(weight, hb + o_w, (size_t)n * 2048);
+  if (color) memcpy(color, hb + o_c, (size_t)n * 4096);
+  return TF_OK;
+}
+
+int tf_chunk_download(tf_volume* v, const int32_t id[3], float* sdf, float* weight, uint16_t* color) {
+  return tf_chunks_download(v, id, 1, sdf, weight, color);
+}
+
+int tf_has_chunk(tf_volume* v, const int32_t id[3], int* out) {
+  if (!v || !id || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  int rc = tf_chunks_download(v, id, 1, nullptr, nullptr, nullptr);
+  if (rc == TF_ERR_MISSING_CHUNK) { *out = 0; return TF_OK; }
+  if (rc) return rc;
+  *out = 1;
+  return TF_OK;
+}
+
+int tf_chunk_upload(tf_volume* v, const int32_t id[3], const float* sdf, const float* weight,
+                    const uint16_t* color) {
+  if (!v || !id) { set_error("null argument"); return TF_ERR_INVALID; }
+  if ((sdf == nullptr) != (weight == nullptr)) { set_error("sdf and weight must be given together"); return TF_ERR_INVALID; }
+  int rc = ensure_tmp(v, 8192);
+  if (rc) return rc;
+  rc = ensure_pinned(v, 8192);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  uint8_t* hb = reinterpret_cast<uint8_t*>(v->h_pinned);
+  uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
+  if (sdf) { memcpy(hb, sdf, 2048); memcpy(hb + 2048, weight, 2048); }
+  if (color) memcpy(hb + 4096, color, 4096);
+  TF_HIP(hipMemcpyAsync(db, hb, 8192, hipMemcpyHostToDevice, v->stream));
+  int4 i4 = make_int4(id[0], id[1], id[2], 0);
+  launch_scatter_chunk(v->dev, i4, sdf ? reinterpret_cast<float*>(db) : nullptr,
+                       sdf ? reinterpret_cast<float*>(db + 2048) : nullptr,
+                       color ? reinterpret_cast<uint16_t*>(db + 4096) : nullptr, v->stream);
+  TF_HIP(hipGetLastError());
+  v->host_list_n = -1;
+  FrameCtl ctl;
+  return fetch_ctl(v, &ctl);
+}
+
+static int list_common(tf_volume* v, bool dirty, int32_t* out_ids, int64_t cap, int64_t* n) {
+  if (!v || !n) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (cap < 0) cap = 0;
+  int rc = ensure_tmp(v, (size_t)cap * 16 + 16);
+  if (rc) return rc;
+  rc = ensure_pinned(v, (size_t)cap * 16 + 16);
+  if (rc) return rc;
+  TF_HIP(hipMemsetAsync(&v->dev.ctl->n_tmp, 0, 4, v->stream));
+  if (dirty) launch_list_dirty(v->dev, reinterpret_cast<int4*>(v->d_tmp), (uint32_t)cap, v->stream);
+  else launch_list_chunks(v->dev, reinterpret_cast<int4*>(v->d_tmp), (uint32_t)cap, v->stream);
+  TF_HIP(hipGetLastError());
+  FrameCtl ctl;
+  rc = fetch_ctl(v, &ctl);
+  if (rc) return rc;
+  *n = ctl.n_tmp;
+  const int64_t m = std::min<int64_t>(cap, ctl.n_tmp);
+  if (m > 0 && out_ids) {
+    TF_HIP(hipMemcpyAsync(v->h_pinned, v->d_tmp, (size_t)m * 16, hipMemcpyDeviceToHost, v->stream));
+    TF_HIP(hipStreamSynchronize(v->stream));
+    const int32_t* st = reinterpret_cast<const int32_t*>(v->h_pinned);
+    for (int64_t i = 0; i < m; ++i) {
+      out_ids[3 * i] = st[4 * i]; out_ids[3 * i + 1] = st[4 * i + 1]; out_ids[3 * i + 2] = st[4 * i + 2];
+    }
+  }
+  if (ctl.n_tmp > cap && out_ids) { set_error("output capacity too small"); return TF_ERR_CAPACITY; }
+  return TF_OK;
+}
+
+int tf_list_chunks(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n) {
+  return list_common(v, false, out_ids, cap, n);
+}
+int tf_list_dirty(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n) {
+  return list_common(v, true, out_ids, cap, n);
+}
+
+int tf_clear_dirty(tf_volume* v) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  // chunksToUpdate.clear() (Chisel.cpp:146): stamps to 0, keys stay (no tombstones needed)
+  TF_HIP(hipMemsetAsync(v->dev.dstamp, 0, ((size_t)v->dev.dmask + 1) * 4, v->stream));
+  return TF_OK;
+}
+
+int tf_get_stats(tf_volume* v, tf_stats* out) {
+  if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  memset(out, 0, sizeof(*out));
+  int rc = ensure_tmp(v, 64);
+  if (rc) return rc;
+  TF_HIP(hipMemsetAsync(v->d_tmp, 0, 24, v->stream));
+  launch_rowstats(v->dev, &v->dev.ctl->n_list, reinterpret_cast<unsigned long long*>(v->d_tmp), v->stream);
+  TF_HIP(hipGetLastError());
+  unsigned long long r3[3];
+  TF_HIP(hipMemcpyAsync(r3, v->d_tmp, 24, hipMemcpyDeviceToHost, v->stream));
+  FrameCtl ctl;
+  rc = fetch_ctl(v, &ctl);
+  if (rc) return rc;
+  out->n_coarse = ctl.n_coarse;
+  out->n_selected = ctl.n_list;
+  out->n_updated = (int64_t)r3[2];
+  out->rows_tsdf = (int64_t)r3[0];
+  out->rows_color = (int64_t)r3[1];
+  out->n_chunks = ctl.n_alive;
+  out->n_slots = ctl.slot_top;
+  for (int a = 0; a < 3; ++a) { out->min_id[a] = ctl.min_id[a]; out->max_id[a] = ctl.max_id[a]; }
+  int64_t nd = 0;
+  rc = list_common(v, true, nullptr, 0, &nd);
+  if (rc) return rc;
+  out->n_dirty = nd;
+  return TF_OK;
+}
+
+// ---- measurement --------------------------------------------------------------------
+int tf_profile_enable(tf_volume* v, int on) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  v->prof_on = on != 0;
+  return TF_OK;
+}
+
+int tf_profile_get(tf_volume* v, tf_profile* out, int reset) {
+  if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_HIP(hipStreamSynchronize(v->stream));
+  prof_collect(v);
+  *out = v->prof_acc;
+  if (reset) memset(&v->prof_acc, 0, sizeof(v->prof_acc));
+  return TF_OK;
+}
+
+// ---- multi-GPU partition ------------------------------------------------------------
+int tf_set_partition(tf_volume* v, int32_t x_lo, int32_t x_hi) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  if (x_lo >= x_hi) { set_error("empty partition"); return TF_ERR_INVALID; }
+  v->dev.part_lo = x_lo;
+  v->dev.part_hi = x_hi;
+  return TF_OK;
+}
+
+int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t* n) {
+  if (!v || !d_records || !n) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_HIP(hipMemsetAsync(&v->dev.ctl->n_tmp, 0, 4, v->stream));
+  launch_boundary_pack(v->dev, &v->dev.ctl->n_list, reinterpret_cast<uint8_t*>(d_records),
+                       (uint32_t)cap_records, v->stream);
+  TF_HIP(hipGetLastError());
+  FrameCtl ctl;
+  int rc = fetch_ctl(v, &ctl);
+  if (rc) return rc;
+  *n = ctl.n_tmp;
+  if ((int64_t)ctl.n_tmp > cap_records) { set_error("boundary buffer too small"); return TF_ERR_CAPACITY; }
+  return TF_OK;
+}
+
+int tf_boundary_unpack(tf_volume* v, const void* d_records, int64_t n_records) {
+  if (!v || (n_records > 0 && !d_records)) { set_error("null argument"); return TF_ERR_INVALID; }
+  launch_boundary_unpack(v->dev, reinterpret_cast<const uint8_t*>(d_records), (uint32_t)n_records, v->stream);
+  TF_HIP(hipGetLastError());
+  v->host_list_n = -1;
+  return TF_OK;
+}
+
+}  // extern "C"

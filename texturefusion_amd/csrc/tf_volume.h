@@ -1,0 +1,103 @@
+// tf_volume.h -- host-side state behind the opaque tf_volume handle.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/tf_fusion.h"
+#include "tf_device.h"
+
+namespace tf {
+
+void set_error(const std::string& msg);
+
+#define TF_HIP(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      ::tf::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+      return TF_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  int kind;
+};
+
+struct KeyframeSlot {
+  uint8_t* rgb = nullptr;   // device, u8[H][W][3]
+  float* depth = nullptr;   // device, f32[H][W]
+  bool owned = false;
+};
+
+struct AtlasState {
+  int32_t aw = 13824, ah = 13824;
+  uint64_t pw = 0, ph = 0;
+  uint64_t loc_next = 0;
+  uint8_t* buf = nullptr;  // device, u8[ah][aw][3]
+  std::unordered_map<uint64_t, uint64_t> texloc;  // packed chunk id -> texloc (Mesh::m_patch)
+  std::unordered_map<int32_t, KeyframeSlot> keyframes;
+  // staging
+  void* d_stage = nullptr;
+  size_t d_stage_bytes = 0;
+  void* h_stage = nullptr;
+  size_t h_stage_bytes = 0;
+};
+
+}  // namespace tf
+
+struct tf_volume {
+  tf_config cfg;
+  int device = 0;
+  float res = 0.005f;
+  int use_color = 1;
+  // camera as given (floats) and as consumed (int-truncated)
+  float fx = 525.f, fy = 525.f, cx = 319.5f, cy = 239.5f;
+  tf::Cam cam;
+  tf::Integ ig;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  tf::VolumeDev dev;
+  std::vector<void*> allocs;
+  // frame images
+  float* d_depth = nullptr;      // owned staging targets
+  uint8_t* d_rgba = nullptr;
+  float* d_quality = nullptr;
+  size_t img_pixels = 0;
+  void* h_pinned = nullptr;      // pinned host staging (uploads / downloads)
+  size_t h_pinned_bytes = 0;
+  tf::FrameImages frame{nullptr, nullptr, nullptr};
+  bool frame_bound = false;
+  // host shadow of the device-resident visible list (int32[3*n]); -1 = device list unknown
+  std::vector<int32_t> host_list;
+  int64_t host_list_n = -1;
+  uint32_t epoch = 0;  // finalize counter (dirty stamps)
+  // on-demand device scratch
+  void* d_tmp = nullptr;
+  size_t d_tmp_bytes = 0;
+  // profiling
+  bool prof_on = false;
+  std::vector<tf::ProfEvent> prof_events;
+  std::vector<hipEvent_t> prof_pool;
+  tf_profile prof_acc{};
+  tf::AtlasState atlas;
+};
+
+namespace tf {
+int ensure_tmp(tf_volume* v, size_t bytes);
+int ensure_pinned(tf_volume* v, size_t bytes);
+void prof_begin(tf_volume* v, int kind);
+void prof_end(tf_volume* v);
+int atlas_init(tf_volume* v);
+void atlas_destroy(tf_volume* v);
+int atlas_reset(tf_volume* v);
+inline uint64_t host_pack_id(const int32_t id[3]) {
+  return ((uint64_t)((uint32_t)(id[0] + (1 << 20)) & 0x1FFFFFu) << 42) |
+         ((uint64_t)((uint32_t)(id[1] + (1 << 20)) & 0x1FFFFFu) << 21) |
+         (uint64_t)((uint32_t)(id[2] + (1 << 20)) & 0x1FFFFFu);
+}
+}  // namespace tf

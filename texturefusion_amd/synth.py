@@ -1,0 +1,131 @@
+"""Seeded synthetic RGB-D streams for the fusion path (measurement + test inputs).
+
+SURVEY.md s.8(d) defines the scenes.  The reference consumes TUM-style datasets through
+Tools/DatasetWrapper.hpp:55-263; none is available offline, so the harness generates:
+
+* S-room: camera inside an axis-aligned 4 x 3 x 4 m box, orbiting; analytic ray/box z-depth.
+* S-wall: fronto-parallel plane (known-answer scene).
+
+Holes (depth 0) are mandatory: ChunkManager::findCubeCornerByMat back-projects only
+``depth + 0.2`` (Structure/ChunkManager.h:331), so a hole-free fronto-parallel wall selects no
+chunks at all.
+
+Everything is numpy; nothing here touches the GPU or the oracle.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+
+import numpy as np
+
+
+@dataclasses.dataclass(frozen=True)
+class Camera:
+    width: int = 640
+    height: int = 480
+    fx: float = 525.0
+    fy: float = 525.0
+    cx: float = 319.5
+    cy: float = 239.5
+    near: float = 0.01
+    far: float = 5.0
+
+    @staticmethod
+    def hires() -> "Camera":
+        return Camera(1280, 960, 1050.0, 1050.0, 639.5, 479.5, 0.01, 5.0)
+
+
+def pose_identity() -> np.ndarray:
+    p = np.zeros((3, 4), np.float32)
+    p[0, 0] = p[1, 1] = p[2, 2] = 1.0
+    return p
+
+
+def pose_yaw(yaw: float, t=(0.0, 0.0, 0.0)) -> np.ndarray:
+    """Camera-to-world [R|t], rotation about +y."""
+    c, s = math.cos(yaw), math.sin(yaw)
+    p = np.array([[c, 0.0, s, t[0]], [0.0, 1.0, 0.0, t[1]], [-s, 0.0, c, t[2]]], np.float64)
+    return p.astype(np.float32)
+
+
+def pose_euler(yaw: float, pitch: float, roll: float, t=(0.0, 0.0, 0.0)) -> np.ndarray:
+    cy, sy = math.cos(yaw), math.sin(yaw)
+    cp, sp = math.cos(pitch), math.sin(pitch)
+    cr, sr = math.cos(roll), math.sin(roll)
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]], np.float64)
+    Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]], np.float64)
+    Rz = np.array([[cr, -sr, 0], [sr, cr, 0], [0, 0, 1]], np.float64)
+    R = Ry @ Rx @ Rz
+    p = np.concatenate([R, np.asarray(t, np.float64).reshape(3, 1)], axis=1)
+    return p.astype(np.float32)
+
+
+def _rays(cam: Camera):
+    u = (np.arange(cam.width, dtype=np.float64) - cam.cx) / cam.fx
+    v = (np.arange(cam.height, dtype=np.float64) - cam.cy) / cam.fy
+    uu, vv = np.meshgrid(u, v)
+    return np.stack([uu, vv, np.ones_like(uu)], axis=-1)  # [H, W, 3], z == 1
+
+
+def _holes(shape, frac: float, seed: int) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.random(shape) < frac
+
+
+def _hash_colour(world: np.ndarray, seed: int) -> np.ndarray:
+    """RGBA8 = integer hash of the world position quantised to 2 cm; A = 1."""
+    q = np.floor(world / 0.02).astype(np.int64)
+    h = (q[..., 0] * 73856093) ^ (q[..., 1] * 19349663) ^ (q[..., 2] * 83492791) ^ (seed * 2654435761)
+    h = (h ^ (h >> 13)) * 0x5BD1E995
+    h = h ^ (h >> 15)
+    rgba = np.empty(world.shape[:-1] + (4,), np.uint8)
+    rgba[..., 0] = (h & 0xFF).astype(np.uint8)
+    rgba[..., 1] = ((h >> 8) & 0xFF).astype(np.uint8)
+    rgba[..., 2] = ((h >> 16) & 0xFF).astype(np.uint8)
+    rgba[..., 3] = 1
+    return rgba
+
+
+def room_frame(k: int, cam: Camera = Camera(), n_orbit: int = 200, hole_frac: float = 0.02,
+               half=(2.0, 1.5, 2.0), radius: float = 0.3, with_quality: bool = True):
+    """Frame k of S-room.  Returns (depth f32[H,W], rgba u8[H,W,4], quality f32[H,W], pose f32[3,4])."""
+    yaw = 2.0 * math.pi * k / n_orbit
+    t = (radius * math.sin(yaw), 0.0, radius * math.cos(yaw))
+    pose = pose_yaw(yaw, t)
+    R = pose[:, :3].astype(np.float64)
+    o = pose[:, 3].astype(np.float64)
+    d_cam = _rays(cam)
+    d_w = d_cam @ R.T
+    hb = np.asarray(half, np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s_hi = (hb - o) / d_w
+        s_lo = (-hb - o) / d_w
+    s_exit = np.where(d_w > 0, s_hi, np.where(d_w < 0, s_lo, np.inf))
+    s = s_exit.min(axis=-1)  # camera is inside the box: first exit; z-depth == s because d_cam.z == 1
+    world = o + d_w * s[..., None]
+    depth = s.astype(np.float32)
+    holes = _holes(depth.shape, hole_frac, 1234 + k)
+    depth[holes] = 0.0
+    rgba = _hash_colour(world, 99)
+    quality = None
+    if with_quality:
+        rng = np.random.Generator(np.random.PCG64(7 + k))
+        quality = rng.random(depth.shape, dtype=np.float32)
+    return depth, rgba, quality, pose
+
+
+def wall_frame(z: float = 1.5, cam: Camera = Camera(), pose: np.ndarray | None = None,
+               hole_stride: int = 53, rgba_value=(200, 100, 50, 1), quality_value: float = 0.25,
+               seed: int = 0):
+    """S-wall: plane at camera-frame depth z (constant z-depth image), every hole_stride-th pixel a hole."""
+    if pose is None:
+        pose = pose_identity()
+    depth = np.full((cam.height, cam.width), z, np.float32)
+    if hole_stride:
+        flat = depth.reshape(-1)
+        flat[seed % hole_stride::hole_stride] = 0.0
+    rgba = np.empty((cam.height, cam.width, 4), np.uint8)
+    rgba[...] = np.asarray(rgba_value, np.uint8)
+    quality = np.full((cam.height, cam.width), quality_value, np.float32)
+    return depth, rgba, quality, pose
