@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RGB-D frames/s of the fused voxel-fusion unit on MI355X.
+
+One "step" = one synthetic 640x480 RGB-D frame of the S-room stream through
+prepare -> integrate(depth+colour) -> finalize (Chisel::IntegrateDepthScanColor 5-arg,
+Structure/Chisel.h:453-468) at 5 mm voxels, frames already resident in HBM.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (metric/value/... + "roofline" + "cpu_baseline").
+N > 1: one process per GPU, static chunk-range (ChunkID.x slab) partition of ONE stream -- every
+rank runs selection in full, integrates only the chunks it owns ("strong" scaling), and the ranks
+all-gather their updated boundary chunks over RCCL every --exchange-every frames.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--res", type=float, default=0.005)
+    ap.add_argument("--hires", action="store_true", help="1280x960 camera (config 4)")
+    ap.add_argument("--unique-frames", type=int, default=200, help="distinct frames of the orbit kept in HBM")
+    ap.add_argument("--exchange-every", type=int, default=20, help="N>1: boundary all-gather period (frames)")
+    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's parallel_for policy")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    import torch  # plumbing: device memory for the frames, barrier/collectives, device sync
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from texturefusion_amd import capi, synth
+    from texturefusion_amd import partition as part
+
+    cam = synth.Camera.hires() if args.hires else synth.Camera()
+    res = np.float32(args.res)
+    K, Wm = args.steps, args.warmup
+    n_unique = max(1, min(args.unique_frames, K + Wm))
+
+    # ---- synthetic stream, generated once and parked in HBM -------------------------------
+    frames = [synth.room_frame(k, cam, with_quality=False) for k in range(n_unique)]
+    d_depth = [torch.from_numpy(f[0]).to(dev) for f in frames]
+    d_rgba = [torch.from_numpy(f[1]).to(dev) for f in frames]
+    poses = np.stack([f[3].reshape(12) for f in frames]).astype(np.float32)
+    torch.cuda.synchronize()
+
+    vol = capi.Volume(res, cam, max_chunks=1 << 19, max_list=1 << 18, device=local_rank)
+    if world > 1:
+        lo, hi = part.slab_for_rank(part.room_extent_chunks(res), rank, world)
+        vol.set_partition(lo, hi)
+        rec_cap = 1 << 14
+        send = torch.empty(rec_cap * capi.TF_BOUNDARY_RECORD_BYTES, dtype=torch.uint8, device=dev)
+        recv = [torch.empty_like(send) for _ in range(world)]
+
+    def exchange():
+        """All-gather of updated boundary chunks over RCCL (xGMI); counts first, then payloads."""
+        n = vol.boundary_pack(send.data_ptr(), rec_cap)
+        cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt)
+        dist.all_gather(recv, send)
+        for r in range(world):
+            m = int(cnts[r].item())
+            if r != rank and m:
+                vol.boundary_unpack(recv[r].data_ptr(), m)
+
+    def run(first, count, timed):
+        """Frames [first, first+count) of the stream (cyclic over the unique frames)."""
+        idx = [(first + i) % n_unique for i in range(count)]
+        if world == 1:
+            vol.integrate_frames_device([d_depth[i].data_ptr() for i in idx],
+                                        [d_rgba[i].data_ptr() for i in idx], poses[idx])
+        else:
+            for b in range(0, count, args.exchange_every):
+                sub = idx[b:b + args.exchange_every]
+                vol.integrate_frames_device([d_depth[i].data_ptr() for i in sub],
+                                            [d_rgba[i].data_ptr() for i in sub], poses[sub])
+                exchange()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warm-up, then the timed region ---------------------------------------------------
+    run(0, Wm, False)
+    vol.sync()
+    if not args.no_roofline:
+        vol.profile_enable(["integrate"])  # HIP events around the dominant kernel only
+    barrier()
+    t0 = time.perf_counter()
+    run(Wm, K, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = vol.profile_get(reset=True) if not args.no_roofline else None
+    vol.profile_enable([])
+    vol.sync()  # surfaces any device-side capacity error of the timed region
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = {
+        "metric": "RGB-D frames/s (TSDF integrate, depth+colour, fused prepare->integrate->finalize)",
+        "value": K / dt,
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": Wm,
+        "ms_per_step": 1e3 * dt / K,
+        "higher_is_better": True,
+        "scaling": "strong" if world > 1 else "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "S-room orbit stream, %dx%d RGB-D, %.0f mm voxels, 8^3 chunks, TSDF+colour integrate, "
+                        "atlas off (BASELINE.json configs[1]); frames resident in HBM"
+                        % (cam.width, cam.height, 1e3 * float(res)),
+            "frames_in_hbm": n_unique,
+            "parallelism": ("1 GPU" if world == 1 else
+                            "%d ranks, ChunkID.x slab partition of one stream, boundary all-gather every %d frames"
+                            % (world, args.exchange_every)),
+        },
+    }
+
+    # ---- roofline of the dominant kernel (k_integrate) ------------------------------------
+    if rank == 0 and prof is not None:
+        # Algorithmic bytes per launch (SURVEY.md s.8d / DESIGN.md): 128 B per rewritten TSDF row
+        # (8 voxels x {sdf,weight} read+write), 128 B per rewritten colour row, plus one read of
+        # the depth and RGBA images.  Row counts depend only on (depth, pose): replay the timed
+        # frames untimed and read the exact integers back.
+        ka_ms, ka_n = prof["integrate"]
+        algo = 0
+        idx = [(Wm + i) % n_unique for i in range(K)]
+        rows_cache = {}
+        for i in sorted(set(idx)):
+            vol.frame_bind_device(d_depth[i].data_ptr(), d_rgba[i].data_ptr(), 0)
+            vol.integrate_frame(poses[i], True)
+            st = vol.stats()
+            rows_cache[i] = (st.rows_tsdf, st.rows_color, st.n_selected, st.n_updated)
+        for i in idx:
+            rt, rc, _, _ = rows_cache[i]
+            algo += 128 * rt + 128 * rc + 8 * cam.width * cam.height
+        per_launch = algo / max(ka_n, 1)
+        avg_s = 1e-3 * ka_ms / max(ka_n, 1)
+        achieved = per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_integrate<color>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_launch": per_launch, "avg_launch_us": 1e6 * avg_s, "launches": ka_n,
+            "chunks_selected_avg": float(np.mean([rows_cache[i][2] for i in idx])),
+            "chunks_updated_avg": float(np.mean([rows_cache[i][3] for i in idx])),
+        }
+
+    # ---- CPU baseline: the oracle (scalar port of the reference path) on the host cores ------
+    if rank == 0 and args.cpu_frames > 0:
+        out["cpu_baseline"] = cpu_baseline(args, cam, res, frames, Wm, n_unique)
+
+    if rank == 0:
+        print(json.dumps(out))
+    vol.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, cam, res, frames, Wm, n_unique):
+    """oracle/ timed on a bounded sample of the same workload: same warm-up frames (untimed),
+    then the next --cpu-frames frames of the stream."""
+    from oracle import api as O
+    ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    ncpu = os.cpu_count() or 1
+    for i in range(min(Wm, 5)):  # a short warm-up bounds the CPU time; state is first-touch either way
+        f = frames[i % n_unique]
+        ov.integrate_frame(f[0], f[1], f[3])
+    n = args.cpu_frames
+    sel = []
+    # thread policy of chisel::parallel_for (threading/Threading.h:36-54)
+    t_all = 0.0
+    threads_used = []
+    for i in range(n):
+        f = frames[(Wm + i) % n_unique]
+        if args.cpu_threads > 0:
+            T = args.cpu_threads
+        else:
+            nsel = sel[-1] if sel else 8000
+            T = max(1, min(ncpu - 2, -(-nsel // 1000)))
+        ov.set_threads(T)
+        threads_used.append(T)
+        t0 = time.perf_counter()
+        _, ns = ov.integrate_frame(f[0], f[1], f[3])
+        t_all += time.perf_counter() - t0
+        sel.append(ns)
+    # single-thread figure on a shorter sample
+    ov1 = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    ov1.set_threads(1)
+    n1 = max(1, n // 4)
+    t1 = 0.0
+    for i in range(n1):
+        f = frames[(Wm + i) % n_unique]
+        t0 = time.perf_counter()
+        ov1.integrate_frame(f[0], f[1], f[3])
+        t1 += time.perf_counter() - t0
+    return {
+        "value": n / t_all, "unit": "frames/s", "cores": int(round(float(np.mean(threads_used)))),
+        "kind": "port",
+        "sample": "oracle/ (scalar C restatement of the reference path, -O2, no FMA) on frames %d..%d of the "
+                  "same S-room stream; threads = reference parallel_for policy min(hw-2, ceil(N/1000)); "
+                  "host has %d logical cores" % (Wm, Wm + n - 1, ncpu),
+        "value_1thread": n1 / t1,
+        "host_cores": ncpu,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -171,7 +171,10 @@ TF_API int tf_clear_dirty(tf_volume* v);
 TF_API int tf_get_stats(tf_volume* v, tf_stats* out);
 
 /* ---- measurement ------------------------------------------------------------------- */
-TF_API int tf_profile_enable(tf_volume* v, int on);
+/* kind_mask: bit k set = bracket every launch of kernel kind TF_PROF_k with a pair of HIP events
+ * on the handle's stream (0 = off).  Timing only the dominant kernel keeps the event overhead
+ * out of the other launches. */
+TF_API int tf_profile_enable(tf_volume* v, uint32_t kind_mask);
 TF_API int tf_profile_get(tf_volume* v, tf_profile* out, int reset);
 
 /* ---- multi-GPU chunk-range partition --------------------------------

@@ -104,7 +104,7 @@ def lib():
     L.tf_list_dirty.argtypes = [vp, i32p, C.c_int64, i64p]
     L.tf_clear_dirty.argtypes = [vp]
     L.tf_get_stats.argtypes = [vp, C.POINTER(Stats)]
-    L.tf_profile_enable.argtypes = [vp, C.c_int]
+    L.tf_profile_enable.argtypes = [vp, C.c_uint32]
     L.tf_profile_get.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.tf_set_partition.argtypes = [vp, C.c_int32, C.c_int32]
     L.tf_boundary_pack.argtypes = [vp, vp, C.c_int64, i64p]
@@ -290,8 +290,12 @@ class Volume:
         return st
 
     # -- measurement
-    def profile_enable(self, on=True):
-        self._ck(self.L.tf_profile_enable(self.h, int(on)))
+    def profile_enable(self, kinds=PROF_NAMES):
+        """kinds: iterable of kernel names from PROF_NAMES (empty / None = off)."""
+        mask = 0
+        for k in (kinds or ()):
+            mask |= 1 << PROF_NAMES.index(k)
+        self._ck(self.L.tf_profile_enable(self.h, mask))
 
     def profile_get(self, reset=True):
         p = Profile()

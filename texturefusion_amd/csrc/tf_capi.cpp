@@ -64,7 +64,8 @@ int ensure_pinned(tf_volume* v, size_t bytes) {
 }
 
 void prof_begin(tf_volume* v, int kind) {
-  if (!v->prof_on) return;
+  v->prof_open = ((v->prof_mask >> kind) & 1u) != 0;
+  if (!v->prof_open) return;
   ProfEvent pe;
   pe.kind = kind;
   auto get = [&](hipEvent_t* e) {
@@ -77,7 +78,8 @@ void prof_begin(tf_volume* v, int kind) {
   v->prof_events.push_back(pe);
 }
 void prof_end(tf_volume* v) {
-  if (!v->prof_on) return;
+  if (!v->prof_open) return;
+  v->prof_open = false;
   hipEventRecord(v->prof_events.back().b, v->stream);
 }
 
@@ -702,9 +704,9 @@ int tf_get_stats(tf_volume* v, tf_stats* out) {
 }
 
 // ---- measurement --------------------------------------------------------------------
-int tf_profile_enable(tf_volume* v, int on) {
+int tf_profile_enable(tf_volume* v, uint32_t kind_mask) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
-  v->prof_on = on != 0;
+  v->prof_mask = kind_mask;
   return TF_OK;
 }
 

@@ -80,7 +80,8 @@ struct tf_volume {
   void* d_tmp = nullptr;
   size_t d_tmp_bytes = 0;
   // profiling
-  bool prof_on = false;
+  bool prof_open = false;
+  uint32_t prof_mask = 0;  // bit k = time kernels of kind TF_PROF_k
   std::vector<tf::ProfEvent> prof_events;
   std::vector<hipEvent_t> prof_pool;
   tf_profile prof_acc{};

@@ -1,0 +1,66 @@
+"""Chunk-range partition of one volume over N ranks.
+
+Ownership is a contiguous slab of ChunkID.x per rank: rank r owns lo_r <= id.x < hi_r.  Every
+rank runs the (deterministic, cheap) visible-chunk selection in full, so all ranks hold the
+identical reference-ordered list; integrate / finalize then touch only owned entries
+(tf_set_partition).  The only data exchanged is the payload of updated chunks on slab faces
+(x == lo or x == hi-1), all-gathered so that neighbour reads of the next stage (meshing,
+Structure/ChunkManager.cpp:618-632) see current TSDFs.
+
+Host logic only (numpy); the collectives themselves are torch.distributed calls in the caller.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+INT_MIN = -(1 << 31)
+INT_MAX = (1 << 31) - 1
+
+
+def room_extent_chunks(res, half_x: float = 2.0, margin: float = 0.3):
+    """ChunkID.x extent [lo, hi) of the S-room scene (walls at |x| = half_x) incl. the TSDF band."""
+    edge = 8.0 * float(res)
+    lo = int(math.floor((-half_x - margin) / edge))
+    hi = int(math.ceil((half_x + margin) / edge)) + 1
+    return lo, hi
+
+
+def slab_bounds(extent, world: int):
+    """Equal-width contiguous slabs; the outermost slabs extend to +-infinity so that every chunk
+    id has exactly one owner."""
+    lo, hi = extent
+    edges = [lo + (hi - lo) * r // world for r in range(world + 1)]
+    edges[0], edges[-1] = INT_MIN, INT_MAX
+    return edges
+
+
+def slab_for_rank(extent, rank: int, world: int):
+    e = slab_bounds(extent, world)
+    return e[rank], e[rank + 1]
+
+
+def owner_of(ids, extent, world: int):
+    """Rank owning each chunk id (ids: int32 [n,3])."""
+    e = np.asarray(slab_bounds(extent, world)[1:-1], np.int64)
+    x = np.asarray(ids, np.int64).reshape(-1, 3)[:, 0]
+    return np.searchsorted(e, x, side="right").astype(np.int32)
+
+
+def boundary_mask(ids, lo: int, hi: int):
+    """Entries of an id list that sit on a face of the slab [lo, hi)."""
+    x = np.asarray(ids, np.int64).reshape(-1, 3)[:, 0]
+    return (x == lo) | (x == hi - 1)
+
+
+def merge_needs(needs_per_rank, ids, extent, world: int):
+    """needsUpdate flags of the full reference-ordered list from the per-rank flags: every rank
+    only sets flags of entries it owns, so the merge is an OR; returned in list order, which makes
+    validChunks / dirty lists reproduce the single-process order."""
+    out = np.zeros(len(ids), np.uint8)
+    own = owner_of(ids, extent, world)
+    for r, nd in enumerate(needs_per_rank):
+        nd = np.asarray(nd, np.uint8)
+        out |= np.where(own == r, nd, 0).astype(np.uint8)
+    return out
