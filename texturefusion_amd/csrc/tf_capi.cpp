@@ -121,13 +121,18 @@ static int status_to_error(uint32_t st) {
   return TF_ERR_CAPACITY;
 }
 
-// D2H of the control block (synchronises the stream), status -> error code, status cleared.
-static int fetch_ctl(tf_volume* v, FrameCtl* out) {
-  TF_HIP(hipMemcpyAsync(out, v->dev.ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, v->stream));
+// D2H of the control blocks (synchronises the stream), status -> error code, status cleared.
+struct CtlSnap {
+  FrameCtl f;
+  VolCtl vc;
+};
+static int fetch_ctl(tf_volume* v, CtlSnap* out) {
+  TF_HIP(hipMemcpyAsync(&out->f, v->dev.sel.ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipMemcpyAsync(&out->vc, v->dev.vctl, sizeof(VolCtl), hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
-  if (out->status) {
-    TF_HIP(hipMemsetAsync(&v->dev.ctl->status, 0, sizeof(uint32_t), v->stream));
-    return status_to_error(out->status);
+  if (out->vc.status) {
+    TF_HIP(hipMemsetAsync(&v->dev.vctl->status, 0, sizeof(uint32_t), v->stream));
+    return status_to_error(out->vc.status);
   }
   return TF_OK;
 }
@@ -135,12 +140,15 @@ static int fetch_ctl(tf_volume* v, FrameCtl* out) {
 static int init_device_state(tf_volume* v) {
   VolumeDev& d = v->dev;
   hipStream_t s = v->stream;
-  TF_HIP(hipMemsetAsync(d.hkeys, 0xFF, ((size_t)d.hmask + 1) * 8, s));
-  TF_HIP(hipMemsetAsync(d.hvals, 0xFF, ((size_t)d.hmask + 1) * 4, s));
+  TF_HIP(hipMemsetAsync(d.hent, 0xFF, ((size_t)d.hmask + 1) * sizeof(HEntry), s));  // key = empty
   TF_HIP(hipMemsetAsync(d.dkeys, 0xFF, ((size_t)d.dmask + 1) * 8, s));
   TF_HIP(hipMemsetAsync(d.dstamp, 0, ((size_t)d.dmask + 1) * 4, s));
-  TF_HIP(hipMemsetAsync(d.alive, 0, d.max_chunks, s));
-  launch_reset_ctl(d, s);
+  for (int k = 0; k < 2; ++k) {
+    d.sel = v->selbuf[k];
+    launch_reset_ctl(d, k == 0, s);
+  }
+  v->cur_sel = 0;
+  d.sel = v->selbuf[0];
   launch_fill_pool(d, 0, d.max_chunks, s);
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
@@ -148,8 +156,9 @@ static int init_device_state(tf_volume* v) {
   return TF_OK;
 }
 
-// The four kernels of Chisel::PrepareIntersectChunks (Structure/Chisel.h:103-140).
-static int launch_prepare(tf_volume* v, const Pose& pose) {
+// The kernels of Chisel::PrepareIntersectChunks (Structure/Chisel.h:103-140).  The fused per-frame
+// unit skips the stand-alone slot lookup: k_integrate<FUSED> does it per chunk.
+static int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire) {
   const SelectConsts sc = make_select_consts(pose.p, v->res);
   prof_begin(v, TF_PROF_BBOX);
   launch_bbox(v->dev, v->frame.depth, v->cam, pose, v->stream);
@@ -158,11 +167,13 @@ static int launch_prepare(tf_volume* v, const Pose& pose) {
   launch_select(v->dev, v->frame.depth, v->cam, v->ig, pose, v->res, v->stream);
   prof_end(v);
   prof_begin(v, TF_PROF_SCAN);
-  launch_scan(v->dev, v->stream);
+  launch_scan(v->dev, sc.step, v->stream);
   prof_end(v);
-  prof_begin(v, TF_PROF_EMIT);
-  launch_emit(v->dev, sc.step, v->stream);
-  prof_end(v);
+  if (with_acquire) {
+    prof_begin(v, TF_PROF_EMIT);
+    launch_acquire(v->dev, v->stream);
+    prof_end(v);
+  }
   return TF_OK;
 }
 
@@ -187,11 +198,11 @@ static int sync_list(tf_volume* v, const int32_t* ids, int64_t n) {
   }
   uint32_t* cnt = reinterpret_cast<uint32_t*>(st + 4 * n);
   *cnt = (uint32_t)n;
-  if (n) TF_HIP(hipMemcpyAsync(v->dev.list_id, st, (size_t)n * 16, hipMemcpyHostToDevice, v->stream));
-  TF_HIP(hipMemcpyAsync(&v->dev.ctl->n_list, cnt, 4, hipMemcpyHostToDevice, v->stream));
+  if (n) TF_HIP(hipMemcpyAsync(v->dev.sel.list_id, st, (size_t)n * 16, hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipMemcpyAsync(&v->dev.sel.ctl->n_list, cnt, 4, hipMemcpyHostToDevice, v->stream));
   if (n) {
-    TF_HIP(hipMemsetAsync(v->dev.list_new, 0, (size_t)n, v->stream));
-    TF_HIP(hipMemsetAsync(v->dev.list_needs, 0, (size_t)n, v->stream));
+    TF_HIP(hipMemsetAsync(v->dev.sel.list_new, 0, (size_t)n, v->stream));
+    TF_HIP(hipMemsetAsync(v->dev.sel.list_needs, 0, (size_t)n, v->stream));
   }
   launch_lookup(v->dev, (uint32_t)n, v->stream);
   TF_HIP(hipGetLastError());
@@ -272,21 +283,23 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   int rc;
   if ((rc = dev_alloc(v, &d.tsdf, (size_t)d.max_chunks * kChunkVoxels))) return fail(rc);
   if ((rc = dev_alloc(v, &d.color, (size_t)d.max_chunks * kChunkVoxels))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.slot_id, (size_t)d.max_chunks))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.alive, (size_t)d.max_chunks))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.hkeys, hcap))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.hvals, hcap))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.hent, hcap))) return fail(rc);
   if ((rc = dev_alloc(v, &d.dkeys, dcap))) return fail(rc);
   if ((rc = dev_alloc(v, &d.dstamp, dcap))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.masks, (size_t)d.max_coarse))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.offsets, (size_t)d.max_coarse))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.list_id, (size_t)d.max_list))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.list_slot, (size_t)d.max_list))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.list_new, (size_t)d.max_list))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.list_needs, (size_t)d.max_list))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.list_quality, (size_t)d.max_list))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.list_rows, (size_t)d.max_list))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.ctl, (size_t)1))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.vctl, (size_t)1))) return fail(rc);
+  for (int k = 0; k < 2; ++k) {
+    SelBuf& L = v->selbuf[k];
+    if ((rc = dev_alloc(v, &L.masks, (size_t)d.max_coarse))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.offsets, (size_t)d.max_coarse))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.list_id, (size_t)d.max_list))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.list_slot, (size_t)d.max_list))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.list_ent, (size_t)d.max_list))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.list_new, (size_t)d.max_list))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.list_needs, (size_t)d.max_list))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.list_quality, (size_t)d.max_list))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.list_rows, (size_t)d.max_list))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.ctl, (size_t)1))) return fail(rc);
+  }
   if ((rc = init_device_state(v))) return fail(rc);
   if ((rc = atlas_init(v))) return fail(rc);
   if (hipStreamSynchronize(v->stream) != hipSuccess) { set_error("device init failed"); return fail(TF_ERR_HIP); }
@@ -410,13 +423,13 @@ int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint8_t* ou
   Pose P;
   memcpy(P.p, pose, sizeof(P.p));
   v->host_list_n = -1;
-  int rc = launch_prepare(v, P);
+  int rc = launch_prepare(v, P, true);
   if (rc) return rc;
   TF_HIP(hipGetLastError());
-  FrameCtl ctl;
+  CtlSnap ctl;
   rc = fetch_ctl(v, &ctl);
   if (rc) return rc;
-  const int64_t cnt = ctl.n_list;
+  const int64_t cnt = ctl.f.n_list;
   *n = cnt;
   if (cnt > cap) { set_error("output capacity too small for the visible list"); return TF_ERR_CAPACITY; }
   if (cnt == 0) { v->host_list.clear(); v->host_list_n = 0; return TF_OK; }
@@ -424,8 +437,8 @@ int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint8_t* ou
   if (rc) return rc;
   int32_t* st = reinterpret_cast<int32_t*>(v->h_pinned);
   uint8_t* stn = reinterpret_cast<uint8_t*>(st + 4 * cnt);
-  TF_HIP(hipMemcpyAsync(st, v->dev.list_id, (size_t)cnt * 16, hipMemcpyDeviceToHost, v->stream));
-  TF_HIP(hipMemcpyAsync(stn, v->dev.list_new, (size_t)cnt, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipMemcpyAsync(st, v->dev.sel.list_id, (size_t)cnt * 16, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipMemcpyAsync(stn, v->dev.sel.list_new, (size_t)cnt, hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   v->host_list.resize((size_t)cnt * 3);
   for (int64_t i = 0; i < cnt; ++i) {
@@ -456,17 +469,17 @@ int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t
   uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);
   float* stq = reinterpret_cast<float*>(st + npad);
   memcpy(st, inout_needs_update, (size_t)n);
-  TF_HIP(hipMemcpyAsync(v->dev.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipMemcpyAsync(v->dev.sel.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
   Pose P;
   memcpy(P.p, pose, sizeof(P.p));
   prof_begin(v, TF_PROF_INTEGRATE);
   launch_integrate(v->dev, v->frame, v->cam, v->ig, P, v->res, integrate_flag, use_color != 0,
-                   use_quality != 0, &v->dev.ctl->n_list, v->stream);
+                   use_quality != 0, false, 0, v->stream);
   prof_end(v);
   TF_HIP(hipGetLastError());
-  TF_HIP(hipMemcpyAsync(st, v->dev.list_needs, (size_t)n, hipMemcpyDeviceToHost, v->stream));
-  TF_HIP(hipMemcpyAsync(stq, v->dev.list_quality, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream));
-  FrameCtl ctl;
+  TF_HIP(hipMemcpyAsync(st, v->dev.sel.list_needs, (size_t)n, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipMemcpyAsync(stq, v->dev.sel.list_quality, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream));
+  CtlSnap ctl;
   rc = fetch_ctl(v, &ctl);
   if (rc) return rc;
   memcpy(inout_needs_update, st, (size_t)n);
@@ -487,10 +500,10 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
     uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);
     memcpy(st, needs_update, (size_t)n);
     memcpy(st + n, is_new, (size_t)n);
-    TF_HIP(hipMemcpyAsync(v->dev.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
-    TF_HIP(hipMemcpyAsync(v->dev.list_new, st + n, (size_t)n, hipMemcpyHostToDevice, v->stream));
+    TF_HIP(hipMemcpyAsync(v->dev.sel.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
+    TF_HIP(hipMemcpyAsync(v->dev.sel.list_new, st + n, (size_t)n, hipMemcpyHostToDevice, v->stream));
     prof_begin(v, TF_PROF_FINALIZE);
-    launch_finalize(v->dev, &v->dev.ctl->n_list, v->epoch++, v->stream);
+    launch_finalize(v->dev, v->epoch++, v->stream);
     prof_end(v);
     TF_HIP(hipGetLastError());
     // validChunks in list order (Chisel.h:204); pure host bookkeeping on the caller's flags
@@ -499,7 +512,7 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
         if (out_valid) memcpy(out_valid + 3 * nv, ids + 3 * i, 12);
         ++nv;
       }
-    FrameCtl ctl;
+    CtlSnap ctl;
     rc = fetch_ctl(v, &ctl);
     if (rc == TF_ERR_MISSING_CHUNK) rc = TF_OK;  // finalize only flags/parks; absent chunks are skipped
     if (rc) return rc;
@@ -509,15 +522,12 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
 }
 
 static int enqueue_frame(tf_volume* v, const Pose& P, int use_color) {
-  int rc = launch_prepare(v, P);
+  int rc = launch_prepare(v, P, false);
   if (rc) return rc;
   const bool col = use_color && v->frame.rgba;
-  prof_begin(v, TF_PROF_INTEGRATE);
-  launch_integrate(v->dev, v->frame, v->cam, v->ig, P, v->res, 1, col, false, &v->dev.ctl->n_list,
+  prof_begin(v, TF_PROF_INTEGRATE);  // slot lookup + voxel update + finalize in one launch
+  launch_integrate(v->dev, v->frame, v->cam, v->ig, P, v->res, 1, col, false, true, v->epoch++,
                    v->stream);
-  prof_end(v);
-  prof_begin(v, TF_PROF_FINALIZE);
-  launch_finalize(v->dev, &v->dev.ctl->n_list, v->epoch++, v->stream);
   prof_end(v);
   return TF_OK;
 }
@@ -552,7 +562,7 @@ int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* cons
 
 int tf_sync(tf_volume* v) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
-  FrameCtl ctl;
+  CtlSnap ctl;
   return fetch_ctl(v, &ctl);
 }
 
@@ -629,7 +639,7 @@ int tf_chunk_upload(tf_volume* v, const int32_t id[3], const float* sdf, const f
                        color ? reinterpret_cast<uint16_t*>(db + 4096) : nullptr, v->stream);
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
-  FrameCtl ctl;
+  CtlSnap ctl;
   return fetch_ctl(v, &ctl);
 }
 
@@ -640,15 +650,15 @@ static int list_common(tf_volume* v, bool dirty, int32_t* out_ids, int64_t cap, 
   if (rc) return rc;
   rc = ensure_pinned(v, (size_t)cap * 16 + 16);
   if (rc) return rc;
-  TF_HIP(hipMemsetAsync(&v->dev.ctl->n_tmp, 0, 4, v->stream));
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
   if (dirty) launch_list_dirty(v->dev, reinterpret_cast<int4*>(v->d_tmp), (uint32_t)cap, v->stream);
   else launch_list_chunks(v->dev, reinterpret_cast<int4*>(v->d_tmp), (uint32_t)cap, v->stream);
   TF_HIP(hipGetLastError());
-  FrameCtl ctl;
+  CtlSnap ctl;
   rc = fetch_ctl(v, &ctl);
   if (rc) return rc;
-  *n = ctl.n_tmp;
-  const int64_t m = std::min<int64_t>(cap, ctl.n_tmp);
+  *n = ctl.vc.n_tmp;
+  const int64_t m = std::min<int64_t>(cap, ctl.vc.n_tmp);
   if (m > 0 && out_ids) {
     TF_HIP(hipMemcpyAsync(v->h_pinned, v->d_tmp, (size_t)m * 16, hipMemcpyDeviceToHost, v->stream));
     TF_HIP(hipStreamSynchronize(v->stream));
@@ -657,7 +667,7 @@ static int list_common(tf_volume* v, bool dirty, int32_t* out_ids, int64_t cap, 
       out_ids[3 * i] = st[4 * i]; out_ids[3 * i + 1] = st[4 * i + 1]; out_ids[3 * i + 2] = st[4 * i + 2];
     }
   }
-  if (ctl.n_tmp > cap && out_ids) { set_error("output capacity too small"); return TF_ERR_CAPACITY; }
+  if (ctl.vc.n_tmp > cap && out_ids) { set_error("output capacity too small"); return TF_ERR_CAPACITY; }
   return TF_OK;
 }
 
@@ -681,25 +691,27 @@ int tf_get_stats(tf_volume* v, tf_stats* out) {
   int rc = ensure_tmp(v, 64);
   if (rc) return rc;
   TF_HIP(hipMemsetAsync(v->d_tmp, 0, 24, v->stream));
-  launch_rowstats(v->dev, &v->dev.ctl->n_list, reinterpret_cast<unsigned long long*>(v->d_tmp), v->stream);
+  launch_rowstats(v->dev, reinterpret_cast<unsigned long long*>(v->d_tmp), v->stream);
   TF_HIP(hipGetLastError());
   unsigned long long r3[3];
   TF_HIP(hipMemcpyAsync(r3, v->d_tmp, 24, hipMemcpyDeviceToHost, v->stream));
-  FrameCtl ctl;
+  CtlSnap ctl;
   rc = fetch_ctl(v, &ctl);
   if (rc) return rc;
-  out->n_coarse = ctl.n_coarse;
-  out->n_selected = ctl.n_list;
+  out->n_coarse = ctl.f.n_coarse;
+  out->n_selected = ctl.f.n_list;
   out->n_updated = (int64_t)r3[2];
   out->rows_tsdf = (int64_t)r3[0];
   out->rows_color = (int64_t)r3[1];
-  out->n_chunks = ctl.n_alive;
-  out->n_slots = ctl.slot_top;
-  for (int a = 0; a < 3; ++a) { out->min_id[a] = ctl.min_id[a]; out->max_id[a] = ctl.max_id[a]; }
-  int64_t nd = 0;
+  out->n_slots = ctl.vc.slot_top;
+  for (int a = 0; a < 3; ++a) { out->min_id[a] = ctl.f.min_id[a]; out->max_id[a] = ctl.f.max_id[a]; }
+  int64_t nd = 0, na = 0;
   rc = list_common(v, true, nullptr, 0, &nd);
   if (rc) return rc;
   out->n_dirty = nd;
+  rc = list_common(v, false, nullptr, 0, &na);  // alive chunks are counted on demand
+  if (rc) return rc;
+  out->n_chunks = na;
   return TF_OK;
 }
 
@@ -730,15 +742,14 @@ int tf_set_partition(tf_volume* v, int32_t x_lo, int32_t x_hi) {
 
 int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t* n) {
   if (!v || !d_records || !n) { set_error("null argument"); return TF_ERR_INVALID; }
-  TF_HIP(hipMemsetAsync(&v->dev.ctl->n_tmp, 0, 4, v->stream));
-  launch_boundary_pack(v->dev, &v->dev.ctl->n_list, reinterpret_cast<uint8_t*>(d_records),
-                       (uint32_t)cap_records, v->stream);
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
+  launch_boundary_pack(v->dev, reinterpret_cast<uint8_t*>(d_records), (uint32_t)cap_records, v->stream);
   TF_HIP(hipGetLastError());
-  FrameCtl ctl;
+  CtlSnap ctl;
   int rc = fetch_ctl(v, &ctl);
   if (rc) return rc;
-  *n = ctl.n_tmp;
-  if ((int64_t)ctl.n_tmp > cap_records) { set_error("boundary buffer too small"); return TF_ERR_CAPACITY; }
+  *n = ctl.vc.n_tmp;
+  if ((int64_t)ctl.vc.n_tmp > cap_records) { set_error("boundary buffer too small"); return TF_ERR_CAPACITY; }
   return TF_OK;
 }
 

@@ -5,10 +5,10 @@
 //   color [max_chunks][512] ushort4 {R,G,B,count}    4 KiB / chunk
 //     -> an 8-voxel row (the reference's AVX2 vector, ProjectionIntegrator.cpp:145-147) is one
 //        64-B segment of either plane; a wave64 touches 8 rows = 512 contiguous bytes per plane.
-//   slot_id [max_chunks] int4, alive [max_chunks] u8
-//   chunk hash: keys u64[hcap] (packed id), vals u32[hcap] (slot); entries are never removed:
-//     a chunk that is garbage-collected (Chisel.h:472-477) is *parked* (alive = 0, storage reset
-//     to the fresh state) and revived as "new" the next time it is selected.
+//   chunk hash: HEntry[hcap] = {packed id u64, slot u32, alive u32}, 16 B, so ONE load answers
+//     "does the chunk exist and where".  Entries are never removed: a chunk that is
+//     garbage-collected (Chisel.h:472-477) is *parked* (alive = 0, storage reset to the fresh
+//     state) and revived as "new" the next time it is selected.
 //   dirty set (Chisel::meshesToUpdate): keys u64[dcap], stamps u32[dcap]; value is true iff the
 //     stamp is odd (mark = atomicMax(2f+1), erase = atomicMax(2f+2), f = finalize counter).
 #pragma once
@@ -22,7 +22,7 @@ constexpr int kChunkVoxels = 512;
 constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
 constexpr uint64_t kEmptyKey = ~0ull;
 
-// status bits (FrameCtl::status)
+// status bits (VolumeDev::status)
 constexpr uint32_t kStPoolFull = 1u;
 constexpr uint32_t kStListFull = 2u;
 constexpr uint32_t kStCoarseFull = 4u;
@@ -43,8 +43,14 @@ struct Pose {
   float p[12];  // row-major 3x4 [R|t]
 };
 
-// Device-resident control block: everything one frame's kernels hand to the next, so the fused
-// per-frame unit never synchronises with the host.
+struct __attribute__((aligned(16))) HEntry {
+  unsigned long long key;
+  uint32_t slot;
+  uint32_t alive;
+};
+
+// Device-resident control block of one selection: everything one frame's kernels hand to the
+// next, so the fused per-frame unit never synchronises with the host.
 struct FrameCtl {
   uint32_t bbox_key[6];  // ordered-uint keys of min xyz / max xyz (K-B reduction)
   int32_t min_id[3];
@@ -52,43 +58,50 @@ struct FrameCtl {
   int32_t dims[3];  // coarse-block grid
   uint32_t n_coarse;
   uint32_t n_list;
-  uint32_t status;
-  uint32_t slot_top;
-  uint32_t n_alive;
-  uint32_t fin_count;  // number of finalize calls so far (dirty-stamp epoch)
-  uint32_t n_tmp;      // scratch counter for list/pack kernels
-  uint32_t pad[3];
+  uint32_t pad[7];
+};
+
+// Volume-wide device words.
+struct VolCtl {
+  uint32_t status;    // sticky error bits
+  uint32_t slot_top;  // next unused pool slot
+  uint32_t n_tmp;     // scratch counter of the on-demand list/pack kernels
+  uint32_t pad;
+};
+
+// Per-frame selection scratch.  Two sets exist so that the selection of frame f+1 (a pure
+// function of its depth image and pose) can run on a second stream while frame f integrates.
+struct SelBuf {
+  unsigned long long* masks;  // [max_coarse]
+  uint32_t* offsets;          // [max_coarse]
+  int4* list_id;              // [max_list]
+  uint32_t* list_slot;        // [max_list]
+  uint32_t* list_ent;         // [max_list] hash entry index of the chunk
+  uint8_t* list_new;          // [max_list]
+  uint8_t* list_needs;        // [max_list]
+  float* list_quality;        // [max_list]
+  uint16_t* list_rows;        // [max_list] low byte tsdf rows, high byte colour rows
+  FrameCtl* ctl;
 };
 
 struct VolumeDev {
   // pool
   float2* tsdf;
   ushort4* color;
-  int4* slot_id;
-  uint8_t* alive;
   uint32_t max_chunks;
+  VolCtl* vctl;
   // chunk hash
-  unsigned long long* hkeys;
-  uint32_t* hvals;
+  HEntry* hent;
   uint32_t hmask;
   // dirty set
   unsigned long long* dkeys;
   uint32_t* dstamp;
   uint32_t dmask;
-  // per-frame scratch
-  unsigned long long* masks;  // [max_coarse]
-  uint32_t* offsets;          // [max_coarse]
-  int4* list_id;              // [max_list]
-  uint32_t* list_slot;        // [max_list]
-  uint8_t* list_new;          // [max_list]
-  uint8_t* list_needs;        // [max_list]
-  float* list_quality;        // [max_list]
-  uint16_t* list_rows;        // [max_list] low byte tsdf rows, high byte colour rows
   uint32_t max_list;
   uint32_t max_coarse;
-  FrameCtl* ctl;
   // partition (multi-GPU chunk-range ownership): lo <= id.x < hi
   int32_t part_lo, part_hi;
+  SelBuf sel;  // the selection set the launch works on
 };
 
 struct FrameImages {
@@ -98,29 +111,27 @@ struct FrameImages {
 };
 
 // ---- launchers (tf_kernels.hip) ------------------------------------------------------
-void launch_reset_ctl(const VolumeDev& v, hipStream_t s);
+void launch_reset_ctl(const VolumeDev& v, bool volume_too, hipStream_t s);
 void launch_bbox(const VolumeDev& v, const float* depth, const Cam& cam, const Pose& pose,
                  hipStream_t s);
 void launch_select(const VolumeDev& v, const float* depth, const Cam& cam, const Integ& ig,
                    const Pose& pose, float res, hipStream_t s);
-void launch_scan(const VolumeDev& v, hipStream_t s);
-void launch_emit(const VolumeDev& v, int step, hipStream_t s);
+void launch_scan(const VolumeDev& v, int step, hipStream_t s);
+void launch_acquire(const VolumeDev& v, hipStream_t s);
 void launch_lookup(const VolumeDev& v, uint32_t n, hipStream_t s);
 void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam, const Integ& ig,
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
-                      const uint32_t* n_dev, hipStream_t s);
-void launch_finalize(const VolumeDev& v, const uint32_t* n_dev, uint32_t epoch, hipStream_t s);
+                      bool fused, uint32_t epoch, hipStream_t s);
+void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
 void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipStream_t s);
-void launch_rowstats(const VolumeDev& v, const uint32_t* n_dev, unsigned long long* out3,
-                     hipStream_t s);
+void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s);
 void launch_list_chunks(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t s);
 void launch_list_dirty(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t s);
 void launch_gather_chunks(const VolumeDev& v, const int4* ids, uint32_t n, float* sdf, float* w,
                           uint16_t* col, uint32_t* found, hipStream_t s);
 void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const float* w,
                           const uint16_t* col, hipStream_t s);
-void launch_boundary_pack(const VolumeDev& v, const uint32_t* n_dev, uint8_t* records,
-                          uint32_t cap, hipStream_t s);
+void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s);
 void launch_boundary_unpack(const VolumeDev& v, const uint8_t* records, uint32_t n, hipStream_t s);
 
 }  // namespace tf

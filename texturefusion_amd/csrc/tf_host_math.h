@@ -85,6 +85,7 @@ struct IntegrateConsts {
   float sigma;    // 1e-4 (:126)
   float qoob;     // -99999999999 (:222)
   int flag;       // integrateFlag
+  uint32_t dbg;   // ablation switches for performance triage (0 in normal operation)
 };
 
 inline IntegrateConsts make_integrate_consts(float cxi, float cyi, float res, int flag) {
@@ -100,6 +101,7 @@ inline IntegrateConsts make_integrate_consts(float cxi, float cyi, float res, in
   kc.sigma = (float)1e-4;
   kc.qoob = (float)(-99999999999.0);
   kc.flag = flag;
+  kc.dbg = 0;
   return kc;
 }
 

@@ -13,10 +13,17 @@
 //   k_integrate ProjectionIntegrator::voxelUpdateSIMD  3rd_party/open_chisel/utils/ProjectionIntegrator.cpp:67-426
 //               + the per-chunk lambda of Chisel::IntegrateDepthScanColor  Structure/Chisel.h:234-248
 //   k_finalize  Chisel::FinalizeIntegrateChunks + GarbageCollect  Structure/Chisel.h:184-216,472-477
+#include <stdlib.h>
+
 #include "tf_device.h"
 #include "tf_host_math.h"
 
 #pragma clang fp contract(off)
+
+#ifndef TF_KA_GP
+#define TF_KA_GP 2
+#endif
+
 
 namespace tf {
 
@@ -63,94 +70,93 @@ __device__ __forceinline__ uint32_t hash_key(unsigned long long k) {
 }
 
 // Lookup only.  Entries are never removed, so the probe sequence of a present key is stable.
+// Returns the entry index or kInvalidSlot.
 __device__ __forceinline__ uint32_t hash_find(const VolumeDev& v, unsigned long long key) {
   uint32_t i = hash_key(key) & v.hmask;
   for (uint32_t probe = 0; probe <= v.hmask; ++probe) {
-    unsigned long long cur = v.hkeys[i];
-    if (cur == key) return v.hvals[i];
+    const unsigned long long cur = v.hent[i].key;
+    if (cur == key) return i;
     if (cur == kEmptyKey) return kInvalidSlot;
     i = (i + 1) & v.hmask;
   }
   return kInvalidSlot;
 }
 
-// Find or create the pool slot of a chunk id.  Within one launch every key is unique (the
-// visible list has no duplicates), so the value of a freshly inserted key is only read by
-// later launches.  *is_new = chunk did not exist (absent or parked).
-__device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, bool* is_new) {
+// Find or create the pool slot of a chunk id (general path: probing, insertion, revival).
+// Within one launch every key is unique (the visible list has no duplicates), so the payload of
+// a freshly inserted key is only read by later launches.  *is_new = chunk did not exist (absent
+// or parked); *ent = hash entry index.
+__device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, bool* is_new,
+                                               uint32_t* ent) {
   const unsigned long long key = pack_id(id.x, id.y, id.z);
   uint32_t i = hash_key(key) & v.hmask;
+  *is_new = true;
   for (uint32_t probe = 0; probe <= v.hmask; ++probe) {
-    unsigned long long cur = v.hkeys[i];
+    unsigned long long cur = v.hent[i].key;
     if (cur == kEmptyKey) {
-      cur = atomicCAS(&v.hkeys[i], kEmptyKey, key);
-      if (cur == kEmptyKey) {  // inserted: allocate a fresh slot
-        uint32_t slot = atomicAdd(&v.ctl->slot_top, 1u);
+      cur = atomicCAS(&v.hent[i].key, kEmptyKey, key);
+      if (cur == kEmptyKey) {  // inserted: allocate a fresh slot (storage is in the fresh state)
+        *ent = i;
+        const uint32_t slot = atomicAdd(&v.vctl->slot_top, 1u);
         if (slot >= v.max_chunks) {
-          atomicOr(&v.ctl->status, kStPoolFull);
-          v.hvals[i] = kInvalidSlot;
-          *is_new = true;
+          atomicOr(&v.vctl->status, kStPoolFull);
+          v.hent[i].slot = kInvalidSlot;
+          v.hent[i].alive = 0;
           return kInvalidSlot;
         }
-        v.hvals[i] = slot;
-        v.slot_id[slot] = id;
-        v.alive[slot] = 1;
-        atomicAdd(&v.ctl->n_alive, 1u);
-        *is_new = true;
+        v.hent[i].slot = slot;
+        v.hent[i].alive = 1;
         return slot;
       }
     }
     if (cur == key) {
-      uint32_t slot = v.hvals[i];
-      if (slot == kInvalidSlot) { *is_new = true; return slot; }
-      if (!v.alive[slot]) {  // parked chunk: storage is in the fresh state, revive it
-        v.alive[slot] = 1;
-        atomicAdd(&v.ctl->n_alive, 1u);
-        *is_new = true;
-      } else {
-        *is_new = false;
-      }
+      *ent = i;
+      const uint32_t slot = v.hent[i].slot;
+      if (slot == kInvalidSlot) return slot;
+      if (!v.hent[i].alive) v.hent[i].alive = 1;  // parked chunk: revive, still "new"
+      else *is_new = false;
       return slot;
     }
     i = (i + 1) & v.hmask;
   }
-  atomicOr(&v.ctl->status, kStHashFull);
-  *is_new = true;
+  atomicOr(&v.vctl->status, kStHashFull);
+  *ent = 0;
   return kInvalidSlot;
 }
 
 // meshesToUpdate[id] = true / erase(id), order-independent within one finalize epoch.
+// One atomic round trip in the common case (key already present or slot empty).
 __device__ __forceinline__ void dirty_stamp(const VolumeDev& v, int x, int y, int z, uint32_t stamp) {
   const unsigned long long key = pack_id(x, y, z);
   uint32_t i = hash_key(key) & v.dmask;
   for (uint32_t probe = 0; probe <= v.dmask; ++probe) {
-    unsigned long long cur = v.dkeys[i];
-    if (cur == kEmptyKey) cur = atomicCAS(&v.dkeys[i], kEmptyKey, key);
+    const unsigned long long cur = atomicCAS(&v.dkeys[i], kEmptyKey, key);
     if (cur == kEmptyKey || cur == key) {
       atomicMax(&v.dstamp[i], stamp);
       return;
     }
     i = (i + 1) & v.dmask;
   }
-  atomicOr(&v.ctl->status, kStHashFull);
+  atomicOr(&v.vctl->status, kStHashFull);
 }
 
 // ---------------------------------------------------------------------------------------
-// control block reset (create / Reset only; per-frame resets ride on k_scan)
+// control block reset (create / Reset only; per-frame re-arming rides on k_scan)
 // ---------------------------------------------------------------------------------------
-__global__ void k_reset_ctl(FrameCtl* ctl) {
+__global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
   if (threadIdx.x == 0) {
     for (int a = 0; a < 3; ++a) {
       ctl->bbox_key[a] = f2key(1e8f);
       ctl->bbox_key[3 + a] = f2key(-1e8f);
       ctl->min_id[a] = ctl->max_id[a] = ctl->dims[a] = 0;
     }
-    ctl->n_coarse = 0; ctl->n_list = 0; ctl->status = 0; ctl->slot_top = 0;
-    ctl->n_alive = 0; ctl->fin_count = 0; ctl->n_tmp = 0;
+    ctl->n_coarse = 0;
+    ctl->n_list = 0;
+    if (vctl) { vctl->status = 0; vctl->slot_top = 0; vctl->n_tmp = 0; }
   }
 }
-void launch_reset_ctl(const VolumeDev& v, hipStream_t s) {
-  hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(64), 0, s, v.ctl);
+void launch_reset_ctl(const VolumeDev& v, bool volume_too, hipStream_t s) {
+  hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(64), 0, s, v.sel.ctl, volume_too ? v.vctl : nullptr);
 }
 
 // fresh chunk state: sdf 999, weight 0 (Chunk.cpp:64-65), colour 0 (ColorVoxel.cpp:26-33)
@@ -236,8 +242,8 @@ void launch_bbox(const VolumeDev& v, const float* depth, const Cam& cam, const P
                  hipStream_t s) {
   int nvec = (cam.W * cam.H) >> 2;
   int blocks = (nvec + 255) / 256;
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, s, depth, cam, pose, v.ctl);
+  if (blocks > 128) blocks = 128;  // 6 atomics per block on 6 words: keep the tail short
+  hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, s, depth, cam, pose, v.sel.ctl);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -264,7 +270,7 @@ __device__ __forceinline__ ProbeRes probe(const float* __restrict__ depth, const
 
 __global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth, Cam cam, Integ ig,
                                                 SelectConsts sc, VolumeDev v) {
-  FrameCtl* ctl = v.ctl;
+  FrameCtl* ctl = v.sel.ctl;
   // GetIDAt (ChunkManager.h:197-207) on the reduced corners; every block derives the same grid.
   int minI[3], maxI[3], dims[3];
 #pragma unroll
@@ -280,35 +286,32 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth,
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int a = 0; a < 3; ++a) { ctl->min_id[a] = minI[a]; ctl->max_id[a] = maxI[a]; ctl->dims[a] = dims[a]; }
     ctl->n_coarse = n_coarse;
-    if (overflow) atomicOr(&ctl->status, kStCoarseFull);
+    if (overflow) atomicOr(&v.vctl->status, kStCoarseFull);
   }
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   const int corner = lane & 7;
   const int step = sc.step;
-  const uint32_t ngroups = (n_coarse + 7) >> 3;
   const uint32_t nzny = (uint32_t)dims[2] * (uint32_t)dims[1];
 
-  for (uint32_t G = wave; G < ngroups; G += nwaves) {
-    const uint32_t cidx = G * 8 + (lane >> 3);
-    const bool inrange = cidx < n_coarse;
-    uint32_t ix = 0, iy = 0, iz = 0;
-    if (inrange) {
-      ix = cidx / nzny;
-      const uint32_t rem = cidx - ix * nzny;
-      iy = rem / (uint32_t)dims[2];
-      iz = rem - iy * (uint32_t)dims[2];
-    }
-    const int x = minI[0] - 1 + (int)ix * step;
-    const int y = minI[1] - 1 + (int)iy * step;
-    const int z = minI[2] - 1 + (int)iz * step;
+  // One wave per coarse block: the 8 corner probes run on lanes 0..7 (replicated 8x), the 64
+  // per-chunk tests of a hit block on the 64 lanes (lane = (i-x)*16 + (j-y)*4 + (k-z), i.e. the
+  // reference's i,j,k push_back order).  Every block is an independent short dependency chain.
+  for (uint32_t cb = wave; cb < n_coarse; cb += nwaves) {
+    const uint32_t bx = cb / nzny;
+    const uint32_t brem = cb - bx * nzny;
+    const uint32_t by = brem / (uint32_t)dims[2];
+    const uint32_t bz = brem - by * (uint32_t)dims[2];
+    const int x0 = minI[0] - 1 + (int)bx * step;
+    const int y0 = minI[1] - 1 + (int)by * step;
+    const int z0 = minI[2] - 1 + (int)bz * step;
     float oc[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {  // :473-479
-      float ox = sc.r0[a] * (float)x - sc.tc[a];
-      float oy = ox + sc.r1[a] * (float)y;
-      oc[a] = oy + (float)z * sc.r2[a];
+      float ox = sc.r0[a] * (float)x0 - sc.tc[a];
+      float oy = ox + sc.r1[a] * (float)y0;
+      oc[a] = oy + (float)z0 * sc.r2[a];
     }
     const float trunc = truncation(ig, oc[2]);
     const float dtp = trunc + sc.diag_step;  // :489
@@ -316,24 +319,9 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth,
     const bool depthValid = (oc[2] > cam.nearP) && (cam.farP > oc[2]);  // :598-602
     ProbeRes pr = probe(depth, cam, oc[0], oc[1], oc[2], sc.coarse[0][corner], sc.coarse[1][corner],
                         sc.coarse[2][corner], dtp, ndtn);
-    const unsigned long long mh = __ballot(inrange && pr.hit && depthValid);
-    // blocks of this group that passed the coarse test
-    unsigned hitbits = 0;
-#pragma unroll
-    for (int b = 0; b < 8; ++b) hitbits |= (((mh >> (8 * b)) & 0xFFull) ? 1u : 0u) << b;
-    if (corner == 0 && inrange && !((hitbits >> (lane >> 3)) & 1u)) v.masks[cidx] = 0ull;
-
-    while (hitbits) {  // wave-uniform loop over the hit blocks
-      const int b = __builtin_ctz(hitbits);
-      hitbits &= hitbits - 1;
-      const uint32_t cb = G * 8 + b;
-      const uint32_t bx = cb / nzny;
-      const uint32_t brem = cb - bx * nzny;
-      const uint32_t by = brem / (uint32_t)dims[2];
-      const uint32_t bz = brem - by * (uint32_t)dims[2];
-      const int x0 = minI[0] - 1 + (int)bx * step;
-      const int y0 = minI[1] - 1 + (int)by * step;
-      const int z0 = minI[2] - 1 + (int)bz * step;
+    const bool coarse_hit = __ballot(pr.hit && depthValid) != 0ull;
+    unsigned long long m = 0ull;
+    if (coarse_hit) {
       bool flag = false;
       if (lane < step * step * step) {
         const int di = (step == 4) ? (lane >> 4) : 0;
@@ -350,8 +338,8 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth,
           of[a] = sacc - sc.tc[a];
         }
         const float tr = truncation(ig, of[2]);
-        const float fdtp = tr + sc.diag;  // :528
-        const float fndtn = -sc.dtn_fine; // :529
+        const float fdtp = tr + sc.diag;   // :528
+        const float fndtn = -sc.dtn_fine;  // :529
         const bool dv = (of[2] > cam.nearP) && (cam.farP > of[2]);
         bool anyhit = false;
 #pragma unroll
@@ -362,30 +350,31 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth,
         }
         flag = anyhit && dv;
       }
-      const unsigned long long m = __ballot(flag);
-      if (lane == 0) v.masks[cb] = m;
+      m = __ballot(flag);
     }
+    if (lane == 0) v.sel.masks[cb] = m;
   }
 }
 void launch_select(const VolumeDev& v, const float* depth, const Cam& cam, const Integ& ig,
                    const Pose& pose, float res, hipStream_t s) {
   SelectConsts sc = make_select_consts(pose.p, res);
-  hipLaunchKernelGGL(k_select, dim3(512), dim3(256), 0, s, depth, cam, ig, sc, v);
+  hipLaunchKernelGGL(k_select, dim3(1024), dim3(256), 0, s, depth, cam, ig, sc, v);
 }
 
 // ---------------------------------------------------------------------------------------
 // exclusive scan of popcount(mask) over the coarse blocks (x-outer .. z-inner order, then lane
-// order i,j,k inside a block = the reference's push_back order); single workgroup.
-// Also re-arms the bbox keys for the next frame (they were consumed by k_select).
+// order i,j,k inside a block = the reference's push_back order) and list write-out; single
+// workgroup.  Also re-arms the bbox keys for the next frame (they were consumed by k_select).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan(VolumeDev v) {
-  FrameCtl* ctl = v.ctl;
+__global__ __launch_bounds__(1024) void k_scan(VolumeDev v, int step) {
+  FrameCtl* ctl = v.sel.ctl;
+  const SelBuf& L = v.sel;
   const uint32_t n = ctl->n_coarse;
   const uint32_t per = (n + 1023) / 1024;
   const uint32_t b = threadIdx.x * per;
   const uint32_t e = (b + per < n) ? b + per : n;
   uint32_t local = 0;
-  for (uint32_t i = b; i < e; ++i) local += (uint32_t)__popcll(v.masks[i]);
+  for (uint32_t i = b; i < e; ++i) local += (uint32_t)__popcll(L.masks[i]);
   // block exclusive scan: wave scan + LDS
   __shared__ uint32_t wsum[16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -402,16 +391,53 @@ __global__ __launch_bounds__(1024) void k_scan(VolumeDev v) {
     if (k < w) wbase += wsum[k];
     total += wsum[k];
   }
+  const bool fits = total <= v.max_list;
   uint32_t run = wbase + inc - local;
   for (uint32_t i = b; i < e; ++i) {
-    v.offsets[i] = run;
-    run += (uint32_t)__popcll(v.masks[i]);
+    L.offsets[i] = run;
+    run += (uint32_t)__popcll(L.masks[i]);
+  }
+  __syncthreads();  // offsets[] written above are read by other waves below
+  if (fits) {
+    // list write-out: each wave scans 64 coarse blocks at a time, then expands the non-empty
+    // ones; lane = bit index = (i-x)*16 + (j-y)*4 + (k-z), the reference's inner-loop order
+    // (:508-548), so entry order == push_back order.
+    const uint32_t dz = (uint32_t)ctl->dims[2], dy = (uint32_t)ctl->dims[1];
+    const uint32_t nzny = dz * dy;
+    const int mx = ctl->min_id[0] - 1, my = ctl->min_id[1] - 1, mz = ctl->min_id[2] - 1;
+    for (uint32_t base = (uint32_t)w * 64; base < n; base += 16 * 64) {
+      const uint32_t mine = base + lane;
+      const unsigned long long mymask = (mine < n) ? L.masks[mine] : 0ull;
+      const uint32_t myoff = (mine < n) ? L.offsets[mine] : 0u;
+      unsigned long long nonempty = __ballot(mymask != 0ull);
+      while (nonempty) {
+        const int src = __builtin_ctzll(nonempty);
+        nonempty &= nonempty - 1;
+        const uint32_t cb = base + src;
+        const unsigned long long m =
+            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mymask >> 32), src) << 32) |
+            (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mymask & 0xFFFFFFFFu), src);
+        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)myoff, src);
+        if ((m >> lane) & 1ull) {
+          const uint32_t pos = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+          const uint32_t bx = cb / nzny;
+          const uint32_t brem = cb - bx * nzny;
+          const uint32_t by = brem / dz;
+          const uint32_t bz = brem - by * dz;
+          int4 id;
+          id.x = mx + (int)bx * step + ((step == 4) ? (lane >> 4) : 0);
+          id.y = my + (int)by * step + ((step == 4) ? ((lane >> 2) & 3) : 0);
+          id.z = mz + (int)bz * step + ((step == 4) ? (lane & 3) : 0);
+          id.w = 0;
+          L.list_id[pos] = id;
+        }
+      }
+    }
   }
   if (threadIdx.x == 0) {
-    if (total > v.max_list) {
-      atomicOr(&ctl->status, kStListFull);
+    if (!fits) {
+      atomicOr(&v.vctl->status, kStListFull);
       total = 0;
-      ctl->n_coarse = 0;
     }
     ctl->n_list = total;
     for (int a = 0; a < 3; ++a) {
@@ -420,68 +446,45 @@ __global__ __launch_bounds__(1024) void k_scan(VolumeDev v) {
     }
   }
 }
-void launch_scan(const VolumeDev& v, hipStream_t s) {
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, v);
+void launch_scan(const VolumeDev& v, int step, hipStream_t s) {
+  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, v, step);
 }
 
 // ---------------------------------------------------------------------------------------
-// list write-out + chunk lookup/creation (PrepareIntersectChunks' loop, Chisel.h:130-138)
+// chunk lookup/creation for a device-resident list (PrepareIntersectChunks' loop,
+// Chisel.h:130-138): newChunkFlag, needsUpdateFlag = false.  One thread per entry.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_emit(VolumeDev v, int step) {
-  FrameCtl* ctl = v.ctl;
-  const uint32_t n_coarse = ctl->n_coarse;
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t dz = (uint32_t)ctl->dims[2], dy = (uint32_t)ctl->dims[1];
-  const uint32_t nzny = dz * dy;
-  // each lane first scans 64 coarse blocks for non-empty masks, then the wave expands them
-  for (uint32_t base = wave * 64; base < n_coarse; base += nwaves * 64) {
-    const uint32_t mine = base + lane;
-    const unsigned long long mymask = (mine < n_coarse) ? v.masks[mine] : 0ull;
-    unsigned long long nonempty = __ballot(mymask != 0ull);
-    while (nonempty) {
-      const int src = __builtin_ctzll(nonempty);
-      nonempty &= nonempty - 1;
-      const uint32_t cb = base + src;
-      const unsigned long long m =
-          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mymask >> 32), src) << 32) |
-          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mymask & 0xFFFFFFFFu), src);
-      if ((m >> lane) & 1ull) {
-        const uint32_t pos = v.offsets[cb] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        const uint32_t bx = cb / nzny;
-        const uint32_t brem = cb - bx * nzny;
-        const uint32_t by = brem / dz;
-        const uint32_t bz = brem - by * dz;
-        int4 id;
-        id.x = ctl->min_id[0] - 1 + (int)bx * step + ((step == 4) ? (lane >> 4) : 0);
-        id.y = ctl->min_id[1] - 1 + (int)by * step + ((step == 4) ? ((lane >> 2) & 3) : 0);
-        id.z = ctl->min_id[2] - 1 + (int)bz * step + ((step == 4) ? (lane & 3) : 0);
-        id.w = 0;
-        bool is_new = false;
-        const uint32_t slot = chunk_acquire(v, id, &is_new);
-        v.list_id[pos] = id;
-        v.list_slot[pos] = slot;
-        v.list_new[pos] = is_new ? 1 : 0;
-        v.list_needs[pos] = 0;
-      }
-    }
+__global__ __launch_bounds__(256) void k_acquire(VolumeDev v) {
+  const SelBuf& L = v.sel;
+  const uint32_t n = L.ctl->n_list;
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int4 id = L.list_id[e];
+    bool is_new = false;
+    uint32_t ent = 0;
+    const uint32_t slot = chunk_acquire(v, id, &is_new, &ent);
+    L.list_slot[e] = slot;
+    L.list_ent[e] = ent;
+    L.list_new[e] = is_new ? 1 : 0;
+    L.list_needs[e] = 0;
   }
 }
-void launch_emit(const VolumeDev& v, int step, hipStream_t s) {
-  hipLaunchKernelGGL(k_emit, dim3(256), dim3(256), 0, s, v, step);
+void launch_acquire(const VolumeDev& v, hipStream_t s) {
+  hipLaunchKernelGGL(k_acquire, dim3(512), dim3(256), 0, s, v);
 }
 
 // Host-supplied list (the 10-argument flow / de-integration replays kf.validChunks):
 // resolve ids to slots; a missing chunk is an error (reference: chunks.at() throws).
 __global__ __launch_bounds__(256) void k_lookup(VolumeDev v, uint32_t n) {
+  const SelBuf& L = v.sel;
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int4 id = v.list_id[i];
-  uint32_t slot = hash_find(v, pack_id(id.x, id.y, id.z));
-  if (slot != kInvalidSlot && !v.alive[slot]) slot = kInvalidSlot;
-  if (slot == kInvalidSlot) atomicOr(&v.ctl->status, kStMissing);
-  v.list_slot[i] = slot;
+  const int4 id = L.list_id[i];
+  const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+  uint32_t slot = kInvalidSlot;
+  if (ent != kInvalidSlot && v.hent[ent].alive) slot = v.hent[ent].slot;
+  if (slot == kInvalidSlot) atomicOr(&v.vctl->status, kStMissing);
+  L.list_slot[i] = slot;
+  L.list_ent[i] = (ent == kInvalidSlot) ? 0u : ent;
 }
 void launch_lookup(const VolumeDev& v, uint32_t n, hipStream_t s) {
   if (!n) return;
@@ -489,11 +492,17 @@ void launch_lookup(const VolumeDev& v, uint32_t n, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------
-// K-A  voxel update.  One wave64 per chunk; lane = (y, x) of the voxel, 8 passes over z, so one
-// pass covers 8 consecutive 8-voxel rows of the reference (row = z*8 + y).  Row-granular
+// K-A  voxel update.  One wave64 per chunk; lane = (y, x) of the voxel, z-slice g = 0..7, so one
+// slice covers 8 consecutive 8-voxel rows of the reference (row = z*8 + y).  Row-granular
 // predicates of the AVX2 code (`any lane of the row`) are bytes of a 64-bit wave ballot.
 // Only rows that are actually rewritten are loaded/stored (exec-masked), so HBM traffic is the
 // row-granular algorithmic traffic of SURVEY.md s.8(d).
+//
+// The kernel is bound by dependent memory round trips, so the order of issue is:
+//   chunk id -> [hash entry load]  ||  geometry of all 8 slices -> 8 depth gathers -> predicates
+//   -> voxel rows of slices 0-3 (tsdf, colour, rgba) -> update -> stores -> slices 4-7 -> dirty
+//   stamps.  FUSED = the per-frame unit (Chisel.h:453-468) in one launch: slot lookup/creation in
+//   front (PrepareIntersectChunks' loop), FinalizeIntegrateChunks + GarbageCollect behind.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long nonzero_bytes(unsigned long long m) {
   unsigned long long t = m | (m >> 1);
@@ -502,30 +511,92 @@ __device__ __forceinline__ unsigned long long nonzero_bytes(unsigned long long m
   return t & 0x0101010101010101ull;
 }
 
-template <bool COLOR, bool QUALITY>
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr int kOOB = 0x7FFFFFF0;  // buffer byte offset that is out of range for every descriptor
+
+// OR over the 8 lanes of a voxel row (lanes 8r..8r+7), three DPP steps, no SGPRs involved.
+__device__ __forceinline__ int row8_or(int x) {
+  x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  x |= __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  return x;
+}
+
+// _mm256_cvtps_epi32 for the predicates that consume it: round-to-nearest-even; NaN -> INT_MIN
+// (v_med3 returns the minimum when an operand is NaN); |x| >= 2^31 saturates, which every
+// consumer (`valid`, `out of observation`) classifies exactly like x86's 0x80000000.
+__device__ __forceinline__ int cvt_sat_rne(float x) {
+  return (int)rintf(__builtin_amdgcn_fmed3f(x, -2147483648.0f, 2147483520.0f));
+}
+
+// GP = z-slices handled per pass: all loads of a pass are issued before the first use, so a wave
+// keeps GP depth gathers and up to 3*GP voxel-row / image loads in flight; registers (hence
+// resident waves per SIMD) grow with GP.
+//
+// Predication is done the CDNA way: every per-lane predicate is folded into the byte offset of a
+// buffer load/store (out-of-range offset = no memory access, loads return 0), so there is no
+// exec-mask juggling and no lane mask has to live in SGPRs across phases.  Descriptors: the three
+// frame images (kernel arguments) and the chunk's two 4-KiB voxel planes (wave-uniform slot).
+template <bool COLOR, bool QUALITY, bool FUSED, int GP>
 __global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img, Cam cam, Integ ig,
-                                                   Pose P, IntegrateConsts kc,
-                                                   const uint32_t* __restrict__ n_dev) {
+                                                   Pose P, IntegrateConsts kc, uint32_t epoch) {
+  const SelBuf& L = v.sel;
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t n = *n_dev;
+  const uint32_t n = L.ctl->n_list;
   const int vx = lane & 7, vy = lane >> 3;
   const int rowshift = lane & 56;
-  // centroid table pieces (Chisel.cpp:67-69): (R^T (x,y,z)) summed as p0 + (p1 + p2)
-  float p0[3], p1[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    p0[a] = P.p[a] * (float)vx;      // R(0,a) * x
-    p1[a] = P.p[4 + a] * (float)vy;  // R(1,a) * y
-  }
   const int W = cam.W, H = cam.H;
 
+  // centroid table (Chisel.cpp:52-110): c[i] = (R^T (x,y,z)) * res + res/2, summed p0 + (p1 + p2);
+  // a function of the pose only, shared by the four waves of the workgroup through LDS.
+  __shared__ float cenT[3][kChunkVoxels];
+  for (int i = threadIdx.x; i < kChunkVoxels; i += blockDim.x) {
+    const float fx = (float)(i & 7), fy = (float)((i >> 3) & 7), fz = (float)(i >> 6);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float q0 = P.p[a] * fx, q1 = P.p[4 + a] * fy, q2 = P.p[8 + a] * fz;
+      const float s12 = q1 + q2;
+      const float d = q0 + s12;
+      cenT[a][i] = d * kc.res + kc.half;
+    }
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rs_depth =
+      __builtin_amdgcn_make_buffer_rsrc((void*)img.depth, 0, W * H * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_rgba =
+      __builtin_amdgcn_make_buffer_rsrc((void*)img.rgba, 0, COLOR ? W * H * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_qual =
+      __builtin_amdgcn_make_buffer_rsrc((void*)img.quality, 0, QUALITY ? W * H * 4 : 0, 0x00020000);
+
   for (uint32_t e = wave; e < n; e += nwaves) {
-    const uint32_t slot = v.list_slot[e];
-    const int4 id = v.list_id[e];
-    if (slot == kInvalidSlot) continue;
-    if (id.x < v.part_lo || id.x >= v.part_hi) continue;
+    const int4 id = L.list_id[e];
+    const bool owned = (id.x >= v.part_lo) && (id.x < v.part_hi);
+    if (!owned) {
+      if (FUSED && lane == 0) {
+        L.list_slot[e] = kInvalidSlot; L.list_ent[e] = 0; L.list_new[e] = 0; L.list_needs[e] = 0;
+        L.list_quality[e] = 0.0f; L.list_rows[e] = 0;
+      }
+      continue;
+    }
+    if (kc.dbg & 32u) {  // triage: loop skeleton only
+      if (lane == 0) { L.list_needs[e] = 0; L.list_rows[e] = 0; }
+      continue;
+    }
+    // slot lookup: ONE 16-B load of the chunk's home hash entry, issued now and consumed after
+    // the first pass' geometry + depth gathers
+    const unsigned long long key = pack_id(id.x, id.y, id.z);
+    const uint32_t i0 = hash_key(key) & v.hmask;
+    uint4 h0 = make_uint4(0, 0, 0, 0);
+    uint32_t slot = kInvalidSlot;
+    if (FUSED) h0 = *reinterpret_cast<const uint4*>(&v.hent[i0]);
+    else slot = L.list_slot[e];
+    bool is_new = false;
+    uint32_t ent = i0;
+    bool have_slot = !FUSED;
+
     // per-chunk scalars (ProjectionIntegrator.cpp:74-101, Chunk.cpp:52)
     float dvec[3];
     dvec[0] = (float)(8 * id.x) * kc.res - P.p[3];
@@ -543,130 +614,296 @@ __global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img,
     if (!kc.flag) wD *= -1.0f;
     const float upper = trunc + kc.resDiag;
 
-    float2* __restrict__ T = v.tsdf + (size_t)slot * kChunkVoxels;
-    ushort4* __restrict__ Cc = v.color + (size_t)slot * kChunkVoxels;
-
     float qsum = 0.0f;
-    bool updated = false;
-    uint32_t rows_t = 0, rows_c = 0;
+    int cnt_t = 0, cnt_c = 0;  // per-lane: rows of mine that were rewritten (same in a row's 8 lanes)
+    int oob_any = 0;
+    bool stopped = (kc.dbg & 64u) != 0;  // triage: skip the passes
+    __amdgpu_buffer_rsrc_t rs_T = __builtin_amdgcn_make_buffer_rsrc((void*)v.tsdf, 0, 0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_C = rs_T;
 
-    for (int g = 0; g < 8; ++g) {
-      const int k = g * 64 + lane;
-      float cen[3];
+#pragma unroll 1
+    for (int g0 = 0; g0 < 8 && !stopped; g0 += GP) {
+      // ---- phase 1: geometry of GP z-slices; rows run in order until the first row with no
+      // valid lane -- the reference's `continue` skips `pos++` (:176-178, :420), so every later
+      // row of the chunk is dead.
+      float sd[GP];  // pz, later the surface distance
+      int off_d[GP]; // image byte offset of the lane's pixel, kOOB when the gather is masked
+      int oobl[GP];
+      int nrows = GP * 8;  // rows of this pass that are processed
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float p2 = P.p[8 + a] * (float)g;  // R(2,a) * z
-        const float s12 = p1[a] + p2;
-        const float d = p0[a] + s12;
-        cen[a] = d * kc.res + kc.half;
+      for (int j = 0; j < GP; ++j) {
+        const int k = (g0 + j) * 64 + lane;
+        const float px = o[0] + cenT[0][k], py = o[1] + cenT[1][k], pz = o[2] + cenT[2][k];
+        sd[j] = pz;
+        const float u = (px / pz) * cam.fxi + kc.cxs;
+        const float w = (py / pz) * cam.fyi + kc.cys;
+        const int X = cvt_sat_rne(u), Y = cvt_sat_rne(w);
+        // 0 < X < W-1 and 0 < Y < H-1 (:167-173) as two unsigned range tests
+        const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
+        off_d[j] = valid ? (Y * W + X) * 4 : kOOB;
+        // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220)
+        if (COLOR) oobl[j] = (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1))) ? 1 : 0;
+        const unsigned long long dead = __ballot(row8_or(valid ? 1 : 0) == 0);
+        if (dead && nrows == GP * 8) nrows = j * 8 + (__builtin_ctzll(dead) >> 3);
       }
-      const float px = o[0] + cen[0], py = o[1] + cen[1], pz = o[2] + cen[2];
-      const float u = (px / pz) * cam.fxi + kc.cxs;
-      const float w = (py / pz) * cam.fyi + kc.cys;
-      const int X = cvt_rne(u), Y = cvt_rne(w);
-      const bool valid = (X > 0) && (W - 1 > X) && (Y > 0) && (H - 1 > Y);
-      const unsigned long long mv = __ballot(valid);
-      // rows are processed in order up to the first row with no valid lane; the reference's
-      // `continue` skips `pos++` (:176-178, :420) so every later row of the chunk is dead.
-      const unsigned long long zero = ~nonzero_bytes(mv) & 0x0101010101010101ull;
-      const int firstzero = zero ? (__builtin_ctzll(zero) >> 3) : 8;
-      if (firstzero == 0) break;
-      const bool active = vy < firstzero;
-      const int idx = Y * W + X;
-      float d = 0.0f;
-      if (active && valid) d = img.depth[idx];
-      const float sd = d - pz;
-
-      if (COLOR) {
-        const bool upd = active && valid && (sd > kc.nthrCol) && (kc.thrCol > sd);
-        const bool oob = active && ((0 > X) || (X > W - 1) || (0 > Y) || (Y > H - 1));
-        const unsigned long long mu = __ballot(upd);
-        const unsigned long long mo = __ballot(oob);
-        float rowsum = 0.0f;
-        if (QUALITY) {
-          if (mu) {
-            float qv = 0.0f;
-            if (upd) qv = img.quality[idx];
-            // sum += observationQuality[i], i = 0..7 (:233-236)
+      if (nrows < GP * 8) {
+        stopped = true;
 #pragma unroll
-            for (int l = 0; l < 8; ++l) rowsum += __shfl(qv, rowshift + l);
-          }
+        for (int j = 0; j < GP; ++j) {
+          if (!((j * 8 + vy) < nrows)) { off_d[j] = kOOB; if (COLOR) oobl[j] = 0; }
         }
-        if ((mu >> rowshift) & 0xFFull) {  // the whole row is rewritten (:267-304)
-          ushort4 c = Cc[k];
-          uchar4 in = make_uchar4(0, 0, 0, 0);
-          if (upd) in = img.rgba[idx];
-          if (kc.flag) {
-            c.x = (unsigned short)(c.x + in.x);
-            c.y = (unsigned short)(c.y + in.y);
-            c.z = (unsigned short)(c.z + in.z);
-            c.w = (unsigned short)(c.w + in.w);
-            if ((short)c.w > 120) { c.x >>= 2; c.y >>= 2; c.z >>= 2; c.w >>= 2; }
-          } else {
-            c.x = (unsigned short)(c.x - in.x);
-            c.y = (unsigned short)(c.y - in.y);
-            c.z = (unsigned short)(c.z - in.z);
-            c.w = (unsigned short)(c.w - in.w);
+      }
+      // ---- phase 2: depth gathers (masked lanes read 0, like the reference's masked gather)
+      float dep[GP];
+#pragma unroll
+      for (int j = 0; j < GP; ++j)
+        dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, (kc.dbg & 8u) ? kOOB : off_d[j], 0, 0));
+      // ---- resolve the slot once (fast path: the home entry holds the key, chunk alive)
+      if (FUSED && !have_slot) {
+        have_slot = true;
+        const uint32_t klo = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.x);
+        const uint32_t khi = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.y);
+        const uint32_t hs = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.z);
+        const uint32_t ha = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.w);
+        if ((((unsigned long long)khi << 32) | klo) == key && ha != 0u && hs != kInvalidSlot) {
+          slot = hs;
+        } else {
+          uint32_t s0 = kInvalidSlot, nw = 1, en = 0;
+          if (lane == 0) {
+            bool bnew = true;
+            s0 = chunk_acquire(v, id, &bnew, &en);
+            nw = bnew ? 1u : 0u;
           }
-          Cc[k] = c;
+          slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0);
+          is_new = __builtin_amdgcn_readfirstlane((int)nw) != 0;
+          ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)en);
         }
-        // observationQualitySum bookkeeping in row order (:212-238)
-        for (int r = 0; r < firstzero; ++r) {
-          if ((mo >> (8 * r)) & 0xFFull) qsum = kc.qoob;
-          if ((mu >> (8 * r)) & 0xFFull) {
-            if (QUALITY)
+      }
+      if (slot == kInvalidSlot || nrows == 0) break;
+      if (kc.dbg & 128u) continue;  // triage: geometry + depth only
+      if (g0 == 0 || FUSED) {
+        rs_T = __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+        rs_C = __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+      }
+      // ---- phase 3: predicates -> offsets
+      float nwv[GP];
+      int off_t[GP], off_c[GP], off_i[GP];
+#pragma unroll
+      for (int j = 0; j < GP; ++j) {
+        const int kb = ((g0 + j) * 64 + lane) * 8;
+        const float d = dep[j];
+        const float s = d - sd[j];
+        sd[j] = s;
+        const bool act = (j * 8 + vy) < nrows;
+        if (COLOR) {
+          const bool upd = (off_d[j] != kOOB) && (s > kc.nthrCol) && (kc.thrCol > s);  // (:202-208)
+          off_i[j] = upd ? off_d[j] : kOOB;
+          const int ru = row8_or(upd ? 1 : 0);
+          off_c[j] = ru ? kb : kOOB;
+          cnt_c += ru;
+          oob_any |= oobl[j];
+        }
+        const bool dv = (d > cam.nearP) && (cam.farP > d);     // (:310-312)
+        const bool inside = (s > kc.lower) && (upper > s);     // (:313-316)
+        const bool F = act && dv && inside;
+        nwv[j] = F ? wD : 0.0f;
+        const int rf = row8_or(F ? 1 : 0);
+        off_t[j] = rf ? kb : kOOB;
+        cnt_t += rf;
+      }
+      // nothing of this pass is rewritten (chunk outside the band, or a hole): skip the RMW
+      // phases for the whole wave -- about a third of the selected chunks never update a row
+      {
+        int anyrow = 0;
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+          anyrow |= (off_t[j] != kOOB) ? 1 : 0;
+          if (COLOR) anyrow |= (off_c[j] != kOOB) ? 1 : 0;
+        }
+        if (__ballot(anyrow != 0) == 0ull && !(COLOR && QUALITY)) continue;
+      }
+      // ---- phase 4: voxel rows that will be rewritten + their inputs
+      u32x2 t[GP], c[GP];
+      uint32_t in[GP];
+      float qv[GP];
+#pragma unroll
+      for (int j = 0; j < GP; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, off_t[j], 0, 0);
+      if (COLOR) {
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+          c[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_C, off_c[j], 0, 0);
+          in[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[j], 0, 0);
+          if (QUALITY) qv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qual, off_i[j], 0, 0));
+        }
+      }
+      // ---- phase 5a: all arithmetic on the loaded rows (every load is consumed here, before
+      // the first store)
+#pragma unroll
+      for (int j = 0; j < GP; ++j) {
+        if (COLOR) {
+          ushort4 cc;
+          cc.x = (unsigned short)(c[j].x & 0xFFFFu); cc.y = (unsigned short)(c[j].x >> 16);
+          cc.z = (unsigned short)(c[j].y & 0xFFFFu); cc.w = (unsigned short)(c[j].y >> 16);
+          const uint32_t ii = in[j];
+          const unsigned short ir = ii & 0xFFu, ig8 = (ii >> 8) & 0xFFu, ib = (ii >> 16) & 0xFFu, ia = ii >> 24;
+          if (kc.flag) {  // (:274-292)
+            cc.x = (unsigned short)(cc.x + ir);
+            cc.y = (unsigned short)(cc.y + ig8);
+            cc.z = (unsigned short)(cc.z + ib);
+            cc.w = (unsigned short)(cc.w + ia);
+            if ((short)cc.w > 120) { cc.x >>= 2; cc.y >>= 2; cc.z >>= 2; cc.w >>= 2; }
+          } else {        // (:293-304)
+            cc.x = (unsigned short)(cc.x - ir);
+            cc.y = (unsigned short)(cc.y - ig8);
+            cc.z = (unsigned short)(cc.z - ib);
+            cc.w = (unsigned short)(cc.w - ia);
+          }
+          c[j].x = (uint32_t)cc.x | ((uint32_t)cc.y << 16);
+          c[j].y = (uint32_t)cc.z | ((uint32_t)cc.w << 16);
+        }
+        const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);  // (:319-341)
+        const float nw = nwv[j];
+        const float num = ts * tw + sd[j] * nw;
+        const float den = (tw + nw) + kc.sigma;
+        const float ns = num / den;
+        const float nwt = tw + nw;
+        const bool keep = nwt > 0.5f;
+        t[j].x = __float_as_uint(keep ? ns : 999.0f);
+        t[j].y = __float_as_uint(keep ? nwt : 0.0f);
+      }
+      // ---- phase 5b: write back the rewritten rows only (masked offsets drop the store)
+#pragma unroll
+      for (int j = 0; j < GP; ++j) {
+        if (COLOR) __builtin_amdgcn_raw_buffer_store_b64(c[j], rs_C, off_c[j], 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, off_t[j], 0, 0);
+      }
+      // ---- phase 6: observationQualitySum bookkeeping in row order (:212-238)
+      if (COLOR && QUALITY) {
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+          const unsigned long long mu = __ballot(off_i[j] != kOOB);
+          const unsigned long long mo = __ballot(oobl[j] != 0);
+          if ((mu | mo) == 0ull) continue;
+          float rowsum = 0.0f;
+          if (mu) {  // sum += observationQuality[i], i = 0..7 (:233-236)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) rowsum += __shfl(qv[j], rowshift + l);
+          }
+          const int rmax = (nrows - j * 8) < 8 ? (nrows - j * 8) : 8;
+          for (int r = 0; r < rmax; ++r) {
+            if ((mo >> (8 * r)) & 0xFFull) qsum = kc.qoob;
+            if ((mu >> (8 * r)) & 0xFFull)
               qsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowsum), 8 * r));
           }
         }
-        rows_c += (uint32_t)__popcll(nonzero_bytes(mu));
       }
+    }
+    if (slot == kInvalidSlot) {
+      if (FUSED && lane == 0) {
+        L.list_slot[e] = kInvalidSlot; L.list_ent[e] = 0; L.list_new[e] = 0; L.list_needs[e] = 0;
+        L.list_quality[e] = 0.0f; L.list_rows[e] = 0;
+      }
+      continue;
+    }
+    // rows rewritten: per-lane counters are equal within a row's 8 lanes and <= 8; sum the
+    // lanes with x == 0 bit-plane by bit-plane (wave-uniform result)
+    uint32_t rows_t = 0, rows_c = 0;
+#pragma unroll
+    for (int bit = 0; bit < 4; ++bit) {
+      rows_t += (uint32_t)__popcll(__ballot(vx == 0 && ((cnt_t >> bit) & 1))) << bit;
+      if (COLOR) rows_c += (uint32_t)__popcll(__ballot(vx == 0 && ((cnt_c >> bit) & 1))) << bit;
+    }
+    const bool updated = rows_t != 0;
+    if (COLOR && !QUALITY) {
+      // without a quality image nothing is ever added: the sum ends as the out-of-observation
+      // constant iff any processed row had an off-image lane (:221-222)
+      if (__ballot(oob_any != 0) != 0ull) qsum = kc.qoob;
+    }
 
-      const bool dv = (d > cam.nearP) && (cam.farP > d);
-      const bool inside = (sd > kc.lower) && (upper > sd);
-      const bool F = active && dv && inside;
-      const unsigned long long mf = __ballot(F);
-      if ((mf >> rowshift) & 0xFFull) {  // the whole row is rewritten (:319-341)
-        float2 t = T[k];
-        const float nw = F ? wD : 0.0f;
-        const float num = t.x * t.y + sd * nw;
-        const float den = (t.y + nw) + kc.sigma;
-        const float ns = num / den;
-        const float nwt = t.y + nw;
-        if (nwt > 0.5f) { t.x = ns; t.y = nwt; }
-        else { t.x = 999.0f; t.y = 0.0f; }
-        T[k] = t;
+    if (FUSED) {
+      // FinalizeIntegrateChunks (Chisel.h:192-208) + GarbageCollect (:472-477) for this entry
+      if (updated) {
+        if (lane < 7 && !(kc.dbg & 1u)) {
+          const int dx = (lane == 1) ? -1 : (lane == 2) ? 1 : 0;
+          const int dy = (lane == 3) ? -1 : (lane == 4) ? 1 : 0;
+          const int dz = (lane == 5) ? -1 : (lane == 6) ? 1 : 0;
+          dirty_stamp(v, id.x + dx, id.y + dy, id.z + dz, 2u * epoch + 1u);
+        }
+      } else if (is_new) {
+        if (lane == 0) {
+          v.hent[ent].alive = 0;
+          dirty_stamp(v, id.x, id.y, id.z, 2u * epoch + 2u);
+        }
+        if (rows_c) {  // parked storage returns to the fresh state (only colour can be dirty)
+          uint4* c4 = reinterpret_cast<uint4*>(v.color + (size_t)slot * kChunkVoxels);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) c4[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
       }
-      updated |= (mf != 0ull);
-      rows_t += (uint32_t)__popcll(nonzero_bytes(mf));
-      if (firstzero < 8) break;
+      if (lane == 0) {
+        L.list_slot[e] = slot;
+        L.list_ent[e] = ent;
+        L.list_new[e] = is_new ? 1 : 0;
+        L.list_needs[e] = updated ? 1 : 0;
+      }
+    } else if (lane == 0) {
+      if (updated) L.list_needs[e] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
     }
     if (lane == 0) {
-      if (updated) v.list_needs[e] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
-      v.list_quality[e] = qsum;
-      v.list_rows[e] = (uint16_t)(rows_t | (rows_c << 8));
+      L.list_quality[e] = qsum;
+      L.list_rows[e] = (uint16_t)(rows_t | (rows_c << 8));
     }
   }
 }
 
+static int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+
+template <bool FUSED, int GP>
+static void launch_integrate_t(const VolumeDev& v, const FrameImages& img, const Cam& cam,
+                               const Integ& ig, const Pose& pose, const IntegrateConsts& kc,
+                               bool use_color, bool use_quality, uint32_t epoch, hipStream_t s) {
+  static const int nblocks = env_int("TF_KA_BLOCKS", 2048);  // tuning knob
+  const dim3 grid(nblocks > 0 ? nblocks : 2048), block(256);
+  if (use_color && use_quality)
+    hipLaunchKernelGGL((k_integrate<true, true, FUSED, GP>), grid, block, 0, s, v, img, cam, ig, pose, kc, epoch);
+  else if (use_color)
+    hipLaunchKernelGGL((k_integrate<true, false, FUSED, GP>), grid, block, 0, s, v, img, cam, ig, pose, kc, epoch);
+  else
+    hipLaunchKernelGGL((k_integrate<false, false, FUSED, GP>), grid, block, 0, s, v, img, cam, ig, pose, kc, epoch);
+}
+
 void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam, const Integ& ig,
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
-                      const uint32_t* n_dev, hipStream_t s) {
+                      bool fused, uint32_t epoch, hipStream_t s) {
   IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
-  const dim3 grid(2048), block(256);
-  if (use_color && use_quality)
-    hipLaunchKernelGGL((k_integrate<true, true>), grid, block, 0, s, v, img, cam, ig, pose, kc, n_dev);
-  else if (use_color)
-    hipLaunchKernelGGL((k_integrate<true, false>), grid, block, 0, s, v, img, cam, ig, pose, kc, n_dev);
-  else
-    hipLaunchKernelGGL((k_integrate<false, false>), grid, block, 0, s, v, img, cam, ig, pose, kc, n_dev);
+  static const int gp = env_int("TF_KA_GP", TF_KA_GP);     // tuning knob: z-slices per pass
+  static const int dbg = env_int("TF_KA_DBG", 0);          // ablation switches (perf triage only)
+  kc.dbg = (uint32_t)dbg;
+  if (gp == 8) {
+    if (fused) launch_integrate_t<true, 8>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
+    else launch_integrate_t<false, 8>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
+  } else if (gp == 2) {
+    if (fused) launch_integrate_t<true, 2>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
+    else launch_integrate_t<false, 2>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
+  } else if (gp == 1) {
+    if (fused) launch_integrate_t<true, 1>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
+    else launch_integrate_t<false, 1>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
+  } else {
+    if (fused) launch_integrate_t<true, 4>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
+    else launch_integrate_t<false, 4>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
-// finalize: dirty marks for updated chunks (+6 neighbours), park new-but-untouched chunks
+// finalize (call-by-call flow): dirty marks for updated chunks (+6 neighbours), park
+// new-but-untouched chunks
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(VolumeDev v, const uint32_t* __restrict__ n_dev,
-                                                  uint32_t epoch) {
-  const uint32_t n = *n_dev;
+__global__ __launch_bounds__(256) void k_finalize(VolumeDev v, uint32_t epoch) {
+  const SelBuf& L = v.sel;
+  const uint32_t n = L.ctl->n_list;
   const int sub = threadIdx.x & 7;
   __shared__ uint32_t dead[32];
   __shared__ uint32_t ndead;
@@ -675,22 +912,22 @@ __global__ __launch_bounds__(256) void k_finalize(VolumeDev v, const uint32_t* _
     __syncthreads();
     const uint32_t e = base + (threadIdx.x >> 3);
     if (e < n) {
-      const int4 id = v.list_id[e];
+      const int4 id = L.list_id[e];
       const bool owned = (id.x >= v.part_lo) && (id.x < v.part_hi);
-      const bool needs = v.list_needs[e] != 0;
-      const bool isnew = v.list_new[e] != 0;
+      const bool needs = L.list_needs[e] != 0;
+      const bool isnew = L.list_new[e] != 0;
       if (owned && needs && sub < 7) {
         const int dx = (sub == 1) ? -1 : (sub == 2) ? 1 : 0;
         const int dy = (sub == 3) ? -1 : (sub == 4) ? 1 : 0;
         const int dz = (sub == 5) ? -1 : (sub == 6) ? 1 : 0;
         dirty_stamp(v, id.x + dx, id.y + dy, id.z + dz, 2u * epoch + 1u);
       }
-      if (sub == 7 && !needs && isnew) {
+      if (owned && sub == 7 && !needs && isnew) {
         // GarbageCollect (Chisel.h:472-477): RemoveChunk + meshesToUpdate.erase
-        const uint32_t slot = v.list_slot[e];
-        if (slot != kInvalidSlot && v.alive[slot]) {
-          v.alive[slot] = 0;
-          atomicSub(&v.ctl->n_alive, 1u);
+        const uint32_t slot = L.list_slot[e];
+        const uint32_t ent = L.list_ent[e];
+        if (slot != kInvalidSlot && v.hent[ent].alive) {
+          v.hent[ent].alive = 0;
           dead[atomicAdd(&ndead, 1u)] = slot;
         }
         dirty_stamp(v, id.x, id.y, id.z, 2u * epoch + 2u);
@@ -707,22 +944,22 @@ __global__ __launch_bounds__(256) void k_finalize(VolumeDev v, const uint32_t* _
     __syncthreads();
   }
 }
-void launch_finalize(const VolumeDev& v, const uint32_t* n_dev, uint32_t epoch, hipStream_t s) {
-  hipLaunchKernelGGL(k_finalize, dim3(512), dim3(256), 0, s, v, n_dev, epoch);
+void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize, dim3(512), dim3(256), 0, s, v, epoch);
 }
 
 // ---------------------------------------------------------------------------------------
 // on-demand utilities (not on the per-frame hot path)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rowstats(VolumeDev v, const uint32_t* __restrict__ n_dev,
-                                                  unsigned long long* out3) {
-  const uint32_t n = *n_dev;
+__global__ __launch_bounds__(256) void k_rowstats(VolumeDev v, unsigned long long* out3) {
+  const SelBuf& L = v.sel;
+  const uint32_t n = L.ctl->n_list;
   unsigned long long rt = 0, rc = 0, nu = 0;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint32_t r = v.list_rows[i];
+    const uint32_t r = L.list_rows[i];
     rt += r & 0xFFu;
     rc += r >> 8;
-    nu += v.list_needs[i] ? 1 : 0;
+    nu += L.list_needs[i] ? 1 : 0;
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -736,28 +973,27 @@ __global__ __launch_bounds__(256) void k_rowstats(VolumeDev v, const uint32_t* _
     atomicAdd(&out3[2], nu);
   }
 }
-void launch_rowstats(const VolumeDev& v, const uint32_t* n_dev, unsigned long long* out3,
-                     hipStream_t s) {
-  hipLaunchKernelGGL(k_rowstats, dim3(64), dim3(256), 0, s, v, n_dev, out3);
+void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s) {
+  hipLaunchKernelGGL(k_rowstats, dim3(64), dim3(256), 0, s, v, out3);
 }
 
 __global__ __launch_bounds__(256) void k_list_chunks(VolumeDev v, int4* out, uint32_t cap) {
-  const uint32_t top = v.ctl->slot_top < v.max_chunks ? v.ctl->slot_top : v.max_chunks;
-  for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < top; s += gridDim.x * 256) {
-    if (v.alive[s]) {
-      const uint32_t p = atomicAdd(&v.ctl->n_tmp, 1u);
-      if (p < cap) out[p] = v.slot_id[s];
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i <= v.hmask; i += gridDim.x * 256) {
+    const HEntry h = v.hent[i];
+    if (h.key != kEmptyKey && h.alive && h.slot != kInvalidSlot) {
+      const uint32_t p = atomicAdd(&v.vctl->n_tmp, 1u);
+      if (p < cap) out[p] = unpack_id(h.key);
     }
   }
 }
 void launch_list_chunks(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t s) {
-  hipLaunchKernelGGL(k_list_chunks, dim3(256), dim3(256), 0, s, v, out, cap);
+  hipLaunchKernelGGL(k_list_chunks, dim3(512), dim3(256), 0, s, v, out, cap);
 }
 
 __global__ __launch_bounds__(256) void k_list_dirty(VolumeDev v, int4* out, uint32_t cap) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i <= v.dmask; i += gridDim.x * 256) {
     if (v.dkeys[i] != kEmptyKey && (v.dstamp[i] & 1u)) {
-      const uint32_t p = atomicAdd(&v.ctl->n_tmp, 1u);
+      const uint32_t p = atomicAdd(&v.vctl->n_tmp, 1u);
       if (p < cap) out[p] = unpack_id(v.dkeys[i]);
     }
   }
@@ -773,8 +1009,9 @@ __global__ __launch_bounds__(512) void k_gather_chunks(VolumeDev v, const int4* 
   const uint32_t c = blockIdx.x;
   if (c >= n) return;
   const int4 id = ids[c];
-  uint32_t slot = hash_find(v, pack_id(id.x, id.y, id.z));
-  if (slot != kInvalidSlot && !v.alive[slot]) slot = kInvalidSlot;
+  const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+  uint32_t slot = kInvalidSlot;
+  if (ent != kInvalidSlot && v.hent[ent].alive) slot = v.hent[ent].slot;
   if (threadIdx.x == 0) found[c] = (slot != kInvalidSlot);
   const uint32_t k = threadIdx.x;
   float2 t = make_float2(999.0f, 0.0f);
@@ -798,7 +1035,8 @@ __global__ __launch_bounds__(512) void k_scatter_chunk(VolumeDev v, int4 id, con
   __shared__ uint32_t sslot;
   if (threadIdx.x == 0) {
     bool is_new;
-    sslot = chunk_acquire(v, id, &is_new);
+    uint32_t ent;
+    sslot = chunk_acquire(v, id, &is_new, &ent);
   }
   __syncthreads();
   const uint32_t slot = sslot;
@@ -815,17 +1053,17 @@ void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const f
 // ---- multi-GPU boundary exchange ------------------------------------------------------
 // Pack the chunks of the current list that this rank owns, that were updated, and that sit
 // on a partition face (x == lo or x == hi-1).  Record: int4 id | float2[512] | ushort4[512].
-__global__ __launch_bounds__(512) void k_boundary_pack(VolumeDev v, const uint32_t* __restrict__ n_dev,
-                                                       uint8_t* records, uint32_t cap) {
-  const uint32_t n = *n_dev;
+__global__ __launch_bounds__(512) void k_boundary_pack(VolumeDev v, uint8_t* records, uint32_t cap) {
+  const SelBuf& L = v.sel;
+  const uint32_t n = L.ctl->n_list;
   __shared__ uint32_t spos;
   for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-    const int4 id = v.list_id[e];
+    const int4 id = L.list_id[e];
     const bool face = (id.x == v.part_lo) || (id.x == v.part_hi - 1);
     const bool owned = (id.x >= v.part_lo) && (id.x < v.part_hi);
-    const uint32_t slot = v.list_slot[e];
-    if (!(face && owned && v.list_needs[e] && slot != kInvalidSlot)) continue;  // block-uniform
-    if (threadIdx.x == 0) spos = atomicAdd(&v.ctl->n_tmp, 1u);
+    const uint32_t slot = L.list_slot[e];
+    if (!(face && owned && L.list_needs[e] && slot != kInvalidSlot)) continue;  // block-uniform
+    if (threadIdx.x == 0) spos = atomicAdd(&v.vctl->n_tmp, 1u);
     __syncthreads();
     const uint32_t p = spos;
     if (p < cap) {
@@ -837,9 +1075,8 @@ __global__ __launch_bounds__(512) void k_boundary_pack(VolumeDev v, const uint32
     __syncthreads();
   }
 }
-void launch_boundary_pack(const VolumeDev& v, const uint32_t* n_dev, uint8_t* records, uint32_t cap,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(k_boundary_pack, dim3(1024), dim3(512), 0, s, v, n_dev, records, cap);
+void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s) {
+  hipLaunchKernelGGL(k_boundary_pack, dim3(1024), dim3(512), 0, s, v, records, cap);
 }
 
 // Store received records of chunks this rank does not own as ghost chunks.
@@ -852,7 +1089,8 @@ __global__ __launch_bounds__(512) void k_boundary_unpack(VolumeDev v, const uint
     if (owned) continue;  // block-uniform
     if (threadIdx.x == 0) {
       bool is_new;
-      sslot = chunk_acquire(v, id, &is_new);
+      uint32_t ent;
+      sslot = chunk_acquire(v, id, &is_new, &ent);
     }
     __syncthreads();
     const uint32_t slot = sslot;

@@ -62,6 +62,8 @@ struct tf_volume {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   tf::VolumeDev dev;
+  tf::SelBuf selbuf[2];  // double-buffered selection scratch (dev.sel = the active set)
+  int cur_sel = 0;
   std::vector<void*> allocs;
   // frame images
   float* d_depth = nullptr;      // owned staging targets
