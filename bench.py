@@ -65,7 +65,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from texturefusion_amd import capi, synth
+    from texturefusion_amd import capi, exchange, synth
     from texturefusion_amd import partition as part
 
     cam = synth.Camera.hires() if args.hires else synth.Camera()
@@ -86,19 +86,15 @@ def main():
         vol.set_partition(lo, hi)
         rec_cap = 1 << 14
         send = torch.empty(rec_cap * capi.TF_BOUNDARY_RECORD_BYTES, dtype=torch.uint8, device=dev)
-        recv = [torch.empty_like(send) for _ in range(world)]
 
-    def exchange():
+    def exchange_boundary():
         """All-gather of updated boundary chunks over RCCL (xGMI); counts first, then payloads."""
         n = vol.boundary_pack(send.data_ptr(), rec_cap)
-        cnt = torch.tensor([n], dtype=torch.int64, device=dev)
-        cnts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(cnts, cnt)
-        dist.all_gather(recv, send)
-        for r in range(world):
-            m = int(cnts[r].item())
+        got = exchange.allgather_records(send, n)
+        for r, (buf, m) in enumerate(got):
             if r != rank and m:
-                vol.boundary_unpack(recv[r].data_ptr(), m)
+                vol.boundary_unpack(buf.data_ptr(), m)
+        vol.sync()
 
     def run(first, count, timed):
         """Frames [first, first+count) of the stream (cyclic over the unique frames)."""
@@ -111,7 +107,7 @@ def main():
                 sub = idx[b:b + args.exchange_every]
                 vol.integrate_frames_device([d_depth[i].data_ptr() for i in sub],
                                             [d_rgba[i].data_ptr() for i in sub], poses[sub])
-                exchange()
+                exchange_boundary()
 
     def barrier():
         if world > 1:

@@ -1,0 +1,67 @@
+"""Chunk-range partitions on ONE GPU: two handles own complementary ChunkID.x slabs, run the fused unit
+on the same frames, exchange boundary records through tf_boundary_pack / tf_boundary_unpack; the union
+of the partitions must equal the single-handle result bit for bit."""
+import numpy as np
+import pytest
+
+from texturefusion_amd import capi, synth
+from tests.util import HipBuffer, sorted_ids
+
+pytestmark = pytest.mark.gpu
+RES5 = np.float32(0.005)
+
+
+def test_two_partitions_equal_one(gpu_required):
+    cam = synth.Camera()
+    split = 3
+    single = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    parts = [capi.Volume(RES5, cam, max_chunks=1 << 16), capi.Volume(RES5, cam, max_chunks=1 << 16)]
+    parts[0].set_partition(-(1 << 31), split)
+    parts[1].set_partition(split, (1 << 31) - 1)
+    cap = 4096
+    bufs = [HipBuffer(cap * capi.TF_BOUNDARY_RECORD_BYTES) for _ in range(2)]
+    for k in (0, 1, 2):
+        depth, rgba, q, pose = synth.room_frame(k, cam)
+        for v in [single] + parts:
+            v.frame_upload(depth, rgba, None)
+            v.integrate_frame(pose, True)
+            v.sync()
+        n = [parts[r].boundary_pack(bufs[r].ptr, cap) for r in range(2)]
+        assert n[0] > 0 and n[1] > 0
+        parts[0].boundary_unpack(bufs[1].ptr, n[1])
+        parts[1].boundary_unpack(bufs[0].ptr, n[0])
+        for v in parts:
+            v.sync()
+        # every packed record is an updated face chunk owned by the packer
+        for r in range(2):
+            rec = bufs[r].to_host(n[r] * capi.TF_BOUNDARY_RECORD_BYTES).reshape(n[r], -1)
+            ids = rec[:, :12].copy().view(np.int32).reshape(-1, 3)
+            face = split - 1 if r == 0 else split
+            assert np.all(ids[:, 0] == face)
+    ref_ids = sorted_ids(single.list_chunks())
+    s_ref, w_ref, c_ref = single.get_chunks(ref_ids)
+    key = {tuple(c): i for i, c in enumerate(ref_ids)}
+    seen = set()
+    for r, v in enumerate(parts):
+        ids = v.list_chunks()
+        lo, hi = (-(1 << 31), split) if r == 0 else (split, (1 << 31) - 1)
+        s, w, c = v.get_chunks(ids)
+        for i, cid in enumerate(ids):
+            t = tuple(int(x) for x in cid)
+            owned = lo <= cid[0] < hi
+            if owned:
+                assert t in key, "partition %d holds a chunk the single volume does not" % r
+                seen.add(t)
+            if t in key:  # owned chunks and ghost copies both carry the reference state
+                j = key[t]
+                assert np.array_equal(s[i].view(np.uint32), s_ref[j].view(np.uint32))
+                assert np.array_equal(w[i].view(np.uint32), w_ref[j].view(np.uint32))
+                assert np.array_equal(c[i], c_ref[j])
+    assert seen == set(key)
+    dirty = set(map(tuple, single.dirty()))
+    dparts = set(map(tuple, parts[0].dirty())) | set(map(tuple, parts[1].dirty()))
+    assert dirty == dparts
+    for v in [single] + parts:
+        v.close()
+    for b in bufs:
+        b.free()

@@ -1,0 +1,75 @@
+"""Host-side logic that needs no GPU: synthetic streams, partition planner, host constants."""
+import numpy as np
+
+from oracle import api as O
+from texturefusion_amd import partition as part
+from texturefusion_amd import synth
+
+RES5 = np.float32(0.005)
+
+
+def test_room_frames_are_deterministic_and_have_holes():
+    a = synth.room_frame(7)
+    b = synth.room_frame(7)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    depth, rgba, q, pose = a
+    assert depth.dtype == np.float32 and depth.shape == (480, 640)
+    assert rgba.shape == (480, 640, 4) and np.all(rgba[..., 3] == 1)
+    holes = (depth == 0).mean()
+    assert 0.01 < holes < 0.03
+    assert 0.7 < depth[depth > 0].min() and depth.max() < 3.5
+    assert q.min() >= 0 and q.max() < 1
+
+
+def test_pose_inverse():
+    p = synth.pose_euler(0.3, -0.2, 0.1, (0.5, -0.25, 1.0))
+    T = synth.pose_inverse16(p).reshape(4, 4).astype(np.float64)
+    M = np.eye(4)
+    M[:3] = p
+    assert np.allclose(T @ M, np.eye(4), atol=1e-6)
+
+
+def test_slabs_cover_every_id_exactly_once():
+    ext = part.room_extent_chunks(RES5)
+    for world in (1, 2, 4, 8):
+        e = part.slab_bounds(ext, world)
+        assert e[0] == part.INT_MIN and e[-1] == part.INT_MAX and len(e) == world + 1
+        assert all(e[i] < e[i + 1] for i in range(world))
+        ids = np.stack([np.arange(-200, 200), np.zeros(400, int), np.zeros(400, int)], 1).astype(np.int32)
+        own = part.owner_of(ids, ext, world)
+        assert own.min() == 0 and own.max() == world - 1
+        for r in range(world):
+            lo, hi = part.slab_for_rank(ext, r, world)
+            assert np.array_equal(own == r, (ids[:, 0] >= lo) & (ids[:, 0] < hi))
+
+
+def test_merge_needs_reproduces_single_process_flags():
+    cam = synth.Camera()
+    C, ig = O.camera_from(cam), O.default_integrator()
+    depth, rgba, q, pose = synth.room_frame(2, cam)
+    ref = O.Volume(RES5, C, ig)
+    ids, new = ref.prepare(depth, pose)
+    needs = np.zeros(len(ids), np.uint8)
+    ref.integrate(depth, rgba, None, pose, ids, needs, 1, -1)
+    ext = part.room_extent_chunks(RES5)
+    world = 4
+    own = part.owner_of(ids, ext, world)
+    per_rank = []
+    for r in range(world):
+        v = O.Volume(RES5, C, ig)
+        ids_r, _ = v.prepare(depth, pose)          # selection runs in full on every rank
+        assert np.array_equal(ids_r, ids)
+        mine = ids[own == r]
+        nd = np.zeros(len(mine), np.uint8)
+        v.integrate(depth, rgba, None, pose, mine, nd, 1, -1)
+        full = np.zeros(len(ids), np.uint8)
+        full[own == r] = nd
+        per_rank.append(full)
+    merged = part.merge_needs(per_rank, ids, ext, world)
+    assert np.array_equal(merged, needs)
+
+
+def test_boundary_mask():
+    ids = np.array([[4, 0, 0], [5, 0, 0], [9, 1, 1], [10, 0, 0]], np.int32)
+    assert list(part.boundary_mask(ids, 5, 10)) == [False, True, True, False]

@@ -1,0 +1,151 @@
+"""N > 1 path on CPU: two processes over gloo.  Each rank owns a ChunkID.x slab, runs selection in
+full, integrates only its slab (oracle as the per-rank compute -- test infrastructure), exchanges
+the records of updated face chunks with the product's exchange helper, and the union of the
+partitions must equal the single-process result bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+WORLD = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _pack(vol, ids, needs, lo, hi):
+    """numpy twin of tf_boundary_pack's record layout (int4 id | {sdf,w}[512] | colour[512][4])."""
+    from texturefusion_amd import exchange, partition as part
+    face = part.boundary_mask(ids, lo, hi) & (needs != 0)
+    sel = ids[face]
+    buf = np.zeros((max(len(sel), 1), exchange.RECORD_BYTES), np.uint8)
+    for i, cid in enumerate(sel):
+        s, w, c = vol.get_chunk(cid)
+        buf[i, :12] = np.asarray(cid, np.int32).view(np.uint8)
+        tw = np.stack([s, w], 1).astype(np.float32)
+        buf[i, 16:16 + 4096] = tw.reshape(-1).view(np.uint8)
+        buf[i, 16 + 4096:] = c.view(np.uint8)
+    return buf, len(sel)
+
+
+def _unpack(vol, buf, n):
+    for i in range(n):
+        cid = buf[i, :12].view(np.int32).copy()
+        tw = buf[i, 16:16 + 4096].view(np.float32).reshape(512, 2)
+        col = buf[i, 16 + 4096:].view(np.uint16).copy()
+        vol.set_chunk(cid, tw[:, 0].copy(), tw[:, 1].copy(), col)
+
+
+def _frame(k, cam):
+    from texturefusion_amd import synth
+    pose = synth.pose_euler(0.15 * (k + 1), 0.05 * k, 0.0, (0.05 * k, 0.0, 0.0))
+    depth, rgba, q, _ = synth.wall_frame(1.2, cam, pose=pose, seed=k)
+    return depth, rgba, q, pose
+
+
+def _worker(rank, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from oracle import api as O
+    from texturefusion_amd import exchange, partition as part, synth
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    res = np.float32(0.01)
+    cam = synth.Camera()
+    C, ig = O.camera_from(cam), O.default_integrator()
+    ext = part.room_extent_chunks(res, half_x=0.6, margin=0.1)
+    lo, hi = part.slab_for_rank(ext, rank, WORLD)
+    vol = O.Volume(res, C, ig)
+    cap = 1024
+    all_needs = []
+    for k in (0, 1):
+        depth, rgba, q, pose = _frame(k, cam)
+        ids, new = vol.prepare(depth, pose)  # full selection on every rank
+        own = part.owner_of(ids, ext, WORLD) == rank
+        mine = ids[own]
+        nd = np.zeros(len(mine), np.uint8)
+        vol.integrate(depth, rgba, None, pose, mine, nd, 1, -1)
+        needs = np.zeros(len(ids), np.uint8)
+        needs[own] = nd
+        # chunks created by prepare but owned elsewhere are not this rank's business
+        newm = new.copy()
+        vol.finalize(ids[own], nd, newm[own])
+        for cid in ids[~own]:
+            pass
+        buf, n = _pack(vol, ids, needs, lo, hi)
+        send = torch.zeros(cap * exchange.RECORD_BYTES, dtype=torch.uint8)
+        send[: buf[:n].size] = torch.from_numpy(buf[:n].reshape(-1))
+        got = exchange.allgather_records(send, n)
+        for r, (t, m) in enumerate(got):
+            if r != rank and m:
+                _unpack(vol, t.numpy()[: m * exchange.RECORD_BYTES].reshape(m, exchange.RECORD_BYTES), m)
+        # merged needsUpdate flags in reference list order
+        tn = torch.from_numpy(needs.copy())
+        gl = [torch.zeros_like(tn) for _ in range(WORLD)]
+        dist.all_gather(gl, tn)
+        merged = part.merge_needs([g.numpy() for g in gl], ids, ext, WORLD)
+        all_needs.append(merged)
+    owned = [cid for cid in vol.list_chunks() if lo <= cid[0] < hi]
+    ghosts = [cid for cid in vol.list_chunks() if not (lo <= cid[0] < hi)]
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
+             owned=np.asarray(owned, np.int32).reshape(-1, 3),
+             ghosts=np.asarray(ghosts, np.int32).reshape(-1, 3),
+             owned_sdf=np.stack([vol.get_chunk(c)[0] for c in owned]),
+             owned_w=np.stack([vol.get_chunk(c)[1] for c in owned]),
+             owned_col=np.stack([vol.get_chunk(c)[2] for c in owned]),
+             ghost_sdf=np.stack([vol.get_chunk(c)[0] for c in ghosts]) if ghosts else np.zeros((0, 512), np.float32),
+             needs=np.concatenate(all_needs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_partition_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import api as O
+    from texturefusion_amd import synth
+
+    port = _free_port()
+    mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+
+    res = np.float32(0.01)
+    cam = synth.Camera()
+    ref = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    ref_needs = []
+    for k in (0, 1):
+        depth, rgba, q, pose = _frame(k, cam)
+        ids, new = ref.prepare(depth, pose)
+        nd = np.zeros(len(ids), np.uint8)
+        ref.integrate(depth, rgba, None, pose, ids, nd, 1, -1)
+        ref.finalize(ids, nd, new)
+        ref_needs.append(nd)
+    ref_needs = np.concatenate(ref_needs)
+    ref_ids = {tuple(c) for c in ref.list_chunks()}
+    seen = set()
+    for r in range(WORLD):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % r))
+        assert np.array_equal(z["needs"], ref_needs)          # merged flags == single-process flags
+        for i, cid in enumerate(z["owned"]):
+            t = tuple(int(x) for x in cid)
+            if t not in ref_ids:
+                # created by the full selection but never updated on the owner: garbage in the reference
+                assert np.all(z["owned_w"][i] == 0)
+                continue
+            seen.add(t)
+            s, w, c = ref.get_chunk(cid)
+            assert np.array_equal(s.view(np.uint32), z["owned_sdf"][i].view(np.uint32))
+            assert np.array_equal(w.view(np.uint32), z["owned_w"][i].view(np.uint32))
+            assert np.array_equal(c, z["owned_col"][i])
+        for i, cid in enumerate(z["ghosts"]):  # ghost copies carry the owner's current TSDF
+            t = tuple(int(x) for x in cid)
+            if t in ref_ids and z["ghost_sdf"][i].min() < 999.0:
+                s, _, _ = ref.get_chunk(cid)
+                assert np.array_equal(s.view(np.uint32), z["ghost_sdf"][i].view(np.uint32))
+    assert seen == ref_ids

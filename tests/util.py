@@ -35,3 +35,32 @@ def sorted_ids(ids):
         return ids
     order = np.lexsort((ids[:, 2], ids[:, 1], ids[:, 0]))
     return ids[order]
+
+
+class HipBuffer:
+    """Raw device buffer through the HIP runtime the product library already loaded (no torch)."""
+
+    def __init__(self, nbytes):
+        import ctypes as C
+        capi.lib()
+        self._hip = C.CDLL("libamdhip64.so")
+        self._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self._hip.hipFree.argtypes = [C.c_void_p]
+        self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        p = C.c_void_p()
+        rc = self._hip.hipMalloc(C.byref(p), nbytes)
+        assert rc == 0, "hipMalloc failed: %d" % rc
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def to_host(self, nbytes=None):
+        n = self.nbytes if nbytes is None else nbytes
+        out = np.empty(n, np.uint8)
+        rc = self._hip.hipMemcpy(out.ctypes.data, self.ptr, n, 2)  # hipMemcpyDeviceToHost
+        assert rc == 0
+        return out
+
+    def free(self):
+        if self.ptr:
+            self._hip.hipFree(self.ptr)
+            self.ptr = None

@@ -1,0 +1,26 @@
+"""Boundary-chunk exchange between chunk-range partitions.
+
+The only collective of the path: an all-gather of the records of updated chunks that sit on a
+slab face.  Counts are gathered first, then fixed-capacity padded payload buffers (RCCL over
+xGMI when the tensors are device-resident and the backend is "nccl"; gloo on CPU in the tests).
+torch.distributed is plumbing here; the records are produced / consumed by tf_boundary_pack /
+tf_boundary_unpack (include/tf_fusion.h).
+"""
+from __future__ import annotations
+
+RECORD_BYTES = 16 + 4096 + 4096
+
+
+def allgather_records(send, n_records: int, group=None):
+    """send: 1-D uint8 tensor of capacity cap*RECORD_BYTES holding n_records records.
+    Returns [(tensor, count)] per rank (own rank included)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    cnt = torch.tensor([int(n_records)], dtype=torch.int64, device=send.device)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt, group=group)
+    recv = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(recv, send, group=group)
+    return [(recv[r], int(cnts[r].item())) for r in range(world)]

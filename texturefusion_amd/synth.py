@@ -129,3 +129,43 @@ def wall_frame(z: float = 1.5, cam: Camera = Camera(), pose: np.ndarray | None =
     rgba[...] = np.asarray(rgba_value, np.uint8)
     quality = np.full((cam.height, cam.width), quality_value, np.float32)
     return depth, rgba, quality, pose
+
+
+def wall_mesh_for_chunks(ids, res, z0: float, seed: int = 5):
+    """Synthetic per-chunk meshes for the atlas stage: for every chunk whose z-extent contains the
+    plane z = z0, a small cloud of vertices on that plane inside the chunk (the reference gets
+    them from marching cubes, Structure/ChunkManager.cpp:595-1002 -- next-stage scope).
+    Returns (chunk ids [m,3], vertex offsets [m+1], verts [nv,3] f32, colors [nv,3] f32 in [0,1])."""
+    ids = np.asarray(ids, np.int32).reshape(-1, 3)
+    edge = 8.0 * float(res)
+    keep, offs, verts, cols = [], [0], [], []
+    for cid in ids:
+        zlo = cid[2] * edge
+        if not (zlo <= z0 < zlo + edge):
+            continue
+        h = (int(cid[0]) * 73856093) ^ (int(cid[1]) * 19349663) ^ (int(cid[2]) * 83492791) ^ seed
+        rng = np.random.Generator(np.random.PCG64(h & 0x7FFFFFFF))
+        n = 12 + int(rng.integers(0, 28))
+        p = np.empty((n, 3), np.float64)
+        p[:, 0] = cid[0] * edge + rng.random(n) * edge
+        p[:, 1] = cid[1] * edge + rng.random(n) * edge
+        p[:, 2] = z0
+        keep.append(cid)
+        verts.append(p.astype(np.float32))
+        cols.append(rng.random((n, 3)).astype(np.float32))
+        offs.append(offs[-1] + n)
+    if not keep:
+        return (np.zeros((0, 3), np.int32), np.zeros(1, np.int64), np.zeros((0, 3), np.float32),
+                np.zeros((0, 3), np.float32))
+    return (np.asarray(keep, np.int32), np.asarray(offs, np.int64), np.concatenate(verts),
+            np.concatenate(cols))
+
+
+def pose_inverse16(pose: np.ndarray) -> np.ndarray:
+    """f32(SE3d.inverse().matrix()) of a camera-to-world [R|t] (Patch.cpp:51): double inverse, then cast."""
+    p = np.asarray(pose, np.float64).reshape(3, 4)
+    R, t = p[:, :3], p[:, 3]
+    T = np.eye(4)
+    T[:3, :3] = R.T
+    T[:3, 3] = -R.T @ t
+    return T.astype(np.float32).reshape(16)
