@@ -9,7 +9,7 @@ import pytest
 
 from oracle import api as O
 from texturefusion_amd import synth
-from tests.util import RES5, RES10, assert_chunks_equal, make_pair, sorted_ids
+from tests.util import RES5, RES10, HipBuffer, assert_chunks_equal, make_pair, sorted_ids
 
 pytestmark = pytest.mark.gpu
 
@@ -201,3 +201,35 @@ def test_pool_capacity_is_reported(gpu_required):
     with pytest.raises(capi.TFError) as e:
         gv.prepare(pose)
     assert e.value.code == capi.TF_ERR_CAPACITY
+
+
+def test_batched_two_stream_pipeline_matches_oracle(gpu_required):
+    """tf_integrate_frames_device: selection of frame f+1 overlaps integration of frame f on a second
+    stream (double-buffered selection scratch); results must equal the oracle's frame-by-frame unit."""
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 16)
+    ks = [0, 1, 2, 3, 4, 5, 6]
+    frames = [synth.room_frame(k, cam, with_quality=False) for k in ks]
+    dd = [HipBuffer(f[0].nbytes).from_host(f[0]) for f in frames]
+    dc = [HipBuffer(f[1].nbytes).from_host(f[1]) for f in frames]
+    poses = np.stack([f[3].reshape(12) for f in frames])
+    # odd and even batch lengths exercise both selection sets as the "last" one
+    for lo, hi in ((0, 3), (3, 7)):
+        gv.integrate_frames_device([b.ptr for b in dd[lo:hi]], [b.ptr for b in dc[lo:hi]], poses[lo:hi])
+        gv.sync()
+        for f in frames[lo:hi]:
+            ov.rowstats(clear=True)
+            nv, ns = ov.integrate_frame(f[0], f[1], f[3])
+        st = gv.stats()
+        ost = ov.rowstats()
+        assert (st.n_selected, st.n_updated) == (ns, nv)
+        assert (st.rows_tsdf, st.rows_color) == (ost.rows_tsdf, ost.rows_color)
+        assert st.n_chunks == ov.num_chunks()
+    ids = ov.list_chunks()
+    assert np.array_equal(sorted_ids(ids), sorted_ids(gv.list_chunks()))
+    assert_chunks_equal(ov, gv, ids, "batched")
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+    # the call-by-call flow still works right after a batch
+    depth, rgba, quality, pose = synth.room_frame(8, cam)
+    _frame_flow(ov, gv, depth, rgba, quality, pose, kf_id=8, use_quality=True)
+    for b in dd + dc:
+        b.free()

@@ -53,6 +53,13 @@ class HipBuffer:
         self.ptr = p.value
         self.nbytes = nbytes
 
+    def from_host(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        rc = self._hip.hipMemcpy(self.ptr, arr.ctypes.data, arr.nbytes, 1)  # hipMemcpyHostToDevice
+        assert rc == 0
+        return self
+
     def to_host(self, nbytes=None):
         n = self.nbytes if nbytes is None else nbytes
         out = np.empty(n, np.uint8)

@@ -63,9 +63,10 @@ int ensure_pinned(tf_volume* v, size_t bytes) {
   return TF_OK;
 }
 
-void prof_begin(tf_volume* v, int kind) {
+void prof_begin(tf_volume* v, int kind, hipStream_t s) {
   v->prof_open = ((v->prof_mask >> kind) & 1u) != 0;
   if (!v->prof_open) return;
+  if (!s) s = v->stream;
   ProfEvent pe;
   pe.kind = kind;
   auto get = [&](hipEvent_t* e) {
@@ -74,13 +75,13 @@ void prof_begin(tf_volume* v, int kind) {
   };
   get(&pe.a);
   get(&pe.b);
-  hipEventRecord(pe.a, v->stream);
+  hipEventRecord(pe.a, s);
   v->prof_events.push_back(pe);
 }
-void prof_end(tf_volume* v) {
+void prof_end(tf_volume* v, hipStream_t s) {
   if (!v->prof_open) return;
   v->prof_open = false;
-  hipEventRecord(v->prof_events.back().b, v->stream);
+  hipEventRecord(v->prof_events.back().b, s ? s : v->stream);
 }
 
 static void prof_collect(tf_volume* v) {
@@ -158,21 +159,22 @@ static int init_device_state(tf_volume* v) {
 
 // The kernels of Chisel::PrepareIntersectChunks (Structure/Chisel.h:103-140).  The fused per-frame
 // unit skips the stand-alone slot lookup: k_integrate<FUSED> does it per chunk.
-static int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire) {
+static int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hipStream_t s = nullptr) {
+  if (!s) s = v->stream;
   const SelectConsts sc = make_select_consts(pose.p, v->res);
-  prof_begin(v, TF_PROF_BBOX);
-  launch_bbox(v->dev, v->frame.depth, v->cam, pose, v->stream);
-  prof_end(v);
-  prof_begin(v, TF_PROF_SELECT);
-  launch_select(v->dev, v->frame.depth, v->cam, v->ig, pose, v->res, v->stream);
-  prof_end(v);
-  prof_begin(v, TF_PROF_SCAN);
-  launch_scan(v->dev, sc.step, v->stream);
-  prof_end(v);
+  prof_begin(v, TF_PROF_BBOX, s);
+  launch_bbox(v->dev, v->frame.depth, v->cam, pose, s);
+  prof_end(v, s);
+  prof_begin(v, TF_PROF_SELECT, s);
+  launch_select(v->dev, v->frame.depth, v->cam, v->ig, pose, v->res, s);
+  prof_end(v, s);
+  prof_begin(v, TF_PROF_SCAN, s);
+  launch_scan(v->dev, sc.step, s);
+  prof_end(v, s);
   if (with_acquire) {
-    prof_begin(v, TF_PROF_EMIT);
-    launch_acquire(v->dev, v->stream);
-    prof_end(v);
+    prof_begin(v, TF_PROF_EMIT, s);
+    launch_acquire(v->dev, s);
+    prof_end(v, s);
   }
   return TF_OK;
 }
@@ -268,6 +270,15 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     return fail(TF_ERR_HIP);
   }
   v->own_stream = true;
+  if (hipStreamCreateWithFlags(&v->sel_stream, hipStreamNonBlocking) != hipSuccess) {
+    set_error("hipStreamCreate failed");
+    return fail(TF_ERR_HIP);
+  }
+  for (int k = 0; k < 2; ++k) {
+    hipEventCreateWithFlags(&v->ev_sel_done[k], hipEventDisableTiming);
+    hipEventCreateWithFlags(&v->ev_ka_done[k], hipEventDisableTiming);
+  }
+  hipEventCreateWithFlags(&v->ev_batch, hipEventDisableTiming);
 
   VolumeDev& d = v->dev;
   memset(&d, 0, sizeof(d));
@@ -320,6 +331,12 @@ int tf_volume_destroy(tf_volume* v) {
   if (v->d_quality) hipFree(v->d_quality);
   if (v->d_tmp) hipFree(v->d_tmp);
   if (v->h_pinned) hipHostFree(v->h_pinned);
+  if (v->sel_stream) { hipStreamSynchronize(v->sel_stream); hipStreamDestroy(v->sel_stream); }
+  for (int k = 0; k < 2; ++k) {
+    if (v->ev_sel_done[k]) hipEventDestroy(v->ev_sel_done[k]);
+    if (v->ev_ka_done[k]) hipEventDestroy(v->ev_ka_done[k]);
+  }
+  if (v->ev_batch) hipEventDestroy(v->ev_batch);
   if (v->own_stream && v->stream) hipStreamDestroy(v->stream);
   delete v;
   return TF_OK;
@@ -547,15 +564,35 @@ int tf_integrate_frame(tf_volume* v, const float pose[12], int use_color) {
 int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* const* d_depth,
                                const uint8_t* const* d_rgba, const float* poses12) {
   if (!v || !d_depth || !poses12) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (n_frames <= 0) return TF_OK;
   v->host_list_n = -1;
+  // Two-stream software pipeline.  Selection (bbox -> select -> scan) of a frame is a pure function
+  // of its depth image and pose, so it runs on sel_stream one frame ahead, into the selection set
+  // the integrate kernel of that frame will read; integration stays in frame order on the main
+  // stream (voxel updates of consecutive frames must not reorder).
+  hipStream_t sA = v->stream, sB = v->sel_stream;
+  TF_HIP(hipEventRecord(v->ev_batch, sA));
+  TF_HIP(hipStreamWaitEvent(sB, v->ev_batch, 0));  // earlier work on the main stream may use either set
   for (int64_t f = 0; f < n_frames; ++f) {
+    const int b = (int)((v->cur_sel + 1 + f) & 1);
     int rc = tf_frame_bind_device(v, d_depth[f], d_rgba ? d_rgba[f] : nullptr, nullptr);
     if (rc) return rc;
     Pose P;
     memcpy(P.p, poses12 + 12 * f, sizeof(P.p));
-    rc = enqueue_frame(v, P, d_rgba && d_rgba[f]);
+    v->dev.sel = v->selbuf[b];
+    if (f >= 2) TF_HIP(hipStreamWaitEvent(sB, v->ev_ka_done[b], 0));  // set b is free again
+    rc = launch_prepare(v, P, false, sB);
     if (rc) return rc;
+    TF_HIP(hipEventRecord(v->ev_sel_done[b], sB));
+    TF_HIP(hipStreamWaitEvent(sA, v->ev_sel_done[b], 0));
+    const bool col = d_rgba && d_rgba[f];
+    prof_begin(v, TF_PROF_INTEGRATE);  // slot lookup + voxel update + finalize in one launch
+    launch_integrate(v->dev, v->frame, v->cam, v->ig, P, v->res, 1, col, false, true, v->epoch++, sA);
+    prof_end(v);
+    TF_HIP(hipEventRecord(v->ev_ka_done[b], sA));
   }
+  v->cur_sel = (int)((v->cur_sel + n_frames) & 1);
+  v->dev.sel = v->selbuf[v->cur_sel];
   TF_HIP(hipGetLastError());
   return TF_OK;
 }

@@ -289,7 +289,9 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth,
     if (overflow) atomicOr(&v.vctl->status, kStCoarseFull);
   }
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to the compiler;
+  // readfirstlane makes the uniformity provable (scalar loads, no waterfall loops around buffer ops)
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   const int corner = lane & 7;
   const int step = sc.step;
@@ -542,7 +544,9 @@ __global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img,
                                                    Pose P, IntegrateConsts kc, uint32_t epoch) {
   const SelBuf& L = v.sel;
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to the compiler;
+  // readfirstlane makes the uniformity provable (scalar loads, no waterfall loops around buffer ops)
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
   const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t n = L.ctl->n_list;
   const int vx = lane & 7, vy = lane >> 3;

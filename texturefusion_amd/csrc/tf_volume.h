@@ -61,6 +61,11 @@ struct tf_volume {
   tf::Integ ig;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  // second stream: selection of frame f+1 overlaps the integration of frame f (batched unit)
+  hipStream_t sel_stream = nullptr;
+  hipEvent_t ev_sel_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_ka_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_batch = nullptr;
   tf::VolumeDev dev;
   tf::SelBuf selbuf[2];  // double-buffered selection scratch (dev.sel = the active set)
   int cur_sel = 0;
@@ -93,8 +98,8 @@ struct tf_volume {
 namespace tf {
 int ensure_tmp(tf_volume* v, size_t bytes);
 int ensure_pinned(tf_volume* v, size_t bytes);
-void prof_begin(tf_volume* v, int kind);
-void prof_end(tf_volume* v);
+void prof_begin(tf_volume* v, int kind, hipStream_t s = nullptr);
+void prof_end(tf_volume* v, hipStream_t s = nullptr);
 int atlas_init(tf_volume* v);
 void atlas_destroy(tf_volume* v);
 int atlas_reset(tf_volume* v);
