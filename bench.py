@@ -122,6 +122,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     run(Wm, K, True)
+    t_enq = time.perf_counter() - t0  # host time to enqueue the timed region (launches are asynchronous)
     barrier()
     dt = time.perf_counter() - t0
     prof = vol.profile_get(reset=True) if not args.no_roofline else None
@@ -140,6 +141,7 @@ def main():
         "steps": K,
         "warmup": Wm,
         "ms_per_step": 1e3 * dt / K,
+        "host_enqueue_ms_per_step": 1e3 * t_enq / K,
         "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,

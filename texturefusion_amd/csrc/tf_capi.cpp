@@ -144,7 +144,7 @@ static int init_device_state(tf_volume* v) {
   TF_HIP(hipMemsetAsync(d.hent, 0xFF, ((size_t)d.hmask + 1) * sizeof(HEntry), s));  // key = empty
   TF_HIP(hipMemsetAsync(d.dkeys, 0xFF, ((size_t)d.dmask + 1) * 8, s));
   TF_HIP(hipMemsetAsync(d.dstamp, 0, ((size_t)d.dmask + 1) * 4, s));
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < tf_volume::kSelSets; ++k) {
     d.sel = v->selbuf[k];
     launch_reset_ctl(d, k == 0, s);
   }
@@ -166,12 +166,12 @@ static int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hip
   launch_bbox(v->dev, v->frame.depth, v->cam, pose, s);
   prof_end(v, s);
   prof_begin(v, TF_PROF_SELECT, s);
-  launch_select(v->dev, v->frame.depth, v->cam, v->ig, pose, v->res, s);
+  launch_select(v->dev, v->frame.depth, v->cam, v->ig, pose, v->res, /*emit=*/!with_acquire, s);
   prof_end(v, s);
-  prof_begin(v, TF_PROF_SCAN, s);
-  launch_scan(v->dev, sc.step, s);
-  prof_end(v, s);
-  if (with_acquire) {
+  if (with_acquire) {  // call-by-call flow: reference-ordered list, then slot lookup
+    prof_begin(v, TF_PROF_SCAN, s);
+    launch_scan(v->dev, sc.step, s);
+    prof_end(v, s);
     prof_begin(v, TF_PROF_EMIT, s);
     launch_acquire(v->dev, s);
     prof_end(v, s);
@@ -270,11 +270,17 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     return fail(TF_ERR_HIP);
   }
   v->own_stream = true;
-  if (hipStreamCreateWithFlags(&v->sel_stream, hipStreamNonBlocking) != hipSuccess) {
-    set_error("hipStreamCreate failed");
-    return fail(TF_ERR_HIP);
+  {
+    // the selection kernels are small and latency-critical (the next integrate launch waits on
+    // them) while k_integrate fills every CU: give their stream the highest dispatch priority
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&v->sel_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
+      set_error("hipStreamCreate failed");
+      return fail(TF_ERR_HIP);
+    }
   }
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < tf_volume::kSelSets; ++k) {
     hipEventCreateWithFlags(&v->ev_sel_done[k], hipEventDisableTiming);
     hipEventCreateWithFlags(&v->ev_ka_done[k], hipEventDisableTiming);
   }
@@ -298,7 +304,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   if ((rc = dev_alloc(v, &d.dkeys, dcap))) return fail(rc);
   if ((rc = dev_alloc(v, &d.dstamp, dcap))) return fail(rc);
   if ((rc = dev_alloc(v, &d.vctl, (size_t)1))) return fail(rc);
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < tf_volume::kSelSets; ++k) {
     SelBuf& L = v->selbuf[k];
     if ((rc = dev_alloc(v, &L.masks, (size_t)d.max_coarse))) return fail(rc);
     if ((rc = dev_alloc(v, &L.offsets, (size_t)d.max_coarse))) return fail(rc);
@@ -332,7 +338,7 @@ int tf_volume_destroy(tf_volume* v) {
   if (v->d_tmp) hipFree(v->d_tmp);
   if (v->h_pinned) hipHostFree(v->h_pinned);
   if (v->sel_stream) { hipStreamSynchronize(v->sel_stream); hipStreamDestroy(v->sel_stream); }
-  for (int k = 0; k < 2; ++k) {
+  for (int k = 0; k < tf_volume::kSelSets; ++k) {
     if (v->ev_sel_done[k]) hipEventDestroy(v->ev_sel_done[k]);
     if (v->ev_ka_done[k]) hipEventDestroy(v->ev_ka_done[k]);
   }
@@ -538,63 +544,61 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
   return TF_OK;
 }
 
-static int enqueue_frame(tf_volume* v, const Pose& P, int use_color) {
-  int rc = launch_prepare(v, P, false);
-  if (rc) return rc;
-  const bool col = use_color && v->frame.rgba;
-  prof_begin(v, TF_PROF_INTEGRATE);  // slot lookup + voxel update + finalize in one launch
-  launch_integrate(v->dev, v->frame, v->cam, v->ig, P, v->res, 1, col, false, true, v->epoch++,
-                   v->stream);
-  prof_end(v);
+// Software-pipelined enqueue of n frames on the handle's stream: launch i carries K-A of frame i,
+// K-C of frame i+1 and K-B of frame i+2 as independent block ranges of one kernel (launch_frame),
+// so a batch of n frames is n + 2 dispatches and the only synchronisation is the kernel boundary.
+static int enqueue_frames(tf_volume* v, int64_t n, const float* const* d_depth,
+                          const uint8_t* const* d_rgba, const float* poses12) {
+  const int NS = tf_volume::kSelSets;
+  auto stage = [&](int64_t f, FrameStage* st) {
+    st->sel = v->selbuf[(v->cur_sel + 1 + f) % NS];
+    st->img.depth = d_depth[f];
+    st->img.rgba = (d_rgba && d_rgba[f]) ? reinterpret_cast<const uchar4*>(d_rgba[f]) : nullptr;
+    st->img.quality = nullptr;
+    memcpy(st->pose.p, poses12 + 12 * f, sizeof(st->pose.p));
+    st->epoch = v->epoch + (uint32_t)f;
+  };
+  for (int64_t i = -2; i < n; ++i) {
+    FrameStage cur, nxt, nx2;
+    const bool hc = i >= 0, hn = (i + 1 >= 0) && (i + 1 < n), h2 = (i + 2 < n);
+    if (hc) stage(i, &cur);
+    if (hn) stage(i + 1, &nxt);
+    if (h2) stage(i + 2, &nx2);
+    if (hc) prof_begin(v, TF_PROF_INTEGRATE);
+    launch_frame(v->dev, hc ? &cur : nullptr, hn ? &nxt : nullptr, h2 ? &nx2 : nullptr, v->cam, v->ig,
+                 v->res, v->stream);
+    if (hc) prof_end(v);
+  }
+  v->epoch += (uint32_t)n;
+  v->cur_sel = (int)((v->cur_sel + n) % NS);
+  v->dev.sel = v->selbuf[v->cur_sel];
+  v->host_list_n = -1;
+  TF_HIP(hipGetLastError());
   return TF_OK;
 }
 
 int tf_integrate_frame(tf_volume* v, const float pose[12], int use_color) {
   if (!v || !pose) { set_error("null argument"); return TF_ERR_INVALID; }
   if (!v->frame_bound) { set_error("no frame bound"); return TF_ERR_INVALID; }
-  Pose P;
-  memcpy(P.p, pose, sizeof(P.p));
-  v->host_list_n = -1;
-  int rc = enqueue_frame(v, P, use_color);
-  if (rc) return rc;
-  TF_HIP(hipGetLastError());
-  return TF_OK;
+  const float* dd[1] = {v->frame.depth};
+  const uint8_t* dc[1] = {use_color ? reinterpret_cast<const uint8_t*>(v->frame.rgba) : nullptr};
+  return enqueue_frames(v, 1, dd, dc, pose);
 }
 
 int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* const* d_depth,
                                const uint8_t* const* d_rgba, const float* poses12) {
   if (!v || !d_depth || !poses12) { set_error("null argument"); return TF_ERR_INVALID; }
   if (n_frames <= 0) return TF_OK;
-  v->host_list_n = -1;
-  // Two-stream software pipeline.  Selection (bbox -> select -> scan) of a frame is a pure function
-  // of its depth image and pose, so it runs on sel_stream one frame ahead, into the selection set
-  // the integrate kernel of that frame will read; integration stays in frame order on the main
-  // stream (voxel updates of consecutive frames must not reorder).
-  hipStream_t sA = v->stream, sB = v->sel_stream;
-  TF_HIP(hipEventRecord(v->ev_batch, sA));
-  TF_HIP(hipStreamWaitEvent(sB, v->ev_batch, 0));  // earlier work on the main stream may use either set
-  for (int64_t f = 0; f < n_frames; ++f) {
-    const int b = (int)((v->cur_sel + 1 + f) & 1);
-    int rc = tf_frame_bind_device(v, d_depth[f], d_rgba ? d_rgba[f] : nullptr, nullptr);
-    if (rc) return rc;
-    Pose P;
-    memcpy(P.p, poses12 + 12 * f, sizeof(P.p));
-    v->dev.sel = v->selbuf[b];
-    if (f >= 2) TF_HIP(hipStreamWaitEvent(sB, v->ev_ka_done[b], 0));  // set b is free again
-    rc = launch_prepare(v, P, false, sB);
-    if (rc) return rc;
-    TF_HIP(hipEventRecord(v->ev_sel_done[b], sB));
-    TF_HIP(hipStreamWaitEvent(sA, v->ev_sel_done[b], 0));
-    const bool col = d_rgba && d_rgba[f];
-    prof_begin(v, TF_PROF_INTEGRATE);  // slot lookup + voxel update + finalize in one launch
-    launch_integrate(v->dev, v->frame, v->cam, v->ig, P, v->res, 1, col, false, true, v->epoch++, sA);
-    prof_end(v);
-    TF_HIP(hipEventRecord(v->ev_ka_done[b], sA));
-  }
-  v->cur_sel = (int)((v->cur_sel + n_frames) & 1);
-  v->dev.sel = v->selbuf[v->cur_sel];
-  TF_HIP(hipGetLastError());
-  return TF_OK;
+  for (int64_t f = 0; f < n_frames; ++f)
+    if ((reinterpret_cast<uintptr_t>(d_depth[f]) & 15) || !d_depth[f] ||
+        (d_rgba && (reinterpret_cast<uintptr_t>(d_rgba[f]) & 3))) {
+      set_error("device images must be aligned (depth 16 B, rgba 4 B)");
+      return TF_ERR_INVALID;
+    }
+  int rc = enqueue_frames(v, n_frames, d_depth, d_rgba, poses12);
+  if (rc) return rc;
+  // leave the last frame bound, like a sequence of tf_frame_bind_device calls would
+  return tf_frame_bind_device(v, d_depth[n_frames - 1], d_rgba ? d_rgba[n_frames - 1] : nullptr, nullptr);
 }
 
 int tf_sync(tf_volume* v) {

@@ -110,12 +110,22 @@ struct FrameImages {
   const float* quality;  // may be null
 };
 
+// One frame of a stream as seen by the pipelined launcher.
+struct FrameStage {
+  SelBuf sel;
+  FrameImages img;
+  Pose pose;
+  uint32_t epoch;
+};
+
 // ---- launchers (tf_kernels.hip) ------------------------------------------------------
+void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* next,
+                  const FrameStage* next2, const Cam& cam, const Integ& ig, float res, hipStream_t s);
 void launch_reset_ctl(const VolumeDev& v, bool volume_too, hipStream_t s);
 void launch_bbox(const VolumeDev& v, const float* depth, const Cam& cam, const Pose& pose,
                  hipStream_t s);
 void launch_select(const VolumeDev& v, const float* depth, const Cam& cam, const Integ& ig,
-                   const Pose& pose, float res, hipStream_t s);
+                   const Pose& pose, float res, bool emit, hipStream_t s);
 void launch_scan(const VolumeDev& v, int step, hipStream_t s);
 void launch_acquire(const VolumeDev& v, hipStream_t s);
 void launch_lookup(const VolumeDev& v, uint32_t n, hipStream_t s);

@@ -183,13 +183,14 @@ void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipSt
 // ---------------------------------------------------------------------------------------
 // K-B  world AABB of the back-projected (depth + 0.2) points
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ depth, Cam cam, Pose P,
-                                              FrameCtl* ctl) {
+__device__ __forceinline__ void bbox_body(const float* __restrict__ depth, const Cam& cam, const Pose& P,
+                                          FrameCtl* ctl, const uint32_t bid, const uint32_t nb) {
+  if (bid == 0 && threadIdx.x == 0) ctl->n_list = 0;  // appended to by k_select<EMIT>
   float mn[3] = {1e8f, 1e8f, 1e8f}, mx[3] = {-1e8f, -1e8f, -1e8f};
   const int W = cam.W;
   const int nvec = (cam.W * cam.H) >> 2;
   const float off = 0.2f;
-  for (int q = blockIdx.x * 256 + threadIdx.x; q < nvec; q += gridDim.x * 256) {
+  for (int q = (int)bid * 256 + threadIdx.x; q < nvec; q += (int)nb * 256) {
     const float4 d4 = reinterpret_cast<const float4*>(depth)[q];
     const int pix = q << 2;
     const int i = pix / W, j = pix - i * W;
@@ -238,6 +239,10 @@ __global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ depth, C
     else atomicMax(&ctl->bbox_key[threadIdx.x], f2key(r));
   }
 }
+__global__ __launch_bounds__(256) void k_bbox(const float* __restrict__ depth, Cam cam, Pose P,
+                                              FrameCtl* ctl) {
+  bbox_body(depth, cam, P, ctl, blockIdx.x, gridDim.x);
+}
 void launch_bbox(const VolumeDev& v, const float* depth, const Cam& cam, const Pose& pose,
                  hipStream_t s) {
   int nvec = (cam.W * cam.H) >> 2;
@@ -268,8 +273,14 @@ __device__ __forceinline__ ProbeRes probe(const float* __restrict__ depth, const
   return r;
 }
 
-__global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth, Cam cam, Integ ig,
-                                                SelectConsts sc, VolumeDev v) {
+// EMIT = the fused per-frame unit: the list is consumed on the device only and its order is
+// irrelevant there (chunks are independent), so each hit block appends its chunk ids straight to
+// the list with one atomic and the ordered scan/write-out kernel is skipped.  The call-by-call
+// flow (tf_prepare) needs the reference order and uses EMIT = false + k_scan.
+template <bool EMIT>
+__device__ __forceinline__ void select_body(const float* __restrict__ depth, const Cam& cam, const Integ& ig,
+                                            const SelectConsts& sc, const VolumeDev& v, const uint32_t bid,
+                                            const uint32_t nb) {
   FrameCtl* ctl = v.sel.ctl;
   // GetIDAt (ChunkManager.h:197-207) on the reduced corners; every block derives the same grid.
   int minI[3], maxI[3], dims[3];
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth,
   const unsigned long long total = (unsigned long long)dims[0] * dims[1] * dims[2];
   const bool overflow = total > v.max_coarse;
   const uint32_t n_coarse = overflow ? 0u : (uint32_t)total;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (bid == 0 && threadIdx.x == 0) {
     for (int a = 0; a < 3; ++a) { ctl->min_id[a] = minI[a]; ctl->max_id[a] = maxI[a]; ctl->dims[a] = dims[a]; }
     ctl->n_coarse = n_coarse;
     if (overflow) atomicOr(&v.vctl->status, kStCoarseFull);
@@ -291,8 +302,8 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth,
   const int lane = threadIdx.x & 63;
   // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to the compiler;
   // readfirstlane makes the uniformity provable (scalar loads, no waterfall loops around buffer ops)
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6));
+  const uint32_t nwaves = nb * 4;
   const int corner = lane & 7;
   const int step = sc.step;
   const uint32_t nzny = (uint32_t)dims[2] * (uint32_t)dims[1];
@@ -354,13 +365,35 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth,
       }
       m = __ballot(flag);
     }
-    if (lane == 0) v.sel.masks[cb] = m;
+    if (!EMIT) {
+      if (lane == 0) v.sel.masks[cb] = m;
+    } else if (m) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&ctl->n_list, (uint32_t)__popcll(m));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      if (base + (uint32_t)__popcll(m) > v.max_list) {
+        if (lane == 0) atomicOr(&v.vctl->status, kStListFull);
+      } else if ((m >> lane) & 1ull) {
+        int4 id;
+        id.x = x0 + ((step == 4) ? (lane >> 4) : 0);
+        id.y = y0 + ((step == 4) ? ((lane >> 2) & 3) : 0);
+        id.z = z0 + ((step == 4) ? (lane & 3) : 0);
+        id.w = 0;
+        v.sel.list_id[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = id;
+      }
+    }
   }
 }
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth, Cam cam, Integ ig,
+                                                SelectConsts sc, VolumeDev v) {
+  select_body<EMIT>(depth, cam, ig, sc, v, blockIdx.x, gridDim.x);
+}
 void launch_select(const VolumeDev& v, const float* depth, const Cam& cam, const Integ& ig,
-                   const Pose& pose, float res, hipStream_t s) {
+                   const Pose& pose, float res, bool emit, hipStream_t s) {
   SelectConsts sc = make_select_consts(pose.p, res);
-  hipLaunchKernelGGL(k_select, dim3(1024), dim3(256), 0, s, depth, cam, ig, sc, v);
+  if (emit) hipLaunchKernelGGL(k_select<true>, dim3(1024), dim3(256), 0, s, depth, cam, ig, sc, v);
+  else hipLaunchKernelGGL(k_select<false>, dim3(1024), dim3(256), 0, s, depth, cam, ig, sc, v);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -540,23 +573,32 @@ __device__ __forceinline__ int cvt_sat_rne(float x) {
 // exec-mask juggling and no lane mask has to live in SGPRs across phases.  Descriptors: the three
 // frame images (kernel arguments) and the chunk's two 4-KiB voxel planes (wave-uniform slot).
 template <bool COLOR, bool QUALITY, bool FUSED, int GP>
-__global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img, Cam cam, Integ ig,
-                                                   Pose P, IntegrateConsts kc, uint32_t epoch) {
+__device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameImages& img, const Cam& cam,
+                                               const Integ& ig, const Pose& P, const IntegrateConsts& kc,
+                                               const uint32_t epoch, const uint32_t bid, const uint32_t nb) {
   const SelBuf& L = v.sel;
   const int lane = threadIdx.x & 63;
   // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to the compiler;
   // readfirstlane makes the uniformity provable (scalar loads, no waterfall loops around buffer ops)
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-  const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-  const uint32_t n = L.ctl->n_list;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6));
+  const uint32_t nwaves = nb * 4;
+  const uint32_t n = L.ctl->n_list < v.max_list ? L.ctl->n_list : v.max_list;
   const int vx = lane & 7, vy = lane >> 3;
   const int rowshift = lane & 56;
   const int W = cam.W, H = cam.H;
+  if (FUSED && bid == 0 && threadIdx.x == 0) {
+    // re-arm the K-B reduction of this selection set for its next frame (k_scan does this in the
+    // call-by-call flow); every k_select block of this frame has finished reading the keys
+    for (int a = 0; a < 3; ++a) {
+      L.ctl->bbox_key[a] = f2key(1e8f);
+      L.ctl->bbox_key[3 + a] = f2key(-1e8f);
+    }
+  }
 
   // centroid table (Chisel.cpp:52-110): c[i] = (R^T (x,y,z)) * res + res/2, summed p0 + (p1 + p2);
   // a function of the pose only, shared by the four waves of the workgroup through LDS.
   __shared__ float cenT[3][kChunkVoxels];
-  for (int i = threadIdx.x; i < kChunkVoxels; i += blockDim.x) {
+  for (int i = threadIdx.x; i < kChunkVoxels; i += 256) {
     const float fx = (float)(i & 7), fy = (float)((i >> 3) & 7), fz = (float)(i >> 6);
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -860,6 +902,66 @@ __global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img,
   }
 }
 
+template <bool COLOR, bool QUALITY, bool FUSED, int GP>
+__global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img, Cam cam, Integ ig,
+                                                   Pose P, IntegrateConsts kc, uint32_t epoch) {
+  integrate_body<COLOR, QUALITY, FUSED, GP>(v, img, cam, ig, P, kc, epoch, blockIdx.x, gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------
+// The per-frame unit as ONE launch: three independent block ranges form a 3-stage software
+// pipeline over consecutive frames of a stream --
+//     [0, n_bbox)                 K-B  of frame f+2  (into selection set f+2)
+//     [n_bbox, n_bbox+n_sel)      K-C  of frame f+1  (reads the keys K-B left one launch ago)
+//     [.., .. + n_ka)             K-A  of frame f    (reads the list K-C left one launch ago)
+// The kernel boundary is the only synchronisation: no events, no second stream, one dispatch per
+// frame.  Selection is a pure function of (depth, pose), so running it ahead changes nothing.
+// ---------------------------------------------------------------------------------------
+struct FrameLaunch {
+  VolumeDev v;           // sel = set of frame f
+  FrameImages img;       // frame f
+  Pose P;                // frame f
+  IntegrateConsts kc;
+  Cam cam;
+  Integ ig;
+  uint32_t epoch;
+  uint32_t n_ka, n_sel, n_bbox;
+  uint32_t ka_first;     // block-range order (tuning)
+  SelBuf sel1;           // set of frame f+1
+  const float* depth1;
+  SelectConsts sc1;
+  FrameCtl* ctl2;        // set of frame f+2
+  const float* depth2;
+  Pose P2;
+};
+
+template <bool COLOR, int GP>
+__global__ __launch_bounds__(256) void k_frame(FrameLaunch a) {
+  const uint32_t b = blockIdx.x;
+  if (a.ka_first) {  // K-A blocks first: the small K-C / K-B ranges fill the tail of the launch
+    if (b < a.n_ka) {
+      integrate_body<COLOR, false, true, GP>(a.v, a.img, a.cam, a.ig, a.P, a.kc, a.epoch, b, a.n_ka);
+    } else if (b < a.n_ka + a.n_sel) {
+      VolumeDev v1 = a.v;
+      v1.sel = a.sel1;
+      select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - a.n_ka, a.n_sel);
+    } else {
+      bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_sel, a.n_bbox);
+    }
+    return;
+  }
+  if (b < a.n_bbox) {
+    bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b, a.n_bbox);
+  } else if (b < a.n_bbox + a.n_sel) {
+    VolumeDev v1 = a.v;
+    v1.sel = a.sel1;
+    select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - a.n_bbox, a.n_sel);
+  } else {
+    integrate_body<COLOR, false, true, GP>(a.v, a.img, a.cam, a.ig, a.P, a.kc, a.epoch,
+                                           b - a.n_bbox - a.n_sel, a.n_ka);
+  }
+}
+
 static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
@@ -869,7 +971,8 @@ template <bool FUSED, int GP>
 static void launch_integrate_t(const VolumeDev& v, const FrameImages& img, const Cam& cam,
                                const Integ& ig, const Pose& pose, const IntegrateConsts& kc,
                                bool use_color, bool use_quality, uint32_t epoch, hipStream_t s) {
-  static const int nblocks = env_int("TF_KA_BLOCKS", 2048);  // tuning knob
+  static const int nblocks = env_int("TF_KA_BLOCKS", 1536);  // tuning knob; < full residency leaves
+                                                              // wave slots for the selection stream
   const dim3 grid(nblocks > 0 ? nblocks : 2048), block(256);
   if (use_color && use_quality)
     hipLaunchKernelGGL((k_integrate<true, true, FUSED, GP>), grid, block, 0, s, v, img, cam, ig, pose, kc, epoch);
@@ -898,6 +1001,57 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
   } else {
     if (fused) launch_integrate_t<true, 4>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
     else launch_integrate_t<false, 4>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
+  }
+}
+
+// One pipelined launch.  Any of the three stages may be absent (pipeline fill / drain):
+// cur != nullptr -> K-A of *cur (its selection set must hold a finished list); next -> K-C of
+// *next (its set must hold finished K-B keys); next2 -> K-B of *next2.
+void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* next,
+                  const FrameStage* next2, const Cam& cam, const Integ& ig, float res, hipStream_t s) {
+  static const int nblocks = env_int("TF_KA_BLOCKS", 2048);
+  static const int gp = env_int("TF_KA_GP", TF_KA_GP);
+  FrameLaunch a;
+  a.v = v;
+  a.cam = cam;
+  a.ig = ig;
+  a.n_ka = a.n_sel = a.n_bbox = 0;
+  a.epoch = 0;
+  static const int ka_first = env_int("TF_KA_FIRST", 1);
+  a.ka_first = (uint32_t)ka_first;
+  static const int nsel = env_int("TF_SEL_BLOCKS", 512);
+  a.kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);
+  bool color = false;
+  if (cur) {
+    a.v.sel = cur->sel;
+    a.img = cur->img;
+    a.P = cur->pose;
+    a.epoch = cur->epoch;
+    a.n_ka = (uint32_t)(nblocks > 0 ? nblocks : 2048);
+    color = cur->img.rgba != nullptr;
+  }
+  if (next) {
+    a.sel1 = next->sel;
+    a.depth1 = next->img.depth;
+    a.sc1 = make_select_consts(next->pose.p, res);
+    a.n_sel = (uint32_t)nsel;
+  }
+  if (next2) {
+    a.ctl2 = next2->sel.ctl;
+    a.depth2 = next2->img.depth;
+    a.P2 = next2->pose;
+    int nvec = (cam.W * cam.H) >> 2;
+    int blocks = (nvec + 255) / 256;
+    a.n_bbox = (uint32_t)(blocks > 128 ? 128 : blocks);
+  }
+  const uint32_t total = a.n_ka + a.n_sel + a.n_bbox;
+  if (!total) return;
+  if (color) {
+    if (gp == 4) hipLaunchKernelGGL((k_frame<true, 4>), dim3(total), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_frame<true, 2>), dim3(total), dim3(256), 0, s, a);
+  } else {
+    if (gp == 4) hipLaunchKernelGGL((k_frame<false, 4>), dim3(total), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_frame<false, 2>), dim3(total), dim3(256), 0, s, a);
   }
 }
 

@@ -51,6 +51,7 @@ struct AtlasState {
 }  // namespace tf
 
 struct tf_volume {
+  static constexpr int kSelSets = 4;  // selection runs up to kSelSets-1 frames ahead of integration
   tf_config cfg;
   int device = 0;
   float res = 0.005f;
@@ -63,11 +64,11 @@ struct tf_volume {
   bool own_stream = false;
   // second stream: selection of frame f+1 overlaps the integration of frame f (batched unit)
   hipStream_t sel_stream = nullptr;
-  hipEvent_t ev_sel_done[2] = {nullptr, nullptr};
-  hipEvent_t ev_ka_done[2] = {nullptr, nullptr};
+  hipEvent_t ev_sel_done[kSelSets] = {};
+  hipEvent_t ev_ka_done[kSelSets] = {};
   hipEvent_t ev_batch = nullptr;
   tf::VolumeDev dev;
-  tf::SelBuf selbuf[2];  // double-buffered selection scratch (dev.sel = the active set)
+  tf::SelBuf selbuf[kSelSets];  // ring of selection scratch sets (dev.sel = the active set)
   int cur_sel = 0;
   std::vector<void*> allocs;
   // frame images
