@@ -180,7 +180,7 @@ def main():
         avg_s = 1e-3 * ka_ms / max(ka_n, 1)
         achieved = per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_integrate<color>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "k_frame<color> = K-A(f) + K-C(f+1) + K-B(f+2) block ranges; bytes counted for K-A only", "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_launch": per_launch, "avg_launch_us": 1e6 * avg_s, "launches": ka_n,
             "chunks_selected_avg": float(np.mean([rows_cache[i][2] for i in idx])),
@@ -203,6 +203,8 @@ def cpu_baseline(args, cam, res, frames, Wm, n_unique):
     then the next --cpu-frames frames of the stream."""
     from oracle import api as O
     ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    avx2 = bool(O.lib().tfo_have_avx2())
+    ov.set_kernel(1 if avx2 else 0)  # AVX2 row kernel (as the reference's), bit-identical to the scalar checker
     ncpu = os.cpu_count() or 1
     for i in range(min(Wm, 5)):  # a short warm-up bounds the CPU time; state is first-touch either way
         f = frames[i % n_unique]
@@ -227,6 +229,7 @@ def cpu_baseline(args, cam, res, frames, Wm, n_unique):
         sel.append(ns)
     # single-thread figure on a shorter sample
     ov1 = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    ov1.set_kernel(1 if avx2 else 0)
     ov1.set_threads(1)
     n1 = max(1, n // 4)
     t1 = 0.0
@@ -238,9 +241,10 @@ def cpu_baseline(args, cam, res, frames, Wm, n_unique):
     return {
         "value": n / t_all, "unit": "frames/s", "cores": int(round(float(np.mean(threads_used)))),
         "kind": "port",
-        "sample": "oracle/ (scalar C restatement of the reference path, -O2, no FMA) on frames %d..%d of the "
-                  "same S-room stream; threads = reference parallel_for policy min(hw-2, ceil(N/1000)); "
-                  "host has %d logical cores" % (Wm, Wm + n - 1, ncpu),
+        "sample": "oracle/ C port of the reference path (%s voxel kernel, no FMA; selection scalar, 1 thread) on "
+                  "frames %d..%d of the same S-room stream; integrate threads = reference parallel_for policy "
+                  "min(hw-2, ceil(N/1000)); host has %d logical cores"
+                  % ("AVX2 8-lane" if avx2 else "scalar", Wm, Wm + n - 1, ncpu),
         "value_1thread": n1 / t1,
         "host_cores": ncpu,
     }

@@ -87,6 +87,8 @@ def lib():
     L.tfo_volume_set_camera.argtypes = [vp, C.POINTER(Camera)]
     L.tfo_volume_set_integrator.argtypes = [vp, C.POINTER(Integrator)]
     L.tfo_volume_set_threads.argtypes = [vp, C.c_int]
+    L.tfo_volume_set_kernel.argtypes = [vp, C.c_int]
+    L.tfo_have_avx2.restype = C.c_int
     L.tfo_volume_num_chunks.restype = C.c_int64
     L.tfo_volume_num_chunks.argtypes = [vp]
     L.tfo_volume_list_chunks.restype = C.c_int64
@@ -228,6 +230,10 @@ class Volume:
 
     def set_threads(self, n):
         self.L.tfo_volume_set_threads(self.h, int(n))
+
+    def set_kernel(self, kernel):
+        """0 = scalar restatement (checker), 1 = AVX2 row kernel (CPU baseline; bit-identical)."""
+        self.L.tfo_volume_set_kernel(self.h, int(kernel))
 
     def num_chunks(self):
         return int(self.L.tfo_volume_num_chunks(self.h))

@@ -201,6 +201,146 @@ int tfo_voxel_update(const float* depth, const uint8_t* rgba, const float* quali
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* K-A, AVX2 form: the same row algorithm as tfo_voxel_update with one __m256 per 8-voxel   */
+/* row, used for the CPU baseline (the reference's kernel is AVX2 too).  Must be            */
+/* bit-identical to the scalar form above -- tests/test_oracle_kat.py checks that.          */
+/* ------------------------------------------------------------------------------------ */
+#if defined(__x86_64__)
+#include <immintrin.h>
+#define TFO_HAVE_AVX2_KERNEL 1
+
+__attribute__((target("avx2"))) static inline __m256 ps_and3(__m256 a, __m256 b, __m256 c) {
+  return _mm256_and_ps(_mm256_and_ps(a, b), c);
+}
+
+__attribute__((target("avx2"))) static int voxel_update_avx2(
+    const float* depth, const uint8_t* rgba, const float* quality, const tfo_camera* cam,
+    const tfo_integrator* ig, const float pose[12], int integrate_flag, const int id[3], float res,
+    const float cen[3 * TFO_CHUNK_VOXELS], float* sdf, float* weight, uint16_t* color,
+    float* quality_out, tfo_rowstats* stats) {
+  const float* c0 = cen;
+  const float* c1 = cen + TFO_CHUNK_VOXELS;
+  const float* c2 = cen + 2 * TFO_CHUNK_VOXELS;
+  float qsum = 0.0f;
+  int updated = 0;
+  const float resDiag = (float)(sqrt(3.0) * (double)res);
+  const int W = cam->width, H = cam->height;
+  float o[3], trunc, wD;
+  tfo_chunk_scalars(ig, pose, id, res, o, &trunc, &wD);
+  if (!integrate_flag) wD *= -1.0f;
+  const float thrCol = (float)((double)(resDiag / 2.0f) + 0.01);
+
+  const __m256 vo0 = _mm256_set1_ps(o[0]), vo1 = _mm256_set1_ps(o[1]), vo2 = _mm256_set1_ps(o[2]);
+  const __m256 vfx = _mm256_set1_ps((float)(int)cam->fx), vfy = _mm256_set1_ps((float)(int)cam->fy);
+  const __m256 vcx = _mm256_set1_ps((float)((double)(float)(int)cam->cx + 0.5));
+  const __m256 vcy = _mm256_set1_ps((float)((double)(float)(int)cam->cy + 0.5));
+  const __m256i izero = _mm256_setzero_si256();
+  const __m256i iWm1 = _mm256_set1_epi32(W - 1), iHm1 = _mm256_set1_epi32(H - 1), iW = _mm256_set1_epi32(W);
+  const __m256 vzero = _mm256_setzero_ps();
+  const __m256 vthr = _mm256_set1_ps(thrCol), vnthr = _mm256_set1_ps(-thrCol);
+  const __m256 vnear = _mm256_set1_ps(cam->near_plane), vfar = _mm256_set1_ps(cam->far_plane);
+  const __m256 vlower = _mm256_set1_ps((float)(-0.03)), vupper = _mm256_set1_ps(trunc + resDiag);
+  const __m256 vwD = _mm256_set1_ps(wD), vsigma = _mm256_set1_ps((float)1e-4);
+  const __m256 vhalf = _mm256_set1_ps(0.5f), v999 = _mm256_set1_ps(999.0f);
+  /* byte shuffle that copies the count channel (u16 #3 of each 4-u16 voxel) over the voxel */
+  const __m256i cntsel = _mm256_setr_epi8(6, 7, 6, 7, 6, 7, 6, 7, 14, 15, 14, 15, 14, 15, 14, 15,
+                                          6, 7, 6, 7, 6, 7, 6, 7, 14, 15, 14, 15, 14, 15, 14, 15);
+  const __m256i i120 = _mm256_set1_epi16(120);
+
+  int pos = 0;
+  for (int it = 0; it < 64; it++) {
+    const __m256 px = _mm256_add_ps(vo0, _mm256_loadu_ps(c0 + 8 * pos));
+    const __m256 py = _mm256_add_ps(vo1, _mm256_loadu_ps(c1 + 8 * pos));
+    const __m256 pz = _mm256_add_ps(vo2, _mm256_loadu_ps(c2 + 8 * pos));
+    const __m256 u = _mm256_add_ps(_mm256_mul_ps(_mm256_div_ps(px, pz), vfx), vcx);
+    const __m256 v = _mm256_add_ps(_mm256_mul_ps(_mm256_div_ps(py, pz), vfy), vcy);
+    const __m256i X = _mm256_cvtps_epi32(u), Y = _mm256_cvtps_epi32(v);
+    __m256i valid = _mm256_and_si256(_mm256_cmpgt_epi32(X, izero), _mm256_cmpgt_epi32(iWm1, X));
+    valid = _mm256_and_si256(valid, _mm256_and_si256(_mm256_cmpgt_epi32(Y, izero), _mm256_cmpgt_epi32(iHm1, Y)));
+    if (_mm256_testz_si256(valid, valid)) continue; /* `pos` is not advanced: the row stalls */
+    const __m256 validf = _mm256_castsi256_ps(valid);
+    const __m256i idx = _mm256_add_epi32(_mm256_mullo_epi32(Y, iW), X);
+    const __m256 d = _mm256_mask_i32gather_ps(vzero, depth, idx, validf, 4);
+    const __m256 sd = _mm256_sub_ps(d, pz);
+
+    if (rgba != NULL) {
+      const __m256 upd = ps_and3(validf, _mm256_cmp_ps(sd, vnthr, _CMP_GT_OS), _mm256_cmp_ps(vthr, sd, _CMP_GT_OS));
+      __m256i oob = _mm256_or_si256(_mm256_cmpgt_epi32(izero, X), _mm256_cmpgt_epi32(X, iWm1));
+      oob = _mm256_or_si256(oob, _mm256_or_si256(_mm256_cmpgt_epi32(izero, Y), _mm256_cmpgt_epi32(Y, iHm1)));
+      if (!_mm256_testz_si256(oob, oob)) qsum = (float)(-99999999999.0);
+      if (!_mm256_testz_ps(upd, upd)) {
+        if (quality != NULL) {
+          float qv[8];
+          _mm256_storeu_ps(qv, _mm256_mask_i32gather_ps(vzero, quality, idx, upd, 4));
+          float sum = 0.0f;
+          for (int l = 0; l < 8; l++) sum += qv[l];
+          qsum += sum;
+        }
+        const __m256i in = _mm256_mask_i32gather_epi32(izero, (const int*)rgba, idx, _mm256_castps_si256(upd), 4);
+        __m256i* crow = (__m256i*)(color + (size_t)pos * 32);
+        for (int hlf = 0; hlf < 2; hlf++) {
+          const __m256i in16 = _mm256_cvtepu8_epi16(hlf ? _mm256_extracti128_si256(in, 1) : _mm256_castsi256_si128(in));
+          __m256i c = _mm256_loadu_si256(crow + hlf);
+          if (integrate_flag) {
+            c = _mm256_add_epi16(c, in16);
+            const __m256i over = _mm256_shuffle_epi8(_mm256_cmpgt_epi16(c, i120), cntsel);
+            c = _mm256_blendv_epi8(c, _mm256_srli_epi16(c, 2), over);
+          } else {
+            c = _mm256_sub_epi16(c, in16);
+          }
+          _mm256_storeu_si256(crow + hlf, c);
+        }
+        if (stats) stats->rows_color++;
+      }
+    }
+
+    const __m256 dv = _mm256_and_ps(_mm256_cmp_ps(d, vnear, _CMP_GT_OS), _mm256_cmp_ps(vfar, d, _CMP_GT_OS));
+    const __m256 F = ps_and3(dv, _mm256_cmp_ps(sd, vlower, _CMP_GT_OS), _mm256_cmp_ps(vupper, sd, _CMP_GT_OS));
+    if (!_mm256_testz_ps(F, F)) {
+      updated = 1;
+      const __m256 w = _mm256_loadu_ps(weight + 8 * pos), s = _mm256_loadu_ps(sdf + 8 * pos);
+      const __m256 nw = _mm256_and_ps(F, vwD);
+      const __m256 num = _mm256_add_ps(_mm256_mul_ps(s, w), _mm256_mul_ps(sd, nw));
+      const __m256 den = _mm256_add_ps(_mm256_add_ps(w, nw), vsigma);
+      const __m256 ns = _mm256_div_ps(num, den);
+      const __m256 nwt = _mm256_add_ps(w, nw);
+      const __m256 keep = _mm256_cmp_ps(nwt, vhalf, _CMP_GT_OS);
+      _mm256_storeu_ps(sdf + 8 * pos, _mm256_blendv_ps(v999, ns, keep));
+      _mm256_storeu_ps(weight + 8 * pos, _mm256_and_ps(nwt, keep));
+      if (stats) stats->rows_tsdf++;
+    }
+    pos++;
+  }
+  if (stats && updated) stats->chunks_updated++;
+  *quality_out = qsum;
+  return updated;
+}
+#endif
+
+int tfo_have_avx2(void) {
+#ifdef TFO_HAVE_AVX2_KERNEL
+  return __builtin_cpu_supports("avx2") ? 1 : 0;
+#else
+  return 0;
+#endif
+}
+
+/* Same contract as tfo_voxel_update; kernel = 1 selects the AVX2 row kernel when the CPU has it. */
+int tfo_voxel_update_k(int kernel, const float* depth, const uint8_t* rgba, const float* quality,
+                       const tfo_camera* cam, const tfo_integrator* ig, const float pose[12],
+                       int integrate_flag, const int id[3], float res,
+                       const float cen[3 * TFO_CHUNK_VOXELS], float* sdf, float* weight,
+                       uint16_t* color, float* quality_out, tfo_rowstats* stats) {
+#ifdef TFO_HAVE_AVX2_KERNEL
+  if (kernel == 1 && tfo_have_avx2())
+    return voxel_update_avx2(depth, rgba, quality, cam, ig, pose, integrate_flag, id, res, cen, sdf,
+                             weight, color, quality_out, stats);
+#endif
+  return tfo_voxel_update(depth, rgba, quality, cam, ig, pose, integrate_flag, id, res, cen, sdf,
+                          weight, color, quality_out, stats);
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* K-B  ChunkManager::findCubeCornerByMat / GetBoundaryChunkID / GetIDAt                */
 /*      (Structure/ChunkManager.h:303-378, 197-207)                                     */
 /* ------------------------------------------------------------------------------------ */
@@ -387,6 +527,7 @@ struct tfo_volume {
   float res;
   int use_color;
   int nthreads;
+  int kernel; /* 0 = scalar restatement (the checker), 1 = AVX2 row kernel (CPU baseline) */
   tfo_camera cam;
   tfo_integrator ig;
   tfo_chunk* chunks;
@@ -485,6 +626,7 @@ void tfo_volume_destroy(tfo_volume* v) {
 void tfo_volume_set_camera(tfo_volume* v, const tfo_camera* cam) { v->cam = *cam; }
 void tfo_volume_set_integrator(tfo_volume* v, const tfo_integrator* ig) { v->ig = *ig; }
 void tfo_volume_set_threads(tfo_volume* v, int n) { v->nthreads = n < 1 ? 1 : n; }
+void tfo_volume_set_kernel(tfo_volume* v, int kernel) { v->kernel = kernel; }
 int64_t tfo_volume_num_chunks(const tfo_volume* v) { return v->map.live; }
 int64_t tfo_volume_list_chunks(const tfo_volume* v, int32_t* ids, int64_t cap) {
   int64_t n = 0;
@@ -622,8 +764,8 @@ int tfo_integrate(tfo_volume* v, const float* depth, const uint8_t* rgba, const 
     float q = 0.0f;
     tfo_rowstats st = {0, 0, 0};
     int id[3] = {ids[3 * i], ids[3 * i + 1], ids[3 * i + 2]};
-    int upd = tfo_voxel_update(depth, rgba, quality, &v->cam, &v->ig, pose, integrate_flag, id,
-                               v->res, cen, c->sdf, c->weight, c->color, &q, &st);
+    int upd = tfo_voxel_update_k(v->kernel, depth, rgba, quality, &v->cam, &v->ig, pose, integrate_flag,
+                                 id, v->res, cen, c->sdf, c->weight, c->color, &q, &st);
     needs_update[i] = (uint8_t)(needs_update[i] || upd); /* :241 */
     if (quality_out) quality_out[i] = q;
     if (keyframe_id >= 0 && q > 0.0f && needs_update[i]) chunk_set_obs(c, keyframe_id, q); /* :244-247 */

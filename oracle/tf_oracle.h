@@ -73,6 +73,15 @@ int tfo_voxel_update(const float* depth, const uint8_t* rgba, const float* quali
                      const float cen[3 * TFO_CHUNK_VOXELS], float* sdf, float* weight,
                      uint16_t* color, float* quality_out, tfo_rowstats* stats);
 
+/* kernel = 0: scalar restatement (the checker); 1: AVX2 row kernel, bit-identical, used for the
+ * CPU baseline (the reference's kernel is AVX2 as well). */
+int tfo_have_avx2(void);
+int tfo_voxel_update_k(int kernel, const float* depth, const uint8_t* rgba, const float* quality,
+                       const tfo_camera* cam, const tfo_integrator* ig, const float pose[12],
+                       int integrate_flag, const int id[3], float res,
+                       const float cen[3 * TFO_CHUNK_VOXELS], float* sdf, float* weight,
+                       uint16_t* color, float* quality_out, tfo_rowstats* stats);
+
 /* ---- K-B / K-C: visible-chunk selection ------------------------------------------- */
 void tfo_bbox(const float* depth, const tfo_camera* cam, const float pose[12], float res,
               int min_id[3], int max_id[3]);
@@ -89,6 +98,7 @@ void tfo_volume_reset(tfo_volume* v);
 void tfo_volume_set_camera(tfo_volume* v, const tfo_camera* cam);
 void tfo_volume_set_integrator(tfo_volume* v, const tfo_integrator* ig);
 void tfo_volume_set_threads(tfo_volume* v, int nthreads);
+void tfo_volume_set_kernel(tfo_volume* v, int kernel);
 int64_t tfo_volume_num_chunks(const tfo_volume* v);
 int64_t tfo_volume_list_chunks(const tfo_volume* v, int32_t* ids, int64_t cap);
 int tfo_volume_has_chunk(const tfo_volume* v, const int id[3]);

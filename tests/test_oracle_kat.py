@@ -211,3 +211,42 @@ def test_finalize_dirty_set_and_garbage(env):
     d = {tuple(x) for x in v.dirty()}
     assert d == {(0, 0, 0), (-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1)}
     assert not v.has_chunk(ids[1]) and v.has_chunk(ids[2]) and v.has_chunk(ids[0])
+
+
+def test_avx2_baseline_kernel_is_bit_identical_to_the_scalar_restatement(env):
+    """The CPU-baseline kernel (AVX2 rows, like the reference's own kernel) must not drift from the checker."""
+    cam, C, ig = env
+    if not O.lib().tfo_have_avx2():
+        pytest.skip("no AVX2 on this host")
+    a = O.Volume(RES5, C, ig)
+    b = O.Volume(RES5, C, ig)
+    b.set_kernel(1)
+    poses = [synth.pose_identity(), synth.pose_euler(0.5, 0.2, -0.1, (0.1, 0.0, 0.1)), synth.pose_euler(-0.9, -0.3, 0.4)]
+    for k, pose in enumerate(poses):
+        depth, rgba, q, _ = synth.room_frame(3 * k, cam)
+        ids, new = a.prepare(depth, pose)
+        ids_b, new_b = b.prepare(depth, pose)
+        assert np.array_equal(ids, ids_b)
+        na, nb = np.zeros(len(ids), np.uint8), np.zeros(len(ids), np.uint8)
+        qa = a.integrate(depth, rgba, q, pose, ids, na, 1, k)
+        qb = b.integrate(depth, rgba, q, pose, ids, nb, 1, k)
+        assert np.array_equal(na, nb) and np.array_equal(qa.view(np.uint32), qb.view(np.uint32))
+        qa = a.integrate(depth, None, None, pose, ids, na, 1, -1)
+        qb = b.integrate(depth, None, None, pose, ids, nb, 1, -1)
+        a.finalize(ids, na, new)
+        b.finalize(ids, nb, new)
+        if k == 1:  # de-integration path
+            va = np.ones(len(ids), np.uint8)
+            keep = np.array([a.has_chunk(c) for c in ids])
+            a.integrate(depth, rgba, q, pose, ids[keep], va[keep].copy(), 0, k)
+            b.integrate(depth, rgba, q, pose, ids[keep], va[keep].copy(), 0, k)
+    ids = a.list_chunks()
+    assert np.array_equal(ids, b.list_chunks())
+    for cid in ids[:: max(1, len(ids) // 400)]:
+        sa, wa, ca = a.get_chunk(cid)
+        sb, wb, cb = b.get_chunk(cid)
+        assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32))
+        assert np.array_equal(wa.view(np.uint32), wb.view(np.uint32))
+        assert np.array_equal(ca, cb)
+    sa, sb = a.rowstats(), b.rowstats()
+    assert (sa.rows_tsdf, sa.rows_color, sa.chunks_updated) == (sb.rows_tsdf, sb.rows_color, sb.chunks_updated)
