@@ -246,6 +246,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   memset(&v->cfg, 0, sizeof(v->cfg));
   if (cfg) v->cfg = *cfg;
   if (v->cfg.max_chunks <= 0) v->cfg.max_chunks = 1ll << 20;
+  v->cfg.max_chunks = (v->cfg.max_chunks + 63) & ~63ll;  // 64 allocation stripes
   if (v->cfg.max_list <= 0) v->cfg.max_list = 1ll << 19;
   if (v->cfg.max_coarse <= 0) v->cfg.max_coarse = 1ll << 20;
   if (v->cfg.atlas_w <= 0) v->cfg.atlas_w = 13824;
@@ -309,6 +310,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     if ((rc = dev_alloc(v, &L.masks, (size_t)d.max_coarse))) return fail(rc);
     if ((rc = dev_alloc(v, &L.offsets, (size_t)d.max_coarse))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_id, (size_t)d.max_list))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.list_pre, (size_t)d.max_list * 2))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_slot, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_ent, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_new, (size_t)d.max_list))) return fail(rc);
@@ -744,7 +746,8 @@ int tf_get_stats(tf_volume* v, tf_stats* out) {
   out->n_updated = (int64_t)r3[2];
   out->rows_tsdf = (int64_t)r3[0];
   out->rows_color = (int64_t)r3[1];
-  out->n_slots = ctl.vc.slot_top;
+  out->n_slots = 0;
+  for (int k = 0; k < kSlotStripes; ++k) out->n_slots += ctl.vc.slot_cnt[k];
   for (int a = 0; a < 3; ++a) { out->min_id[a] = ctl.f.min_id[a]; out->max_id[a] = ctl.f.max_id[a]; }
   int64_t nd = 0, na = 0;
   rc = list_common(v, true, nullptr, 0, &nd);

@@ -62,11 +62,15 @@ struct FrameCtl {
 };
 
 // Volume-wide device words.
+constexpr int kSlotStripes = 64;
 struct VolCtl {
   uint32_t status;    // sticky error bits
-  uint32_t slot_top;  // next unused pool slot
   uint32_t n_tmp;     // scratch counter of the on-demand list/pack kernels
-  uint32_t pad;
+  uint32_t pad[2];
+  // Pool slots are handed out from 64 independent stripes (stripe s owns slots
+  // [s*max_chunks/64, (s+1)*max_chunks/64)) so that the thousands of chunk creations of a
+  // first-touch frame do not serialise on one atomic word.
+  uint32_t slot_cnt[kSlotStripes];
 };
 
 // Per-frame selection scratch.  Two sets exist so that the selection of frame f+1 (a pure
@@ -75,6 +79,7 @@ struct SelBuf {
   unsigned long long* masks;  // [max_coarse]
   uint32_t* offsets;          // [max_coarse]
   int4* list_id;              // [max_list]
+  float4* list_pre;           // [2*max_list] per-chunk scalars {o.x,o.y,o.z,trunc}, {wD,upper,-,-}
   uint32_t* list_slot;        // [max_list]
   uint32_t* list_ent;         // [max_list] hash entry index of the chunk
   uint8_t* list_new;          // [max_list]

@@ -23,11 +23,15 @@ struct SelectConsts {
   float r0[3], r1[3], r2[3];  // (:431-436)
   float coarse[3][8];         // diffCentroidCoarse (:444-456)
   float fine[3][8];           // diffCentroidRefine
+  float pose[12];             // the frame pose (per-chunk scalars of the emitted list entries)
+  float resDiag;              // sqrt(3.0f) * resolution (ProjectionIntegrator.cpp:77)
 };
 
 inline SelectConsts make_select_consts(const float* p /*pose[12]*/, float res) {
   SelectConsts sc;
   sc.res = res;
+  for (int i = 0; i < 12; ++i) sc.pose[i] = p[i];
+  sc.resDiag = (float)(sqrt(3.0) * (double)res);
   sc.id_factor = 1.0f / (8.0f * res);
   float diag = 8.0f * res / 2.0f;
   int step = 4;

@@ -69,6 +69,34 @@ __device__ __forceinline__ uint32_t hash_key(unsigned long long k) {
   return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 24);
 }
 
+
+// Per-chunk scalars of voxelUpdateSIMD (ProjectionIntegrator.cpp:74-101, Chunk.cpp:52) for one list
+// entry.  Computed lane-per-entry where the list is produced (64 chunks per wave instruction
+// instead of one redundant copy per lane inside k_integrate) and read back through scalar loads.
+struct ChunkPre {
+  float4 a;  // o.x, o.y, o.z (origin in camera), truncation
+  float4 b;  // weight / (2 * truncation) (unsigned; the de-integration sign is applied in K-A), upper band
+};
+__device__ __forceinline__ ChunkPre chunk_pre(const int4 id, const float* __restrict__ Pp, const Integ& ig,
+                                              float res, float resDiag) {
+  float dvec[3];
+  dvec[0] = (float)(8 * id.x) * res - Pp[3];
+  dvec[1] = (float)(8 * id.y) * res - Pp[7];
+  dvec[2] = (float)(8 * id.z) * res - Pp[11];
+  float o[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float q0 = Pp[a] * dvec[0], q1 = Pp[4 + a] * dvec[1], q2 = Pp[8 + a] * dvec[2];
+    const float s12 = q1 + q2;
+    o[a] = q0 + s12;
+  }
+  const float trunc = truncation(ig, o[2]);
+  ChunkPre r;
+  r.a = make_float4(o[0], o[1], o[2], trunc);
+  r.b = make_float4(ig.weight / (2.0f * trunc), trunc + resDiag, 0.0f, 0.0f);
+  return r;
+}
+
 // Lookup only.  Entries are never removed, so the probe sequence of a present key is stable.
 // Returns the entry index or kInvalidSlot.
 __device__ __forceinline__ uint32_t hash_find(const VolumeDev& v, unsigned long long key) {
@@ -97,8 +125,11 @@ __device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, b
       cur = atomicCAS(&v.hent[i].key, kEmptyKey, key);
       if (cur == kEmptyKey) {  // inserted: allocate a fresh slot (storage is in the fresh state)
         *ent = i;
-        const uint32_t slot = atomicAdd(&v.vctl->slot_top, 1u);
-        if (slot >= v.max_chunks) {
+        const uint32_t stripe = (hash_key(key) >> 7) & (kSlotStripes - 1);
+        const uint32_t per = v.max_chunks / kSlotStripes;
+        const uint32_t k = atomicAdd(&v.vctl->slot_cnt[stripe], 1u);
+        const uint32_t slot = stripe * per + k;
+        if (k >= per) {
           atomicOr(&v.vctl->status, kStPoolFull);
           v.hent[i].slot = kInvalidSlot;
           v.hent[i].alive = 0;
@@ -152,7 +183,10 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
     }
     ctl->n_coarse = 0;
     ctl->n_list = 0;
-    if (vctl) { vctl->status = 0; vctl->slot_top = 0; vctl->n_tmp = 0; }
+    if (vctl) {
+      vctl->status = 0; vctl->n_tmp = 0;
+      for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
+    }
   }
 }
 void launch_reset_ctl(const VolumeDev& v, bool volume_too, hipStream_t s) {
@@ -379,7 +413,11 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         id.y = y0 + ((step == 4) ? ((lane >> 2) & 3) : 0);
         id.z = z0 + ((step == 4) ? (lane & 3) : 0);
         id.w = 0;
-        v.sel.list_id[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = id;
+        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        v.sel.list_id[pos] = id;
+        const ChunkPre cp = chunk_pre(id, sc.pose, ig, sc.res, sc.resDiag);
+        v.sel.list_pre[2 * pos] = cp.a;
+        v.sel.list_pre[2 * pos + 1] = cp.b;
       }
     }
   }
@@ -505,6 +543,18 @@ __global__ __launch_bounds__(256) void k_acquire(VolumeDev v) {
 }
 void launch_acquire(const VolumeDev& v, hipStream_t s) {
   hipLaunchKernelGGL(k_acquire, dim3(512), dim3(256), 0, s, v);
+}
+
+// Per-chunk scalars for a list that is integrated with an explicit pose (call-by-call flow: every
+// IntegrateDepthScanColor call brings its own pose, Chisel.h:226).  One thread per entry.
+__global__ __launch_bounds__(256) void k_pre(VolumeDev v, Pose P, Integ ig, float res, float resDiag) {
+  const SelBuf& L = v.sel;
+  const uint32_t n = L.ctl->n_list < v.max_list ? L.ctl->n_list : v.max_list;
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const ChunkPre cp = chunk_pre(L.list_id[e], P.p, ig, res, resDiag);
+    L.list_pre[2 * e] = cp.a;
+    L.list_pre[2 * e + 1] = cp.b;
+  }
 }
 
 // Host-supplied list (the 10-argument flow / de-integration replays kf.validChunks):
@@ -643,22 +693,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     uint32_t ent = i0;
     bool have_slot = !FUSED;
 
-    // per-chunk scalars (ProjectionIntegrator.cpp:74-101, Chunk.cpp:52)
-    float dvec[3];
-    dvec[0] = (float)(8 * id.x) * kc.res - P.p[3];
-    dvec[1] = (float)(8 * id.y) * kc.res - P.p[7];
-    dvec[2] = (float)(8 * id.z) * kc.res - P.p[11];
-    float o[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float q0 = P.p[a] * dvec[0], q1 = P.p[4 + a] * dvec[1], q2 = P.p[8 + a] * dvec[2];
-      const float s12 = q1 + q2;
-      o[a] = q0 + s12;
-    }
-    const float trunc = truncation(ig, o[2]);
-    float wD = ig.weight / (2.0f * trunc);
-    if (!kc.flag) wD *= -1.0f;
-    const float upper = trunc + kc.resDiag;
+    // per-chunk scalars (ProjectionIntegrator.cpp:74-101), precomputed per list entry; e is
+    // wave-uniform so these are scalar loads
+    const float4 pa = L.list_pre[2 * e];
+    const float4 pb = L.list_pre[2 * e + 1];
+    const float o[3] = {pa.x, pa.y, pa.z};
+    const float wD = kc.flag ? pb.x : -pb.x;  // depth_weight *= -1 when de-integrating (:95-99)
+    const float upper = pb.y;
 
     float qsum = 0.0f;
     int cnt_t = 0, cnt_c = 0;  // per-lane: rows of mine that were rewritten (same in a row's 8 lanes)
@@ -742,7 +783,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         sd[j] = s;
         const bool act = (j * 8 + vy) < nrows;
         if (COLOR) {
-          const bool upd = (off_d[j] != kOOB) && (s > kc.nthrCol) && (kc.thrCol > s);  // (:202-208)
+          const bool upd = (off_d[j] != kOOB) && (fabsf(s) < kc.thrCol);  // -thr < sd < thr (:202-208)
           off_i[j] = upd ? off_d[j] : kOOB;
           const int ru = row8_or(upd ? 1 : 0);
           off_c[j] = ru ? kb : kOOB;
@@ -886,16 +927,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           for (int k = 0; k < 4; ++k) c4[k * 64 + lane] = make_uint4(0, 0, 0, 0);
         }
       }
-      if (lane == 0) {
+      if (lane == 0) {  // what later stages read of a fused frame: slot, needsUpdate, row counts
         L.list_slot[e] = slot;
-        L.list_ent[e] = ent;
-        L.list_new[e] = is_new ? 1 : 0;
         L.list_needs[e] = updated ? 1 : 0;
+        L.list_rows[e] = (uint16_t)(rows_t | (rows_c << 8));
       }
     } else if (lane == 0) {
       if (updated) L.list_needs[e] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
-    }
-    if (lane == 0) {
       L.list_quality[e] = qsum;
       L.list_rows[e] = (uint16_t)(rows_t | (rows_c << 8));
     }
@@ -986,6 +1024,7 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
                       bool fused, uint32_t epoch, hipStream_t s) {
   IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
+  if (!fused) hipLaunchKernelGGL(k_pre, dim3(256), dim3(256), 0, s, v, pose, ig, res, kc.resDiag);
   static const int gp = env_int("TF_KA_GP", TF_KA_GP);     // tuning knob: z-slices per pass
   static const int dbg = env_int("TF_KA_DBG", 0);          // ablation switches (perf triage only)
   kc.dbg = (uint32_t)dbg;
