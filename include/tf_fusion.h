@@ -179,9 +179,9 @@ TF_API int tf_profile_get(tf_volume* v, tf_profile* out, int reset);
 
 /* ---- multi-GPU chunk-range partition --------------------------------
  * A rank owns chunks with lo <= id.x < hi; selection runs in full on every rank, integrate /
- * finalize touch only owned chunks.  Boundary chunks (x == lo or x == hi-1, updated by the
- * last integrate) are packed into / unpacked from a device buffer the caller all-gathers over
- * RCCL.  Record = 16 B header {x,y,z,0} + 4 KiB {sdf,weight}[512] + 4 KiB colour[512][4]. */
+ * finalize touch only owned chunks.  Boundary chunks (x == lo or x == hi-1, updated since
+ * the previous tf_boundary_pack) are packed into / unpacked from a device buffer the caller
+ * all-gathers over RCCL.  Record = 16 B header {x,y,z,0} + 4 KiB {sdf,weight}[512] + 4 KiB colour[512][4]. */
 #define TF_BOUNDARY_RECORD_BYTES (16 + 4096 + 4096)
 TF_API int tf_set_partition(tf_volume* v, int32_t x_lo, int32_t x_hi);
 TF_API int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t* n);

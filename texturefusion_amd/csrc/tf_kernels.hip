@@ -907,6 +907,11 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       if (__ballot(oob_any != 0) != 0ull) qsum = kc.qoob;
     }
 
+    // multi-GPU: remember that this slab-face chunk changed since the last boundary exchange
+    if (updated && lane == 0 && (id.x == v.part_lo || id.x == v.part_hi - 1)) {
+      const uint32_t en = FUSED ? ent : L.list_ent[e];
+      v.hent[en].alive = 3u;  // bit0 alive, bit1 touched
+    }
     if (FUSED) {
       // FinalizeIntegrateChunks (Chisel.h:192-208) + GarbageCollect (:472-477) for this entry
       if (updated) {
@@ -1248,32 +1253,48 @@ void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const f
 }
 
 // ---- multi-GPU boundary exchange ------------------------------------------------------
-// Pack the chunks of the current list that this rank owns, that were updated, and that sit
-// on a partition face (x == lo or x == hi-1).  Record: int4 id | float2[512] | ushort4[512].
-__global__ __launch_bounds__(512) void k_boundary_pack(VolumeDev v, uint8_t* records, uint32_t cap) {
-  const SelBuf& L = v.sel;
-  const uint32_t n = L.ctl->n_list;
-  __shared__ uint32_t spos;
-  for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-    const int4 id = L.list_id[e];
-    const bool face = (id.x == v.part_lo) || (id.x == v.part_hi - 1);
-    const bool owned = (id.x >= v.part_lo) && (id.x < v.part_hi);
-    const uint32_t slot = L.list_slot[e];
-    if (!(face && owned && L.list_needs[e] && slot != kInvalidSlot)) continue;  // block-uniform
-    if (threadIdx.x == 0) spos = atomicAdd(&v.vctl->n_tmp, 1u);
-    __syncthreads();
-    const uint32_t p = spos;
-    if (p < cap) {
+// Pack every chunk this rank owns whose "touched" bit is set (slab-face chunks updated since the
+// last exchange) and clear the bit.  Record: int4 id | float2[512] | ushort4[512].  One wave scans
+// 64 hash entries at a time and copies the (rare) flagged chunks cooperatively.
+__global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* records, uint32_t cap) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const uint32_t nwaves = gridDim.x * 4;
+  const uint32_t nent = v.hmask + 1;
+  for (uint32_t base = wave * 64; base < nent; base += nwaves * 64) {
+    const uint32_t i = base + lane;
+    HEntry h;
+    h.key = kEmptyKey; h.slot = kInvalidSlot; h.alive = 0;
+    if (i < nent) h = v.hent[i];
+    const bool want = h.key != kEmptyKey && (h.alive & 2u) && h.slot != kInvalidSlot;
+    unsigned long long m = __ballot(want);
+    if (want) v.hent[i].alive = h.alive & 1u;
+    while (m) {
+      const int src = __builtin_ctzll(m);
+      m &= m - 1;
+      const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)h.slot, src);
+      const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(h.key & 0xFFFFFFFFu), src);
+      const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(h.key >> 32), src);
+      uint32_t p = 0;
+      if (lane == 0) p = atomicAdd(&v.vctl->n_tmp, 1u);
+      p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+      if (p >= cap) continue;
       uint8_t* rec = records + (size_t)p * (16 + 4096 + 4096);
-      if (threadIdx.x == 0) *reinterpret_cast<int4*>(rec) = id;
-      reinterpret_cast<float2*>(rec + 16)[threadIdx.x] = v.tsdf[(size_t)slot * kChunkVoxels + threadIdx.x];
-      reinterpret_cast<ushort4*>(rec + 16 + 4096)[threadIdx.x] = v.color[(size_t)slot * kChunkVoxels + threadIdx.x];
+      if (lane == 0) *reinterpret_cast<int4*>(rec) = unpack_id(((unsigned long long)khi << 32) | klo);
+      const uint4* st = reinterpret_cast<const uint4*>(v.tsdf + (size_t)slot * kChunkVoxels);
+      const uint4* sc = reinterpret_cast<const uint4*>(v.color + (size_t)slot * kChunkVoxels);
+      uint4* dt = reinterpret_cast<uint4*>(rec + 16);
+      uint4* dc = reinterpret_cast<uint4*>(rec + 16 + 4096);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        dt[k * 64 + lane] = st[k * 64 + lane];
+        dc[k * 64 + lane] = sc[k * 64 + lane];
+      }
     }
-    __syncthreads();
   }
 }
 void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s) {
-  hipLaunchKernelGGL(k_boundary_pack, dim3(1024), dim3(512), 0, s, v, records, cap);
+  hipLaunchKernelGGL(k_boundary_pack, dim3(1024), dim3(256), 0, s, v, records, cap);
 }
 
 // Store received records of chunks this rank does not own as ghost chunks.

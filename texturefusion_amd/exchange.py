@@ -23,4 +23,8 @@ def allgather_records(send, n_records: int, group=None):
     dist.all_gather(cnts, cnt, group=group)
     recv = [torch.empty_like(send) for _ in range(world)]
     dist.all_gather(recv, send, group=group)
+    if send.is_cuda:
+        # the consumer (tf_boundary_unpack) runs on the volume's own HIP stream: make the collective's
+        # result visible to it before returning
+        torch.cuda.synchronize(send.device)
     return [(recv[r], int(cnts[r].item())) for r in range(world)]
