@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's parallel_for policy")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--atlas-every", type=int, default=0,
+                    help="N>0: every N frames run GeneratePatches+UpdateAtlas on that frame (BASELINE configs[2])")
     return ap.parse_args()
 
 
@@ -81,6 +83,18 @@ def main():
     torch.cuda.synchronize()
 
     vol = capi.Volume(res, cam, max_chunks=1 << 19, max_list=1 << 18, device=local_rank)
+    # atlas leg: keyframe = every --atlas-every-th frame; its per-chunk meshes are depth-derived
+    # vertex clouds (meshing is the next-stage scope), its RGB / depth are already in HBM
+    atlas = {}
+    if args.atlas_every > 0 and world == 1:
+        for i in range(0, n_unique, args.atlas_every):
+            rgb = torch.from_numpy(np.ascontiguousarray(frames[i][1][..., :3])).to(dev)
+            ids, voff, verts, cols = synth.mesh_from_depth(frames[i][0], frames[i][1], frames[i][3], cam, res, 4)
+            atlas[i] = dict(rgb=rgb, ids=ids, voff=voff, verts=verts, cols=cols,
+                            kf=np.full(len(ids), i, np.int32),
+                            T=np.tile(synth.pose_inverse16(frames[i][3]), (len(ids), 1)))
+            vol.keyframe_cache_device(i, rgb.data_ptr(), d_depth[i].data_ptr())
+        torch.cuda.synchronize()
     if world > 1:
         lo, hi = part.slab_for_rank(part.room_extent_chunks(res), rank, world)
         vol.set_partition(lo, hi)
@@ -99,7 +113,23 @@ def main():
     def run(first, count, timed):
         """Frames [first, first+count) of the stream (cyclic over the unique frames)."""
         idx = [(first + i) % n_unique for i in range(count)]
-        if world == 1:
+        if world == 1 and atlas:
+            b0 = 0
+            for j, i in enumerate(idx):
+                if i in atlas:  # flush the frames up to and including the keyframe, then texture it
+                    sub = idx[b0:j + 1]
+                    vol.integrate_frames_device([d_depth[k].data_ptr() for k in sub],
+                                                [d_rgba[k].data_ptr() for k in sub], poses[sub])
+                    a = atlas[i]
+                    r = vol.patches_update(a["ids"], a["kf"], a["T"], a["voff"], a["verts"], a["cols"])
+                    if r["rc"] != 0:
+                        raise SystemExit("atlas full")
+                    b0 = j + 1
+            sub = idx[b0:]
+            if sub:
+                vol.integrate_frames_device([d_depth[k].data_ptr() for k in sub],
+                                            [d_rgba[k].data_ptr() for k in sub], poses[sub])
+        elif world == 1:
             vol.integrate_frames_device([d_depth[i].data_ptr() for i in idx],
                                         [d_rgba[i].data_ptr() for i in idx], poses[idx])
         else:
@@ -160,9 +190,11 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "S-room orbit stream, %dx%d RGB-D, %.0f mm voxels, 8^3 chunks, TSDF+colour integrate, "
-                        "atlas off (BASELINE.json configs[1]); frames resident in HBM"
-                        % (cam.width, cam.height, 1e3 * float(res)),
+            "workload": "S-room orbit stream, %dx%d RGB-D, %.0f mm voxels, 8^3 chunks, TSDF+colour integrate, %s; "
+                        "frames resident in HBM"
+                        % (cam.width, cam.height, 1e3 * float(res),
+                           ("atlas patch update every %d frames (BASELINE.json configs[2])" % args.atlas_every)
+                           if atlas else "atlas off (BASELINE.json configs[1])"),
             "frames_in_hbm": n_unique,
             "parallelism": ("1 GPU" if world == 1 else
                             "%d ranks, ChunkID.x slab partition of one stream, boundary all-gather every %d frames"

@@ -120,3 +120,22 @@ def test_vertices_outside_the_image_are_flagged(gpu_required):
     assert np.array_equal(out["texcoord"].view(np.uint32), o["texcoord"].view(np.uint32))
     assert np.array_equal(out["texcolor"][:2].view(np.uint32), o["texcolor"][:2].view(np.uint32))
     gv.close()
+
+
+def test_room_frame_patches_match_oracle(gpu_required):
+    """General pose, depth-derived vertices (synth.mesh_from_depth), ~1.5 k patches in one batch."""
+    _run_both.seen = {}
+    cam = synth.Camera()
+    C = O.camera_from(cam)
+    depth, rgba, q, pose = synth.room_frame(12, cam)
+    rgb = np.ascontiguousarray(rgba[..., :3])
+    AH = 18 * 8
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 12, atlas_w=13824, atlas_h=AH)
+    oa = O.Atlas(RES5, 13824, AH)
+    gv.keyframe_cache(12, rgb, depth)
+    ids, voff, verts, cols = synth.mesh_from_depth(depth, rgba, pose, cam, RES5, stride=4, max_chunks=1500)
+    assert len(ids) == 1500 and voff[-1] > 5000
+    T = synth.pose_inverse16(pose)
+    out, texlocs = _run_both(gv, oa, cam, C, ids, voff, verts, cols, 12, T, rgb, depth)
+    assert np.array_equal(gv.atlas_rows(0, AH, 13824), oa.buffer()[:AH])
+    gv.close()

@@ -233,3 +233,29 @@ def test_batched_two_stream_pipeline_matches_oracle(gpu_required):
     _frame_flow(ov, gv, depth, rgba, quality, pose, kf_id=8, use_quality=True)
     for b in dd + dc:
         b.free()
+
+
+def test_meshes_to_update_clear_and_erase_semantics(gpu_required):
+    """meshesToUpdate is expanded lazily from per-chunk mark / erase epochs: check it against the
+    oracle's explicit set across fused frames, call-by-call frames, a clear, and garbage-collection."""
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 16)
+    for k in (0, 1):
+        depth, rgba, q, pose = synth.room_frame(k, cam)
+        ov.integrate_frame(depth, rgba, pose)
+        gv.frame_upload(depth, rgba, None)
+        gv.integrate_frame(pose, True)
+    gv.sync()
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+    ov.clear_dirty()
+    gv.clear_dirty()
+    assert len(gv.dirty()) == 0
+    depth, rgba, q, pose = synth.room_frame(30, cam)          # mostly new region after the clear
+    _frame_flow(ov, gv, depth, rgba, q, pose, kf_id=30, use_quality=True)
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+    depth, rgba, q, pose = synth.room_frame(31, cam)
+    ov.integrate_frame(depth, rgba, pose)
+    gv.frame_upload(depth, rgba, None)
+    gv.integrate_frame(pose, True)
+    gv.sync()
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+    assert gv.stats().n_dirty == len(ov.dirty())

@@ -142,8 +142,9 @@ static int init_device_state(tf_volume* v) {
   VolumeDev& d = v->dev;
   hipStream_t s = v->stream;
   TF_HIP(hipMemsetAsync(d.hent, 0xFF, ((size_t)d.hmask + 1) * sizeof(HEntry), s));  // key = empty
-  TF_HIP(hipMemsetAsync(d.dkeys, 0xFF, ((size_t)d.dmask + 1) * 8, s));
-  TF_HIP(hipMemsetAsync(d.dstamp, 0, ((size_t)d.dmask + 1) * 4, s));
+  TF_HIP(hipMemsetAsync(d.mark_epoch, 0, (size_t)d.max_chunks * 4, s));
+  TF_HIP(hipMemsetAsync(d.erase_epoch, 0, (size_t)d.max_chunks * 4, s));
+  v->clear_floor = 0;
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
     d.sel = v->selbuf[k];
     launch_reset_ctl(d, k == 0, s);
@@ -295,15 +296,13 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   d.part_lo = std::numeric_limits<int32_t>::min();
   d.part_hi = std::numeric_limits<int32_t>::max();
   const size_t hcap = pow2_at_least((size_t)d.max_chunks * 2);
-  const size_t dcap = pow2_at_least((size_t)d.max_chunks * 4);
   d.hmask = (uint32_t)(hcap - 1);
-  d.dmask = (uint32_t)(dcap - 1);
   int rc;
   if ((rc = dev_alloc(v, &d.tsdf, (size_t)d.max_chunks * kChunkVoxels))) return fail(rc);
   if ((rc = dev_alloc(v, &d.color, (size_t)d.max_chunks * kChunkVoxels))) return fail(rc);
   if ((rc = dev_alloc(v, &d.hent, hcap))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.dkeys, dcap))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.dstamp, dcap))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.mark_epoch, (size_t)d.max_chunks))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.erase_epoch, (size_t)d.max_chunks))) return fail(rc);
   if ((rc = dev_alloc(v, &d.vctl, (size_t)1))) return fail(rc);
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
     SelBuf& L = v->selbuf[k];
@@ -694,7 +693,7 @@ static int list_common(tf_volume* v, bool dirty, int32_t* out_ids, int64_t cap, 
   rc = ensure_pinned(v, (size_t)cap * 16 + 16);
   if (rc) return rc;
   TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
-  if (dirty) launch_list_dirty(v->dev, reinterpret_cast<int4*>(v->d_tmp), (uint32_t)cap, v->stream);
+  if (dirty) launch_list_dirty(v->dev, reinterpret_cast<int4*>(v->d_tmp), (uint32_t)cap, v->clear_floor, v->stream);
   else launch_list_chunks(v->dev, reinterpret_cast<int4*>(v->d_tmp), (uint32_t)cap, v->stream);
   TF_HIP(hipGetLastError());
   CtlSnap ctl;
@@ -723,8 +722,9 @@ int tf_list_dirty(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n) {
 
 int tf_clear_dirty(tf_volume* v) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
-  // chunksToUpdate.clear() (Chisel.cpp:146): stamps to 0, keys stay (no tombstones needed)
-  TF_HIP(hipMemsetAsync(v->dev.dstamp, 0, ((size_t)v->dev.dmask + 1) * 4, v->stream));
+  // chunksToUpdate.clear() (Chisel.cpp:146): every mark written so far carries an epoch stamp
+  // <= the number of finalizes enqueued; raising the floor to it empties the set without touching HBM
+  v->clear_floor = v->epoch;
   return TF_OK;
 }
 

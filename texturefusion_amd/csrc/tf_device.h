@@ -9,8 +9,9 @@
 //     "does the chunk exist and where".  Entries are never removed: a chunk that is
 //     garbage-collected (Chisel.h:472-477) is *parked* (alive = 0, storage reset to the fresh
 //     state) and revived as "new" the next time it is selected.
-//   dirty set (Chisel::meshesToUpdate): keys u64[dcap], stamps u32[dcap]; value is true iff the
-//     stamp is odd (mark = atomicMax(2f+1), erase = atomicMax(2f+2), f = finalize counter).
+//   meshesToUpdate (Chisel.h:489): mark_epoch / erase_epoch u32[max_chunks] by pool slot, written
+//     with plain stores by the chunk's own wave; id is dirty iff the newest mark among id and its
+//     six neighbours is newer than id's erase and than the last clear (expanded on demand).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -98,10 +99,11 @@ struct VolumeDev {
   // chunk hash
   HEntry* hent;
   uint32_t hmask;
-  // dirty set
-  unsigned long long* dkeys;
-  uint32_t* dstamp;
-  uint32_t dmask;
+  // Chisel::meshesToUpdate, kept implicitly: per pool slot the finalize epoch (+1) in which the
+  // chunk was last updated (mark) / garbage-collected (erase).  The 6-neighbourhood closure of
+  // Chisel.h:197-203 is expanded when the set is read (k_list_dirty), not on the per-frame path.
+  uint32_t* mark_epoch;   // [max_chunks]
+  uint32_t* erase_epoch;  // [max_chunks]
   uint32_t max_list;
   uint32_t max_coarse;
   // partition (multi-GPU chunk-range ownership): lo <= id.x < hi
@@ -141,7 +143,7 @@ void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
 void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipStream_t s);
 void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s);
 void launch_list_chunks(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t s);
-void launch_list_dirty(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t s);
+void launch_list_dirty(const VolumeDev& v, int4* out, uint32_t cap, uint32_t clear_floor, hipStream_t s);
 void launch_gather_chunks(const VolumeDev& v, const int4* ids, uint32_t n, float* sdf, float* w,
                           uint16_t* col, uint32_t* found, hipStream_t s);
 void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const float* w,

@@ -155,22 +155,6 @@ __device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, b
   return kInvalidSlot;
 }
 
-// meshesToUpdate[id] = true / erase(id), order-independent within one finalize epoch.
-// One atomic round trip in the common case (key already present or slot empty).
-__device__ __forceinline__ void dirty_stamp(const VolumeDev& v, int x, int y, int z, uint32_t stamp) {
-  const unsigned long long key = pack_id(x, y, z);
-  uint32_t i = hash_key(key) & v.dmask;
-  for (uint32_t probe = 0; probe <= v.dmask; ++probe) {
-    const unsigned long long cur = atomicCAS(&v.dkeys[i], kEmptyKey, key);
-    if (cur == kEmptyKey || cur == key) {
-      atomicMax(&v.dstamp[i], stamp);
-      return;
-    }
-    i = (i + 1) & v.dmask;
-  }
-  atomicOr(&v.vctl->status, kStHashFull);
-}
-
 // ---------------------------------------------------------------------------------------
 // control block reset (create / Reset only; per-frame re-arming rides on k_scan)
 // ---------------------------------------------------------------------------------------
@@ -614,6 +598,37 @@ __device__ __forceinline__ int cvt_sat_rne(float x) {
   return (int)rintf(__builtin_amdgcn_fmed3f(x, -2147483648.0f, 2147483520.0f));
 }
 
+
+// IEEE-correct f32 quotients with a shared denominator.  This is the instruction sequence hipcc
+// emits for `a / b` (v_rcp, two FMA refinements of the reciprocal, product, three residual FMAs)
+// without v_div_scale / v_div_fmas' scaling / v_div_fixup, which only act on operands or quotients
+// outside the normal exponent range, zeros, infinities and NaNs.  `safe` (wave-uniform) tells
+// whether every lane is inside that range; otherwise the generic division is used, so results are
+// bit-identical to `/` in all cases.  Sharing the reciprocal saves one quarter-rate v_rcp_f32 and
+// two FMAs per voxel in the projection (two quotients over p.z).
+struct Recip { float d, r; };
+__device__ __forceinline__ Recip recip_refined(float d) {
+  Recip R;
+  R.d = d;
+  const float r0 = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r0, 1.0f);
+  R.r = __builtin_fmaf(e, r0, r0);
+  return R;
+}
+__device__ __forceinline__ float div_by(const float n, const Recip& R) {
+  const float q0 = n * R.r;
+  const float e0 = __builtin_fmaf(-R.d, q0, n);
+  const float q1 = __builtin_fmaf(e0, R.r, q0);
+  const float e1 = __builtin_fmaf(-R.d, q1, n);
+  return __builtin_fmaf(e1, R.r, q1);
+}
+// operand inside the range where the sequence above needs no scaling / fix-up (or an exact zero
+// numerator): 2^-40 < |x| < 2^40
+__device__ __forceinline__ bool in_div_range(float x) {
+  const uint32_t e = (__float_as_uint(x) >> 23) & 0xFFu;
+  return e > 127u - 40u && e < 127u + 40u;
+}
+
 // GP = z-slices handled per pass: all loads of a pass are issued before the first use, so a wave
 // keeps GP depth gathers and up to 3*GP voxel-row / image loads in flight; registers (hence
 // resident waves per SIMD) grow with GP.
@@ -700,6 +715,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const float o[3] = {pa.x, pa.y, pa.z};
     const float wD = kc.flag ? pb.x : -pb.x;  // depth_weight *= -1 when de-integrating (:95-99)
     const float upper = pb.y;
+    // every voxel centre of the chunk is o + c with 0 < c < 16 * res * sqrt(3): if |o.z| clears that
+    // band, p.z is far inside the normal exponent range; numerators o + c are exact zeros or at
+    // least one ulp of c (> 2^-40), and |o| < 2^20 keeps quotients finite -> no scaling / fix-up
+    // case of the division can occur in this chunk (wave-uniform)
+    const float band = 32.0f * kc.res;
+    const bool div_safe = (fabsf(o[2]) > band) && (fabsf(o[2]) < 1048576.0f) && (fabsf(o[0]) < 1048576.0f) &&
+                          (fabsf(o[1]) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
 
     float qsum = 0.0f;
     int cnt_t = 0, cnt_c = 0;  // per-lane: rows of mine that were rewritten (same in a row's 8 lanes)
@@ -722,12 +744,22 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         const int k = (g0 + j) * 64 + lane;
         const float px = o[0] + cenT[0][k], py = o[1] + cenT[1][k], pz = o[2] + cenT[2][k];
         sd[j] = pz;
-        const float u = (px / pz) * cam.fxi + kc.cxs;
-        const float w = (py / pz) * cam.fyi + kc.cys;
+        // px / pz and py / pz (:155-164), correctly rounded; fast path when every lane is in range
+        float qx, qy;
+        if (div_safe) {
+          const Recip R = recip_refined(pz);
+          qx = div_by(px, R);
+          qy = div_by(py, R);
+        } else {
+          qx = px / pz;
+          qy = py / pz;
+        }
+        const float u = qx * cam.fxi + kc.cxs;
+        const float w = qy * cam.fyi + kc.cys;
         const int X = cvt_sat_rne(u), Y = cvt_sat_rne(w);
         // 0 < X < W-1 and 0 < Y < H-1 (:167-173) as two unsigned range tests
         const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
-        off_d[j] = valid ? (Y * W + X) * 4 : kOOB;
+        off_d[j] = valid ? (__mul24(Y, W) + X) * 4 : kOOB;  // valid => 0 < Y < H, exact in 24 bits
         // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220)
         if (COLOR) oobl[j] = (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1))) ? 1 : 0;
         const unsigned long long dead = __ballot(row8_or(valid ? 1 : 0) == 0);
@@ -772,6 +804,18 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         rs_T = __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
         rs_C = __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
       }
+      // speculative TSDF row loads of every processed row of the pass, issued before the depth
+      // values are back (tuning knob kc.dbg bit 8 = 256): trades some extra reads of rows that end
+      // up untouched for one dependent memory round trip less per pass
+      u32x2 t[GP];
+      const bool spec = (kc.dbg & 256u) != 0;
+      if (spec) {
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+          const bool act = (j * 8 + vy) < nrows;
+          t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, act ? ((g0 + j) * 64 + lane) * 8 : kOOB, 0, 0);
+        }
+      }
       // ---- phase 3: predicates -> offsets
       float nwv[GP];
       int off_t[GP], off_c[GP], off_i[GP];
@@ -810,11 +854,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         if (__ballot(anyrow != 0) == 0ull && !(COLOR && QUALITY)) continue;
       }
       // ---- phase 4: voxel rows that will be rewritten + their inputs
-      u32x2 t[GP], c[GP];
+      u32x2 c[GP];
       uint32_t in[GP];
       float qv[GP];
+      if (!spec) {
 #pragma unroll
-      for (int j = 0; j < GP; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, off_t[j], 0, 0);
+        for (int j = 0; j < GP; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, off_t[j], 0, 0);
+      }
       if (COLOR) {
 #pragma unroll
         for (int j = 0; j < GP; ++j) {
@@ -915,16 +961,11 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     if (FUSED) {
       // FinalizeIntegrateChunks (Chisel.h:192-208) + GarbageCollect (:472-477) for this entry
       if (updated) {
-        if (lane < 7 && !(kc.dbg & 1u)) {
-          const int dx = (lane == 1) ? -1 : (lane == 2) ? 1 : 0;
-          const int dy = (lane == 3) ? -1 : (lane == 4) ? 1 : 0;
-          const int dz = (lane == 5) ? -1 : (lane == 6) ? 1 : 0;
-          dirty_stamp(v, id.x + dx, id.y + dy, id.z + dz, 2u * epoch + 1u);
-        }
+        if (lane == 0) v.mark_epoch[slot] = epoch + 1u;  // meshesToUpdate[id and 6 nbrs] = true, expanded lazily
       } else if (is_new) {
         if (lane == 0) {
           v.hent[ent].alive = 0;
-          dirty_stamp(v, id.x, id.y, id.z, 2u * epoch + 2u);
+          v.erase_epoch[slot] = epoch + 1u;  // meshesToUpdate.erase(id)
         }
         if (rows_c) {  // parked storage returns to the fresh state (only colour can be dirty)
           uint4* c4 = reinterpret_cast<uint4*>(v.color + (size_t)slot * kChunkVoxels);
@@ -985,10 +1026,12 @@ __global__ __launch_bounds__(256) void k_frame(FrameLaunch a) {
     if (b < a.n_ka) {
       integrate_body<COLOR, false, true, GP>(a.v, a.img, a.cam, a.ig, a.P, a.kc, a.epoch, b, a.n_ka);
     } else if (b < a.n_ka + a.n_sel) {
+      if (a.kc.dbg & 512u) return;  // triage
       VolumeDev v1 = a.v;
       v1.sel = a.sel1;
       select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - a.n_ka, a.n_sel);
     } else {
+      if (a.kc.dbg & 1024u) return;  // triage
       bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_sel, a.n_bbox);
     }
     return;
@@ -1065,6 +1108,8 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   a.ka_first = (uint32_t)ka_first;
   static const int nsel = env_int("TF_SEL_BLOCKS", 512);
   a.kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);
+  static const int dbg = env_int("TF_KA_DBG", 0);
+  a.kc.dbg = (uint32_t)dbg;
   bool color = false;
   if (cur) {
     a.v.sel = cur->sel;
@@ -1118,11 +1163,9 @@ __global__ __launch_bounds__(256) void k_finalize(VolumeDev v, uint32_t epoch) {
       const bool owned = (id.x >= v.part_lo) && (id.x < v.part_hi);
       const bool needs = L.list_needs[e] != 0;
       const bool isnew = L.list_new[e] != 0;
-      if (owned && needs && sub < 7) {
-        const int dx = (sub == 1) ? -1 : (sub == 2) ? 1 : 0;
-        const int dy = (sub == 3) ? -1 : (sub == 4) ? 1 : 0;
-        const int dz = (sub == 5) ? -1 : (sub == 6) ? 1 : 0;
-        dirty_stamp(v, id.x + dx, id.y + dy, id.z + dz, 2u * epoch + 1u);
+      if (owned && needs && sub == 0) {
+        const uint32_t slot = L.list_slot[e];
+        if (slot != kInvalidSlot) v.mark_epoch[slot] = epoch + 1u;  // expanded to the 6 nbrs on read
       }
       if (owned && sub == 7 && !needs && isnew) {
         // GarbageCollect (Chisel.h:472-477): RemoveChunk + meshesToUpdate.erase
@@ -1132,7 +1175,7 @@ __global__ __launch_bounds__(256) void k_finalize(VolumeDev v, uint32_t epoch) {
           v.hent[ent].alive = 0;
           dead[atomicAdd(&ndead, 1u)] = slot;
         }
-        dirty_stamp(v, id.x, id.y, id.z, 2u * epoch + 2u);
+        if (slot != kInvalidSlot) v.erase_epoch[slot] = epoch + 1u;  // meshesToUpdate.erase(id)
       }
     }
     __syncthreads();
@@ -1192,16 +1235,55 @@ void launch_list_chunks(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t
   hipLaunchKernelGGL(k_list_chunks, dim3(512), dim3(256), 0, s, v, out, cap);
 }
 
-__global__ __launch_bounds__(256) void k_list_dirty(VolumeDev v, int4* out, uint32_t cap) {
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i <= v.dmask; i += gridDim.x * 256) {
-    if (v.dkeys[i] != kEmptyKey && (v.dstamp[i] & 1u)) {
+// meshesToUpdate on demand.  For every chunk n whose mark is newer than the last clear, its seven
+// candidates id in {n, n+-x, n+-y, n+-z} are examined; id is dirty iff the newest mark among ITS
+// seven neighbours is newer than max(clear floor, erase(id)) (marks of one finalize precede its
+// erases, Chisel.h:192-214, so an equal epoch means erased).  id is emitted by the first marked
+// neighbour in a fixed order, i.e. exactly once.
+__device__ __forceinline__ int4 nbr7(const int4 c, int k) {
+  int4 r = c;
+  if (k == 1) r.x -= 1; else if (k == 2) r.x += 1;
+  else if (k == 3) r.y -= 1; else if (k == 4) r.y += 1;
+  else if (k == 5) r.z -= 1; else if (k == 6) r.z += 1;
+  return r;
+}
+__global__ __launch_bounds__(256) void k_list_dirty(VolumeDev v, int4* out, uint32_t cap, uint32_t floor_) {
+  const uint32_t total = (v.hmask + 1u) * 8u;  // 8 threads per hash entry: candidate k = 0..6
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    const uint32_t i = t >> 3, k = t & 7u;
+    if (k == 7u) continue;
+    const HEntry h = v.hent[i];
+    if (h.key == kEmptyKey || h.slot == kInvalidSlot) continue;
+    if (v.mark_epoch[h.slot] <= floor_) continue;
+    const int4 n = unpack_id(h.key);
+    const int4 id = nbr7(n, (int)k);
+    uint32_t M = 0, erase = 0;
+    int first = -1;
+    for (int j = 0; j < 7; ++j) {
+      const int4 q = nbr7(id, j);
+      const uint32_t e = hash_find(v, pack_id(q.x, q.y, q.z));
+      if (e == kInvalidSlot) continue;
+      const uint32_t s = v.hent[e].slot;
+      if (s == kInvalidSlot) continue;
+      const uint32_t m = v.mark_epoch[s];
+      if (j == 0) erase = v.erase_epoch[s];
+      if (m > floor_) {
+        if (first < 0) first = j;
+        M = m > M ? m : M;
+      }
+    }
+    if (first < 0) continue;
+    const int4 f = nbr7(id, first);
+    if (f.x != n.x || f.y != n.y || f.z != n.z) continue;  // another marked neighbour emits id
+    const uint32_t lim = erase > floor_ ? erase : floor_;
+    if (M > lim) {
       const uint32_t p = atomicAdd(&v.vctl->n_tmp, 1u);
-      if (p < cap) out[p] = unpack_id(v.dkeys[i]);
+      if (p < cap) out[p] = id;
     }
   }
 }
-void launch_list_dirty(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t s) {
-  hipLaunchKernelGGL(k_list_dirty, dim3(512), dim3(256), 0, s, v, out, cap);
+void launch_list_dirty(const VolumeDev& v, int4* out, uint32_t cap, uint32_t clear_floor, hipStream_t s) {
+  hipLaunchKernelGGL(k_list_dirty, dim3(2048), dim3(256), 0, s, v, out, cap, clear_floor);
 }
 
 // De-interleave chunks into the reference's host layouts (sdf[512], weight[512], color[2048]).

@@ -83,7 +83,8 @@ struct tf_volume {
   // host shadow of the device-resident visible list (int32[3*n]); -1 = device list unknown
   std::vector<int32_t> host_list;
   int64_t host_list_n = -1;
-  uint32_t epoch = 0;  // finalize counter (dirty stamps)
+  uint32_t epoch = 0;        // finalize counter (mark / erase stamps are epoch + 1)
+  uint32_t clear_floor = 0;  // stamps <= this were cleared (Chisel::CompressMeshes' chunksToUpdate.clear())
   // on-demand device scratch
   void* d_tmp = nullptr;
   size_t d_tmp_bytes = 0;

@@ -169,3 +169,35 @@ def pose_inverse16(pose: np.ndarray) -> np.ndarray:
     T[:3, :3] = R.T
     T[:3, 3] = -R.T @ t
     return T.astype(np.float32).reshape(16)
+
+
+def mesh_from_depth(depth, rgba, pose, cam: Camera, res, stride: int = 4, max_chunks: int | None = None):
+    """Synthetic per-chunk "meshes" for the atlas stage of an arbitrary frame: every stride-th valid
+    pixel is back-projected onto the observed surface and the points are grouped by the chunk they
+    fall into (the reference takes marching-cubes vertices, Structure/ChunkManager.cpp:595-1002).
+    Vertex colours are the pixel colours / 255.  Chunks are returned in first-seen (row-major) order.
+    Returns (chunk ids [m,3] i32, vertex offsets [m+1] i64, verts [nv,3] f32, colors [nv,3] f32)."""
+    d = np.asarray(depth, np.float32)[::stride, ::stride].astype(np.float64)
+    v, u = np.meshgrid(np.arange(0, cam.height, stride), np.arange(0, cam.width, stride), indexing="ij")
+    ok = d > 0
+    x = (u[ok] - cam.cx) / cam.fx * d[ok]
+    y = (v[ok] - cam.cy) / cam.fy * d[ok]
+    pc = np.stack([x, y, d[ok]], 1)
+    P = np.asarray(pose, np.float64).reshape(3, 4)
+    pw = (pc @ P[:, :3].T + P[:, 3]).astype(np.float32)
+    col = np.asarray(rgba)[::stride, ::stride][ok][:, :3].astype(np.float32) / np.float32(255.0)
+    edge = np.float32(8.0) * np.float32(res)
+    cid = np.floor(pw / edge).astype(np.int32)
+    key = (cid[:, 0].astype(np.int64) << 42) ^ (cid[:, 1].astype(np.int64) << 21) ^ cid[:, 2].astype(np.int64)
+    _, first, inv = np.unique(key, return_index=True, return_inverse=True)
+    order_of_group = np.argsort(np.argsort(first))  # groups numbered by first appearance
+    g = order_of_group[inv]
+    srt = np.argsort(g, kind="stable")
+    counts = np.bincount(g)
+    if max_chunks is not None and len(counts) > max_chunks:
+        keep = g[srt] < max_chunks
+        srt = srt[keep]
+        counts = counts[:max_chunks]
+    ids = cid[first[np.argsort(first)]][: len(counts)]
+    voff = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return ids.astype(np.int32), voff, np.ascontiguousarray(pw[srt]), np.ascontiguousarray(col[srt])
