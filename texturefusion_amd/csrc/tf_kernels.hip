@@ -21,7 +21,7 @@
 #pragma clang fp contract(off)
 
 #ifndef TF_KA_GP
-#define TF_KA_GP 2
+#define TF_KA_GP 4
 #endif
 
 
@@ -1136,10 +1136,12 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   const uint32_t total = a.n_ka + a.n_sel + a.n_bbox;
   if (!total) return;
   if (color) {
-    if (gp == 4) hipLaunchKernelGGL((k_frame<true, 4>), dim3(total), dim3(256), 0, s, a);
+    if (gp == 8) hipLaunchKernelGGL((k_frame<true, 8>), dim3(total), dim3(256), 0, s, a);
+    else if (gp == 4) hipLaunchKernelGGL((k_frame<true, 4>), dim3(total), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_frame<true, 2>), dim3(total), dim3(256), 0, s, a);
   } else {
-    if (gp == 4) hipLaunchKernelGGL((k_frame<false, 4>), dim3(total), dim3(256), 0, s, a);
+    if (gp == 8) hipLaunchKernelGGL((k_frame<false, 8>), dim3(total), dim3(256), 0, s, a);
+    else if (gp == 4) hipLaunchKernelGGL((k_frame<false, 4>), dim3(total), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_frame<false, 2>), dim3(total), dim3(256), 0, s, a);
   }
 }
