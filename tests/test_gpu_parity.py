@@ -259,3 +259,45 @@ def test_meshes_to_update_clear_and_erase_semantics(gpu_required):
     gv.sync()
     assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
     assert gv.stats().n_dirty == len(ov.dirty())
+
+
+def _random_pose(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    t = rng.uniform(-0.5, 0.5, size=3)
+    return np.concatenate([R, t.reshape(3, 1)], 1).astype(np.float32)
+
+
+def test_random_rigid_poses_and_explicit_lists(gpu_required):
+    """Arbitrary rotations and hand-made chunk lists: chunks around and behind the camera plane
+    (p.z near 0 or negative -> generic division path), far chunks, chunks that project off-image
+    (pos-stall), all against the oracle bit for bit."""
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 16)
+    rng = np.random.default_rng(20261001)
+    for it in range(4):
+        depth, rgba, quality, _ = synth.room_frame(11 * it, cam)
+        pose = _random_pose(rng)
+        _frame_flow(ov, gv, depth, rgba, quality, pose, kf_id=it, use_quality=True)
+    # explicit list: a cube of chunks around the camera centre of the last pose, incl. behind it
+    c = np.floor(pose[:, 3] / (8 * float(RES5))).astype(np.int32)
+    ids = np.array([[c[0] + i, c[1] + j, c[2] + k] for i in range(-3, 4) for j in range(-3, 4) for k in range(-3, 4)],
+                   np.int32)
+    far = np.array([[c[0] + 80 + i, c[1] + j, c[2] + 60] for i in range(3) for j in range(3)], np.int32)
+    ids = np.concatenate([ids, far])
+    for cid in ids:
+        if not ov.has_chunk(cid):
+            ov.set_chunk(cid, *O.fresh_chunk())
+            gv.set_chunk(cid, *O.fresh_chunk())
+    depth = np.full((cam.height, cam.width), 0.06, np.float32)   # a surface 6 cm in front of the camera
+    depth[::7, ::5] = 2.5
+    gv.frame_upload(depth, rgba, quality)
+    on, gn = np.zeros(len(ids), np.uint8), np.zeros(len(ids), np.uint8)
+    oq = ov.integrate(depth, rgba, quality, pose, ids, on, 1, 9)
+    gq = gv.integrate(pose, ids, gn, 1, True, True)
+    assert np.array_equal(on, gn)
+    assert np.array_equal(oq.view(np.uint32), gq.view(np.uint32))
+    assert_chunks_equal(ov, gv, ids, "explicit list")
