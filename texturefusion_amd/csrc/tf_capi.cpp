@@ -272,22 +272,6 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     return fail(TF_ERR_HIP);
   }
   v->own_stream = true;
-  {
-    // the selection kernels are small and latency-critical (the next integrate launch waits on
-    // them) while k_integrate fills every CU: give their stream the highest dispatch priority
-    int prio_lo = 0, prio_hi = 0;
-    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (hipStreamCreateWithPriority(&v->sel_stream, hipStreamNonBlocking, prio_hi) != hipSuccess) {
-      set_error("hipStreamCreate failed");
-      return fail(TF_ERR_HIP);
-    }
-  }
-  for (int k = 0; k < tf_volume::kSelSets; ++k) {
-    hipEventCreateWithFlags(&v->ev_sel_done[k], hipEventDisableTiming);
-    hipEventCreateWithFlags(&v->ev_ka_done[k], hipEventDisableTiming);
-  }
-  hipEventCreateWithFlags(&v->ev_batch, hipEventDisableTiming);
-
   VolumeDev& d = v->dev;
   memset(&d, 0, sizeof(d));
   d.max_chunks = (uint32_t)v->cfg.max_chunks;
@@ -338,12 +322,6 @@ int tf_volume_destroy(tf_volume* v) {
   if (v->d_quality) hipFree(v->d_quality);
   if (v->d_tmp) hipFree(v->d_tmp);
   if (v->h_pinned) hipHostFree(v->h_pinned);
-  if (v->sel_stream) { hipStreamSynchronize(v->sel_stream); hipStreamDestroy(v->sel_stream); }
-  for (int k = 0; k < tf_volume::kSelSets; ++k) {
-    if (v->ev_sel_done[k]) hipEventDestroy(v->ev_sel_done[k]);
-    if (v->ev_ka_done[k]) hipEventDestroy(v->ev_ka_done[k]);
-  }
-  if (v->ev_batch) hipEventDestroy(v->ev_batch);
   if (v->own_stream && v->stream) hipStreamDestroy(v->stream);
   delete v;
   return TF_OK;

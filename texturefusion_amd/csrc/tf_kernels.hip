@@ -21,7 +21,7 @@
 #pragma clang fp contract(off)
 
 #ifndef TF_KA_GP
-#define TF_KA_GP 4
+#define TF_KA_GP 2
 #endif
 
 
@@ -706,7 +706,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     else slot = L.list_slot[e];
     bool is_new = false;
     uint32_t ent = i0;
-    bool have_slot = !FUSED;
 
     // per-chunk scalars (ProjectionIntegrator.cpp:74-101), precomputed per list entry; e is
     // wave-uniform so these are scalar loads
@@ -726,24 +725,29 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     float qsum = 0.0f;
     int cnt_t = 0, cnt_c = 0;  // per-lane: rows of mine that were rewritten (same in a row's 8 lanes)
     int oob_any = 0;
-    bool stopped = (kc.dbg & 64u) != 0;  // triage: skip the passes
     __amdgpu_buffer_rsrc_t rs_T = __builtin_amdgcn_make_buffer_rsrc((void*)v.tsdf, 0, 0, 0x00020000);
     __amdgpu_buffer_rsrc_t rs_C = rs_T;
 
-#pragma unroll 1
-    for (int g0 = 0; g0 < 8 && !stopped; g0 += GP) {
-      // ---- phase 1: geometry of GP z-slices; rows run in order until the first row with no
-      // valid lane -- the reference's `continue` skips `pos++` (:176-178, :420), so every later
-      // row of the chunk is dead.
-      float sd[GP];  // pz, later the surface distance
-      int off_d[GP]; // image byte offset of the lane's pixel, kOOB when the gather is masked
+    // The passes over the chunk (GP z-slices each) run as a software pipeline.  gfx9 has ONE
+    // in-order vmcnt for loads and stores, so a wait for a gather also waits for every store issued
+    // before it: the next pass' geometry is therefore computed while this pass' voxel rows are in
+    // flight, and its depth gathers are issued BEFORE this pass' stores.
+    struct PassGeo {
+      float pz[GP];
+      int off_d[GP];  // image byte offset of the lane's pixel, kOOB when the gather is masked
       int oobl[GP];
-      int nrows = GP * 8;  // rows of this pass that are processed
+      int nrows;      // rows of the pass that are processed (GP*8 unless the chunk stalls here)
+    };
+    // ---- phase 1: geometry of GP z-slices; rows run in order until the first row with no valid
+    // lane -- the reference's `continue` skips `pos++` (:176-178, :420), so every later row of the
+    // chunk is dead.
+    auto geometry = [&](const int g0, PassGeo& G) {
+      int nrows = GP * 8;
 #pragma unroll
       for (int j = 0; j < GP; ++j) {
         const int k = (g0 + j) * 64 + lane;
         const float px = o[0] + cenT[0][k], py = o[1] + cenT[1][k], pz = o[2] + cenT[2][k];
-        sd[j] = pz;
+        G.pz[j] = pz;
         // px / pz and py / pz (:155-164), correctly rounded; fast path when every lane is in range
         float qx, qy;
         if (div_safe) {
@@ -759,80 +763,96 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         const int X = cvt_sat_rne(u), Y = cvt_sat_rne(w);
         // 0 < X < W-1 and 0 < Y < H-1 (:167-173) as two unsigned range tests
         const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
-        off_d[j] = valid ? (__mul24(Y, W) + X) * 4 : kOOB;  // valid => 0 < Y < H, exact in 24 bits
+        G.off_d[j] = valid ? (__mul24(Y, W) + X) * 4 : kOOB;  // valid => 0 < Y < H, exact in 24 bits
         // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220)
-        if (COLOR) oobl[j] = (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1))) ? 1 : 0;
+        G.oobl[j] = (COLOR && (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1)))) ? 1 : 0;
         const unsigned long long dead = __ballot(row8_or(valid ? 1 : 0) == 0);
         if (dead && nrows == GP * 8) nrows = j * 8 + (__builtin_ctzll(dead) >> 3);
       }
       if (nrows < GP * 8) {
-        stopped = true;
 #pragma unroll
         for (int j = 0; j < GP; ++j) {
-          if (!((j * 8 + vy) < nrows)) { off_d[j] = kOOB; if (COLOR) oobl[j] = 0; }
+          if (!((j * 8 + vy) < nrows)) { G.off_d[j] = kOOB; G.oobl[j] = 0; }
         }
       }
-      // ---- phase 2: depth gathers (masked lanes read 0, like the reference's masked gather)
-      float dep[GP];
+      G.nrows = nrows;
+    };
+    // ---- phase 2: depth gathers (masked lanes read 0, like the reference's masked gather)
+    auto gather_depth = [&](const PassGeo& G, float (&dep)[GP]) {
 #pragma unroll
       for (int j = 0; j < GP; ++j)
-        dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, (kc.dbg & 8u) ? kOOB : off_d[j], 0, 0));
-      // ---- resolve the slot once (fast path: the home entry holds the key, chunk alive)
-      if (FUSED && !have_slot) {
-        have_slot = true;
-        const uint32_t klo = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.x);
-        const uint32_t khi = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.y);
-        const uint32_t hs = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.z);
-        const uint32_t ha = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.w);
-        if ((((unsigned long long)khi << 32) | klo) == key && ha != 0u && hs != kInvalidSlot) {
-          slot = hs;
-        } else {
-          uint32_t s0 = kInvalidSlot, nw = 1, en = 0;
-          if (lane == 0) {
-            bool bnew = true;
-            s0 = chunk_acquire(v, id, &bnew, &en);
-            nw = bnew ? 1u : 0u;
-          }
-          slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0);
-          is_new = __builtin_amdgcn_readfirstlane((int)nw) != 0;
-          ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)en);
+        dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, (kc.dbg & 8u) ? kOOB : G.off_d[j], 0, 0));
+    };
+
+    constexpr int NP = 8 / GP;
+    PassGeo G[2];
+    float dep[2][GP];
+    bool live = (kc.dbg & 64u) == 0;  // triage switch: skip the passes
+    if (live) {
+      geometry(0, G[0]);
+      gather_depth(G[0], dep[0]);
+    }
+    // ---- resolve the slot once (fast path: the home entry holds the key, chunk alive)
+    if (FUSED) {
+      const uint32_t klo = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.x);
+      const uint32_t khi = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.y);
+      const uint32_t hs = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.z);
+      const uint32_t ha = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.w);
+      if ((((unsigned long long)khi << 32) | klo) == key && ha != 0u && hs != kInvalidSlot) {
+        slot = hs;
+      } else {
+        uint32_t s0 = kInvalidSlot, nw = 1, en = 0;
+        if (lane == 0) {
+          bool bnew = true;
+          s0 = chunk_acquire(v, id, &bnew, &en);
+          nw = bnew ? 1u : 0u;
         }
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0);
+        is_new = __builtin_amdgcn_readfirstlane((int)nw) != 0;
+        ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)en);
       }
-      if (slot == kInvalidSlot || nrows == 0) break;
-      if (kc.dbg & 128u) continue;  // triage: geometry + depth only
-      if (g0 == 0 || FUSED) {
-        rs_T = __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
-        rs_C = __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
-      }
-      // speculative TSDF row loads of every processed row of the pass, issued before the depth
-      // values are back (tuning knob kc.dbg bit 8 = 256): trades some extra reads of rows that end
-      // up untouched for one dependent memory round trip less per pass
-      u32x2 t[GP];
-      const bool spec = (kc.dbg & 256u) != 0;
-      if (spec) {
+    }
+    if (slot == kInvalidSlot) live = false;
+    if (live) {
+      rs_T = __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+      rs_C = __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+    }
+
 #pragma unroll
-        for (int j = 0; j < GP; ++j) {
-          const bool act = (j * 8 + vy) < nrows;
-          t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, act ? ((g0 + j) * 64 + lane) * 8 : kOOB, 0, 0);
-        }
+    for (int p = 0; p < NP; ++p) {
+      if (!live) break;
+      const int g0 = p * GP;
+      PassGeo& Gc = G[p & 1];
+      PassGeo& Gn = G[(p + 1) & 1];
+      float(&dc)[GP] = dep[p & 1];
+      float(&dn)[GP] = dep[(p + 1) & 1];
+      const int nrows = Gc.nrows;
+      const bool more = (p + 1 < NP) && (nrows == GP * 8);  // a stalled row ends the chunk
+      if (nrows == 0) break;
+      if (kc.dbg & 128u) {  // triage: geometry + depth only
+        if (more) { geometry(g0 + GP, Gn); gather_depth(Gn, dn); }
+        live = more;
+        continue;
       }
       // ---- phase 3: predicates -> offsets
-      float nwv[GP];
+      float nwv[GP], sd[GP];
       int off_t[GP], off_c[GP], off_i[GP];
+      int anyrow = 0;
 #pragma unroll
       for (int j = 0; j < GP; ++j) {
         const int kb = ((g0 + j) * 64 + lane) * 8;
-        const float d = dep[j];
-        const float s = d - sd[j];
+        const float d = dc[j];
+        const float s = d - Gc.pz[j];
         sd[j] = s;
         const bool act = (j * 8 + vy) < nrows;
         if (COLOR) {
-          const bool upd = (off_d[j] != kOOB) && (fabsf(s) < kc.thrCol);  // -thr < sd < thr (:202-208)
-          off_i[j] = upd ? off_d[j] : kOOB;
+          const bool upd = (Gc.off_d[j] != kOOB) && (fabsf(s) < kc.thrCol);  // -thr < sd < thr (:202-208)
+          off_i[j] = upd ? Gc.off_d[j] : kOOB;
           const int ru = row8_or(upd ? 1 : 0);
           off_c[j] = ru ? kb : kOOB;
           cnt_c += ru;
-          oob_any |= oobl[j];
+          oob_any |= Gc.oobl[j];
+          anyrow |= ru;
         }
         const bool dv = (d > cam.nearP) && (cam.farP > d);     // (:310-312)
         const bool inside = (s > kc.lower) && (upper > s);     // (:313-316)
@@ -841,81 +861,82 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         const int rf = row8_or(F ? 1 : 0);
         off_t[j] = rf ? kb : kOOB;
         cnt_t += rf;
+        anyrow |= rf;
       }
       // nothing of this pass is rewritten (chunk outside the band, or a hole): skip the RMW
       // phases for the whole wave -- about a third of the selected chunks never update a row
-      {
-        int anyrow = 0;
-#pragma unroll
-        for (int j = 0; j < GP; ++j) {
-          anyrow |= (off_t[j] != kOOB) ? 1 : 0;
-          if (COLOR) anyrow |= (off_c[j] != kOOB) ? 1 : 0;
-        }
-        if (__ballot(anyrow != 0) == 0ull && !(COLOR && QUALITY)) continue;
-      }
+      const bool rmw = (__ballot(anyrow != 0) != 0ull) || (COLOR && QUALITY);
       // ---- phase 4: voxel rows that will be rewritten + their inputs
-      u32x2 c[GP];
+      u32x2 t[GP], c[GP];
       uint32_t in[GP];
       float qv[GP];
-      if (!spec) {
+      if (rmw) {
 #pragma unroll
         for (int j = 0; j < GP; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, off_t[j], 0, 0);
-      }
-      if (COLOR) {
+        if (COLOR) {
 #pragma unroll
-        for (int j = 0; j < GP; ++j) {
-          c[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_C, off_c[j], 0, 0);
-          in[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[j], 0, 0);
-          if (QUALITY) qv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qual, off_i[j], 0, 0));
+          for (int j = 0; j < GP; ++j) {
+            c[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_C, off_c[j], 0, 0);
+            in[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[j], 0, 0);
+            if (QUALITY) qv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qual, off_i[j], 0, 0));
+          }
         }
       }
+      // ---- next pass' geometry while the loads above are in flight
+      if (more) geometry(g0 + GP, Gn);
       // ---- phase 5a: all arithmetic on the loaded rows (every load is consumed here, before
       // the first store)
+      if (rmw) {
 #pragma unroll
-      for (int j = 0; j < GP; ++j) {
-        if (COLOR) {
-          ushort4 cc;
-          cc.x = (unsigned short)(c[j].x & 0xFFFFu); cc.y = (unsigned short)(c[j].x >> 16);
-          cc.z = (unsigned short)(c[j].y & 0xFFFFu); cc.w = (unsigned short)(c[j].y >> 16);
-          const uint32_t ii = in[j];
-          const unsigned short ir = ii & 0xFFu, ig8 = (ii >> 8) & 0xFFu, ib = (ii >> 16) & 0xFFu, ia = ii >> 24;
-          if (kc.flag) {  // (:274-292)
-            cc.x = (unsigned short)(cc.x + ir);
-            cc.y = (unsigned short)(cc.y + ig8);
-            cc.z = (unsigned short)(cc.z + ib);
-            cc.w = (unsigned short)(cc.w + ia);
-            if ((short)cc.w > 120) { cc.x >>= 2; cc.y >>= 2; cc.z >>= 2; cc.w >>= 2; }
-          } else {        // (:293-304)
-            cc.x = (unsigned short)(cc.x - ir);
-            cc.y = (unsigned short)(cc.y - ig8);
-            cc.z = (unsigned short)(cc.z - ib);
-            cc.w = (unsigned short)(cc.w - ia);
+        for (int j = 0; j < GP; ++j) {
+          if (COLOR) {
+            ushort4 cc;
+            cc.x = (unsigned short)(c[j].x & 0xFFFFu); cc.y = (unsigned short)(c[j].x >> 16);
+            cc.z = (unsigned short)(c[j].y & 0xFFFFu); cc.w = (unsigned short)(c[j].y >> 16);
+            const uint32_t ii = in[j];
+            const unsigned short ir = ii & 0xFFu, ig8 = (ii >> 8) & 0xFFu, ib = (ii >> 16) & 0xFFu, ia = ii >> 24;
+            if (kc.flag) {  // (:274-292)
+              cc.x = (unsigned short)(cc.x + ir);
+              cc.y = (unsigned short)(cc.y + ig8);
+              cc.z = (unsigned short)(cc.z + ib);
+              cc.w = (unsigned short)(cc.w + ia);
+              if ((short)cc.w > 120) { cc.x >>= 2; cc.y >>= 2; cc.z >>= 2; cc.w >>= 2; }
+            } else {        // (:293-304)
+              cc.x = (unsigned short)(cc.x - ir);
+              cc.y = (unsigned short)(cc.y - ig8);
+              cc.z = (unsigned short)(cc.z - ib);
+              cc.w = (unsigned short)(cc.w - ia);
+            }
+            c[j].x = (uint32_t)cc.x | ((uint32_t)cc.y << 16);
+            c[j].y = (uint32_t)cc.z | ((uint32_t)cc.w << 16);
           }
-          c[j].x = (uint32_t)cc.x | ((uint32_t)cc.y << 16);
-          c[j].y = (uint32_t)cc.z | ((uint32_t)cc.w << 16);
+          const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);  // (:319-341)
+          const float nw = nwv[j];
+          const float num = ts * tw + sd[j] * nw;
+          const float den = (tw + nw) + kc.sigma;
+          const float ns = num / den;
+          const float nwt = tw + nw;
+          const bool keep = nwt > 0.5f;
+          t[j].x = __float_as_uint(keep ? ns : 999.0f);
+          t[j].y = __float_as_uint(keep ? nwt : 0.0f);
         }
-        const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);  // (:319-341)
-        const float nw = nwv[j];
-        const float num = ts * tw + sd[j] * nw;
-        const float den = (tw + nw) + kc.sigma;
-        const float ns = num / den;
-        const float nwt = tw + nw;
-        const bool keep = nwt > 0.5f;
-        t[j].x = __float_as_uint(keep ? ns : 999.0f);
-        t[j].y = __float_as_uint(keep ? nwt : 0.0f);
       }
+      // ---- next pass' depth gathers go out BEFORE this pass' stores (one in-order vmcnt)
+      if (more) gather_depth(Gn, dn);
       // ---- phase 5b: write back the rewritten rows only (masked offsets drop the store)
+      if (rmw) {
 #pragma unroll
-      for (int j = 0; j < GP; ++j) {
-        if (COLOR) __builtin_amdgcn_raw_buffer_store_b64(c[j], rs_C, off_c[j], 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, off_t[j], 0, 0);
+        for (int j = 0; j < GP; ++j) {
+          if (COLOR) __builtin_amdgcn_raw_buffer_store_b64(c[j], rs_C, off_c[j], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, off_t[j], 0, 0);
+        }
       }
       // ---- phase 6: observationQualitySum bookkeeping in row order (:212-238)
       if (COLOR && QUALITY) {
 #pragma unroll
         for (int j = 0; j < GP; ++j) {
           const unsigned long long mu = __ballot(off_i[j] != kOOB);
-          const unsigned long long mo = __ballot(oobl[j] != 0);
+          const unsigned long long mo = __ballot(Gc.oobl[j] != 0);
           if ((mu | mo) == 0ull) continue;
           float rowsum = 0.0f;
           if (mu) {  // sum += observationQuality[i], i = 0..7 (:233-236)
@@ -930,6 +951,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           }
         }
       }
+      live = more;
     }
     if (slot == kInvalidSlot) {
       if (FUSED && lane == 0) {
@@ -1010,7 +1032,7 @@ struct FrameLaunch {
   Integ ig;
   uint32_t epoch;
   uint32_t n_ka, n_sel, n_bbox;
-  uint32_t ka_first;     // block-range order (tuning)
+  uint32_t ka_first;     // K-A blocks dispatched ahead of the K-C / K-B ranges (tuning)
   SelBuf sel1;           // set of frame f+1
   const float* depth1;
   SelectConsts sc1;
@@ -1021,30 +1043,23 @@ struct FrameLaunch {
 
 template <bool COLOR, int GP>
 __global__ __launch_bounds__(256) void k_frame(FrameLaunch a) {
+  // Block ranges: K-A blocks [0, split) and [split + n_sel + n_bbox, total) with the small K-C / K-B
+  // ranges in between (ka_first = number of K-A blocks dispatched ahead of them; tuning knob).
   const uint32_t b = blockIdx.x;
-  if (a.ka_first) {  // K-A blocks first: the small K-C / K-B ranges fill the tail of the launch
-    if (b < a.n_ka) {
-      integrate_body<COLOR, false, true, GP>(a.v, a.img, a.cam, a.ig, a.P, a.kc, a.epoch, b, a.n_ka);
-    } else if (b < a.n_ka + a.n_sel) {
-      if (a.kc.dbg & 512u) return;  // triage
-      VolumeDev v1 = a.v;
-      v1.sel = a.sel1;
-      select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - a.n_ka, a.n_sel);
-    } else {
-      if (a.kc.dbg & 1024u) return;  // triage
-      bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_sel, a.n_bbox);
-    }
-    return;
-  }
-  if (b < a.n_bbox) {
-    bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b, a.n_bbox);
-  } else if (b < a.n_bbox + a.n_sel) {
+  const uint32_t split = a.ka_first < a.n_ka ? a.ka_first : a.n_ka;
+  if (b < split) {
+    integrate_body<COLOR, false, true, GP>(a.v, a.img, a.cam, a.ig, a.P, a.kc, a.epoch, b, a.n_ka);
+  } else if (b < split + a.n_sel) {
+    if (a.kc.dbg & 512u) return;  // triage
     VolumeDev v1 = a.v;
     v1.sel = a.sel1;
-    select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - a.n_bbox, a.n_sel);
+    select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - split, a.n_sel);
+  } else if (b < split + a.n_sel + a.n_bbox) {
+    if (a.kc.dbg & 1024u) return;  // triage
+    bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - split - a.n_sel, a.n_bbox);
   } else {
     integrate_body<COLOR, false, true, GP>(a.v, a.img, a.cam, a.ig, a.P, a.kc, a.epoch,
-                                           b - a.n_bbox - a.n_sel, a.n_ka);
+                                           b - a.n_sel - a.n_bbox, a.n_ka);
   }
 }
 
@@ -1104,7 +1119,7 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   a.ig = ig;
   a.n_ka = a.n_sel = a.n_bbox = 0;
   a.epoch = 0;
-  static const int ka_first = env_int("TF_KA_FIRST", 1);
+  static const int ka_first = env_int("TF_KA_FIRST", 1 << 30);
   a.ka_first = (uint32_t)ka_first;
   static const int nsel = env_int("TF_SEL_BLOCKS", 512);
   a.kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);
@@ -1131,7 +1146,8 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
     a.P2 = next2->pose;
     int nvec = (cam.W * cam.H) >> 2;
     int blocks = (nvec + 255) / 256;
-    a.n_bbox = (uint32_t)(blocks > 128 ? 128 : blocks);
+    static const int nbb = env_int("TF_BBOX_BLOCKS", 128);
+    a.n_bbox = (uint32_t)(blocks > nbb ? nbb : blocks);
   }
   const uint32_t total = a.n_ka + a.n_sel + a.n_bbox;
   if (!total) return;

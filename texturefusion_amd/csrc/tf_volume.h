@@ -51,7 +51,7 @@ struct AtlasState {
 }  // namespace tf
 
 struct tf_volume {
-  static constexpr int kSelSets = 4;  // selection runs up to kSelSets-1 frames ahead of integration
+  static constexpr int kSelSets = 4;  // ring of selection sets: K-B / K-C run 2 / 1 frames ahead of K-A
   tf_config cfg;
   int device = 0;
   float res = 0.005f;
@@ -62,11 +62,6 @@ struct tf_volume {
   tf::Integ ig;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  // second stream: selection of frame f+1 overlaps the integration of frame f (batched unit)
-  hipStream_t sel_stream = nullptr;
-  hipEvent_t ev_sel_done[kSelSets] = {};
-  hipEvent_t ev_ka_done[kSelSets] = {};
-  hipEvent_t ev_batch = nullptr;
   tf::VolumeDev dev;
   tf::SelBuf selbuf[kSelSets];  // ring of selection scratch sets (dev.sel = the active set)
   int cur_sel = 0;
