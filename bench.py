@@ -39,10 +39,12 @@ def parse():
     ap.add_argument("--res", type=float, default=0.005)
     ap.add_argument("--hires", action="store_true", help="1280x960 camera (config 4)")
     ap.add_argument("--unique-frames", type=int, default=200, help="distinct frames of the orbit kept in HBM")
-    ap.add_argument("--exchange-every", type=int, default=20, help="N>1: boundary all-gather period (frames)")
+    ap.add_argument("--exchange-every", type=int, default=40, help="N>1: boundary all-gather period (frames)")
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's parallel_for policy")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the N>1 code path (partition + boundary all-gather) even with one rank (smoke test)")
     ap.add_argument("--atlas-every", type=int, default=0,
                     help="N>0: every N frames run GeneratePatches+UpdateAtlas on that frame (BASELINE configs[2])")
     return ap.parse_args()
@@ -63,8 +65,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_exchange
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from texturefusion_amd import capi, exchange, synth
@@ -86,7 +90,7 @@ def main():
     # atlas leg: keyframe = every --atlas-every-th frame; its per-chunk meshes are depth-derived
     # vertex clouds (meshing is the next-stage scope), its RGB / depth are already in HBM
     atlas = {}
-    if args.atlas_every > 0 and world == 1:
+    if args.atlas_every > 0 and not multi:
         for i in range(0, n_unique, args.atlas_every):
             rgb = torch.from_numpy(np.ascontiguousarray(frames[i][1][..., :3])).to(dev)
             ids, voff, verts, cols = synth.mesh_from_depth(frames[i][0], frames[i][1], frames[i][3], cam, res, 4)
@@ -95,8 +99,10 @@ def main():
                             T=np.tile(synth.pose_inverse16(frames[i][3]), (len(ids), 1)))
             vol.keyframe_cache_device(i, rgb.data_ptr(), d_depth[i].data_ptr())
         torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         lo, hi = part.slab_for_rank(part.room_extent_chunks(res), rank, world)
+        if args.force_exchange and world == 1:
+            lo, hi = -5, 5  # a real interior slab so that faces exist and get packed
         vol.set_partition(lo, hi)
         rec_cap = 1 << 14
         send = torch.empty(rec_cap * capi.TF_BOUNDARY_RECORD_BYTES, dtype=torch.uint8, device=dev)
@@ -113,7 +119,7 @@ def main():
     def run(first, count, timed):
         """Frames [first, first+count) of the stream (cyclic over the unique frames)."""
         idx = [(first + i) % n_unique for i in range(count)]
-        if world == 1 and atlas:
+        if not multi and atlas:
             b0 = 0
             for j, i in enumerate(idx):
                 if i in atlas:  # flush the frames up to and including the keyframe, then texture it
@@ -129,7 +135,7 @@ def main():
             if sub:
                 vol.integrate_frames_device([d_depth[k].data_ptr() for k in sub],
                                             [d_rgba[k].data_ptr() for k in sub], poses[sub])
-        elif world == 1:
+        elif not multi:
             vol.integrate_frames_device([d_depth[i].data_ptr() for i in idx],
                                         [d_rgba[i].data_ptr() for i in idx], poses[idx])
         else:
@@ -140,7 +146,7 @@ def main():
                 exchange_boundary()
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -154,7 +160,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     vol.sync()  # surfaces any device-side capacity error of the timed region
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -239,7 +245,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     vol.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

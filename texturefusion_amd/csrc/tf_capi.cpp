@@ -300,6 +300,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     if ((rc = dev_alloc(v, &L.list_needs, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_quality, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_rows, (size_t)d.max_list))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.cen, (size_t)3 * kChunkVoxels))) return fail(rc);
     if ((rc = dev_alloc(v, &L.ctl, (size_t)1))) return fail(rc);
   }
   if ((rc = init_device_state(v))) return fail(rc);

@@ -87,6 +87,7 @@ struct SelBuf {
   uint8_t* list_needs;        // [max_list]
   float* list_quality;        // [max_list]
   uint16_t* list_rows;        // [max_list] low byte tsdf rows, high byte colour rows
+  float* cen;                 // [3*512] centroid table of the frame (Chisel.cpp:52-110), c[a][voxel]
   FrameCtl* ctl;
 };
 

@@ -97,6 +97,24 @@ __device__ __forceinline__ ChunkPre chunk_pre(const int4 id, const float* __rest
   return r;
 }
 
+
+// Centroid table of a frame (Chisel::bufferIntegratorSIMDCentroids, Structure/Chisel.cpp:52-110):
+// c[a][i] = (R^T (x,y,z))_a * res + res/2, i = (z*8+y)*8+x, summed p0 + (p1 + p2); a function of the
+// pose only.  Written once per frame by one workgroup (ahead of K-A), read by every K-A workgroup.
+__device__ __forceinline__ void centroid_table(const float* __restrict__ Pp, float res, float* __restrict__ cen) {
+  const float half = res * 0.5f;
+  for (int i = threadIdx.x; i < kChunkVoxels; i += 256) {
+    const float fx = (float)(i & 7), fy = (float)((i >> 3) & 7), fz = (float)(i >> 6);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float q0 = Pp[a] * fx, q1 = Pp[4 + a] * fy, q2 = Pp[8 + a] * fz;
+      const float s12 = q1 + q2;
+      const float d = q0 + s12;
+      cen[a * kChunkVoxels + i] = d * res + half;
+    }
+  }
+}
+
 // Lookup only.  Entries are never removed, so the probe sequence of a present key is stable.
 // Returns the entry index or kInvalidSlot.
 __device__ __forceinline__ uint32_t hash_find(const VolumeDev& v, unsigned long long key) {
@@ -317,6 +335,7 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
     ctl->n_coarse = n_coarse;
     if (overflow) atomicOr(&v.vctl->status, kStCoarseFull);
   }
+  if (EMIT && bid == 0) centroid_table(sc.pose, sc.res, v.sel.cen);  // for K-A of this frame, one launch later
   const int lane = threadIdx.x & 63;
   // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to the compiler;
   // readfirstlane makes the uniformity provable (scalar loads, no waterfall loops around buffer ops)
@@ -533,6 +552,7 @@ void launch_acquire(const VolumeDev& v, hipStream_t s) {
 // IntegrateDepthScanColor call brings its own pose, Chisel.h:226).  One thread per entry.
 __global__ __launch_bounds__(256) void k_pre(VolumeDev v, Pose P, Integ ig, float res, float resDiag) {
   const SelBuf& L = v.sel;
+  if (blockIdx.x == 0) centroid_table(P.p, res, L.cen);
   const uint32_t n = L.ctl->n_list < v.max_list ? L.ctl->n_list : v.max_list;
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const ChunkPre cp = chunk_pre(L.list_id[e], P.p, ig, res, resDiag);
@@ -660,18 +680,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     }
   }
 
-  // centroid table (Chisel.cpp:52-110): c[i] = (R^T (x,y,z)) * res + res/2, summed p0 + (p1 + p2);
-  // a function of the pose only, shared by the four waves of the workgroup through LDS.
+  // centroid table (Chisel.cpp:52-110), computed once per frame ahead of this launch; copied into
+  // LDS and shared by the four waves of the workgroup (6 KB).
   __shared__ float cenT[3][kChunkVoxels];
-  for (int i = threadIdx.x; i < kChunkVoxels; i += 256) {
-    const float fx = (float)(i & 7), fy = (float)((i >> 3) & 7), fz = (float)(i >> 6);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float q0 = P.p[a] * fx, q1 = P.p[4 + a] * fy, q2 = P.p[8 + a] * fz;
-      const float s12 = q1 + q2;
-      const float d = q0 + s12;
-      cenT[a][i] = d * kc.res + kc.half;
-    }
+  {
+    const float4* src = reinterpret_cast<const float4*>(L.cen);
+    float4* dst = reinterpret_cast<float4*>(&cenT[0][0]);
+    for (int i = threadIdx.x; i < 3 * kChunkVoxels / 4; i += 256) dst[i] = src[i];
   }
   __syncthreads();
 

@@ -1,7 +1,7 @@
 """Boundary-chunk exchange between chunk-range partitions.
 
 The only collective of the path: an all-gather of the records of updated chunks that sit on a
-slab face.  Counts are gathered first, then fixed-capacity padded payload buffers (RCCL over
+slab face.  Counts are gathered first, then payloads padded to the largest count (RCCL over
 xGMI when the tensors are device-resident and the backend is "nccl"; gloo on CPU in the tests).
 torch.distributed is plumbing here; the records are produced / consumed by tf_boundary_pack /
 tf_boundary_unpack (include/tf_fusion.h).
@@ -21,10 +21,17 @@ def allgather_records(send, n_records: int, group=None):
     cnt = torch.tensor([int(n_records)], dtype=torch.int64, device=send.device)
     cnts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(cnts, cnt, group=group)
-    recv = [torch.empty_like(send) for _ in range(world)]
-    dist.all_gather(recv, send, group=group)
+    counts = [int(c.item()) for c in cnts]
+    m = max(counts)
+    if m == 0:
+        return [(send[:0], 0) for _ in range(world)]
+    # equal-sized payloads: every rank contributes its first max(count) records (the tail of a
+    # shorter contribution is padding and is never unpacked)
+    part = send[: m * RECORD_BYTES]
+    recv = [torch.empty_like(part) for _ in range(world)]
+    dist.all_gather(recv, part, group=group)
     if send.is_cuda:
         # the consumer (tf_boundary_unpack) runs on the volume's own HIP stream: make the collective's
         # result visible to it before returning
         torch.cuda.synchronize(send.device)
-    return [(recv[r], int(cnts[r].item())) for r in range(world)]
+    return [(recv[r], counts[r]) for r in range(world)]
