@@ -144,6 +144,7 @@ static int init_device_state(tf_volume* v) {
   TF_HIP(hipMemsetAsync(d.hent, 0xFF, ((size_t)d.hmask + 1) * sizeof(HEntry), s));  // key = empty
   TF_HIP(hipMemsetAsync(d.mark_epoch, 0, (size_t)d.max_chunks * 4, s));
   TF_HIP(hipMemsetAsync(d.erase_epoch, 0, (size_t)d.max_chunks * 4, s));
+  TF_HIP(hipMemsetAsync(d.phase_buf, 0, (size_t)kPhaseWaves * 16 * 8, s));
   v->clear_floor = 0;
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
     d.sel = v->selbuf[k];
@@ -287,6 +288,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   if ((rc = dev_alloc(v, &d.hent, hcap))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mark_epoch, (size_t)d.max_chunks))) return fail(rc);
   if ((rc = dev_alloc(v, &d.erase_epoch, (size_t)d.max_chunks))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.phase_buf, (size_t)kPhaseWaves * 16))) return fail(rc);
   if ((rc = dev_alloc(v, &d.vctl, (size_t)1))) return fail(rc);
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
     SelBuf& L = v->selbuf[k];
@@ -477,7 +479,7 @@ int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t
   memcpy(P.p, pose, sizeof(P.p));
   prof_begin(v, TF_PROF_INTEGRATE);
   launch_integrate(v->dev, v->frame, v->cam, v->ig, P, v->res, integrate_flag, use_color != 0,
-                   use_quality != 0, false, 0, v->stream);
+                   use_quality != 0, 0, v->stream);
   prof_end(v);
   TF_HIP(hipGetLastError());
   TF_HIP(hipMemcpyAsync(st, v->dev.sel.list_needs, (size_t)n, hipMemcpyDeviceToHost, v->stream));
@@ -751,6 +753,27 @@ int tf_profile_get(tf_volume* v, tf_profile* out, int reset) {
   prof_collect(v);
   *out = v->prof_acc;
   if (reset) memset(&v->prof_acc, 0, sizeof(v->prof_acc));
+  return TF_OK;
+}
+
+int tf_debug_phase_raw(tf_volume* v, uint64_t* out, int64_t cap_words) {
+  if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  size_t n = (size_t)kPhaseWaves * 16;
+  if ((size_t)cap_words < n) n = (size_t)cap_words;
+  TF_HIP(hipMemcpyAsync(out, v->dev.phase_buf, n * 8, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  return TF_OK;
+}
+
+int tf_debug_phase_cycles(tf_volume* v, uint64_t out[16], int reset) {
+  if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  std::vector<unsigned long long> h((size_t)kPhaseWaves * 16);
+  TF_HIP(hipMemcpyAsync(h.data(), v->dev.phase_buf, h.size() * 8, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  for (int k = 0; k < 16; ++k) out[k] = 0;
+  for (size_t w = 0; w < (size_t)kPhaseWaves; ++w)
+    for (int k = 0; k < 16; ++k) out[k] += h[w * 16 + k];
+  if (reset) TF_HIP(hipMemsetAsync(v->dev.phase_buf, 0, h.size() * 8, v->stream));
   return TF_OK;
 }
 

@@ -91,6 +91,8 @@ struct SelBuf {
   FrameCtl* ctl;
 };
 
+constexpr int kPhaseWaves = 16384;
+
 struct VolumeDev {
   // pool
   float2* tsdf;
@@ -105,6 +107,7 @@ struct VolumeDev {
   // Chisel.h:197-203 is expanded when the set is read (k_list_dirty), not on the per-frame path.
   uint32_t* mark_epoch;   // [max_chunks]
   uint32_t* erase_epoch;  // [max_chunks]
+  unsigned long long* phase_buf;  // [kPhaseWaves][16] tuning aid: per-wave phase cycles of K-A (TF_KA_DBG bit 11)
   uint32_t max_list;
   uint32_t max_coarse;
   // partition (multi-GPU chunk-range ownership): lo <= id.x < hi
@@ -139,7 +142,7 @@ void launch_acquire(const VolumeDev& v, hipStream_t s);
 void launch_lookup(const VolumeDev& v, uint32_t n, hipStream_t s);
 void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam, const Integ& ig,
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
-                      bool fused, uint32_t epoch, hipStream_t s);
+                      uint32_t epoch, hipStream_t s);
 void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
 void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipStream_t s);
 void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s);

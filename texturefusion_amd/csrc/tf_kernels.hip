@@ -602,6 +602,9 @@ __device__ __forceinline__ unsigned long long nonzero_bytes(unsigned long long m
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kOOB = 0x7FFFFFF0;  // buffer byte offset that is out of range for every descriptor
+#ifndef TF_ST_AUX
+#define TF_ST_AUX 0  // cache-policy bits of the voxel-row stores (tuning)
+#endif
 
 // OR over the 8 lanes of a voxel row (lanes 8r..8r+7), three DPP steps, no SGPRs involved.
 __device__ __forceinline__ int row8_or(int x) {
@@ -649,18 +652,38 @@ __device__ __forceinline__ bool in_div_range(float x) {
   return e > 127u - 40u && e < 127u + 40u;
 }
 
-// GP = z-slices handled per pass: all loads of a pass are issued before the first use, so a wave
-// keeps GP depth gathers and up to 3*GP voxel-row / image loads in flight; registers (hence
-// resident waves per SIMD) grow with GP.
+// K-A runs per chunk as:   list entry + hash entry (scalar loads)  ->  geometry of all 8 z-slices
+// -> 8 depth gathers in flight  ->  slot resolve  ->  RMW passes of GP slices (predicates -> voxel
+// rows + colour image pixels -> arithmetic -> stores).  A wave therefore pays one scalar, one
+// gather and 8/GP voxel round trips per chunk; everything else is hidden by the other waves of
+// the SIMD, so the register budget (<= 64 VGPRs: 8 waves per SIMD) matters more than ILP.
 //
 // Predication is done the CDNA way: every per-lane predicate is folded into the byte offset of a
 // buffer load/store (out-of-range offset = no memory access, loads return 0), so there is no
 // exec-mask juggling and no lane mask has to live in SGPRs across phases.  Descriptors: the three
 // frame images (kernel arguments) and the chunk's two 4-KiB voxel planes (wave-uniform slot).
-template <bool COLOR, bool QUALITY, bool FUSED, int GP>
+//
+// Tuning aid (TIMING instantiation, TF_KA_DBG bit 11): per-phase shader-cycle stamps summed per
+// wave into VolumeDev::phase_buf.  Phase ids: 0 list entry, 1 geometry + gather issue, 2 slot
+// resolve, 3 predicates + voxel load issue (waits depth), 4 arithmetic (waits voxel rows),
+// 5 stores issue, 6 finalize, 9 chunks.
+#define TF_STAMP(ph)                                                             \
+  do {                                                                           \
+    if (TIMING) {                                                                \
+      const unsigned long long _t = __builtin_readcyclecounter();                \
+      acc[ph] += _t - tprev;                                                     \
+      tprev = _t;                                                                \
+    }                                                                            \
+  } while (0)
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) u32x4* const_u32x4_ptr;
+
+template <bool COLOR, bool QUALITY, bool FUSED, bool FLAG, int GP, bool TIMING>
 __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameImages& img, const Cam& cam,
-                                               const Integ& ig, const Pose& P, const IntegrateConsts& kc,
-                                               const uint32_t epoch, const uint32_t bid, const uint32_t nb) {
+                                               const IntegrateConsts& kc, const uint32_t epoch,
+                                               const uint32_t bid, const uint32_t nb) {
   const SelBuf& L = v.sel;
   const int lane = threadIdx.x & 63;
   // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to the compiler;
@@ -669,7 +692,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   const uint32_t nwaves = nb * 4;
   const uint32_t n = L.ctl->n_list < v.max_list ? L.ctl->n_list : v.max_list;
   const int vx = lane & 7, vy = lane >> 3;
-  const int rowshift = lane & 56;
   const int W = cam.W, H = cam.H;
   if (FUSED && bid == 0 && threadIdx.x == 0) {
     // re-arm the K-B reduction of this selection set for its next frame (k_scan does this in the
@@ -697,6 +719,17 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   const __amdgpu_buffer_rsrc_t rs_qual =
       __builtin_amdgcn_make_buffer_rsrc((void*)img.quality, 0, QUALITY ? W * H * 4 : 0, 0x00020000);
 
+  // "any lane of my 8-voxel row" from a wave ballot: the row's byte of the lane's half of the mask
+  const bool upper_half = lane >= 32;
+  const uint32_t row_bit = (uint32_t)(lane & 24);
+  auto row_any = [&](const unsigned long long m) -> bool {
+    const uint32_t w32 = upper_half ? (uint32_t)(m >> 32) : (uint32_t)m;
+    return __builtin_amdgcn_ubfe(w32, row_bit, 8u) != 0u;
+  };
+
+  unsigned long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = TIMING ? __builtin_readcyclecounter() : 0ull;
+
   for (uint32_t e = wave; e < n; e += nwaves) {
     const int4 id = L.list_id[e];
     const bool owned = (id.x >= v.part_lo) && (id.x < v.part_hi);
@@ -707,17 +740,14 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       }
       continue;
     }
-    if (kc.dbg & 32u) {  // triage: loop skeleton only
-      if (lane == 0) { L.list_needs[e] = 0; L.list_rows[e] = 0; }
-      continue;
-    }
-    // slot lookup: ONE 16-B load of the chunk's home hash entry, issued now and consumed after
-    // the first pass' geometry + depth gathers
+    // slot lookup: ONE 16-B scalar load of the chunk's home hash entry, consumed after the
+    // geometry.  The scalar cache can only be stale for entries written during THIS launch, i.e.
+    // for other chunks' keys; a miss of any kind goes through the atomic path (chunk_acquire).
     const unsigned long long key = pack_id(id.x, id.y, id.z);
     const uint32_t i0 = hash_key(key) & v.hmask;
-    uint4 h0 = make_uint4(0, 0, 0, 0);
+    u32x4 h0 = {0u, 0u, 0u, 0u};
     uint32_t slot = kInvalidSlot;
-    if (FUSED) h0 = *reinterpret_cast<const uint4*>(&v.hent[i0]);
+    if (FUSED) h0 = *(const_u32x4_ptr)(unsigned long long)(&v.hent[i0]);
     else slot = L.list_slot[e];
     bool is_new = false;
     uint32_t ent = i0;
@@ -726,95 +756,85 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     // wave-uniform so these are scalar loads
     const float4 pa = L.list_pre[2 * e];
     const float4 pb = L.list_pre[2 * e + 1];
-    const float o[3] = {pa.x, pa.y, pa.z};
-    const float wD = kc.flag ? pb.x : -pb.x;  // depth_weight *= -1 when de-integrating (:95-99)
+    const float o0 = pa.x, o1 = pa.y, o2 = pa.z;
+    const float wD = FLAG ? pb.x : -pb.x;  // depth_weight *= -1 when de-integrating (:95-99)
     const float upper = pb.y;
     // every voxel centre of the chunk is o + c with 0 < c < 16 * res * sqrt(3): if |o.z| clears that
     // band, p.z is far inside the normal exponent range; numerators o + c are exact zeros or at
     // least one ulp of c (> 2^-40), and |o| < 2^20 keeps quotients finite -> no scaling / fix-up
     // case of the division can occur in this chunk (wave-uniform)
     const float band = 32.0f * kc.res;
-    const bool div_safe = (fabsf(o[2]) > band) && (fabsf(o[2]) < 1048576.0f) && (fabsf(o[0]) < 1048576.0f) &&
-                          (fabsf(o[1]) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
+    const bool div_safe = (fabsf(o2) > band) && (fabsf(o2) < 1048576.0f) && (fabsf(o0) < 1048576.0f) &&
+                          (fabsf(o1) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
+    TF_STAMP(0);
 
-    float qsum = 0.0f;
-    int cnt_t = 0, cnt_c = 0;  // per-lane: rows of mine that were rewritten (same in a row's 8 lanes)
+    // ---- phase 1: geometry of the 8 z-slices.  Rows run in order until the first row with no
+    // valid lane -- the reference's `continue` skips `pos++` (:176-178, :420), so that row and
+    // every later row of the chunk is dead: R = number of processed rows.
+    float pz[8];
+    int off_d[8];             // image byte offset of the lane's pixel, kOOB when the gather is masked
+    int oobl[QUALITY ? 8 : 1];
     int oob_any = 0;
-    __amdgpu_buffer_rsrc_t rs_T = __builtin_amdgcn_make_buffer_rsrc((void*)v.tsdf, 0, 0, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_C = rs_T;
-
-    // The passes over the chunk (GP z-slices each) run as a software pipeline.  gfx9 has ONE
-    // in-order vmcnt for loads and stores, so a wait for a gather also waits for every store issued
-    // before it: the next pass' geometry is therefore computed while this pass' voxel rows are in
-    // flight, and its depth gathers are issued BEFORE this pass' stores.
-    struct PassGeo {
-      float pz[GP];
-      int off_d[GP];  // image byte offset of the lane's pixel, kOOB when the gather is masked
-      int oobl[GP];
-      int nrows;      // rows of the pass that are processed (GP*8 unless the chunk stalls here)
-    };
-    // ---- phase 1: geometry of GP z-slices; rows run in order until the first row with no valid
-    // lane -- the reference's `continue` skips `pos++` (:176-178, :420), so every later row of the
-    // chunk is dead.
-    auto geometry = [&](const int g0, PassGeo& G) {
-      int nrows = GP * 8;
+    uint32_t R = 64;
+    auto geometry = [&](auto safe_tag) {
+      constexpr bool SAFE = decltype(safe_tag)::value;
 #pragma unroll
-      for (int j = 0; j < GP; ++j) {
-        const int k = (g0 + j) * 64 + lane;
-        const float px = o[0] + cenT[0][k], py = o[1] + cenT[1][k], pz = o[2] + cenT[2][k];
-        G.pz[j] = pz;
+      for (int j = 0; j < 8; ++j) {
+        if (QUALITY) oobl[j] = 0;
+        if (R != 64u) {  // the chunk stalled in an earlier slice
+          pz[j] = 0.0f;
+          off_d[j] = kOOB;
+          continue;
+        }
+        const int k = j * 64 + lane;
+        const float px = o0 + cenT[0][k], py = o1 + cenT[1][k], pzv = o2 + cenT[2][k];
+        pz[j] = pzv;
         // px / pz and py / pz (:155-164), correctly rounded; fast path when every lane is in range
         float qx, qy;
-        if (div_safe) {
-          const Recip R = recip_refined(pz);
-          qx = div_by(px, R);
-          qy = div_by(py, R);
+        if (SAFE) {
+          const Recip Rz = recip_refined(pzv);
+          qx = div_by(px, Rz);
+          qy = div_by(py, Rz);
         } else {
-          qx = px / pz;
-          qy = py / pz;
+          qx = px / pzv;
+          qy = py / pzv;
         }
         const float u = qx * cam.fxi + kc.cxs;
         const float w = qy * cam.fyi + kc.cys;
         const int X = cvt_sat_rne(u), Y = cvt_sat_rne(w);
         // 0 < X < W-1 and 0 < Y < H-1 (:167-173) as two unsigned range tests
         const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
-        G.off_d[j] = valid ? (__mul24(Y, W) + X) * 4 : kOOB;  // valid => 0 < Y < H, exact in 24 bits
-        // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220)
-        G.oobl[j] = (COLOR && (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1)))) ? 1 : 0;
-        const unsigned long long dead = __ballot(row8_or(valid ? 1 : 0) == 0);
-        if (dead && nrows == GP * 8) nrows = j * 8 + (__builtin_ctzll(dead) >> 3);
-      }
-      if (nrows < GP * 8) {
-#pragma unroll
-        for (int j = 0; j < GP; ++j) {
-          if (!((j * 8 + vy) < nrows)) { G.off_d[j] = kOOB; G.oobl[j] = 0; }
+        int od = valid ? (__mul24(Y, W) + X) * 4 : kOOB;  // valid => 0 < Y < H, exact in 24 bits
+        const unsigned long long m = __ballot(valid);
+        if (m != ~0ull) {  // chunks that project entirely inside the image skip all of this
+          const unsigned long long dead = nonzero_bytes(m) ^ 0x0101010101010101ull;
+          if (dead) R = (uint32_t)(j * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
+          const bool live_lane = (uint32_t)(j * 8 + vy) < R;
+          if (COLOR) {
+            // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220), lanes of processed rows only
+            const bool oob = live_lane && (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1)));
+            oob_any |= oob ? 1 : 0;
+            if (QUALITY) oobl[j] = oob ? 1 : 0;
+          }
+          od = live_lane ? od : kOOB;
         }
+        off_d[j] = od;
       }
-      G.nrows = nrows;
     };
-    // ---- phase 2: depth gathers (masked lanes read 0, like the reference's masked gather)
-    auto gather_depth = [&](const PassGeo& G, float (&dep)[GP]) {
-#pragma unroll
-      for (int j = 0; j < GP; ++j)
-        dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, (kc.dbg & 8u) ? kOOB : G.off_d[j], 0, 0));
-    };
+    if (div_safe) geometry(std::true_type{});
+    else geometry(std::false_type{});
 
-    constexpr int NP = 8 / GP;
-    PassGeo G[2];
-    float dep[2][GP];
-    bool live = (kc.dbg & 64u) == 0;  // triage switch: skip the passes
-    if (live) {
-      geometry(0, G[0]);
-      gather_depth(G[0], dep[0]);
-    }
+    // ---- phase 2: depth gathers (masked lanes read 0, like the reference's masked gather)
+    float dep[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j], 0, 0));
+    TF_STAMP(1);
+
     // ---- resolve the slot once (fast path: the home entry holds the key, chunk alive)
     if (FUSED) {
-      const uint32_t klo = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.x);
-      const uint32_t khi = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.y);
-      const uint32_t hs = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.z);
-      const uint32_t ha = (uint32_t)__builtin_amdgcn_readfirstlane((int)h0.w);
-      if ((((unsigned long long)khi << 32) | klo) == key && ha != 0u && hs != kInvalidSlot) {
-        slot = hs;
+      if ((((unsigned long long)h0.y << 32) | h0.x) == key && h0.w != 0u && h0.z != kInvalidSlot) {
+        slot = h0.z;
       } else {
         uint32_t s0 = kInvalidSlot, nw = 1, en = 0;
         if (lane == 0) {
@@ -827,60 +847,60 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)en);
       }
     }
-    if (slot == kInvalidSlot) live = false;
-    if (live) {
-      rs_T = __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
-      rs_C = __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+    if (slot == kInvalidSlot) {
+      if (FUSED && lane == 0) {
+        L.list_slot[e] = kInvalidSlot; L.list_ent[e] = 0; L.list_new[e] = 0; L.list_needs[e] = 0;
+        L.list_quality[e] = 0.0f; L.list_rows[e] = 0;
+      }
+      continue;
     }
+    TF_STAMP(2);
+    const __amdgpu_buffer_rsrc_t rs_T =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_C =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+
+    float qsum = 0.0f;
+    uint32_t lanes_t = 0, lanes_c = 0;  // lanes of rewritten rows (8 per row), wave-uniform
 
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-      if (!live) break;
+    for (int p = 0; p < 8 / GP; ++p) {
       const int g0 = p * GP;
-      PassGeo& Gc = G[p & 1];
-      PassGeo& Gn = G[(p + 1) & 1];
-      float(&dc)[GP] = dep[p & 1];
-      float(&dn)[GP] = dep[(p + 1) & 1];
-      const int nrows = Gc.nrows;
-      const bool more = (p + 1 < NP) && (nrows == GP * 8);  // a stalled row ends the chunk
-      if (nrows == 0) break;
-      if (kc.dbg & 128u) {  // triage: geometry + depth only
-        if (more) { geometry(g0 + GP, Gn); gather_depth(Gn, dn); }
-        live = more;
-        continue;
-      }
+      if ((uint32_t)(g0 * 8) >= R) break;  // a stalled row ends the chunk
       // ---- phase 3: predicates -> offsets
       float nwv[GP], sd[GP];
       int off_t[GP], off_c[GP], off_i[GP];
-      int anyrow = 0;
+      unsigned long long any = 0ull;
 #pragma unroll
       for (int j = 0; j < GP; ++j) {
-        const int kb = ((g0 + j) * 64 + lane) * 8;
-        const float d = dc[j];
-        const float s = d - Gc.pz[j];
+        const int gj = g0 + j;
+        const int kb = (gj * 64 + lane) * 8;
+        const float d = dep[gj];
+        const float s = d - pz[gj];
         sd[j] = s;
-        const bool act = (j * 8 + vy) < nrows;
         if (COLOR) {
-          const bool upd = (Gc.off_d[j] != kOOB) && (fabsf(s) < kc.thrCol);  // -thr < sd < thr (:202-208)
-          off_i[j] = upd ? Gc.off_d[j] : kOOB;
-          const int ru = row8_or(upd ? 1 : 0);
-          off_c[j] = ru ? kb : kOOB;
-          cnt_c += ru;
-          oob_any |= Gc.oobl[j];
-          anyrow |= ru;
+          const bool upd = (off_d[gj] != kOOB) && (fabsf(s) < kc.thrCol);  // -thr < sd < thr (:202-208)
+          off_i[j] = upd ? off_d[gj] : kOOB;
+          const bool ru_l = row_any(__ballot(upd));
+          const unsigned long long ru = __ballot(ru_l);
+          off_c[j] = ru_l ? kb : kOOB;
+          lanes_c += (uint32_t)__popcll(ru);
+          any |= ru;
         }
+        const bool act = (uint32_t)(gj * 8 + vy) < R;
         const bool dv = (d > cam.nearP) && (cam.farP > d);     // (:310-312)
         const bool inside = (s > kc.lower) && (upper > s);     // (:313-316)
         const bool F = act && dv && inside;
         nwv[j] = F ? wD : 0.0f;
-        const int rf = row8_or(F ? 1 : 0);
-        off_t[j] = rf ? kb : kOOB;
-        cnt_t += rf;
-        anyrow |= rf;
+        const bool rf_l = row_any(__ballot(F));
+        const unsigned long long rf = __ballot(rf_l);
+        off_t[j] = rf_l ? kb : kOOB;
+        lanes_t += (uint32_t)__popcll(rf);
+        any |= rf;
       }
       // nothing of this pass is rewritten (chunk outside the band, or a hole): skip the RMW
       // phases for the whole wave -- about a third of the selected chunks never update a row
-      const bool rmw = (__ballot(anyrow != 0) != 0ull) || (COLOR && QUALITY);
+      const bool rmw = (any != 0ull) || (COLOR && QUALITY);
       // ---- phase 4: voxel rows that will be rewritten + their inputs
       u32x2 t[GP], c[GP];
       uint32_t in[GP];
@@ -897,33 +917,34 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           }
         }
       }
-      // ---- next pass' geometry while the loads above are in flight
-      if (more) geometry(g0 + GP, Gn);
-      // ---- phase 5a: all arithmetic on the loaded rows (every load is consumed here, before
-      // the first store)
+      TF_STAMP(3);
+      // ---- phase 5a: arithmetic on the loaded rows
       if (rmw) {
 #pragma unroll
         for (int j = 0; j < GP; ++j) {
           if (COLOR) {
-            ushort4 cc;
-            cc.x = (unsigned short)(c[j].x & 0xFFFFu); cc.y = (unsigned short)(c[j].x >> 16);
-            cc.z = (unsigned short)(c[j].y & 0xFFFFu); cc.w = (unsigned short)(c[j].y >> 16);
-            const uint32_t ii = in[j];
-            const unsigned short ir = ii & 0xFFu, ig8 = (ii >> 8) & 0xFFu, ib = (ii >> 16) & 0xFFu, ia = ii >> 24;
-            if (kc.flag) {  // (:274-292)
-              cc.x = (unsigned short)(cc.x + ir);
-              cc.y = (unsigned short)(cc.y + ig8);
-              cc.z = (unsigned short)(cc.z + ib);
-              cc.w = (unsigned short)(cc.w + ia);
-              if ((short)cc.w > 120) { cc.x >>= 2; cc.y >>= 2; cc.z >>= 2; cc.w >>= 2; }
-            } else {        // (:293-304)
-              cc.x = (unsigned short)(cc.x - ir);
-              cc.y = (unsigned short)(cc.y - ig8);
-              cc.z = (unsigned short)(cc.z - ib);
-              cc.w = (unsigned short)(cc.w - ia);
+            // colour planes are 4 x u16 {r, g, b, count} per voxel = two packed-u16 dwords; the
+            // image pixel is widened with two byte permutes ({r, g} and {b, a} as u16 pairs)
+            // (__builtin_bit_cast needs plain scalars: applied to a vector element it reads element 0)
+            const uint32_t p_rg = __builtin_amdgcn_perm(0u, in[j], 0x0c010c00u);
+            const uint32_t p_ba = __builtin_amdgcn_perm(0u, in[j], 0x0c030c02u);
+            const uint32_t w_rg = c[j].x, w_ba = c[j].y;
+            const u16x2 in_rg = __builtin_bit_cast(u16x2, p_rg), in_ba = __builtin_bit_cast(u16x2, p_ba);
+            u16x2 c_rg = __builtin_bit_cast(u16x2, w_rg), c_ba = __builtin_bit_cast(u16x2, w_ba);
+            if (FLAG) {  // (:274-292)
+              c_rg += in_rg;
+              c_ba += in_ba;
+              // (short)count > 120  <=>  the dword, read as signed, is >= 121 << 16
+              const bool halve = (int)__builtin_bit_cast(uint32_t, c_ba) >= (121 << 16);
+              const u16x2 h_rg = c_rg >> (unsigned short)2, h_ba = c_ba >> (unsigned short)2;
+              c_rg = halve ? h_rg : c_rg;
+              c_ba = halve ? h_ba : c_ba;
+            } else {     // (:293-304)
+              c_rg -= in_rg;
+              c_ba -= in_ba;
             }
-            c[j].x = (uint32_t)cc.x | ((uint32_t)cc.y << 16);
-            c[j].y = (uint32_t)cc.z | ((uint32_t)cc.w << 16);
+            c[j].x = __builtin_bit_cast(uint32_t, c_rg);
+            c[j].y = __builtin_bit_cast(uint32_t, c_ba);
           }
           const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);  // (:319-341)
           const float nw = nwv[j];
@@ -936,8 +957,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           t[j].y = __float_as_uint(keep ? nwt : 0.0f);
         }
       }
-      // ---- next pass' depth gathers go out BEFORE this pass' stores (one in-order vmcnt)
-      if (more) gather_depth(Gn, dn);
+      TF_STAMP(4);
       // ---- phase 5b: write back the rewritten rows only (masked offsets drop the store)
       if (rmw) {
 #pragma unroll
@@ -946,19 +966,23 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, off_t[j], 0, 0);
         }
       }
+      TF_STAMP(5);
       // ---- phase 6: observationQualitySum bookkeeping in row order (:212-238)
       if (COLOR && QUALITY) {
+        const int rowshift = lane & 56;
 #pragma unroll
         for (int j = 0; j < GP; ++j) {
+          const int gj = g0 + j;
           const unsigned long long mu = __ballot(off_i[j] != kOOB);
-          const unsigned long long mo = __ballot(Gc.oobl[j] != 0);
+          const unsigned long long mo = __ballot(oobl[gj] != 0);
           if ((mu | mo) == 0ull) continue;
           float rowsum = 0.0f;
           if (mu) {  // sum += observationQuality[i], i = 0..7 (:233-236)
 #pragma unroll
             for (int l = 0; l < 8; ++l) rowsum += __shfl(qv[j], rowshift + l);
           }
-          const int rmax = (nrows - j * 8) < 8 ? (nrows - j * 8) : 8;
+          const int left = (int)R - gj * 8;
+          const int rmax = left < 8 ? left : 8;
           for (int r = 0; r < rmax; ++r) {
             if ((mo >> (8 * r)) & 0xFFull) qsum = kc.qoob;
             if ((mu >> (8 * r)) & 0xFFull)
@@ -966,23 +990,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           }
         }
       }
-      live = more;
     }
-    if (slot == kInvalidSlot) {
-      if (FUSED && lane == 0) {
-        L.list_slot[e] = kInvalidSlot; L.list_ent[e] = 0; L.list_new[e] = 0; L.list_needs[e] = 0;
-        L.list_quality[e] = 0.0f; L.list_rows[e] = 0;
-      }
-      continue;
-    }
-    // rows rewritten: per-lane counters are equal within a row's 8 lanes and <= 8; sum the
-    // lanes with x == 0 bit-plane by bit-plane (wave-uniform result)
-    uint32_t rows_t = 0, rows_c = 0;
-#pragma unroll
-    for (int bit = 0; bit < 4; ++bit) {
-      rows_t += (uint32_t)__popcll(__ballot(vx == 0 && ((cnt_t >> bit) & 1))) << bit;
-      if (COLOR) rows_c += (uint32_t)__popcll(__ballot(vx == 0 && ((cnt_c >> bit) & 1))) << bit;
-    }
+    const uint32_t rows_t = lanes_t >> 3, rows_c = COLOR ? (lanes_c >> 3) : 0u;
     const bool updated = rows_t != 0;
     if (COLOR && !QUALITY) {
       // without a quality image nothing is ever added: the sum ends as the out-of-observation
@@ -1020,13 +1029,20 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       L.list_quality[e] = qsum;
       L.list_rows[e] = (uint16_t)(rows_t | (rows_c << 8));
     }
+    TF_STAMP(6);
+    if (TIMING) acc[9] += 1;
   }
+  if (TIMING && lane == 0 && wave < (uint32_t)kPhaseWaves) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) v.phase_buf[wave * 16 + k] += acc[k];
+  }
+  (void)vx;
 }
 
-template <bool COLOR, bool QUALITY, bool FUSED, int GP>
-__global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img, Cam cam, Integ ig,
-                                                   Pose P, IntegrateConsts kc, uint32_t epoch) {
-  integrate_body<COLOR, QUALITY, FUSED, GP>(v, img, cam, ig, P, kc, epoch, blockIdx.x, gridDim.x);
+template <bool COLOR, bool QUALITY, bool FLAG>
+__global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img, Cam cam, IntegrateConsts kc,
+                                                   uint32_t epoch) {
+  integrate_body<COLOR, QUALITY, false, FLAG, TF_KA_GP, false>(v, img, cam, kc, epoch, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1056,25 +1072,42 @@ struct FrameLaunch {
   Pose P2;
 };
 
-template <bool COLOR, int GP>
+template <bool COLOR, bool TIMING>
 __global__ __launch_bounds__(256) void k_frame(FrameLaunch a) {
   // Block ranges: K-A blocks [0, split) and [split + n_sel + n_bbox, total) with the small K-C / K-B
   // ranges in between (ka_first = number of K-A blocks dispatched ahead of them; tuning knob).
   const uint32_t b = blockIdx.x;
   const uint32_t split = a.ka_first < a.n_ka ? a.ka_first : a.n_ka;
+  // tuning aid (dbg bit 12): per-wave {start, end, role} stamps of the last launch -> phase_buf
+  const bool timeline = (a.kc.dbg & 4096u) != 0 && a.n_sel > 0 && a.n_bbox > 0;  // steady launches only
+  const unsigned long long t0 = timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz, chip-wide
+  uint32_t role;
   if (b < split) {
-    integrate_body<COLOR, false, true, GP>(a.v, a.img, a.cam, a.ig, a.P, a.kc, a.epoch, b, a.n_ka);
+    role = 0;
+    integrate_body<COLOR, false, true, true, TF_KA_GP, TIMING>(a.v, a.img, a.cam, a.kc, a.epoch, b, a.n_ka);
   } else if (b < split + a.n_sel) {
-    if (a.kc.dbg & 512u) return;  // triage
-    VolumeDev v1 = a.v;
-    v1.sel = a.sel1;
-    select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - split, a.n_sel);
+    role = 1;
+    if (!(a.kc.dbg & 512u)) {  // triage switch
+      VolumeDev v1 = a.v;
+      v1.sel = a.sel1;
+      select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - split, a.n_sel);
+    }
   } else if (b < split + a.n_sel + a.n_bbox) {
-    if (a.kc.dbg & 1024u) return;  // triage
-    bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - split - a.n_sel, a.n_bbox);
+    role = 2;
+    if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - split - a.n_sel, a.n_bbox);
   } else {
-    integrate_body<COLOR, false, true, GP>(a.v, a.img, a.cam, a.ig, a.P, a.kc, a.epoch,
-                                           b - a.n_sel - a.n_bbox, a.n_ka);
+    role = 0;
+    integrate_body<COLOR, false, true, true, TF_KA_GP, TIMING>(a.v, a.img, a.cam, a.kc, a.epoch,
+                                                               b - a.n_sel - a.n_bbox, a.n_ka);
+  }
+  if (timeline) {
+    const uint32_t gw = (b * 256 + threadIdx.x) >> 6;
+    if ((threadIdx.x & 63) == 0 && gw < (uint32_t)kPhaseWaves) {
+      a.v.phase_buf[gw * 16 + 10] = t0;
+      a.v.phase_buf[gw * 16 + 11] = __builtin_amdgcn_s_memrealtime();
+      a.v.phase_buf[gw * 16 + 12] = role + 1;
+      a.v.phase_buf[gw * 16 + 13] = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;  // XCC_ID
+    }
   }
 }
 
@@ -1083,42 +1116,22 @@ static int env_int(const char* name, int dflt) {
   return e ? atoi(e) : dflt;
 }
 
-template <bool FUSED, int GP>
-static void launch_integrate_t(const VolumeDev& v, const FrameImages& img, const Cam& cam,
-                               const Integ& ig, const Pose& pose, const IntegrateConsts& kc,
-                               bool use_color, bool use_quality, uint32_t epoch, hipStream_t s) {
-  static const int nblocks = env_int("TF_KA_BLOCKS", 1536);  // tuning knob; < full residency leaves
-                                                              // wave slots for the selection stream
-  const dim3 grid(nblocks > 0 ? nblocks : 2048), block(256);
-  if (use_color && use_quality)
-    hipLaunchKernelGGL((k_integrate<true, true, FUSED, GP>), grid, block, 0, s, v, img, cam, ig, pose, kc, epoch);
-  else if (use_color)
-    hipLaunchKernelGGL((k_integrate<true, false, FUSED, GP>), grid, block, 0, s, v, img, cam, ig, pose, kc, epoch);
-  else
-    hipLaunchKernelGGL((k_integrate<false, false, FUSED, GP>), grid, block, 0, s, v, img, cam, ig, pose, kc, epoch);
-}
-
 void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam, const Integ& ig,
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
-                      bool fused, uint32_t epoch, hipStream_t s) {
+                      uint32_t epoch, hipStream_t s) {
   IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
-  if (!fused) hipLaunchKernelGGL(k_pre, dim3(256), dim3(256), 0, s, v, pose, ig, res, kc.resDiag);
-  static const int gp = env_int("TF_KA_GP", TF_KA_GP);     // tuning knob: z-slices per pass
-  static const int dbg = env_int("TF_KA_DBG", 0);          // ablation switches (perf triage only)
-  kc.dbg = (uint32_t)dbg;
-  if (gp == 8) {
-    if (fused) launch_integrate_t<true, 8>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
-    else launch_integrate_t<false, 8>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
-  } else if (gp == 2) {
-    if (fused) launch_integrate_t<true, 2>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
-    else launch_integrate_t<false, 2>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
-  } else if (gp == 1) {
-    if (fused) launch_integrate_t<true, 1>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
-    else launch_integrate_t<false, 1>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
-  } else {
-    if (fused) launch_integrate_t<true, 4>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
-    else launch_integrate_t<false, 4>(v, img, cam, ig, pose, kc, use_color, use_quality, epoch, s);
-  }
+  hipLaunchKernelGGL(k_pre, dim3(256), dim3(256), 0, s, v, pose, ig, res, kc.resDiag);
+  static const int nblocks = env_int("TF_KA_BLOCKS", 2048);  // tuning knob
+  const dim3 grid(nblocks > 0 ? nblocks : 2048), block(256);
+#define TF_LAUNCH_KA(C, Q)                                                                           \
+  do {                                                                                               \
+    if (flag) hipLaunchKernelGGL((k_integrate<C, Q, true>), grid, block, 0, s, v, img, cam, kc, epoch);  \
+    else hipLaunchKernelGGL((k_integrate<C, Q, false>), grid, block, 0, s, v, img, cam, kc, epoch);      \
+  } while (0)
+  if (use_color && use_quality) TF_LAUNCH_KA(true, true);
+  else if (use_color) TF_LAUNCH_KA(true, false);
+  else TF_LAUNCH_KA(false, false);
+#undef TF_LAUNCH_KA
 }
 
 // One pipelined launch.  Any of the three stages may be absent (pipeline fill / drain):
@@ -1127,7 +1140,6 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
 void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* next,
                   const FrameStage* next2, const Cam& cam, const Integ& ig, float res, hipStream_t s) {
   static const int nblocks = env_int("TF_KA_BLOCKS", 2048);
-  static const int gp = env_int("TF_KA_GP", TF_KA_GP);
   FrameLaunch a;
   a.v = v;
   a.cam = cam;
@@ -1166,14 +1178,12 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   }
   const uint32_t total = a.n_ka + a.n_sel + a.n_bbox;
   if (!total) return;
+  const bool timing = (dbg & 2048) != 0;  // tuning aid: per-phase cycle stamps (tf_debug_phase_cycles)
   if (color) {
-    if (gp == 8) hipLaunchKernelGGL((k_frame<true, 8>), dim3(total), dim3(256), 0, s, a);
-    else if (gp == 4) hipLaunchKernelGGL((k_frame<true, 4>), dim3(total), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_frame<true, 2>), dim3(total), dim3(256), 0, s, a);
+    if (timing) hipLaunchKernelGGL((k_frame<true, true>), dim3(total), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_frame<true, false>), dim3(total), dim3(256), 0, s, a);
   } else {
-    if (gp == 8) hipLaunchKernelGGL((k_frame<false, 8>), dim3(total), dim3(256), 0, s, a);
-    else if (gp == 4) hipLaunchKernelGGL((k_frame<false, 4>), dim3(total), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_frame<false, 2>), dim3(total), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_frame<false, false>), dim3(total), dim3(256), 0, s, a);
   }
 }
 
