@@ -65,8 +65,11 @@ __device__ __forceinline__ int4 unpack_id(unsigned long long k) {
   r.w = 0;
   return r;
 }
+// Fibonacci hashing folded to 32 bits: every bit of (x, y, z) reaches the index bits (the upper
+// half of the product carries z, the lower half x and y), so columns of chunks do not share a home.
 __device__ __forceinline__ uint32_t hash_key(unsigned long long k) {
-  return (uint32_t)((k * 0x9E3779B97F4A7C15ull) >> 24);
+  const unsigned long long h = k * 0x9E3779B97F4A7C15ull;
+  return (uint32_t)(h >> 32) ^ (uint32_t)h;
 }
 
 
@@ -602,6 +605,9 @@ __device__ __forceinline__ unsigned long long nonzero_bytes(unsigned long long m
 
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kOOB = 0x7FFFFFF0;  // buffer byte offset that is out of range for every descriptor
+#ifndef TF_KF_WAVES
+#define TF_KF_WAVES 7  // resident waves per SIMD the fused kernel is compiled for (register budget)
+#endif
 #ifndef TF_ST_AUX
 #define TF_ST_AUX 0  // cache-policy bits of the voxel-row stores (tuning)
 #endif
@@ -621,6 +627,14 @@ __device__ __forceinline__ int cvt_sat_rne(float x) {
   return (int)rintf(__builtin_amdgcn_fmed3f(x, -2147483648.0f, 2147483520.0f));
 }
 
+// The same for operands known not to be NaN: v_cvt_i32_f32 saturates by itself (a C++ cast of an
+// out-of-range float would be undefined, hence the instruction is named explicitly).
+__device__ __forceinline__ int cvt_rne_hw(float x) {
+  int r;
+  const float n = rintf(x);
+  asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(n));
+  return r;
+}
 
 // IEEE-correct f32 quotients with a shared denominator.  This is the instruction sequence hipcc
 // emits for `a / b` (v_rcp, two FMA refinements of the reciprocal, product, three residual FMAs)
@@ -644,6 +658,16 @@ __device__ __forceinline__ float div_by(const float n, const Recip& R) {
   const float q1 = __builtin_fmaf(e0, R.r, q0);
   const float e1 = __builtin_fmaf(-R.d, q1, n);
   return __builtin_fmaf(e1, R.r, q1);
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// the same sequence for two numerators at once on the packed-f32 pipe (v_pk_mul / v_pk_fma)
+__device__ __forceinline__ f32x2 div2_by(const f32x2 n, const Recip& R) {
+  const f32x2 d = {-R.d, -R.d}, r = {R.r, R.r};
+  const f32x2 q0 = n * r;
+  const f32x2 e0 = __builtin_elementwise_fma(d, q0, n);
+  const f32x2 q1 = __builtin_elementwise_fma(e0, r, q0);
+  const f32x2 e1 = __builtin_elementwise_fma(d, q1, n);
+  return __builtin_elementwise_fma(e1, r, q1);
 }
 // operand inside the range where the sequence above needs no scaling / fix-up (or an exact zero
 // numerator): 2^-40 < |x| < 2^40
@@ -719,13 +743,14 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   const __amdgpu_buffer_rsrc_t rs_qual =
       __builtin_amdgcn_make_buffer_rsrc((void*)img.quality, 0, QUALITY ? W * H * 4 : 0, 0x00020000);
 
-  // "any lane of my 8-voxel row" from a wave ballot: the row's byte of the lane's half of the mask
-  const bool upper_half = lane >= 32;
-  const uint32_t row_bit = (uint32_t)(lane & 24);
+  // "any lane of my 8-voxel row" from a wave ballot: the row's byte of the mask, picked with two
+  // loop-invariant per-lane byte masks (v_and + v_and_or + v_cmp, all full rate)
+  const uint32_t row_lo = lane < 32 ? (0xFFu << (lane & 24)) : 0u;
+  const uint32_t row_hi = lane < 32 ? 0u : (0xFFu << (lane & 24));
   auto row_any = [&](const unsigned long long m) -> bool {
-    const uint32_t w32 = upper_half ? (uint32_t)(m >> 32) : (uint32_t)m;
-    return __builtin_amdgcn_ubfe(w32, row_bit, 8u) != 0u;
+    return ((((uint32_t)m) & row_lo) | (((uint32_t)(m >> 32)) & row_hi)) != 0u;
   };
+  auto ballot = [](const bool b) -> unsigned long long { return __builtin_amdgcn_ballot_w64(b); };
 
   unsigned long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev = TIMING ? __builtin_readcyclecounter() : 0ull;
@@ -757,6 +782,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const float4 pa = L.list_pre[2 * e];
     const float4 pb = L.list_pre[2 * e + 1];
     const float o0 = pa.x, o1 = pa.y, o2 = pa.z;
+    const f32x2 o01 = {o0, o1};
+    const f32x2 fxy = {cam.fxi, cam.fyi}, cxy = {kc.cxs, kc.cys};
     const float wD = FLAG ? pb.x : -pb.x;  // depth_weight *= -1 when de-integrating (:95-99)
     const float upper = pb.y;
     // every voxel centre of the chunk is o + c with 0 < c < 16 * res * sqrt(3): if |o.z| clears that
@@ -771,7 +798,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     // ---- phase 1: geometry of the 8 z-slices.  Rows run in order until the first row with no
     // valid lane -- the reference's `continue` skips `pos++` (:176-178, :420), so that row and
     // every later row of the chunk is dead: R = number of processed rows.
-    float pz[8];
     int off_d[8];             // image byte offset of the lane's pixel, kOOB when the gather is masked
     int oobl[QUALITY ? 8 : 1];
     int oob_any = 0;
@@ -782,30 +808,31 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       for (int j = 0; j < 8; ++j) {
         if (QUALITY) oobl[j] = 0;
         if (R != 64u) {  // the chunk stalled in an earlier slice
-          pz[j] = 0.0f;
           off_d[j] = kOOB;
           continue;
         }
         const int k = j * 64 + lane;
-        const float px = o0 + cenT[0][k], py = o1 + cenT[1][k], pzv = o2 + cenT[2][k];
-        pz[j] = pzv;
+        // x and y run as the two halves of packed-f32 instructions (each half rounded on its own)
+        const f32x2 pxy = o01 + (f32x2){cenT[0][k], cenT[1][k]};
+        const float pzv = o2 + cenT[2][k];
         // px / pz and py / pz (:155-164), correctly rounded; fast path when every lane is in range
-        float qx, qy;
+        f32x2 q;
         if (SAFE) {
-          const Recip Rz = recip_refined(pzv);
-          qx = div_by(px, Rz);
-          qy = div_by(py, Rz);
+          q = div2_by(pxy, recip_refined(pzv));
         } else {
-          qx = px / pzv;
-          qy = py / pzv;
+          q.x = pxy.x / pzv;
+          q.y = pxy.y / pzv;
         }
-        const float u = qx * cam.fxi + kc.cxs;
-        const float w = qy * cam.fyi + kc.cys;
-        const int X = cvt_sat_rne(u), Y = cvt_sat_rne(w);
+        const f32x2 uw = q * fxy + cxy;
+        // in the SAFE range no quotient is NaN, so v_cvt's own saturation classifies like x86's
+        const int X = SAFE ? cvt_rne_hw(uw.x) : cvt_sat_rne(uw.x);
+        const int Y = SAFE ? cvt_rne_hw(uw.y) : cvt_sat_rne(uw.y);
         // 0 < X < W-1 and 0 < Y < H-1 (:167-173) as two unsigned range tests
         const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
-        int od = valid ? (__mul24(Y, W) + X) * 4 : kOOB;  // valid => 0 < Y < H, exact in 24 bits
-        const unsigned long long m = __ballot(valid);
+        const unsigned long long m = ballot(valid);
+        int od = (__mul24(Y, W) + X) * 4;  // valid => 0 < Y < H, exact in 24 bits
+        asm volatile("" : "+v"(od));       // keep the select a v_cndmask (no exec-mask branch)
+        od = valid ? od : kOOB;
         if (m != ~0ull) {  // chunks that project entirely inside the image skip all of this
           const unsigned long long dead = nonzero_bytes(m) ^ 0x0101010101010101ull;
           if (dead) R = (uint32_t)(j * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
@@ -826,17 +853,29 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 
     // ---- phase 2: depth gathers (masked lanes read 0, like the reference's masked gather)
     float dep[8];
+#ifdef TF_EXP_COALESCED   // experiment: same number of gathers, all lanes in two cache lines
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j] == kOOB ? kOOB : lane * 4 + j * 256, 0, 0));
+#else
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j], 0, 0));
+#endif
     TF_STAMP(1);
 
-    // ---- resolve the slot once (fast path: the home entry holds the key, chunk alive)
+    // ---- resolve the slot once.  Fast path: the home entry holds the key.  A parked chunk (alive
+    // == 0: created by an earlier frame, never updated, garbage-collected) counts as new again; it is
+    // revived only if this frame updates it, so the usual "selected, outside the band, parked again"
+    // round trip of the chunks in front of the surface costs no hash traffic at all.
+    bool lazy_revive = false;
     if (FUSED) {
-      if ((((unsigned long long)h0.y << 32) | h0.x) == key && h0.w != 0u && h0.z != kInvalidSlot) {
+      if ((((unsigned long long)h0.y << 32) | h0.x) == key && h0.z != kInvalidSlot) {
         slot = h0.z;
+        is_new = lazy_revive = (h0.w == 0u);
       } else {
         uint32_t s0 = kInvalidSlot, nw = 1, en = 0;
+        if (TIMING) acc[7] += 1;  // slow-path slot resolutions
         if (lane == 0) {
           bool bnew = true;
           s0 = chunk_acquire(v, id, &bnew, &en);
@@ -876,13 +915,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         const int gj = g0 + j;
         const int kb = (gj * 64 + lane) * 8;
         const float d = dep[gj];
-        const float s = d - pz[gj];
+        const float s = d - (o2 + cenT[2][gj * 64 + lane]);  // p.z again: an LDS read is cheaper than 8 live VGPRs
         sd[j] = s;
         if (COLOR) {
           const bool upd = (off_d[gj] != kOOB) && (fabsf(s) < kc.thrCol);  // -thr < sd < thr (:202-208)
           off_i[j] = upd ? off_d[gj] : kOOB;
-          const bool ru_l = row_any(__ballot(upd));
-          const unsigned long long ru = __ballot(ru_l);
+          const bool ru_l = row_any(ballot(upd));
+          const unsigned long long ru = ballot(ru_l);
           off_c[j] = ru_l ? kb : kOOB;
           lanes_c += (uint32_t)__popcll(ru);
           any |= ru;
@@ -892,8 +931,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         const bool inside = (s > kc.lower) && (upper > s);     // (:313-316)
         const bool F = act && dv && inside;
         nwv[j] = F ? wD : 0.0f;
-        const bool rf_l = row_any(__ballot(F));
-        const unsigned long long rf = __ballot(rf_l);
+        const bool rf_l = row_any(ballot(F));
+        const unsigned long long rf = ballot(rf_l);
         off_t[j] = rf_l ? kb : kOOB;
         lanes_t += (uint32_t)__popcll(rf);
         any |= rf;
@@ -912,12 +951,17 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 #pragma unroll
           for (int j = 0; j < GP; ++j) {
             c[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_C, off_c[j], 0, 0);
+#ifdef TF_EXP_COALESCED
+            in[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[j] == kOOB ? kOOB : lane * 4 + j * 256, 0, 0);
+#else
             in[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[j], 0, 0);
+#endif
             if (QUALITY) qv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qual, off_i[j], 0, 0));
           }
         }
       }
       TF_STAMP(3);
+      if (TIMING && rmw) acc[8] += 1;  // RMW passes executed
       // ---- phase 5a: arithmetic on the loaded rows
       if (rmw) {
 #pragma unroll
@@ -973,8 +1017,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 #pragma unroll
         for (int j = 0; j < GP; ++j) {
           const int gj = g0 + j;
-          const unsigned long long mu = __ballot(off_i[j] != kOOB);
-          const unsigned long long mo = __ballot(oobl[gj] != 0);
+          const unsigned long long mu = ballot(off_i[j] != kOOB);
+          const unsigned long long mo = ballot(oobl[gj] != 0);
           if ((mu | mo) == 0ull) continue;
           float rowsum = 0.0f;
           if (mu) {  // sum += observationQuality[i], i = 0..7 (:233-236)
@@ -996,13 +1040,14 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     if (COLOR && !QUALITY) {
       // without a quality image nothing is ever added: the sum ends as the out-of-observation
       // constant iff any processed row had an off-image lane (:221-222)
-      if (__ballot(oob_any != 0) != 0ull) qsum = kc.qoob;
+      if (ballot(oob_any != 0) != 0ull) qsum = kc.qoob;
     }
 
     // multi-GPU: remember that this slab-face chunk changed since the last boundary exchange
-    if (updated && lane == 0 && (id.x == v.part_lo || id.x == v.part_hi - 1)) {
+    const bool face = (id.x == v.part_lo || id.x == v.part_hi - 1);
+    if (updated && lane == 0 && (face || lazy_revive)) {
       const uint32_t en = FUSED ? ent : L.list_ent[e];
-      v.hent[en].alive = 3u;  // bit0 alive, bit1 touched
+      v.hent[en].alive = face ? 3u : 1u;  // bit0 alive, bit1 touched
     }
     if (FUSED) {
       // FinalizeIntegrateChunks (Chisel.h:192-208) + GarbageCollect (:472-477) for this entry
@@ -1010,7 +1055,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         if (lane == 0) v.mark_epoch[slot] = epoch + 1u;  // meshesToUpdate[id and 6 nbrs] = true, expanded lazily
       } else if (is_new) {
         if (lane == 0) {
-          v.hent[ent].alive = 0;
+          if (!lazy_revive) v.hent[ent].alive = 0;
           v.erase_epoch[slot] = epoch + 1u;  // meshesToUpdate.erase(id)
         }
         if (rows_c) {  // parked storage returns to the fresh state (only colour can be dirty)
@@ -1063,7 +1108,6 @@ struct FrameLaunch {
   Integ ig;
   uint32_t epoch;
   uint32_t n_ka, n_sel, n_bbox;
-  uint32_t ka_first;     // K-A blocks dispatched ahead of the K-C / K-B ranges (tuning)
   SelBuf sel1;           // set of frame f+1
   const float* depth1;
   SelectConsts sc1;
@@ -1073,32 +1117,26 @@ struct FrameLaunch {
 };
 
 template <bool COLOR, bool TIMING>
-__global__ __launch_bounds__(256) void k_frame(FrameLaunch a) {
-  // Block ranges: K-A blocks [0, split) and [split + n_sel + n_bbox, total) with the small K-C / K-B
-  // ranges in between (ka_first = number of K-A blocks dispatched ahead of them; tuning knob).
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TF_KF_WAVES, TF_KF_WAVES))) void k_frame(FrameLaunch a) {
+  // Block ranges: K-A [0, n_ka), K-C [n_ka, n_ka + n_sel), K-B behind them.
   const uint32_t b = blockIdx.x;
-  const uint32_t split = a.ka_first < a.n_ka ? a.ka_first : a.n_ka;
   // tuning aid (dbg bit 12): per-wave {start, end, role} stamps of the last launch -> phase_buf
   const bool timeline = (a.kc.dbg & 4096u) != 0 && a.n_sel > 0 && a.n_bbox > 0;  // steady launches only
   const unsigned long long t0 = timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz, chip-wide
   uint32_t role;
-  if (b < split) {
+  if (b < a.n_ka) {
     role = 0;
     integrate_body<COLOR, false, true, true, TF_KA_GP, TIMING>(a.v, a.img, a.cam, a.kc, a.epoch, b, a.n_ka);
-  } else if (b < split + a.n_sel) {
+  } else if (b < a.n_ka + a.n_sel) {
     role = 1;
     if (!(a.kc.dbg & 512u)) {  // triage switch
       VolumeDev v1 = a.v;
       v1.sel = a.sel1;
-      select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - split, a.n_sel);
+      select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - a.n_ka, a.n_sel);
     }
-  } else if (b < split + a.n_sel + a.n_bbox) {
-    role = 2;
-    if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - split - a.n_sel, a.n_bbox);
   } else {
-    role = 0;
-    integrate_body<COLOR, false, true, true, TF_KA_GP, TIMING>(a.v, a.img, a.cam, a.kc, a.epoch,
-                                                               b - a.n_sel - a.n_bbox, a.n_ka);
+    role = 2;
+    if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_sel, a.n_bbox);
   }
   if (timeline) {
     const uint32_t gw = (b * 256 + threadIdx.x) >> 6;
@@ -1146,8 +1184,6 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   a.ig = ig;
   a.n_ka = a.n_sel = a.n_bbox = 0;
   a.epoch = 0;
-  static const int ka_first = env_int("TF_KA_FIRST", 1 << 30);
-  a.ka_first = (uint32_t)ka_first;
   static const int nsel = env_int("TF_SEL_BLOCKS", 512);
   a.kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);
   static const int dbg = env_int("TF_KA_DBG", 0);

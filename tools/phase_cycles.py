@@ -13,9 +13,10 @@ v = capi.Volume(res, cam, max_chunks=1 << 19, max_list=1 << 18)
 for rep in range(2):
     v.integrate_frames_device([t.data_ptr() for t in dd], [t.data_ptr() for t in dc], poses); v.sync()
     cyc = v.debug_phase_cycles(reset=True)
-names = ["list/scalars", "geom0+gather", "slot resolve", "predicates(wait depth)", "voxel load issue", "next geometry",
-         "arith(wait voxels)", "gathers+stores issue", "finalize", "chunks"]
-n = max(cyc[9], 1); tot = sum(cyc[:9])
-for k in range(9):
-    print("%-26s %8.0f cycles/chunk  %5.1f%%" % (names[k], cyc[k] / n, 100.0 * cyc[k] / max(tot, 1)))
-print("total %.0f cycles/chunk over %d chunks" % (tot / n, n))
+names = ["list entry", "geometry + gather issue", "slot resolve", "predicates + row loads (wait depth)",
+         "arithmetic (wait rows)", "stores issue", "finalize"]
+n = max(cyc[9], 1); tot = sum(cyc[:7])
+for k in range(7):
+    print("%-38s %8.0f cycles/chunk  %5.1f%%" % (names[k], cyc[k] / n, 100.0 * cyc[k] / max(tot, 1)))
+print("total %.0f cycles/chunk over %d chunks; slow-path slot resolutions %d; RMW passes %d (%.2f per chunk)" % (
+    tot / n, n, cyc[7], cyc[8], cyc[8] / n))

@@ -10,10 +10,10 @@ frames = [synth.room_frame(k, cam, with_quality=False) for k in range(60)]
 dd = [torch.from_numpy(f[0]).to(dev) for f in frames]; dc = [torch.from_numpy(f[1]).to(dev) for f in frames]
 poses = np.stack([f[3].reshape(12) for f in frames]).astype(np.float32)
 v = capi.Volume(res, cam, max_chunks=1 << 19, max_list=1 << 18)
-for rep in range(2):
+# REPS=2: the second pass over the same 60 frames (steady state); REPS=1: first touch (the default
+# bench's regime).  Stamps are those of the last launch that had all three roles.
+for rep in range(int(os.environ.get("REPS", "2"))):
     v.integrate_frames_device([t.data_ptr() for t in dd], [t.data_ptr() for t in dc], poses); v.sync()
-# the last launch of a batch only drains (no K-C / K-B); run a batch of 3 more with the steady set and
-# read the stamps of ... the last launch again; so instead integrate 1 frame batch => launches f, f+1, f+2:
 raw = v.debug_phase_raw()
 t0, t1, role = raw[:, 10].astype(np.int64), raw[:, 11].astype(np.int64), raw[:, 12].astype(np.int64)
 m = role > 0
