@@ -176,12 +176,10 @@ TF_API int tf_get_stats(tf_volume* v, tf_stats* out);
  * out of the other launches. */
 TF_API int tf_profile_enable(tf_volume* v, uint32_t kind_mask);
 TF_API int tf_profile_get(tf_volume* v, tf_profile* out, int reset);
-/* Tuning aid: per-phase shader cycles of the voxel-update kernel, summed over all waves, collected
- * only while the environment variable TF_KA_DBG has bit 11 (2048) set.  out[0..8] = phases (see
- * tf_kernels.hip, TF_STAMP), out[9] = chunks processed. */
-TF_API int tf_debug_phase_cycles(tf_volume* v, uint64_t out[16], int reset);
-/* Tuning aid: the raw per-wave table (16 words per wave; words 10..12 = {start, end, role+1} of the
- * last fused launch when TF_KA_DBG has bit 12 (4096) set). */
+/* Tuning aid: the raw per-wave timeline table (16 words per wave; words 10..13 = {start, end, role+1,
+ * XCC id}, 14..15 = K-A prologue end / first list record loaded, in 100 MHz ticks) of the last
+ * fused launch that ran all three roles; filled only while the environment variable TF_KA_DBG has
+ * bit 12 (4096) set. */
 TF_API int tf_debug_phase_raw(tf_volume* v, uint64_t* out, int64_t cap_words);
 
 /* ---- multi-GPU chunk-range partition --------------------------------

@@ -33,7 +33,7 @@ SYMBOLS = (
     "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
     "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
-    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_cycles", "tf_debug_phase_raw", "tf_set_partition", "tf_boundary_pack",
+    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_raw", "tf_set_partition", "tf_boundary_pack",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_release",
     "tf_atlas_patch_size", "tf_atlas_add_patch", "tf_atlas_loc_next", "tf_patches_update",
     "tf_atlas_download_rows",
@@ -106,7 +106,6 @@ def lib():
     L.tf_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.tf_profile_enable.argtypes = [vp, C.c_uint32]
     L.tf_profile_get.argtypes = [vp, C.POINTER(Profile), C.c_int]
-    L.tf_debug_phase_cycles.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int]
     L.tf_debug_phase_raw.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
     L.tf_set_partition.argtypes = [vp, C.c_int32, C.c_int32]
     L.tf_boundary_pack.argtypes = [vp, vp, C.c_int64, i64p]
@@ -303,11 +302,6 @@ class Volume:
         p = Profile()
         self._ck(self.L.tf_profile_get(self.h, C.byref(p), int(reset)))
         return {PROF_NAMES[i]: (p.ms[i], p.launches[i]) for i in range(len(PROF_NAMES))}
-
-    def debug_phase_cycles(self, reset=True):
-        out = (C.c_uint64 * 16)()
-        self._ck(self.L.tf_debug_phase_cycles(self.h, out, int(reset)))
-        return [int(x) for x in out]
 
     def debug_phase_raw(self):
         out = np.zeros((16384, 16), np.uint64)

@@ -295,7 +295,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     if ((rc = dev_alloc(v, &L.masks, (size_t)d.max_coarse))) return fail(rc);
     if ((rc = dev_alloc(v, &L.offsets, (size_t)d.max_coarse))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_id, (size_t)d.max_list))) return fail(rc);
-    if ((rc = dev_alloc(v, &L.list_pre, (size_t)d.max_list * 2))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.list_pre, (size_t)d.max_list * 4))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_slot, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_ent, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_new, (size_t)d.max_list))) return fail(rc);
@@ -762,18 +762,6 @@ int tf_debug_phase_raw(tf_volume* v, uint64_t* out, int64_t cap_words) {
   if ((size_t)cap_words < n) n = (size_t)cap_words;
   TF_HIP(hipMemcpyAsync(out, v->dev.phase_buf, n * 8, hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
-  return TF_OK;
-}
-
-int tf_debug_phase_cycles(tf_volume* v, uint64_t out[16], int reset) {
-  if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
-  std::vector<unsigned long long> h((size_t)kPhaseWaves * 16);
-  TF_HIP(hipMemcpyAsync(h.data(), v->dev.phase_buf, h.size() * 8, hipMemcpyDeviceToHost, v->stream));
-  TF_HIP(hipStreamSynchronize(v->stream));
-  for (int k = 0; k < 16; ++k) out[k] = 0;
-  for (size_t w = 0; w < (size_t)kPhaseWaves; ++w)
-    for (int k = 0; k < 16; ++k) out[k] += h[w * 16 + k];
-  if (reset) TF_HIP(hipMemsetAsync(v->dev.phase_buf, 0, h.size() * 8, v->stream));
   return TF_OK;
 }
 

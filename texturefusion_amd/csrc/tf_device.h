@@ -80,7 +80,7 @@ struct SelBuf {
   unsigned long long* masks;  // [max_coarse]
   uint32_t* offsets;          // [max_coarse]
   int4* list_id;              // [max_list]
-  float4* list_pre;           // [2*max_list] per-chunk scalars {o.x,o.y,o.z,trunc}, {wD,upper,-,-}
+  float4* list_pre;           // [4*max_list] 64-B records {o.x,o.y,o.z,trunc}, {wD,upper,-,-}, {id.x,id.y,id.z,-}, spare
   uint32_t* list_slot;        // [max_list]
   uint32_t* list_ent;         // [max_list] hash entry index of the chunk
   uint8_t* list_new;          // [max_list]
@@ -91,7 +91,7 @@ struct SelBuf {
   FrameCtl* ctl;
 };
 
-constexpr int kPhaseWaves = 16384;
+constexpr int kPhaseWaves = 16384;  // rows of the wave-timeline table (tuning aid)
 
 struct VolumeDev {
   // pool
@@ -107,7 +107,7 @@ struct VolumeDev {
   // Chisel.h:197-203 is expanded when the set is read (k_list_dirty), not on the per-frame path.
   uint32_t* mark_epoch;   // [max_chunks]
   uint32_t* erase_epoch;  // [max_chunks]
-  unsigned long long* phase_buf;  // [kPhaseWaves][16] tuning aid: per-wave phase cycles of K-A (TF_KA_DBG bit 11)
+  unsigned long long* phase_buf;  // [kPhaseWaves][16] tuning aid: per-wave {start, end, role, XCC} stamps (TF_KA_DBG bit 12)
   uint32_t max_list;
   uint32_t max_coarse;
   // partition (multi-GPU chunk-range ownership): lo <= id.x < hi

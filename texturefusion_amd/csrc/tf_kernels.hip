@@ -422,8 +422,9 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         v.sel.list_id[pos] = id;
         const ChunkPre cp = chunk_pre(id, sc.pose, ig, sc.res, sc.resDiag);
-        v.sel.list_pre[2 * pos] = cp.a;
-        v.sel.list_pre[2 * pos + 1] = cp.b;
+        v.sel.list_pre[4 * pos] = cp.a;
+        v.sel.list_pre[4 * pos + 1] = cp.b;
+        v.sel.list_pre[4 * pos + 2] = make_float4(__int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z), 0.0f);
       }
     }
   }
@@ -558,9 +559,11 @@ __global__ __launch_bounds__(256) void k_pre(VolumeDev v, Pose P, Integ ig, floa
   if (blockIdx.x == 0) centroid_table(P.p, res, L.cen);
   const uint32_t n = L.ctl->n_list < v.max_list ? L.ctl->n_list : v.max_list;
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-    const ChunkPre cp = chunk_pre(L.list_id[e], P.p, ig, res, resDiag);
-    L.list_pre[2 * e] = cp.a;
-    L.list_pre[2 * e + 1] = cp.b;
+    const int4 id = L.list_id[e];
+    const ChunkPre cp = chunk_pre(id, P.p, ig, res, resDiag);
+    L.list_pre[4 * e] = cp.a;
+    L.list_pre[4 * e + 1] = cp.b;
+    L.list_pre[4 * e + 2] = make_float4(__int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z), 0.0f);
   }
 }
 
@@ -676,35 +679,25 @@ __device__ __forceinline__ bool in_div_range(float x) {
   return e > 127u - 40u && e < 127u + 40u;
 }
 
-// K-A runs per chunk as:   list entry + hash entry (scalar loads)  ->  geometry of all 8 z-slices
-// -> 8 depth gathers in flight  ->  slot resolve  ->  RMW passes of GP slices (predicates -> voxel
-// rows + colour image pixels -> arithmetic -> stores).  A wave therefore pays one scalar, one
-// gather and 8/GP voxel round trips per chunk; everything else is hidden by the other waves of
-// the SIMD, so the register budget (<= 64 VGPRs: 8 waves per SIMD) matters more than ILP.
+// K-A runs per chunk as:   64-B list record + hash entry (scalar loads)  ->  geometry of all 8
+// z-slices  ->  8 depth gathers in flight  ->  slot resolve  ->  RMW passes of GP slices (predicates
+// -> voxel rows + colour pixels -> arithmetic -> stores).  A wave pays one scalar, one gather and
+// 8/GP voxel round trips per chunk; the kernel is bound by these dependent round trips and by the
+// launch/drain of a 30-us kernel, not by VALU (2x headroom), HBM (removing every voxel access saves
+// 10 %) or the vector-memory front end (staging the image footprint in LDS removes all TA FIFO
+// back-pressure and changes nothing) -- profiles/r1/README.md has the ablations.
 //
 // Predication is done the CDNA way: every per-lane predicate is folded into the byte offset of a
 // buffer load/store (out-of-range offset = no memory access, loads return 0), so there is no
 // exec-mask juggling and no lane mask has to live in SGPRs across phases.  Descriptors: the three
 // frame images (kernel arguments) and the chunk's two 4-KiB voxel planes (wave-uniform slot).
-//
-// Tuning aid (TIMING instantiation, TF_KA_DBG bit 11): per-phase shader-cycle stamps summed per
-// wave into VolumeDev::phase_buf.  Phase ids: 0 list entry, 1 geometry + gather issue, 2 slot
-// resolve, 3 predicates + voxel load issue (waits depth), 4 arithmetic (waits voxel rows),
-// 5 stores issue, 6 finalize, 9 chunks.
-#define TF_STAMP(ph)                                                             \
-  do {                                                                           \
-    if (TIMING) {                                                                \
-      const unsigned long long _t = __builtin_readcyclecounter();                \
-      acc[ph] += _t - tprev;                                                     \
-      tprev = _t;                                                                \
-    }                                                                            \
-  } while (0)
-
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) u32x4* const_u32x4_ptr;
+typedef const __attribute__((address_space(4))) u32x16* const_u32x16_ptr;
 
-template <bool COLOR, bool QUALITY, bool FUSED, bool FLAG, int GP, bool TIMING>
+template <bool COLOR, bool QUALITY, bool FUSED, bool FLAG, int GP>
 __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameImages& img, const Cam& cam,
                                                const IntegrateConsts& kc, const uint32_t epoch,
                                                const uint32_t bid, const uint32_t nb) {
@@ -715,7 +708,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6));
   const uint32_t nwaves = nb * 4;
   const uint32_t n = L.ctl->n_list < v.max_list ? L.ctl->n_list : v.max_list;
-  const int vx = lane & 7, vy = lane >> 3;
+  const int vy = lane >> 3;
   const int W = cam.W, H = cam.H;
   if (FUSED && bid == 0 && threadIdx.x == 0) {
     // re-arm the K-B reduction of this selection set for its next frame (k_scan does this in the
@@ -752,11 +745,15 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   };
   auto ballot = [](const bool b) -> unsigned long long { return __builtin_amdgcn_ballot_w64(b); };
 
-  unsigned long long acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long tprev = TIMING ? __builtin_readcyclecounter() : 0ull;
+  if ((kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves)  // timeline aid: prologue end
+    v.phase_buf[wave * 16 + 14] = __builtin_amdgcn_s_memrealtime();
 
   for (uint32_t e = wave; e < n; e += nwaves) {
-    const int4 id = L.list_id[e];
+    // The list entry (per-chunk scalars + id) was written by the previous launch, so it is read
+    // through the scalar cache: one 64-B record, one s_load, one wait, off the vector-memory queue
+    // of the CU (a vector load here would wait behind every gather of the other waves).
+    const u32x16 prw = *(const_u32x16_ptr)(unsigned long long)(&L.list_pre[4 * e]);
+    const int4 id = make_int4((int)prw[8], (int)prw[9], (int)prw[10], 0);
     const bool owned = (id.x >= v.part_lo) && (id.x < v.part_hi);
     if (!owned) {
       if (FUSED && lane == 0) {
@@ -777,15 +774,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     bool is_new = false;
     uint32_t ent = i0;
 
-    // per-chunk scalars (ProjectionIntegrator.cpp:74-101), precomputed per list entry; e is
-    // wave-uniform so these are scalar loads
-    const float4 pa = L.list_pre[2 * e];
-    const float4 pb = L.list_pre[2 * e + 1];
-    const float o0 = pa.x, o1 = pa.y, o2 = pa.z;
+    // per-chunk scalars (ProjectionIntegrator.cpp:74-101), precomputed per list entry
+    const float o0 = __uint_as_float(prw[0]), o1 = __uint_as_float(prw[1]), o2 = __uint_as_float(prw[2]);
+    const float pbx = __uint_as_float(prw[4]), pby = __uint_as_float(prw[5]);
     const f32x2 o01 = {o0, o1};
     const f32x2 fxy = {cam.fxi, cam.fyi}, cxy = {kc.cxs, kc.cys};
-    const float wD = FLAG ? pb.x : -pb.x;  // depth_weight *= -1 when de-integrating (:95-99)
-    const float upper = pb.y;
+    const float wD = FLAG ? pbx : -pbx;  // depth_weight *= -1 when de-integrating (:95-99)
+    const float upper = pby;
     // every voxel centre of the chunk is o + c with 0 < c < 16 * res * sqrt(3): if |o.z| clears that
     // band, p.z is far inside the normal exponent range; numerators o + c are exact zeros or at
     // least one ulp of c (> 2^-40), and |o| < 2^20 keeps quotients finite -> no scaling / fix-up
@@ -793,7 +788,10 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const float band = 32.0f * kc.res;
     const bool div_safe = (fabsf(o2) > band) && (fabsf(o2) < 1048576.0f) && (fabsf(o0) < 1048576.0f) &&
                           (fabsf(o1) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
-    TF_STAMP(0);
+    if ((kc.dbg & 8192u) && e == wave && lane == 0 && wave < (uint32_t)kPhaseWaves) {
+      asm volatile("" :: "s"(o0), "s"(o1), "s"(o2), "s"(id.x));
+      v.phase_buf[wave * 16 + 15] = __builtin_amdgcn_s_memrealtime();  // timeline aid: first entry loaded
+    }
 
     // ---- phase 1: geometry of the 8 z-slices.  Rows run in order until the first row with no
     // valid lane -- the reference's `continue` skips `pos++` (:176-178, :420), so that row and
@@ -853,16 +851,9 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 
     // ---- phase 2: depth gathers (masked lanes read 0, like the reference's masked gather)
     float dep[8];
-#ifdef TF_EXP_COALESCED   // experiment: same number of gathers, all lanes in two cache lines
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j] == kOOB ? kOOB : lane * 4 + j * 256, 0, 0));
-#else
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j], 0, 0));
-#endif
-    TF_STAMP(1);
 
     // ---- resolve the slot once.  Fast path: the home entry holds the key.  A parked chunk (alive
     // == 0: created by an earlier frame, never updated, garbage-collected) counts as new again; it is
@@ -875,7 +866,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         is_new = lazy_revive = (h0.w == 0u);
       } else {
         uint32_t s0 = kInvalidSlot, nw = 1, en = 0;
-        if (TIMING) acc[7] += 1;  // slow-path slot resolutions
         if (lane == 0) {
           bool bnew = true;
           s0 = chunk_acquire(v, id, &bnew, &en);
@@ -893,7 +883,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       }
       continue;
     }
-    TF_STAMP(2);
     const __amdgpu_buffer_rsrc_t rs_T =
         __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_C =
@@ -951,17 +940,11 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 #pragma unroll
           for (int j = 0; j < GP; ++j) {
             c[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_C, off_c[j], 0, 0);
-#ifdef TF_EXP_COALESCED
-            in[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[j] == kOOB ? kOOB : lane * 4 + j * 256, 0, 0);
-#else
             in[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[j], 0, 0);
-#endif
             if (QUALITY) qv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qual, off_i[j], 0, 0));
           }
         }
       }
-      TF_STAMP(3);
-      if (TIMING && rmw) acc[8] += 1;  // RMW passes executed
       // ---- phase 5a: arithmetic on the loaded rows
       if (rmw) {
 #pragma unroll
@@ -1001,7 +984,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           t[j].y = __float_as_uint(keep ? nwt : 0.0f);
         }
       }
-      TF_STAMP(4);
       // ---- phase 5b: write back the rewritten rows only (masked offsets drop the store)
       if (rmw) {
 #pragma unroll
@@ -1010,7 +992,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, off_t[j], 0, 0);
         }
       }
-      TF_STAMP(5);
       // ---- phase 6: observationQualitySum bookkeeping in row order (:212-238)
       if (COLOR && QUALITY) {
         const int rowshift = lane & 56;
@@ -1074,20 +1055,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       L.list_quality[e] = qsum;
       L.list_rows[e] = (uint16_t)(rows_t | (rows_c << 8));
     }
-    TF_STAMP(6);
-    if (TIMING) acc[9] += 1;
   }
-  if (TIMING && lane == 0 && wave < (uint32_t)kPhaseWaves) {
-#pragma unroll
-    for (int k = 0; k < 10; ++k) v.phase_buf[wave * 16 + k] += acc[k];
-  }
-  (void)vx;
 }
 
 template <bool COLOR, bool QUALITY, bool FLAG>
 __global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img, Cam cam, IntegrateConsts kc,
                                                    uint32_t epoch) {
-  integrate_body<COLOR, QUALITY, false, FLAG, TF_KA_GP, false>(v, img, cam, kc, epoch, blockIdx.x, gridDim.x);
+  integrate_body<COLOR, QUALITY, false, FLAG, TF_KA_GP>(v, img, cam, kc, epoch, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1108,6 +1082,7 @@ struct FrameLaunch {
   Integ ig;
   uint32_t epoch;
   uint32_t n_ka, n_sel, n_bbox;
+  uint32_t rot;          // dispatch-order rotation of the block ranges
   SelBuf sel1;           // set of frame f+1
   const float* depth1;
   SelectConsts sc1;
@@ -1116,17 +1091,19 @@ struct FrameLaunch {
   Pose P2;
 };
 
-template <bool COLOR, bool TIMING>
+template <bool COLOR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TF_KF_WAVES, TF_KF_WAVES))) void k_frame(FrameLaunch a) {
   // Block ranges: K-A [0, n_ka), K-C [n_ka, n_ka + n_sel), K-B behind them.
-  const uint32_t b = blockIdx.x;
+  // a.rot rotates the dispatch order: 0 = K-A blocks first, n_ka = K-C / K-B first
+  const uint32_t total = a.n_ka + a.n_sel + a.n_bbox;
+  const uint32_t b = blockIdx.x + a.rot < total ? blockIdx.x + a.rot : blockIdx.x + a.rot - total;
   // tuning aid (dbg bit 12): per-wave {start, end, role} stamps of the last launch -> phase_buf
   const bool timeline = (a.kc.dbg & 4096u) != 0 && a.n_sel > 0 && a.n_bbox > 0;  // steady launches only
   const unsigned long long t0 = timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz, chip-wide
   uint32_t role;
   if (b < a.n_ka) {
     role = 0;
-    integrate_body<COLOR, false, true, true, TF_KA_GP, TIMING>(a.v, a.img, a.cam, a.kc, a.epoch, b, a.n_ka);
+    integrate_body<COLOR, false, true, true, TF_KA_GP>(a.v, a.img, a.cam, a.kc, a.epoch, b, a.n_ka);
   } else if (b < a.n_ka + a.n_sel) {
     role = 1;
     if (!(a.kc.dbg & 512u)) {  // triage switch
@@ -1153,13 +1130,23 @@ static int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
+// K-A grid: exactly the resident capacity (TF_KF_WAVES waves per SIMD = that many 256-thread
+// workgroups per CU), so every K-A wave starts at once and walks the list with a fixed stride.
+static int ka_blocks_default() {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+  }
+  return cus * TF_KF_WAVES;
+}
 
 void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam, const Integ& ig,
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
                       uint32_t epoch, hipStream_t s) {
   IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
   hipLaunchKernelGGL(k_pre, dim3(256), dim3(256), 0, s, v, pose, ig, res, kc.resDiag);
-  static const int nblocks = env_int("TF_KA_BLOCKS", 2048);  // tuning knob
+  static const int nblocks = env_int("TF_KA_BLOCKS", ka_blocks_default());  // tuning knob
   const dim3 grid(nblocks > 0 ? nblocks : 2048), block(256);
 #define TF_LAUNCH_KA(C, Q)                                                                           \
   do {                                                                                               \
@@ -1177,7 +1164,7 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
 // *next (its set must hold finished K-B keys); next2 -> K-B of *next2.
 void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* next,
                   const FrameStage* next2, const Cam& cam, const Integ& ig, float res, hipStream_t s) {
-  static const int nblocks = env_int("TF_KA_BLOCKS", 2048);
+  static const int nblocks = env_int("TF_KA_BLOCKS", ka_blocks_default());
   FrameLaunch a;
   a.v = v;
   a.cam = cam;
@@ -1214,13 +1201,11 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   }
   const uint32_t total = a.n_ka + a.n_sel + a.n_bbox;
   if (!total) return;
-  const bool timing = (dbg & 2048) != 0;  // tuning aid: per-phase cycle stamps (tf_debug_phase_cycles)
-  if (color) {
-    if (timing) hipLaunchKernelGGL((k_frame<true, true>), dim3(total), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_frame<true, false>), dim3(total), dim3(256), 0, s, a);
-  } else {
-    hipLaunchKernelGGL((k_frame<false, false>), dim3(total), dim3(256), 0, s, a);
-  }
+  if ((a.kc.dbg & 4096u) && a.n_sel && a.n_bbox) a.kc.dbg |= 8192u;  // timeline stamps: steady launches only
+  static const int sel_first = env_int("TF_SEL_FIRST", 0);  // tuning knob: dispatch K-C / K-B ahead of K-A
+  a.rot = sel_first ? a.n_ka : 0u;
+  if (color) hipLaunchKernelGGL((k_frame<true>), dim3(total), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_frame<false>), dim3(total), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------

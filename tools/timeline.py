@@ -7,6 +7,9 @@ import torch
 from texturefusion_amd import capi, synth
 cam = synth.Camera(); res = np.float32(0.005); dev = torch.device("cuda", 0)
 frames = [synth.room_frame(k, cam, with_quality=False) for k in range(60)]
+frac = float(os.environ.get("FRAC", "1"))   # only the first frac*W image columns carry depth
+for f in frames:
+    f[0][:, int(frac * cam.width):] = 0.0
 dd = [torch.from_numpy(f[0]).to(dev) for f in frames]; dc = [torch.from_numpy(f[1]).to(dev) for f in frames]
 poses = np.stack([f[3].reshape(12) for f in frames]).astype(np.float32)
 v = capi.Volume(res, cam, max_chunks=1 << 19, max_list=1 << 18)
@@ -35,3 +38,8 @@ for r, name in ((1, "K-A"), (2, "K-C"), (3, "K-B")):
 for x in range(8):
     k = m & (xcd == x) & (role == 1)
     print("xcd %d K-A: first start %.2f last end %.2f" % (x, t0[k].min() / 100.0, t1[k].max() / 100.0))
+k = m & (role == 1)
+pro = (raw[:, 14].astype(np.int64) - b0 - t0)[k] / 100.0
+print("K-A prologue (wave start -> chunk loop): min/med/max %.2f %.2f %.2f us" % (pro.min(), np.median(pro), pro.max()))
+ent = (raw[:, 15].astype(np.int64) - raw[:, 14].astype(np.int64))[k & (raw[:, 15] > 0)] / 100.0
+print("K-A first list entry (loop start -> scalars loaded): min/med/max %.2f %.2f %.2f us" % (ent.min(), np.median(ent), ent.max()))
