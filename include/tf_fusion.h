@@ -225,6 +225,21 @@ TF_API int tf_patches_update(tf_volume* v, int64_t n_patches, const int32_t* ids
                              float* out_texcoord, float* out_texcolor, int32_t* out_bbox,
                              int32_t* out_flags, float* out_ratio, uint64_t* out_texloc,
                              uint64_t out_hot[2]);
+/* Chisel::CompensateColor  Structure/Chisel.cpp:198-286 (+ computeMeanAndCov, Structure/Patch.cpp:342-348)
+ *   over a batch of patches in the reference's iteration order.  Patches with has_adjusted != 0 are
+ *   skipped; the rest is clustered by frame id (cluster order = first appearance).  Per cluster: mean /
+ *   covariance of texcolor (what the keyframe shows) and of the mesh colours (what the volume holds)
+ *   over the patches without wrong_mapping, the 3x3 transfer T, then
+ *   labs[k] = T (texcolor[k] - mean_src) + mean_tar for the vertices of the correctly mapped patches
+ *   (Patch::labs; wrong-mapped patches end with labs cleared, their entries of out_labs are left as
+ *   passed in) and has_adjusted := 1.  A cluster without a correctly mapped vertex is left untouched.
+ *   texcolor / meshcolor / out_labs: f32[3 * vert_offsets[n_patches]].  Reductions and the per-vertex
+ *   transfer run on the device, the 3x3 eigen-decompositions on the host (f64 Jacobi; Eigen's own
+ *   iteration is not restated, the result agrees to float rounding). */
+TF_API int tf_color_compensate(tf_volume* v, int64_t n_patches, const int32_t* frame_ids,
+                               const uint8_t* wrong_mapping, uint8_t* has_adjusted,
+                               const int64_t* vert_offsets, const float* texcolor, const float* meshcolor,
+                               float* out_labs, int64_t* out_n_clusters);
 /* Atlas::texture_buffer rows [row0,row1) (MobileFusion.h:406-421 uploads the hot rows) */
 TF_API int tf_atlas_download_rows(tf_volume* v, int64_t row0, int64_t row1, uint8_t* dst);
 

@@ -126,6 +126,9 @@ def lib():
     L.tfo_patch_project.argtypes = [fp, fp, C.c_int64, fp, u8p, fp, C.POINTER(Camera), fp, fp,
                                     i32p, C.POINTER(C.c_int), i64p]
     L.tfo_atlas_blit.argtypes = [vp, C.c_uint64, u8p, C.c_int, C.c_int, i32p, fp]
+    L.tfo_color_transfer.argtypes = [fp, fp, fp]
+    L.tfo_color_compensate.argtypes = [C.c_int64, i32p, u8p, u8p, i64p, fp, fp, fp, fp, i32p]
+    L.tfo_color_compensate.restype = C.c_int64
     L.tfo_atlas_hot_range.argtypes = [vp, u64p, C.c_int64, u64p, u64p]
     _lib = L
     return L
@@ -396,3 +399,30 @@ def patch_project(verts, colors, T, rgb, depth, cam: Camera):
                                    C.byref(wm), C.byref(nc))
     return dict(flag=flag, texcoord=tc[:n], texcolor=tcol[:n], bbox=bb, wrong_mapping=bool(wm.value),
                 n_caution=int(nc.value))
+
+
+def color_transfer(cov_src, cov_tar):
+    """Transfer matrix of Chisel::CompensateColor (Chisel.cpp:247-266)."""
+    a = np.ascontiguousarray(cov_src, np.float32).reshape(9)
+    b = np.ascontiguousarray(cov_tar, np.float32).reshape(9)
+    T = np.zeros(9, np.float32)
+    lib().tfo_color_transfer(_p(a, C.c_float), _p(b, C.c_float), _p(T, C.c_float))
+    return T.reshape(3, 3)
+
+
+def color_compensate(frame_ids, wrong_mapping, has_adjusted, voff, texcolor, meshcolor):
+    """Chisel::CompensateColor over a batch of patches.  Returns (labs, has_adjusted, T per cluster, cluster per patch)."""
+    frame_ids = np.ascontiguousarray(frame_ids, np.int32)
+    n = len(frame_ids)
+    wrong = np.ascontiguousarray(wrong_mapping, np.uint8)
+    adj = np.ascontiguousarray(has_adjusted, np.uint8).copy()
+    voff = np.ascontiguousarray(voff, np.int64)
+    tc = np.ascontiguousarray(texcolor, np.float32).reshape(-1, 3)
+    mc = np.ascontiguousarray(meshcolor, np.float32).reshape(-1, 3)
+    labs = np.full_like(tc, np.nan)
+    T = np.zeros((max(n, 1), 9), np.float32)
+    cl = np.full(max(n, 1), -1, np.int32)
+    ncl = lib().tfo_color_compensate(n, _p(frame_ids, C.c_int32), _p(wrong, C.c_uint8), _p(adj, C.c_uint8),
+                                     _p(voff, C.c_int64), _p(tc, C.c_float), _p(mc, C.c_float), _p(labs, C.c_float),
+                                     _p(T, C.c_float), _p(cl, C.c_int32))
+    return labs, adj, T[:ncl].reshape(-1, 3, 3), cl[:n]

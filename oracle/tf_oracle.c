@@ -1071,3 +1071,139 @@ void tfo_atlas_hot_range(const tfo_atlas* a, const uint64_t* texlocs, int64_t n,
   *hot_start = (lo / (uint64_t)a->aw) * (uint64_t)a->aw;
   *hot_end = (hi / (uint64_t)a->aw + a->ph) * (uint64_t)a->aw;
 }
+
+/* ===================================================================================== */
+/* a15  Chisel::CompensateColor (Structure/Chisel.cpp:198-286)                            */
+/* ===================================================================================== */
+/* eigen-decomposition of a symmetric 3x3 (cyclic Jacobi, double): A = V diag(w) V^T */
+static void sym3_eig(const float A[9], double w[3], double V[9]) {
+  double a[9];
+  for (int i = 0; i < 9; i++) { a[i] = (double)A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 64; sweep++) {
+    double off = a[1] * a[1] + a[2] * a[2] + a[5] * a[5];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        double apq = a[3 * p + q];
+        if (apq == 0.0) continue;
+        double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
+        double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < 3; k++) { /* A <- A J */
+          double akp = a[3 * k + p], akq = a[3 * k + q];
+          a[3 * k + p] = cs * akp - sn * akq;
+          a[3 * k + q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < 3; k++) { /* A <- J^T A */
+          double apk = a[3 * p + k], aqk = a[3 * q + k];
+          a[3 * p + k] = cs * apk - sn * aqk;
+          a[3 * q + k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < 3; k++) {
+          double vkp = V[3 * k + p], vkq = V[3 * k + q];
+          V[3 * k + p] = cs * vkp - sn * vkq;
+          V[3 * k + q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < 3; i++) w[i] = a[4 * i];
+}
+static void mat3_mul(const double A[9], const double B[9], double C[9]) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+/* the transfer matrix of Chisel.cpp:247-268 from the two covariances */
+void tfo_color_transfer(const float cov_src[9], const float cov_tar[9], float T[9]) {
+  double ws[3], U[9], Ut[9], ct[9], D[9] = {0}, M1[9], M2[9], media[9];
+  sym3_eig(cov_src, ws, U);
+  for (int i = 0; i < 3; i++) {
+    D[4 * i] = (double)(float)sqrt(ws[i] > 0.0 ? ws[i] : 0.0); /* eigenvalues().cwiseSqrt() in f32 */
+    for (int j = 0; j < 3; j++) { Ut[3 * i + j] = U[3 * j + i]; ct[3 * i + j] = (double)cov_tar[3 * i + j]; }
+  }
+  /* media = diag_src * oth_src^T * cov_tar * oth_src * diag_src (:252-254) */
+  mat3_mul(D, Ut, M1); mat3_mul(M1, ct, M2); mat3_mul(M2, U, M1); mat3_mul(M1, D, media);
+  float mediaf[9];
+  for (int i = 0; i < 9; i++) mediaf[i] = (float)media[i];
+  for (int i = 0; i < 3; i++) /* symmetrise the rounding so that the solver sees a symmetric matrix */
+    for (int j = i + 1; j < 3; j++) mediaf[3 * j + i] = mediaf[3 * i + j];
+  double wm[3], Um[9], Umt[9], Dm[9] = {0}, Di[9] = {0};
+  sym3_eig(mediaf, wm, Um);
+  for (int i = 0; i < 3; i++) {
+    Dm[4 * i] = (double)(float)sqrt(wm[i] > 0.0 ? wm[i] : 0.0);
+    Di[4 * i] = (double)(float)(1.0 / ((double)(float)D[4 * i] + 1e-2)); /* 1 / (diag + 1e-2), double literal (:260-262) */
+    for (int j = 0; j < 3; j++) Umt[3 * i + j] = Um[3 * j + i];
+  }
+  /* T = oth_src * diag_src * oth_media * diag_media * oth_media^T * diag_src * oth_src^T (:264-266) */
+  double A1[9], A2[9];
+  mat3_mul(U, Di, A1); mat3_mul(A1, Um, A2); mat3_mul(A2, Dm, A1); mat3_mul(A1, Umt, A2);
+  mat3_mul(A2, Di, A1); mat3_mul(A1, Ut, A2);
+  for (int i = 0; i < 9; i++) T[i] = (float)A2[i];
+}
+
+int64_t tfo_color_compensate(int64_t n_patches, const int32_t* frame_ids, const uint8_t* wrong_mapping,
+                             uint8_t* has_adjusted, const int64_t* voff, const float* texcolor,
+                             const float* meshcolor, float* labs, float* out_T, int32_t* out_cluster) {
+  int32_t* cl = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_patches > 0 ? n_patches : 1));
+  int32_t* first = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_patches > 0 ? n_patches : 1));
+  int64_t ncl = 0;
+  for (int64_t p = 0; p < n_patches; p++) { /* :199-214 */
+    cl[p] = -1;
+    if (has_adjusted[p]) continue;
+    int64_t k;
+    for (k = 0; k < ncl; k++)
+      if (frame_ids[first[k]] == frame_ids[p]) break;
+    if (k == ncl) first[ncl++] = (int32_t)p;
+    cl[p] = (int32_t)k;
+  }
+  for (int64_t c = 0; c < ncl; c++) {
+    /* computeMeanAndCov (Patch.cpp:342-348): rowwise mean, centre, src * src^T / (N - 1); f32, in order */
+    float mean[2][3] = {{0, 0, 0}, {0, 0, 0}}, cov[2][9];
+    int64_t n = 0;
+    for (int64_t p = 0; p < n_patches; p++) {
+      if (cl[p] != c || wrong_mapping[p]) continue;
+      for (int64_t k = voff[p]; k < voff[p + 1]; k++) {
+        for (int a = 0; a < 3; a++) { mean[0][a] += texcolor[3 * k + a]; mean[1][a] += meshcolor[3 * k + a]; }
+        n++;
+      }
+    }
+    if (out_T) for (int i = 0; i < 9; i++) out_T[9 * c + i] = 0.0f;
+    if (n == 0) continue; /* :242: nothing to learn from; has_adjusted stays false */
+    for (int s = 0; s < 2; s++) {
+      for (int a = 0; a < 3; a++) mean[s][a] = mean[s][a] / (float)n;
+      for (int i = 0; i < 9; i++) cov[s][i] = 0.0f;
+    }
+    for (int64_t p = 0; p < n_patches; p++) {
+      if (cl[p] != c || wrong_mapping[p]) continue;
+      for (int64_t k = voff[p]; k < voff[p + 1]; k++)
+        for (int s = 0; s < 2; s++) {
+          const float* x = (s == 0 ? texcolor : meshcolor) + 3 * k;
+          float d[3] = {x[0] - mean[s][0], x[1] - mean[s][1], x[2] - mean[s][2]};
+          for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) cov[s][3 * i + j] += d[i] * d[j];
+        }
+    }
+    for (int s = 0; s < 2; s++)
+      for (int i = 0; i < 9; i++) cov[s][i] = cov[s][i] / (float)(n - 1);
+    float T[9];
+    tfo_color_transfer(cov[0], cov[1], T);
+    if (out_T) memcpy(out_T + 9 * c, T, sizeof(T));
+    for (int64_t p = 0; p < n_patches; p++) {
+      if (cl[p] != c) continue;
+      if (!wrong_mapping[p]) /* wrong-mapped patches end with labs cleared (:276-278) */
+        for (int64_t k = voff[p]; k < voff[p + 1]; k++) {
+          float d[3] = {texcolor[3 * k] - mean[0][0], texcolor[3 * k + 1] - mean[0][1], texcolor[3 * k + 2] - mean[0][2]};
+          for (int i = 0; i < 3; i++) {
+            float acc = T[3 * i] * d[0];
+            acc = acc + T[3 * i + 1] * d[1];
+            acc = acc + T[3 * i + 2] * d[2];
+            labs[3 * k + i] = acc + mean[1][i];
+          }
+        }
+      has_adjusted[p] = 1; /* :280 */
+    }
+  }
+  if (out_cluster) memcpy(out_cluster, cl, sizeof(int32_t) * (size_t)n_patches);
+  free(cl);
+  free(first);
+  return ncl;
+}

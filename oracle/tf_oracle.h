@@ -146,6 +146,22 @@ int tfo_patch_project(const float* verts, const float* colors, int64_t n_v, cons
 /* Atlas::UpdateBuffer (Atlas.cpp:71-91); ratio[2] in/out */
 int tfo_atlas_blit(tfo_atlas* a, uint64_t texloc, const uint8_t* rgb, int img_w, int img_h,
                    const int32_t bbox[4], float ratio[2]);
+/* Chisel::CompensateColor (Structure/Chisel.cpp:198-286) + computeMeanAndCov (Structure/Patch.cpp:342-348)
+ * over a batch of patches in the reference's iteration order.  Patches with has_adjusted != 0 are
+ * skipped; the others are clustered by frame id (cluster order = first appearance).  Per cluster:
+ * mean / covariance (N-1) of texcolor and of the mesh colours over the patches without
+ * wrong_mapping, the 3x3 transfer T, labs[k] = T (texcolor[k] - mean_src) + mean_tar for every
+ * vertex of the cluster's patches that map correctly, has_adjusted := 1.  A cluster whose patches
+ * are all wrong-mapped is left untouched (the reference `continue`s before the flag is set).
+ * Symmetric eigen-decompositions: cyclic Jacobi in double on the f32 matrices -- Eigen's own
+ * iteration is not restated ("parity unpinned", 1-ulp class); the transfer
+ * matrix does not depend on eigenvector signs or order.  out_T (optional): 9 floats per cluster,
+ * out_cluster (optional): cluster index per patch (-1 = skipped).  Returns the cluster count. */
+/* the 3x3 transfer matrix alone (Chisel.cpp:247-266) */
+void tfo_color_transfer(const float cov_src[9], const float cov_tar[9], float T[9]);
+int64_t tfo_color_compensate(int64_t n_patches, const int32_t* frame_ids, const uint8_t* wrong_mapping,
+                             uint8_t* has_adjusted, const int64_t* vert_offsets, const float* texcolor,
+                             const float* meshcolor, float* labs, float* out_T, int32_t* out_cluster);
 /* hot row range, Chisel.cpp:153-186 */
 void tfo_atlas_hot_range(const tfo_atlas* a, const uint64_t* texlocs, int64_t n,
                          uint64_t* hot_start, uint64_t* hot_end);

@@ -36,6 +36,7 @@ SYMBOLS = (
     "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_raw", "tf_set_partition", "tf_boundary_pack",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_release",
     "tf_atlas_patch_size", "tf_atlas_add_patch", "tf_atlas_loc_next", "tf_patches_update",
+    "tf_color_compensate",
     "tf_atlas_download_rows",
 )
 
@@ -118,6 +119,7 @@ def lib():
     L.tf_atlas_loc_next.argtypes = [vp, u64p]
     L.tf_patches_update.argtypes = [vp, C.c_int64, i32p, i32p, fp, i64p, fp, fp, fp, fp, i32p, i32p,
                                     fp, u64p, u64p]
+    L.tf_color_compensate.argtypes = [vp, C.c_int64, i32p, u8p, u8p, i64p, fp, fp, fp, i64p]
     L.tf_atlas_download_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p]
     _lib = L
     return L
@@ -371,6 +373,22 @@ class Volume:
         self._ck(rc)
         return dict(rc=rc, texcoord=tc[:nv], texcolor=tcol[:nv], bbox=bbox[:np_], flags=flags[:np_],
                     ratio=ratio[:np_], texloc=texloc[:np_], hot=(int(hot[0]), int(hot[1])))
+
+    def color_compensate(self, frame_ids, wrong_mapping, has_adjusted, voff, texcolor, meshcolor):
+        """Chisel::CompensateColor over a batch of patches -> (labs, has_adjusted, n_clusters)."""
+        frame_ids = np.ascontiguousarray(frame_ids, np.int32)
+        n = len(frame_ids)
+        wrong = np.ascontiguousarray(wrong_mapping, np.uint8)
+        adj = np.ascontiguousarray(has_adjusted, np.uint8).copy()
+        voff = np.ascontiguousarray(voff, np.int64)
+        tc = _f32(texcolor).reshape(-1, 3)
+        mc = _f32(meshcolor).reshape(-1, 3)
+        labs = np.full_like(tc, np.nan)
+        ncl = C.c_int64(0)
+        self._ck(self.L.tf_color_compensate(self.h, n, _p(frame_ids, C.c_int32), _p(wrong, C.c_uint8),
+                                            _p(adj, C.c_uint8), _p(voff, C.c_int64), _p(tc, C.c_float),
+                                            _p(mc, C.c_float), _p(labs, C.c_float), C.byref(ncl)))
+        return labs, adj, int(ncl.value)
 
     def atlas_rows(self, row0, row1, width):
         out = np.zeros((row1 - row0, width, 3), np.uint8)

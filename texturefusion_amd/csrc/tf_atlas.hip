@@ -9,6 +9,7 @@
 // same 11-bit fixed point (third-party arithmetic -- parity unpinned).
 #include <math.h>
 #include <string.h>
+#include <vector>
 
 #include "tf_volume.h"
 
@@ -300,6 +301,80 @@ int atlas_reset(tf_volume* v) {
   return TF_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Chisel::CompensateColor (Structure/Chisel.cpp:198-286).  The reductions over all vertices of a
+// cluster and the per-vertex transfer run here; the two 3x3 eigen-decompositions per cluster are
+// host work (a few hundred flops).  Reductions are fixed-shape trees (thread-strided partial sums
+// in patch order, then an LDS tree), so results do not depend on timing.
+// ---------------------------------------------------------------------------------------
+struct CcPatch {
+  int64_t v0, v1;
+  int32_t cluster;  // -1 = skipped (already adjusted)
+  int32_t wrong;
+};
+// pass 0: sums of texcolor / mesh colour -> out[c][0..5], count -> out[c][6];
+// pass 1: centred second moments (6 unique entries each) -> out[c][0..11] given mean[c][0..5]
+template <int PASS>
+__global__ __launch_bounds__(256) void k_cc_reduce(const CcPatch* __restrict__ pt, int64_t np,
+                                                   const float* __restrict__ src, const float* __restrict__ tar,
+                                                   const float* __restrict__ mean, float* __restrict__ out) {
+  constexpr int NV = PASS == 0 ? 7 : 12;
+  const int c = blockIdx.x;
+  float acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
+  float m[6] = {0, 0, 0, 0, 0, 0};
+  if (PASS == 1)
+    for (int i = 0; i < 6; ++i) m[i] = mean[c * 6 + i];
+  for (int64_t p = 0; p < np; ++p) {
+    if (pt[p].cluster != c || pt[p].wrong) continue;
+    for (int64_t k = pt[p].v0 + threadIdx.x; k < pt[p].v1; k += 256) {
+      const float s0 = src[3 * k], s1 = src[3 * k + 1], s2 = src[3 * k + 2];
+      const float t0 = tar[3 * k], t1 = tar[3 * k + 1], t2 = tar[3 * k + 2];
+      if (PASS == 0) {
+        acc[0] += s0; acc[1] += s1; acc[2] += s2;
+        acc[3] += t0; acc[4] += t1; acc[5] += t2;
+        acc[6] += 1.0f;
+      } else {
+        const float a = s0 - m[0], b = s1 - m[1], d = s2 - m[2];
+        const float e = t0 - m[3], f = t1 - m[4], g = t2 - m[5];
+        acc[0] += a * a; acc[1] += a * b; acc[2] += a * d; acc[3] += b * b; acc[4] += b * d; acc[5] += d * d;
+        acc[6] += e * e; acc[7] += e * f; acc[8] += e * g; acc[9] += f * f; acc[10] += f * g; acc[11] += g * g;
+      }
+    }
+  }
+  __shared__ float red[NV][256];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) red[i][threadIdx.x] = acc[i];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) red[i][threadIdx.x] += red[i][threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x < NV) out[c * 12 + threadIdx.x] = red[threadIdx.x][0];
+}
+// labs[k] = T (texcolor[k] - mean_src) + mean_tar (Chisel.cpp:274)
+__global__ __launch_bounds__(256) void k_cc_apply(const CcPatch* __restrict__ pt, const float* __restrict__ src,
+                                                  const float* __restrict__ xf /* per cluster: T[9], mean_src[3], mean_tar[3], ok */,
+                                                  float* __restrict__ labs) {
+  const CcPatch P = pt[blockIdx.x];
+  if (P.cluster < 0 || P.wrong) return;
+  const float* X = xf + (size_t)P.cluster * 16;
+  if (X[15] == 0.0f) return;  // nothing was learnt for this cluster
+  for (int64_t k = P.v0 + threadIdx.x; k < P.v1; k += 256) {
+    const float d0 = src[3 * k] - X[9], d1 = src[3 * k + 1] - X[10], d2 = src[3 * k + 2] - X[11];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float a = X[3 * i] * d0;
+      a = a + X[3 * i + 1] * d1;
+      a = a + X[3 * i + 2] * d2;
+      labs[3 * k + i] = a + X[12 + i];
+    }
+  }
+}
+
 static int atlas_stage(tf_volume* v, size_t bytes) {
   AtlasState& a = v->atlas;
   if (bytes > a.d_stage_bytes) {
@@ -497,6 +572,160 @@ int tf_patches_update(tf_volume* v, int64_t np, const int32_t* ids, const int32_
     out_hot[0] = (loc_start / (uint64_t)a.aw) * (uint64_t)a.aw;
     out_hot[1] = (loc_end / (uint64_t)a.aw + a.ph) * (uint64_t)a.aw;
   }
+  return TF_OK;
+}
+
+// symmetric 3x3 eigen-decomposition, cyclic Jacobi in double: A = V diag(w) V^T
+static void sym3_eig(const float A[9], double w[3], double V[9]) {
+  double a[9];
+  for (int i = 0; i < 9; i++) { a[i] = (double)A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+  for (int sweep = 0; sweep < 64; sweep++) {
+    if (a[1] * a[1] + a[2] * a[2] + a[5] * a[5] < 1e-300) break;
+    for (int p = 0; p < 2; p++)
+      for (int q = p + 1; q < 3; q++) {
+        const double apq = a[3 * p + q];
+        if (apq == 0.0) continue;
+        const double theta = (a[3 * q + q] - a[3 * p + p]) / (2.0 * apq);
+        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < 3; k++) {
+          const double akp = a[3 * k + p], akq = a[3 * k + q];
+          a[3 * k + p] = cs * akp - sn * akq;
+          a[3 * k + q] = sn * akp + cs * akq;
+        }
+        for (int k = 0; k < 3; k++) {
+          const double apk = a[3 * p + k], aqk = a[3 * q + k];
+          a[3 * p + k] = cs * apk - sn * aqk;
+          a[3 * q + k] = sn * apk + cs * aqk;
+        }
+        for (int k = 0; k < 3; k++) {
+          const double vkp = V[3 * k + p], vkq = V[3 * k + q];
+          V[3 * k + p] = cs * vkp - sn * vkq;
+          V[3 * k + q] = sn * vkp + cs * vkq;
+        }
+      }
+  }
+  for (int i = 0; i < 3; i++) w[i] = a[4 * i];
+}
+static void mat3_mul(const double A[9], const double B[9], double C[9]) {
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+}
+// Chisel.cpp:247-266: T = U Ds' Um Dm Um^T Ds' U^T with media = Ds U^T Ct U Ds
+static void color_transfer(const float cov_src[9], const float cov_tar[9], float T[9]) {
+  double ws[3], U[9], Ut[9], ct[9], D[9] = {0}, M1[9], M2[9], media[9];
+  sym3_eig(cov_src, ws, U);
+  for (int i = 0; i < 3; i++) {
+    D[4 * i] = (double)(float)sqrt(ws[i] > 0.0 ? ws[i] : 0.0);
+    for (int j = 0; j < 3; j++) { Ut[3 * i + j] = U[3 * j + i]; ct[3 * i + j] = (double)cov_tar[3 * i + j]; }
+  }
+  mat3_mul(D, Ut, M1); mat3_mul(M1, ct, M2); mat3_mul(M2, U, M1); mat3_mul(M1, D, media);
+  float mediaf[9];
+  for (int i = 0; i < 9; i++) mediaf[i] = (float)media[i];
+  for (int i = 0; i < 3; i++)
+    for (int j = i + 1; j < 3; j++) mediaf[3 * j + i] = mediaf[3 * i + j];
+  double wm[3], Um[9], Umt[9], Dm[9] = {0}, Di[9] = {0};
+  sym3_eig(mediaf, wm, Um);
+  for (int i = 0; i < 3; i++) {
+    Dm[4 * i] = (double)(float)sqrt(wm[i] > 0.0 ? wm[i] : 0.0);
+    Di[4 * i] = (double)(float)(1.0 / ((double)(float)D[4 * i] + 1e-2));  // 1 / (diag + 1e-2), double literal (:260-262)
+    for (int j = 0; j < 3; j++) Umt[3 * i + j] = Um[3 * j + i];
+  }
+  double A1[9], A2[9];
+  mat3_mul(U, Di, A1); mat3_mul(A1, Um, A2); mat3_mul(A2, Dm, A1); mat3_mul(A1, Umt, A2);
+  mat3_mul(A2, Di, A1); mat3_mul(A1, Ut, A2);
+  for (int i = 0; i < 9; i++) T[i] = (float)A2[i];
+}
+
+int tf_color_compensate(tf_volume* v, int64_t np, const int32_t* frame_ids, const uint8_t* wrong_mapping,
+                        uint8_t* has_adjusted, const int64_t* voff, const float* texcolor,
+                        const float* meshcolor, float* out_labs, int64_t* out_n_clusters) {
+  if (out_n_clusters) *out_n_clusters = 0;
+  if (!v || (np > 0 && (!frame_ids || !wrong_mapping || !has_adjusted || !voff || !texcolor || !meshcolor || !out_labs))) {
+    set_error("null argument");
+    return TF_ERR_INVALID;
+  }
+  if (np <= 0) return TF_OK;
+  // clusters by source frame in order of first appearance (Chisel.cpp:199-214)
+  std::vector<int32_t> cl((size_t)np, -1), first;
+  for (int64_t p = 0; p < np; ++p) {
+    if (has_adjusted[p]) continue;
+    size_t k = 0;
+    for (; k < first.size(); ++k)
+      if (frame_ids[first[k]] == frame_ids[p]) break;
+    if (k == first.size()) first.push_back((int32_t)p);
+    cl[(size_t)p] = (int32_t)k;
+  }
+  const size_t ncl = first.size();
+  if (out_n_clusters) *out_n_clusters = (int64_t)ncl;
+  if (!ncl) return TF_OK;
+  const int64_t nv = voff[np];
+  AtlasState& a = v->atlas;
+  const size_t o_pt = 0;
+  const size_t o_src = (o_pt + sizeof(CcPatch) * (size_t)np + 15) & ~(size_t)15;
+  const size_t o_tar = o_src + (size_t)nv * 12;
+  const size_t o_labs = o_tar + (size_t)nv * 12;
+  const size_t o_red = (o_labs + (size_t)nv * 12 + 15) & ~(size_t)15;  // [ncl][12] sums / moments
+  const size_t o_mean = o_red + ncl * 48;                                // [ncl][6]
+  const size_t o_xf = o_mean + ncl * 24;                                 // [ncl][16]
+  const size_t total = o_xf + ncl * 64;
+  int rc = atlas_stage(v, total);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  uint8_t* hs = reinterpret_cast<uint8_t*>(a.h_stage);
+  uint8_t* ds = reinterpret_cast<uint8_t*>(a.d_stage);
+  CcPatch* hp = reinterpret_cast<CcPatch*>(hs + o_pt);
+  for (int64_t p = 0; p < np; ++p) {
+    hp[p].v0 = voff[p]; hp[p].v1 = voff[p + 1];
+    hp[p].cluster = cl[(size_t)p]; hp[p].wrong = wrong_mapping[p] ? 1 : 0;
+  }
+  memcpy(hs + o_src, texcolor, (size_t)nv * 12);
+  memcpy(hs + o_tar, meshcolor, (size_t)nv * 12);
+  memcpy(hs + o_labs, out_labs, (size_t)nv * 12);  // entries of untouched patches keep the caller's values
+  TF_HIP(hipMemcpyAsync(ds, hs, o_red, hipMemcpyHostToDevice, v->stream));
+  const CcPatch* dp = reinterpret_cast<const CcPatch*>(ds + o_pt);
+  const float* dsrc = reinterpret_cast<const float*>(ds + o_src);
+  const float* dtar = reinterpret_cast<const float*>(ds + o_tar);
+  float* dred = reinterpret_cast<float*>(ds + o_red);
+  float* hred = reinterpret_cast<float*>(hs + o_red);
+  float* hmean = reinterpret_cast<float*>(hs + o_mean);
+  float* hxf = reinterpret_cast<float*>(hs + o_xf);
+  // computeMeanAndCov (Patch.cpp:342-348): mean, then centred second moments / (N - 1)
+  hipLaunchKernelGGL(k_cc_reduce<0>, dim3((unsigned)ncl), dim3(256), 0, v->stream, dp, np, dsrc, dtar,
+                     (const float*)nullptr, dred);
+  TF_HIP(hipMemcpyAsync(hred, dred, ncl * 48, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  std::vector<float> cnt(ncl);
+  for (size_t c = 0; c < ncl; ++c) {
+    cnt[c] = hred[c * 12 + 6];
+    for (int i = 0; i < 6; ++i) hmean[c * 6 + i] = cnt[c] > 0.0f ? hred[c * 12 + i] / cnt[c] : 0.0f;
+  }
+  TF_HIP(hipMemcpyAsync(ds + o_mean, hmean, ncl * 24, hipMemcpyHostToDevice, v->stream));
+  hipLaunchKernelGGL(k_cc_reduce<1>, dim3((unsigned)ncl), dim3(256), 0, v->stream, dp, np, dsrc, dtar,
+                     reinterpret_cast<const float*>(ds + o_mean), dred);
+  TF_HIP(hipMemcpyAsync(hred, dred, ncl * 48, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  for (size_t c = 0; c < ncl; ++c) {
+    float* X = hxf + c * 16;
+    for (int i = 0; i < 16; ++i) X[i] = 0.0f;
+    if (cnt[c] <= 0.0f) continue;  // Chisel.cpp:242: empty cluster, has_adjusted stays false
+    const float nm1 = cnt[c] - 1.0f;
+    float cs[9], ct[9];
+    const int idx[9] = {0, 1, 2, 1, 3, 4, 2, 4, 5};
+    for (int i = 0; i < 9; ++i) { cs[i] = hred[c * 12 + idx[i]] / nm1; ct[i] = hred[c * 12 + 6 + idx[i]] / nm1; }
+    color_transfer(cs, ct, X);
+    for (int i = 0; i < 3; ++i) { X[9 + i] = hmean[c * 6 + i]; X[12 + i] = hmean[c * 6 + 3 + i]; }
+    X[15] = 1.0f;
+  }
+  TF_HIP(hipMemcpyAsync(ds + o_xf, hxf, ncl * 64, hipMemcpyHostToDevice, v->stream));
+  hipLaunchKernelGGL(k_cc_apply, dim3((unsigned)np), dim3(256), 0, v->stream, dp, dsrc,
+                     reinterpret_cast<const float*>(ds + o_xf), reinterpret_cast<float*>(ds + o_labs));
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(hs + o_labs, ds + o_labs, (size_t)nv * 12, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  memcpy(out_labs, hs + o_labs, (size_t)nv * 12);
+  for (int64_t p = 0; p < np; ++p)
+    if (cl[(size_t)p] >= 0 && cnt[(size_t)cl[(size_t)p]] > 0.0f) has_adjusted[p] = 1;  // :280
   return TF_OK;
 }
 

@@ -240,6 +240,9 @@ struct PatchResult {
   int flag = 0;  // CalculateTexCoords' return value (0 / -1)
   float ratio[2] = {1, 1};
   std::vector<float> texcoord, texcolor;
+  int frameid = -1;           // Patch::frameid: source keyframe (the label)
+  bool has_adjusted = false;  // Patch::has_adjusted
+  std::vector<float> labs;    // Patch::labs: compensated colours (empty when wrong_mapping)
 };
 
 // ---- Chisel (Structure/Chisel.h:46-493) ----------------------------------------------------
@@ -415,11 +418,42 @@ class Chisel {
       r.ratio[1] = ratio[2 * p + 1];
       r.texcoord.assign(tc.begin() + 2 * voff[p], tc.begin() + 2 * voff[p + 1]);
       r.texcolor.assign(tcol.begin() + 3 * voff[p], tcol.begin() + 3 * voff[p + 1]);
+      r.frameid = labels[p];
     }
     atlas.hot_start = hot[0];
     atlas.hot_end = hot[1];
     atlas.Refresh();
     return 0;
+  }
+
+  // Chisel::CompensateColor (Chisel.cpp:198-286) over the patches GeneratePatches produced, in the
+  // caller's (mesh map) order: clusters the not yet adjusted patches by source frame, learns one
+  // colour transfer per cluster from the correctly mapped patches and fills PatchResult::labs.
+  void CompensateColor(const std::vector<PatchMesh>& meshes, std::vector<PatchResult>& patches) {
+    const size_t np = patches.size();
+    if (!np) return;
+    std::vector<int32_t> fid(np);
+    std::vector<uint8_t> wrong(np), adj(np);
+    std::vector<int64_t> voff(np + 1, 0);
+    std::vector<float> tex, mesh;
+    for (size_t p = 0; p < np; ++p) {
+      fid[p] = patches[p].frameid;
+      wrong[p] = patches[p].wrong_mapping ? 1 : 0;
+      adj[p] = patches[p].has_adjusted ? 1 : 0;
+      tex.insert(tex.end(), patches[p].texcolor.begin(), patches[p].texcolor.end());
+      mesh.insert(mesh.end(), meshes[p].colors.begin(), meshes[p].colors.end());
+      voff[p + 1] = (int64_t)tex.size() / 3;
+    }
+    std::vector<float> labs(tex.size() + 3, 0.0f);
+    int64_t ncl = 0;
+    tf_check(tf_color_compensate(vol, (int64_t)np, fid.data(), wrong.data(), adj.data(), voff.data(), tex.data(),
+                                 mesh.data(), labs.data(), &ncl), "CompensateColor");
+    for (size_t p = 0; p < np; ++p) {
+      if (patches[p].has_adjusted || !adj[p]) continue;  // skipped, or its cluster had nothing to learn from
+      patches[p].has_adjusted = true;
+      if (patches[p].wrong_mapping) patches[p].labs.clear();  // :276-278
+      else patches[p].labs.assign(labs.begin() + 3 * voff[p], labs.begin() + 3 * voff[p + 1]);
+    }
   }
 
   ChunkID maxChunkID, minChunkID;
