@@ -1286,13 +1286,32 @@ void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s
   hipLaunchKernelGGL(k_rowstats, dim3(64), dim3(256), 0, s, v, out3);
 }
 
+// Append with ONE atomic per wave: the lanes that emit are counted with a ballot and ranked by
+// their position in it (same-address device atomics retire at ~20 ns each, so a per-lane atomic
+// costs milliseconds on a 10^5-entry list).  Must be reached by every lane of the wave.
+__device__ __forceinline__ void wave_append(uint32_t* counter, const bool emit, int4* out, const uint32_t cap,
+                                            const int4 value) {
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(emit);
+  if (!m) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+  if (emit) {
+    const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    if (p < cap) out[p] = value;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_list_chunks(VolumeDev v, int4* out, uint32_t cap) {
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i <= v.hmask; i += gridDim.x * 256) {
-    const HEntry h = v.hent[i];
-    if (h.key != kEmptyKey && h.alive && h.slot != kInvalidSlot) {
-      const uint32_t p = atomicAdd(&v.vctl->n_tmp, 1u);
-      if (p < cap) out[p] = unpack_id(h.key);
-    }
+  const uint32_t n = v.hmask + 1u;
+  for (uint32_t i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+    const uint32_t i = i0 + threadIdx.x;
+    HEntry h;
+    h.key = kEmptyKey; h.slot = kInvalidSlot; h.alive = 0;
+    if (i < n) h = v.hent[i];
+    const bool emit = h.key != kEmptyKey && h.alive && h.slot != kInvalidSlot;
+    wave_append(&v.vctl->n_tmp, emit, out, cap, emit ? unpack_id(h.key) : make_int4(0, 0, 0, 0));
   }
 }
 void launch_list_chunks(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t s) {
@@ -1313,37 +1332,40 @@ __device__ __forceinline__ int4 nbr7(const int4 c, int k) {
 }
 __global__ __launch_bounds__(256) void k_list_dirty(VolumeDev v, int4* out, uint32_t cap, uint32_t floor_) {
   const uint32_t total = (v.hmask + 1u) * 8u;  // 8 threads per hash entry: candidate k = 0..6
-  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+  for (uint32_t t0 = blockIdx.x * 256; t0 < total; t0 += gridDim.x * 256) {
+    const uint32_t t = t0 + threadIdx.x;
     const uint32_t i = t >> 3, k = t & 7u;
-    if (k == 7u) continue;
-    const HEntry h = v.hent[i];
-    if (h.key == kEmptyKey || h.slot == kInvalidSlot) continue;
-    if (v.mark_epoch[h.slot] <= floor_) continue;
-    const int4 n = unpack_id(h.key);
-    const int4 id = nbr7(n, (int)k);
-    uint32_t M = 0, erase = 0;
-    int first = -1;
-    for (int j = 0; j < 7; ++j) {
-      const int4 q = nbr7(id, j);
-      const uint32_t e = hash_find(v, pack_id(q.x, q.y, q.z));
-      if (e == kInvalidSlot) continue;
-      const uint32_t s = v.hent[e].slot;
-      if (s == kInvalidSlot) continue;
-      const uint32_t m = v.mark_epoch[s];
-      if (j == 0) erase = v.erase_epoch[s];
-      if (m > floor_) {
-        if (first < 0) first = j;
-        M = m > M ? m : M;
+    bool emit = false;
+    int4 id = make_int4(0, 0, 0, 0);
+    if (k != 7u && t < total) {
+      const HEntry h = v.hent[i];
+      if (h.key != kEmptyKey && h.slot != kInvalidSlot && v.mark_epoch[h.slot] > floor_) {
+        const int4 n = unpack_id(h.key);
+        id = nbr7(n, (int)k);
+        uint32_t M = 0, erase = 0;
+        int first = -1;
+        for (int j = 0; j < 7; ++j) {
+          const int4 q = nbr7(id, j);
+          const uint32_t e = hash_find(v, pack_id(q.x, q.y, q.z));
+          if (e == kInvalidSlot) continue;
+          const uint32_t s = v.hent[e].slot;
+          if (s == kInvalidSlot) continue;
+          const uint32_t m = v.mark_epoch[s];
+          if (j == 0) erase = v.erase_epoch[s];
+          if (m > floor_) {
+            if (first < 0) first = j;
+            M = m > M ? m : M;
+          }
+        }
+        if (first >= 0) {
+          const int4 f = nbr7(id, first);
+          const bool mine = f.x == n.x && f.y == n.y && f.z == n.z;  // else another marked neighbour emits id
+          const uint32_t lim = erase > floor_ ? erase : floor_;
+          emit = mine && M > lim;
+        }
       }
     }
-    if (first < 0) continue;
-    const int4 f = nbr7(id, first);
-    if (f.x != n.x || f.y != n.y || f.z != n.z) continue;  // another marked neighbour emits id
-    const uint32_t lim = erase > floor_ ? erase : floor_;
-    if (M > lim) {
-      const uint32_t p = atomicAdd(&v.vctl->n_tmp, 1u);
-      if (p < cap) out[p] = id;
-    }
+    wave_append(&v.vctl->n_tmp, emit, out, cap, id);
   }
 }
 void launch_list_dirty(const VolumeDev& v, int4* out, uint32_t cap, uint32_t clear_floor, hipStream_t s) {
