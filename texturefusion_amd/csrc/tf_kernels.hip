@@ -351,7 +351,23 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
   // One wave per coarse block: the 8 corner probes run on lanes 0..7 (replicated 8x), the 64
   // per-chunk tests of a hit block on the 64 lanes (lane = (i-x)*16 + (j-y)*4 + (k-z), i.e. the
   // reference's i,j,k push_back order).  Every block is an independent short dependency chain.
-  for (uint32_t cb = wave; cb < n_coarse; cb += nwaves) {
+  // Multi-GPU, fused flow: the list only has to hold this rank's slab, so the coarse blocks are
+  // enumerated over the x-range that intersects [part_lo, part_hi) (bx is the slowest index) and
+  // chunks outside the slab are dropped from hit blocks.  The call-by-call flow keeps the full,
+  // reference-ordered list (every rank returns the same list; K-A skips what it does not own).
+  uint32_t cb_lo = 0, cb_hi = n_coarse;
+  if (EMIT && n_coarse) {
+    const long long base = (long long)minI[0] - 1;
+    long long lo = ((long long)v.part_lo - base) / step;          // first block that can hold part_lo
+    if ((long long)v.part_lo - base < 0) lo = 0;
+    long long hi = ((long long)v.part_hi - base + step - 1) / step;  // one past the last block below part_hi
+    if ((long long)v.part_hi - base < 0) hi = 0;
+    if (lo > dims[0]) lo = dims[0];
+    if (hi > dims[0]) hi = dims[0];
+    cb_lo = (uint32_t)lo * nzny;
+    cb_hi = hi > lo ? (uint32_t)hi * nzny : cb_lo;
+  }
+  for (uint32_t cb = cb_lo + wave; cb < cb_hi; cb += nwaves) {
     const uint32_t bx = cb / nzny;
     const uint32_t brem = cb - bx * nzny;
     const uint32_t by = brem / (uint32_t)dims[2];
@@ -402,6 +418,7 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
           anyhit |= fr.hit;
         }
         flag = anyhit && dv;
+        if (EMIT) flag = flag && (x0 + di >= v.part_lo) && (x0 + di < v.part_hi);
       }
       m = __ballot(flag);
     }
@@ -1315,7 +1332,8 @@ __global__ __launch_bounds__(256) void k_list_chunks(VolumeDev v, int4* out, uin
   }
 }
 void launch_list_chunks(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t s) {
-  hipLaunchKernelGGL(k_list_chunks, dim3(512), dim3(256), 0, s, v, out, cap);
+  const uint32_t blocks = (v.hmask + 256u) / 256u;  // one entry per thread: a pure streaming read
+  hipLaunchKernelGGL(k_list_chunks, dim3(blocks < 65535u * 16u ? blocks : 65535u * 16u), dim3(256), 0, s, v, out, cap);
 }
 
 // meshesToUpdate on demand.  For every chunk n whose mark is newer than the last clear, its seven
@@ -1369,7 +1387,8 @@ __global__ __launch_bounds__(256) void k_list_dirty(VolumeDev v, int4* out, uint
   }
 }
 void launch_list_dirty(const VolumeDev& v, int4* out, uint32_t cap, uint32_t clear_floor, hipStream_t s) {
-  hipLaunchKernelGGL(k_list_dirty, dim3(2048), dim3(256), 0, s, v, out, cap, clear_floor);
+  const uint32_t blocks = (v.hmask + 1u) / 32u + 1u;  // 8 threads per entry, one pass
+  hipLaunchKernelGGL(k_list_dirty, dim3(blocks < 1048576u ? blocks : 1048576u), dim3(256), 0, s, v, out, cap, clear_floor);
 }
 
 // De-interleave chunks into the reference's host layouts (sdf[512], weight[512], color[2048]).
