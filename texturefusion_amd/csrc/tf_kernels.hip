@@ -1303,37 +1303,57 @@ void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s
   hipLaunchKernelGGL(k_rowstats, dim3(64), dim3(256), 0, s, v, out3);
 }
 
-// Append with ONE atomic per wave: the lanes that emit are counted with a ballot and ranked by
-// their position in it (same-address device atomics retire at ~20 ns each, so a per-lane atomic
-// costs milliseconds on a 10^5-entry list).  Must be reached by every lane of the wave.
-__device__ __forceinline__ void wave_append(uint32_t* counter, const bool emit, int4* out, const uint32_t cap,
-                                            const int4 value) {
-  const unsigned long long m = __builtin_amdgcn_ballot_w64(emit);
-  if (!m) return;
-  const int lane = threadIdx.x & 63;
-  uint32_t base = 0;
-  if (lane == (int)__builtin_ctzll(m)) base = atomicAdd(counter, (uint32_t)__popcll(m));
-  base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
-  if (emit) {
-    const uint32_t p = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    if (p < cap) out[p] = value;
+// Compacting appends with ONE global atomic per workgroup: a thread keeps the outcome of its (up
+// to 32) candidates as a bit mask, the workgroup scans the counts, reserves its output range once
+// and writes.  Same-address device atomics retire at ~10 ns per wave instruction, so an atomic per
+// wave costs 160 us on a 2^20-entry table and an atomic per workgroup of 8 passes 5 us.
+__device__ __forceinline__ uint32_t block_reserve(uint32_t* counter, const uint32_t mine) {
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t gbase;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t inc = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = __shfl_up(inc, o);
+    if (lane >= o) inc += t;
   }
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (k < w) before += wsum[k];
+    total += wsum[k];
+  }
+  if (threadIdx.x == 0) gbase = total ? atomicAdd(counter, total) : 0u;
+  __syncthreads();
+  return gbase + before + inc - mine;  // first output position of this thread
 }
+
+constexpr int kListPasses = 8;  // candidates per thread (<= 32)
 
 __global__ __launch_bounds__(256) void k_list_chunks(VolumeDev v, int4* out, uint32_t cap) {
   const uint32_t n = v.hmask + 1u;
-  for (uint32_t i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
-    const uint32_t i = i0 + threadIdx.x;
-    HEntry h;
-    h.key = kEmptyKey; h.slot = kInvalidSlot; h.alive = 0;
-    if (i < n) h = v.hent[i];
-    const bool emit = h.key != kEmptyKey && h.alive && h.slot != kInvalidSlot;
-    wave_append(&v.vctl->n_tmp, emit, out, cap, emit ? unpack_id(h.key) : make_int4(0, 0, 0, 0));
+  const uint32_t first = blockIdx.x * (256u * kListPasses) + threadIdx.x;
+  uint32_t bits = 0;
+#pragma unroll
+  for (int k = 0; k < kListPasses; ++k) {
+    const uint32_t i = first + (uint32_t)k * 256u;
+    if (i < n) {
+      const HEntry h = v.hent[i];
+      if (h.key != kEmptyKey && h.alive && h.slot != kInvalidSlot) bits |= 1u << k;
+    }
+  }
+  uint32_t p = block_reserve(&v.vctl->n_tmp, (uint32_t)__popc(bits));
+  while (bits) {
+    const int k = __builtin_ctz(bits);
+    bits &= bits - 1;
+    if (p < cap) out[p] = unpack_id(v.hent[first + (uint32_t)k * 256u].key);
+    ++p;
   }
 }
 void launch_list_chunks(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t s) {
-  const uint32_t blocks = (v.hmask + 256u) / 256u;  // one entry per thread: a pure streaming read
-  hipLaunchKernelGGL(k_list_chunks, dim3(blocks < 65535u * 16u ? blocks : 65535u * 16u), dim3(256), 0, s, v, out, cap);
+  const uint32_t per = 256u * kListPasses;
+  hipLaunchKernelGGL(k_list_chunks, dim3((v.hmask + per) / per), dim3(256), 0, s, v, out, cap);
 }
 
 // meshesToUpdate on demand.  For every chunk n whose mark is newer than the last clear, its seven
@@ -1348,47 +1368,57 @@ __device__ __forceinline__ int4 nbr7(const int4 c, int k) {
   else if (k == 5) r.z -= 1; else if (k == 6) r.z += 1;
   return r;
 }
+__device__ __forceinline__ bool dirty_candidate(const VolumeDev& v, const uint32_t t, const uint32_t total,
+                                                const uint32_t floor_, int4* id_out) {
+  const uint32_t i = t >> 3, k = t & 7u;
+  if (k == 7u || t >= total) return false;
+  const HEntry h = v.hent[i];
+  if (h.key == kEmptyKey || h.slot == kInvalidSlot || v.mark_epoch[h.slot] <= floor_) return false;
+  const int4 n = unpack_id(h.key);
+  const int4 id = nbr7(n, (int)k);
+  *id_out = id;
+  uint32_t M = 0, erase = 0;
+  int first = -1;
+  for (int j = 0; j < 7; ++j) {
+    const int4 q = nbr7(id, j);
+    const uint32_t e = hash_find(v, pack_id(q.x, q.y, q.z));
+    if (e == kInvalidSlot) continue;
+    const uint32_t s = v.hent[e].slot;
+    if (s == kInvalidSlot) continue;
+    const uint32_t m = v.mark_epoch[s];
+    if (j == 0) erase = v.erase_epoch[s];
+    if (m > floor_) {
+      if (first < 0) first = j;
+      M = m > M ? m : M;
+    }
+  }
+  if (first < 0) return false;
+  const int4 f = nbr7(id, first);
+  if (f.x != n.x || f.y != n.y || f.z != n.z) return false;  // another marked neighbour emits id
+  const uint32_t lim = erase > floor_ ? erase : floor_;
+  return M > lim;
+}
 __global__ __launch_bounds__(256) void k_list_dirty(VolumeDev v, int4* out, uint32_t cap, uint32_t floor_) {
   const uint32_t total = (v.hmask + 1u) * 8u;  // 8 threads per hash entry: candidate k = 0..6
-  for (uint32_t t0 = blockIdx.x * 256; t0 < total; t0 += gridDim.x * 256) {
-    const uint32_t t = t0 + threadIdx.x;
-    const uint32_t i = t >> 3, k = t & 7u;
-    bool emit = false;
-    int4 id = make_int4(0, 0, 0, 0);
-    if (k != 7u && t < total) {
-      const HEntry h = v.hent[i];
-      if (h.key != kEmptyKey && h.slot != kInvalidSlot && v.mark_epoch[h.slot] > floor_) {
-        const int4 n = unpack_id(h.key);
-        id = nbr7(n, (int)k);
-        uint32_t M = 0, erase = 0;
-        int first = -1;
-        for (int j = 0; j < 7; ++j) {
-          const int4 q = nbr7(id, j);
-          const uint32_t e = hash_find(v, pack_id(q.x, q.y, q.z));
-          if (e == kInvalidSlot) continue;
-          const uint32_t s = v.hent[e].slot;
-          if (s == kInvalidSlot) continue;
-          const uint32_t m = v.mark_epoch[s];
-          if (j == 0) erase = v.erase_epoch[s];
-          if (m > floor_) {
-            if (first < 0) first = j;
-            M = m > M ? m : M;
-          }
-        }
-        if (first >= 0) {
-          const int4 f = nbr7(id, first);
-          const bool mine = f.x == n.x && f.y == n.y && f.z == n.z;  // else another marked neighbour emits id
-          const uint32_t lim = erase > floor_ ? erase : floor_;
-          emit = mine && M > lim;
-        }
-      }
-    }
-    wave_append(&v.vctl->n_tmp, emit, out, cap, id);
+  const uint32_t first = blockIdx.x * (256u * kListPasses) + threadIdx.x;
+  uint32_t bits = 0;
+  int4 id;
+#pragma unroll
+  for (int k = 0; k < kListPasses; ++k)
+    if (dirty_candidate(v, first + (uint32_t)k * 256u, total, floor_, &id)) bits |= 1u << k;
+  uint32_t p = block_reserve(&v.vctl->n_tmp, (uint32_t)__popc(bits));
+  while (bits) {
+    const int k = __builtin_ctz(bits);
+    bits &= bits - 1;
+    const uint32_t t = first + (uint32_t)k * 256u;
+    if (p < cap) out[p] = nbr7(unpack_id(v.hent[t >> 3].key), (int)(t & 7u));
+    ++p;
   }
 }
 void launch_list_dirty(const VolumeDev& v, int4* out, uint32_t cap, uint32_t clear_floor, hipStream_t s) {
-  const uint32_t blocks = (v.hmask + 1u) / 32u + 1u;  // 8 threads per entry, one pass
-  hipLaunchKernelGGL(k_list_dirty, dim3(blocks < 1048576u ? blocks : 1048576u), dim3(256), 0, s, v, out, cap, clear_floor);
+  const uint32_t per = 256u * kListPasses;
+  const unsigned long long total = ((unsigned long long)v.hmask + 1ull) * 8ull;
+  hipLaunchKernelGGL(k_list_dirty, dim3((unsigned)((total + per - 1) / per)), dim3(256), 0, s, v, out, cap, clear_floor);
 }
 
 // De-interleave chunks into the reference's host layouts (sdf[512], weight[512], color[2048]).
