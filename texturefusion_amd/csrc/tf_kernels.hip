@@ -762,6 +762,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   };
   auto ballot = [](const bool b) -> unsigned long long { return __builtin_amdgcn_ballot_w64(b); };
 
+  // Per-pass constants live in VGPRs on purpose: as SGPRs they lose the register allocation against
+  // descriptors and lane masks and get re-read from the kernel-argument segment at the top of every
+  // pass (an s_load + s_waitcnt on the critical path of each of the 2.6 passes of a chunk, and on
+  // the scalar cache shared between CUs).
+  float c_near = cam.nearP, c_far = cam.farP, c_thr = kc.thrCol, c_lower = kc.lower, c_sigma = kc.sigma;
+  asm volatile("" : "+v"(c_near), "+v"(c_far), "+v"(c_thr), "+v"(c_lower), "+v"(c_sigma));
+
   if ((kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves)  // timeline aid: prologue end
     v.phase_buf[wave * 16 + 14] = __builtin_amdgcn_s_memrealtime();
 
@@ -924,7 +931,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         const float s = d - (o2 + cenT[2][gj * 64 + lane]);  // p.z again: an LDS read is cheaper than 8 live VGPRs
         sd[j] = s;
         if (COLOR) {
-          const bool upd = (off_d[gj] != kOOB) && (fabsf(s) < kc.thrCol);  // -thr < sd < thr (:202-208)
+          const bool upd = (off_d[gj] != kOOB) && (fabsf(s) < c_thr);  // -thr < sd < thr (:202-208)
           off_i[j] = upd ? off_d[gj] : kOOB;
           const bool ru_l = row_any(ballot(upd));
           const unsigned long long ru = ballot(ru_l);
@@ -933,8 +940,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           any |= ru;
         }
         const bool act = (uint32_t)(gj * 8 + vy) < R;
-        const bool dv = (d > cam.nearP) && (cam.farP > d);     // (:310-312)
-        const bool inside = (s > kc.lower) && (upper > s);     // (:313-316)
+        const bool dv = (d > c_near) && (c_far > d);           // (:310-312)
+        const bool inside = (s > c_lower) && (upper > s);      // (:313-316)
         const bool F = act && dv && inside;
         nwv[j] = F ? wD : 0.0f;
         const bool rf_l = row_any(ballot(F));
@@ -993,7 +1000,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);  // (:319-341)
           const float nw = nwv[j];
           const float num = ts * tw + sd[j] * nw;
-          const float den = (tw + nw) + kc.sigma;
+          const float den = (tw + nw) + c_sigma;
           const float ns = num / den;
           const float nwt = tw + nw;
           const bool keep = nwt > 0.5f;
