@@ -11,8 +11,8 @@ Structure/Chisel.h:453-468) at 5 mm voxels, frames already resident in HBM.
 
 Rank 0 prints ONE JSON line (metric/value/... + "roofline" + "cpu_baseline").
 N > 1: one process per GPU, static chunk-range (ChunkID.x slab) partition of ONE stream -- every
-rank runs selection in full, integrates only the chunks it owns ("strong" scaling), and the ranks
-all-gather their updated boundary chunks over RCCL every --exchange-every frames.
+rank sees every frame, selects and integrates only the chunks of its slab ("strong" scaling), and
+the ranks all-gather their updated boundary chunks over RCCL every --exchange-every frames.
 """
 from __future__ import annotations
 

@@ -240,6 +240,22 @@ TF_API int tf_color_compensate(tf_volume* v, int64_t n_patches, const int32_t* f
                                const uint8_t* wrong_mapping, uint8_t* has_adjusted,
                                const int64_t* vert_offsets, const float* texcolor, const float* meshcolor,
                                float* out_labs, int64_t* out_n_clusters);
+/* Chisel::DrawMeshes  Structure/Chisel.cpp:288-355 (the step after the atlas
+ *   update): the interleaved vertex stream the renderer / exporter consumes, 12 f32 per vertex
+ *     [x, y, z, 50, (float)(R<<16|G<<8|B), adj, u/atlas_w, v/atlas_h, nx, ny, nz, wrong_mapping]
+ *   with (u,v) = texcoord * (ratio < 1 ? ratio : 1) + slot origin (Atlas::GetTexLoc) and
+ *   adj = labs_valid ? (float)(3 x 9 bit of int((labs - texcolor) * 255) + 255) : 0, plus the index
+ *   stream rebased by the running vertex count, for the patches with complete[p] != 0
+ *   (Patch::complete), in patch order.  labs_valid[p] = Patch::has_adjusted && !labs.empty().
+ *   Per-patch arrays: texloc u64[np], ratio f32[2 np]; per-vertex arrays use vert_offsets, indices
+ *   use index_offsets.  out_vertices f32[12 * vert_offsets[np]], out_indices u32[index_offsets[np]]. */
+TF_API int tf_pack_vertices(tf_volume* v, int64_t n_patches, const uint8_t* complete,
+                            const uint8_t* wrong_mapping, const uint8_t* labs_valid, const uint64_t* texloc,
+                            const float* ratio, const int64_t* vert_offsets, const float* verts,
+                            const float* colors, const float* normals, const float* texcoord,
+                            const float* texcolor, const float* labs, const int64_t* index_offsets,
+                            const uint32_t* indices, float* out_vertices, uint32_t* out_indices,
+                            int64_t* out_n_vertices, int64_t* out_n_indices);
 /* Atlas::texture_buffer rows [row0,row1) (MobileFusion.h:406-421 uploads the hot rows) */
 TF_API int tf_atlas_download_rows(tf_volume* v, int64_t row0, int64_t row1, uint8_t* dst);
 

@@ -126,6 +126,9 @@ def lib():
     L.tfo_patch_project.argtypes = [fp, fp, C.c_int64, fp, u8p, fp, C.POINTER(Camera), fp, fp,
                                     i32p, C.POINTER(C.c_int), i64p]
     L.tfo_atlas_blit.argtypes = [vp, C.c_uint64, u8p, C.c_int, C.c_int, i32p, fp]
+    L.tfo_pack_vertices.argtypes = [C.c_int64, u8p, u8p, u8p, C.POINTER(C.c_uint64), fp, C.c_int, C.c_int, i64p, fp, fp,
+                                    fp, fp, fp, fp, i64p, C.POINTER(C.c_uint32), fp, C.POINTER(C.c_uint32), i64p]
+    L.tfo_pack_vertices.restype = C.c_int64
     L.tfo_color_transfer.argtypes = [fp, fp, fp]
     L.tfo_color_compensate.argtypes = [C.c_int64, i32p, u8p, u8p, i64p, fp, fp, fp, fp, i32p]
     L.tfo_color_compensate.restype = C.c_int64
@@ -426,3 +429,25 @@ def color_compensate(frame_ids, wrong_mapping, has_adjusted, voff, texcolor, mes
                                      _p(voff, C.c_int64), _p(tc, C.c_float), _p(mc, C.c_float), _p(labs, C.c_float),
                                      _p(T, C.c_float), _p(cl, C.c_int32))
     return labs, adj, T[:ncl].reshape(-1, 3, 3), cl[:n]
+
+
+def pack_vertices(complete, wrong_mapping, labs_valid, texloc, ratio, atlas_w, atlas_h, voff, verts, colors, normals,
+                  texcoord, texcolor, labs, ioff, indices):
+    """Chisel::DrawMeshes (Chisel.cpp:288-355) -> (vertices f32[n,12], indices u32[m])."""
+    a8 = lambda x: np.ascontiguousarray(x, np.uint8)
+    f = lambda x: np.ascontiguousarray(x, np.float32)
+    complete, wrong_mapping, labs_valid = a8(complete), a8(wrong_mapping), a8(labs_valid)
+    texloc = np.ascontiguousarray(texloc, np.uint64)
+    voff = np.ascontiguousarray(voff, np.int64); ioff = np.ascontiguousarray(ioff, np.int64)
+    indices = np.ascontiguousarray(indices, np.uint32)
+    ratio, verts, colors, normals, texcoord, texcolor, labs = map(f, (ratio, verts, colors, normals, texcoord, texcolor, labs))
+    out_v = np.zeros((max(int(voff[-1]), 1), 12), np.float32)
+    out_i = np.zeros(max(int(ioff[-1]), 1), np.uint32)
+    ni = C.c_int64(0)
+    nv = lib().tfo_pack_vertices(len(complete), _p(complete, C.c_uint8), _p(wrong_mapping, C.c_uint8),
+                                 _p(labs_valid, C.c_uint8), _p(texloc, C.c_uint64), _p(ratio, C.c_float),
+                                 int(atlas_w), int(atlas_h), _p(voff, C.c_int64), _p(verts, C.c_float),
+                                 _p(colors, C.c_float), _p(normals, C.c_float), _p(texcoord, C.c_float),
+                                 _p(texcolor, C.c_float), _p(labs, C.c_float), _p(ioff, C.c_int64),
+                                 _p(indices, C.c_uint32), _p(out_v, C.c_float), _p(out_i, C.c_uint32), C.byref(ni))
+    return out_v[:nv], out_i[:ni.value]

@@ -1207,3 +1207,51 @@ int64_t tfo_color_compensate(int64_t n_patches, const int32_t* frame_ids, const 
   free(first);
   return ncl;
 }
+
+/* ===================================================================================== */
+/* f-2  Chisel::DrawMeshes (Structure/Chisel.cpp:288-355)                                 */
+/* ===================================================================================== */
+int64_t tfo_pack_vertices(int64_t n_patches, const uint8_t* complete, const uint8_t* wrong_mapping,
+                          const uint8_t* labs_valid, const uint64_t* texloc, const float* ratio,
+                          int atlas_w, int atlas_h, const int64_t* voff, const float* verts,
+                          const float* colors, const float* normals, const float* texcoord,
+                          const float* texcolor, const float* labs, const int64_t* ioff,
+                          const uint32_t* indices, float* out_v, uint32_t* out_i, int64_t* n_indices) {
+  int64_t vert_num = 0, index_num = 0;
+  for (int64_t p = 0; p < n_patches; p++) {
+    if (!complete[p]) continue; /* :298 */
+    for (int64_t j = ioff[p]; j < ioff[p + 1]; j++) out_i[index_num++] = indices[j] + (uint32_t)vert_num; /* :300-305 */
+    const float ox = (float)(texloc[p] % (uint64_t)atlas_w), oy = (float)(texloc[p] / (uint64_t)atlas_w); /* Atlas.cpp:66-69 */
+    for (int64_t k = voff[p]; k < voff[p + 1]; k++) {
+      float* o = out_v + 12 * vert_num;
+      float tx = texcoord[2 * k], ty = texcoord[2 * k + 1];
+      if (ratio[2 * p] < 1) tx = tx * ratio[2 * p];         /* :316-317 */
+      if (ratio[2 * p + 1] < 1) ty = ty * ratio[2 * p + 1];
+      tx = tx + ox;
+      ty = ty + oy;
+      o[0] = verts[3 * k]; o[1] = verts[3 * k + 1]; o[2] = verts[3 * k + 2];
+      o[3] = 50.0f;
+      int rgb = (int)(colors[3 * k] * 255.0f);               /* :325-328 */
+      rgb = (rgb << 8) + (int)(colors[3 * k + 1] * 255.0f);
+      rgb = (rgb << 8) + (int)(colors[3 * k + 2] * 255.0f);
+      o[4] = (float)rgb;
+      if (labs_valid[p]) {                                   /* :330-337 */
+        const float a0 = labs[3 * k] - texcolor[3 * k], a1 = labs[3 * k + 1] - texcolor[3 * k + 1],
+                    a2 = labs[3 * k + 2] - texcolor[3 * k + 2];
+        int ad = (int)(a0 * 255.0f) + 255;
+        ad = (ad << 9) + (int)(a1 * 255.0f) + 255;
+        ad = (ad << 9) + (int)(a2 * 255.0f) + 255;
+        o[5] = (float)ad;
+      } else {
+        o[5] = 0.0f;
+      }
+      o[6] = tx / (float)atlas_w;                            /* :340-341 */
+      o[7] = ty / (float)atlas_h;
+      o[8] = normals[3 * k]; o[9] = normals[3 * k + 1]; o[10] = normals[3 * k + 2];
+      o[11] = wrong_mapping[p] ? 1.0f : 0.0f;
+      vert_num++;
+    }
+  }
+  if (n_indices) *n_indices = index_num;
+  return vert_num;
+}

@@ -162,6 +162,20 @@ void tfo_color_transfer(const float cov_src[9], const float cov_tar[9], float T[
 int64_t tfo_color_compensate(int64_t n_patches, const int32_t* frame_ids, const uint8_t* wrong_mapping,
                              uint8_t* has_adjusted, const int64_t* vert_offsets, const float* texcolor,
                              const float* meshcolor, float* labs, float* out_T, int32_t* out_cluster);
+/* Chisel::DrawMeshes (Structure/Chisel.cpp:288-355): the interleaved
+ * vertex stream the renderer / exporter consumes -- 12 f32 per vertex
+ *   [x, y, z, 50, (float)(R<<16|G<<8|B), adj, u/atlas_w, v/atlas_h, nx, ny, nz, wrong_mapping]
+ * with (u,v) = texcoord * (ratio < 1 ? ratio : 1) + slot origin (Atlas::GetTexLoc, Atlas.cpp:66-69),
+ * adj = labs valid ? (float)(3 x 9 bit of int((labs - texcolor) * 255) + 255) : 0 -- and the index
+ * stream rebased by the running vertex count, for the patches that are complete() (Patch.cpp:191-196),
+ * in patch order.  Returns the vertex count; *n_indices = index count. */
+int64_t tfo_pack_vertices(int64_t n_patches, const uint8_t* complete, const uint8_t* wrong_mapping,
+                          const uint8_t* labs_valid, const uint64_t* texloc, const float* ratio,
+                          int atlas_w, int atlas_h, const int64_t* vert_offsets, const float* verts,
+                          const float* colors, const float* normals, const float* texcoord,
+                          const float* texcolor, const float* labs, const int64_t* index_offsets,
+                          const uint32_t* indices, float* out_vertices, uint32_t* out_indices,
+                          int64_t* n_indices);
 /* hot row range, Chisel.cpp:153-186 */
 void tfo_atlas_hot_range(const tfo_atlas* a, const uint64_t* texlocs, int64_t n,
                          uint64_t* hot_start, uint64_t* hot_end);

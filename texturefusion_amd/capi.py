@@ -36,7 +36,7 @@ SYMBOLS = (
     "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_raw", "tf_set_partition", "tf_boundary_pack",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_release",
     "tf_atlas_patch_size", "tf_atlas_add_patch", "tf_atlas_loc_next", "tf_patches_update",
-    "tf_color_compensate",
+    "tf_color_compensate", "tf_pack_vertices",
     "tf_atlas_download_rows",
 )
 
@@ -120,6 +120,8 @@ def lib():
     L.tf_patches_update.argtypes = [vp, C.c_int64, i32p, i32p, fp, i64p, fp, fp, fp, fp, i32p, i32p,
                                     fp, u64p, u64p]
     L.tf_color_compensate.argtypes = [vp, C.c_int64, i32p, u8p, u8p, i64p, fp, fp, fp, i64p]
+    L.tf_pack_vertices.argtypes = [vp, C.c_int64, u8p, u8p, u8p, u64p, fp, i64p, fp, fp, fp, fp, fp, fp, i64p,
+                                   C.POINTER(C.c_uint32), fp, C.POINTER(C.c_uint32), i64p, i64p]
     L.tf_atlas_download_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p]
     _lib = L
     return L
@@ -389,6 +391,28 @@ class Volume:
                                             _p(adj, C.c_uint8), _p(voff, C.c_int64), _p(tc, C.c_float),
                                             _p(mc, C.c_float), _p(labs, C.c_float), C.byref(ncl)))
         return labs, adj, int(ncl.value)
+
+    def pack_vertices(self, complete, wrong_mapping, labs_valid, texloc, ratio, voff, verts, colors, normals,
+                      texcoord, texcolor, labs, ioff, indices):
+        """Chisel::DrawMeshes -> (vertices f32[n,12], indices u32[m])."""
+        a8 = lambda x: np.ascontiguousarray(x, np.uint8)
+        complete, wrong_mapping, labs_valid = a8(complete), a8(wrong_mapping), a8(labs_valid)
+        texloc = np.ascontiguousarray(texloc, np.uint64)
+        voff = np.ascontiguousarray(voff, np.int64)
+        ioff = np.ascontiguousarray(ioff, np.int64)
+        indices = np.ascontiguousarray(indices, np.uint32)
+        ratio, verts, colors, normals, texcoord, texcolor, labs = map(_f32, (ratio, verts, colors, normals, texcoord,
+                                                                               texcolor, labs))
+        out_v = np.zeros((max(int(voff[-1]), 1), 12), np.float32)
+        out_i = np.zeros(max(int(ioff[-1]), 1), np.uint32)
+        nv, ni = C.c_int64(0), C.c_int64(0)
+        self._ck(self.L.tf_pack_vertices(self.h, len(complete), _p(complete, C.c_uint8), _p(wrong_mapping, C.c_uint8),
+                                         _p(labs_valid, C.c_uint8), _p(texloc, C.c_uint64), _p(ratio, C.c_float),
+                                         _p(voff, C.c_int64), _p(verts, C.c_float), _p(colors, C.c_float),
+                                         _p(normals, C.c_float), _p(texcoord, C.c_float), _p(texcolor, C.c_float),
+                                         _p(labs, C.c_float), _p(ioff, C.c_int64), _p(indices, C.c_uint32),
+                                         _p(out_v, C.c_float), _p(out_i, C.c_uint32), C.byref(nv), C.byref(ni)))
+        return out_v[:nv.value], out_i[:ni.value]
 
     def atlas_rows(self, row0, row1, width):
         out = np.zeros((row1 - row0, width, 3), np.uint8)

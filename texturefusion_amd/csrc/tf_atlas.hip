@@ -375,6 +375,55 @@ __global__ __launch_bounds__(256) void k_cc_apply(const CcPatch* __restrict__ pt
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Chisel::DrawMeshes (Structure/Chisel.cpp:288-355): interleaved vertex stream + rebased indices.
+// One workgroup per complete() patch; every output element is written once, 48 B per vertex.
+// ---------------------------------------------------------------------------------------
+struct PvPatch {
+  int64_t v0, v1, i0, i1;  // input vertex / index ranges
+  int64_t vout, iout;      // output positions (running counts over the complete patches before this one)
+  float ox, oy;            // slot origin (Atlas::GetTexLoc)
+  float rx, ry;            // Patch::ratio
+  int32_t flags;           // bit0 complete, bit1 wrong_mapping, bit2 labs valid
+  int32_t pad;
+};
+__global__ __launch_bounds__(256) void k_pack_vertices(const PvPatch* __restrict__ pt, const float* __restrict__ verts,
+                                                       const float* __restrict__ colors, const float* __restrict__ normals,
+                                                       const float* __restrict__ texcoord, const float* __restrict__ texcolor,
+                                                       const float* __restrict__ labs, const uint32_t* __restrict__ indices,
+                                                       float inv_unused, float aw, float ah, float* __restrict__ out_v,
+                                                       uint32_t* __restrict__ out_i) {
+  const PvPatch P = pt[blockIdx.x];
+  if (!(P.flags & 1)) return;
+  for (int64_t j = P.i0 + threadIdx.x; j < P.i1; j += 256) out_i[P.iout + (j - P.i0)] = indices[j] + (uint32_t)P.vout;
+  for (int64_t k = P.v0 + threadIdx.x; k < P.v1; k += 256) {
+    float* o = out_v + 12 * (P.vout + (k - P.v0));
+    float tx = texcoord[2 * k], ty = texcoord[2 * k + 1];
+    if (P.rx < 1.0f) tx = tx * P.rx;
+    if (P.ry < 1.0f) ty = ty * P.ry;
+    tx = tx + P.ox;
+    ty = ty + P.oy;
+    int rgb = (int)(colors[3 * k] * 255.0f);
+    rgb = (rgb << 8) + (int)(colors[3 * k + 1] * 255.0f);
+    rgb = (rgb << 8) + (int)(colors[3 * k + 2] * 255.0f);
+    float adj = 0.0f;
+    if (P.flags & 4) {
+      const float a0 = labs[3 * k] - texcolor[3 * k], a1 = labs[3 * k + 1] - texcolor[3 * k + 1],
+                  a2 = labs[3 * k + 2] - texcolor[3 * k + 2];
+      int ad = (int)(a0 * 255.0f) + 255;
+      ad = (ad << 9) + (int)(a1 * 255.0f) + 255;
+      ad = (ad << 9) + (int)(a2 * 255.0f) + 255;
+      adj = (float)ad;
+    }
+    const float4 q0 = make_float4(verts[3 * k], verts[3 * k + 1], verts[3 * k + 2], 50.0f);
+    const float4 q1 = make_float4((float)rgb, adj, tx / aw, ty / ah);
+    const float4 q2 = make_float4(normals[3 * k], normals[3 * k + 1], normals[3 * k + 2], (P.flags & 2) ? 1.0f : 0.0f);
+    reinterpret_cast<float4*>(o)[0] = q0;
+    reinterpret_cast<float4*>(o)[1] = q1;
+    reinterpret_cast<float4*>(o)[2] = q2;
+  }
+}
+
 static int atlas_stage(tf_volume* v, size_t bytes) {
   AtlasState& a = v->atlas;
   if (bytes > a.d_stage_bytes) {
@@ -726,6 +775,75 @@ int tf_color_compensate(tf_volume* v, int64_t np, const int32_t* frame_ids, cons
   memcpy(out_labs, hs + o_labs, (size_t)nv * 12);
   for (int64_t p = 0; p < np; ++p)
     if (cl[(size_t)p] >= 0 && cnt[(size_t)cl[(size_t)p]] > 0.0f) has_adjusted[p] = 1;  // :280
+  return TF_OK;
+}
+
+int tf_pack_vertices(tf_volume* v, int64_t np, const uint8_t* complete, const uint8_t* wrong_mapping,
+                     const uint8_t* labs_valid, const uint64_t* texloc, const float* ratio,
+                     const int64_t* voff, const float* verts, const float* colors, const float* normals,
+                     const float* texcoord, const float* texcolor, const float* labs, const int64_t* ioff,
+                     const uint32_t* indices, float* out_vertices, uint32_t* out_indices,
+                     int64_t* out_n_vertices, int64_t* out_n_indices) {
+  if (out_n_vertices) *out_n_vertices = 0;
+  if (out_n_indices) *out_n_indices = 0;
+  if (!v || (np > 0 && (!complete || !wrong_mapping || !labs_valid || !texloc || !ratio || !voff || !verts ||
+                        !colors || !normals || !texcoord || !texcolor || !labs || !ioff || !out_vertices))) {
+    set_error("null argument");
+    return TF_ERR_INVALID;
+  }
+  if (np <= 0) return TF_OK;
+  AtlasState& a = v->atlas;
+  const int64_t nv = voff[np], ni = ioff[np];
+  if (ni > 0 && (!indices || !out_indices)) { set_error("null index argument"); return TF_ERR_INVALID; }
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+  const size_t o_pt = take(sizeof(PvPatch) * (size_t)np);
+  const size_t o_verts = take((size_t)nv * 12), o_cols = take((size_t)nv * 12), o_nrm = take((size_t)nv * 12);
+  const size_t o_tc = take((size_t)nv * 8), o_tcol = take((size_t)nv * 12), o_labs = take((size_t)nv * 12);
+  const size_t o_idx = take((size_t)ni * 4);
+  const size_t o_in_end = o;
+  const size_t o_outv = take((size_t)nv * 48), o_outi = take((size_t)ni * 4);
+  const size_t total = o;
+  int rc = atlas_stage(v, total);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  uint8_t* hs = reinterpret_cast<uint8_t*>(a.h_stage);
+  uint8_t* ds = reinterpret_cast<uint8_t*>(a.d_stage);
+  PvPatch* hp = reinterpret_cast<PvPatch*>(hs + o_pt);
+  int64_t vout = 0, iout = 0;
+  for (int64_t p = 0; p < np; ++p) {
+    PvPatch& P = hp[p];
+    P.v0 = voff[p]; P.v1 = voff[p + 1]; P.i0 = ioff[p]; P.i1 = ioff[p + 1];
+    P.vout = vout; P.iout = iout;
+    P.ox = (float)(texloc[p] % (uint64_t)a.aw);  // Atlas::GetTexLoc (Atlas.cpp:66-69)
+    P.oy = (float)(texloc[p] / (uint64_t)a.aw);
+    P.rx = ratio[2 * p]; P.ry = ratio[2 * p + 1];
+    P.flags = (complete[p] ? 1 : 0) | (wrong_mapping[p] ? 2 : 0) | (labs_valid[p] ? 4 : 0);
+    P.pad = 0;
+    if (complete[p]) { vout += P.v1 - P.v0; iout += P.i1 - P.i0; }
+  }
+  memcpy(hs + o_verts, verts, (size_t)nv * 12);
+  memcpy(hs + o_cols, colors, (size_t)nv * 12);
+  memcpy(hs + o_nrm, normals, (size_t)nv * 12);
+  memcpy(hs + o_tc, texcoord, (size_t)nv * 8);
+  memcpy(hs + o_tcol, texcolor, (size_t)nv * 12);
+  memcpy(hs + o_labs, labs, (size_t)nv * 12);
+  if (ni) memcpy(hs + o_idx, indices, (size_t)ni * 4);
+  TF_HIP(hipMemcpyAsync(ds, hs, o_in_end, hipMemcpyHostToDevice, v->stream));
+  hipLaunchKernelGGL(k_pack_vertices, dim3((unsigned)np), dim3(256), 0, v->stream,
+                     reinterpret_cast<const PvPatch*>(ds + o_pt), reinterpret_cast<const float*>(ds + o_verts),
+                     reinterpret_cast<const float*>(ds + o_cols), reinterpret_cast<const float*>(ds + o_nrm),
+                     reinterpret_cast<const float*>(ds + o_tc), reinterpret_cast<const float*>(ds + o_tcol),
+                     reinterpret_cast<const float*>(ds + o_labs), reinterpret_cast<const uint32_t*>(ds + o_idx),
+                     0.0f, (float)a.aw, (float)a.ah, reinterpret_cast<float*>(ds + o_outv),
+                     reinterpret_cast<uint32_t*>(ds + o_outi));
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(hs + o_outv, ds + o_outv, total - o_outv, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  memcpy(out_vertices, hs + o_outv, (size_t)vout * 48);
+  if (iout) memcpy(out_indices, hs + o_outi, (size_t)iout * 4);
+  if (out_n_vertices) *out_n_vertices = vout;
+  if (out_n_indices) *out_n_indices = iout;
   return TF_OK;
 }
 

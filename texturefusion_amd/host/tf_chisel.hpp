@@ -231,6 +231,8 @@ struct PatchMesh {
   ChunkID chunkID;
   std::vector<float> vertices;  // xyz per vertex
   std::vector<float> colors;    // rgb in [0,1] per vertex
+  std::vector<float> normals;   // xyz per vertex (DrawMeshes only)
+  std::vector<unsigned int> indices;  // (DrawMeshes only)
 };
 // Patch results (Structure/Patch.h:51-94 members the callers read).
 struct PatchResult {
@@ -454,6 +456,51 @@ class Chisel {
       if (patches[p].wrong_mapping) patches[p].labs.clear();  // :276-278
       else patches[p].labs.assign(labs.begin() + 3 * voff[p], labs.begin() + 3 * voff[p + 1]);
     }
+  }
+
+  // Chisel::DrawMeshes (Chisel.cpp:288-355): 12 floats per vertex + rebased indices for the meshes
+  // whose patch is complete() (here: a patch result exists, has texcoords and a source frame).
+  void DrawMeshes(const std::vector<PatchMesh>& meshes, const std::vector<PatchResult>& patches, float* vertices,
+                  unsigned int* indices, unsigned int& tsdf_indice_num, unsigned int& tsdf_vertice_num) {
+    const size_t np = patches.size();
+    tsdf_indice_num = tsdf_vertice_num = 0;
+    if (!np) return;
+    std::vector<uint8_t> complete(np), wrong(np), lv(np);
+    std::vector<uint64_t> texloc(np);
+    std::vector<float> ratio(2 * np), verts, cols, nrm, tc, tcol, labs;
+    std::vector<int64_t> voff(np + 1, 0), ioff(np + 1, 0);
+    std::vector<uint32_t> idx;
+    for (size_t p = 0; p < np; ++p) {
+      const PatchResult& r = patches[p];
+      const PatchMesh& m = meshes[p];
+      const size_t nv = m.vertices.size() / 3;
+      complete[p] = (nv > 0 && r.texcoord.size() == 2 * nv && r.frameid >= 0) ? 1 : 0;  // Patch::complete (Patch.cpp:191-196)
+      wrong[p] = r.wrong_mapping ? 1 : 0;
+      lv[p] = (r.has_adjusted && r.labs.size() == 3 * nv) ? 1 : 0;
+      texloc[p] = r.texloc;
+      ratio[2 * p] = r.ratio[0];
+      ratio[2 * p + 1] = r.ratio[1];
+      verts.insert(verts.end(), m.vertices.begin(), m.vertices.end());
+      cols.insert(cols.end(), m.colors.begin(), m.colors.end());
+      nrm.insert(nrm.end(), m.normals.begin(), m.normals.end());
+      nrm.resize(verts.size(), 0.0f);
+      tc.insert(tc.end(), r.texcoord.begin(), r.texcoord.end());
+      tc.resize(verts.size() / 3 * 2, 0.0f);
+      tcol.insert(tcol.end(), r.texcolor.begin(), r.texcolor.end());
+      tcol.resize(verts.size(), 0.0f);
+      if (lv[p]) labs.insert(labs.end(), r.labs.begin(), r.labs.end());
+      labs.resize(verts.size(), 0.0f);
+      idx.insert(idx.end(), m.indices.begin(), m.indices.end());
+      voff[p + 1] = (int64_t)verts.size() / 3;
+      ioff[p + 1] = (int64_t)idx.size();
+    }
+    idx.resize(idx.size() + 1);
+    int64_t nv_out = 0, ni_out = 0;
+    tf_check(tf_pack_vertices(vol, (int64_t)np, complete.data(), wrong.data(), lv.data(), texloc.data(), ratio.data(),
+                              voff.data(), verts.data(), cols.data(), nrm.data(), tc.data(), tcol.data(), labs.data(),
+                              ioff.data(), idx.data(), vertices, indices, &nv_out, &ni_out), "DrawMeshes");
+    tsdf_vertice_num = (unsigned int)nv_out;
+    tsdf_indice_num = (unsigned int)ni_out;
   }
 
   ChunkID maxChunkID, minChunkID;
