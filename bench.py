@@ -86,7 +86,12 @@ def main():
     poses = np.stack([f[3].reshape(12) for f in frames]).astype(np.float32)
     torch.cuda.synchronize()
 
-    vol = capi.Volume(res, cam, max_chunks=1 << 19, max_list=1 << 18, device=local_rank)
+    # N > 1: the volume runs on a torch stream so that the boundary exchange (its own stream) can be
+    # ordered against it with events and overlap the next frame batch
+    s_main = torch.cuda.Stream(device=dev) if multi else None
+    s_xchg = torch.cuda.Stream(device=dev) if multi else None
+    vol = capi.Volume(res, cam, max_chunks=1 << 19, max_list=1 << 18, device=local_rank,
+                      stream=s_main.cuda_stream if multi else None)
     # atlas leg: keyframe = every --atlas-every-th frame; its per-chunk meshes are depth-derived
     # vertex clouds (meshing is the next-stage scope), its RGB / depth are already in HBM
     atlas = {}
@@ -105,16 +110,33 @@ def main():
             lo, hi = -5, 5  # a real interior slab so that faces exist and get packed
         vol.set_partition(lo, hi)
         rec_cap = 1 << 14
-        send = torch.empty(rec_cap * capi.TF_BOUNDARY_RECORD_BYTES, dtype=torch.uint8, device=dev)
+        send = [torch.empty(rec_cap * capi.TF_BOUNDARY_RECORD_BYTES, dtype=torch.uint8, device=dev) for _ in range(2)]
+        cnt = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
+        keep = []  # received buffers stay referenced until the unpack kernels that read them have run
 
-    def exchange_boundary():
-        """All-gather of updated boundary chunks over RCCL (xGMI); counts first, then payloads."""
-        n = vol.boundary_pack(send.data_ptr(), rec_cap)
-        got = exchange.allgather_records(send, n)
+    def start_exchange(slot):
+        """Pack the boundary chunks updated since the last exchange (asynchronous, on the volume's stream)."""
+        vol.boundary_pack_async(send[slot].data_ptr(), rec_cap, cnt[slot].data_ptr())
+        ev = torch.cuda.Event()
+        ev.record(s_main)
+        return slot, ev
+
+    def finish_exchange(pending):
+        """All-gather over RCCL (xGMI) on the exchange stream: counts first, then payloads; host waits of
+        this step overlap the frame batch that is already enqueued on the volume's stream."""
+        slot, ev = pending
+        with torch.cuda.stream(s_xchg):
+            s_xchg.wait_event(ev)
+            got = exchange.allgather_records(send[slot], cnt[slot], synchronize=False)
+            done = torch.cuda.Event()
+            done.record(s_xchg)
+        s_main.wait_event(done)
         for r, (buf, m) in enumerate(got):
             if r != rank and m:
                 vol.boundary_unpack(buf.data_ptr(), m)
-        vol.sync()
+        keep.append(got)
+        if len(keep) > 2:
+            keep.pop(0)
 
     def run(first, count, timed):
         """Frames [first, first+count) of the stream (cyclic over the unique frames)."""
@@ -139,11 +161,17 @@ def main():
             vol.integrate_frames_device([d_depth[i].data_ptr() for i in idx],
                                         [d_rgba[i].data_ptr() for i in idx], poses[idx])
         else:
-            for b in range(0, count, args.exchange_every):
+            pending = None
+            for k, b in enumerate(range(0, count, args.exchange_every)):
                 sub = idx[b:b + args.exchange_every]
                 vol.integrate_frames_device([d_depth[i].data_ptr() for i in sub],
                                             [d_rgba[i].data_ptr() for i in sub], poses[sub])
-                exchange_boundary()
+                nxt = start_exchange(k & 1)
+                if pending is not None:
+                    finish_exchange(pending)  # exchange of the previous batch, hidden behind this one
+                pending = nxt
+            if pending is not None:
+                finish_exchange(pending)
 
     def barrier():
         if multi:

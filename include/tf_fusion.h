@@ -190,6 +190,10 @@ TF_API int tf_debug_phase_raw(tf_volume* v, uint64_t* out, int64_t cap_words);
 #define TF_BOUNDARY_RECORD_BYTES (16 + 4096 + 4096)
 TF_API int tf_set_partition(tf_volume* v, int32_t x_lo, int32_t x_hi);
 TF_API int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t* n);
+/* The same without a host round trip: the record count (which may exceed cap_records; only the first
+ * cap_records were written) lands in the device word *d_count, ordered on the handle's stream, so
+ * that the exchange of one frame batch can overlap the integration of the next. */
+TF_API int tf_boundary_pack_async(tf_volume* v, void* d_records, int64_t cap_records, uint32_t* d_count);
 TF_API int tf_boundary_unpack(tf_volume* v, const void* d_records, int64_t n_records);
 
 /* ---- texture atlas ------------------------------------------------------------------

@@ -33,7 +33,7 @@ SYMBOLS = (
     "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
     "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
-    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_raw", "tf_set_partition", "tf_boundary_pack",
+    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_raw", "tf_set_partition", "tf_boundary_pack", "tf_boundary_pack_async",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_release",
     "tf_atlas_patch_size", "tf_atlas_add_patch", "tf_atlas_loc_next", "tf_patches_update",
     "tf_color_compensate", "tf_pack_vertices",
@@ -110,6 +110,7 @@ def lib():
     L.tf_debug_phase_raw.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
     L.tf_set_partition.argtypes = [vp, C.c_int32, C.c_int32]
     L.tf_boundary_pack.argtypes = [vp, vp, C.c_int64, i64p]
+    L.tf_boundary_pack_async.argtypes = [vp, vp, C.c_int64, vp]
     L.tf_boundary_unpack.argtypes = [vp, vp, C.c_int64]
     L.tf_keyframe_cache.argtypes = [vp, C.c_int32, u8p, fp]
     L.tf_keyframe_cache_device.argtypes = [vp, C.c_int32, vp, vp]
@@ -317,6 +318,10 @@ class Volume:
         n = C.c_int64(0)
         self._ck(self.L.tf_boundary_pack(self.h, C.c_void_p(d_buf), cap, C.byref(n)))
         return n.value
+
+    def boundary_pack_async(self, d_buf, cap, d_count):
+        """Pack without a host round trip; the record count lands in the device u32 at d_count."""
+        self._ck(self.L.tf_boundary_pack_async(self.h, C.c_void_p(d_buf), cap, C.c_void_p(d_count)))
 
     def boundary_unpack(self, d_buf, n):
         self._ck(self.L.tf_boundary_unpack(self.h, C.c_void_p(d_buf), n))

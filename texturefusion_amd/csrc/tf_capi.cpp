@@ -787,6 +787,15 @@ int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t
   return TF_OK;
 }
 
+int tf_boundary_pack_async(tf_volume* v, void* d_records, int64_t cap_records, uint32_t* d_count) {
+  if (!v || !d_records || !d_count) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
+  launch_boundary_pack(v->dev, reinterpret_cast<uint8_t*>(d_records), (uint32_t)cap_records, v->stream);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(d_count, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));
+  return TF_OK;
+}
+
 int tf_boundary_unpack(tf_volume* v, const void* d_records, int64_t n_records) {
   if (!v || (n_records > 0 && !d_records)) { set_error("null argument"); return TF_ERR_INVALID; }
   launch_boundary_unpack(v->dev, reinterpret_cast<const uint8_t*>(d_records), (uint32_t)n_records, v->stream);
