@@ -824,15 +824,16 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     int oobl[QUALITY ? 8 : 1];
     int oob_any = 0;
     uint32_t R = 64;
+    // All eight slices are computed in ONE straight-line block (eight independent dependency chains
+    // the scheduler can interleave); the order-dependent part -- which row stalls the chunk -- is
+    // resolved afterwards from the eight validity ballots, and only for chunks that do not project
+    // entirely inside the image.
+    unsigned long long vm[8];
+    uint32_t oob_bits = 0;  // bit j: the lane's pixel of slice j is off the image
     auto geometry = [&](auto safe_tag) {
       constexpr bool SAFE = decltype(safe_tag)::value;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        if (QUALITY) oobl[j] = 0;
-        if (R != 64u) {  // the chunk stalled in an earlier slice
-          off_d[j] = kOOB;
-          continue;
-        }
         const int k = j * 64 + lane;
         // x and y run as the two halves of packed-f32 instructions (each half rounded on its own)
         const f32x2 pxy = o01 + (f32x2){cenT[0][k], cenT[1][k]};
@@ -851,27 +852,39 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         const int Y = SAFE ? cvt_rne_hw(uw.y) : cvt_sat_rne(uw.y);
         // 0 < X < W-1 and 0 < Y < H-1 (:167-173) as two unsigned range tests
         const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
-        const unsigned long long m = ballot(valid);
+        vm[j] = ballot(valid);
         int od = (__mul24(Y, W) + X) * 4;  // valid => 0 < Y < H, exact in 24 bits
         asm volatile("" : "+v"(od));       // keep the select a v_cndmask (no exec-mask branch)
-        od = valid ? od : kOOB;
-        if (m != ~0ull) {  // chunks that project entirely inside the image skip all of this
-          const unsigned long long dead = nonzero_bytes(m) ^ 0x0101010101010101ull;
-          if (dead) R = (uint32_t)(j * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
-          const bool live_lane = (uint32_t)(j * 8 + vy) < R;
-          if (COLOR) {
-            // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220), lanes of processed rows only
-            const bool oob = live_lane && (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1)));
-            oob_any |= oob ? 1 : 0;
-            if (QUALITY) oobl[j] = oob ? 1 : 0;
-          }
-          od = live_lane ? od : kOOB;
-        }
-        off_d[j] = od;
+        off_d[j] = valid ? od : kOOB;
+        // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220); implies !valid
+        if (COLOR) oob_bits |= (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1))) ? (1u << j) : 0u;
       }
     };
     if (div_safe) geometry(std::true_type{});
     else geometry(std::false_type{});
+    if (QUALITY) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) oobl[j] = 0;
+    }
+    unsigned long long all_valid = ~0ull;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) all_valid &= vm[j];
+    if (all_valid != ~0ull) {  // chunks that project entirely inside the image skip all of this
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (R == 64u) {
+          const unsigned long long dead = nonzero_bytes(vm[j]) ^ 0x0101010101010101ull;
+          if (dead) R = (uint32_t)(j * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
+        }
+        const bool live_lane = (uint32_t)(j * 8 + vy) < R;
+        if (COLOR) {  // off-image lanes of processed rows only
+          const bool oob = live_lane && ((oob_bits >> j) & 1u);
+          oob_any |= oob ? 1 : 0;
+          if (QUALITY) oobl[j] = oob ? 1 : 0;
+        }
+        off_d[j] = live_lane ? off_d[j] : kOOB;
+      }
+    }
 
     // ---- phase 2: depth gathers (masked lanes read 0, like the reference's masked gather)
     float dep[8];
