@@ -268,7 +268,7 @@ def main():
 
     # ---- CPU baseline: the oracle (scalar port of the reference path) on the host cores ------
     if rank == 0 and args.cpu_frames > 0:
-        out["cpu_baseline"] = cpu_baseline(args, cam, res, frames, Wm, n_unique)
+        out["cpu_baseline"] = cpu_baseline(args, cam, res, frames, Wm, n_unique, atlas)
 
     if rank == 0:
         print(json.dumps(out))
@@ -277,7 +277,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, cam, res, frames, Wm, n_unique):
+def cpu_baseline(args, cam, res, frames, Wm, n_unique, atlas=None):
     """oracle/ timed on a bounded sample of the same workload: same warm-up frames (untimed),
     then the next --cpu-frames frames of the stream."""
     from oracle import api as O
@@ -289,6 +289,9 @@ def cpu_baseline(args, cam, res, frames, Wm, n_unique):
         f = frames[i % n_unique]
         ov.integrate_frame(f[0], f[1], f[3])
     n = args.cpu_frames
+    oa = O.Atlas(res) if atlas else None   # --atlas-every: GeneratePatches + UpdateAtlas on the keyframes, serial as in the reference
+    seen = {}
+    n_kf = 0
     sel = []
     # thread policy of chisel::parallel_for (threading/Threading.h:36-54)
     t_all = 0.0
@@ -304,6 +307,19 @@ def cpu_baseline(args, cam, res, frames, Wm, n_unique):
         threads_used.append(T)
         t0 = time.perf_counter()
         _, ns = ov.integrate_frame(f[0], f[1], f[3])
+        fi = (Wm + i) % n_unique
+        if atlas and fi in atlas:
+            a = atlas[fi]
+            rgb = np.ascontiguousarray(f[1][..., :3])
+            Cc = O.camera_from(cam)
+            tls = []
+            for p in range(len(a["ids"])):
+                key = tuple(int(x) for x in a["ids"][p])
+                if key not in seen:
+                    rc, seen[key] = oa.alloc()
+                tls.append(seen[key])
+            oa.patches_batch(tls, a["voff"], a["verts"], a["cols"], a["T"], rgb, f[0], Cc)
+            n_kf += 1
         t_all += time.perf_counter() - t0
         sel.append(ns)
     # single-thread figure on a shorter sample
@@ -322,8 +338,10 @@ def cpu_baseline(args, cam, res, frames, Wm, n_unique):
         "kind": "port",
         "sample": "oracle/ C port of the reference path (%s voxel kernel, no FMA; selection scalar, 1 thread) on "
                   "frames %d..%d of the same S-room stream; integrate threads = reference parallel_for policy "
-                  "min(hw-2, ceil(N/1000)); host has %d logical cores"
-                  % ("AVX2 8-lane" if avx2 else "scalar", Wm, Wm + n - 1, ncpu),
+                  "min(hw-2, ceil(N/1000)); host has %d logical cores%s"
+                  % ("AVX2 8-lane" if avx2 else "scalar", Wm, Wm + n - 1, ncpu,
+                     ("; %d keyframes of the sample also ran GeneratePatches + UpdateAtlas (1 thread, as the reference)" % n_kf)
+                     if atlas else ""),
         "value_1thread": n1 / t1,
         "host_cores": ncpu,
     }

@@ -129,6 +129,7 @@ def lib():
     L.tfo_pack_vertices.argtypes = [C.c_int64, u8p, u8p, u8p, C.POINTER(C.c_uint64), fp, C.c_int, C.c_int, i64p, fp, fp,
                                     fp, fp, fp, fp, i64p, C.POINTER(C.c_uint32), fp, C.POINTER(C.c_uint32), i64p]
     L.tfo_pack_vertices.restype = C.c_int64
+    L.tfo_patches_batch.argtypes = [vp, C.c_int64, C.POINTER(C.c_uint64), i64p, fp, fp, fp, u8p, fp, C.POINTER(Camera), fp, fp]
     L.tfo_color_transfer.argtypes = [fp, fp, fp]
     L.tfo_color_compensate.argtypes = [C.c_int64, i32p, u8p, u8p, i64p, fp, fp, fp, fp, i32p]
     L.tfo_color_compensate.restype = C.c_int64
@@ -375,6 +376,19 @@ class Atlas:
         r = self.L.tfo_atlas_blit(self.h, texloc, _p(rgb, C.c_uint8), rgb.shape[1], rgb.shape[0],
                                   _p(bbox, C.c_int32), _p(ratio, C.c_float))
         return r, ratio
+
+    def patches_batch(self, texlocs, voff, verts, cols, T16, rgb, depth, cam):
+        """GeneratePatches + UpdateAtlas for the patches of one keyframe in one C call (CPU baseline)."""
+        tl = np.ascontiguousarray(texlocs, np.uint64)
+        voff = np.ascontiguousarray(voff, np.int64)
+        verts = np.ascontiguousarray(verts, np.float32); cols = np.ascontiguousarray(cols, np.float32)
+        T16 = np.ascontiguousarray(T16, np.float32)
+        nv = int(voff[-1])
+        tc = np.zeros((max(nv, 1), 2), np.float32); tcol = np.zeros((max(nv, 1), 3), np.float32)
+        self.L.tfo_patches_batch(self.h, len(tl), _p(tl, C.c_uint64), _p(voff, C.c_int64), _p(verts, C.c_float),
+                                 _p(cols, C.c_float), _p(T16, C.c_float), _p(rgb, C.c_uint8), _p(depth, C.c_float),
+                                 C.byref(cam), _p(tc, C.c_float), _p(tcol, C.c_float))
+        return tc[:nv], tcol[:nv]
 
     def hot_range(self, texlocs):
         t = np.ascontiguousarray(texlocs, np.uint64)

@@ -1255,3 +1255,20 @@ int64_t tfo_pack_vertices(int64_t n_patches, const uint8_t* complete, const uint
   if (n_indices) *n_indices = index_num;
   return vert_num;
 }
+
+/* GeneratePatches + UpdateAtlas for a batch of patches of one keyframe in one call (the loop of
+ * Chisel.cpp:156-183,191-196), for the CPU baseline: no per-patch binding overhead. */
+int tfo_patches_batch(tfo_atlas* a, int64_t n_patches, const uint64_t* texloc, const int64_t* voff,
+                      const float* verts, const float* colors, const float* T16, const uint8_t* rgb,
+                      const float* depth, const tfo_camera* cam, float* texcoord, float* texcolor) {
+  for (int64_t p = 0; p < n_patches; p++) {
+    int32_t bbox[4];
+    int wrong = 0;
+    int64_t caution = 0;
+    float ratio[2] = {1.0f, 1.0f};
+    tfo_patch_project(verts + 3 * voff[p], colors + 3 * voff[p], voff[p + 1] - voff[p], T16 + 16 * p, rgb, depth,
+                      cam, texcoord + 2 * voff[p], texcolor + 3 * voff[p], bbox, &wrong, &caution);
+    tfo_atlas_blit(a, texloc[p], rgb, cam->width, cam->height, bbox, ratio);
+  }
+  return 0;
+}

@@ -176,6 +176,10 @@ int64_t tfo_pack_vertices(int64_t n_patches, const uint8_t* complete, const uint
                           const float* texcolor, const float* labs, const int64_t* index_offsets,
                           const uint32_t* indices, float* out_vertices, uint32_t* out_indices,
                           int64_t* n_indices);
+/* GeneratePatches + UpdateAtlas over a batch of patches of one keyframe (CPU-baseline helper) */
+int tfo_patches_batch(tfo_atlas* a, int64_t n_patches, const uint64_t* texloc, const int64_t* voff,
+                      const float* verts, const float* colors, const float* T16, const uint8_t* rgb,
+                      const float* depth, const tfo_camera* cam, float* texcoord, float* texcolor);
 /* hot row range, Chisel.cpp:153-186 */
 void tfo_atlas_hot_range(const tfo_atlas* a, const uint64_t* texlocs, int64_t n,
                          uint64_t* hot_start, uint64_t* hot_end);
