@@ -99,9 +99,17 @@ def main():
         for i in range(0, n_unique, args.atlas_every):
             rgb = torch.from_numpy(np.ascontiguousarray(frames[i][1][..., :3])).to(dev)
             ids, voff, verts, cols = synth.mesh_from_depth(frames[i][0], frames[i][1], frames[i][3], cam, res, 4)
+            # the per-chunk meshes are inputs of the atlas stage: resident in HBM like the frames, and
+            # the per-vertex / per-patch results stay there (tf_patches_update_device, asynchronous)
+            nv = int(voff[-1])
             atlas[i] = dict(rgb=rgb, ids=ids, voff=voff, verts=verts, cols=cols,
                             kf=np.full(len(ids), i, np.int32),
-                            T=np.tile(synth.pose_inverse16(frames[i][3]), (len(ids), 1)))
+                            T=np.tile(synth.pose_inverse16(frames[i][3]), (len(ids), 1)),
+                            d_verts=torch.from_numpy(np.ascontiguousarray(verts, np.float32)).to(dev),
+                            d_cols=torch.from_numpy(np.ascontiguousarray(cols, np.float32)).to(dev),
+                            d_tc=torch.empty(max(nv, 1) * 2, dtype=torch.float32, device=dev),
+                            d_tcol=torch.empty(max(nv, 1) * 3, dtype=torch.float32, device=dev),
+                            d_po=torch.empty(max(len(ids), 1) * 8, dtype=torch.int32, device=dev))
             vol.keyframe_cache_device(i, rgb.data_ptr(), d_depth[i].data_ptr())
         torch.cuda.synchronize()
     if multi:
@@ -149,8 +157,10 @@ def main():
                     vol.integrate_frames_device([d_depth[k].data_ptr() for k in sub],
                                                 [d_rgba[k].data_ptr() for k in sub], poses[sub])
                     a = atlas[i]
-                    r = vol.patches_update(a["ids"], a["kf"], a["T"], a["voff"], a["verts"], a["cols"])
-                    if r["rc"] != 0:
+                    rc, _, _ = vol.patches_update_device(a["ids"], a["kf"], a["T"], a["voff"], a["d_verts"].data_ptr(),
+                                                         a["d_cols"].data_ptr(), a["d_tc"].data_ptr(),
+                                                         a["d_tcol"].data_ptr(), a["d_po"].data_ptr())
+                    if rc != 0:
                         raise SystemExit("atlas full")
                     b0 = j + 1
             sub = idx[b0:]

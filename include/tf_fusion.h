@@ -229,6 +229,21 @@ TF_API int tf_patches_update(tf_volume* v, int64_t n_patches, const int32_t* ids
                              float* out_texcoord, float* out_texcolor, int32_t* out_bbox,
                              int32_t* out_flags, float* out_ratio, uint64_t* out_texloc,
                              uint64_t out_hot[2]);
+/* The same with the mesh data already in HBM and the results left there (d_* are device pointers;
+ *   d_patch_out receives one tf_patch_out per patch): only the per-patch descriptors cross PCIe and the
+ *   call does not synchronise, so a keyframe's atlas update is enqueued between two frames of
+ *   tf_integrate_frames_device.  Slot allocation (out_texloc, out_hot: host) is immediate. */
+typedef struct tf_patch_out {
+  int32_t bbox[4];   /* x, y, w, h */
+  int32_t flags;     /* bit0: CalculateTexCoords returned -1; bit1: wrong_mapping */
+  float ratio[2];
+  int32_t n_caution;
+} tf_patch_out;
+TF_API int tf_patches_update_device(tf_volume* v, int64_t n_patches, const int32_t* ids,
+                                    const int32_t* kf_ids, const float* pose_inv16,
+                                    const int64_t* vert_offsets, const float* d_verts,
+                                    const float* d_colors, float* d_texcoord, float* d_texcolor,
+                                    tf_patch_out* d_patch_out, uint64_t* out_texloc, uint64_t out_hot[2]);
 /* Chisel::CompensateColor  Structure/Chisel.cpp:198-286 (+ computeMeanAndCov, Structure/Patch.cpp:342-348)
  *   over a batch of patches in the reference's iteration order.  Patches with has_adjusted != 0 are
  *   skipped; the rest is clustered by frame id (cluster order = first appearance).  Per cluster: mean /

@@ -139,3 +139,46 @@ def test_room_frame_patches_match_oracle(gpu_required):
     out, texlocs = _run_both(gv, oa, cam, C, ids, voff, verts, cols, 12, T, rgb, depth)
     assert np.array_equal(gv.atlas_rows(0, AH, 13824), oa.buffer()[:AH])
     gv.close()
+
+
+def test_device_resident_update_equals_host_variant(gpu_required):
+    """tf_patches_update_device (meshes and results in HBM, asynchronous) == tf_patches_update, bit for bit:
+    slots, per-patch records, texcoords, texcolours and the atlas texels."""
+    from tests.util import HipBuffer
+    cam = synth.Camera()
+    AH = 18 * 40
+    vols = [capi.Volume(RES5, cam, max_chunks=1 << 10, atlas_w=13824, atlas_h=AH) for _ in range(2)]
+    pose = synth.pose_euler(0.2, -0.1, 0.05, (0.05, 0.0, 0.1))
+    depth, rgb = _scene(1.4, cam, pose)
+    ids, voff, verts_c, cols = synth.wall_mesh_for_chunks(_chunk_grid(1.4, RES5, nx=8, ny=6), RES5, 1.4)
+    R, t = pose[:, :3].astype(np.float64), pose[:, 3].astype(np.float64)
+    verts = (verts_c.astype(np.float64) @ R.T + t).astype(np.float32)
+    T = synth.pose_inverse16(pose)
+    n = len(ids)
+    for v in vols:
+        v.keyframe_cache(3, rgb, depth)
+    ref = vols[0].patches_update(ids, np.full(n, 3, np.int32), np.tile(T, (n, 1)), voff, verts, cols)
+    nv = int(voff[-1])
+    bufs = dict(verts=HipBuffer(nv * 12), cols=HipBuffer(nv * 12), tc=HipBuffer(nv * 8), tcol=HipBuffer(nv * 12),
+                po=HipBuffer(n * 32))
+    bufs["verts"].from_host(np.ascontiguousarray(verts, np.float32))
+    bufs["cols"].from_host(np.ascontiguousarray(cols, np.float32))
+    for rep in range(2):  # the second call re-uses the slots (Patch::clear keeps texloc) and the descriptor ring
+        rc, texloc, hot = vols[1].patches_update_device(ids, np.full(n, 3, np.int32), np.tile(T, (n, 1)), voff,
+                                                        bufs["verts"].ptr, bufs["cols"].ptr, bufs["tc"].ptr,
+                                                        bufs["tcol"].ptr, bufs["po"].ptr)
+        assert rc == 0
+    vols[1].sync()
+    assert np.array_equal(texloc, ref["texloc"]) and hot == ref["hot"]
+    tc = bufs["tc"].to_host(nv * 8).view(np.float32).reshape(-1, 2)
+    tcol = bufs["tcol"].to_host(nv * 12).view(np.float32).reshape(-1, 3)
+    po = bufs["po"].to_host(n * 32).view(np.int32).reshape(n, 8)
+    assert np.array_equal(tc.view(np.uint32), ref["texcoord"].view(np.uint32))
+    assert np.array_equal(tcol.view(np.uint32), ref["texcolor"].view(np.uint32))
+    assert np.array_equal(po[:, :4], ref["bbox"]) and np.array_equal(po[:, 4], ref["flags"])
+    assert np.array_equal(po[:, 5:7].view(np.float32).view(np.uint32), ref["ratio"].view(np.uint32))
+    assert np.array_equal(vols[0].atlas_rows(0, AH, 13824), vols[1].atlas_rows(0, AH, 13824))
+    for v in vols:
+        v.close()
+    for b in bufs.values():
+        b.free()

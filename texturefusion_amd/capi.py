@@ -36,7 +36,7 @@ SYMBOLS = (
     "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_raw", "tf_set_partition", "tf_boundary_pack", "tf_boundary_pack_async",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_release",
     "tf_atlas_patch_size", "tf_atlas_add_patch", "tf_atlas_loc_next", "tf_patches_update",
-    "tf_color_compensate", "tf_pack_vertices",
+    "tf_patches_update_device", "tf_color_compensate", "tf_pack_vertices",
     "tf_atlas_download_rows",
 )
 
@@ -120,6 +120,7 @@ def lib():
     L.tf_atlas_loc_next.argtypes = [vp, u64p]
     L.tf_patches_update.argtypes = [vp, C.c_int64, i32p, i32p, fp, i64p, fp, fp, fp, fp, i32p, i32p,
                                     fp, u64p, u64p]
+    L.tf_patches_update_device.argtypes = [vp, C.c_int64, i32p, i32p, fp, i64p, vp, vp, vp, vp, vp, u64p, u64p]
     L.tf_color_compensate.argtypes = [vp, C.c_int64, i32p, u8p, u8p, i64p, fp, fp, fp, i64p]
     L.tf_pack_vertices.argtypes = [vp, C.c_int64, u8p, u8p, u8p, u64p, fp, i64p, fp, fp, fp, fp, fp, fp, i64p,
                                    C.POINTER(C.c_uint32), fp, C.POINTER(C.c_uint32), i64p, i64p]
@@ -380,6 +381,23 @@ class Volume:
         self._ck(rc)
         return dict(rc=rc, texcoord=tc[:nv], texcolor=tcol[:nv], bbox=bbox[:np_], flags=flags[:np_],
                     ratio=ratio[:np_], texloc=texloc[:np_], hot=(int(hot[0]), int(hot[1])))
+
+    def patches_update_device(self, ids, kf_ids, pose_inv, voff, d_verts, d_colors, d_texcoord, d_texcolor, d_patch_out):
+        """Asynchronous GeneratePatches + UpdateAtlas on device-resident meshes -> (rc, texloc, hot)."""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        np_ = len(ids)
+        kf_ids = np.ascontiguousarray(kf_ids, np.int32)
+        pose_inv = _f32(pose_inv).reshape(np_, 16)
+        voff = np.ascontiguousarray(voff, np.int64)
+        texloc = np.zeros(max(np_, 1), np.uint64)
+        hot = np.zeros(2, np.uint64)
+        rc = self.L.tf_patches_update_device(self.h, np_, _p(ids, C.c_int32), _p(kf_ids, C.c_int32),
+                                             _p(pose_inv, C.c_float), _p(voff, C.c_int64), C.c_void_p(d_verts),
+                                             C.c_void_p(d_colors), C.c_void_p(d_texcoord), C.c_void_p(d_texcolor),
+                                             C.c_void_p(d_patch_out), _p(texloc, C.c_uint64), _p(hot, C.c_uint64))
+        if rc != TF_ERR_ATLAS_FULL:
+            self._ck(rc)
+        return rc, texloc[:np_], (int(hot[0]), int(hot[1]))
 
     def color_compensate(self, frame_ids, wrong_mapping, has_adjusted, voff, texcolor, meshcolor):
         """Chisel::CompensateColor over a batch of patches -> (labs, has_adjusted, n_clusters)."""

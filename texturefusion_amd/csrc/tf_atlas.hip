@@ -291,6 +291,12 @@ void atlas_destroy(tf_volume* v) {
   if (a.d_stage) hipFree(a.d_stage);
   if (a.h_stage) hipHostFree(a.h_stage);
   a.buf = nullptr; a.d_stage = nullptr; a.h_stage = nullptr;
+  for (int k = 0; k < 4; ++k) {
+    if (a.pin_ev[k]) hipEventDestroy(a.pin_ev[k]);
+    if (a.pin_host[k]) hipHostFree(a.pin_host[k]);
+    if (a.pin_dev[k]) hipFree(a.pin_dev[k]);
+    a.pin_ev[k] = nullptr; a.pin_host[k] = nullptr; a.pin_dev[k] = nullptr; a.pin_bytes[k] = 0;
+  }
 }
 
 int atlas_reset(tf_volume* v) {
@@ -684,6 +690,84 @@ static void color_transfer(const float cov_src[9], const float cov_tar[9], float
   mat3_mul(U, Di, A1); mat3_mul(A1, Um, A2); mat3_mul(A2, Dm, A1); mat3_mul(A1, Umt, A2);
   mat3_mul(A2, Di, A1); mat3_mul(A1, Ut, A2);
   for (int i = 0; i < 9; i++) T[i] = (float)A2[i];
+}
+
+// tf_patches_update with the mesh data already resident and the results left in HBM: nothing but the
+// per-patch descriptors (112 B each) crosses PCIe and nothing synchronises, so a keyframe's atlas
+// update rides in the frame stream.  Slot allocation stays on the host (immediate, in patch order).
+int tf_patches_update_device(tf_volume* v, int64_t np, const int32_t* ids, const int32_t* kf_ids,
+                             const float* pose_inv16, const int64_t* voff, const float* d_verts,
+                             const float* d_colors, float* d_texcoord, float* d_texcolor,
+                             tf_patch_out* d_patch_out, uint64_t* out_texloc, uint64_t out_hot[2]) {
+  if (!v || (np > 0 && (!ids || !kf_ids || !pose_inv16 || !voff || !d_verts || !d_colors || !d_texcoord ||
+                        !d_texcolor || !d_patch_out))) {
+    set_error("null argument");
+    return TF_ERR_INVALID;
+  }
+  static_assert(sizeof(tf_patch_out) == sizeof(PatchOut), "public and device patch records differ");
+  AtlasState& a = v->atlas;
+  if (np <= 0) {
+    if (out_hot) {
+      const uint64_t ls = (uint64_t)a.aw * (uint64_t)a.ah;
+      out_hot[0] = (ls / a.aw) * a.aw;
+      out_hot[1] = (0 / a.aw + a.ph) * a.aw;
+    }
+    return TF_OK;
+  }
+  // descriptor ring: pinned host copies must outlive their asynchronous upload
+  constexpr int kRing = 4;
+  const size_t bytes = sizeof(PatchIn) * (size_t)np;
+  const int slot = a.pin_next;
+  a.pin_next = (a.pin_next + 1) % kRing;
+  if (a.pin_ev[slot]) TF_HIP(hipEventSynchronize(a.pin_ev[slot]));
+  else TF_HIP(hipEventCreateWithFlags(&a.pin_ev[slot], hipEventDisableTiming));
+  if (bytes > a.pin_bytes[slot]) {
+    if (a.pin_host[slot]) hipHostFree(a.pin_host[slot]);
+    if (a.pin_dev[slot]) { TF_HIP(hipStreamSynchronize(v->stream)); hipFree(a.pin_dev[slot]); }
+    size_t want = 4096;
+    while (want < bytes) want <<= 1;
+    TF_HIP(hipHostMalloc(&a.pin_host[slot], want, hipHostMallocDefault));
+    TF_HIP(hipMalloc(&a.pin_dev[slot], want));
+    a.pin_bytes[slot] = want;
+  }
+  PatchIn* hp = reinterpret_cast<PatchIn*>(a.pin_host[slot]);
+  uint64_t loc_start = (uint64_t)a.aw * (uint64_t)a.ah, loc_end = 0;  // Chisel.cpp:153-154
+  for (int64_t p = 0; p < np; ++p) {
+    uint64_t tl = 0;
+    int rc = add_patch(a, ids + 3 * p, &tl);  // Chisel.cpp:167-173: overflow aborts GeneratePatches
+    if (rc) return TF_ERR_ATLAS_FULL;
+    auto it = a.keyframes.find(kf_ids[p]);
+    if (it == a.keyframes.end()) {
+      set_error("keyframe " + std::to_string(kf_ids[p]) + " is not cached (tf_keyframe_cache)");
+      return TF_ERR_INVALID;
+    }
+    memcpy(hp[p].T, pose_inv16 + 16 * p, 64);
+    hp[p].rgb = it->second.rgb;
+    hp[p].depth = it->second.depth;
+    hp[p].v0 = voff[p];
+    hp[p].v1 = voff[p + 1];
+    hp[p].texloc = tl;
+    if (out_texloc) out_texloc[p] = tl;
+    if (tl < loc_start) loc_start = tl;
+    if (tl > loc_end) loc_end = tl;
+  }
+  const PatchIn* dp = reinterpret_cast<const PatchIn*>(a.pin_dev[slot]);
+  TF_HIP(hipMemcpyAsync(a.pin_dev[slot], hp, bytes, hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipEventRecord(a.pin_ev[slot], v->stream));
+  prof_begin(v, TF_PROF_PATCH_PROJECT);
+  hipLaunchKernelGGL(k_patch_project, dim3((unsigned)np), dim3(256), 0, v->stream, dp, d_verts, d_colors, v->cam,
+                     d_texcoord, d_texcolor, reinterpret_cast<PatchOut*>(d_patch_out));
+  prof_end(v);
+  prof_begin(v, TF_PROF_ATLAS_BLIT);
+  hipLaunchKernelGGL(k_atlas_blit, dim3((unsigned)np), dim3(256), kMaxRoiBytes, v->stream, dp,
+                     reinterpret_cast<PatchOut*>(d_patch_out), a.buf, a.aw, a.ah, (int)a.pw, (int)a.ph, v->cam.W);
+  prof_end(v);
+  TF_HIP(hipGetLastError());
+  if (out_hot) {  // Chisel.cpp:184-186
+    out_hot[0] = (loc_start / (uint64_t)a.aw) * (uint64_t)a.aw;
+    out_hot[1] = (loc_end / (uint64_t)a.aw + a.ph) * (uint64_t)a.aw;
+  }
+  return TF_OK;
 }
 
 int tf_color_compensate(tf_volume* v, int64_t np, const int32_t* frame_ids, const uint8_t* wrong_mapping,

@@ -46,6 +46,12 @@ struct AtlasState {
   size_t d_stage_bytes = 0;
   void* h_stage = nullptr;
   size_t h_stage_bytes = 0;
+  // descriptor ring of the asynchronous (device-resident) patch update
+  void* pin_host[4] = {nullptr, nullptr, nullptr, nullptr};
+  void* pin_dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t pin_bytes[4] = {0, 0, 0, 0};
+  hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  int pin_next = 0;
 };
 
 }  // namespace tf
