@@ -770,7 +770,11 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   asm volatile("" : "+v"(c_near), "+v"(c_far), "+v"(c_thr), "+v"(c_lower), "+v"(c_sigma));
 
   if ((kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves)  // timeline aid: prologue end
+  {
     v.phase_buf[wave * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+    v.phase_buf[wave * 16 + 8] = 0;
+    v.phase_buf[wave * 16 + 9] = 0;
+  }
 
   for (uint32_t e = wave; e < n; e += nwaves) {
     // The list entry (per-chunk scalars + id) was written by the previous launch, so it is read
@@ -1055,6 +1059,10 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     }
     const uint32_t rows_t = lanes_t >> 3, rows_c = COLOR ? (lanes_c >> 3) : 0u;
     const bool updated = rows_t != 0;
+    if ((kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves) {  // timeline aid: work of this wave
+      v.phase_buf[wave * 16 + 8] += 1;                 // chunks
+      v.phase_buf[wave * 16 + 9] += rows_t + rows_c;   // rows rewritten
+    }
     if (COLOR && !QUALITY) {
       // without a quality image nothing is ever added: the sum ends as the out-of-observation
       // constant iff any processed row had an off-image lane (:221-222)

@@ -43,3 +43,11 @@ pro = (raw[:, 14].astype(np.int64) - b0 - t0)[k] / 100.0
 print("K-A prologue (wave start -> chunk loop): min/med/max %.2f %.2f %.2f us" % (pro.min(), np.median(pro), pro.max()))
 ent = (raw[:, 15].astype(np.int64) - raw[:, 14].astype(np.int64))[k & (raw[:, 15] > 0)] / 100.0
 print("K-A first list entry (loop start -> scalars loaded): min/med/max %.2f %.2f %.2f us" % (ent.min(), np.median(ent), ent.max()))
+# work per K-A wave vs when it finished
+nch = raw[:, 8].astype(np.int64)[k]; nrow = raw[:, 9].astype(np.int64)[k]; endt = t1[k] / 100.0; dur = (t1[k] - t0[k]) / 100.0
+for c in sorted(set(nch.tolist())):
+    sel = nch == c
+    print("waves with %d chunks: %5d  end med %.2f max %.2f us  rows med %d" % (c, sel.sum(), np.median(endt[sel]), endt[sel].max(), np.median(nrow[sel])))
+late = endt > np.percentile(endt, 95)
+print("latest 5%% of the waves: chunks mean %.2f, rows mean %.0f (all waves: %.2f, %.0f)" % (nch[late].mean(), nrow[late].mean(), nch.mean(), nrow.mean()))
+print("corr(duration, rows) = %.2f   corr(duration, chunks) = %.2f" % (np.corrcoef(dur, nrow)[0, 1], np.corrcoef(dur, nch)[0, 1]))
