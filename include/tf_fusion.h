@@ -120,6 +120,11 @@ TF_API int tf_set_weight(tf_volume* v, float weight);
  * already device-resident (valid until the next upload/bind).  rgba / quality may be NULL. */
 TF_API int tf_frame_upload(tf_volume* v, const float* depth, const uint8_t* rgba,
                            const float* quality);
+/* The caller's RGBA staging loop (GCFusion/MobileFusion.cpp:144-163) on the device: rgb = u8[H][W][3]
+ * (Frame::rgb), color_valid = u8[H][W] (Frame::colorValidFlag); the path sees
+ * rgba = color_valid > 0 ? (r, g, b, 1) : (0, 0, 0, 0). */
+TF_API int tf_frame_upload_rgb(tf_volume* v, const float* depth, const uint8_t* rgb,
+                               const uint8_t* color_valid, const float* quality);
 TF_API int tf_frame_bind_device(tf_volume* v, const float* d_depth, const uint8_t* d_rgba,
                                 const float* d_quality);
 

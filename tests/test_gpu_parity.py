@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import api as O
-from texturefusion_amd import synth
+from texturefusion_amd import capi, synth
 from tests.util import RES5, RES10, HipBuffer, assert_chunks_equal, make_pair, sorted_ids
 
 pytestmark = pytest.mark.gpu
@@ -301,3 +301,28 @@ def test_random_rigid_poses_and_explicit_lists(gpu_required):
     assert np.array_equal(on, gn)
     assert np.array_equal(oq.view(np.uint32), gq.view(np.uint32))
     assert_chunks_equal(ov, gv, ids, "explicit list")
+
+
+def test_rgb_plus_valid_mask_packs_like_the_callers_loop(gpu_required):
+    """tf_frame_upload_rgb == the RGBA staging loop of MobileFusion.cpp:144-163 done on the host."""
+    cam = synth.Camera()
+    depth, rgba, quality, pose = synth.room_frame(4, cam)
+    rng = np.random.default_rng(3)
+    valid = (rng.random((cam.height, cam.width)) > 0.2).astype(np.uint8) * rng.integers(1, 255, (cam.height, cam.width)).astype(np.uint8)
+    rgb = np.ascontiguousarray(rgba[..., :3])
+    packed = np.zeros_like(rgba)
+    packed[..., :3] = np.where(valid[..., None] > 0, rgb, 0)
+    packed[..., 3] = (valid > 0).astype(np.uint8)
+    a = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    b = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    a.frame_upload(depth, packed, quality)
+    b.frame_upload_rgb(depth, rgb, valid, quality)
+    for v in (a, b):
+        v.integrate_frame(pose, True)
+        v.sync()
+    ids = sorted_ids(a.list_chunks())
+    assert np.array_equal(ids, sorted_ids(b.list_chunks()))
+    sa, wa, ca = a.get_chunks(ids)
+    sb, wb, cb = b.get_chunks(ids)
+    assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32)) and np.array_equal(wa.view(np.uint32), wb.view(np.uint32))
+    assert np.array_equal(ca, cb) and ca.any()

@@ -30,6 +30,7 @@ PROF_NAMES = ("bbox", "select", "scan", "emit", "integrate", "finalize", "patch_
 SYMBOLS = (
     "tf_last_error", "tf_device_count", "tf_volume_create", "tf_volume_destroy", "tf_volume_reset",
     "tf_set_stream", "tf_set_camera", "tf_set_truncation", "tf_set_weight", "tf_frame_upload",
+    "tf_frame_upload_rgb",
     "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
     "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
@@ -90,6 +91,7 @@ def lib():
     L.tf_set_truncation.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
     L.tf_set_weight.argtypes = [vp, C.c_float]
     L.tf_frame_upload.argtypes = [vp, fp, u8p, fp]
+    L.tf_frame_upload_rgb.argtypes = [vp, fp, u8p, u8p, fp]
     L.tf_frame_bind_device.argtypes = [vp, vp, vp, vp]
     L.tf_prepare.argtypes = [vp, fp, i32p, u8p, C.c_int64, i64p]
     L.tf_integrate.argtypes = [vp, fp, i32p, C.c_int64, C.c_int, C.c_int, C.c_int, u8p, fp]
@@ -197,6 +199,16 @@ class Volume:
         self._keep = (depth, rgba, quality)
         self._ck(self.L.tf_frame_upload(self.h, _p(depth, C.c_float), _p(rgba, C.c_uint8),
                                         _p(quality, C.c_float)))
+
+    def frame_upload_rgb(self, depth, rgb, color_valid, quality=None):
+        """Frame::rgb (u8[H,W,3]) + Frame::colorValidFlag (u8[H,W]) packed into the path's RGBA on the device."""
+        depth = _f32(depth)
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        color_valid = np.ascontiguousarray(color_valid, np.uint8)
+        quality = None if quality is None else _f32(quality)
+        self._keep = (depth, rgb, color_valid, quality)
+        self._ck(self.L.tf_frame_upload_rgb(self.h, _p(depth, C.c_float), _p(rgb, C.c_uint8),
+                                            _p(color_valid, C.c_uint8), _p(quality, C.c_float)))
 
     def frame_bind_device(self, d_depth, d_rgba=0, d_quality=0):
         self._ck(self.L.tf_frame_bind_device(self.h, C.c_void_p(d_depth), C.c_void_p(d_rgba or None),

@@ -406,6 +406,28 @@ int tf_frame_upload(tf_volume* v, const float* depth, const uint8_t* rgba, const
   return TF_OK;
 }
 
+// The caller-side RGBA staging loop of MobileFusion.cpp:144-163 on the device: the keyframe's RGB (3 bytes
+// per pixel) and colorValidFlag travel as they are (4 B/pixel instead of the 4 B/pixel RGBA plus the host
+// loop) and are packed into the RGBA image the path consumes: valid ? (r, g, b, 1) : 0.
+int tf_frame_upload_rgb(tf_volume* v, const float* depth, const uint8_t* rgb, const uint8_t* color_valid,
+                        const float* quality) {
+  if (!v || !depth || !rgb || !color_valid) { set_error("null argument"); return TF_ERR_INVALID; }
+  int rc = tf_frame_upload(v, depth, nullptr, quality);
+  if (rc) return rc;
+  const size_t npix = (size_t)v->cam.W * v->cam.H;
+  rc = ensure_tmp(v, npix * 4);
+  if (rc) return rc;
+  uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);  // [0, 12 npix): tf_frame_upload used depth (0..4) and quality (8..12)
+  memcpy(st + npix * 4, rgb, npix * 3);
+  memcpy(st + npix * 7, color_valid, npix);
+  uint8_t* dt = reinterpret_cast<uint8_t*>(v->d_tmp);
+  TF_HIP(hipMemcpyAsync(dt, st + npix * 4, npix * 4, hipMemcpyHostToDevice, v->stream));
+  launch_pack_rgba(dt, dt + npix * 3, reinterpret_cast<uchar4*>(v->d_rgba), (uint32_t)npix, v->stream);
+  TF_HIP(hipGetLastError());
+  v->frame.rgba = reinterpret_cast<const uchar4*>(v->d_rgba);
+  return TF_OK;
+}
+
 int tf_frame_bind_device(tf_volume* v, const float* d_depth, const uint8_t* d_rgba,
                          const float* d_quality) {
   if (!v || !d_depth) { set_error("null argument"); return TF_ERR_INVALID; }

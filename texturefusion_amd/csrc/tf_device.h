@@ -144,6 +144,7 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
                       uint32_t epoch, hipStream_t s);
 void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
+void launch_pack_rgba(const uint8_t* rgb, const uint8_t* valid, uchar4* rgba, uint32_t npix, hipStream_t s);
 void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipStream_t s);
 void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s);
 void launch_list_chunks(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t s);

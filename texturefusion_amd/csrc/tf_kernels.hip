@@ -220,6 +220,20 @@ void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipSt
 }
 
 // ---------------------------------------------------------------------------------------
+// RGBA staging of the caller (GCFusion/MobileFusion.cpp:144-163): rgba = valid ? (r, g, b, 1) : 0
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_rgba(const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ valid,
+                                                   uchar4* __restrict__ rgba, uint32_t npix) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
+    const bool ok = valid[i] > 0;
+    rgba[i] = ok ? make_uchar4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1) : make_uchar4(0, 0, 0, 0);
+  }
+}
+void launch_pack_rgba(const uint8_t* rgb, const uint8_t* valid, uchar4* rgba, uint32_t npix, hipStream_t s) {
+  hipLaunchKernelGGL(k_pack_rgba, dim3(1024), dim3(256), 0, s, rgb, valid, rgba, npix);
+}
+
+// ---------------------------------------------------------------------------------------
 // K-B  world AABB of the back-projected (depth + 0.2) points
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void bbox_body(const float* __restrict__ depth, const Cam& cam, const Pose& P,
