@@ -267,9 +267,10 @@ def main():
         per_launch = algo / max(ka_n, 1)
         avg_s = 1e-3 * ka_ms / max(ka_n, 1)
         achieved = per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+        traffic, traffic_src = pmc_traffic(args)
         out["roofline"] = {
             "bound": "hbm", "kernel": "k_frame<color> = K-A(f) + K-C(f+1) + K-B(f+2) block ranges; bytes counted for K-A only", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": per_launch, "avg_launch_us": 1e6 * avg_s, "launches": ka_n,
             "instrumented_ms_per_step": 1e3 * dt_instr / K,
             "chunks_selected_avg": float(np.mean([rows_cache[i][2] for i in idx])),
@@ -285,6 +286,25 @@ def main():
     vol.close()
     if multi:
         dist.destroy_process_group()
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this very
+    command (FETCH_SIZE and WRITE_SIZE need separate --pmc passes, so they cannot be collected inside a
+    timed run): raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes.  The gfx950 x2 correction of FETCH_SIZE applies
+    to 16-B-per-lane streaming reads only; this kernel reads 8 B and 4 B per lane, so the raw value is
+    reported (a lower bound).  None when the workload is not the profiled one."""
+    if args.hires or args.atlas_every or args.gpus > 1 or abs(args.res - 0.005) > 1e-9:
+        return None, None
+    path = os.path.join(ROOT, "profiles", "r1", "05_pmc_k_frame.csv")
+    try:
+        vals = {}
+        for line in open(path).read().splitlines()[1:]:
+            k, v, _ = line.split(",")
+            vals[k] = float(v)
+        return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r1/05_pmc_k_frame.csv (raw FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(args, cam, res, frames, Wm, n_unique, atlas=None):
