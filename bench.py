@@ -10,7 +10,7 @@ Structure/Chisel.h:453-468) at 5 mm voxels, frames already resident in HBM.
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line (metric/value/... + "roofline" + "cpu_baseline").
-N > 1: one process per GPU, static chunk-range (ChunkID.x slab) partition of ONE stream -- every
+N > 1: one process per GPU, static chunk-range partition of ONE stream (slabs of the key x + y + z) -- every
 rank sees every frame, selects and integrates only the chunks of its slab ("strong" scaling), and
 the ranks all-gather their updated boundary chunks over RCCL every --exchange-every frames.
 """
@@ -119,10 +119,23 @@ def main():
             vol.keyframe_cache_device(i, rgb.data_ptr(), d_depth[i].data_ptr())
         torch.cuda.synchronize()
     if multi:
-        lo, hi = part.slab_for_rank(part.room_extent_chunks(res), rank, world)
+        # Ownership key x + y + z: axis-aligned walls and floors are cut diagonally, so no rank holds a
+        # whole wall.  Slab edges split the chunk keys of eight sample frames spread over the orbit into
+        # equally populated slabs; every rank computes them itself (selection is deterministic), so
+        # nothing has to be communicated.
+        axis = (1, 1, 1)
+        keys = []
+        for i in range(0, 200, 25):
+            f = frames[i % n_unique] if i < n_unique else synth.room_frame(i, cam, with_quality=False)
+            vol.frame_upload(f[0], None, None)
+            ids_s, _ = vol.prepare(f[3])
+            keys.append(part.key_of(ids_s, axis))
+        vol.reset()
+        edges = part.balanced_edges(np.concatenate(keys), max(world, 2) if args.force_exchange and world == 1 else world)
+        lo, hi = edges[rank], edges[rank + 1]
         if args.force_exchange and world == 1:
-            lo, hi = -5, 5  # a real interior slab so that faces exist and get packed
-        vol.set_partition(lo, hi)
+            lo, hi = edges[1] - 12, edges[1] + 12  # a real interior slab so that faces exist and get packed
+        vol.set_partition(lo, hi, axis)
         rec_cap = 1 << 14
         send = [torch.empty(rec_cap * capi.TF_BOUNDARY_RECORD_BYTES, dtype=torch.uint8, device=dev) for _ in range(2)]
         cnt = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]

@@ -194,6 +194,11 @@ TF_API int tf_debug_phase_raw(tf_volume* v, uint64_t* out, int64_t cap_words);
  * all-gathers over RCCL.  Record = 16 B header {x,y,z,0} + 4 KiB {sdf,weight}[512] + 4 KiB colour[512][4]. */
 #define TF_BOUNDARY_RECORD_BYTES (16 + 4096 + 4096)
 TF_API int tf_set_partition(tf_volume* v, int32_t x_lo, int32_t x_hi);
+/* The same with the ownership key a*x + b*y + c*z (a, b, c in {0, 1}) instead of x: a rank owns
+ * key_lo <= key < key_hi and its boundary chunks are those with key == key_lo or key_hi - 1 (every
+ * face neighbour of a chunk differs by exactly one coefficient).  (1, 1, 1) cuts axis-aligned walls
+ * and floors diagonally, so no single rank holds a whole wall. */
+TF_API int tf_set_partition_key(tf_volume* v, int32_t a, int32_t b, int32_t c, int32_t key_lo, int32_t key_hi);
 TF_API int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t* n);
 /* The same without a host round trip: the record count (which may exceed cap_records; only the first
  * cap_records were written) lands in the device word *d_count, ordered on the handle's stream, so

@@ -11,13 +11,13 @@ pytestmark = pytest.mark.gpu
 RES5 = np.float32(0.005)
 
 
-def test_two_partitions_equal_one(gpu_required):
+@pytest.mark.parametrize("axis,split", [((1, 0, 0), 3), ((1, 1, 1), 35), ((1, 0, 1), 45)])
+def test_two_partitions_equal_one(gpu_required, axis, split):
     cam = synth.Camera()
-    split = 3
     single = capi.Volume(RES5, cam, max_chunks=1 << 16)
     parts = [capi.Volume(RES5, cam, max_chunks=1 << 16), capi.Volume(RES5, cam, max_chunks=1 << 16)]
-    parts[0].set_partition(-(1 << 31), split)
-    parts[1].set_partition(split, (1 << 31) - 1)
+    parts[0].set_partition(-(1 << 31), split, axis)
+    parts[1].set_partition(split, (1 << 31) - 1, axis)
     cap = 4096
     bufs = [HipBuffer(cap * capi.TF_BOUNDARY_RECORD_BYTES) for _ in range(2)]
     for k in (0, 1, 2):
@@ -37,7 +37,7 @@ def test_two_partitions_equal_one(gpu_required):
             rec = bufs[r].to_host(n[r] * capi.TF_BOUNDARY_RECORD_BYTES).reshape(n[r], -1)
             ids = rec[:, :12].copy().view(np.int32).reshape(-1, 3)
             face = split - 1 if r == 0 else split
-            assert np.all(ids[:, 0] == face)
+            assert np.all(ids.astype(np.int64) @ np.array(axis) == face)
     ref_ids = sorted_ids(single.list_chunks())
     s_ref, w_ref, c_ref = single.get_chunks(ref_ids)
     key = {tuple(c): i for i, c in enumerate(ref_ids)}
@@ -48,7 +48,7 @@ def test_two_partitions_equal_one(gpu_required):
         s, w, c = v.get_chunks(ids)
         for i, cid in enumerate(ids):
             t = tuple(int(x) for x in cid)
-            owned = lo <= cid[0] < hi
+            owned = lo <= int(np.dot(cid.astype(np.int64), axis)) < hi
             if owned:
                 assert t in key, "partition %d holds a chunk the single volume does not" % r
                 seen.add(t)

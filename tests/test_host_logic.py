@@ -73,3 +73,25 @@ def test_merge_needs_reproduces_single_process_flags():
 def test_boundary_mask():
     ids = np.array([[4, 0, 0], [5, 0, 0], [9, 1, 1], [10, 0, 0]], np.int32)
     assert list(part.boundary_mask(ids, 5, 10)) == [False, True, True, False]
+
+
+def test_balanced_edges_split_a_sample_evenly_and_cover_everything():
+    rng = np.random.default_rng(7)
+    ids = np.concatenate([rng.integers(-50, 50, (4000, 3)), np.tile([49, 0, 0], (3000, 1)) + rng.integers(0, 2, (3000, 3)) * [0, 30, 40]])
+    for axis in ((1, 0, 0), (1, 1, 1), (1, 0, 1)):
+        for world in (2, 3, 8):
+            edges = part.balanced_edges(part.key_of(ids, axis), world)
+            assert len(edges) == world + 1 and edges[0] == part.INT_MIN and edges[-1] == part.INT_MAX
+            assert all(edges[i] < edges[i + 1] for i in range(world))
+            own = part.owner_of_key(ids, edges, axis)
+            assert own.min() >= 0 and own.max() < world
+            k = part.key_of(ids, axis)
+            for r in range(world):
+                assert np.all((k[own == r] >= edges[r]) & (k[own == r] < edges[r + 1]))
+    # the diagonal key spreads a wall that one x slab would hold alone
+    wall = np.array([[49, y, z] for y in range(-30, 30) for z in range(-40, 40)])
+    ex = part.balanced_edges(part.key_of(wall, (1, 0, 0)), 4)
+    ed = part.balanced_edges(part.key_of(wall, (1, 1, 1)), 4)
+    assert np.bincount(part.owner_of_key(wall, ex, (1, 0, 0)), minlength=4).max() == len(wall)
+    assert np.bincount(part.owner_of_key(wall, ed, (1, 1, 1)), minlength=4).max() < 0.3 * len(wall)
+    assert part.balanced_edges([], 3)[1:-1] == [1, 2]

@@ -34,7 +34,7 @@ SYMBOLS = (
     "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
     "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
-    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_raw", "tf_set_partition", "tf_boundary_pack", "tf_boundary_pack_async",
+    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_release",
     "tf_atlas_patch_size", "tf_atlas_add_patch", "tf_atlas_loc_next", "tf_patches_update",
     "tf_patches_update_device", "tf_color_compensate", "tf_pack_vertices",
@@ -111,6 +111,7 @@ def lib():
     L.tf_profile_get.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.tf_debug_phase_raw.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
     L.tf_set_partition.argtypes = [vp, C.c_int32, C.c_int32]
+    L.tf_set_partition_key.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.tf_boundary_pack.argtypes = [vp, vp, C.c_int64, i64p]
     L.tf_boundary_pack_async.argtypes = [vp, vp, C.c_int64, vp]
     L.tf_boundary_unpack.argtypes = [vp, vp, C.c_int64]
@@ -188,8 +189,9 @@ class Volume:
     def reset(self):
         self._ck(self.L.tf_volume_reset(self.h))
 
-    def set_partition(self, lo, hi):
-        self._ck(self.L.tf_set_partition(self.h, lo, hi))
+    def set_partition(self, lo, hi, axis=(1, 0, 0)):
+        """Own the chunks with lo <= axis . id < hi (axis in {0,1}^3; (1,0,0) = ChunkID.x slabs)."""
+        self._ck(self.L.tf_set_partition_key(self.h, int(axis[0]), int(axis[1]), int(axis[2]), lo, hi))
 
     # -- frames
     def frame_upload(self, depth, rgba=None, quality=None):

@@ -280,6 +280,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   d.max_coarse = (uint32_t)v->cfg.max_coarse;
   d.part_lo = std::numeric_limits<int32_t>::min();
   d.part_hi = std::numeric_limits<int32_t>::max();
+  d.part_a = 1; d.part_b = 0; d.part_c = 0;
   const size_t hcap = pow2_at_least((size_t)d.max_chunks * 2);
   d.hmask = (uint32_t)(hcap - 1);
   int rc;
@@ -788,13 +789,20 @@ int tf_debug_phase_raw(tf_volume* v, uint64_t* out, int64_t cap_words) {
 }
 
 // ---- multi-GPU partition ------------------------------------------------------------
-int tf_set_partition(tf_volume* v, int32_t x_lo, int32_t x_hi) {
+int tf_set_partition_key(tf_volume* v, int32_t a, int32_t b, int32_t c, int32_t key_lo, int32_t key_hi) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
-  if (x_lo >= x_hi) { set_error("empty partition"); return TF_ERR_INVALID; }
-  v->dev.part_lo = x_lo;
-  v->dev.part_hi = x_hi;
+  if (key_lo >= key_hi) { set_error("empty partition"); return TF_ERR_INVALID; }
+  if (a < 0 || b < 0 || c < 0 || a > 1 || b > 1 || c > 1 || a + b + c == 0) {
+    set_error("partition key coefficients must be 0 or 1, not all 0 (face chunks are found as key == lo / hi - 1)");
+    return TF_ERR_INVALID;
+  }
+  v->dev.part_lo = key_lo;
+  v->dev.part_hi = key_hi;
+  v->dev.part_a = a; v->dev.part_b = b; v->dev.part_c = c;
   return TF_OK;
 }
+
+int tf_set_partition(tf_volume* v, int32_t x_lo, int32_t x_hi) { return tf_set_partition_key(v, 1, 0, 0, x_lo, x_hi); }
 
 int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t* n) {
   if (!v || !d_records || !n) { set_error("null argument"); return TF_ERR_INVALID; }

@@ -111,7 +111,10 @@ struct VolumeDev {
   uint32_t max_list;
   uint32_t max_coarse;
   // partition (multi-GPU chunk-range ownership): lo <= id.x < hi
+  // multi-GPU ownership: key(id) = part_a * x + part_b * y + part_c * z (coefficients >= 0), owned
+  // iff part_lo <= key < part_hi; (1, 0, 0) = ChunkID.x slabs
   int32_t part_lo, part_hi;
+  int32_t part_a, part_b, part_c;
   SelBuf sel;  // the selection set the launch works on
 };
 

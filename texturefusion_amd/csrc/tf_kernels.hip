@@ -65,6 +65,15 @@ __device__ __forceinline__ int4 unpack_id(unsigned long long k) {
   r.w = 0;
   return r;
 }
+// multi-GPU ownership key of a chunk id (VolumeDev::part_*)
+__device__ __forceinline__ int part_key(const VolumeDev& v, int x, int y, int z) {
+  return v.part_a * x + v.part_b * y + v.part_c * z;
+}
+__device__ __forceinline__ bool part_owned(const VolumeDev& v, int x, int y, int z) {
+  const int k = part_key(v, x, y, z);
+  return k >= v.part_lo && k < v.part_hi;
+}
+
 // Fibonacci hashing folded to 32 bits: every bit of (x, y, z) reaches the index bits (the upper
 // half of the product carries z, the lower half x and y), so columns of chunks do not share a home.
 __device__ __forceinline__ uint32_t hash_key(unsigned long long k) {
@@ -365,23 +374,11 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
   // One wave per coarse block: the 8 corner probes run on lanes 0..7 (replicated 8x), the 64
   // per-chunk tests of a hit block on the 64 lanes (lane = (i-x)*16 + (j-y)*4 + (k-z), i.e. the
   // reference's i,j,k push_back order).  Every block is an independent short dependency chain.
-  // Multi-GPU, fused flow: the list only has to hold this rank's slab, so the coarse blocks are
-  // enumerated over the x-range that intersects [part_lo, part_hi) (bx is the slowest index) and
-  // chunks outside the slab are dropped from hit blocks.  The call-by-call flow keeps the full,
-  // reference-ordered list (every rank returns the same list; K-A skips what it does not own).
-  uint32_t cb_lo = 0, cb_hi = n_coarse;
-  if (EMIT && n_coarse) {
-    const long long base = (long long)minI[0] - 1;
-    long long lo = ((long long)v.part_lo - base) / step;          // first block that can hold part_lo
-    if ((long long)v.part_lo - base < 0) lo = 0;
-    long long hi = ((long long)v.part_hi - base + step - 1) / step;  // one past the last block below part_hi
-    if ((long long)v.part_hi - base < 0) hi = 0;
-    if (lo > dims[0]) lo = dims[0];
-    if (hi > dims[0]) hi = dims[0];
-    cb_lo = (uint32_t)lo * nzny;
-    cb_hi = hi > lo ? (uint32_t)hi * nzny : cb_lo;
-  }
-  for (uint32_t cb = cb_lo + wave; cb < cb_hi; cb += nwaves) {
+  // Multi-GPU, fused flow: the list only has to hold this rank's slab, so coarse blocks whose key
+  // range misses [part_lo, part_hi) are skipped before any probe and chunks outside the slab are
+  // dropped from hit blocks.  The call-by-call flow keeps the full, reference-ordered list (every
+  // rank returns the same list; K-A skips what it does not own).
+  for (uint32_t cb = wave; cb < n_coarse; cb += nwaves) {
     const uint32_t bx = cb / nzny;
     const uint32_t brem = cb - bx * nzny;
     const uint32_t by = brem / (uint32_t)dims[2];
@@ -389,6 +386,10 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
     const int x0 = minI[0] - 1 + (int)bx * step;
     const int y0 = minI[1] - 1 + (int)by * step;
     const int z0 = minI[2] - 1 + (int)bz * step;
+    if (EMIT) {  // coefficients are >= 0: the block's smallest / largest key sit at opposite corners
+      const int kmin = part_key(v, x0, y0, z0), kmax = part_key(v, x0 + step - 1, y0 + step - 1, z0 + step - 1);
+      if (kmax < v.part_lo || kmin >= v.part_hi) continue;
+    }
     float oc[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {  // :473-479
@@ -432,7 +433,7 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
           anyhit |= fr.hit;
         }
         flag = anyhit && dv;
-        if (EMIT) flag = flag && (x0 + di >= v.part_lo) && (x0 + di < v.part_hi);
+        if (EMIT) flag = flag && part_owned(v, x0 + di, y0 + dj, z0 + dk);
       }
       m = __ballot(flag);
     }
@@ -796,7 +797,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     // of the CU (a vector load here would wait behind every gather of the other waves).
     const u32x16 prw = *(const_u32x16_ptr)(unsigned long long)(&L.list_pre[4 * e]);
     const int4 id = make_int4((int)prw[8], (int)prw[9], (int)prw[10], 0);
-    const bool owned = (id.x >= v.part_lo) && (id.x < v.part_hi);
+    const bool owned = part_owned(v, id.x, id.y, id.z);
     if (!owned) {
       if (FUSED && lane == 0) {
         L.list_slot[e] = kInvalidSlot; L.list_ent[e] = 0; L.list_new[e] = 0; L.list_needs[e] = 0;
@@ -1084,7 +1085,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     }
 
     // multi-GPU: remember that this slab-face chunk changed since the last boundary exchange
-    const bool face = (id.x == v.part_lo || id.x == v.part_hi - 1);
+    const int pkey = part_key(v, id.x, id.y, id.z);  // every face neighbour differs by one coefficient
+    const bool face = (pkey == v.part_lo || pkey == v.part_hi - 1);
     if (updated && lane == 0 && (face || lazy_revive)) {
       const uint32_t en = FUSED ? ent : L.list_ent[e];
       v.hent[en].alive = face ? 3u : 1u;  // bit0 alive, bit1 touched
@@ -1283,7 +1285,7 @@ __global__ __launch_bounds__(256) void k_finalize(VolumeDev v, uint32_t epoch) {
     const uint32_t e = base + (threadIdx.x >> 3);
     if (e < n) {
       const int4 id = L.list_id[e];
-      const bool owned = (id.x >= v.part_lo) && (id.x < v.part_hi);
+      const bool owned = part_owned(v, id.x, id.y, id.z);
       const bool needs = L.list_needs[e] != 0;
       const bool isnew = L.list_new[e] != 0;
       if (owned && needs && sub == 0) {
@@ -1438,7 +1440,9 @@ __device__ __forceinline__ bool dirty_candidate(const VolumeDev& v, const uint32
   const int4 f = nbr7(id, first);
   if (f.x != n.x || f.y != n.y || f.z != n.z) return false;  // another marked neighbour emits id
   const uint32_t lim = erase > floor_ ? erase : floor_;
-  return M > lim;
+  // multi-GPU: an id is reported by its owner only (who alone knows whether it was erased); marks of
+  // the neighbours across the slab face arrive with the boundary records
+  return M > lim && part_owned(v, id.x, id.y, id.z);
 }
 __global__ __launch_bounds__(256) void k_list_dirty(VolumeDev v, int4* out, uint32_t cap, uint32_t floor_) {
   const uint32_t total = (v.hmask + 1u) * 8u;  // 8 threads per hash entry: candidate k = 0..6
@@ -1539,7 +1543,11 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
       p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
       if (p >= cap) continue;
       uint8_t* rec = records + (size_t)p * (16 + 4096 + 4096);
-      if (lane == 0) *reinterpret_cast<int4*>(rec) = unpack_id(((unsigned long long)khi << 32) | klo);
+      if (lane == 0) {  // header: id + the epoch of the chunk's last update (Chisel::meshesToUpdate travels with it)
+        int4 hd = unpack_id(((unsigned long long)khi << 32) | klo);
+        hd.w = (int)v.mark_epoch[slot];
+        *reinterpret_cast<int4*>(rec) = hd;
+      }
       const uint4* st = reinterpret_cast<const uint4*>(v.tsdf + (size_t)slot * kChunkVoxels);
       const uint4* sc = reinterpret_cast<const uint4*>(v.color + (size_t)slot * kChunkVoxels);
       uint4* dt = reinterpret_cast<uint4*>(rec + 16);
@@ -1562,12 +1570,15 @@ __global__ __launch_bounds__(512) void k_boundary_unpack(VolumeDev v, const uint
   for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
     const uint8_t* rec = records + (size_t)r * (16 + 4096 + 4096);
     const int4 id = *reinterpret_cast<const int4*>(rec);
-    const bool owned = (id.x >= v.part_lo) && (id.x < v.part_hi);
+    const bool owned = part_owned(v, id.x, id.y, id.z);
     if (owned) continue;  // block-uniform
     if (threadIdx.x == 0) {
       bool is_new;
       uint32_t ent;
       sslot = chunk_acquire(v, id, &is_new, &ent);
+      // the ghost carries its owner's update epoch: the owned neighbours of this chunk become dirty
+      // exactly as they do in a single volume (same frame numbering on every rank)
+      if (sslot != kInvalidSlot && (uint32_t)id.w > v.mark_epoch[sslot]) v.mark_epoch[sslot] = (uint32_t)id.w;
     }
     __syncthreads();
     const uint32_t slot = sslot;

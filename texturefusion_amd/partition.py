@@ -64,3 +64,32 @@ def merge_needs(needs_per_rank, ids, extent, world: int):
         nd = np.asarray(nd, np.uint8)
         out |= np.where(own == r, nd, 0).astype(np.uint8)
     return out
+
+
+# ---- general ownership key ------------------------------------------------------------------
+# key(id) = axis . id with axis in {0,1}^3.  (1,0,0) are the x slabs above; (1,1,1) cuts every
+# axis-aligned wall / floor diagonally, so that a rank never holds a whole wall on its own.
+
+def key_of(ids, axis=(1, 0, 0)):
+    ids = np.asarray(ids, np.int64).reshape(-1, 3)
+    return ids @ np.asarray(axis, np.int64)
+
+
+def balanced_edges(keys, world: int):
+    """Slab edges [INT_MIN, e_1, ..., e_{world-1}, INT_MAX] that split the given sample of chunk keys
+    (e.g. the selections of a few frames spread over the stream) into equally populated slabs.
+    Deterministic; edges are strictly increasing even for degenerate samples."""
+    keys = np.sort(np.asarray(keys, np.int64).ravel())
+    edges = [INT_MIN]
+    if len(keys) == 0:
+        keys = np.arange(world, dtype=np.int64)
+    for r in range(1, world):
+        e = int(keys[min(len(keys) - 1, (len(keys) * r) // world)])
+        edges.append(max(e, edges[-1] + 1 if edges[-1] != INT_MIN else e))
+    edges.append(INT_MAX)
+    return edges
+
+
+def owner_of_key(ids, edges, axis=(1, 0, 0)):
+    e = np.asarray(edges[1:-1], np.int64)
+    return np.searchsorted(e, key_of(ids, axis), side="right").astype(np.int32)
