@@ -80,7 +80,7 @@ struct SelBuf {
   unsigned long long* masks;  // [max_coarse]
   uint32_t* offsets;          // [max_coarse]
   int4* list_id;              // [max_list]
-  float4* list_pre;           // [4*max_list] 64-B records {o.x,o.y,o.z,trunc}, {wD,upper,-,-}, {id.x,id.y,id.z,-}, spare
+  float4* list_pre;           // [4*max_list] 64-B records {o.x,o.y,o.z,wD}, {upper,id.x,id.y,id.z}, spare x2
   uint32_t* list_slot;        // [max_list]
   uint32_t* list_ent;         // [max_list] hash entry index of the chunk
   uint8_t* list_new;          // [max_list]

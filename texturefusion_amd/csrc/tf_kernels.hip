@@ -454,9 +454,8 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
         v.sel.list_id[pos] = id;
         const ChunkPre cp = chunk_pre(id, sc.pose, ig, sc.res, sc.resDiag);
-        v.sel.list_pre[4 * pos] = cp.a;
-        v.sel.list_pre[4 * pos + 1] = cp.b;
-        v.sel.list_pre[4 * pos + 2] = make_float4(__int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z), 0.0f);
+        v.sel.list_pre[4 * pos] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
+        v.sel.list_pre[4 * pos + 1] = make_float4(cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
       }
     }
   }
@@ -593,9 +592,8 @@ __global__ __launch_bounds__(256) void k_pre(VolumeDev v, Pose P, Integ ig, floa
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const int4 id = L.list_id[e];
     const ChunkPre cp = chunk_pre(id, P.p, ig, res, resDiag);
-    L.list_pre[4 * e] = cp.a;
-    L.list_pre[4 * e + 1] = cp.b;
-    L.list_pre[4 * e + 2] = make_float4(__int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z), 0.0f);
+    L.list_pre[4 * e] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
+    L.list_pre[4 * e + 1] = make_float4(cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
   }
 }
 
@@ -725,9 +723,9 @@ __device__ __forceinline__ bool in_div_range(float x) {
 // frame images (kernel arguments) and the chunk's two 4-KiB voxel planes (wave-uniform slot).
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(4))) u32x4* const_u32x4_ptr;
-typedef const __attribute__((address_space(4))) u32x16* const_u32x16_ptr;
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(4))) u32x8* const_u32x8_ptr;
 
 template <bool COLOR, bool QUALITY, bool FUSED, bool FLAG, int GP>
 __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameImages& img, const Cam& cam,
@@ -750,6 +748,10 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       L.ctl->bbox_key[3 + a] = f2key(-1e8f);
     }
   }
+
+  // the wave's first list record is requested before anything else: it arrives while the centroid
+  // table is copied (64-B records {o.xyz, wD | upper, id.xyz | spare}; the slot exists for any wave id)
+  u32x8 rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (wave < v.max_list ? wave : 0u)]);
 
   // centroid table (Chisel.cpp:52-110), computed once per frame ahead of this launch; copied into
   // LDS and shared by the four waves of the workgroup (6 KB).
@@ -795,8 +797,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     // The list entry (per-chunk scalars + id) was written by the previous launch, so it is read
     // through the scalar cache: one 64-B record, one s_load, one wait, off the vector-memory queue
     // of the CU (a vector load here would wait behind every gather of the other waves).
-    const u32x16 prw = *(const_u32x16_ptr)(unsigned long long)(&L.list_pre[4 * e]);
-    const int4 id = make_int4((int)prw[8], (int)prw[9], (int)prw[10], 0);
+    const u32x8 prw = rec_next;
+    {  // the next record of this wave travels while this chunk is processed (speculative: the slot
+       // exists even when e + nwaves >= n, it just holds an older frame's record)
+      const uint32_t en = e + nwaves < v.max_list ? e + nwaves : e;
+      rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * en]);
+    }
+    const int4 id = make_int4((int)prw[5], (int)prw[6], (int)prw[7], 0);
     const bool owned = part_owned(v, id.x, id.y, id.z);
     if (!owned) {
       if (FUSED && lane == 0) {
@@ -819,7 +826,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 
     // per-chunk scalars (ProjectionIntegrator.cpp:74-101), precomputed per list entry
     const float o0 = __uint_as_float(prw[0]), o1 = __uint_as_float(prw[1]), o2 = __uint_as_float(prw[2]);
-    const float pbx = __uint_as_float(prw[4]), pby = __uint_as_float(prw[5]);
+    const float pbx = __uint_as_float(prw[3]), pby = __uint_as_float(prw[4]);
     const f32x2 o01 = {o0, o1};
     const f32x2 fxy = {cam.fxi, cam.fyi}, cxy = {kc.cxs, kc.cys};
     const float wD = FLAG ? pbx : -pbx;  // depth_weight *= -1 when de-integrating (:95-99)
