@@ -145,7 +145,121 @@ int main() {
   try { chiselMap.GetMutableChunkManager().GetChunk(chisel::ChunkID(9999, 9999, 9999)); } catch (const std::out_of_range&) { threw = true; }
   CHECK(threw);
 
+  // ---- atlas stage as MobileFusion.cpp:347-384 drives it: GeneratePatches + UpdateAtlas,
+  // CompensateColor, DrawMeshes on per-chunk meshes (synthetic vertex clouds on the wall)
+  size_t n_patches = 0;
+  {
+    std::vector<unsigned char> rgb((size_t)W * H * 3);
+    for (int i = 0; i < W * H; ++i) { rgb[3 * i] = rgba[4 * i]; rgb[3 * i + 1] = rgba[4 * i + 1]; rgb[3 * i + 2] = rgba[4 * i + 2]; }
+    chiselMap.CacheKeyframe(kfIndex, rgb.data(), depth.data());
+    chiselMap.CacheKeyframe(kfIndex + 1, rgb.data(), depth2.data());
+    std::vector<chisel::PatchMesh> meshes;
+    std::vector<int> labels;
+    std::vector<const float*> poseInv;
+    float Tinv[16] = {1, 0, 0, -0.01f, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // inverse of lastPose
+    const float edge = 8 * res;
+    for (int64_t i = 0; i < nv && meshes.size() < 150; i += 7) {
+      const chisel::ChunkID id = validChunks[i];
+      if (!(id(2) * edge <= 1.5f && 1.5f < (id(2) + 1) * edge)) continue;
+      chisel::PatchMesh m;
+      m.chunkID = id;
+      unsigned h = (unsigned)(id(0) * 73856093) ^ (unsigned)(id(1) * 19349663);
+      const int nvert = 6 + (int)(h % 20u);
+      for (int k = 0; k < nvert; ++k) {
+        h = h * 1664525u + 1013904223u;
+        const float fx = (float)((h >> 8) & 0xFFFF) / 65536.0f, fy = (float)((h >> 12) & 0xFFFF) / 65536.0f;
+        m.vertices.push_back((id(0) + fx) * edge); m.vertices.push_back((id(1) + fy) * edge); m.vertices.push_back(1.5f);
+        m.colors.push_back((float)((h >> 3) & 0xFF) / 255.0f); m.colors.push_back((float)((h >> 11) & 0xFF) / 255.0f);
+        m.colors.push_back((float)((h >> 19) & 0xFF) / 255.0f);
+        m.normals.push_back(0.0f); m.normals.push_back(0.0f); m.normals.push_back(-1.0f);
+      }
+      for (int k = 0; k + 2 < nvert; ++k) { m.indices.push_back(0); m.indices.push_back(k + 1); m.indices.push_back(k + 2); }
+      meshes.push_back(m);
+      labels.push_back(kfIndex + (int)(meshes.size() % 2));
+      poseInv.push_back(Tinv);
+    }
+    n_patches = meshes.size();
+    CHECK(n_patches > 40);
+    std::vector<chisel::PatchResult> patches;
+    CHECK(chiselMap.GeneratePatchesAndUpdateAtlas(meshes, labels, poseInv, cameraModel, patches) == 0);
+    // oracle: slot, projection, blit per patch in the same order
+    tfo_camera ocam = {W, H, 525.0f, 525.0f, 319.5f, 239.5f, 0.01f, 5.0f};
+    tfo_atlas* oa = tfo_atlas_create(res, 0, cfg.atlas_h);
+    std::vector<int32_t> fid(n_patches);
+    std::vector<uint8_t> wrong(n_patches), adj(n_patches, 0), complete(n_patches, 1), labs_valid(n_patches);
+    std::vector<int64_t> voff(n_patches + 1, 0), ioff(n_patches + 1, 0);
+    std::vector<float> tex, meshc, verts, nrm, tcoord, ratio(2 * n_patches);
+    std::vector<uint64_t> texlocs(n_patches);
+    std::vector<uint32_t> idx;
+    for (size_t p = 0; p < n_patches; ++p) {
+      const size_t nvp = meshes[p].vertices.size() / 3;
+      uint64_t tl = 0;
+      CHECK(tfo_atlas_alloc(oa, &tl) == 0);
+      CHECK(tl == patches[p].texloc);
+      std::vector<float> tc(2 * nvp), tcol(3 * nvp);
+      int32_t bbox[4];
+      int wm = 0;
+      int64_t caution = 0;
+      const float* dimg = labels[p] == kfIndex ? depth.data() : depth2.data();
+      const int flag = tfo_patch_project(meshes[p].vertices.data(), meshes[p].colors.data(), (int64_t)nvp, Tinv, rgb.data(),
+                                         dimg, &ocam, tc.data(), tcol.data(), bbox, &wm, &caution);
+      CHECK(flag == patches[p].flag && (wm != 0) == patches[p].wrong_mapping);
+      CHECK(std::memcmp(bbox, patches[p].boundingbox, 16) == 0);
+      CHECK(std::memcmp(tc.data(), patches[p].texcoord.data(), tc.size() * 4) == 0);
+      CHECK(std::memcmp(tcol.data(), patches[p].texcolor.data(), tcol.size() * 4) == 0);
+      float r2[2] = {1.0f, 1.0f};
+      CHECK(tfo_atlas_blit(oa, tl, rgb.data(), W, H, bbox, r2) == 0);
+      CHECK(r2[0] == patches[p].ratio[0] && r2[1] == patches[p].ratio[1]);
+      fid[p] = labels[p]; wrong[p] = wm ? 1 : 0; texlocs[p] = tl;
+      ratio[2 * p] = r2[0]; ratio[2 * p + 1] = r2[1];
+      tex.insert(tex.end(), tcol.begin(), tcol.end());
+      tcoord.insert(tcoord.end(), tc.begin(), tc.end());
+      meshc.insert(meshc.end(), meshes[p].colors.begin(), meshes[p].colors.end());
+      verts.insert(verts.end(), meshes[p].vertices.begin(), meshes[p].vertices.end());
+      nrm.insert(nrm.end(), meshes[p].normals.begin(), meshes[p].normals.end());
+      idx.insert(idx.end(), meshes[p].indices.begin(), meshes[p].indices.end());
+      voff[p + 1] = (int64_t)verts.size() / 3;
+      ioff[p + 1] = (int64_t)idx.size();
+    }
+    std::vector<unsigned char> rows((size_t)cfg.atlas_h * 13824 * 3);
+    chiselMap.atlas.DownloadRows(0, cfg.atlas_h, rows.data());
+    CHECK(std::memcmp(rows.data(), tfo_atlas_buffer(oa), rows.size()) == 0);
+    // CompensateColor (Chisel.cpp:198-286): flags exact, colours within the stated tolerance
+    chiselMap.CompensateColor(meshes, patches);
+    std::vector<float> olabs(tex.size(), 0.0f);
+    tfo_color_compensate((int64_t)n_patches, fid.data(), wrong.data(), adj.data(), voff.data(), tex.data(), meshc.data(),
+                         olabs.data(), NULL, NULL);
+    std::vector<float> mlabs(tex.size(), 0.0f);
+    for (size_t p = 0; p < n_patches; ++p) {
+      CHECK(patches[p].has_adjusted == (adj[p] != 0));
+      const bool lv = patches[p].has_adjusted && !patches[p].labs.empty();
+      CHECK(lv == (adj[p] != 0 && !wrong[p]));
+      labs_valid[p] = lv ? 1 : 0;
+      if (!lv) continue;
+      for (size_t k = 0; k < patches[p].labs.size(); ++k) {
+        const float d = patches[p].labs[k] - olabs[3 * voff[p] + k];
+        CHECK(d < 2e-5f && d > -2e-5f);
+        mlabs[3 * voff[p] + k] = patches[p].labs[k];
+      }
+    }
+    // DrawMeshes (Chisel.cpp:288-355): bit-exact given the same compensated colours
+    std::vector<float> gv(12 * (size_t)voff[n_patches] + 12), ovx(gv.size());
+    std::vector<unsigned int> gi(idx.size() + 1);
+    std::vector<uint32_t> oi(idx.size() + 1);
+    unsigned int ni = 0, nvx = 0;
+    chiselMap.DrawMeshes(meshes, patches, gv.data(), gi.data(), ni, nvx);
+    int64_t oni = 0;
+    const int64_t onv = tfo_pack_vertices((int64_t)n_patches, complete.data(), wrong.data(), labs_valid.data(), texlocs.data(),
+                                          ratio.data(), 13824, cfg.atlas_h, voff.data(), verts.data(), meshc.data(), nrm.data(),
+                                          tcoord.data(), tex.data(), mlabs.data(), ioff.data(), idx.data(), ovx.data(),
+                                          oi.data(), &oni);
+    CHECK((int64_t)nvx == onv && (int64_t)ni == oni && onv == voff[n_patches]);
+    CHECK(std::memcmp(gv.data(), ovx.data(), (size_t)onv * 48) == 0);
+    CHECK(std::memcmp(gi.data(), oi.data(), (size_t)oni * 4) == 0);
+    tfo_atlas_destroy(oa);
+  }
+
   tfo_volume_destroy(ov);
-  std::printf("HOST MIRROR PARITY OK (%zu chunks in list, %lld valid, %zu observations)\n", n, (long long)nv, nobs);
+  std::printf("HOST MIRROR PARITY OK (%zu chunks in list, %lld valid, %zu observations, %zu patches)\n", n, (long long)nv, nobs, n_patches);
   return 0;
 }
