@@ -8,11 +8,13 @@
 // Kernel map (reference file:line each one replaces):
 //   k_bbox      ChunkManager::findCubeCornerByMat / GetBoundaryChunkID  Structure/ChunkManager.h:303-378
 //   k_select    ChunkManager::GetChunkIDsObservedByCamera + CheckCornerIntersectingSIMD  :380-636
-//   k_scan      order-preserving compaction offsets of the visible list (push_back order :544)
-//   k_emit      list write-out + Chisel::PrepareIntersectChunks' HasChunk/CreateChunk  Structure/Chisel.h:130-138
+//   k_scan      order-preserving compaction + write-out of the visible list (push_back order :544)
+//   k_acquire   Chisel::PrepareIntersectChunks' HasChunk / CreateChunk  Structure/Chisel.h:130-138
 //   k_integrate ProjectionIntegrator::voxelUpdateSIMD  3rd_party/open_chisel/utils/ProjectionIntegrator.cpp:67-426
 //               + the per-chunk lambda of Chisel::IntegrateDepthScanColor  Structure/Chisel.h:234-248
 //   k_finalize  Chisel::FinalizeIntegrateChunks + GarbageCollect  Structure/Chisel.h:184-216,472-477
+//   k_frame     the 5-argument per-frame unit (Structure/Chisel.h:453-468) as ONE launch: K-A of frame f,
+//               K-C (k_select's body) of frame f+1, K-B (k_bbox's body) of frame f+2 as block ranges
 #include <stdlib.h>
 
 #include "tf_device.h"
@@ -641,17 +643,7 @@ constexpr int kOOB = 0x7FFFFFF0;  // buffer byte offset that is out of range for
 #ifndef TF_KF_WAVES
 #define TF_KF_WAVES 7  // resident waves per SIMD the fused kernel is compiled for (register budget)
 #endif
-#ifndef TF_ST_AUX
-#define TF_ST_AUX 0  // cache-policy bits of the voxel-row stores (tuning)
-#endif
 
-// OR over the 8 lanes of a voxel row (lanes 8r..8r+7), three DPP steps, no SGPRs involved.
-__device__ __forceinline__ int row8_or(int x) {
-  x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
-  x |= __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);  // row_half_mirror
-  return x;
-}
 
 // _mm256_cvtps_epi32 for the predicates that consume it: round-to-nearest-even; NaN -> INT_MIN
 // (v_med3 returns the minimum when an operand is NaN); |x| >= 2^31 saturates, which every
@@ -685,13 +677,6 @@ __device__ __forceinline__ Recip recip_refined(float d) {
   R.r = __builtin_fmaf(e, r0, r0);
   return R;
 }
-__device__ __forceinline__ float div_by(const float n, const Recip& R) {
-  const float q0 = n * R.r;
-  const float e0 = __builtin_fmaf(-R.d, q0, n);
-  const float q1 = __builtin_fmaf(e0, R.r, q0);
-  const float e1 = __builtin_fmaf(-R.d, q1, n);
-  return __builtin_fmaf(e1, R.r, q1);
-}
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // the same sequence for two numerators at once on the packed-f32 pipe (v_pk_mul / v_pk_fma)
 __device__ __forceinline__ f32x2 div2_by(const f32x2 n, const Recip& R) {
@@ -701,12 +686,6 @@ __device__ __forceinline__ f32x2 div2_by(const f32x2 n, const Recip& R) {
   const f32x2 q1 = __builtin_elementwise_fma(e0, r, q0);
   const f32x2 e1 = __builtin_elementwise_fma(d, q1, n);
   return __builtin_elementwise_fma(e1, r, q1);
-}
-// operand inside the range where the sequence above needs no scaling / fix-up (or an exact zero
-// numerator): 2^-40 < |x| < 2^40
-__device__ __forceinline__ bool in_div_range(float x) {
-  const uint32_t e = (__float_as_uint(x) >> 23) & 0xFFu;
-  return e > 127u - 40u && e < 127u + 40u;
 }
 
 // K-A runs per chunk as:   64-B list record + hash entry (scalar loads)  ->  geometry of all 8
