@@ -449,18 +449,20 @@ static int atlas_stage(tf_volume* v, size_t bytes) {
 // Atlas::AddPatch (Atlas.cpp:43-64)
 static int add_patch(AtlasState& a, const int32_t id[3], uint64_t* texloc) {
   const uint64_t key = host_pack_id(id);
-  auto it = a.texloc.find(key);
-  if (it != a.texloc.end()) { *texloc = it->second; return TF_OK; }  // Patch::clear keeps texloc
+  bool inserted = false;
+  uint64_t* slot = a.texloc.find_or_insert(key, &inserted);
+  if (!inserted && *slot != FlatMap64::kNone) { *texloc = *slot; return TF_OK; }  // Patch::clear keeps texloc
   *texloc = a.loc_next;
   uint64_t x = a.loc_next % (uint64_t)a.aw, y = a.loc_next / (uint64_t)a.aw;
   if (x >= (uint64_t)a.aw || y >= (uint64_t)a.ah) {
+    *slot = FlatMap64::kNone;  // known id without a slot: a later call tries again (and overflows again)
     set_error("No enough space for texture storage.");  // std::overflow_error text, Atlas.cpp:53
     return TF_ERR_ATLAS_FULL;
   }
   if (x + a.pw >= (uint64_t)a.aw) { x = 0; y += a.ph; }
   else x += a.pw;
   a.loc_next = x + y * (uint64_t)a.aw;
-  a.texloc[key] = *texloc;
+  *slot = *texloc;
   return TF_OK;
 }
 
@@ -575,11 +577,12 @@ int tf_patches_update(tf_volume* v, int64_t np, const int32_t* ids, const int32_
   uint64_t loc_start = (uint64_t)a.aw * (uint64_t)a.ah, loc_end = 0;  // Chisel.cpp:153-154
   int64_t n_ok = np;
   int overflow = 0;
+  auto it = a.keyframes.end();
   for (int64_t p = 0; p < np; ++p) {
     uint64_t tl = 0;
     rc = add_patch(a, ids + 3 * p, &tl);  // Chisel.cpp:167-173: overflow aborts GeneratePatches
     if (rc) { n_ok = p; overflow = 1; break; }
-    auto it = a.keyframes.find(kf_ids[p]);
+    if (p == 0 || kf_ids[p] != kf_ids[p - 1]) it = a.keyframes.find(kf_ids[p]);
     if (it == a.keyframes.end()) {
       set_error("keyframe " + std::to_string(kf_ids[p]) + " is not cached (tf_keyframe_cache)");
       return TF_ERR_INVALID;
@@ -732,11 +735,12 @@ int tf_patches_update_device(tf_volume* v, int64_t np, const int32_t* ids, const
   }
   PatchIn* hp = reinterpret_cast<PatchIn*>(a.pin_host[slot]);
   uint64_t loc_start = (uint64_t)a.aw * (uint64_t)a.ah, loc_end = 0;  // Chisel.cpp:153-154
+  auto it = a.keyframes.end();
   for (int64_t p = 0; p < np; ++p) {
     uint64_t tl = 0;
     int rc = add_patch(a, ids + 3 * p, &tl);  // Chisel.cpp:167-173: overflow aborts GeneratePatches
     if (rc) return TF_ERR_ATLAS_FULL;
-    auto it = a.keyframes.find(kf_ids[p]);
+    if (p == 0 || kf_ids[p] != kf_ids[p - 1]) it = a.keyframes.find(kf_ids[p]);
     if (it == a.keyframes.end()) {
       set_error("keyframe " + std::to_string(kf_ids[p]) + " is not cached (tf_keyframe_cache)");
       return TF_ERR_INVALID;

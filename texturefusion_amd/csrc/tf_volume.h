@@ -34,12 +34,44 @@ struct KeyframeSlot {
   bool owned = false;
 };
 
+// chunk id -> texloc: open addressing, no allocation per insert (GeneratePatches looks up / inserts
+// thousands of ids per keyframe on the host)
+struct FlatMap64 {
+  std::vector<uint64_t> keys, vals;
+  size_t used = 0;
+  static constexpr uint64_t kNone = ~0ull;
+  void clear() { keys.clear(); vals.clear(); used = 0; }
+  static size_t slot_of(uint64_t k, size_t mask) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20) & mask; }
+  void grow() {
+    std::vector<uint64_t> ok, ov;
+    ok.swap(keys); ov.swap(vals);
+    const size_t cap = ok.empty() ? 4096 : ok.size() * 2;
+    keys.assign(cap, kNone); vals.assign(cap, 0);
+    for (size_t i = 0; i < ok.size(); ++i)
+      if (ok[i] != kNone) {
+        size_t s = slot_of(ok[i], cap - 1);
+        while (keys[s] != kNone) s = (s + 1) & (cap - 1);
+        keys[s] = ok[i]; vals[s] = ov[i];
+      }
+  }
+  // returns the value slot of key; *inserted tells whether it is new (value then undefined)
+  uint64_t* find_or_insert(uint64_t k, bool* inserted) {
+    if (keys.empty() || used * 2 >= keys.size()) grow();
+    const size_t mask = keys.size() - 1;
+    size_t s = slot_of(k, mask);
+    while (keys[s] != kNone && keys[s] != k) s = (s + 1) & mask;
+    *inserted = keys[s] == kNone;
+    if (*inserted) { keys[s] = k; ++used; }
+    return &vals[s];
+  }
+};
+
 struct AtlasState {
   int32_t aw = 13824, ah = 13824;
   uint64_t pw = 0, ph = 0;
   uint64_t loc_next = 0;
   uint8_t* buf = nullptr;  // device, u8[ah][aw][3]
-  std::unordered_map<uint64_t, uint64_t> texloc;  // packed chunk id -> texloc (Mesh::m_patch)
+  FlatMap64 texloc;  // packed chunk id -> texloc (Mesh::m_patch)
   std::unordered_map<int32_t, KeyframeSlot> keyframes;
   // staging
   void* d_stage = nullptr;
