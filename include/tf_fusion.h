@@ -189,15 +189,18 @@ TF_API int tf_debug_phase_raw(tf_volume* v, uint64_t* out, int64_t cap_words);
 
 /* ---- multi-GPU chunk-range partition --------------------------------
  * A rank owns chunks with lo <= id.x < hi; selection runs in full on every rank, integrate /
- * finalize touch only owned chunks.  Boundary chunks (x == lo or x == hi-1, updated since
- * the previous tf_boundary_pack) are packed into / unpacked from a device buffer the caller
- * all-gathers over RCCL.  Record = 16 B header {x,y,z,0} + 4 KiB {sdf,weight}[512] + 4 KiB colour[512][4]. */
+ * finalize touch only owned chunks.  The chunks of the slab's ghost band that were updated since
+ * the previous tf_boundary_pack are packed into / unpacked from a device buffer that is
+ * all-gathered over RCCL.  Ghost band = what another rank's mesher reads of this slab: the layer
+ * key == hi-1, and the layers lo <= key <= lo + (a+b+c) -- GenerateMeshEfficient reads c + {0,1}^3
+ * (Structure/ChunkManager.cpp:618-632) and extractGradientFromCubic the face neighbours of those
+ * (:288-315).  Record = 16 B header {x,y,z,update epoch} + 4 KiB {sdf,weight}[512] + 4 KiB colour[512][4].
+ * A record that does not fit the buffer stays flagged (TF_ERR_CAPACITY; call again with more room). */
 #define TF_BOUNDARY_RECORD_BYTES (16 + 4096 + 4096)
 TF_API int tf_set_partition(tf_volume* v, int32_t x_lo, int32_t x_hi);
 /* The same with the ownership key a*x + b*y + c*z (a, b, c in {0, 1}) instead of x: a rank owns
- * key_lo <= key < key_hi and its boundary chunks are those with key == key_lo or key_hi - 1 (every
- * face neighbour of a chunk differs by exactly one coefficient).  (1, 1, 1) cuts axis-aligned walls
- * and floors diagonally, so no single rank holds a whole wall. */
+ * key_lo <= key < key_hi.  (1, 1, 1) cuts axis-aligned walls and floors diagonally, so no single
+ * rank holds a whole wall (its ghost band is four layers thick on the lower side). */
 TF_API int tf_set_partition_key(tf_volume* v, int32_t a, int32_t b, int32_t c, int32_t key_lo, int32_t key_hi);
 TF_API int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t* n);
 /* The same without a host round trip: the record count (which may exceed cap_records; only the first

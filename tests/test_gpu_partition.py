@@ -32,12 +32,18 @@ def test_two_partitions_equal_one(gpu_required, axis, split):
         parts[1].boundary_unpack(bufs[0].ptr, n[0])
         for v in parts:
             v.sync()
-        # every packed record is an updated face chunk owned by the packer
+        # every packed record is an updated chunk of the packer's ghost band: the layer below the upper
+        # face, and the sum(axis) + 1 layers above the lower face (what the mesher of the rank below reads:
+        # c + {0,1}^3 and the face neighbours of those, Structure/ChunkManager.cpp:288-315,618-632)
         for r in range(2):
             rec = bufs[r].to_host(n[r] * capi.TF_BOUNDARY_RECORD_BYTES).reshape(n[r], -1)
             ids = rec[:, :12].copy().view(np.int32).reshape(-1, 3)
-            face = split - 1 if r == 0 else split
-            assert np.all(ids.astype(np.int64) @ np.array(axis) == face)
+            k = ids.astype(np.int64) @ np.array(axis)
+            if r == 0:
+                assert np.all(k == split - 1)
+            else:
+                assert np.all((k >= split) & (k <= split + sum(axis)))
+                assert set(np.unique(k)) == set(range(split, split + sum(axis) + 1))
     ref_ids = sorted_ids(single.list_chunks())
     s_ref, w_ref, c_ref = single.get_chunks(ref_ids)
     key = {tuple(c): i for i, c in enumerate(ref_ids)}
@@ -58,6 +64,25 @@ def test_two_partitions_equal_one(gpu_required, axis, split):
                 assert np.array_equal(w[i].view(np.uint32), w_ref[j].view(np.uint32))
                 assert np.array_equal(c[i], c_ref[j])
     assert seen == set(key)
+    # every chunk the mesher of an owned chunk reads is present (and, by the loop above, bit-identical)
+    offs = set()
+    for o in np.ndindex(2, 2, 2):
+        offs.add(o)
+        for a in range(3):
+            for d in (-1, 1):
+                q = list(o)
+                q[a] += d
+                offs.add(tuple(q))
+    for r, v in enumerate(parts):
+        have = set(map(tuple, v.list_chunks().tolist()))
+        lo, hi = (-(1 << 31), split) if r == 0 else (split, (1 << 31) - 1)
+        for t in key:
+            if not (lo <= int(np.dot(np.array(t, np.int64), axis)) < hi):
+                continue
+            for o in offs:
+                q = (t[0] + o[0], t[1] + o[1], t[2] + o[2])
+                if q in key:
+                    assert q in have, "partition %d lacks mesher neighbour %s of owned chunk %s" % (r, q, t)
     dirty = set(map(tuple, single.dirty()))
     dparts = set(map(tuple, parts[0].dirty())) | set(map(tuple, parts[1].dirty()))
     assert dirty == dparts

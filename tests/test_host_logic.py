@@ -71,8 +71,13 @@ def test_merge_needs_reproduces_single_process_flags():
 
 
 def test_boundary_mask():
-    ids = np.array([[4, 0, 0], [5, 0, 0], [9, 1, 1], [10, 0, 0]], np.int32)
-    assert list(part.boundary_mask(ids, 5, 10)) == [False, True, True, False]
+    # ghost band of the slab [5, 10) of ChunkID.x: key 9 (read by the rank above) and keys 5..6 (the
+    # mesher of the rank below reads c + {0,1}^3 and the face neighbours of those)
+    ids = np.array([[4, 0, 0], [5, 0, 0], [6, 3, 3], [7, 0, 0], [9, 1, 1], [10, 0, 0]], np.int32)
+    assert list(part.boundary_mask(ids, 5, 10)) == [False, True, True, False, True, False]
+    # key x + y + z: four layers above the lower face
+    ids = np.array([[5, 0, 0], [5, 1, 2], [5, 2, 2], [0, 0, 19], [4, 0, 0]], np.int32)
+    assert list(part.boundary_mask(ids, 5, 20, (1, 1, 1))) == [True, True, False, True, False]
 
 
 def test_balanced_edges_split_a_sample_evenly_and_cover_everything():

@@ -474,6 +474,7 @@ extern "C" {
 
 int tf_keyframe_cache(tf_volume* v, int32_t kf_id, const uint8_t* rgb, const float* depth) {
   if (!v || !rgb || !depth) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   AtlasState& a = v->atlas;
   const size_t npix = (size_t)v->cam.W * v->cam.H;
   KeyframeSlot& ks = a.keyframes[kf_id];
@@ -502,6 +503,7 @@ int tf_keyframe_cache(tf_volume* v, int32_t kf_id, const uint8_t* rgb, const flo
 
 int tf_keyframe_cache_device(tf_volume* v, int32_t kf_id, const uint8_t* d_rgb, const float* d_depth) {
   if (!v || !d_rgb || !d_depth) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   AtlasState& a = v->atlas;
   auto it = a.keyframes.find(kf_id);
   if (it != a.keyframes.end() && it->second.owned) { hipFree(it->second.rgb); hipFree(it->second.depth); }
@@ -515,6 +517,7 @@ int tf_keyframe_cache_device(tf_volume* v, int32_t kf_id, const uint8_t* d_rgb, 
 
 int tf_keyframe_release(tf_volume* v, int32_t kf_id) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   AtlasState& a = v->atlas;
   auto it = a.keyframes.find(kf_id);
   if (it == a.keyframes.end()) return TF_OK;
@@ -526,6 +529,7 @@ int tf_keyframe_release(tf_volume* v, int32_t kf_id) {
 
 int tf_atlas_patch_size(tf_volume* v, int32_t* pw, int32_t* ph) {
   if (!v || !pw || !ph) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   *pw = (int32_t)v->atlas.pw;
   *ph = (int32_t)v->atlas.ph;
   return TF_OK;
@@ -533,11 +537,13 @@ int tf_atlas_patch_size(tf_volume* v, int32_t* pw, int32_t* ph) {
 
 int tf_atlas_add_patch(tf_volume* v, const int32_t id[3], uint64_t* texloc) {
   if (!v || !id || !texloc) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   return add_patch(v->atlas, id, texloc);
 }
 
 int tf_atlas_loc_next(tf_volume* v, uint64_t* loc_next) {
   if (!v || !loc_next) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   *loc_next = v->atlas.loc_next;
   return TF_OK;
 }
@@ -551,6 +557,7 @@ int tf_patches_update(tf_volume* v, int64_t np, const int32_t* ids, const int32_
     set_error("null argument");
     return TF_ERR_INVALID;
   }
+  TF_DEV(v);
   AtlasState& a = v->atlas;
   if (np <= 0) {
     if (out_hot) {  // Chisel.cpp:153-154,184-186 with an empty loop
@@ -707,6 +714,7 @@ int tf_patches_update_device(tf_volume* v, int64_t np, const int32_t* ids, const
     set_error("null argument");
     return TF_ERR_INVALID;
   }
+  TF_DEV(v);
   static_assert(sizeof(tf_patch_out) == sizeof(PatchOut), "public and device patch records differ");
   AtlasState& a = v->atlas;
   if (np <= 0) {
@@ -782,6 +790,7 @@ int tf_color_compensate(tf_volume* v, int64_t np, const int32_t* frame_ids, cons
     set_error("null argument");
     return TF_ERR_INVALID;
   }
+  TF_DEV(v);
   if (np <= 0) return TF_OK;
   // clusters by source frame in order of first appearance (Chisel.cpp:199-214)
   std::vector<int32_t> cl((size_t)np, -1), first;
@@ -879,6 +888,7 @@ int tf_pack_vertices(tf_volume* v, int64_t np, const uint8_t* complete, const ui
     set_error("null argument");
     return TF_ERR_INVALID;
   }
+  TF_DEV(v);
   if (np <= 0) return TF_OK;
   AtlasState& a = v->atlas;
   const int64_t nv = voff[np], ni = ioff[np];
@@ -937,6 +947,7 @@ int tf_pack_vertices(tf_volume* v, int64_t np, const uint8_t* complete, const ui
 
 int tf_atlas_download_rows(tf_volume* v, int64_t row0, int64_t row1, uint8_t* dst) {
   if (!v || !dst) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   AtlasState& a = v->atlas;
   if (row0 < 0 || row1 > a.ah || row0 > row1) { set_error("row range outside the atlas"); return TF_ERR_INVALID; }
   const size_t step = (size_t)a.aw * 3;

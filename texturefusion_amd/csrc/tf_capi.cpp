@@ -333,6 +333,7 @@ int tf_volume_destroy(tf_volume* v) {
 
 int tf_volume_reset(tf_volume* v) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   int rc = init_device_state(v);
   if (rc) return rc;
   return atlas_reset(v);
@@ -340,6 +341,7 @@ int tf_volume_reset(tf_volume* v) {
 
 int tf_set_stream(tf_volume* v, void* hip_stream) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   TF_HIP(hipStreamSynchronize(v->stream));
   if (v->own_stream && v->stream) hipStreamDestroy(v->stream);
   v->stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -350,6 +352,7 @@ int tf_set_stream(tf_volume* v, void* hip_stream) {
 int tf_set_camera(tf_volume* v, float fx, float fy, float cx, float cy, int width, int height,
                   float near_plane, float far_plane) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   if (width <= 0 || height <= 0 || (width & 7)) {
     set_error("image width must be a positive multiple of 8 (the reference reads 8 pixels per step, ChunkManager.h:326)");
     return TF_ERR_INVALID;
@@ -362,18 +365,21 @@ int tf_set_camera(tf_volume* v, float fx, float fy, float cx, float cy, int widt
 
 int tf_set_truncation(tf_volume* v, float q, float l, float c, float s) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   v->ig.quad = q; v->ig.lin = l; v->ig.cons = c; v->ig.scale = s;
   return TF_OK;
 }
 
 int tf_set_weight(tf_volume* v, float w) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   v->ig.weight = w;
   return TF_OK;
 }
 
 int tf_frame_upload(tf_volume* v, const float* depth, const uint8_t* rgba, const float* quality) {
   if (!v || !depth) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   const size_t npix = (size_t)v->cam.W * v->cam.H;
   if (v->img_pixels != npix) {
     TF_HIP(hipStreamSynchronize(v->stream));
@@ -413,6 +419,7 @@ int tf_frame_upload(tf_volume* v, const float* depth, const uint8_t* rgba, const
 int tf_frame_upload_rgb(tf_volume* v, const float* depth, const uint8_t* rgb, const uint8_t* color_valid,
                         const float* quality) {
   if (!v || !depth || !rgb || !color_valid) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   int rc = tf_frame_upload(v, depth, nullptr, quality);
   if (rc) return rc;
   const size_t npix = (size_t)v->cam.W * v->cam.H;
@@ -432,6 +439,7 @@ int tf_frame_upload_rgb(tf_volume* v, const float* depth, const uint8_t* rgb, co
 int tf_frame_bind_device(tf_volume* v, const float* d_depth, const uint8_t* d_rgba,
                          const float* d_quality) {
   if (!v || !d_depth) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   if ((reinterpret_cast<uintptr_t>(d_depth) & 15) || (reinterpret_cast<uintptr_t>(d_rgba) & 3) ||
       (reinterpret_cast<uintptr_t>(d_quality) & 3)) {
     set_error("device images must be aligned (depth 16 B, rgba/quality 4 B)");
@@ -447,6 +455,7 @@ int tf_frame_bind_device(tf_volume* v, const float* d_depth, const uint8_t* d_rg
 int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint8_t* out_new, int64_t cap,
                int64_t* n) {
   if (!v || !pose || !n) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   if (!v->frame_bound) { set_error("no frame bound (tf_frame_upload / tf_frame_bind_device)"); return TF_ERR_INVALID; }
   Pose P;
   memcpy(P.p, pose, sizeof(P.p));
@@ -484,6 +493,7 @@ int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t
                  int integrate_flag, int use_color, int use_quality, uint8_t* inout_needs_update,
                  float* out_quality) {
   if (!v || !pose || (n > 0 && (!ids || !inout_needs_update))) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   if (!v->frame_bound) { set_error("no frame bound"); return TF_ERR_INVALID; }
   if (n < 1) return TF_OK;  // Chisel.h:228
   if (use_color && !v->frame.rgba) { set_error("use_color set but the bound frame has no colour image"); return TF_ERR_INVALID; }
@@ -518,6 +528,7 @@ int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t
 int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, const uint8_t* is_new,
                 int64_t n, int32_t* out_valid, int64_t* n_valid) {
   if (!v || (n > 0 && (!ids || !needs_update || !is_new))) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   int64_t nv = 0;
   if (n > 0) {
     int rc = sync_list(v, ids, n);
@@ -584,6 +595,7 @@ static int enqueue_frames(tf_volume* v, int64_t n, const float* const* d_depth,
 
 int tf_integrate_frame(tf_volume* v, const float pose[12], int use_color) {
   if (!v || !pose) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   if (!v->frame_bound) { set_error("no frame bound"); return TF_ERR_INVALID; }
   const float* dd[1] = {v->frame.depth};
   const uint8_t* dc[1] = {use_color ? reinterpret_cast<const uint8_t*>(v->frame.rgba) : nullptr};
@@ -593,6 +605,7 @@ int tf_integrate_frame(tf_volume* v, const float pose[12], int use_color) {
 int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* const* d_depth,
                                const uint8_t* const* d_rgba, const float* poses12) {
   if (!v || !d_depth || !poses12) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   if (n_frames <= 0) return TF_OK;
   for (int64_t f = 0; f < n_frames; ++f)
     if ((reinterpret_cast<uintptr_t>(d_depth[f]) & 15) || !d_depth[f] ||
@@ -608,6 +621,7 @@ int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* cons
 
 int tf_sync(tf_volume* v) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   CtlSnap ctl;
   return fetch_ctl(v, &ctl);
 }
@@ -616,6 +630,7 @@ int tf_sync(tf_volume* v) {
 int tf_chunks_download(tf_volume* v, const int32_t* ids, int64_t n, float* sdf, float* weight,
                        uint16_t* color) {
   if (!v || (n > 0 && !ids)) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   if (n <= 0) return TF_OK;
   const size_t per = 16 + 2048 + 2048 + 4096 + 4;  // id, sdf, weight, colour, found
   int rc = ensure_tmp(v, (size_t)n * per);
@@ -658,6 +673,7 @@ int tf_chunk_download(tf_volume* v, const int32_t id[3], float* sdf, float* weig
 
 int tf_has_chunk(tf_volume* v, const int32_t id[3], int* out) {
   if (!v || !id || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   int rc = tf_chunks_download(v, id, 1, nullptr, nullptr, nullptr);
   if (rc == TF_ERR_MISSING_CHUNK) { *out = 0; return TF_OK; }
   if (rc) return rc;
@@ -668,6 +684,7 @@ int tf_has_chunk(tf_volume* v, const int32_t id[3], int* out) {
 int tf_chunk_upload(tf_volume* v, const int32_t id[3], const float* sdf, const float* weight,
                     const uint16_t* color) {
   if (!v || !id) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   if ((sdf == nullptr) != (weight == nullptr)) { set_error("sdf and weight must be given together"); return TF_ERR_INVALID; }
   int rc = ensure_tmp(v, 8192);
   if (rc) return rc;
@@ -691,6 +708,7 @@ int tf_chunk_upload(tf_volume* v, const int32_t id[3], const float* sdf, const f
 
 static int list_common(tf_volume* v, bool dirty, int32_t* out_ids, int64_t cap, int64_t* n) {
   if (!v || !n) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   if (cap < 0) cap = 0;
   int rc = ensure_tmp(v, (size_t)cap * 16 + 16);
   if (rc) return rc;
@@ -726,6 +744,7 @@ int tf_list_dirty(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n) {
 
 int tf_clear_dirty(tf_volume* v) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   // chunksToUpdate.clear() (Chisel.cpp:146): every mark written so far carries an epoch stamp
   // <= the number of finalizes enqueued; raising the floor to it empties the set without touching HBM
   v->clear_floor = v->epoch;
@@ -734,6 +753,7 @@ int tf_clear_dirty(tf_volume* v) {
 
 int tf_get_stats(tf_volume* v, tf_stats* out) {
   if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   memset(out, 0, sizeof(*out));
   int rc = ensure_tmp(v, 64);
   if (rc) return rc;
@@ -766,12 +786,14 @@ int tf_get_stats(tf_volume* v, tf_stats* out) {
 // ---- measurement --------------------------------------------------------------------
 int tf_profile_enable(tf_volume* v, uint32_t kind_mask) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   v->prof_mask = kind_mask;
   return TF_OK;
 }
 
 int tf_profile_get(tf_volume* v, tf_profile* out, int reset) {
   if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   TF_HIP(hipStreamSynchronize(v->stream));
   prof_collect(v);
   *out = v->prof_acc;
@@ -781,6 +803,7 @@ int tf_profile_get(tf_volume* v, tf_profile* out, int reset) {
 
 int tf_debug_phase_raw(tf_volume* v, uint64_t* out, int64_t cap_words) {
   if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   size_t n = (size_t)kPhaseWaves * 16;
   if ((size_t)cap_words < n) n = (size_t)cap_words;
   TF_HIP(hipMemcpyAsync(out, v->dev.phase_buf, n * 8, hipMemcpyDeviceToHost, v->stream));
@@ -791,6 +814,7 @@ int tf_debug_phase_raw(tf_volume* v, uint64_t* out, int64_t cap_words) {
 // ---- multi-GPU partition ------------------------------------------------------------
 int tf_set_partition_key(tf_volume* v, int32_t a, int32_t b, int32_t c, int32_t key_lo, int32_t key_hi) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   if (key_lo >= key_hi) { set_error("empty partition"); return TF_ERR_INVALID; }
   if (a < 0 || b < 0 || c < 0 || a > 1 || b > 1 || c > 1 || a + b + c == 0) {
     set_error("partition key coefficients must be 0 or 1, not all 0 (face chunks are found as key == lo / hi - 1)");
@@ -806,6 +830,7 @@ int tf_set_partition(tf_volume* v, int32_t x_lo, int32_t x_hi) { return tf_set_p
 
 int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t* n) {
   if (!v || !d_records || !n) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
   launch_boundary_pack(v->dev, reinterpret_cast<uint8_t*>(d_records), (uint32_t)cap_records, v->stream);
   TF_HIP(hipGetLastError());
@@ -819,6 +844,7 @@ int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t
 
 int tf_boundary_pack_async(tf_volume* v, void* d_records, int64_t cap_records, uint32_t* d_count) {
   if (!v || !d_records || !d_count) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
   launch_boundary_pack(v->dev, reinterpret_cast<uint8_t*>(d_records), (uint32_t)cap_records, v->stream);
   TF_HIP(hipGetLastError());
@@ -828,6 +854,7 @@ int tf_boundary_pack_async(tf_volume* v, void* d_records, int64_t cap_records, u
 
 int tf_boundary_unpack(tf_volume* v, const void* d_records, int64_t n_records) {
   if (!v || (n_records > 0 && !d_records)) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
   launch_boundary_unpack(v->dev, reinterpret_cast<const uint8_t*>(d_records), (uint32_t)n_records, v->stream);
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;

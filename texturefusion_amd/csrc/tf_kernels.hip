@@ -75,6 +75,16 @@ __device__ __forceinline__ bool part_owned(const VolumeDev& v, int x, int y, int
   const int k = part_key(v, x, y, z);
   return k >= v.part_lo && k < v.part_hi;
 }
+// Chunks of this slab another rank reads as ghosts.  The mesher of a chunk c reads c + {0,1}^3
+// (Structure/ChunkManager.cpp:618-632) and the six face neighbours of each of those (gradients,
+// :288-315): key offsets -1 .. (a + b + c) + 1.  So the rank below needs this slab's keys
+// lo .. lo + (a + b + c), the rank above needs key hi - 1 (which also covers the +-1 layer the
+// dirty-mark closure of Chisel.h:197-203 looks at).
+__device__ __forceinline__ bool part_band(const VolumeDev& v, int x, int y, int z) {
+  const long long k = part_key(v, x, y, z);
+  const long long s = v.part_a + v.part_b + v.part_c;
+  return (k >= (long long)v.part_lo && k - (long long)v.part_lo <= s) || k == (long long)v.part_hi - 1;
+}
 
 // Fibonacci hashing folded to 32 bits: every bit of (x, y, z) reaches the index bits (the upper
 // half of the product carries z, the lower half x and y), so columns of chunks do not share a home.
@@ -590,7 +600,7 @@ void launch_acquire(const VolumeDev& v, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_pre(VolumeDev v, Pose P, Integ ig, float res, float resDiag) {
   const SelBuf& L = v.sel;
   if (blockIdx.x == 0) centroid_table(P.p, res, L.cen);
-  const uint32_t n = L.ctl->n_list < v.max_list ? L.ctl->n_list : v.max_list;
+  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const int4 id = L.list_id[e];
     const ChunkPre cp = chunk_pre(id, P.p, ig, res, resDiag);
@@ -716,7 +726,9 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   // readfirstlane makes the uniformity provable (scalar loads, no waterfall loops around buffer ops)
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6));
   const uint32_t nwaves = nb * 4;
-  const uint32_t n = L.ctl->n_list < v.max_list ? L.ctl->n_list : v.max_list;
+  // a list that overflowed (kStListFull is raised by its producer) holds stale tail records of an
+  // older frame: the frame is skipped as a whole instead of integrating them against this image
+  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
   const int vy = lane >> 3;
   const int W = cam.W, H = cam.H;
   if (FUSED && bid == 0 && threadIdx.x == 0) {
@@ -1071,8 +1083,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     }
 
     // multi-GPU: remember that this slab-face chunk changed since the last boundary exchange
-    const int pkey = part_key(v, id.x, id.y, id.z);  // every face neighbour differs by one coefficient
-    const bool face = (pkey == v.part_lo || pkey == v.part_hi - 1);
+    const bool face = part_band(v, id.x, id.y, id.z);
     if (updated && lane == 0 && (face || lazy_revive)) {
       const uint32_t en = FUSED ? ent : L.list_ent[e];
       v.hent[en].alive = face ? 3u : 1u;  // bit0 alive, bit1 touched
@@ -1517,7 +1528,6 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
     if (i < nent) h = v.hent[i];
     const bool want = h.key != kEmptyKey && (h.alive & 2u) && h.slot != kInvalidSlot;
     unsigned long long m = __ballot(want);
-    if (want) v.hent[i].alive = h.alive & 1u;
     while (m) {
       const int src = __builtin_ctzll(m);
       m &= m - 1;
@@ -1527,7 +1537,8 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
       uint32_t p = 0;
       if (lane == 0) p = atomicAdd(&v.vctl->n_tmp, 1u);
       p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
-      if (p >= cap) continue;
+      if (p >= cap) continue;  // does not fit: the chunk stays flagged, a retry with a larger buffer packs it
+      if (lane == src) v.hent[i].alive = h.alive & 1u;
       uint8_t* rec = records + (size_t)p * (16 + 4096 + 4096);
       if (lane == 0) {  // header: id + the epoch of the chunk's last update (Chisel::meshesToUpdate travels with it)
         int4 hd = unpack_id(((unsigned long long)khi << 32) | klo);

@@ -23,6 +23,18 @@ void set_error(const std::string& msg);
     }                                                                                       \
   } while (0)
 
+// Every C-ABI entry point binds the calling thread to the handle's device first: scratch allocations,
+// launches and copies must land on the GPU the volume lives on, whatever device the caller's thread
+// had current (two volumes on different GPUs in one process, framework worker threads).
+#define TF_DEV(v)                                                                           \
+  do {                                                                                      \
+    hipError_t _e = hipSetDevice((v)->device);                                              \
+    if (_e != hipSuccess) {                                                                 \
+      ::tf::set_error(std::string("hipSetDevice: ") + hipGetErrorString(_e));               \
+      return TF_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+
 struct ProfEvent {
   hipEvent_t a, b;
   int kind;

@@ -3,9 +3,10 @@
 Ownership is a contiguous slab of ChunkID.x per rank: rank r owns lo_r <= id.x < hi_r.  Every
 rank runs the (deterministic, cheap) visible-chunk selection in full, so all ranks hold the
 identical reference-ordered list; integrate / finalize then touch only owned entries
-(tf_set_partition).  The only data exchanged is the payload of updated chunks on slab faces
-(x == lo or x == hi-1), all-gathered so that neighbour reads of the next stage (meshing,
-Structure/ChunkManager.cpp:618-632) see current TSDFs.
+(tf_set_partition).  The only data exchanged is the payload of updated chunks in the ghost band of a
+slab -- key == hi-1 and lo <= key <= lo + sum(axis): the mesher of a chunk c reads c + {0,1}^3
+(Structure/ChunkManager.cpp:618-632) and the face neighbours of those (gradients, :288-315) --
+all-gathered so that neighbour reads of the next stage see current TSDFs.
 
 Host logic only (numpy); the collectives themselves are torch.distributed calls in the caller.
 """
@@ -48,10 +49,10 @@ def owner_of(ids, extent, world: int):
     return np.searchsorted(e, x, side="right").astype(np.int32)
 
 
-def boundary_mask(ids, lo: int, hi: int):
-    """Entries of an id list that sit on a face of the slab [lo, hi)."""
-    x = np.asarray(ids, np.int64).reshape(-1, 3)[:, 0]
-    return (x == lo) | (x == hi - 1)
+def boundary_mask(ids, lo: int, hi: int, axis=(1, 0, 0)):
+    """Entries of an id list that sit in the ghost band of the slab [lo, hi) of key axis . id."""
+    k = np.asarray(ids, np.int64).reshape(-1, 3) @ np.asarray(axis, np.int64)
+    return ((k >= lo) & (k <= lo + int(sum(axis)))) | (k == hi - 1)
 
 
 def merge_needs(needs_per_rank, ids, extent, world: int):
