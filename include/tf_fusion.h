@@ -58,6 +58,12 @@ typedef struct {
   int32_t atlas_h;       /* default 13824 (Structure/Atlas.h:30) */
   int32_t max_keyframes; /* keyframe image cache slots for the atlas; default 64 */
   int32_t reserved;
+  /* device-resident meshes (ChunkManager::allMeshes): one fixed block per chunk-pool slot.  A mesh has at
+   * most 2187 vertices / 2560 triangles (9x9x9x3 edge grid, 512 cells x 5); a mesh that does not fit is
+   * stored empty and reported as TF_ERR_CAPACITY at the next synchronising call.  0 = default 256 / 512
+   * (a planar surface through a chunk has 81 / 128). */
+  int32_t mesh_max_vertices;
+  int32_t mesh_max_triangles;
 } tf_config;
 
 /* Counters of the most recent frame / list (device-side integers, read back on request). */
@@ -83,7 +89,10 @@ typedef struct {
 #define TF_PROF_FINALIZE 5
 #define TF_PROF_PATCH_PROJECT 6
 #define TF_PROF_ATLAS_BLIT 7
-#define TF_PROF_COUNT 8
+#define TF_PROF_MESH 8
+#define TF_PROF_DIRTY 9
+#define TF_PROF_PATCH_RANK 10
+#define TF_PROF_COUNT 12
 typedef struct {
   double ms[TF_PROF_COUNT];       /* summed elapsed time per kernel */
   int64_t launches[TF_PROF_COUNT];
@@ -174,6 +183,30 @@ TF_API int tf_list_chunks(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* 
 TF_API int tf_list_dirty(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n);
 TF_API int tf_clear_dirty(tf_volume* v);
 TF_API int tf_get_stats(tf_volume* v, tf_stats* out);
+
+/* ---- meshing (the stage between the volume and the atlas) -----
+ * Chisel::UpdateMeshes (Structure/Chisel.h:479-481) -> ChunkManager::RecomputeMeshes
+ *   (Structure/ChunkManager.cpp:232-264): every chunk of meshesToUpdate that exists is re-meshed by
+ *   GenerateMeshEfficient (:595-1002, gradient normals :277-455) on the device; meshes stay in HBM
+ *   (ChunkManager::allMeshes).  *n_meshed = size of the dirty set handed to the mesher. */
+TF_API int tf_update_meshes(tf_volume* v, int64_t* n_meshed);
+/* keys of ChunkManager::GetAllMeshes() (Structure/ChunkManager.h:714) */
+TF_API int tf_list_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n);
+/* Mesh::vertices.size() / indices.size() / adj[6] / simplified of listed chunks (Mesh.h:70-85);
+ *   TF_ERR_MISSING_CHUNK when a chunk has no mesh (allMeshes.at() throws).  Outputs may be NULL. */
+TF_API int tf_mesh_counts(tf_volume* v, const int32_t* ids, int64_t n, int32_t* n_vertices,
+                          int32_t* n_indices, uint8_t* adj, uint8_t* simplified);
+/* Mesh::vertices / normals / colors (Vec3List: 3 f32 per vertex) and Mesh::indices of listed chunks,
+ *   packed by the caller's running offsets (vert_offsets[n+1], index_offsets[n+1] from tf_mesh_counts). */
+TF_API int tf_meshes_download(tf_volume* v, const int32_t* ids, int64_t n, const int64_t* vert_offsets,
+                              const int64_t* index_offsets, float* verts, float* normals, float* colors,
+                              uint32_t* indices);
+/* Chisel::CompressMeshes(meshesToUpdate) (Structure/Chisel.cpp:112-147): Mesh::SimplifyByClustering's
+ *   adjacency flags (geometry/Mesh.cpp:39-83) exchanged with the face neighbours, meshesToUpdate
+ *   cleared.  out_ids receives tsdfFusion's chunksToUpdate -- the dirty keys that have a mesh
+ *   (GCFusion/MobileFusion.cpp:345-353) -- in ascending (x, y, z) order (the reference's order is its
+ *   unordered_map's iteration order, i.e. unspecified). */
+TF_API int tf_compress_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n);
 
 /* ---- measurement ------------------------------------------------------------------- */
 /* kind_mask: bit k set = bracket every launch of kernel kind TF_PROF_k with a pair of HIP events

@@ -134,6 +134,19 @@ def lib():
     L.tfo_color_compensate.argtypes = [C.c_int64, i32p, u8p, u8p, i64p, fp, fp, fp, fp, i32p]
     L.tfo_color_compensate.restype = C.c_int64
     L.tfo_atlas_hot_range.argtypes = [vp, u64p, C.c_int64, u64p, u64p]
+    u32p = C.POINTER(C.c_uint32)
+    L.tfo_mesh_chunk.restype = C.c_int64
+    L.tfo_mesh_chunk.argtypes = [vp, i32p, fp, fp, fp, u32p, i64p]
+    L.tfo_update_meshes.restype = C.c_int64
+    L.tfo_update_meshes.argtypes = [vp]
+    L.tfo_volume_num_meshes.restype = C.c_int64
+    L.tfo_volume_num_meshes.argtypes = [vp]
+    L.tfo_volume_list_meshes.restype = C.c_int64
+    L.tfo_volume_list_meshes.argtypes = [vp, i32p, C.c_int64]
+    L.tfo_volume_get_mesh.argtypes = [vp, i32p, i64p, i64p, fp, fp, fp, u32p, u8p, C.POINTER(C.c_int)]
+    L.tfo_mesh_adjacency.argtypes = [fp, C.c_int64, fp, C.c_float, u8p]
+    L.tfo_compress_meshes.restype = C.c_int64
+    L.tfo_compress_meshes.argtypes = [vp, i32p, C.c_int64]
     _lib = L
     return L
 
@@ -319,6 +332,50 @@ class Volume:
         if r != 0:
             raise RuntimeError("oracle integrate: %d chunks missing" % -r)
         return qout[:n]
+
+    # ---- meshing ----
+    def mesh_chunk(self, cid):
+        """GenerateMeshEfficient of one chunk -> (verts [nv,3], normals, colors, indices u32[ni]) or None."""
+        cid = np.ascontiguousarray(cid, np.int32)
+        v = np.zeros((2187, 3), np.float32); nrm = np.zeros((2187, 3), np.float32)
+        col = np.zeros((2187, 3), np.float32); idx = np.zeros(7680, np.uint32)
+        ni = C.c_int64(0)
+        nv = self.L.tfo_mesh_chunk(self.h, _p(cid, C.c_int32), _p(v, C.c_float), _p(nrm, C.c_float),
+                                   _p(col, C.c_float), _p(idx, C.c_uint32), C.byref(ni))
+        if nv < 0:
+            return None
+        return v[:nv].copy(), nrm[:nv].copy(), col[:nv].copy(), idx[:ni.value].copy()
+
+    def update_meshes(self):
+        return int(self.L.tfo_update_meshes(self.h))
+
+    def list_meshes(self):
+        n = int(self.L.tfo_volume_num_meshes(self.h))
+        ids = np.zeros((max(n, 1), 3), np.int32)
+        self.L.tfo_volume_list_meshes(self.h, _p(ids, C.c_int32), n)
+        return ids[:n]
+
+    def get_mesh(self, cid):
+        """-> dict(verts, normals, colors, indices, adj u8[6], simplified) or None."""
+        cid = np.ascontiguousarray(cid, np.int32)
+        nv = C.c_int64(0); ni = C.c_int64(0)
+        if self.L.tfo_volume_get_mesh(self.h, _p(cid, C.c_int32), C.byref(nv), C.byref(ni), None, None, None,
+                                      None, None, None) != 0:
+            return None
+        v = np.zeros((max(nv.value, 1), 3), np.float32); nrm = np.zeros_like(v); col = np.zeros_like(v)
+        idx = np.zeros(max(ni.value, 1), np.uint32)
+        adj = np.zeros(6, np.uint8); simp = C.c_int(0)
+        self.L.tfo_volume_get_mesh(self.h, _p(cid, C.c_int32), None, None, _p(v, C.c_float), _p(nrm, C.c_float),
+                                   _p(col, C.c_float), _p(idx, C.c_uint32), _p(adj, C.c_uint8), C.byref(simp))
+        return dict(verts=v[:nv.value], normals=nrm[:nv.value], colors=col[:nv.value], indices=idx[:ni.value],
+                    adj=adj, simplified=bool(simp.value))
+
+    def compress_meshes(self):
+        """CompressMeshes on meshesToUpdate (cleared); returns chunksToUpdate in ascending id order."""
+        n = int(self.L.tfo_volume_num_dirty(self.h))
+        ids = np.zeros((max(n, 1), 3), np.int32)
+        m = self.L.tfo_compress_meshes(self.h, _p(ids, C.c_int32), n)
+        return ids[:m].copy()
 
     def finalize(self, ids, needs, new):
         ids = np.ascontiguousarray(ids, np.int32)

@@ -537,7 +537,13 @@ struct tfo_volume {
   tfo_map map;   /* ChunkID -> index in chunks[] */
   tfo_map dirty; /* meshesToUpdate: ChunkID -> 1 */
   tfo_rowstats stats;
+  /* ChunkManager::allMeshes (ChunkManager.h:1304): ChunkID -> index in meshes[] */
+  struct tfo_mesh* meshes;
+  int64_t n_meshes, cap_meshes;
+  tfo_map mesh_map;
 };
+static void vol_erase_mesh(tfo_volume* v, const int32_t* id);
+static void vol_meshes_clear(tfo_volume* v);
 
 static uint64_t hash3(const int32_t* k) { /* Teschner hash, ChunkManager.h:44-53 */
   return ((uint64_t)(int64_t)k[0] * 73856093ull) ^ ((uint64_t)(int64_t)k[1] * 19349663ull) ^
@@ -596,6 +602,7 @@ tfo_volume* tfo_volume_create(float res, int use_color) {
   v->nthreads = 1;
   map_init(&v->map, 1 << 12);
   map_init(&v->dirty, 1 << 12);
+  map_init(&v->mesh_map, 1 << 12);
   /* defaults of MobileFusion::initChiselMap (GCFusion/MobileFusion.h:205-258) */
   v->ig.quad = 0.0019f; v->ig.lin = 0.00152f; v->ig.cons = 0.001504f; v->ig.scale = 6.0f;
   v->ig.weight = 1.0f;
@@ -614,13 +621,14 @@ void tfo_volume_reset(tfo_volume* v) { /* Chisel::Reset (Chisel.cpp:47-50) */
   v->n_chunks = 0; v->n_free = 0;
   map_free(&v->map); map_free(&v->dirty);
   map_init(&v->map, 1 << 12); map_init(&v->dirty, 1 << 12);
+  vol_meshes_clear(v); /* chunkManager.Reset(): allMeshes.clear() (ChunkManager.cpp:272-275) */
   memset(&v->stats, 0, sizeof(v->stats));
 }
 void tfo_volume_destroy(tfo_volume* v) {
   if (!v) return;
   tfo_volume_reset(v);
-  map_free(&v->map); map_free(&v->dirty);
-  free(v->chunks); free(v->free_list);
+  map_free(&v->map); map_free(&v->dirty); map_free(&v->mesh_map);
+  free(v->chunks); free(v->free_list); free(v->meshes);
   free(v);
 }
 void tfo_volume_set_camera(tfo_volume* v, const tfo_camera* cam) { v->cam = *cam; }
@@ -672,6 +680,7 @@ static void vol_remove_chunk(tfo_volume* v, const int32_t* id) {
   int64_t slot = v->map.vals[i];
   chunk_release(&v->chunks[slot]);
   map_erase(&v->map, id);
+  vol_erase_mesh(v, id); /* RemoveChunk also drops the chunk's mesh (ChunkManager.h:151-161) */
   if (v->n_free == v->cap_free) {
     v->cap_free = v->cap_free ? v->cap_free * 2 : 1024;
     v->free_list = (int64_t*)realloc(v->free_list, sizeof(int64_t) * v->cap_free);
@@ -1271,4 +1280,366 @@ int tfo_patches_batch(tfo_atlas* a, int64_t n_patches, const uint64_t* texloc, c
     tfo_atlas_blit(a, texloc[p], rgb, cam->width, cam->height, bbox, ratio);
   }
   return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* meshing: ChunkManager::GenerateMeshEfficient,               */
+/* extractGradientFromCubic, RecomputeMeshes; Mesh::SimplifyByClustering;                 */
+/* Chisel::UpdateMeshes / CompressMeshes                                                 */
+/* ------------------------------------------------------------------------------------ */
+#include "mc_table.inc"
+
+/* cubeIndexOffsets (ChunkManager.cpp:65-66): column k = corner k of a cell */
+static const int kCorner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0},
+                                  {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+/* edgeIndexPairs (ChunkManager.cpp:68-75) */
+static const int kEdgePair[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6},
+                                     {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+
+struct tfo_mesh {
+  int32_t id[3];
+  int alive;
+  int32_t nv, ni;
+  float* verts;   /* [3*nv] Mesh::vertices */
+  float* normals; /* [3*nv] Mesh::normals */
+  float* colors;  /* [3*nv] Mesh::colors */
+  uint32_t* indices; /* [ni] Mesh::indices */
+  uint8_t adj[6];    /* Mesh::adj */
+  int simplified;    /* Mesh::simplified */
+};
+
+/* sdf of the voxel at chunk `cid`, voxel index `vi`; returns 0 when the chunk does not exist
+ * (ChunkMap::find fails, ChunkManager.h:808-822) */
+static int chunk_sdf(const tfo_volume* v, const int32_t cid[3], int vi, float* out) {
+  const tfo_chunk* c = vol_get(v, cid);
+  if (!c) return 0;
+  *out = c->sdf[vi];
+  return 1;
+}
+
+/* ChunkManager::extractGradientFromCubic (ChunkManager.cpp:277-455) with GetNeighborSDF
+ * (ChunkManager.h:790-823).  cube[8] = corner sdfs of the cell, cell = (x,y,z) of the cell in its
+ * chunk, k = corner of the cell whose gradient is wanted, corner_vi / corner_chunk = voxel index
+ * and chunk id the corner lives in.  The three differences that stay inside the cube come from
+ * cube[], the other three from the corner's own chunk or -- when the corner sits on a chunk face
+ * (edgeFlag, :304-309, tested on the cell coordinate + corner offset, range 0..8) -- from the face
+ * neighbour chunk (voxelNeighborIndex = the wrapped neighbour index, ChunkManager.cpp:108-157).
+ * A fetched value must be < 1 (and its chunk must exist), else there is no normal.
+ * grad.norm()/normalize(): Eigen fixed-size reduction x*x + (y*y + z*z); normalize() divides by
+ * sqrt when the squared norm is > 0 (Eigen >= 3.3; 3.2 multiplies by the reciprocal and has no
+ * zero test -- third-party arithmetic, parity unpinned). */
+static int gradient_from_cubic(const tfo_volume* v, const float cube[8], const int cell[3], int k,
+                               int corner_vi, const int32_t corner_chunk[3], float grad[3]) {
+  float dd[6];
+  const int vx = corner_vi & 7, vy = (corner_vi >> 3) & 7, vz = corner_vi >> 6;
+  const int vc[3] = {vx, vy, vz};
+  for (int a = 0; a < 3; a++) {
+    const int near = cell[a] + kCorner[k][a];
+    /* the in-cube partner: corner k with offset a flipped */
+    int kk = -1;
+    for (int q = 0; q < 8; q++) {
+      int same = 1;
+      for (int b = 0; b < 3; b++)
+        if (kCorner[q][b] != (b == a ? 1 - kCorner[k][b] : kCorner[k][b])) same = 0;
+      if (same) kk = q;
+    }
+    const int dir = kCorner[k][a] ? 1 : 0; /* 0: fetch the -a neighbour, 1: fetch the +a neighbour */
+    dd[2 * a + (1 - dir)] = cube[kk];
+    const int edge = dir ? (near == 7) : (near == 0);
+    int nv[3] = {vc[0], vc[1], vc[2]};
+    nv[a] = (vc[a] + (dir ? 1 : -1) + 8) % 8;
+    const int nvi = nv[0] + nv[1] * 8 + nv[2] * 64;
+    int32_t nc[3] = {corner_chunk[0], corner_chunk[1], corner_chunk[2]};
+    if (edge) nc[a] += dir ? 1 : -1;
+    float val;
+    if (!chunk_sdf(v, nc, nvi, &val)) return 0;
+    dd[2 * a + dir] = val;
+    if (!(val < 1.0f)) return 0;
+  }
+  const float gx = dd[1] - dd[0], gy = dd[3] - dd[2], gz = dd[5] - dd[4];
+  const float yz = gy * gy + gz * gz;
+  const float sq = gx * gx + yz;
+  const float g = sqrtf(sq);
+  grad[0] = gx; grad[1] = gy; grad[2] = gz;
+  if (sq > 0.0f) { grad[0] = gx / g; grad[1] = gy / g; grad[2] = gz / g; }
+  if (g > v->res * 100.0f) return 0;
+  return 1;
+}
+
+#define TFO_MESH_SLOTS (3 * 729)
+#define TFO_MESH_MAX_INDICES (512 * 15)
+
+/* ChunkManager::GenerateMeshEfficient (ChunkManager.cpp:595-1002) */
+int64_t tfo_mesh_chunk(const tfo_volume* v, const int id[3], float* verts, float* normals,
+                       float* colors, uint32_t* indices, int64_t* n_indices) {
+  const tfo_chunk* c0 = vol_get(v, id);
+  if (n_indices) *n_indices = 0;
+  if (!c0) return -1;
+  const float res = v->res;
+  const tfo_chunk* nb[8];
+  int32_t nbid[8][3];
+  for (int i = 0; i < 8; i++) { /* :618-632 */
+    nbid[i][0] = id[0] + (i % 2); nbid[i][1] = id[1] + (i % 4) / 2; nbid[i][2] = id[2] + i / 4;
+    nb[i] = i ? vol_get(v, nbid[i]) : c0;
+  }
+  /* Chunk origin (Chunk.cpp:52) and CacheCentroids' table (ChunkManager.cpp:49-63) */
+  const float org[3] = {(float)(8 * id[0]) * res, (float)(8 * id[1]) * res, (float)(8 * id[2]) * res};
+  const float half = res * 0.5f;
+  float* vbe = (float*)malloc(sizeof(float) * 3 * TFO_MESH_SLOTS * 3);
+  float* cbe = vbe + 3 * TFO_MESH_SLOTS;
+  float* nbe = cbe + 3 * TFO_MESH_SLOTS;
+  uint8_t used[TFO_MESH_SLOTS];
+  memset(used, 0, sizeof(used)); /* colorByEdge == (-1,-1,-1) <=> never written (:649,:890) */
+  int64_t ni = 0;
+  float cube[8]; /* cornerSDF lives across cells (:636); stale lanes are never consumed */
+  for (int i = 0; i < 8; i++) cube[i] = 0.0f;
+  for (int z = 0; z < 8; z++)
+    for (int y = 0; y < 8; y++)
+      for (int x = 0; x < 8; x++) {
+        const int cell[3] = {x, y, z};
+        float cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int observed = 1, pos = 0;
+        int cvi[8], cch[8];
+        for (int k = 0; k < 8; k++) { /* :669-720; neighbor*IndexChunkWise LUTs :77-107 */
+          const int cx = x + kCorner[k][0], cy = y + kCorner[k][1], cz = z + kCorner[k][2];
+          cch[k] = (cx == 8) + (cy == 8) * 2 + (cz == 8) * 4;
+          cvi[k] = (cx & 7) + (cy & 7) * 8 + (cz & 7) * 64;
+        }
+        for (int k = 0; k < 8; k++) {
+          if (!nb[cch[k]]) { observed = 0; break; }
+          const float s = nb[cch[k]]->sdf[cvi[k]];
+          cw[k] = nb[cch[k]]->weight[cvi[k]];
+          if (s > 1.0f) { observed = 0; break; }
+          cube[k] = s;
+          pos += s > 0.0f;
+        }
+        if (!(observed && pos % 8 > 0)) continue; /* :722 */
+        int index = 0;
+        for (int k = 0; k < 8; k++) index |= (0.0f > cube[k]) << k; /* :726-735 */
+        const unsigned long long row = tfo_mc_tri_table[index];
+        if ((row & 0xF) == 0xF) continue; /* :747 */
+        const float origin[3] = {org[0] + ((float)x * res + half), org[1] + ((float)y * res + half),
+                                 org[2] + ((float)z * res + half)};
+        float ev[12][3], en[12][3], ec[12][3];
+        int nvalid[12];
+        for (int e = 0; e < 12; e++) { /* :748-834 */
+          nvalid[e] = 0;
+          const int e0 = kEdgePair[e][0], e1 = kEdgePair[e][1];
+          const float s0 = cube[e0], s1 = cube[e1];
+          if (!(s0 * s1 < 0.0f)) continue;
+          const float t = s0 / (s0 - s1);
+          for (int a = 0; a < 3; a++) {
+            const float p0 = (float)kCorner[e0][a] * res, p1 = (float)kCorner[e1][a] * res;
+            ev[e][a] = p0 + t * (p1 - p0);
+          }
+          const int k = kEdgePair[e][fabsf(s0) > fabsf(s1)];
+          float grad[3] = {0, 0, 0};
+          const int ok = gradient_from_cubic(v, cube, cell, k, cvi[k], nbid[cch[k]], grad);
+          if (cw[k] > 50.0f) { /* :776-827 */
+            for (int a = 0; a < 3; a++) en[e][a] = grad[a];
+            const uint16_t* col = nb[cch[k]]->color + cvi[k] * 4;
+            const float cwt = (float)col[3];
+            if (cwt > 0.0f) {
+              for (int a = 0; a < 3; a++) ec[e][a] = ((float)col[a] / 255.0f) / cwt;
+            } else {
+              ec[e][0] = ec[e][1] = ec[e][2] = 1.0f;
+            }
+            nvalid[e] = ok;
+          }
+        }
+        for (int col = 0; col < 15 && ((row >> (4 * col)) & 0xF) != 0xF; col += 3) { /* :836-918 */
+          const int s[3] = {(int)((row >> (4 * col + 8)) & 0xF), (int)((row >> (4 * col + 4)) & 0xF),
+                            (int)((row >> (4 * col)) & 0xF)}; /* s2, s1, s0 */
+          if (!nvalid[s[0]] || !nvalid[s[1]] || !nvalid[s[2]]) continue;
+          for (int q = 0; q < 3; q++) {
+            const int e = s[q];
+            const int bx = x + (e == 1 || e == 5 || e == 9 || e == 10);
+            const int by = y + (e == 2 || e == 6 || e == 10 || e == 11);
+            const int bz = z + (e == 4 || e == 5 || e == 6 || e == 7);
+            const int ax = (e == 0 || e == 2 || e == 4 || e == 6) ? 0 : ((e == 1 || e == 3 || e == 5 || e == 7) ? 1 : 2);
+            const int m = ax + (bx + by * 9 + bz * 81) * 3;
+            for (int a = 0; a < 3; a++) {
+              vbe[3 * m + a] = ev[e][a] + origin[a];
+              cbe[3 * m + a] = ec[e][a];
+              nbe[3 * m + a] = en[e][a];
+            }
+            used[m] = 1;
+            if (indices && ni < TFO_MESH_MAX_INDICES) indices[ni] = (uint32_t)m;
+            ni++;
+          }
+        }
+      }
+  /* de-duplication by edge slot (:886-897) */
+  int ref[TFO_MESH_SLOTS];
+  int64_t nv = 0;
+  for (int m = 0; m < TFO_MESH_SLOTS; m++) {
+    ref[m] = -1;
+    if (!used[m]) continue;
+    ref[m] = (int)nv;
+    for (int a = 0; a < 3; a++) {
+      if (verts) verts[3 * nv + a] = vbe[3 * m + a];
+      if (colors) colors[3 * nv + a] = cbe[3 * m + a];
+      if (normals) normals[3 * nv + a] = nbe[3 * m + a];
+    }
+    nv++;
+  }
+  if (indices)
+    for (int64_t i = 0; i < ni; i++) indices[i] = (uint32_t)ref[indices[i]];
+  if (n_indices) *n_indices = ni;
+  free(vbe);
+  return nv;
+}
+
+/* ---- allMeshes --------------------------------------------------------------------------- */
+static struct tfo_mesh* vol_get_mesh(const tfo_volume* v, const int32_t* id) {
+  int64_t i = map_find(&v->mesh_map, id);
+  return i < 0 ? NULL : &v->meshes[v->mesh_map.vals[i]];
+}
+static void mesh_release(struct tfo_mesh* m) {
+  free(m->verts); free(m->normals); free(m->colors); free(m->indices);
+  memset(m, 0, sizeof(*m));
+}
+static void vol_erase_mesh(tfo_volume* v, const int32_t* id) {
+  int64_t i = map_find(&v->mesh_map, id);
+  if (i < 0) return;
+  mesh_release(&v->meshes[v->mesh_map.vals[i]]);
+  map_erase(&v->mesh_map, id);
+}
+static void vol_meshes_clear(tfo_volume* v) {
+  for (int64_t i = 0; i < v->n_meshes; i++)
+    if (v->meshes[i].alive) mesh_release(&v->meshes[i]);
+  v->n_meshes = 0;
+  map_free(&v->mesh_map);
+  map_init(&v->mesh_map, 1 << 12);
+}
+
+/* Chisel::UpdateMeshes (Chisel.h:479-481) -> ChunkManager::RecomputeMeshes (ChunkManager.cpp:232-264):
+ * every chunk of meshesToUpdate that exists is re-meshed; a mesh enters allMeshes when it has
+ * vertices, and a mesh that is already there stays (possibly empty).  Returns the number of chunks
+ * meshed. */
+int64_t tfo_update_meshes(tfo_volume* v) {
+  int64_t n = 0;
+  float* vb = (float*)malloc(sizeof(float) * 9 * TFO_MESH_SLOTS);
+  uint32_t* ib = (uint32_t*)malloc(sizeof(uint32_t) * TFO_MESH_MAX_INDICES);
+  for (int64_t i = 0; i < v->dirty.cap; i++) {
+    if (v->dirty.vals[i] < 0) continue;
+    const int32_t* id = v->dirty.keys + 3 * i;
+    if (!vol_get(v, id)) continue;
+    int64_t ni = 0;
+    const int64_t nv = tfo_mesh_chunk(v, id, vb, vb + 3 * TFO_MESH_SLOTS, vb + 6 * TFO_MESH_SLOTS, ib, &ni);
+    n++;
+    struct tfo_mesh* m = vol_get_mesh(v, id);
+    if (!m) {
+      if (nv <= 0) continue;
+      if (v->n_meshes == v->cap_meshes) {
+        v->cap_meshes = v->cap_meshes ? v->cap_meshes * 2 : 4096;
+        v->meshes = (struct tfo_mesh*)realloc(v->meshes, sizeof(struct tfo_mesh) * v->cap_meshes);
+      }
+      m = &v->meshes[v->n_meshes];
+      memset(m, 0, sizeof(*m));
+      memcpy(m->id, id, 12);
+      m->alive = 1;
+      map_put(&v->mesh_map, id, v->n_meshes++);
+    }
+    free(m->verts); free(m->normals); free(m->colors); free(m->indices);
+    m->nv = (int32_t)nv; m->ni = (int32_t)ni;
+    m->verts = (float*)malloc(sizeof(float) * 3 * (nv ? nv : 1));
+    m->normals = (float*)malloc(sizeof(float) * 3 * (nv ? nv : 1));
+    m->colors = (float*)malloc(sizeof(float) * 3 * (nv ? nv : 1));
+    m->indices = (uint32_t*)malloc(sizeof(uint32_t) * (ni ? ni : 1));
+    memcpy(m->verts, vb, sizeof(float) * 3 * nv);
+    memcpy(m->normals, vb + 3 * TFO_MESH_SLOTS, sizeof(float) * 3 * nv);
+    memcpy(m->colors, vb + 6 * TFO_MESH_SLOTS, sizeof(float) * 3 * nv);
+    memcpy(m->indices, ib, sizeof(uint32_t) * ni);
+    memset(m->adj, 0, 6); /* Mesh::Clear (Mesh.h:52-68) */
+    m->simplified = 0;
+  }
+  free(vb); free(ib);
+  return n;
+}
+
+int64_t tfo_volume_num_meshes(const tfo_volume* v) { return v->mesh_map.live; }
+int64_t tfo_volume_list_meshes(const tfo_volume* v, int32_t* ids, int64_t cap) {
+  int64_t n = 0;
+  for (int64_t i = 0; i < v->n_meshes; i++)
+    if (v->meshes[i].alive) {
+      if (n < cap) memcpy(ids + 3 * n, v->meshes[i].id, 12);
+      n++;
+    }
+  return n;
+}
+/* counts first (buffers may be NULL), then the arrays */
+int tfo_volume_get_mesh(const tfo_volume* v, const int id[3], int64_t* nv, int64_t* ni, float* verts,
+                        float* normals, float* colors, uint32_t* indices, uint8_t adj[6], int* simplified) {
+  const struct tfo_mesh* m = vol_get_mesh(v, id);
+  if (!m) return -1;
+  if (nv) *nv = m->nv;
+  if (ni) *ni = m->ni;
+  if (verts) memcpy(verts, m->verts, sizeof(float) * 3 * m->nv);
+  if (normals) memcpy(normals, m->normals, sizeof(float) * 3 * m->nv);
+  if (colors) memcpy(colors, m->colors, sizeof(float) * 3 * m->nv);
+  if (indices) memcpy(indices, m->indices, sizeof(uint32_t) * m->ni);
+  if (adj) memcpy(adj, m->adj, 6);
+  if (simplified) *simplified = m->simplified;
+  return 0;
+}
+
+/* Mesh::SimplifyByClustering / GetIndice (3rd_party/open_chisel/geometry/Mesh.cpp:39-83): only the
+ * adjacency flags survive -- a vertex in grid cell <= 0 / >= GRID_EACH_DIM (8) of an axis marks that
+ * face.  verts[3*nv], origin = Chunk::GetOrigin(), grid = resolution * (8 / GRID_EACH_DIM). */
+void tfo_mesh_adjacency(const float* verts, int64_t nv, const float origin[3], float grid, uint8_t adj[6]) {
+  for (int64_t i = 0; i < nv; i++)
+    for (int j = 0; j < 3; j++) {
+      const int pos = (int)floor((double)((verts[3 * i + j] - origin[j]) / grid));
+      if (pos >= 8) adj[2 * j + 1] = 1;
+      if (pos <= 0) adj[2 * j] = 1;
+    }
+}
+
+/* Chisel::CompressMeshes (Structure/Chisel.cpp:112-147) on meshesToUpdate: adjacency flags of the
+ * dirty chunks' meshes, exchanged with the face neighbours' meshes, then meshesToUpdate.clear().
+ * out_ids (optional) receives tsdfFusion's chunksToUpdate -- the dirty keys that have a mesh
+ * (GCFusion/MobileFusion.cpp:345-353) -- in ascending (x, y, z) order: the reference's order is its
+ * unordered_map's iteration order, i.e. unspecified; the harness defines it. */
+static int cmp_id3(const void* a, const void* b) {
+  const int32_t* p = (const int32_t*)a; const int32_t* q = (const int32_t*)b;
+  for (int k = 0; k < 3; k++) if (p[k] != q[k]) return p[k] < q[k] ? -1 : 1;
+  return 0;
+}
+int64_t tfo_compress_meshes(tfo_volume* v, int32_t* out_ids, int64_t cap) {
+  static const int nbh[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+  int64_t n = 0;
+  int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * 3 * (v->dirty.live ? v->dirty.live : 1));
+  for (int64_t i = 0; i < v->dirty.cap; i++) {
+    if (v->dirty.vals[i] < 0) continue;
+    const int32_t* id = v->dirty.keys + 3 * i;
+    if (!vol_get_mesh(v, id)) continue;
+    memcpy(ids + 3 * n, id, 12);
+    n++;
+  }
+  qsort(ids, (size_t)n, 12, cmp_id3);
+  const float grid = v->res * (float)(8 / 8);
+  for (int64_t i = 0; i < n; i++) {
+    struct tfo_mesh* m = vol_get_mesh(v, ids + 3 * i);
+    if (m->simplified) continue;
+    const float org[3] = {(float)(8 * m->id[0]) * v->res, (float)(8 * m->id[1]) * v->res,
+                          (float)(8 * m->id[2]) * v->res};
+    tfo_mesh_adjacency(m->verts, m->nv, org, grid, m->adj);
+    m->simplified = 1;
+  }
+  for (int64_t i = 0; i < n; i++) {
+    struct tfo_mesh* m = vol_get_mesh(v, ids + 3 * i);
+    for (int k = 0; k < 6; k++) {
+      const int32_t q[3] = {m->id[0] + nbh[k][0], m->id[1] + nbh[k][1], m->id[2] + nbh[k][2]};
+      struct tfo_mesh* a = vol_get_mesh(v, q);
+      if (!a || !a->simplified) continue;
+      const int mm = (k % 2 == 0) ? k + 1 : k - 1;
+      if (m->adj[k] && !a->adj[mm]) a->adj[mm] = 1;
+      if (!m->adj[k] && a->adj[mm]) m->adj[k] = 1;
+    }
+  }
+  if (out_ids) memcpy(out_ids, ids, sizeof(int32_t) * 3 * (size_t)(n < cap ? n : cap));
+  free(ids);
+  tfo_volume_clear_dirty(v);
+  return n;
 }

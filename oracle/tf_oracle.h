@@ -184,6 +184,31 @@ int tfo_patches_batch(tfo_atlas* a, int64_t n_patches, const uint64_t* texloc, c
 void tfo_atlas_hot_range(const tfo_atlas* a, const uint64_t* texlocs, int64_t n,
                          uint64_t* hot_start, uint64_t* hot_end);
 
+/* ---- meshing ------------------------------------------------
+ * ChunkManager::GenerateMeshEfficient (Structure/ChunkManager.cpp:595-1002) incl.
+ * extractGradientFromCubic (:277-455) for one chunk of the volume: marching cubes over the 512
+ * cells (corners may live in the 7 chunks id + {0,1}^3, gradients read the face neighbours of
+ * those), vertices kept when the corner's weight > 50 and its gradient is valid, de-duplicated on
+ * the 9x9x9x3 edge grid (last writer in cell order wins), indices remapped.  Buffers (may be NULL):
+ * verts / normals / colors f32[3 * 2187], indices u32[7680].  Returns the vertex count, -1 when
+ * the chunk does not exist; *n_indices = index count. */
+#define TFO_MESH_MAX_VERTS 2187
+#define TFO_MESH_MAX_INDS 7680
+int64_t tfo_mesh_chunk(const tfo_volume* v, const int id[3], float* verts, float* normals,
+                       float* colors, uint32_t* indices, int64_t* n_indices);
+/* Chisel::UpdateMeshes (Structure/Chisel.h:479-481) = ChunkManager::RecomputeMeshes
+ * (Structure/ChunkManager.cpp:232-264) over meshesToUpdate; returns the number of chunks meshed */
+int64_t tfo_update_meshes(tfo_volume* v);
+int64_t tfo_volume_num_meshes(const tfo_volume* v);
+int64_t tfo_volume_list_meshes(const tfo_volume* v, int32_t* ids, int64_t cap);
+int tfo_volume_get_mesh(const tfo_volume* v, const int id[3], int64_t* nv, int64_t* ni, float* verts,
+                        float* normals, float* colors, uint32_t* indices, uint8_t adj[6], int* simplified);
+/* Mesh::SimplifyByClustering / GetIndice (3rd_party/open_chisel/geometry/Mesh.cpp:39-83) */
+void tfo_mesh_adjacency(const float* verts, int64_t nv, const float origin[3], float grid, uint8_t adj[6]);
+/* Chisel::CompressMeshes (Structure/Chisel.cpp:112-147) on meshesToUpdate (which it clears);
+ * out_ids = tsdfFusion's chunksToUpdate (GCFusion/MobileFusion.cpp:345-353) in ascending id order */
+int64_t tfo_compress_meshes(tfo_volume* v, int32_t* out_ids, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,167 @@
+"""HIP meshing (k_mesh behind tf_update_meshes / tf_compress_meshes) vs the oracle's restatement of
+ChunkManager::GenerateMeshEfficient / RecomputeMeshes / Mesh::SimplifyByClustering / Chisel::CompressMeshes:
+mesh keys, vertex / index counts and order, vertices, normals, colours, adjacency flags -- bit for bit."""
+import numpy as np
+import pytest
+
+from oracle import api as O
+from texturefusion_amd import synth
+from tests.util import RES5, RES10, assert_chunks_equal, make_pair, sorted_ids
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare_meshes(ov, gv, what=""):
+    oids = sorted_ids(ov.list_meshes())
+    gids = sorted_ids(gv.list_meshes())
+    assert np.array_equal(oids, gids), "%s: allMeshes keys differ (%d vs %d)" % (what, len(oids), len(gids))
+    if len(oids) == 0:
+        return 0
+    voff, ioff, V, N, Cc, I, adj, simp = gv.get_meshes(oids)
+    for i, cid in enumerate(oids):
+        m = ov.get_mesh(cid)
+        a, b = voff[i], voff[i + 1]
+        assert b - a == len(m["verts"]), "%s: vertex count of %s: %d vs %d" % (what, cid, b - a, len(m["verts"]))
+        assert ioff[i + 1] - ioff[i] == len(m["indices"]), "%s: index count of %s" % (what, cid)
+        assert np.array_equal(I[ioff[i]:ioff[i + 1]], m["indices"]), "%s: indices of %s" % (what, cid)
+        for name, dev, ref in (("vertices", V, m["verts"]), ("normals", N, m["normals"]), ("colors", Cc, m["colors"])):
+            assert np.array_equal(dev[a:b].view(np.uint32), ref.view(np.uint32)), "%s: %s of %s differ" % (what, name, cid)
+        assert bool(simp[i]) == m["simplified"]
+        if m["simplified"]:
+            assert np.array_equal(adj[i], m["adj"]), "%s: adj of %s" % (what, cid)
+    return len(oids)
+
+
+def _run(frames, cam, res, **kw):
+    ov, gv, cam, ig = make_pair(res, cam, max_chunks=1 << 15, **kw)
+    for depth, rgba, pose in frames:
+        ov.integrate_frame(depth, rgba, pose)
+        gv.frame_upload(depth, rgba, None)
+        gv.integrate_frame(pose, True)
+    gv.sync()
+    return ov, gv
+
+
+def test_wall_meshes_match_oracle(gpu_required):
+    cam = synth.Camera()
+    frames = [synth.wall_frame(1.2, cam, seed=k) for k in range(5)]
+    ov, gv = _run([(f[0], f[1], f[3]) for f in frames], cam, RES5)
+    no = ov.update_meshes()
+    ng = gv.update_meshes()
+    assert ng == len(ov.dirty()) and no <= ng  # the dirty set includes ids of chunks that do not exist
+    assert _compare_meshes(ov, gv, "wall") > 500
+    # CompressMeshes: adjacency flags, chunksToUpdate (ascending), dirty set cleared
+    oc = ov.compress_meshes()
+    gc = gv.compress_meshes()
+    assert np.array_equal(oc, gc)
+    assert len(gv.dirty()) == 0
+    _compare_meshes(ov, gv, "wall after compress")
+    gv.close()
+
+
+def test_room_meshes_over_a_stream(gpu_required):
+    """S-room orbit: re-meshing of dirty chunks after every few frames (meshes that lose all vertices stay in
+    allMeshes, new ones enter), walls / floor / ceiling / corners, oblique views."""
+    cam = synth.Camera()
+    ov, gv, cam, ig = make_pair(RES5, cam, max_chunks=1 << 16)
+    total = 0
+    for k in range(12):
+        depth, rgba, q, pose = synth.room_frame(3 * k, cam, with_quality=False)
+        ov.integrate_frame(depth, rgba, pose)
+        gv.frame_upload(depth, rgba, None)
+        gv.integrate_frame(pose, True)
+        if k % 4 == 3:
+            ov.update_meshes()
+            gv.update_meshes()
+            total = _compare_meshes(ov, gv, "room frame %d" % k)
+            assert np.array_equal(ov.compress_meshes(), gv.compress_meshes())
+    assert total > 1000
+    assert_chunks_equal(ov, gv, sorted_ids(ov.list_chunks())[:50], "room")
+    gv.close()
+
+
+def test_tilted_plane_and_random_field(gpu_required):
+    """Synthetic chunk contents uploaded on both sides: a tilted linear field (every MC case along the cut,
+    vertices on all three edge families) and random sdf / weight / colour around the thresholds (sdf > 1, == 0,
+    weight <= 50, colour count 0, missing neighbour chunks)."""
+    cam = synth.Camera()
+    ov, gv, cam, ig = make_pair(RES5, cam, max_chunks=1 << 12, mesh_max_vertices=2240, mesh_max_triangles=2560)
+    rng = np.random.default_rng(5)
+    res = float(RES5)
+    nrm = np.array([0.3, -0.5, 0.81]); nrm /= np.linalg.norm(nrm)
+    d0 = float(nrm @ (np.array([4.0, 4.0, 4.0]) * res))
+    ids = []
+    for c in np.ndindex(3, 3, 3):
+        cid = np.array(c, np.int32) - 1
+        zz, yy, xx = np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij")
+        p = (np.stack([xx, yy, zz], -1).reshape(-1, 3) + cid * 8 + 0.5) * res
+        sdf = (p @ nrm - d0).astype(np.float32)
+        w = rng.choice(np.float32([49.0, 50.0, 51.0, 80.0]), 512, p=[0.05, 0.05, 0.1, 0.8]).astype(np.float32)
+        col = rng.integers(0, 4000, 2048).astype(np.uint16)
+        col[3::4] = rng.integers(0, 30, 512)
+        for v in (ov, gv):
+            v.set_chunk(cid, sdf, w, col)
+        ids.append(cid)
+    # a second cluster far away with random fields and a hole in the neighbourhood
+    for c in np.ndindex(3, 3, 3):
+        if c == (2, 1, 1):
+            continue
+        cid = np.array(c, np.int32) + 40
+        sdf = (rng.standard_normal(512) * 0.01).astype(np.float32)
+        sdf[rng.random(512) < 0.05] = 999.0
+        sdf[rng.random(512) < 0.05] = 0.0
+        sdf[rng.random(512) < 0.03] = 1.0
+        w = rng.choice(np.float32([0.0, 50.0, 50.5, 200.0]), 512).astype(np.float32)
+        col = rng.integers(0, 65535, 2048).astype(np.uint16)
+        col[3::4] = rng.integers(0, 3, 512)
+        for v in (ov, gv):
+            v.set_chunk(cid, sdf, w, col)
+        ids.append(cid)
+    # a dense random field: large meshes (beyond the default block size)
+    for c in np.ndindex(2, 2, 2):
+        cid = np.array(c, np.int32) - 40
+        sdf = (rng.standard_normal(512) * 0.01).astype(np.float32)
+        col = rng.integers(1, 9, 2048).astype(np.uint16)
+        for v in (ov, gv):
+            v.set_chunk(cid, sdf, np.full(512, 200.0, np.float32), col)
+        ids.append(cid)
+    ids = np.array(ids, np.int32)
+    # make every chunk dirty on both sides through the public flow: finalize with needsUpdate set
+    needs = np.ones(len(ids), np.uint8)
+    new = np.zeros(len(ids), np.uint8)
+    ov.finalize(ids, needs, new)
+    gv.finalize(ids, needs, new)
+    ov.update_meshes()
+    gv.update_meshes()
+    n = _compare_meshes(ov, gv, "synthetic fields")
+    assert n >= 40
+    big = max(len(ov.get_mesh(c)["verts"]) for c in ov.list_meshes())
+    assert big > 256  # the random field exceeds the default block size: this volume was created with the maximum
+    gv.close()
+
+
+def test_mesh_capacity_overflow_is_reported(gpu_required):
+    from texturefusion_amd import capi
+    cam = synth.Camera()
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 10, mesh_max_vertices=64, mesh_max_triangles=64)
+    rng = np.random.default_rng(1)
+    for c in np.ndindex(2, 2, 2):
+        cid = np.array(c, np.int32)
+        sdf = (rng.standard_normal(512) * 0.01).astype(np.float32)
+        gv.set_chunk(cid, sdf, np.full(512, 100.0, np.float32), np.ones(2048, np.uint16))
+    ids = np.array(list(np.ndindex(2, 2, 2)), np.int32)
+    gv.finalize(ids, np.ones(8, np.uint8), np.zeros(8, np.uint8))
+    with pytest.raises(capi.TFError) as e:
+        gv.update_meshes()
+    assert e.value.code == capi.TF_ERR_CAPACITY and "mesh" in str(e.value)
+    gv.close()
+
+
+def test_voxel_size_10mm(gpu_required):
+    cam = synth.Camera()
+    frames = [synth.wall_frame(1.0, cam, seed=k) for k in range(6)]
+    ov, gv = _run([(f[0], f[1], f[3]) for f in frames], cam, RES10)
+    ov.update_meshes()
+    gv.update_meshes()
+    assert _compare_meshes(ov, gv, "10 mm") > 100
+    gv.close()

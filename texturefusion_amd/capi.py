@@ -24,7 +24,7 @@ TF_ERR_MISSING_CHUNK = -6
 TF_BOUNDARY_RECORD_BYTES = 16 + 4096 + 4096
 
 PROF_NAMES = ("bbox", "select", "scan", "emit", "integrate", "finalize", "patch_project",
-              "atlas_blit")
+              "atlas_blit", "mesh", "dirty", "patch_rank", "spare")
 
 # every symbol include/tf_fusion.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
@@ -39,6 +39,7 @@ SYMBOLS = (
     "tf_atlas_patch_size", "tf_atlas_add_patch", "tf_atlas_loc_next", "tf_patches_update",
     "tf_patches_update_device", "tf_color_compensate", "tf_pack_vertices",
     "tf_atlas_download_rows",
+    "tf_update_meshes", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
 )
 
 
@@ -51,7 +52,8 @@ class TFError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_chunks", C.c_int64), ("max_list", C.c_int64),
                 ("max_coarse", C.c_int64), ("atlas_w", C.c_int32), ("atlas_h", C.c_int32),
-                ("max_keyframes", C.c_int32), ("reserved", C.c_int32)]
+                ("max_keyframes", C.c_int32), ("reserved", C.c_int32),
+                ("mesh_max_vertices", C.c_int32), ("mesh_max_triangles", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -62,7 +64,7 @@ class Stats(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_int64 * 8)]
+    _fields_ = [("ms", C.c_double * 12), ("launches", C.c_int64 * 12)]
 
 
 _lib = None
@@ -128,6 +130,12 @@ def lib():
     L.tf_pack_vertices.argtypes = [vp, C.c_int64, u8p, u8p, u8p, u64p, fp, i64p, fp, fp, fp, fp, fp, fp, i64p,
                                    C.POINTER(C.c_uint32), fp, C.POINTER(C.c_uint32), i64p, i64p]
     L.tf_atlas_download_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p]
+    u32p = C.POINTER(C.c_uint32)
+    L.tf_update_meshes.argtypes = [vp, i64p]
+    L.tf_list_meshes.argtypes = [vp, i32p, C.c_int64, i64p]
+    L.tf_mesh_counts.argtypes = [vp, i32p, C.c_int64, i32p, i32p, u8p, u8p]
+    L.tf_meshes_download.argtypes = [vp, i32p, C.c_int64, i64p, i64p, fp, fp, fp, u32p]
+    L.tf_compress_meshes.argtypes = [vp, i32p, C.c_int64, i64p]
     _lib = L
     return L
 
@@ -144,10 +152,12 @@ class Volume:
     """Device-resident chunk volume + atlas behind one tf_volume handle."""
 
     def __init__(self, res, cam=None, max_chunks=1 << 17, max_list=1 << 18, max_coarse=1 << 20,
-                 atlas_w=0, atlas_h=0, device=0, use_color=True, stream=None):
+                 atlas_w=0, atlas_h=0, device=0, use_color=True, stream=None, mesh_max_vertices=0,
+                 mesh_max_triangles=0):
         self.L = lib()
         self.h = C.c_void_p()
-        cfg = Config(device, max_chunks, max_list, max_coarse, atlas_w, atlas_h, 0, 0)
+        cfg = Config(device, max_chunks, max_list, max_coarse, atlas_w, atlas_h, 0, 0, mesh_max_vertices,
+                     mesh_max_triangles)
         dims = (C.c_int32 * 3)(8, 8, 8)
         rc = self.L.tf_volume_create(dims, np.float32(res), int(use_color), C.byref(cfg), C.byref(self.h))
         if rc != TF_OK:
@@ -309,6 +319,51 @@ class Volume:
         st = Stats()
         self._ck(self.L.tf_get_stats(self.h, C.byref(st)))
         return st
+
+    # -- meshing (Chisel::UpdateMeshes / CompressMeshes, ChunkManager::allMeshes)
+    def update_meshes(self):
+        n = C.c_int64(0)
+        self._ck(self.L.tf_update_meshes(self.h, C.byref(n)))
+        return n.value
+
+    def list_meshes(self):
+        return self._list(self.L.tf_list_meshes)
+
+    def mesh_counts(self, ids):
+        """-> (n_vertices i32[n], n_indices i32[n], adj u8[n,6], simplified u8[n])"""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        n = len(ids)
+        nv = np.zeros(max(n, 1), np.int32); ni = np.zeros(max(n, 1), np.int32)
+        adj = np.zeros((max(n, 1), 6), np.uint8); simp = np.zeros(max(n, 1), np.uint8)
+        self._ck(self.L.tf_mesh_counts(self.h, _p(ids, C.c_int32), n, _p(nv, C.c_int32), _p(ni, C.c_int32),
+                                       _p(adj, C.c_uint8), _p(simp, C.c_uint8)))
+        return nv[:n], ni[:n], adj[:n], simp[:n]
+
+    def get_meshes(self, ids):
+        """Mesh::vertices / normals / colors / indices of the listed chunks ->
+        (voff i64[n+1], ioff i64[n+1], verts [nv,3], normals, colors, indices u32[ni], adj, simplified)"""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        n = len(ids)
+        nv, ni, adj, simp = self.mesh_counts(ids)
+        voff = np.concatenate([[0], np.cumsum(nv)]).astype(np.int64)
+        ioff = np.concatenate([[0], np.cumsum(ni)]).astype(np.int64)
+        V = np.zeros((max(int(voff[-1]), 1), 3), np.float32); N = np.zeros_like(V); Cc = np.zeros_like(V)
+        I = np.zeros(max(int(ioff[-1]), 1), np.uint32)
+        self._ck(self.L.tf_meshes_download(self.h, _p(ids, C.c_int32), n, _p(voff, C.c_int64), _p(ioff, C.c_int64),
+                                           _p(V, C.c_float), _p(N, C.c_float), _p(Cc, C.c_float), _p(I, C.c_uint32)))
+        return voff, ioff, V[:voff[-1]], N[:voff[-1]], Cc[:voff[-1]], I[:ioff[-1]], adj, simp
+
+    def compress_meshes(self):
+        """Chisel::CompressMeshes(meshesToUpdate) -> chunksToUpdate (ascending id); clears the dirty set."""
+        n = C.c_int64(0)
+        cap = 1 << 16
+        while True:
+            ids = np.zeros((cap, 3), np.int32)
+            rc = self.L.tf_compress_meshes(self.h, _p(ids, C.c_int32), cap, C.byref(n))
+            if rc == TF_ERR_CAPACITY and n.value > cap:
+                raise TFError(rc, "compress_meshes: list larger than %d" % cap)
+            self._ck(rc)
+            return ids[:n.value].copy()
 
     # -- measurement
     def profile_enable(self, kinds=PROF_NAMES):

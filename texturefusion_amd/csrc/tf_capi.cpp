@@ -117,7 +117,10 @@ static int status_to_error(uint32_t st) {
   if (st & kStCoarseFull) m += " candidate grid full (raise tf_config.max_coarse)";
   if (st & kStMissing) m += " list names a chunk that does not exist";
   if (st & kStHashFull) m += " hash table full";
+  if (st & kStMeshFull) m += " a mesh exceeds the per-chunk mesh block (raise tf_config.mesh_max_vertices / mesh_max_triangles)";
+  if (st & kStAtlasFull) m += " No enough space for texture storage.";  // std::overflow_error text, Atlas.cpp:53
   set_error(m);
+  if (st & kStAtlasFull) return TF_ERR_ATLAS_FULL;
   if (st & kStMissing) return TF_ERR_MISSING_CHUNK;
   return TF_ERR_CAPACITY;
 }
@@ -153,9 +156,11 @@ static int init_device_state(tf_volume* v) {
   v->cur_sel = 0;
   d.sel = v->selbuf[0];
   launch_fill_pool(d, 0, d.max_chunks, s);
+  launch_init_meshes(d, s);  // chunkManager.Reset(): allMeshes.clear() (ChunkManager.cpp:272-275)
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
   v->epoch = 0;
+  v->mesh_epoch = 0;
   return TF_OK;
 }
 
@@ -254,6 +259,10 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   if (v->cfg.atlas_w <= 0) v->cfg.atlas_w = 13824;
   if (v->cfg.atlas_h <= 0) v->cfg.atlas_h = 13824;
   if (v->cfg.max_keyframes <= 0) v->cfg.max_keyframes = 64;
+  if (v->cfg.mesh_max_vertices <= 0) v->cfg.mesh_max_vertices = 256;
+  if (v->cfg.mesh_max_triangles <= 0) v->cfg.mesh_max_triangles = 512;
+  v->cfg.mesh_max_vertices = std::min((v->cfg.mesh_max_vertices + 63) & ~63, 2240);    // whole wave rows
+  v->cfg.mesh_max_triangles = std::min((v->cfg.mesh_max_triangles + 63) & ~63, 2560);
   if (v->cfg.device < 0 || v->cfg.device >= ndev) {
     set_error("tf_config.device out of range");
     delete v;
@@ -291,6 +300,11 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   if ((rc = dev_alloc(v, &d.erase_epoch, (size_t)d.max_chunks))) return fail(rc);
   if ((rc = dev_alloc(v, &d.phase_buf, (size_t)kPhaseWaves * 16))) return fail(rc);
   if ((rc = dev_alloc(v, &d.vctl, (size_t)1))) return fail(rc);
+  d.mesh_cv = (uint32_t)v->cfg.mesh_max_vertices;
+  d.mesh_ct = (uint32_t)v->cfg.mesh_max_triangles;
+  if ((rc = dev_alloc(v, &d.mesh_v, (size_t)d.max_chunks * kMeshPlanes * d.mesh_cv))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.mesh_t, (size_t)d.max_chunks * 3 * d.mesh_ct))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.mesh_rec, (size_t)d.max_chunks))) return fail(rc);
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
     SelBuf& L = v->selbuf[k];
     if ((rc = dev_alloc(v, &L.masks, (size_t)d.max_coarse))) return fail(rc);

@@ -1,0 +1,107 @@
+// tf_devfn.h -- device-side helpers shared by the kernel files: chunk-id packing, the chunk hash
+// (lookup / find-or-create), the multi-GPU ownership key.
+#pragma once
+
+#include "tf_device.h"
+
+namespace tf {
+
+__device__ __forceinline__ unsigned long long pack_id(int x, int y, int z) {
+  return ((unsigned long long)((uint32_t)(x + (1 << 20)) & 0x1FFFFFu) << 42) |
+         ((unsigned long long)((uint32_t)(y + (1 << 20)) & 0x1FFFFFu) << 21) |
+         (unsigned long long)((uint32_t)(z + (1 << 20)) & 0x1FFFFFu);
+}
+__device__ __forceinline__ int4 unpack_id(unsigned long long k) {
+  int4 r;
+  r.x = (int)((k >> 42) & 0x1FFFFFu) - (1 << 20);
+  r.y = (int)((k >> 21) & 0x1FFFFFu) - (1 << 20);
+  r.z = (int)(k & 0x1FFFFFu) - (1 << 20);
+  r.w = 0;
+  return r;
+}
+// multi-GPU ownership key of a chunk id (VolumeDev::part_*)
+__device__ __forceinline__ int part_key(const VolumeDev& v, int x, int y, int z) {
+  return v.part_a * x + v.part_b * y + v.part_c * z;
+}
+__device__ __forceinline__ bool part_owned(const VolumeDev& v, int x, int y, int z) {
+  const int k = part_key(v, x, y, z);
+  return k >= v.part_lo && k < v.part_hi;
+}
+// Chunks of this slab another rank reads as ghosts.  The mesher of a chunk c reads c + {0,1}^3
+// (Structure/ChunkManager.cpp:618-632) and the six face neighbours of each of those (gradients,
+// :288-315): key offsets -1 .. (a + b + c) + 1.  So the rank below needs this slab's keys
+// lo .. lo + (a + b + c), the rank above needs key hi - 1 (which also covers the +-1 layer the
+// dirty-mark closure of Chisel.h:197-203 looks at).
+__device__ __forceinline__ bool part_band(const VolumeDev& v, int x, int y, int z) {
+  const long long k = part_key(v, x, y, z);
+  const long long s = v.part_a + v.part_b + v.part_c;
+  return (k >= (long long)v.part_lo && k - (long long)v.part_lo <= s) || k == (long long)v.part_hi - 1;
+}
+
+// Fibonacci hashing folded to 32 bits: every bit of (x, y, z) reaches the index bits (the upper
+// half of the product carries z, the lower half x and y), so columns of chunks do not share a home.
+__device__ __forceinline__ uint32_t hash_key(unsigned long long k) {
+  const unsigned long long h = k * 0x9E3779B97F4A7C15ull;
+  return (uint32_t)(h >> 32) ^ (uint32_t)h;
+}
+
+
+// Lookup only.  Entries are never removed, so the probe sequence of a present key is stable.
+// Returns the entry index or kInvalidSlot.
+__device__ __forceinline__ uint32_t hash_find(const VolumeDev& v, unsigned long long key) {
+  uint32_t i = hash_key(key) & v.hmask;
+  for (uint32_t probe = 0; probe <= v.hmask; ++probe) {
+    const unsigned long long cur = v.hent[i].key;
+    if (cur == key) return i;
+    if (cur == kEmptyKey) return kInvalidSlot;
+    i = (i + 1) & v.hmask;
+  }
+  return kInvalidSlot;
+}
+
+// Find or create the pool slot of a chunk id (general path: probing, insertion, revival).
+// Within one launch every key is unique (the visible list has no duplicates), so the payload of
+// a freshly inserted key is only read by later launches.  *is_new = chunk did not exist (absent
+// or parked); *ent = hash entry index.
+__device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, bool* is_new,
+                                               uint32_t* ent) {
+  const unsigned long long key = pack_id(id.x, id.y, id.z);
+  uint32_t i = hash_key(key) & v.hmask;
+  *is_new = true;
+  for (uint32_t probe = 0; probe <= v.hmask; ++probe) {
+    unsigned long long cur = v.hent[i].key;
+    if (cur == kEmptyKey) {
+      cur = atomicCAS(&v.hent[i].key, kEmptyKey, key);
+      if (cur == kEmptyKey) {  // inserted: allocate a fresh slot (storage is in the fresh state)
+        *ent = i;
+        const uint32_t stripe = (hash_key(key) >> 7) & (kSlotStripes - 1);
+        const uint32_t per = v.max_chunks / kSlotStripes;
+        const uint32_t k = atomicAdd(&v.vctl->slot_cnt[stripe], 1u);
+        const uint32_t slot = stripe * per + k;
+        if (k >= per) {
+          atomicOr(&v.vctl->status, kStPoolFull);
+          v.hent[i].slot = kInvalidSlot;
+          v.hent[i].alive = 0;
+          return kInvalidSlot;
+        }
+        v.hent[i].slot = slot;
+        v.hent[i].alive = 1;
+        return slot;
+      }
+    }
+    if (cur == key) {
+      *ent = i;
+      const uint32_t slot = v.hent[i].slot;
+      if (slot == kInvalidSlot) return slot;
+      if (!v.hent[i].alive) v.hent[i].alive = 1;  // parked chunk: revive, still "new"
+      else *is_new = false;
+      return slot;
+    }
+    i = (i + 1) & v.hmask;
+  }
+  atomicOr(&v.vctl->status, kStHashFull);
+  *ent = 0;
+  return kInvalidSlot;
+}
+
+}  // namespace tf

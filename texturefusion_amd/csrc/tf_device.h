@@ -29,6 +29,8 @@ constexpr uint32_t kStListFull = 2u;
 constexpr uint32_t kStCoarseFull = 4u;
 constexpr uint32_t kStMissing = 8u;
 constexpr uint32_t kStHashFull = 16u;
+constexpr uint32_t kStMeshFull = 32u;   // a mesh exceeds tf_config.mesh_max_vertices / mesh_max_triangles
+constexpr uint32_t kStAtlasFull = 64u;  // Atlas::AddPatch overflow (std::overflow_error, Atlas.cpp:52-53)
 
 struct Cam {
   int W, H;
@@ -91,6 +93,37 @@ struct SelBuf {
   FrameCtl* ctl;
 };
 
+// ---- device-resident meshes (ChunkManager::allMeshes) and their patches (Mesh::m_patch) ----------
+// One fixed block per pool slot, planar (lane = vertex / triangle, every plane row is a coalesced
+// segment):  mesh_v [slot][17][CV] f32 -- Mesh::vertices x y z | normals x y z | colors r g b |
+// Patch::texcoord u v | texcolor r g b | labs r g b;  mesh_t [slot][3][CT] u16 -- Mesh::indices as
+// triangle corner planes (a mesh has at most 3 * 729 vertices).  CV / CT come from tf_config
+// (mesh_max_vertices / mesh_max_triangles); the theoretical maximum is 2187 / 2560.
+constexpr int kMeshPlanes = 17;
+constexpr int kMpPos = 0, kMpNrm = 3, kMpCol = 6, kMpTc = 9, kMpTcol = 11, kMpLabs = 14;
+constexpr unsigned long long kNoTexloc = ~0ull;
+constexpr uint32_t kMsInMap = 1u;       // the chunk has an entry in allMeshes (ChunkManager::HasMesh)
+constexpr uint32_t kMsSimplified = 2u;  // Mesh::simplified
+constexpr uint32_t kMsOverflow = 4u;    // did not fit CV / CT: stored empty, kStMeshFull raised
+constexpr int kMsAdjShift = 8;          // bits 8..13 = Mesh::adj[0..5]
+constexpr uint32_t kPfHasPatch = 1u;    // Atlas::HasPatch
+constexpr uint32_t kPfCaution = 2u;     // CalculateTexCoords returned -1
+constexpr uint32_t kPfWrong = 4u;       // Patch::wrong_mapping
+constexpr uint32_t kPfHasImage = 8u;    // Patch::has_image
+constexpr uint32_t kPfAdjusted = 16u;   // Patch::has_adjusted
+struct __attribute__((aligned(16))) MeshRec {  // 64 B per pool slot
+  uint32_t nv, nt;
+  uint32_t state;
+  uint32_t epoch;             // the meshing pass that wrote the block (0 = never)
+  unsigned long long texloc;  // Patch::texloc (linear texel index of the atlas slot), kNoTexloc = no slot yet
+  int32_t frameid;            // Patch::frameid
+  uint32_t pflags;
+  int32_t bbox[4];            // Patch::boundingbox x y w h
+  float ratio[2];             // Patch::ratio
+  int32_t n_caution;
+  uint32_t stamp;             // de-duplication stamp of the per-frame dirty list
+};
+
 constexpr int kPhaseWaves = 16384;  // rows of the wave-timeline table (tuning aid)
 
 struct VolumeDev {
@@ -115,8 +148,19 @@ struct VolumeDev {
   // iff part_lo <= key < part_hi; (1, 0, 0) = ChunkID.x slabs
   int32_t part_lo, part_hi;
   int32_t part_a, part_b, part_c;
+  // meshes
+  float* mesh_v;
+  uint16_t* mesh_t;
+  MeshRec* mesh_rec;
+  uint32_t mesh_cv, mesh_ct;
   SelBuf sel;  // the selection set the launch works on
 };
+__host__ __device__ inline float* mesh_plane(const VolumeDev& v, uint32_t slot, int plane) {
+  return v.mesh_v + ((size_t)slot * kMeshPlanes + plane) * v.mesh_cv;
+}
+__host__ __device__ inline uint16_t* tri_plane(const VolumeDev& v, uint32_t slot, int corner) {
+  return v.mesh_t + ((size_t)slot * 3 + corner) * v.mesh_ct;
+}
 
 struct FrameImages {
   const float* depth;
@@ -158,5 +202,10 @@ void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const f
                           const uint16_t* col, hipStream_t s);
 void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s);
 void launch_boundary_unpack(const VolumeDev& v, const uint8_t* records, uint32_t n, hipStream_t s);
+// ---- launchers (tf_mesh.hip) ---------------------------------------------------------
+// dlist: int4 {id.x, id.y, id.z, -} per dirty chunk, *dcount entries
+void launch_init_meshes(const VolumeDev& v, hipStream_t s);
+void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
+                 uint32_t epoch, float res, hipStream_t s);
 
 }  // namespace tf

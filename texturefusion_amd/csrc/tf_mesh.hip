@@ -1,0 +1,651 @@
+// tf_mesh.hip -- marching-cubes meshing of dirty chunks on the device.
+//
+//   k_mesh           ChunkManager::GenerateMeshEfficient + extractGradientFromCubic
+//                    (Structure/ChunkManager.cpp:595-1002, :277-455), RecomputeMeshes' bookkeeping
+//                    (:232-264) and Mesh::SimplifyByClustering's own adjacency flags
+//                    (3rd_party/open_chisel/geometry/Mesh.cpp:39-83)
+//   k_compress       Chisel::CompressMeshes' neighbour exchange of the flags (Structure/Chisel.cpp:127-145)
+//   k_list_meshes / k_mesh_counts / k_mesh_gather   host mirrors of ChunkManager::allMeshes
+//
+// One workgroup per chunk.  The chunk's 8^3 cells read the sdf of the 9^3 cell corners and, for the
+// gradient normals, one more voxel on every side: the whole 11^3 neighbourhood (27 chunks) is
+// staged in LDS once, a chunk that does not exist reads as the fresh state (sdf 999, weight 0) --
+// exactly what the reference's "chunk missing" / "sdf > 1" / "dd < 1" tests reduce to.  The
+// reference de-duplicates vertices on a 9x9x9x3 edge grid where the LAST cell (z, y, x loop order)
+// that emits a triangle on an edge leaves its own rounding of the vertex; here every emitting cell
+// posts its index with an LDS atomicMax per edge slot, a block scan ranks the used slots (= the
+// reference's ascending-slot vertex order) and the winners are evaluated once, lane = output vertex.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "tf_devfn.h"
+#include "tf_mc_table.h"
+#include "tf_volume.h"
+
+#pragma clang fp contract(off)
+
+namespace tf {
+
+__device__ const unsigned long long d_mc_tri[256] = TF_MC_TRI_TABLE_INIT;
+
+constexpr int kR = 11;               // staged region: voxel coordinates -1 .. 9 per axis
+constexpr int kRV = kR * kR * kR;    // 1331
+constexpr int kEdgeSlots = 3 * 729;  // vertByEdge (ChunkManager.cpp:646-648)
+
+__device__ __forceinline__ int ridx(int x, int y, int z) { return (x + 1) + (y + 1) * kR + (z + 1) * kR * kR; }
+
+// cubeIndexOffsets (ChunkManager.cpp:65-66): corner k = (ox, oy, oz)
+__device__ __forceinline__ int cox(int k) { return (0x66 >> k) & 1; }
+__device__ __forceinline__ int coy(int k) { return (0xCC >> k) & 1; }
+__device__ __forceinline__ int coz(int k) { return (0xF0 >> k) & 1; }
+// edgeIndexPairs (ChunkManager.cpp:68-75), nibble e
+__device__ __forceinline__ int edge_c0(int e) { return (int)((0x321076543210ull >> (4 * e)) & 0xF); }
+__device__ __forceinline__ int edge_c1(int e) { return (int)((0x765447650321ull >> (4 * e)) & 0xF); }
+
+// edge grid slot of edge e of cell (x, y, z) (ChunkManager.cpp:856-885)
+__device__ __forceinline__ int edge_slot(int x, int y, int z, int e) {
+  const int bx = x + ((0x622 >> e) & 1);  // e in {1, 5, 9, 10}
+  const int by = y + ((0xC44 >> e) & 1);  // e in {2, 6, 10, 11}
+  const int bz = z + ((0x0F0 >> e) & 1);  // e in {4, 5, 6, 7}
+  const int ax = e >= 8 ? 2 : (e & 1);    // 0,2,4,6 -> x edges; 1,3,5,7 -> y edges; 8..11 -> z edges
+  return ax + (bx + by * 9 + bz * 81) * 3;
+}
+// inverse: which edge of cell (x, y, z) is slot (axis, bx, by, bz)
+__device__ __forceinline__ int edge_of_slot(int ax, int dx, int dy, int dz) {
+  if (ax == 0) return dz ? (dy ? 6 : 4) : (dy ? 2 : 0);
+  if (ax == 1) return dz ? (dx ? 5 : 7) : (dx ? 1 : 3);
+  return dy ? (dx ? 10 : 11) : (dx ? 9 : 8);
+}
+
+// extractGradientFromCubic (ChunkManager.cpp:277-455) at the cell corner with region coordinates
+// (px, py, pz) in 0..8 whose cube offset is (ox, oy, oz).  Both partners of every central
+// difference are the physical neighbour voxels (in-cube partner / own chunk / face-neighbour chunk,
+// voxelNeighborIndex :108-157); the partner OUTSIDE the cube is the one GetNeighborSDF fetches and
+// it must be < 1 (ChunkManager.h:790-823).  Reduction order of Eigen's fixed-size norm:
+// x*x + (y*y + z*z); normalize() divides by the root when the squared norm is positive.
+__device__ __forceinline__ bool gradient_at(const float* __restrict__ S, int px, int py, int pz, int ox, int oy,
+                                            int oz, float res, float g[3]) {
+  const int c = ridx(px, py, pz);
+  const float xm = S[c - 1], xp = S[c + 1];
+  const float ym = S[c - kR], yp = S[c + kR];
+  const float zm = S[c - kR * kR], zp = S[c + kR * kR];
+  const bool ok = ((ox ? xp : xm) < 1.0f) && ((oy ? yp : ym) < 1.0f) && ((oz ? zp : zm) < 1.0f);
+  const float gx = xp - xm, gy = yp - ym, gz = zp - zm;
+  const float yz = gy * gy + gz * gz;
+  const float sq = gx * gx + yz;
+  const float n = sqrtf(sq);
+  g[0] = gx; g[1] = gy; g[2] = gz;
+  if (sq > 0.0f) { g[0] = gx / n; g[1] = gy / n; g[2] = gz / n; }
+  return ok && !(n > res * 100.0f);
+}
+
+struct MeshSh {
+  float S[kRV];            // sdf, region coordinates -1..9
+  float Wt[729];           // weight at the cell corners 0..8
+  uint32_t nslot[27];      // pool slot of chunk id + (-1..1)^3, kInvalidSlot = missing
+  int owner[kEdgeSlots];   // last emitting cell per edge slot, -1 = unused
+  uint16_t ref[kEdgeSlots];   // output vertex index of a used slot
+  uint16_t vlist[kEdgeSlots]; // used slots in ascending order
+  uint32_t cinfo[512];     // MC case | valid-edge mask << 8 | triangle count << 20
+  uint32_t toff[512];      // first output triangle of the cell
+  uint32_t wsum[8];
+  uint32_t nv, nt, adj, any;
+};
+
+__global__ __launch_bounds__(256) void k_mesh(VolumeDev v, const int4* __restrict__ dlist,
+                                              const uint32_t* __restrict__ dcount, uint32_t max_entries,
+                                              uint32_t epoch, float res) {
+  __shared__ MeshSh sh;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  uint32_t n = *dcount;
+  if (n > max_entries) n = max_entries;
+  const float half = res * 0.5f;
+  for (uint32_t entry = blockIdx.x; entry < n; entry += gridDim.x) {
+    const int4 id = dlist[entry];
+    if (t < 27) {
+      const int ox = t % 3 - 1, oy = (t / 3) % 3 - 1, oz = t / 9 - 1;
+      const uint32_t ent = hash_find(v, pack_id(id.x + ox, id.y + oy, id.z + oz));
+      uint32_t slot = kInvalidSlot;
+      if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
+      sh.nslot[t] = slot;
+    }
+    if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; sh.any = 0; }
+    __syncthreads();
+    const uint32_t own = sh.nslot[13];
+    if (own == kInvalidSlot) { __syncthreads(); continue; }  // RecomputeMeshes: !HasChunk -> skip (:240-242)
+    MeshRec* rec = &v.mesh_rec[own];
+
+    // ---- own chunk first: a cell needs its corner 0 (always an own voxel) to have sdf <= 1, so a chunk
+    // without such a voxel has no mesh and the 27-chunk neighbourhood is never touched
+    const float2 a0 = v.tsdf[(size_t)own * kChunkVoxels + t];
+    const float2 a1 = v.tsdf[(size_t)own * kChunkVoxels + 256 + t];
+    const bool cand = !(a0.x > 1.0f) || !(a1.x > 1.0f);
+    if (__ballot(cand) != 0ull && lane == 0) sh.any = 1;  // benign race: every writer stores 1
+    __syncthreads();
+    if (!sh.any) {
+      if (t == 0) {  // Mesh::Clear + "stays in allMeshes if it was there" (:244-262)
+        rec->nv = 0; rec->nt = 0; rec->state = rec->state & kMsInMap; rec->epoch = epoch;
+      }
+      __syncthreads();
+      continue;
+    }
+    // ---- stage the neighbourhood
+    for (int i = t; i < kRV; i += 256) {
+      const int rx = i % kR - 1, ry = (i / kR) % kR - 1, rz = i / (kR * kR) - 1;
+      const int cx = (rx + 8) >> 3, cy = (ry + 8) >> 3, cz = (rz + 8) >> 3;  // 0..2 = chunk offset + 1
+      const uint32_t s = sh.nslot[cx + cy * 3 + cz * 9];
+      float2 val = make_float2(999.0f, 0.0f);
+      if (s != kInvalidSlot) val = v.tsdf[(size_t)s * kChunkVoxels + (rx & 7) + (ry & 7) * 8 + (rz & 7) * 64];
+      sh.S[i] = val.x;
+      if (rx >= 0 && ry >= 0 && rz >= 0 && rx <= 8 && ry <= 8 && rz <= 8) sh.Wt[rx + ry * 9 + rz * 81] = val.y;
+    }
+    for (int i = t; i < kEdgeSlots; i += 256) sh.owner[i] = -1;
+    __syncthreads();
+
+    // ---- pass 1: per cell, the MC case, which edges carry a usable vertex, how many triangles
+    for (int cell = t; cell < 512; cell += 256) {
+      const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
+      float cube[8];
+      bool observed = true;
+      int pos = 0, index = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float s = sh.S[ridx(x + cox(k), y + coy(k), z + coz(k))];
+        cube[k] = s;
+        observed = observed && !(s > 1.0f);  // :669-720
+        pos += (s > 0.0f) ? 1 : 0;
+        index |= (0.0f > s) ? (1 << k) : 0;  // :726-735
+      }
+      uint32_t info = 0;
+      if (observed && (pos % 8) > 0) {  // :722
+        const unsigned long long row = d_mc_tri[index];
+        uint32_t valid = 0;
+        if ((row & 0xFull) != 0xFull) {
+          for (int e = 0; e < 12; ++e) {  // :748-834
+            const int e0 = edge_c0(e), e1 = edge_c1(e);
+            const float s0 = cube[e0], s1 = cube[e1];
+            if (!(s0 * s1 < 0.0f)) continue;
+            const int k = (fabsf(s0) > fabsf(s1)) ? e1 : e0;
+            const int px = x + cox(k), py = y + coy(k), pz = z + coz(k);
+            if (!(sh.Wt[px + py * 9 + pz * 81] > 50.0f)) continue;  // weight_threshold (:776-777)
+            float g[3];
+            if (gradient_at(sh.S, px, py, pz, cox(k), coy(k), coz(k), res, g)) valid |= 1u << e;
+          }
+          uint32_t ntri = 0;
+          for (int col = 0; col < 15; col += 3) {  // :836-918
+            const int s0 = (int)((row >> (4 * col)) & 0xF);
+            if (s0 == 0xF) break;
+            const int s1 = (int)((row >> (4 * col + 4)) & 0xF), s2 = (int)((row >> (4 * col + 8)) & 0xF);
+            if (!((valid >> s0) & (valid >> s1) & (valid >> s2) & 1u)) continue;
+            ++ntri;
+            atomicMax(&sh.owner[edge_slot(x, y, z, s2)], cell);
+            atomicMax(&sh.owner[edge_slot(x, y, z, s1)], cell);
+            atomicMax(&sh.owner[edge_slot(x, y, z, s0)], cell);
+          }
+          info = (uint32_t)index | (valid << 8) | (ntri << 20);
+        }
+      }
+      sh.cinfo[cell] = info;
+    }
+    __syncthreads();
+
+    // ---- ranks: used edge slots in ascending order (the reference's vertex order, :886-897) and the
+    // cells' triangle offsets in cell order (the order of mesh->indices)
+    {
+      const int first = t * 9;  // 256 x 9 = 2304 >= 2187
+      uint32_t cnt = 0;
+      for (int j = 0; j < 9; ++j) cnt += (first + j < kEdgeSlots && sh.owner[first + j] >= 0) ? 1u : 0u;
+      const uint32_t tc = (sh.cinfo[2 * t] >> 20) + (sh.cinfo[2 * t + 1] >> 20);
+      uint32_t pk = cnt | (tc << 16);  // both counts scanned at once (each < 2^16)
+      uint32_t inc = pk;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = __shfl_up(inc, o);
+        if (lane >= o) inc += u;
+      }
+      if (lane == 63) sh.wsum[w] = inc;
+      __syncthreads();
+      uint32_t before = 0, total = 0;
+      for (int k = 0; k < 4; ++k) {
+        if (k < w) before += sh.wsum[k];
+        total += sh.wsum[k];
+      }
+      const uint32_t excl = before + inc - pk;
+      uint32_t r = excl & 0xFFFFu;
+      for (int j = 0; j < 9; ++j)
+        if (first + j < kEdgeSlots && sh.owner[first + j] >= 0) {
+          sh.ref[first + j] = (uint16_t)r;
+          sh.vlist[r] = (uint16_t)(first + j);
+          ++r;
+        }
+      const uint32_t t0 = excl >> 16;
+      sh.toff[2 * t] = t0;
+      sh.toff[2 * t + 1] = t0 + (sh.cinfo[2 * t] >> 20);
+      if (t == 0) { sh.nv = total & 0xFFFFu; sh.nt = total >> 16; }
+    }
+    __syncthreads();
+    const uint32_t nv = sh.nv, nt = sh.nt;
+    if (nv > v.mesh_cv || nt > v.mesh_ct) {  // does not fit the slot's block: reported, stored empty
+      if (t == 0) {
+        atomicOr(&v.vctl->status, kStMeshFull);
+        rec->nv = 0; rec->nt = 0; rec->state = (rec->state & kMsInMap) | kMsOverflow; rec->epoch = epoch;
+      }
+      __syncthreads();
+      continue;
+    }
+
+    // ---- pass 2: the winning cell of every used slot evaluates the vertex; lane = output vertex
+    const float org[3] = {(float)(8 * id.x) * res, (float)(8 * id.y) * res, (float)(8 * id.z) * res};  // Chunk.cpp:52
+    uint32_t adj = 0;
+    for (uint32_t i = t; i < nv; i += 256) {
+      const int m = sh.vlist[i];
+      const int cell = sh.owner[m];
+      const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
+      const int ax = m % 3, b = m / 3;
+      const int bx = b % 9, by = (b / 9) % 9, bz = b / 81;
+      const int e = edge_of_slot(ax, bx - x, by - y, bz - z);
+      const int e0 = edge_c0(e), e1 = edge_c1(e);
+      const float s0 = sh.S[ridx(x + cox(e0), y + coy(e0), z + coz(e0))];
+      const float s1 = sh.S[ridx(x + cox(e1), y + coy(e1), z + coz(e1))];
+      const float tt = s0 / (s0 - s1);  // :757-762
+      const int o0[3] = {cox(e0), coy(e0), coz(e0)}, o1[3] = {cox(e1), coy(e1), coz(e1)};
+      const int cc[3] = {x, y, z};
+      float pv[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float p0 = (float)o0[a] * res, p1 = (float)o1[a] * res;  // cubeCoordOffsets (:635-636)
+        const float ev = p0 + tt * (p1 - p0);
+        const float origin = org[a] + ((float)cc[a] * res + half);     // Chunk origin + centroids[voxel] (:662)
+        pv[a] = ev + origin;                                           // :872-877
+      }
+      const int k = (fabsf(s0) > fabsf(s1)) ? e1 : e0;
+      const int px = x + cox(k), py = y + coy(k), pz = z + coz(k);
+      float g[3];
+      gradient_at(sh.S, px, py, pz, cox(k), coy(k), coz(k), res, g);
+      // voxel colour of that corner (:808-824)
+      const uint32_t cs = sh.nslot[((px + 8) >> 3) + ((py + 8) >> 3) * 3 + ((pz + 8) >> 3) * 9];
+      const ushort4 c4 = v.color[(size_t)cs * kChunkVoxels + (px & 7) + (py & 7) * 8 + (pz & 7) * 64];
+      float col[3] = {1.0f, 1.0f, 1.0f};
+      const float cw = (float)c4.w;
+      if (cw > 0.0f) {
+        col[0] = ((float)c4.x / 255.0f) / cw;
+        col[1] = ((float)c4.y / 255.0f) / cw;
+        col[2] = ((float)c4.z / 255.0f) / cw;
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        mesh_plane(v, own, kMpPos + a)[i] = pv[a];
+        mesh_plane(v, own, kMpNrm + a)[i] = g[a];
+        mesh_plane(v, own, kMpCol + a)[i] = col[a];
+        // Mesh::GetIndice (Mesh.cpp:52-83) with grid_resolution = resolution * (8 / GRID_EACH_DIM)
+        const int gp = (int)floorf((pv[a] - org[a]) / (res * 1.0f));
+        if (gp >= 8) adj |= 1u << (2 * a + 1);
+        if (gp <= 0) adj |= 1u << (2 * a);
+      }
+    }
+    if (adj) atomicOr(&sh.adj, adj);
+    // ---- triangles, in cell order; (s2, s1, s0) per triangle (:914-916)
+    for (int cell = t; cell < 512; cell += 256) {
+      const uint32_t info = sh.cinfo[cell];
+      if (!(info >> 20)) continue;
+      const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
+      const unsigned long long row = d_mc_tri[info & 0xFFu];
+      const uint32_t valid = (info >> 8) & 0xFFFu;
+      uint32_t o = sh.toff[cell];
+      for (int col = 0; col < 15; col += 3) {
+        const int s0 = (int)((row >> (4 * col)) & 0xF);
+        if (s0 == 0xF) break;
+        const int s1 = (int)((row >> (4 * col + 4)) & 0xF), s2 = (int)((row >> (4 * col + 8)) & 0xF);
+        if (!((valid >> s0) & (valid >> s1) & (valid >> s2) & 1u)) continue;
+        tri_plane(v, own, 0)[o] = sh.ref[edge_slot(x, y, z, s2)];
+        tri_plane(v, own, 1)[o] = sh.ref[edge_slot(x, y, z, s1)];
+        tri_plane(v, own, 2)[o] = sh.ref[edge_slot(x, y, z, s0)];
+        ++o;
+      }
+    }
+    __syncthreads();
+    if (t == 0) {
+      // a mesh enters allMeshes when it has vertices and stays there afterwards (:260-262); its own
+      // adjacency flags are final now (SimplifyByClustering runs once per generation, Chisel.cpp:124)
+      const uint32_t inmap = (rec->state & kMsInMap) | (nv ? kMsInMap : 0u);
+      rec->nv = nv; rec->nt = nt; rec->epoch = epoch;
+      rec->state = inmap | (sh.adj << kMsAdjShift);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_init_mesh_rec(MeshRec* rec, uint32_t n) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    MeshRec r;
+    memset(&r, 0, sizeof(r));
+    r.texloc = kNoTexloc;
+    r.frameid = -1;
+    r.ratio[0] = r.ratio[1] = 1.0f;
+    rec[i] = r;
+  }
+}
+void launch_init_meshes(const VolumeDev& v, hipStream_t s) {
+  hipLaunchKernelGGL(k_init_mesh_rec, dim3(1024), dim3(256), 0, s, v.mesh_rec, v.max_chunks);
+}
+
+void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
+                 uint32_t epoch, float res, hipStream_t s) {
+  if (!max_entries) return;
+  const uint32_t grid = max_entries < 8192u ? max_entries : 8192u;
+  hipLaunchKernelGGL(k_mesh, dim3(grid), dim3(256), 0, s, v, dlist, dcount, max_entries, epoch, res);
+}
+
+// ---------------------------------------------------------------------------------------
+// Chisel::CompressMeshes (Structure/Chisel.cpp:112-147) for a list of chunks: mark the meshes
+// simplified (their own flags were computed with the mesh), then exchange the flags with the face
+// neighbours' meshes: after the pass flag k of a mesh and flag k^1 of its k-th neighbour are the OR
+// of the two (the reference's pairwise updates reach the same fixed point in any iteration order).
+// Two kernels: the neighbour pass must see every listed mesh already marked simplified.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_compress_mark(VolumeDev v, const int4* __restrict__ list,
+                                                       const uint32_t* __restrict__ count, uint32_t cap) {
+  uint32_t n = *count;
+  if (n > cap) n = cap;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int4 id = list[i];
+    const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+    if (ent == kInvalidSlot || !(v.hent[ent].alive & 1u)) continue;
+    const uint32_t slot = v.hent[ent].slot;
+    if (slot == kInvalidSlot) continue;
+    MeshRec* r = &v.mesh_rec[slot];
+    if (r->state & kMsInMap) r->state |= kMsSimplified;
+  }
+}
+__global__ __launch_bounds__(256) void k_compress_exchange(VolumeDev v, const int4* __restrict__ list,
+                                                           const uint32_t* __restrict__ count, uint32_t cap) {
+  uint32_t n = *count;
+  if (n > cap) n = cap;
+  const uint32_t total = n * 6u;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int4 id = list[i / 6u];
+    const int k = (int)(i % 6u), m = k ^ 1;
+    const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+    if (ent == kInvalidSlot || !(v.hent[ent].alive & 1u) || v.hent[ent].slot == kInvalidSlot) continue;
+    MeshRec* a = &v.mesh_rec[v.hent[ent].slot];
+    if (!(a->state & kMsInMap)) continue;
+    int4 q = id;
+    if (k == 0) q.x -= 1; else if (k == 1) q.x += 1; else if (k == 2) q.y -= 1;
+    else if (k == 3) q.y += 1; else if (k == 4) q.z -= 1; else q.z += 1;
+    const uint32_t en = hash_find(v, pack_id(q.x, q.y, q.z));
+    if (en == kInvalidSlot || !(v.hent[en].alive & 1u) || v.hent[en].slot == kInvalidSlot) continue;
+    MeshRec* b = &v.mesh_rec[v.hent[en].slot];
+    const uint32_t bs = b->state;
+    if (!(bs & kMsInMap) || !(bs & kMsSimplified)) continue;
+    const uint32_t abit = 1u << (kMsAdjShift + k), bbit = 1u << (kMsAdjShift + m);
+    const bool fa = (a->state & abit) != 0, fb = (bs & bbit) != 0;
+    if (fa && !fb) atomicOr(&b->state, bbit);
+    if (!fa && fb) atomicOr(&a->state, abit);
+  }
+}
+
+// keys of allMeshes
+__global__ __launch_bounds__(256) void k_list_meshes(VolumeDev v, int4* out, uint32_t cap) {
+  const uint32_t nent = v.hmask + 1u;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nent; i += gridDim.x * 256) {
+    const HEntry h = v.hent[i];
+    if (h.key == kEmptyKey || !(h.alive & 1u) || h.slot == kInvalidSlot) continue;
+    if (!(v.mesh_rec[h.slot].state & kMsInMap)) continue;
+    const uint32_t p = atomicAdd(&v.vctl->n_tmp, 1u);
+    if (p < cap) out[p] = unpack_id(h.key);
+  }
+}
+
+// per listed chunk: {nv, ni, state, found}
+__global__ __launch_bounds__(256) void k_mesh_counts(VolumeDev v, const int4* __restrict__ ids, uint32_t n, int4* out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int4 id = ids[i];
+  const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+  int4 r = make_int4(0, 0, 0, 0);
+  if (ent != kInvalidSlot && (v.hent[ent].alive & 1u) && v.hent[ent].slot != kInvalidSlot) {
+    const MeshRec m = v.mesh_rec[v.hent[ent].slot];
+    if (m.state & kMsInMap) r = make_int4((int)m.nv, (int)(3u * m.nt), (int)m.state, 1);
+  }
+  out[i] = r;
+}
+
+// Mesh::vertices / normals / colors / indices in the reference's layouts (Vec3List = xyz per vertex)
+__global__ __launch_bounds__(256) void k_mesh_gather(VolumeDev v, const int4* __restrict__ ids, uint32_t n,
+                                                     const long long* __restrict__ voff, const long long* __restrict__ ioff,
+                                                     float* verts, float* normals, float* colors, uint32_t* indices) {
+  const uint32_t c = blockIdx.x;
+  if (c >= n) return;
+  const int4 id = ids[c];
+  const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+  if (ent == kInvalidSlot || !(v.hent[ent].alive & 1u) || v.hent[ent].slot == kInvalidSlot) return;
+  const uint32_t slot = v.hent[ent].slot;
+  const MeshRec m = v.mesh_rec[slot];
+  if (!(m.state & kMsInMap)) return;
+  const long long v0 = voff[c], i0 = ioff[c];
+  const uint32_t nv = (uint32_t)(voff[c + 1] - v0) < m.nv ? (uint32_t)(voff[c + 1] - v0) : m.nv;
+  const uint32_t nt = (uint32_t)(ioff[c + 1] - i0) / 3u < m.nt ? (uint32_t)(ioff[c + 1] - i0) / 3u : m.nt;
+  for (uint32_t i = threadIdx.x; i < nv; i += 256)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      if (verts) verts[3 * (v0 + i) + a] = mesh_plane(v, slot, kMpPos + a)[i];
+      if (normals) normals[3 * (v0 + i) + a] = mesh_plane(v, slot, kMpNrm + a)[i];
+      if (colors) colors[3 * (v0 + i) + a] = mesh_plane(v, slot, kMpCol + a)[i];
+    }
+  if (indices)
+    for (uint32_t i = threadIdx.x; i < nt; i += 256)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) indices[i0 + 3 * i + a] = tri_plane(v, slot, a)[i];
+}
+
+// ids (host, int32[3n]) -> device int4 list in d_tmp at byte offset `at`
+static int upload_ids(tf_volume* v, const int32_t* ids, int64_t n, size_t at) {
+  int rc = ensure_pinned(v, (size_t)n * 16 + 16);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  int32_t* hid = reinterpret_cast<int32_t*>(v->h_pinned);
+  for (int64_t i = 0; i < n; ++i) {
+    hid[4 * i] = ids[3 * i]; hid[4 * i + 1] = ids[3 * i + 1]; hid[4 * i + 2] = ids[3 * i + 2]; hid[4 * i + 3] = 0;
+  }
+  TF_HIP(hipMemcpyAsync(reinterpret_cast<uint8_t*>(v->d_tmp) + at, hid, (size_t)n * 16, hipMemcpyHostToDevice, v->stream));
+  return TF_OK;
+}
+
+// the dirty set (Chisel::meshesToUpdate) as a device list in d_tmp: [0,16) count word, ids from byte 16
+static int dirty_list_device(tf_volume* v, uint32_t* n_out) {
+  const size_t cap = (size_t)v->dev.max_chunks;
+  int rc = ensure_tmp(v, cap * 16 + 16);
+  if (rc) return rc;
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
+  launch_list_dirty(v->dev, reinterpret_cast<int4*>(reinterpret_cast<uint8_t*>(v->d_tmp) + 16), (uint32_t)cap,
+                    v->clear_floor, v->stream);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(v->d_tmp, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));
+  uint32_t n = 0;
+  TF_HIP(hipMemcpyAsync(&n, v->d_tmp, 4, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  *n_out = n;
+  return TF_OK;
+}
+
+}  // namespace tf
+
+using namespace tf;
+
+extern "C" {
+
+int tf_update_meshes(tf_volume* v, int64_t* n_meshed) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  uint32_t n = 0;
+  int rc = dirty_list_device(v, &n);
+  if (rc) return rc;
+  if (n_meshed) *n_meshed = n;
+  if (!n) return TF_OK;
+  const uint8_t* db = reinterpret_cast<const uint8_t*>(v->d_tmp);
+  prof_begin(v, TF_PROF_MESH);
+  launch_mesh(v->dev, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), n,
+              ++v->mesh_epoch, v->res, v->stream);
+  prof_end(v);
+  TF_HIP(hipGetLastError());
+  return tf_sync(v);
+}
+
+int tf_list_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n) {
+  if (!v || !n) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (cap < 0) cap = 0;
+  int rc = ensure_tmp(v, (size_t)cap * 16 + 16);
+  if (rc) return rc;
+  rc = ensure_pinned(v, (size_t)cap * 16 + 16);
+  if (rc) return rc;
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
+  hipLaunchKernelGGL(k_list_meshes, dim3(1024), dim3(256), 0, v->stream, v->dev, reinterpret_cast<int4*>(v->d_tmp),
+                     (uint32_t)cap);
+  TF_HIP(hipGetLastError());
+  uint32_t cnt = 0;
+  TF_HIP(hipMemcpyAsync(&cnt, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  *n = cnt;
+  const int64_t m = cnt < (uint64_t)cap ? cnt : cap;
+  if (m > 0 && out_ids) {
+    TF_HIP(hipMemcpyAsync(v->h_pinned, v->d_tmp, (size_t)m * 16, hipMemcpyDeviceToHost, v->stream));
+    TF_HIP(hipStreamSynchronize(v->stream));
+    const int32_t* st = reinterpret_cast<const int32_t*>(v->h_pinned);
+    for (int64_t i = 0; i < m; ++i) {
+      out_ids[3 * i] = st[4 * i]; out_ids[3 * i + 1] = st[4 * i + 1]; out_ids[3 * i + 2] = st[4 * i + 2];
+    }
+  }
+  if ((int64_t)cnt > cap && out_ids) { set_error("output capacity too small"); return TF_ERR_CAPACITY; }
+  return TF_OK;
+}
+
+int tf_mesh_counts(tf_volume* v, const int32_t* ids, int64_t n, int32_t* n_vertices, int32_t* n_indices,
+                   uint8_t* adj, uint8_t* simplified) {
+  if (!v || (n > 0 && !ids)) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (n <= 0) return TF_OK;
+  int rc = ensure_tmp(v, (size_t)n * 32);
+  if (rc) return rc;
+  rc = upload_ids(v, ids, n, 0);
+  if (rc) return rc;
+  uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
+  hipLaunchKernelGGL(k_mesh_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, v->stream, v->dev,
+                     reinterpret_cast<const int4*>(db), (uint32_t)n, reinterpret_cast<int4*>(db + (size_t)n * 16));
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(v->h_pinned, db + (size_t)n * 16, (size_t)n * 16, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  const int32_t* r = reinterpret_cast<const int32_t*>(v->h_pinned);
+  for (int64_t i = 0; i < n; ++i) {
+    if (!r[4 * i + 3]) {
+      set_error("chunk (" + std::to_string(ids[3 * i]) + "," + std::to_string(ids[3 * i + 1]) + "," +
+                std::to_string(ids[3 * i + 2]) + ") has no mesh");
+      return TF_ERR_MISSING_CHUNK;  // allMeshes.at() would throw
+    }
+    if (n_vertices) n_vertices[i] = r[4 * i];
+    if (n_indices) n_indices[i] = r[4 * i + 1];
+    if (adj)
+      for (int k = 0; k < 6; ++k) adj[6 * i + k] = (uint8_t)(((uint32_t)r[4 * i + 2] >> (kMsAdjShift + k)) & 1u);
+    if (simplified) simplified[i] = (uint8_t)(((uint32_t)r[4 * i + 2] & kMsSimplified) ? 1 : 0);
+  }
+  return TF_OK;
+}
+
+int tf_meshes_download(tf_volume* v, const int32_t* ids, int64_t n, const int64_t* vert_offsets,
+                       const int64_t* index_offsets, float* verts, float* normals, float* colors,
+                       uint32_t* indices) {
+  if (!v || (n > 0 && (!ids || !vert_offsets || !index_offsets))) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (n <= 0) return TF_OK;
+  const int64_t nv = vert_offsets[n], ni = index_offsets[n];
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+  const size_t o_ids = take((size_t)n * 16), o_vo = take((size_t)(n + 1) * 8), o_io = take((size_t)(n + 1) * 8);
+  const size_t o_in_end = o;
+  const size_t o_v = take((size_t)nv * 12), o_n = take((size_t)nv * 12), o_c = take((size_t)nv * 12), o_i = take((size_t)ni * 4);
+  const size_t total = o;
+  int rc = ensure_tmp(v, total);
+  if (rc) return rc;
+  rc = ensure_pinned(v, total);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  uint8_t* hb = reinterpret_cast<uint8_t*>(v->h_pinned);
+  uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
+  int32_t* hid = reinterpret_cast<int32_t*>(hb + o_ids);
+  for (int64_t i = 0; i < n; ++i) {
+    hid[4 * i] = ids[3 * i]; hid[4 * i + 1] = ids[3 * i + 1]; hid[4 * i + 2] = ids[3 * i + 2]; hid[4 * i + 3] = 0;
+  }
+  memcpy(hb + o_vo, vert_offsets, (size_t)(n + 1) * 8);
+  memcpy(hb + o_io, index_offsets, (size_t)(n + 1) * 8);
+  TF_HIP(hipMemcpyAsync(db, hb, o_in_end, hipMemcpyHostToDevice, v->stream));
+  hipLaunchKernelGGL(k_mesh_gather, dim3((unsigned)n), dim3(256), 0, v->stream, v->dev,
+                     reinterpret_cast<const int4*>(db + o_ids), (uint32_t)n,
+                     reinterpret_cast<const long long*>(db + o_vo), reinterpret_cast<const long long*>(db + o_io),
+                     reinterpret_cast<float*>(db + o_v), reinterpret_cast<float*>(db + o_n),
+                     reinterpret_cast<float*>(db + o_c), reinterpret_cast<uint32_t*>(db + o_i));
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(hb + o_v, db + o_v, total - o_v, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  if (verts) memcpy(verts, hb + o_v, (size_t)nv * 12);
+  if (normals) memcpy(normals, hb + o_n, (size_t)nv * 12);
+  if (colors) memcpy(colors, hb + o_c, (size_t)nv * 12);
+  if (indices) memcpy(indices, hb + o_i, (size_t)ni * 4);
+  return TF_OK;
+}
+
+static bool id_less(const int32_t* a, const int32_t* b) {
+  for (int k = 0; k < 3; ++k)
+    if (a[k] != b[k]) return a[k] < b[k];
+  return false;
+}
+
+int tf_compress_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n_out) {
+  if (!v || !n_out) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  *n_out = 0;
+  uint32_t n = 0;
+  int rc = dirty_list_device(v, &n);
+  if (rc) return rc;
+  int64_t m = 0;
+  if (n) {
+    uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
+    const int4* list = reinterpret_cast<const int4*>(db + 16);
+    const uint32_t* cnt = reinterpret_cast<const uint32_t*>(db);
+    hipLaunchKernelGGL(k_compress_mark, dim3(256), dim3(256), 0, v->stream, v->dev, list, cnt, n);
+    hipLaunchKernelGGL(k_compress_exchange, dim3(512), dim3(256), 0, v->stream, v->dev, list, cnt, n);
+    TF_HIP(hipGetLastError());
+    // chunksToUpdate = the dirty keys that have a mesh (GCFusion/MobileFusion.cpp:345-353), ascending id
+    const size_t o_cnt = ((size_t)n * 16 + 16 + 15) & ~(size_t)15;
+    rc = ensure_tmp(v, o_cnt + (size_t)n * 16);
+    if (rc) return rc;
+    db = reinterpret_cast<uint8_t*>(v->d_tmp);
+    hipLaunchKernelGGL(k_mesh_counts, dim3((n + 255) / 256), dim3(256), 0, v->stream, v->dev,
+                       reinterpret_cast<const int4*>(db + 16), n, reinterpret_cast<int4*>(db + o_cnt));
+    TF_HIP(hipGetLastError());
+    rc = ensure_pinned(v, (size_t)n * 32);
+    if (rc) return rc;
+    uint8_t* hb = reinterpret_cast<uint8_t*>(v->h_pinned);
+    TF_HIP(hipMemcpyAsync(hb, db + 16, (size_t)n * 16, hipMemcpyDeviceToHost, v->stream));
+    TF_HIP(hipMemcpyAsync(hb + (size_t)n * 16, db + o_cnt, (size_t)n * 16, hipMemcpyDeviceToHost, v->stream));
+    TF_HIP(hipStreamSynchronize(v->stream));
+    const int32_t* hid = reinterpret_cast<const int32_t*>(hb);
+    const int32_t* hc = reinterpret_cast<const int32_t*>(hb + (size_t)n * 16);
+    std::vector<const int32_t*> keep;
+    keep.reserve(n);
+    for (uint32_t i = 0; i < n; ++i)
+      if (hc[4 * i + 3]) keep.push_back(hid + 4 * i);
+    std::sort(keep.begin(), keep.end(), id_less);
+    m = (int64_t)keep.size();
+    if (out_ids)
+      for (int64_t i = 0; i < m && i < cap; ++i) memcpy(out_ids + 3 * i, keep[(size_t)i], 12);
+  }
+  *n_out = m;
+  rc = tf_clear_dirty(v);  // chunksToUpdate.clear() (Chisel.cpp:146)
+  if (rc) return rc;
+  if (out_ids && m > cap) { set_error("output capacity too small"); return TF_ERR_CAPACITY; }
+  return TF_OK;
+}
+
+}  // extern "C"

@@ -130,6 +130,7 @@ struct tf_volume {
   int64_t host_list_n = -1;
   uint32_t epoch = 0;        // finalize counter (mark / erase stamps are epoch + 1)
   uint32_t clear_floor = 0;  // stamps <= this were cleared (Chisel::CompressMeshes' chunksToUpdate.clear())
+  uint32_t mesh_epoch = 0;   // meshing passes so far (MeshRec::epoch)
   // on-demand device scratch
   void* d_tmp = nullptr;
   size_t d_tmp_bytes = 0;
