@@ -80,6 +80,17 @@ typedef struct {
   int32_t max_id[3];      /* Chisel::maxChunkID */
 } tf_stats;
 
+/* What the textured per-frame unit did for its most recent frame (integers behind the byte counts). */
+typedef struct {
+  int64_t n_dirty;      /* chunks handed to the mesher */
+  int64_t n_meshes;     /* of those, chunks in allMeshes (= patches projected) */
+  int64_t n_vertices;   /* vertices of those meshes */
+  int64_t n_triangles;
+  int64_t roi_pixels;   /* sum of the patches' bounding-box areas */
+  int64_t n_patches;    /* patches with an image */
+  int64_t n_slots;      /* atlas slots handed out so far */
+} tf_texture_stats;
+
 /* Per-kernel timings collected with HIP events on the handle's stream (tf_profile_*). */
 #define TF_PROF_BBOX 0
 #define TF_PROF_SELECT 1
@@ -163,6 +174,23 @@ TF_API int tf_integrate_frame(tf_volume* v, const float pose[12], int use_color)
 /* Same, for a batch of device-resident frames (arrays of n device pointers / n poses). */
 TF_API int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* const* d_depth,
                                       const uint8_t* const* d_rgba, const float* poses12);
+/* The same for a stream that is fed call by call: the arrays hold n_ahead (0..2) frames more than the
+ * n_frames that are integrated; those run through their selection stages (bounding box, visible-chunk
+ * list) in this call's launches and the next call, if it starts with exactly these frames (same depth
+ * pointer and pose), begins with the voxel update at once -- one launch per frame across calls. */
+TF_API int tf_stream_frames_device(tf_volume* v, int64_t n_frames, int64_t n_ahead, const float* const* d_depth,
+                                   const uint8_t* const* d_rgba, const float* poses12);
+/* The per-frame unit with texturing (BASELINE configs[2]): after frame f is
+ * integrated its dirty chunks -- the updated chunks and their six face neighbours, Chisel.h:192-208 -- run
+ * through Chisel::UpdateMeshes, CompressMeshes, GeneratePatches with label = frame f and UpdateAtlas
+ * (GCFusion/MobileFusion.cpp:327-382 without the host-side view selection), all on the device and without
+ * a host synchronisation.  The keyframe of a patch is the frame itself: its RGBA image (alpha ignored) and
+ * depth, pose_inv16[f] = f32(SE3d.inverse().matrix()) of its pose; Patch::frameid = first_frame_id + f.
+ * New patches take their atlas slots in ascending (x, y, z) chunk-id order within a frame (the reference's
+ * order is an unordered_map's). */
+TF_API int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int64_t n_ahead,
+                                            const float* const* d_depth, const uint8_t* const* d_rgba,
+                                            const float* poses12, const float* pose_inv16, int32_t first_frame_id);
 TF_API int tf_sync(tf_volume* v);
 
 /* ---- state access (host mirrors of Chunk::voxels / colors, ChunkManager queries) -----
@@ -183,6 +211,7 @@ TF_API int tf_list_chunks(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* 
 TF_API int tf_list_dirty(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n);
 TF_API int tf_clear_dirty(tf_volume* v);
 TF_API int tf_get_stats(tf_volume* v, tf_stats* out);
+TF_API int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out);
 
 /* ---- meshing (the stage between the volume and the atlas) -----
  * Chisel::UpdateMeshes (Structure/Chisel.h:479-481) -> ChunkManager::RecomputeMeshes
@@ -242,85 +271,76 @@ TF_API int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, 
 TF_API int tf_boundary_pack_async(tf_volume* v, void* d_records, int64_t cap_records, uint32_t* d_count);
 TF_API int tf_boundary_unpack(tf_volume* v, const void* d_records, int64_t n_records);
 
-/* ---- texture atlas ------------------------------------------------------------------
- * Atlas / Patch (Structure/Atlas.{h,cpp}, Structure/Patch.{h,cpp}) as driven by
- * Chisel::GeneratePatches / UpdateAtlas (Structure/Chisel.cpp:149-196).
+/* ---- texture atlas on device-resident meshes --------------------------------------------
+ * Atlas / Patch (Structure/Atlas.{h,cpp}, Structure/Patch.{h,cpp}) as driven by Chisel::GeneratePatches /
+ * CompensateColor / UpdateAtlas / DrawMeshes (Structure/Chisel.cpp:149-355).  Meshes (ChunkManager::allMeshes)
+ * and their patches (Mesh::m_patch: texloc, frameid, boundingbox, ratio, texcoord, texcolor, labs) stay in
+ * HBM; the host sees them through the *_download mirrors.
  *
- * tf_keyframe_cache: the reference keeps Frame::rgb / refined_depth alive and Patch::SetImage
- *   holds a non-owning ROI into it (Patch.cpp:172-175); here the keyframe's images are cached
- *   in HBM under kf_id. rgb = u8[H][W][3], depth = f32[H][W]. */
+ * tf_keyframe_cache: the reference keeps Frame::rgb / refined_depth alive and Patch::SetImage holds a
+ *   non-owning ROI into it (Patch.cpp:172-175); here the keyframe's images are cached in HBM under kf_id
+ *   (= the frame id view selection hands out as label).  rgb = u8[H][W][3], depth = f32[H][W].
+ *   _device borrows images that are already resident (rgb_pixel_stride 3, or 4 for an RGBA image whose
+ *   alpha is ignored).  tf_keyframe_set_pose: f32(SE3d.inverse().matrix()) of Frame::pose_sophus[0],
+ *   16 floats row-major (Patch.cpp:51) -- poses move with every bundle adjustment, so it is set before
+ *   GeneratePatches. */
 TF_API int tf_keyframe_cache(tf_volume* v, int32_t kf_id, const uint8_t* rgb, const float* depth);
-TF_API int tf_keyframe_cache_device(tf_volume* v, int32_t kf_id, const uint8_t* d_rgb,
+TF_API int tf_keyframe_cache_device(tf_volume* v, int32_t kf_id, const uint8_t* d_rgb, int32_t rgb_pixel_stride,
                                     const float* d_depth);
+TF_API int tf_keyframe_set_pose(tf_volume* v, int32_t kf_id, const float pose_inv16[16]);
 TF_API int tf_keyframe_release(tf_volume* v, int32_t kf_id);
 /* Atlas::SetResolution  Structure/Atlas.h:62-65 */
 TF_API int tf_atlas_patch_size(tf_volume* v, int32_t* patch_w, int32_t* patch_h);
-/* Atlas::AddPatch  Structure/Atlas.cpp:43-64: first call for a chunk hands out the next slot
- *   (TF_ERR_ATLAS_FULL = std::overflow_error); later calls keep the slot (Patch::clear). */
-TF_API int tf_atlas_add_patch(tf_volume* v, const int32_t id[3], uint64_t* texloc);
-/* Atlas::GetTexLoc / loc_next */
+/* Atlas::loc_next */
 TF_API int tf_atlas_loc_next(tf_volume* v, uint64_t* loc_next);
-/* Chisel::GeneratePatches + Chisel::UpdateAtlas for a batch of chunks
- *   (Structure/Chisel.cpp:149-196): for patch p with vertices [voff[p], voff[p+1]):
- *   AddPatch -> Patch::CalculateTexCoords(frame kf_ids[p]) (Patch.cpp:40-108) ->
- *   Atlas::UpdateBuffer (Atlas.cpp:71-91).  pose_inv = f32(SE3d.inverse().matrix()), 16
- *   floats row-major per patch.  Outputs (caller-allocated, may be NULL):
- *   texcoord f32[2*nv], texcolor f32[3*nv], bbox i32[4*np] (x,y,w,h), flags i32[np]
- *   (bit0 = CalculateTexCoords returned -1, bit1 = wrong_mapping), ratio f32[2*np],
- *   texloc u64[np]; hot[2] = atlas.hot_start / hot_end.
- *   Returns TF_ERR_ATLAS_FULL when the atlas overflows (GeneratePatches' -1). */
-TF_API int tf_patches_update(tf_volume* v, int64_t n_patches, const int32_t* ids,
-                             const int32_t* kf_ids, const float* pose_inv16,
-                             const int64_t* vert_offsets, const float* verts, const float* colors,
-                             float* out_texcoord, float* out_texcolor, int32_t* out_bbox,
-                             int32_t* out_flags, float* out_ratio, uint64_t* out_texloc,
-                             uint64_t out_hot[2]);
-/* The same with the mesh data already in HBM and the results left there (d_* are device pointers;
- *   d_patch_out receives one tf_patch_out per patch): only the per-patch descriptors cross PCIe and the
- *   call does not synchronise, so a keyframe's atlas update is enqueued between two frames of
- *   tf_integrate_frames_device.  Slot allocation (out_texloc, out_hot: host) is immediate. */
-typedef struct tf_patch_out {
-  int32_t bbox[4];   /* x, y, w, h */
-  int32_t flags;     /* bit0: CalculateTexCoords returned -1; bit1: wrong_mapping */
-  float ratio[2];
-  int32_t n_caution;
-} tf_patch_out;
-TF_API int tf_patches_update_device(tf_volume* v, int64_t n_patches, const int32_t* ids,
-                                    const int32_t* kf_ids, const float* pose_inv16,
-                                    const int64_t* vert_offsets, const float* d_verts,
-                                    const float* d_colors, float* d_texcoord, float* d_texcolor,
-                                    tf_patch_out* d_patch_out, uint64_t* out_texloc, uint64_t out_hot[2]);
-/* Chisel::CompensateColor  Structure/Chisel.cpp:198-286 (+ computeMeanAndCov, Structure/Patch.cpp:342-348)
- *   over a batch of patches in the reference's iteration order.  Patches with has_adjusted != 0 are
- *   skipped; the rest is clustered by frame id (cluster order = first appearance).  Per cluster: mean /
- *   covariance of texcolor (what the keyframe shows) and of the mesh colours (what the volume holds)
- *   over the patches without wrong_mapping, the 3x3 transfer T, then
- *   labs[k] = T (texcolor[k] - mean_src) + mean_tar for the vertices of the correctly mapped patches
- *   (Patch::labs; wrong-mapped patches end with labs cleared, their entries of out_labs are left as
- *   passed in) and has_adjusted := 1.  A cluster without a correctly mapped vertex is left untouched.
- *   texcolor / meshcolor / out_labs: f32[3 * vert_offsets[n_patches]].  Reductions and the per-vertex
- *   transfer run on the device, the 3x3 eigen-decompositions on the host (f64 Jacobi; Eigen's own
- *   iteration is not restated, the result agrees to float rounding). */
-TF_API int tf_color_compensate(tf_volume* v, int64_t n_patches, const int32_t* frame_ids,
-                               const uint8_t* wrong_mapping, uint8_t* has_adjusted,
-                               const int64_t* vert_offsets, const float* texcolor, const float* meshcolor,
-                               float* out_labs, int64_t* out_n_clusters);
-/* Chisel::DrawMeshes  Structure/Chisel.cpp:288-355 (the step after the atlas
- *   update): the interleaved vertex stream the renderer / exporter consumes, 12 f32 per vertex
+/* ChunkManager::allMeshes[id] = a mesh built by the caller (a host that keeps its own mesher): Mesh::vertices /
+ *   normals / colors as 3 f32 per vertex, Mesh::indices, packed by running offsets; creates missing chunks. */
+TF_API int tf_meshes_upload(tf_volume* v, const int32_t* ids, int64_t n, const int64_t* vert_offsets,
+                            const int64_t* index_offsets, const float* verts, const float* normals,
+                            const float* colors, const uint32_t* indices);
+/* Chisel::GeneratePatches(chunksToUpdate, labelset, frame_list, camera)  Structure/Chisel.cpp:149-189: for the
+ *   listed chunks that have a mesh, in list order: Atlas::AddPatch (first call hands out the next slot,
+ *   Atlas.cpp:43-64; later calls keep it, Patch::clear) -> Patch::CalculateTexCoords in keyframe labels[i]
+ *   (Patch.cpp:40-108) -> SetFrameid / SetImage.  out_hot = atlas.hot_start / hot_end.
+ *   Returns TF_ERR_ATLAS_FULL when the atlas overflows (GeneratePatches' -1): the entry that did not get a
+ *   slot and everything behind it in the list stays unprocessed. */
+TF_API int tf_generate_patches(tf_volume* v, const int32_t* ids, int64_t n, const int32_t* labels,
+                               uint64_t out_hot[2]);
+/* Chisel::CompensateColor()  Structure/Chisel.cpp:198-286 (+ computeMeanAndCov, Structure/Patch.cpp:342-348)
+ *   over every mesh with a patch, in ascending chunk-id order (the reference iterates an unordered_map).
+ *   Patches with has_adjusted are skipped; the rest is clustered by frame id (cluster order = first
+ *   appearance).  Per cluster: mean / covariance of texcolor and of the mesh colours over the patches without
+ *   wrong_mapping, the 3x3 transfer T, labs[k] = T (texcolor[k] - mean_src) + mean_tar, has_adjusted = 1.
+ *   Reductions and the per-vertex transfer run on the device, the 3x3 eigen-decompositions on the host (f64
+ *   Jacobi; Eigen's own iteration is not restated, the result agrees to float rounding). */
+TF_API int tf_compensate_color(tf_volume* v, int64_t* out_n_clusters);
+/* Chisel::UpdateAtlas(chunksToUpdate)  Structure/Chisel.cpp:191-196 -> Atlas::UpdateBuffer (Atlas.cpp:71-91):
+ *   the keyframe ROI of every listed complete() patch is copied -- or cv::resize'd when it exceeds the slot --
+ *   into the atlas. */
+TF_API int tf_update_atlas(tf_volume* v, const int32_t* ids, int64_t n);
+/* Chisel::DrawMeshes  Structure/Chisel.cpp:288-355: the interleaved vertex stream the renderer / exporter
+ *   consumes, 12 f32 per vertex
  *     [x, y, z, 50, (float)(R<<16|G<<8|B), adj, u/atlas_w, v/atlas_h, nx, ny, nz, wrong_mapping]
  *   with (u,v) = texcoord * (ratio < 1 ? ratio : 1) + slot origin (Atlas::GetTexLoc) and
- *   adj = labs_valid ? (float)(3 x 9 bit of int((labs - texcolor) * 255) + 255) : 0, plus the index
- *   stream rebased by the running vertex count, for the patches with complete[p] != 0
- *   (Patch::complete), in patch order.  labs_valid[p] = Patch::has_adjusted && !labs.empty().
- *   Per-patch arrays: texloc u64[np], ratio f32[2 np]; per-vertex arrays use vert_offsets, indices
- *   use index_offsets.  out_vertices f32[12 * vert_offsets[np]], out_indices u32[index_offsets[np]]. */
-TF_API int tf_pack_vertices(tf_volume* v, int64_t n_patches, const uint8_t* complete,
-                            const uint8_t* wrong_mapping, const uint8_t* labs_valid, const uint64_t* texloc,
-                            const float* ratio, const int64_t* vert_offsets, const float* verts,
-                            const float* colors, const float* normals, const float* texcoord,
-                            const float* texcolor, const float* labs, const int64_t* index_offsets,
-                            const uint32_t* indices, float* out_vertices, uint32_t* out_indices,
-                            int64_t* out_n_vertices, int64_t* out_n_indices);
+ *   adj = has_adjusted && !labs.empty() ? (float)(3 x 9 bit of int((labs - texcolor) * 255) + 255) : 0, plus
+ *   the index stream rebased by the running vertex count, over every mesh whose patch is complete()
+ *   (Patch.cpp:191-196), in ascending chunk-id order.  _device leaves both streams in HBM (e.g. a mapped GL
+ *   buffer, MobileFusion.h:404-446). */
+TF_API int tf_draw_meshes(tf_volume* v, float* vertices, uint32_t* indices, int64_t cap_vertices,
+                          int64_t cap_indices, int64_t* n_vertices, int64_t* n_indices);
+TF_API int tf_draw_meshes_device(tf_volume* v, float* d_vertices, uint32_t* d_indices, int64_t cap_vertices,
+                                 int64_t cap_indices, int64_t* n_vertices, int64_t* n_indices);
+/* Patch mirrors of listed chunks (Structure/Patch.h:51-94): texloc (~0 = no slot), frameid, boundingbox
+ *   (x, y, w, h), flags (TF_PATCH_*), ratio; texcoord f32[2 nv], texcolor / labs f32[3 nv] packed by
+ *   vert_offsets (from tf_mesh_counts).  Any output may be NULL. */
+#define TF_PATCH_HAS_PATCH 1      /* Mesh::m_patch != nullptr */
+#define TF_PATCH_CAUTION 2        /* CalculateTexCoords returned -1 */
+#define TF_PATCH_WRONG_MAPPING 4  /* Patch::wrong_mapping */
+#define TF_PATCH_HAS_IMAGE 8      /* Patch::has_image */
+#define TF_PATCH_HAS_ADJUSTED 16  /* Patch::has_adjusted */
+TF_API int tf_patches_download(tf_volume* v, const int32_t* ids, int64_t n, const int64_t* vert_offsets,
+                               uint64_t* texloc, int32_t* frameid, int32_t* bbox, int32_t* flags, float* ratio,
+                               float* texcoord, float* texcolor, float* labs);
 /* Atlas::texture_buffer rows [row0,row1) (MobileFusion.h:406-421 uploads the hot rows) */
 TF_API int tf_atlas_download_rows(tf_volume* v, int64_t row0, int64_t row1, uint8_t* dst);
 

@@ -37,6 +37,11 @@ class Integrator(C.Structure):
                 ("scale", C.c_float), ("weight", C.c_float)]
 
 
+class Keyframe(C.Structure):
+    _fields_ = [("rgb", C.POINTER(C.c_uint8)), ("depth", C.POINTER(C.c_float)), ("T", C.c_float * 16),
+                ("kf_id", C.c_int)]
+
+
 class RowStats(C.Structure):
     _fields_ = [("rows_tsdf", C.c_int64), ("rows_color", C.c_int64),
                 ("chunks_updated", C.c_int64)]
@@ -147,6 +152,15 @@ def lib():
     L.tfo_mesh_adjacency.argtypes = [fp, C.c_int64, fp, C.c_float, u8p]
     L.tfo_compress_meshes.restype = C.c_int64
     L.tfo_compress_meshes.argtypes = [vp, i32p, C.c_int64]
+    L.tfo_generate_patches.argtypes = [vp, vp, i32p, C.c_int64, i32p, C.POINTER(Keyframe), u64p]
+    L.tfo_update_atlas.argtypes = [vp, vp, i32p, C.c_int64]
+    L.tfo_compensate_color_volume.restype = C.c_int64
+    L.tfo_compensate_color_volume.argtypes = [vp]
+    L.tfo_draw_meshes.restype = C.c_int64
+    L.tfo_draw_meshes.argtypes = [vp, vp, fp, u32p, C.c_int64, C.c_int64, i64p]
+    L.tfo_volume_get_patch.argtypes = [vp, i32p, u64p, C.POINTER(C.c_int), i32p, C.POINTER(C.c_int), fp, i64p, fp, fp, fp]
+    L.tfo_frame_textured.restype = C.c_int64
+    L.tfo_frame_textured.argtypes = [vp, vp, fp, u8p, fp, fp, C.c_int, u8p]
     _lib = L
     return L
 
@@ -376,6 +390,69 @@ class Volume:
         ids = np.zeros((max(n, 1), 3), np.int32)
         m = self.L.tfo_compress_meshes(self.h, _p(ids, C.c_int32), n)
         return ids[:m].copy()
+
+    # ---- atlas stage on the volume's meshes ----
+    def generate_patches(self, atlas, ids, labels, keyframes):
+        """Chisel::GeneratePatches.  keyframes: dict kf_id -> (rgb u8[H,W,3], depth f32[H,W], T16); the arrays are
+        kept alive by this object (Patch::image is a view).  Returns (rc, hot)."""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        n = len(ids)
+        order = sorted(keyframes)
+        kfs = (Keyframe * max(len(order), 1))()
+        self._kf_keep = getattr(self, "_kf_keep", {})
+        for j, k in enumerate(order):
+            rgb, depth, T = keyframes[k]
+            rgb = np.ascontiguousarray(rgb, np.uint8); depth = f32(depth)
+            self._kf_keep[k] = (rgb, depth)
+            kfs[j].rgb = _p(rgb, C.c_uint8); kfs[j].depth = _p(depth, C.c_float); kfs[j].kf_id = int(k)
+            for q, val in enumerate(f32(T).reshape(16)):
+                kfs[j].T[q] = val
+        idx = np.array([order.index(int(l)) for l in labels], np.int32)
+        hot = np.zeros(2, np.uint64)
+        rc = self.L.tfo_generate_patches(self.h, atlas.h, _p(ids, C.c_int32), n, _p(idx, C.c_int32), kfs,
+                                         _p(hot, C.c_uint64))
+        return rc, (int(hot[0]), int(hot[1]))
+
+    def update_atlas(self, atlas, ids):
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        self.L.tfo_update_atlas(self.h, atlas.h, _p(ids, C.c_int32), len(ids))
+
+    def compensate_color(self):
+        return int(self.L.tfo_compensate_color_volume(self.h))
+
+    def draw_meshes(self, atlas):
+        ni = C.c_int64(0)
+        nv = self.L.tfo_draw_meshes(self.h, atlas.h, None, None, 0, 0, C.byref(ni))
+        V = np.zeros((max(nv, 1), 12), np.float32); I = np.zeros(max(ni.value, 1), np.uint32)
+        self.L.tfo_draw_meshes(self.h, atlas.h, _p(V, C.c_float), _p(I, C.c_uint32), nv, ni.value, C.byref(ni))
+        return V[:nv], I[:ni.value]
+
+    def get_patch(self, cid):
+        cid = np.ascontiguousarray(cid, np.int32)
+        tl = C.c_uint64(0); fid = C.c_int(0); flags = C.c_int(0); pnv = C.c_int64(0)
+        bbox = np.zeros(4, np.int32); ratio = np.zeros(2, np.float32)
+        if self.L.tfo_volume_get_patch(self.h, _p(cid, C.c_int32), C.byref(tl), C.byref(fid), _p(bbox, C.c_int32),
+                                       C.byref(flags), _p(ratio, C.c_float), C.byref(pnv), None, None, None) != 0:
+            return None
+        n = pnv.value
+        tc = np.zeros((max(n, 1), 2), np.float32); tcol = np.zeros((max(n, 1), 3), np.float32)
+        labs = np.zeros((max(n, 1), 3), np.float32)
+        self.L.tfo_volume_get_patch(self.h, _p(cid, C.c_int32), None, None, None, None, None, None,
+                                    _p(tc, C.c_float), _p(tcol, C.c_float), _p(labs, C.c_float))
+        return dict(texloc=int(tl.value), frameid=fid.value, bbox=bbox, flags=flags.value, ratio=ratio,
+                    texcoord=tc[:n], texcolor=tcol[:n], labs=labs[:n])
+
+    def frame_textured(self, atlas, depth, rgba, pose, pose_inv16, frame_id):
+        """The textured per-frame unit; returns the number of patches (chunksToUpdate)."""
+        depth = f32(depth); rgba = np.ascontiguousarray(rgba, np.uint8)
+        pose = f32(pose).reshape(12); T = f32(pose_inv16).reshape(16)
+        self._scratch = getattr(self, "_scratch", None)
+        if self._scratch is None or self._scratch.size != depth.size * 3:
+            self._scratch = np.zeros(depth.size * 3, np.uint8)
+        self._frame_keep = (depth, rgba)
+        return int(self.L.tfo_frame_textured(self.h, atlas.h, _p(depth, C.c_float), _p(rgba, C.c_uint8),
+                                             _p(pose, C.c_float), _p(T, C.c_float), int(frame_id),
+                                             _p(self._scratch, C.c_uint8)))
 
     def finalize(self, ids, needs, new):
         ids = np.ascontiguousarray(ids, np.int32)

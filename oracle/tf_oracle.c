@@ -1306,6 +1306,19 @@ struct tfo_mesh {
   uint32_t* indices; /* [ni] Mesh::indices */
   uint8_t adj[6];    /* Mesh::adj */
   int simplified;    /* Mesh::simplified */
+  /* Mesh::m_patch (Structure/Patch.h:51-94) */
+  int has_patch;     /* m_patch != nullptr */
+  uint64_t texloc;
+  int frameid, has_image, has_adjusted, wrong_mapping, caution;
+  int32_t bbox[4];
+  float ratio[2];
+  int32_t pnv;       /* texcoord.size() */
+  float* texcoord;   /* [2*pnv] */
+  float* texcolor;   /* [3*pnv] */
+  float* labs;       /* [3*pnv]; labs_n = 0 <=> labs.empty() */
+  int32_t labs_n;
+  const uint8_t* img_rgb; /* Patch::image = a non-owning ROI of the keyframe's rgb (Patch.cpp:172-175) */
+  int img_w, img_h;
 };
 
 /* sdf of the voxel at chunk `cid`, voxel index `vi`; returns 0 when the chunk does not exist
@@ -1497,6 +1510,7 @@ static struct tfo_mesh* vol_get_mesh(const tfo_volume* v, const int32_t* id) {
 }
 static void mesh_release(struct tfo_mesh* m) {
   free(m->verts); free(m->normals); free(m->colors); free(m->indices);
+  free(m->texcoord); free(m->texcolor); free(m->labs);
   memset(m, 0, sizeof(*m));
 }
 static void vol_erase_mesh(tfo_volume* v, const int32_t* id) {
@@ -1641,5 +1655,200 @@ int64_t tfo_compress_meshes(tfo_volume* v, int32_t* out_ids, int64_t cap) {
   if (out_ids) memcpy(out_ids, ids, sizeof(int32_t) * 3 * (size_t)(n < cap ? n : cap));
   free(ids);
   tfo_volume_clear_dirty(v);
+  return n;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* the atlas stage on the volume's meshes: Chisel::GeneratePatches / UpdateAtlas /         */
+/* CompensateColor / DrawMeshes (Structure/Chisel.cpp:149-355) with Mesh::m_patch state    */
+/* ------------------------------------------------------------------------------------ */
+/* Chisel::GeneratePatches (Chisel.cpp:149-189) over `ids` in list order; kf_index[i] selects the
+ * keyframe of entry i (the label view selection hands out).  Returns 0, or -1 when AddPatch
+ * overflows (the entry and everything behind it stays unprocessed). */
+int tfo_generate_patches(tfo_volume* v, tfo_atlas* a, const int32_t* ids, int64_t n, const int32_t* kf_index,
+                         const tfo_keyframe* kfs, uint64_t hot[2]) {
+  uint64_t loc_start = (uint64_t)a->aw * (uint64_t)a->ah, loc_end = 0;
+  int rc = 0;
+  for (int64_t i = 0; i < n; i++) {
+    struct tfo_mesh* m = vol_get_mesh(v, ids + 3 * i);
+    if (!m) continue; /* :157 */
+    const tfo_keyframe* kf = &kfs[kf_index[i]];
+    if (!m->has_patch) { /* Atlas::AddPatch (Atlas.cpp:43-64) */
+      uint64_t tl;
+      if (tfo_atlas_alloc(a, &tl) != 0) { rc = -1; break; }
+      m->has_patch = 1;
+      m->texloc = tl;
+    }
+    /* Patch::clear (Patch.cpp:177-189) */
+    m->frameid = -1; m->has_image = 0; m->has_adjusted = 0; m->labs_n = 0;
+    m->ratio[0] = m->ratio[1] = 1.0f;
+    free(m->texcoord); free(m->texcolor); free(m->labs);
+    m->pnv = m->nv;
+    m->texcoord = (float*)malloc(sizeof(float) * 2 * (m->nv ? m->nv : 1));
+    m->texcolor = (float*)malloc(sizeof(float) * 3 * (m->nv ? m->nv : 1));
+    m->labs = (float*)malloc(sizeof(float) * 3 * (m->nv ? m->nv : 1));
+    int64_t ncau = 0;
+    int wrong = 0;
+    const int flag = tfo_patch_project(m->verts, m->colors, m->nv, kf->T, kf->rgb, kf->depth, &v->cam,
+                                       m->texcoord, m->texcolor, m->bbox, &wrong, &ncau);
+    m->wrong_mapping = wrong;
+    m->caution = flag < 0;
+    m->frameid = kf->kf_id;                        /* SetFrameid */
+    m->img_rgb = kf->rgb; m->img_w = v->cam.width; m->img_h = v->cam.height; m->has_image = 1; /* SetImage */
+    if (m->texloc < loc_start) loc_start = m->texloc;
+    if (m->texloc > loc_end) loc_end = m->texloc;
+  }
+  if (hot) {
+    hot[0] = (loc_start / (uint64_t)a->aw) * (uint64_t)a->aw;
+    hot[1] = (loc_end / (uint64_t)a->aw + a->ph) * (uint64_t)a->aw;
+  }
+  return rc;
+}
+
+/* Patch::complete (Patch.cpp:191-196) */
+static int patch_complete(const struct tfo_mesh* m) {
+  if (m->nv == 0 || !m->simplified) return 0;
+  if (!m->has_patch || !m->has_image || m->pnv == 0 || m->frameid < 0) return 0;
+  return 1;
+}
+
+/* Chisel::UpdateAtlas (Chisel.cpp:191-196) -> Atlas::UpdateBuffer (Atlas.cpp:71-91) */
+void tfo_update_atlas(tfo_volume* v, tfo_atlas* a, const int32_t* ids, int64_t n) {
+  for (int64_t i = 0; i < n; i++) {
+    struct tfo_mesh* m = vol_get_mesh(v, ids + 3 * i);
+    if (!m || !m->has_patch || !patch_complete(m)) continue;
+    tfo_atlas_blit(a, m->texloc, m->img_rgb, m->img_w, m->img_h, m->bbox, m->ratio);
+  }
+}
+
+/* every mesh in ascending (x, y, z) order (the reference iterates an unordered_map) */
+static int64_t meshes_sorted(const tfo_volume* v, int32_t** out) {
+  int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * 3 * (v->mesh_map.live ? v->mesh_map.live : 1));
+  const int64_t n = tfo_volume_list_meshes(v, ids, v->mesh_map.live);
+  qsort(ids, (size_t)n, 12, cmp_id3);
+  *out = ids;
+  return n;
+}
+
+/* Chisel::CompensateColor (Chisel.cpp:198-286) over allMeshes; returns the cluster count */
+int64_t tfo_compensate_color_volume(tfo_volume* v) {
+  int32_t* ids;
+  const int64_t nm = meshes_sorted(v, &ids);
+  int64_t np = 0, nvt = 0;
+  struct tfo_mesh** pm = (struct tfo_mesh**)malloc(sizeof(void*) * (nm ? nm : 1));
+  for (int64_t i = 0; i < nm; i++) {
+    struct tfo_mesh* m = vol_get_mesh(v, ids + 3 * i);
+    if (!m->has_patch) continue;
+    pm[np++] = m;
+    nvt += m->pnv;
+  }
+  int32_t* fid = (int32_t*)malloc(sizeof(int32_t) * (np ? np : 1));
+  uint8_t* wrong = (uint8_t*)malloc(np ? np : 1);
+  uint8_t* adj = (uint8_t*)malloc(np ? np : 1);
+  int64_t* voff = (int64_t*)malloc(sizeof(int64_t) * (np + 1));
+  float* tc = (float*)malloc(sizeof(float) * 3 * (nvt ? nvt : 1));
+  float* mc = (float*)malloc(sizeof(float) * 3 * (nvt ? nvt : 1));
+  float* labs = (float*)malloc(sizeof(float) * 3 * (nvt ? nvt : 1));
+  voff[0] = 0;
+  for (int64_t p = 0; p < np; p++) {
+    fid[p] = pm[p]->frameid; wrong[p] = (uint8_t)pm[p]->wrong_mapping; adj[p] = (uint8_t)pm[p]->has_adjusted;
+    voff[p + 1] = voff[p] + pm[p]->pnv;
+    memcpy(tc + 3 * voff[p], pm[p]->texcolor, sizeof(float) * 3 * pm[p]->pnv);
+    /* patch->mesh->colors: the mesh as it is now (same vertex count when the patch is current) */
+    memcpy(mc + 3 * voff[p], pm[p]->colors, sizeof(float) * 3 * (pm[p]->pnv < pm[p]->nv ? pm[p]->pnv : pm[p]->nv));
+  }
+  uint8_t* adj0 = (uint8_t*)malloc(np ? np : 1);
+  memcpy(adj0, adj, np);
+  const int64_t ncl = tfo_color_compensate(np, fid, wrong, adj, voff, tc, mc, labs, NULL, NULL);
+  for (int64_t p = 0; p < np; p++) {
+    if (adj0[p]) continue; /* skipped: untouched */
+    if (!adj[p]) { /* cluster without a correctly mapped vertex: labs = texcolor copy, cleared when wrong (:228-236) */
+      memcpy(pm[p]->labs, pm[p]->texcolor, sizeof(float) * 3 * pm[p]->pnv);
+      pm[p]->labs_n = pm[p]->wrong_mapping ? 0 : pm[p]->pnv;
+      continue;
+    }
+    pm[p]->has_adjusted = 1;
+    if (pm[p]->wrong_mapping) { pm[p]->labs_n = 0; continue; }
+    memcpy(pm[p]->labs, labs + 3 * voff[p], sizeof(float) * 3 * pm[p]->pnv);
+    pm[p]->labs_n = pm[p]->pnv;
+  }
+  free(ids); free(pm); free(fid); free(wrong); free(adj); free(adj0); free(voff); free(tc); free(mc); free(labs);
+  return ncl;
+}
+
+/* Chisel::DrawMeshes (Chisel.cpp:288-355) over allMeshes (ascending id).  Buffers: out_vertices f32[12 * cap_v],
+ * out_indices u32[cap_i]; returns the vertex count (even when it exceeds cap_v: nothing is written then). */
+int64_t tfo_draw_meshes(tfo_volume* v, const tfo_atlas* a, float* out_vertices, uint32_t* out_indices,
+                        int64_t cap_v, int64_t cap_i, int64_t* n_indices) {
+  int32_t* ids;
+  const int64_t nm = meshes_sorted(v, &ids);
+  int64_t nv = 0, ni = 0;
+  for (int64_t i = 0; i < nm; i++) {
+    const struct tfo_mesh* m = vol_get_mesh(v, ids + 3 * i);
+    if (!m->has_patch || !patch_complete(m)) continue;
+    nv += m->nv; ni += m->ni;
+  }
+  if (n_indices) *n_indices = ni;
+  if (nv > cap_v || ni > cap_i) { free(ids); return nv; }
+  int64_t vout = 0, iout = 0;
+  for (int64_t i = 0; i < nm; i++) {
+    const struct tfo_mesh* m = vol_get_mesh(v, ids + 3 * i);
+    if (!m->has_patch || !patch_complete(m)) continue;
+    const uint8_t one = 1, wr = (uint8_t)m->wrong_mapping, lv = (uint8_t)(m->has_adjusted && m->labs_n > 0);
+    const int64_t voff[2] = {0, m->nv}, ioff[2] = {0, m->ni};
+    int64_t nidx = 0;
+    uint32_t* tmp_i = out_indices + iout;
+    tfo_pack_vertices(1, &one, &wr, &lv, &m->texloc, m->ratio, a->aw, a->ah, voff, m->verts, m->colors, m->normals,
+                      m->texcoord, m->texcolor, m->labs, ioff, m->indices, out_vertices + 12 * vout, tmp_i, &nidx);
+    for (int64_t k = 0; k < nidx; k++) tmp_i[k] += (uint32_t)vout; /* indices rebased by the running vertex count */
+    vout += m->nv; iout += nidx;
+  }
+  free(ids);
+  return nv;
+}
+
+/* Patch mirror of one chunk; buffers may be NULL */
+int tfo_volume_get_patch(const tfo_volume* v, const int id[3], uint64_t* texloc, int* frameid, int32_t bbox[4],
+                         int* flags, float ratio[2], int64_t* pnv, float* texcoord, float* texcolor, float* labs) {
+  const struct tfo_mesh* m = vol_get_mesh(v, id);
+  if (!m) return -1;
+  if (texloc) *texloc = m->has_patch ? m->texloc : ~0ull;
+  if (frameid) *frameid = m->has_patch ? m->frameid : -1;
+  if (bbox) memcpy(bbox, m->bbox, 16);
+  if (flags) *flags = (m->has_patch ? 1 : 0) | (m->caution ? 2 : 0) | (m->wrong_mapping ? 4 : 0) |
+                      (m->has_image ? 8 : 0) | (m->has_adjusted ? 16 : 0) | ((m->labs_n > 0) ? 32 : 0);
+  if (ratio) { ratio[0] = m->ratio[0]; ratio[1] = m->ratio[1]; }
+  if (pnv) *pnv = m->has_patch ? m->pnv : 0;
+  if (m->has_patch) {
+    if (texcoord) memcpy(texcoord, m->texcoord, sizeof(float) * 2 * m->pnv);
+    if (texcolor) memcpy(texcolor, m->texcolor, sizeof(float) * 3 * m->pnv);
+    if (labs && m->labs_n > 0) memcpy(labs, m->labs, sizeof(float) * 3 * m->pnv);
+  }
+  return 0;
+}
+
+/* The textured per-frame unit (BASELINE configs[2]): IntegrateFrame, then over the
+ * frame's dirty chunks UpdateMeshes -> CompressMeshes -> GeneratePatches with label = this frame ->
+ * UpdateAtlas (GCFusion/MobileFusion.cpp:327-382 without the host-side view selection).  The keyframe is the
+ * frame itself: rgb_scratch (u8[H*W*3], kept alive by the caller as long as the patches view it) receives the
+ * RGB of its RGBA image.  chunksToUpdate is taken in ascending id order.  Returns the number of patches. */
+int64_t tfo_frame_textured(tfo_volume* v, tfo_atlas* a, const float* depth, const uint8_t* rgba, const float pose[12],
+                           const float pose_inv16[16], int frame_id, uint8_t* rgb_scratch) {
+  tfo_integrate_frame(v, depth, rgba, pose, NULL);
+  tfo_update_meshes(v);
+  const int64_t cap = v->dirty.live;
+  int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * 3 * (cap ? cap : 1));
+  const int64_t n = tfo_compress_meshes(v, ids, cap);
+  const size_t npix = (size_t)v->cam.width * v->cam.height;
+  for (size_t i = 0; i < npix; i++) {
+    rgb_scratch[3 * i] = rgba[4 * i]; rgb_scratch[3 * i + 1] = rgba[4 * i + 1]; rgb_scratch[3 * i + 2] = rgba[4 * i + 2];
+  }
+  tfo_keyframe kf;
+  kf.rgb = rgb_scratch; kf.depth = depth; kf.kf_id = frame_id;
+  memcpy(kf.T, pose_inv16, 64);
+  int32_t* idx = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
+  tfo_generate_patches(v, a, ids, n, idx, &kf, NULL);
+  tfo_update_atlas(v, a, ids, n);
+  free(ids); free(idx);
   return n;
 }

@@ -209,6 +209,24 @@ void tfo_mesh_adjacency(const float* verts, int64_t nv, const float origin[3], f
  * out_ids = tsdfFusion's chunksToUpdate (GCFusion/MobileFusion.cpp:345-353) in ascending id order */
 int64_t tfo_compress_meshes(tfo_volume* v, int32_t* out_ids, int64_t cap);
 
+/* ---- the atlas stage on the volume's meshes (Mesh::m_patch state kept with the mesh) -------- */
+typedef struct {
+  const uint8_t* rgb; /* u8[H][W][3] Frame::rgb */
+  const float* depth; /* f32[H][W] Frame::refined_depth */
+  float T[16];        /* f32(SE3d.inverse().matrix()) of the keyframe's pose, row-major */
+  int kf_id;          /* the frame id (label) */
+} tfo_keyframe;
+int tfo_generate_patches(tfo_volume* v, tfo_atlas* a, const int32_t* ids, int64_t n, const int32_t* kf_index,
+                         const tfo_keyframe* kfs, uint64_t hot[2]);
+void tfo_update_atlas(tfo_volume* v, tfo_atlas* a, const int32_t* ids, int64_t n);
+int64_t tfo_compensate_color_volume(tfo_volume* v);
+int64_t tfo_draw_meshes(tfo_volume* v, const tfo_atlas* a, float* out_vertices, uint32_t* out_indices,
+                        int64_t cap_v, int64_t cap_i, int64_t* n_indices);
+int tfo_volume_get_patch(const tfo_volume* v, const int id[3], uint64_t* texloc, int* frameid, int32_t bbox[4],
+                         int* flags, float ratio[2], int64_t* pnv, float* texcoord, float* texcolor, float* labs);
+int64_t tfo_frame_textured(tfo_volume* v, tfo_atlas* a, const float* depth, const uint8_t* rgba, const float pose[12],
+                           const float pose_inv16[16], int frame_id, uint8_t* rgb_scratch);
+
 #ifdef __cplusplus
 }
 #endif

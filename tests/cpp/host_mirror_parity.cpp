@@ -2,6 +2,7 @@
 // GCFusion/MobileFusion.cpp drives the reference classes (ReIntegrateKeyframe :114-221,
 // IntegrateFrame :223-250) and checks every result against the CPU oracle (test infrastructure).
 // Plain C++14, no Eigen/OpenCV; built with g++ against libtexfusion_hip.so and libtf_oracle.so.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -46,7 +47,7 @@ int main() {
   tf_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));
   cfg.max_chunks = 1 << 15;
-  cfg.atlas_h = 36;
+  cfg.atlas_h = 72;
 
   // MobileFusion::initChiselMap (GCFusion/MobileFusion.h:205-258)
   chisel::Chisel chiselMap(chunkSize, res, true, &cfg);
@@ -145,117 +146,144 @@ int main() {
   try { chiselMap.GetMutableChunkManager().GetChunk(chisel::ChunkID(9999, 9999, 9999)); } catch (const std::out_of_range&) { threw = true; }
   CHECK(threw);
 
-  // ---- atlas stage as MobileFusion.cpp:347-384 drives it: GeneratePatches + UpdateAtlas,
-  // CompensateColor, DrawMeshes on per-chunk meshes (synthetic vertex clouds on the wall)
+  // ---- the rest of MobileFusion::tsdfFusion (GCFusion/MobileFusion.cpp:327-384) on real meshes: a few more
+  // frames so that voxel weights pass the mesher's threshold, then UpdateMeshes, chunksToUpdate, CompressMeshes,
+  // GeneratePatches (labels from a stand-in for the MRF), CompensateColor, UpdateAtlas, DrawMeshes
   size_t n_patches = 0;
   {
-    std::vector<unsigned char> rgb((size_t)W * H * 3);
-    for (int i = 0; i < W * H; ++i) { rgb[3 * i] = rgba[4 * i]; rgb[3 * i + 1] = rgba[4 * i + 1]; rgb[3 * i + 2] = rgba[4 * i + 2]; }
-    chiselMap.CacheKeyframe(kfIndex, rgb.data(), depth.data());
-    chiselMap.CacheKeyframe(kfIndex + 1, rgb.data(), depth2.data());
-    std::vector<chisel::PatchMesh> meshes;
-    std::vector<int> labels;
-    std::vector<const float*> poseInv;
-    float Tinv[16] = {1, 0, 0, -0.01f, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // inverse of lastPose
-    const float edge = 8 * res;
-    for (int64_t i = 0; i < nv && meshes.size() < 150; i += 7) {
-      const chisel::ChunkID id = validChunks[i];
-      if (!(id(2) * edge <= 1.5f && 1.5f < (id(2) + 1) * edge)) continue;
-      chisel::PatchMesh m;
-      m.chunkID = id;
-      unsigned h = (unsigned)(id(0) * 73856093) ^ (unsigned)(id(1) * 19349663);
-      const int nvert = 6 + (int)(h % 20u);
-      for (int k = 0; k < nvert; ++k) {
-        h = h * 1664525u + 1013904223u;
-        const float fx = (float)((h >> 8) & 0xFFFF) / 65536.0f, fy = (float)((h >> 12) & 0xFFFF) / 65536.0f;
-        m.vertices.push_back((id(0) + fx) * edge); m.vertices.push_back((id(1) + fy) * edge); m.vertices.push_back(1.5f);
-        m.colors.push_back((float)((h >> 3) & 0xFF) / 255.0f); m.colors.push_back((float)((h >> 11) & 0xFF) / 255.0f);
-        m.colors.push_back((float)((h >> 19) & 0xFF) / 255.0f);
-        m.normals.push_back(0.0f); m.normals.push_back(0.0f); m.normals.push_back(-1.0f);
-      }
-      for (int k = 0; k + 2 < nvert; ++k) { m.indices.push_back(0); m.indices.push_back(k + 1); m.indices.push_back(k + 2); }
-      meshes.push_back(m);
-      labels.push_back(kfIndex + (int)(meshes.size() % 2));
-      poseInv.push_back(Tinv);
+    for (int k = 0; k < 7; ++k) {
+      std::vector<float> d, q;
+      std::vector<unsigned char> c;
+      make_frame(W, H, 1.5f, 20 + k, d, c, q);
+      chiselMap.IntegrateDepthScanColor(projectionIntegrator, d.data(), c.data(), lastPose, cameraModel);
+      tfo_integrate_frame(ov, d.data(), c.data(), lastPose.data(), NULL);
     }
-    n_patches = meshes.size();
-    CHECK(n_patches > 40);
-    std::vector<chisel::PatchResult> patches;
-    CHECK(chiselMap.GeneratePatchesAndUpdateAtlas(meshes, labels, poseInv, cameraModel, patches) == 0);
-    // oracle: slot, projection, blit per patch in the same order
+    chiselMap.UpdateMeshes(cameraModel);
+    tfo_update_meshes(ov);
+    const chisel::MeshMap& allMeshes = chiselMap.GetChunkManager().GetAllMeshes();
+    CHECK((int64_t)allMeshes.size() == tfo_volume_num_meshes(ov));
+    // chunksToUpdate (MobileFusion.cpp:345-353); the reference's order is its unordered_map's, the test sorts
+    chisel::ChunkIDList chunksToUpdate;
+    for (const auto& it : chiselMap.GetMeshesToUpdate()) {
+      if (!it.second) continue;
+      if (allMeshes.find(it.first) == allMeshes.end()) continue;
+      chunksToUpdate.emplace_back(it.first);
+    }
+    std::sort(chunksToUpdate.begin(), chunksToUpdate.end(), [](const chisel::ChunkID& x, const chisel::ChunkID& y) {
+      for (int k = 0; k < 3; ++k) if (x(k) != y(k)) return x(k) < y(k);
+      return false;
+    });
+    chiselMap.CompressMeshes(chiselMap.meshesToUpdate);
+    n_patches = chunksToUpdate.size();
+    CHECK(n_patches > 300);
+    std::vector<int32_t> oids2(n_patches * 3 + 3);
+    CHECK(tfo_compress_meshes(ov, oids2.data(), (int64_t)n_patches) == (int64_t)n_patches);
+    for (size_t i = 0; i < n_patches; ++i)
+      CHECK(oids2[3 * i] == chunksToUpdate[i](0) && oids2[3 * i + 1] == chunksToUpdate[i](1) && oids2[3 * i + 2] == chunksToUpdate[i](2));
+    CHECK(chiselMap.GetMeshesToUpdate().empty() && tfo_volume_num_dirty(ov) == 0);
+    // mesh mirrors: counts, flags, and the arrays of a few meshes
+    for (size_t i = 0; i < n_patches; i += 17) {
+      const chisel::ChunkID id = chunksToUpdate[i];
+      chiselMap.GetMutableChunkManager().FetchMeshData(id);
+      const chisel::MeshPtr& m = chiselMap.GetChunkManager().GetMesh(id);
+      int64_t onv = 0, oni = 0;
+      uint8_t oadj[6];
+      int osimp = 0;
+      std::vector<float> ovx(3 * 2187), onr(3 * 2187), ocl(3 * 2187);
+      std::vector<uint32_t> oix(7680);
+      int cid[3] = {id(0), id(1), id(2)};
+      CHECK(tfo_volume_get_mesh(ov, cid, &onv, &oni, ovx.data(), onr.data(), ocl.data(), oix.data(), oadj, &osimp) == 0);
+      CHECK(m->n_vertices == onv && m->n_indices == oni && m->simplified == (osimp != 0));
+      for (int k = 0; k < 6; ++k) CHECK(m->adj[k] == (oadj[k] != 0));
+      CHECK(std::memcmp(m->vertices.data(), ovx.data(), (size_t)onv * 12) == 0);
+      CHECK(std::memcmp(m->normals.data(), onr.data(), (size_t)onv * 12) == 0);
+      CHECK(std::memcmp(m->colors.data(), ocl.data(), (size_t)onv * 12) == 0);
+      CHECK(std::memcmp(m->indices.data(), oix.data(), (size_t)oni * 4) == 0);
+    }
+    // keyframes + labels (TexMap / mapMAP are host code outside the path: a fixed assignment stands in)
+    std::vector<unsigned char> rgb((size_t)W * H * 3), rgbB((size_t)W * H * 3);
+    for (int i = 0; i < W * H; ++i)
+      for (int c = 0; c < 3; ++c) { rgb[3 * i + c] = rgba[4 * i + c]; rgbB[3 * i + c] = (unsigned char)(rgba2[4 * i + c] * 3 / 4); }
+    std::vector<chisel::Frame> frame_list(kfIndex + 2);
+    const float Tinv[16] = {1, 0, 0, -0.01f, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // inverse of lastPose
+    for (int f = kfIndex; f < kfIndex + 2; ++f) {
+      frame_list[f].frame_index = f;
+      frame_list[f].rgb = f == kfIndex ? rgb.data() : rgbB.data();
+      frame_list[f].refined_depth = f == kfIndex ? depth.data() : depth2.data();
+      std::memcpy(frame_list[f].pose_inv, Tinv, 64);
+    }
+    chisel::UniGraph labelset;
+    std::vector<int32_t> kfidx(n_patches);
+    for (size_t i = 0; i < n_patches; ++i) {
+      labelset.chunks[chunksToUpdate[i]] = i;
+      labelset.labels.push_back(kfIndex + (int)(i % 2));
+      kfidx[i] = (int32_t)(i % 2);
+    }
+    CHECK(chiselMap.GeneratePatches(chunksToUpdate, labelset, frame_list, cameraModel) == 0);
     tfo_camera ocam = {W, H, 525.0f, 525.0f, 319.5f, 239.5f, 0.01f, 5.0f};
+    tfo_volume_set_camera(ov, &ocam);
     tfo_atlas* oa = tfo_atlas_create(res, 0, cfg.atlas_h);
-    std::vector<int32_t> fid(n_patches);
-    std::vector<uint8_t> wrong(n_patches), adj(n_patches, 0), complete(n_patches, 1), labs_valid(n_patches);
-    std::vector<int64_t> voff(n_patches + 1, 0), ioff(n_patches + 1, 0);
-    std::vector<float> tex, meshc, verts, nrm, tcoord, ratio(2 * n_patches);
-    std::vector<uint64_t> texlocs(n_patches);
-    std::vector<uint32_t> idx;
-    for (size_t p = 0; p < n_patches; ++p) {
-      const size_t nvp = meshes[p].vertices.size() / 3;
-      uint64_t tl = 0;
-      CHECK(tfo_atlas_alloc(oa, &tl) == 0);
-      CHECK(tl == patches[p].texloc);
-      std::vector<float> tc(2 * nvp), tcol(3 * nvp);
-      int32_t bbox[4];
-      int wm = 0;
-      int64_t caution = 0;
-      const float* dimg = labels[p] == kfIndex ? depth.data() : depth2.data();
-      const int flag = tfo_patch_project(meshes[p].vertices.data(), meshes[p].colors.data(), (int64_t)nvp, Tinv, rgb.data(),
-                                         dimg, &ocam, tc.data(), tcol.data(), bbox, &wm, &caution);
-      CHECK(flag == patches[p].flag && (wm != 0) == patches[p].wrong_mapping);
-      CHECK(std::memcmp(bbox, patches[p].boundingbox, 16) == 0);
-      CHECK(std::memcmp(tc.data(), patches[p].texcoord.data(), tc.size() * 4) == 0);
-      CHECK(std::memcmp(tcol.data(), patches[p].texcolor.data(), tcol.size() * 4) == 0);
-      float r2[2] = {1.0f, 1.0f};
-      CHECK(tfo_atlas_blit(oa, tl, rgb.data(), W, H, bbox, r2) == 0);
-      CHECK(r2[0] == patches[p].ratio[0] && r2[1] == patches[p].ratio[1]);
-      fid[p] = labels[p]; wrong[p] = wm ? 1 : 0; texlocs[p] = tl;
-      ratio[2 * p] = r2[0]; ratio[2 * p + 1] = r2[1];
-      tex.insert(tex.end(), tcol.begin(), tcol.end());
-      tcoord.insert(tcoord.end(), tc.begin(), tc.end());
-      meshc.insert(meshc.end(), meshes[p].colors.begin(), meshes[p].colors.end());
-      verts.insert(verts.end(), meshes[p].vertices.begin(), meshes[p].vertices.end());
-      nrm.insert(nrm.end(), meshes[p].normals.begin(), meshes[p].normals.end());
-      idx.insert(idx.end(), meshes[p].indices.begin(), meshes[p].indices.end());
-      voff[p + 1] = (int64_t)verts.size() / 3;
-      ioff[p + 1] = (int64_t)idx.size();
+    tfo_keyframe okf[2];
+    for (int f = 0; f < 2; ++f) {
+      okf[f].rgb = frame_list[kfIndex + f].rgb; okf[f].depth = frame_list[kfIndex + f].refined_depth;
+      okf[f].kf_id = kfIndex + f;
+      std::memcpy(okf[f].T, Tinv, 64);
+    }
+    uint64_t ohot[2];
+    CHECK(tfo_generate_patches(ov, oa, oids2.data(), (int64_t)n_patches, kfidx.data(), okf, ohot) == 0);
+    CHECK(chiselMap.atlas.hot_start == ohot[0] && chiselMap.atlas.hot_end == ohot[1]);
+    CHECK(chiselMap.atlas.loc_next == tfo_atlas_loc_next(oa));
+    chiselMap.CompensateColor();
+    CHECK(tfo_compensate_color_volume(ov) == 2);
+    chiselMap.UpdateAtlas(chunksToUpdate);
+    tfo_update_atlas(ov, oa, oids2.data(), (int64_t)n_patches);
+    for (size_t i = 0; i < n_patches; ++i) {
+      const chisel::ChunkID id = chunksToUpdate[i];
+      CHECK(chiselMap.atlas.HasPatch(id));
+      chisel::PatchPtr p = chiselMap.atlas.GetPatch(id);
+      CHECK(p != nullptr);
+      uint64_t otl = 0;
+      int ofid = 0, oflags = 0;
+      int32_t obb[4];
+      float orat[2];
+      int64_t opnv = 0;
+      int cid[3] = {id(0), id(1), id(2)};
+      std::vector<float> otc(2 * 2187), otcol(3 * 2187), olabs(3 * 2187);
+      CHECK(tfo_volume_get_patch(ov, cid, &otl, &ofid, obb, &oflags, orat, &opnv, otc.data(), otcol.data(), olabs.data()) == 0);
+      CHECK(p->texloc == otl && p->frameid == ofid && p->frameid == labelset.labels[i]);
+      CHECK(p->boundingbox.x == obb[0] && p->boundingbox.y == obb[1] && p->boundingbox.width == obb[2] && p->boundingbox.height == obb[3]);
+      CHECK(p->wrong_mapping == ((oflags & 4) != 0) && p->has_image == ((oflags & 8) != 0) && p->has_adjusted == ((oflags & 16) != 0));
+      CHECK(p->ratio(0) == orat[0] && p->ratio(1) == orat[1]);
+      CHECK(p->complete());
+      if (i % 23 == 0) {
+        chiselMap.FetchPatchData(id);
+        CHECK((int64_t)p->texcoord.size() == opnv);
+        CHECK(std::memcmp(p->texcoord.data(), otc.data(), (size_t)opnv * 8) == 0);
+        CHECK(std::memcmp(p->texcolor.data(), otcol.data(), (size_t)opnv * 12) == 0);
+        if ((oflags & 16) && (oflags & 32))
+          for (int64_t k = 0; k < 3 * opnv; ++k) {
+            const float dlt = (&p->labs[0].v[0])[k] - olabs[(size_t)k];
+            CHECK(dlt < 2e-5f && dlt > -2e-5f);  // colour compensation: the one stated tolerance
+          }
+      }
     }
     std::vector<unsigned char> rows((size_t)cfg.atlas_h * 13824 * 3);
     chiselMap.atlas.DownloadRows(0, cfg.atlas_h, rows.data());
     CHECK(std::memcmp(rows.data(), tfo_atlas_buffer(oa), rows.size()) == 0);
-    // CompensateColor (Chisel.cpp:198-286): flags exact, colours within the stated tolerance
-    chiselMap.CompensateColor(meshes, patches);
-    std::vector<float> olabs(tex.size(), 0.0f);
-    tfo_color_compensate((int64_t)n_patches, fid.data(), wrong.data(), adj.data(), voff.data(), tex.data(), meshc.data(),
-                         olabs.data(), NULL, NULL);
-    std::vector<float> mlabs(tex.size(), 0.0f);
-    for (size_t p = 0; p < n_patches; ++p) {
-      CHECK(patches[p].has_adjusted == (adj[p] != 0));
-      const bool lv = patches[p].has_adjusted && !patches[p].labs.empty();
-      CHECK(lv == (adj[p] != 0 && !wrong[p]));
-      labs_valid[p] = lv ? 1 : 0;
-      if (!lv) continue;
-      for (size_t k = 0; k < patches[p].labs.size(); ++k) {
-        const float d = patches[p].labs[k] - olabs[3 * voff[p] + k];
-        CHECK(d < 2e-5f && d > -2e-5f);
-        mlabs[3 * voff[p] + k] = patches[p].labs[k];
-      }
-    }
-    // DrawMeshes (Chisel.cpp:288-355): bit-exact given the same compensated colours
-    std::vector<float> gv(12 * (size_t)voff[n_patches] + 12), ovx(gv.size());
-    std::vector<unsigned int> gi(idx.size() + 1);
-    std::vector<uint32_t> oi(idx.size() + 1);
-    unsigned int ni = 0, nvx = 0;
-    chiselMap.DrawMeshes(meshes, patches, gv.data(), gi.data(), ni, nvx);
+    // DrawMeshes: counts, indices and every vertex column but the packed colour delta are identical
     int64_t oni = 0;
-    const int64_t onv = tfo_pack_vertices((int64_t)n_patches, complete.data(), wrong.data(), labs_valid.data(), texlocs.data(),
-                                          ratio.data(), 13824, cfg.atlas_h, voff.data(), verts.data(), meshc.data(), nrm.data(),
-                                          tcoord.data(), tex.data(), mlabs.data(), ioff.data(), idx.data(), ovx.data(),
-                                          oi.data(), &oni);
-    CHECK((int64_t)nvx == onv && (int64_t)ni == oni && onv == voff[n_patches]);
-    CHECK(std::memcmp(gv.data(), ovx.data(), (size_t)onv * 48) == 0);
+    const int64_t onv = tfo_draw_meshes(ov, oa, NULL, NULL, 0, 0, &oni);
+    std::vector<float> gv(12 * (size_t)onv + 12), ovx(gv.size());
+    std::vector<unsigned int> gi((size_t)oni + 1);
+    std::vector<uint32_t> oi((size_t)oni + 1);
+    unsigned int ni = 0, nvx = 0;
+    chiselMap.DrawMeshes(gv.data(), gi.data(), ni, nvx, onv, oni);
+    CHECK(tfo_draw_meshes(ov, oa, ovx.data(), oi.data(), onv, oni, &oni) == onv);
+    CHECK((int64_t)nvx == onv && (int64_t)ni == oni && onv > 1000);
     CHECK(std::memcmp(gi.data(), oi.data(), (size_t)oni * 4) == 0);
+    for (int64_t k = 0; k < onv; ++k)
+      for (int c = 0; c < 12; ++c)
+        if (c != 5) CHECK(std::memcmp(&gv[12 * (size_t)k + c], &ovx[12 * (size_t)k + c], 4) == 0);
     tfo_atlas_destroy(oa);
   }
 

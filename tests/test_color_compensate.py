@@ -1,5 +1,5 @@
 """Chisel::CompensateColor (Structure/Chisel.cpp:198-286): analytic known-answer tests of the oracle
-restatement (CPU) and the HIP path against it (GPU).
+restatement (CPU); the HIP path is compared against it in tests/test_gpu_atlas.py.
 
 Tolerance: the eigen-solver of the reference (Eigen's iterative SelfAdjointEigenSolver) is third-party
 arithmetic that is not restated ("parity unpinned", 1-ulp class); oracle and product
@@ -80,35 +80,3 @@ def test_oracle_all_wrong_cluster_is_left_untouched():
     wrong[fid == 2] = 1  # every patch of frame 2 maps wrongly: color_src empty -> `continue` (:242)
     labs, adj2, T, cl = O.color_compensate(fid, wrong, adj, voff, tex, mesh)
     assert (adj2[fid == 1] == 1).all() and (adj2[fid == 2] == 0).all()
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("seed,adjusted_every", [(11, 0), (12, 4), (13, 1)])
-def test_hip_matches_oracle(gpu_required, seed, adjusted_every):
-    from texturefusion_amd import capi, synth
-    fid, wrong, adj, voff, tex, mesh = _batch(seed, n_patches=300, frames=(3, 7, 3, 9, 11), adjusted_every=adjusted_every)
-    gv = capi.Volume(np.float32(0.005), synth.Camera(), max_chunks=1 << 10)
-    olabs, oadj, oT, ocl = O.color_compensate(fid, wrong, adj, voff, tex, mesh)
-    glabs, gadj, ncl = gv.color_compensate(fid, wrong, adj, voff, tex, mesh)
-    assert ncl == len(oT)
-    assert np.array_equal(gadj, oadj)
-    assert np.array_equal(np.isnan(glabs), np.isnan(olabs))
-    m = ~np.isnan(olabs)
-    assert np.abs(glabs[m] - olabs[m]).max() <= TOL if m.any() else True
-
-
-@pytest.mark.gpu
-def test_hip_all_wrong_cluster_and_empty_batch(gpu_required):
-    from texturefusion_amd import capi, synth
-    gv = capi.Volume(np.float32(0.005), synth.Camera(), max_chunks=1 << 10)
-    fid, wrong, adj, voff, tex, mesh = _batch(2, n_patches=6, frames=(1, 2), wrong_every=2)
-    wrong[:] = 0
-    wrong[fid == 2] = 1
-    glabs, gadj, ncl = gv.color_compensate(fid, wrong, adj, voff, tex, mesh)
-    olabs, oadj, _, _ = O.color_compensate(fid, wrong, adj, voff, tex, mesh)
-    assert ncl == 2 and np.array_equal(gadj, oadj)
-    m = ~np.isnan(olabs)
-    assert np.array_equal(np.isnan(glabs), np.isnan(olabs)) and np.abs(glabs[m] - olabs[m]).max() <= TOL
-    labs, adj2, ncl = gv.color_compensate(np.zeros(0, np.int32), np.zeros(0, np.uint8), np.zeros(0, np.uint8),
-                                          np.zeros(1, np.int64), np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
-    assert ncl == 0 and len(labs) == 0

@@ -1,184 +1,277 @@
-"""Texture-atlas path on the GPU vs the oracle: slot assignment / bbox / flags bit-exact, texcoord and
-texcolour bit-exact (same operation order), atlas texels exact in the copy branch and exact against the
-oracle's INTER_LINEAR restatement in the resize branch (that restatement itself is parity-unpinned
-third-party arithmetic)."""
+"""The atlas stage on device-resident meshes -- Chisel::GeneratePatches / UpdateAtlas / CompensateColor /
+DrawMeshes (Structure/Chisel.cpp:149-355), Atlas::AddPatch / UpdateBuffer (Structure/Atlas.cpp:43-91),
+Patch::CalculateTexCoords (Structure/Patch.cpp:40-108) -- against the oracle, on meshes both sides produced
+by marching cubes from the same integrated frames.  Everything integer (slots, boxes, flags, texels) and the
+per-vertex projections are compared bit for bit; colour compensation within the tolerance stated in
+tests/test_color_compensate.py."""
 import numpy as np
 import pytest
 
 from oracle import api as O
 from texturefusion_amd import capi, synth
+from tests.util import RES5, HipBuffer, make_pair, sorted_ids
 
 pytestmark = pytest.mark.gpu
-RES5 = np.float32(0.005)
+TOL = 2e-5  # colour compensation only (see tests/test_color_compensate.py)
 
 
-def _scene(z, cam, pose):
-    depth = np.full((cam.height, cam.width), z, np.float32)
-    rays = synth._rays(cam)
-    R = pose[:, :3].astype(np.float64)
-    world = pose[:, 3].astype(np.float64) + (rays * z) @ R.T
-    rgb = np.ascontiguousarray(synth._hash_colour(world, 17)[..., :3])
-    return depth, rgb
+def _integrate(ov, gv, frames):
+    for depth, rgba, pose in frames:
+        ov.integrate_frame(depth, rgba, pose)
+        gv.frame_upload(depth, rgba, None)
+        gv.integrate_frame(pose, True)
+    ov.update_meshes()
+    gv.update_meshes()
+    oc, gc = ov.compress_meshes(), gv.compress_meshes()
+    assert np.array_equal(oc, gc) and len(oc) > 0
+    return oc
 
 
-def _chunk_grid(z, res, nx=10, ny=8):
-    edge = 8 * float(res)
-    kz = int(np.floor(z / edge))
-    return np.array([[i, j, kz] for i in range(-nx, nx) for j in range(-ny, ny)], np.int32)
+def _keyframe(frame):
+    depth, rgba, pose = frame
+    return np.ascontiguousarray(rgba[..., :3]), depth, synth.pose_inverse16(pose)
 
 
-def _run_both(gv, oa, cam, C, ids, voff, verts, cols, kf, T, rgb, depth):
-    n = len(ids)
-    out = gv.patches_update(ids, np.full(n, kf, np.int32), np.tile(T, (n, 1)), voff, verts, cols)
-    assert out["rc"] == 0
-    texlocs = []
-    for p in range(n):
-        sl = slice(voff[p], voff[p + 1])
-        rc, tl = oa.alloc() if tuple(ids[p]) not in _run_both.seen else (0, _run_both.seen[tuple(ids[p])])
-        assert rc == 0
-        _run_both.seen[tuple(ids[p])] = tl
-        texlocs.append(tl)
-        o = O.patch_project(verts[sl], cols[sl], T, rgb, depth, C)
-        assert out["texloc"][p] == tl
-        assert np.array_equal(out["bbox"][p], o["bbox"]), (p, out["bbox"][p], o["bbox"])
-        assert (out["flags"][p] & 1) == (1 if o["flag"] == -1 else 0)
-        assert bool(out["flags"][p] & 2) == o["wrong_mapping"]
-        assert np.array_equal(out["texcoord"][sl].view(np.uint32), o["texcoord"].view(np.uint32))
-        assert np.array_equal(out["texcolor"][sl].view(np.uint32), o["texcolor"].view(np.uint32))
-        rc, ratio = oa.blit(tl, rgb, o["bbox"])
-        assert rc == 0
-        assert np.array_equal(out["ratio"][p].view(np.uint32), ratio.view(np.uint32))
-    hs, he = oa.hot_range(texlocs)
-    assert out["hot"] == (hs, he)
-    return out, texlocs
+def _cache(gv, kfs):
+    for k, (rgb, depth, T) in kfs.items():
+        gv.keyframe_cache(k, rgb, depth, T)
 
 
-_run_both.seen = {}
+def _compare_patches(ov, gv, ids, what="", labs=False):
+    g = gv.get_patches(ids)
+    for i, cid in enumerate(ids):
+        o = ov.get_patch(cid)
+        a, b = g["voff"][i], g["voff"][i + 1]
+        tl = o["texloc"] if o["flags"] & 1 else (1 << 64) - 1
+        assert int(g["texloc"][i]) == tl, "%s: texloc of %s" % (what, cid)
+        assert g["frameid"][i] == o["frameid"], "%s: frameid of %s" % (what, cid)
+        assert (int(g["flags"][i]) & 31) == (o["flags"] & 31), "%s: flags of %s: %d vs %d" % (what, cid, g["flags"][i], o["flags"])
+        if not (o["flags"] & 1):
+            continue
+        assert np.array_equal(g["bbox"][i], o["bbox"]), "%s: bbox of %s" % (what, cid)
+        assert np.array_equal(g["ratio"][i].view(np.uint32), o["ratio"].view(np.uint32)), "%s: ratio of %s" % (what, cid)
+        assert b - a == len(o["texcoord"])
+        assert np.array_equal(g["texcoord"][a:b].view(np.uint32), o["texcoord"].view(np.uint32)), "%s: texcoord of %s" % (what, cid)
+        assert np.array_equal(g["texcolor"][a:b].view(np.uint32), o["texcolor"].view(np.uint32)), "%s: texcolor of %s" % (what, cid)
+        if labs and (o["flags"] & 16) and (o["flags"] & 32):
+            assert np.abs(g["labs"][a:b] - o["labs"]).max() <= TOL, "%s: labs of %s" % (what, cid)
+    return g
 
 
-@pytest.mark.parametrize("z,tilt", [(1.5, 0.0), (0.8, 0.0), (1.1, 0.25)])
-def test_patches_match_oracle(gpu_required, z, tilt):
-    _run_both.seen = {}
+def _compare_atlas(oa, gv, hot, width=13824):
+    r0, r1 = hot[0] // width, hot[1] // width
+    assert r1 > r0
+    ga = gv.atlas_rows(r0, r1, width)
+    assert np.array_equal(ga, oa.buffer()[r0:r1]), "atlas rows %d..%d differ" % (r0, r1)
+
+
+def test_generate_patches_update_atlas(gpu_required):
     cam = synth.Camera()
-    C = O.camera_from(cam)
-    pose = synth.pose_euler(tilt, tilt / 2, 0.0, (0.02, -0.01, 0.0))
-    depth, rgb = _scene(z, cam, pose)
-    AH = 18 * 40
-    gv = capi.Volume(RES5, cam, max_chunks=1 << 12, atlas_w=13824, atlas_h=AH)
-    oa = O.Atlas(RES5, 13824, AH)
-    assert gv.atlas_patch_size() == (oa.pw, oa.ph) == (24, 18)
-    gv.keyframe_cache(3, rgb, depth)
-    # plane z = const in CAMERA space expressed in world space: build vertices in camera space, move to world
-    ids, voff, verts_c, cols = synth.wall_mesh_for_chunks(_chunk_grid(z, RES5), RES5, z)
-    R, t = pose[:, :3].astype(np.float64), pose[:, 3].astype(np.float64)
-    verts = (verts_c.astype(np.float64) @ R.T + t).astype(np.float32)
-    T = synth.pose_inverse16(pose)
-    out, texlocs = _run_both(gv, oa, cam, C, ids, voff, verts, cols, 3, T, rgb, depth)
-    big = (out["ratio"] < 1).any(axis=1).sum()
-    if z < 1.0:
-        assert big > 0          # close wall: ROI larger than the 24x18 slot -> resize branch exercised
-    rows = gv.atlas_rows(0, AH, 13824)
-    assert np.array_equal(rows, oa.buffer()[:AH])
-    # second update of the same chunks keeps every slot (Patch::clear keeps texloc, Atlas.cpp:60-62)
-    nxt = gv.atlas_loc_next()
-    out2, _ = _run_both(gv, oa, cam, C, ids, voff, verts, cols, 3, T, rgb, depth)
-    assert gv.atlas_loc_next() == nxt == oa.loc_next()
-    assert np.array_equal(out2["texloc"], out["texloc"])
+    ov, gv, cam, ig = make_pair(RES5, cam, max_chunks=1 << 15)
+    poses = [synth.pose_identity(), synth.pose_euler(0.12, -0.05, 0.02, (0.04, -0.02, 0.0))]
+    frames = []
+    for k in range(6):
+        d, rgba, q, pose = synth.wall_frame(1.2, cam, pose=poses[k % 2], seed=k, rgba_value=(40 * k + 10, 100, 250 - 30 * k, 1))
+        rgba = synth._hash_colour(np.stack(np.meshgrid(np.arange(cam.width) * 0.01, np.arange(cam.height) * 0.01), -1)[..., [0, 1, 1]] + k, 5)
+        frames.append((d, rgba, pose))
+    ids = _integrate(ov, gv, frames)
+    oa = O.Atlas(RES5)
+    kfs = {3: _keyframe(frames[4]), 8: _keyframe(frames[5])}
+    _cache(gv, kfs)
+    labels = np.where(np.arange(len(ids)) % 3 == 0, 8, 3).astype(np.int32)
+    orc, ohot = ov.generate_patches(oa, ids, labels, kfs)
+    grc, ghot = gv.generate_patches(ids, labels)
+    assert orc == 0 and grc == 0 and ohot == ghot
+    assert gv.atlas_loc_next() == oa.loc_next()
+    _compare_patches(ov, gv, ids, "first GeneratePatches")
+    ov.update_atlas(oa, ids)
+    gv.update_atlas(ids)
+    _compare_patches(ov, gv, ids, "after UpdateAtlas")  # ratio is written by UpdateBuffer
+    _compare_atlas(oa, gv, ohot)
+    # second keyframe round: slots are kept (Patch::clear), labels swap, a sub-list in another order
+    sub = ids[::-1][: len(ids) // 2]
+    labels2 = np.where(np.arange(len(sub)) % 2 == 0, 8, 3).astype(np.int32)
+    orc, ohot2 = ov.generate_patches(oa, sub, labels2, kfs)
+    grc, ghot2 = gv.generate_patches(sub, labels2)
+    assert orc == 0 and grc == 0 and ohot2 == ghot2 and gv.atlas_loc_next() == oa.loc_next()
+    ov.update_atlas(oa, sub)
+    gv.update_atlas(sub)
+    _compare_patches(ov, gv, ids, "second round")
+    _compare_atlas(oa, gv, ohot)
+    # chunks without a mesh in the list are skipped on both sides (Chisel.cpp:157)
+    extra = np.concatenate([ids[:5], np.array([[900, 900, 900]], np.int32), ids[5:9]])
+    lab3 = np.full(len(extra), 3, np.int32)
+    assert ov.generate_patches(oa, extra, lab3, kfs)[1] == gv.generate_patches(extra, lab3)[1]
+    gv.close()
+
+
+def test_resize_branch_close_wall(gpu_required):
+    """Wall at 0.55 m: a 4 cm chunk spans ~38 px, the ROI exceeds the 24 x 18 slot -> cv::resize branch."""
+    cam = synth.Camera()
+    ov, gv, cam, ig = make_pair(RES5, cam, max_chunks=1 << 14)
+    frames = []
+    for k in range(4):
+        d, rgba, q, pose = synth.wall_frame(0.55, cam, seed=k)
+        rgba = synth._hash_colour(np.stack(np.meshgrid(np.arange(cam.width) * 0.013, np.arange(cam.height) * 0.017), -1)[..., [0, 1, 1]], 7)
+        frames.append((d, rgba, pose))
+    ids = _integrate(ov, gv, frames)
+    oa = O.Atlas(RES5)
+    kfs = {0: _keyframe(frames[0])}
+    _cache(gv, kfs)
+    labels = np.zeros(len(ids), np.int32)
+    _, ohot = ov.generate_patches(oa, ids, labels, kfs)
+    _, ghot = gv.generate_patches(ids, labels)
+    ov.update_atlas(oa, ids)
+    gv.update_atlas(ids)
+    g = _compare_patches(ov, gv, ids, "close wall")
+    assert (g["ratio"] < 1).any(), "the scene was meant to exercise the resize branch"
+    _compare_atlas(oa, gv, ohot)
     gv.close()
 
 
 def test_atlas_overflow_is_minus_one(gpu_required):
+    """A 96 x 36 atlas holds 2 bands x 4 slots: the ninth AddPatch throws (Atlas.cpp:52-53), GeneratePatches
+    returns -1 (Chisel.cpp:170-173), the entries before it are processed."""
     cam = synth.Camera()
-    pose = synth.pose_identity()
-    depth, rgb = _scene(1.5, cam, pose)
-    gv = capi.Volume(RES5, cam, max_chunks=1 << 10, atlas_w=96, atlas_h=36)  # 8 slots
-    gv.keyframe_cache(0, rgb, depth)
-    ids, voff, verts, cols = synth.wall_mesh_for_chunks(_chunk_grid(1.5, RES5, 3, 2), RES5, 1.5)
-    assert len(ids) > 8
-    T = synth.pose_inverse16(pose)
-    out = gv.patches_update(ids, np.zeros(len(ids), np.int32), np.tile(T, (len(ids), 1)), voff, verts, cols)
-    assert out["rc"] == capi.TF_ERR_ATLAS_FULL == -1   # Chisel::GeneratePatches' return value
+    ov = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 14, atlas_w=96, atlas_h=36)
+    frames = [(f[0], f[1], f[3]) for f in (synth.wall_frame(1.2, cam, seed=k) for k in range(5))]
+    ids = _integrate(ov, gv, frames)[:20]
+    oa = O.Atlas(RES5, 96, 36)
+    kfs = {0: _keyframe(frames[0])}
+    _cache(gv, kfs)
+    labels = np.zeros(len(ids), np.int32)
+    orc, _ = ov.generate_patches(oa, ids, labels, kfs)
+    grc, _ = gv.generate_patches(ids, labels)
+    assert orc == -1 and grc == capi.TF_ERR_ATLAS_FULL
+    g = gv.get_patches(ids)
+    for i, cid in enumerate(ids):
+        o = ov.get_patch(cid)
+        assert bool(g["flags"][i] & 1) == bool(o["flags"] & 1) == (i < 8)
+        if i < 8:
+            assert int(g["texloc"][i]) == o["texloc"]
     gv.close()
 
 
-def test_vertices_outside_the_image_are_flagged(gpu_required):
+def test_compensate_color_and_draw_meshes(gpu_required):
     cam = synth.Camera()
-    C = O.camera_from(cam)
-    pose = synth.pose_identity()
-    depth, rgb = _scene(1.5, cam, pose)
-    gv = capi.Volume(RES5, cam, max_chunks=1 << 10, atlas_w=13824, atlas_h=36)
-    gv.keyframe_cache(1, rgb, depth)
-    verts = np.array([[0.0, 0.0, 1.5], [0.05, 0.02, 1.5], [5.0, 0.0, 1.5], [0.0, -4.0, 1.5]], np.float32)
-    cols = np.full((4, 3), 0.5, np.float32)
-    ids = np.array([[0, 0, 37]], np.int32)
-    T = synth.pose_inverse16(pose)
-    out = gv.patches_update(ids, np.array([1], np.int32), T[None], np.array([0, 4], np.int64), verts, cols)
-    o = O.patch_project(verts, cols, T, rgb, depth, C)
-    assert o["flag"] == -1 and (out["flags"][0] & 1)
-    assert np.array_equal(out["bbox"][0], o["bbox"])
-    # in-image vertices must agree bit for bit; clamped ones read outside the image in the reference
-    assert np.array_equal(out["texcoord"].view(np.uint32), o["texcoord"].view(np.uint32))
-    assert np.array_equal(out["texcolor"][:2].view(np.uint32), o["texcolor"][:2].view(np.uint32))
+    ov, gv, cam, ig = make_pair(RES5, cam, max_chunks=1 << 15)
+    frames = []
+    for k in range(6):
+        d, rgba, q, pose = synth.wall_frame(1.2, cam, seed=k)
+        rgba = synth._hash_colour(np.stack(np.meshgrid(np.arange(cam.width) * 0.01, np.arange(cam.height) * 0.01), -1)[..., [0, 1, 1]], 5)
+        frames.append((d, rgba, pose))
+    ids = _integrate(ov, gv, frames)
+    oa = O.Atlas(RES5)
+    dark = (frames[1][0], (frames[1][1].astype(np.float32) * 0.7).astype(np.uint8), frames[1][2])
+    far = (np.where(frames[2][0] > 0, frames[2][0] + 1.0, 0).astype(np.float32), frames[2][1], frames[2][2])  # depth test fails
+    kfs = {2: _keyframe(frames[0]), 5: _keyframe(dark), 7: _keyframe(far)}
+    _cache(gv, kfs)
+    labels = np.array([(2, 5, 7)[i % 3] for i in range(len(ids))], np.int32)
+    ov.generate_patches(oa, ids, labels, kfs)
+    gv.generate_patches(ids, labels)
+    g = _compare_patches(ov, gv, ids, "three keyframes")
+    assert (g["flags"] & 4).any() and not (g["flags"] & 4).all()  # wrong_mapping on the "far" keyframe only
+    ov.update_atlas(oa, ids)
+    gv.update_atlas(ids)
+    assert ov.compensate_color() == gv.compensate_color() == 3
+    _compare_patches(ov, gv, ids, "after CompensateColor", labs=True)
+    # a second call finds every patch adjusted -- except the cluster of the "far" keyframe, whose patches all map
+    # wrongly: nothing was learnt, has_adjusted stayed false (Chisel.cpp:242)
+    assert ov.compensate_color() == gv.compensate_color() == 1
+    # DrawMeshes: identical streams except the packed colour delta (column 5), which quantises labs - texcolor
+    oV, oI = ov.draw_meshes(oa)
+    gV, gI = gv.draw_meshes()
+    assert oV.shape == gV.shape and np.array_equal(oI, gI) and len(oI) > 0
+    cols = [c for c in range(12) if c != 5]
+    assert np.array_equal(oV[:, cols].view(np.uint32), gV[:, cols].view(np.uint32))
+
+    def unpack(a):  # the 27-bit code sits in a float32: its low 3 bits (third channel) are rounded away
+        a = a.astype(np.int64)
+        return np.stack([(a >> 18) & 511, (a >> 9) & 511], -1)
+    assert np.abs(unpack(oV[:, 5]) - unpack(gV[:, 5])).max() <= 1
+    # ... and exact given the device's own labs (the oracle's packer on the downloaded patch arrays)
+    voff, ioff, V, N, Cc, I, adj, simp = gv.get_meshes(ids)
+    p = gv.get_patches(ids)
+    complete = ((np.diff(voff) > 0) & (simp > 0) & ((p["flags"] & 8) > 0) & (p["frameid"] >= 0)).astype(np.uint8)
+    wrong = ((p["flags"] & 4) > 0).astype(np.uint8)
+    labs_valid = (((p["flags"] & 16) > 0) & (wrong == 0)).astype(np.uint8)
+    rV, rI = O.pack_vertices(complete, wrong, labs_valid, p["texloc"], p["ratio"], 13824, 13824, voff, V, Cc, N,
+                             p["texcoord"], p["texcolor"], p["labs"], ioff, I)
+    assert np.array_equal(rV.view(np.uint32), gV.view(np.uint32)) and np.array_equal(rI, gI)
     gv.close()
 
 
-def test_room_frame_patches_match_oracle(gpu_required):
-    """General pose, depth-derived vertices (synth.mesh_from_depth), ~1.5 k patches in one batch."""
-    _run_both.seen = {}
+def test_meshes_upload_feeds_the_atlas_stage(gpu_required):
+    """A host that keeps its own mesher: tf_meshes_upload puts its meshes into allMeshes, the atlas stage runs
+    on them like on device-built ones."""
     cam = synth.Camera()
-    C = O.camera_from(cam)
-    depth, rgba, q, pose = synth.room_frame(12, cam)
-    rgb = np.ascontiguousarray(rgba[..., :3])
-    AH = 18 * 8
-    gv = capi.Volume(RES5, cam, max_chunks=1 << 12, atlas_w=13824, atlas_h=AH)
-    oa = O.Atlas(RES5, 13824, AH)
-    gv.keyframe_cache(12, rgb, depth)
-    ids, voff, verts, cols = synth.mesh_from_depth(depth, rgba, pose, cam, RES5, stride=4, max_chunks=1500)
-    assert len(ids) == 1500 and voff[-1] > 5000
-    T = synth.pose_inverse16(pose)
-    out, texlocs = _run_both(gv, oa, cam, C, ids, voff, verts, cols, 12, T, rgb, depth)
-    assert np.array_equal(gv.atlas_rows(0, AH, 13824), oa.buffer()[:AH])
+    ov, gv, cam, ig = make_pair(RES5, cam, max_chunks=1 << 14)
+    frames = [(f[0], f[1], f[3]) for f in (synth.wall_frame(1.2, cam, seed=k) for k in range(5))]
+    for depth, rgba, pose in frames:
+        ov.integrate_frame(depth, rgba, pose)
+    ov.update_meshes()
+    ids = ov.compress_meshes()
+    ms = [ov.get_mesh(c) for c in ids]
+    voff = np.concatenate([[0], np.cumsum([len(m["verts"]) for m in ms])]).astype(np.int64)
+    ioff = np.concatenate([[0], np.cumsum([len(m["indices"]) for m in ms])]).astype(np.int64)
+    gv.meshes_upload(ids, voff, ioff, np.concatenate([m["verts"] for m in ms]), np.concatenate([m["normals"] for m in ms]),
+                     np.concatenate([m["colors"] for m in ms]), np.concatenate([m["indices"] for m in ms]))
+    assert np.array_equal(sorted_ids(gv.list_meshes()), sorted_ids(ids))
+    v2, i2, V, N, Cc, I, adj, simp = gv.get_meshes(ids)
+    assert np.array_equal(v2, voff) and np.array_equal(i2, ioff)
+    assert np.array_equal(V.view(np.uint32), np.concatenate([m["verts"] for m in ms]).view(np.uint32))
+    assert np.array_equal(I, np.concatenate([m["indices"] for m in ms]))
+    oa = O.Atlas(RES5)
+    kfs = {1: _keyframe(frames[0])}
+    _cache(gv, kfs)
+    labels = np.ones(len(ids), np.int32)
+    ov.generate_patches(oa, ids, labels, kfs)
+    gv.generate_patches(ids, labels)
+    _compare_patches(ov, gv, ids, "uploaded meshes")
     gv.close()
 
 
-def test_device_resident_update_equals_host_variant(gpu_required):
-    """tf_patches_update_device (meshes and results in HBM, asynchronous) == tf_patches_update, bit for bit:
-    slots, per-patch records, texcoords, texcolours and the atlas texels."""
-    from tests.util import HipBuffer
+def test_fused_textured_stream(gpu_required):
+    """tf_stream_frames_textured_device (integrate -> UpdateMeshes -> CompressMeshes -> GeneratePatches with label
+    = the frame -> UpdateAtlas per frame, asynchronous, frames resident in HBM) == the oracle's per-frame unit:
+    volume, meshes, patches, slot order (ascending chunk id among a frame's new patches), atlas texels."""
     cam = synth.Camera()
-    AH = 18 * 40
-    vols = [capi.Volume(RES5, cam, max_chunks=1 << 10, atlas_w=13824, atlas_h=AH) for _ in range(2)]
-    pose = synth.pose_euler(0.2, -0.1, 0.05, (0.05, 0.0, 0.1))
-    depth, rgb = _scene(1.4, cam, pose)
-    ids, voff, verts_c, cols = synth.wall_mesh_for_chunks(_chunk_grid(1.4, RES5, nx=8, ny=6), RES5, 1.4)
-    R, t = pose[:, :3].astype(np.float64), pose[:, 3].astype(np.float64)
-    verts = (verts_c.astype(np.float64) @ R.T + t).astype(np.float32)
-    T = synth.pose_inverse16(pose)
-    n = len(ids)
-    for v in vols:
-        v.keyframe_cache(3, rgb, depth)
-    ref = vols[0].patches_update(ids, np.full(n, 3, np.int32), np.tile(T, (n, 1)), voff, verts, cols)
-    nv = int(voff[-1])
-    bufs = dict(verts=HipBuffer(nv * 12), cols=HipBuffer(nv * 12), tc=HipBuffer(nv * 8), tcol=HipBuffer(nv * 12),
-                po=HipBuffer(n * 32))
-    bufs["verts"].from_host(np.ascontiguousarray(verts, np.float32))
-    bufs["cols"].from_host(np.ascontiguousarray(cols, np.float32))
-    for rep in range(2):  # the second call re-uses the slots (Patch::clear keeps texloc) and the descriptor ring
-        rc, texloc, hot = vols[1].patches_update_device(ids, np.full(n, 3, np.int32), np.tile(T, (n, 1)), voff,
-                                                        bufs["verts"].ptr, bufs["cols"].ptr, bufs["tc"].ptr,
-                                                        bufs["tcol"].ptr, bufs["po"].ptr)
-        assert rc == 0
-    vols[1].sync()
-    assert np.array_equal(texloc, ref["texloc"]) and hot == ref["hot"]
-    tc = bufs["tc"].to_host(nv * 8).view(np.float32).reshape(-1, 2)
-    tcol = bufs["tcol"].to_host(nv * 12).view(np.float32).reshape(-1, 3)
-    po = bufs["po"].to_host(n * 32).view(np.int32).reshape(n, 8)
-    assert np.array_equal(tc.view(np.uint32), ref["texcoord"].view(np.uint32))
-    assert np.array_equal(tcol.view(np.uint32), ref["texcolor"].view(np.uint32))
-    assert np.array_equal(po[:, :4], ref["bbox"]) and np.array_equal(po[:, 4], ref["flags"])
-    assert np.array_equal(po[:, 5:7].view(np.float32).view(np.uint32), ref["ratio"].view(np.uint32))
-    assert np.array_equal(vols[0].atlas_rows(0, AH, 13824), vols[1].atlas_rows(0, AH, 13824))
-    for v in vols:
-        v.close()
-    for b in bufs.values():
-        b.free()
+    ov, gv, cam, ig = make_pair(RES5, cam, max_chunks=1 << 16)
+    oa = O.Atlas(RES5)
+    n = 9
+    fr = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(n)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in fr]
+    poses = np.stack([f[3].reshape(12) for f in fr])
+    pinv = np.stack([synth.pose_inverse16(f[3]) for f in fr])
+    for k, f in enumerate(fr):
+        ov.frame_textured(oa, f[0], f[1], f[3], pinv[k], 100 + k)
+    # three calls: 4 frames (2 selected ahead), 3 frames starting primed (1 ahead), 2 frames
+    dd, dr = [b[0].ptr for b in bufs], [b[1].ptr for b in bufs]
+    gv.stream_frames_textured_device(dd[0:6], dr[0:6], poses[0:6], pinv[0:6], 100, n_ahead=2)
+    gv.stream_frames_textured_device(dd[4:8], dr[4:8], poses[4:8], pinv[4:8], 104, n_ahead=1)
+    gv.stream_frames_textured_device(dd[7:9], dr[7:9], poses[7:9], pinv[7:9], 107, n_ahead=0)
+    gv.sync()
+    from tests.util import assert_chunks_equal
+    oids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(oids, sorted_ids(gv.list_chunks()))
+    assert_chunks_equal(ov, gv, oids[::7], "fused stream")
+    mids = sorted_ids(ov.list_meshes())
+    assert np.array_equal(mids, sorted_ids(gv.list_meshes())) and len(mids) > 500
+    voff, ioff, V, N, Cc, I, adj, simp = gv.get_meshes(mids)
+    for i, cid in enumerate(mids):
+        m = ov.get_mesh(cid)
+        assert np.array_equal(V[voff[i]:voff[i + 1]].view(np.uint32), m["verts"].view(np.uint32)), cid
+        assert np.array_equal(I[ioff[i]:ioff[i + 1]], m["indices"]), cid
+        assert bool(simp[i]) == m["simplified"] and np.array_equal(adj[i], m["adj"]), cid
+    assert gv.atlas_loc_next() == oa.loc_next()
+    g = _compare_patches(ov, gv, mids, "fused stream")
+    used = g["texloc"][g["texloc"] != np.uint64((1 << 64) - 1)]
+    hot = oa.hot_range(used)
+    _compare_atlas(oa, gv, hot)
+    st = gv.texture_stats()
+    assert st.n_slots == len(used) and st.n_dirty > 0 and st.n_meshes > 0
+    assert len(gv.dirty()) == 0  # CompressMeshes cleared meshesToUpdate after every frame
+    for a, b in bufs:
+        a.free(); b.free()
+    gv.close()

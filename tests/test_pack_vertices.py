@@ -1,5 +1,6 @@
 """Chisel::DrawMeshes vertex / index packing (Structure/Chisel.cpp:288-355):
-a hand-computed known answer for the oracle restatement (CPU) and the HIP path against it, bit-exact."""
+a hand-computed known answer for the oracle restatement (CPU); the HIP path is compared against it, bit-exact,
+in tests/test_gpu_atlas.py."""
 import numpy as np
 import pytest
 
@@ -63,15 +64,3 @@ def test_oracle_skips_incomplete_and_rebases_indices():
         assert np.array_equal(blk - base, b["indices"][b["ioff"][p]:b["ioff"][p + 1]])
         base += b["voff"][p + 1] - b["voff"][p]
         pos += n_i
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("seed", [1, 2])
-def test_hip_matches_oracle_bit_exact(gpu_required, seed):
-    from texturefusion_amd import capi, synth
-    b = _batch(seed, n_patches=400)
-    gv = capi.Volume(np.float32(0.005), synth.Camera(), max_chunks=1 << 10)
-    ov, oi = O.pack_vertices(atlas_w=AW, atlas_h=AH, **b)
-    gvx, gi = gv.pack_vertices(**b)
-    assert gvx.shape == ov.shape and np.array_equal(gvx.view(np.uint32), ov.view(np.uint32))
-    assert np.array_equal(gi, oi)

@@ -35,10 +35,11 @@ SYMBOLS = (
     "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
     "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
-    "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_release",
-    "tf_atlas_patch_size", "tf_atlas_add_patch", "tf_atlas_loc_next", "tf_patches_update",
-    "tf_patches_update_device", "tf_color_compensate", "tf_pack_vertices",
-    "tf_atlas_download_rows",
+    "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_set_pose",
+    "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_meshes_upload",
+    "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
+    "tf_patches_download", "tf_atlas_download_rows", "tf_stream_frames_device",
+    "tf_stream_frames_textured_device", "tf_get_texture_stats",
     "tf_update_meshes", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
 )
 
@@ -61,6 +62,12 @@ class Stats(C.Structure):
                 ("rows_tsdf", C.c_int64), ("rows_color", C.c_int64), ("n_chunks", C.c_int64),
                 ("n_slots", C.c_int64), ("n_dirty", C.c_int64), ("min_id", C.c_int32 * 3),
                 ("max_id", C.c_int32 * 3)]
+
+
+class TextureStats(C.Structure):
+    _fields_ = [("n_dirty", C.c_int64), ("n_meshes", C.c_int64), ("n_vertices", C.c_int64),
+                ("n_triangles", C.c_int64), ("roi_pixels", C.c_int64), ("n_patches", C.c_int64),
+                ("n_slots", C.c_int64)]
 
 
 class Profile(C.Structure):
@@ -118,17 +125,22 @@ def lib():
     L.tf_boundary_pack_async.argtypes = [vp, vp, C.c_int64, vp]
     L.tf_boundary_unpack.argtypes = [vp, vp, C.c_int64]
     L.tf_keyframe_cache.argtypes = [vp, C.c_int32, u8p, fp]
-    L.tf_keyframe_cache_device.argtypes = [vp, C.c_int32, vp, vp]
+    L.tf_keyframe_cache_device.argtypes = [vp, C.c_int32, vp, C.c_int32, vp]
+    L.tf_keyframe_set_pose.argtypes = [vp, C.c_int32, fp]
     L.tf_keyframe_release.argtypes = [vp, C.c_int32]
     L.tf_atlas_patch_size.argtypes = [vp, i32p, i32p]
-    L.tf_atlas_add_patch.argtypes = [vp, i32p, u64p]
     L.tf_atlas_loc_next.argtypes = [vp, u64p]
-    L.tf_patches_update.argtypes = [vp, C.c_int64, i32p, i32p, fp, i64p, fp, fp, fp, fp, i32p, i32p,
-                                    fp, u64p, u64p]
-    L.tf_patches_update_device.argtypes = [vp, C.c_int64, i32p, i32p, fp, i64p, vp, vp, vp, vp, vp, u64p, u64p]
-    L.tf_color_compensate.argtypes = [vp, C.c_int64, i32p, u8p, u8p, i64p, fp, fp, fp, i64p]
-    L.tf_pack_vertices.argtypes = [vp, C.c_int64, u8p, u8p, u8p, u64p, fp, i64p, fp, fp, fp, fp, fp, fp, i64p,
-                                   C.POINTER(C.c_uint32), fp, C.POINTER(C.c_uint32), i64p, i64p]
+    L.tf_meshes_upload.argtypes = [vp, i32p, C.c_int64, i64p, i64p, fp, fp, fp, C.POINTER(C.c_uint32)]
+    L.tf_generate_patches.argtypes = [vp, i32p, C.c_int64, i32p, u64p]
+    L.tf_compensate_color.argtypes = [vp, i64p]
+    L.tf_update_atlas.argtypes = [vp, i32p, C.c_int64]
+    L.tf_draw_meshes.argtypes = [vp, fp, C.POINTER(C.c_uint32), C.c_int64, C.c_int64, i64p, i64p]
+    L.tf_draw_meshes_device.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, i64p, i64p]
+    L.tf_patches_download.argtypes = [vp, i32p, C.c_int64, i64p, u64p, i32p, i32p, i32p, fp, fp, fp, fp]
+    L.tf_stream_frames_device.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(vp), C.POINTER(vp), fp]
+    L.tf_stream_frames_textured_device.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(vp), C.POINTER(vp), fp, fp,
+                                                   C.c_int32]
+    L.tf_get_texture_stats.argtypes = [vp, C.POINTER(TextureStats)]
     L.tf_atlas_download_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p]
     u32p = C.POINTER(C.c_uint32)
     L.tf_update_meshes.argtypes = [vp, i64p]
@@ -267,6 +279,23 @@ class Volume:
         dr = None if d_rgbas is None else (C.c_void_p * n)(*d_rgbas)
         self._ck(self.L.tf_integrate_frames_device(self.h, n, dd, dr, _p(poses, C.c_float)))
 
+    def stream_frames_device(self, d_depths, d_rgbas, poses, n_ahead=0):
+        """d_depths / d_rgbas / poses hold n + n_ahead frames: the first n are integrated, the rest only selected."""
+        m = len(d_depths)
+        poses = _f32(poses).reshape(m, 12)
+        dd = (C.c_void_p * m)(*d_depths)
+        dr = None if d_rgbas is None else (C.c_void_p * m)(*d_rgbas)
+        self._ck(self.L.tf_stream_frames_device(self.h, m - n_ahead, n_ahead, dd, dr, _p(poses, C.c_float)))
+
+    def stream_frames_textured_device(self, d_depths, d_rgbas, poses, pose_inv, first_frame_id, n_ahead=0):
+        m = len(d_depths)
+        poses = _f32(poses).reshape(m, 12)
+        pose_inv = _f32(pose_inv).reshape(m, 16)
+        dd = (C.c_void_p * m)(*d_depths)
+        dr = (C.c_void_p * m)(*d_rgbas)
+        self._ck(self.L.tf_stream_frames_textured_device(self.h, m - n_ahead, n_ahead, dd, dr, _p(poses, C.c_float),
+                                                         _p(pose_inv, C.c_float), int(first_frame_id)))
+
     def sync(self):
         self._ck(self.L.tf_sync(self.h))
 
@@ -396,14 +425,22 @@ class Volume:
     def boundary_unpack(self, d_buf, n):
         self._ck(self.L.tf_boundary_unpack(self.h, C.c_void_p(d_buf), n))
 
-    # -- atlas
-    def keyframe_cache(self, kf_id, rgb, depth):
+    # -- atlas (device-resident meshes and patches)
+    def keyframe_cache(self, kf_id, rgb, depth, pose_inv16=None):
         rgb = np.ascontiguousarray(rgb, np.uint8)
         depth = _f32(depth)
         self._ck(self.L.tf_keyframe_cache(self.h, kf_id, _p(rgb, C.c_uint8), _p(depth, C.c_float)))
+        if pose_inv16 is not None:
+            self.keyframe_set_pose(kf_id, pose_inv16)
 
-    def keyframe_cache_device(self, kf_id, d_rgb, d_depth):
-        self._ck(self.L.tf_keyframe_cache_device(self.h, kf_id, C.c_void_p(d_rgb), C.c_void_p(d_depth)))
+    def keyframe_cache_device(self, kf_id, d_rgb, d_depth, stride=3, pose_inv16=None):
+        self._ck(self.L.tf_keyframe_cache_device(self.h, kf_id, C.c_void_p(d_rgb), stride, C.c_void_p(d_depth)))
+        if pose_inv16 is not None:
+            self.keyframe_set_pose(kf_id, pose_inv16)
+
+    def keyframe_set_pose(self, kf_id, pose_inv16):
+        T = _f32(pose_inv16).reshape(16)
+        self._ck(self.L.tf_keyframe_set_pose(self.h, kf_id, _p(T, C.c_float)))
 
     def keyframe_release(self, kf_id):
         self._ck(self.L.tf_keyframe_release(self.h, kf_id))
@@ -413,98 +450,73 @@ class Volume:
         self._ck(self.L.tf_atlas_patch_size(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def atlas_add_patch(self, cid):
-        cid = np.ascontiguousarray(cid, np.int32)
-        t = C.c_uint64(0)
-        rc = self.L.tf_atlas_add_patch(self.h, _p(cid, C.c_int32), C.byref(t))
-        return rc, t.value
-
     def atlas_loc_next(self):
         t = C.c_uint64(0)
         self._ck(self.L.tf_atlas_loc_next(self.h, C.byref(t)))
         return t.value
 
-    def patches_update(self, ids, kf_ids, pose_inv, voff, verts, colors):
+    def meshes_upload(self, ids, voff, ioff, verts, normals, colors, indices):
         ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
-        np_ = len(ids)
-        kf_ids = np.ascontiguousarray(kf_ids, np.int32)
-        pose_inv = _f32(pose_inv).reshape(np_, 16)
-        voff = np.ascontiguousarray(voff, np.int64)
-        verts = _f32(verts).reshape(-1, 3)
-        colors = _f32(colors).reshape(-1, 3)
-        nv = len(verts)
-        tc = np.zeros((max(nv, 1), 2), np.float32)
-        tcol = np.zeros((max(nv, 1), 3), np.float32)
-        bbox = np.zeros((max(np_, 1), 4), np.int32)
-        flags = np.zeros(max(np_, 1), np.int32)
-        ratio = np.zeros((max(np_, 1), 2), np.float32)
-        texloc = np.zeros(max(np_, 1), np.uint64)
-        hot = np.zeros(2, np.uint64)
-        rc = self.L.tf_patches_update(self.h, np_, _p(ids, C.c_int32), _p(kf_ids, C.c_int32),
-                                      _p(pose_inv, C.c_float), _p(voff, C.c_int64), _p(verts, C.c_float),
-                                      _p(colors, C.c_float), _p(tc, C.c_float), _p(tcol, C.c_float),
-                                      _p(bbox, C.c_int32), _p(flags, C.c_int32), _p(ratio, C.c_float),
-                                      _p(texloc, C.c_uint64), _p(hot, C.c_uint64))
-        if rc == TF_ERR_ATLAS_FULL:
-            return dict(rc=rc)
-        self._ck(rc)
-        return dict(rc=rc, texcoord=tc[:nv], texcolor=tcol[:nv], bbox=bbox[:np_], flags=flags[:np_],
-                    ratio=ratio[:np_], texloc=texloc[:np_], hot=(int(hot[0]), int(hot[1])))
+        voff = np.ascontiguousarray(voff, np.int64); ioff = np.ascontiguousarray(ioff, np.int64)
+        indices = np.ascontiguousarray(indices, np.uint32)
+        self._ck(self.L.tf_meshes_upload(self.h, _p(ids, C.c_int32), len(ids), _p(voff, C.c_int64), _p(ioff, C.c_int64),
+                                         _p(_f32(verts), C.c_float), _p(_f32(normals), C.c_float),
+                                         _p(_f32(colors), C.c_float), _p(indices, C.c_uint32)))
 
-    def patches_update_device(self, ids, kf_ids, pose_inv, voff, d_verts, d_colors, d_texcoord, d_texcolor, d_patch_out):
-        """Asynchronous GeneratePatches + UpdateAtlas on device-resident meshes -> (rc, texloc, hot)."""
+    def generate_patches(self, ids, labels):
+        """Chisel::GeneratePatches -> (rc, (hot_start, hot_end)); rc == TF_ERR_ATLAS_FULL is GeneratePatches' -1."""
         ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
-        np_ = len(ids)
-        kf_ids = np.ascontiguousarray(kf_ids, np.int32)
-        pose_inv = _f32(pose_inv).reshape(np_, 16)
-        voff = np.ascontiguousarray(voff, np.int64)
-        texloc = np.zeros(max(np_, 1), np.uint64)
+        labels = np.ascontiguousarray(labels, np.int32)
         hot = np.zeros(2, np.uint64)
-        rc = self.L.tf_patches_update_device(self.h, np_, _p(ids, C.c_int32), _p(kf_ids, C.c_int32),
-                                             _p(pose_inv, C.c_float), _p(voff, C.c_int64), C.c_void_p(d_verts),
-                                             C.c_void_p(d_colors), C.c_void_p(d_texcoord), C.c_void_p(d_texcolor),
-                                             C.c_void_p(d_patch_out), _p(texloc, C.c_uint64), _p(hot, C.c_uint64))
+        rc = self.L.tf_generate_patches(self.h, _p(ids, C.c_int32), len(ids), _p(labels, C.c_int32), _p(hot, C.c_uint64))
         if rc != TF_ERR_ATLAS_FULL:
             self._ck(rc)
-        return rc, texloc[:np_], (int(hot[0]), int(hot[1]))
+        return rc, (int(hot[0]), int(hot[1]))
 
-    def color_compensate(self, frame_ids, wrong_mapping, has_adjusted, voff, texcolor, meshcolor):
-        """Chisel::CompensateColor over a batch of patches -> (labs, has_adjusted, n_clusters)."""
-        frame_ids = np.ascontiguousarray(frame_ids, np.int32)
-        n = len(frame_ids)
-        wrong = np.ascontiguousarray(wrong_mapping, np.uint8)
-        adj = np.ascontiguousarray(has_adjusted, np.uint8).copy()
-        voff = np.ascontiguousarray(voff, np.int64)
-        tc = _f32(texcolor).reshape(-1, 3)
-        mc = _f32(meshcolor).reshape(-1, 3)
-        labs = np.full_like(tc, np.nan)
-        ncl = C.c_int64(0)
-        self._ck(self.L.tf_color_compensate(self.h, n, _p(frame_ids, C.c_int32), _p(wrong, C.c_uint8),
-                                            _p(adj, C.c_uint8), _p(voff, C.c_int64), _p(tc, C.c_float),
-                                            _p(mc, C.c_float), _p(labs, C.c_float), C.byref(ncl)))
-        return labs, adj, int(ncl.value)
+    def compensate_color(self):
+        n = C.c_int64(0)
+        self._ck(self.L.tf_compensate_color(self.h, C.byref(n)))
+        return n.value
 
-    def pack_vertices(self, complete, wrong_mapping, labs_valid, texloc, ratio, voff, verts, colors, normals,
-                      texcoord, texcolor, labs, ioff, indices):
-        """Chisel::DrawMeshes -> (vertices f32[n,12], indices u32[m])."""
-        a8 = lambda x: np.ascontiguousarray(x, np.uint8)
-        complete, wrong_mapping, labs_valid = a8(complete), a8(wrong_mapping), a8(labs_valid)
-        texloc = np.ascontiguousarray(texloc, np.uint64)
-        voff = np.ascontiguousarray(voff, np.int64)
-        ioff = np.ascontiguousarray(ioff, np.int64)
-        indices = np.ascontiguousarray(indices, np.uint32)
-        ratio, verts, colors, normals, texcoord, texcolor, labs = map(_f32, (ratio, verts, colors, normals, texcoord,
-                                                                               texcolor, labs))
-        out_v = np.zeros((max(int(voff[-1]), 1), 12), np.float32)
-        out_i = np.zeros(max(int(ioff[-1]), 1), np.uint32)
+    def update_atlas(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        self._ck(self.L.tf_update_atlas(self.h, _p(ids, C.c_int32), len(ids)))
+
+    def draw_meshes(self):
+        """Chisel::DrawMeshes -> (vertices f32[n,12], indices u32[m])"""
         nv, ni = C.c_int64(0), C.c_int64(0)
-        self._ck(self.L.tf_pack_vertices(self.h, len(complete), _p(complete, C.c_uint8), _p(wrong_mapping, C.c_uint8),
-                                         _p(labs_valid, C.c_uint8), _p(texloc, C.c_uint64), _p(ratio, C.c_float),
-                                         _p(voff, C.c_int64), _p(verts, C.c_float), _p(colors, C.c_float),
-                                         _p(normals, C.c_float), _p(texcoord, C.c_float), _p(texcolor, C.c_float),
-                                         _p(labs, C.c_float), _p(ioff, C.c_int64), _p(indices, C.c_uint32),
-                                         _p(out_v, C.c_float), _p(out_i, C.c_uint32), C.byref(nv), C.byref(ni)))
-        return out_v[:nv.value], out_i[:ni.value]
+        dummy_v = np.zeros(12, np.float32); dummy_i = np.zeros(1, np.uint32)
+        rc = self.L.tf_draw_meshes(self.h, _p(dummy_v, C.c_float), _p(dummy_i, C.c_uint32), 0, 0, C.byref(nv), C.byref(ni))
+        if rc not in (TF_OK, TF_ERR_CAPACITY):
+            self._ck(rc)
+        V = np.zeros((max(nv.value, 1), 12), np.float32); I = np.zeros(max(ni.value, 1), np.uint32)
+        self._ck(self.L.tf_draw_meshes(self.h, _p(V, C.c_float), _p(I, C.c_uint32), nv.value, ni.value,
+                                       C.byref(nv), C.byref(ni)))
+        return V[:nv.value], I[:ni.value]
+
+    def get_patches(self, ids):
+        """Patch mirrors of the listed chunks -> dict(voff, texloc, frameid, bbox, flags, ratio, texcoord, texcolor, labs)"""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        n = len(ids)
+        nv, _, _, _ = self.mesh_counts(ids)
+        voff = np.concatenate([[0], np.cumsum(nv)]).astype(np.int64)
+        tot = int(voff[-1])
+        texloc = np.zeros(max(n, 1), np.uint64); frameid = np.zeros(max(n, 1), np.int32)
+        bbox = np.zeros((max(n, 1), 4), np.int32); flags = np.zeros(max(n, 1), np.int32)
+        ratio = np.zeros((max(n, 1), 2), np.float32)
+        tc = np.zeros((max(tot, 1), 2), np.float32); tcol = np.zeros((max(tot, 1), 3), np.float32)
+        labs = np.zeros((max(tot, 1), 3), np.float32)
+        self._ck(self.L.tf_patches_download(self.h, _p(ids, C.c_int32), n, _p(voff, C.c_int64), _p(texloc, C.c_uint64),
+                                            _p(frameid, C.c_int32), _p(bbox, C.c_int32), _p(flags, C.c_int32),
+                                            _p(ratio, C.c_float), _p(tc, C.c_float), _p(tcol, C.c_float),
+                                            _p(labs, C.c_float)))
+        return dict(voff=voff, texloc=texloc[:n], frameid=frameid[:n], bbox=bbox[:n], flags=flags[:n], ratio=ratio[:n],
+                    texcoord=tc[:tot], texcolor=tcol[:tot], labs=labs[:tot])
+
+    def texture_stats(self):
+        st = TextureStats()
+        self._ck(self.L.tf_get_texture_stats(self.h, C.byref(st)))
+        return st
 
     def atlas_rows(self, row0, row1, width):
         out = np.zeros((row1 - row0, width, 3), np.uint8)

@@ -1,43 +1,40 @@
-// tf_atlas.hip -- texture-atlas side of the path: slot allocator, keyframe cache, per-patch
-// vertex projection (Patch::CalculateTexCoords, Structure/Patch.cpp:40-108) and the patch
-// blit / resample into the device-resident atlas (Atlas::UpdateBuffer, Structure/Atlas.cpp:71-91).
+// tf_atlas.hip -- texture-atlas side of the path on device-resident meshes (ChunkManager::allMeshes
+// lives in HBM as planar per-slot blocks, tf_device.h; Mesh::m_patch is part of the slot's MeshRec).
 //
-// One workgroup per patch.  k_patch_project streams the patch's vertices (coalesced 12-B
-// reads), gathers the keyframe image bilinearly, reduces the bounding box in LDS.
-// k_atlas_blit stages the keyframe ROI in LDS (the ROI is tens of pixels on a side) and writes
-// the atlas slot rows; the resize branch restates cv::resize INTER_LINEAR for 8UC3 in the
-// same 11-bit fixed point (third-party arithmetic -- parity unpinned).
+//   k_patch_assign     Atlas::AddPatch for an ordered chunk list (Structure/Atlas.cpp:43-64): the slot a
+//                      new patch gets is loc_next at its turn = a prefix sum over the list
+//   k_patch_collect / k_patch_rank   the same for the unordered per-frame dirty list of the fused flow:
+//                      new patches take their slots in ascending chunk-id order (rank by comparison)
+//   k_patch<P, B, F>   one WAVE per patch: Patch::CalculateTexCoords (Structure/Patch.cpp:40-108, lane =
+//                      vertex, coalesced plane rows, bbox / vote by wave reductions) and / or
+//                      Atlas::UpdateBuffer (Structure/Atlas.cpp:71-91, slot rows written as dwords)
+//   k_cc_*             Chisel::CompensateColor reductions + transfer (Structure/Chisel.cpp:198-286)
+//   k_draw             Chisel::DrawMeshes vertex / index packing (Structure/Chisel.cpp:288-355)
+//
+// cv::resize INTER_LINEAR for 8UC3 is restated in the same 11-bit fixed point (third-party arithmetic --
+// parity unpinned); the copy branch is exact.
 #include <math.h>
 #include <string.h>
+
+#include <algorithm>
 #include <vector>
 
+#include "tf_devfn.h"
 #include "tf_volume.h"
 
 #pragma clang fp contract(off)
 
 namespace tf {
 
-struct PatchIn {       // one per patch, uploaded
-  float T[16];         // f32(SE3d.inverse().matrix()), row-major
-  const uint8_t* rgb;  // keyframe rgb u8[H][W][3]
-  const float* depth;  // keyframe depth f32[H][W]
-  int64_t v0, v1;      // vertex range
-  uint64_t texloc;
-};
-
-struct PatchOut {  // one per patch, downloaded
-  int32_t bbox[4];
-  int32_t flags;  // bit0: CalculateTexCoords returned -1; bit1: wrong_mapping
-  float ratio[2];
-  int32_t n_caution;
-};
-
-// cv::Mat::at is unchecked pointer arithmetic: x == W lands on the next row.  Reads past the
-// image (undefined in the reference) return 0.
-__device__ __forceinline__ void rgb_at(const uint8_t* rgb, int W, int H, int y, int x, float c[3]) {
+// ---------------------------------------------------------------------------------------
+// image access.  cv::Mat::at is unchecked pointer arithmetic: x == W lands on the next row.  Reads past
+// the image (undefined in the reference) return 0.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void rgb_at(const uint8_t* rgb, int stride, int W, int H, int y, int x, float c[3]) {
   const long i = (long)y * W + x;
   if (i < 0 || i >= (long)W * H) { c[0] = c[1] = c[2] = 0.0f; return; }
-  c[0] = (float)rgb[3 * i]; c[1] = (float)rgb[3 * i + 1]; c[2] = (float)rgb[3 * i + 2];
+  const uint8_t* p = rgb + (size_t)i * stride;
+  c[0] = (float)p[0]; c[1] = (float)p[1]; c[2] = (float)p[2];
 }
 __device__ __forceinline__ float f_at(const float* img, int W, int H, int y, int x) {
   const long i = (long)y * W + x;
@@ -46,12 +43,12 @@ __device__ __forceinline__ float f_at(const float* img, int W, int H, int y, int
 }
 
 // Patch::bilinear (Patch.cpp:110-145) -- c2 stands where c4 belongs (:125-128).
-__device__ __forceinline__ void bilinear_rgb(const uint8_t* rgb, int W, int H, float lx, float ly,
+__device__ __forceinline__ void bilinear_rgb(const uint8_t* rgb, int stride, int W, int H, float lx, float ly,
                                              float out[3]) {
   const int x = (int)floorf(lx), y = (int)floorf(ly);
   float c1[3], c2[3], c3[3];
   if (x < W - 1 && y < H - 1) {
-    rgb_at(rgb, W, H, y, x, c1); rgb_at(rgb, W, H, y, x + 1, c2); rgb_at(rgb, W, H, y + 1, x, c3);
+    rgb_at(rgb, stride, W, H, y, x, c1); rgb_at(rgb, stride, W, H, y, x + 1, c2); rgb_at(rgb, stride, W, H, y + 1, x, c3);
     const float ax = (float)(x + 1) - lx, bx = lx - (float)x;
     const float ay = (float)(y + 1) - ly, by = ly - (float)y;
 #pragma unroll
@@ -63,17 +60,17 @@ __device__ __forceinline__ void bilinear_rgb(const uint8_t* rgb, int W, int H, f
       out[k] = t;
     }
   } else if (x < W - 1 && y == H - 1) {
-    rgb_at(rgb, W, H, y, x, c1); rgb_at(rgb, W, H, y, x + 1, c2);
+    rgb_at(rgb, stride, W, H, y, x, c1); rgb_at(rgb, stride, W, H, y, x + 1, c2);
     const float ax = (float)(x + 1) - lx, bx = lx - (float)x;
 #pragma unroll
     for (int k = 0; k < 3; ++k) out[k] = c1[k] * ax + c2[k] * bx;
   } else if (x == W - 1 && y < H - 1) {
-    rgb_at(rgb, W, H, y, x, c1); rgb_at(rgb, W, H, y + 1, x, c2);
+    rgb_at(rgb, stride, W, H, y, x, c1); rgb_at(rgb, stride, W, H, y + 1, x, c2);
     const float ay = (float)(y + 1) - ly, by = ly - (float)y;
 #pragma unroll
     for (int k = 0; k < 3; ++k) out[k] = c1[k] * ay + c2[k] * by;
   } else {
-    rgb_at(rgb, W, H, y, x, out);
+    rgb_at(rgb, stride, W, H, y, x, out);
   }
 }
 // Patch::bilinear_depth (Patch.cpp:147-170)
@@ -98,231 +95,401 @@ __device__ __forceinline__ float bilinear_f(const float* img, int W, int H, floa
   return f_at(img, W, H, y, x);
 }
 
-__global__ __launch_bounds__(256) void k_patch_project(const PatchIn* __restrict__ pin,
-                                                       const float* __restrict__ verts,
-                                                       const float* __restrict__ colors, Cam cam,
-                                                       float* __restrict__ texcoord,
-                                                       float* __restrict__ texcolor,
-                                                       PatchOut* __restrict__ pout) {
-  const PatchIn P = pin[blockIdx.x];
-  const int W = cam.W, H = cam.H;
-  const float Wf = (float)W, Hf = (float)H;
-  float minX = Wf, maxX = 0.0f, minY = Hf, maxY = 0.0f;  // Patch.cpp:46-49
-  int dcmp = 0, ccmp = 0, ncau = 0;
-  for (int64_t i = P.v0 + threadIdx.x; i < P.v1; i += 256) {
-    const float vx = verts[3 * i], vy = verts[3 * i + 1], vz = verts[3 * i + 2];
-    float vl[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {  // T_g_l * (v,1), accumulated column by column
-      float s = P.T[4 * r] * vx;
-      s = s + P.T[4 * r + 1] * vy;
-      s = s + P.T[4 * r + 2] * vz;
-      s = s + P.T[4 * r + 3] * 1.0f;
-      vl[r] = s;
-    }
-    const float dist = vl[2];
-    const float x = vl[0] / vl[2], y = vl[1] / vl[2];
-    float cX = (float)((double)(x * cam.fxi + cam.cxi) + 0.5);  // :55-56
-    float cY = (float)((double)(y * cam.fyi + cam.cyi) + 0.5);
-    if (cX < 0 || cX >= Wf || cY < 0 || cY >= Hf) ncau++;  // :58-62
-    if (cX < 0) cX = 0;
-    if (cX >= Wf) cX = Wf;
-    if (cY < 0) cY = 0;
-    if (cY >= Hf) cY = Hf;
-    texcoord[2 * i] = cX;
-    texcoord[2 * i + 1] = cY;
-    minX = minX < cX ? minX : cX; maxX = maxX > cX ? maxX : cX;
-    minY = minY < cY ? minY : cY; maxY = maxY > cY ? maxY : cY;
-    float tc[3];
-    bilinear_rgb(P.rgb, W, H, cX, cY, tc);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { tc[k] = tc[k] / 255.0f; texcolor[3 * i + k] = tc[k]; }
-    const float dpt = bilinear_f(P.depth, W, H, cX, cY);
-    const float d0 = tc[0] - colors[3 * i], d1 = tc[1] - colors[3 * i + 1], d2 = tc[2] - colors[3 * i + 2];
-    const float s12 = d1 * d1 + d2 * d2;
-    const float nrm = sqrtf(d0 * d0 + s12);
-    if ((double)nrm > 0.6) ccmp++;                   // :88
-    if ((double)fabsf(dist - dpt) > 0.7) dcmp++;     // :89
+// n-th slot the allocator hands out (Atlas.cpp:48-58): x advances by PW and wraps to the next band of PH
+// rows once x + PW >= AW, so a band holds K = ceil(AW / PW) slots; the hand-out fails once y >= AH.
+__host__ __device__ inline bool slot_texloc(int atlas_w, int atlas_h, int pw, int ph, unsigned long long n,
+                                            unsigned long long* texloc) {
+  const unsigned long long K = ((unsigned long long)atlas_w + pw - 1) / (unsigned long long)pw;
+  const unsigned long long band = n / K, k = n - band * K;
+  const unsigned long long y = band * (unsigned long long)ph;
+  *texloc = k * (unsigned long long)pw + y * (unsigned long long)atlas_w;
+  return y < (unsigned long long)atlas_h;
+}
+__device__ __forceinline__ bool slot_texloc(const VolumeDev& v, unsigned long long n, unsigned long long* texloc) {
+  return slot_texloc(v.atlas_w, v.atlas_h, v.patch_w, v.patch_h, n, texloc);
+}
+
+// Patch::clear (Patch.cpp:177-189) + SetFrameid of a patch that is about to be re-projected
+__device__ __forceinline__ void patch_begin(MeshRec* r, const KfDev& kf, int kf_slot) {
+  r->frameid = kf.kf_id;
+  r->kf_slot = kf_slot;
+  r->pflags = kPfHasPatch;
+  r->ratio[0] = 1.0f; r->ratio[1] = 1.0f;
+}
+
+// work-list entry -> pool slot of a chunk that has a mesh (Atlas::HasPatch == ChunkManager::HasMesh, Atlas.h:55)
+__device__ __forceinline__ uint32_t mesh_slot_of(const VolumeDev& v, const int4 id) {
+  const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+  uint32_t slot = kInvalidSlot;
+  if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
+  if (slot != kInvalidSlot && !(v.mesh_rec[slot].state & kMsInMap)) slot = kInvalidSlot;
+  return slot;
+}
+__global__ __launch_bounds__(256) void k_work_lookup(VolumeDev v, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) v.work_slot[i] = mesh_slot_of(v, v.work_ids[i]);
+}
+
+// ---------------------------------------------------------------------------------------
+// Atlas::AddPatch over an ordered list (Chisel::GeneratePatches' loop, Chisel.cpp:156-181): single
+// workgroup; entry j needs a slot iff its chunk has a mesh without one, the slot number is the number of
+// such entries before it.  The first entry whose hand-out fails ends the call: it and everything behind it
+// stays unprocessed (GeneratePatches returns -1 there).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_patch_assign(VolumeDev v, uint32_t n) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t first_fail;
+  __shared__ unsigned long long smin, smax;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const uint32_t per = (n + 1023u) / 1024u;
+  const uint32_t b = (uint32_t)t * per < n ? (uint32_t)t * per : n, e = (b + per < n) ? b + per : n;
+  if (t == 0) { first_fail = 0xFFFFFFFFu; smin = ~0ull; smax = 0ull; }
+  uint32_t cnt = 0;
+  for (uint32_t i = b; i < e; ++i) {
+    const uint32_t slot = mesh_slot_of(v, v.work_ids[i]);  // !HasMesh -> continue (:157)
+    v.work_slot[i] = slot;
+    if (slot != kInvalidSlot && v.mesh_rec[slot].texloc == kNoTexloc) ++cnt;
   }
-  // block reduction (min/max and integer counts are order-independent)
+  uint32_t inc = cnt;
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    float t = __shfl_xor(minX, o); minX = t < minX ? t : minX;
-    t = __shfl_xor(maxX, o); maxX = t > maxX ? t : maxX;
-    t = __shfl_xor(minY, o); minY = t < minY ? t : minY;
-    t = __shfl_xor(maxY, o); maxY = t > maxY ? t : maxY;
-    dcmp += __shfl_xor(dcmp, o); ccmp += __shfl_xor(ccmp, o); ncau += __shfl_xor(ncau, o);
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(inc, o);
+    if (lane >= o) inc += u;
   }
-  __shared__ float sred[4][4];
-  __shared__ int sint[4][3];
-  __shared__ int sbox[2];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) {
-    sred[w][0] = minX; sred[w][1] = maxX; sred[w][2] = minY; sred[w][3] = maxY;
-    sint[w][0] = dcmp; sint[w][1] = ccmp; sint[w][2] = ncau;
+  if (lane == 63) wsum[w] = inc;
+  __syncthreads();
+  uint32_t before = 0;
+  for (int k = 0; k < w; ++k) before += wsum[k];
+  const unsigned long long base = v.actl->n_slots;
+  uint32_t r = before + inc - cnt;
+  uint32_t handed = 0;
+  for (uint32_t i = b; i < e; ++i) {
+    const uint32_t slot = v.work_slot[i];
+    if (slot == kInvalidSlot) continue;
+    MeshRec* rec = &v.mesh_rec[slot];
+    if (rec->texloc != kNoTexloc) continue;
+    unsigned long long tl;
+    if (slot_texloc(v, base + r, &tl)) { rec->texloc = tl; ++handed; }
+    else atomicMin(&first_fail, i);
+    ++r;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; ++k) {
-      minX = sred[k][0] < minX ? sred[k][0] : minX; maxX = sred[k][1] > maxX ? sred[k][1] : maxX;
-      minY = sred[k][2] < minY ? sred[k][2] : minY; maxY = sred[k][3] > maxY ? sred[k][3] : maxY;
-      dcmp += sint[k][0]; ccmp += sint[k][1]; ncau += sint[k][2];
-    }
-    const double nv = (double)(P.v1 - P.v0);
-    const bool wrong = ((double)dcmp > 0.3 * nv) || ((double)ccmp > 0.3 * nv);  // :92-96
-    PatchOut o;
-    int x1 = 0, y1 = 0, bw = 0, bh = 0;
-    if (maxX >= minX && maxY >= minY) {  // :98-99, cv::Rect(float..) truncation, intersection
-      const int ax = (int)(minX - 2.0f), ay = (int)(minY - 2.0f);
-      const int aw = (int)(maxX - minX + 5.0f), ah = (int)(maxY - minY + 5.0f);
-      x1 = ax > 0 ? ax : 0; y1 = ay > 0 ? ay : 0;
-      const int x2 = (ax + aw) < (W - 1) ? (ax + aw) : (W - 1);
-      const int y2 = (ay + ah) < (H - 1) ? (ay + ah) : (H - 1);
-      bw = x2 - x1; bh = y2 - y1;
-      if (bw <= 0 || bh <= 0) { x1 = y1 = bw = bh = 0; }
-    }
-    o.bbox[0] = x1; o.bbox[1] = y1; o.bbox[2] = bw; o.bbox[3] = bh;
-    o.flags = (ncau > 0 ? 1 : 0) | (wrong ? 2 : 0);
-    o.ratio[0] = 1.0f; o.ratio[1] = 1.0f;
-    o.n_caution = ncau;
-    pout[blockIdx.x] = o;
-    sbox[0] = (maxX >= minX && maxY >= minY) ? x1 : 0;
-    sbox[1] = (maxX >= minX && maxY >= minY) ? y1 : 0;
+  const uint32_t ff = first_fail;
+  unsigned long long lmin = ~0ull, lmax = 0ull;
+  for (uint32_t i = b; i < e; ++i) {
+    const uint32_t slot = v.work_slot[i];
+    if (slot == kInvalidSlot) continue;
+    if (i >= ff) { v.work_slot[i] = kInvalidSlot; continue; }
+    MeshRec* rec = &v.mesh_rec[slot];
+    const int kf_slot = v.work_ids[i].w;
+    patch_begin(rec, v.kf_tab[kf_slot], kf_slot);
+    lmin = rec->texloc < lmin ? rec->texloc : lmin;
+    lmax = rec->texloc > lmax ? rec->texloc : lmax;
   }
+  atomicMin(&smin, lmin);
+  atomicMax(&smax, lmax);
+  uint32_t tot = handed;  // every successful hand-out precedes the first failure (slot numbers grow with the list)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
   __syncthreads();
-  const float bx = (float)sbox[0], by = (float)sbox[1];
-  for (int64_t i = P.v0 + threadIdx.x; i < P.v1; i += 256) {  // :100-102
-    texcoord[2 * i] -= bx;
-    texcoord[2 * i + 1] -= by;
+  if (lane == 0) wsum[w] = tot;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t all = 0;
+    for (int k = 0; k < 16; ++k) all += wsum[k];
+    v.actl->n_slots += all;
+    v.actl->loc_min = smin;
+    v.actl->loc_max = smax;
+    v.actl->set[0].n_work = n;
+    v.actl->set[0].fail_key = ~0ull;
+    if (ff != 0xFFFFFFFFu) atomicOr(&v.vctl->status, kStAtlasFull);
   }
 }
 
-// Atlas::UpdateBuffer.  LDS tile = the keyframe ROI (rows x cols x 3 bytes, capped); the slot
-// (PW x PH texels) is written as contiguous row segments of the atlas.
-constexpr int kMaxRoiBytes = 48 * 1024;
-
-__device__ __forceinline__ int cv_round_f(float v) { return (int)rintf(v); }
-
-__global__ __launch_bounds__(256) void k_atlas_blit(const PatchIn* __restrict__ pin,
-                                                    PatchOut* __restrict__ pout, uint8_t* atlas,
-                                                    int aw, int ah, int PW, int PH, int W) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t roi[];
-  const PatchIn P = pin[blockIdx.x];
-  PatchOut* O = &pout[blockIdx.x];
-  const int bx = O->bbox[0], by = O->bbox[1], cols = O->bbox[2], rows = O->bbox[3];
-  if (cols <= 0 || rows <= 0) return;
-  float r0 = 1.0f, r1 = 1.0f;
-  if (cols > PW) r0 = (float)PW / (float)cols;  // Atlas.cpp:77-80
-  if (rows > PH) r1 = (float)PH / (float)rows;
-  if (threadIdx.x == 0) { O->ratio[0] = r0; O->ratio[1] = r1; }
-  const uint64_t ox = P.texloc % (uint64_t)aw, oy = P.texloc / (uint64_t)aw;
-  const size_t astep = (size_t)aw * 3;
-  const bool in_lds = (size_t)cols * rows * 3 <= (size_t)kMaxRoiBytes;
-  const int rowbytes = cols * 3;
-  if (in_lds) {
-    for (int i = threadIdx.x; i < rows * rowbytes; i += 256) {
-      const int r = i / rowbytes, c = i - r * rowbytes;
-      roi[i] = P.rgb[((size_t)(by + r) * W + bx) * 3 + c];
-    }
-    __syncthreads();
-  }
-  auto src = [&](int r, int cbyte) -> int {
-    return in_lds ? roi[r * rowbytes + cbyte] : P.rgb[((size_t)(by + r) * W + bx) * 3 + cbyte];
-  };
-  if (r0 < 1 || r1 < 1) {  // cv::resize(image, texroi, texroi.size()) into the FULL slot
-    if (ox + PW > (uint64_t)aw || oy + PH > (uint64_t)ah) return;
-    const double scale_x = 1.0 / ((double)PW / cols), scale_y = 1.0 / ((double)PH / rows);
-    for (int t = threadIdx.x; t < PW * PH; t += 256) {
-      const int dy = t / PW, dx = t - dy * PW;
-      float fx = (float)((dx + 0.5) * scale_x - 0.5);
-      int sx = (int)floorf(fx);
-      fx -= (float)sx;
-      if (sx < 0) { fx = 0; sx = 0; }
-      if (sx >= cols - 1) { fx = 0; sx = cols - 1; }
-      const int a0 = (short)cv_round_f((1.f - fx) * 2048.f), a1 = (short)cv_round_f(fx * 2048.f);
-      float fy = (float)((dy + 0.5) * scale_y - 0.5);
-      int sy = (int)floorf(fy);
-      fy -= (float)sy;
-      int sy0 = sy, sy1 = sy + 1;
-      sy0 = sy0 < 0 ? 0 : (sy0 > rows - 1 ? rows - 1 : sy0);
-      sy1 = sy1 < 0 ? 0 : (sy1 > rows - 1 ? rows - 1 : sy1);
-      const int b0 = (short)cv_round_f((1.f - fy) * 2048.f), b1 = (short)cv_round_f(fy * 2048.f);
-      const int sx1 = sx + 1 < cols ? sx + 1 : sx;
-      uint8_t* D = atlas + (oy + dy) * astep + (ox + dx) * 3;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int h0 = src(sy0, 3 * sx + k) * a0 + src(sy0, 3 * sx1 + k) * a1;
-        const int h1 = src(sy1, 3 * sx + k) * a0 + src(sy1, 3 * sx1 + k) * a1;
-        int val = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
-        val = val < 0 ? 0 : (val > 255 ? 255 : val);
-        D[k] = (uint8_t)val;
+// ---------------------------------------------------------------------------------------
+// fused per-frame flow: the work list is the frame's dirty set, unordered.  k_patch_collect keeps the entries
+// that have a mesh and lists the ones without an atlas slot; k_patch_rank hands the slots out in ascending
+// chunk-id order (rank of a key = number of smaller keys among the candidates, counted by comparison: the
+// candidate count is a few hundred in steady state, a few thousand on first touch).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_patch_collect(VolumeDev v, int par) {
+  AtlasCtl::Set* S = &v.actl->set[par];
+  const uint32_t n = S->n_work;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
+    const uint32_t i = base + threadIdx.x;
+    bool need = false;
+    unsigned long long key = 0;
+    if (i < n) {
+      uint32_t slot = v.work_slot[i];
+      if (slot != kInvalidSlot && !(v.mesh_rec[slot].state & kMsInMap)) { slot = kInvalidSlot; v.work_slot[i] = slot; }
+      if (slot != kInvalidSlot && v.mesh_rec[slot].texloc == kNoTexloc) {
+        const int4 id = v.work_ids[i];
+        key = pack_id(id.x, id.y, id.z);
+        need = true;
       }
     }
-  } else {  // image.copyTo(texroi) at the slot origin
-    if (ox + cols > (uint64_t)aw || oy + rows > (uint64_t)ah) return;
-    for (int i = threadIdx.x; i < rows * rowbytes; i += 256) {
-      const int r = i / rowbytes, c = i - r * rowbytes;
-      atlas[(oy + r) * astep + ox * 3 + c] = (uint8_t)src(r, c);
+    const unsigned long long m = __ballot(need);
+    if (m) {
+      uint32_t p0 = 0;
+      if (lane == 0) p0 = atomicAdd(&S->n_cand, (uint32_t)__popcll(m));
+      p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
+      if (need) v.cand[p0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void k_patch_rank(VolumeDev v, int par) {
+  AtlasCtl::Set* S = &v.actl->set[par];
+  const uint32_t n = S->n_cand;
+  const unsigned long long base = v.actl->n_slots;
+  __shared__ unsigned long long tile[256];
+  for (uint32_t b0 = blockIdx.x * 256; b0 < n; b0 += gridDim.x * 256) {
+    const uint32_t i = b0 + threadIdx.x;
+    const unsigned long long mine = i < n ? v.cand[i] : ~0ull;
+    uint32_t rank = 0;
+    for (uint32_t t0 = 0; t0 < n; t0 += 256) {
+      __syncthreads();
+      tile[threadIdx.x] = (t0 + threadIdx.x < n) ? v.cand[t0 + threadIdx.x] : ~0ull;
+      __syncthreads();
+      const uint32_t m = (n - t0 < 256u) ? n - t0 : 256u;
+      for (uint32_t k = 0; k < m; ++k) rank += tile[k] < mine ? 1u : 0u;
+    }
+    if (i < n) {
+      const uint32_t ent = hash_find(v, mine);
+      const uint32_t slot = v.hent[ent].slot;
+      unsigned long long tl;
+      if (slot_texloc(v, base + rank, &tl)) v.mesh_rec[slot].texloc = tl;
+      else {
+        atomicMin(&S->fail_key, mine);
+        atomicOr(&v.vctl->status, kStAtlasFull);
+      }
     }
   }
 }
 
-// ---- host side ------------------------------------------------------------------------
-int atlas_init(tf_volume* v) {
-  AtlasState& a = v->atlas;
-  a.aw = v->cfg.atlas_w;
-  a.ah = v->cfg.atlas_h;
-  a.pw = (uint64_t)floor((double)(4800.0f * v->res));  // Atlas::SetResolution, Atlas.h:62-65
-  a.ph = (uint64_t)floor((double)(3600.0f * v->res));
-  a.loc_next = 0;
-  const size_t bytes = (size_t)a.aw * a.ah * 3;
-  hipError_t e = hipMalloc((void**)&a.buf, bytes);  // Atlas.cpp:34: 13824 x 13824 x RGB8 = 573 MB
-  if (e != hipSuccess) { set_error("atlas hipMalloc failed"); return TF_ERR_HIP; }
-  TF_HIP(hipMemsetAsync(a.buf, 0, bytes, v->stream));  // Atlas.cpp:35-36
-  return TF_OK;
-}
+// ---------------------------------------------------------------------------------------
+// One wave per patch.  PROJECT = Patch::CalculateTexCoords + SetFrameid + SetImage (GeneratePatches' loop
+// body), BLIT = Atlas::UpdateBuffer.  FUSED = the work list is the frame's dirty set of the fused flow
+// (patch_begin here, overflow = keys >= fail_key are skipped, counters of the next frame re-armed).
+// ---------------------------------------------------------------------------------------
+typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
-void atlas_destroy(tf_volume* v) {
-  AtlasState& a = v->atlas;
-  for (auto& kv : a.keyframes)
-    if (kv.second.owned) { hipFree(kv.second.rgb); hipFree(kv.second.depth); }
-  a.keyframes.clear();
-  if (a.buf) hipFree(a.buf);
-  if (a.d_stage) hipFree(a.d_stage);
-  if (a.h_stage) hipHostFree(a.h_stage);
-  a.buf = nullptr; a.d_stage = nullptr; a.h_stage = nullptr;
-  for (int k = 0; k < 4; ++k) {
-    if (a.pin_ev[k]) hipEventDestroy(a.pin_ev[k]);
-    if (a.pin_host[k]) hipHostFree(a.pin_host[k]);
-    if (a.pin_dev[k]) hipFree(a.pin_dev[k]);
-    a.pin_ev[k] = nullptr; a.pin_host[k] = nullptr; a.pin_dev[k] = nullptr; a.pin_bytes[k] = 0;
+__device__ __forceinline__ int cv_round_f(float x) { return (int)rintf(x); }
+
+template <bool PROJECT, bool BLIT, bool FUSED>
+__global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, KfDev kf_fused) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const uint32_t nwaves = gridDim.x * 4;
+  AtlasCtl::Set* S = &v.actl->set[par];
+  const uint32_t n = S->n_work;
+  const unsigned long long fail_key = FUSED ? S->fail_key : ~0ull;
+  const int W = cam.W, H = cam.H;
+  const float Wf = (float)W, Hf = (float)H;
+  if (FUSED && blockIdx.x == 0 && threadIdx.x == 0) {
+    // every kernel of the previous frame has finished with the other counter set: re-arm it; account for the
+    // slots this frame's ranking handed out (nobody reads n_slots while this kernel runs)
+    AtlasCtl::Set* O = &v.actl->set[par ^ 1];
+    O->n_work = 0; O->n_cand = 0; O->fail_key = ~0ull;
+    unsigned long long tl;
+    uint32_t got = S->n_cand;
+    while (got && !slot_texloc(v, (unsigned long long)v.actl->n_slots + got - 1, &tl)) --got;
+    v.actl->n_slots += got;
+  }
+  for (uint32_t e = wave; e < n; e += nwaves) {
+    const uint32_t slot = v.work_slot[e];
+    if (slot == kInvalidSlot) continue;
+    const int4 id = v.work_ids[e];
+    if (FUSED && pack_id(id.x, id.y, id.z) >= fail_key) continue;
+    MeshRec* rec = &v.mesh_rec[slot];
+    const uint32_t nv = rec->nv;
+    const uint32_t state = rec->state;
+    // fused flow: the keyframe is the frame itself, handed over by value; its image is not retained (kf_slot -1)
+    const int kf_slot = FUSED ? -1 : (PROJECT ? id.w : rec->kf_slot);
+    if (!PROJECT && (!(rec->pflags & kPfHasPatch) || kf_slot < 0)) continue;  // GetPatch == nullptr (Atlas.cpp:73-74)
+    const KfDev kf = FUSED ? kf_fused : v.kf_tab[kf_slot];
+    int bx = 0, by = 0, cols = 0, rows = 0;
+    bool have_image = false;
+    if (PROJECT) {
+      if (FUSED && lane == 0) patch_begin(rec, kf, kf_slot);
+      float minX = Wf, maxX = 0.0f, minY = Hf, maxY = 0.0f;  // Patch.cpp:46-49
+      uint32_t dcmp = 0, ccmp = 0, ncau = 0;
+      float* tu = mesh_plane(v, slot, kMpTc);
+      float* tv = mesh_plane(v, slot, kMpTc + 1);
+      for (uint32_t i = lane; i < ((nv + 63u) & ~63u); i += 64) {
+        const bool act = i < nv;
+        bool cau = false, cc = false, dc = false;
+        if (act) {
+          const float vx = mesh_plane(v, slot, kMpPos)[i], vy = mesh_plane(v, slot, kMpPos + 1)[i],
+                      vz = mesh_plane(v, slot, kMpPos + 2)[i];
+          float vl[3];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {  // T_g_l * (v, 1), accumulated column by column (:52-53)
+            float s = kf.T[4 * r] * vx;
+            s = s + kf.T[4 * r + 1] * vy;
+            s = s + kf.T[4 * r + 2] * vz;
+            s = s + kf.T[4 * r + 3] * 1.0f;
+            vl[r] = s;
+          }
+          const float dist = vl[2];
+          const float x = vl[0] / vl[2], y = vl[1] / vl[2];
+          float cX = (float)((double)(x * cam.fxi + cam.cxi) + 0.5);  // :55-56
+          float cY = (float)((double)(y * cam.fyi + cam.cyi) + 0.5);
+          cau = (cX < 0 || cX >= Wf || cY < 0 || cY >= Hf);  // :58-62
+          if (cX < 0) cX = 0;
+          if (cX >= Wf) cX = Wf;
+          if (cY < 0) cY = 0;
+          if (cY >= Hf) cY = Hf;
+          tu[i] = cX;
+          tv[i] = cY;
+          minX = minX < cX ? minX : cX; maxX = maxX > cX ? maxX : cX;
+          minY = minY < cY ? minY : cY; maxY = maxY > cY ? maxY : cY;
+          float tc[3];
+          bilinear_rgb(kf.rgb, kf.stride, W, H, cX, cY, tc);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { tc[k] = tc[k] / 255.0f; mesh_plane(v, slot, kMpTcol + k)[i] = tc[k]; }
+          const float dpt = bilinear_f(kf.depth, W, H, cX, cY);
+          const float d0 = tc[0] - mesh_plane(v, slot, kMpCol)[i], d1 = tc[1] - mesh_plane(v, slot, kMpCol + 1)[i],
+                      d2 = tc[2] - mesh_plane(v, slot, kMpCol + 2)[i];
+          const float s12 = d1 * d1 + d2 * d2;
+          const float nrm = sqrtf(d0 * d0 + s12);
+          cc = (double)nrm > 0.6;                 // :88
+          dc = (double)fabsf(dist - dpt) > 0.7;   // :89
+        }
+        ncau += (uint32_t)__popcll(__ballot(cau));
+        ccmp += (uint32_t)__popcll(__ballot(cc));
+        dcmp += (uint32_t)__popcll(__ballot(dc));
+      }
+      // min / max are exact and order-free
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        float q = __shfl_xor(minX, o); minX = q < minX ? q : minX;
+        q = __shfl_xor(maxX, o); maxX = q > maxX ? q : maxX;
+        q = __shfl_xor(minY, o); minY = q < minY ? q : minY;
+        q = __shfl_xor(maxY, o); maxY = q > maxY ? q : maxY;
+      }
+      const double nvd = (double)nv;
+      const bool wrong = ((double)dcmp > 0.3 * nvd) || ((double)ccmp > 0.3 * nvd);  // :92-96
+      if (maxX >= minX && maxY >= minY) {  // :98-99: cv::Rect(float..) truncates, & intersects
+        const int ax = (int)(minX - 2.0f), ay = (int)(minY - 2.0f);
+        const int aw = (int)(maxX - minX + 5.0f), ah = (int)(maxY - minY + 5.0f);
+        bx = ax > 0 ? ax : 0; by = ay > 0 ? ay : 0;
+        const int x2 = (ax + aw) < (W - 1) ? (ax + aw) : (W - 1);
+        const int y2 = (ay + ah) < (H - 1) ? (ay + ah) : (H - 1);
+        cols = x2 - bx; rows = y2 - by;
+        if (cols <= 0 || rows <= 0) { bx = by = cols = rows = 0; }
+        const float fbx = (float)bx, fby = (float)by;
+        for (uint32_t i = lane; i < nv; i += 64) {  // :100-102 (a lane re-reads what it wrote)
+          tu[i] = tu[i] - fbx;
+          tv[i] = tv[i] - fby;
+        }
+      }
+      if (lane == 0) {
+        rec->bbox[0] = bx; rec->bbox[1] = by; rec->bbox[2] = cols; rec->bbox[3] = rows;
+        rec->pflags = kPfHasPatch | kPfHasImage | (ncau ? kPfCaution : 0u) | (wrong ? kPfWrong : 0u);
+        rec->ratio[0] = 1.0f; rec->ratio[1] = 1.0f;
+        atomicAdd(&v.actl->n_done, 1u);
+      }
+      have_image = true;
+    } else {
+      bx = rec->bbox[0]; by = rec->bbox[1]; cols = rec->bbox[2]; rows = rec->bbox[3];
+      have_image = (rec->pflags & kPfHasImage) != 0;
+    }
+    if (!BLIT) continue;
+    // Patch::complete (Patch.cpp:191-196): vertices, simplified mesh, image, texcoords, frame id
+    if (!(nv > 0 && (state & kMsSimplified) && have_image && kf.kf_id >= 0)) continue;
+    if (cols <= 0 || rows <= 0) continue;  // empty ROI: nothing to copy
+    const int PW = v.patch_w, PH = v.patch_h;
+    float r0 = 1.0f, r1 = 1.0f;
+    if (cols > PW) r0 = (float)PW / (float)cols;  // Atlas.cpp:77-80
+    if (rows > PH) r1 = (float)PH / (float)rows;
+    if (lane == 0) { rec->ratio[0] = r0; rec->ratio[1] = r1; }
+    const unsigned long long tl = rec->texloc;
+    const unsigned long long ox = tl % (unsigned long long)v.atlas_w, oy = tl / (unsigned long long)v.atlas_w;
+    const size_t astep = (size_t)v.atlas_w * 3;
+    const int st = kf.stride;
+    if (r0 < 1 || r1 < 1) {  // cv::resize(image, texroi, texroi.size()) into the FULL slot
+      if (ox + PW > (unsigned long long)v.atlas_w || oy + PH > (unsigned long long)v.atlas_h) continue;
+      const double scale_x = 1.0 / ((double)PW / cols), scale_y = 1.0 / ((double)PH / rows);
+      for (int t = lane; t < PW * PH; t += 64) {
+        const int dy = t / PW, dx = t - dy * PW;
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= cols - 1) { fx = 0; sx = cols - 1; }
+        const int a0 = (short)cv_round_f((1.f - fx) * 2048.f), a1 = (short)cv_round_f(fx * 2048.f);
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= (float)sy;
+        int sy0 = sy, sy1 = sy + 1;
+        sy0 = sy0 < 0 ? 0 : (sy0 > rows - 1 ? rows - 1 : sy0);
+        sy1 = sy1 < 0 ? 0 : (sy1 > rows - 1 ? rows - 1 : sy1);
+        const int b0 = (short)cv_round_f((1.f - fy) * 2048.f), b1 = (short)cv_round_f(fy * 2048.f);
+        const int sx1 = sx + 1 < cols ? sx + 1 : sx;
+        const uint8_t* s00 = kf.rgb + ((size_t)(by + sy0) * W + bx + sx) * st;
+        const uint8_t* s01 = kf.rgb + ((size_t)(by + sy0) * W + bx + sx1) * st;
+        const uint8_t* s10 = kf.rgb + ((size_t)(by + sy1) * W + bx + sx) * st;
+        const uint8_t* s11 = kf.rgb + ((size_t)(by + sy1) * W + bx + sx1) * st;
+        uint8_t* D = v.atlas + (oy + dy) * astep + (ox + dx) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int h0 = s00[k] * a0 + s01[k] * a1;
+          const int h1 = s10[k] * a0 + s11[k] * a1;
+          int val = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+          val = val < 0 ? 0 : (val > 255 ? 255 : val);
+          D[k] = (uint8_t)val;
+        }
+      }
+    } else {  // image.copyTo(texroi) at the slot origin
+      if (ox + cols > (unsigned long long)v.atlas_w || oy + rows > (unsigned long long)v.atlas_h) continue;
+      const int rowbytes = cols * 3;
+      if (st == 3) {
+        // rows are contiguous byte runs on both sides: the destination is written as aligned dwords
+        // (unaligned dword reads of the source), head / tail bytes one by one
+        const int ndw = (rowbytes + 3 + 3) >> 2;  // dwords touched at most (head misalignment up to 3)
+        for (int t = lane; t < rows * ndw; t += 64) {
+          const int r = t / ndw, j = t - r * ndw;
+          uint8_t* drow = v.atlas + (oy + r) * astep + ox * 3;
+          const uint8_t* srow = kf.rgb + ((size_t)(by + r) * W + bx) * 3;
+          const int mis = (int)((uintptr_t)drow & 3u);
+          const int o = 4 * j - mis;  // row byte offset of this aligned destination dword
+          if (o >= rowbytes) continue;
+          if (o >= 0 && o + 4 <= rowbytes) {
+            *reinterpret_cast<uint32_t*>(drow + o) = *reinterpret_cast<const u32_unaligned*>(srow + o);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (o + q >= 0 && o + q < rowbytes) drow[o + q] = srow[o + q];
+          }
+        }
+      } else {
+        for (int t = lane; t < rows * cols; t += 64) {
+          const int r = t / cols, c = t - r * cols;
+          const uint8_t* sp = kf.rgb + ((size_t)(by + r) * W + bx + c) * st;
+          uint8_t* dp = v.atlas + (oy + r) * astep + (ox + c) * 3;
+          dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2];
+        }
+      }
+    }
   }
 }
 
-int atlas_reset(tf_volume* v) {
-  AtlasState& a = v->atlas;
-  a.loc_next = 0;
-  a.texloc.clear();
-  TF_HIP(hipMemsetAsync(a.buf, 0, (size_t)a.aw * a.ah * 3, v->stream));
-  return TF_OK;
-}
-
 // ---------------------------------------------------------------------------------------
-// Chisel::CompensateColor (Structure/Chisel.cpp:198-286).  The reductions over all vertices of a
-// cluster and the per-vertex transfer run here; the two 3x3 eigen-decompositions per cluster are
-// host work (a few hundred flops).  Reductions are fixed-shape trees (thread-strided partial sums
-// in patch order, then an LDS tree), so results do not depend on timing.
+// Chisel::CompensateColor (Structure/Chisel.cpp:198-286).  The reductions over all vertices of a cluster and
+// the per-vertex transfer run here; the two 3x3 eigen-decompositions per cluster are host work (a few
+// hundred flops).  Reductions are fixed-shape trees (thread-strided partial sums in patch order, then an
+// LDS tree), so results do not depend on timing.
 // ---------------------------------------------------------------------------------------
 struct CcPatch {
-  int64_t v0, v1;
+  uint32_t slot, nv;
   int32_t cluster;  // -1 = skipped (already adjusted)
   int32_t wrong;
 };
 // pass 0: sums of texcolor / mesh colour -> out[c][0..5], count -> out[c][6];
 // pass 1: centred second moments (6 unique entries each) -> out[c][0..11] given mean[c][0..5]
 template <int PASS>
-__global__ __launch_bounds__(256) void k_cc_reduce(const CcPatch* __restrict__ pt, int64_t np,
-                                                   const float* __restrict__ src, const float* __restrict__ tar,
+__global__ __launch_bounds__(256) void k_cc_reduce(VolumeDev v, const CcPatch* __restrict__ pt, int64_t np,
                                                    const float* __restrict__ mean, float* __restrict__ out) {
   constexpr int NV = PASS == 0 ? 7 : 12;
   const int c = blockIdx.x;
@@ -330,14 +497,17 @@ __global__ __launch_bounds__(256) void k_cc_reduce(const CcPatch* __restrict__ p
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
   float m[6] = {0, 0, 0, 0, 0, 0};
-  if (PASS == 1)
+  if constexpr (PASS == 1)
     for (int i = 0; i < 6; ++i) m[i] = mean[c * 6 + i];
   for (int64_t p = 0; p < np; ++p) {
     if (pt[p].cluster != c || pt[p].wrong) continue;
-    for (int64_t k = pt[p].v0 + threadIdx.x; k < pt[p].v1; k += 256) {
-      const float s0 = src[3 * k], s1 = src[3 * k + 1], s2 = src[3 * k + 2];
-      const float t0 = tar[3 * k], t1 = tar[3 * k + 1], t2 = tar[3 * k + 2];
-      if (PASS == 0) {
+    const uint32_t slot = pt[p].slot;
+    for (uint32_t k = threadIdx.x; k < pt[p].nv; k += 256) {
+      const float s0 = mesh_plane(v, slot, kMpTcol)[k], s1 = mesh_plane(v, slot, kMpTcol + 1)[k],
+                  s2 = mesh_plane(v, slot, kMpTcol + 2)[k];
+      const float t0 = mesh_plane(v, slot, kMpCol)[k], t1 = mesh_plane(v, slot, kMpCol + 1)[k],
+                  t2 = mesh_plane(v, slot, kMpCol + 2)[k];
+      if constexpr (PASS == 0) {
         acc[0] += s0; acc[1] += s1; acc[2] += s2;
         acc[3] += t0; acc[4] += t1; acc[5] += t2;
         acc[6] += 1.0f;
@@ -361,23 +531,52 @@ __global__ __launch_bounds__(256) void k_cc_reduce(const CcPatch* __restrict__ p
   }
   if (threadIdx.x < NV) out[c * 12 + threadIdx.x] = red[threadIdx.x][0];
 }
-// labs[k] = T (texcolor[k] - mean_src) + mean_tar (Chisel.cpp:274)
-__global__ __launch_bounds__(256) void k_cc_apply(const CcPatch* __restrict__ pt, const float* __restrict__ src,
-                                                  const float* __restrict__ xf /* per cluster: T[9], mean_src[3], mean_tar[3], ok */,
-                                                  float* __restrict__ labs) {
+// labs[k] = T (texcolor[k] - mean_src) + mean_tar (Chisel.cpp:274); has_adjusted = true (:280)
+__global__ __launch_bounds__(256) void k_cc_apply(VolumeDev v, const CcPatch* __restrict__ pt,
+                                                  const float* __restrict__ xf /* per cluster: T[9], mean_src[3], mean_tar[3], ok */) {
   const CcPatch P = pt[blockIdx.x];
-  if (P.cluster < 0 || P.wrong) return;
+  if (P.cluster < 0) return;
   const float* X = xf + (size_t)P.cluster * 16;
-  if (X[15] == 0.0f) return;  // nothing was learnt for this cluster
-  for (int64_t k = P.v0 + threadIdx.x; k < P.v1; k += 256) {
-    const float d0 = src[3 * k] - X[9], d1 = src[3 * k + 1] - X[10], d2 = src[3 * k + 2] - X[11];
+  if (X[15] == 0.0f) return;  // nothing was learnt for this cluster (:242): has_adjusted stays false
+  if (threadIdx.x == 0) v.mesh_rec[P.slot].pflags |= kPfAdjusted;
+  if (P.wrong) return;  // labs cleared (:277-279)
+  for (uint32_t k = threadIdx.x; k < P.nv; k += 256) {
+    const float d0 = mesh_plane(v, P.slot, kMpTcol)[k] - X[9], d1 = mesh_plane(v, P.slot, kMpTcol + 1)[k] - X[10],
+                d2 = mesh_plane(v, P.slot, kMpTcol + 2)[k] - X[11];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float a = X[3 * i] * d0;
       a = a + X[3 * i + 1] * d1;
       a = a + X[3 * i + 2] * d2;
-      labs[3 * k + i] = a + X[12 + i];
+      mesh_plane(v, P.slot, kMpLabs + i)[k] = a + X[12 + i];
     }
+  }
+}
+
+// Every mesh that has a patch -- the host sorts by id (the reference iterates allMeshes, an unordered_map:
+// the harness order is ascending chunk id).
+struct PatchRow {
+  int32_t id[3];
+  uint32_t slot;
+  uint32_t nv, nt;
+  int32_t frameid;
+  uint32_t state, pflags;
+  uint32_t pad;
+};
+__global__ __launch_bounds__(256) void k_list_patches(VolumeDev v, PatchRow* out, uint32_t cap) {
+  const uint32_t nent = v.hmask + 1u;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nent; i += gridDim.x * 256) {
+    const HEntry h = v.hent[i];
+    if (h.key == kEmptyKey || !(h.alive & 1u) || h.slot == kInvalidSlot) continue;
+    const MeshRec m = v.mesh_rec[h.slot];
+    if (!(m.state & kMsInMap) || !(m.pflags & kPfHasPatch)) continue;
+    const uint32_t p = atomicAdd(&v.vctl->n_tmp, 1u);
+    if (p >= cap) continue;
+    const int4 id = unpack_id(h.key);
+    PatchRow r;
+    r.id[0] = id.x; r.id[1] = id.y; r.id[2] = id.z;
+    r.slot = h.slot; r.nv = m.nv; r.nt = m.nt; r.frameid = m.frameid; r.state = m.state; r.pflags = m.pflags; r.pad = 0;
+    out[p] = r;
   }
 }
 
@@ -385,49 +584,219 @@ __global__ __launch_bounds__(256) void k_cc_apply(const CcPatch* __restrict__ pt
 // Chisel::DrawMeshes (Structure/Chisel.cpp:288-355): interleaved vertex stream + rebased indices.
 // One workgroup per complete() patch; every output element is written once, 48 B per vertex.
 // ---------------------------------------------------------------------------------------
-struct PvPatch {
-  int64_t v0, v1, i0, i1;  // input vertex / index ranges
-  int64_t vout, iout;      // output positions (running counts over the complete patches before this one)
-  float ox, oy;            // slot origin (Atlas::GetTexLoc)
-  float rx, ry;            // Patch::ratio
-  int32_t flags;           // bit0 complete, bit1 wrong_mapping, bit2 labs valid
-  int32_t pad;
+struct DrawPatch {
+  uint32_t slot, nv, nt, flags;  // flags: bit1 wrong_mapping, bit2 labs valid
+  unsigned long long vout, iout;  // output positions (running counts over the patches before this one)
 };
-__global__ __launch_bounds__(256) void k_pack_vertices(const PvPatch* __restrict__ pt, const float* __restrict__ verts,
-                                                       const float* __restrict__ colors, const float* __restrict__ normals,
-                                                       const float* __restrict__ texcoord, const float* __restrict__ texcolor,
-                                                       const float* __restrict__ labs, const uint32_t* __restrict__ indices,
-                                                       float inv_unused, float aw, float ah, float* __restrict__ out_v,
-                                                       uint32_t* __restrict__ out_i) {
-  const PvPatch P = pt[blockIdx.x];
-  if (!(P.flags & 1)) return;
-  for (int64_t j = P.i0 + threadIdx.x; j < P.i1; j += 256) out_i[P.iout + (j - P.i0)] = indices[j] + (uint32_t)P.vout;
-  for (int64_t k = P.v0 + threadIdx.x; k < P.v1; k += 256) {
-    float* o = out_v + 12 * (P.vout + (k - P.v0));
-    float tx = texcoord[2 * k], ty = texcoord[2 * k + 1];
-    if (P.rx < 1.0f) tx = tx * P.rx;
-    if (P.ry < 1.0f) ty = ty * P.ry;
-    tx = tx + P.ox;
-    ty = ty + P.oy;
-    int rgb = (int)(colors[3 * k] * 255.0f);
-    rgb = (rgb << 8) + (int)(colors[3 * k + 1] * 255.0f);
-    rgb = (rgb << 8) + (int)(colors[3 * k + 2] * 255.0f);
+__global__ __launch_bounds__(256) void k_draw(VolumeDev v, const DrawPatch* __restrict__ pt, float* __restrict__ out_v,
+                                              uint32_t* __restrict__ out_i) {
+  const DrawPatch P = pt[blockIdx.x];
+  const MeshRec rec = v.mesh_rec[P.slot];
+  const float ox = (float)(rec.texloc % (unsigned long long)v.atlas_w);  // Atlas::GetTexLoc (Atlas.cpp:66-69)
+  const float oy = (float)(rec.texloc / (unsigned long long)v.atlas_w);
+  const float rx = rec.ratio[0], ry = rec.ratio[1];
+  const float aw = (float)v.atlas_w, ah = (float)v.atlas_h;
+  for (uint32_t j = threadIdx.x; j < P.nt; j += 256)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) out_i[P.iout + 3 * (size_t)j + a] = (uint32_t)tri_plane(v, P.slot, a)[j] + (uint32_t)P.vout;
+  for (uint32_t k = threadIdx.x; k < P.nv; k += 256) {
+    float* o = out_v + 12 * (P.vout + k);
+    float tx = mesh_plane(v, P.slot, kMpTc)[k], ty = mesh_plane(v, P.slot, kMpTc + 1)[k];
+    if (rx < 1.0f) tx = tx * rx;
+    if (ry < 1.0f) ty = ty * ry;
+    tx = tx + ox;
+    ty = ty + oy;
+    const float c0 = mesh_plane(v, P.slot, kMpCol)[k], c1 = mesh_plane(v, P.slot, kMpCol + 1)[k],
+                c2 = mesh_plane(v, P.slot, kMpCol + 2)[k];
+    int rgb = (int)(c0 * 255.0f);
+    rgb = (rgb << 8) + (int)(c1 * 255.0f);
+    rgb = (rgb << 8) + (int)(c2 * 255.0f);
     float adj = 0.0f;
-    if (P.flags & 4) {
-      const float a0 = labs[3 * k] - texcolor[3 * k], a1 = labs[3 * k + 1] - texcolor[3 * k + 1],
-                  a2 = labs[3 * k + 2] - texcolor[3 * k + 2];
+    if (P.flags & 4u) {
+      const float a0 = mesh_plane(v, P.slot, kMpLabs)[k] - mesh_plane(v, P.slot, kMpTcol)[k],
+                  a1 = mesh_plane(v, P.slot, kMpLabs + 1)[k] - mesh_plane(v, P.slot, kMpTcol + 1)[k],
+                  a2 = mesh_plane(v, P.slot, kMpLabs + 2)[k] - mesh_plane(v, P.slot, kMpTcol + 2)[k];
       int ad = (int)(a0 * 255.0f) + 255;
       ad = (ad << 9) + (int)(a1 * 255.0f) + 255;
       ad = (ad << 9) + (int)(a2 * 255.0f) + 255;
       adj = (float)ad;
     }
-    const float4 q0 = make_float4(verts[3 * k], verts[3 * k + 1], verts[3 * k + 2], 50.0f);
+    const float4 q0 = make_float4(mesh_plane(v, P.slot, kMpPos)[k], mesh_plane(v, P.slot, kMpPos + 1)[k],
+                                  mesh_plane(v, P.slot, kMpPos + 2)[k], 50.0f);
     const float4 q1 = make_float4((float)rgb, adj, tx / aw, ty / ah);
-    const float4 q2 = make_float4(normals[3 * k], normals[3 * k + 1], normals[3 * k + 2], (P.flags & 2) ? 1.0f : 0.0f);
+    const float4 q2 = make_float4(mesh_plane(v, P.slot, kMpNrm)[k], mesh_plane(v, P.slot, kMpNrm + 1)[k],
+                                  mesh_plane(v, P.slot, kMpNrm + 2)[k], (P.flags & 2u) ? 1.0f : 0.0f);
     reinterpret_cast<float4*>(o)[0] = q0;
     reinterpret_cast<float4*>(o)[1] = q1;
     reinterpret_cast<float4*>(o)[2] = q2;
   }
+}
+
+// Patch mirrors of listed chunks: per patch record + texcoord / texcolor / labs in the reference's layouts
+struct PatchHost {
+  unsigned long long texloc;
+  int32_t frameid;
+  uint32_t pflags;
+  int32_t bbox[4];
+  float ratio[2];
+  uint32_t nv, found;
+};
+__global__ __launch_bounds__(256) void k_patch_gather(VolumeDev v, const int4* __restrict__ ids, uint32_t n,
+                                                      const long long* __restrict__ voff, PatchHost* __restrict__ ph,
+                                                      float* texcoord, float* texcolor, float* labs) {
+  const uint32_t c = blockIdx.x;
+  if (c >= n) return;
+  PatchHost h;
+  memset(&h, 0, sizeof(h));
+  h.texloc = kNoTexloc; h.frameid = -1;
+  const uint32_t slot = mesh_slot_of(v, ids[c]);
+  if (slot != kInvalidSlot) {
+    const MeshRec m = v.mesh_rec[slot];
+    h.texloc = m.texloc; h.frameid = m.frameid; h.pflags = m.pflags;
+    for (int k = 0; k < 4; ++k) h.bbox[k] = m.bbox[k];
+    h.ratio[0] = m.ratio[0]; h.ratio[1] = m.ratio[1];
+    h.nv = m.nv; h.found = 1;
+    if (voff) {
+      const long long v0 = voff[c];
+      const uint32_t nv = (uint32_t)(voff[c + 1] - v0) < m.nv ? (uint32_t)(voff[c + 1] - v0) : m.nv;
+      for (uint32_t i = threadIdx.x; i < nv; i += 256) {
+        if (texcoord) { texcoord[2 * (v0 + i)] = mesh_plane(v, slot, kMpTc)[i]; texcoord[2 * (v0 + i) + 1] = mesh_plane(v, slot, kMpTc + 1)[i]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          if (texcolor) texcolor[3 * (v0 + i) + a] = mesh_plane(v, slot, kMpTcol + a)[i];
+          if (labs) labs[3 * (v0 + i) + a] = mesh_plane(v, slot, kMpLabs + a)[i];
+        }
+      }
+    }
+  }
+  if (threadIdx.x == 0) ph[c] = h;
+}
+
+// allMeshes[id] = a host-built mesh (Mesh::vertices / normals / colors / indices): creates the chunk when
+// it does not exist yet
+__global__ __launch_bounds__(256) void k_mesh_scatter(VolumeDev v, const int4* __restrict__ ids, uint32_t n,
+                                                      const long long* __restrict__ voff, const long long* __restrict__ ioff,
+                                                      const float* __restrict__ verts, const float* __restrict__ normals,
+                                                      const float* __restrict__ colors, const uint32_t* __restrict__ indices,
+                                                      uint32_t epoch) {
+  __shared__ uint32_t sslot;
+  const uint32_t c = blockIdx.x;
+  if (c >= n) return;
+  const int4 id = ids[c];
+  if (threadIdx.x == 0) {
+    bool is_new;
+    uint32_t ent;
+    sslot = chunk_acquire(v, id, &is_new, &ent);
+  }
+  __syncthreads();
+  const uint32_t slot = sslot;
+  if (slot == kInvalidSlot) return;
+  const long long v0 = voff[c], i0 = ioff[c];
+  const uint32_t nv = (uint32_t)(voff[c + 1] - v0), nt = (uint32_t)(ioff[c + 1] - i0) / 3u;
+  if (nv > v.mesh_cv || nt > v.mesh_ct) {
+    if (threadIdx.x == 0) atomicOr(&v.vctl->status, kStMeshFull);
+    return;
+  }
+  for (uint32_t i = threadIdx.x; i < nv; i += 256)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      mesh_plane(v, slot, kMpPos + a)[i] = verts[3 * (v0 + i) + a];
+      mesh_plane(v, slot, kMpNrm + a)[i] = normals[3 * (v0 + i) + a];
+      mesh_plane(v, slot, kMpCol + a)[i] = colors[3 * (v0 + i) + a];
+    }
+  for (uint32_t i = threadIdx.x; i < nt; i += 256)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) tri_plane(v, slot, a)[i] = (uint16_t)indices[i0 + 3 * (size_t)i + a];
+  if (threadIdx.x == 0) {
+    MeshRec* r = &v.mesh_rec[slot];
+    r->nv = nv; r->nt = nt; r->epoch = epoch;
+    r->state = kMsInMap;  // Mesh::Clear: adj = false, simplified = false
+  }
+}
+
+// measurement aid: what the fused flow did for the work list of counter set `par`
+__global__ __launch_bounds__(256) void k_texture_stats(VolumeDev v, int par, unsigned long long* out) {
+  const uint32_t n = v.actl->set[par].n_work;
+  unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    a[0] += 1;
+    const uint32_t slot = v.work_slot[i];
+    if (slot == kInvalidSlot) continue;
+    const MeshRec m = v.mesh_rec[slot];
+    if (!(m.state & kMsInMap)) continue;
+    a[1] += 1; a[2] += m.nv; a[3] += m.nt;
+    if (m.pflags & kPfHasImage) { a[4] += (unsigned long long)(m.bbox[2] > 0 ? m.bbox[2] : 0) * (unsigned long long)(m.bbox[3] > 0 ? m.bbox[3] : 0); a[5] += 1; }
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) a[k] += __shfl_xor(a[k], o);
+    if ((threadIdx.x & 63) == 0 && a[k]) atomicAdd(&out[k], a[k]);
+  }
+}
+void launch_texture_stats(const VolumeDev& v, int par, unsigned long long* out6, hipStream_t s) {
+  hipLaunchKernelGGL(k_texture_stats, dim3(64), dim3(256), 0, s, v, par, out6);
+}
+
+// ---- host side ------------------------------------------------------------------------
+int atlas_init(tf_volume* v) {
+  AtlasState& a = v->atlas;
+  VolumeDev& d = v->dev;
+  a.aw = v->cfg.atlas_w;
+  a.ah = v->cfg.atlas_h;
+  a.pw = (uint64_t)floor((double)(4800.0f * v->res));  // Atlas::SetResolution, Atlas.h:62-65
+  a.ph = (uint64_t)floor((double)(3600.0f * v->res));
+  if (a.pw < 1 || a.ph < 1) { set_error("voxel resolution too small for an atlas patch"); return TF_ERR_INVALID; }
+  const size_t bytes = (size_t)a.aw * a.ah * 3;
+  hipError_t e = hipMalloc((void**)&a.buf, bytes);  // Atlas.cpp:34: 13824 x 13824 x RGB8 = 573 MB
+  if (e != hipSuccess) { set_error("atlas hipMalloc failed"); return TF_ERR_HIP; }
+  a.kf_cap = v->cfg.max_keyframes;
+  TF_HIP(hipMalloc((void**)&a.d_kf, sizeof(KfDev) * (size_t)a.kf_cap));
+  TF_HIP(hipMalloc((void**)&a.d_actl, sizeof(AtlasCtl)));
+  TF_HIP(hipMalloc((void**)&a.d_work_ids, sizeof(int4) * (size_t)d.max_chunks));
+  TF_HIP(hipMalloc((void**)&a.d_work_slot, sizeof(uint32_t) * (size_t)d.max_chunks));
+  TF_HIP(hipMalloc((void**)&a.d_cand, sizeof(unsigned long long) * (size_t)d.max_chunks));
+  KfDev blank;
+  memset(&blank, 0, sizeof(blank));
+  blank.kf_id = -1; blank.stride = 3;
+  a.h_kf.assign((size_t)a.kf_cap, blank);
+  a.kf_used.assign((size_t)a.kf_cap, 0);
+  TF_HIP(hipMemcpy(a.d_kf, a.h_kf.data(), sizeof(KfDev) * (size_t)a.kf_cap, hipMemcpyHostToDevice));
+  d.atlas = a.buf; d.atlas_w = a.aw; d.atlas_h = a.ah; d.patch_w = (int32_t)a.pw; d.patch_h = (int32_t)a.ph;
+  d.actl = a.d_actl; d.kf_tab = a.d_kf; d.work_ids = a.d_work_ids; d.work_slot = a.d_work_slot; d.cand = a.d_cand;
+  return atlas_reset(v);
+}
+
+void atlas_destroy(tf_volume* v) {
+  AtlasState& a = v->atlas;
+  for (auto& kv : a.keyframes) {
+    KeyframeSlot& ks = kv.second;
+    if (ks.owned) { hipFree(ks.rgb); hipFree(ks.depth); }
+  }
+  a.keyframes.clear();
+  if (a.buf) hipFree(a.buf);
+  if (a.d_kf) hipFree(a.d_kf);
+  if (a.d_actl) hipFree(a.d_actl);
+  if (a.d_work_ids) hipFree(a.d_work_ids);
+  if (a.d_work_slot) hipFree(a.d_work_slot);
+  if (a.d_cand) hipFree(a.d_cand);
+  if (a.d_stage) hipFree(a.d_stage);
+  if (a.h_stage) hipHostFree(a.h_stage);
+  a.buf = nullptr; a.d_stage = nullptr; a.h_stage = nullptr; a.d_kf = nullptr; a.d_actl = nullptr;
+  a.d_work_ids = nullptr; a.d_work_slot = nullptr; a.d_cand = nullptr;
+}
+
+int atlas_reset(tf_volume* v) {
+  AtlasState& a = v->atlas;
+  TF_HIP(hipMemsetAsync(a.buf, 0, (size_t)a.aw * a.ah * 3, v->stream));  // Atlas.cpp:35-36
+  AtlasCtl c;
+  memset(&c, 0, sizeof(c));
+  c.loc_min = ~0ull;
+  c.set[0].fail_key = c.set[1].fail_key = ~0ull;
+  TF_HIP(hipMemcpyAsync(a.d_actl, &c, sizeof(c), hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  a.fused_par = 0;
+  return TF_OK;
 }
 
 static int atlas_stage(tf_volume* v, size_t bytes) {
@@ -446,197 +815,34 @@ static int atlas_stage(tf_volume* v, size_t bytes) {
   return TF_OK;
 }
 
-// Atlas::AddPatch (Atlas.cpp:43-64)
-static int add_patch(AtlasState& a, const int32_t id[3], uint64_t* texloc) {
-  const uint64_t key = host_pack_id(id);
-  bool inserted = false;
-  uint64_t* slot = a.texloc.find_or_insert(key, &inserted);
-  if (!inserted && *slot != FlatMap64::kNone) { *texloc = *slot; return TF_OK; }  // Patch::clear keeps texloc
-  *texloc = a.loc_next;
-  uint64_t x = a.loc_next % (uint64_t)a.aw, y = a.loc_next / (uint64_t)a.aw;
-  if (x >= (uint64_t)a.aw || y >= (uint64_t)a.ah) {
-    *slot = FlatMap64::kNone;  // known id without a slot: a later call tries again (and overflows again)
-    set_error("No enough space for texture storage.");  // std::overflow_error text, Atlas.cpp:53
-    return TF_ERR_ATLAS_FULL;
-  }
-  if (x + a.pw >= (uint64_t)a.aw) { x = 0; y += a.ph; }
-  else x += a.pw;
-  a.loc_next = x + y * (uint64_t)a.aw;
-  *slot = *texloc;
-  return TF_OK;
-}
-
-}  // namespace tf
-
-using namespace tf;
-
-extern "C" {
-
-int tf_keyframe_cache(tf_volume* v, int32_t kf_id, const uint8_t* rgb, const float* depth) {
-  if (!v || !rgb || !depth) { set_error("null argument"); return TF_ERR_INVALID; }
-  TF_DEV(v);
+// keyframe table: host mirror -> device (tiny)
+int kf_push(tf_volume* v, int slot) {
   AtlasState& a = v->atlas;
-  const size_t npix = (size_t)v->cam.W * v->cam.H;
-  KeyframeSlot& ks = a.keyframes[kf_id];
-  if (!ks.owned) {
-    if ((int)a.keyframes.size() > v->cfg.max_keyframes) {
-      a.keyframes.erase(kf_id);
-      set_error("keyframe cache full (tf_config.max_keyframes)");
-      return TF_ERR_CAPACITY;
-    }
-    ks.rgb = nullptr; ks.depth = nullptr;
-    TF_HIP(hipMalloc((void**)&ks.rgb, npix * 3));
-    TF_HIP(hipMalloc((void**)&ks.depth, npix * 4));
-    ks.owned = true;
-  }
-  int rc = atlas_stage(v, npix * 7);
-  if (rc) return rc;
-  TF_HIP(hipStreamSynchronize(v->stream));
-  uint8_t* hs = reinterpret_cast<uint8_t*>(a.h_stage);
-  memcpy(hs, rgb, npix * 3);
-  memcpy(hs + npix * 3, depth, npix * 4);
-  TF_HIP(hipMemcpyAsync(ks.rgb, hs, npix * 3, hipMemcpyHostToDevice, v->stream));
-  TF_HIP(hipMemcpyAsync(ks.depth, hs + npix * 3, npix * 4, hipMemcpyHostToDevice, v->stream));
-  TF_HIP(hipStreamSynchronize(v->stream));
+  TF_HIP(hipMemcpyAsync(a.d_kf + slot, &a.h_kf[(size_t)slot], sizeof(KfDev), hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));  // the pageable host source must not change under the copy
   return TF_OK;
 }
-
-int tf_keyframe_cache_device(tf_volume* v, int32_t kf_id, const uint8_t* d_rgb, const float* d_depth) {
-  if (!v || !d_rgb || !d_depth) { set_error("null argument"); return TF_ERR_INVALID; }
-  TF_DEV(v);
+static int kf_slot_for(tf_volume* v, int32_t kf_id, bool create, int* out) {
   AtlasState& a = v->atlas;
   auto it = a.keyframes.find(kf_id);
-  if (it != a.keyframes.end() && it->second.owned) { hipFree(it->second.rgb); hipFree(it->second.depth); }
-  KeyframeSlot ks;
-  ks.rgb = const_cast<uint8_t*>(d_rgb);
-  ks.depth = const_cast<float*>(d_depth);
-  ks.owned = false;
-  a.keyframes[kf_id] = ks;
-  return TF_OK;
-}
-
-int tf_keyframe_release(tf_volume* v, int32_t kf_id) {
-  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
-  TF_DEV(v);
-  AtlasState& a = v->atlas;
-  auto it = a.keyframes.find(kf_id);
-  if (it == a.keyframes.end()) return TF_OK;
-  TF_HIP(hipStreamSynchronize(v->stream));
-  if (it->second.owned) { hipFree(it->second.rgb); hipFree(it->second.depth); }
-  a.keyframes.erase(it);
-  return TF_OK;
-}
-
-int tf_atlas_patch_size(tf_volume* v, int32_t* pw, int32_t* ph) {
-  if (!v || !pw || !ph) { set_error("null argument"); return TF_ERR_INVALID; }
-  TF_DEV(v);
-  *pw = (int32_t)v->atlas.pw;
-  *ph = (int32_t)v->atlas.ph;
-  return TF_OK;
-}
-
-int tf_atlas_add_patch(tf_volume* v, const int32_t id[3], uint64_t* texloc) {
-  if (!v || !id || !texloc) { set_error("null argument"); return TF_ERR_INVALID; }
-  TF_DEV(v);
-  return add_patch(v->atlas, id, texloc);
-}
-
-int tf_atlas_loc_next(tf_volume* v, uint64_t* loc_next) {
-  if (!v || !loc_next) { set_error("null argument"); return TF_ERR_INVALID; }
-  TF_DEV(v);
-  *loc_next = v->atlas.loc_next;
-  return TF_OK;
-}
-
-int tf_patches_update(tf_volume* v, int64_t np, const int32_t* ids, const int32_t* kf_ids,
-                      const float* pose_inv16, const int64_t* voff, const float* verts,
-                      const float* colors, float* out_texcoord, float* out_texcolor,
-                      int32_t* out_bbox, int32_t* out_flags, float* out_ratio, uint64_t* out_texloc,
-                      uint64_t out_hot[2]) {
-  if (!v || (np > 0 && (!ids || !kf_ids || !pose_inv16 || !voff || !verts || !colors))) {
-    set_error("null argument");
+  if (it != a.keyframes.end()) { *out = it->second.slot; return TF_OK; }
+  if (!create) {
+    set_error("keyframe " + std::to_string(kf_id) + " is not cached (tf_keyframe_cache)");
     return TF_ERR_INVALID;
   }
-  TF_DEV(v);
-  AtlasState& a = v->atlas;
-  if (np <= 0) {
-    if (out_hot) {  // Chisel.cpp:153-154,184-186 with an empty loop
-      const uint64_t ls = (uint64_t)a.aw * (uint64_t)a.ah;
-      out_hot[0] = (ls / a.aw) * a.aw;
-      out_hot[1] = (0 / a.aw + a.ph) * a.aw;
-    }
-    return TF_OK;
-  }
-  const int64_t nv = voff[np];
-  const size_t o_pin = 0;
-  const size_t o_verts = o_pin + sizeof(PatchIn) * (size_t)np;
-  const size_t o_cols = o_verts + (size_t)nv * 12;
-  const size_t o_tc = o_cols + (size_t)nv * 12;
-  const size_t o_tcol = o_tc + (size_t)nv * 8;
-  const size_t o_pout = (o_tcol + (size_t)nv * 12 + 15) & ~(size_t)15;
-  const size_t total = o_pout + sizeof(PatchOut) * (size_t)np;
-  int rc = atlas_stage(v, total);
-  if (rc) return rc;
-  TF_HIP(hipStreamSynchronize(v->stream));
-  uint8_t* hs = reinterpret_cast<uint8_t*>(a.h_stage);
-  uint8_t* ds = reinterpret_cast<uint8_t*>(a.d_stage);
-  PatchIn* hp = reinterpret_cast<PatchIn*>(hs + o_pin);
-  uint64_t loc_start = (uint64_t)a.aw * (uint64_t)a.ah, loc_end = 0;  // Chisel.cpp:153-154
-  int64_t n_ok = np;
-  int overflow = 0;
-  auto it = a.keyframes.end();
-  for (int64_t p = 0; p < np; ++p) {
-    uint64_t tl = 0;
-    rc = add_patch(a, ids + 3 * p, &tl);  // Chisel.cpp:167-173: overflow aborts GeneratePatches
-    if (rc) { n_ok = p; overflow = 1; break; }
-    if (p == 0 || kf_ids[p] != kf_ids[p - 1]) it = a.keyframes.find(kf_ids[p]);
-    if (it == a.keyframes.end()) {
-      set_error("keyframe " + std::to_string(kf_ids[p]) + " is not cached (tf_keyframe_cache)");
-      return TF_ERR_INVALID;
-    }
-    memcpy(hp[p].T, pose_inv16 + 16 * p, 64);
-    hp[p].rgb = it->second.rgb;
-    hp[p].depth = it->second.depth;
-    hp[p].v0 = voff[p];
-    hp[p].v1 = voff[p + 1];
-    hp[p].texloc = tl;
-    if (out_texloc) out_texloc[p] = tl;
-    if (tl < loc_start) loc_start = tl;
-    if (tl > loc_end) loc_end = tl;
-  }
-  if (overflow) return TF_ERR_ATLAS_FULL;  // tsdfFusion stops (MobileFusion.cpp:376-379)
-  memcpy(hs + o_verts, verts, (size_t)nv * 12);
-  memcpy(hs + o_cols, colors, (size_t)nv * 12);
-  TF_HIP(hipMemcpyAsync(ds, hs, o_tc, hipMemcpyHostToDevice, v->stream));
-  prof_begin(v, TF_PROF_PATCH_PROJECT);
-  hipLaunchKernelGGL(k_patch_project, dim3((unsigned)n_ok), dim3(256), 0, v->stream,
-                     reinterpret_cast<const PatchIn*>(ds + o_pin),
-                     reinterpret_cast<const float*>(ds + o_verts),
-                     reinterpret_cast<const float*>(ds + o_cols), v->cam,
-                     reinterpret_cast<float*>(ds + o_tc), reinterpret_cast<float*>(ds + o_tcol),
-                     reinterpret_cast<PatchOut*>(ds + o_pout));
-  prof_end(v);
-  prof_begin(v, TF_PROF_ATLAS_BLIT);
-  hipLaunchKernelGGL(k_atlas_blit, dim3((unsigned)n_ok), dim3(256), kMaxRoiBytes, v->stream,
-                     reinterpret_cast<const PatchIn*>(ds + o_pin),
-                     reinterpret_cast<PatchOut*>(ds + o_pout), a.buf, a.aw, a.ah, (int)a.pw,
-                     (int)a.ph, v->cam.W);
-  prof_end(v);
-  TF_HIP(hipGetLastError());
-  TF_HIP(hipMemcpyAsync(hs + o_tc, ds + o_tc, total - o_tc, hipMemcpyDeviceToHost, v->stream));
-  TF_HIP(hipStreamSynchronize(v->stream));
-  if (out_texcoord) memcpy(out_texcoord, hs + o_tc, (size_t)nv * 8);
-  if (out_texcolor) memcpy(out_texcolor, hs + o_tcol, (size_t)nv * 12);
-  const PatchOut* po = reinterpret_cast<const PatchOut*>(hs + o_pout);
-  for (int64_t p = 0; p < np; ++p) {
-    if (out_bbox) memcpy(out_bbox + 4 * p, po[p].bbox, 16);
-    if (out_flags) out_flags[p] = po[p].flags;
-    if (out_ratio) { out_ratio[2 * p] = po[p].ratio[0]; out_ratio[2 * p + 1] = po[p].ratio[1]; }
-  }
-  if (out_hot) {  // Chisel.cpp:184-186
-    out_hot[0] = (loc_start / (uint64_t)a.aw) * (uint64_t)a.aw;
-    out_hot[1] = (loc_end / (uint64_t)a.aw + a.ph) * (uint64_t)a.aw;
-  }
+  int slot = -1;
+  for (int s = 0; s < v->cfg.max_keyframes; ++s)
+    if (!a.kf_used[(size_t)s]) { slot = s; break; }
+  if (slot < 0) { set_error("keyframe cache full (tf_config.max_keyframes)"); return TF_ERR_CAPACITY; }
+  KeyframeSlot ks;
+  ks.slot = slot;
+  a.keyframes[kf_id] = ks;
+  a.kf_used[(size_t)slot] = 1;
+  KfDev& k = a.h_kf[(size_t)slot];
+  memset(&k, 0, sizeof(k));
+  k.kf_id = kf_id; k.stride = 3;
+  for (int i = 0; i < 4; ++i) k.T[5 * i] = 1.0f;
+  *out = slot;
   return TF_OK;
 }
 
@@ -702,143 +908,307 @@ static void color_transfer(const float cov_src[9], const float cov_tar[9], float
   for (int i = 0; i < 9; i++) T[i] = (float)A2[i];
 }
 
-// tf_patches_update with the mesh data already resident and the results left in HBM: nothing but the
-// per-patch descriptors (112 B each) crosses PCIe and nothing synchronises, so a keyframe's atlas
-// update rides in the frame stream.  Slot allocation stays on the host (immediate, in patch order).
-int tf_patches_update_device(tf_volume* v, int64_t np, const int32_t* ids, const int32_t* kf_ids,
-                             const float* pose_inv16, const int64_t* voff, const float* d_verts,
-                             const float* d_colors, float* d_texcoord, float* d_texcolor,
-                             tf_patch_out* d_patch_out, uint64_t* out_texloc, uint64_t out_hot[2]) {
-  if (!v || (np > 0 && (!ids || !kf_ids || !pose_inv16 || !voff || !d_verts || !d_colors || !d_texcoord ||
-                        !d_texcolor || !d_patch_out))) {
-    set_error("null argument");
-    return TF_ERR_INVALID;
-  }
-  TF_DEV(v);
-  static_assert(sizeof(tf_patch_out) == sizeof(PatchOut), "public and device patch records differ");
+static bool row_less(const PatchRow& a, const PatchRow& b) {
+  for (int k = 0; k < 3; ++k)
+    if (a.id[k] != b.id[k]) return a.id[k] < b.id[k];
+  return false;
+}
+
+// every mesh with a patch, ascending chunk id (host copy)
+static int list_patches(tf_volume* v, std::vector<PatchRow>* rows) {
+  const size_t cap = (size_t)v->dev.max_chunks;
+  int rc = atlas_stage(v, cap * sizeof(PatchRow));
+  if (rc) return rc;
   AtlasState& a = v->atlas;
-  if (np <= 0) {
-    if (out_hot) {
-      const uint64_t ls = (uint64_t)a.aw * (uint64_t)a.ah;
-      out_hot[0] = (ls / a.aw) * a.aw;
-      out_hot[1] = (0 / a.aw + a.ph) * a.aw;
-    }
-    return TF_OK;
-  }
-  // descriptor ring: pinned host copies must outlive their asynchronous upload
-  constexpr int kRing = 4;
-  const size_t bytes = sizeof(PatchIn) * (size_t)np;
-  const int slot = a.pin_next;
-  a.pin_next = (a.pin_next + 1) % kRing;
-  if (a.pin_ev[slot]) TF_HIP(hipEventSynchronize(a.pin_ev[slot]));
-  else TF_HIP(hipEventCreateWithFlags(&a.pin_ev[slot], hipEventDisableTiming));
-  if (bytes > a.pin_bytes[slot]) {
-    if (a.pin_host[slot]) hipHostFree(a.pin_host[slot]);
-    if (a.pin_dev[slot]) { TF_HIP(hipStreamSynchronize(v->stream)); hipFree(a.pin_dev[slot]); }
-    size_t want = 4096;
-    while (want < bytes) want <<= 1;
-    TF_HIP(hipHostMalloc(&a.pin_host[slot], want, hipHostMallocDefault));
-    TF_HIP(hipMalloc(&a.pin_dev[slot], want));
-    a.pin_bytes[slot] = want;
-  }
-  PatchIn* hp = reinterpret_cast<PatchIn*>(a.pin_host[slot]);
-  uint64_t loc_start = (uint64_t)a.aw * (uint64_t)a.ah, loc_end = 0;  // Chisel.cpp:153-154
-  auto it = a.keyframes.end();
-  for (int64_t p = 0; p < np; ++p) {
-    uint64_t tl = 0;
-    int rc = add_patch(a, ids + 3 * p, &tl);  // Chisel.cpp:167-173: overflow aborts GeneratePatches
-    if (rc) return TF_ERR_ATLAS_FULL;
-    if (p == 0 || kf_ids[p] != kf_ids[p - 1]) it = a.keyframes.find(kf_ids[p]);
-    if (it == a.keyframes.end()) {
-      set_error("keyframe " + std::to_string(kf_ids[p]) + " is not cached (tf_keyframe_cache)");
-      return TF_ERR_INVALID;
-    }
-    memcpy(hp[p].T, pose_inv16 + 16 * p, 64);
-    hp[p].rgb = it->second.rgb;
-    hp[p].depth = it->second.depth;
-    hp[p].v0 = voff[p];
-    hp[p].v1 = voff[p + 1];
-    hp[p].texloc = tl;
-    if (out_texloc) out_texloc[p] = tl;
-    if (tl < loc_start) loc_start = tl;
-    if (tl > loc_end) loc_end = tl;
-  }
-  const PatchIn* dp = reinterpret_cast<const PatchIn*>(a.pin_dev[slot]);
-  TF_HIP(hipMemcpyAsync(a.pin_dev[slot], hp, bytes, hipMemcpyHostToDevice, v->stream));
-  TF_HIP(hipEventRecord(a.pin_ev[slot], v->stream));
-  prof_begin(v, TF_PROF_PATCH_PROJECT);
-  hipLaunchKernelGGL(k_patch_project, dim3((unsigned)np), dim3(256), 0, v->stream, dp, d_verts, d_colors, v->cam,
-                     d_texcoord, d_texcolor, reinterpret_cast<PatchOut*>(d_patch_out));
-  prof_end(v);
-  prof_begin(v, TF_PROF_ATLAS_BLIT);
-  hipLaunchKernelGGL(k_atlas_blit, dim3((unsigned)np), dim3(256), kMaxRoiBytes, v->stream, dp,
-                     reinterpret_cast<PatchOut*>(d_patch_out), a.buf, a.aw, a.ah, (int)a.pw, (int)a.ph, v->cam.W);
-  prof_end(v);
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
+  hipLaunchKernelGGL(k_list_patches, dim3(1024), dim3(256), 0, v->stream, v->dev,
+                     reinterpret_cast<PatchRow*>(a.d_stage), (uint32_t)cap);
   TF_HIP(hipGetLastError());
-  if (out_hot) {  // Chisel.cpp:184-186
-    out_hot[0] = (loc_start / (uint64_t)a.aw) * (uint64_t)a.aw;
-    out_hot[1] = (loc_end / (uint64_t)a.aw + a.ph) * (uint64_t)a.aw;
+  uint32_t n = 0;
+  TF_HIP(hipMemcpyAsync(&n, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  rows->resize(n);
+  if (n) {
+    TF_HIP(hipMemcpyAsync(a.h_stage, a.d_stage, (size_t)n * sizeof(PatchRow), hipMemcpyDeviceToHost, v->stream));
+    TF_HIP(hipStreamSynchronize(v->stream));
+    memcpy(rows->data(), a.h_stage, (size_t)n * sizeof(PatchRow));
+    std::sort(rows->begin(), rows->end(), row_less);
   }
   return TF_OK;
 }
 
-int tf_color_compensate(tf_volume* v, int64_t np, const int32_t* frame_ids, const uint8_t* wrong_mapping,
-                        uint8_t* has_adjusted, const int64_t* voff, const float* texcolor,
-                        const float* meshcolor, float* out_labs, int64_t* out_n_clusters) {
-  if (out_n_clusters) *out_n_clusters = 0;
-  if (!v || (np > 0 && (!frame_ids || !wrong_mapping || !has_adjusted || !voff || !texcolor || !meshcolor || !out_labs))) {
+// ids (host) -> device work list (w = keyframe-table entry per entry, or 0); the entry count goes to
+// counter set 0
+static int upload_work(tf_volume* v, const int32_t* ids, const int* kfslot, int64_t n) {
+  AtlasState& a = v->atlas;
+  if (n > (int64_t)v->dev.max_chunks) { set_error("chunk list longer than tf_config.max_chunks"); return TF_ERR_CAPACITY; }
+  int rc = atlas_stage(v, (size_t)n * 16 + 16);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  int32_t* h = reinterpret_cast<int32_t*>(a.h_stage);
+  for (int64_t i = 0; i < n; ++i) {
+    h[4 * i] = ids[3 * i]; h[4 * i + 1] = ids[3 * i + 1]; h[4 * i + 2] = ids[3 * i + 2];
+    h[4 * i + 3] = kfslot ? kfslot[i] : 0;
+  }
+  h[4 * n] = (int32_t)n;
+  TF_HIP(hipMemcpyAsync(a.d_work_ids, h, (size_t)n * 16, hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipMemcpyAsync(&a.d_actl->set[0].n_work, h + 4 * n, 4, hipMemcpyHostToDevice, v->stream));
+  return TF_OK;
+}
+
+// fused per-frame flow: AddPatch in ascending id order, CalculateTexCoords + UpdateBuffer for the frame's dirty set
+void launch_patch_fused(tf_volume* v, int par, const KfDev& kf, hipStream_t s) {
+  prof_begin(v, TF_PROF_PATCH_RANK, s);
+  hipLaunchKernelGGL(k_patch_collect, dim3(256), dim3(256), 0, s, v->dev, par);
+  hipLaunchKernelGGL(k_patch_rank, dim3(256), dim3(256), 0, s, v->dev, par);
+  prof_end(v, s);
+  prof_begin(v, TF_PROF_PATCH_PROJECT, s);
+  hipLaunchKernelGGL((k_patch<true, true, true>), dim3(1024), dim3(256), 0, s, v->dev, v->cam, par, kf);
+  prof_end(v, s);
+}
+
+}  // namespace tf
+
+using namespace tf;
+
+extern "C" {
+
+int tf_keyframe_cache(tf_volume* v, int32_t kf_id, const uint8_t* rgb, const float* depth) {
+  if (!v || !rgb || !depth) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  AtlasState& a = v->atlas;
+  const size_t npix = (size_t)v->cam.W * v->cam.H;
+  int slot = -1;
+  int rc = kf_slot_for(v, kf_id, true, &slot);
+  if (rc) return rc;
+  KeyframeSlot& ks = a.keyframes[kf_id];
+  if (!ks.owned) {
+    ks.rgb = nullptr; ks.depth = nullptr;
+    TF_HIP(hipMalloc((void**)&ks.rgb, npix * 3));
+    TF_HIP(hipMalloc((void**)&ks.depth, npix * 4));
+    ks.owned = true;
+  }
+  rc = atlas_stage(v, npix * 7);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  uint8_t* hs = reinterpret_cast<uint8_t*>(a.h_stage);
+  memcpy(hs, rgb, npix * 3);
+  memcpy(hs + npix * 3, depth, npix * 4);
+  TF_HIP(hipMemcpyAsync(ks.rgb, hs, npix * 3, hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipMemcpyAsync(ks.depth, hs + npix * 3, npix * 4, hipMemcpyHostToDevice, v->stream));
+  a.h_kf[(size_t)slot].rgb = ks.rgb;
+  a.h_kf[(size_t)slot].depth = ks.depth;
+  a.h_kf[(size_t)slot].stride = 3;
+  return kf_push(v, slot);
+}
+
+int tf_keyframe_cache_device(tf_volume* v, int32_t kf_id, const uint8_t* d_rgb, int32_t rgb_pixel_stride,
+                             const float* d_depth) {
+  if (!v || !d_rgb || !d_depth) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (rgb_pixel_stride != 3 && rgb_pixel_stride != 4) { set_error("rgb_pixel_stride must be 3 or 4"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  AtlasState& a = v->atlas;
+  int slot = -1;
+  int rc = kf_slot_for(v, kf_id, true, &slot);
+  if (rc) return rc;
+  KeyframeSlot& ks = a.keyframes[kf_id];
+  if (ks.owned) { TF_HIP(hipStreamSynchronize(v->stream)); hipFree(ks.rgb); hipFree(ks.depth); ks.owned = false; }
+  ks.rgb = const_cast<uint8_t*>(d_rgb);
+  ks.depth = const_cast<float*>(d_depth);
+  a.h_kf[(size_t)slot].rgb = d_rgb;
+  a.h_kf[(size_t)slot].depth = d_depth;
+  a.h_kf[(size_t)slot].stride = rgb_pixel_stride;
+  return kf_push(v, slot);
+}
+
+int tf_keyframe_set_pose(tf_volume* v, int32_t kf_id, const float pose_inv16[16]) {
+  if (!v || !pose_inv16) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  int slot = -1;
+  int rc = kf_slot_for(v, kf_id, false, &slot);
+  if (rc) return rc;
+  memcpy(v->atlas.h_kf[(size_t)slot].T, pose_inv16, 64);
+  return kf_push(v, slot);
+}
+
+int tf_keyframe_release(tf_volume* v, int32_t kf_id) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  AtlasState& a = v->atlas;
+  auto it = a.keyframes.find(kf_id);
+  if (it == a.keyframes.end()) return TF_OK;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  if (it->second.owned) { hipFree(it->second.rgb); hipFree(it->second.depth); }
+  const int slot = it->second.slot;
+  a.keyframes.erase(it);
+  a.kf_used[(size_t)slot] = 0;
+  KfDev& k = a.h_kf[(size_t)slot];
+  memset(&k, 0, sizeof(k));
+  k.kf_id = -1; k.stride = 3;  // patches that still view this keyframe are no longer complete()
+  return kf_push(v, slot);
+}
+
+int tf_atlas_patch_size(tf_volume* v, int32_t* pw, int32_t* ph) {
+  if (!v || !pw || !ph) { set_error("null argument"); return TF_ERR_INVALID; }
+  *pw = (int32_t)v->atlas.pw;
+  *ph = (int32_t)v->atlas.ph;
+  return TF_OK;
+}
+
+int tf_atlas_loc_next(tf_volume* v, uint64_t* loc_next) {
+  if (!v || !loc_next) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  AtlasState& a = v->atlas;
+  AtlasCtl c;
+  TF_HIP(hipMemcpyAsync(&c, a.d_actl, sizeof(c), hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  unsigned long long tl = 0;
+  slot_texloc(a.aw, a.ah, (int)a.pw, (int)a.ph, c.n_slots, &tl);
+  *loc_next = tl;
+  return TF_OK;
+}
+
+int tf_meshes_upload(tf_volume* v, const int32_t* ids, int64_t n, const int64_t* vert_offsets,
+                     const int64_t* index_offsets, const float* verts, const float* normals, const float* colors,
+                     const uint32_t* indices) {
+  if (!v || (n > 0 && (!ids || !vert_offsets || !index_offsets || !verts || !normals || !colors))) {
     set_error("null argument");
     return TF_ERR_INVALID;
   }
   TF_DEV(v);
-  if (np <= 0) return TF_OK;
+  if (n <= 0) return TF_OK;
+  const int64_t nv = vert_offsets[n], ni = index_offsets[n];
+  if (ni > 0 && !indices) { set_error("null index argument"); return TF_ERR_INVALID; }
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+  const size_t o_ids = take((size_t)n * 16), o_vo = take((size_t)(n + 1) * 8), o_io = take((size_t)(n + 1) * 8);
+  const size_t o_v = take((size_t)nv * 12), o_n = take((size_t)nv * 12), o_c = take((size_t)nv * 12), o_i = take((size_t)ni * 4);
+  int rc = atlas_stage(v, o);
+  if (rc) return rc;
+  AtlasState& a = v->atlas;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  uint8_t* hs = reinterpret_cast<uint8_t*>(a.h_stage);
+  uint8_t* ds = reinterpret_cast<uint8_t*>(a.d_stage);
+  int32_t* hid = reinterpret_cast<int32_t*>(hs + o_ids);
+  for (int64_t i = 0; i < n; ++i) {
+    hid[4 * i] = ids[3 * i]; hid[4 * i + 1] = ids[3 * i + 1]; hid[4 * i + 2] = ids[3 * i + 2]; hid[4 * i + 3] = 0;
+  }
+  memcpy(hs + o_vo, vert_offsets, (size_t)(n + 1) * 8);
+  memcpy(hs + o_io, index_offsets, (size_t)(n + 1) * 8);
+  memcpy(hs + o_v, verts, (size_t)nv * 12);
+  memcpy(hs + o_n, normals, (size_t)nv * 12);
+  memcpy(hs + o_c, colors, (size_t)nv * 12);
+  if (ni) memcpy(hs + o_i, indices, (size_t)ni * 4);
+  TF_HIP(hipMemcpyAsync(ds, hs, o, hipMemcpyHostToDevice, v->stream));
+  hipLaunchKernelGGL(k_mesh_scatter, dim3((unsigned)n), dim3(256), 0, v->stream, v->dev,
+                     reinterpret_cast<const int4*>(ds + o_ids), (uint32_t)n, reinterpret_cast<const long long*>(ds + o_vo),
+                     reinterpret_cast<const long long*>(ds + o_io), reinterpret_cast<const float*>(ds + o_v),
+                     reinterpret_cast<const float*>(ds + o_n), reinterpret_cast<const float*>(ds + o_c),
+                     reinterpret_cast<const uint32_t*>(ds + o_i), ++v->mesh_epoch);
+  TF_HIP(hipGetLastError());
+  v->host_list_n = -1;
+  return tf_sync(v);
+}
+
+int tf_generate_patches(tf_volume* v, const int32_t* ids, int64_t n, const int32_t* labels, uint64_t out_hot[2]) {
+  if (!v || (n > 0 && (!ids || !labels))) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  AtlasState& a = v->atlas;
+  if (out_hot) {  // Chisel.cpp:153-154,184-186 with an empty loop
+    const uint64_t ls = (uint64_t)a.aw * (uint64_t)a.ah;
+    out_hot[0] = (ls / a.aw) * a.aw;
+    out_hot[1] = (0 / a.aw + a.ph) * a.aw;
+  }
+  if (n <= 0) return TF_OK;
+  std::vector<int> kfs((size_t)n);
+  int last_id = 0, last_slot = -1;
+  for (int64_t i = 0; i < n; ++i) {
+    if (last_slot < 0 || labels[i] != last_id) {
+      int rc = kf_slot_for(v, labels[i], false, &last_slot);
+      if (rc) return rc;
+      last_id = labels[i];
+    }
+    kfs[(size_t)i] = last_slot;
+  }
+  int rc = upload_work(v, ids, kfs.data(), n);
+  if (rc) return rc;
+  TF_HIP(hipMemsetAsync(&v->dev.actl->n_done, 0, 4, v->stream));
+  hipLaunchKernelGGL(k_patch_assign, dim3(1), dim3(1024), 0, v->stream, v->dev, (uint32_t)n);
+  prof_begin(v, TF_PROF_PATCH_PROJECT);
+  hipLaunchKernelGGL((k_patch<true, false, false>), dim3(1024), dim3(256), 0, v->stream, v->dev, v->cam, 0, KfDev{});
+  prof_end(v);
+  TF_HIP(hipGetLastError());
+  AtlasCtl c;
+  TF_HIP(hipMemcpyAsync(&c, a.d_actl, sizeof(c), hipMemcpyDeviceToHost, v->stream));
+  rc = tf_sync(v);
+  if (out_hot && c.n_done > 0) {  // Chisel.cpp:184-186
+    out_hot[0] = (c.loc_min / (uint64_t)a.aw) * (uint64_t)a.aw;
+    out_hot[1] = (c.loc_max / (uint64_t)a.aw + a.ph) * (uint64_t)a.aw;
+  }
+  return rc;  // TF_ERR_ATLAS_FULL = GeneratePatches' -1 (Chisel.cpp:170-173)
+}
+
+int tf_update_atlas(tf_volume* v, const int32_t* ids, int64_t n) {
+  if (!v || (n > 0 && !ids)) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (n <= 0) return TF_OK;
+  int rc = upload_work(v, ids, nullptr, n);
+  if (rc) return rc;
+  const uint32_t n32 = (uint32_t)n;
+  hipLaunchKernelGGL(k_work_lookup, dim3((n32 + 255) / 256), dim3(256), 0, v->stream, v->dev, n32);
+  prof_begin(v, TF_PROF_ATLAS_BLIT);
+  hipLaunchKernelGGL((k_patch<false, true, false>), dim3(1024), dim3(256), 0, v->stream, v->dev, v->cam, 0, KfDev{});
+  prof_end(v);
+  TF_HIP(hipGetLastError());
+  return tf_sync(v);
+}
+
+int tf_compensate_color(tf_volume* v, int64_t* out_n_clusters) {
+  if (out_n_clusters) *out_n_clusters = 0;
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  std::vector<PatchRow> rows;
+  int rc = list_patches(v, &rows);
+  if (rc) return rc;
+  const int64_t np = (int64_t)rows.size();
+  if (!np) return TF_OK;
   // clusters by source frame in order of first appearance (Chisel.cpp:199-214)
   std::vector<int32_t> cl((size_t)np, -1), first;
   for (int64_t p = 0; p < np; ++p) {
-    if (has_adjusted[p]) continue;
+    if (rows[(size_t)p].pflags & kPfAdjusted) continue;
     size_t k = 0;
     for (; k < first.size(); ++k)
-      if (frame_ids[first[k]] == frame_ids[p]) break;
+      if (rows[(size_t)first[k]].frameid == rows[(size_t)p].frameid) break;
     if (k == first.size()) first.push_back((int32_t)p);
     cl[(size_t)p] = (int32_t)k;
   }
   const size_t ncl = first.size();
   if (out_n_clusters) *out_n_clusters = (int64_t)ncl;
   if (!ncl) return TF_OK;
-  const int64_t nv = voff[np];
   AtlasState& a = v->atlas;
   const size_t o_pt = 0;
-  const size_t o_src = (o_pt + sizeof(CcPatch) * (size_t)np + 15) & ~(size_t)15;
-  const size_t o_tar = o_src + (size_t)nv * 12;
-  const size_t o_labs = o_tar + (size_t)nv * 12;
-  const size_t o_red = (o_labs + (size_t)nv * 12 + 15) & ~(size_t)15;  // [ncl][12] sums / moments
-  const size_t o_mean = o_red + ncl * 48;                                // [ncl][6]
-  const size_t o_xf = o_mean + ncl * 24;                                 // [ncl][16]
+  const size_t o_red = (o_pt + sizeof(CcPatch) * (size_t)np + 15) & ~(size_t)15;  // [ncl][12] sums / moments
+  const size_t o_mean = o_red + ncl * 48;                                             // [ncl][6]
+  const size_t o_xf = o_mean + ncl * 24;                                              // [ncl][16]
   const size_t total = o_xf + ncl * 64;
-  int rc = atlas_stage(v, total);
+  rc = atlas_stage(v, total);
   if (rc) return rc;
   TF_HIP(hipStreamSynchronize(v->stream));
   uint8_t* hs = reinterpret_cast<uint8_t*>(a.h_stage);
   uint8_t* ds = reinterpret_cast<uint8_t*>(a.d_stage);
   CcPatch* hp = reinterpret_cast<CcPatch*>(hs + o_pt);
   for (int64_t p = 0; p < np; ++p) {
-    hp[p].v0 = voff[p]; hp[p].v1 = voff[p + 1];
-    hp[p].cluster = cl[(size_t)p]; hp[p].wrong = wrong_mapping[p] ? 1 : 0;
+    hp[p].slot = rows[(size_t)p].slot; hp[p].nv = rows[(size_t)p].nv;
+    hp[p].cluster = cl[(size_t)p]; hp[p].wrong = (rows[(size_t)p].pflags & kPfWrong) ? 1 : 0;
   }
-  memcpy(hs + o_src, texcolor, (size_t)nv * 12);
-  memcpy(hs + o_tar, meshcolor, (size_t)nv * 12);
-  memcpy(hs + o_labs, out_labs, (size_t)nv * 12);  // entries of untouched patches keep the caller's values
   TF_HIP(hipMemcpyAsync(ds, hs, o_red, hipMemcpyHostToDevice, v->stream));
   const CcPatch* dp = reinterpret_cast<const CcPatch*>(ds + o_pt);
-  const float* dsrc = reinterpret_cast<const float*>(ds + o_src);
-  const float* dtar = reinterpret_cast<const float*>(ds + o_tar);
   float* dred = reinterpret_cast<float*>(ds + o_red);
   float* hred = reinterpret_cast<float*>(hs + o_red);
   float* hmean = reinterpret_cast<float*>(hs + o_mean);
   float* hxf = reinterpret_cast<float*>(hs + o_xf);
   // computeMeanAndCov (Patch.cpp:342-348): mean, then centred second moments / (N - 1)
-  hipLaunchKernelGGL(k_cc_reduce<0>, dim3((unsigned)ncl), dim3(256), 0, v->stream, dp, np, dsrc, dtar,
-                     (const float*)nullptr, dred);
+  hipLaunchKernelGGL(k_cc_reduce<0>, dim3((unsigned)ncl), dim3(256), 0, v->stream, v->dev, dp, np, (const float*)nullptr, dred);
   TF_HIP(hipMemcpyAsync(hred, dred, ncl * 48, hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   std::vector<float> cnt(ncl);
@@ -847,7 +1217,7 @@ int tf_color_compensate(tf_volume* v, int64_t np, const int32_t* frame_ids, cons
     for (int i = 0; i < 6; ++i) hmean[c * 6 + i] = cnt[c] > 0.0f ? hred[c * 12 + i] / cnt[c] : 0.0f;
   }
   TF_HIP(hipMemcpyAsync(ds + o_mean, hmean, ncl * 24, hipMemcpyHostToDevice, v->stream));
-  hipLaunchKernelGGL(k_cc_reduce<1>, dim3((unsigned)ncl), dim3(256), 0, v->stream, dp, np, dsrc, dtar,
+  hipLaunchKernelGGL(k_cc_reduce<1>, dim3((unsigned)ncl), dim3(256), 0, v->stream, v->dev, dp, np,
                      reinterpret_cast<const float*>(ds + o_mean), dred);
   TF_HIP(hipMemcpyAsync(hred, dred, ncl * 48, hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
@@ -864,84 +1234,131 @@ int tf_color_compensate(tf_volume* v, int64_t np, const int32_t* frame_ids, cons
     X[15] = 1.0f;
   }
   TF_HIP(hipMemcpyAsync(ds + o_xf, hxf, ncl * 64, hipMemcpyHostToDevice, v->stream));
-  hipLaunchKernelGGL(k_cc_apply, dim3((unsigned)np), dim3(256), 0, v->stream, dp, dsrc,
-                     reinterpret_cast<const float*>(ds + o_xf), reinterpret_cast<float*>(ds + o_labs));
+  hipLaunchKernelGGL(k_cc_apply, dim3((unsigned)np), dim3(256), 0, v->stream, v->dev, dp,
+                     reinterpret_cast<const float*>(ds + o_xf));
   TF_HIP(hipGetLastError());
-  TF_HIP(hipMemcpyAsync(hs + o_labs, ds + o_labs, (size_t)nv * 12, hipMemcpyDeviceToHost, v->stream));
-  TF_HIP(hipStreamSynchronize(v->stream));
-  memcpy(out_labs, hs + o_labs, (size_t)nv * 12);
-  for (int64_t p = 0; p < np; ++p)
-    if (cl[(size_t)p] >= 0 && cnt[(size_t)cl[(size_t)p]] > 0.0f) has_adjusted[p] = 1;  // :280
-  return TF_OK;
+  return tf_sync(v);
 }
 
-int tf_pack_vertices(tf_volume* v, int64_t np, const uint8_t* complete, const uint8_t* wrong_mapping,
-                     const uint8_t* labs_valid, const uint64_t* texloc, const float* ratio,
-                     const int64_t* voff, const float* verts, const float* colors, const float* normals,
-                     const float* texcoord, const float* texcolor, const float* labs, const int64_t* ioff,
-                     const uint32_t* indices, float* out_vertices, uint32_t* out_indices,
-                     int64_t* out_n_vertices, int64_t* out_n_indices) {
-  if (out_n_vertices) *out_n_vertices = 0;
-  if (out_n_indices) *out_n_indices = 0;
-  if (!v || (np > 0 && (!complete || !wrong_mapping || !labs_valid || !texloc || !ratio || !voff || !verts ||
-                        !colors || !normals || !texcoord || !texcolor || !labs || !ioff || !out_vertices))) {
-    set_error("null argument");
-    return TF_ERR_INVALID;
+// Patch::complete (Patch.cpp:191-196) from a listed row
+static bool row_complete(const PatchRow& r) {
+  return r.nv > 0 && (r.state & kMsSimplified) && (r.pflags & kPfHasImage) && r.frameid >= 0;
+}
+
+static int draw_common(tf_volume* v, float* d_vertices, uint32_t* d_indices, float* h_vertices, uint32_t* h_indices,
+                       int64_t cap_v, int64_t cap_i, int64_t* out_nv, int64_t* out_ni) {
+  if (out_nv) *out_nv = 0;
+  if (out_ni) *out_ni = 0;
+  std::vector<PatchRow> rows;
+  int rc = list_patches(v, &rows);
+  if (rc) return rc;
+  std::vector<DrawPatch> dp;
+  dp.reserve(rows.size());
+  unsigned long long vout = 0, iout = 0;
+  for (const PatchRow& r : rows) {
+    if (!row_complete(r)) continue;
+    DrawPatch P;
+    P.slot = r.slot; P.nv = r.nv; P.nt = r.nt;
+    const bool labs_valid = (r.pflags & kPfAdjusted) && !(r.pflags & kPfWrong);  // has_adjusted && !labs.empty()
+    P.flags = 1u | ((r.pflags & kPfWrong) ? 2u : 0u) | (labs_valid ? 4u : 0u);
+    P.vout = vout; P.iout = iout;
+    vout += r.nv; iout += 3ull * r.nt;
+    dp.push_back(P);
   }
-  TF_DEV(v);
-  if (np <= 0) return TF_OK;
+  if (out_nv) *out_nv = (int64_t)vout;
+  if (out_ni) *out_ni = (int64_t)iout;
+  if ((int64_t)vout > cap_v || (int64_t)iout > cap_i) { set_error("vertex / index buffer too small"); return TF_ERR_CAPACITY; }
+  if (dp.empty()) return TF_OK;
   AtlasState& a = v->atlas;
-  const int64_t nv = voff[np], ni = ioff[np];
-  if (ni > 0 && (!indices || !out_indices)) { set_error("null index argument"); return TF_ERR_INVALID; }
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
-  const size_t o_pt = take(sizeof(PvPatch) * (size_t)np);
-  const size_t o_verts = take((size_t)nv * 12), o_cols = take((size_t)nv * 12), o_nrm = take((size_t)nv * 12);
-  const size_t o_tc = take((size_t)nv * 8), o_tcol = take((size_t)nv * 12), o_labs = take((size_t)nv * 12);
-  const size_t o_idx = take((size_t)ni * 4);
-  const size_t o_in_end = o;
-  const size_t o_outv = take((size_t)nv * 48), o_outi = take((size_t)ni * 4);
-  const size_t total = o;
-  int rc = atlas_stage(v, total);
+  const size_t o_pt = take(sizeof(DrawPatch) * dp.size());
+  const size_t o_v = d_vertices ? 0 : take((size_t)vout * 48), o_i = d_indices ? 0 : take((size_t)iout * 4);
+  rc = atlas_stage(v, o);
   if (rc) return rc;
   TF_HIP(hipStreamSynchronize(v->stream));
   uint8_t* hs = reinterpret_cast<uint8_t*>(a.h_stage);
   uint8_t* ds = reinterpret_cast<uint8_t*>(a.d_stage);
-  PvPatch* hp = reinterpret_cast<PvPatch*>(hs + o_pt);
-  int64_t vout = 0, iout = 0;
-  for (int64_t p = 0; p < np; ++p) {
-    PvPatch& P = hp[p];
-    P.v0 = voff[p]; P.v1 = voff[p + 1]; P.i0 = ioff[p]; P.i1 = ioff[p + 1];
-    P.vout = vout; P.iout = iout;
-    P.ox = (float)(texloc[p] % (uint64_t)a.aw);  // Atlas::GetTexLoc (Atlas.cpp:66-69)
-    P.oy = (float)(texloc[p] / (uint64_t)a.aw);
-    P.rx = ratio[2 * p]; P.ry = ratio[2 * p + 1];
-    P.flags = (complete[p] ? 1 : 0) | (wrong_mapping[p] ? 2 : 0) | (labs_valid[p] ? 4 : 0);
-    P.pad = 0;
-    if (complete[p]) { vout += P.v1 - P.v0; iout += P.i1 - P.i0; }
-  }
-  memcpy(hs + o_verts, verts, (size_t)nv * 12);
-  memcpy(hs + o_cols, colors, (size_t)nv * 12);
-  memcpy(hs + o_nrm, normals, (size_t)nv * 12);
-  memcpy(hs + o_tc, texcoord, (size_t)nv * 8);
-  memcpy(hs + o_tcol, texcolor, (size_t)nv * 12);
-  memcpy(hs + o_labs, labs, (size_t)nv * 12);
-  if (ni) memcpy(hs + o_idx, indices, (size_t)ni * 4);
-  TF_HIP(hipMemcpyAsync(ds, hs, o_in_end, hipMemcpyHostToDevice, v->stream));
-  hipLaunchKernelGGL(k_pack_vertices, dim3((unsigned)np), dim3(256), 0, v->stream,
-                     reinterpret_cast<const PvPatch*>(ds + o_pt), reinterpret_cast<const float*>(ds + o_verts),
-                     reinterpret_cast<const float*>(ds + o_cols), reinterpret_cast<const float*>(ds + o_nrm),
-                     reinterpret_cast<const float*>(ds + o_tc), reinterpret_cast<const float*>(ds + o_tcol),
-                     reinterpret_cast<const float*>(ds + o_labs), reinterpret_cast<const uint32_t*>(ds + o_idx),
-                     0.0f, (float)a.aw, (float)a.ah, reinterpret_cast<float*>(ds + o_outv),
-                     reinterpret_cast<uint32_t*>(ds + o_outi));
+  memcpy(hs + o_pt, dp.data(), sizeof(DrawPatch) * dp.size());
+  TF_HIP(hipMemcpyAsync(ds + o_pt, hs + o_pt, sizeof(DrawPatch) * dp.size(), hipMemcpyHostToDevice, v->stream));
+  float* dv = d_vertices ? d_vertices : reinterpret_cast<float*>(ds + o_v);
+  uint32_t* di = d_indices ? d_indices : reinterpret_cast<uint32_t*>(ds + o_i);
+  hipLaunchKernelGGL(k_draw, dim3((unsigned)dp.size()), dim3(256), 0, v->stream, v->dev,
+                     reinterpret_cast<const DrawPatch*>(ds + o_pt), dv, di);
   TF_HIP(hipGetLastError());
-  TF_HIP(hipMemcpyAsync(hs + o_outv, ds + o_outv, total - o_outv, hipMemcpyDeviceToHost, v->stream));
+  if (!d_vertices) TF_HIP(hipMemcpyAsync(hs + o_v, ds + o_v, (size_t)vout * 48, hipMemcpyDeviceToHost, v->stream));
+  if (!d_indices && iout) TF_HIP(hipMemcpyAsync(hs + o_i, ds + o_i, (size_t)iout * 4, hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
-  memcpy(out_vertices, hs + o_outv, (size_t)vout * 48);
-  if (iout) memcpy(out_indices, hs + o_outi, (size_t)iout * 4);
-  if (out_n_vertices) *out_n_vertices = vout;
-  if (out_n_indices) *out_n_indices = iout;
+  if (!d_vertices && h_vertices) memcpy(h_vertices, hs + o_v, (size_t)vout * 48);
+  if (!d_indices && h_indices && iout) memcpy(h_indices, hs + o_i, (size_t)iout * 4);
+  return TF_OK;
+}
+
+int tf_draw_meshes(tf_volume* v, float* vertices, uint32_t* indices, int64_t cap_vertices, int64_t cap_indices,
+                   int64_t* n_vertices, int64_t* n_indices) {
+  if (!v || !vertices || !indices) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  return draw_common(v, nullptr, nullptr, vertices, indices, cap_vertices, cap_indices, n_vertices, n_indices);
+}
+int tf_draw_meshes_device(tf_volume* v, float* d_vertices, uint32_t* d_indices, int64_t cap_vertices,
+                          int64_t cap_indices, int64_t* n_vertices, int64_t* n_indices) {
+  if (!v || !d_vertices || !d_indices) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  return draw_common(v, d_vertices, d_indices, nullptr, nullptr, cap_vertices, cap_indices, n_vertices, n_indices);
+}
+
+int tf_patches_download(tf_volume* v, const int32_t* ids, int64_t n, const int64_t* vert_offsets, uint64_t* texloc,
+                        int32_t* frameid, int32_t* bbox, int32_t* flags, float* ratio, float* texcoord,
+                        float* texcolor, float* labs) {
+  if (!v || (n > 0 && !ids)) { set_error("null argument"); return TF_ERR_INVALID; }
+  if ((texcoord || texcolor || labs) && !vert_offsets) { set_error("per-vertex outputs need vert_offsets"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (n <= 0) return TF_OK;
+  const int64_t nv = vert_offsets ? vert_offsets[n] : 0;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o = (o + bytes + 15) & ~(size_t)15; return at; };
+  const size_t o_ids = take((size_t)n * 16), o_vo = take((size_t)(n + 1) * 8);
+  const size_t o_in_end = o;
+  const size_t o_ph = take(sizeof(PatchHost) * (size_t)n), o_tc = take((size_t)nv * 8), o_tcol = take((size_t)nv * 12),
+               o_labs = take((size_t)nv * 12);
+  int rc = atlas_stage(v, o);
+  if (rc) return rc;
+  AtlasState& a = v->atlas;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  uint8_t* hs = reinterpret_cast<uint8_t*>(a.h_stage);
+  uint8_t* ds = reinterpret_cast<uint8_t*>(a.d_stage);
+  int32_t* hid = reinterpret_cast<int32_t*>(hs + o_ids);
+  for (int64_t i = 0; i < n; ++i) {
+    hid[4 * i] = ids[3 * i]; hid[4 * i + 1] = ids[3 * i + 1]; hid[4 * i + 2] = ids[3 * i + 2]; hid[4 * i + 3] = 0;
+  }
+  if (vert_offsets) memcpy(hs + o_vo, vert_offsets, (size_t)(n + 1) * 8);
+  TF_HIP(hipMemcpyAsync(ds, hs, o_in_end, hipMemcpyHostToDevice, v->stream));
+  if (o > o_tc) TF_HIP(hipMemsetAsync(ds + o_tc, 0, o - o_tc, v->stream));
+  hipLaunchKernelGGL(k_patch_gather, dim3((unsigned)n), dim3(256), 0, v->stream, v->dev,
+                     reinterpret_cast<const int4*>(ds + o_ids), (uint32_t)n,
+                     vert_offsets ? reinterpret_cast<const long long*>(ds + o_vo) : nullptr,
+                     reinterpret_cast<PatchHost*>(ds + o_ph), texcoord ? reinterpret_cast<float*>(ds + o_tc) : nullptr,
+                     texcolor ? reinterpret_cast<float*>(ds + o_tcol) : nullptr,
+                     labs ? reinterpret_cast<float*>(ds + o_labs) : nullptr);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(hs + o_ph, ds + o_ph, o - o_ph, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  const PatchHost* ph = reinterpret_cast<const PatchHost*>(hs + o_ph);
+  for (int64_t i = 0; i < n; ++i) {
+    if (!ph[i].found) {
+      set_error("chunk (" + std::to_string(ids[3 * i]) + "," + std::to_string(ids[3 * i + 1]) + "," +
+                std::to_string(ids[3 * i + 2]) + ") has no mesh");
+      return TF_ERR_MISSING_CHUNK;
+    }
+    if (texloc) texloc[i] = ph[i].texloc;
+    if (frameid) frameid[i] = ph[i].frameid;
+    if (bbox) memcpy(bbox + 4 * i, ph[i].bbox, 16);
+    if (flags) flags[i] = (int32_t)ph[i].pflags;
+    if (ratio) { ratio[2 * i] = ph[i].ratio[0]; ratio[2 * i + 1] = ph[i].ratio[1]; }
+  }
+  if (texcoord) memcpy(texcoord, hs + o_tc, (size_t)nv * 8);
+  if (texcolor) memcpy(texcolor, hs + o_tcol, (size_t)nv * 12);
+  if (labs) memcpy(labs, hs + o_labs, (size_t)nv * 12);
   return TF_OK;
 }
 

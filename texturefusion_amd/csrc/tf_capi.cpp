@@ -161,6 +161,7 @@ static int init_device_state(tf_volume* v) {
   v->host_list_n = -1;
   v->epoch = 0;
   v->mesh_epoch = 0;
+  v->n_primed = 0;
   return TF_OK;
 }
 
@@ -576,10 +577,19 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
 
 // Software-pipelined enqueue of n frames on the handle's stream: launch i carries K-A of frame i,
 // K-C of frame i+1 and K-B of frame i+2 as independent block ranges of one kernel (launch_frame),
-// so a batch of n frames is n + 2 dispatches and the only synchronisation is the kernel boundary.
-static int enqueue_frames(tf_volume* v, int64_t n, const float* const* d_depth,
-                          const uint8_t* const* d_rgba, const float* poses12) {
+// so the only synchronisation is the kernel boundary.  The arrays may hold n_ahead (<= 2) frames more
+// than the n that are integrated: their selection stages run in this call's last launches and stay
+// valid ("primed") for the next call, which then starts with K-A at once -- a stream fed call by call
+// costs one launch per frame, not n + 2 per call.  tex != nullptr: after K-A of frame i its dirty chunks
+// are meshed and textured from the frame itself (the per-frame unit of BASELINE configs[2]).
+struct TexturedArgs {
+  const float* pose_inv16;  // per frame: f32(SE3d.inverse().matrix()) of the frame's pose
+  int32_t first_frame_id;
+};
+static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float* const* d_depth,
+                          const uint8_t* const* d_rgba, const float* poses12, const TexturedArgs* tex) {
   const int NS = tf_volume::kSelSets;
+  const int64_t n_all = n + n_ahead;
   auto stage = [&](int64_t f, FrameStage* st) {
     st->sel = v->selbuf[(v->cur_sel + 1 + f) % NS];
     st->img.depth = d_depth[f];
@@ -588,18 +598,72 @@ static int enqueue_frames(tf_volume* v, int64_t n, const float* const* d_depth,
     memcpy(st->pose.p, poses12 + 12 * f, sizeof(st->pose.p));
     st->epoch = v->epoch + (uint32_t)f;
   };
-  for (int64_t i = -2; i < n; ++i) {
+  // how many leading frames already went through their selection stages in the previous call?
+  int primed = 0;
+  for (int k = 0; k < v->n_primed && k < n_all; ++k) {
+    const tf_volume::Primed& p = v->primed[k];
+    if (p.depth != d_depth[k] || memcmp(p.pose, poses12 + 12 * k, 48) != 0) break;
+    primed = k + 1;
+  }
+  if (primed < v->n_primed) {  // the stream changed course: discard the selections made ahead
+    for (int k = 0; k < v->n_primed; ++k) {
+      VolumeDev d = v->dev;
+      d.sel = v->selbuf[(v->cur_sel + 1 + k) % NS];
+      launch_reset_ctl(d, false, v->stream);
+    }
+    primed = 0;
+  }
+  v->n_primed = 0;
+  // a primed frame 0 has its list (K-B and K-C ran), a primed frame 1 its bounding box (K-B ran)
+  for (int64_t i = (primed == 2 ? 0 : (primed == 1 ? -1 : -2)); i < n; ++i) {
     FrameStage cur, nxt, nx2;
-    const bool hc = i >= 0, hn = (i + 1 >= 0) && (i + 1 < n), h2 = (i + 2 < n);
+    const bool hc = i >= 0;
+    bool hn = (i + 1 >= 0) && (i + 1 < n_all), h2 = (i + 2 < n_all);
+    if (i + 2 < primed) h2 = false;               // K-B of that frame ran in the previous call
+    if (primed >= 1 && i + 1 == 0) hn = false;    // K-C of frame 0 ran in the previous call
     if (hc) stage(i, &cur);
     if (hn) stage(i + 1, &nxt);
     if (h2) stage(i + 2, &nx2);
+    if (!hc && !hn && !h2) continue;
     if (hc) prof_begin(v, TF_PROF_INTEGRATE);
     launch_frame(v->dev, hc ? &cur : nullptr, hn ? &nxt : nullptr, h2 ? &nx2 : nullptr, v->cam, v->ig,
                  v->res, v->stream);
     if (hc) prof_end(v);
+    if (hc && tex) {
+      // Chisel::UpdateMeshes -> CompressMeshes -> GeneratePatches(label = this frame) -> UpdateAtlas over
+      // the frame's dirty chunks (GCFusion/MobileFusion.cpp:327-382 without the host-side view selection)
+      AtlasState& a = v->atlas;
+      const int par = a.fused_par;
+      a.fused_par ^= 1;
+      VolumeDev d = v->dev;
+      d.sel = cur.sel;
+      prof_begin(v, TF_PROF_DIRTY);
+      launch_dirty_frame(d, par, cur.epoch + 1u, v->stream);
+      prof_end(v);
+      prof_begin(v, TF_PROF_MESH);
+      launch_mesh(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, v->stream);
+      prof_end(v);
+      prof_begin(v, TF_PROF_FINALIZE);
+      launch_compress(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, false, v->stream);
+      prof_end(v);
+      KfDev kf;
+      memset(&kf, 0, sizeof(kf));
+      kf.rgb = reinterpret_cast<const uint8_t*>(cur.img.rgba);
+      kf.depth = cur.img.depth;
+      kf.stride = 4;
+      kf.kf_id = tex->first_frame_id + (int32_t)i;
+      memcpy(kf.T, tex->pose_inv16 + 16 * i, 64);
+      launch_patch_fused(v, par, kf, v->stream);
+    }
   }
+  for (int64_t k = 0; k < n_ahead; ++k) {
+    tf_volume::Primed& p = v->primed[k];
+    p.depth = d_depth[n + k];
+    memcpy(p.pose, poses12 + 12 * (n + k), 48);
+  }
+  v->n_primed = (int)n_ahead;
   v->epoch += (uint32_t)n;
+  if (tex) v->clear_floor = v->epoch;  // CompressMeshes cleared meshesToUpdate after every frame
   v->cur_sel = (int)((v->cur_sel + n) % NS);
   v->dev.sel = v->selbuf[v->cur_sel];
   v->host_list_n = -1;
@@ -613,24 +677,73 @@ int tf_integrate_frame(tf_volume* v, const float pose[12], int use_color) {
   if (!v->frame_bound) { set_error("no frame bound"); return TF_ERR_INVALID; }
   const float* dd[1] = {v->frame.depth};
   const uint8_t* dc[1] = {use_color ? reinterpret_cast<const uint8_t*>(v->frame.rgba) : nullptr};
-  return enqueue_frames(v, 1, dd, dc, pose);
+  return enqueue_frames(v, 1, 0, dd, dc, pose, nullptr);
 }
 
-int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* const* d_depth,
-                               const uint8_t* const* d_rgba, const float* poses12) {
-  if (!v || !d_depth || !poses12) { set_error("null argument"); return TF_ERR_INVALID; }
-  TF_DEV(v);
-  if (n_frames <= 0) return TF_OK;
-  for (int64_t f = 0; f < n_frames; ++f)
+static int check_frames(int64_t n_all, const float* const* d_depth, const uint8_t* const* d_rgba) {
+  for (int64_t f = 0; f < n_all; ++f)
     if ((reinterpret_cast<uintptr_t>(d_depth[f]) & 15) || !d_depth[f] ||
         (d_rgba && (reinterpret_cast<uintptr_t>(d_rgba[f]) & 3))) {
       set_error("device images must be aligned (depth 16 B, rgba 4 B)");
       return TF_ERR_INVALID;
     }
-  int rc = enqueue_frames(v, n_frames, d_depth, d_rgba, poses12);
+  return TF_OK;
+}
+
+int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* const* d_depth,
+                               const uint8_t* const* d_rgba, const float* poses12) {
+  return tf_stream_frames_device(v, n_frames, 0, d_depth, d_rgba, poses12);
+}
+
+int tf_stream_frames_device(tf_volume* v, int64_t n_frames, int64_t n_ahead, const float* const* d_depth,
+                            const uint8_t* const* d_rgba, const float* poses12) {
+  if (!v || !d_depth || !poses12) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (n_ahead < 0 || n_ahead > 2) { set_error("n_ahead must be 0, 1 or 2"); return TF_ERR_INVALID; }
+  if (n_frames <= 0) return TF_OK;
+  int rc = check_frames(n_frames + n_ahead, d_depth, d_rgba);
+  if (rc) return rc;
+  rc = enqueue_frames(v, n_frames, n_ahead, d_depth, d_rgba, poses12, nullptr);
   if (rc) return rc;
   // leave the last frame bound, like a sequence of tf_frame_bind_device calls would
   return tf_frame_bind_device(v, d_depth[n_frames - 1], d_rgba ? d_rgba[n_frames - 1] : nullptr, nullptr);
+}
+
+int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int64_t n_ahead, const float* const* d_depth,
+                                     const uint8_t* const* d_rgba, const float* poses12, const float* pose_inv16,
+                                     int32_t first_frame_id) {
+  if (!v || !d_depth || !d_rgba || !poses12 || !pose_inv16) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (n_ahead < 0 || n_ahead > 2) { set_error("n_ahead must be 0, 1 or 2"); return TF_ERR_INVALID; }
+  if (n_frames <= 0) return TF_OK;
+  int rc = check_frames(n_frames + n_ahead, d_depth, d_rgba);
+  if (rc) return rc;
+  for (int64_t f = 0; f < n_frames; ++f)
+    if (!d_rgba[f]) { set_error("the textured flow needs a colour image per frame"); return TF_ERR_INVALID; }
+  TexturedArgs tex{pose_inv16, first_frame_id};
+  rc = enqueue_frames(v, n_frames, n_ahead, d_depth, d_rgba, poses12, &tex);
+  if (rc) return rc;
+  return tf_frame_bind_device(v, d_depth[n_frames - 1], d_rgba[n_frames - 1], nullptr);
+}
+
+int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {
+  if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  memset(out, 0, sizeof(*out));
+  int rc = ensure_tmp(v, 64);
+  if (rc) return rc;
+  TF_HIP(hipMemsetAsync(v->d_tmp, 0, 48, v->stream));
+  launch_texture_stats(v->dev, v->atlas.fused_par ^ 1, reinterpret_cast<unsigned long long*>(v->d_tmp), v->stream);
+  TF_HIP(hipGetLastError());
+  unsigned long long r[6];
+  TF_HIP(hipMemcpyAsync(r, v->d_tmp, 48, hipMemcpyDeviceToHost, v->stream));
+  AtlasCtl c;
+  TF_HIP(hipMemcpyAsync(&c, v->dev.actl, sizeof(c), hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  out->n_dirty = (int64_t)r[0]; out->n_meshes = (int64_t)r[1]; out->n_vertices = (int64_t)r[2];
+  out->n_triangles = (int64_t)r[3]; out->roi_pixels = (int64_t)r[4]; out->n_patches = (int64_t)r[5];
+  out->n_slots = (int64_t)c.n_slots;
+  return TF_OK;
 }
 
 int tf_sync(tf_volume* v) {

@@ -104,4 +104,12 @@ __device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, b
   return kInvalidSlot;
 }
 
+// id and its six face neighbours (Chisel.h:197-203): k = 0 self, 1 -x, 2 +x, 3 -y, 4 +y, 5 -z, 6 +z
+__device__ __forceinline__ int4 nbr7(const int4 c, int k) {
+  int4 r = c;
+  if (k == 1) r.x -= 1; else if (k == 2) r.x += 1;
+  else if (k == 3) r.y -= 1; else if (k == 4) r.y += 1;
+  else if (k == 5) r.z -= 1; else if (k == 6) r.z += 1;
+  return r;
+}
 }  // namespace tf

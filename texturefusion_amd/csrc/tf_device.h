@@ -120,8 +120,33 @@ struct __attribute__((aligned(16))) MeshRec {  // 64 B per pool slot
   uint32_t pflags;
   int32_t bbox[4];            // Patch::boundingbox x y w h
   float ratio[2];             // Patch::ratio
-  int32_t n_caution;
+  int32_t kf_slot;            // keyframe-table entry Patch::image views (-1 = released)
   uint32_t stamp;             // de-duplication stamp of the per-frame dirty list
+};
+
+// Keyframe images the patches are cut from (Frame::rgb / refined_depth, Patch::SetImage holds a
+// non-owning ROI, Patch.cpp:172-175) and the keyframe's pose as CalculateTexCoords uses it.
+struct __attribute__((aligned(16))) KfDev {
+  const uint8_t* rgb;   // u8[H][W][stride], stride 3 (Frame::rgb) or 4 (the path's RGBA staging image)
+  const float* depth;   // f32[H][W]
+  float T[16];          // f32(SE3d.inverse().matrix()), row-major (Patch.cpp:51)
+  int32_t stride;
+  int32_t kf_id;        // Frame id = the label view selection hands out
+  int32_t pad[2];
+};
+// Device words of the atlas: the slot allocator's position (Atlas::loc_next as a slot count), the hot
+// range of the last GeneratePatches, the fused per-frame work lists.
+struct AtlasCtl {
+  uint32_t n_slots;              // slots handed out so far
+  uint32_t n_done;               // patches projected by the last GeneratePatches
+  unsigned long long loc_min, loc_max;  // min / max texloc of the last GeneratePatches (Chisel.cpp:153-186)
+  // work-list counters, double-buffered by frame parity in the fused per-frame flow (the kernels of frame
+  // f re-arm the set of frame f + 1; the call-by-call flow uses set 0)
+  struct Set {
+    uint32_t n_work;               // entries of the patch work list
+    uint32_t n_cand;               // work entries that still need an atlas slot
+    unsigned long long fail_key;   // smallest packed id whose AddPatch overflowed (~0 = none)
+  } set[2];
 };
 
 constexpr int kPhaseWaves = 16384;  // rows of the wave-timeline table (tuning aid)
@@ -153,6 +178,14 @@ struct VolumeDev {
   uint16_t* mesh_t;
   MeshRec* mesh_rec;
   uint32_t mesh_cv, mesh_ct;
+  // atlas (Structure/Atlas.h:43-75): u8 [atlas_h][atlas_w][3], slots of patch_w x patch_h texels
+  uint8_t* atlas;
+  int32_t atlas_w, atlas_h, patch_w, patch_h;
+  AtlasCtl* actl;
+  KfDev* kf_tab;      // [max_keyframes]
+  int4* work_ids;       // [max_chunks] work list (dirty chunks of a frame / chunksToUpdate): id, w = keyframe-table entry
+  uint32_t* work_slot;  // [max_chunks] pool slot of the entry, kInvalidSlot = not processed
+  unsigned long long* cand;  // [max_chunks] packed ids of the work entries that need an atlas slot
   SelBuf sel;  // the selection set the launch works on
 };
 __host__ __device__ inline float* mesh_plane(const VolumeDev& v, uint32_t slot, int plane) {
@@ -205,7 +238,13 @@ void launch_boundary_unpack(const VolumeDev& v, const uint8_t* records, uint32_t
 // ---- launchers (tf_mesh.hip) ---------------------------------------------------------
 // dlist: int4 {id.x, id.y, id.z, -} per dirty chunk, *dcount entries
 void launch_init_meshes(const VolumeDev& v, hipStream_t s);
+// fused = the per-frame flow: the mesh is marked simplified at once (CompressMeshes follows in the same frame)
 void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
-                 uint32_t epoch, float res, hipStream_t s);
+                 uint32_t epoch, float res, bool fused, hipStream_t s);
+// per-frame dirty set of the fused flow -> work list of counter set `par`
+void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s);
+void launch_compress(const VolumeDev& v, const int4* list, const uint32_t* count, uint32_t cap, bool mark, hipStream_t s);
+// sums over the work list of counter set `par`: {entries, with mesh, vertices, triangles, ROI pixels, patches}
+void launch_texture_stats(const VolumeDev& v, int par, unsigned long long* out6, hipStream_t s);
 
 }  // namespace tf

@@ -1305,13 +1305,6 @@ void launch_list_chunks(const VolumeDev& v, int4* out, uint32_t cap, hipStream_t
 // seven neighbours is newer than max(clear floor, erase(id)) (marks of one finalize precede its
 // erases, Chisel.h:192-214, so an equal epoch means erased).  id is emitted by the first marked
 // neighbour in a fixed order, i.e. exactly once.
-__device__ __forceinline__ int4 nbr7(const int4 c, int k) {
-  int4 r = c;
-  if (k == 1) r.x -= 1; else if (k == 2) r.x += 1;
-  else if (k == 3) r.y -= 1; else if (k == 4) r.y += 1;
-  else if (k == 5) r.z -= 1; else if (k == 6) r.z += 1;
-  return r;
-}
 __device__ __forceinline__ bool dirty_candidate(const VolumeDev& v, const uint32_t t, const uint32_t total,
                                                 const uint32_t floor_, int4* id_out) {
   const uint32_t i = t >> 3, k = t & 7u;

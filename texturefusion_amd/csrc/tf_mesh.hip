@@ -96,7 +96,7 @@ struct MeshSh {
 
 __global__ __launch_bounds__(256) void k_mesh(VolumeDev v, const int4* __restrict__ dlist,
                                               const uint32_t* __restrict__ dcount, uint32_t max_entries,
-                                              uint32_t epoch, float res) {
+                                              uint32_t epoch, float res, uint32_t simplified) {
   __shared__ MeshSh sh;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   uint32_t n = *dcount;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_mesh(VolumeDev v, const int4* __restric
       // adjacency flags are final now (SimplifyByClustering runs once per generation, Chisel.cpp:124)
       const uint32_t inmap = (rec->state & kMsInMap) | (nv ? kMsInMap : 0u);
       rec->nv = nv; rec->nt = nt; rec->epoch = epoch;
-      rec->state = inmap | (sh.adj << kMsAdjShift);
+      rec->state = inmap | (sh.adj << kMsAdjShift) | (nv ? simplified : 0u);
     }
     __syncthreads();
   }
@@ -332,10 +332,58 @@ void launch_init_meshes(const VolumeDev& v, hipStream_t s) {
 }
 
 void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
-                 uint32_t epoch, float res, hipStream_t s) {
+                 uint32_t epoch, float res, bool fused, hipStream_t s) {
   if (!max_entries) return;
   const uint32_t grid = max_entries < 8192u ? max_entries : 8192u;
-  hipLaunchKernelGGL(k_mesh, dim3(grid), dim3(256), 0, s, v, dlist, dcount, max_entries, epoch, res);
+  hipLaunchKernelGGL(k_mesh, dim3(grid), dim3(256), 0, s, v, dlist, dcount, max_entries, epoch, res,
+                     fused ? kMsSimplified : 0u);
+}
+
+// ---------------------------------------------------------------------------------------
+// Per-frame dirty set of the fused flow = Chisel::meshesToUpdate after ONE FinalizeIntegrateChunks
+// (Structure/Chisel.h:192-208): every updated chunk of the frame's list and its six face neighbours, those
+// that exist, each once (a stamp per pool slot de-duplicates), appended to the work list.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dirty_frame(VolumeDev v, int par, uint32_t stamp) {
+  const SelBuf& L = v.sel;
+  const uint32_t nl = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
+  const uint32_t total = nl * 8u;  // 8 threads per entry: k = 0..6 self + neighbours, 7 idle
+  AtlasCtl::Set* S = &v.actl->set[par];
+  const int lane = threadIdx.x & 63;
+  for (uint32_t b0 = blockIdx.x * 256; b0 < total; b0 += gridDim.x * 256) {
+    const uint32_t t = b0 + threadIdx.x;
+    bool emit = false;
+    int4 q = make_int4(0, 0, 0, 0);
+    uint32_t slot = kInvalidSlot;
+    if (t < total && (t & 7u) != 7u) {
+      const uint32_t e = t >> 3;
+      const int k = (int)(t & 7u);
+      if (L.list_needs[e]) {
+        q = nbr7(L.list_id[e], k);
+        q.w = 0;
+        if (k == 0) slot = L.list_slot[e];
+        else {
+          const uint32_t ent = hash_find(v, pack_id(q.x, q.y, q.z));
+          if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
+        }
+        if (slot != kInvalidSlot && part_owned(v, q.x, q.y, q.z))
+          emit = atomicMax(&v.mesh_rec[slot].stamp, stamp) < stamp;
+      }
+    }
+    const unsigned long long m = __ballot(emit);
+    if (m) {
+      uint32_t p0 = 0;
+      if (lane == 0) p0 = atomicAdd(&S->n_work, (uint32_t)__popcll(m));
+      p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
+      if (emit) {
+        const uint32_t p = p0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (p < v.max_chunks) { v.work_ids[p] = q; v.work_slot[p] = slot; }
+      }
+    }
+  }
+}
+void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s) {
+  hipLaunchKernelGGL(k_dirty_frame, dim3(512), dim3(256), 0, s, v, par, stamp);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -384,6 +432,11 @@ __global__ __launch_bounds__(256) void k_compress_exchange(VolumeDev v, const in
     if (fa && !fb) atomicOr(&b->state, bbit);
     if (!fa && fb) atomicOr(&a->state, abit);
   }
+}
+
+void launch_compress(const VolumeDev& v, const int4* list, const uint32_t* count, uint32_t cap, bool mark, hipStream_t s) {
+  if (mark) hipLaunchKernelGGL(k_compress_mark, dim3(256), dim3(256), 0, s, v, list, count, cap);
+  hipLaunchKernelGGL(k_compress_exchange, dim3(512), dim3(256), 0, s, v, list, count, cap);
 }
 
 // keys of allMeshes
@@ -487,7 +540,7 @@ int tf_update_meshes(tf_volume* v, int64_t* n_meshed) {
   const uint8_t* db = reinterpret_cast<const uint8_t*>(v->d_tmp);
   prof_begin(v, TF_PROF_MESH);
   launch_mesh(v->dev, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), n,
-              ++v->mesh_epoch, v->res, v->stream);
+              ++v->mesh_epoch, v->res, false, v->stream);
   prof_end(v);
   TF_HIP(hipGetLastError());
   return tf_sync(v);
@@ -613,8 +666,7 @@ int tf_compress_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n_o
     uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
     const int4* list = reinterpret_cast<const int4*>(db + 16);
     const uint32_t* cnt = reinterpret_cast<const uint32_t*>(db);
-    hipLaunchKernelGGL(k_compress_mark, dim3(256), dim3(256), 0, v->stream, v->dev, list, cnt, n);
-    hipLaunchKernelGGL(k_compress_exchange, dim3(512), dim3(256), 0, v->stream, v->dev, list, cnt, n);
+    launch_compress(v->dev, list, cnt, n, true, v->stream);
     TF_HIP(hipGetLastError());
     // chunksToUpdate = the dirty keys that have a mesh (GCFusion/MobileFusion.cpp:345-353), ascending id
     const size_t o_cnt = ((size_t)n * 16 + 16 + 15) & ~(size_t)15;

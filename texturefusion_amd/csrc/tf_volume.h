@@ -41,61 +41,32 @@ struct ProfEvent {
 };
 
 struct KeyframeSlot {
-  uint8_t* rgb = nullptr;   // device, u8[H][W][3]
+  uint8_t* rgb = nullptr;   // device, u8[H][W][stride]
   float* depth = nullptr;   // device, f32[H][W]
   bool owned = false;
-};
-
-// chunk id -> texloc: open addressing, no allocation per insert (GeneratePatches looks up / inserts
-// thousands of ids per keyframe on the host)
-struct FlatMap64 {
-  std::vector<uint64_t> keys, vals;
-  size_t used = 0;
-  static constexpr uint64_t kNone = ~0ull;
-  void clear() { keys.clear(); vals.clear(); used = 0; }
-  static size_t slot_of(uint64_t k, size_t mask) { return (size_t)((k * 0x9E3779B97F4A7C15ull) >> 20) & mask; }
-  void grow() {
-    std::vector<uint64_t> ok, ov;
-    ok.swap(keys); ov.swap(vals);
-    const size_t cap = ok.empty() ? 4096 : ok.size() * 2;
-    keys.assign(cap, kNone); vals.assign(cap, 0);
-    for (size_t i = 0; i < ok.size(); ++i)
-      if (ok[i] != kNone) {
-        size_t s = slot_of(ok[i], cap - 1);
-        while (keys[s] != kNone) s = (s + 1) & (cap - 1);
-        keys[s] = ok[i]; vals[s] = ov[i];
-      }
-  }
-  // returns the value slot of key; *inserted tells whether it is new (value then undefined)
-  uint64_t* find_or_insert(uint64_t k, bool* inserted) {
-    if (keys.empty() || used * 2 >= keys.size()) grow();
-    const size_t mask = keys.size() - 1;
-    size_t s = slot_of(k, mask);
-    while (keys[s] != kNone && keys[s] != k) s = (s + 1) & mask;
-    *inserted = keys[s] == kNone;
-    if (*inserted) { keys[s] = k; ++used; }
-    return &vals[s];
-  }
+  int slot = -1;            // entry of the device keyframe table
 };
 
 struct AtlasState {
   int32_t aw = 13824, ah = 13824;
   uint64_t pw = 0, ph = 0;
-  uint64_t loc_next = 0;
   uint8_t* buf = nullptr;  // device, u8[ah][aw][3]
-  FlatMap64 texloc;  // packed chunk id -> texloc (Mesh::m_patch)
+  // keyframe table (device copy + host mirror)
   std::unordered_map<int32_t, KeyframeSlot> keyframes;
+  std::vector<KfDev> h_kf;
+  std::vector<uint8_t> kf_used;
+  KfDev* d_kf = nullptr;
+  int kf_cap = 0;
+  AtlasCtl* d_actl = nullptr;
+  int4* d_work_ids = nullptr;
+  uint32_t* d_work_slot = nullptr;
+  unsigned long long* d_cand = nullptr;
+  int fused_par = 0;   // counter set of the next fused frame
   // staging
   void* d_stage = nullptr;
   size_t d_stage_bytes = 0;
   void* h_stage = nullptr;
   size_t h_stage_bytes = 0;
-  // descriptor ring of the asynchronous (device-resident) patch update
-  void* pin_host[4] = {nullptr, nullptr, nullptr, nullptr};
-  void* pin_dev[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t pin_bytes[4] = {0, 0, 0, 0};
-  hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  int pin_next = 0;
 };
 
 }  // namespace tf
@@ -115,6 +86,10 @@ struct tf_volume {
   tf::VolumeDev dev;
   tf::SelBuf selbuf[kSelSets];  // ring of selection scratch sets (dev.sel = the active set)
   int cur_sel = 0;
+  // frames whose selection stages already ran at the end of the previous streaming call (n_ahead)
+  struct Primed { const float* depth; float pose[12]; };
+  Primed primed[2];
+  int n_primed = 0;
   std::vector<void*> allocs;
   // frame images
   float* d_depth = nullptr;      // owned staging targets
@@ -151,6 +126,8 @@ void prof_end(tf_volume* v, hipStream_t s = nullptr);
 int atlas_init(tf_volume* v);
 void atlas_destroy(tf_volume* v);
 int atlas_reset(tf_volume* v);
+int kf_push(tf_volume* v, int slot);
+void launch_patch_fused(tf_volume* v, int par, const KfDev& kf, hipStream_t s);
 inline uint64_t host_pack_id(const int32_t id[3]) {
   return ((uint64_t)((uint32_t)(id[0] + (1 << 20)) & 0x1FFFFFu) << 42) |
          ((uint64_t)((uint32_t)(id[1] + (1 << 20)) & 0x1FFFFFu) << 21) |

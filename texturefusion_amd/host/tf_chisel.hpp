@@ -21,6 +21,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <unordered_map>
 #include <vector>
 
@@ -151,6 +152,82 @@ class Chunk {
 };
 typedef std::shared_ptr<Chunk> ChunkPtr;
 
+// ---- Mesh / Patch mirrors (3rd_party/open_chisel/geometry/Mesh.h:36-89, Structure/Patch.h:51-94) ----------
+// The data lives in HBM; these carry the members the path's callers read.  Counts and flags are refreshed
+// by the Chisel methods that change them; the per-vertex arrays are filled on request
+// (ChunkManager::FetchMeshData / Chisel::FetchPatchData) because nothing on the path reads them on the host.
+struct Box {  // cv::Rect
+  int x = 0, y = 0, width = 0, height = 0;
+};
+struct Vec2 {
+  float v[2];
+  Vec2() : v{0, 0} {}
+  Vec2(float a, float b) : v{a, b} {}
+  float operator()(int i) const { return v[i]; }
+  float& operator()(int i) { return v[i]; }
+};
+typedef std::vector<Vec3> Vec3List;
+typedef std::vector<Vec2> Vec2List;
+typedef std::vector<unsigned int> VertIndexList;
+
+class Mesh;
+typedef std::shared_ptr<Mesh> MeshPtr;
+
+class Patch {  // Structure/Patch.h:51-94
+ public:
+  explicit Patch(Mesh* meshit) : mesh(meshit) {}
+  int frameid = -1;
+  Mesh* mesh = nullptr;
+  std::size_t texloc = 0;
+  bool has_image = false, has_adjusted = false, has_updated = false, wrong_mapping = false;
+  Box boundingbox;
+  Vec2List texcoord;
+  Vec3List texcolor;
+  Vec2 ratio = Vec2(1, 1);
+  Vec3List labs;
+  int n_texcoord = 0;     // texcoord.size() of the device-resident patch
+  bool labs_empty = true;  // labs.empty() of the device-resident patch
+  inline void SetFrameid(int frameit) { frameid = frameit; }
+  inline float GetWidth() const { return (float)boundingbox.width; }
+  inline float GetHeight() const { return (float)boundingbox.height; }
+  inline int GetCoordsNum() const { return n_texcoord; }
+  bool complete() const;  // Patch.cpp:191-196
+};
+typedef std::shared_ptr<Patch> PatchPtr;
+
+class Mesh {  // geometry/Mesh.h:36-89
+ public:
+  inline bool HasVertices() const { return n_vertices > 0; }
+  inline bool HasIndices() const { return n_indices > 0; }
+  Vec3List vertices, normals, colors;  // filled by ChunkManager::FetchMeshData
+  VertIndexList indices;
+  ChunkID chunkID;
+  bool simplified = false;
+  bool adj[6] = {false, false, false, false, false, false};
+  int n_vertices = 0, n_indices = 0;  // vertices.size() / indices.size() of the device-resident mesh
+  PatchPtr m_patch;
+};
+inline bool Patch::complete() const {
+  if (mesh == nullptr || mesh->n_vertices == 0 || !mesh->simplified) return false;
+  if (!has_image || n_texcoord == 0 || frameid < 0) return false;
+  return true;
+}
+typedef std::unordered_map<ChunkID, MeshPtr, ChunkHasher> MeshMap;
+
+// GCSLAM/frame.h: the members of a keyframe the atlas stage reads (Patch.cpp:51,69-70,172-175)
+struct Frame {
+  int frame_index = -1;
+  const unsigned char* rgb = nullptr;    // cv::Mat rgb, 8UC3, H x W
+  const float* refined_depth = nullptr;  // cv::Mat refined_depth, 32F, H x W
+  float pose_inv[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // f32(pose_sophus[0].inverse().matrix()), row-major
+};
+// Structure/uni_graph.h: what GeneratePatches asks of the label set (Chisel.cpp:159-160)
+struct UniGraph {
+  std::unordered_map<ChunkID, std::size_t, ChunkHasher> chunks;
+  std::vector<int> labels;
+  inline int get_label(std::size_t n) const { return labels[n]; }
+};
+
 inline void tf_check(int rc, const char* what) {
   if (rc != TF_OK) throw std::runtime_error(std::string(what) + ": " + tf_last_error());
 }
@@ -192,26 +269,74 @@ class ChunkManager {
     mirrors.emplace(id, c);
     return c;
   }
-  void DropMirror(const ChunkID& id) { mirrors.erase(id); }
-  void Reset() { mirrors.clear(); }
+  // RemoveChunk also drops the chunk's mesh (ChunkManager.h:151-161)
+  void DropMirror(const ChunkID& id) { mirrors.erase(id); allMeshes.erase(id); }
+  void Reset() { mirrors.clear(); allMeshes.clear(); }  // ChunkManager.cpp:272-275
+
+  // ---- meshes (ChunkManager.h:714-724) ----
+  inline const MeshMap& GetAllMeshes() const { return allMeshes; }
+  inline MeshMap& GetAllMutableMeshes() { return allMeshes; }
+  inline const MeshPtr& GetMesh(const ChunkID& chunkID) const { return allMeshes.at(chunkID); }
+  inline MeshPtr& GetMutableMesh(const ChunkID& chunkID) { return allMeshes.at(chunkID); }
+  inline bool HasMesh(const ChunkID& chunkID) const { return allMeshes.find(chunkID) != allMeshes.end(); }
+  // refresh counts / flags of the listed chunks' meshes from the device; chunks without a mesh there are
+  // left out (RecomputeMeshes only adds, :260-262)
+  void RefreshMeshes(const std::vector<int32_t>& ids3) {
+    const int64_t n = (int64_t)ids3.size() / 3;
+    if (!n) return;
+    std::vector<int32_t> nv((size_t)n), ni((size_t)n);
+    std::vector<uint8_t> adj((size_t)n * 6), simp((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {  // per chunk: a chunk of the dirty set may have no mesh
+      const int rc = tf_mesh_counts(vol, &ids3[3 * (size_t)i], 1, &nv[(size_t)i], &ni[(size_t)i], &adj[6 * (size_t)i], &simp[(size_t)i]);
+      if (rc == TF_ERR_MISSING_CHUNK) continue;
+      tf_check(rc, "RefreshMeshes");
+      const ChunkID id(ids3[3 * (size_t)i], ids3[3 * (size_t)i + 1], ids3[3 * (size_t)i + 2]);
+      MeshPtr& m = allMeshes[id];
+      if (!m) { m = std::make_shared<Mesh>(); m->chunkID = id; }
+      m->n_vertices = nv[(size_t)i]; m->n_indices = ni[(size_t)i];
+      m->simplified = simp[(size_t)i] != 0;
+      for (int k = 0; k < 6; ++k) m->adj[k] = adj[6 * (size_t)i + k] != 0;
+      m->vertices.clear(); m->normals.clear(); m->colors.clear(); m->indices.clear();
+    }
+  }
+  // Mesh::vertices / normals / colors / indices of one mesh into the mirror
+  void FetchMeshData(const ChunkID& id) {
+    MeshPtr& m = allMeshes.at(id);
+    const int64_t voff[2] = {0, m->n_vertices}, ioff[2] = {0, m->n_indices};
+    std::vector<float> v((size_t)m->n_vertices * 3 + 3), nr(v.size()), c(v.size());
+    m->indices.assign((size_t)m->n_indices, 0u);
+    std::vector<uint32_t> idx((size_t)m->n_indices + 1);
+    tf_check(tf_meshes_download(vol, id.v, 1, voff, ioff, v.data(), nr.data(), c.data(), idx.data()), "FetchMeshData");
+    m->vertices.clear(); m->normals.clear(); m->colors.clear();
+    for (int i = 0; i < m->n_vertices; ++i) {
+      m->vertices.emplace_back(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+      m->normals.emplace_back(nr[3 * i], nr[3 * i + 1], nr[3 * i + 2]);
+      m->colors.emplace_back(c[3 * i], c[3 * i + 1], c[3 * i + 2]);
+    }
+    for (int i = 0; i < m->n_indices; ++i) m->indices[(size_t)i] = idx[(size_t)i];
+  }
 
  private:
   tf_volume* vol = nullptr;
   float voxelResolutionMeters = 0.005f;
   std::unordered_map<ChunkID, ChunkPtr, ChunkHasher> mirrors;
+  MeshMap allMeshes;
 };
 
 // ---- Atlas (Structure/Atlas.h:43-75) -------------------------------------------------------
 class Atlas {
  public:
   std::size_t loc_next = 0, PATCH_WIDTH = 0, PATCH_HEIGHT = 0, hot_start = 0, hot_end = 0;
-  void Bind(tf_volume* v) {
+  void Bind(tf_volume* v, ChunkManager* m) {
     vol = v;
+    manager = m;
     int32_t pw = 0, ph = 0;
     tf_check(tf_atlas_patch_size(vol, &pw, &ph), "Atlas");
     PATCH_WIDTH = pw;
     PATCH_HEIGHT = ph;
   }
+  inline bool HasPatch(const ChunkID& id) const { return manager->HasMesh(id); }            // Atlas.h:55
+  inline PatchPtr GetPatch(const ChunkID& id) { return manager->GetMutableMesh(id)->m_patch; }  // :56-58
   // texture_buffer rows [row0,row1) (the GUI uploads only the hot rows, MobileFusion.h:406-421)
   void DownloadRows(int64_t row0, int64_t row1, unsigned char* dst) {
     tf_check(tf_atlas_download_rows(vol, row0, row1, dst), "Atlas::DownloadRows");
@@ -224,27 +349,7 @@ class Atlas {
 
  private:
   tf_volume* vol = nullptr;
-};
-
-// Mesh input of the atlas stage (geometry/Mesh.h:70-85: vertices / colors of one chunk's mesh).
-struct PatchMesh {
-  ChunkID chunkID;
-  std::vector<float> vertices;  // xyz per vertex
-  std::vector<float> colors;    // rgb in [0,1] per vertex
-  std::vector<float> normals;   // xyz per vertex (DrawMeshes only)
-  std::vector<unsigned int> indices;  // (DrawMeshes only)
-};
-// Patch results (Structure/Patch.h:51-94 members the callers read).
-struct PatchResult {
-  std::size_t texloc = 0;
-  int boundingbox[4] = {0, 0, 0, 0};  // x, y, width, height
-  bool wrong_mapping = false;
-  int flag = 0;  // CalculateTexCoords' return value (0 / -1)
-  float ratio[2] = {1, 1};
-  std::vector<float> texcoord, texcolor;
-  int frameid = -1;           // Patch::frameid: source keyframe (the label)
-  bool has_adjusted = false;  // Patch::has_adjusted
-  std::vector<float> labs;    // Patch::labs: compensated colours (empty when wrong_mapping)
+  ChunkManager* manager = nullptr;
 };
 
 // ---- Chisel (Structure/Chisel.h:46-493) ----------------------------------------------------
@@ -255,7 +360,7 @@ class Chisel {
     tf_check(tf_volume_create(dims, voxelResolution, useColor ? 1 : 0, cfg, &vol), "Chisel");
     res = voxelResolution;
     chunkManager.Bind(vol, res);
-    atlas.Bind(vol);
+    atlas.Bind(vol, &chunkManager);
   }
   virtual ~Chisel() { tf_volume_destroy(vol); }
   Chisel(const Chisel&) = delete;
@@ -376,131 +481,118 @@ class Chisel {
     meshes_stale = false;
   }
 
-  // Frame::rgb / refined_depth of a keyframe, kept alive for Patch::SetImage (Patch.cpp:172-175).
-  void CacheKeyframe(int frameid, const unsigned char* rgb, const float* depth) {
-    tf_check(tf_keyframe_cache(vol, frameid, rgb, depth), "CacheKeyframe");
+  // Structure/Chisel.h:479-481 -> ChunkManager::RecomputeMeshes (ChunkManager.cpp:232-264) on the device
+  void UpdateMeshes(const PinholeCamera& camera) {
+    (void)camera;
+    const ChunkSet& dirty = GetMeshesToUpdate();
+    std::vector<int32_t> ids;
+    for (const auto& kv : dirty)
+      if (kv.second) { ids.push_back(kv.first(0)); ids.push_back(kv.first(1)); ids.push_back(kv.first(2)); }
+    int64_t n = 0;
+    tf_check(tf_update_meshes(vol, &n), "UpdateMeshes");
+    chunkManager.RefreshMeshes(ids);
   }
 
-  // Chisel::GeneratePatches + Chisel::UpdateAtlas (Chisel.cpp:149-196) over the chunks that have a
-  // mesh.  labels[i] = source keyframe of chunk i (the MRF's output), pose_inv[i] = f32 of that
-  // keyframe's SE3d inverse (16 floats row-major).  Returns 0, or -1 when the atlas is full.
-  int GeneratePatchesAndUpdateAtlas(const std::vector<PatchMesh>& meshes, const std::vector<int>& labels,
-                                    const std::vector<const float*>& pose_inv, const PinholeCamera& cameraModel,
-                                    std::vector<PatchResult>& out) {
+  // Structure/Chisel.cpp:112-147.  The reference is handed chiselMap->meshesToUpdate and clears it.
+  void CompressMeshes(ChunkSet& chunksToUpdate) {
+    std::vector<int32_t> ids((size_t)chunksToUpdate.size() * 3 + 3);
+    int64_t n = 0;
+    tf_check(tf_compress_meshes(vol, ids.data(), (int64_t)chunksToUpdate.size(), &n), "CompressMeshes");
+    ids.resize((size_t)n * 3);
+    // flags of the listed meshes and of their face neighbours changed
+    std::vector<int32_t> touch;
+    static const int nb[7][3] = {{0, 0, 0}, {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+    for (int64_t i = 0; i < n; ++i)
+      for (int k = 0; k < 7; ++k) {
+        const ChunkID q(ids[3 * (size_t)i] + nb[k][0], ids[3 * (size_t)i + 1] + nb[k][1], ids[3 * (size_t)i + 2] + nb[k][2]);
+        if (k == 0 || chunkManager.HasMesh(q)) { touch.push_back(q(0)); touch.push_back(q(1)); touch.push_back(q(2)); }
+      }
+    std::vector<int> keep_patch_state;  // RefreshMeshes leaves m_patch alone
+    chunkManager.RefreshMeshes(touch);
+    chunksToUpdate.clear();
+    meshesToUpdate.clear();
+    meshes_stale = false;
+  }
+
+  // Structure/Chisel.cpp:149-189.  frame_list is indexed by label like in the reference; the frames named by
+  // the labels are cached in HBM (Frame::rgb / refined_depth) and their poses refreshed.
+  int GeneratePatches(ChunkIDList& chunksToUpdate, UniGraph& labelset, std::vector<Frame>& frame_list,
+                      PinholeCamera& cameraModel) {
     ProjectionIntegrator dummy;
     Configure(dummy, cameraModel, false);
-    const size_t np = meshes.size();
-    std::vector<int32_t> ids(np * 3), kf(np), bbox(np * 4), flags(np);
-    std::vector<float> T(np * 16), ratio(np * 2), verts, cols;
-    std::vector<int64_t> voff(np + 1, 0);
-    std::vector<uint64_t> texloc(np);
-    for (size_t p = 0; p < np; ++p) {
-      for (int a = 0; a < 3; ++a) ids[3 * p + a] = meshes[p].chunkID(a);
-      kf[p] = labels[p];
-      std::memcpy(&T[16 * p], pose_inv[p], 64);
-      verts.insert(verts.end(), meshes[p].vertices.begin(), meshes[p].vertices.end());
-      cols.insert(cols.end(), meshes[p].colors.begin(), meshes[p].colors.end());
-      voff[p + 1] = (int64_t)verts.size() / 3;
+    const size_t n = chunksToUpdate.size();
+    std::vector<int32_t> ids(n * 3 + 3), labels(n + 1);
+    for (size_t i = 0; i < n; ++i) {
+      for (int a = 0; a < 3; ++a) ids[3 * i + a] = chunksToUpdate[i](a);
+      const int frameid = labelset.get_label(labelset.chunks.find(chunksToUpdate[i])->second);
+      labels[i] = frameid;
+      Frame& f = frame_list[(size_t)frameid];
+      if (!cached_kf.count(frameid) || cached_kf[frameid] != f.rgb) {
+        tf_check(tf_keyframe_cache(vol, frameid, f.rgb, f.refined_depth), "GeneratePatches: keyframe");
+        cached_kf[frameid] = f.rgb;
+      }
+      if (!pose_set.count(frameid) || std::memcmp(pose_set[frameid].data(), f.pose_inv, 64) != 0) {
+        tf_check(tf_keyframe_set_pose(vol, frameid, f.pose_inv), "GeneratePatches: pose");
+        pose_set[frameid].assign(f.pose_inv, f.pose_inv + 16);
+      }
     }
-    std::vector<float> tc((size_t)voff[np] * 2 + 2), tcol((size_t)voff[np] * 3 + 3);
     uint64_t hot[2] = {0, 0};
-    int rc = tf_patches_update(vol, (int64_t)np, ids.data(), kf.data(), T.data(), voff.data(), verts.data(),
-                               cols.data(), tc.data(), tcol.data(), bbox.data(), flags.data(), ratio.data(),
-                               texloc.data(), hot);
-    if (rc == TF_ERR_ATLAS_FULL) return -1;  // Chisel.cpp:170-173
-    tf_check(rc, "GeneratePatches");
-    out.assign(np, PatchResult());
-    for (size_t p = 0; p < np; ++p) {
-      PatchResult& r = out[p];
-      r.texloc = texloc[p];
-      std::memcpy(r.boundingbox, &bbox[4 * p], 16);
-      r.flag = (flags[p] & 1) ? -1 : 0;
-      r.wrong_mapping = (flags[p] & 2) != 0;
-      r.ratio[0] = ratio[2 * p];
-      r.ratio[1] = ratio[2 * p + 1];
-      r.texcoord.assign(tc.begin() + 2 * voff[p], tc.begin() + 2 * voff[p + 1]);
-      r.texcolor.assign(tcol.begin() + 3 * voff[p], tcol.begin() + 3 * voff[p + 1]);
-      r.frameid = labels[p];
-    }
+    const int rc = tf_generate_patches(vol, ids.data(), (int64_t)n, labels.data(), hot);
+    if (rc != TF_ERR_ATLAS_FULL) tf_check(rc, "GeneratePatches");
+    RefreshPatches(ids, n);
     atlas.hot_start = hot[0];
     atlas.hot_end = hot[1];
     atlas.Refresh();
-    return 0;
+    return rc == TF_ERR_ATLAS_FULL ? -1 : 0;  // Chisel.cpp:170-173
   }
 
-  // Chisel::CompensateColor (Chisel.cpp:198-286) over the patches GeneratePatches produced, in the
-  // caller's (mesh map) order: clusters the not yet adjusted patches by source frame, learns one
-  // colour transfer per cluster from the correctly mapped patches and fills PatchResult::labs.
-  void CompensateColor(const std::vector<PatchMesh>& meshes, std::vector<PatchResult>& patches) {
-    const size_t np = patches.size();
-    if (!np) return;
-    std::vector<int32_t> fid(np);
-    std::vector<uint8_t> wrong(np), adj(np);
-    std::vector<int64_t> voff(np + 1, 0);
-    std::vector<float> tex, mesh;
-    for (size_t p = 0; p < np; ++p) {
-      fid[p] = patches[p].frameid;
-      wrong[p] = patches[p].wrong_mapping ? 1 : 0;
-      adj[p] = patches[p].has_adjusted ? 1 : 0;
-      tex.insert(tex.end(), patches[p].texcolor.begin(), patches[p].texcolor.end());
-      mesh.insert(mesh.end(), meshes[p].colors.begin(), meshes[p].colors.end());
-      voff[p + 1] = (int64_t)tex.size() / 3;
-    }
-    std::vector<float> labs(tex.size() + 3, 0.0f);
+  // Structure/Chisel.cpp:198-286
+  void CompensateColor() {
     int64_t ncl = 0;
-    tf_check(tf_color_compensate(vol, (int64_t)np, fid.data(), wrong.data(), adj.data(), voff.data(), tex.data(),
-                                 mesh.data(), labs.data(), &ncl), "CompensateColor");
-    for (size_t p = 0; p < np; ++p) {
-      if (patches[p].has_adjusted || !adj[p]) continue;  // skipped, or its cluster had nothing to learn from
-      patches[p].has_adjusted = true;
-      if (patches[p].wrong_mapping) patches[p].labs.clear();  // :276-278
-      else patches[p].labs.assign(labs.begin() + 3 * voff[p], labs.begin() + 3 * voff[p + 1]);
-    }
+    tf_check(tf_compensate_color(vol, &ncl), "CompensateColor");
+    std::vector<int32_t> ids;
+    for (const auto& kv : chunkManager.GetAllMeshes())
+      if (kv.second->m_patch) { ids.push_back(kv.first(0)); ids.push_back(kv.first(1)); ids.push_back(kv.first(2)); }
+    RefreshPatches(ids, ids.size() / 3);
   }
 
-  // Chisel::DrawMeshes (Chisel.cpp:288-355): 12 floats per vertex + rebased indices for the meshes
-  // whose patch is complete() (here: a patch result exists, has texcoords and a source frame).
-  void DrawMeshes(const std::vector<PatchMesh>& meshes, const std::vector<PatchResult>& patches, float* vertices,
-                  unsigned int* indices, unsigned int& tsdf_indice_num, unsigned int& tsdf_vertice_num) {
-    const size_t np = patches.size();
-    tsdf_indice_num = tsdf_vertice_num = 0;
-    if (!np) return;
-    std::vector<uint8_t> complete(np), wrong(np), lv(np);
-    std::vector<uint64_t> texloc(np);
-    std::vector<float> ratio(2 * np), verts, cols, nrm, tc, tcol, labs;
-    std::vector<int64_t> voff(np + 1, 0), ioff(np + 1, 0);
-    std::vector<uint32_t> idx;
-    for (size_t p = 0; p < np; ++p) {
-      const PatchResult& r = patches[p];
-      const PatchMesh& m = meshes[p];
-      const size_t nv = m.vertices.size() / 3;
-      complete[p] = (nv > 0 && r.texcoord.size() == 2 * nv && r.frameid >= 0) ? 1 : 0;  // Patch::complete (Patch.cpp:191-196)
-      wrong[p] = r.wrong_mapping ? 1 : 0;
-      lv[p] = (r.has_adjusted && r.labs.size() == 3 * nv) ? 1 : 0;
-      texloc[p] = r.texloc;
-      ratio[2 * p] = r.ratio[0];
-      ratio[2 * p + 1] = r.ratio[1];
-      verts.insert(verts.end(), m.vertices.begin(), m.vertices.end());
-      cols.insert(cols.end(), m.colors.begin(), m.colors.end());
-      nrm.insert(nrm.end(), m.normals.begin(), m.normals.end());
-      nrm.resize(verts.size(), 0.0f);
-      tc.insert(tc.end(), r.texcoord.begin(), r.texcoord.end());
-      tc.resize(verts.size() / 3 * 2, 0.0f);
-      tcol.insert(tcol.end(), r.texcolor.begin(), r.texcolor.end());
-      tcol.resize(verts.size(), 0.0f);
-      if (lv[p]) labs.insert(labs.end(), r.labs.begin(), r.labs.end());
-      labs.resize(verts.size(), 0.0f);
-      idx.insert(idx.end(), m.indices.begin(), m.indices.end());
-      voff[p + 1] = (int64_t)verts.size() / 3;
-      ioff[p + 1] = (int64_t)idx.size();
+  // Structure/Chisel.cpp:191-196
+  void UpdateAtlas(ChunkIDList& chunksToUpdate) {
+    const size_t n = chunksToUpdate.size();
+    std::vector<int32_t> ids(n * 3 + 3);
+    for (size_t i = 0; i < n; ++i)
+      for (int a = 0; a < 3; ++a) ids[3 * i + a] = chunksToUpdate[i](a);
+    tf_check(tf_update_atlas(vol, ids.data(), (int64_t)n), "UpdateAtlas");
+    RefreshPatches(ids, n);  // Patch::ratio is written by Atlas::UpdateBuffer
+  }
+
+  // Structure/Chisel.cpp:288-355.  The caller's buffers must hold the whole model, as in the reference
+  // (MobileFusion.h:109-178 reserves 30 M vertices).
+  void DrawMeshes(float* vertices, unsigned int* indices, unsigned int& tsdf_indice_num, unsigned int& tsdf_vertice_num,
+                  int64_t cap_vertices = (int64_t)1 << 40, int64_t cap_indices = (int64_t)1 << 40) {
+    int64_t nv = 0, ni = 0;
+    tf_check(tf_draw_meshes(vol, vertices, indices, cap_vertices, cap_indices, &nv, &ni), "DrawMeshes");
+    tsdf_vertice_num = (unsigned int)nv;
+    tsdf_indice_num = (unsigned int)ni;
+    for (auto& kv : chunkManager.GetAllMutableMeshes())
+      if (kv.second->m_patch && kv.second->m_patch->complete()) kv.second->m_patch->has_updated = true;  // :351
+  }
+
+  // Patch::texcoord / texcolor / labs of one chunk into the mirror
+  void FetchPatchData(const ChunkID& id) {
+    MeshPtr& m = chunkManager.GetMutableMesh(id);
+    if (!m->m_patch) return;
+    const int64_t voff[2] = {0, m->n_vertices};
+    std::vector<float> tc((size_t)m->n_vertices * 2 + 2), tcol((size_t)m->n_vertices * 3 + 3), labs(tcol.size());
+    tf_check(tf_patches_download(vol, id.v, 1, voff, nullptr, nullptr, nullptr, nullptr, nullptr, tc.data(), tcol.data(),
+                                 labs.data()), "FetchPatchData");
+    Patch& p = *m->m_patch;
+    p.texcoord.clear(); p.texcolor.clear(); p.labs.clear();
+    for (int i = 0; i < p.n_texcoord; ++i) {
+      p.texcoord.emplace_back(tc[2 * i], tc[2 * i + 1]);
+      p.texcolor.emplace_back(tcol[3 * i], tcol[3 * i + 1], tcol[3 * i + 2]);
+      if (!p.labs_empty) p.labs.emplace_back(labs[3 * i], labs[3 * i + 1], labs[3 * i + 2]);
     }
-    idx.resize(idx.size() + 1);
-    int64_t nv_out = 0, ni_out = 0;
-    tf_check(tf_pack_vertices(vol, (int64_t)np, complete.data(), wrong.data(), lv.data(), texloc.data(), ratio.data(),
-                              voff.data(), verts.data(), cols.data(), nrm.data(), tc.data(), tcol.data(), labs.data(),
-                              ioff.data(), idx.data(), vertices, indices, &nv_out, &ni_out), "DrawMeshes");
-    tsdf_vertice_num = (unsigned int)nv_out;
-    tsdf_indice_num = (unsigned int)ni_out;
   }
 
   ChunkID maxChunkID, minChunkID;
@@ -527,9 +619,41 @@ class Chisel {
     if (ids_buf.size() < l.size() * 3) ids_buf.resize(l.size() * 3);
     for (size_t i = 0; i < l.size(); ++i) { ids_buf[3 * i] = l[i](0); ids_buf[3 * i + 1] = l[i](1); ids_buf[3 * i + 2] = l[i](2); }
   }
+  // Patch members of the listed chunks' meshes from the device (Mesh::m_patch is created by Atlas::AddPatch)
+  void RefreshPatches(const std::vector<int32_t>& ids3, size_t n) {
+    if (!n) return;
+    std::vector<uint64_t> texloc(n);
+    std::vector<int32_t> frameid(n), bbox(4 * n), flags(n);
+    std::vector<float> ratio(2 * n);
+    for (size_t i = 0; i < n; ++i) {  // per chunk: listed chunks without a mesh are skipped by the path
+      const ChunkID id(ids3[3 * i], ids3[3 * i + 1], ids3[3 * i + 2]);
+      if (!chunkManager.HasMesh(id)) continue;
+      const int rc = tf_patches_download(vol, &ids3[3 * i], 1, nullptr, &texloc[i], &frameid[i], &bbox[4 * i], &flags[i],
+                                         &ratio[2 * i], nullptr, nullptr, nullptr);
+      if (rc == TF_ERR_MISSING_CHUNK) continue;
+      tf_check(rc, "RefreshPatches");
+      if (!(flags[i] & TF_PATCH_HAS_PATCH)) continue;
+      MeshPtr& m = chunkManager.GetMutableMesh(id);
+      if (!m->m_patch) m->m_patch = std::make_shared<Patch>(m.get());
+      Patch& p = *m->m_patch;
+      p.texloc = (std::size_t)texloc[i];
+      p.frameid = frameid[i];
+      p.boundingbox.x = bbox[4 * i]; p.boundingbox.y = bbox[4 * i + 1];
+      p.boundingbox.width = bbox[4 * i + 2]; p.boundingbox.height = bbox[4 * i + 3];
+      p.wrong_mapping = (flags[i] & TF_PATCH_WRONG_MAPPING) != 0;
+      p.has_image = (flags[i] & TF_PATCH_HAS_IMAGE) != 0;
+      p.has_adjusted = (flags[i] & TF_PATCH_HAS_ADJUSTED) != 0;
+      p.ratio = Vec2(ratio[2 * i], ratio[2 * i + 1]);
+      p.n_texcoord = p.has_image ? m->n_vertices : 0;
+      p.labs_empty = !(p.has_adjusted && !p.wrong_mapping && p.n_texcoord > 0);
+      p.texcoord.clear(); p.texcolor.clear(); p.labs.clear();
+    }
+  }
   tf_volume* vol = nullptr;
   float res = 0.005f;
   bool meshes_stale = true;
+  std::unordered_map<int, const unsigned char*> cached_kf;
+  std::unordered_map<int, std::vector<float>> pose_set;
   std::vector<int32_t> ids_buf;
   std::vector<uint8_t> new_buf, needs_buf;
   std::vector<float> qual_buf;
