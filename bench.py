@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""Headline benchmark: RGB-D frames/s of the fused voxel-fusion unit on MI355X.
+"""Headline benchmark: RGB-D frames/s of the textured per-frame unit on MI355X (BASELINE.json configs[2]).
 
 One "step" = one synthetic 640x480 RGB-D frame of the S-room stream through
-prepare -> integrate(depth+colour) -> finalize (Chisel::IntegrateDepthScanColor 5-arg,
-Structure/Chisel.h:453-468) at 5 mm voxels, frames already resident in HBM.
+  prepare -> integrate(depth+colour) -> finalize          Chisel::IntegrateDepthScanColor 5-arg, Structure/Chisel.h:453-468
+  -> UpdateMeshes -> CompressMeshes                        over that frame's dirty chunks (Structure/Chisel.h:479-481, Chisel.cpp:112-147)
+  -> GeneratePatches(label = this frame) -> UpdateAtlas    Structure/Chisel.cpp:149-196
+at 5 mm voxels, frames already resident in HBM, nothing copied back, no host synchronisation inside the
+timed region (tf_stream_frames_textured_device).  --mode tsdf runs configs[1] (atlas off).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -11,8 +14,8 @@ Structure/Chisel.h:453-468) at 5 mm voxels, frames already resident in HBM.
 
 Rank 0 prints ONE JSON line (metric/value/... + "roofline" + "cpu_baseline").
 N > 1: one process per GPU, static chunk-range partition of ONE stream (slabs of the key x + y + z) -- every
-rank sees every frame, selects and integrates only the chunks of its slab ("strong" scaling), and
-the ranks all-gather their updated boundary chunks over RCCL every --exchange-every frames.
+rank sees every frame, selects / integrates / meshes / textures only the chunks of its slab ("strong"
+scaling); the ranks all-gather the chunks of their ghost bands over RCCL.
 """
 from __future__ import annotations
 
@@ -29,6 +32,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+STEP_KERNELS = ("integrate", "dirty", "mesh", "finalize", "patch_rank", "patch_project")
 
 
 def parse():
@@ -37,17 +41,28 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--res", type=float, default=0.005)
-    ap.add_argument("--hires", action="store_true", help="1280x960 camera (config 4)")
+    ap.add_argument("--mode", choices=("textured", "tsdf"), default="textured",
+                    help="textured = BASELINE configs[2] (TSDF + mesh + atlas per frame); tsdf = configs[1]")
+    ap.add_argument("--hires", action="store_true", help="1280x960 camera (configs[3])")
+    ap.add_argument("--scene", choices=("room", "big"), default="room",
+                    help="room = S-room 4x3x4 m; big = 8x6x8 m hall, walls at 3-4 m (configs[3] HBM stress)")
     ap.add_argument("--unique-frames", type=int, default=200, help="distinct frames of the orbit kept in HBM")
-    ap.add_argument("--exchange-every", type=int, default=40, help="N>1: boundary all-gather period (frames)")
-    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--exchange-every", type=int, default=40, help="N>1, --mode tsdf: boundary all-gather period (frames)")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-warmup", type=int, default=24, help="untimed frames that build up the CPU baseline's volume")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's parallel_for policy")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the host-frames (H2D per frame) measurement")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N>1 code path (partition + boundary all-gather) even with one rank (smoke test)")
-    ap.add_argument("--atlas-every", type=int, default=0,
-                    help="N>0: every N frames run GeneratePatches+UpdateAtlas on that frame (BASELINE configs[2])")
     return ap.parse_args()
+
+
+def make_frame(k, cam, args):
+    from texturefusion_amd import synth
+    if args.scene == "big":
+        return synth.room_frame(k, cam, half=(4.0, 3.0, 4.0), radius=0.5, with_quality=False)
+    return synth.room_frame(k, cam, with_quality=False)
 
 
 def main():
@@ -83,41 +98,23 @@ def main():
     cam = synth.Camera.hires() if args.hires else synth.Camera()
     res = np.float32(args.res)
     K, Wm = args.steps, args.warmup
-    n_unique = max(1, min(args.unique_frames, K + Wm))
+    n_unique = max(1, min(args.unique_frames, 3 * K + Wm + 4))
+    textured = args.mode == "textured" and not multi
 
     # ---- synthetic stream, generated once and parked in HBM -------------------------------
-    frames = [synth.room_frame(k, cam, with_quality=False) for k in range(n_unique)]
+    frames = [make_frame(k, cam, args) for k in range(n_unique)]
     d_depth = [torch.from_numpy(f[0]).to(dev) for f in frames]
     d_rgba = [torch.from_numpy(f[1]).to(dev) for f in frames]
     poses = np.stack([f[3].reshape(12) for f in frames]).astype(np.float32)
+    pinv = np.stack([synth.pose_inverse16(f[3]) for f in frames]).astype(np.float32)
     torch.cuda.synchronize()
 
-    # N > 1: the volume runs on a torch stream so that the boundary exchange (its own stream) can be
-    # ordered against it with events and overlap the next frame batch
     s_main = torch.cuda.Stream(device=dev) if multi else None
     s_xchg = torch.cuda.Stream(device=dev) if multi else None
-    vol = capi.Volume(res, cam, max_chunks=1 << 19, max_list=1 << 18, device=local_rank,
+    big = args.scene == "big"
+    vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+                      max_coarse=1 << 22 if big else 1 << 20, device=local_rank,
                       stream=s_main.cuda_stream if multi else None)
-    # atlas leg: keyframe = every --atlas-every-th frame; its per-chunk meshes are depth-derived
-    # vertex clouds (meshing is the next-stage scope), its RGB / depth are already in HBM
-    atlas = {}
-    if args.atlas_every > 0 and not multi:
-        for i in range(0, n_unique, args.atlas_every):
-            rgb = torch.from_numpy(np.ascontiguousarray(frames[i][1][..., :3])).to(dev)
-            ids, voff, verts, cols = synth.mesh_from_depth(frames[i][0], frames[i][1], frames[i][3], cam, res, 4)
-            # the per-chunk meshes are inputs of the atlas stage: resident in HBM like the frames, and
-            # the per-vertex / per-patch results stay there (tf_patches_update_device, asynchronous)
-            nv = int(voff[-1])
-            atlas[i] = dict(rgb=rgb, ids=ids, voff=voff, verts=verts, cols=cols,
-                            kf=np.full(len(ids), i, np.int32),
-                            T=np.tile(synth.pose_inverse16(frames[i][3]), (len(ids), 1)),
-                            d_verts=torch.from_numpy(np.ascontiguousarray(verts, np.float32)).to(dev),
-                            d_cols=torch.from_numpy(np.ascontiguousarray(cols, np.float32)).to(dev),
-                            d_tc=torch.empty(max(nv, 1) * 2, dtype=torch.float32, device=dev),
-                            d_tcol=torch.empty(max(nv, 1) * 3, dtype=torch.float32, device=dev),
-                            d_po=torch.empty(max(len(ids), 1) * 8, dtype=torch.int32, device=dev))
-            vol.keyframe_cache_device(i, rgb.data_ptr(), d_depth[i].data_ptr())
-        torch.cuda.synchronize()
     if multi:
         # Ownership key x + y + z: axis-aligned walls and floors are cut diagonally, so no rank holds a
         # whole wall.  Slab edges split the chunk keys of eight sample frames spread over the orbit into
@@ -126,7 +123,7 @@ def main():
         axis = (1, 1, 1)
         keys = []
         for i in range(0, 200, 25):
-            f = frames[i % n_unique] if i < n_unique else synth.room_frame(i, cam, with_quality=False)
+            f = frames[i % n_unique] if i < n_unique else make_frame(i, cam, args)
             vol.frame_upload(f[0], None, None)
             ids_s, _ = vol.prepare(f[3])
             keys.append(part.key_of(ids_s, axis))
@@ -165,34 +162,20 @@ def main():
         if len(keep) > 2:
             keep.pop(0)
 
-    def run(first, count, timed):
-        """Frames [first, first+count) of the stream (cyclic over the unique frames)."""
-        idx = [(first + i) % n_unique for i in range(count)]
-        if not multi and atlas:
-            b0 = 0
-            for j, i in enumerate(idx):
-                if i in atlas:  # flush the frames up to and including the keyframe, then texture it
-                    sub = idx[b0:j + 1]
-                    vol.integrate_frames_device([d_depth[k].data_ptr() for k in sub],
-                                                [d_rgba[k].data_ptr() for k in sub], poses[sub])
-                    a = atlas[i]
-                    rc, _, _ = vol.patches_update_device(a["ids"], a["kf"], a["T"], a["voff"], a["d_verts"].data_ptr(),
-                                                         a["d_cols"].data_ptr(), a["d_tc"].data_ptr(),
-                                                         a["d_tcol"].data_ptr(), a["d_po"].data_ptr())
-                    if rc != 0:
-                        raise SystemExit("atlas full")
-                    b0 = j + 1
-            sub = idx[b0:]
-            if sub:
-                vol.integrate_frames_device([d_depth[k].data_ptr() for k in sub],
-                                            [d_rgba[k].data_ptr() for k in sub], poses[sub])
+    def run(first, count, ahead=2):
+        """Frames [first, first+count) of the stream (cyclic over the unique frames); the next `ahead` frames go
+        through their selection stages too, so that a following run(first + count, ...) starts primed."""
+        idx = [(first + i) % n_unique for i in range(count + ahead)]
+        dd = [d_depth[i].data_ptr() for i in idx]
+        dr = [d_rgba[i].data_ptr() for i in idx]
+        if textured:
+            vol.stream_frames_textured_device(dd, dr, poses[idx], pinv[idx], first, n_ahead=ahead)
         elif not multi:
-            vol.integrate_frames_device([d_depth[i].data_ptr() for i in idx],
-                                        [d_rgba[i].data_ptr() for i in idx], poses[idx])
+            vol.stream_frames_device(dd, dr, poses[idx], n_ahead=ahead)
         else:
             pending = None
             for k, b in enumerate(range(0, count, args.exchange_every)):
-                sub = idx[b:b + args.exchange_every]
+                sub = idx[b:min(b + args.exchange_every, count)]
                 vol.integrate_frames_device([d_depth[i].data_ptr() for i in sub],
                                             [d_rgba[i].data_ptr() for i in sub], poses[sub])
                 nxt = start_exchange(k & 1)
@@ -207,12 +190,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up, then the timed region ---------------------------------------------------
-    run(0, Wm, False)
+    # ---- warm-up, then the timed region (the launch pipeline stays primed across the boundary) ---
+    run(0, Wm)
     vol.sync()
     barrier()
     t0 = time.perf_counter()
-    run(Wm, K, True)
+    run(Wm, K)
     t_enq = time.perf_counter() - t0  # host time to enqueue the timed region (launches are asynchronous)
     barrier()
     dt = time.perf_counter() - t0
@@ -222,24 +205,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # ---- instrumented repeat of the same K frames: HIP events (on the handle's stream) around
-    # every launch of the dominant kernel.  Kept out of the timed region above because the event
-    # pairs cost ~10 % throughput; the per-launch duration is what the roofline needs.
+    # ---- instrumented repeat of the next K frames: HIP events (on the handle's stream) around every
+    # kernel of the step.  Kept out of the timed region above because the event pairs cost throughput;
+    # the per-launch durations are what the roofline needs.
     prof = None
     dt_instr = None
+    kinds = STEP_KERNELS if textured else ("integrate",)
     if not args.no_roofline:
-        vol.profile_enable(["integrate"])
+        vol.profile_enable(kinds)
         barrier()
         t1 = time.perf_counter()
-        run(Wm + K, K, False)
+        run(Wm + K, K)
         barrier()
         dt_instr = time.perf_counter() - t1
         prof = vol.profile_get(reset=True)
         vol.profile_enable([])
         vol.sync()
 
+    what = ("TSDF integrate + mesh + atlas update per frame (BASELINE.json configs[%d])" % (3 if args.hires or big else 2)
+            if textured else "TSDF integrate, atlas off (BASELINE.json configs[%d])" % (4 if multi else (3 if args.hires or big else 1)))
     out = {
-        "metric": "RGB-D frames/s (TSDF integrate, depth+colour, fused prepare->integrate->finalize)",
+        "metric": ("RGB-D frames/s (TSDF integrate + atlas update: prepare->integrate->finalize, UpdateMeshes, "
+                   "GeneratePatches + UpdateAtlas over the frame's dirty chunks)" if textured else
+                   "RGB-D frames/s (TSDF integrate, depth+colour, fused prepare->integrate->finalize)"),
         "value": K / dt,
         "unit": "frames/s",
         "n_gpus": world,
@@ -253,52 +241,27 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "S-room orbit stream, %dx%d RGB-D, %.0f mm voxels, 8^3 chunks, TSDF+colour integrate, %s; "
-                        "frames resident in HBM"
-                        % (cam.width, cam.height, 1e3 * float(res),
-                           ("atlas patch update every %d frames (BASELINE.json configs[2])" % args.atlas_every)
-                           if atlas else "atlas off (BASELINE.json configs[1])"),
+            "workload": "%s orbit stream, %dx%d RGB-D, %.0f mm voxels, 8^3 chunks, %s; frames resident in HBM"
+                        % ("S-hall 8x6x8 m" if big else "S-room 4x3x4 m", cam.width, cam.height, 1e3 * float(res), what),
             "frames_in_hbm": n_unique,
             "parallelism": ("1 GPU" if world == 1 else
-                            "%d ranks, ChunkID.x slab partition of one stream, boundary all-gather every %d frames"
+                            "%d ranks, chunk-range slabs of the key x+y+z of one stream, boundary all-gather every %d frames"
                             % (world, args.exchange_every)),
         },
     }
 
-    # ---- roofline of the dominant kernel (k_integrate) ------------------------------------
+    # ---- roofline over ALL kernels of a step ------------------------------------------------
     if rank == 0 and prof is not None:
-        # Algorithmic bytes per launch (SURVEY.md s.8d / DESIGN.md): 128 B per rewritten TSDF row
-        # (8 voxels x {sdf,weight} read+write), 128 B per rewritten colour row, plus one read of
-        # the depth and RGBA images.  Row counts depend only on (depth, pose): replay the timed
-        # frames untimed and read the exact integers back.
-        ka_ms, ka_n = prof["integrate"]
-        algo = 0
-        idx = [(Wm + K + i) % n_unique for i in range(K)]
-        rows_cache = {}
-        for i in sorted(set(idx)):
-            vol.frame_bind_device(d_depth[i].data_ptr(), d_rgba[i].data_ptr(), 0)
-            vol.integrate_frame(poses[i], True)
-            st = vol.stats()
-            rows_cache[i] = (st.rows_tsdf, st.rows_color, st.n_selected, st.n_updated)
-        for i in idx:
-            rt, rc, _, _ = rows_cache[i]
-            algo += 128 * rt + 128 * rc + 8 * cam.width * cam.height
-        per_launch = algo / max(ka_n, 1)
-        avg_s = 1e-3 * ka_ms / max(ka_n, 1)
-        achieved = per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-        traffic, traffic_src = pmc_traffic(args)
-        out["roofline"] = {
-            "bound": "hbm", "kernel": "k_frame<color> = K-A(f) + K-C(f+1) + K-B(f+2) block ranges; bytes counted for K-A only", "achieved": achieved, "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": per_launch, "avg_launch_us": 1e6 * avg_s, "launches": ka_n,
-            "instrumented_ms_per_step": 1e3 * dt_instr / K,
-            "chunks_selected_avg": float(np.mean([rows_cache[i][2] for i in idx])),
-            "chunks_updated_avg": float(np.mean([rows_cache[i][3] for i in idx])),
-        }
+        out["roofline"] = roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, poses, pinv, textured,
+                                   dt_instr)
 
-    # ---- CPU baseline: the oracle (scalar port of the reference path) on the host cores ------
+    # ---- the drop-in per-frame path: host images in, one call per frame (H2D included) ---------
+    if rank == 0 and not multi and not args.no_host_path:
+        out["host_frames"] = host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique)
+
+    # ---- CPU baseline: the oracle (C port of the reference path) on the host cores ------------
     if rank == 0 and args.cpu_frames > 0:
-        out["cpu_baseline"] = cpu_baseline(args, cam, res, frames, Wm, n_unique, atlas)
+        out["cpu_baseline"] = cpu_baseline(args, cam, res, frames, n_unique, textured)
 
     if rank == 0:
         print(json.dumps(out))
@@ -307,93 +270,144 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary of this very
-    command (FETCH_SIZE and WRITE_SIZE need separate --pmc passes, so they cannot be collected inside a
-    timed run): raw FETCH_SIZE + WRITE_SIZE, KiB -> bytes.  The gfx950 x2 correction of FETCH_SIZE applies
-    to 16-B-per-lane streaming reads only; this kernel reads 8 B and 4 B per lane, so the raw value is
-    reported (a lower bound).  None when the workload is not the profiled one."""
-    if args.hires or args.atlas_every or args.gpus > 1 or abs(args.res - 0.005) > 1e-9:
-        return None, None
-    path = os.path.join(ROOT, "profiles", "r1", "05_pmc_k_frame.csv")
-    try:
-        vals = {}
-        for line in open(path).read().splitlines()[1:]:
-            k, v, _ = line.split(",")
-            vals[k] = float(v)
-        return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, "profiles/r1/05_pmc_k_frame.csv (raw FETCH_SIZE + WRITE_SIZE, separate --pmc passes)"
-    except Exception:
-        return None, None
+def roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, poses, pinv, textured, dt_instr):
+    """Algorithmic bytes of a step / summed kernel time of a step (HIP events of this run).
+
+    Bytes: voxel update 128 B per rewritten TSDF row + 128 B per rewritten colour
+    row + one read of the depth and RGBA images; meshing 4 KiB (the chunk's own sdf/weight plane) per dirty
+    chunk + 6552 B (the 11^3 - 8^3 halo voxels) per chunk that yields a mesh + 8 B colour read and 36 B written
+    per vertex + 6 B per triangle; atlas 44 B per projected vertex (24 read, 20 written) + 3 B read and 3 B
+    written per ROI pixel.  The integer counts depend only on the stream: the instrumented frames are replayed
+    one by one (untimed) and the exact integers read back after each."""
+    idx = [(Wm + 2 * K + i) % n_unique for i in range(K)]
+    b_tsdf = b_mesh = b_atlas = 0
+    cnt = dict(sel=0, upd=0, dirty=0, meshes=0, verts=0, tris=0, roi=0, patches=0)
+    first = Wm + 2 * K
+    for j, i in enumerate(idx):
+        i1, i2 = (first + j + 1) % n_unique, (first + j + 2) % n_unique
+        sub = [i, i1, i2]
+        dd = [d_depth[q].data_ptr() for q in sub]
+        dr = [d_rgba[q].data_ptr() for q in sub]
+        if textured:
+            vol.stream_frames_textured_device(dd, dr, poses[sub], pinv[sub], first + j, n_ahead=2)
+        else:
+            vol.stream_frames_device(dd, dr, poses[sub], n_ahead=2)
+        st = vol.stats()
+        b_tsdf += 128 * st.rows_tsdf + 128 * st.rows_color + 8 * cam.width * cam.height
+        cnt["sel"] += st.n_selected
+        cnt["upd"] += st.n_updated
+        if textured:
+            ts = vol.texture_stats()
+            b_mesh += 4096 * ts.n_dirty + 6552 * ts.n_meshes + 44 * ts.n_vertices + 6 * ts.n_triangles
+            b_atlas += 44 * ts.n_vertices + 6 * ts.roi_pixels
+            for k, v in (("dirty", ts.n_dirty), ("meshes", ts.n_meshes), ("verts", ts.n_vertices),
+                         ("tris", ts.n_triangles), ("roi", ts.roi_pixels), ("patches", ts.n_patches)):
+                cnt[k] += v
+    per_kernel = {}
+    t_step = 0.0
+    for k in kinds:
+        ms, n = prof[k]
+        if n:
+            per_kernel[k] = {"us_per_step": 1e3 * ms / K, "launches_per_step": n / K}
+            t_step += 1e-3 * ms / K
+    bytes_step = (b_tsdf + b_mesh + b_atlas) / K
+    achieved = bytes_step / t_step / 1e9 if t_step > 0 else 0.0
+    group = {"integrate": b_tsdf / K, "mesh": b_mesh / K, "patch_project": b_atlas / K}
+    for k, b in group.items():
+        if k in per_kernel and per_kernel[k]["us_per_step"] > 0:
+            per_kernel[k]["algorithmic_bytes_per_step"] = b
+            per_kernel[k]["achieved_GBs"] = b / per_kernel[k]["us_per_step"] / 1e3
+    return {
+        "bound": "hbm",
+        "kernel": ("all kernels of a step: k_frame (K-A + K-C + K-B roles), k_dirty_frame, k_mesh, k_compress_exchange, "
+                   "k_patch_collect + k_patch_rank, k_patch (project + blit)" if textured else
+                   "k_frame<color> = K-A(f) + K-C(f+1) + K-B(f+2) block ranges"),
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "traffic_note": "HBM counters need separate rocprofv3 --pmc passes: see profiles/r2/ for the collected FETCH_SIZE / WRITE_SIZE",
+        "algorithmic_bytes_per_step": bytes_step, "kernel_us_per_step": 1e6 * t_step,
+        "kernels": per_kernel,
+        "instrumented_ms_per_step": 1e3 * dt_instr / K,
+        "per_step": {k: v / K for k, v in cnt.items()},
+    }
 
 
-def cpu_baseline(args, cam, res, frames, Wm, n_unique, atlas=None):
-    """oracle/ timed on a bounded sample of the same workload: same warm-up frames (untimed),
-    then the next --cpu-frames frames of the stream."""
+def host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique):
+    """The reference's calling convention: one call per frame with HOST images (MobileFusion::IntegrateFrame,
+    GCFusion/MobileFusion.cpp:223-250): double-buffered pinned staging, H2D of frame f+1 overlapped with the
+    kernels of frame f.  PCIe-inclusive; never the headline value."""
+    n = min(K, 100)
+    first = Wm + 3 * K
+    idx = [(first + i) % n_unique for i in range(n)]
+    for i in idx[:4]:  # warm the staging path
+        f = frames[i]
+        vol.integrate_frame_host(f[0], f[1], poses[i], pinv[i] if textured else None, i)
+    vol.sync()
+    t0 = time.perf_counter()
+    for j, i in enumerate(idx):
+        f = frames[i]
+        vol.integrate_frame_host(f[0], f[1], poses[i], pinv[i] if textured else None, first + j)
+    vol.sync()
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "frames": n,
+            "note": "tf_integrate_frame_host: host depth + RGBA in, H2D (3.7 MB at 640x480) inside the timed region, "
+                    "one call per frame, one synchronisation at the end"}
+
+
+def cpu_baseline(args, cam, res, frames, n_unique, textured):
+    """oracle/ timed on a bounded sample of the same workload: --cpu-warmup untimed frames build up the volume
+    (meshes need weight > 50), then the next --cpu-frames frames of the stream are timed."""
     from oracle import api as O
+    from texturefusion_amd import synth
     ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
     avx2 = bool(O.lib().tfo_have_avx2())
     ov.set_kernel(1 if avx2 else 0)  # AVX2 row kernel (as the reference's), bit-identical to the scalar checker
     ncpu = os.cpu_count() or 1
-    for i in range(min(Wm, 5)):  # a short warm-up bounds the CPU time; state is first-touch either way
-        f = frames[i % n_unique]
-        ov.integrate_frame(f[0], f[1], f[3])
-    n = args.cpu_frames
-    oa = O.Atlas(res) if atlas else None   # --atlas-every: GeneratePatches + UpdateAtlas on the keyframes, serial as in the reference
-    seen = {}
-    n_kf = 0
-    sel = []
-    # thread policy of chisel::parallel_for (threading/Threading.h:36-54)
-    t_all = 0.0
-    threads_used = []
-    for i in range(n):
-        f = frames[(Wm + i) % n_unique]
-        if args.cpu_threads > 0:
-            T = args.cpu_threads
+    oa = O.Atlas(res) if textured else None
+    T = args.cpu_threads if args.cpu_threads > 0 else max(1, ncpu - 2)  # chisel::parallel_for: hardware_concurrency - 2,
+    ov.set_threads(T)                                                    # groups of >= 1000 items (applied per call inside)
+
+    def step(k):
+        f = frames[k % n_unique]
+        if textured:
+            ov.frame_textured(oa, f[0], f[1], f[3], synth.pose_inverse16(f[3]), k)
         else:
-            nsel = sel[-1] if sel else 8000
-            T = max(1, min(ncpu - 2, -(-nsel // 1000)))
-        ov.set_threads(T)
-        threads_used.append(T)
-        t0 = time.perf_counter()
-        _, ns = ov.integrate_frame(f[0], f[1], f[3])
-        fi = (Wm + i) % n_unique
-        if atlas and fi in atlas:
-            a = atlas[fi]
-            rgb = np.ascontiguousarray(f[1][..., :3])
-            Cc = O.camera_from(cam)
-            tls = []
-            for p in range(len(a["ids"])):
-                key = tuple(int(x) for x in a["ids"][p])
-                if key not in seen:
-                    rc, seen[key] = oa.alloc()
-                tls.append(seen[key])
-            oa.patches_batch(tls, a["voff"], a["verts"], a["cols"], a["T"], rgb, f[0], Cc)
-            n_kf += 1
-        t_all += time.perf_counter() - t0
-        sel.append(ns)
-    # single-thread figure on a shorter sample
-    ov1 = O.Volume(res, O.camera_from(cam), O.default_integrator())
-    ov1.set_kernel(1 if avx2 else 0)
-    ov1.set_threads(1)
-    n1 = max(1, n // 4)
-    t1 = 0.0
-    for i in range(n1):
-        f = frames[(Wm + i) % n_unique]
-        t0 = time.perf_counter()
-        ov1.integrate_frame(f[0], f[1], f[3])
-        t1 += time.perf_counter() - t0
-    return {
-        "value": n / t_all, "unit": "frames/s", "cores": int(round(float(np.mean(threads_used)))),
+            ov.integrate_frame(f[0], f[1], f[3])
+
+    for k in range(args.cpu_warmup):
+        step(k)
+    n = args.cpu_frames
+    t0 = time.perf_counter()
+    for k in range(args.cpu_warmup, args.cpu_warmup + n):
+        step(k)
+    t_all = time.perf_counter() - t0
+    # TSDF-only figure of the same port (1 thread and the reference policy) on a shorter sample
+    out = {
+        "value": n / t_all, "unit": "frames/s", "cores": T,
         "kind": "port",
-        "sample": "oracle/ C port of the reference path (%s voxel kernel, no FMA; selection scalar, 1 thread) on "
-                  "frames %d..%d of the same S-room stream; integrate threads = reference parallel_for policy "
-                  "min(hw-2, ceil(N/1000)); host has %d logical cores%s"
-                  % ("AVX2 8-lane" if avx2 else "scalar", Wm, Wm + n - 1, ncpu,
-                     ("; %d keyframes of the sample also ran GeneratePatches + UpdateAtlas (1 thread, as the reference)" % n_kf)
-                     if atlas else ""),
-        "value_1thread": n1 / t1,
+        "sample": "oracle/ C port of the reference path (%s voxel kernel, no FMA; selection scalar, 1 thread; %s) on frames "
+                  "%d..%d of the same stream after %d untimed frames; parallel stages use chisel::parallel_for's policy "
+                  "(hardware_concurrency - 2 = %d threads, groups of >= 1000 items); host has %d logical cores"
+                  % ("AVX2 8-lane" if avx2 else "scalar",
+                     "UpdateMeshes parallel, CompressMeshes / GeneratePatches / UpdateAtlas serial as in the reference" if textured
+                     else "atlas off",
+                     args.cpu_warmup, args.cpu_warmup + n - 1, args.cpu_warmup, T, ncpu),
         "host_cores": ncpu,
     }
+    if textured:
+        ov1 = O.Volume(res, O.camera_from(cam), O.default_integrator())
+        ov1.set_kernel(1 if avx2 else 0)
+        ov1.set_threads(T)
+        n1 = max(4, n // 4)
+        for k in range(4):
+            f = frames[k % n_unique]
+            ov1.integrate_frame(f[0], f[1], f[3])
+        t0 = time.perf_counter()
+        for k in range(4, 4 + n1):
+            f = frames[k % n_unique]
+            ov1.integrate_frame(f[0], f[1], f[3])
+        out["value_tsdf_only"] = n1 / (time.perf_counter() - t0)
+    return out
 
 
 if __name__ == "__main__":

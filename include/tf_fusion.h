@@ -191,6 +191,16 @@ TF_API int tf_stream_frames_device(tf_volume* v, int64_t n_frames, int64_t n_ahe
 TF_API int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int64_t n_ahead,
                                             const float* const* d_depth, const uint8_t* const* d_rgba,
                                             const float* poses12, const float* pose_inv16, int32_t first_frame_id);
+/* MobileFusion::IntegrateFrame (GCFusion/MobileFusion.cpp:223-250) as the reference calls it: HOST images in,
+ * one call per frame.  The images go through a ring of three pinned staging / device slots and are uploaded
+ * on a second stream, so the H2D of frame f + 1 overlaps the kernels of frame f and the call returns without
+ * synchronising (tf_sync / any state access waits).  pose_inv16 != NULL runs the textured unit
+ * (tf_stream_frames_textured_device's per-frame work) with Patch::frameid = frame_id; NULL = TSDF only.
+ * tf_host_frame_buffers hands out the pinned slot the NEXT call will upload from: a caller that composes its
+ * depth / RGBA images there (and passes these pointers) saves the staging copy. */
+TF_API int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgba, const float pose[12],
+                                   const float* pose_inv16, int32_t frame_id);
+TF_API int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba);
 TF_API int tf_sync(tf_volume* v);
 
 /* ---- state access (host mirrors of Chunk::voxels / colors, ChunkManager queries) -----

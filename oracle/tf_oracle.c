@@ -766,7 +766,12 @@ int tfo_integrate(tfo_volume* v, const float* depth, const uint8_t* rgba, const 
   if (n < 1) return 0;               /* :228 */
   int missing = 0;
   int64_t rt = 0, rc = 0, cu = 0;
-#pragma omp parallel for schedule(static) num_threads(v->nthreads) reduction(+ : missing, rt, rc, cu)
+  /* chisel::parallel_for (threading/Threading.h:36-54): groups of max(1000, N / nthreads) items, one
+   * thread per group -- with fewer than 1000 chunks the reference runs this loop on one thread */
+  int T = v->nthreads;
+  const int64_t groups = (n + 999) / 1000;
+  if (T > groups) T = (int)(groups > 0 ? groups : 1);
+#pragma omp parallel for schedule(static) num_threads(T) reduction(+ : missing, rt, rc, cu)
   for (int64_t i = 0; i < n; i++) {
     tfo_chunk* c = vol_get(v, ids + 3 * i);
     if (!c) { missing++; continue; } /* reference: chunks.at() would throw */
@@ -1532,16 +1537,46 @@ static void vol_meshes_clear(tfo_volume* v) {
  * vertices, and a mesh that is already there stays (possibly empty).  Returns the number of chunks
  * meshed. */
 int64_t tfo_update_meshes(tfo_volume* v) {
+  /* the dirty chunks that exist (:236-250) */
   int64_t n = 0;
-  float* vb = (float*)malloc(sizeof(float) * 9 * TFO_MESH_SLOTS);
-  uint32_t* ib = (uint32_t*)malloc(sizeof(uint32_t) * TFO_MESH_MAX_INDICES);
+  int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * 3 * (v->dirty.live ? v->dirty.live : 1));
   for (int64_t i = 0; i < v->dirty.cap; i++) {
     if (v->dirty.vals[i] < 0) continue;
     const int32_t* id = v->dirty.keys + 3 * i;
     if (!vol_get(v, id)) continue;
-    int64_t ni = 0;
-    const int64_t nv = tfo_mesh_chunk(v, id, vb, vb + 3 * TFO_MESH_SLOTS, vb + 6 * TFO_MESH_SLOTS, ib, &ni);
+    memcpy(ids + 3 * n, id, 12);
     n++;
+  }
+  /* parallel_for(meshes, GenerateMeshEfficient) (:256-259) with chisel::parallel_for's thread policy
+   * (threading/Threading.h:36-54: groups of max(1000, N / nthreads) items) */
+  typedef struct { int64_t nv, ni; float* vb; uint32_t* ib; } res_t;
+  res_t* R = (res_t*)calloc(n ? n : 1, sizeof(res_t));
+  int T = v->nthreads;
+  const int64_t by_group = (n + 999) / 1000;
+  if (T > by_group) T = (int)(by_group > 0 ? by_group : 1);
+#pragma omp parallel num_threads(T)
+  {
+    float* vb = (float*)malloc(sizeof(float) * 9 * TFO_MESH_SLOTS);
+    uint32_t* ib = (uint32_t*)malloc(sizeof(uint32_t) * TFO_MESH_MAX_INDICES);
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+      int64_t ni = 0;
+      const int64_t nv = tfo_mesh_chunk(v, ids + 3 * i, vb, vb + 3 * TFO_MESH_SLOTS, vb + 6 * TFO_MESH_SLOTS, ib, &ni);
+      R[i].nv = nv; R[i].ni = ni;
+      if (nv > 0) {
+        R[i].vb = (float*)malloc(sizeof(float) * 9 * nv);
+        memcpy(R[i].vb, vb, sizeof(float) * 3 * nv);
+        memcpy(R[i].vb + 3 * nv, vb + 3 * TFO_MESH_SLOTS, sizeof(float) * 3 * nv);
+        memcpy(R[i].vb + 6 * nv, vb + 6 * TFO_MESH_SLOTS, sizeof(float) * 3 * nv);
+        R[i].ib = (uint32_t*)malloc(sizeof(uint32_t) * (ni ? ni : 1));
+        memcpy(R[i].ib, ib, sizeof(uint32_t) * ni);
+      }
+    }
+    free(vb); free(ib);
+  }
+  for (int64_t i = 0; i < n; i++) { /* allMeshes[id] = mesh if it has vertices; an existing entry stays (:260-262) */
+    const int32_t* id = ids + 3 * i;
+    const int64_t nv = R[i].nv, ni = R[i].ni;
     struct tfo_mesh* m = vol_get_mesh(v, id);
     if (!m) {
       if (nv <= 0) continue;
@@ -1561,14 +1596,17 @@ int64_t tfo_update_meshes(tfo_volume* v) {
     m->normals = (float*)malloc(sizeof(float) * 3 * (nv ? nv : 1));
     m->colors = (float*)malloc(sizeof(float) * 3 * (nv ? nv : 1));
     m->indices = (uint32_t*)malloc(sizeof(uint32_t) * (ni ? ni : 1));
-    memcpy(m->verts, vb, sizeof(float) * 3 * nv);
-    memcpy(m->normals, vb + 3 * TFO_MESH_SLOTS, sizeof(float) * 3 * nv);
-    memcpy(m->colors, vb + 6 * TFO_MESH_SLOTS, sizeof(float) * 3 * nv);
-    memcpy(m->indices, ib, sizeof(uint32_t) * ni);
+    if (nv > 0) {
+      memcpy(m->verts, R[i].vb, sizeof(float) * 3 * nv);
+      memcpy(m->normals, R[i].vb + 3 * nv, sizeof(float) * 3 * nv);
+      memcpy(m->colors, R[i].vb + 6 * nv, sizeof(float) * 3 * nv);
+      memcpy(m->indices, R[i].ib, sizeof(uint32_t) * ni);
+    }
     memset(m->adj, 0, 6); /* Mesh::Clear (Mesh.h:52-68) */
     m->simplified = 0;
+    free(R[i].vb); free(R[i].ib);
   }
-  free(vb); free(ib);
+  free(R); free(ids);
   return n;
 }
 

@@ -39,7 +39,8 @@ SYMBOLS = (
     "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_meshes_upload",
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
     "tf_patches_download", "tf_atlas_download_rows", "tf_stream_frames_device",
-    "tf_stream_frames_textured_device", "tf_get_texture_stats",
+    "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host",
+    "tf_host_frame_buffers",
     "tf_update_meshes", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
 )
 
@@ -141,6 +142,8 @@ def lib():
     L.tf_stream_frames_textured_device.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(vp), C.POINTER(vp), fp, fp,
                                                    C.c_int32]
     L.tf_get_texture_stats.argtypes = [vp, C.POINTER(TextureStats)]
+    L.tf_integrate_frame_host.argtypes = [vp, fp, u8p, fp, fp, C.c_int32]
+    L.tf_host_frame_buffers.argtypes = [vp, C.POINTER(fp), C.POINTER(u8p)]
     L.tf_atlas_download_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p]
     u32p = C.POINTER(C.c_uint32)
     L.tf_update_meshes.argtypes = [vp, i64p]
@@ -295,6 +298,22 @@ class Volume:
         dr = (C.c_void_p * m)(*d_rgbas)
         self._ck(self.L.tf_stream_frames_textured_device(self.h, m - n_ahead, n_ahead, dd, dr, _p(poses, C.c_float),
                                                          _p(pose_inv, C.c_float), int(first_frame_id)))
+
+    def integrate_frame_host(self, depth, rgba, pose, pose_inv16=None, frame_id=0):
+        """MobileFusion::IntegrateFrame with host images (asynchronous; pose_inv16 = textured unit)."""
+        depth = _f32(depth)
+        rgba = None if rgba is None else np.ascontiguousarray(rgba, np.uint8)
+        pose = _f32(pose).reshape(12)
+        T = None if pose_inv16 is None else _f32(pose_inv16).reshape(16)
+        self._ck(self.L.tf_integrate_frame_host(self.h, _p(depth, C.c_float), _p(rgba, C.c_uint8), _p(pose, C.c_float),
+                                                _p(T, C.c_float), int(frame_id)))
+
+    def host_frame_buffers(self):
+        """numpy views (depth f32[H,W], rgba u8[H,W,4]) of the pinned slot the next integrate_frame_host uploads from."""
+        d, c = C.POINTER(C.c_float)(), C.POINTER(C.c_uint8)()
+        self._ck(self.L.tf_host_frame_buffers(self.h, C.byref(d), C.byref(c)))
+        H, W = self.cam.height, self.cam.width
+        return (np.ctypeslib.as_array(d, shape=(H, W)), np.ctypeslib.as_array(c, shape=(H, W, 4)))
 
     def sync(self):
         self._ck(self.L.tf_sync(self.h))

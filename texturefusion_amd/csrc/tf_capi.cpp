@@ -341,6 +341,13 @@ int tf_volume_destroy(tf_volume* v) {
   if (v->d_quality) hipFree(v->d_quality);
   if (v->d_tmp) hipFree(v->d_tmp);
   if (v->h_pinned) hipHostFree(v->h_pinned);
+  for (int k = 0; k < tf_volume::kHostRing; ++k) {
+    if (v->hslot[k].h) hipHostFree(v->hslot[k].h);
+    if (v->hslot[k].d) hipFree(v->hslot[k].d);
+    if (v->hslot[k].copied) hipEventDestroy(v->hslot[k].copied);
+    if (v->hslot[k].freed) hipEventDestroy(v->hslot[k].freed);
+  }
+  if (v->copy_stream) hipStreamDestroy(v->copy_stream);
   if (v->own_stream && v->stream) hipStreamDestroy(v->stream);
   delete v;
   return TF_OK;
@@ -724,6 +731,74 @@ int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int64_t n_a
   rc = enqueue_frames(v, n_frames, n_ahead, d_depth, d_rgba, poses12, &tex);
   if (rc) return rc;
   return tf_frame_bind_device(v, d_depth[n_frames - 1], d_rgba[n_frames - 1], nullptr);
+}
+
+// ring of staging slots of the per-frame host path, (re)sized to the camera
+static int host_ring_prepare(tf_volume* v) {
+  const size_t npix = (size_t)v->cam.W * v->cam.H;
+  if (v->hslot_pixels == npix && v->copy_stream) return TF_OK;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  if (!v->copy_stream) TF_HIP(hipStreamCreateWithFlags(&v->copy_stream, hipStreamNonBlocking));
+  TF_HIP(hipStreamSynchronize(v->copy_stream));
+  for (int k = 0; k < tf_volume::kHostRing; ++k) {
+    tf_volume::HostSlot& s = v->hslot[k];
+    if (s.h) hipHostFree(s.h);
+    if (s.d) hipFree(s.d);
+    s.h = nullptr; s.d = nullptr;
+    TF_HIP(hipHostMalloc((void**)&s.h, npix * 8, hipHostMallocDefault));
+    TF_HIP(hipMalloc((void**)&s.d, npix * 8));
+    if (!s.copied) TF_HIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
+    if (!s.freed) TF_HIP(hipEventCreateWithFlags(&s.freed, hipEventDisableTiming));
+  }
+  v->hslot_pixels = npix;
+  v->hslot_next = 0;
+  return TF_OK;
+}
+
+int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba) {
+  if (!v || !depth || !rgba) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  int rc = host_ring_prepare(v);
+  if (rc) return rc;
+  tf_volume::HostSlot& s = v->hslot[v->hslot_next];
+  TF_HIP(hipEventSynchronize(s.copied));  // the previous upload out of this slot has left the host buffer
+  *depth = reinterpret_cast<float*>(s.h);
+  *rgba = s.h + v->hslot_pixels * 4;
+  return TF_OK;
+}
+
+int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgba, const float pose[12],
+                            const float* pose_inv16, int32_t frame_id) {
+  if (!v || !depth || !pose) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (pose_inv16 && !rgba) { set_error("the textured unit needs a colour image"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  int rc = host_ring_prepare(v);
+  if (rc) return rc;
+  const size_t npix = v->hslot_pixels;
+  tf_volume::HostSlot& s = v->hslot[v->hslot_next];
+  v->hslot_next = (v->hslot_next + 1) % tf_volume::kHostRing;
+  // the kernels that read this slot's device images (three frames ago) and the upload out of its pinned
+  // buffer have finished
+  TF_HIP(hipEventSynchronize(s.freed));
+  TF_HIP(hipEventSynchronize(s.copied));
+  float* hd = reinterpret_cast<float*>(s.h);
+  uint8_t* hc = s.h + npix * 4;
+  if (depth != hd) memcpy(hd, depth, npix * 4);           // frames composed in tf_host_frame_buffers' slot skip this
+  if (rgba && rgba != hc) memcpy(hc, rgba, npix * 4);
+  TF_HIP(hipMemcpyAsync(s.d, s.h, rgba ? npix * 8 : npix * 4, hipMemcpyHostToDevice, v->copy_stream));
+  TF_HIP(hipEventRecord(s.copied, v->copy_stream));
+  TF_HIP(hipStreamWaitEvent(v->stream, s.copied, 0));
+  const float* dd[1] = {reinterpret_cast<const float*>(s.d)};
+  const uint8_t* dc[1] = {rgba ? s.d + npix * 4 : nullptr};
+  if (pose_inv16) {
+    TexturedArgs tex{pose_inv16, frame_id};
+    rc = enqueue_frames(v, 1, 0, dd, dc, pose, &tex);
+  } else {
+    rc = enqueue_frames(v, 1, 0, dd, dc, pose, nullptr);
+  }
+  if (rc) return rc;
+  TF_HIP(hipEventRecord(s.freed, v->stream));
+  return tf_frame_bind_device(v, dd[0], dc[0], nullptr);
 }
 
 int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {

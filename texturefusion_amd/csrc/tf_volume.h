@@ -96,6 +96,18 @@ struct tf_volume {
   uint8_t* d_rgba = nullptr;
   float* d_quality = nullptr;
   size_t img_pixels = 0;
+  // drop-in per-frame host path (tf_integrate_frame_host): ring of pinned staging + device image slots, H2D on
+  // its own stream so that the copy of frame f+1 overlaps the kernels of frame f
+  static constexpr int kHostRing = 3;
+  struct HostSlot {
+    uint8_t* h = nullptr;      // pinned: depth f32[npix] | rgba u8[4 npix]
+    uint8_t* d = nullptr;      // device: same layout
+    hipEvent_t copied = nullptr, freed = nullptr;
+  };
+  HostSlot hslot[kHostRing];
+  size_t hslot_pixels = 0;
+  int hslot_next = 0;
+  hipStream_t copy_stream = nullptr;
   void* h_pinned = nullptr;      // pinned host staging (uploads / downloads)
   size_t h_pinned_bytes = 0;
   tf::FrameImages frame{nullptr, nullptr, nullptr};
