@@ -176,28 +176,33 @@ __global__ __launch_bounds__(1024) void k_patch_assign(VolumeDev v, uint32_t n) 
   __syncthreads();
   const uint32_t ff = first_fail;
   unsigned long long lmin = ~0ull, lmax = 0ull;
+  uint32_t kept = 0;
   for (uint32_t i = b; i < e; ++i) {
     const uint32_t slot = v.work_slot[i];
     if (slot == kInvalidSlot) continue;
     if (i >= ff) { v.work_slot[i] = kInvalidSlot; continue; }
     MeshRec* rec = &v.mesh_rec[slot];
     const int kf_slot = v.work_ids[i].w;
+    ++kept;
     patch_begin(rec, v.kf_tab[kf_slot], kf_slot);
     lmin = rec->texloc < lmin ? rec->texloc : lmin;
     lmax = rec->texloc > lmax ? rec->texloc : lmax;
   }
   atomicMin(&smin, lmin);
   atomicMax(&smax, lmax);
-  uint32_t tot = handed;  // every successful hand-out precedes the first failure (slot numbers grow with the list)
+  // every successful hand-out precedes the first failure (slot numbers grow with the list)
+  uint32_t tot = handed, tk = kept;
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+  for (int o = 32; o >= 1; o >>= 1) { tot += __shfl_xor(tot, o); tk += __shfl_xor(tk, o); }
   __syncthreads();
-  if (lane == 0) wsum[w] = tot;
+  __shared__ uint32_t ksum[16];
+  if (lane == 0) { wsum[w] = tot; ksum[w] = tk; }
   __syncthreads();
   if (t == 0) {
-    uint32_t all = 0;
-    for (int k = 0; k < 16; ++k) all += wsum[k];
+    uint32_t all = 0, allk = 0;
+    for (int k = 0; k < 16; ++k) { all += wsum[k]; allk += ksum[k]; }
     v.actl->n_slots += all;
+    v.actl->n_done = allk;
     v.actl->loc_min = smin;
     v.actl->loc_max = smax;
     v.actl->set[0].n_work = n;
@@ -388,7 +393,6 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
         rec->bbox[0] = bx; rec->bbox[1] = by; rec->bbox[2] = cols; rec->bbox[3] = rows;
         rec->pflags = kPfHasPatch | kPfHasImage | (ncau ? kPfCaution : 0u) | (wrong ? kPfWrong : 0u);
         rec->ratio[0] = 1.0f; rec->ratio[1] = 1.0f;
-        atomicAdd(&v.actl->n_done, 1u);
       }
       have_image = true;
     } else {
@@ -1132,7 +1136,6 @@ int tf_generate_patches(tf_volume* v, const int32_t* ids, int64_t n, const int32
   }
   int rc = upload_work(v, ids, kfs.data(), n);
   if (rc) return rc;
-  TF_HIP(hipMemsetAsync(&v->dev.actl->n_done, 0, 4, v->stream));
   hipLaunchKernelGGL(k_patch_assign, dim3(1), dim3(1024), 0, v->stream, v->dev, (uint32_t)n);
   prof_begin(v, TF_PROF_PATCH_PROJECT);
   hipLaunchKernelGGL((k_patch<true, false, false>), dim3(1024), dim3(256), 0, v->stream, v->dev, v->cam, 0, KfDev{});

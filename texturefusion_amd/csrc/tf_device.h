@@ -178,6 +178,7 @@ struct VolumeDev {
   uint16_t* mesh_t;
   MeshRec* mesh_rec;
   uint32_t mesh_cv, mesh_ct;
+  uint32_t* mesh_nbr;  // [max_chunks][32] mesher scratch: pool slots of a surviving work entry's 27-chunk neighbourhood
   // atlas (Structure/Atlas.h:43-75): u8 [atlas_h][atlas_w][3], slots of patch_w x patch_h texels
   uint8_t* atlas;
   int32_t atlas_w, atlas_h, patch_w, patch_h;

@@ -15,6 +15,7 @@
 // that emits a triangle on an edge leaves its own rounding of the vertex; here every emitting cell
 // posts its index with an LDS atomicMax per edge slot, a block scan ranks the used slots (= the
 // reference's ascending-slot vertex order) and the winners are evaluated once, lane = output vertex.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -81,78 +82,208 @@ __device__ __forceinline__ bool gradient_at(const float* __restrict__ S, int px,
   return ok && !(n > res * 100.0f);
 }
 
+// per-corner flags of the staged 9^3 cell corners
+constexpr uint32_t kCfHeavy = 64u;   // weight > 50 (weight_threshold, ChunkManager.cpp:776-777)
+constexpr uint32_t kCfGradOk = 128u; // |gradient| <= 100 * resolution (:449-452)
+// bits 0..5: the voxel one step along -x, +x, -y, +y, -z, +z has sdf < 1 (GetNeighborSDF, ChunkManager.h:790-823)
+
 struct MeshSh {
-  float S[kRV];            // sdf, region coordinates -1..9
-  float Wt[729];           // weight at the cell corners 0..8
-  uint32_t nslot[27];      // pool slot of chunk id + (-1..1)^3, kInvalidSlot = missing
-  int owner[kEdgeSlots];   // last emitting cell per edge slot, -1 = unused
+  float S[kRV];               // sdf, region coordinates -1..9
+  uint8_t cflag[732];         // per cell corner: kCf* | neighbour bits
+  uint32_t nslot[27];         // pool slot of chunk id + (-1..1)^3, kInvalidSlot = missing
   uint16_t ref[kEdgeSlots];   // output vertex index of a used slot
   uint16_t vlist[kEdgeSlots]; // used slots in ascending order
-  uint32_t cinfo[512];     // MC case | valid-edge mask << 8 | triangle count << 20
-  uint32_t toff[512];      // first output triangle of the cell
+  uint32_t ownq[(kEdgeSlots + 7) / 8];  // per edge slot a nibble: bit q = the q-th cell around the edge emits on it
+  uint32_t cinfo[512];        // MC case | edges used by emitted triangles << 8 | triangle count << 20
+  uint32_t toff[512];         // first output triangle of the cell
   uint32_t wsum[8];
   uint32_t nv, nt, adj, any;
 };
 
-__global__ __launch_bounds__(256) void k_mesh(VolumeDev v, const int4* __restrict__ dlist,
-                                              const uint32_t* __restrict__ dcount, uint32_t max_entries,
-                                              uint32_t epoch, float res, uint32_t simplified) {
+// The (up to four) cells around edge slot (ax, bx, by, bz), numbered q = 0..3 in DESCENDING cell index (z, then
+// y, then x): the reference's cell loop runs in ascending index and the last emitting cell overwrites
+// vertByEdge (:872-885), so the emitter with the smallest q owns the vertex.  q = d0 + 2 d1 with
+//   x edges: (d0, d1) = (by - y, bz - z);  y edges: (bx - x, bz - z);  z edges: (bx - x, by - y).
+__device__ __forceinline__ int edge_q(int e) {  // q of edge e seen from its cell
+  // e: 0 1 2 3 4 5 6 7 8 9 10 11 -> 0 1 1 0 2 3 3 2 0 1 3 2
+  return (int)((0x231023320110ull >> (4 * e)) & 0x3);
+}
+__device__ __forceinline__ int owner_cell(int m, int q) {
+  const int ax = m % 3, b = m / 3;
+  const int bx = b % 9, by = (b / 9) % 9, bz = b / 81;
+  const int d0 = q & 1, d1 = q >> 1;
+  int x, y, z;
+  if (ax == 0) { x = bx; y = by - d0; z = bz - d1; }
+  else if (ax == 1) { x = bx - d0; y = by; z = bz - d1; }
+  else { x = bx - d0; y = by - d1; z = bz; }
+  return x + 8 * y + 64 * z;
+}
+
+// ---------------------------------------------------------------------------------------
+// Filter, one WAVE per dirty chunk.  A vertex needs a cell whose 8 corners are all observed (sdf <= 1) with
+// both signs among them, and a corner with weight > 50 (:669-722, :776-777): if the 9^3 corner voxels of
+// the chunk do not hold a positive sdf, a negative sdf and a weight above 50, the mesh is empty.  Most dirty
+// chunks (in front of / behind the surface inside the truncation band, or seen too few times) end here
+// after reading their own 4 KiB, or that plus the 217 corner voxels the +x/+y/+z neighbours contribute;
+// survivors are flagged for k_mesh: surv[32 * entry + 0..26] = pool slots of the survivor's 27-chunk
+// neighbourhood (13 = the chunk itself), surv[32 * entry + 13] = kInvalidSlot for everything else.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t classify_voxel(const float sdf, const float w) {
+  const bool ok = !(sdf > 1.0f);
+  return (ok ? 1u : 0u) | ((ok && sdf > 0.0f) ? 2u : 0u) | ((sdf < 0.0f) ? 4u : 0u) | ((w > 50.0f) ? 8u : 0u);
+}
+__global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
+                                                     const uint32_t* __restrict__ dslot,
+                                                     const uint32_t* __restrict__ dcount, uint32_t max_entries,
+                                                     uint32_t epoch, uint32_t* __restrict__ surv) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const uint32_t nwaves = gridDim.x * 4;
+  uint32_t n = *dcount;
+  if (n > max_entries) n = max_entries;
+  for (uint32_t entry = wave; entry < n; entry += nwaves) {
+    const int4 id = dlist[entry];
+    uint32_t own = kInvalidSlot;
+    if (dslot) own = dslot[entry];
+    else {
+      const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+      if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) own = v.hent[ent].slot;
+    }
+    if (own == kInvalidSlot) {  // RecomputeMeshes: !HasChunk -> skip (:240-242)
+      if (lane == 0) surv[32 * (size_t)entry + 13] = kInvalidSlot;
+      continue;
+    }
+    const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
+    uint32_t fl = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 q = T4[j * 64 + lane];  // two voxels {sdf, w, sdf, w}
+      fl |= classify_voxel(q.x, q.y) | classify_voxel(q.z, q.w);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) fl |= (uint32_t)__shfl_xor((int)fl, o);
+    bool empty = !(fl & 1u);
+    if (!empty && (fl & 14u) != 14u) {
+      // chunks id + (1,0,0), (0,1,0), (1,1,0), (0,0,1), (1,0,1), (0,1,1), (1,1,1): lanes 1..7 look them up
+      uint32_t ns = kInvalidSlot;
+      if (lane >= 1 && lane < 8) {
+        const uint32_t ent = hash_find(v, pack_id(id.x + (lane & 1), id.y + ((lane >> 1) & 1), id.z + (lane >> 2)));
+        if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) ns = v.hent[ent].slot;
+      }
+      uint32_t f2 = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {  // corner voxels with a coordinate 8: 3 faces of 64, 3 edges of 8, 1 corner
+        const int q = j * 64 + lane;
+        int cx = 0, cy = 0, cz = 0;
+        if (q < 64) { cx = 8; cy = q & 7; cz = q >> 3; }
+        else if (q < 128) { cx = q & 7; cy = 8; cz = (q >> 3) & 7; }
+        else if (q < 192) { cx = q & 7; cy = (q >> 3) & 7; cz = 8; }
+        else if (q < 200) { cx = 8; cy = 8; cz = q & 7; }
+        else if (q < 208) { cx = 8; cy = q & 7; cz = 8; }
+        else if (q < 216) { cx = q & 7; cy = 8; cz = 8; }
+        else { cx = 8; cy = 8; cz = 8; }
+        const uint32_t s = (uint32_t)__shfl((int)ns, (cx >> 3) + 2 * (cy >> 3) + 4 * (cz >> 3));
+        if (q < 217 && s != kInvalidSlot) {
+          const float2 val = v.tsdf[(size_t)s * kChunkVoxels + (cx & 7) + (cy & 7) * 8 + (cz & 7) * 64];
+          f2 |= classify_voxel(val.x, val.y);
+        }
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) f2 |= (uint32_t)__shfl_xor((int)f2, o);
+      empty = ((fl | f2) & 14u) != 14u;
+    }
+    if (empty) {
+      if (lane == 0) {  // Mesh::Clear + "stays in allMeshes if it was there" (:244-262)
+        surv[32 * (size_t)entry + 13] = kInvalidSlot;
+        MeshRec* rec = &v.mesh_rec[own];
+        rec->nv = 0; rec->nt = 0; rec->state = rec->state & kMsInMap; rec->epoch = epoch;
+      }
+    } else if (lane < 27) {  // a survivor: the pool slots of chunk id + (-1..1)^3 for the mesher's staging
+      uint32_t slot = own;
+      if (lane != 13) {
+        slot = kInvalidSlot;
+        const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
+        if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
+      }
+      surv[32 * (size_t)entry + lane] = slot;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 6) void k_mesh(VolumeDev v, const int4* __restrict__ dlist,
+                                                 const uint32_t* __restrict__ surv,
+                                                 const uint32_t* __restrict__ dcount, uint32_t max_entries,
+                                                 uint32_t epoch, float res, uint32_t simplified, uint32_t dbg) {
   __shared__ MeshSh sh;
+  __shared__ unsigned long long mc[256];  // the triangle table, once per (persistent) workgroup
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   uint32_t n = *dcount;
   if (n > max_entries) n = max_entries;
   const float half = res * 0.5f;
+  bool have_mc = false;
   for (uint32_t entry = blockIdx.x; entry < n; entry += gridDim.x) {
+    const uint32_t own = surv[32 * (size_t)entry + 13];  // k_mesh_filter: the chunk's pool slot, or "nothing to mesh"
+    if (own == kInvalidSlot) continue;
+    if (!have_mc) { mc[t] = d_mc_tri[t]; have_mc = true; }  // visible after the first barrier below
     const int4 id = dlist[entry];
-    if (t < 27) {
-      const int ox = t % 3 - 1, oy = (t / 3) % 3 - 1, oz = t / 9 - 1;
-      const uint32_t ent = hash_find(v, pack_id(id.x + ox, id.y + oy, id.z + oz));
-      uint32_t slot = kInvalidSlot;
-      if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
-      sh.nslot[t] = slot;
-    }
-    if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; sh.any = 0; }
-    __syncthreads();
-    const uint32_t own = sh.nslot[13];
-    if (own == kInvalidSlot) { __syncthreads(); continue; }  // RecomputeMeshes: !HasChunk -> skip (:240-242)
     MeshRec* rec = &v.mesh_rec[own];
-
-    // ---- own chunk first: a cell needs its corner 0 (always an own voxel) to have sdf <= 1, so a chunk
-    // without such a voxel has no mesh and the 27-chunk neighbourhood is never touched
     const float2 a0 = v.tsdf[(size_t)own * kChunkVoxels + t];
     const float2 a1 = v.tsdf[(size_t)own * kChunkVoxels + 256 + t];
-    const bool cand = !(a0.x > 1.0f) || !(a1.x > 1.0f);
-    if (__ballot(cand) != 0ull && lane == 0) sh.any = 1;  // benign race: every writer stores 1
-    __syncthreads();
-    if (!sh.any) {
-      if (t == 0) {  // Mesh::Clear + "stays in allMeshes if it was there" (:244-262)
-        rec->nv = 0; rec->nt = 0; rec->state = rec->state & kMsInMap; rec->epoch = epoch;
-      }
-      __syncthreads();
-      continue;
+    __syncthreads();  // the previous chunk of this workgroup is done with the shared tables
+    if (t < 27) sh.nslot[t] = surv[32 * (size_t)entry + t];
+    if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; }
+    if (dbg == 1) continue;  // triage: filter only
+    // ---- stage the 11^3 voxels of the neighbourhood (own ones from registers)
+    {
+      const int x0 = t & 7, y0 = (t >> 3) & 7, z0 = t >> 6;  // voxels t and t + 256 = (x0, y0, z0) and (x0, y0, z0 + 4)
+      sh.S[ridx(x0, y0, z0)] = a0.x; sh.cflag[x0 + y0 * 9 + z0 * 81] = (a0.y > 50.0f) ? kCfHeavy : 0u;
+      sh.S[ridx(x0, y0, z0 + 4)] = a1.x; sh.cflag[x0 + y0 * 9 + (z0 + 4) * 81] = (a1.y > 50.0f) ? kCfHeavy : 0u;
     }
-    // ---- stage the neighbourhood
+    __syncthreads();
     for (int i = t; i < kRV; i += 256) {
       const int rx = i % kR - 1, ry = (i / kR) % kR - 1, rz = i / (kR * kR) - 1;
+      if ((unsigned)rx < 8u && (unsigned)ry < 8u && (unsigned)rz < 8u) continue;  // own voxel: already there
       const int cx = (rx + 8) >> 3, cy = (ry + 8) >> 3, cz = (rz + 8) >> 3;  // 0..2 = chunk offset + 1
       const uint32_t s = sh.nslot[cx + cy * 3 + cz * 9];
       float2 val = make_float2(999.0f, 0.0f);
       if (s != kInvalidSlot) val = v.tsdf[(size_t)s * kChunkVoxels + (rx & 7) + (ry & 7) * 8 + (rz & 7) * 64];
       sh.S[i] = val.x;
-      if (rx >= 0 && ry >= 0 && rz >= 0 && rx <= 8 && ry <= 8 && rz <= 8) sh.Wt[rx + ry * 9 + rz * 81] = val.y;
+      if (rx >= 0 && ry >= 0 && rz >= 0 && rx <= 8 && ry <= 8 && rz <= 8)
+        sh.cflag[rx + ry * 9 + rz * 81] = (val.y > 50.0f) ? kCfHeavy : 0u;
     }
-    for (int i = t; i < kEdgeSlots; i += 256) sh.owner[i] = -1;
+    __syncthreads();
+    // ---- per corner: which of its six neighbours are below 1, is its gradient short enough.  A cell asks
+    // for the three neighbours OUTSIDE its cube (extractGradientFromCubic fetches those through
+    // GetNeighborSDF, :320-447), so the answer per (cell, corner) is three of these bits.
+    for (int c = t; c < 729; c += 256) {
+      const int px = c % 9, py = (c / 9) % 9, pz = c / 81;
+      const int r = ridx(px, py, pz);
+      const float xm = sh.S[r - 1], xp = sh.S[r + 1], ym = sh.S[r - kR], yp = sh.S[r + kR];
+      const float zm = sh.S[r - kR * kR], zp = sh.S[r + kR * kR];
+      uint32_t f = (xm < 1.0f ? 1u : 0u) | (xp < 1.0f ? 2u : 0u) | (ym < 1.0f ? 4u : 0u) | (yp < 1.0f ? 8u : 0u) |
+                   (zm < 1.0f ? 16u : 0u) | (zp < 1.0f ? 32u : 0u);
+      const float gx = xp - xm, gy = yp - ym, gz = zp - zm;
+      const float yz = gy * gy + gz * gz;
+      const float nrm = sqrtf(gx * gx + yz);
+      if (!(nrm > res * 100.0f)) f |= kCfGradOk;
+      sh.cflag[c] |= (uint8_t)f;
+    }
+    for (int i = t; i < (kEdgeSlots + 7) / 8; i += 256) sh.ownq[i] = 0u;
     __syncthreads();
 
-    // ---- pass 1: per cell, the MC case, which edges carry a usable vertex, how many triangles
+    if (dbg == 2) continue;  // triage: + staging and corner flags
+    // ---- pass 1: per cell, the MC case, the edges its emitted triangles use, how many triangles.  Loops stay
+    // rolled and re-read LDS instead of keeping the cube in registers: the kernel is latency-bound, occupancy
+    // (registers) matters more than a few LDS reads.
     for (int cell = t; cell < 512; cell += 256) {
       const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
+      const int c0 = ridx(x, y, z);
       float cube[8];
       bool observed = true;
       int pos = 0, index = 0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float s = sh.S[ridx(x + cox(k), y + coy(k), z + coz(k))];
+        const float s = sh.S[c0 + cox(k) + coy(k) * kR + coz(k) * kR * kR];
         cube[k] = s;
         observed = observed && !(s > 1.0f);  // :669-720
         pos += (s > 0.0f) ? 1 : 0;
@@ -160,43 +291,58 @@ __global__ __launch_bounds__(256) void k_mesh(VolumeDev v, const int4* __restric
       }
       uint32_t info = 0;
       if (observed && (pos % 8) > 0) {  // :722
-        const unsigned long long row = d_mc_tri[index];
-        uint32_t valid = 0;
+        const unsigned long long row = mc[index];
         if ((row & 0xFull) != 0xFull) {
-          for (int e = 0; e < 12; ++e) {  // :748-834
-            const int e0 = edge_c0(e), e1 = edge_c1(e);
+          uint32_t valid = 0;
+          const int cf0 = x + y * 9 + z * 81;
+#pragma unroll
+          for (int e = 0; e < 12; ++e) {  // :748-834 (e0 / e1 are compile-time constants here)
+            const int e0 = (int)((0x321076543210ull >> (4 * e)) & 0xF), e1 = (int)((0x765447650321ull >> (4 * e)) & 0xF);
             const float s0 = cube[e0], s1 = cube[e1];
-            if (!(s0 * s1 < 0.0f)) continue;
-            const int k = (fabsf(s0) > fabsf(s1)) ? e1 : e0;
-            const int px = x + cox(k), py = y + coy(k), pz = z + coz(k);
-            if (!(sh.Wt[px + py * 9 + pz * 81] > 50.0f)) continue;  // weight_threshold (:776-777)
-            float g[3];
-            if (gradient_at(sh.S, px, py, pz, cox(k), coy(k), coz(k), res, g)) valid |= 1u << e;
+            const bool far = fabsf(s0) > fabsf(s1);  // the corner with the smaller |sdf| (:765)
+            const int ko = far ? (cox(e1) + coy(e1) * 9 + coz(e1) * 81) : (cox(e0) + coy(e0) * 9 + coz(e0) * 81);
+            const uint32_t need0 = kCfHeavy | kCfGradOk | (1u << cox(e0)) | (4u << coy(e0)) | (16u << coz(e0));
+            const uint32_t need1 = kCfHeavy | kCfGradOk | (1u << cox(e1)) | (4u << coy(e1)) | (16u << coz(e1));
+            const uint32_t need = far ? need1 : need0;
+            if (s0 * s1 < 0.0f) {
+              const uint32_t have = sh.cflag[cf0 + ko];
+              if ((have & need) == need) valid |= 1u << e;
+            }
           }
-          uint32_t ntri = 0;
+          uint32_t ntri = 0, used = 0;
+#pragma unroll 1
           for (int col = 0; col < 15; col += 3) {  // :836-918
             const int s0 = (int)((row >> (4 * col)) & 0xF);
             if (s0 == 0xF) break;
             const int s1 = (int)((row >> (4 * col + 4)) & 0xF), s2 = (int)((row >> (4 * col + 8)) & 0xF);
             if (!((valid >> s0) & (valid >> s1) & (valid >> s2) & 1u)) continue;
             ++ntri;
-            atomicMax(&sh.owner[edge_slot(x, y, z, s2)], cell);
-            atomicMax(&sh.owner[edge_slot(x, y, z, s1)], cell);
-            atomicMax(&sh.owner[edge_slot(x, y, z, s0)], cell);
+            used |= (1u << s0) | (1u << s1) | (1u << s2);
           }
-          info = (uint32_t)index | (valid << 8) | (ntri << 20);
+          for (uint32_t u = used; u; u &= u - 1) {  // this cell emits on these edges
+            const int e = __builtin_ctz(u);
+            const int m = edge_slot(x, y, z, e);
+            atomicOr(&sh.ownq[m >> 3], 1u << (4 * (m & 7) + edge_q(e)));
+          }
+          info = (uint32_t)index | (used << 8) | (ntri << 20);
         }
       }
       sh.cinfo[cell] = info;
     }
     __syncthreads();
 
+    if (dbg == 3) continue;  // triage: + cell pass
     // ---- ranks: used edge slots in ascending order (the reference's vertex order, :886-897) and the
     // cells' triangle offsets in cell order (the order of mesh->indices)
     {
-      const int first = t * 9;  // 256 x 9 = 2304 >= 2187
+      const int first = t * 9;  // 256 x 9 = 2304 >= 2187: three edge-grid points (x, y, z edge each) per thread
       uint32_t cnt = 0;
-      for (int j = 0; j < 9; ++j) cnt += (first + j < kEdgeSlots && sh.owner[first + j] >= 0) ? 1u : 0u;
+#pragma unroll 1
+      for (int j = 0; j < 9; ++j) {
+        const int m = first + j;
+        if (m >= kEdgeSlots) break;
+        cnt += ((sh.ownq[m >> 3] >> (4 * (m & 7))) & 0xFu) ? 1u : 0u;
+      }
       const uint32_t tc = (sh.cinfo[2 * t] >> 20) + (sh.cinfo[2 * t + 1] >> 20);
       uint32_t pk = cnt | (tc << 16);  // both counts scanned at once (each < 2^16)
       uint32_t inc = pk;
@@ -214,12 +360,16 @@ __global__ __launch_bounds__(256) void k_mesh(VolumeDev v, const int4* __restric
       }
       const uint32_t excl = before + inc - pk;
       uint32_t r = excl & 0xFFFFu;
-      for (int j = 0; j < 9; ++j)
-        if (first + j < kEdgeSlots && sh.owner[first + j] >= 0) {
-          sh.ref[first + j] = (uint16_t)r;
-          sh.vlist[r] = (uint16_t)(first + j);
+#pragma unroll 1
+      for (int j = 0; j < 9; ++j) {
+        const int m = first + j;
+        if (m >= kEdgeSlots) break;
+        if ((sh.ownq[m >> 3] >> (4 * (m & 7))) & 0xFu) {
+          sh.ref[m] = (uint16_t)r;
+          sh.vlist[r] = (uint16_t)m;
           ++r;
         }
+      }
       const uint32_t t0 = excl >> 16;
       sh.toff[2 * t] = t0;
       sh.toff[2 * t + 1] = t0 + (sh.cinfo[2 * t] >> 20);
@@ -236,12 +386,13 @@ __global__ __launch_bounds__(256) void k_mesh(VolumeDev v, const int4* __restric
       continue;
     }
 
+    if (dbg == 4) continue;  // triage: + ranking
     // ---- pass 2: the winning cell of every used slot evaluates the vertex; lane = output vertex
     const float org[3] = {(float)(8 * id.x) * res, (float)(8 * id.y) * res, (float)(8 * id.z) * res};  // Chunk.cpp:52
     uint32_t adj = 0;
     for (uint32_t i = t; i < nv; i += 256) {
       const int m = sh.vlist[i];
-      const int cell = sh.owner[m];
+      const int cell = owner_cell(m, __builtin_ctz((sh.ownq[m >> 3] >> (4 * (m & 7))) & 0xFu));
       const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
       const int ax = m % 3, b = m / 3;
       const int bx = b % 9, by = (b / 9) % 9, bz = b / 81;
@@ -291,7 +442,7 @@ __global__ __launch_bounds__(256) void k_mesh(VolumeDev v, const int4* __restric
       const uint32_t info = sh.cinfo[cell];
       if (!(info >> 20)) continue;
       const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
-      const unsigned long long row = d_mc_tri[info & 0xFFu];
+      const unsigned long long row = mc[info & 0xFFu];
       const uint32_t valid = (info >> 8) & 0xFFFu;
       uint32_t o = sh.toff[cell];
       for (int col = 0; col < 15; col += 3) {
@@ -331,12 +482,30 @@ void launch_init_meshes(const VolumeDev& v, hipStream_t s) {
   hipLaunchKernelGGL(k_init_mesh_rec, dim3(1024), dim3(256), 0, s, v.mesh_rec, v.max_chunks);
 }
 
+static int mesh_resident_blocks() {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+  }
+  const char* e = getenv("TF_MESH_BLOCKS_PER_CU");
+  return cus * (e ? atoi(e) : 6);
+}
+
 void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, hipStream_t s) {
   if (!max_entries) return;
-  const uint32_t grid = max_entries < 8192u ? max_entries : 8192u;
-  hipLaunchKernelGGL(k_mesh, dim3(grid), dim3(256), 0, s, v, dlist, dcount, max_entries, epoch, res,
-                     fused ? kMsSimplified : 0u);
+  static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch
+  uint32_t* surv = v.mesh_nbr;
+  const uint32_t fgrid = (max_entries + 3) / 4 < 2048u ? (max_entries + 3) / 4 : 2048u;
+  hipLaunchKernelGGL(k_mesh_filter, dim3(fgrid), dim3(256), 0, s, v, dlist, fused ? v.work_slot : nullptr, dcount,
+                     max_entries, epoch, surv);
+  // one workgroup per entry up to a grid the dispatcher balances by itself (survivors are irregularly spread
+  // over the list: a persistent grid with a fixed stride leaves a tail); TF_MESH_GRID overrides
+  static const uint32_t gmax = getenv("TF_MESH_GRID") ? (uint32_t)atoi(getenv("TF_MESH_GRID")) : 16384u;
+  const uint32_t grid = max_entries < gmax ? max_entries : gmax;
+  hipLaunchKernelGGL(k_mesh, dim3(grid), dim3(256), 0, s, v, dlist, surv, dcount, max_entries, epoch, res,
+                     fused ? kMsSimplified : 0u, dbg);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -344,13 +513,15 @@ void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, 
 // (Structure/Chisel.h:192-208): every updated chunk of the frame's list and its six face neighbours, those
 // that exist, each once (a stamp per pool slot de-duplicates), appended to the work list.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_dirty_frame(VolumeDev v, int par, uint32_t stamp) {
+__global__ __launch_bounds__(1024) void k_dirty_frame(VolumeDev v, int par, uint32_t stamp) {
   const SelBuf& L = v.sel;
   const uint32_t nl = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
   const uint32_t total = nl * 8u;  // 8 threads per entry: k = 0..6 self + neighbours, 7 idle
   AtlasCtl::Set* S = &v.actl->set[par];
-  const int lane = threadIdx.x & 63;
-  for (uint32_t b0 = blockIdx.x * 256; b0 < total; b0 += gridDim.x * 256) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __shared__ uint32_t wcnt[16];
+  __shared__ uint32_t gbase;
+  for (uint32_t b0 = blockIdx.x * 1024; b0 < total; b0 += gridDim.x * 1024) {
     const uint32_t t = b0 + threadIdx.x;
     bool emit = false;
     int4 q = make_int4(0, 0, 0, 0);
@@ -370,20 +541,25 @@ __global__ __launch_bounds__(256) void k_dirty_frame(VolumeDev v, int par, uint3
           emit = atomicMax(&v.mesh_rec[slot].stamp, stamp) < stamp;
       }
     }
+    // one same-address atomic per workgroup of 1024 (they retire at ~10 ns each)
     const unsigned long long m = __ballot(emit);
-    if (m) {
-      uint32_t p0 = 0;
-      if (lane == 0) p0 = atomicAdd(&S->n_work, (uint32_t)__popcll(m));
-      p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
-      if (emit) {
-        const uint32_t p = p0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (p < v.max_chunks) { v.work_ids[p] = q; v.work_slot[p] = slot; }
-      }
+    if (lane == 0) wcnt[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t tot = 0;
+      for (int k = 0; k < 16; ++k) { const uint32_t c = wcnt[k]; wcnt[k] = tot; tot += c; }
+      gbase = tot ? atomicAdd(&S->n_work, tot) : 0u;
     }
+    __syncthreads();
+    if (emit) {
+      const uint32_t p = gbase + wcnt[w] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (p < v.max_chunks) { v.work_ids[p] = q; v.work_slot[p] = slot; }
+    }
+    __syncthreads();
   }
 }
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s) {
-  hipLaunchKernelGGL(k_dirty_frame, dim3(512), dim3(256), 0, s, v, par, stamp);
+  hipLaunchKernelGGL(k_dirty_frame, dim3(256), dim3(1024), 0, s, v, par, stamp);
 }
 
 // ---------------------------------------------------------------------------------------
