@@ -3,7 +3,7 @@
 //
 //   k_patch_assign     Atlas::AddPatch for an ordered chunk list (Structure/Atlas.cpp:43-64): the slot a
 //                      new patch gets is loc_next at its turn = a prefix sum over the list
-//   k_patch_collect / k_patch_rank   the same for the unordered per-frame dirty list of the fused flow:
+//   k_patch_rank       the same for the unordered per-frame dirty list of the fused flow:
 //                      new patches take their slots in ascending chunk-id order (rank by comparison)
 //   k_patch<P, B, F>   one WAVE per patch: Patch::CalculateTexCoords (Structure/Patch.cpp:40-108, lane =
 //                      vertex, coalesced plane rows, bbox / vote by wave reductions) and / or
@@ -212,37 +212,11 @@ __global__ __launch_bounds__(1024) void k_patch_assign(VolumeDev v, uint32_t n) 
 }
 
 // ---------------------------------------------------------------------------------------
-// fused per-frame flow: the work list is the frame's dirty set, unordered.  k_patch_collect keeps the entries
-// that have a mesh and lists the ones without an atlas slot; k_patch_rank hands the slots out in ascending
+// fused per-frame flow: the work list is the frame's dirty set, unordered.  k_compress_exchange (tf_mesh.hip) keeps the
+// entries that have a mesh and lists the ones without an atlas slot; k_patch_rank hands the slots out in ascending
 // chunk-id order (rank of a key = number of smaller keys among the candidates, counted by comparison: the
 // candidate count is a few hundred in steady state, a few thousand on first touch).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_patch_collect(VolumeDev v, int par) {
-  AtlasCtl::Set* S = &v.actl->set[par];
-  const uint32_t n = S->n_work;
-  const int lane = threadIdx.x & 63;
-  for (uint32_t base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
-    const uint32_t i = base + threadIdx.x;
-    bool need = false;
-    unsigned long long key = 0;
-    if (i < n) {
-      uint32_t slot = v.work_slot[i];
-      if (slot != kInvalidSlot && !(v.mesh_rec[slot].state & kMsInMap)) { slot = kInvalidSlot; v.work_slot[i] = slot; }
-      if (slot != kInvalidSlot && v.mesh_rec[slot].texloc == kNoTexloc) {
-        const int4 id = v.work_ids[i];
-        key = pack_id(id.x, id.y, id.z);
-        need = true;
-      }
-    }
-    const unsigned long long m = __ballot(need);
-    if (m) {
-      uint32_t p0 = 0;
-      if (lane == 0) p0 = atomicAdd(&S->n_cand, (uint32_t)__popcll(m));
-      p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
-      if (need) v.cand[p0 + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key;
-    }
-  }
-}
 __global__ __launch_bounds__(256) void k_patch_rank(VolumeDev v, int par) {
   AtlasCtl::Set* S = &v.actl->set[par];
   const uint32_t n = S->n_cand;
@@ -281,6 +255,54 @@ typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
 __device__ __forceinline__ int cv_round_f(float x) { return (int)rintf(x); }
 
+// ---- gather helpers of the batched projection: addresses first, all loads in flight, arithmetic last ----------
+// Patch::bilinear / bilinear_depth (Patch.cpp:110-170) read up to three pixels: (y, x), then (y, x + 1) or
+// (y + 1, x), then (y + 1, x).  kind: 0 = interior (c1, c2, c3; c2 stands where c4 belongs, :125-128),
+// 1 = last row (c1, c2 along x), 2 = last column (c1, c2 along y), 3 = corner / beyond (c1 only).
+struct Taps {
+  int i1, i2, i3;  // linear pixel indices, -1 = outside the image (reads 0, see rgb_at)
+  int kind;
+  float ax, bx, ay, by;
+};
+__device__ __forceinline__ int pix_index(int W, int H, int y, int x) {
+  const long i = (long)y * W + x;
+  return (i < 0 || i >= (long)W * H) ? -1 : (int)i;
+}
+__device__ __forceinline__ Taps make_taps(int W, int H, float lx, float ly) {
+  Taps t;
+  const int x = (int)floorf(lx), y = (int)floorf(ly);
+  t.ax = (float)(x + 1) - lx; t.bx = lx - (float)x;
+  t.ay = (float)(y + 1) - ly; t.by = ly - (float)y;
+  t.i1 = pix_index(W, H, y, x);
+  t.i2 = t.i3 = -1;
+  if (x < W - 1 && y < H - 1) { t.kind = 0; t.i2 = pix_index(W, H, y, x + 1); t.i3 = pix_index(W, H, y + 1, x); }
+  else if (x < W - 1 && y == H - 1) { t.kind = 1; t.i2 = pix_index(W, H, y, x + 1); }
+  else if (x == W - 1 && y < H - 1) { t.kind = 2; t.i2 = pix_index(W, H, y + 1, x); }
+  else t.kind = 3;
+  return t;
+}
+// one pixel as r | g << 8 | b << 16 (0 outside the image)
+__device__ __forceinline__ uint32_t load_px(const uint8_t* rgb, int stride, int i) {
+  if (i < 0) return 0u;
+  if (stride == 4) return *reinterpret_cast<const uint32_t*>(rgb + 4 * (size_t)i) & 0xFFFFFFu;
+  const uint8_t* p = rgb + 3 * (size_t)i;
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
+}
+__device__ __forceinline__ float blend(const Taps& t, float c1, float c2, float c3) {
+  if (t.kind == 0) {
+    float r = (c1 * t.ax) * t.ay;
+    r = r + (c2 * t.bx) * t.ay;
+    r = r + (c3 * t.ax) * t.by;
+    r = r + (c2 * t.bx) * t.by;
+    return r;
+  }
+  if (t.kind == 1) return c1 * t.ax + c2 * t.bx;
+  if (t.kind == 2) return c1 * t.ay + c2 * t.by;
+  return c1;
+}
+
+constexpr int kVB = 4;  // 64-vertex blocks of a patch kept in registers: one sweep for meshes up to 256 vertices
+
 template <bool PROJECT, bool BLIT, bool FUSED>
 __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, KfDev kf_fused) {
   const int lane = threadIdx.x & 63;
@@ -292,10 +314,8 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
   const int W = cam.W, H = cam.H;
   const float Wf = (float)W, Hf = (float)H;
   if (FUSED && blockIdx.x == 0 && threadIdx.x == 0) {
-    // every kernel of the previous frame has finished with the other counter set: re-arm it; account for the
-    // slots this frame's ranking handed out (nobody reads n_slots while this kernel runs)
-    AtlasCtl::Set* O = &v.actl->set[par ^ 1];
-    O->n_work = 0; O->n_cand = 0; O->fail_key = ~0ull;
+    // account for the slots this frame's ranking handed out (nobody reads n_slots while this kernel runs; the
+    // next reader is the next frame's ranking, behind this kernel on the same stream)
     unsigned long long tl;
     uint32_t got = S->n_cand;
     while (got && !slot_texloc(v, (unsigned long long)v.actl->n_slots + got - 1, &tl)) --got;
@@ -307,63 +327,102 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
     const int4 id = v.work_ids[e];
     if (FUSED && pack_id(id.x, id.y, id.z) >= fail_key) continue;
     MeshRec* rec = &v.mesh_rec[slot];
-    const uint32_t nv = rec->nv;
-    const uint32_t state = rec->state;
+    const MeshRec R = *rec;  // one 64-B record: counts, flags, slot position, box
+    const uint32_t nv = R.nv;
     // fused flow: the keyframe is the frame itself, handed over by value; its image is not retained (kf_slot -1)
-    const int kf_slot = FUSED ? -1 : (PROJECT ? id.w : rec->kf_slot);
-    if (!PROJECT && (!(rec->pflags & kPfHasPatch) || kf_slot < 0)) continue;  // GetPatch == nullptr (Atlas.cpp:73-74)
+    const int kf_slot = FUSED ? -1 : (PROJECT ? id.w : R.kf_slot);
+    if (!PROJECT && (!(R.pflags & kPfHasPatch) || kf_slot < 0)) continue;  // GetPatch == nullptr (Atlas.cpp:73-74)
     const KfDev kf = FUSED ? kf_fused : v.kf_tab[kf_slot];
     int bx = 0, by = 0, cols = 0, rows = 0;
     bool have_image = false;
+    if (FUSED && kf_fused.pad[0] == 2) continue;  // triage: list walk + record read only
     if (PROJECT) {
-      if (FUSED && lane == 0) patch_begin(rec, kf, kf_slot);
       float minX = Wf, maxX = 0.0f, minY = Hf, maxY = 0.0f;  // Patch.cpp:46-49
       uint32_t dcmp = 0, ccmp = 0, ncau = 0;
       float* tu = mesh_plane(v, slot, kMpTc);
       float* tv = mesh_plane(v, slot, kMpTc + 1);
-      for (uint32_t i = lane; i < ((nv + 63u) & ~63u); i += 64) {
-        const bool act = i < nv;
-        bool cau = false, cc = false, dc = false;
-        if (act) {
-          const float vx = mesh_plane(v, slot, kMpPos)[i], vy = mesh_plane(v, slot, kMpPos + 1)[i],
-                      vz = mesh_plane(v, slot, kMpPos + 2)[i];
+      float keepX[kVB], keepY[kVB];  // texcoords of a one-sweep patch stay in registers until the box is known
+      const bool one_sweep = nv <= 64u * kVB;
+      for (uint32_t base = 0; base < nv; base += 64u * kVB) {
+        // ---- loads of the sweep: vertex positions and colours
+        float px[kVB], py[kVB], pz[kVB], m0[kVB], m1[kVB], m2[kVB];
+#pragma unroll
+        for (int j = 0; j < kVB; ++j) {
+          const uint32_t i = base + 64u * j + lane;
+          const uint32_t ii = i < nv ? i : 0u;
+          px[j] = mesh_plane(v, slot, kMpPos)[ii]; py[j] = mesh_plane(v, slot, kMpPos + 1)[ii];
+          pz[j] = mesh_plane(v, slot, kMpPos + 2)[ii];
+          m0[j] = mesh_plane(v, slot, kMpCol)[ii]; m1[j] = mesh_plane(v, slot, kMpCol + 1)[ii];
+          m2[j] = mesh_plane(v, slot, kMpCol + 2)[ii];
+        }
+        // ---- projection (:52-66), then every image gather of the sweep in flight at once
+        float cX[kVB], cY[kVB], dist[kVB];
+        Taps tp[kVB];
+        uint32_t q1[kVB], q2[kVB], q3[kVB];
+        float d1[kVB], d2[kVB], d3[kVB];
+        bool cau[kVB];
+#pragma unroll
+        for (int j = 0; j < kVB; ++j) {
           float vl[3];
 #pragma unroll
           for (int r = 0; r < 3; ++r) {  // T_g_l * (v, 1), accumulated column by column (:52-53)
-            float s = kf.T[4 * r] * vx;
-            s = s + kf.T[4 * r + 1] * vy;
-            s = s + kf.T[4 * r + 2] * vz;
+            float s = kf.T[4 * r] * px[j];
+            s = s + kf.T[4 * r + 1] * py[j];
+            s = s + kf.T[4 * r + 2] * pz[j];
             s = s + kf.T[4 * r + 3] * 1.0f;
             vl[r] = s;
           }
-          const float dist = vl[2];
+          dist[j] = vl[2];
           const float x = vl[0] / vl[2], y = vl[1] / vl[2];
-          float cX = (float)((double)(x * cam.fxi + cam.cxi) + 0.5);  // :55-56
-          float cY = (float)((double)(y * cam.fyi + cam.cyi) + 0.5);
-          cau = (cX < 0 || cX >= Wf || cY < 0 || cY >= Hf);  // :58-62
-          if (cX < 0) cX = 0;
-          if (cX >= Wf) cX = Wf;
-          if (cY < 0) cY = 0;
-          if (cY >= Hf) cY = Hf;
-          tu[i] = cX;
-          tv[i] = cY;
-          minX = minX < cX ? minX : cX; maxX = maxX > cX ? maxX : cX;
-          minY = minY < cY ? minY : cY; maxY = maxY > cY ? maxY : cY;
-          float tc[3];
-          bilinear_rgb(kf.rgb, kf.stride, W, H, cX, cY, tc);
-#pragma unroll
-          for (int k = 0; k < 3; ++k) { tc[k] = tc[k] / 255.0f; mesh_plane(v, slot, kMpTcol + k)[i] = tc[k]; }
-          const float dpt = bilinear_f(kf.depth, W, H, cX, cY);
-          const float d0 = tc[0] - mesh_plane(v, slot, kMpCol)[i], d1 = tc[1] - mesh_plane(v, slot, kMpCol + 1)[i],
-                      d2 = tc[2] - mesh_plane(v, slot, kMpCol + 2)[i];
-          const float s12 = d1 * d1 + d2 * d2;
-          const float nrm = sqrtf(d0 * d0 + s12);
-          cc = (double)nrm > 0.6;                 // :88
-          dc = (double)fabsf(dist - dpt) > 0.7;   // :89
+          float a = (float)((double)(x * cam.fxi + cam.cxi) + 0.5);  // :55-56
+          float b = (float)((double)(y * cam.fyi + cam.cyi) + 0.5);
+          cau[j] = (a < 0 || a >= Wf || b < 0 || b >= Hf);  // :58-62
+          if (a < 0) a = 0;
+          if (a >= Wf) a = Wf;
+          if (b < 0) b = 0;
+          if (b >= Hf) b = Hf;
+          cX[j] = a; cY[j] = b;
+          tp[j] = make_taps(W, H, a, b);
         }
-        ncau += (uint32_t)__popcll(__ballot(cau));
-        ccmp += (uint32_t)__popcll(__ballot(cc));
-        dcmp += (uint32_t)__popcll(__ballot(dc));
+#pragma unroll
+        for (int j = 0; j < kVB; ++j) {
+          q1[j] = load_px(kf.rgb, kf.stride, tp[j].i1);
+          q2[j] = load_px(kf.rgb, kf.stride, tp[j].i2);
+          q3[j] = load_px(kf.rgb, kf.stride, tp[j].i3);
+          d1[j] = tp[j].i1 >= 0 ? kf.depth[tp[j].i1] : 0.0f;
+          d2[j] = tp[j].i2 >= 0 ? kf.depth[tp[j].i2] : 0.0f;
+          d3[j] = tp[j].i3 >= 0 ? kf.depth[tp[j].i3] : 0.0f;
+        }
+        // ---- arithmetic + stores
+#pragma unroll
+        for (int j = 0; j < kVB; ++j) {
+          const uint32_t i = base + 64u * j + lane;
+          const bool act = i < nv;
+          bool cc = false, dc = false;
+          if (act) {
+            minX = minX < cX[j] ? minX : cX[j]; maxX = maxX > cX[j] ? maxX : cX[j];
+            minY = minY < cY[j] ? minY : cY[j]; maxY = maxY > cY[j] ? maxY : cY[j];
+            float tc[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+              const float c1 = (float)((q1[j] >> (8 * k)) & 0xFFu), c2 = (float)((q2[j] >> (8 * k)) & 0xFFu),
+                          c3 = (float)((q3[j] >> (8 * k)) & 0xFFu);
+              tc[k] = blend(tp[j], c1, c2, c3) / 255.0f;
+              mesh_plane(v, slot, kMpTcol + k)[i] = tc[k];
+            }
+            const float dpt = blend(tp[j], d1[j], d2[j], d3[j]);
+            const float e0 = tc[0] - m0[j], e1 = tc[1] - m1[j], e2 = tc[2] - m2[j];
+            const float s12 = e1 * e1 + e2 * e2;
+            const float nrm = sqrtf(e0 * e0 + s12);
+            cc = (double)nrm > 0.6;                    // :88
+            dc = (double)fabsf(dist[j] - dpt) > 0.7;   // :89
+            if (!one_sweep) { tu[i] = cX[j]; tv[i] = cY[j]; }
+          }
+          ncau += (uint32_t)__popcll(__ballot(act && cau[j]));
+          ccmp += (uint32_t)__popcll(__ballot(cc));
+          dcmp += (uint32_t)__popcll(__ballot(dc));
+          if (one_sweep) { keepX[j] = cX[j]; keepY[j] = cY[j]; }
+        }
       }
       // min / max are exact and order-free
 #pragma unroll
@@ -375,6 +434,8 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
       }
       const double nvd = (double)nv;
       const bool wrong = ((double)dcmp > 0.3 * nvd) || ((double)ccmp > 0.3 * nvd);  // :92-96
+      float fbx = 0.0f, fby = 0.0f;
+      bool have_box = false;
       if (maxX >= minX && maxY >= minY) {  // :98-99: cv::Rect(float..) truncates, & intersects
         const int ax = (int)(minX - 2.0f), ay = (int)(minY - 2.0f);
         const int aw = (int)(maxX - minX + 5.0f), ah = (int)(maxY - minY + 5.0f);
@@ -383,8 +444,17 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
         const int y2 = (ay + ah) < (H - 1) ? (ay + ah) : (H - 1);
         cols = x2 - bx; rows = y2 - by;
         if (cols <= 0 || rows <= 0) { bx = by = cols = rows = 0; }
-        const float fbx = (float)bx, fby = (float)by;
-        for (uint32_t i = lane; i < nv; i += 64) {  // :100-102 (a lane re-reads what it wrote)
+        fbx = (float)bx; fby = (float)by;
+        have_box = true;
+      }
+      if (one_sweep) {  // :100-102: texcoord -= box origin (or unshifted when there is no box)
+#pragma unroll
+        for (int j = 0; j < kVB; ++j) {
+          const uint32_t i = 64u * j + lane;
+          if (i < nv) { tu[i] = have_box ? keepX[j] - fbx : keepX[j]; tv[i] = have_box ? keepY[j] - fby : keepY[j]; }
+        }
+      } else if (have_box) {
+        for (uint32_t i = lane; i < nv; i += 64) {  // a lane re-reads what it wrote
           tu[i] = tu[i] - fbx;
           tv[i] = tv[i] - fby;
         }
@@ -393,22 +463,24 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
         rec->bbox[0] = bx; rec->bbox[1] = by; rec->bbox[2] = cols; rec->bbox[3] = rows;
         rec->pflags = kPfHasPatch | kPfHasImage | (ncau ? kPfCaution : 0u) | (wrong ? kPfWrong : 0u);
         rec->ratio[0] = 1.0f; rec->ratio[1] = 1.0f;
+        if (FUSED) { rec->frameid = kf.kf_id; rec->kf_slot = -1; }  // Patch::clear + SetFrameid of the fused flow
       }
       have_image = true;
     } else {
-      bx = rec->bbox[0]; by = rec->bbox[1]; cols = rec->bbox[2]; rows = rec->bbox[3];
-      have_image = (rec->pflags & kPfHasImage) != 0;
+      bx = R.bbox[0]; by = R.bbox[1]; cols = R.bbox[2]; rows = R.bbox[3];
+      have_image = (R.pflags & kPfHasImage) != 0;
     }
     if (!BLIT) continue;
+    if (FUSED && kf_fused.pad[0] == 1) continue;  // triage: no blit
     // Patch::complete (Patch.cpp:191-196): vertices, simplified mesh, image, texcoords, frame id
-    if (!(nv > 0 && (state & kMsSimplified) && have_image && kf.kf_id >= 0)) continue;
+    if (!(nv > 0 && (R.state & kMsSimplified) && have_image && kf.kf_id >= 0)) continue;
     if (cols <= 0 || rows <= 0) continue;  // empty ROI: nothing to copy
     const int PW = v.patch_w, PH = v.patch_h;
     float r0 = 1.0f, r1 = 1.0f;
     if (cols > PW) r0 = (float)PW / (float)cols;  // Atlas.cpp:77-80
     if (rows > PH) r1 = (float)PH / (float)rows;
     if (lane == 0) { rec->ratio[0] = r0; rec->ratio[1] = r1; }
-    const unsigned long long tl = rec->texloc;
+    const unsigned long long tl = R.texloc;
     const unsigned long long ox = tl % (unsigned long long)v.atlas_w, oy = tl / (unsigned long long)v.atlas_w;
     const size_t astep = (size_t)v.atlas_w * 3;
     const int st = kf.stride;
@@ -431,15 +503,13 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
         sy1 = sy1 < 0 ? 0 : (sy1 > rows - 1 ? rows - 1 : sy1);
         const int b0 = (short)cv_round_f((1.f - fy) * 2048.f), b1 = (short)cv_round_f(fy * 2048.f);
         const int sx1 = sx + 1 < cols ? sx + 1 : sx;
-        const uint8_t* s00 = kf.rgb + ((size_t)(by + sy0) * W + bx + sx) * st;
-        const uint8_t* s01 = kf.rgb + ((size_t)(by + sy0) * W + bx + sx1) * st;
-        const uint8_t* s10 = kf.rgb + ((size_t)(by + sy1) * W + bx + sx) * st;
-        const uint8_t* s11 = kf.rgb + ((size_t)(by + sy1) * W + bx + sx1) * st;
+        const uint32_t p00 = load_px(kf.rgb, st, (by + sy0) * W + bx + sx), p01 = load_px(kf.rgb, st, (by + sy0) * W + bx + sx1);
+        const uint32_t p10 = load_px(kf.rgb, st, (by + sy1) * W + bx + sx), p11 = load_px(kf.rgb, st, (by + sy1) * W + bx + sx1);
         uint8_t* D = v.atlas + (oy + dy) * astep + (ox + dx) * 3;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          const int h0 = s00[k] * a0 + s01[k] * a1;
-          const int h1 = s10[k] * a0 + s11[k] * a1;
+          const int h0 = (int)((p00 >> (8 * k)) & 0xFFu) * a0 + (int)((p01 >> (8 * k)) & 0xFFu) * a1;
+          const int h1 = (int)((p10 >> (8 * k)) & 0xFFu) * a0 + (int)((p11 >> (8 * k)) & 0xFFu) * a1;
           int val = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
           val = val < 0 ? 0 : (val > 255 ? 255 : val);
           D[k] = (uint8_t)val;
@@ -448,31 +518,50 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
     } else {  // image.copyTo(texroi) at the slot origin
       if (ox + cols > (unsigned long long)v.atlas_w || oy + rows > (unsigned long long)v.atlas_h) continue;
       const int rowbytes = cols * 3;
-      if (st == 3) {
-        // rows are contiguous byte runs on both sides: the destination is written as aligned dwords
-        // (unaligned dword reads of the source), head / tail bytes one by one
-        const int ndw = (rowbytes + 3 + 3) >> 2;  // dwords touched at most (head misalignment up to 3)
-        for (int t = lane; t < rows * ndw; t += 64) {
-          const int r = t / ndw, j = t - r * ndw;
-          uint8_t* drow = v.atlas + (oy + r) * astep + ox * 3;
-          const uint8_t* srow = kf.rgb + ((size_t)(by + r) * W + bx) * 3;
-          const int mis = (int)((uintptr_t)drow & 3u);
-          const int o = 4 * j - mis;  // row byte offset of this aligned destination dword
-          if (o >= rowbytes) continue;
-          if (o >= 0 && o + 4 <= rowbytes) {
-            *reinterpret_cast<uint32_t*>(drow + o) = *reinterpret_cast<const u32_unaligned*>(srow + o);
-          } else {
+      // the destination is written as aligned dwords; a destination dword gathers its (up to) four bytes
+      // from the source row, whatever the source layout (3 or 4 bytes per pixel)
+      uint8_t* d0 = v.atlas + oy * astep + ox * 3;
+      const int mis = (int)((uintptr_t)d0 & 3u);  // the same for every row when the atlas row stride is a multiple of 4
+      const bool rows_aligned = (astep & 3u) == 0;
+      const int ndw = (rowbytes + mis + 3) >> 2;
+      const float inv = 1.0f / (float)ndw;
+      constexpr int kB = 8;  // 512 dwords in flight: a 24 x 18 slot has 18 x 18 = 324
+      for (int t0 = 0; t0 < rows * ndw; t0 += 64 * kB) {
+        uint32_t val[kB];
+        int off[kB], rr[kB];
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+          const int t = t0 + 64 * k + lane;
+          const int r = (int)(((float)t + 0.5f) * inv);  // t / ndw for t < 2^20 (never within 0.5 / ndw of an integer)
+          const int j = t - r * ndw;
+          rr[k] = t < rows * ndw ? r : -1;
+          const int o = 4 * j - (rows_aligned ? mis : (int)((uintptr_t)(d0 + (size_t)r * astep) & 3u));
+          off[k] = o;
+          uint32_t x = 0;
+          if (rr[k] >= 0) {
+            const uint8_t* srow = kf.rgb + ((size_t)(by + r) * W + bx) * st;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int bb = o + q;  // byte of the row
+              if (bb >= 0 && bb < rowbytes) {
+                const int px = bb / 3, ch = bb - 3 * px;
+                x |= (uint32_t)srow[px * st + ch] << (8 * q);
+              }
+            }
+          }
+          val[k] = x;
+        }
+#pragma unroll
+        for (int k = 0; k < kB; ++k) {
+          if (rr[k] < 0) continue;
+          uint8_t* drow = d0 + (size_t)rr[k] * astep;
+          const int o = off[k];
+          if (o >= 0 && o + 4 <= rowbytes) *reinterpret_cast<uint32_t*>(drow + o) = val[k];
+          else {
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              if (o + q >= 0 && o + q < rowbytes) drow[o + q] = srow[o + q];
+              if (o + q >= 0 && o + q < rowbytes) drow[o + q] = (uint8_t)(val[k] >> (8 * q));
           }
-        }
-      } else {
-        for (int t = lane; t < rows * cols; t += 64) {
-          const int r = t / cols, c = t - r * cols;
-          const uint8_t* sp = kf.rgb + ((size_t)(by + r) * W + bx + c) * st;
-          uint8_t* dp = v.atlas + (oy + r) * astep + (ox + c) * 3;
-          dp[0] = sp[0]; dp[1] = sp[1]; dp[2] = sp[2];
         }
       }
     }
@@ -757,9 +846,15 @@ int atlas_init(tf_volume* v) {
   a.kf_cap = v->cfg.max_keyframes;
   TF_HIP(hipMalloc((void**)&a.d_kf, sizeof(KfDev) * (size_t)a.kf_cap));
   TF_HIP(hipMalloc((void**)&a.d_actl, sizeof(AtlasCtl)));
-  TF_HIP(hipMalloc((void**)&a.d_work_ids, sizeof(int4) * (size_t)d.max_chunks));
-  TF_HIP(hipMalloc((void**)&a.d_work_slot, sizeof(uint32_t) * (size_t)d.max_chunks));
+  // two work lists: the fused flow builds the list of frame f + 1 while the patches of frame f still read theirs
+  TF_HIP(hipMalloc((void**)&a.d_work_ids, sizeof(int4) * (size_t)d.max_chunks * 2));
+  TF_HIP(hipMalloc((void**)&a.d_work_slot, sizeof(uint32_t) * (size_t)d.max_chunks * 2));
   TF_HIP(hipMalloc((void**)&a.d_cand, sizeof(unsigned long long) * (size_t)d.max_chunks));
+  TF_HIP(hipStreamCreateWithFlags(&a.aux_stream, hipStreamNonBlocking));
+  for (int k = 0; k < 2; ++k) {
+    TF_HIP(hipEventCreateWithFlags(&a.ev_mesh[k], hipEventDisableTiming));
+    TF_HIP(hipEventCreateWithFlags(&a.ev_patch[k], hipEventDisableTiming));
+  }
   KfDev blank;
   memset(&blank, 0, sizeof(blank));
   blank.kf_id = -1; blank.stride = 3;
@@ -778,6 +873,12 @@ void atlas_destroy(tf_volume* v) {
     if (ks.owned) { hipFree(ks.rgb); hipFree(ks.depth); }
   }
   a.keyframes.clear();
+  if (a.aux_stream) { hipStreamSynchronize(a.aux_stream); hipStreamDestroy(a.aux_stream); a.aux_stream = nullptr; }
+  for (int k = 0; k < 2; ++k) {
+    if (a.ev_mesh[k]) hipEventDestroy(a.ev_mesh[k]);
+    if (a.ev_patch[k]) hipEventDestroy(a.ev_patch[k]);
+    a.ev_mesh[k] = a.ev_patch[k] = nullptr;
+  }
   if (a.buf) hipFree(a.buf);
   if (a.d_kf) hipFree(a.d_kf);
   if (a.d_actl) hipFree(a.d_actl);
@@ -800,6 +901,8 @@ int atlas_reset(tf_volume* v) {
   TF_HIP(hipMemcpyAsync(a.d_actl, &c, sizeof(c), hipMemcpyHostToDevice, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   a.fused_par = 0;
+  a.fused_armed = true;
+  a.patch_pending[0] = a.patch_pending[1] = false;
   return TF_OK;
 }
 
@@ -961,13 +1064,12 @@ static int upload_work(tf_volume* v, const int32_t* ids, const int* kfslot, int6
 }
 
 // fused per-frame flow: AddPatch in ascending id order, CalculateTexCoords + UpdateBuffer for the frame's dirty set
-void launch_patch_fused(tf_volume* v, int par, const KfDev& kf, hipStream_t s) {
-  prof_begin(v, TF_PROF_PATCH_RANK, s);
-  hipLaunchKernelGGL(k_patch_collect, dim3(256), dim3(256), 0, s, v->dev, par);
-  hipLaunchKernelGGL(k_patch_rank, dim3(256), dim3(256), 0, s, v->dev, par);
+void launch_patch_fused(tf_volume* v, const VolumeDev& d, int par, const KfDev& kf, hipStream_t s) {
+  prof_begin(v, TF_PROF_PATCH_RANK, s);  // (the candidates were collected by k_compress_exchange)
+  hipLaunchKernelGGL(k_patch_rank, dim3(256), dim3(256), 0, s, d, par);
   prof_end(v, s);
   prof_begin(v, TF_PROF_PATCH_PROJECT, s);
-  hipLaunchKernelGGL((k_patch<true, true, true>), dim3(1024), dim3(256), 0, s, v->dev, v->cam, par, kf);
+  hipLaunchKernelGGL((k_patch<true, true, true>), dim3(1024), dim3(256), 0, s, d, v->cam, par, kf);
   prof_end(v, s);
 }
 
@@ -1136,6 +1238,7 @@ int tf_generate_patches(tf_volume* v, const int32_t* ids, int64_t n, const int32
   }
   int rc = upload_work(v, ids, kfs.data(), n);
   if (rc) return rc;
+  a.fused_armed = false;
   hipLaunchKernelGGL(k_patch_assign, dim3(1), dim3(1024), 0, v->stream, v->dev, (uint32_t)n);
   prof_begin(v, TF_PROF_PATCH_PROJECT);
   hipLaunchKernelGGL((k_patch<true, false, false>), dim3(1024), dim3(256), 0, v->stream, v->dev, v->cam, 0, KfDev{});
@@ -1157,6 +1260,7 @@ int tf_update_atlas(tf_volume* v, const int32_t* ids, int64_t n) {
   if (n <= 0) return TF_OK;
   int rc = upload_work(v, ids, nullptr, n);
   if (rc) return rc;
+  v->atlas.fused_armed = false;
   const uint32_t n32 = (uint32_t)n;
   hipLaunchKernelGGL(k_work_lookup, dim3((n32 + 255) / 256), dim3(256), 0, v->stream, v->dev, n32);
   prof_begin(v, TF_PROF_ATLAS_BLIT);

@@ -639,30 +639,67 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     if (hc) prof_end(v);
     if (hc && tex) {
       // Chisel::UpdateMeshes -> CompressMeshes -> GeneratePatches(label = this frame) -> UpdateAtlas over
-      // the frame's dirty chunks (GCFusion/MobileFusion.cpp:327-382 without the host-side view selection)
+      // the frame's dirty chunks (GCFusion/MobileFusion.cpp:327-382 without the host-side view selection).
+      // The patch stages (adjacency exchange, slot hand-out, projection, blit) read meshes and images only,
+      // so they MAY run on a second stream next to the voxel update of the following frame; the next
+      // frame's mesher then waits for them (it rewrites the mesh blocks they read).
       AtlasState& a = v->atlas;
+      if (!a.fused_armed) {  // first textured frame after a reset / a call-by-call atlas call: empty work lists
+        AtlasCtl::Set z[2];
+        memset(z, 0, sizeof(z));
+        z[0].fail_key = z[1].fail_key = ~0ull;
+        TF_HIP(hipMemcpyAsync(&a.d_actl->set[0], z, sizeof(z), hipMemcpyHostToDevice, v->stream));
+        TF_HIP(hipStreamSynchronize(v->stream));
+        a.fused_par = 0;
+        a.fused_armed = true;
+      }
       const int par = a.fused_par;
       a.fused_par ^= 1;
       VolumeDev d = v->dev;
       d.sel = cur.sel;
+      d.work_ids = a.d_work_ids + (size_t)par * d.max_chunks;
+      d.work_slot = a.d_work_slot + (size_t)par * d.max_chunks;
       prof_begin(v, TF_PROF_DIRTY);
       launch_dirty_frame(d, par, cur.epoch + 1u, v->stream);
       prof_end(v);
+      // TF_TWO_STREAMS=1 (tuning knob) moves the patch stages to a second stream; measured on MI355X the two
+      // cross-stream event waits per frame (~12 us each) cost what the overlap gains (profiles/r2/README.md)
+      static const bool one_stream = !(getenv("TF_TWO_STREAMS") && atoi(getenv("TF_TWO_STREAMS")));
+      hipStream_t ps = one_stream ? v->stream : a.aux_stream;
+      if (!one_stream && a.patch_pending[par ^ 1]) {  // the previous frame's patches still read the meshes
+        TF_HIP(hipStreamWaitEvent(v->stream, a.ev_patch[par ^ 1], 0));
+        a.patch_pending[par ^ 1] = false;
+      }
       prof_begin(v, TF_PROF_MESH);
-      launch_mesh(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, v->stream);
+      launch_mesh(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1, v->stream);
       prof_end(v);
-      prof_begin(v, TF_PROF_FINALIZE);
-      launch_compress(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, false, v->stream);
-      prof_end(v);
+      if (!one_stream) {
+        TF_HIP(hipEventRecord(a.ev_mesh[par], v->stream));
+        TF_HIP(hipStreamWaitEvent(ps, a.ev_mesh[par], 0));
+      }
+      prof_begin(v, TF_PROF_FINALIZE, ps);
+      launch_compress(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, false, par, ps);
+      prof_end(v, ps);
       KfDev kf;
       memset(&kf, 0, sizeof(kf));
       kf.rgb = reinterpret_cast<const uint8_t*>(cur.img.rgba);
       kf.depth = cur.img.depth;
       kf.stride = 4;
       kf.kf_id = tex->first_frame_id + (int32_t)i;
+      static const int pdbg = getenv("TF_PATCH_DBG") ? atoi(getenv("TF_PATCH_DBG")) : 0;  // triage switch
+      kf.pad[0] = pdbg;
       memcpy(kf.T, tex->pose_inv16 + 16 * i, 64);
-      launch_patch_fused(v, par, kf, v->stream);
+      launch_patch_fused(v, d, par, kf, ps);
+      if (!one_stream) {
+        TF_HIP(hipEventRecord(a.ev_patch[par], ps));
+        a.patch_pending[par] = true;
+      }
     }
+  }
+  if (tex) {  // whatever follows on the main stream sees the patches of the last frames
+    AtlasState& a = v->atlas;
+    for (int k = 0; k < 2; ++k)
+      if (a.patch_pending[k]) { TF_HIP(hipStreamWaitEvent(v->stream, a.ev_patch[k], 0)); a.patch_pending[k] = false; }
   }
   for (int64_t k = 0; k < n_ahead; ++k) {
     tf_volume::Primed& p = v->primed[k];
@@ -809,7 +846,13 @@ int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {
   int rc = ensure_tmp(v, 64);
   if (rc) return rc;
   TF_HIP(hipMemsetAsync(v->d_tmp, 0, 48, v->stream));
-  launch_texture_stats(v->dev, v->atlas.fused_par ^ 1, reinterpret_cast<unsigned long long*>(v->d_tmp), v->stream);
+  {
+    const int par = v->atlas.fused_par ^ 1;
+    VolumeDev d = v->dev;
+    d.work_ids = v->atlas.d_work_ids + (size_t)par * d.max_chunks;
+    d.work_slot = v->atlas.d_work_slot + (size_t)par * d.max_chunks;
+    launch_texture_stats(d, par, reinterpret_cast<unsigned long long*>(v->d_tmp), v->stream);
+  }
   TF_HIP(hipGetLastError());
   unsigned long long r[6];
   TF_HIP(hipMemcpyAsync(r, v->d_tmp, 48, hipMemcpyDeviceToHost, v->stream));

@@ -241,10 +241,11 @@ void launch_boundary_unpack(const VolumeDev& v, const uint8_t* records, uint32_t
 void launch_init_meshes(const VolumeDev& v, hipStream_t s);
 // fused = the per-frame flow: the mesh is marked simplified at once (CompressMeshes follows in the same frame)
 void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
-                 uint32_t epoch, float res, bool fused, hipStream_t s);
+                 uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s);
 // per-frame dirty set of the fused flow -> work list of counter set `par`
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s);
-void launch_compress(const VolumeDev& v, const int4* list, const uint32_t* count, uint32_t cap, bool mark, hipStream_t s);
+void launch_compress(const VolumeDev& v, const int4* list, const uint32_t* count, uint32_t cap, bool mark,
+                     int collect_par, hipStream_t s);
 // sums over the work list of counter set `par`: {entries, with mesh, vertices, triangles, ROI pixels, patches}
 void launch_texture_stats(const VolumeDev& v, int par, unsigned long long* out6, hipStream_t s);
 

@@ -213,13 +213,20 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
 __global__ __launch_bounds__(256, 6) void k_mesh(VolumeDev v, const int4* __restrict__ dlist,
                                                  const uint32_t* __restrict__ surv,
                                                  const uint32_t* __restrict__ dcount, uint32_t max_entries,
-                                                 uint32_t epoch, float res, uint32_t simplified, uint32_t dbg) {
+                                                 uint32_t epoch, float res, uint32_t simplified, uint32_t dbg,
+                                                 int rearm) {
   __shared__ MeshSh sh;
   __shared__ unsigned long long mc[256];  // the triangle table, once per (persistent) workgroup
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   uint32_t n = *dcount;
   if (n > max_entries) n = max_entries;
   const float half = res * 0.5f;
+  if (rearm >= 0 && blockIdx.x == 0 && t == 0) {
+    // fused flow: the patches of the previous frame are done (the main stream waited for them ahead of this
+    // frame's filter), so the counter set the NEXT frame's dirty list will append to can be re-armed
+    AtlasCtl::Set* O = &v.actl->set[rearm];
+    O->n_work = 0; O->n_cand = 0; O->fail_key = ~0ull;
+  }
   bool have_mc = false;
   for (uint32_t entry = blockIdx.x; entry < n; entry += gridDim.x) {
     const uint32_t own = surv[32 * (size_t)entry + 13];  // k_mesh_filter: the chunk's pool slot, or "nothing to mesh"
@@ -493,7 +500,7 @@ static int mesh_resident_blocks() {
 }
 
 void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
-                 uint32_t epoch, float res, bool fused, hipStream_t s) {
+                 uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s) {
   if (!max_entries) return;
   static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch
   uint32_t* surv = v.mesh_nbr;
@@ -505,7 +512,7 @@ void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, 
   static const uint32_t gmax = getenv("TF_MESH_GRID") ? (uint32_t)atoi(getenv("TF_MESH_GRID")) : 16384u;
   const uint32_t grid = max_entries < gmax ? max_entries : gmax;
   hipLaunchKernelGGL(k_mesh, dim3(grid), dim3(256), 0, s, v, dlist, surv, dcount, max_entries, epoch, res,
-                     fused ? kMsSimplified : 0u, dbg);
+                     fused ? kMsSimplified : 0u, dbg, rearm_set);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -583,18 +590,46 @@ __global__ __launch_bounds__(256) void k_compress_mark(VolumeDev v, const int4* 
     if (r->state & kMsInMap) r->state |= kMsSimplified;
   }
 }
+// collect_par >= 0 (fused flow): thread k == 0 of an entry also does k_patch_collect's job for it -- entries
+// without a mesh leave the work list, entries without an atlas slot are listed as candidates for the ranking
 __global__ __launch_bounds__(256) void k_compress_exchange(VolumeDev v, const int4* __restrict__ list,
-                                                           const uint32_t* __restrict__ count, uint32_t cap) {
+                                                           const uint32_t* __restrict__ count, uint32_t cap,
+                                                           int collect_par) {
   uint32_t n = *count;
   if (n > cap) n = cap;
-  const uint32_t total = n * 6u;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    const int4 id = list[i / 6u];
-    const int k = (int)(i % 6u), m = k ^ 1;
-    const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
-    if (ent == kInvalidSlot || !(v.hent[ent].alive & 1u) || v.hent[ent].slot == kInvalidSlot) continue;
-    MeshRec* a = &v.mesh_rec[v.hent[ent].slot];
-    if (!(a->state & kMsInMap)) continue;
+  const uint32_t total = n * 8u;  // 8 threads per entry: k = 0..5 neighbours, 6 and 7 idle
+  const int lane = threadIdx.x & 63;
+  for (uint32_t b0 = blockIdx.x * 256; b0 < total; b0 += gridDim.x * 256) {
+    const uint32_t i = b0 + threadIdx.x;
+    const bool act = i < total && (i & 7u) < 6u;
+    const int4 id = list[(i < total ? i : 0u) >> 3];
+    const int k = (int)(i & 7u), m = k ^ 1;
+    uint32_t slot = kInvalidSlot;
+    if (act) {
+      if (collect_par >= 0) slot = v.work_slot[i >> 3];
+      else {
+        const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+        if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
+      }
+    }
+    const bool has_mesh = slot != kInvalidSlot && (v.mesh_rec[slot].state & kMsInMap);
+    if (collect_par >= 0) {
+      bool need = false;
+      if (act && k == 0) {
+        if (slot != kInvalidSlot && !has_mesh) v.work_slot[i >> 3] = kInvalidSlot;
+        need = has_mesh && v.mesh_rec[slot].texloc == kNoTexloc;
+      }
+      const unsigned long long mm = __ballot(need);
+      if (mm) {
+        AtlasCtl::Set* S = &v.actl->set[collect_par];
+        uint32_t p0 = 0;
+        if (lane == 0) p0 = atomicAdd(&S->n_cand, (uint32_t)__popcll(mm));
+        p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
+        if (need) v.cand[p0 + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = pack_id(id.x, id.y, id.z);
+      }
+    }
+    if (!act || !has_mesh) continue;
+    MeshRec* a = &v.mesh_rec[slot];
     int4 q = id;
     if (k == 0) q.x -= 1; else if (k == 1) q.x += 1; else if (k == 2) q.y -= 1;
     else if (k == 3) q.y += 1; else if (k == 4) q.z -= 1; else q.z += 1;
@@ -610,9 +645,10 @@ __global__ __launch_bounds__(256) void k_compress_exchange(VolumeDev v, const in
   }
 }
 
-void launch_compress(const VolumeDev& v, const int4* list, const uint32_t* count, uint32_t cap, bool mark, hipStream_t s) {
+void launch_compress(const VolumeDev& v, const int4* list, const uint32_t* count, uint32_t cap, bool mark,
+                     int collect_par, hipStream_t s) {
   if (mark) hipLaunchKernelGGL(k_compress_mark, dim3(256), dim3(256), 0, s, v, list, count, cap);
-  hipLaunchKernelGGL(k_compress_exchange, dim3(512), dim3(256), 0, s, v, list, count, cap);
+  hipLaunchKernelGGL(k_compress_exchange, dim3(512), dim3(256), 0, s, v, list, count, cap, collect_par);
 }
 
 // keys of allMeshes
@@ -716,7 +752,7 @@ int tf_update_meshes(tf_volume* v, int64_t* n_meshed) {
   const uint8_t* db = reinterpret_cast<const uint8_t*>(v->d_tmp);
   prof_begin(v, TF_PROF_MESH);
   launch_mesh(v->dev, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), n,
-              ++v->mesh_epoch, v->res, false, v->stream);
+              ++v->mesh_epoch, v->res, false, -1, v->stream);
   prof_end(v);
   TF_HIP(hipGetLastError());
   return tf_sync(v);
@@ -842,7 +878,7 @@ int tf_compress_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n_o
     uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
     const int4* list = reinterpret_cast<const int4*>(db + 16);
     const uint32_t* cnt = reinterpret_cast<const uint32_t*>(db);
-    launch_compress(v->dev, list, cnt, n, true, v->stream);
+    launch_compress(v->dev, list, cnt, n, true, -1, v->stream);
     TF_HIP(hipGetLastError());
     // chunksToUpdate = the dirty keys that have a mesh (GCFusion/MobileFusion.cpp:345-353), ascending id
     const size_t o_cnt = ((size_t)n * 16 + 16 + 15) & ~(size_t)15;

@@ -62,6 +62,12 @@ struct AtlasState {
   uint32_t* d_work_slot = nullptr;
   unsigned long long* d_cand = nullptr;
   int fused_par = 0;   // counter set of the next fused frame
+  // fused flow: the patch stages of frame f (second stream) overlap the voxel update of frame f + 1
+  hipStream_t aux_stream = nullptr;
+  hipEvent_t ev_mesh[2] = {nullptr, nullptr};   // meshes of a frame are final (recorded on the main stream)
+  hipEvent_t ev_patch[2] = {nullptr, nullptr};  // patches of a frame are done (recorded on the second stream)
+  bool patch_pending[2] = {false, false};
+  bool fused_armed = false;  // the counter sets are in the state the fused flow expects
   // staging
   void* d_stage = nullptr;
   size_t d_stage_bytes = 0;
@@ -139,7 +145,7 @@ int atlas_init(tf_volume* v);
 void atlas_destroy(tf_volume* v);
 int atlas_reset(tf_volume* v);
 int kf_push(tf_volume* v, int slot);
-void launch_patch_fused(tf_volume* v, int par, const KfDev& kf, hipStream_t s);
+void launch_patch_fused(tf_volume* v, const VolumeDev& d, int par, const KfDev& kf, hipStream_t s);
 inline uint64_t host_pack_id(const int32_t id[3]) {
   return ((uint64_t)((uint32_t)(id[0] + (1 << 20)) & 0x1FFFFFu) << 42) |
          ((uint64_t)((uint32_t)(id[1] + (1 << 20)) & 0x1FFFFFu) << 21) |
