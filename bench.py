@@ -48,6 +48,8 @@ def parse():
                     help="room = S-room 4x3x4 m; big = 8x6x8 m hall, walls at 3-4 m (configs[3] HBM stress)")
     ap.add_argument("--unique-frames", type=int, default=200, help="distinct frames of the orbit kept in HBM")
     ap.add_argument("--exchange-every", type=int, default=40, help="N>1, --mode tsdf: boundary all-gather period (frames)")
+    ap.add_argument("--exchange-cap", type=int, default=1024,
+                    help="N>1: records per rank of the fixed-capacity boundary all-gather (8 KiB each)")
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-warmup", type=int, default=24, help="untimed frames that build up the CPU baseline's volume")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's parallel_for policy")
@@ -92,14 +94,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from texturefusion_amd import capi, exchange, synth
+    from texturefusion_amd import capi, synth
     from texturefusion_amd import partition as part
 
     cam = synth.Camera.hires() if args.hires else synth.Camera()
     res = np.float32(args.res)
     K, Wm = args.steps, args.warmup
     n_unique = max(1, min(args.unique_frames, 3 * K + Wm + 4))
-    textured = args.mode == "textured" and not multi
+    textured = args.mode == "textured"
 
     # ---- synthetic stream, generated once and parked in HBM -------------------------------
     frames = [make_frame(k, cam, args) for k in range(n_unique)]
@@ -110,7 +112,6 @@ def main():
     torch.cuda.synchronize()
 
     s_main = torch.cuda.Stream(device=dev) if multi else None
-    s_xchg = torch.cuda.Stream(device=dev) if multi else None
     big = args.scene == "big"
     vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
                       max_coarse=1 << 22 if big else 1 << 20, device=local_rank,
@@ -133,34 +134,33 @@ def main():
         if args.force_exchange and world == 1:
             lo, hi = edges[1] - 12, edges[1] + 12  # a real interior slab so that faces exist and get packed
         vol.set_partition(lo, hi, axis)
-        rec_cap = 1 << 14
-        send = [torch.empty(rec_cap * capi.TF_BOUNDARY_RECORD_BYTES, dtype=torch.uint8, device=dev) for _ in range(2)]
-        cnt = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(2)]
-        keep = []  # received buffers stay referenced until the unpack kernels that read them have run
+        # The collective: ONE fixed-capacity all-gather of [count | records] blocks, no host round trip.
+        # backend nccl: RCCL inside the library (tf_comm_init / tf_exchange_boundary) on the volume's stream;
+        # other backends (test hook: several ranks on one GPU over gloo): the same blocks through torch.distributed.
+        cap = args.exchange_cap
+        use_rccl = world > 1 and os.environ.get("TF_BENCH_BACKEND", "nccl") == "nccl"
+        if use_rccl:
+            uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            vol.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+            if textured:
+                vol.comm_exchange_every_frame(cap)
+        else:
+            bb = capi.boundary_block_bytes(cap)
+            blk = torch.zeros(bb, dtype=torch.uint8, device=dev)
+            allb = torch.zeros(bb * max(world, 1), dtype=torch.uint8, device=dev)
 
-    def start_exchange(slot):
-        """Pack the boundary chunks updated since the last exchange (asynchronous, on the volume's stream)."""
-        vol.boundary_pack_async(send[slot].data_ptr(), rec_cap, cnt[slot].data_ptr())
-        ev = torch.cuda.Event()
-        ev.record(s_main)
-        return slot, ev
-
-    def finish_exchange(pending):
-        """All-gather over RCCL (xGMI) on the exchange stream: counts first, then payloads; host waits of
-        this step overlap the frame batch that is already enqueued on the volume's stream."""
-        slot, ev = pending
-        with torch.cuda.stream(s_xchg):
-            s_xchg.wait_event(ev)
-            got = exchange.allgather_records(send[slot], cnt[slot], synchronize=False)
-            done = torch.cuda.Event()
-            done.record(s_xchg)
-        s_main.wait_event(done)
-        for r, (buf, m) in enumerate(got):
-            if r != rank and m:
-                vol.boundary_unpack(buf.data_ptr(), m)
-        keep.append(got)
-        if len(keep) > 2:
-            keep.pop(0)
+    def torch_exchange(join_dirty):
+        """[count | records] blocks through torch.distributed on the volume's stream (no .item(), no host wait)."""
+        with torch.cuda.stream(s_main):
+            vol.boundary_pack_block(blk.data_ptr(), cap)
+            if world > 1:
+                dist.all_gather_into_tensor(allb, blk)
+            else:
+                allb.copy_(blk)
+            vol.boundary_unpack_blocks(allb.data_ptr(), max(world, 1), rank, cap, join_dirty=join_dirty)
 
     def run(first, count, ahead=2):
         """Frames [first, first+count) of the stream (cyclic over the unique frames); the next `ahead` frames go
@@ -168,22 +168,27 @@ def main():
         idx = [(first + i) % n_unique for i in range(count + ahead)]
         dd = [d_depth[i].data_ptr() for i in idx]
         dr = [d_rgba[i].data_ptr() for i in idx]
-        if textured:
-            vol.stream_frames_textured_device(dd, dr, poses[idx], pinv[idx], first, n_ahead=ahead)
+        if textured and (not multi or use_rccl):
+            vol.stream_frames_textured_device(dd, dr, poses[idx], pinv[idx], first, n_ahead=ahead)  # N>1: exchange inside
         elif not multi:
             vol.stream_frames_device(dd, dr, poses[idx], n_ahead=ahead)
-        else:
-            pending = None
-            for k, b in enumerate(range(0, count, args.exchange_every)):
-                sub = idx[b:min(b + args.exchange_every, count)]
-                vol.integrate_frames_device([d_depth[i].data_ptr() for i in sub],
-                                            [d_rgba[i].data_ptr() for i in sub], poses[sub])
-                nxt = start_exchange(k & 1)
-                if pending is not None:
-                    finish_exchange(pending)  # exchange of the previous batch, hidden behind this one
-                pending = nxt
-            if pending is not None:
-                finish_exchange(pending)
+        elif textured:  # torch transport: voxel update, exchange, texture stage -- frame by frame
+            for j in range(count):
+                sub = idx[j:j + 1 + min(2, count + ahead - j - 1)]
+                vol.stream_frames_device([d_depth[i].data_ptr() for i in sub], [d_rgba[i].data_ptr() for i in sub],
+                                         poses[sub], n_ahead=len(sub) - 1)
+                torch_exchange(True)
+                vol.texture_frame_device(pinv[idx[j]], first + j)
+        else:  # TSDF only: batches of --exchange-every frames, one exchange behind each
+            for b in range(0, count, args.exchange_every):
+                e = min(b + args.exchange_every, count)
+                sub = idx[b:e + (ahead if e == count else 0)]
+                vol.stream_frames_device([d_depth[i].data_ptr() for i in sub], [d_rgba[i].data_ptr() for i in sub],
+                                         poses[sub], n_ahead=len(sub) - (e - b))
+                if use_rccl:
+                    vol.exchange_boundary(cap)
+                else:
+                    torch_exchange(False)
 
     def barrier():
         if multi:
@@ -211,7 +216,7 @@ def main():
     prof = None
     dt_instr = None
     kinds = STEP_KERNELS if textured else ("integrate",)
-    if not args.no_roofline:
+    if not args.no_roofline and not multi:
         vol.profile_enable(kinds)
         barrier()
         t1 = time.perf_counter()
@@ -222,8 +227,8 @@ def main():
         vol.profile_enable([])
         vol.sync()
 
-    what = ("TSDF integrate + mesh + atlas update per frame (BASELINE.json configs[%d])" % (3 if args.hires or big else 2)
-            if textured else "TSDF integrate, atlas off (BASELINE.json configs[%d])" % (4 if multi else (3 if args.hires or big else 1)))
+    what = ("TSDF integrate + mesh + atlas update per frame (BASELINE.json configs[%d])" % (4 if world > 1 else (3 if args.hires or big else 2))
+            if textured else "TSDF integrate, atlas off (BASELINE.json configs[%d])" % (4 if world > 1 else (3 if args.hires or big else 1)))
     out = {
         "metric": ("RGB-D frames/s (TSDF integrate + atlas update: prepare->integrate->finalize, UpdateMeshes, "
                    "GeneratePatches + UpdateAtlas over the frame's dirty chunks)" if textured else
@@ -245,13 +250,16 @@ def main():
                         % ("S-hall 8x6x8 m" if big else "S-room 4x3x4 m", cam.width, cam.height, 1e3 * float(res), what),
             "frames_in_hbm": n_unique,
             "parallelism": ("1 GPU" if world == 1 else
-                            "%d ranks, chunk-range slabs of the key x+y+z of one stream, boundary all-gather every %d frames"
-                            % (world, args.exchange_every)),
+                            "%d ranks, chunk-range slabs of the key x+y+z of one stream; one fixed-capacity RCCL all-gather "
+                            "(%d records of 8 KiB per rank) of the updated ghost-band chunks %s"
+                            % (world, args.exchange_cap,
+                               "after every voxel update, ahead of the mesher" if textured else
+                               "every %d frames" % args.exchange_every)),
         },
     }
 
     # ---- roofline over ALL kernels of a step ------------------------------------------------
-    if rank == 0 and prof is not None:
+    if rank == 0 and prof is not None and not multi:
         out["roofline"] = roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, poses, pinv, textured,
                                    dt_instr)
 

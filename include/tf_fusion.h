@@ -201,6 +201,12 @@ TF_API int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int6
 TF_API int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgba, const float pose[12],
                                    const float* pose_inv16, int32_t frame_id);
 TF_API int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba);
+/* The texturing half of the per-frame unit on its own, for the frame integrated last (its images still bound):
+ * UpdateMeshes -> CompressMeshes -> GeneratePatches(label = frame_id) -> UpdateAtlas over that frame's dirty
+ * chunks.  tf_stream_frames_textured_device == per frame: voxel update, then this.  A multi-GPU host that
+ * brings its own transport calls tf_boundary_pack_block / its all-gather / tf_boundary_unpack_blocks(join_dirty)
+ * in between. */
+TF_API int tf_texture_frame_device(tf_volume* v, const float pose_inv16[16], int32_t frame_id);
 TF_API int tf_sync(tf_volume* v);
 
 /* ---- state access (host mirrors of Chunk::voxels / colors, ChunkManager queries) -----
@@ -280,6 +286,28 @@ TF_API int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, 
  * that the exchange of one frame batch can overlap the integration of the next. */
 TF_API int tf_boundary_pack_async(tf_volume* v, void* d_records, int64_t cap_records, uint32_t* d_count);
 TF_API int tf_boundary_unpack(tf_volume* v, const void* d_records, int64_t n_records);
+/* Fixed-capacity form for a single collective without a host round trip: a block is
+ *   [u32 record count, 12 B padding | cap_records records]   (tf_boundary_block_bytes(cap) bytes);
+ * tf_boundary_pack_block fills this rank's block (the count may exceed cap_records: the surplus stays flagged
+ * for the next exchange and the receivers report TF_ERR_CAPACITY at their next synchronising call);
+ * tf_boundary_unpack_blocks consumes the all-gathered blocks of every rank but own_block; join_dirty != 0
+ * (between the voxel update of a frame and tf_texture_frame_device): the owned face neighbours of every ghost
+ * that arrives join that frame's dirty set -- their neighbour was updated on another rank.  Asynchronous. */
+TF_API size_t tf_boundary_block_bytes(int64_t cap_records);
+TF_API int tf_boundary_pack_block(tf_volume* v, void* d_block, int64_t cap_records);
+TF_API int tf_boundary_unpack_blocks(tf_volume* v, const void* d_blocks, int32_t n_blocks, int32_t own_block,
+                                     int64_t cap_records, int join_dirty);
+/* RCCL inside the library: one process per GPU.  tf_comm_unique_id on one rank, the 128 bytes
+ * distributed by the host's own means, tf_comm_init(rank, nranks, id) on every rank (ncclCommInitRank);
+ * tf_exchange_boundary = tf_boundary_pack_block -> ONE ncclAllGather over xGMI on the handle's stream ->
+ * tf_boundary_unpack_blocks, nothing copied to the host.  tf_comm_exchange_every_frame(cap): the textured
+ * per-frame flow (tf_stream_frames_textured_device / tf_integrate_frame_host) then exchanges after every
+ * voxel update, ahead of the mesher; owned face neighbours of arriving ghost chunks join the frame's dirty set. */
+TF_API int tf_comm_unique_id(void* out128);
+TF_API int tf_comm_init(tf_volume* v, int rank, int nranks, const void* unique_id128);
+TF_API int tf_comm_destroy(tf_volume* v);
+TF_API int tf_exchange_boundary(tf_volume* v, int64_t cap_records);
+TF_API int tf_comm_exchange_every_frame(tf_volume* v, int64_t cap_records);
 
 /* ---- texture atlas on device-resident meshes --------------------------------------------
  * Atlas / Patch (Structure/Atlas.{h,cpp}, Structure/Patch.{h,cpp}) as driven by Chisel::GeneratePatches /

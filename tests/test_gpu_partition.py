@@ -123,3 +123,111 @@ def test_async_pack_leaves_the_same_records_and_count(gpu_required):
         v.close()
     for x in bufs + [cnt]:
         x.free()
+
+
+def _copy_d2d(dst_ptr, src_ptr, nbytes):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hip.hipMemcpy(dst_ptr, src_ptr, nbytes, 3) == 0  # hipMemcpyDeviceToDevice
+
+
+def test_textured_two_partitions_equal_one(gpu_required):
+    """The textured per-frame unit on two chunk-range partitions (x + y + z slabs) of one GPU: per frame voxel
+    update on both, fixed-capacity blocks [count | records] exchanged as an all-gather would deliver them
+    (tf_boundary_pack_block / tf_boundary_unpack_blocks with join_dirty), then the texture stage.  The union of
+    the partitions' chunks and meshes equals the single volume bit for bit; every mesh is owned by exactly one."""
+    cam = synth.Camera()
+    axis, split = (1, 1, 1), 35
+    single = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    parts = [capi.Volume(RES5, cam, max_chunks=1 << 16) for _ in range(2)]
+    parts[0].set_partition(-(1 << 31), split, axis)
+    parts[1].set_partition(split, (1 << 31) - 1, axis)
+    cap = 4096
+    bb = capi.boundary_block_bytes(cap)
+    blocks = [HipBuffer(2 * bb) for _ in range(2)]  # what each rank holds after the all-gather
+    mine = [HipBuffer(bb) for _ in range(2)]
+    n = 8
+    frames = [synth.room_frame(3 * k, cam, with_quality=False) for k in range(n)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+    for k, f in enumerate(frames):
+        T = synth.pose_inverse16(f[3])
+        dd, dr = [bufs[k][0].ptr], [bufs[k][1].ptr]
+        single.stream_frames_textured_device(dd, dr, f[3].reshape(1, 12), T.reshape(1, 16), k)
+        for r, v in enumerate(parts):
+            v.stream_frames_device(dd, dr, f[3].reshape(1, 12))
+            v.boundary_pack_block(mine[r].ptr, cap)
+        for v in parts:
+            v.sync()
+        for r in range(2):  # "all-gather": every rank ends up with [block of rank 0 | block of rank 1]
+            for q in range(2):
+                _copy_d2d(blocks[r].ptr + q * bb, mine[q].ptr, bb)
+        for r, v in enumerate(parts):
+            v.boundary_unpack_blocks(blocks[r].ptr, 2, r, cap, join_dirty=True)
+            v.texture_frame_device(T, k)
+            v.sync()
+    single.sync()
+    ref_ids = sorted_ids(single.list_chunks())
+    key = {tuple(c): i for i, c in enumerate(ref_ids)}
+    s_ref, w_ref, c_ref = single.get_chunks(ref_ids)
+    ref_m = sorted_ids(single.list_meshes())
+    assert len(ref_m) > 300
+    mvoff, mioff, mV, mN, mC, mI, madj, msimp = single.get_meshes(ref_m)
+    mkey = {tuple(c): i for i, c in enumerate(ref_m)}
+    seen_m = set()
+    for r, v in enumerate(parts):
+        lo, hi = (-(1 << 31), split) if r == 0 else (split, (1 << 31) - 1)
+        ids = v.list_chunks()
+        s, w, c = v.get_chunks(ids)
+        for i, cid in enumerate(ids):
+            t = tuple(int(x) for x in cid)
+            if t in key:
+                j = key[t]
+                assert np.array_equal(s[i].view(np.uint32), s_ref[j].view(np.uint32)), (r, t)
+                assert np.array_equal(c[i], c_ref[j])
+        pm = sorted_ids(v.list_meshes())
+        own = [m for m in pm if lo <= int(np.dot(m.astype(np.int64), axis)) < hi]
+        assert len(own) == len(pm), "a rank meshes only the chunks it owns"
+        voff, ioff, V, N, Cc, I, adj, simp = v.get_meshes(pm)
+        for i, cid in enumerate(pm):
+            t = tuple(int(x) for x in cid)
+            assert t in mkey and t not in seen_m
+            seen_m.add(t)
+            j = mkey[t]
+            assert np.array_equal(V[voff[i]:voff[i + 1]].view(np.uint32), mV[mvoff[j]:mvoff[j + 1]].view(np.uint32)), (r, t)
+            assert np.array_equal(N[voff[i]:voff[i + 1]].view(np.uint32), mN[mvoff[j]:mvoff[j + 1]].view(np.uint32)), (r, t)
+            assert np.array_equal(I[ioff[i]:ioff[i + 1]], mI[mioff[j]:mioff[j + 1]]), (r, t)
+    assert seen_m == set(mkey)
+    for v in [single] + parts:
+        v.close()
+    for b in blocks + mine + [x for p in bufs for x in p]:
+        b.free()
+
+
+def test_rccl_single_rank_plumbing(gpu_required):
+    """tf_comm_init / tf_exchange_boundary with one rank: librccl is opened, the communicator comes up, the
+    all-gather runs on the handle's stream, the own block is skipped -- and the textured flow with an exchange
+    after every frame equals the plain one."""
+    cam = synth.Camera()
+    a = capi.Volume(RES5, cam, max_chunks=1 << 15)
+    b = capi.Volume(RES5, cam, max_chunks=1 << 15)
+    b.set_partition(-40, 60, (1, 1, 1))
+    a.set_partition(-40, 60, (1, 1, 1))
+    b.comm_init(0, 1, capi.comm_unique_id())
+    b.comm_exchange_every_frame(2048)
+    frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(4)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+    for k, f in enumerate(frames):
+        T = synth.pose_inverse16(f[3])
+        for v in (a, b):
+            v.stream_frames_textured_device([bufs[k][0].ptr], [bufs[k][1].ptr], f[3].reshape(1, 12), T.reshape(1, 16), k)
+    b.exchange_boundary(2048)
+    a.sync(); b.sync()
+    ia, ib = sorted_ids(a.list_chunks()), sorted_ids(b.list_chunks())
+    assert np.array_equal(ia, ib)
+    sa, wa, ca = a.get_chunks(ia[::9]); sb, wb, cb = b.get_chunks(ia[::9])
+    assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32)) and np.array_equal(ca, cb)
+    assert np.array_equal(sorted_ids(a.list_meshes()), sorted_ids(b.list_meshes()))
+    a.close(); b.close()
+    for p in bufs:
+        p[0].free(); p[1].free()

@@ -1,7 +1,8 @@
 """N > 1 path on CPU: two processes over gloo.  Each rank owns a ChunkID.x slab, runs selection in
 full, integrates only its slab (oracle as the per-rank compute -- test infrastructure), exchanges
-the records of updated face chunks with the product's exchange helper, and the union of the
-partitions must equal the single-process result bit for bit."""
+the [count | records] blocks of the updated ghost-band chunks with ONE all-gather (the product's exchange
+helper, same block layout as tf_boundary_pack_block), and the union of the partitions must equal the
+single-process result bit for bit."""
 import os
 import socket
 
@@ -19,27 +20,39 @@ def _free_port():
     return p
 
 
-def _pack(vol, ids, needs, lo, hi):
-    """numpy twin of tf_boundary_pack's record layout (int4 id | {sdf,w}[512] | colour[512][4])."""
+def _pack_block(vol, ids, needs, lo, hi, cap):
+    """numpy twin of tf_boundary_pack_block: [u32 count, pad | records of int4 id | {sdf,w}[512] | colour[512][4]]."""
     from texturefusion_amd import exchange, partition as part
     face = part.boundary_mask(ids, lo, hi) & (needs != 0)
     sel = ids[face]
-    buf = np.zeros((max(len(sel), 1), exchange.RECORD_BYTES), np.uint8)
+    assert len(sel) <= cap
+    blk = np.zeros(exchange.block_bytes(cap), np.uint8)
+    blk[:4] = np.array([len(sel)], np.uint32).view(np.uint8)
+    rec = blk[exchange.HEADER_BYTES:].reshape(cap, exchange.RECORD_BYTES)
     for i, cid in enumerate(sel):
         s, w, c = vol.get_chunk(cid)
-        buf[i, :12] = np.asarray(cid, np.int32).view(np.uint8)
+        rec[i, :12] = np.asarray(cid, np.int32).view(np.uint8)
         tw = np.stack([s, w], 1).astype(np.float32)
-        buf[i, 16:16 + 4096] = tw.reshape(-1).view(np.uint8)
-        buf[i, 16 + 4096:] = c.view(np.uint8)
-    return buf, len(sel)
+        rec[i, 16:16 + 4096] = tw.reshape(-1).view(np.uint8)
+        rec[i, 16 + 4096:] = c.view(np.uint8)
+    return blk
 
 
-def _unpack(vol, buf, n):
-    for i in range(n):
-        cid = buf[i, :12].view(np.int32).copy()
-        tw = buf[i, 16:16 + 4096].view(np.float32).reshape(512, 2)
-        col = buf[i, 16 + 4096:].view(np.uint16).copy()
-        vol.set_chunk(cid, tw[:, 0].copy(), tw[:, 1].copy(), col)
+def _unpack_blocks(vol, allb, world, own, cap):
+    """numpy twin of tf_boundary_unpack_blocks."""
+    from texturefusion_amd import exchange
+    bb = exchange.block_bytes(cap)
+    for r in range(world):
+        if r == own:
+            continue
+        blk = allb[r * bb:(r + 1) * bb]
+        n = int(blk[:4].view(np.uint32)[0])
+        rec = blk[exchange.HEADER_BYTES:].reshape(cap, exchange.RECORD_BYTES)
+        for i in range(n):
+            cid = rec[i, :12].view(np.int32).copy()
+            tw = rec[i, 16:16 + 4096].view(np.float32).reshape(512, 2)
+            col = rec[i, 16 + 4096:].view(np.uint16).copy()
+            vol.set_chunk(cid, tw[:, 0].copy(), tw[:, 1].copy(), col)
 
 
 def _frame(k, cam):
@@ -64,7 +77,7 @@ def _worker(rank, port, out_dir):
     ext = part.room_extent_chunks(res, half_x=0.6, margin=0.1)
     lo, hi = part.slab_for_rank(ext, rank, WORLD)
     vol = O.Volume(res, C, ig)
-    cap = 1024
+    cap = 256
     all_needs = []
     for k in (0, 1):
         depth, rgba, q, pose = _frame(k, cam)
@@ -80,13 +93,10 @@ def _worker(rank, port, out_dir):
         vol.finalize(ids[own], nd, newm[own])
         for cid in ids[~own]:
             pass
-        buf, n = _pack(vol, ids, needs, lo, hi)
-        send = torch.zeros(cap * exchange.RECORD_BYTES, dtype=torch.uint8)
-        send[: buf[:n].size] = torch.from_numpy(buf[:n].reshape(-1))
-        got = exchange.allgather_records(send, n)
-        for r, (t, m) in enumerate(got):
-            if r != rank and m:
-                _unpack(vol, t.numpy()[: m * exchange.RECORD_BYTES].reshape(m, exchange.RECORD_BYTES), m)
+        # the path's one collective: a fixed-capacity all-gather of [count | records] blocks, counts in-band
+        blk = torch.from_numpy(_pack_block(vol, ids, needs, lo, hi, cap))
+        allb = exchange.allgather_blocks(blk)
+        _unpack_blocks(vol, allb.numpy(), WORLD, rank, cap)
         # merged needsUpdate flags in reference list order
         tn = torch.from_numpy(needs.copy())
         gl = [torch.zeros_like(tn) for _ in range(WORLD)]

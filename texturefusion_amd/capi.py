@@ -40,7 +40,9 @@ SYMBOLS = (
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
     "tf_patches_download", "tf_atlas_download_rows", "tf_stream_frames_device",
     "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host",
-    "tf_host_frame_buffers",
+    "tf_host_frame_buffers", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block",
+    "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
+    "tf_comm_exchange_every_frame",
     "tf_update_meshes", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
 )
 
@@ -144,6 +146,16 @@ def lib():
     L.tf_get_texture_stats.argtypes = [vp, C.POINTER(TextureStats)]
     L.tf_integrate_frame_host.argtypes = [vp, fp, u8p, fp, fp, C.c_int32]
     L.tf_host_frame_buffers.argtypes = [vp, C.POINTER(fp), C.POINTER(u8p)]
+    L.tf_texture_frame_device.argtypes = [vp, fp, C.c_int32]
+    L.tf_boundary_block_bytes.restype = C.c_size_t
+    L.tf_boundary_block_bytes.argtypes = [C.c_int64]
+    L.tf_boundary_pack_block.argtypes = [vp, vp, C.c_int64]
+    L.tf_boundary_unpack_blocks.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int]
+    L.tf_comm_unique_id.argtypes = [vp]
+    L.tf_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.tf_comm_destroy.argtypes = [vp]
+    L.tf_exchange_boundary.argtypes = [vp, C.c_int64]
+    L.tf_comm_exchange_every_frame.argtypes = [vp, C.c_int64]
     L.tf_atlas_download_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p]
     u32p = C.POINTER(C.c_uint32)
     L.tf_update_meshes.argtypes = [vp, i64p]
@@ -153,6 +165,19 @@ def lib():
     L.tf_compress_meshes.argtypes = [vp, i32p, C.c_int64, i64p]
     _lib = L
     return L
+
+
+def boundary_block_bytes(cap):
+    return int(lib().tf_boundary_block_bytes(cap))
+
+
+def comm_unique_id():
+    """128-byte RCCL id (ncclGetUniqueId) for tf_comm_init."""
+    buf = (C.c_uint8 * 128)()
+    rc = lib().tf_comm_unique_id(C.cast(buf, C.c_void_p))
+    if rc != TF_OK:
+        raise TFError(rc, lib().tf_last_error().decode())
+    return bytes(buf)
 
 
 def _p(a, ty):
@@ -443,6 +468,29 @@ class Volume:
 
     def boundary_unpack(self, d_buf, n):
         self._ck(self.L.tf_boundary_unpack(self.h, C.c_void_p(d_buf), n))
+
+    def boundary_pack_block(self, d_block, cap):
+        """[count | cap records] block of this rank's updated ghost-band chunks; asynchronous."""
+        self._ck(self.L.tf_boundary_pack_block(self.h, C.c_void_p(d_block), cap))
+
+    def boundary_unpack_blocks(self, d_blocks, n_blocks, own_block, cap, join_dirty=False):
+        self._ck(self.L.tf_boundary_unpack_blocks(self.h, C.c_void_p(d_blocks), n_blocks, own_block, cap, int(join_dirty)))
+
+    def texture_frame_device(self, pose_inv16, frame_id):
+        T = _f32(pose_inv16).reshape(16)
+        self._ck(self.L.tf_texture_frame_device(self.h, _p(T, C.c_float), int(frame_id)))
+
+    # -- RCCL inside the library
+    def comm_init(self, rank, nranks, unique_id):
+        """unique_id: 128 bytes from comm_unique_id() of one rank, distributed by the caller."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self._ck(self.L.tf_comm_init(self.h, rank, nranks, C.cast(buf, C.c_void_p)))
+
+    def exchange_boundary(self, cap):
+        self._ck(self.L.tf_exchange_boundary(self.h, cap))
+
+    def comm_exchange_every_frame(self, cap):
+        self._ck(self.L.tf_comm_exchange_every_frame(self.h, cap))
 
     # -- atlas (device-resident meshes and patches)
     def keyframe_cache(self, kf_id, rgb, depth, pose_inv16=None):

@@ -119,6 +119,7 @@ static int status_to_error(uint32_t st) {
   if (st & kStHashFull) m += " hash table full";
   if (st & kStMeshFull) m += " a mesh exceeds the per-chunk mesh block (raise tf_config.mesh_max_vertices / mesh_max_triangles)";
   if (st & kStAtlasFull) m += " No enough space for texture storage.";  // std::overflow_error text, Atlas.cpp:53
+  if (st & kStXchgFull) m += " a rank's ghost band did not fit the boundary exchange block (raise cap_records)";
   set_error(m);
   if (st & kStAtlasFull) return TF_ERR_ATLAS_FULL;
   if (st & kStMissing) return TF_ERR_MISSING_CHUNK;
@@ -336,6 +337,7 @@ int tf_volume_destroy(tf_volume* v) {
   prof_collect(v);
   for (hipEvent_t e : v->prof_pool) hipEventDestroy(e);
   atlas_destroy(v);
+  comm_destroy(v);
   for (void* p : v->allocs) hipFree(p);
   if (v->d_depth) hipFree(v->d_depth);
   if (v->d_rgba) hipFree(v->d_rgba);
@@ -583,6 +585,86 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
   return TF_OK;
 }
 
+// Chisel::UpdateMeshes -> CompressMeshes -> GeneratePatches(label = this frame) -> UpdateAtlas over the dirty
+// chunks of ONE integrated frame (GCFusion/MobileFusion.cpp:327-382 without the host-side view selection): `sel`
+// holds the frame's visible list with its needsUpdate flags, `frame_epoch` the finalize epoch of that frame.
+// The patch stages (adjacency exchange, slot hand-out, projection, blit) read meshes and images only, so they MAY
+// run on a second stream next to the voxel update of the following frame; the next frame's mesher then waits
+// for them (it rewrites the mesh blocks they read).
+static int fused_arm(tf_volume* v) {
+  AtlasState& a = v->atlas;
+  if (a.fused_armed) return TF_OK;
+  // first textured frame after a reset / a call-by-call atlas call: empty work lists
+  AtlasCtl::Set z[2];
+  memset(z, 0, sizeof(z));
+  z[0].fail_key = z[1].fail_key = ~0ull;
+  TF_HIP(hipMemcpyAsync(&a.d_actl->set[0], z, sizeof(z), hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  a.fused_par = 0;
+  a.fused_armed = true;
+  return TF_OK;
+}
+
+static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
+                         const float* pose_inv16, int32_t frame_id) {
+  AtlasState& a = v->atlas;
+  int rc = fused_arm(v);
+  if (rc) return rc;
+  const int par = a.fused_par;
+  a.fused_par ^= 1;
+  VolumeDev d = v->dev;
+  d.sel = sel;
+  d.work_ids = a.d_work_ids + (size_t)par * d.max_chunks;
+  d.work_slot = a.d_work_slot + (size_t)par * d.max_chunks;
+  prof_begin(v, TF_PROF_DIRTY);
+  launch_dirty_frame(d, par, frame_epoch + 1u, v->stream);
+  prof_end(v);
+  if (v->comm_cap > 0) {  // multi-GPU: ghost bands of this frame's updates, before the mesher reads them
+    rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u);
+    if (rc) return rc;
+  }
+  // TF_TWO_STREAMS=1 (tuning knob) moves the patch stages to a second stream; measured on MI355X the two
+  // cross-stream event waits per frame (~12 us each) cost what the overlap gains (profiles/r2/README.md)
+  static const bool one_stream = !(getenv("TF_TWO_STREAMS") && atoi(getenv("TF_TWO_STREAMS")));
+  hipStream_t ps = one_stream ? v->stream : a.aux_stream;
+  if (!one_stream && a.patch_pending[par ^ 1]) {  // the previous frame's patches still read the meshes
+    TF_HIP(hipStreamWaitEvent(v->stream, a.ev_patch[par ^ 1], 0));
+    a.patch_pending[par ^ 1] = false;
+  }
+  prof_begin(v, TF_PROF_MESH);
+  launch_mesh(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1, v->stream);
+  prof_end(v);
+  if (!one_stream) {
+    TF_HIP(hipEventRecord(a.ev_mesh[par], v->stream));
+    TF_HIP(hipStreamWaitEvent(ps, a.ev_mesh[par], 0));
+  }
+  prof_begin(v, TF_PROF_FINALIZE, ps);
+  launch_compress(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, false, par, ps);
+  prof_end(v, ps);
+  KfDev kf;
+  memset(&kf, 0, sizeof(kf));
+  kf.rgb = reinterpret_cast<const uint8_t*>(img.rgba);
+  kf.depth = img.depth;
+  kf.stride = 4;
+  kf.kf_id = frame_id;
+  static const int pdbg = getenv("TF_PATCH_DBG") ? atoi(getenv("TF_PATCH_DBG")) : 0;  // triage switch
+  kf.pad[0] = pdbg;
+  memcpy(kf.T, pose_inv16, 64);
+  launch_patch_fused(v, d, par, kf, ps);
+  if (!one_stream) {
+    TF_HIP(hipEventRecord(a.ev_patch[par], ps));
+    a.patch_pending[par] = true;
+  }
+  v->clear_floor = frame_epoch + 1u;  // CompressMeshes cleared meshesToUpdate
+  return TF_OK;
+}
+static int texture_flush(tf_volume* v) {  // whatever follows on the main stream sees the patches of the last frames
+  AtlasState& a = v->atlas;
+  for (int k = 0; k < 2; ++k)
+    if (a.patch_pending[k]) { TF_HIP(hipStreamWaitEvent(v->stream, a.ev_patch[k], 0)); a.patch_pending[k] = false; }
+  return TF_OK;
+}
+
 // Software-pipelined enqueue of n frames on the handle's stream: launch i carries K-A of frame i,
 // K-C of frame i+1 and K-B of frame i+2 as independent block ranges of one kernel (launch_frame),
 // so the only synchronisation is the kernel boundary.  The arrays may hold n_ahead (<= 2) frames more
@@ -638,69 +720,11 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
                  v->res, v->stream);
     if (hc) prof_end(v);
     if (hc && tex) {
-      // Chisel::UpdateMeshes -> CompressMeshes -> GeneratePatches(label = this frame) -> UpdateAtlas over
-      // the frame's dirty chunks (GCFusion/MobileFusion.cpp:327-382 without the host-side view selection).
-      // The patch stages (adjacency exchange, slot hand-out, projection, blit) read meshes and images only,
-      // so they MAY run on a second stream next to the voxel update of the following frame; the next
-      // frame's mesher then waits for them (it rewrites the mesh blocks they read).
-      AtlasState& a = v->atlas;
-      if (!a.fused_armed) {  // first textured frame after a reset / a call-by-call atlas call: empty work lists
-        AtlasCtl::Set z[2];
-        memset(z, 0, sizeof(z));
-        z[0].fail_key = z[1].fail_key = ~0ull;
-        TF_HIP(hipMemcpyAsync(&a.d_actl->set[0], z, sizeof(z), hipMemcpyHostToDevice, v->stream));
-        TF_HIP(hipStreamSynchronize(v->stream));
-        a.fused_par = 0;
-        a.fused_armed = true;
-      }
-      const int par = a.fused_par;
-      a.fused_par ^= 1;
-      VolumeDev d = v->dev;
-      d.sel = cur.sel;
-      d.work_ids = a.d_work_ids + (size_t)par * d.max_chunks;
-      d.work_slot = a.d_work_slot + (size_t)par * d.max_chunks;
-      prof_begin(v, TF_PROF_DIRTY);
-      launch_dirty_frame(d, par, cur.epoch + 1u, v->stream);
-      prof_end(v);
-      // TF_TWO_STREAMS=1 (tuning knob) moves the patch stages to a second stream; measured on MI355X the two
-      // cross-stream event waits per frame (~12 us each) cost what the overlap gains (profiles/r2/README.md)
-      static const bool one_stream = !(getenv("TF_TWO_STREAMS") && atoi(getenv("TF_TWO_STREAMS")));
-      hipStream_t ps = one_stream ? v->stream : a.aux_stream;
-      if (!one_stream && a.patch_pending[par ^ 1]) {  // the previous frame's patches still read the meshes
-        TF_HIP(hipStreamWaitEvent(v->stream, a.ev_patch[par ^ 1], 0));
-        a.patch_pending[par ^ 1] = false;
-      }
-      prof_begin(v, TF_PROF_MESH);
-      launch_mesh(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1, v->stream);
-      prof_end(v);
-      if (!one_stream) {
-        TF_HIP(hipEventRecord(a.ev_mesh[par], v->stream));
-        TF_HIP(hipStreamWaitEvent(ps, a.ev_mesh[par], 0));
-      }
-      prof_begin(v, TF_PROF_FINALIZE, ps);
-      launch_compress(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, false, par, ps);
-      prof_end(v, ps);
-      KfDev kf;
-      memset(&kf, 0, sizeof(kf));
-      kf.rgb = reinterpret_cast<const uint8_t*>(cur.img.rgba);
-      kf.depth = cur.img.depth;
-      kf.stride = 4;
-      kf.kf_id = tex->first_frame_id + (int32_t)i;
-      static const int pdbg = getenv("TF_PATCH_DBG") ? atoi(getenv("TF_PATCH_DBG")) : 0;  // triage switch
-      kf.pad[0] = pdbg;
-      memcpy(kf.T, tex->pose_inv16 + 16 * i, 64);
-      launch_patch_fused(v, d, par, kf, ps);
-      if (!one_stream) {
-        TF_HIP(hipEventRecord(a.ev_patch[par], ps));
-        a.patch_pending[par] = true;
-      }
+      int rc = texture_stage(v, cur.sel, cur.img, cur.epoch, tex->pose_inv16 + 16 * i, tex->first_frame_id + (int32_t)i);
+      if (rc) return rc;
     }
   }
-  if (tex) {  // whatever follows on the main stream sees the patches of the last frames
-    AtlasState& a = v->atlas;
-    for (int k = 0; k < 2; ++k)
-      if (a.patch_pending[k]) { TF_HIP(hipStreamWaitEvent(v->stream, a.ev_patch[k], 0)); a.patch_pending[k] = false; }
-  }
+  if (tex) { int rc = texture_flush(v); if (rc) return rc; }
   for (int64_t k = 0; k < n_ahead; ++k) {
     tf_volume::Primed& p = v->primed[k];
     p.depth = d_depth[n + k];
@@ -708,7 +732,6 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
   }
   v->n_primed = (int)n_ahead;
   v->epoch += (uint32_t)n;
-  if (tex) v->clear_floor = v->epoch;  // CompressMeshes cleared meshesToUpdate after every frame
   v->cur_sel = (int)((v->cur_sel + n) % NS);
   v->dev.sel = v->selbuf[v->cur_sel];
   v->host_list_n = -1;
@@ -837,6 +860,16 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   if (rc) return rc;
   TF_HIP(hipEventRecord(s.freed, v->stream));
   return tf_frame_bind_device(v, dd[0], dc[0], nullptr);
+}
+
+int tf_texture_frame_device(tf_volume* v, const float pose_inv16[16], int32_t frame_id) {
+  if (!v || !pose_inv16) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (!v->frame_bound || !v->frame.rgba) { set_error("no colour frame bound"); return TF_ERR_INVALID; }
+  if (v->epoch == 0) { set_error("no frame has been integrated"); return TF_ERR_INVALID; }
+  int rc = texture_stage(v, v->dev.sel, v->frame, v->epoch - 1u, pose_inv16, frame_id);
+  if (rc) return rc;
+  return texture_flush(v);
 }
 
 int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {
@@ -1095,6 +1128,39 @@ int tf_boundary_pack_async(tf_volume* v, void* d_records, int64_t cap_records, u
   launch_boundary_pack(v->dev, reinterpret_cast<uint8_t*>(d_records), (uint32_t)cap_records, v->stream);
   TF_HIP(hipGetLastError());
   TF_HIP(hipMemcpyAsync(d_count, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));
+  return TF_OK;
+}
+
+size_t tf_boundary_block_bytes(int64_t cap_records) { return 16 + (size_t)cap_records * TF_BOUNDARY_RECORD_BYTES; }
+
+int tf_boundary_pack_block(tf_volume* v, void* d_block, int64_t cap_records) {
+  if (!v || !d_block) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  uint8_t* blk = reinterpret_cast<uint8_t*>(d_block);
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
+  launch_boundary_pack(v->dev, blk + 16, (uint32_t)cap_records, v->stream);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(blk, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));  // the count travels in-band
+  return TF_OK;
+}
+
+int tf_boundary_unpack_blocks(tf_volume* v, const void* d_blocks, int32_t n_blocks, int32_t own_block,
+                              int64_t cap_records, int join_dirty) {
+  if (!v || !d_blocks) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  VolumeDev d = v->dev;
+  int par = -1;
+  if (join_dirty) {  // the ghosts belong to the frame integrated last; its texture stage has not run yet
+    int rc = fused_arm(v);
+    if (rc) return rc;
+    par = v->atlas.fused_par;
+    d.work_ids = v->atlas.d_work_ids + (size_t)par * d.max_chunks;
+    d.work_slot = v->atlas.d_work_slot + (size_t)par * d.max_chunks;
+  }
+  launch_boundary_unpack_blocks(d, reinterpret_cast<const uint8_t*>(d_blocks), n_blocks, own_block,
+                                (uint32_t)cap_records, par, v->epoch, v->stream);
+  TF_HIP(hipGetLastError());
+  v->host_list_n = -1;
   return TF_OK;
 }
 

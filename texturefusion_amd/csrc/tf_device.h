@@ -30,7 +30,8 @@ constexpr uint32_t kStCoarseFull = 4u;
 constexpr uint32_t kStMissing = 8u;
 constexpr uint32_t kStHashFull = 16u;
 constexpr uint32_t kStMeshFull = 32u;   // a mesh exceeds tf_config.mesh_max_vertices / mesh_max_triangles
-constexpr uint32_t kStAtlasFull = 64u;  // Atlas::AddPatch overflow (std::overflow_error, Atlas.cpp:52-53)
+constexpr uint32_t kStAtlasFull = 64u;
+constexpr uint32_t kStXchgFull = 128u;  // a rank's ghost band did not fit the exchange block (raise cap_records)  // Atlas::AddPatch overflow (std::overflow_error, Atlas.cpp:52-53)
 
 struct Cam {
   int W, H;
@@ -236,6 +237,9 @@ void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const f
                           const uint16_t* col, hipStream_t s);
 void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s);
 void launch_boundary_unpack(const VolumeDev& v, const uint8_t* records, uint32_t n, hipStream_t s);
+// blocks of [16-B header {count} | cap records] per rank, the block of `skip` is this rank's own
+void launch_boundary_unpack_blocks(const VolumeDev& v, const uint8_t* blocks, int nblocks, int skip, uint32_t cap,
+                                   int dirty_par, uint32_t stamp, hipStream_t s);
 // ---- launchers (tf_mesh.hip) ---------------------------------------------------------
 // dlist: int4 {id.x, id.y, id.z, -} per dirty chunk, *dcount entries
 void launch_init_meshes(const VolumeDev& v, hipStream_t s);

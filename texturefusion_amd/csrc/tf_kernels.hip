@@ -1487,4 +1487,60 @@ void launch_boundary_unpack(const VolumeDev& v, const uint8_t* records, uint32_t
   hipLaunchKernelGGL(k_boundary_unpack, dim3(n < 1024 ? n : 1024), dim3(512), 0, s, v, records, n);
 }
 
+
+// The same over the blocks of an all-gather: block b = [u32 count, 12 B pad | cap records]; the own block is
+// skipped.  dirty_par >= 0 (fused textured flow, one exchange per frame): a ghost that arrives was updated on
+// its owner's side in this frame, so its owned face neighbours belong to this frame's dirty set
+// (Chisel.h:197-203) -- they join the work list, de-duplicated by the per-slot stamp like k_dirty_frame's.
+__global__ __launch_bounds__(512) void k_boundary_unpack_blocks(VolumeDev v, const uint8_t* blocks, int nblocks, int skip,
+                                                                uint32_t cap, int dirty_par, uint32_t stamp) {
+  __shared__ uint32_t sslot;
+  const size_t block_bytes = 16 + (size_t)cap * (16 + 4096 + 4096);
+  for (int b = 0; b < nblocks; ++b) {
+    if (b == skip) continue;
+    const uint8_t* blk = blocks + (size_t)b * block_bytes;
+    uint32_t n = *reinterpret_cast<const uint32_t*>(blk);
+    if (n > cap) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&v.vctl->status, kStXchgFull);
+      n = cap;
+    }
+    for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
+      const uint8_t* rec = blk + 16 + (size_t)r * (16 + 4096 + 4096);
+      const int4 id = *reinterpret_cast<const int4*>(rec);
+      if (part_owned(v, id.x, id.y, id.z)) continue;  // block-uniform
+      if (threadIdx.x == 0) {
+        bool is_new;
+        uint32_t ent;
+        sslot = chunk_acquire(v, id, &is_new, &ent);
+        if (sslot != kInvalidSlot && (uint32_t)id.w > v.mark_epoch[sslot]) v.mark_epoch[sslot] = (uint32_t)id.w;
+      }
+      __syncthreads();
+      const uint32_t slot = sslot;
+      if (slot != kInvalidSlot) {
+        v.tsdf[(size_t)slot * kChunkVoxels + threadIdx.x] = reinterpret_cast<const float2*>(rec + 16)[threadIdx.x];
+        v.color[(size_t)slot * kChunkVoxels + threadIdx.x] = reinterpret_cast<const ushort4*>(rec + 16 + 4096)[threadIdx.x];
+      }
+      if (dirty_par >= 0 && threadIdx.x >= 1 && threadIdx.x <= 6) {
+        int4 q = nbr7(id, (int)threadIdx.x);
+        q.w = 0;
+        if (part_owned(v, q.x, q.y, q.z)) {
+          const uint32_t ent = hash_find(v, pack_id(q.x, q.y, q.z));
+          if (ent != kInvalidSlot && (v.hent[ent].alive & 1u) && v.hent[ent].slot != kInvalidSlot) {
+            const uint32_t qs = v.hent[ent].slot;
+            if (atomicMax(&v.mesh_rec[qs].stamp, stamp) < stamp) {
+              const uint32_t p = atomicAdd(&v.actl->set[dirty_par].n_work, 1u);
+              if (p < v.max_chunks) { v.work_ids[p] = q; v.work_slot[p] = qs; }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+void launch_boundary_unpack_blocks(const VolumeDev& v, const uint8_t* blocks, int nblocks, int skip, uint32_t cap,
+                                   int dirty_par, uint32_t stamp, hipStream_t s) {
+  hipLaunchKernelGGL(k_boundary_unpack_blocks, dim3(1024), dim3(512), 0, s, v, blocks, nblocks, skip, cap, dirty_par, stamp);
+}
+
 }  // namespace tf

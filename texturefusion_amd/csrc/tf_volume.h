@@ -75,6 +75,15 @@ struct AtlasState {
   size_t h_stage_bytes = 0;
 };
 
+// RCCL communicator of the handle (tf_comm_init) and the exchange buffers
+struct CommState {
+  void* comm = nullptr;  // ncclComm_t
+  int rank = 0, nranks = 0;
+  void* d_send = nullptr;
+  void* d_recv = nullptr;
+  int64_t cap_records = 0;
+};
+
 }  // namespace tf
 
 struct tf_volume {
@@ -134,6 +143,8 @@ struct tf_volume {
   std::vector<hipEvent_t> prof_pool;
   tf_profile prof_acc{};
   tf::AtlasState atlas;
+  tf::CommState comm;
+  int64_t comm_cap = 0;  // > 0: the fused textured flow exchanges the ghost band after every voxel update
 };
 
 namespace tf {
@@ -144,6 +155,8 @@ void prof_end(tf_volume* v, hipStream_t s = nullptr);
 int atlas_init(tf_volume* v);
 void atlas_destroy(tf_volume* v);
 int atlas_reset(tf_volume* v);
+int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t stamp);
+void comm_destroy(tf_volume* v);
 int kf_push(tf_volume* v, int slot);
 void launch_patch_fused(tf_volume* v, const VolumeDev& d, int par, const KfDev& kf, hipStream_t s);
 inline uint64_t host_pack_id(const int32_t id[3]) {

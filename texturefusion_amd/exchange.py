@@ -1,46 +1,30 @@
-"""Boundary-chunk exchange between chunk-range partitions.
+"""Boundary-chunk exchange between chunk-range partitions through torch.distributed.
 
-The only collective of the path: an all-gather of the records of updated chunks that sit on a
-slab face.  Counts are gathered first, then payloads padded to the largest count (RCCL over
-xGMI when the tensors are device-resident and the backend is "nccl"; gloo on CPU in the tests).
-torch.distributed is plumbing here; the records are produced / consumed by tf_boundary_pack /
-tf_boundary_unpack (include/tf_fusion.h).
+The path's only collective is ONE fixed-capacity all-gather of blocks
+    [u32 record count, 12 B padding | cap records of 16 + 4096 + 4096 B]
+-- the count travels in-band, so nothing has to come back to the host between packing and unpacking
+(tf_boundary_pack_block / tf_boundary_unpack_blocks, include/tf_fusion.h).  The product's own transport is RCCL
+inside the library (tf_comm_init / tf_exchange_boundary, texturefusion_amd/csrc/tf_comm.cpp); this helper moves the
+same blocks with whatever backend the process group has (gloo on CPU in the tests, where RCCL cannot run).
+torch.distributed is plumbing here.
 """
 from __future__ import annotations
 
 RECORD_BYTES = 16 + 4096 + 4096
+HEADER_BYTES = 16
 
 
-def allgather_records(send, n_records, group=None, synchronize=True):
-    """send: 1-D uint8 tensor of capacity cap*RECORD_BYTES holding n_records records; n_records is an
-    int or a 1-element device tensor (tf_boundary_pack_async leaves the count on the device).
-    Returns [(tensor, count)] per rank (own rank included).  With synchronize=False the caller orders
-    the consumer behind the collective itself (stream events), e.g. to overlap the exchange of one
-    frame batch with the integration of the next."""
+def block_bytes(cap: int) -> int:
+    return HEADER_BYTES + cap * RECORD_BYTES
+
+
+def allgather_blocks(block, group=None):
+    """block: 1-D uint8 tensor of block_bytes(cap) bytes (this rank's [count | records]).  Returns the 1-D uint8
+    tensor of world * block_bytes(cap) bytes every rank ends up with, rank r's block at r * block_bytes(cap)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    if torch.is_tensor(n_records):
-        cnt = n_records.reshape(1).to(torch.int64)
-    else:
-        cnt = torch.tensor([int(n_records)], dtype=torch.int64, device=send.device)
-    cnts = [torch.zeros_like(cnt) for _ in range(world)]
-    dist.all_gather(cnts, cnt, group=group)
-    counts = [int(c.item()) for c in cnts]
-    cap = send.numel() // RECORD_BYTES
-    if max(counts) > cap:
-        raise RuntimeError("boundary buffer too small: %d records > capacity %d" % (max(counts), cap))
-    m = max(counts)
-    if m == 0:
-        return [(send[:0], 0) for _ in range(world)]
-    # equal-sized payloads: every rank contributes its first max(count) records (the tail of a
-    # shorter contribution is padding and is never unpacked)
-    part = send[: m * RECORD_BYTES]
-    recv = [torch.empty_like(part) for _ in range(world)]
-    dist.all_gather(recv, part, group=group)
-    if send.is_cuda and synchronize:
-        # the consumer (tf_boundary_unpack) runs on the volume's own HIP stream: make the collective's
-        # result visible to it before returning
-        torch.cuda.synchronize(send.device)
-    return [(recv[r], counts[r]) for r in range(world)]
+    out = torch.empty(block.numel() * world, dtype=torch.uint8, device=block.device)
+    dist.all_gather_into_tensor(out, block, group=group)
+    return out
