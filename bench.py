@@ -54,6 +54,10 @@ def parse():
     ap.add_argument("--cpu-warmup", type=int, default=24, help="untimed frames that build up the CPU baseline's volume")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's parallel_for policy")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that fill roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the workload only, run under rocprofv3
+    ap.add_argument("--pmc-steps", type=int, default=40, help="frames of each counter pass")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-frames (H2D per frame) measurement")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N>1 code path (partition + boundary all-gather) even with one rank (smoke test)")
@@ -76,6 +80,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    if args.pmc_child:
+        args.no_roofline = args.no_host_path = True
+        args.cpu_frames = 0
+    # HBM-traffic counters first, in child processes, before this process touches the GPU
+    traffic = None
+    if world == 1 and not (args.no_pmc or args.pmc_child or args.no_roofline or args.force_exchange):
+        traffic = pmc_traffic(args)
 
     import torch  # plumbing: device memory for the frames, barrier/collectives, device sync
     import torch.distributed as dist
@@ -262,6 +274,9 @@ def main():
     if rank == 0 and prof is not None and not multi:
         out["roofline"] = roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, poses, pinv, textured,
                                    dt_instr)
+        if traffic is not None and "bytes_per_step" in traffic:
+            out["roofline"]["traffic"] = traffic["bytes_per_step"]
+        out["roofline"]["traffic_detail"] = traffic
 
     # ---- the drop-in per-frame path: host images in, one call per frame (H2D included) ---------
     if rank == 0 and not multi and not args.no_host_path:
@@ -331,13 +346,82 @@ def roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, pose
                    "k_patch_collect + k_patch_rank, k_patch (project + blit)" if textured else
                    "k_frame<color> = K-A(f) + K-C(f+1) + K-B(f+2) block ranges"),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,
-        "traffic_note": "HBM counters need separate rocprofv3 --pmc passes: see profiles/r2/ for the collected FETCH_SIZE / WRITE_SIZE",
+        "traffic": None,  # filled from the --pmc child passes of this run (pmc_traffic), stays null without them
         "algorithmic_bytes_per_step": bytes_step, "kernel_us_per_step": 1e6 * t_step,
         "kernels": per_kernel,
         "instrumented_ms_per_step": 1e3 * dt_instr / K,
         "per_step": {k: v / K for k, v in cnt.items()},
     }
+
+
+# rocprofv3 kernel names of one step (one launch each per frame)
+PMC_STEP_KERNELS = {"textured": ("k_frame<true>", "k_dirty_frame", "k_mesh_filter", "k_mesh", "k_compress_exchange",
+                                 "k_patch_rank", "k_patch<true, true, true>"),
+                    "tsdf": ("k_frame<true>",)}
+# profiles/r2/README.md (tools/calib_fetch on this box type): both counters are in KiB; WRITE_SIZE is exact;
+# FETCH_SIZE reads exactly 1/2 of the bytes for every read shape the kernels use (4/8/16 B per lane streams,
+# scattered 4-KiB blocks, 4-B gathers: 128-B requests tallied as 64 B), as MI355X_MICROARCH.md states for 16 B/lane.
+PMC_BYTES = {"FETCH_SIZE": 2048.0, "WRITE_SIZE": 1024.0}
+
+
+def pmc_traffic(args):
+    """HBM-side bytes per step of the same workload from the L2's fabric counters: one rocprofv3 --pmc pass per
+    counter (they do not fit one pass), no trace domain in the same run, the program itself behind "--"
+    (MI355X_MICROARCH.md, HBM / PMC sections).  Returns None when rocprofv3 is missing, else a dict; on any
+    failure the dict carries "error" and no "bytes_per_step" (roofline.traffic stays null -- never a constant)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    want = PMC_STEP_KERNELS[args.mode]
+    Wc, Kc = 10, args.pmc_steps
+    per_kernel = {k: {} for k in want}
+    tmp = tempfile.mkdtemp(prefix="tf_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", str(Kc), "--warmup", str(Wc),
+                   "--mode", args.mode, "--scene", args.scene, "--res", repr(args.res),
+                   "--unique-frames", str(args.unique_frames)] + (["--hires"] if args.hires else [])
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": "rocprofv3 --pmc %s: rc %d, %d csv: %s" % (counter, r.returncode, len(files), r.stderr[-300:])}
+            rows = {k: [] for k in want}
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") != counter:
+                            continue
+                        name = re.sub(r"^void ", "", row["Kernel_Name"])
+                        name = re.sub(r"\(.*$", "", name).replace("tf::", "").strip()
+                        if name in rows:
+                            rows[name].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+            for k in want:
+                v = [c for _, c in sorted(rows[k])][Wc:]  # launches behind the warm-up frames
+                if not v:
+                    return {"error": "no %s samples of %s" % (counter, k)}
+                per_kernel[k][counter] = PMC_BYTES[counter] * sum(v) / len(v)
+                per_kernel[k]["launches"] = len(v)
+    except Exception as e:  # a counter pass must never take the benchmark down
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for k in want:
+        per_kernel[k]["bytes_per_launch"] = per_kernel[k]["FETCH_SIZE"] + per_kernel[k]["WRITE_SIZE"]
+    return {"bytes_per_step": sum(v["bytes_per_launch"] for v in per_kernel.values()),
+            "kernels": per_kernel,
+            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this command (%d frames each behind %d "
+                   "warm-up frames), bytes = 2048 x FETCH_SIZE + 1024 x WRITE_SIZE per launch (KiB units; FETCH_SIZE counts "
+                   "128-B requests as 64 B on gfx950 -- calibration in profiles/r2/README.md), one launch of each kernel per step; "
+                   "L2-miss traffic: Infinity-Cache hits are included" % (Kc, Wc)}
 
 
 def host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique):

@@ -130,6 +130,7 @@ def _copy_d2d(dst_ptr, src_ptr, nbytes):
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     assert hip.hipMemcpy(dst_ptr, src_ptr, nbytes, 3) == 0  # hipMemcpyDeviceToDevice
+    assert hip.hipDeviceSynchronize() == 0  # a D2D hipMemcpy may return before the copy has landed
 
 
 def test_textured_two_partitions_equal_one(gpu_required):

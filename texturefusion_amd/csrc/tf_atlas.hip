@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const uint32_t nwaves = gridDim.x * 4;
   AtlasCtl::Set* S = &v.actl->set[par];
-  const uint32_t n = S->n_work;
+  const uint32_t n = FUSED ? S->n_patch : S->n_work;  // fused flow: the compacted list of entries that own a mesh
   const unsigned long long fail_key = FUSED ? S->fail_key : ~0ull;
   const int W = cam.W, H = cam.H;
   const float Wf = (float)W, Hf = (float)H;
@@ -321,10 +321,11 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
     while (got && !slot_texloc(v, (unsigned long long)v.actl->n_slots + got - 1, &tl)) --got;
     v.actl->n_slots += got;
   }
-  for (uint32_t e = wave; e < n; e += nwaves) {
-    const uint32_t slot = v.work_slot[e];
+  for (uint32_t pe = wave; pe < n; pe += nwaves) {
+    // fused flow: {id, pool slot} straight from the compacted list (one dependent load less per patch)
+    const int4 id = FUSED ? v.patch_list[pe] : v.work_ids[pe];
+    const uint32_t slot = FUSED ? (uint32_t)id.w : v.work_slot[pe];
     if (slot == kInvalidSlot) continue;
-    const int4 id = v.work_ids[e];
     if (FUSED && pack_id(id.x, id.y, id.z) >= fail_key) continue;
     MeshRec* rec = &v.mesh_rec[slot];
     const MeshRec R = *rec;  // one 64-B record: counts, flags, slot position, box
@@ -343,13 +344,16 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
       float* tv = mesh_plane(v, slot, kMpTc + 1);
       float keepX[kVB], keepY[kVB];  // texcoords of a one-sweep patch stay in registers until the box is known
       const bool one_sweep = nv <= 64u * kVB;
-      for (uint32_t base = 0; base < nv; base += 64u * kVB) {
+      // the first sweep does not wait for the record: its loads are clamped to the block, not to nv, and go out
+      // together with the record's (lanes beyond nv are masked below)
+      for (uint32_t base = 0; base == 0 || base < nv; base += 64u * kVB) {
         // ---- loads of the sweep: vertex positions and colours
         float px[kVB], py[kVB], pz[kVB], m0[kVB], m1[kVB], m2[kVB];
+        const uint32_t lim = base == 0 ? v.mesh_cv : nv;
 #pragma unroll
         for (int j = 0; j < kVB; ++j) {
           const uint32_t i = base + 64u * j + lane;
-          const uint32_t ii = i < nv ? i : 0u;
+          const uint32_t ii = i < lim ? i : 0u;
           px[j] = mesh_plane(v, slot, kMpPos)[ii]; py[j] = mesh_plane(v, slot, kMpPos + 1)[ii];
           pz[j] = mesh_plane(v, slot, kMpPos + 2)[ii];
           m0[j] = mesh_plane(v, slot, kMpCol)[ii]; m1[j] = mesh_plane(v, slot, kMpCol + 1)[ii];
@@ -849,6 +853,7 @@ int atlas_init(tf_volume* v) {
   // two work lists: the fused flow builds the list of frame f + 1 while the patches of frame f still read theirs
   TF_HIP(hipMalloc((void**)&a.d_work_ids, sizeof(int4) * (size_t)d.max_chunks * 2));
   TF_HIP(hipMalloc((void**)&a.d_work_slot, sizeof(uint32_t) * (size_t)d.max_chunks * 2));
+  TF_HIP(hipMalloc((void**)&a.d_patch_list, sizeof(int4) * (size_t)d.max_chunks * 2));
   TF_HIP(hipMalloc((void**)&a.d_cand, sizeof(unsigned long long) * (size_t)d.max_chunks));
   TF_HIP(hipStreamCreateWithFlags(&a.aux_stream, hipStreamNonBlocking));
   for (int k = 0; k < 2; ++k) {
@@ -862,7 +867,7 @@ int atlas_init(tf_volume* v) {
   a.kf_used.assign((size_t)a.kf_cap, 0);
   TF_HIP(hipMemcpy(a.d_kf, a.h_kf.data(), sizeof(KfDev) * (size_t)a.kf_cap, hipMemcpyHostToDevice));
   d.atlas = a.buf; d.atlas_w = a.aw; d.atlas_h = a.ah; d.patch_w = (int32_t)a.pw; d.patch_h = (int32_t)a.ph;
-  d.actl = a.d_actl; d.kf_tab = a.d_kf; d.work_ids = a.d_work_ids; d.work_slot = a.d_work_slot; d.cand = a.d_cand;
+  d.actl = a.d_actl; d.kf_tab = a.d_kf; d.work_ids = a.d_work_ids; d.work_slot = a.d_work_slot; d.patch_list = a.d_patch_list; d.cand = a.d_cand;
   return atlas_reset(v);
 }
 
@@ -884,11 +889,12 @@ void atlas_destroy(tf_volume* v) {
   if (a.d_actl) hipFree(a.d_actl);
   if (a.d_work_ids) hipFree(a.d_work_ids);
   if (a.d_work_slot) hipFree(a.d_work_slot);
+  if (a.d_patch_list) hipFree(a.d_patch_list);
   if (a.d_cand) hipFree(a.d_cand);
   if (a.d_stage) hipFree(a.d_stage);
   if (a.h_stage) hipHostFree(a.h_stage);
   a.buf = nullptr; a.d_stage = nullptr; a.h_stage = nullptr; a.d_kf = nullptr; a.d_actl = nullptr;
-  a.d_work_ids = nullptr; a.d_work_slot = nullptr; a.d_cand = nullptr;
+  a.d_work_ids = nullptr; a.d_work_slot = nullptr; a.d_patch_list = nullptr; a.d_cand = nullptr;
 }
 
 int atlas_reset(tf_volume* v) {

@@ -162,6 +162,7 @@ static int init_device_state(tf_volume* v) {
   v->host_list_n = -1;
   v->epoch = 0;
   v->mesh_epoch = 0;
+  v->mesh_par = 0;
   v->n_primed = 0;
   return TF_OK;
 }
@@ -307,7 +308,8 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   if ((rc = dev_alloc(v, &d.mesh_v, (size_t)d.max_chunks * kMeshPlanes * d.mesh_cv))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_t, (size_t)d.max_chunks * 3 * d.mesh_ct))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_rec, (size_t)d.max_chunks))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.mesh_nbr, (size_t)d.max_chunks * 32))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.mesh_nbr, ((size_t)d.max_chunks + 2 * kMeshShards) * 32))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.mesh_cnt, (size_t)2 * kMeshShards * 16))) return fail(rc);
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
     SelBuf& L = v->selbuf[k];
     if ((rc = dev_alloc(v, &L.masks, (size_t)d.max_coarse))) return fail(rc);
@@ -616,6 +618,7 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
   d.sel = sel;
   d.work_ids = a.d_work_ids + (size_t)par * d.max_chunks;
   d.work_slot = a.d_work_slot + (size_t)par * d.max_chunks;
+  d.patch_list = a.d_patch_list + (size_t)par * d.max_chunks;
   prof_begin(v, TF_PROF_DIRTY);
   launch_dirty_frame(d, par, frame_epoch + 1u, v->stream);
   prof_end(v);
@@ -632,7 +635,8 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
     a.patch_pending[par ^ 1] = false;
   }
   prof_begin(v, TF_PROF_MESH);
-  launch_mesh(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1, v->stream);
+  launch_mesh(d, v->mesh_par, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1, v->stream);
+  v->mesh_par ^= 1;
   prof_end(v);
   if (!one_stream) {
     TF_HIP(hipEventRecord(a.ev_mesh[par], v->stream));
@@ -884,6 +888,7 @@ int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {
     VolumeDev d = v->dev;
     d.work_ids = v->atlas.d_work_ids + (size_t)par * d.max_chunks;
     d.work_slot = v->atlas.d_work_slot + (size_t)par * d.max_chunks;
+    d.patch_list = v->atlas.d_patch_list + (size_t)par * d.max_chunks;
     launch_texture_stats(d, par, reinterpret_cast<unsigned long long*>(v->d_tmp), v->stream);
   }
   TF_HIP(hipGetLastError());
@@ -1156,6 +1161,7 @@ int tf_boundary_unpack_blocks(tf_volume* v, const void* d_blocks, int32_t n_bloc
     par = v->atlas.fused_par;
     d.work_ids = v->atlas.d_work_ids + (size_t)par * d.max_chunks;
     d.work_slot = v->atlas.d_work_slot + (size_t)par * d.max_chunks;
+    d.patch_list = v->atlas.d_patch_list + (size_t)par * d.max_chunks;
   }
   launch_boundary_unpack_blocks(d, reinterpret_cast<const uint8_t*>(d_blocks), n_blocks, own_block,
                                 (uint32_t)cap_records, par, v->epoch, v->stream);

@@ -147,9 +147,12 @@ struct AtlasCtl {
     uint32_t n_work;               // entries of the patch work list
     uint32_t n_cand;               // work entries that still need an atlas slot
     unsigned long long fail_key;   // smallest packed id whose AddPatch overflowed (~0 = none)
+    uint32_t n_patch;              // fused flow: work entries that own a mesh (compacted into patch_list)
+    uint32_t pad;
   } set[2];
 };
 
+constexpr uint32_t kMeshShards = 32;  // survivor rows are appended shard by shard: 32 counters instead of one
 constexpr int kPhaseWaves = 16384;  // rows of the wave-timeline table (tuning aid)
 
 struct VolumeDev {
@@ -179,7 +182,9 @@ struct VolumeDev {
   uint16_t* mesh_t;
   MeshRec* mesh_rec;
   uint32_t mesh_cv, mesh_ct;
-  uint32_t* mesh_nbr;  // [max_chunks][32] mesher scratch: pool slots of a surviving work entry's 27-chunk neighbourhood
+  uint32_t* mesh_nbr;  // [kMeshShards][max_chunks / kMeshShards + 2][32] mesher scratch, one row per SURVIVING work entry
+                       // (k_mesh_filter): pool slots of its 27-chunk neighbourhood, [27] = the entry's list index
+  uint32_t* mesh_cnt;  // [2][kMeshShards][16] rows used per shard (one counter per 64-B line), double-buffered by launch parity
   // atlas (Structure/Atlas.h:43-75): u8 [atlas_h][atlas_w][3], slots of patch_w x patch_h texels
   uint8_t* atlas;
   int32_t atlas_w, atlas_h, patch_w, patch_h;
@@ -187,6 +192,7 @@ struct VolumeDev {
   KfDev* kf_tab;      // [max_keyframes]
   int4* work_ids;       // [max_chunks] work list (dirty chunks of a frame / chunksToUpdate): id, w = keyframe-table entry
   uint32_t* work_slot;  // [max_chunks] pool slot of the entry, kInvalidSlot = not processed
+  int4* patch_list;     // [max_chunks] fused flow: {id, w = pool slot} of the work entries that own a mesh, in no particular order
   unsigned long long* cand;  // [max_chunks] packed ids of the work entries that need an atlas slot
   SelBuf sel;  // the selection set the launch works on
 };
@@ -244,7 +250,7 @@ void launch_boundary_unpack_blocks(const VolumeDev& v, const uint8_t* blocks, in
 // dlist: int4 {id.x, id.y, id.z, -} per dirty chunk, *dcount entries
 void launch_init_meshes(const VolumeDev& v, hipStream_t s);
 // fused = the per-frame flow: the mesh is marked simplified at once (CompressMeshes follows in the same frame)
-void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
+void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s);
 // per-frame dirty set of the fused flow -> work list of counter set `par`
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s);

@@ -37,6 +37,36 @@ constexpr int kEdgeSlots = 3 * 729;  // vertByEdge (ChunkManager.cpp:646-648)
 
 __device__ __forceinline__ int ridx(int x, int y, int z) { return (x + 1) + (y + 1) * kR + (z + 1) * kR * kR; }
 
+// Index tables of the staging passes (the kernel is VALU-bound: no div / mod by 11 or 9 per voxel).
+//   halo: the 11^3 - 8^3 = 819 region voxels that belong to neighbour chunks, in region order:
+//         region index | neighbour (0..26) << 11 | voxel index in that chunk << 16 | (corner index + 1, 0 = not a corner) << 25
+//   corner: region index of cell corner c = px + 9 py + 81 pz
+constexpr int kHalo = kRV - 512;
+struct MeshTabs {
+  unsigned long long halo[kHalo];
+  uint16_t corner[729];
+};
+constexpr MeshTabs make_mesh_tabs() {
+  MeshTabs t{};
+  int n = 0;
+  for (int i = 0; i < kRV; ++i) {
+    const int rx = i % kR - 1, ry = (i / kR) % kR - 1, rz = i / (kR * kR) - 1;
+    if (rx >= 0 && rx < 8 && ry >= 0 && ry < 8 && rz >= 0 && rz < 8) continue;
+    const int cx = (rx + 8) >> 3, cy = (ry + 8) >> 3, cz = (rz + 8) >> 3;
+    const unsigned long long nb = (unsigned long long)(cx + cy * 3 + cz * 9);
+    const unsigned long long vox = (unsigned long long)(((rx + 8) & 7) + ((ry + 8) & 7) * 8 + ((rz + 8) & 7) * 64);
+    unsigned long long cf = 0;
+    if (rx >= 0 && ry >= 0 && rz >= 0 && rx <= 8 && ry <= 8 && rz <= 8) cf = (unsigned long long)(rx + ry * 9 + rz * 81 + 1);
+    t.halo[n++] = (unsigned long long)i | (nb << 11) | (vox << 16) | (cf << 25);
+  }
+  for (int c = 0; c < 729; ++c) {
+    const int px = c % 9, py = (c / 9) % 9, pz = c / 81;
+    t.corner[c] = (uint16_t)((px + 1) + (py + 1) * kR + (pz + 1) * kR * kR);
+  }
+  return t;
+}
+__device__ const MeshTabs d_mesh_tabs = make_mesh_tabs();
+
 // cubeIndexOffsets (ChunkManager.cpp:65-66): corner k = (ox, oy, oz)
 __device__ __forceinline__ int cox(int k) { return (0x66 >> k) & 1; }
 __device__ __forceinline__ int coy(int k) { return (0xCC >> k) & 1; }
@@ -135,7 +165,8 @@ __device__ __forceinline__ uint32_t classify_voxel(const float sdf, const float 
 __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
-                                                     uint32_t epoch, uint32_t* __restrict__ surv) {
+                                                     uint32_t epoch, uint32_t* __restrict__ surv,
+                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const uint32_t nwaves = gridDim.x * 4;
@@ -149,10 +180,7 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
       const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
       if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) own = v.hent[ent].slot;
     }
-    if (own == kInvalidSlot) {  // RecomputeMeshes: !HasChunk -> skip (:240-242)
-      if (lane == 0) surv[32 * (size_t)entry + 13] = kInvalidSlot;
-      continue;
-    }
+    if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
     const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
     uint32_t fl = 0;
 #pragma unroll
@@ -194,77 +222,93 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
     }
     if (empty) {
       if (lane == 0) {  // Mesh::Clear + "stays in allMeshes if it was there" (:244-262)
-        surv[32 * (size_t)entry + 13] = kInvalidSlot;
         MeshRec* rec = &v.mesh_rec[own];
         rec->nv = 0; rec->nt = 0; rec->state = rec->state & kMsInMap; rec->epoch = epoch;
       }
-    } else if (lane < 27) {  // a survivor: the pool slots of chunk id + (-1..1)^3 for the mesher's staging
+    } else {  // a survivor: a row of its shard with the pool slots of chunk id + (-1..1)^3 for the mesher's staging
+      const uint32_t shard = wave & (kMeshShards - 1u);
+      uint32_t p = 0;
+      if (lane == 0) p = atomicAdd(&cnt[shard * 16], 1u);
+      p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+      if (p >= cap_sh) {  // cannot happen for lists within max_chunks (entries are dealt round-robin to the waves)
+        if (lane == 0) atomicOr(&v.vctl->status, kStMeshFull);
+        continue;
+      }
       uint32_t slot = own;
-      if (lane != 13) {
+      if (lane < 27 && lane != 13) {
         slot = kInvalidSlot;
         const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
         if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
       }
-      surv[32 * (size_t)entry + lane] = slot;
+      if (lane == 27) slot = entry;
+      if (lane < 28) surv[32 * ((size_t)shard * cap_sh + p) + lane] = slot;
     }
   }
 }
 
-__global__ __launch_bounds__(256, 6) void k_mesh(VolumeDev v, const int4* __restrict__ dlist,
-                                                 const uint32_t* __restrict__ surv,
-                                                 const uint32_t* __restrict__ dcount, uint32_t max_entries,
+template <int NT>  // threads per chunk: 256, or 128 (twice the chunks in flight per CU, half the lanes per barrier)
+__global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restrict__ dlist,
+                                                 const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
+                                                 uint32_t* __restrict__ cnt_next, uint32_t cap_sh,
                                                  uint32_t epoch, float res, uint32_t simplified, uint32_t dbg,
                                                  int rearm) {
   __shared__ MeshSh sh;
   __shared__ unsigned long long mc[256];  // the triangle table, once per (persistent) workgroup
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  uint32_t n = *dcount;
-  if (n > max_entries) n = max_entries;
+  // workgroup b walks the rows of shard b % 32 (the filter appended the survivors there): a dense list, so a
+  // grid far smaller than the dirty list keeps every workgroup busy
+  const uint32_t shard = blockIdx.x & (kMeshShards - 1u);
+  uint32_t n = cnt[shard * 16];
+  if (n > cap_sh) n = cap_sh;
+  if (blockIdx.x == 0 && t < (int)kMeshShards) cnt_next[t * 16] = 0u;  // the counters of the NEXT launch's filter
   const float half = res * 0.5f;
   if (rearm >= 0 && blockIdx.x == 0 && t == 0) {
     // fused flow: the patches of the previous frame are done (the main stream waited for them ahead of this
     // frame's filter), so the counter set the NEXT frame's dirty list will append to can be re-armed
     AtlasCtl::Set* O = &v.actl->set[rearm];
-    O->n_work = 0; O->n_cand = 0; O->fail_key = ~0ull;
+    O->n_work = 0; O->n_cand = 0; O->n_patch = 0; O->fail_key = ~0ull;
   }
   bool have_mc = false;
-  for (uint32_t entry = blockIdx.x; entry < n; entry += gridDim.x) {
-    const uint32_t own = surv[32 * (size_t)entry + 13];  // k_mesh_filter: the chunk's pool slot, or "nothing to mesh"
-    if (own == kInvalidSlot) continue;
-    if (!have_mc) { mc[t] = d_mc_tri[t]; have_mc = true; }  // visible after the first barrier below
+  for (uint32_t idx = blockIdx.x / kMeshShards; idx < n; idx += gridDim.x / kMeshShards) {
+    const size_t row = (size_t)shard * cap_sh + idx;
+    const uint32_t own = surv[32 * row + 13];    // the chunk's pool slot
+    const uint32_t entry = surv[32 * row + 27];  // its place in the list
+    if (!have_mc) {  // visible after the first barrier below
+      for (int i = t; i < 256; i += NT) mc[i] = d_mc_tri[i];
+      have_mc = true;
+    }
     const int4 id = dlist[entry];
     MeshRec* rec = &v.mesh_rec[own];
-    const float2 a0 = v.tsdf[(size_t)own * kChunkVoxels + t];
-    const float2 a1 = v.tsdf[(size_t)own * kChunkVoxels + 256 + t];
+    float2 a[512 / NT];
+#pragma unroll
+    for (int j = 0; j < 512 / NT; ++j) a[j] = v.tsdf[(size_t)own * kChunkVoxels + j * NT + t];
     __syncthreads();  // the previous chunk of this workgroup is done with the shared tables
-    if (t < 27) sh.nslot[t] = surv[32 * (size_t)entry + t];
+    if (t < 27) sh.nslot[t] = surv[32 * row + t];
     if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; }
     if (dbg == 1) continue;  // triage: filter only
     // ---- stage the 11^3 voxels of the neighbourhood (own ones from registers)
-    {
-      const int x0 = t & 7, y0 = (t >> 3) & 7, z0 = t >> 6;  // voxels t and t + 256 = (x0, y0, z0) and (x0, y0, z0 + 4)
-      sh.S[ridx(x0, y0, z0)] = a0.x; sh.cflag[x0 + y0 * 9 + z0 * 81] = (a0.y > 50.0f) ? kCfHeavy : 0u;
-      sh.S[ridx(x0, y0, z0 + 4)] = a1.x; sh.cflag[x0 + y0 * 9 + (z0 + 4) * 81] = (a1.y > 50.0f) ? kCfHeavy : 0u;
+#pragma unroll
+    for (int j = 0; j < 512 / NT; ++j) {
+      const int q = j * NT + t;
+      const int x0 = q & 7, y0 = (q >> 3) & 7, z0 = q >> 6;
+      sh.S[ridx(x0, y0, z0)] = a[j].x; sh.cflag[x0 + y0 * 9 + z0 * 81] = (a[j].y > 50.0f) ? kCfHeavy : 0u;
     }
     __syncthreads();
-    for (int i = t; i < kRV; i += 256) {
-      const int rx = i % kR - 1, ry = (i / kR) % kR - 1, rz = i / (kR * kR) - 1;
-      if ((unsigned)rx < 8u && (unsigned)ry < 8u && (unsigned)rz < 8u) continue;  // own voxel: already there
-      const int cx = (rx + 8) >> 3, cy = (ry + 8) >> 3, cz = (rz + 8) >> 3;  // 0..2 = chunk offset + 1
-      const uint32_t s = sh.nslot[cx + cy * 3 + cz * 9];
+    for (int k = t; k < kHalo; k += NT) {
+      const unsigned long long e = d_mesh_tabs.halo[k];
+      const uint32_t s = sh.nslot[(uint32_t)(e >> 11) & 31u];
       float2 val = make_float2(999.0f, 0.0f);
-      if (s != kInvalidSlot) val = v.tsdf[(size_t)s * kChunkVoxels + (rx & 7) + (ry & 7) * 8 + (rz & 7) * 64];
-      sh.S[i] = val.x;
-      if (rx >= 0 && ry >= 0 && rz >= 0 && rx <= 8 && ry <= 8 && rz <= 8)
-        sh.cflag[rx + ry * 9 + rz * 81] = (val.y > 50.0f) ? kCfHeavy : 0u;
+      if (s != kInvalidSlot) val = v.tsdf[(size_t)s * kChunkVoxels + ((uint32_t)(e >> 16) & 511u)];
+      sh.S[(uint32_t)e & 2047u] = val.x;
+      const uint32_t cf = (uint32_t)(e >> 25) & 1023u;
+      if (cf) sh.cflag[cf - 1u] = (val.y > 50.0f) ? kCfHeavy : 0u;
     }
     __syncthreads();
     // ---- per corner: which of its six neighbours are below 1, is its gradient short enough.  A cell asks
     // for the three neighbours OUTSIDE its cube (extractGradientFromCubic fetches those through
     // GetNeighborSDF, :320-447), so the answer per (cell, corner) is three of these bits.
-    for (int c = t; c < 729; c += 256) {
-      const int px = c % 9, py = (c / 9) % 9, pz = c / 81;
-      const int r = ridx(px, py, pz);
+    for (int c = t; c < 729; c += NT) {
+      const int r = d_mesh_tabs.corner[c];
       const float xm = sh.S[r - 1], xp = sh.S[r + 1], ym = sh.S[r - kR], yp = sh.S[r + kR];
       const float zm = sh.S[r - kR * kR], zp = sh.S[r + kR * kR];
       uint32_t f = (xm < 1.0f ? 1u : 0u) | (xp < 1.0f ? 2u : 0u) | (ym < 1.0f ? 4u : 0u) | (yp < 1.0f ? 8u : 0u) |
@@ -275,14 +319,14 @@ __global__ __launch_bounds__(256, 6) void k_mesh(VolumeDev v, const int4* __rest
       if (!(nrm > res * 100.0f)) f |= kCfGradOk;
       sh.cflag[c] |= (uint8_t)f;
     }
-    for (int i = t; i < (kEdgeSlots + 7) / 8; i += 256) sh.ownq[i] = 0u;
+    for (int i = t; i < (kEdgeSlots + 7) / 8; i += NT) sh.ownq[i] = 0u;
     __syncthreads();
 
     if (dbg == 2) continue;  // triage: + staging and corner flags
     // ---- pass 1: per cell, the MC case, the edges its emitted triangles use, how many triangles.  Loops stay
     // rolled and re-read LDS instead of keeping the cube in registers: the kernel is latency-bound, occupancy
     // (registers) matters more than a few LDS reads.
-    for (int cell = t; cell < 512; cell += 256) {
+    for (int cell = t; cell < 512; cell += NT) {
       const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
       const int c0 = ridx(x, y, z);
       float cube[8];
@@ -342,15 +386,33 @@ __global__ __launch_bounds__(256, 6) void k_mesh(VolumeDev v, const int4* __rest
     // ---- ranks: used edge slots in ascending order (the reference's vertex order, :886-897) and the
     // cells' triangle offsets in cell order (the order of mesh->indices)
     {
-      const int first = t * 9;  // 256 x 9 = 2304 >= 2187: three edge-grid points (x, y, z edge each) per thread
-      uint32_t cnt = 0;
-#pragma unroll 1
-      for (int j = 0; j < 9; ++j) {
-        const int m = first + j;
-        if (m >= kEdgeSlots) break;
-        cnt += ((sh.ownq[m >> 3] >> (4 * (m & 7))) & 0xFu) ? 1u : 0u;
+      constexpr int kEpt = 2304 / NT, kCpt = 512 / NT;  // NT x kEpt = 2304 >= 2187 edge slots; kCpt cells per thread
+      // the thread's kEpt slots are kEpt nibbles of the ownership stream: pull them out as one bit per slot
+      // (nibble != 0) instead of walking them one by one
+      const int first = t * kEpt;
+      unsigned long long usedm = 0;  // bit j = slot first + j is used
+      {
+        constexpr int kWords = (kEpt * 4 + 31) / 32 + 1;
+        const int w0 = first >> 3, sh0 = 4 * (first & 7);
+#pragma unroll
+        for (int q = 0; q < kWords; ++q) {
+          const int wi = w0 + q;
+          uint32_t x = wi < (kEdgeSlots + 7) / 8 ? sh.ownq[wi] : 0u;
+          x |= x >> 1; x |= x >> 2; x &= 0x11111111u;          // bit 4k = nibble k is non-zero
+          x = (x | (x >> 3)) & 0x03030303u;                    // gather: 2 bits per byte
+          x = (x | (x >> 6)) & 0x000F000Fu;                    //         4 bits per half
+          x = (x | (x >> 12)) & 0xFFu;                         //         8 bits: slot 8 wi + k -> bit k
+          usedm |= (unsigned long long)x << (8 * q);
+        }
+        usedm >>= (sh0 >> 2);
+        usedm &= (1ull << kEpt) - 1ull;
+        const int left = kEdgeSlots - first;
+        if (left < kEpt) usedm = left > 0 ? (usedm & ((1ull << left) - 1ull)) : 0ull;
       }
-      const uint32_t tc = (sh.cinfo[2 * t] >> 20) + (sh.cinfo[2 * t + 1] >> 20);
+      const uint32_t cnt = (uint32_t)__popcll(usedm);
+      uint32_t tc = 0;
+#pragma unroll
+      for (int j = 0; j < kCpt; ++j) tc += sh.cinfo[kCpt * t + j] >> 20;
       uint32_t pk = cnt | (tc << 16);  // both counts scanned at once (each < 2^16)
       uint32_t inc = pk;
 #pragma unroll
@@ -361,25 +423,24 @@ __global__ __launch_bounds__(256, 6) void k_mesh(VolumeDev v, const int4* __rest
       if (lane == 63) sh.wsum[w] = inc;
       __syncthreads();
       uint32_t before = 0, total = 0;
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NT / 64; ++k) {
         if (k < w) before += sh.wsum[k];
         total += sh.wsum[k];
       }
       const uint32_t excl = before + inc - pk;
       uint32_t r = excl & 0xFFFFu;
-#pragma unroll 1
-      for (int j = 0; j < 9; ++j) {
-        const int m = first + j;
-        if (m >= kEdgeSlots) break;
-        if ((sh.ownq[m >> 3] >> (4 * (m & 7))) & 0xFu) {
-          sh.ref[m] = (uint16_t)r;
-          sh.vlist[r] = (uint16_t)m;
-          ++r;
-        }
+      for (unsigned long long u = usedm; u; u &= u - 1ull) {
+        const int m = first + (int)__builtin_ctzll(u);
+        sh.ref[m] = (uint16_t)r;
+        sh.vlist[r] = (uint16_t)m;
+        ++r;
       }
-      const uint32_t t0 = excl >> 16;
-      sh.toff[2 * t] = t0;
-      sh.toff[2 * t + 1] = t0 + (sh.cinfo[2 * t] >> 20);
+      uint32_t t0 = excl >> 16;
+#pragma unroll
+      for (int j = 0; j < kCpt; ++j) {
+        sh.toff[kCpt * t + j] = t0;
+        t0 += sh.cinfo[kCpt * t + j] >> 20;
+      }
       if (t == 0) { sh.nv = total & 0xFFFFu; sh.nt = total >> 16; }
     }
     __syncthreads();
@@ -397,7 +458,7 @@ __global__ __launch_bounds__(256, 6) void k_mesh(VolumeDev v, const int4* __rest
     // ---- pass 2: the winning cell of every used slot evaluates the vertex; lane = output vertex
     const float org[3] = {(float)(8 * id.x) * res, (float)(8 * id.y) * res, (float)(8 * id.z) * res};  // Chunk.cpp:52
     uint32_t adj = 0;
-    for (uint32_t i = t; i < nv; i += 256) {
+    for (uint32_t i = t; i < nv; i += NT) {
       const int m = sh.vlist[i];
       const int cell = owner_cell(m, __builtin_ctz((sh.ownq[m >> 3] >> (4 * (m & 7))) & 0xFu));
       const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
@@ -445,7 +506,7 @@ __global__ __launch_bounds__(256, 6) void k_mesh(VolumeDev v, const int4* __rest
     }
     if (adj) atomicOr(&sh.adj, adj);
     // ---- triangles, in cell order; (s2, s1, s0) per triangle (:914-916)
-    for (int cell = t; cell < 512; cell += 256) {
+    for (int cell = t; cell < 512; cell += NT) {
       const uint32_t info = sh.cinfo[cell];
       if (!(info >> 20)) continue;
       const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
@@ -487,6 +548,7 @@ __global__ __launch_bounds__(256) void k_init_mesh_rec(MeshRec* rec, uint32_t n)
 }
 void launch_init_meshes(const VolumeDev& v, hipStream_t s) {
   hipLaunchKernelGGL(k_init_mesh_rec, dim3(1024), dim3(256), 0, s, v.mesh_rec, v.max_chunks);
+  (void)hipMemsetAsync(v.mesh_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16, s);
 }
 
 static int mesh_resident_blocks() {
@@ -499,20 +561,31 @@ static int mesh_resident_blocks() {
   return cus * (e ? atoi(e) : 6);
 }
 
-void launch_mesh(const VolumeDev& v, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
+void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s) {
   if (!max_entries) return;
   static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch
   uint32_t* surv = v.mesh_nbr;
+  uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
+  uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshShards * 16;
+  const uint32_t cap_sh = v.max_chunks / kMeshShards + 2;
+  if (max_entries > v.max_chunks) max_entries = v.max_chunks;
   const uint32_t fgrid = (max_entries + 3) / 4 < 2048u ? (max_entries + 3) / 4 : 2048u;
   hipLaunchKernelGGL(k_mesh_filter, dim3(fgrid), dim3(256), 0, s, v, dlist, fused ? v.work_slot : nullptr, dcount,
-                     max_entries, epoch, surv);
-  // one workgroup per entry up to a grid the dispatcher balances by itself (survivors are irregularly spread
-  // over the list: a persistent grid with a fixed stride leaves a tail); TF_MESH_GRID overrides
-  static const uint32_t gmax = getenv("TF_MESH_GRID") ? (uint32_t)atoi(getenv("TF_MESH_GRID")) : 16384u;
-  const uint32_t grid = max_entries < gmax ? max_entries : gmax;
-  hipLaunchKernelGGL(k_mesh, dim3(grid), dim3(256), 0, s, v, dlist, surv, dcount, max_entries, epoch, res,
-                     fused ? kMsSimplified : 0u, dbg, rearm_set);
+                     max_entries, epoch, surv, cnt, cap_sh);
+  // the survivors form dense per-shard lists: a grid of a few resident rounds, each workgroup striding its shard
+  // (TF_MESH_GRID overrides; rounded to a multiple of the shard count)
+  static const uint32_t gmax = getenv("TF_MESH_GRID") ? (uint32_t)atoi(getenv("TF_MESH_GRID")) : 4096u;
+  uint32_t grid = ((max_entries + kMeshShards - 1) / kMeshShards + 1) * kMeshShards;
+  if (grid > gmax) grid = gmax;
+  grid = (grid + kMeshShards - 1) / kMeshShards * kMeshShards;
+  static const int nt = getenv("TF_MESH_THREADS") ? atoi(getenv("TF_MESH_THREADS")) : 256;  // experiment knob
+  if (nt == 256)
+    hipLaunchKernelGGL(k_mesh<256>, dim3(grid), dim3(256), 0, s, v, dlist, surv, cnt, cnt_next, cap_sh, epoch, res,
+                       fused ? kMsSimplified : 0u, dbg, rearm_set);
+  else
+    hipLaunchKernelGGL(k_mesh<128>, dim3(grid), dim3(128), 0, s, v, dlist, surv, cnt, cnt_next, cap_sh, epoch, res,
+                       fused ? kMsSimplified : 0u, dbg, rearm_set);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -598,7 +671,9 @@ __global__ __launch_bounds__(256) void k_compress_exchange(VolumeDev v, const in
   uint32_t n = *count;
   if (n > cap) n = cap;
   const uint32_t total = n * 8u;  // 8 threads per entry: k = 0..5 neighbours, 6 and 7 idle
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __shared__ uint32_t wcnt[4];
+  __shared__ uint32_t gbase;
   for (uint32_t b0 = blockIdx.x * 256; b0 < total; b0 += gridDim.x * 256) {
     const uint32_t i = b0 + threadIdx.x;
     const bool act = i < total && (i & 7u) < 6u;
@@ -627,6 +702,20 @@ __global__ __launch_bounds__(256) void k_compress_exchange(VolumeDev v, const in
         p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
         if (need) v.cand[p0 + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = pack_id(id.x, id.y, id.z);
       }
+      // the entries that own a mesh, compacted for the patch kernel (one wave per patch, one patch per wave);
+      // one same-address atomic per workgroup
+      const bool keep = act && k == 0 && has_mesh;
+      const unsigned long long km = __ballot(keep);
+      if (lane == 0) wcnt[w] = (uint32_t)__popcll(km);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int q = 0; q < 4; ++q) { const uint32_t c = wcnt[q]; wcnt[q] = tot; tot += c; }
+        gbase = tot ? atomicAdd(&v.actl->set[collect_par].n_patch, tot) : 0u;
+      }
+      __syncthreads();
+      if (keep) v.patch_list[gbase + wcnt[w] + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = make_int4(id.x, id.y, id.z, (int)slot);
+      __syncthreads();
     }
     if (!act || !has_mesh) continue;
     MeshRec* a = &v.mesh_rec[slot];
@@ -751,8 +840,9 @@ int tf_update_meshes(tf_volume* v, int64_t* n_meshed) {
   if (!n) return TF_OK;
   const uint8_t* db = reinterpret_cast<const uint8_t*>(v->d_tmp);
   prof_begin(v, TF_PROF_MESH);
-  launch_mesh(v->dev, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), n,
+  launch_mesh(v->dev, v->mesh_par, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), n,
               ++v->mesh_epoch, v->res, false, -1, v->stream);
+  v->mesh_par ^= 1;
   prof_end(v);
   TF_HIP(hipGetLastError());
   return tf_sync(v);

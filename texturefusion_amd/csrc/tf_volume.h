@@ -60,6 +60,7 @@ struct AtlasState {
   AtlasCtl* d_actl = nullptr;
   int4* d_work_ids = nullptr;
   uint32_t* d_work_slot = nullptr;
+  int4* d_patch_list = nullptr;
   unsigned long long* d_cand = nullptr;
   int fused_par = 0;   // counter set of the next fused frame
   // fused flow: the patch stages of frame f (second stream) overlap the voxel update of frame f + 1
@@ -133,6 +134,7 @@ struct tf_volume {
   uint32_t epoch = 0;        // finalize counter (mark / erase stamps are epoch + 1)
   uint32_t clear_floor = 0;  // stamps <= this were cleared (Chisel::CompressMeshes' chunksToUpdate.clear())
   uint32_t mesh_epoch = 0;   // meshing passes so far (MeshRec::epoch)
+  int mesh_par = 0;          // parity of the next mesher launch (VolumeDev::mesh_cnt)
   // on-demand device scratch
   void* d_tmp = nullptr;
   size_t d_tmp_bytes = 0;
