@@ -342,8 +342,8 @@ def roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, pose
             per_kernel[k]["achieved_GBs"] = b / per_kernel[k]["us_per_step"] / 1e3
     return {
         "bound": "hbm",
-        "kernel": ("all kernels of a step: k_frame (K-A + K-C + K-B roles), k_dirty_frame, k_mesh, k_compress_exchange, "
-                   "k_patch_collect + k_patch_rank, k_patch (project + blit)" if textured else
+        "kernel": ("all kernels of a step: k_frame (K-A + K-C + K-B roles), k_dirty_frame, k_mesh_filter + k_mesh, "
+                   "k_compress_exchange, k_patch_rank, k_patch (project + blit)" if textured else
                    "k_frame<color> = K-A(f) + K-C(f+1) + K-B(f+2) block ranges"),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": None,  # filled from the --pmc child passes of this run (pmc_traffic), stays null without them
@@ -355,7 +355,7 @@ def roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, pose
 
 
 # rocprofv3 kernel names of one step (one launch each per frame)
-PMC_STEP_KERNELS = {"textured": ("k_frame<true>", "k_dirty_frame", "k_mesh_filter", "k_mesh", "k_compress_exchange",
+PMC_STEP_KERNELS = {"textured": ("k_frame<true>", "k_dirty_frame", "k_mesh_filter", "k_mesh<256>", "k_compress_exchange",
                                  "k_patch_rank", "k_patch<true, true, true>"),
                     "tsdf": ("k_frame<true>",)}
 # profiles/r2/README.md (tools/calib_fetch on this box type): both counters are in KiB; WRITE_SIZE is exact;
@@ -442,8 +442,8 @@ def host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique):
     vol.sync()
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "frames": n,
-            "note": "tf_integrate_frame_host: host depth + RGBA in, H2D (3.7 MB at 640x480) inside the timed region, "
-                    "one call per frame, one synchronisation at the end"}
+            "note": "tf_integrate_frame_host: host depth + RGBA in, H2D (%.1f MB per frame) inside the timed region, "
+                    "one call per frame, one synchronisation at the end" % (8e-6 * frames[0][0].size)}
 
 
 def cpu_baseline(args, cam, res, frames, n_unique, textured):

@@ -308,7 +308,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   if ((rc = dev_alloc(v, &d.mesh_v, (size_t)d.max_chunks * kMeshPlanes * d.mesh_cv))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_t, (size_t)d.max_chunks * 3 * d.mesh_ct))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_rec, (size_t)d.max_chunks))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.mesh_nbr, ((size_t)d.max_chunks + 2 * kMeshShards) * 32))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.mesh_nbr, (size_t)kMeshShards * mesh_shard_rows(d.max_chunks) * 32))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_cnt, (size_t)2 * kMeshShards * 16))) return fail(rc);
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
     SelBuf& L = v->selbuf[k];

@@ -182,7 +182,7 @@ struct VolumeDev {
   uint16_t* mesh_t;
   MeshRec* mesh_rec;
   uint32_t mesh_cv, mesh_ct;
-  uint32_t* mesh_nbr;  // [kMeshShards][max_chunks / kMeshShards + 2][32] mesher scratch, one row per SURVIVING work entry
+  uint32_t* mesh_nbr;  // [kMeshShards][mesh_shard_rows(max_chunks)][32] mesher scratch, one row per SURVIVING work entry
                        // (k_mesh_filter): pool slots of its 27-chunk neighbourhood, [27] = the entry's list index
   uint32_t* mesh_cnt;  // [2][kMeshShards][16] rows used per shard (one counter per 64-B line), double-buffered by launch parity
   // atlas (Structure/Atlas.h:43-75): u8 [atlas_h][atlas_w][3], slots of patch_w x patch_h texels
@@ -250,6 +250,7 @@ void launch_boundary_unpack_blocks(const VolumeDev& v, const uint8_t* blocks, in
 // dlist: int4 {id.x, id.y, id.z, -} per dirty chunk, *dcount entries
 void launch_init_meshes(const VolumeDev& v, hipStream_t s);
 // fused = the per-frame flow: the mesh is marked simplified at once (CompressMeshes follows in the same frame)
+uint32_t mesh_shard_rows(uint32_t max_chunks);
 void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s);
 // per-frame dirty set of the fused flow -> work list of counter set `par`

@@ -168,18 +168,28 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
                                                      uint32_t* __restrict__ cnt, uint32_t cap_sh) {
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const uint32_t nwaves = gridDim.x * 4;
+  // wave w takes entries w, w + nwaves, ...; its survivors go to shard w % 32.  (Measured on MI355X: handing each
+  // XCD a contiguous stretch of the list instead -- for L2 reuse of the halo reads -- is slower, 15.6 -> 19.9 us here
+  // and 38 -> 54 us in k_mesh: survivors cluster in the list, so contiguous shards are unevenly filled.)
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const uint32_t shard = wave & (kMeshShards - 1u);
   uint32_t n = *dcount;
   if (n > max_entries) n = max_entries;
   for (uint32_t entry = wave; entry < n; entry += nwaves) {
     const int4 id = dlist[entry];
-    uint32_t own = kInvalidSlot;
-    if (dslot) own = dslot[entry];
-    else {
-      const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
-      if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) own = v.hent[ent].slot;
+    // The kernel is a chain of dependent round trips (one entry per wave), so everything that only depends on
+    // the id goes out at once: lanes 0..26 look up the 27 chunks of the neighbourhood -- the survivors' row
+    // needs them all, the boundary test the +x/+y/+z seven of them -- while the own voxels are read.
+    uint32_t nslot = kInvalidSlot;
+    if (lane < 27) {
+      if (lane == 13 && dslot) nslot = dslot[entry];
+      else {
+        const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
+        if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
+      }
     }
+    const uint32_t own = (uint32_t)__shfl((int)nslot, 13);
     if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
     const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
     uint32_t fl = 0;
@@ -192,12 +202,6 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
     for (int o = 32; o >= 1; o >>= 1) fl |= (uint32_t)__shfl_xor((int)fl, o);
     bool empty = !(fl & 1u);
     if (!empty && (fl & 14u) != 14u) {
-      // chunks id + (1,0,0), (0,1,0), (1,1,0), (0,0,1), (1,0,1), (0,1,1), (1,1,1): lanes 1..7 look them up
-      uint32_t ns = kInvalidSlot;
-      if (lane >= 1 && lane < 8) {
-        const uint32_t ent = hash_find(v, pack_id(id.x + (lane & 1), id.y + ((lane >> 1) & 1), id.z + (lane >> 2)));
-        if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) ns = v.hent[ent].slot;
-      }
       uint32_t f2 = 0;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {  // corner voxels with a coordinate 8: 3 faces of 64, 3 edges of 8, 1 corner
@@ -210,7 +214,8 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
         else if (q < 208) { cx = 8; cy = q & 7; cz = 8; }
         else if (q < 216) { cx = q & 7; cy = 8; cz = 8; }
         else { cx = 8; cy = 8; cz = 8; }
-        const uint32_t s = (uint32_t)__shfl((int)ns, (cx >> 3) + 2 * (cy >> 3) + 4 * (cz >> 3));
+        // chunk id + (cx >> 3, cy >> 3, cz >> 3) = neighbourhood index 13 + dx + 3 dy + 9 dz
+        const uint32_t s = (uint32_t)__shfl((int)nslot, 13 + (cx >> 3) + 3 * (cy >> 3) + 9 * (cz >> 3));
         if (q < 217 && s != kInvalidSlot) {
           const float2 val = v.tsdf[(size_t)s * kChunkVoxels + (cx & 7) + (cy & 7) * 8 + (cz & 7) * 64];
           f2 |= classify_voxel(val.x, val.y);
@@ -226,7 +231,6 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
         rec->nv = 0; rec->nt = 0; rec->state = rec->state & kMsInMap; rec->epoch = epoch;
       }
     } else {  // a survivor: a row of its shard with the pool slots of chunk id + (-1..1)^3 for the mesher's staging
-      const uint32_t shard = wave & (kMeshShards - 1u);
       uint32_t p = 0;
       if (lane == 0) p = atomicAdd(&cnt[shard * 16], 1u);
       p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
@@ -234,14 +238,8 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
         if (lane == 0) atomicOr(&v.vctl->status, kStMeshFull);
         continue;
       }
-      uint32_t slot = own;
-      if (lane < 27 && lane != 13) {
-        slot = kInvalidSlot;
-        const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
-        if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
-      }
-      if (lane == 27) slot = entry;
-      if (lane < 28) surv[32 * ((size_t)shard * cap_sh + p) + lane] = slot;
+      if (lane == 27) nslot = entry;
+      if (lane < 28) surv[32 * ((size_t)shard * cap_sh + p) + lane] = nslot;
     }
   }
 }
@@ -294,6 +292,8 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restr
       sh.S[ridx(x0, y0, z0)] = a[j].x; sh.cflag[x0 + y0 * 9 + z0 * 81] = (a[j].y > 50.0f) ? kCfHeavy : 0u;
     }
     __syncthreads();
+    // (measured: issuing the row, the table entries and then own + halo voxels as two batches of loads -- two
+    // dependent hops instead of four -- is slower, 36 -> 46 us: the extra registers spill)
     for (int k = t; k < kHalo; k += NT) {
       const unsigned long long e = d_mesh_tabs.halo[k];
       const uint32_t s = sh.nslot[(uint32_t)(e >> 11) & 31u];
@@ -561,6 +561,10 @@ static int mesh_resident_blocks() {
   return cus * (e ? atoi(e) : 6);
 }
 
+// rows per shard: a shard takes every 32nd of the filter's (at most 8192) waves, a wave every 8192-th entry
+// -> at most max_chunks / 32 rows, plus one partial pass of 256
+uint32_t mesh_shard_rows(uint32_t max_chunks) { return max_chunks / kMeshShards + 258u; }
+
 void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s) {
   if (!max_entries) return;
@@ -568,7 +572,7 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   uint32_t* surv = v.mesh_nbr;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
   uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshShards * 16;
-  const uint32_t cap_sh = v.max_chunks / kMeshShards + 2;
+  const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
   if (max_entries > v.max_chunks) max_entries = v.max_chunks;
   const uint32_t fgrid = (max_entries + 3) / 4 < 2048u ? (max_entries + 3) / 4 : 2048u;
   hipLaunchKernelGGL(k_mesh_filter, dim3(fgrid), dim3(256), 0, s, v, dlist, fused ? v.work_slot : nullptr, dcount,
@@ -593,6 +597,7 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
 // (Structure/Chisel.h:192-208): every updated chunk of the frame's list and its six face neighbours, those
 // that exist, each once (a stamp per pool slot de-duplicates), appended to the work list.
 // ---------------------------------------------------------------------------------------
+constexpr uint32_t kDirtyBlocks = 256;
 __global__ __launch_bounds__(1024) void k_dirty_frame(VolumeDev v, int par, uint32_t stamp) {
   const SelBuf& L = v.sel;
   const uint32_t nl = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
@@ -601,7 +606,7 @@ __global__ __launch_bounds__(1024) void k_dirty_frame(VolumeDev v, int par, uint
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   __shared__ uint32_t wcnt[16];
   __shared__ uint32_t gbase;
-  for (uint32_t b0 = blockIdx.x * 1024; b0 < total; b0 += gridDim.x * 1024) {
+  for (uint32_t b0 = blockIdx.x * 1024; b0 < total; b0 += kDirtyBlocks * 1024) {
     const uint32_t t = b0 + threadIdx.x;
     bool emit = false;
     int4 q = make_int4(0, 0, 0, 0);
@@ -639,7 +644,7 @@ __global__ __launch_bounds__(1024) void k_dirty_frame(VolumeDev v, int par, uint
   }
 }
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s) {
-  hipLaunchKernelGGL(k_dirty_frame, dim3(256), dim3(1024), 0, s, v, par, stamp);
+  hipLaunchKernelGGL(k_dirty_frame, dim3(kDirtyBlocks), dim3(1024), 0, s, v, par, stamp);
 }
 
 // ---------------------------------------------------------------------------------------
