@@ -94,6 +94,8 @@ def lib():
     L.tfo_volume_set_threads.argtypes = [vp, C.c_int]
     L.tfo_volume_set_kernel.argtypes = [vp, C.c_int]
     L.tfo_have_avx2.restype = C.c_int
+    L.tfo_set_sum_order.argtypes = [C.c_int]
+    L.tfo_get_sum_order.restype = C.c_int
     L.tfo_volume_num_chunks.restype = C.c_int64
     L.tfo_volume_num_chunks.argtypes = [vp]
     L.tfo_volume_list_chunks.restype = C.c_int64

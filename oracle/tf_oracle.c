@@ -40,6 +40,21 @@ static inline float dot3_seq(float a0, float a1, float a2, float b0, float b1, f
   return s;
 }
 
+/* The two orders above are this restatement's reading of Eigen's code paths; Eigen is not in the image, so
+ * which one the reference's build uses is unpinned.  tools/oracle_sum_order.py re-runs the stream with the
+ * alternatives to bound what the choice can change: bit 0 = fixed-size sites accumulate sequentially, bit 1 =
+ * dynamic sites use the tree order, bit 2 = the gradient's squared norm as (x*x + y*y) + z*z, bit 3 = normalize()
+ * multiplies by the reciprocal (Eigen 3.2) instead of dividing (Eigen >= 3.3). */
+static int g_sum_order = 0;
+void tfo_set_sum_order(int bits) { g_sum_order = bits; }
+int tfo_get_sum_order(void) { return g_sum_order; }
+static inline float dot3_fixed(float a0, float a1, float a2, float b0, float b1, float b2) {
+  return (g_sum_order & 1) ? dot3_seq(a0, a1, a2, b0, b1, b2) : dot3_tree(a0, a1, a2, b0, b1, b2);
+}
+static inline float dot3_dyn(float a0, float a1, float a2, float b0, float b1, float b2) {
+  return (g_sum_order & 2) ? dot3_tree(a0, a1, a2, b0, b1, b2) : dot3_seq(a0, a1, a2, b0, b1, b2);
+}
+
 /* QuadraticTruncator::GetTruncationDistance (truncation/QuadraticTruncator.h:45-48):
  * std::abs(q * pow(z, 2) + l * z + c) * s  with pow(float,int) -> double, l*z in float. */
 float tfo_truncation(const tfo_integrator* ig, float z) {
@@ -60,7 +75,7 @@ void tfo_centroids(const float pose[12], float res, float cen[3 * TFO_CHUNK_VOXE
         float fx = (float)x, fy = (float)y, fz = (float)z;
         for (int a = 0; a < 3; a++) {
           /* row a of R^T = column a of R */
-          float d = dot3_tree(R_(pose, 0, a), R_(pose, 1, a), R_(pose, 2, a), fx, fy, fz);
+          float d = dot3_fixed(R_(pose, 0, a), R_(pose, 1, a), R_(pose, 2, a), fx, fy, fz);
           cen[a * TFO_CHUNK_VOXELS + i] = d * res + half;
         }
       }
@@ -76,7 +91,7 @@ void tfo_chunk_scalars(const tfo_integrator* ig, const float pose[12], const int
     d[a] = o[a] - T_(pose, a);
   }
   for (int a = 0; a < 3; a++)
-    origin_cam[a] = dot3_tree(R_(pose, 0, a), R_(pose, 1, a), R_(pose, 2, a), d[0], d[1], d[2]);
+    origin_cam[a] = dot3_fixed(R_(pose, 0, a), R_(pose, 1, a), R_(pose, 2, a), d[0], d[1], d[2]);
   float tr = tfo_truncation(ig, origin_cam[2]);
   *truncation = tr;
   *weight = ig->weight / (2.0f * tr); /* ConstantWeighter.h:43-46 */
@@ -441,7 +456,7 @@ int64_t tfo_select(const float* depth, const tfo_camera* cam, const tfo_integrat
   for (int i = 0; i < 3; i++)
     for (int j = 0; j < 3; j++) rot[i][j] = R_(pose, j, i);
   for (int i = 0; i < 3; i++)
-    tc[i] = dot3_seq(rot[i][0], rot[i][1], rot[i][2], T_(pose, 0), T_(pose, 1), T_(pose, 2));
+    tc[i] = dot3_dyn(rot[i][0], rot[i][1], rot[i][2], T_(pose, 0), T_(pose, 1), T_(pose, 2));
   float r0[3], r1[3], r2[3]; /* :431-436: columns scaled by 8 then res */
   for (int i = 0; i < 3; i++) {
     r0[i] = (rot[i][0] * 8.0f) * res;
@@ -456,7 +471,7 @@ int64_t tfo_select(const float* depth, const tfo_camera* cam, const tfo_integrat
         float cur[3] = {(float)(x * 8), (float)(y * 8), (float)(z * 8)};
         int k = x + y * 2 + z * 4;
         for (int a = 0; a < 3; a++) {
-          float d = dot3_seq(rot[a][0], rot[a][1], rot[a][2], cur[0], cur[1], cur[2]);
+          float d = dot3_dyn(rot[a][0], rot[a][1], rot[a][2], cur[0], cur[1], cur[2]);
           coarse[a][k] = (d * res) * (float)step + half;
           fine[a][k] = (d * res) * 1.0f + half;
         }
@@ -483,7 +498,7 @@ int64_t tfo_select(const float* depth, const tfo_camera* cam, const tfo_integrat
               float org[3] = {(float)(i * 8) * res, (float)(j * 8) * res, (float)(k * 8) * res};
               float of[3];
               for (int a = 0; a < 3; a++) /* :521-524 */
-                of[a] = dot3_seq(rot[a][0], rot[a][1], rot[a][2], org[0], org[1], org[2]) - tc[a];
+                of[a] = dot3_dyn(rot[a][0], rot[a][1], rot[a][2], org[0], org[1], org[2]) - tc[a];
               float tr = tfo_truncation(ig, of[2]);
               float fdtp = tr + diag;
               float fdtn = negTrunc + diag;
@@ -1376,10 +1391,14 @@ static int gradient_from_cubic(const tfo_volume* v, const float cube[8], const i
   }
   const float gx = dd[1] - dd[0], gy = dd[3] - dd[2], gz = dd[5] - dd[4];
   const float yz = gy * gy + gz * gz;
-  const float sq = gx * gx + yz;
+  float sq = gx * gx + yz;
+  if (g_sum_order & 4) { const float xy = gx * gx + gy * gy; sq = xy + gz * gz; } /* alternative: sequential */
   const float g = sqrtf(sq);
   grad[0] = gx; grad[1] = gy; grad[2] = gz;
-  if (sq > 0.0f) { grad[0] = gx / g; grad[1] = gy / g; grad[2] = gz / g; }
+  if (sq > 0.0f) {
+    if (g_sum_order & 8) { const float r = 1.0f / g; grad[0] = gx * r; grad[1] = gy * r; grad[2] = gz * r; } /* Eigen 3.2 */
+    else { grad[0] = gx / g; grad[1] = gy / g; grad[2] = gz / g; }
+  }
   if (g > v->res * 100.0f) return 0;
   return 1;
 }

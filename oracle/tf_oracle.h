@@ -61,6 +61,10 @@ typedef struct {
 /* Pose = Eigen::Affine3f as 12 floats, row-major 3x4 [R | t]: R(i,j)=p[4*i+j], t(i)=p[4*i+3]. */
 
 /* ---- scalar pieces ---------------------------------------------------------------- */
+/* test aid: alternative summation orders at the sites where Eigen's order is unpinned (bit 0: fixed-size dots
+ * sequential instead of a0b0 + (a1b1 + a2b2); bit 1: dynamic mat-vec in that tree order instead of sequential) */
+void tfo_set_sum_order(int bits);
+int tfo_get_sum_order(void);
 float tfo_truncation(const tfo_integrator* ig, float z);
 void tfo_centroids(const float pose[12], float res, float cen[3 * TFO_CHUNK_VOXELS]);
 void tfo_chunk_scalars(const tfo_integrator* ig, const float pose[12], const int id[3], float res,

@@ -129,6 +129,44 @@ def test_resize_branch_close_wall(gpu_required):
     gv.close()
 
 
+def test_resize_branch_constant_image_property(gpu_required):
+    """The resize branch on the device, checked against a fact instead of the oracle: a constant keyframe image
+    fills every resized slot with exactly that constant (all tap-coefficient pairs sum to 2048), and the ratios
+    written back are slot / ROI."""
+    cam = synth.Camera()
+    ov, gv, cam, ig = make_pair(RES5, cam, max_chunks=1 << 14)
+    frames = []
+    for k in range(4):
+        d, rgba, q, pose = synth.wall_frame(0.55, cam, seed=k, rgba_value=(91, 203, 17, 1))
+        frames.append((d, rgba, pose))
+    ids = _integrate(ov, gv, frames)
+    kfs = {0: _keyframe(frames[0])}
+    _cache(gv, kfs)
+    labels = np.zeros(len(ids), np.int32)
+    _, ghot = gv.generate_patches(ids, labels)
+    gv.update_atlas(ids)
+    P = gv.get_patches(ids)
+    width, pw, ph = 13824, 24, 18
+    r0, r1 = int(ghot[0]) // width, int(ghot[1]) // width + ph
+    rows = gv.atlas_rows(r0, r1, width)
+    n_resized = 0
+    for i in range(len(ids)):
+        if not (P["flags"][i] & 1) or P["bbox"][i][2] <= 0:
+            continue
+        cols, rws = int(P["bbox"][i][2]), int(P["bbox"][i][3])
+        x, y = int(P["texloc"][i]) % width, int(P["texloc"][i]) // width - r0
+        if cols > pw or rws > ph:
+            n_resized += 1
+            assert (rows[y:y + ph, x:x + pw] == np.array([91, 203, 17], np.uint8)).all()
+            want = (np.float32(pw) / np.float32(cols) if cols > pw else np.float32(1),
+                    np.float32(ph) / np.float32(rws) if rws > ph else np.float32(1))
+            assert P["ratio"][i][0] == want[0] and P["ratio"][i][1] == want[1]
+        else:
+            assert (rows[y:y + rws, x:x + cols] == np.array([91, 203, 17], np.uint8)).all()
+    assert n_resized > 50
+    gv.close()
+
+
 def test_atlas_overflow_is_minus_one(gpu_required):
     """A 96 x 36 atlas holds 2 bands x 4 slots: the ninth AddPatch throws (Atlas.cpp:52-53), GeneratePatches
     returns -1 (Chisel.cpp:170-173), the entries before it are processed."""

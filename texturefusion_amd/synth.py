@@ -88,11 +88,16 @@ def _hash_colour(world: np.ndarray, seed: int) -> np.ndarray:
 
 
 def room_frame(k: int, cam: Camera = Camera(), n_orbit: int = 200, hole_frac: float = 0.02,
-               half=(2.0, 1.5, 2.0), radius: float = 0.3, with_quality: bool = True):
-    """Frame k of S-room.  Returns (depth f32[H,W], rgba u8[H,W,4], quality f32[H,W], pose f32[3,4])."""
+               half=(2.0, 1.5, 2.0), radius: float = 0.3, with_quality: bool = True, wobble: float = 0.0):
+    """Frame k of S-room.  Returns (depth f32[H,W], rgba u8[H,W,4], quality f32[H,W], pose f32[3,4]).
+    wobble > 0 (radians) adds a hand-held pitch / roll on top of the yaw orbit: general rotation matrices
+    (the plain orbit's have four exact zeros, which hides every summation-order question)."""
     yaw = 2.0 * math.pi * k / n_orbit
     t = (radius * math.sin(yaw), 0.0, radius * math.cos(yaw))
-    pose = pose_yaw(yaw, t)
+    if wobble:
+        pose = pose_euler(yaw, wobble * math.sin(7.0 * yaw + 0.3), wobble * math.cos(5.0 * yaw + 1.1), t)
+    else:
+        pose = pose_yaw(yaw, t)
     R = pose[:, :3].astype(np.float64)
     o = pose[:, 3].astype(np.float64)
     d_cam = _rays(cam)
