@@ -382,6 +382,31 @@ TF_API int tf_patches_download(tf_volume* v, const int32_t* ids, int64_t n, cons
 /* Atlas::texture_buffer rows [row0,row1) (MobileFusion.h:406-421 uploads the hot rows) */
 TF_API int tf_atlas_download_rows(tf_volume* v, int64_t row0, int64_t row1, uint8_t* dst);
 
+/* ---- frame pre-processing that feeds the path ---------------------------------
+ * The per-frame image passes main.cpp:117-147 runs before a frame reaches the fusion path, on images resident in
+ * device memory (row-major f32 depth / weight / quality, PLANAR f32 normal maps [3][H][W], packed u8 RGB), with the
+ * untruncated intrinsics given to tf_set_camera (the reference passes camera.c_fx ...).  Asynchronous on the
+ * handle's stream except tf_pre_refine_keyframe.  Pixels the reference leaves uninitialised are written as 0;
+ * _mm256_rsqrt_ps is the correctly rounded 1 / sqrt (see oracle/tf_oracle.c).
+ *   tf_pre_normal_map            BasicAPI::extractNormalMapSIMD      BasicAPI.cpp:849-905
+ *   tf_pre_refine_depth_normal   BasicAPI::refineDepthUseNormalSIMD  BasicAPI.cpp:728-781   (normal, depth in place)
+ *   tf_pre_color_valid           BasicAPI::checkColorQuality         BasicAPI.cpp:783-806   (Frame::colorValidFlag)
+ *   tf_pre_color_quality         BasicAPI::estimateColorQuality      BasicAPI.cpp:815-847   (Frame::observationQualityMap)
+ *   tf_pre_refine_newframe       BasicAPI::refineNewframesSIMD       BasicAPI.cpp:378-443   (depth_new in place;
+ *                                T = f32 of (pose_ref^-1 * pose_new).matrix()[3x4], row-major)
+ *   tf_pre_refine_keyframe       BasicAPI::refineKeyframesSIMD       BasicAPI.cpp:506-636   (depth_ref, weight_ref in
+ *                                place with the reference's sequential in-place semantics; T = f32 of
+ *                                (pose_new^-1 * pose_ref).matrix()[3x4]; synchronises; *rounds = passes it took) */
+TF_API int tf_pre_normal_map(tf_volume* v, const float* d_depth, float* d_normal);
+TF_API int tf_pre_refine_depth_normal(tf_volume* v, float* d_normal, float* d_depth);
+TF_API int tf_pre_color_valid(tf_volume* v, const float* d_normal, uint8_t* d_flag);
+TF_API int tf_pre_color_quality(tf_volume* v, const float* d_depth, const float* d_normal, const uint8_t* d_rgb,
+                                float* d_quality);
+TF_API int tf_pre_refine_newframe(tf_volume* v, const float* d_depth_ref, float* d_depth_new,
+                                  const float T_new_to_ref[12]);
+TF_API int tf_pre_refine_keyframe(tf_volume* v, float* d_depth_ref, float* d_weight_ref, const float* d_depth_new,
+                                  const float T_ref_to_new[12], int32_t* rounds);
+
 #ifdef __cplusplus
 }
 #endif

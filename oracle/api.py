@@ -95,6 +95,13 @@ def lib():
     L.tfo_volume_set_kernel.argtypes = [vp, C.c_int]
     L.tfo_have_avx2.restype = C.c_int
     L.tfo_set_sum_order.argtypes = [C.c_int]
+    f4 = [C.c_float] * 4
+    L.tfo_pre_normal_map.argtypes = [fp, C.c_int, C.c_int] + f4 + [fp]
+    L.tfo_pre_refine_depth_normal.argtypes = [fp, fp, C.c_int, C.c_int] + f4
+    L.tfo_pre_color_valid.argtypes = [fp, C.c_int, C.c_int] + f4 + [u8p]
+    L.tfo_pre_color_quality.argtypes = [fp, fp, u8p, C.c_int, C.c_int] + f4 + [fp]
+    L.tfo_pre_refine_newframe.argtypes = [fp, fp, C.c_int, C.c_int] + f4 + [fp]
+    L.tfo_pre_refine_keyframe.argtypes = [fp, fp, fp, C.c_int, C.c_int] + f4 + [fp]
     L.tfo_get_sum_order.restype = C.c_int
     L.tfo_volume_num_chunks.restype = C.c_int64
     L.tfo_volume_num_chunks.argtypes = [vp]
@@ -601,3 +608,58 @@ def pack_vertices(complete, wrong_mapping, labs_valid, texloc, ratio, atlas_w, a
                                  _p(texcolor, C.c_float), _p(labs, C.c_float), _p(ioff, C.c_int64),
                                  _p(indices, C.c_uint32), _p(out_v, C.c_float), _p(out_i, C.c_uint32), C.byref(ni))
     return out_v[:nv], out_i[:ni.value]
+
+
+# ---- frame pre-processing (BasicAPI.cpp:378-905): numpy in, numpy out ------------------------------------
+def _k4(cam):
+    return [C.c_float(cam.fx), C.c_float(cam.fy), C.c_float(cam.cx), C.c_float(cam.cy)]
+
+
+def pre_normal_map(depth, cam):
+    depth = f32(depth)
+    H, W = depth.shape
+    n = np.zeros((3, H, W), np.float32)
+    lib().tfo_pre_normal_map(_p(depth, C.c_float), W, H, *_k4(cam), _p(n, C.c_float))
+    return n
+
+
+def pre_refine_depth_normal(normal, depth, cam):
+    """-> (normal, depth) refined copies"""
+    n, d = f32(normal).copy(), f32(depth).copy()
+    H, W = d.shape
+    lib().tfo_pre_refine_depth_normal(_p(n, C.c_float), _p(d, C.c_float), W, H, *_k4(cam))
+    return n, d
+
+
+def pre_color_valid(normal, cam):
+    n = f32(normal)
+    _, H, W = n.shape
+    flag = np.zeros((H, W), np.uint8)
+    lib().tfo_pre_color_valid(_p(n, C.c_float), W, H, *_k4(cam), _p(flag, C.c_uint8))
+    return flag
+
+
+def pre_color_quality(depth, normal, rgb, cam):
+    d, n = f32(depth), f32(normal)
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    H, W = d.shape
+    q = np.zeros((H, W), np.float32)
+    lib().tfo_pre_color_quality(_p(d, C.c_float), _p(n, C.c_float), _p(rgb, C.c_uint8), W, H, *_k4(cam), _p(q, C.c_float))
+    return q
+
+
+def pre_refine_newframe(depth_ref, depth_new, cam, T12):
+    r, d = f32(depth_ref), f32(depth_new).copy()
+    T = f32(T12).reshape(12)
+    H, W = d.shape
+    lib().tfo_pre_refine_newframe(_p(r, C.c_float), _p(d, C.c_float), W, H, *_k4(cam), _p(T, C.c_float))
+    return d
+
+
+def pre_refine_keyframe(depth_ref, weight_ref, depth_new, cam, T12):
+    """-> (depth_ref, weight_ref) refined copies"""
+    r, w, d = f32(depth_ref).copy(), f32(weight_ref).copy(), f32(depth_new)
+    T = f32(T12).reshape(12)
+    H, W = r.shape
+    lib().tfo_pre_refine_keyframe(_p(r, C.c_float), _p(w, C.c_float), _p(d, C.c_float), W, H, *_k4(cam), _p(T, C.c_float))
+    return r, w

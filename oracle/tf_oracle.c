@@ -1909,3 +1909,200 @@ int64_t tfo_frame_textured(tfo_volume* v, tfo_atlas* a, const float* depth, cons
   free(ids); free(idx);
   return n;
 }
+
+/* =====================================================================================================
+ * Frame pre-processing that feeds the path: BasicAPI::extractNormalMapSIMD,
+ * refineDepthUseNormalSIMD, refineKeyframesSIMD, refineNewframesSIMD, checkColorQuality,
+ * estimateColorQuality (BasicAPI.cpp:378-443, 506-636, 728-905), called per frame from main.cpp:117-147.
+ * Images are row-major; normal maps are PLANAR (x plane, y plane, z plane) as the reference stores them.
+ *
+ * Harness definitions where the reference leaves a value undefined:
+ *   - cv::Mat::create does not clear: the border of the normal map (row 0, the last row, column 0, the columns
+ *     behind the last full 8-wide group) and the cleared bits of colorValidFlag are garbage there, ZERO here;
+ *   - _mm256_rsqrt_ps is an implementation-specific approximation (relative error <= 1.5 * 2^-12, different on
+ *     Intel and AMD cores): restated as the correctly rounded 1 / sqrt(x) -- results agree with any x86 run of
+ *     the reference within that relative error, not bit for bit ("parity unpinned" for these two functions);
+ *   - cv::cvtColor(CV_RGB2GRAY) and cv::Sobel(dx = 1, dy = 1, ksize 3, BORDER_REFLECT_101) follow OpenCV's
+ *     published 8-bit algorithms (gray = (4899 R + 9617 G + 1868 B + 8192) >> 14; the mixed 3x3 derivative
+ *     I(x+1,y+1) - I(x-1,y+1) - I(x+1,y-1) + I(x-1,y-1)), OpenCV itself is not in the image.
+ * No FMA anywhere (operations in the order the vec8 operators apply them).
+ * ===================================================================================================== */
+static inline float pre_rsqrt(float x) { return 1.0f / sqrtf(x); }
+
+/* BasicAPI::extractNormalMapSIMD (BasicAPI.cpp:849-905) */
+void tfo_pre_normal_map(const float* depth, int W, int H, float fx, float fy, float cx, float cy, float* normal) {
+  const size_t np = (size_t)W * H;
+  memset(normal, 0, 3 * np * sizeof(float));
+  const float thr = 0.3f;
+  const unsigned width_dst = (unsigned)(W - 1), height_dst = (unsigned)(H - 1);
+  for (unsigned i = 1; i < height_dst; i++) {
+    for (unsigned j = 1; (int)j < (int)width_dst - 9; j += 8) { /* j < width_dst - 9 (unsigned vs int: values stay small) */
+      for (unsigned l = 0; l < 8; l++) {
+        const size_t p = (size_t)i * W + j + l;
+        const float dr = depth[p + 1], db = depth[p + W], dl = depth[p - 1], dt = depth[p - W];
+        const float xs = ((float)l + (float)j) - cx;      /* inc + vec8(j) - vec8(cx) */
+        const float ys = (float)((float)i - cy);          /* vec8(i - cy): unsigned i converted to float */
+        const float u3 = dr - dl, v3 = db - dt;
+        const float u1 = ((xs * u3 + dr) + dl) / fx;
+        const float u2 = (ys * u3) / fy;
+        const float v1 = (xs * v3) / fx;
+        const float v2 = ((ys * v3 + db) + dt) / fy;
+        float nX = u2 * v3 - u3 * v2;
+        float nY = u3 * v1 - u1 * v3;
+        float nZ = u1 * v2 - u2 * v1;
+        const float nsq = (nX * nX + nY * nY) + nZ * nZ;
+        const int valid = (u3 < thr) && (u3 > -thr) && (v3 < thr) && (v3 > -thr) && (nsq > 1e-24f);
+        const float r = pre_rsqrt(nsq);
+        nX = nX * r; nY = nY * r; nZ = nZ * r;
+        normal[p] = valid ? nX : 0.0f;
+        normal[p + np] = valid ? nY : 0.0f;
+        normal[p + 2 * np] = valid ? nZ : 0.0f;
+      }
+    }
+  }
+}
+
+/* BasicAPI::refineDepthUseNormalSIMD (BasicAPI.cpp:728-781), in place */
+void tfo_pre_refine_depth_normal(float* normal, float* depth, int W, int H, float fx, float fy, float cx, float cy) {
+  const size_t np = (size_t)W * H;
+  for (int i = 0; i < H; i++)
+    for (int j = 0; j < W; j++) {
+      const size_t p = (size_t)i * W + j;
+      float vX = ((float)j - cx) / fx, vY = ((float)i - cy) / fy, vZ = 1.0f;
+      const float r = pre_rsqrt((vX * vX + vY * vY) + vZ * vZ);
+      vX = vX * r; vY = vY * r; vZ = vZ * r;
+      const float q = (vX * normal[p] + vY * normal[p + np]) + vZ * normal[p + 2 * np];
+      if (q > -0.1f && q < 0.1f) { depth[p] = 0.0f; normal[p] = 0.0f; normal[p + np] = 0.0f; normal[p + 2 * np] = 0.0f; }
+    }
+}
+
+static inline void pre_view_angle(int i, int j, float fx, float fy, float cx, float cy, float v[3]) {
+  /* Eigen::Vector3f((j - cx) / fx, (i - cy) / fy, 1).normalize(): squaredNorm in the fixed-size redux order
+   * x*x + (y*y + z*z), division by the root (Eigen >= 3.3) -- the conventions of the rest of this file */
+  const float x = ((float)j - cx) / fx, y = ((float)i - cy) / fy, z = 1.0f;
+  const float yz = y * y + z * z;
+  const float sq = x * x + yz;
+  v[0] = x; v[1] = y; v[2] = z;
+  if (sq > 0.0f) { const float n = sqrtf(sq); v[0] = x / n; v[1] = y / n; v[2] = z / n; }
+}
+
+/* BasicAPI::checkColorQuality (BasicAPI.cpp:783-806): flag = 1 where |view . normal| >= 0.2 */
+void tfo_pre_color_valid(const float* normal, int W, int H, float fx, float fy, float cx, float cy, uint8_t* flag) {
+  const size_t np = (size_t)W * H;
+  memset(flag, 0, np);
+  for (int i = 0; i < H; i++)
+    for (int j = 0; j < W; j++) {
+      const size_t p = (size_t)i * W + j;
+      float v[3];
+      pre_view_angle(i, j, fx, fy, cx, cy, v);
+      const float q = dot3_tree(v[0], v[1], v[2], normal[p], normal[p + np], normal[p + 2 * np]);
+      if ((double)fabsf(q) >= 0.2) flag[p] = 1;
+    }
+}
+
+/* BasicAPI::estimateColorQuality (BasicAPI.cpp:815-847): |Sobel_xy(gray)| * |view . normal| where depth > 0,
+ * the raw mixed derivative elsewhere */
+void tfo_pre_color_quality(const float* depth, const float* normal, const uint8_t* rgb, int W, int H, float fx,
+                           float fy, float cx, float cy, float* quality) {
+  const size_t np = (size_t)W * H;
+  uint8_t* gray = (uint8_t*)malloc(np);
+  for (size_t p = 0; p < np; p++)
+    gray[p] = (uint8_t)((4899 * (int)rgb[3 * p] + 9617 * (int)rgb[3 * p + 1] + 1868 * (int)rgb[3 * p + 2] + 8192) >> 14);
+  for (int i = 0; i < H; i++) {
+    const int im = i == 0 ? 1 : i - 1, ip = i == H - 1 ? H - 2 : i + 1; /* BORDER_REFLECT_101 */
+    for (int j = 0; j < W; j++) {
+      const int jm = j == 0 ? 1 : j - 1, jp = j == W - 1 ? W - 2 : j + 1;
+      const int s = (int)gray[(size_t)ip * W + jp] - (int)gray[(size_t)ip * W + jm] - (int)gray[(size_t)im * W + jp] +
+                    (int)gray[(size_t)im * W + jm];
+      const size_t p = (size_t)i * W + j;
+      float qv = (float)s;
+      if (depth[p] > 0) {
+        float v[3];
+        pre_view_angle(i, j, fx, fy, cx, cy, v);
+        const float vq = fabsf(dot3_tree(v[0], v[1], v[2], normal[p], normal[p + np], normal[p + 2 * np]));
+        qv = fabsf(qv) * vq;
+      }
+      quality[p] = qv;
+    }
+  }
+  free(gray);
+}
+
+/* the projection both refinement passes share: the pixel's vertex (x - cx) / fx * d, ..., moved by [R | t] */
+static inline void pre_project(const float T[12], float cx, float cy, float fx, float fy, int i, int j, float d,
+                               float V[3]) {
+  const float lx = (((float)j - cx) / fx) * d, ly = (((float)i - cy) / fy) * d;
+  for (int r = 0; r < 3; r++) V[r] = ((T[4 * r] * lx + T[4 * r + 1] * ly) + T[4 * r + 2] * d) + T[4 * r + 3];
+}
+
+/* BasicAPI::refineNewframesSIMD (BasicAPI.cpp:378-443): depth_new (in place) keeps the pixels whose projection
+ * into the keyframe finds a depth within 5 % of their own; T = f32 of (pose_ref^-1 * pose_new)[3x4]. */
+void tfo_pre_refine_newframe(const float* depth_ref, float* depth_new, int W, int H, float fx, float fy, float cx,
+                             float cy, const float T[12]) {
+  const float thr = 0.05f;
+  const float cxh = cx + 0.5f, cyh = cy + 0.5f; /* vec8(cx + 0.5): float + double literal -> double -> float */
+  const float cxh2 = (float)((double)cx + 0.5), cyh2 = (float)((double)cy + 0.5);
+  (void)cxh; (void)cyh;
+  for (int i = 0; i < H; i++)
+    for (int j = 0; j < W; j++) {
+      const size_t p = (size_t)i * W + j;
+      const float d = depth_new[p];
+      float V[3];
+      pre_project(T, cx, cy, fx, fy, i, j, d, V);
+      const float rx = (V[0] / V[2]) * fx + cxh2, ry = (V[1] / V[2]) * fy + cyh2;
+      const int valid = (rx > 1.0f) && (rx < (float)(W - 1)) && (ry > 1.0f) && (ry < (float)(H - 1));
+      float nd = 0.0f;
+      if (valid) nd = depth_ref[(size_t)cvt_rne(floorf(rx) + floorf(ry) * (float)W)];
+      const float diff = nd - V[2];
+      const int keep = (diff > (-thr) * V[2]) && (diff < thr * V[2]);
+      depth_new[p] = keep ? d : 0.0f;
+    }
+}
+
+/* BasicAPI::refineKeyframesSIMD (BasicAPI.cpp:506-636): running weighted mean of the keyframe's depth with the new
+ * frame's, per pixel; depth_ref and weight_ref are updated IN PLACE in row-major order, 8 pixels at a time, and
+ * the nearest-neighbour fallback gathers from depth_ref itself -- at a position an earlier group may already have
+ * rewritten.  T = f32 of (pose_new^-1 * pose_ref)[3x4]. */
+void tfo_pre_refine_keyframe(float* depth_ref, float* weight_ref, const float* depth_new, int W, int H, float fx,
+                             float fy, float cx, float cy, const float T[12]) {
+  const float thr = 0.05f;
+  for (int i = 0; i < H; i++)
+    for (int j0 = 0; j0 < W; j0 += 8) {
+      float outd[8], outw[8];
+      for (int l = 0; l < 8; l++) {
+        const int j = j0 + l;
+        const size_t p = (size_t)i * W + j;
+        const float d = depth_ref[p];
+        float V[3];
+        pre_project(T, cx, cy, fx, fy, i, j, d, V);
+        const float rx = (V[0] / V[2]) * fx + cx, ry = (V[1] / V[2]) * fy + cy;
+        const int valid = (rx > 2.0f) && (rx < (float)(W - 2)) && (ry > 2.0f) && (ry < (float)(H - 2));
+        float ul = 0, ur = 0, bl = 0, br = 0, nn = 0;
+        const float fxr = floorf(rx), fyr = floorf(ry);
+        if (valid) {
+          const int32_t q = cvt_rne(fxr + fyr * (float)W);
+          ul = depth_new[q]; ur = depth_new[q + 1]; bl = depth_new[q + W]; br = depth_new[q + W + 1];
+          const int32_t qn = cvt_rne(floorf(rx + 0.5f) + floorf(ry + 0.5f) * (float)W);
+          nn = depth_ref[qn]; /* the keyframe's own map, possibly already refined at qn (groups before this one) */
+        }
+        const float dx = rx - fxr, dy = ry - fyr;
+        const int smooth = ((ul - ur) < 0.1f) && ((ul - ur) > -0.1f) && ((ul - bl) < 0.1f) && ((ul - bl) > -0.1f) &&
+                           ((ul - br) < 0.1f) && ((ul - br) > -0.1f);
+        float bil = ((((1.0f - dx) * (1.0f - dy)) * ul + ((1.0f - dx) * dy) * ur) + (dx * (1.0f - dy)) * bl) +
+                    (dx * dy) * br;
+        if (!smooth) bil = nn;
+        const float diff = bil - V[2];
+        const int ok = (diff > (-thr) * V[2]) && (diff < thr * V[2]);
+        const float scale = bil / V[2];
+        const float X = V[0] * scale - T[3], Y = V[1] * scale - T[7], Z = V[2] * scale - T[11];
+        const float vZ = (T[2] * X + T[6] * Y) + T[10] * Z; /* row 2 of R^T = column 2 of R */
+        const float w = weight_ref[p];
+        outd[l] = ok ? (d * w + vZ) / (w + 1.0f) : d;
+        outw[l] = ok ? w + 1.0f : w;
+      }
+      for (int l = 0; l < 8; l++) {
+        depth_ref[(size_t)i * W + j0 + l] = outd[l];
+        weight_ref[(size_t)i * W + j0 + l] = outw[l];
+      }
+    }
+}

@@ -231,6 +231,17 @@ int tfo_volume_get_patch(const tfo_volume* v, const int id[3], uint64_t* texloc,
 int64_t tfo_frame_textured(tfo_volume* v, tfo_atlas* a, const float* depth, const uint8_t* rgba, const float pose[12],
                            const float pose_inv16[16], int frame_id, uint8_t* rgb_scratch);
 
+/* ---- frame pre-processing feeding the path (BasicAPI.cpp:378-443, 506-636, 728-905; see tf_oracle.c) ---- */
+void tfo_pre_normal_map(const float* depth, int W, int H, float fx, float fy, float cx, float cy, float* normal);
+void tfo_pre_refine_depth_normal(float* normal, float* depth, int W, int H, float fx, float fy, float cx, float cy);
+void tfo_pre_color_valid(const float* normal, int W, int H, float fx, float fy, float cx, float cy, uint8_t* flag);
+void tfo_pre_color_quality(const float* depth, const float* normal, const uint8_t* rgb, int W, int H, float fx,
+                           float fy, float cx, float cy, float* quality);
+void tfo_pre_refine_newframe(const float* depth_ref, float* depth_new, int W, int H, float fx, float fy, float cx,
+                             float cy, const float T[12]);
+void tfo_pre_refine_keyframe(float* depth_ref, float* weight_ref, const float* depth_new, int W, int H, float fx,
+                             float fy, float cx, float cy, const float T[12]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,8 @@ SYMBOLS = (
     "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
     "tf_comm_exchange_every_frame",
     "tf_update_meshes", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
+    "tf_pre_normal_map", "tf_pre_refine_depth_normal", "tf_pre_color_valid", "tf_pre_color_quality",
+    "tf_pre_refine_newframe", "tf_pre_refine_keyframe",
 )
 
 
@@ -155,6 +157,12 @@ def lib():
     L.tf_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.tf_comm_destroy.argtypes = [vp]
     L.tf_exchange_boundary.argtypes = [vp, C.c_int64]
+    L.tf_pre_normal_map.argtypes = [vp, vp, vp]
+    L.tf_pre_refine_depth_normal.argtypes = [vp, vp, vp]
+    L.tf_pre_color_valid.argtypes = [vp, vp, vp]
+    L.tf_pre_color_quality.argtypes = [vp, vp, vp, vp, vp]
+    L.tf_pre_refine_newframe.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
+    L.tf_pre_refine_keyframe.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.tf_comm_exchange_every_frame.argtypes = [vp, C.c_int64]
     L.tf_atlas_download_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p]
     u32p = C.POINTER(C.c_uint32)
@@ -491,6 +499,30 @@ class Volume:
 
     def comm_exchange_every_frame(self, cap):
         self._ck(self.L.tf_comm_exchange_every_frame(self.h, cap))
+
+    # -- frame pre-processing on device-resident images (raw device pointers; BasicAPI.cpp:378-905)
+    def pre_normal_map(self, d_depth, d_normal):
+        self._ck(self.L.tf_pre_normal_map(self.h, d_depth, d_normal))
+
+    def pre_refine_depth_normal(self, d_normal, d_depth):
+        self._ck(self.L.tf_pre_refine_depth_normal(self.h, d_normal, d_depth))
+
+    def pre_color_valid(self, d_normal, d_flag):
+        self._ck(self.L.tf_pre_color_valid(self.h, d_normal, d_flag))
+
+    def pre_color_quality(self, d_depth, d_normal, d_rgb, d_quality):
+        self._ck(self.L.tf_pre_color_quality(self.h, d_depth, d_normal, d_rgb, d_quality))
+
+    def pre_refine_newframe(self, d_depth_ref, d_depth_new, T12):
+        T = _f32(T12).reshape(12)
+        self._ck(self.L.tf_pre_refine_newframe(self.h, d_depth_ref, d_depth_new, _p(T, C.c_float)))
+
+    def pre_refine_keyframe(self, d_depth_ref, d_weight_ref, d_depth_new, T12):
+        T = _f32(T12).reshape(12)
+        rounds = C.c_int32(0)
+        self._ck(self.L.tf_pre_refine_keyframe(self.h, d_depth_ref, d_weight_ref, d_depth_new, _p(T, C.c_float),
+                                               C.byref(rounds)))
+        return int(rounds.value)
 
     # -- atlas (device-resident meshes and patches)
     def keyframe_cache(self, kf_id, rgb, depth, pose_inv16=None):
