@@ -442,8 +442,12 @@ def host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique):
     vol.sync()
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "frames": n,
-            "note": "tf_integrate_frame_host: host depth + RGBA in, H2D (%.1f MB per frame) inside the timed region, "
-                    "one call per frame, one synchronisation at the end" % (8e-6 * frames[0][0].size)}
+            "note": "tf_integrate_frame_host: host depth + RGBA in, staged through pinned memory and copied H2D (%.1f MB per "
+                    "frame) inside the timed region, one call per frame (no look-ahead: the two selection stages of a "
+                    "frame run as launches of their own), one synchronisation at the end.  The source frames are %d "
+                    "distinct host arrays (%.0f MB, not cache-resident): the single-threaded copy into the pinned slot "
+                    "is what bounds this rate on the host side"
+                    % (8e-6 * frames[0][0].size, len(frames), 8e-6 * frames[0][0].size * len(frames))}
 
 
 def cpu_baseline(args, cam, res, frames, n_unique, textured):

@@ -661,3 +661,49 @@ class Chisel {
 typedef std::shared_ptr<Chisel> ChiselPtr;
 
 }  // namespace chisel
+
+// ---------------------------------------------------------------------------------------------------------
+// BasicAPI's per-frame image passes (BasicAPI.h:112-131, called from main.cpp:117-147) with the reference's
+// names and argument order.  The reference hands over cv::Mat headers of host images; here the images stay in
+// device memory (depth / weight / quality f32[H][W], normal maps planar f32[3][H][W], RGB u8[H][W][3]) and the
+// intrinsics are the ones the volume's camera was given (PinholeCamera::SetIntrinsics).
+// ---------------------------------------------------------------------------------------------------------
+namespace BasicAPI {
+
+struct DeviceFrame {  // the image members of ::Frame the passes touch (Frame.h), as device pointers
+  float* refined_depth = nullptr;           // Frame::refined_depth
+  float* weight = nullptr;                  // Frame::weight
+  float* normal_map = nullptr;              // Frame::normal_map (planar)
+  unsigned char* rgb = nullptr;             // Frame::rgb
+  unsigned char* colorValidFlag = nullptr;  // Frame::colorValidFlag
+  float* observationQualityMap = nullptr;   // Frame::observationQualityMap
+};
+
+inline void extractNormalMapSIMD(chisel::Chisel& map, const float* depthMap, float* normalMap) {
+  chisel::tf_check(tf_pre_normal_map(map.Handle(), depthMap, normalMap), "extractNormalMapSIMD");
+}
+inline void refineDepthUseNormalSIMD(chisel::Chisel& map, float* normal, float* depth) {
+  chisel::tf_check(tf_pre_refine_depth_normal(map.Handle(), normal, depth), "refineDepthUseNormalSIMD");
+}
+// T_ref_from_new = float((pose_ref^-1 * pose_new).matrix()) rows 0..2, row-major (BasicAPI.cpp:402-406)
+inline void refineNewframesSIMD(chisel::Chisel& map, DeviceFrame& frame_ref, DeviceFrame& frame_new,
+                                const float T_ref_from_new[12]) {
+  chisel::tf_check(tf_pre_refine_newframe(map.Handle(), frame_ref.refined_depth, frame_new.refined_depth, T_ref_from_new),
+                   "refineNewframesSIMD");
+}
+// T_new_from_ref = float((pose_new^-1 * pose_ref).matrix()) rows 0..2 (BasicAPI.cpp:528-533)
+inline void refineKeyframesSIMD(chisel::Chisel& map, DeviceFrame& frame_ref, DeviceFrame& frame_new,
+                                const float T_new_from_ref[12]) {
+  chisel::tf_check(tf_pre_refine_keyframe(map.Handle(), frame_ref.refined_depth, frame_ref.weight, frame_new.refined_depth,
+                                          T_new_from_ref, nullptr),
+                   "refineKeyframesSIMD");
+}
+inline void checkColorQuality(chisel::Chisel& map, const float* normalMap, unsigned char* validColorFlag) {
+  chisel::tf_check(tf_pre_color_valid(map.Handle(), normalMap, validColorFlag), "checkColorQuality");
+}
+inline void estimateColorQuality(chisel::Chisel& map, const float* depthMap, const float* normalMap, float* qualityMap,
+                                 const unsigned char* rgb) {
+  chisel::tf_check(tf_pre_color_quality(map.Handle(), depthMap, normalMap, rgb, qualityMap), "estimateColorQuality");
+}
+
+}  // namespace BasicAPI
