@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <array>
+#include <map>
+#include <set>
 #include <vector>
 
 #include "../../oracle/tf_oracle.h"
@@ -199,6 +202,71 @@ int main() {
       CHECK(std::memcmp(m->normals.data(), onr.data(), (size_t)onv * 12) == 0);
       CHECK(std::memcmp(m->colors.data(), ocl.data(), (size_t)onv * 12) == 0);
       CHECK(std::memcmp(m->indices.data(), oix.data(), (size_t)oni * 4) == 0);
+    }
+    // ---- TexMap's bookkeeping over the mirror (Structure/TexMap.cpp:50-119: chunk graph from Mesh::adj, data costs
+    // from Chunk::observations) against the same facts read from the oracle and combined independently
+    {
+      chisel::TexMap texmap;
+      chisel::ChunkManager& cm = chiselMap.GetMutableChunkManager();
+      texmap.update_chunkgraph(chunksToUpdate, cm);
+      CHECK(texmap.chunkGraph.num_nodes() == n_patches);
+      std::map<std::array<int, 3>, size_t> index;
+      for (size_t i = 0; i < n_patches; ++i) {
+        index[{chunksToUpdate[i](0), chunksToUpdate[i](1), chunksToUpdate[i](2)}] = i;
+        CHECK(texmap.chunkGraph.chunks.find(chunksToUpdate[i])->second == i);
+      }
+      static const int dd[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+      std::set<std::pair<size_t, size_t>> edges;
+      std::vector<float> ovx(3 * 2187), onr(3 * 2187), ocl(3 * 2187);
+      std::vector<uint32_t> oix(7680);
+      for (size_t i = 0; i < n_patches; ++i) {
+        int cid[3] = {chunksToUpdate[i](0), chunksToUpdate[i](1), chunksToUpdate[i](2)};
+        int64_t onv = 0, oni = 0;
+        uint8_t oadj[6];
+        int osimp = 0;
+        CHECK(tfo_volume_get_mesh(ov, cid, &onv, &oni, ovx.data(), onr.data(), ocl.data(), oix.data(), oadj, &osimp) == 0);
+        for (int k = 0; k < 6; ++k) {
+          if (!oadj[k]) continue;
+          auto it = index.find({cid[0] + dd[k][0], cid[1] + dd[k][1], cid[2] + dd[k][2]});
+          if (it != index.end()) edges.insert({std::min(i, it->second), std::max(i, it->second)});
+        }
+      }
+      CHECK(edges.size() > 100 && texmap.chunkGraph.num_edges() == edges.size());
+      size_t degree = 0;
+      for (size_t i = 0; i < n_patches; ++i) degree += texmap.chunkGraph.get_adj_nodes(i).size();
+      CHECK(degree == 2 * edges.size());
+      for (const auto& e : edges) CHECK(texmap.chunkGraph.has_edge(e.first, e.second) && texmap.chunkGraph.has_edge(e.second, e.first));
+      // data costs: the keyframe just fused has no observations (row 1 stays empty), keyframe kfIndex is refreshed
+      std::vector<int> lookup(kfIndex + 2, -1), framesToUpdate(1, kfIndex);
+      lookup[kfIndex] = 0;
+      lookup[kfIndex + 1] = 1;
+      texmap.dataCost.set_value(0, 0, 123.0f);  // a stale entry of node 0: overwritten or removed below
+      texmap.update_datacost(chunksToUpdate, cm, lookup, kfIndex + 1, framesToUpdate);
+      size_t entries = 0;
+      for (size_t i = 0; i < n_patches; ++i) {
+        int cid[3] = {chunksToUpdate[i](0), chunksToUpdate[i](1), chunksToUpdate[i](2)};
+        int32_t kf[8];
+        float qq[8];
+        const int64_t no = tfo_volume_get_observations(ov, cid, kf, qq, 8);
+        std::map<std::size_t, float> want;
+        float stat = 1.0f;
+        for (int64_t k = 0; k < no; ++k) {
+          if (kf[k] != kfIndex && kf[k] != kfIndex + 1) continue;
+          if (qq[k] > stat) stat = qq[k];
+          if (qq[k] > 0.0f) want[(size_t)lookup[kf[k]]] = qq[k];
+        }
+        if (i == 0 && !want.count(0)) {
+          bool seen = false;
+          for (int64_t k = 0; k < no; ++k) seen = seen || kf[k] == kfIndex;
+          if (seen) want[0] = 123.0f;  // observed with quality 0: set_value is skipped, the stale entry survives
+        }
+        CHECK(texmap.dataCost.col(i) == want);
+        CHECK(texmap.statistic[i] == stat);
+        entries += want.size();
+      }
+      CHECK(entries > 50);
+      texmap.check_graph(cm);  // every node still has its mesh: nothing is removed
+      CHECK(texmap.chunkGraph.num_edges() == edges.size() && texmap.chunkGraph.get_adj_nodes(edges.begin()->first).size() > 0);
     }
     // keyframes + labels (TexMap / mapMAP are host code outside the path: a fixed assignment stands in)
     std::vector<unsigned char> rgb((size_t)W * H * 3), rgbB((size_t)W * H * 3);

@@ -221,12 +221,94 @@ struct Frame {
   const float* refined_depth = nullptr;  // cv::Mat refined_depth, 32F, H x W
   float pose_inv[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};  // f32(pose_sophus[0].inverse().matrix()), row-major
 };
-// Structure/uni_graph.h: what GeneratePatches asks of the label set (Chisel.cpp:159-160)
-struct UniGraph {
+// Structure/uni_graph.{h,cpp}: the chunk graph of the view selection -- nodes are chunks in insertion order, an
+// undirected edge joins two face neighbours whose meshes touch across the face.  GeneratePatches only asks it for
+// a chunk's node index and label (Chisel.cpp:159-160); TexMap below builds it.
+class UniGraph {
+ public:
   std::unordered_map<ChunkID, std::size_t, ChunkHasher> chunks;
   std::vector<int> labels;
+
+  explicit UniGraph(std::size_t nodes = 0) : labels(nodes, 0), nbrs(nodes), n_edges(0) {}
   inline int get_label(std::size_t n) const { return labels[n]; }
+  inline void set_label(std::size_t n, std::size_t label) { labels[n] = (int)label; }
+  inline std::size_t num_nodes() const { return nbrs.size(); }
+  inline std::size_t num_edges() const { return n_edges; }
+  inline const std::vector<std::size_t>& get_adj_nodes(std::size_t n) const { return nbrs[n]; }
+
+  bool add_node(const ChunkID& id) {  // uni_graph.cpp:22-28: the new node's index is the node count so far
+    if (chunks.count(id)) return false;
+    chunks.emplace(id, nbrs.size());
+    nbrs.emplace_back();
+    if (labels.size() < nbrs.size()) labels.resize(nbrs.size(), 0);
+    return true;
+  }
+  bool has_edge(std::size_t a, std::size_t b) const {
+    for (std::size_t x : nbrs[a]) if (x == b) return true;
+    return false;
+  }
+  void add_edge(std::size_t a, std::size_t b) {  // uni_graph.h:110-117: no loops, no duplicates
+    if (a == b || has_edge(a, b)) return;
+    nbrs[a].push_back(b);
+    nbrs[b].push_back(a);
+    ++n_edges;
+  }
+  // uni_graph.cpp:41-50: for every face whose flag is set and whose neighbour chunk is a node
+  void add_edge_by_node(const ChunkID& id, const bool flag[6]) {
+    auto self = chunks.find(id);
+    if (self == chunks.end()) return;
+    static const int d[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};  // ChunkManager.h:55-57
+    for (int k = 0; k < 6; ++k) {
+      if (!flag[k]) continue;
+      auto other = chunks.find(ChunkID(id(0) + d[k][0], id(1) + d[k][1], id(2) + d[k][2]));
+      if (other != chunks.end()) add_edge(self->second, other->second);
+    }
+  }
+  void remove_node(const ChunkID& id) {  // uni_graph.cpp:91-110: the node keeps its index, it loses its edges
+    auto self = chunks.find(id);
+    if (self == chunks.end()) return;
+    const std::size_t n = self->second;
+    for (std::size_t m : nbrs[n]) {
+      std::vector<std::size_t>& l = nbrs[m];
+      l.erase(std::remove(l.begin(), l.end(), n), l.end());
+    }
+    nbrs[n].clear();  // (the edge counter is left alone, as in the reference)
+  }
+  void clear() { nbrs.clear(); labels.clear(); chunks.clear(); n_edges = 0; }
+
+ private:
+  std::vector<std::vector<std::size_t>> nbrs;
+  std::size_t n_edges;
 };
+
+// Structure/sparse_matrix.{h,cpp}: data costs, one ordered column (frame row -> quality) per graph node
+class SparseMat {
+ public:
+  typedef std::map<std::size_t, float> Column;
+  inline std::size_t cols() const { return columns.size(); }
+  inline std::size_t rows() const { return row_len; }
+  inline std::size_t get_nnz() const { return nnz; }
+  inline const Column& col(std::size_t c) const { return columns[c]; }
+  inline void resize(std::size_t c) { columns.resize(c); }
+  bool add_value(std::size_t c, std::size_t r, float v) {  // sparse_matrix.cpp:27-36: an existing entry is kept
+    grow(c, r);
+    ++nnz;  // counted even when nothing is inserted, as in the reference
+    return columns[c].emplace(r, v).second;
+  }
+  void set_value(std::size_t c, std::size_t r, float v) { grow(c, r); columns[c][r] = v; }  // :38-43
+  void remove_observation(std::size_t c, std::size_t r) { if (c < columns.size()) columns[c].erase(r); }  // :45-50
+  void remove_node(std::size_t c) { if (c < columns.size()) columns[c].clear(); }
+  void clear() { columns.clear(); nnz = 0; row_len = 0; }
+
+ private:
+  void grow(std::size_t c, std::size_t r) {
+    if (c >= columns.size()) columns.resize(c + 1);
+    if (r >= row_len) row_len = r + 1;
+  }
+  std::vector<Column> columns;
+  std::size_t nnz = 0, row_len = 0;
+};
+typedef SparseMat DataCosts;
 
 inline void tf_check(int rc, const char* what) {
   if (rc != TF_OK) throw std::runtime_error(std::string(what) + ": " + tf_last_error());
@@ -659,6 +741,70 @@ class Chisel {
   std::vector<float> qual_buf;
 };
 typedef std::shared_ptr<Chisel> ChiselPtr;
+
+// Structure/TexMap.{h,cpp}: the bookkeeping of the view selection that consumes this path's outputs -- the chunk
+// graph from the meshes' adjacency flags (update_chunkgraph, TexMap.cpp:50-62) and the data costs from the
+// chunks' observation qualities (update_datacost, :64-105; check_graph, :107-119).  The MRF solve itself
+// (view_selection, mapMAP) is third-party host code outside the path and stays where it is.
+class TexMap {
+ public:
+  float adjacent_cost = 0.5f;  // TexMap.h:53-54
+  float pairwise_cost = 1.0f;
+  UniGraph chunkGraph;
+  DataCosts dataCost;
+  std::vector<float> statistic;
+
+  void update_chunkgraph(ChunkIDList& chunksToUpdate, ChunkManager& chunkManager) {
+    MeshMap& allMeshes = chunkManager.GetAllMutableMeshes();
+    for (const ChunkID& id : chunksToUpdate) chunkGraph.add_node(id);
+    for (const ChunkID& id : chunksToUpdate) {
+      auto m = allMeshes.find(id);
+      if (m != allMeshes.end()) chunkGraph.add_edge_by_node(id, m->second->adj);
+    }
+  }
+
+  // lookup[frame] = row of that keyframe in the cost table; frameindex = the keyframe just fused, framesToUpdate
+  // = keyframes whose observations may have been retracted or re-integrated since
+  void update_datacost(ChunkIDList& chunksToUpdate, ChunkManager& chunkManager, std::vector<int>& lookup, int frameindex,
+                       std::vector<int>& framesToUpdate) {
+    for (const ChunkID& id : chunksToUpdate) {
+      // (the reference calls GetChunk; only the host-side observation map is read, so the mirror is not refreshed
+      // from the device here)
+      ChunkPtr chunk = chunkManager.Mirror(id);
+      const std::size_t node = chunkGraph.chunks.find(id)->second;
+      if (statistic.size() < node + 1) statistic.resize(node + 1, 1.0f);  // (vector::resize only ever grows here)
+      float quality = 0.0f;
+      auto now = chunk->observations.find(frameindex);
+      if (now != chunk->observations.end()) quality = now->second;
+      if (quality > statistic[node]) statistic[node] = quality;
+      if (quality > 0.0f) dataCost.add_value(node, (std::size_t)lookup[frameindex], quality);
+      if (dataCost.cols() <= node) dataCost.resize(node + 1);
+      for (int f : framesToUpdate) {
+        const std::size_t row = (std::size_t)lookup[f];
+        auto seen = chunk->observations.find(f);
+        if (seen == chunk->observations.end()) {
+          dataCost.remove_observation(node, row);
+        } else {
+          quality = seen->second;
+          if (quality > statistic[node]) statistic[node] = quality;
+          if (quality > 0.0f) dataCost.set_value(node, row, quality);
+        }
+      }
+    }
+  }
+
+  void check_graph(ChunkManager& chunkManager) {  // nodes whose mesh is gone lose their edges and costs
+    const MeshMap& allMeshes = chunkManager.GetAllMeshes();
+    for (const auto& it : chunkGraph.chunks) {
+      if (allMeshes.find(it.first) != allMeshes.end()) continue;
+      chunkGraph.remove_node(it.first);
+      dataCost.remove_node(it.second);
+    }
+  }
+
+  void clear() { chunkGraph.clear(); dataCost.clear(); statistic.clear(); }
+};
+typedef TexMap* TexPtr;
 
 }  // namespace chisel
 
