@@ -209,9 +209,9 @@ static int sync_list(tf_volume* v, const int32_t* ids, int64_t n) {
     st[4 * i + 3] = 0;
   }
   uint32_t* cnt = reinterpret_cast<uint32_t*>(st + 4 * n);
-  *cnt = (uint32_t)n;
+  cnt[0] = cnt[1] = (uint32_t)n;  // n_list and n_front: a plain list
   if (n) TF_HIP(hipMemcpyAsync(v->dev.sel.list_id, st, (size_t)n * 16, hipMemcpyHostToDevice, v->stream));
-  TF_HIP(hipMemcpyAsync(&v->dev.sel.ctl->n_list, cnt, 4, hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipMemcpyAsync(&v->dev.sel.ctl->n_list, cnt, 8, hipMemcpyHostToDevice, v->stream));
   if (n) {
     TF_HIP(hipMemsetAsync(v->dev.sel.list_new, 0, (size_t)n, v->stream));
     TF_HIP(hipMemsetAsync(v->dev.sel.list_needs, 0, (size_t)n, v->stream));

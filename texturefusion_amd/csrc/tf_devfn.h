@@ -112,4 +112,9 @@ __device__ __forceinline__ int4 nbr7(const int4 c, int k) {
   else if (k == 5) r.z -= 1; else if (k == 6) r.z += 1;
   return r;
 }
+// physical position of logical list entry e of a (possibly two-ended) visible list, see FrameCtl::n_front
+__device__ __forceinline__ uint32_t list_phys(const VolumeDev& v, uint32_t e, uint32_t n_front) {
+  return e < n_front ? e : v.max_list - 1u - (e - n_front);
+}
+
 }  // namespace tf

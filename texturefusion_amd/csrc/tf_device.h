@@ -61,8 +61,16 @@ struct FrameCtl {
   int32_t max_id[3];
   int32_t dims[3];  // coarse-block grid
   uint32_t n_coarse;
-  uint32_t n_list;
-  uint32_t pad[7];
+  uint32_t n_list;   // entries of the visible list
+  // Lists written by the fused selection role are TWO-ENDED: chunks the selection expects to be rewritten
+  // ("expensive": some probe corner inside the truncation band) are appended from the front, the others from the
+  // back of the arrays, so that logical entry e sits at list_phys(e).  K-A deals logical entries round-robin to
+  // its resident waves; with ~1.5 entries per wave the second entry of a wave is then a cheap one.  Lists of the
+  // call-by-call flow are plain (n_front = n_list).
+  uint32_t n_front;
+  uint32_t pad0;
+  unsigned long long emit_pack;  // the selection role's append counters: low word front, high word back entries
+  uint32_t pad[2];
 };
 
 // Volume-wide device words.

@@ -112,6 +112,8 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
     }
     ctl->n_coarse = 0;
     ctl->n_list = 0;
+    ctl->n_front = 0;
+    ctl->emit_pack = 0ull;
     if (vctl) {
       vctl->status = 0; vctl->n_tmp = 0;
       for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
@@ -162,7 +164,7 @@ void launch_pack_rgba(const uint8_t* rgb, const uint8_t* valid, uchar4* rgba, ui
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void bbox_body(const float* __restrict__ depth, const Cam& cam, const Pose& P,
                                           FrameCtl* ctl, const uint32_t bid, const uint32_t nb) {
-  if (bid == 0 && threadIdx.x == 0) ctl->n_list = 0;  // appended to by k_select<EMIT>
+  if (bid == 0 && threadIdx.x == 0) { ctl->n_list = 0; ctl->n_front = 0; ctl->emit_pack = 0ull; }  // appended to by k_select<EMIT>
   float mn[3] = {1e8f, 1e8f, 1e8f}, mx[3] = {-1e8f, -1e8f, -1e8f};
   const int W = cam.W;
   const int nvec = (cam.W * cam.H) >> 2;
@@ -231,7 +233,7 @@ void launch_bbox(const VolumeDev& v, const float* depth, const Cam& cam, const P
 // ---------------------------------------------------------------------------------------
 // K-C  coarse 4x4x4-block test, then per-chunk test; one 64-bit mask per coarse block
 // ---------------------------------------------------------------------------------------
-struct ProbeRes { bool valid; bool hit; };
+struct ProbeRes { bool valid; bool hit; float sd; };
 
 // One lane = one of the 8 probe points of CheckCornerIntersectingSIMD (ChunkManager.h:561-636).
 __device__ __forceinline__ ProbeRes probe(const float* __restrict__ depth, const Cam& cam,
@@ -247,6 +249,7 @@ __device__ __forceinline__ ProbeRes probe(const float* __restrict__ depth, const
   if (r.valid) d = depth[Y * cam.W + X];
   const float sd = d - pz;
   r.hit = r.valid && (sd > ndtn) && (dtp > sd);
+  r.sd = sd;
   return r;
 }
 
@@ -320,6 +323,7 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
                         sc.coarse[2][corner], dtp, ndtn);
     const bool coarse_hit = __ballot(pr.hit && depthValid) != 0ull;
     unsigned long long m = 0ull;
+    bool costly = false;
     if (coarse_hit) {
       bool flag = false;
       if (lane < step * step * step) {
@@ -341,13 +345,19 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         const float fndtn = -sc.dtn_fine;  // :529
         const bool dv = (of[2] > cam.nearP) && (cam.farP > of[2]);
         bool anyhit = false;
+        bool below = false, above = false;  // EMIT: some probed corner sits below the band's far edge / above its near edge
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           ProbeRes fr = probe(depth, cam, of[0], of[1], of[2], sc.fine[0][c], sc.fine[1][c],
                               sc.fine[2][c], fdtp, fndtn);
           anyhit |= fr.hit;
+          if (EMIT) { below |= fr.valid && (tr > fr.sd); above |= fr.valid && (fr.sd > fndtn + sc.diag); }  // the band without the chunk-diagonal margin
         }
         flag = anyhit && dv;
+        // cost prediction for K-A's work distribution (never a correctness matter): a chunk none of whose probed
+        // corners lies between the near and the far edge of the truncation band (all in front of it, or all
+        // behind) will most likely rewrite no voxel row
+        costly = below && above;
         if (EMIT) flag = flag && part_owned(v, x0 + di, y0 + dj, z0 + dk);
       }
       m = __ballot(flag);
@@ -355,10 +365,14 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
     if (!EMIT) {
       if (lane == 0) v.sel.masks[cb] = m;
     } else if (m) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&ctl->n_list, (uint32_t)__popcll(m));
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (base + (uint32_t)__popcll(m) > v.max_list) {
+      // two-ended append (FrameCtl::n_front): one 64-bit atomic hands out front and back positions together
+      const unsigned long long mf = __ballot(((m >> lane) & 1ull) && costly);
+      const uint32_t kf = (uint32_t)__popcll(mf), kb = (uint32_t)__popcll(m) - kf;
+      unsigned long long pk = 0ull;
+      if (lane == 0) pk = atomicAdd(&ctl->emit_pack, (unsigned long long)kf | ((unsigned long long)kb << 32));
+      const uint32_t basef = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pk);
+      const uint32_t baseb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pk >> 32));
+      if ((unsigned long long)basef + kf + baseb + kb > (unsigned long long)v.max_list) {
         if (lane == 0) atomicOr(&v.vctl->status, kStListFull);
       } else if ((m >> lane) & 1ull) {
         int4 id;
@@ -366,7 +380,9 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         id.y = y0 + ((step == 4) ? ((lane >> 2) & 3) : 0);
         id.z = z0 + ((step == 4) ? (lane & 3) : 0);
         id.w = 0;
-        const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        const unsigned long long lower = (1ull << lane) - 1ull;
+        const uint32_t pos = costly ? basef + (uint32_t)__popcll(mf & lower)
+                                    : v.max_list - 1u - (baseb + (uint32_t)__popcll(m & ~mf & lower));
         v.sel.list_id[pos] = id;
         const ChunkPre cp = chunk_pre(id, sc.pose, ig, sc.res, sc.resDiag);
         v.sel.list_pre[4 * pos] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
@@ -466,6 +482,7 @@ __global__ __launch_bounds__(1024) void k_scan(VolumeDev v, int step) {
       total = 0;
     }
     ctl->n_list = total;
+    ctl->n_front = total;  // a plain list
     for (int a = 0; a < 3; ++a) {
       ctl->bbox_key[a] = f2key(1e8f);
       ctl->bbox_key[3 + a] = f2key(-1e8f);
@@ -631,7 +648,16 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   const uint32_t nwaves = nb * 4;
   // a list that overflowed (kStListFull is raised by its producer) holds stale tail records of an
   // older frame: the frame is skipped as a whole instead of integrating them against this image
-  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
+  uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
+  uint32_t nf = n;  // entries at the front of a two-ended list
+  if (FUSED) {
+    const unsigned long long pk = L.ctl->emit_pack;  // complete: the selection role ran one launch ago
+    nf = (uint32_t)pk;
+    const unsigned long long tot = (pk & 0xFFFFFFFFull) + (pk >> 32);
+    n = tot <= (unsigned long long)v.max_list ? (uint32_t)tot : 0u;
+    if (!n) nf = 0;
+    if (bid == 0 && threadIdx.x == 0) { L.ctl->n_list = n; L.ctl->n_front = nf; }  // for the stages behind this launch
+  }
   const int vy = lane >> 3;
   const int W = cam.W, H = cam.H;
   if (FUSED && bid == 0 && threadIdx.x == 0) {
@@ -645,7 +671,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 
   // the wave's first list record is requested before anything else: it arrives while the centroid
   // table is copied (64-B records {o.xyz, wD | upper, id.xyz | spare}; the slot exists for any wave id)
-  u32x8 rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (wave < v.max_list ? wave : 0u)]);
+  u32x8 rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (wave < v.max_list ? (FUSED ? list_phys(v, wave, nf) : wave) : 0u)]);
 
   // centroid table (Chisel.cpp:52-110), computed once per frame ahead of this launch; copied into
   // LDS and shared by the four waves of the workgroup (6 KB).
@@ -688,6 +714,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   }
 
   for (uint32_t e = wave; e < n; e += nwaves) {
+    const uint32_t pe = FUSED ? list_phys(v, e, nf) : e;  // where the entry's record and outputs live
     // The list entry (per-chunk scalars + id) was written by the previous launch, so it is read
     // through the scalar cache: one 64-B record, one s_load, one wait, off the vector-memory queue
     // of the CU (a vector load here would wait behind every gather of the other waves).
@@ -695,14 +722,14 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     {  // the next record of this wave travels while this chunk is processed (speculative: the slot
        // exists even when e + nwaves >= n, it just holds an older frame's record)
       const uint32_t en = e + nwaves < v.max_list ? e + nwaves : e;
-      rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * en]);
+      rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (FUSED ? list_phys(v, en, nf) : en)]);
     }
     const int4 id = make_int4((int)prw[5], (int)prw[6], (int)prw[7], 0);
     const bool owned = part_owned(v, id.x, id.y, id.z);
     if (!owned) {
       if (FUSED && lane == 0) {
-        L.list_slot[e] = kInvalidSlot; L.list_ent[e] = 0; L.list_new[e] = 0; L.list_needs[e] = 0;
-        L.list_quality[e] = 0.0f; L.list_rows[e] = 0;
+        L.list_slot[pe] = kInvalidSlot; L.list_ent[pe] = 0; L.list_new[pe] = 0; L.list_needs[pe] = 0;
+        L.list_quality[pe] = 0.0f; L.list_rows[pe] = 0;
       }
       continue;
     }
@@ -714,7 +741,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     u32x4 h0 = {0u, 0u, 0u, 0u};
     uint32_t slot = kInvalidSlot;
     if (FUSED) h0 = *(const_u32x4_ptr)(unsigned long long)(&v.hent[i0]);
-    else slot = L.list_slot[e];
+    else slot = L.list_slot[pe];
     bool is_new = false;
     uint32_t ent = i0;
 
@@ -835,8 +862,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     }
     if (slot == kInvalidSlot) {
       if (FUSED && lane == 0) {
-        L.list_slot[e] = kInvalidSlot; L.list_ent[e] = 0; L.list_new[e] = 0; L.list_needs[e] = 0;
-        L.list_quality[e] = 0.0f; L.list_rows[e] = 0;
+        L.list_slot[pe] = kInvalidSlot; L.list_ent[pe] = 0; L.list_new[pe] = 0; L.list_needs[pe] = 0;
+        L.list_quality[pe] = 0.0f; L.list_rows[pe] = 0;
       }
       continue;
     }
@@ -988,7 +1015,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     // multi-GPU: remember that this slab-face chunk changed since the last boundary exchange
     const bool face = part_band(v, id.x, id.y, id.z);
     if (updated && lane == 0 && (face || lazy_revive)) {
-      const uint32_t en = FUSED ? ent : L.list_ent[e];
+      const uint32_t en = FUSED ? ent : L.list_ent[pe];
       v.hent[en].alive = face ? 3u : 1u;  // bit0 alive, bit1 touched
     }
     if (FUSED) {
@@ -1007,14 +1034,14 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         }
       }
       if (lane == 0) {  // what later stages read of a fused frame: slot, needsUpdate, row counts
-        L.list_slot[e] = slot;
-        L.list_needs[e] = updated ? 1 : 0;
-        L.list_rows[e] = (uint16_t)(rows_t | (rows_c << 8));
+        L.list_slot[pe] = slot;
+        L.list_needs[pe] = updated ? 1 : 0;
+        L.list_rows[pe] = (uint16_t)(rows_t | (rows_c << 8));
       }
     } else if (lane == 0) {
-      if (updated) L.list_needs[e] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
-      L.list_quality[e] = qsum;
-      L.list_rows[e] = (uint16_t)(rows_t | (rows_c << 8));
+      if (updated) L.list_needs[pe] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
+      L.list_quality[pe] = qsum;
+      L.list_rows[pe] = (uint16_t)(rows_t | (rows_c << 8));
     }
   }
 }
@@ -1223,9 +1250,10 @@ void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s) {
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_rowstats(VolumeDev v, unsigned long long* out3) {
   const SelBuf& L = v.sel;
-  const uint32_t n = L.ctl->n_list;
+  const uint32_t n = L.ctl->n_list, nf = L.ctl->n_front;
   unsigned long long rt = 0, rc = 0, nu = 0;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const uint32_t i = list_phys(v, e, nf);
     const uint32_t r = L.list_rows[i];
     rt += r & 0xFFu;
     rc += r >> 8;

@@ -612,7 +612,7 @@ __global__ __launch_bounds__(1024) void k_dirty_frame(VolumeDev v, int par, uint
     int4 q = make_int4(0, 0, 0, 0);
     uint32_t slot = kInvalidSlot;
     if (t < total && (t & 7u) != 7u) {
-      const uint32_t e = t >> 3;
+      const uint32_t e = list_phys(v, t >> 3, L.ctl->n_front);  // (fused lists are two-ended, FrameCtl::n_front)
       const int k = (int)(t & 7u);
       if (L.list_needs[e]) {
         q = nbr7(L.list_id[e], k);
