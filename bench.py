@@ -283,7 +283,7 @@ def main():
         out["host_frames"] = host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique)
 
     # ---- CPU baseline: the oracle (C port of the reference path) on the host cores ------------
-    if rank == 0 and args.cpu_frames > 0:
+    if rank == 0 and world == 1 and args.cpu_frames > 0:  # (rank 0 at N = 1 only)
         out["cpu_baseline"] = cpu_baseline(args, cam, res, frames, n_unique, textured)
 
     if rank == 0:
