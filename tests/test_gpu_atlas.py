@@ -313,3 +313,39 @@ def test_fused_textured_stream(gpu_required):
     for a, b in bufs:
         a.free(); b.free()
     gv.close()
+
+
+def test_fused_stream_atlas_overflow(gpu_required):
+    """The fused per-frame unit with an atlas of 2 bands x 4 slots: from the frame whose new patches no longer fit,
+    the entries behind the first failing AddPatch (ascending chunk id) are skipped in every frame, exactly as the
+    oracle's GeneratePatches returns -1 there (Chisel.cpp:170-173); the error surfaces at the next synchronisation
+    and everything up to it is identical."""
+    cam = synth.Camera()
+    ov = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 14, atlas_w=96, atlas_h=36)
+    oa = O.Atlas(RES5, 96, 36)
+    n = 8
+    fr = []
+    for k in range(n):
+        d, rgba, q, pose = synth.wall_frame(1.2, cam, seed=k)
+        rgba = synth._hash_colour(np.stack(np.meshgrid(np.arange(cam.width) * 0.01, np.arange(cam.height) * 0.01), -1)[..., [0, 1, 1]] + k, 5)
+        fr.append((d, rgba, pose))
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in fr]
+    poses = np.stack([f[2].reshape(12) for f in fr])
+    pinv = np.stack([synth.pose_inverse16(f[2]) for f in fr])
+    for k, f in enumerate(fr):
+        ov.frame_textured(oa, f[0], f[1], f[2], pinv[k], 50 + k)
+    gv.stream_frames_textured_device([b[0].ptr for b in bufs], [b[1].ptr for b in bufs], poses, pinv, 50)
+    with pytest.raises(capi.TFError) as e:
+        gv.sync()
+    assert e.value.code == capi.TF_ERR_ATLAS_FULL
+    mids = sorted_ids(ov.list_meshes())
+    assert np.array_equal(mids, sorted_ids(gv.list_meshes())) and len(mids) > 100
+    g = _compare_patches(ov, gv, mids, "fused overflow")
+    have = g["texloc"] != np.uint64((1 << 64) - 1)
+    assert have.sum() == 8, "2 bands x 4 slots"
+    assert gv.atlas_loc_next() == oa.loc_next()
+    assert np.array_equal(gv.atlas_rows(0, 36, 96), oa.buffer()[0:36])
+    for a, b in bufs:
+        a.free(); b.free()
+    gv.close()

@@ -206,50 +206,21 @@ __global__ __launch_bounds__(1024) void k_patch_assign(VolumeDev v, uint32_t n) 
     v.actl->loc_min = smin;
     v.actl->loc_max = smax;
     v.actl->set[0].n_work = n;
-    v.actl->set[0].fail_key = ~0ull;
     if (ff != 0xFFFFFFFFu) atomicOr(&v.vctl->status, kStAtlasFull);
   }
 }
 
 // ---------------------------------------------------------------------------------------
 // fused per-frame flow: the work list is the frame's dirty set, unordered.  k_compress_exchange (tf_mesh.hip) keeps the
-// entries that have a mesh and lists the ones without an atlas slot; k_patch_rank hands the slots out in ascending
-// chunk-id order (rank of a key = number of smaller keys among the candidates, counted by comparison: the
-// candidate count is a few hundred in steady state, a few thousand on first touch).
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_patch_rank(VolumeDev v, int par) {
-  AtlasCtl::Set* S = &v.actl->set[par];
-  const uint32_t n = S->n_cand;
-  const unsigned long long base = v.actl->n_slots;
-  __shared__ unsigned long long tile[256];
-  for (uint32_t b0 = blockIdx.x * 256; b0 < n; b0 += gridDim.x * 256) {
-    const uint32_t i = b0 + threadIdx.x;
-    const unsigned long long mine = i < n ? v.cand[i] : ~0ull;
-    uint32_t rank = 0;
-    for (uint32_t t0 = 0; t0 < n; t0 += 256) {
-      __syncthreads();
-      tile[threadIdx.x] = (t0 + threadIdx.x < n) ? v.cand[t0 + threadIdx.x] : ~0ull;
-      __syncthreads();
-      const uint32_t m = (n - t0 < 256u) ? n - t0 : 256u;
-      for (uint32_t k = 0; k < m; ++k) rank += tile[k] < mine ? 1u : 0u;
-    }
-    if (i < n) {
-      const uint32_t ent = hash_find(v, mine);
-      const uint32_t slot = v.hent[ent].slot;
-      unsigned long long tl;
-      if (slot_texloc(v, base + rank, &tl)) v.mesh_rec[slot].texloc = tl;
-      else {
-        atomicMin(&S->fail_key, mine);
-        atomicOr(&v.vctl->status, kStAtlasFull);
-      }
-    }
-  }
-}
-
+// entries that have a mesh and lists the ones without an atlas slot ("candidates").  The slots go out in ascending
+// chunk-id order (the harness' definition of chunksToUpdate's order): a candidate's slot is slots_base + its rank,
+// rank = number of candidates with a smaller key, which the candidate's own wave counts in the patch kernel (a
+// few hundred candidates in steady state, a few thousand on first touch).
 // ---------------------------------------------------------------------------------------
 // One wave per patch.  PROJECT = Patch::CalculateTexCoords + SetFrameid + SetImage (GeneratePatches' loop
 // body), BLIT = Atlas::UpdateBuffer.  FUSED = the work list is the frame's dirty set of the fused flow
-// (patch_begin here, overflow = keys >= fail_key are skipped, counters of the next frame re-armed).
+// (patch_begin here; slots of new patches by self-ranking; on atlas overflow the entries behind the first failing
+// AddPatch in id order are skipped, Chisel.cpp:170-173).
 // ---------------------------------------------------------------------------------------
 typedef uint32_t u32_unaligned __attribute__((aligned(1)));
 
@@ -310,25 +281,53 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
   const uint32_t nwaves = gridDim.x * 4;
   AtlasCtl::Set* S = &v.actl->set[par];
   const uint32_t n = FUSED ? S->n_patch : S->n_work;  // fused flow: the compacted list of entries that own a mesh
-  const unsigned long long fail_key = FUSED ? S->fail_key : ~0ull;
+  // FUSED: slot hand-out.  total = slots the atlas holds (slot n exists iff (n / K) * PH < AH), room = slots left
+  // before this frame, n_cand = patches of this frame that need one.
+  const uint32_t n_cand = FUSED ? S->n_cand : 0u;
+  const unsigned long long slots_base = FUSED ? S->slots_base : 0ull;
+  unsigned long long room = 0;
+  if (FUSED) {
+    const unsigned long long K = ((unsigned long long)v.atlas_w + v.patch_w - 1) / (unsigned long long)v.patch_w;
+    const unsigned long long bands = ((unsigned long long)v.atlas_h + v.patch_h - 1) / (unsigned long long)v.patch_h;
+    const unsigned long long total = K * bands;
+    room = total > slots_base ? total - slots_base : 0ull;
+  }
+  const bool overflow = FUSED && (unsigned long long)n_cand > room;  // some AddPatch of this frame throws
   const int W = cam.W, H = cam.H;
   const float Wf = (float)W, Hf = (float)H;
   if (FUSED && blockIdx.x == 0 && threadIdx.x == 0) {
-    // account for the slots this frame's ranking handed out (nobody reads n_slots while this kernel runs; the
-    // next reader is the next frame's ranking, behind this kernel on the same stream)
-    unsigned long long tl;
-    uint32_t got = S->n_cand;
-    while (got && !slot_texloc(v, (unsigned long long)v.actl->n_slots + got - 1, &tl)) --got;
-    v.actl->n_slots += got;
+    // account for the slots this frame hands out (the waves of this kernel read the snapshot slots_base, the next
+    // reader of n_slots is the next frame's k_compress_exchange, behind this kernel on the same stream)
+    const unsigned long long got = (unsigned long long)n_cand < room ? (unsigned long long)n_cand : room;
+    v.actl->n_slots = (uint32_t)(slots_base + got);
+    if (overflow) atomicOr(&v.vctl->status, kStAtlasFull);
   }
   for (uint32_t pe = wave; pe < n; pe += nwaves) {
     // fused flow: {id, pool slot} straight from the compacted list (one dependent load less per patch)
     const int4 id = FUSED ? v.patch_list[pe] : v.work_ids[pe];
     const uint32_t slot = FUSED ? (uint32_t)id.w : v.work_slot[pe];
     if (slot == kInvalidSlot) continue;
-    if (FUSED && pack_id(id.x, id.y, id.z) >= fail_key) continue;
     MeshRec* rec = &v.mesh_rec[slot];
-    const MeshRec R = *rec;  // one 64-B record: counts, flags, slot position, box
+    MeshRec R = *rec;  // one 64-B record: counts, flags, slot position, box
+    if (FUSED) {
+      const bool cand = R.texloc == kNoTexloc;
+      if (cand || overflow) {
+        // c = candidates with a smaller key = this patch's rank if it is one itself
+        const unsigned long long key = pack_id(id.x, id.y, id.z);
+        uint32_t c = 0;
+        for (uint32_t i = lane; i < n_cand; i += 64) c += v.cand[i] < key ? 1u : 0u;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
+        // the first failing AddPatch is the candidate of rank `room`; it and every entry behind it are skipped
+        if ((unsigned long long)c >= room + (cand ? 0ull : 1ull) && overflow) continue;
+        if (cand) {
+          unsigned long long tl;
+          if (!slot_texloc(v, slots_base + c, &tl)) continue;  // (cannot happen: c < room)
+          R.texloc = tl;
+          if (lane == 0) rec->texloc = tl;
+        }
+      }
+    }
     const uint32_t nv = R.nv;
     // fused flow: the keyframe is the frame itself, handed over by value; its image is not retained (kf_slot -1)
     const int kf_slot = FUSED ? -1 : (PROJECT ? id.w : R.kf_slot);
@@ -903,7 +902,6 @@ int atlas_reset(tf_volume* v) {
   AtlasCtl c;
   memset(&c, 0, sizeof(c));
   c.loc_min = ~0ull;
-  c.set[0].fail_key = c.set[1].fail_key = ~0ull;
   TF_HIP(hipMemcpyAsync(a.d_actl, &c, sizeof(c), hipMemcpyHostToDevice, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   a.fused_par = 0;
@@ -1071,9 +1069,6 @@ static int upload_work(tf_volume* v, const int32_t* ids, const int* kfslot, int6
 
 // fused per-frame flow: AddPatch in ascending id order, CalculateTexCoords + UpdateBuffer for the frame's dirty set
 void launch_patch_fused(tf_volume* v, const VolumeDev& d, int par, const KfDev& kf, hipStream_t s) {
-  prof_begin(v, TF_PROF_PATCH_RANK, s);  // (the candidates were collected by k_compress_exchange)
-  hipLaunchKernelGGL(k_patch_rank, dim3(256), dim3(256), 0, s, d, par);
-  prof_end(v, s);
   prof_begin(v, TF_PROF_PATCH_PROJECT, s);
   hipLaunchKernelGGL((k_patch<true, true, true>), dim3(1024), dim3(256), 0, s, d, v->cam, par, kf);
   prof_end(v, s);

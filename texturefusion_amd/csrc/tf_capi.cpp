@@ -599,7 +599,6 @@ static int fused_arm(tf_volume* v) {
   // first textured frame after a reset / a call-by-call atlas call: empty work lists
   AtlasCtl::Set z[2];
   memset(z, 0, sizeof(z));
-  z[0].fail_key = z[1].fail_key = ~0ull;
   TF_HIP(hipMemcpyAsync(&a.d_actl->set[0], z, sizeof(z), hipMemcpyHostToDevice, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   a.fused_par = 0;

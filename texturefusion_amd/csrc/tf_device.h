@@ -154,7 +154,7 @@ struct AtlasCtl {
   struct Set {
     uint32_t n_work;               // entries of the patch work list
     uint32_t n_cand;               // work entries that still need an atlas slot
-    unsigned long long fail_key;   // smallest packed id whose AddPatch overflowed (~0 = none)
+    unsigned long long slots_base; // fused flow: AtlasCtl::n_slots before this frame's new patches (snapshot by k_compress_exchange)
     uint32_t n_patch;              // fused flow: work entries that own a mesh (compacted into patch_list)
     uint32_t pad;
   } set[2];

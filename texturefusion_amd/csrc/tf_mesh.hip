@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restr
     // fused flow: the patches of the previous frame are done (the main stream waited for them ahead of this
     // frame's filter), so the counter set the NEXT frame's dirty list will append to can be re-armed
     AtlasCtl::Set* O = &v.actl->set[rearm];
-    O->n_work = 0; O->n_cand = 0; O->n_patch = 0; O->fail_key = ~0ull;
+    O->n_work = 0; O->n_cand = 0; O->n_patch = 0; O->slots_base = 0ull;
   }
   bool have_mc = false;
   for (uint32_t idx = blockIdx.x / kMeshShards; idx < n; idx += gridDim.x / kMeshShards) {
@@ -679,6 +679,9 @@ __global__ __launch_bounds__(256) void k_compress_exchange(VolumeDev v, const in
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   __shared__ uint32_t wcnt[4];
   __shared__ uint32_t gbase;
+  // the slot allocator's position before this frame's new patches: the patch kernel's waves rank themselves
+  // against it while its first thread advances AtlasCtl::n_slots
+  if (collect_par >= 0 && blockIdx.x == 0 && threadIdx.x == 0) v.actl->set[collect_par].slots_base = v.actl->n_slots;
   for (uint32_t b0 = blockIdx.x * 256; b0 < total; b0 += gridDim.x * 256) {
     const uint32_t i = b0 + threadIdx.x;
     const bool act = i < total && (i & 7u) < 6u;
