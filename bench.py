@@ -343,7 +343,7 @@ def roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, pose
     return {
         "bound": "hbm",
         "kernel": ("all kernels of a step: k_frame (K-A + K-C + K-B roles), k_dirty_frame, k_mesh_filter + k_mesh, "
-                   "k_compress_exchange, k_patch (slot ranks + project + blit)" if textured else
+                   "k_patch (adjacency exchange + slot ranks + project + blit)" if textured else
                    "k_frame<color> = K-A(f) + K-C(f+1) + K-B(f+2) block ranges"),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": None,  # filled from the --pmc child passes of this run (pmc_traffic), stays null without them
@@ -355,7 +355,7 @@ def roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, pose
 
 
 # rocprofv3 kernel names of one step (one launch each per frame)
-PMC_STEP_KERNELS = {"textured": ("k_frame<true>", "k_dirty_frame", "k_mesh_filter", "k_mesh<256>", "k_compress_exchange",
+PMC_STEP_KERNELS = {"textured": ("k_frame<true>", "k_dirty_frame", "k_mesh_filter", "k_mesh<256>",
                                  "k_patch<true, true, true>"),
                     "tsdf": ("k_frame<true>",)}
 # profiles/r2/README.md (tools/calib_fetch on this box type): both counters are in KiB; WRITE_SIZE is exact;

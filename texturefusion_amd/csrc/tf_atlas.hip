@@ -105,6 +105,7 @@ __host__ __device__ inline bool slot_texloc(int atlas_w, int atlas_h, int pw, in
   *texloc = k * (unsigned long long)pw + y * (unsigned long long)atlas_w;
   return y < (unsigned long long)atlas_h;
 }
+__device__ __forceinline__ uint32_t mesh_shard_rows_dev(uint32_t max_chunks) { return max_chunks / kMeshShards + 258u; }  // = mesh_shard_rows()
 __device__ __forceinline__ bool slot_texloc(const VolumeDev& v, unsigned long long n, unsigned long long* texloc) {
   return slot_texloc(v.atlas_w, v.atlas_h, v.patch_w, v.patch_h, n, texloc);
 }
@@ -280,7 +281,16 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const uint32_t nwaves = gridDim.x * 4;
   AtlasCtl::Set* S = &v.actl->set[par];
-  const uint32_t n = FUSED ? S->n_patch : S->n_work;  // fused flow: the compacted list of entries that own a mesh
+  // fused flow: the frame's dirty chunks that own a mesh sit in 32 shard lists (the mesher and its filter
+  // appended them); wave w walks shard w % 32
+  const uint32_t shard = wave & (kMeshShards - 1u);
+  const uint32_t shard_rows = mesh_shard_rows_dev(v.max_chunks);
+  const int4* plist = v.patch_list + ((size_t)(par & 1) * kMeshShards + shard) * shard_rows;
+  uint32_t n = S->n_work;
+  if (FUSED) {
+    n = v.patch_cnt[((par & 1) * kMeshShards + shard) * 16];
+    if (n > shard_rows) n = shard_rows;
+  }
   // FUSED: slot hand-out.  total = slots the atlas holds (slot n exists iff (n / K) * PH < AH), room = slots left
   // before this frame, n_cand = patches of this frame that need one.
   const uint32_t n_cand = FUSED ? S->n_cand : 0u;
@@ -302,13 +312,33 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
     v.actl->n_slots = (uint32_t)(slots_base + got);
     if (overflow) atomicOr(&v.vctl->status, kStAtlasFull);
   }
-  for (uint32_t pe = wave; pe < n; pe += nwaves) {
-    // fused flow: {id, pool slot} straight from the compacted list (one dependent load less per patch)
-    const int4 id = FUSED ? v.patch_list[pe] : v.work_ids[pe];
+  for (uint32_t pe = FUSED ? wave / kMeshShards : wave; pe < n; pe += FUSED ? nwaves / kMeshShards : nwaves) {
+    // fused flow: {id, pool slot} straight from the list (one dependent load less per patch)
+    const int4 id = FUSED ? plist[pe] : v.work_ids[pe];
     const uint32_t slot = FUSED ? (uint32_t)id.w : v.work_slot[pe];
     if (slot == kInvalidSlot) continue;
     MeshRec* rec = &v.mesh_rec[slot];
     MeshRec R = *rec;  // one 64-B record: counts, flags, slot position, box
+    if (FUSED && lane < 6) {
+      // Chisel::CompressMeshes' neighbour exchange (Chisel.cpp:127-145) for this chunk: flag k of the mesh and flag
+      // k ^ 1 of its k-th face neighbour's mesh become the OR of the two.  Every mesh of the frame is complete (the
+      // mesher ran before this kernel); the pairwise updates are idempotent, so concurrent waves cannot disagree.
+      const int k = lane, m = k ^ 1;
+      int4 q = id;
+      if (k == 0) q.x -= 1; else if (k == 1) q.x += 1; else if (k == 2) q.y -= 1;
+      else if (k == 3) q.y += 1; else if (k == 4) q.z -= 1; else q.z += 1;
+      const uint32_t en = hash_find(v, pack_id(q.x, q.y, q.z));
+      if (en != kInvalidSlot && (v.hent[en].alive & 1u) && v.hent[en].slot != kInvalidSlot) {
+        MeshRec* b = &v.mesh_rec[v.hent[en].slot];
+        const uint32_t bs = b->state;
+        if ((bs & kMsInMap) && (bs & kMsSimplified)) {
+          const uint32_t abit = 1u << (kMsAdjShift + k), bbit = 1u << (kMsAdjShift + m);
+          const bool fa = (R.state & abit) != 0, fb = (bs & bbit) != 0;
+          if (fa && !fb) atomicOr(&b->state, bbit);
+          if (!fa && fb) atomicOr(&rec->state, abit);
+        }
+      }
+    }
     if (FUSED) {
       const bool cand = R.texloc == kNoTexloc;
       if (cand || overflow) {
@@ -852,7 +882,9 @@ int atlas_init(tf_volume* v) {
   // two work lists: the fused flow builds the list of frame f + 1 while the patches of frame f still read theirs
   TF_HIP(hipMalloc((void**)&a.d_work_ids, sizeof(int4) * (size_t)d.max_chunks * 2));
   TF_HIP(hipMalloc((void**)&a.d_work_slot, sizeof(uint32_t) * (size_t)d.max_chunks * 2));
-  TF_HIP(hipMalloc((void**)&a.d_patch_list, sizeof(int4) * (size_t)d.max_chunks * 2));
+  TF_HIP(hipMalloc((void**)&a.d_patch_list, sizeof(int4) * (size_t)2 * kMeshShards * mesh_shard_rows(d.max_chunks)));
+  TF_HIP(hipMalloc((void**)&a.d_patch_cnt, sizeof(uint32_t) * 2 * kMeshShards * 16));
+  TF_HIP(hipMemset(a.d_patch_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16));
   TF_HIP(hipMalloc((void**)&a.d_cand, sizeof(unsigned long long) * (size_t)d.max_chunks));
   TF_HIP(hipStreamCreateWithFlags(&a.aux_stream, hipStreamNonBlocking));
   for (int k = 0; k < 2; ++k) {
@@ -866,7 +898,7 @@ int atlas_init(tf_volume* v) {
   a.kf_used.assign((size_t)a.kf_cap, 0);
   TF_HIP(hipMemcpy(a.d_kf, a.h_kf.data(), sizeof(KfDev) * (size_t)a.kf_cap, hipMemcpyHostToDevice));
   d.atlas = a.buf; d.atlas_w = a.aw; d.atlas_h = a.ah; d.patch_w = (int32_t)a.pw; d.patch_h = (int32_t)a.ph;
-  d.actl = a.d_actl; d.kf_tab = a.d_kf; d.work_ids = a.d_work_ids; d.work_slot = a.d_work_slot; d.patch_list = a.d_patch_list; d.cand = a.d_cand;
+  d.actl = a.d_actl; d.kf_tab = a.d_kf; d.work_ids = a.d_work_ids; d.work_slot = a.d_work_slot; d.patch_list = a.d_patch_list; d.patch_cnt = a.d_patch_cnt; d.cand = a.d_cand;
   return atlas_reset(v);
 }
 
@@ -889,11 +921,12 @@ void atlas_destroy(tf_volume* v) {
   if (a.d_work_ids) hipFree(a.d_work_ids);
   if (a.d_work_slot) hipFree(a.d_work_slot);
   if (a.d_patch_list) hipFree(a.d_patch_list);
+  if (a.d_patch_cnt) hipFree(a.d_patch_cnt);
   if (a.d_cand) hipFree(a.d_cand);
   if (a.d_stage) hipFree(a.d_stage);
   if (a.h_stage) hipHostFree(a.h_stage);
   a.buf = nullptr; a.d_stage = nullptr; a.h_stage = nullptr; a.d_kf = nullptr; a.d_actl = nullptr;
-  a.d_work_ids = nullptr; a.d_work_slot = nullptr; a.d_patch_list = nullptr; a.d_cand = nullptr;
+  a.d_work_ids = nullptr; a.d_work_slot = nullptr; a.d_patch_list = nullptr; a.d_patch_cnt = nullptr; a.d_cand = nullptr;
 }
 
 int atlas_reset(tf_volume* v) {
@@ -903,6 +936,7 @@ int atlas_reset(tf_volume* v) {
   memset(&c, 0, sizeof(c));
   c.loc_min = ~0ull;
   TF_HIP(hipMemcpyAsync(a.d_actl, &c, sizeof(c), hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipMemsetAsync(a.d_patch_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   a.fused_par = 0;
   a.fused_armed = true;

@@ -600,6 +600,7 @@ static int fused_arm(tf_volume* v) {
   AtlasCtl::Set z[2];
   memset(z, 0, sizeof(z));
   TF_HIP(hipMemcpyAsync(&a.d_actl->set[0], z, sizeof(z), hipMemcpyHostToDevice, v->stream));
+  TF_HIP(hipMemsetAsync(a.d_patch_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   a.fused_par = 0;
   a.fused_armed = true;
@@ -617,7 +618,6 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
   d.sel = sel;
   d.work_ids = a.d_work_ids + (size_t)par * d.max_chunks;
   d.work_slot = a.d_work_slot + (size_t)par * d.max_chunks;
-  d.patch_list = a.d_patch_list + (size_t)par * d.max_chunks;
   prof_begin(v, TF_PROF_DIRTY);
   launch_dirty_frame(d, par, frame_epoch + 1u, v->stream);
   prof_end(v);
@@ -641,9 +641,8 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
     TF_HIP(hipEventRecord(a.ev_mesh[par], v->stream));
     TF_HIP(hipStreamWaitEvent(ps, a.ev_mesh[par], 0));
   }
-  prof_begin(v, TF_PROF_FINALIZE, ps);
-  launch_compress(d, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, false, par, ps);
-  prof_end(v, ps);
+  // (CompressMeshes' neighbour exchange, the list of chunks that own a mesh and the slot candidates are produced
+  // by the mesher and consumed by the patch kernel: no kernel of their own in the fused flow)
   KfDev kf;
   memset(&kf, 0, sizeof(kf));
   kf.rgb = reinterpret_cast<const uint8_t*>(img.rgba);
@@ -887,7 +886,6 @@ int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {
     VolumeDev d = v->dev;
     d.work_ids = v->atlas.d_work_ids + (size_t)par * d.max_chunks;
     d.work_slot = v->atlas.d_work_slot + (size_t)par * d.max_chunks;
-    d.patch_list = v->atlas.d_patch_list + (size_t)par * d.max_chunks;
     launch_texture_stats(d, par, reinterpret_cast<unsigned long long*>(v->d_tmp), v->stream);
   }
   TF_HIP(hipGetLastError());
@@ -1160,7 +1158,6 @@ int tf_boundary_unpack_blocks(tf_volume* v, const void* d_blocks, int32_t n_bloc
     par = v->atlas.fused_par;
     d.work_ids = v->atlas.d_work_ids + (size_t)par * d.max_chunks;
     d.work_slot = v->atlas.d_work_slot + (size_t)par * d.max_chunks;
-    d.patch_list = v->atlas.d_patch_list + (size_t)par * d.max_chunks;
   }
   launch_boundary_unpack_blocks(d, reinterpret_cast<const uint8_t*>(d_blocks), n_blocks, own_block,
                                 (uint32_t)cap_records, par, v->epoch, v->stream);

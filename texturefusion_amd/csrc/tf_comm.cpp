@@ -82,7 +82,6 @@ int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t sta
   if (dirty_par >= 0) {
     d.work_ids = v->atlas.d_work_ids + (size_t)dirty_par * d.max_chunks;
     d.work_slot = v->atlas.d_work_slot + (size_t)dirty_par * d.max_chunks;
-    d.patch_list = v->atlas.d_patch_list + (size_t)dirty_par * d.max_chunks;
   }
   launch_boundary_unpack_blocks(d, reinterpret_cast<const uint8_t*>(c.d_recv), c.nranks, c.rank, (uint32_t)c.cap_records,
                                 dirty_par, stamp, v->stream);

@@ -155,7 +155,7 @@ struct AtlasCtl {
     uint32_t n_work;               // entries of the patch work list
     uint32_t n_cand;               // work entries that still need an atlas slot
     unsigned long long slots_base; // fused flow: AtlasCtl::n_slots before this frame's new patches (snapshot by k_compress_exchange)
-    uint32_t n_patch;              // fused flow: work entries that own a mesh (compacted into patch_list)
+    uint32_t n_patch;              // (unused)
     uint32_t pad;
   } set[2];
 };
@@ -200,7 +200,9 @@ struct VolumeDev {
   KfDev* kf_tab;      // [max_keyframes]
   int4* work_ids;       // [max_chunks] work list (dirty chunks of a frame / chunksToUpdate): id, w = keyframe-table entry
   uint32_t* work_slot;  // [max_chunks] pool slot of the entry, kInvalidSlot = not processed
-  int4* patch_list;     // [max_chunks] fused flow: {id, w = pool slot} of the work entries that own a mesh, in no particular order
+  int4* patch_list;     // [2][kMeshShards][mesh_shard_rows] fused flow: {id, w = pool slot} of the frame's dirty chunks that own a
+                        // mesh, appended by the mesher (and by its filter for meshes that just became empty), shard by shard
+  uint32_t* patch_cnt;  // [2][kMeshShards][16] entries per shard (one counter per 64-B line), by frame parity
   unsigned long long* cand;  // [max_chunks] packed ids of the work entries that need an atlas slot
   SelBuf sel;  // the selection set the launch works on
 };
@@ -264,7 +266,7 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
 // per-frame dirty set of the fused flow -> work list of counter set `par`
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s);
 void launch_compress(const VolumeDev& v, const int4* list, const uint32_t* count, uint32_t cap, bool mark,
-                     int collect_par, hipStream_t s);
+                     hipStream_t s);
 // sums over the work list of counter set `par`: {entries, with mesh, vertices, triangles, ROI pixels, patches}
 void launch_texture_stats(const VolumeDev& v, int par, unsigned long long* out6, hipStream_t s);
 

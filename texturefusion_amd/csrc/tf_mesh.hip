@@ -34,6 +34,7 @@ __device__ const unsigned long long d_mc_tri[256] = TF_MC_TRI_TABLE_INIT;
 constexpr int kR = 11;               // staged region: voxel coordinates -1 .. 9 per axis
 constexpr int kRV = kR * kR * kR;    // 1331
 constexpr int kEdgeSlots = 3 * 729;  // vertByEdge (ChunkManager.cpp:646-648)
+__device__ __forceinline__ uint32_t mesh_shard_rows_d(uint32_t max_chunks) { return max_chunks / kMeshShards + 258u; }  // = mesh_shard_rows()
 
 __device__ __forceinline__ int ridx(int x, int y, int z) { return (x + 1) + (y + 1) * kR + (z + 1) * kR * kR; }
 
@@ -162,11 +163,26 @@ __device__ __forceinline__ uint32_t classify_voxel(const float sdf, const float 
   const bool ok = !(sdf > 1.0f);
   return (ok ? 1u : 0u) | ((ok && sdf > 0.0f) ? 2u : 0u) | ((sdf < 0.0f) ? 4u : 0u) | ((w > 50.0f) ? 8u : 0u);
 }
+// fused flow: a dirty chunk that owns a mesh (ChunkManager::HasMesh) goes to the patch list of its shard; one
+// without an atlas slot is also a slot candidate (Atlas::AddPatch will be called for it, in ascending id order).
+// Called by ONE thread per chunk.
+__device__ __forceinline__ void patch_list_append(const VolumeDev& v, int ppar, uint32_t shard, const int4 id,
+                                                  uint32_t slot, unsigned long long texloc) {
+  const uint32_t rows = mesh_shard_rows_d(v.max_chunks);
+  const uint32_t p = atomicAdd(&v.patch_cnt[((ppar & 1) * kMeshShards + shard) * 16], 1u);
+  if (p < rows) v.patch_list[((size_t)(ppar & 1) * kMeshShards + shard) * rows + p] = make_int4(id.x, id.y, id.z, (int)slot);
+  else atomicOr(&v.vctl->status, kStMeshFull);
+  if (texloc == kNoTexloc) {
+    const uint32_t c = atomicAdd(&v.actl->set[ppar & 1].n_cand, 1u);
+    if (c < v.max_chunks) v.cand[c] = pack_id(id.x, id.y, id.z);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
-                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh) {
+                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar) {
   const int lane = threadIdx.x & 63;
   const uint32_t nwaves = gridDim.x * 4;
   // wave w takes entries w, w + nwaves, ...; its survivors go to shard w % 32.  (Measured on MI355X: handing each
@@ -228,7 +244,9 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
     if (empty) {
       if (lane == 0) {  // Mesh::Clear + "stays in allMeshes if it was there" (:244-262)
         MeshRec* rec = &v.mesh_rec[own];
-        rec->nv = 0; rec->nt = 0; rec->state = rec->state & kMsInMap; rec->epoch = epoch;
+        const uint32_t inmap = rec->state & kMsInMap;
+        rec->nv = 0; rec->nt = 0; rec->state = inmap; rec->epoch = epoch;
+        if (ppar >= 0 && inmap) patch_list_append(v, ppar, shard, id, own, rec->texloc);  // an emptied mesh keeps its patch
       }
     } else {  // a survivor: a row of its shard with the pool slots of chunk id + (-1..1)^3 for the mesher's staging
       uint32_t p = 0;
@@ -265,7 +283,10 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restr
     // frame's filter), so the counter set the NEXT frame's dirty list will append to can be re-armed
     AtlasCtl::Set* O = &v.actl->set[rearm];
     O->n_work = 0; O->n_cand = 0; O->n_patch = 0; O->slots_base = 0ull;
+    // ... and the slot allocator's position is final: the patch kernel of THIS frame ranks its new patches against it
+    v.actl->set[rearm ^ 1].slots_base = v.actl->n_slots;
   }
+  if (rearm >= 0 && blockIdx.x == 0 && t < (int)kMeshShards) v.patch_cnt[((rearm & 1) * kMeshShards + t) * 16] = 0u;
   bool have_mc = false;
   for (uint32_t idx = blockIdx.x / kMeshShards; idx < n; idx += gridDim.x / kMeshShards) {
     const size_t row = (size_t)shard * cap_sh + idx;
@@ -448,7 +469,9 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restr
     if (nv > v.mesh_cv || nt > v.mesh_ct) {  // does not fit the slot's block: reported, stored empty
       if (t == 0) {
         atomicOr(&v.vctl->status, kStMeshFull);
-        rec->nv = 0; rec->nt = 0; rec->state = (rec->state & kMsInMap) | kMsOverflow; rec->epoch = epoch;
+        const uint32_t was = rec->state & kMsInMap;
+        rec->nv = 0; rec->nt = 0; rec->state = was | kMsOverflow; rec->epoch = epoch;
+        if (rearm >= 0 && was) patch_list_append(v, rearm ^ 1, shard, id, own, rec->texloc);
       }
       __syncthreads();
       continue;
@@ -531,6 +554,7 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restr
       const uint32_t inmap = (rec->state & kMsInMap) | (nv ? kMsInMap : 0u);
       rec->nv = nv; rec->nt = nt; rec->epoch = epoch;
       rec->state = inmap | (sh.adj << kMsAdjShift) | (nv ? simplified : 0u);
+      if (rearm >= 0 && inmap) patch_list_append(v, rearm ^ 1, shard, id, own, rec->texloc);
     }
     __syncthreads();
   }
@@ -576,7 +600,7 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   if (max_entries > v.max_chunks) max_entries = v.max_chunks;
   const uint32_t fgrid = (max_entries + 3) / 4 < 2048u ? (max_entries + 3) / 4 : 2048u;
   hipLaunchKernelGGL(k_mesh_filter, dim3(fgrid), dim3(256), 0, s, v, dlist, fused ? v.work_slot : nullptr, dcount,
-                     max_entries, epoch, surv, cnt, cap_sh);
+                     max_entries, epoch, surv, cnt, cap_sh, fused ? (rearm_set ^ 1) : -1);
   // the survivors form dense per-shard lists: a grid of a few resident rounds, each workgroup striding its shard
   // (TF_MESH_GRID overrides; rounded to a multiple of the shard count)
   static const uint32_t gmax = getenv("TF_MESH_GRID") ? (uint32_t)atoi(getenv("TF_MESH_GRID")) : 4096u;
@@ -668,64 +692,21 @@ __global__ __launch_bounds__(256) void k_compress_mark(VolumeDev v, const int4* 
     if (r->state & kMsInMap) r->state |= kMsSimplified;
   }
 }
-// collect_par >= 0 (fused flow): thread k == 0 of an entry also does k_patch_collect's job for it -- entries
-// without a mesh leave the work list, entries without an atlas slot are listed as candidates for the ranking
+// (the fused per-frame flow does this exchange inside the patch kernel, one wave per chunk)
 __global__ __launch_bounds__(256) void k_compress_exchange(VolumeDev v, const int4* __restrict__ list,
-                                                           const uint32_t* __restrict__ count, uint32_t cap,
-                                                           int collect_par) {
+                                                           const uint32_t* __restrict__ count, uint32_t cap) {
   uint32_t n = *count;
   if (n > cap) n = cap;
   const uint32_t total = n * 8u;  // 8 threads per entry: k = 0..5 neighbours, 6 and 7 idle
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  __shared__ uint32_t wcnt[4];
-  __shared__ uint32_t gbase;
-  // the slot allocator's position before this frame's new patches: the patch kernel's waves rank themselves
-  // against it while its first thread advances AtlasCtl::n_slots
-  if (collect_par >= 0 && blockIdx.x == 0 && threadIdx.x == 0) v.actl->set[collect_par].slots_base = v.actl->n_slots;
   for (uint32_t b0 = blockIdx.x * 256; b0 < total; b0 += gridDim.x * 256) {
     const uint32_t i = b0 + threadIdx.x;
-    const bool act = i < total && (i & 7u) < 6u;
-    const int4 id = list[(i < total ? i : 0u) >> 3];
+    if (i >= total || (i & 7u) >= 6u) continue;
+    const int4 id = list[i >> 3];
     const int k = (int)(i & 7u), m = k ^ 1;
     uint32_t slot = kInvalidSlot;
-    if (act) {
-      if (collect_par >= 0) slot = v.work_slot[i >> 3];
-      else {
-        const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
-        if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
-      }
-    }
-    const bool has_mesh = slot != kInvalidSlot && (v.mesh_rec[slot].state & kMsInMap);
-    if (collect_par >= 0) {
-      bool need = false;
-      if (act && k == 0) {
-        if (slot != kInvalidSlot && !has_mesh) v.work_slot[i >> 3] = kInvalidSlot;
-        need = has_mesh && v.mesh_rec[slot].texloc == kNoTexloc;
-      }
-      const unsigned long long mm = __ballot(need);
-      if (mm) {
-        AtlasCtl::Set* S = &v.actl->set[collect_par];
-        uint32_t p0 = 0;
-        if (lane == 0) p0 = atomicAdd(&S->n_cand, (uint32_t)__popcll(mm));
-        p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
-        if (need) v.cand[p0 + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = pack_id(id.x, id.y, id.z);
-      }
-      // the entries that own a mesh, compacted for the patch kernel (one wave per patch, one patch per wave);
-      // one same-address atomic per workgroup
-      const bool keep = act && k == 0 && has_mesh;
-      const unsigned long long km = __ballot(keep);
-      if (lane == 0) wcnt[w] = (uint32_t)__popcll(km);
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int q = 0; q < 4; ++q) { const uint32_t c = wcnt[q]; wcnt[q] = tot; tot += c; }
-        gbase = tot ? atomicAdd(&v.actl->set[collect_par].n_patch, tot) : 0u;
-      }
-      __syncthreads();
-      if (keep) v.patch_list[gbase + wcnt[w] + (uint32_t)__popcll(km & ((1ull << lane) - 1ull))] = make_int4(id.x, id.y, id.z, (int)slot);
-      __syncthreads();
-    }
-    if (!act || !has_mesh) continue;
+    const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+    if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
+    if (slot == kInvalidSlot || !(v.mesh_rec[slot].state & kMsInMap)) continue;
     MeshRec* a = &v.mesh_rec[slot];
     int4 q = id;
     if (k == 0) q.x -= 1; else if (k == 1) q.x += 1; else if (k == 2) q.y -= 1;
@@ -743,9 +724,9 @@ __global__ __launch_bounds__(256) void k_compress_exchange(VolumeDev v, const in
 }
 
 void launch_compress(const VolumeDev& v, const int4* list, const uint32_t* count, uint32_t cap, bool mark,
-                     int collect_par, hipStream_t s) {
+                     hipStream_t s) {
   if (mark) hipLaunchKernelGGL(k_compress_mark, dim3(256), dim3(256), 0, s, v, list, count, cap);
-  hipLaunchKernelGGL(k_compress_exchange, dim3(512), dim3(256), 0, s, v, list, count, cap, collect_par);
+  hipLaunchKernelGGL(k_compress_exchange, dim3(512), dim3(256), 0, s, v, list, count, cap);
 }
 
 // keys of allMeshes
@@ -976,7 +957,7 @@ int tf_compress_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n_o
     uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
     const int4* list = reinterpret_cast<const int4*>(db + 16);
     const uint32_t* cnt = reinterpret_cast<const uint32_t*>(db);
-    launch_compress(v->dev, list, cnt, n, true, -1, v->stream);
+    launch_compress(v->dev, list, cnt, n, true, v->stream);
     TF_HIP(hipGetLastError());
     // chunksToUpdate = the dirty keys that have a mesh (GCFusion/MobileFusion.cpp:345-353), ascending id
     const size_t o_cnt = ((size_t)n * 16 + 16 + 15) & ~(size_t)15;

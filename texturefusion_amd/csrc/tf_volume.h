@@ -61,6 +61,7 @@ struct AtlasState {
   int4* d_work_ids = nullptr;
   uint32_t* d_work_slot = nullptr;
   int4* d_patch_list = nullptr;
+  uint32_t* d_patch_cnt = nullptr;
   unsigned long long* d_cand = nullptr;
   int fused_par = 0;   // counter set of the next fused frame
   // fused flow: the patch stages of frame f (second stream) overlap the voxel update of frame f + 1
