@@ -573,12 +573,28 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
           uint32_t x = 0;
           if (rr[k] >= 0) {
             const uint8_t* srow = kf.rgb + ((size_t)(by + r) * W + bx) * st;
+            if (st == 4) {
+              // RGBA source: the four bytes o .. o + 3 of the RGB row lie in at most two pixels, p0 and p0 + 1 --
+              // two aligned dword loads instead of four byte loads
+              const int p0 = (o > 0 ? o : 0) / 3;
+              const uint32_t w0 = *reinterpret_cast<const uint32_t*>(srow + 4 * p0);
+              const uint32_t w1 = (p0 + 1 < cols) ? *reinterpret_cast<const uint32_t*>(srow + 4 * (p0 + 1)) : 0u;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int bb = o + q;  // byte of the row
-              if (bb >= 0 && bb < rowbytes) {
-                const int px = bb / 3, ch = bb - 3 * px;
-                x |= (uint32_t)srow[px * st + ch] << (8 * q);
+              for (int q = 0; q < 4; ++q) {
+                const int bb = o + q;  // byte of the row
+                if (bb >= 0 && bb < rowbytes) {
+                  const int px = bb / 3, ch = bb - 3 * px;
+                  x |= (((px == p0 ? w0 : w1) >> (8 * ch)) & 0xFFu) << (8 * q);
+                }
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int bb = o + q;  // byte of the row
+                if (bb >= 0 && bb < rowbytes) {
+                  const int px = bb / 3, ch = bb - 3 * px;
+                  x |= (uint32_t)srow[px * st + ch] << (8 * q);
+                }
               }
             }
           }
