@@ -390,7 +390,7 @@ def pmc_traffic(args):
                    os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", str(Kc), "--warmup", str(Wc),
                    "--mode", args.mode, "--scene", args.scene, "--res", repr(args.res),
                    "--unique-frames", str(args.unique_frames)] + (["--hires"] if args.hires else [])
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=420)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=150)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return {"error": "rocprofv3 --pmc %s: rc %d, %d csv: %s" % (counter, r.returncode, len(files), r.stderr[-300:])}
