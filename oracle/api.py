@@ -13,10 +13,13 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libtf_oracle.so")
+# TF_ORACLE_LIB points the tests at another build of the same sources (the sanitizer run: tools/oracle_asan.sh)
+_LIB_PATH = os.environ.get("TF_ORACLE_LIB") or os.path.join(_HERE, "libtf_oracle.so")
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("TF_ORACLE_LIB"):
+        return _LIB_PATH
     src = [os.path.join(_HERE, f) for f in ("tf_oracle.c", "tf_oracle.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src)
