@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the workload only, run under rocprofv3
     ap.add_argument("--pmc-steps", type=int, default=40, help="frames of each counter pass")
     ap.add_argument("--no-host-path", action="store_true", help="skip the host-frames (H2D per frame) measurement")
+    ap.add_argument("--no-group", action="store_true", help="skip the keyframe-group (1 colour + 6 depth frames) measurement")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N>1 code path (partition + boundary all-gather) even with one rank (smoke test)")
     return ap.parse_args()
@@ -82,7 +83,7 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     if args.pmc_child:
-        args.no_roofline = args.no_host_path = True
+        args.no_roofline = args.no_host_path = args.no_group = True
         args.cpu_frames = 0
     # HBM-traffic counters first, in child processes, before this process touches the GPU
     traffic = None
@@ -282,6 +283,10 @@ def main():
     if rank == 0 and not multi and not args.no_host_path:
         out["host_frames"] = host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique)
 
+    # ---- the keyframe-group flow of TSDFFusion: 1 colour + 6 depth-only frames over one chunk list -------
+    if rank == 0 and not multi and not args.no_group and not args.no_host_path:
+        out["keyframe_group"] = keyframe_group(args, cam, res, frames, d_depth, d_rgba, poses, n_unique, local_rank)
+
     # ---- CPU baseline: the oracle (C port of the reference path) on the host cores ------------
     if rank == 0 and world == 1 and args.cpu_frames > 0:  # (rank 0 at N = 1 only)
         out["cpu_baseline"] = cpu_baseline(args, cam, res, frames, n_unique, textured)
@@ -448,6 +453,53 @@ def host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique):
                     "distinct host arrays (%.0f MB, not cache-resident): the single-threaded copy into the pinned slot "
                     "is what bounds this rate on the host side"
                     % (8e-6 * frames[0][0].size, len(frames), 8e-6 * frames[0][0].size * len(frames))}
+
+
+def keyframe_group(args, cam, res, frames, d_depth, d_rgba, poses, n_unique, device):
+    """MobileFusion::TSDFFusion's integration loop (GCFusion/MobileFusion.cpp:165-217): PrepareIntersectChunks for the
+    keyframe, its depth + colour, then the six local frames depth-only over the SAME list, FinalizeIntegrateChunks.
+    Two volumes get the same groups: one integrates the local frames with six tf_integrate calls, the other with one
+    tf_integrate_depth_group; the kernel times come from HIP events around the launches (the calls themselves
+    return lists and flags to the host, so their wall time is dominated by host round trips)."""
+    from texturefusion_amd import capi
+    n_groups, n_local = 8, 6
+    vols = [capi.Volume(res, cam, max_chunks=1 << 18, max_list=1 << 17, max_coarse=1 << 20, device=device) for _ in range(2)]
+    t_loc = [0.0, 0.0]
+    t_kf = 0.0
+    chunks = 0
+    for g in range(n_groups + 1):  # group 0 warms up
+        k0 = (7 * g) % max(1, n_unique - n_local - 1)
+        loc = [k0 + 1 + i for i in range(n_local)]
+        for w, vol in enumerate(vols):
+            vol.profile_enable(["integrate"])
+            vol.frame_bind_device(d_depth[k0].data_ptr(), d_rgba[k0].data_ptr(), 0)
+            ids, new = vol.prepare(poses[k0])
+            needs = np.zeros(len(ids), np.uint8)
+            vol.integrate(poses[k0], ids, needs, 1, True, False)
+            a = vol.profile_get(reset=True)["integrate"][0]
+            if w == 0:
+                for i in loc:
+                    vol.frame_bind_device(d_depth[i].data_ptr(), 0, 0)
+                    vol.integrate(poses[i], ids, needs, 1, False, False)
+            else:
+                vol.integrate_depth_group([d_depth[i].data_ptr() for i in loc], poses[loc], ids, needs, 1)
+            b = vol.profile_get(reset=True)["integrate"][0]
+            vol.finalize(ids, needs, new)
+            if g:
+                t_loc[w] += b
+                if w == 0:
+                    t_kf += a
+                    chunks += len(ids)
+    for vol in vols:
+        vol.close()
+    us_seq, us_grp, us_kf = 1e3 * t_loc[0] / n_groups, 1e3 * t_loc[1] / n_groups, 1e3 * t_kf / n_groups
+    return {"frames_per_group": 1 + n_local, "chunks_per_list": chunks / n_groups,
+            "keyframe_colour_depth_us": us_kf,
+            "local_frames_one_by_one_us": us_seq, "local_frames_grouped_us": us_grp,
+            "kernel_frames_per_s": {"one_by_one": (1 + n_local) / ((us_kf + us_seq) * 1e-6),
+                                    "grouped": (1 + n_local) / ((us_kf + us_grp) * 1e-6)},
+            "note": "HIP-event kernel time of the integration launches of a group (k_pre + k_integrate per frame, or "
+                    "k_pre x 6 + k_integrate_group); selection and finalize are the same on both sides and excluded"}
 
 
 def cpu_baseline(args, cam, res, frames, n_unique, textured):

@@ -160,6 +160,16 @@ TF_API int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint
 TF_API int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t n,
                         int integrate_flag, int use_color, int use_quality,
                         uint8_t* inout_needs_update, float* out_quality);
+/* The local frames of a keyframe group in one visit per chunk (GCFusion/MobileFusion.cpp:187-203: after the keyframe's
+ * own IntegrateDepthScanColor, its corresponding frames are integrated depth-only over the SAME chunk list, each with
+ * its own pose).  Equivalent, bit for bit, to n_frames successive tf_integrate(use_color = 0) calls with these depth
+ * images (device pointers, 16-B aligned) and poses (n_frames x 12 floats); the voxel rows are read and written once
+ * instead of n_frames times.  n_frames <= 6 (integrateLocalFrameNum, main.cpp:91). */
+TF_API int tf_integrate_depth_group(tf_volume* v, int32_t n_frames, const float* const* d_depth, const float* poses12,
+                                    const int32_t* ids, int64_t n, int integrate_flag, uint8_t* inout_needs_update);
+/* the same with host depth images (borrowed for the call; staged into a device buffer the handle keeps) */
+TF_API int tf_integrate_depth_group_host(tf_volume* v, int32_t n_frames, const float* const* depth, const float* poses12,
+                                         const int32_t* ids, int64_t n, int integrate_flag, uint8_t* inout_needs_update);
 /* Chisel::FinalizeIntegrateChunks + GarbageCollect   Structure/Chisel.h:184-216,472-477
  *   out_valid receives validChunks (may be NULL). */
 TF_API int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update,

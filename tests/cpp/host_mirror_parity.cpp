@@ -101,6 +101,21 @@ int main() {
                                     localChunksIntersecting, localNeedsUpdateFlag, 1);
   CHECK(tfo_integrate(ov, depth2.data(), NULL, NULL, lastPose.data(), oids.data(), (int64_t)n, 1, -1, oneeds.data(),
                       oq.data()) == 0);
+  // two more local frames in ONE call (IntegrateDepthScanGroup = the same loop body, one visit per chunk)
+  {
+    std::vector<float> d3, d4, qx;
+    std::vector<unsigned char> cx;
+    make_frame(W, H, 1.47f, 11, d3, cx, qx);
+    make_frame(W, H, 1.52f, 12, d4, cx, qx);
+    chisel::Transform p3 = lastPose, p4 = lastPose;
+    p3(0, 3) = 0.012f; p4(1, 3) = -0.004f;
+    std::vector<float*> imgs{d3.data(), d4.data()};
+    std::vector<chisel::Transform> poses{p3, p4};
+    chiselMap.IntegrateDepthScanGroup(projectionIntegrator, imgs, poses, cameraModel, localChunksIntersecting,
+                                      localNeedsUpdateFlag, 1);
+    CHECK(tfo_integrate(ov, d3.data(), NULL, NULL, p3.data(), oids.data(), (int64_t)n, 1, -1, oneeds.data(), oq.data()) == 0);
+    CHECK(tfo_integrate(ov, d4.data(), NULL, NULL, p4.data(), oids.data(), (int64_t)n, 1, -1, oneeds.data(), oq.data()) == 0);
+  }
   for (size_t i = 0; i < n; ++i) CHECK((oneeds[i] != 0) == localNeedsUpdateFlag[i]);
   chiselMap.FinalizeIntegrateChunks(localChunksIntersecting, localNeedsUpdateFlag, localNewChunkFlag, validChunks);
   std::vector<int32_t> ovalid(n * 3 + 3);

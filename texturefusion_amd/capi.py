@@ -45,7 +45,7 @@ SYMBOLS = (
     "tf_comm_exchange_every_frame",
     "tf_update_meshes", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
     "tf_pre_normal_map", "tf_pre_refine_depth_normal", "tf_pre_color_valid", "tf_pre_color_quality",
-    "tf_pre_refine_newframe", "tf_pre_refine_keyframe",
+    "tf_pre_refine_newframe", "tf_pre_refine_keyframe", "tf_integrate_depth_group", "tf_integrate_depth_group_host",
 )
 
 
@@ -157,6 +157,9 @@ def lib():
     L.tf_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.tf_comm_destroy.argtypes = [vp]
     L.tf_exchange_boundary.argtypes = [vp, C.c_int64]
+    L.tf_integrate_depth_group.argtypes = [vp, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                           C.c_int64, C.c_int, C.POINTER(C.c_uint8)]
+    L.tf_integrate_depth_group_host.argtypes = L.tf_integrate_depth_group.argtypes
     L.tf_pre_normal_map.argtypes = [vp, vp, vp]
     L.tf_pre_refine_depth_normal.argtypes = [vp, vp, vp]
     L.tf_pre_color_valid.argtypes = [vp, vp, vp]
@@ -499,6 +502,25 @@ class Volume:
 
     def comm_exchange_every_frame(self, cap):
         self._ck(self.L.tf_comm_exchange_every_frame(self.h, cap))
+
+    def integrate_depth_group(self, d_depth_ptrs, poses12, ids, needs, flag=1):
+        """n depth-only frames (device pointers) over the list `ids` in one visit per chunk; needs is updated in place."""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        P = _f32(poses12).reshape(-1, 12)
+        nf = len(d_depth_ptrs)
+        assert P.shape[0] == nf and needs.dtype == np.uint8 and len(needs) == len(ids)
+        arr = (C.c_void_p * nf)(*[int(p) for p in d_depth_ptrs])
+        self._ck(self.L.tf_integrate_depth_group(self.h, nf, arr, _p(P, C.c_float), _p(ids, C.c_int32), len(ids), int(flag),
+                                                 _p(needs, C.c_uint8)))
+
+    def integrate_depth_group_host(self, depths, poses12, ids, needs, flag=1):
+        """the same with host depth images"""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        P = _f32(poses12).reshape(-1, 12)
+        keep = [_f32(d) for d in depths]
+        arr = (C.c_void_p * len(keep))(*[d.ctypes.data for d in keep])
+        self._ck(self.L.tf_integrate_depth_group_host(self.h, len(keep), arr, _p(P, C.c_float), _p(ids, C.c_int32), len(ids),
+                                                      int(flag), _p(needs, C.c_uint8)))
 
     # -- frame pre-processing on device-resident images (raw device pointers; BasicAPI.cpp:378-905)
     def pre_normal_map(self, d_depth, d_normal):

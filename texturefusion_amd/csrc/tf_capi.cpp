@@ -345,6 +345,7 @@ int tf_volume_destroy(tf_volume* v) {
   if (v->d_rgba) hipFree(v->d_rgba);
   if (v->d_quality) hipFree(v->d_quality);
   if (v->d_tmp) hipFree(v->d_tmp);
+  if (v->d_group) hipFree(v->d_group);
   if (v->h_pinned) hipHostFree(v->h_pinned);
   for (int k = 0; k < tf_volume::kHostRing; ++k) {
     if (v->hslot[k].h) hipHostFree(v->hslot[k].h);
@@ -550,6 +551,63 @@ int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t
   memcpy(inout_needs_update, st, (size_t)n);
   if (out_quality) memcpy(out_quality, stq, (size_t)n * 4);
   return TF_OK;
+}
+
+int tf_integrate_depth_group(tf_volume* v, int32_t n_frames, const float* const* d_depth, const float* poses12,
+                             const int32_t* ids, int64_t n, int integrate_flag, uint8_t* inout_needs_update) {
+  if (!v || !d_depth || !poses12 || (n > 0 && (!ids || !inout_needs_update))) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (n_frames < 1 || n_frames > 6) { set_error("a keyframe group holds 1..6 local frames (GCFusion/MobileFusion.h: integrateLocalFrameNum)"); return TF_ERR_INVALID; }
+  for (int f = 0; f < n_frames; ++f)
+    if (!d_depth[f]) { set_error("null depth image"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (n < 1) return TF_OK;  // Chisel.h:228
+  int rc = sync_list(v, ids, n);
+  if (rc) return rc;
+  const size_t npad = (size_t)((n + 3) & ~(int64_t)3);
+  rc = ensure_pinned(v, npad);
+  if (rc) return rc;
+  // scratch: per frame the list records (2 x float4 per entry, stride 4) and the centroid table
+  const size_t pre_bytes = (size_t)n_frames * 4 * v->dev.max_list * sizeof(float4);
+  const size_t cen_bytes = (size_t)n_frames * 3 * kChunkVoxels * sizeof(float);
+  rc = ensure_tmp(v, pre_bytes + cen_bytes);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));
+  uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);
+  memcpy(st, inout_needs_update, (size_t)n);
+  TF_HIP(hipMemcpyAsync(v->dev.sel.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
+  float4* pre = reinterpret_cast<float4*>(v->d_tmp);
+  float* cen = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(v->d_tmp) + pre_bytes);
+  prof_begin(v, TF_PROF_INTEGRATE);
+  launch_integrate_group(v->dev, n_frames, d_depth, poses12, pre, cen, v->cam, v->ig, v->res, integrate_flag, v->stream);
+  prof_end(v);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(st, v->dev.sel.list_needs, (size_t)n, hipMemcpyDeviceToHost, v->stream));
+  CtlSnap ctl;
+  rc = fetch_ctl(v, &ctl);
+  if (rc) return rc;
+  memcpy(inout_needs_update, st, (size_t)n);
+  return TF_OK;
+}
+
+int tf_integrate_depth_group_host(tf_volume* v, int32_t n_frames, const float* const* depth, const float* poses12,
+                                  const int32_t* ids, int64_t n, int integrate_flag, uint8_t* inout_needs_update) {
+  if (!v || !depth) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (n_frames < 1 || n_frames > 6) { set_error("a keyframe group holds 1..6 local frames"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  const size_t npix = (size_t)v->cam.W * v->cam.H;
+  if (v->d_group_pixels != npix) {
+    if (v->d_group) hipFree(v->d_group);
+    v->d_group = nullptr;
+    TF_HIP(hipMalloc((void**)&v->d_group, 6 * npix * sizeof(float)));
+    v->d_group_pixels = npix;
+  }
+  const float* dd[6];
+  for (int f = 0; f < n_frames; ++f) {
+    if (!depth[f]) { set_error("null depth image"); return TF_ERR_INVALID; }
+    dd[f] = v->d_group + (size_t)f * npix;
+    TF_HIP(hipMemcpyAsync(v->d_group + (size_t)f * npix, depth[f], npix * sizeof(float), hipMemcpyHostToDevice, v->stream));
+  }
+  return tf_integrate_depth_group(v, n_frames, dd, poses12, ids, n, integrate_flag, inout_needs_update);
 }
 
 int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, const uint8_t* is_new,

@@ -260,6 +260,9 @@ void launch_boundary_unpack_blocks(const VolumeDev& v, const uint8_t* blocks, in
 // dlist: int4 {id.x, id.y, id.z, -} per dirty chunk, *dcount entries
 void launch_init_meshes(const VolumeDev& v, hipStream_t s);
 // fused = the per-frame flow: the mesh is marked simplified at once (CompressMeshes follows in the same frame)
+// keyframe group: n (<= 6) depth-only frames over the current list in one visit per chunk; scratch = n x (4 x max_list float4 + 1536 floats)
+void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
+                            float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s);
 uint32_t mesh_shard_rows(uint32_t max_chunks);
 void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s);

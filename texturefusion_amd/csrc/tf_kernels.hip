@@ -517,15 +517,17 @@ void launch_acquire(const VolumeDev& v, hipStream_t s) {
 
 // Per-chunk scalars for a list that is integrated with an explicit pose (call-by-call flow: every
 // IntegrateDepthScanColor call brings its own pose, Chisel.h:226).  One thread per entry.
-__global__ __launch_bounds__(256) void k_pre(VolumeDev v, Pose P, Integ ig, float res, float resDiag) {
+__global__ __launch_bounds__(256) void k_pre(VolumeDev v, Pose P, Integ ig, float res, float resDiag, float4* out_pre,
+                                             float* out_cen) {
   const SelBuf& L = v.sel;
-  if (blockIdx.x == 0) centroid_table(P.p, res, L.cen);
+  float4* pre = out_pre ? out_pre : L.list_pre;  // (the keyframe-group kernel keeps one set of records per frame)
+  if (blockIdx.x == 0) centroid_table(P.p, res, out_cen ? out_cen : L.cen);
   const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const int4 id = L.list_id[e];
     const ChunkPre cp = chunk_pre(id, P.p, ig, res, resDiag);
-    L.list_pre[4 * e] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
-    L.list_pre[4 * e + 1] = make_float4(cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
+    pre[4 * e] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
+    pre[4 * e + 1] = make_float4(cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
   }
 }
 
@@ -1053,6 +1055,172 @@ __global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img,
 }
 
 // ---------------------------------------------------------------------------------------
+// The local frames of a keyframe group in ONE visit per chunk (GCFusion/MobileFusion.cpp:187-203: after the
+// keyframe's own depth + colour, up to six depth-only frames are integrated over the SAME chunk list, each with
+// its own pose).  Frame by frame that is six launches that each read and rewrite the same voxel rows; here a wave
+// loads the chunk's 512 {sdf, weight} pairs once, applies the frames in order while they stay in registers -- the
+// arithmetic of integrate_body<COLOR = false>, operation for operation, including the row-granular rewrite of lanes
+// with weight 0 and the pos-stall of a fully off-image row -- and writes back the rows any frame rewrote.
+// ---------------------------------------------------------------------------------------
+constexpr int kGroupMax = 6;
+struct GroupArgs {
+  const float* depth[kGroupMax];   // device depth images
+  const float4* pre[kGroupMax];    // per-frame list records (k_pre)
+  const float* cen[kGroupMax];     // per-frame centroid tables
+  int n;
+};
+
+struct GroupPoses {
+  Pose P[kGroupMax];
+};
+// list records and centroid tables of all frames of a group in one launch (blockIdx.y = frame)
+__global__ __launch_bounds__(256) void k_pre_group(VolumeDev v, GroupPoses gp, Integ ig, float res, float resDiag,
+                                                   float4* pre_scratch, float* cen_scratch) {
+  const SelBuf& L = v.sel;
+  const int f = blockIdx.y;
+  float4* pre = pre_scratch + (size_t)f * 4 * v.max_list;
+  if (blockIdx.x == 0) centroid_table(gp.P[f].p, res, cen_scratch + (size_t)f * 3 * kChunkVoxels);
+  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int4 id = L.list_id[e];
+    const ChunkPre cp = chunk_pre(id, gp.P[f].p, ig, res, resDiag);
+    pre[4 * e] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
+    pre[4 * e + 1] = make_float4(cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
+  }
+}
+
+template <bool FLAG>
+__global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs ga, Cam cam, IntegrateConsts kc) {
+  const SelBuf& L = v.sel;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  const uint32_t nwaves = gridDim.x * 4;
+  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
+  const int vy = lane >> 3;
+  const int W = cam.W, H = cam.H;
+  __shared__ float cenT[kGroupMax][3][kChunkVoxels];  // 6 KB per frame
+  for (int f = 0; f < ga.n; ++f) {
+    const float4* src = reinterpret_cast<const float4*>(ga.cen[f]);
+    float4* dst = reinterpret_cast<float4*>(&cenT[f][0][0]);
+    for (int i = threadIdx.x; i < 3 * kChunkVoxels / 4; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const uint32_t row_lo = lane < 32 ? (0xFFu << (lane & 24)) : 0u;
+  const uint32_t row_hi = lane < 32 ? 0u : (0xFFu << (lane & 24));
+  auto row_any = [&](const unsigned long long m) -> bool {
+    return ((((uint32_t)m) & row_lo) | (((uint32_t)(m >> 32)) & row_hi)) != 0u;
+  };
+  auto ballot = [](const bool b) -> unsigned long long { return __builtin_amdgcn_ballot_w64(b); };
+  const f32x2 fxy = {cam.fxi, cam.fyi}, cxy = {kc.cxs, kc.cys};
+
+  for (uint32_t e = wave; e < n; e += nwaves) {
+    const int4 id = L.list_id[e];
+    if (!part_owned(v, id.x, id.y, id.z)) continue;
+    const uint32_t slot = L.list_slot[e];
+    if (slot == kInvalidSlot) continue;
+    const __amdgpu_buffer_rsrc_t rs_T =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+    u32x2 t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, (j * 64 + lane) * 8, 0, 0);
+    uint32_t dirty_rows = 0;   // bit j: the lane's row of slice j was rewritten by some frame
+    uint32_t rows_total = 0;
+    for (int f = 0; f < ga.n; ++f) {
+      const float4 r0 = ga.pre[f][4 * e], r1 = ga.pre[f][4 * e + 1];
+      const float o0 = r0.x, o1 = r0.y, o2 = r0.z, pbx = r0.w, pby = r1.x;
+      const f32x2 o01 = {o0, o1};
+      const float wD = FLAG ? pbx : -pbx;
+      const float upper = pby;
+      const float band = 32.0f * kc.res;
+      const bool div_safe = (fabsf(o2) > band) && (fabsf(o2) < 1048576.0f) && (fabsf(o0) < 1048576.0f) &&
+                            (fabsf(o1) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
+      const __amdgpu_buffer_rsrc_t rs_depth =
+          __builtin_amdgcn_make_buffer_rsrc((void*)ga.depth[f], 0, W * H * 4, 0x00020000);
+      int off_d[8];
+      unsigned long long vm[8];
+      uint32_t R = 64;
+      auto geometry = [&](auto safe_tag) {
+        constexpr bool SAFE = decltype(safe_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = j * 64 + lane;
+          const f32x2 pxy = o01 + (f32x2){cenT[f][0][k], cenT[f][1][k]};
+          const float pzv = o2 + cenT[f][2][k];
+          f32x2 q;
+          if (SAFE) {
+            q = div2_by(pxy, recip_refined(pzv));
+          } else {
+            q.x = pxy.x / pzv;
+            q.y = pxy.y / pzv;
+          }
+          const f32x2 uw = q * fxy + cxy;
+          const int X = SAFE ? cvt_rne_hw(uw.x) : cvt_sat_rne(uw.x);
+          const int Y = SAFE ? cvt_rne_hw(uw.y) : cvt_sat_rne(uw.y);
+          const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
+          vm[j] = ballot(valid);
+          int od = (__mul24(Y, W) + X) * 4;
+          asm volatile("" : "+v"(od));
+          off_d[j] = valid ? od : kOOB;
+        }
+      };
+      if (div_safe) geometry(std::true_type{});
+      else geometry(std::false_type{});
+      unsigned long long all_valid = ~0ull;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) all_valid &= vm[j];
+      if (all_valid != ~0ull) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (R == 64u) {
+            const unsigned long long dead = nonzero_bytes(vm[j]) ^ 0x0101010101010101ull;
+            if (dead) R = (uint32_t)(j * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
+          }
+          const bool live_lane = (uint32_t)(j * 8 + vy) < R;
+          off_d[j] = live_lane ? off_d[j] : kOOB;
+        }
+      }
+      float dep[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j], 0, 0));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if ((uint32_t)(j * 8) >= R) break;  // a stalled row ends the chunk
+        const float d = dep[j];
+        const float sd = d - (o2 + cenT[f][2][j * 64 + lane]);
+        const bool act = (uint32_t)(j * 8 + vy) < R;
+        const bool dv = (d > cam.nearP) && (cam.farP > d);
+        const bool inside = (sd > kc.lower) && (upper > sd);
+        const bool F = act && dv && inside;
+        const float nw = F ? wD : 0.0f;
+        const bool rf_l = row_any(ballot(F));
+        rows_total += (uint32_t)__popcll(ballot(rf_l)) >> 3;
+        if (rf_l) {  // every lane of a rewritten row is recomputed, with weight 0 where the voxel itself is not hit
+          const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);
+          const float num = ts * tw + sd * nw;
+          const float den = (tw + nw) + kc.sigma;
+          const float ns = num / den;
+          const float nwt = tw + nw;
+          const bool keep = nwt > 0.5f;
+          t[j].x = __float_as_uint(keep ? ns : 999.0f);
+          t[j].y = __float_as_uint(keep ? nwt : 0.0f);
+          dirty_rows |= 1u << j;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, ((dirty_rows >> j) & 1u) ? (j * 64 + lane) * 8 : kOOB, 0, 0);
+    const bool updated = rows_total != 0;
+    if (updated && lane == 0) {
+      L.list_needs[e] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
+      if (part_band(v, id.x, id.y, id.z)) v.hent[L.list_ent[e]].alive = 3u;  // multi-GPU: touched since the last exchange
+    }
+    if (lane == 0) L.list_rows[e] = (uint16_t)(rows_total < 255u ? rows_total : 255u);  // (statistic; saturates)
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // The per-frame unit as ONE launch: three independent block ranges form a 3-stage software
 // pipeline over consecutive frames of a stream --
 //     [0, n_bbox)                 K-B  of frame f+2  (into selection set f+2)
@@ -1133,7 +1301,7 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
                       uint32_t epoch, hipStream_t s) {
   IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
-  hipLaunchKernelGGL(k_pre, dim3(256), dim3(256), 0, s, v, pose, ig, res, kc.resDiag);
+  hipLaunchKernelGGL(k_pre, dim3(256), dim3(256), 0, s, v, pose, ig, res, kc.resDiag, (float4*)nullptr, (float*)nullptr);
   static const int nblocks = env_int("TF_KA_BLOCKS", ka_blocks_default());  // tuning knob
   const dim3 grid(nblocks > 0 ? nblocks : 2048), block(256);
 #define TF_LAUNCH_KA(C, Q)                                                                           \
@@ -1145,6 +1313,26 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
   else if (use_color) TF_LAUNCH_KA(true, false);
   else TF_LAUNCH_KA(false, false);
 #undef TF_LAUNCH_KA
+}
+
+void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
+                            float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s) {
+  IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
+  GroupArgs ga = {};
+  GroupPoses gp = {};
+  ga.n = n;
+  for (int f = 0; f < n; ++f) {
+    for (int q = 0; q < 12; ++q) gp.P[f].p[q] = poses12[12 * f + q];
+    ga.depth[f] = d_depth[f];
+    ga.pre[f] = pre_scratch + (size_t)f * 4 * v.max_list;
+    ga.cen[f] = cen_scratch + (size_t)f * 3 * kChunkVoxels;
+  }
+  hipLaunchKernelGGL(k_pre_group, dim3(128, n), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch);
+  static const int nblocks = env_int("TF_KG_BLOCKS", 0);
+  int cus = ka_blocks_default() / TF_KF_WAVES;
+  const dim3 grid(nblocks > 0 ? nblocks : cus * 4), block(256);  // 36 KB of LDS per workgroup: four per CU
+  if (flag) hipLaunchKernelGGL(k_integrate_group<true>, grid, block, 0, s, v, ga, cam, kc);
+  else hipLaunchKernelGGL(k_integrate_group<false>, grid, block, 0, s, v, ga, cam, kc);
 }
 
 // One pipelined launch.  Any of the three stages may be absent (pipeline fill / drain):

@@ -136,6 +136,8 @@ struct tf_volume {
   uint32_t clear_floor = 0;  // stamps <= this were cleared (Chisel::CompressMeshes' chunksToUpdate.clear())
   uint32_t mesh_epoch = 0;   // meshing passes so far (MeshRec::epoch)
   int mesh_par = 0;          // parity of the next mesher launch (VolumeDev::mesh_cnt)
+  float* d_group = nullptr;  // staging of tf_integrate_depth_group_host: six depth images
+  size_t d_group_pixels = 0;
   // on-demand device scratch
   void* d_tmp = nullptr;
   size_t d_tmp_bytes = 0;

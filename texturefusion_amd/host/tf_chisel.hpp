@@ -513,6 +513,27 @@ class Chisel {
     }
   }
 
+  // The local-frame loop of MobileFusion::TSDFFusion (GCFusion/MobileFusion.cpp:187-203) as one call: the depth-only
+  // IntegrateDepthScanColor of up to six frames over the keyframe's chunk list, each frame with its own pose, applied
+  // in order in one visit per chunk (same results as calling the overload above once per frame with colorImage = NULL).
+  void IntegrateDepthScanGroup(ProjectionIntegrator& integrator, const std::vector<float*>& depthImages,
+                               const std::vector<Transform>& depthExtrinsics, const PinholeCamera& depthCamera,
+                               ChunkIDList& chunksIntersecting, std::vector<bool>& needsUpdateFlag, int integrate_flag) {
+    Configure(integrator, depthCamera);
+    const size_t n = chunksIntersecting.size(), nf = depthImages.size();
+    if (n < 1 || nf < 1) return;
+    Flatten(chunksIntersecting);
+    needs_buf.resize(n);
+    for (size_t i = 0; i < n; ++i) needs_buf[i] = needsUpdateFlag[i] ? 1 : 0;
+    std::vector<float> poses(12 * nf);
+    for (size_t f = 0; f < nf; ++f) std::memcpy(&poses[12 * f], depthExtrinsics[f].data(), 48);
+    std::vector<const float*> dp(depthImages.begin(), depthImages.end());
+    tf_check(tf_integrate_depth_group_host(vol, (int32_t)nf, dp.data(), poses.data(), ids_buf.data(), (int64_t)n, integrate_flag,
+                                           needs_buf.data()),
+             "IntegrateDepthScanGroup");
+    for (size_t i = 0; i < n; ++i) needsUpdateFlag[i] = needs_buf[i] != 0;
+  }
+
   // Structure/Chisel.h:184-216.
   void FinalizeIntegrateChunks(ChunkIDList& chunksIntersecting, std::vector<bool>& needsUpdateFlag,
                                std::vector<bool>& newChunkFlag, ChunkIDList& validChunks) {
