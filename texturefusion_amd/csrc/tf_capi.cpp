@@ -353,6 +353,8 @@ int tf_volume_destroy(tf_volume* v) {
     if (v->hslot[k].copied) hipEventDestroy(v->hslot[k].copied);
     if (v->hslot[k].freed) hipEventDestroy(v->hslot[k].freed);
   }
+  delete v->copy_pool;
+  v->copy_pool = nullptr;
   if (v->copy_stream) hipStreamDestroy(v->copy_stream);
   if (v->own_stream && v->stream) hipStreamDestroy(v->stream);
   delete v;
@@ -904,8 +906,24 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   TF_HIP(hipEventSynchronize(s.copied));
   float* hd = reinterpret_cast<float*>(s.h);
   uint8_t* hc = s.h + npix * 4;
-  if (depth != hd) memcpy(hd, depth, npix * 4);           // frames composed in tf_host_frame_buffers' slot skip this
-  if (rgba && rgba != hc) memcpy(hc, rgba, npix * 4);
+  {  // frames composed in tf_host_frame_buffers' slot skip the staging copy
+    void* dst[2];
+    const void* src[2];
+    size_t nb[2];
+    int nr = 0;
+    if (depth != hd) { dst[nr] = hd; src[nr] = depth; nb[nr++] = npix * 4; }
+    if (rgba && rgba != hc) { dst[nr] = hc; src[nr] = rgba; nb[nr++] = npix * 4; }
+    if (nr) {
+      if (!v->copy_pool) {
+        const char* e = getenv("TF_COPY_THREADS");
+        int helpers = e ? atoi(e) : 3;
+        if (helpers < 0) helpers = 0;
+        if (helpers > 15) helpers = 15;
+        v->copy_pool = new CopyPool(helpers);
+      }
+      v->copy_pool->copy(dst, src, nb, nr);
+    }
+  }
   TF_HIP(hipMemcpyAsync(s.d, s.h, rgba ? npix * 8 : npix * 4, hipMemcpyHostToDevice, v->copy_stream));
   TF_HIP(hipEventRecord(s.copied, v->copy_stream));
   TF_HIP(hipStreamWaitEvent(v->stream, s.copied, 0));

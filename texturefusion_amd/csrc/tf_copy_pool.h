@@ -1,0 +1,92 @@
+// tf_copy_pool.h -- a few helper threads for the host-side staging copy of tf_integrate_frame_host.
+//
+// The reference hands over pageable host images (cv::Mat data); they have to be copied into pinned memory before
+// the asynchronous H2D transfer, and one thread copies a 2.4 MB frame out of DRAM at ~5 GB/s -- slower than the
+// device processes it.  The pool splits a copy into equal parts; the calling thread takes parts too.
+#ifndef TF_COPY_POOL_H_
+#define TF_COPY_POOL_H_
+#include <string.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace tf {
+
+class CopyPool {
+ public:
+  explicit CopyPool(int helpers) {
+    for (int i = 0; i < helpers; ++i) workers_.emplace_back([this] { loop(); });
+  }
+  ~CopyPool() {
+    {
+      std::lock_guard<std::mutex> g(m_);
+      stop_ = true;
+      ++gen_;
+    }
+    cv_.notify_all();
+    for (std::thread& t : workers_) t.join();
+  }
+  CopyPool(const CopyPool&) = delete;
+  CopyPool& operator=(const CopyPool&) = delete;
+
+  // dst[i] <- src[i] for the given regions (up to 4), each split into parts of about 256 KiB
+  void copy(void* const* dst, const void* const* src, const size_t* bytes, int regions) {
+    tasks_.clear();
+    for (int r = 0; r < regions; ++r) {
+      const size_t part = 256u << 10;
+      for (size_t o = 0; o < bytes[r]; o += part)
+        tasks_.push_back({static_cast<char*>(dst[r]) + o, static_cast<const char*>(src[r]) + o,
+                          bytes[r] - o < part ? bytes[r] - o : part});
+    }
+    if (tasks_.empty()) return;
+    if (workers_.empty() || tasks_.size() < 2) {
+      for (const Task& t : tasks_) memcpy(t.d, t.s, t.n);
+      return;
+    }
+    next_.store(0, std::memory_order_relaxed);
+    left_.store((int)tasks_.size(), std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> g(m_);
+      ++gen_;
+    }
+    cv_.notify_all();
+    pull();
+    while (left_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+  }
+
+ private:
+  struct Task { char* d; const char* s; size_t n; };
+  void pull() {
+    for (;;) {
+      const int i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= (int)tasks_.size()) return;
+      memcpy(tasks_[i].d, tasks_[i].s, tasks_[i].n);
+      left_.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  void loop() {
+    unsigned long seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> g(m_);
+        cv_.wait(g, [&] { return gen_ != seen; });
+        seen = gen_;
+        if (stop_) return;
+      }
+      pull();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::vector<Task> tasks_;
+  std::atomic<int> next_{0}, left_{0};
+  std::mutex m_;
+  std::condition_variable cv_;
+  unsigned long gen_ = 0;
+  bool stop_ = false;
+};
+
+}  // namespace tf
+#endif  // TF_COPY_POOL_H_

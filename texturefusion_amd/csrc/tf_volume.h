@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/tf_fusion.h"
+#include "tf_copy_pool.h"
 #include "tf_device.h"
 
 namespace tf {
@@ -125,6 +126,7 @@ struct tf_volume {
   size_t hslot_pixels = 0;
   int hslot_next = 0;
   hipStream_t copy_stream = nullptr;
+  tf::CopyPool* copy_pool = nullptr;  // helper threads of the staging copy (TF_COPY_THREADS, default 3)
   void* h_pinned = nullptr;      // pinned host staging (uploads / downloads)
   size_t h_pinned_bytes = 0;
   tf::FrameImages frame{nullptr, nullptr, nullptr};
