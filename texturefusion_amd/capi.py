@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtexfusion_hip.so")
+# TF_LIB points at another build of the same sources (A/B runs of tuning variants under variants/)
+LIB_PATH = os.environ.get("TF_LIB") or os.path.join(_HERE, "libtexfusion_hip.so")
 
 TF_OK = 0
 TF_ERR_ATLAS_FULL = -1
