@@ -182,14 +182,18 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
-                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar) {
+                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool xcd_contig) {
   const int lane = threadIdx.x & 63;
   const uint32_t nwaves = gridDim.x * 4;
-  // wave w takes entries w, w + nwaves, ...; its survivors go to shard w % 32.  (Measured on MI355X: handing each
-  // XCD a contiguous stretch of the list instead -- for L2 reuse of the halo reads -- is slower, 15.6 -> 19.9 us here
-  // and 38 -> 54 us in k_mesh: survivors cluster in the list, so contiguous shards are unevenly filled.)
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-  const uint32_t shard = wave & (kMeshShards - 1u);
+  // wave w takes entries w, w + nwaves, ...
+  uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+  if (xcd_contig) {  // TF_FILTER_XCD=1: XCD x (workgroups x, x + 8, ...) takes a contiguous eighth of the wave numbers, for
+                     // L2 reuse of the halo reads among list neighbours: -6 % on filter + mesher in the 1280x960 hall, +3 %
+                     // in the room (profiles/r2/README.md); off by default
+    const uint32_t per = gridDim.x >> 3;
+    const uint32_t b = (per && blockIdx.x < per * 8u) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
+    wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b * 4u + (threadIdx.x >> 6)));
+  }
   uint32_t n = *dcount;
   if (n > max_entries) n = max_entries;
   for (uint32_t entry = wave; entry < n; entry += nwaves) {
@@ -207,6 +211,9 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
     }
     const uint32_t own = (uint32_t)__shfl((int)nslot, 13);
     if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
+    // rows and patch entries go to shard own % 32: pool slots are unique, so a shard never holds more than
+    // max_chunks / 32 of them whatever the order of the work
+    const uint32_t shard = own & (kMeshShards - 1u);
     const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
     uint32_t fl = 0;
 #pragma unroll
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
       uint32_t p = 0;
       if (lane == 0) p = atomicAdd(&cnt[shard * 16], 1u);
       p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
-      if (p >= cap_sh) {  // cannot happen for lists within max_chunks (entries are dealt round-robin to the waves)
+      if (p >= cap_sh) {  // (cannot happen: at most max_chunks / 32 pool slots share a shard)
         if (lane == 0) atomicOr(&v.vctl->status, kStMeshFull);
         continue;
       }
@@ -585,14 +592,15 @@ static int mesh_resident_blocks() {
   return cus * (e ? atoi(e) : 6);
 }
 
-// rows per shard: a shard takes every 32nd of the filter's (at most 8192) waves, a wave every 8192-th entry
-// -> at most max_chunks / 32 rows, plus one partial pass of 256
+// rows per shard: a chunk's row and patch entry go to shard (pool slot % 32) and pool slots are unique, so a shard
+// holds at most ceil(max_chunks / 32) of them (the margin is historical)
 uint32_t mesh_shard_rows(uint32_t max_chunks) { return max_chunks / kMeshShards + 258u; }
 
 void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s) {
   if (!max_entries) return;
   static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch
+  static const bool xcd_contig = getenv("TF_FILTER_XCD") && atoi(getenv("TF_FILTER_XCD"));
   uint32_t* surv = v.mesh_nbr;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
   uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshShards * 16;
@@ -600,7 +608,7 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   if (max_entries > v.max_chunks) max_entries = v.max_chunks;
   const uint32_t fgrid = (max_entries + 3) / 4 < 2048u ? (max_entries + 3) / 4 : 2048u;
   hipLaunchKernelGGL(k_mesh_filter, dim3(fgrid), dim3(256), 0, s, v, dlist, fused ? v.work_slot : nullptr, dcount,
-                     max_entries, epoch, surv, cnt, cap_sh, fused ? (rearm_set ^ 1) : -1);
+                     max_entries, epoch, surv, cnt, cap_sh, fused ? (rearm_set ^ 1) : -1, xcd_contig);
   // the survivors form dense per-shard lists: a grid of a few resident rounds, each workgroup striding its shard
   // (TF_MESH_GRID overrides; rounded to a multiple of the shard count)
   static const uint32_t gmax = getenv("TF_MESH_GRID") ? (uint32_t)atoi(getenv("TF_MESH_GRID")) : 4096u;
