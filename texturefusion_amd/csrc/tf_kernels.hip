@@ -1022,12 +1022,15 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     }
     if (FUSED) {
       // FinalizeIntegrateChunks (Chisel.h:192-208) + GarbageCollect (:472-477) for this entry
+      // (erase_epoch == mark_epoch + max_chunks, one allocation: both stores go through ONE pointer member.  With
+      // two, the compiler merges the stores into one through a phi of the members' addresses inside the
+      // kernel-argument struct, which kept the depth-only instance's copy of that struct in private memory.)
       if (updated) {
         if (lane == 0) v.mark_epoch[slot] = epoch + 1u;  // meshesToUpdate[id and 6 nbrs] = true, expanded lazily
       } else if (is_new) {
         if (lane == 0) {
           if (!lazy_revive) v.hent[ent].alive = 0;
-          v.erase_epoch[slot] = epoch + 1u;  // meshesToUpdate.erase(id)
+          v.mark_epoch[(size_t)v.max_chunks + slot] = epoch + 1u;  // erase_epoch[slot]: meshesToUpdate.erase(id)
         }
         if (rows_c) {  // parked storage returns to the fresh state (only colour can be dirty)
           uint4* c4 = reinterpret_cast<uint4*>(v.color + (size_t)slot * kChunkVoxels);
