@@ -1,0 +1,50 @@
+"""Register / private-memory budget of the hot kernels, checked at build time (hipcc cross-compiles without a GPU):
+a kernel that silently starts to spill, or whose kernel-argument struct ends up in private memory (as the depth-only
+instance of k_frame once did: 1.2 KB per lane, 9x slower), still passes every parity test -- this catches it."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "texturefusion_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+# kernel name fragment -> (max VGPRs, max scratch bytes per lane)
+BUDGET = {
+    "tf_kernels.hip": {"k_frameILb1E": (72, 0), "k_frameILb0E": (72, 0), "k_integrate_groupILb1E": (96, 0),
+                       "k_integrate_groupILb0E": (96, 0)},
+    "tf_mesh.hip": {"k_meshILi256E": (80, 0), "k_mesh_filter": (64, 0)},
+    "tf_atlas.hip": {"k_patchILb1ELb1ELb1E": (136, 0)},  # one patch per wave, ~3 waves per SIMD: occupancy is not the limit
+}
+
+
+def _usage(src):
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+           "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", os.devnull]
+    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            out[name] = {}
+        m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if m and name:
+            out[name][m.group(1).split(" ")[0]] = int(m.group(2))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src", sorted(BUDGET))
+def test_hot_kernels_stay_within_their_register_budget(src):
+    usage = _usage(src)
+    for frag, (max_vgpr, max_scratch) in BUDGET[src].items():
+        hits = {k: v for k, v in usage.items() if frag in k}
+        assert hits, "kernel %s not found in %s" % (frag, src)
+        for k, v in hits.items():
+            assert v["ScratchSize"] <= max_scratch, "%s uses %d B/lane of private memory" % (k, v["ScratchSize"])
+            assert v["VGPRs"] <= max_vgpr, "%s uses %d VGPRs (budget %d)" % (k, v["VGPRs"], max_vgpr)
