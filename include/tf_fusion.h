@@ -202,9 +202,12 @@ TF_API int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int6
                                             const float* const* d_depth, const uint8_t* const* d_rgba,
                                             const float* poses12, const float* pose_inv16, int32_t first_frame_id);
 /* MobileFusion::IntegrateFrame (GCFusion/MobileFusion.cpp:223-250) as the reference calls it: HOST images in,
- * one call per frame.  The images go through a ring of three pinned staging / device slots and are uploaded
- * on a second stream, so the H2D of frame f + 1 overlaps the kernels of frame f and the call returns without
- * synchronising (tf_sync / any state access waits).  pose_inv16 != NULL runs the textured unit
+ * one call per frame.  The images go through a ring of five pinned staging / device slots and are uploaded
+ * on a second stream, so the H2D of a frame overlaps the kernels of earlier ones and the call returns without
+ * synchronising (tf_sync / any state access waits).  Internally the call for frame f launches the integration of
+ * frame f - 2 together with the chunk selection of f - 1 and f (the launch pipeline of the streaming entry points,
+ * kept alive across calls); every other entry point first integrates the frames still in that pipeline, so the
+ * deferral is not observable through this API.  pose_inv16 != NULL runs the textured unit
  * (tf_stream_frames_textured_device's per-frame work) with Patch::frameid = frame_id; NULL = TSDF only.
  * tf_host_frame_buffers hands out the pinned slot the NEXT call will upload from: a caller that composes its
  * depth / RGBA images there (and passes these pointers) saves the staging copy. */

@@ -857,6 +857,14 @@ int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int64_t n_a
 }
 
 // ring of staging slots of the per-frame host path, (re)sized to the camera
+static int bind_frame(tf_volume* v, const float* d_depth, const uint8_t* d_rgba) {  // tf_frame_bind_device without the entry checks
+  v->frame.depth = d_depth;
+  v->frame.rgba = reinterpret_cast<const uchar4*>(d_rgba);
+  v->frame.quality = nullptr;
+  v->frame_bound = true;
+  return TF_OK;
+}
+
 static int host_ring_prepare(tf_volume* v) {
   const size_t npix = (size_t)v->cam.W * v->cam.H;
   if (v->hslot_pixels == npix && v->copy_stream) return TF_OK;
@@ -880,7 +888,7 @@ static int host_ring_prepare(tf_volume* v) {
 
 int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba) {
   if (!v || !depth || !rgba) { set_error("null argument"); return TF_ERR_INVALID; }
-  TF_DEV(v);
+  TF_DEV_NOFLUSH(v);
   int rc = host_ring_prepare(v);
   if (rc) return rc;
   tf_volume::HostSlot& s = v->hslot[v->hslot_next];
@@ -894,11 +902,12 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
                             const float* pose_inv16, int32_t frame_id) {
   if (!v || !depth || !pose) { set_error("null argument"); return TF_ERR_INVALID; }
   if (pose_inv16 && !rgba) { set_error("the textured unit needs a colour image"); return TF_ERR_INVALID; }
-  TF_DEV(v);
+  TF_DEV_NOFLUSH(v);
   int rc = host_ring_prepare(v);
   if (rc) return rc;
   const size_t npix = v->hslot_pixels;
-  tf_volume::HostSlot& s = v->hslot[v->hslot_next];
+  const int slot_index = v->hslot_next;
+  tf_volume::HostSlot& s = v->hslot[slot_index];
   v->hslot_next = (v->hslot_next + 1) % tf_volume::kHostRing;
   // the kernels that read this slot's device images (three frames ago) and the upload out of its pinned
   // buffer have finished
@@ -927,18 +936,70 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   TF_HIP(hipMemcpyAsync(s.d, s.h, rgba ? npix * 8 : npix * 4, hipMemcpyHostToDevice, v->copy_stream));
   TF_HIP(hipEventRecord(s.copied, v->copy_stream));
   TF_HIP(hipStreamWaitEvent(v->stream, s.copied, 0));
-  const float* dd[1] = {reinterpret_cast<const float*>(s.d)};
-  const uint8_t* dc[1] = {rgba ? s.d + npix * 4 : nullptr};
-  if (pose_inv16) {
-    TexturedArgs tex{pose_inv16, frame_id};
-    rc = enqueue_frames(v, 1, 0, dd, dc, pose, &tex);
-  } else {
-    rc = enqueue_frames(v, 1, 0, dd, dc, pose, nullptr);
+  tf_volume::Pending cur;
+  cur.d = reinterpret_cast<const float*>(s.d);
+  cur.c = rgba ? s.d + npix * 4 : nullptr;
+  memcpy(cur.pose, pose, sizeof(cur.pose));
+  cur.tex = pose_inv16 != nullptr;
+  if (pose_inv16) memcpy(cur.pinv, pose_inv16, sizeof(cur.pinv));
+  cur.fid = frame_id;
+  cur.slot = slot_index;
+  static const bool defer = !(getenv("TF_HOST_DEFER") && !atoi(getenv("TF_HOST_DEFER")));
+  if (!defer) {  // integrate at once: two selection-only launches per frame
+    const float* dd[1] = {cur.d};
+    const uint8_t* dc[1] = {cur.c};
+    TexturedArgs tex{cur.pinv, cur.fid};
+    rc = enqueue_frames(v, 1, 0, dd, dc, cur.pose, cur.tex ? &tex : nullptr);
+    if (rc) return rc;
+    TF_HIP(hipEventRecord(s.freed, v->stream));
+    return bind_frame(v, cur.d, cur.c);
   }
+  // The launch pipeline of the streaming entry points, kept alive across per-frame calls: this call integrates the
+  // frame that arrived two calls ago, and that launch carries the selection stages of the two frames behind it
+  // (K-A(f-2) | K-C(f-1) | K-B(f)).  The deferral cannot be observed: every other entry point flushes first (TF_DEV).
+  if (v->n_pend < 2) {
+    v->pend[v->n_pend++] = cur;
+    return TF_OK;
+  }
+  const tf_volume::Pending p0 = v->pend[0], p1 = v->pend[1];
+  const float* dd[3] = {p0.d, p1.d, cur.d};
+  const uint8_t* dc[3] = {p0.c, p1.c, cur.c};
+  float poses[36];
+  memcpy(poses, p0.pose, 48); memcpy(poses + 12, p1.pose, 48); memcpy(poses + 24, cur.pose, 48);
+  TexturedArgs tex{p0.pinv, p0.fid};
+  v->n_pend = 0;  // (helpers below enqueue_frames may pass through TF_DEV: nothing to flush while this call runs)
+  rc = enqueue_frames(v, 1, 2, dd, dc, poses, p0.tex ? &tex : nullptr);
+  v->pend[0] = p1;
+  v->pend[1] = cur;
+  v->n_pend = 2;
   if (rc) return rc;
-  TF_HIP(hipEventRecord(s.freed, v->stream));
-  return tf_frame_bind_device(v, dd[0], dc[0], nullptr);
+  TF_HIP(hipEventRecord(v->hslot[p0.slot].freed, v->stream));
+  return bind_frame(v, p0.d, p0.c);
 }
+
+}  // extern "C" (C++ linkage for the helper below)
+namespace tf {
+// brings the deferred frames of tf_integrate_frame_host onto the stream, oldest first (each launch still carries
+// the selection stages of the frames behind it)
+int flush_deferred(tf_volume* v) {
+  const int n = v->n_pend;
+  if (!n) return TF_OK;
+  tf_volume::Pending p[2] = {v->pend[0], v->pend[1]};
+  v->n_pend = 0;  // (enqueue_frames' helpers may pass through TF_DEV)
+  for (int k = 0; k < n; ++k) {
+    const float* dd[2];
+    const uint8_t* dc[2];
+    float poses[24];
+    for (int j = k; j < n; ++j) { dd[j - k] = p[j].d; dc[j - k] = p[j].c; memcpy(poses + 12 * (j - k), p[j].pose, 48); }
+    TexturedArgs tex{p[k].pinv, p[k].fid};
+    int rc = enqueue_frames(v, 1, n - 1 - k, dd, dc, poses, p[k].tex ? &tex : nullptr);
+    if (rc) return rc;
+    TF_HIP(hipEventRecord(v->hslot[p[k].slot].freed, v->stream));
+  }
+  return bind_frame(v, p[n - 1].d, p[n - 1].c);
+}
+}  // namespace tf
+extern "C" {
 
 int tf_texture_frame_device(tf_volume* v, const float pose_inv16[16], int32_t frame_id) {
   if (!v || !pose_inv16) { set_error("null argument"); return TF_ERR_INVALID; }

@@ -27,12 +27,22 @@ void set_error(const std::string& msg);
 // Every C-ABI entry point binds the calling thread to the handle's device first: scratch allocations,
 // launches and copies must land on the GPU the volume lives on, whatever device the caller's thread
 // had current (two volumes on different GPUs in one process, framework worker threads).
-#define TF_DEV(v)                                                                           \
+#define TF_DEV_NOFLUSH(v)                                                                   \
   do {                                                                                      \
     hipError_t _e = hipSetDevice((v)->device);                                              \
     if (_e != hipSuccess) {                                                                 \
       ::tf::set_error(std::string("hipSetDevice: ") + hipGetErrorString(_e));               \
       return TF_ERR_HIP;                                                                    \
+    }                                                                                       \
+  } while (0)
+// Every entry point but tf_integrate_frame_host first brings the frames that entry point has deferred (its
+// two-frame launch pipeline, see tf_capi.cpp) onto the stream, so that nothing can observe the deferral.
+#define TF_DEV(v)                                                                           \
+  do {                                                                                      \
+    TF_DEV_NOFLUSH(v);                                                                      \
+    if ((v)->n_pend) {                                                                      \
+      int _rc = ::tf::flush_deferred(v);                                                    \
+      if (_rc) return _rc;                                                                  \
     }                                                                                       \
   } while (0)
 
@@ -116,7 +126,7 @@ struct tf_volume {
   size_t img_pixels = 0;
   // drop-in per-frame host path (tf_integrate_frame_host): ring of pinned staging + device image slots, H2D on
   // its own stream so that the copy of frame f+1 overlaps the kernels of frame f
-  static constexpr int kHostRing = 3;
+  static constexpr int kHostRing = 5;  // two deferred frames + the one being staged + two whose kernels may still run
   struct HostSlot {
     uint8_t* h = nullptr;      // pinned: depth f32[npix] | rgba u8[4 npix]
     uint8_t* d = nullptr;      // device: same layout
@@ -138,6 +148,19 @@ struct tf_volume {
   uint32_t clear_floor = 0;  // stamps <= this were cleared (Chisel::CompressMeshes' chunksToUpdate.clear())
   uint32_t mesh_epoch = 0;   // meshing passes so far (MeshRec::epoch)
   int mesh_par = 0;          // parity of the next mesher launch (VolumeDev::mesh_cnt)
+  // frames tf_integrate_frame_host has staged but not integrated yet (it runs two frames behind: K-A of frame f - 2
+  // shares its launch with the selection stages of f - 1 and f, like the streaming entry points)
+  struct Pending {
+    const float* d = nullptr;
+    const uint8_t* c = nullptr;
+    float pose[12];
+    float pinv[16];
+    bool tex = false;
+    int32_t fid = 0;
+    int slot = 0;
+  };
+  Pending pend[2];
+  int n_pend = 0;
   float* d_group = nullptr;  // staging of tf_integrate_depth_group_host: six depth images
   size_t d_group_pixels = 0;
   // on-demand device scratch
@@ -156,6 +179,7 @@ struct tf_volume {
 
 namespace tf {
 int ensure_tmp(tf_volume* v, size_t bytes);
+int flush_deferred(tf_volume* v);
 int ensure_pinned(tf_volume* v, size_t bytes);
 void prof_begin(tf_volume* v, int kind, hipStream_t s = nullptr);
 void prof_end(tf_volume* v, hipStream_t s = nullptr);
