@@ -84,3 +84,48 @@ def test_hall_1280x960(gpu_required):
     frames = [synth.room_frame(k, cam, half=(4.0, 3.0, 4.0), radius=3.2, with_quality=False) for k in range(18, 24)]
     n = _run(cam, np.float32(0.005), frames, max_chunks=1 << 19, stride=11)
     assert n > 200
+
+
+def test_host_frames_deferral_is_not_observable(gpu_required):
+    """tf_integrate_frame_host runs two frames behind internally; any other entry point has to see every frame that was
+    handed over: state queries after 1, 2, 3, 5 and 6 calls (pipeline depths 1, 2, 2, 2, 1 at the flush), a
+    call-by-call integration in between, and another stream of host frames behind it."""
+    cam = synth.Camera()
+    res = np.float32(0.005)
+    ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(res, cam, max_chunks=1 << 16)
+    oa = O.Atlas(res)
+    frames = [synth.room_frame(3 * k, cam, with_quality=False, wobble=0.04) for k in range(9)]
+    pinv = [synth.pose_inverse16(f[3]) for f in frames]
+
+    def check(tag):
+        oids = sorted_ids(ov.list_chunks())
+        assert np.array_equal(oids, sorted_ids(gv.list_chunks())), tag  # (list_chunks is one of the flushing entry points)
+        assert_chunks_equal(ov, gv, oids[::9], tag)
+        assert np.array_equal(sorted_ids(ov.list_meshes()), sorted_ids(gv.list_meshes())), tag
+
+    for k in range(6):
+        f = frames[k]
+        ov.frame_textured(oa, f[0], f[1], f[3], pinv[k], 70 + k)
+        gv.integrate_frame_host(f[0], f[1], f[3].reshape(12), pinv[k], 70 + k)
+        if k in (0, 1, 2, 4, 5):
+            check("after %d host frames" % (k + 1))
+    # a call-by-call frame in between (prepare / integrate / finalize), then host frames again
+    f = frames[6]
+    oids, onew = ov.prepare(f[0], f[3])
+    gv.frame_upload(f[0], f[1], None)
+    gids, gnew = gv.prepare(f[3])
+    assert np.array_equal(oids, gids)
+    on, gn = np.zeros(len(oids), np.uint8), np.zeros(len(oids), np.uint8)
+    ov.integrate(f[0], f[1], None, f[3], oids, on, 1, -1)
+    gv.integrate(f[3], gids, gn, 1, True, False)
+    assert np.array_equal(on, gn)
+    assert np.array_equal(ov.finalize(oids, on, onew), gv.finalize(gids, gn, gnew))
+    for k in (7, 8):
+        f = frames[k]
+        ov.integrate_frame(f[0], f[1], f[3])
+        gv.integrate_frame_host(f[0], f[1], f[3].reshape(12), None, 0)
+    oids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(oids, sorted_ids(gv.list_chunks()))
+    assert_chunks_equal(ov, gv, oids[::9], "host frames behind a call-by-call frame")
+    gv.close()
