@@ -248,6 +248,13 @@ TF_API int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out);
  *   GenerateMeshEfficient (:595-1002, gradient normals :277-455) on the device; meshes stay in HBM
  *   (ChunkManager::allMeshes).  *n_meshed = size of the dirty set handed to the mesher. */
 TF_API int tf_update_meshes(tf_volume* v, int64_t* n_meshed);
+/* Diagnostic of the filter ahead of the mesher.  The library keeps per chunk a 16-bit summary of the classes
+ *   (observed / positive / negative / weight > 50, i.e. what GenerateMeshEfficient's per-cell tests at
+ *   ChunkManager.cpp:669-722 and :776-777 ask for) that occur among its voxels and on its three low faces; a chunk
+ *   whose summaries rule out a vertex is not read at all.  A summary must be a superset of the truth: *n_missing =
+ *   chunks whose voxels hold a class the summary lacks (must be 0), *n_stale = chunks whose summary holds a class the
+ *   voxels no longer do (allowed: costs time, never changes a result).  Any output may be NULL. */
+TF_API int tf_check_summaries(tf_volume* v, int64_t* n_chunks, int64_t* n_missing, int64_t* n_stale);
 /* keys of ChunkManager::GetAllMeshes() (Structure/ChunkManager.h:714) */
 TF_API int tf_list_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n);
 /* Mesh::vertices.size() / indices.size() / adj[6] / simplified of listed chunks (Mesh.h:70-85);

@@ -27,3 +27,28 @@ def gpu_required():
     if n <= 0:
         pytest.fail("no HIP device visible: gpu-marked tests need the MI355X (there is no CPU fallback)")
     return n
+
+
+@pytest.fixture(autouse=True)
+def _summaries_cover_the_voxels(request, monkeypatch):
+    """Every GPU test doubles as a check of the filter summaries the voxel writers maintain (tf_check_summaries): when
+    a test closes a volume, no chunk's summary may lack a class its voxels hold."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from texturefusion_amd import capi
+    real_close = capi.Volume.close
+    seen = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            try:
+                seen.append(self.check_summaries())
+            except capi.TFError:
+                pass  # a handle a test has deliberately left in an error state
+        real_close(self)
+
+    monkeypatch.setattr(capi.Volume, "close", close)
+    yield
+    for n, missing, stale in seen:
+        assert missing == 0, "filter summaries lack classes in %d of %d chunks" % (missing, n)

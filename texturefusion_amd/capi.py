@@ -44,7 +44,7 @@ SYMBOLS = (
     "tf_host_frame_buffers", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block",
     "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
     "tf_comm_exchange_every_frame",
-    "tf_update_meshes", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
+    "tf_update_meshes", "tf_check_summaries", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
     "tf_pre_normal_map", "tf_pre_refine_depth_normal", "tf_pre_color_valid", "tf_pre_color_quality",
     "tf_pre_refine_newframe", "tf_pre_refine_keyframe", "tf_integrate_depth_group", "tf_integrate_depth_group_host",
 )
@@ -172,6 +172,7 @@ def lib():
     u32p = C.POINTER(C.c_uint32)
     L.tf_update_meshes.argtypes = [vp, i64p]
     L.tf_list_meshes.argtypes = [vp, i32p, C.c_int64, i64p]
+    L.tf_check_summaries.argtypes = [vp, i64p, i64p, i64p]
     L.tf_mesh_counts.argtypes = [vp, i32p, C.c_int64, i32p, i32p, u8p, u8p]
     L.tf_meshes_download.argtypes = [vp, i32p, C.c_int64, i64p, i64p, fp, fp, fp, u32p]
     L.tf_compress_meshes.argtypes = [vp, i32p, C.c_int64, i64p]
@@ -413,6 +414,12 @@ class Volume:
 
     def list_meshes(self):
         return self._list(self.L.tf_list_meshes)
+
+    def check_summaries(self):
+        """-> (alive chunks, chunks whose filter summary lacks a class their voxels hold, chunks with a stale class)"""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self._ck(self.L.tf_check_summaries(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def mesh_counts(self, ids):
         """-> (n_vertices i32[n], n_indices i32[n], adj u8[n,6], simplified u8[n])"""

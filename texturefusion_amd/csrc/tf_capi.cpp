@@ -299,6 +299,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   if ((rc = dev_alloc(v, &d.tsdf, (size_t)d.max_chunks * kChunkVoxels))) return fail(rc);
   if ((rc = dev_alloc(v, &d.color, (size_t)d.max_chunks * kChunkVoxels))) return fail(rc);
   if ((rc = dev_alloc(v, &d.hent, hcap))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.summ, (size_t)d.max_chunks))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mark_epoch, (size_t)d.max_chunks * 2))) return fail(rc);  // mark | erase, one allocation
   d.erase_epoch = d.mark_epoch + d.max_chunks;
   if ((rc = dev_alloc(v, &d.phase_buf, (size_t)kPhaseWaves * 16))) return fail(rc);

@@ -104,6 +104,24 @@ __device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, b
   return kInvalidSlot;
 }
 
+// class of one voxel for the mesher's filter (ChunkManager.cpp:669-722, :776-777): observed (sdf <= 1), observed and
+// positive, negative, weight above the vertex threshold
+__device__ __forceinline__ uint32_t classify_voxel(const float sdf, const float w) {
+  const bool ok = !(sdf > 1.0f);
+  return (ok ? 1u : 0u) | ((ok && sdf > 0.0f) ? 2u : 0u) | ((sdf < 0.0f) ? 4u : 0u) | ((w > 50.0f) ? 8u : 0u);
+}
+// VolumeDev::summ contribution of the voxel with in-chunk index k = x + 8 y + 64 z
+__device__ __forceinline__ uint32_t chunk_summary_bits(const float sdf, const float w, uint32_t k) {
+  const uint32_t c = classify_voxel(sdf, w);
+  return c | ((k & 7u) ? 0u : c << 4) | ((k & 56u) ? 0u : c << 8) | ((k & 448u) ? 0u : c << 12);
+}
+__device__ __forceinline__ uint32_t wave_or(uint32_t x) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x |= (uint32_t)__shfl_xor((int)x, o);
+  return x;
+}
+
+
 // id and its six face neighbours (Chisel.h:197-203): k = 0 self, 1 -x, 2 +x, 3 -y, 4 +y, 5 -z, 6 +z
 __device__ __forceinline__ int4 nbr7(const int4 c, int k) {
   int4 r = c;

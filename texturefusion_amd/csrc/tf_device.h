@@ -177,6 +177,12 @@ struct VolumeDev {
   // Chisel.h:197-203 is expanded when the set is read (k_list_dirty), not on the per-frame path.
   uint32_t* mark_epoch;   // [max_chunks]
   uint32_t* erase_epoch;  // [max_chunks]
+  // Per pool slot a conservative summary of the chunk's voxels for the mesher's filter (chunk_summary_bits in
+  // tf_devfn.h): bits 0-3 = {some sdf <= 1, some 0 < sdf <= 1, some sdf < 0, some weight > 50} over the whole chunk,
+  // bits 4-7 / 8-11 / 12-15 the same over its x = 0 / y = 0 / z = 0 face.  Every voxel writer ORs the class of what
+  // it writes in, so a bit may outlive the voxel that set it (never the other way round); k_mesh_filter rewrites
+  // the word exactly whenever it reads the chunk's voxels.
+  uint32_t* summ;         // [max_chunks]
   unsigned long long* phase_buf;  // [kPhaseWaves][16] tuning aid: per-wave {start, end, role, XCC} stamps (TF_KA_DBG bit 12)
   uint32_t max_list;
   uint32_t max_coarse;

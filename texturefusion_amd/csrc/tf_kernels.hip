@@ -125,7 +125,7 @@ void launch_reset_ctl(const VolumeDev& v, bool volume_too, hipStream_t s) {
 }
 
 // fresh chunk state: sdf 999, weight 0 (Chunk.cpp:64-65), colour 0 (ColorVoxel.cpp:26-33)
-__global__ __launch_bounds__(256) void k_fill_pool(float2* tsdf, ushort4* color, size_t first,
+__global__ __launch_bounds__(256) void k_fill_pool(float2* tsdf, ushort4* color, uint32_t* summ, size_t first,
                                                    size_t count) {
   const float4 f = make_float4(999.0f, 0.0f, 999.0f, 0.0f);
   const uint4 z = make_uint4(0, 0, 0, 0);
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void k_fill_pool(float2* tsdf, ushort4* color,
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     t4[i] = f;
     c4[i] = z;
+    if (i < count / kChunkVoxels) summ[first / kChunkVoxels + i] = 0u;  // nothing observed (VolumeDev::summ)
   }
 }
 void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipStream_t s) {
@@ -142,7 +143,7 @@ void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipSt
   size_t first = (size_t)slot0 * kChunkVoxels, count = (size_t)nslots * kChunkVoxels;
   size_t blocks = (count / 2 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_fill_pool, dim3((unsigned)blocks), dim3(256), 0, s, v.tsdf, v.color, first, count);
+  hipLaunchKernelGGL(k_fill_pool, dim3((unsigned)blocks), dim3(256), 0, s, v.tsdf, v.color, v.summ, first, count);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -876,6 +877,9 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 
     float qsum = 0.0f;
     uint32_t lanes_t = 0, lanes_c = 0;  // lanes of rewritten rows (8 per row), wave-uniform
+    // classes of the voxels written (VolumeDev::summ), reduced row by row into ONE scalar word: the kernel has no
+    // VGPR to spare for per-lane classes and no SGPRs for four lane masks
+    uint32_t sword = 0;
 
 #pragma unroll
     for (int p = 0; p < 8 / GP; ++p) {
@@ -968,6 +972,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           const bool keep = nwt > 0.5f;
           t[j].x = __float_as_uint(keep ? ns : 999.0f);
           t[j].y = __float_as_uint(keep ? nwt : 0.0f);
+          // (a row that is not rewritten was loaded as zeros and comes out as {999, 0}: class 0)
         }
       }
       // ---- phase 5b: write back the rewritten rows only (masked offsets drop the store)
@@ -976,6 +981,20 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         for (int j = 0; j < GP; ++j) {
           if (COLOR) __builtin_amdgcn_raw_buffer_store_b64(c[j], rs_C, off_c[j], 0, 0);
           __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, off_t[j], 0, 0);
+          {  // lane = x + 8 y of row z = g0 + j
+            const float fs = __uint_as_float(t[j].x), fw = __uint_as_float(t[j].y);
+            unsigned long long bm[4];
+            bm[0] = ballot(!(fs > 1.0f));
+            bm[1] = ballot(fs > 0.0f) & bm[0];
+            bm[2] = ballot(fs < 0.0f);
+            bm[3] = ballot(fw > 50.0f);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              const uint32_t f = (bm[b] ? 1u : 0u) | ((bm[b] & 0x0101010101010101ull) ? 0x10u : 0u) | ((bm[b] & 0xFFull) ? 0x100u : 0u) |
+                                 ((g0 + j == 0 && bm[b]) ? 0x1000u : 0u);
+              sword |= f << b;
+            }
+          }
         }
       }
       // ---- phase 6: observationQualitySum bookkeeping in row order (:212-238)
@@ -1004,6 +1023,9 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     }
     const uint32_t rows_t = lanes_t >> 3, rows_c = COLOR ? (lanes_c >> 3) : 0u;
     const bool updated = rows_t != 0;
+    if (updated) {  // the classes of what was written join the chunk's summary: lane = x + 8 y of a row
+      if (lane == 0 && sword) atomicOr(&v.summ[slot], sword);
+    }
     if ((kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves) {  // timeline aid: work of this wave
       v.phase_buf[wave * 16 + 8] += 1;                 // chunks
       v.phase_buf[wave * 16 + 9] += rows_t + rows_c;   // rows rewritten
@@ -1211,9 +1233,15 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
         }
       }
     }
+    uint32_t word = 0;  // VolumeDev::summ: classes of the rewritten rows' final values
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, ((dirty_rows >> j) & 1u) ? (j * 64 + lane) * 8 : kOOB, 0, 0);
+    for (int j = 0; j < 8; ++j) {
+      const bool wr = ((dirty_rows >> j) & 1u) != 0;
+      __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, wr ? (j * 64 + lane) * 8 : kOOB, 0, 0);
+      if (wr) word |= chunk_summary_bits(__uint_as_float(t[j].x), __uint_as_float(t[j].y), (uint32_t)(j * 64 + lane));
+    }
+    word = wave_or(word);
+    if (lane == 0 && word) atomicOr(&v.summ[slot], word);
     const bool updated = rows_total != 0;
     if (updated && lane == 0) {
       L.list_needs[e] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
@@ -1619,7 +1647,11 @@ __global__ __launch_bounds__(512) void k_scatter_chunk(VolumeDev v, int4 id, con
   const uint32_t slot = sslot;
   if (slot == kInvalidSlot) return;
   const uint32_t k = threadIdx.x;
-  if (sdf && w) v.tsdf[(size_t)slot * kChunkVoxels + k] = make_float2(sdf[k], w[k]);
+  if (sdf && w) {
+    v.tsdf[(size_t)slot * kChunkVoxels + k] = make_float2(sdf[k], w[k]);
+    const uint32_t word = wave_or(chunk_summary_bits(sdf[k], w[k], (uint32_t)k));
+    if ((threadIdx.x & 63) == 0 && word) atomicOr(&v.summ[slot], word);
+  }
   if (col) v.color[(size_t)slot * kChunkVoxels + k] = reinterpret_cast<const ushort4*>(col)[k];
 }
 void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const float* w,
@@ -1695,8 +1727,11 @@ __global__ __launch_bounds__(512) void k_boundary_unpack(VolumeDev v, const uint
     __syncthreads();
     const uint32_t slot = sslot;
     if (slot != kInvalidSlot) {
-      v.tsdf[(size_t)slot * kChunkVoxels + threadIdx.x] = reinterpret_cast<const float2*>(rec + 16)[threadIdx.x];
+      const float2 tv = reinterpret_cast<const float2*>(rec + 16)[threadIdx.x];
+      v.tsdf[(size_t)slot * kChunkVoxels + threadIdx.x] = tv;
       v.color[(size_t)slot * kChunkVoxels + threadIdx.x] = reinterpret_cast<const ushort4*>(rec + 16 + 4096)[threadIdx.x];
+      const uint32_t word = wave_or(chunk_summary_bits(tv.x, tv.y, threadIdx.x));
+      if ((threadIdx.x & 63) == 0 && word) atomicOr(&v.summ[slot], word);
     }
     __syncthreads();
   }
@@ -1736,8 +1771,11 @@ __global__ __launch_bounds__(512) void k_boundary_unpack_blocks(VolumeDev v, con
       __syncthreads();
       const uint32_t slot = sslot;
       if (slot != kInvalidSlot) {
-        v.tsdf[(size_t)slot * kChunkVoxels + threadIdx.x] = reinterpret_cast<const float2*>(rec + 16)[threadIdx.x];
+        const float2 tv = reinterpret_cast<const float2*>(rec + 16)[threadIdx.x];
+        v.tsdf[(size_t)slot * kChunkVoxels + threadIdx.x] = tv;
         v.color[(size_t)slot * kChunkVoxels + threadIdx.x] = reinterpret_cast<const ushort4*>(rec + 16 + 4096)[threadIdx.x];
+        const uint32_t word = wave_or(chunk_summary_bits(tv.x, tv.y, threadIdx.x));
+        if ((threadIdx.x & 63) == 0 && word) atomicOr(&v.summ[slot], word);
       }
       if (dirty_par >= 0 && threadIdx.x >= 1 && threadIdx.x <= 6) {
         int4 q = nbr7(id, (int)threadIdx.x);

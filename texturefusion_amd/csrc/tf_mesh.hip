@@ -159,10 +159,6 @@ __device__ __forceinline__ int owner_cell(int m, int q) {
 // survivors are flagged for k_mesh: surv[32 * entry + 0..26] = pool slots of the survivor's 27-chunk
 // neighbourhood (13 = the chunk itself), surv[32 * entry + 13] = kInvalidSlot for everything else.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t classify_voxel(const float sdf, const float w) {
-  const bool ok = !(sdf > 1.0f);
-  return (ok ? 1u : 0u) | ((ok && sdf > 0.0f) ? 2u : 0u) | ((sdf < 0.0f) ? 4u : 0u) | ((w > 50.0f) ? 8u : 0u);
-}
 // fused flow: a dirty chunk that owns a mesh (ChunkManager::HasMesh) goes to the patch list of its shard; one
 // without an atlas slot is also a slot candidate (Atlas::AddPatch will be called for it, in ascending id order).
 // Called by ONE thread per chunk.
@@ -182,7 +178,8 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
-                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool xcd_contig) {
+                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool xcd_contig,
+                                                     bool use_summ) {
   const int lane = threadIdx.x & 63;
   const uint32_t nwaves = gridDim.x * 4;
   // wave w takes entries w, w + nwaves, ...
@@ -211,19 +208,37 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
     }
     const uint32_t own = (uint32_t)__shfl((int)nslot, 13);
     if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
+    // First the summaries (VolumeDev::summ, 4 B per chunk): the classes that may occur among the chunk's voxels and
+    // on the faces the +x / +y / +z neighbours contribute (an edge or the corner counts as the whole face it lies
+    // in).  They are supersets, so a chunk they rule out is ruled out for good without touching its 4 KiB; the
+    // others go through the exact test below, which also rewrites the chunk's own summary exactly.
+    bool maybe = true;
+    if (use_summ) {
+      uint32_t sm = 0;
+      if (lane < 27 && nslot != kInvalidSlot) sm = v.summ[nslot];
+      // neighbourhood index 13 + dx + 3 dy + 9 dz: +x 14, +y 16, +x+y 17, +z 22, +x+z 23, +y+z 25, +x+y+z 26
+      const uint32_t sel = (0x4824000u >> lane) & 1u ? 4u : ((0x2010000u >> lane) & 1u ? 8u : (lane == 22 ? 12u : (lane == 13 ? 0u : 32u)));
+      const uint32_t u = wave_or(sel < 32u ? ((sm >> sel) & 15u) : 0u);
+      const uint32_t so = (uint32_t)__shfl((int)sm, 13);
+      maybe = (so & 1u) && (u & 14u) == 14u;
+    }
     // rows and patch entries go to shard own % 32: pool slots are unique, so a shard never holds more than
     // max_chunks / 32 of them whatever the order of the work
     const uint32_t shard = own & (kMeshShards - 1u);
+    bool empty = true;
+    if (maybe) {
     const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
     uint32_t fl = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float4 q = T4[j * 64 + lane];  // two voxels {sdf, w, sdf, w}
-      fl |= classify_voxel(q.x, q.y) | classify_voxel(q.z, q.w);
+      const float4 q = T4[j * 64 + lane];  // voxels 2 i and 2 i + 1 of the chunk, i = 64 j + lane: {sdf, w, sdf, w}
+      const uint32_t c0 = classify_voxel(q.x, q.y), c1 = classify_voxel(q.z, q.w);
+      // x = 0: the first voxel of every fourth pair; y = 0: (i >> 2) & 7 == 0; z = 0: i < 32
+      fl |= c0 | c1 | ((lane & 3) ? 0u : c0 << 4) | ((lane & 28) ? 0u : (c0 | c1) << 8) | ((j || lane >= 32) ? 0u : (c0 | c1) << 12);
     }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) fl |= (uint32_t)__shfl_xor((int)fl, o);
-    bool empty = !(fl & 1u);
+    fl = wave_or(fl);
+    if (use_summ && lane == 0) v.summ[own] = fl;  // exact again
+    empty = !(fl & 1u);
     if (!empty && (fl & 14u) != 14u) {
       uint32_t f2 = 0;
 #pragma unroll
@@ -247,6 +262,7 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) f2 |= (uint32_t)__shfl_xor((int)f2, o);
       empty = ((fl | f2) & 14u) != 14u;
+    }
     }
     if (empty) {
       if (lane == 0) {  // Mesh::Clear + "stays in allMeshes if it was there" (:244-262)
@@ -601,6 +617,7 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   if (!max_entries) return;
   static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch
   static const bool xcd_contig = getenv("TF_FILTER_XCD") && atoi(getenv("TF_FILTER_XCD"));
+  static const bool use_summ = !(getenv("TF_FILTER_SUMM") && !atoi(getenv("TF_FILTER_SUMM")));  // A/B knob, default on
   uint32_t* surv = v.mesh_nbr;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
   uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshShards * 16;
@@ -608,7 +625,7 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   if (max_entries > v.max_chunks) max_entries = v.max_chunks;
   const uint32_t fgrid = (max_entries + 3) / 4 < 2048u ? (max_entries + 3) / 4 : 2048u;
   hipLaunchKernelGGL(k_mesh_filter, dim3(fgrid), dim3(256), 0, s, v, dlist, fused ? v.work_slot : nullptr, dcount,
-                     max_entries, epoch, surv, cnt, cap_sh, fused ? (rearm_set ^ 1) : -1, xcd_contig);
+                     max_entries, epoch, surv, cnt, cap_sh, fused ? (rearm_set ^ 1) : -1, xcd_contig, use_summ);
   // the survivors form dense per-shard lists: a grid of a few resident rounds, each workgroup striding its shard
   // (TF_MESH_GRID overrides; rounded to a multiple of the shard count)
   static const uint32_t gmax = getenv("TF_MESH_GRID") ? (uint32_t)atoi(getenv("TF_MESH_GRID")) : 4096u;
@@ -821,6 +838,28 @@ static int dirty_list_device(tf_volume* v, uint32_t* n_out) {
   return TF_OK;
 }
 
+// diagnostic (tf_check_summaries): every alive chunk's VolumeDev::summ against the classes of its voxels
+__global__ __launch_bounds__(256) void k_check_summaries(VolumeDev v, unsigned long long* out) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * 4;
+  for (uint32_t e = (blockIdx.x * 256 + threadIdx.x) >> 6; e <= v.hmask; e += nwaves) {
+    const HEntry h = v.hent[e];
+    if (h.slot == kInvalidSlot || !(h.alive & 1u)) continue;
+    uint32_t w = 0;
+    for (int j = 0; j < 8; ++j) {
+      const float2 t = v.tsdf[(size_t)h.slot * kChunkVoxels + j * 64 + lane];
+      w |= chunk_summary_bits(t.x, t.y, (uint32_t)(j * 64 + lane));
+    }
+    w = wave_or(w);
+    const uint32_t have = v.summ[h.slot];
+    if (lane == 0) {
+      atomicAdd(&out[0], 1ull);
+      if (w & ~have) atomicAdd(&out[1], 1ull);
+      if (have & ~w) atomicAdd(&out[2], 1ull);
+    }
+  }
+}
+
 }  // namespace tf
 
 using namespace tf;
@@ -996,6 +1035,23 @@ int tf_compress_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n_o
   rc = tf_clear_dirty(v);  // chunksToUpdate.clear() (Chisel.cpp:146)
   if (rc) return rc;
   if (out_ids && m > cap) { set_error("output capacity too small"); return TF_ERR_CAPACITY; }
+  return TF_OK;
+}
+
+int tf_check_summaries(tf_volume* v, int64_t* n_chunks, int64_t* n_missing, int64_t* n_stale) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  int rc = ensure_tmp(v, 32);
+  if (rc) return rc;
+  TF_HIP(hipMemsetAsync(v->d_tmp, 0, 32, v->stream));
+  hipLaunchKernelGGL(k_check_summaries, dim3(1024), dim3(256), 0, v->stream, v->dev, reinterpret_cast<unsigned long long*>(v->d_tmp));
+  TF_HIP(hipGetLastError());
+  unsigned long long h[3] = {0, 0, 0};
+  TF_HIP(hipMemcpyAsync(h, v->d_tmp, sizeof(h), hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  if (n_chunks) *n_chunks = (int64_t)h[0];
+  if (n_missing) *n_missing = (int64_t)h[1];
+  if (n_stale) *n_stale = (int64_t)h[2];
   return TF_OK;
 }
 
