@@ -408,6 +408,7 @@ TF_API int tf_atlas_download_rows(tf_volume* v, int64_t row0, int64_t row1, uint
  * untruncated intrinsics given to tf_set_camera (the reference passes camera.c_fx ...).  Asynchronous on the
  * handle's stream except tf_pre_refine_keyframe.  Pixels the reference leaves uninitialised are written as 0;
  * _mm256_rsqrt_ps is the correctly rounded 1 / sqrt (see oracle/tf_oracle.c).
+ *   tf_pre_frame_depth           DatasetWrapper::framePreprocess     Tools/DatasetWrapper.hpp:186-263 (see below)
  *   tf_pre_normal_map            BasicAPI::extractNormalMapSIMD      BasicAPI.cpp:849-905
  *   tf_pre_refine_depth_normal   BasicAPI::refineDepthUseNormalSIMD  BasicAPI.cpp:728-781   (normal, depth in place)
  *   tf_pre_color_valid           BasicAPI::checkColorQuality         BasicAPI.cpp:783-806   (Frame::colorValidFlag)
@@ -417,6 +418,15 @@ TF_API int tf_atlas_download_rows(tf_volume* v, int64_t row0, int64_t row1, uint
  *   tf_pre_refine_keyframe       BasicAPI::refineKeyframesSIMD       BasicAPI.cpp:506-636   (depth_ref, weight_ref in
  *                                place with the reference's sequential in-place semantics; T = f32 of
  *                                (pose_new^-1 * pose_ref).matrix()[3x4]; synchronises; *rounds = passes it took) */
+/* DatasetWrapper::framePreprocess (Tools/DatasetWrapper.hpp:186-263, the loader's depth pass ahead of all of the
+ *   above): raw u16 depth (device, updated in place like Frame::depth) -> readings above maximum_depth * depth_scale
+ *   dropped -> metres -> cv::bilateralFilter(refined_depth, ., d = 9 (7 on MobileCPU builds), sigma_color = 0.03,
+ *   sigma_space = 10) -> d_refined (Frame::refined_depth, f32, may be NULL) and written back to the u16 map.  The
+ *   filter restates OpenCV's CV_32FC1 algorithm (4096-bin colour table over the image's own range, circular taps,
+ *   BORDER_REFLECT_101); tap sums run in tap order, which OpenCV's vector builds do not pin (oracle/tf_oracle.c).
+ *   Asynchronous on the handle's stream; d <= 15. */
+TF_API int tf_pre_frame_depth(tf_volume* v, uint16_t* d_depth, float* d_refined, float maximum_depth, float depth_scale,
+                              int d, double sigma_color, double sigma_space);
 TF_API int tf_pre_normal_map(tf_volume* v, const float* d_depth, float* d_normal);
 TF_API int tf_pre_refine_depth_normal(tf_volume* v, float* d_normal, float* d_depth);
 TF_API int tf_pre_color_valid(tf_volume* v, const float* d_normal, uint8_t* d_flag);

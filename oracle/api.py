@@ -105,6 +105,8 @@ def lib():
     L.tfo_pre_color_quality.argtypes = [fp, fp, u8p, C.c_int, C.c_int] + f4 + [fp]
     L.tfo_pre_refine_newframe.argtypes = [fp, fp, C.c_int, C.c_int] + f4 + [fp]
     L.tfo_pre_refine_keyframe.argtypes = [fp, fp, fp, C.c_int, C.c_int] + f4 + [fp]
+    L.tfo_pre_frame_depth.argtypes = [C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_double,
+                                      C.c_double, fp]
     L.tfo_get_sum_order.restype = C.c_int
     L.tfo_volume_num_chunks.restype = C.c_int64
     L.tfo_volume_num_chunks.argtypes = [vp]
@@ -666,3 +668,13 @@ def pre_refine_keyframe(depth_ref, weight_ref, depth_new, cam, T12):
     H, W = r.shape
     lib().tfo_pre_refine_keyframe(_p(r, C.c_float), _p(w, C.c_float), _p(d, C.c_float), W, H, *_k4(cam), _p(T, C.c_float))
     return r, w
+
+
+def pre_frame_depth(depth_u16, maximum_depth, depth_scale, d=9, sigma_color=0.03, sigma_space=10.0):
+    """DatasetWrapper::framePreprocess -> (depth u16 after the write-back, refined depth f32)"""
+    dz = np.ascontiguousarray(depth_u16, np.uint16).copy()
+    H, W = dz.shape
+    out = np.zeros((H, W), np.float32)
+    lib().tfo_pre_frame_depth(_p(dz, C.c_uint16), W, H, C.c_float(maximum_depth), C.c_float(depth_scale), int(d),
+                              C.c_double(sigma_color), C.c_double(sigma_space), _p(out, C.c_float))
+    return dz, out

@@ -7,6 +7,7 @@
  */
 #include "tf_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -2105,4 +2106,97 @@ void tfo_pre_refine_keyframe(float* depth_ref, float* weight_ref, const float* d
         weight_ref[(size_t)i * W + j0 + l] = outw[l];
       }
     }
+}
+
+/* DatasetWrapper::framePreprocess (Tools/DatasetWrapper.hpp:186-263 with UNDISTORTION / DEVIGNETTING off): the
+ * loader's depth pass.  raw u16 depth -> readings beyond maximum_depth dropped (:211-221) -> metres ->
+ * cv::bilateralFilter(refined_depth, filtered, 9 (7 on MobileCPU builds), 0.03, 10) (:223-233) -> written back to
+ * the u16 map (:249-252).
+ *
+ * cv::bilateralFilter is OpenCV (README.md:87 pins commit 8f1356c), absent from /root/reference: what follows
+ * restates the published CV_32FC1 algorithm of imgproc (bilateralFilter_32f + BilateralFilter_32f_Invoker):
+ *   radius = d / 2, taps (i, j) with sqrt(i^2 + j^2) <= radius in row-major order, space weight
+ *   (float)exp(r * r * -0.5 / sigma_space^2) in double; BORDER_REFLECT_101; the colour weight is a 4096-bin lookup
+ *   table of (float)exp(v * v * -0.5 / sigma_color^2), v = i / scale_index, scale_index = 4096 / (max - min) of
+ *   the image (both f32), read with linear interpolation at alpha = |val - val0| * scale_index;
+ *   out = sum(val * w) / sum(w), w = space * colour; an image with max - min < FLT_EPSILON is copied.
+ * PARITY UNPINNED at the rounding level: OpenCV's vector builds accumulate the tap sums in 4 / 8 partial lanes,
+ * this restatement (and the device kernel, bit for bit) in tap order; no reference test holds a filtered image.
+ * patchNaNs is skipped: a u16 reading cannot be NaN.  refined_out may be NULL. */
+void tfo_pre_frame_depth(uint16_t* depth, int W, int H, float maximum_depth, float depth_scale, int d,
+                         double sigma_color, double sigma_space, float* refined_out) {
+  const size_t np = (size_t)W * H;
+  float* src = (float*)malloc(np * sizeof(float));
+  float* dst = (float*)malloc(np * sizeof(float));
+  for (size_t p = 0; p < np; p++) {
+    if ((float)depth[p] > maximum_depth * depth_scale) depth[p] = 0;
+    src[p] = (float)depth[p] / depth_scale;
+  }
+  if (sigma_color <= 0) sigma_color = 1;
+  if (sigma_space <= 0) sigma_space = 1;
+  const double gauss_color_coeff = -0.5 / (sigma_color * sigma_color);
+  const double gauss_space_coeff = -0.5 / (sigma_space * sigma_space);
+  int radius = d <= 0 ? (int)lrint(sigma_space * 1.5) : d / 2;
+  if (radius < 1) radius = 1;
+  float mn = src[0], mx = src[0];
+  for (size_t p = 1; p < np; p++) {
+    if (src[p] < mn) mn = src[p];
+    if (src[p] > mx) mx = src[p];
+  }
+  if (fabs((double)mn - (double)mx) < FLT_EPSILON) {
+    memcpy(dst, src, np * sizeof(float));
+  } else {
+    enum { kBins = 1 << 12 };
+    float* lut = (float*)malloc((kBins + 2) * sizeof(float));
+    const float len = (float)((double)mx - (double)mn);
+    const float scale_index = (float)kBins / len;
+    float last = 1.0f;
+    for (int i = 0; i < kBins + 2; i++) {
+      if (last > 0.0f) {
+        const double val = (double)((float)i / scale_index);
+        lut[i] = (float)exp(val * val * gauss_color_coeff);
+        last = lut[i];
+      } else {
+        lut[i] = 0.0f;
+      }
+    }
+    const int dd = 2 * radius + 1;
+    float* sw = (float*)malloc((size_t)dd * dd * sizeof(float));
+    int* oi = (int*)malloc((size_t)dd * dd * sizeof(int));
+    int* oj = (int*)malloc((size_t)dd * dd * sizeof(int));
+    int maxk = 0;
+    for (int i = -radius; i <= radius; i++)
+      for (int j = -radius; j <= radius; j++) {
+        const double r = sqrt((double)i * i + (double)j * j);
+        if (r > radius) continue;
+        sw[maxk] = (float)exp(r * r * gauss_space_coeff);
+        oi[maxk] = i; oj[maxk] = j;
+        maxk++;
+      }
+    for (int y = 0; y < H; y++)
+      for (int x = 0; x < W; x++) {
+        const float val0 = src[(size_t)y * W + x];
+        float sum = 0.0f, wsum = 0.0f;
+        for (int k = 0; k < maxk; k++) {
+          int yy = y + oi[k], xx = x + oj[k];
+          /* BORDER_REFLECT_101: gfedcb|abcdefgh|gfedcba */
+          if (H == 1) yy = 0; else { while (yy < 0 || yy >= H) yy = yy < 0 ? -yy : 2 * (H - 1) - yy; }
+          if (W == 1) xx = 0; else { while (xx < 0 || xx >= W) xx = xx < 0 ? -xx : 2 * (W - 1) - xx; }
+          const float val = src[(size_t)yy * W + xx];
+          float alpha = fabsf(val - val0) * scale_index;
+          int idx = (int)floorf(alpha);
+          alpha -= (float)idx;
+          const float w = sw[k] * (lut[idx] + alpha * (lut[idx + 1] - lut[idx]));
+          sum += val * w;
+          wsum += w;
+        }
+        dst[(size_t)y * W + x] = sum / wsum;
+      }
+    free(lut); free(sw); free(oi); free(oj);
+  }
+  for (size_t p = 0; p < np; p++) {
+    depth[p] = (uint16_t)(dst[p] * depth_scale); /* float -> unsigned short (:250-251) */
+    if (refined_out) refined_out[p] = dst[p];
+  }
+  free(src); free(dst);
 }

@@ -241,6 +241,8 @@ void tfo_pre_refine_newframe(const float* depth_ref, float* depth_new, int W, in
                              float cy, const float T[12]);
 void tfo_pre_refine_keyframe(float* depth_ref, float* weight_ref, const float* depth_new, int W, int H, float fx,
                              float fy, float cx, float cy, const float T[12]);
+void tfo_pre_frame_depth(uint16_t* depth, int W, int H, float maximum_depth, float depth_scale, int d,
+                         double sigma_color, double sigma_space, float* refined_out);
 
 #ifdef __cplusplus
 }

@@ -100,3 +100,41 @@ def test_in_place_dependency_chain(gpu_required):
     for b in (bd, bw, bn):
         b.free()
     gv.close()
+
+
+def _raw_depth(cam, k, depth_scale=1000.0):
+    """a room frame as the sensor delivers it: u16 millimetres with holes, noise and a few readings beyond the cut"""
+    d = synth.room_frame(k, cam, with_quality=False)[0]
+    rng = np.random.default_rng(100 + k)
+    z = d * depth_scale + rng.normal(0.0, 3.0, d.shape) * (d > 0)
+    z[rng.random(d.shape) < 0.001] = 9000.0
+    return np.clip(z, 0, 65535).astype(np.uint16)
+
+
+@pytest.mark.parametrize("size,d", [((640, 480), 9), ((640, 480), 7), ((160, 120), 9), ((40, 29), 5)])
+def test_loader_depth_pass_matches_the_oracle(gpu_required, size, d):
+    """DatasetWrapper::framePreprocess: maximum-depth cut, metres, cv::bilateralFilter, write-back -- bit for bit"""
+    w, h = size
+    cam = synth.Camera() if w == 640 else synth.Camera(width=w, height=h, fx=131.25 * w / 160, fy=131.25 * w / 160,
+                                                        cx=w / 2 - 0.5, cy=h / 2 - 0.5)
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 10, max_list=1 << 10, max_coarse=1 << 12)
+    z = _raw_depth(cam, 3)
+    z_o, r_o = O.pre_frame_depth(z, 4.0, 1000.0, d)
+    bz, br = _dev(z), HipBuffer(r_o.nbytes)
+    gv.pre_frame_depth(bz.ptr, br.ptr, 4.0, 1000.0, d)
+    gv.sync()
+    assert np.array_equal(_bits(_get(br, np.float32, r_o.shape)), _bits(r_o))
+    assert np.array_equal(_get(bz, np.uint16, z.shape), z_o)
+    assert (z_o != z).mean() > 0.5 and z_o.max() <= 4000
+    # a constant image is copied (max - min < FLT_EPSILON), and so is an empty one
+    for const in (1234, 0):
+        zc = np.full(z.shape, const, np.uint16)
+        zc_o, rc_o = O.pre_frame_depth(zc, 4.0, 1000.0, d)
+        bz.from_host(zc)
+        gv.pre_frame_depth(bz.ptr, br.ptr, 4.0, 1000.0, d)
+        gv.sync()
+        assert np.array_equal(_bits(_get(br, np.float32, r_o.shape)), _bits(rc_o))
+        assert np.array_equal(_get(bz, np.uint16, z.shape), zc_o)
+    for b in (bz, br):
+        b.free()
+    gv.close()

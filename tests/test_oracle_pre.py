@@ -153,3 +153,37 @@ def in_place_chain_case(cam):
     T[1, 3] = np.float32(-3.2 / cam.fy)  # at depth 1 the projection lands 3.2 rows up
     r, w2 = O.pre_refine_keyframe(d, w, new, cam, T)
     return r, w2, (d, w, new, T)
+
+
+def test_loader_depth_pass_follows_the_published_bilateral_filter():
+    """tfo_pre_frame_depth against the defining formula of the bilateral filter (Gaussian in space over the circular
+    window, Gaussian in value, reflect-101 border) evaluated directly in f64: the restatement's 4096-bin table with
+    linear interpolation stays within 2e-6 of it; the cut, the units and the u16 write-back are exact."""
+    rng = np.random.default_rng(5)
+    H, W = 48, 64
+    z = (1500 + 300 * np.sin(np.arange(W) / 9.0)[None, :] + 400 * (np.arange(H)[:, None] > 24) + rng.normal(0, 4, (H, W)))
+    z = z.astype(np.uint16)
+    z[5:9, 5:9] = 0
+    z[20, 30] = 9000
+    for d in (9, 7):
+        zo, ref = O.pre_frame_depth(z, 4.0, 1000.0, d)
+        src = np.where(z.astype(np.float32) > np.float32(4.0) * np.float32(1000.0), 0, z).astype(np.float32) / np.float32(1000.0)
+        r = d // 2
+        pad = np.pad(src.astype(np.float64), r, mode="reflect")
+        num, den = np.zeros((H, W)), np.zeros((H, W))
+        for i in range(-r, r + 1):
+            for j in range(-r, r + 1):
+                if i * i + j * j > r * r:
+                    continue
+                v = pad[r + i:r + i + H, r + j:r + j + W]
+                wgt = np.exp(-0.5 * (i * i + j * j) / 10.0 ** 2) * np.exp(-0.5 * (v - src) ** 2 / 0.03 ** 2)
+                num += v * wgt
+                den += wgt
+        assert np.abs(ref - num / den).max() < 2e-6
+        assert np.array_equal(zo, (ref * np.float32(1000.0)).astype(np.uint16))
+        assert ref[6, 6] == 0.0 and zo[20, 30] < 4000  # a hole among holes stays a hole; the far reading was cut
+    # constant and empty images are copied
+    for const in (0, 777):
+        zc = np.full((H, W), const, np.uint16)
+        zo, ref = O.pre_frame_depth(zc, 4.0, 1000.0)
+        assert np.array_equal(ref, np.full((H, W), np.float32(const) / np.float32(1000.0)))

@@ -46,7 +46,7 @@ SYMBOLS = (
     "tf_comm_exchange_every_frame",
     "tf_update_meshes", "tf_check_summaries", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
     "tf_pre_normal_map", "tf_pre_refine_depth_normal", "tf_pre_color_valid", "tf_pre_color_quality",
-    "tf_pre_refine_newframe", "tf_pre_refine_keyframe", "tf_integrate_depth_group", "tf_integrate_depth_group_host",
+    "tf_pre_refine_newframe", "tf_pre_refine_keyframe", "tf_pre_frame_depth", "tf_integrate_depth_group", "tf_integrate_depth_group_host",
 )
 
 
@@ -166,6 +166,7 @@ def lib():
     L.tf_pre_color_valid.argtypes = [vp, vp, vp]
     L.tf_pre_color_quality.argtypes = [vp, vp, vp, vp, vp]
     L.tf_pre_refine_newframe.argtypes = [vp, vp, vp, C.POINTER(C.c_float)]
+    L.tf_pre_frame_depth.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_int, C.c_double, C.c_double]
     L.tf_pre_refine_keyframe.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.tf_comm_exchange_every_frame.argtypes = [vp, C.c_int64]
     L.tf_atlas_download_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p]
@@ -542,6 +543,11 @@ class Volume:
 
     def pre_color_quality(self, d_depth, d_normal, d_rgb, d_quality):
         self._ck(self.L.tf_pre_color_quality(self.h, d_depth, d_normal, d_rgb, d_quality))
+
+    def pre_frame_depth(self, d_depth_u16, d_refined, maximum_depth, depth_scale, d=9, sigma_color=0.03, sigma_space=10.0):
+        """DatasetWrapper::framePreprocess on a device u16 depth map (updated in place) -> d_refined f32 (may be 0)"""
+        self._ck(self.L.tf_pre_frame_depth(self.h, d_depth_u16, d_refined, maximum_depth, depth_scale, d, sigma_color,
+                                           sigma_space))
 
     def pre_refine_newframe(self, d_depth_ref, d_depth_new, T12):
         T = _f32(T12).reshape(12)

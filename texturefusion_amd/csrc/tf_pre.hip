@@ -201,6 +201,104 @@ __global__ __launch_bounds__(256) void k_pre_refine_keyframe(const float* __rest
   if (__builtin_amdgcn_ballot_w64(any) != 0ull && (threadIdx.x & 63) == 0) atomicOr(changed, 1u);
 }
 
+// ---- DatasetWrapper::framePreprocess (Tools/DatasetWrapper.hpp:186-263): the loader's depth pass.  Three launches on
+// the handle's stream, nothing returns to the host: (1) u16 -> metres with the maximum-depth cut, and the image's
+// min / max (non-negative floats order like their bit patterns); (2) the 4096-bin colour table of cv::bilateralFilter's
+// CV_32FC1 path from that range; (3) the filter itself, one thread per pixel over a 16 x 16 tile staged in LDS with
+// its halo (BORDER_REFLECT_101), taps in row-major order, and the write-back to the u16 map.  See oracle/tf_oracle.c
+// (tfo_pre_frame_depth) for the restated OpenCV algorithm and what is unpinned about it.
+constexpr int kBfBins = 1 << 12;
+constexpr int kBfMaxRadius = 7;
+constexpr int kBfTile = 16;
+struct BfTaps {
+  int radius, maxk;
+  float weight[(2 * kBfMaxRadius + 1) * (2 * kBfMaxRadius + 1)];
+  int8_t di[(2 * kBfMaxRadius + 1) * (2 * kBfMaxRadius + 1)], dj[(2 * kBfMaxRadius + 1) * (2 * kBfMaxRadius + 1)];
+};
+struct BfState {  // device scratch header
+  uint32_t min_bits, max_bits;
+  float scale_index;
+  uint32_t copy;  // max - min < FLT_EPSILON: the filter is the identity
+};
+
+__global__ __launch_bounds__(256) void k_pre_depth_metres(uint16_t* __restrict__ depth, size_t np, float cut, float depth_scale,
+                                                          float* __restrict__ metres, BfState* st) {
+  uint32_t mn = 0x7F800000u, mx = 0u;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < np; p += (size_t)gridDim.x * 256) {
+    uint16_t z = depth[p];
+    if ((float)z > cut) { z = 0; depth[p] = 0; }
+    const float m = (float)z / depth_scale;
+    metres[p] = m;
+    const uint32_t b = __float_as_uint(m);
+    mn = b < mn ? b : mn;
+    mx = b > mx ? b : mx;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const uint32_t a = (uint32_t)__shfl_xor((int)mn, o), b = (uint32_t)__shfl_xor((int)mx, o);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&st->min_bits, mn); atomicMax(&st->max_bits, mx); }
+}
+
+__global__ __launch_bounds__(256) void k_pre_bilateral_table(BfState* st, float* __restrict__ lut, double gauss_color_coeff) {
+  const float mn = __uint_as_float(st->min_bits), mx = __uint_as_float(st->max_bits);
+  const bool copy = fabs((double)mn - (double)mx) < 1.1920928955078125e-7;  // FLT_EPSILON
+  const float len = (float)((double)mx - (double)mn);
+  const float scale_index = (float)kBfBins / len;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) { st->scale_index = scale_index; st->copy = copy ? 1u : 0u; }
+  if (copy || i >= kBfBins + 2) return;
+  // (the reference stops evaluating after the first entry that underflows to 0; exp is monotone, so every later
+  // entry evaluates to 0 as well)
+  const double val = (double)((float)i / scale_index);
+  lut[i] = (float)exp(val * val * gauss_color_coeff);
+}
+
+__device__ __forceinline__ int bf_reflect(int p, int n) {
+  if (n == 1) return 0;
+  while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+  return p;
+}
+
+__global__ __launch_bounds__(kBfTile * kBfTile) void k_pre_bilateral(const float* __restrict__ src, int W, int H, BfTaps taps,
+                                                                    const BfState* __restrict__ st,
+                                                                    const float* __restrict__ lut, float depth_scale,
+                                                                    float* __restrict__ refined, uint16_t* __restrict__ depth) {
+  constexpr int kSide = kBfTile + 2 * kBfMaxRadius;
+  __shared__ float tile[kSide * kSide];
+  const int R = taps.radius, side = kBfTile + 2 * R;
+  const int x0 = blockIdx.x * kBfTile, y0 = blockIdx.y * kBfTile;
+  for (int q = threadIdx.x; q < side * side; q += kBfTile * kBfTile) {
+    const int ty = q / side, tx = q - ty * side;
+    tile[ty * kSide + tx] = src[(size_t)bf_reflect(y0 + ty - R, H) * W + bf_reflect(x0 + tx - R, W)];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (kBfTile - 1), ly = threadIdx.x / kBfTile;
+  const int x = x0 + lx, y = y0 + ly;
+  if (x >= W || y >= H) return;
+  const float val0 = tile[(ly + R) * kSide + lx + R];
+  float out = val0;
+  if (!st->copy) {
+    const float scale_index = st->scale_index;
+    float sum = 0.0f, wsum = 0.0f;
+    for (int k = 0; k < taps.maxk; ++k) {
+      const float val = tile[(ly + R + taps.di[k]) * kSide + lx + R + taps.dj[k]];
+      float alpha = fabsf(val - val0) * scale_index;
+      const int idx = (int)floorf(alpha);
+      alpha -= (float)idx;
+      const float l0 = lut[idx], l1 = lut[idx + 1];
+      const float w = taps.weight[k] * (l0 + alpha * (l1 - l0));
+      sum += val * w;
+      wsum += w;
+    }
+    out = sum / wsum;
+  }
+  if (refined) refined[(size_t)y * W + x] = out;
+  depth[(size_t)y * W + x] = (uint16_t)(out * depth_scale);  // float -> unsigned short (:250-251)
+}
+
 static PreCam pre_cam(const tf_volume* v) {
   PreCam c;
   c.W = v->cam.W; c.H = v->cam.H;
@@ -305,6 +403,50 @@ int tf_pre_refine_keyframe(tf_volume* v, float* d_depth_ref, float* d_weight_ref
   TF_HIP(hipMemcpyAsync(d_depth_ref, in, bytes, hipMemcpyDeviceToDevice, v->stream));
   TF_HIP(hipMemcpyAsync(d_weight_ref, wout, bytes, hipMemcpyDeviceToDevice, v->stream));
   if (rounds) *rounds = k + 1;
+  return TF_OK;
+}
+
+int tf_pre_frame_depth(tf_volume* v, uint16_t* d_depth, float* d_refined, float maximum_depth, float depth_scale, int d,
+                       double sigma_color, double sigma_space) {
+  if (!v || !d_depth) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (!(depth_scale > 0.0f)) { set_error("depth_scale must be positive"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  const PreCam c = pre_cam(v);
+  if (sigma_color <= 0) sigma_color = 1;
+  if (sigma_space <= 0) sigma_space = 1;
+  int radius = d <= 0 ? (int)lrint(sigma_space * 1.5) : d / 2;
+  if (radius < 1) radius = 1;
+  if (radius > kBfMaxRadius) { set_error("bilateral filter: diameter above 15 is not supported"); return TF_ERR_INVALID; }
+  BfTaps taps;
+  memset(&taps, 0, sizeof(taps));
+  taps.radius = radius;
+  const double gauss_space_coeff = -0.5 / (sigma_space * sigma_space);
+  for (int i = -radius; i <= radius; ++i)
+    for (int j = -radius; j <= radius; ++j) {
+      const double r = sqrt((double)i * i + (double)j * j);
+      if (r > radius) continue;
+      taps.weight[taps.maxk] = (float)exp(r * r * gauss_space_coeff);
+      taps.di[taps.maxk] = (int8_t)i;
+      taps.dj[taps.maxk] = (int8_t)j;
+      ++taps.maxk;
+    }
+  const size_t np = (size_t)c.W * c.H;
+  const size_t lut_at = 64, img_at = lut_at + ((kBfBins + 2) * sizeof(float) + 63) / 64 * 64;
+  int rc = ensure_tmp(v, img_at + np * sizeof(float));
+  if (rc) return rc;
+  uint8_t* base = reinterpret_cast<uint8_t*>(v->d_tmp);
+  BfState* st = reinterpret_cast<BfState*>(base);
+  float* lut = reinterpret_cast<float*>(base + lut_at);
+  float* metres = reinterpret_cast<float*>(base + img_at);
+  const BfState init = {0x7F800000u, 0u, 0.0f, 0u};
+  TF_HIP(hipMemcpyAsync(st, &init, sizeof(init), hipMemcpyHostToDevice, v->stream));
+  hipLaunchKernelGGL(k_pre_depth_metres, pre_grid(c), dim3(256), 0, v->stream, d_depth, np, maximum_depth * depth_scale,
+                     depth_scale, metres, st);
+  hipLaunchKernelGGL(k_pre_bilateral_table, dim3((kBfBins + 2 + 255) / 256), dim3(256), 0, v->stream, st, lut,
+                     -0.5 / (sigma_color * sigma_color));
+  hipLaunchKernelGGL(k_pre_bilateral, dim3((c.W + kBfTile - 1) / kBfTile, (c.H + kBfTile - 1) / kBfTile), dim3(kBfTile * kBfTile),
+                     0, v->stream, metres, c.W, c.H, taps, st, lut, depth_scale, d_refined, d_depth);
+  TF_HIP(hipGetLastError());
   return TF_OK;
 }
 

@@ -873,4 +873,14 @@ inline void estimateColorQuality(chisel::Chisel& map, const float* depthMap, con
   chisel::tf_check(tf_pre_color_quality(map.Handle(), depthMap, normalMap, rgb, qualityMap), "estimateColorQuality");
 }
 
+// DatasetWrapper::framePreprocess (Tools/DatasetWrapper.hpp:186-263): depth = Frame::depth (u16, device, in place),
+// frame.refined_depth receives the filtered metres; bilateralFilterRange 9 (7 on MobileCPU builds), 0.03, 10 (:226-232).
+// (Frame::weight = 0 of :220 is the caller's hipMemsetAsync.)
+inline void framePreprocess(chisel::Chisel& map, unsigned short* depth, DeviceFrame& frame, float maximum_depth,
+                            float depth_scale, int bilateralFilterRange = 9) {
+  chisel::tf_check(tf_pre_frame_depth(map.Handle(), depth, frame.refined_depth, maximum_depth, depth_scale,
+                                      bilateralFilterRange, 0.03, 10.0),
+                   "framePreprocess");
+}
+
 }  // namespace BasicAPI
