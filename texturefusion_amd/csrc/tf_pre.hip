@@ -205,8 +205,8 @@ __global__ __launch_bounds__(256) void k_pre_refine_keyframe(const float* __rest
 // the handle's stream, nothing returns to the host: (1) u16 -> metres with the maximum-depth cut, and the image's
 // min / max (non-negative floats order like their bit patterns); (2) the 4096-bin colour table of cv::bilateralFilter's
 // CV_32FC1 path from that range; (3) the filter itself, one thread per pixel over a 16 x 16 tile staged in LDS with
-// its halo (BORDER_REFLECT_101), taps in row-major order, and the write-back to the u16 map.  See oracle/tf_oracle.c
-// (tfo_pre_frame_depth) for the restated OpenCV algorithm and what is unpinned about it.
+// its halo (BORDER_REFLECT_101), taps in row-major order, and the write-back to the u16 map.  DESIGN.md s.5 states
+// which OpenCV algorithm this restates and what is unpinned about it.
 constexpr int kBfBins = 1 << 12;
 constexpr int kBfMaxRadius = 7;
 constexpr int kBfTile = 16;
