@@ -444,14 +444,16 @@ def host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique):
     for j, i in enumerate(idx):
         f = frames[i]
         vol.integrate_frame_host(f[0], f[1], poses[i], pinv[i] if textured else None, first + j)
+    t1 = time.perf_counter()
     vol.sync()
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "frames": n,
-            "note": "tf_integrate_frame_host: host depth + RGBA in, staged through pinned memory and copied H2D (%.1f MB per "
-                    "frame) inside the timed region, one call per frame (no look-ahead: the two selection stages of a "
-                    "frame run as launches of their own), one synchronisation at the end.  The source frames are %d "
-                    "distinct host arrays (%.0f MB, not cache-resident): the single-threaded copy into the pinned slot "
-                    "is what bounds this rate on the host side"
+            "host_call_us": 1e6 * (t1 - t0) / n, "drain_ms": 1e3 * (dt - (t1 - t0)),
+            "note": "tf_integrate_frame_host: host depth + RGBA in, staged through pinned memory (helper threads share the "
+                    "copy) and copied H2D (%.1f MB per frame) inside the timed region, one call per frame, one "
+                    "synchronisation at the end.  The entry point runs two frames behind the caller so that a frame's "
+                    "voxel update shares its launch with the selection stages of the next two (any other entry point "
+                    "flushes first).  The source frames are %d distinct host arrays (%.0f MB, not cache-resident)"
                     % (8e-6 * frames[0][0].size, len(frames), 8e-6 * frames[0][0].size * len(frames))}
 
 

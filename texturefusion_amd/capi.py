@@ -195,7 +195,14 @@ def comm_unique_id():
 
 
 def _p(a, ty):
-    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+    """pointer to a numpy array's data.  Not ndarray.ctypes.data_as: that builds a reference cycle per call, and the
+    collections it triggers cost 30-60 us per pointer in a process with many live objects (e.g. after `import
+    torch`) -- more than the whole per-frame call."""
+    if a is None:
+        return None
+    ptr = C.cast(a.__array_interface__["data"][0], C.POINTER(ty))
+    ptr._keep = a  # the array outlives the pointer (plain reference, no cycle)
+    return ptr
 
 
 def _f32(a):

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <limits>
 
 #include "tf_host_math.h"
@@ -354,6 +355,11 @@ int tf_volume_destroy(tf_volume* v) {
     if (v->hslot[k].copied) hipEventDestroy(v->hslot[k].copied);
     if (v->hslot[k].freed) hipEventDestroy(v->hslot[k].freed);
   }
+  if (v->host_trace[5] > 0)
+    fprintf(stderr, "tf host frames: %.0f calls; per call us: wait kernels %.1f, wait upload %.1f, staging copy %.1f, "
+                    "upload enqueue %.1f, launches %.1f\n", v->host_trace[5], v->host_trace[0] / v->host_trace[5],
+            v->host_trace[1] / v->host_trace[5], v->host_trace[2] / v->host_trace[5], v->host_trace[3] / v->host_trace[5],
+            v->host_trace[4] / v->host_trace[5]);
   delete v->copy_pool;
   v->copy_pool = nullptr;
   if (v->copy_stream) hipStreamDestroy(v->copy_stream);
@@ -912,8 +918,19 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   v->hslot_next = (v->hslot_next + 1) % tf_volume::kHostRing;
   // the kernels that read this slot's device images (three frames ago) and the upload out of its pinned
   // buffer have finished
+  static const bool trace = getenv("TF_HOST_TRACE") && atoi(getenv("TF_HOST_TRACE"));  // per-phase host time, printed at destroy
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto lap = [&](int k, std::chrono::steady_clock::time_point& t) {
+    if (!trace) return;
+    const auto t1 = now();
+    v->host_trace[k] += std::chrono::duration<double, std::micro>(t1 - t).count();
+    t = t1;
+  };
+  auto t = now();
   TF_HIP(hipEventSynchronize(s.freed));
+  lap(0, t);
   TF_HIP(hipEventSynchronize(s.copied));
+  lap(1, t);
   float* hd = reinterpret_cast<float*>(s.h);
   uint8_t* hc = s.h + npix * 4;
   {  // frames composed in tf_host_frame_buffers' slot skip the staging copy
@@ -934,9 +951,11 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
       v->copy_pool->copy(dst, src, nb, nr);
     }
   }
+  lap(2, t);
   TF_HIP(hipMemcpyAsync(s.d, s.h, rgba ? npix * 8 : npix * 4, hipMemcpyHostToDevice, v->copy_stream));
   TF_HIP(hipEventRecord(s.copied, v->copy_stream));
   TF_HIP(hipStreamWaitEvent(v->stream, s.copied, 0));
+  lap(3, t);
   tf_volume::Pending cur;
   cur.d = reinterpret_cast<const float*>(s.d);
   cur.c = rgba ? s.d + npix * 4 : nullptr;
@@ -975,6 +994,8 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   v->n_pend = 2;
   if (rc) return rc;
   TF_HIP(hipEventRecord(v->hslot[p0.slot].freed, v->stream));
+  lap(4, t);
+  v->host_trace[5] += 1.0;
   return bind_frame(v, p0.d, p0.c);
 }
 

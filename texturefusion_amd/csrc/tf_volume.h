@@ -136,6 +136,7 @@ struct tf_volume {
   size_t hslot_pixels = 0;
   int hslot_next = 0;
   hipStream_t copy_stream = nullptr;
+  double host_trace[6] = {0, 0, 0, 0, 0, 0};  // TF_HOST_TRACE=1: microseconds per phase of tf_integrate_frame_host, [5] = calls
   tf::CopyPool* copy_pool = nullptr;  // helper threads of the staging copy (TF_COPY_THREADS, default 3)
   void* h_pinned = nullptr;      // pinned host staging (uploads / downloads)
   size_t h_pinned_bytes = 0;
