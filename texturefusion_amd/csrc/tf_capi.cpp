@@ -756,6 +756,7 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     st->img.quality = nullptr;
     memcpy(st->pose.p, poses12 + 12 * f, sizeof(st->pose.p));
     st->epoch = v->epoch + (uint32_t)f;
+    st->coarse_summ = tex == nullptr;  // a TSDF-only stream: K-A skips the class ballots (tf_device.h)
   };
   // how many leading frames already went through their selection stages in the previous call?
   int primed = 0;

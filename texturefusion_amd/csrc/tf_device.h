@@ -231,7 +231,11 @@ struct FrameStage {
   FrameImages img;
   Pose pose;
   uint32_t epoch;
+  bool coarse_summ = false;  // no mesher follows this frame: an updated chunk's summary becomes "anything" (kSummAny)
+                             // instead of the classes written; the filter makes it exact when it next reads the chunk
 };
+constexpr uint32_t kSummAny = 0xFFFFu;        // VolumeDev::summ: every class may occur
+constexpr uint32_t kKaCoarseSumm = 16384u;    // IntegrateConsts::dbg bit: FrameStage::coarse_summ
 
 // ---- launchers (tf_kernels.hip) ------------------------------------------------------
 void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* next,

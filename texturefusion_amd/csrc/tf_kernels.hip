@@ -981,7 +981,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         for (int j = 0; j < GP; ++j) {
           if (COLOR) __builtin_amdgcn_raw_buffer_store_b64(c[j], rs_C, off_c[j], 0, 0);
           __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, off_t[j], 0, 0);
-          {  // lane = x + 8 y of row z = g0 + j
+          if (!(kc.dbg & kKaCoarseSumm)) {  // lane = x + 8 y of row z = g0 + j
             const float fs = __uint_as_float(t[j].x), fw = __uint_as_float(t[j].y);
             unsigned long long bm[4];
             bm[0] = ballot(!(fs > 1.0f));
@@ -1024,7 +1024,11 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const uint32_t rows_t = lanes_t >> 3, rows_c = COLOR ? (lanes_c >> 3) : 0u;
     const bool updated = rows_t != 0;
     if (updated) {  // the classes of what was written join the chunk's summary: lane = x + 8 y of a row
-      if (lane == 0 && sword) atomicOr(&v.summ[slot], sword);
+      if (kc.dbg & kKaCoarseSumm) {
+        if (lane == 0) v.summ[slot] = kSummAny;
+      } else if (lane == 0 && sword) {
+        atomicOr(&v.summ[slot], sword);
+      }
     }
     if ((kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves) {  // timeline aid: work of this wave
       v.phase_buf[wave * 16 + 8] += 1;                 // chunks
@@ -1390,6 +1394,7 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
     a.epoch = cur->epoch;
     a.n_ka = (uint32_t)(nblocks > 0 ? nblocks : 2048);
     color = cur->img.rgba != nullptr;
+    if (cur->coarse_summ) a.kc.dbg |= kKaCoarseSumm;
   }
   if (next) {
     a.sel1 = next->sel;
