@@ -880,6 +880,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     // classes of the voxels written (VolumeDev::summ), reduced row by row into ONE scalar word: the kernel has no
     // VGPR to spare for per-lane classes and no SGPRs for four lane masks
     uint32_t sword = 0;
+    unsigned long long m_ok = 0, m_pos = 0, m_neg = 0, m_hvy = 0;
 
 #pragma unroll
     for (int p = 0; p < 8 / GP; ++p) {
@@ -983,17 +984,11 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, off_t[j], 0, 0);
           if (!(kc.dbg & kKaCoarseSumm)) {  // lane = x + 8 y of row z = g0 + j
             const float fs = __uint_as_float(t[j].x), fw = __uint_as_float(t[j].y);
-            unsigned long long bm[4];
-            bm[0] = ballot(!(fs > 1.0f));
-            bm[1] = ballot(fs > 0.0f) & bm[0];
-            bm[2] = ballot(fs < 0.0f);
-            bm[3] = ballot(fw > 50.0f);
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-              const uint32_t f = (bm[b] ? 1u : 0u) | ((bm[b] & 0x0101010101010101ull) ? 0x10u : 0u) | ((bm[b] & 0xFFull) ? 0x100u : 0u) |
-                                 ((g0 + j == 0 && bm[b]) ? 0x1000u : 0u);
-              sword |= f << b;
-            }
+            const unsigned long long b_ok = ballot(!(fs > 1.0f)), b_pos = ballot(fs > 0.0f) & b_ok;
+            const unsigned long long b_neg = ballot(fs < 0.0f), b_hvy = ballot(fw > 50.0f);
+            m_ok |= b_ok; m_pos |= b_pos; m_neg |= b_neg; m_hvy |= b_hvy;
+            if (g0 + j == 0)
+              sword = (b_ok ? 0x1000u : 0u) | (b_pos ? 0x2000u : 0u) | (b_neg ? 0x4000u : 0u) | (b_hvy ? 0x8000u : 0u);
           }
         }
       }
@@ -1026,8 +1021,12 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     if (updated) {  // the classes of what was written join the chunk's summary: lane = x + 8 y of a row
       if (kc.dbg & kKaCoarseSumm) {
         if (lane == 0) v.summ[slot] = kSummAny;
-      } else if (lane == 0 && sword) {
-        atomicOr(&v.summ[slot], sword);
+      } else {
+        const unsigned long long mm[4] = {m_ok, m_pos, m_neg, m_hvy};
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          sword |= (mm[b] ? (1u << b) : 0u) | ((mm[b] & 0x0101010101010101ull) ? (0x10u << b) : 0u) | ((mm[b] & 0xFFull) ? (0x100u << b) : 0u);
+        if (lane == 0 && sword) atomicOr(&v.summ[slot], sword);
       }
     }
     if ((kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves) {  // timeline aid: work of this wave
