@@ -129,6 +129,8 @@ struct MeshSh {
   uint32_t toff[512];         // first output triangle of the cell
   uint32_t wsum[8];
   uint32_t nv, nt, adj, any;
+  uint32_t rstate;            // MeshRec::state as it was before this pass
+  unsigned long long rtexloc; // MeshRec::texloc
 };
 
 // The (up to four) cells around edge slot (ax, bx, by, bz), numbered q = 0..3 in DESCENDING cell index (z, then
@@ -327,6 +329,8 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restr
     __syncthreads();  // the previous chunk of this workgroup is done with the shared tables
     if (t < 27) sh.nslot[t] = surv[32 * row + t];
     if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; }
+    // the record's previous state travels with the first batch of loads, so that the tail of the chunk is stores only
+    if (t == NT - 64) { sh.rstate = rec->state; sh.rtexloc = rec->texloc; }
     if (dbg == 1) continue;  // triage: filter only
     // ---- stage the 11^3 voxels of the neighbourhood (own ones from registers)
 #pragma unroll
@@ -492,15 +496,20 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restr
     if (nv > v.mesh_cv || nt > v.mesh_ct) {  // does not fit the slot's block: reported, stored empty
       if (t == 0) {
         atomicOr(&v.vctl->status, kStMeshFull);
-        const uint32_t was = rec->state & kMsInMap;
+        const uint32_t was = sh.rstate & kMsInMap;
         rec->nv = 0; rec->nt = 0; rec->state = was | kMsOverflow; rec->epoch = epoch;
-        if (rearm >= 0 && was) patch_list_append(v, rearm ^ 1, shard, id, own, rec->texloc);
+        if (rearm >= 0 && was) patch_list_append(v, rearm ^ 1, shard, id, own, sh.rtexloc);
       }
       __syncthreads();
       continue;
     }
 
     if (dbg == 4) continue;  // triage: + ranking
+    // a mesh enters allMeshes when it has vertices and stays there afterwards (:260-262).  The patch-list entry does
+    // not depend on the vertices: the last wave (it rarely has vertex work) appends it now, so that the round trips
+    // of the two counters overlap the vertex pass instead of ending the chunk.
+    const uint32_t inmap = (sh.rstate & kMsInMap) | (nv ? kMsInMap : 0u);
+    if (t == NT - 64 && rearm >= 0 && inmap) patch_list_append(v, rearm ^ 1, shard, id, own, sh.rtexloc);
     // ---- pass 2: the winning cell of every used slot evaluates the vertex; lane = output vertex
     const float org[3] = {(float)(8 * id.x) * res, (float)(8 * id.y) * res, (float)(8 * id.z) * res};  // Chunk.cpp:52
     uint32_t adj = 0;
@@ -572,12 +581,9 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restr
     }
     __syncthreads();
     if (t == 0) {
-      // a mesh enters allMeshes when it has vertices and stays there afterwards (:260-262); its own
-      // adjacency flags are final now (SimplifyByClustering runs once per generation, Chisel.cpp:124)
-      const uint32_t inmap = (rec->state & kMsInMap) | (nv ? kMsInMap : 0u);
+      // its own adjacency flags are final now (SimplifyByClustering runs once per generation, Chisel.cpp:124)
       rec->nv = nv; rec->nt = nt; rec->epoch = epoch;
       rec->state = inmap | (sh.adj << kMsAdjShift) | (nv ? simplified : 0u);
-      if (rearm >= 0 && inmap) patch_list_append(v, rearm ^ 1, shard, id, own, rec->texloc);
     }
     __syncthreads();
   }
