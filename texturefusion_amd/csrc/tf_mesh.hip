@@ -201,13 +201,20 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
     // the id goes out at once: lanes 0..26 look up the 27 chunks of the neighbourhood -- the survivors' row
     // needs them all, the boundary test the +x/+y/+z seven of them -- while the own voxels are read.
     uint32_t nslot = kInvalidSlot;
-    if (lane < 27) {
-      if (lane == 13 && dslot) nslot = dslot[entry];
-      else {
-        const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
-        if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
-      }
-    }
+    // (with the summaries: first the chunk and its seven +x / +y / +z neighbours -- all the summary test and the
+    // boundary reads need; the other 19 only for a chunk that can have a vertex, together with its voxel reads)
+    constexpr uint32_t kNear = (1u << 13) | (1u << 14) | (1u << 16) | (1u << 17) | (1u << 22) | (1u << 23) | (1u << 25) | (1u << 26);
+    auto lookup = [&](bool mine) {
+      if (!mine) return;
+      const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
+      if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
+    };
+    // (the fused flow's list carries the chunk's own pool slot.  Read under a wave-uniform test only: inside the
+    // per-lane lookup the compiler turned it into a scalar load that ran with no lane active, null pointer or not.)
+    uint32_t own_listed = kInvalidSlot;
+    if (dslot) own_listed = dslot[entry];
+    lookup(lane < 27 && !(dslot && lane == 13) && (!use_summ || ((kNear >> lane) & 1u)));
+    if (dslot && lane == 13) nslot = own_listed;
     const uint32_t own = (uint32_t)__shfl((int)nslot, 13);
     if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
     // First the summaries (VolumeDev::summ, 4 B per chunk): the classes that may occur among the chunk's voxels and
@@ -231,9 +238,13 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
     if (maybe) {
     const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
     uint32_t fl = 0;
+    float4 qv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qv[j] = T4[j * 64 + lane];  // voxels 2 i and 2 i + 1 of the chunk, i = 64 j + lane: {sdf, w, sdf, w}
+    if (use_summ) lookup(lane < 27 && !((kNear >> lane) & 1u));  // the far 19 of the neighbourhood, behind the voxel reads
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float4 q = T4[j * 64 + lane];  // voxels 2 i and 2 i + 1 of the chunk, i = 64 j + lane: {sdf, w, sdf, w}
+      const float4 q = qv[j];
       const uint32_t c0 = classify_voxel(q.x, q.y), c1 = classify_voxel(q.z, q.w);
       // x = 0: the first voxel of every fourth pair; y = 0: (i >> 2) & 7 == 0; z = 0: i < 32
       fl |= c0 | c1 | ((lane & 3) ? 0u : c0 << 4) | ((lane & 28) ? 0u : (c0 | c1) << 8) | ((j || lane >= 32) ? 0u : (c0 | c1) << 12);
