@@ -176,125 +176,191 @@ __device__ __forceinline__ void patch_list_append(const VolumeDev& v, int ppar, 
   }
 }
 
+// Mesh::Clear + "stays in allMeshes if it was there" (:244-262) for a chunk the filter ruled out; one thread
+__device__ __forceinline__ void filter_reset_record(const VolumeDev& v, uint32_t own, const int4 id, uint32_t epoch, int ppar) {
+  MeshRec* rec = &v.mesh_rec[own];
+  const uint32_t inmap = rec->state & kMsInMap;
+  rec->nv = 0; rec->nt = 0; rec->state = inmap; rec->epoch = epoch;
+  if (ppar >= 0 && inmap) patch_list_append(v, ppar, own & (kMeshShards - 1u), id, own, rec->texloc);  // an emptied mesh keeps its patch
+}
+
+// phase A of the filter for the 8-lane group a lane belongs to (k8 = its place in the group): lane k looks up chunk
+// id + (k & 1, (k >> 1) & 1, k >> 2) -- the chunk itself and its seven +x / +y / +z neighbours -- and reads that
+// chunk's class summary.  The summaries are supersets of the classes that occur among a chunk's voxels / on the faces
+// the neighbours contribute (an edge or the corner counts as the whole face it lies in), so a chunk they rule out is
+// ruled out for good.  Returns the lane's pool slot; *own = the chunk's, *maybe = the exact test is needed.
+__device__ __forceinline__ uint32_t filter_near(const VolumeDev& v, const int4 id, int lane, int k8, bool have_own,
+                                                uint32_t own_listed, bool use_summ, uint32_t* own, bool* maybe) {
+  uint32_t nslot = kInvalidSlot;
+  if (k8 == 0 && have_own) {
+    nslot = own_listed;  // the fused flow's list carries the chunk's own pool slot
+  } else {
+    const uint32_t ent = hash_find(v, pack_id(id.x + (k8 & 1), id.y + ((k8 >> 1) & 1), id.z + (k8 >> 2)));
+    if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
+  }
+  *own = (uint32_t)__shfl((int)nslot, lane & 56);
+  *maybe = true;
+  if (use_summ && *own != kInvalidSlot) {
+    const uint32_t sm = nslot != kInvalidSlot ? v.summ[nslot] : 0u;
+    // self: whole chunk; +x, +x+y, +x+z, +x+y+z: x = 0 face; +y, +y+z: y = 0 face; +z: z = 0 face
+    const uint32_t sel = k8 == 0 ? 0u : ((k8 & 1) ? 4u : ((k8 & 2) ? 8u : 12u));
+    uint32_t u = (sm >> sel) & 15u;
+    u |= (uint32_t)__shfl_xor((int)u, 1); u |= (uint32_t)__shfl_xor((int)u, 2); u |= (uint32_t)__shfl_xor((int)u, 4);
+    const uint32_t so = (uint32_t)__shfl((int)sm, lane & 56);
+    *maybe = (so & 1u) && (u & 14u) == 14u;
+  }
+  return nslot;
+}
+
+// phase B, one wave per entry.  A vertex needs a cell whose 8 corners are all observed with both signs among them,
+// and a corner with weight > 50 (:669-722, :776-777): the exact test reads the chunk's own 4 KiB and, if those do not
+// decide, the 217 corner voxels the +x / +y / +z neighbours contribute.  nslot: lanes 0..26 = neighbourhood index
+// 13 + dx + 3 dy + 9 dz, the near eight filled in by the caller; the far 19 are looked up here, behind the voxel reads
+// (only a survivor's row needs them).  A survivor gets a row of its shard for the mesher's staging.
+__device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, uint32_t entry, uint32_t nslot, int lane,
+                                             uint32_t epoch, uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
+                                             uint32_t cap_sh, int ppar, bool use_summ) {
+  const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
+  const uint32_t own = (uint32_t)__shfl((int)nslot, 13);
+  // rows and patch entries go to shard own % 32: pool slots are unique, so a shard never holds more than
+  // max_chunks / 32 of them whatever the order of the work
+  const uint32_t shard = own & (kMeshShards - 1u);
+  const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
+  float4 qv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qv[j] = T4[j * 64 + lane];  // voxels 2 i and 2 i + 1 of the chunk, i = 64 j + lane: {sdf, w, sdf, w}
+  if (lane < 27 && !is_near) {
+    const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
+    if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
+  }
+  uint32_t fl = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 q = qv[j];
+    const uint32_t c0 = classify_voxel(q.x, q.y), c1 = classify_voxel(q.z, q.w);
+    // x = 0: the first voxel of every fourth pair; y = 0: (i >> 2) & 7 == 0; z = 0: i < 32
+    fl |= c0 | c1 | ((lane & 3) ? 0u : c0 << 4) | ((lane & 28) ? 0u : (c0 | c1) << 8) | ((j || lane >= 32) ? 0u : (c0 | c1) << 12);
+  }
+  fl = wave_or(fl);
+  if (use_summ && lane == 0) v.summ[own] = fl;  // the chunk's summary is exact again
+  bool empty = !(fl & 1u);
+  if (!empty && (fl & 14u) != 14u) {
+    uint32_t f2 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // corner voxels with a coordinate 8: 3 faces of 64, 3 edges of 8, 1 corner
+      const int q = j * 64 + lane;
+      int cx = 0, cy = 0, cz = 0;
+      if (q < 64) { cx = 8; cy = q & 7; cz = q >> 3; }
+      else if (q < 128) { cx = q & 7; cy = 8; cz = (q >> 3) & 7; }
+      else if (q < 192) { cx = q & 7; cy = (q >> 3) & 7; cz = 8; }
+      else if (q < 200) { cx = 8; cy = 8; cz = q & 7; }
+      else if (q < 208) { cx = 8; cy = q & 7; cz = 8; }
+      else if (q < 216) { cx = q & 7; cy = 8; cz = 8; }
+      else { cx = 8; cy = 8; cz = 8; }
+      const uint32_t s = (uint32_t)__shfl((int)nslot, 13 + (cx >> 3) + 3 * (cy >> 3) + 9 * (cz >> 3));
+      if (q < 217 && s != kInvalidSlot) {
+        const float2 val = v.tsdf[(size_t)s * kChunkVoxels + (cx & 7) + (cy & 7) * 8 + (cz & 7) * 64];
+        f2 |= classify_voxel(val.x, val.y);
+      }
+    }
+    f2 = wave_or(f2);
+    empty = ((fl | f2) & 14u) != 14u;
+  }
+  if (empty) {
+    if (lane == 0) filter_reset_record(v, own, id, epoch, ppar);
+    return;
+  }
+  uint32_t p = 0;
+  if (lane == 0) p = atomicAdd(&cnt[shard * 16], 1u);
+  p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+  if (p >= cap_sh) {  // (cannot happen: at most max_chunks / 32 pool slots share a shard)
+    if (lane == 0) atomicOr(&v.vctl->status, kStMeshFull);
+    return;
+  }
+  if (lane == 27) nslot = entry;
+  if (lane < 28) surv[32 * ((size_t)shard * cap_sh + p) + lane] = nslot;
+}
+
+// neighbourhood index of a lane (0..26) -> its place k among the near eight (only for is_near lanes)
+__device__ __forceinline__ int near_k(int lane) { return (lane % 3 - 1) + 2 * ((lane / 3) % 3 - 1) + 4 * (lane / 9 - 1); }
+
 __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
-                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool xcd_contig,
-                                                     bool use_summ) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t nwaves = gridDim.x * 4;
-  // wave w takes entries w, w + nwaves, ...
-  uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-  if (xcd_contig) {  // TF_FILTER_XCD=1: XCD x (workgroups x, x + 8, ...) takes a contiguous eighth of the wave numbers, for
-                     // L2 reuse of the halo reads among list neighbours: -6 % on filter + mesher in the 1280x960 hall, +3 %
-                     // in the room (profiles/r2/README.md); off by default
-    const uint32_t per = gridDim.x >> 3;
-    const uint32_t b = (per && blockIdx.x < per * 8u) ? (blockIdx.x & 7u) * per + (blockIdx.x >> 3) : blockIdx.x;
-    wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(b * 4u + (threadIdx.x >> 6)));
-  }
+                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool use_summ) {
+  __shared__ uint32_t s_n, s_ne;
+  __shared__ uint32_t s_eown[32];  // entries the summaries ruled out: their records are reset behind the barrier, by the
+  __shared__ int4 s_eid[32];       // last wave, so that no entry of phase B waits for those round trips
+  __shared__ uint32_t s_entry[32];
+  __shared__ int4 s_id[32];
+  __shared__ uint32_t s_near[32][8];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
   uint32_t n = *dcount;
   if (n > max_entries) n = max_entries;
-  for (uint32_t entry = wave; entry < n; entry += nwaves) {
+  const uint32_t nwaves = gridDim.x * 4;
+  if (n <= nwaves) {
+    // ---- a list that gives every wave at most one entry (the 640x480 room: 8 k dirty chunks): the wave runs both
+    // phases for its entry, lanes 0..7 phase A -- nothing to share, no barrier
+    const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
+    if (entry >= n) return;
     const int4 id = dlist[entry];
-    // The kernel is a chain of dependent round trips (one entry per wave), so everything that only depends on
-    // the id goes out at once: lanes 0..26 look up the 27 chunks of the neighbourhood -- the survivors' row
-    // needs them all, the boundary test the +x/+y/+z seven of them -- while the own voxels are read.
-    uint32_t nslot = kInvalidSlot;
-    // (with the summaries: first the chunk and its seven +x / +y / +z neighbours -- all the summary test and the
-    // boundary reads need; the other 19 only for a chunk that can have a vertex, together with its voxel reads)
-    constexpr uint32_t kNear = (1u << 13) | (1u << 14) | (1u << 16) | (1u << 17) | (1u << 22) | (1u << 23) | (1u << 25) | (1u << 26);
-    auto lookup = [&](bool mine) {
-      if (!mine) return;
-      const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
-      if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
-    };
-    // (the fused flow's list carries the chunk's own pool slot.  Read under a wave-uniform test only: inside the
-    // per-lane lookup the compiler turned it into a scalar load that ran with no lane active, null pointer or not.)
     uint32_t own_listed = kInvalidSlot;
     if (dslot) own_listed = dslot[entry];
-    lookup(lane < 27 && !(dslot && lane == 13) && (!use_summ || ((kNear >> lane) & 1u)));
-    if (dslot && lane == 13) nslot = own_listed;
-    const uint32_t own = (uint32_t)__shfl((int)nslot, 13);
-    if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
-    // First the summaries (VolumeDev::summ, 4 B per chunk): the classes that may occur among the chunk's voxels and
-    // on the faces the +x / +y / +z neighbours contribute (an edge or the corner counts as the whole face it lies
-    // in).  They are supersets, so a chunk they rule out is ruled out for good without touching its 4 KiB; the
-    // others go through the exact test below, which also rewrites the chunk's own summary exactly.
-    bool maybe = true;
-    if (use_summ) {
-      uint32_t sm = 0;
-      if (lane < 27 && nslot != kInvalidSlot) sm = v.summ[nslot];
-      // neighbourhood index 13 + dx + 3 dy + 9 dz: +x 14, +y 16, +x+y 17, +z 22, +x+z 23, +y+z 25, +x+y+z 26
-      const uint32_t sel = (0x4824000u >> lane) & 1u ? 4u : ((0x2010000u >> lane) & 1u ? 8u : (lane == 22 ? 12u : (lane == 13 ? 0u : 32u)));
-      const uint32_t u = wave_or(sel < 32u ? ((sm >> sel) & 15u) : 0u);
-      const uint32_t so = (uint32_t)__shfl((int)sm, 13);
-      maybe = (so & 1u) && (u & 14u) == 14u;
+    uint32_t own = kInvalidSlot;
+    bool maybe = false;
+    uint32_t near8 = kInvalidSlot;
+    if (lane < 8) near8 = filter_near(v, id, lane, lane, dslot != nullptr, own_listed, use_summ, &own, &maybe);
+    own = (uint32_t)__shfl((int)own, 0);
+    maybe = __shfl((int)maybe, 0) != 0;
+    if (own == kInvalidSlot) return;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
+    if (!maybe) {
+      if (lane == 0) filter_reset_record(v, own, id, epoch, ppar);
+      return;
     }
-    // rows and patch entries go to shard own % 32: pool slots are unique, so a shard never holds more than
-    // max_chunks / 32 of them whatever the order of the work
-    const uint32_t shard = own & (kMeshShards - 1u);
-    bool empty = true;
-    if (maybe) {
-    const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
-    uint32_t fl = 0;
-    float4 qv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) qv[j] = T4[j * 64 + lane];  // voxels 2 i and 2 i + 1 of the chunk, i = 64 j + lane: {sdf, w, sdf, w}
-    if (use_summ) lookup(lane < 27 && !((kNear >> lane) & 1u));  // the far 19 of the neighbourhood, behind the voxel reads
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 q = qv[j];
-      const uint32_t c0 = classify_voxel(q.x, q.y), c1 = classify_voxel(q.z, q.w);
-      // x = 0: the first voxel of every fourth pair; y = 0: (i >> 2) & 7 == 0; z = 0: i < 32
-      fl |= c0 | c1 | ((lane & 3) ? 0u : c0 << 4) | ((lane & 28) ? 0u : (c0 | c1) << 8) | ((j || lane >= 32) ? 0u : (c0 | c1) << 12);
-    }
-    fl = wave_or(fl);
-    if (use_summ && lane == 0) v.summ[own] = fl;  // exact again
-    empty = !(fl & 1u);
-    if (!empty && (fl & 14u) != 14u) {
-      uint32_t f2 = 0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {  // corner voxels with a coordinate 8: 3 faces of 64, 3 edges of 8, 1 corner
-        const int q = j * 64 + lane;
-        int cx = 0, cy = 0, cz = 0;
-        if (q < 64) { cx = 8; cy = q & 7; cz = q >> 3; }
-        else if (q < 128) { cx = q & 7; cy = 8; cz = (q >> 3) & 7; }
-        else if (q < 192) { cx = q & 7; cy = (q >> 3) & 7; cz = 8; }
-        else if (q < 200) { cx = 8; cy = 8; cz = q & 7; }
-        else if (q < 208) { cx = 8; cy = q & 7; cz = 8; }
-        else if (q < 216) { cx = q & 7; cy = 8; cz = 8; }
-        else { cx = 8; cy = 8; cz = 8; }
-        // chunk id + (cx >> 3, cy >> 3, cz >> 3) = neighbourhood index 13 + dx + 3 dy + 9 dz
-        const uint32_t s = (uint32_t)__shfl((int)nslot, 13 + (cx >> 3) + 3 * (cy >> 3) + 9 * (cz >> 3));
-        if (q < 217 && s != kInvalidSlot) {
-          const float2 val = v.tsdf[(size_t)s * kChunkVoxels + (cx & 7) + (cy & 7) * 8 + (cz & 7) * 64];
-          f2 |= classify_voxel(val.x, val.y);
+    const uint32_t got = (uint32_t)__shfl((int)near8, is_near ? near_k(lane) : 0);
+    filter_exact(v, id, entry, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ);
+    return;
+  }
+  // ---- a long list (the 69 k dirty chunks of the 1280x960 hall): per workgroup, batches of up to 32 entries;
+  //  A: EIGHT LANES per entry decide "cannot have a vertex" for most of them without touching a voxel; an entry that
+  //     passes is parked in LDS;   B: ONE WAVE per parked entry.
+  const int grp = threadIdx.x >> 3, k8 = threadIdx.x & 7;
+  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+  const uint32_t first = blockIdx.x * per;
+  const uint32_t last = first + per < n ? first + per : n;
+  for (uint32_t base = first; base < last; base += 32u) {
+    if (threadIdx.x == 0) { s_n = 0; s_ne = 0; }
+    __syncthreads();
+    const uint32_t entry = base + (uint32_t)grp;
+    if (entry < last) {
+      const int4 id = dlist[entry];
+      uint32_t own_listed = kInvalidSlot;
+      if (dslot && k8 == 0) own_listed = dslot[entry];
+      uint32_t own;
+      bool maybe;
+      const uint32_t nslot = filter_near(v, id, lane, k8, dslot != nullptr, own_listed, use_summ, &own, &maybe);
+      if (own != kInvalidSlot) {  // RecomputeMeshes: !HasChunk -> skip (:240-242)
+        if (maybe) {
+          uint32_t at = 0;
+          if (k8 == 0) at = atomicAdd(&s_n, 1u);
+          at = (uint32_t)__shfl((int)at, lane & 56);
+          s_near[at][k8] = nslot;
+          if (k8 == 0) { s_entry[at] = entry; s_id[at] = id; }
+        } else if (k8 == 0) {
+          const uint32_t at = atomicAdd(&s_ne, 1u);
+          s_eown[at] = own; s_eid[at] = id;
         }
       }
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) f2 |= (uint32_t)__shfl_xor((int)f2, o);
-      empty = ((fl | f2) & 14u) != 14u;
     }
-    }
-    if (empty) {
-      if (lane == 0) {  // Mesh::Clear + "stays in allMeshes if it was there" (:244-262)
-        MeshRec* rec = &v.mesh_rec[own];
-        const uint32_t inmap = rec->state & kMsInMap;
-        rec->nv = 0; rec->nt = 0; rec->state = inmap; rec->epoch = epoch;
-        if (ppar >= 0 && inmap) patch_list_append(v, ppar, shard, id, own, rec->texloc);  // an emptied mesh keeps its patch
-      }
-    } else {  // a survivor: a row of its shard with the pool slots of chunk id + (-1..1)^3 for the mesher's staging
-      uint32_t p = 0;
-      if (lane == 0) p = atomicAdd(&cnt[shard * 16], 1u);
-      p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
-      if (p >= cap_sh) {  // (cannot happen: at most max_chunks / 32 pool slots share a shard)
-        if (lane == 0) atomicOr(&v.vctl->status, kStMeshFull);
-        continue;
-      }
-      if (lane == 27) nslot = entry;
-      if (lane < 28) surv[32 * ((size_t)shard * cap_sh + p) + lane] = nslot;
-    }
+    __syncthreads();
+    if (w == 3 && lane < (int)s_ne) filter_reset_record(v, s_eown[lane], s_eid[lane], epoch, ppar);
+    const uint32_t nm = s_n;
+    for (uint32_t m = (uint32_t)w; m < nm; m += 4u)
+      filter_exact(v, s_id[m], s_entry[m], is_near ? s_near[m][near_k(lane)] : kInvalidSlot, lane, epoch, surv, cnt, cap_sh,
+                   ppar, use_summ);
+    __syncthreads();  // the parked entries are consumed before the next batch overwrites them
   }
 }
 
@@ -633,16 +699,16 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
                  uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s) {
   if (!max_entries) return;
   static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch
-  static const bool xcd_contig = getenv("TF_FILTER_XCD") && atoi(getenv("TF_FILTER_XCD"));
   static const bool use_summ = !(getenv("TF_FILTER_SUMM") && !atoi(getenv("TF_FILTER_SUMM")));  // A/B knob, default on
   uint32_t* surv = v.mesh_nbr;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
   uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshShards * 16;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
   if (max_entries > v.max_chunks) max_entries = v.max_chunks;
-  const uint32_t fgrid = (max_entries + 3) / 4 < 2048u ? (max_entries + 3) / 4 : 2048u;
+  // (2560 workgroups = 1.25 x the resident capacity: a frame's list of up to 10 k entries runs one entry per wave)
+  const uint32_t fgrid = (max_entries + 3) / 4 < 2560u ? (max_entries + 3) / 4 : 2560u;
   hipLaunchKernelGGL(k_mesh_filter, dim3(fgrid), dim3(256), 0, s, v, dlist, fused ? v.work_slot : nullptr, dcount,
-                     max_entries, epoch, surv, cnt, cap_sh, fused ? (rearm_set ^ 1) : -1, xcd_contig, use_summ);
+                     max_entries, epoch, surv, cnt, cap_sh, fused ? (rearm_set ^ 1) : -1, use_summ);
   // the survivors form dense per-shard lists: a grid of a few resident rounds, each workgroup striding its shard
   // (TF_MESH_GRID overrides; rounded to a multiple of the shard count)
   static const uint32_t gmax = getenv("TF_MESH_GRID") ? (uint32_t)atoi(getenv("TF_MESH_GRID")) : 4096u;
