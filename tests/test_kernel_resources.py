@@ -16,7 +16,9 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGET = {
     "tf_kernels.hip": {"k_frameILb1E": (72, 0), "k_frameILb0E": (72, 0), "k_integrate_groupILb1E": (96, 0),
                        "k_integrate_groupILb0E": (96, 0)},
-    "tf_mesh.hip": {"k_meshILi256E": (80, 0), "k_mesh_filter": (64, 0)},
+    # (the filter's two forms -- wave per entry / workgroup batches -- share one kernel: 78 VGPRs, 6 waves per SIMD;
+    # forcing 7 or 8 spills, and the measured time does not depend on it: the kernel is a chain of round trips)
+    "tf_mesh.hip": {"k_meshILi256E": (80, 0), "k_mesh_filter": (80, 0)},
     "tf_atlas.hip": {"k_patchILb1ELb1ELb1E": (136, 0)},  # one patch per wave, ~3 waves per SIMD: occupancy is not the limit
 }
 
