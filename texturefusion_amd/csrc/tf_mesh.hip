@@ -217,7 +217,7 @@ __device__ __forceinline__ uint32_t filter_near(const VolumeDev& v, const int4 i
 // decide, the 217 corner voxels the +x / +y / +z neighbours contribute.  nslot: lanes 0..26 = neighbourhood index
 // 13 + dx + 3 dy + 9 dz, the near eight filled in by the caller; the far 19 are looked up here, behind the voxel reads
 // (only a survivor's row needs them).  A survivor gets a row of its shard for the mesher's staging.
-__device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, uint32_t entry, uint32_t nslot, int lane,
+__device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, uint32_t nslot, int lane,
                                              uint32_t epoch, uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
                                              uint32_t cap_sh, int ppar, bool use_summ) {
   const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
@@ -277,8 +277,9 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
     if (lane == 0) atomicOr(&v.vctl->status, kStMeshFull);
     return;
   }
-  if (lane == 27) nslot = entry;
-  if (lane < 28) surv[32 * ((size_t)shard * cap_sh + p) + lane] = nslot;
+  // [27..29] = the chunk id (the mesher does not go back to the list)
+  if (lane >= 27 && lane < 30) nslot = (uint32_t)(lane == 27 ? id.x : (lane == 28 ? id.y : id.z));
+  if (lane < 30) surv[32 * ((size_t)shard * cap_sh + p) + lane] = nslot;
 }
 
 // neighbourhood index of a lane (0..26) -> its place k among the near eight (only for is_near lanes)
@@ -292,7 +293,6 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
   __shared__ uint32_t s_n, s_ne;
   __shared__ uint32_t s_eown[32];  // entries the summaries ruled out: their records are reset behind the barrier, by the
   __shared__ int4 s_eid[32];       // last wave, so that no entry of phase B waits for those round trips
-  __shared__ uint32_t s_entry[32];
   __shared__ int4 s_id[32];
   __shared__ uint32_t s_near[32][8];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
       return;
     }
     const uint32_t got = (uint32_t)__shfl((int)near8, is_near ? near_k(lane) : 0);
-    filter_exact(v, id, entry, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ);
+    filter_exact(v, id, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ);
     return;
   }
   // ---- a long list (the 69 k dirty chunks of the 1280x960 hall): per workgroup, batches of up to 32 entries;
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
           if (k8 == 0) at = atomicAdd(&s_n, 1u);
           at = (uint32_t)__shfl((int)at, lane & 56);
           s_near[at][k8] = nslot;
-          if (k8 == 0) { s_entry[at] = entry; s_id[at] = id; }
+          if (k8 == 0) s_id[at] = id;
         } else if (k8 == 0) {
           const uint32_t at = atomicAdd(&s_ne, 1u);
           s_eown[at] = own; s_eid[at] = id;
@@ -358,15 +358,14 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
     if (w == 3 && lane < (int)s_ne) filter_reset_record(v, s_eown[lane], s_eid[lane], epoch, ppar);
     const uint32_t nm = s_n;
     for (uint32_t m = (uint32_t)w; m < nm; m += 4u)
-      filter_exact(v, s_id[m], s_entry[m], is_near ? s_near[m][near_k(lane)] : kInvalidSlot, lane, epoch, surv, cnt, cap_sh,
-                   ppar, use_summ);
+      filter_exact(v, s_id[m], is_near ? s_near[m][near_k(lane)] : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar,
+                   use_summ);
     __syncthreads();  // the parked entries are consumed before the next batch overwrites them
   }
 }
 
 template <int NT>  // threads per chunk: 256, or 128 (twice the chunks in flight per CU, half the lanes per barrier)
-__global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restrict__ dlist,
-                                                 const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
+__global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
                                                  uint32_t* __restrict__ cnt_next, uint32_t cap_sh,
                                                  uint32_t epoch, float res, uint32_t simplified, uint32_t dbg,
                                                  int rearm) {
@@ -393,12 +392,11 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const int4* __restr
   for (uint32_t idx = blockIdx.x / kMeshShards; idx < n; idx += gridDim.x / kMeshShards) {
     const size_t row = (size_t)shard * cap_sh + idx;
     const uint32_t own = surv[32 * row + 13];    // the chunk's pool slot
-    const uint32_t entry = surv[32 * row + 27];  // its place in the list
     if (!have_mc) {  // visible after the first barrier below
       for (int i = t; i < 256; i += NT) mc[i] = d_mc_tri[i];
       have_mc = true;
     }
-    const int4 id = dlist[entry];
+    const int4 id = make_int4((int)surv[32 * row + 27], (int)surv[32 * row + 28], (int)surv[32 * row + 29], 0);
     MeshRec* rec = &v.mesh_rec[own];
     float2 a[512 / NT];
 #pragma unroll
@@ -695,20 +693,13 @@ static int mesh_resident_blocks() {
 // holds at most ceil(max_chunks / 32) of them (the margin is historical)
 uint32_t mesh_shard_rows(uint32_t max_chunks) { return max_chunks / kMeshShards + 258u; }
 
-void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
-                 uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s) {
-  if (!max_entries) return;
+static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries, uint32_t epoch, float res, bool fused,
+                          int rearm_set, hipStream_t s) {
   static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch
-  static const bool use_summ = !(getenv("TF_FILTER_SUMM") && !atoi(getenv("TF_FILTER_SUMM")));  // A/B knob, default on
   uint32_t* surv = v.mesh_nbr;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
   uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshShards * 16;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
-  if (max_entries > v.max_chunks) max_entries = v.max_chunks;
-  // (2560 workgroups = 1.25 x the resident capacity: a frame's list of up to 10 k entries runs one entry per wave)
-  const uint32_t fgrid = (max_entries + 3) / 4 < 2560u ? (max_entries + 3) / 4 : 2560u;
-  hipLaunchKernelGGL(k_mesh_filter, dim3(fgrid), dim3(256), 0, s, v, dlist, fused ? v.work_slot : nullptr, dcount,
-                     max_entries, epoch, surv, cnt, cap_sh, fused ? (rearm_set ^ 1) : -1, use_summ);
   // the survivors form dense per-shard lists: a grid of a few resident rounds, each workgroup striding its shard
   // (TF_MESH_GRID overrides; rounded to a multiple of the shard count)
   static const uint32_t gmax = getenv("TF_MESH_GRID") ? (uint32_t)atoi(getenv("TF_MESH_GRID")) : 4096u;
@@ -717,11 +708,29 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   grid = (grid + kMeshShards - 1) / kMeshShards * kMeshShards;
   static const int nt = getenv("TF_MESH_THREADS") ? atoi(getenv("TF_MESH_THREADS")) : 256;  // experiment knob
   if (nt == 256)
-    hipLaunchKernelGGL(k_mesh<256>, dim3(grid), dim3(256), 0, s, v, dlist, surv, cnt, cnt_next, cap_sh, epoch, res,
+    hipLaunchKernelGGL(k_mesh<256>, dim3(grid), dim3(256), 0, s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
                        fused ? kMsSimplified : 0u, dbg, rearm_set);
   else
-    hipLaunchKernelGGL(k_mesh<128>, dim3(grid), dim3(128), 0, s, v, dlist, surv, cnt, cnt_next, cap_sh, epoch, res,
+    hipLaunchKernelGGL(k_mesh<128>, dim3(grid), dim3(128), 0, s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
                        fused ? kMsSimplified : 0u, dbg, rearm_set);
+}
+
+static bool filter_uses_summaries() {
+  static const bool use_summ = !(getenv("TF_FILTER_SUMM") && !atoi(getenv("TF_FILTER_SUMM")));  // A/B knob, default on
+  return use_summ;
+}
+
+void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
+                 uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s) {
+  if (!max_entries) return;
+  uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
+  const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
+  if (max_entries > v.max_chunks) max_entries = v.max_chunks;
+  // (2560 workgroups = 1.25 x the resident capacity: a frame's list of up to 10 k entries runs one entry per wave)
+  const uint32_t fgrid = (max_entries + 3) / 4 < 2560u ? (max_entries + 3) / 4 : 2560u;
+  hipLaunchKernelGGL(k_mesh_filter, dim3(fgrid), dim3(256), 0, s, v, dlist, fused ? v.work_slot : nullptr, dcount,
+                     max_entries, epoch, v.mesh_nbr, cnt, cap_sh, fused ? (rearm_set ^ 1) : -1, filter_uses_summaries());
+  launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, s);
 }
 
 // ---------------------------------------------------------------------------------------
