@@ -61,6 +61,16 @@ def test_hand_held_orbit(gpu_required):
     assert _run(cam, np.float32(0.005), frames, stride=3) > 500
 
 
+def test_long_orbit_of_the_bench_stream(gpu_required):
+    """90 consecutive frames of the stream bench.py times (almost half the orbit): weights pass the mesher's
+    threshold of 50, colour counts reach their cap of 120, meshes lose and regain vertices, patches are re-projected
+    dozens of times and the filter's class summaries (kept by the voxel writers, made exact by the filter) live
+    through thousands of updates per chunk."""
+    cam = synth.Camera()
+    frames = [synth.room_frame(k, cam, with_quality=False) for k in range(90)]
+    assert _run(cam, np.float32(0.005), frames, max_chunks=1 << 18, stride=5) > 5000
+
+
 @pytest.mark.parametrize("W,H,f,res", [(320, 240, 262.5, 0.01), (400, 304, 330.0, 0.008)])
 def test_other_cameras_and_voxel_sizes(gpu_required, W, H, f, res):
     cam = synth.Camera(W, H, f, f, W / 2 - 0.5, H / 2 - 0.5, 0.01, 5.0)

@@ -180,7 +180,9 @@ __device__ __forceinline__ void patch_list_append(const VolumeDev& v, int ppar, 
 __device__ __forceinline__ void filter_reset_record(const VolumeDev& v, uint32_t own, const int4 id, uint32_t epoch, int ppar) {
   MeshRec* rec = &v.mesh_rec[own];
   const uint32_t inmap = rec->state & kMsInMap;
-  rec->nv = 0; rec->nt = 0; rec->state = inmap; rec->epoch = epoch;
+  // fused flow (ppar >= 0): CompressMeshes follows in the same frame and its SimplifyByClustering marks EVERY dirty
+  // mesh of allMeshes simplified, with or without vertices (Chisel.cpp:116-126, Mesh.cpp:39-48)
+  rec->nv = 0; rec->nt = 0; rec->state = inmap | ((ppar >= 0 && inmap) ? kMsSimplified : 0u); rec->epoch = epoch;
   if (ppar >= 0 && inmap) patch_list_append(v, ppar, own & (kMeshShards - 1u), id, own, rec->texloc);  // an emptied mesh keeps its patch
 }
 
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
     if (t == 0) {
       // its own adjacency flags are final now (SimplifyByClustering runs once per generation, Chisel.cpp:124)
       rec->nv = nv; rec->nt = nt; rec->epoch = epoch;
-      rec->state = inmap | (sh.adj << kMsAdjShift) | (nv ? simplified : 0u);
+      rec->state = inmap | (sh.adj << kMsAdjShift) | (inmap ? simplified : 0u);  // (simplified: every mesh of allMeshes, Chisel.cpp:116-126)
     }
     __syncthreads();
   }
