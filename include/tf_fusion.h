@@ -197,7 +197,9 @@ TF_API int tf_stream_frames_device(tf_volume* v, int64_t n_frames, int64_t n_ahe
  * a host synchronisation.  The keyframe of a patch is the frame itself: its RGBA image (alpha ignored) and
  * depth, pose_inv16[f] = f32(SE3d.inverse().matrix()) of its pose; Patch::frameid = first_frame_id + f.
  * New patches take their atlas slots in ascending (x, y, z) chunk-id order within a frame (the reference's
- * order is an unordered_map's). */
+ * order is an unordered_map's).  Chisel::meshesToUpdate collects marks until CompressMeshes clears it: a frame
+ * that follows frames integrated WITHOUT this unit (tf_stream_frames_device, tf_integrate ...) inherits their
+ * marks and meshes / textures everything they touched as well. */
 TF_API int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int64_t n_ahead,
                                             const float* const* d_depth, const uint8_t* const* d_rgba,
                                             const float* poses12, const float* pose_inv16, int32_t first_frame_id);

@@ -139,3 +139,55 @@ def test_host_frames_deferral_is_not_observable(gpu_required):
     assert np.array_equal(oids, sorted_ids(gv.list_chunks()))
     assert_chunks_equal(ov, gv, oids[::9], "host frames behind a call-by-call frame")
     gv.close()
+
+
+def test_textured_frames_after_a_tsdf_only_stretch(gpu_required):
+    """Chisel::meshesToUpdate collects marks until CompressMeshes clears it: the first textured frame behind frames that
+    were integrated without the textured unit meshes and textures everything those frames touched, not its own chunks
+    alone (and the summaries those frames left as 'anything' are made exact on the way)."""
+    cam = synth.Camera()
+    res = np.float32(0.005)
+    frames = [synth.room_frame(2 * k, cam, with_quality=False, wobble=0.03) for k in range(14)]
+    pinv = [synth.pose_inverse16(f[3]) for f in frames]
+    ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(res, cam, max_chunks=1 << 17)
+    oa = O.Atlas(res)
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+    poses = np.stack([f[3].reshape(12) for f in frames])
+
+    def tsdf(lo, hi):
+        for k in range(lo, hi):
+            ov.integrate_frame(frames[k][0], frames[k][1], frames[k][3])
+        gv.stream_frames_device([b[0].ptr for b in bufs[lo:hi]], [b[1].ptr for b in bufs[lo:hi]], poses[lo:hi])
+
+    def textured(lo, hi):
+        for k in range(lo, hi):
+            ov.frame_textured(oa, frames[k][0], frames[k][1], frames[k][3], pinv[k], 40 + k)
+        gv.stream_frames_textured_device([b[0].ptr for b in bufs[lo:hi]], [b[1].ptr for b in bufs[lo:hi]], poses[lo:hi],
+                                         np.stack(pinv[lo:hi]), 40 + lo)
+
+    def check(tag):
+        gv.sync()
+        mids = sorted_ids(ov.list_meshes())
+        assert np.array_equal(mids, sorted_ids(gv.list_meshes())), tag
+        assert len(gv.dirty()) == len(ov.dirty()), tag
+        voff, ioff, V, N, Cc, I, adj, simp = gv.get_meshes(mids)
+        for i, cid in enumerate(mids):
+            m = ov.get_mesh(cid)
+            assert np.array_equal(V[voff[i]:voff[i + 1]].view(np.uint32), m["verts"].view(np.uint32)), (tag, cid)
+            assert bool(simp[i]) == m["simplified"] and np.array_equal(adj[i], m["adj"]), (tag, cid)
+        assert gv.atlas_loc_next() == oa.loc_next(), tag
+        _compare_patches(ov, gv, mids, tag)
+        return len(mids)
+
+    tsdf(0, 6)
+    textured(6, 8)      # frame 6 inherits the marks of frames 0..5
+    n1 = check("behind six TSDF-only frames")
+    tsdf(8, 10)
+    gv.update_meshes(); ov.update_meshes()   # call-by-call mesher in between: the marks stay (no CompressMeshes)
+    textured(10, 14)
+    n2 = check("behind two more and an UpdateMeshes")
+    assert n1 > 300 and n2 >= n1
+    for a, b in bufs:
+        a.free(); b.free()
+    gv.close()

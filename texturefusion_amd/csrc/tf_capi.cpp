@@ -686,7 +686,11 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
   d.work_ids = a.d_work_ids + (size_t)par * d.max_chunks;
   d.work_slot = a.d_work_slot + (size_t)par * d.max_chunks;
   prof_begin(v, TF_PROF_DIRTY);
-  launch_dirty_frame(d, par, frame_epoch + 1u, v->stream);
+  // meshesToUpdate = everything marked since CompressMeshes last cleared it (Chisel.h:192-208, Chisel.cpp:146).  In a
+  // textured stream that is this frame's chunks (stamps <= frame_epoch are cleared); after frames integrated without
+  // the textured unit the older marks are still there and the general dirty list takes over for this frame.
+  if (v->clear_floor < frame_epoch) launch_dirty_backlog(d, par, v->clear_floor, v->stream);
+  else launch_dirty_frame(d, par, frame_epoch + 1u, v->stream);
   prof_end(v);
   if (v->comm_cap > 0) {  // multi-GPU: ghost bands of this frame's updates, before the mesher reads them
     rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u);

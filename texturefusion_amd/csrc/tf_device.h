@@ -278,6 +278,8 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
                  uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s);
 // per-frame dirty set of the fused flow -> work list of counter set `par`
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s);
+// ... when marks of earlier frames are still waiting for a mesher: everything marked since clear_floor
+void launch_dirty_backlog(const VolumeDev& v, int par, uint32_t clear_floor, hipStream_t s);
 void launch_compress(const VolumeDev& v, const int4* list, const uint32_t* count, uint32_t cap, bool mark,
                      hipStream_t s);
 // sums over the work list of counter set `par`: {entries, with mesh, vertices, triangles, ROI pixels, patches}

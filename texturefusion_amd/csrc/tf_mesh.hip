@@ -790,6 +790,25 @@ void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t
   hipLaunchKernelGGL(k_dirty_frame, dim3(kDirtyBlocks), dim3(1024), 0, s, v, par, stamp);
 }
 
+// A fused frame that finds marks of EARLIER frames still waiting for a mesher (frames integrated without the textured
+// unit since the last CompressMeshes): Chisel::meshesToUpdate is everything marked since it was last cleared, not
+// this frame's chunks alone.  The general dirty list (k_list_dirty) becomes the frame's work list.
+__global__ __launch_bounds__(256) void k_adopt_dirty_list(VolumeDev v, int par) {
+  uint32_t n = v.vctl->n_tmp;
+  if (n > v.max_chunks) n = v.max_chunks;
+  if (blockIdx.x == 0 && threadIdx.x == 0) v.actl->set[par].n_work = n;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int4 id = v.work_ids[i];
+    const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+    v.work_slot[i] = (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) ? v.hent[ent].slot : kInvalidSlot;
+  }
+}
+void launch_dirty_backlog(const VolumeDev& v, int par, uint32_t clear_floor, hipStream_t s) {
+  (void)hipMemsetAsync(&v.vctl->n_tmp, 0, 4, s);
+  launch_list_dirty(v, v.work_ids, v.max_chunks, clear_floor, s);
+  hipLaunchKernelGGL(k_adopt_dirty_list, dim3(512), dim3(256), 0, s, v, par);
+}
+
 // ---------------------------------------------------------------------------------------
 // Chisel::CompressMeshes (Structure/Chisel.cpp:112-147) for a list of chunks: mark the meshes
 // simplified (their own flags were computed with the mesh), then exchange the flags with the face
