@@ -96,6 +96,16 @@ def test_hall_1280x960(gpu_required):
     assert n > 200
 
 
+def test_hall_bench_stream_30_frames(gpu_required):
+    """the 1280x960 hall exactly as bench.py streams it (configs[3]: orbit at 0.5 m, 70-80 k chunks per frame): long
+    dirty lists take the filter's batch form (eight lanes per entry), the visible list is two-ended with ~66 k costly
+    chunks, and the walls' weights pass the mesher's threshold after a couple of dozen frames"""
+    cam = synth.Camera.hires()
+    frames = [synth.room_frame(k, cam, half=(4.0, 3.0, 4.0), radius=0.5, with_quality=False) for k in range(30)]
+    n = _run(cam, np.float32(0.005), frames, max_chunks=1 << 20, stride=23)
+    assert n > 2000
+
+
 def test_host_frames_deferral_is_not_observable(gpu_required):
     """tf_integrate_frame_host runs two frames behind internally; any other entry point has to see every frame that was
     handed over: state queries after 1, 2, 3, 5 and 6 calls (pipeline depths 1, 2, 2, 2, 1 at the flush), a
