@@ -273,7 +273,7 @@ __device__ __forceinline__ float blend(const Taps& t, float c1, float c2, float 
   return c1;
 }
 
-constexpr int kVB = 4;  // 64-vertex blocks of a patch kept in registers: one sweep for meshes up to 256 vertices
+constexpr int kVB = 2;  // 64-vertex blocks of a patch kept in registers: one sweep for meshes up to 128 vertices
 
 template <bool PROJECT, bool BLIT, bool FUSED>
 __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, KfDev kf_fused) {
