@@ -405,6 +405,11 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
     float2 a[512 / NT];
 #pragma unroll
     for (int j = 0; j < 512 / NT; ++j) a[j] = v.tsdf[(size_t)own * kChunkVoxels + j * NT + t];
+    // the thread's entries of the halo table travel with the own voxels: the staging pass below is then ONE hop of
+    // scattered loads instead of table -> voxel
+    unsigned long long htab[(kHalo + NT - 1) / NT];
+#pragma unroll
+    for (int j = 0; j < (kHalo + NT - 1) / NT; ++j) htab[j] = (j * NT + t < kHalo) ? d_mesh_tabs.halo[j * NT + t] : ~0ull;
     __syncthreads();  // the previous chunk of this workgroup is done with the shared tables
     if (t < 27) sh.nslot[t] = surv[32 * row + t];
     if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; sh.ncell = 0; }
@@ -421,8 +426,10 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
     __syncthreads();
     // (measured: issuing the row, the table entries and then own + halo voxels as two batches of loads -- two
     // dependent hops instead of four -- is slower, 36 -> 46 us: the extra registers spill)
-    for (int k = t; k < kHalo; k += NT) {
-      const unsigned long long e = d_mesh_tabs.halo[k];
+#pragma unroll
+    for (int j = 0; j < (kHalo + NT - 1) / NT; ++j) {
+      const unsigned long long e = htab[j];
+      if (e == ~0ull) continue;
       const uint32_t s = sh.nslot[(uint32_t)(e >> 11) & 31u];
       float2 val = make_float2(999.0f, 0.0f);
       if (s != kInvalidSlot) val = v.tsdf[(size_t)s * kChunkVoxels + ((uint32_t)(e >> 16) & 511u)];
