@@ -659,7 +659,9 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
     }
     if (adj) atomicOr(&sh.adj, adj);
     // ---- triangles, in cell order; (s2, s1, s0) per triangle (:914-916)
-    for (uint32_t ci = t; ci < sh.ncell; ci += NT) {
+    // (taken from the END of the workgroup: the vertices above keep the first waves busy -- a mesh has 78 of them --
+    // while the last ones would otherwise have nothing to do)
+    for (uint32_t ci = (uint32_t)(NT - 1 - t); ci < sh.ncell; ci += NT) {
       const int cell = sh.clist[ci];
       const uint32_t info = sh.cinfo[cell];
       if (!(info >> 20)) continue;
