@@ -360,7 +360,7 @@ def roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, pose
 
 
 # rocprofv3 kernel names of one step (one launch each per frame)
-PMC_STEP_KERNELS = {"textured": ("k_frame<true>", "k_dirty_frame", "k_mesh_filter", "k_mesh<256>",
+PMC_STEP_KERNELS = {"textured": ("k_frame<true>", "k_dirty_frame", "k_mesh_filter", "k_mesh<128>",
                                  "k_patch<true, true, true>"),
                     "tsdf": ("k_frame<true>",)}
 # profiles/r2/README.md (tools/calib_fetch on this box type): both counters are in KiB; WRITE_SIZE is exact;

@@ -123,10 +123,10 @@ struct MeshSh {
   uint8_t cflag[732];         // per cell corner: kCf* | neighbour bits
   uint32_t nslot[27];         // pool slot of chunk id + (-1..1)^3, kInvalidSlot = missing
   uint16_t ref[kEdgeSlots];   // output vertex index of a used slot
-  uint16_t vlist[kEdgeSlots]; // used slots in ascending order
   uint32_t ownq[(kEdgeSlots + 7) / 8];  // per edge slot a nibble: bit q = the q-th cell around the edge emits on it
-  uint32_t cinfo[512];        // MC case | edges used by emitted triangles << 8 | triangle count << 20
-  uint32_t toff[512];         // first output triangle of the cell
+  uint16_t cinfo[512];        // edges used by the cell's emitted triangles | triangle count << 12
+  uint8_t cidx[512];          // the cell's MC case
+  uint16_t toff[512];         // first output triangle of the cell (a mesh that fits has < 2^16)
   uint32_t wsum[8];
   uint32_t nv, nt, adj, any;
   uint32_t ncell;             // cells the surface passes through
@@ -368,13 +368,15 @@ __global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __
   }
 }
 
-template <int NT>  // threads per chunk: 256, or 128 (twice the chunks in flight per CU, half the lanes per barrier)
-__global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
+template <int NT>  // threads per chunk: 128 (default), or 256
+__global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
                                                  uint32_t* __restrict__ cnt_next, uint32_t cap_sh,
                                                  uint32_t epoch, float res, uint32_t simplified, uint32_t dbg,
                                                  int rearm) {
   __shared__ MeshSh sh;
-  __shared__ unsigned long long mc[256];  // the triangle table, once per (persistent) workgroup
+  // (LDS per workgroup decides how many chunks a CU holds at once: the triangle table is read from memory -- a few
+  // dozen cached 8-byte reads per chunk --, the list of used edge slots is sized by the mesh capacity: dynamic LDS)
+  extern __shared__ uint16_t vlist[];  // [mesh_cv] used edge slots in ascending order
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   // workgroup b walks the rows of shard b % 32 (the filter appended the survivors there): a dense list, so a
   // grid far smaller than the dirty list keeps every workgroup busy
@@ -392,14 +394,9 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
     v.actl->set[rearm ^ 1].slots_base = v.actl->n_slots;
   }
   if (rearm >= 0 && blockIdx.x == 0 && t < (int)kMeshShards) v.patch_cnt[((rearm & 1) * kMeshShards + t) * 16] = 0u;
-  bool have_mc = false;
   for (uint32_t idx = blockIdx.x / kMeshShards; idx < n; idx += gridDim.x / kMeshShards) {
     const size_t row = (size_t)shard * cap_sh + idx;
     const uint32_t own = surv[32 * row + 13];    // the chunk's pool slot
-    if (!have_mc) {  // visible after the first barrier below
-      for (int i = t; i < 256; i += NT) mc[i] = d_mc_tri[i];
-      have_mc = true;
-    }
     const int4 id = make_int4((int)surv[32 * row + 27], (int)surv[32 * row + 28], (int)surv[32 * row + 29], 0);
     MeshRec* rec = &v.mesh_rec[own];
     float2 a[512 / NT];
@@ -475,7 +472,7 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
         index |= (0.0f > s) ? (1 << k) : 0;  // :726-735
       }
       sh.cinfo[cell] = 0;
-      if (observed && (pos % 8) > 0 && (mc[index] & 0xFull) != 0xFull)  // :722
+      if (observed && (pos % 8) > 0 && index != 0 && index != 255)  // :722; cases 0 and 255 are the ones without a triangle
         sh.clist[atomicAdd(&sh.ncell, 1u)] = (uint16_t)cell;
     }
     __syncthreads();
@@ -492,7 +489,7 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
         cube[k] = s;
         index |= (0.0f > s) ? (1 << k) : 0;
       }
-      const unsigned long long row = mc[index];
+      const unsigned long long row = d_mc_tri[index];
       uint32_t valid = 0;
       const int cf0 = x + y * 9 + z * 81;
 #pragma unroll
@@ -524,7 +521,8 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
         const int m = edge_slot(x, y, z, e);
         atomicOr(&sh.ownq[m >> 3], 1u << (4 * (m & 7) + edge_q(e)));
       }
-      sh.cinfo[cell] = (uint32_t)index | (used << 8) | (ntri << 20);
+      sh.cinfo[cell] = (uint16_t)(used | (ntri << 12));
+      sh.cidx[cell] = (uint8_t)index;
     }
     __syncthreads();
 
@@ -558,7 +556,7 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
       const uint32_t cnt = (uint32_t)__popcll(usedm);
       uint32_t tc = 0;
 #pragma unroll
-      for (int j = 0; j < kCpt; ++j) tc += sh.cinfo[kCpt * t + j] >> 20;
+      for (int j = 0; j < kCpt; ++j) tc += (uint32_t)sh.cinfo[kCpt * t + j] >> 12;
       uint32_t pk = cnt | (tc << 16);  // both counts scanned at once (each < 2^16)
       uint32_t inc = pk;
 #pragma unroll
@@ -578,14 +576,14 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
       for (unsigned long long u = usedm; u; u &= u - 1ull) {
         const int m = first + (int)__builtin_ctzll(u);
         sh.ref[m] = (uint16_t)r;
-        sh.vlist[r] = (uint16_t)m;
+        if (r < v.mesh_cv) vlist[r] = (uint16_t)m;  // (a mesh with more is rejected below)
         ++r;
       }
       uint32_t t0 = excl >> 16;
 #pragma unroll
       for (int j = 0; j < kCpt; ++j) {
-        sh.toff[kCpt * t + j] = t0;
-        t0 += sh.cinfo[kCpt * t + j] >> 20;
+        sh.toff[kCpt * t + j] = (uint16_t)t0;
+        t0 += (uint32_t)sh.cinfo[kCpt * t + j] >> 12;
       }
       if (t == 0) { sh.nv = total & 0xFFFFu; sh.nt = total >> 16; }
     }
@@ -612,7 +610,7 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
     const float org[3] = {(float)(8 * id.x) * res, (float)(8 * id.y) * res, (float)(8 * id.z) * res};  // Chunk.cpp:52
     uint32_t adj = 0;
     for (uint32_t i = t; i < nv; i += NT) {
-      const int m = sh.vlist[i];
+      const int m = vlist[i];
       const int cell = owner_cell(m, __builtin_ctz((sh.ownq[m >> 3] >> (4 * (m & 7))) & 0xFu));
       const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
       const int ax = m % 3, b = m / 3;
@@ -664,10 +662,10 @@ __global__ __launch_bounds__(NT, 6) void k_mesh(VolumeDev v, const uint32_t* __r
     for (uint32_t ci = (uint32_t)(NT - 1 - t); ci < sh.ncell; ci += NT) {
       const int cell = sh.clist[ci];
       const uint32_t info = sh.cinfo[cell];
-      if (!(info >> 20)) continue;
+      if (!(info >> 12)) continue;
       const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
-      const unsigned long long row = mc[info & 0xFFu];
-      const uint32_t valid = (info >> 8) & 0xFFFu;
+      const unsigned long long row = d_mc_tri[sh.cidx[cell]];
+      const uint32_t valid = info & 0xFFFu;
       uint32_t o = sh.toff[cell];
       for (int col = 0; col < 15; col += 3) {
         const int s0 = (int)((row >> (4 * col)) & 0xF);
@@ -732,12 +730,14 @@ static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries,
   uint32_t grid = ((max_entries + kMeshShards - 1) / kMeshShards + 1) * kMeshShards;
   if (grid > gmax) grid = gmax;
   grid = (grid + kMeshShards - 1) / kMeshShards * kMeshShards;
-  static const int nt = getenv("TF_MESH_THREADS") ? atoi(getenv("TF_MESH_THREADS")) : 256;  // experiment knob
+  // 128 threads per chunk: with 15.8 KB of LDS and 94 VGPRs ten chunks are resident per CU (six with 256 threads at 80
+  // VGPRs).  Same time on the room stream, 8 % less on the 1280x960 hall (TF_MESH_THREADS=256 for the other form).
+  static const int nt = getenv("TF_MESH_THREADS") ? atoi(getenv("TF_MESH_THREADS")) : 128;
   if (nt == 256)
-    hipLaunchKernelGGL(k_mesh<256>, dim3(grid), dim3(256), 0, s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
+    hipLaunchKernelGGL(k_mesh<256>, dim3(grid), dim3(256), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
                        fused ? kMsSimplified : 0u, dbg, rearm_set);
   else
-    hipLaunchKernelGGL(k_mesh<128>, dim3(grid), dim3(128), 0, s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
+    hipLaunchKernelGGL(k_mesh<128>, dim3(grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
                        fused ? kMsSimplified : 0u, dbg, rearm_set);
 }
 
