@@ -407,6 +407,7 @@ def pmc_traffic(args):
                             continue
                         name = re.sub(r"^void ", "", row["Kernel_Name"])
                         name = re.sub(r"\(.*$", "", name).replace("tf::", "").strip()
+                        name = re.sub(r"^k_mesh_filter<\w+>$", "k_mesh_filter", name)  # (two forms of one stage)
                         if name in rows:
                             rows[name].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
             for k in want:

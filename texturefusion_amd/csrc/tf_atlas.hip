@@ -901,6 +901,8 @@ int atlas_init(tf_volume* v) {
   TF_HIP(hipMalloc((void**)&a.d_patch_list, sizeof(int4) * (size_t)2 * kMeshShards * mesh_shard_rows(d.max_chunks)));
   TF_HIP(hipMalloc((void**)&a.d_patch_cnt, sizeof(uint32_t) * 2 * kMeshShards * 16));
   TF_HIP(hipMemset(a.d_patch_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16));
+  TF_HIP(hipHostMalloc((void**)&a.h_dirty_len, 64, hipHostMallocDefault));
+  *a.h_dirty_len = 0u;
   TF_HIP(hipMalloc((void**)&a.d_cand, sizeof(unsigned long long) * (size_t)d.max_chunks));
   TF_HIP(hipStreamCreateWithFlags(&a.aux_stream, hipStreamNonBlocking));
   for (int k = 0; k < 2; ++k) {
@@ -938,6 +940,8 @@ void atlas_destroy(tf_volume* v) {
   if (a.d_work_slot) hipFree(a.d_work_slot);
   if (a.d_patch_list) hipFree(a.d_patch_list);
   if (a.d_patch_cnt) hipFree(a.d_patch_cnt);
+  if (a.h_dirty_len) hipHostFree(a.h_dirty_len);
+  a.h_dirty_len = nullptr;
   if (a.d_cand) hipFree(a.d_cand);
   if (a.d_stage) hipFree(a.d_stage);
   if (a.h_stage) hipHostFree(a.h_stage);

@@ -705,7 +705,11 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
     a.patch_pending[par ^ 1] = false;
   }
   prof_begin(v, TF_PROF_MESH);
-  launch_mesh(d, v->mesh_par, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1, v->stream);
+  // (the filter's form follows the dirty-list length of an earlier frame: the kernel leaves it in host-visible memory,
+  // read here without any synchronisation -- whatever value is there is good enough)
+  const uint32_t len_guess = a.h_dirty_len ? *reinterpret_cast<volatile uint32_t*>(a.h_dirty_len) : 0u;
+  launch_mesh(d, v->mesh_par, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1,
+              len_guess, a.h_dirty_len, v->stream);
   v->mesh_par ^= 1;
   prof_end(v);
   if (!one_stream) {

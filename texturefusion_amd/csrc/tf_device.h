@@ -274,8 +274,10 @@ void launch_init_meshes(const VolumeDev& v, hipStream_t s);
 void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
                             float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s);
 uint32_t mesh_shard_rows(uint32_t max_chunks);
+// len_guess: the list length as far as the host knows (picks the filter's form); len_hint: host-visible word that
+// receives the actual length (may be null)
 void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
-                 uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s);
+                 uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, hipStream_t s);
 // per-frame dirty set of the fused flow -> work list of counter set `par`
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s);
 // ... when marks of earlier frames are still waiting for a mesher: everything marked since clear_floor

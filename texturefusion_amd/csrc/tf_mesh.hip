@@ -289,47 +289,55 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
 // neighbourhood index of a lane (0..26) -> its place k among the near eight (only for is_near lanes)
 __device__ __forceinline__ int near_k(int lane) { return (lane % 3 - 1) + 2 * ((lane / 3) % 3 - 1) + 4 * (lane / 9 - 1); }
 
-__global__ __launch_bounds__(256) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
+// Two forms of the filter, one kernel each (one kernel holding both needs 78 VGPRs; the wave form alone fits the 64
+// that let eight waves per SIMD -- the whole list of a 640x480 frame -- be resident at once):
+//  WAVE_FORM: one entry per wave (strided when the list is longer than the grid): lanes 0..7 run phase A, the wave
+//             phase B for the same entry -- nothing to share, no barrier;
+//  batches:   per workgroup, batches of up to 32 entries; phase A with EIGHT LANES per entry decides "cannot have a
+//             vertex" for most of them without touching a voxel, an entry that passes is parked in LDS; phase B takes
+//             the parked entries one wave each.  For long lists (the 69 k dirty chunks of the 1280x960 hall).
+// Either form is correct for any list; the host picks by the list length it last heard of (*len_hint, written here
+// into host-visible memory for the NEXT frame's choice -- no synchronisation, a stale value only costs time).
+template <bool WAVE_FORM>
+__global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
-                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool use_summ) {
+                                                     uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool use_summ,
+                                                     uint32_t* __restrict__ len_hint) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
+  uint32_t n = *dcount;
+  if (n > max_entries) n = max_entries;
+  if (len_hint && blockIdx.x == 0 && threadIdx.x == 0) *len_hint = n;
+  const uint32_t nwaves = gridDim.x * 4;
+  if (WAVE_FORM) {
+    for (uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6)); entry < n;
+         entry += nwaves) {
+      const int4 id = dlist[entry];
+      uint32_t own_listed = kInvalidSlot;
+      if (dslot) own_listed = dslot[entry];  // (under a wave-uniform test: see profiles/r2/README.md)
+      uint32_t own = kInvalidSlot;
+      bool maybe = false;
+      uint32_t near8 = kInvalidSlot;
+      if (lane < 8) near8 = filter_near(v, id, lane, lane, dslot != nullptr, own_listed, use_summ, &own, &maybe);
+      own = (uint32_t)__shfl((int)own, 0);
+      maybe = __shfl((int)maybe, 0) != 0;
+      if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
+      if (!maybe) {
+        if (lane == 0) filter_reset_record(v, own, id, epoch, ppar);
+        continue;
+      }
+      const uint32_t got = (uint32_t)__shfl((int)near8, is_near ? near_k(lane) : 0);
+      filter_exact(v, id, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ);
+    }
+    return;
+  }
   __shared__ uint32_t s_n, s_ne;
   __shared__ uint32_t s_eown[32];  // entries the summaries ruled out: their records are reset behind the barrier, by the
   __shared__ int4 s_eid[32];       // last wave, so that no entry of phase B waits for those round trips
   __shared__ int4 s_id[32];
   __shared__ uint32_t s_near[32][8];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
-  uint32_t n = *dcount;
-  if (n > max_entries) n = max_entries;
-  const uint32_t nwaves = gridDim.x * 4;
-  if (n <= nwaves) {
-    // ---- a list that gives every wave at most one entry (the 640x480 room: 8 k dirty chunks): the wave runs both
-    // phases for its entry, lanes 0..7 phase A -- nothing to share, no barrier
-    const uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-    if (entry >= n) return;
-    const int4 id = dlist[entry];
-    uint32_t own_listed = kInvalidSlot;
-    if (dslot) own_listed = dslot[entry];
-    uint32_t own = kInvalidSlot;
-    bool maybe = false;
-    uint32_t near8 = kInvalidSlot;
-    if (lane < 8) near8 = filter_near(v, id, lane, lane, dslot != nullptr, own_listed, use_summ, &own, &maybe);
-    own = (uint32_t)__shfl((int)own, 0);
-    maybe = __shfl((int)maybe, 0) != 0;
-    if (own == kInvalidSlot) return;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
-    if (!maybe) {
-      if (lane == 0) filter_reset_record(v, own, id, epoch, ppar);
-      return;
-    }
-    const uint32_t got = (uint32_t)__shfl((int)near8, is_near ? near_k(lane) : 0);
-    filter_exact(v, id, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ);
-    return;
-  }
-  // ---- a long list (the 69 k dirty chunks of the 1280x960 hall): per workgroup, batches of up to 32 entries;
-  //  A: EIGHT LANES per entry decide "cannot have a vertex" for most of them without touching a voxel; an entry that
-  //     passes is parked in LDS;   B: ONE WAVE per parked entry.
   const int grp = threadIdx.x >> 3, k8 = threadIdx.x & 7;
   const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
   const uint32_t first = blockIdx.x * per;
@@ -747,15 +755,21 @@ static bool filter_uses_summaries() {
 }
 
 void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
-                 uint32_t epoch, float res, bool fused, int rearm_set, hipStream_t s) {
+                 uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, hipStream_t s) {
   if (!max_entries) return;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
   if (max_entries > v.max_chunks) max_entries = v.max_chunks;
-  // (2560 workgroups = 1.25 x the resident capacity: a frame's list of up to 10 k entries runs one entry per wave)
+  // 2560 workgroups = 1.25 x the wave form's resident capacity: a list of up to 10 k entries runs one entry per wave
   const uint32_t fgrid = (max_entries + 3) / 4 < 2560u ? (max_entries + 3) / 4 : 2560u;
-  hipLaunchKernelGGL(k_mesh_filter, dim3(fgrid), dim3(256), 0, s, v, dlist, fused ? v.work_slot : nullptr, dcount,
-                     max_entries, epoch, v.mesh_nbr, cnt, cap_sh, fused ? (rearm_set ^ 1) : -1, filter_uses_summaries());
+  const uint32_t* dslot = fused ? v.work_slot : nullptr;
+  const int ppar = fused ? (rearm_set ^ 1) : -1;
+  if (len_guess <= fgrid * 4u)
+    hipLaunchKernelGGL(k_mesh_filter<true>, dim3(fgrid), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, epoch,
+                       v.mesh_nbr, cnt, cap_sh, ppar, filter_uses_summaries(), len_hint);
+  else
+    hipLaunchKernelGGL(k_mesh_filter<false>, dim3(fgrid), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, epoch,
+                       v.mesh_nbr, cnt, cap_sh, ppar, filter_uses_summaries(), len_hint);
   launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, s);
 }
 
@@ -1014,7 +1028,7 @@ int tf_update_meshes(tf_volume* v, int64_t* n_meshed) {
   const uint8_t* db = reinterpret_cast<const uint8_t*>(v->d_tmp);
   prof_begin(v, TF_PROF_MESH);
   launch_mesh(v->dev, v->mesh_par, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), n,
-              ++v->mesh_epoch, v->res, false, -1, v->stream);
+              ++v->mesh_epoch, v->res, false, -1, n, nullptr, v->stream);
   v->mesh_par ^= 1;
   prof_end(v);
   TF_HIP(hipGetLastError());

@@ -73,6 +73,7 @@ struct AtlasState {
   uint32_t* d_work_slot = nullptr;
   int4* d_patch_list = nullptr;
   uint32_t* d_patch_cnt = nullptr;
+  uint32_t* h_dirty_len = nullptr;  // pinned, device-visible: the mesher's filter leaves the length of a frame's dirty list here
   unsigned long long* d_cand = nullptr;
   int fused_par = 0;   // counter set of the next fused frame
   // fused flow: the patch stages of frame f (second stream) overlap the voxel update of frame f + 1
