@@ -778,7 +778,7 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
 // (Structure/Chisel.h:192-208): every updated chunk of the frame's list and its six face neighbours, those
 // that exist, each once (a stamp per pool slot de-duplicates), appended to the work list.
 // ---------------------------------------------------------------------------------------
-constexpr uint32_t kDirtyBlocks = 256;
+constexpr uint32_t kDirtyBlocks = 512;  // two 1024-thread workgroups per CU: every block resident
 __global__ __launch_bounds__(1024) void k_dirty_frame(VolumeDev v, int par, uint32_t stamp) {
   const SelBuf& L = v.sel;
   const uint32_t nl = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
@@ -795,14 +795,13 @@ __global__ __launch_bounds__(1024) void k_dirty_frame(VolumeDev v, int par, uint
     if (t < total && (t & 7u) != 7u) {
       const uint32_t e = list_phys(v, t >> 3, L.ctl->n_front);  // (fused lists are two-ended, FrameCtl::n_front)
       const int k = (int)(t & 7u);
+      const int4 id0 = L.list_id[e];           // (id and slot go out with the flag, not behind it)
+      const uint32_t slot0 = L.list_slot[e];
       if (L.list_needs[e]) {
-        q = nbr7(L.list_id[e], k);
+        q = nbr7(id0, k);
         q.w = 0;
-        if (k == 0) slot = L.list_slot[e];
-        else {
-          const uint32_t ent = hash_find(v, pack_id(q.x, q.y, q.z));
-          if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) slot = v.hent[ent].slot;
-        }
+        if (k == 0) slot = slot0;
+        else slot = hash_slot_alive(v, pack_id(q.x, q.y, q.z));  // key, slot and state of an entry in one 16-byte load
         if (slot != kInvalidSlot && part_owned(v, q.x, q.y, q.z))
           emit = atomicMax(&v.mesh_rec[slot].stamp, stamp) < stamp;
       }
