@@ -1004,7 +1004,7 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   if (rc) return rc;
   TF_HIP(hipEventRecord(v->hslot[p0.slot].freed, v->stream));
   lap(4, t);
-  v->host_trace[5] += 1.0;
+  if (trace) v->host_trace[5] += 1.0;
   return bind_frame(v, p0.d, p0.c);
 }
 
