@@ -281,6 +281,16 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const uint32_t nwaves = gridDim.x * 4;
   AtlasCtl::Set* S = &v.actl->set[par];
+  // tuning aid (TF_PATCH_DBG=3, tools/stamps.py): lane 0 of a wave stamps the phases of its patch into the debug table,
+  // row = wave; a phase that ends in loads is closed with a wait so that the stamp means "data arrived"
+  const bool tl = FUSED && kf_fused.pad[0] == 3 && wave < (uint32_t)kPhaseWaves;
+  auto stampw = [&](int k) {
+    if (tl) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) v.phase_buf[wave * 16 + k] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
+  if (tl && lane == 0) v.phase_buf[wave * 16 + 0] = __builtin_amdgcn_s_memrealtime();
   // fused flow: the frame's dirty chunks that own a mesh sit in 32 shard lists (the mesher and its filter
   // appended them); wave w walks shard w % 32
   const uint32_t shard = wave & (kMeshShards - 1u);
@@ -319,6 +329,7 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
     if (slot == kInvalidSlot) continue;
     MeshRec* rec = &v.mesh_rec[slot];
     MeshRec R = *rec;  // one 64-B record: counts, flags, slot position, box
+    stampw(1);
     if (FUSED && lane < 6) {
       // Chisel::CompressMeshes' neighbour exchange (Chisel.cpp:127-145) for this chunk: flag k of the mesh and flag
       // k ^ 1 of its k-th face neighbour's mesh become the OR of the two.  Every mesh of the frame is complete (the
@@ -358,6 +369,7 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
         }
       }
     }
+    stampw(2);
     const uint32_t nv = R.nv;
     // fused flow: the keyframe is the frame itself, handed over by value; its image is not retained (kf_slot -1)
     const int kf_slot = FUSED ? -1 : (PROJECT ? id.w : R.kf_slot);
@@ -388,6 +400,7 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
           m0[j] = mesh_plane(v, slot, kMpCol)[ii]; m1[j] = mesh_plane(v, slot, kMpCol + 1)[ii];
           m2[j] = mesh_plane(v, slot, kMpCol + 2)[ii];
         }
+        stampw(3);
         // ---- projection (:52-66), then every image gather of the sweep in flight at once
         float cX[kVB], cY[kVB], dist[kVB];
         Taps tp[kVB];
@@ -426,6 +439,7 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
           d2[j] = tp[j].i2 >= 0 ? kf.depth[tp[j].i2] : 0.0f;
           d3[j] = tp[j].i3 >= 0 ? kf.depth[tp[j].i3] : 0.0f;
         }
+        stampw(4);
         // ---- arithmetic + stores
 #pragma unroll
         for (int j = 0; j < kVB; ++j) {
@@ -503,6 +517,7 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
       bx = R.bbox[0]; by = R.bbox[1]; cols = R.bbox[2]; rows = R.bbox[3];
       have_image = (R.pflags & kPfHasImage) != 0;
     }
+    stampw(5);
     if (!BLIT) continue;
     if (FUSED && kf_fused.pad[0] == 1) continue;  // triage: no blit
     // Patch::complete (Patch.cpp:191-196): vertices, simplified mesh, image, texcoords, frame id
@@ -600,6 +615,7 @@ __global__ __launch_bounds__(256) void k_patch(VolumeDev v, Cam cam, int par, Kf
           }
           val[k] = x;
         }
+        stampw(6);
 #pragma unroll
         for (int k = 0; k < kB; ++k) {
           if (rr[k] < 0) continue;

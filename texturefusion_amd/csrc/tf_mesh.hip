@@ -118,11 +118,16 @@ constexpr uint32_t kCfHeavy = 64u;   // weight > 50 (weight_threshold, ChunkMana
 constexpr uint32_t kCfGradOk = 128u; // |gradient| <= 100 * resolution (:449-452)
 // bits 0..5: the voxel one step along -x, +x, -y, +y, -z, +z has sdf < 1 (GetNeighborSDF, ChunkManager.h:790-823)
 
+template <int NT>
 struct MeshSh {
   float S[kRV];               // sdf, region coordinates -1..9
   uint8_t cflag[732];         // per cell corner: kCf* | neighbour bits
   uint32_t nslot[27];         // pool slot of chunk id + (-1..1)^3, kInvalidSlot = missing
-  uint16_t ref[kEdgeSlots];   // output vertex index of a used slot
+  // output vertex index of a used edge slot m = rbase[m / kEpt] + popcount(rmask[m / kEpt] below bit m % kEpt), kEpt =
+  // 2304 / threads: one {base, mask} pair per THREAD of the ranking pass instead of 2187 16-bit entries (LDS per
+  // workgroup decides how many chunks a CU holds)
+  unsigned long long rmask[NT];
+  uint16_t rbase[NT];
   uint32_t ownq[(kEdgeSlots + 7) / 8];  // per edge slot a nibble: bit q = the q-th cell around the edge emits on it
   uint16_t cinfo[512];        // edges used by the cell's emitted triangles | triangle count << 12
   uint8_t cidx[512];          // the cell's MC case
@@ -376,21 +381,47 @@ __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDe
   }
 }
 
+// tuning aid (TF_MESH_DBG=9, tools/stamps.py): thread 0 of a workgroup stamps the phases of its FIRST chunk into the
+// debug table, row = workgroup
+__device__ __forceinline__ void mesh_stamp(const VolumeDev& v, uint32_t r, int k) {
+  if (threadIdx.x == 0 && blockIdx.x < (uint32_t)kPhaseWaves && r == blockIdx.x)
+    v.phase_buf[blockIdx.x * 16 + k] = __builtin_amdgcn_s_memrealtime();
+}
+
 template <int NT>  // threads per chunk: 128 (default), or 256
 __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
                                                  uint32_t* __restrict__ cnt_next, uint32_t cap_sh,
                                                  uint32_t epoch, float res, uint32_t simplified, uint32_t dbg,
                                                  int rearm) {
-  __shared__ MeshSh sh;
+  __shared__ MeshSh<NT> sh;
   // (LDS per workgroup decides how many chunks a CU holds at once: the triangle table is read from memory -- a few
   // dozen cached 8-byte reads per chunk --, the list of used edge slots is sized by the mesh capacity: dynamic LDS)
   extern __shared__ uint16_t vlist[];  // [mesh_cv] used edge slots in ascending order
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  // workgroup b walks the rows of shard b % 32 (the filter appended the survivors there): a dense list, so a
-  // grid far smaller than the dirty list keeps every workgroup busy
-  const uint32_t shard = blockIdx.x & (kMeshShards - 1u);
-  uint32_t n = cnt[shard * 16];
-  if (n > cap_sh) n = cap_sh;
+  // The survivors sit in 32 shard lists of different lengths.  Workgroup b takes the b-th row of their CONCATENATION
+  // (every wave reads the 32 counters and scans them): the workgroups that have a chunk are then exactly the first
+  // N of the grid, and with N below the resident capacity (2560) all of them start at once.  With b -> (shard b % 32,
+  // row b / 32) the busy workgroups reached up to 32 x the LONGEST list; the few beyond the resident capacity started
+  // when the first round ended and set the kernel's time (time stamps: last start 18-20 us, last end 34 us of which a
+  // chunk takes 20).
+  uint32_t n_rows, excl_l, incl_l;
+  {
+    uint32_t my_n = 0;
+    if (lane < (int)kMeshShards) { my_n = cnt[lane * 16]; if (my_n > cap_sh) my_n = cap_sh; }
+    uint32_t incl = my_n;
+#pragma unroll
+    for (int o = 1; o < (int)kMeshShards; o <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= o) incl += u;
+    }
+    n_rows = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, kMeshShards - 1));  // (wave-uniform: scalar registers)
+    // this workgroup's first row (the common case: its only one), resolved here so that nothing of the scan stays live
+    const uint32_t r0 = blockIdx.x;
+    const uint32_t sh0 = (uint32_t)__popcll(__ballot(lane < (int)kMeshShards && incl <= r0));
+    incl_l = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, (int)(sh0 & 31u)));
+    excl_l = incl_l - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)my_n, (int)(sh0 & 31u)));
+    incl_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh0);  // (reused: the shard of the first row)
+  }
   if (blockIdx.x == 0 && t < (int)kMeshShards) cnt_next[t * 16] = 0u;  // the counters of the NEXT launch's filter
   const float half = res * 0.5f;
   if (rearm >= 0 && blockIdx.x == 0 && t == 0) {
@@ -402,7 +433,21 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
     v.actl->set[rearm ^ 1].slots_base = v.actl->n_slots;
   }
   if (rearm >= 0 && blockIdx.x == 0 && t < (int)kMeshShards) v.patch_cnt[((rearm & 1) * kMeshShards + t) * 16] = 0u;
-  for (uint32_t idx = blockIdx.x / kMeshShards; idx < n; idx += gridDim.x / kMeshShards) {
+  if (dbg == 9) mesh_stamp(v, blockIdx.x, 0);
+  for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
+    uint32_t shard = incl_l, idx = r - excl_l;
+    if (r != blockIdx.x) {  // a further row of this workgroup (lists longer than the grid): scan again
+      uint32_t my_n = 0;
+      if (lane < (int)kMeshShards) { my_n = cnt[lane * 16]; if (my_n > cap_sh) my_n = cap_sh; }
+      uint32_t incl = my_n;
+#pragma unroll
+      for (int o = 1; o < (int)kMeshShards; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= o) incl += u;
+      }
+      shard = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(lane < (int)kMeshShards && incl <= r)));
+      idx = r - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, (int)(shard & 31u)) - __shfl((int)my_n, (int)(shard & 31u)));
+    }
     const size_t row = (size_t)shard * cap_sh + idx;
     const uint32_t own = surv[32 * row + 13];    // the chunk's pool slot
     const int4 id = make_int4((int)surv[32 * row + 27], (int)surv[32 * row + 28], (int)surv[32 * row + 29], 0);
@@ -416,6 +461,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
 #pragma unroll
     for (int j = 0; j < (kHalo + NT - 1) / NT; ++j) htab[j] = (j * NT + t < kHalo) ? d_mesh_tabs.halo[j * NT + t] : ~0ull;
     __syncthreads();  // the previous chunk of this workgroup is done with the shared tables
+    if (dbg == 9) mesh_stamp(v, r, 1);
     if (t < 27) sh.nslot[t] = surv[32 * row + t];
     if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; sh.ncell = 0; }
     // the record's previous state travels with the first batch of loads, so that the tail of the chunk is stores only
@@ -443,6 +489,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
       if (cf) sh.cflag[cf - 1u] = (val.y > 50.0f) ? kCfHeavy : 0u;
     }
     __syncthreads();
+    if (dbg == 9) mesh_stamp(v, r, 3);
     // ---- per corner: which of its six neighbours are below 1, is its gradient short enough.  A cell asks
     // for the three neighbours OUTSIDE its cube (extractGradientFromCubic fetches those through
     // GetNeighborSDF, :320-447), so the answer per (cell, corner) is three of these bits.
@@ -462,6 +509,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
     __syncthreads();
 
     if (dbg == 2) continue;  // triage: + staging and corner flags
+    if (dbg == 9) mesh_stamp(v, r, 4);
     // ---- pass 1: per cell, the MC case, the edges its emitted triangles use, how many triangles.
     // 1a: every cell's case from its 8 corners; the few cells the surface passes through (64 of 512 for a plane) go
     // to a list, so that 1b -- edge validity, triangles, edge ownership: the long part -- runs on dense lanes instead
@@ -535,6 +583,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
     __syncthreads();
 
     if (dbg == 3) continue;  // triage: + cell pass
+    if (dbg == 9) mesh_stamp(v, r, 5);
     // ---- ranks: used edge slots in ascending order (the reference's vertex order, :886-897) and the
     // cells' triangle offsets in cell order (the order of mesh->indices)
     {
@@ -581,9 +630,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
       }
       const uint32_t excl = before + inc - pk;
       uint32_t r = excl & 0xFFFFu;
+      sh.rbase[t] = (uint16_t)r;
+      sh.rmask[t] = usedm;
       for (unsigned long long u = usedm; u; u &= u - 1ull) {
         const int m = first + (int)__builtin_ctzll(u);
-        sh.ref[m] = (uint16_t)r;
         if (r < v.mesh_cv) vlist[r] = (uint16_t)m;  // (a mesh with more is rejected below)
         ++r;
       }
@@ -609,6 +659,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
     }
 
     if (dbg == 4) continue;  // triage: + ranking
+    if (dbg == 9) mesh_stamp(v, r, 6);
     // a mesh enters allMeshes when it has vertices and stays there afterwards (:260-262).  The patch-list entry does
     // not depend on the vertices: the last wave (it rarely has vertex work) appends it now, so that the round trips
     // of the two counters overlap the vertex pass instead of ending the chunk.
@@ -664,6 +715,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
       }
     }
     if (adj) atomicOr(&sh.adj, adj);
+    if (dbg == 9) mesh_stamp(v, r, 7);
     // ---- triangles, in cell order; (s2, s1, s0) per triangle (:914-916)
     // (taken from the END of the workgroup: the vertices above keep the first waves busy -- a mesh has 78 of them --
     // while the last ones would otherwise have nothing to do)
@@ -680,9 +732,14 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
         if (s0 == 0xF) break;
         const int s1 = (int)((row >> (4 * col + 4)) & 0xF), s2 = (int)((row >> (4 * col + 8)) & 0xF);
         if (!((valid >> s0) & (valid >> s1) & (valid >> s2) & 1u)) continue;
-        tri_plane(v, own, 0)[o] = sh.ref[edge_slot(x, y, z, s2)];
-        tri_plane(v, own, 1)[o] = sh.ref[edge_slot(x, y, z, s1)];
-        tri_plane(v, own, 2)[o] = sh.ref[edge_slot(x, y, z, s0)];
+        constexpr int kEptT = 2304 / NT;
+        auto ref_of = [&](int m) {
+          const int tt = m / kEptT, j = m - tt * kEptT;
+          return (uint16_t)(sh.rbase[tt] + (uint32_t)__popcll(sh.rmask[tt] & ((1ull << j) - 1ull)));
+        };
+        tri_plane(v, own, 0)[o] = ref_of(edge_slot(x, y, z, s2));
+        tri_plane(v, own, 1)[o] = ref_of(edge_slot(x, y, z, s1));
+        tri_plane(v, own, 2)[o] = ref_of(edge_slot(x, y, z, s0));
         ++o;
       }
     }
@@ -693,6 +750,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
       rec->state = inmap | (sh.adj << kMsAdjShift) | (inmap ? simplified : 0u);  // (simplified: every mesh of allMeshes, Chisel.cpp:116-126)
     }
     __syncthreads();
+    if (dbg == 9) mesh_stamp(v, r, 8);
   }
 }
 
