@@ -672,9 +672,35 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     }
   }
 
+  // Which entries does this wave take?  Round-robin over the logical list (costly chunks first) -- or, XCD-local
+  // (fused flow): workgroup g runs on XCD g % 8, and XCD x takes the x-th eighth of the costly entries followed by the
+  // x-th eighth of the cheap ones, its waves round-robin over that sequence.  The list is in the selection's
+  // (spatial) order, so an XCD's chunks project into one part of the image and its L2 holds that part instead of
+  // every L2 holding the whole image.
+  const bool xcd_local = FUSED && (kc.dbg & 32768u) && (nb % 8u) == 0u;
+  uint32_t seq_first = wave, seq_stride = nwaves, seq_len = n;
+  uint32_t f_start = 0, f_cnt = n, b_start = 0;
+  if (xcd_local) {
+    const uint32_t x = bid & 7u;
+    seq_first = (bid >> 3) * 4u + (wave & 3u);
+    seq_stride = nwaves >> 3;
+    const uint32_t nbk = n - nf;
+    f_start = (uint32_t)(((unsigned long long)x * nf) >> 3);
+    f_cnt = (uint32_t)(((unsigned long long)(x + 1u) * nf) >> 3) - f_start;
+    b_start = nf + (uint32_t)(((unsigned long long)x * nbk) >> 3);
+    seq_len = f_cnt + (nf + (uint32_t)(((unsigned long long)(x + 1u) * nbk) >> 3) - b_start);
+  }
+  auto logical_of = [&](uint32_t k) -> uint32_t {  // sequence position -> logical list index
+    if (!xcd_local) return k;
+    return k < f_cnt ? f_start + k : b_start + (k - f_cnt);
+  };
   // the wave's first list record is requested before anything else: it arrives while the centroid
   // table is copied (64-B records {o.xyz, wD | upper, id.xyz | spare}; the slot exists for any wave id)
-  u32x8 rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (wave < v.max_list ? (FUSED ? list_phys(v, wave, nf) : wave) : 0u)]);
+  u32x8 rec_next;
+  {
+    const uint32_t e0 = seq_first < seq_len ? logical_of(seq_first) : 0u;
+    rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (e0 < v.max_list ? (FUSED ? list_phys(v, e0, nf) : e0) : 0u)]);
+  }
 
   // centroid table (Chisel.cpp:52-110), computed once per frame ahead of this launch; copied into
   // LDS and shared by the four waves of the workgroup (6 KB).
@@ -716,7 +742,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     v.phase_buf[wave * 16 + 9] = 0;
   }
 
-  for (uint32_t e = wave; e < n; e += nwaves) {
+  for (uint32_t k = seq_first; k < seq_len; k += seq_stride) {
+    const uint32_t e = logical_of(k);
     const uint32_t pe = FUSED ? list_phys(v, e, nf) : e;  // where the entry's record and outputs live
     // The list entry (per-chunk scalars + id) was written by the previous launch, so it is read
     // through the scalar cache: one 64-B record, one s_load, one wait, off the vector-memory queue
@@ -724,7 +751,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const u32x8 prw = rec_next;
     {  // the next record of this wave travels while this chunk is processed (speculative: the slot
        // exists even when e + nwaves >= n, it just holds an older frame's record)
-      const uint32_t en = e + nwaves < v.max_list ? e + nwaves : e;
+      const uint32_t kn = k + seq_stride < seq_len ? k + seq_stride : k;
+      const uint32_t en = logical_of(kn);
       rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (FUSED ? list_phys(v, en, nf) : en)]);
     }
     const int4 id = make_int4((int)prw[5], (int)prw[6], (int)prw[7], 0);
@@ -762,7 +790,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const float band = 32.0f * kc.res;
     const bool div_safe = (fabsf(o2) > band) && (fabsf(o2) < 1048576.0f) && (fabsf(o0) < 1048576.0f) &&
                           (fabsf(o1) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
-    if ((kc.dbg & 8192u) && e == wave && lane == 0 && wave < (uint32_t)kPhaseWaves) {
+    if ((kc.dbg & 8192u) && k == seq_first && lane == 0 && wave < (uint32_t)kPhaseWaves) {
       asm volatile("" :: "s"(o0), "s"(o1), "s"(o2), "s"(id.x));
       v.phase_buf[wave * 16 + 15] = __builtin_amdgcn_s_memrealtime();  // timeline aid: first entry loaded
     }
