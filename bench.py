@@ -1,12 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: RGB-D frames/s of the textured per-frame unit on MI355X (BASELINE.json configs[2]).
 
-One "step" = one synthetic 640x480 RGB-D frame of the S-room stream through
+One "step" = one synthetic 640x480 RGB-D frame of the S-room stream, handed over as HOST images
+(the reference's calling convention, GCFusion/MobileFusion.cpp:223-250), through
+  H2D copy of depth + RGBA (inside the timed region)
   prepare -> integrate(depth+colour) -> finalize          Chisel::IntegrateDepthScanColor 5-arg, Structure/Chisel.h:453-468
   -> UpdateMeshes -> CompressMeshes                        over that frame's dirty chunks (Structure/Chisel.h:479-481, Chisel.cpp:112-147)
   -> GeneratePatches(label = this frame) -> UpdateAtlas    Structure/Chisel.cpp:149-196
-at 5 mm voxels, frames already resident in HBM, nothing copied back, no host synchronisation inside the
-timed region (tf_stream_frames_textured_device).  --mode tsdf runs configs[1] (atlas off).
+at 5 mm voxels (tf_integrate_frame_host), nothing copied back, no host synchronisation inside the timed region.
+--mode tsdf runs configs[1] (atlas off).
+
+Frame windows (ORBIT = 200 frames = one turn of the camera; every window starts at the same orbit position):
+  pre-roll   one full orbit, untimed: every later frame meets a steady-state volume (~2.9 k meshes per frame)
+  warm-up    W frames through the timed entry point
+  timed      K frames -> "value", "ms_per_step" (wall clock, barrier + device synchronisation on both sides)
+  resident   the same K orbit positions one turn later, frames already in HBM (no H2D) -> "resident"
+  events     the same positions again with HIP events around every launch -> per-kernel times
+  replay     the same positions again, frame by frame, reading back the exact integer counts -> algorithmic bytes
+A rocprofv3 --kernel-trace child pass and two --pmc child passes of the same command (same pre-roll / warm-up /
+steps: the same frames, the launches of the timed window sliced out) give the profiler's kernel durations and
+the HBM-side traffic.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -15,7 +28,7 @@ timed region (tf_stream_frames_textured_device).  --mode tsdf runs configs[1] (a
 Rank 0 prints ONE JSON line (metric/value/... + "roofline" + "cpu_baseline").
 N > 1: one process per GPU, static chunk-range partition of ONE stream (slabs of the key x + y + z) -- every
 rank sees every frame, selects / integrates / meshes / textures only the chunks of its slab ("strong"
-scaling); the ranks all-gather the chunks of their ghost bands over RCCL.
+scaling); the ranks exchange the chunks of their ghost bands over RCCL.
 """
 from __future__ import annotations
 
@@ -46,30 +59,65 @@ def parse():
     ap.add_argument("--hires", action="store_true", help="1280x960 camera (configs[3])")
     ap.add_argument("--scene", choices=("room", "big"), default="room",
                     help="room = S-room 4x3x4 m; big = 8x6x8 m hall, walls at 3-4 m (configs[3] HBM stress)")
-    ap.add_argument("--unique-frames", type=int, default=200, help="distinct frames of the orbit kept in HBM")
-    ap.add_argument("--exchange-every", type=int, default=40, help="N>1, --mode tsdf: boundary all-gather period (frames)")
+    ap.add_argument("--unique-frames", type=int, default=200, help="frames of one camera orbit (distinct host / HBM images)")
+    ap.add_argument("--no-preroll", action="store_true", help="start the warm-up on an empty volume (lighter frames)")
+    ap.add_argument("--resident-headline", action="store_true",
+                    help="report the HBM-resident rate (no H2D) as `value` instead of the host-frames rate")
+    ap.add_argument("--exchange-every", type=int, default=40, help="N>1, --mode tsdf: boundary exchange period (frames)")
     ap.add_argument("--exchange-cap", type=int, default=1024,
-                    help="N>1: records per rank of the fixed-capacity boundary all-gather (8 KiB each)")
+                    help="N>1: records per rank of the fixed-capacity boundary exchange (8 KiB each)")
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-warmup", type=int, default=24, help="untimed frames that build up the CPU baseline's volume")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the reference's parallel_for policy")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
-                    help="skip the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE) that fill roofline.traffic")
-    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the workload only, run under rocprofv3
-    ap.add_argument("--pmc-steps", type=int, default=40, help="frames of each counter pass")
-    ap.add_argument("--no-host-path", action="store_true", help="skip the host-frames (H2D per frame) measurement")
+                    help="skip the rocprofv3 child passes (kernel trace, FETCH_SIZE, WRITE_SIZE)")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # the timed workload only, run under rocprofv3
     ap.add_argument("--no-group", action="store_true", help="skip the keyframe-group (1 colour + 6 depth frames) measurement")
     ap.add_argument("--force-exchange", action="store_true",
-                    help="run the N>1 code path (partition + boundary all-gather) even with one rank (smoke test)")
+                    help="run the N>1 code path (partition + boundary exchange) even with one rank (smoke test)")
     return ap.parse_args()
 
 
-def make_frame(k, cam, args):
+# ---------------------------------------------------------------------------------------------------------
+# the synthetic stream: generated once per parameter set, kept in /tmp so that the profiler child passes (and a
+# second run on the same box) load it instead of generating it again
+# ---------------------------------------------------------------------------------------------------------
+def load_stream(args, cam):
     from texturefusion_amd import synth
-    if args.scene == "big":
-        return synth.room_frame(k, cam, half=(4.0, 3.0, 4.0), radius=0.5, with_quality=False)
-    return synth.room_frame(k, cam, with_quality=False)
+    n = args.unique_frames
+    key = "%s_%dx%d_%d" % (args.scene, cam.width, cam.height, n)
+    base = os.path.join("/tmp", "tf_bench_stream_" + key)
+    names = [base + suf for suf in ("_depth.npy", "_rgba.npy", "_pose.npy")]
+    try:
+        if all(os.path.exists(f) for f in names):
+            depth, rgba, pose = (np.load(f) for f in names)
+            if depth.shape == (n, cam.height, cam.width) and rgba.shape == (n, cam.height, cam.width, 4):
+                return depth, rgba, pose
+    except Exception:
+        pass
+    depth = np.empty((n, cam.height, cam.width), np.float32)
+    rgba = np.empty((n, cam.height, cam.width, 4), np.uint8)
+    pose = np.empty((n, 3, 4), np.float32)
+    for k in range(n):
+        if args.scene == "big":
+            f = synth.room_frame(k, cam, half=(4.0, 3.0, 4.0), radius=0.5, with_quality=False)
+        else:
+            f = synth.room_frame(k, cam, with_quality=False)
+        depth[k], rgba[k], pose[k] = f[0], f[1], np.asarray(f[3], np.float32).reshape(3, 4)
+    try:
+        for f, a in zip(names, (depth, rgba, pose)):
+            tmp = f + ".%d.tmp.npy" % os.getpid()
+            np.save(tmp, a)
+            os.replace(tmp, f)
+    except Exception:
+        pass
+    return depth, rgba, pose
+
+
+def under_profiler():
+    pre = os.environ.get("LD_PRELOAD", "")
+    return "rocprof" in pre or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
 
 
 def main():
@@ -82,13 +130,17 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
-    if args.pmc_child:
-        args.no_roofline = args.no_host_path = args.no_group = True
+    from texturefusion_amd import synth
+    cam = synth.Camera.hires() if args.hires else synth.Camera()
+    h_depth, h_rgba, h_pose = load_stream(args, cam)  # CPU only: before the child passes, before any GPU use
+
+    if args.child:
+        args.no_roofline = args.no_group = True
         args.cpu_frames = 0
-    # HBM-traffic counters first, in child processes, before this process touches the GPU
-    traffic = None
-    if world == 1 and not (args.no_pmc or args.pmc_child or args.no_roofline or args.force_exchange):
-        traffic = pmc_traffic(args)
+    # profiler child passes first, before this process touches the GPU
+    prof_child = None
+    if world == 1 and not (args.no_pmc or args.child or args.no_roofline or args.force_exchange):
+        prof_child = {"error": "running under a profiler"} if under_profiler() else child_passes(args)
 
     import torch  # plumbing: device memory for the frames, barrier/collectives, device sync
     import torch.distributed as dist
@@ -107,21 +159,19 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from texturefusion_amd import capi, synth
+    from texturefusion_amd import capi
     from texturefusion_amd import partition as part
 
-    cam = synth.Camera.hires() if args.hires else synth.Camera()
     res = np.float32(args.res)
     K, Wm = args.steps, args.warmup
-    n_unique = max(1, min(args.unique_frames, 3 * K + Wm + 4))
+    ORBIT = n_unique = args.unique_frames
     textured = args.mode == "textured"
 
-    # ---- synthetic stream, generated once and parked in HBM -------------------------------
-    frames = [make_frame(k, cam, args) for k in range(n_unique)]
-    d_depth = [torch.from_numpy(f[0]).to(dev) for f in frames]
-    d_rgba = [torch.from_numpy(f[1]).to(dev) for f in frames]
-    poses = np.stack([f[3].reshape(12) for f in frames]).astype(np.float32)
-    pinv = np.stack([synth.pose_inverse16(f[3]) for f in frames]).astype(np.float32)
+    # ---- the stream once more in HBM (pre-roll, resident / event / replay passes) -------------
+    d_depth = [torch.from_numpy(h_depth[k]).to(dev) for k in range(n_unique)]
+    d_rgba = [torch.from_numpy(h_rgba[k]).to(dev) for k in range(n_unique)]
+    poses = h_pose.reshape(n_unique, 12).astype(np.float32)
+    pinv = np.stack([synth.pose_inverse16(h_pose[k]) for k in range(n_unique)]).astype(np.float32)
     torch.cuda.synchronize()
 
     s_main = torch.cuda.Stream(device=dev) if multi else None
@@ -129,6 +179,7 @@ def main():
     vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
                       max_coarse=1 << 22 if big else 1 << 20, device=local_rank,
                       stream=s_main.cuda_stream if multi else None)
+    use_rccl = False
     if multi:
         # Ownership key x + y + z: axis-aligned walls and floors are cut diagonally, so no rank holds a
         # whole wall.  Slab edges split the chunk keys of eight sample frames spread over the orbit into
@@ -136,10 +187,9 @@ def main():
         # nothing has to be communicated.
         axis = (1, 1, 1)
         keys = []
-        for i in range(0, 200, 25):
-            f = frames[i % n_unique] if i < n_unique else make_frame(i, cam, args)
-            vol.frame_upload(f[0], None, None)
-            ids_s, _ = vol.prepare(f[3])
+        for i in range(0, ORBIT, max(1, ORBIT // 8)):
+            vol.frame_upload(h_depth[i], None, None)
+            ids_s, _ = vol.prepare(h_pose[i])
             keys.append(part.key_of(ids_s, axis))
         vol.reset()
         edges = part.balanced_edges(np.concatenate(keys), max(world, 2) if args.force_exchange and world == 1 else world)
@@ -147,7 +197,7 @@ def main():
         if args.force_exchange and world == 1:
             lo, hi = edges[1] - 12, edges[1] + 12  # a real interior slab so that faces exist and get packed
         vol.set_partition(lo, hi, axis)
-        # The collective: ONE fixed-capacity all-gather of [count | records] blocks, no host round trip.
+        # The exchange: fixed-capacity [count | records] blocks, no host round trip.
         # backend nccl: RCCL inside the library (tf_comm_init / tf_exchange_boundary) on the volume's stream;
         # other backends (test hook: several ranks on one GPU over gloo): the same blocks through torch.distributed.
         cap = args.exchange_cap
@@ -176,8 +226,8 @@ def main():
             vol.boundary_unpack_blocks(allb.data_ptr(), max(world, 1), rank, cap, join_dirty=join_dirty)
 
     def run(first, count, ahead=2):
-        """Frames [first, first+count) of the stream (cyclic over the unique frames); the next `ahead` frames go
-        through their selection stages too, so that a following run(first + count, ...) starts primed."""
+        """Frames [first, first+count) of the stream (cyclic over the orbit), images already in HBM; the next `ahead`
+        frames go through their selection stages too, so that a following run(first + count, ...) starts primed."""
         idx = [(first + i) % n_unique for i in range(count + ahead)]
         dd = [d_depth[i].data_ptr() for i in idx]
         dr = [d_rgba[i].data_ptr() for i in idx]
@@ -203,42 +253,100 @@ def main():
                 else:
                     torch_exchange(False)
 
+    # host frames: the reference's calling convention.  Every rank of an N > 1 run is handed every frame.
+    host_ok = (not multi) or (use_rccl and textured)
+
+    def run_host(first, count):
+        """Frames [first, first+count) as HOST images, one tf_integrate_frame_host call per frame (staging copy into
+        pinned memory + H2D inside).  The entry point runs two frames behind the caller (its launch for frame f carries
+        the voxel update of f - 2 next to the selection stages of f - 1 and f), so `count` calls put `count` frames'
+        H2D copies and `count` frames' kernels on the device."""
+        for j in range(count):
+            i = (first + j) % n_unique
+            vol.integrate_frame_host(h_depth[i], h_rgba[i], poses[i], pinv[i] if textured else None, first + j)
+
     def barrier():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warm-up, then the timed region (the launch pipeline stays primed across the boundary) ---
-    run(0, Wm)
-    vol.sync()
-    barrier()
-    t0 = time.perf_counter()
-    run(Wm, K)
-    t_enq = time.perf_counter() - t0  # host time to enqueue the timed region (launches are asynchronous)
-    barrier()
-    dt = time.perf_counter() - t0
-    vol.sync()  # surfaces any device-side capacity error of the timed region
+    # ---- pre-roll (one orbit, untimed), warm-up, then the timed region --------------------------
+    pos = 0
+    if not args.no_preroll:
+        run(0, ORBIT)
+        pos = ORBIT
+    p0 = pos + Wm  # stream position of the timed window; p0 % ORBIT = its orbit position
+    use_host = host_ok and not args.resident_headline
+    if use_host:
+        run_host(pos, Wm)  # (leaves the entry point's two-frame pipeline primed)
+        barrier()
+        t0 = time.perf_counter()
+        run_host(p0, K)
+        t_enq = time.perf_counter() - t0
+        barrier()
+        dt = time.perf_counter() - t0
+    else:
+        run(pos, Wm)
+        vol.sync()
+        barrier()
+        t0 = time.perf_counter()
+        run(p0, K)
+        t_enq = time.perf_counter() - t0  # host time to enqueue the timed region (launches are asynchronous)
+        barrier()
+        dt = time.perf_counter() - t0
+    vol.sync()  # brings the deferred frames onto the stream; surfaces any device-side capacity error
+    pos = p0 + K
     if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if args.child:  # profiler child pass: the workload above is all there is
+        vol.close()
+        return
 
-    # ---- instrumented repeat of the next K frames: HIP events (on the handle's stream) around every
-    # kernel of the step.  Kept out of the timed region above because the event pairs cost throughput;
-    # the per-launch durations are what the roofline needs.
+    def skip_to_window():
+        """advance the stream (untimed, resident frames) to the timed window's orbit position in the next turn"""
+        nonlocal pos
+        nxt = pos + ((p0 - pos) % ORBIT)
+        if nxt > pos:
+            run(pos, nxt - pos)
+        pos = nxt
+
+    # ---- the same orbit positions with the frames already in HBM --------------------------------
+    resident = None
+    if use_host and not multi:
+        skip_to_window()
+        vol.sync()
+        barrier()
+        t1 = time.perf_counter()
+        run(pos, K)
+        barrier()
+        dt_res = time.perf_counter() - t1
+        vol.sync()
+        pos += K
+        resident = {"value": K / dt_res, "unit": "frames/s", "ms_per_step": 1e3 * dt_res / K,
+                    "note": "tf_stream_frames_textured_device on the same %d orbit positions one turn later: images "
+                            "already in HBM, no H2D, one call for all frames" % K}
+
+    # ---- the same positions again: HIP events (on the handle's stream) around every launch of a step --------
     prof = None
     dt_instr = None
+    pair_us = None
     kinds = STEP_KERNELS if textured else ("integrate",)
     if not args.no_roofline and not multi:
+        pair_us = vol.profile_calibrate(200)
+        skip_to_window()
+        vol.sync()
         vol.profile_enable(kinds)
         barrier()
         t1 = time.perf_counter()
-        run(Wm + K, K)
+        run(pos, K)
         barrier()
         dt_instr = time.perf_counter() - t1
         prof = vol.profile_get(reset=True)
         vol.profile_enable([])
         vol.sync()
+        pos += K
 
     what = ("TSDF integrate + mesh + atlas update per frame (BASELINE.json configs[%d])" % (4 if world > 1 else (3 if args.hires or big else 2))
             if textured else "TSDF integrate, atlas off (BASELINE.json configs[%d])" % (4 if world > 1 else (3 if args.hires or big else 1)))
@@ -259,37 +367,39 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "%s orbit stream, %dx%d RGB-D, %.0f mm voxels, 8^3 chunks, %s; frames resident in HBM"
-                        % ("S-hall 8x6x8 m" if big else "S-room 4x3x4 m", cam.width, cam.height, 1e3 * float(res), what),
-            "frames_in_hbm": n_unique,
+            "workload": "%s orbit stream, %dx%d RGB-D, %.0f mm voxels, 8^3 chunks, %s; %s"
+                        % ("S-hall 8x6x8 m" if big else "S-room 4x3x4 m", cam.width, cam.height, 1e3 * float(res), what,
+                           "frames handed over as host images, staging + H2D copy (%.2f MB per frame) inside the timed region"
+                           % (8e-6 * cam.width * cam.height) if use_host else "frames resident in HBM"),
+            "h2d_in_timed_region": bool(use_host),
+            "frames_per_orbit": ORBIT,
+            "preroll_frames": 0 if args.no_preroll else ORBIT,
+            "timed_window": {"first_frame": p0, "orbit_position": p0 % ORBIT, "frames": K},
             "parallelism": ("1 GPU" if world == 1 else
-                            "%d ranks, chunk-range slabs of the key x+y+z of one stream; one fixed-capacity RCCL all-gather "
+                            "%d ranks, chunk-range slabs of the key x+y+z of one stream; one fixed-capacity RCCL exchange "
                             "(%d records of 8 KiB per rank) of the updated ghost-band chunks %s"
                             % (world, args.exchange_cap,
                                "after every voxel update, ahead of the mesher" if textured else
                                "every %d frames" % args.exchange_every)),
         },
     }
+    if resident is not None:
+        out["resident"] = resident
 
     # ---- roofline over ALL kernels of a step ------------------------------------------------
     if rank == 0 and prof is not None and not multi:
-        out["roofline"] = roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, poses, pinv, textured,
-                                   dt_instr)
-        if traffic is not None and "bytes_per_step" in traffic:
-            out["roofline"]["traffic"] = traffic["bytes_per_step"]
-        out["roofline"]["traffic_detail"] = traffic
-
-    # ---- the drop-in per-frame path: host images in, one call per frame (H2D included) ---------
-    if rank == 0 and not multi and not args.no_host_path:
-        out["host_frames"] = host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique)
+        skip_to_window()
+        out["roofline"] = roofline(args, vol, cam, prof, kinds, K, pos, n_unique, d_depth, d_rgba, poses, pinv, textured,
+                                   dt_instr, pair_us, prof_child, 1e3 * dt / K)
+        pos += K
 
     # ---- the keyframe-group flow of TSDFFusion: 1 colour + 6 depth-only frames over one chunk list -------
-    if rank == 0 and not multi and not args.no_group and not args.no_host_path:
-        out["keyframe_group"] = keyframe_group(args, cam, res, frames, d_depth, d_rgba, poses, n_unique, local_rank)
+    if rank == 0 and not multi and not args.no_group and not args.no_roofline:
+        out["keyframe_group"] = keyframe_group(args, cam, res, d_depth, d_rgba, poses, n_unique, local_rank)
 
     # ---- CPU baseline: the oracle (C port of the reference path) on the host cores ------------
     if rank == 0 and world == 1 and args.cpu_frames > 0:  # (rank 0 at N = 1 only)
-        out["cpu_baseline"] = cpu_baseline(args, cam, res, frames, n_unique, textured)
+        out["cpu_baseline"] = cpu_baseline(args, cam, res, h_depth, h_rgba, h_pose, n_unique, textured)
 
     if rank == 0:
         print(json.dumps(out))
@@ -298,22 +408,25 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, poses, pinv, textured, dt_instr):
-    """Algorithmic bytes of a step / summed kernel time of a step (HIP events of this run).
+def roofline(args, vol, cam, prof, kinds, K, first, n_unique, d_depth, d_rgba, poses, pinv, textured, dt_instr, pair_us,
+             prof_child, wall_us):
+    """Algorithmic bytes of a step / summed kernel time of a step.
 
-    Bytes: voxel update 128 B per rewritten TSDF row + 128 B per rewritten colour
-    row + one read of the depth and RGBA images; meshing 4 KiB (the chunk's own sdf/weight plane) per dirty
-    chunk + 6552 B (the 11^3 - 8^3 halo voxels) per chunk that yields a mesh + 8 B colour read and 36 B written
-    per vertex + 6 B per triangle; atlas 44 B per projected vertex (24 read, 20 written) + 3 B read and 3 B
-    written per ROI pixel.  The integer counts depend only on the stream: the instrumented frames are replayed
-    one by one (untimed) and the exact integers read back after each."""
-    idx = [(Wm + 2 * K + i) % n_unique for i in range(K)]
+    Bytes = what the DEVICE algorithm has to move: voxel update 128 B per rewritten
+    TSDF row + 128 B per rewritten colour row + one read of the depth and RGBA images; meshing 32 B of class summaries
+    per dirty chunk (its own and its seven +x/+y/+z neighbours' words) + 4 KiB (the chunk's own sdf/weight plane) per
+    chunk the summaries cannot rule out + 6552 B (the 11^3 - 8^3 halo voxels) per chunk handed to marching cubes + 8 B
+    colour read and 36 B written per vertex + 6 B per triangle; atlas 44 B per projected vertex (24 read, 20 written)
+    + 3 B read and 3 B written per ROI pixel.  The integer counts are read back frame by frame in an untimed replay of
+    the timed window's orbit positions (steady state: the same work as the timed frames one turn earlier).
+
+    Kernel time: the profiler's own durations of the timed window's launches when the rocprofv3 --kernel-trace child
+    pass ran (the same command, the same frames); otherwise the HIP-event times of the event pass minus the calibrated
+    cost of an event pair around an empty launch."""
     b_tsdf = b_mesh = b_atlas = 0
-    cnt = dict(sel=0, upd=0, dirty=0, meshes=0, verts=0, tris=0, roi=0, patches=0)
-    first = Wm + 2 * K
-    for j, i in enumerate(idx):
-        i1, i2 = (first + j + 1) % n_unique, (first + j + 2) % n_unique
-        sub = [i, i1, i2]
+    cnt = dict(sel=0, upd=0, dirty=0, exact=0, survivors=0, meshes=0, verts=0, tris=0, roi=0, patches=0)
+    for j in range(K):
+        sub = [(first + j + q) % n_unique for q in range(3)]
         dd = [d_depth[q].data_ptr() for q in sub]
         dr = [d_rgba[q].data_ptr() for q in sub]
         if textured:
@@ -326,57 +439,103 @@ def roofline(args, vol, cam, prof, kinds, K, Wm, n_unique, d_depth, d_rgba, pose
         cnt["upd"] += st.n_updated
         if textured:
             ts = vol.texture_stats()
-            b_mesh += 4096 * ts.n_dirty + 6552 * ts.n_meshes + 44 * ts.n_vertices + 6 * ts.n_triangles
+            b_mesh += 32 * ts.n_dirty + 4096 * ts.n_exact + 6552 * ts.n_survivors + 44 * ts.n_vertices + 6 * ts.n_triangles
             b_atlas += 44 * ts.n_vertices + 6 * ts.roi_pixels
-            for k, v in (("dirty", ts.n_dirty), ("meshes", ts.n_meshes), ("verts", ts.n_vertices),
-                         ("tris", ts.n_triangles), ("roi", ts.roi_pixels), ("patches", ts.n_patches)):
+            for k, v in (("dirty", ts.n_dirty), ("exact", ts.n_exact), ("survivors", ts.n_survivors), ("meshes", ts.n_meshes),
+                         ("verts", ts.n_vertices), ("tris", ts.n_triangles), ("roi", ts.roi_pixels), ("patches", ts.n_patches)):
                 cnt[k] += v
-    per_kernel = {}
-    t_step = 0.0
+    # event pass: per kind, raw and with the empty-pair cost taken off every launch
+    ev = {}
     for k in kinds:
         ms, n = prof[k]
         if n:
-            per_kernel[k] = {"us_per_step": 1e3 * ms / K, "launches_per_step": n / K}
-            t_step += 1e-3 * ms / K
+            ev[k] = {"event_us_per_step": 1e3 * ms / K, "launches_per_step": n / K,
+                     "event_us_minus_pair": max(0.0, 1e3 * ms / K - pair_us * n / K)}
+    t_events = sum(v["event_us_minus_pair"] for v in ev.values())
     bytes_step = (b_tsdf + b_mesh + b_atlas) / K
-    achieved = bytes_step / t_step / 1e9 if t_step > 0 else 0.0
-    group = {"integrate": b_tsdf / K, "mesh": b_mesh / K, "patch_project": b_atlas / K}
-    for k, b in group.items():
-        if k in per_kernel and per_kernel[k]["us_per_step"] > 0:
-            per_kernel[k]["algorithmic_bytes_per_step"] = b
-            per_kernel[k]["achieved_GBs"] = b / per_kernel[k]["us_per_step"] / 1e3
-    return {
+    # the patch stage of frame f - 1 runs inside the launch of frame f's voxel update: their bytes share its time
+    groups = {"k_frame": (b_tsdf + b_atlas) / K, "mesh": b_mesh / K} if textured else {"k_frame": b_tsdf / K}
+    trace = (prof_child or {}).get("trace")
+    kern = {}
+    if trace and "kernels" in trace:
+        t_step = trace["us_per_step"]
+        source = "rocprofv3 --kernel-trace child pass of this command: durations of the timed window's launches"
+        for name, v in trace["kernels"].items():
+            kern[name] = dict(v)
+        t_kframe = sum(v["us_per_step"] for n, v in trace["kernels"].items() if n.startswith("k_frame") or n.startswith("k_patch"))
+        t_mesh = sum(v["us_per_step"] for n, v in trace["kernels"].items() if n.startswith("k_mesh") or n.startswith("k_dirty"))
+    else:
+        t_step = t_events
+        source = ("HIP events around every launch of the event pass minus %.2f us per launch (an event pair around an "
+                  "empty launch)" % pair_us)
+        t_kframe = sum(ev[k]["event_us_minus_pair"] for k in ("integrate", "patch_project", "patch_rank") if k in ev)
+        t_mesh = sum(ev[k]["event_us_minus_pair"] for k in ("dirty", "mesh") if k in ev)
+    achieved = bytes_step / t_step / 1e3 if t_step > 0 else 0.0
+    per_group = {"k_frame (+ k_patch launches)": {"us_per_step": t_kframe, "algorithmic_bytes_per_step": groups["k_frame"],
+                                                  "achieved_GBs": groups["k_frame"] / t_kframe / 1e3 if t_kframe else 0.0}}
+    if textured:
+        per_group["k_dirty_frame + k_mesh_filter + k_mesh"] = {
+            "us_per_step": t_mesh, "algorithmic_bytes_per_step": groups["mesh"],
+            "achieved_GBs": groups["mesh"] / t_mesh / 1e3 if t_mesh else 0.0}
+    r = {
         "bound": "hbm",
-        "kernel": ("all kernels of a step: k_frame (K-A + K-C + K-B roles), k_dirty_frame, k_mesh_filter + k_mesh, "
-                   "k_patch (adjacency exchange + slot ranks + project + blit)" if textured else
+        "kernel": ("all kernels of a step: k_frame (voxel update of frame f + patch stage of frame f-1 + selection of f+1, f+2), "
+                   "k_dirty_frame, k_mesh_filter, k_mesh" if textured else
                    "k_frame<color> = K-A(f) + K-C(f+1) + K-B(f+2) block ranges"),
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,  # filled from the --pmc child passes of this run (pmc_traffic), stays null without them
-        "algorithmic_bytes_per_step": bytes_step, "kernel_us_per_step": 1e6 * t_step,
-        "kernels": per_kernel,
-        "instrumented_ms_per_step": 1e3 * dt_instr / K,
+        "traffic": None,  # filled from the --pmc child passes of this run, stays null without them
+        "algorithmic_bytes_per_step": bytes_step, "kernel_us_per_step": t_step, "kernel_time_source": source,
+        "wall_us_per_step": wall_us,
+        "groups": per_group,
+        "kernels": kern,
+        "events": {"pair_us": pair_us, "kernel_us_per_step_minus_pair": t_events, "instrumented_ms_per_step": 1e3 * dt_instr / K,
+                   "kinds": ev},
         "per_step": {k: v / K for k, v in cnt.items()},
+        "windows": "timed, resident, event and replay passes cover the same %d orbit positions in consecutive turns of a "
+                   "steady-state volume; the profiler child passes run the timed window itself" % K,
     }
+    pmc = (prof_child or {}).get("pmc")
+    if pmc and "bytes_per_step" in pmc:
+        r["traffic"] = pmc["bytes_per_step"]
+    r["traffic_detail"] = pmc if pmc else ({"error": prof_child["error"]} if prof_child and "error" in prof_child else None)
+    return r
 
 
-# rocprofv3 kernel names of one step (one launch each per frame)
-PMC_STEP_KERNELS = {"textured": ("k_frame<true>", "k_dirty_frame", "k_mesh_filter", "k_mesh<128>",
-                                 "k_patch<true, true, true>"),
-                    "tsdf": ("k_frame<true>",)}
 # profiles/r2/README.md (tools/calib_fetch on this box type): both counters are in KiB; WRITE_SIZE is exact;
 # FETCH_SIZE reads exactly 1/2 of the bytes for every read shape the kernels use (4/8/16 B per lane streams,
 # scattered 4-KiB blocks, 4-B gathers: 128-B requests tallied as 64 B), as MI355X_MICROARCH.md states for 16 B/lane.
 PMC_BYTES = {"FETCH_SIZE": 2048.0, "WRITE_SIZE": 1024.0}
 
 
-def pmc_traffic(args):
-    """HBM-side bytes per step of the same workload from the L2's fabric counters: one rocprofv3 --pmc pass per
-    counter (they do not fit one pass), no trace domain in the same run, the program itself behind "--"
-    (MI355X_MICROARCH.md, HBM / PMC sections).  Returns None when rocprofv3 is missing, else a dict; on any
-    failure the dict carries "error" and no "bytes_per_step" (roofline.traffic stays null -- never a constant)."""
+def _kernel_name(raw):
+    import re
+    name = re.sub(r"^void ", "", raw)
+    name = re.sub(r"\(.*$", "", name).replace("tf::", "").strip()
+    return name
+
+
+def _window(rows, first_frame, K):
+    """rows: (dispatch id, kernel name, value) of one child pass.  The step launches of frame f start at the f-th
+    launch of a k_frame instance that carries a colour voxel update (k_frame<true, *>; the selection-only launches of
+    a pipeline fill are the depth-only instance).  Returns the rows between the launch of frame `first_frame` and the
+    launch of frame `first_frame + K`."""
+    rows = sorted(rows)
+    starts = [d for d, n, _ in rows if n.startswith("k_frame<true")]
+    if len(starts) < first_frame + K:
+        return None
+    lo = starts[first_frame]
+    hi = starts[first_frame + K] if len(starts) > first_frame + K else rows[-1][0] + 1
+    return [(d, n, v) for d, n, v in rows if lo <= d < hi]
+
+
+def child_passes(args):
+    """The same command (pre-roll, warm-up, K host frames) three more times as child processes under rocprofv3, before
+    this process touches the GPU: one --kernel-trace pass (kernel durations) and one --pmc pass each for FETCH_SIZE and
+    WRITE_SIZE (they do not fit one pass; no trace domain in a counter pass; the program itself behind "--":
+    MI355X_MICROARCH.md, HBM / PMC sections).  From each the launches of the timed window are sliced out.  Returns None
+    when rocprofv3 is missing; a failing pass leaves "error" in its part -- never a constant."""
     import csv
     import glob
-    import re
     import shutil
     import subprocess
     import tempfile
@@ -384,81 +543,86 @@ def pmc_traffic(args):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None
-    want = PMC_STEP_KERNELS[args.mode]
-    Wc, Kc = 10, args.pmc_steps
-    per_kernel = {k: {} for k in want}
-    tmp = tempfile.mkdtemp(prefix="tf_pmc_", dir="/tmp")
+    K, Wm = args.steps, args.warmup
+    pre = 0 if args.no_preroll else args.unique_frames
+    # the host entry point runs two frames behind: the launches inside the parent's timed region are those of the
+    # frames [pre + Wm - 2, pre + Wm + K - 2) of the stream
+    first = max(0, pre + Wm - (0 if args.resident_headline else 2))
+    base_cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--child", "--steps", str(K), "--warmup", str(Wm),
+                "--mode", args.mode, "--scene", args.scene, "--res", repr(args.res), "--unique-frames", str(args.unique_frames)]
+    base_cmd += (["--hires"] if args.hires else []) + (["--no-preroll"] if args.no_preroll else [])
+    base_cmd += ["--resident-headline"] if args.resident_headline else []
+    if args.mode != "textured":
+        return {"error": "child passes are sliced by the textured stream's launches"}
+    tmp = tempfile.mkdtemp(prefix="tf_prof_", dir="/tmp")
+    out = {}
+
+    def run_pass(tag, flags, pattern, col_name, col_val, want_counter=None):
+        d = os.path.join(tmp, tag)
+        cmd = [exe] + flags + ["--output-format", "csv", "-d", d, "-o", "t", "--"] + base_cmd
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=400)
+        files = glob.glob(os.path.join(d, "**", pattern), recursive=True)
+        if r.returncode != 0 or not files:
+            return "rocprofv3 %s: rc %d, %d csv: %s" % (tag, r.returncode, len(files), r.stderr[-300:])
+        rows = []
+        for f in files:
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    if want_counter and row.get("Counter_Name") != want_counter:
+                        continue
+                    rows.append((int(row["Dispatch_Id"]), _kernel_name(row[col_name]), col_val(row)))
+        return rows
+
     try:
+        rows = run_pass("trace", ["--kernel-trace"], "*kernel_trace.csv", "Kernel_Name",
+                        lambda r: 1e-3 * (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        if isinstance(rows, str):
+            out["trace"] = {"error": rows}
+        else:
+            win = _window(rows, first, K)
+            if win is None:
+                out["trace"] = {"error": "fewer k_frame launches than frames in the kernel trace"}
+            else:
+                per = {}
+                for _, n, v in win:
+                    e = per.setdefault(n, {"us_per_step": 0.0, "launches_per_step": 0.0})
+                    e["us_per_step"] += v / K
+                    e["launches_per_step"] += 1.0 / K
+                out["trace"] = {"kernels": per, "us_per_step": sum(e["us_per_step"] for e in per.values()),
+                                "frames": [first, first + K]}
+        pmc = {"kernels": {}}
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "t", "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", str(Kc), "--warmup", str(Wc),
-                   "--mode", args.mode, "--scene", args.scene, "--res", repr(args.res),
-                   "--unique-frames", str(args.unique_frames)] + (["--hires"] if args.hires else [])
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=150)
-            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return {"error": "rocprofv3 --pmc %s: rc %d, %d csv: %s" % (counter, r.returncode, len(files), r.stderr[-300:])}
-            rows = {k: [] for k in want}
-            for f in files:
-                with open(f) as fh:
-                    for row in csv.DictReader(fh):
-                        if row.get("Counter_Name") != counter:
-                            continue
-                        name = re.sub(r"^void ", "", row["Kernel_Name"])
-                        name = re.sub(r"\(.*$", "", name).replace("tf::", "").strip()
-                        name = re.sub(r"^k_mesh_filter<\w+>$", "k_mesh_filter", name)  # (two forms of one stage)
-                        if name in rows:
-                            rows[name].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
-            for k in want:
-                v = [c for _, c in sorted(rows[k])][Wc:]  # launches behind the warm-up frames
-                if not v:
-                    return {"error": "no %s samples of %s" % (counter, k)}
-                per_kernel[k][counter] = PMC_BYTES[counter] * sum(v) / len(v)
-                per_kernel[k]["launches"] = len(v)
-    except Exception as e:  # a counter pass must never take the benchmark down
-        return {"error": "%s: %s" % (type(e).__name__, e)}
+            rows = run_pass(counter, ["--pmc", counter], "*counter_collection.csv", "Kernel_Name",
+                            lambda r: float(r["Counter_Value"]), want_counter=counter)
+            if isinstance(rows, str):
+                pmc = {"error": rows}
+                break
+            win = _window(rows, first, K)
+            if win is None:
+                pmc = {"error": "fewer k_frame launches than frames in the %s pass" % counter}
+                break
+            for _, n, v in win:
+                e = pmc["kernels"].setdefault(n, {})
+                e[counter] = e.get(counter, 0.0) + PMC_BYTES[counter] * v / K
+        if "kernels" in pmc:
+            for e in pmc["kernels"].values():
+                e["bytes_per_step"] = e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0)
+            pmc["bytes_per_step"] = sum(e["bytes_per_step"] for e in pmc["kernels"].values())
+            pmc["frames"] = [first, first + K]
+            pmc["how"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this command; the launches of the "
+                          "timed window (frames %d..%d of the stream) summed per kernel and divided by %d steps; bytes = "
+                          "2048 x FETCH_SIZE + 1024 x WRITE_SIZE (KiB units; FETCH_SIZE counts 128-B requests as 64 B on "
+                          "gfx950 -- calibration in profiles/r2/README.md); L2-miss traffic: Infinity-Cache hits are included"
+                          % (first, first + K - 1, K))
+        out["pmc"] = pmc
+    except Exception as e:  # a profiler pass must never take the benchmark down
+        out.setdefault("pmc", {"error": "%s: %s" % (type(e).__name__, e)})
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    for k in want:
-        per_kernel[k]["bytes_per_launch"] = per_kernel[k]["FETCH_SIZE"] + per_kernel[k]["WRITE_SIZE"]
-    return {"bytes_per_step": sum(v["bytes_per_launch"] for v in per_kernel.values()),
-            "kernels": per_kernel,
-            "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this command (%d frames each behind %d "
-                   "warm-up frames), bytes = 2048 x FETCH_SIZE + 1024 x WRITE_SIZE per launch (KiB units; FETCH_SIZE counts "
-                   "128-B requests as 64 B on gfx950 -- calibration in profiles/r2/README.md), one launch of each kernel per step; "
-                   "L2-miss traffic: Infinity-Cache hits are included" % (Kc, Wc)}
+    return out
 
 
-def host_path(args, vol, frames, poses, pinv, textured, Wm, K, n_unique):
-    """The reference's calling convention: one call per frame with HOST images (MobileFusion::IntegrateFrame,
-    GCFusion/MobileFusion.cpp:223-250): double-buffered pinned staging, H2D of frame f+1 overlapped with the
-    kernels of frame f.  PCIe-inclusive; never the headline value."""
-    n = min(K, 100)
-    first = Wm + 3 * K
-    idx = [(first + i) % n_unique for i in range(n)]
-    for i in idx[:4]:  # warm the staging path
-        f = frames[i]
-        vol.integrate_frame_host(f[0], f[1], poses[i], pinv[i] if textured else None, i)
-    vol.sync()
-    t0 = time.perf_counter()
-    for j, i in enumerate(idx):
-        f = frames[i]
-        vol.integrate_frame_host(f[0], f[1], poses[i], pinv[i] if textured else None, first + j)
-    t1 = time.perf_counter()
-    vol.sync()
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "frames": n,
-            "host_call_us": 1e6 * (t1 - t0) / n, "drain_ms": 1e3 * (dt - (t1 - t0)),
-            "note": "tf_integrate_frame_host: host depth + RGBA in, staged through pinned memory (helper threads share the "
-                    "copy) and copied H2D (%.1f MB per frame) inside the timed region, one call per frame, one "
-                    "synchronisation at the end.  The entry point runs two frames behind the caller so that a frame's "
-                    "voxel update shares its launch with the selection stages of the next two (any other entry point "
-                    "flushes first).  The source frames are %d distinct host arrays (%.0f MB, not cache-resident)"
-                    % (8e-6 * frames[0][0].size, len(frames), 8e-6 * frames[0][0].size * len(frames))}
-
-
-def keyframe_group(args, cam, res, frames, d_depth, d_rgba, poses, n_unique, device):
+def keyframe_group(args, cam, res, d_depth, d_rgba, poses, n_unique, device):
     """MobileFusion::TSDFFusion's integration loop (GCFusion/MobileFusion.cpp:165-217): PrepareIntersectChunks for the
     keyframe, its depth + colour, then the six local frames depth-only over the SAME list, FinalizeIntegrateChunks.
     Two volumes get the same groups: one integrates the local frames with six tf_integrate calls, the other with one
@@ -505,7 +669,7 @@ def keyframe_group(args, cam, res, frames, d_depth, d_rgba, poses, n_unique, dev
                     "k_pre x 6 + k_integrate_group); selection and finalize are the same on both sides and excluded"}
 
 
-def cpu_baseline(args, cam, res, frames, n_unique, textured):
+def cpu_baseline(args, cam, res, h_depth, h_rgba, h_pose, n_unique, textured):
     """oracle/ timed on a bounded sample of the same workload: --cpu-warmup untimed frames build up the volume
     (meshes need weight > 50), then the next --cpu-frames frames of the stream are timed."""
     from oracle import api as O
@@ -519,11 +683,11 @@ def cpu_baseline(args, cam, res, frames, n_unique, textured):
     ov.set_threads(T)                                                    # groups of >= 1000 items (applied per call inside)
 
     def step(k):
-        f = frames[k % n_unique]
+        i = k % n_unique
         if textured:
-            ov.frame_textured(oa, f[0], f[1], f[3], synth.pose_inverse16(f[3]), k)
+            ov.frame_textured(oa, h_depth[i], h_rgba[i], h_pose[i], synth.pose_inverse16(h_pose[i]), k)
         else:
-            ov.integrate_frame(f[0], f[1], f[3])
+            ov.integrate_frame(h_depth[i], h_rgba[i], h_pose[i])
 
     for k in range(args.cpu_warmup):
         step(k)
@@ -532,12 +696,12 @@ def cpu_baseline(args, cam, res, frames, n_unique, textured):
     for k in range(args.cpu_warmup, args.cpu_warmup + n):
         step(k)
     t_all = time.perf_counter() - t0
-    # TSDF-only figure of the same port (1 thread and the reference policy) on a shorter sample
     out = {
         "value": n / t_all, "unit": "frames/s", "cores": T,
         "kind": "port",
         "sample": "oracle/ C port of the reference path (%s voxel kernel, no FMA; selection scalar, 1 thread; %s) on frames "
-                  "%d..%d of the same stream after %d untimed frames; parallel stages use chisel::parallel_for's policy "
+                  "%d..%d of the same stream after %d untimed frames on an empty volume (lighter than the GPU's steady-state "
+                  "frames: the GPU / CPU ratio is understated); parallel stages use chisel::parallel_for's policy "
                   "(hardware_concurrency - 2 = %d threads, groups of >= 1000 items); host has %d logical cores"
                   % ("AVX2 8-lane" if avx2 else "scalar",
                      "UpdateMeshes parallel, CompressMeshes / GeneratePatches / UpdateAtlas serial as in the reference" if textured
@@ -545,18 +709,16 @@ def cpu_baseline(args, cam, res, frames, n_unique, textured):
                      args.cpu_warmup, args.cpu_warmup + n - 1, args.cpu_warmup, T, ncpu),
         "host_cores": ncpu,
     }
-    if textured:
+    if textured:  # TSDF-only figure of the same port on a shorter sample
         ov1 = O.Volume(res, O.camera_from(cam), O.default_integrator())
         ov1.set_kernel(1 if avx2 else 0)
         ov1.set_threads(T)
         n1 = max(4, n // 4)
         for k in range(4):
-            f = frames[k % n_unique]
-            ov1.integrate_frame(f[0], f[1], f[3])
+            ov1.integrate_frame(h_depth[k % n_unique], h_rgba[k % n_unique], h_pose[k % n_unique])
         t0 = time.perf_counter()
         for k in range(4, 4 + n1):
-            f = frames[k % n_unique]
-            ov1.integrate_frame(f[0], f[1], f[3])
+            ov1.integrate_frame(h_depth[k % n_unique], h_rgba[k % n_unique], h_pose[k % n_unique])
         out["value_tsdf_only"] = n1 / (time.perf_counter() - t0)
     return out
 

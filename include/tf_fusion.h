@@ -89,6 +89,8 @@ typedef struct {
   int64_t roi_pixels;   /* sum of the patches' bounding-box areas */
   int64_t n_patches;    /* patches with an image */
   int64_t n_slots;      /* atlas slots handed out so far */
+  int64_t n_exact;      /* dirty chunks whose own voxels the mesher's filter read (the class summaries ruled out the rest) */
+  int64_t n_survivors;  /* of those, chunks handed to the marching-cubes kernel */
 } tf_texture_stats;
 
 /* Per-kernel timings collected with HIP events on the handle's stream (tf_profile_*). */
@@ -281,6 +283,9 @@ TF_API int tf_compress_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64
  * out of the other launches. */
 TF_API int tf_profile_enable(tf_volume* v, uint32_t kind_mask);
 TF_API int tf_profile_get(tf_volume* v, tf_profile* out, int reset);
+/* What a HIP-event pair around an EMPTY launch reads on the handle's stream (microseconds, mean of n_pairs): the
+ *   floor contained in every per-kernel time of tf_profile_get (launch + marker latency, not kernel work). */
+TF_API int tf_profile_calibrate(tf_volume* v, int32_t n_pairs, double* us_per_pair);
 /* Tuning aid: the raw per-wave timeline table (16 words per wave; words 10..13 = {start, end, role+1,
  * XCC id}, 14..15 = K-A prologue end / first list record loaded, in 100 MHz ticks) of the last
  * fused launch that ran all three roles; filled only while the environment variable TF_KA_DBG has

@@ -315,6 +315,66 @@ def test_fused_textured_stream(gpu_required):
     gv.close()
 
 
+def test_deferred_patch_stage_cannot_be_observed(gpu_required):
+    """The patch stage of a textured frame rides on the NEXT frame's launch (AtlasState::pend_patch).  Whatever looks
+    at patches / atlas / meshes in between sees it done: a download right behind a streaming call that left the stage
+    pending (n_ahead > 0), then host frames (the stage crosses from one entry point to the other), a TSDF-only frame
+    (the stage goes out on its own), and a final comparison -- each against the oracle's state at that point."""
+    cam = synth.Camera()
+    ov, gv, cam, ig = make_pair(RES5, cam, max_chunks=1 << 16)
+    oa = O.Atlas(RES5)
+    n = 8
+    fr = [synth.room_frame(3 * k, cam, with_quality=False) for k in range(n)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in fr]
+    poses = np.stack([f[3].reshape(12) for f in fr])
+    pinv = np.stack([synth.pose_inverse16(f[3]) for f in fr])
+    dd, dr = [b[0].ptr for b in bufs], [b[1].ptr for b in bufs]
+
+    def check(tag):
+        mids = sorted_ids(ov.list_meshes())
+        assert np.array_equal(mids, sorted_ids(gv.list_meshes())), tag
+        g = _compare_patches(ov, gv, mids, tag)
+        used = g["texloc"][g["texloc"] != np.uint64((1 << 64) - 1)]
+        _compare_atlas(oa, gv, oa.hot_range(used))
+        assert gv.atlas_loc_next() == oa.loc_next(), tag
+
+    for k in range(3):
+        ov.frame_textured(oa, fr[k][0], fr[k][1], fr[k][3], pinv[k], 10 + k)
+    gv.stream_frames_textured_device(dd[0:5], dr[0:5], poses[0:5], pinv[0:5], 10, n_ahead=2)  # frame 2's stage stays pending
+    check("behind a streaming call")
+    for k in range(3, 6):  # host frames: deferred two calls, the pending stage crosses the entry points
+        ov.frame_textured(oa, fr[k][0], fr[k][1], fr[k][3], pinv[k], 10 + k)
+        gv.integrate_frame_host(fr[k][0], fr[k][1], fr[k][3], pinv[k], 10 + k)
+    check("behind host frames")
+    ov.integrate_frame(fr[6][0], fr[6][1], fr[6][3])  # a TSDF-only frame between textured ones
+    gv.integrate_frame_host(fr[6][0], fr[6][1], fr[6][3], None, 0)
+    ov.frame_textured(oa, fr[7][0], fr[7][1], fr[7][3], pinv[7], 17)
+    gv.integrate_frame_host(fr[7][0], fr[7][1], fr[7][3], pinv[7], 17)
+    gv.sync()
+    from tests.util import assert_chunks_equal
+    oids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(oids, sorted_ids(gv.list_chunks()))
+    assert_chunks_equal(ov, gv, oids[::11], "deferred patch stage")
+    check("at the end")
+    for a, b in bufs:
+        a.free(); b.free()
+    gv.close()
+
+
+def test_wrongly_sized_host_images_are_rejected(gpu_required):
+    cam = synth.Camera()
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 12)
+    d, rgba, q, pose = synth.wall_frame(1.2, cam, seed=0)
+    with pytest.raises(capi.TFError) as e:
+        gv.integrate_frame_host(d[:100], rgba, pose, None, 0)
+    assert e.value.code == capi.TF_ERR_INVALID
+    with pytest.raises(capi.TFError):
+        gv.integrate_frame_host(d, rgba[:, :320], pose, None, 0)
+    with pytest.raises(capi.TFError):
+        gv.frame_upload(d, rgba[:10])
+    gv.close()
+
+
 def test_fused_stream_atlas_overflow(gpu_required):
     """The fused per-frame unit with an atlas of 2 bands x 4 slots: from the frame whose new patches no longer fit,
     the entries behind the first failing AddPatch (ascending chunk id) are skipped in every frame, exactly as the

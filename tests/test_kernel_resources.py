@@ -14,7 +14,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # kernel name fragment -> (max VGPRs, max scratch bytes per lane)
 BUDGET = {
-    "tf_kernels.hip": {"k_frameILb1E": (72, 0), "k_frameILb0E": (72, 0), "k_integrate_groupILb1E": (96, 0),
+    "tf_kernels.hip": {"k_frameILb1ELb0E": (72, 0), "k_frameILb0ELb0E": (72, 0), "k_frameILb1ELb1E": (80, 40), "k_integrate_groupILb1E": (96, 0),
                        "k_integrate_groupILb0E": (96, 0)},
     # (the filter's two forms -- wave per entry / workgroup batches -- share one kernel: 78 VGPRs, 6 waves per SIMD;
     # forcing 7 or 8 spills, and the measured time does not depend on it: the kernel is a chain of round trips)

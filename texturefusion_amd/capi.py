@@ -35,7 +35,7 @@ SYMBOLS = (
     "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
     "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
-    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
+    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_profile_calibrate", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_set_pose",
     "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_meshes_upload",
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
@@ -73,7 +73,7 @@ class Stats(C.Structure):
 class TextureStats(C.Structure):
     _fields_ = [("n_dirty", C.c_int64), ("n_meshes", C.c_int64), ("n_vertices", C.c_int64),
                 ("n_triangles", C.c_int64), ("roi_pixels", C.c_int64), ("n_patches", C.c_int64),
-                ("n_slots", C.c_int64)]
+                ("n_slots", C.c_int64), ("n_exact", C.c_int64), ("n_survivors", C.c_int64)]
 
 
 class Profile(C.Structure):
@@ -124,6 +124,7 @@ def lib():
     L.tf_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.tf_profile_enable.argtypes = [vp, C.c_uint32]
     L.tf_profile_get.argtypes = [vp, C.POINTER(Profile), C.c_int]
+    L.tf_profile_calibrate.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
     L.tf_debug_phase_raw.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
     L.tf_set_partition.argtypes = [vp, C.c_int32, C.c_int32]
     L.tf_set_partition_key.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
@@ -269,6 +270,8 @@ class Volume:
         depth = _f32(depth)
         rgba = None if rgba is None else np.ascontiguousarray(rgba, np.uint8)
         quality = None if quality is None else _f32(quality)
+        self._check_images(depth, rgba)
+        self._check_images(quality)
         self._keep = (depth, rgba, quality)
         self._ck(self.L.tf_frame_upload(self.h, _p(depth, C.c_float), _p(rgba, C.c_uint8),
                                         _p(quality, C.c_float)))
@@ -349,10 +352,20 @@ class Volume:
         """MobileFusion::IntegrateFrame with host images (asynchronous; pose_inv16 = textured unit)."""
         depth = _f32(depth)
         rgba = None if rgba is None else np.ascontiguousarray(rgba, np.uint8)
+        self._check_images(depth, rgba)
         pose = _f32(pose).reshape(12)
         T = None if pose_inv16 is None else _f32(pose_inv16).reshape(16)
         self._ck(self.L.tf_integrate_frame_host(self.h, _p(depth, C.c_float), _p(rgba, C.c_uint8), _p(pose, C.c_float),
                                                 _p(T, C.c_float), int(frame_id)))
+
+    def _check_images(self, depth, rgba=None):
+        """the C side copies W*H*4 bytes from each pointer: a wrongly sized array is an error here, not an
+        out-of-bounds host read there"""
+        npix = self.cam.width * self.cam.height
+        if depth is not None and depth.size != npix:
+            raise TFError(TF_ERR_INVALID, "depth has %d pixels, the bound camera %dx%d" % (depth.size, self.cam.width, self.cam.height))
+        if rgba is not None and rgba.size != 4 * npix:
+            raise TFError(TF_ERR_INVALID, "rgba has %d bytes, the bound camera needs %d" % (rgba.size, 4 * npix))
 
     def host_frame_buffers(self):
         """numpy views (depth f32[H,W], rgba u8[H,W,4]) of the pinned slot the next integrate_frame_host uploads from."""
@@ -478,6 +491,12 @@ class Volume:
         self._ck(self.L.tf_profile_get(self.h, C.byref(p), int(reset)))
         return {PROF_NAMES[i]: (p.ms[i], p.launches[i]) for i in range(len(PROF_NAMES))}
 
+    def profile_calibrate(self, n_pairs=200):
+        """microseconds a HIP-event pair around an empty launch reads (the floor inside every profile_get time)"""
+        us = C.c_double(0.0)
+        self._ck(self.L.tf_profile_calibrate(self.h, int(n_pairs), C.byref(us)))
+        return us.value
+
     def debug_phase_raw(self):
         out = np.zeros((16384, 16), np.uint64)
         self._ck(self.L.tf_debug_phase_raw(self.h, _p(out, C.c_uint64), out.size))
@@ -534,6 +553,8 @@ class Volume:
         ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
         P = _f32(poses12).reshape(-1, 12)
         keep = [_f32(d) for d in depths]
+        for d in keep:
+            self._check_images(d)
         arr = (C.c_void_p * len(keep))(*[d.ctypes.data for d in keep])
         self._ck(self.L.tf_integrate_depth_group_host(self.h, len(keep), arr, _p(P, C.c_float), _p(ids, C.c_int32), len(ids),
                                                       int(flag), _p(needs, C.c_uint8)))

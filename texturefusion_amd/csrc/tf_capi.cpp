@@ -170,6 +170,17 @@ static int init_device_state(tf_volume* v) {
 
 // The kernels of Chisel::PrepareIntersectChunks (Structure/Chisel.h:103-140).  The fused per-frame
 // unit skips the stand-alone slot lookup: k_integrate<FUSED> does it per chunk.
+// Selections made ahead for frames of a previous streaming call (n_ahead) depend on the camera, the truncation
+// model and the partition: a setter that changes one of these discards them, so that the next call selects again.
+static void discard_primed(tf_volume* v) {
+  for (int k = 0; k < v->n_primed; ++k) {
+    VolumeDev d = v->dev;
+    d.sel = v->selbuf[(v->cur_sel + 1 + k) % tf_volume::kSelSets];
+    launch_reset_ctl(d, false, v->stream);
+  }
+  v->n_primed = 0;
+}
+
 static int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hipStream_t s = nullptr) {
   if (!s) s = v->stream;
   const SelectConsts sc = make_select_consts(pose.p, v->res);
@@ -394,6 +405,7 @@ int tf_set_camera(tf_volume* v, float fx, float fy, float cx, float cy, int widt
     set_error("image width must be a positive multiple of 8 (the reference reads 8 pixels per step, ChunkManager.h:326)");
     return TF_ERR_INVALID;
   }
+  discard_primed(v);
   v->fx = fx; v->fy = fy; v->cx = cx; v->cy = cy;
   refresh_cam(v, width, height, near_plane, far_plane);
   v->frame_bound = false;
@@ -403,6 +415,7 @@ int tf_set_camera(tf_volume* v, float fx, float fy, float cx, float cy, int widt
 int tf_set_truncation(tf_volume* v, float q, float l, float c, float s) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
   TF_DEV(v);
+  discard_primed(v);
   v->ig.quad = q; v->ig.lin = l; v->ig.cons = c; v->ig.scale = s;
   return TF_OK;
 }
@@ -657,9 +670,8 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
 // Chisel::UpdateMeshes -> CompressMeshes -> GeneratePatches(label = this frame) -> UpdateAtlas over the dirty
 // chunks of ONE integrated frame (GCFusion/MobileFusion.cpp:327-382 without the host-side view selection): `sel`
 // holds the frame's visible list with its needsUpdate flags, `frame_epoch` the finalize epoch of that frame.
-// The patch stages (adjacency exchange, slot hand-out, projection, blit) read meshes and images only, so they MAY
-// run on a second stream next to the voxel update of the following frame; the next frame's mesher then waits
-// for them (it rewrites the mesh blocks they read).
+// The patch stage (adjacency exchange, slot hand-out, projection, blit) reads meshes and images only; it is left
+// PENDING here and rides on the next frame's launch next to that frame's voxel update (AtlasState::pend_patch).
 static int fused_arm(tf_volume* v) {
   AtlasState& a = v->atlas;
   if (a.fused_armed) return TF_OK;
@@ -677,7 +689,9 @@ static int fused_arm(tf_volume* v) {
 static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
                          const float* pose_inv16, int32_t frame_id) {
   AtlasState& a = v->atlas;
-  int rc = fused_arm(v);
+  int rc = patch_flush(v);  // (a stage still pending here must read its meshes before this frame's mesher rewrites them)
+  if (rc) return rc;
+  rc = fused_arm(v);
   if (rc) return rc;
   const int par = a.fused_par;
   a.fused_par ^= 1;
@@ -696,14 +710,6 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
     rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u);
     if (rc) return rc;
   }
-  // TF_TWO_STREAMS=1 (tuning knob) moves the patch stages to a second stream; measured on MI355X the two
-  // cross-stream event waits per frame (~12 us each) cost what the overlap gains (profiles/r2/README.md)
-  static const bool one_stream = !(getenv("TF_TWO_STREAMS") && atoi(getenv("TF_TWO_STREAMS")));
-  hipStream_t ps = one_stream ? v->stream : a.aux_stream;
-  if (!one_stream && a.patch_pending[par ^ 1]) {  // the previous frame's patches still read the meshes
-    TF_HIP(hipStreamWaitEvent(v->stream, a.ev_patch[par ^ 1], 0));
-    a.patch_pending[par ^ 1] = false;
-  }
   prof_begin(v, TF_PROF_MESH);
   // (the filter's form follows the dirty-list length of an earlier frame: the kernel leaves it in host-visible memory,
   // read here without any synchronisation -- whatever value is there is good enough)
@@ -712,10 +718,6 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
               len_guess, a.h_dirty_len, v->stream);
   v->mesh_par ^= 1;
   prof_end(v);
-  if (!one_stream) {
-    TF_HIP(hipEventRecord(a.ev_mesh[par], v->stream));
-    TF_HIP(hipStreamWaitEvent(ps, a.ev_mesh[par], 0));
-  }
   // (CompressMeshes' neighbour exchange, the list of chunks that own a mesh and the slot candidates are produced
   // by the mesher and consumed by the patch kernel: no kernel of their own in the fused flow)
   KfDev kf;
@@ -727,20 +729,36 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
   static const int pdbg = getenv("TF_PATCH_DBG") ? atoi(getenv("TF_PATCH_DBG")) : 0;  // triage switch
   kf.pad[0] = pdbg;
   memcpy(kf.T, pose_inv16, 64);
-  launch_patch_fused(v, d, par, kf, ps);
-  if (!one_stream) {
-    TF_HIP(hipEventRecord(a.ev_patch[par], ps));
-    a.patch_pending[par] = true;
-  }
+  a.pend_patch.on = true;
+  a.pend_patch.st.par = par;
+  a.pend_patch.st.kf = kf;
+  a.pend_patch.host_slot = -1;
+  static const bool defer_patch = !(getenv("TF_PATCH_DEFER") && !atoi(getenv("TF_PATCH_DEFER")));  // A/B knob, default on
+  if (!defer_patch) { rc = patch_flush(v); if (rc) return rc; }
   v->clear_floor = frame_epoch + 1u;  // CompressMeshes cleared meshesToUpdate
   return TF_OK;
 }
-static int texture_flush(tf_volume* v) {  // whatever follows on the main stream sees the patches of the last frames
+// the pending patch stage has been put on the stream (as a role of a frame launch or on its own)
+static int patch_launched(tf_volume* v) {
   AtlasState& a = v->atlas;
-  for (int k = 0; k < 2; ++k)
-    if (a.patch_pending[k]) { TF_HIP(hipStreamWaitEvent(v->stream, a.ev_patch[k], 0)); a.patch_pending[k] = false; }
+  a.pend_patch.on = false;
+  if (a.pend_patch.host_slot >= 0) {  // its frame's staging slot is free once this launch is through
+    TF_HIP(hipEventRecord(v->hslot[a.pend_patch.host_slot].freed, v->stream));
+    a.pend_patch.host_slot = -1;
+  }
   return TF_OK;
 }
+}  // extern "C" (C++ linkage for the helper below)
+namespace tf {
+int patch_flush(tf_volume* v) {  // the pending patch stage as a launch of its own
+  AtlasState& a = v->atlas;
+  if (!a.pend_patch.on) return TF_OK;
+  launch_patch_fused(v, v->dev, a.pend_patch.st.par, a.pend_patch.st.kf, v->stream);
+  TF_HIP(hipGetLastError());
+  return patch_launched(v);
+}
+}  // namespace tf
+extern "C" {
 
 // Software-pipelined enqueue of n frames on the handle's stream: launch i carries K-A of frame i,
 // K-C of frame i+1 and K-B of frame i+2 as independent block ranges of one kernel (launch_frame),
@@ -793,16 +811,21 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     if (hn) stage(i + 1, &nxt);
     if (h2) stage(i + 2, &nx2);
     if (!hc && !hn && !h2) continue;
+    // the patch stage of the previous textured frame rides on this launch when it carries a colour voxel update
+    // (the fused kernel has no depth-only instance with that role); otherwise it goes out on its own first
+    AtlasState::PendPatch& pp = v->atlas.pend_patch;
+    const bool carry = pp.on && hc && cur.img.rgba != nullptr;
+    if (pp.on && hc && !carry) { int rc = patch_flush(v); if (rc) return rc; }
     if (hc) prof_begin(v, TF_PROF_INTEGRATE);
-    launch_frame(v->dev, hc ? &cur : nullptr, hn ? &nxt : nullptr, h2 ? &nx2 : nullptr, v->cam, v->ig,
-                 v->res, v->stream);
+    launch_frame(v->dev, hc ? &cur : nullptr, hn ? &nxt : nullptr, h2 ? &nx2 : nullptr, carry ? &pp.st : nullptr, v->cam,
+                 v->ig, v->res, v->stream);
     if (hc) prof_end(v);
+    if (carry) { int rc = patch_launched(v); if (rc) return rc; }
     if (hc && tex) {
       int rc = texture_stage(v, cur.sel, cur.img, cur.epoch, tex->pose_inv16 + 16 * i, tex->first_frame_id + (int32_t)i);
       if (rc) return rc;
     }
   }
-  if (tex) { int rc = texture_flush(v); if (rc) return rc; }
   for (int64_t k = 0; k < n_ahead; ++k) {
     tf_volume::Primed& p = v->primed[k];
     p.depth = d_depth[n + k];
@@ -826,6 +849,22 @@ int tf_integrate_frame(tf_volume* v, const float pose[12], int use_color) {
   return enqueue_frames(v, 1, 0, dd, dc, pose, nullptr);
 }
 
+static int bind_frame(tf_volume* v, const float* d_depth, const uint8_t* d_rgba) {  // tf_frame_bind_device without the entry checks
+  v->frame.depth = d_depth;
+  v->frame.rgba = reinterpret_cast<const uchar4*>(d_rgba);
+  v->frame.quality = nullptr;
+  v->frame_bound = true;
+  return TF_OK;
+}
+// a frame of the host ring has been enqueued: its staging slot is free when the last launch that reads its device
+// images is through -- the frame's own launch, or the one that carries its pending patch stage
+static int host_slot_done(tf_volume* v, int slot) {
+  AtlasState::PendPatch& pp = v->atlas.pend_patch;
+  if (pp.on && pp.host_slot < 0) { pp.host_slot = slot; return TF_OK; }
+  TF_HIP(hipEventRecord(v->hslot[slot].freed, v->stream));
+  return TF_OK;
+}
+
 static int check_frames(int64_t n_all, const float* const* d_depth, const uint8_t* const* d_rgba) {
   for (int64_t f = 0; f < n_all; ++f)
     if ((reinterpret_cast<uintptr_t>(d_depth[f]) & 15) || !d_depth[f] ||
@@ -844,7 +883,7 @@ int tf_integrate_frames_device(tf_volume* v, int64_t n_frames, const float* cons
 int tf_stream_frames_device(tf_volume* v, int64_t n_frames, int64_t n_ahead, const float* const* d_depth,
                             const uint8_t* const* d_rgba, const float* poses12) {
   if (!v || !d_depth || !poses12) { set_error("null argument"); return TF_ERR_INVALID; }
-  TF_DEV(v);
+  TF_DEV_STREAM(v);
   if (n_ahead < 0 || n_ahead > 2) { set_error("n_ahead must be 0, 1 or 2"); return TF_ERR_INVALID; }
   if (n_frames <= 0) return TF_OK;
   int rc = check_frames(n_frames + n_ahead, d_depth, d_rgba);
@@ -852,14 +891,14 @@ int tf_stream_frames_device(tf_volume* v, int64_t n_frames, int64_t n_ahead, con
   rc = enqueue_frames(v, n_frames, n_ahead, d_depth, d_rgba, poses12, nullptr);
   if (rc) return rc;
   // leave the last frame bound, like a sequence of tf_frame_bind_device calls would
-  return tf_frame_bind_device(v, d_depth[n_frames - 1], d_rgba ? d_rgba[n_frames - 1] : nullptr, nullptr);
+  return bind_frame(v, d_depth[n_frames - 1], d_rgba ? d_rgba[n_frames - 1] : nullptr);
 }
 
 int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int64_t n_ahead, const float* const* d_depth,
                                      const uint8_t* const* d_rgba, const float* poses12, const float* pose_inv16,
                                      int32_t first_frame_id) {
   if (!v || !d_depth || !d_rgba || !poses12 || !pose_inv16) { set_error("null argument"); return TF_ERR_INVALID; }
-  TF_DEV(v);
+  TF_DEV_STREAM(v);
   if (n_ahead < 0 || n_ahead > 2) { set_error("n_ahead must be 0, 1 or 2"); return TF_ERR_INVALID; }
   if (n_frames <= 0) return TF_OK;
   int rc = check_frames(n_frames + n_ahead, d_depth, d_rgba);
@@ -869,17 +908,13 @@ int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int64_t n_a
   TexturedArgs tex{pose_inv16, first_frame_id};
   rc = enqueue_frames(v, n_frames, n_ahead, d_depth, d_rgba, poses12, &tex);
   if (rc) return rc;
-  return tf_frame_bind_device(v, d_depth[n_frames - 1], d_rgba[n_frames - 1], nullptr);
+  // n_ahead > 0: the caller keeps feeding this stream (and keeps the images of the frames in flight alive), so the
+  // patch stage of the last frame waits for the next call's first launch; otherwise it goes out now
+  if (n_ahead == 0) { rc = patch_flush(v); if (rc) return rc; }
+  return bind_frame(v, d_depth[n_frames - 1], d_rgba[n_frames - 1]);
 }
 
 // ring of staging slots of the per-frame host path, (re)sized to the camera
-static int bind_frame(tf_volume* v, const float* d_depth, const uint8_t* d_rgba) {  // tf_frame_bind_device without the entry checks
-  v->frame.depth = d_depth;
-  v->frame.rgba = reinterpret_cast<const uchar4*>(d_rgba);
-  v->frame.quality = nullptr;
-  v->frame_bound = true;
-  return TF_OK;
-}
 
 static int host_ring_prepare(tf_volume* v) {
   const size_t npix = (size_t)v->cam.W * v->cam.H;
@@ -980,7 +1015,8 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     TexturedArgs tex{cur.pinv, cur.fid};
     rc = enqueue_frames(v, 1, 0, dd, dc, cur.pose, cur.tex ? &tex : nullptr);
     if (rc) return rc;
-    TF_HIP(hipEventRecord(s.freed, v->stream));
+    rc = host_slot_done(v, slot_index);
+    if (rc) return rc;
     return bind_frame(v, cur.d, cur.c);
   }
   // The launch pipeline of the streaming entry points, kept alive across per-frame calls: this call integrates the
@@ -1002,7 +1038,8 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   v->pend[1] = cur;
   v->n_pend = 2;
   if (rc) return rc;
-  TF_HIP(hipEventRecord(v->hslot[p0.slot].freed, v->stream));
+  rc = host_slot_done(v, p0.slot);
+  if (rc) return rc;
   lap(4, t);
   if (trace) v->host_trace[5] += 1.0;
   return bind_frame(v, p0.d, p0.c);
@@ -1025,7 +1062,8 @@ int flush_deferred(tf_volume* v) {
     TexturedArgs tex{p[k].pinv, p[k].fid};
     int rc = enqueue_frames(v, 1, n - 1 - k, dd, dc, poses, p[k].tex ? &tex : nullptr);
     if (rc) return rc;
-    TF_HIP(hipEventRecord(v->hslot[p[k].slot].freed, v->stream));
+    rc = host_slot_done(v, p[k].slot);
+    if (rc) return rc;
   }
   return bind_frame(v, p[n - 1].d, p[n - 1].c);
 }
@@ -1037,9 +1075,7 @@ int tf_texture_frame_device(tf_volume* v, const float pose_inv16[16], int32_t fr
   TF_DEV(v);
   if (!v->frame_bound || !v->frame.rgba) { set_error("no colour frame bound"); return TF_ERR_INVALID; }
   if (v->epoch == 0) { set_error("no frame has been integrated"); return TF_ERR_INVALID; }
-  int rc = texture_stage(v, v->dev.sel, v->frame, v->epoch - 1u, pose_inv16, frame_id);
-  if (rc) return rc;
-  return texture_flush(v);
+  return texture_stage(v, v->dev.sel, v->frame, v->epoch - 1u, pose_inv16, frame_id);
 }
 
 int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {
@@ -1061,7 +1097,11 @@ int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {
   TF_HIP(hipMemcpyAsync(r, v->d_tmp, 48, hipMemcpyDeviceToHost, v->stream));
   AtlasCtl c;
   TF_HIP(hipMemcpyAsync(&c, v->dev.actl, sizeof(c), hipMemcpyDeviceToHost, v->stream));
+  uint32_t mc[kMeshShards * 16];  // the per-shard counters of the last mesher launch: [0] survivors, [1] exact tests
+  TF_HIP(hipMemcpyAsync(mc, v->dev.mesh_cnt + (size_t)((v->mesh_par & 1) ^ 1) * kMeshShards * 16, sizeof(mc),
+                        hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
+  for (uint32_t k = 0; k < kMeshShards; ++k) { out->n_survivors += mc[k * 16]; out->n_exact += mc[k * 16 + 1]; }
   out->n_dirty = (int64_t)r[0]; out->n_meshes = (int64_t)r[1]; out->n_vertices = (int64_t)r[2];
   out->n_triangles = (int64_t)r[3]; out->roi_pixels = (int64_t)r[4]; out->n_patches = (int64_t)r[5];
   out->n_slots = (int64_t)c.n_slots;
@@ -1250,6 +1290,29 @@ int tf_profile_get(tf_volume* v, tf_profile* out, int reset) {
   return TF_OK;
 }
 
+int tf_profile_calibrate(tf_volume* v, int32_t n_pairs, double* us_per_pair) {
+  if (!v || !us_per_pair || n_pairs <= 0) { set_error("invalid argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  std::vector<hipEvent_t> ev((size_t)2 * n_pairs);
+  for (auto& e : ev) TF_HIP(hipEventCreate(&e));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  for (int i = 0; i < n_pairs; ++i) {
+    TF_HIP(hipEventRecord(ev[2 * i], v->stream));
+    launch_null(v->stream);
+    TF_HIP(hipEventRecord(ev[2 * i + 1], v->stream));
+  }
+  TF_HIP(hipStreamSynchronize(v->stream));
+  double sum = 0.0;
+  for (int i = 0; i < n_pairs; ++i) {
+    float ms = 0.f;
+    TF_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+    sum += ms;
+  }
+  for (auto& e : ev) hipEventDestroy(e);
+  *us_per_pair = 1e3 * sum / n_pairs;
+  return TF_OK;
+}
+
 int tf_debug_phase_raw(tf_volume* v, uint64_t* out, int64_t cap_words) {
   if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
   TF_DEV(v);
@@ -1269,6 +1332,7 @@ int tf_set_partition_key(tf_volume* v, int32_t a, int32_t b, int32_t c, int32_t 
     set_error("partition key coefficients must be 0 or 1, not all 0 (face chunks are found as key == lo / hi - 1)");
     return TF_ERR_INVALID;
   }
+  discard_primed(v);  // (the fused selection drops chunks outside the slab)
   v->dev.part_lo = key_lo;
   v->dev.part_hi = key_hi;
   v->dev.part_a = a; v->dev.part_b = b; v->dev.part_c = c;

@@ -32,32 +32,42 @@ class CopyPool {
   CopyPool(const CopyPool&) = delete;
   CopyPool& operator=(const CopyPool&) = delete;
 
-  // dst[i] <- src[i] for the given regions (up to 4), each split into parts of about 256 KiB
+  // dst[i] <- src[i] for the given regions (up to 4), each split into parts of about 256 KiB.
+  // The task table is only ever rebuilt under the mutex while no helper is inside pull() (active_ == 0), and a
+  // helper only enters pull() after registering under the same mutex: a helper that was notified for call N but is
+  // scheduled during call N + 1 either registers before the rebuild (and finds next_ >= size: nothing to do, the
+  // rebuild waits for it to leave) or after it (and works on call N + 1's table).
   void copy(void* const* dst, const void* const* src, const size_t* bytes, int regions) {
-    tasks_.clear();
-    for (int r = 0; r < regions; ++r) {
-      const size_t part = 256u << 10;
-      for (size_t o = 0; o < bytes[r]; o += part)
-        tasks_.push_back({static_cast<char*>(dst[r]) + o, static_cast<const char*>(src[r]) + o,
-                          bytes[r] - o < part ? bytes[r] - o : part});
-    }
-    if (tasks_.empty()) return;
-    if (workers_.empty() || tasks_.size() < 2) {
-      for (const Task& t : tasks_) memcpy(t.d, t.s, t.n);
+    size_t ntask = 0;
+    for (int r = 0; r < regions; ++r) ntask += (bytes[r] + kPart - 1) / kPart;
+    if (!ntask) return;
+    if (workers_.empty() || ntask < 2) {
+      for (int r = 0; r < regions; ++r) memcpy(dst[r], src[r], bytes[r]);
       return;
     }
-    next_.store(0, std::memory_order_relaxed);
-    left_.store((int)tasks_.size(), std::memory_order_release);
     {
-      std::lock_guard<std::mutex> g(m_);
+      std::unique_lock<std::mutex> g(m_);
+      while (active_.load(std::memory_order_acquire) > 0) {  // stragglers of the previous call leave pull() first
+        g.unlock();
+        std::this_thread::yield();
+        g.lock();
+      }
+      tasks_.clear();
+      for (int r = 0; r < regions; ++r)
+        for (size_t o = 0; o < bytes[r]; o += kPart)
+          tasks_.push_back({static_cast<char*>(dst[r]) + o, static_cast<const char*>(src[r]) + o,
+                            bytes[r] - o < kPart ? bytes[r] - o : kPart});
+      next_.store(0, std::memory_order_relaxed);
+      left_.store((int)tasks_.size(), std::memory_order_release);
       ++gen_;
     }
     cv_.notify_all();
     pull();
-    while (left_.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+    while (left_.load(std::memory_order_acquire) > 0) std::this_thread::yield();  // every part has been copied
   }
 
  private:
+  static constexpr size_t kPart = 256u << 10;
   struct Task { char* d; const char* s; size_t n; };
   void pull() {
     for (;;) {
@@ -75,13 +85,15 @@ class CopyPool {
         cv_.wait(g, [&] { return gen_ != seen; });
         seen = gen_;
         if (stop_) return;
+        active_.fetch_add(1, std::memory_order_acq_rel);  // registered under the mutex: the table is stable from here on
       }
       pull();
+      active_.fetch_sub(1, std::memory_order_acq_rel);
     }
   }
   std::vector<std::thread> workers_;
   std::vector<Task> tasks_;
-  std::atomic<int> next_{0}, left_{0};
+  std::atomic<int> next_{0}, left_{0}, active_{0};
   std::mutex m_;
   std::condition_variable cv_;
   unsigned long gen_ = 0;

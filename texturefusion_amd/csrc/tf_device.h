@@ -234,13 +234,20 @@ struct FrameStage {
   bool coarse_summ = false;  // no mesher follows this frame: an updated chunk's summary becomes "anything" (kSummAny)
                              // instead of the classes written; the filter makes it exact when it next reads the chunk
 };
+// The patch stage of the previous textured frame, carried by the next frame's launch (FrameLaunch::kf_patch).
+struct PatchStage {
+  int par;   // counter-set parity of that frame (AtlasCtl::set, patch_list, patch_cnt)
+  KfDev kf;  // the frame itself as the keyframe its patches are cut from
+};
 constexpr uint32_t kSummAny = 0xFFFFu;        // VolumeDev::summ: every class may occur
 constexpr uint32_t kKaCoarseSumm = 16384u;    // IntegrateConsts::dbg bit: FrameStage::coarse_summ
 
 // ---- launchers (tf_kernels.hip) ------------------------------------------------------
+// patch != nullptr (and cur a colour frame): the launch also carries the patch stage of the previous frame
 void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* next,
-                  const FrameStage* next2, const Cam& cam, const Integ& ig, float res, hipStream_t s);
+                  const FrameStage* next2, const PatchStage* patch, const Cam& cam, const Integ& ig, float res, hipStream_t s);
 void launch_reset_ctl(const VolumeDev& v, bool volume_too, hipStream_t s);
+void launch_null(hipStream_t s);
 void launch_bbox(const VolumeDev& v, const float* depth, const Cam& cam, const Pose& pose,
                  hipStream_t s);
 void launch_select(const VolumeDev& v, const float* depth, const Cam& cam, const Integ& ig,

@@ -20,6 +20,7 @@
 #include "tf_device.h"
 #include "tf_devfn.h"
 #include "tf_host_math.h"
+#include "tf_patch_body.h"
 
 #pragma clang fp contract(off)
 
@@ -123,6 +124,10 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
 void launch_reset_ctl(const VolumeDev& v, bool volume_too, hipStream_t s) {
   hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(64), 0, s, v.sel.ctl, volume_too ? v.vctl : nullptr);
 }
+
+// an empty launch (tf_profile_calibrate: what a HIP-event pair around ANY launch reads at least)
+__global__ void k_null() {}
+void launch_null(hipStream_t s) { hipLaunchKernelGGL(k_null, dim3(1), dim3(64), 0, s); }
 
 // fresh chunk state: sdf 999, weight 0 (Chunk.cpp:64-65), colour 0 (ColorVoxel.cpp:26-33)
 __global__ __launch_bounds__(256) void k_fill_pool(float2* tsdf, ushort4* color, uint32_t* summ, size_t first,
@@ -575,6 +580,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kOOB = 0x7FFFFFF0;  // buffer byte offset that is out of range for every descriptor
 #ifndef TF_KF_WAVES
 #define TF_KF_WAVES 7  // resident waves per SIMD the fused kernel is compiled for (register budget)
+#endif
+#ifndef TF_KFP_WAVES
+#define TF_KFP_WAVES 6  // ... the instance that also carries the patch stage of the previous frame (80 VGPRs)
 #endif
 
 
@@ -1283,13 +1291,17 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
 }
 
 // ---------------------------------------------------------------------------------------
-// The per-frame unit as ONE launch: three independent block ranges form a 3-stage software
-// pipeline over consecutive frames of a stream --
-//     [0, n_bbox)                 K-B  of frame f+2  (into selection set f+2)
-//     [n_bbox, n_bbox+n_sel)      K-C  of frame f+1  (reads the keys K-B left one launch ago)
-//     [.., .. + n_ka)             K-A  of frame f    (reads the list K-C left one launch ago)
+// The per-frame unit as ONE launch: independent block ranges form a software pipeline over
+// consecutive frames of a stream --
+//     K-A   of frame f    (reads the list K-C left one launch ago)
+//     patch stage of frame f-1 (textured stream: reads the meshes the mesher of f-1 left, the images of f-1 and
+//           writes texcoords / atlas texels; K-A touches voxels, summaries and epochs only -- disjoint)
+//     K-C   of frame f+1  (reads the keys K-B left one launch ago)
+//     K-B   of frame f+2  (into selection set f+2)
 // The kernel boundary is the only synchronisation: no events, no second stream, one dispatch per
-// frame.  Selection is a pure function of (depth, pose), so running it ahead changes nothing.
+// frame.  Selection is a pure function of (depth, pose), so running it ahead changes nothing; the
+// patch stage reads nothing K-A writes, so running it one launch late changes nothing either (the mesher of
+// frame f, which rewrites the mesh blocks it reads, runs behind this launch).
 // ---------------------------------------------------------------------------------------
 struct FrameLaunch {
   VolumeDev v;           // sel = set of frame f
@@ -1307,13 +1319,16 @@ struct FrameLaunch {
   FrameCtl* ctl2;        // set of frame f+2
   const float* depth2;
   Pose P2;
+  uint32_t n_patch;      // patch stage of frame f-1: workgroups, counter-set parity, the frame as keyframe
+  int patch_par;
+  KfDev kf_patch;
 };
 
-template <bool COLOR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TF_KF_WAVES, TF_KF_WAVES))) void k_frame(FrameLaunch a) {
-  // Block ranges: K-A [0, n_ka), K-C [n_ka, n_ka + n_sel), K-B behind them.
-  // a.rot rotates the dispatch order: 0 = K-A blocks first, n_ka = K-C / K-B first
-  const uint32_t total = a.n_ka + a.n_sel + a.n_bbox;
+template <bool COLOR, bool PATCH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATCH ? TF_KFP_WAVES : TF_KF_WAVES, PATCH ? TF_KFP_WAVES : TF_KF_WAVES))) void k_frame(FrameLaunch a) {
+  // Block ranges: K-A [0, n_ka), patches [n_ka, n_ka + n_patch), K-C, K-B behind them.
+  // a.rot rotates the dispatch order: 0 = K-A blocks first, n_ka = the other roles first
+  const uint32_t total = a.n_ka + a.n_patch + a.n_sel + a.n_bbox;
   const uint32_t b = blockIdx.x + a.rot < total ? blockIdx.x + a.rot : blockIdx.x + a.rot - total;
   // tuning aid (dbg bit 12): per-wave {start, end, role} stamps of the last launch -> phase_buf
   const bool timeline = (a.kc.dbg & 4096u) != 0 && a.n_sel > 0 && a.n_bbox > 0;  // steady launches only
@@ -1322,16 +1337,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TF_KF_WAVES
   if (b < a.n_ka) {
     role = 0;
     integrate_body<COLOR, false, true, true, TF_KA_GP>(a.v, a.img, a.cam, a.kc, a.epoch, b, a.n_ka);
-  } else if (b < a.n_ka + a.n_sel) {
+  } else if (PATCH && b < a.n_ka + a.n_patch) {
+    role = 3;
+    patch_body<true, true, true>(a.v, a.cam, a.patch_par, a.kf_patch, b - a.n_ka, a.n_patch);
+  } else if (b < a.n_ka + a.n_patch + a.n_sel) {
     role = 1;
     if (!(a.kc.dbg & 512u)) {  // triage switch
       VolumeDev v1 = a.v;
       v1.sel = a.sel1;
-      select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - a.n_ka, a.n_sel);
+      select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - a.n_ka - a.n_patch, a.n_sel);
     }
   } else {
     role = 2;
-    if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_sel, a.n_bbox);
+    if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_patch - a.n_sel, a.n_bbox);
   }
   if (timeline) {
     const uint32_t gw = (b * 256 + threadIdx.x) >> 6;
@@ -1350,14 +1368,15 @@ static int env_int(const char* name, int dflt) {
 }
 // K-A grid: exactly the resident capacity (TF_KF_WAVES waves per SIMD = that many 256-thread
 // workgroups per CU), so every K-A wave starts at once and walks the list with a fixed stride.
-static int ka_blocks_default() {
+static int device_cus() {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
   }
-  return cus * TF_KF_WAVES;
+  return cus;
 }
+static int ka_blocks_default() { return device_cus() * TF_KF_WAVES; }
 
 void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam, const Integ& ig,
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
@@ -1401,14 +1420,24 @@ void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_dep
 // cur != nullptr -> K-A of *cur (its selection set must hold a finished list); next -> K-C of
 // *next (its set must hold finished K-B keys); next2 -> K-B of *next2.
 void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* next,
-                  const FrameStage* next2, const Cam& cam, const Integ& ig, float res, hipStream_t s) {
-  static const int nblocks = env_int("TF_KA_BLOCKS", ka_blocks_default());
+                  const FrameStage* next2, const PatchStage* patch, const Cam& cam, const Integ& ig, float res, hipStream_t s) {
+  const bool with_patch = patch != nullptr && cur != nullptr && cur->img.rgba != nullptr;
+  static const int nblocks7 = env_int("TF_KA_BLOCKS", ka_blocks_default());
+  static const int nblocksP = env_int("TF_KAP_BLOCKS", device_cus() * TF_KFP_WAVES);
+  const int nblocks = with_patch ? nblocksP : nblocks7;
   FrameLaunch a;
   a.v = v;
   a.cam = cam;
   a.ig = ig;
-  a.n_ka = a.n_sel = a.n_bbox = 0;
+  a.n_ka = a.n_sel = a.n_bbox = a.n_patch = 0;
+  a.patch_par = 0;
   a.epoch = 0;
+  if (with_patch) {
+    static const int npb = env_int("TF_PATCH_BLOCKS", 1024);
+    a.n_patch = (uint32_t)npb;
+    a.patch_par = patch->par;
+    a.kf_patch = patch->kf;
+  }
   static const int nsel = env_int("TF_SEL_BLOCKS", 512);
   a.kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);
   static const int dbg = env_int("TF_KA_DBG", 0);
@@ -1438,13 +1467,14 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
     static const int nbb = env_int("TF_BBOX_BLOCKS", 128);
     a.n_bbox = (uint32_t)(blocks > nbb ? nbb : blocks);
   }
-  const uint32_t total = a.n_ka + a.n_sel + a.n_bbox;
+  const uint32_t total = a.n_ka + a.n_patch + a.n_sel + a.n_bbox;
   if (!total) return;
   if ((a.kc.dbg & 4096u) && a.n_sel && a.n_bbox) a.kc.dbg |= 8192u;  // timeline stamps: steady launches only
-  static const int sel_first = env_int("TF_SEL_FIRST", 0);  // tuning knob: dispatch K-C / K-B ahead of K-A
+  static const int sel_first = env_int("TF_SEL_FIRST", 0);  // tuning knob: dispatch the other roles ahead of K-A
   a.rot = sel_first ? a.n_ka : 0u;
-  if (color) hipLaunchKernelGGL((k_frame<true>), dim3(total), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_frame<false>), dim3(total), dim3(256), 0, s, a);
+  if (with_patch) hipLaunchKernelGGL((k_frame<true, true>), dim3(total), dim3(256), 0, s, a);
+  else if (color) hipLaunchKernelGGL((k_frame<true, false>), dim3(total), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_frame<false, false>), dim3(total), dim3(256), 0, s, a);
 }
 
 // ---------------------------------------------------------------------------------------

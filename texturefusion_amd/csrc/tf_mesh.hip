@@ -252,6 +252,7 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
   }
   fl = wave_or(fl);
   if (use_summ && lane == 0) v.summ[own] = fl;  // the chunk's summary is exact again
+  if (lane == 0) atomicAdd(&cnt[shard * 16 + 1], 1u);  // statistic (tf_texture_stats::n_exact): chunks whose voxels the filter read
   bool empty = !(fl & 1u);
   if (!empty && (fl & 14u) != 14u) {
     uint32_t f2 = 0;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
     excl_l = incl_l - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)my_n, (int)(sh0 & 31u)));
     incl_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh0);  // (reused: the shard of the first row)
   }
-  if (blockIdx.x == 0 && t < (int)kMeshShards) cnt_next[t * 16] = 0u;  // the counters of the NEXT launch's filter
+  if (blockIdx.x == 0 && t < (int)kMeshShards) { cnt_next[t * 16] = 0u; cnt_next[t * 16 + 1] = 0u; }  // the counters of the NEXT launch's filter
   const float half = res * 0.5f;
   if (rearm >= 0 && blockIdx.x == 0 && t == 0) {
     // fused flow: the patches of the previous frame are done (the main stream waited for them ahead of this

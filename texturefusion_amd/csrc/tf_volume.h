@@ -37,11 +37,21 @@ void set_error(const std::string& msg);
   } while (0)
 // Every entry point but tf_integrate_frame_host first brings the frames that entry point has deferred (its
 // two-frame launch pipeline, see tf_capi.cpp) onto the stream, so that nothing can observe the deferral.
-#define TF_DEV(v)                                                                           \
+#define TF_DEV_STREAM(v)                                                                    \
   do {                                                                                      \
     TF_DEV_NOFLUSH(v);                                                                      \
     if ((v)->n_pend) {                                                                      \
       int _rc = ::tf::flush_deferred(v);                                                    \
+      if (_rc) return _rc;                                                                  \
+    }                                                                                       \
+  } while (0)
+// ... and, except for the streaming entry points (whose next launch carries it), the patch stage of the last
+// textured frame (AtlasState::pend_patch).
+#define TF_DEV(v)                                                                           \
+  do {                                                                                      \
+    TF_DEV_STREAM(v);                                                                       \
+    if ((v)->atlas.pend_patch.on) {                                                         \
+      int _rc = ::tf::patch_flush(v);                                                       \
       if (_rc) return _rc;                                                                  \
     }                                                                                       \
   } while (0)
@@ -76,11 +86,15 @@ struct AtlasState {
   uint32_t* h_dirty_len = nullptr;  // pinned, device-visible: the mesher's filter leaves the length of a frame's dirty list here
   unsigned long long* d_cand = nullptr;
   int fused_par = 0;   // counter set of the next fused frame
-  // fused flow: the patch stages of frame f (second stream) overlap the voxel update of frame f + 1
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t ev_mesh[2] = {nullptr, nullptr};   // meshes of a frame are final (recorded on the main stream)
-  hipEvent_t ev_patch[2] = {nullptr, nullptr};  // patches of a frame are done (recorded on the second stream)
-  bool patch_pending[2] = {false, false};
+  // fused flow: the patch stage of textured frame f (slot hand-out, CompressMeshes' exchange, CalculateTexCoords,
+  // UpdateBuffer) is not launched behind the frame's mesher but rides on the NEXT frame's launch, next to its voxel
+  // update (k_frame, tf_kernels.hip) -- it reads meshes, the frame's own images and the atlas, nothing K-A touches.
+  // Anything that could observe the deferral flushes it first (TF_DEV -> patch_flush: the stage as a launch of its own).
+  struct PendPatch {
+    bool on = false;
+    PatchStage st;
+    int host_slot = -1;  // tf_integrate_frame_host: the staging slot whose device images the stage still reads
+  } pend_patch;
   bool fused_armed = false;  // the counter sets are in the state the fused flow expects
   // staging
   void* d_stage = nullptr;
@@ -127,7 +141,8 @@ struct tf_volume {
   size_t img_pixels = 0;
   // drop-in per-frame host path (tf_integrate_frame_host): ring of pinned staging + device image slots, H2D on
   // its own stream so that the copy of frame f+1 overlaps the kernels of frame f
-  static constexpr int kHostRing = 5;  // two deferred frames + the one being staged + two whose kernels may still run
+  static constexpr int kHostRing = 6;  // two deferred frames + the one being staged + three whose kernels may still run
+                                       // (a frame's images are read by its patch stage one launch behind its voxel update)
   struct HostSlot {
     uint8_t* h = nullptr;      // pinned: depth f32[npix] | rgba u8[4 npix]
     uint8_t* d = nullptr;      // device: same layout
@@ -182,6 +197,7 @@ struct tf_volume {
 namespace tf {
 int ensure_tmp(tf_volume* v, size_t bytes);
 int flush_deferred(tf_volume* v);
+int patch_flush(tf_volume* v);
 int ensure_pinned(tf_volume* v, size_t bytes);
 void prof_begin(tf_volume* v, int kind, hipStream_t s = nullptr);
 void prof_end(tf_volume* v, hipStream_t s = nullptr);
