@@ -323,8 +323,8 @@ def test_deferred_patch_stage_cannot_be_observed(gpu_required):
     cam = synth.Camera()
     ov, gv, cam, ig = make_pair(RES5, cam, max_chunks=1 << 16)
     oa = O.Atlas(RES5)
-    n = 8
-    fr = [synth.room_frame(3 * k, cam, with_quality=False) for k in range(n)]
+    n = 11
+    fr = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(n)]
     bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in fr]
     poses = np.stack([f[3].reshape(12) for f in fr])
     pinv = np.stack([synth.pose_inverse16(f[3]) for f in fr])
@@ -333,23 +333,25 @@ def test_deferred_patch_stage_cannot_be_observed(gpu_required):
     def check(tag):
         mids = sorted_ids(ov.list_meshes())
         assert np.array_equal(mids, sorted_ids(gv.list_meshes())), tag
+        assert len(mids) > 300, tag
         g = _compare_patches(ov, gv, mids, tag)
         used = g["texloc"][g["texloc"] != np.uint64((1 << 64) - 1)]
+        assert len(used) > 300, tag
         _compare_atlas(oa, gv, oa.hot_range(used))
         assert gv.atlas_loc_next() == oa.loc_next(), tag
 
-    for k in range(3):
+    for k in range(6):
         ov.frame_textured(oa, fr[k][0], fr[k][1], fr[k][3], pinv[k], 10 + k)
-    gv.stream_frames_textured_device(dd[0:5], dr[0:5], poses[0:5], pinv[0:5], 10, n_ahead=2)  # frame 2's stage stays pending
+    gv.stream_frames_textured_device(dd[0:8], dr[0:8], poses[0:8], pinv[0:8], 10, n_ahead=2)  # frame 5's stage stays pending
     check("behind a streaming call")
-    for k in range(3, 6):  # host frames: deferred two calls, the pending stage crosses the entry points
+    for k in range(6, 9):  # host frames: deferred two calls, the pending stage crosses the entry points
         ov.frame_textured(oa, fr[k][0], fr[k][1], fr[k][3], pinv[k], 10 + k)
         gv.integrate_frame_host(fr[k][0], fr[k][1], fr[k][3], pinv[k], 10 + k)
     check("behind host frames")
-    ov.integrate_frame(fr[6][0], fr[6][1], fr[6][3])  # a TSDF-only frame between textured ones
-    gv.integrate_frame_host(fr[6][0], fr[6][1], fr[6][3], None, 0)
-    ov.frame_textured(oa, fr[7][0], fr[7][1], fr[7][3], pinv[7], 17)
-    gv.integrate_frame_host(fr[7][0], fr[7][1], fr[7][3], pinv[7], 17)
+    ov.integrate_frame(fr[9][0], fr[9][1], fr[9][3])  # a TSDF-only frame between textured ones
+    gv.integrate_frame_host(fr[9][0], fr[9][1], fr[9][3], None, 0)
+    ov.frame_textured(oa, fr[10][0], fr[10][1], fr[10][3], pinv[10], 20)
+    gv.integrate_frame_host(fr[10][0], fr[10][1], fr[10][3], pinv[10], 20)
     gv.sync()
     from tests.util import assert_chunks_equal
     oids = sorted_ids(ov.list_chunks())

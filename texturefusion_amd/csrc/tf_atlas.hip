@@ -374,11 +374,23 @@ __global__ __launch_bounds__(256) void k_mesh_scatter(VolumeDev v, const int4* _
 
 // measurement aid: what the fused flow did for the work list of counter set `par`
 __global__ __launch_bounds__(256) void k_texture_stats(VolumeDev v, int par, unsigned long long* out) {
-  const uint32_t n = v.actl->set[par].n_work;
+  const uint32_t n_flat = v.actl->set[par].n_work;
+  const uint32_t rows = mesh_shard_rows_dev(v.max_chunks);
   unsigned long long a[6] = {0, 0, 0, 0, 0, 0};
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  // the frame's dirty set: the flat work list, then the shard lists K-A filled (slot i of shard s = index n_flat + s * rows + i)
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_flat + kMeshShards * rows; i += gridDim.x * 256) {
+    uint32_t slot;
+    if (i < n_flat) {
+      slot = v.work_slot[i];
+    } else {
+      const uint32_t sh = (i - n_flat) / rows, k = (i - n_flat) - sh * rows;
+      if (k >= v.wl_cnt[((par & 1) * kMeshShards + sh) * 16]) continue;
+      const size_t at = ((size_t)(par & 1) * kMeshShards + sh) * rows + k;
+      slot = v.wl_slot[at];
+      const int4 id = v.wl_ids[at];
+      if (id.w > 0 && !(v.hent[(uint32_t)id.w - 1u].alive & 1u)) continue;  // (parked behind the claim: not a chunk)
+    }
     a[0] += 1;
-    const uint32_t slot = v.work_slot[i];
     if (slot == kInvalidSlot) continue;
     const MeshRec m = v.mesh_rec[slot];
     if (!(m.state & kMsInMap)) continue;
@@ -415,6 +427,10 @@ int atlas_init(tf_volume* v) {
   TF_HIP(hipMalloc((void**)&a.d_work_ids, sizeof(int4) * (size_t)d.max_chunks * 2));
   TF_HIP(hipMalloc((void**)&a.d_work_slot, sizeof(uint32_t) * (size_t)d.max_chunks * 2));
   TF_HIP(hipMalloc((void**)&a.d_patch_list, sizeof(int4) * (size_t)2 * kMeshShards * mesh_shard_rows(d.max_chunks)));
+  TF_HIP(hipMalloc((void**)&a.d_wl_ids, sizeof(int4) * (size_t)2 * kMeshShards * mesh_shard_rows(d.max_chunks)));
+  TF_HIP(hipMalloc((void**)&a.d_wl_slot, sizeof(uint32_t) * (size_t)2 * kMeshShards * mesh_shard_rows(d.max_chunks)));
+  TF_HIP(hipMalloc((void**)&a.d_wl_cnt, sizeof(uint32_t) * 2 * kMeshShards * 16));
+  TF_HIP(hipMemset(a.d_wl_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16));
   TF_HIP(hipMalloc((void**)&a.d_patch_cnt, sizeof(uint32_t) * 2 * kMeshShards * 16));
   TF_HIP(hipMemset(a.d_patch_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16));
   TF_HIP(hipHostMalloc((void**)&a.h_dirty_len, 64, hipHostMallocDefault));
@@ -428,6 +444,7 @@ int atlas_init(tf_volume* v) {
   TF_HIP(hipMemcpy(a.d_kf, a.h_kf.data(), sizeof(KfDev) * (size_t)a.kf_cap, hipMemcpyHostToDevice));
   d.atlas = a.buf; d.atlas_w = a.aw; d.atlas_h = a.ah; d.patch_w = (int32_t)a.pw; d.patch_h = (int32_t)a.ph;
   d.actl = a.d_actl; d.kf_tab = a.d_kf; d.work_ids = a.d_work_ids; d.work_slot = a.d_work_slot; d.patch_list = a.d_patch_list; d.patch_cnt = a.d_patch_cnt; d.cand = a.d_cand;
+  d.wl_ids = a.d_wl_ids; d.wl_slot = a.d_wl_slot; d.wl_cnt = a.d_wl_cnt;
   return atlas_reset(v);
 }
 
@@ -443,6 +460,10 @@ void atlas_destroy(tf_volume* v) {
   if (a.d_actl) hipFree(a.d_actl);
   if (a.d_work_ids) hipFree(a.d_work_ids);
   if (a.d_work_slot) hipFree(a.d_work_slot);
+  if (a.d_wl_ids) hipFree(a.d_wl_ids);
+  if (a.d_wl_slot) hipFree(a.d_wl_slot);
+  if (a.d_wl_cnt) hipFree(a.d_wl_cnt);
+  a.d_wl_ids = nullptr; a.d_wl_slot = nullptr; a.d_wl_cnt = nullptr;
   if (a.d_patch_list) hipFree(a.d_patch_list);
   if (a.d_patch_cnt) hipFree(a.d_patch_cnt);
   if (a.h_dirty_len) hipHostFree(a.h_dirty_len);
@@ -462,6 +483,7 @@ int atlas_reset(tf_volume* v) {
   c.loc_min = ~0ull;
   TF_HIP(hipMemcpyAsync(a.d_actl, &c, sizeof(c), hipMemcpyHostToDevice, v->stream));
   TF_HIP(hipMemsetAsync(a.d_patch_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16, v->stream));
+  TF_HIP(hipMemsetAsync(a.d_wl_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   a.fused_par = 0;
   a.fused_armed = true;

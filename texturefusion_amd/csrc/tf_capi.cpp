@@ -680,14 +680,16 @@ static int fused_arm(tf_volume* v) {
   memset(z, 0, sizeof(z));
   TF_HIP(hipMemcpyAsync(&a.d_actl->set[0], z, sizeof(z), hipMemcpyHostToDevice, v->stream));
   TF_HIP(hipMemsetAsync(a.d_patch_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16, v->stream));
+  TF_HIP(hipMemsetAsync(a.d_wl_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   a.fused_par = 0;
   a.fused_armed = true;
   return TF_OK;
 }
 
+// claimed: K-A of this frame built the dirty set itself (FrameStage::claim_par = the parity used here)
 static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
-                         const float* pose_inv16, int32_t frame_id) {
+                         const float* pose_inv16, int32_t frame_id, bool claimed = false) {
   AtlasState& a = v->atlas;
   int rc = patch_flush(v);  // (a stage still pending here must read its meshes before this frame's mesher rewrites them)
   if (rc) return rc;
@@ -703,7 +705,8 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
   // meshesToUpdate = everything marked since CompressMeshes last cleared it (Chisel.h:192-208, Chisel.cpp:146).  In a
   // textured stream that is this frame's chunks (stamps <= frame_epoch are cleared); after frames integrated without
   // the textured unit the older marks are still there and the general dirty list takes over for this frame.
-  if (v->clear_floor < frame_epoch) launch_dirty_backlog(d, par, v->clear_floor, v->stream);
+  if (claimed) { /* nothing to launch: the shard lists of `par` hold the set */ }
+  else if (v->clear_floor < frame_epoch) launch_dirty_backlog(d, par, v->clear_floor, v->stream);
   else launch_dirty_frame(d, par, frame_epoch + 1u, v->stream);
   prof_end(v);
   if (v->comm_cap > 0) {  // multi-GPU: ghost bands of this frame's updates, before the mesher reads them
@@ -714,8 +717,10 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
   // (the filter's form follows the dirty-list length of an earlier frame: the kernel leaves it in host-visible memory,
   // read here without any synchronisation -- whatever value is there is good enough)
   const uint32_t len_guess = a.h_dirty_len ? *reinterpret_cast<volatile uint32_t*>(a.h_dirty_len) : 0u;
+  // (the shard lists of this parity are walked in any case: empty when K-A did not claim -- the previous frame's mesher
+  // re-armed them)
   launch_mesh(d, v->mesh_par, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1,
-              len_guess, a.h_dirty_len, v->stream);
+              len_guess, a.h_dirty_len, par, v->stream);
   v->mesh_par ^= 1;
   prof_end(v);
   // (CompressMeshes' neighbour exchange, the list of chunks that own a mesh and the slot candidates are produced
@@ -783,7 +788,10 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     memcpy(st->pose.p, poses12 + 12 * f, sizeof(st->pose.p));
     st->epoch = v->epoch + (uint32_t)f;
     st->coarse_summ = tex == nullptr;  // a TSDF-only stream: K-A skips the class ballots (tf_device.h)
+    st->claim_par = -1;
   };
+  static const bool ka_claims = !(getenv("TF_KA_CLAIM") && !atoi(getenv("TF_KA_CLAIM")));  // A/B knob, default on
+  if (tex) { int rc = fused_arm(v); if (rc) return rc; }  // (before the first launch appends to the shard lists)
   // how many leading frames already went through their selection stages in the previous call?
   int primed = 0;
   for (int k = 0; k < v->n_primed && k < n_all; ++k) {
@@ -808,6 +816,10 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     if (i + 2 < primed) h2 = false;               // K-B of that frame ran in the previous call
     if (primed >= 1 && i + 1 == 0) hn = false;    // K-C of frame 0 ran in the previous call
     if (hc) stage(i, &cur);
+    // K-A builds the frame's dirty set itself when the frame's own chunks are all there is to mesh (marks of earlier,
+    // untextured frames still waiting -> the general dirty list, texture_stage)
+    const bool claimed = hc && tex && ka_claims && v->clear_floor >= cur.epoch;
+    if (claimed) cur.claim_par = v->atlas.fused_par;
     if (hn) stage(i + 1, &nxt);
     if (h2) stage(i + 2, &nx2);
     if (!hc && !hn && !h2) continue;
@@ -822,7 +834,7 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     if (hc) prof_end(v);
     if (carry) { int rc = patch_launched(v); if (rc) return rc; }
     if (hc && tex) {
-      int rc = texture_stage(v, cur.sel, cur.img, cur.epoch, tex->pose_inv16 + 16 * i, tex->first_frame_id + (int32_t)i);
+      int rc = texture_stage(v, cur.sel, cur.img, cur.epoch, tex->pose_inv16 + 16 * i, tex->first_frame_id + (int32_t)i, claimed);
       if (rc) return rc;
     }
   }

@@ -73,6 +73,19 @@ __device__ __forceinline__ uint32_t hash_slot_alive(const VolumeDev& v, unsigned
   return kInvalidSlot;
 }
 
+// ... the same, also returning the entry index
+__device__ __forceinline__ uint32_t hash_slot_alive_ent(const VolumeDev& v, unsigned long long key, uint32_t* ent) {
+  uint32_t i = hash_key(key) & v.hmask;
+  for (uint32_t probe = 0; probe <= v.hmask; ++probe) {
+    const uint4 e = *reinterpret_cast<const uint4*>(&v.hent[i]);  // {key lo, key hi, slot, alive}
+    const unsigned long long cur = ((unsigned long long)e.y << 32) | e.x;
+    if (cur == key) { *ent = i; return (e.w & 1u) ? e.z : kInvalidSlot; }
+    if (cur == kEmptyKey) return kInvalidSlot;
+    i = (i + 1) & v.hmask;
+  }
+  return kInvalidSlot;
+}
+
 // Find or create the pool slot of a chunk id (general path: probing, insertion, revival).
 // Within one launch every key is unique (the visible list has no duplicates), so the payload of
 // a freshly inserted key is only read by later launches.  *is_new = chunk did not exist (absent

@@ -210,6 +210,12 @@ struct VolumeDev {
                         // mesh, appended by the mesher (and by its filter for meshes that just became empty), shard by shard
   uint32_t* patch_cnt;  // [2][kMeshShards][16] entries per shard (one counter per 64-B line), by frame parity
   unsigned long long* cand;  // [max_chunks] packed ids of the work entries that need an atlas slot
+  // dirty set of a textured frame as K-A builds it (each updated chunk's wave claims the chunk and its six face
+  // neighbours by stamp, Chisel.h:197-203): 32 shard lists by pool slot % 32, double-buffered by frame parity like the
+  // flat work list, which other producers (backlog list, ghost arrivals) keep using -- the mesher's filter walks both
+  int4* wl_ids;        // [2][kMeshShards][mesh_shard_rows] {id, w = hash entry index + 1 (0 = the slot is known alive)}
+  uint32_t* wl_slot;   // [2][kMeshShards][mesh_shard_rows] pool slot
+  uint32_t* wl_cnt;    // [2][kMeshShards][16] entries per shard (one counter per 64-B line)
   SelBuf sel;  // the selection set the launch works on
 };
 __host__ __device__ inline float* mesh_plane(const VolumeDev& v, uint32_t slot, int plane) {
@@ -231,6 +237,7 @@ struct FrameStage {
   FrameImages img;
   Pose pose;
   uint32_t epoch;
+  int claim_par = -1;        // >= 0: a mesher follows this frame; K-A builds the frame's dirty set into the shard lists of this parity
   bool coarse_summ = false;  // no mesher follows this frame: an updated chunk's summary becomes "anything" (kSummAny)
                              // instead of the classes written; the filter makes it exact when it next reads the chunk
 };
@@ -283,9 +290,11 @@ void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_dep
 uint32_t mesh_shard_rows(uint32_t max_chunks);
 // len_guess: the list length as far as the host knows (picks the filter's form); len_hint: host-visible word that
 // receives the actual length (may be null)
+// shards_par >= 0: the dirty set is the flat list PLUS the shard lists of that parity (VolumeDev::wl_*)
 void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
-                 uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, hipStream_t s);
-// per-frame dirty set of the fused flow -> work list of counter set `par`
+                 uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, int shards_par,
+                 hipStream_t s);
+// per-frame dirty set of the fused flow -> work list of counter set `par` (when K-A did not build it: FrameStage::claim_par)
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s);
 // ... when marks of earlier frames are still waiting for a mesher: everything marked since clear_floor
 void launch_dirty_backlog(const VolumeDev& v, int par, uint32_t clear_floor, hipStream_t s);

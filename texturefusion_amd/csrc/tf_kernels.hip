@@ -650,7 +650,7 @@ typedef const __attribute__((address_space(4))) u32x8* const_u32x8_ptr;
 template <bool COLOR, bool QUALITY, bool FUSED, bool FLAG, int GP>
 __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameImages& img, const Cam& cam,
                                                const IntegrateConsts& kc, const uint32_t epoch,
-                                               const uint32_t bid, const uint32_t nb) {
+                                               const uint32_t bid, const uint32_t nb, const int claim_par = -1) {
   const SelBuf& L = v.sel;
   const int lane = threadIdx.x & 63;
   // the wave id IS wave-uniform, but anything derived from threadIdx is divergent to the compiler;
@@ -1088,6 +1088,35 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       // kernel-argument struct, which kept the depth-only instance's copy of that struct in private memory.)
       if (updated) {
         if (lane == 0) v.mark_epoch[slot] = epoch + 1u;  // meshesToUpdate[id and 6 nbrs] = true, expanded lazily
+        if (claim_par >= 0) {
+          // A mesher follows this frame: the frame's dirty set (this chunk and its six face neighbours, those that
+          // exist, Chisel.h:197-203) is built here, behind the chunk's stores, instead of by a kernel of its own.
+          // Lane k looks neighbour k up, the per-slot stamp de-duplicates, the winner appends {id, slot} to the shard
+          // list of its pool slot.  A neighbour created or revived by another wave of THIS launch may be missed: it is
+          // then updated in this frame and claims itself, or it is parked again and does not exist for the mesher.  A
+          // neighbour that is alive now and parked later in this launch stays in the list: the entry carries its hash
+          // entry, and the mesher's filter drops chunks that are not alive (RecomputeMeshes' !HasChunk).
+          uint32_t cs = kInvalidSlot, ce = 0;
+          int4 q = id;
+          if (lane < 7) {
+            q = nbr7(id, lane);
+            if (lane == 0) { cs = slot; ce = ent; }
+            else if (part_owned(v, q.x, q.y, q.z)) cs = hash_slot_alive_ent(v, pack_id(q.x, q.y, q.z), &ce);
+            if (cs != kInvalidSlot && !(atomicMax(&v.mesh_rec[cs].stamp, epoch + 1u) < epoch + 1u)) cs = kInvalidSlot;
+            if (cs != kInvalidSlot) {
+              const uint32_t rows = v.max_chunks / kMeshShards + 258u;  // = mesh_shard_rows()
+              const uint32_t sh = cs & (kMeshShards - 1u);
+              const uint32_t p = atomicAdd(&v.wl_cnt[((claim_par & 1) * kMeshShards + sh) * 16], 1u);
+              if (p < rows) {
+                const size_t at = ((size_t)(claim_par & 1) * kMeshShards + sh) * rows + p;
+                v.wl_ids[at] = make_int4(q.x, q.y, q.z, (int)(ce + 1u));
+                v.wl_slot[at] = cs;
+              } else {
+                atomicOr(&v.vctl->status, kStMeshFull);
+              }
+            }
+          }
+        }
       } else if (is_new) {
         if (lane == 0) {
           if (!lazy_revive) v.hent[ent].alive = 0;
@@ -1319,6 +1348,7 @@ struct FrameLaunch {
   FrameCtl* ctl2;        // set of frame f+2
   const float* depth2;
   Pose P2;
+  int claim_par;         // FrameStage::claim_par of frame f
   uint32_t n_patch;      // patch stage of frame f-1: workgroups, counter-set parity, the frame as keyframe
   int patch_par;
   KfDev kf_patch;
@@ -1336,7 +1366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATCH ? TF_
   uint32_t role;
   if (b < a.n_ka) {
     role = 0;
-    integrate_body<COLOR, false, true, true, TF_KA_GP>(a.v, a.img, a.cam, a.kc, a.epoch, b, a.n_ka);
+    integrate_body<COLOR, false, true, true, TF_KA_GP>(a.v, a.img, a.cam, a.kc, a.epoch, b, a.n_ka, a.claim_par);
   } else if (PATCH && b < a.n_ka + a.n_patch) {
     role = 3;
     patch_body<true, true, true>(a.v, a.cam, a.patch_par, a.kf_patch, b - a.n_ka, a.n_patch);
@@ -1431,6 +1461,7 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   a.ig = ig;
   a.n_ka = a.n_sel = a.n_bbox = a.n_patch = 0;
   a.patch_par = 0;
+  a.claim_par = -1;
   a.epoch = 0;
   if (with_patch) {
     static const int npb = env_int("TF_PATCH_BLOCKS", 1024);
@@ -1450,6 +1481,7 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
     a.epoch = cur->epoch;
     a.n_ka = (uint32_t)(nblocks > 0 ? nblocks : 2048);
     color = cur->img.rgba != nullptr;
+    a.claim_par = cur->claim_par;
     if (cur->coarse_summ) a.kc.dbg |= kKaCoarseSumm;
   }
   if (next) {

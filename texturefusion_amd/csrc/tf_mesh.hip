@@ -203,6 +203,9 @@ __device__ __forceinline__ uint32_t filter_near(const VolumeDev& v, const int4 i
   uint32_t nslot = kInvalidSlot;
   if (k8 == 0 && have_own) {
     nslot = own_listed;  // the fused flow's list carries the chunk's own pool slot
+    // an entry K-A claimed (id.w = hash entry + 1) may have been parked later in that launch: RecomputeMeshes skips a
+    // chunk that does not exist (:240-242).  This load travels with the other lanes' hash probes.
+    if (id.w > 0 && !(v.hent[(uint32_t)id.w - 1u].alive & 1u)) nslot = kInvalidSlot;
   } else {
     const uint32_t ent = hash_find(v, pack_id(id.x + (k8 & 1), id.y + ((k8 >> 1) & 1), id.z + (k8 >> 2)));
     if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
@@ -304,29 +307,57 @@ __device__ __forceinline__ int near_k(int lane) { return (lane % 3 - 1) + 2 * ((
 //             the parked entries one wave each.  For long lists (the 69 k dirty chunks of the 1280x960 hall).
 // Either form is correct for any list; the host picks by the list length it last heard of (*len_hint, written here
 // into host-visible memory for the NEXT frame's choice -- no synchronisation, a stale value only costs time).
+// The dirty set = the flat list [0, *dcount) followed by the concatenation of the 32 shard lists K-A filled (shards_par >= 0,
+// VolumeDev::wl_*): entry e >= n_flat is row e - n_flat of that concatenation, resolved with a 32-lane scan of the counters.
 template <bool WAVE_FORM>
 __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
                                                      uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool use_summ,
-                                                     uint32_t* __restrict__ len_hint) {
+                                                     uint32_t* __restrict__ len_hint, int shards_par) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
-  uint32_t n = *dcount;
+  uint32_t n_flat = *dcount;
+  if (n_flat > max_entries) n_flat = max_entries;
+  // shard lists: per-lane inclusive scan of the 32 counters
+  const uint32_t wl_rows = mesh_shard_rows_d(v.max_chunks);
+  const size_t wl_base = (size_t)(shards_par & 1) * kMeshShards * wl_rows;
+  uint32_t sh_n = 0, sh_incl = 0;
+  if (shards_par >= 0) {
+    if (lane < (int)kMeshShards) { sh_n = v.wl_cnt[((shards_par & 1) * kMeshShards + lane) * 16]; if (sh_n > wl_rows) sh_n = wl_rows; }
+    sh_incl = sh_n;
+#pragma unroll
+    for (int o = 1; o < (int)kMeshShards; o <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)sh_incl, o);
+      if (lane >= o) sh_incl += u;
+    }
+  }
+  const uint32_t n_sh = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)sh_incl, kMeshShards - 1));
+  uint32_t n = n_flat + n_sh;
   if (n > max_entries) n = max_entries;
   if (len_hint && blockIdx.x == 0 && threadIdx.x == 0) *len_hint = n;
   const uint32_t nwaves = gridDim.x * 4;
   if (WAVE_FORM) {
     for (uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6)); entry < n;
          entry += nwaves) {
-      const int4 id = dlist[entry];
+      int4 id;
       uint32_t own_listed = kInvalidSlot;
-      if (dslot) own_listed = dslot[entry];  // (under a wave-uniform test: see profiles/r2/README.md)
+      if (entry < n_flat) {
+        id = dlist[entry];
+        if (dslot) own_listed = dslot[entry];  // (under a wave-uniform test: see profiles/r2/README.md)
+      } else {
+        const uint32_t r = entry - n_flat;
+        const uint32_t shd = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(lane < (int)kMeshShards && sh_incl <= r)));
+        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(sh_incl - sh_n), (int)(shd & 31u)));
+        const size_t at = wl_base + (size_t)shd * wl_rows + (r - first);
+        id = v.wl_ids[at];
+        own_listed = v.wl_slot[at];
+      }
       uint32_t own = kInvalidSlot;
       bool maybe = false;
       uint32_t near8 = kInvalidSlot;
-      if (lane < 8) near8 = filter_near(v, id, lane, lane, dslot != nullptr, own_listed, use_summ, &own, &maybe);
+      if (lane < 8) near8 = filter_near(v, id, lane, lane, dslot != nullptr || entry >= n_flat, own_listed, use_summ, &own, &maybe);
       own = (uint32_t)__shfl((int)own, 0);
       maybe = __shfl((int)maybe, 0) != 0;
       if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
@@ -340,6 +371,8 @@ __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDe
     return;
   }
   __shared__ uint32_t s_n, s_ne;
+  __shared__ uint32_t s_incl[kMeshShards], s_cnt[kMeshShards];
+  if (threadIdx.x < kMeshShards) { s_incl[threadIdx.x] = sh_incl; s_cnt[threadIdx.x] = sh_n; }  // (wave 0's lanes 0..31)
   __shared__ uint32_t s_eown[32];  // entries the summaries ruled out: their records are reset behind the barrier, by the
   __shared__ int4 s_eid[32];       // last wave, so that no entry of phase B waits for those round trips
   __shared__ int4 s_id[32];
@@ -353,12 +386,23 @@ __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDe
     __syncthreads();
     const uint32_t entry = base + (uint32_t)grp;
     if (entry < last) {
-      const int4 id = dlist[entry];
+      int4 id;
       uint32_t own_listed = kInvalidSlot;
-      if (dslot && k8 == 0) own_listed = dslot[entry];
+      if (entry < n_flat) {
+        id = dlist[entry];
+        if (dslot && k8 == 0) own_listed = dslot[entry];
+      } else {
+        const uint32_t r = entry - n_flat;
+        uint32_t shd = 0;
+        for (uint32_t q = 0; q < kMeshShards; ++q) shd += s_incl[q] <= r ? 1u : 0u;  // (32 LDS words: a linear pass)
+        shd &= kMeshShards - 1u;
+        const size_t at = wl_base + (size_t)shd * wl_rows + (r - (s_incl[shd] - s_cnt[shd]));
+        id = v.wl_ids[at];
+        if (k8 == 0) own_listed = v.wl_slot[at];
+      }
       uint32_t own;
       bool maybe;
-      const uint32_t nslot = filter_near(v, id, lane, k8, dslot != nullptr, own_listed, use_summ, &own, &maybe);
+      const uint32_t nslot = filter_near(v, id, lane, k8, dslot != nullptr || entry >= n_flat, own_listed, use_summ, &own, &maybe);
       if (own != kInvalidSlot) {  // RecomputeMeshes: !HasChunk -> skip (:240-242)
         if (maybe) {
           uint32_t at = 0;
@@ -433,7 +477,10 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : 5) void k_mesh(VolumeDev v, con
     // ... and the slot allocator's position is final: the patch kernel of THIS frame ranks its new patches against it
     v.actl->set[rearm ^ 1].slots_base = v.actl->n_slots;
   }
-  if (rearm >= 0 && blockIdx.x == 0 && t < (int)kMeshShards) v.patch_cnt[((rearm & 1) * kMeshShards + t) * 16] = 0u;
+  if (rearm >= 0 && blockIdx.x == 0 && t < (int)kMeshShards) {
+    v.patch_cnt[((rearm & 1) * kMeshShards + t) * 16] = 0u;
+    v.wl_cnt[((rearm & 1) * kMeshShards + t) * 16] = 0u;  // ... and the shard lists K-A of the next frame appends its dirty set to
+  }
   if (dbg == 9) mesh_stamp(v, blockIdx.x, 0);
   for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
     uint32_t shard = incl_l, idx = r - excl_l;
@@ -814,7 +861,8 @@ static bool filter_uses_summaries() {
 }
 
 void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
-                 uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, hipStream_t s) {
+                 uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, int shards_par,
+                 hipStream_t s) {
   if (!max_entries) return;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
@@ -825,10 +873,10 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   const int ppar = fused ? (rearm_set ^ 1) : -1;
   if (len_guess <= fgrid * 4u)
     hipLaunchKernelGGL(k_mesh_filter<true>, dim3(fgrid), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, epoch,
-                       v.mesh_nbr, cnt, cap_sh, ppar, filter_uses_summaries(), len_hint);
+                       v.mesh_nbr, cnt, cap_sh, ppar, filter_uses_summaries(), len_hint, shards_par);
   else
     hipLaunchKernelGGL(k_mesh_filter<false>, dim3(fgrid), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, epoch,
-                       v.mesh_nbr, cnt, cap_sh, ppar, filter_uses_summaries(), len_hint);
+                       v.mesh_nbr, cnt, cap_sh, ppar, filter_uses_summaries(), len_hint, shards_par);
   launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, s);
 }
 
@@ -1086,7 +1134,7 @@ int tf_update_meshes(tf_volume* v, int64_t* n_meshed) {
   const uint8_t* db = reinterpret_cast<const uint8_t*>(v->d_tmp);
   prof_begin(v, TF_PROF_MESH);
   launch_mesh(v->dev, v->mesh_par, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), n,
-              ++v->mesh_epoch, v->res, false, -1, n, nullptr, v->stream);
+              ++v->mesh_epoch, v->res, false, -1, n, nullptr, -1, v->stream);
   v->mesh_par ^= 1;
   prof_end(v);
   TF_HIP(hipGetLastError());

@@ -162,7 +162,13 @@ __device__ __forceinline__ float blend(const Taps& t, float c1, float c2, float 
   return c1;
 }
 
-constexpr int kVB = 2;  // 64-vertex blocks of a patch kept in registers: one sweep for meshes up to 128 vertices
+#ifndef TF_PATCH_KVB
+#define TF_PATCH_KVB 2
+#endif
+#ifndef TF_PATCH_KB
+#define TF_PATCH_KB 8
+#endif
+constexpr int kVB = TF_PATCH_KVB;  // 64-vertex blocks of a patch kept in registers: one sweep for meshes up to 128 vertices
 
 // bid / nb: this workgroup's index among the nb 256-thread workgroups that run the stage
 template <bool PROJECT, bool BLIT, bool FUSED>
@@ -464,7 +470,7 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
       const bool rows_aligned = (astep & 3u) == 0;
       const int ndw = (rowbytes + mis + 3) >> 2;
       const float inv = 1.0f / (float)ndw;
-      constexpr int kB = 8;  // 512 dwords in flight: a 24 x 18 slot has 18 x 18 = 324
+      constexpr int kB = TF_PATCH_KB;  // 512 dwords in flight: a 24 x 18 slot has 18 x 18 = 324
       for (int t0 = 0; t0 < rows * ndw; t0 += 64 * kB) {
         uint32_t val[kB];
         int off[kB], rr[kB];

@@ -81,6 +81,9 @@ struct AtlasState {
   AtlasCtl* d_actl = nullptr;
   int4* d_work_ids = nullptr;
   uint32_t* d_work_slot = nullptr;
+  int4* d_wl_ids = nullptr;        // VolumeDev::wl_*: the dirty set K-A builds (shard lists, two parities)
+  uint32_t* d_wl_slot = nullptr;
+  uint32_t* d_wl_cnt = nullptr;
   int4* d_patch_list = nullptr;
   uint32_t* d_patch_cnt = nullptr;
   uint32_t* h_dirty_len = nullptr;  // pinned, device-visible: the mesher's filter leaves the length of a frame's dirty list here
