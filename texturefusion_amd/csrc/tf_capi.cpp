@@ -368,9 +368,9 @@ int tf_volume_destroy(tf_volume* v) {
   }
   if (v->host_trace[5] > 0)
     fprintf(stderr, "tf host frames: %.0f calls; per call us: wait kernels %.1f, wait upload %.1f, staging copy %.1f, "
-                    "upload enqueue %.1f, launches %.1f\n", v->host_trace[5], v->host_trace[0] / v->host_trace[5],
-            v->host_trace[1] / v->host_trace[5], v->host_trace[2] / v->host_trace[5], v->host_trace[3] / v->host_trace[5],
-            v->host_trace[4] / v->host_trace[5]);
+                    "upload enqueue %.1f, launches %.1f; copies a launch waited for in the stream: %ld\n", v->host_trace[5],
+            v->host_trace[0] / v->host_trace[5], v->host_trace[1] / v->host_trace[5], v->host_trace[2] / v->host_trace[5],
+            v->host_trace[3] / v->host_trace[5], v->host_trace[4] / v->host_trace[5], v->host_waits);
   delete v->copy_pool;
   v->copy_pool = nullptr;
   if (v->copy_stream) hipStreamDestroy(v->copy_stream);
@@ -877,6 +877,24 @@ static int host_slot_done(tf_volume* v, int slot) {
   return TF_OK;
 }
 
+// the H2D copy of a staged host frame must be through before a launch reads its device images: nothing to do when the
+// copy event is already complete (the usual case: the entry point runs behind), otherwise the stream waits for it
+static int host_copy_ready(tf_volume* v, tf_volume::Pending* p) {
+  if (p->copied) return TF_OK;
+  static const bool dbg_nowait = getenv("TF_HOST_NOWAIT") && atoi(getenv("TF_HOST_NOWAIT"));  // timing experiment only: WRONG results
+  static const bool always_wait = getenv("TF_HOST_ALWAYS_WAIT") && atoi(getenv("TF_HOST_ALWAYS_WAIT"));  // A/B knob
+  hipEvent_t ev = v->hslot[p->slot].copied;
+  const hipError_t q = always_wait ? hipErrorNotReady : hipEventQuery(ev);
+  if (q == hipErrorNotReady) {
+    if (!dbg_nowait) TF_HIP(hipStreamWaitEvent(v->stream, ev, 0));
+    if (v->host_trace[5] >= 0) v->host_waits += 1;
+  } else if (q != hipSuccess) {
+    TF_HIP(q);
+  }
+  p->copied = true;
+  return TF_OK;
+}
+
 static int check_frames(int64_t n_all, const float* const* d_depth, const uint8_t* const* d_rgba) {
   for (int64_t f = 0; f < n_all; ++f)
     if ((reinterpret_cast<uintptr_t>(d_depth[f]) & 15) || !d_depth[f] ||
@@ -999,10 +1017,11 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     if (nr) {
       if (!v->copy_pool) {
         const char* e = getenv("TF_COPY_THREADS");
-        int helpers = e ? atoi(e) : 3;
+        int helpers = e ? atoi(e) : 7;
         if (helpers < 0) helpers = 0;
         if (helpers > 15) helpers = 15;
-        v->copy_pool = new CopyPool(helpers);
+        static const bool pin = !(getenv("TF_COPY_PIN") && !atoi(getenv("TF_COPY_PIN")));  // A/B knob, default on
+        v->copy_pool = new CopyPool(helpers, pin);
       }
       v->copy_pool->copy(dst, src, nb, nr);
     }
@@ -1010,7 +1029,6 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   lap(2, t);
   TF_HIP(hipMemcpyAsync(s.d, s.h, rgba ? npix * 8 : npix * 4, hipMemcpyHostToDevice, v->copy_stream));
   TF_HIP(hipEventRecord(s.copied, v->copy_stream));
-  TF_HIP(hipStreamWaitEvent(v->stream, s.copied, 0));
   lap(3, t);
   tf_volume::Pending cur;
   cur.d = reinterpret_cast<const float*>(s.d);
@@ -1020,8 +1038,11 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   if (pose_inv16) memcpy(cur.pinv, pose_inv16, sizeof(cur.pinv));
   cur.fid = frame_id;
   cur.slot = slot_index;
+  cur.copied = false;
   static const bool defer = !(getenv("TF_HOST_DEFER") && !atoi(getenv("TF_HOST_DEFER")));
-  if (!defer) {  // integrate at once: two selection-only launches per frame
+  if (!defer) {  // integrate at once: two selection-only launches per frame, the stream waits for the copy
+    rc = host_copy_ready(v, &cur);
+    if (rc) return rc;
     const float* dd[1] = {cur.d};
     const uint8_t* dc[1] = {cur.c};
     TexturedArgs tex{cur.pinv, cur.fid};
@@ -1032,23 +1053,29 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     return bind_frame(v, cur.d, cur.c);
   }
   // The launch pipeline of the streaming entry points, kept alive across per-frame calls: this call integrates the
-  // frame that arrived two calls ago, and that launch carries the selection stages of the two frames behind it
-  // (K-A(f-2) | K-C(f-1) | K-B(f)).  The deferral cannot be observed: every other entry point flushes first (TF_DEV).
-  if (v->n_pend < 2) {
+  // frame that arrived three calls ago, and that launch carries the selection stages of the two frames behind it
+  // (K-A(f-3) | K-C(f-2) | K-B(f-1)); frame f itself is only staged and copied.  Its copy has a whole call's time to
+  // finish before a launch needs it, so the host finds the copy event complete and no wait goes into the stream (a
+  // cross-stream wait ahead of every launch cost the textured stream 10 % -- profiles/r3).  The deferral cannot be
+  // observed: every other entry point flushes first (TF_DEV).
+  constexpr int ND = tf_volume::kHostDefer;
+  if (v->n_pend < ND) {
     v->pend[v->n_pend++] = cur;
     return TF_OK;
   }
-  const tf_volume::Pending p0 = v->pend[0], p1 = v->pend[1];
-  const float* dd[3] = {p0.d, p1.d, cur.d};
-  const uint8_t* dc[3] = {p0.c, p1.c, cur.c};
+  tf_volume::Pending p0 = v->pend[0], p1 = v->pend[1], p2 = v->pend[2];
+  for (tf_volume::Pending* q : {&p0, &p1, &p2}) { rc = host_copy_ready(v, q); if (rc) return rc; }
+  const float* dd[3] = {p0.d, p1.d, p2.d};
+  const uint8_t* dc[3] = {p0.c, p1.c, p2.c};
   float poses[36];
-  memcpy(poses, p0.pose, 48); memcpy(poses + 12, p1.pose, 48); memcpy(poses + 24, cur.pose, 48);
+  memcpy(poses, p0.pose, 48); memcpy(poses + 12, p1.pose, 48); memcpy(poses + 24, p2.pose, 48);
   TexturedArgs tex{p0.pinv, p0.fid};
   v->n_pend = 0;  // (helpers below enqueue_frames may pass through TF_DEV: nothing to flush while this call runs)
   rc = enqueue_frames(v, 1, 2, dd, dc, poses, p0.tex ? &tex : nullptr);
   v->pend[0] = p1;
-  v->pend[1] = cur;
-  v->n_pend = 2;
+  v->pend[1] = p2;
+  v->pend[2] = cur;
+  v->n_pend = ND;
   if (rc) return rc;
   rc = host_slot_done(v, p0.slot);
   if (rc) return rc;
@@ -1064,15 +1091,22 @@ namespace tf {
 int flush_deferred(tf_volume* v) {
   const int n = v->n_pend;
   if (!n) return TF_OK;
-  tf_volume::Pending p[2] = {v->pend[0], v->pend[1]};
+  constexpr int ND = tf_volume::kHostDefer;
+  tf_volume::Pending p[ND];
+  for (int k = 0; k < n; ++k) p[k] = v->pend[k];
   v->n_pend = 0;  // (enqueue_frames' helpers may pass through TF_DEV)
   for (int k = 0; k < n; ++k) {
-    const float* dd[2];
-    const uint8_t* dc[2];
-    float poses[24];
+    int rc = host_copy_ready(v, &p[k]);
+    if (rc) return rc;
+  }
+  for (int k = 0; k < n; ++k) {
+    const float* dd[ND];
+    const uint8_t* dc[ND];
+    float poses[12 * ND];
     for (int j = k; j < n; ++j) { dd[j - k] = p[j].d; dc[j - k] = p[j].c; memcpy(poses + 12 * (j - k), p[j].pose, 48); }
     TexturedArgs tex{p[k].pinv, p[k].fid};
-    int rc = enqueue_frames(v, 1, n - 1 - k, dd, dc, poses, p[k].tex ? &tex : nullptr);
+    const int ahead = n - 1 - k < 2 ? n - 1 - k : 2;
+    int rc = enqueue_frames(v, 1, ahead, dd, dc, poses, p[k].tex ? &tex : nullptr);
     if (rc) return rc;
     rc = host_slot_done(v, p[k].slot);
     if (rc) return rc;

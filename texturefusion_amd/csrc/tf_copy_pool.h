@@ -5,6 +5,8 @@
 // device processes it.  The pool splits a copy into equal parts; the calling thread takes parts too.
 #ifndef TF_COPY_POOL_H_
 #define TF_COPY_POOL_H_
+#include <pthread.h>
+#include <sched.h>
 #include <string.h>
 
 #include <atomic>
@@ -17,8 +19,29 @@ namespace tf {
 
 class CopyPool {
  public:
-  explicit CopyPool(int helpers) {
-    for (int i = 0; i < helpers; ++i) workers_.emplace_back([this] { loop(); });
+  // pin_near: keep the helpers on CPUs next to the calling thread's (the same group of eight logical CPUs, which
+  // shares a last-level cache slice on the hosts this runs on): helpers the scheduler parks on another socket halve the
+  // copy rate (measured: 37 vs 66-75 us per 2.4 MB frame from run to run).  Only CPUs the process may use are taken; with
+  // fewer than two of them in the group nothing is pinned.
+  explicit CopyPool(int helpers, bool pin_near = true) {
+    std::vector<int> near;
+    if (pin_near) {
+      cpu_set_t allowed;
+      const int me = sched_getcpu();
+      if (me >= 0 && sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+        for (int c = (me / 8) * 8; c < (me / 8) * 8 + 8; ++c)
+          if (c != me && c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) near.push_back(c);
+      if (near.size() < 2) near.clear();
+    }
+    for (int i = 0; i < helpers; ++i) {
+      workers_.emplace_back([this] { loop(); });
+      if (!near.empty()) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        CPU_SET(near[(size_t)i % near.size()], &one);
+        pthread_setaffinity_np(workers_.back().native_handle(), sizeof(one), &one);  // best effort
+      }
+    }
   }
   ~CopyPool() {
     {

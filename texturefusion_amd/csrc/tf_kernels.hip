@@ -1453,7 +1453,9 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
                   const FrameStage* next2, const PatchStage* patch, const Cam& cam, const Integ& ig, float res, hipStream_t s) {
   const bool with_patch = patch != nullptr && cur != nullptr && cur->img.rgba != nullptr;
   static const int nblocks7 = env_int("TF_KA_BLOCKS", ka_blocks_default());
-  static const int nblocksP = env_int("TF_KAP_BLOCKS", device_cus() * TF_KFP_WAVES);
+  // with the patch stage on board K-A gets one workgroup per CU more than the instance's residency: the patch / selection
+  // ranges are dispatched FIRST (below) and K-A's workgroups take the slots they leave as they finish
+  static const int nblocksP = env_int("TF_KAP_BLOCKS", device_cus() * (TF_KFP_WAVES + 1));
   const int nblocks = with_patch ? nblocksP : nblocks7;
   FrameLaunch a;
   a.v = v;
@@ -1502,8 +1504,12 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   const uint32_t total = a.n_ka + a.n_patch + a.n_sel + a.n_bbox;
   if (!total) return;
   if ((a.kc.dbg & 4096u) && a.n_sel && a.n_bbox) a.kc.dbg |= 8192u;  // timeline stamps: steady launches only
-  static const int sel_first = env_int("TF_SEL_FIRST", 0);  // tuning knob: dispatch the other roles ahead of K-A
-  a.rot = sel_first ? a.n_ka : 0u;
+  // Dispatch order.  K-A alone fills the chip, so its workgroups go first and the selection roles take the slots it
+  // frees.  With the patch stage on board that order leaves the stage's 15-us chains to start when K-A's waves end
+  // (profiles/r3: span 48 us); patch + selection first, K-A behind them as their waves finish: 44 us.
+  static const int sel_first = env_int("TF_SEL_FIRST", -1);  // tuning knob: 1 = the other roles ahead of K-A, 0 = K-A first
+  const bool others_first = sel_first >= 0 ? sel_first != 0 : with_patch;
+  a.rot = others_first ? a.n_ka : 0u;
   if (with_patch) hipLaunchKernelGGL((k_frame<true, true>), dim3(total), dim3(256), 0, s, a);
   else if (color) hipLaunchKernelGGL((k_frame<true, false>), dim3(total), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k_frame<false, false>), dim3(total), dim3(256), 0, s, a);

@@ -144,7 +144,7 @@ struct tf_volume {
   size_t img_pixels = 0;
   // drop-in per-frame host path (tf_integrate_frame_host): ring of pinned staging + device image slots, H2D on
   // its own stream so that the copy of frame f+1 overlaps the kernels of frame f
-  static constexpr int kHostRing = 6;  // two deferred frames + the one being staged + three whose kernels may still run
+  static constexpr int kHostRing = 8;  // three deferred frames + the one being staged + four whose kernels may still run
                                        // (a frame's images are read by its patch stage one launch behind its voxel update)
   struct HostSlot {
     uint8_t* h = nullptr;      // pinned: depth f32[npix] | rgba u8[4 npix]
@@ -155,6 +155,7 @@ struct tf_volume {
   size_t hslot_pixels = 0;
   int hslot_next = 0;
   hipStream_t copy_stream = nullptr;
+  long host_waits = 0;  // copies a launch had to wait for in the stream (TF_HOST_TRACE prints it)
   double host_trace[6] = {0, 0, 0, 0, 0, 0};  // TF_HOST_TRACE=1: microseconds per phase of tf_integrate_frame_host, [5] = calls
   tf::CopyPool* copy_pool = nullptr;  // helper threads of the staging copy (TF_COPY_THREADS, default 3)
   void* h_pinned = nullptr;      // pinned host staging (uploads / downloads)
@@ -168,8 +169,9 @@ struct tf_volume {
   uint32_t clear_floor = 0;  // stamps <= this were cleared (Chisel::CompressMeshes' chunksToUpdate.clear())
   uint32_t mesh_epoch = 0;   // meshing passes so far (MeshRec::epoch)
   int mesh_par = 0;          // parity of the next mesher launch (VolumeDev::mesh_cnt)
-  // frames tf_integrate_frame_host has staged but not integrated yet (it runs two frames behind: K-A of frame f - 2
-  // shares its launch with the selection stages of f - 1 and f, like the streaming entry points)
+  // frames tf_integrate_frame_host has staged but not integrated yet (it runs three frames behind: K-A of frame f - 3
+  // shares its launch with the selection stages of f - 2 and f - 1, like the streaming entry points; frame f itself is
+  // only being copied, so that no launch ever has to wait for a copy in the stream)
   struct Pending {
     const float* d = nullptr;
     const uint8_t* c = nullptr;
@@ -178,8 +180,10 @@ struct tf_volume {
     bool tex = false;
     int32_t fid = 0;
     int slot = 0;
+    bool copied = false;  // its H2D copy is known to be complete, or the handle's stream has been told to wait for it
   };
-  Pending pend[2];
+  static constexpr int kHostDefer = 3;  // frames tf_integrate_frame_host runs behind its caller
+  Pending pend[kHostDefer];
   int n_pend = 0;
   float* d_group = nullptr;  // staging of tf_integrate_depth_group_host: six depth images
   size_t d_group_pixels = 0;
