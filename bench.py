@@ -434,7 +434,7 @@ def main():
     if rank == 0 and prof is not None and not multi:
         skip_to_window()
         out["roofline"] = roofline(args, vol, cam, prof, kinds, K, pos, n_unique, d_depth, d_rgba, poses, pinv, textured,
-                                   dt_instr, pair_us, prof_child, 1e3 * dt / K)
+                                   dt_instr, pair_us, prof_child, 1e6 * dt / K)
         pos += K
 
     # ---- the keyframe-group flow of TSDFFusion: 1 colour + 6 depth-only frames over one chunk list -------

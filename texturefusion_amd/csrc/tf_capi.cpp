@@ -133,7 +133,7 @@ struct CtlSnap {
   VolCtl vc;
 };
 static int fetch_ctl(tf_volume* v, CtlSnap* out) {
-  TF_HIP(hipMemcpyAsync(&out->f, v->dev.sel.ctl, sizeof(FrameCtl), hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipMemcpyAsync(&out->f, v->dev.sel.ctl, offsetof(FrameCtl, ka_next), hipMemcpyDeviceToHost, v->stream));  // (without the pull counters)
   TF_HIP(hipMemcpyAsync(&out->vc, v->dev.vctl, sizeof(VolCtl), hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   if (out->vc.status) {

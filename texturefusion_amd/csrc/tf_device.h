@@ -55,6 +55,7 @@ struct __attribute__((aligned(16))) HEntry {
 
 // Device-resident control block of one selection: everything one frame's kernels hand to the
 // next, so the fused per-frame unit never synchronises with the host.
+constexpr int kKaCounters = 64, kKaCounterStride = 64;
 struct FrameCtl {
   uint32_t bbox_key[6];  // ordered-uint keys of min xyz / max xyz (K-B reduction)
   int32_t min_id[3];
@@ -71,6 +72,9 @@ struct FrameCtl {
   uint32_t pad0;
   unsigned long long emit_pack;  // the selection role's append counters: low word front, high word back entries
   uint32_t pad[2];
+  // fused flow: K-A's waves pull their entries from these counters (each 256 B from the next); counter c hands out the
+  // logical entries c, c + kKaCounters, ...  Zeroed by the frame's K-B stage, two launches ahead.
+  uint32_t ka_next[kKaCounters * kKaCounterStride];
 };
 
 // Volume-wide device words.

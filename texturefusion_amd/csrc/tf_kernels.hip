@@ -27,6 +27,9 @@
 #ifndef TF_KA_GP
 #define TF_KA_GP 2
 #endif
+#ifndef TF_KA_DYNAMIC
+#define TF_KA_DYNAMIC 0  // fused K-A: 1 = waves pull their list entries from 64 counters (measured slower, profiles/r3: off)
+#endif
 
 
 namespace tf {
@@ -115,6 +118,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
     ctl->n_list = 0;
     ctl->n_front = 0;
     ctl->emit_pack = 0ull;
+    for (int k = 0; k < kKaCounters; ++k) ctl->ka_next[k * kKaCounterStride] = 0u;
     if (vctl) {
       vctl->status = 0; vctl->n_tmp = 0;
       for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
@@ -171,6 +175,7 @@ void launch_pack_rgba(const uint8_t* rgb, const uint8_t* valid, uchar4* rgba, ui
 __device__ __forceinline__ void bbox_body(const float* __restrict__ depth, const Cam& cam, const Pose& P,
                                           FrameCtl* ctl, const uint32_t bid, const uint32_t nb) {
   if (bid == 0 && threadIdx.x == 0) { ctl->n_list = 0; ctl->n_front = 0; ctl->emit_pack = 0ull; }  // appended to by k_select<EMIT>
+  if (bid == 0 && threadIdx.x < kKaCounters) ctl->ka_next[threadIdx.x * kKaCounterStride] = 0u;  // K-A of this frame (two launches on) pulls its entries here
   float mn[3] = {1e8f, 1e8f, 1e8f}, mx[3] = {-1e8f, -1e8f, -1e8f};
   const int W = cam.W;
   const int nvec = (cam.W * cam.H) >> 2;
@@ -680,33 +685,34 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     }
   }
 
-  // Which entries does this wave take?  Round-robin over the logical list (costly chunks first) -- or, XCD-local
-  // (fused flow): workgroup g runs on XCD g % 8, and XCD x takes the x-th eighth of the costly entries followed by the
-  // x-th eighth of the cheap ones, its waves round-robin over that sequence.  The list is in the selection's
-  // (spatial) order, so an XCD's chunks project into one part of the image and its L2 holds that part instead of
-  // every L2 holding the whole image.
-  const bool xcd_local = FUSED && (kc.dbg & 32768u) && (nb % 8u) == 0u;
-  uint32_t seq_first = wave, seq_stride = nwaves, seq_len = n;
-  uint32_t f_start = 0, f_cnt = n, b_start = 0;
-  if (xcd_local) {
-    const uint32_t x = bid & 7u;
-    seq_first = (bid >> 3) * 4u + (wave & 3u);
-    seq_stride = nwaves >> 3;
-    const uint32_t nbk = n - nf;
-    f_start = (uint32_t)(((unsigned long long)x * nf) >> 3);
-    f_cnt = (uint32_t)(((unsigned long long)(x + 1u) * nf) >> 3) - f_start;
-    b_start = nf + (uint32_t)(((unsigned long long)x * nbk) >> 3);
-    seq_len = f_cnt + (nf + (uint32_t)(((unsigned long long)(x + 1u) * nbk) >> 3) - b_start);
+  // Which entries does this wave take?
+  //  call-by-call flow: round-robin over the list (wave w: entries w, w + nwaves, ...).
+  //  fused flow: the same, over the two-ended list (costly entries first).
+  //  TF_KA_DYNAMIC=1 (A/B knob, off): a wave PULLS its entries from one of 64 counters in the frame's control block
+  //  (a device word serves ~88 pulls per us, MI355X_MICROARCH.md "dequeue": with eight counters the 18 k pulls of a
+  //  launch stalled the whole chip, k_frame 42 -> 90 us); counter c hands out the logical entries c, c + 64, ...  The
+  //  idea: waves that start late (the patch / selection ranges are dispatched ahead of K-A) or draw costly chunks take
+  //  fewer entries, so the launch ends when the work does.  Measured (profiles/r3): holding two indices per wave is
+  //  static dealing by another name (42 -> 51 us: early waves park work late waves could have started); holding one and
+  //  reading its record at the top of the iteration 42 -> 48 us, TSDF-only 27.5 -> 28.8 us -- the returning atomic sits
+  //  ahead of the depth gathers in the wave's in-order memory queue.  The pull is a buffer atomic whose offset is out of
+  //  range for every lane but lane 0: no exec-mask branch (`if (lane == 0) atomicAdd` made the kernel spill 200 B/lane).
+  constexpr bool DYN = FUSED && TF_KA_DYNAMIC;
+  const uint32_t kac = DYN ? (wave & (uint32_t)(kKaCounters - 1)) : 0u;
+  const __amdgpu_buffer_rsrc_t rs_ctr = __builtin_amdgcn_make_buffer_rsrc((void*)&L.ctl->ka_next[kac * kKaCounterStride], 0, 4, 0x00020000);
+  const int ctr_off = lane == 0 ? 0 : kOOB;
+  uint32_t e_first = wave, e_second = wave + nwaves;
+  if (DYN) {
+    uint32_t k0 = (uint32_t)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rs_ctr, ctr_off, 0, 0);
+    k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);
+    e_first = (uint32_t)kKaCounters * k0 + kac;
+    e_second = e_first;  // (unknown yet: pulled while the first entry is processed)
   }
-  auto logical_of = [&](uint32_t k) -> uint32_t {  // sequence position -> logical list index
-    if (!xcd_local) return k;
-    return k < f_cnt ? f_start + k : b_start + (k - f_cnt);
-  };
   // the wave's first list record is requested before anything else: it arrives while the centroid
-  // table is copied (64-B records {o.xyz, wD | upper, id.xyz | spare}; the slot exists for any wave id)
+  // table is copied (64-B records {o.xyz, wD | upper, id.xyz | spare}; the slot exists for any index)
   u32x8 rec_next;
   {
-    const uint32_t e0 = seq_first < seq_len ? logical_of(seq_first) : 0u;
+    const uint32_t e0 = e_first < n ? e_first : 0u;
     rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (e0 < v.max_list ? (FUSED ? list_phys(v, e0, nf) : e0) : 0u)]);
   }
 
@@ -750,19 +756,27 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     v.phase_buf[wave * 16 + 9] = 0;
   }
 
-  for (uint32_t k = seq_first; k < seq_len; k += seq_stride) {
-    const uint32_t e = logical_of(k);
+  // static scheme: e_next = e + nwaves, its record requested at the top of the iteration.  dynamic scheme: the wave
+  // holds ONE entry (with ~1.5 entries per wave anything a wave parks in advance is work another wave could have
+  // started); the next index is pulled at the top of the iteration, and its record is read at the top of the next one
+  for (uint32_t e = e_first, e_next = e_second; e < n; e = e_next) {
     const uint32_t pe = FUSED ? list_phys(v, e, nf) : e;  // where the entry's record and outputs live
     // The list entry (per-chunk scalars + id) was written by the previous launch, so it is read
     // through the scalar cache: one 64-B record, one s_load, one wait, off the vector-memory queue
     // of the CU (a vector load here would wait behind every gather of the other waves).
+    if (DYN && e != e_first) rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * list_phys(v, e, nf)]);
     const u32x8 prw = rec_next;
-    {  // the next record of this wave travels while this chunk is processed (speculative: the slot
-       // exists even when e + nwaves >= n, it just holds an older frame's record)
-      const uint32_t kn = k + seq_stride < seq_len ? k + seq_stride : k;
-      const uint32_t en = logical_of(kn);
+    uint32_t pull = 0;  // dynamic scheme: the next index, in flight until the end of the iteration
+    if (DYN) {
+      pull = (uint32_t)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rs_ctr, ctr_off, 0, 0);
+    } else {
+      // the next record of this wave travels while this chunk is processed (speculative: the slot
+      // exists even when the index is past the list, it just holds an older frame's record)
+      e_next = e + nwaves;
+      const uint32_t en = e_next < n ? e_next : e;
       rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (FUSED ? list_phys(v, en, nf) : en)]);
     }
+    auto advance = [&]() { if (DYN) e_next = (uint32_t)kKaCounters * (uint32_t)__builtin_amdgcn_readfirstlane((int)pull) + kac; };
     const int4 id = make_int4((int)prw[5], (int)prw[6], (int)prw[7], 0);
     const bool owned = part_owned(v, id.x, id.y, id.z);
     if (!owned) {
@@ -770,6 +784,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         L.list_slot[pe] = kInvalidSlot; L.list_ent[pe] = 0; L.list_new[pe] = 0; L.list_needs[pe] = 0;
         L.list_quality[pe] = 0.0f; L.list_rows[pe] = 0;
       }
+      advance();
       continue;
     }
     // slot lookup: ONE 16-B scalar load of the chunk's home hash entry, consumed after the
@@ -798,7 +813,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const float band = 32.0f * kc.res;
     const bool div_safe = (fabsf(o2) > band) && (fabsf(o2) < 1048576.0f) && (fabsf(o0) < 1048576.0f) &&
                           (fabsf(o1) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
-    if ((kc.dbg & 8192u) && k == seq_first && lane == 0 && wave < (uint32_t)kPhaseWaves) {
+    if ((kc.dbg & 8192u) && e == e_first && lane == 0 && wave < (uint32_t)kPhaseWaves) {
       asm volatile("" :: "s"(o0), "s"(o1), "s"(o2), "s"(id.x));
       v.phase_buf[wave * 16 + 15] = __builtin_amdgcn_s_memrealtime();  // timeline aid: first entry loaded
     }
@@ -904,6 +919,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         L.list_slot[pe] = kInvalidSlot; L.list_ent[pe] = 0; L.list_new[pe] = 0; L.list_needs[pe] = 0;
         L.list_quality[pe] = 0.0f; L.list_rows[pe] = 0;
       }
+      advance();
       continue;
     }
     const __amdgpu_buffer_rsrc_t rs_T =
@@ -1138,6 +1154,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       L.list_quality[pe] = qsum;
       L.list_rows[pe] = (uint16_t)(rows_t | (rows_c << 8));
     }
+    advance();
   }
 }
 
