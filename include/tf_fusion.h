@@ -57,11 +57,15 @@ typedef struct {
   int32_t atlas_w;       /* default 13824 (Structure/Atlas.h:29) */
   int32_t atlas_h;       /* default 13824 (Structure/Atlas.h:30) */
   int32_t max_keyframes; /* keyframe image cache slots for the atlas; default 64 */
-  int32_t reserved;
+  /* blocks of the shared mesh overflow pool (167 KB each, room for the largest mesh a chunk can have); 0 = default
+   * max(64, max_chunks / 256), at most 2047; -1 = none */
+  int32_t mesh_overflow_blocks;
   /* device-resident meshes (ChunkManager::allMeshes): one fixed block per chunk-pool slot.  A mesh has at
-   * most 2187 vertices / 2560 triangles (9x9x9x3 edge grid, 512 cells x 5); a mesh that does not fit is
-   * stored empty and reported as TF_ERR_CAPACITY at the next synchronising call.  0 = default 256 / 512
-   * (a planar surface through a chunk has 81 / 128). */
+   * most 2187 vertices / 2560 triangles (9x9x9x3 edge grid, 512 cells x 5); a mesh that does not fit the slot's
+   * block is kept in a block of the overflow pool (handed out once per chunk, never returned before
+   * tf_volume_reset) -- the reference emits whatever a chunk produces (Structure/ChunkManager.cpp:856-918).  Only
+   * when that pool is exhausted is a mesh stored empty and reported as TF_ERR_CAPACITY at the next synchronising
+   * call.  0 = default 256 / 512 (a planar surface through a chunk has 81 / 128). */
   int32_t mesh_max_vertices;
   int32_t mesh_max_triangles;
 } tf_config;
@@ -162,6 +166,26 @@ TF_API int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint
 TF_API int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t n,
                         int integrate_flag, int use_color, int use_quality,
                         uint8_t* inout_needs_update, float* out_quality);
+/* ---- view-selection bookkeeping on the device ------------------------------
+ * Chunk::observations (3rd_party/open_chisel/geometry/Chunk.h:171) lives in HBM, keyed by (chunk, keyframe):
+ * tf_observations_record   the write of Chisel::IntegrateDepthScanColor (Structure/Chisel.h:244-247) for the list the
+ *                          last tf_integrate worked on: observations[keyframe_id] = quality where quality > 0 and the
+ *                          chunk's needsUpdateFlag is set (keyframe_id < 0: nothing, as in the reference)
+ * tf_observations_retract  MobileFusion::RetractObservations' chunk side (GCFusion/MobileFusion.cpp:252-260):
+ *                          observations.erase(keyframe_id) for the listed chunks that exist
+ * tf_export_datacost       what TexMap::update_datacost (Structure/TexMap.cpp:64-105) reads, as one table: for chunk i of
+ *                          chunksToUpdate out[i * (1 + n_frames) + 0] = observations[frame_index], [1 + j] =
+ *                          observations[frames_to_update[j]]; 0 = no observation (recorded qualities are > 0)
+ * tf_export_adjacency      the edges TexMap::update_chunkgraph (Structure/TexMap.cpp:50-62) / UniGraph::add_edge_by_node
+ *                          (uni_graph.cpp:41-49) add: one record int32[4] = {i, neighbour id} per set Mesh::adj flag of
+ *                          chunk ids[i] whose face neighbour (chisel::neighbourhood, ChunkManager.h:55-57) owns a mesh
+ *                          (the caller keeps the graph and drops neighbours that are not nodes); order arbitrary */
+TF_API int tf_observations_record(tf_volume* v, int32_t keyframe_id);
+TF_API int tf_observations_retract(tf_volume* v, int32_t keyframe_id, const int32_t* ids, int64_t n);
+TF_API int tf_export_datacost(tf_volume* v, const int32_t* ids, int64_t n, int32_t frame_index,
+                              const int32_t* frames_to_update, int32_t n_frames, float* out);
+TF_API int tf_export_adjacency(tf_volume* v, const int32_t* ids, int64_t n, int32_t* out_edges, int64_t cap_edges,
+                               int64_t* n_edges);
 /* The local frames of a keyframe group in one visit per chunk (GCFusion/MobileFusion.cpp:187-203: after the keyframe's
  * own IntegrateDepthScanColor, its corresponding frames are integrated depth-only over the SAME chunk list, each with
  * its own pose).  Equivalent, bit for bit, to n_frames successive tf_integrate(use_color = 0) calls with these depth

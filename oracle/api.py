@@ -115,6 +115,8 @@ def lib():
     L.tfo_volume_has_chunk.argtypes = [vp, i32p]
     L.tfo_volume_get_chunk.argtypes = [vp, i32p, fp, fp, u16p]
     L.tfo_volume_set_chunk.argtypes = [vp, i32p, fp, fp, u16p]
+    L.tfo_volume_retract_observations.restype = C.c_int64
+    L.tfo_volume_retract_observations.argtypes = [vp, C.c_int, i32p, C.c_int64]
     L.tfo_volume_get_observations.restype = C.c_int64
     L.tfo_volume_get_observations.argtypes = [vp, i32p, i32p, fp, C.c_int64]
     L.tfo_volume_num_dirty.restype = C.c_int64
@@ -320,6 +322,11 @@ class Volume:
         if n < 0:
             raise KeyError(tuple(cid))
         return {int(kf[i]): float(q[i]) for i in range(n)}
+
+    def retract_observations(self, kf, ids):
+        """MobileFusion::RetractObservations' chunk side: observations.erase(kf) for the listed chunks"""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        return int(self.L.tfo_volume_retract_observations(self.h, int(kf), _p(ids, C.c_int32), len(ids)))
 
     def dirty(self):
         n = int(self.L.tfo_volume_num_dirty(self.h))

@@ -733,6 +733,23 @@ static void chunk_set_obs(tfo_chunk* c, int kf, float q) { /* observations[kf] =
   c->obs[i].kf = kf; c->obs[i].q = q;
   c->n_obs++;
 }
+/* MobileFusion::RetractObservations, the chunk side (GCFusion/MobileFusion.cpp:252-260): for every listed chunk that
+ * exists, chunk->observations.erase(frame_id).  Returns the number of observations erased. */
+int64_t tfo_volume_retract_observations(tfo_volume* v, int kf, const int32_t* ids, int64_t n) {
+  int64_t erased = 0;
+  for (int64_t k = 0; k < n; k++) {
+    tfo_chunk* c = vol_get(v, ids + 3 * k);
+    if (!c) continue; /* !manager.HasChunk(kf.validChunks[i]) */
+    for (int i = 0; i < c->n_obs; i++)
+      if (c->obs[i].kf == kf) {
+        memmove(c->obs + i, c->obs + i + 1, sizeof(tfo_obs) * (c->n_obs - i - 1));
+        c->n_obs--;
+        erased++;
+        break;
+      }
+  }
+  return erased;
+}
 int64_t tfo_volume_get_observations(const tfo_volume* v, const int id[3], int32_t* kf, float* q,
                                     int64_t cap) {
   tfo_chunk* c = vol_get(v, id);

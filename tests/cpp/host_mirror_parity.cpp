@@ -280,6 +280,20 @@ int main() {
         entries += want.size();
       }
       CHECK(entries > 50);
+      // ... and the same bookkeeping fed by the DEVICE's exports (tf_export_adjacency / tf_export_datacost over the
+      // observation table tf_observations_record keeps in HBM): identical graph, costs and statistics
+      {
+        chisel::TexMap dev;
+        CHECK(dev.update_chunkgraph_device(chunksToUpdate, chiselMap.Handle()) == TF_OK);
+        CHECK(dev.chunkGraph.num_nodes() == n_patches && dev.chunkGraph.num_edges() == edges.size());
+        for (const auto& e : edges) CHECK(dev.chunkGraph.has_edge(e.first, e.second) && dev.chunkGraph.has_edge(e.second, e.first));
+        dev.dataCost.set_value(0, 0, 123.0f);
+        CHECK(dev.update_datacost_device(chunksToUpdate, chiselMap.Handle(), lookup, kfIndex + 1, framesToUpdate) == TF_OK);
+        for (size_t i = 0; i < n_patches; ++i) {
+          CHECK(dev.dataCost.col(i) == texmap.dataCost.col(i));
+          CHECK(dev.statistic[i] == texmap.statistic[i]);
+        }
+      }
       texmap.check_graph(cm);  // every node still has its mesh: nothing is removed
       CHECK(texmap.chunkGraph.num_edges() == edges.size() && texmap.chunkGraph.get_adj_nodes(edges.begin()->first).size() > 0);
     }

@@ -140,10 +140,61 @@ def test_tilted_plane_and_random_field(gpu_required):
     gv.close()
 
 
-def test_mesh_capacity_overflow_is_reported(gpu_required):
+def test_meshes_beyond_the_slot_block_live_in_the_overflow_pool(gpu_required):
+    """Blocks of 64 vertices / 64 triangles per pool slot and dense random fields (meshes of several hundred vertices):
+    every mesh goes to a block of the shared overflow pool and equals the oracle's (the reference emits whatever a chunk
+    produces, ChunkManager.cpp:856-918); a re-mesh keeps the chunk's block; meshes that shrink stay where they are; the
+    atlas stage and the vertex packing read them there."""
     from texturefusion_amd import capi
     cam = synth.Camera()
-    gv = capi.Volume(RES5, cam, max_chunks=1 << 10, mesh_max_vertices=64, mesh_max_triangles=64)
+    ov = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 10, mesh_max_vertices=64, mesh_max_triangles=64, mesh_overflow_blocks=16)
+    rng = np.random.default_rng(1)
+    ids = np.array(list(np.ndindex(2, 2, 2)), np.int32)
+
+    def fill(scale):
+        for cid in ids:
+            sdf = (rng.standard_normal(512) * scale).astype(np.float32)
+            col = rng.integers(1, 9, 2048).astype(np.uint16)
+            for v in (ov, gv):
+                v.set_chunk(cid, sdf, np.full(512, 100.0, np.float32), col)
+        for v in (ov, gv):
+            v.finalize(ids, np.ones(8, np.uint8), np.zeros(8, np.uint8))
+            v.update_meshes()
+
+    fill(0.01)
+    assert _compare_meshes(ov, gv, "overflow pool") == 8
+    assert max(len(ov.get_mesh(c)["verts"]) for c in ids) > 256
+    fill(0.01)  # re-meshed: the same eight blocks are reused (16 in the pool, 8 chunks: a leak would exhaust it next time)
+    assert _compare_meshes(ov, gv, "overflow pool, second pass") == 8
+    fill(0.01)
+    assert _compare_meshes(ov, gv, "overflow pool, third pass") == 8
+    # the atlas stage on meshes that live in the overflow pool (GeneratePatches -> UpdateAtlas, label = keyframe 1)
+    oa = O.Atlas(RES5)
+    depth, rgba, _, pose = synth.wall_frame(1.0, cam, seed=3)
+    kfs = {1: (np.ascontiguousarray(rgba[..., :3]), depth, synth.pose_inverse16(pose))}
+    gv.keyframe_cache(1, *kfs[1])
+    cids = ov.compress_meshes()
+    assert np.array_equal(cids, gv.compress_meshes()) and len(cids) == 8
+    labels = np.ones(8, np.int32)
+    ov.generate_patches(oa, cids, labels, kfs)
+    gv.generate_patches(cids, labels)
+    g = gv.get_patches(cids)
+    for i, c in enumerate(cids):
+        o = ov.get_patch(c)
+        a, b = g["voff"][i], g["voff"][i + 1]
+        assert int(g["texloc"][i]) == o["texloc"] and np.array_equal(g["bbox"][i], o["bbox"])
+        assert b - a == len(o["texcoord"]) and b - a > 64
+        assert np.array_equal(g["texcoord"][a:b].view(np.uint32), o["texcoord"].view(np.uint32))
+        assert np.array_equal(g["texcolor"][a:b].view(np.uint32), o["texcolor"].view(np.uint32))
+    gv.close()
+
+
+def test_mesh_overflow_pool_exhaustion_is_reported(gpu_required):
+    """no overflow pool (mesh_overflow_blocks = -1): a mesh beyond the slot's block is stored empty and reported"""
+    from texturefusion_amd import capi
+    cam = synth.Camera()
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 10, mesh_max_vertices=64, mesh_max_triangles=64, mesh_overflow_blocks=-1)
     rng = np.random.default_rng(1)
     for c in np.ndindex(2, 2, 2):
         cid = np.array(c, np.int32)

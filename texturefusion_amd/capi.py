@@ -35,7 +35,7 @@ SYMBOLS = (
     "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
     "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
-    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_profile_calibrate", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
+    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_profile_calibrate", "tf_observations_record", "tf_observations_retract", "tf_export_datacost", "tf_export_adjacency", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_set_pose",
     "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_meshes_upload",
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
@@ -59,7 +59,7 @@ class TFError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_chunks", C.c_int64), ("max_list", C.c_int64),
                 ("max_coarse", C.c_int64), ("atlas_w", C.c_int32), ("atlas_h", C.c_int32),
-                ("max_keyframes", C.c_int32), ("reserved", C.c_int32),
+                ("max_keyframes", C.c_int32), ("mesh_overflow_blocks", C.c_int32),
                 ("mesh_max_vertices", C.c_int32), ("mesh_max_triangles", C.c_int32)]
 
 
@@ -125,6 +125,10 @@ def lib():
     L.tf_profile_enable.argtypes = [vp, C.c_uint32]
     L.tf_profile_get.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.tf_profile_calibrate.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
+    L.tf_observations_record.argtypes = [vp, C.c_int32]
+    L.tf_observations_retract.argtypes = [vp, C.c_int32, i32p, C.c_int64]
+    L.tf_export_datacost.argtypes = [vp, i32p, C.c_int64, C.c_int32, i32p, C.c_int32, fp]
+    L.tf_export_adjacency.argtypes = [vp, i32p, C.c_int64, i32p, C.c_int64, i64p]
     L.tf_debug_phase_raw.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int64]
     L.tf_set_partition.argtypes = [vp, C.c_int32, C.c_int32]
     L.tf_set_partition_key.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
@@ -215,10 +219,10 @@ class Volume:
 
     def __init__(self, res, cam=None, max_chunks=1 << 17, max_list=1 << 18, max_coarse=1 << 20,
                  atlas_w=0, atlas_h=0, device=0, use_color=True, stream=None, mesh_max_vertices=0,
-                 mesh_max_triangles=0):
+                 mesh_max_triangles=0, mesh_overflow_blocks=0):
         self.L = lib()
         self.h = C.c_void_p()
-        cfg = Config(device, max_chunks, max_list, max_coarse, atlas_w, atlas_h, 0, 0, mesh_max_vertices,
+        cfg = Config(device, max_chunks, max_list, max_coarse, atlas_w, atlas_h, 0, mesh_overflow_blocks, mesh_max_vertices,
                      mesh_max_triangles)
         dims = (C.c_int32 * 3)(8, 8, 8)
         rc = self.L.tf_volume_create(dims, np.float32(res), int(use_color), C.byref(cfg), C.byref(self.h))
@@ -490,6 +494,31 @@ class Volume:
         p = Profile()
         self._ck(self.L.tf_profile_get(self.h, C.byref(p), int(reset)))
         return {PROF_NAMES[i]: (p.ms[i], p.launches[i]) for i in range(len(PROF_NAMES))}
+
+    # -- Chunk::observations on the device and the exports TexMap consumes
+    def observations_record(self, keyframe_id):
+        self._ck(self.L.tf_observations_record(self.h, int(keyframe_id)))
+
+    def observations_retract(self, keyframe_id, ids):
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        self._ck(self.L.tf_observations_retract(self.h, int(keyframe_id), _p(ids, C.c_int32), len(ids)))
+
+    def export_datacost(self, ids, frame_index, frames_to_update=()):
+        """table [n, 1 + len(frames_to_update)] of observation qualities (0 = none), TexMap::update_datacost's input"""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        fr = np.ascontiguousarray(frames_to_update, np.int32).reshape(-1)
+        out = np.zeros((len(ids), 1 + len(fr)), np.float32)
+        self._ck(self.L.tf_export_datacost(self.h, _p(ids, C.c_int32), len(ids), int(frame_index),
+                                           _p(fr, C.c_int32) if len(fr) else None, len(fr), _p(out, C.c_float)))
+        return out
+
+    def export_adjacency(self, ids):
+        """edges [m, 4] = (index into ids, neighbour id) of TexMap::update_chunkgraph"""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1, 3)
+        out = np.zeros((6 * max(1, len(ids)), 4), np.int32)
+        n = C.c_int64(0)
+        self._ck(self.L.tf_export_adjacency(self.h, _p(ids, C.c_int32), len(ids), _p(out, C.c_int32), len(out), C.byref(n)))
+        return out[:n.value]
 
     def profile_calibrate(self, n_pairs=200):
         """microseconds a HIP-event pair around an empty launch reads (the floor inside every profile_get time)"""

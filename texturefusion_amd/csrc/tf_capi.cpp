@@ -118,7 +118,7 @@ static int status_to_error(uint32_t st) {
   if (st & kStCoarseFull) m += " candidate grid full (raise tf_config.max_coarse)";
   if (st & kStMissing) m += " list names a chunk that does not exist";
   if (st & kStHashFull) m += " hash table full";
-  if (st & kStMeshFull) m += " a mesh exceeds the per-chunk mesh block (raise tf_config.mesh_max_vertices / mesh_max_triangles)";
+  if (st & kStMeshFull) m += " a mesh exceeds the per-chunk mesh block and the overflow pool is exhausted (raise tf_config.mesh_overflow_blocks or mesh_max_vertices / mesh_max_triangles)";
   if (st & kStAtlasFull) m += " No enough space for texture storage.";  // std::overflow_error text, Atlas.cpp:53
   if (st & kStXchgFull) m += " a rank's ghost band did not fit the boundary exchange block (raise cap_records)";
   set_error(m);
@@ -158,6 +158,7 @@ static int init_device_state(tf_volume* v) {
   v->cur_sel = 0;
   d.sel = v->selbuf[0];
   launch_fill_pool(d, 0, d.max_chunks, s);
+  TF_HIP(hipMemsetAsync(d.obs_key, 0xFF, sizeof(unsigned long long) * ((size_t)d.obs_mask + 1), s));  // no observations
   launch_init_meshes(d, s);  // chunkManager.Reset(): allMeshes.clear() (ChunkManager.cpp:272-275)
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
@@ -316,11 +317,29 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   d.erase_epoch = d.mark_epoch + d.max_chunks;
   if ((rc = dev_alloc(v, &d.phase_buf, (size_t)kPhaseWaves * 16))) return fail(rc);
   if ((rc = dev_alloc(v, &d.vctl, (size_t)1))) return fail(rc);
+  {  // Chunk::observations on the device: four (chunk, keyframe) pairs per chunk of capacity, at least 64 k
+    const size_t ocap = pow2_at_least(std::max<size_t>((size_t)d.max_chunks * 4, (size_t)1 << 16));
+    d.obs_mask = (uint32_t)(ocap - 1);
+    if ((rc = dev_alloc(v, &d.obs_key, ocap))) return fail(rc);
+    if ((rc = dev_alloc(v, &d.obs_q, ocap))) return fail(rc);
+  }
   d.mesh_cv = (uint32_t)v->cfg.mesh_max_vertices;
   d.mesh_ct = (uint32_t)v->cfg.mesh_max_triangles;
   if ((rc = dev_alloc(v, &d.mesh_v, (size_t)d.max_chunks * kMeshPlanes * d.mesh_cv))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_t, (size_t)d.max_chunks * 3 * d.mesh_ct))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_rec, (size_t)d.max_chunks))) return fail(rc);
+  {  // overflow pool for meshes beyond the slot's block (entries of the patch lists carry the block in 11 bits)
+    int64_t nb = v->cfg.mesh_overflow_blocks;
+    if (nb == 0) nb = std::max<int64_t>(64, v->cfg.max_chunks / 256);
+    if (nb < 0 || d.max_chunks > (1u << kPlOvfShift)) nb = 0;
+    if (nb > 2047) nb = 2047;
+    d.ovf_blocks = (uint32_t)nb;
+    if (nb) {
+      if ((rc = dev_alloc(v, &d.ovf_v, (size_t)nb * kMeshPlanes * kOvfCV))) return fail(rc);
+      if ((rc = dev_alloc(v, &d.ovf_t, (size_t)nb * 3 * kOvfCT))) return fail(rc);
+      if ((rc = dev_alloc(v, &d.ovf_vlist, (size_t)nb * kOvfCV))) return fail(rc);
+    }
+  }
   if ((rc = dev_alloc(v, &d.mesh_nbr, (size_t)kMeshShards * mesh_shard_rows(d.max_chunks) * 32))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_cnt, (size_t)2 * kMeshShards * 16))) return fail(rc);
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
@@ -1333,6 +1352,93 @@ int tf_profile_get(tf_volume* v, tf_profile* out, int reset) {
   prof_collect(v);
   *out = v->prof_acc;
   if (reset) memset(&v->prof_acc, 0, sizeof(v->prof_acc));
+  return TF_OK;
+}
+
+// ---- Chunk::observations on the device + the exports TexMap consumes -----------------
+// ids (host, int32[3n]) -> int4 list at the start of d_tmp (which must hold 16 n + extra bytes); returns after the copy
+// has been enqueued
+static int ids_to_device(tf_volume* v, const int32_t* ids, int64_t n, size_t extra) {
+  int rc = ensure_tmp(v, (size_t)n * 16 + extra + 64);
+  if (rc) return rc;
+  rc = ensure_pinned(v, (size_t)n * 16 + extra + 64);
+  if (rc) return rc;
+  TF_HIP(hipStreamSynchronize(v->stream));  // previous use of the staging buffer
+  int32_t* h = reinterpret_cast<int32_t*>(v->h_pinned);
+  for (int64_t i = 0; i < n; ++i) { h[4 * i] = ids[3 * i]; h[4 * i + 1] = ids[3 * i + 1]; h[4 * i + 2] = ids[3 * i + 2]; h[4 * i + 3] = 0; }
+  TF_HIP(hipMemcpyAsync(v->d_tmp, h, (size_t)n * 16, hipMemcpyHostToDevice, v->stream));
+  return TF_OK;
+}
+
+int tf_observations_record(tf_volume* v, int32_t keyframe_id) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (keyframe_id < 0) return TF_OK;  // Chisel.h:244: keyframeID >= 0
+  launch_obs_record(v->dev, keyframe_id, v->stream);
+  TF_HIP(hipGetLastError());
+  return TF_OK;
+}
+
+int tf_observations_retract(tf_volume* v, int32_t keyframe_id, const int32_t* ids, int64_t n) {
+  if (!v || (n > 0 && !ids)) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (n <= 0) return TF_OK;
+  int rc = ids_to_device(v, ids, n, 0);
+  if (rc) return rc;
+  launch_obs_retract(v->dev, keyframe_id, reinterpret_cast<const int4*>(v->d_tmp), (uint32_t)n, v->stream);
+  TF_HIP(hipGetLastError());
+  return TF_OK;
+}
+
+int tf_export_datacost(tf_volume* v, const int32_t* ids, int64_t n, int32_t frame_index, const int32_t* frames_to_update,
+                       int32_t n_frames, float* out) {
+  if (!v || (n > 0 && (!ids || !out)) || n_frames < 0 || (n_frames > 0 && !frames_to_update)) { set_error("invalid argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  if (n <= 0) return TF_OK;
+  const size_t cols = (size_t)1 + (size_t)n_frames;
+  const size_t o_fr = (size_t)n * 16, o_out = (o_fr + (size_t)n_frames * 4 + 15) & ~(size_t)15;
+  int rc = ids_to_device(v, ids, n, (size_t)n_frames * 4 + 16 + (size_t)n * cols * 4);
+  if (rc) return rc;
+  uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
+  uint8_t* hb = reinterpret_cast<uint8_t*>(v->h_pinned);
+  if (n_frames) {
+    memcpy(hb + o_fr, frames_to_update, (size_t)n_frames * 4);
+    TF_HIP(hipMemcpyAsync(db + o_fr, hb + o_fr, (size_t)n_frames * 4, hipMemcpyHostToDevice, v->stream));
+  }
+  launch_obs_export(v->dev, reinterpret_cast<const int4*>(db), (uint32_t)n, frame_index, reinterpret_cast<const int32_t*>(db + o_fr),
+                    n_frames, reinterpret_cast<float*>(db + o_out), v->stream);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(hb + o_out, db + o_out, (size_t)n * cols * 4, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  memcpy(out, hb + o_out, (size_t)n * cols * 4);
+  return TF_OK;
+}
+
+int tf_export_adjacency(tf_volume* v, const int32_t* ids, int64_t n, int32_t* out_edges, int64_t cap_edges, int64_t* n_edges) {
+  if (!v || !n_edges || (n > 0 && !ids) || cap_edges < 0 || (cap_edges > 0 && !out_edges)) { set_error("invalid argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  *n_edges = 0;
+  if (n <= 0) return TF_OK;
+  const size_t o_cnt = (size_t)n * 16, o_out = o_cnt + 16;
+  int rc = ids_to_device(v, ids, n, 16 + (size_t)cap_edges * 16);
+  if (rc) return rc;
+  uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
+  uint8_t* hb = reinterpret_cast<uint8_t*>(v->h_pinned);
+  TF_HIP(hipMemsetAsync(db + o_cnt, 0, 16, v->stream));
+  launch_adj_export(v->dev, reinterpret_cast<const int4*>(db), (uint32_t)n, reinterpret_cast<int4*>(db + o_out), (uint32_t)cap_edges,
+                    reinterpret_cast<uint32_t*>(db + o_cnt), v->stream);
+  TF_HIP(hipGetLastError());
+  uint32_t cnt = 0;
+  TF_HIP(hipMemcpyAsync(&cnt, db + o_cnt, 4, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  *n_edges = cnt;
+  const int64_t m = (int64_t)cnt < cap_edges ? (int64_t)cnt : cap_edges;
+  if (m > 0) {
+    TF_HIP(hipMemcpyAsync(hb + o_out, db + o_out, (size_t)m * 16, hipMemcpyDeviceToHost, v->stream));
+    TF_HIP(hipStreamSynchronize(v->stream));
+    memcpy(out_edges, hb + o_out, (size_t)m * 16);
+  }
+  if ((int64_t)cnt > cap_edges && out_edges) { set_error("output capacity too small"); return TF_ERR_CAPACITY; }
   return TF_OK;
 }
 

@@ -82,7 +82,8 @@ constexpr int kSlotStripes = 64;
 struct VolCtl {
   uint32_t status;    // sticky error bits
   uint32_t n_tmp;     // scratch counter of the on-demand list/pack kernels
-  uint32_t pad[2];
+  uint32_t ovf_next;  // mesh overflow pool: blocks handed out (bump allocation, reset with the volume)
+  uint32_t pad;
   // Pool slots are handed out from 64 independent stripes (stripe s owns slots
   // [s*max_chunks/64, (s+1)*max_chunks/64)) so that the thousands of chunk creations of a
   // first-touch frame do not serialise on one atomic word.
@@ -117,8 +118,16 @@ constexpr int kMpPos = 0, kMpNrm = 3, kMpCol = 6, kMpTc = 9, kMpTcol = 11, kMpLa
 constexpr unsigned long long kNoTexloc = ~0ull;
 constexpr uint32_t kMsInMap = 1u;       // the chunk has an entry in allMeshes (ChunkManager::HasMesh)
 constexpr uint32_t kMsSimplified = 2u;  // Mesh::simplified
-constexpr uint32_t kMsOverflow = 4u;    // did not fit CV / CT: stored empty, kStMeshFull raised
+constexpr uint32_t kMsOverflow = 4u;    // did not fit CV / CT and no overflow block was left: stored empty, kStMeshFull raised
 constexpr int kMsAdjShift = 8;          // bits 8..13 = Mesh::adj[0..5]
+// A mesh that does not fit its pool slot's block (CV vertices / CT triangles) lives in a block of the shared overflow
+// pool, sized for the largest mesh a chunk can have (3 x 9^3 = 2187 vertices, 512 x 5 = 2560 triangles,
+// Structure/ChunkManager.cpp:856-918 emits whatever a chunk produces).  Bits 16..31 of MeshRec::state = block index + 1;
+// a chunk keeps the block it was given (its later, smaller meshes stay there too).
+constexpr int kMsOvfShift = 16;
+constexpr uint32_t kMsOvfMask = 0xFFFF0000u;
+constexpr int kOvfCV = 2240, kOvfCT = 2560;
+constexpr int kPlOvfShift = 21;  // patch-list entries: w = pool slot | overflow block << 21 (pools of up to 2^21 slots, 2047 blocks)
 constexpr uint32_t kPfHasPatch = 1u;    // Atlas::HasPatch
 constexpr uint32_t kPfCaution = 2u;     // CalculateTexCoords returned -1
 constexpr uint32_t kPfWrong = 4u;       // Patch::wrong_mapping
@@ -200,6 +209,10 @@ struct VolumeDev {
   uint16_t* mesh_t;
   MeshRec* mesh_rec;
   uint32_t mesh_cv, mesh_ct;
+  float* ovf_v;         // [ovf_blocks][17][kOvfCV] overflow pool, same planar layout as mesh_v
+  uint16_t* ovf_t;      // [ovf_blocks][3][kOvfCT]
+  uint16_t* ovf_vlist;  // [ovf_blocks][kOvfCV] mesher scratch of a block (its used edge slots; the slot-sized list sits in LDS)
+  uint32_t ovf_blocks;  // blocks of the pool; VolCtl::ovf_next = blocks handed out
   uint32_t* mesh_nbr;  // [kMeshShards][mesh_shard_rows(max_chunks)][32] mesher scratch, one row per SURVIVING work entry
                        // (k_mesh_filter): pool slots of its 27-chunk neighbourhood, [27] = the entry's list index
   uint32_t* mesh_cnt;  // [2][kMeshShards][16] rows used per shard (one counter per 64-B line), double-buffered by launch parity
@@ -220,14 +233,24 @@ struct VolumeDev {
   int4* wl_ids;        // [2][kMeshShards][mesh_shard_rows] {id, w = hash entry index + 1 (0 = the slot is known alive)}
   uint32_t* wl_slot;   // [2][kMeshShards][mesh_shard_rows] pool slot
   uint32_t* wl_cnt;    // [2][kMeshShards][16] entries per shard (one counter per 64-B line)
+  // Chunk::observations (Chunk.h:171) on the device: open-addressing table keyed by (pool slot << 32 | keyframe id) ->
+  // quality; an erased observation keeps its key with quality 0 (recorded qualities are > 0, Chisel.h:244)
+  unsigned long long* obs_key;  // [obs_mask + 1], kEmptyKey = free
+  float* obs_q;
+  uint32_t obs_mask;
   SelBuf sel;  // the selection set the launch works on
 };
-__host__ __device__ inline float* mesh_plane(const VolumeDev& v, uint32_t slot, int plane) {
-  return v.mesh_v + ((size_t)slot * kMeshPlanes + plane) * v.mesh_cv;
+// planes of the mesh of pool slot `slot` whose record says `state` (the slot's own block or its overflow block)
+__host__ __device__ inline float* mesh_plane(const VolumeDev& v, uint32_t slot, uint32_t state, int plane) {
+  const uint32_t o = state >> kMsOvfShift;
+  return o ? v.ovf_v + ((size_t)(o - 1u) * kMeshPlanes + plane) * kOvfCV : v.mesh_v + ((size_t)slot * kMeshPlanes + plane) * v.mesh_cv;
 }
-__host__ __device__ inline uint16_t* tri_plane(const VolumeDev& v, uint32_t slot, int corner) {
-  return v.mesh_t + ((size_t)slot * 3 + corner) * v.mesh_ct;
+__host__ __device__ inline uint16_t* tri_plane(const VolumeDev& v, uint32_t slot, uint32_t state, int corner) {
+  const uint32_t o = state >> kMsOvfShift;
+  return o ? v.ovf_t + ((size_t)(o - 1u) * 3 + corner) * kOvfCT : v.mesh_t + ((size_t)slot * 3 + corner) * v.mesh_ct;
 }
+__host__ __device__ inline uint32_t mesh_cap_v(const VolumeDev& v, uint32_t state) { return (state >> kMsOvfShift) ? (uint32_t)kOvfCV : v.mesh_cv; }
+__host__ __device__ inline uint32_t mesh_cap_t(const VolumeDev& v, uint32_t state) { return (state >> kMsOvfShift) ? (uint32_t)kOvfCT : v.mesh_ct; }
 
 struct FrameImages {
   const float* depth;
@@ -284,6 +307,15 @@ void launch_boundary_unpack(const VolumeDev& v, const uint8_t* records, uint32_t
 // blocks of [16-B header {count} | cap records] per rank, the block of `skip` is this rank's own
 void launch_boundary_unpack_blocks(const VolumeDev& v, const uint8_t* blocks, int nblocks, int skip, uint32_t cap,
                                    int dirty_par, uint32_t stamp, hipStream_t s);
+// Chunk::observations on the device (f-4: what TexMap::update_datacost reads, Structure/TexMap.cpp:64-105)
+void launch_obs_record(const VolumeDev& v, int32_t kf_id, hipStream_t s);                   // Chisel.h:244-247 over the current list
+void launch_obs_retract(const VolumeDev& v, int32_t kf_id, const int4* ids, uint32_t n, hipStream_t s);  // MobileFusion.cpp:252-272
+// out[i * (1 + m) + 0] = observations[frame_index] of chunk ids[i], [1 + j] = observations[frames[j]]; 0 = none
+void launch_obs_export(const VolumeDev& v, const int4* ids, uint32_t n, int32_t frame_index, const int32_t* frames, int32_t m,
+                       float* out, hipStream_t s);
+// edges of TexMap::update_chunkgraph (TexMap.cpp:50-62): {i, neighbour id} for every set Mesh::adj flag of ids[i] whose
+// neighbour owns a mesh; *count edges (atomic append, order arbitrary)
+void launch_adj_export(const VolumeDev& v, const int4* ids, uint32_t n, int4* out, uint32_t cap, uint32_t* count, hipStream_t s);
 // ---- launchers (tf_mesh.hip) ---------------------------------------------------------
 // dlist: int4 {id.x, id.y, id.z, -} per dirty chunk, *dcount entries
 void launch_init_meshes(const VolumeDev& v, hipStream_t s);

@@ -120,7 +120,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
     ctl->emit_pack = 0ull;
     for (int k = 0; k < kKaCounters; ++k) ctl->ka_next[k * kKaCounterStride] = 0u;
     if (vctl) {
-      vctl->status = 0; vctl->n_tmp = 0;
+      vctl->status = 0; vctl->n_tmp = 0; vctl->ovf_next = 0;
       for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
     }
   }
@@ -1915,6 +1915,106 @@ __global__ __launch_bounds__(512) void k_boundary_unpack_blocks(VolumeDev v, con
 void launch_boundary_unpack_blocks(const VolumeDev& v, const uint8_t* blocks, int nblocks, int skip, uint32_t cap,
                                    int dirty_par, uint32_t stamp, hipStream_t s) {
   hipLaunchKernelGGL(k_boundary_unpack_blocks, dim3(1024), dim3(512), 0, s, v, blocks, nblocks, skip, cap, dirty_par, stamp);
+}
+
+
+// ---------------------------------------------------------------------------------------
+// Chunk::observations on the device (view-selection bookkeeping).  The reference keeps
+// std::map<int, float> per chunk (Chunk.h:171), written by IntegrateDepthScanColor (Chisel.h:244-247), erased by
+// MobileFusion::RetractObservations (GCFusion/MobileFusion.cpp:252-272), read by TexMap::update_datacost
+// (Structure/TexMap.cpp:64-105).  Here: one table for the volume, key = (pool slot, keyframe id).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long obs_pack(uint32_t slot, int32_t kf) {
+  return ((unsigned long long)slot << 32) | (unsigned long long)(uint32_t)kf;
+}
+__device__ __forceinline__ uint32_t obs_find(const VolumeDev& v, unsigned long long key, bool insert) {
+  uint32_t i = hash_key(key) & v.obs_mask;
+  for (uint32_t probe = 0; probe <= v.obs_mask; ++probe) {
+    unsigned long long cur = v.obs_key[i];
+    if (cur == kEmptyKey) {
+      if (!insert) return kInvalidSlot;
+      cur = atomicCAS(&v.obs_key[i], kEmptyKey, key);
+      if (cur == kEmptyKey) return i;
+    }
+    if (cur == key) return i;
+    i = (i + 1) & v.obs_mask;
+  }
+  if (insert) atomicOr(&v.vctl->status, kStHashFull);
+  return kInvalidSlot;
+}
+// chunk->observations[keyframeID] = chunkObservationQuality where keyframeID >= 0, quality > 0 and the chunk's
+// needsUpdateFlag is set (Chisel.h:244-247), for every entry of the list the last integrate call worked on
+__global__ __launch_bounds__(256) void k_obs_record(VolumeDev v, int32_t kf_id) {
+  const SelBuf& L = v.sel;
+  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const float q = L.list_quality[e];
+    const uint32_t slot = L.list_slot[e];
+    if (!(q > 0.0f) || !L.list_needs[e] || slot == kInvalidSlot) continue;
+    const uint32_t at = obs_find(v, obs_pack(slot, kf_id), true);
+    if (at != kInvalidSlot) v.obs_q[at] = q;
+  }
+}
+void launch_obs_record(const VolumeDev& v, int32_t kf_id, hipStream_t s) {
+  if (kf_id < 0) return;
+  hipLaunchKernelGGL(k_obs_record, dim3(256), dim3(256), 0, s, v, kf_id);
+}
+__global__ __launch_bounds__(256) void k_obs_retract(VolumeDev v, int32_t kf_id, const int4* __restrict__ ids, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int4 id = ids[i];
+  const uint32_t slot = hash_slot_alive(v, pack_id(id.x, id.y, id.z));  // !HasChunk -> continue (:258)
+  if (slot == kInvalidSlot) return;
+  const uint32_t at = obs_find(v, obs_pack(slot, kf_id), false);
+  if (at != kInvalidSlot) v.obs_q[at] = 0.0f;  // observations.erase(frame_id)
+}
+void launch_obs_retract(const VolumeDev& v, int32_t kf_id, const int4* ids, uint32_t n, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_obs_retract, dim3((n + 255) / 256), dim3(256), 0, s, v, kf_id, ids, n);
+}
+__global__ __launch_bounds__(256) void k_obs_export(VolumeDev v, const int4* __restrict__ ids, uint32_t n, int32_t frame_index,
+                                                    const int32_t* __restrict__ frames, int32_t m, float* __restrict__ out) {
+  const uint32_t total = n * (uint32_t)(1 + m);
+  for (uint32_t t = blockIdx.x * 256 + threadIdx.x; t < total; t += gridDim.x * 256) {
+    const uint32_t i = t / (uint32_t)(1 + m), j = t - i * (uint32_t)(1 + m);
+    const int4 id = ids[i];
+    const uint32_t slot = hash_slot_alive(v, pack_id(id.x, id.y, id.z));
+    float q = 0.0f;
+    if (slot != kInvalidSlot) {
+      const int32_t kf = j == 0 ? frame_index : frames[j - 1];
+      const uint32_t at = obs_find(v, obs_pack(slot, kf), false);
+      if (at != kInvalidSlot) q = v.obs_q[at];
+    }
+    out[t] = q;
+  }
+}
+void launch_obs_export(const VolumeDev& v, const int4* ids, uint32_t n, int32_t frame_index, const int32_t* frames, int32_t m,
+                       float* out, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_obs_export, dim3(512), dim3(256), 0, s, v, ids, n, frame_index, frames, m, out);
+}
+__global__ __launch_bounds__(256) void k_adj_export(VolumeDev v, const int4* __restrict__ ids, uint32_t n, int4* __restrict__ out,
+                                                    uint32_t cap, uint32_t* __restrict__ count) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t i = t >> 3, k = t & 7u;
+  if (i >= n || k >= 6u) return;
+  const int4 id = ids[i];
+  const uint32_t slot = hash_slot_alive(v, pack_id(id.x, id.y, id.z));
+  if (slot == kInvalidSlot) return;
+  const uint32_t st = v.mesh_rec[slot].state;
+  if (!(st & kMsInMap) || !((st >> (kMsAdjShift + k)) & 1u)) return;  // allMeshes.find(id) / mesh->adj[k]
+  // chisel::neighbourhood (Structure/ChunkManager.h:55-57): -x, +x, -y, +y, -z, +z, the order of Mesh::adj
+  int4 q = id;
+  if (k == 0) q.x -= 1; else if (k == 1) q.x += 1; else if (k == 2) q.y -= 1;
+  else if (k == 3) q.y += 1; else if (k == 4) q.z -= 1; else q.z += 1;
+  const uint32_t qs = hash_slot_alive(v, pack_id(q.x, q.y, q.z));
+  if (qs == kInvalidSlot || !(v.mesh_rec[qs].state & kMsInMap)) return;  // a chunk that never owned a mesh is no graph node
+  const uint32_t p = atomicAdd(count, 1u);
+  if (p < cap) out[p] = make_int4((int)i, q.x, q.y, q.z);
+}
+void launch_adj_export(const VolumeDev& v, const int4* ids, uint32_t n, int4* out, uint32_t cap, uint32_t* count, hipStream_t s) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_adj_export, dim3((n * 8 + 255) / 256), dim3(256), 0, s, v, ids, n, out, cap, count);
 }
 
 }  // namespace tf

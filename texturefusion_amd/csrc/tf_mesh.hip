@@ -139,6 +139,7 @@ struct MeshSh {
   uint32_t nv, nt, adj, any;
   uint32_t ncell;             // cells the surface passes through
   uint16_t clist[512];        // ... in no particular order (what is computed per cell is stored per cell)
+  uint32_t ovf;               // overflow block of the chunk (index + 1, 0 = none): owned before this pass or handed out in it
   uint32_t rstate;            // MeshRec::state as it was before this pass
   unsigned long long rtexloc; // MeshRec::texloc
 };
@@ -174,11 +175,12 @@ __device__ __forceinline__ int owner_cell(int m, int q) {
 // fused flow: a dirty chunk that owns a mesh (ChunkManager::HasMesh) goes to the patch list of its shard; one
 // without an atlas slot is also a slot candidate (Atlas::AddPatch will be called for it, in ascending id order).
 // Called by ONE thread per chunk.
+// (w = pool slot | overflow block << 21: the patch stage reads the mesh planes without waiting for the record)
 __device__ __forceinline__ void patch_list_append(const VolumeDev& v, int ppar, uint32_t shard, const int4 id,
-                                                  uint32_t slot, unsigned long long texloc) {
+                                                  uint32_t slot, unsigned long long texloc, uint32_t ovf) {
   const uint32_t rows = mesh_shard_rows_d(v.max_chunks);
   const uint32_t p = atomicAdd(&v.patch_cnt[((ppar & 1) * kMeshShards + shard) * 16], 1u);
-  if (p < rows) v.patch_list[((size_t)(ppar & 1) * kMeshShards + shard) * rows + p] = make_int4(id.x, id.y, id.z, (int)slot);
+  if (p < rows) v.patch_list[((size_t)(ppar & 1) * kMeshShards + shard) * rows + p] = make_int4(id.x, id.y, id.z, (int)(slot | (ovf << kPlOvfShift)));
   else atomicOr(&v.vctl->status, kStMeshFull);
   if (texloc == kNoTexloc) {
     const uint32_t c = atomicAdd(&v.actl->set[ppar & 1].n_cand, 1u);
@@ -189,11 +191,12 @@ __device__ __forceinline__ void patch_list_append(const VolumeDev& v, int ppar, 
 // Mesh::Clear + "stays in allMeshes if it was there" (:244-262) for a chunk the filter ruled out; one thread
 __device__ __forceinline__ void filter_reset_record(const VolumeDev& v, uint32_t own, const int4 id, uint32_t epoch, int ppar) {
   MeshRec* rec = &v.mesh_rec[own];
-  const uint32_t inmap = rec->state & kMsInMap;
+  const uint32_t was = rec->state;
+  const uint32_t inmap = was & kMsInMap;
   // fused flow (ppar >= 0): CompressMeshes follows in the same frame and its SimplifyByClustering marks EVERY dirty
   // mesh of allMeshes simplified, with or without vertices (Chisel.cpp:116-126, Mesh.cpp:39-48)
-  rec->nv = 0; rec->nt = 0; rec->state = inmap | ((ppar >= 0 && inmap) ? kMsSimplified : 0u); rec->epoch = epoch;
-  if (ppar >= 0 && inmap) patch_list_append(v, ppar, own & (kMeshShards - 1u), id, own, rec->texloc);  // an emptied mesh keeps its patch
+  rec->nv = 0; rec->nt = 0; rec->state = inmap | (was & kMsOvfMask) | ((ppar >= 0 && inmap) ? kMsSimplified : 0u); rec->epoch = epoch;
+  if (ppar >= 0 && inmap) patch_list_append(v, ppar, own & (kMeshShards - 1u), id, own, rec->texloc, was >> kMsOvfShift);  // an emptied mesh keeps its patch
 }
 
 // phase A of the filter for the 8-lane group a lane belongs to (k8 = its place in the group): lane k looks up chunk
@@ -682,13 +685,26 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
         if (k < w) before += sh.wsum[k];
         total += sh.wsum[k];
       }
+      // Does the mesh fit the pool slot's block?  If not it goes to a block of the overflow pool: the one the chunk
+      // already owns, else the next free one (one bump allocation per chunk, ever).  Block-uniform.
+      if (t == 0) sh.ovf = sh.rstate >> kMsOvfShift;
+      if (((total & 0xFFFFu) > v.mesh_cv || (total >> 16) > v.mesh_ct) && !(sh.rstate >> kMsOvfShift)) {
+        if (t == 0) {
+          const uint32_t p = atomicAdd(&v.vctl->ovf_next, 1u);
+          sh.ovf = p < v.ovf_blocks ? p + 1u : 0u;
+        }
+      }
+      __syncthreads();
+      const uint32_t ovf_blk = sh.ovf;
+      uint16_t* const gvl = ovf_blk ? v.ovf_vlist + (size_t)(ovf_blk - 1u) * kOvfCV : nullptr;
       const uint32_t excl = before + inc - pk;
       uint32_t r = excl & 0xFFFFu;
       sh.rbase[t] = (uint16_t)r;
       sh.rmask[t] = usedm;
       for (unsigned long long u = usedm; u; u &= u - 1ull) {
         const int m = first + (int)__builtin_ctzll(u);
-        if (r < v.mesh_cv) vlist[r] = (uint16_t)m;  // (a mesh with more is rejected below)
+        if (gvl) { if (r < (uint32_t)kOvfCV) gvl[r] = (uint16_t)m; }
+        else if (r < v.mesh_cv) vlist[r] = (uint16_t)m;  // (a mesh with more is rejected below)
         ++r;
       }
       uint32_t t0 = excl >> 16;
@@ -701,16 +717,19 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     }
     __syncthreads();
     const uint32_t nv = sh.nv, nt = sh.nt;
-    if (nv > v.mesh_cv || nt > v.mesh_ct) {  // does not fit the slot's block: reported, stored empty
+    const uint32_t ovf = sh.ovf;
+    const uint32_t st_ovf = ovf << kMsOvfShift;  // (selects the block in mesh_plane / tri_plane)
+    if (nv > mesh_cap_v(v, st_ovf) || nt > mesh_cap_t(v, st_ovf)) {  // no block left in the overflow pool: reported, stored empty
       if (t == 0) {
         atomicOr(&v.vctl->status, kStMeshFull);
         const uint32_t was = sh.rstate & kMsInMap;
         rec->nv = 0; rec->nt = 0; rec->state = was | kMsOverflow; rec->epoch = epoch;
-        if (rearm >= 0 && was) patch_list_append(v, rearm ^ 1, shard, id, own, sh.rtexloc);
+        if (rearm >= 0 && was) patch_list_append(v, rearm ^ 1, shard, id, own, sh.rtexloc, 0u);
       }
       __syncthreads();
       continue;
     }
+    const uint16_t* const gvlist = ovf ? v.ovf_vlist + (size_t)(ovf - 1u) * kOvfCV : nullptr;
 
     if (dbg == 4) continue;  // triage: + ranking
     if (dbg == 9) mesh_stamp(v, r, 6);
@@ -718,12 +737,12 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     // not depend on the vertices: the last wave (it rarely has vertex work) appends it now, so that the round trips
     // of the two counters overlap the vertex pass instead of ending the chunk.
     const uint32_t inmap = (sh.rstate & kMsInMap) | (nv ? kMsInMap : 0u);
-    if (t == NT - 64 && rearm >= 0 && inmap) patch_list_append(v, rearm ^ 1, shard, id, own, sh.rtexloc);
+    if (t == NT - 64 && rearm >= 0 && inmap) patch_list_append(v, rearm ^ 1, shard, id, own, sh.rtexloc, ovf);
     // ---- pass 2: the winning cell of every used slot evaluates the vertex; lane = output vertex
     const float org[3] = {(float)(8 * id.x) * res, (float)(8 * id.y) * res, (float)(8 * id.z) * res};  // Chunk.cpp:52
     uint32_t adj = 0;
     for (uint32_t i = t; i < nv; i += NT) {
-      const int m = vlist[i];
+      const int m = gvlist ? gvlist[i] : vlist[i];
       const int cell = owner_cell(m, __builtin_ctz((sh.ownq[m >> 3] >> (4 * (m & 7))) & 0xFu));
       const int x = cell & 7, y = (cell >> 3) & 7, z = cell >> 6;
       const int ax = m % 3, b = m / 3;
@@ -759,9 +778,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
       }
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        mesh_plane(v, own, kMpPos + a)[i] = pv[a];
-        mesh_plane(v, own, kMpNrm + a)[i] = g[a];
-        mesh_plane(v, own, kMpCol + a)[i] = col[a];
+        mesh_plane(v, own, st_ovf, kMpPos + a)[i] = pv[a];
+        mesh_plane(v, own, st_ovf, kMpNrm + a)[i] = g[a];
+        mesh_plane(v, own, st_ovf, kMpCol + a)[i] = col[a];
         // Mesh::GetIndice (Mesh.cpp:52-83) with grid_resolution = resolution * (8 / GRID_EACH_DIM)
         const int gp = (int)floorf((pv[a] - org[a]) / (res * 1.0f));
         if (gp >= 8) adj |= 1u << (2 * a + 1);
@@ -791,9 +810,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
           const int tt = m / kEptT, j = m - tt * kEptT;
           return (uint16_t)(sh.rbase[tt] + (uint32_t)__popcll(sh.rmask[tt] & ((1ull << j) - 1ull)));
         };
-        tri_plane(v, own, 0)[o] = ref_of(edge_slot(x, y, z, s2));
-        tri_plane(v, own, 1)[o] = ref_of(edge_slot(x, y, z, s1));
-        tri_plane(v, own, 2)[o] = ref_of(edge_slot(x, y, z, s0));
+        tri_plane(v, own, st_ovf, 0)[o] = ref_of(edge_slot(x, y, z, s2));
+        tri_plane(v, own, st_ovf, 1)[o] = ref_of(edge_slot(x, y, z, s1));
+        tri_plane(v, own, st_ovf, 2)[o] = ref_of(edge_slot(x, y, z, s0));
         ++o;
       }
     }
@@ -801,7 +820,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     if (t == 0) {
       // its own adjacency flags are final now (SimplifyByClustering runs once per generation, Chisel.cpp:124)
       rec->nv = nv; rec->nt = nt; rec->epoch = epoch;
-      rec->state = inmap | (sh.adj << kMsAdjShift) | (inmap ? simplified : 0u);  // (simplified: every mesh of allMeshes, Chisel.cpp:116-126)
+      rec->state = inmap | st_ovf | (sh.adj << kMsAdjShift) | (inmap ? simplified : 0u);  // (simplified: every mesh of allMeshes, Chisel.cpp:116-126)
     }
     __syncthreads();
     if (dbg == 9) mesh_stamp(v, r, 8);
@@ -1061,14 +1080,14 @@ __global__ __launch_bounds__(256) void k_mesh_gather(VolumeDev v, const int4* __
   for (uint32_t i = threadIdx.x; i < nv; i += 256)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      if (verts) verts[3 * (v0 + i) + a] = mesh_plane(v, slot, kMpPos + a)[i];
-      if (normals) normals[3 * (v0 + i) + a] = mesh_plane(v, slot, kMpNrm + a)[i];
-      if (colors) colors[3 * (v0 + i) + a] = mesh_plane(v, slot, kMpCol + a)[i];
+      if (verts) verts[3 * (v0 + i) + a] = mesh_plane(v, slot, m.state, kMpPos + a)[i];
+      if (normals) normals[3 * (v0 + i) + a] = mesh_plane(v, slot, m.state, kMpNrm + a)[i];
+      if (colors) colors[3 * (v0 + i) + a] = mesh_plane(v, slot, m.state, kMpCol + a)[i];
     }
   if (indices)
     for (uint32_t i = threadIdx.x; i < nt; i += 256)
 #pragma unroll
-      for (int a = 0; a < 3; ++a) indices[i0 + 3 * i + a] = tri_plane(v, slot, a)[i];
+      for (int a = 0; a < 3; ++a) indices[i0 + 3 * i + a] = tri_plane(v, slot, m.state, a)[i];
 }
 
 // ids (host, int32[3n]) -> device int4 list in d_tmp at byte offset `at`

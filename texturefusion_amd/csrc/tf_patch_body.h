@@ -222,10 +222,13 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
   for (uint32_t pe = FUSED ? wave / kMeshShards : wave; pe < n; pe += FUSED ? nwaves / kMeshShards : nwaves) {
     // fused flow: {id, pool slot} straight from the list (one dependent load less per patch)
     const int4 id = FUSED ? plist[pe] : v.work_ids[pe];
-    const uint32_t slot = FUSED ? (uint32_t)id.w : v.work_slot[pe];
+    // fused list entries carry the mesh's overflow block next to the pool slot (w = slot | block << 21), so that the
+    // vertex loads below need not wait for the record; the call-by-call flow reads it from the record
+    const uint32_t slot = FUSED ? ((uint32_t)id.w & ((1u << kPlOvfShift) - 1u)) : v.work_slot[pe];
     if (slot == kInvalidSlot) continue;
     MeshRec* rec = &v.mesh_rec[slot];
     MeshRec R = *rec;  // one 64-B record: counts, flags, slot position, box
+    const uint32_t mst = FUSED ? (((uint32_t)id.w >> kPlOvfShift) << kMsOvfShift) : (R.state & kMsOvfMask);
     stampw(1);
     if (FUSED && lane < 6) {
       // Chisel::CompressMeshes' neighbour exchange (Chisel.cpp:127-145) for this chunk: flag k of the mesh and flag
@@ -278,8 +281,8 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     if (PROJECT) {
       float minX = Wf, maxX = 0.0f, minY = Hf, maxY = 0.0f;  // Patch.cpp:46-49
       uint32_t dcmp = 0, ccmp = 0, ncau = 0;
-      float* tu = mesh_plane(v, slot, kMpTc);
-      float* tv = mesh_plane(v, slot, kMpTc + 1);
+      float* tu = mesh_plane(v, slot, mst, kMpTc);
+      float* tv = mesh_plane(v, slot, mst, kMpTc + 1);
       float keepX[kVB], keepY[kVB];  // texcoords of a one-sweep patch stay in registers until the box is known
       const bool one_sweep = nv <= 64u * kVB;
       // the first sweep does not wait for the record: its loads are clamped to the block, not to nv, and go out
@@ -287,15 +290,15 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
       for (uint32_t base = 0; base == 0 || base < nv; base += 64u * kVB) {
         // ---- loads of the sweep: vertex positions and colours
         float px[kVB], py[kVB], pz[kVB], m0[kVB], m1[kVB], m2[kVB];
-        const uint32_t lim = base == 0 ? v.mesh_cv : nv;
+        const uint32_t lim = base == 0 ? mesh_cap_v(v, mst) : nv;
 #pragma unroll
         for (int j = 0; j < kVB; ++j) {
           const uint32_t i = base + 64u * j + lane;
           const uint32_t ii = i < lim ? i : 0u;
-          px[j] = mesh_plane(v, slot, kMpPos)[ii]; py[j] = mesh_plane(v, slot, kMpPos + 1)[ii];
-          pz[j] = mesh_plane(v, slot, kMpPos + 2)[ii];
-          m0[j] = mesh_plane(v, slot, kMpCol)[ii]; m1[j] = mesh_plane(v, slot, kMpCol + 1)[ii];
-          m2[j] = mesh_plane(v, slot, kMpCol + 2)[ii];
+          px[j] = mesh_plane(v, slot, mst, kMpPos)[ii]; py[j] = mesh_plane(v, slot, mst, kMpPos + 1)[ii];
+          pz[j] = mesh_plane(v, slot, mst, kMpPos + 2)[ii];
+          m0[j] = mesh_plane(v, slot, mst, kMpCol)[ii]; m1[j] = mesh_plane(v, slot, mst, kMpCol + 1)[ii];
+          m2[j] = mesh_plane(v, slot, mst, kMpCol + 2)[ii];
         }
         stampw(3);
         // ---- projection (:52-66), then every image gather of the sweep in flight at once
@@ -352,7 +355,7 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
               const float c1 = (float)((q1[j] >> (8 * k)) & 0xFFu), c2 = (float)((q2[j] >> (8 * k)) & 0xFFu),
                           c3 = (float)((q3[j] >> (8 * k)) & 0xFFu);
               tc[k] = blend(tp[j], c1, c2, c3) / 255.0f;
-              mesh_plane(v, slot, kMpTcol + k)[i] = tc[k];
+              mesh_plane(v, slot, mst, kMpTcol + k)[i] = tc[k];
             }
             const float dpt = blend(tp[j], d1[j], d2[j], d3[j]);
             const float e0 = tc[0] - m0[j], e1 = tc[1] - m1[j], e2 = tc[2] - m2[j];

@@ -506,6 +506,7 @@ class Chisel {
                           colorImage != NULL, observationQualityPointer != NULL && colorImage != NULL,
                           needs_buf.data(), qual_buf.data()),
              "IntegrateDepthScanColor");
+    if (keyframeID >= 0) tf_check(tf_observations_record(vol, keyframeID), "observations");  // Chisel.h:244-247, device copy
     for (size_t i = 0; i < n; ++i) {
       needsUpdateFlag[i] = needs_buf[i] != 0;
       if (keyframeID >= 0 && qual_buf[i] > 0 && needsUpdateFlag[i])  // Chisel.h:244-247
@@ -812,6 +813,54 @@ class TexMap {
         }
       }
     }
+  }
+
+  // ---- the same two updates fed by the device's exports instead of the host mirrors (tf_export_adjacency /
+  // tf_export_datacost: Mesh::adj and Chunk::observations stay in HBM, tf_observations_record / _retract keep the latter)
+  int update_chunkgraph_device(ChunkIDList& chunksToUpdate, tf_volume* vol) {
+    for (const ChunkID& id : chunksToUpdate) chunkGraph.add_node(id);
+    const int64_t n = (int64_t)chunksToUpdate.size();
+    if (!n) return TF_OK;
+    std::vector<int32_t> ids((std::size_t)n * 3), edges((std::size_t)n * 6 * 4);
+    for (int64_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) ids[(std::size_t)(3 * i + a)] = chunksToUpdate[(std::size_t)i](a);
+    int64_t ne = 0;
+    const int rc = tf_export_adjacency(vol, ids.data(), n, edges.data(), n * 6, &ne);
+    if (rc) return rc;
+    for (int64_t e = 0; e < ne; ++e) {
+      const int32_t* r = &edges[(std::size_t)e * 4];
+      auto a = chunkGraph.chunks.find(chunksToUpdate[(std::size_t)r[0]]);
+      auto b = chunkGraph.chunks.find(ChunkID(r[1], r[2], r[3]));
+      if (a != chunkGraph.chunks.end() && b != chunkGraph.chunks.end()) chunkGraph.add_edge(a->second, b->second);
+    }
+    return TF_OK;
+  }
+  int update_datacost_device(ChunkIDList& chunksToUpdate, tf_volume* vol, std::vector<int>& lookup, int frameindex,
+                             std::vector<int>& framesToUpdate) {
+    const int64_t n = (int64_t)chunksToUpdate.size();
+    if (!n) return TF_OK;
+    const std::size_t m = framesToUpdate.size();
+    std::vector<int32_t> ids((std::size_t)n * 3), fr(framesToUpdate.begin(), framesToUpdate.end());
+    for (int64_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) ids[(std::size_t)(3 * i + a)] = chunksToUpdate[(std::size_t)i](a);
+    std::vector<float> tab((std::size_t)n * (1 + m));
+    const int rc = tf_export_datacost(vol, ids.data(), n, frameindex, fr.empty() ? nullptr : fr.data(), (int32_t)m, tab.data());
+    if (rc) return rc;
+    for (int64_t i = 0; i < n; ++i) {  // TexMap.cpp:67-104 with "observation present" == table entry > 0
+      const float* row = &tab[(std::size_t)i * (1 + m)];
+      const std::size_t node = chunkGraph.chunks.find(chunksToUpdate[(std::size_t)i])->second;
+      if (statistic.size() < node + 1) statistic.resize(node + 1, 1.0f);
+      float quality = row[0];
+      if (quality > statistic[node]) statistic[node] = quality;
+      if (quality > 0.0f) dataCost.add_value(node, (std::size_t)lookup[frameindex], quality);
+      if (dataCost.cols() <= node) dataCost.resize(node + 1);
+      for (std::size_t j = 0; j < m; ++j) {
+        const std::size_t r = (std::size_t)lookup[framesToUpdate[j]];
+        quality = row[1 + j];
+        if (!(quality > 0.0f)) { dataCost.remove_observation(node, r); continue; }
+        if (quality > statistic[node]) statistic[node] = quality;
+        dataCost.set_value(node, r, quality);
+      }
+    }
+    return TF_OK;
   }
 
   void check_graph(ChunkManager& chunkManager) {  // nodes whose mesh is gone lose their edges and costs
