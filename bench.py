@@ -339,7 +339,15 @@ def main():
         dt = time.perf_counter() - t0
     vol.sync()  # brings the deferred frames onto the stream; surfaces any device-side capacity error
     pos = p0 + K
+    per_rank = None
     if multi:
+        # per rank: its own wall time for the K frames and what the exchange moved (tf_comm_stats)
+        ex_n, ex_bytes = vol.comm_stats() if use_rccl else (0, 0)
+        mine = {"rank": rank, "ms_per_step": 1e3 * dt / K, "exchanges": ex_n, "exchange_bytes_received": ex_bytes}
+        gathered = [None] * world if world > 1 else [mine]
+        if world > 1:
+            dist.all_gather_object(gathered, mine)
+        per_rank = gathered
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -421,7 +429,8 @@ def main():
             "timed_window": {"first_frame": p0, "orbit_position": p0 % ORBIT, "frames": K},
             "parallelism": ("1 GPU" if world == 1 else
                             "%d ranks, chunk-range slabs of the key x+y+z of one stream; one fixed-capacity RCCL exchange "
-                            "(%d records of 8 KiB per rank) of the updated ghost-band chunks %s"
+                            "(blocks of %d records of 8 KiB; neighbour send / receive pairs: the band below to rank - 1, the band above "
+                            "to rank + 1) of the updated ghost-band chunks %s"
                             % (world, args.exchange_cap,
                                "after every voxel update, ahead of the mesher" if textured else
                                "every %d frames" % args.exchange_every)),
@@ -429,6 +438,8 @@ def main():
     }
     if resident is not None:
         out["resident"] = resident
+    if per_rank is not None:
+        out["per_rank"] = per_rank
 
     # ---- roofline over ALL kernels of a step ------------------------------------------------
     if rank == 0 and prof is not None and not multi:

@@ -348,6 +348,11 @@ TF_API size_t tf_boundary_block_bytes(int64_t cap_records);
 TF_API int tf_boundary_pack_block(tf_volume* v, void* d_block, int64_t cap_records);
 TF_API int tf_boundary_unpack_blocks(tf_volume* v, const void* d_blocks, int32_t n_blocks, int32_t own_block,
                                      int64_t cap_records, int join_dirty);
+/* Two blocks instead of one, for a neighbour-only exchange: slabs are contiguous key ranges, so the chunks the rank
+ * BELOW reads as ghosts are those with key - key_lo <= a + b + c (d_block_down) and the rank ABOVE reads key == key_hi - 1
+ * (d_block_up); a chunk of a thin slab goes to both.  Valid as the only exchange when every slab is at least
+ * a + b + c + 1 keys wide.  Consume a neighbour's block with tf_boundary_unpack_blocks(..., own_block = -1, ...). */
+TF_API int tf_boundary_pack_bands(tf_volume* v, void* d_block_down, void* d_block_up, int64_t cap_records);
 /* RCCL inside the library: one process per GPU.  tf_comm_unique_id on one rank, the 128 bytes
  * distributed by the host's own means, tf_comm_init(rank, nranks, id) on every rank (ncclCommInitRank);
  * tf_exchange_boundary = tf_boundary_pack_block -> ONE ncclAllGather over xGMI on the handle's stream ->
@@ -359,6 +364,14 @@ TF_API int tf_comm_init(tf_volume* v, int rank, int nranks, const void* unique_i
 TF_API int tf_comm_destroy(tf_volume* v);
 TF_API int tf_exchange_boundary(tf_volume* v, int64_t cap_records);
 TF_API int tf_comm_exchange_every_frame(tf_volume* v, int64_t cap_records);
+/* How tf_exchange_boundary / the per-frame exchange move the blocks: TF_XCHG_NEIGHBOURS (default) = one grouped
+ * ncclSend / ncclRecv pair with the rank below and the rank above (tf_boundary_pack_bands: a rank receives two blocks
+ * whatever the number of ranks); TF_XCHG_ALLGATHER = one ncclAllGather of every rank's block (for partitions with slabs
+ * thinner than a + b + c + 1 keys).  tf_comm_stats: exchanges run and bytes received by this rank so far. */
+#define TF_XCHG_NEIGHBOURS 0
+#define TF_XCHG_ALLGATHER 1
+TF_API int tf_comm_exchange_mode(tf_volume* v, int mode);
+TF_API int tf_comm_stats(tf_volume* v, int64_t* exchanges, int64_t* bytes_received);
 
 /* ---- texture atlas on device-resident meshes --------------------------------------------
  * Atlas / Patch (Structure/Atlas.{h,cpp}, Structure/Patch.{h,cpp}) as driven by Chisel::GeneratePatches /

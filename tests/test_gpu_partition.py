@@ -92,6 +92,91 @@ def test_two_partitions_equal_one(gpu_required, axis, split):
         b.free()
 
 
+@pytest.mark.parametrize("axis,edges", [((1, 0, 0), (-2, 4)), ((1, 1, 1), (20, 45))])
+def test_three_partitions_with_neighbour_band_blocks_equal_one(gpu_required, axis, edges):
+    """The neighbour form of the exchange on one GPU: three handles own consecutive slabs; after every frame a handle's
+    DOWN block (tf_boundary_pack_bands) goes to the handle below and its UP block to the one above, nobody else sees
+    them.  Every owned chunk and every chunk an owned chunk's mesher reads equals the single volume bit for bit."""
+    cam = synth.Camera()
+    single = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    bounds = [-(1 << 31), edges[0], edges[1], (1 << 31) - 1]
+    parts = [capi.Volume(RES5, cam, max_chunks=1 << 16) for _ in range(3)]
+    for r, v in enumerate(parts):
+        v.set_partition(bounds[r], bounds[r + 1], axis)
+    cap = 2048
+    bb = capi.boundary_block_bytes(cap)
+    blk = [[HipBuffer(bb), HipBuffer(bb)] for _ in range(3)]  # [rank][down, up]
+    pair = HipBuffer(2 * bb)
+    sent = 0
+    for k in (0, 1, 2, 3):
+        depth, rgba, q, pose = synth.room_frame(2 * k, cam)
+        for v in [single] + parts:
+            v.frame_upload(depth, rgba, None)
+            v.integrate_frame(pose, True)
+        for r, v in enumerate(parts):
+            v.boundary_pack_bands(blk[r][0].ptr, blk[r][1].ptr, cap)
+            v.sync()
+        for r in range(3):
+            n_dn = int(blk[r][0].to_host(4).view(np.uint32)[0]); n_up = int(blk[r][1].to_host(4).view(np.uint32)[0])
+            assert n_dn <= cap and n_up <= cap
+            sent += n_dn + n_up
+            for side, n in ((0, n_dn), (1, n_up)):  # every record sits in the band its block is for
+                if n:
+                    rec = blk[r][side].to_host(bb)[16:16 + n * capi.TF_BOUNDARY_RECORD_BYTES].reshape(n, -1)
+                    key = rec[:, :12].copy().view(np.int32).reshape(-1, 3).astype(np.int64) @ np.array(axis)
+                    if side == 0:
+                        assert np.all((key >= bounds[r]) & (key <= bounds[r] + sum(axis)))
+                    else:
+                        assert np.all(key == bounds[r + 1] - 1)
+        for r, v in enumerate(parts):  # from below: its UP block; from above: its DOWN block
+            srcs = [blk[r - 1][1] if r > 0 else None, blk[r + 1][0] if r < 2 else None]
+            host = np.zeros(2 * bb, np.uint8)
+            for j, src in enumerate(srcs):
+                if src is not None:
+                    host[j * bb:(j + 1) * bb] = src.to_host(bb)
+            pair.from_host(host)
+            v.boundary_unpack_blocks(pair.ptr, 2, -1, cap, join_dirty=False)
+            v.sync()
+    assert sent > 100
+    ref_ids = sorted_ids(single.list_chunks())
+    s_ref, w_ref, c_ref = single.get_chunks(ref_ids)
+    key = {tuple(c): i for i, c in enumerate(ref_ids)}
+    offs = set()
+    for o in np.ndindex(2, 2, 2):
+        offs.add(o)
+        for a in range(3):
+            for d in (-1, 1):
+                q = list(o); q[a] += d
+                offs.add(tuple(q))
+    seen = set()
+    for r, v in enumerate(parts):
+        ids = v.list_chunks()
+        s, w, c = v.get_chunks(ids)
+        have = {tuple(int(x) for x in cid): i for i, cid in enumerate(ids)}
+        lo, hi = bounds[r], bounds[r + 1]
+        for t, i in have.items():
+            if lo <= int(np.dot(np.array(t, np.int64), axis)) < hi:
+                assert t in key
+                seen.add(t)
+        for t in key:  # owned chunks and everything their meshers read
+            if not (lo <= int(np.dot(np.array(t, np.int64), axis)) < hi):
+                continue
+            for o in offs:
+                q = (t[0] + o[0], t[1] + o[1], t[2] + o[2])
+                if q not in key:
+                    continue
+                assert q in have, "partition %d lacks mesher neighbour %s of owned chunk %s" % (r, q, t)
+                i, j = have[q], key[q]
+                assert np.array_equal(s[i].view(np.uint32), s_ref[j].view(np.uint32)), (r, q)
+                assert np.array_equal(w[i].view(np.uint32), w_ref[j].view(np.uint32)), (r, q)
+                assert np.array_equal(c[i], c_ref[j]), (r, q)
+    assert seen == set(key)
+    for v in [single] + parts:
+        v.close()
+    for b in [x for pr in blk for x in pr] + [pair]:
+        b.free()
+
+
 def test_async_pack_leaves_the_same_records_and_count(gpu_required):
     """tf_boundary_pack_async (count on the device, no host round trip) == tf_boundary_pack."""
     cam = synth.Camera()

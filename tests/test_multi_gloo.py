@@ -159,3 +159,108 @@ def test_two_rank_partition_equals_single_process(tmp_path):
                 s, _, _ = ref.get_chunk(cid)
                 assert np.array_equal(s.view(np.uint32), z["ghost_sdf"][i].view(np.uint32))
     assert seen == ref_ids
+
+
+# ---- the neighbour form: three ranks, blocks only between adjacent slabs -------------------------------------
+def _pack_bands(vol, ids, needs, lo, hi, cap):
+    """numpy twin of tf_boundary_pack_bands (ownership key = ChunkID.x, so a + b + c = 1): the down block holds the
+    updated chunks with lo <= x <= lo + 1, the up block those with x == hi - 1."""
+    from texturefusion_amd import exchange
+    x = np.asarray(ids, np.int64)[:, 0]
+    upd = needs != 0
+    out = []
+    for face in ((x >= lo) & (x <= lo + 1) & upd, (x == hi - 1) & upd):
+        sel = ids[face]
+        assert len(sel) <= cap
+        blk = np.zeros(exchange.block_bytes(cap), np.uint8)
+        blk[:4] = np.array([len(sel)], np.uint32).view(np.uint8)
+        rec = blk[exchange.HEADER_BYTES:].reshape(cap, exchange.RECORD_BYTES)
+        for i, cid in enumerate(sel):
+            s_, w, c = vol.get_chunk(cid)
+            rec[i, :12] = np.asarray(cid, np.int32).view(np.uint8)
+            rec[i, 16:16 + 4096] = np.stack([s_, w], 1).astype(np.float32).reshape(-1).view(np.uint8)
+            rec[i, 16 + 4096:] = c.view(np.uint8)
+        out.append(blk)
+    return out
+
+
+def _worker3(rank, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from oracle import api as O
+    from texturefusion_amd import exchange, partition as part, synth
+
+    world = 3
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = np.float32(0.01)
+    cam = synth.Camera()
+    ext = part.room_extent_chunks(res, half_x=0.6, margin=0.1)
+    lo, hi = part.slab_for_rank(ext, rank, world)
+    vol = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    cap = 256
+    received = 0
+    for k in (0, 1, 2):
+        depth, rgba, q, pose = _frame(k, cam)
+        ids, new = vol.prepare(depth, pose)
+        own = part.owner_of(ids, ext, world) == rank
+        nd = np.zeros(int(own.sum()), np.uint8)
+        vol.integrate(depth, rgba, None, pose, ids[own], nd, 1, -1)
+        needs = np.zeros(len(ids), np.uint8)
+        needs[own] = nd
+        vol.finalize(ids[own], nd, new[own])
+        down, up = _pack_bands(vol, ids, needs, lo, hi, cap)
+        below, above = exchange.neighbour_exchange(torch.from_numpy(down), torch.from_numpy(up))
+        two = np.concatenate([below.numpy(), above.numpy()])
+        received += int(below.numpy()[:4].view(np.uint32)[0]) + int(above.numpy()[:4].view(np.uint32)[0])
+        _unpack_blocks(vol, two, 2, -1, cap)
+    chunks = vol.list_chunks()
+    np.savez(os.path.join(out_dir, "n%d.npz" % rank), ids=np.asarray(chunks, np.int32).reshape(-1, 3),
+             sdf=np.stack([vol.get_chunk(c)[0] for c in chunks]), w=np.stack([vol.get_chunk(c)[1] for c in chunks]),
+             lo=lo, hi=hi, received=received)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_rank_neighbour_exchange_equals_single_process(tmp_path):
+    """Slabs [.., e1) [e1, e2) [e2, ..): every rank sends its down band to the rank below and its up band to the rank
+    above (two blocks received whatever the number of ranks).  Owned chunks and the ghost copies a rank's mesher would
+    read (x in [lo - 1, hi + 1]) equal the single-process volume bit for bit."""
+    import torch.multiprocessing as mp
+    from oracle import api as O
+    from texturefusion_amd import synth
+
+    port = _free_port()
+    mp.spawn(_worker3, args=(port, str(tmp_path)), nprocs=3, join=True)
+    res = np.float32(0.01)
+    cam = synth.Camera()
+    ref = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    for k in (0, 1, 2):
+        depth, rgba, q, pose = _frame(k, cam)
+        ids, new = ref.prepare(depth, pose)
+        nd = np.zeros(len(ids), np.uint8)
+        ref.integrate(depth, rgba, None, pose, ids, nd, 1, -1)
+        ref.finalize(ids, nd, new)
+    ref_ids = {tuple(c) for c in ref.list_chunks()}
+    owned_seen, ghosts_checked, received = set(), 0, 0
+    for r in range(3):
+        z = np.load(os.path.join(str(tmp_path), "n%d.npz" % r))
+        lo, hi = int(z["lo"]), int(z["hi"])
+        received += int(z["received"])
+        for i, cid in enumerate(z["ids"]):
+            t = tuple(int(x) for x in cid)
+            mine = lo <= t[0] < hi
+            if t not in ref_ids:
+                assert np.all(z["w"][i] == 0)  # selected everywhere, updated nowhere: garbage in the reference
+                continue
+            if mine:
+                owned_seen.add(t)
+            elif not (lo - 1 <= t[0] <= hi + 1) or z["sdf"][i].min() >= 999.0:
+                continue  # outside the band this rank reads, or never received (not updated on its owner)
+            else:
+                ghosts_checked += 1
+            s_, w, _ = ref.get_chunk(cid)
+            assert np.array_equal(s_.view(np.uint32), z["sdf"][i].view(np.uint32)), (r, t, mine)
+            assert np.array_equal(w.view(np.uint32), z["w"][i].view(np.uint32)), (r, t, mine)
+    assert owned_seen == ref_ids and ghosts_checked > 20 and received > 20

@@ -41,7 +41,7 @@ SYMBOLS = (
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
     "tf_patches_download", "tf_atlas_download_rows", "tf_stream_frames_device",
     "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host",
-    "tf_host_frame_buffers", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block",
+    "tf_host_frame_buffers", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_comm_exchange_mode", "tf_comm_stats",
     "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
     "tf_comm_exchange_every_frame",
     "tf_update_meshes", "tf_check_summaries", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
@@ -158,6 +158,9 @@ def lib():
     L.tf_boundary_block_bytes.restype = C.c_size_t
     L.tf_boundary_block_bytes.argtypes = [C.c_int64]
     L.tf_boundary_pack_block.argtypes = [vp, vp, C.c_int64]
+    L.tf_boundary_pack_bands.argtypes = [vp, vp, vp, C.c_int64]
+    L.tf_comm_exchange_mode.argtypes = [vp, C.c_int]
+    L.tf_comm_stats.argtypes = [vp, i64p, i64p]
     L.tf_boundary_unpack_blocks.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int]
     L.tf_comm_unique_id.argtypes = [vp]
     L.tf_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
@@ -560,6 +563,19 @@ class Volume:
         """unique_id: 128 bytes from comm_unique_id() of one rank, distributed by the caller."""
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
         self._ck(self.L.tf_comm_init(self.h, rank, nranks, C.cast(buf, C.c_void_p)))
+
+    def boundary_pack_bands(self, d_block_down, d_block_up, cap):
+        """the ghost band as two blocks: what the rank below / the rank above reads"""
+        self._ck(self.L.tf_boundary_pack_bands(self.h, C.c_void_p(d_block_down), C.c_void_p(d_block_up), cap))
+
+    def comm_exchange_mode(self, mode):
+        """0 = neighbour send / receive pairs (default), 1 = all-gather"""
+        self._ck(self.L.tf_comm_exchange_mode(self.h, int(mode)))
+
+    def comm_stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._ck(self.L.tf_comm_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def exchange_boundary(self, cap):
         self._ck(self.L.tf_exchange_boundary(self.h, cap))

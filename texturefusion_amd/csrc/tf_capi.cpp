@@ -1530,6 +1530,20 @@ int tf_boundary_pack_block(tf_volume* v, void* d_block, int64_t cap_records) {
   return TF_OK;
 }
 
+int tf_boundary_pack_bands(tf_volume* v, void* d_block_down, void* d_block_up, int64_t cap_records) {
+  if (!v || !d_block_down || !d_block_up) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  uint8_t* dn = reinterpret_cast<uint8_t*>(d_block_down);
+  uint8_t* up = reinterpret_cast<uint8_t*>(d_block_up);
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp2, 0, 4, v->stream));
+  launch_boundary_pack_bands(v->dev, dn + 16, up + 16, (uint32_t)cap_records, v->stream);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipMemcpyAsync(dn, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));  // the counts travel in-band
+  TF_HIP(hipMemcpyAsync(up, &v->dev.vctl->n_tmp2, 4, hipMemcpyDeviceToDevice, v->stream));
+  return TF_OK;
+}
+
 int tf_boundary_unpack_blocks(tf_volume* v, const void* d_blocks, int32_t n_blocks, int32_t own_block,
                               int64_t cap_records, int join_dirty) {
   if (!v || !d_blocks) { set_error("null argument"); return TF_ERR_INVALID; }

@@ -1,8 +1,13 @@
 // tf_comm.cpp -- multi-GPU boundary exchange inside the C ABI: one process per GPU,
-// RCCL over xGMI.  The path has exactly one collective: an all-gather of the ghost-band chunks a rank updated
-// since the previous exchange.  It is ONE fixed-capacity ncclAllGather of [count | records] blocks -- the record
-// count travels in-band, so nothing comes back to the host and the exchange is just another operation on the
-// handle's stream between the voxel update and the mesher.
+// RCCL over xGMI.  The path has exactly one exchange step: the ghost-band chunks a rank updated since the previous
+// exchange travel to the ranks that read them.  Two forms, both fixed-capacity [count | records] blocks with the record
+// count in-band, so nothing comes back to the host and the exchange is just another operation on the handle's stream
+// between the voxel update and the mesher:
+//   neighbours (default): slabs are contiguous key ranges, so a rank's ghost band is read by the rank below (keys
+//     lo .. lo + a + b + c) and the rank above (key hi - 1) only -- one grouped ncclSend / ncclRecv pair per neighbour:
+//     a rank receives TWO blocks whatever the number of ranks, and each block holds only that neighbour's band;
+//   all-gather: ONE ncclAllGather of every rank's block to every rank (7 received blocks at 8 ranks); needed when a slab
+//     is thinner than a + b + c + 1 keys, so that a band reaches beyond the adjacent slab.
 //
 // librccl is opened at run time (dlopen) when tf_comm_init is first called: single-GPU users never load it,
 // and a host process that already carries an RCCL (e.g. PyTorch's) keeps exactly one copy.
@@ -20,6 +25,10 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 static Rccl g_rccl;
@@ -36,6 +45,10 @@ static int rccl_load() {
   g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(dlsym(g_rccl.lib, "ncclCommInitRank"));
   g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(dlsym(g_rccl.lib, "ncclCommDestroy"));
   g_rccl.AllGather = reinterpret_cast<decltype(g_rccl.AllGather)>(dlsym(g_rccl.lib, "ncclAllGather"));
+  g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(dlsym(g_rccl.lib, "ncclSend"));
+  g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(dlsym(g_rccl.lib, "ncclRecv"));
+  g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(dlsym(g_rccl.lib, "ncclGroupStart"));
+  g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(dlsym(g_rccl.lib, "ncclGroupEnd"));
   g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(dlsym(g_rccl.lib, "ncclGetErrorString"));
   if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllGather) {
     set_error("librccl lacks an expected symbol");
@@ -61,8 +74,8 @@ static int comm_buffers(tf_volume* v, int64_t cap_records) {
   if (c.d_send) hipFree(c.d_send);
   if (c.d_recv) hipFree(c.d_recv);
   c.d_send = c.d_recv = nullptr;
-  TF_HIP(hipMalloc(&c.d_send, block));
-  TF_HIP(hipMalloc(&c.d_recv, block * (size_t)(c.nranks > 0 ? c.nranks : 1)));
+  TF_HIP(hipMalloc(&c.d_send, block * 2));  // all-gather: one block; neighbours: the down block, then the up block
+  TF_HIP(hipMalloc(&c.d_recv, block * (size_t)(c.nranks > 2 ? c.nranks : 2)));
   c.cap_records = cap_records;
   return TF_OK;
 }
@@ -75,16 +88,47 @@ int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t sta
   int rc = comm_buffers(v, cap_records);
   if (rc) return rc;
   const size_t block = tf_boundary_block_bytes(c.cap_records);
-  rc = tf_boundary_pack_block(v, c.d_send, c.cap_records);
-  if (rc) return rc;
-  TF_NCCL(g_rccl.AllGather(c.d_send, c.d_recv, block, ncclUint8, reinterpret_cast<ncclComm_t>(c.comm), v->stream));
+  ncclComm_t comm = reinterpret_cast<ncclComm_t>(c.comm);
+  uint8_t* send = reinterpret_cast<uint8_t*>(c.d_send);
+  uint8_t* recv = reinterpret_cast<uint8_t*>(c.d_recv);
+  int nblocks = c.nranks, skip = c.rank;
+  const bool neighbours = c.mode == TF_XCHG_NEIGHBOURS && g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd;
+  if (neighbours) {
+    // down block -> rank - 1, up block -> rank + 1; from rank - 1 comes ITS up block, from rank + 1 its down block.
+    // A missing neighbour's receive slot keeps a zero count.
+    rc = tf_boundary_pack_bands(v, send, send + block, c.cap_records);
+    if (rc) return rc;
+    const bool lower = c.rank > 0, upper = c.rank + 1 < c.nranks;
+    if (!lower) TF_HIP(hipMemsetAsync(recv, 0, 16, v->stream));
+    if (!upper) TF_HIP(hipMemsetAsync(recv + block, 0, 16, v->stream));
+    if (lower || upper) {
+      TF_NCCL(g_rccl.GroupStart());
+      if (lower) {
+        TF_NCCL(g_rccl.Send(send, block, ncclUint8, c.rank - 1, comm, v->stream));
+        TF_NCCL(g_rccl.Recv(recv, block, ncclUint8, c.rank - 1, comm, v->stream));
+      }
+      if (upper) {
+        TF_NCCL(g_rccl.Send(send + block, block, ncclUint8, c.rank + 1, comm, v->stream));
+        TF_NCCL(g_rccl.Recv(recv + block, block, ncclUint8, c.rank + 1, comm, v->stream));
+      }
+      TF_NCCL(g_rccl.GroupEnd());
+    }
+    nblocks = 2;
+    skip = -1;
+    c.bytes_received += (uint64_t)((lower ? 1 : 0) + (upper ? 1 : 0)) * block;
+  } else {
+    rc = tf_boundary_pack_block(v, send, c.cap_records);
+    if (rc) return rc;
+    TF_NCCL(g_rccl.AllGather(send, recv, block, ncclUint8, comm, v->stream));
+    c.bytes_received += (uint64_t)(c.nranks > 1 ? c.nranks - 1 : 0) * block;
+  }
+  c.exchanges += 1;
   VolumeDev d = v->dev;
   if (dirty_par >= 0) {
     d.work_ids = v->atlas.d_work_ids + (size_t)dirty_par * d.max_chunks;
     d.work_slot = v->atlas.d_work_slot + (size_t)dirty_par * d.max_chunks;
   }
-  launch_boundary_unpack_blocks(d, reinterpret_cast<const uint8_t*>(c.d_recv), c.nranks, c.rank, (uint32_t)c.cap_records,
-                                dirty_par, stamp, v->stream);
+  launch_boundary_unpack_blocks(d, recv, nblocks, skip, (uint32_t)c.cap_records, dirty_par, stamp, v->stream);
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
   return TF_OK;
@@ -137,6 +181,20 @@ int tf_comm_destroy(tf_volume* v) {
   TF_DEV(v);
   TF_HIP(hipStreamSynchronize(v->stream));
   comm_destroy(v);
+  return TF_OK;
+}
+
+int tf_comm_exchange_mode(tf_volume* v, int mode) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  if (mode != TF_XCHG_NEIGHBOURS && mode != TF_XCHG_ALLGATHER) { set_error("unknown exchange mode"); return TF_ERR_INVALID; }
+  v->comm.mode = mode;
+  return TF_OK;
+}
+
+int tf_comm_stats(tf_volume* v, int64_t* exchanges, int64_t* bytes_received) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  if (exchanges) *exchanges = (int64_t)v->comm.exchanges;
+  if (bytes_received) *bytes_received = (int64_t)v->comm.bytes_received;
   return TF_OK;
 }
 

@@ -83,7 +83,7 @@ struct VolCtl {
   uint32_t status;    // sticky error bits
   uint32_t n_tmp;     // scratch counter of the on-demand list/pack kernels
   uint32_t ovf_next;  // mesh overflow pool: blocks handed out (bump allocation, reset with the volume)
-  uint32_t pad;
+  uint32_t n_tmp2;    // second scratch counter (the "up" block of the two-band boundary pack)
   // Pool slots are handed out from 64 independent stripes (stripe s owns slots
   // [s*max_chunks/64, (s+1)*max_chunks/64)) so that the thousands of chunk creations of a
   // first-touch frame do not serialise on one atomic word.
@@ -303,6 +303,8 @@ void launch_gather_chunks(const VolumeDev& v, const int4* ids, uint32_t n, float
 void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const float* w,
                           const uint16_t* col, hipStream_t s);
 void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s);
+// two blocks: what the rank below / the rank above reads as ghosts (counts in VolCtl::n_tmp / n_tmp2)
+void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* records_down, uint8_t* records_up, uint32_t cap, hipStream_t s);
 void launch_boundary_unpack(const VolumeDev& v, const uint8_t* records, uint32_t n, hipStream_t s);
 // blocks of [16-B header {count} | cap records] per rank, the block of `skip` is this rank's own
 void launch_boundary_unpack_blocks(const VolumeDev& v, const uint8_t* blocks, int nblocks, int skip, uint32_t cap,

@@ -120,7 +120,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
     ctl->emit_pack = 0ull;
     for (int k = 0; k < kKaCounters; ++k) ctl->ka_next[k * kKaCounterStride] = 0u;
     if (vctl) {
-      vctl->status = 0; vctl->n_tmp = 0; vctl->ovf_next = 0;
+      vctl->status = 0; vctl->n_tmp = 0; vctl->n_tmp2 = 0; vctl->ovf_next = 0;
       for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
     }
   }
@@ -1780,7 +1780,11 @@ void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const f
 // Pack every chunk this rank owns whose "touched" bit is set (slab-face chunks updated since the
 // last exchange) and clear the bit.  Record: int4 id | float2[512] | ushort4[512].  One wave scans
 // 64 hash entries at a time and copies the (rare) flagged chunks cooperatively.
-__global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* records, uint32_t cap) {
+// BANDS: two blocks instead of one -- `records` takes the chunks the rank BELOW reads as ghosts (key - lo <= a + b + c),
+// `records_up` those the rank ABOVE reads (key == hi - 1); a chunk of a thin slab may go to both.  Slabs are contiguous key
+// ranges, so with every slab at least a + b + c + 1 keys wide these two neighbours are the only readers (part_band).
+template <bool BANDS>
+__global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* records, uint8_t* records_up, uint32_t cap) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const uint32_t nwaves = gridDim.x * 4;
@@ -1798,31 +1802,46 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
       const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)h.slot, src);
       const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(h.key & 0xFFFFFFFFu), src);
       const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(h.key >> 32), src);
-      uint32_t p = 0;
-      if (lane == 0) p = atomicAdd(&v.vctl->n_tmp, 1u);
-      p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
-      if (p >= cap) continue;  // does not fit: the chunk stays flagged, a retry with a larger buffer packs it
-      if (lane == src) v.hent[i].alive = h.alive & 1u;
-      uint8_t* rec = records + (size_t)p * (16 + 4096 + 4096);
-      if (lane == 0) {  // header: id + the epoch of the chunk's last update (Chisel::meshesToUpdate travels with it)
-        int4 hd = unpack_id(((unsigned long long)khi << 32) | klo);
-        hd.w = (int)v.mark_epoch[slot];
-        *reinterpret_cast<int4*>(rec) = hd;
+      int4 hd = unpack_id(((unsigned long long)khi << 32) | klo);
+      bool down = true, up = false;
+      if (BANDS) {
+        const long long k = part_key(v, hd.x, hd.y, hd.z);
+        down = k >= (long long)v.part_lo && k - (long long)v.part_lo <= (long long)(v.part_a + v.part_b + v.part_c);
+        up = k == (long long)v.part_hi - 1;
       }
+      uint32_t p = 0, q = 0;
+      if (lane == 0) {
+        if (down) p = atomicAdd(&v.vctl->n_tmp, 1u);
+        if (up) q = atomicAdd(&v.vctl->n_tmp2, 1u);
+      }
+      p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+      q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+      if ((down && p >= cap) || (up && q >= cap)) continue;  // does not fit: the chunk stays flagged, a retry with a larger buffer packs it
+      if (lane == src) v.hent[i].alive = h.alive & 1u;
+      hd.w = (int)v.mark_epoch[slot];  // header: id + the epoch of the chunk's last update (Chisel::meshesToUpdate travels with it)
       const uint4* st = reinterpret_cast<const uint4*>(v.tsdf + (size_t)slot * kChunkVoxels);
       const uint4* sc = reinterpret_cast<const uint4*>(v.color + (size_t)slot * kChunkVoxels);
-      uint4* dt = reinterpret_cast<uint4*>(rec + 16);
-      uint4* dc = reinterpret_cast<uint4*>(rec + 16 + 4096);
+      uint4 vt[4], vc[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        dt[k * 64 + lane] = st[k * 64 + lane];
-        dc[k * 64 + lane] = sc[k * 64 + lane];
+      for (int k = 0; k < 4; ++k) { vt[k] = st[k * 64 + lane]; vc[k] = sc[k * 64 + lane]; }
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+        if (side == 0 ? !down : !up) continue;
+        uint8_t* rec = (side == 0 ? records : records_up) + (size_t)(side == 0 ? p : q) * (16 + 4096 + 4096);
+        if (lane == 0) *reinterpret_cast<int4*>(rec) = hd;
+        uint4* dt = reinterpret_cast<uint4*>(rec + 16);
+        uint4* dc = reinterpret_cast<uint4*>(rec + 16 + 4096);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dt[k * 64 + lane] = vt[k]; dc[k * 64 + lane] = vc[k]; }
       }
     }
   }
 }
 void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s) {
-  hipLaunchKernelGGL(k_boundary_pack, dim3(1024), dim3(256), 0, s, v, records, cap);
+  hipLaunchKernelGGL(k_boundary_pack<false>, dim3(1024), dim3(256), 0, s, v, records, (uint8_t*)nullptr, cap);
+}
+void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* records_down, uint8_t* records_up, uint32_t cap, hipStream_t s) {
+  hipLaunchKernelGGL(k_boundary_pack<true>, dim3(1024), dim3(256), 0, s, v, records_down, records_up, cap);
 }
 
 // Store received records of chunks this rank does not own as ghost chunks.

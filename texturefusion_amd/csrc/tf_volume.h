@@ -113,6 +113,8 @@ struct CommState {
   void* d_send = nullptr;
   void* d_recv = nullptr;
   int64_t cap_records = 0;
+  int mode = TF_XCHG_NEIGHBOURS;
+  uint64_t exchanges = 0, bytes_received = 0;  // tf_comm_stats
 };
 
 }  // namespace tf
