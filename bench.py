@@ -251,6 +251,9 @@ def main():
                 uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, 0)
             vol.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+            # neighbour send / receive pairs need every slab to hold its own ghost band (a + b + c + 1 keys); else all-gather
+            widths = [edges[r + 1] - edges[r] for r in range(1, world - 1)]
+            vol.comm_exchange_mode(0 if all(w >= sum(axis) + 1 for w in widths) else 1)
             if textured:
                 vol.comm_exchange_every_frame(cap)
         else:
@@ -737,6 +740,7 @@ def cpu_baseline(args, cam, res, h_depth, h_rgba, h_pose, n_unique, textured):
     ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
     avx2 = bool(O.lib().tfo_have_avx2())
     ov.set_kernel(1 if avx2 else 0)  # AVX2 row kernel (as the reference's), bit-identical to the scalar checker
+    O.lib().tfo_set_select_kernel(1 if avx2 else 0)  # ... and the AVX2 selection (ChunkManager.h:303-364,561-636)
     ncpu = os.cpu_count() or 1
     oa = O.Atlas(res) if textured else None
     T = args.cpu_threads if args.cpu_threads > 0 else max(1, ncpu - 2)  # chisel::parallel_for: hardware_concurrency - 2,
@@ -759,7 +763,7 @@ def cpu_baseline(args, cam, res, h_depth, h_rgba, h_pose, n_unique, textured):
     out = {
         "value": n / t_all, "unit": "frames/s", "cores": T,
         "kind": "port",
-        "sample": "oracle/ C port of the reference path (%s voxel kernel, no FMA; selection scalar, 1 thread; %s) on frames "
+        "sample": "oracle/ C port of the reference path (%s voxel kernel and selection, no FMA; selection on 1 thread as in the reference; %s) on frames "
                   "%d..%d of the same stream after %d untimed frames on an empty volume (lighter than the GPU's steady-state "
                   "frames: the GPU / CPU ratio is understated); parallel stages use chisel::parallel_for's policy "
                   "(hardware_concurrency - 2 = %d threads, groups of >= 1000 items); host has %d logical cores"

@@ -115,6 +115,8 @@ def lib():
     L.tfo_volume_has_chunk.argtypes = [vp, i32p]
     L.tfo_volume_get_chunk.argtypes = [vp, i32p, fp, fp, u16p]
     L.tfo_volume_set_chunk.argtypes = [vp, i32p, fp, fp, u16p]
+    L.tfo_set_select_kernel.argtypes = [C.c_int]
+    L.tfo_set_select_kernel.restype = None
     L.tfo_volume_retract_observations.restype = C.c_int64
     L.tfo_volume_retract_observations.argtypes = [vp, C.c_int, i32p, C.c_int64]
     L.tfo_volume_get_observations.restype = C.c_int64

@@ -431,10 +431,102 @@ static int probe8(const probe_ctx* pc, const float oc[3], float dtp, float dtn,
   return hit;
 }
 
+#ifdef TFO_HAVE_AVX2_KERNEL
+/* The same two stages with the reference's own vector shapes (the CPU baseline's form; bit-identical to the scalar
+ * checker above, tests/test_oracle_kat.py): findCubeCornerByMat reads 8 pixels per step and keeps 8-lane running
+ * min / max (ChunkManager.h:326-363); CheckCornerIntersectingSIMD puts the 8 probe corners into one vector (:561-636).
+ * Element arithmetic is unchanged (separate mul / add, IEEE div), min / max are exact and order-free. */
+__attribute__((target("avx2"))) static void bbox_avx2(const float* depth, const tfo_camera* cam, const float pose[12],
+                                                       float res, int min_id[3], int max_id[3]) {
+  const int W = cam->width, H = cam->height;
+  const float fx = (float)(int)cam->fx, fy = (float)(int)cam->fy;
+  const float cx = (float)(int)cam->cx, cy = (float)(int)cam->cy;
+  __m256 vmx[3], vmn[3];
+  for (int a = 0; a < 3; a++) { vmx[a] = _mm256_set1_ps(-1e8f); vmn[a] = _mm256_set1_ps(1e8f); }
+  const __m256 off = _mm256_set1_ps((float)0.2), vfx = _mm256_set1_ps(fx), vcx = _mm256_set1_ps(cx);
+  const __m256 lane = _mm256_setr_ps(0, 1, 2, 3, 4, 5, 6, 7);
+  float mx[3] = {-1e8f, -1e8f, -1e8f}, mn[3] = {1e8f, 1e8f, 1e8f};
+  const int W8 = W & ~7;
+  for (int i = 0; i < H; i++) {
+    const float ly = ((float)i - cy) / fy;
+    const __m256 vly = _mm256_set1_ps(ly);
+    for (int j = 0; j < W8; j += 8) {
+      const __m256 dz = _mm256_add_ps(_mm256_loadu_ps(depth + (size_t)i * W + j), off);
+      const __m256 lx = _mm256_div_ps(_mm256_sub_ps(_mm256_add_ps(_mm256_set1_ps((float)j), lane), vcx), vfx);
+      const __m256 vx = _mm256_mul_ps(lx, dz), vy = _mm256_mul_ps(vly, dz);
+      for (int a = 0; a < 3; a++) {
+        __m256 p = _mm256_mul_ps(_mm256_set1_ps(R_(pose, a, 0)), vx);
+        p = _mm256_add_ps(p, _mm256_mul_ps(_mm256_set1_ps(R_(pose, a, 1)), vy));
+        p = _mm256_add_ps(p, _mm256_mul_ps(_mm256_set1_ps(R_(pose, a, 2)), dz));
+        p = _mm256_add_ps(p, _mm256_set1_ps(T_(pose, a)));
+        vmx[a] = _mm256_max_ps(p, vmx[a]);
+        vmn[a] = _mm256_min_ps(p, vmn[a]);
+      }
+    }
+    for (int j = W8; j < W; j++) { /* (widths that are no multiple of 8: the scalar form) */
+      float dz = depth[(size_t)i * W + j] + (float)0.2;
+      float lx = ((float)j - cx) / fx;
+      float vx = lx * dz, vy = ly * dz;
+      for (int a = 0; a < 3; a++) {
+        float p = R_(pose, a, 0) * vx;
+        p = p + R_(pose, a, 1) * vy;
+        p = p + R_(pose, a, 2) * dz;
+        p = p + T_(pose, a);
+        mx[a] = (p > mx[a]) ? p : mx[a];
+        mn[a] = (p < mn[a]) ? p : mn[a];
+      }
+    }
+  }
+  for (int a = 0; a < 3; a++) {
+    float tx[8], tn[8];
+    _mm256_storeu_ps(tx, vmx[a]);
+    _mm256_storeu_ps(tn, vmn[a]);
+    for (int l = 0; l < 8; l++) { mx[a] = tx[l] > mx[a] ? tx[l] : mx[a]; mn[a] = tn[l] < mn[a] ? tn[l] : mn[a]; }
+  }
+  const float f = 1.0f / (8.0f * res);
+  for (int a = 0; a < 3; a++) {
+    max_id[a] = (int)floorf(mx[a] * f);
+    min_id[a] = (int)floorf(mn[a] * f);
+  }
+}
+
+__attribute__((target("avx2"))) static int probe8_avx2(const probe_ctx* pc, const float oc[3], float dtp, float dtn,
+                                                        const float off[3][8]) {
+  const __m256 px = _mm256_add_ps(_mm256_set1_ps(oc[0]), _mm256_loadu_ps(off[0]));
+  const __m256 py = _mm256_add_ps(_mm256_set1_ps(oc[1]), _mm256_loadu_ps(off[1]));
+  const __m256 pz = _mm256_add_ps(_mm256_set1_ps(oc[2]), _mm256_loadu_ps(off[2]));
+  const __m256 u = _mm256_add_ps(_mm256_mul_ps(_mm256_div_ps(px, pz), _mm256_set1_ps(pc->fx)), _mm256_set1_ps(pc->cx));
+  const __m256 v = _mm256_add_ps(_mm256_mul_ps(_mm256_div_ps(py, pz), _mm256_set1_ps(pc->fy)), _mm256_set1_ps(pc->cy));
+  const __m256i X = _mm256_cvtps_epi32(u), Y = _mm256_cvtps_epi32(v); /* rne; NaN / out of range -> 0x80000000 */
+  const __m256i one = _mm256_set1_epi32(1);
+  __m256i valid = _mm256_and_si256(_mm256_cmpgt_epi32(X, one), _mm256_cmpgt_epi32(_mm256_set1_epi32(pc->W - 1), X));
+  valid = _mm256_and_si256(valid, _mm256_and_si256(_mm256_cmpgt_epi32(Y, one), _mm256_cmpgt_epi32(_mm256_set1_epi32(pc->H - 1), Y)));
+  if (_mm256_testz_si256(valid, valid)) return 0; /* :611-613 */
+  const int depthValid = (oc[2] > pc->nearP) && (pc->farP > oc[2]);
+  if (!depthValid) return 0; /* (every lane's hit is ANDed with it) */
+  const __m256i idx = _mm256_add_epi32(_mm256_mullo_epi32(Y, _mm256_set1_epi32(pc->W)), X);
+  const __m256 d = _mm256_mask_i32gather_ps(_mm256_setzero_ps(), pc->depth, idx, _mm256_castsi256_ps(valid), 4);
+  const __m256 sd = _mm256_sub_ps(d, pz);
+  __m256 inside = _mm256_and_ps(_mm256_cmp_ps(sd, _mm256_set1_ps(-dtn), _CMP_GT_OS), _mm256_cmp_ps(_mm256_set1_ps(dtp), sd, _CMP_GT_OS));
+  inside = _mm256_and_ps(inside, _mm256_castsi256_ps(valid));
+  return _mm256_movemask_ps(inside) != 0;
+}
+#endif
+
+/* 0 = the scalar checker, 1 = the AVX2 forms above (the CPU baseline, when the CPU has AVX2) */
+static int g_select_kernel = 0;
+void tfo_set_select_kernel(int kernel) { g_select_kernel = kernel; }
+
 int64_t tfo_select(const float* depth, const tfo_camera* cam, const tfo_integrator* ig,
                    const float pose[12], float res, int32_t* ids, int64_t cap,
                    int64_t* n_coarse_tested) {
   int minID[3], maxID[3];
+  int (*probe)(const probe_ctx*, const float[3], float, float, const float[3][8]) = probe8;
+#ifdef TFO_HAVE_AVX2_KERNEL
+  const int vec = g_select_kernel == 1 && tfo_have_avx2();
+  if (vec) { bbox_avx2(depth, cam, pose, res, minID, maxID); probe = probe8_avx2; }
+  else
+#endif
   tfo_bbox(depth, cam, pose, res, minID, maxID); /* :395-396 (second full-image pass) */
 
   float diag = 8.0f * res / 2.0f; /* :398 */
@@ -492,7 +584,7 @@ int64_t tfo_select(const float* depth, const tfo_camera* cam, const tfo_integrat
         float trunc = tfo_truncation(ig, oc[2]);
         float dtp = trunc + diag * (float)step; /* :489-490 */
         float dtn = negTrunc + diag * (float)step;
-        if (!probe8(&pc, oc, dtp, dtn, coarse)) continue;
+        if (!probe(&pc, oc, dtp, dtn, coarse)) continue;
         for (int i = x; i < x + step; i++)
           for (int j = y; j < y + step; j++)
             for (int k = z; k < z + step; k++) {
@@ -503,7 +595,7 @@ int64_t tfo_select(const float* depth, const tfo_camera* cam, const tfo_integrat
               float tr = tfo_truncation(ig, of[2]);
               float fdtp = tr + diag;
               float fdtn = negTrunc + diag;
-              if (probe8(&pc, of, fdtp, fdtn, fine)) {
+              if (probe(&pc, of, fdtp, fdtn, fine)) {
                 if (n < cap) { ids[3 * n] = i; ids[3 * n + 1] = j; ids[3 * n + 2] = k; }
                 n++;
               }

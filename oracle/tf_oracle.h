@@ -113,6 +113,8 @@ int tfo_volume_set_chunk(tfo_volume* v, const int id[3], const float* sdf, const
 int64_t tfo_volume_get_observations(const tfo_volume* v, const int id[3], int32_t* kf,
                                     float* q, int64_t cap);
 int64_t tfo_volume_retract_observations(tfo_volume* v, int kf, const int32_t* ids, int64_t n);
+/* selection (K-B / K-C): 0 = scalar checker, 1 = AVX2 forms with the reference's vector shapes (CPU baseline) */
+void tfo_set_select_kernel(int kernel);
 int64_t tfo_volume_num_dirty(const tfo_volume* v);
 int64_t tfo_volume_list_dirty(const tfo_volume* v, int32_t* ids, int64_t cap);
 void tfo_volume_clear_dirty(tfo_volume* v);
