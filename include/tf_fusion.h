@@ -166,6 +166,43 @@ TF_API int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint
 TF_API int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t n,
                         int integrate_flag, int use_color, int use_quality,
                         uint8_t* inout_needs_update, float* out_quality);
+/* ---- the keyframe unit (what the product's map thread runs per keyframe) -----------------------------
+ * MobileFusion::tsdfFusion (GCFusion/MobileFusion.cpp:274-406) as ONE asynchronous call on device-resident images:
+ *   for every MOVED keyframe (GetMapDynamics' keyframesToUpdate, <= 12): RetractObservations (:252-272), then
+ *     ReIntegrateKeyframe(flag 0) (:114-221) over the keyframe's stored Frame::validChunks at the OLD poses -- the
+ *     keyframe's depth + colour + quality, then its <= 6 local frames depth-only over the same list -- and
+ *     ReIntegrateKeyframe(flag 1) at the NEW poses (PrepareIntersectChunks, the same frames, FinalizeIntegrateChunks,
+ *     validChunks stored again);
+ *   the NEW keyframe group (`fresh`, may be NULL), flag 1;
+ *   Chisel::UpdateMeshes over everything marked since the last CompressMeshes (:327);
+ *   texture != 0: CompressMeshes, GeneratePatches with the new keyframe as the label of every chunk of chunksToUpdate,
+ *     UpdateAtlas (:355-382; pose_inv16 = f32(SE3d.inverse().matrix()) of the new keyframe, Patch.cpp:51).  With
+ *     texture == 0 the unit ends behind UpdateMeshes: the caller's tf_compress_meshes returns chunksToUpdate, its view
+ *     selection (host code outside the path) runs, tf_generate_patches / tf_update_atlas take its labels.
+ * Visible lists, needsUpdate / new flags, every keyframe's validChunks and Chunk::observations (tf_observations_*)
+ * stay in HBM; nothing is copied back and the host does not wait.  All images are device pointers (depth f32 16-B
+ * aligned; rgba u8[H][W][4] = valid ? (r, g, b, 1) : 0, MobileFusion.cpp:144-163; quality f32 or NULL) that must stay
+ * valid until the next synchronising call.  A moved keyframe must have been integrated through this entry point before
+ * (its validChunks live in the handle).  tf_keyframe_unit_release frees the per-handle store (also done by
+ * tf_volume_reset / tf_volume_destroy). */
+typedef struct {
+  const float* d_depth;
+  const uint8_t* d_rgba;     /* keyframe only; NULL for local frames */
+  const float* d_quality;    /* keyframe only; may be NULL */
+  float pose[12];            /* row-major [R|t], the pose to integrate with (pose_sophus[0]) */
+} tf_unit_frame;
+typedef struct {
+  int32_t kf_id;             /* Frame::frame_index: key of Chunk::observations, label of its patches */
+  int32_t n_local;           /* 0..6 */
+  tf_unit_frame keyframe;
+  tf_unit_frame local[6];    /* KeyFrameDatabase::corresponding_frames with a refined depth (:189-190) */
+  float old_keyframe_pose[12];  /* moved keyframes: the poses of the previous integration (pose_sophus[1]) */
+  float old_local_pose[6][12];
+} tf_unit_group;
+TF_API int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_unit_group* moved, int32_t n_moved,
+                                   int32_t texture, const float* pose_inv16);
+TF_API int tf_keyframe_unit_release(tf_volume* v);
+
 /* ---- view-selection bookkeeping on the device ------------------------------
  * Chunk::observations (3rd_party/open_chisel/geometry/Chunk.h:171) lives in HBM, keyed by (chunk, keyframe):
  * tf_observations_record   the write of Chisel::IntegrateDepthScanColor (Structure/Chisel.h:244-247) for the list the

@@ -35,7 +35,7 @@ SYMBOLS = (
     "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
     "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
-    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_profile_calibrate", "tf_observations_record", "tf_observations_retract", "tf_export_datacost", "tf_export_adjacency", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
+    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_profile_calibrate", "tf_keyframe_unit_device", "tf_keyframe_unit_release", "tf_observations_record", "tf_observations_retract", "tf_export_datacost", "tf_export_adjacency", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_set_pose",
     "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_meshes_upload",
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
@@ -74,6 +74,15 @@ class TextureStats(C.Structure):
     _fields_ = [("n_dirty", C.c_int64), ("n_meshes", C.c_int64), ("n_vertices", C.c_int64),
                 ("n_triangles", C.c_int64), ("roi_pixels", C.c_int64), ("n_patches", C.c_int64),
                 ("n_slots", C.c_int64), ("n_exact", C.c_int64), ("n_survivors", C.c_int64)]
+
+
+class UnitFrame(C.Structure):
+    _fields_ = [("d_depth", C.c_void_p), ("d_rgba", C.c_void_p), ("d_quality", C.c_void_p), ("pose", C.c_float * 12)]
+
+
+class UnitGroup(C.Structure):
+    _fields_ = [("kf_id", C.c_int32), ("n_local", C.c_int32), ("keyframe", UnitFrame), ("local", UnitFrame * 6),
+                ("old_keyframe_pose", C.c_float * 12), ("old_local_pose", (C.c_float * 12) * 6)]
 
 
 class Profile(C.Structure):
@@ -125,6 +134,8 @@ def lib():
     L.tf_profile_enable.argtypes = [vp, C.c_uint32]
     L.tf_profile_get.argtypes = [vp, C.POINTER(Profile), C.c_int]
     L.tf_profile_calibrate.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
+    L.tf_keyframe_unit_device.argtypes = [vp, C.POINTER(UnitGroup), C.POINTER(UnitGroup), C.c_int32, C.c_int32, fp]
+    L.tf_keyframe_unit_release.argtypes = [vp]
     L.tf_observations_record.argtypes = [vp, C.c_int32]
     L.tf_observations_retract.argtypes = [vp, C.c_int32, i32p, C.c_int64]
     L.tf_export_datacost.argtypes = [vp, i32p, C.c_int64, C.c_int32, i32p, C.c_int32, fp]
@@ -497,6 +508,32 @@ class Volume:
         p = Profile()
         self._ck(self.L.tf_profile_get(self.h, C.byref(p), int(reset)))
         return {PROF_NAMES[i]: (p.ms[i], p.launches[i]) for i in range(len(PROF_NAMES))}
+
+    # -- the keyframe unit (MobileFusion::tsdfFusion as one asynchronous call)
+    @staticmethod
+    def unit_group(kf_id, keyframe, local=(), old_keyframe_pose=None, old_local_poses=()):
+        """keyframe = (d_depth, d_rgba, d_quality, pose); local = [(d_depth, pose), ...] (device pointers)"""
+        g = UnitGroup()
+        g.kf_id = int(kf_id)
+        g.n_local = len(local)
+
+        def fill(fr, dd, dc, dq, pose):
+            fr.d_depth, fr.d_rgba, fr.d_quality = dd or None, dc or None, dq or None
+            fr.pose[:] = list(_f32(pose).reshape(12))
+        fill(g.keyframe, *keyframe)
+        for i, (dd, pose) in enumerate(local):
+            fill(g.local[i], dd, 0, 0, pose)
+        if old_keyframe_pose is not None:
+            g.old_keyframe_pose[:] = list(_f32(old_keyframe_pose).reshape(12))
+        for i, p in enumerate(old_local_poses):
+            g.old_local_pose[i][:] = list(_f32(p).reshape(12))
+        return g
+
+    def keyframe_unit(self, fresh=None, moved=(), texture=False, pose_inv16=None):
+        arr = (UnitGroup * max(1, len(moved)))(*moved)
+        T = None if pose_inv16 is None else _f32(pose_inv16).reshape(16)
+        self._ck(self.L.tf_keyframe_unit_device(self.h, C.byref(fresh) if fresh is not None else None, arr, len(moved),
+                                                int(bool(texture)), _p(T, C.c_float)))
 
     # -- Chunk::observations on the device and the exports TexMap consumes
     def observations_record(self, keyframe_id):

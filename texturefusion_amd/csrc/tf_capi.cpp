@@ -182,7 +182,9 @@ static void discard_primed(tf_volume* v) {
   v->n_primed = 0;
 }
 
-static int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hipStream_t s = nullptr) {
+}  // namespace tf (the two functions below are shared with tf_unit.hip: declared in tf_volume.h)
+int tf::launch_prepare(tf_volume* v, const tf::Pose& pose, bool with_acquire, hipStream_t s) {
+  using namespace tf;
   if (!s) s = v->stream;
   const SelectConsts sc = make_select_consts(pose.p, v->res);
   prof_begin(v, TF_PROF_BBOX, s);
@@ -202,6 +204,7 @@ static int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hip
   return TF_OK;
 }
 
+namespace tf {
 // Make the device-resident list equal to the caller's list (upload + slot lookup if it is not
 // the list the last tf_prepare produced).
 static int sync_list(tf_volume* v, const int32_t* ids, int64_t n) {
@@ -368,6 +371,7 @@ int tf_volume_destroy(tf_volume* v) {
   if (!v) return TF_OK;
   hipSetDevice(v->device);
   if (v->stream) hipStreamSynchronize(v->stream);
+  tf_keyframe_unit_release(v);
   prof_collect(v);
   for (hipEvent_t e : v->prof_pool) hipEventDestroy(e);
   atlas_destroy(v);
@@ -401,7 +405,9 @@ int tf_volume_destroy(tf_volume* v) {
 int tf_volume_reset(tf_volume* v) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
   TF_DEV(v);
-  int rc = init_device_state(v);
+  int rc = tf_keyframe_unit_release(v);  // Frame::validChunks of the keyframes integrated so far
+  if (rc) return rc;
+  rc = init_device_state(v);
   if (rc) return rc;
   return atlas_reset(v);
 }
@@ -707,8 +713,9 @@ static int fused_arm(tf_volume* v) {
 }
 
 // claimed: K-A of this frame built the dirty set itself (FrameStage::claim_par = the parity used here)
-static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
-                         const float* pose_inv16, int32_t frame_id, bool claimed = false) {
+}  // extern "C"
+int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
+                      const float* pose_inv16, int32_t frame_id, bool claimed) {
   AtlasState& a = v->atlas;
   int rc = patch_flush(v);  // (a stage still pending here must read its meshes before this frame's mesher rewrites them)
   if (rc) return rc;
@@ -762,6 +769,7 @@ static int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img
   v->clear_floor = frame_epoch + 1u;  // CompressMeshes cleared meshesToUpdate
   return TF_OK;
 }
+extern "C" {
 // the pending patch stage has been put on the stream (as a role of a frame launch or on its own)
 static int patch_launched(tf_volume* v) {
   AtlasState& a = v->atlas;

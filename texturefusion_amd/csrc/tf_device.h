@@ -20,6 +20,7 @@
 namespace tf {
 
 constexpr int kChunkVoxels = 512;
+constexpr int kGroupFrames = 6;  // local frames of a keyframe group (GCFusion/MobileFusion.h: integrateLocalFrameNum)
 constexpr uint32_t kInvalidSlot = 0xFFFFFFFFu;
 constexpr uint64_t kEmptyKey = ~0ull;
 

@@ -1,0 +1,278 @@
+// tf_unit.hip -- the keyframe unit of MobileFusion::tsdfFusion (GCFusion/MobileFusion.cpp:274-406) as ONE asynchronous
+// call: for every keyframe whose pose moved, RetractObservations (:252-272) + ReIntegrateKeyframe(flag 0) over the
+// keyframe's stored validChunks at the OLD poses + ReIntegrateKeyframe(flag 1) at the NEW ones (:114-221: the
+// keyframe's depth + colour + quality, then its <= 6 local frames depth-only over the same list); then the new keyframe
+// group; then UpdateMeshes -> chunksToUpdate -> CompressMeshes (:327-355) and, optionally, GeneratePatches with the new
+// keyframe as every chunk's label + UpdateAtlas (:374-382).  Everything stays on the handle's stream: the visible
+// lists, the needsUpdate / new flags, Frame::validChunks of every keyframe and Chunk::observations live in HBM, nothing
+// is copied back and the host never waits.  (The view selection of :357-366 is host code outside the path; a caller that
+// runs it stops the unit behind CompressMeshes -- texture = 0 -- and continues with tf_generate_patches and its labels.)
+#include <string.h>
+
+#include <mutex>
+#include <unordered_map>
+
+#include "tf_devfn.h"
+#include "tf_volume.h"
+
+namespace tf {
+
+// Frame::validChunks of the keyframes (GCFusion/frame.h), device-resident: an append-only arena of chunk ids and, per
+// keyframe slot, where its list starts and how long it is.  A keyframe that is integrated again appends a new list
+// (its old one is dead space until tf_volume_reset).
+constexpr int kUnitMaxKf = 1024;
+struct KfTab {
+  uint32_t top;  // ids handed out so far
+  uint32_t pad[3];
+  uint32_t off[kUnitMaxKf];
+  uint32_t n[kUnitMaxKf];
+};
+struct UnitState {
+  int4* arena = nullptr;
+  uint32_t cap = 0;
+  KfTab* tab = nullptr;
+  std::unordered_map<int32_t, int> slot_of;
+  float4* group_pre = nullptr;  // scratch of the keyframe-group kernel (list records + centroid tables of six frames)
+  float* group_cen = nullptr;
+};
+static std::unordered_map<tf_volume*, UnitState> g_units;  // (one per handle; freed by tf_keyframe_unit_release)
+static std::mutex g_units_mu;                              // (handles may live on different threads)
+
+// FinalizeIntegrateChunks' validChunks (Chisel.h:192-208): the entries of the current list whose needsUpdate flag is set,
+// in list order, appended to the arena.  One workgroup: the order must be kept.
+__global__ __launch_bounds__(1024) void k_kf_store(VolumeDev v, KfTab* tab, int4* arena, uint32_t cap, int slot) {
+  const SelBuf& L = v.sel;
+  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t base, run;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) run = 0;
+  // pass 1: count
+  uint32_t cnt = 0;
+  for (uint32_t e = threadIdx.x; e < n; e += 1024) cnt += L.list_needs[e] ? 1u : 0u;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+  if (lane == 0) wsum[w] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int k = 0; k < 16; ++k) tot += wsum[k];
+    uint32_t at = atomicAdd(&tab->top, tot);
+    if (at + tot > cap) { atomicOr(&v.vctl->status, kStListFull); tot = 0; at = 0; }
+    tab->off[slot] = at;
+    tab->n[slot] = tot;
+    base = tot ? at : 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  if (base == 0xFFFFFFFFu) return;
+  // pass 2: ordered compaction, 1024 entries per round
+  for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
+    const uint32_t e = b0 + threadIdx.x;
+    const bool keep = e < n && L.list_needs[e] != 0;
+    const unsigned long long m = __ballot(keep);
+    if (lane == 0) wsum[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) { if (k < w) before += wsum[k]; tot += wsum[k]; }
+    if (keep) arena[base + run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = L.list_id[e];
+    __syncthreads();
+    if (threadIdx.x == 0) run += tot;
+    __syncthreads();
+  }
+}
+
+// localChunksIntersecting = kf.validChunks; needsUpdate = true, newChunk = false for every entry (MobileFusion.cpp:135-143);
+// slots resolved like tf_integrate does for a caller's list (a missing chunk is an error: chunks.at() throws)
+__global__ __launch_bounds__(256) void k_kf_load(VolumeDev v, const KfTab* tab, const int4* arena, int slot) {
+  const SelBuf& L = v.sel;
+  uint32_t n = tab->n[slot];
+  if (n > v.max_list) { n = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&v.vctl->status, kStListFull); }
+  const uint32_t off = tab->off[slot];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { L.ctl->n_list = n; L.ctl->n_front = n; }
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int4 id = arena[off + e];
+    L.list_id[e] = id;
+    L.list_needs[e] = 1;
+    L.list_new[e] = 0;
+    L.list_quality[e] = 0.0f;
+    uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+    uint32_t s = kInvalidSlot;
+    if (ent != kInvalidSlot && v.hent[ent].alive) s = v.hent[ent].slot;
+    if (s == kInvalidSlot) atomicOr(&v.vctl->status, kStMissing);
+    L.list_slot[e] = s;
+    L.list_ent[e] = ent == kInvalidSlot ? 0u : ent;
+  }
+}
+__global__ void k_kf_clear(KfTab* tab, int slot) { tab->n[slot] = 0; }  // kf.validChunks.clear() (:217)
+
+// MobileFusion::RetractObservations' chunk side over the list just loaded: observations.erase(frame_id)
+__global__ __launch_bounds__(256) void k_kf_retract(VolumeDev v, int32_t kf_id) {
+  const SelBuf& L = v.sel;
+  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const uint32_t s = L.list_slot[e];
+    if (s == kInvalidSlot) continue;
+    const unsigned long long key = ((unsigned long long)s << 32) | (unsigned long long)(uint32_t)kf_id;
+    uint32_t i = hash_key(key) & v.obs_mask;
+    for (uint32_t probe = 0; probe <= v.obs_mask; ++probe) {
+      const unsigned long long cur = v.obs_key[i];
+      if (cur == key) { v.obs_q[i] = 0.0f; break; }
+      if (cur == kEmptyKey) break;
+      i = (i + 1) & v.obs_mask;
+    }
+  }
+}
+
+static int unit_state(tf_volume* v, UnitState** out) {
+  std::unique_lock<std::mutex> lock(g_units_mu);
+  UnitState& u = g_units[v];  // (references into an unordered_map stay valid when other handles are added)
+  lock.unlock();
+  if (!u.arena) {
+    u.cap = (uint32_t)std::min<size_t>((size_t)v->dev.max_list * 16, (size_t)1 << 26);
+    TF_HIP(hipMalloc((void**)&u.arena, sizeof(int4) * (size_t)u.cap));
+    TF_HIP(hipMalloc((void**)&u.tab, sizeof(KfTab)));
+    TF_HIP(hipMemsetAsync(u.tab, 0, sizeof(KfTab), v->stream));
+    TF_HIP(hipMalloc((void**)&u.group_pre, sizeof(float4) * (size_t)kGroupFrames * 4 * v->dev.max_list));
+    TF_HIP(hipMalloc((void**)&u.group_cen, sizeof(float) * (size_t)kGroupFrames * 3 * kChunkVoxels));
+  }
+  *out = &u;
+  return TF_OK;
+}
+
+// ReIntegrateKeyframe (MobileFusion.cpp:114-221) for one group with one flag
+static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, int flag, int kf_slot) {
+  hipStream_t s = v->stream;
+  VolumeDev& d = v->dev;
+  FrameImages img{g->keyframe.d_depth, reinterpret_cast<const uchar4*>(g->keyframe.d_rgba), g->keyframe.d_quality};
+  const float* kpose = flag ? g->keyframe.pose : g->old_keyframe_pose;
+  Pose P;
+  memcpy(P.p, kpose, sizeof(P.p));
+  if (flag) {
+    // PrepareIntersectChunks at the keyframe's pose: the ordered list, chunks created, needsUpdate = false
+    v->frame = img;
+    v->frame_bound = true;
+    int rc = launch_prepare(v, P, true, s);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(k_kf_load, dim3(256), dim3(256), 0, s, d, u->tab, u->arena, kf_slot);
+    hipLaunchKernelGGL(k_kf_retract, dim3(256), dim3(256), 0, s, d, g->kf_id);
+  }
+  // the keyframe's own depth + colour (+ quality) ...
+  const bool color = img.rgba != nullptr, quality = color && img.quality != nullptr;
+  launch_integrate(d, img, v->cam, v->ig, P, v->res, flag, color, quality, 0, s);
+  launch_obs_record(d, g->kf_id, s);  // chunk->observations[keyframeID] for BOTH flags (Chisel.h:244-247)
+  // ... then its local frames depth-only over the same list, one visit per chunk
+  if (g->n_local > 0) {
+    const float* dd[kGroupFrames];
+    float poses[12 * kGroupFrames];
+    for (int f = 0; f < g->n_local; ++f) {
+      dd[f] = g->local[f].d_depth;
+      memcpy(poses + 12 * f, flag ? g->local[f].pose : g->old_local_pose[f], 48);
+    }
+    launch_integrate_group(d, g->n_local, dd, poses, u->group_pre, u->group_cen, v->cam, v->ig, v->res, flag, s);
+  }
+  launch_finalize(d, v->epoch++, s);
+  if (flag) hipLaunchKernelGGL(k_kf_store, dim3(1), dim3(1024), 0, s, d, u->tab, u->arena, u->cap, kf_slot);
+  else hipLaunchKernelGGL(k_kf_clear, dim3(1), dim3(1), 0, s, u->tab, kf_slot);
+  TF_HIP(hipGetLastError());
+  v->host_list_n = -1;
+  return TF_OK;
+}
+
+static int check_group(const tf_unit_group* g, bool moved) {
+  if (!g->keyframe.d_depth) { set_error("a keyframe group needs the keyframe's depth image"); return TF_ERR_INVALID; }
+  if (g->kf_id < 0) { set_error("keyframe id must be >= 0"); return TF_ERR_INVALID; }
+  if (g->n_local < 0 || g->n_local > kGroupFrames) { set_error("a keyframe group holds at most 6 local frames"); return TF_ERR_INVALID; }
+  if ((reinterpret_cast<uintptr_t>(g->keyframe.d_depth) & 15) || (reinterpret_cast<uintptr_t>(g->keyframe.d_rgba) & 3) ||
+      (reinterpret_cast<uintptr_t>(g->keyframe.d_quality) & 3)) { set_error("device images must be aligned (depth 16 B, rgba / quality 4 B)"); return TF_ERR_INVALID; }
+  for (int f = 0; f < g->n_local; ++f)
+    if (!g->local[f].d_depth || (reinterpret_cast<uintptr_t>(g->local[f].d_depth) & 15)) { set_error("local frames need an aligned depth image"); return TF_ERR_INVALID; }
+  (void)moved;
+  return TF_OK;
+}
+
+}  // namespace tf
+
+using namespace tf;
+
+extern "C" {
+
+int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_unit_group* moved, int32_t n_moved,
+                            int32_t texture, const float* pose_inv16) {
+  if (!v || (n_moved > 0 && !moved) || n_moved < 0) { set_error("invalid argument"); return TF_ERR_INVALID; }
+  if (!fresh && n_moved == 0) return TF_OK;
+  if (texture && (!fresh || !fresh->keyframe.d_rgba || !pose_inv16)) {
+    set_error("the texture stage needs the new keyframe's colour image and inverse pose");
+    return TF_ERR_INVALID;
+  }
+  TF_DEV(v);
+  UnitState* u = nullptr;
+  int rc = unit_state(v, &u);
+  if (rc) return rc;
+  if (fresh && (rc = check_group(fresh, false))) return rc;
+  for (int m = 0; m < n_moved; ++m)
+    if ((rc = check_group(&moved[m], true))) return rc;
+  auto slot_for = [&](int32_t kf, bool create) -> int {
+    auto it = u->slot_of.find(kf);
+    if (it != u->slot_of.end()) return it->second;
+    if (!create || (int)u->slot_of.size() >= kUnitMaxKf) return -1;
+    const int s = (int)u->slot_of.size();
+    u->slot_of.emplace(kf, s);
+    return s;
+  };
+  // tsdfFusion's loop over keyframesToUpdate (:296-312): retract, de-integrate at the old poses, integrate at the new
+  for (int m = 0; m < n_moved; ++m) {
+    const int slot = slot_for(moved[m].kf_id, false);
+    if (slot < 0) { set_error("a moved keyframe was never integrated through this entry point"); return TF_ERR_INVALID; }
+    if ((rc = integrate_group(v, u, &moved[m], 0, slot))) return rc;
+    if ((rc = integrate_group(v, u, &moved[m], 1, slot))) return rc;
+  }
+  if (fresh) {  // :316-323
+    const int slot = slot_for(fresh->kf_id, true);
+    if (slot < 0) { set_error("too many keyframes"); return TF_ERR_CAPACITY; }
+    if ((rc = integrate_group(v, u, fresh, 1, slot))) return rc;
+  }
+  if (texture) {
+    // UpdateMeshes over everything marked since the last CompressMeshes, CompressMeshes, GeneratePatches with the new
+    // keyframe as the label of every chunk of chunksToUpdate, UpdateAtlas (the fused texture stage; its patch stage stays
+    // pending like a streamed frame's and goes out with the next launch or the next call that looks)
+    FrameImages img{fresh->keyframe.d_depth, reinterpret_cast<const uchar4*>(fresh->keyframe.d_rgba), nullptr};
+    return texture_stage(v, v->dev.sel, img, v->epoch - 1u, pose_inv16, fresh->kf_id);
+  }
+  // texture == 0: UpdateMeshes only (asynchronous).  The caller's tf_compress_meshes then returns chunksToUpdate, marks /
+  // exchanges the adjacency flags and clears meshesToUpdate (MobileFusion.cpp:343-355), its view selection runs, and
+  // tf_generate_patches / tf_update_atlas take its labels.
+  const size_t cap = (size_t)v->dev.max_chunks;
+  rc = ensure_tmp(v, cap * 16 + 16);
+  if (rc) return rc;
+  uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
+  launch_list_dirty(v->dev, reinterpret_cast<int4*>(db + 16), (uint32_t)cap, v->clear_floor, v->stream);
+  TF_HIP(hipMemcpyAsync(db, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));
+  launch_mesh(v->dev, v->mesh_par, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), (uint32_t)cap,
+              ++v->mesh_epoch, v->res, false, -1, 1u << 30, nullptr, -1, v->stream);
+  v->mesh_par ^= 1;
+  TF_HIP(hipGetLastError());
+  return TF_OK;
+}
+
+int tf_keyframe_unit_release(tf_volume* v) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  {
+    std::lock_guard<std::mutex> lock(g_units_mu);
+    if (g_units.find(v) == g_units.end()) return TF_OK;
+  }
+  TF_DEV(v);
+  TF_HIP(hipStreamSynchronize(v->stream));
+  std::lock_guard<std::mutex> lock(g_units_mu);
+  auto it = g_units.find(v);
+  UnitState& u = it->second;
+  if (u.arena) hipFree(u.arena);
+  if (u.tab) hipFree(u.tab);
+  if (u.group_pre) hipFree(u.group_pre);
+  if (u.group_cen) hipFree(u.group_cen);
+  g_units.erase(it);
+  return TF_OK;
+}
+
+}  // extern "C"

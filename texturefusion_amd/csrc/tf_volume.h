@@ -205,6 +205,9 @@ struct tf_volume {
 
 namespace tf {
 int ensure_tmp(tf_volume* v, size_t bytes);
+int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hipStream_t s = nullptr);  // tf_capi.cpp
+int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16,
+                  int32_t frame_id, bool claimed = false);
 int flush_deferred(tf_volume* v);
 int patch_flush(tf_volume* v);
 int ensure_pinned(tf_volume* v, size_t bytes);

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../texturefusion_amd/csrc"
 name=$1; src=$2; shift; shift
 mkdir -p ../../variants /tmp/tfvar
 objs=""
-for f in tf_kernels.hip tf_mesh.hip tf_atlas.hip tf_pre.hip tf_capi.cpp tf_comm.cpp; do
+for f in tf_kernels.hip tf_mesh.hip tf_atlas.hip tf_pre.hip tf_unit.hip tf_capi.cpp tf_comm.cpp; do
   if [ "$f" = "$src" ]; then
     x=""; case $f in *.cpp) x="-x hip";; esac
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden "$@" $x -c $f -o /tmp/tfvar/$name.o
