@@ -455,6 +455,10 @@ def main():
     if rank == 0 and not multi and not args.no_group and not args.no_roofline:
         out["keyframe_group"] = keyframe_group(args, cam, res, d_depth, d_rgba, poses, n_unique, local_rank)
 
+    # ---- the keyframe unit: tsdfFusion as one asynchronous call per keyframe -------------------------------
+    if rank == 0 and not multi and not args.no_group and not args.no_roofline:
+        out["keyframe_unit"] = keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, local_rank)
+
     # ---- CPU baseline: the oracle (C port of the reference path) on the host cores ------------
     if rank == 0 and world == 1 and args.cpu_frames > 0:  # (rank 0 at N = 1 only)
         if orig_affinity:
@@ -730,6 +734,59 @@ def keyframe_group(args, cam, res, d_depth, d_rgba, poses, n_unique, device):
                                     "grouped": (1 + n_local) / ((us_kf + us_grp) * 1e-6)},
             "note": "HIP-event kernel time of the integration launches of a group (k_pre + k_integrate per frame, or "
                     "k_pre x 6 + k_integrate_group); selection and finalize are the same on both sides and excluded"}
+
+
+def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device):
+    """tf_keyframe_unit_device (MobileFusion::tsdfFusion, GCFusion/MobileFusion.cpp:274-406) along the orbit: every
+    7th frame is a keyframe (depth + colour), the six frames behind it are its local frames (depth-only, one visit
+    per chunk); per keyframe: integrate the group, UpdateMeshes, CompressMeshes, GeneratePatches (label = the
+    keyframe), UpdateAtlas -- one call, nothing synchronised.  Second figure: every call also carries ONE moved
+    keyframe (the group integrated two calls earlier, de-integrated over its stored validChunks and re-integrated
+    with the poses of the neighbouring frames)."""
+    from texturefusion_amd import capi
+    n_local = 6
+    stride = 1 + n_local
+    n_kf = max(4, min(24, n_unique // stride - 1))
+    res_out = {}
+    for with_moved in (False, True):
+        vol = capi.Volume(res, cam, max_chunks=1 << 19, max_list=1 << 18, max_coarse=1 << 20, device=device)
+
+        def group(g, shift=0, old=False):
+            k0 = (stride * g) % n_unique
+            loc = [(k0 + 1 + i) % n_unique for i in range(n_local)]
+            P = lambda k: poses[(k + shift) % n_unique]
+            kw = {}
+            if old:
+                kw = dict(old_keyframe_pose=poses[k0], old_local_poses=[poses[k] for k in loc])
+            return capi.Volume.unit_group(1000 + g, (d_depth[k0].data_ptr(), d_rgba[k0].data_ptr(), 0, P(k0)),
+                                          [(d_depth[k].data_ptr(), P(k)) for k in loc], **kw), k0
+
+        def call(g):
+            fresh, k0 = group(g)
+            moved = [group(g - 2, shift=1, old=True)[0]] if with_moved and g >= 2 and g % 2 == 0 else []
+            # (a group is moved once: its second move would need the shifted poses as the old ones)
+            vol.keyframe_unit(fresh=fresh, moved=moved, texture=True, pose_inv16=pinv[k0])
+            return len(moved)
+
+        warm = 4
+        for g in range(warm):
+            call(g)
+        vol.sync()
+        t0 = time.perf_counter()
+        n_moved = 0
+        for g in range(warm, warm + n_kf):
+            n_moved += call(g)
+        vol.sync()
+        dt = time.perf_counter() - t0
+        frames = n_kf * stride + n_moved * 2 * stride  # a moved group is integrated twice (flag 0, flag 1)
+        res_out["with_one_moved_keyframe_every_other_call" if with_moved else "new_keyframes_only"] = {
+            "keyframes_per_s": n_kf / dt, "ms_per_keyframe": 1e3 * dt / n_kf, "frame_integrations_per_s": frames / dt,
+            "keyframes": n_kf, "moved_groups": n_moved}
+        vol.close()
+    res_out["note"] = ("one tf_keyframe_unit_device call per keyframe: 1 colour + %d depth-only frames over one chunk list, "
+                       "meshes of everything marked, CompressMeshes, GeneratePatches (label = the keyframe), UpdateAtlas; "
+                       "asynchronous, device-resident images, wall time over the calls + one final synchronisation" % n_local)
+    return res_out
 
 
 def cpu_baseline(args, cam, res, h_depth, h_rgba, h_pose, n_unique, textured):
