@@ -697,7 +697,9 @@ def keyframe_group(args, cam, res, d_depth, d_rgba, poses, n_unique, device):
     return lists and flags to the host, so their wall time is dominated by host round trips)."""
     from texturefusion_amd import capi
     n_groups, n_local = 8, 6
-    vols = [capi.Volume(res, cam, max_chunks=1 << 18, max_list=1 << 17, max_coarse=1 << 20, device=device) for _ in range(2)]
+    big = args.scene == "big"
+    vols = [capi.Volume(res, cam, max_chunks=(1 << 20) if big else (1 << 18), max_list=(1 << 19) if big else (1 << 17),
+                        max_coarse=(1 << 22) if big else (1 << 20), device=device) for _ in range(2)]
     t_loc = [0.0, 0.0]
     t_kf = 0.0
     chunks = 0
@@ -748,8 +750,10 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
     stride = 1 + n_local
     n_kf = max(4, min(24, n_unique // stride - 1))
     res_out = {}
+    big = args.scene == "big"
     for with_moved in (False, True):
-        vol = capi.Volume(res, cam, max_chunks=1 << 19, max_list=1 << 18, max_coarse=1 << 20, device=device)
+        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+                          max_coarse=(1 << 22) if big else (1 << 20), device=device)
 
         def group(g, shift=0, old=False):
             k0 = (stride * g) % n_unique

@@ -845,7 +845,15 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     if (hc) stage(i, &cur);
     // K-A builds the frame's dirty set itself when the frame's own chunks are all there is to mesh (marks of earlier,
     // untextured frames still waiting -> the general dirty list, texture_stage)
-    const bool claimed = hc && tex && ka_claims && v->clear_floor >= cur.epoch;
+    // Both shortcuts pay for room-sized frames (a K-A wave has one or two chunks) and cost on hall-sized ones, where a
+    // wave walks ten chunks and the claim's dependent hops add up behind each of them (hall: k_frame 250 -> 296 us for
+    // 26 us of k_dirty_frame, profiles/r3): decided by the length of an earlier frame's dirty list, which the mesher's
+    // filter leaves in host-visible memory (no synchronisation; any value gives correct results).
+    const uint32_t dirty_hint = v->atlas.h_dirty_len ? *reinterpret_cast<volatile uint32_t*>(v->atlas.h_dirty_len) : 0u;
+    static const uint32_t small_max = getenv("TF_SMALL_FRAME") ? (uint32_t)atoi(getenv("TF_SMALL_FRAME")) : 20000u;
+    const bool small_frame = dirty_hint <= small_max;
+    if (hc) cur.small_frame = small_frame;
+    const bool claimed = hc && tex && ka_claims && small_frame && v->clear_floor >= cur.epoch;
     if (claimed) cur.claim_par = v->atlas.fused_par;
     if (hn) stage(i + 1, &nxt);
     if (h2) stage(i + 2, &nx2);

@@ -266,6 +266,8 @@ struct FrameStage {
   Pose pose;
   uint32_t epoch;
   int claim_par = -1;        // >= 0: a mesher follows this frame; K-A builds the frame's dirty set into the shard lists of this parity
+  bool small_frame = true;   // the frame's lists are short (a room, not a hall): the patch / selection ranges are dispatched
+                             // ahead of K-A (launch_frame)
   bool coarse_summ = false;  // no mesher follows this frame: an updated chunk's summary becomes "anything" (kSummAny)
                              // instead of the classes written; the filter makes it exact when it next reads the chunk
 };

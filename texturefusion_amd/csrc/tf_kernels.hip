@@ -1525,7 +1525,8 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   // frees.  With the patch stage on board that order leaves the stage's 15-us chains to start when K-A's waves end
   // (profiles/r3: span 48 us); patch + selection first, K-A behind them as their waves finish: 44 us.
   static const int sel_first = env_int("TF_SEL_FIRST", -1);  // tuning knob: 1 = the other roles ahead of K-A, 0 = K-A first
-  const bool others_first = sel_first >= 0 ? sel_first != 0 : with_patch;
+  // (a hall-sized frame -- K-A waves with ten chunks each -- wants K-A first: the other ranges then fill its tail)
+  const bool others_first = sel_first >= 0 ? sel_first != 0 : (with_patch && cur->small_frame);
   a.rot = others_first ? a.n_ka : 0u;
   if (with_patch) hipLaunchKernelGGL((k_frame<true, true>), dim3(total), dim3(256), 0, s, a);
   else if (color) hipLaunchKernelGGL((k_frame<true, false>), dim3(total), dim3(256), 0, s, a);

@@ -39,15 +39,14 @@ __device__ __forceinline__ uint32_t mesh_shard_rows_d(uint32_t max_chunks) { ret
 __device__ __forceinline__ int ridx(int x, int y, int z) { return (x + 1) + (y + 1) * kR + (z + 1) * kR * kR; }
 
 // Index tables of the staging passes (the kernel is VALU-bound: no div / mod by 11 or 9 per voxel).
-//   halo: the 11^3 - 8^3 = 819 region voxels that belong to neighbour chunks, in region order, one 32-bit word each
-//         (a thread keeps its seven entries in registers across the first barrier):
-//         region index | neighbour (0..26) << 11 | voxel index in that chunk << 16
-//   rcorner: region index -> cell-corner index + 1 (px + 9 py + 81 pz), 0 = not one of the 9^3 corners
+//   halo: the 11^3 - 8^3 = 819 region voxels that belong to neighbour chunks, in region order:
+//         region index | neighbour (0..26) << 11 | voxel index in that chunk << 16 | (corner index + 1, 0 = not a corner) << 25
+//         (64-bit entries on purpose: with 32-bit entries and the corner index from a second table the staging pass issues
+//         twice the loads, and it is bound by their number -- hall: k_mesh 70 -> 110 us, profiles/r3)
 //   corner: region index of cell corner c = px + 9 py + 81 pz
 constexpr int kHalo = kRV - 512;
 struct MeshTabs {
-  uint32_t halo[kHalo];
-  uint16_t rcorner[kRV];
+  unsigned long long halo[kHalo];
   uint16_t corner[729];
 };
 constexpr MeshTabs make_mesh_tabs() {
@@ -55,13 +54,13 @@ constexpr MeshTabs make_mesh_tabs() {
   int n = 0;
   for (int i = 0; i < kRV; ++i) {
     const int rx = i % kR - 1, ry = (i / kR) % kR - 1, rz = i / (kR * kR) - 1;
-    t.rcorner[i] = 0;
-    if (rx >= 0 && ry >= 0 && rz >= 0 && rx <= 8 && ry <= 8 && rz <= 8) t.rcorner[i] = (uint16_t)(rx + ry * 9 + rz * 81 + 1);
     if (rx >= 0 && rx < 8 && ry >= 0 && ry < 8 && rz >= 0 && rz < 8) continue;
     const int cx = (rx + 8) >> 3, cy = (ry + 8) >> 3, cz = (rz + 8) >> 3;
-    const uint32_t nb = (uint32_t)(cx + cy * 3 + cz * 9);
-    const uint32_t vox = (uint32_t)(((rx + 8) & 7) + ((ry + 8) & 7) * 8 + ((rz + 8) & 7) * 64);
-    t.halo[n++] = (uint32_t)i | (nb << 11) | (vox << 16);
+    const unsigned long long nb = (unsigned long long)(cx + cy * 3 + cz * 9);
+    const unsigned long long vox = (unsigned long long)(((rx + 8) & 7) + ((ry + 8) & 7) * 8 + ((rz + 8) & 7) * 64);
+    unsigned long long cf = 0;
+    if (rx >= 0 && ry >= 0 && rz >= 0 && rx <= 8 && ry <= 8 && rz <= 8) cf = (unsigned long long)(rx + ry * 9 + rz * 81 + 1);
+    t.halo[n++] = (unsigned long long)i | (nb << 11) | (vox << 16) | (cf << 25);
   }
   for (int c = 0; c < 729; ++c) {
     const int px = c % 9, py = (c / 9) % 9, pz = c / 81;
@@ -514,9 +513,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     for (int j = 0; j < 512 / NT; ++j) a[j] = v.tsdf[(size_t)own * kChunkVoxels + j * NT + t];
     // the thread's entries of the halo table travel with the own voxels: the staging pass below is then ONE hop of
     // scattered loads instead of table -> voxel
-    uint32_t htab[(kHalo + NT - 1) / NT];
+    unsigned long long htab[(kHalo + NT - 1) / NT];
 #pragma unroll
-    for (int j = 0; j < (kHalo + NT - 1) / NT; ++j) htab[j] = (j * NT + t < kHalo) ? d_mesh_tabs.halo[j * NT + t] : ~0u;
+    for (int j = 0; j < (kHalo + NT - 1) / NT; ++j) htab[j] = (j * NT + t < kHalo) ? d_mesh_tabs.halo[j * NT + t] : ~0ull;
     __syncthreads();  // the previous chunk of this workgroup is done with the shared tables
     if (dbg == 9) mesh_stamp(v, r, 1);
     if (t < 27) sh.nslot[t] = surv[32 * row + t];
@@ -536,13 +535,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     // dependent hops instead of four -- is slower, 36 -> 46 us: the extra registers spill)
 #pragma unroll
     for (int j = 0; j < (kHalo + NT - 1) / NT; ++j) {
-      const uint32_t e = htab[j];
-      if (e == ~0u) continue;
-      const uint32_t s = sh.nslot[(e >> 11) & 31u];
-      const uint32_t cf = d_mesh_tabs.rcorner[e & 2047u];  // (travels with the voxel load)
+      const unsigned long long e = htab[j];
+      if (e == ~0ull) continue;
+      const uint32_t s = sh.nslot[(uint32_t)(e >> 11) & 31u];
       float2 val = make_float2(999.0f, 0.0f);
-      if (s != kInvalidSlot) val = v.tsdf[(size_t)s * kChunkVoxels + ((e >> 16) & 511u)];
-      sh.S[e & 2047u] = val.x;
+      if (s != kInvalidSlot) val = v.tsdf[(size_t)s * kChunkVoxels + ((uint32_t)(e >> 16) & 511u)];
+      sh.S[(uint32_t)e & 2047u] = val.x;
+      const uint32_t cf = (uint32_t)(e >> 25) & 1023u;
       if (cf) sh.cflag[cf - 1u] = (val.y > 50.0f) ? kCfHeavy : 0u;
     }
     __syncthreads();
