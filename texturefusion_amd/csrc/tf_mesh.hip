@@ -39,29 +39,63 @@ __device__ __forceinline__ uint32_t mesh_shard_rows_d(uint32_t max_chunks) { ret
 __device__ __forceinline__ int ridx(int x, int y, int z) { return (x + 1) + (y + 1) * kR + (z + 1) * kR * kR; }
 
 // Index tables of the staging passes (the kernel is VALU-bound: no div / mod by 11 or 9 per voxel).
-//   halo: the 11^3 - 8^3 = 819 region voxels that belong to neighbour chunks, in region order:
-//         region index | neighbour (0..26) << 11 | voxel index in that chunk << 16 | (corner index + 1, 0 = not a corner) << 25
-//         (64-bit entries on purpose: with 32-bit entries and the corner index from a second table the staging pass issues
-//         twice the loads, and it is bound by their number -- hall: k_mesh 70 -> 110 us, profiles/r3)
+//   halo: the region voxels that belong to neighbour chunks AND are read by somebody -- a cell corner (all coordinates in
+//         0..8) or the partner of a corner's central difference (one coordinate -1 or 9, the other two in 0..8): 703 of
+//         the 11^3 - 8^3 = 819 -- fetched as PAIRS of x-adjacent voxels (voxels 2k, 2k + 1 of a chunk are 16 contiguous
+//         bytes): 406 loads of 16 B instead of 819 of 8 B.  The staging pass is bound by the number of its scattered
+//         loads (TA / L1 tag rate: every one is its own cache line), not by their bytes.  One 64-bit entry per pair:
+//         region index of the pair's FIRST voxel | neighbour (0..26) << 11 | pair index in that chunk (voxel >> 1) << 16
+//         | use first << 24 | use second << 25 | corner index + 1 of the first (0 = not a corner) << 26 | ... of the
+//         second << 36   (the second voxel's region index is the first's + 1: x-adjacent)
 //   corner: region index of cell corner c = px + 9 py + 81 pz
-constexpr int kHalo = kRV - 512;
+constexpr bool halo_needed(int rx, int ry, int rz) {
+  if (rx < -1 || rx > 9 || ry < -1 || ry > 9 || rz < -1 || rz > 9) return false;  // outside the staged region
+  if (rx >= 0 && rx < 8 && ry >= 0 && ry < 8 && rz >= 0 && rz < 8) return false;  // the chunk's own voxels
+  const int out = ((rx < 0 || rx > 8) ? 1 : 0) + ((ry < 0 || ry > 8) ? 1 : 0) + ((rz < 0 || rz > 8) ? 1 : 0);
+  return out <= 1;
+}
+constexpr int count_halo_pairs() {
+  int n = 0;
+  for (int rz = -1; rz <= 9; ++rz)
+    for (int ry = -1; ry <= 9; ++ry)
+      for (int rx = -1; rx <= 9; ++rx) {
+        if (!halo_needed(rx, ry, rz)) continue;
+        const int vx = (rx + 8) & 7;
+        // counted at the pair's first needed member
+        if ((vx & 1) && halo_needed(rx - 1, ry, rz) && (((rx - 1 + 8) >> 3) == ((rx + 8) >> 3))) continue;
+        ++n;
+      }
+  return n;
+}
+constexpr int kHalo = count_halo_pairs();
 struct MeshTabs {
   unsigned long long halo[kHalo];
   uint16_t corner[729];
 };
+constexpr unsigned long long corner_of(int rx, int ry, int rz) {
+  return (rx >= 0 && ry >= 0 && rz >= 0 && rx <= 8 && ry <= 8 && rz <= 8) ? (unsigned long long)(rx + ry * 9 + rz * 81 + 1) : 0ull;
+}
 constexpr MeshTabs make_mesh_tabs() {
   MeshTabs t{};
   int n = 0;
-  for (int i = 0; i < kRV; ++i) {
-    const int rx = i % kR - 1, ry = (i / kR) % kR - 1, rz = i / (kR * kR) - 1;
-    if (rx >= 0 && rx < 8 && ry >= 0 && ry < 8 && rz >= 0 && rz < 8) continue;
-    const int cx = (rx + 8) >> 3, cy = (ry + 8) >> 3, cz = (rz + 8) >> 3;
-    const unsigned long long nb = (unsigned long long)(cx + cy * 3 + cz * 9);
-    const unsigned long long vox = (unsigned long long)(((rx + 8) & 7) + ((ry + 8) & 7) * 8 + ((rz + 8) & 7) * 64);
-    unsigned long long cf = 0;
-    if (rx >= 0 && ry >= 0 && rz >= 0 && rx <= 8 && ry <= 8 && rz <= 8) cf = (unsigned long long)(rx + ry * 9 + rz * 81 + 1);
-    t.halo[n++] = (unsigned long long)i | (nb << 11) | (vox << 16) | (cf << 25);
-  }
+  for (int rz = -1; rz <= 9; ++rz)
+    for (int ry = -1; ry <= 9; ++ry)
+      for (int rx = -1; rx <= 9; ++rx) {
+        if (!halo_needed(rx, ry, rz)) continue;
+        const int vx = (rx + 8) & 7;
+        const bool same_chunk_left = ((rx - 1 + 8) >> 3) == ((rx + 8) >> 3);
+        if ((vx & 1) && halo_needed(rx - 1, ry, rz) && same_chunk_left) continue;  // second member of a pair already emitted
+        // this voxel is the first needed member of its pair: rx0 = region x of the pair's first (even) voxel
+        const int rx0 = (vx & 1) ? rx - 1 : rx;
+        const bool use0 = !(vx & 1);
+        const bool use1 = (vx & 1) ? true : (halo_needed(rx + 1, ry, rz) && (((rx + 1 + 8) >> 3) == ((rx + 8) >> 3)));
+        const int cx = (rx + 8) >> 3, cy = (ry + 8) >> 3, cz = (rz + 8) >> 3;
+        const unsigned long long nb = (unsigned long long)(cx + cy * 3 + cz * 9);
+        const unsigned long long pair = (unsigned long long)((((rx0 + 8) & 7) + ((ry + 8) & 7) * 8 + ((rz + 8) & 7) * 64) >> 1);
+        const unsigned long long r0 = (unsigned long long)((rx0 + 1) + (ry + 1) * kR + (rz + 1) * kR * kR);  // (rx0 = -2 never indexes: use0 is false then)
+        t.halo[n++] = (r0 & 2047ull) | (nb << 11) | (pair << 16) | ((use0 ? 1ull : 0ull) << 24) | ((use1 ? 1ull : 0ull) << 25) |
+                      ((use0 ? corner_of(rx0, ry, rz) : 0ull) << 26) | ((use1 ? corner_of(rx0 + 1, ry, rz) : 0ull) << 36);
+      }
   for (int c = 0; c < 729; ++c) {
     const int px = c % 9, py = (c / 9) % 9, pz = c / 81;
     t.corner[c] = (uint16_t)((px + 1) + (py + 1) * kR + (pz + 1) * kR * kR);
@@ -138,6 +172,7 @@ struct MeshSh {
   uint32_t nv, nt, adj, any;
   uint32_t ncell;             // cells the surface passes through
   uint16_t clist[512];        // ... in no particular order (what is computed per cell is stored per cell)
+  uint32_t f_own, f_maybe, f_fl[4], f_incl[kMeshShards], f_n[kMeshShards];  // fused filter: the entry's pool slot, "the summaries cannot rule it out", class words of the waves
   uint32_t ovf;               // overflow block of the chunk (index + 1, 0 = none): owned before this pass or handed out in it
   uint32_t rstate;            // MeshRec::state as it was before this pass
   unsigned long long rtexloc; // MeshRec::texloc
@@ -441,11 +476,24 @@ __device__ __forceinline__ void mesh_stamp(const VolumeDev& v, uint32_t r, int k
 #ifndef TF_MESH_WAVES
 #define TF_MESH_WAVES 5  // waves per SIMD the 128-thread mesher is compiled for: 5 = 96 VGPRs, ten chunks per CU
 #endif
-template <int NT>  // threads per chunk: 128 (default), or 256
+// FF ("fused filter", the textured per-frame flow): the launch has one workgroup per DIRTY entry and runs the filter's two
+// phases itself -- phase A on eight lanes, the exact test on the chunk's own voxels, which the mesher needs in registers
+// anyway -- and carries on as the mesher when the entry survives; the others leave after 3-5 us and the hardware hands
+// their slot to the next workgroup.  No filter launch, no survivor rows, the own plane read once.
+struct FilterArgs {
+  const int4* dlist;
+  const uint32_t* dslot;
+  const uint32_t* dcount;
+  uint32_t max_entries;
+  int shards_par;
+  uint32_t use_summ;
+  uint32_t* len_hint;
+};
+template <int NT, bool FF>  // threads per chunk: 128 (default), or 256
 __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(VolumeDev v, const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
                                                  uint32_t* __restrict__ cnt_next, uint32_t cap_sh,
                                                  uint32_t epoch, float res, uint32_t simplified, uint32_t dbg,
-                                                 int rearm) {
+                                                 int rearm, FilterArgs fa) {
   __shared__ MeshSh<NT> sh;
   // (LDS per workgroup decides how many chunks a CU holds at once: the triangle table is read from memory -- a few
   // dozen cached 8-byte reads per chunk --, the list of used edge slots is sized by the mesh capacity: dynamic LDS)
@@ -457,8 +505,28 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
   // row b / 32) the busy workgroups reached up to 32 x the LONGEST list; the few beyond the resident capacity started
   // when the first round ended and set the kernel's time (time stamps: last start 18-20 us, last end 34 us of which a
   // chunk takes 20).
-  uint32_t n_rows, excl_l, incl_l;
-  {
+  uint32_t n_rows = 0, excl_l = 0, incl_l = 0;
+  // FF: the dirty set = flat list [0, n_flat) + the shard lists K-A filled; per-lane inclusive scan of their counters
+  uint32_t n_flat = 0;
+  if (FF) {
+    n_flat = *fa.dcount;
+    if (n_flat > fa.max_entries) n_flat = fa.max_entries;
+    uint32_t sh_n = 0, sh_incl = 0;
+    if (fa.shards_par >= 0) {
+      const uint32_t wl_rows = mesh_shard_rows_d(v.max_chunks);
+      if (lane < (int)kMeshShards) { sh_n = v.wl_cnt[((fa.shards_par & 1) * kMeshShards + lane) * 16]; if (sh_n > wl_rows) sh_n = wl_rows; }
+      sh_incl = sh_n;
+#pragma unroll
+      for (int o = 1; o < (int)kMeshShards; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)sh_incl, o);
+        if (lane >= o) sh_incl += u;
+      }
+    }
+    if (t < (int)kMeshShards) { sh.f_incl[t] = sh_incl; sh.f_n[t] = sh_n; }
+    n_rows = n_flat + (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)sh_incl, kMeshShards - 1));
+    if (n_rows > fa.max_entries) n_rows = fa.max_entries;
+    if (fa.len_hint && blockIdx.x == 0 && t == 0) *fa.len_hint = n_rows;
+  } else {
     uint32_t my_n = 0;
     if (lane < (int)kMeshShards) { my_n = cnt[lane * 16]; if (my_n > cap_sh) my_n = cap_sh; }
     uint32_t incl = my_n;
@@ -490,35 +558,134 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     v.wl_cnt[((rearm & 1) * kMeshShards + t) * 16] = 0u;  // ... and the shard lists K-A of the next frame appends its dirty set to
   }
   if (dbg == 9) mesh_stamp(v, blockIdx.x, 0);
+  if (FF) __syncthreads();  // f_incl / f_n
   for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
-    uint32_t shard = incl_l, idx = r - excl_l;
-    if (r != blockIdx.x) {  // a further row of this workgroup (lists longer than the grid): scan again
-      uint32_t my_n = 0;
-      if (lane < (int)kMeshShards) { my_n = cnt[lane * 16]; if (my_n > cap_sh) my_n = cap_sh; }
-      uint32_t incl = my_n;
-#pragma unroll
-      for (int o = 1; o < (int)kMeshShards; o <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
-        if (lane >= o) incl += u;
-      }
-      shard = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(lane < (int)kMeshShards && incl <= r)));
-      idx = r - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, (int)(shard & 31u)) - __shfl((int)my_n, (int)(shard & 31u)));
-    }
-    const size_t row = (size_t)shard * cap_sh + idx;
-    const uint32_t own = surv[32 * row + 13];    // the chunk's pool slot
-    const int4 id = make_int4((int)surv[32 * row + 27], (int)surv[32 * row + 28], (int)surv[32 * row + 29], 0);
-    MeshRec* rec = &v.mesh_rec[own];
+    uint32_t shard, own;
+    int4 id;
     float2 a[512 / NT];
+    if constexpr (!FF) {
+      shard = incl_l;
+      uint32_t idx = r - excl_l;
+      if (r != blockIdx.x) {  // a further row of this workgroup (lists longer than the grid): scan again
+        uint32_t my_n = 0;
+        if (lane < (int)kMeshShards) { my_n = cnt[lane * 16]; if (my_n > cap_sh) my_n = cap_sh; }
+        uint32_t incl = my_n;
 #pragma unroll
-    for (int j = 0; j < 512 / NT; ++j) a[j] = v.tsdf[(size_t)own * kChunkVoxels + j * NT + t];
+        for (int o = 1; o < (int)kMeshShards; o <<= 1) {
+          const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
+          if (lane >= o) incl += u;
+        }
+        shard = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(lane < (int)kMeshShards && incl <= r)));
+        idx = r - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, (int)(shard & 31u)) - __shfl((int)my_n, (int)(shard & 31u)));
+      }
+      const size_t row = (size_t)shard * cap_sh + idx;
+      own = surv[32 * row + 13];    // the chunk's pool slot
+      id = make_int4((int)surv[32 * row + 27], (int)surv[32 * row + 28], (int)surv[32 * row + 29], 0);
+#pragma unroll
+      for (int j = 0; j < 512 / NT; ++j) a[j] = v.tsdf[(size_t)own * kChunkVoxels + j * NT + t];
+      __syncthreads();  // the previous chunk of this workgroup is done with the shared tables
+      if (t < 27) sh.nslot[t] = surv[32 * row + t];
+    } else {
+      // ---- the entry (flat list, then row r - n_flat of the concatenated shard lists)
+      uint32_t own_listed = kInvalidSlot;
+      if (r < n_flat) {
+        id = fa.dlist[r];
+        if (fa.dslot) own_listed = fa.dslot[r];
+      } else {
+        const uint32_t rr = r - n_flat;
+        const uint32_t wl_rows = mesh_shard_rows_d(v.max_chunks);
+        const uint32_t shd = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(lane < (int)kMeshShards && sh.f_incl[lane & 31] <= rr))) & 31u;
+        const size_t at = ((size_t)(fa.shards_par & 1) * kMeshShards + shd) * wl_rows + (rr - (sh.f_incl[shd] - sh.f_n[shd]));
+        id = v.wl_ids[at];
+        own_listed = v.wl_slot[at];
+      }
+      __syncthreads();  // the previous entry of this workgroup is done with the shared tables
+      // ---- phase A (k_mesh_filter's, on eight lanes): the chunk and its seven +x / +y / +z neighbours, their class summaries
+      if (w == 0) {
+        uint32_t own_ = kInvalidSlot, near8 = kInvalidSlot;
+        bool maybe_ = false;
+        if (lane < 27) sh.nslot[lane] = kInvalidSlot;
+        if (lane < 8) near8 = filter_near(v, id, lane, lane, fa.dslot != nullptr || r >= n_flat, own_listed, fa.use_summ != 0, &own_, &maybe_);
+        if (lane < 8) sh.nslot[13 + (lane & 1) + 3 * ((lane >> 1) & 1) + 9 * (lane >> 2)] = near8;  // (same wave: behind the reset above)
+        if (lane == 0) { sh.f_own = own_; sh.f_maybe = maybe_ ? 1u : 0u; }
+      }
+      __syncthreads();
+      own = sh.f_own;
+      if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
+      if (!sh.f_maybe) {
+        if (t == 0) filter_reset_record(v, own, id, epoch, rearm >= 0 ? (rearm ^ 1) : -1);
+        continue;
+      }
+      shard = own & (kMeshShards - 1u);
+      // ---- the exact test on the chunk's own voxels (they stay in registers for the staging pass); meanwhile the other
+      // 19 chunks of the neighbourhood are looked up (only a survivor needs them, but the probes are free here)
+#pragma unroll
+      for (int j = 0; j < 512 / NT; ++j) a[j] = v.tsdf[(size_t)own * kChunkVoxels + j * NT + t];
+      if (w == NT / 64 - 1 && lane < 27) {
+        const bool is_near = (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
+        if (!is_near) {
+          const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
+          if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) sh.nslot[lane] = v.hent[ent].slot;
+        }
+      }
+      uint32_t fl = 0;
+#pragma unroll
+      for (int j = 0; j < 512 / NT; ++j) fl |= chunk_summary_bits(a[j].x, a[j].y, (uint32_t)(j * NT + t));
+      fl = wave_or(fl);
+      if (lane == 0) sh.f_fl[w] = fl;
+      __syncthreads();
+      fl = 0;
+#pragma unroll
+      for (int k = 0; k < NT / 64; ++k) fl |= sh.f_fl[k];
+      if (t == 0) {
+        if (fa.use_summ) v.summ[own] = fl;            // the chunk's summary is exact again
+        atomicAdd(&cnt[shard * 16 + 1], 1u);          // statistic (tf_texture_stats::n_exact)
+      }
+      bool empty = !(fl & 1u);
+      if (!empty && (fl & 14u) != 14u) {  // undecided: the 217 corner voxels the +x / +y / +z neighbours contribute
+        uint32_t f2 = 0;
+        for (int q = t; q < 217; q += NT) {
+          int cx = 0, cy = 0, cz = 0;
+          if (q < 64) { cx = 8; cy = q & 7; cz = q >> 3; }
+          else if (q < 128) { cx = q & 7; cy = 8; cz = (q >> 3) & 7; }
+          else if (q < 192) { cx = q & 7; cy = (q >> 3) & 7; cz = 8; }
+          else if (q < 200) { cx = 8; cy = 8; cz = q & 7; }
+          else if (q < 208) { cx = 8; cy = q & 7; cz = 8; }
+          else if (q < 216) { cx = q & 7; cy = 8; cz = 8; }
+          else { cx = 8; cy = 8; cz = 8; }
+          const uint32_t sl = sh.nslot[13 + (cx >> 3) + 3 * (cy >> 3) + 9 * (cz >> 3)];
+          if (sl != kInvalidSlot) {
+            const float2 val = v.tsdf[(size_t)sl * kChunkVoxels + (cx & 7) + (cy & 7) * 8 + (cz & 7) * 64];
+            f2 |= classify_voxel(val.x, val.y);
+          }
+        }
+        f2 = wave_or(f2);
+        __syncthreads();  // (f_fl was read by every thread above)
+        if (lane == 0) sh.f_fl[w] = f2;
+        __syncthreads();
+        f2 = 0;
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) f2 |= sh.f_fl[k];
+        empty = ((fl | f2) & 14u) != 14u;
+      }
+      if (empty) {
+        if (t == 0) filter_reset_record(v, own, id, epoch, rearm >= 0 ? (rearm ^ 1) : -1);
+        continue;
+      }
+      if (t == 0) atomicAdd(&cnt[shard * 16], 1u);    // statistic (n_survivors)
+    }
+    // (FF: what the mesher derives from the thread index must not be computed ahead of the filter -- it would sit in
+    // registers, or in private memory, across it: the index is re-read behind an opaque statement)
+    int t_ = threadIdx.x;
+    if (FF) asm volatile("" : "+v"(t_));
+    const int t = t_, lane = t & 63, w = t >> 6;
+    MeshRec* rec = &v.mesh_rec[own];
     // the thread's entries of the halo table travel with the own voxels: the staging pass below is then ONE hop of
     // scattered loads instead of table -> voxel
     unsigned long long htab[(kHalo + NT - 1) / NT];
 #pragma unroll
     for (int j = 0; j < (kHalo + NT - 1) / NT; ++j) htab[j] = (j * NT + t < kHalo) ? d_mesh_tabs.halo[j * NT + t] : ~0ull;
-    __syncthreads();  // the previous chunk of this workgroup is done with the shared tables
     if (dbg == 9) mesh_stamp(v, r, 1);
-    if (t < 27) sh.nslot[t] = surv[32 * row + t];
     if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; sh.ncell = 0; }
     // the record's previous state travels with the first batch of loads, so that the tail of the chunk is stores only
     if (t == NT - 64) { sh.rstate = rec->state; sh.rtexloc = rec->texloc; }
@@ -538,11 +705,19 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
       const unsigned long long e = htab[j];
       if (e == ~0ull) continue;
       const uint32_t s = sh.nslot[(uint32_t)(e >> 11) & 31u];
-      float2 val = make_float2(999.0f, 0.0f);
-      if (s != kInvalidSlot) val = v.tsdf[(size_t)s * kChunkVoxels + ((uint32_t)(e >> 16) & 511u)];
-      sh.S[(uint32_t)e & 2047u] = val.x;
-      const uint32_t cf = (uint32_t)(e >> 25) & 1023u;
-      if (cf) sh.cflag[cf - 1u] = (val.y > 50.0f) ? kCfHeavy : 0u;
+      float4 val = make_float4(999.0f, 0.0f, 999.0f, 0.0f);  // a missing chunk reads as the fresh state
+      if (s != kInvalidSlot) val = reinterpret_cast<const float4*>(v.tsdf + (size_t)s * kChunkVoxels)[(uint32_t)(e >> 16) & 255u];
+      const uint32_t r0 = (uint32_t)e & 2047u;
+      if ((e >> 24) & 1ull) {
+        sh.S[r0] = val.x;
+        const uint32_t cf = (uint32_t)(e >> 26) & 1023u;
+        if (cf) sh.cflag[cf - 1u] = (val.y > 50.0f) ? kCfHeavy : 0u;
+      }
+      if ((e >> 25) & 1ull) {
+        sh.S[r0 + 1u] = val.z;
+        const uint32_t cf = (uint32_t)(e >> 36) & 1023u;
+        if (cf) sh.cflag[cf - 1u] = (val.w > 50.0f) ? kCfHeavy : 0u;
+      }
     }
     __syncthreads();
     if (dbg == 9) mesh_stamp(v, r, 3);
@@ -856,7 +1031,7 @@ static int mesh_resident_blocks() {
 uint32_t mesh_shard_rows(uint32_t max_chunks) { return max_chunks / kMeshShards + 258u; }
 
 static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries, uint32_t epoch, float res, bool fused,
-                          int rearm_set, hipStream_t s) {
+                          int rearm_set, const FilterArgs* ff, uint32_t ff_grid, hipStream_t s) {
   static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch
   uint32_t* surv = v.mesh_nbr;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
@@ -871,12 +1046,16 @@ static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries,
   // 128 threads per chunk: with 15.8 KB of LDS and 94 VGPRs ten chunks are resident per CU (six with 256 threads at 80
   // VGPRs).  Same time on the room stream, 8 % less on the 1280x960 hall (TF_MESH_THREADS=256 for the other form).
   static const int nt = getenv("TF_MESH_THREADS") ? atoi(getenv("TF_MESH_THREADS")) : 128;
-  if (nt == 256)
-    hipLaunchKernelGGL(k_mesh<256>, dim3(grid), dim3(256), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
-                       fused ? kMsSimplified : 0u, dbg, rearm_set);
+  const FilterArgs none{};
+  if (ff)
+    hipLaunchKernelGGL((k_mesh<128, true>), dim3(ff_grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh,
+                       epoch, res, fused ? kMsSimplified : 0u, dbg, rearm_set, *ff);
+  else if (nt == 256)
+    hipLaunchKernelGGL((k_mesh<256, false>), dim3(grid), dim3(256), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
+                       fused ? kMsSimplified : 0u, dbg, rearm_set, none);
   else
-    hipLaunchKernelGGL(k_mesh<128>, dim3(grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
-                       fused ? kMsSimplified : 0u, dbg, rearm_set);
+    hipLaunchKernelGGL((k_mesh<128, false>), dim3(grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
+                       fused ? kMsSimplified : 0u, dbg, rearm_set, none);
 }
 
 static bool filter_uses_summaries() {
@@ -895,13 +1074,25 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   const uint32_t fgrid = (max_entries + 3) / 4 < 2560u ? (max_entries + 3) / 4 : 2560u;
   const uint32_t* dslot = fused ? v.work_slot : nullptr;
   const int ppar = fused ? (rearm_set ^ 1) : -1;
+  // TF_MESH_FUSED=1: the mesher runs the filter itself, one workgroup per entry of a short list (k_mesh<128, true>).
+  // Measured on the room stream (profiles/r3/README.md): the pair of launches 48.9 us, the fused form 54.2 us -- 6.5 k
+  // workgroups that hold a mesher's registers and LDS through phase A's dependent loads keep the ~900 survivors out of
+  // the first resident round, which costs more than the launch boundary and the 3.6 MB of re-read voxels saved.
+  static const int mesh_fused = getenv("TF_MESH_FUSED") ? atoi(getenv("TF_MESH_FUSED")) : 0;
+  if (mesh_fused && len_guess <= 10000u) {
+    const FilterArgs fa{dlist, dslot, dcount, max_entries, shards_par, filter_uses_summaries() ? 1u : 0u, len_hint};
+    uint32_t g = len_guess + len_guess / 8u + 256u;  // the list of the frame before + slack; a longer list strides
+    if (g > max_entries) g = max_entries;
+    launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, &fa, g, s);
+    return;
+  }
   if (len_guess <= fgrid * 4u)
     hipLaunchKernelGGL(k_mesh_filter<true>, dim3(fgrid), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, epoch,
                        v.mesh_nbr, cnt, cap_sh, ppar, filter_uses_summaries(), len_hint, shards_par);
   else
     hipLaunchKernelGGL(k_mesh_filter<false>, dim3(fgrid), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, epoch,
                        v.mesh_nbr, cnt, cap_sh, ppar, filter_uses_summaries(), len_hint, shards_par);
-  launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, s);
+  launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, nullptr, 0, s);
 }
 
 // ---------------------------------------------------------------------------------------
