@@ -482,7 +482,7 @@ def roofline(args, vol, cam, prof, kinds, K, first, n_unique, d_depth, d_rgba, p
     Bytes = what the DEVICE algorithm has to move: voxel update 128 B per rewritten
     TSDF row + 128 B per rewritten colour row + one read of the depth and RGBA images; meshing 32 B of class summaries
     per dirty chunk (its own and its seven +x/+y/+z neighbours' words) + 4 KiB (the chunk's own sdf/weight plane) per
-    chunk the summaries cannot rule out + 6552 B (the 11^3 - 8^3 halo voxels) per chunk handed to marching cubes + 8 B
+    chunk the summaries cannot rule out + 6552 B (the 11^3 - 8^3 halo voxels) per chunk the surface passes through + 8 B
     colour read and 36 B written per vertex + 6 B per triangle; atlas 44 B per projected vertex (24 read, 20 written)
     + 3 B read and 3 B written per ROI pixel.  The integer counts are read back frame by frame in an untimed replay of
     the timed window's orbit positions (steady state: the same work as the timed frames one turn earlier).
@@ -491,7 +491,7 @@ def roofline(args, vol, cam, prof, kinds, K, first, n_unique, d_depth, d_rgba, p
     pass ran (the same command, the same frames); otherwise the HIP-event times of the event pass minus the calibrated
     cost of an event pair around an empty launch."""
     b_tsdf = b_mesh = b_atlas = 0
-    cnt = dict(sel=0, upd=0, dirty=0, exact=0, survivors=0, meshes=0, verts=0, tris=0, roi=0, patches=0)
+    cnt = dict(sel=0, upd=0, dirty=0, exact=0, survivors=0, surface=0, meshes=0, verts=0, tris=0, roi=0, patches=0)
     for j in range(K):
         sub = [(first + j + q) % n_unique for q in range(3)]
         dd = [d_depth[q].data_ptr() for q in sub]
@@ -506,9 +506,10 @@ def roofline(args, vol, cam, prof, kinds, K, first, n_unique, d_depth, d_rgba, p
         cnt["upd"] += st.n_updated
         if textured:
             ts = vol.texture_stats()
-            b_mesh += 32 * ts.n_dirty + 4096 * ts.n_exact + 6552 * ts.n_survivors + 44 * ts.n_vertices + 6 * ts.n_triangles
+            b_mesh += 32 * ts.n_dirty + 4096 * ts.n_exact + 6552 * ts.n_surface + 44 * ts.n_vertices + 6 * ts.n_triangles
             b_atlas += 44 * ts.n_vertices + 6 * ts.roi_pixels
-            for k, v in (("dirty", ts.n_dirty), ("exact", ts.n_exact), ("survivors", ts.n_survivors), ("meshes", ts.n_meshes),
+            for k, v in (("dirty", ts.n_dirty), ("exact", ts.n_exact), ("survivors", ts.n_survivors), ("surface", ts.n_surface),
+                         ("meshes", ts.n_meshes),
                          ("verts", ts.n_vertices), ("tris", ts.n_triangles), ("roi", ts.roi_pixels), ("patches", ts.n_patches)):
                 cnt[k] += v
     # event pass: per kind, raw and with the empty-pair cost taken off every launch

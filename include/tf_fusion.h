@@ -93,8 +93,9 @@ typedef struct {
   int64_t roi_pixels;   /* sum of the patches' bounding-box areas */
   int64_t n_patches;    /* patches with an image */
   int64_t n_slots;      /* atlas slots handed out so far */
-  int64_t n_exact;      /* dirty chunks whose own voxels the mesher's filter read (the class summaries ruled out the rest) */
+  int64_t n_exact;      /* dirty chunks whose own voxels were read for the "can it have a vertex" test (the class summaries ruled out the rest) */
   int64_t n_survivors;  /* of those, chunks handed to the marching-cubes kernel */
+  int64_t n_surface;    /* of those, chunks in which marching cubes found a cell the surface passes through */
 } tf_texture_stats;
 
 /* Per-kernel timings collected with HIP events on the handle's stream (tf_profile_*). */

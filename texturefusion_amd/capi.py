@@ -73,7 +73,8 @@ class Stats(C.Structure):
 class TextureStats(C.Structure):
     _fields_ = [("n_dirty", C.c_int64), ("n_meshes", C.c_int64), ("n_vertices", C.c_int64),
                 ("n_triangles", C.c_int64), ("roi_pixels", C.c_int64), ("n_patches", C.c_int64),
-                ("n_slots", C.c_int64), ("n_exact", C.c_int64), ("n_survivors", C.c_int64)]
+                ("n_slots", C.c_int64), ("n_exact", C.c_int64), ("n_survivors", C.c_int64),
+                ("n_surface", C.c_int64)]
 
 
 class UnitFrame(C.Structure):

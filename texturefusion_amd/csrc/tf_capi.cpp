@@ -344,7 +344,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     }
   }
   if ((rc = dev_alloc(v, &d.mesh_nbr, (size_t)kMeshShards * mesh_shard_rows(d.max_chunks) * 32))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.mesh_cnt, (size_t)2 * kMeshShards * 16))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.mesh_cnt, (size_t)2 * kMeshCntWords))) return fail(rc);
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
     SelBuf& L = v->selbuf[k];
     if ((rc = dev_alloc(v, &L.masks, (size_t)d.max_coarse))) return fail(rc);
@@ -1178,11 +1178,13 @@ int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {
   TF_HIP(hipMemcpyAsync(r, v->d_tmp, 48, hipMemcpyDeviceToHost, v->stream));
   AtlasCtl c;
   TF_HIP(hipMemcpyAsync(&c, v->dev.actl, sizeof(c), hipMemcpyDeviceToHost, v->stream));
-  uint32_t mc[kMeshShards * 16];  // the per-shard counters of the last mesher launch: [0] survivors, [1] exact tests
-  TF_HIP(hipMemcpyAsync(mc, v->dev.mesh_cnt + (size_t)((v->mesh_par & 1) ^ 1) * kMeshShards * 16, sizeof(mc),
+  uint32_t mc[kMeshCntWords];  // the counters of the last mesher launch: rows per shard | {exact tests, rows with a surface cell} per shard
+  TF_HIP(hipMemcpyAsync(mc, v->dev.mesh_cnt + (size_t)((v->mesh_par & 1) ^ 1) * kMeshCntWords, sizeof(mc),
                         hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
-  for (uint32_t k = 0; k < kMeshShards; ++k) { out->n_survivors += mc[k * 16]; out->n_exact += mc[k * 16 + 1]; }
+  for (uint32_t k = 0; k < kMeshShards; ++k) {
+    out->n_survivors += mc[k * 16]; out->n_exact += mc[(kMeshShards + k) * 16]; out->n_surface += mc[(kMeshShards + k) * 16 + 1];
+  }
   out->n_dirty = (int64_t)r[0]; out->n_meshes = (int64_t)r[1]; out->n_vertices = (int64_t)r[2];
   out->n_triangles = (int64_t)r[3]; out->roi_pixels = (int64_t)r[4]; out->n_patches = (int64_t)r[5];
   out->n_slots = (int64_t)c.n_slots;

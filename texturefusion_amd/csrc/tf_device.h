@@ -175,6 +175,7 @@ struct AtlasCtl {
 };
 
 constexpr uint32_t kMeshShards = 32;  // survivor rows are appended shard by shard: 32 counters instead of one
+constexpr uint32_t kMeshCntWords = kMeshShards * 32;  // VolumeDev::mesh_cnt per launch parity: row counters, then statistics
 constexpr int kPhaseWaves = 16384;  // rows of the wave-timeline table (tuning aid)
 
 struct VolumeDev {
@@ -216,7 +217,11 @@ struct VolumeDev {
   uint32_t ovf_blocks;  // blocks of the pool; VolCtl::ovf_next = blocks handed out
   uint32_t* mesh_nbr;  // [kMeshShards][mesh_shard_rows(max_chunks)][32] mesher scratch, one row per SURVIVING work entry
                        // (k_mesh_filter): pool slots of its 27-chunk neighbourhood, [27] = the entry's list index
-  uint32_t* mesh_cnt;  // [2][kMeshShards][16] rows used per shard (one counter per 64-B line), double-buffered by launch parity
+  // [2][kMeshCntWords], double-buffered by launch parity: [shard][16] rows used per shard (one counter per 64-B line), then
+  // [shard][16] statistics {exact tests, rows with a surface cell} -- in lines of their own: every workgroup of the mesher
+  // reads the row counters at its start, and atomics landing in those lines during the launch delayed that read (mesher
+  // 36 -> 49 us with two statistics atomics per chunk next to the row counter)
+  uint32_t* mesh_cnt;
   // atlas (Structure/Atlas.h:43-75): u8 [atlas_h][atlas_w][3], slots of patch_w x patch_h texels
   uint8_t* atlas;
   int32_t atlas_w, atlas_h, patch_w, patch_h;

@@ -271,12 +271,30 @@ __device__ __forceinline__ uint32_t filter_near(const VolumeDev& v, const int4 i
 // (only a survivor's row needs them).  A survivor gets a row of its shard for the mesher's staging.
 __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, uint32_t nslot, int lane,
                                              uint32_t epoch, uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
-                                             uint32_t cap_sh, int ppar, bool use_summ) {
+                                             uint32_t cap_sh, int ppar, bool use_summ, bool exact) {
   const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
   const uint32_t own = (uint32_t)__shfl((int)nslot, 13);
   // rows and patch entries go to shard own % 32: pool slots are unique, so a shard never holds more than
   // max_chunks / 32 of them whatever the order of the work
   const uint32_t shard = own & (kMeshShards - 1u);
+  if (!exact) {
+    // TF_FILTER_EXACT=0 (wave form only): no voxel is read here.  Every chunk the summaries cannot rule out gets a row;
+    // the mesher rewrites the summary from the own voxels it loads anyway (launch_mesh has the numbers)
+    if (lane < 27 && !is_near) {
+      const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
+      if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
+    }
+    uint32_t p = 0;
+    if (lane == 0) p = atomicAdd(&cnt[shard * 16], 1u);
+    p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+    if (p >= cap_sh) {
+      if (lane == 0) atomicOr(&v.vctl->status, kStMeshFull);
+      return;
+    }
+    if (lane >= 27 && lane < 30) nslot = (uint32_t)(lane == 27 ? id.x : (lane == 28 ? id.y : id.z));
+    if (lane < 30) surv[32 * ((size_t)shard * cap_sh + p) + lane] = nslot;
+    return;
+  }
   const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
   float4 qv[4];
 #pragma unroll
@@ -295,7 +313,7 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
   }
   fl = wave_or(fl);
   if (use_summ && lane == 0) v.summ[own] = fl;  // the chunk's summary is exact again
-  if (lane == 0) atomicAdd(&cnt[shard * 16 + 1], 1u);  // statistic (tf_texture_stats::n_exact): chunks whose voxels the filter read
+  if (lane == 0) atomicAdd(&cnt[(kMeshShards + shard) * 16], 1u);  // statistic (tf_texture_stats::n_exact): chunks whose voxels the filter read
   bool empty = !(fl & 1u);
   if (!empty && (fl & 14u) != 14u) {
     uint32_t f2 = 0;
@@ -355,7 +373,7 @@ __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDe
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
                                                      uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool use_summ,
-                                                     uint32_t* __restrict__ len_hint, int shards_par) {
+                                                     uint32_t* __restrict__ len_hint, int shards_par, bool exact) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
   uint32_t n_flat = *dcount;
@@ -406,7 +424,7 @@ __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDe
         continue;
       }
       const uint32_t got = (uint32_t)__shfl((int)near8, is_near ? near_k(lane) : 0);
-      filter_exact(v, id, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ);
+      filter_exact(v, id, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ, exact);
     }
     return;
   }
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDe
     const uint32_t nm = s_n;
     for (uint32_t m = (uint32_t)w; m < nm; m += 4u)
       filter_exact(v, s_id[m], is_near ? s_near[m][near_k(lane)] : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar,
-                   use_summ);
+                   use_summ, true);
     __syncthreads();  // the parked entries are consumed before the next batch overwrites them
   }
 }
@@ -488,6 +506,7 @@ struct FilterArgs {
   int shards_par;
   uint32_t use_summ;
   uint32_t* len_hint;
+  uint32_t refresh_summ;  // two-launch form: the filter did not read the voxels, the mesher makes the summary exact
 };
 template <int NT, bool FF>  // threads per chunk: 128 (default), or 256
 __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(VolumeDev v, const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
@@ -543,7 +562,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     excl_l = incl_l - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)my_n, (int)(sh0 & 31u)));
     incl_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh0);  // (reused: the shard of the first row)
   }
-  if (blockIdx.x == 0 && t < (int)kMeshShards) { cnt_next[t * 16] = 0u; cnt_next[t * 16 + 1] = 0u; }  // the counters of the NEXT launch's filter
+  if (blockIdx.x == 0 && t < (int)kMeshShards) { cnt_next[t * 16] = 0u; cnt_next[(kMeshShards + t) * 16] = 0u; cnt_next[(kMeshShards + t) * 16 + 1] = 0u; }  // the counters of the NEXT launch's filter
   const float half = res * 0.5f;
   if (rearm >= 0 && blockIdx.x == 0 && t == 0) {
     // fused flow: the patches of the previous frame are done (the main stream waited for them ahead of this
@@ -639,7 +658,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
       for (int k = 0; k < NT / 64; ++k) fl |= sh.f_fl[k];
       if (t == 0) {
         if (fa.use_summ) v.summ[own] = fl;            // the chunk's summary is exact again
-        atomicAdd(&cnt[shard * 16 + 1], 1u);          // statistic (tf_texture_stats::n_exact)
+        atomicAdd(&cnt[(kMeshShards + shard) * 16], 1u);          // statistic (tf_texture_stats::n_exact)
       }
       bool empty = !(fl & 1u);
       if (!empty && (fl & 14u) != 14u) {  // undecided: the 217 corner voxels the +x / +y / +z neighbours contribute
@@ -677,7 +696,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     // (FF: what the mesher derives from the thread index must not be computed ahead of the filter -- it would sit in
     // registers, or in private memory, across it: the index is re-read behind an opaque statement)
     int t_ = threadIdx.x;
-    if (FF) asm volatile("" : "+v"(t_));
+    asm volatile("" : "+v"(t_));
     const int t = t_, lane = t & 63, w = t >> 6;
     MeshRec* rec = &v.mesh_rec[own];
     // the thread's entries of the halo table travel with the own voxels: the staging pass below is then ONE hop of
@@ -691,13 +710,26 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     if (t == NT - 64) { sh.rstate = rec->state; sh.rtexloc = rec->texloc; }
     if (dbg == 1) continue;  // triage: filter only
     // ---- stage the 11^3 voxels of the neighbourhood (own ones from registers)
+    uint32_t sfl = 0;
 #pragma unroll
     for (int j = 0; j < 512 / NT; ++j) {
       const int q = j * NT + t;
       const int x0 = q & 7, y0 = (q >> 3) & 7, z0 = q >> 6;
       sh.S[ridx(x0, y0, z0)] = a[j].x; sh.cflag[x0 + y0 * 9 + z0 * 81] = (a[j].y > 50.0f) ? kCfHeavy : 0u;
+      if (!FF) sfl |= chunk_summary_bits(a[j].x, a[j].y, (uint32_t)q);
+    }
+    if (!FF && fa.refresh_summ) {  // the chunk's class summary, exact again (what the filter's exact test used to do)
+      sfl = wave_or(sfl);
+      if (lane == 0) sh.f_fl[w] = sfl;
     }
     __syncthreads();
+    if (!FF && fa.refresh_summ && t == NT - 1) {
+      uint32_t fl = 0;
+#pragma unroll
+      for (int k = 0; k < NT / 64; ++k) fl |= sh.f_fl[k];
+      v.summ[own] = fl;
+      atomicAdd(&cnt[(kMeshShards + shard) * 16], 1u);  // statistic (n_exact): the chunk's voxels were read for the test -- here
+    }
     // (measured: issuing the row, the table entries and then own + halo voxels as two batches of loads -- two
     // dependent hops instead of four -- is slower, 36 -> 46 us: the extra registers spill)
 #pragma unroll
@@ -763,6 +795,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
         sh.clist[atomicAdd(&sh.ncell, 1u)] = (uint16_t)cell;
     }
     __syncthreads();
+    if (t == 0 && sh.ncell) atomicAdd(&cnt[(kMeshShards + shard) * 16 + 1], 1u);  // statistic (tf_texture_stats::n_surface)
     // 1b (loops stay rolled and re-read LDS instead of keeping more in registers: occupancy matters more)
     for (uint32_t ci = t; ci < sh.ncell; ci += NT) {
       const int cell = sh.clist[ci];
@@ -1013,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_init_mesh_rec(MeshRec* rec, uint32_t n)
 }
 void launch_init_meshes(const VolumeDev& v, hipStream_t s) {
   hipLaunchKernelGGL(k_init_mesh_rec, dim3(1024), dim3(256), 0, s, v.mesh_rec, v.max_chunks);
-  (void)hipMemsetAsync(v.mesh_cnt, 0, sizeof(uint32_t) * 2 * kMeshShards * 16, s);
+  (void)hipMemsetAsync(v.mesh_cnt, 0, sizeof(uint32_t) * 2 * kMeshCntWords, s);
 }
 
 static int mesh_resident_blocks() {
@@ -1031,11 +1064,11 @@ static int mesh_resident_blocks() {
 uint32_t mesh_shard_rows(uint32_t max_chunks) { return max_chunks / kMeshShards + 258u; }
 
 static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries, uint32_t epoch, float res, bool fused,
-                          int rearm_set, const FilterArgs* ff, uint32_t ff_grid, hipStream_t s) {
+                          int rearm_set, const FilterArgs* ff, uint32_t ff_grid, bool refresh_summ, hipStream_t s) {
   static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch
   uint32_t* surv = v.mesh_nbr;
-  uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
-  uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshShards * 16;
+  uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshCntWords;
+  uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshCntWords;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
   // the survivors form dense per-shard lists: a grid of a few resident rounds, each workgroup striding its shard
   // (TF_MESH_GRID overrides; rounded to a multiple of the shard count)
@@ -1046,7 +1079,8 @@ static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries,
   // 128 threads per chunk: with 15.8 KB of LDS and 94 VGPRs ten chunks are resident per CU (six with 256 threads at 80
   // VGPRs).  Same time on the room stream, 8 % less on the 1280x960 hall (TF_MESH_THREADS=256 for the other form).
   static const int nt = getenv("TF_MESH_THREADS") ? atoi(getenv("TF_MESH_THREADS")) : 128;
-  const FilterArgs none{};
+  FilterArgs none{};
+  none.refresh_summ = refresh_summ ? 1u : 0u;
   if (ff)
     hipLaunchKernelGGL((k_mesh<128, true>), dim3(ff_grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh,
                        epoch, res, fused ? kMsSimplified : 0u, dbg, rearm_set, *ff);
@@ -1067,7 +1101,7 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
                  uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, int shards_par,
                  hipStream_t s) {
   if (!max_entries) return;
-  uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshShards * 16;
+  uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshCntWords;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
   if (max_entries > v.max_chunks) max_entries = v.max_chunks;
   // 2560 workgroups = 1.25 x the wave form's resident capacity: a list of up to 10 k entries runs one entry per wave
@@ -1080,19 +1114,27 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   // the first resident round, which costs more than the launch boundary and the 3.6 MB of re-read voxels saved.
   static const int mesh_fused = getenv("TF_MESH_FUSED") ? atoi(getenv("TF_MESH_FUSED")) : 0;
   if (mesh_fused && len_guess <= 10000u) {
-    const FilterArgs fa{dlist, dslot, dcount, max_entries, shards_par, filter_uses_summaries() ? 1u : 0u, len_hint};
+    const FilterArgs fa{dlist, dslot, dcount, max_entries, shards_par, filter_uses_summaries() ? 1u : 0u, len_hint, 0u};
     uint32_t g = len_guess + len_guess / 8u + 256u;  // the list of the frame before + slack; a longer list strides
     if (g > max_entries) g = max_entries;
-    launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, &fa, g, s);
+    launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, &fa, g, false, s);
     return;
   }
-  if (len_guess <= fgrid * 4u)
+  // TF_FILTER_EXACT=0: the wave form leaves the exact test to the mesher (which finds no surface cell in the ~20 % the
+  // test would have caught, and rewrites the summary from the own voxels it loads anyway).  Measured on the room stream
+  // (profiles/r3/README.md): filter 14.3 -> 11.1 us, mesher 33.0 -> 37.5 us (3619 chunks instead of 2929 against 2560
+  // resident workgroups) -- no gain, so the filter keeps the test.
+  static const bool wave_exact = !(getenv("TF_FILTER_EXACT") && !atoi(getenv("TF_FILTER_EXACT")));
+  const bool use_summ = filter_uses_summaries();
+  const bool wave_form = len_guess <= fgrid * 4u;
+  const bool exact = !wave_form || wave_exact || !use_summ;
+  if (wave_form)
     hipLaunchKernelGGL(k_mesh_filter<true>, dim3(fgrid), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, epoch,
-                       v.mesh_nbr, cnt, cap_sh, ppar, filter_uses_summaries(), len_hint, shards_par);
+                       v.mesh_nbr, cnt, cap_sh, ppar, use_summ, len_hint, shards_par, exact);
   else
     hipLaunchKernelGGL(k_mesh_filter<false>, dim3(fgrid), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, epoch,
-                       v.mesh_nbr, cnt, cap_sh, ppar, filter_uses_summaries(), len_hint, shards_par);
-  launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, nullptr, 0, s);
+                       v.mesh_nbr, cnt, cap_sh, ppar, use_summ, len_hint, shards_par, true);
+  launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, nullptr, 0, !exact, s);
 }
 
 // ---------------------------------------------------------------------------------------
