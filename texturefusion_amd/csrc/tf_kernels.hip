@@ -1488,7 +1488,10 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
     a.patch_par = patch->par;
     a.kf_patch = patch->kf;
   }
-  static const int nsel = env_int("TF_SEL_BLOCKS", 512);
+  // workgroups of the selection role (run 24, profiles/r3/README.md): 256 where K-A is dispatched first and the role fills
+  // its tail (TSDF-only 27.5 us at 256 and 512, 30.8 at 128; hall 225 / 237 / 232 us); 128 where the patch and selection
+  // ranges go first and every wave they hold delays a K-A wave (textured room: k_frame 42.2 us at 512, 40.8 at 256, 39.8 at 128)
+  static const int nsel_env = env_int("TF_SEL_BLOCKS", 0);
   a.kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);
   static const int dbg = env_int("TF_KA_DBG", 0);
   a.kc.dbg = (uint32_t)dbg;
@@ -1507,7 +1510,7 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
     a.sel1 = next->sel;
     a.depth1 = next->img.depth;
     a.sc1 = make_select_consts(next->pose.p, res);
-    a.n_sel = (uint32_t)nsel;
+    a.n_sel = 1u;  // (sized below, once the dispatch order is known)
   }
   if (next2) {
     a.ctl2 = next2->sel.ctl;
@@ -1518,15 +1521,16 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
     static const int nbb = env_int("TF_BBOX_BLOCKS", 128);
     a.n_bbox = (uint32_t)(blocks > nbb ? nbb : blocks);
   }
+  static const int sel_first = env_int("TF_SEL_FIRST", -1);  // tuning knob: 1 = the other roles ahead of K-A, 0 = K-A first
+  // (a hall-sized frame -- K-A waves with ten chunks each -- wants K-A first: the other ranges then fill its tail)
+  const bool others_first = sel_first >= 0 ? sel_first != 0 : (with_patch && cur->small_frame);
+  if (a.n_sel) a.n_sel = (uint32_t)(nsel_env > 0 ? nsel_env : (others_first ? 128 : 256));
   const uint32_t total = a.n_ka + a.n_patch + a.n_sel + a.n_bbox;
   if (!total) return;
   if ((a.kc.dbg & 4096u) && a.n_sel && a.n_bbox) a.kc.dbg |= 8192u;  // timeline stamps: steady launches only
   // Dispatch order.  K-A alone fills the chip, so its workgroups go first and the selection roles take the slots it
   // frees.  With the patch stage on board that order leaves the stage's 15-us chains to start when K-A's waves end
   // (profiles/r3: span 48 us); patch + selection first, K-A behind them as their waves finish: 44 us.
-  static const int sel_first = env_int("TF_SEL_FIRST", -1);  // tuning knob: 1 = the other roles ahead of K-A, 0 = K-A first
-  // (a hall-sized frame -- K-A waves with ten chunks each -- wants K-A first: the other ranges then fill its tail)
-  const bool others_first = sel_first >= 0 ? sel_first != 0 : (with_patch && cur->small_frame);
   a.rot = others_first ? a.n_ka : 0u;
   if (with_patch) hipLaunchKernelGGL((k_frame<true, true>), dim3(total), dim3(256), 0, s, a);
   else if (color) hipLaunchKernelGGL((k_frame<true, false>), dim3(total), dim3(256), 0, s, a);
