@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <sched.h>
 #include <limits>
 
 #include "tf_host_math.h"
@@ -383,11 +384,12 @@ int tf_volume_destroy(tf_volume* v) {
   if (v->d_tmp) hipFree(v->d_tmp);
   if (v->d_group) hipFree(v->d_group);
   if (v->h_pinned) hipHostFree(v->h_pinned);
+  if (v->h_progress) hipHostFree(v->h_progress);
+  v->h_progress = nullptr;
   for (int k = 0; k < tf_volume::kHostRing; ++k) {
     if (v->hslot[k].h) hipHostFree(v->hslot[k].h);
     if (v->hslot[k].d) hipFree(v->hslot[k].d);
     if (v->hslot[k].copied) hipEventDestroy(v->hslot[k].copied);
-    if (v->hslot[k].freed) hipEventDestroy(v->hslot[k].freed);
   }
   if (v->host_trace[5] > 0)
     fprintf(stderr, "tf host frames: %.0f calls; per call us: wait kernels %.1f, wait upload %.1f, staging copy %.1f, "
@@ -774,8 +776,8 @@ extern "C" {
 static int patch_launched(tf_volume* v) {
   AtlasState& a = v->atlas;
   a.pend_patch.on = false;
-  if (a.pend_patch.host_slot >= 0) {  // its frame's staging slot is free once this launch is through
-    TF_HIP(hipEventRecord(v->hslot[a.pend_patch.host_slot].freed, v->stream));
+  if (a.pend_patch.host_slot >= 0) {  // its frame's staging slot is free once this launch is through = the next one has started
+    v->hslot[a.pend_patch.host_slot].free_when = v->progress_seq + 1u;
     a.pend_patch.host_slot = -1;
   }
   return TF_OK;
@@ -865,7 +867,7 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     if (pp.on && hc && !carry) { int rc = patch_flush(v); if (rc) return rc; }
     if (hc) prof_begin(v, TF_PROF_INTEGRATE);
     launch_frame(v->dev, hc ? &cur : nullptr, hn ? &nxt : nullptr, h2 ? &nx2 : nullptr, carry ? &pp.st : nullptr, v->cam,
-                 v->ig, v->res, v->stream);
+                 v->ig, v->res, v->stream, v->h_progress, &v->progress_seq);
     if (hc) prof_end(v);
     if (carry) { int rc = patch_launched(v); if (rc) return rc; }
     if (hc && tex) {
@@ -908,7 +910,33 @@ static int bind_frame(tf_volume* v, const float* d_depth, const uint8_t* d_rgba)
 static int host_slot_done(tf_volume* v, int slot) {
   AtlasState::PendPatch& pp = v->atlas.pend_patch;
   if (pp.on && pp.host_slot < 0) { pp.host_slot = slot; return TF_OK; }
-  TF_HIP(hipEventRecord(v->hslot[slot].freed, v->stream));
+  v->hslot[slot].free_when = v->progress_seq + 1u;  // through = a later frame launch has started
+  return TF_OK;
+}
+
+// Blocks until the last launch that reads a staging slot's device images is through.  No stream event: the frame
+// launches stamp tf_volume::h_progress when they start.  The launch that follows the slot's last reader is normally on
+// the stream already (the entry point runs three frames behind); if none comes (the caller changed entry points), the
+// stream is drained instead.
+static int host_slot_wait(tf_volume* v, tf_volume::HostSlot& s) {
+  if (!s.free_when) return TF_OK;
+  volatile uint32_t* p = v->h_progress;
+  if ((int32_t)(v->progress_seq - s.free_when) < 0) {  // no launch that would stamp it is on the stream
+    TF_HIP(hipStreamSynchronize(v->stream));
+    s.free_when = 0;
+    return TF_OK;
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t spin = 0;; ++spin) {
+    if ((int32_t)(*p - s.free_when) >= 0) break;
+    __builtin_ia32_pause();
+    if ((spin & 1023u) == 1023u) {
+      const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+      if (us > 20000.0) { TF_HIP(hipStreamSynchronize(v->stream)); break; }  // (a stalled device: fail through the API)
+      if (us > 200.0) sched_yield();
+    }
+  }
+  s.free_when = 0;
   return TF_OK;
 }
 
@@ -995,7 +1023,11 @@ static int host_ring_prepare(tf_volume* v) {
     TF_HIP(hipHostMalloc((void**)&s.h, npix * 8, hipHostMallocDefault));
     TF_HIP(hipMalloc((void**)&s.d, npix * 8));
     if (!s.copied) TF_HIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
-    if (!s.freed) TF_HIP(hipEventCreateWithFlags(&s.freed, hipEventDisableTiming));
+    s.free_when = 0;  // (both streams were drained above)
+  }
+  if (!v->h_progress) {
+    TF_HIP(hipHostMalloc((void**)&v->h_progress, 64, hipHostMallocDefault));
+    *v->h_progress = v->progress_seq;
   }
   v->hslot_pixels = npix;
   v->hslot_next = 0;
@@ -1036,7 +1068,8 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     t = t1;
   };
   auto t = now();
-  TF_HIP(hipEventSynchronize(s.freed));
+  rc = host_slot_wait(v, s);
+  if (rc) return rc;
   lap(0, t);
   TF_HIP(hipEventSynchronize(s.copied));
   lap(1, t);
@@ -1062,7 +1095,8 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     }
   }
   lap(2, t);
-  TF_HIP(hipMemcpyAsync(s.d, s.h, rgba ? npix * 8 : npix * 4, hipMemcpyHostToDevice, v->copy_stream));
+  static const bool dbg_noh2d = getenv("TF_HOST_NOH2D") && atoi(getenv("TF_HOST_NOH2D"));  // timing experiment only: WRONG results
+  if (!dbg_noh2d) TF_HIP(hipMemcpyAsync(s.d, s.h, rgba ? npix * 8 : npix * 4, hipMemcpyHostToDevice, v->copy_stream));
   TF_HIP(hipEventRecord(s.copied, v->copy_stream));
   lap(3, t);
   tf_volume::Pending cur;

@@ -287,7 +287,8 @@ constexpr uint32_t kKaCoarseSumm = 16384u;    // IntegrateConsts::dbg bit: Frame
 // ---- launchers (tf_kernels.hip) ------------------------------------------------------
 // patch != nullptr (and cur a colour frame): the launch also carries the patch stage of the previous frame
 void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* next,
-                  const FrameStage* next2, const PatchStage* patch, const Cam& cam, const Integ& ig, float res, hipStream_t s);
+                  const FrameStage* next2, const PatchStage* patch, const Cam& cam, const Integ& ig, float res, hipStream_t s,
+                  uint32_t* progress = nullptr, uint32_t* progress_seq = nullptr);  // host-visible word a launch with a K-B role stamps with ++*progress_seq
 void launch_reset_ctl(const VolumeDev& v, bool volume_too, hipStream_t s);
 void launch_null(hipStream_t s);
 void launch_bbox(const VolumeDev& v, const float* depth, const Cam& cam, const Pose& pose,

@@ -1369,6 +1369,8 @@ struct FrameLaunch {
   uint32_t n_patch;      // patch stage of frame f-1: workgroups, counter-set parity, the frame as keyframe
   int patch_par;
   KfDev kf_patch;
+  uint32_t* progress;    // host-visible word (or null): stamped with progress_val by a workgroup of the launch, i.e. when
+  uint32_t progress_val; // every launch ahead of it on the stream is through (tf_volume::h_progress)
 };
 
 template <bool COLOR, bool PATCH>
@@ -1396,6 +1398,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATCH ? TF_
     }
   } else {
     role = 2;
+    // the progress stamp lives in this (lightest) role: next to K-A it cost 36-212 B/lane of private memory
+    if (a.progress && b + 1 == total && threadIdx.x == 0)
+      __hip_atomic_store(a.progress, a.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_patch - a.n_sel, a.n_bbox);
   }
   if (timeline) {
@@ -1467,7 +1472,8 @@ void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_dep
 // cur != nullptr -> K-A of *cur (its selection set must hold a finished list); next -> K-C of
 // *next (its set must hold finished K-B keys); next2 -> K-B of *next2.
 void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* next,
-                  const FrameStage* next2, const PatchStage* patch, const Cam& cam, const Integ& ig, float res, hipStream_t s) {
+                  const FrameStage* next2, const PatchStage* patch, const Cam& cam, const Integ& ig, float res, hipStream_t s,
+                  uint32_t* progress, uint32_t* progress_seq) {
   const bool with_patch = patch != nullptr && cur != nullptr && cur->img.rgba != nullptr;
   static const int nblocks7 = env_int("TF_KA_BLOCKS", ka_blocks_default());
   // with the patch stage on board K-A gets one workgroup per CU more than the instance's residency: the patch / selection
@@ -1482,6 +1488,8 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   a.patch_par = 0;
   a.claim_par = -1;
   a.epoch = 0;
+  a.progress = nullptr;
+  a.progress_val = 0;
   if (with_patch) {
     static const int npb = env_int("TF_PATCH_BLOCKS", 1024);
     a.n_patch = (uint32_t)npb;
@@ -1527,6 +1535,10 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   if (a.n_sel) a.n_sel = (uint32_t)(nsel_env > 0 ? nsel_env : (others_first ? 128 : 256));
   const uint32_t total = a.n_ka + a.n_patch + a.n_sel + a.n_bbox;
   if (!total) return;
+  if (progress && progress_seq && a.n_bbox) {  // (the K-B role carries the stamp: steady launches of a stream have one)
+    a.progress = progress;
+    a.progress_val = ++*progress_seq;
+  }
   if ((a.kc.dbg & 4096u) && a.n_sel && a.n_bbox) a.kc.dbg |= 8192u;  // timeline stamps: steady launches only
   // Dispatch order.  K-A alone fills the chip, so its workgroups go first and the selection roles take the slots it
   // frees.  With the patch stage on board that order leaves the stage's 15-us chains to start when K-A's waves end

@@ -151,8 +151,14 @@ struct tf_volume {
   struct HostSlot {
     uint8_t* h = nullptr;      // pinned: depth f32[npix] | rgba u8[4 npix]
     uint8_t* d = nullptr;      // device: same layout
-    hipEvent_t copied = nullptr, freed = nullptr;
+    hipEvent_t copied = nullptr;
+    uint32_t free_when = 0;    // 0: free; else the progress stamp (h_progress) at which the last launch that reads d is through
   };
+  // Launch progress without stream events: every frame launch writes its sequence number into this pinned word when it
+  // STARTS (= every launch ahead of it on the stream is through).  An event record between two launches of a frame cost
+  // the host-frames path 6.8 us per frame of idle device time (profiles/r3, run 29).
+  uint32_t* h_progress = nullptr;
+  uint32_t progress_seq = 0;   // stamp of the last frame launch put on the stream
   HostSlot hslot[kHostRing];
   size_t hslot_pixels = 0;
   int hslot_next = 0;
