@@ -1053,12 +1053,6 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   TF_DEV_NOFLUSH(v);
   int rc = host_ring_prepare(v);
   if (rc) return rc;
-  const size_t npix = v->hslot_pixels;
-  const int slot_index = v->hslot_next;
-  tf_volume::HostSlot& s = v->hslot[slot_index];
-  v->hslot_next = (v->hslot_next + 1) % tf_volume::kHostRing;
-  // the kernels that read this slot's device images (three frames ago) and the upload out of its pinned
-  // buffer have finished
   static const bool trace = getenv("TF_HOST_TRACE") && atoi(getenv("TF_HOST_TRACE"));  // per-phase host time, printed at destroy
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto lap = [&](int k, std::chrono::steady_clock::time_point& t) {
@@ -1068,6 +1062,48 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     t = t1;
   };
   auto t = now();
+  // The launch pipeline of the streaming entry points, kept alive across per-frame calls: this call integrates the
+  // frame that arrived three calls ago, and that launch carries the selection stages of the two frames behind it
+  // (K-A(f-3) | K-C(f-2) | K-B(f-1)); frame f itself is only staged and copied.  Its copy has a whole call's time to
+  // finish before a launch needs it, so the host finds the copy event complete and no wait goes into the stream (a
+  // cross-stream wait ahead of every launch cost the textured stream 10 % -- profiles/r3).  The deferral cannot be
+  // observed: every other entry point flushes first (TF_DEV).
+  // The launches go out FIRST -- they need nothing of the new frame -- so that the device is at work while this call
+  // stages and uploads (an idle device starts ~45 us earlier: 2 % of a 20-frame window).
+  static const bool defer = !(getenv("TF_HOST_DEFER") && !atoi(getenv("TF_HOST_DEFER")));
+  constexpr int ND = tf_volume::kHostDefer;
+  const float* bound_d = nullptr;
+  const uint8_t* bound_c = nullptr;
+  static const bool launch_first = !(getenv("TF_HOST_LAUNCH_FIRST") && !atoi(getenv("TF_HOST_LAUNCH_FIRST")));  // A/B knob
+  auto launch_oldest = [&]() -> int {
+    if (!(defer && v->n_pend == ND)) return TF_OK;
+    tf_volume::Pending p0 = v->pend[0], p1 = v->pend[1], p2 = v->pend[2];
+    for (tf_volume::Pending* q : {&p0, &p1, &p2}) { rc = host_copy_ready(v, q); if (rc) return rc; }
+    const float* dd[3] = {p0.d, p1.d, p2.d};
+    const uint8_t* dc[3] = {p0.c, p1.c, p2.c};
+    float poses[36];
+    memcpy(poses, p0.pose, 48); memcpy(poses + 12, p1.pose, 48); memcpy(poses + 24, p2.pose, 48);
+    TexturedArgs tex{p0.pinv, p0.fid};
+    v->n_pend = 0;  // (helpers below enqueue_frames may pass through TF_DEV: nothing to flush while this call runs)
+    rc = enqueue_frames(v, 1, 2, dd, dc, poses, p0.tex ? &tex : nullptr);
+    v->pend[0] = p1;
+    v->pend[1] = p2;
+    v->n_pend = ND - 1;
+    if (rc) return rc;
+    rc = host_slot_done(v, p0.slot);
+    if (rc) return rc;
+    bound_d = p0.d;
+    bound_c = p0.c;
+    lap(4, t);
+    if (trace) v->host_trace[5] += 1.0;
+    return TF_OK;
+  };
+  if (launch_first) { rc = launch_oldest(); if (rc) return rc; }
+  const size_t npix = v->hslot_pixels;
+  const int slot_index = v->hslot_next;
+  tf_volume::HostSlot& s = v->hslot[slot_index];
+  v->hslot_next = (v->hslot_next + 1) % tf_volume::kHostRing;
+  // the kernels that read this slot's device images and the upload out of its pinned buffer have finished
   rc = host_slot_wait(v, s);
   if (rc) return rc;
   lap(0, t);
@@ -1088,7 +1124,10 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
         int helpers = e ? atoi(e) : 7;
         if (helpers < 0) helpers = 0;
         if (helpers > 15) helpers = 15;
-        static const bool pin = !(getenv("TF_COPY_PIN") && !atoi(getenv("TF_COPY_PIN")));  // A/B knob, default on
+        // 0 = helpers run where the scheduler puts them (default: on a shared host pinned helpers gave 1 run in 3 a
+        // 10-ms stall -- 100.8 us per frame at best, 150+ at worst, against a steady 102.6 unpinned; run 36),
+        // 1 = the caller's group of eight CPUs, 2 = one CPU of that group per helper
+        static const int pin = getenv("TF_COPY_PIN") ? atoi(getenv("TF_COPY_PIN")) : 0;
         v->copy_pool = new CopyPool(helpers, pin);
       }
       v->copy_pool->copy(dst, src, nb, nr);
@@ -1108,7 +1147,6 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   cur.fid = frame_id;
   cur.slot = slot_index;
   cur.copied = false;
-  static const bool defer = !(getenv("TF_HOST_DEFER") && !atoi(getenv("TF_HOST_DEFER")));
   if (!defer) {  // integrate at once: two selection-only launches per frame, the stream waits for the copy
     rc = host_copy_ready(v, &cur);
     if (rc) return rc;
@@ -1121,36 +1159,10 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     if (rc) return rc;
     return bind_frame(v, cur.d, cur.c);
   }
-  // The launch pipeline of the streaming entry points, kept alive across per-frame calls: this call integrates the
-  // frame that arrived three calls ago, and that launch carries the selection stages of the two frames behind it
-  // (K-A(f-3) | K-C(f-2) | K-B(f-1)); frame f itself is only staged and copied.  Its copy has a whole call's time to
-  // finish before a launch needs it, so the host finds the copy event complete and no wait goes into the stream (a
-  // cross-stream wait ahead of every launch cost the textured stream 10 % -- profiles/r3).  The deferral cannot be
-  // observed: every other entry point flushes first (TF_DEV).
-  constexpr int ND = tf_volume::kHostDefer;
-  if (v->n_pend < ND) {
-    v->pend[v->n_pend++] = cur;
-    return TF_OK;
-  }
-  tf_volume::Pending p0 = v->pend[0], p1 = v->pend[1], p2 = v->pend[2];
-  for (tf_volume::Pending* q : {&p0, &p1, &p2}) { rc = host_copy_ready(v, q); if (rc) return rc; }
-  const float* dd[3] = {p0.d, p1.d, p2.d};
-  const uint8_t* dc[3] = {p0.c, p1.c, p2.c};
-  float poses[36];
-  memcpy(poses, p0.pose, 48); memcpy(poses + 12, p1.pose, 48); memcpy(poses + 24, p2.pose, 48);
-  TexturedArgs tex{p0.pinv, p0.fid};
-  v->n_pend = 0;  // (helpers below enqueue_frames may pass through TF_DEV: nothing to flush while this call runs)
-  rc = enqueue_frames(v, 1, 2, dd, dc, poses, p0.tex ? &tex : nullptr);
-  v->pend[0] = p1;
-  v->pend[1] = p2;
-  v->pend[2] = cur;
-  v->n_pend = ND;
-  if (rc) return rc;
-  rc = host_slot_done(v, p0.slot);
-  if (rc) return rc;
-  lap(4, t);
-  if (trace) v->host_trace[5] += 1.0;
-  return bind_frame(v, p0.d, p0.c);
+  if (!launch_first) { rc = launch_oldest(); if (rc) return rc; }
+  v->pend[v->n_pend++] = cur;
+  if (bound_d) return bind_frame(v, bound_d, bound_c);
+  return TF_OK;
 }
 
 }  // extern "C" (C++ linkage for the helper below)

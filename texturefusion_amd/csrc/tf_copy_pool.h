@@ -21,25 +21,28 @@ class CopyPool {
  public:
   // pin_near: keep the helpers on CPUs next to the calling thread's (the same group of eight logical CPUs, which
   // shares a last-level cache slice on the hosts this runs on): helpers the scheduler parks on another socket halve the
-  // copy rate (measured: 37 vs 66-75 us per 2.4 MB frame from run to run).  Only CPUs the process may use are taken; with
-  // fewer than two of them in the group nothing is pinned.
-  explicit CopyPool(int helpers, bool pin_near = true) {
+  // copy rate (measured: 37 vs 66-75 us per 2.4 MB frame from run to run).  1 = every helper may run on any CPU of the
+  // group (the scheduler moves a helper whose CPU is taken by another process); 2 = one CPU per helper (a helper
+  // preempted in the middle of its part then stalls the call for a time slice: on a shared host 1 call in ~1000 took
+  // 10+ ms).  Only CPUs the process may use are taken; with fewer than two of them in the group nothing is pinned.
+  explicit CopyPool(int helpers, int pin_near = 1) {
     std::vector<int> near;
     if (pin_near) {
       cpu_set_t allowed;
       const int me = sched_getcpu();
       if (me >= 0 && sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
         for (int c = (me / 8) * 8; c < (me / 8) * 8 + 8; ++c)
-          if (c != me && c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) near.push_back(c);
+          if ((pin_near == 1 || c != me) && c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) near.push_back(c);
       if (near.size() < 2) near.clear();
     }
     for (int i = 0; i < helpers; ++i) {
       workers_.emplace_back([this] { loop(); });
       if (!near.empty()) {
-        cpu_set_t one;
-        CPU_ZERO(&one);
-        CPU_SET(near[(size_t)i % near.size()], &one);
-        pthread_setaffinity_np(workers_.back().native_handle(), sizeof(one), &one);  // best effort
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (pin_near == 1) for (int c : near) CPU_SET(c, &set);
+        else CPU_SET(near[(size_t)i % near.size()], &set);
+        pthread_setaffinity_np(workers_.back().native_handle(), sizeof(set), &set);  // best effort
       }
     }
   }
@@ -55,7 +58,7 @@ class CopyPool {
   CopyPool(const CopyPool&) = delete;
   CopyPool& operator=(const CopyPool&) = delete;
 
-  // dst[i] <- src[i] for the given regions (up to 4), each split into parts of about 256 KiB.
+  // dst[i] <- src[i] for the given regions (up to 4), each split into parts of 128 KiB.
   // The task table is only ever rebuilt under the mutex while no helper is inside pull() (active_ == 0), and a
   // helper only enters pull() after registering under the same mutex: a helper that was notified for call N but is
   // scheduled during call N + 1 either registers before the rebuild (and finds next_ >= size: nothing to do, the
@@ -90,7 +93,7 @@ class CopyPool {
   }
 
  private:
-  static constexpr size_t kPart = 256u << 10;
+  static constexpr size_t kPart = 128u << 10;
   struct Task { char* d; const char* s; size_t n; };
   void pull() {
     for (;;) {
