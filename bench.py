@@ -620,8 +620,6 @@ def child_passes(args):
                 "--mode", args.mode, "--scene", args.scene, "--res", repr(args.res), "--unique-frames", str(args.unique_frames)]
     base_cmd += (["--hires"] if args.hires else []) + (["--no-preroll"] if args.no_preroll else [])
     base_cmd += ["--resident-headline"] if args.resident_headline else []
-    if args.mode != "textured":
-        return {"error": "child passes are sliced by the textured stream's launches"}
     tmp = tempfile.mkdtemp(prefix="tf_prof_", dir="/tmp")
     out = {}
 
