@@ -218,25 +218,33 @@ def _copy_d2d(dst_ptr, src_ptr, nbytes):
     assert hip.hipDeviceSynchronize() == 0  # a D2D hipMemcpy may return before the copy has landed
 
 
-def test_textured_two_partitions_equal_one(gpu_required):
+@pytest.mark.parametrize("caps", [[4096] * 8, [24, 24, 24, 4096, 4096, 4096, 4096, 4096]], ids=["fits", "overflow_then_recover"])
+def test_textured_two_partitions_equal_one(gpu_required, caps):
     """The textured per-frame unit on two chunk-range partitions (x + y + z slabs) of one GPU: per frame voxel
     update on both, fixed-capacity blocks [count | records] exchanged as an all-gather would deliver them
     (tf_boundary_pack_block / tf_boundary_unpack_blocks with join_dirty), then the texture stage.  The union of
-    the partitions' chunks and meshes equals the single volume bit for bit; every mesh is owned by exactly one."""
+    the partitions' chunks and meshes equals the single volume bit for bit; every mesh is owned by exactly one.
+
+    overflow_then_recover: the first three exchanges have room for 24 records (a ghost band has hundreds).  Those frames
+    report TF_ERR_CAPACITY and mesh against stale ghosts; the senders keep what did not fit flagged, and the frame in
+    which a ghost finally arrives puts its owned neighbours into THAT frame's dirty set -- so at the end voxels and mesh
+    geometry are those of the single volume again."""
     cam = synth.Camera()
     axis, split = (1, 1, 1), 35
     single = capi.Volume(RES5, cam, max_chunks=1 << 16)
     parts = [capi.Volume(RES5, cam, max_chunks=1 << 16) for _ in range(2)]
     parts[0].set_partition(-(1 << 31), split, axis)
     parts[1].set_partition(split, (1 << 31) - 1, axis)
-    cap = 4096
-    bb = capi.boundary_block_bytes(cap)
-    blocks = [HipBuffer(2 * bb) for _ in range(2)]  # what each rank holds after the all-gather
-    mine = [HipBuffer(bb) for _ in range(2)]
-    n = 8
+    bb_max = capi.boundary_block_bytes(max(caps))
+    blocks = [HipBuffer(2 * bb_max) for _ in range(2)]  # what each rank holds after the all-gather
+    mine = [HipBuffer(bb_max) for _ in range(2)]
+    n = len(caps)
     frames = [synth.room_frame(3 * k, cam, with_quality=False) for k in range(n)]
     bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+    overflows = 0
     for k, f in enumerate(frames):
+        cap = caps[k]
+        bb = capi.boundary_block_bytes(cap)
         T = synth.pose_inverse16(f[3])
         dd, dr = [bufs[k][0].ptr], [bufs[k][1].ptr]
         single.stream_frames_textured_device(dd, dr, f[3].reshape(1, 12), T.reshape(1, 16), k)
@@ -251,7 +259,12 @@ def test_textured_two_partitions_equal_one(gpu_required):
         for r, v in enumerate(parts):
             v.boundary_unpack_blocks(blocks[r].ptr, 2, r, cap, join_dirty=True)
             v.texture_frame_device(T, k)
-            v.sync()
+            try:
+                v.sync()
+            except capi.TFError as e:
+                assert cap < 4096 and e.code == capi.TF_ERR_CAPACITY, e
+                overflows += 1
+    assert overflows == (0 if min(caps) == 4096 else 6)
     single.sync()
     ref_ids = sorted_ids(single.list_chunks())
     key = {tuple(c): i for i, c in enumerate(ref_ids)}
