@@ -203,6 +203,10 @@ typedef struct {
 TF_API int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_unit_group* moved, int32_t n_moved,
                                    int32_t texture, const float* pose_inv16);
 TF_API int tf_keyframe_unit_release(tf_volume* v);
+/* the store of the keyframes' validChunks: out = {capacity, entries in use (top), compactions, stores into an existing
+ * region, regions handed out}.  A re-integrated keyframe writes into its region when the list fits, else it gets a new
+ * one; the live regions are moved together when the top reaches the capacity.  Synchronises. */
+TF_API int tf_keyframe_unit_stats(tf_volume* v, int64_t out[5]);
 
 /* ---- view-selection bookkeeping on the device ------------------------------
  * Chunk::observations (3rd_party/open_chisel/geometry/Chunk.h:171) lives in HBM, keyed by (chunk, keyframe):

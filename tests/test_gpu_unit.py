@@ -109,3 +109,62 @@ def test_keyframe_unit_with_a_moved_keyframe(gpu_required):
         for b in t:
             b.free()
     gv.close()
+
+
+def test_keyframe_store_reuses_regions_and_compacts(gpu_required, monkeypatch):
+    """The keyframes' validChunks store (tf_unit.hip): a chain of four keyframe groups in which every earlier keyframe is
+    moved again each time, with exact-fit regions (TF_UNIT_NO_SLACK: any growth of a list needs a new region) in an arena
+    of 6.5 first-keyframe lists for four keyframes whose lists grow to 1.1-1.6 of that (TF_UNIT_ARENA) -- lists are rewritten in place, regions die, the live ones are moved together.  A list
+    that came back wrong would de-integrate the wrong chunks: the volume is compared with the oracle's, chunk by chunk."""
+    cam = synth.Camera()
+    fr = [synth.room_frame(2 * k, cam, with_quality=True) for k in range(14)]
+    probe = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
+    list_len = len(_oracle_group(probe, 1, fr[0], [(fr[1][0], fr[1][3])], 1))
+    monkeypatch.setenv("TF_UNIT_NO_SLACK", "1")
+    monkeypatch.setenv("TF_UNIT_ARENA", str(int(6.5 * list_len)))
+    ov = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1]), HipBuffer(f[2].nbytes).from_host(f[2]))
+            for f in fr]
+    groups = {1: (0, [1]), 2: (3, [4]), 3: (6, [7]), 4: (9, [10])}  # keyframe id -> (its frame, its local frames)
+    pose_now = {}   # keyframe id -> [keyframe pose, local poses...] of its last integration
+    valid = {}      # keyframe id -> the oracle's validChunks
+
+    def dev_group(kf, poses, old=None):
+        key, loc = groups[kf]
+        return capi.Volume.unit_group(kf, (bufs[key][0].ptr, bufs[key][1].ptr, bufs[key][2].ptr, poses[0]),
+                                      [(bufs[k][0].ptr, poses[1 + i]) for i, k in enumerate(loc)],
+                                      **({} if old is None else dict(old_keyframe_pose=old[0], old_local_poses=old[1:])))
+
+    def oracle_group(kf, poses, flag):
+        key, loc = groups[kf]
+        k = (fr[key][0], fr[key][1], fr[key][2], poses[0])
+        return _oracle_group(ov, kf, k, [(fr[j][0], poses[1 + i]) for i, j in enumerate(loc)], flag,
+                             ids=valid.get(kf) if flag == 0 else None)
+
+    for step, kf in enumerate([1, 2, 3, 4]):
+        key, loc = groups[kf]
+        fresh_poses = [fr[key][3]] + [fr[j][3] for j in loc]
+        moved = []
+        for m in sorted(pose_now):  # every earlier keyframe moves: its frames get the poses `step` frames further along
+            mk, ml = groups[m]
+            new = [fr[min(j + step, len(fr) - 1)][3] for j in [mk] + ml]
+            moved.append((m, pose_now[m], new))
+        gv.keyframe_unit(fresh=dev_group(kf, fresh_poses), moved=[dev_group(m, new, old) for m, old, new in moved], texture=False)
+        for m, old, new in moved:
+            assert ov.retract_observations(m, valid[m]) > 0
+            oracle_group(m, old, 0)
+            valid[m] = oracle_group(m, new, 1)
+            pose_now[m] = new
+        valid[kf] = oracle_group(kf, fresh_poses, 1)
+        pose_now[kf] = fresh_poses
+    gv.sync()
+    st = gv.keyframe_unit_stats()
+    assert st["compactions"] >= 1 and st["reuses"] >= 1 and st["regions"] > 4 and st["top"] <= st["capacity"], st
+    oids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(oids, sorted_ids(gv.list_chunks())) and len(oids) > 3000
+    assert_chunks_equal(ov, gv, oids[::5], "keyframe store")
+    for t in bufs:
+        for b in t:
+            b.free()
+    gv.close()

@@ -35,7 +35,7 @@ SYMBOLS = (
     "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
     "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
-    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_profile_calibrate", "tf_keyframe_unit_device", "tf_keyframe_unit_release", "tf_observations_record", "tf_observations_retract", "tf_export_datacost", "tf_export_adjacency", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
+    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_profile_calibrate", "tf_keyframe_unit_device", "tf_keyframe_unit_release", "tf_keyframe_unit_stats", "tf_observations_record", "tf_observations_retract", "tf_export_datacost", "tf_export_adjacency", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_set_pose",
     "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_meshes_upload",
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
@@ -137,6 +137,7 @@ def lib():
     L.tf_profile_calibrate.argtypes = [vp, C.c_int32, C.POINTER(C.c_double)]
     L.tf_keyframe_unit_device.argtypes = [vp, C.POINTER(UnitGroup), C.POINTER(UnitGroup), C.c_int32, C.c_int32, fp]
     L.tf_keyframe_unit_release.argtypes = [vp]
+    L.tf_keyframe_unit_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     L.tf_observations_record.argtypes = [vp, C.c_int32]
     L.tf_observations_retract.argtypes = [vp, C.c_int32, i32p, C.c_int64]
     L.tf_export_datacost.argtypes = [vp, i32p, C.c_int64, C.c_int32, i32p, C.c_int32, fp]
@@ -535,6 +536,12 @@ class Volume:
         T = None if pose_inv16 is None else _f32(pose_inv16).reshape(16)
         self._ck(self.L.tf_keyframe_unit_device(self.h, C.byref(fresh) if fresh is not None else None, arr, len(moved),
                                                 int(bool(texture)), _p(T, C.c_float)))
+
+    def keyframe_unit_stats(self):
+        """{capacity, top, compactions, reuses, regions} of the keyframes' validChunks store"""
+        out = (C.c_int64 * 5)()
+        self._ck(self.L.tf_keyframe_unit_stats(self.h, out))
+        return dict(zip(("capacity", "top", "compactions", "reuses", "regions"), [int(x) for x in out]))
 
     # -- Chunk::observations on the device and the exports TexMap consumes
     def observations_record(self, keyframe_id):

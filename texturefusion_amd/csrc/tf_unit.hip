@@ -17,15 +17,18 @@
 
 namespace tf {
 
-// Frame::validChunks of the keyframes (GCFusion/frame.h), device-resident: an append-only arena of chunk ids and, per
-// keyframe slot, where its list starts and how long it is.  A keyframe that is integrated again appends a new list
-// (its old one is dead space until tf_volume_reset).
+// Frame::validChunks of the keyframes (GCFusion/frame.h), device-resident: an arena of chunk ids and, per keyframe slot,
+// its region (start, capacity) and the length of its list.  A keyframe that is integrated again writes into its region
+// when the new list fits (regions are handed out with a quarter of slack), else it gets a new region at the top; when
+// the top reaches the end of the arena the live regions are moved together first (k_kf_store, one workgroup, no host
+// involvement).
 constexpr int kUnitMaxKf = 1024;
 struct KfTab {
   uint32_t top;  // ids handed out so far
-  uint32_t pad[3];
+  uint32_t n_compact, n_reuse, n_regions;  // statistics: compactions, stores into an existing region, regions handed out
   uint32_t off[kUnitMaxKf];
   uint32_t n[kUnitMaxKf];
+  uint32_t capn[kUnitMaxKf];  // size of the slot's region (0: none)
 };
 struct UnitState {
   int4* arena = nullptr;
@@ -40,7 +43,7 @@ static std::mutex g_units_mu;                              // (handles may live 
 
 // FinalizeIntegrateChunks' validChunks (Chisel.h:192-208): the entries of the current list whose needsUpdate flag is set,
 // in list order, appended to the arena.  One workgroup: the order must be kept.
-__global__ __launch_bounds__(1024) void k_kf_store(VolumeDev v, KfTab* tab, int4* arena, uint32_t cap, int slot) {
+__global__ __launch_bounds__(1024) void k_kf_store(VolumeDev v, KfTab* tab, int4* arena, uint32_t cap, int slot, int slack) {
   const SelBuf& L = v.sel;
   const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
   __shared__ uint32_t wsum[16];
@@ -54,14 +57,74 @@ __global__ __launch_bounds__(1024) void k_kf_store(VolumeDev v, KfTab* tab, int4
   for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
   if (lane == 0) wsum[w] = cnt;
   __syncthreads();
+  __shared__ uint32_t s_tot, s_need, s_compact;
   if (threadIdx.x == 0) {
     uint32_t tot = 0;
     for (int k = 0; k < 16; ++k) tot += wsum[k];
-    uint32_t at = atomicAdd(&tab->top, tot);
-    if (at + tot > cap) { atomicOr(&v.vctl->status, kStListFull); tot = 0; at = 0; }
-    tab->off[slot] = at;
-    tab->n[slot] = tot;
-    base = tot ? at : 0xFFFFFFFFu;
+    s_tot = tot;
+    s_compact = 0;
+    if (tot <= tab->capn[slot]) {  // fits the region the keyframe already has
+      s_need = 0;
+      tab->n_reuse += 1;
+    } else {
+      uint32_t need = tot + (slack ? tot / 4u + 64u : 0u);
+      tab->capn[slot] = 0;         // the old region (if any) is dead space from here on
+      tab->n[slot] = 0;
+      if (tab->top + need > cap) s_compact = 1;
+      s_need = need;
+    }
+  }
+  __syncthreads();
+  if (s_compact) {
+    // Move the live regions together, in the order they lie in the arena (slot t's thread counts the live regions
+    // below its own; the moves go downwards one region after the other, each by the whole workgroup).
+    __shared__ uint32_t s_order[kUnitMaxKf];
+    __shared__ uint32_t s_live;
+    const uint32_t t = threadIdx.x;  // (kUnitMaxKf == the workgroup's size)
+    const uint32_t my_cap = tab->capn[t], my_off = tab->off[t];
+    if (t == 0) s_live = 0;
+    __syncthreads();
+    if (my_cap) {
+      uint32_t below = 0;
+      for (int k = 0; k < kUnitMaxKf; ++k) below += (tab->capn[k] && tab->off[k] < my_off) ? 1u : 0u;
+      s_order[below] = t;
+      atomicAdd(&s_live, 1u);
+    }
+    __syncthreads();
+    uint32_t to = 0;
+    for (uint32_t r = 0; r < s_live; ++r) {
+      const uint32_t k = s_order[r];
+      const uint32_t from = tab->off[k], len = tab->n[k], oldcap = tab->capn[k];
+      const uint32_t roomy = len + (slack ? len / 4u + 64u : 0u);
+      const uint32_t newcap = roomy < oldcap ? roomy : oldcap;
+      __syncthreads();  // (every thread has read the region's old record)
+      if (from != to) {
+        for (uint32_t b0 = 0; b0 < len; b0 += 1024u) {  // ascending, a block at a time: target <= source, they may overlap
+          int4 val = make_int4(0, 0, 0, 0);
+          if (b0 + t < len) val = arena[from + b0 + t];
+          __syncthreads();
+          if (b0 + t < len) arena[to + b0 + t] = val;
+          __syncthreads();
+        }
+      }
+      if (t == 0) { tab->off[k] = to; tab->capn[k] = newcap; }
+      to += newcap;
+      __syncthreads();
+    }
+    if (t == 0) { tab->top = to; tab->n_compact += 1; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const uint32_t tot = s_tot;
+    uint32_t need = s_need;
+    bool ok = true;
+    if (need) {
+      if (tab->top + need > cap) need = tot;  // no slack left: an exact fit
+      if (tab->top + need > cap) { atomicOr(&v.vctl->status, kStListFull); ok = false; }
+      else { tab->off[slot] = tab->top; tab->capn[slot] = need; tab->top += need; tab->n_regions += 1; }
+    }
+    tab->n[slot] = ok ? tot : 0u;
+    base = (ok && tot) ? tab->off[slot] : 0xFFFFFFFFu;
   }
   __syncthreads();
   if (base == 0xFFFFFFFFu) return;
@@ -129,6 +192,7 @@ static int unit_state(tf_volume* v, UnitState** out) {
   lock.unlock();
   if (!u.arena) {
     u.cap = (uint32_t)std::min<size_t>((size_t)v->dev.max_list * 16, (size_t)1 << 26);
+    if (const char* e = getenv("TF_UNIT_ARENA")) u.cap = (uint32_t)std::max(1024, atoi(e));  // test knob: a small arena
     TF_HIP(hipMalloc((void**)&u.arena, sizeof(int4) * (size_t)u.cap));
     TF_HIP(hipMalloc((void**)&u.tab, sizeof(KfTab)));
     TF_HIP(hipMemsetAsync(u.tab, 0, sizeof(KfTab), v->stream));
@@ -172,7 +236,8 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     launch_integrate_group(d, g->n_local, dd, poses, u->group_pre, u->group_cen, v->cam, v->ig, v->res, flag, s);
   }
   launch_finalize(d, v->epoch++, s);
-  if (flag) hipLaunchKernelGGL(k_kf_store, dim3(1), dim3(1024), 0, s, d, u->tab, u->arena, u->cap, kf_slot);
+  const int slack = !(getenv("TF_UNIT_NO_SLACK") && atoi(getenv("TF_UNIT_NO_SLACK")));  // test knob (read per call): exact-fit regions
+  if (flag) hipLaunchKernelGGL(k_kf_store, dim3(1), dim3(1024), 0, s, d, u->tab, u->arena, u->cap, kf_slot, slack);
   else hipLaunchKernelGGL(k_kf_clear, dim3(1), dim3(1), 0, s, u->tab, kf_slot);
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
@@ -253,6 +318,24 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
               ++v->mesh_epoch, v->res, false, -1, 1u << 30, nullptr, -1, v->stream);
   v->mesh_par ^= 1;
   TF_HIP(hipGetLastError());
+  return TF_OK;
+}
+
+int tf_keyframe_unit_stats(tf_volume* v, int64_t out[5]) {
+  if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  for (int k = 0; k < 5; ++k) out[k] = 0;
+  UnitState* u = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_units_mu);
+    auto it = g_units.find(v);
+    if (it == g_units.end() || !it->second.tab) return TF_OK;
+    u = &it->second;
+  }
+  TF_DEV(v);
+  uint32_t h[4];
+  TF_HIP(hipMemcpyAsync(h, u->tab, sizeof(h), hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  out[0] = u->cap; out[1] = h[0]; out[2] = h[1]; out[3] = h[2]; out[4] = h[3];
   return TF_OK;
 }
 
