@@ -1063,13 +1063,14 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   };
   auto t = now();
   // The launch pipeline of the streaming entry points, kept alive across per-frame calls: this call integrates the
-  // frame that arrived three calls ago, and that launch carries the selection stages of the two frames behind it
-  // (K-A(f-3) | K-C(f-2) | K-B(f-1)); frame f itself is only staged and copied.  Its copy has a whole call's time to
-  // finish before a launch needs it, so the host finds the copy event complete and no wait goes into the stream (a
-  // cross-stream wait ahead of every launch cost the textured stream 10 % -- profiles/r3).  The deferral cannot be
+  // frame that arrived FOUR calls ago, and that launch carries the selection stages of the two frames behind it
+  // (K-A(f-4) | K-C(f-3) | K-B(f-2)); frames f-1 and f are only staged and copied.  A copy therefore has a whole
+  // call's time to finish before a launch needs it, so the host finds the copy event complete and no wait goes into
+  // the stream (a cross-stream wait ahead of a launch costs ~7 us of idle device; with three frames of deferral the
+  // newest image a launch reads was uploaded by the call before, and 6-20 % of the launches still waited).  The deferral cannot be
   // observed: every other entry point flushes first (TF_DEV).
-  // The launches go out FIRST -- they need nothing of the new frame -- so that the device is at work while this call
-  // stages and uploads (an idle device starts ~45 us earlier: 2 % of a 20-frame window).
+  // The launches go out FIRST where that costs nothing -- they need nothing of the new frame -- so that an idle device is
+  // at work while this call stages and uploads (it starts ~45 us earlier: 2 % of a 20-frame window).
   static const bool defer = !(getenv("TF_HOST_DEFER") && !atoi(getenv("TF_HOST_DEFER")));
   constexpr int ND = tf_volume::kHostDefer;
   const float* bound_d = nullptr;
@@ -1077,7 +1078,9 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   static const bool launch_first = !(getenv("TF_HOST_LAUNCH_FIRST") && !atoi(getenv("TF_HOST_LAUNCH_FIRST")));  // A/B knob
   auto launch_oldest = [&]() -> int {
     if (!(defer && v->n_pend == ND)) return TF_OK;
-    tf_volume::Pending p0 = v->pend[0], p1 = v->pend[1], p2 = v->pend[2];
+    tf_volume::Pending all[ND];
+    for (int k = 0; k < ND; ++k) all[k] = v->pend[k];
+    tf_volume::Pending &p0 = all[0], &p1 = all[1], &p2 = all[2];  // the launch reads the oldest frame and the two behind it
     for (tf_volume::Pending* q : {&p0, &p1, &p2}) { rc = host_copy_ready(v, q); if (rc) return rc; }
     const float* dd[3] = {p0.d, p1.d, p2.d};
     const uint8_t* dc[3] = {p0.c, p1.c, p2.c};
@@ -1086,8 +1089,7 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     TexturedArgs tex{p0.pinv, p0.fid};
     v->n_pend = 0;  // (helpers below enqueue_frames may pass through TF_DEV: nothing to flush while this call runs)
     rc = enqueue_frames(v, 1, 2, dd, dc, poses, p0.tex ? &tex : nullptr);
-    v->pend[0] = p1;
-    v->pend[1] = p2;
+    for (int k = 1; k < ND; ++k) v->pend[k - 1] = all[k];
     v->n_pend = ND - 1;
     if (rc) return rc;
     rc = host_slot_done(v, p0.slot);
@@ -1098,7 +1100,17 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     if (trace) v->host_trace[5] += 1.0;
     return TF_OK;
   };
-  if (launch_first) { rc = launch_oldest(); if (rc) return rc; }
+  // ... but only when they would not wait: the launch also reads the images of the two frames behind the oldest one
+  // (selection roles), and the newest of those was uploaded by the PREVIOUS call.  On an idle device (the start of a
+  // stream, a caller that paces its frames) that copy is through and the launches go out at once; in a saturated stream
+  // it is a few microseconds old -- launching now would put a wait for it into the stream (7 us of idle device per
+  // frame, run 46), launching behind the staging copy finds it complete.
+  bool early = false;
+  if (launch_first && defer && v->n_pend == ND) {
+    const tf_volume::Pending& newest = v->pend[2];  // (the newest frame the launch reads)
+    early = newest.copied || hipEventQuery(v->hslot[newest.slot].copied) == hipSuccess;
+  }
+  if (early) { rc = launch_oldest(); if (rc) return rc; }
   const size_t npix = v->hslot_pixels;
   const int slot_index = v->hslot_next;
   tf_volume::HostSlot& s = v->hslot[slot_index];
@@ -1159,7 +1171,7 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     if (rc) return rc;
     return bind_frame(v, cur.d, cur.c);
   }
-  if (!launch_first) { rc = launch_oldest(); if (rc) return rc; }
+  if (!early) { rc = launch_oldest(); if (rc) return rc; }
   v->pend[v->n_pend++] = cur;
   if (bound_d) return bind_frame(v, bound_d, bound_c);
   return TF_OK;

@@ -146,7 +146,7 @@ struct tf_volume {
   size_t img_pixels = 0;
   // drop-in per-frame host path (tf_integrate_frame_host): ring of pinned staging + device image slots, H2D on
   // its own stream so that the copy of frame f+1 overlaps the kernels of frame f
-  static constexpr int kHostRing = 8;  // three deferred frames + the one being staged + four whose kernels may still run
+  static constexpr int kHostRing = 8;  // four deferred frames + the one being staged + three whose kernels may still run
                                        // (a frame's images are read by its patch stage one launch behind its voxel update)
   struct HostSlot {
     uint8_t* h = nullptr;      // pinned: depth f32[npix] | rgba u8[4 npix]
@@ -190,7 +190,7 @@ struct tf_volume {
     int slot = 0;
     bool copied = false;  // its H2D copy is known to be complete, or the handle's stream has been told to wait for it
   };
-  static constexpr int kHostDefer = 3;  // frames tf_integrate_frame_host runs behind its caller
+  static constexpr int kHostDefer = 4;  // frames tf_integrate_frame_host runs behind its caller (a launch reads the oldest three)
   Pending pend[kHostDefer];
   int n_pend = 0;
   float* d_group = nullptr;  // staging of tf_integrate_depth_group_host: six depth images
