@@ -562,6 +562,11 @@ def roofline(args, vol, cam, prof, kinds, K, first, n_unique, d_depth, d_rgba, p
         "windows": "timed, resident, event and replay passes cover the same %d orbit positions in consecutive turns of a "
                    "steady-state volume; the profiler child passes run the timed window itself" % K,
     }
+    if wall_us and t_step > wall_us:
+        # the profiled pass is another process: with ~1 us of idle device per frame its kernel durations (which carry the
+        # profiler's per-dispatch overhead) can exceed this process's unprofiled wall time of the same frames
+        r["kernel_vs_wall"] = ("kernel_us_per_step (%.1f, %s) exceeds wall_us_per_step (%.1f, this process, unprofiled) by %.1f %%: "
+                               "two runs of the same frames; `frac` uses the larger one" % (t_step, "profiled child pass" if (trace and "kernels" in trace) else "events", wall_us, 100.0 * (t_step / wall_us - 1.0)))
     pmc = (prof_child or {}).get("pmc")
     if pmc and "bytes_per_step" in pmc:
         r["traffic"] = pmc["bytes_per_step"]
