@@ -699,7 +699,8 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
 // holds the frame's visible list with its needsUpdate flags, `frame_epoch` the finalize epoch of that frame.
 // The patch stage (adjacency exchange, slot hand-out, projection, blit) reads meshes and images only; it is left
 // PENDING here and rides on the next frame's launch next to that frame's voxel update (AtlasState::pend_patch).
-static int fused_arm(tf_volume* v) {
+}  // extern "C" (C++ linkage for the helper below)
+int tf::fused_arm(tf_volume* v) {
   AtlasState& a = v->atlas;
   if (a.fused_armed) return TF_OK;
   // first textured frame after a reset / a call-by-call atlas call: empty work lists
@@ -714,8 +715,8 @@ static int fused_arm(tf_volume* v) {
   return TF_OK;
 }
 
-// claimed: K-A of this frame built the dirty set itself (FrameStage::claim_par = the parity used here)
-}  // extern "C"
+// claimed: the dirty set of this frame is already in the lists of the current parity -- K-A built it (FrameStage::claim_par
+// = the parity used here), or the caller ran launch_dirty_frame over each of its lists (the keyframe unit)
 int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
                       const float* pose_inv16, int32_t frame_id, bool claimed) {
   AtlasState& a = v->atlas;

@@ -216,6 +216,7 @@ int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint3
                   int32_t frame_id, bool claimed = false);
 int flush_deferred(tf_volume* v);
 int patch_flush(tf_volume* v);
+int fused_arm(tf_volume* v);  // the fused flow's counter sets in their start state (no-op once armed)
 int ensure_pinned(tf_volume* v, size_t bytes);
 void prof_begin(tf_volume* v, int kind, hipStream_t s = nullptr);
 void prof_end(tf_volume* v, hipStream_t s = nullptr);
