@@ -195,6 +195,25 @@ def truncation(ig: Integrator, z: float) -> float:
     return float(lib().tfo_truncation(C.byref(ig), np.float32(z)))
 
 
+def weight(ig: Integrator, trunc: float) -> float:
+    L = lib()
+    L.tfo_weight.restype = C.c_float
+    L.tfo_weight.argtypes = [C.POINTER(Integrator), C.c_float]
+    return float(L.tfo_weight(C.byref(ig), np.float32(trunc)))
+
+
+def chunk_scalars(ig: Integrator, pose, cid, res):
+    """(originInCamera[3], truncation, weight) of one chunk (ProjectionIntegrator.cpp:74-101)."""
+    pose = f32(pose).reshape(12)
+    cid = np.ascontiguousarray(cid, np.int32)
+    oc = np.zeros(3, np.float32)
+    tr = C.c_float(0)
+    w = C.c_float(0)
+    lib().tfo_chunk_scalars(C.byref(ig), _p(pose, C.c_float), _p(cid, C.c_int32), np.float32(res),
+                            _p(oc, C.c_float), C.byref(tr), C.byref(w))
+    return oc, tr.value, w.value
+
+
 def centroids(pose, res) -> np.ndarray:
     pose = f32(pose).reshape(12)
     out = np.empty(3 * 512, np.float32)

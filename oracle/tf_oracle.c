@@ -65,6 +65,25 @@ float tfo_truncation(const tfo_integrator* ig, float z) {
   return (float)(fabs(v) * (double)ig->scale);
 }
 
+/* ConstantWeighter::GetWeight (weighting/ConstantWeighter.h:43-46): weight / (2 * truncationDist), all float */
+float tfo_weight(const tfo_integrator* ig, float truncation) { return ig->weight / (2.0f * truncation); }
+
+/* chisel::parallel_for (threading/Threading.h:36-54) as a plan: items are cut into stretches of
+ * group = max(max(1, |threshold|), n / |nthreads|) (integer division); one std::thread per stretch that starts
+ * below n - group, the calling thread runs what is left (at most one group).  Returns the number of threads that
+ * run items (spawned + the caller), i.e. ceil(n / group) for n > 0.  nthreads is the reference's function-static
+ * hardware_concurrency() - 2. */
+int tfo_parallel_for_plan(int64_t n, int nthreads, int threshold, int64_t* group_out) {
+  int64_t thr = threshold < 0 ? -(int64_t)threshold : threshold;
+  int64_t nt = nthreads < 0 ? -(int64_t)nthreads : nthreads;
+  int64_t group = thr > 1 ? thr : 1;
+  if (nt > 0 && n / nt > group) group = n / nt;
+  if (group_out) *group_out = group;
+  int spawned = 0;
+  for (int64_t it = 0; it < n - group; it += group) spawned++;
+  return spawned + 1;
+}
+
 /* Chisel::bufferIntegratorSIMDCentroids (Structure/Chisel.cpp:52-110):
  * c[i] = (R^T * (x,y,z)) * res + res/2, i = (z*8+y)*8+x; half voxel added un-rotated. */
 void tfo_centroids(const float pose[12], float res, float cen[3 * TFO_CHUNK_VOXELS]) {
@@ -95,7 +114,7 @@ void tfo_chunk_scalars(const tfo_integrator* ig, const float pose[12], const int
     origin_cam[a] = dot3_fixed(R_(pose, 0, a), R_(pose, 1, a), R_(pose, 2, a), d[0], d[1], d[2]);
   float tr = tfo_truncation(ig, origin_cam[2]);
   *truncation = tr;
-  *weight = ig->weight / (2.0f * tr); /* ConstantWeighter.h:43-46 */
+  *weight = tfo_weight(ig, tr);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -891,12 +910,11 @@ int tfo_integrate(tfo_volume* v, const float* depth, const uint8_t* rgba, const 
   if (n < 1) return 0;               /* :228 */
   int missing = 0;
   int64_t rt = 0, rc = 0, cu = 0;
-  /* chisel::parallel_for (threading/Threading.h:36-54): groups of max(1000, N / nthreads) items, one
-   * thread per group -- with fewer than 1000 chunks the reference runs this loop on one thread */
-  int T = v->nthreads;
-  const int64_t groups = (n + 999) / 1000;
-  if (T > groups) T = (int)(groups > 0 ? groups : 1);
-#pragma omp parallel for schedule(static) num_threads(T) reduction(+ : missing, rt, rc, cu)
+  /* chisel::parallel_for (threading/Threading.h:36-54): stretches of max(1000, N / nthreads) items, one
+   * thread per stretch -- with fewer than 1000 chunks the reference runs this loop on one thread */
+  int64_t group = 1000;
+  const int T = tfo_parallel_for_plan(n, v->nthreads, 1000, &group);
+#pragma omp parallel for schedule(static, group) num_threads(T) reduction(+ : missing, rt, rc, cu)
   for (int64_t i = 0; i < n; i++) {
     tfo_chunk* c = vol_get(v, ids + 3 * i);
     if (!c) { missing++; continue; } /* reference: chunks.at() would throw */
@@ -1680,14 +1698,13 @@ int64_t tfo_update_meshes(tfo_volume* v) {
    * (threading/Threading.h:36-54: groups of max(1000, N / nthreads) items) */
   typedef struct { int64_t nv, ni; float* vb; uint32_t* ib; } res_t;
   res_t* R = (res_t*)calloc(n ? n : 1, sizeof(res_t));
-  int T = v->nthreads;
-  const int64_t by_group = (n + 999) / 1000;
-  if (T > by_group) T = (int)(by_group > 0 ? by_group : 1);
+  int64_t group = 1000;
+  const int T = tfo_parallel_for_plan(n, v->nthreads, 1000, &group);
 #pragma omp parallel num_threads(T)
   {
     float* vb = (float*)malloc(sizeof(float) * 9 * TFO_MESH_SLOTS);
     uint32_t* ib = (uint32_t*)malloc(sizeof(uint32_t) * TFO_MESH_MAX_INDICES);
-#pragma omp for schedule(static)
+#pragma omp for schedule(static, group)
     for (int64_t i = 0; i < n; i++) {
       int64_t ni = 0;
       const int64_t nv = tfo_mesh_chunk(v, ids + 3 * i, vb, vb + 3 * TFO_MESH_SLOTS, vb + 6 * TFO_MESH_SLOTS, ib, &ni);

@@ -66,6 +66,11 @@ typedef struct {
 void tfo_set_sum_order(int bits);
 int tfo_get_sum_order(void);
 float tfo_truncation(const tfo_integrator* ig, float z);
+/* ConstantWeighter::GetWeight (weighting/ConstantWeighter.h:43-46) */
+float tfo_weight(const tfo_integrator* ig, float truncation);
+/* chisel::parallel_for's cut of n items (threading/Threading.h:36-54): stretch length to *group_out, returns the
+ * number of threads that run items (spawned + caller).  Pinned against the compiled header by tests/test_ref_pin.py. */
+int tfo_parallel_for_plan(int64_t n, int nthreads, int threshold, int64_t* group_out);
 void tfo_centroids(const float pose[12], float res, float cen[3 * TFO_CHUNK_VOXELS]);
 void tfo_chunk_scalars(const tfo_integrator* ig, const float pose[12], const int id[3], float res,
                        float origin_cam[3], float* truncation, float* weight);
