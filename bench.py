@@ -73,6 +73,7 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 child passes (kernel trace, FETCH_SIZE, WRITE_SIZE)")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # the timed workload only, run under rocprofv3
+    ap.add_argument("--repeats", type=int, default=5, help="N=1: further timed windows on the same orbit positions (median / min / max next to value)")
     ap.add_argument("--no-group", action="store_true", help="skip the keyframe-group (1 colour + 6 depth frames) measurement")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N>1 code path (partition + boundary exchange) even with one rank (smoke test)")
@@ -251,15 +252,17 @@ def main():
                 uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, 0)
             vol.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
-            # neighbour send / receive pairs need every slab to hold its own ghost band (a + b + c + 1 keys); else all-gather
-            widths = [edges[r + 1] - edges[r] for r in range(1, world - 1)]
-            vol.comm_exchange_mode(0 if all(w >= sum(axis) + 1 for w in widths) else 1)
+            # (neighbour send / receive pairs need every slab above the lowest to hold its own ghost band; the library
+            # checks that itself at the first exchange and falls back to the all-gather form on every rank otherwise)
             if textured:
                 vol.comm_exchange_every_frame(cap)
         else:
             bb = capi.boundary_block_bytes(cap)
             blk = torch.zeros(bb, dtype=torch.uint8, device=dev)
             allb = torch.zeros(bb * max(world, 1), dtype=torch.uint8, device=dev)
+            blk_dn = torch.zeros(bb, dtype=torch.uint8, device=dev)
+            blk_up = torch.zeros(bb, dtype=torch.uint8, device=dev)
+            torch_wire = [0, 0]  # bytes sent / received through the torch transport
 
     def torch_exchange(join_dirty):
         """[count | records] blocks through torch.distributed on the volume's stream (no .item(), no host wait)."""
@@ -270,6 +273,28 @@ def main():
             else:
                 allb.copy_(blk)
             vol.boundary_unpack_blocks(allb.data_ptr(), max(world, 1), rank, cap, join_dirty=join_dirty)
+
+    def torch_exchange_sized():
+        """The per-frame exchange of the textured unit through torch.distributed in its SIZED neighbour form: the four
+        block capacities come from the frame's own selection (tf_boundary_band_bounds: the same numbers on both ends of
+        every transfer), so a block is as long as what the frame can have changed."""
+        from texturefusion_amd import exchange
+        sd, su, rb, ra = vol.boundary_band_bounds(cap)
+        with torch.cuda.stream(s_main):
+            vol.boundary_pack_bands2(blk_dn.data_ptr(), sd, blk_up.data_ptr(), su)
+            nd, nu = capi.boundary_block_bytes(sd), capi.boundary_block_bytes(su)
+            if world > 1:
+                s_main.synchronize()  # (gloo moves host copies; RCCL inside the library needs none of this)
+                below, above = exchange.neighbour_exchange_sized(blk_dn[:nd].cpu(), blk_up[:nu].cpu(),
+                                                                 capi.boundary_block_bytes(rb), capi.boundary_block_bytes(ra))
+                below, above = below.to(dev), above.to(dev)
+                torch_wire[0] += (nd if rank > 0 else 0) + (nu if rank + 1 < world else 0)
+                torch_wire[1] += (below.numel() if rank > 0 else 0) + (above.numel() if rank + 1 < world else 0)
+            else:
+                below = torch.zeros(16, dtype=torch.uint8, device=dev)
+                above = torch.zeros(16, dtype=torch.uint8, device=dev)
+            vol.boundary_unpack_pair(below.data_ptr(), rb, above.data_ptr(), ra, join_dirty=True)
+            s_main.synchronize()  # (below / above are temporaries)
 
     def run(first, count, ahead=2):
         """Frames [first, first+count) of the stream (cyclic over the orbit), images already in HBM; the next `ahead`
@@ -286,7 +311,7 @@ def main():
                 sub = idx[j:j + 1 + min(2, count + ahead - j - 1)]
                 vol.stream_frames_device([d_depth[i].data_ptr() for i in sub], [d_rgba[i].data_ptr() for i in sub],
                                          poses[sub], n_ahead=len(sub) - 1)
-                torch_exchange(True)
+                torch_exchange_sized()
                 vol.texture_frame_device(pinv[idx[j]], first + j)
         else:  # TSDF only: batches of --exchange-every frames, one exchange behind each
             for b in range(0, count, args.exchange_every):
@@ -304,9 +329,9 @@ def main():
 
     def run_host(first, count):
         """Frames [first, first+count) as HOST images, one tf_integrate_frame_host call per frame (staging copy into
-        pinned memory + H2D inside).  The entry point runs two frames behind the caller (its launch for frame f carries
-        the voxel update of f - 2 next to the selection stages of f - 1 and f), so `count` calls put `count` frames'
-        H2D copies and `count` frames' kernels on the device."""
+        pinned memory + H2D inside).  The entry point runs tf_host_frame_deferral() = four frames behind the caller (its
+        launch for frame f carries the voxel update of f - 4 next to the selection stages of f - 3 and f - 2), so `count`
+        calls put `count` frames' H2D copies and `count` frames' kernels on the device."""
         for j in range(count):
             i = (first + j) % n_unique
             vol.integrate_frame_host(h_depth[i], h_rgba[i], poses[i], pinv[i] if textured else None, first + j)
@@ -324,7 +349,7 @@ def main():
     p0 = pos + Wm  # stream position of the timed window; p0 % ORBIT = its orbit position
     use_host = host_ok and not args.resident_headline
     if use_host:
-        run_host(pos, Wm)  # (leaves the entry point's two-frame pipeline primed)
+        run_host(pos, Wm)  # (leaves the entry point's four-frame pipeline primed)
         barrier()
         t0 = time.perf_counter()
         run_host(p0, K)
@@ -344,9 +369,27 @@ def main():
     pos = p0 + K
     per_rank = None
     if multi:
-        # per rank: its own wall time for the K frames and what the exchange moved (tf_comm_stats)
-        ex_n, ex_bytes = vol.comm_stats() if use_rccl else (0, 0)
-        mine = {"rank": rank, "ms_per_step": 1e3 * dt / K, "exchanges": ex_n, "exchange_bytes_received": ex_bytes}
+        # per rank: its own wall time for the K frames and what the exchange moved (tf_comm_stats_ex: counted since the
+        # volume was made, i.e. over pre-roll + warm-up + timed frames)
+        st = vol.comm_stats_ex()
+        if not use_rccl and textured:
+            st["bytes_sent"], st["bytes_received"] = torch_wire
+        mine = {"rank": rank, "ms_per_step": 1e3 * dt / K, "exchanges": st["exchanges"],
+                "exchange_bytes_sent": st["bytes_sent"], "exchange_bytes_received": st["bytes_received"],
+                "ghost_records_packed": st["records_sent"], "ghost_records_received": st["records_received"],
+                "bytes_received_per_record_received": (st["bytes_received"] / st["records_received"]) if st["records_received"] else None,
+                "exchange_form": "neighbours (sized by the frame's selection)" if st["mode"] == 0 else "all-gather (fixed capacity)",
+                "transport": "RCCL inside the library" if use_rccl else "torch.distributed test hook"}
+        if use_rccl and textured and not args.child:
+            # the same window once more with HIP events around every launch and around the exchange (untimed diagnostic)
+            vol.sync()
+            vol.profile_enable(("integrate", "dirty", "mesh", "xchg"))
+            run(pos, K)
+            vol.sync()
+            pr = vol.profile_get(reset=True)
+            vol.profile_enable(())
+            pos += K
+            mine["event_us_per_step"] = {k: 1e3 * pr[k][0] / K for k in ("integrate", "dirty", "mesh", "xchg") if pr[k][1]}
         gathered = [None] * world if world > 1 else [mine]
         if world > 1:
             dist.all_gather_object(gathered, mine)
@@ -365,6 +408,34 @@ def main():
         if nxt > pos:
             run(pos, nxt - pos)
         pos = nxt
+
+    # ---- the timed window again (same orbit positions, later turns of the steady-state volume): spread of `value` ----
+    repeats = None
+    if not multi and args.repeats > 0:
+        rep = []
+        for _ in range(args.repeats):
+            # land Wm frames ahead of the window, warm the entry point up over them, time the K frames
+            nxt = pos + ((p0 - Wm - pos) % ORBIT)
+            if nxt > pos:
+                run(pos, nxt - pos)
+            pos = nxt
+            (run_host if use_host else run)(pos, Wm)
+            if not use_host:
+                vol.sync()
+            barrier()
+            t1 = time.perf_counter()
+            (run_host if use_host else run)(pos + Wm, K)
+            barrier()
+            rep.append(1e3 * (time.perf_counter() - t1) / K)
+            vol.sync()
+            pos += Wm + K
+        allw = sorted(rep + [1e3 * dt / K])
+        repeats = {"windows": len(allw), "ms_per_step_median": allw[len(allw) // 2] if len(allw) % 2 else 0.5 * (allw[len(allw) // 2 - 1] + allw[len(allw) // 2]),
+                   "ms_per_step_min": allw[0], "ms_per_step_max": allw[-1],
+                   "value_median": 1e3 / (allw[len(allw) // 2] if len(allw) % 2 else 0.5 * (allw[len(allw) // 2 - 1] + allw[len(allw) // 2])),
+                   "value_min": 1e3 / allw[-1], "value_max": 1e3 / allw[0],
+                   "note": "`value` is the FIRST window (the contract's K timed steps); the others time the same %d orbit positions "
+                           "in later turns, each behind its own %d warm-up frames" % (K, Wm)}
 
     # ---- the same orbit positions with the frames already in HBM --------------------------------
     resident = None
@@ -431,14 +502,16 @@ def main():
             "preroll_frames": 0 if args.no_preroll else ORBIT,
             "timed_window": {"first_frame": p0, "orbit_position": p0 % ORBIT, "frames": K},
             "parallelism": ("1 GPU" if world == 1 else
-                            "%d ranks, chunk-range slabs of the key x+y+z of one stream; one fixed-capacity RCCL exchange "
-                            "(blocks of %d records of 8 KiB; neighbour send / receive pairs: the band below to rank - 1, the band above "
-                            "to rank + 1) of the updated ghost-band chunks %s"
-                            % (world, args.exchange_cap,
-                               "after every voxel update, ahead of the mesher" if textured else
-                               "every %d frames" % args.exchange_every)),
+                            "%d ranks, chunk-range slabs of the key x+y+z of one stream; one RCCL exchange (neighbour send / "
+                            "receive pairs: the band below to rank - 1, the band above to rank + 1) of the updated ghost-band "
+                            "chunks %s"
+                            % (world, "after every voxel update, ahead of the mesher, each block sized by the frame's own "
+                               "selection (8-record buckets, at most %d records of 8 KiB)" % args.exchange_cap if textured else
+                               "every %d frames, fixed blocks of %d records" % (args.exchange_every, args.exchange_cap))),
         },
     }
+    if repeats is not None:
+        out["repeats"] = repeats
     if resident is not None:
         out["resident"] = resident
     if per_rank is not None:
@@ -618,9 +691,11 @@ def child_passes(args):
         return None
     K, Wm = args.steps, args.warmup
     pre = 0 if args.no_preroll else args.unique_frames
-    # the host entry point runs two frames behind: the launches inside the parent's timed region are those of the
-    # frames [pre + Wm - 2, pre + Wm + K - 2) of the stream
-    first = max(0, pre + Wm - (0 if args.resident_headline else 2))
+    # the host entry point runs `behind` frames behind its caller (tf_host_frame_deferral: kHostDefer of the build): the
+    # launches inside the parent's timed region are those of the frames [pre + Wm - behind, pre + Wm + K - behind)
+    from texturefusion_amd import capi as _capi
+    behind = 0 if args.resident_headline else _capi.host_frame_deferral()[0]
+    first = max(0, pre + Wm - behind)
     base_cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--child", "--steps", str(K), "--warmup", str(Wm),
                 "--mode", args.mode, "--scene", args.scene, "--res", repr(args.res), "--unique-frames", str(args.unique_frames)]
     base_cmd += (["--hires"] if args.hires else []) + (["--no-preroll"] if args.no_preroll else [])

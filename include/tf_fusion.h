@@ -110,6 +110,7 @@ typedef struct {
 #define TF_PROF_MESH 8
 #define TF_PROF_DIRTY 9
 #define TF_PROF_PATCH_RANK 10
+#define TF_PROF_XCHG 11        /* N > 1: pack -> transport -> unpack of one boundary exchange (tf_comm.cpp) */
 #define TF_PROF_COUNT 12
 typedef struct {
   double ms[TF_PROF_COUNT];       /* summed elapsed time per kernel */
@@ -267,23 +268,35 @@ TF_API int tf_stream_frames_device(tf_volume* v, int64_t n_frames, int64_t n_ahe
  * New patches take their atlas slots in ascending (x, y, z) chunk-id order within a frame (the reference's
  * order is an unordered_map's).  Chisel::meshesToUpdate collects marks until CompressMeshes clears it: a frame
  * that follows frames integrated WITHOUT this unit (tf_stream_frames_device, tf_integrate ...) inherits their
- * marks and meshes / textures everything they touched as well. */
+ * marks and meshes / textures everything they touched as well.
+ * IMAGE LIFETIME: with n_ahead == 0 everything that reads the images is on the stream when the call returns.  With
+ * n_ahead > 0 the caller declares that it keeps feeding this stream, and the texture stage of the LAST integrated frame
+ * (which reads d_rgba[n_frames - 1] and d_depth[n_frames - 1]) is not launched yet: it rides on the next call's first
+ * launch.  Those two images must therefore stay valid and unmodified until the next tf_* call on the handle has
+ * returned -- a device-wide synchronisation (hipDeviceSynchronize, torch.cuda.synchronize) does NOT cover it, tf_sync
+ * does (every non-streaming entry point puts the pending stage on the stream first).  A ring of image buffers needs
+ * n_ahead + 2 slots. */
 TF_API int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int64_t n_ahead,
                                             const float* const* d_depth, const uint8_t* const* d_rgba,
                                             const float* poses12, const float* pose_inv16, int32_t first_frame_id);
 /* MobileFusion::IntegrateFrame (GCFusion/MobileFusion.cpp:223-250) as the reference calls it: HOST images in,
- * one call per frame.  The images go through a ring of five pinned staging / device slots and are uploaded
+ * one call per frame.  The images go through a ring of eight pinned staging / device slots and are uploaded
  * on a second stream, so the H2D of a frame overlaps the kernels of earlier ones and the call returns without
  * synchronising (tf_sync / any state access waits).  Internally the call for frame f launches the integration of
- * frame f - 2 together with the chunk selection of f - 1 and f (the launch pipeline of the streaming entry points,
- * kept alive across calls); every other entry point first integrates the frames still in that pipeline, so the
- * deferral is not observable through this API.  pose_inv16 != NULL runs the textured unit
+ * frame f - 4 together with the chunk selection of f - 3 and f - 2 (the launch pipeline of the streaming entry points,
+ * kept alive across calls; frames f - 1 and f are only staged and copied, so that no launch ever waits for an upload);
+ * every other entry point first integrates the frames still in that pipeline, so the deferral is not observable
+ * through this API -- but it is LATENCY: a live caller sees frame f in the volume only after four more calls (about
+ * 0.4 ms at the bench's rate) or after any synchronising call; the offline loop of main.cpp:272-277 does not care, a
+ * caller that needs every frame at once sets TF_HOST_DEFER=0 (integrate in the call that brings the frame).
+ * tf_host_frame_deferral reports both numbers (frames behind, ring slots; v may be NULL).  pose_inv16 != NULL runs the textured unit
  * (tf_stream_frames_textured_device's per-frame work) with Patch::frameid = frame_id; NULL = TSDF only.
  * tf_host_frame_buffers hands out the pinned slot the NEXT call will upload from: a caller that composes its
  * depth / RGBA images there (and passes these pointers) saves the staging copy. */
 TF_API int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgba, const float pose[12],
                                    const float* pose_inv16, int32_t frame_id);
 TF_API int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba);
+TF_API int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_slots);
 /* The texturing half of the per-frame unit on its own, for the frame integrated last (its images still bound):
  * UpdateMeshes -> CompressMeshes -> GeneratePatches(label = frame_id) -> UpdateAtlas over that frame's dirty
  * chunks.  tf_stream_frames_textured_device == per frame: voxel update, then this.  A multi-GPU host that
@@ -395,6 +408,22 @@ TF_API int tf_boundary_unpack_blocks(tf_volume* v, const void* d_blocks, int32_t
  * (d_block_up); a chunk of a thin slab goes to both.  Valid as the only exchange when every slab is at least
  * a + b + c + 1 keys wide.  Consume a neighbour's block with tf_boundary_unpack_blocks(..., own_block = -1, ...). */
 TF_API int tf_boundary_pack_bands(tf_volume* v, void* d_block_down, void* d_block_up, int64_t cap_records);
+/* The SIZED form of the neighbour exchange: blocks as large as what the frame can have changed, not a fixed capacity.
+ * Every rank runs the same selection, so each one counts -- identically -- the selected chunks of its own two bands and of
+ * the two neighbouring bands it receives (the selection role does it on the device for the frame integrated last by a
+ * streaming entry point).  tf_boundary_band_bounds returns the four record capacities
+ *     bounds = { send_down, send_up, recv_from_below, recv_from_above }
+ * (counts rounded up to multiples of 8, at least 8, at most cap_records): rank r's send_down equals rank r - 1's
+ * recv_from_above by construction, so both sides of a transfer post tf_boundary_block_bytes(bound) bytes without talking
+ * to each other.  Selected chunks are a superset of updated ones, so nothing a frame flagged is left behind; whatever an
+ * EARLIER overflow left flagged rides in the slack or waits (it stays flagged).  tf_boundary_band_bounds waits for the
+ * device to publish the counts (it does not drain the stream).  tf_boundary_pack_bands2 / tf_boundary_unpack_pair are
+ * pack_bands / unpack_blocks with one capacity per block and separately placed blocks.
+ * Replaces nothing in the reference (single process); SURVEY.md s.8e. */
+TF_API int tf_boundary_band_bounds(tf_volume* v, int64_t cap_records, int64_t bounds[4]);
+TF_API int tf_boundary_pack_bands2(tf_volume* v, void* d_block_down, int64_t cap_down, void* d_block_up, int64_t cap_up);
+TF_API int tf_boundary_unpack_pair(tf_volume* v, const void* d_from_below, int64_t cap_below, const void* d_from_above,
+                                   int64_t cap_above, int join_dirty);
 /* RCCL inside the library: one process per GPU.  tf_comm_unique_id on one rank, the 128 bytes
  * distributed by the host's own means, tf_comm_init(rank, nranks, id) on every rank (ncclCommInitRank);
  * tf_exchange_boundary = tf_boundary_pack_block -> ONE ncclAllGather over xGMI on the handle's stream ->
@@ -408,12 +437,20 @@ TF_API int tf_exchange_boundary(tf_volume* v, int64_t cap_records);
 TF_API int tf_comm_exchange_every_frame(tf_volume* v, int64_t cap_records);
 /* How tf_exchange_boundary / the per-frame exchange move the blocks: TF_XCHG_NEIGHBOURS (default) = one grouped
  * ncclSend / ncclRecv pair with the rank below and the rank above (tf_boundary_pack_bands: a rank receives two blocks
- * whatever the number of ranks); TF_XCHG_ALLGATHER = one ncclAllGather of every rank's block (for partitions with slabs
- * thinner than a + b + c + 1 keys).  tf_comm_stats: exchanges run and bytes received by this rank so far. */
+ * whatever the number of ranks); TF_XCHG_ALLGATHER = one ncclAllGather of every rank's block.  The neighbour form
+ * REQUIRES rank r's slab to sit directly above rank r - 1's (key_lo of r == key_hi of r - 1, the same key coefficients on
+ * every rank) and every slab above the lowest to be at least a + b + c + 1 keys wide; the library checks this with one
+ * 32-byte all-gather at the first exchange after tf_comm_init / tf_set_partition_key (a collective: every rank gets
+ * there) and uses the all-gather form on ALL ranks when it does not hold.  The per-frame exchange of the neighbour form
+ * is sized by the frame's selection (tf_boundary_band_bounds above); cap_records is then only the upper limit.
+ * tf_comm_stats: exchanges run and bytes received by this rank so far.  tf_comm_stats_ex (synchronises): out =
+ * { exchanges, bytes sent, bytes received, ghost records written into blocks, ghost records read from received blocks,
+ *   record capacity of the blocks sent, the form in use (TF_XCHG_*), 1 once the partition check has run }. */
 #define TF_XCHG_NEIGHBOURS 0
 #define TF_XCHG_ALLGATHER 1
 TF_API int tf_comm_exchange_mode(tf_volume* v, int mode);
 TF_API int tf_comm_stats(tf_volume* v, int64_t* exchanges, int64_t* bytes_received);
+TF_API int tf_comm_stats_ex(tf_volume* v, int64_t out[8]);
 
 /* ---- texture atlas on device-resident meshes --------------------------------------------
  * Atlas / Patch (Structure/Atlas.{h,cpp}, Structure/Patch.{h,cpp}) as driven by Chisel::GeneratePatches /
@@ -437,6 +474,8 @@ TF_API int tf_keyframe_release(tf_volume* v, int32_t kf_id);
 TF_API int tf_atlas_patch_size(tf_volume* v, int32_t* patch_w, int32_t* patch_h);
 /* Atlas::loc_next */
 TF_API int tf_atlas_loc_next(tf_volume* v, uint64_t* loc_next);
+/* MAX_PATCH_WIDTH x MAX_PATCH_HEIGHT of this volume's texture_buffer (Structure/Atlas.h:29-30; tf_config.atlas_w / _h) */
+TF_API int tf_atlas_size(tf_volume* v, int32_t* atlas_w, int32_t* atlas_h);
 /* ChunkManager::allMeshes[id] = a mesh built by the caller (a host that keeps its own mesher): Mesh::vertices /
  *   normals / colors as 3 f32 per vertex, Mesh::indices, packed by running offsets; creates missing chunks. */
 TF_API int tf_meshes_upload(tf_volume* v, const int32_t* ids, int64_t n, const int64_t* vert_offsets,

@@ -3,6 +3,9 @@
 // IntegrateFrame :223-250) and checks every result against the CPU oracle (test infrastructure).
 // Plain C++14, no Eigen/OpenCV; built with g++ against libtexfusion_hip.so and libtf_oracle.so.
 #include <algorithm>
+#include <iostream>
+#include <fstream>
+#include <sstream>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +21,80 @@
   do {                                                                             \
     if (!(c)) { std::fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } \
   } while (0)
+
+// What initChiselMap's text needs from its surroundings and this image lacks: Eigen (the mirror's constructor takes
+// any vector indexed with (i); the test names its own) and the calibration record of GCSLAM/MultiViewGeometry.h.
+namespace Eigen { typedef chisel::ChunkID Vector3i; }
+namespace MultiViewGeometry {
+struct CameraPara { float c_fx, c_fy, c_cx, c_cy; int width, height; };
+}
+
+// The members of MobileFusion the function touches (GCFusion/MobileFusion.h:62-76) and the function itself:
+// ***the body of initChiselMap below is the reference's text, GCFusion/MobileFusion.h:205-258, verbatim*** --
+// that it compiles against tf_chisel.hpp and configures the volume is the test.
+struct MobileFusion {
+  chisel::ChiselPtr chiselMap;
+  chisel::ProjectionIntegrator projectionIntegrator;
+  chisel::PinholeCamera cameraModel;
+  int chunkSizeX, chunkSizeY, chunkSizeZ;
+  float voxelResolution;
+  bool useColor;
+
+  void initChiselMap(const MultiViewGeometry::CameraPara &camera,
+                     float ipnutVoxelResolution, float farPlaneDist = 3) {
+    float fx = camera.c_fx;
+    float fy = camera.c_fy;
+    float cx = camera.c_cx;
+    float cy = camera.c_cy;
+    int width = camera.width;
+    int height = camera.height;
+
+#if 1
+    float truncationDistConst = 0.001504;
+    float truncationDistLinear = 0.00152;
+    float truncationDistQuad = 0.0019;
+    float truncationDistScale = 6.0;
+#else
+    float truncationDistConst = 0.01;
+    float truncationDistLinear = 0.01;
+    float truncationDistQuad = 0.01;
+    float truncationDistScale = 1.0;
+#endif
+    float weight = 1;
+    bool useCarving = true;
+    float carvingDist = 0.05;
+    float nearPlaneDist = 0.01;
+
+    std::cout << "far plane dist: " << farPlaneDist << std::endl;
+    chunkSizeX = 8;
+    chunkSizeY = 8;
+    chunkSizeZ = 8;
+    voxelResolution = ipnutVoxelResolution;
+    useColor = true;
+
+    chisel::Vec4 truncation(truncationDistQuad, truncationDistLinear,
+                            truncationDistConst, truncationDistScale);
+    chiselMap = chisel::ChiselPtr(
+        new chisel::Chisel(Eigen::Vector3i(chunkSizeX, chunkSizeY, chunkSizeZ),
+                           voxelResolution, useColor));
+
+    projectionIntegrator.SetCentroids(
+        chiselMap->GetChunkManager().GetCentroids());
+    projectionIntegrator.SetTruncator(
+        chisel::TruncatorPtr(new chisel::QuadraticTruncator(
+            truncation(0), truncation(1), truncation(2), truncation(3))));
+    projectionIntegrator.SetWeighter(
+        chisel::WeighterPtr(new chisel::ConstantWeighter(weight)));
+    projectionIntegrator.SetCarvingDist(carvingDist);
+    projectionIntegrator.SetCarvingEnabled(useCarving);
+
+    cameraModel.SetIntrinsics(fx, fy, cx, cy);
+    cameraModel.SetNearPlane(nearPlaneDist);
+    cameraModel.SetFarPlane(farPlaneDist);
+    cameraModel.SetWidth(width);
+    cameraModel.SetHeight(height);
+  }
+};
 
 static void make_frame(int W, int H, float z, int seed, std::vector<float>& depth,
                        std::vector<unsigned char>& rgba, std::vector<float>& quality) {
@@ -46,25 +123,27 @@ static void compare_chunk(chisel::Chisel& ch, tfo_volume* ov, const chisel::Chun
 int main() {
   const int W = 640, H = 480;
   const float res = 0.005f;
-  const int chunkSize[3] = {8, 8, 8};
   tf_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));
   cfg.max_chunks = 1 << 15;
   cfg.atlas_h = 72;
+  chisel::Chisel::DefaultConfig() = &cfg;  // device-side sizing of the volume the reference's 3-argument constructor makes
 
-  // MobileFusion::initChiselMap (GCFusion/MobileFusion.h:205-258)
-  chisel::Chisel chiselMap(chunkSize, res, true, &cfg);
-  chisel::ProjectionIntegrator projectionIntegrator;
-  projectionIntegrator.SetTruncator(chisel::TruncatorPtr(new chisel::QuadraticTruncator(0.0019f, 0.00152f, 0.001504f, 6.0f)));
-  projectionIntegrator.SetWeighter(chisel::WeighterPtr(new chisel::ConstantWeighter(1)));
-  projectionIntegrator.SetCarvingDist(0.05f);
-  projectionIntegrator.SetCarvingEnabled(true);
-  chisel::PinholeCamera cameraModel;
-  cameraModel.SetIntrinsics(525.0f, 525.0f, 319.5f, 239.5f);
-  cameraModel.SetNearPlane(0.01f);
-  cameraModel.SetFarPlane(5.0f);
-  cameraModel.SetWidth(W);
-  cameraModel.SetHeight(H);
+  // MobileFusion::initChiselMap (GCFusion/MobileFusion.h:205-258), the reference's text (above)
+  MobileFusion gcFusion;
+  const MultiViewGeometry::CameraPara camera = {525.0f, 525.0f, 319.5f, 239.5f, W, H};
+  gcFusion.initChiselMap(camera, res, 5.0f);
+  chisel::Chisel& chiselMap = *gcFusion.chiselMap;
+  chisel::ProjectionIntegrator& projectionIntegrator = gcFusion.projectionIntegrator;
+  chisel::PinholeCamera& cameraModel = gcFusion.cameraModel;
+  CHECK(projectionIntegrator.GetCentroids().size() == 512);
+  {
+    float cen[3 * 512];
+    const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    tfo_centroids(ident, res, cen);  // identity pose: the per-pose table IS ChunkManager::centroids
+    for (int i = 0; i < 512; ++i)
+      for (int a = 0; a < 3; ++a) CHECK(projectionIntegrator.GetCentroids()[(size_t)i](a) == cen[a * 512 + i]);
+  }
 
   tfo_volume* ov = tfo_volume_create(res, 1);
 
@@ -382,6 +461,71 @@ int main() {
       for (int c = 0; c < 12; ++c)
         if (c != 5) CHECK(std::memcmp(&gv[12 * (size_t)k + c], &ovx[12 * (size_t)k + c], 4) == 0);
     tfo_atlas_destroy(oa);
+
+    // ---- main.cpp:262-270: SaveAllMeshesToPLY + atlas.SaveTexturedModel -- the files, read back and compared
+    // with the mirrors they were written from (which the blocks above compared with the oracle)
+    {
+      const char* tmp = std::getenv("TF_TEST_TMP");
+      const std::string base = tmp ? tmp : "/tmp";
+      const std::string ply = base + "/OnlineModel_5mm.ply";
+      CHECK(chiselMap.SaveAllMeshesToPLY(ply));
+      size_t tri_verts = 0;
+      for (const auto& it : chiselMap.GetChunkManager().GetAllMeshes()) tri_verts += (size_t)it.second->n_indices;
+      std::ifstream in(ply.c_str());
+      std::string line;
+      size_t header_v = 0, header_f = 0, body = 0;
+      bool in_body = false;
+      while (std::getline(in, line)) {
+        if (in_body) { ++body; continue; }
+        if (line.compare(0, 15, "element vertex ") == 0) header_v = (size_t)std::atol(line.c_str() + 15);
+        if (line.compare(0, 13, "element face ") == 0) header_f = (size_t)std::atol(line.c_str() + 13);
+        if (line == "end_header") in_body = true;
+      }
+      CHECK(header_v == tri_verts && header_f == tri_verts / 3 && body == header_v + header_f && tri_verts > 3000);
+      gcFusion.chiselMap->atlas.SaveTexturedModel(base);
+      // texture_material.png: signature, IHDR of the whole texture_buffer, size of a stored-deflate stream
+      std::ifstream png((base + "/texture_material.png").c_str(), std::ios::binary);
+      unsigned char hd[24];
+      png.read((char*)hd, 24);
+      CHECK(png.gcount() == 24 && hd[1] == 'P' && hd[2] == 'N' && hd[3] == 'G');
+      const uint32_t pw = (uint32_t)hd[16] << 24 | hd[17] << 16 | hd[18] << 8 | hd[19];
+      const uint32_t ph = (uint32_t)hd[20] << 24 | hd[21] << 16 | hd[22] << 8 | hd[23];
+      CHECK(pw == 13824 && ph == (uint32_t)cfg.atlas_h);
+      // texture_model.obj: one v / vt / vn per vertex of every complete patch, one f per triangle; vt of the first
+      // vertex of the first mesh = (texloc + texcoord * ratio) / atlas size, v flipped (Atlas.cpp:124-130,143)
+      size_t want_v = 0, want_f = 0;
+      for (const auto& it : chiselMap.GetChunkManager().GetAllMeshes())
+        if (it.second->m_patch && it.second->m_patch->complete()) { want_v += (size_t)it.second->n_vertices; want_f += (size_t)it.second->n_indices / 3; }
+      std::ifstream obj((base + "/texture_model.obj").c_str());
+      size_t nv_ = 0, nvt = 0, nvn = 0, nf = 0;
+      std::string first_vt;
+      while (std::getline(obj, line)) {
+        if (line.compare(0, 2, "v ") == 0) ++nv_;
+        else if (line.compare(0, 3, "vt ") == 0) { if (!nvt) first_vt = line; ++nvt; }
+        else if (line.compare(0, 3, "vn ") == 0) ++nvn;
+        else if (line.compare(0, 2, "f ") == 0) ++nf;
+      }
+      CHECK(want_v > 1000 && nv_ == want_v && nvt == want_v && nvn == want_v && nf == want_f);
+      for (const auto& it : chiselMap.GetChunkManager().GetAllMeshes()) {
+        if (!(it.second->m_patch && it.second->m_patch->complete())) continue;
+        const chisel::Patch& p = *it.second->m_patch;
+        chisel::Vec2 tex((float)(p.texloc % 13824), (float)(p.texloc / 13824));
+        tex(0) += p.texcoord[0](0) * p.ratio(0);
+        tex(1) += p.texcoord[0](1) * p.ratio(1);
+        tex(0) /= 13824;
+        tex(1) /= (float)cfg.atlas_h;
+        std::ostringstream want;
+        want << std::fixed << std::setprecision(6) << "vt " << tex(0) << " " << 1.0f - tex(1);
+        CHECK(first_vt == want.str());
+        break;
+      }
+      std::ifstream mtl((base + "/texture_model.mtl").c_str());
+      std::getline(mtl, line);
+      CHECK(line == "newmtl demo_texture");
+      // main.cpp:267: Reset() empties the map; the atlas keeps its texels (Chisel.cpp:47-50)
+      gcFusion.chiselMap->Reset();
+      CHECK(chiselMap.GetChunkManager().GetAllMeshes().empty() && chiselMap.GetChunkManager().GetChunkIDs().empty());
+    }
   }
 
   tfo_volume_destroy(ov);

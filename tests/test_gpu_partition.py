@@ -330,3 +330,176 @@ def test_rccl_single_rank_plumbing(gpu_required):
     a.close(); b.close()
     for p in bufs:
         p[0].free(); p[1].free()
+
+
+def test_sized_neighbour_exchange_three_partitions_textured(gpu_required):
+    """The SIZED neighbour exchange (tf_boundary_band_bounds / tf_boundary_pack_bands2 / tf_boundary_unpack_pair) with
+    the textured unit on three consecutive x + y + z slabs of one GPU.  Every rank sizes its four blocks from its own
+    copy of the frame's selection; the test checks that the two sides of every transfer computed the SAME capacity (on a
+    real transport a mismatch is a hang), that nothing overflowed, that the bytes moved stay within 1.5x of what the
+    records need, and that chunks and meshes of the union equal the single volume bit for bit."""
+    cam = synth.Camera()
+    axis, edges = (1, 1, 1), (24, 46)
+    bounds = [-(1 << 31), edges[0], edges[1], (1 << 31) - 1]
+    single = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    parts = [capi.Volume(RES5, cam, max_chunks=1 << 16) for _ in range(3)]
+    for r, v in enumerate(parts):
+        v.set_partition(bounds[r], bounds[r + 1], axis)
+    cap = 4096
+    bb = capi.boundary_block_bytes(cap)
+    out = [[HipBuffer(bb), HipBuffer(bb)] for _ in range(3)]    # [rank][down, up]
+    inn = [[HipBuffer(bb), HipBuffer(bb)] for _ in range(3)]    # [rank][from below, from above]
+    n = 8
+    frames = [synth.room_frame(3 * k, cam, with_quality=False) for k in range(n)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+    wire = 0
+    zero_hdr = np.zeros(16, np.uint8)
+    for k, f in enumerate(frames):
+        T = synth.pose_inverse16(f[3])
+        dd, dr = [bufs[k][0].ptr], [bufs[k][1].ptr]
+        single.stream_frames_textured_device(dd, dr, f[3].reshape(1, 12), T.reshape(1, 16), k)
+        bnd = []
+        for r, v in enumerate(parts):
+            v.stream_frames_device(dd, dr, f[3].reshape(1, 12))
+            bnd.append(v.boundary_band_bounds(cap))
+        for r in range(3):
+            sd, su, rb, ra = bnd[r]
+            assert all(8 <= x <= cap and x % 8 == 0 for x in bnd[r])
+            if r > 0:
+                assert sd == bnd[r - 1][3] and rb == bnd[r - 1][1], (k, r, bnd)   # both ends of a transfer agree
+            if r < 2:
+                assert su == bnd[r + 1][2] and ra == bnd[r + 1][0], (k, r, bnd)
+        for r, v in enumerate(parts):
+            v.boundary_pack_bands2(out[r][0].ptr, bnd[r][0], out[r][1].ptr, bnd[r][1])
+            v.sync()
+        for r in range(3):  # the "wire": exactly tf_boundary_block_bytes(bound) bytes per transfer
+            if r > 0:
+                nb = capi.boundary_block_bytes(bnd[r][0])
+                _copy_d2d(inn[r - 1][1].ptr, out[r][0].ptr, nb); wire += nb
+            else:
+                inn[r][0].from_host(zero_hdr)
+            if r < 2:
+                nb = capi.boundary_block_bytes(bnd[r][1])
+                _copy_d2d(inn[r + 1][0].ptr, out[r][1].ptr, nb); wire += nb
+            else:
+                inn[r][1].from_host(zero_hdr)
+        for r, v in enumerate(parts):
+            v.boundary_unpack_pair(inn[r][0].ptr, bnd[r][2], inn[r][1].ptr, bnd[r][3], join_dirty=True)
+            v.texture_frame_device(T, k)
+            v.sync()    # (raises TF_ERR_CAPACITY if a block overflowed: the bound must hold everything the frame flagged)
+    single.sync()
+    sent = sum(v.comm_stats_ex()["records_sent"] for v in parts)
+    recv = sum(v.comm_stats_ex()["records_received"] for v in parts)
+    # rank 0's down block and rank 2's up block go nowhere (no such neighbour): records_sent counts them, the wire does not
+    assert recv > 300 and sent >= recv
+    # (a cold volume, frames three orbit steps apart: selected / updated is at its largest here, ~1.4, + 8-record buckets;
+    # tools/exp_sized_exchange.py measures the steady-state stream of the bench)
+    assert wire <= 1.6 * recv * capi.TF_BOUNDARY_RECORD_BYTES, (wire, recv)
+    ref_ids = sorted_ids(single.list_chunks())
+    key = {tuple(c): i for i, c in enumerate(ref_ids)}
+    s_ref, w_ref, c_ref = single.get_chunks(ref_ids)
+    ref_m = sorted_ids(single.list_meshes())
+    assert len(ref_m) > 300
+    mvoff, mioff, mV, mN, mC, mI, madj, msimp = single.get_meshes(ref_m)
+    mkey = {tuple(c): i for i, c in enumerate(ref_m)}
+    seen_m, seen_c = set(), set()
+    for r, v in enumerate(parts):
+        lo, hi = bounds[r], bounds[r + 1]
+        ids = v.list_chunks()
+        s, w, c = v.get_chunks(ids)
+        for i, cid in enumerate(ids):
+            t = tuple(int(x) for x in cid)
+            if lo <= sum(t) < hi:
+                assert t in key
+                seen_c.add(t)
+            if t in key:
+                j = key[t]
+                assert np.array_equal(s[i].view(np.uint32), s_ref[j].view(np.uint32)), (r, t)
+                assert np.array_equal(w[i].view(np.uint32), w_ref[j].view(np.uint32)), (r, t)
+                assert np.array_equal(c[i], c_ref[j])
+        pm = sorted_ids(v.list_meshes())
+        voff, ioff, V, N, Cc, I, adj, simp = v.get_meshes(pm)
+        for i, cid in enumerate(pm):
+            t = tuple(int(x) for x in cid)
+            assert lo <= sum(t) < hi and t in mkey and t not in seen_m
+            seen_m.add(t)
+            j = mkey[t]
+            assert np.array_equal(V[voff[i]:voff[i + 1]].view(np.uint32), mV[mvoff[j]:mvoff[j + 1]].view(np.uint32)), (r, t)
+            assert np.array_equal(N[voff[i]:voff[i + 1]].view(np.uint32), mN[mvoff[j]:mvoff[j + 1]].view(np.uint32)), (r, t)
+            assert np.array_equal(I[ioff[i]:ioff[i + 1]], mI[mioff[j]:mioff[j + 1]]), (r, t)
+    assert seen_c == set(key) and seen_m == set(mkey)
+    for v in [single] + parts:
+        v.close()
+    for b in [x for pr in out + inn for x in pr] + [x for p in bufs for x in p]:
+        b.free()
+
+
+def test_pack_bands_overflow_on_one_side_keeps_the_other_block_whole(gpu_required):
+    """A chunk of a thin slab belongs to both bands.  When only ONE block is too small, the other still gets every
+    record its count announces (no counted-but-unwritten record), and what did not fit stays flagged for a retry."""
+    cam = synth.Camera()
+    v = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    v.set_partition(30, 33, (1, 1, 1))  # three keys wide: every owned chunk is in the down band, key 32 also in the up band
+    depth, rgba, q, pose = synth.room_frame(0, cam)
+    v.frame_upload(depth, rgba, None)
+    v.integrate_frame(pose, True)
+    big, small = 4096, 8
+    dn, up = HipBuffer(capi.boundary_block_bytes(big)), HipBuffer(capi.boundary_block_bytes(big))
+    v.boundary_pack_bands2(dn.ptr, big, up.ptr, small)
+    v.sync()
+    n_dn = int(dn.to_host(4).view(np.uint32)[0]); n_up = int(up.to_host(4).view(np.uint32)[0])
+    assert n_dn > 100 and n_up > small
+    rec = dn.to_host(capi.boundary_block_bytes(big))[16:16 + n_dn * capi.TF_BOUNDARY_RECORD_BYTES].reshape(n_dn, -1)
+    ids = rec[:, :12].copy().view(np.int32).reshape(-1, 3)
+    keys = ids.astype(np.int64).sum(1)
+    assert np.all((keys >= 30) & (keys <= 32)) and len({tuple(x) for x in ids.tolist()}) == n_dn   # every record written, once
+    # retry with room: exactly the chunks whose up side did not fit come again (in both blocks: still flagged as a whole)
+    v.boundary_pack_bands2(dn.ptr, big, up.ptr, big)
+    v.sync()
+    n_dn2 = int(dn.to_host(4).view(np.uint32)[0]); n_up2 = int(up.to_host(4).view(np.uint32)[0])
+    assert n_up2 == n_up - small and n_dn2 == n_up2
+    v.boundary_pack_bands2(dn.ptr, big, up.ptr, big)
+    v.sync()
+    assert int(dn.to_host(4).view(np.uint32)[0]) == 0 and int(up.to_host(4).view(np.uint32)[0]) == 0
+    v.close(); dn.free(); up.free()
+
+
+@pytest.mark.parametrize("ahead", [0, 2], ids=["call_by_call", "primed_pipeline"])
+def test_rccl_single_rank_sized_per_frame_exchange(gpu_required, ahead):
+    """The in-library per-frame exchange in its sized form with one rank (what can run without a second GPU): the band
+    counts travel from the selection role to the host (published by the previous exchange's unpack launch when the stream
+    is fed with frames ahead, by a launch of its own otherwise), the blocks are packed with the sized capacities, nothing
+    overflows, and the volume equals one that never exchanged."""
+    cam = synth.Camera()
+    a = capi.Volume(RES5, cam, max_chunks=1 << 15)
+    b = capi.Volume(RES5, cam, max_chunks=1 << 15)
+    for v in (a, b):
+        v.set_partition(20, 48, (1, 1, 1))
+    b.comm_init(0, 1, capi.comm_unique_id())
+    b.comm_exchange_every_frame(2048)
+    n = 6
+    frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(n + ahead)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+    poses = np.stack([f[3].reshape(12) for f in frames])
+    pinv = np.stack([synth.pose_inverse16(f[3]) for f in frames])
+    for k in range(n):
+        idx = list(range(k, k + 1 + ahead))
+        for v in (a, b):
+            v.stream_frames_textured_device([bufs[i][0].ptr for i in idx], [bufs[i][1].ptr for i in idx], poses[idx], pinv[idx], k,
+                                            n_ahead=ahead)
+    a.sync(); b.sync()   # (TF_ERR_CAPACITY here = a sized block was too small)
+    st = b.comm_stats_ex()
+    assert st["exchanges"] == n and st["checked"] == 1 and st["mode"] == 0
+    assert st["records_sent"] > 200          # packed (the single rank has nobody to send to)
+    assert st["bytes_sent"] == 0 and st["bytes_received"] == 0
+    ia, ib = sorted_ids(a.list_chunks()), sorted_ids(b.list_chunks())
+    assert np.array_equal(ia, ib)
+    sa, wa, ca = a.get_chunks(ia[::7]); sb, wb, cb = b.get_chunks(ia[::7])
+    assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32)) and np.array_equal(ca, cb)
+    ma, mb = sorted_ids(a.list_meshes()), sorted_ids(b.list_meshes())
+    assert np.array_equal(ma, mb) and len(ma) > 100
+    ga, gb = a.get_meshes(ma), b.get_meshes(mb)
+    assert np.array_equal(ga[2].view(np.uint32), gb[2].view(np.uint32)) and np.array_equal(ga[5], gb[5])
+    a.close(); b.close()
+    for p in bufs:
+        p[0].free(); p[1].free()

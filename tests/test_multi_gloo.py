@@ -184,7 +184,7 @@ def _pack_bands(vol, ids, needs, lo, hi, cap):
     return out
 
 
-def _worker3(rank, port, out_dir):
+def _worker3(rank, port, out_dir, sized=False):
     import torch
     import torch.distributed as dist
     from oracle import api as O
@@ -211,19 +211,37 @@ def _worker3(rank, port, out_dir):
         needs[own] = nd
         vol.finalize(ids[own], nd, new[own])
         down, up = _pack_bands(vol, ids, needs, lo, hi, cap)
-        below, above = exchange.neighbour_exchange(torch.from_numpy(down), torch.from_numpy(up))
-        two = np.concatenate([below.numpy(), above.numpy()])
+        if sized:
+            # every rank sizes its four blocks from ITS copy of the full selection; gloo rejects a receive whose length
+            # differs from the matching send, so a disagreement between the two sides of a transfer fails here
+            cnt = part.band_counts(ids, lo, hi)
+            b = [part.xchg_bucket(c, cap) for c in cnt]
+            assert int(down[:4].view(np.uint32)[0]) <= b[0] and int(up[:4].view(np.uint32)[0]) <= b[1]  # selected >= updated
+            below, above = exchange.neighbour_exchange_sized(
+                torch.from_numpy(down[:exchange.block_bytes(b[0])].copy()), torch.from_numpy(up[:exchange.block_bytes(b[1])].copy()),
+                exchange.block_bytes(b[2]), exchange.block_bytes(b[3]))
+            moved = (exchange.block_bytes(b[2]) if rank > 0 else 0) + (exchange.block_bytes(b[3]) if rank + 1 < world else 0)
+            bb = exchange.block_bytes(cap)
+            two = np.zeros(2 * bb, np.uint8)
+            two[:len(below)] = below.numpy()
+            two[bb:bb + len(above)] = above.numpy()
+            wire = locals().get("wire", 0) + moved
+        else:
+            below, above = exchange.neighbour_exchange(torch.from_numpy(down), torch.from_numpy(up))
+            two = np.concatenate([below.numpy(), above.numpy()])
+            wire = locals().get("wire", 0) + (rank > 0) * len(down) + (rank + 1 < world) * len(up)
         received += int(below.numpy()[:4].view(np.uint32)[0]) + int(above.numpy()[:4].view(np.uint32)[0])
         _unpack_blocks(vol, two, 2, -1, cap)
     chunks = vol.list_chunks()
     np.savez(os.path.join(out_dir, "n%d.npz" % rank), ids=np.asarray(chunks, np.int32).reshape(-1, 3),
              sdf=np.stack([vol.get_chunk(c)[0] for c in chunks]), w=np.stack([vol.get_chunk(c)[1] for c in chunks]),
-             lo=lo, hi=hi, received=received)
+             lo=lo, hi=hi, received=received, wire=wire)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_three_rank_neighbour_exchange_equals_single_process(tmp_path):
+@pytest.mark.parametrize("sized", [False, True], ids=["fixed_capacity", "sized_by_selection"])
+def test_three_rank_neighbour_exchange_equals_single_process(tmp_path, sized):
     """Slabs [.., e1) [e1, e2) [e2, ..): every rank sends its down band to the rank below and its up band to the rank
     above (two blocks received whatever the number of ranks).  Owned chunks and the ghost copies a rank's mesher would
     read (x in [lo - 1, hi + 1]) equal the single-process volume bit for bit."""
@@ -232,7 +250,7 @@ def test_three_rank_neighbour_exchange_equals_single_process(tmp_path):
     from texturefusion_amd import synth
 
     port = _free_port()
-    mp.spawn(_worker3, args=(port, str(tmp_path)), nprocs=3, join=True)
+    mp.spawn(_worker3, args=(port, str(tmp_path), sized), nprocs=3, join=True)
     res = np.float32(0.01)
     cam = synth.Camera()
     ref = O.Volume(res, O.camera_from(cam), O.default_integrator())
@@ -243,11 +261,12 @@ def test_three_rank_neighbour_exchange_equals_single_process(tmp_path):
         ref.integrate(depth, rgba, None, pose, ids, nd, 1, -1)
         ref.finalize(ids, nd, new)
     ref_ids = {tuple(c) for c in ref.list_chunks()}
-    owned_seen, ghosts_checked, received = set(), 0, 0
+    owned_seen, ghosts_checked, received, wire = set(), 0, 0, 0
     for r in range(3):
         z = np.load(os.path.join(str(tmp_path), "n%d.npz" % r))
         lo, hi = int(z["lo"]), int(z["hi"])
         received += int(z["received"])
+        wire += int(z["wire"])
         for i, cid in enumerate(z["ids"]):
             t = tuple(int(x) for x in cid)
             mine = lo <= t[0] < hi
@@ -264,3 +283,8 @@ def test_three_rank_neighbour_exchange_equals_single_process(tmp_path):
             assert np.array_equal(s_.view(np.uint32), z["sdf"][i].view(np.uint32)), (r, t, mine)
             assert np.array_equal(w.view(np.uint32), z["w"][i].view(np.uint32)), (r, t, mine)
     assert owned_seen == ref_ids and ghosts_checked > 20 and received > 20
+    if sized:  # what moved is proportional to what changed (8-record buckets on a small scene: allow 2x + one bucket each)
+        from texturefusion_amd import exchange
+        assert wire <= 2.0 * received * exchange.RECORD_BYTES + 12 * exchange.block_bytes(8), (wire, received)
+    else:
+        assert wire > 4 * received * 8208   # the fixed blocks this replaces

@@ -25,7 +25,7 @@ TF_ERR_MISSING_CHUNK = -6
 TF_BOUNDARY_RECORD_BYTES = 16 + 4096 + 4096
 
 PROF_NAMES = ("bbox", "select", "scan", "emit", "integrate", "finalize", "patch_project",
-              "atlas_blit", "mesh", "dirty", "patch_rank", "spare")
+              "atlas_blit", "mesh", "dirty", "patch_rank", "xchg")
 
 # every symbol include/tf_fusion.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
@@ -37,17 +37,24 @@ SYMBOLS = (
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
     "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_profile_calibrate", "tf_keyframe_unit_device", "tf_keyframe_unit_release", "tf_keyframe_unit_stats", "tf_observations_record", "tf_observations_retract", "tf_export_datacost", "tf_export_adjacency", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_set_pose",
-    "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_meshes_upload",
+    "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_atlas_size", "tf_meshes_upload",
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
     "tf_patches_download", "tf_atlas_download_rows", "tf_stream_frames_device",
     "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host",
-    "tf_host_frame_buffers", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_comm_exchange_mode", "tf_comm_stats",
+    "tf_host_frame_buffers", "tf_host_frame_deferral", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_boundary_band_bounds", "tf_boundary_pack_bands2", "tf_boundary_unpack_pair", "tf_comm_exchange_mode", "tf_comm_stats", "tf_comm_stats_ex",
     "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
     "tf_comm_exchange_every_frame",
     "tf_update_meshes", "tf_check_summaries", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
     "tf_pre_normal_map", "tf_pre_refine_depth_normal", "tf_pre_color_valid", "tf_pre_color_quality",
     "tf_pre_refine_newframe", "tf_pre_refine_keyframe", "tf_pre_frame_depth", "tf_integrate_depth_group", "tf_integrate_depth_group_host",
 )
+
+
+def host_frame_deferral():
+    """(frames tf_integrate_frame_host runs behind its caller, staging slots of its ring) -- needs no GPU"""
+    a, b = C.c_int32(0), C.c_int32(0)
+    lib().tf_host_frame_deferral(None, C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 class TFError(RuntimeError):
@@ -153,6 +160,7 @@ def lib():
     L.tf_keyframe_set_pose.argtypes = [vp, C.c_int32, fp]
     L.tf_keyframe_release.argtypes = [vp, C.c_int32]
     L.tf_atlas_patch_size.argtypes = [vp, i32p, i32p]
+    L.tf_atlas_size.argtypes = [vp, i32p, i32p]
     L.tf_atlas_loc_next.argtypes = [vp, u64p]
     L.tf_meshes_upload.argtypes = [vp, i32p, C.c_int64, i64p, i64p, fp, fp, fp, C.POINTER(C.c_uint32)]
     L.tf_generate_patches.argtypes = [vp, i32p, C.c_int64, i32p, u64p]
@@ -167,11 +175,16 @@ def lib():
     L.tf_get_texture_stats.argtypes = [vp, C.POINTER(TextureStats)]
     L.tf_integrate_frame_host.argtypes = [vp, fp, u8p, fp, fp, C.c_int32]
     L.tf_host_frame_buffers.argtypes = [vp, C.POINTER(fp), C.POINTER(u8p)]
+    L.tf_host_frame_deferral.argtypes = [vp, i32p, i32p]
     L.tf_texture_frame_device.argtypes = [vp, fp, C.c_int32]
     L.tf_boundary_block_bytes.restype = C.c_size_t
     L.tf_boundary_block_bytes.argtypes = [C.c_int64]
     L.tf_boundary_pack_block.argtypes = [vp, vp, C.c_int64]
     L.tf_boundary_pack_bands.argtypes = [vp, vp, vp, C.c_int64]
+    L.tf_boundary_band_bounds.argtypes = [vp, C.c_int64, i64p]
+    L.tf_boundary_pack_bands2.argtypes = [vp, vp, C.c_int64, vp, C.c_int64]
+    L.tf_boundary_unpack_pair.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_int]
+    L.tf_comm_stats_ex.argtypes = [vp, i64p]
     L.tf_comm_exchange_mode.argtypes = [vp, C.c_int]
     L.tf_comm_stats.argtypes = [vp, i64p, i64p]
     L.tf_boundary_unpack_blocks.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int64, C.c_int]
@@ -612,6 +625,32 @@ class Volume:
     def boundary_pack_bands(self, d_block_down, d_block_up, cap):
         """the ghost band as two blocks: what the rank below / the rank above reads"""
         self._ck(self.L.tf_boundary_pack_bands(self.h, C.c_void_p(d_block_down), C.c_void_p(d_block_up), cap))
+
+    def host_frame_deferral(self):
+        """(frames tf_integrate_frame_host runs behind its caller, staging slots of its ring)"""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._ck(self.L.tf_host_frame_deferral(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def boundary_band_bounds(self, cap):
+        """record capacities (send_down, send_up, recv_from_below, recv_from_above) of the sized neighbour exchange for
+        the frame integrated last: the same numbers on both sides of every transfer, from the frame's own selection"""
+        out = (C.c_int64 * 4)()
+        self._ck(self.L.tf_boundary_band_bounds(self.h, cap, out))
+        return tuple(int(x) for x in out)
+
+    def boundary_pack_bands2(self, d_block_down, cap_down, d_block_up, cap_up):
+        self._ck(self.L.tf_boundary_pack_bands2(self.h, C.c_void_p(d_block_down), cap_down, C.c_void_p(d_block_up), cap_up))
+
+    def boundary_unpack_pair(self, d_from_below, cap_below, d_from_above, cap_above, join_dirty=True):
+        self._ck(self.L.tf_boundary_unpack_pair(self.h, C.c_void_p(d_from_below), cap_below, C.c_void_p(d_from_above),
+                                                cap_above, 1 if join_dirty else 0))
+
+    def comm_stats_ex(self):
+        out = (C.c_int64 * 8)()
+        self._ck(self.L.tf_comm_stats_ex(self.h, out))
+        return dict(zip(("exchanges", "bytes_sent", "bytes_received", "records_sent", "records_received", "bound_records",
+                         "mode", "checked"), (int(x) for x in out)))
 
     def comm_exchange_mode(self, mode):
         """0 = neighbour send / receive pairs (default), 1 = all-gather"""

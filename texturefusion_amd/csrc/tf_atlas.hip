@@ -757,6 +757,13 @@ int tf_atlas_patch_size(tf_volume* v, int32_t* pw, int32_t* ph) {
   return TF_OK;
 }
 
+int tf_atlas_size(tf_volume* v, int32_t* aw, int32_t* ah) {
+  if (!v || !aw || !ah) { set_error("null argument"); return TF_ERR_INVALID; }
+  *aw = v->atlas.aw;
+  *ah = v->atlas.ah;
+  return TF_OK;
+}
+
 int tf_atlas_loc_next(tf_volume* v, uint64_t* loc_next) {
   if (!v || !loc_next) { set_error("null argument"); return TF_ERR_INVALID; }
   TF_DEV(v);

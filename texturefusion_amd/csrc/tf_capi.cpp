@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <sched.h>
 #include <limits>
 
@@ -167,6 +168,11 @@ static int init_device_state(tf_volume* v) {
   v->mesh_epoch = 0;
   v->mesh_par = 0;
   v->n_primed = 0;
+  v->xchg_pub_enq = 0;
+  if (v->h_xchg) {  // epochs start over: a tag of the old numbering must not be mistaken for a new frame's
+    TF_HIP(hipStreamSynchronize(s));
+    memset(v->h_xchg, 0, 64);
+  }
   return TF_OK;
 }
 
@@ -181,9 +187,36 @@ static void discard_primed(tf_volume* v) {
     launch_reset_ctl(d, false, v->stream);
   }
   v->n_primed = 0;
+  v->xchg_pub_enq = 0;  // (band counts published for a discarded selection are stale)
 }
 
 }  // namespace tf (the two functions below are shared with tf_unit.hip: declared in tf_volume.h)
+int tf::xchg_band_counts(tf_volume* v, const tf::FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]) {
+  using namespace tf;
+  if (!v->h_xchg) {
+    TF_HIP(hipHostMalloc((void**)&v->h_xchg, 64, hipHostMallocDefault));
+    memset(v->h_xchg, 0, 64);
+  }
+  if (v->xchg_pub_enq != tag) {  // nobody published this frame's counts behind an earlier exchange: do it now
+    launch_xchg_publish(ctl, v->h_xchg, tag, v->stream);
+    TF_HIP(hipGetLastError());
+    v->xchg_pub_enq = tag;
+  }
+  // the publishing launch sits behind the selection on the stream; the words arrive with a system-scope release
+  volatile uint32_t* w = v->h_xchg;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spin = 0; __atomic_load_n(&w[0], __ATOMIC_ACQUIRE) != tag; ++spin) {
+    if ((spin & 0xFFFu) == 0xFFFu) {
+      if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+        set_error("band counts of the frame never arrived (device stalled?)");
+        return TF_ERR_HIP;
+      }
+      std::this_thread::yield();
+    }
+  }
+  for (int q = 0; q < 4; ++q) cnt[q] = w[1 + q];
+  return TF_OK;
+}
 int tf::launch_prepare(tf_volume* v, const tf::Pose& pose, bool with_acquire, hipStream_t s) {
   using namespace tf;
   if (!s) s = v->stream;
@@ -274,6 +307,13 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   if (cfg) v->cfg = *cfg;
   if (v->cfg.max_chunks <= 0) v->cfg.max_chunks = 1ll << 20;
   v->cfg.max_chunks = (v->cfg.max_chunks + 63) & ~63ll;  // 64 allocation stripes
+  if (v->cfg.max_chunks > (1ll << kPlOvfShift)) {
+    // pool slots travel in 21 bits of the fused flow's patch-list entries (tf_device.h: kPlOvfShift); a larger pool
+    // would have its slots truncated there.  2^21 chunks = 16 GiB of voxels + 42 GiB of mesh store.
+    set_error("tf_config.max_chunks must not exceed 2^21 (2097152): pool slots are 21-bit fields of the patch lists");
+    delete v;
+    return TF_ERR_INVALID;
+  }
   if (v->cfg.max_list <= 0) v->cfg.max_list = 1ll << 19;
   if (v->cfg.max_coarse <= 0) v->cfg.max_coarse = 1ll << 20;
   if (v->cfg.atlas_w <= 0) v->cfg.atlas_w = 13824;
@@ -386,6 +426,8 @@ int tf_volume_destroy(tf_volume* v) {
   if (v->h_pinned) hipHostFree(v->h_pinned);
   if (v->h_progress) hipHostFree(v->h_progress);
   v->h_progress = nullptr;
+  if (v->h_xchg) hipHostFree(v->h_xchg);
+  v->h_xchg = nullptr;
   for (int k = 0; k < tf_volume::kHostRing; ++k) {
     if (v->hslot[k].h) hipHostFree(v->hslot[k].h);
     if (v->hslot[k].d) hipFree(v->hslot[k].d);
@@ -718,7 +760,7 @@ int tf::fused_arm(tf_volume* v) {
 // claimed: the dirty set of this frame is already in the lists of the current parity -- K-A built it (FrameStage::claim_par
 // = the parity used here), or the caller ran launch_dirty_frame over each of its lists (the keyframe unit)
 int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
-                      const float* pose_inv16, int32_t frame_id, bool claimed) {
+                      const float* pose_inv16, int32_t frame_id, bool claimed, const FrameCtl* next_ctl) {
   AtlasState& a = v->atlas;
   int rc = patch_flush(v);  // (a stage still pending here must read its meshes before this frame's mesher rewrites them)
   if (rc) return rc;
@@ -739,7 +781,8 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
   else launch_dirty_frame(d, par, frame_epoch + 1u, v->stream);
   prof_end(v);
   if (v->comm_cap > 0) {  // multi-GPU: ghost bands of this frame's updates, before the mesher reads them
-    rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u);
+    // (sized by this frame's selection: sel.ctl holds the band counts, tagged with the frame's epoch + 1)
+    rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u, sel.ctl, frame_epoch + 1u, next_ctl);
     if (rc) return rc;
   }
   prof_begin(v, TF_PROF_MESH);
@@ -836,6 +879,7 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
       launch_reset_ctl(d, false, v->stream);
     }
     primed = 0;
+    v->xchg_pub_enq = 0;
   }
   v->n_primed = 0;
   // a primed frame 0 has its list (K-B and K-C ran), a primed frame 1 its bounding box (K-B ran)
@@ -872,7 +916,9 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     if (hc) prof_end(v);
     if (carry) { int rc = patch_launched(v); if (rc) return rc; }
     if (hc && tex) {
-      int rc = texture_stage(v, cur.sel, cur.img, cur.epoch, tex->pose_inv16 + 16 * i, tex->first_frame_id + (int32_t)i, claimed);
+      // (the next frame's selection role rode on this launch: its band counts can be published behind this frame's exchange)
+      int rc = texture_stage(v, cur.sel, cur.img, cur.epoch, tex->pose_inv16 + 16 * i, tex->first_frame_id + (int32_t)i, claimed,
+                             hn ? nxt.sel.ctl : nullptr);
       if (rc) return rc;
     }
   }
@@ -1032,6 +1078,14 @@ static int host_ring_prepare(tf_volume* v) {
   }
   v->hslot_pixels = npix;
   v->hslot_next = 0;
+  return TF_OK;
+}
+
+int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_slots) {
+  (void)v;  // (constants of the build + the TF_HOST_DEFER knob; a null handle is fine)
+  static const bool defer = !(getenv("TF_HOST_DEFER") && !atoi(getenv("TF_HOST_DEFER")));
+  if (frames_behind) *frames_behind = defer ? tf_volume::kHostDefer : 0;
+  if (ring_slots) *ring_slots = tf_volume::kHostRing;
   return TF_OK;
 }
 
@@ -1562,6 +1616,7 @@ int tf_set_partition_key(tf_volume* v, int32_t a, int32_t b, int32_t c, int32_t 
     return TF_ERR_INVALID;
   }
   discard_primed(v);  // (the fused selection drops chunks outside the slab)
+  v->comm.checked = false;  // the neighbour form of the exchange is re-validated against the new slabs
   v->dev.part_lo = key_lo;
   v->dev.part_hi = key_hi;
   v->dev.part_a = a; v->dev.part_b = b; v->dev.part_c = c;
@@ -1602,29 +1657,43 @@ int tf_boundary_pack_block(tf_volume* v, void* d_block, int64_t cap_records) {
   uint8_t* blk = reinterpret_cast<uint8_t*>(d_block);
   TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
   launch_boundary_pack(v->dev, blk + 16, (uint32_t)cap_records, v->stream);
+  launch_boundary_headers(v->dev, reinterpret_cast<uint32_t*>(blk), (uint32_t)cap_records, nullptr, 0, v->stream);  // the count travels in-band
   TF_HIP(hipGetLastError());
-  TF_HIP(hipMemcpyAsync(blk, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));  // the count travels in-band
   return TF_OK;
 }
 
-int tf_boundary_pack_bands(tf_volume* v, void* d_block_down, void* d_block_up, int64_t cap_records) {
+int tf_boundary_pack_bands2(tf_volume* v, void* d_block_down, int64_t cap_down, void* d_block_up, int64_t cap_up) {
   if (!v || !d_block_down || !d_block_up) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (cap_down < 0 || cap_up < 0) { set_error("negative capacity"); return TF_ERR_INVALID; }
   TF_DEV(v);
   uint8_t* dn = reinterpret_cast<uint8_t*>(d_block_down);
   uint8_t* up = reinterpret_cast<uint8_t*>(d_block_up);
   TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
   TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp2, 0, 4, v->stream));
-  launch_boundary_pack_bands(v->dev, dn + 16, up + 16, (uint32_t)cap_records, v->stream);
+  launch_boundary_pack_bands(v->dev, dn + 16, up + 16, (uint32_t)cap_down, (uint32_t)cap_up, v->stream);
+  launch_boundary_headers(v->dev, reinterpret_cast<uint32_t*>(dn), (uint32_t)cap_down, reinterpret_cast<uint32_t*>(up),
+                          (uint32_t)cap_up, v->stream);  // the counts travel in-band
   TF_HIP(hipGetLastError());
-  TF_HIP(hipMemcpyAsync(dn, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));  // the counts travel in-band
-  TF_HIP(hipMemcpyAsync(up, &v->dev.vctl->n_tmp2, 4, hipMemcpyDeviceToDevice, v->stream));
   return TF_OK;
 }
 
-int tf_boundary_unpack_blocks(tf_volume* v, const void* d_blocks, int32_t n_blocks, int32_t own_block,
-                              int64_t cap_records, int join_dirty) {
-  if (!v || !d_blocks) { set_error("null argument"); return TF_ERR_INVALID; }
+int tf_boundary_pack_bands(tf_volume* v, void* d_block_down, void* d_block_up, int64_t cap_records) {
+  return tf_boundary_pack_bands2(v, d_block_down, cap_records, d_block_up, cap_records);
+}
+
+int tf_boundary_band_bounds(tf_volume* v, int64_t cap_records, int64_t bounds[4]) {
+  if (!v || !bounds) { set_error("null argument"); return TF_ERR_INVALID; }
   TF_DEV(v);
+  // the frame integrated last by a streaming entry point: its selection set is the current one, its epoch v->epoch - 1
+  uint32_t cnt[4];
+  int rc = xchg_band_counts(v, v->dev.sel.ctl, v->epoch, cnt);
+  if (rc) return rc;
+  for (int q = 0; q < 4; ++q) bounds[q] = xchg_bucket(cnt[q], cap_records);
+  return TF_OK;
+}
+
+static int unpack_blocks(tf_volume* v, const void* d_blocks, int32_t n_blocks, int32_t own_block, int64_t cap_records,
+                         int join_dirty, const void* d_block_b, int64_t cap_b) {
   VolumeDev d = v->dev;
   int par = -1;
   if (join_dirty) {  // the ghosts belong to the frame integrated last; its texture stage has not run yet
@@ -1635,10 +1704,25 @@ int tf_boundary_unpack_blocks(tf_volume* v, const void* d_blocks, int32_t n_bloc
     d.work_slot = v->atlas.d_work_slot + (size_t)par * d.max_chunks;
   }
   launch_boundary_unpack_blocks(d, reinterpret_cast<const uint8_t*>(d_blocks), n_blocks, own_block,
-                                (uint32_t)cap_records, par, v->epoch, v->stream);
+                                (uint32_t)cap_records, par, v->epoch, v->stream, reinterpret_cast<const uint8_t*>(d_block_b),
+                                (uint32_t)cap_b);
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
   return TF_OK;
+}
+
+int tf_boundary_unpack_blocks(tf_volume* v, const void* d_blocks, int32_t n_blocks, int32_t own_block,
+                              int64_t cap_records, int join_dirty) {
+  if (!v || !d_blocks) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  return unpack_blocks(v, d_blocks, n_blocks, own_block, cap_records, join_dirty, nullptr, 0);
+}
+
+int tf_boundary_unpack_pair(tf_volume* v, const void* d_from_below, int64_t cap_below, const void* d_from_above,
+                            int64_t cap_above, int join_dirty) {
+  if (!v || !d_from_below || !d_from_above) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  return unpack_blocks(v, d_from_below, 2, -1, cap_below, join_dirty, d_from_above, cap_above);
 }
 
 int tf_boundary_unpack(tf_volume* v, const void* d_records, int64_t n_records) {

@@ -15,6 +15,8 @@
 #include <rccl/rccl.h>
 #include <string.h>
 
+#include <vector>
+
 #include "tf_volume.h"
 
 namespace tf {
@@ -66,6 +68,37 @@ static int rccl_load() {
     }                                                                                                   \
   } while (0)
 
+// The neighbour form moves a band only to the adjacent rank, which is right when (1) rank r's slab sits directly above
+// rank r - 1's (lo_r == hi_{r-1}, same key coefficients everywhere) and (2) every slab above the lowest is at least
+// a + b + c + 1 keys wide, so that no band reaches past the adjacent slab.  One 32-byte all-gather of {lo, hi, a, b, c} decides it for all
+// ranks alike; when it does not hold every rank uses the all-gather form (works for any partition).
+static int comm_check_partition(tf_volume* v) {
+  CommState& c = v->comm;
+  ncclComm_t comm = reinterpret_cast<ncclComm_t>(c.comm);
+  const int n = c.nranks;
+  int32_t mine[8] = {v->dev.part_lo, v->dev.part_hi, v->dev.part_a, v->dev.part_b, v->dev.part_c, 0, 0, 0};
+  int32_t* d_buf = nullptr;
+  TF_HIP(hipMalloc((void**)&d_buf, sizeof(mine) * (size_t)(n + 1)));
+  TF_HIP(hipMemcpyAsync(d_buf, mine, sizeof(mine), hipMemcpyHostToDevice, v->stream));
+  TF_NCCL(g_rccl.AllGather(d_buf, d_buf + 8, sizeof(mine), ncclUint8, comm, v->stream));
+  std::vector<int32_t> all((size_t)8 * n);
+  TF_HIP(hipMemcpyAsync(all.data(), d_buf + 8, sizeof(mine) * (size_t)n, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  hipFree(d_buf);
+  bool ok = true;
+  for (int r = 0; r < n; ++r) {
+    const int32_t* p = &all[(size_t)8 * r];
+    const long long w = (long long)p[2] + p[3] + p[4];
+    if (p[2] != mine[2] || p[3] != mine[3] || p[4] != mine[4]) ok = false;
+    if (r > 0 && p[0] != all[(size_t)8 * (r - 1) + 1]) ok = false;                       // contiguous, in rank order
+    // a slab with a rank below it holds its whole down band (and stops the reads of the rank two below): >= w + 1 keys
+    if ((long long)p[1] - (long long)p[0] < (r > 0 ? w + 1 : 1)) ok = false;
+  }
+  c.neighbours_ok = ok;
+  c.checked = true;
+  return TF_OK;
+}
+
 static int comm_buffers(tf_volume* v, int64_t cap_records) {
   CommState& c = v->comm;
   const size_t block = tf_boundary_block_bytes(cap_records);
@@ -80,9 +113,17 @@ static int comm_buffers(tf_volume* v, int64_t cap_records) {
   return TF_OK;
 }
 
-// pack -> all-gather -> unpack on the handle's stream; dirty_par >= 0: the owned face neighbours of every ghost
-// chunk that arrives join the fused flow's per-frame dirty list (their neighbour was updated on another rank)
-int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t stamp) {
+// pack -> transport -> unpack on the handle's stream; dirty_par >= 0: the owned face neighbours of every ghost
+// chunk that arrives join the fused flow's per-frame dirty list (their neighbour was updated on another rank).
+// ctl != nullptr (the per-frame exchange of the fused flow, neighbour form): the blocks are SIZED by the frame's own
+// selection -- FrameCtl::band_cnt holds, identically on every rank, how many selected chunks lie in this rank's two
+// bands and in the two neighbouring bands it receives; selected is a superset of updated, so a block of
+// xchg_bucket(count) records holds everything the frame flagged, and sender and receiver agree on every size without
+// talking to each other.  The counts reach the host through a pinned word the previous exchange's unpack launch (or a
+// launch of its own) publishes; nothing else synchronises.  Without ctl (tf_exchange_boundary on demand, all-gather
+// form) the blocks have the caller's fixed capacity.
+int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t stamp, const FrameCtl* ctl, uint32_t tag,
+                  const FrameCtl* next_ctl) {
   CommState& c = v->comm;
   if (!c.comm) { set_error("tf_comm_init has not been called"); return TF_ERR_INVALID; }
   int rc = comm_buffers(v, cap_records);
@@ -92,43 +133,76 @@ int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t sta
   uint8_t* send = reinterpret_cast<uint8_t*>(c.d_send);
   uint8_t* recv = reinterpret_cast<uint8_t*>(c.d_recv);
   int nblocks = c.nranks, skip = c.rank;
-  const bool neighbours = c.mode == TF_XCHG_NEIGHBOURS && g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd;
-  if (neighbours) {
-    // down block -> rank - 1, up block -> rank + 1; from rank - 1 comes ITS up block, from rank + 1 its down block.
-    // A missing neighbour's receive slot keeps a zero count.
-    rc = tf_boundary_pack_bands(v, send, send + block, c.cap_records);
+  bool neighbours = c.mode == TF_XCHG_NEIGHBOURS && g_rccl.Send && g_rccl.Recv && g_rccl.GroupStart && g_rccl.GroupEnd;
+  if (neighbours && !c.checked) {  // slabs wide enough and in rank order?  (one tiny all-gather, once per partition)
+    rc = comm_check_partition(v);
     if (rc) return rc;
-    const bool lower = c.rank > 0, upper = c.rank + 1 < c.nranks;
-    if (!lower) TF_HIP(hipMemsetAsync(recv, 0, 16, v->stream));
-    if (!upper) TF_HIP(hipMemsetAsync(recv + block, 0, 16, v->stream));
-    if (lower || upper) {
-      TF_NCCL(g_rccl.GroupStart());
-      if (lower) {
-        TF_NCCL(g_rccl.Send(send, block, ncclUint8, c.rank - 1, comm, v->stream));
-        TF_NCCL(g_rccl.Recv(recv, block, ncclUint8, c.rank - 1, comm, v->stream));
-      }
-      if (upper) {
-        TF_NCCL(g_rccl.Send(send + block, block, ncclUint8, c.rank + 1, comm, v->stream));
-        TF_NCCL(g_rccl.Recv(recv + block, block, ncclUint8, c.rank + 1, comm, v->stream));
-      }
-      TF_NCCL(g_rccl.GroupEnd());
-    }
-    nblocks = 2;
-    skip = -1;
-    c.bytes_received += (uint64_t)((lower ? 1 : 0) + (upper ? 1 : 0)) * block;
-  } else {
-    rc = tf_boundary_pack_block(v, send, c.cap_records);
-    if (rc) return rc;
-    TF_NCCL(g_rccl.AllGather(send, recv, block, ncclUint8, comm, v->stream));
-    c.bytes_received += (uint64_t)(c.nranks > 1 ? c.nranks - 1 : 0) * block;
   }
-  c.exchanges += 1;
+  neighbours = neighbours && c.neighbours_ok;
   VolumeDev d = v->dev;
   if (dirty_par >= 0) {
     d.work_ids = v->atlas.d_work_ids + (size_t)dirty_par * d.max_chunks;
     d.work_slot = v->atlas.d_work_slot + (size_t)dirty_par * d.max_chunks;
   }
-  launch_boundary_unpack_blocks(d, recv, nblocks, skip, (uint32_t)c.cap_records, dirty_par, stamp, v->stream);
+  struct ProfScope {  // HIP events around the whole exchange when tf_profile_enable asked for TF_PROF_XCHG
+    tf_volume* v;
+    explicit ProfScope(tf_volume* vv) : v(vv) { prof_begin(v, TF_PROF_XCHG); }
+    ~ProfScope() { prof_end(v); }
+  } prof_scope(v);
+  if (neighbours) {
+    // down block -> rank - 1, up block -> rank + 1; from rank - 1 comes ITS up block, from rank + 1 its down block.
+    // A missing neighbour's receive slot keeps a zero count.
+    uint32_t cap_dn = (uint32_t)c.cap_records, cap_up = cap_dn, cap_lo = cap_dn, cap_hi = cap_dn;
+    if (ctl) {
+      uint32_t cnt[4];
+      rc = xchg_band_counts(v, ctl, tag, cnt);
+      if (rc) return rc;
+      cap_dn = xchg_bucket(cnt[0], c.cap_records); cap_up = xchg_bucket(cnt[1], c.cap_records);
+      cap_lo = xchg_bucket(cnt[2], c.cap_records); cap_hi = xchg_bucket(cnt[3], c.cap_records);
+    }
+    rc = tf_boundary_pack_bands2(v, send, cap_dn, send + block, cap_up);
+    if (rc) return rc;
+    const bool lower = c.rank > 0, upper = c.rank + 1 < c.nranks;
+    if (!lower) TF_HIP(hipMemsetAsync(recv, 0, 16, v->stream));
+    if (!upper) TF_HIP(hipMemsetAsync(recv + block, 0, 16, v->stream));
+    const size_t b_dn = tf_boundary_block_bytes(cap_dn), b_up = tf_boundary_block_bytes(cap_up);
+    const size_t b_lo = tf_boundary_block_bytes(cap_lo), b_hi = tf_boundary_block_bytes(cap_hi);
+    if (lower || upper) {
+      TF_NCCL(g_rccl.GroupStart());
+      if (lower) {
+        TF_NCCL(g_rccl.Send(send, b_dn, ncclUint8, c.rank - 1, comm, v->stream));
+        TF_NCCL(g_rccl.Recv(recv, b_lo, ncclUint8, c.rank - 1, comm, v->stream));
+      }
+      if (upper) {
+        TF_NCCL(g_rccl.Send(send + block, b_up, ncclUint8, c.rank + 1, comm, v->stream));
+        TF_NCCL(g_rccl.Recv(recv + block, b_hi, ncclUint8, c.rank + 1, comm, v->stream));
+      }
+      TF_NCCL(g_rccl.GroupEnd());
+    }
+    c.bytes_received += (uint64_t)(lower ? b_lo : 0) + (uint64_t)(upper ? b_hi : 0);
+    c.bytes_sent += (uint64_t)(lower ? b_dn : 0) + (uint64_t)(upper ? b_up : 0);
+    c.bound_records += (uint64_t)(lower ? cap_dn : 0) + (uint64_t)(upper ? cap_up : 0);
+    c.exchanges += 1;
+    // (the launch that stores the ghosts also tells the host the NEXT frame's band counts: that frame's selection ran
+    // next to this frame's voxel update, so the next exchange finds its sizes waiting)
+    const bool pub = ctl && next_ctl;
+    if (pub && !v->h_xchg) {
+      TF_HIP(hipHostMalloc((void**)&v->h_xchg, 64, hipHostMallocDefault));
+      memset(v->h_xchg, 0, 64);
+    }
+    launch_boundary_unpack_blocks(d, recv, 2, -1, cap_lo, dirty_par, stamp, v->stream, recv + block, cap_hi,
+                                  pub ? next_ctl : nullptr, pub ? v->h_xchg : nullptr, pub ? tag + 1u : 0u);
+    if (pub) v->xchg_pub_enq = tag + 1u;
+  } else {
+    rc = tf_boundary_pack_block(v, send, c.cap_records);
+    if (rc) return rc;
+    TF_NCCL(g_rccl.AllGather(send, recv, block, ncclUint8, comm, v->stream));
+    c.bytes_received += (uint64_t)(c.nranks > 1 ? c.nranks - 1 : 0) * block;
+    c.bytes_sent += (uint64_t)(c.nranks > 1 ? c.nranks - 1 : 0) * block;
+    c.bound_records += (uint64_t)(c.nranks > 1 ? c.cap_records : 0);
+    c.exchanges += 1;
+    launch_boundary_unpack_blocks(d, recv, nblocks, skip, (uint32_t)c.cap_records, dirty_par, stamp, v->stream);
+  }
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
   return TF_OK;
@@ -195,6 +269,23 @@ int tf_comm_stats(tf_volume* v, int64_t* exchanges, int64_t* bytes_received) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
   if (exchanges) *exchanges = (int64_t)v->comm.exchanges;
   if (bytes_received) *bytes_received = (int64_t)v->comm.bytes_received;
+  return TF_OK;
+}
+
+int tf_comm_stats_ex(tf_volume* v, int64_t out[8]) {
+  if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  uint32_t rec[2] = {0, 0};
+  TF_HIP(hipMemcpyAsync(rec, &v->dev.vctl->xchg_sent, 8, hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  out[0] = (int64_t)v->comm.exchanges;
+  out[1] = (int64_t)v->comm.bytes_sent;
+  out[2] = (int64_t)v->comm.bytes_received;
+  out[3] = (int64_t)rec[0];                      // ghost records written into blocks (all pack entry points)
+  out[4] = (int64_t)rec[1];                      // ghost records read out of received blocks
+  out[5] = (int64_t)v->comm.bound_records;       // record capacity of the blocks sent
+  out[6] = v->comm.neighbours_ok ? TF_XCHG_NEIGHBOURS : TF_XCHG_ALLGATHER;  // the form in use (after the first exchange)
+  out[7] = v->comm.checked ? 1 : 0;
   return TF_OK;
 }
 

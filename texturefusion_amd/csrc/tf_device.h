@@ -73,6 +73,12 @@ struct FrameCtl {
   uint32_t pad0;
   unsigned long long emit_pack;  // the selection role's append counters: low word front, high word back entries
   uint32_t pad[2];
+  // multi-GPU, fused flow: selected chunks of this frame per ghost band -- [0] own down band (keys lo .. lo + a + b + c,
+  // read by the rank below), [1] own up band (key hi - 1, read by the rank above), [2] the up band of the rank below
+  // (key lo - 1), [3] the down band of the rank above (keys hi .. hi + a + b + c).  Every rank runs the same selection,
+  // so sender and receiver of a block count the same number: the exchange of the frame is sized by it (selected is a
+  // superset of updated).  Zeroed with emit_pack by the frame's K-B stage.
+  uint32_t band_cnt[4];
   // fused flow: K-A's waves pull their entries from these counters (each 256 B from the next); counter c hands out the
   // logical entries c, c + kKaCounters, ...  Zeroed by the frame's K-B stage, two launches ahead.
   uint32_t ka_next[kKaCounters * kKaCounterStride];
@@ -85,6 +91,8 @@ struct VolCtl {
   uint32_t n_tmp;     // scratch counter of the on-demand list/pack kernels
   uint32_t ovf_next;  // mesh overflow pool: blocks handed out (bump allocation, reset with the volume)
   uint32_t n_tmp2;    // second scratch counter (the "up" block of the two-band boundary pack)
+  uint32_t xchg_sent, xchg_recv;  // ghost records written into / stored from exchange blocks since create (tf_comm_stats_ex)
+  uint32_t xchg_pad[2];
   // Pool slots are handed out from 64 independent stripes (stripe s owns slots
   // [s*max_chunks/64, (s+1)*max_chunks/64)) so that the thousands of chunk creations of a
   // first-touch frame do not serialise on one atomic word.
@@ -313,11 +321,20 @@ void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const f
                           const uint16_t* col, hipStream_t s);
 void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s);
 // two blocks: what the rank below / the rank above reads as ghosts (counts in VolCtl::n_tmp / n_tmp2)
-void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* records_down, uint8_t* records_up, uint32_t cap, hipStream_t s);
+void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* records_down, uint8_t* records_up, uint32_t cap_down,
+                                uint32_t cap_up, hipStream_t s);
+// the blocks' in-band counts (first word of each header) from VolCtl::n_tmp / n_tmp2; hdr_b may be null
+void launch_boundary_headers(const VolumeDev& v, uint32_t* hdr_a, uint32_t cap_a, uint32_t* hdr_b, uint32_t cap_b, hipStream_t s);
+// FrameCtl::band_cnt -> host_words[1..4], then host_words[0] = tag (system-scope release)
+void launch_xchg_publish(const FrameCtl* ctl, uint32_t* host_words, uint32_t tag, hipStream_t s);
 void launch_boundary_unpack(const VolumeDev& v, const uint8_t* records, uint32_t n, hipStream_t s);
 // blocks of [16-B header {count} | cap records] per rank, the block of `skip` is this rank's own
+// (blocks_b: the second of exactly two separately placed blocks with its own capacity; pub_*: also publish the next
+// frame's band counts like launch_xchg_publish)
 void launch_boundary_unpack_blocks(const VolumeDev& v, const uint8_t* blocks, int nblocks, int skip, uint32_t cap,
-                                   int dirty_par, uint32_t stamp, hipStream_t s);
+                                   int dirty_par, uint32_t stamp, hipStream_t s, const uint8_t* blocks_b = nullptr,
+                                   uint32_t cap_b = 0, const FrameCtl* pub_ctl = nullptr, uint32_t* pub_words = nullptr,
+                                   uint32_t pub_tag = 0);
 // Chunk::observations on the device (f-4: what TexMap::update_datacost reads, Structure/TexMap.cpp:64-105)
 void launch_obs_record(const VolumeDev& v, int32_t kf_id, hipStream_t s);                   // Chisel.h:244-247 over the current list
 void launch_obs_retract(const VolumeDev& v, int32_t kf_id, const int4* ids, uint32_t n, hipStream_t s);  // MobileFusion.cpp:252-272

@@ -118,9 +118,10 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
     ctl->n_list = 0;
     ctl->n_front = 0;
     ctl->emit_pack = 0ull;
+    for (int k = 0; k < 4; ++k) ctl->band_cnt[k] = 0u;
     for (int k = 0; k < kKaCounters; ++k) ctl->ka_next[k * kKaCounterStride] = 0u;
     if (vctl) {
-      vctl->status = 0; vctl->n_tmp = 0; vctl->n_tmp2 = 0; vctl->ovf_next = 0;
+      vctl->status = 0; vctl->n_tmp = 0; vctl->n_tmp2 = 0; vctl->ovf_next = 0; vctl->xchg_sent = 0; vctl->xchg_recv = 0;
       for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
     }
   }
@@ -175,6 +176,7 @@ void launch_pack_rgba(const uint8_t* rgb, const uint8_t* valid, uchar4* rgba, ui
 __device__ __forceinline__ void bbox_body(const float* __restrict__ depth, const Cam& cam, const Pose& P,
                                           FrameCtl* ctl, const uint32_t bid, const uint32_t nb) {
   if (bid == 0 && threadIdx.x == 0) { ctl->n_list = 0; ctl->n_front = 0; ctl->emit_pack = 0ull; }  // appended to by k_select<EMIT>
+  if (bid == 0 && threadIdx.x < 4) ctl->band_cnt[threadIdx.x] = 0u;
   if (bid == 0 && threadIdx.x < kKaCounters) ctl->ka_next[threadIdx.x * kKaCounterStride] = 0u;  // K-A of this frame (two launches on) pulls its entries here
   float mn[3] = {1e8f, 1e8f, 1e8f}, mx[3] = {-1e8f, -1e8f, -1e8f};
   const int W = cam.W;
@@ -299,6 +301,8 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
   const int corner = lane & 7;
   const int step = sc.step;
   const uint32_t nzny = (uint32_t)dims[2] * (uint32_t)dims[1];
+  const bool partitioned = EMIT && (v.part_lo != INT32_MIN || v.part_hi != INT32_MAX);
+  const long long band_w = partitioned ? (long long)(v.part_a + v.part_b + v.part_c) : -1ll;
 
   // One wave per coarse block: the 8 corner probes run on lanes 0..7 (replicated 8x), the 64
   // per-chunk tests of a hit block on the 64 lanes (lane = (i-x)*16 + (j-y)*4 + (k-z), i.e. the
@@ -317,7 +321,9 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
     const int z0 = minI[2] - 1 + (int)bz * step;
     if (EMIT) {  // coefficients are >= 0: the block's smallest / largest key sit at opposite corners
       const int kmin = part_key(v, x0, y0, z0), kmax = part_key(v, x0 + step - 1, y0 + step - 1, z0 + step - 1);
-      if (kmax < v.part_lo || kmin >= v.part_hi) continue;
+      // (a partitioned volume also looks at the neighbours' ghost bands -- key lo - 1 below, hi .. hi + a + b + c above --
+      // to count what they will send: FrameCtl::band_cnt)
+      if ((long long)kmax < (long long)v.part_lo - 1ll || (long long)kmin > (long long)v.part_hi + band_w) continue;
     }
     float oc[3];
 #pragma unroll
@@ -337,6 +343,7 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
     bool costly = false;
     if (coarse_hit) {
       bool flag = false;
+      uint32_t band = 0u;
       if (lane < step * step * step) {
         const int di = (step == 4) ? (lane >> 4) : 0;
         const int dj = (step == 4) ? ((lane >> 2) & 3) : 0;
@@ -369,9 +376,23 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         // corners lies between the near and the far edge of the truncation band (all in front of it, or all
         // behind) will most likely rewrite no voxel row
         costly = below && above;
-        if (EMIT) flag = flag && part_owned(v, x0 + di, y0 + dj, z0 + dk);
+        if (EMIT) {
+          const long long k = part_key(v, x0 + di, y0 + dj, z0 + dk);
+          const long long lo = v.part_lo, hi = v.part_hi;
+          if (partitioned && flag)
+            band = (k >= lo && k - lo <= band_w ? 1u : 0u) | (k == hi - 1 ? 2u : 0u) | (k == lo - 1 ? 4u : 0u) |
+                   (k >= hi && k - hi <= band_w ? 8u : 0u);
+          flag = flag && k >= lo && k < hi;
+        }
       }
       m = __ballot(flag);
+      if (partitioned) {  // (wave-uniform; the four counts of FrameCtl::band_cnt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t c = (uint32_t)__popcll(__ballot((band >> q) & 1u));
+          if (c && lane == 0) atomicAdd(&ctl->band_cnt[q], c);
+        }
+      }
     }
     if (!EMIT) {
       if (lane == 0) v.sel.masks[cb] = m;
@@ -1801,7 +1822,8 @@ void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const f
 // `records_up` those the rank ABOVE reads (key == hi - 1); a chunk of a thin slab may go to both.  Slabs are contiguous key
 // ranges, so with every slab at least a + b + c + 1 keys wide these two neighbours are the only readers (part_band).
 template <bool BANDS>
-__global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* records, uint8_t* records_up, uint32_t cap) {
+__global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* records, uint8_t* records_up, uint32_t cap,
+                                                       uint32_t cap_up) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const uint32_t nwaves = gridDim.x * 4;
@@ -1833,8 +1855,12 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
       }
       p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
       q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-      if ((down && p >= cap) || (up && q >= cap)) continue;  // does not fit: the chunk stays flagged, a retry with a larger buffer packs it
-      if (lane == src) v.hent[i].alive = h.alive & 1u;
+      // A side that does not fit is skipped on its own (the other block still gets its record); the chunk stays flagged
+      // until every side that wants it has been written -- a later exchange with room packs it again (the side that
+      // already has it receives an identical or newer copy).
+      const bool fit_down = down && p < cap, fit_up = up && q < cap_up;
+      if (!fit_down && !fit_up) continue;
+      if (lane == src && (fit_down || !down) && (fit_up || !up)) v.hent[i].alive = h.alive & 1u;
       hd.w = (int)v.mark_epoch[slot];  // header: id + the epoch of the chunk's last update (Chisel::meshesToUpdate travels with it)
       const uint4* st = reinterpret_cast<const uint4*>(v.tsdf + (size_t)slot * kChunkVoxels);
       const uint4* sc = reinterpret_cast<const uint4*>(v.color + (size_t)slot * kChunkVoxels);
@@ -1843,7 +1869,7 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
       for (int k = 0; k < 4; ++k) { vt[k] = st[k * 64 + lane]; vc[k] = sc[k * 64 + lane]; }
 #pragma unroll
       for (int side = 0; side < 2; ++side) {
-        if (side == 0 ? !down : !up) continue;
+        if (side == 0 ? !fit_down : !fit_up) continue;
         uint8_t* rec = (side == 0 ? records : records_up) + (size_t)(side == 0 ? p : q) * (16 + 4096 + 4096);
         if (lane == 0) *reinterpret_cast<int4*>(rec) = hd;
         uint4* dt = reinterpret_cast<uint4*>(rec + 16);
@@ -1855,10 +1881,32 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
   }
 }
 void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s) {
-  hipLaunchKernelGGL(k_boundary_pack<false>, dim3(1024), dim3(256), 0, s, v, records, (uint8_t*)nullptr, cap);
+  hipLaunchKernelGGL(k_boundary_pack<false>, dim3(1024), dim3(256), 0, s, v, records, (uint8_t*)nullptr, cap, 0u);
 }
-void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* records_down, uint8_t* records_up, uint32_t cap, hipStream_t s) {
-  hipLaunchKernelGGL(k_boundary_pack<true>, dim3(1024), dim3(256), 0, s, v, records_down, records_up, cap);
+void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* records_down, uint8_t* records_up, uint32_t cap_down,
+                                uint32_t cap_up, hipStream_t s) {
+  hipLaunchKernelGGL(k_boundary_pack<true>, dim3(1024), dim3(256), 0, s, v, records_down, records_up, cap_down, cap_up);
+}
+// The in-band counts of freshly packed blocks (VolCtl::n_tmp / n_tmp2 -> the first word of each block) and the running
+// total of records written (what fitted), for tf_comm_stats_ex.
+__global__ void k_boundary_headers(VolumeDev v, uint32_t* hdr_a, uint32_t cap_a, uint32_t* hdr_b, uint32_t cap_b) {
+  if (threadIdx.x != 0) return;
+  const uint32_t na = v.vctl->n_tmp, nb = hdr_b ? v.vctl->n_tmp2 : 0u;
+  *hdr_a = na;
+  if (hdr_b) *hdr_b = nb;
+  v.vctl->xchg_sent += (na < cap_a ? na : cap_a) + (nb < cap_b ? nb : cap_b);
+}
+void launch_boundary_headers(const VolumeDev& v, uint32_t* hdr_a, uint32_t cap_a, uint32_t* hdr_b, uint32_t cap_b, hipStream_t s) {
+  hipLaunchKernelGGL(k_boundary_headers, dim3(1), dim3(64), 0, s, v, hdr_a, cap_a, hdr_b, cap_b);
+}
+// FrameCtl::band_cnt of a frame whose selection is through -> host-visible memory, the tag last (the host polls it).
+__global__ void k_xchg_publish(const FrameCtl* ctl, uint32_t* host_words, uint32_t tag) {
+  if (threadIdx.x != 0) return;
+  for (int q = 0; q < 4; ++q) __hip_atomic_store(&host_words[1 + q], ctl->band_cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(&host_words[0], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_xchg_publish(const FrameCtl* ctl, uint32_t* host_words, uint32_t tag, hipStream_t s) {
+  hipLaunchKernelGGL(k_xchg_publish, dim3(1), dim3(64), 0, s, ctl, host_words, tag);
 }
 
 // Store received records of chunks this rank does not own as ghost chunks.
@@ -1899,18 +1947,29 @@ void launch_boundary_unpack(const VolumeDev& v, const uint8_t* records, uint32_t
 // skipped.  dirty_par >= 0 (fused textured flow, one exchange per frame): a ghost that arrives was updated on
 // its owner's side in this frame, so its owned face neighbours belong to this frame's dirty set
 // (Chisel.h:197-203) -- they join the work list, de-duplicated by the per-slot stamp like k_dirty_frame's.
+// blocks_b != nullptr: exactly two blocks with their own addresses and capacities (the neighbour form: what came from the
+// rank below, cap records, and from the rank above, cap_b records).  pub_ctl != nullptr: this launch also publishes the
+// band counts of the NEXT frame's selection (already through: it ran next to this frame's voxel update) for the host.
 __global__ __launch_bounds__(512) void k_boundary_unpack_blocks(VolumeDev v, const uint8_t* blocks, int nblocks, int skip,
-                                                                uint32_t cap, int dirty_par, uint32_t stamp) {
+                                                                uint32_t cap, int dirty_par, uint32_t stamp,
+                                                                const uint8_t* blocks_b, uint32_t cap_b,
+                                                                const FrameCtl* pub_ctl, uint32_t* pub_words, uint32_t pub_tag) {
   __shared__ uint32_t sslot;
+  if (pub_ctl && blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int q = 0; q < 4; ++q) __hip_atomic_store(&pub_words[1 + q], pub_ctl->band_cnt[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&pub_words[0], pub_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   const size_t block_bytes = 16 + (size_t)cap * (16 + 4096 + 4096);
   for (int b = 0; b < nblocks; ++b) {
     if (b == skip) continue;
-    const uint8_t* blk = blocks + (size_t)b * block_bytes;
+    const uint8_t* blk = (blocks_b && b == 1) ? blocks_b : blocks + (size_t)b * block_bytes;
+    const uint32_t bcap = (blocks_b && b == 1) ? cap_b : cap;
     uint32_t n = *reinterpret_cast<const uint32_t*>(blk);
-    if (n > cap) {
+    if (n > bcap) {
       if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&v.vctl->status, kStXchgFull);
-      n = cap;
+      n = bcap;
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n) atomicAdd(&v.vctl->xchg_recv, n);
     for (uint32_t r = blockIdx.x; r < n; r += gridDim.x) {
       const uint8_t* rec = blk + 16 + (size_t)r * (16 + 4096 + 4096);
       const int4 id = *reinterpret_cast<const int4*>(rec);
@@ -1949,8 +2008,10 @@ __global__ __launch_bounds__(512) void k_boundary_unpack_blocks(VolumeDev v, con
   }
 }
 void launch_boundary_unpack_blocks(const VolumeDev& v, const uint8_t* blocks, int nblocks, int skip, uint32_t cap,
-                                   int dirty_par, uint32_t stamp, hipStream_t s) {
-  hipLaunchKernelGGL(k_boundary_unpack_blocks, dim3(1024), dim3(512), 0, s, v, blocks, nblocks, skip, cap, dirty_par, stamp);
+                                   int dirty_par, uint32_t stamp, hipStream_t s, const uint8_t* blocks_b, uint32_t cap_b,
+                                   const FrameCtl* pub_ctl, uint32_t* pub_words, uint32_t pub_tag) {
+  hipLaunchKernelGGL(k_boundary_unpack_blocks, dim3(1024), dim3(512), 0, s, v, blocks, nblocks, skip, cap, dirty_par, stamp,
+                     blocks_b, cap_b, pub_ctl, pub_words, pub_tag);
 }
 
 

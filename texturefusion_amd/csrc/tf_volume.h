@@ -114,8 +114,19 @@ struct CommState {
   void* d_recv = nullptr;
   int64_t cap_records = 0;
   int mode = TF_XCHG_NEIGHBOURS;
-  uint64_t exchanges = 0, bytes_received = 0;  // tf_comm_stats
+  uint64_t exchanges = 0, bytes_received = 0, bytes_sent = 0;  // tf_comm_stats / tf_comm_stats_ex
+  uint64_t bound_records = 0;  // sum of the record capacities the sized exchanges were given (sent sides)
+  bool neighbours_ok = false;  // tf_comm_check_partition found every slab wide enough and rank-ordered
+  bool checked = false;
 };
+// the sized exchange's record capacity for a band with c selected chunks: multiples of 8 records, at least 8 (room
+// for what an earlier, overflowing exchange left flagged), never more than the caller's cap
+inline uint32_t xchg_bucket(uint32_t c, int64_t cap) {
+  uint64_t b = ((uint64_t)c + 7u) & ~7ull;
+  if (b < 8) b = 8;
+  if (cap > 0 && b > (uint64_t)cap) b = (uint64_t)cap;
+  return (uint32_t)b;
+}
 
 }  // namespace tf
 
@@ -207,13 +218,18 @@ struct tf_volume {
   tf::AtlasState atlas;
   tf::CommState comm;
   int64_t comm_cap = 0;  // > 0: the fused textured flow exchanges the ghost band after every voxel update
+  // band counts of a frame's selection as the host sees them: pinned words [0] tag (frame epoch + 1), [1..4] FrameCtl::band_cnt
+  uint32_t* h_xchg = nullptr;
+  uint32_t xchg_pub_enq = 0;  // tag of the publish that is already on the stream (0: none)
 };
 
 namespace tf {
 int ensure_tmp(tf_volume* v, size_t bytes);
 int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hipStream_t s = nullptr);  // tf_capi.cpp
 int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16,
-                  int32_t frame_id, bool claimed = false);
+                  int32_t frame_id, bool claimed = false, const FrameCtl* next_ctl = nullptr);
+// the four band counts of the frame whose selection wrote `ctl` (tag = its epoch + 1): waits for the device to publish them
+int xchg_band_counts(tf_volume* v, const FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]);
 int flush_deferred(tf_volume* v);
 int patch_flush(tf_volume* v);
 int fused_arm(tf_volume* v);  // the fused flow's counter sets in their start state (no-op once armed)
@@ -223,7 +239,8 @@ void prof_end(tf_volume* v, hipStream_t s = nullptr);
 int atlas_init(tf_volume* v);
 void atlas_destroy(tf_volume* v);
 int atlas_reset(tf_volume* v);
-int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t stamp);
+int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t stamp, const FrameCtl* ctl = nullptr,
+                  uint32_t tag = 0, const FrameCtl* next_ctl = nullptr);
 void comm_destroy(tf_volume* v);
 int kf_push(tf_volume* v, int slot);
 void launch_patch_fused(tf_volume* v, const VolumeDev& d, int par, const KfDev& kf, hipStream_t s);

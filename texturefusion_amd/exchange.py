@@ -51,3 +51,24 @@ def neighbour_exchange(block_down, block_up, group=None):
         for req in dist.batch_isend_irecv(ops):
             req.wait()
     return below, above
+
+
+def neighbour_exchange_sized(block_down, block_up, recv_below_bytes: int, recv_above_bytes: int, group=None):
+    """The sized neighbour form: the blocks have whatever length the frame's selection gave them
+    (tf_boundary_band_bounds -> tf_boundary_block_bytes); the receive lengths come from the same computation on THIS
+    rank, so nothing is negotiated.  Returns (from_below, from_above); a zero-count header where there is no neighbour."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    below = torch.zeros(max(recv_below_bytes, HEADER_BYTES), dtype=torch.uint8, device=block_down.device)
+    above = torch.zeros(max(recv_above_bytes, HEADER_BYTES), dtype=torch.uint8, device=block_up.device)
+    ops = []
+    if rank > 0:
+        ops += [dist.P2POp(dist.isend, block_down, rank - 1, group), dist.P2POp(dist.irecv, below, rank - 1, group)]
+    if rank + 1 < world:
+        ops += [dist.P2POp(dist.isend, block_up, rank + 1, group), dist.P2POp(dist.irecv, above, rank + 1, group)]
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    return below, above

@@ -16,7 +16,10 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <fstream>
+#include <iomanip>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -53,7 +56,16 @@ struct Vec3 {
   Vec3() : v{0, 0, 0} {}
   Vec3(float x, float y, float z) : v{x, y, z} {}
   float operator()(int i) const { return v[i]; }
+  float& operator()(int i) { return v[i]; }
 };
+struct Vec4 {  // Eigen::Vector4f (geometry/Geometry.h); initChiselMap packs the truncator's terms into one
+  float v[4];
+  Vec4() : v{0, 0, 0, 0} {}
+  Vec4(float a, float b, float c, float d) : v{a, b, c, d} {}
+  float operator()(int i) const { return v[i]; }
+  float& operator()(int i) { return v[i]; }
+};
+typedef std::vector<Vec3> Vec3List;
 
 // Eigen::Affine3f: camera-to-world [R | t], row-major 3x4.
 struct Transform {
@@ -85,26 +97,62 @@ class PinholeCamera {  // camera/PinholeCamera.h:36-77
   float nearPlane = 0.01f, farPlane = 5.0f;
 };
 
-class QuadraticTruncator {  // truncation/QuadraticTruncator.h:33-48
+class Truncator {  // truncation/Truncator.h:28-40
+ public:
+  Truncator() = default;
+  virtual ~Truncator() {}
+  virtual float GetTruncationDistance(float depthReading) const = 0;
+};
+typedef std::shared_ptr<Truncator> TruncatorPtr;
+typedef std::shared_ptr<const Truncator> TruncatorConstPtr;
+
+class QuadraticTruncator : public Truncator {  // truncation/QuadraticTruncator.h:33-48
  public:
   QuadraticTruncator() = default;
   QuadraticTruncator(float quadratic, float linear, float constant, float scale)
       : quadraticTerm(quadratic), linearTerm(linear), constantTerm(constant), scalingFactor(scale) {}
-  float GetTruncationDistance(float reading) const {
+  float GetTruncationDistance(float reading) const override {
     return std::abs(quadraticTerm * std::pow((double)reading, 2) + linearTerm * reading + constantTerm) * scalingFactor;
   }
+  inline float GetQuadraticTerm() const { return quadraticTerm; }
+  inline float GetLinearTerm() const { return linearTerm; }
+  inline float GetConstantTerm() const { return constantTerm; }
+  inline float GetScalingFactor() const { return scalingFactor; }
+  inline void SetQuadraticTerm(float value) { quadraticTerm = value; }
+  inline void SetLinearTerm(float value) { linearTerm = value; }
+  inline void SetConstantTerm(float value) { constantTerm = value; }
+  inline void SetScalingFactor(float value) { scalingFactor = value; }
   float quadraticTerm = 0.0019f, linearTerm = 0.00152f, constantTerm = 0.001504f, scalingFactor = 6.0f;
 };
-typedef std::shared_ptr<QuadraticTruncator> TruncatorPtr;
+typedef std::shared_ptr<QuadraticTruncator> QuadraticTruncatorPtr;
 
-class ConstantWeighter {  // weighting/ConstantWeighter.h:34-46
+class ConstantTruncator : public Truncator {  // truncation/ConstantTruncator.h:31-56
+ public:
+  ConstantTruncator() = default;
+  ConstantTruncator(float value) : truncationDistance(value) {}
+  inline void SetTruncationDistance(float value) { truncationDistance = value; }
+  float GetTruncationDistance(float) const override { return truncationDistance; }
+  float truncationDistance = 0.0f;
+};
+typedef std::shared_ptr<ConstantTruncator> ConstantTruncatorPtr;
+
+class Weighter {  // weighting/Weighter.h:28-40
+ public:
+  Weighter() = default;
+  virtual ~Weighter() {}
+  virtual float GetWeight(float surfaceDist, float truncationDist) const = 0;
+};
+typedef std::shared_ptr<Weighter> WeighterPtr;
+typedef std::shared_ptr<const Weighter> WeighterConstPtr;
+
+class ConstantWeighter : public Weighter {  // weighting/ConstantWeighter.h:34-46
  public:
   ConstantWeighter() = default;
-  explicit ConstantWeighter(float w) : weight(w) {}
-  float GetWeight(float, float truncationDist) const { return weight / (2 * truncationDist); }
+  ConstantWeighter(float w) : weight(w) {}
+  float GetWeight(float, float truncationDist) const override { return weight / (2 * truncationDist); }
   float weight = 1.0f;
 };
-typedef std::shared_ptr<ConstantWeighter> WeighterPtr;
+typedef std::shared_ptr<ConstantWeighter> ConstantWeighterPtr;
 
 class ProjectionIntegrator {  // utils/ProjectionIntegrator.h:42-94 (parameters only; the kernel is on the GPU)
  public:
@@ -116,8 +164,14 @@ class ProjectionIntegrator {  // utils/ProjectionIntegrator.h:42-94 (parameters 
   inline bool IsCarvingEnabled() const { return enableVoxelCarving; }
   inline void SetCarvingDist(float dist) { carvingDist = dist; }       // unused by the reference kernel
   inline void SetCarvingEnabled(bool enabled) { enableVoxelCarving = enabled; }
+  // ProjectionIntegrator.h:81.  The reference keeps the un-rotated voxel centres here and re-derives the per-pose
+  // table from them on every call (Chisel.cpp:52-110); on the device the selection role builds that table itself
+  // from (pose, resolution), so the list is only held for callers that read it back.
+  inline void SetCentroids(const Vec3List& c) { centroids = c; }
+  inline const Vec3List& GetCentroids() const { return centroids; }
 
  protected:
+  Vec3List centroids;
   TruncatorPtr truncator = std::make_shared<QuadraticTruncator>();
   WeighterPtr weighter = std::make_shared<ConstantWeighter>();
   float carvingDist = 0;
@@ -166,7 +220,6 @@ struct Vec2 {
   float operator()(int i) const { return v[i]; }
   float& operator()(int i) { return v[i]; }
 };
-typedef std::vector<Vec3> Vec3List;
 typedef std::vector<Vec2> Vec2List;
 typedef std::vector<unsigned int> VertIndexList;
 
@@ -318,8 +371,18 @@ inline void tf_check(int rc, const char* what) {
 class ChunkManager {
  public:
   ChunkManager() = default;
-  void Bind(tf_volume* v, float res) { vol = v; voxelResolutionMeters = res; }
+  void Bind(tf_volume* v, float res) { vol = v; voxelResolutionMeters = res; CacheCentroids(); }
   inline float GetResolution() const { return voxelResolutionMeters; }
+  // ChunkManager::CacheCentroids / GetCentroids (ChunkManager.cpp:49-63, ChunkManager.h:735): voxel centres of a chunk
+  // relative to its origin, x fastest.  MobileFusion::initChiselMap hands them to the integrator (MobileFusion.h:242-243).
+  void CacheCentroids() {
+    const float r = voxelResolutionMeters, half = r * 0.5f;
+    centroids.clear();
+    for (int z = 0; z < 8; z++)
+      for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) centroids.emplace_back((float)x * r + half, (float)y * r + half, (float)z * r + half);
+  }
+  inline const Vec3List& GetCentroids() const { return centroids; }
   inline bool HasChunk(const ChunkID& chunk) const {  // ChunkManager.h:133-135
     int out = 0;
     tf_check(tf_has_chunk(vol, chunk.v, &out), "HasChunk");
@@ -401,9 +464,100 @@ class ChunkManager {
  private:
   tf_volume* vol = nullptr;
   float voxelResolutionMeters = 0.005f;
+  Vec3List centroids;
   std::unordered_map<ChunkID, ChunkPtr, ChunkHasher> mirrors;
   MeshMap allMeshes;
 };
+
+// io/PLY.cpp:29-80 SaveMeshPLYASCII: vertices (+ uchar colours when the mesh has them), one triangle per three
+// consecutive indices; numbers in the stream's default formatting.
+inline bool SaveMeshPLYASCII(const std::string& fileName, const MeshPtr& mesh) {
+  std::ofstream stream(fileName.c_str());
+  if (!stream) return false;
+  const size_t numPoints = mesh->vertices.size();
+  const bool hasColors = !mesh->colors.empty();  // Mesh::HasColors
+  stream << "ply" << std::endl << "format ascii 1.0" << std::endl << "element vertex " << numPoints << std::endl;
+  stream << "property float x" << std::endl << "property float y" << std::endl << "property float z" << std::endl;
+  if (hasColors)
+    stream << "property uchar red" << std::endl << "property uchar green" << std::endl << "property uchar blue" << std::endl;
+  stream << "element face " << numPoints / 3 << std::endl;
+  stream << "property list uchar int vertex_index" << std::endl << "end_header" << std::endl;
+  for (size_t i = 0; i < numPoints; ++i) {
+    const Vec3& vert = mesh->vertices[i];
+    stream << vert(0) << " " << vert(1) << " " << vert(2);
+    if (hasColors) {
+      const Vec3& color = mesh->colors[i];
+      stream << " " << static_cast<int>(color(0) * 255.0f) << " " << static_cast<int>(color(1) * 255.0f) << " "
+             << static_cast<int>(color(2) * 255.0f);
+    }
+    stream << std::endl;
+  }
+  for (size_t i = 0; i + 2 < mesh->indices.size(); i += 3) {
+    stream << "3 ";
+    for (int j = 0; j < 3; j++) stream << mesh->indices[i + j] << " ";
+    stream << std::endl;
+  }
+  return true;
+}
+
+// A PNG file of an RGB8 image written with stored (uncompressed) deflate blocks -- what cv::imwrite produces for
+// Atlas::SaveTexturedModel, minus the compression (no zlib dependency here).  rows(y) returns row y's w * 3 bytes.
+template <class RowFn>
+inline bool WritePngRgb(const std::string& fileName, uint32_t w, uint32_t h, RowFn rows) {
+  std::FILE* f = std::fopen(fileName.c_str(), "wb");
+  if (!f) return false;
+  static uint32_t table[256];
+  static bool have = false;
+  if (!have) {
+    for (uint32_t n = 0; n < 256; n++) {
+      uint32_t c = n;
+      for (int k = 0; k < 8; k++) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      table[n] = c;
+    }
+    have = true;
+  }
+  uint32_t crc = 0;
+  auto crc_feed = [&](const unsigned char* p, size_t n) { for (size_t i = 0; i < n; i++) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8); };
+  auto be32 = [](unsigned char* p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; };
+  auto put = [&](const unsigned char* p, size_t n) { std::fwrite(p, 1, n, f); crc_feed(p, n); };
+  auto begin = [&](const char* type, uint32_t len) {
+    unsigned char b[4]; be32(b, len); std::fwrite(b, 1, 4, f);
+    crc = 0xFFFFFFFFu; put((const unsigned char*)type, 4);
+  };
+  auto end = [&]() { unsigned char b[4]; be32(b, crc ^ 0xFFFFFFFFu); std::fwrite(b, 1, 4, f); };
+  static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  std::fwrite(sig, 1, 8, f);
+  unsigned char ihdr[13];
+  be32(ihdr, w); be32(ihdr + 4, h); ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+  begin("IHDR", 13); put(ihdr, 13); end();
+  // one IDAT chunk per image row: a piece of the zlib stream = stored blocks of <= 65535 bytes holding filter byte + row
+  const size_t line = (size_t)w * 3 + 1;
+  std::vector<unsigned char> buf(line);
+  uint32_t a1 = 1, a2 = 0;  // Adler-32 of the raw stream
+  for (uint32_t y = 0; y < h; y++) {
+    buf[0] = 0;
+    std::memcpy(&buf[1], rows(y), (size_t)w * 3);
+    for (size_t i = 0; i < line;) {  // 5552 bytes keep the sums below 2^32
+      const size_t n = std::min<size_t>(5552, line - i);
+      for (size_t k = 0; k < n; k++) { a1 += buf[i + k]; a2 += a1; }
+      a1 %= 65521u; a2 %= 65521u; i += n;
+    }
+    const size_t nblk = (line + 65534) / 65535;
+    const bool first = y == 0, last = y + 1 == h;
+    begin("IDAT", (uint32_t)((first ? 2 : 0) + line + 5 * nblk + (last ? 4 : 0)));
+    if (first) { const unsigned char z[2] = {0x78, 0x01}; put(z, 2); }
+    for (size_t b = 0; b < nblk; b++) {
+      const size_t off = b * 65535, n = std::min<size_t>(65535, line - off);
+      const unsigned char hd[5] = {(unsigned char)((last && b + 1 == nblk) ? 1 : 0), (unsigned char)(n & 0xFF), (unsigned char)(n >> 8),
+                                   (unsigned char)(~n & 0xFF), (unsigned char)((~n >> 8) & 0xFF)};
+      put(hd, 5); put(&buf[off], n);
+    }
+    if (last) { unsigned char ad[4]; be32(ad, (a2 << 16) | a1); put(ad, 4); }
+    end();
+  }
+  begin("IEND", 0); end();
+  return std::fclose(f) == 0;
+}
 
 // ---- Atlas (Structure/Atlas.h:43-75) -------------------------------------------------------
 class Atlas {
@@ -416,7 +570,92 @@ class Atlas {
     tf_check(tf_atlas_patch_size(vol, &pw, &ph), "Atlas");
     PATCH_WIDTH = pw;
     PATCH_HEIGHT = ph;
+    int32_t aw = 0, ah = 0;
+    tf_check(tf_atlas_size(vol, &aw, &ah), "Atlas");
+    MAX_PATCH_WIDTH_ = (std::size_t)aw;
+    MAX_PATCH_HEIGHT_ = (std::size_t)ah;
   }
+  std::size_t MAX_PATCH_WIDTH_ = 13824, MAX_PATCH_HEIGHT_ = 13824;  // the macros of Atlas.h:29-30 (tf_config.atlas_w / _h)
+  inline Vec2 GetTexLoc(const ChunkID& id) {  // Atlas.cpp:66-69
+    const std::size_t k = GetPatch(id)->texloc;
+    return Vec2((float)(k % MAX_PATCH_WIDTH_), (float)(k / MAX_PATCH_WIDTH_));
+  }
+  // Atlas::SaveTexturedModel (Atlas.cpp:93-179): texture_material.png (the whole texture_buffer; RGB, as cv::imwrite
+  // of the BGR-converted buffer stores it), texture_model.obj over every mesh with a complete patch (allMeshes
+  // iteration order, which the reference leaves to std::unordered_map), texture_model.mtl.  Meshes, texcoords and
+  // atlas rows come from the device (fetch(id) = Chisel::FetchPatchData + ChunkManager::FetchMeshData).
+  template <class FetchFn>
+  void SaveTexturedModelWith(std::string const& basepath, FetchFn fetch) {
+    {
+      const std::size_t band = 64;
+      std::vector<unsigned char> rows(band * MAX_PATCH_WIDTH_ * 3);
+      std::size_t have0 = 1, have1 = 0;
+      WritePngRgb(basepath + "/texture_material.png", (uint32_t)MAX_PATCH_WIDTH_, (uint32_t)MAX_PATCH_HEIGHT_, [&](uint32_t y) {
+        if (y < have0 || y >= have1) {
+          have0 = y;
+          have1 = std::min<std::size_t>(MAX_PATCH_HEIGHT_, have0 + band);
+          DownloadRows((int64_t)have0, (int64_t)have1, rows.data());
+        }
+        return (const unsigned char*)&rows[(y - have0) * MAX_PATCH_WIDTH_ * 3];
+      });
+    }
+    Vec3List vertices, normals;
+    Vec2List texcoords;
+    VertIndexList indices, txindices;
+    std::size_t vts = 0;
+    for (auto it : manager->GetAllMeshes()) {
+      MeshPtr mesh = it.second;
+      PatchPtr patch = mesh->m_patch;
+      if (patch == nullptr || !patch->complete()) continue;
+      fetch(mesh->chunkID);
+      for (std::size_t j = 0; j < mesh->indices.size(); j++) {
+        const std::size_t k = mesh->indices[j] + vts;
+        indices.emplace_back((unsigned int)k);
+        txindices.emplace_back((unsigned int)k);
+      }
+      for (std::size_t j = 0; j < mesh->vertices.size(); j++) {
+        vertices.emplace_back(mesh->vertices[j]);
+        normals.emplace_back(mesh->normals[j]);
+        Vec2 tex = GetTexLoc(mesh->chunkID);
+        tex(0) += patch->texcoord[j](0) * patch->ratio(0);
+        tex(1) += patch->texcoord[j](1) * patch->ratio(1);
+        tex(0) /= MAX_PATCH_WIDTH_;
+        tex(1) /= MAX_PATCH_HEIGHT_;
+        texcoords.emplace_back(tex);
+        vts++;
+      }
+    }
+    std::ofstream mout((basepath + "/texture_model.obj").c_str());
+    mout << "mtllib " << "texture_model.mtl" << '\n';
+    mout << std::fixed << std::setprecision(6);
+    for (std::size_t i = 0; i < vertices.size(); ++i)
+      mout << "v " << vertices[i](0) << " " << vertices[i](1) << " " << vertices[i](2) << '\n';
+    for (std::size_t i = 0; i < texcoords.size(); ++i) mout << "vt " << texcoords[i](0) << " " << 1.0f - texcoords[i](1) << '\n';
+    for (std::size_t i = 0; i < normals.size(); ++i)
+      mout << "vn " << normals[i](0) << " " << normals[i](1) << " " << normals[i](2) << '\n';
+    mout << "s off" << '\n';
+    mout << "usemtl " << "demo_texture" << '\n';
+    for (std::size_t i = 0; i < indices.size() / 3; ++i) {
+      mout << "g " << "face" << i << '\n';
+      mout << "f";
+      for (std::size_t k = 0; k < 3; ++k)
+        mout << " " << indices[i * 3 + k] + 1 << "/" << txindices[i * 3 + k] + 1 << "/" << indices[i * 3 + k] + 1;
+      mout << '\n';
+    }
+    mout.close();
+    std::ofstream out((basepath + "/texture_model.mtl").c_str());
+    out << "newmtl " << "demo_texture" << '\n'
+        << "Ka 1.000000 1.000000 1.000000" << '\n'
+        << "Kd 1.000000 1.000000 1.000000" << '\n'
+        << "Ks 0.000000 0.000000 0.000000" << '\n'
+        << "Tr 0.000000" << '\n'
+        << "illum 1" << '\n'
+        << "Ns 1.000000" << '\n'
+        << "map_Kd " << "texture_material.png" << std::endl;
+    out.close();
+  }
+  void SaveTexturedModel(std::string const& basepath);  // defined behind Chisel (needs its fetchers)
+  void BindOwner(class Chisel* c) { owner = c; }
   inline bool HasPatch(const ChunkID& id) const { return manager->HasMesh(id); }            // Atlas.h:55
   inline PatchPtr GetPatch(const ChunkID& id) { return manager->GetMutableMesh(id)->m_patch; }  // :56-58
   // texture_buffer rows [row0,row1) (the GUI uploads only the hot rows, MobileFusion.h:406-421)
@@ -432,18 +671,23 @@ class Atlas {
  private:
   tf_volume* vol = nullptr;
   ChunkManager* manager = nullptr;
+  class Chisel* owner = nullptr;
 };
 
 // ---- Chisel (Structure/Chisel.h:46-493) ----------------------------------------------------
 class Chisel {
  public:
   Chisel(const int chunkSize[3], float voxelResolution, bool useColor, const tf_config* cfg = nullptr) {
-    int32_t dims[3] = {chunkSize[0], chunkSize[1], chunkSize[2]};
-    tf_check(tf_volume_create(dims, voxelResolution, useColor ? 1 : 0, cfg, &vol), "Chisel");
-    res = voxelResolution;
-    chunkManager.Bind(vol, res);
-    atlas.Bind(vol, &chunkManager);
+    Init(chunkSize[0], chunkSize[1], chunkSize[2], voxelResolution, useColor, cfg);
   }
+  // Chisel(const Eigen::Vector3i& chunkSize, float voxelResolution, bool useColor) (Chisel.cpp:38-41): any vector
+  // type indexed with (i) -- Eigen::Vector3i in a caller that has Eigen, ChunkID here.
+  template <class V3, class = decltype(std::declval<const V3&>()(0))>
+  Chisel(const V3& chunkSize, float voxelResolution, bool useColor, const tf_config* cfg = nullptr) {
+    Init(chunkSize(0), chunkSize(1), chunkSize(2), voxelResolution, useColor, cfg);
+  }
+  // Device-side sizing (pool, lists, atlas) of the volumes the three-argument constructor makes; nullptr = library defaults.
+  static const tf_config*& DefaultConfig() { static const tf_config* c = nullptr; return c; }
   virtual ~Chisel() { tf_volume_destroy(vol); }
   Chisel(const Chisel&) = delete;
   Chisel& operator=(const Chisel&) = delete;
@@ -699,19 +943,59 @@ class Chisel {
     }
   }
 
+  // Chisel::SaveAllMeshesToPLY (Chisel.cpp:357-379): every mesh of allMeshes un-indexed into one triangle soup
+  // (unordered_map iteration order, as in the reference) and written by SaveMeshPLYASCII.
+  bool SaveAllMeshesToPLY(const std::string& filename) {
+    std::printf("Saving all meshes to PLY file...\n");
+    MeshPtr fullMesh(new Mesh());
+    size_t v = 0;
+    for (const auto& it : chunkManager.GetAllMeshes()) {
+      chunkManager.FetchMeshData(it.first);
+      const Mesh& m = *it.second;
+      for (size_t i = 0; i < m.indices.size(); i++) {
+        const size_t index = m.indices[i];
+        fullMesh->indices.emplace_back((unsigned int)(i + v));
+        fullMesh->vertices.emplace_back(m.vertices[index]);
+        fullMesh->colors.emplace_back(m.colors[index]);
+        fullMesh->normals.emplace_back(m.normals[index]);
+      }
+      v += m.indices.size();
+    }
+    std::printf("Full mesh has %lu verts\n", (unsigned long)v);
+    const bool success = SaveMeshPLYASCII(filename, fullMesh);
+    if (!success) std::printf("Saving failed!\n");
+    return success;
+  }
+
   ChunkID maxChunkID, minChunkID;
   ChunkManager chunkManager;
   ChunkSet meshesToUpdate;
   Atlas atlas;
 
  protected:
+  void Init(int sx, int sy, int sz, float voxelResolution, bool useColor, const tf_config* cfg) {
+    int32_t dims[3] = {sx, sy, sz};
+    tf_check(tf_volume_create(dims, voxelResolution, useColor ? 1 : 0, cfg ? cfg : DefaultConfig(), &vol), "Chisel");
+    res = voxelResolution;
+    chunkManager.Bind(vol, res);
+    atlas.Bind(vol, &chunkManager);
+    atlas.BindOwner(this);
+  }
   void Configure(const ProjectionIntegrator& integ, const PinholeCamera& cam, bool with_integrator = true) {
     tf_check(tf_set_camera(vol, cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height, cam.nearPlane, cam.farPlane),
              "camera");
     if (with_integrator) {
-      const QuadraticTruncator& t = *integ.GetTruncator();
-      tf_check(tf_set_truncation(vol, t.quadraticTerm, t.linearTerm, t.constantTerm, t.scalingFactor), "truncator");
-      tf_check(tf_set_weight(vol, integ.GetWeighter()->weight), "weighter");
+      // the device evaluates the two classes the reference ships (truncation/*.h, weighting/*.h)
+      const Truncator* tb = integ.GetTruncator().get();
+      if (const QuadraticTruncator* t = dynamic_cast<const QuadraticTruncator*>(tb))
+        tf_check(tf_set_truncation(vol, t->quadraticTerm, t->linearTerm, t->constantTerm, t->scalingFactor), "truncator");
+      else if (const ConstantTruncator* c = dynamic_cast<const ConstantTruncator*>(tb))
+        tf_check(tf_set_truncation(vol, 0.0f, 0.0f, c->truncationDistance, 1.0f), "truncator");  // |0 + 0 + c| * 1
+      else
+        throw std::invalid_argument("ProjectionIntegrator: only QuadraticTruncator / ConstantTruncator run on the device");
+      const ConstantWeighter* w = dynamic_cast<const ConstantWeighter*>(integ.GetWeighter().get());
+      if (!w) throw std::invalid_argument("ProjectionIntegrator: only ConstantWeighter runs on the device");
+      tf_check(tf_set_weight(vol, w->weight), "weighter");
     }
     const size_t want = (size_t)1 << 16;
     if (ids_buf.size() < want * 3) { ids_buf.resize(want * 3); new_buf.resize(want); }
@@ -763,6 +1047,15 @@ class Chisel {
   std::vector<float> qual_buf;
 };
 typedef std::shared_ptr<Chisel> ChiselPtr;
+
+inline void Atlas::SaveTexturedModel(std::string const& basepath) {
+  if (!owner) throw std::runtime_error("Atlas::SaveTexturedModel: atlas not bound to a Chisel");
+  Chisel* c = owner;
+  SaveTexturedModelWith(basepath, [c](const ChunkID& id) {
+    c->GetMutableChunkManager().FetchMeshData(id);
+    c->FetchPatchData(id);
+  });
+}
 
 // Structure/TexMap.{h,cpp}: the bookkeeping of the view selection that consumes this path's outputs -- the chunk
 // graph from the meshes' adjacency flags (update_chunkgraph, TexMap.cpp:50-62) and the data costs from the
@@ -877,6 +1170,12 @@ class TexMap {
 typedef TexMap* TexPtr;
 
 }  // namespace chisel
+
+// Structure/uni_graph.h, sparse_matrix.h and TexMap.h declare these at global scope
+using chisel::DataCosts;
+using chisel::SparseMat;
+using chisel::TexMap;
+using chisel::UniGraph;
 
 // ---------------------------------------------------------------------------------------------------------
 // BasicAPI's per-frame image passes (BasicAPI.h:112-131, called from main.cpp:117-147) with the reference's

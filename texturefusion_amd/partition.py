@@ -94,3 +94,20 @@ def balanced_edges(keys, world: int):
 def owner_of_key(ids, edges, axis=(1, 0, 0)):
     e = np.asarray(edges[1:-1], np.int64)
     return np.searchsorted(e, key_of(ids, axis), side="right").astype(np.int32)
+
+
+# ---- the sized neighbour exchange (host twin of FrameCtl::band_cnt / xchg_bucket, tf_volume.h) ------------------
+def band_counts(ids, lo: int, hi: int, axis=(1, 0, 0)):
+    """Selected chunks of a frame per ghost band, from the FULL selection every rank holds: (own down band, own up band,
+    the up band of the rank below, the down band of the rank above).  Rank r's first number is what rank r - 1 computes
+    as its fourth, and so on: both sides of a transfer size it alike without talking to each other."""
+    k = key_of(ids, axis)
+    w = int(sum(axis))
+    return (int(((k >= lo) & (k - lo <= w)).sum()), int((k == hi - 1).sum()), int((k == lo - 1).sum()),
+            int(((k >= hi) & (k - hi <= w)).sum()))
+
+
+def xchg_bucket(count: int, cap: int = 0) -> int:
+    """Record capacity of a sized block: multiples of 8, at least 8, at most cap (cap > 0)."""
+    b = max(8, (int(count) + 7) // 8 * 8)
+    return min(b, cap) if cap > 0 else b
