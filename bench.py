@@ -693,8 +693,12 @@ def child_passes(args):
     pre = 0 if args.no_preroll else args.unique_frames
     # the host entry point runs `behind` frames behind its caller (tf_host_frame_deferral: kHostDefer of the build): the
     # launches inside the parent's timed region are those of the frames [pre + Wm - behind, pre + Wm + K - behind)
-    from texturefusion_amd import capi as _capi
-    behind = 0 if args.resident_headline else _capi.host_frame_deferral()[0]
+    # (asked in a process of its own: this one must not map the HIP runtime before torch brings its copy)
+    behind = 0
+    if not args.resident_headline:
+        q = subprocess.run([sys.executable, "-c", "from texturefusion_amd import capi; print(capi.host_frame_deferral()[0])"],
+                           cwd=ROOT, capture_output=True, text=True, timeout=120)
+        behind = int(q.stdout.strip().splitlines()[-1]) if q.returncode == 0 and q.stdout.strip() else 4
     first = max(0, pre + Wm - behind)
     base_cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--child", "--steps", str(K), "--warmup", str(Wm),
                 "--mode", args.mode, "--scene", args.scene, "--res", repr(args.res), "--unique-frames", str(args.unique_frames)]

@@ -203,18 +203,19 @@ def test_textured_frames_after_a_tsdf_only_stretch(gpu_required):
     gv.close()
 
 
-@pytest.mark.parametrize("knob", ["TF_MESH_FUSED=1", "TF_FILTER_EXACT=0"])
+@pytest.mark.parametrize("knob", ["TF_MESH_FUSED=1", "TF_FILTER_EXACT=0", "TF_PATCH_IN_FILTER=1"])
 def test_mesher_form_knobs(gpu_required, knob):
     """The measured-and-rejected forms of the filter / mesher pair stay bit-exact: TF_MESH_FUSED=1 (k_mesh<128, true>: the
-    mesher runs the filter itself) and TF_FILTER_EXACT=0 (the filter reads no voxels, the mesher makes the summaries exact)
-    are read once per process -- the orbits run in a child process with the knob set."""
+    mesher runs the filter itself), TF_FILTER_EXACT=0 (the filter reads no voxels, the mesher makes the summaries exact)
+    and TF_PATCH_IN_FILTER=1 (the patch stage of frame f - 1 rides on the filter launch of frame f instead of k_frame(f);
+    round 4) are read once per process -- the orbits run in a child process with the knob set."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     name, val = knob.split("=")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_textured_soak.py", "-m", "gpu", "-x", "-q", "-k",
-                        "hand_held or long_orbit or tsdf_only_stretch"], cwd=root, env=dict(os.environ, **{name: val}),
+                        "hand_held or long_orbit or tsdf_only_stretch or host_frames_entry or deferral_is_not"], cwd=root, env=dict(os.environ, **{name: val}),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "3 passed" in r.stdout, r.stdout[-500:]
+    assert "5 passed" in r.stdout, r.stdout[-500:]

@@ -19,7 +19,10 @@ BUDGET = {
     # (the filter's two forms -- wave per entry / workgroup batches -- share one kernel: 78 VGPRs, 6 waves per SIMD;
     # forcing 7 or 8 spills, and the measured time does not depend on it: the kernel is a chain of round trips)
     # (k_mesh<256> is the alternative form behind TF_MESH_THREADS=256: 80 VGPRs with a few spilled)
-    "tf_mesh.hip": {"k_meshILi128E": (96, 0), "k_meshILi256E": (80, 32), "k_mesh_filter": (80, 0)},
+    # the filter instances that carry the previous frame's patch stage (PATCH = true: the default of the textured flow) are
+    # compiled for 6 waves per SIMD like k_frame<true, true> was: 80 VGPRs, the patch range spills 28 B/lane
+    "tf_mesh.hip": {"k_meshILi128E": (96, 0), "k_meshILi256E": (80, 32), "k_mesh_filterILb1ELb0E": (64, 16),
+                    "k_mesh_filterILb0ELb0E": (80, 0), "k_mesh_filterILb1ELb1E": (80, 40), "k_mesh_filterILb0ELb1E": (80, 40)},
     "tf_atlas.hip": {"k_patchILb1ELb1ELb1E": (96, 0)},  # one patch per wave, two 64-vertex blocks in registers: 5 waves per SIMD
 }
 

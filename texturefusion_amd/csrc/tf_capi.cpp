@@ -386,6 +386,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   }
   if ((rc = dev_alloc(v, &d.mesh_nbr, (size_t)kMeshShards * mesh_shard_rows(d.max_chunks) * 32))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_cnt, (size_t)2 * kMeshCntWords))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.reset_list, (size_t)kMeshShards * mesh_shard_rows(d.max_chunks)))) return fail(rc);
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
     SelBuf& L = v->selbuf[k];
     if ((rc = dev_alloc(v, &L.masks, (size_t)d.max_coarse))) return fail(rc);
@@ -742,6 +743,18 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
 // The patch stage (adjacency exchange, slot hand-out, projection, blit) reads meshes and images only; it is left
 // PENDING here and rides on the next frame's launch next to that frame's voxel update (AtlasState::pend_patch).
 }  // extern "C" (C++ linkage for the helper below)
+static int patch_launched(tf_volume* v);
+// Where does the pending patch stage of frame f - 1 ride?  Default: on k_frame(f), next to K-A.  TF_PATCH_IN_FILTER=1: on
+// the filter launch of frame f (k_mesh_filter<*, true>; the records the filter empties are written by the mesher launch
+// so that the stage can still read them).  Measured on the room stream (profiles/r4/README.md, run s1): k_frame 40.6 ->
+// 31.3 us as expected, but filter + mesher 50.3 -> 61.8 us -- the two latency chains slow each other down by more than
+// K-A gains (step 90.9 -> 93.1 us of kernels; fewer patch workgroups, a smaller filter grid, the other dispatch order:
+// 97-102 us) -- so the default stays k_frame.
+bool tf::patch_rides_filter() {
+  static const bool on = getenv("TF_PATCH_IN_FILTER") && atoi(getenv("TF_PATCH_IN_FILTER")) &&
+                         !(getenv("TF_MESH_FUSED") && atoi(getenv("TF_MESH_FUSED")));
+  return on;
+}
 int tf::fused_arm(tf_volume* v) {
   AtlasState& a = v->atlas;
   if (a.fused_armed) return TF_OK;
@@ -762,8 +775,12 @@ int tf::fused_arm(tf_volume* v) {
 int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
                       const float* pose_inv16, int32_t frame_id, bool claimed, const FrameCtl* next_ctl) {
   AtlasState& a = v->atlas;
-  int rc = patch_flush(v);  // (a stage still pending here must read its meshes before this frame's mesher rewrites them)
-  if (rc) return rc;
+  // A patch stage still pending here (the previous textured frame's) must read its meshes before this frame's mesher
+  // rewrites them: it goes out on its own first -- or, with TF_PATCH_IN_FILTER=1, rides on this frame's FILTER launch
+  // (launch_mesh below; measured slower than riding on k_frame: see patch_rides_filter)
+  const bool ride = a.pend_patch.on && patch_rides_filter() && a.fused_armed;
+  int rc = TF_OK;
+  if (!ride) { rc = patch_flush(v); if (rc) return rc; }
   rc = fused_arm(v);
   if (rc) return rc;
   const int par = a.fused_par;
@@ -791,10 +808,16 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
   const uint32_t len_guess = a.h_dirty_len ? *reinterpret_cast<volatile uint32_t*>(a.h_dirty_len) : 0u;
   // (the shard lists of this parity are walked in any case: empty when K-A did not claim -- the previous frame's mesher
   // re-armed them)
-  launch_mesh(d, v->mesh_par, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1,
-              len_guess, a.h_dirty_len, par, v->stream);
+  const PatchStage prev = a.pend_patch.st;  // (copied: the pending record is overwritten below)
+  const bool rode = launch_mesh(d, v->mesh_par, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true,
+                                par ^ 1, len_guess, a.h_dirty_len, par, v->stream, ride ? &prev : nullptr, &v->cam);
   v->mesh_par ^= 1;
   prof_end(v);
+  if (ride) {
+    if (!rode) { set_error("internal: the pending patch stage found no filter launch"); return TF_ERR_INVALID; }
+    rc = patch_launched(v);
+    if (rc) return rc;
+  }
   // (CompressMeshes' neighbour exchange, the list of chunks that own a mesh and the slot candidates are produced
   // by the mesher and consumed by the patch kernel: no kernel of their own in the fused flow)
   KfDev kf;
@@ -815,8 +838,7 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
   v->clear_floor = frame_epoch + 1u;  // CompressMeshes cleared meshesToUpdate
   return TF_OK;
 }
-extern "C" {
-// the pending patch stage has been put on the stream (as a role of a frame launch or on its own)
+// the pending patch stage has been put on the stream (as a role of a frame / filter launch or on its own)
 static int patch_launched(tf_volume* v) {
   AtlasState& a = v->atlas;
   a.pend_patch.on = false;
@@ -826,7 +848,6 @@ static int patch_launched(tf_volume* v) {
   }
   return TF_OK;
 }
-}  // extern "C" (C++ linkage for the helper below)
 namespace tf {
 int patch_flush(tf_volume* v) {  // the pending patch stage as a launch of its own
   AtlasState& a = v->atlas;
@@ -907,9 +928,11 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     if (!hc && !hn && !h2) continue;
     // the patch stage of the previous textured frame rides on this launch when it carries a colour voxel update
     // (the fused kernel has no depth-only instance with that role); otherwise it goes out on its own first
+    // -- or (TF_PATCH_IN_FILTER=1) on the frame's FILTER launch (texture_stage)
     AtlasState::PendPatch& pp = v->atlas.pend_patch;
-    const bool carry = pp.on && hc && cur.img.rgba != nullptr;
-    if (pp.on && hc && !carry) { int rc = patch_flush(v); if (rc) return rc; }
+    const bool to_filter = pp.on && hc && tex && patch_rides_filter();
+    const bool carry = pp.on && hc && cur.img.rgba != nullptr && !to_filter;
+    if (pp.on && hc && !carry && !to_filter) { int rc = patch_flush(v); if (rc) return rc; }
     if (hc) prof_begin(v, TF_PROF_INTEGRATE);
     launch_frame(v->dev, hc ? &cur : nullptr, hn ? &nxt : nullptr, h2 ? &nx2 : nullptr, carry ? &pp.st : nullptr, v->cam,
                  v->ig, v->res, v->stream, v->h_progress, &v->progress_seq);

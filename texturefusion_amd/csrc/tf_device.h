@@ -183,7 +183,7 @@ struct AtlasCtl {
 };
 
 constexpr uint32_t kMeshShards = 32;  // survivor rows are appended shard by shard: 32 counters instead of one
-constexpr uint32_t kMeshCntWords = kMeshShards * 32;  // VolumeDev::mesh_cnt per launch parity: row counters, then statistics
+constexpr uint32_t kMeshCntWords = kMeshShards * 48;  // VolumeDev::mesh_cnt per launch parity: row counters, statistics, deferred-reset counters
 constexpr int kPhaseWaves = 16384;  // rows of the wave-timeline table (tuning aid)
 
 struct VolumeDev {
@@ -230,6 +230,11 @@ struct VolumeDev {
   // reads the row counters at its start, and atomics landing in those lines during the launch delayed that read (mesher
   // 36 -> 49 us with two statistics atomics per chunk next to the row counter)
   uint32_t* mesh_cnt;
+  // Records the filter wants emptied ("cannot have a vertex": Mesh::Clear, ChunkManager.cpp:244-262) are not written by the
+  // filter launch -- the patch stage of the PREVIOUS frame runs in that launch and still reads those records -- but listed
+  // here {id, w = pool slot}, shard by shard (counters: third block of mesh_cnt), and applied by the first workgroups of
+  // the mesher launch behind it.
+  int4* reset_list;  // [kMeshShards][mesh_shard_rows(max_chunks)]
   // atlas (Structure/Atlas.h:43-75): u8 [atlas_h][atlas_w][3], slots of patch_w x patch_h texels
   uint8_t* atlas;
   int32_t atlas_w, atlas_h, patch_w, patch_h;
@@ -355,9 +360,11 @@ uint32_t mesh_shard_rows(uint32_t max_chunks);
 // len_guess: the list length as far as the host knows (picks the filter's form); len_hint: host-visible word that
 // receives the actual length (may be null)
 // shards_par >= 0: the dirty set is the flat list PLUS the shard lists of that parity (VolumeDev::wl_*)
-void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
+// patch != nullptr: the filter launch also carries the patch stage of the PREVIOUS frame (block range ahead of the
+// filter's; tf_patch_body.h) -- returns true when it did (the fused-filter form of the mesher has no such launch)
+bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, int shards_par,
-                 hipStream_t s);
+                 hipStream_t s, const PatchStage* patch = nullptr, const Cam* cam = nullptr);
 // per-frame dirty set of the fused flow -> work list of counter set `par` (when K-A did not build it: FrameStage::claim_par)
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s);
 // ... when marks of earlier frames are still waiting for a mesher: everything marked since clear_floor

@@ -23,6 +23,7 @@
 
 #include "tf_devfn.h"
 #include "tf_mc_table.h"
+#include "tf_patch_body.h"
 #include "tf_volume.h"
 
 #pragma clang fp contract(off)
@@ -233,6 +234,14 @@ __device__ __forceinline__ void filter_reset_record(const VolumeDev& v, uint32_t
   if (ppar >= 0 && inmap) patch_list_append(v, ppar, own & (kMeshShards - 1u), id, own, rec->texloc, was >> kMsOvfShift);  // an emptied mesh keeps its patch
 }
 
+// The same, postponed to the mesher launch (VolumeDev::reset_list): one thread
+__device__ __forceinline__ void filter_defer_reset(const VolumeDev& v, uint32_t* cnt, uint32_t cap_sh, uint32_t own, const int4 id) {
+  const uint32_t shard = own & (kMeshShards - 1u);
+  const uint32_t p = atomicAdd(&cnt[(2u * kMeshShards + shard) * 16u], 1u);
+  if (p < cap_sh) v.reset_list[(size_t)shard * cap_sh + p] = make_int4(id.x, id.y, id.z, (int)own);
+  // (p >= cap_sh cannot happen: at most max_chunks / 32 pool slots share a shard, each listed once per frame)
+}
+
 // phase A of the filter for the 8-lane group a lane belongs to (k8 = its place in the group): lane k looks up chunk
 // id + (k & 1, (k >> 1) & 1, k >> 2) -- the chunk itself and its seven +x / +y / +z neighbours -- and reads that
 // chunk's class summary.  The summaries are supersets of the classes that occur among a chunk's voxels / on the faces
@@ -338,7 +347,7 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
     empty = ((fl | f2) & 14u) != 14u;
   }
   if (empty) {
-    if (lane == 0) filter_reset_record(v, own, id, epoch, ppar);
+    if (lane == 0) filter_defer_reset(v, cnt, cap_sh, own, id);
     return;
   }
   uint32_t p = 0;
@@ -367,13 +376,36 @@ __device__ __forceinline__ int near_k(int lane) { return (lane % 3 - 1) + 2 * ((
 // into host-visible memory for the NEXT frame's choice -- no synchronisation, a stale value only costs time).
 // The dirty set = the flat list [0, *dcount) followed by the concatenation of the 32 shard lists K-A filled (shards_par >= 0,
 // VolumeDev::wl_*): entry e >= n_flat is row e - n_flat of that concatenation, resolved with a 32-lane scan of the counters.
-template <bool WAVE_FORM>
-__global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
+// PATCH: the launch also carries the patch stage of the PREVIOUS frame as its first n_patch workgroups (patch_body,
+// tf_patch_body.h: one wave per patch).  That stage reads the meshes the previous mesher left, the previous frame's images
+// and the atlas; the filter touches hash, summaries, voxels, survivor rows and the reset list -- disjoint (the records it
+// wants emptied are written by the mesher launch: filter_defer_reset) -- and this frame's mesher, which rewrites mesh
+// blocks, runs behind the launch.  OFF by default (TF_PATCH_IN_FILTER=1): the filter alone is a 15-us latency chain and so
+// are the patch chains, but next to each other they take 26 us -- more than the 9 us the stage costs K-A when it rides on
+// k_frame (profiles/r4/README.md).
+#ifndef TF_FILTER_PATCH_WAVES
+#define TF_FILTER_PATCH_WAVES 6  // waves per SIMD of the filter instances that carry the patch stage (80 VGPRs)
+#endif
+struct FilterPatch {
+  uint32_t n_patch;  // workgroups of the patch range (0: none)
+  uint32_t first;    // first workgroup of the patch range: 0 = dispatched ahead of the filter's, else behind them
+  int par;
+  Cam cam;
+  KfDev kf;
+};
+template <bool WAVE_FORM, bool PATCH>
+__global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 8 : 6)) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
                                                      uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool use_summ,
-                                                     uint32_t* __restrict__ len_hint, int shards_par, bool exact) {
+                                                     uint32_t* __restrict__ len_hint, int shards_par, bool exact, FilterPatch fp) {
+  if (PATCH && blockIdx.x - fp.first < fp.n_patch) {
+    patch_body<true, true, true>(v, fp.cam, fp.par, fp.kf, blockIdx.x - fp.first, fp.n_patch);
+    return;
+  }
+  const uint32_t bid = PATCH ? (fp.first ? blockIdx.x : blockIdx.x - fp.n_patch) : blockIdx.x;   // the filter's own block index / grid
+  const uint32_t nblk = PATCH ? gridDim.x - fp.n_patch : gridDim.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
   uint32_t n_flat = *dcount;
@@ -394,10 +426,10 @@ __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDe
   const uint32_t n_sh = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)sh_incl, kMeshShards - 1));
   uint32_t n = n_flat + n_sh;
   if (n > max_entries) n = max_entries;
-  if (len_hint && blockIdx.x == 0 && threadIdx.x == 0) *len_hint = n;
-  const uint32_t nwaves = gridDim.x * 4;
+  if (len_hint && bid == 0 && threadIdx.x == 0) *len_hint = n;
+  const uint32_t nwaves = nblk * 4;
   if (WAVE_FORM) {
-    for (uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6)); entry < n;
+    for (uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6)); entry < n;
          entry += nwaves) {
       int4 id;
       uint32_t own_listed = kInvalidSlot;
@@ -420,7 +452,7 @@ __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDe
       maybe = __shfl((int)maybe, 0) != 0;
       if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
       if (!maybe) {
-        if (lane == 0) filter_reset_record(v, own, id, epoch, ppar);
+        if (lane == 0) filter_defer_reset(v, cnt, cap_sh, own, id);
         continue;
       }
       const uint32_t got = (uint32_t)__shfl((int)near8, is_near ? near_k(lane) : 0);
@@ -436,8 +468,8 @@ __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDe
   __shared__ int4 s_id[32];
   __shared__ uint32_t s_near[32][8];
   const int grp = threadIdx.x >> 3, k8 = threadIdx.x & 7;
-  const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
-  const uint32_t first = blockIdx.x * per;
+  const uint32_t per = (n + nblk - 1) / nblk;
+  const uint32_t first = bid * per;
   const uint32_t last = first + per < n ? first + per : n;
   for (uint32_t base = first; base < last; base += 32u) {
     if (threadIdx.x == 0) { s_n = 0; s_ne = 0; }
@@ -475,7 +507,7 @@ __global__ __launch_bounds__(256, WAVE_FORM ? 8 : 6) void k_mesh_filter(VolumeDe
       }
     }
     __syncthreads();
-    if (w == 3 && lane < (int)s_ne) filter_reset_record(v, s_eown[lane], s_eid[lane], epoch, ppar);
+    if (w == 3 && lane < (int)s_ne) filter_defer_reset(v, cnt, cap_sh, s_eown[lane], s_eid[lane]);
     const uint32_t nm = s_n;
     for (uint32_t m = (uint32_t)w; m < nm; m += 4u)
       filter_exact(v, s_id[m], is_near ? s_near[m][near_k(lane)] : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar,
@@ -562,7 +594,17 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     excl_l = incl_l - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)my_n, (int)(sh0 & 31u)));
     incl_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh0);  // (reused: the shard of the first row)
   }
-  if (blockIdx.x == 0 && t < (int)kMeshShards) { cnt_next[t * 16] = 0u; cnt_next[(kMeshShards + t) * 16] = 0u; cnt_next[(kMeshShards + t) * 16 + 1] = 0u; }  // the counters of the NEXT launch's filter
+  if (blockIdx.x == 0 && t < (int)kMeshShards) { cnt_next[t * 16] = 0u; cnt_next[(kMeshShards + t) * 16] = 0u; cnt_next[(kMeshShards + t) * 16 + 1] = 0u; cnt_next[(2 * kMeshShards + t) * 16] = 0u; }  // the counters of the NEXT launch's filter
+  if (!FF && blockIdx.x < kMeshShards) {
+    // the records the filter wanted emptied (filter_defer_reset): shard b by workgroup b, one thread per record, ahead
+    // of the workgroup's own chunk -- nothing in this launch reads another chunk's record
+    uint32_t n_reset = cnt[(2u * kMeshShards + blockIdx.x) * 16u];
+    if (n_reset > cap_sh) n_reset = cap_sh;
+    for (uint32_t i = (uint32_t)t; i < n_reset; i += NT) {
+      const int4 e = v.reset_list[(size_t)blockIdx.x * cap_sh + i];
+      filter_reset_record(v, (uint32_t)e.w, make_int4(e.x, e.y, e.z, 0), epoch, rearm >= 0 ? (rearm ^ 1) : -1);
+    }
+  }
   const float half = res * 0.5f;
   if (rearm >= 0 && blockIdx.x == 0 && t == 0) {
     // fused flow: the patches of the previous frame are done (the main stream waited for them ahead of this
@@ -1097,15 +1139,19 @@ static bool filter_uses_summaries() {
   return use_summ;
 }
 
-void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
+bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, int shards_par,
-                 hipStream_t s) {
-  if (!max_entries) return;
+                 hipStream_t s, const PatchStage* patch, const Cam* cam) {
+  if (!max_entries) return false;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshCntWords;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
   if (max_entries > v.max_chunks) max_entries = v.max_chunks;
   // 2560 workgroups = 1.25 x the wave form's resident capacity: a list of up to 10 k entries runs one entry per wave
-  const uint32_t fgrid = (max_entries + 3) / 4 < 2560u ? (max_entries + 3) / 4 : 2560u;
+  // (with the patch stage in the launch the two ranges share 6 waves per SIMD: TF_FILTER_GRID_PATCH sizes the filter's)
+  static const uint32_t fg_plain = getenv("TF_FILTER_GRID") ? (uint32_t)atoi(getenv("TF_FILTER_GRID")) : 2560u;
+  static const uint32_t fg_patch = getenv("TF_FILTER_GRID_PATCH") ? (uint32_t)atoi(getenv("TF_FILTER_GRID_PATCH")) : 2560u;
+  const uint32_t fmax = (patch && cam) ? fg_patch : fg_plain;
+  const uint32_t fgrid = (max_entries + 3) / 4 < fmax ? (max_entries + 3) / 4 : fmax;
   const uint32_t* dslot = fused ? v.work_slot : nullptr;
   const int ppar = fused ? (rearm_set ^ 1) : -1;
   // TF_MESH_FUSED=1: the mesher runs the filter itself, one workgroup per entry of a short list (k_mesh<128, true>).
@@ -1118,7 +1164,7 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
     uint32_t g = len_guess + len_guess / 8u + 256u;  // the list of the frame before + slack; a longer list strides
     if (g > max_entries) g = max_entries;
     launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, &fa, g, false, s);
-    return;
+    return false;
   }
   // TF_FILTER_EXACT=0: the wave form leaves the exact test to the mesher (which finds no surface cell in the ~20 % the
   // test would have caught, and rewrites the summary from the own voxels it loads anyway).  Measured on the room stream
@@ -1126,15 +1172,28 @@ void launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   // resident workgroups) -- no gain, so the filter keeps the test.
   static const bool wave_exact = !(getenv("TF_FILTER_EXACT") && !atoi(getenv("TF_FILTER_EXACT")));
   const bool use_summ = filter_uses_summaries();
-  const bool wave_form = len_guess <= fgrid * 4u;
+  const bool wave_form = len_guess <= 2560u * 4u;  // (the wave form strides when its grid is smaller than the list)
   const bool exact = !wave_form || wave_exact || !use_summ;
-  if (wave_form)
-    hipLaunchKernelGGL(k_mesh_filter<true>, dim3(fgrid), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, epoch,
-                       v.mesh_nbr, cnt, cap_sh, ppar, use_summ, len_hint, shards_par, exact);
-  else
-    hipLaunchKernelGGL(k_mesh_filter<false>, dim3(fgrid), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, epoch,
-                       v.mesh_nbr, cnt, cap_sh, ppar, use_summ, len_hint, shards_par, true);
+  FilterPatch fp;
+  memset(&fp, 0, sizeof(fp));
+  if (patch && cam) {
+    // one wave per patch; the range is dispatched AHEAD of the filter's workgroups (its chains are the longer ones)
+    static const uint32_t np = getenv("TF_FILTER_PATCH_BLOCKS") ? (uint32_t)atoi(getenv("TF_FILTER_PATCH_BLOCKS")) : 1024u;
+    static const bool patch_last = getenv("TF_FILTER_PATCH_LAST") && atoi(getenv("TF_FILTER_PATCH_LAST"));
+    fp.n_patch = np;
+    fp.first = patch_last ? fgrid : 0u;
+    fp.par = patch->par;
+    fp.cam = *cam;
+    fp.kf = patch->kf;
+  }
+#define TF_LAUNCH_FILTER(W, P, EX)                                                                                   \
+  hipLaunchKernelGGL((k_mesh_filter<W, P>), dim3(fgrid + fp.n_patch), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, \
+                     epoch, v.mesh_nbr, cnt, cap_sh, ppar, use_summ, len_hint, shards_par, EX, fp)
+  if (wave_form) { if (fp.n_patch) TF_LAUNCH_FILTER(true, true, exact); else TF_LAUNCH_FILTER(true, false, exact); }
+  else { if (fp.n_patch) TF_LAUNCH_FILTER(false, true, true); else TF_LAUNCH_FILTER(false, false, true); }
+#undef TF_LAUNCH_FILTER
   launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, nullptr, 0, !exact, s);
+  return fp.n_patch != 0;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -232,6 +232,7 @@ int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint3
 int xchg_band_counts(tf_volume* v, const FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]);
 int flush_deferred(tf_volume* v);
 int patch_flush(tf_volume* v);
+bool patch_rides_filter();  // TF_PATCH_IN_FILTER=1 (off by default: measured slower, tf_capi.cpp)
 int fused_arm(tf_volume* v);  // the fused flow's counter sets in their start state (no-op once armed)
 int ensure_pinned(tf_volume* v, size_t bytes);
 void prof_begin(tf_volume* v, int kind, hipStream_t s = nullptr);
