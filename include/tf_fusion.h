@@ -208,6 +208,11 @@ TF_API int tf_keyframe_unit_release(tf_volume* v);
  * region, regions handed out}.  A re-integrated keyframe writes into its region when the list fits, else it gets a new
  * one; the live regions are moved together when the top reaches the capacity.  Synchronises. */
 TF_API int tf_keyframe_unit_stats(tf_volume* v, int64_t out[5]);
+/* The store has no fixed ceiling: the region table starts with 1024 keyframe slots and doubles when a new keyframe needs
+ * one more (the reference sizes its keyframe database for 20 000 frames, main.cpp:81); the arena doubles when the live
+ * regions pass three quarters of it (one stream synchronisation + one device copy per doubling).
+ * out = {slots of the table, keyframes that own one, doublings so far (table + arena), arena entries}.  Does not synchronise. */
+TF_API int tf_keyframe_unit_stats_ex(tf_volume* v, int64_t out[4]);
 
 /* ---- view-selection bookkeeping on the device ------------------------------
  * Chunk::observations (3rd_party/open_chisel/geometry/Chunk.h:171) lives in HBM, keyed by (chunk, keyframe):

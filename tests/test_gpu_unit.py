@@ -168,3 +168,99 @@ def test_keyframe_store_reuses_regions_and_compacts(gpu_required, monkeypatch):
         for b in t:
             b.free()
     gv.close()
+
+
+def test_keyframe_store_grows_past_its_first_table_and_arena(gpu_required, monkeypatch):
+    """No fixed ceiling on keyframes (the reference sizes its database for 20 000 frames, main.cpp:81): with a first table
+    of 8 slots (TF_UNIT_SLOTS) and the default growth rule, 40 keyframes go in, the table doubles three times, and keyframes
+    stored BEFORE the doublings are moved afterwards -- their validChunks must have survived the copies: the volume is
+    compared with one that never grew (TF_UNIT_SLOTS = 64) and with the oracle for the moved groups' chunks."""
+    cam = synth.Camera()
+    n_kf = 40
+    fr = [synth.room_frame(3 * k, cam, with_quality=False) for k in range(n_kf + 2)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in fr]
+
+    def run(slots):
+        monkeypatch.setenv("TF_UNIT_SLOTS", str(slots))
+        gv = capi.Volume(RES5, cam, max_chunks=1 << 17, max_list=1 << 16)   # (arena 16 x 65536 entries: never grows here)
+
+        def grp(k, shift=0, old=False):
+            kw = dict(old_keyframe_pose=fr[k][3], old_local_poses=[]) if old else {}
+            return capi.Volume.unit_group(100 + k, (bufs[k][0].ptr, bufs[k][1].ptr, 0, fr[k + shift][3]), [], **kw)
+
+        for k in range(n_kf):
+            moved = []
+            if k == 30:
+                moved = [grp(2, 1, True), grp(7, 1, True)]      # stored while the table had 8 slots
+            if k == 39:
+                moved = [grp(20, 1, True)]                      # ... and while it had 32
+            gv.keyframe_unit(fresh=grp(k), moved=moved, texture=False)
+        gv.sync()
+        return gv
+
+    a = run(8)
+    sa = a.keyframe_unit_stats_ex()
+    assert sa["keyframes"] == n_kf and sa["slots"] == 64 and sa["doublings"] >= 3, sa
+    b = run(64)
+    sb = b.keyframe_unit_stats_ex()
+    assert sb["slots"] == 64 and sb["doublings"] == 0, sb
+    ia, ib = sorted_ids(a.list_chunks()), sorted_ids(b.list_chunks())
+    assert np.array_equal(ia, ib) and len(ia) > 5000
+    for lo in range(0, len(ia), 4096):
+        s1, w1, c1 = a.get_chunks(ia[lo:lo + 4096:3])
+        s2, w2, c2 = b.get_chunks(ia[lo:lo + 4096:3])
+        assert np.array_equal(s1.view(np.uint32), s2.view(np.uint32)) and np.array_equal(w1.view(np.uint32), w2.view(np.uint32))
+        assert np.array_equal(c1, c2)
+    # the moved keyframes against the oracle: after de-integrating frame 2 at its old pose and re-integrating it at frame
+    # 3's, the oracle volume that did the same holds the same voxels in the chunks of that keyframe's new list
+    ov = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
+    valid = {}
+    for k in range(n_kf):
+        if k == 30:
+            for m in (2, 7):
+                _oracle_group(ov, 100 + m, (fr[m][0], fr[m][1], None, fr[m][3]), [], 0, ids=valid[m])
+                valid[m] = _oracle_group(ov, 100 + m, (fr[m][0], fr[m][1], None, fr[m + 1][3]), [], 1)
+        if k == 39:
+            _oracle_group(ov, 120, (fr[20][0], fr[20][1], None, fr[20][3]), [], 0, ids=valid[20])
+            valid[20] = _oracle_group(ov, 120, (fr[20][0], fr[20][1], None, fr[21][3]), [], 1)
+        valid[k] = _oracle_group(ov, 100 + k, (fr[k][0], fr[k][1], None, fr[k][3]), [], 1)
+    oids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(oids, ia)
+    assert_chunks_equal(ov, a, oids[::7], "grown keyframe store")
+    a.close(); b.close()
+    for p in bufs:
+        p[0].free(); p[1].free()
+
+
+def test_keyframe_arena_doubles_when_the_live_lists_fill_it(gpu_required, monkeypatch):
+    """The arena side of the same: started at a size the first few lists fill (the initial size follows tf_config.max_list),
+    it doubles instead of reporting TF_ERR_CAPACITY, and a keyframe stored before the doubling is moved after it."""
+    cam = synth.Camera()
+    n_kf = 24
+    fr = [synth.room_frame(4 * k, cam, with_quality=False) for k in range(n_kf + 1)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in fr]
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 17, max_list=1 << 14)   # arena = 16 x 16384 entries: ~26 room lists with slack
+    ov = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
+    valid = {}
+    cap0 = None
+    for k in range(n_kf):
+        moved = []
+        if k == n_kf - 1:
+            moved = [capi.Volume.unit_group(100 + 1, (bufs[1][0].ptr, bufs[1][1].ptr, 0, fr[2][3]), [], old_keyframe_pose=fr[1][3],
+                                            old_local_poses=[])]
+            _oracle_group(ov, 101, (fr[1][0], fr[1][1], None, fr[1][3]), [], 0, ids=valid[1])
+            valid[1] = _oracle_group(ov, 101, (fr[1][0], fr[1][1], None, fr[2][3]), [], 1)
+        gv.keyframe_unit(fresh=capi.Volume.unit_group(100 + k, (bufs[k][0].ptr, bufs[k][1].ptr, 0, fr[k][3]), []), moved=moved,
+                         texture=False)
+        valid[k] = _oracle_group(ov, 100 + k, (fr[k][0], fr[k][1], None, fr[k][3]), [], 1)
+        if cap0 is None:
+            cap0 = gv.keyframe_unit_stats_ex()["arena"]
+    gv.sync()   # (an arena that ran full would raise TF_ERR_CAPACITY here)
+    st, sx = gv.keyframe_unit_stats(), gv.keyframe_unit_stats_ex()
+    assert sx["arena"] > cap0 and sx["doublings"] >= 1 and st["top"] <= st["capacity"] == sx["arena"], (st, sx, cap0)
+    oids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(oids, sorted_ids(gv.list_chunks()))
+    assert_chunks_equal(ov, gv, oids[::9], "doubled arena")
+    gv.close()
+    for p in bufs:
+        p[0].free(); p[1].free()

@@ -35,7 +35,7 @@ SYMBOLS = (
     "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
     "tf_integrate_frames_device", "tf_sync", "tf_has_chunk", "tf_chunk_download",
     "tf_chunks_download", "tf_chunk_upload", "tf_list_chunks", "tf_list_dirty", "tf_clear_dirty",
-    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_profile_calibrate", "tf_keyframe_unit_device", "tf_keyframe_unit_release", "tf_keyframe_unit_stats", "tf_observations_record", "tf_observations_retract", "tf_export_datacost", "tf_export_adjacency", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
+    "tf_get_stats", "tf_profile_enable", "tf_profile_get", "tf_profile_calibrate", "tf_keyframe_unit_device", "tf_keyframe_unit_release", "tf_keyframe_unit_stats", "tf_keyframe_unit_stats_ex", "tf_observations_record", "tf_observations_retract", "tf_export_datacost", "tf_export_adjacency", "tf_debug_phase_raw", "tf_set_partition", "tf_set_partition_key", "tf_boundary_pack", "tf_boundary_pack_async",
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_set_pose",
     "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_atlas_size", "tf_meshes_upload",
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
@@ -145,6 +145,7 @@ def lib():
     L.tf_keyframe_unit_device.argtypes = [vp, C.POINTER(UnitGroup), C.POINTER(UnitGroup), C.c_int32, C.c_int32, fp]
     L.tf_keyframe_unit_release.argtypes = [vp]
     L.tf_keyframe_unit_stats.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.tf_keyframe_unit_stats_ex.argtypes = [vp, C.POINTER(C.c_int64)]
     L.tf_observations_record.argtypes = [vp, C.c_int32]
     L.tf_observations_retract.argtypes = [vp, C.c_int32, i32p, C.c_int64]
     L.tf_export_datacost.argtypes = [vp, i32p, C.c_int64, C.c_int32, i32p, C.c_int32, fp]
@@ -555,6 +556,12 @@ class Volume:
         out = (C.c_int64 * 5)()
         self._ck(self.L.tf_keyframe_unit_stats(self.h, out))
         return dict(zip(("capacity", "top", "compactions", "reuses", "regions"), [int(x) for x in out]))
+
+    def keyframe_unit_stats_ex(self):
+        """{slots, keyframes, doublings, arena} of the keyframes' validChunks store (grows on demand)"""
+        out = (C.c_int64 * 4)()
+        self._ck(self.L.tf_keyframe_unit_stats_ex(self.h, out))
+        return dict(zip(("slots", "keyframes", "doublings", "arena"), [int(x) for x in out]))
 
     # -- Chunk::observations on the device and the exports TexMap consumes
     def observations_record(self, keyframe_id):

@@ -442,6 +442,8 @@ int tf_volume_destroy(tf_volume* v) {
   delete v->copy_pool;
   v->copy_pool = nullptr;
   if (v->copy_stream) hipStreamDestroy(v->copy_stream);
+  if (v->copy_stream2) hipStreamDestroy(v->copy_stream2);
+  if (v->copy_join) hipEventDestroy(v->copy_join);
   if (v->own_stream && v->stream) hipStreamDestroy(v->stream);
   delete v;
   return TF_OK;
@@ -773,12 +775,14 @@ int tf::fused_arm(tf_volume* v) {
 // claimed: the dirty set of this frame is already in the lists of the current parity -- K-A built it (FrameStage::claim_par
 // = the parity used here), or the caller ran launch_dirty_frame over each of its lists (the keyframe unit)
 int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
-                      const float* pose_inv16, int32_t frame_id, bool claimed, const FrameCtl* next_ctl) {
+                      const float* pose_inv16, int32_t frame_id, bool claimed, const FrameCtl* next_ctl, bool ride_filter) {
   AtlasState& a = v->atlas;
   // A patch stage still pending here (the previous textured frame's) must read its meshes before this frame's mesher
   // rewrites them: it goes out on its own first -- or, with TF_PATCH_IN_FILTER=1, rides on this frame's FILTER launch
   // (launch_mesh below; measured slower than riding on k_frame: see patch_rides_filter)
-  const bool ride = a.pend_patch.on && patch_rides_filter() && a.fused_armed;
+  static const bool unit_ride = !(getenv("TF_UNIT_PATCH_RIDE") && !atoi(getenv("TF_UNIT_PATCH_RIDE")));  // A/B knob, default on
+  static const bool mesh_fused_form = getenv("TF_MESH_FUSED") && atoi(getenv("TF_MESH_FUSED"));
+  const bool ride = a.pend_patch.on && a.fused_armed && (patch_rides_filter() || (ride_filter && unit_ride && !mesh_fused_form));
   int rc = TF_OK;
   if (!ride) { rc = patch_flush(v); if (rc) return rc; }
   rc = fused_arm(v);
@@ -1225,7 +1229,27 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   }
   lap(2, t);
   static const bool dbg_noh2d = getenv("TF_HOST_NOH2D") && atoi(getenv("TF_HOST_NOH2D"));  // timing experiment only: WRONG results
-  if (!dbg_noh2d) TF_HIP(hipMemcpyAsync(s.d, s.h, rgba ? npix * 8 : npix * 4, hipMemcpyHostToDevice, v->copy_stream));
+  // TF_HOST_COPY_SPLIT=1: depth and colour go up on two copy streams (two SDMA queues); the join happens between the copy
+  // streams, so the stream the kernels run on still sees ONE event per frame
+  // Default: only for TSDF-only frames -- that stream is bound by the upload (62 -> 52 us per frame, 16.1 k -> 19 k
+  // frames/s, profiles/r4), while the textured stream is bound by the host side of the call, where the second copy call
+  // and the join cost 3 us per frame (99.6 -> 103.2).  TF_HOST_COPY_SPLIT=0 / 1 forces it off / on.
+  static const int split_knob = getenv("TF_HOST_COPY_SPLIT") ? atoi(getenv("TF_HOST_COPY_SPLIT")) : -1;
+  const bool split = split_knob < 0 ? pose_inv16 == nullptr : split_knob != 0;
+  if (!dbg_noh2d) {
+    if (split && rgba) {
+      if (!v->copy_stream2) {
+        TF_HIP(hipStreamCreateWithFlags(&v->copy_stream2, hipStreamNonBlocking));
+        TF_HIP(hipEventCreateWithFlags(&v->copy_join, hipEventDisableTiming));
+      }
+      TF_HIP(hipMemcpyAsync(s.d + npix * 4, s.h + npix * 4, npix * 4, hipMemcpyHostToDevice, v->copy_stream2));
+      TF_HIP(hipEventRecord(v->copy_join, v->copy_stream2));
+      TF_HIP(hipMemcpyAsync(s.d, s.h, npix * 4, hipMemcpyHostToDevice, v->copy_stream));
+      TF_HIP(hipStreamWaitEvent(v->copy_stream, v->copy_join, 0));
+    } else {
+      TF_HIP(hipMemcpyAsync(s.d, s.h, rgba ? npix * 8 : npix * 4, hipMemcpyHostToDevice, v->copy_stream));
+    }
+  }
   TF_HIP(hipEventRecord(s.copied, v->copy_stream));
   lap(3, t);
   tf_volume::Pending cur;

@@ -311,9 +311,14 @@ void launch_select(const VolumeDev& v, const float* depth, const Cam& cam, const
 void launch_scan(const VolumeDev& v, int step, hipStream_t s);
 void launch_acquire(const VolumeDev& v, hipStream_t s);
 void launch_lookup(const VolumeDev& v, uint32_t n, hipStream_t s);
+// have_pre: the list records / centroid table of this pose are already there (launch_pre_frames)
 void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam, const Integ& ig,
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
-                      uint32_t epoch, hipStream_t s);
+                      uint32_t epoch, hipStream_t s, bool have_pre = false);
+// list records + centroid tables of a keyframe (into the selection set, as k_pre leaves them) and of its n local frames
+// (into the group scratch, as k_pre_group leaves them) in ONE launch
+void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const float* poses12, float4* pre_scratch,
+                       float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s);
 void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
 void launch_pack_rgba(const uint8_t* rgb, const uint8_t* valid, uchar4* rgba, uint32_t npix, hipStream_t s);
 void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipStream_t s);
@@ -355,7 +360,8 @@ void launch_init_meshes(const VolumeDev& v, hipStream_t s);
 // fused = the per-frame flow: the mesh is marked simplified at once (CompressMeshes follows in the same frame)
 // keyframe group: n (<= 6) depth-only frames over the current list in one visit per chunk; scratch = n x (4 x max_list float4 + 1536 floats)
 void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
-                            float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s);
+                            float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s,
+                            bool have_pre = false);
 uint32_t mesh_shard_rows(uint32_t max_chunks);
 // len_guess: the list length as far as the host knows (picks the filter's form); len_hint: host-visible word that
 // receives the actual length (may be null)

@@ -1205,16 +1205,20 @@ struct GroupPoses {
   Pose P[kGroupMax];
 };
 // list records and centroid tables of all frames of a group in one launch (blockIdx.y = frame)
+// (with_key: blockIdx.y == 0 is the KEYFRAME -- pose `key`, records into the selection set like k_pre's -- and the local
+// frames follow at y = 1 + f: the keyframe unit computes all seven frames' records in one launch)
 __global__ __launch_bounds__(256) void k_pre_group(VolumeDev v, GroupPoses gp, Integ ig, float res, float resDiag,
-                                                   float4* pre_scratch, float* cen_scratch) {
+                                                   float4* pre_scratch, float* cen_scratch, Pose key, int with_key) {
   const SelBuf& L = v.sel;
-  const int f = blockIdx.y;
-  float4* pre = pre_scratch + (size_t)f * 4 * v.max_list;
-  if (blockIdx.x == 0) centroid_table(gp.P[f].p, res, cen_scratch + (size_t)f * 3 * kChunkVoxels);
+  const bool is_key = with_key && blockIdx.y == 0;
+  const int f = is_key ? 0 : (int)blockIdx.y - (with_key ? 1 : 0);
+  const float* P = is_key ? key.p : gp.P[f].p;
+  float4* pre = is_key ? L.list_pre : pre_scratch + (size_t)f * 4 * v.max_list;
+  if (blockIdx.x == 0) centroid_table(P, res, is_key ? L.cen : cen_scratch + (size_t)f * 3 * kChunkVoxels);
   const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const int4 id = L.list_id[e];
-    const ChunkPre cp = chunk_pre(id, gp.P[f].p, ig, res, resDiag);
+    const ChunkPre cp = chunk_pre(id, P, ig, res, resDiag);
     pre[4 * e] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
     pre[4 * e + 1] = make_float4(cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
   }
@@ -1453,9 +1457,9 @@ static int ka_blocks_default() { return device_cus() * TF_KF_WAVES; }
 
 void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam, const Integ& ig,
                       const Pose& pose, float res, int flag, bool use_color, bool use_quality,
-                      uint32_t epoch, hipStream_t s) {
+                      uint32_t epoch, hipStream_t s, bool have_pre) {
   IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
-  hipLaunchKernelGGL(k_pre, dim3(256), dim3(256), 0, s, v, pose, ig, res, kc.resDiag, (float4*)nullptr, (float*)nullptr);
+  if (!have_pre) hipLaunchKernelGGL(k_pre, dim3(256), dim3(256), 0, s, v, pose, ig, res, kc.resDiag, (float4*)nullptr, (float*)nullptr);
   static const int nblocks = env_int("TF_KA_BLOCKS", ka_blocks_default());  // tuning knob
   const dim3 grid(nblocks > 0 ? nblocks : 2048), block(256);
 #define TF_LAUNCH_KA(C, Q)                                                                           \
@@ -1469,8 +1473,17 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
 #undef TF_LAUNCH_KA
 }
 
+void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const float* poses12, float4* pre_scratch,
+                       float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s) {
+  const IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);  // (resDiag does not depend on the flag)
+  GroupPoses gp = {};
+  for (int f = 0; f < n; ++f)
+    for (int q = 0; q < 12; ++q) gp.P[f].p[q] = poses12[12 * f + q];
+  hipLaunchKernelGGL(k_pre_group, dim3(128, n + 1), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch, keyframe, 1);
+}
+
 void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
-                            float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s) {
+                            float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s, bool have_pre) {
   IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
   GroupArgs ga = {};
   GroupPoses gp = {};
@@ -1481,7 +1494,7 @@ void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_dep
     ga.pre[f] = pre_scratch + (size_t)f * 4 * v.max_list;
     ga.cen[f] = cen_scratch + (size_t)f * 3 * kChunkVoxels;
   }
-  hipLaunchKernelGGL(k_pre_group, dim3(128, n), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch);
+  if (!have_pre) hipLaunchKernelGGL(k_pre_group, dim3(128, n), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch, Pose{}, 0);
   static const int nblocks = env_int("TF_KG_BLOCKS", 0);
   int cus = ka_blocks_default() / TF_KF_WAVES;
   const dim3 grid(nblocks > 0 ? nblocks : cus * 4), block(256);  // 36 KB of LDS per workgroup: four per CU

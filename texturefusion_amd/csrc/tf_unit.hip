@@ -22,18 +22,31 @@ namespace tf {
 // when the new list fits (regions are handed out with a quarter of slack), else it gets a new region at the top; when
 // the top reaches the end of the arena the live regions are moved together first (k_kf_store, one workgroup, no host
 // involvement).
-constexpr int kUnitMaxKf = 1024;
+// The table of regions has one slot per keyframe and GROWS (the reference sizes its keyframe database for 20 000 frames,
+// main.cpp:81, GCSLAM/GCSLAM.h:24-26): header + four arrays of `slots` words behind it.  The arena grows too: the store
+// kernel leaves {top, largest list, live words} in host-visible memory, and a call that finds the live regions above
+// three quarters of the arena (with room for the lists still in flight) doubles it -- one stream synchronisation and one
+// device copy per doubling; below that the device-side compaction reclaims dead regions on its own.
+constexpr uint32_t kUnitSlots0 = 1024;  // initial slots (doubles on demand)
 struct KfTab {
   uint32_t top;  // ids handed out so far
   uint32_t n_compact, n_reuse, n_regions;  // statistics: compactions, stores into an existing region, regions handed out
-  uint32_t off[kUnitMaxKf];
-  uint32_t n[kUnitMaxKf];
-  uint32_t capn[kUnitMaxKf];  // size of the slot's region (0: none)
+  uint32_t max_tot;  // longest list stored so far
+  uint32_t live;     // sum of the live regions' sizes
+  uint32_t pad[2];
+  // uint32_t off[slots], n[slots], capn[slots] (size of the slot's region, 0: none), order[slots] (compaction scratch)
 };
+__host__ __device__ inline uint32_t* kf_off(KfTab* t) { return reinterpret_cast<uint32_t*>(t + 1); }
+__host__ __device__ inline const uint32_t* kf_off(const KfTab* t) { return reinterpret_cast<const uint32_t*>(t + 1); }
+inline size_t kf_tab_bytes(uint32_t slots) { return sizeof(KfTab) + (size_t)4 * slots * sizeof(uint32_t); }
 struct UnitState {
   int4* arena = nullptr;
   uint32_t cap = 0;
+  bool fixed_arena = false;  // TF_UNIT_ARENA: a test pins the arena (compaction is then the only way to make room)
   KfTab* tab = nullptr;
+  uint32_t slots = 0;
+  uint32_t* h_fill = nullptr;  // pinned: [0] top, [1] longest list, [2] live words -- as of the last store the device finished
+  uint64_t grows = 0;
   std::unordered_map<int32_t, int> slot_of;
   float4* group_pre = nullptr;  // scratch of the keyframe-group kernel (list records + centroid tables of six frames)
   float* group_cen = nullptr;
@@ -43,18 +56,39 @@ static std::mutex g_units_mu;                              // (handles may live 
 
 // FinalizeIntegrateChunks' validChunks (Chisel.h:192-208): the entries of the current list whose needsUpdate flag is set,
 // in list order, appended to the arena.  One workgroup: the order must be kept.
-__global__ __launch_bounds__(1024) void k_kf_store(VolumeDev v, KfTab* tab, int4* arena, uint32_t cap, int slot, int slack) {
+__global__ __launch_bounds__(1024) void k_kf_store(VolumeDev v, KfTab* tab, uint32_t slots, int4* arena, uint32_t cap, int slot,
+                                                   int slack, uint32_t* fill) {
   const SelBuf& L = v.sel;
+  uint32_t* const t_off = kf_off(tab);
+  uint32_t* const t_n = t_off + slots;
+  uint32_t* const t_capn = t_n + slots;
+  uint32_t* const t_order = t_capn + slots;
   const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
   __shared__ uint32_t wsum[16];
-  __shared__ uint32_t base, run;
+  __shared__ uint32_t base;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) run = 0;
-  // pass 1: count
-  uint32_t cnt = 0;
-  for (uint32_t e = threadIdx.x; e < n; e += 1024) cnt += L.list_needs[e] ? 1u : 0u;
+  // The flags of the first 16 384 entries as ballots (wave w: the 1024 consecutive entries from 1024 w, sixteen coalesced
+  // rounds) -- for a list that short (a room frame has 11 k) these ARE the count, and the compaction below reuses them;
+  // a longer list is counted with a strided pass.  Thread 0 fetches the table's header and the slot's record meanwhile,
+  // so that the serial part between the barriers is arithmetic on registers (it was a chain of ten dependent loads).
+  unsigned long long masks0[16];
+  uint32_t mine0 = 0;
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+  for (int r = 0; r < 16; ++r) {
+    const uint32_t e = (uint32_t)w * 1024u + (uint32_t)r * 64u + (uint32_t)lane;
+    masks0[r] = __ballot(e < n && L.list_needs[e] != 0);
+    mine0 += (uint32_t)__popcll(masks0[r]);
+  }
+  KfTab h = {};
+  uint32_t capn_s = 0, off_s = 0;
+  if (threadIdx.x == 0) { h = *tab; capn_s = t_capn[slot]; off_s = t_off[slot]; }
+  uint32_t cnt = mine0;  // (wave-uniform)
+  if (n > 16384u) {
+    cnt = 0;
+    for (uint32_t e = threadIdx.x; e < n; e += 1024) cnt += L.list_needs[e] ? 1u : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+  }
   if (lane == 0) wsum[w] = cnt;
   __syncthreads();
   __shared__ uint32_t s_tot, s_need, s_compact;
@@ -63,38 +97,45 @@ __global__ __launch_bounds__(1024) void k_kf_store(VolumeDev v, KfTab* tab, int4
     for (int k = 0; k < 16; ++k) tot += wsum[k];
     s_tot = tot;
     s_compact = 0;
-    if (tot <= tab->capn[slot]) {  // fits the region the keyframe already has
+    if (tot > h.max_tot) h.max_tot = tot;
+    if (tot <= capn_s) {  // fits the region the keyframe already has
       s_need = 0;
-      tab->n_reuse += 1;
+      h.n_reuse += 1;
     } else {
       uint32_t need = tot + (slack ? tot / 4u + 64u : 0u);
-      tab->capn[slot] = 0;         // the old region (if any) is dead space from here on
-      tab->n[slot] = 0;
-      if (tab->top + need > cap) s_compact = 1;
+      h.live -= capn_s;
+      capn_s = 0;               // the old region (if any) is dead space from here on
+      if (h.top + need > cap) {  // (rare) the compaction below works on the table in memory
+        s_compact = 1;
+        *tab = h;
+        t_capn[slot] = 0;
+        t_n[slot] = 0;
+      }
       s_need = need;
     }
   }
   __syncthreads();
   if (s_compact) {
-    // Move the live regions together, in the order they lie in the arena (slot t's thread counts the live regions
-    // below its own; the moves go downwards one region after the other, each by the whole workgroup).
-    __shared__ uint32_t s_order[kUnitMaxKf];
+    // Move the live regions together, in the order they lie in the arena (a slot's thread counts the live regions
+    // below its own -- quadratic in the number of slots, but a compaction is rare --; the moves go downwards one
+    // region after the other, each by the whole workgroup).
     __shared__ uint32_t s_live;
-    const uint32_t t = threadIdx.x;  // (kUnitMaxKf == the workgroup's size)
-    const uint32_t my_cap = tab->capn[t], my_off = tab->off[t];
+    const uint32_t t = threadIdx.x;
     if (t == 0) s_live = 0;
     __syncthreads();
-    if (my_cap) {
+    for (uint32_t k = t; k < slots; k += 1024u) {
+      if (!t_capn[k]) continue;
+      const uint32_t my_off = t_off[k];
       uint32_t below = 0;
-      for (int k = 0; k < kUnitMaxKf; ++k) below += (tab->capn[k] && tab->off[k] < my_off) ? 1u : 0u;
-      s_order[below] = t;
+      for (uint32_t j = 0; j < slots; ++j) below += (t_capn[j] && t_off[j] < my_off) ? 1u : 0u;
+      t_order[below] = k;
       atomicAdd(&s_live, 1u);
     }
     __syncthreads();
     uint32_t to = 0;
     for (uint32_t r = 0; r < s_live; ++r) {
-      const uint32_t k = s_order[r];
-      const uint32_t from = tab->off[k], len = tab->n[k], oldcap = tab->capn[k];
+      const uint32_t k = t_order[r];
+      const uint32_t from = t_off[k], len = t_n[k], oldcap = t_capn[k];
       const uint32_t roomy = len + (slack ? len / 4u + 64u : 0u);
       const uint32_t newcap = roomy < oldcap ? roomy : oldcap;
       __syncthreads();  // (every thread has read the region's old record)
@@ -107,11 +148,11 @@ __global__ __launch_bounds__(1024) void k_kf_store(VolumeDev v, KfTab* tab, int4
           __syncthreads();
         }
       }
-      if (t == 0) { tab->off[k] = to; tab->capn[k] = newcap; }
+      if (t == 0) { t_off[k] = to; t_capn[k] = newcap; }
       to += newcap;
       __syncthreads();
     }
-    if (t == 0) { tab->top = to; tab->n_compact += 1; }
+    if (t == 0) { tab->top = to; tab->live = to; tab->n_compact += 1; h = *tab; }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
@@ -119,38 +160,69 @@ __global__ __launch_bounds__(1024) void k_kf_store(VolumeDev v, KfTab* tab, int4
     uint32_t need = s_need;
     bool ok = true;
     if (need) {
-      if (tab->top + need > cap) need = tot;  // no slack left: an exact fit
-      if (tab->top + need > cap) { atomicOr(&v.vctl->status, kStListFull); ok = false; }
-      else { tab->off[slot] = tab->top; tab->capn[slot] = need; tab->top += need; tab->n_regions += 1; }
+      if (h.top + need > cap) need = tot;  // no slack left: an exact fit
+      if (h.top + need > cap) { atomicOr(&v.vctl->status, kStListFull); ok = false; capn_s = 0; }
+      else { off_s = h.top; capn_s = need; h.top += need; h.live += need; h.n_regions += 1; }
     }
-    tab->n[slot] = ok ? tot : 0u;
-    base = (ok && tot) ? tab->off[slot] : 0xFFFFFFFFu;
+    *tab = h;
+    t_off[slot] = off_s;
+    t_capn[slot] = capn_s;
+    t_n[slot] = ok ? tot : 0u;
+    base = (ok && tot) ? off_s : 0xFFFFFFFFu;
+    if (fill) {  // what the host sizes the arena by (no synchronisation: whatever it reads is at most a few calls old)
+      __hip_atomic_store(&fill[1], h.max_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&fill[2], h.live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&fill[0], h.top, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   __syncthreads();
   if (base == 0xFFFFFFFFu) return;
-  // pass 2: ordered compaction, 1024 entries per round
-  for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
-    const uint32_t e = b0 + threadIdx.x;
-    const bool keep = e < n && L.list_needs[e] != 0;
-    const unsigned long long m = __ballot(keep);
-    if (lane == 0) wsum[w] = (uint32_t)__popcll(m);
+  // pass 2: ordered compaction in stretches of 16 384 entries -- wave w takes the 1024 consecutive entries
+  // [s0 + 1024 w, s0 + 1024 (w + 1)) as 16 coalesced rounds of 64 whose ballots stay in registers, ONE scan over the 16
+  // wave counts places the waves, and every flagged entry is written behind the flagged entries before it.  (Rounds of
+  // 1024 entries with three barriers each took 13.9 us per keyframe of the room stream, profiles/r4: a list of 11 k
+  // entries is one stretch here.)
+  __shared__ uint32_t wcnt[16];
+  uint32_t run = 0;  // flagged entries of the stretches before this one (block-uniform)
+  for (uint32_t s0 = 0; s0 < n; s0 += 16384u) {
+    const uint32_t w0 = s0 + (uint32_t)w * 1024u;
+    unsigned long long masks[16];
+    uint32_t mine = mine0;
+    if (s0 == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) masks[r] = masks0[r];
+    } else {
+      mine = 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const uint32_t e = w0 + (uint32_t)r * 64u + (uint32_t)lane;
+        masks[r] = __ballot(e < n && L.list_needs[e] != 0);
+        mine += (uint32_t)__popcll(masks[r]);
+      }
+    }
+    __syncthreads();  // (wcnt of the previous stretch has been read)
+    if (lane == 0) wcnt[w] = mine;
     __syncthreads();
-    uint32_t before = 0, tot = 0;
-    for (int k = 0; k < 16; ++k) { if (k < w) before += wsum[k]; tot += wsum[k]; }
-    if (keep) arena[base + run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = L.list_id[e];
-    __syncthreads();
-    if (threadIdx.x == 0) run += tot;
-    __syncthreads();
+    uint32_t before = run, tot = 0;
+    for (int k = 0; k < 16; ++k) { if (k < w) before += wcnt[k]; tot += wcnt[k]; }
+    uint32_t at = base + before;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned long long m = masks[r];
+      if ((m >> lane) & 1ull) arena[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = L.list_id[w0 + (uint32_t)r * 64u + (uint32_t)lane];
+      at += (uint32_t)__popcll(m);
+    }
+    run += tot;
   }
 }
 
 // localChunksIntersecting = kf.validChunks; needsUpdate = true, newChunk = false for every entry (MobileFusion.cpp:135-143);
 // slots resolved like tf_integrate does for a caller's list (a missing chunk is an error: chunks.at() throws)
-__global__ __launch_bounds__(256) void k_kf_load(VolumeDev v, const KfTab* tab, const int4* arena, int slot) {
+__global__ __launch_bounds__(256) void k_kf_load(VolumeDev v, const KfTab* tab, uint32_t slots, const int4* arena, int slot) {
   const SelBuf& L = v.sel;
-  uint32_t n = tab->n[slot];
+  uint32_t n = kf_off(tab)[slots + slot];
   if (n > v.max_list) { n = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&v.vctl->status, kStListFull); }
-  const uint32_t off = tab->off[slot];
+  const uint32_t off = kf_off(tab)[slot];
   if (blockIdx.x == 0 && threadIdx.x == 0) { L.ctl->n_list = n; L.ctl->n_front = n; }
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const int4 id = arena[off + e];
@@ -166,7 +238,7 @@ __global__ __launch_bounds__(256) void k_kf_load(VolumeDev v, const KfTab* tab, 
     L.list_ent[e] = ent == kInvalidSlot ? 0u : ent;
   }
 }
-__global__ void k_kf_clear(KfTab* tab, int slot) { tab->n[slot] = 0; }  // kf.validChunks.clear() (:217)
+__global__ void k_kf_clear(KfTab* tab, uint32_t slots, int slot) { kf_off(tab)[slots + slot] = 0; }  // kf.validChunks.clear() (:217)
 
 // MobileFusion::RetractObservations' chunk side over the list just loaded: observations.erase(frame_id)
 __global__ __launch_bounds__(256) void k_kf_retract(VolumeDev v, int32_t kf_id) {
@@ -192,10 +264,14 @@ static int unit_state(tf_volume* v, UnitState** out) {
   lock.unlock();
   if (!u.arena) {
     u.cap = (uint32_t)std::min<size_t>((size_t)v->dev.max_list * 16, (size_t)1 << 26);
-    if (const char* e = getenv("TF_UNIT_ARENA")) u.cap = (uint32_t)std::max(1024, atoi(e));  // test knob: a small arena
+    if (const char* e = getenv("TF_UNIT_ARENA")) { u.cap = (uint32_t)std::max(1024, atoi(e)); u.fixed_arena = true; }  // test knob: a small, pinned arena
+    u.slots = kUnitSlots0;
+    if (const char* e = getenv("TF_UNIT_SLOTS")) u.slots = (uint32_t)std::max(4, atoi(e));  // test knob: initial slots
     TF_HIP(hipMalloc((void**)&u.arena, sizeof(int4) * (size_t)u.cap));
-    TF_HIP(hipMalloc((void**)&u.tab, sizeof(KfTab)));
-    TF_HIP(hipMemsetAsync(u.tab, 0, sizeof(KfTab), v->stream));
+    TF_HIP(hipMalloc((void**)&u.tab, kf_tab_bytes(u.slots)));
+    TF_HIP(hipMemsetAsync(u.tab, 0, kf_tab_bytes(u.slots), v->stream));
+    TF_HIP(hipHostMalloc((void**)&u.h_fill, 64, hipHostMallocDefault));
+    memset(u.h_fill, 0, 64);
     TF_HIP(hipMalloc((void**)&u.group_pre, sizeof(float4) * (size_t)kGroupFrames * 4 * v->dev.max_list));
     TF_HIP(hipMalloc((void**)&u.group_cen, sizeof(float) * (size_t)kGroupFrames * 3 * kChunkVoxels));
   }
@@ -221,23 +297,24 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     int rc = launch_prepare(v, P, true, s);
     if (rc) return rc;
   } else {
-    hipLaunchKernelGGL(k_kf_load, dim3(256), dim3(256), 0, s, d, u->tab, u->arena, kf_slot);
+    hipLaunchKernelGGL(k_kf_load, dim3(256), dim3(256), 0, s, d, u->tab, u->slots, u->arena, kf_slot);
     hipLaunchKernelGGL(k_kf_retract, dim3(256), dim3(256), 0, s, d, g->kf_id);
   }
+  // the per-chunk records and centroid tables of all the group's frames in ONE launch (k_pre + k_pre_group were two)
+  const float* dd[kGroupFrames];
+  float poses[12 * kGroupFrames];
+  for (int f = 0; f < g->n_local; ++f) {
+    dd[f] = g->local[f].d_depth;
+    memcpy(poses + 12 * f, flag ? g->local[f].pose : g->old_local_pose[f], 48);
+  }
+  launch_pre_frames(d, P, g->n_local, poses, u->group_pre, u->group_cen, v->ig, v->res, v->cam, s);
   // the keyframe's own depth + colour (+ quality) ...
   const bool color = img.rgba != nullptr, quality = color && img.quality != nullptr;
-  launch_integrate(d, img, v->cam, v->ig, P, v->res, flag, color, quality, 0, s);
+  launch_integrate(d, img, v->cam, v->ig, P, v->res, flag, color, quality, 0, s, true);
   launch_obs_record(d, g->kf_id, s);  // chunk->observations[keyframeID] for BOTH flags (Chisel.h:244-247)
   // ... then its local frames depth-only over the same list, one visit per chunk
-  if (g->n_local > 0) {
-    const float* dd[kGroupFrames];
-    float poses[12 * kGroupFrames];
-    for (int f = 0; f < g->n_local; ++f) {
-      dd[f] = g->local[f].d_depth;
-      memcpy(poses + 12 * f, flag ? g->local[f].pose : g->old_local_pose[f], 48);
-    }
-    launch_integrate_group(d, g->n_local, dd, poses, u->group_pre, u->group_cen, v->cam, v->ig, v->res, flag, s);
-  }
+  if (g->n_local > 0)
+    launch_integrate_group(d, g->n_local, dd, poses, u->group_pre, u->group_cen, v->cam, v->ig, v->res, flag, s, true);
   launch_finalize(d, v->epoch++, s);
   if (dirty_par >= 0) {
     VolumeDev dd = d;
@@ -246,10 +323,55 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     launch_dirty_frame(dd, dirty_par, dirty_stamp, s);
   }
   const int slack = !(getenv("TF_UNIT_NO_SLACK") && atoi(getenv("TF_UNIT_NO_SLACK")));  // test knob (read per call): exact-fit regions
-  if (flag) hipLaunchKernelGGL(k_kf_store, dim3(1), dim3(1024), 0, s, d, u->tab, u->arena, u->cap, kf_slot, slack);
-  else hipLaunchKernelGGL(k_kf_clear, dim3(1), dim3(1), 0, s, u->tab, kf_slot);
+  if (flag) hipLaunchKernelGGL(k_kf_store, dim3(1), dim3(1024), 0, s, d, u->tab, u->slots, u->arena, u->cap, kf_slot, slack, u->h_fill);
+  else hipLaunchKernelGGL(k_kf_clear, dim3(1), dim3(1), 0, s, u->tab, u->slots, kf_slot);
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
+  return TF_OK;
+}
+
+// One more keyframe than the table has slots: a table of twice the size (stream drained once per doubling).
+static int grow_slots(tf_volume* v, UnitState* u) {
+  TF_HIP(hipStreamSynchronize(v->stream));
+  const uint32_t ns = u->slots * 2u;
+  KfTab* nt = nullptr;
+  TF_HIP(hipMalloc((void**)&nt, kf_tab_bytes(ns)));
+  TF_HIP(hipMemset(nt, 0, kf_tab_bytes(ns)));
+  TF_HIP(hipMemcpy(nt, u->tab, sizeof(KfTab), hipMemcpyDeviceToDevice));
+  for (int a = 0; a < 3; ++a)  // off | n | capn (the order scratch carries nothing)
+    TF_HIP(hipMemcpy(kf_off(nt) + (size_t)a * ns, kf_off(u->tab) + (size_t)a * u->slots, sizeof(uint32_t) * u->slots, hipMemcpyDeviceToDevice));
+  TF_HIP(hipDeviceSynchronize());
+  hipFree(u->tab);
+  u->tab = nt;
+  u->slots = ns;
+  u->grows += 1;
+  return TF_OK;
+}
+// Enough arena for the lists this call stores and the ones still in flight?  Decided on what the device last reported
+// (h_fill, a few calls old at most -- hence the margin of eight further lists); an arena that runs full anyway compacts
+// itself and, failing that, reports TF_ERR_CAPACITY as before.
+static int grow_arena_if_needed(tf_volume* v, UnitState* u, int stores) {
+  if (u->fixed_arena) return TF_OK;
+  const uint64_t top = __atomic_load_n(&u->h_fill[0], __ATOMIC_ACQUIRE), longest = u->h_fill[1], live = u->h_fill[2];
+  (void)top;
+  const uint64_t per = std::max<uint64_t>(longest, 1024) * 5 / 4 + 64;
+  const uint64_t margin = (uint64_t)(stores + 8) * per;
+  if (live + margin <= (uint64_t)u->cap * 3 / 4) return TF_OK;
+  uint64_t ncap = (uint64_t)u->cap * 2;
+  while (live + margin > ncap * 3 / 4) ncap *= 2;
+  if (ncap > 0xFFFFFFF0ull) { set_error("the keyframes' validChunks exceed 2^32 entries"); return TF_ERR_CAPACITY; }
+  TF_HIP(hipStreamSynchronize(v->stream));
+  int4* na = nullptr;
+  if (hipMalloc((void**)&na, sizeof(int4) * (size_t)ncap) != hipSuccess) {
+    set_error("cannot grow the keyframes' validChunks store (hipMalloc)");
+    return TF_ERR_HIP;
+  }
+  TF_HIP(hipMemcpy(na, u->arena, sizeof(int4) * (size_t)u->cap, hipMemcpyDeviceToDevice));  // (regions keep their offsets)
+  TF_HIP(hipDeviceSynchronize());
+  hipFree(u->arena);
+  u->arena = na;
+  u->cap = (uint32_t)ncap;
+  u->grows += 1;
   return TF_OK;
 }
 
@@ -279,7 +401,10 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
     set_error("the texture stage needs the new keyframe's colour image and inverse pose");
     return TF_ERR_INVALID;
   }
-  TF_DEV(v);
+  TF_DEV_STREAM(v);
+  // the patch stage of the previous unit call / textured frame, if still pending: with a texture stage in this call it
+  // rides on that stage's filter launch (23.6 us as a launch of its own, profiles/r4/keyframe_unit_*); else it goes first
+  if (!texture && v->atlas.pend_patch.on) { int rcf = patch_flush(v); if (rcf) return rcf; }
   UnitState* u = nullptr;
   int rc = unit_state(v, &u);
   if (rc) return rc;
@@ -289,7 +414,8 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
   auto slot_for = [&](int32_t kf, bool create) -> int {
     auto it = u->slot_of.find(kf);
     if (it != u->slot_of.end()) return it->second;
-    if (!create || (int)u->slot_of.size() >= kUnitMaxKf) return -1;
+    if (!create) return -1;
+    if (u->slot_of.size() >= (size_t)u->slots && grow_slots(v, u) != TF_OK) return -2;
     const int s = (int)u->slot_of.size();
     u->slot_of.emplace(kf, s);
     return s;
@@ -303,11 +429,13 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
   int dirty_par = -1;
   uint32_t dirty_stamp = 0;
   if (texture && v->clear_floor >= v->epoch) {
-    if ((rc = patch_flush(v))) return rc;  // (a pending stage reads the meshes this call's mesher will rewrite: same order as texture_stage)
+    // (a pending patch stage -- the previous call's -- reads the meshes this call's mesher will rewrite: it rides on
+    // this call's filter launch, texture_stage below; nothing in between touches what it reads)
     if ((rc = fused_arm(v))) return rc;
     dirty_par = v->atlas.fused_par;
     dirty_stamp = v->epoch + (uint32_t)(2 * n_moved + (fresh ? 1 : 0));  // = the stage's frame_epoch + 1
   }
+  if ((rc = grow_arena_if_needed(v, u, n_moved + (fresh ? 1 : 0)))) return rc;
   // tsdfFusion's loop over keyframesToUpdate (:296-312): retract, de-integrate at the old poses, integrate at the new
   for (int m = 0; m < n_moved; ++m) {
     const int slot = slot_for(moved[m].kf_id, false);
@@ -317,7 +445,7 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
   }
   if (fresh) {  // :316-323
     const int slot = slot_for(fresh->kf_id, true);
-    if (slot < 0) { set_error("too many keyframes"); return TF_ERR_CAPACITY; }
+    if (slot < 0) return TF_ERR_HIP;  // (the table could not grow: hipMalloc's message is in tf_last_error)
     if ((rc = integrate_group(v, u, fresh, 1, slot, dirty_par, dirty_stamp))) return rc;
   }
   if (texture) {
@@ -325,7 +453,7 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
     // keyframe as the label of every chunk of chunksToUpdate, UpdateAtlas (the fused texture stage; its patch stage stays
     // pending like a streamed frame's and goes out with the next launch or the next call that looks)
     FrameImages img{fresh->keyframe.d_depth, reinterpret_cast<const uchar4*>(fresh->keyframe.d_rgba), nullptr};
-    return texture_stage(v, v->dev.sel, img, v->epoch - 1u, pose_inv16, fresh->kf_id, dirty_par >= 0);
+    return texture_stage(v, v->dev.sel, img, v->epoch - 1u, pose_inv16, fresh->kf_id, dirty_par >= 0, nullptr, true);
   }
   // texture == 0: UpdateMeshes only (asynchronous).  The caller's tf_compress_meshes then returns chunksToUpdate, marks /
   // exchanges the adjacency flags and clears meshesToUpdate (MobileFusion.cpp:343-355), its view selection runs, and
@@ -362,6 +490,19 @@ int tf_keyframe_unit_stats(tf_volume* v, int64_t out[5]) {
   return TF_OK;
 }
 
+int tf_keyframe_unit_stats_ex(tf_volume* v, int64_t out[4]) {
+  if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  for (int k = 0; k < 4; ++k) out[k] = 0;
+  std::lock_guard<std::mutex> lock(g_units_mu);
+  auto it = g_units.find(v);
+  if (it == g_units.end() || !it->second.tab) return TF_OK;
+  out[0] = (int64_t)it->second.slots;           // slots of the region table
+  out[1] = (int64_t)it->second.slot_of.size();  // keyframes that own one
+  out[2] = (int64_t)it->second.grows;           // doublings (table + arena) so far
+  out[3] = (int64_t)it->second.cap;             // arena entries
+  return TF_OK;
+}
+
 int tf_keyframe_unit_release(tf_volume* v) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
   {
@@ -375,6 +516,7 @@ int tf_keyframe_unit_release(tf_volume* v) {
   UnitState& u = it->second;
   if (u.arena) hipFree(u.arena);
   if (u.tab) hipFree(u.tab);
+  if (u.h_fill) hipHostFree(u.h_fill);
   if (u.group_pre) hipFree(u.group_pre);
   if (u.group_cen) hipFree(u.group_cen);
   g_units.erase(it);

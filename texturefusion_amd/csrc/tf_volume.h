@@ -174,6 +174,8 @@ struct tf_volume {
   size_t hslot_pixels = 0;
   int hslot_next = 0;
   hipStream_t copy_stream = nullptr;
+  hipStream_t copy_stream2 = nullptr;  // TF_HOST_COPY_SPLIT: the second half of a frame's upload (a second copy engine)
+  hipEvent_t copy_join = nullptr;
   long host_waits = 0;  // copies a launch had to wait for in the stream (TF_HOST_TRACE prints it)
   double host_trace[6] = {0, 0, 0, 0, 0, 0};  // TF_HOST_TRACE=1: microseconds per phase of tf_integrate_frame_host, [5] = calls
   tf::CopyPool* copy_pool = nullptr;  // helper threads of the staging copy (TF_COPY_THREADS, default 3)
@@ -226,8 +228,10 @@ struct tf_volume {
 namespace tf {
 int ensure_tmp(tf_volume* v, size_t bytes);
 int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hipStream_t s = nullptr);  // tf_capi.cpp
+// ride_filter: a patch stage still pending when the stage starts rides on its filter launch (the keyframe unit: there is
+// no k_frame launch for it to ride on) instead of going out as a launch of its own
 int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16,
-                  int32_t frame_id, bool claimed = false, const FrameCtl* next_ctl = nullptr);
+                  int32_t frame_id, bool claimed = false, const FrameCtl* next_ctl = nullptr, bool ride_filter = false);
 // the four band counts of the frame whose selection wrote `ctl` (tag = its epoch + 1): waits for the device to publish them
 int xchg_band_counts(tf_volume* v, const FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]);
 int flush_deferred(tf_volume* v);

@@ -2,7 +2,8 @@
 """Profile of the keyframe unit -- tf_keyframe_unit_device = MobileFusion::tsdfFusion (GCFusion/MobileFusion.cpp:274-406),
 the product's real caller -- on the bench's S-room orbit: every 7th frame a keyframe (depth + colour), the six behind it
 its local frames (depth only), meshes / patches / atlas per keyframe; optionally one MOVED keyframe in every other call
-(de-integrated over its stored validChunks, re-integrated at shifted poses).
+(de-integrated over its stored validChunks and re-integrated -- at the SAME poses: a full orbit of groups re-integrated one
+frame off builds double walls whose meshes exhaust the overflow pool; the work per moved group is the same).
 
   --run                 the workload (under rocprofv3: the program itself behind "--"); the timed window of keyframes is
                         bracketed by two launches of the library's empty kernel (tf_profile_calibrate(1) = k_null), which
@@ -62,7 +63,7 @@ def run(moved):
 
     def call(g):
         fresh, k0, _ = group_of(capi, dd, dc, poses, g)
-        mv = [group_of(capi, dd, dc, poses, g - 2, shift=1, old=True)[0]] if moved and g >= 2 and g % 2 == 0 else []
+        mv = [group_of(capi, dd, dc, poses, g - 2, shift=0, old=True)[0]] if moved and g >= 2 and g % 2 == 0 else []
         vol.keyframe_unit(fresh=fresh, moved=mv, texture=True, pose_inv16=pinv[k0])
         return len(mv)
 
@@ -96,7 +97,7 @@ def count(moved):
 
     def unit(g):
         fresh, k0, _ = group_of(capi, dd, dc, poses, g)
-        mv = [group_of(capi, dd, dc, poses, g - 2, shift=1, old=True)[0]] if moved and g >= 2 and g % 2 == 0 else []
+        mv = [group_of(capi, dd, dc, poses, g - 2, shift=0, old=True)[0]] if moved and g >= 2 and g % 2 == 0 else []
         vol.keyframe_unit(fresh=fresh, moved=mv, texture=True, pose_inv16=pinv[k0])
 
     for g in range(n_pre):

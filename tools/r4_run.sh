@@ -31,6 +31,29 @@ for step in "$@"; do
             python3 tools/prof_unit.py --summarize "$T" "$F" "$W" $U/counts.json > $U/summary.json 2> $U/summary.err
             rm -rf $U/trace $U/fetch $U/write
             echo "$step rc=$?"; cat $U/run_line.json; tail -c 1800 $U/summary.json; tail -3 $U/summary.err $U/count.err ;;
+    sq)     # SQ counters of the per-frame kernels over the timed workload (bench.py --child), three passes
+            U=$PWD/$O/sq; mkdir -p $U; rm -rf $U/*
+            B="python3 $PWD/bench.py --child --steps 60 --warmup 20"
+            (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $U -o a -- $B >/dev/null 2>&1)
+            (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE --output-format csv -d $U -o b -- $B >/dev/null 2>&1)
+            (cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_INSTS_FLAT --output-format csv -d $U -o c -- $B >/dev/null 2>&1)
+            python3 - $U > $O/sq_summary.txt <<'PY'
+import csv, glob, collections, sys
+U = sys.argv[1]
+print("SQ counters per launch, steady-state half of `bench.py --child --steps 60 --warmup 20` (rocprofv3 --pmc, three passes)")
+for kern in ("k_frame", "k_mesh_filter", "k_mesh<"):
+    print(kern)
+    for f in sorted(glob.glob(U + "/**/*_counter_collection.csv", recursive=True)):
+        acc = collections.defaultdict(lambda: [0.0, 0])
+        rows = list(csv.DictReader(open(f)))
+        rows = rows[len(rows) // 2:]
+        for r in rows:
+            if kern in r["Kernel_Name"]:
+                a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1] += 1
+        for k, (s, n) in sorted(acc.items()):
+            print("  %-22s per launch %14.0f  (%d launches)" % (k, s / max(n, 1), n))
+PY
+            rm -rf $U; cat $O/sq_summary.txt | head -80 ;;
     *)      echo "unknown step $step" ;;
   esac
 done
