@@ -162,6 +162,15 @@ int main() {
                                    localChunksIntersecting, localNeedsUpdateFlag, localNewChunkFlag);
   const size_t n = localChunksIntersecting.size();
   CHECK(n > 1000);
+  {  // Chisel::candidateCubes (Chisel.h:101,129) and GetSearchRegion (:74-99): debug geometry of the selection
+    CHECK(chiselMap.candidateCubes.size() == 24 * n);
+    const chisel::ChunkID c0 = localChunksIntersecting[0];
+    CHECK(chiselMap.candidateCubes[0] == 8 * c0(0) * res && chiselMap.candidateCubes[21] == 8 * c0(0) * res + res * 8.0f);
+    float corners[24];
+    chiselMap.GetSearchRegion(corners, cameraModel, lastPose);
+    CHECK(corners[0] == chiselMap.minChunkID(0) * 8.0f * res && corners[23] == chiselMap.maxChunkID(2) * 8.0f * res);
+    CHECK(chiselMap.GetChunkManager().GetChunkSize()(0) == 8);
+  }
   std::vector<int32_t> oids(n * 3 + 3);
   std::vector<uint8_t> onew(n + 1), oneeds(n + 1, 0);
   CHECK(tfo_prepare(ov, depth.data(), lastPose.data(), oids.data(), onew.data(), (int64_t)n) == (int64_t)n);

@@ -10,7 +10,7 @@
 //     is thinner than a + b + c + 1 keys, so that a band reaches beyond the adjacent slab.
 //
 // librccl is opened at run time (dlopen) when tf_comm_init is first called: single-GPU users never load it,
-// and a host process that already carries an RCCL (e.g. PyTorch's) keeps exactly one copy.
+// and a host process that already carries an RCCL (e.g. PyTorch's) keeps exactly one copy (RTLD_NOLOAD first).
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <string.h>
@@ -38,9 +38,16 @@ static Rccl g_rccl;
 static int rccl_load() {
   if (g_rccl.lib) return TF_OK;
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // an RCCL the process already carries (PyTorch's, when the caller lives in a torch process) is reused: ONE library
+  // instance, one set of its global state, whatever made the communicators -- RTLD_NOLOAD only succeeds for a library
+  // that is mapped already
   for (const char* n : names) {
-    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
     if (g_rccl.lib) break;
+  }
+  for (const char* n : names) {
+    if (g_rccl.lib) break;
+    g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
   }
   if (!g_rccl.lib) { set_error(std::string("cannot load librccl: ") + dlerror()); return TF_ERR_HIP; }
   g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(dlsym(g_rccl.lib, "ncclGetUniqueId"));

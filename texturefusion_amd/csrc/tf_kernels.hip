@@ -23,6 +23,9 @@
 #include "tf_patch_body.h"
 
 #pragma clang fp contract(off)
+#ifndef TF_KA_VM_ARRAY
+#define TF_KA_VM_ARRAY 0
+#endif
 
 #ifndef TF_KA_GP
 #define TF_KA_GP 2
@@ -850,7 +853,11 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     // the scheduler can interleave); the order-dependent part -- which row stalls the chunk -- is
     // resolved afterwards from the eight validity ballots, and only for chunks that do not project
     // entirely inside the image.
+#if TF_KA_VM_ARRAY
     unsigned long long vm[8];
+#endif
+    unsigned long long all_valid = ~0ull;  // (the eight validity ballots are only kept as their AND: 14 scalar registers less
+                                           // at the kernel's tightest spot; the rare chunk that needs them gets them back from off_d)
     uint32_t oob_bits = 0;  // bit j: the lane's pixel of slice j is off the image
     auto geometry = [&](auto safe_tag) {
       constexpr bool SAFE = decltype(safe_tag)::value;
@@ -874,7 +881,12 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         const int Y = SAFE ? cvt_rne_hw(uw.y) : cvt_sat_rne(uw.y);
         // 0 < X < W-1 and 0 < Y < H-1 (:167-173) as two unsigned range tests
         const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
+#if TF_KA_VM_ARRAY
         vm[j] = ballot(valid);
+        all_valid &= vm[j];
+#else
+        all_valid &= ballot(valid);
+#endif
         int od = (__mul24(Y, W) + X) * 4;  // valid => 0 < Y < H, exact in 24 bits
         asm volatile("" : "+v"(od));       // keep the select a v_cndmask (no exec-mask branch)
         off_d[j] = valid ? od : kOOB;
@@ -888,14 +900,16 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 #pragma unroll
       for (int j = 0; j < 8; ++j) oobl[j] = 0;
     }
-    unsigned long long all_valid = ~0ull;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) all_valid &= vm[j];
     if (all_valid != ~0ull) {  // chunks that project entirely inside the image skip all of this
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (R == 64u) {
-          const unsigned long long dead = nonzero_bytes(vm[j]) ^ 0x0101010101010101ull;
+#if TF_KA_VM_ARRAY
+          const unsigned long long vmj = vm[j];
+#else
+          const unsigned long long vmj = ballot(off_d[j] != kOOB);  // (off_d[j] == kOOB <=> !valid at this point)
+#endif
+          const unsigned long long dead = nonzero_bytes(vmj) ^ 0x0101010101010101ull;
           if (dead) R = (uint32_t)(j * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
         }
         const bool live_lane = (uint32_t)(j * 8 + vy) < R;

@@ -383,6 +383,7 @@ class ChunkManager {
         for (int x = 0; x < 8; x++) centroids.emplace_back((float)x * r + half, (float)y * r + half, (float)z * r + half);
   }
   inline const Vec3List& GetCentroids() const { return centroids; }
+  inline const ChunkID& GetChunkSize() const { return chunkSize; }  // ChunkManager.h:732 (8 x 8 x 8: the kernel's only shape)
   inline bool HasChunk(const ChunkID& chunk) const {  // ChunkManager.h:133-135
     int out = 0;
     tf_check(tf_has_chunk(vol, chunk.v, &out), "HasChunk");
@@ -464,6 +465,7 @@ class ChunkManager {
  private:
   tf_volume* vol = nullptr;
   float voxelResolutionMeters = 0.005f;
+  ChunkID chunkSize = ChunkID(8, 8, 8);
   Vec3List centroids;
   std::unordered_map<ChunkID, ChunkPtr, ChunkHasher> mirrors;
   MeshMap allMeshes;
@@ -702,6 +704,32 @@ class Chisel {
     meshesToUpdate.clear();
   }
 
+  // Structure/Chisel.h:74-99: the eight corners of the box [minChunkID, maxChunkID] * chunk edge (debug drawing,
+  // MobileFusion.cpp:170); min / maxChunkID are those of the last PrepareIntersectChunks
+  void GetSearchRegion(float* corners, const PinholeCamera& depthCamera, const Transform& depthExtrinsic) {
+    (void)depthCamera; (void)depthExtrinsic;
+    const float e = 8.0f * chunkManager.GetResolution();
+    const float minX = minChunkID(0) * e, minY = minChunkID(1) * e, minZ = minChunkID(2) * e;
+    const float maxX = maxChunkID(0) * e, maxY = maxChunkID(1) * e, maxZ = maxChunkID(2) * e;
+    const float vertexList[24] = {minX, minY, minZ, maxX, minY, minZ, minX, maxY, minZ, maxX, maxY, minZ,
+                                  minX, minY, maxZ, maxX, minY, maxZ, minX, maxY, maxZ, maxX, maxY, maxZ};
+    std::memcpy(corners, vertexList, sizeof(vertexList));
+  }
+  // Structure/Chisel.h:344-375: 8 corners x 3 floats per listed chunk (MobileFusion.h:505 draws them)
+  void GetChunkCubes(std::vector<float>& cubes, ChunkIDList& chunksIntersecting) {
+    cubes.clear();
+    static const int off[8][3] = {{0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {1, 1, 0}, {0, 0, 1}, {1, 0, 1}, {0, 1, 1}, {1, 1, 1}};
+    const float r = chunkManager.GetResolution();
+    const float edge = r * 8.0f;
+    for (size_t i = 0; i < chunksIntersecting.size(); i++) {
+      const ChunkID& c = chunksIntersecting[i];
+      const float origin[3] = {8 * c(0) * r, 8 * c(1) * r, 8 * c(2) * r};
+      for (int j = 0; j < 8; j++)
+        for (int a = 0; a < 3; a++) cubes.emplace_back(origin[a] + (float)off[j][a] * edge);
+    }
+  }
+  std::vector<float> candidateCubes;  // Chisel.h:101, refreshed by PrepareIntersectChunks (:129)
+
   // Structure/Chisel.h:103-140.  depthImage is borrowed for the call (uploaded to HBM and kept
   // bound for the IntegrateDepthScanColor calls that follow, like the reference keeps the cv::Mat).
   void PrepareIntersectChunks(ProjectionIntegrator& integrator, float* depthImage,
@@ -726,6 +754,7 @@ class Chisel {
       newChunkFlag.emplace_back(new_buf[i] != 0);
       needsUpdateFlag.emplace_back(false);
     }
+    GetChunkCubes(candidateCubes, chunksIntersecting);  // :129
     tf_stats st;
     if (tf_get_stats(vol, &st) == TF_OK) {
       minChunkID = ChunkID(st.min_id[0], st.min_id[1], st.min_id[2]);
