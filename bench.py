@@ -576,6 +576,7 @@ def roofline(args, vol, cam, prof, kinds, K, first, n_unique, d_depth, d_rgba, p
         st = vol.stats()
         b_tsdf += 128 * st.rows_tsdf + 128 * st.rows_color + 8 * cam.width * cam.height
         cnt["sel"] += st.n_selected
+        cnt["listed"] = cnt.get("listed", 0) + st.n_listed
         cnt["upd"] += st.n_updated
         if textured:
             ts = vol.texture_stats()

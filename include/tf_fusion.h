@@ -73,7 +73,7 @@ typedef struct {
 /* Counters of the most recent frame / list (device-side integers, read back on request). */
 typedef struct {
   int64_t n_coarse;       /* candidate 4x4x4 blocks tested */
-  int64_t n_selected;     /* chunks in the visible list */
+  int64_t n_selected;     /* chunks the reference's selection flags (GetChunkIDsObservedByCamera) */
   int64_t n_updated;      /* list entries whose needsUpdate flag is set */
   int64_t rows_tsdf;      /* 8-voxel rows whose sdf/weight were rewritten by the last integrate */
   int64_t rows_color;     /* 8-voxel rows whose colour was rewritten by the last integrate */
@@ -82,6 +82,8 @@ typedef struct {
   int64_t n_dirty;        /* entries of meshesToUpdate */
   int32_t min_id[3];      /* Chisel::minChunkID */
   int32_t max_id[3];      /* Chisel::maxChunkID */
+  int64_t n_listed;       /* n_selected minus (fused flow) the entries whose depth tiles prove that no voxel of the chunk can
+                             be written: the voxel update does their bookkeeping only */
 } tf_stats;
 
 /* What the textured per-frame unit did for its most recent frame (integers behind the byte counts). */

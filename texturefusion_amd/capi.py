@@ -74,7 +74,7 @@ class Stats(C.Structure):
     _fields_ = [("n_coarse", C.c_int64), ("n_selected", C.c_int64), ("n_updated", C.c_int64),
                 ("rows_tsdf", C.c_int64), ("rows_color", C.c_int64), ("n_chunks", C.c_int64),
                 ("n_slots", C.c_int64), ("n_dirty", C.c_int64), ("min_id", C.c_int32 * 3),
-                ("max_id", C.c_int32 * 3)]
+                ("max_id", C.c_int32 * 3), ("n_listed", C.c_int64)]
 
 
 class TextureStats(C.Structure):

@@ -400,6 +400,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     if ((rc = dev_alloc(v, &L.list_quality, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_rows, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.cen, (size_t)3 * kChunkVoxels))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.tiles, (size_t)kMaxTiles))) return fail(rc);
     if ((rc = dev_alloc(v, &L.ctl, (size_t)1))) return fail(rc);
   }
   if ((rc = init_device_state(v))) return fail(rc);
@@ -1489,16 +1490,17 @@ int tf_get_stats(tf_volume* v, tf_stats* out) {
   memset(out, 0, sizeof(*out));
   int rc = ensure_tmp(v, 64);
   if (rc) return rc;
-  TF_HIP(hipMemsetAsync(v->d_tmp, 0, 24, v->stream));
+  TF_HIP(hipMemsetAsync(v->d_tmp, 0, 32, v->stream));
   launch_rowstats(v->dev, reinterpret_cast<unsigned long long*>(v->d_tmp), v->stream);
   TF_HIP(hipGetLastError());
-  unsigned long long r3[3];
-  TF_HIP(hipMemcpyAsync(r3, v->d_tmp, 24, hipMemcpyDeviceToHost, v->stream));
+  unsigned long long r3[4];
+  TF_HIP(hipMemcpyAsync(r3, v->d_tmp, 32, hipMemcpyDeviceToHost, v->stream));
   CtlSnap ctl;
   rc = fetch_ctl(v, &ctl);
   if (rc) return rc;
   out->n_coarse = ctl.f.n_coarse;
   out->n_selected = ctl.f.n_list;
+  out->n_listed = (int64_t)ctl.f.n_list - (int64_t)r3[3];
   out->n_updated = (int64_t)r3[2];
   out->rows_tsdf = (int64_t)r3[0];
   out->rows_color = (int64_t)r3[1];

@@ -113,8 +113,14 @@ struct SelBuf {
   float* list_quality;        // [max_list]
   uint16_t* list_rows;        // [max_list] low byte tsdf rows, high byte colour rows
   float* cen;                 // [3*512] centroid table of the frame (Chisel.cpp:52-110), c[a][voxel]
+  // Fused flow: per 16 x 16 pixel tile of the frame's depth image {key of the smallest depth > 0, key of the largest depth}
+  // (ordered-uint keys, f2key).  Filled by the frame's K-B role, read by its selection role to mark chunks that provably
+  // rewrite nothing (select_body: K-A then only does their bookkeeping), re-armed by the frame's K-A role.  [kMaxTiles]
+  uint2* tiles;
   FrameCtl* ctl;
 };
+constexpr uint32_t kMaxTiles = 65536;  // images of up to 65536 tiles of 16 x 16 pixels (4096 x 4096); larger ones are not pruned
+constexpr int kTileShift = 4;          // 16 x 16 pixels: a chunk beyond ~0.65 m spans at most 3 x 3 of them (one batch of loads)
 
 // ---- device-resident meshes (ChunkManager::allMeshes) and their patches (Mesh::m_patch) ----------
 // One fixed block per pool slot, planar (lane = vertex / triangle, every plane row is a coalesced

@@ -26,6 +26,16 @@
 #ifndef TF_KA_VM_ARRAY
 #define TF_KA_VM_ARRAY 0
 #endif
+// Depth-tile pruning of the fused selection (compile-time experiment, OFF): the K-B role leaves {smallest positive, largest}
+// depth per 16 x 16 pixel tile, the selection role marks the flagged chunks whose tiles prove that no voxel can be written
+// (an exact, conservative test: all 83 GPU parity tests pass with it) and K-A does only their bookkeeping.  Measured on the
+// room stream (profiles/r4/README.md, run c9): of the 3186 selected-but-not-updated chunks per frame the tiles catch 507 --
+// on walls seen at an angle the depth range of a 3 x 3 tile box exceeds the truncation band -- and K-A gains nothing
+// (k_frame 39.7 -> 40.1 us textured, 28.9 -> 30.2 us TSDF-only: the selection role, which fills K-A's tail, got longer and
+// spills 28 B/lane).  A finer footprint is K-A's own geometry pass, which already skips the write phases of such chunks.
+#ifndef TF_SEL_PRUNE
+#define TF_SEL_PRUNE 0
+#endif
 
 #ifndef TF_KA_GP
 #define TF_KA_GP 2
@@ -110,8 +120,11 @@ __device__ __forceinline__ void centroid_table(const float* __restrict__ Pp, flo
 // ---------------------------------------------------------------------------------------
 // control block reset (create / Reset only; per-frame re-arming rides on k_scan)
 // ---------------------------------------------------------------------------------------
-__global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
-  if (threadIdx.x == 0) {
+// the state of "no depth seen" of a tile: smallest positive depth = +inf, largest depth = below every depth
+__device__ __forceinline__ uint2 tile_empty() { return make_uint2(f2key(3.0e38f), f2key(-1.0f)); }
+__global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl, uint2* tiles) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; tiles && i < kMaxTiles; i += gridDim.x * blockDim.x) tiles[i] = tile_empty();
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int a = 0; a < 3; ++a) {
       ctl->bbox_key[a] = f2key(1e8f);
       ctl->bbox_key[3 + a] = f2key(-1e8f);
@@ -130,7 +143,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
   }
 }
 void launch_reset_ctl(const VolumeDev& v, bool volume_too, hipStream_t s) {
-  hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(64), 0, s, v.sel.ctl, volume_too ? v.vctl : nullptr);
+  hipLaunchKernelGGL(k_reset_ctl, dim3(64), dim3(256), 0, s, v.sel.ctl, volume_too ? v.vctl : nullptr, v.sel.tiles);
 }
 
 // an empty launch (tf_profile_calibrate: what a HIP-event pair around ANY launch reads at least)
@@ -176,8 +189,10 @@ void launch_pack_rgba(const uint8_t* rgb, const uint8_t* valid, uchar4* rgba, ui
 // ---------------------------------------------------------------------------------------
 // K-B  world AABB of the back-projected (depth + 0.2) points
 // ---------------------------------------------------------------------------------------
+// tiles != nullptr (the fused flow's K-B role): the same sweep also leaves, per 16 x 16 pixel tile, the smallest depth > 0
+// and the largest depth (SelBuf::tiles; atomics on ordered keys, one pair per four adjacent float4 = one tile row).
 __device__ __forceinline__ void bbox_body(const float* __restrict__ depth, const Cam& cam, const Pose& P,
-                                          FrameCtl* ctl, const uint32_t bid, const uint32_t nb) {
+                                          FrameCtl* ctl, const uint32_t bid, const uint32_t nb, uint2* __restrict__ tiles = nullptr) {
   if (bid == 0 && threadIdx.x == 0) { ctl->n_list = 0; ctl->n_front = 0; ctl->emit_pack = 0ull; }  // appended to by k_select<EMIT>
   if (bid == 0 && threadIdx.x < 4) ctl->band_cnt[threadIdx.x] = 0u;
   if (bid == 0 && threadIdx.x < kKaCounters) ctl->ka_next[threadIdx.x * kKaCounterStride] = 0u;  // K-A of this frame (two launches on) pulls its entries here
@@ -191,6 +206,26 @@ __device__ __forceinline__ void bbox_body(const float* __restrict__ depth, const
     const int i = pix / W, j = pix - i * W;
     const float ly = ((float)i - cam.cyi) / cam.fyi;
     const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+    if (tiles) {
+      float tmn = 3.0e38f, tmx = -1.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        tmn = (dd[k] > 0.0f && dd[k] < tmn) ? dd[k] : tmn;
+        tmx = (dd[k] > tmx) ? dd[k] : tmx;  // (a NaN depth compares false everywhere: it updates nothing in K-A either)
+      }
+      // four adjacent lanes hold one 16-pixel tile row (W is a multiple of 16, or the tiles are off): one pair of atomics
+#pragma unroll
+      for (int o = 1; o <= 2; o <<= 1) {
+        const float omn = __shfl_xor(tmn, o), omx = __shfl_xor(tmx, o);
+        tmn = omn < tmn ? omn : tmn;
+        tmx = omx > tmx ? omx : tmx;
+      }
+      const uint32_t t = (uint32_t)(i >> kTileShift) * (uint32_t)(W >> kTileShift) + (uint32_t)(j >> kTileShift);
+      if (!(q & 3) && t < kMaxTiles) {
+        if (tmn < 3.0e38f) atomicMin(&tiles[t].x, f2key(tmn));
+        atomicMax(&tiles[t].y, f2key(tmx));
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float dz = dd[k] + off;
@@ -249,7 +284,7 @@ void launch_bbox(const VolumeDev& v, const float* depth, const Cam& cam, const P
 // ---------------------------------------------------------------------------------------
 // K-C  coarse 4x4x4-block test, then per-chunk test; one 64-bit mask per coarse block
 // ---------------------------------------------------------------------------------------
-struct ProbeRes { bool valid; bool hit; float sd; };
+struct ProbeRes { bool valid; bool hit; float sd; float u, w, pz; };
 
 // One lane = one of the 8 probe points of CheckCornerIntersectingSIMD (ChunkManager.h:561-636).
 __device__ __forceinline__ ProbeRes probe(const float* __restrict__ depth, const Cam& cam,
@@ -266,6 +301,7 @@ __device__ __forceinline__ ProbeRes probe(const float* __restrict__ depth, const
   const float sd = d - pz;
   r.hit = r.valid && (sd > ndtn) && (dtp > sd);
   r.sd = sd;
+  r.u = u; r.w = w; r.pz = pz;
   return r;
 }
 
@@ -344,6 +380,7 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
     const bool coarse_hit = __ballot(pr.hit && depthValid) != 0ull;
     unsigned long long m = 0ull;
     bool costly = false;
+    bool pruned = false;  // flagged by the reference's test, but the depth tiles prove that no voxel of the chunk can be written
     if (coarse_hit) {
       bool flag = false;
       uint32_t band = 0u;
@@ -367,22 +404,68 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         const bool dv = (of[2] > cam.nearP) && (cam.farP > of[2]);
         bool anyhit = false;
         bool below = false, above = false;  // EMIT: some probed corner sits below the band's far edge / above its near edge
+        float umin = 3.0e38f, umax = -3.0e38f, wmin = 3.0e38f, wmax = -3.0e38f, zmin = 3.0e38f, zmax = -3.0e38f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           ProbeRes fr = probe(depth, cam, of[0], of[1], of[2], sc.fine[0][c], sc.fine[1][c],
                               sc.fine[2][c], fdtp, fndtn);
           anyhit |= fr.hit;
           if (EMIT) { below |= fr.valid && (tr > fr.sd); above |= fr.valid && (fr.sd > fndtn + sc.diag); }  // the band without the chunk-diagonal margin
+          if (TF_SEL_PRUNE && EMIT) {
+            umin = fminf(umin, fr.u); umax = fmaxf(umax, fr.u); wmin = fminf(wmin, fr.w); wmax = fmaxf(wmax, fr.w);
+            zmin = fminf(zmin, fr.pz); zmax = fmaxf(zmax, fr.pz);
+          }
         }
         flag = anyhit && dv;
-        // cost prediction for K-A's work distribution (never a correctness matter): a chunk none of whose probed
-        // corners lies between the near and the far edge of the truncation band (all in front of it, or all
-        // behind) will most likely rewrite no voxel row
-        costly = below && above;
+        if (TF_SEL_PRUNE && EMIT && sc.prune && flag) {
+          // ---- can this chunk rewrite anything at all?  (an exact no lets K-A skip its voxels; results are unchanged)
+          // The eight probe points are the corners of a box that contains every voxel centre of the chunk as K-A places
+          // it (centroid table: R^T (x, y, z) res + res / 2 with x, y, z in 0..7; the probes use 0 / 8).  With all of
+          // them in front of the camera the chunk's pixels lie inside the bounding box of their projections (+ 1 for
+          // K-A's own rounding of u + 0.5, + 1 for the last bits in which its per-chunk origin may differ from this
+          // role's), and its voxels' camera depth inside [zmin, zmax].  K-A rewrites a TSDF row only where a pixel has
+          // lower < d - z < upper (ProjectionIntegrator.cpp:313-316; upper = truncation + sqrt(3) res, lower = -0.03) and
+          // a colour row only where |d - z| < sqrt(3) res / 2 + 0.01 (:202-208): no pixel of the box with
+          // zmin + min(lower, -thr) < d < zmax + max(upper, thr) -- read off the 16 x 16 tiles' {min positive, max} depth
+          // the frame's K-B role left -- means no voxel of the chunk is written.  (A depth of 0, a hole, fails both tests
+          // unless the chunk sits within thr of the camera plane, which zmin > 0.1 rules out.)
+          const float thr = sc.resDiag * 0.5f + 0.01f;
+          const float zlo = zmin - fmaxf(0.03f, thr) - 1e-3f;
+          const float zhi = zmax + fmaxf(tr + sc.resDiag, thr) + 1e-3f + 1e-4f * fabsf(zmax);
+          if (zmin > 0.1f && umax - umin < 4096.0f && wmax - wmin < 4096.0f) {
+            const int TW = cam.W >> kTileShift, TH = (cam.H + 15) >> kTileShift;
+            const float ts = 1.0f / (float)(1 << kTileShift);
+            int tx0 = (int)floorf((umin - 2.0f) * ts), tx1 = (int)floorf((umax + 3.0f) * ts);
+            int ty0 = (int)floorf((wmin - 2.0f) * ts), ty1 = (int)floorf((wmax + 3.0f) * ts);
+            tx0 = tx0 < 0 ? 0 : tx0; ty0 = ty0 < 0 ? 0 : ty0;
+            tx1 = tx1 >= TW ? TW - 1 : tx1; ty1 = ty1 >= TH ? TH - 1 : ty1;
+            const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
+            if (nx <= 0 || ny <= 0) {
+              pruned = true;  // the whole chunk projects off the image: every row of K-A's is dead
+            } else if (nx <= 3 && ny <= 3) {
+              // ONE batch of nine independent loads (tiles outside the box repeat its first one): a loop with an early exit
+              // was a chain of round trips per hit block -- it cost the selection role more than K-A gained
+              const uint32_t klo = f2key(zlo), khi = f2key(zhi);
+              bool may = false;
+#pragma unroll
+              for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                  const int tx = tx0 + (dx < nx ? dx : 0), ty = ty0 + (dy < ny ? dy : 0);
+                  const uint2 t = v.sel.tiles[ty * TW + tx];
+                  // some depth of the tile may lie inside (zlo, zhi): its smallest positive one is below zhi and its
+                  // largest above zlo (the tile's depths need not fill the interval: conservative)
+                  may = may || (t.x < khi && t.y > klo);
+                }
+              pruned = !may;
+            }
+          }
+        }
+        costly = below && above && !pruned;
         if (EMIT) {
           const long long k = part_key(v, x0 + di, y0 + dj, z0 + dk);
           const long long lo = v.part_lo, hi = v.part_hi;
-          if (partitioned && flag)
+          if (partitioned && flag && !pruned)
             band = (k >= lo && k - lo <= band_w ? 1u : 0u) | (k == hi - 1 ? 2u : 0u) | (k == lo - 1 ? 4u : 0u) |
                    (k >= hi && k - hi <= band_w ? 8u : 0u);
           flag = flag && k >= lo && k < hi;
@@ -421,7 +504,9 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         v.sel.list_id[pos] = id;
         const ChunkPre cp = chunk_pre(id, sc.pose, ig, sc.res, sc.resDiag);
         v.sel.list_pre[4 * pos] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
-        v.sel.list_pre[4 * pos + 1] = make_float4(cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
+        // (a pruned entry stays in the list -- PrepareIntersectChunks creates its chunk and GarbageCollect parks it and takes
+        // it out of meshesToUpdate again, which K-A's bookkeeping reproduces -- but K-A skips its voxels: sign bit of `upper`)
+        v.sel.list_pre[4 * pos + 1] = make_float4(pruned ? -cp.b.y : cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
       }
     }
   }
@@ -482,10 +567,18 @@ __global__ __launch_bounds__(1024) void k_scan(VolumeDev v, int step) {
     const uint32_t dz = (uint32_t)ctl->dims[2], dy = (uint32_t)ctl->dims[1];
     const uint32_t nzny = dz * dy;
     const int mx = ctl->min_id[0] - 1, my = ctl->min_id[1] - 1, mz = ctl->min_id[2] - 1;
+    // (the masks and offsets of the wave's NEXT 64 blocks are requested before the current ones are expanded: the
+    // loop was a chain of dependent round trips, 17 us of a keyframe's 258 -- profiles/r4/keyframe_unit_*)
+    unsigned long long nmask = ((uint32_t)w * 64 + lane < n) ? L.masks[(uint32_t)w * 64 + lane] : 0ull;
+    uint32_t noff = ((uint32_t)w * 64 + lane < n) ? L.offsets[(uint32_t)w * 64 + lane] : 0u;
     for (uint32_t base = (uint32_t)w * 64; base < n; base += 16 * 64) {
-      const uint32_t mine = base + lane;
-      const unsigned long long mymask = (mine < n) ? L.masks[mine] : 0ull;
-      const uint32_t myoff = (mine < n) ? L.offsets[mine] : 0u;
+      const unsigned long long mymask = nmask;
+      const uint32_t myoff = noff;
+      {
+        const uint32_t nx = base + 16 * 64 + lane;
+        nmask = (nx < n) ? L.masks[nx] : 0ull;
+        noff = (nx < n) ? L.offsets[nx] : 0u;
+      }
       unsigned long long nonempty = __ballot(mymask != 0ull);
       while (nonempty) {
         const int src = __builtin_ctzll(nonempty);
@@ -700,6 +793,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   }
   const int vy = lane >> 3;
   const int W = cam.W, H = cam.H;
+  if (TF_SEL_PRUNE && FUSED) {
+    // re-arm the depth tiles of this selection set for its next frame: the frame's selection role (one launch ago) was
+    // their last reader
+    const uint32_t nt = (uint32_t)(W >> kTileShift) * (uint32_t)((H + 15) >> kTileShift);
+    const uint32_t ti = bid * 256u + threadIdx.x;
+    if (ti < nt && ti < kMaxTiles) L.tiles[ti] = tile_empty();
+  }
   if (FUSED && bid == 0 && threadIdx.x == 0) {
     // re-arm the K-B reduction of this selection set for its next frame (k_scan does this in the
     // call-by-call flow); every k_select block of this frame has finished reading the keys
@@ -829,7 +929,10 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const f32x2 o01 = {o0, o1};
     const f32x2 fxy = {cam.fxi, cam.fyi}, cxy = {kc.cxs, kc.cys};
     const float wD = FLAG ? pbx : -pbx;  // depth_weight *= -1 when de-integrating (:95-99)
-    const float upper = pby;
+    // (fused lists: a negative `upper` marks an entry whose depth tiles rule out any voxel write -- select_body --: the
+    // wave does the chunk's bookkeeping, creation / parking / meshesToUpdate, and none of its 512 voxels)
+    const bool pruned = TF_SEL_PRUNE && FUSED && (prw[4] >> 31) != 0u;
+    const float upper = (TF_SEL_PRUNE && FUSED) ? fabsf(pby) : pby;
     // every voxel centre of the chunk is o + c with 0 < c < 16 * res * sqrt(3): if |o.z| clears that
     // band, p.z is far inside the normal exponent range; numerators o + c are exact zeros or at
     // least one ulp of c (> 2^-40), and |o| < 2^20 keeps quotients finite -> no scaling / fix-up
@@ -894,7 +997,11 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         if (COLOR) oob_bits |= (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1))) ? (1u << j) : 0u;
       }
     };
-    if (div_safe) geometry(std::true_type{});
+    if (pruned) {
+      R = 0;  // no row is processed: the passes below end at once
+#pragma unroll
+      for (int j = 0; j < 8; ++j) off_d[j] = kOOB;
+    } else if (div_safe) geometry(std::true_type{});
     else geometry(std::false_type{});
     if (QUALITY) {
 #pragma unroll
@@ -1402,6 +1509,7 @@ struct FrameLaunch {
   const float* depth1;
   SelectConsts sc1;
   FrameCtl* ctl2;        // set of frame f+2
+  uint2* tiles2;         // ... its depth tiles (null: the selection does not prune)
   const float* depth2;
   Pose P2;
   int claim_par;         // FrameStage::claim_par of frame f
@@ -1440,7 +1548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATCH ? TF_
     // the progress stamp lives in this (lightest) role: next to K-A it cost 36-212 B/lane of private memory
     if (a.progress && b + 1 == total && threadIdx.x == 0)
       __hip_atomic_store(a.progress, a.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_patch - a.n_sel, a.n_bbox);
+    if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_patch - a.n_sel, a.n_bbox, a.tiles2);
   }
   if (timeline) {
     const uint32_t gw = (b * 256 + threadIdx.x) >> 6;
@@ -1548,6 +1656,11 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   // its tail (TSDF-only 27.5 us at 256 and 512, 30.8 at 128; hall 225 / 237 / 232 us); 128 where the patch and selection
   // ranges go first and every wave they hold delays a K-A wave (textured room: k_frame 42.2 us at 512, 40.8 at 256, 39.8 at 128)
   static const int nsel_env = env_int("TF_SEL_BLOCKS", 0);
+  // depth-tile pruning of the selection (TF_SEL_PRUNE=0: off): every frame's K-B role fills the tiles, its selection role
+  // reads them, its K-A role re-arms them -- all three or none
+  static const int prune_env = env_int("TF_SEL_PRUNE", 1);
+  const bool prune = TF_SEL_PRUNE && prune_env != 0 && (cam.W & 15) == 0 &&
+                     (uint32_t)(cam.W >> kTileShift) * (uint32_t)((cam.H + 15) >> kTileShift) <= kMaxTiles;
   a.kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);
   static const int dbg = env_int("TF_KA_DBG", 0);
   a.kc.dbg = (uint32_t)dbg;
@@ -1566,9 +1679,12 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
     a.sel1 = next->sel;
     a.depth1 = next->img.depth;
     a.sc1 = make_select_consts(next->pose.p, res);
+    a.sc1.prune = prune ? 1 : 0;  // (that frame's K-B role -- one launch ago -- filled its depth tiles)
     a.n_sel = 1u;  // (sized below, once the dispatch order is known)
   }
+  a.tiles2 = nullptr;
   if (next2) {
+    a.tiles2 = prune ? next2->sel.tiles : nullptr;
     a.ctl2 = next2->sel.ctl;
     a.depth2 = next2->img.depth;
     a.P2 = next2->pose;
@@ -1652,24 +1768,27 @@ void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_rowstats(VolumeDev v, unsigned long long* out3) {
   const SelBuf& L = v.sel;
   const uint32_t n = L.ctl->n_list, nf = L.ctl->n_front;
-  unsigned long long rt = 0, rc = 0, nu = 0;
+  unsigned long long rt = 0, rc = 0, nu = 0, np = 0;
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const uint32_t i = list_phys(v, e, nf);
     const uint32_t r = L.list_rows[i];
     rt += r & 0xFFu;
     rc += r >> 8;
     nu += L.list_needs[i] ? 1 : 0;
+    np += (__float_as_uint(L.list_pre[4 * i + 1].x) >> 31) ? 1 : 0;  // entries the depth tiles ruled out (fused lists)
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     rt += __shfl_xor(rt, o);
     rc += __shfl_xor(rc, o);
     nu += __shfl_xor(nu, o);
+    np += __shfl_xor(np, o);
   }
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&out3[0], rt);
     atomicAdd(&out3[1], rc);
     atomicAdd(&out3[2], nu);
+    atomicAdd(&out3[3], np);
   }
 }
 void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s) {

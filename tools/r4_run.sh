@@ -16,7 +16,12 @@ for step in "$@"; do
     tsdf)   timeout 900 python bench.py --mode tsdf --steps 200 --warmup 20 > $O/tsdf.json 2> $O/tsdf.err; echo "tsdf rc=$?"; tail -c 1500 $O/tsdf.json ;;
     hall)   timeout 900 python bench.py --scene big --hires --steps 60 --warmup 10 > $O/hall.json 2> $O/hall.err; echo "hall rc=$?"; tail -c 1500 $O/hall.json ;;
     quick)  timeout 600 python bench.py --steps 200 --warmup 20 --no-pmc --cpu-frames 0 --no-group > $O/quick.json 2> $O/quick.err; echo "quick rc=$?"; tail -c 2500 $O/quick.json ;;
-    prof)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/$O/prof -o prof -- python3 $OLDPWD/bench.py --steps 200 --warmup 20 --no-pmc --cpu-frames 0 --no-group > $OLDPWD/$O/prof.log 2>&1); echo "prof rc=$?"; ls $O/prof* | head ;;
+    prof|prof_tsdf|prof_hall)   # rocprofv3 --kernel-trace --stats of the same command as bench / tsdf / hall (whole run: pre-roll, windows, replay)
+            case $step in prof) A="--steps 200 --warmup 20";; prof_tsdf) A="--mode tsdf --steps 200 --warmup 20";; prof_hall) A="--scene big --hires --steps 60 --warmup 10";; esac
+            U=$PWD/$O/$step; mkdir -p $U
+            (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $U/trace -o t -- python3 $OLDPWD/bench.py $A --no-pmc --cpu-frames 0 --no-group --repeats 0 > $U/bench_line_profiled.json 2> $U/prof.err)
+            S=$(find $U/trace -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $O/${step}_kernel_stats.csv
+            rm -rf $U/trace; echo "$step rc=$?"; head -8 $O/${step}_kernel_stats.csv | cut -c1-150 ;;
     unit|unit_moved)
             # the keyframe unit under rocprofv3: kernel trace, FETCH_SIZE, WRITE_SIZE (separate passes), exact counts, summary
             MV=""; [ $step = unit_moved ] && MV="--moved"
@@ -30,7 +35,7 @@ for step in "$@"; do
             S=$(find $U/trace -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $U/kernel_stats.csv
             python3 tools/prof_unit.py --summarize "$T" "$F" "$W" $U/counts.json > $U/summary.json 2> $U/summary.err
             rm -rf $U/trace $U/fetch $U/write
-            echo "$step rc=$?"; cat $U/run_line.json; tail -c 1800 $U/summary.json; tail -3 $U/summary.err $U/count.err ;;
+            echo "$step rc=$?"; cat $U/run_line.json; tail -c 1800 $U/summary.json; tail -n 3 $U/summary.err; tail -n 3 $U/count.err ;;
     sq)     # SQ counters of the per-frame kernels over the timed workload (bench.py --child), three passes
             U=$PWD/$O/sq; mkdir -p $U; rm -rf $U/*
             B="python3 $PWD/bench.py --child --steps 60 --warmup 20"
