@@ -33,11 +33,16 @@ namespace tf {
 __device__ const unsigned long long d_mc_tri[256] = TF_MC_TRI_TABLE_INIT;
 
 constexpr int kR = 11;               // staged region: voxel coordinates -1 .. 9 per axis
-constexpr int kRV = kR * kR * kR;    // 1331
+#ifndef TF_MESH_RS
+#define TF_MESH_RS 11                // LDS row stride of the staged region in words (>= 11; A/B of bank conflicts, profiles/r4)
+#endif
+constexpr int kRS = TF_MESH_RS;      // row stride
+constexpr int kPS = kRS * kR;        // plane stride
+constexpr int kRV = kPS * kR;        // 1331 words at the natural stride
 constexpr int kEdgeSlots = 3 * 729;  // vertByEdge (ChunkManager.cpp:646-648)
 __device__ __forceinline__ uint32_t mesh_shard_rows_d(uint32_t max_chunks) { return max_chunks / kMeshShards + 258u; }  // = mesh_shard_rows()
 
-__device__ __forceinline__ int ridx(int x, int y, int z) { return (x + 1) + (y + 1) * kR + (z + 1) * kR * kR; }
+__device__ __forceinline__ int ridx(int x, int y, int z) { return (x + 1) + (y + 1) * kRS + (z + 1) * kPS; }
 
 // Index tables of the staging passes (the kernel is VALU-bound: no div / mod by 11 or 9 per voxel).
 //   halo: the region voxels that belong to neighbour chunks AND are read by somebody -- a cell corner (all coordinates in
@@ -93,13 +98,13 @@ constexpr MeshTabs make_mesh_tabs() {
         const int cx = (rx + 8) >> 3, cy = (ry + 8) >> 3, cz = (rz + 8) >> 3;
         const unsigned long long nb = (unsigned long long)(cx + cy * 3 + cz * 9);
         const unsigned long long pair = (unsigned long long)((((rx0 + 8) & 7) + ((ry + 8) & 7) * 8 + ((rz + 8) & 7) * 64) >> 1);
-        const unsigned long long r0 = (unsigned long long)((rx0 + 1) + (ry + 1) * kR + (rz + 1) * kR * kR);  // (rx0 = -2 never indexes: use0 is false then)
+        const unsigned long long r0 = (unsigned long long)((rx0 + 1) + (ry + 1) * kRS + (rz + 1) * kPS);  // (rx0 = -2 never indexes: use0 is false then)
         t.halo[n++] = (r0 & 2047ull) | (nb << 11) | (pair << 16) | ((use0 ? 1ull : 0ull) << 24) | ((use1 ? 1ull : 0ull) << 25) |
                       ((use0 ? corner_of(rx0, ry, rz) : 0ull) << 26) | ((use1 ? corner_of(rx0 + 1, ry, rz) : 0ull) << 36);
       }
   for (int c = 0; c < 729; ++c) {
     const int px = c % 9, py = (c / 9) % 9, pz = c / 81;
-    t.corner[c] = (uint16_t)((px + 1) + (py + 1) * kR + (pz + 1) * kR * kR);
+    t.corner[c] = (uint16_t)((px + 1) + (py + 1) * kRS + (pz + 1) * kPS);
   }
   return t;
 }
@@ -138,8 +143,8 @@ __device__ __forceinline__ bool gradient_at(const float* __restrict__ S, int px,
                                             int oz, float res, float g[3]) {
   const int c = ridx(px, py, pz);
   const float xm = S[c - 1], xp = S[c + 1];
-  const float ym = S[c - kR], yp = S[c + kR];
-  const float zm = S[c - kR * kR], zp = S[c + kR * kR];
+  const float ym = S[c - kRS], yp = S[c + kRS];
+  const float zm = S[c - kPS], zp = S[c + kPS];
   const bool ok = ((ox ? xp : xm) < 1.0f) && ((oy ? yp : ym) < 1.0f) && ((oz ? zp : zm) < 1.0f);
   const float gx = xp - xm, gy = yp - ym, gz = zp - zm;
   const float yz = gy * gy + gz * gz;
@@ -155,10 +160,13 @@ constexpr uint32_t kCfHeavy = 64u;   // weight > 50 (weight_threshold, ChunkMana
 constexpr uint32_t kCfGradOk = 128u; // |gradient| <= 100 * resolution (:449-452)
 // bits 0..5: the voxel one step along -x, +x, -y, +y, -z, +z has sdf < 1 (GetNeighborSDF, ChunkManager.h:790-823)
 
+#ifndef TF_MESH_CFLAG_T
+#define TF_MESH_CFLAG_T uint8_t   // (uint32_t: 2.2 KB more LDS per workgroup, no sub-dword LDS accesses; A/B in profiles/r4)
+#endif
 template <int NT>
 struct MeshSh {
   float S[kRV];               // sdf, region coordinates -1..9
-  uint8_t cflag[732];         // per cell corner: kCf* | neighbour bits
+  TF_MESH_CFLAG_T cflag[732]; // per cell corner: kCf* | neighbour bits
   uint32_t nslot[27];         // pool slot of chunk id + (-1..1)^3, kInvalidSlot = missing
   // output vertex index of a used edge slot m = rbase[m / kEpt] + popcount(rmask[m / kEpt] below bit m % kEpt), kEpt =
   // 2304 / threads: one {base, mask} pair per THREAD of the ranking pass instead of 2187 16-bit entries (LDS per
@@ -800,15 +808,15 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     // GetNeighborSDF, :320-447), so the answer per (cell, corner) is three of these bits.
     for (int c = t; c < 729; c += NT) {
       const int r = d_mesh_tabs.corner[c];
-      const float xm = sh.S[r - 1], xp = sh.S[r + 1], ym = sh.S[r - kR], yp = sh.S[r + kR];
-      const float zm = sh.S[r - kR * kR], zp = sh.S[r + kR * kR];
+      const float xm = sh.S[r - 1], xp = sh.S[r + 1], ym = sh.S[r - kRS], yp = sh.S[r + kRS];
+      const float zm = sh.S[r - kPS], zp = sh.S[r + kPS];
       uint32_t f = (xm < 1.0f ? 1u : 0u) | (xp < 1.0f ? 2u : 0u) | (ym < 1.0f ? 4u : 0u) | (yp < 1.0f ? 8u : 0u) |
                    (zm < 1.0f ? 16u : 0u) | (zp < 1.0f ? 32u : 0u);
       const float gx = xp - xm, gy = yp - ym, gz = zp - zm;
       const float yz = gy * gy + gz * gz;
       const float nrm = sqrtf(gx * gx + yz);
       if (!(nrm > res * 100.0f)) f |= kCfGradOk;
-      sh.cflag[c] |= (uint8_t)f;
+      sh.cflag[c] |= (TF_MESH_CFLAG_T)f;
     }
     for (int i = t; i < (kEdgeSlots + 7) / 8; i += NT) sh.ownq[i] = 0u;
     __syncthreads();
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
       int pos = 0, index = 0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float s = sh.S[c0 + cox(k) + coy(k) * kR + coz(k) * kR * kR];
+        const float s = sh.S[c0 + cox(k) + coy(k) * kRS + coz(k) * kPS];
         observed = observed && !(s > 1.0f);  // :669-720
         pos += (s > 0.0f) ? 1 : 0;
         index |= (0.0f > s) ? (1 << k) : 0;  // :726-735
@@ -847,7 +855,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
       int index = 0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float s = sh.S[c0 + cox(k) + coy(k) * kR + coz(k) * kR * kR];
+        const float s = sh.S[c0 + cox(k) + coy(k) * kRS + coz(k) * kPS];
         cube[k] = s;
         index |= (0.0f > s) ? (1 << k) : 0;
       }
