@@ -313,9 +313,10 @@ void launch_null(hipStream_t s);
 void launch_bbox(const VolumeDev& v, const float* depth, const Cam& cam, const Pose& pose,
                  hipStream_t s);
 void launch_select(const VolumeDev& v, const float* depth, const Cam& cam, const Integ& ig,
-                   const Pose& pose, float res, bool emit, hipStream_t s);
+                   const Pose& pose, float res, bool emit, hipStream_t s, bool plain = false);
 void launch_scan(const VolumeDev& v, int step, hipStream_t s);
 void launch_acquire(const VolumeDev& v, hipStream_t s);
+void launch_acquire_emitted(const VolumeDev& v, hipStream_t s);  // behind launch_select(emit = true, plain = true)
 void launch_lookup(const VolumeDev& v, uint32_t n, hipStream_t s);
 // have_pre: the list records / centroid table of this pose are already there (launch_pre_frames)
 void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam, const Integ& ig,

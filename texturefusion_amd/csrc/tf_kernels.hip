@@ -461,7 +461,7 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
             }
           }
         }
-        costly = below && above && !pruned;
+        costly = (below && above && !pruned) || sc.plain != 0;
         if (EMIT) {
           const long long k = part_key(v, x0 + di, y0 + dj, z0 + dk);
           const long long lo = v.part_lo, hi = v.part_hi;
@@ -517,8 +517,9 @@ __global__ __launch_bounds__(256) void k_select(const float* __restrict__ depth,
   select_body<EMIT>(depth, cam, ig, sc, v, blockIdx.x, gridDim.x);
 }
 void launch_select(const VolumeDev& v, const float* depth, const Cam& cam, const Integ& ig,
-                   const Pose& pose, float res, bool emit, hipStream_t s) {
+                   const Pose& pose, float res, bool emit, hipStream_t s, bool plain) {
   SelectConsts sc = make_select_consts(pose.p, res);
+  sc.plain = plain ? 1 : 0;
   if (emit) hipLaunchKernelGGL(k_select<true>, dim3(1024), dim3(256), 0, s, depth, cam, ig, sc, v);
   else hipLaunchKernelGGL(k_select<false>, dim3(1024), dim3(256), 0, s, depth, cam, ig, sc, v);
 }
@@ -641,6 +642,33 @@ __global__ __launch_bounds__(256) void k_acquire(VolumeDev v) {
 }
 void launch_acquire(const VolumeDev& v, hipStream_t s) {
   hipLaunchKernelGGL(k_acquire, dim3(512), dim3(256), 0, s, v);
+}
+// The same behind k_select<EMIT> with SelectConsts::plain: the list is the unordered one the selection appended (all of it
+// from the front), its length still sits in the append counter -- this launch turns it into a finished plain list
+// (n_list = n_front = length, bounding-box keys re-armed as k_scan does) while it resolves the slots.
+__global__ __launch_bounds__(256) void k_acquire_emitted(VolumeDev v) {
+  const SelBuf& L = v.sel;
+  const unsigned long long pk = L.ctl->emit_pack;
+  uint32_t n = (uint32_t)pk;
+  if ((pk >> 32) != 0ull || n > v.max_list) n = 0;  // (a list that did not fit was reported by the selection: kStListFull)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    L.ctl->n_list = n;
+    L.ctl->n_front = n;
+    for (int a = 0; a < 3; ++a) { L.ctl->bbox_key[a] = f2key(1e8f); L.ctl->bbox_key[3 + a] = f2key(-1e8f); }
+  }
+  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+    const int4 id = L.list_id[e];
+    bool is_new = false;
+    uint32_t ent = 0;
+    const uint32_t slot = chunk_acquire(v, id, &is_new, &ent);
+    L.list_slot[e] = slot;
+    L.list_ent[e] = ent;
+    L.list_new[e] = is_new ? 1 : 0;
+    L.list_needs[e] = 0;
+  }
+}
+void launch_acquire_emitted(const VolumeDev& v, hipStream_t s) {
+  hipLaunchKernelGGL(k_acquire_emitted, dim3(512), dim3(256), 0, s, v);
 }
 
 // Per-chunk scalars for a list that is integrated with an explicit pose (call-by-call flow: every

@@ -288,7 +288,7 @@ __device__ __forceinline__ uint32_t filter_near(const VolumeDev& v, const int4 i
 // (only a survivor's row needs them).  A survivor gets a row of its shard for the mesher's staging.
 __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, uint32_t nslot, int lane,
                                              uint32_t epoch, uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
-                                             uint32_t cap_sh, int ppar, bool use_summ, bool exact) {
+                                             uint32_t cap_sh, int ppar, bool use_summ, bool exact, bool defer) {
   const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
   const uint32_t own = (uint32_t)__shfl((int)nslot, 13);
   // rows and patch entries go to shard own % 32: pool slots are unique, so a shard never holds more than
@@ -355,7 +355,7 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
     empty = ((fl | f2) & 14u) != 14u;
   }
   if (empty) {
-    if (lane == 0) filter_defer_reset(v, cnt, cap_sh, own, id);
+    if (lane == 0) { if (defer) filter_defer_reset(v, cnt, cap_sh, own, id); else filter_reset_record(v, own, id, epoch, ppar); }
     return;
   }
   uint32_t p = 0;
@@ -395,6 +395,9 @@ __device__ __forceinline__ int near_k(int lane) { return (lane % 3 - 1) + 2 * ((
 #define TF_FILTER_PATCH_WAVES 6  // waves per SIMD of the filter instances that carry the patch stage (80 VGPRs)
 #endif
 struct FilterPatch {
+  uint32_t defer;    // the records the filter wants emptied go to the reset list (a patch stage shares the launch) instead of
+                     // being written here (32 counters take one atomic per ruled-out chunk: 57 k of them in a hall frame
+                     // cost the filter 17 us, 5 k in a room frame 2-4 us -- profiles/r4 -- so only when it is needed)
   uint32_t n_patch;  // workgroups of the patch range (0: none)
   uint32_t first;    // first workgroup of the patch range: 0 = dispatched ahead of the filter's, else behind them
   int par;
@@ -460,11 +463,11 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 8
       maybe = __shfl((int)maybe, 0) != 0;
       if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
       if (!maybe) {
-        if (lane == 0) filter_defer_reset(v, cnt, cap_sh, own, id);
+        if (lane == 0) { if (fp.defer) filter_defer_reset(v, cnt, cap_sh, own, id); else filter_reset_record(v, own, id, epoch, ppar); }
         continue;
       }
       const uint32_t got = (uint32_t)__shfl((int)near8, is_near ? near_k(lane) : 0);
-      filter_exact(v, id, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ, exact);
+      filter_exact(v, id, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ, exact, fp.defer != 0);
     }
     return;
   }
@@ -515,11 +518,14 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 8
       }
     }
     __syncthreads();
-    if (w == 3 && lane < (int)s_ne) filter_defer_reset(v, cnt, cap_sh, s_eown[lane], s_eid[lane]);
+    if (w == 3 && lane < (int)s_ne) {
+      if (fp.defer) filter_defer_reset(v, cnt, cap_sh, s_eown[lane], s_eid[lane]);
+      else filter_reset_record(v, s_eown[lane], s_eid[lane], epoch, ppar);
+    }
     const uint32_t nm = s_n;
     for (uint32_t m = (uint32_t)w; m < nm; m += 4u)
       filter_exact(v, s_id[m], is_near ? s_near[m][near_k(lane)] : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar,
-                   use_summ, true);
+                   use_summ, true, fp.defer != 0);
     __syncthreads();  // the parked entries are consumed before the next batch overwrites them
   }
 }
@@ -1184,10 +1190,13 @@ bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   const bool exact = !wave_form || wave_exact || !use_summ;
   FilterPatch fp;
   memset(&fp, 0, sizeof(fp));
+  static const bool always_defer = getenv("TF_FILTER_DEFER") && atoi(getenv("TF_FILTER_DEFER"));  // A/B knob
+  fp.defer = always_defer ? 1u : 0u;
   if (patch && cam) {
     // one wave per patch; the range is dispatched AHEAD of the filter's workgroups (its chains are the longer ones)
     static const uint32_t np = getenv("TF_FILTER_PATCH_BLOCKS") ? (uint32_t)atoi(getenv("TF_FILTER_PATCH_BLOCKS")) : 1024u;
     static const bool patch_last = getenv("TF_FILTER_PATCH_LAST") && atoi(getenv("TF_FILTER_PATCH_LAST"));
+    fp.defer = 1u;
     fp.n_patch = np;
     fp.first = patch_last ? fgrid : 0u;
     fp.par = patch->par;

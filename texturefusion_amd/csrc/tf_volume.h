@@ -228,6 +228,7 @@ struct tf_volume {
 namespace tf {
 int ensure_tmp(tf_volume* v, size_t bytes);
 int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hipStream_t s = nullptr);  // tf_capi.cpp
+int launch_prepare_unordered(tf_volume* v, const Pose& pose, hipStream_t s = nullptr);
 // ride_filter: a patch stage still pending when the stage starts rides on its filter launch (the keyframe unit: there is
 // no k_frame launch for it to ride on) instead of going out as a launch of its own
 int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16,
