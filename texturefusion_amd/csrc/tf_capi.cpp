@@ -1242,11 +1242,13 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   static const bool dbg_noh2d = getenv("TF_HOST_NOH2D") && atoi(getenv("TF_HOST_NOH2D"));  // timing experiment only: WRONG results
   // TF_HOST_COPY_SPLIT=1: depth and colour go up on two copy streams (two SDMA queues); the join happens between the copy
   // streams, so the stream the kernels run on still sees ONE event per frame
-  // Default: only for TSDF-only frames -- that stream is bound by the upload (62 -> 52 us per frame, 16.1 k -> 19 k
-  // frames/s, profiles/r4), while the textured stream is bound by the host side of the call, where the second copy call
-  // and the join cost 3 us per frame (99.6 -> 103.2).  TF_HOST_COPY_SPLIT=0 / 1 forces it off / on.
-  static const int split_knob = getenv("TF_HOST_COPY_SPLIT") ? atoi(getenv("TF_HOST_COPY_SPLIT")) : -1;
-  const bool split = split_knob < 0 ? pose_inv16 == nullptr : split_knob != 0;
+  // OFF by default.  A TSDF-only stream is bound by the upload and the split helps it in steady state on a quiet host (62 ->
+  // 52-54 us per frame), but over four alternating A/B pairs on a shared host (profiles/r4, run s13) the first timed
+  // window behind a stretch of resident frames took 115-123 us per frame with it against 59-82 without, later windows
+  // 53-77 against 59-64: not a gain one can count on.  The textured stream is bound by the host side of the call, where
+  // the second copy call and the join cost 3 us per frame (99.6 -> 103.2).
+  static const int split_knob = getenv("TF_HOST_COPY_SPLIT") ? atoi(getenv("TF_HOST_COPY_SPLIT")) : 0;
+  const bool split = split_knob != 0;
   if (!dbg_noh2d) {
     if (split && rgba) {
       if (!v->copy_stream2) {

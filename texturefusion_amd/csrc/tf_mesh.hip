@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "tf_devfn.h"
+#include "tf_kf_store.h"
 #include "tf_mc_table.h"
 #include "tf_patch_body.h"
 #include "tf_volume.h"
@@ -1219,7 +1220,7 @@ bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
 // that exist, each once (a stamp per pool slot de-duplicates), appended to the work list.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kDirtyBlocks = 512;  // two 1024-thread workgroups per CU: every block resident
-__global__ __launch_bounds__(1024) void k_dirty_frame(VolumeDev v, int par, uint32_t stamp) {
+__device__ __forceinline__ void dirty_frame_body(const VolumeDev& v, int par, uint32_t stamp) {
   const SelBuf& L = v.sel;
   const uint32_t nl = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
   const uint32_t total = nl * 8u;  // 8 threads per entry: k = 0..6 self + neighbours, 7 idle
@@ -1263,8 +1264,18 @@ __global__ __launch_bounds__(1024) void k_dirty_frame(VolumeDev v, int par, uint
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(1024) void k_dirty_frame(VolumeDev v, int par, uint32_t stamp) { dirty_frame_body(v, par, stamp); }
+// The keyframe unit: the same launch carries, as one more workgroup, the ordered store of the group's validChunks
+// (kf_store_body, tf_kf_store.h) -- both only read the finalized list
+__global__ __launch_bounds__(1024) void k_dirty_frame_store(VolumeDev v, int par, uint32_t stamp, KfStoreArgs a) {
+  if (blockIdx.x == kDirtyBlocks) { kf_store_body(v, a.tab, a.slots, a.arena, a.cap, a.slot, a.slack, a.fill); return; }
+  dirty_frame_body(v, par, stamp);
+}
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s) {
   hipLaunchKernelGGL(k_dirty_frame, dim3(kDirtyBlocks), dim3(1024), 0, s, v, par, stamp);
+}
+void launch_dirty_frame_store(const VolumeDev& v, int par, uint32_t stamp, const KfStoreArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_dirty_frame_store, dim3(kDirtyBlocks + 1), dim3(1024), 0, s, v, par, stamp, a);
 }
 
 // A fused frame that finds marks of EARLIER frames still waiting for a mesher (frames integrated without the textured

@@ -236,6 +236,8 @@ int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint3
 // the four band counts of the frame whose selection wrote `ctl` (tag = its epoch + 1): waits for the device to publish them
 int xchg_band_counts(tf_volume* v, const FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]);
 int flush_deferred(tf_volume* v);
+struct KfStoreArgs;  // tf_kf_store.h
+void launch_dirty_frame_store(const VolumeDev& v, int par, uint32_t stamp, const KfStoreArgs& a, hipStream_t s);  // tf_mesh.hip
 int patch_flush(tf_volume* v);
 bool patch_rides_filter();  // TF_PATCH_IN_FILTER=1 (off by default: measured slower, tf_capi.cpp)
 int fused_arm(tf_volume* v);  // the fused flow's counter sets in their start state (no-op once armed)
