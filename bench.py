@@ -871,6 +871,53 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
             "keyframes_per_s": n_kf / dt, "ms_per_keyframe": 1e3 * dt / n_kf, "frame_integrations_per_s": frames / dt,
             "keyframes": n_kf, "moved_groups": n_moved}
         vol.close()
+    # ---- the same keyframes through the reference's OWN call sequence (what a caller that only swaps the headers gets,
+    # INTEGRATION.md approach A): PrepareIntersectChunks -> IntegrateDepthScanColor (keyframe) -> 6 x IntegrateDepthScanColor
+    # (depth only) -> FinalizeIntegrateChunks -> UpdateMeshes -> CompressMeshes -> GeneratePatches -> UpdateAtlas, every call
+    # synchronous with its lists and flags on the host, images device-resident
+    try:
+        import numpy as np
+        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+                          max_coarse=(1 << 22) if big else (1 << 20), device=device)
+        rgb3 = {}
+
+        def call_by_call(g):
+            k0 = (stride * g) % n_unique
+            loc = [(k0 + 1 + i) % n_unique for i in range(n_local)]
+            vol.frame_bind_device(d_depth[k0].data_ptr(), d_rgba[k0].data_ptr(), 0)
+            ids, new = vol.prepare(poses[k0])
+            needs = np.zeros(len(ids), np.uint8)
+            vol.integrate(poses[k0], ids, needs, 1, True, False)
+            for k in loc:
+                vol.frame_bind_device(d_depth[k].data_ptr(), 0, 0)
+                vol.integrate(poses[k], ids, needs, 1, False, False)
+            vol.finalize(ids, needs, new)
+            vol.update_meshes()
+            upd = vol.compress_meshes()
+            vol.keyframe_cache_device(1000 + g, d_rgba[k0].data_ptr(), d_depth[k0].data_ptr(), stride=4, pose_inv16=pinv[k0])
+            vol.generate_patches(upd, np.full(len(upd), 1000 + g, np.int32))
+            vol.update_atlas(upd)
+            if g >= 8:
+                vol.keyframe_release(1000 + g - 8)
+
+        for g in range(4):
+            call_by_call(g)
+        vol.sync()
+        n_cc = max(4, n_kf // 2)
+        t0 = time.perf_counter()
+        for g in range(4, 4 + n_cc):
+            call_by_call(g)
+        vol.sync()
+        dt = time.perf_counter() - t0
+        res_out["call_by_call_reference_sequence"] = {
+            "keyframes_per_s": n_cc / dt, "ms_per_keyframe": 1e3 * dt / n_cc, "frame_integrations_per_s": n_cc * stride / dt,
+            "keyframes": n_cc,
+            "note": "the reference's own sequence of entry points (tf_prepare / tf_integrate x 7 / tf_finalize / tf_update_meshes / "
+                    "tf_compress_meshes / tf_generate_patches / tf_update_atlas), each synchronising with lists and flags on the host: "
+                    "what swapping the headers alone buys; the one-call unit above keeps everything on the device"}
+        vol.close()
+    except Exception as e:  # (a diagnostic figure: never fail the bench line for it)
+        res_out["call_by_call_reference_sequence"] = {"error": repr(e)[:300]}
     res_out["note"] = ("one tf_keyframe_unit_device call per keyframe: 1 colour + %d depth-only frames over one chunk list, "
                        "meshes of everything marked, CompressMeshes, GeneratePatches (label = the keyframe), UpdateAtlas; "
                        "asynchronous, device-resident images, wall time over the calls + one final synchronisation" % n_local)

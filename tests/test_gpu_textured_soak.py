@@ -203,12 +203,15 @@ def test_textured_frames_after_a_tsdf_only_stretch(gpu_required):
     gv.close()
 
 
-@pytest.mark.parametrize("knob", ["TF_MESH_FUSED=1", "TF_FILTER_EXACT=0", "TF_PATCH_IN_FILTER=1"])
+@pytest.mark.parametrize("knob", ["TF_MESH_FUSED=1", "TF_FILTER_EXACT=0", "TF_PATCH_IN_FILTER=1", "TF_FILTER_DEFER=1",
+                                  "TF_HOST_COPY_SPLIT=1"])
 def test_mesher_form_knobs(gpu_required, knob):
     """The measured-and-rejected forms of the filter / mesher pair stay bit-exact: TF_MESH_FUSED=1 (k_mesh<128, true>: the
     mesher runs the filter itself), TF_FILTER_EXACT=0 (the filter reads no voxels, the mesher makes the summaries exact)
-    and TF_PATCH_IN_FILTER=1 (the patch stage of frame f - 1 rides on the filter launch of frame f instead of k_frame(f);
-    round 4) are read once per process -- the orbits run in a child process with the knob set."""
+    TF_PATCH_IN_FILTER=1 (the patch stage of frame f - 1 rides on the filter launch of frame f instead of k_frame(f);
+    round 4), TF_FILTER_DEFER=1 (the filter always lists the records it empties for the mesher launch) and
+    TF_HOST_COPY_SPLIT=1 (host frames uploaded on two copy streams) are read once per process -- the orbits run in a child
+    process with the knob set."""
     import os
     import subprocess
     import sys

@@ -135,9 +135,12 @@ struct CtlSnap {
   VolCtl vc;
 };
 static int fetch_ctl(tf_volume* v, CtlSnap* out) {
-  TF_HIP(hipMemcpyAsync(&out->f, v->dev.sel.ctl, offsetof(FrameCtl, ka_next), hipMemcpyDeviceToHost, v->stream));  // (without the pull counters)
-  TF_HIP(hipMemcpyAsync(&out->vc, v->dev.vctl, sizeof(VolCtl), hipMemcpyDeviceToHost, v->stream));
+  if (!v->h_ctl) TF_HIP(hipHostMalloc((void**)&v->h_ctl, offsetof(FrameCtl, ka_next) + sizeof(VolCtl), hipHostMallocDefault));
+  launch_export_ctl(v->dev.sel.ctl, v->dev.vctl, v->h_ctl, v->stream);
+  TF_HIP(hipGetLastError());
   TF_HIP(hipStreamSynchronize(v->stream));
+  memcpy(&out->f, v->h_ctl, offsetof(FrameCtl, ka_next));  // (without the pull counters)
+  memcpy(&out->vc, reinterpret_cast<const uint8_t*>(v->h_ctl) + offsetof(FrameCtl, ka_next), sizeof(VolCtl));
   if (out->vc.status) {
     TF_HIP(hipMemsetAsync(&v->dev.vctl->status, 0, sizeof(uint32_t), v->stream));
     return status_to_error(out->vc.status);
@@ -281,7 +284,14 @@ static int sync_list(tf_volume* v, const int32_t* ids, int64_t n) {
   TF_HIP(hipStreamSynchronize(v->stream));
   v->host_list.assign(ids, ids + 3 * n);
   v->host_list_n = n;
+  v->host_needs.assign((size_t)n, 0);
+  v->host_new.assign((size_t)n, 0);
+  v->host_flags_n = n;
   return TF_OK;
+}
+// the caller's flags are what the device list already holds?
+static bool flags_current(const tf_volume* v, const std::vector<uint8_t>& mirror, const uint8_t* flags, int64_t n) {
+  return v->host_flags_n == n && v->host_list_n == n && (int64_t)mirror.size() == n && memcmp(mirror.data(), flags, (size_t)n) == 0;
 }
 
 }  // namespace tf
@@ -436,6 +446,7 @@ int tf_volume_destroy(tf_volume* v) {
   if (v->d_tmp) hipFree(v->d_tmp);
   if (v->d_group) hipFree(v->d_group);
   if (v->h_pinned) hipHostFree(v->h_pinned);
+  if (v->h_ctl) hipHostFree(v->h_ctl);
   if (v->h_progress) hipHostFree(v->h_progress);
   v->h_progress = nullptr;
   if (v->h_xchg) hipHostFree(v->h_xchg);
@@ -602,7 +613,7 @@ int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint8_t* ou
   const int64_t cnt = ctl.f.n_list;
   *n = cnt;
   if (cnt > cap) { set_error("output capacity too small for the visible list"); return TF_ERR_CAPACITY; }
-  if (cnt == 0) { v->host_list.clear(); v->host_list_n = 0; return TF_OK; }
+  if (cnt == 0) { v->host_list.clear(); v->host_list_n = 0; v->host_flags_n = -2; return TF_OK; }
   rc = ensure_pinned(v, (size_t)cnt * 17);
   if (rc) return rc;
   int32_t* st = reinterpret_cast<int32_t*>(v->h_pinned);
@@ -617,6 +628,9 @@ int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint8_t* ou
     v->host_list[3 * i + 2] = st[4 * i + 2];
   }
   v->host_list_n = cnt;
+  v->host_needs.assign((size_t)cnt, 0);  // (the selection leaves needsUpdate clear)
+  v->host_new.assign(stn, stn + cnt);
+  v->host_flags_n = cnt;
   if (out_ids) memcpy(out_ids, v->host_list.data(), (size_t)cnt * 12);
   if (out_new) memcpy(out_new, stn, (size_t)cnt);
   return TF_OK;
@@ -634,13 +648,18 @@ int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t
   int rc = sync_list(v, ids, n);
   if (rc) return rc;
   const size_t npad = (size_t)((n + 3) & ~(int64_t)3);
-  rc = ensure_pinned(v, npad + (size_t)n * 4);
+  rc = ensure_pinned(v, 2 * npad + (size_t)n * 4 + 16);
   if (rc) return rc;
   TF_HIP(hipStreamSynchronize(v->stream));
-  uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);
-  float* stq = reinterpret_cast<float*>(st + npad);
-  memcpy(st, inout_needs_update, (size_t)n);
-  TF_HIP(hipMemcpyAsync(v->dev.sel.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
+  uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);           // flags going in
+  uint8_t* st_out = st + npad;                                      // flags coming back (written by the device)
+  float* stq = reinterpret_cast<float*>(st + 2 * npad);
+  uint32_t* stat = reinterpret_cast<uint32_t*>(st + 2 * npad + (size_t)n * 4);
+  if (!flags_current(v, v->host_needs, inout_needs_update, n)) {
+    memcpy(st, inout_needs_update, (size_t)n);
+    TF_HIP(hipMemcpyAsync(v->dev.sel.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
+  }
+  v->host_flags_n = -2;
   Pose P;
   memcpy(P.p, pose, sizeof(P.p));
   prof_begin(v, TF_PROF_INTEGRATE);
@@ -648,13 +667,22 @@ int tf_integrate(tf_volume* v, const float pose[12], const int32_t* ids, int64_t
                    use_quality != 0, 0, v->stream);
   prof_end(v);
   TF_HIP(hipGetLastError());
-  TF_HIP(hipMemcpyAsync(st, v->dev.sel.list_needs, (size_t)n, hipMemcpyDeviceToHost, v->stream));
-  TF_HIP(hipMemcpyAsync(stq, v->dev.sel.list_quality, (size_t)n * 4, hipMemcpyDeviceToHost, v->stream));
-  CtlSnap ctl;
-  rc = fetch_ctl(v, &ctl);
-  if (rc) return rc;
-  memcpy(inout_needs_update, st, (size_t)n);
-  if (out_quality) memcpy(out_quality, stq, (size_t)n * 4);
+  // (a depth-only call has no quality sum: chunkObservationQuality stays 0, ProjectionIntegrator.cpp:212-238)
+  const bool want_q = out_quality && use_color;
+  *stat = 0;
+  launch_export_integrate(v->dev, (uint32_t)n, st_out, want_q ? stq : nullptr, stat, v->stream);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipStreamSynchronize(v->stream));
+  if (*stat) {  // (rare: the usual path reads, resets and translates the sticky bits)
+    CtlSnap ctl;
+    rc = fetch_ctl(v, &ctl);
+    if (rc) return rc;
+  }
+  memcpy(inout_needs_update, st_out, (size_t)n);
+  v->host_needs.assign(st_out, st_out + n);
+  v->host_flags_n = n;
+  if (want_q) memcpy(out_quality, stq, (size_t)n * 4);
+  else if (out_quality) memset(out_quality, 0, (size_t)n * 4);
   return TF_OK;
 }
 
@@ -678,8 +706,11 @@ int tf_integrate_depth_group(tf_volume* v, int32_t n_frames, const float* const*
   if (rc) return rc;
   TF_HIP(hipStreamSynchronize(v->stream));
   uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);
-  memcpy(st, inout_needs_update, (size_t)n);
-  TF_HIP(hipMemcpyAsync(v->dev.sel.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
+  if (!flags_current(v, v->host_needs, inout_needs_update, n)) {
+    memcpy(st, inout_needs_update, (size_t)n);
+    TF_HIP(hipMemcpyAsync(v->dev.sel.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
+  }
+  v->host_flags_n = -2;
   float4* pre = reinterpret_cast<float4*>(v->d_tmp);
   float* cen = reinterpret_cast<float*>(reinterpret_cast<uint8_t*>(v->d_tmp) + pre_bytes);
   prof_begin(v, TF_PROF_INTEGRATE);
@@ -691,6 +722,8 @@ int tf_integrate_depth_group(tf_volume* v, int32_t n_frames, const float* const*
   rc = fetch_ctl(v, &ctl);
   if (rc) return rc;
   memcpy(inout_needs_update, st, (size_t)n);
+  v->host_needs.assign(st, st + n);
+  v->host_flags_n = n;
   return TF_OK;
 }
 
@@ -727,10 +760,17 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
     if (rc) return rc;
     TF_HIP(hipStreamSynchronize(v->stream));
     uint8_t* st = reinterpret_cast<uint8_t*>(v->h_pinned);
-    memcpy(st, needs_update, (size_t)n);
-    memcpy(st + n, is_new, (size_t)n);
-    TF_HIP(hipMemcpyAsync(v->dev.sel.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
-    TF_HIP(hipMemcpyAsync(v->dev.sel.list_new, st + n, (size_t)n, hipMemcpyHostToDevice, v->stream));
+    if (!flags_current(v, v->host_needs, needs_update, n)) {
+      memcpy(st, needs_update, (size_t)n);
+      TF_HIP(hipMemcpyAsync(v->dev.sel.list_needs, st, (size_t)n, hipMemcpyHostToDevice, v->stream));
+      v->host_needs.assign(needs_update, needs_update + n);
+    }
+    if (!flags_current(v, v->host_new, is_new, n)) {
+      memcpy(st + n, is_new, (size_t)n);
+      TF_HIP(hipMemcpyAsync(v->dev.sel.list_new, st + n, (size_t)n, hipMemcpyHostToDevice, v->stream));
+      v->host_new.assign(is_new, is_new + n);
+    }
+    v->host_flags_n = n;
     prof_begin(v, TF_PROF_FINALIZE);
     launch_finalize(v->dev, v->epoch++, v->stream);
     prof_end(v);

@@ -327,6 +327,10 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
 void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const float* poses12, float4* pre_scratch,
                        float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s);
 void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
+// FrameCtl (without the pull counters) followed by VolCtl, as words, into host-visible memory
+void launch_export_ctl(const FrameCtl* f, const VolCtl* vc, uint32_t* h, hipStream_t s);
+// needs flags (+ quality sums) of the current list and VolCtl::status into host-visible pinned memory
+void launch_export_integrate(const VolumeDev& v, uint32_t n, uint8_t* h_needs, float* h_quality, uint32_t* h_status, hipStream_t s);
 void launch_pack_rgba(const uint8_t* rgb, const uint8_t* valid, uchar4* rgba, uint32_t npix, hipStream_t s);
 void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipStream_t s);
 void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s);

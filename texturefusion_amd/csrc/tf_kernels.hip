@@ -1819,6 +1819,39 @@ __global__ __launch_bounds__(256) void k_rowstats(VolumeDev v, unsigned long lon
     atomicAdd(&out3[3], np);
   }
 }
+// The outputs of a call-by-call tf_integrate -- needsUpdate flags, quality sums, the status word -- written straight into
+// host-visible pinned memory: one synchronisation instead of three small device-to-host copies and theirs
+// (94 -> ~70 us per call; a keyframe of the reference's own sequence makes seven, tools/call_by_call_times.py).
+__global__ __launch_bounds__(256) void k_export_integrate(VolumeDev v, uint32_t n, uint8_t* __restrict__ h_needs,
+                                                          float* __restrict__ h_quality, uint32_t* __restrict__ h_status) {
+  const SelBuf& L = v.sel;
+  const uint32_t i4 = (blockIdx.x * 256 + threadIdx.x) * 4u;
+  if (i4 < n) {
+    if (i4 + 4 <= n) *reinterpret_cast<uint32_t*>(h_needs + i4) = *reinterpret_cast<const uint32_t*>(L.list_needs + i4);
+    else for (uint32_t k = i4; k < n; ++k) h_needs[k] = L.list_needs[k];
+    if (h_quality) for (uint32_t k = i4; k < n && k < i4 + 4; ++k) h_quality[k] = L.list_quality[k];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *h_status = v.vctl->status;
+}
+void launch_export_integrate(const VolumeDev& v, uint32_t n, uint8_t* h_needs, float* h_quality, uint32_t* h_status, hipStream_t s) {
+  hipLaunchKernelGGL(k_export_integrate, dim3((n / 4 + 256) / 256), dim3(256), 0, s, v, n, h_needs, h_quality, h_status);
+}
+
+// The control blocks as the host reads them after a call-by-call entry point: into pinned memory by a launch (a copy
+// into pageable host memory goes through the runtime's own staging: two of them cost more than this launch + the wait)
+__global__ __launch_bounds__(128) void k_export_ctl(const uint32_t* __restrict__ f, uint32_t nf, const uint32_t* __restrict__ vc,
+                                                    uint32_t nv, uint32_t* __restrict__ h) {
+  const uint32_t t = threadIdx.x;
+  if (t < nf) h[t] = f[t];
+  if (t < nv) h[nf + t] = vc[t];
+}
+void launch_export_ctl(const FrameCtl* f, const VolCtl* vc, uint32_t* h, hipStream_t s) {
+  constexpr uint32_t nf = offsetof(FrameCtl, ka_next) / 4, nv = sizeof(VolCtl) / 4;
+  static_assert(nf <= 128 && nv <= 128, "one workgroup exports the control blocks");
+  hipLaunchKernelGGL(k_export_ctl, dim3(1), dim3(128), 0, s, reinterpret_cast<const uint32_t*>(f), nf,
+                     reinterpret_cast<const uint32_t*>(vc), nv, h);
+}
+
 void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s) {
   hipLaunchKernelGGL(k_rowstats, dim3(64), dim3(256), 0, s, v, out3);
 }

@@ -186,6 +186,12 @@ struct tf_volume {
   // host shadow of the device-resident visible list (int32[3*n]); -1 = device list unknown
   std::vector<int32_t> host_list;
   int64_t host_list_n = -1;
+  // what the device list's needsUpdate / isNew flags hold, as far as the call-by-call entry points know (valid while
+  // host_flags_n == host_list_n): a caller that hands back the flags it was given -- the reference's loop over one
+  // keyframe's frames does -- costs no upload
+  std::vector<uint8_t> host_needs, host_new;
+  int64_t host_flags_n = -2;
+  uint32_t* h_ctl = nullptr;  // pinned: FrameCtl head + VolCtl as fetch_ctl reads them
   uint32_t epoch = 0;        // finalize counter (mark / erase stamps are epoch + 1)
   uint32_t clear_floor = 0;  // stamps <= this were cleared (Chisel::CompressMeshes' chunksToUpdate.clear())
   uint32_t mesh_epoch = 0;   // meshing passes so far (MeshRec::epoch)
