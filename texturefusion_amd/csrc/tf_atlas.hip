@@ -839,7 +839,11 @@ int tf_generate_patches(tf_volume* v, const int32_t* ids, int64_t n, const int32
     }
     kfs[(size_t)i] = last_slot;
   }
-  int rc = upload_work(v, ids, kfs.data(), n);
+  // (room behind the work list for the counters coming back: pinned, so that the copy does not go through the runtime's staging)
+  const size_t o_ctl = ((size_t)n * 16 + 16 + 63) & ~(size_t)63;
+  int rc = atlas_stage(v, o_ctl + sizeof(AtlasCtl));
+  if (rc) return rc;
+  rc = upload_work(v, ids, kfs.data(), n);
   if (rc) return rc;
   a.fused_armed = false;
   hipLaunchKernelGGL(k_patch_assign, dim3(1), dim3(1024), 0, v->stream, v->dev, (uint32_t)n);
@@ -847,9 +851,10 @@ int tf_generate_patches(tf_volume* v, const int32_t* ids, int64_t n, const int32
   hipLaunchKernelGGL((k_patch<true, false, false>), dim3(1024), dim3(256), 0, v->stream, v->dev, v->cam, 0, KfDev{});
   prof_end(v);
   TF_HIP(hipGetLastError());
-  AtlasCtl c;
-  TF_HIP(hipMemcpyAsync(&c, a.d_actl, sizeof(c), hipMemcpyDeviceToHost, v->stream));
-  rc = tf_sync(v);
+  AtlasCtl* hc = reinterpret_cast<AtlasCtl*>(reinterpret_cast<uint8_t*>(a.h_stage) + o_ctl);
+  TF_HIP(hipMemcpyAsync(hc, a.d_actl, sizeof(AtlasCtl), hipMemcpyDeviceToHost, v->stream));
+  rc = sync_status(v, nullptr);
+  const AtlasCtl c = *hc;
   if (out_hot && c.n_done > 0) {  // Chisel.cpp:184-186
     out_hot[0] = (c.loc_min / (uint64_t)a.aw) * (uint64_t)a.aw;
     out_hot[1] = (c.loc_max / (uint64_t)a.aw + a.ph) * (uint64_t)a.aw;

@@ -148,6 +148,15 @@ static int fetch_ctl(tf_volume* v, CtlSnap* out) {
   return TF_OK;
 }
 
+}  // namespace tf
+int tf::sync_status(tf_volume* v, uint32_t* n_tmp) {
+  CtlSnap ctl;
+  const int rc = fetch_ctl(v, &ctl);
+  if (n_tmp) *n_tmp = ctl.vc.n_tmp;
+  return rc;
+}
+namespace tf {
+
 static int init_device_state(tf_volume* v) {
   VolumeDev& d = v->dev;
   hipStream_t s = v->stream;
@@ -604,8 +613,16 @@ int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint8_t* ou
   Pose P;
   memcpy(P.p, pose, sizeof(P.p));
   v->host_list_n = -1;
-  int rc = launch_prepare(v, P, true);
+  // the list goes to host-visible memory behind the kernels that make it: one synchronisation per call
+  const size_t cap_list = (size_t)v->dev.max_list;
+  int rc = ensure_pinned(v, cap_list * 17);
   if (rc) return rc;
+  rc = launch_prepare(v, P, true);
+  if (rc) return rc;
+  TF_HIP(hipGetLastError());
+  int32_t* st = reinterpret_cast<int32_t*>(v->h_pinned);
+  uint8_t* stn = reinterpret_cast<uint8_t*>(st + 4 * cap_list);
+  launch_export_list(v->dev, reinterpret_cast<int4*>(st), stn, (uint32_t)cap_list, v->stream);
   TF_HIP(hipGetLastError());
   CtlSnap ctl;
   rc = fetch_ctl(v, &ctl);
@@ -614,13 +631,6 @@ int tf_prepare(tf_volume* v, const float pose[12], int32_t* out_ids, uint8_t* ou
   *n = cnt;
   if (cnt > cap) { set_error("output capacity too small for the visible list"); return TF_ERR_CAPACITY; }
   if (cnt == 0) { v->host_list.clear(); v->host_list_n = 0; v->host_flags_n = -2; return TF_OK; }
-  rc = ensure_pinned(v, (size_t)cnt * 17);
-  if (rc) return rc;
-  int32_t* st = reinterpret_cast<int32_t*>(v->h_pinned);
-  uint8_t* stn = reinterpret_cast<uint8_t*>(st + 4 * cnt);
-  TF_HIP(hipMemcpyAsync(st, v->dev.sel.list_id, (size_t)cnt * 16, hipMemcpyDeviceToHost, v->stream));
-  TF_HIP(hipMemcpyAsync(stn, v->dev.sel.list_new, (size_t)cnt, hipMemcpyDeviceToHost, v->stream));
-  TF_HIP(hipStreamSynchronize(v->stream));
   v->host_list.resize((size_t)cnt * 3);
   for (int64_t i = 0; i < cnt; ++i) {
     v->host_list[3 * i] = st[4 * i];

@@ -327,6 +327,8 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
 void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const float* poses12, float4* pre_scratch,
                        float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s);
 void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
+// the plain list's ids and isNew flags (first min(n_list, cap) entries) into host-visible memory
+void launch_export_list(const VolumeDev& v, int4* h_ids, uint8_t* h_new, uint32_t cap, hipStream_t s);
 // FrameCtl (without the pull counters) followed by VolCtl, as words, into host-visible memory
 void launch_export_ctl(const FrameCtl* f, const VolCtl* vc, uint32_t* h, hipStream_t s);
 // needs flags (+ quality sums) of the current list and VolCtl::status into host-visible pinned memory

@@ -1852,6 +1852,20 @@ void launch_export_ctl(const FrameCtl* f, const VolCtl* vc, uint32_t* h, hipStre
                      reinterpret_cast<const uint32_t*>(vc), nv, h);
 }
 
+// tf_prepare's outputs -- the ordered list and its isNew flags -- into host-visible memory, behind the acquire launch
+__global__ __launch_bounds__(256) void k_export_list(VolumeDev v, int4* __restrict__ h_ids, uint8_t* __restrict__ h_new, uint32_t cap) {
+  const SelBuf& L = v.sel;
+  uint32_t n = L.ctl->n_list;
+  if (n > cap) n = cap;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    h_ids[i] = L.list_id[i];
+    h_new[i] = L.list_new[i];
+  }
+}
+void launch_export_list(const VolumeDev& v, int4* h_ids, uint8_t* h_new, uint32_t cap, hipStream_t s) {
+  hipLaunchKernelGGL(k_export_list, dim3(128), dim3(256), 0, s, v, h_ids, h_new, cap);
+}
+
 void launch_rowstats(const VolumeDev& v, unsigned long long* out3, hipStream_t s) {
   hipLaunchKernelGGL(k_rowstats, dim3(64), dim3(256), 0, s, v, out3);
 }

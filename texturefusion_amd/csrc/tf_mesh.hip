@@ -1422,8 +1422,9 @@ static int upload_ids(tf_volume* v, const int32_t* ids, int64_t n, size_t at) {
   return TF_OK;
 }
 
-// the dirty set (Chisel::meshesToUpdate) as a device list in d_tmp: [0,16) count word, ids from byte 16
-static int dirty_list_device(tf_volume* v, uint32_t* n_out) {
+// the dirty set (Chisel::meshesToUpdate) as a device list in d_tmp: [0,16) count word, ids from byte 16.  Enqueued only:
+// the count is also in VolCtl::n_tmp, which sync_status reads behind whatever the caller launches on the list.
+static int dirty_list_enqueue(tf_volume* v) {
   const size_t cap = (size_t)v->dev.max_chunks;
   int rc = ensure_tmp(v, cap * 16 + 16);
   if (rc) return rc;
@@ -1432,10 +1433,6 @@ static int dirty_list_device(tf_volume* v, uint32_t* n_out) {
                     v->clear_floor, v->stream);
   TF_HIP(hipGetLastError());
   TF_HIP(hipMemcpyAsync(v->d_tmp, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));
-  uint32_t n = 0;
-  TF_HIP(hipMemcpyAsync(&n, v->d_tmp, 4, hipMemcpyDeviceToHost, v->stream));
-  TF_HIP(hipStreamSynchronize(v->stream));
-  *n_out = n;
   return TF_OK;
 }
 
@@ -1470,19 +1467,25 @@ extern "C" {
 int tf_update_meshes(tf_volume* v, int64_t* n_meshed) {
   if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
   TF_DEV(v);
-  uint32_t n = 0;
-  int rc = dirty_list_device(v, &n);
+  int rc = dirty_list_enqueue(v);
   if (rc) return rc;
-  if (n_meshed) *n_meshed = n;
-  if (!n) return TF_OK;
+  // (the launches take the list's length from the device word: no synchronisation between the scan and the mesher; an
+  // empty list costs two empty launches)
   const uint8_t* db = reinterpret_cast<const uint8_t*>(v->d_tmp);
   prof_begin(v, TF_PROF_MESH);
-  launch_mesh(v->dev, v->mesh_par, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), n,
-              ++v->mesh_epoch, v->res, false, -1, n, nullptr, -1, v->stream);
+  launch_mesh(v->dev, v->mesh_par, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), v->dev.max_chunks,
+              ++v->mesh_epoch, v->res, false, -1, v->dirty_list_n, nullptr, -1, v->stream);
   v->mesh_par ^= 1;
   prof_end(v);
   TF_HIP(hipGetLastError());
-  return tf_sync(v);
+  uint32_t n = 0;
+  rc = sync_status(v, &n);
+  if (n > v->dev.max_chunks) n = v->dev.max_chunks;
+  if (n_meshed) *n_meshed = n;
+  if (rc) return rc;
+  v->dirty_list_n = n;
+  v->dirty_list_seq = v->call_seq;  // d_tmp holds the list: a tf_compress_meshes right behind this call takes it from there
+  return TF_OK;
 }
 
 int tf_list_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n) {
@@ -1587,52 +1590,83 @@ int tf_meshes_download(tf_volume* v, const int32_t* ids, int64_t n, const int64_
   return TF_OK;
 }
 
-static bool id_less(const int32_t* a, const int32_t* b) {
-  for (int k = 0; k < 3; ++k)
-    if (a[k] != b[k]) return a[k] < b[k];
-  return false;
+// chunksToUpdate = the dirty keys that have a mesh (GCFusion/MobileFusion.cpp:345-353), written straight into host-visible
+// memory (pool slot in w: the host sorts by id)
+__global__ __launch_bounds__(256) void k_dirty_with_mesh(VolumeDev v, const int4* __restrict__ ids, const uint32_t* __restrict__ count,
+                                                         uint32_t cap, int4* __restrict__ h_out, uint32_t cap_out) {
+  uint32_t n = *count;
+  if (n > cap) n = cap;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int4 id = ids[i];
+    const uint32_t ent = hash_find(v, pack_id(id.x, id.y, id.z));
+    if (ent == kInvalidSlot || !(v.hent[ent].alive & 1u) || v.hent[ent].slot == kInvalidSlot) continue;
+    if (!(v.mesh_rec[v.hent[ent].slot].state & kMsInMap)) continue;
+    const uint32_t p = atomicAdd(&v.vctl->n_tmp, 1u);
+    if (p < cap_out) h_out[p] = make_int4(id.x, id.y, id.z, 0);
+  }
 }
 
 int tf_compress_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n_out) {
   if (!v || !n_out) { set_error("null argument"); return TF_ERR_INVALID; }
   TF_DEV(v);
   *n_out = 0;
-  uint32_t n = 0;
-  int rc = dirty_list_device(v, &n);
-  if (rc) return rc;
+  int rc = TF_OK;
+  const bool have_list = v->dirty_list_seq + 1 == v->call_seq && v->d_tmp;  // (the call before this one was tf_update_meshes)
+  if (!have_list) { rc = dirty_list_enqueue(v); if (rc) return rc; }
+  const uint32_t cap_list = v->dev.max_chunks;
+  // room for every listed chunk: known when the list is update_meshes', the whole pool otherwise
+  const size_t cap_host = have_list ? (size_t)v->dirty_list_n : (size_t)cap_list;
   int64_t m = 0;
-  if (n) {
+  if (cap_host) {
+    rc = ensure_pinned(v, cap_host * 16);
+    if (rc) return rc;
     uint8_t* db = reinterpret_cast<uint8_t*>(v->d_tmp);
     const int4* list = reinterpret_cast<const int4*>(db + 16);
     const uint32_t* cnt = reinterpret_cast<const uint32_t*>(db);
-    launch_compress(v->dev, list, cnt, n, true, v->stream);
+    launch_compress(v->dev, list, cnt, cap_list, true, v->stream);
     TF_HIP(hipGetLastError());
-    // chunksToUpdate = the dirty keys that have a mesh (GCFusion/MobileFusion.cpp:345-353), ascending id
-    const size_t o_cnt = ((size_t)n * 16 + 16 + 15) & ~(size_t)15;
-    rc = ensure_tmp(v, o_cnt + (size_t)n * 16);
-    if (rc) return rc;
-    db = reinterpret_cast<uint8_t*>(v->d_tmp);
-    hipLaunchKernelGGL(k_mesh_counts, dim3((n + 255) / 256), dim3(256), 0, v->stream, v->dev,
-                       reinterpret_cast<const int4*>(db + 16), n, reinterpret_cast<int4*>(db + o_cnt));
+    TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
+    const uint32_t grid = have_list ? (v->dirty_list_n + 255u) / 256u : 1024u;
+    hipLaunchKernelGGL(k_dirty_with_mesh, dim3(grid ? grid : 1u), dim3(256), 0, v->stream, v->dev, list, cnt, cap_list,
+                       reinterpret_cast<int4*>(v->h_pinned), (uint32_t)cap_host);
     TF_HIP(hipGetLastError());
-    rc = ensure_pinned(v, (size_t)n * 32);
+    uint32_t got = 0;
+    rc = sync_status(v, &got);
     if (rc) return rc;
-    uint8_t* hb = reinterpret_cast<uint8_t*>(v->h_pinned);
-    TF_HIP(hipMemcpyAsync(hb, db + 16, (size_t)n * 16, hipMemcpyDeviceToHost, v->stream));
-    TF_HIP(hipMemcpyAsync(hb + (size_t)n * 16, db + o_cnt, (size_t)n * 16, hipMemcpyDeviceToHost, v->stream));
-    TF_HIP(hipStreamSynchronize(v->stream));
-    const int32_t* hid = reinterpret_cast<const int32_t*>(hb);
-    const int32_t* hc = reinterpret_cast<const int32_t*>(hb + (size_t)n * 16);
-    std::vector<const int32_t*> keep;
-    keep.reserve(n);
-    for (uint32_t i = 0; i < n; ++i)
-      if (hc[4 * i + 3]) keep.push_back(hid + 4 * i);
-    std::sort(keep.begin(), keep.end(), id_less);
-    m = (int64_t)keep.size();
-    if (out_ids)
-      for (int64_t i = 0; i < m && i < cap; ++i) memcpy(out_ids + 3 * i, keep[(size_t)i], 12);
+    m = got < cap_host ? got : (int64_t)cap_host;
+    // ascending id (std::set<ChunkID> order): one 64-bit key per id, x most significant
+    const int32_t* hid = reinterpret_cast<const int32_t*>(v->h_pinned);
+    std::vector<unsigned long long> keys((size_t)m);
+    bool wide = false;
+    for (int64_t i = 0; i < m; ++i) {
+      const int32_t x = hid[4 * i], y = hid[4 * i + 1], z = hid[4 * i + 2];
+      if (x < -(1 << 20) || x >= (1 << 20) || y < -(1 << 20) || y >= (1 << 20) || z < -(1 << 20) || z >= (1 << 20)) { wide = true; break; }
+      keys[(size_t)i] = ((unsigned long long)(uint32_t)(x + (1 << 20)) << 42) | ((unsigned long long)(uint32_t)(y + (1 << 20)) << 21) |
+                        (unsigned long long)(uint32_t)(z + (1 << 20));
+    }
+    if (!wide) {
+      std::sort(keys.begin(), keys.end());
+      if (out_ids)
+        for (int64_t i = 0; i < m && i < cap; ++i) {
+          const unsigned long long k = keys[(size_t)i];
+          out_ids[3 * i] = (int32_t)(k >> 42) - (1 << 20);
+          out_ids[3 * i + 1] = (int32_t)((k >> 21) & 0x1FFFFFu) - (1 << 20);
+          out_ids[3 * i + 2] = (int32_t)(k & 0x1FFFFFu) - (1 << 20);
+        }
+    } else {  // ids beyond 21 bits per axis: compare the triples
+      std::vector<const int32_t*> keep((size_t)m);
+      for (int64_t i = 0; i < m; ++i) keep[(size_t)i] = hid + 4 * i;
+      std::sort(keep.begin(), keep.end(), [](const int32_t* a, const int32_t* b) {
+        for (int k = 0; k < 3; ++k)
+          if (a[k] != b[k]) return a[k] < b[k];
+        return false;
+      });
+      if (out_ids)
+        for (int64_t i = 0; i < m && i < cap; ++i) memcpy(out_ids + 3 * i, keep[(size_t)i], 12);
+    }
   }
   *n_out = m;
+  v->dirty_list_seq = ~0ull;
   rc = tf_clear_dirty(v);  // chunksToUpdate.clear() (Chisel.cpp:146)
   if (rc) return rc;
   if (out_ids && m > cap) { set_error("output capacity too small"); return TF_ERR_CAPACITY; }

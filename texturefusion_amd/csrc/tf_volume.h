@@ -29,6 +29,7 @@ void set_error(const std::string& msg);
 // had current (two volumes on different GPUs in one process, framework worker threads).
 #define TF_DEV_NOFLUSH(v)                                                                   \
   do {                                                                                      \
+    ++(v)->call_seq;                                                                        \
     hipError_t _e = hipSetDevice((v)->device);                                              \
     if (_e != hipSuccess) {                                                                 \
       ::tf::set_error(std::string("hipSetDevice: ") + hipGetErrorString(_e));               \
@@ -191,6 +192,10 @@ struct tf_volume {
   // keyframe's frames does -- costs no upload
   std::vector<uint8_t> host_needs, host_new;
   int64_t host_flags_n = -2;
+  // entry points counted (TF_DEV*): tf_compress_meshes reuses the dirty list tf_update_meshes left in d_tmp when that was
+  // the call right before it (MobileFusion.cpp:327-345 calls them back to back; nothing in between can have marked a chunk)
+  uint64_t call_seq = 0, dirty_list_seq = ~0ull;
+  uint32_t dirty_list_n = 0;
   uint32_t* h_ctl = nullptr;  // pinned: FrameCtl head + VolCtl as fetch_ctl reads them
   uint32_t epoch = 0;        // finalize counter (mark / erase stamps are epoch + 1)
   uint32_t clear_floor = 0;  // stamps <= this were cleared (Chisel::CompressMeshes' chunksToUpdate.clear())
@@ -232,6 +237,8 @@ struct tf_volume {
 };
 
 namespace tf {
+// stream synchronisation + control blocks; VolCtl::n_tmp as read (may be NULL); sticky status -> error code
+int sync_status(tf_volume* v, uint32_t* n_tmp);
 int ensure_tmp(tf_volume* v, size_t bytes);
 int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hipStream_t s = nullptr);  // tf_capi.cpp
 int launch_prepare_unordered(tf_volume* v, const Pose& pose, hipStream_t s = nullptr);
