@@ -1960,27 +1960,48 @@ __device__ __forceinline__ bool dirty_candidate(const VolumeDev& v, const uint32
   // the neighbours across the slab face arrive with the boundary records
   return M > lim && part_owned(v, id.x, id.y, id.z);
 }
+// One thread per hash entry finds the marked chunks of the workgroup's 2048 entries; eight threads per MARKED chunk then
+// examine its candidates (the table is ~1 % marked: eight threads per entry spent 8.4 M threads on a 2^20-entry table).
+// Emitted ids collect in LDS and leave with one counter atomic per 1792+ of them.
+constexpr uint32_t kLdEntries = 2048;
 __global__ __launch_bounds__(256) void k_list_dirty(VolumeDev v, int4* out, uint32_t cap, uint32_t floor_) {
-  const uint32_t total = (v.hmask + 1u) * 8u;  // 8 threads per hash entry: candidate k = 0..6
-  const uint32_t first = blockIdx.x * (256u * kListPasses) + threadIdx.x;
-  uint32_t bits = 0;
-  int4 id;
-#pragma unroll
-  for (int k = 0; k < kListPasses; ++k)
-    if (dirty_candidate(v, first + (uint32_t)k * 256u, total, floor_, &id)) bits |= 1u << k;
-  uint32_t p = block_reserve(&v.vctl->n_tmp, (uint32_t)__popc(bits));
-  while (bits) {
-    const int k = __builtin_ctz(bits);
-    bits &= bits - 1;
-    const uint32_t t = first + (uint32_t)k * 256u;
-    if (p < cap) out[p] = nbr7(unpack_id(v.hent[t >> 3].key), (int)(t & 7u));
-    ++p;
+  __shared__ uint32_t s_ent[kLdEntries];
+  __shared__ int4 s_out[kLdEntries];
+  __shared__ uint32_t s_n, s_fill, s_base;
+  const uint32_t nent = v.hmask + 1u;
+  const uint32_t total = nent * 8u;
+  const uint32_t e0 = blockIdx.x * kLdEntries;
+  if (threadIdx.x == 0) { s_n = 0; s_fill = 0; }
+  __syncthreads();
+  for (uint32_t k = 0; k < kLdEntries / 256u; ++k) {
+    const uint32_t i = e0 + k * 256u + threadIdx.x;
+    if (i < nent) {
+      const HEntry h = v.hent[i];
+      if (h.key != kEmptyKey && h.slot != kInvalidSlot && v.mark_epoch[h.slot] > floor_) s_ent[atomicAdd(&s_n, 1u)] = i;
+    }
+  }
+  __syncthreads();
+  const uint32_t npair = s_n * 8u;
+  for (uint32_t r0 = 0; r0 <= npair; r0 += 256u) {  // (one round more than the pairs need: the last one only flushes)
+    const uint32_t idx = r0 + threadIdx.x;
+    int4 id = make_int4(0, 0, 0, 0);
+    if (idx < npair && dirty_candidate(v, (s_ent[idx >> 3] << 3) | (idx & 7u), total, floor_, &id)) s_out[atomicAdd(&s_fill, 1u)] = id;
+    __syncthreads();
+    const uint32_t fill = s_fill;
+    const bool last = r0 + 256u > npair;
+    __syncthreads();
+    if (fill && (last || fill + 256u > kLdEntries)) {  // (workgroup-uniform)
+      if (threadIdx.x == 0) { s_base = atomicAdd(&v.vctl->n_tmp, fill); s_fill = 0; }
+      __syncthreads();
+      for (uint32_t j = threadIdx.x; j < fill; j += 256u)
+        if (s_base + j < cap) out[s_base + j] = s_out[j];
+      __syncthreads();
+    }
   }
 }
 void launch_list_dirty(const VolumeDev& v, int4* out, uint32_t cap, uint32_t clear_floor, hipStream_t s) {
-  const uint32_t per = 256u * kListPasses;
-  const unsigned long long total = ((unsigned long long)v.hmask + 1ull) * 8ull;
-  hipLaunchKernelGGL(k_list_dirty, dim3((unsigned)((total + per - 1) / per)), dim3(256), 0, s, v, out, cap, clear_floor);
+  const unsigned long long nent = (unsigned long long)v.hmask + 1ull;
+  hipLaunchKernelGGL(k_list_dirty, dim3((unsigned)((nent + kLdEntries - 1) / kLdEntries)), dim3(256), 0, s, v, out, cap, clear_floor);
 }
 
 // De-interleave chunks into the reference's host layouts (sdf[512], weight[512], color[2048]).
