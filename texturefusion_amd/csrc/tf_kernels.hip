@@ -854,6 +854,18 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   const __amdgpu_buffer_rsrc_t rs_ctr = __builtin_amdgcn_make_buffer_rsrc((void*)&L.ctl->ka_next[kac * kKaCounterStride], 0, 4, 0x00020000);
   const int ctr_off = lane == 0 ? 0 : kOOB;
   uint32_t e_first = wave, e_second = wave + nwaves;
+  // TF_KA_DBG bits 15 / 16 (experiment): waves in odd hardware slots of a SIMD (bit 15) / of odd workgroups (bit 16) walk
+  // their entries LAST FIRST -- their cheap chunk (the back of the two-ended list) runs under the other waves' costly ones
+  // instead of every wave's costly chunk first and the latency-bound cheap ones together at the end
+  uint32_t e_step = nwaves;
+  if (!DYN && (kc.dbg & (32768u | 65536u))) {
+    const bool odd = (kc.dbg & 32768u) ? (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u) != 0u : (bid & 1u) != 0u;
+    if (odd && wave < n) {
+      e_first = wave + ((n - 1u - wave) / nwaves) * nwaves;
+      e_step = 0u - nwaves;
+      e_second = e_first + e_step;  // (wraps past zero behind the wave's first entry: the loop ends on e >= n)
+    }
+  }
   if (DYN) {
     uint32_t k0 = (uint32_t)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rs_ctr, ctr_off, 0, 0);
     k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);
@@ -924,7 +936,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     } else {
       // the next record of this wave travels while this chunk is processed (speculative: the slot
       // exists even when the index is past the list, it just holds an older frame's record)
-      e_next = e + nwaves;
+      e_next = e + e_step;
       const uint32_t en = e_next < n ? e_next : e;
       rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (FUSED ? list_phys(v, en, nf) : en)]);
     }
