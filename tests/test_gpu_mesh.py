@@ -59,6 +59,31 @@ def test_wall_meshes_match_oracle(gpu_required):
     gv.close()
 
 
+def test_compress_right_behind_update_reuses_its_list(gpu_required):
+    """tf_compress_meshes directly behind tf_update_meshes takes that call's device list (no second scan of the hash table);
+    with any call in between it scans again.  Same chunksToUpdate, same adjacency flags, and an empty set afterwards."""
+    cam = synth.Camera()
+    frames = [synth.wall_frame(1.1, cam, seed=10 + k) for k in range(4)]
+    fr = [(f[0], f[1], f[3]) for f in frames]
+    ov, ga = _run(fr, cam, RES5)
+    _, gb = _run(fr, cam, RES5)
+    ov.update_meshes()
+    na = ga.update_meshes()
+    ca = ga.compress_meshes()          # the list of the call before
+    nb = gb.update_meshes()
+    assert len(gb.dirty()) == nb == na  # (a call in between)
+    cb = gb.compress_meshes()          # scans again
+    oc = ov.compress_meshes()
+    assert np.array_equal(oc, ca) and np.array_equal(oc, cb) and len(oc) > 300
+    _compare_meshes(ov, ga, "compress behind update")
+    _compare_meshes(ov, gb, "compress after another call")
+    for g in (ga, gb):
+        assert len(g.dirty()) == 0
+        assert g.update_meshes() == 0 and len(g.compress_meshes()) == 0  # nothing marked: empty launches, empty list
+        assert len(g.compress_meshes()) == 0
+        g.close()
+
+
 def test_room_meshes_over_a_stream(gpu_required):
     """S-room orbit: re-meshing of dirty chunks after every few frames (meshes that lose all vertices stay in
     allMeshes, new ones enter), walls / floor / ceiling / corners, oblique views."""

@@ -133,6 +133,60 @@ def test_depth_only_and_deintegrate(gpu_required):
     assert_chunks_equal(ov, gv, ovalid, "de-integrated")
 
 
+def test_flags_changed_by_the_caller_between_calls(gpu_required):
+    """The library remembers which needsUpdate / isNew flags the device list holds and skips the upload when the caller hands
+    the same ones back; a caller that clears, sets or flips flags between calls must see exactly the reference's
+    `needsUpdateFlag[i] |= updated` on WHAT IT PASSED, and finalize must act on the flags it is given."""
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 16)
+    depth, rgba, quality, pose = synth.room_frame(20, cam)
+    oids, onew = ov.prepare(depth, pose)
+    gv.frame_upload(depth, rgba, quality)
+    gids, gnew = gv.prepare(pose)
+    assert np.array_equal(oids, gids) and np.array_equal(onew, gnew)
+    n = len(oids)
+    on, gn = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    ov.integrate(depth, rgba, quality, pose, oids, on, 1, 20)
+    gv.integrate(pose, gids, gn, 1, True, True)
+    assert np.array_equal(on, gn) and on.any()
+    rng = np.random.default_rng(7)
+    for k, mode in ((21, "same"), (22, "cleared"), (23, "random"), (24, "same"), (25, "ones")):
+        d2, _, _, p2 = synth.room_frame(k, cam)
+        if mode == "cleared":
+            on[:] = 0; gn[:] = 0
+        elif mode == "random":
+            r = rng.integers(0, 2, n).astype(np.uint8)
+            on[:] = r; gn[:] = r
+        elif mode == "ones":
+            on[:] = 1; gn[:] = 1
+        ov.integrate(d2, None, None, p2, oids, on, 1, -1)
+        gv.frame_upload(d2, None, None)
+        gv.integrate(p2, gids, gn, 1, False, False)
+        assert np.array_equal(on, gn), mode
+    assert_chunks_equal(ov, gv, oids, "flags changed between calls")
+    # finalize on flags the device has never seen: every second updated chunk dropped, isNew flipped on a few
+    on[::2] = 0; gn[::2] = 0
+    onew2, gnew2 = onew.copy(), gnew.copy()
+    onew2[1::5] ^= 1; gnew2[1::5] ^= 1
+    ovalid = ov.finalize(oids, on, onew2)
+    gvalid = gv.finalize(gids, gn, gnew2)
+    assert np.array_equal(ovalid, gvalid)
+    assert np.array_equal(sorted_ids(ov.list_chunks()), sorted_ids(gv.list_chunks()))
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+    # chunks removed WITH data (new, updated, but finalized as not updated: RemoveChunk) come back fresh when a later frame
+    # selects them again
+    removed = oids[(on == 0) & (onew2 == 1)]
+    assert len(removed) > 100 and not any(ov.has_chunk(c) for c in removed[:20])
+    for k in (26, 27):
+        d3, c3, q3, p3 = synth.room_frame(k, cam)
+        ids3, _, _ = _frame_flow(ov, gv, d3, c3, q3, p3, kf_id=k, use_quality=True)
+    assert [bool(gv.has_chunk(c)) for c in ids3] == [bool(ov.has_chunk(c)) for c in ids3]
+    assert_chunks_equal(ov, gv, np.array([c for c in ids3 if ov.has_chunk(c)], np.int32), "after removal with data")
+    back = [c for c in removed if ov.has_chunk(c)]
+    assert len(back) > 20
+    assert_chunks_equal(ov, gv, np.array(back, np.int32), "removed chunks that came back")
+    gv.close()
+
+
 def test_colour_saturation_cap(gpu_required):
     """Colour count never exceeds 120: 121 -> all four channels >> 2 (ProjectionIntegrator.cpp:281-287)."""
     ov, gv, cam, ig = make_pair(max_chunks=1 << 12)

@@ -1788,12 +1788,30 @@ __global__ __launch_bounds__(256) void k_finalize(VolumeDev v, uint32_t epoch) {
       }
     }
     __syncthreads();
-    // parked storage goes back to the fresh state: TSDF rows were never written (updated ==
-    // false), only colour rows can be (colour band hit with depth outside [near, far]).
+    // parked storage goes back to the fresh state.  In the reference's own flow TSDF rows of such a chunk were never
+    // written (updated == false), only colour rows can be (colour band hit with depth outside [near, far]).  A caller
+    // that hands in other flags than the calls before produced can remove a chunk WITH data (RemoveChunk erases chunk
+    // and mesh, ChunkManager.h:151-161): its summary word tells (every voxel writer ORs into it) -- then the TSDF plane
+    // is reset too and the chunk's mesh leaves allMeshes.
     const uint32_t nd = ndead;
     for (uint32_t k = 0; k < nd; ++k) {
-      uint4* c4 = reinterpret_cast<uint4*>(v.color + (size_t)dead[k] * kChunkVoxels);
+      const uint32_t ds = dead[k];
+      uint4* c4 = reinterpret_cast<uint4*>(v.color + (size_t)ds * kChunkVoxels);
       c4[threadIdx.x] = make_uint4(0, 0, 0, 0);
+      if (v.summ[ds] != 0u) {  // (workgroup-uniform)
+        const uint32_t f999 = __float_as_uint(999.0f);
+        uint4* t4 = reinterpret_cast<uint4*>(v.tsdf + (size_t)ds * kChunkVoxels);
+        t4[threadIdx.x] = make_uint4(f999, 0u, f999, 0u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < nd) {
+      const uint32_t ds = dead[threadIdx.x];
+      if (v.summ[ds] != 0u) {
+        v.summ[ds] = 0u;
+        MeshRec* r = &v.mesh_rec[ds];
+        if (r->state & kMsInMap) { r->state &= kMsOvfMask; r->nv = 0; r->nt = 0; }
+      }
     }
     __syncthreads();
   }
