@@ -54,3 +54,12 @@ def test_hot_kernels_stay_within_their_register_budget(src):
         for k, v in hits.items():
             assert v["ScratchSize"] <= max_scratch, "%s uses %d B/lane of private memory" % (k, v["ScratchSize"])
             assert v["VGPRs"] <= max_vgpr, "%s uses %d VGPRs (budget %d)" % (k, v["VGPRs"], max_vgpr)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_compile_time_experiments_still_build():
+    """The K-A experiments kept behind macros (four-slice steps, half-chunk work items: DESIGN.md s.9) must keep compiling."""
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
+           "-DTF_KA_SPLIT=1", "-c", os.path.join(CSRC, "tf_kernels.hip"), "-o", os.devnull]
+    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]

@@ -122,6 +122,7 @@ static int status_to_error(uint32_t st) {
   if (st & kStHashFull) m += " hash table full";
   if (st & kStMeshFull) m += " a mesh exceeds the per-chunk mesh block and the overflow pool is exhausted (raise tf_config.mesh_overflow_blocks or mesh_max_vertices / mesh_max_triangles)";
   if (st & kStAtlasFull) m += " No enough space for texture storage.";  // std::overflow_error text, Atlas.cpp:53
+  if (st & kStSplit) m += " internal: a chunk flagged for half-chunk work items was not alive or not inside the image";
   if (st & kStXchgFull) m += " a rank's ghost band did not fit the boundary exchange block (raise cap_records)";
   set_error(m);
   if (st & kStAtlasFull) return TF_ERR_ATLAS_FULL;
@@ -430,6 +431,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     if ((rc = dev_alloc(v, &L.list_rows, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.cen, (size_t)3 * kChunkVoxels))) return fail(rc);
     if ((rc = dev_alloc(v, &L.tiles, (size_t)kMaxTiles))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.split_list, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.ctl, (size_t)1))) return fail(rc);
   }
   if ((rc = init_device_state(v))) return fail(rc);
@@ -781,6 +783,7 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
       v->host_new.assign(is_new, is_new + n);
     }
     v->host_flags_n = n;
+    discard_primed(v);  // (GarbageCollect parks chunks: selections made ahead for a stream may name them as permanently alive)
     prof_begin(v, TF_PROF_FINALIZE);
     launch_finalize(v->dev, v->epoch++, v->stream);
     prof_end(v);

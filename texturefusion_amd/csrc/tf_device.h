@@ -32,6 +32,7 @@ constexpr uint32_t kStMissing = 8u;
 constexpr uint32_t kStHashFull = 16u;
 constexpr uint32_t kStMeshFull = 32u;   // a mesh exceeds tf_config.mesh_max_vertices / mesh_max_triangles
 constexpr uint32_t kStAtlasFull = 64u;
+constexpr uint32_t kStSplit = 256u;     // internal: a chunk flagged for half-chunk work items was not alive / not inside the image
 constexpr uint32_t kStXchgFull = 128u;  // a rank's ghost band did not fit the exchange block (raise cap_records)  // Atlas::AddPatch overflow (std::overflow_error, Atlas.cpp:52-53)
 
 struct Cam {
@@ -51,7 +52,7 @@ struct Pose {
 struct __attribute__((aligned(16))) HEntry {
   unsigned long long key;
   uint32_t slot;
-  uint32_t alive;
+  uint32_t alive;  // bit 0 alive, bit 1 touched since the last boundary exchange, bit 2 (TF_KA_SPLIT) updated at least once while alive
 };
 
 // Device-resident control block of one selection: everything one frame's kernels hand to the
@@ -70,7 +71,7 @@ struct FrameCtl {
   // its resident waves; with ~1.5 entries per wave the second entry of a wave is then a cheap one.  Lists of the
   // call-by-call flow are plain (n_front = n_list).
   uint32_t n_front;
-  uint32_t pad0;
+  uint32_t n_split;  // TF_KA_SPLIT: entries of SelBuf::split_list (zeroed with emit_pack)
   unsigned long long emit_pack;  // the selection role's append counters: low word front, high word back entries
   uint32_t pad[2];
   // multi-GPU, fused flow: selected chunks of this frame per ghost band -- [0] own down band (keys lo .. lo + a + b + c,
@@ -116,6 +117,7 @@ struct SelBuf {
   // Fused flow: per 16 x 16 pixel tile of the frame's depth image {key of the smallest depth > 0, key of the largest depth}
   // (ordered-uint keys, f2key).  Filled by the frame's K-B role, read by its selection role to mark chunks that provably
   // rewrite nothing (select_body: K-A then only does their bookkeeping), re-armed by the frame's K-A role.  [kMaxTiles]
+  uint32_t* split_list;       // [max_list] TF_KA_SPLIT: physical positions of the entries K-A walks as two half-chunk items
   uint2* tiles;
   FrameCtl* ctl;
 };

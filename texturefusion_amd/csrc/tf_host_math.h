@@ -27,6 +27,7 @@ struct SelectConsts {
   float resDiag;              // sqrt(3.0f) * resolution (ProjectionIntegrator.cpp:77)
   int prune;                  // fused flow: drop chunks whose depth tiles rule out any voxel write (select_body)
   int plain;                  // EMIT: append every entry from the front (a plain, unordered list: n_front = n_list)
+  int split;                  // TF_KA_SPLIT: flag the costly chunks that two waves may share (select_body)
 };
 
 inline SelectConsts make_select_consts(const float* p /*pose[12]*/, float res) {
@@ -36,6 +37,7 @@ inline SelectConsts make_select_consts(const float* p /*pose[12]*/, float res) {
   sc.resDiag = (float)(sqrt(3.0) * (double)res);
   sc.prune = 0;
   sc.plain = 0;
+  sc.split = 0;
   sc.id_factor = 1.0f / (8.0f * res);
   float diag = 8.0f * res / 2.0f;
   int step = 4;

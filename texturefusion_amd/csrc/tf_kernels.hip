@@ -37,9 +37,21 @@
 #define TF_SEL_PRUNE 0
 #endif
 
+// Half-chunk work items (compile-time experiment): costly chunks that project entirely inside the image
+// and are permanently alive (updated at least once: HEntry::alive bit 2) are walked by TWO waves, four z-slices each.  The
+// fused selection flags them (sign bit of the record's `upper`) and lists their records in SelBuf::split_list; K-A's items
+// are [0, n_split) = the upper halves, [n_split, n_split + n_list) = the list entries (a flagged entry = its lower half).
+#ifndef TF_KA_SPLIT
+#define TF_KA_SPLIT 0
+#endif
+#ifndef TF_KA_HALVES
+#define TF_KA_HALVES (TF_KA_SPLIT ? 1 : 0)  // K-A walks a chunk in two steps of four z-slices (experiment: profiles/r4/README.md)
+#endif
 #ifndef TF_KA_GP
 #define TF_KA_GP 2
 #endif
+static_assert(!(TF_KA_SPLIT && !TF_KA_HALVES), "half-chunk work items need the four-slice steps");
+static_assert(!(TF_KA_SPLIT && TF_SEL_PRUNE), "both experiments use the sign bit of the record's `upper`");
 #ifndef TF_KA_DYNAMIC
 #define TF_KA_DYNAMIC 0  // fused K-A: 1 = waves pull their list entries from 64 counters (measured slower, profiles/r3: off)
 #endif
@@ -134,6 +146,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl, uint2* tiles) {
     ctl->n_list = 0;
     ctl->n_front = 0;
     ctl->emit_pack = 0ull;
+    ctl->n_split = 0;
     for (int k = 0; k < 4; ++k) ctl->band_cnt[k] = 0u;
     for (int k = 0; k < kKaCounters; ++k) ctl->ka_next[k * kKaCounterStride] = 0u;
     if (vctl) {
@@ -193,7 +206,7 @@ void launch_pack_rgba(const uint8_t* rgb, const uint8_t* valid, uchar4* rgba, ui
 // and the largest depth (SelBuf::tiles; atomics on ordered keys, one pair per four adjacent float4 = one tile row).
 __device__ __forceinline__ void bbox_body(const float* __restrict__ depth, const Cam& cam, const Pose& P,
                                           FrameCtl* ctl, const uint32_t bid, const uint32_t nb, uint2* __restrict__ tiles = nullptr) {
-  if (bid == 0 && threadIdx.x == 0) { ctl->n_list = 0; ctl->n_front = 0; ctl->emit_pack = 0ull; }  // appended to by k_select<EMIT>
+  if (bid == 0 && threadIdx.x == 0) { ctl->n_list = 0; ctl->n_front = 0; ctl->emit_pack = 0ull; ctl->n_split = 0; }  // appended to by k_select<EMIT>
   if (bid == 0 && threadIdx.x < 4) ctl->band_cnt[threadIdx.x] = 0u;
   if (bid == 0 && threadIdx.x < kKaCounters) ctl->ka_next[threadIdx.x * kKaCounterStride] = 0u;  // K-A of this frame (two launches on) pulls its entries here
   float mn[3] = {1e8f, 1e8f, 1e8f}, mx[3] = {-1e8f, -1e8f, -1e8f};
@@ -380,6 +393,7 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
     const bool coarse_hit = __ballot(pr.hit && depthValid) != 0ull;
     unsigned long long m = 0ull;
     bool costly = false;
+    bool split = false;   // TF_KA_SPLIT: two waves may share this chunk
     bool pruned = false;  // flagged by the reference's test, but the depth tiles prove that no voxel of the chunk can be written
     if (coarse_hit) {
       bool flag = false;
@@ -411,7 +425,7 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
                               sc.fine[2][c], fdtp, fndtn);
           anyhit |= fr.hit;
           if (EMIT) { below |= fr.valid && (tr > fr.sd); above |= fr.valid && (fr.sd > fndtn + sc.diag); }  // the band without the chunk-diagonal margin
-          if (TF_SEL_PRUNE && EMIT) {
+          if ((TF_SEL_PRUNE || TF_KA_SPLIT) && EMIT) {
             umin = fminf(umin, fr.u); umax = fmaxf(umax, fr.u); wmin = fminf(wmin, fr.w); wmax = fmaxf(wmax, fr.w);
             zmin = fminf(zmin, fr.pz); zmax = fmaxf(zmax, fr.pz);
           }
@@ -470,6 +484,26 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
                    (k >= hi && k - hi <= band_w ? 8u : 0u);
           flag = flag && k >= lo && k < hi;
         }
+        if (TF_KA_SPLIT && EMIT && sc.split && flag && costly && sc.plain == 0) {
+          // Two waves may share the chunk if (a) every voxel projects inside the image -- the eight probes are the corners
+          // of a box around the voxel centres, so with all of them in front of the camera the chunk's pixels lie inside the
+          // bounding box of their projections; three pixels of margin cover K-A's + 0.5, its rounding and the last bits of
+          // its per-chunk origin -- so that no row can stall the chunk (ProjectionIntegrator.cpp:176-178), and (b) the chunk
+          // is alive and was updated at least once (HEntry::alive bits 0 and 2): such a chunk is never new, never parked
+          // by K-A, and tf_finalize -- the one other place that parks -- discards selections made ahead.  A stale read
+          // here can only say no.
+          if (zmin > 0.1f && umin >= 3.0f && umax <= (float)(cam.W - 4) && wmin >= 3.0f && wmax <= (float)(cam.H - 4)) {
+            const unsigned long long key = pack_id(x0 + di, y0 + dj, z0 + dk);
+            uint32_t i = hash_key(key) & v.hmask;
+            for (uint32_t pr2 = 0; pr2 < 64u; ++pr2) {
+              const uint4 en = *reinterpret_cast<const uint4*>(&v.hent[i]);  // {key lo, key hi, slot, alive}
+              const unsigned long long cur = ((unsigned long long)en.y << 32) | en.x;
+              if (cur == key) { split = (en.w & 5u) == 5u && en.z != kInvalidSlot; break; }
+              if (cur == kEmptyKey) break;
+              i = (i + 1) & v.hmask;
+            }
+          }
+        }
       }
       m = __ballot(flag);
       if (partitioned) {  // (wave-uniform; the four counts of FrameCtl::band_cnt)
@@ -506,7 +540,21 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         v.sel.list_pre[4 * pos] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
         // (a pruned entry stays in the list -- PrepareIntersectChunks creates its chunk and GarbageCollect parks it and takes
         // it out of meshesToUpdate again, which K-A's bookkeeping reproduces -- but K-A skips its voxels: sign bit of `upper`)
-        v.sel.list_pre[4 * pos + 1] = make_float4(pruned ? -cp.b.y : cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
+        v.sel.list_pre[4 * pos + 1] = make_float4((pruned || (TF_KA_SPLIT && split)) ? -cp.b.y : cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
+      }
+      if (TF_KA_SPLIT && (unsigned long long)basef + kf + baseb + kb <= (unsigned long long)v.max_list) {
+        const unsigned long long ms = __ballot(split && ((m >> lane) & 1ull));  // (split implies costly: a front position)
+        if (ms) {
+          uint32_t bs = 0;
+          if (lane == 0) bs = atomicAdd(&ctl->n_split, (uint32_t)__popcll(ms));
+          bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs);
+          if ((ms >> lane) & 1ull) {
+            const uint32_t pos = basef + (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
+            v.sel.split_list[bs + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull))] = pos;
+            v.sel.list_needs[pos] = 0;  // the two halves OR their outcome in
+            v.sel.list_pre[4 * pos + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // .x: the upper half's row counts
+          }
+        }
       }
     }
   }
@@ -819,6 +867,17 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     if (!n) nf = 0;
     if (bid == 0 && threadIdx.x == 0) { L.ctl->n_list = n; L.ctl->n_front = nf; }  // for the stages behind this launch
   }
+  // TF_KA_SPLIT: items [0, ns) are the upper halves of the flagged entries, items [ns, ns + n) the entries themselves
+  constexpr bool SPLIT = FUSED && (TF_KA_SPLIT != 0);
+  uint32_t ns = 0;
+  if (SPLIT) { ns = L.ctl->n_split; if (ns > n) ns = 0u; }
+  const uint32_t n_items = n + ns;
+  // where an item's record (and its outputs) live
+  auto item_pos = [&](const uint32_t it) -> uint32_t {
+    if (SPLIT && it < ns) return *(const __attribute__((address_space(4))) uint32_t*)(unsigned long long)(&L.split_list[it]);
+    const uint32_t e = SPLIT ? it - ns : it;
+    return FUSED ? list_phys(v, e, nf) : e;
+  };
   const int vy = lane >> 3;
   const int W = cam.W, H = cam.H;
   if (TF_SEL_PRUNE && FUSED) {
@@ -860,8 +919,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   uint32_t e_step = nwaves;
   if (!DYN && (kc.dbg & (32768u | 65536u))) {
     const bool odd = (kc.dbg & 32768u) ? (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u) != 0u : (bid & 1u) != 0u;
-    if (odd && wave < n) {
-      e_first = wave + ((n - 1u - wave) / nwaves) * nwaves;
+    if (odd && wave < n_items) {
+      e_first = wave + ((n_items - 1u - wave) / nwaves) * nwaves;
       e_step = 0u - nwaves;
       e_second = e_first + e_step;  // (wraps past zero behind the wave's first entry: the loop ends on e >= n)
     }
@@ -876,8 +935,9 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   // table is copied (64-B records {o.xyz, wD | upper, id.xyz | spare}; the slot exists for any index)
   u32x8 rec_next;
   {
-    const uint32_t e0 = e_first < n ? e_first : 0u;
-    rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (e0 < v.max_list ? (FUSED ? list_phys(v, e0, nf) : e0) : 0u)]);
+    const uint32_t e0 = e_first < n_items ? e_first : 0u;
+    const uint32_t p0 = n_items ? item_pos(e0) : 0u;
+    rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (p0 < v.max_list ? p0 : 0u)]);
   }
 
   // centroid table (Chisel.cpp:52-110), computed once per frame ahead of this launch; copied into
@@ -923,12 +983,13 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   // static scheme: e_next = e + nwaves, its record requested at the top of the iteration.  dynamic scheme: the wave
   // holds ONE entry (with ~1.5 entries per wave anything a wave parks in advance is work another wave could have
   // started); the next index is pulled at the top of the iteration, and its record is read at the top of the next one
-  for (uint32_t e = e_first, e_next = e_second; e < n; e = e_next) {
-    const uint32_t pe = FUSED ? list_phys(v, e, nf) : e;  // where the entry's record and outputs live
+  for (uint32_t e = e_first, e_next = e_second; e < n_items; e = e_next) {
+    const uint32_t pe = item_pos(e);  // where the entry's record and outputs live
+    int half = (SPLIT && e < ns) ? 2 : 0;  // 0 = the whole chunk, 1 = its lower four z-slices, 2 = its upper four
     // The list entry (per-chunk scalars + id) was written by the previous launch, so it is read
     // through the scalar cache: one 64-B record, one s_load, one wait, off the vector-memory queue
     // of the CU (a vector load here would wait behind every gather of the other waves).
-    if (DYN && e != e_first) rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * list_phys(v, e, nf)]);
+    if (DYN && e != e_first) rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * pe]);
     const u32x8 prw = rec_next;
     uint32_t pull = 0;  // dynamic scheme: the next index, in flight until the end of the iteration
     if (DYN) {
@@ -937,14 +998,14 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       // the next record of this wave travels while this chunk is processed (speculative: the slot
       // exists even when the index is past the list, it just holds an older frame's record)
       e_next = e + e_step;
-      const uint32_t en = e_next < n ? e_next : e;
-      rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * (FUSED ? list_phys(v, en, nf) : en)]);
+      const uint32_t en = e_next < n_items ? e_next : e;
+      rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * item_pos(en)]);
     }
     auto advance = [&]() { if (DYN) e_next = (uint32_t)kKaCounters * (uint32_t)__builtin_amdgcn_readfirstlane((int)pull) + kac; };
     const int4 id = make_int4((int)prw[5], (int)prw[6], (int)prw[7], 0);
     const bool owned = part_owned(v, id.x, id.y, id.z);
     if (!owned) {
-      if (FUSED && lane == 0) {
+      if (FUSED && lane == 0 && half != 2) {
         L.list_slot[pe] = kInvalidSlot; L.list_ent[pe] = 0; L.list_new[pe] = 0; L.list_needs[pe] = 0;
         L.list_quality[pe] = 0.0f; L.list_rows[pe] = 0;
       }
@@ -972,7 +1033,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     // (fused lists: a negative `upper` marks an entry whose depth tiles rule out any voxel write -- select_body --: the
     // wave does the chunk's bookkeeping, creation / parking / meshesToUpdate, and none of its 512 voxels)
     const bool pruned = TF_SEL_PRUNE && FUSED && (prw[4] >> 31) != 0u;
-    const float upper = (TF_SEL_PRUNE && FUSED) ? fabsf(pby) : pby;
+    const float upper = ((TF_SEL_PRUNE || TF_KA_SPLIT) && FUSED) ? fabsf(pby) : pby;
+    if (SPLIT && half == 0 && (prw[4] >> 31) != 0u) half = 1;  // a flagged entry: another wave has its upper half
     // every voxel centre of the chunk is o + c with 0 < c < 16 * res * sqrt(3): if |o.z| clears that
     // band, p.z is far inside the normal exponent range; numerators o + c are exact zeros or at
     // least one ulp of c (> 2^-40), and |o| < 2^20 keeps quotients finite -> no scaling / fix-up
@@ -985,6 +1047,277 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       v.phase_buf[wave * 16 + 15] = __builtin_amdgcn_s_memrealtime();  // timeline aid: first entry loaded
     }
 
+#if TF_KA_HALVES
+    const int h_begin = half == 2 ? 1 : 0, h_end = half == 1 ? 1 : 2;
+    bool perm = false;  // the home entry says: alive and updated before (HEntry::alive bit 2)
+    // ---- TF_KA_HALVES: the chunk in steps of FOUR z-slices (step h covers slices 4h .. 4h + 3): geometry, gathers and
+    // RMW passes of a step, then the next -- four slices' offsets and depths live at a time instead of eight, and a step
+    // is the unit a second wave could take (the half-chunk work item of VERDICT r3 item 4).  Row order is kept: a row with
+    // no valid lane in step 0 ends the chunk before step 1 starts (R), the quality sum runs on through both steps.
+    constexpr int NJ = 4;
+    int oob_any = 0;
+    uint32_t R = 64;
+    bool lazy_revive = false;
+    bool resolved = false, no_slot = false;
+    float qsum = 0.0f;
+    uint32_t lanes_t = 0, lanes_c = 0;  // lanes of rewritten rows (8 per row), wave-uniform
+    // classes of the voxels written (VolumeDev::summ), reduced row by row into ONE scalar word: the kernel has no
+    // VGPR to spare for per-lane classes and no SGPRs for four lane masks
+    uint32_t sword = 0;
+    unsigned long long m_ok = 0, m_pos = 0, m_neg = 0, m_hvy = 0;
+#pragma nounroll
+    for (int h = h_begin; h < h_end; ++h) {
+    const int jb = h * NJ;
+    if ((uint32_t)(jb * 8) >= R) break;  // a stalled row in the step before ends the chunk
+    // ---- phase 1: geometry of the step's z-slices.  Rows run in order until the first row with no
+    // valid lane -- the reference's `continue` skips `pos++` (:176-178, :420), so that row and
+    // every later row of the chunk is dead: R = number of processed rows.
+    int off_d[NJ];            // image byte offset of the lane's pixel, kOOB when the gather is masked
+    int oobl[QUALITY ? NJ : 1];
+    unsigned long long all_valid = ~0ull;
+    uint32_t oob_bits = 0;  // bit j: the lane's pixel of slice jb + j is off the image
+    auto geometry = [&](auto safe_tag) {
+      constexpr bool SAFE = decltype(safe_tag)::value;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int k = (jb + j) * 64 + lane;
+        // x and y run as the two halves of packed-f32 instructions (each half rounded on its own)
+        const f32x2 pxy = o01 + (f32x2){cenT[0][k], cenT[1][k]};
+        const float pzv = o2 + cenT[2][k];
+        // px / pz and py / pz (:155-164), correctly rounded; fast path when every lane is in range
+        f32x2 q;
+        if (SAFE) {
+          q = div2_by(pxy, recip_refined(pzv));
+        } else {
+          q.x = pxy.x / pzv;
+          q.y = pxy.y / pzv;
+        }
+        const f32x2 uw = q * fxy + cxy;
+        // in the SAFE range no quotient is NaN, so v_cvt's own saturation classifies like x86's
+        const int X = SAFE ? cvt_rne_hw(uw.x) : cvt_sat_rne(uw.x);
+        const int Y = SAFE ? cvt_rne_hw(uw.y) : cvt_sat_rne(uw.y);
+        // 0 < X < W-1 and 0 < Y < H-1 (:167-173) as two unsigned range tests
+        const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
+        all_valid &= ballot(valid);
+        int od = (__mul24(Y, W) + X) * 4;  // valid => 0 < Y < H, exact in 24 bits
+        asm volatile("" : "+v"(od));       // keep the select a v_cndmask (no exec-mask branch)
+        off_d[j] = valid ? od : kOOB;
+        // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220); implies !valid
+        if (COLOR) oob_bits |= (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1))) ? (1u << j) : 0u;
+      }
+    };
+    if (pruned) {
+      R = 0;  // no row is processed: the passes below end at once
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) off_d[j] = kOOB;
+    } else if (div_safe) geometry(std::true_type{});
+    else geometry(std::false_type{});
+    if (QUALITY) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) oobl[j] = 0;
+    }
+    if (all_valid != ~0ull) {  // steps that project entirely inside the image skip all of this
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if (R == 64u) {
+          const unsigned long long vmj = ballot(off_d[j] != kOOB);  // (off_d[j] == kOOB <=> !valid at this point)
+          const unsigned long long dead = nonzero_bytes(vmj) ^ 0x0101010101010101ull;
+          if (dead) R = (uint32_t)((jb + j) * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
+        }
+        const bool live_lane = (uint32_t)((jb + j) * 8 + vy) < R;
+        if (COLOR) {  // off-image lanes of processed rows only
+          const bool oob = live_lane && ((oob_bits >> j) & 1u);
+          oob_any |= oob ? 1 : 0;
+          if (QUALITY) oobl[j] = oob ? 1 : 0;
+        }
+        off_d[j] = live_lane ? off_d[j] : kOOB;
+      }
+    }
+
+    // ---- phase 2: depth gathers (masked lanes read 0, like the reference's masked gather)
+    float dep[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+      dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j], 0, 0));
+
+    // ---- resolve the slot once (first step).  Fast path: the home entry holds the key.  A parked chunk (alive
+    // == 0: created by an earlier frame, never updated, garbage-collected) counts as new again; it is
+    // revived only if this frame updates it, so the usual "selected, outside the band, parked again"
+    // round trip of the chunks in front of the surface costs no hash traffic at all.
+    if (!resolved) {
+      resolved = true;
+      if (FUSED) {
+        if ((((unsigned long long)h0.y << 32) | h0.x) == key && h0.z != kInvalidSlot) {
+          slot = h0.z;
+          is_new = lazy_revive = (h0.w == 0u);
+          perm = (h0.w & 4u) != 0u;
+        } else {
+          uint32_t s0 = kInvalidSlot, nw = 1, en = 0;
+          if (lane == 0) {
+            bool bnew = true;
+            s0 = chunk_acquire(v, id, &bnew, &en);
+            nw = bnew ? 1u : 0u;
+          }
+          slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0);
+          is_new = __builtin_amdgcn_readfirstlane((int)nw) != 0;
+          ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)en);
+        }
+      }
+      if (SPLIT && half != 0 && (is_new || all_valid != ~0ull)) {  // cannot happen (select_body); loud if it does
+        if (lane == 0) atomicOr(&v.vctl->status, kStSplit);
+        slot = kInvalidSlot;
+      }
+      if (slot == kInvalidSlot) { no_slot = true; break; }
+    }
+    const __amdgpu_buffer_rsrc_t rs_T =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_C =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+
+#pragma unroll
+    for (int p = 0; p < NJ / GP; ++p) {
+      const int g0 = p * GP;
+      if ((uint32_t)((jb + g0) * 8) >= R) break;  // a stalled row ends the chunk
+      // ---- phase 3: predicates -> offsets
+      float nwv[GP], sd[GP];
+      int off_t[GP], off_c[GP], off_i[GP];
+      unsigned long long any = 0ull;
+#pragma unroll
+      for (int j = 0; j < GP; ++j) {
+        const int gj = g0 + j;
+        const int kb = ((jb + gj) * 64 + lane) * 8;
+        const float d = dep[gj];
+        const float s = d - (o2 + cenT[2][(jb + gj) * 64 + lane]);  // p.z again: an LDS read is cheaper than live VGPRs
+        sd[j] = s;
+        if (COLOR) {
+          const bool upd = (off_d[gj] != kOOB) && (fabsf(s) < c_thr);  // -thr < sd < thr (:202-208)
+          off_i[j] = upd ? off_d[gj] : kOOB;
+          const bool ru_l = row_any(ballot(upd));
+          const unsigned long long ru = ballot(ru_l);
+          off_c[j] = ru_l ? kb : kOOB;
+          lanes_c += (uint32_t)__popcll(ru);
+          any |= ru;
+        }
+        const bool act = (uint32_t)((jb + gj) * 8 + vy) < R;
+        const bool dv = (d > c_near) && (c_far > d);           // (:310-312)
+        const bool inside = (s > c_lower) && (upper > s);      // (:313-316)
+        const bool F = act && dv && inside;
+        nwv[j] = F ? wD : 0.0f;
+        const bool rf_l = row_any(ballot(F));
+        const unsigned long long rf = ballot(rf_l);
+        off_t[j] = rf_l ? kb : kOOB;
+        lanes_t += (uint32_t)__popcll(rf);
+        any |= rf;
+      }
+      // nothing of this pass is rewritten (chunk outside the band, or a hole): skip the RMW
+      // phases for the whole wave -- about a third of the selected chunks never update a row
+      const bool rmw = (any != 0ull) || (COLOR && QUALITY);
+      // ---- phase 4: voxel rows that will be rewritten + their inputs
+      u32x2 t[GP], c[GP];
+      uint32_t in[GP];
+      float qv[GP];
+      if (rmw) {
+#pragma unroll
+        for (int j = 0; j < GP; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, off_t[j], 0, 0);
+        if (COLOR) {
+#pragma unroll
+          for (int j = 0; j < GP; ++j) {
+            c[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_C, off_c[j], 0, 0);
+            in[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[j], 0, 0);
+            if (QUALITY) qv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qual, off_i[j], 0, 0));
+          }
+        }
+      }
+      // ---- phase 5a: arithmetic on the loaded rows
+      if (rmw) {
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+          if (COLOR) {
+            // colour planes are 4 x u16 {r, g, b, count} per voxel = two packed-u16 dwords; the
+            // image pixel is widened with two byte permutes ({r, g} and {b, a} as u16 pairs)
+            // (__builtin_bit_cast needs plain scalars: applied to a vector element it reads element 0)
+            const uint32_t p_rg = __builtin_amdgcn_perm(0u, in[j], 0x0c010c00u);
+            const uint32_t p_ba = __builtin_amdgcn_perm(0u, in[j], 0x0c030c02u);
+            const uint32_t w_rg = c[j].x, w_ba = c[j].y;
+            const u16x2 in_rg = __builtin_bit_cast(u16x2, p_rg), in_ba = __builtin_bit_cast(u16x2, p_ba);
+            u16x2 c_rg = __builtin_bit_cast(u16x2, w_rg), c_ba = __builtin_bit_cast(u16x2, w_ba);
+            if (FLAG) {  // (:274-292)
+              c_rg += in_rg;
+              c_ba += in_ba;
+              // (short)count > 120  <=>  the dword, read as signed, is >= 121 << 16
+              const bool halve = (int)__builtin_bit_cast(uint32_t, c_ba) >= (121 << 16);
+              const u16x2 h_rg = c_rg >> (unsigned short)2, h_ba = c_ba >> (unsigned short)2;
+              c_rg = halve ? h_rg : c_rg;
+              c_ba = halve ? h_ba : c_ba;
+            } else {     // (:293-304)
+              c_rg -= in_rg;
+              c_ba -= in_ba;
+            }
+            c[j].x = __builtin_bit_cast(uint32_t, c_rg);
+            c[j].y = __builtin_bit_cast(uint32_t, c_ba);
+          }
+          const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);  // (:319-341)
+          const float nw = nwv[j];
+          const float num = ts * tw + sd[j] * nw;
+          const float den = (tw + nw) + c_sigma;
+          const float ns = num / den;
+          const float nwt = tw + nw;
+          const bool keep = nwt > 0.5f;
+          t[j].x = __float_as_uint(keep ? ns : 999.0f);
+          t[j].y = __float_as_uint(keep ? nwt : 0.0f);
+          // (a row that is not rewritten was loaded as zeros and comes out as {999, 0}: class 0)
+        }
+      }
+      // ---- phase 5b: write back the rewritten rows only (masked offsets drop the store)
+      if (rmw) {
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+          if (COLOR) __builtin_amdgcn_raw_buffer_store_b64(c[j], rs_C, off_c[j], 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, off_t[j], 0, 0);
+          if (!(kc.dbg & kKaCoarseSumm)) {  // lane = x + 8 y of row z = jb + g0 + j
+            const float fs = __uint_as_float(t[j].x), fw = __uint_as_float(t[j].y);
+            const unsigned long long b_ok = ballot(!(fs > 1.0f)), b_pos = ballot(fs > 0.0f) & b_ok;
+            const unsigned long long b_neg = ballot(fs < 0.0f), b_hvy = ballot(fw > 50.0f);
+            m_ok |= b_ok; m_pos |= b_pos; m_neg |= b_neg; m_hvy |= b_hvy;
+            if (jb + g0 + j == 0)
+              sword = (b_ok ? 0x1000u : 0u) | (b_pos ? 0x2000u : 0u) | (b_neg ? 0x4000u : 0u) | (b_hvy ? 0x8000u : 0u);
+          }
+        }
+      }
+      // ---- phase 6: observationQualitySum bookkeeping in row order (:212-238)
+      if (COLOR && QUALITY) {
+        const int rowshift = lane & 56;
+#pragma unroll
+        for (int j = 0; j < GP; ++j) {
+          const int gj = g0 + j;
+          const unsigned long long mu = ballot(off_i[j] != kOOB);
+          const unsigned long long mo = ballot(oobl[gj] != 0);
+          if ((mu | mo) == 0ull) continue;
+          float rowsum = 0.0f;
+          if (mu) {  // sum += observationQuality[i], i = 0..7 (:233-236)
+#pragma unroll
+            for (int l = 0; l < 8; ++l) rowsum += __shfl(qv[j], rowshift + l);
+          }
+          const int left = (int)R - (jb + gj) * 8;
+          const int rmax = left < 8 ? left : 8;
+          for (int r = 0; r < rmax; ++r) {
+            if ((mo >> (8 * r)) & 0xFFull) qsum = kc.qoob;
+            if ((mu >> (8 * r)) & 0xFFull)
+              qsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowsum), 8 * r));
+          }
+        }
+      }
+    }
+    }  // steps
+    if (no_slot) {
+      if (FUSED && lane == 0 && half != 2) {
+        L.list_slot[pe] = kInvalidSlot; L.list_ent[pe] = 0; L.list_new[pe] = 0; L.list_needs[pe] = 0;
+        L.list_quality[pe] = 0.0f; L.list_rows[pe] = 0;
+      }
+      advance();
+      continue;
+    }
+#else
     // ---- phase 1: geometry of the 8 z-slices.  Rows run in order until the first row with no
     // valid lane -- the reference's `continue` skips `pos++` (:176-178, :420), so that row and
     // every later row of the chunk is dead: R = number of processed rows.
@@ -1250,6 +1583,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         }
       }
     }
+#endif
     const uint32_t rows_t = lanes_t >> 3, rows_c = COLOR ? (lanes_c >> 3) : 0u;
     const bool updated = rows_t != 0;
     if (updated) {  // the classes of what was written join the chunk's summary: lane = x + 8 y of a row
@@ -1275,10 +1609,17 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 
     // multi-GPU: remember that this slab-face chunk changed since the last boundary exchange
     const bool face = part_band(v, id.x, id.y, id.z);
+#if TF_KA_SPLIT
+    if (updated && lane == 0 && (face || lazy_revive || (FUSED && !perm))) {
+      const uint32_t en = FUSED ? ent : L.list_ent[pe];
+      v.hent[en].alive = (face ? 3u : 1u) | (FUSED ? 4u : 0u);  // bit0 alive, bit1 touched, bit2 updated at least once
+    }
+#else
     if (updated && lane == 0 && (face || lazy_revive)) {
       const uint32_t en = FUSED ? ent : L.list_ent[pe];
       v.hent[en].alive = face ? 3u : 1u;  // bit0 alive, bit1 touched
     }
+#endif
     if (FUSED) {
       // FinalizeIntegrateChunks (Chisel.h:192-208) + GarbageCollect (:472-477) for this entry
       // (erase_epoch == mark_epoch + max_chunks, one allocation: both stores go through ONE pointer member.  With
@@ -1327,9 +1668,18 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         }
       }
       if (lane == 0) {  // what later stages read of a fused frame: slot, needsUpdate, row counts
-        L.list_slot[pe] = slot;
-        L.list_needs[pe] = updated ? 1 : 0;
-        L.list_rows[pe] = (uint16_t)(rows_t | (rows_c << 8));
+        if (!SPLIT || half == 0) {
+          L.list_slot[pe] = slot;
+          L.list_needs[pe] = updated ? 1 : 0;
+          L.list_rows[pe] = (uint16_t)(rows_t | (rows_c << 8));
+        } else if (half == 1) {  // (the selection cleared needsUpdate: the halves OR their outcome in)
+          L.list_slot[pe] = slot;
+          if (updated) L.list_needs[pe] = 1;
+          L.list_rows[pe] = (uint16_t)(rows_t | (rows_c << 8));
+        } else {
+          if (updated) L.list_needs[pe] = 1;
+          reinterpret_cast<uint32_t*>(&L.list_pre[4 * pe + 2])[0] = rows_t | (rows_c << 8);
+        }
       }
     } else if (lane == 0) {
       if (updated) L.list_needs[pe] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
@@ -1720,6 +2070,8 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
     a.depth1 = next->img.depth;
     a.sc1 = make_select_consts(next->pose.p, res);
     a.sc1.prune = prune ? 1 : 0;  // (that frame's K-B role -- one launch ago -- filled its depth tiles)
+    static const int split_env = env_int("TF_KA_SPLIT", 1);  // (A/B knob of the compile-time experiment)
+    a.sc1.split = (TF_KA_SPLIT && split_env) ? 1 : 0;
     a.n_sel = 1u;  // (sized below, once the dispatch order is known)
   }
   a.tiles2 = nullptr;
@@ -1833,7 +2185,13 @@ __global__ __launch_bounds__(256) void k_rowstats(VolumeDev v, unsigned long lon
     rt += r & 0xFFu;
     rc += r >> 8;
     nu += L.list_needs[i] ? 1 : 0;
-    np += (__float_as_uint(L.list_pre[4 * i + 1].x) >> 31) ? 1 : 0;  // entries the depth tiles ruled out (fused lists)
+    const bool flagged = (__float_as_uint(L.list_pre[4 * i + 1].x) >> 31) != 0u;
+    np += flagged ? 1 : 0;  // entries the depth tiles ruled out (TF_SEL_PRUNE) / entries walked as two halves (TF_KA_SPLIT)
+    if (TF_KA_SPLIT && flagged) {  // the upper half's rows
+      const uint32_t r2 = __float_as_uint(L.list_pre[4 * i + 2].x);
+      rt += r2 & 0xFFu;
+      rc += (r2 >> 8) & 0xFFu;
+    }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
@@ -2132,7 +2490,7 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
       // already has it receives an identical or newer copy).
       const bool fit_down = down && p < cap, fit_up = up && q < cap_up;
       if (!fit_down && !fit_up) continue;
-      if (lane == src && (fit_down || !down) && (fit_up || !up)) v.hent[i].alive = h.alive & 1u;
+      if (lane == src && (fit_down || !down) && (fit_up || !up)) v.hent[i].alive = h.alive & 5u;
       hd.w = (int)v.mark_epoch[slot];  // header: id + the epoch of the chunk's last update (Chisel::meshesToUpdate travels with it)
       const uint4* st = reinterpret_cast<const uint4*>(v.tsdf + (size_t)slot * kChunkVoxels);
       const uint4* sc = reinterpret_cast<const uint4*>(v.color + (size_t)slot * kChunkVoxels);
