@@ -15,6 +15,7 @@ Frame windows (ORBIT = 200 frames = one turn of the camera; every window starts 
   warm-up    W frames through the timed entry point
   timed      K frames -> "value", "ms_per_step" (wall clock, barrier + device synchronisation on both sides)
   resident   the same K orbit positions one turn later, frames already in HBM (no H2D) -> "resident"
+  rgb host   the same positions as host frames with Frame::rgb (3 B per pixel) instead of the RGBA staging image -> "rgb_host_frames"
   events     the same positions again with HIP events around every launch -> per-kernel times
   replay     the same positions again, frame by frame, reading back the exact integer counts -> algorithmic bytes
 A rocprofv3 --kernel-trace child pass and two --pmc child passes of the same command (same pre-roll / warm-up /
@@ -453,6 +454,40 @@ def main():
                     "note": "tf_stream_frames_textured_device on the same %d orbit positions one turn later: images "
                             "already in HBM, no H2D, one call for all frames" % K}
 
+    # ---- the same positions as HOST frames with the colour image as the caller holds it (Frame::rgb, 3 B per pixel) ----
+    rgb_host = None
+    if use_host and not multi:
+        try:
+            h_rgb = [np.ascontiguousarray(h_rgba[k][..., :3]) for k in range(n_unique)]
+            all_valid = all(bool(h_rgba[k][..., 3].all()) for k in range(n_unique))
+            h_valid = None if all_valid else [np.ascontiguousarray(h_rgba[k][..., 3]) for k in range(n_unique)]
+
+            def run_host_rgb(first, count):
+                for j in range(count):
+                    i = (first + j) % n_unique
+                    vol.integrate_frame_host_rgb(h_depth[i], h_rgb[i], None if h_valid is None else h_valid[i], poses[i],
+                                                 pinv[i] if textured else None, first + j)
+
+            nxt = pos + ((p0 - Wm - pos) % ORBIT)
+            if nxt > pos:
+                run(pos, nxt - pos)
+            pos = nxt
+            run_host_rgb(pos, Wm)
+            barrier()
+            t1 = time.perf_counter()
+            run_host_rgb(pos + Wm, K)
+            barrier()
+            dt_rgb = time.perf_counter() - t1
+            vol.sync()
+            pos += Wm + K
+            rgb_host = {"value": K / dt_rgb, "unit": "frames/s", "ms_per_step": 1e3 * dt_rgb / K,
+                        "bytes_uploaded_per_frame": cam.width * cam.height * (7 if h_valid is None else 8),
+                        "note": "tf_integrate_frame_host_rgb on the same %d orbit positions: depth + Frame::rgb (3 B per pixel%s) "
+                                "as the reference's caller holds them; its RGBA staging loop (MobileFusion.cpp:232-243) runs on "
+                                "the device behind the upload" % (K, "" if h_valid is None else " + colorValidFlag")}
+        except Exception as e:  # (a side figure: never fail the bench line for it)
+            rgb_host = {"error": repr(e)[:300]}
+
     # ---- the same positions again: HIP events (on the handle's stream) around every launch of a step --------
     prof = None
     dt_instr = None
@@ -514,6 +549,8 @@ def main():
         out["repeats"] = repeats
     if resident is not None:
         out["resident"] = resident
+    if rgb_host is not None:
+        out["rgb_host_frames"] = rgb_host
     if per_rank is not None:
         out["per_rank"] = per_rank
 

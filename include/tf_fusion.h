@@ -302,6 +302,13 @@ TF_API int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int6
  * depth / RGBA images there (and passes these pointers) saves the staging copy. */
 TF_API int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgba, const float pose[12],
                                    const float* pose_inv16, int32_t frame_id);
+/* The same with the colour image as the caller holds it: rgb = u8[H][W][3] (Frame::rgb) and color_valid = u8[H][W]
+ * (Frame::colorValidFlag) or NULL (every pixel valid) -- the inputs of the RGBA staging loops the reference runs on the CPU
+ * before it calls the path (MobileFusion::IntegrateFrame, GCFusion/MobileFusion.cpp:232-243: alpha = 1 everywhere;
+ * :144-163: alpha = colorValid > 0).  7 (or 8) bytes per pixel travel instead of 8 and the loop runs on the device behind
+ * the upload.  With tf_host_frame_buffers: rgb at the `rgba` pointer, the flags 3 * W * H bytes behind it. */
+TF_API int tf_integrate_frame_host_rgb(tf_volume* v, const float* depth, const uint8_t* rgb, const uint8_t* color_valid,
+                                       const float pose[12], const float* pose_inv16, int32_t frame_id);
 TF_API int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba);
 TF_API int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_slots);
 /* The texturing half of the per-frame unit on its own, for the frame integrated last (its images still bound):

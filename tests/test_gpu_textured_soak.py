@@ -20,7 +20,13 @@ def _run(cam, res, frames, host_frames=False, max_chunks=1 << 17, stride=1):
     for k, f in enumerate(frames):
         ov.frame_textured(oa, f[0], f[1], f[3], pinv[k], 10 + k)
     bufs = []
-    if host_frames:
+    if host_frames == "rgb":  # Frame::rgb + Frame::colorValidFlag (or none) as the caller holds them; packed on the device
+        for k, f in enumerate(frames):
+            valid = np.ascontiguousarray(f[1][..., 3])
+            rgb = np.ascontiguousarray(f[1][..., :3]).copy()
+            rgb[valid == 0] = 77  # (whatever the camera delivered where the flag says invalid)
+            gv.integrate_frame_host_rgb(f[0], rgb, None if valid.all() else valid, f[3].reshape(12), pinv[k], 10 + k)
+    elif host_frames:
         for k, f in enumerate(frames):
             gv.integrate_frame_host(f[0], f[1], f[3].reshape(12), pinv[k], 10 + k)
     else:
@@ -82,6 +88,22 @@ def test_host_frames_entry_point(gpu_required):
     cam = synth.Camera()
     frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(10)]
     assert _run(cam, np.float32(0.005), frames, host_frames=True, stride=3) > 400
+
+
+def test_host_frames_as_rgb_and_valid_flags(gpu_required):
+    """tf_integrate_frame_host_rgb: the caller's RGBA staging loops (MobileFusion.cpp:144-163, :232-243) on the device --
+    once with every pixel valid (no flags: alpha = 1 everywhere), once with flagged-out regions (rgba = 0 there)"""
+    cam = synth.Camera()
+    frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(10)]
+    assert all(f[1][..., 3].all() for f in frames)
+    assert _run(cam, np.float32(0.005), frames, host_frames="rgb", stride=3) > 400
+    holes = []
+    for k, f in enumerate(frames):
+        rgba = f[1].copy()
+        rgba[40 + 7 * k:200, 100:300 + 11 * k] = 0   # colorValidFlag == 0: the staging loop zeroes all four bytes
+        rgba[::5, ::3] = 0
+        holes.append((f[0], rgba, f[2], f[3]))
+    assert _run(cam, np.float32(0.005), holes, host_frames="rgb", stride=3) > 400
 
 
 def test_hall_1280x960(gpu_required):

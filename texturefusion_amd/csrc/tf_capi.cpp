@@ -1159,7 +1159,7 @@ static int host_ring_prepare(tf_volume* v) {
     if (s.d) hipFree(s.d);
     s.h = nullptr; s.d = nullptr;
     TF_HIP(hipHostMalloc((void**)&s.h, npix * 8, hipHostMallocDefault));
-    TF_HIP(hipMalloc((void**)&s.d, npix * 8));
+    TF_HIP(hipMalloc((void**)&s.d, npix * 12));  // depth | colour as uploaded (RGBA, or RGB + valid flags) | RGBA packed from an RGB upload
     if (!s.copied) TF_HIP(hipEventCreateWithFlags(&s.copied, hipEventDisableTiming));
     s.free_when = 0;  // (both streams were drained above)
   }
@@ -1192,10 +1192,14 @@ int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba) {
   return TF_OK;
 }
 
-int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgba, const float pose[12],
-                            const float* pose_inv16, int32_t frame_id) {
+}  // extern "C"
+// rgb != nullptr: the colour image comes as Frame::rgb (3 bytes per pixel) with Frame::colorValidFlag (or none: every pixel
+// valid) -- the inputs of the caller's own RGBA staging loops (MobileFusion.cpp:144-163, :232-243), which then run on the
+// device behind the upload, on the copy stream
+static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uint8_t* rgba, const uint8_t* rgb,
+                                     const uint8_t* color_valid, const float pose[12], const float* pose_inv16, int32_t frame_id) {
   if (!v || !depth || !pose) { set_error("null argument"); return TF_ERR_INVALID; }
-  if (pose_inv16 && !rgba) { set_error("the textured unit needs a colour image"); return TF_ERR_INVALID; }
+  if (pose_inv16 && !rgba && !rgb) { set_error("the textured unit needs a colour image"); return TF_ERR_INVALID; }
   TF_DEV_NOFLUSH(v);
   int rc = host_ring_prepare(v);
   if (rc) return rc;
@@ -1275,7 +1279,15 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
     size_t nb[2];
     int nr = 0;
     if (depth != hd) { dst[nr] = hd; src[nr] = depth; nb[nr++] = npix * 4; }
+    void* dst3[3];
+    const void* src3[3];
+    size_t nb3[3];
     if (rgba && rgba != hc) { dst[nr] = hc; src[nr] = rgba; nb[nr++] = npix * 4; }
+    if (rgb) {  // RGB at hc, the valid flags behind it (composed in place by a caller of tf_host_frame_buffers: no copy)
+      if (nr) { dst3[0] = dst[0]; src3[0] = src[0]; nb3[0] = nb[0]; }
+      if (rgb != hc) { dst3[nr] = hc; src3[nr] = rgb; nb3[nr++] = npix * 3; }
+      if (color_valid && color_valid != hc + npix * 3) { dst3[nr] = hc + npix * 3; src3[nr] = color_valid; nb3[nr++] = npix; }
+    }
     if (nr) {
       if (!v->copy_pool) {
         const char* e = getenv("TF_COPY_THREADS");
@@ -1288,7 +1300,8 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
         static const int pin = getenv("TF_COPY_PIN") ? atoi(getenv("TF_COPY_PIN")) : 0;
         v->copy_pool = new CopyPool(helpers, pin);
       }
-      v->copy_pool->copy(dst, src, nb, nr);
+      if (rgb) v->copy_pool->copy(dst3, src3, nb3, nr);
+      else v->copy_pool->copy(dst, src, nb, nr);
     }
   }
   lap(2, t);
@@ -1301,7 +1314,7 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   // 53-77 against 59-64: not a gain one can count on.  The textured stream is bound by the host side of the call, where
   // the second copy call and the join cost 3 us per frame (99.6 -> 103.2).
   static const int split_knob = getenv("TF_HOST_COPY_SPLIT") ? atoi(getenv("TF_HOST_COPY_SPLIT")) : 0;
-  const bool split = split_knob != 0;
+  const bool split = split_knob != 0 && !rgb;
   if (!dbg_noh2d) {
     if (split && rgba) {
       if (!v->copy_stream2) {
@@ -1313,14 +1326,20 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
       TF_HIP(hipMemcpyAsync(s.d, s.h, npix * 4, hipMemcpyHostToDevice, v->copy_stream));
       TF_HIP(hipStreamWaitEvent(v->copy_stream, v->copy_join, 0));
     } else {
-      TF_HIP(hipMemcpyAsync(s.d, s.h, rgba ? npix * 8 : npix * 4, hipMemcpyHostToDevice, v->copy_stream));
+      const size_t up = rgba ? npix * 8 : (rgb ? (color_valid ? npix * 8 : npix * 7) : npix * 4);
+      TF_HIP(hipMemcpyAsync(s.d, s.h, up, hipMemcpyHostToDevice, v->copy_stream));
+    }
+    if (rgb) {  // rgba = valid ? (r, g, b, 1) : 0, behind the upload on the copy stream (null flags: every pixel valid)
+      launch_pack_rgba(s.d + npix * 4, color_valid ? s.d + npix * 7 : nullptr, reinterpret_cast<uchar4*>(s.d + npix * 8), (uint32_t)npix,
+                       v->copy_stream);
+      TF_HIP(hipGetLastError());
     }
   }
   TF_HIP(hipEventRecord(s.copied, v->copy_stream));
   lap(3, t);
   tf_volume::Pending cur;
   cur.d = reinterpret_cast<const float*>(s.d);
-  cur.c = rgba ? s.d + npix * 4 : nullptr;
+  cur.c = rgba ? s.d + npix * 4 : (rgb ? s.d + npix * 8 : nullptr);
   memcpy(cur.pose, pose, sizeof(cur.pose));
   cur.tex = pose_inv16 != nullptr;
   if (pose_inv16) memcpy(cur.pinv, pose_inv16, sizeof(cur.pinv));
@@ -1343,6 +1362,16 @@ int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgb
   v->pend[v->n_pend++] = cur;
   if (bound_d) return bind_frame(v, bound_d, bound_c);
   return TF_OK;
+}
+extern "C" {
+int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8_t* rgba, const float pose[12],
+                            const float* pose_inv16, int32_t frame_id) {
+  return integrate_frame_host_impl(v, depth, rgba, nullptr, nullptr, pose, pose_inv16, frame_id);
+}
+int tf_integrate_frame_host_rgb(tf_volume* v, const float* depth, const uint8_t* rgb, const uint8_t* color_valid,
+                                const float pose[12], const float* pose_inv16, int32_t frame_id) {
+  if (!rgb) { set_error("null colour image (tf_integrate_frame_host takes depth-only frames)"); return TF_ERR_INVALID; }
+  return integrate_frame_host_impl(v, depth, nullptr, rgb, color_valid, pose, pose_inv16, frame_id);
 }
 
 }  // extern "C" (C++ linkage for the helper below)

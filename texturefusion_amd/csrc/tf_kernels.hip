@@ -191,7 +191,7 @@ void launch_fill_pool(const VolumeDev& v, uint32_t slot0, uint32_t nslots, hipSt
 __global__ __launch_bounds__(256) void k_pack_rgba(const uint8_t* __restrict__ rgb, const uint8_t* __restrict__ valid,
                                                    uchar4* __restrict__ rgba, uint32_t npix) {
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < npix; i += gridDim.x * 256) {
-    const bool ok = valid[i] > 0;
+    const bool ok = !valid || valid[i] > 0;  // (no flags: MobileFusion::IntegrateFrame's loop, alpha = 1 everywhere)
     rgba[i] = ok ? make_uchar4(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], 1) : make_uchar4(0, 0, 0, 0);
   }
 }
