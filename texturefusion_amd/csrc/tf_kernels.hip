@@ -2113,7 +2113,7 @@ __global__ __launch_bounds__(256) void k_finalize(VolumeDev v, uint32_t epoch) {
   const SelBuf& L = v.sel;
   const uint32_t n = L.ctl->n_list;
   const int sub = threadIdx.x & 7;
-  __shared__ uint32_t dead[32];
+  __shared__ uint32_t dead[32], dsumm[32];
   __shared__ uint32_t ndead;
   for (uint32_t base = blockIdx.x * 32; base < n; base += gridDim.x * 32) {
     if (threadIdx.x == 0) ndead = 0;
@@ -2134,7 +2134,9 @@ __global__ __launch_bounds__(256) void k_finalize(VolumeDev v, uint32_t epoch) {
         const uint32_t ent = L.list_ent[e];
         if (slot != kInvalidSlot && v.hent[ent].alive) {
           v.hent[ent].alive = 0;
-          dead[atomicAdd(&ndead, 1u)] = slot;
+          const uint32_t di = atomicAdd(&ndead, 1u);
+          dead[di] = slot;
+          dsumm[di] = v.summ[slot];  // (read here, by the parking threads side by side: not one load per chunk in the loop below)
         }
         if (slot != kInvalidSlot) v.erase_epoch[slot] = epoch + 1u;  // meshesToUpdate.erase(id)
       }
@@ -2150,16 +2152,15 @@ __global__ __launch_bounds__(256) void k_finalize(VolumeDev v, uint32_t epoch) {
       const uint32_t ds = dead[k];
       uint4* c4 = reinterpret_cast<uint4*>(v.color + (size_t)ds * kChunkVoxels);
       c4[threadIdx.x] = make_uint4(0, 0, 0, 0);
-      if (v.summ[ds] != 0u) {  // (workgroup-uniform)
+      if (dsumm[k] != 0u) {  // (workgroup-uniform)
         const uint32_t f999 = __float_as_uint(999.0f);
         uint4* t4 = reinterpret_cast<uint4*>(v.tsdf + (size_t)ds * kChunkVoxels);
         t4[threadIdx.x] = make_uint4(f999, 0u, f999, 0u);
       }
     }
-    __syncthreads();
-    if (threadIdx.x < nd) {
+    if (threadIdx.x < nd && dsumm[threadIdx.x] != 0u) {
       const uint32_t ds = dead[threadIdx.x];
-      if (v.summ[ds] != 0u) {
+      {
         v.summ[ds] = 0u;
         MeshRec* r = &v.mesh_rec[ds];
         if (r->state & kMsInMap) { r->state &= kMsOvfMask; r->nv = 0; r->nt = 0; }
