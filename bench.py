@@ -349,14 +349,17 @@ def main():
         pos = ORBIT
     p0 = pos + Wm  # stream position of the timed window; p0 % ORBIT = its orbit position
     use_host = host_ok and not args.resident_headline
+    host_phases = None
     if use_host:
         run_host(pos, Wm)  # (leaves the entry point's four-frame pipeline primed)
         barrier()
+        vol.host_frame_times(reset=True)
         t0 = time.perf_counter()
         run_host(p0, K)
         t_enq = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
+        host_phases = vol.host_frame_times(reset=True)
     else:
         run(pos, Wm)
         vol.sync()
@@ -551,6 +554,10 @@ def main():
         out["resident"] = resident
     if rgb_host is not None:
         out["rgb_host_frames"] = rgb_host
+    if use_host and host_phases:
+        host_phases["note"] = ("host microseconds per call inside the timed window: host_enqueue_ms_per_step includes wait_for_device_us "
+                               "(the entry point blocks until the device frees a staging slot -- back-pressure, not host work)")
+        out["host_phases_us_per_step"] = host_phases
     if per_rank is not None:
         out["per_rank"] = per_rank
 

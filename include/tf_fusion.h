@@ -311,6 +311,11 @@ TF_API int tf_integrate_frame_host_rgb(tf_volume* v, const float* depth, const u
                                        const float pose[12], const float* pose_inv16, int32_t frame_id);
 TF_API int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba);
 TF_API int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_slots);
+/* Where the host side of tf_integrate_frame_host(_rgb) spends its time, summed since create / the last reset:
+ * out[0] = calls that put a frame's launches on the stream, out[1..5] = microseconds spent waiting for the device to free
+ * a staging slot (back-pressure: the device is the bound), waiting for the slot's previous upload, in the staging copy, in
+ * the upload enqueue, in the kernel launches; out[6] = launches that had to wait in the stream for an upload. */
+TF_API int tf_host_frame_times(tf_volume* v, double out[7], int reset);
 /* The texturing half of the per-frame unit on its own, for the frame integrated last (its images still bound):
  * UpdateMeshes -> CompressMeshes -> GeneratePatches(label = frame_id) -> UpdateAtlas over that frame's dirty
  * chunks.  tf_stream_frames_textured_device == per frame: voxel update, then this.  A multi-GPU host that

@@ -40,7 +40,7 @@ SYMBOLS = (
     "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_atlas_size", "tf_meshes_upload",
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
     "tf_patches_download", "tf_atlas_download_rows", "tf_stream_frames_device",
-    "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host", "tf_integrate_frame_host_rgb",
+    "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host", "tf_integrate_frame_host_rgb", "tf_host_frame_times",
     "tf_host_frame_buffers", "tf_host_frame_deferral", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_boundary_band_bounds", "tf_boundary_pack_bands2", "tf_boundary_unpack_pair", "tf_comm_exchange_mode", "tf_comm_stats", "tf_comm_stats_ex",
     "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
     "tf_comm_exchange_every_frame",
@@ -176,6 +176,7 @@ def lib():
     L.tf_get_texture_stats.argtypes = [vp, C.POINTER(TextureStats)]
     L.tf_integrate_frame_host.argtypes = [vp, fp, u8p, fp, fp, C.c_int32]
     L.tf_integrate_frame_host_rgb.argtypes = [vp, fp, u8p, u8p, fp, fp, C.c_int32]
+    L.tf_host_frame_times.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
     L.tf_host_frame_buffers.argtypes = [vp, C.POINTER(fp), C.POINTER(u8p)]
     L.tf_host_frame_deferral.argtypes = [vp, i32p, i32p]
     L.tf_texture_frame_device.argtypes = [vp, fp, C.c_int32]
@@ -392,6 +393,14 @@ class Volume:
         T = None if pose_inv16 is None else _f32(pose_inv16).reshape(16)
         self._ck(self.L.tf_integrate_frame_host(self.h, _p(depth, C.c_float), _p(rgba, C.c_uint8), _p(pose, C.c_float),
                                                 _p(T, C.c_float), int(frame_id)))
+
+    def host_frame_times(self, reset=False):
+        """host microseconds per call of integrate_frame_host since create / the last reset, by phase"""
+        o = (C.c_double * 7)()
+        self._ck(self.L.tf_host_frame_times(self.h, o, int(reset)))
+        n = o[0] or 1.0
+        return {"calls": int(o[0]), "wait_for_device_us": o[1] / n, "wait_for_upload_us": o[2] / n, "staging_copy_us": o[3] / n,
+                "upload_enqueue_us": o[4] / n, "launches_us": o[5] / n, "launches_that_waited_for_an_upload": int(o[6])}
 
     def integrate_frame_host_rgb(self, depth, rgb, color_valid, pose, pose_inv16=None, frame_id=0):
         """the same with Frame::rgb (u8[H][W][3]) and Frame::colorValidFlag (u8[H][W], or None = every pixel valid): the

@@ -467,7 +467,7 @@ int tf_volume_destroy(tf_volume* v) {
     if (v->hslot[k].d) hipFree(v->hslot[k].d);
     if (v->hslot[k].copied) hipEventDestroy(v->hslot[k].copied);
   }
-  if (v->host_trace[5] > 0)
+  if (v->host_trace[5] > 0 && getenv("TF_HOST_TRACE") && atoi(getenv("TF_HOST_TRACE")))
     fprintf(stderr, "tf host frames: %.0f calls; per call us: wait kernels %.1f, wait upload %.1f, staging copy %.1f, "
                     "upload enqueue %.1f, launches %.1f; copies a launch waited for in the stream: %ld\n", v->host_trace[5],
             v->host_trace[0] / v->host_trace[5], v->host_trace[1] / v->host_trace[5], v->host_trace[2] / v->host_trace[5],
@@ -1180,6 +1180,15 @@ int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_s
   return TF_OK;
 }
 
+int tf_host_frame_times(tf_volume* v, double out[7], int reset) {
+  if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
+  out[0] = v->host_trace[5];  // calls that put a frame's launches on the stream
+  for (int k = 0; k < 5; ++k) out[1 + k] = v->host_trace[k];  // us: waiting for the device to free a slot | waiting for the slot's last upload | staging copy | upload enqueue | launches
+  out[6] = (double)v->host_waits;  // launches that had to wait in the stream for an upload
+  if (reset) { for (int k = 0; k < 6; ++k) v->host_trace[k] = 0.0; v->host_waits = 0; }
+  return TF_OK;
+}
+
 int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba) {
   if (!v || !depth || !rgba) { set_error("null argument"); return TF_ERR_INVALID; }
   TF_DEV_NOFLUSH(v);
@@ -1203,7 +1212,7 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   TF_DEV_NOFLUSH(v);
   int rc = host_ring_prepare(v);
   if (rc) return rc;
-  static const bool trace = getenv("TF_HOST_TRACE") && atoi(getenv("TF_HOST_TRACE"));  // per-phase host time, printed at destroy
+  constexpr bool trace = true;  // per-phase host time (five clock reads per call): tf_host_frame_times; TF_HOST_TRACE=1 prints it at destroy
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto lap = [&](int k, std::chrono::steady_clock::time_point& t) {
     if (!trace) return;
