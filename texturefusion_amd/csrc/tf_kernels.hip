@@ -1895,6 +1895,7 @@ struct FrameLaunch {
   uint32_t epoch;
   uint32_t n_ka, n_sel, n_bbox;
   uint32_t rot;          // dispatch-order rotation of the block ranges
+  uint32_t mix;          // > 0: the patch range is dealt INTO the K-A range, one patch workgroup per `mix` K-A workgroups (TF_FRAME_MIX)
   SelBuf sel1;           // set of frame f+1
   const float* depth1;
   SelectConsts sc1;
@@ -1915,7 +1916,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATCH ? TF_
   // Block ranges: K-A [0, n_ka), patches [n_ka, n_ka + n_patch), K-C, K-B behind them.
   // a.rot rotates the dispatch order: 0 = K-A blocks first, n_ka = the other roles first
   const uint32_t total = a.n_ka + a.n_patch + a.n_sel + a.n_bbox;
-  const uint32_t b = blockIdx.x + a.rot < total ? blockIdx.x + a.rot : blockIdx.x + a.rot - total;
+  uint32_t b = blockIdx.x + a.rot < total ? blockIdx.x + a.rot : blockIdx.x + a.rot - total;
+  if (PATCH && a.mix) {
+    // dispatch order P A..A P A..A ... while patch workgroups last, then the rest of K-A, then the selection roles: the
+    // stage's latency chains and K-A's arithmetic run side by side from the start of the launch
+    const uint32_t i = blockIdx.x, m1 = a.mix + 1u, zone = a.n_patch * m1;
+    if (i < zone) { const uint32_t g = i / m1, r = i - g * m1; b = r == 0u ? a.n_ka + g : g * a.mix + (r - 1u); }
+    else if (i < a.n_ka + a.n_patch) b = i - a.n_patch;
+    else b = i;
+  }
   // tuning aid (dbg bit 12): per-wave {start, end, role} stamps of the last launch -> phase_buf
   const bool timeline = (a.kc.dbg & 4096u) != 0 && a.n_sel > 0 && a.n_bbox > 0;  // steady launches only
   const unsigned long long t0 = timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz, chip-wide
@@ -2100,6 +2109,9 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   // frees.  With the patch stage on board that order leaves the stage's 15-us chains to start when K-A's waves end
   // (profiles/r3: span 48 us); patch + selection first, K-A behind them as their waves finish: 44 us.
   a.rot = others_first ? a.n_ka : 0u;
+  static const int mix_env = env_int("TF_FRAME_MIX", 0);
+  a.mix = 0u;
+  if (with_patch && mix_env > 0 && a.n_ka >= a.n_patch * (uint32_t)mix_env) { a.mix = (uint32_t)mix_env; a.rot = 0u; }
   if (with_patch) hipLaunchKernelGGL((k_frame<true, true>), dim3(total), dim3(256), 0, s, a);
   else if (color) hipLaunchKernelGGL((k_frame<true, false>), dim3(total), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k_frame<false, false>), dim3(total), dim3(256), 0, s, a);
