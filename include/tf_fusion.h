@@ -310,6 +310,13 @@ TF_API int tf_integrate_frame_host(tf_volume* v, const float* depth, const uint8
 TF_API int tf_integrate_frame_host_rgb(tf_volume* v, const float* depth, const uint8_t* rgb, const uint8_t* color_valid,
                                        const float pose[12], const float* pose_inv16, int32_t frame_id);
 TF_API int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba);
+/* A caller that keeps its images in buffers of its own (cv::Mat data, a camera ring) registers them once: the pages are
+ * locked in place (hipHostRegister) and host frames that lie inside a registered buffer are uploaded straight out of it --
+ * no staging copy, no helper threads -- while the call puts the launches of the frames before on the stream; the call
+ * returns when the upload is through, so the buffer is the caller's again on return, as with the staging path.  Registering
+ * costs about a millisecond per megabyte: once per buffer, not per frame.  tf_volume_destroy unregisters what is left. */
+TF_API int tf_host_register(tf_volume* v, const void* p, int64_t bytes);
+TF_API int tf_host_unregister(tf_volume* v, const void* p);
 TF_API int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_slots);
 /* Where the host side of tf_integrate_frame_host(_rgb) spends its time, summed since create / the last reset:
  * out[0] = calls that put a frame's launches on the stream, out[1..5] = microseconds spent waiting for the device to free

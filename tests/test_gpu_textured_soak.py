@@ -26,6 +26,16 @@ def _run(cam, res, frames, host_frames=False, max_chunks=1 << 17, stride=1):
             rgb = np.ascontiguousarray(f[1][..., :3]).copy()
             rgb[valid == 0] = 77  # (whatever the camera delivered where the flag says invalid)
             gv.integrate_frame_host_rgb(f[0], rgb, None if valid.all() else valid, f[3].reshape(12), pinv[k], 10 + k)
+    elif host_frames == "registered":  # ONE pair of caller buffers, registered once, refilled for every frame and
+        d = np.empty_like(frames[0][0]); c = np.empty_like(frames[0][1])  # scribbled over as soon as the call returns
+        gv.host_register(d); gv.host_register(c)
+        gv.host_register(d)  # (inside a registered range already: a no-op)
+        for k, f in enumerate(frames):
+            d[...] = f[0]; c[...] = f[1]
+            gv.integrate_frame_host(d, c, f[3].reshape(12), pinv[k], 10 + k)
+            d[...] = 123.0; c[...] = 200
+        gv.sync()
+        gv.host_unregister(c); gv.host_unregister(d)
     elif host_frames:
         for k, f in enumerate(frames):
             gv.integrate_frame_host(f[0], f[1], f[3].reshape(12), pinv[k], 10 + k)
@@ -88,6 +98,14 @@ def test_host_frames_entry_point(gpu_required):
     cam = synth.Camera()
     frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(10)]
     assert _run(cam, np.float32(0.005), frames, host_frames=True, stride=3) > 400
+
+
+def test_host_frames_out_of_registered_caller_buffers(gpu_required):
+    """tf_host_register: frames uploaded straight out of the caller's own (page-locked in place) buffers; the buffers are the
+    caller's again when the call returns -- they are overwritten at once here"""
+    cam = synth.Camera()
+    frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(10)]
+    assert _run(cam, np.float32(0.005), frames, host_frames="registered", stride=3) > 400
 
 
 def test_host_frames_as_rgb_and_valid_flags(gpu_required):

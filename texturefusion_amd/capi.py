@@ -40,7 +40,7 @@ SYMBOLS = (
     "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_atlas_size", "tf_meshes_upload",
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
     "tf_patches_download", "tf_atlas_download_rows", "tf_stream_frames_device",
-    "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host", "tf_integrate_frame_host_rgb", "tf_host_frame_times",
+    "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host", "tf_integrate_frame_host_rgb", "tf_host_frame_times", "tf_host_register", "tf_host_unregister",
     "tf_host_frame_buffers", "tf_host_frame_deferral", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_boundary_band_bounds", "tf_boundary_pack_bands2", "tf_boundary_unpack_pair", "tf_comm_exchange_mode", "tf_comm_stats", "tf_comm_stats_ex",
     "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
     "tf_comm_exchange_every_frame",
@@ -177,6 +177,8 @@ def lib():
     L.tf_integrate_frame_host.argtypes = [vp, fp, u8p, fp, fp, C.c_int32]
     L.tf_integrate_frame_host_rgb.argtypes = [vp, fp, u8p, u8p, fp, fp, C.c_int32]
     L.tf_host_frame_times.argtypes = [vp, C.POINTER(C.c_double), C.c_int]
+    L.tf_host_register.argtypes = [vp, C.c_void_p, C.c_int64]
+    L.tf_host_unregister.argtypes = [vp, C.c_void_p]
     L.tf_host_frame_buffers.argtypes = [vp, C.POINTER(fp), C.POINTER(u8p)]
     L.tf_host_frame_deferral.argtypes = [vp, i32p, i32p]
     L.tf_texture_frame_device.argtypes = [vp, fp, C.c_int32]
@@ -393,6 +395,13 @@ class Volume:
         T = None if pose_inv16 is None else _f32(pose_inv16).reshape(16)
         self._ck(self.L.tf_integrate_frame_host(self.h, _p(depth, C.c_float), _p(rgba, C.c_uint8), _p(pose, C.c_float),
                                                 _p(T, C.c_float), int(frame_id)))
+
+    def host_register(self, array):
+        """page-lock a caller-owned numpy array in place: host frames passed from it are uploaded without a staging copy"""
+        self._ck(self.L.tf_host_register(self.h, C.c_void_p(array.ctypes.data), int(array.nbytes)))
+
+    def host_unregister(self, array):
+        self._ck(self.L.tf_host_unregister(self.h, C.c_void_p(array.ctypes.data)))
 
     def host_frame_times(self, reset=False):
         """host microseconds per call of integrate_frame_host since create / the last reset, by phase"""

@@ -462,6 +462,8 @@ int tf_volume_destroy(tf_volume* v) {
   v->h_progress = nullptr;
   if (v->h_xchg) hipHostFree(v->h_xchg);
   v->h_xchg = nullptr;
+  for (const tf_volume::HostRange& r : v->host_ranges) (void)hipHostUnregister(const_cast<uint8_t*>(r.p));
+  v->host_ranges.clear();
   for (int k = 0; k < tf_volume::kHostRing; ++k) {
     if (v->hslot[k].h) hipHostFree(v->hslot[k].h);
     if (v->hslot[k].d) hipFree(v->hslot[k].d);
@@ -1180,6 +1182,30 @@ int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_s
   return TF_OK;
 }
 
+int tf_host_register(tf_volume* v, const void* p, int64_t bytes) {
+  if (!v || !p || bytes <= 0) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV_NOFLUSH(v);
+  const uint8_t* b = static_cast<const uint8_t*>(p);
+  for (const tf_volume::HostRange& r : v->host_ranges)
+    if (b >= r.p && b + bytes <= r.p + r.n) return TF_OK;  // already inside a registered range
+  TF_HIP(hipHostRegister(const_cast<uint8_t*>(b), (size_t)bytes, hipHostRegisterDefault));
+  v->host_ranges.push_back({b, (size_t)bytes});
+  return TF_OK;
+}
+int tf_host_unregister(tf_volume* v, const void* p) {
+  if (!v || !p) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);  // (frames still in the entry point's pipeline have been uploaded; their launches go out now)
+  TF_HIP(hipStreamSynchronize(v->copy_stream ? v->copy_stream : v->stream));
+  for (size_t i = 0; i < v->host_ranges.size(); ++i)
+    if (v->host_ranges[i].p == static_cast<const uint8_t*>(p)) {
+      TF_HIP(hipHostUnregister(const_cast<void*>(p)));
+      v->host_ranges.erase(v->host_ranges.begin() + (long)i);
+      return TF_OK;
+    }
+  set_error("not a registered buffer");
+  return TF_ERR_INVALID;
+}
+
 int tf_host_frame_times(tf_volume* v, double out[7], int reset) {
   if (!v || !out) { set_error("null argument"); return TF_ERR_INVALID; }
   out[0] = v->host_trace[5];  // calls that put a frame's launches on the stream
@@ -1282,7 +1308,16 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   lap(1, t);
   float* hd = reinterpret_cast<float*>(s.h);
   uint8_t* hc = s.h + npix * 4;
-  {  // frames composed in tf_host_frame_buffers' slot skip the staging copy
+  // images inside registered caller buffers (tf_host_register) go up straight from there
+  auto registered = [&](const void* q, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(q);
+    for (const tf_volume::HostRange& r : v->host_ranges)
+      if (b >= r.p && b + n <= r.p + r.n) return true;
+    return false;
+  };
+  const bool direct = !v->host_ranges.empty() && registered(depth, npix * 4) && (!rgba || registered(rgba, npix * 4)) &&
+                      (!rgb || (registered(rgb, npix * 3) && (!color_valid || registered(color_valid, npix))));
+  if (!direct) {  // frames composed in tf_host_frame_buffers' slot skip the staging copy
     void* dst[2];
     const void* src[2];
     size_t nb[2];
@@ -1307,7 +1342,8 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
         // 10-ms stall -- 100.8 us per frame at best, 150+ at worst, against a steady 102.6 unpinned; run 36),
         // 1 = the caller's group of eight CPUs, 2 = one CPU of that group per helper
         static const int pin = getenv("TF_COPY_PIN") ? atoi(getenv("TF_COPY_PIN")) : 0;
-        v->copy_pool = new CopyPool(helpers, pin);
+        static const int spin_us = getenv("TF_COPY_SPIN_US") ? atoi(getenv("TF_COPY_SPIN_US")) : 200;
+        v->copy_pool = new CopyPool(helpers, pin, spin_us);
       }
       if (rgb) v->copy_pool->copy(dst3, src3, nb3, nr);
       else v->copy_pool->copy(dst, src, nb, nr);
@@ -1324,7 +1360,32 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   // the second copy call and the join cost 3 us per frame (99.6 -> 103.2).
   static const int split_knob = getenv("TF_HOST_COPY_SPLIT") ? atoi(getenv("TF_HOST_COPY_SPLIT")) : 0;
   const bool split = split_knob != 0 && !rgb;
-  if (!dbg_noh2d) {
+  if (direct) {
+    // (the call waits for this upload: depth and colour go up side by side on two copy queues -- TF_HOST_DIRECT_SPLIT=0: one)
+    static const bool dsplit = !(getenv("TF_HOST_DIRECT_SPLIT") && !atoi(getenv("TF_HOST_DIRECT_SPLIT")));
+    // (a kernel that fetches the images itself -- 16-byte loads out of the mapped pages -- was no faster than the DMA
+    // transfers, 60 us, and slowed the step kernels it ran next to: 100 -> 125 us per frame, profiles/r4/README.md)
+    if (rgba && dsplit) {
+      if (!v->copy_stream2) {
+        TF_HIP(hipStreamCreateWithFlags(&v->copy_stream2, hipStreamNonBlocking));
+        TF_HIP(hipEventCreateWithFlags(&v->copy_join, hipEventDisableTiming));
+      }
+      TF_HIP(hipMemcpyAsync(s.d + npix * 4, rgba, npix * 4, hipMemcpyHostToDevice, v->copy_stream2));
+      TF_HIP(hipEventRecord(v->copy_join, v->copy_stream2));
+      TF_HIP(hipMemcpyAsync(s.d, depth, npix * 4, hipMemcpyHostToDevice, v->copy_stream));
+      TF_HIP(hipStreamWaitEvent(v->copy_stream, v->copy_join, 0));
+    } else {
+      TF_HIP(hipMemcpyAsync(s.d, depth, npix * 4, hipMemcpyHostToDevice, v->copy_stream));
+      if (rgba) TF_HIP(hipMemcpyAsync(s.d + npix * 4, rgba, npix * 4, hipMemcpyHostToDevice, v->copy_stream));
+    }
+    if (rgb) {
+      TF_HIP(hipMemcpyAsync(s.d + npix * 4, rgb, npix * 3, hipMemcpyHostToDevice, v->copy_stream));
+      if (color_valid) TF_HIP(hipMemcpyAsync(s.d + npix * 7, color_valid, npix, hipMemcpyHostToDevice, v->copy_stream));
+      launch_pack_rgba(s.d + npix * 4, color_valid ? s.d + npix * 7 : nullptr, reinterpret_cast<uchar4*>(s.d + npix * 8), (uint32_t)npix,
+                       v->copy_stream);
+      TF_HIP(hipGetLastError());
+    }
+  } else if (!dbg_noh2d) {
     if (split && rgba) {
       if (!v->copy_stream2) {
         TF_HIP(hipStreamCreateWithFlags(&v->copy_stream2, hipStreamNonBlocking));
@@ -1355,7 +1416,15 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   cur.fid = frame_id;
   cur.slot = slot_index;
   cur.copied = false;
+  // the caller's buffers are its own again when the call returns: an upload straight out of them must be through
+  auto wait_direct = [&]() {
+    auto tw = now();
+    for (uint32_t spin = 0; hipEventQuery(s.copied) == hipErrorNotReady; ++spin)
+      if ((spin & 63u) == 63u) __builtin_ia32_pause();
+    lap(1, tw);
+  };
   if (!defer) {  // integrate at once: two selection-only launches per frame, the stream waits for the copy
+    if (direct) { wait_direct(); cur.copied = true; }
     rc = host_copy_ready(v, &cur);
     if (rc) return rc;
     const float* dd[1] = {cur.d};
@@ -1369,6 +1438,7 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   }
   if (!early) { rc = launch_oldest(); if (rc) return rc; }
   v->pend[v->n_pend++] = cur;
+  if (direct) { wait_direct(); v->pend[v->n_pend - 1].copied = true; }
   if (bound_d) return bind_frame(v, bound_d, bound_c);
   return TF_OK;
 }

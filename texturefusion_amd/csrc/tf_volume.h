@@ -172,6 +172,10 @@ struct tf_volume {
   uint32_t* h_progress = nullptr;
   uint32_t progress_seq = 0;   // stamp of the last frame launch put on the stream
   HostSlot hslot[kHostRing];
+  // caller buffers registered with tf_host_register (page-locked in place): host frames that lie inside one are uploaded
+  // straight out of it -- no staging copy -- and the call returns when that upload is through
+  struct HostRange { const uint8_t* p; size_t n; };
+  std::vector<HostRange> host_ranges;
   size_t hslot_pixels = 0;
   int hslot_next = 0;
   hipStream_t copy_stream = nullptr;
