@@ -3,7 +3,7 @@
 
 One "step" = one synthetic 640x480 RGB-D frame of the S-room stream, handed over as HOST images
 (the reference's calling convention, GCFusion/MobileFusion.cpp:223-250), through
-  H2D copy of depth + RGBA out of the caller's buffers (inside the timed region; the 400 image buffers of the orbit are
+  H2D copy of depth + RGBA out of the caller's buffers (inside the timed region; the two arrays that hold the orbit's images are
   registered once with tf_host_register before the pre-roll, as a caller with a fixed set of frame buffers does at start-up:
   no staging copy, one host thread, the call returns when the upload is through; --staged-host-frames = the copy through the
   library's pinned slots by helper threads, reported as "staged_host_frames" either way)
@@ -236,9 +236,8 @@ def main():
     host_registered = False
     if not args.staged_host_frames:
         try:
-            for k in range(n_unique):
-                vol.host_register(h_depth[k])
-                vol.host_register(h_rgba[k])
+            vol.host_register(h_depth)  # (the two arrays that hold the orbit's images)
+            vol.host_register(h_rgba)
             host_registered = True
         except Exception as e:  # (e.g. a locked-memory limit: the staging path works everywhere)
             print("bench: tf_host_register failed (%r): host frames take the staging path" % (e,), file=sys.stderr)
