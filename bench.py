@@ -3,10 +3,11 @@
 
 One "step" = one synthetic 640x480 RGB-D frame of the S-room stream, handed over as HOST images
 (the reference's calling convention, GCFusion/MobileFusion.cpp:223-250), through
-  H2D copy of depth + RGBA out of the caller's buffers (inside the timed region; the two arrays that hold the orbit's images are
+  H2D copy of depth + RGBA out of the caller's arrays (inside the timed region; the two arrays that hold the orbit's images are
   registered once with tf_host_register before the pre-roll, as a caller with a fixed set of frame buffers does at start-up:
-  no staging copy, one host thread, the call returns when the upload is through; --staged-host-frames = the copy through the
-  library's pinned slots by helper threads, reported as "staged_host_frames" either way)
+  no staging copy, one host thread, the call returns when its upload is through; "staged_host_frames" = the same frames
+  through the library's pinned staging slots -- a CPU copy by helper threads + an asynchronous upload; --staged-host-frames
+  makes that the timed path)
   prepare -> integrate(depth+colour) -> finalize          Chisel::IntegrateDepthScanColor 5-arg, Structure/Chisel.h:453-468
   -> UpdateMeshes -> CompressMeshes                        over that frame's dirty chunks (Structure/Chisel.h:479-481, Chisel.cpp:112-147)
   -> GeneratePatches(label = this frame) -> UpdateAtlas    Structure/Chisel.cpp:149-196
@@ -18,7 +19,7 @@ Frame windows (ORBIT = 200 frames = one turn of the camera; every window starts 
   warm-up    W frames through the timed entry point
   timed      K frames -> "value", "ms_per_step" (wall clock, barrier + device synchronisation on both sides)
   resident   the same K orbit positions one turn later, frames already in HBM (no H2D) -> "resident"
-  staged     the same positions as host frames from unregistered buffers (staging copy by helper threads) -> "staged_host_frames"
+  staged     the same positions as host frames from unregistered arrays (staging copy by helper threads) -> "staged_host_frames"
   rgb host   the same positions as host frames with Frame::rgb (3 B per pixel) instead of the RGBA staging image -> "rgb_host_frames"
   events     the same positions again with HIP events around every launch -> per-kernel times
   replay     the same positions again, frame by frame, reading back the exact integer counts -> algorithmic bytes
@@ -81,8 +82,8 @@ def parse():
     ap.add_argument("--repeats", type=int, default=5, help="N=1: further timed windows on the same orbit positions (median / min / max next to value)")
     ap.add_argument("--no-group", action="store_true", help="skip the keyframe-group (1 colour + 6 depth frames) measurement")
     ap.add_argument("--staged-host-frames", action="store_true",
-                    help="host frames through the library's pinned staging slots (a CPU copy per frame by a pool of helper threads) "
-                         "instead of out of caller buffers registered once with tf_host_register")
+                    help="the timed host frames go through the library's pinned staging slots (a CPU copy per frame by a pool of "
+                         "helper threads) instead of straight out of the caller's arrays, registered once with tf_host_register")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N>1 code path (partition + boundary exchange) even with one rank (smoke test)")
     return ap.parse_args()
@@ -92,6 +93,21 @@ def parse():
 # the synthetic stream: generated once per parameter set, kept in /tmp so that the profiler child passes (and a
 # second run on the same box) load it instead of generating it again
 # ---------------------------------------------------------------------------------------------------------
+def cgroup_cpu_quota():
+    """CPUs' worth of CFS quota of this container (cgroup v2 cpu.max / v1 cfs_quota_us), or None when unlimited"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / p
+    except Exception:
+        return None
+
+
 def load_stream(args, cam):
     from texturefusion_amd import synth
     n = args.unique_frames
@@ -196,6 +212,7 @@ def main():
 
     import torch  # plumbing: device memory for the frames, barrier/collectives, device sync
     import torch.distributed as dist
+    torch.set_num_threads(1)  # (no CPU tensor work here; an idle OpenMP pool would only burn the container's CPU quota)
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
@@ -231,8 +248,12 @@ def main():
     vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
                       max_coarse=1 << 22 if big else 1 << 20, device=local_rank,
                       stream=s_main.cuda_stream if multi else None)
-    # the caller's frame buffers are registered once, as a caller with a fixed set of image buffers would at start-up: host
-    # frames then go up straight out of them (no staging copy); --staged-host-frames keeps the copy through pinned slots
+    # The caller's frame buffers are registered once, as a caller with a fixed set of image buffers does at start-up; host
+    # frames then go up straight out of them (no staging copy, ONE host thread, the call returns when the upload is through).
+    # --staged-host-frames: the copy through the library's pinned slots (any caller buffer, nothing registered) -- faster on
+    # a quiet host (its upload is asynchronous), but its eight copy threads must all be scheduled promptly: on the shared
+    # hosts of the GPU boxes (load average 20-40, a CFS quota of 16 CPUs) the same build measured 59-116 us per TSDF-only
+    # frame from box to box, against 80-82 us with registered buffers on every one of them (profiles/r4/README.md).
     host_registered = False
     if not args.staged_host_frames:
         try:
@@ -359,6 +380,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    quota = cgroup_cpu_quota()
+
+    def fresh_period():
+        """The GPU boxes run this process under a CFS quota (cpu.max: e.g. 16 CPUs per 100 ms on a 256-CPU host): a burst of
+        many runnable threads ahead of a timed window (image upload, registration, the profiler child passes, the runtime's
+        helper threads) can exhaust the period's budget, and the kernel then freezes EVERY thread of the container until the
+        period ends -- tens of milliseconds inside a 2-ms window.  A window's own work needs well under the quota; waiting
+        out one period before the warm-up frames lets it start with a full budget."""
+        if quota is not None:
+            torch.cuda.synchronize()
+            time.sleep(0.12)
+
     # ---- pre-roll (one orbit, untimed), warm-up, then the timed region --------------------------
     # (the driver loop is Python: a cyclic-GC pass over torch's and numpy's objects takes milliseconds -- longer than the
     # whole window at the driver's --steps 20 -- and has nothing to do with the path; nothing below builds cycles)
@@ -373,6 +406,7 @@ def main():
     p0 = pos + Wm  # stream position of the timed window; p0 % ORBIT = its orbit position
     use_host = host_ok and not args.resident_headline
     host_phases = None
+    fresh_period()
     if use_host:
         run_host(pos, Wm)  # (leaves the entry point's four-frame pipeline primed)
         barrier()
@@ -446,6 +480,7 @@ def main():
             if nxt > pos:
                 run(pos, nxt - pos)
             pos = nxt
+            fresh_period()
             (run_host if use_host else run)(pos, Wm)
             if not use_host:
                 vol.sync()
@@ -480,41 +515,49 @@ def main():
                     "note": "tf_stream_frames_textured_device on the same %d orbit positions one turn later: images "
                             "already in HBM, no H2D, one call for all frames" % K}
 
-    # ---- the same positions as HOST frames through the library's staging slots (buffers the caller never registered) ----
-    staged_host = None
-    if use_host and not multi and host_registered:
+    # ---- the same positions as HOST frames by the OTHER way in: registered caller buffers <-> the library's staging slots ----
+    other_host = None
+    if use_host and not multi:
         try:
-            s_depth = [a.copy() for a in h_depth[:n_unique]]   # (copies: not inside any registered range)
-            s_rgba = [a.copy() for a in h_rgba[:n_unique]]
+            o_depth = h_depth[:n_unique].copy()   # (a second set of caller arrays: outside the registered ranges)
+            o_rgba = h_rgba[:n_unique].copy()
+            if not host_registered:
+                vol.host_register(o_depth)
+                vol.host_register(o_rgba)
 
-            def run_host_staged(first, count):
+            def run_host_other(first, count):
                 for j in range(count):
                     i = (first + j) % n_unique
-                    vol.integrate_frame_host(s_depth[i], s_rgba[i], poses[i], pinv[i] if textured else None, first + j)
+                    vol.integrate_frame_host(o_depth[i], o_rgba[i], poses[i], pinv[i] if textured else None, first + j)
 
             nxt = pos + ((p0 - Wm - pos) % ORBIT)
             if nxt > pos:
                 run(pos, nxt - pos)
             pos = nxt
-            run_host_staged(pos, Wm)
+            fresh_period()
+            run_host_other(pos, Wm)
             barrier()
             vol.host_frame_times(reset=True)
             t1 = time.perf_counter()
-            run_host_staged(pos + Wm, K)
+            run_host_other(pos + Wm, K)
             barrier()
-            dt_st = time.perf_counter() - t1
-            st_ph = vol.host_frame_times(reset=True)
+            dt_o = time.perf_counter() - t1
+            o_ph = vol.host_frame_times(reset=True)
             vol.sync()
             pos += Wm + K
-            staged_host = {"value": K / dt_st, "unit": "frames/s", "ms_per_step": 1e3 * dt_st / K,
-                           "staging_copy_us_per_step": st_ph["staging_copy_us"], "wait_for_device_us_per_step": st_ph["wait_for_device_us"],
-                           "note": "tf_integrate_frame_host on the same %d orbit positions from buffers that were never registered: "
-                                   "a copy into the library's pinned slots by a pool of helper threads (faster when the helpers run "
-                                   "undisturbed; a helper the host deschedules in the middle of its part stalls the call for "
-                                   "milliseconds)" % K}
-            del s_depth, s_rgba
+            if not host_registered:
+                vol.host_unregister(o_rgba)
+                vol.host_unregister(o_depth)
+            other_host = {"value": K / dt_o, "unit": "frames/s", "ms_per_step": 1e3 * dt_o / K,
+                          "host_phases_us_per_step": {k: v for k, v in o_ph.items()},
+                          "note": ("tf_integrate_frame_host on the same %d orbit positions " % K) +
+                                  ("from arrays that were never registered: a copy into the library's pinned slots by a pool of helper "
+                                   "threads, asynchronous upload" if host_registered else
+                                   "out of caller arrays registered once with tf_host_register: no staging copy, no helper threads, the "
+                                   "call returns when its upload is through")}
+            del o_depth, o_rgba
         except Exception as e:  # (a side figure: never fail the bench line for it)
-            staged_host = {"error": repr(e)[:300]}
+            other_host = {"error": repr(e)[:300]}
 
     # ---- the same positions as HOST frames with the colour image as the caller holds it (Frame::rgb, 3 B per pixel) ----
     rgb_host = None
@@ -534,6 +577,7 @@ def main():
             if nxt > pos:
                 run(pos, nxt - pos)
             pos = nxt
+            fresh_period()
             run_host_rgb(pos, Wm)
             barrier()
             t1 = time.perf_counter()
@@ -611,8 +655,8 @@ def main():
         out["repeats"] = repeats
     if resident is not None:
         out["resident"] = resident
-    if staged_host is not None:
-        out["staged_host_frames"] = staged_host
+    if other_host is not None:
+        out["staged_host_frames" if host_registered else "registered_host_frames"] = other_host
     if rgb_host is not None:
         out["rgb_host_frames"] = rgb_host
     if use_host and host_phases:
@@ -1045,6 +1089,7 @@ def cpu_baseline(args, cam, res, h_depth, h_rgba, h_pose, n_unique, textured):
     oa = O.Atlas(res) if textured else None
     T = args.cpu_threads if args.cpu_threads > 0 else max(1, ncpu - 2)  # chisel::parallel_for: hardware_concurrency - 2,
     ov.set_threads(T)                                                    # groups of >= 1000 items (applied per call inside)
+    quota = cgroup_cpu_quota()  # (std::thread::hardware_concurrency() does not see a CFS quota: the policy above is the reference's)
 
     def step(k):
         i = k % n_unique
@@ -1072,7 +1117,24 @@ def cpu_baseline(args, cam, res, h_depth, h_rgba, h_pose, n_unique, textured):
                      else "atlas off",
                      args.cpu_warmup, args.cpu_warmup + n - 1, args.cpu_warmup, T, ncpu),
         "host_cores": ncpu,
+        "cpu_quota_cpus": quota,
     }
+    if quota is not None and quota < T and args.cpu_threads <= 0:
+        # the container may only use `quota` CPUs' worth of time: the same frames once more with that many threads (the
+        # reference's policy oversubscribes a throttled container); `value` / `cores` report the faster of the two
+        Tq = max(1, int(quota))
+        ov.set_threads(Tq)
+        t0 = time.perf_counter()
+        for k in range(args.cpu_warmup + n, args.cpu_warmup + 2 * n):
+            step(k)
+        vq = n / (time.perf_counter() - t0)
+        out["value_reference_thread_policy"] = out["value"]
+        out["value_quota_threads"] = vq
+        out["sample"] += ("; the container's CFS quota is %.0f CPUs: %d threads give %.1f frames/s on the next %d frames, the "
+                          "reference's %d threads %.1f" % (quota, Tq, vq, n, T, out["value"]))
+        if vq > out["value"]:
+            out["value"], out["cores"] = vq, Tq
+        ov.set_threads(T)
     if textured:  # TSDF-only figure of the same port on a shorter sample
         ov1 = O.Volume(res, O.camera_from(cam), O.default_integrator())
         ov1.set_kernel(1 if avx2 else 0)
