@@ -373,7 +373,14 @@ def main():
         calls put `count` frames' H2D copies and `count` frames' kernels on the device."""
         for j in range(count):
             i = (first + j) % n_unique
-            vol.integrate_frame_host(h_depth[i], h_rgba[i], poses[i], pinv[i] if textured else None, first + j)
+            vol.integrate_frame_host_addr(a_depth[i], a_rgba[i], a_pose[i], a_pinv[i] if textured else 0, first + j)
+
+    # (addresses of the frames' arrays, taken once: the driver loop is Python, and turning four numpy arrays into ctypes
+    # pointers costs ~10 us per call -- a tenth of a step -- that a C++ caller does not pay)
+    a_depth = [h_depth[i].ctypes.data for i in range(n_unique)]
+    a_rgba = [h_rgba[i].ctypes.data for i in range(n_unique)]
+    a_pose = [poses[i].ctypes.data for i in range(n_unique)]
+    a_pinv = [pinv[i].ctypes.data for i in range(n_unique)]
 
     def barrier():
         if multi:
@@ -525,10 +532,13 @@ def main():
                 vol.host_register(o_depth)
                 vol.host_register(o_rgba)
 
+            ao_depth = [o_depth[i].ctypes.data for i in range(n_unique)]
+            ao_rgba = [o_rgba[i].ctypes.data for i in range(n_unique)]
+
             def run_host_other(first, count):
                 for j in range(count):
                     i = (first + j) % n_unique
-                    vol.integrate_frame_host(o_depth[i], o_rgba[i], poses[i], pinv[i] if textured else None, first + j)
+                    vol.integrate_frame_host_addr(ao_depth[i], ao_rgba[i], a_pose[i], a_pinv[i] if textured else 0, first + j)
 
             nxt = pos + ((p0 - Wm - pos) % ORBIT)
             if nxt > pos:

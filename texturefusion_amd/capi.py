@@ -396,6 +396,15 @@ class Volume:
         self._ck(self.L.tf_integrate_frame_host(self.h, _p(depth, C.c_float), _p(rgba, C.c_uint8), _p(pose, C.c_float),
                                                 _p(T, C.c_float), int(frame_id)))
 
+    def integrate_frame_host_addr(self, depth_addr, rgba_addr, pose_addr, pose_inv16_addr, frame_id=0):
+        """integrate_frame_host for a driver loop that has its arrays' ADDRESSES at hand (array.ctypes.data, 0 = NULL): no
+        per-call conversion of numpy arrays into ctypes pointers (~10 us of Python per call).  The caller vouches for sizes."""
+        f = self.__dict__.get("_ifh_raw")
+        if f is None:
+            proto = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32)
+            f = self._ifh_raw = C.cast(self.L.tf_integrate_frame_host, proto)
+        self._ck(f(self.h, depth_addr, rgba_addr or None, pose_addr, pose_inv16_addr or None, int(frame_id)))
+
     def host_register(self, array):
         """page-lock a caller-owned numpy array in place: host frames passed from it are uploaded without a staging copy"""
         self._ck(self.L.tf_host_register(self.h, C.c_void_p(array.ctypes.data), int(array.nbytes)))
