@@ -1022,6 +1022,8 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
         for g in range(warm):
             call(g)
         vol.sync()
+        if cgroup_cpu_quota() is not None:
+            time.sleep(0.12)  # (a fresh CFS period: see fresh_period() in main)
         t0 = time.perf_counter()
         n_moved = 0
         for g in range(warm, warm + n_kf):
@@ -1065,6 +1067,8 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
         for g in range(4):
             call_by_call(g)
         vol.sync()
+        if cgroup_cpu_quota() is not None:
+            time.sleep(0.12)
         n_cc = max(4, n_kf // 2)
         t0 = time.perf_counter()
         for g in range(4, 4 + n_cc):
