@@ -834,10 +834,17 @@ class Chisel {
   void IntegrateDepthScanColor(ProjectionIntegrator& integrator, float* depthImage, unsigned char* colorImage,
                                const Transform& depthExtrinsic, const PinholeCamera& depthCamera) {
     Configure(integrator, depthCamera);
-    UploadFrame(depthImage, colorImage, nullptr, depthCamera);
-    tf_check(tf_integrate_frame(vol, depthExtrinsic.data(), colorImage != NULL), "IntegrateDepthScanColor");
+    // the host-frames entry point: the images are staged (or, if the caller registered its buffers with RegisterHostBuffer,
+    // uploaded in place) and the frame joins a four-deep launch pipeline -- a stream of IntegrateFrame calls runs at the
+    // device's rate instead of one upload + three launches + a wait per frame; every other call flushes the pipeline
+    // first, so the deferral is not observable (tf_fusion.h: tf_integrate_frame_host)
+    tf_check(tf_integrate_frame_host(vol, depthImage, colorImage, depthExtrinsic.data(), nullptr, 0), "IntegrateDepthScanColor");
     meshes_stale = true;
   }
+  // a caller whose images live in a fixed set of buffers (cv::Mat data, a camera ring) registers them once: host frames
+  // then go up straight out of them (tf_host_register)
+  void RegisterHostBuffer(const void* p, size_t bytes) { tf_check(tf_host_register(vol, p, (int64_t)bytes), "RegisterHostBuffer"); }
+  void UnregisterHostBuffer(const void* p) { tf_check(tf_host_unregister(vol, p), "UnregisterHostBuffer"); }
 
   // Chisel::meshesToUpdate (Chisel.h:489), refreshed from the device dirty set on access.
   const ChunkSet& GetMeshesToUpdate() {
