@@ -197,6 +197,11 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
+    if world > 1:
+        # N ranks share the container's CPU quota (16 CPUs on the 1-GPU boxes): a rank's host thread sleeps between polls of
+        # "is my upload / my staging slot through" instead of spinning, so that eight ranks and their RCCL proxy threads do
+        # not exhaust a period's budget and get the whole job frozen (profiles/r4/README.md, "Host frames")
+        os.environ.setdefault("TF_HOST_POLL_SLEEP_US", "20")
     orig_affinity, numa_note = pin_to_numa_node(local_rank)  # before any buffer is allocated
     from texturefusion_amd import synth
     cam = synth.Camera.hires() if args.hires else synth.Camera()

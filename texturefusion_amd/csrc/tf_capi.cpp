@@ -1069,6 +1069,8 @@ static int host_slot_wait(tf_volume* v, tf_volume::HostSlot& s) {
   const auto t0 = std::chrono::steady_clock::now();
   for (uint32_t spin = 0;; ++spin) {
     if ((int32_t)(*p - s.free_when) >= 0) break;
+    static const int poll_sleep = getenv("TF_HOST_POLL_SLEEP_US") ? atoi(getenv("TF_HOST_POLL_SLEEP_US")) : 0;
+    if (poll_sleep > 0) { std::this_thread::sleep_for(std::chrono::microseconds(poll_sleep)); continue; }
     __builtin_ia32_pause();
     if ((spin & 1023u) == 1023u) {
       const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -1419,8 +1421,12 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   // the caller's buffers are its own again when the call returns: an upload straight out of them must be through
   auto wait_direct = [&]() {
     auto tw = now();
-    for (uint32_t spin = 0; hipEventQuery(s.copied) == hipErrorNotReady; ++spin)
-      if ((spin & 63u) == 63u) __builtin_ia32_pause();
+    // (TF_HOST_POLL_SLEEP_US > 0: sleep between polls instead of spinning -- several ranks under one CPU quota)
+    static const int poll_sleep = getenv("TF_HOST_POLL_SLEEP_US") ? atoi(getenv("TF_HOST_POLL_SLEEP_US")) : 0;
+    for (uint32_t spin = 0; hipEventQuery(s.copied) == hipErrorNotReady; ++spin) {
+      if (poll_sleep > 0) std::this_thread::sleep_for(std::chrono::microseconds(poll_sleep));
+      else if ((spin & 63u) == 63u) __builtin_ia32_pause();
+    }
     lap(1, tw);
   };
   if (!defer) {  // integrate at once: two selection-only launches per frame, the stream waits for the copy
