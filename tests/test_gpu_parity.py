@@ -380,3 +380,32 @@ def test_rgb_plus_valid_mask_packs_like_the_callers_loop(gpu_required):
     sb, wb, cb = b.get_chunks(ids)
     assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32)) and np.array_equal(wa.view(np.uint32), wb.view(np.uint32))
     assert np.array_equal(ca, cb) and ca.any()
+
+
+def test_non_finite_and_negative_depth_pixels(gpu_required):
+    """Depth images with NaN, +-Inf, negative, huge and denormal pixels (what a filter chain ahead of the path can leave
+    behind): the reference's comparisons are all ordered (false on NaN), its min / max reductions keep the running value --
+    bounding box, selection, voxel update, colour and the fused per-frame unit must agree with the oracle bit for bit."""
+    ov, gv, cam, ig = make_pair(max_chunks=1 << 16)
+    rng = np.random.default_rng(99)
+    for it, k in enumerate((3, 4, 5)):
+        depth, rgba, quality, pose = synth.room_frame(k, cam)
+        depth = depth.copy()
+        H, W = depth.shape
+        bad = [np.nan, np.inf, -np.inf, -1.5, 1e30, 1e-40, 0.0, 5.0, 0.01]
+        ys = rng.integers(0, H, 4000); xs = rng.integers(0, W, 4000)
+        depth[ys, xs] = np.float32(rng.choice(bad, 4000))
+        depth[100:104, 200:260] = np.nan        # a block of NaNs: whole rows of a chunk's footprint
+        depth[300:303, 50:90] = np.inf
+        if it < 2:
+            _frame_flow(ov, gv, depth, rgba, quality, pose, kf_id=it, use_quality=True)
+        else:  # the fused unit on the same kind of image
+            ov.integrate_frame(depth, rgba, pose)
+            gv.frame_upload(depth, rgba, None)
+            gv.integrate_frame(pose, True)
+            gv.sync()
+    ids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(ids, sorted_ids(gv.list_chunks()))
+    assert_chunks_equal(ov, gv, ids[::3], "non-finite depth")
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+    gv.close()
