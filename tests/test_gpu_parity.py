@@ -409,3 +409,37 @@ def test_non_finite_and_negative_depth_pixels(gpu_required):
     assert_chunks_equal(ov, gv, ids[::3], "non-finite depth")
     assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
     gv.close()
+
+
+def test_list_and_candidate_grid_capacity_errors_leave_no_trace(gpu_required):
+    """A frame whose visible list (tf_config.max_list) or candidate grid (max_coarse) does not fit is an error of THAT call
+    -- call by call and in the fused unit (where the frame is skipped as a whole) --, the sticky status is cleared by the
+    call that reports it, and the volume goes on exactly like one that never saw the frame."""
+    cam = synth.Camera()
+    big = synth.room_frame(7, cam)            # ~10 k chunks
+    small = synth.wall_frame(0.35, cam, seed=3)  # a wall 35 cm away: a few hundred chunks
+    for kw, text in ((dict(max_list=512), "visible list full"), (dict(max_coarse=64), "candidate grid full")):
+        ov, gv, cam, ig = make_pair(cam=cam, max_chunks=1 << 16, **kw)
+        gv.frame_upload(big[0], big[1], None)
+        with pytest.raises(capi.TFError) as e:
+            gv.prepare(big[3])
+        assert e.value.code == capi.TF_ERR_CAPACITY and text in str(e.value)
+        with pytest.raises(capi.TFError) as e:   # the fused unit: enqueued, reported by the next synchronising call
+            gv.integrate_frame(big[3], True)
+            gv.sync()
+        assert e.value.code == capi.TF_ERR_CAPACITY and text in str(e.value)
+        gv.sync()                                 # (cleared)
+        assert len(gv.list_chunks()) == 0 or kw.get("max_coarse")  # nothing of the oversized frame was integrated ...
+        n_before = len(gv.list_chunks())
+        if kw.get("max_coarse") is None:
+            # ... and a frame that fits runs as on a fresh volume
+            ov.integrate_frame(small[0], small[1], small[3])
+            gv.frame_upload(small[0], small[1], None)
+            gv.integrate_frame(small[3], True)
+            gv.sync()
+            ids = sorted_ids(ov.list_chunks())
+            assert len(ids) > 50 and np.array_equal(ids, sorted_ids(gv.list_chunks()))
+            assert_chunks_equal(ov, gv, ids, "after a capacity error")
+        else:
+            assert n_before == 0
+        gv.close()
