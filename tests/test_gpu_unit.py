@@ -281,3 +281,31 @@ def test_unit_form_knobs(gpu_required, knob):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "3 passed" in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("n_local", [0, 1, 6])
+def test_keyframe_groups_of_every_size(gpu_required, n_local):
+    """a keyframe alone (no local frame), with one, and with the maximum of six (integrateLocalFrameNum): TSDF-only unit
+    calls (texture = 0) against the oracle's ReIntegrateKeyframe, two keyframes in a row"""
+    cam = synth.Camera()
+    ov = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    fr = [synth.room_frame(k, cam, with_quality=True) for k in range(2 * (1 + n_local))]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1]), HipBuffer(f[2].nbytes).from_host(f[2]))
+            for f in fr]
+    for g in range(2):
+        k0 = g * (1 + n_local)
+        loc = list(range(k0 + 1, k0 + 1 + n_local))
+        grp = capi.Volume.unit_group(20 + g, (bufs[k0][0].ptr, bufs[k0][1].ptr, bufs[k0][2].ptr, fr[k0][3]),
+                                     [(bufs[k][0].ptr, fr[k][3]) for k in loc])
+        gv.keyframe_unit(fresh=grp, texture=False)
+        _oracle_group(ov, 20 + g, fr[k0], [(fr[k][0], fr[k][3]) for k in loc], 1)
+    gv.sync()
+    ids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(ids, sorted_ids(gv.list_chunks())) and len(ids) > 1000
+    assert_chunks_equal(ov, gv, ids[::7], "group of 1 + %d frames" % n_local)
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+    for b in bufs:
+        for x in b:
+            x.free()
+    gv.close()
