@@ -332,14 +332,17 @@ def test_rccl_single_rank_plumbing(gpu_required):
         p[0].free(); p[1].free()
 
 
-def test_sized_neighbour_exchange_three_partitions_textured(gpu_required):
+@pytest.mark.parametrize("edges,min_recv", [((24, 46), 300), ((-400, -390), 0), ((40, 44), 100)])
+def test_sized_neighbour_exchange_three_partitions_textured(gpu_required, edges, min_recv):
     """The SIZED neighbour exchange (tf_boundary_band_bounds / tf_boundary_pack_bands2 / tf_boundary_unpack_pair) with
     the textured unit on three consecutive x + y + z slabs of one GPU.  Every rank sizes its four blocks from its own
     copy of the frame's selection; the test checks that the two sides of every transfer computed the SAME capacity (on a
     real transport a mismatch is a hang), that nothing overflowed, that the bytes moved stay within 1.5x of what the
     records need, and that chunks and meshes of the union equal the single volume bit for bit."""
+    # (second case: two slabs far outside the scene -- empty lists, empty blocks of the minimum size, one rank does all the
+    # work; third case: a middle slab of the minimum width the neighbour form allows, a + b + c + 1 = 4 keys)
     cam = synth.Camera()
-    axis, edges = (1, 1, 1), (24, 46)
+    axis = (1, 1, 1)
     bounds = [-(1 << 31), edges[0], edges[1], (1 << 31) - 1]
     single = capi.Volume(RES5, cam, max_chunks=1 << 16)
     parts = [capi.Volume(RES5, cam, max_chunks=1 << 16) for _ in range(3)]
@@ -391,10 +394,11 @@ def test_sized_neighbour_exchange_three_partitions_textured(gpu_required):
     sent = sum(v.comm_stats_ex()["records_sent"] for v in parts)
     recv = sum(v.comm_stats_ex()["records_received"] for v in parts)
     # rank 0's down block and rank 2's up block go nowhere (no such neighbour): records_sent counts them, the wire does not
-    assert recv > 300 and sent >= recv
+    assert recv >= min_recv and sent >= recv
     # (a cold volume, frames three orbit steps apart: selected / updated is at its largest here, ~1.4, + 8-record buckets;
     # tools/exp_sized_exchange.py measures the steady-state stream of the bench)
-    assert wire <= 1.6 * recv * capi.TF_BOUNDARY_RECORD_BYTES, (wire, recv)
+    if min_recv >= 300:
+        assert wire <= 1.6 * recv * capi.TF_BOUNDARY_RECORD_BYTES, (wire, recv)
     ref_ids = sorted_ids(single.list_chunks())
     key = {tuple(c): i for i, c in enumerate(ref_ids)}
     s_ref, w_ref, c_ref = single.get_chunks(ref_ids)
