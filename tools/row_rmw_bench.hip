@@ -46,7 +46,15 @@ int main() {
   hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
   const int grid = pr.multiProcessorCount * 7;
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  printf("%s, %d CUs, grid %d x 256 (7 waves per SIMD), %u chunks per launch\n", pr.name, pr.multiProcessorCount, grid, nlist);
+  float pair = 1e9f;  // what an (almost) empty launch costs between the same two events: taken off below
+  for (int rep = 0; rep < 8; ++rep) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_rows, dim3(1), dim3(256), 0, 0, A, B, perm, 0u, 0u, 0);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    if (rep && ms < pair) pair = ms;
+  }
+  printf("%s, %d CUs, grid %d x 256 (7 waves per SIMD); an empty launch between the two events: %.1f us (taken off in the last column)\n", pr.name, pr.multiProcessorCount, grid, pair * 1e3);
   for (unsigned nl : {nlist, 11000u})  // 80 k chunks (ramp and tail amortised) and one S-room frame's worth
   for (int both = 0; both <= 1; ++both)
     for (unsigned th : {256u, 192u, 128u, 64u, 32u}) {
@@ -62,7 +70,7 @@ int main() {
       }
       rows = (double)nl * 64.0 * th / 256.0;
       const double bytes = rows * 128.0 * (both ? 2 : 1);  // read + write of 64 B per rewritten row and plane
-      printf("%6u chunks, planes %d, %3u/256 of the rows rewritten: %7.1f us, %6.2f TB/s algorithmic (%.0f MB)\n", nl, both + 1, th, best * 1e3, bytes / (best * 1e-3) / 1e12, bytes / 1e6);
+      printf("%6u chunks, planes %d, %3u/256 of the rows rewritten: %7.1f us, %6.2f TB/s algorithmic (%.0f MB) | without the launch: %6.1f us, %5.2f TB/s\n", nl, both + 1, th, best * 1e3, bytes / (best * 1e-3) / 1e12, bytes / 1e6, (best - pair) * 1e3, bytes / ((best - pair) * 1e-3) / 1e12);
     }
   {  // the same amount of data as a streaming read-modify-write
     const size_t n = (size_t)nlist * 8192 / 16;
@@ -74,7 +82,7 @@ int main() {
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
       if (rep && ms < best) best = ms;
     }
-    printf("streaming RMW of the same %.0f MB: %7.1f us, %6.2f TB/s\n", (double)n * 16 / 1e6, best * 1e3, (double)n * 32 / (best * 1e-3) / 1e12);
+    printf("streaming RMW of the same %.0f MB: %7.1f us, %6.2f TB/s | without the launch: %6.1f us, %5.2f TB/s\n", (double)n * 16 / 1e6, best * 1e3, (double)n * 32 / (best * 1e-3) / 1e12, (best - pair) * 1e3, (double)n * 32 / ((best - pair) * 1e-3) / 1e12);
   }
   return 0;
 }
