@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--staged-host-frames", action="store_true",
                     help="the timed host frames go through the library's pinned staging slots (a CPU copy per frame by a pool of "
                          "helper threads) instead of straight out of the caller's arrays, registered once with tf_host_register")
+    ap.add_argument("--no-independent", action="store_true",
+                    help="N>1: skip the independent-streams (one whole volume per GPU) and sharded keyframe-unit figures")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N>1 code path (partition + boundary exchange) even with one rank (smoke test)")
     return ap.parse_args()
@@ -187,14 +189,96 @@ def under_profiler():
     return "rocprof" in pre or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
 
 
+def visible_gpus():
+    """HIP devices this process could use, WITHOUT initialising the GPU (the launcher below must stay a process that
+    never touched it: its children are started with fork + exec).  torch.cuda.device_count() reads the driver's device
+    list on this image and makes no HIP context; the sysfs census of KFD nodes is the fallback."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        pass
+    try:
+        import glob
+        n = 0
+        for p in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            props = dict(l.split()[:2] for l in open(p).read().splitlines() if len(l.split()) >= 2)
+            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+        return n
+    except Exception:
+        return 0
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): this process becomes the
+    launcher.  It starts N fresh child processes of this very command -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, one
+    per GPU -- BEFORE it makes any GPU call itself (it never does), passes rank 0's JSON line through, and fails when
+    fewer than N devices are visible or any rank fails: an N = 1 number is never printed under an N > 1 flag."""
+    import socket
+    import subprocess
+    n = args.gpus
+    one_gpu_hook = "TF_BENCH_DEVICE" in os.environ  # (tests: several ranks on ONE device, blocks over gloo)
+    have = visible_gpus()
+    if not one_gpu_hook and have < n:
+        sys.stderr.write("bench.py: --gpus %d but only %d HIP device(s) visible -- not running (a smaller job under this flag "
+                         "would be a wrong number)\n" % (n, have))
+        return 3
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:  # a free rendezvous port on the loopback
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    import tempfile
+    procs = []
+    rc = 0
+    with tempfile.TemporaryFile(mode="w+") as out0:  # rank 0's stdout (the other ranks print nothing there)
+        try:
+            for r in range(n):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), TF_BENCH_SPAWNED="1")
+                env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL between processes needs it on this pool)
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, cwd=ROOT,
+                                              stdout=out0 if r == 0 else subprocess.DEVNULL))
+            deadline = time.time() + float(os.environ.get("TF_BENCH_SPAWN_TIMEOUT", "1500"))
+            while any(p.poll() is None for p in procs):
+                bad = [(r, p.returncode) for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+                if bad or time.time() > deadline:  # one rank gone (or the job stuck): the others would wait in a collective
+                    rc = (bad[0][1] if bad else 4) or 1
+                    break
+                time.sleep(0.05)
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    sys.stderr.write("bench.py: rank %d exited with %s\n" % (r, p.returncode))
+                    rc = rc or int(p.returncode) or 1
+        finally:
+            for p in procs:  # (exactly the processes started here)
+                if p.poll() is None:
+                    p.kill()
+                    p.wait()
+        out0.seek(0)
+        text = out0.read()
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        sys.stderr.write("bench.py: rank 0 printed %d JSON lines\n" % len(lines))
+        rc = 5
+    if rc == 0:
+        d = json.loads(lines[0])
+        if d.get("n_gpus") != n:
+            sys.stderr.write("bench.py: rank 0 reports n_gpus = %r under --gpus %d\n" % (d.get("n_gpus"), n))
+            rc = 6
+    if rc == 0:
+        print(lines[0])
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.child:
+        raise SystemExit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "TF_BENCH_DEVICE" in os.environ:  # test hook: several ranks on one GPU (with TF_BENCH_BACKEND=gloo)
         local_rank = int(os.environ["TF_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     if world > 1:
@@ -474,6 +558,23 @@ def main():
         vol.close()
         return
 
+    # ---- N > 1: the same N GPUs as N INDEPENDENT streams (one whole volume per GPU, no partition, no exchange: SURVEY.md
+    # s.8(e)'s stated fallback, "replicas") and the sharded keyframe unit -- printed next to the strong-scaling `value`
+    indep = sharded_unit = None
+    if multi and not args.no_independent:
+        vol.close()  # (its registered host ranges are released: the replica volume registers the same arrays)
+        try:
+            indep = independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses, pinv, a_depth, a_rgba, a_pose,
+                                        a_pinv, n_unique, local_rank, world, dist if world > 1 else None, dev, textured, fresh_period)
+        except Exception as e:  # (a side figure: never fail the bench line for it)
+            indep = {"error": repr(e)[:300]}
+        if use_rccl and textured and not args.no_group:
+            try:
+                sharded_unit = sharded_keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, local_rank, rank, world,
+                                                     dist, dev, (lo, hi, axis), args.exchange_cap)
+            except Exception as e:
+                sharded_unit = {"error": repr(e)[:300]}
+
     def skip_to_window():
         """advance the stream (untimed, resident frames) to the timed window's orbit position in the next turn"""
         nonlocal pos
@@ -682,6 +783,10 @@ def main():
         out["host_phases_us_per_step"] = host_phases
     if per_rank is not None:
         out["per_rank"] = per_rank
+    if indep is not None:
+        out["independent_streams"] = indep
+    if sharded_unit is not None:
+        out["keyframe_unit_sharded"] = sharded_unit
 
     # ---- roofline over ALL kernels of a step ------------------------------------------------
     if rank == 0 and prof is not None and not multi:
@@ -712,6 +817,131 @@ def main():
     vol.close()
     if multi:
         dist.destroy_process_group()
+
+
+def independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses, pinv, a_depth, a_rgba, a_pose, a_pinv,
+                        n_unique, device, world, dist, dev, textured, fresh_period):
+    """N GPUs as N independent streams: every rank integrates the WHOLE stream into a volume of its own (no partition, no
+    exchange) -- the reference scaled out by running one sequence per GPU.  Same method as the N = 1 headline: pre-roll
+    of one orbit, warm-up, K host frames (H2D inside), barrier + device synchronisation on both sides, MAX over ranks;
+    value = N x K / that time ("weak": per-GPU work is fixed)."""
+    import torch
+    from texturefusion_amd import capi
+    K, Wm = args.steps, args.warmup
+    big = args.scene == "big"
+    vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+                      max_coarse=1 << 22 if big else 1 << 20, device=device)
+    registered = False
+    if not args.staged_host_frames:
+        try:
+            vol.host_register(h_depth)
+            vol.host_register(h_rgba)
+            registered = True
+        except Exception:
+            pass
+
+    def run(first, count, ahead=2):
+        idx = [(first + i) % n_unique for i in range(count + ahead)]
+        dd = [d_depth[i].data_ptr() for i in idx]
+        dr = [d_rgba[i].data_ptr() for i in idx]
+        if textured:
+            vol.stream_frames_textured_device(dd, dr, poses[idx], pinv[idx], first, n_ahead=ahead)
+        else:
+            vol.stream_frames_device(dd, dr, poses[idx], n_ahead=ahead)
+
+    def run_host(first, count):
+        for j in range(count):
+            i = (first + j) % n_unique
+            vol.integrate_frame_host_addr(a_depth[i], a_rgba[i], a_pose[i], a_pinv[i] if textured else 0, first + j)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    pos = 0
+    if not args.no_preroll:
+        run(0, n_unique)
+        pos = n_unique
+    fresh_period()
+    run_host(pos, Wm)
+    barrier()
+    t0 = time.perf_counter()
+    run_host(pos + Wm, K)
+    barrier()
+    dt = time.perf_counter() - t0
+    vol.sync()
+    mine = 1e3 * dt / K
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        allms = [None] * world
+        dist.all_gather_object(allms, mine)
+    else:
+        allms = [mine]
+    vol.close()
+    return {"value": world * K / dt, "unit": "frames/s", "scaling": "weak", "n_gpus": world, "ms_per_step_per_stream": 1e3 * dt / K,
+            "per_rank_ms_per_step": allms, "host_buffers": "registered" if registered else "staged",
+            "note": "%d independent streams, one whole (unpartitioned) volume per GPU, no exchange: every rank runs the N = 1 "
+                    "headline workload (host frames, H2D inside) on its own GPU at the same time; value = N x K / max-over-ranks "
+                    "time" % world}
+
+
+def sharded_keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device, rank, world, dist, dev, part_spec, cap):
+    """tf_keyframe_unit_device (one call per keyframe: 1 colour + 6 depth frames, meshes, patches, atlas) on the
+    chunk-range partition of the strong-scaling run: every rank runs every keyframe over its slab, the ghost band is
+    exchanged (fixed-capacity neighbour blocks: the unit's lists are not sized by a fused selection) once per keyframe
+    ahead of the mesher.  Seven frames of voxel work per exchange instead of one."""
+    import torch
+    from texturefusion_amd import capi
+    lo, hi, axis = part_spec
+    n_local = 6
+    stride = 1 + n_local
+    n_kf = max(4, min(24, n_unique // stride - 1))
+    big = args.scene == "big"
+    s_main = torch.cuda.Stream(device=dev)
+    vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+                      max_coarse=(1 << 22) if big else (1 << 20), device=device, stream=s_main.cuda_stream)
+    vol.set_partition(lo, hi, axis)
+    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(uid, 0)
+    vol.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+    vol.comm_exchange_every_frame(cap)
+
+    def call(g):
+        k0 = (stride * g) % n_unique
+        loc = [(k0 + 1 + i) % n_unique for i in range(n_local)]
+        fresh = capi.Volume.unit_group(1000 + g, (d_depth[k0].data_ptr(), d_rgba[k0].data_ptr(), 0, poses[k0]),
+                                       [(d_depth[k].data_ptr(), poses[k]) for k in loc])
+        vol.keyframe_unit(fresh=fresh, moved=[], texture=True, pose_inv16=pinv[k0])
+
+    warm = 4
+    for g in range(warm):
+        call(g)
+    vol.sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for g in range(warm, warm + n_kf):
+        call(g)
+    vol.sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    st = vol.comm_stats_ex()
+    vol.close()
+    return {"keyframes_per_s": n_kf / dt, "ms_per_keyframe": 1e3 * dt / n_kf, "frame_integrations_per_s": n_kf * stride / dt,
+            "keyframes": n_kf, "n_gpus": world, "scaling": "strong", "exchanges": st["exchanges"],
+            "exchange_bytes_sent_rank0": st["bytes_sent"],
+            "note": "one tf_keyframe_unit_device call per keyframe on every rank over its slab of the chunk-range partition; one "
+                    "fixed-capacity neighbour exchange (%d records per block) per keyframe between the group's voxel updates and "
+                    "the mesher" % cap}
 
 
 def roofline(args, vol, cam, prof, kinds, K, first, n_unique, d_depth, d_rgba, poses, pinv, textured, dt_instr, pair_us,

@@ -507,3 +507,46 @@ def test_rccl_single_rank_sized_per_frame_exchange(gpu_required, ahead):
     a.close(); b.close()
     for p in bufs:
         p[0].free(); p[1].free()
+
+
+@pytest.mark.parametrize("flow", ["texture_frame_device", "keyframe_unit"])
+def test_rccl_single_rank_exchange_behind_lists_without_band_counts(gpu_required, flow):
+    """The per-frame exchange behind entry points whose lists carry NO band counts (tf_texture_frame_device after a plain
+    voxel update; the keyframe unit, whose selection is the unordered non-fused one): the blocks must have the caller's fixed
+    capacity there -- sizing them from FrameCtl::band_cnt, which only the fused stream's selection role counts, gave
+    8-record blocks and TF_ERR_CAPACITY as soon as more than eight band chunks were touched."""
+    cam = synth.Camera()
+    a = capi.Volume(RES5, cam, max_chunks=1 << 15)
+    b = capi.Volume(RES5, cam, max_chunks=1 << 15)
+    for v in (a, b):
+        v.set_partition(20, 48, (1, 1, 1))
+    b.comm_init(0, 1, capi.comm_unique_id())
+    b.comm_exchange_every_frame(2048)
+    n = 7 if flow == "keyframe_unit" else 4
+    frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(n)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+    if flow == "texture_frame_device":
+        for k, f in enumerate(frames):
+            T = synth.pose_inverse16(f[3])
+            for v in (a, b):
+                v.stream_frames_device([bufs[k][0].ptr], [bufs[k][1].ptr], f[3].reshape(1, 12))
+                v.texture_frame_device(T, k)
+        want_x = n
+    else:
+        for v in (a, b):
+            g = capi.Volume.unit_group(77, (bufs[0][0].ptr, bufs[0][1].ptr, 0, frames[0][3]),
+                                       [(bufs[k][0].ptr, frames[k][3]) for k in range(1, 7)])
+            v.keyframe_unit(fresh=g, moved=[], texture=True, pose_inv16=synth.pose_inverse16(frames[0][3]))
+        want_x = 1
+    a.sync(); b.sync()   # (TF_ERR_CAPACITY here = a block was sized from counts nobody made)
+    st = b.comm_stats_ex()
+    assert st["exchanges"] == want_x and st["records_sent"] > 8
+    ia, ib = sorted_ids(a.list_chunks()), sorted_ids(b.list_chunks())
+    assert np.array_equal(ia, ib) and len(ia) > 500
+    sa, wa, ca = a.get_chunks(ia[::7]); sb, wb, cb = b.get_chunks(ia[::7])
+    assert np.array_equal(sa.view(np.uint32), sb.view(np.uint32)) and np.array_equal(ca, cb)
+    ma, mb = sorted_ids(a.list_meshes()), sorted_ids(b.list_meshes())
+    assert np.array_equal(ma, mb)
+    a.close(); b.close()
+    for p in bufs:
+        p[0].free(); p[1].free()

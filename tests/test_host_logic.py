@@ -1,5 +1,8 @@
 """Host-side logic that needs no GPU: synthetic streams, partition planner, host constants."""
+import os
+
 import numpy as np
+import pytest
 
 from oracle import api as O
 from texturefusion_amd import partition as part
@@ -100,3 +103,29 @@ def test_balanced_edges_split_a_sample_evenly_and_cover_everything():
     assert np.bincount(part.owner_of_key(wall, ex, (1, 0, 0)), minlength=4).max() == len(wall)
     assert np.bincount(part.owner_of_key(wall, ed, (1, 1, 1)), minlength=4).max() < 0.3 * len(wall)
     assert part.balanced_edges([], 3)[1:-1] == [1, 2]
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus 8` with no launcher around it and fewer than eight devices visible (none in the CPU container)
+    exits non-zero without printing a line -- never an N = 1 number under an N = 8 flag (missing 2)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("eight devices visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TF_BENCH_DEVICE", "TF_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1"], cwd=root,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "device" in r.stderr
+
+
+def test_bench_rejects_a_world_size_that_contradicts_the_flag():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "1"], cwd=root,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr

@@ -181,11 +181,7 @@ static int init_device_state(tf_volume* v) {
   v->mesh_epoch = 0;
   v->mesh_par = 0;
   v->n_primed = 0;
-  v->xchg_pub_enq = 0;
-  if (v->h_xchg) {  // epochs start over: a tag of the old numbering must not be mistaken for a new frame's
-    TF_HIP(hipStreamSynchronize(s));
-    memset(v->h_xchg, 0, 64);
-  }
+  v->xchg_pub_enq = 0;  // (epochs start over; the publish sequence numbers the host waits for do not)
   return TF_OK;
 }
 
@@ -211,14 +207,19 @@ int tf::xchg_band_counts(tf_volume* v, const tf::FrameCtl* ctl, uint32_t tag, ui
     memset(v->h_xchg, 0, 64);
   }
   if (v->xchg_pub_enq != tag) {  // nobody published this frame's counts behind an earlier exchange: do it now
-    launch_xchg_publish(ctl, v->h_xchg, tag, v->stream);
+    // (the word the host waits for is a publish SEQUENCE number, never reused: a frame that replaces a discarded selection
+    // has the same epoch tag as the frame it replaces, and the old publish may still sit in the pinned word)
+    const uint32_t seq = ++v->xchg_seq;
+    launch_xchg_publish(ctl, v->h_xchg, seq, v->stream);
     TF_HIP(hipGetLastError());
     v->xchg_pub_enq = tag;
+    v->xchg_pub_seq = seq;
   }
   // the publishing launch sits behind the selection on the stream; the words arrive with a system-scope release
   volatile uint32_t* w = v->h_xchg;
+  const uint32_t want = v->xchg_pub_seq;
   const auto t0 = std::chrono::steady_clock::now();
-  for (uint64_t spin = 0; __atomic_load_n(&w[0], __ATOMIC_ACQUIRE) != tag; ++spin) {
+  for (uint64_t spin = 0; __atomic_load_n(&w[0], __ATOMIC_ACQUIRE) != want; ++spin) {
     if ((spin & 0xFFFu) == 0xFFFu) {
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
         set_error("band counts of the frame never arrived (device stalled?)");
@@ -841,7 +842,8 @@ int tf::fused_arm(tf_volume* v) {
 // claimed: the dirty set of this frame is already in the lists of the current parity -- K-A built it (FrameStage::claim_par
 // = the parity used here), or the caller ran launch_dirty_frame over each of its lists (the keyframe unit)
 int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
-                      const float* pose_inv16, int32_t frame_id, bool claimed, const FrameCtl* next_ctl, bool ride_filter) {
+                      const float* pose_inv16, int32_t frame_id, bool claimed, const FrameCtl* next_ctl, bool ride_filter,
+                      bool sized_xchg) {
   AtlasState& a = v->atlas;
   // A patch stage still pending here (the previous textured frame's) must read its meshes before this frame's mesher
   // rewrites them: it goes out on its own first -- or, with TF_PATCH_IN_FILTER=1, rides on this frame's FILTER launch
@@ -868,8 +870,10 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
   else launch_dirty_frame(d, par, frame_epoch + 1u, v->stream);
   prof_end(v);
   if (v->comm_cap > 0) {  // multi-GPU: ghost bands of this frame's updates, before the mesher reads them
-    // (sized by this frame's selection: sel.ctl holds the band counts, tagged with the frame's epoch + 1)
-    rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u, sel.ctl, frame_epoch + 1u, next_ctl);
+    // (sized by this frame's selection when the fused stream ran it -- sel.ctl then holds the band counts, tagged with the
+    // frame's epoch + 1; lists of the call-by-call flow and the keyframe unit carry no counts: fixed-capacity blocks)
+    rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u, sized_xchg ? sel.ctl : nullptr, frame_epoch + 1u,
+                       sized_xchg ? next_ctl : nullptr);
     if (rc) return rc;
   }
   prof_begin(v, TF_PROF_MESH);
@@ -1011,7 +1015,7 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     if (hc && tex) {
       // (the next frame's selection role rode on this launch: its band counts can be published behind this frame's exchange)
       int rc = texture_stage(v, cur.sel, cur.img, cur.epoch, tex->pose_inv16 + 16 * i, tex->first_frame_id + (int32_t)i, claimed,
-                             hn ? nxt.sel.ctl : nullptr);
+                             hn ? nxt.sel.ctl : nullptr, false, /*sized_xchg=*/true);
       if (rc) return rc;
     }
   }

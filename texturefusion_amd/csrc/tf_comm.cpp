@@ -86,12 +86,12 @@ static int comm_check_partition(tf_volume* v) {
   int32_t mine[8] = {v->dev.part_lo, v->dev.part_hi, v->dev.part_a, v->dev.part_b, v->dev.part_c, 0, 0, 0};
   int32_t* d_buf = nullptr;
   TF_HIP(hipMalloc((void**)&d_buf, sizeof(mine) * (size_t)(n + 1)));
+  struct Free { int32_t* p; ~Free() { if (p) hipFree(p); } } guard{d_buf};  // (also on the error returns below)
   TF_HIP(hipMemcpyAsync(d_buf, mine, sizeof(mine), hipMemcpyHostToDevice, v->stream));
   TF_NCCL(g_rccl.AllGather(d_buf, d_buf + 8, sizeof(mine), ncclUint8, comm, v->stream));
   std::vector<int32_t> all((size_t)8 * n);
   TF_HIP(hipMemcpyAsync(all.data(), d_buf + 8, sizeof(mine) * (size_t)n, hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
-  hipFree(d_buf);
   bool ok = true;
   for (int r = 0; r < n; ++r) {
     const int32_t* p = &all[(size_t)8 * r];
@@ -197,9 +197,10 @@ int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t sta
       TF_HIP(hipHostMalloc((void**)&v->h_xchg, 64, hipHostMallocDefault));
       memset(v->h_xchg, 0, 64);
     }
+    const uint32_t pub_seq = pub ? ++v->xchg_seq : 0u;  // (a sequence number of its own: see xchg_band_counts)
     launch_boundary_unpack_blocks(d, recv, 2, -1, cap_lo, dirty_par, stamp, v->stream, recv + block, cap_hi,
-                                  pub ? next_ctl : nullptr, pub ? v->h_xchg : nullptr, pub ? tag + 1u : 0u);
-    if (pub) v->xchg_pub_enq = tag + 1u;
+                                  pub ? next_ctl : nullptr, pub ? v->h_xchg : nullptr, pub_seq);
+    if (pub) { v->xchg_pub_enq = tag + 1u; v->xchg_pub_seq = pub_seq; }
   } else {
     rc = tf_boundary_pack_block(v, send, c.cap_records);
     if (rc) return rc;

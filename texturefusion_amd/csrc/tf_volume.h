@@ -237,7 +237,9 @@ struct tf_volume {
   int64_t comm_cap = 0;  // > 0: the fused textured flow exchanges the ghost band after every voxel update
   // band counts of a frame's selection as the host sees them: pinned words [0] tag (frame epoch + 1), [1..4] FrameCtl::band_cnt
   uint32_t* h_xchg = nullptr;
-  uint32_t xchg_pub_enq = 0;  // tag of the publish that is already on the stream (0: none)
+  uint32_t xchg_pub_enq = 0;  // frame tag of the publish that is already on the stream (0: none)
+  uint32_t xchg_pub_seq = 0;  // ... the sequence number that publish writes into h_xchg[0] (what the host waits for)
+  uint32_t xchg_seq = 0;      // publish sequence numbers handed out (monotonic over the handle's life: a stale word never matches)
 };
 
 namespace tf {
@@ -249,7 +251,8 @@ int launch_prepare_unordered(tf_volume* v, const Pose& pose, hipStream_t s = nul
 // ride_filter: a patch stage still pending when the stage starts rides on its filter launch (the keyframe unit: there is
 // no k_frame launch for it to ride on) instead of going out as a launch of its own
 int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16,
-                  int32_t frame_id, bool claimed = false, const FrameCtl* next_ctl = nullptr, bool ride_filter = false);
+                  int32_t frame_id, bool claimed = false, const FrameCtl* next_ctl = nullptr, bool ride_filter = false,
+                  bool sized_xchg = false);  // sized_xchg: sel.ctl holds the frame's band counts (fused stream only)
 // the four band counts of the frame whose selection wrote `ctl` (tag = its epoch + 1): waits for the device to publish them
 int xchg_band_counts(tf_volume* v, const FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]);
 int flush_deferred(tf_volume* v);
