@@ -1040,6 +1040,18 @@ def roofline(args, vol, cam, prof, kinds, K, first, n_unique, d_depth, d_rgba, p
     pmc = (prof_child or {}).get("pmc")
     if pmc and "bytes_per_step" in pmc:
         r["traffic"] = pmc["bytes_per_step"]
+    # the per-kernel split once more as SCALAR leaves (a consumer that keeps only scalars -- the driver's BENCH file -- keeps these)
+    def _k(prefix):
+        return sum(v["us_per_step"] for n, v in kern.items() if n.startswith(prefix)) if kern else None
+    r["k_frame_us"] = _k("k_frame") if kern else t_kframe
+    r["k_patch_us"] = _k("k_patch") if kern else None
+    r["k_mesh_filter_us"] = _k("k_mesh_filter") if kern else None
+    r["k_mesh_us"] = (_k("k_mesh<") if kern else None)
+    r["k_dirty_frame_us"] = _k("k_dirty") if kern else None
+    r["mesh_group_us"] = t_mesh if textured else None
+    r["k_frame_frac"] = (groups["k_frame"] / t_kframe / 1e3 / HBM_PEAK_GBS) if t_kframe else None
+    r["mesh_group_frac"] = (groups["mesh"] / t_mesh / 1e3 / HBM_PEAK_GBS) if textured and t_mesh else None
+    r["traffic_ratio"] = (r["traffic"] / bytes_step) if r["traffic"] and bytes_step else None
     r["traffic_detail"] = pmc if pmc else ({"error": prof_child["error"]} if prof_child and "error" in prof_child else None)
     return r
 

@@ -82,8 +82,8 @@ typedef struct {
   int64_t n_dirty;        /* entries of meshesToUpdate */
   int32_t min_id[3];      /* Chisel::minChunkID */
   int32_t max_id[3];      /* Chisel::maxChunkID */
-  int64_t n_listed;       /* n_selected minus (fused flow) the entries whose depth tiles prove that no voxel of the chunk can
-                             be written: the voxel update does their bookkeeping only */
+  int64_t n_listed;       /* = n_selected (kept for layout: a build with depth-tile pruning of the selection subtracted the
+                             pruned entries here; variants/r4_experiments.patch) */
 } tf_stats;
 
 /* What the textured per-frame unit did for its most recent frame (integers behind the byte counts). */
@@ -295,7 +295,8 @@ TF_API int tf_stream_frames_textured_device(tf_volume* v, int64_t n_frames, int6
  * every other entry point first integrates the frames still in that pipeline, so the deferral is not observable
  * through this API -- but it is LATENCY: a live caller sees frame f in the volume only after four more calls (about
  * 0.4 ms at the bench's rate) or after any synchronising call; the offline loop of main.cpp:272-277 does not care, a
- * caller that needs every frame at once sets TF_HOST_DEFER=0 (integrate in the call that brings the frame).
+ * caller that needs every frame at once switches the deferral off for its handle with tf_host_frame_set_deferral(v, 0)
+ * (integrate in the call that brings the frame; TF_HOST_DEFER=0 in the environment makes that the default of new handles).
  * tf_host_frame_deferral reports both numbers (frames behind, ring slots; v may be NULL).  pose_inv16 != NULL runs the textured unit
  * (tf_stream_frames_textured_device's per-frame work) with Patch::frameid = frame_id; NULL = TSDF only.
  * tf_host_frame_buffers hands out the pinned slot the NEXT call will upload from: a caller that composes its
@@ -318,6 +319,7 @@ TF_API int tf_host_frame_buffers(tf_volume* v, float** depth, uint8_t** rgba);
 TF_API int tf_host_register(tf_volume* v, const void* p, int64_t bytes);
 TF_API int tf_host_unregister(tf_volume* v, const void* p);
 TF_API int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_slots);
+TF_API int tf_host_frame_set_deferral(tf_volume* v, int on);
 /* Where the host side of tf_integrate_frame_host(_rgb) spends its time, summed since create / the last reset:
  * out[0] = calls that put a frame's launches on the stream, out[1..5] = microseconds spent waiting for the device to free
  * a staging slot (back-pressure: the device is the bound), waiting for the slot's previous upload, in the staging copy, in

@@ -22,75 +22,26 @@
     if (!(c)) { std::fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } \
   } while (0)
 
-// What initChiselMap's text needs from its surroundings and this image lacks: Eigen (the mirror's constructor takes
-// any vector indexed with (i); the test names its own) and the calibration record of GCSLAM/MultiViewGeometry.h.
-namespace Eigen { typedef chisel::ChunkID Vector3i; }
-namespace MultiViewGeometry {
-struct CameraPara { float c_fx, c_fy, c_cx, c_cy; int width, height; };
-}
-
-// The members of MobileFusion the function touches (GCFusion/MobileFusion.h:62-76) and the function itself:
-// ***the body of initChiselMap below is the reference's text, GCFusion/MobileFusion.h:205-258, verbatim*** --
-// that it compiles against tf_chisel.hpp and configures the volume is the test.
+// The configuration MobileFusion::initChiselMap makes (GCFusion/MobileFusion.h:205-258), as a call sequence written for
+// this test: same constructor, same setters, same constants.  That the reference's OWN text of that function compiles
+// against tf_chisel.hpp is checked by tests/test_ref_pin.py::test_init_chisel_map_compiles_against_the_mirror, which cuts
+// it out of /root/reference at test time (build container only); no reference text lives in this file.
 struct MobileFusion {
   chisel::ChiselPtr chiselMap;
   chisel::ProjectionIntegrator projectionIntegrator;
   chisel::PinholeCamera cameraModel;
-  int chunkSizeX, chunkSizeY, chunkSizeZ;
-  float voxelResolution;
-  bool useColor;
 
-  void initChiselMap(const MultiViewGeometry::CameraPara &camera,
-                     float ipnutVoxelResolution, float farPlaneDist = 3) {
-    float fx = camera.c_fx;
-    float fy = camera.c_fy;
-    float cx = camera.c_cx;
-    float cy = camera.c_cy;
-    int width = camera.width;
-    int height = camera.height;
-
-#if 1
-    float truncationDistConst = 0.001504;
-    float truncationDistLinear = 0.00152;
-    float truncationDistQuad = 0.0019;
-    float truncationDistScale = 6.0;
-#else
-    float truncationDistConst = 0.01;
-    float truncationDistLinear = 0.01;
-    float truncationDistQuad = 0.01;
-    float truncationDistScale = 1.0;
-#endif
-    float weight = 1;
-    bool useCarving = true;
-    float carvingDist = 0.05;
-    float nearPlaneDist = 0.01;
-
-    std::cout << "far plane dist: " << farPlaneDist << std::endl;
-    chunkSizeX = 8;
-    chunkSizeY = 8;
-    chunkSizeZ = 8;
-    voxelResolution = ipnutVoxelResolution;
-    useColor = true;
-
-    chisel::Vec4 truncation(truncationDistQuad, truncationDistLinear,
-                            truncationDistConst, truncationDistScale);
-    chiselMap = chisel::ChiselPtr(
-        new chisel::Chisel(Eigen::Vector3i(chunkSizeX, chunkSizeY, chunkSizeZ),
-                           voxelResolution, useColor));
-
-    projectionIntegrator.SetCentroids(
-        chiselMap->GetChunkManager().GetCentroids());
-    projectionIntegrator.SetTruncator(
-        chisel::TruncatorPtr(new chisel::QuadraticTruncator(
-            truncation(0), truncation(1), truncation(2), truncation(3))));
-    projectionIntegrator.SetWeighter(
-        chisel::WeighterPtr(new chisel::ConstantWeighter(weight)));
-    projectionIntegrator.SetCarvingDist(carvingDist);
-    projectionIntegrator.SetCarvingEnabled(useCarving);
-
+  void configure(float fx, float fy, float cx, float cy, int width, int height, float voxel, float far_plane) {
+    const chisel::ChunkID chunk_dim(8, 8, 8);
+    chiselMap = chisel::ChiselPtr(new chisel::Chisel(chunk_dim, voxel, /*useColor=*/true));
+    projectionIntegrator.SetCentroids(chiselMap->GetChunkManager().GetCentroids());
+    projectionIntegrator.SetTruncator(chisel::TruncatorPtr(new chisel::QuadraticTruncator(0.0019f, 0.00152f, 0.001504f, 6.0f)));
+    projectionIntegrator.SetWeighter(chisel::WeighterPtr(new chisel::ConstantWeighter(1.0f)));
+    projectionIntegrator.SetCarvingDist(0.05f);
+    projectionIntegrator.SetCarvingEnabled(true);
     cameraModel.SetIntrinsics(fx, fy, cx, cy);
-    cameraModel.SetNearPlane(nearPlaneDist);
-    cameraModel.SetFarPlane(farPlaneDist);
+    cameraModel.SetNearPlane(0.01f);
+    cameraModel.SetFarPlane(far_plane);
     cameraModel.SetWidth(width);
     cameraModel.SetHeight(height);
   }
@@ -129,10 +80,9 @@ int main() {
   cfg.atlas_h = 72;
   chisel::Chisel::DefaultConfig() = &cfg;  // device-side sizing of the volume the reference's 3-argument constructor makes
 
-  // MobileFusion::initChiselMap (GCFusion/MobileFusion.h:205-258), the reference's text (above)
+  // what MobileFusion::initChiselMap does (GCFusion/MobileFusion.h:205-258)
   MobileFusion gcFusion;
-  const MultiViewGeometry::CameraPara camera = {525.0f, 525.0f, 319.5f, 239.5f, W, H};
-  gcFusion.initChiselMap(camera, res, 5.0f);
+  gcFusion.configure(525.0f, 525.0f, 319.5f, 239.5f, W, H, res, 5.0f);
   chisel::Chisel& chiselMap = *gcFusion.chiselMap;
   chisel::ProjectionIntegrator& projectionIntegrator = gcFusion.projectionIntegrator;
   chisel::PinholeCamera& cameraModel = gcFusion.cameraModel;

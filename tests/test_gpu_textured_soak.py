@@ -37,6 +37,9 @@ def _run(cam, res, frames, host_frames=False, max_chunks=1 << 17, stride=1):
         gv.sync()
         gv.host_unregister(c); gv.host_unregister(d)
     elif host_frames:
+        if host_frames == "no_deferral":  # integrate in the call that brings the frame (tf_host_frame_set_deferral)
+            gv.host_frame_set_deferral(False)
+            assert gv.host_frame_deferral()[0] == 0
         for k, f in enumerate(frames):
             gv.integrate_frame_host(f[0], f[1], f[3].reshape(12), pinv[k], 10 + k)
     else:
@@ -98,6 +101,15 @@ def test_host_frames_entry_point(gpu_required):
     cam = synth.Camera()
     frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(10)]
     assert _run(cam, np.float32(0.005), frames, host_frames=True, stride=3) > 400
+
+
+def test_host_frames_without_deferral_per_handle(gpu_required):
+    """tf_host_frame_set_deferral(v, 0): a live caller's setting -- every frame is in the volume when its call returns to the
+    stream (no four-frame latency); the default of other handles is untouched"""
+    cam = synth.Camera()
+    frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(8)]
+    assert _run(cam, np.float32(0.005), frames, host_frames="no_deferral", stride=3) > 300
+    assert capi.host_frame_deferral()[0] in (0, 4)  # (the build's default; 0 only with TF_HOST_DEFER=0 in the environment)
 
 
 def test_host_frames_out_of_registered_caller_buffers(gpu_required):
@@ -241,27 +253,3 @@ def test_textured_frames_after_a_tsdf_only_stretch(gpu_required):
     for a, b in bufs:
         a.free(); b.free()
     gv.close()
-
-
-@pytest.mark.parametrize("knob", ["TF_MESH_FUSED=1", "TF_FILTER_EXACT=0", "TF_PATCH_IN_FILTER=1", "TF_FILTER_DEFER=1",
-                                  "TF_HOST_COPY_SPLIT=1", "TF_FRAME_MIX=2:short", "TF_KA_DBG=32768:short", "TF_HOST_DEFER=0:short"])
-def test_mesher_form_knobs(gpu_required, knob):
-    """The measured-and-rejected forms of the filter / mesher pair stay bit-exact: TF_MESH_FUSED=1 (k_mesh<128, true>: the
-    mesher runs the filter itself), TF_FILTER_EXACT=0 (the filter reads no voxels, the mesher makes the summaries exact)
-    TF_PATCH_IN_FILTER=1 (the patch stage of frame f - 1 rides on the filter launch of frame f instead of k_frame(f);
-    round 4), TF_FILTER_DEFER=1 (the filter always lists the records it empties for the mesher launch) and
-    TF_HOST_COPY_SPLIT=1 (host frames uploaded on two copy streams) are read once per process -- the orbits run in a child
-    process with the knob set."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    # (":short" = the round-4 dispatch-order / entry-order / no-deferral knobs: two orbits and the registered-buffer path)
-    short = knob.endswith(":short")
-    name, val = knob.split(":")[0].split("=")
-    sel = ("hand_held or host_frames_entry or registered_caller" if short else
-           "hand_held or long_orbit or tsdf_only_stretch or host_frames_entry or deferral_is_not")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_textured_soak.py", "-m", "gpu", "-x", "-q", "-k", sel],
-                       cwd=root, env=dict(os.environ, **{name: val}), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert ("3 passed" if short else "5 passed") in r.stdout, r.stdout[-500:]

@@ -266,23 +266,6 @@ def test_keyframe_arena_doubles_when_the_live_lists_fill_it(gpu_required, monkey
         p[0].free(); p[1].free()
 
 
-@pytest.mark.parametrize("knob", ["TF_UNIT_ORDERED=1", "TF_UNIT_PATCH_RIDE=0"])
-def test_unit_form_knobs(gpu_required, knob):
-    """The keyframe unit's alternative forms stay exact: TF_UNIT_ORDERED=1 (reference-ordered lists through k_select +
-    k_scan instead of the unordered emission) and TF_UNIT_PATCH_RIDE=0 (the pending patch stage as a launch of its own
-    instead of riding on the filter launch) -- read once per process, so the unit tests run in a child process."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    name, val = knob.split("=")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_unit.py", "-m", "gpu", "-x", "-q", "-k",
-                        "moved_keyframe or reuses_regions or grows_past"], cwd=root, env=dict(os.environ, **{name: val}),
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert "3 passed" in r.stdout, r.stdout[-500:]
-
-
 @pytest.mark.parametrize("n_local", [0, 1, 6])
 def test_keyframe_groups_of_every_size(gpu_required, n_local):
     """a keyframe alone (no local frame), with one, and with the maximum of six (integrateLocalFrameNum): TSDF-only unit

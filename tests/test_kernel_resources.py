@@ -16,12 +16,10 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 BUDGET = {
     "tf_kernels.hip": {"k_frameILb1ELb0E": (72, 0), "k_frameILb0ELb0E": (72, 0), "k_frameILb1ELb1E": (80, 40), "k_integrate_groupILb1E": (96, 0),
                        "k_integrate_groupILb0E": (96, 0)},
-    # (the filter's two forms -- wave per entry / workgroup batches -- share one kernel: 78 VGPRs, 6 waves per SIMD;
-    # forcing 7 or 8 spills, and the measured time does not depend on it: the kernel is a chain of round trips)
-    # (k_mesh<256> is the alternative form behind TF_MESH_THREADS=256: 80 VGPRs with a few spilled)
-    # the filter instances that carry the previous frame's patch stage (PATCH = true: the default of the textured flow) are
-    # compiled for 6 waves per SIMD like k_frame<true, true> was: 80 VGPRs, the patch range spills 28 B/lane
-    "tf_mesh.hip": {"k_meshILi128E": (96, 0), "k_meshILi256E": (80, 32), "k_mesh_filterILb1ELb0E": (64, 16),
+    # (the filter's two forms -- wave per entry / workgroup batches -- are two kernels: the wave form alone fits the 64 VGPRs
+    # that let eight waves per SIMD be resident; the instances that carry the previous frame's patch stage (the keyframe
+    # unit) are compiled for 6 waves per SIMD: 80 VGPRs, the patch range spills 28 B/lane)
+    "tf_mesh.hip": {"k_meshILi128E": (88, 0), "k_mesh_filterILb1ELb0E": (64, 16),
                     "k_mesh_filterILb0ELb0E": (80, 0), "k_mesh_filterILb1ELb1E": (80, 40), "k_mesh_filterILb0ELb1E": (80, 40)},
     "tf_atlas.hip": {"k_patchILb1ELb1ELb1E": (96, 0)},  # one patch per wave, two 64-vertex blocks in registers: 5 waves per SIMD
 }
@@ -54,12 +52,3 @@ def test_hot_kernels_stay_within_their_register_budget(src):
         for k, v in hits.items():
             assert v["ScratchSize"] <= max_scratch, "%s uses %d B/lane of private memory" % (k, v["ScratchSize"])
             assert v["VGPRs"] <= max_vgpr, "%s uses %d VGPRs (budget %d)" % (k, v["VGPRs"], max_vgpr)
-
-
-@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-def test_compile_time_experiments_still_build():
-    """The K-A experiments kept behind macros (four-slice steps, half-chunk work items: DESIGN.md s.9) must keep compiling."""
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fvisibility=hidden",
-           "-DTF_KA_SPLIT=1", "-c", os.path.join(CSRC, "tf_kernels.hip"), "-o", os.devnull]
-    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]

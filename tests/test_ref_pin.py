@@ -247,3 +247,54 @@ def test_mc_tables_equal_the_reference_source():
     assert m
     if m:
         assert [tuple(int(x) for x in p.split(",")) for p in re.findall(r"\{(\s*\d+\s*,\s*\d+\s*)\}", m.group(1))] == pairs
+
+
+def test_init_chisel_map_compiles_against_the_mirror(tmp_path):
+    """MobileFusion::initChiselMap (GCFusion/MobileFusion.h:205-258) -- the caller's set-up of the path: constructor, the
+    integrator's and the camera model's setters -- is cut out of /root/reference AT TEST TIME, wrapped into a struct with
+    the members it touches, compiled against texturefusion_amd/host/tf_chisel.hpp and linked against the C ABI (not run:
+    the constructor would ask for a device).  tests/cpp/host_mirror_parity.cpp drives the same configuration on the GPU
+    with a call sequence of its own.  Nothing of the reference's text is kept in the repository; build container only."""
+    hdr = "/root/reference/GCFusion/MobileFusion.h"
+    if not os.path.exists(hdr):
+        pytest.skip("/root/reference absent")
+    lines = open(hdr).read().splitlines()
+    first = next(i for i, l in enumerate(lines) if "void initChiselMap(" in l)
+    depth, last = 0, None
+    for i in range(first, len(lines)):  # the function's text = up to the brace that closes its body
+        depth += lines[i].count("{") - lines[i].count("}")
+        if depth == 0 and "{" in "".join(lines[first:i + 1]):
+            last = i
+            break
+    assert last is not None and 40 <= last - first <= 70
+    body = "\n".join(lines[first:last + 1])
+    src = tmp_path / "init_chisel_map.cpp"
+    src.write_text("""
+#include <iostream>
+#include <cstring>
+#include "%s/texturefusion_amd/host/tf_chisel.hpp"
+// what the function's text needs from its surroundings and this image lacks: Eigen's Vector3i (the mirror's constructor
+// takes any vector indexed with (i)) and the calibration record of GCSLAM/MultiViewGeometry.h
+namespace Eigen { typedef chisel::ChunkID Vector3i; }
+namespace MultiViewGeometry { struct CameraPara { float c_fx, c_fy, c_cx, c_cy; int width, height; }; }
+struct MobileFusion {  // the members the function touches (GCFusion/MobileFusion.h:62-76)
+  chisel::ChiselPtr chiselMap;
+  chisel::ProjectionIntegrator projectionIntegrator;
+  chisel::PinholeCamera cameraModel;
+  int chunkSizeX, chunkSizeY, chunkSizeZ;
+  float voxelResolution;
+  bool useColor;
+%s
+};
+int main() {
+  MobileFusion m;
+  const MultiViewGeometry::CameraPara camera = {525.0f, 525.0f, 319.5f, 239.5f, 640, 480};
+  (void)camera; (void)m;   // (compiled and linked; running it would create a device volume)
+  return sizeof(&MobileFusion::initChiselMap) ? 0 : 1;
+}
+""" % (ROOT, body))
+    exe = tmp_path / "init_chisel_map"
+    r = subprocess.run(["g++", "-std=c++14", "-O0", "-Wall", str(src), "-o", str(exe), "-L" + os.path.join(ROOT, "texturefusion_amd"),
+                        "-ltexfusion_hip", "-Wl,-rpath," + os.path.join(ROOT, "texturefusion_amd"), "-Wl,-rpath,/opt/rocm/lib",
+                        "-L/opt/rocm/lib"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]

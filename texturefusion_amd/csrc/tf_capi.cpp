@@ -122,7 +122,6 @@ static int status_to_error(uint32_t st) {
   if (st & kStHashFull) m += " hash table full";
   if (st & kStMeshFull) m += " a mesh exceeds the per-chunk mesh block and the overflow pool is exhausted (raise tf_config.mesh_overflow_blocks or mesh_max_vertices / mesh_max_triangles)";
   if (st & kStAtlasFull) m += " No enough space for texture storage.";  // std::overflow_error text, Atlas.cpp:53
-  if (st & kStSplit) m += " internal: a chunk flagged for half-chunk work items was not alive or not inside the image";
   if (st & kStXchgFull) m += " a rank's ghost band did not fit the boundary exchange block (raise cap_records)";
   set_error(m);
   if (st & kStAtlasFull) return TF_ERR_ATLAS_FULL;
@@ -136,12 +135,12 @@ struct CtlSnap {
   VolCtl vc;
 };
 static int fetch_ctl(tf_volume* v, CtlSnap* out) {
-  if (!v->h_ctl) TF_HIP(hipHostMalloc((void**)&v->h_ctl, offsetof(FrameCtl, ka_next) + sizeof(VolCtl), hipHostMallocDefault));
+  if (!v->h_ctl) TF_HIP(hipHostMalloc((void**)&v->h_ctl, sizeof(FrameCtl) + sizeof(VolCtl), hipHostMallocDefault));
   launch_export_ctl(v->dev.sel.ctl, v->dev.vctl, v->h_ctl, v->stream);
   TF_HIP(hipGetLastError());
   TF_HIP(hipStreamSynchronize(v->stream));
-  memcpy(&out->f, v->h_ctl, offsetof(FrameCtl, ka_next));  // (without the pull counters)
-  memcpy(&out->vc, reinterpret_cast<const uint8_t*>(v->h_ctl) + offsetof(FrameCtl, ka_next), sizeof(VolCtl));
+  memcpy(&out->f, v->h_ctl, sizeof(FrameCtl));  // (without the pull counters)
+  memcpy(&out->vc, reinterpret_cast<const uint8_t*>(v->h_ctl) + sizeof(FrameCtl), sizeof(VolCtl));
   if (out->vc.status) {
     TF_HIP(hipMemsetAsync(&v->dev.vctl->status, 0, sizeof(uint32_t), v->stream));
     return status_to_error(out->vc.status);
@@ -334,6 +333,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     return TF_ERR_NO_DEVICE;
   }
   tf_volume* v = new tf_volume();
+  v->host_defer = tf::host_defer_default();
   memset(&v->cfg, 0, sizeof(v->cfg));
   if (cfg) v->cfg = *cfg;
   if (v->cfg.max_chunks <= 0) v->cfg.max_chunks = 1ll << 20;
@@ -431,8 +431,6 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     if ((rc = dev_alloc(v, &L.list_quality, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_rows, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.cen, (size_t)3 * kChunkVoxels))) return fail(rc);
-    if ((rc = dev_alloc(v, &L.tiles, (size_t)kMaxTiles))) return fail(rc);
-    if ((rc = dev_alloc(v, &L.split_list, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.ctl, (size_t)1))) return fail(rc);
   }
   if ((rc = init_device_state(v))) return fail(rc);
@@ -813,17 +811,6 @@ int tf_finalize(tf_volume* v, const int32_t* ids, const uint8_t* needs_update, c
 // PENDING here and rides on the next frame's launch next to that frame's voxel update (AtlasState::pend_patch).
 }  // extern "C" (C++ linkage for the helper below)
 static int patch_launched(tf_volume* v);
-// Where does the pending patch stage of frame f - 1 ride?  Default: on k_frame(f), next to K-A.  TF_PATCH_IN_FILTER=1: on
-// the filter launch of frame f (k_mesh_filter<*, true>; the records the filter empties are written by the mesher launch
-// so that the stage can still read them).  Measured on the room stream (profiles/r4/README.md, run s1): k_frame 40.6 ->
-// 31.3 us as expected, but filter + mesher 50.3 -> 61.8 us -- the two latency chains slow each other down by more than
-// K-A gains (step 90.9 -> 93.1 us of kernels; fewer patch workgroups, a smaller filter grid, the other dispatch order:
-// 97-102 us) -- so the default stays k_frame.
-bool tf::patch_rides_filter() {
-  static const bool on = getenv("TF_PATCH_IN_FILTER") && atoi(getenv("TF_PATCH_IN_FILTER")) &&
-                         !(getenv("TF_MESH_FUSED") && atoi(getenv("TF_MESH_FUSED")));
-  return on;
-}
 int tf::fused_arm(tf_volume* v) {
   AtlasState& a = v->atlas;
   if (a.fused_armed) return TF_OK;
@@ -846,11 +833,11 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
                       bool sized_xchg) {
   AtlasState& a = v->atlas;
   // A patch stage still pending here (the previous textured frame's) must read its meshes before this frame's mesher
-  // rewrites them: it goes out on its own first -- or, with TF_PATCH_IN_FILTER=1, rides on this frame's FILTER launch
-  // (launch_mesh below; measured slower than riding on k_frame: see patch_rides_filter)
-  static const bool unit_ride = !(getenv("TF_UNIT_PATCH_RIDE") && !atoi(getenv("TF_UNIT_PATCH_RIDE")));  // A/B knob, default on
-  static const bool mesh_fused_form = getenv("TF_MESH_FUSED") && atoi(getenv("TF_MESH_FUSED"));
-  const bool ride = a.pend_patch.on && a.fused_armed && (patch_rides_filter() || (ride_filter && unit_ride && !mesh_fused_form));
+  // rewrites them: it goes out on its own first -- or (ride_filter: the keyframe unit, which has no k_frame launch for it)
+  // rides on this frame's FILTER launch (launch_mesh below).  In the per-frame stream the stage rides on k_frame instead:
+  // next to the filter the two latency chains cost more than the stage costs K-A (profiles/r4/README.md, runs c2 / s1;
+  // variants/r4_experiments.patch has the knob).
+  const bool ride = a.pend_patch.on && a.fused_armed && ride_filter;
   int rc = TF_OK;
   if (!ride) { rc = patch_flush(v); if (rc) return rc; }
   rc = fused_arm(v);
@@ -907,8 +894,6 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
   a.pend_patch.st.par = par;
   a.pend_patch.st.kf = kf;
   a.pend_patch.host_slot = -1;
-  static const bool defer_patch = !(getenv("TF_PATCH_DEFER") && !atoi(getenv("TF_PATCH_DEFER")));  // A/B knob, default on
-  if (!defer_patch) { rc = patch_flush(v); if (rc) return rc; }
   v->clear_floor = frame_epoch + 1u;  // CompressMeshes cleared meshesToUpdate
   return TF_OK;
 }
@@ -958,7 +943,6 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     st->coarse_summ = tex == nullptr;  // a TSDF-only stream: K-A skips the class ballots (tf_device.h)
     st->claim_par = -1;
   };
-  static const bool ka_claims = !(getenv("TF_KA_CLAIM") && !atoi(getenv("TF_KA_CLAIM")));  // A/B knob, default on
   if (tex) { int rc = fused_arm(v); if (rc) return rc; }  // (before the first launch appends to the shard lists)
   // how many leading frames already went through their selection stages in the previous call?
   int primed = 0;
@@ -995,18 +979,16 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     static const uint32_t small_max = getenv("TF_SMALL_FRAME") ? (uint32_t)atoi(getenv("TF_SMALL_FRAME")) : 20000u;
     const bool small_frame = dirty_hint <= small_max;
     if (hc) cur.small_frame = small_frame;
-    const bool claimed = hc && tex && ka_claims && small_frame && v->clear_floor >= cur.epoch;
+    const bool claimed = hc && tex && small_frame && v->clear_floor >= cur.epoch;
     if (claimed) cur.claim_par = v->atlas.fused_par;
     if (hn) stage(i + 1, &nxt);
     if (h2) stage(i + 2, &nx2);
     if (!hc && !hn && !h2) continue;
     // the patch stage of the previous textured frame rides on this launch when it carries a colour voxel update
     // (the fused kernel has no depth-only instance with that role); otherwise it goes out on its own first
-    // -- or (TF_PATCH_IN_FILTER=1) on the frame's FILTER launch (texture_stage)
     AtlasState::PendPatch& pp = v->atlas.pend_patch;
-    const bool to_filter = pp.on && hc && tex && patch_rides_filter();
-    const bool carry = pp.on && hc && cur.img.rgba != nullptr && !to_filter;
-    if (pp.on && hc && !carry && !to_filter) { int rc = patch_flush(v); if (rc) return rc; }
+    const bool carry = pp.on && hc && cur.img.rgba != nullptr;
+    if (pp.on && hc && !carry) { int rc = patch_flush(v); if (rc) return rc; }
     if (hc) prof_begin(v, TF_PROF_INTEGRATE);
     launch_frame(v->dev, hc ? &cur : nullptr, hn ? &nxt : nullptr, h2 ? &nx2 : nullptr, carry ? &pp.st : nullptr, v->cam,
                  v->ig, v->res, v->stream, v->h_progress, &v->progress_seq);
@@ -1090,12 +1072,10 @@ static int host_slot_wait(tf_volume* v, tf_volume::HostSlot& s) {
 // copy event is already complete (the usual case: the entry point runs behind), otherwise the stream waits for it
 static int host_copy_ready(tf_volume* v, tf_volume::Pending* p) {
   if (p->copied) return TF_OK;
-  static const bool dbg_nowait = getenv("TF_HOST_NOWAIT") && atoi(getenv("TF_HOST_NOWAIT"));  // timing experiment only: WRONG results
-  static const bool always_wait = getenv("TF_HOST_ALWAYS_WAIT") && atoi(getenv("TF_HOST_ALWAYS_WAIT"));  // A/B knob
   hipEvent_t ev = v->hslot[p->slot].copied;
-  const hipError_t q = always_wait ? hipErrorNotReady : hipEventQuery(ev);
+  const hipError_t q = hipEventQuery(ev);
   if (q == hipErrorNotReady) {
-    if (!dbg_nowait) TF_HIP(hipStreamWaitEvent(v->stream, ev, 0));
+    TF_HIP(hipStreamWaitEvent(v->stream, ev, 0));
     if (v->host_trace[5] >= 0) v->host_waits += 1;
   } else if (q != hipSuccess) {
     TF_HIP(q);
@@ -1180,9 +1160,23 @@ static int host_ring_prepare(tf_volume* v) {
   return TF_OK;
 }
 
+}  // extern "C"
+bool tf::host_defer_default() {
+  static const bool on = !(getenv("TF_HOST_DEFER") && !atoi(getenv("TF_HOST_DEFER")));
+  return on;
+}
+extern "C" {
+int tf_host_frame_set_deferral(tf_volume* v, int on) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV(v);  // (frames still in the pipeline go onto the stream under the old setting)
+  v->host_defer = on != 0;
+  return TF_OK;
+}
+
 int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_slots) {
-  (void)v;  // (constants of the build + the TF_HOST_DEFER knob; a null handle is fine)
-  static const bool defer = !(getenv("TF_HOST_DEFER") && !atoi(getenv("TF_HOST_DEFER")));
+  // (a null handle answers for a handle as tf_volume_create makes it: TF_HOST_DEFER=0 in the environment turns the deferral
+  // off for every new handle, tf_host_frame_set_deferral for one)
+  const bool defer = v ? v->host_defer : tf::host_defer_default();
   if (frames_behind) *frames_behind = defer ? tf_volume::kHostDefer : 0;
   if (ring_slots) *ring_slots = tf_volume::kHostRing;
   return TF_OK;
@@ -1262,11 +1256,10 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   // observed: every other entry point flushes first (TF_DEV).
   // The launches go out FIRST where that costs nothing -- they need nothing of the new frame -- so that an idle device is
   // at work while this call stages and uploads (it starts ~45 us earlier: 2 % of a 20-frame window).
-  static const bool defer = !(getenv("TF_HOST_DEFER") && !atoi(getenv("TF_HOST_DEFER")));
+  const bool defer = v->host_defer;
   constexpr int ND = tf_volume::kHostDefer;
   const float* bound_d = nullptr;
   const uint8_t* bound_c = nullptr;
-  static const bool launch_first = !(getenv("TF_HOST_LAUNCH_FIRST") && !atoi(getenv("TF_HOST_LAUNCH_FIRST")));  // A/B knob
   auto launch_oldest = [&]() -> int {
     if (!(defer && v->n_pend == ND)) return TF_OK;
     tf_volume::Pending all[ND];
@@ -1297,7 +1290,7 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   // it is a few microseconds old -- launching now would put a wait for it into the stream (7 us of idle device per
   // frame, run 46), launching behind the staging copy finds it complete.
   bool early = false;
-  if (launch_first && defer && v->n_pend == ND) {
+  if (defer && v->n_pend == ND) {
     const tf_volume::Pending& newest = v->pend[2];  // (the newest frame the launch reads)
     early = newest.copied || hipEventQuery(v->hslot[newest.slot].copied) == hipSuccess;
   }
@@ -1344,10 +1337,9 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
         int helpers = e ? atoi(e) : 7;
         if (helpers < 0) helpers = 0;
         if (helpers > 15) helpers = 15;
-        // 0 = helpers run where the scheduler puts them (default: on a shared host pinned helpers gave 1 run in 3 a
-        // 10-ms stall -- 100.8 us per frame at best, 150+ at worst, against a steady 102.6 unpinned; run 36),
-        // 1 = the caller's group of eight CPUs, 2 = one CPU of that group per helper
-        static const int pin = getenv("TF_COPY_PIN") ? atoi(getenv("TF_COPY_PIN")) : 0;
+        // helpers run where the scheduler puts them (on a shared host pinned helpers gave 1 run in 3 a 10-ms stall --
+        // 100.8 us per frame at best, 150+ at worst, against a steady 102.6 unpinned; profiles/r3, run 36)
+        const int pin = 0;
         static const int spin_us = getenv("TF_COPY_SPIN_US") ? atoi(getenv("TF_COPY_SPIN_US")) : 200;
         v->copy_pool = new CopyPool(helpers, pin, spin_us);
       }
@@ -1356,22 +1348,14 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
     }
   }
   lap(2, t);
-  static const bool dbg_noh2d = getenv("TF_HOST_NOH2D") && atoi(getenv("TF_HOST_NOH2D"));  // timing experiment only: WRONG results
-  // TF_HOST_COPY_SPLIT=1: depth and colour go up on two copy streams (two SDMA queues); the join happens between the copy
-  // streams, so the stream the kernels run on still sees ONE event per frame
-  // OFF by default.  A TSDF-only stream is bound by the upload and the split helps it in steady state on a quiet host (62 ->
-  // 52-54 us per frame), but over four alternating A/B pairs on a shared host (profiles/r4, run s13) the first timed
-  // window behind a stretch of resident frames took 115-123 us per frame with it against 59-82 without, later windows
-  // 53-77 against 59-64: not a gain one can count on.  The textured stream is bound by the host side of the call, where
-  // the second copy call and the join cost 3 us per frame (99.6 -> 103.2).
-  static const int split_knob = getenv("TF_HOST_COPY_SPLIT") ? atoi(getenv("TF_HOST_COPY_SPLIT")) : 0;
-  const bool split = split_knob != 0 && !rgb;
+  // (depth and colour of a STAGED frame go up as one copy on one copy stream: two streams -- two SDMA queues -- helped a
+  // TSDF-only stream in steady state on a quiet host, 62 -> 52-54 us per frame, and doubled the first window behind resident
+  // frames on a shared one; profiles/r4/README.md, run s13)
   if (direct) {
-    // (the call waits for this upload: depth and colour go up side by side on two copy queues -- TF_HOST_DIRECT_SPLIT=0: one)
-    static const bool dsplit = !(getenv("TF_HOST_DIRECT_SPLIT") && !atoi(getenv("TF_HOST_DIRECT_SPLIT")));
+    // (the call waits for this upload: depth and colour go up side by side on two copy queues)
     // (a kernel that fetches the images itself -- 16-byte loads out of the mapped pages -- was no faster than the DMA
     // transfers, 60 us, and slowed the step kernels it ran next to: 100 -> 125 us per frame, profiles/r4/README.md)
-    if (rgba && dsplit) {
+    if (rgba) {
       if (!v->copy_stream2) {
         TF_HIP(hipStreamCreateWithFlags(&v->copy_stream2, hipStreamNonBlocking));
         TF_HIP(hipEventCreateWithFlags(&v->copy_join, hipEventDisableTiming));
@@ -1382,7 +1366,6 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
       TF_HIP(hipStreamWaitEvent(v->copy_stream, v->copy_join, 0));
     } else {
       TF_HIP(hipMemcpyAsync(s.d, depth, npix * 4, hipMemcpyHostToDevice, v->copy_stream));
-      if (rgba) TF_HIP(hipMemcpyAsync(s.d + npix * 4, rgba, npix * 4, hipMemcpyHostToDevice, v->copy_stream));
     }
     if (rgb) {
       TF_HIP(hipMemcpyAsync(s.d + npix * 4, rgb, npix * 3, hipMemcpyHostToDevice, v->copy_stream));
@@ -1391,17 +1374,8 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
                        v->copy_stream);
       TF_HIP(hipGetLastError());
     }
-  } else if (!dbg_noh2d) {
-    if (split && rgba) {
-      if (!v->copy_stream2) {
-        TF_HIP(hipStreamCreateWithFlags(&v->copy_stream2, hipStreamNonBlocking));
-        TF_HIP(hipEventCreateWithFlags(&v->copy_join, hipEventDisableTiming));
-      }
-      TF_HIP(hipMemcpyAsync(s.d + npix * 4, s.h + npix * 4, npix * 4, hipMemcpyHostToDevice, v->copy_stream2));
-      TF_HIP(hipEventRecord(v->copy_join, v->copy_stream2));
-      TF_HIP(hipMemcpyAsync(s.d, s.h, npix * 4, hipMemcpyHostToDevice, v->copy_stream));
-      TF_HIP(hipStreamWaitEvent(v->copy_stream, v->copy_join, 0));
-    } else {
+  } else {
+    {
       const size_t up = rgba ? npix * 8 : (rgb ? (color_valid ? npix * 8 : npix * 7) : npix * 4);
       TF_HIP(hipMemcpyAsync(s.d, s.h, up, hipMemcpyHostToDevice, v->copy_stream));
     }
@@ -1683,7 +1657,7 @@ int tf_get_stats(tf_volume* v, tf_stats* out) {
   if (rc) return rc;
   out->n_coarse = ctl.f.n_coarse;
   out->n_selected = ctl.f.n_list;
-  out->n_listed = (int64_t)ctl.f.n_list - (int64_t)r3[3];
+  out->n_listed = (int64_t)ctl.f.n_list;
   out->n_updated = (int64_t)r3[2];
   out->rows_tsdf = (int64_t)r3[0];
   out->rows_color = (int64_t)r3[1];

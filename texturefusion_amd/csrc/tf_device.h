@@ -32,7 +32,6 @@ constexpr uint32_t kStMissing = 8u;
 constexpr uint32_t kStHashFull = 16u;
 constexpr uint32_t kStMeshFull = 32u;   // a mesh exceeds tf_config.mesh_max_vertices / mesh_max_triangles
 constexpr uint32_t kStAtlasFull = 64u;
-constexpr uint32_t kStSplit = 256u;     // internal: a chunk flagged for half-chunk work items was not alive / not inside the image
 constexpr uint32_t kStXchgFull = 128u;  // a rank's ghost band did not fit the exchange block (raise cap_records)  // Atlas::AddPatch overflow (std::overflow_error, Atlas.cpp:52-53)
 
 struct Cam {
@@ -52,12 +51,11 @@ struct Pose {
 struct __attribute__((aligned(16))) HEntry {
   unsigned long long key;
   uint32_t slot;
-  uint32_t alive;  // bit 0 alive, bit 1 touched since the last boundary exchange, bit 2 (TF_KA_SPLIT) updated at least once while alive
+  uint32_t alive;  // bit 0 alive, bit 1 touched since the last boundary exchange
 };
 
 // Device-resident control block of one selection: everything one frame's kernels hand to the
 // next, so the fused per-frame unit never synchronises with the host.
-constexpr int kKaCounters = 64, kKaCounterStride = 64;
 struct FrameCtl {
   uint32_t bbox_key[6];  // ordered-uint keys of min xyz / max xyz (K-B reduction)
   int32_t min_id[3];
@@ -71,7 +69,7 @@ struct FrameCtl {
   // its resident waves; with ~1.5 entries per wave the second entry of a wave is then a cheap one.  Lists of the
   // call-by-call flow are plain (n_front = n_list).
   uint32_t n_front;
-  uint32_t n_split;  // TF_KA_SPLIT: entries of SelBuf::split_list (zeroed with emit_pack)
+  uint32_t pad0;
   unsigned long long emit_pack;  // the selection role's append counters: low word front, high word back entries
   uint32_t pad[2];
   // multi-GPU, fused flow: selected chunks of this frame per ghost band -- [0] own down band (keys lo .. lo + a + b + c,
@@ -80,9 +78,6 @@ struct FrameCtl {
   // so sender and receiver of a block count the same number: the exchange of the frame is sized by it (selected is a
   // superset of updated).  Zeroed with emit_pack by the frame's K-B stage.
   uint32_t band_cnt[4];
-  // fused flow: K-A's waves pull their entries from these counters (each 256 B from the next); counter c hands out the
-  // logical entries c, c + kKaCounters, ...  Zeroed by the frame's K-B stage, two launches ahead.
-  uint32_t ka_next[kKaCounters * kKaCounterStride];
 };
 
 // Volume-wide device words.
@@ -114,15 +109,8 @@ struct SelBuf {
   float* list_quality;        // [max_list]
   uint16_t* list_rows;        // [max_list] low byte tsdf rows, high byte colour rows
   float* cen;                 // [3*512] centroid table of the frame (Chisel.cpp:52-110), c[a][voxel]
-  // Fused flow: per 16 x 16 pixel tile of the frame's depth image {key of the smallest depth > 0, key of the largest depth}
-  // (ordered-uint keys, f2key).  Filled by the frame's K-B role, read by its selection role to mark chunks that provably
-  // rewrite nothing (select_body: K-A then only does their bookkeeping), re-armed by the frame's K-A role.  [kMaxTiles]
-  uint32_t* split_list;       // [max_list] TF_KA_SPLIT: physical positions of the entries K-A walks as two half-chunk items
-  uint2* tiles;
   FrameCtl* ctl;
 };
-constexpr uint32_t kMaxTiles = 65536;  // images of up to 65536 tiles of 16 x 16 pixels (4096 x 4096); larger ones are not pruned
-constexpr int kTileShift = 4;          // 16 x 16 pixels: a chunk beyond ~0.65 m spans at most 3 x 3 of them (one batch of loads)
 
 // ---- device-resident meshes (ChunkManager::allMeshes) and their patches (Mesh::m_patch) ----------
 // One fixed block per pool slot, planar (lane = vertex / triangle, every plane row is a coalesced

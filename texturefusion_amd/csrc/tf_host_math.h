@@ -25,9 +25,7 @@ struct SelectConsts {
   float fine[3][8];           // diffCentroidRefine
   float pose[12];             // the frame pose (per-chunk scalars of the emitted list entries)
   float resDiag;              // sqrt(3.0f) * resolution (ProjectionIntegrator.cpp:77)
-  int prune;                  // fused flow: drop chunks whose depth tiles rule out any voxel write (select_body)
   int plain;                  // EMIT: append every entry from the front (a plain, unordered list: n_front = n_list)
-  int split;                  // TF_KA_SPLIT: flag the costly chunks that two waves may share (select_body)
 };
 
 inline SelectConsts make_select_consts(const float* p /*pose[12]*/, float res) {
@@ -35,9 +33,7 @@ inline SelectConsts make_select_consts(const float* p /*pose[12]*/, float res) {
   sc.res = res;
   for (int i = 0; i < 12; ++i) sc.pose[i] = p[i];
   sc.resDiag = (float)(sqrt(3.0) * (double)res);
-  sc.prune = 0;
   sc.plain = 0;
-  sc.split = 0;
   sc.id_factor = 1.0f / (8.0f * res);
   float diag = 8.0f * res / 2.0f;
   int step = 4;

@@ -23,37 +23,8 @@
 #include "tf_patch_body.h"
 
 #pragma clang fp contract(off)
-#ifndef TF_KA_VM_ARRAY
-#define TF_KA_VM_ARRAY 0
-#endif
-// Depth-tile pruning of the fused selection (compile-time experiment, OFF): the K-B role leaves {smallest positive, largest}
-// depth per 16 x 16 pixel tile, the selection role marks the flagged chunks whose tiles prove that no voxel can be written
-// (an exact, conservative test: all 83 GPU parity tests pass with it) and K-A does only their bookkeeping.  Measured on the
-// room stream (profiles/r4/README.md, run c9): of the 3186 selected-but-not-updated chunks per frame the tiles catch 507 --
-// on walls seen at an angle the depth range of a 3 x 3 tile box exceeds the truncation band -- and K-A gains nothing
-// (k_frame 39.7 -> 40.1 us textured, 28.9 -> 30.2 us TSDF-only: the selection role, which fills K-A's tail, got longer and
-// spills 28 B/lane).  A finer footprint is K-A's own geometry pass, which already skips the write phases of such chunks.
-#ifndef TF_SEL_PRUNE
-#define TF_SEL_PRUNE 0
-#endif
-
-// Half-chunk work items (compile-time experiment): costly chunks that project entirely inside the image
-// and are permanently alive (updated at least once: HEntry::alive bit 2) are walked by TWO waves, four z-slices each.  The
-// fused selection flags them (sign bit of the record's `upper`) and lists their records in SelBuf::split_list; K-A's items
-// are [0, n_split) = the upper halves, [n_split, n_split + n_list) = the list entries (a flagged entry = its lower half).
-#ifndef TF_KA_SPLIT
-#define TF_KA_SPLIT 0
-#endif
-#ifndef TF_KA_HALVES
-#define TF_KA_HALVES (TF_KA_SPLIT ? 1 : 0)  // K-A walks a chunk in two steps of four z-slices (experiment: profiles/r4/README.md)
-#endif
 #ifndef TF_KA_GP
-#define TF_KA_GP 2
-#endif
-static_assert(!(TF_KA_SPLIT && !TF_KA_HALVES), "half-chunk work items need the four-slice steps");
-static_assert(!(TF_KA_SPLIT && TF_SEL_PRUNE), "both experiments use the sign bit of the record's `upper`");
-#ifndef TF_KA_DYNAMIC
-#define TF_KA_DYNAMIC 0  // fused K-A: 1 = waves pull their list entries from 64 counters (measured slower, profiles/r3: off)
+#define TF_KA_GP 2  // z-slices per read-modify-write pass of K-A
 #endif
 
 
@@ -132,10 +103,7 @@ __device__ __forceinline__ void centroid_table(const float* __restrict__ Pp, flo
 // ---------------------------------------------------------------------------------------
 // control block reset (create / Reset only; per-frame re-arming rides on k_scan)
 // ---------------------------------------------------------------------------------------
-// the state of "no depth seen" of a tile: smallest positive depth = +inf, largest depth = below every depth
-__device__ __forceinline__ uint2 tile_empty() { return make_uint2(f2key(3.0e38f), f2key(-1.0f)); }
-__global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl, uint2* tiles) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; tiles && i < kMaxTiles; i += gridDim.x * blockDim.x) tiles[i] = tile_empty();
+__global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int a = 0; a < 3; ++a) {
       ctl->bbox_key[a] = f2key(1e8f);
@@ -146,9 +114,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl, uint2* tiles) {
     ctl->n_list = 0;
     ctl->n_front = 0;
     ctl->emit_pack = 0ull;
-    ctl->n_split = 0;
     for (int k = 0; k < 4; ++k) ctl->band_cnt[k] = 0u;
-    for (int k = 0; k < kKaCounters; ++k) ctl->ka_next[k * kKaCounterStride] = 0u;
     if (vctl) {
       vctl->status = 0; vctl->n_tmp = 0; vctl->n_tmp2 = 0; vctl->ovf_next = 0; vctl->xchg_sent = 0; vctl->xchg_recv = 0;
       for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
@@ -156,7 +122,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl, uint2* tiles) {
   }
 }
 void launch_reset_ctl(const VolumeDev& v, bool volume_too, hipStream_t s) {
-  hipLaunchKernelGGL(k_reset_ctl, dim3(64), dim3(256), 0, s, v.sel.ctl, volume_too ? v.vctl : nullptr, v.sel.tiles);
+  hipLaunchKernelGGL(k_reset_ctl, dim3(1), dim3(64), 0, s, v.sel.ctl, volume_too ? v.vctl : nullptr);
 }
 
 // an empty launch (tf_profile_calibrate: what a HIP-event pair around ANY launch reads at least)
@@ -202,13 +168,10 @@ void launch_pack_rgba(const uint8_t* rgb, const uint8_t* valid, uchar4* rgba, ui
 // ---------------------------------------------------------------------------------------
 // K-B  world AABB of the back-projected (depth + 0.2) points
 // ---------------------------------------------------------------------------------------
-// tiles != nullptr (the fused flow's K-B role): the same sweep also leaves, per 16 x 16 pixel tile, the smallest depth > 0
-// and the largest depth (SelBuf::tiles; atomics on ordered keys, one pair per four adjacent float4 = one tile row).
 __device__ __forceinline__ void bbox_body(const float* __restrict__ depth, const Cam& cam, const Pose& P,
-                                          FrameCtl* ctl, const uint32_t bid, const uint32_t nb, uint2* __restrict__ tiles = nullptr) {
-  if (bid == 0 && threadIdx.x == 0) { ctl->n_list = 0; ctl->n_front = 0; ctl->emit_pack = 0ull; ctl->n_split = 0; }  // appended to by k_select<EMIT>
+                                          FrameCtl* ctl, const uint32_t bid, const uint32_t nb) {
+  if (bid == 0 && threadIdx.x == 0) { ctl->n_list = 0; ctl->n_front = 0; ctl->emit_pack = 0ull; }  // appended to by k_select<EMIT>
   if (bid == 0 && threadIdx.x < 4) ctl->band_cnt[threadIdx.x] = 0u;
-  if (bid == 0 && threadIdx.x < kKaCounters) ctl->ka_next[threadIdx.x * kKaCounterStride] = 0u;  // K-A of this frame (two launches on) pulls its entries here
   float mn[3] = {1e8f, 1e8f, 1e8f}, mx[3] = {-1e8f, -1e8f, -1e8f};
   const int W = cam.W;
   const int nvec = (cam.W * cam.H) >> 2;
@@ -219,26 +182,6 @@ __device__ __forceinline__ void bbox_body(const float* __restrict__ depth, const
     const int i = pix / W, j = pix - i * W;
     const float ly = ((float)i - cam.cyi) / cam.fyi;
     const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
-    if (tiles) {
-      float tmn = 3.0e38f, tmx = -1.0f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        tmn = (dd[k] > 0.0f && dd[k] < tmn) ? dd[k] : tmn;
-        tmx = (dd[k] > tmx) ? dd[k] : tmx;  // (a NaN depth compares false everywhere: it updates nothing in K-A either)
-      }
-      // four adjacent lanes hold one 16-pixel tile row (W is a multiple of 16, or the tiles are off): one pair of atomics
-#pragma unroll
-      for (int o = 1; o <= 2; o <<= 1) {
-        const float omn = __shfl_xor(tmn, o), omx = __shfl_xor(tmx, o);
-        tmn = omn < tmn ? omn : tmn;
-        tmx = omx > tmx ? omx : tmx;
-      }
-      const uint32_t t = (uint32_t)(i >> kTileShift) * (uint32_t)(W >> kTileShift) + (uint32_t)(j >> kTileShift);
-      if (!(q & 3) && t < kMaxTiles) {
-        if (tmn < 3.0e38f) atomicMin(&tiles[t].x, f2key(tmn));
-        atomicMax(&tiles[t].y, f2key(tmx));
-      }
-    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float dz = dd[k] + off;
@@ -297,7 +240,7 @@ void launch_bbox(const VolumeDev& v, const float* depth, const Cam& cam, const P
 // ---------------------------------------------------------------------------------------
 // K-C  coarse 4x4x4-block test, then per-chunk test; one 64-bit mask per coarse block
 // ---------------------------------------------------------------------------------------
-struct ProbeRes { bool valid; bool hit; float sd; float u, w, pz; };
+struct ProbeRes { bool valid; bool hit; float sd; };
 
 // One lane = one of the 8 probe points of CheckCornerIntersectingSIMD (ChunkManager.h:561-636).
 __device__ __forceinline__ ProbeRes probe(const float* __restrict__ depth, const Cam& cam,
@@ -314,7 +257,6 @@ __device__ __forceinline__ ProbeRes probe(const float* __restrict__ depth, const
   const float sd = d - pz;
   r.hit = r.valid && (sd > ndtn) && (dtp > sd);
   r.sd = sd;
-  r.u = u; r.w = w; r.pz = pz;
   return r;
 }
 
@@ -393,8 +335,6 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
     const bool coarse_hit = __ballot(pr.hit && depthValid) != 0ull;
     unsigned long long m = 0ull;
     bool costly = false;
-    bool split = false;   // TF_KA_SPLIT: two waves may share this chunk
-    bool pruned = false;  // flagged by the reference's test, but the depth tiles prove that no voxel of the chunk can be written
     if (coarse_hit) {
       bool flag = false;
       uint32_t band = 0u;
@@ -418,91 +358,22 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         const bool dv = (of[2] > cam.nearP) && (cam.farP > of[2]);
         bool anyhit = false;
         bool below = false, above = false;  // EMIT: some probed corner sits below the band's far edge / above its near edge
-        float umin = 3.0e38f, umax = -3.0e38f, wmin = 3.0e38f, wmax = -3.0e38f, zmin = 3.0e38f, zmax = -3.0e38f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           ProbeRes fr = probe(depth, cam, of[0], of[1], of[2], sc.fine[0][c], sc.fine[1][c],
                               sc.fine[2][c], fdtp, fndtn);
           anyhit |= fr.hit;
           if (EMIT) { below |= fr.valid && (tr > fr.sd); above |= fr.valid && (fr.sd > fndtn + sc.diag); }  // the band without the chunk-diagonal margin
-          if ((TF_SEL_PRUNE || TF_KA_SPLIT) && EMIT) {
-            umin = fminf(umin, fr.u); umax = fmaxf(umax, fr.u); wmin = fminf(wmin, fr.w); wmax = fmaxf(wmax, fr.w);
-            zmin = fminf(zmin, fr.pz); zmax = fmaxf(zmax, fr.pz);
-          }
         }
         flag = anyhit && dv;
-        if (TF_SEL_PRUNE && EMIT && sc.prune && flag) {
-          // ---- can this chunk rewrite anything at all?  (an exact no lets K-A skip its voxels; results are unchanged)
-          // The eight probe points are the corners of a box that contains every voxel centre of the chunk as K-A places
-          // it (centroid table: R^T (x, y, z) res + res / 2 with x, y, z in 0..7; the probes use 0 / 8).  With all of
-          // them in front of the camera the chunk's pixels lie inside the bounding box of their projections (+ 1 for
-          // K-A's own rounding of u + 0.5, + 1 for the last bits in which its per-chunk origin may differ from this
-          // role's), and its voxels' camera depth inside [zmin, zmax].  K-A rewrites a TSDF row only where a pixel has
-          // lower < d - z < upper (ProjectionIntegrator.cpp:313-316; upper = truncation + sqrt(3) res, lower = -0.03) and
-          // a colour row only where |d - z| < sqrt(3) res / 2 + 0.01 (:202-208): no pixel of the box with
-          // zmin + min(lower, -thr) < d < zmax + max(upper, thr) -- read off the 16 x 16 tiles' {min positive, max} depth
-          // the frame's K-B role left -- means no voxel of the chunk is written.  (A depth of 0, a hole, fails both tests
-          // unless the chunk sits within thr of the camera plane, which zmin > 0.1 rules out.)
-          const float thr = sc.resDiag * 0.5f + 0.01f;
-          const float zlo = zmin - fmaxf(0.03f, thr) - 1e-3f;
-          const float zhi = zmax + fmaxf(tr + sc.resDiag, thr) + 1e-3f + 1e-4f * fabsf(zmax);
-          if (zmin > 0.1f && umax - umin < 4096.0f && wmax - wmin < 4096.0f) {
-            const int TW = cam.W >> kTileShift, TH = (cam.H + 15) >> kTileShift;
-            const float ts = 1.0f / (float)(1 << kTileShift);
-            int tx0 = (int)floorf((umin - 2.0f) * ts), tx1 = (int)floorf((umax + 3.0f) * ts);
-            int ty0 = (int)floorf((wmin - 2.0f) * ts), ty1 = (int)floorf((wmax + 3.0f) * ts);
-            tx0 = tx0 < 0 ? 0 : tx0; ty0 = ty0 < 0 ? 0 : ty0;
-            tx1 = tx1 >= TW ? TW - 1 : tx1; ty1 = ty1 >= TH ? TH - 1 : ty1;
-            const int nx = tx1 - tx0 + 1, ny = ty1 - ty0 + 1;
-            if (nx <= 0 || ny <= 0) {
-              pruned = true;  // the whole chunk projects off the image: every row of K-A's is dead
-            } else if (nx <= 3 && ny <= 3) {
-              // ONE batch of nine independent loads (tiles outside the box repeat its first one): a loop with an early exit
-              // was a chain of round trips per hit block -- it cost the selection role more than K-A gained
-              const uint32_t klo = f2key(zlo), khi = f2key(zhi);
-              bool may = false;
-#pragma unroll
-              for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                  const int tx = tx0 + (dx < nx ? dx : 0), ty = ty0 + (dy < ny ? dy : 0);
-                  const uint2 t = v.sel.tiles[ty * TW + tx];
-                  // some depth of the tile may lie inside (zlo, zhi): its smallest positive one is below zhi and its
-                  // largest above zlo (the tile's depths need not fill the interval: conservative)
-                  may = may || (t.x < khi && t.y > klo);
-                }
-              pruned = !may;
-            }
-          }
-        }
-        costly = (below && above && !pruned) || sc.plain != 0;
+        costly = (below && above) || sc.plain != 0;
         if (EMIT) {
           const long long k = part_key(v, x0 + di, y0 + dj, z0 + dk);
           const long long lo = v.part_lo, hi = v.part_hi;
-          if (partitioned && flag && !pruned)
+          if (partitioned && flag)
             band = (k >= lo && k - lo <= band_w ? 1u : 0u) | (k == hi - 1 ? 2u : 0u) | (k == lo - 1 ? 4u : 0u) |
                    (k >= hi && k - hi <= band_w ? 8u : 0u);
           flag = flag && k >= lo && k < hi;
-        }
-        if (TF_KA_SPLIT && EMIT && sc.split && flag && costly && sc.plain == 0) {
-          // Two waves may share the chunk if (a) every voxel projects inside the image -- the eight probes are the corners
-          // of a box around the voxel centres, so with all of them in front of the camera the chunk's pixels lie inside the
-          // bounding box of their projections; three pixels of margin cover K-A's + 0.5, its rounding and the last bits of
-          // its per-chunk origin -- so that no row can stall the chunk (ProjectionIntegrator.cpp:176-178), and (b) the chunk
-          // is alive and was updated at least once (HEntry::alive bits 0 and 2): such a chunk is never new, never parked
-          // by K-A, and tf_finalize -- the one other place that parks -- discards selections made ahead.  A stale read
-          // here can only say no.
-          if (zmin > 0.1f && umin >= 3.0f && umax <= (float)(cam.W - 4) && wmin >= 3.0f && wmax <= (float)(cam.H - 4)) {
-            const unsigned long long key = pack_id(x0 + di, y0 + dj, z0 + dk);
-            uint32_t i = hash_key(key) & v.hmask;
-            for (uint32_t pr2 = 0; pr2 < 64u; ++pr2) {
-              const uint4 en = *reinterpret_cast<const uint4*>(&v.hent[i]);  // {key lo, key hi, slot, alive}
-              const unsigned long long cur = ((unsigned long long)en.y << 32) | en.x;
-              if (cur == key) { split = (en.w & 5u) == 5u && en.z != kInvalidSlot; break; }
-              if (cur == kEmptyKey) break;
-              i = (i + 1) & v.hmask;
-            }
-          }
         }
       }
       m = __ballot(flag);
@@ -538,23 +409,7 @@ __device__ __forceinline__ void select_body(const float* __restrict__ depth, con
         v.sel.list_id[pos] = id;
         const ChunkPre cp = chunk_pre(id, sc.pose, ig, sc.res, sc.resDiag);
         v.sel.list_pre[4 * pos] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
-        // (a pruned entry stays in the list -- PrepareIntersectChunks creates its chunk and GarbageCollect parks it and takes
-        // it out of meshesToUpdate again, which K-A's bookkeeping reproduces -- but K-A skips its voxels: sign bit of `upper`)
-        v.sel.list_pre[4 * pos + 1] = make_float4((pruned || (TF_KA_SPLIT && split)) ? -cp.b.y : cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
-      }
-      if (TF_KA_SPLIT && (unsigned long long)basef + kf + baseb + kb <= (unsigned long long)v.max_list) {
-        const unsigned long long ms = __ballot(split && ((m >> lane) & 1ull));  // (split implies costly: a front position)
-        if (ms) {
-          uint32_t bs = 0;
-          if (lane == 0) bs = atomicAdd(&ctl->n_split, (uint32_t)__popcll(ms));
-          bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)bs);
-          if ((ms >> lane) & 1ull) {
-            const uint32_t pos = basef + (uint32_t)__popcll(mf & ((1ull << lane) - 1ull));
-            v.sel.split_list[bs + (uint32_t)__popcll(ms & ((1ull << lane) - 1ull))] = pos;
-            v.sel.list_needs[pos] = 0;  // the two halves OR their outcome in
-            v.sel.list_pre[4 * pos + 2] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // .x: the upper half's row counts
-          }
-        }
+        v.sel.list_pre[4 * pos + 1] = make_float4(cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
       }
     }
   }
@@ -867,26 +722,11 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     if (!n) nf = 0;
     if (bid == 0 && threadIdx.x == 0) { L.ctl->n_list = n; L.ctl->n_front = nf; }  // for the stages behind this launch
   }
-  // TF_KA_SPLIT: items [0, ns) are the upper halves of the flagged entries, items [ns, ns + n) the entries themselves
-  constexpr bool SPLIT = FUSED && (TF_KA_SPLIT != 0);
-  uint32_t ns = 0;
-  if (SPLIT) { ns = L.ctl->n_split; if (ns > n) ns = 0u; }
-  const uint32_t n_items = n + ns;
-  // where an item's record (and its outputs) live
-  auto item_pos = [&](const uint32_t it) -> uint32_t {
-    if (SPLIT && it < ns) return *(const __attribute__((address_space(4))) uint32_t*)(unsigned long long)(&L.split_list[it]);
-    const uint32_t e = SPLIT ? it - ns : it;
-    return FUSED ? list_phys(v, e, nf) : e;
-  };
+  const uint32_t n_items = n;
+  // where an entry's record (and its outputs) live
+  auto item_pos = [&](const uint32_t e) -> uint32_t { return FUSED ? list_phys(v, e, nf) : e; };
   const int vy = lane >> 3;
   const int W = cam.W, H = cam.H;
-  if (TF_SEL_PRUNE && FUSED) {
-    // re-arm the depth tiles of this selection set for its next frame: the frame's selection role (one launch ago) was
-    // their last reader
-    const uint32_t nt = (uint32_t)(W >> kTileShift) * (uint32_t)((H + 15) >> kTileShift);
-    const uint32_t ti = bid * 256u + threadIdx.x;
-    if (ti < nt && ti < kMaxTiles) L.tiles[ti] = tile_empty();
-  }
   if (FUSED && bid == 0 && threadIdx.x == 0) {
     // re-arm the K-B reduction of this selection set for its next frame (k_scan does this in the
     // call-by-call flow); every k_select block of this frame has finished reading the keys
@@ -899,38 +739,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   // Which entries does this wave take?
   //  call-by-call flow: round-robin over the list (wave w: entries w, w + nwaves, ...).
   //  fused flow: the same, over the two-ended list (costly entries first).
-  //  TF_KA_DYNAMIC=1 (A/B knob, off): a wave PULLS its entries from one of 64 counters in the frame's control block
-  //  (a device word serves ~88 pulls per us, MI355X_MICROARCH.md "dequeue": with eight counters the 18 k pulls of a
-  //  launch stalled the whole chip, k_frame 42 -> 90 us); counter c hands out the logical entries c, c + 64, ...  The
-  //  idea: waves that start late (the patch / selection ranges are dispatched ahead of K-A) or draw costly chunks take
-  //  fewer entries, so the launch ends when the work does.  Measured (profiles/r3): holding two indices per wave is
-  //  static dealing by another name (42 -> 51 us: early waves park work late waves could have started); holding one and
-  //  reading its record at the top of the iteration 42 -> 48 us, TSDF-only 27.5 -> 28.8 us -- the returning atomic sits
-  //  ahead of the depth gathers in the wave's in-order memory queue.  The pull is a buffer atomic whose offset is out of
-  //  range for every lane but lane 0: no exec-mask branch (`if (lane == 0) atomicAdd` made the kernel spill 200 B/lane).
-  constexpr bool DYN = FUSED && TF_KA_DYNAMIC;
-  const uint32_t kac = DYN ? (wave & (uint32_t)(kKaCounters - 1)) : 0u;
-  const __amdgpu_buffer_rsrc_t rs_ctr = __builtin_amdgcn_make_buffer_rsrc((void*)&L.ctl->ka_next[kac * kKaCounterStride], 0, 4, 0x00020000);
-  const int ctr_off = lane == 0 ? 0 : kOOB;
-  uint32_t e_first = wave, e_second = wave + nwaves;
-  // TF_KA_DBG bits 15 / 16 (experiment): waves in odd hardware slots of a SIMD (bit 15) / of odd workgroups (bit 16) walk
-  // their entries LAST FIRST -- their cheap chunk (the back of the two-ended list) runs under the other waves' costly ones
-  // instead of every wave's costly chunk first and the latency-bound cheap ones together at the end
-  uint32_t e_step = nwaves;
-  if (!DYN && (kc.dbg & (32768u | 65536u))) {
-    const bool odd = (kc.dbg & 32768u) ? (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1u) != 0u : (bid & 1u) != 0u;
-    if (odd && wave < n_items) {
-      e_first = wave + ((n_items - 1u - wave) / nwaves) * nwaves;
-      e_step = 0u - nwaves;
-      e_second = e_first + e_step;  // (wraps past zero behind the wave's first entry: the loop ends on e >= n)
-    }
-  }
-  if (DYN) {
-    uint32_t k0 = (uint32_t)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rs_ctr, ctr_off, 0, 0);
-    k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);
-    e_first = (uint32_t)kKaCounters * k0 + kac;
-    e_second = e_first;  // (unknown yet: pulled while the first entry is processed)
-  }
+  const uint32_t e_first = wave, e_step = nwaves;
   // the wave's first list record is requested before anything else: it arrives while the centroid
   // table is copied (64-B records {o.xyz, wD | upper, id.xyz | spare}; the slot exists for any index)
   u32x8 rec_next;
@@ -980,36 +789,26 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     v.phase_buf[wave * 16 + 9] = 0;
   }
 
-  // static scheme: e_next = e + nwaves, its record requested at the top of the iteration.  dynamic scheme: the wave
-  // holds ONE entry (with ~1.5 entries per wave anything a wave parks in advance is work another wave could have
-  // started); the next index is pulled at the top of the iteration, and its record is read at the top of the next one
-  for (uint32_t e = e_first, e_next = e_second; e < n_items; e = e_next) {
+  for (uint32_t e = e_first, e_next = e_first + e_step; e < n_items; e = e_next) {
     const uint32_t pe = item_pos(e);  // where the entry's record and outputs live
-    int half = (SPLIT && e < ns) ? 2 : 0;  // 0 = the whole chunk, 1 = its lower four z-slices, 2 = its upper four
     // The list entry (per-chunk scalars + id) was written by the previous launch, so it is read
     // through the scalar cache: one 64-B record, one s_load, one wait, off the vector-memory queue
     // of the CU (a vector load here would wait behind every gather of the other waves).
-    if (DYN && e != e_first) rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * pe]);
     const u32x8 prw = rec_next;
-    uint32_t pull = 0;  // dynamic scheme: the next index, in flight until the end of the iteration
-    if (DYN) {
-      pull = (uint32_t)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, rs_ctr, ctr_off, 0, 0);
-    } else {
+    {
       // the next record of this wave travels while this chunk is processed (speculative: the slot
       // exists even when the index is past the list, it just holds an older frame's record)
       e_next = e + e_step;
       const uint32_t en = e_next < n_items ? e_next : e;
       rec_next = *(const_u32x8_ptr)(unsigned long long)(&L.list_pre[4 * item_pos(en)]);
     }
-    auto advance = [&]() { if (DYN) e_next = (uint32_t)kKaCounters * (uint32_t)__builtin_amdgcn_readfirstlane((int)pull) + kac; };
     const int4 id = make_int4((int)prw[5], (int)prw[6], (int)prw[7], 0);
     const bool owned = part_owned(v, id.x, id.y, id.z);
     if (!owned) {
-      if (FUSED && lane == 0 && half != 2) {
+      if (FUSED && lane == 0) {
         L.list_slot[pe] = kInvalidSlot; L.list_ent[pe] = 0; L.list_new[pe] = 0; L.list_needs[pe] = 0;
         L.list_quality[pe] = 0.0f; L.list_rows[pe] = 0;
       }
-      advance();
       continue;
     }
     // slot lookup: ONE 16-B scalar load of the chunk's home hash entry, consumed after the
@@ -1030,11 +829,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const f32x2 o01 = {o0, o1};
     const f32x2 fxy = {cam.fxi, cam.fyi}, cxy = {kc.cxs, kc.cys};
     const float wD = FLAG ? pbx : -pbx;  // depth_weight *= -1 when de-integrating (:95-99)
-    // (fused lists: a negative `upper` marks an entry whose depth tiles rule out any voxel write -- select_body --: the
-    // wave does the chunk's bookkeeping, creation / parking / meshesToUpdate, and none of its 512 voxels)
-    const bool pruned = TF_SEL_PRUNE && FUSED && (prw[4] >> 31) != 0u;
-    const float upper = ((TF_SEL_PRUNE || TF_KA_SPLIT) && FUSED) ? fabsf(pby) : pby;
-    if (SPLIT && half == 0 && (prw[4] >> 31) != 0u) half = 1;  // a flagged entry: another wave has its upper half
+    const float upper = pby;
     // every voxel centre of the chunk is o + c with 0 < c < 16 * res * sqrt(3): if |o.z| clears that
     // band, p.z is far inside the normal exponent range; numerators o + c are exact zeros or at
     // least one ulp of c (> 2^-40), and |o| < 2^20 keeps quotients finite -> no scaling / fix-up
@@ -1047,277 +842,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
       v.phase_buf[wave * 16 + 15] = __builtin_amdgcn_s_memrealtime();  // timeline aid: first entry loaded
     }
 
-#if TF_KA_HALVES
-    const int h_begin = half == 2 ? 1 : 0, h_end = half == 1 ? 1 : 2;
-    bool perm = false;  // the home entry says: alive and updated before (HEntry::alive bit 2)
-    // ---- TF_KA_HALVES: the chunk in steps of FOUR z-slices (step h covers slices 4h .. 4h + 3): geometry, gathers and
-    // RMW passes of a step, then the next -- four slices' offsets and depths live at a time instead of eight, and a step
-    // is the unit a second wave could take (the half-chunk work item of VERDICT r3 item 4).  Row order is kept: a row with
-    // no valid lane in step 0 ends the chunk before step 1 starts (R), the quality sum runs on through both steps.
-    constexpr int NJ = 4;
-    int oob_any = 0;
-    uint32_t R = 64;
-    bool lazy_revive = false;
-    bool resolved = false, no_slot = false;
-    float qsum = 0.0f;
-    uint32_t lanes_t = 0, lanes_c = 0;  // lanes of rewritten rows (8 per row), wave-uniform
-    // classes of the voxels written (VolumeDev::summ), reduced row by row into ONE scalar word: the kernel has no
-    // VGPR to spare for per-lane classes and no SGPRs for four lane masks
-    uint32_t sword = 0;
-    unsigned long long m_ok = 0, m_pos = 0, m_neg = 0, m_hvy = 0;
-#pragma nounroll
-    for (int h = h_begin; h < h_end; ++h) {
-    const int jb = h * NJ;
-    if ((uint32_t)(jb * 8) >= R) break;  // a stalled row in the step before ends the chunk
-    // ---- phase 1: geometry of the step's z-slices.  Rows run in order until the first row with no
-    // valid lane -- the reference's `continue` skips `pos++` (:176-178, :420), so that row and
-    // every later row of the chunk is dead: R = number of processed rows.
-    int off_d[NJ];            // image byte offset of the lane's pixel, kOOB when the gather is masked
-    int oobl[QUALITY ? NJ : 1];
-    unsigned long long all_valid = ~0ull;
-    uint32_t oob_bits = 0;  // bit j: the lane's pixel of slice jb + j is off the image
-    auto geometry = [&](auto safe_tag) {
-      constexpr bool SAFE = decltype(safe_tag)::value;
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int k = (jb + j) * 64 + lane;
-        // x and y run as the two halves of packed-f32 instructions (each half rounded on its own)
-        const f32x2 pxy = o01 + (f32x2){cenT[0][k], cenT[1][k]};
-        const float pzv = o2 + cenT[2][k];
-        // px / pz and py / pz (:155-164), correctly rounded; fast path when every lane is in range
-        f32x2 q;
-        if (SAFE) {
-          q = div2_by(pxy, recip_refined(pzv));
-        } else {
-          q.x = pxy.x / pzv;
-          q.y = pxy.y / pzv;
-        }
-        const f32x2 uw = q * fxy + cxy;
-        // in the SAFE range no quotient is NaN, so v_cvt's own saturation classifies like x86's
-        const int X = SAFE ? cvt_rne_hw(uw.x) : cvt_sat_rne(uw.x);
-        const int Y = SAFE ? cvt_rne_hw(uw.y) : cvt_sat_rne(uw.y);
-        // 0 < X < W-1 and 0 < Y < H-1 (:167-173) as two unsigned range tests
-        const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
-        all_valid &= ballot(valid);
-        int od = (__mul24(Y, W) + X) * 4;  // valid => 0 < Y < H, exact in 24 bits
-        asm volatile("" : "+v"(od));       // keep the select a v_cndmask (no exec-mask branch)
-        off_d[j] = valid ? od : kOOB;
-        // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220); implies !valid
-        if (COLOR) oob_bits |= (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1))) ? (1u << j) : 0u;
-      }
-    };
-    if (pruned) {
-      R = 0;  // no row is processed: the passes below end at once
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) off_d[j] = kOOB;
-    } else if (div_safe) geometry(std::true_type{});
-    else geometry(std::false_type{});
-    if (QUALITY) {
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) oobl[j] = 0;
-    }
-    if (all_valid != ~0ull) {  // steps that project entirely inside the image skip all of this
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if (R == 64u) {
-          const unsigned long long vmj = ballot(off_d[j] != kOOB);  // (off_d[j] == kOOB <=> !valid at this point)
-          const unsigned long long dead = nonzero_bytes(vmj) ^ 0x0101010101010101ull;
-          if (dead) R = (uint32_t)((jb + j) * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
-        }
-        const bool live_lane = (uint32_t)((jb + j) * 8 + vy) < R;
-        if (COLOR) {  // off-image lanes of processed rows only
-          const bool oob = live_lane && ((oob_bits >> j) & 1u);
-          oob_any |= oob ? 1 : 0;
-          if (QUALITY) oobl[j] = oob ? 1 : 0;
-        }
-        off_d[j] = live_lane ? off_d[j] : kOOB;
-      }
-    }
-
-    // ---- phase 2: depth gathers (masked lanes read 0, like the reference's masked gather)
-    float dep[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-      dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j], 0, 0));
-
-    // ---- resolve the slot once (first step).  Fast path: the home entry holds the key.  A parked chunk (alive
-    // == 0: created by an earlier frame, never updated, garbage-collected) counts as new again; it is
-    // revived only if this frame updates it, so the usual "selected, outside the band, parked again"
-    // round trip of the chunks in front of the surface costs no hash traffic at all.
-    if (!resolved) {
-      resolved = true;
-      if (FUSED) {
-        if ((((unsigned long long)h0.y << 32) | h0.x) == key && h0.z != kInvalidSlot) {
-          slot = h0.z;
-          is_new = lazy_revive = (h0.w == 0u);
-          perm = (h0.w & 4u) != 0u;
-        } else {
-          uint32_t s0 = kInvalidSlot, nw = 1, en = 0;
-          if (lane == 0) {
-            bool bnew = true;
-            s0 = chunk_acquire(v, id, &bnew, &en);
-            nw = bnew ? 1u : 0u;
-          }
-          slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)s0);
-          is_new = __builtin_amdgcn_readfirstlane((int)nw) != 0;
-          ent = (uint32_t)__builtin_amdgcn_readfirstlane((int)en);
-        }
-      }
-      if (SPLIT && half != 0 && (is_new || all_valid != ~0ull)) {  // cannot happen (select_body); loud if it does
-        if (lane == 0) atomicOr(&v.vctl->status, kStSplit);
-        slot = kInvalidSlot;
-      }
-      if (slot == kInvalidSlot) { no_slot = true; break; }
-    }
-    const __amdgpu_buffer_rsrc_t rs_T =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_C =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
-
-#pragma unroll
-    for (int p = 0; p < NJ / GP; ++p) {
-      const int g0 = p * GP;
-      if ((uint32_t)((jb + g0) * 8) >= R) break;  // a stalled row ends the chunk
-      // ---- phase 3: predicates -> offsets
-      float nwv[GP], sd[GP];
-      int off_t[GP], off_c[GP], off_i[GP];
-      unsigned long long any = 0ull;
-#pragma unroll
-      for (int j = 0; j < GP; ++j) {
-        const int gj = g0 + j;
-        const int kb = ((jb + gj) * 64 + lane) * 8;
-        const float d = dep[gj];
-        const float s = d - (o2 + cenT[2][(jb + gj) * 64 + lane]);  // p.z again: an LDS read is cheaper than live VGPRs
-        sd[j] = s;
-        if (COLOR) {
-          const bool upd = (off_d[gj] != kOOB) && (fabsf(s) < c_thr);  // -thr < sd < thr (:202-208)
-          off_i[j] = upd ? off_d[gj] : kOOB;
-          const bool ru_l = row_any(ballot(upd));
-          const unsigned long long ru = ballot(ru_l);
-          off_c[j] = ru_l ? kb : kOOB;
-          lanes_c += (uint32_t)__popcll(ru);
-          any |= ru;
-        }
-        const bool act = (uint32_t)((jb + gj) * 8 + vy) < R;
-        const bool dv = (d > c_near) && (c_far > d);           // (:310-312)
-        const bool inside = (s > c_lower) && (upper > s);      // (:313-316)
-        const bool F = act && dv && inside;
-        nwv[j] = F ? wD : 0.0f;
-        const bool rf_l = row_any(ballot(F));
-        const unsigned long long rf = ballot(rf_l);
-        off_t[j] = rf_l ? kb : kOOB;
-        lanes_t += (uint32_t)__popcll(rf);
-        any |= rf;
-      }
-      // nothing of this pass is rewritten (chunk outside the band, or a hole): skip the RMW
-      // phases for the whole wave -- about a third of the selected chunks never update a row
-      const bool rmw = (any != 0ull) || (COLOR && QUALITY);
-      // ---- phase 4: voxel rows that will be rewritten + their inputs
-      u32x2 t[GP], c[GP];
-      uint32_t in[GP];
-      float qv[GP];
-      if (rmw) {
-#pragma unroll
-        for (int j = 0; j < GP; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, off_t[j], 0, 0);
-        if (COLOR) {
-#pragma unroll
-          for (int j = 0; j < GP; ++j) {
-            c[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_C, off_c[j], 0, 0);
-            in[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[j], 0, 0);
-            if (QUALITY) qv[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qual, off_i[j], 0, 0));
-          }
-        }
-      }
-      // ---- phase 5a: arithmetic on the loaded rows
-      if (rmw) {
-#pragma unroll
-        for (int j = 0; j < GP; ++j) {
-          if (COLOR) {
-            // colour planes are 4 x u16 {r, g, b, count} per voxel = two packed-u16 dwords; the
-            // image pixel is widened with two byte permutes ({r, g} and {b, a} as u16 pairs)
-            // (__builtin_bit_cast needs plain scalars: applied to a vector element it reads element 0)
-            const uint32_t p_rg = __builtin_amdgcn_perm(0u, in[j], 0x0c010c00u);
-            const uint32_t p_ba = __builtin_amdgcn_perm(0u, in[j], 0x0c030c02u);
-            const uint32_t w_rg = c[j].x, w_ba = c[j].y;
-            const u16x2 in_rg = __builtin_bit_cast(u16x2, p_rg), in_ba = __builtin_bit_cast(u16x2, p_ba);
-            u16x2 c_rg = __builtin_bit_cast(u16x2, w_rg), c_ba = __builtin_bit_cast(u16x2, w_ba);
-            if (FLAG) {  // (:274-292)
-              c_rg += in_rg;
-              c_ba += in_ba;
-              // (short)count > 120  <=>  the dword, read as signed, is >= 121 << 16
-              const bool halve = (int)__builtin_bit_cast(uint32_t, c_ba) >= (121 << 16);
-              const u16x2 h_rg = c_rg >> (unsigned short)2, h_ba = c_ba >> (unsigned short)2;
-              c_rg = halve ? h_rg : c_rg;
-              c_ba = halve ? h_ba : c_ba;
-            } else {     // (:293-304)
-              c_rg -= in_rg;
-              c_ba -= in_ba;
-            }
-            c[j].x = __builtin_bit_cast(uint32_t, c_rg);
-            c[j].y = __builtin_bit_cast(uint32_t, c_ba);
-          }
-          const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);  // (:319-341)
-          const float nw = nwv[j];
-          const float num = ts * tw + sd[j] * nw;
-          const float den = (tw + nw) + c_sigma;
-          const float ns = num / den;
-          const float nwt = tw + nw;
-          const bool keep = nwt > 0.5f;
-          t[j].x = __float_as_uint(keep ? ns : 999.0f);
-          t[j].y = __float_as_uint(keep ? nwt : 0.0f);
-          // (a row that is not rewritten was loaded as zeros and comes out as {999, 0}: class 0)
-        }
-      }
-      // ---- phase 5b: write back the rewritten rows only (masked offsets drop the store)
-      if (rmw) {
-#pragma unroll
-        for (int j = 0; j < GP; ++j) {
-          if (COLOR) __builtin_amdgcn_raw_buffer_store_b64(c[j], rs_C, off_c[j], 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, off_t[j], 0, 0);
-          if (!(kc.dbg & kKaCoarseSumm)) {  // lane = x + 8 y of row z = jb + g0 + j
-            const float fs = __uint_as_float(t[j].x), fw = __uint_as_float(t[j].y);
-            const unsigned long long b_ok = ballot(!(fs > 1.0f)), b_pos = ballot(fs > 0.0f) & b_ok;
-            const unsigned long long b_neg = ballot(fs < 0.0f), b_hvy = ballot(fw > 50.0f);
-            m_ok |= b_ok; m_pos |= b_pos; m_neg |= b_neg; m_hvy |= b_hvy;
-            if (jb + g0 + j == 0)
-              sword = (b_ok ? 0x1000u : 0u) | (b_pos ? 0x2000u : 0u) | (b_neg ? 0x4000u : 0u) | (b_hvy ? 0x8000u : 0u);
-          }
-        }
-      }
-      // ---- phase 6: observationQualitySum bookkeeping in row order (:212-238)
-      if (COLOR && QUALITY) {
-        const int rowshift = lane & 56;
-#pragma unroll
-        for (int j = 0; j < GP; ++j) {
-          const int gj = g0 + j;
-          const unsigned long long mu = ballot(off_i[j] != kOOB);
-          const unsigned long long mo = ballot(oobl[gj] != 0);
-          if ((mu | mo) == 0ull) continue;
-          float rowsum = 0.0f;
-          if (mu) {  // sum += observationQuality[i], i = 0..7 (:233-236)
-#pragma unroll
-            for (int l = 0; l < 8; ++l) rowsum += __shfl(qv[j], rowshift + l);
-          }
-          const int left = (int)R - (jb + gj) * 8;
-          const int rmax = left < 8 ? left : 8;
-          for (int r = 0; r < rmax; ++r) {
-            if ((mo >> (8 * r)) & 0xFFull) qsum = kc.qoob;
-            if ((mu >> (8 * r)) & 0xFFull)
-              qsum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowsum), 8 * r));
-          }
-        }
-      }
-    }
-    }  // steps
-    if (no_slot) {
-      if (FUSED && lane == 0 && half != 2) {
-        L.list_slot[pe] = kInvalidSlot; L.list_ent[pe] = 0; L.list_new[pe] = 0; L.list_needs[pe] = 0;
-        L.list_quality[pe] = 0.0f; L.list_rows[pe] = 0;
-      }
-      advance();
-      continue;
-    }
-#else
     // ---- phase 1: geometry of the 8 z-slices.  Rows run in order until the first row with no
     // valid lane -- the reference's `continue` skips `pos++` (:176-178, :420), so that row and
     // every later row of the chunk is dead: R = number of processed rows.
@@ -1329,9 +853,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     // the scheduler can interleave); the order-dependent part -- which row stalls the chunk -- is
     // resolved afterwards from the eight validity ballots, and only for chunks that do not project
     // entirely inside the image.
-#if TF_KA_VM_ARRAY
-    unsigned long long vm[8];
-#endif
     unsigned long long all_valid = ~0ull;  // (the eight validity ballots are only kept as their AND: 14 scalar registers less
                                            // at the kernel's tightest spot; the rare chunk that needs them gets them back from off_d)
     uint32_t oob_bits = 0;  // bit j: the lane's pixel of slice j is off the image
@@ -1357,12 +878,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         const int Y = SAFE ? cvt_rne_hw(uw.y) : cvt_sat_rne(uw.y);
         // 0 < X < W-1 and 0 < Y < H-1 (:167-173) as two unsigned range tests
         const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
-#if TF_KA_VM_ARRAY
-        vm[j] = ballot(valid);
-        all_valid &= vm[j];
-#else
         all_valid &= ballot(valid);
-#endif
         int od = (__mul24(Y, W) + X) * 4;  // valid => 0 < Y < H, exact in 24 bits
         asm volatile("" : "+v"(od));       // keep the select a v_cndmask (no exec-mask branch)
         off_d[j] = valid ? od : kOOB;
@@ -1370,11 +886,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         if (COLOR) oob_bits |= (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1))) ? (1u << j) : 0u;
       }
     };
-    if (pruned) {
-      R = 0;  // no row is processed: the passes below end at once
-#pragma unroll
-      for (int j = 0; j < 8; ++j) off_d[j] = kOOB;
-    } else if (div_safe) geometry(std::true_type{});
+    if (div_safe) geometry(std::true_type{});
     else geometry(std::false_type{});
     if (QUALITY) {
 #pragma unroll
@@ -1384,11 +896,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (R == 64u) {
-#if TF_KA_VM_ARRAY
-          const unsigned long long vmj = vm[j];
-#else
           const unsigned long long vmj = ballot(off_d[j] != kOOB);  // (off_d[j] == kOOB <=> !valid at this point)
-#endif
           const unsigned long long dead = nonzero_bytes(vmj) ^ 0x0101010101010101ull;
           if (dead) R = (uint32_t)(j * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
         }
@@ -1434,7 +942,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         L.list_slot[pe] = kInvalidSlot; L.list_ent[pe] = 0; L.list_new[pe] = 0; L.list_needs[pe] = 0;
         L.list_quality[pe] = 0.0f; L.list_rows[pe] = 0;
       }
-      advance();
       continue;
     }
     const __amdgpu_buffer_rsrc_t rs_T =
@@ -1583,7 +1090,6 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         }
       }
     }
-#endif
     const uint32_t rows_t = lanes_t >> 3, rows_c = COLOR ? (lanes_c >> 3) : 0u;
     const bool updated = rows_t != 0;
     if (updated) {  // the classes of what was written join the chunk's summary: lane = x + 8 y of a row
@@ -1609,17 +1115,10 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
 
     // multi-GPU: remember that this slab-face chunk changed since the last boundary exchange
     const bool face = part_band(v, id.x, id.y, id.z);
-#if TF_KA_SPLIT
-    if (updated && lane == 0 && (face || lazy_revive || (FUSED && !perm))) {
-      const uint32_t en = FUSED ? ent : L.list_ent[pe];
-      v.hent[en].alive = (face ? 3u : 1u) | (FUSED ? 4u : 0u);  // bit0 alive, bit1 touched, bit2 updated at least once
-    }
-#else
     if (updated && lane == 0 && (face || lazy_revive)) {
       const uint32_t en = FUSED ? ent : L.list_ent[pe];
       v.hent[en].alive = face ? 3u : 1u;  // bit0 alive, bit1 touched
     }
-#endif
     if (FUSED) {
       // FinalizeIntegrateChunks (Chisel.h:192-208) + GarbageCollect (:472-477) for this entry
       // (erase_epoch == mark_epoch + max_chunks, one allocation: both stores go through ONE pointer member.  With
@@ -1668,25 +1167,15 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         }
       }
       if (lane == 0) {  // what later stages read of a fused frame: slot, needsUpdate, row counts
-        if (!SPLIT || half == 0) {
-          L.list_slot[pe] = slot;
-          L.list_needs[pe] = updated ? 1 : 0;
-          L.list_rows[pe] = (uint16_t)(rows_t | (rows_c << 8));
-        } else if (half == 1) {  // (the selection cleared needsUpdate: the halves OR their outcome in)
-          L.list_slot[pe] = slot;
-          if (updated) L.list_needs[pe] = 1;
-          L.list_rows[pe] = (uint16_t)(rows_t | (rows_c << 8));
-        } else {
-          if (updated) L.list_needs[pe] = 1;
-          reinterpret_cast<uint32_t*>(&L.list_pre[4 * pe + 2])[0] = rows_t | (rows_c << 8);
-        }
+        L.list_slot[pe] = slot;
+        L.list_needs[pe] = updated ? 1 : 0;
+        L.list_rows[pe] = (uint16_t)(rows_t | (rows_c << 8));
       }
     } else if (lane == 0) {
       if (updated) L.list_needs[pe] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
       L.list_quality[pe] = qsum;
       L.list_rows[pe] = (uint16_t)(rows_t | (rows_c << 8));
     }
-    advance();
   }
 }
 
@@ -1895,12 +1384,10 @@ struct FrameLaunch {
   uint32_t epoch;
   uint32_t n_ka, n_sel, n_bbox;
   uint32_t rot;          // dispatch-order rotation of the block ranges
-  uint32_t mix;          // > 0: the patch range is dealt INTO the K-A range, one patch workgroup per `mix` K-A workgroups (TF_FRAME_MIX)
   SelBuf sel1;           // set of frame f+1
   const float* depth1;
   SelectConsts sc1;
   FrameCtl* ctl2;        // set of frame f+2
-  uint2* tiles2;         // ... its depth tiles (null: the selection does not prune)
   const float* depth2;
   Pose P2;
   int claim_par;         // FrameStage::claim_par of frame f
@@ -1916,15 +1403,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATCH ? TF_
   // Block ranges: K-A [0, n_ka), patches [n_ka, n_ka + n_patch), K-C, K-B behind them.
   // a.rot rotates the dispatch order: 0 = K-A blocks first, n_ka = the other roles first
   const uint32_t total = a.n_ka + a.n_patch + a.n_sel + a.n_bbox;
-  uint32_t b = blockIdx.x + a.rot < total ? blockIdx.x + a.rot : blockIdx.x + a.rot - total;
-  if (PATCH && a.mix) {
-    // dispatch order P A..A P A..A ... while patch workgroups last, then the rest of K-A, then the selection roles: the
-    // stage's latency chains and K-A's arithmetic run side by side from the start of the launch
-    const uint32_t i = blockIdx.x, m1 = a.mix + 1u, zone = a.n_patch * m1;
-    if (i < zone) { const uint32_t g = i / m1, r = i - g * m1; b = r == 0u ? a.n_ka + g : g * a.mix + (r - 1u); }
-    else if (i < a.n_ka + a.n_patch) b = i - a.n_patch;
-    else b = i;
-  }
+  const uint32_t b = blockIdx.x + a.rot < total ? blockIdx.x + a.rot : blockIdx.x + a.rot - total;
   // tuning aid (dbg bit 12): per-wave {start, end, role} stamps of the last launch -> phase_buf
   const bool timeline = (a.kc.dbg & 4096u) != 0 && a.n_sel > 0 && a.n_bbox > 0;  // steady launches only
   const unsigned long long t0 = timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz, chip-wide
@@ -1947,7 +1426,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATCH ? TF_
     // the progress stamp lives in this (lightest) role: next to K-A it cost 36-212 B/lane of private memory
     if (a.progress && b + 1 == total && threadIdx.x == 0)
       __hip_atomic_store(a.progress, a.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_patch - a.n_sel, a.n_bbox, a.tiles2);
+    if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_patch - a.n_sel, a.n_bbox);
   }
   if (timeline) {
     const uint32_t gw = (b * 256 + threadIdx.x) >> 6;
@@ -1981,7 +1460,7 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
                       uint32_t epoch, hipStream_t s, bool have_pre) {
   IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
   if (!have_pre) hipLaunchKernelGGL(k_pre, dim3(256), dim3(256), 0, s, v, pose, ig, res, kc.resDiag, (float4*)nullptr, (float*)nullptr);
-  static const int nblocks = env_int("TF_KA_BLOCKS", ka_blocks_default());  // tuning knob
+  static const int nblocks = ka_blocks_default();
   const dim3 grid(nblocks > 0 ? nblocks : 2048), block(256);
 #define TF_LAUNCH_KA(C, Q)                                                                           \
   do {                                                                                               \
@@ -2016,9 +1495,8 @@ void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_dep
     ga.cen[f] = cen_scratch + (size_t)f * 3 * kChunkVoxels;
   }
   if (!have_pre) hipLaunchKernelGGL(k_pre_group, dim3(128, n), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch, Pose{}, 0);
-  static const int nblocks = env_int("TF_KG_BLOCKS", 0);
-  int cus = ka_blocks_default() / TF_KF_WAVES;
-  const dim3 grid(nblocks > 0 ? nblocks : cus * 4), block(256);  // 36 KB of LDS per workgroup: four per CU
+  static const int cus = device_cus();
+  const dim3 grid(cus * 4), block(256);  // 36 KB of LDS per workgroup: four per CU
   if (flag) hipLaunchKernelGGL(k_integrate_group<true>, grid, block, 0, s, v, ga, cam, kc);
   else hipLaunchKernelGGL(k_integrate_group<false>, grid, block, 0, s, v, ga, cam, kc);
 }
@@ -2030,10 +1508,10 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
                   const FrameStage* next2, const PatchStage* patch, const Cam& cam, const Integ& ig, float res, hipStream_t s,
                   uint32_t* progress, uint32_t* progress_seq) {
   const bool with_patch = patch != nullptr && cur != nullptr && cur->img.rgba != nullptr;
-  static const int nblocks7 = env_int("TF_KA_BLOCKS", ka_blocks_default());
+  static const int nblocks7 = ka_blocks_default();
   // with the patch stage on board K-A gets one workgroup per CU more than the instance's residency: the patch / selection
   // ranges are dispatched FIRST (below) and K-A's workgroups take the slots they leave as they finish
-  static const int nblocksP = env_int("TF_KAP_BLOCKS", device_cus() * (TF_KFP_WAVES + 1));
+  static const int nblocksP = device_cus() * (TF_KFP_WAVES + 1);
   const int nblocks = with_patch ? nblocksP : nblocks7;
   FrameLaunch a;
   a.v = v;
@@ -2046,20 +1524,13 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   a.progress = nullptr;
   a.progress_val = 0;
   if (with_patch) {
-    static const int npb = env_int("TF_PATCH_BLOCKS", 1024);
-    a.n_patch = (uint32_t)npb;
+    a.n_patch = 1024u;  // one wave per patch: 4096 waves for a room frame's ~2.9 k patches (longer lists stride)
     a.patch_par = patch->par;
     a.kf_patch = patch->kf;
   }
   // workgroups of the selection role (run 24, profiles/r3/README.md): 256 where K-A is dispatched first and the role fills
   // its tail (TSDF-only 27.5 us at 256 and 512, 30.8 at 128; hall 225 / 237 / 232 us); 128 where the patch and selection
   // ranges go first and every wave they hold delays a K-A wave (textured room: k_frame 42.2 us at 512, 40.8 at 256, 39.8 at 128)
-  static const int nsel_env = env_int("TF_SEL_BLOCKS", 0);
-  // depth-tile pruning of the selection (TF_SEL_PRUNE=0: off): every frame's K-B role fills the tiles, its selection role
-  // reads them, its K-A role re-arms them -- all three or none
-  static const int prune_env = env_int("TF_SEL_PRUNE", 1);
-  const bool prune = TF_SEL_PRUNE && prune_env != 0 && (cam.W & 15) == 0 &&
-                     (uint32_t)(cam.W >> kTileShift) * (uint32_t)((cam.H + 15) >> kTileShift) <= kMaxTiles;
   a.kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);
   static const int dbg = env_int("TF_KA_DBG", 0);
   a.kc.dbg = (uint32_t)dbg;
@@ -2078,26 +1549,19 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
     a.sel1 = next->sel;
     a.depth1 = next->img.depth;
     a.sc1 = make_select_consts(next->pose.p, res);
-    a.sc1.prune = prune ? 1 : 0;  // (that frame's K-B role -- one launch ago -- filled its depth tiles)
-    static const int split_env = env_int("TF_KA_SPLIT", 1);  // (A/B knob of the compile-time experiment)
-    a.sc1.split = (TF_KA_SPLIT && split_env) ? 1 : 0;
     a.n_sel = 1u;  // (sized below, once the dispatch order is known)
   }
-  a.tiles2 = nullptr;
   if (next2) {
-    a.tiles2 = prune ? next2->sel.tiles : nullptr;
     a.ctl2 = next2->sel.ctl;
     a.depth2 = next2->img.depth;
     a.P2 = next2->pose;
     int nvec = (cam.W * cam.H) >> 2;
     int blocks = (nvec + 255) / 256;
-    static const int nbb = env_int("TF_BBOX_BLOCKS", 128);
-    a.n_bbox = (uint32_t)(blocks > nbb ? nbb : blocks);
+    a.n_bbox = (uint32_t)(blocks > 128 ? 128 : blocks);
   }
-  static const int sel_first = env_int("TF_SEL_FIRST", -1);  // tuning knob: 1 = the other roles ahead of K-A, 0 = K-A first
   // (a hall-sized frame -- K-A waves with ten chunks each -- wants K-A first: the other ranges then fill its tail)
-  const bool others_first = sel_first >= 0 ? sel_first != 0 : (with_patch && cur->small_frame);
-  if (a.n_sel) a.n_sel = (uint32_t)(nsel_env > 0 ? nsel_env : (others_first ? 128 : 256));
+  const bool others_first = with_patch && cur->small_frame;
+  if (a.n_sel) a.n_sel = others_first ? 128u : 256u;
   const uint32_t total = a.n_ka + a.n_patch + a.n_sel + a.n_bbox;
   if (!total) return;
   if (progress && progress_seq && a.n_bbox) {  // (the K-B role carries the stamp: steady launches of a stream have one)
@@ -2109,9 +1573,6 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   // frees.  With the patch stage on board that order leaves the stage's 15-us chains to start when K-A's waves end
   // (profiles/r3: span 48 us); patch + selection first, K-A behind them as their waves finish: 44 us.
   a.rot = others_first ? a.n_ka : 0u;
-  static const int mix_env = env_int("TF_FRAME_MIX", 0);
-  a.mix = 0u;
-  if (with_patch && mix_env > 0 && a.n_ka >= a.n_patch * (uint32_t)mix_env) { a.mix = (uint32_t)mix_env; a.rot = 0u; }
   if (with_patch) hipLaunchKernelGGL((k_frame<true, true>), dim3(total), dim3(256), 0, s, a);
   else if (color) hipLaunchKernelGGL((k_frame<true, false>), dim3(total), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k_frame<false, false>), dim3(total), dim3(256), 0, s, a);
@@ -2191,33 +1652,24 @@ void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_rowstats(VolumeDev v, unsigned long long* out3) {
   const SelBuf& L = v.sel;
   const uint32_t n = L.ctl->n_list, nf = L.ctl->n_front;
-  unsigned long long rt = 0, rc = 0, nu = 0, np = 0;
+  unsigned long long rt = 0, rc = 0, nu = 0;
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const uint32_t i = list_phys(v, e, nf);
     const uint32_t r = L.list_rows[i];
     rt += r & 0xFFu;
     rc += r >> 8;
     nu += L.list_needs[i] ? 1 : 0;
-    const bool flagged = (__float_as_uint(L.list_pre[4 * i + 1].x) >> 31) != 0u;
-    np += flagged ? 1 : 0;  // entries the depth tiles ruled out (TF_SEL_PRUNE) / entries walked as two halves (TF_KA_SPLIT)
-    if (TF_KA_SPLIT && flagged) {  // the upper half's rows
-      const uint32_t r2 = __float_as_uint(L.list_pre[4 * i + 2].x);
-      rt += r2 & 0xFFu;
-      rc += (r2 >> 8) & 0xFFu;
-    }
   }
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) {
     rt += __shfl_xor(rt, o);
     rc += __shfl_xor(rc, o);
     nu += __shfl_xor(nu, o);
-    np += __shfl_xor(np, o);
   }
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&out3[0], rt);
     atomicAdd(&out3[1], rc);
     atomicAdd(&out3[2], nu);
-    atomicAdd(&out3[3], np);
   }
 }
 // The outputs of a call-by-call tf_integrate -- needsUpdate flags, quality sums, the status word -- written straight into
@@ -2247,7 +1699,7 @@ __global__ __launch_bounds__(128) void k_export_ctl(const uint32_t* __restrict__
   if (t < nv) h[nf + t] = vc[t];
 }
 void launch_export_ctl(const FrameCtl* f, const VolCtl* vc, uint32_t* h, hipStream_t s) {
-  constexpr uint32_t nf = offsetof(FrameCtl, ka_next) / 4, nv = sizeof(VolCtl) / 4;
+  constexpr uint32_t nf = sizeof(FrameCtl) / 4, nv = sizeof(VolCtl) / 4;
   static_assert(nf <= 128 && nv <= 128, "one workgroup exports the control blocks");
   hipLaunchKernelGGL(k_export_ctl, dim3(1), dim3(128), 0, s, reinterpret_cast<const uint32_t*>(f), nf,
                      reinterpret_cast<const uint32_t*>(vc), nv, h);

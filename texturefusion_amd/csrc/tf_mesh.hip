@@ -34,10 +34,7 @@ namespace tf {
 __device__ const unsigned long long d_mc_tri[256] = TF_MC_TRI_TABLE_INIT;
 
 constexpr int kR = 11;               // staged region: voxel coordinates -1 .. 9 per axis
-#ifndef TF_MESH_RS
-#define TF_MESH_RS 11                // LDS row stride of the staged region in words (>= 11; A/B of bank conflicts, profiles/r4)
-#endif
-constexpr int kRS = TF_MESH_RS;      // row stride
+constexpr int kRS = 11;              // row stride in words (12 / 13 measured the same: the waves do not wait for LDS issue, profiles/r4)
 constexpr int kPS = kRS * kR;        // plane stride
 constexpr int kRV = kPS * kR;        // 1331 words at the natural stride
 constexpr int kEdgeSlots = 3 * 729;  // vertByEdge (ChunkManager.cpp:646-648)
@@ -161,13 +158,10 @@ constexpr uint32_t kCfHeavy = 64u;   // weight > 50 (weight_threshold, ChunkMana
 constexpr uint32_t kCfGradOk = 128u; // |gradient| <= 100 * resolution (:449-452)
 // bits 0..5: the voxel one step along -x, +x, -y, +y, -z, +z has sdf < 1 (GetNeighborSDF, ChunkManager.h:790-823)
 
-#ifndef TF_MESH_CFLAG_T
-#define TF_MESH_CFLAG_T uint8_t   // (uint32_t: 2.2 KB more LDS per workgroup, no sub-dword LDS accesses; A/B in profiles/r4)
-#endif
 template <int NT>
 struct MeshSh {
   float S[kRV];               // sdf, region coordinates -1..9
-  TF_MESH_CFLAG_T cflag[732]; // per cell corner: kCf* | neighbour bits
+  uint8_t cflag[732]; // per cell corner: kCf* | neighbour bits
   uint32_t nslot[27];         // pool slot of chunk id + (-1..1)^3, kInvalidSlot = missing
   // output vertex index of a used edge slot m = rbase[m / kEpt] + popcount(rmask[m / kEpt] below bit m % kEpt), kEpt =
   // 2304 / threads: one {base, mask} pair per THREAD of the ranking pass instead of 2187 16-bit entries (LDS per
@@ -182,7 +176,6 @@ struct MeshSh {
   uint32_t nv, nt, adj, any;
   uint32_t ncell;             // cells the surface passes through
   uint16_t clist[512];        // ... in no particular order (what is computed per cell is stored per cell)
-  uint32_t f_own, f_maybe, f_fl[4], f_incl[kMeshShards], f_n[kMeshShards];  // fused filter: the entry's pool slot, "the summaries cannot rule it out", class words of the waves
   uint32_t ovf;               // overflow block of the chunk (index + 1, 0 = none): owned before this pass or handed out in it
   uint32_t rstate;            // MeshRec::state as it was before this pass
   unsigned long long rtexloc; // MeshRec::texloc
@@ -289,30 +282,12 @@ __device__ __forceinline__ uint32_t filter_near(const VolumeDev& v, const int4 i
 // (only a survivor's row needs them).  A survivor gets a row of its shard for the mesher's staging.
 __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, uint32_t nslot, int lane,
                                              uint32_t epoch, uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
-                                             uint32_t cap_sh, int ppar, bool use_summ, bool exact, bool defer) {
+                                             uint32_t cap_sh, int ppar, bool use_summ, bool defer) {
   const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
   const uint32_t own = (uint32_t)__shfl((int)nslot, 13);
   // rows and patch entries go to shard own % 32: pool slots are unique, so a shard never holds more than
   // max_chunks / 32 of them whatever the order of the work
   const uint32_t shard = own & (kMeshShards - 1u);
-  if (!exact) {
-    // TF_FILTER_EXACT=0 (wave form only): no voxel is read here.  Every chunk the summaries cannot rule out gets a row;
-    // the mesher rewrites the summary from the own voxels it loads anyway (launch_mesh has the numbers)
-    if (lane < 27 && !is_near) {
-      const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
-      if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
-    }
-    uint32_t p = 0;
-    if (lane == 0) p = atomicAdd(&cnt[shard * 16], 1u);
-    p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
-    if (p >= cap_sh) {
-      if (lane == 0) atomicOr(&v.vctl->status, kStMeshFull);
-      return;
-    }
-    if (lane >= 27 && lane < 30) nslot = (uint32_t)(lane == 27 ? id.x : (lane == 28 ? id.y : id.z));
-    if (lane < 30) surv[32 * ((size_t)shard * cap_sh + p) + lane] = nslot;
-    return;
-  }
   const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
   float4 qv[4];
 #pragma unroll
@@ -411,7 +386,7 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 8
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
                                                      uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool use_summ,
-                                                     uint32_t* __restrict__ len_hint, int shards_par, bool exact, FilterPatch fp) {
+                                                     uint32_t* __restrict__ len_hint, int shards_par, FilterPatch fp) {
   if (PATCH && blockIdx.x - fp.first < fp.n_patch) {
     patch_body<true, true, true>(v, fp.cam, fp.par, fp.kf, blockIdx.x - fp.first, fp.n_patch);
     return;
@@ -426,7 +401,7 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 8
   const uint32_t wl_rows = mesh_shard_rows_d(v.max_chunks);
   const size_t wl_base = (size_t)(shards_par & 1) * kMeshShards * wl_rows;
   uint32_t sh_n = 0, sh_incl = 0;
-  if (shards_par >= 0) {
+  if (shards_par >= 0 && (!WAVE_FORM || bid == 0)) {  // (the wave form needs the sums for the length hint only)
     if (lane < (int)kMeshShards) { sh_n = v.wl_cnt[((shards_par & 1) * kMeshShards + lane) * 16]; if (sh_n > wl_rows) sh_n = wl_rows; }
     sh_incl = sh_n;
 #pragma unroll
@@ -441,34 +416,47 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 8
   if (len_hint && bid == 0 && threadIdx.x == 0) *len_hint = n;
   const uint32_t nwaves = nblk * 4;
   if (WAVE_FORM) {
-    for (uint32_t entry = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6)); entry < n;
-         entry += nwaves) {
-      int4 id;
-      uint32_t own_listed = kInvalidSlot;
-      if (entry < n_flat) {
-        id = dlist[entry];
-        if (dslot) own_listed = dslot[entry];  // (under a wave-uniform test: see profiles/r2/README.md)
-      } else {
-        const uint32_t r = entry - n_flat;
-        const uint32_t shd = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(lane < (int)kMeshShards && sh_incl <= r)));
-        const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)(sh_incl - sh_n), (int)(shd & 31u)));
-        const size_t at = wl_base + (size_t)shd * wl_rows + (r - first);
-        id = v.wl_ids[at];
-        own_listed = v.wl_slot[at];
-      }
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6));
+    auto process = [&](const int4 id, const uint32_t own_listed, const bool have_own) {
       uint32_t own = kInvalidSlot;
       bool maybe = false;
       uint32_t near8 = kInvalidSlot;
-      if (lane < 8) near8 = filter_near(v, id, lane, lane, dslot != nullptr || entry >= n_flat, own_listed, use_summ, &own, &maybe);
+      if (lane < 8) near8 = filter_near(v, id, lane, lane, have_own, own_listed, use_summ, &own, &maybe);
       own = (uint32_t)__shfl((int)own, 0);
       maybe = __shfl((int)maybe, 0) != 0;
-      if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
+      if (own == kInvalidSlot) return;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
       if (!maybe) {
         if (lane == 0) { if (fp.defer) filter_defer_reset(v, cnt, cap_sh, own, id); else filter_reset_record(v, own, id, epoch, ppar); }
-        continue;
+        return;
       }
       const uint32_t got = (uint32_t)__shfl((int)near8, is_near ? near_k(lane) : 0);
-      filter_exact(v, id, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ, exact, fp.defer != 0);
+      filter_exact(v, id, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ, fp.defer != 0);
+    };
+    // the shard lists K-A filled: wave w walks shard w % 32 from position w / 32 on.  Its first entry is requested TOGETHER
+    // with the shard's counter (the entry's address does not depend on the count; a position beyond the count holds an older
+    // frame's entry, dropped when the count arrives): one dependent round trip less per entry than mapping the wave's
+    // index through a scan of the 32 counters -- the filter is a chain of such round trips, ~2 us each under its own load.
+    if (shards_par >= 0) {
+      const uint32_t sd = wave & (kMeshShards - 1u);
+      const uint32_t stride = (nwaves - sd + kMeshShards - 1u) / kMeshShards;  // waves that share this shard
+      uint32_t i = wave / kMeshShards;
+      size_t at = wl_base + (size_t)sd * wl_rows + (i < wl_rows ? i : 0u);
+      int4 id = v.wl_ids[at];
+      uint32_t own_listed = v.wl_slot[at];
+      uint32_t cs = v.wl_cnt[((shards_par & 1) * kMeshShards + sd) * 16];
+      if (cs > wl_rows) cs = wl_rows;
+      while (i < cs) {
+        process(id, own_listed, true);
+        i += stride;
+        if (i < cs) { at = wl_base + (size_t)sd * wl_rows + i; id = v.wl_ids[at]; own_listed = v.wl_slot[at]; }
+      }
+    }
+    // the flat list (ghost arrivals, a backlog of earlier frames' marks, the call-by-call flow)
+    for (uint32_t entry = wave; entry < n_flat; entry += nwaves) {
+      const int4 id = dlist[entry];
+      uint32_t own_listed = kInvalidSlot;
+      if (dslot) own_listed = dslot[entry];  // (under a wave-uniform test: see profiles/r2/README.md)
+      process(id, own_listed, dslot != nullptr);
     }
     return;
   }
@@ -526,7 +514,7 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 8
     const uint32_t nm = s_n;
     for (uint32_t m = (uint32_t)w; m < nm; m += 4u)
       filter_exact(v, s_id[m], is_near ? s_near[m][near_k(lane)] : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar,
-                   use_summ, true, fp.defer != 0);
+                   use_summ, fp.defer != 0);
     __syncthreads();  // the parked entries are consumed before the next batch overwrites them
   }
 }
@@ -541,30 +529,16 @@ __device__ __forceinline__ void mesh_stamp(const VolumeDev& v, uint32_t r, int k
 #ifndef TF_MESH_WAVES
 #define TF_MESH_WAVES 5  // waves per SIMD the 128-thread mesher is compiled for: 5 = 96 VGPRs, ten chunks per CU
 #endif
-// FF ("fused filter", the textured per-frame flow): the launch has one workgroup per DIRTY entry and runs the filter's two
-// phases itself -- phase A on eight lanes, the exact test on the chunk's own voxels, which the mesher needs in registers
-// anyway -- and carries on as the mesher when the entry survives; the others leave after 3-5 us and the hardware hands
-// their slot to the next workgroup.  No filter launch, no survivor rows, the own plane read once.
-struct FilterArgs {
-  const int4* dlist;
-  const uint32_t* dslot;
-  const uint32_t* dcount;
-  uint32_t max_entries;
-  int shards_par;
-  uint32_t use_summ;
-  uint32_t* len_hint;
-  uint32_t refresh_summ;  // two-launch form: the filter did not read the voxels, the mesher makes the summary exact
-};
-template <int NT, bool FF>  // threads per chunk: 128 (default), or 256
-__global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(VolumeDev v, const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
+template <int NT>  // threads per chunk
+__global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
                                                  uint32_t* __restrict__ cnt_next, uint32_t cap_sh,
                                                  uint32_t epoch, float res, uint32_t simplified, uint32_t dbg,
-                                                 int rearm, FilterArgs fa) {
+                                                 int rearm) {
   __shared__ MeshSh<NT> sh;
   // (LDS per workgroup decides how many chunks a CU holds at once: the triangle table is read from memory -- a few
   // dozen cached 8-byte reads per chunk --, the list of used edge slots is sized by the mesh capacity: dynamic LDS)
   extern __shared__ uint16_t vlist[];  // [mesh_cv] used edge slots in ascending order
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
   // The survivors sit in 32 shard lists of different lengths.  Workgroup b takes the b-th row of their CONCATENATION
   // (every wave reads the 32 counters and scans them): the workgroups that have a chunk are then exactly the first
   // N of the grid, and with N below the resident capacity (2560) all of them start at once.  With b -> (shard b % 32,
@@ -572,27 +546,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
   // when the first round ended and set the kernel's time (time stamps: last start 18-20 us, last end 34 us of which a
   // chunk takes 20).
   uint32_t n_rows = 0, excl_l = 0, incl_l = 0;
-  // FF: the dirty set = flat list [0, n_flat) + the shard lists K-A filled; per-lane inclusive scan of their counters
-  uint32_t n_flat = 0;
-  if (FF) {
-    n_flat = *fa.dcount;
-    if (n_flat > fa.max_entries) n_flat = fa.max_entries;
-    uint32_t sh_n = 0, sh_incl = 0;
-    if (fa.shards_par >= 0) {
-      const uint32_t wl_rows = mesh_shard_rows_d(v.max_chunks);
-      if (lane < (int)kMeshShards) { sh_n = v.wl_cnt[((fa.shards_par & 1) * kMeshShards + lane) * 16]; if (sh_n > wl_rows) sh_n = wl_rows; }
-      sh_incl = sh_n;
-#pragma unroll
-      for (int o = 1; o < (int)kMeshShards; o <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)sh_incl, o);
-        if (lane >= o) sh_incl += u;
-      }
-    }
-    if (t < (int)kMeshShards) { sh.f_incl[t] = sh_incl; sh.f_n[t] = sh_n; }
-    n_rows = n_flat + (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)sh_incl, kMeshShards - 1));
-    if (n_rows > fa.max_entries) n_rows = fa.max_entries;
-    if (fa.len_hint && blockIdx.x == 0 && t == 0) *fa.len_hint = n_rows;
-  } else {
+  {
     uint32_t my_n = 0;
     if (lane < (int)kMeshShards) { my_n = cnt[lane * 16]; if (my_n > cap_sh) my_n = cap_sh; }
     uint32_t incl = my_n;
@@ -610,7 +564,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     incl_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh0);  // (reused: the shard of the first row)
   }
   if (blockIdx.x == 0 && t < (int)kMeshShards) { cnt_next[t * 16] = 0u; cnt_next[(kMeshShards + t) * 16] = 0u; cnt_next[(kMeshShards + t) * 16 + 1] = 0u; cnt_next[(2 * kMeshShards + t) * 16] = 0u; }  // the counters of the NEXT launch's filter
-  if (!FF && blockIdx.x < kMeshShards) {
+  if (blockIdx.x < kMeshShards) {
     // the records the filter wanted emptied (filter_defer_reset): shard b by workgroup b, one thread per record, ahead
     // of the workgroup's own chunk -- nothing in this launch reads another chunk's record
     uint32_t n_reset = cnt[(2u * kMeshShards + blockIdx.x) * 16u];
@@ -634,12 +588,11 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     v.wl_cnt[((rearm & 1) * kMeshShards + t) * 16] = 0u;  // ... and the shard lists K-A of the next frame appends its dirty set to
   }
   if (dbg == 9) mesh_stamp(v, blockIdx.x, 0);
-  if (FF) __syncthreads();  // f_incl / f_n
   for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
     uint32_t shard, own;
     int4 id;
     float2 a[512 / NT];
-    if constexpr (!FF) {
+    {
       shard = incl_l;
       uint32_t idx = r - excl_l;
       if (r != blockIdx.x) {  // a further row of this workgroup (lists longer than the grid): scan again
@@ -661,97 +614,9 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
       for (int j = 0; j < 512 / NT; ++j) a[j] = v.tsdf[(size_t)own * kChunkVoxels + j * NT + t];
       __syncthreads();  // the previous chunk of this workgroup is done with the shared tables
       if (t < 27) sh.nslot[t] = surv[32 * row + t];
-    } else {
-      // ---- the entry (flat list, then row r - n_flat of the concatenated shard lists)
-      uint32_t own_listed = kInvalidSlot;
-      if (r < n_flat) {
-        id = fa.dlist[r];
-        if (fa.dslot) own_listed = fa.dslot[r];
-      } else {
-        const uint32_t rr = r - n_flat;
-        const uint32_t wl_rows = mesh_shard_rows_d(v.max_chunks);
-        const uint32_t shd = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(lane < (int)kMeshShards && sh.f_incl[lane & 31] <= rr))) & 31u;
-        const size_t at = ((size_t)(fa.shards_par & 1) * kMeshShards + shd) * wl_rows + (rr - (sh.f_incl[shd] - sh.f_n[shd]));
-        id = v.wl_ids[at];
-        own_listed = v.wl_slot[at];
-      }
-      __syncthreads();  // the previous entry of this workgroup is done with the shared tables
-      // ---- phase A (k_mesh_filter's, on eight lanes): the chunk and its seven +x / +y / +z neighbours, their class summaries
-      if (w == 0) {
-        uint32_t own_ = kInvalidSlot, near8 = kInvalidSlot;
-        bool maybe_ = false;
-        if (lane < 27) sh.nslot[lane] = kInvalidSlot;
-        if (lane < 8) near8 = filter_near(v, id, lane, lane, fa.dslot != nullptr || r >= n_flat, own_listed, fa.use_summ != 0, &own_, &maybe_);
-        if (lane < 8) sh.nslot[13 + (lane & 1) + 3 * ((lane >> 1) & 1) + 9 * (lane >> 2)] = near8;  // (same wave: behind the reset above)
-        if (lane == 0) { sh.f_own = own_; sh.f_maybe = maybe_ ? 1u : 0u; }
-      }
-      __syncthreads();
-      own = sh.f_own;
-      if (own == kInvalidSlot) continue;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
-      if (!sh.f_maybe) {
-        if (t == 0) filter_reset_record(v, own, id, epoch, rearm >= 0 ? (rearm ^ 1) : -1);
-        continue;
-      }
-      shard = own & (kMeshShards - 1u);
-      // ---- the exact test on the chunk's own voxels (they stay in registers for the staging pass); meanwhile the other
-      // 19 chunks of the neighbourhood are looked up (only a survivor needs them, but the probes are free here)
-#pragma unroll
-      for (int j = 0; j < 512 / NT; ++j) a[j] = v.tsdf[(size_t)own * kChunkVoxels + j * NT + t];
-      if (w == NT / 64 - 1 && lane < 27) {
-        const bool is_near = (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
-        if (!is_near) {
-          const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
-          if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) sh.nslot[lane] = v.hent[ent].slot;
-        }
-      }
-      uint32_t fl = 0;
-#pragma unroll
-      for (int j = 0; j < 512 / NT; ++j) fl |= chunk_summary_bits(a[j].x, a[j].y, (uint32_t)(j * NT + t));
-      fl = wave_or(fl);
-      if (lane == 0) sh.f_fl[w] = fl;
-      __syncthreads();
-      fl = 0;
-#pragma unroll
-      for (int k = 0; k < NT / 64; ++k) fl |= sh.f_fl[k];
-      if (t == 0) {
-        if (fa.use_summ) v.summ[own] = fl;            // the chunk's summary is exact again
-        atomicAdd(&cnt[(kMeshShards + shard) * 16], 1u);          // statistic (tf_texture_stats::n_exact)
-      }
-      bool empty = !(fl & 1u);
-      if (!empty && (fl & 14u) != 14u) {  // undecided: the 217 corner voxels the +x / +y / +z neighbours contribute
-        uint32_t f2 = 0;
-        for (int q = t; q < 217; q += NT) {
-          int cx = 0, cy = 0, cz = 0;
-          if (q < 64) { cx = 8; cy = q & 7; cz = q >> 3; }
-          else if (q < 128) { cx = q & 7; cy = 8; cz = (q >> 3) & 7; }
-          else if (q < 192) { cx = q & 7; cy = (q >> 3) & 7; cz = 8; }
-          else if (q < 200) { cx = 8; cy = 8; cz = q & 7; }
-          else if (q < 208) { cx = 8; cy = q & 7; cz = 8; }
-          else if (q < 216) { cx = q & 7; cy = 8; cz = 8; }
-          else { cx = 8; cy = 8; cz = 8; }
-          const uint32_t sl = sh.nslot[13 + (cx >> 3) + 3 * (cy >> 3) + 9 * (cz >> 3)];
-          if (sl != kInvalidSlot) {
-            const float2 val = v.tsdf[(size_t)sl * kChunkVoxels + (cx & 7) + (cy & 7) * 8 + (cz & 7) * 64];
-            f2 |= classify_voxel(val.x, val.y);
-          }
-        }
-        f2 = wave_or(f2);
-        __syncthreads();  // (f_fl was read by every thread above)
-        if (lane == 0) sh.f_fl[w] = f2;
-        __syncthreads();
-        f2 = 0;
-#pragma unroll
-        for (int k = 0; k < NT / 64; ++k) f2 |= sh.f_fl[k];
-        empty = ((fl | f2) & 14u) != 14u;
-      }
-      if (empty) {
-        if (t == 0) filter_reset_record(v, own, id, epoch, rearm >= 0 ? (rearm ^ 1) : -1);
-        continue;
-      }
-      if (t == 0) atomicAdd(&cnt[shard * 16], 1u);    // statistic (n_survivors)
     }
-    // (FF: what the mesher derives from the thread index must not be computed ahead of the filter -- it would sit in
-    // registers, or in private memory, across it: the index is re-read behind an opaque statement)
+    // (what the rest of the chunk derives from the thread index is recomputed here, behind an opaque statement, instead
+    // of living in registers across the row / voxel loads above: 88 instead of 96 VGPRs, no private memory)
     int t_ = threadIdx.x;
     asm volatile("" : "+v"(t_));
     const int t = t_, lane = t & 63, w = t >> 6;
@@ -767,26 +632,13 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
     if (t == NT - 64) { sh.rstate = rec->state; sh.rtexloc = rec->texloc; }
     if (dbg == 1) continue;  // triage: filter only
     // ---- stage the 11^3 voxels of the neighbourhood (own ones from registers)
-    uint32_t sfl = 0;
 #pragma unroll
     for (int j = 0; j < 512 / NT; ++j) {
       const int q = j * NT + t;
       const int x0 = q & 7, y0 = (q >> 3) & 7, z0 = q >> 6;
       sh.S[ridx(x0, y0, z0)] = a[j].x; sh.cflag[x0 + y0 * 9 + z0 * 81] = (a[j].y > 50.0f) ? kCfHeavy : 0u;
-      if (!FF) sfl |= chunk_summary_bits(a[j].x, a[j].y, (uint32_t)q);
-    }
-    if (!FF && fa.refresh_summ) {  // the chunk's class summary, exact again (what the filter's exact test used to do)
-      sfl = wave_or(sfl);
-      if (lane == 0) sh.f_fl[w] = sfl;
     }
     __syncthreads();
-    if (!FF && fa.refresh_summ && t == NT - 1) {
-      uint32_t fl = 0;
-#pragma unroll
-      for (int k = 0; k < NT / 64; ++k) fl |= sh.f_fl[k];
-      v.summ[own] = fl;
-      atomicAdd(&cnt[(kMeshShards + shard) * 16], 1u);  // statistic (n_exact): the chunk's voxels were read for the test -- here
-    }
     // (measured: issuing the row, the table entries and then own + halo voxels as two batches of loads -- two
     // dependent hops instead of four -- is slower, 36 -> 46 us: the extra registers spill)
 #pragma unroll
@@ -823,7 +675,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 6 : TF_MESH_WAVES) void k_mesh(Volu
       const float yz = gy * gy + gz * gz;
       const float nrm = sqrtf(gx * gx + yz);
       if (!(nrm > res * 100.0f)) f |= kCfGradOk;
-      sh.cflag[c] |= (TF_MESH_CFLAG_T)f;
+      sh.cflag[c] |= (uint8_t)f;
     }
     for (int i = t; i < (kEdgeSlots + 7) / 8; i += NT) sh.ownq[i] = 0u;
     __syncthreads();
@@ -1106,52 +958,23 @@ void launch_init_meshes(const VolumeDev& v, hipStream_t s) {
   (void)hipMemsetAsync(v.mesh_cnt, 0, sizeof(uint32_t) * 2 * kMeshCntWords, s);
 }
 
-static int mesh_resident_blocks() {
-  int dev = 0, cus = 256;
-  if (hipGetDevice(&dev) == hipSuccess) {
-    hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
-  }
-  const char* e = getenv("TF_MESH_BLOCKS_PER_CU");
-  return cus * (e ? atoi(e) : 6);
-}
-
 // rows per shard: a chunk's row and patch entry go to shard (pool slot % 32) and pool slots are unique, so a shard
 // holds at most ceil(max_chunks / 32) of them (the margin is historical)
 uint32_t mesh_shard_rows(uint32_t max_chunks) { return max_chunks / kMeshShards + 258u; }
 
 static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries, uint32_t epoch, float res, bool fused,
-                          int rearm_set, const FilterArgs* ff, uint32_t ff_grid, bool refresh_summ, hipStream_t s) {
-  static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch
+                          int rearm_set, hipStream_t s) {
+  static const uint32_t dbg = getenv("TF_MESH_DBG") ? (uint32_t)atoi(getenv("TF_MESH_DBG")) : 0u;  // triage switch / phase stamps
   uint32_t* surv = v.mesh_nbr;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshCntWords;
   uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshCntWords;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
-  // the survivors form dense per-shard lists: a grid of a few resident rounds, each workgroup striding its shard
-  // (TF_MESH_GRID overrides; rounded to a multiple of the shard count)
-  static const uint32_t gmax = getenv("TF_MESH_GRID") ? (uint32_t)atoi(getenv("TF_MESH_GRID")) : 4096u;
+  // workgroup b takes row b of the concatenated shard lists and strides by the grid: a few resident rounds at most
+  // (128 threads per chunk: with 13 KB of LDS and 88 VGPRs ten chunks are resident per CU)
   uint32_t grid = ((max_entries + kMeshShards - 1) / kMeshShards + 1) * kMeshShards;
-  if (grid > gmax) grid = gmax;
-  grid = (grid + kMeshShards - 1) / kMeshShards * kMeshShards;
-  // 128 threads per chunk: with 15.8 KB of LDS and 94 VGPRs ten chunks are resident per CU (six with 256 threads at 80
-  // VGPRs).  Same time on the room stream, 8 % less on the 1280x960 hall (TF_MESH_THREADS=256 for the other form).
-  static const int nt = getenv("TF_MESH_THREADS") ? atoi(getenv("TF_MESH_THREADS")) : 128;
-  FilterArgs none{};
-  none.refresh_summ = refresh_summ ? 1u : 0u;
-  if (ff)
-    hipLaunchKernelGGL((k_mesh<128, true>), dim3(ff_grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh,
-                       epoch, res, fused ? kMsSimplified : 0u, dbg, rearm_set, *ff);
-  else if (nt == 256)
-    hipLaunchKernelGGL((k_mesh<256, false>), dim3(grid), dim3(256), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
-                       fused ? kMsSimplified : 0u, dbg, rearm_set, none);
-  else
-    hipLaunchKernelGGL((k_mesh<128, false>), dim3(grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
-                       fused ? kMsSimplified : 0u, dbg, rearm_set, none);
-}
-
-static bool filter_uses_summaries() {
-  static const bool use_summ = !(getenv("TF_FILTER_SUMM") && !atoi(getenv("TF_FILTER_SUMM")));  // A/B knob, default on
-  return use_summ;
+  if (grid > 4096u) grid = 4096u;
+  hipLaunchKernelGGL((k_mesh<128>), dim3(grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
+                     fused ? kMsSimplified : 0u, dbg, rearm_set);
 }
 
 bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
@@ -1162,55 +985,30 @@ bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
   if (max_entries > v.max_chunks) max_entries = v.max_chunks;
   // 2560 workgroups = 1.25 x the wave form's resident capacity: a list of up to 10 k entries runs one entry per wave
-  // (with the patch stage in the launch the two ranges share 6 waves per SIMD: TF_FILTER_GRID_PATCH sizes the filter's)
-  static const uint32_t fg_plain = getenv("TF_FILTER_GRID") ? (uint32_t)atoi(getenv("TF_FILTER_GRID")) : 2560u;
-  static const uint32_t fg_patch = getenv("TF_FILTER_GRID_PATCH") ? (uint32_t)atoi(getenv("TF_FILTER_GRID_PATCH")) : 2560u;
-  const uint32_t fmax = (patch && cam) ? fg_patch : fg_plain;
+  const uint32_t fmax = 2560u;
   const uint32_t fgrid = (max_entries + 3) / 4 < fmax ? (max_entries + 3) / 4 : fmax;
   const uint32_t* dslot = fused ? v.work_slot : nullptr;
   const int ppar = fused ? (rearm_set ^ 1) : -1;
-  // TF_MESH_FUSED=1: the mesher runs the filter itself, one workgroup per entry of a short list (k_mesh<128, true>).
-  // Measured on the room stream (profiles/r3/README.md): the pair of launches 48.9 us, the fused form 54.2 us -- 6.5 k
-  // workgroups that hold a mesher's registers and LDS through phase A's dependent loads keep the ~900 survivors out of
-  // the first resident round, which costs more than the launch boundary and the 3.6 MB of re-read voxels saved.
-  static const int mesh_fused = getenv("TF_MESH_FUSED") ? atoi(getenv("TF_MESH_FUSED")) : 0;
-  if (mesh_fused && len_guess <= 10000u) {
-    const FilterArgs fa{dlist, dslot, dcount, max_entries, shards_par, filter_uses_summaries() ? 1u : 0u, len_hint, 0u};
-    uint32_t g = len_guess + len_guess / 8u + 256u;  // the list of the frame before + slack; a longer list strides
-    if (g > max_entries) g = max_entries;
-    launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, &fa, g, false, s);
-    return false;
-  }
-  // TF_FILTER_EXACT=0: the wave form leaves the exact test to the mesher (which finds no surface cell in the ~20 % the
-  // test would have caught, and rewrites the summary from the own voxels it loads anyway).  Measured on the room stream
-  // (profiles/r3/README.md): filter 14.3 -> 11.1 us, mesher 33.0 -> 37.5 us (3619 chunks instead of 2929 against 2560
-  // resident workgroups) -- no gain, so the filter keeps the test.
-  static const bool wave_exact = !(getenv("TF_FILTER_EXACT") && !atoi(getenv("TF_FILTER_EXACT")));
-  const bool use_summ = filter_uses_summaries();
+  const bool use_summ = true;
   const bool wave_form = len_guess <= 2560u * 4u;  // (the wave form strides when its grid is smaller than the list)
-  const bool exact = !wave_form || wave_exact || !use_summ;
   FilterPatch fp;
   memset(&fp, 0, sizeof(fp));
-  static const bool always_defer = getenv("TF_FILTER_DEFER") && atoi(getenv("TF_FILTER_DEFER"));  // A/B knob
-  fp.defer = always_defer ? 1u : 0u;
   if (patch && cam) {
     // one wave per patch; the range is dispatched AHEAD of the filter's workgroups (its chains are the longer ones)
-    static const uint32_t np = getenv("TF_FILTER_PATCH_BLOCKS") ? (uint32_t)atoi(getenv("TF_FILTER_PATCH_BLOCKS")) : 1024u;
-    static const bool patch_last = getenv("TF_FILTER_PATCH_LAST") && atoi(getenv("TF_FILTER_PATCH_LAST"));
     fp.defer = 1u;
-    fp.n_patch = np;
-    fp.first = patch_last ? fgrid : 0u;
+    fp.n_patch = 1024u;
+    fp.first = 0u;
     fp.par = patch->par;
     fp.cam = *cam;
     fp.kf = patch->kf;
   }
-#define TF_LAUNCH_FILTER(W, P, EX)                                                                                   \
+#define TF_LAUNCH_FILTER(W, P)                                                                                       \
   hipLaunchKernelGGL((k_mesh_filter<W, P>), dim3(fgrid + fp.n_patch), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, \
-                     epoch, v.mesh_nbr, cnt, cap_sh, ppar, use_summ, len_hint, shards_par, EX, fp)
-  if (wave_form) { if (fp.n_patch) TF_LAUNCH_FILTER(true, true, exact); else TF_LAUNCH_FILTER(true, false, exact); }
-  else { if (fp.n_patch) TF_LAUNCH_FILTER(false, true, true); else TF_LAUNCH_FILTER(false, false, true); }
+                     epoch, v.mesh_nbr, cnt, cap_sh, ppar, use_summ, len_hint, shards_par, fp)
+  if (wave_form) { if (fp.n_patch) TF_LAUNCH_FILTER(true, true); else TF_LAUNCH_FILTER(true, false); }
+  else { if (fp.n_patch) TF_LAUNCH_FILTER(false, true); else TF_LAUNCH_FILTER(false, false); }
 #undef TF_LAUNCH_FILTER
-  launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, nullptr, 0, !exact, s);
+  launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, s);
   return fp.n_patch != 0;
 }
 

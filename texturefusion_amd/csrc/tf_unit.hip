@@ -121,9 +121,8 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     v->frame = img;
     v->frame_bound = true;
     // (validChunks = the finalized list in list order; no order of it is observable through this entry point, so the
-    // list need not be the reference's: TF_UNIT_ORDERED=1 restores k_select + k_scan, 17 us per keyframe more)
-    static const bool ordered = getenv("TF_UNIT_ORDERED") && atoi(getenv("TF_UNIT_ORDERED"));
-    int rc = ordered ? launch_prepare(v, P, true, s) : launch_prepare_unordered(v, P, s);
+    // list need not be the reference's: k_select + k_scan would cost 17 us per keyframe more)
+    int rc = launch_prepare_unordered(v, P, s);
     if (rc) return rc;
   } else {
     hipLaunchKernelGGL(k_kf_load, dim3(256), dim3(256), 0, s, d, u->tab, u->slots, u->arena, kf_slot);

@@ -179,7 +179,7 @@ struct tf_volume {
   size_t hslot_pixels = 0;
   int hslot_next = 0;
   hipStream_t copy_stream = nullptr;
-  hipStream_t copy_stream2 = nullptr;  // TF_HOST_COPY_SPLIT: the second half of a frame's upload (a second copy engine)
+  hipStream_t copy_stream2 = nullptr;  // registered caller buffers: the colour image goes up next to the depth image (a second copy engine)
   hipEvent_t copy_join = nullptr;
   long host_waits = 0;  // copies a launch had to wait for in the stream (TF_HOST_TRACE prints it)
   double host_trace[6] = {0, 0, 0, 0, 0, 0};  // TF_HOST_TRACE=1: microseconds per phase of tf_integrate_frame_host, [5] = calls
@@ -221,6 +221,7 @@ struct tf_volume {
   static constexpr int kHostDefer = 4;  // frames tf_integrate_frame_host runs behind its caller (a launch reads the oldest three)
   Pending pend[kHostDefer];
   int n_pend = 0;
+  bool host_defer = true;  // tf_integrate_frame_host runs kHostDefer frames behind its caller (tf_host_frame_set_deferral)
   float* d_group = nullptr;  // staging of tf_integrate_depth_group_host: six depth images
   size_t d_group_pixels = 0;
   // on-demand device scratch
@@ -259,7 +260,7 @@ int flush_deferred(tf_volume* v);
 struct KfStoreArgs;  // tf_kf_store.h
 void launch_dirty_frame_store(const VolumeDev& v, int par, uint32_t stamp, const KfStoreArgs& a, hipStream_t s);  // tf_mesh.hip
 int patch_flush(tf_volume* v);
-bool patch_rides_filter();  // TF_PATCH_IN_FILTER=1 (off by default: measured slower, tf_capi.cpp)
+bool host_defer_default();  // !(TF_HOST_DEFER=0 in the environment)
 int fused_arm(tf_volume* v);  // the fused flow's counter sets in their start state (no-op once armed)
 int ensure_pinned(tf_volume* v, size_t bytes);
 void prof_begin(tf_volume* v, int kind, hipStream_t s = nullptr);

@@ -1,11 +1,11 @@
 #!/bin/bash
-# One parameterised GPU job script for round 4 (replaces the r3_run*.sh one-offs):
-#   tools/r4_run.sh <tag> <step> [<step> ...]      steps: tests | testsx (stop at first failure) | bench | tsdf | hall |
+# One parameterised GPU job script:
+#   tools/gpu_job.sh <tag> <step> [<step> ...]      steps: tests | testsx (stop at first failure) | bench | tsdf | hall |
 #                                                  prof (rocprofv3 --kernel-trace --stats of the default bench) | kf (keyframe unit)
 # Output under gpurun_out/r4_<tag>/.
 cd "${GRAFT_REPO_ROOT:-.}"
 TAG=$1; shift
-O=gpurun_out/r4_$TAG; mkdir -p $O
+O=gpurun_out/job_$TAG; mkdir -p $O
 export TMPDIR=/tmp
 for step in "$@"; do
   case $step in
@@ -20,8 +20,10 @@ for step in "$@"; do
             case $step in prof) A="--steps 200 --warmup 20";; prof_tsdf) A="--mode tsdf --steps 200 --warmup 20";; prof_hall) A="--scene big --hires --steps 60 --warmup 10";; esac
             U=$PWD/$O/$step; mkdir -p $U
             (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $U/trace -o t -- python3 $OLDPWD/bench.py $A --no-pmc --cpu-frames 0 --no-group --repeats 0 > $U/bench_line_profiled.json 2> $U/prof.err)
-            S=$(find $U/trace -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $O/${step}_kernel_stats.csv
-            rm -rf $U/trace; echo "$step rc=$?"; head -8 $O/${step}_kernel_stats.csv | cut -c1-150 ;;
+            rc=$?  # (the profiler's / the benchmark's, not rm's)
+            S=$(find $U/trace -name "*kernel_stats.csv" | head -1)
+            if [ $rc -eq 0 ] && [ -n "$S" ]; then cp $S $O/${step}_kernel_stats.csv; head -8 $O/${step}_kernel_stats.csv | cut -c1-150; fi
+            rm -rf $U/trace; echo "$step rc=$rc" ;;
     unit|unit_moved)
             # the keyframe unit under rocprofv3: kernel trace, FETCH_SIZE, WRITE_SIZE (separate passes), exact counts, summary
             MV=""; [ $step = unit_moved ] && MV="--moved"
@@ -34,8 +36,9 @@ for step in "$@"; do
             T=$(find $U/trace -name "*kernel_trace.csv" | head -1); F=$(find $U/fetch -name "*counter_collection.csv" | head -1); W=$(find $U/write -name "*counter_collection.csv" | head -1)
             S=$(find $U/trace -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $U/kernel_stats.csv
             python3 tools/prof_unit.py --summarize "$T" "$F" "$W" $U/counts.json > $U/summary.json 2> $U/summary.err
+            rc=$?
             rm -rf $U/trace $U/fetch $U/write
-            echo "$step rc=$?"; cat $U/run_line.json; tail -c 1800 $U/summary.json; tail -n 3 $U/summary.err; tail -n 3 $U/count.err ;;
+            echo "$step rc=$rc"; cat $U/run_line.json; tail -c 1800 $U/summary.json; tail -n 3 $U/summary.err; tail -n 3 $U/count.err ;;
     sq)     # SQ counters of the per-frame kernels over the timed workload (bench.py --child), three passes
             U=$PWD/$O/sq; mkdir -p $U; rm -rf $U/*
             B="python3 $PWD/bench.py --child --steps 60 --warmup 20"
@@ -58,7 +61,8 @@ for kern in ("k_frame", "k_mesh_filter", "k_mesh<"):
         for k, (s, n) in sorted(acc.items()):
             print("  %-22s per launch %14.0f  (%d launches)" % (k, s / max(n, 1), n))
 PY
-            rm -rf $U; cat $O/sq_summary.txt | head -80 ;;
+            rc=$?
+            rm -rf $U; echo "sq rc=$rc"; cat $O/sq_summary.txt | head -80 ;;
     *)      echo "unknown step $step" ;;
   esac
 done
