@@ -540,13 +540,21 @@ def main():
         if use_rccl and textured and not args.child:
             # the same window once more with HIP events around every launch and around the exchange (untimed diagnostic)
             vol.sync()
-            vol.profile_enable(("integrate", "dirty", "mesh", "xchg"))
+            vol.profile_enable(("integrate", "dirty", "mesh", "xchg", "xchg_wait"))
             run(pos, K)
             vol.sync()
             pr = vol.profile_get(reset=True)
             vol.profile_enable(())
             pos += K
-            mine["event_us_per_step"] = {k: 1e3 * pr[k][0] / K for k in ("integrate", "dirty", "mesh", "xchg") if pr[k][1]}
+            mine["event_us_per_step"] = {k: 1e3 * pr[k][0] / K for k in ("integrate", "dirty", "mesh", "xchg", "xchg_wait") if pr[k][1]}
+            # the exchange runs on the library's second stream next to the interior mesh pass: what the main stream still
+            # waits for it is exposed, the rest hidden (an event pair costs ~6 us by itself: small values are that floor)
+            x_all = mine["event_us_per_step"].get("xchg")
+            x_wait = mine["event_us_per_step"].get("xchg_wait")
+            if x_all is not None and x_wait is not None:
+                mine["exchange_us_exposed"] = x_wait
+                mine["exchange_us_hidden"] = max(0.0, x_all - x_wait)
+        mine["exchanges_overlapped_with_interior_meshes"] = st.get("overlapped", 0)
         gathered = [None] * world if world > 1 else [mine]
         if world > 1:
             dist.all_gather_object(gathered, mine)
@@ -562,12 +570,15 @@ def main():
     # s.8(e)'s stated fallback, "replicas") and the sharded keyframe unit -- printed next to the strong-scaling `value`
     indep = sharded_unit = None
     if multi and not args.no_independent:
-        vol.close()  # (its registered host ranges are released: the replica volume registers the same arrays)
+        # (the partitioned volume stays open through the replica's run: the library counts registrations of the caller's
+        # arrays per process -- and on this ROCm a volume destroyed BEFORE another one streams host frames leaves that one's
+        # uploads at ~10 GB/s instead of ~40, tools/two_volumes_probe.py; cause not found)
         try:
             indep = independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses, pinv, a_depth, a_rgba, a_pose,
                                         a_pinv, n_unique, local_rank, world, dist if world > 1 else None, dev, textured, fresh_period)
         except Exception as e:  # (a side figure: never fail the bench line for it)
             indep = {"error": repr(e)[:300]}
+        vol.close()
         if use_rccl and textured and not args.no_group:
             try:
                 sharded_unit = sharded_keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, local_rank, rank, world,
@@ -866,10 +877,12 @@ def independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses,
     fresh_period()
     run_host(pos, Wm)
     barrier()
+    vol.host_frame_times(reset=True)
     t0 = time.perf_counter()
     run_host(pos + Wm, K)
     barrier()
     dt = time.perf_counter() - t0
+    phases = vol.host_frame_times(reset=True)
     vol.sync()
     mine = 1e3 * dt / K
     if dist is not None:
@@ -883,6 +896,7 @@ def independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses,
     vol.close()
     return {"value": world * K / dt, "unit": "frames/s", "scaling": "weak", "n_gpus": world, "ms_per_step_per_stream": 1e3 * dt / K,
             "per_rank_ms_per_step": allms, "host_buffers": "registered" if registered else "staged",
+            "host_phases_us_per_step_rank0": phases,
             "note": "%d independent streams, one whole (unpartitioned) volume per GPU, no exchange: every rank runs the N = 1 "
                     "headline workload (host frames, H2D inside) on its own GPU at the same time; value = N x K / max-over-ranks "
                     "time" % world}

@@ -113,7 +113,8 @@ typedef struct {
 #define TF_PROF_DIRTY 9
 #define TF_PROF_PATCH_RANK 10
 #define TF_PROF_XCHG 11        /* N > 1: pack -> transport -> unpack of one boundary exchange (tf_comm.cpp) */
-#define TF_PROF_COUNT 12
+#define TF_PROF_XCHG_WAIT 12   /* N > 1, overlapped exchange: what the main stream still waits for it behind the interior mesh pass */
+#define TF_PROF_COUNT 13
 typedef struct {
   double ms[TF_PROF_COUNT];       /* summed elapsed time per kernel */
   int64_t launches[TF_PROF_COUNT];
@@ -331,6 +332,15 @@ TF_API int tf_host_frame_times(tf_volume* v, double out[7], int reset);
  * brings its own transport calls tf_boundary_pack_block / its all-gather / tf_boundary_unpack_blocks(join_dirty)
  * in between. */
 TF_API int tf_texture_frame_device(tf_volume* v, const float pose_inv16[16], int32_t frame_id);
+/* The same in two halves around the caller's own boundary exchange, so that the exchange overlaps work: phase 1 builds the
+ * frame's dirty set and meshes its INTERIOR chunks (those whose 27-chunk neighbourhood this rank owns: nothing they read
+ * comes from another rank); then pack / transport / tf_boundary_unpack_*(join_dirty) -- on any stream the caller orders
+ * behind phase 1's launches or, for overlap, next to them: phase 1 reads no ghost chunk and no list the unpack writes --;
+ * phase 2 meshes the boundary chunks and everything the arriving ghosts added, and leaves the patch stage pending as
+ * tf_texture_frame_device does.  Results equal the one-call form bit for bit.  (With tf_comm_exchange_every_frame the
+ * library does exactly this itself, the exchange on a second stream: tf_comm_exchange_overlap(v, 0) switches that off.) */
+TF_API int tf_texture_frame_device_phase(tf_volume* v, const float pose_inv16[16], int32_t frame_id, int phase);
+TF_API int tf_comm_exchange_overlap(tf_volume* v, int on);
 TF_API int tf_sync(tf_volume* v);
 
 /* ---- state access (host mirrors of Chunk::voxels / colors, ChunkManager queries) -----
@@ -473,7 +483,8 @@ TF_API int tf_comm_exchange_every_frame(tf_volume* v, int64_t cap_records);
  * is sized by the frame's selection (tf_boundary_band_bounds above); cap_records is then only the upper limit.
  * tf_comm_stats: exchanges run and bytes received by this rank so far.  tf_comm_stats_ex (synchronises): out =
  * { exchanges, bytes sent, bytes received, ghost records written into blocks, ghost records read from received blocks,
- *   record capacity of the blocks sent, the form in use (TF_XCHG_*), 1 once the partition check has run }. */
+ *   record capacity of the blocks sent, the form in use (TF_XCHG_*), bit 0: the partition check has run | (exchanges that
+ *   ran on the library's second stream next to an interior mesh pass) << 1 }. */
 #define TF_XCHG_NEIGHBOURS 0
 #define TF_XCHG_ALLGATHER 1
 TF_API int tf_comm_exchange_mode(tf_volume* v, int mode);

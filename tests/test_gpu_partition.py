@@ -494,6 +494,7 @@ def test_rccl_single_rank_sized_per_frame_exchange(gpu_required, ahead):
     a.sync(); b.sync()   # (TF_ERR_CAPACITY here = a sized block was too small)
     st = b.comm_stats_ex()
     assert st["exchanges"] == n and st["checked"] == 1 and st["mode"] == 0
+    assert st["overlapped"] == n             # every exchange ran on the second stream next to the interior mesh pass
     assert st["records_sent"] > 200          # packed (the single rank has nobody to send to)
     assert st["bytes_sent"] == 0 and st["bytes_received"] == 0
     ia, ib = sorted_ids(a.list_chunks()), sorted_ids(b.list_chunks())
@@ -550,3 +551,107 @@ def test_rccl_single_rank_exchange_behind_lists_without_band_counts(gpu_required
     a.close(); b.close()
     for p in bufs:
         p[0].free(); p[1].free()
+
+
+@pytest.mark.parametrize("edges", [(24, 46), (40, 44)])
+def test_three_partitions_textured_exchange_overlapped_with_interior_meshes(gpu_required, edges):
+    """The overlapped order: every rank meshes the INTERIOR chunks of its dirty set (27-neighbourhood
+    owned) BEFORE the ghosts arrive (tf_texture_frame_device_phase 1), the exchange happens, then the boundary chunks
+    and what the ghosts added (phase 2).  Chunks, meshes, patches' slots of the union equal the single volume bit for bit:
+    the interior pass read nothing the exchange brings."""
+    cam = synth.Camera()
+    axis = (1, 1, 1)
+    bounds = [-(1 << 31), edges[0], edges[1], (1 << 31) - 1]
+    single = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    parts = [capi.Volume(RES5, cam, max_chunks=1 << 16) for _ in range(3)]
+    for r, v in enumerate(parts):
+        v.set_partition(bounds[r], bounds[r + 1], axis)
+    cap = 4096
+    bb = capi.boundary_block_bytes(cap)
+    out = [[HipBuffer(bb), HipBuffer(bb)] for _ in range(3)]
+    inn = [[HipBuffer(bb), HipBuffer(bb)] for _ in range(3)]
+    n = 8
+    frames = [synth.room_frame(3 * k, cam, with_quality=False) for k in range(n)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+    zero_hdr = np.zeros(16, np.uint8)
+    for k, f in enumerate(frames):
+        T = synth.pose_inverse16(f[3])
+        dd, dr = [bufs[k][0].ptr], [bufs[k][1].ptr]
+        single.stream_frames_textured_device(dd, dr, f[3].reshape(1, 12), T.reshape(1, 16), k)
+        for v in parts:
+            v.stream_frames_device(dd, dr, f[3].reshape(1, 12))
+            v.texture_frame_device_phase(T, k, 1)          # interior meshes: no ghost of this frame has arrived
+        for r, v in enumerate(parts):
+            v.boundary_pack_bands(out[r][0].ptr, out[r][1].ptr, cap)
+            v.sync()
+        for r in range(3):
+            if r > 0:
+                _copy_d2d(inn[r - 1][1].ptr, out[r][0].ptr, bb)
+            else:
+                inn[r][0].from_host(zero_hdr)
+            if r < 2:
+                _copy_d2d(inn[r + 1][0].ptr, out[r][1].ptr, bb)
+            else:
+                inn[r][1].from_host(zero_hdr)
+        for r, v in enumerate(parts):
+            v.boundary_unpack_pair(inn[r][0].ptr, cap, inn[r][1].ptr, cap, join_dirty=True)
+            v.texture_frame_device_phase(T, k, 2)          # boundary meshes + what the ghosts added
+            v.sync()
+    single.sync()
+    ref_ids = sorted_ids(single.list_chunks())
+    key = {tuple(c): i for i, c in enumerate(ref_ids)}
+    s_ref, w_ref, c_ref = single.get_chunks(ref_ids)
+    ref_m = sorted_ids(single.list_meshes())
+    assert len(ref_m) > 300
+    mvoff, mioff, mV, mN, mC, mI, madj, msimp = single.get_meshes(ref_m)
+    mkey = {tuple(c): i for i, c in enumerate(ref_m)}
+    seen_m, n_interior, n_boundary = set(), 0, 0
+    for r, v in enumerate(parts):
+        lo, hi = bounds[r], bounds[r + 1]
+        ids = v.list_chunks()
+        s, w, c = v.get_chunks(ids)
+        for i, cid in enumerate(ids):
+            t = tuple(int(x) for x in cid)
+            if t in key:
+                j = key[t]
+                assert np.array_equal(s[i].view(np.uint32), s_ref[j].view(np.uint32)), (r, t)
+                assert np.array_equal(c[i], c_ref[j])
+        pm = sorted_ids(v.list_meshes())
+        voff, ioff, V, N, Cc, I, adj, simp = v.get_meshes(pm)
+        for i, cid in enumerate(pm):
+            t = tuple(int(x) for x in cid)
+            assert lo <= sum(t) < hi and t in mkey and t not in seen_m
+            seen_m.add(t)
+            j = mkey[t]
+            if sum(t) - 3 >= lo and sum(t) + 3 < hi:
+                n_interior += 1
+            else:
+                n_boundary += 1
+            assert np.array_equal(V[voff[i]:voff[i + 1]].view(np.uint32), mV[mvoff[j]:mvoff[j + 1]].view(np.uint32)), (r, t)
+            assert np.array_equal(N[voff[i]:voff[i + 1]].view(np.uint32), mN[mvoff[j]:mvoff[j + 1]].view(np.uint32)), (r, t)
+            assert np.array_equal(I[ioff[i]:ioff[i + 1]], mI[mioff[j]:mioff[j + 1]]), (r, t)
+            assert np.array_equal(adj[i], madj[j]), (r, t)
+    assert seen_m == set(mkey)
+    assert n_boundary > 20 and n_interior > 100   # both passes had meshes to make
+    for v in [single] + parts:
+        v.close()
+    for b in [x for pr in out + inn for x in pr] + [x for p in bufs for x in p]:
+        b.free()
+
+
+def test_phase_two_without_phase_one_is_refused(gpu_required):
+    cam = synth.Camera()
+    v = capi.Volume(RES5, cam, max_chunks=1 << 14)
+    f = synth.room_frame(0, cam, with_quality=False)
+    d, c = HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])
+    v.stream_frames_device([d.ptr], [c.ptr], f[3].reshape(1, 12))
+    T = synth.pose_inverse16(f[3])
+    with pytest.raises(capi.TFError):
+        v.texture_frame_device_phase(T, 0, 2)
+    v.texture_frame_device_phase(T, 0, 1)
+    with pytest.raises(capi.TFError):
+        v.texture_frame_device(T, 0)            # half a stage pending
+    v.texture_frame_device_phase(T, 0, 2)
+    v.sync()
+    assert len(v.list_meshes()) >= 0
+    v.close(); d.free(); c.free()

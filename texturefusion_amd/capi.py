@@ -25,7 +25,7 @@ TF_ERR_MISSING_CHUNK = -6
 TF_BOUNDARY_RECORD_BYTES = 16 + 4096 + 4096
 
 PROF_NAMES = ("bbox", "select", "scan", "emit", "integrate", "finalize", "patch_project",
-              "atlas_blit", "mesh", "dirty", "patch_rank", "xchg")
+              "atlas_blit", "mesh", "dirty", "patch_rank", "xchg", "xchg_wait")
 
 # every symbol include/tf_fusion.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
@@ -41,7 +41,7 @@ SYMBOLS = (
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
     "tf_patches_download", "tf_atlas_download_rows", "tf_stream_frames_device",
     "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host", "tf_integrate_frame_host_rgb", "tf_host_frame_times", "tf_host_register", "tf_host_unregister",
-    "tf_host_frame_buffers", "tf_host_frame_deferral", "tf_host_frame_set_deferral", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_boundary_band_bounds", "tf_boundary_pack_bands2", "tf_boundary_unpack_pair", "tf_comm_exchange_mode", "tf_comm_stats", "tf_comm_stats_ex",
+    "tf_host_frame_buffers", "tf_host_frame_deferral", "tf_host_frame_set_deferral", "tf_texture_frame_device_phase", "tf_comm_exchange_overlap", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_boundary_band_bounds", "tf_boundary_pack_bands2", "tf_boundary_unpack_pair", "tf_comm_exchange_mode", "tf_comm_stats", "tf_comm_stats_ex",
     "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
     "tf_comm_exchange_every_frame",
     "tf_update_meshes", "tf_check_summaries", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
@@ -94,7 +94,7 @@ class UnitGroup(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("ms", C.c_double * 12), ("launches", C.c_int64 * 12)]
+    _fields_ = [("ms", C.c_double * len(PROF_NAMES)), ("launches", C.c_int64 * len(PROF_NAMES))]  # TF_PROF_COUNT
 
 
 _lib = None
@@ -183,6 +183,8 @@ def lib():
     L.tf_host_frame_deferral.argtypes = [vp, i32p, i32p]
     L.tf_host_frame_set_deferral.argtypes = [vp, C.c_int]
     L.tf_texture_frame_device.argtypes = [vp, fp, C.c_int32]
+    L.tf_texture_frame_device_phase.argtypes = [vp, fp, C.c_int32, C.c_int]
+    L.tf_comm_exchange_overlap.argtypes = [vp, C.c_int]
     L.tf_boundary_block_bytes.restype = C.c_size_t
     L.tf_boundary_block_bytes.argtypes = [C.c_int64]
     L.tf_boundary_pack_block.argtypes = [vp, vp, C.c_int64]
@@ -665,6 +667,14 @@ class Volume:
     def boundary_unpack_blocks(self, d_blocks, n_blocks, own_block, cap, join_dirty=False):
         self._ck(self.L.tf_boundary_unpack_blocks(self.h, C.c_void_p(d_blocks), n_blocks, own_block, cap, int(join_dirty)))
 
+    def texture_frame_device_phase(self, pose_inv16, frame_id, phase):
+        """phase 1: dirty set + interior meshes (before the caller's exchange); phase 2: boundary meshes + pending patch stage"""
+        T = _f32(pose_inv16).reshape(16)
+        self._ck(self.L.tf_texture_frame_device_phase(self.h, _p(T, C.c_float), int(frame_id), int(phase)))
+
+    def comm_exchange_overlap(self, on):
+        self._ck(self.L.tf_comm_exchange_overlap(self.h, 1 if on else 0))
+
     def texture_frame_device(self, pose_inv16, frame_id):
         T = _f32(pose_inv16).reshape(16)
         self._ck(self.L.tf_texture_frame_device(self.h, _p(T, C.c_float), int(frame_id)))
@@ -707,8 +717,11 @@ class Volume:
     def comm_stats_ex(self):
         out = (C.c_int64 * 8)()
         self._ck(self.L.tf_comm_stats_ex(self.h, out))
-        return dict(zip(("exchanges", "bytes_sent", "bytes_received", "records_sent", "records_received", "bound_records",
-                         "mode", "checked"), (int(x) for x in out)))
+        d = dict(zip(("exchanges", "bytes_sent", "bytes_received", "records_sent", "records_received", "bound_records",
+                      "mode", "checked"), (int(x) for x in out)))
+        d["overlapped"] = d["checked"] >> 1  # exchanges that ran on the second stream next to an interior mesh pass
+        d["checked"] &= 1
+        return d
 
     def comm_exchange_mode(self, mode):
         """0 = neighbour send / receive pairs (default), 1 = all-gather"""

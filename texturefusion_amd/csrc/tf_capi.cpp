@@ -10,9 +10,30 @@
 #include <thread>
 #include <sched.h>
 #include <limits>
+#include <map>
+#include <mutex>
 
 #include "tf_host_math.h"
 #include "tf_volume.h"
+
+// Page-locking is a property of the PROCESS: two handles (two volumes on one GPU, or a volume per GPU) may be fed from the
+// same caller buffers.  The ranges the library locked are counted here; the pages are locked by the first handle that
+// registers a range and released by the last that lets go of it.
+namespace {
+struct LockedRange { size_t n; int refs; };
+std::mutex g_locked_mu;
+std::map<const uint8_t*, LockedRange> g_locked;
+}  // namespace
+static int host_range_release(const uint8_t* p) {
+  using namespace tf;
+  std::lock_guard<std::mutex> lk(g_locked_mu);
+  auto it = g_locked.find(p);
+  if (it == g_locked.end()) return TF_OK;
+  if (--it->second.refs > 0) return TF_OK;
+  g_locked.erase(it);
+  TF_HIP(hipHostUnregister(const_cast<uint8_t*>(p)));
+  return TF_OK;
+}
 
 namespace tf {
 
@@ -461,7 +482,10 @@ int tf_volume_destroy(tf_volume* v) {
   v->h_progress = nullptr;
   if (v->h_xchg) hipHostFree(v->h_xchg);
   v->h_xchg = nullptr;
-  for (const tf_volume::HostRange& r : v->host_ranges) (void)hipHostUnregister(const_cast<uint8_t*>(r.p));
+  if (v->xstream) { hipStreamSynchronize(v->xstream); hipStreamDestroy(v->xstream); v->xstream = nullptr; }
+  if (v->ev_fork) { hipEventDestroy(v->ev_fork); v->ev_fork = nullptr; }
+  if (v->ev_join) { hipEventDestroy(v->ev_join); v->ev_join = nullptr; }
+  for (const tf_volume::HostRange& r : v->host_ranges) (void)host_range_release(r.p);
   v->host_ranges.clear();
   for (int k = 0; k < tf_volume::kHostRing; ++k) {
     if (v->hslot[k].h) hipHostFree(v->hslot[k].h);
@@ -830,8 +854,26 @@ int tf::fused_arm(tf_volume* v) {
 // = the parity used here), or the caller ran launch_dirty_frame over each of its lists (the keyframe unit)
 int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
                       const float* pose_inv16, int32_t frame_id, bool claimed, const FrameCtl* next_ctl, bool ride_filter,
-                      bool sized_xchg) {
+                      bool sized_xchg, int phase) {
   AtlasState& a = v->atlas;
+  if (phase == 2) {
+    // second half of a stage whose first half (dirty set + interior meshes) ran before the caller's own exchange
+    if (!a.phase1_on || a.phase1_epoch != frame_epoch) { set_error("tf_texture_frame_device_phase: phase 2 without phase 1 of the same frame"); return TF_ERR_INVALID; }
+    a.phase1_on = false;
+    const int par = a.fused_par;
+    a.fused_par ^= 1;
+    VolumeDev d = v->dev;
+    d.sel = sel;
+    d.work_ids = a.d_work_ids + (size_t)par * d.max_chunks;
+    d.work_slot = a.d_work_slot + (size_t)par * d.max_chunks;
+    prof_begin(v, TF_PROF_MESH);
+    launch_mesh(d, v->mesh_par, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1, 0u, nullptr, par,
+                v->stream, nullptr, &v->cam, /*cls=*/2);
+    v->mesh_par ^= 1;
+    prof_end(v);
+    return texture_stage_finish(v, img, frame_epoch, pose_inv16, frame_id, par);
+  }
+  if (a.phase1_on) { set_error("a texture stage is half done: call tf_texture_frame_device_phase(.., 2) first"); return TF_ERR_INVALID; }
   // A patch stage still pending here (the previous textured frame's) must read its meshes before this frame's mesher
   // rewrites them: it goes out on its own first -- or (ride_filter: the keyframe unit, which has no k_frame launch for it)
   // rides on this frame's FILTER launch (launch_mesh below).  In the per-frame stream the stage rides on k_frame instead:
@@ -843,7 +885,7 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
   rc = fused_arm(v);
   if (rc) return rc;
   const int par = a.fused_par;
-  a.fused_par ^= 1;
+  if (phase != 1) a.fused_par ^= 1;  // (phase 1: the caller's unpack still appends to this parity's list)
   VolumeDev d = v->dev;
   d.sel = sel;
   d.work_ids = a.d_work_ids + (size_t)par * d.max_chunks;
@@ -856,29 +898,83 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
   else if (v->clear_floor < frame_epoch) launch_dirty_backlog(d, par, v->clear_floor, v->stream);
   else launch_dirty_frame(d, par, frame_epoch + 1u, v->stream);
   prof_end(v);
-  if (v->comm_cap > 0) {  // multi-GPU: ghost bands of this frame's updates, before the mesher reads them
-    // (sized by this frame's selection when the fused stream ran it -- sel.ctl then holds the band counts, tagged with the
-    // frame's epoch + 1; lists of the call-by-call flow and the keyframe unit carry no counts: fixed-capacity blocks)
-    rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u, sized_xchg ? sel.ctl : nullptr, frame_epoch + 1u,
-                       sized_xchg ? next_ctl : nullptr);
-    if (rc) return rc;
-  }
-  prof_begin(v, TF_PROF_MESH);
   // (the filter's form follows the dirty-list length of an earlier frame: the kernel leaves it in host-visible memory,
   // read here without any synchronisation -- whatever value is there is good enough)
   const uint32_t len_guess = a.h_dirty_len ? *reinterpret_cast<volatile uint32_t*>(a.h_dirty_len) : 0u;
-  // (the shard lists of this parity are walked in any case: empty when K-A did not claim -- the previous frame's mesher
-  // re-armed them)
   const PatchStage prev = a.pend_patch.st;  // (copied: the pending record is overwritten below)
-  const bool rode = launch_mesh(d, v->mesh_par, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true,
-                                par ^ 1, len_guess, a.h_dirty_len, par, v->stream, ride ? &prev : nullptr, &v->cam);
-  v->mesh_par ^= 1;
-  prof_end(v);
+  // one filter + mesher pass over the frame's dirty set (cls: every chunk / interior chunks only / boundary chunks only);
+  // the shard lists of this parity are walked in any case: empty when K-A did not claim -- the previous frame's mesher
+  // re-armed them
+  auto mesh_pass = [&](int cls, const uint32_t* flat_count, bool with_hint, bool with_ride) -> bool {
+    prof_begin(v, TF_PROF_MESH);
+    const bool rode = launch_mesh(d, v->mesh_par, d.work_ids, flat_count, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1,
+                                  len_guess, with_hint ? a.h_dirty_len : nullptr, par, v->stream, with_ride ? &prev : nullptr,
+                                  &v->cam, cls);
+    v->mesh_par ^= 1;
+    prof_end(v);
+    return rode;
+  };
+  bool rode = false;
+  if (phase == 1) {
+    // a caller with its own transport: the interior meshes now, the boundary ones behind its unpack (phase 2).  The flat
+    // list of this parity holds the frame's own entries (stream order: the unpack has not run yet)
+    rode = mesh_pass(1, &d.actl->set[par].n_work, true, false);
+    a.phase1_on = true;
+    a.phase1_epoch = frame_epoch;
+    return TF_OK;
+  }
+  if (v->comm_cap > 0) {  // multi-GPU: ghost bands of this frame's updates, before the mesher reads them
+    // (sized by this frame's selection when the fused stream ran it -- sel.ctl then holds the band counts, tagged with the
+    // frame's epoch + 1; lists of the call-by-call flow and the keyframe unit carry no counts: fixed-capacity blocks)
+    const FrameCtl* xc = sized_xchg ? sel.ctl : nullptr;
+    const FrameCtl* xn = sized_xchg ? next_ctl : nullptr;
+    // The exchange leaves the critical path: pack -> send / receive -> unpack run on a second stream while the main
+    // stream filters and meshes the INTERIOR chunks of the dirty set -- those whose 27-chunk neighbourhood is owned, so that
+    // nothing they read can arrive from another rank -- and only the boundary chunks (and what the arriving ghosts add to
+    // the dirty set) wait for it.  Needs the dirty set in the shard lists K-A filled (claimed: the flat list, which the
+    // unpack launch appends to, is then ignored by the interior pass) and no patch stage riding on the filter launch.
+    // (sized_xchg = the stage comes from the fused stream: `claimed` then means K-A's shard lists; the keyframe unit also
+    // passes claimed, with its dirty set in the FLAT list)
+    const bool overlap = claimed && sized_xchg && !ride && v->xchg_overlap;
+    if (overlap) {
+      if (!v->xstream) {
+        TF_HIP(hipStreamCreateWithFlags(&v->xstream, hipStreamNonBlocking));
+        TF_HIP(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
+        TF_HIP(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
+      }
+      TF_HIP(hipEventRecord(v->ev_fork, v->stream));          // behind the voxel update of this frame
+      TF_HIP(hipStreamWaitEvent(v->xstream, v->ev_fork, 0));
+      hipStream_t main_stream = v->stream;
+      v->stream = v->xstream;  // (comm_exchange and what it calls enqueue on the handle's stream)
+      rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u, xc, frame_epoch + 1u, xn);
+      v->stream = main_stream;
+      if (rc) return rc;
+      TF_HIP(hipEventRecord(v->ev_join, v->xstream));
+      rode = mesh_pass(1, &d.vctl->zero_word, true, false);
+      prof_begin(v, TF_PROF_XCHG_WAIT);                        // what of the exchange is NOT hidden behind the interior pass
+      TF_HIP(hipStreamWaitEvent(v->stream, v->ev_join, 0));
+      prof_end(v);
+      rode = mesh_pass(2, &d.actl->set[par].n_work, false, false);
+      v->xchg_overlapped += 1;
+    } else {
+      rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u, xc, frame_epoch + 1u, xn);
+      if (rc) return rc;
+      rode = mesh_pass(0, &d.actl->set[par].n_work, true, ride);
+    }
+  } else {
+    rode = mesh_pass(0, &d.actl->set[par].n_work, true, ride);
+  }
   if (ride) {
     if (!rode) { set_error("internal: the pending patch stage found no filter launch"); return TF_ERR_INVALID; }
     rc = patch_launched(v);
     if (rc) return rc;
   }
+  return texture_stage_finish(v, img, frame_epoch, pose_inv16, frame_id, par);
+}
+// the tail of a texture stage: this frame's patch stage becomes the pending one
+int tf::texture_stage_finish(tf_volume* v, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16, int32_t frame_id,
+                             int par) {
+  AtlasState& a = v->atlas;
   // (CompressMeshes' neighbour exchange, the list of chunks that own a mesh and the slot candidates are produced
   // by the mesher and consumed by the patch kernel: no kernel of their own in the fused flow)
   KfDev kf;
@@ -1182,13 +1278,27 @@ int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_s
   return TF_OK;
 }
 
+}  // extern "C"
+extern "C" {
 int tf_host_register(tf_volume* v, const void* p, int64_t bytes) {
   if (!v || !p || bytes <= 0) { set_error("null argument"); return TF_ERR_INVALID; }
   TF_DEV_NOFLUSH(v);
   const uint8_t* b = static_cast<const uint8_t*>(p);
   for (const tf_volume::HostRange& r : v->host_ranges)
-    if (b >= r.p && b + bytes <= r.p + r.n) return TF_OK;  // already inside a registered range
-  TF_HIP(hipHostRegister(const_cast<uint8_t*>(b), (size_t)bytes, hipHostRegisterDefault));
+    if (b >= r.p && b + bytes <= r.p + r.n) return TF_OK;  // already inside a range of this handle
+  {
+    std::lock_guard<std::mutex> lk(g_locked_mu);
+    auto it = g_locked.find(b);
+    if (it != g_locked.end() && it->second.n >= (size_t)bytes) {
+      it->second.refs += 1;  // another handle of this process locked these pages already
+    } else if (it != g_locked.end()) {
+      set_error("tf_host_register: the buffer is registered with a smaller size by another handle");
+      return TF_ERR_INVALID;
+    } else {
+      TF_HIP(hipHostRegister(const_cast<uint8_t*>(b), (size_t)bytes, hipHostRegisterDefault));
+      g_locked[b] = LockedRange{(size_t)bytes, 1};
+    }
+  }
   v->host_ranges.push_back({b, (size_t)bytes});
   return TF_OK;
 }
@@ -1198,9 +1308,8 @@ int tf_host_unregister(tf_volume* v, const void* p) {
   TF_HIP(hipStreamSynchronize(v->copy_stream ? v->copy_stream : v->stream));
   for (size_t i = 0; i < v->host_ranges.size(); ++i)
     if (v->host_ranges[i].p == static_cast<const uint8_t*>(p)) {
-      TF_HIP(hipHostUnregister(const_cast<void*>(p)));
       v->host_ranges.erase(v->host_ranges.begin() + (long)i);
-      return TF_OK;
+      return host_range_release(static_cast<const uint8_t*>(p));
     }
   set_error("not a registered buffer");
   return TF_ERR_INVALID;
@@ -1475,6 +1584,22 @@ int tf_texture_frame_device(tf_volume* v, const float pose_inv16[16], int32_t fr
   if (!v->frame_bound || !v->frame.rgba) { set_error("no colour frame bound"); return TF_ERR_INVALID; }
   if (v->epoch == 0) { set_error("no frame has been integrated"); return TF_ERR_INVALID; }
   return texture_stage(v, v->dev.sel, v->frame, v->epoch - 1u, pose_inv16, frame_id);
+}
+
+int tf_texture_frame_device_phase(tf_volume* v, const float pose_inv16[16], int32_t frame_id, int phase) {
+  if (!v || !pose_inv16) { set_error("null argument"); return TF_ERR_INVALID; }
+  if (phase != 1 && phase != 2) { set_error("phase must be 1 or 2"); return TF_ERR_INVALID; }
+  TF_DEV_STREAM(v);
+  if (phase == 1 && v->atlas.pend_patch.on) { int rc = patch_flush(v); if (rc) return rc; }
+  if (!v->frame_bound || !v->frame.rgba) { set_error("no colour frame bound"); return TF_ERR_INVALID; }
+  if (v->epoch == 0) { set_error("no frame has been integrated"); return TF_ERR_INVALID; }
+  return texture_stage(v, v->dev.sel, v->frame, v->epoch - 1u, pose_inv16, frame_id, false, nullptr, false, false, phase);
+}
+
+int tf_comm_exchange_overlap(tf_volume* v, int on) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  v->xchg_overlap = on != 0;
+  return TF_OK;
 }
 
 int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {

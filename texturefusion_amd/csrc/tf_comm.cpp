@@ -293,7 +293,7 @@ int tf_comm_stats_ex(tf_volume* v, int64_t out[8]) {
   out[4] = (int64_t)rec[1];                      // ghost records read out of received blocks
   out[5] = (int64_t)v->comm.bound_records;       // record capacity of the blocks sent
   out[6] = v->comm.neighbours_ok ? TF_XCHG_NEIGHBOURS : TF_XCHG_ALLGATHER;  // the form in use (after the first exchange)
-  out[7] = v->comm.checked ? 1 : 0;
+  out[7] = (v->comm.checked ? 1 : 0) | (int64_t)(v->xchg_overlapped << 1);  // bit 0: partition checked; >> 1: exchanges overlapped with an interior mesh pass
   return TF_OK;
 }
 

@@ -38,6 +38,15 @@ __device__ __forceinline__ bool part_band(const VolumeDev& v, int x, int y, int 
   return (k >= (long long)v.part_lo && k - (long long)v.part_lo <= s) || k == (long long)v.part_hi - 1;
 }
 
+// A chunk whose whole 27-chunk neighbourhood (what its mesh reads: keys within a + b + c of its own) is owned by this
+// rank: its mesh does not depend on the boundary exchange of the frame.  Everything else this rank meshes is a
+// "boundary" chunk and has to wait for the ghosts.
+__device__ __forceinline__ bool part_interior(const VolumeDev& v, int x, int y, int z) {
+  const long long k = part_key(v, x, y, z);
+  const long long s = (long long)v.part_a + v.part_b + v.part_c;
+  return k - s >= (long long)v.part_lo && k + s < (long long)v.part_hi;
+}
+
 // Fibonacci hashing folded to 32 bits: every bit of (x, y, z) reaches the index bits (the upper
 // half of the product carries z, the lower half x and y), so columns of chunks do not share a home.
 __device__ __forceinline__ uint32_t hash_key(unsigned long long k) {

@@ -88,7 +88,8 @@ struct VolCtl {
   uint32_t ovf_next;  // mesh overflow pool: blocks handed out (bump allocation, reset with the volume)
   uint32_t n_tmp2;    // second scratch counter (the "up" block of the two-band boundary pack)
   uint32_t xchg_sent, xchg_recv;  // ghost records written into / stored from exchange blocks since create (tf_comm_stats_ex)
-  uint32_t xchg_pad[2];
+  uint32_t zero_word;  // always 0: an empty list's count (the interior mesh pass of an overlapped exchange ignores the flat list)
+  uint32_t xchg_pad;
   // Pool slots are handed out from 64 independent stripes (stripe s owns slots
   // [s*max_chunks/64, (s+1)*max_chunks/64)) so that the thousands of chunk creations of a
   // first-touch frame do not serialise on one atomic word.
@@ -373,7 +374,7 @@ uint32_t mesh_shard_rows(uint32_t max_chunks);
 // filter's; tf_patch_body.h) -- returns true when it did (the fused-filter form of the mesher has no such launch)
 bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, int shards_par,
-                 hipStream_t s, const PatchStage* patch = nullptr, const Cam* cam = nullptr);
+                 hipStream_t s, const PatchStage* patch = nullptr, const Cam* cam = nullptr, int cls = 0);  // cls: FilterPatch::cls
 // per-frame dirty set of the fused flow -> work list of counter set `par` (when K-A did not build it: FrameStage::claim_par)
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s);
 // ... when marks of earlier frames are still waiting for a mesher: everything marked since clear_floor

@@ -377,6 +377,9 @@ struct FilterPatch {
   uint32_t n_patch;  // workgroups of the patch range (0: none)
   uint32_t first;    // first workgroup of the patch range: 0 = dispatched ahead of the filter's, else behind them
   int par;
+  // N > 1, exchange overlapped with the interior meshes: 0 = every entry, 1 = only chunks whose 27-neighbourhood is owned
+  // (part_interior: nothing of their meshes waits for the ghosts), 2 = only the others
+  uint32_t cls;
   Cam cam;
   KfDev kf;
 };
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 8
   if (WAVE_FORM) {
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6));
     auto process = [&](const int4 id, const uint32_t own_listed, const bool have_own) {
+      if (fp.cls && ((fp.cls == 1u) != part_interior(v, id.x, id.y, id.z))) return;  // (the other pass of this frame takes it)
       uint32_t own = kInvalidSlot;
       bool maybe = false;
       uint32_t near8 = kInvalidSlot;
@@ -493,6 +497,7 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 8
       uint32_t own;
       bool maybe;
       const uint32_t nslot = filter_near(v, id, lane, k8, dslot != nullptr || entry >= n_flat, own_listed, use_summ, &own, &maybe);
+      if (fp.cls && ((fp.cls == 1u) != part_interior(v, id.x, id.y, id.z))) own = kInvalidSlot;  // (group-uniform: the other pass takes it)
       if (own != kInvalidSlot) {  // RecomputeMeshes: !HasChunk -> skip (:240-242)
         if (maybe) {
           uint32_t at = 0;
@@ -979,7 +984,7 @@ static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries,
 
 bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, int shards_par,
-                 hipStream_t s, const PatchStage* patch, const Cam* cam) {
+                 hipStream_t s, const PatchStage* patch, const Cam* cam, int cls) {
   if (!max_entries) return false;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshCntWords;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
@@ -993,6 +998,7 @@ bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   const bool wave_form = len_guess <= 2560u * 4u;  // (the wave form strides when its grid is smaller than the list)
   FilterPatch fp;
   memset(&fp, 0, sizeof(fp));
+  fp.cls = (uint32_t)cls;
   if (patch && cam) {
     // one wave per patch; the range is dispatched AHEAD of the filter's workgroups (its chains are the longer ones)
     fp.defer = 1u;

@@ -100,6 +100,10 @@ struct AtlasState {
     int host_slot = -1;  // tf_integrate_frame_host: the staging slot whose device images the stage still reads
   } pend_patch;
   bool fused_armed = false;  // the counter sets are in the state the fused flow expects
+  // tf_texture_frame_device_phase: phase 1 (dirty set + interior meshes) of the stage of frame `phase1_epoch` has run,
+  // phase 2 (boundary meshes behind the caller's unpack, pending patch stage) has not
+  bool phase1_on = false;
+  uint32_t phase1_epoch = 0;
   // staging
   void* d_stage = nullptr;
   size_t d_stage_bytes = 0;
@@ -240,6 +244,11 @@ struct tf_volume {
   uint32_t* h_xchg = nullptr;
   uint32_t xchg_pub_enq = 0;  // frame tag of the publish that is already on the stream (0: none)
   uint32_t xchg_pub_seq = 0;  // ... the sequence number that publish writes into h_xchg[0] (what the host waits for)
+  // the per-frame exchange overlapped with the interior meshes (texture_stage): second stream, fork / join events
+  hipStream_t xstream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool xchg_overlap = true;        // tf_comm_exchange_overlap
+  uint64_t xchg_overlapped = 0;    // exchanges that ran next to an interior mesh pass (tf_comm_stats_ex)
   uint32_t xchg_seq = 0;      // publish sequence numbers handed out (monotonic over the handle's life: a stale word never matches)
 };
 
@@ -253,7 +262,8 @@ int launch_prepare_unordered(tf_volume* v, const Pose& pose, hipStream_t s = nul
 // no k_frame launch for it to ride on) instead of going out as a launch of its own
 int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16,
                   int32_t frame_id, bool claimed = false, const FrameCtl* next_ctl = nullptr, bool ride_filter = false,
-                  bool sized_xchg = false);  // sized_xchg: sel.ctl holds the frame's band counts (fused stream only)
+                  bool sized_xchg = false, int phase = 0);  // sized_xchg: sel.ctl holds the frame's band counts (fused stream only)
+int texture_stage_finish(tf_volume* v, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16, int32_t frame_id, int par);
 // the four band counts of the frame whose selection wrote `ctl` (tag = its epoch + 1): waits for the device to publish them
 int xchg_band_counts(tf_volume* v, const FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]);
 int flush_deferred(tf_volume* v);
