@@ -57,17 +57,21 @@ typedef struct {
   int32_t atlas_w;       /* default 13824 (Structure/Atlas.h:29) */
   int32_t atlas_h;       /* default 13824 (Structure/Atlas.h:30) */
   int32_t max_keyframes; /* keyframe image cache slots for the atlas; default 64 */
-  /* blocks of the shared mesh overflow pool (167 KB each, room for the largest mesh a chunk can have); 0 = default
-   * max(64, max_chunks / 256), at most 2047; -1 = none */
+  /* blocks of the LARGE pool of the mesh store (167 KB each, room for the largest mesh a chunk can have); 0 = default
+   * max(64, max_chunks / 256), at most 65535; -1 = none */
   int32_t mesh_overflow_blocks;
-  /* device-resident meshes (ChunkManager::allMeshes): one fixed block per chunk-pool slot.  A mesh has at
-   * most 2187 vertices / 2560 triangles (9x9x9x3 edge grid, 512 cells x 5); a mesh that does not fit the slot's
-   * block is kept in a block of the overflow pool (handed out once per chunk, never returned before
-   * tf_volume_reset) -- the reference emits whatever a chunk produces (Structure/ChunkManager.cpp:856-918).  Only
-   * when that pool is exhausted is a mesh stored empty and reported as TF_ERR_CAPACITY at the next synchronising
-   * call.  0 = default 256 / 512 (a planar surface through a chunk has 81 / 128). */
+  /* device-resident meshes (ChunkManager::allMeshes) live in a store that is allocated ON DEMAND: a chunk-pool slot owns
+   * no mesh storage until its chunk first has a mesh with vertices; then it is given a block of mesh_max_vertices /
+   * mesh_max_triangles (0 = default 256 / 512: 20.4 KiB; a planar surface through a chunk has 81 / 128) out of
+   * mesh_blocks blocks, or -- a mesh has at most 2187 vertices / 2560 triangles (9x9x9x3 edge grid, 512 cells x 5), and
+   * the reference emits whatever a chunk produces (Structure/ChunkManager.cpp:856-918) -- a block of the large pool.
+   * Blocks are handed out once per chunk and never returned before tf_volume_reset.  Only when the pool a mesh needs is
+   * exhausted is the mesh stored empty and reported as TF_ERR_CAPACITY at the next synchronising call. */
   int32_t mesh_max_vertices;
   int32_t mesh_max_triangles;
+  /* blocks of the small pool; 0 = default max(4096, max_chunks / 4) (a quarter of the chunks of a scanned scene lie on a
+   * surface; the rest -- in front of it, behind it, parked -- never own a mesh), at most max_chunks */
+  int64_t mesh_blocks;
 } tf_config;
 
 /* Counters of the most recent frame / list (device-side integers, read back on request). */

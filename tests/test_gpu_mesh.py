@@ -241,3 +241,49 @@ def test_voxel_size_10mm(gpu_required):
     gv.update_meshes()
     assert _compare_meshes(ov, gv, "10 mm") > 100
     gv.close()
+
+
+def test_mesh_store_is_allocated_on_demand(gpu_required):
+    """The mesh store hands out a block the first time a chunk has a mesh with vertices and never before: a volume of 2^14
+    pool slots with only 64 blocks (mesh_blocks = 64: 1.3 MB instead of 327 MB of store) meshes 27 chunks, re-meshes them in
+    the blocks they own, and reports exhaustion -- stored empty, TF_ERR_CAPACITY -- when more chunks get meshes than
+    blocks exist; chunks without a surface never take one."""
+    from texturefusion_amd import capi
+    cam = synth.Camera()
+    ov = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(RES5, cam, max_chunks=1 << 14, mesh_blocks=64)
+    rng = np.random.default_rng(11)
+    res = float(RES5)
+    nrm = np.array([0.2, 0.3, 0.93]); nrm /= np.linalg.norm(nrm)
+
+    def put(origin, n_side, seed_off):
+        ids = []
+        for c in np.ndindex(n_side, n_side, 3):
+            cid = np.array(c, np.int32) + origin
+            zz, yy, xx = np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij")
+            p = (np.stack([xx, yy, zz], -1).reshape(-1, 3) + cid * 8 + 0.5) * res
+            d0 = float(nrm @ ((np.array(origin) * 8 + np.array([4.0 * n_side, 4.0 * n_side, 12.0])) * res))
+            sdf = (p @ nrm - d0).astype(np.float32)
+            col = rng.integers(1, 200, 2048).astype(np.uint16)
+            for v in (ov, gv):
+                v.set_chunk(cid, sdf, np.full(512, 100.0, np.float32), col)
+            ids.append(cid)
+        ids = np.array(ids, np.int32)
+        for v in (ov, gv):
+            v.finalize(ids, np.ones(len(ids), np.uint8), np.zeros(len(ids), np.uint8))
+        return ids
+
+    put((0, 0, 0), 3, 0)          # 27 chunks, the plane passes through the middle layer and its neighbours
+    ov.update_meshes(); gv.update_meshes()
+    n1 = _compare_meshes(ov, gv, "on-demand store")
+    assert 9 <= n1 <= 27
+    ov.update_meshes(); gv.update_meshes()      # (nothing dirty: no-op)
+    put((0, 0, 0), 3, 1)          # the same chunks again: they keep their blocks (a leak would show below)
+    ov.update_meshes(); gv.update_meshes()
+    assert _compare_meshes(ov, gv, "on-demand store, re-meshed") == n1
+    put((40, 0, 0), 9, 2)         # 243 more chunks, at least 81 of them with a surface: more meshes than the 64 blocks can hold
+    ov.update_meshes()
+    with pytest.raises(capi.TFError) as e:
+        gv.update_meshes()
+    assert e.value.code == capi.TF_ERR_CAPACITY and "mesh_blocks" in str(e.value)
+    gv.close()

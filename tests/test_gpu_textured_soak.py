@@ -253,3 +253,13 @@ def test_textured_frames_after_a_tsdf_only_stretch(gpu_required):
     for a, b in bufs:
         a.free(); b.free()
     gv.close()
+
+
+def test_pool_of_four_million_chunks(gpu_required):
+    """tf_config.max_chunks beyond 2^21 (the ceiling of rounds 1-4: pool slots were 21-bit fields of the patch lists): a
+    2^22-slot pool -- 32 GiB of voxels, the mesh store allocated on demand -- takes the hall's frames bit for bit like any
+    other.  The reference's ChunkMap is an unordered_map (Structure/ChunkManager.h:111): only memory bounds it."""
+    cam = synth.Camera.hires()
+    frames = [synth.room_frame(k, cam, half=(4.0, 3.0, 4.0), radius=3.2, with_quality=False) for k in range(18, 24)]
+    n = _run(cam, np.float32(0.005), frames, max_chunks=1 << 22, stride=17)
+    assert n > 200

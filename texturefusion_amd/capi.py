@@ -67,7 +67,7 @@ class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_chunks", C.c_int64), ("max_list", C.c_int64),
                 ("max_coarse", C.c_int64), ("atlas_w", C.c_int32), ("atlas_h", C.c_int32),
                 ("max_keyframes", C.c_int32), ("mesh_overflow_blocks", C.c_int32),
-                ("mesh_max_vertices", C.c_int32), ("mesh_max_triangles", C.c_int32)]
+                ("mesh_max_vertices", C.c_int32), ("mesh_max_triangles", C.c_int32), ("mesh_blocks", C.c_int64)]
 
 
 class Stats(C.Structure):
@@ -256,11 +256,11 @@ class Volume:
 
     def __init__(self, res, cam=None, max_chunks=1 << 17, max_list=1 << 18, max_coarse=1 << 20,
                  atlas_w=0, atlas_h=0, device=0, use_color=True, stream=None, mesh_max_vertices=0,
-                 mesh_max_triangles=0, mesh_overflow_blocks=0):
+                 mesh_max_triangles=0, mesh_overflow_blocks=0, mesh_blocks=0):
         self.L = lib()
         self.h = C.c_void_p()
         cfg = Config(device, max_chunks, max_list, max_coarse, atlas_w, atlas_h, 0, mesh_overflow_blocks, mesh_max_vertices,
-                     mesh_max_triangles)
+                     mesh_max_triangles, mesh_blocks)
         dims = (C.c_int32 * 3)(8, 8, 8)
         rc = self.L.tf_volume_create(dims, np.float32(res), int(use_color), C.byref(cfg), C.byref(self.h))
         if rc != TF_OK:

@@ -160,12 +160,12 @@ __global__ __launch_bounds__(256) void k_cc_reduce(VolumeDev v, const CcPatch* _
   for (int64_t p = 0; p < np; ++p) {
     if (pt[p].cluster != c || pt[p].wrong) continue;
     const uint32_t slot = pt[p].slot;
-    const uint32_t mst = v.mesh_rec[slot].state;  // (which block holds the mesh)
+    const uint32_t mst = v.mesh_rec[slot].block;  // (which block holds the mesh)
     for (uint32_t k = threadIdx.x; k < pt[p].nv; k += 256) {
-      const float s0 = mesh_plane(v, slot, mst, kMpTcol)[k], s1 = mesh_plane(v, slot, mst, kMpTcol + 1)[k],
-                  s2 = mesh_plane(v, slot, mst, kMpTcol + 2)[k];
-      const float t0 = mesh_plane(v, slot, mst, kMpCol)[k], t1 = mesh_plane(v, slot, mst, kMpCol + 1)[k],
-                  t2 = mesh_plane(v, slot, mst, kMpCol + 2)[k];
+      const float s0 = mesh_plane(v, mst, kMpTcol)[k], s1 = mesh_plane(v, mst, kMpTcol + 1)[k],
+                  s2 = mesh_plane(v, mst, kMpTcol + 2)[k];
+      const float t0 = mesh_plane(v, mst, kMpCol)[k], t1 = mesh_plane(v, mst, kMpCol + 1)[k],
+                  t2 = mesh_plane(v, mst, kMpCol + 2)[k];
       if constexpr (PASS == 0) {
         acc[0] += s0; acc[1] += s1; acc[2] += s2;
         acc[3] += t0; acc[4] += t1; acc[5] += t2;
@@ -199,16 +199,16 @@ __global__ __launch_bounds__(256) void k_cc_apply(VolumeDev v, const CcPatch* __
   if (X[15] == 0.0f) return;  // nothing was learnt for this cluster (:242): has_adjusted stays false
   if (threadIdx.x == 0) v.mesh_rec[P.slot].pflags |= kPfAdjusted;
   if (P.wrong) return;  // labs cleared (:277-279)
-  const uint32_t mst = v.mesh_rec[P.slot].state;
+  const uint32_t mst = v.mesh_rec[P.slot].block;
   for (uint32_t k = threadIdx.x; k < P.nv; k += 256) {
-    const float d0 = mesh_plane(v, P.slot, mst, kMpTcol)[k] - X[9], d1 = mesh_plane(v, P.slot, mst, kMpTcol + 1)[k] - X[10],
-                d2 = mesh_plane(v, P.slot, mst, kMpTcol + 2)[k] - X[11];
+    const float d0 = mesh_plane(v, mst, kMpTcol)[k] - X[9], d1 = mesh_plane(v, mst, kMpTcol + 1)[k] - X[10],
+                d2 = mesh_plane(v, mst, kMpTcol + 2)[k] - X[11];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float a = X[3 * i] * d0;
       a = a + X[3 * i + 1] * d1;
       a = a + X[3 * i + 2] * d2;
-      mesh_plane(v, P.slot, mst, kMpLabs + i)[k] = a + X[12 + i];
+      mesh_plane(v, mst, kMpLabs + i)[k] = a + X[12 + i];
     }
   }
 }
@@ -258,34 +258,34 @@ __global__ __launch_bounds__(256) void k_draw(VolumeDev v, const DrawPatch* __re
   const float aw = (float)v.atlas_w, ah = (float)v.atlas_h;
   for (uint32_t j = threadIdx.x; j < P.nt; j += 256)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) out_i[P.iout + 3 * (size_t)j + a] = (uint32_t)tri_plane(v, P.slot, rec.state, a)[j] + (uint32_t)P.vout;
+    for (int a = 0; a < 3; ++a) out_i[P.iout + 3 * (size_t)j + a] = (uint32_t)tri_plane(v, rec.block, a)[j] + (uint32_t)P.vout;
   for (uint32_t k = threadIdx.x; k < P.nv; k += 256) {
     float* o = out_v + 12 * (P.vout + k);
-    float tx = mesh_plane(v, P.slot, rec.state, kMpTc)[k], ty = mesh_plane(v, P.slot, rec.state, kMpTc + 1)[k];
+    float tx = mesh_plane(v, rec.block, kMpTc)[k], ty = mesh_plane(v, rec.block, kMpTc + 1)[k];
     if (rx < 1.0f) tx = tx * rx;
     if (ry < 1.0f) ty = ty * ry;
     tx = tx + ox;
     ty = ty + oy;
-    const float c0 = mesh_plane(v, P.slot, rec.state, kMpCol)[k], c1 = mesh_plane(v, P.slot, rec.state, kMpCol + 1)[k],
-                c2 = mesh_plane(v, P.slot, rec.state, kMpCol + 2)[k];
+    const float c0 = mesh_plane(v, rec.block, kMpCol)[k], c1 = mesh_plane(v, rec.block, kMpCol + 1)[k],
+                c2 = mesh_plane(v, rec.block, kMpCol + 2)[k];
     int rgb = (int)(c0 * 255.0f);
     rgb = (rgb << 8) + (int)(c1 * 255.0f);
     rgb = (rgb << 8) + (int)(c2 * 255.0f);
     float adj = 0.0f;
     if (P.flags & 4u) {
-      const float a0 = mesh_plane(v, P.slot, rec.state, kMpLabs)[k] - mesh_plane(v, P.slot, rec.state, kMpTcol)[k],
-                  a1 = mesh_plane(v, P.slot, rec.state, kMpLabs + 1)[k] - mesh_plane(v, P.slot, rec.state, kMpTcol + 1)[k],
-                  a2 = mesh_plane(v, P.slot, rec.state, kMpLabs + 2)[k] - mesh_plane(v, P.slot, rec.state, kMpTcol + 2)[k];
+      const float a0 = mesh_plane(v, rec.block, kMpLabs)[k] - mesh_plane(v, rec.block, kMpTcol)[k],
+                  a1 = mesh_plane(v, rec.block, kMpLabs + 1)[k] - mesh_plane(v, rec.block, kMpTcol + 1)[k],
+                  a2 = mesh_plane(v, rec.block, kMpLabs + 2)[k] - mesh_plane(v, rec.block, kMpTcol + 2)[k];
       int ad = (int)(a0 * 255.0f) + 255;
       ad = (ad << 9) + (int)(a1 * 255.0f) + 255;
       ad = (ad << 9) + (int)(a2 * 255.0f) + 255;
       adj = (float)ad;
     }
-    const float4 q0 = make_float4(mesh_plane(v, P.slot, rec.state, kMpPos)[k], mesh_plane(v, P.slot, rec.state, kMpPos + 1)[k],
-                                  mesh_plane(v, P.slot, rec.state, kMpPos + 2)[k], 50.0f);
+    const float4 q0 = make_float4(mesh_plane(v, rec.block, kMpPos)[k], mesh_plane(v, rec.block, kMpPos + 1)[k],
+                                  mesh_plane(v, rec.block, kMpPos + 2)[k], 50.0f);
     const float4 q1 = make_float4((float)rgb, adj, tx / aw, ty / ah);
-    const float4 q2 = make_float4(mesh_plane(v, P.slot, rec.state, kMpNrm)[k], mesh_plane(v, P.slot, rec.state, kMpNrm + 1)[k],
-                                  mesh_plane(v, P.slot, rec.state, kMpNrm + 2)[k], (P.flags & 2u) ? 1.0f : 0.0f);
+    const float4 q2 = make_float4(mesh_plane(v, rec.block, kMpNrm)[k], mesh_plane(v, rec.block, kMpNrm + 1)[k],
+                                  mesh_plane(v, rec.block, kMpNrm + 2)[k], (P.flags & 2u) ? 1.0f : 0.0f);
     reinterpret_cast<float4*>(o)[0] = q0;
     reinterpret_cast<float4*>(o)[1] = q1;
     reinterpret_cast<float4*>(o)[2] = q2;
@@ -320,11 +320,11 @@ __global__ __launch_bounds__(256) void k_patch_gather(VolumeDev v, const int4* _
       const long long v0 = voff[c];
       const uint32_t nv = (uint32_t)(voff[c + 1] - v0) < m.nv ? (uint32_t)(voff[c + 1] - v0) : m.nv;
       for (uint32_t i = threadIdx.x; i < nv; i += 256) {
-        if (texcoord) { texcoord[2 * (v0 + i)] = mesh_plane(v, slot, m.state, kMpTc)[i]; texcoord[2 * (v0 + i) + 1] = mesh_plane(v, slot, m.state, kMpTc + 1)[i]; }
+        if (texcoord) { texcoord[2 * (v0 + i)] = mesh_plane(v, m.block, kMpTc)[i]; texcoord[2 * (v0 + i) + 1] = mesh_plane(v, m.block, kMpTc + 1)[i]; }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-          if (texcolor) texcolor[3 * (v0 + i) + a] = mesh_plane(v, slot, m.state, kMpTcol + a)[i];
-          if (labs) labs[3 * (v0 + i) + a] = mesh_plane(v, slot, m.state, kMpLabs + a)[i];
+          if (texcolor) texcolor[3 * (v0 + i) + a] = mesh_plane(v, m.block, kMpTcol + a)[i];
+          if (labs) labs[3 * (v0 + i) + a] = mesh_plane(v, m.block, kMpLabs + a)[i];
         }
       }
     }
@@ -353,36 +353,43 @@ __global__ __launch_bounds__(256) void k_mesh_scatter(VolumeDev v, const int4* _
   if (slot == kInvalidSlot) return;
   const long long v0 = voff[c], i0 = ioff[c];
   const uint32_t nv = (uint32_t)(voff[c + 1] - v0), nt = (uint32_t)(ioff[c + 1] - i0) / 3u;
-  // a mesh beyond the slot's block goes to the chunk's overflow block (the one it owns, or a new one)
-  __shared__ uint32_t s_ovf;
+  // the mesh goes into the block the chunk owns when it fits there, else into a block handed out now (small pool, or the
+  // large one for a mesh beyond CV / CT)
+  __shared__ uint32_t s_blk;
   if (threadIdx.x == 0) {
-    uint32_t o = v.mesh_rec[slot].state >> kMsOvfShift;
-    if (!o && (nv > v.mesh_cv || nt > v.mesh_ct)) {
+    uint32_t b = v.mesh_rec[slot].block;
+    const bool big = nv > v.mesh_cv || nt > v.mesh_ct;
+    if (nv == 0u && nt == 0u) {
+      // nothing to store
+    } else if (big && !(b & kBlkLarge)) {
       const uint32_t p = atomicAdd(&v.vctl->ovf_next, 1u);
-      o = p < v.ovf_blocks ? p + 1u : 0u;
+      b = p < v.ovf_blocks ? ((p + 1u) | kBlkLarge) : 0x7FFFFFFFu;
+    } else if (!big && b == kBlkNone) {
+      const uint32_t p = atomicAdd(&v.vctl->blk_next, 1u);
+      b = p < v.mesh_blocks ? p + 1u : 0x7FFFFFFFu;
     }
-    s_ovf = o;
+    s_blk = b;
   }
   __syncthreads();
-  const uint32_t mst = s_ovf << kMsOvfShift;
-  if (nv > mesh_cap_v(v, mst) || nt > mesh_cap_t(v, mst)) {
+  const uint32_t mst = s_blk;
+  if (mst == 0x7FFFFFFFu) {
     if (threadIdx.x == 0) atomicOr(&v.vctl->status, kStMeshFull);
     return;
   }
   for (uint32_t i = threadIdx.x; i < nv; i += 256)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      mesh_plane(v, slot, mst, kMpPos + a)[i] = verts[3 * (v0 + i) + a];
-      mesh_plane(v, slot, mst, kMpNrm + a)[i] = normals[3 * (v0 + i) + a];
-      mesh_plane(v, slot, mst, kMpCol + a)[i] = colors[3 * (v0 + i) + a];
+      mesh_plane(v, mst, kMpPos + a)[i] = verts[3 * (v0 + i) + a];
+      mesh_plane(v, mst, kMpNrm + a)[i] = normals[3 * (v0 + i) + a];
+      mesh_plane(v, mst, kMpCol + a)[i] = colors[3 * (v0 + i) + a];
     }
   for (uint32_t i = threadIdx.x; i < nt; i += 256)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) tri_plane(v, slot, mst, a)[i] = (uint16_t)indices[i0 + 3 * (size_t)i + a];
+    for (int a = 0; a < 3; ++a) tri_plane(v, mst, a)[i] = (uint16_t)indices[i0 + 3 * (size_t)i + a];
   if (threadIdx.x == 0) {
     MeshRec* r = &v.mesh_rec[slot];
-    r->nv = nv; r->nt = nt; r->epoch = epoch;
-    r->state = kMsInMap | mst;  // Mesh::Clear: adj = false, simplified = false
+    r->nv = (uint16_t)nv; r->nt = (uint16_t)nt; r->epoch = epoch; r->block = mst;
+    r->state = kMsInMap;  // Mesh::Clear: adj = false, simplified = false
   }
 }
 

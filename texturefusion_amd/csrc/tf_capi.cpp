@@ -141,7 +141,7 @@ static int status_to_error(uint32_t st) {
   if (st & kStCoarseFull) m += " candidate grid full (raise tf_config.max_coarse)";
   if (st & kStMissing) m += " list names a chunk that does not exist";
   if (st & kStHashFull) m += " hash table full";
-  if (st & kStMeshFull) m += " a mesh exceeds the per-chunk mesh block and the overflow pool is exhausted (raise tf_config.mesh_overflow_blocks or mesh_max_vertices / mesh_max_triangles)";
+  if (st & kStMeshFull) m += " the mesh store is exhausted: no block left for a chunk's first mesh (raise tf_config.mesh_blocks) or for a mesh beyond mesh_max_vertices / mesh_max_triangles (raise tf_config.mesh_overflow_blocks or those)";
   if (st & kStAtlasFull) m += " No enough space for texture storage.";  // std::overflow_error text, Atlas.cpp:53
   if (st & kStXchgFull) m += " a rank's ghost band did not fit the boundary exchange block (raise cap_records)";
   set_error(m);
@@ -359,10 +359,10 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   if (cfg) v->cfg = *cfg;
   if (v->cfg.max_chunks <= 0) v->cfg.max_chunks = 1ll << 20;
   v->cfg.max_chunks = (v->cfg.max_chunks + 63) & ~63ll;  // 64 allocation stripes
-  if (v->cfg.max_chunks > (1ll << kPlOvfShift)) {
-    // pool slots travel in 21 bits of the fused flow's patch-list entries (tf_device.h: kPlOvfShift); a larger pool
-    // would have its slots truncated there.  2^21 chunks = 16 GiB of voxels + 42 GiB of mesh store.
-    set_error("tf_config.max_chunks must not exceed 2^21 (2097152): pool slots are 21-bit fields of the patch lists");
+  if (v->cfg.max_chunks > (1ll << 27)) {
+    // (pool slots are 32-bit everywhere; the hash table -- two entries per slot, indexed with 32 bits -- and the per-slot
+    // tables bound the pool well before that.  2^27 chunks would be 1 TiB of voxels: HBM is the limit, not an encoding.)
+    set_error("tf_config.max_chunks must not exceed 2^27");
     delete v;
     return TF_ERR_INVALID;
   }
@@ -421,14 +421,21 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   }
   d.mesh_cv = (uint32_t)v->cfg.mesh_max_vertices;
   d.mesh_ct = (uint32_t)v->cfg.mesh_max_triangles;
-  if ((rc = dev_alloc(v, &d.mesh_v, (size_t)d.max_chunks * kMeshPlanes * d.mesh_cv))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.mesh_t, (size_t)d.max_chunks * 3 * d.mesh_ct))) return fail(rc);
+  {  // the mesh store's small pool: handed out block by block to the chunks that get a mesh (MeshRec::block)
+    int64_t nb = v->cfg.mesh_blocks;
+    if (nb <= 0) nb = std::max<int64_t>(4096, v->cfg.max_chunks / 4);
+    if (nb > v->cfg.max_chunks) nb = v->cfg.max_chunks;
+    v->cfg.mesh_blocks = nb;
+    d.mesh_blocks = (uint32_t)nb;
+  }
+  if ((rc = dev_alloc(v, &d.mesh_v, (size_t)d.mesh_blocks * kMeshPlanes * d.mesh_cv))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.mesh_t, (size_t)d.mesh_blocks * 3 * d.mesh_ct))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_rec, (size_t)d.max_chunks))) return fail(rc);
-  {  // overflow pool for meshes beyond the slot's block (entries of the patch lists carry the block in 11 bits)
+  {  // the large pool, for meshes beyond CV / CT
     int64_t nb = v->cfg.mesh_overflow_blocks;
     if (nb == 0) nb = std::max<int64_t>(64, v->cfg.max_chunks / 256);
-    if (nb < 0 || d.max_chunks > (1u << kPlOvfShift)) nb = 0;
-    if (nb > 2047) nb = 2047;
+    if (nb < 0) nb = 0;
+    if (nb > 65535) nb = 65535;
     d.ovf_blocks = (uint32_t)nb;
     if (nb) {
       if ((rc = dev_alloc(v, &d.ovf_v, (size_t)nb * kMeshPlanes * kOvfCV))) return fail(rc);

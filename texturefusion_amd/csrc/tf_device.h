@@ -85,11 +85,11 @@ constexpr int kSlotStripes = 64;
 struct VolCtl {
   uint32_t status;    // sticky error bits
   uint32_t n_tmp;     // scratch counter of the on-demand list/pack kernels
-  uint32_t ovf_next;  // mesh overflow pool: blocks handed out (bump allocation, reset with the volume)
+  uint32_t ovf_next;  // mesh store, large pool: blocks handed out (bump allocation, reset with the volume)
   uint32_t n_tmp2;    // second scratch counter (the "up" block of the two-band boundary pack)
   uint32_t xchg_sent, xchg_recv;  // ghost records written into / stored from exchange blocks since create (tf_comm_stats_ex)
   uint32_t zero_word;  // always 0: an empty list's count (the interior mesh pass of an overlapped exchange ignores the flat list)
-  uint32_t xchg_pad;
+  uint32_t blk_next;   // mesh store, small pool: blocks handed out (bump allocation, reset with the volume)
   // Pool slots are handed out from 64 independent stripes (stripe s owns slots
   // [s*max_chunks/64, (s+1)*max_chunks/64)) so that the thousands of chunk creations of a
   // first-touch frame do not serialise on one atomic word.
@@ -114,9 +114,9 @@ struct SelBuf {
 };
 
 // ---- device-resident meshes (ChunkManager::allMeshes) and their patches (Mesh::m_patch) ----------
-// One fixed block per pool slot, planar (lane = vertex / triangle, every plane row is a coalesced
-// segment):  mesh_v [slot][17][CV] f32 -- Mesh::vertices x y z | normals x y z | colors r g b |
-// Patch::texcoord u v | texcolor r g b | labs r g b;  mesh_t [slot][3][CT] u16 -- Mesh::indices as
+// Blocks of the mesh store, planar (lane = vertex / triangle, every plane row is a coalesced
+// segment):  mesh_v [block][17][CV] f32 -- Mesh::vertices x y z | normals x y z | colors r g b |
+// Patch::texcoord u v | texcolor r g b | labs r g b;  mesh_t [block][3][CT] u16 -- Mesh::indices as
 // triangle corner planes (a mesh has at most 3 * 729 vertices).  CV / CT come from tf_config
 // (mesh_max_vertices / mesh_max_triangles); the theoretical maximum is 2187 / 2560.
 constexpr int kMeshPlanes = 17;
@@ -124,23 +124,25 @@ constexpr int kMpPos = 0, kMpNrm = 3, kMpCol = 6, kMpTc = 9, kMpTcol = 11, kMpLa
 constexpr unsigned long long kNoTexloc = ~0ull;
 constexpr uint32_t kMsInMap = 1u;       // the chunk has an entry in allMeshes (ChunkManager::HasMesh)
 constexpr uint32_t kMsSimplified = 2u;  // Mesh::simplified
-constexpr uint32_t kMsOverflow = 4u;    // did not fit CV / CT and no overflow block was left: stored empty, kStMeshFull raised
+constexpr uint32_t kMsOverflow = 4u;    // no block of the mesh store was left for it: stored empty, kStMeshFull raised
 constexpr int kMsAdjShift = 8;          // bits 8..13 = Mesh::adj[0..5]
-// A mesh that does not fit its pool slot's block (CV vertices / CT triangles) lives in a block of the shared overflow
-// pool, sized for the largest mesh a chunk can have (3 x 9^3 = 2187 vertices, 512 x 5 = 2560 triangles,
-// Structure/ChunkManager.cpp:856-918 emits whatever a chunk produces).  Bits 16..31 of MeshRec::state = block index + 1;
-// a chunk keeps the block it was given (its later, smaller meshes stay there too).
-constexpr int kMsOvfShift = 16;
-constexpr uint32_t kMsOvfMask = 0xFFFF0000u;
+// The mesh store is allocated ON DEMAND: a pool slot owns no mesh storage until its chunk first has a mesh with vertices.
+// Then it is given a block (one bump allocation per chunk, ever; MeshRec::block = index + 1, 0 = none) of the SMALL
+// pool -- CV vertices / CT triangles (tf_config.mesh_max_*), 20.4 KiB at the defaults -- or, for a mesh that does not fit
+// that, of the LARGE pool, sized for the largest mesh a chunk can have (3 x 9^3 = 2187 vertices, 512 x 5 = 2560 triangles,
+// Structure/ChunkManager.cpp:856-918 emits whatever a chunk produces): bit 31 of MeshRec::block.  A chunk keeps the block
+// it was given (its later, smaller meshes stay there too; a chunk that outgrows a small block moves to a large one).
+constexpr uint32_t kBlkLarge = 0x80000000u;
+constexpr uint32_t kBlkNone = 0u;
 constexpr int kOvfCV = 2240, kOvfCT = 2560;
-constexpr int kPlOvfShift = 21;  // patch-list entries: w = pool slot | overflow block << 21 (pools of up to 2^21 slots, 2047 blocks)
 constexpr uint32_t kPfHasPatch = 1u;    // Atlas::HasPatch
 constexpr uint32_t kPfCaution = 2u;     // CalculateTexCoords returned -1
 constexpr uint32_t kPfWrong = 4u;       // Patch::wrong_mapping
 constexpr uint32_t kPfHasImage = 8u;    // Patch::has_image
 constexpr uint32_t kPfAdjusted = 16u;   // Patch::has_adjusted
 struct __attribute__((aligned(16))) MeshRec {  // 64 B per pool slot
-  uint32_t nv, nt;
+  uint16_t nv, nt;            // (a mesh has at most 2187 vertices / 2560 triangles)
+  uint32_t block;             // the mesh's storage: block index + 1 | kBlkLarge, kBlkNone = no storage yet
   uint32_t state;
   uint32_t epoch;             // the meshing pass that wrote the block (0 = never)
   unsigned long long texloc;  // Patch::texloc (linear texel index of the atlas slot), kNoTexloc = no slot yet
@@ -216,7 +218,8 @@ struct VolumeDev {
   uint16_t* mesh_t;
   MeshRec* mesh_rec;
   uint32_t mesh_cv, mesh_ct;
-  float* ovf_v;         // [ovf_blocks][17][kOvfCV] overflow pool, same planar layout as mesh_v
+  uint32_t mesh_blocks;  // blocks of the small pool (mesh_v / mesh_t); VolCtl::blk_next = blocks handed out
+  float* ovf_v;         // [ovf_blocks][17][kOvfCV] large pool, same planar layout as mesh_v
   uint16_t* ovf_t;      // [ovf_blocks][3][kOvfCT]
   uint16_t* ovf_vlist;  // [ovf_blocks][kOvfCV] mesher scratch of a block (its used edge slots; the slot-sized list sits in LDS)
   uint32_t ovf_blocks;  // blocks of the pool; VolCtl::ovf_next = blocks handed out
@@ -239,8 +242,8 @@ struct VolumeDev {
   KfDev* kf_tab;      // [max_keyframes]
   int4* work_ids;       // [max_chunks] work list (dirty chunks of a frame / chunksToUpdate): id, w = keyframe-table entry
   uint32_t* work_slot;  // [max_chunks] pool slot of the entry, kInvalidSlot = not processed
-  int4* patch_list;     // [2][kMeshShards][mesh_shard_rows] fused flow: {id, w = pool slot} of the frame's dirty chunks that own a
-                        // mesh, appended by the mesher (and by its filter for meshes that just became empty), shard by shard
+  int4* patch_list;     // [2][kMeshShards][mesh_shard_rows] fused flow: {packed id lo, packed id hi, pool slot, mesh block} of the frame's
+                        // dirty chunks that own a mesh, appended by the mesher (and by its filter for meshes that just became empty)
   uint32_t* patch_cnt;  // [2][kMeshShards][16] entries per shard (one counter per 64-B line), by frame parity
   unsigned long long* cand;  // [max_chunks] packed ids of the work entries that need an atlas slot
   // dirty set of a textured frame as K-A builds it (each updated chunk's wave claims the chunk and its six face
@@ -256,17 +259,17 @@ struct VolumeDev {
   uint32_t obs_mask;
   SelBuf sel;  // the selection set the launch works on
 };
-// planes of the mesh of pool slot `slot` whose record says `state` (the slot's own block or its overflow block)
-__host__ __device__ inline float* mesh_plane(const VolumeDev& v, uint32_t slot, uint32_t state, int plane) {
-  const uint32_t o = state >> kMsOvfShift;
-  return o ? v.ovf_v + ((size_t)(o - 1u) * kMeshPlanes + plane) * kOvfCV : v.mesh_v + ((size_t)slot * kMeshPlanes + plane) * v.mesh_cv;
+// planes of the mesh stored in block `blk` (MeshRec::block; only dereferenced for a mesh with vertices, i.e. blk != kBlkNone)
+__host__ __device__ inline float* mesh_plane(const VolumeDev& v, uint32_t blk, int plane) {
+  const size_t i = (size_t)((blk & ~kBlkLarge) - 1u);
+  return (blk & kBlkLarge) ? v.ovf_v + (i * kMeshPlanes + plane) * kOvfCV : v.mesh_v + (i * kMeshPlanes + plane) * v.mesh_cv;
 }
-__host__ __device__ inline uint16_t* tri_plane(const VolumeDev& v, uint32_t slot, uint32_t state, int corner) {
-  const uint32_t o = state >> kMsOvfShift;
-  return o ? v.ovf_t + ((size_t)(o - 1u) * 3 + corner) * kOvfCT : v.mesh_t + ((size_t)slot * 3 + corner) * v.mesh_ct;
+__host__ __device__ inline uint16_t* tri_plane(const VolumeDev& v, uint32_t blk, int corner) {
+  const size_t i = (size_t)((blk & ~kBlkLarge) - 1u);
+  return (blk & kBlkLarge) ? v.ovf_t + (i * 3 + corner) * kOvfCT : v.mesh_t + (i * 3 + corner) * v.mesh_ct;
 }
-__host__ __device__ inline uint32_t mesh_cap_v(const VolumeDev& v, uint32_t state) { return (state >> kMsOvfShift) ? (uint32_t)kOvfCV : v.mesh_cv; }
-__host__ __device__ inline uint32_t mesh_cap_t(const VolumeDev& v, uint32_t state) { return (state >> kMsOvfShift) ? (uint32_t)kOvfCT : v.mesh_ct; }
+__host__ __device__ inline uint32_t mesh_cap_v(const VolumeDev& v, uint32_t blk) { return blk == kBlkNone ? 0u : ((blk & kBlkLarge) ? (uint32_t)kOvfCV : v.mesh_cv); }
+__host__ __device__ inline uint32_t mesh_cap_t(const VolumeDev& v, uint32_t blk) { return blk == kBlkNone ? 0u : ((blk & kBlkLarge) ? (uint32_t)kOvfCT : v.mesh_ct); }
 
 struct FrameImages {
   const float* depth;

@@ -117,7 +117,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
     for (int k = 0; k < 4; ++k) ctl->band_cnt[k] = 0u;
     if (vctl) {
       vctl->status = 0; vctl->n_tmp = 0; vctl->n_tmp2 = 0; vctl->ovf_next = 0; vctl->xchg_sent = 0; vctl->xchg_recv = 0;
-      vctl->zero_word = 0; vctl->xchg_pad = 0;
+      vctl->zero_word = 0; vctl->blk_next = 0;
       for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
     }
   }
@@ -1637,7 +1637,7 @@ __global__ __launch_bounds__(256) void k_finalize(VolumeDev v, uint32_t epoch) {
       {
         v.summ[ds] = 0u;
         MeshRec* r = &v.mesh_rec[ds];
-        if (r->state & kMsInMap) { r->state &= kMsOvfMask; r->nv = 0; r->nt = 0; }
+        if (r->state & kMsInMap) { r->state = 0u; r->nv = 0; r->nt = 0; }  // (the chunk's block of the mesh store stays its own)
       }
     }
     __syncthreads();

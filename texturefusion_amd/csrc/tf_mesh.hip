@@ -176,7 +176,8 @@ struct MeshSh {
   uint32_t nv, nt, adj, any;
   uint32_t ncell;             // cells the surface passes through
   uint16_t clist[512];        // ... in no particular order (what is computed per cell is stored per cell)
-  uint32_t ovf;               // overflow block of the chunk (index + 1, 0 = none): owned before this pass or handed out in it
+  uint32_t ovf;               // the chunk's block of the mesh store (MeshRec::block): owned before this pass or handed out in it
+  uint32_t rblock;            // MeshRec::block as it was before this pass
   uint32_t rstate;            // MeshRec::state as it was before this pass
   unsigned long long rtexloc; // MeshRec::texloc
 };
@@ -212,12 +213,14 @@ __device__ __forceinline__ int owner_cell(int m, int q) {
 // fused flow: a dirty chunk that owns a mesh (ChunkManager::HasMesh) goes to the patch list of its shard; one
 // without an atlas slot is also a slot candidate (Atlas::AddPatch will be called for it, in ascending id order).
 // Called by ONE thread per chunk.
-// (w = pool slot | overflow block << 21: the patch stage reads the mesh planes without waiting for the record)
+// (entry = {packed id lo, packed id hi, pool slot, mesh block}: the patch stage reads the mesh planes without waiting for
+// the record; ids are 21 bits per axis everywhere -- the hash keys are the same packing)
 __device__ __forceinline__ void patch_list_append(const VolumeDev& v, int ppar, uint32_t shard, const int4 id,
-                                                  uint32_t slot, unsigned long long texloc, uint32_t ovf) {
+                                                  uint32_t slot, unsigned long long texloc, uint32_t blk) {
   const uint32_t rows = mesh_shard_rows_d(v.max_chunks);
   const uint32_t p = atomicAdd(&v.patch_cnt[((ppar & 1) * kMeshShards + shard) * 16], 1u);
-  if (p < rows) v.patch_list[((size_t)(ppar & 1) * kMeshShards + shard) * rows + p] = make_int4(id.x, id.y, id.z, (int)(slot | (ovf << kPlOvfShift)));
+  const unsigned long long key = pack_id(id.x, id.y, id.z);
+  if (p < rows) v.patch_list[((size_t)(ppar & 1) * kMeshShards + shard) * rows + p] = make_int4((int)(uint32_t)key, (int)(uint32_t)(key >> 32), (int)slot, (int)blk);
   else atomicOr(&v.vctl->status, kStMeshFull);
   if (texloc == kNoTexloc) {
     const uint32_t c = atomicAdd(&v.actl->set[ppar & 1].n_cand, 1u);
@@ -232,8 +235,8 @@ __device__ __forceinline__ void filter_reset_record(const VolumeDev& v, uint32_t
   const uint32_t inmap = was & kMsInMap;
   // fused flow (ppar >= 0): CompressMeshes follows in the same frame and its SimplifyByClustering marks EVERY dirty
   // mesh of allMeshes simplified, with or without vertices (Chisel.cpp:116-126, Mesh.cpp:39-48)
-  rec->nv = 0; rec->nt = 0; rec->state = inmap | (was & kMsOvfMask) | ((ppar >= 0 && inmap) ? kMsSimplified : 0u); rec->epoch = epoch;
-  if (ppar >= 0 && inmap) patch_list_append(v, ppar, own & (kMeshShards - 1u), id, own, rec->texloc, was >> kMsOvfShift);  // an emptied mesh keeps its patch
+  rec->nv = 0; rec->nt = 0; rec->state = inmap | ((ppar >= 0 && inmap) ? kMsSimplified : 0u); rec->epoch = epoch;
+  if (ppar >= 0 && inmap) patch_list_append(v, ppar, own & (kMeshShards - 1u), id, own, rec->texloc, rec->block);  // an emptied mesh keeps its patch
 }
 
 // The same, postponed to the mesher launch (VolumeDev::reset_list): one thread
@@ -634,7 +637,7 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
     if (dbg == 9) mesh_stamp(v, r, 1);
     if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; sh.ncell = 0; }
     // the record's previous state travels with the first batch of loads, so that the tail of the chunk is stores only
-    if (t == NT - 64) { sh.rstate = rec->state; sh.rtexloc = rec->texloc; }
+    if (t == NT - 64) { sh.rstate = rec->state; sh.rblock = rec->block; sh.rtexloc = rec->texloc; }
     if (dbg == 1) continue;  // triage: filter only
     // ---- stage the 11^3 voxels of the neighbourhood (own ones from registers)
 #pragma unroll
@@ -806,18 +809,27 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
         if (k < w) before += sh.wsum[k];
         total += sh.wsum[k];
       }
-      // Does the mesh fit the pool slot's block?  If not it goes to a block of the overflow pool: the one the chunk
-      // already owns, else the next free one (one bump allocation per chunk, ever).  Block-uniform.
-      if (t == 0) sh.ovf = sh.rstate >> kMsOvfShift;
-      if (((total & 0xFFFFu) > v.mesh_cv || (total >> 16) > v.mesh_ct) && !(sh.rstate >> kMsOvfShift)) {
-        if (t == 0) {
+      // Where does the mesh go?  Into the block the chunk already owns when it fits there; else into a block handed out
+      // now -- of the small pool (CV / CT), or of the large one for a mesh beyond that (one bump allocation per chunk and
+      // pool, ever; a mesh without vertices needs none).  kBlkFail: the pool is exhausted.  Block-uniform.
+      constexpr uint32_t kBlkFail = 0x7FFFFFFFu;
+      if (t == 0) {
+        uint32_t b = sh.rblock;
+        const bool big = (total & 0xFFFFu) > v.mesh_cv || (total >> 16) > v.mesh_ct;
+        if ((total & 0xFFFFu) == 0u && (total >> 16) == 0u) {
+          // nothing to store
+        } else if (big && !(b & kBlkLarge)) {
           const uint32_t p = atomicAdd(&v.vctl->ovf_next, 1u);
-          sh.ovf = p < v.ovf_blocks ? p + 1u : 0u;
+          b = p < v.ovf_blocks ? ((p + 1u) | kBlkLarge) : kBlkFail;
+        } else if (!big && b == kBlkNone) {
+          const uint32_t p = atomicAdd(&v.vctl->blk_next, 1u);
+          b = p < v.mesh_blocks ? p + 1u : kBlkFail;
         }
+        sh.ovf = b;
       }
       __syncthreads();
       const uint32_t ovf_blk = sh.ovf;
-      uint16_t* const gvl = ovf_blk ? v.ovf_vlist + (size_t)(ovf_blk - 1u) * kOvfCV : nullptr;
+      uint16_t* const gvl = (ovf_blk != kBlkFail && (ovf_blk & kBlkLarge)) ? v.ovf_vlist + (size_t)((ovf_blk & ~kBlkLarge) - 1u) * kOvfCV : nullptr;
       const uint32_t excl = before + inc - pk;
       uint32_t r = excl & 0xFFFFu;
       sh.rbase[t] = (uint16_t)r;
@@ -825,7 +837,7 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
       for (unsigned long long u = usedm; u; u &= u - 1ull) {
         const int m = first + (int)__builtin_ctzll(u);
         if (gvl) { if (r < (uint32_t)kOvfCV) gvl[r] = (uint16_t)m; }
-        else if (r < v.mesh_cv) vlist[r] = (uint16_t)m;  // (a mesh with more is rejected below)
+        else if (r < v.mesh_cv) vlist[r] = (uint16_t)m;  // (a mesh with more went to the large pool, or is rejected below)
         ++r;
       }
       uint32_t t0 = excl >> 16;
@@ -839,18 +851,17 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
     __syncthreads();
     const uint32_t nv = sh.nv, nt = sh.nt;
     const uint32_t ovf = sh.ovf;
-    const uint32_t st_ovf = ovf << kMsOvfShift;  // (selects the block in mesh_plane / tri_plane)
-    if (nv > mesh_cap_v(v, st_ovf) || nt > mesh_cap_t(v, st_ovf)) {  // no block left in the overflow pool: reported, stored empty
+    if (ovf == 0x7FFFFFFFu) {  // no block left in the pool the mesh needs: reported, stored empty (the chunk keeps what it had)
       if (t == 0) {
         atomicOr(&v.vctl->status, kStMeshFull);
         const uint32_t was = sh.rstate & kMsInMap;
         rec->nv = 0; rec->nt = 0; rec->state = was | kMsOverflow; rec->epoch = epoch;
-        if (rearm >= 0 && was) patch_list_append(v, rearm ^ 1, shard, id, own, sh.rtexloc, 0u);
+        if (rearm >= 0 && was) patch_list_append(v, rearm ^ 1, shard, id, own, sh.rtexloc, sh.rblock);
       }
       __syncthreads();
       continue;
     }
-    const uint16_t* const gvlist = ovf ? v.ovf_vlist + (size_t)(ovf - 1u) * kOvfCV : nullptr;
+    const uint16_t* const gvlist = (ovf & kBlkLarge) ? v.ovf_vlist + (size_t)((ovf & ~kBlkLarge) - 1u) * kOvfCV : nullptr;
 
     if (dbg == 4) continue;  // triage: + ranking
     if (dbg == 9) mesh_stamp(v, r, 6);
@@ -899,9 +910,9 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
       }
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        mesh_plane(v, own, st_ovf, kMpPos + a)[i] = pv[a];
-        mesh_plane(v, own, st_ovf, kMpNrm + a)[i] = g[a];
-        mesh_plane(v, own, st_ovf, kMpCol + a)[i] = col[a];
+        mesh_plane(v, ovf, kMpPos + a)[i] = pv[a];
+        mesh_plane(v, ovf, kMpNrm + a)[i] = g[a];
+        mesh_plane(v, ovf, kMpCol + a)[i] = col[a];
         // Mesh::GetIndice (Mesh.cpp:52-83) with grid_resolution = resolution * (8 / GRID_EACH_DIM)
         const int gp = (int)floorf((pv[a] - org[a]) / (res * 1.0f));
         if (gp >= 8) adj |= 1u << (2 * a + 1);
@@ -931,17 +942,17 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
           const int tt = m / kEptT, j = m - tt * kEptT;
           return (uint16_t)(sh.rbase[tt] + (uint32_t)__popcll(sh.rmask[tt] & ((1ull << j) - 1ull)));
         };
-        tri_plane(v, own, st_ovf, 0)[o] = ref_of(edge_slot(x, y, z, s2));
-        tri_plane(v, own, st_ovf, 1)[o] = ref_of(edge_slot(x, y, z, s1));
-        tri_plane(v, own, st_ovf, 2)[o] = ref_of(edge_slot(x, y, z, s0));
+        tri_plane(v, ovf, 0)[o] = ref_of(edge_slot(x, y, z, s2));
+        tri_plane(v, ovf, 1)[o] = ref_of(edge_slot(x, y, z, s1));
+        tri_plane(v, ovf, 2)[o] = ref_of(edge_slot(x, y, z, s0));
         ++o;
       }
     }
     __syncthreads();
     if (t == 0) {
       // its own adjacency flags are final now (SimplifyByClustering runs once per generation, Chisel.cpp:124)
-      rec->nv = nv; rec->nt = nt; rec->epoch = epoch;
-      rec->state = inmap | st_ovf | (sh.adj << kMsAdjShift) | (inmap ? simplified : 0u);  // (simplified: every mesh of allMeshes, Chisel.cpp:116-126)
+      rec->nv = (uint16_t)nv; rec->nt = (uint16_t)nt; rec->epoch = epoch; rec->block = ovf;
+      rec->state = inmap | (sh.adj << kMsAdjShift) | (inmap ? simplified : 0u);  // (simplified: every mesh of allMeshes, Chisel.cpp:116-126)
     }
     __syncthreads();
     if (dbg == 9) mesh_stamp(v, r, 8);
@@ -1203,14 +1214,14 @@ __global__ __launch_bounds__(256) void k_mesh_gather(VolumeDev v, const int4* __
   for (uint32_t i = threadIdx.x; i < nv; i += 256)
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-      if (verts) verts[3 * (v0 + i) + a] = mesh_plane(v, slot, m.state, kMpPos + a)[i];
-      if (normals) normals[3 * (v0 + i) + a] = mesh_plane(v, slot, m.state, kMpNrm + a)[i];
-      if (colors) colors[3 * (v0 + i) + a] = mesh_plane(v, slot, m.state, kMpCol + a)[i];
+      if (verts) verts[3 * (v0 + i) + a] = mesh_plane(v, m.block, kMpPos + a)[i];
+      if (normals) normals[3 * (v0 + i) + a] = mesh_plane(v, m.block, kMpNrm + a)[i];
+      if (colors) colors[3 * (v0 + i) + a] = mesh_plane(v, m.block, kMpCol + a)[i];
     }
   if (indices)
     for (uint32_t i = threadIdx.x; i < nt; i += 256)
 #pragma unroll
-      for (int a = 0; a < 3; ++a) indices[i0 + 3 * i + a] = tri_plane(v, slot, m.state, a)[i];
+      for (int a = 0; a < 3; ++a) indices[i0 + 3 * i + a] = tri_plane(v, m.block, a)[i];
 }
 
 // ids (host, int32[3n]) -> device int4 list in d_tmp at byte offset `at`

@@ -220,15 +220,23 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     if (overflow) atomicOr(&v.vctl->status, kStAtlasFull);
   }
   for (uint32_t pe = FUSED ? wave / kMeshShards : wave; pe < n; pe += FUSED ? nwaves / kMeshShards : nwaves) {
-    // fused flow: {id, pool slot} straight from the list (one dependent load less per patch)
-    const int4 id = FUSED ? plist[pe] : v.work_ids[pe];
-    // fused list entries carry the mesh's overflow block next to the pool slot (w = slot | block << 21), so that the
-    // vertex loads below need not wait for the record; the call-by-call flow reads it from the record
-    const uint32_t slot = FUSED ? ((uint32_t)id.w & ((1u << kPlOvfShift) - 1u)) : v.work_slot[pe];
+    // fused flow: {packed id, pool slot, mesh block} straight from the list (one dependent load less per patch: the vertex
+    // loads below need not wait for the record); the call-by-call flow reads the block from the record
+    int4 id;
+    uint32_t slot, lblk = kBlkNone;
+    if (FUSED) {
+      const int4 e = plist[pe];
+      id = unpack_id(((unsigned long long)(uint32_t)e.y << 32) | (uint32_t)e.x);
+      slot = (uint32_t)e.z;
+      lblk = (uint32_t)e.w;
+    } else {
+      id = v.work_ids[pe];
+      slot = v.work_slot[pe];
+    }
     if (slot == kInvalidSlot) continue;
     MeshRec* rec = &v.mesh_rec[slot];
     MeshRec R = *rec;  // one 64-B record: counts, flags, slot position, box
-    const uint32_t mst = FUSED ? (((uint32_t)id.w >> kPlOvfShift) << kMsOvfShift) : (R.state & kMsOvfMask);
+    const uint32_t mst = FUSED ? lblk : R.block;  // (the block of the mesh store that holds the mesh)
     stampw(1);
     if (FUSED && lane < 6) {
       // Chisel::CompressMeshes' neighbour exchange (Chisel.cpp:127-145) for this chunk: flag k of the mesh and flag
@@ -281,8 +289,8 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     if (PROJECT) {
       float minX = Wf, maxX = 0.0f, minY = Hf, maxY = 0.0f;  // Patch.cpp:46-49
       uint32_t dcmp = 0, ccmp = 0, ncau = 0;
-      float* tu = mesh_plane(v, slot, mst, kMpTc);
-      float* tv = mesh_plane(v, slot, mst, kMpTc + 1);
+      float* tu = mesh_plane(v, mst, kMpTc);
+      float* tv = mesh_plane(v, mst, kMpTc + 1);
       float keepX[kVB], keepY[kVB];  // texcoords of a one-sweep patch stay in registers until the box is known
       const bool one_sweep = nv <= 64u * kVB;
       // the first sweep does not wait for the record: its loads are clamped to the block, not to nv, and go out
@@ -295,10 +303,10 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
         for (int j = 0; j < kVB; ++j) {
           const uint32_t i = base + 64u * j + lane;
           const uint32_t ii = i < lim ? i : 0u;
-          px[j] = mesh_plane(v, slot, mst, kMpPos)[ii]; py[j] = mesh_plane(v, slot, mst, kMpPos + 1)[ii];
-          pz[j] = mesh_plane(v, slot, mst, kMpPos + 2)[ii];
-          m0[j] = mesh_plane(v, slot, mst, kMpCol)[ii]; m1[j] = mesh_plane(v, slot, mst, kMpCol + 1)[ii];
-          m2[j] = mesh_plane(v, slot, mst, kMpCol + 2)[ii];
+          px[j] = mesh_plane(v, mst, kMpPos)[ii]; py[j] = mesh_plane(v, mst, kMpPos + 1)[ii];
+          pz[j] = mesh_plane(v, mst, kMpPos + 2)[ii];
+          m0[j] = mesh_plane(v, mst, kMpCol)[ii]; m1[j] = mesh_plane(v, mst, kMpCol + 1)[ii];
+          m2[j] = mesh_plane(v, mst, kMpCol + 2)[ii];
         }
         stampw(3);
         // ---- projection (:52-66), then every image gather of the sweep in flight at once
@@ -355,7 +363,7 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
               const float c1 = (float)((q1[j] >> (8 * k)) & 0xFFu), c2 = (float)((q2[j] >> (8 * k)) & 0xFFu),
                           c3 = (float)((q3[j] >> (8 * k)) & 0xFFu);
               tc[k] = blend(tp[j], c1, c2, c3) / 255.0f;
-              mesh_plane(v, slot, mst, kMpTcol + k)[i] = tc[k];
+              mesh_plane(v, mst, kMpTcol + k)[i] = tc[k];
             }
             const float dpt = blend(tp[j], d1[j], d2[j], d3[j]);
             const float e0 = tc[0] - m0[j], e1 = tc[1] - m1[j], e2 = tc[2] - m2[j];
