@@ -84,6 +84,7 @@ def parse():
     ap.add_argument("--staged-host-frames", action="store_true",
                     help="the timed host frames go through the library's pinned staging slots (a CPU copy per frame by a pool of "
                          "helper threads) instead of straight out of the caller's arrays, registered once with tf_host_register")
+    ap.add_argument("--max-chunks-log2", type=int, default=0, help="chunk pool of 2^n slots (default: 19 room / 21 hall)")
     ap.add_argument("--no-independent", action="store_true",
                     help="N>1: skip the independent-streams (one whole volume per GPU) and sharded keyframe-unit figures")
     ap.add_argument("--force-exchange", action="store_true",
@@ -334,7 +335,8 @@ def main():
 
     s_main = torch.cuda.Stream(device=dev) if multi else None
     big = args.scene == "big"
-    vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+    pool = (1 << args.max_chunks_log2) if args.max_chunks_log2 > 0 else ((1 << 21) if big else (1 << 19))
+    vol = capi.Volume(res, cam, max_chunks=pool, max_list=(1 << 20) if big else (1 << 18),
                       max_coarse=1 << 22 if big else 1 << 20, device=local_rank,
                       stream=s_main.cuda_stream if multi else None)
     # The caller's frame buffers are registered once, as a caller with a fixed set of image buffers does at start-up; host
@@ -686,6 +688,35 @@ def main():
         except Exception as e:  # (a side figure: never fail the bench line for it)
             other_host = {"error": repr(e)[:300]}
 
+    # ---- the same positions out of the registered arrays WITHOUT waiting for every upload (tf_host_frame_set_async: the
+    # caller keeps the "do not touch a buffer before the fence" contract itself -- here: 200 distinct frames, one fence at the end)
+    async_host = None
+    if use_host and not multi and host_registered:
+        try:
+            nxt = pos + ((p0 - Wm - pos) % ORBIT)
+            if nxt > pos:
+                run(pos, nxt - pos)
+            pos = nxt
+            fresh_period()
+            vol.host_frame_set_async(True)
+            run_host(pos, Wm)
+            vol.host_frame_fence()
+            barrier()
+            t1 = time.perf_counter()
+            run_host(pos + Wm, K)
+            vol.host_frame_fence()
+            barrier()
+            dt_a = time.perf_counter() - t1
+            vol.sync()
+            vol.host_frame_set_async(False)
+            pos += Wm + K
+            async_host = {"value": K / dt_a, "unit": "frames/s", "ms_per_step": 1e3 * dt_a / K,
+                          "note": "the same %d orbit positions out of the registered arrays with tf_host_frame_set_async(1): a call returns "
+                                  "when its upload is QUEUED, one tf_host_frame_fence at the end (a caller with a ring of frame buffers); "
+                                  "the upload of frame f overlaps the call for f + 1" % K}
+        except Exception as e:  # (a side figure: never fail the bench line for it)
+            async_host = {"error": repr(e)[:300]}
+
     # ---- the same positions as HOST frames with the colour image as the caller holds it (Frame::rgb, 3 B per pixel) ----
     rgb_host = None
     if use_host and not multi:
@@ -786,6 +817,8 @@ def main():
         out["staged_host_frames" if host_registered else "registered_host_frames"] = other_host
     if rgb_host is not None:
         out["rgb_host_frames"] = rgb_host
+    if async_host is not None:
+        out["registered_async_host_frames"] = async_host
     if use_host and host_phases:
         host_phases["host_buffers"] = ("registered with tf_host_register: uploaded in place, the call returns when the upload is through "
                                        "(wait_for_upload_us)" if host_registered else "copied into the library's pinned staging slots (staging_copy_us)")
@@ -1126,6 +1159,7 @@ def child_passes(args):
     base_cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--child", "--steps", str(K), "--warmup", str(Wm),
                 "--mode", args.mode, "--scene", args.scene, "--res", repr(args.res), "--unique-frames", str(args.unique_frames)]
     base_cmd += (["--hires"] if args.hires else []) + (["--no-preroll"] if args.no_preroll else [])
+    base_cmd += ["--max-chunks-log2", str(args.max_chunks_log2)] if args.max_chunks_log2 > 0 else []
     base_cmd += ["--resident-headline"] if args.resident_headline else []
     base_cmd += ["--staged-host-frames"] if args.staged_host_frames else []
     tmp = tempfile.mkdtemp(prefix="tf_prof_", dir="/tmp")

@@ -325,6 +325,14 @@ TF_API int tf_host_register(tf_volume* v, const void* p, int64_t bytes);
 TF_API int tf_host_unregister(tf_volume* v, const void* p);
 TF_API int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_slots);
 TF_API int tf_host_frame_set_deferral(tf_volume* v, int on);
+/* A caller with a RING of registered frame buffers need not wait for every upload: tf_host_frame_set_async(v, 1) lets a call
+ * out of registered buffers return as soon as its upload is queued (the reference's contract -- "the buffer is mine again
+ * when the call returns", MobileFusion.cpp:249 -- is then the caller's to keep); tf_host_frame_fence(v) returns when every
+ * upload queued so far is through, i.e. every buffer handed over so far may be written again.  The upload of frame f then
+ * overlaps the call for f + 1: a TSDF-only stream runs at the link's rate (2.46 MB per 640x480 frame at 46 GB/s = 53 us,
+ * tools/h2d_probe.py) instead of upload + call time.  Default off. */
+TF_API int tf_host_frame_set_async(tf_volume* v, int on);
+TF_API int tf_host_frame_fence(tf_volume* v);
 /* Where the host side of tf_integrate_frame_host(_rgb) spends its time, summed since create / the last reset:
  * out[0] = calls that put a frame's launches on the stream, out[1..5] = microseconds spent waiting for the device to free
  * a staging slot (back-pressure: the device is the bound), waiting for the slot's previous upload, in the staging copy, in

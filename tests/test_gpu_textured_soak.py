@@ -36,6 +36,24 @@ def _run(cam, res, frames, host_frames=False, max_chunks=1 << 17, stride=1):
             d[...] = 123.0; c[...] = 200
         gv.sync()
         gv.host_unregister(c); gv.host_unregister(d)
+    elif host_frames == "registered_async":  # a ring of four registered buffer pairs, calls that do not wait for their upload,
+        ring = [(np.empty_like(frames[0][0]), np.empty_like(frames[0][1])) for _ in range(4)]  # a fence before a pair is refilled
+        for d, c in ring:
+            gv.host_register(d); gv.host_register(c)
+        gv.host_frame_set_async(True)
+        for k, f in enumerate(frames):
+            d, c = ring[k % 4]
+            if k >= 4:
+                gv.host_frame_fence()   # every upload queued so far is through: the pair may be written again
+            d[...] = f[0]; c[...] = f[1]
+            gv.integrate_frame_host(d, c, f[3].reshape(12), pinv[k], 10 + k)
+        gv.host_frame_fence()
+        for d, c in ring:
+            d[...] = 7.0; c[...] = 9
+        gv.sync()
+        gv.host_frame_set_async(False)
+        for d, c in ring:
+            gv.host_unregister(c); gv.host_unregister(d)
     elif host_frames:
         if host_frames == "no_deferral":  # integrate in the call that brings the frame (tf_host_frame_set_deferral)
             gv.host_frame_set_deferral(False)
@@ -101,6 +119,14 @@ def test_host_frames_entry_point(gpu_required):
     cam = synth.Camera()
     frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(10)]
     assert _run(cam, np.float32(0.005), frames, host_frames=True, stride=3) > 400
+
+
+def test_host_frames_async_with_fence(gpu_required):
+    """tf_host_frame_set_async + tf_host_frame_fence: calls out of a ring of registered buffers return before their upload
+    is through, the caller fences before it refills a buffer; results as with waiting calls"""
+    cam = synth.Camera()
+    frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(10)]
+    assert _run(cam, np.float32(0.005), frames, host_frames="registered_async", stride=3) > 400
 
 
 def test_host_frames_without_deferral_per_handle(gpu_required):

@@ -41,7 +41,7 @@ SYMBOLS = (
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
     "tf_patches_download", "tf_atlas_download_rows", "tf_stream_frames_device",
     "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host", "tf_integrate_frame_host_rgb", "tf_host_frame_times", "tf_host_register", "tf_host_unregister",
-    "tf_host_frame_buffers", "tf_host_frame_deferral", "tf_host_frame_set_deferral", "tf_texture_frame_device_phase", "tf_comm_exchange_overlap", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_boundary_band_bounds", "tf_boundary_pack_bands2", "tf_boundary_unpack_pair", "tf_comm_exchange_mode", "tf_comm_stats", "tf_comm_stats_ex",
+    "tf_host_frame_buffers", "tf_host_frame_deferral", "tf_host_frame_set_deferral", "tf_host_frame_set_async", "tf_host_frame_fence", "tf_texture_frame_device_phase", "tf_comm_exchange_overlap", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_boundary_band_bounds", "tf_boundary_pack_bands2", "tf_boundary_unpack_pair", "tf_comm_exchange_mode", "tf_comm_stats", "tf_comm_stats_ex",
     "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
     "tf_comm_exchange_every_frame",
     "tf_update_meshes", "tf_check_summaries", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
@@ -182,6 +182,8 @@ def lib():
     L.tf_host_frame_buffers.argtypes = [vp, C.POINTER(fp), C.POINTER(u8p)]
     L.tf_host_frame_deferral.argtypes = [vp, i32p, i32p]
     L.tf_host_frame_set_deferral.argtypes = [vp, C.c_int]
+    L.tf_host_frame_set_async.argtypes = [vp, C.c_int]
+    L.tf_host_frame_fence.argtypes = [vp]
     L.tf_texture_frame_device.argtypes = [vp, fp, C.c_int32]
     L.tf_texture_frame_device_phase.argtypes = [vp, fp, C.c_int32, C.c_int]
     L.tf_comm_exchange_overlap.argtypes = [vp, C.c_int]
@@ -693,6 +695,13 @@ class Volume:
         """on = False: tf_integrate_frame_host integrates a frame in the call that brings it (no latency, two more
         selection-only launches per frame)"""
         self._ck(self.L.tf_host_frame_set_deferral(self.h, 1 if on else 0))
+
+    def host_frame_set_async(self, on):
+        """on: calls out of registered buffers return before their upload is through; host_frame_fence() before a buffer is reused"""
+        self._ck(self.L.tf_host_frame_set_async(self.h, 1 if on else 0))
+
+    def host_frame_fence(self):
+        self._ck(self.L.tf_host_frame_fence(self.h))
 
     def host_frame_deferral(self):
         """(frames tf_integrate_frame_host runs behind its caller, staging slots of its ring)"""

@@ -1276,6 +1276,18 @@ int tf_host_frame_set_deferral(tf_volume* v, int on) {
   return TF_OK;
 }
 
+int tf_host_frame_set_async(tf_volume* v, int on) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  v->host_async = on != 0;
+  return TF_OK;
+}
+int tf_host_frame_fence(tf_volume* v) {
+  if (!v) { set_error("null handle"); return TF_ERR_INVALID; }
+  TF_DEV_NOFLUSH(v);
+  if (v->last_upload) TF_HIP(hipEventSynchronize(v->last_upload));  // (uploads of one handle complete in order)
+  return TF_OK;
+}
+
 int tf_host_frame_deferral(tf_volume* v, int32_t* frames_behind, int32_t* ring_slots) {
   // (a null handle answers for a handle as tf_volume_create makes it: TF_HOST_DEFER=0 in the environment turns the deferral
   // off for every new handle, tf_host_frame_set_deferral for one)
@@ -1468,9 +1480,11 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   // TSDF-only stream in steady state on a quiet host, 62 -> 52-54 us per frame, and doubled the first window behind resident
   // frames on a shared one; profiles/r4/README.md, run s13)
   if (direct) {
-    // (the call waits for this upload: depth and colour go up side by side on two copy queues)
-    // (a kernel that fetches the images itself -- 16-byte loads out of the mapped pages -- was no faster than the DMA
-    // transfers, 60 us, and slowed the step kernels it ran next to: 100 -> 125 us per frame, profiles/r4/README.md)
+    // (depth and colour are two caller arrays = two copies.  The link moves 2.46 MB as ONE copy in 53 us -- 46 GB/s,
+    // page-locked by hipHostMalloc or in place alike, tools/h2d_probe.py --; as two copies of 1.2 MB it takes 60 us when
+    // they travel side by side on two copy queues and 66 us one behind the other on one queue (profiles/r5/README.md).  A
+    // kernel that fetches the images itself -- 16-byte loads out of the mapped pages -- was no faster than the DMA
+    // transfers and slowed the step kernels it ran next to: 100 -> 125 us per frame, profiles/r4/README.md)
     if (rgba) {
       if (!v->copy_stream2) {
         TF_HIP(hipStreamCreateWithFlags(&v->copy_stream2, hipStreamNonBlocking));
@@ -1512,8 +1526,11 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   cur.fid = frame_id;
   cur.slot = slot_index;
   cur.copied = false;
-  // the caller's buffers are its own again when the call returns: an upload straight out of them must be through
+  // the caller's buffers are its own again when the call returns: an upload straight out of them must be through -- unless
+  // the caller took that on itself (tf_host_frame_set_async: it calls tf_host_frame_fence before it touches a buffer again)
+  v->last_upload = s.copied;
   auto wait_direct = [&]() {
+    if (v->host_async) return;
     auto tw = now();
     // (TF_HOST_POLL_SLEEP_US > 0: sleep between polls instead of spinning -- several ranks under one CPU quota)
     static const int poll_sleep = getenv("TF_HOST_POLL_SLEEP_US") ? atoi(getenv("TF_HOST_POLL_SLEEP_US")) : 0;
@@ -1524,7 +1541,7 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
     lap(1, tw);
   };
   if (!defer) {  // integrate at once: two selection-only launches per frame, the stream waits for the copy
-    if (direct) { wait_direct(); cur.copied = true; }
+    if (direct) { wait_direct(); cur.copied = !v->host_async; }
     rc = host_copy_ready(v, &cur);
     if (rc) return rc;
     const float* dd[1] = {cur.d};
@@ -1538,7 +1555,7 @@ static int integrate_frame_host_impl(tf_volume* v, const float* depth, const uin
   }
   if (!early) { rc = launch_oldest(); if (rc) return rc; }
   v->pend[v->n_pend++] = cur;
-  if (direct) { wait_direct(); v->pend[v->n_pend - 1].copied = true; }
+  if (direct) { wait_direct(); v->pend[v->n_pend - 1].copied = !v->host_async; }
   if (bound_d) return bind_frame(v, bound_d, bound_c);
   return TF_OK;
 }

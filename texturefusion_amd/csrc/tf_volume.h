@@ -183,7 +183,7 @@ struct tf_volume {
   size_t hslot_pixels = 0;
   int hslot_next = 0;
   hipStream_t copy_stream = nullptr;
-  hipStream_t copy_stream2 = nullptr;  // registered caller buffers: the colour image goes up next to the depth image (a second copy engine)
+  hipStream_t copy_stream2 = nullptr;  // registered caller buffers: the colour image goes up next to the depth image (a second copy queue)
   hipEvent_t copy_join = nullptr;
   long host_waits = 0;  // copies a launch had to wait for in the stream (TF_HOST_TRACE prints it)
   double host_trace[6] = {0, 0, 0, 0, 0, 0};  // TF_HOST_TRACE=1: microseconds per phase of tf_integrate_frame_host, [5] = calls
@@ -226,6 +226,8 @@ struct tf_volume {
   Pending pend[kHostDefer];
   int n_pend = 0;
   bool host_defer = true;  // tf_integrate_frame_host runs kHostDefer frames behind its caller (tf_host_frame_set_deferral)
+  bool host_async = false;           // tf_host_frame_set_async: a call out of registered buffers returns before its upload is through
+  hipEvent_t last_upload = nullptr;  // the newest frame's upload (tf_host_frame_fence waits for it)
   float* d_group = nullptr;  // staging of tf_integrate_depth_group_host: six depth images
   size_t d_group_pixels = 0;
   // on-demand device scratch
