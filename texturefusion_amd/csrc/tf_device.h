@@ -368,7 +368,7 @@ void launch_init_meshes(const VolumeDev& v, hipStream_t s);
 // keyframe group: n (<= 6) depth-only frames over the current list in one visit per chunk; scratch = n x (4 x max_list float4 + 1536 floats)
 void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
                             float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s,
-                            bool have_pre = false);
+                            bool have_pre = false, int32_t obs_kf = -1);  // obs_kf >= 0: also tf_observations_record of the keyframe
 uint32_t mesh_shard_rows(uint32_t max_chunks);
 // len_guess: the list length as far as the host knows (picks the filter's form); len_hint: host-visible word that
 // receives the actual length (may be null)

@@ -139,10 +139,13 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
   // the keyframe's own depth + colour (+ quality) ...
   const bool color = img.rgba != nullptr, quality = color && img.quality != nullptr;
   launch_integrate(d, img, v->cam, v->ig, P, v->res, flag, color, quality, 0, s, true);
-  launch_obs_record(d, g->kf_id, s);  // chunk->observations[keyframeID] for BOTH flags (Chisel.h:244-247)
+  // chunk->observations[keyframeID] for BOTH flags (Chisel.h:244-247): recorded by the group kernel's waves ahead of their
+  // own work, by a launch of its own when the group has no local frame
   // ... then its local frames depth-only over the same list, one visit per chunk
   if (g->n_local > 0)
-    launch_integrate_group(d, g->n_local, dd, poses, u->group_pre, u->group_cen, v->cam, v->ig, v->res, flag, s, true);
+    launch_integrate_group(d, g->n_local, dd, poses, u->group_pre, u->group_cen, v->cam, v->ig, v->res, flag, s, true, g->kf_id);
+  else
+    launch_obs_record(d, g->kf_id, s);
   launch_finalize(d, v->epoch++, s);
   const int slack = !(getenv("TF_UNIT_NO_SLACK") && atoi(getenv("TF_UNIT_NO_SLACK")));  // test knob (read per call): exact-fit regions
   const KfStoreArgs sa{u->tab, u->slots, u->arena, u->cap, kf_slot, slack, u->h_fill};
