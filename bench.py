@@ -87,6 +87,8 @@ def parse():
     ap.add_argument("--max-chunks-log2", type=int, default=0, help="chunk pool of 2^n slots (default: 19 room / 21 hall)")
     ap.add_argument("--no-independent", action="store_true",
                     help="N>1: skip the independent-streams (one whole volume per GPU) and sharded keyframe-unit figures")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1: the boundary exchange serially in the stream (round 4's order) instead of next to the interior mesh pass")
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N>1 code path (partition + boundary exchange) even with one rank (smoke test)")
     return ap.parse_args()
@@ -375,17 +377,22 @@ def main():
         # backend nccl: RCCL inside the library (tf_comm_init / tf_exchange_boundary) on the volume's stream;
         # other backends (test hook: several ranks on one GPU over gloo): the same blocks through torch.distributed.
         cap = args.exchange_cap
-        use_rccl = world > 1 and os.environ.get("TF_BENCH_BACKEND", "nccl") == "nccl"
+        # (--force-exchange with one rank: the in-library path all the same -- RCCL with a single rank: pack, the exchange's
+        # second stream, unpack, the interior / boundary mesh passes; nothing travels)
+        use_rccl = (world > 1 or args.force_exchange) and os.environ.get("TF_BENCH_BACKEND", "nccl") == "nccl"
         if use_rccl:
             uid = torch.zeros(128, dtype=torch.uint8, device=dev)
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
+            if world > 1:
+                dist.broadcast(uid, 0)
             vol.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
             # (neighbour send / receive pairs need every slab above the lowest to hold its own ghost band; the library
             # checks that itself at the first exchange and falls back to the all-gather form on every rank otherwise)
             if textured:
                 vol.comm_exchange_every_frame(cap)
+                if args.no_overlap:
+                    vol.comm_exchange_overlap(False)  # (A/B: the exchange in the stream between the voxel update and the mesher)
         else:
             bb = capi.boundary_block_bytes(cap)
             blk = torch.zeros(bb, dtype=torch.uint8, device=dev)
@@ -501,6 +508,31 @@ def main():
     if not args.no_preroll:
         run(0, ORBIT)
         pos = ORBIT
+    # N > 1: the order of the per-frame exchange -- on the library's second stream next to the interior mesh pass, or in the
+    # main stream between the voxel update and the mesher -- is picked by measurement: the overlapped order costs a second
+    # filter + mesher pass and a stream fork / join per frame and pays only when the wire time exceeds that
+    exchange_order = None
+    if use_rccl and textured and not args.no_overlap and not args.child:
+        t_ord = {}
+        for on in (True, False):
+            vol.comm_exchange_overlap(on)
+            run(pos, 8)
+            vol.sync()
+            barrier()
+            tq = time.perf_counter()
+            run(pos + 8, 24)
+            vol.sync()
+            barrier()
+            tt = torch.tensor([time.perf_counter() - tq], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_ord[on] = float(tt.item()) / 24
+            pos += 32
+        pick = t_ord[True] <= t_ord[False]
+        vol.comm_exchange_overlap(pick)
+        exchange_order = {"picked": "overlapped with the interior mesh pass" if pick else "serial, between voxel update and mesher",
+                          "us_per_frame_overlapped": 1e6 * t_ord[True], "us_per_frame_serial": 1e6 * t_ord[False],
+                          "how": "24 resident frames each way behind 8 warm-up frames, max over ranks; the faster order runs the timed window"}
     p0 = pos + Wm  # stream position of the timed window; p0 % ORBIT = its orbit position
     use_host = host_ok and not args.resident_headline
     host_phases = None
@@ -827,6 +859,8 @@ def main():
         out["host_phases_us_per_step"] = host_phases
     if per_rank is not None:
         out["per_rank"] = per_rank
+    if exchange_order is not None:
+        out["exchange_order"] = exchange_order
     if indep is not None:
         out["independent_streams"] = indep
     if sharded_unit is not None:

@@ -2023,11 +2023,10 @@ int tf_boundary_pack_bands2(tf_volume* v, void* d_block_down, int64_t cap_down, 
   TF_DEV(v);
   uint8_t* dn = reinterpret_cast<uint8_t*>(d_block_down);
   uint8_t* up = reinterpret_cast<uint8_t*>(d_block_up);
-  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
-  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp2, 0, 4, v->stream));
-  launch_boundary_pack_bands(v->dev, dn + 16, up + 16, (uint32_t)cap_down, (uint32_t)cap_up, v->stream);
-  launch_boundary_headers(v->dev, reinterpret_cast<uint32_t*>(dn), (uint32_t)cap_down, reinterpret_cast<uint32_t*>(up),
-                          (uint32_t)cap_up, v->stream);  // the counts travel in-band
+  // ONE launch: the counters live in VolCtl::xchg_cnt, the last workgroup writes the in-band counts and re-arms them
+  // (round 4: two memsets + the pack + a header launch -- the exchange of a frame was seven stream operations at their
+  // launch floor, 49 us with nothing on the wire; profiles/r5/README.md)
+  launch_boundary_pack_bands(v->dev, dn, up, (uint32_t)cap_down, (uint32_t)cap_up, v->stream);
   TF_HIP(hipGetLastError());
   return TF_OK;
 }

@@ -116,6 +116,8 @@ static int comm_buffers(tf_volume* v, int64_t cap_records) {
   c.d_send = c.d_recv = nullptr;
   TF_HIP(hipMalloc(&c.d_send, block * 2));  // all-gather: one block; neighbours: the down block, then the up block
   TF_HIP(hipMalloc(&c.d_recv, block * (size_t)(c.nranks > 2 ? c.nranks : 2)));
+  // (a receive slot without a neighbour is never written: its count stays zero, no memset per exchange)
+  TF_HIP(hipMemset(c.d_recv, 0, block * (size_t)(c.nranks > 2 ? c.nranks : 2)));
   c.cap_records = cap_records;
   return TF_OK;
 }
@@ -170,8 +172,6 @@ int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t sta
     rc = tf_boundary_pack_bands2(v, send, cap_dn, send + block, cap_up);
     if (rc) return rc;
     const bool lower = c.rank > 0, upper = c.rank + 1 < c.nranks;
-    if (!lower) TF_HIP(hipMemsetAsync(recv, 0, 16, v->stream));
-    if (!upper) TF_HIP(hipMemsetAsync(recv + block, 0, 16, v->stream));
     const size_t b_dn = tf_boundary_block_bytes(cap_dn), b_up = tf_boundary_block_bytes(cap_up);
     const size_t b_lo = tf_boundary_block_bytes(cap_lo), b_hi = tf_boundary_block_bytes(cap_hi);
     if (lower || upper) {

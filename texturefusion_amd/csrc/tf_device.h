@@ -90,6 +90,11 @@ struct VolCtl {
   uint32_t xchg_sent, xchg_recv;  // ghost records written into / stored from exchange blocks since create (tf_comm_stats_ex)
   uint32_t zero_word;  // always 0: an empty list's count (the interior mesh pass of an overlapped exchange ignores the flat list)
   uint32_t blk_next;   // mesh store, small pool: blocks handed out (bump allocation, reset with the volume)
+  // the two-band boundary pack (k_boundary_pack<true>): records counted per block, workgroups that are through; the LAST
+  // workgroup writes the blocks' headers and re-arms the three words (no memset, no header launch per exchange)
+  uint32_t xchg_cnt[2];
+  uint32_t xchg_ticket;
+  uint32_t xchg_pad2;
   // Pool slots are handed out from 64 independent stripes (stripe s owns slots
   // [s*max_chunks/64, (s+1)*max_chunks/64)) so that the thousands of chunk creations of a
   // first-touch frame do not serialise on one atomic word.
@@ -338,7 +343,8 @@ void launch_scatter_chunk(const VolumeDev& v, int4 id, const float* sdf, const f
                           const uint16_t* col, hipStream_t s);
 void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s);
 // two blocks: what the rank below / the rank above reads as ghosts (counts in VolCtl::n_tmp / n_tmp2)
-void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* records_down, uint8_t* records_up, uint32_t cap_down,
+// (the blocks' in-band counts -- first word of each 16-byte header ahead of the records -- are written by the launch itself)
+void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* block_down, uint8_t* block_up, uint32_t cap_down,
                                 uint32_t cap_up, hipStream_t s);
 // the blocks' in-band counts (first word of each header) from VolCtl::n_tmp / n_tmp2; hdr_b may be null
 void launch_boundary_headers(const VolumeDev& v, uint32_t* hdr_a, uint32_t cap_a, uint32_t* hdr_b, uint32_t cap_b, hipStream_t s);

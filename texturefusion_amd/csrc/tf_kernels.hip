@@ -117,7 +117,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
     for (int k = 0; k < 4; ++k) ctl->band_cnt[k] = 0u;
     if (vctl) {
       vctl->status = 0; vctl->n_tmp = 0; vctl->n_tmp2 = 0; vctl->ovf_next = 0; vctl->xchg_sent = 0; vctl->xchg_recv = 0;
-      vctl->zero_word = 0; vctl->blk_next = 0;
+      vctl->zero_word = 0; vctl->blk_next = 0; vctl->xchg_cnt[0] = vctl->xchg_cnt[1] = 0; vctl->xchg_ticket = 0; vctl->xchg_pad2 = 0;
       for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
     }
   }
@@ -1976,8 +1976,8 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
       }
       uint32_t p = 0, q = 0;
       if (lane == 0) {
-        if (down) p = atomicAdd(&v.vctl->n_tmp, 1u);
-        if (up) q = atomicAdd(&v.vctl->n_tmp2, 1u);
+        if (down) p = atomicAdd(BANDS ? &v.vctl->xchg_cnt[0] : &v.vctl->n_tmp, 1u);
+        if (up) q = atomicAdd(&v.vctl->xchg_cnt[1], 1u);
       }
       p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
       q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
@@ -2005,13 +2005,31 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
       }
     }
   }
+  if (BANDS) {
+    // the last workgroup through writes the two blocks' in-band counts (the first word of the 16-byte header in front of
+    // the records), adds what fitted to the running total and re-arms the counters for the next exchange
+    __shared__ uint32_t s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      s_last = atomicAdd(&v.vctl->xchg_ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+      const uint32_t na = atomicExch(&v.vctl->xchg_cnt[0], 0u), nb = atomicExch(&v.vctl->xchg_cnt[1], 0u);
+      *reinterpret_cast<uint32_t*>(records - 16) = na;
+      *reinterpret_cast<uint32_t*>(records_up - 16) = nb;
+      v.vctl->xchg_sent += (na < cap ? na : cap) + (nb < cap_up ? nb : cap_up);
+      v.vctl->xchg_ticket = 0u;
+    }
+  }
 }
 void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s) {
   hipLaunchKernelGGL(k_boundary_pack<false>, dim3(1024), dim3(256), 0, s, v, records, (uint8_t*)nullptr, cap, 0u);
 }
-void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* records_down, uint8_t* records_up, uint32_t cap_down,
+void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* block_down, uint8_t* block_up, uint32_t cap_down,
                                 uint32_t cap_up, hipStream_t s) {
-  hipLaunchKernelGGL(k_boundary_pack<true>, dim3(1024), dim3(256), 0, s, v, records_down, records_up, cap_down, cap_up);
+  hipLaunchKernelGGL(k_boundary_pack<true>, dim3(1024), dim3(256), 0, s, v, block_down + 16, block_up + 16, cap_down, cap_up);
 }
 // The in-band counts of freshly packed blocks (VolCtl::n_tmp / n_tmp2 -> the first word of each block) and the running
 // total of records written (what fitted), for tf_comm_stats_ex.
