@@ -19,7 +19,7 @@ BUDGET = {
     # (the filter's two forms -- wave per entry / workgroup batches -- are two kernels: the wave form alone fits the 64 VGPRs
     # that let eight waves per SIMD be resident; the instances that carry the previous frame's patch stage (the keyframe
     # unit) are compiled for 6 waves per SIMD: 80 VGPRs, the patch range spills 28 B/lane)
-    "tf_mesh.hip": {"k_meshILi128E": (88, 0), "k_mesh_filterILb1ELb0E": (64, 16),
+    "tf_mesh.hip": {"k_meshILi128E": (80, 0), "k_mesh_filterILb1ELb0E": (72, 0),
                     "k_mesh_filterILb0ELb0E": (80, 0), "k_mesh_filterILb1ELb1E": (80, 40), "k_mesh_filterILb0ELb1E": (80, 40)},
     "tf_atlas.hip": {"k_patchILb1ELb1ELb1E": (96, 0)},  # one patch per wave, two 64-vertex blocks in registers: 5 waves per SIMD
 }

@@ -352,8 +352,10 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
 // neighbourhood index of a lane (0..26) -> its place k among the near eight (only for is_near lanes)
 __device__ __forceinline__ int near_k(int lane) { return (lane % 3 - 1) + 2 * ((lane / 3) % 3 - 1) + 4 * (lane / 9 - 1); }
 
-// Two forms of the filter, one kernel each (one kernel holding both needs 78 VGPRs; the wave form alone fits the 64
-// that let eight waves per SIMD -- the whole list of a 640x480 frame -- be resident at once):
+// Two forms of the filter, one kernel each (one kernel holding both needs 78 VGPRs).  The wave form is compiled for SEVEN
+// waves per SIMD: 72 VGPRs and no private memory.  At eight -- the whole list of a 640x480 frame resident at once -- it
+// fits 64 VGPRs only with 12 B / lane spilled, and waves that own private memory are dispatched more slowly than the
+// second round of a 7 k-wave launch costs: 15.8 -> 15.4 us (profiles/r5/README.md).
 //  WAVE_FORM: one entry per wave (strided when the list is longer than the grid): lanes 0..7 run phase A, the wave
 //             phase B for the same entry -- nothing to share, no barrier;
 //  batches:   per workgroup, batches of up to 32 entries; phase A with EIGHT LANES per entry decides "cannot have a
@@ -387,7 +389,7 @@ struct FilterPatch {
   KfDev kf;
 };
 template <bool WAVE_FORM, bool PATCH>
-__global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 8 : 6)) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
+__global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7 : 6)) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
@@ -535,7 +537,12 @@ __device__ __forceinline__ void mesh_stamp(const VolumeDev& v, uint32_t r, int k
 }
 
 #ifndef TF_MESH_WAVES
-#define TF_MESH_WAVES 5  // waves per SIMD the 128-thread mesher is compiled for: 5 = 96 VGPRs, ten chunks per CU
+// waves per SIMD the 128-thread mesher is compiled for.  6 = 80 VGPRs (no private memory) and, with 12.4 KB of LDS per
+// workgroup, TWELVE chunks per CU = 3072 resident workgroups: a room frame's ~2.9 k surviving chunks all start at once (time
+// stamps, profiles/r5: last start 1.2 us instead of 20 us, first start to last end 28.3 instead of 35.2 us; a chunk then takes
+// 20.9 instead of 19.4 us -- the CU is shared by more).  Over the orbit, whose frames reach 3.3 k chunks: 33.1 -> 31.7 us.
+// (Round 4 measured no gain at 6: its kernel needed 88 VGPRs, and the 80 the compiler was forced to cost more than they gave.)
+#define TF_MESH_WAVES 6
 #endif
 template <int NT>  // threads per chunk
 __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
@@ -986,7 +993,7 @@ static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries,
   uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshCntWords;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
   // workgroup b takes row b of the concatenated shard lists and strides by the grid: a few resident rounds at most
-  // (128 threads per chunk: with 13 KB of LDS and 88 VGPRs ten chunks are resident per CU)
+  // (128 threads per chunk: with 12.4 KB of LDS and 80 VGPRs twelve chunks are resident per CU)
   uint32_t grid = ((max_entries + kMeshShards - 1) / kMeshShards + 1) * kMeshShards;
   if (grid > 4096u) grid = 4096u;
   hipLaunchKernelGGL((k_mesh<128>), dim3(grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,

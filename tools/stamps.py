@@ -18,7 +18,7 @@ from tests.util import HipBuffer
 what = sys.argv[1] if len(sys.argv) > 1 else "mesh"
 cam = synth.Camera()
 gv = capi.Volume(np.float32(0.005), cam, max_chunks=1 << 18)
-frames = [synth.room_frame(k, cam, with_quality=False) for k in range(70)]
+frames = [synth.room_frame(k, cam, with_quality=False) for k in range(int(os.environ.get("FRAMES", "70")))]
 bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
 poses = np.stack([f[3].reshape(12) for f in frames])
 pinv = np.stack([synth.pose_inverse16(f[3]) for f in frames])
