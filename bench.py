@@ -897,6 +897,17 @@ def main():
         dist.destroy_process_group()
 
 
+def all_ranks_ok(dist, dev, ok):
+    """True when `ok` holds on every rank (one small all-reduce): a rank whose local set-up failed must not leave the
+    others waiting in the collectives that follow"""
+    if dist is None:
+        return bool(ok)
+    import torch
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
 def independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses, pinv, a_depth, a_rgba, a_pose, a_pinv,
                         n_unique, device, world, dist, dev, textured, fresh_period):
     """N GPUs as N independent streams: every rank integrates the WHOLE stream into a volume of its own (no partition, no
@@ -907,8 +918,16 @@ def independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses,
     from texturefusion_amd import capi
     K, Wm = args.steps, args.warmup
     big = args.scene == "big"
-    vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
-                      max_coarse=1 << 22 if big else 1 << 20, device=device)
+    vol, err = None, None
+    try:
+        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+                          max_coarse=1 << 22 if big else 1 << 20, device=device)
+    except Exception as e:
+        err = repr(e)[:200]
+    if not all_ranks_ok(dist, dev, vol is not None):
+        if vol is not None:
+            vol.close()
+        return {"error": err or "another rank could not create its volume"}
     registered = False
     if not args.staged_host_frames:
         try:
@@ -938,17 +957,30 @@ def independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses,
         torch.cuda.synchronize()
 
     pos = 0
-    if not args.no_preroll:
-        run(0, n_unique)
-        pos = n_unique
-    fresh_period()
-    run_host(pos, Wm)
+    ok = True
+    try:
+        if not args.no_preroll:
+            run(0, n_unique)
+            pos = n_unique
+        fresh_period()
+        run_host(pos, Wm)
+    except Exception as e:
+        ok, err = False, repr(e)[:200]
+    if not all_ranks_ok(dist, dev, ok):  # (before the first barrier: nobody waits for a rank that failed)
+        vol.close()
+        return {"error": err or "another rank failed ahead of the timed window"}
     barrier()
     vol.host_frame_times(reset=True)
     t0 = time.perf_counter()
-    run_host(pos + Wm, K)
+    try:
+        run_host(pos + Wm, K)
+    except Exception as e:
+        ok, err = False, repr(e)[:200]
     barrier()
     dt = time.perf_counter() - t0
+    if not all_ranks_ok(dist, dev, ok):
+        vol.close()
+        return {"error": err or "another rank failed inside the timed window"}
     phases = vol.host_frame_times(reset=True)
     vol.sync()
     mine = 1e3 * dt / K
@@ -982,13 +1014,22 @@ def sharded_keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique
     n_kf = max(4, min(24, n_unique // stride - 1))
     big = args.scene == "big"
     s_main = torch.cuda.Stream(device=dev)
-    vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
-                      max_coarse=(1 << 22) if big else (1 << 20), device=device, stream=s_main.cuda_stream)
-    vol.set_partition(lo, hi, axis)
+    vol, err = None, None
+    try:
+        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+                          max_coarse=(1 << 22) if big else (1 << 20), device=device, stream=s_main.cuda_stream)
+        vol.set_partition(lo, hi, axis)
+    except Exception as e:
+        err = repr(e)[:200]
+    if not all_ranks_ok(dist if world > 1 else None, dev, err is None):  # (ncclCommInitRank below is a collective)
+        if vol is not None:
+            vol.close()
+        return {"error": err or "another rank could not create its volume"}
     uid = torch.zeros(128, dtype=torch.uint8, device=dev)
     if rank == 0:
         uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
-    dist.broadcast(uid, 0)
+    if world > 1:
+        dist.broadcast(uid, 0)
     vol.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
     vol.comm_exchange_every_frame(cap)
 
@@ -1000,20 +1041,36 @@ def sharded_keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique
         vol.keyframe_unit(fresh=fresh, moved=[], texture=True, pose_inv16=pinv[k0])
 
     warm = 4
-    for g in range(warm):
-        call(g)
-    vol.sync()
-    dist.barrier()
+    ok = True
+    try:
+        for g in range(warm):
+            call(g)
+        vol.sync()
+    except Exception as e:
+        ok, err = False, repr(e)[:200]
+    if not all_ranks_ok(dist if world > 1 else None, dev, ok):
+        vol.close()
+        return {"error": err or "another rank failed in the warm-up keyframes"}
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for g in range(warm, warm + n_kf):
-        call(g)
-    vol.sync()
-    dist.barrier()
+    try:
+        for g in range(warm, warm + n_kf):
+            call(g)
+        vol.sync()
+    except Exception as e:
+        ok, err = False, repr(e)[:200]
+    if not all_ranks_ok(dist if world > 1 else None, dev, ok):
+        vol.close()
+        return {"error": err or "another rank failed in the timed keyframes"}
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     st = vol.comm_stats_ex()
     vol.close()
