@@ -19,6 +19,6 @@ for case in range(int(sys.argv[2]) if len(sys.argv) > 2 else 8):
     k0 = int(rng.integers(0, 180)); step = int(rng.integers(1, 4)); n = int(rng.integers(10, 26))
     wob = float(rng.uniform(0, 0.1)); radius = float(rng.uniform(0.2, 1.2))
     frames = [synth.room_frame(k0 + step * i, cam, with_quality=False, wobble=wob, radius=radius) for i in range(n)]
-    host = bool(rng.integers(0, 2))
+    host = [False, True, "registered", "registered_async", "no_deferral", "rgb"][int(rng.integers(0, 6))]  # entry point / host-frame path
     nm = _run(cam, np.float32(res), frames, host_frames=host, max_chunks=1 << 18, stride=int(rng.integers(1, 6)))
     print("case %d: %dx%d f %.0f res %.3f frames %d step %d wobble %.2f radius %.2f host %s -> %d meshes OK (%.0f s)" % (case, W, H, f, res, n, step, wob, radius, host, nm, time.time() - t0), flush=True)
