@@ -253,12 +253,13 @@ int tf::xchg_band_counts(tf_volume* v, const tf::FrameCtl* ctl, uint32_t tag, ui
 }
 // PrepareIntersectChunks without the reference's list ORDER (the keyframe unit: its lists never leave the device and
 // nothing it computes depends on their order): the selection appends straight to the list, no scan / write-out launch
-int tf::launch_prepare_unordered(tf_volume* v, const tf::Pose& pose, hipStream_t s) {
+// (acquire = false: the caller's next launch resolves the slots -- launch_pre_frames(acquire = true))
+int tf::launch_prepare_unordered(tf_volume* v, const tf::Pose& pose, hipStream_t s, bool acquire) {
   using namespace tf;
   if (!s) s = v->stream;
   launch_bbox(v->dev, v->frame.depth, v->cam, pose, s);
   launch_select(v->dev, v->frame.depth, v->cam, v->ig, pose, v->res, /*emit=*/true, s, /*plain=*/true);
-  launch_acquire_emitted(v->dev, s);
+  if (acquire) launch_acquire_emitted(v->dev, s);
   return TF_OK;
 }
 int tf::launch_prepare(tf_volume* v, const tf::Pose& pose, bool with_acquire, hipStream_t s) {
@@ -455,7 +456,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     if ((rc = dev_alloc(v, &L.list_slot, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_ent, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_new, (size_t)d.max_list))) return fail(rc);
-    if ((rc = dev_alloc(v, &L.list_needs, (size_t)d.max_list))) return fail(rc);
+    if ((rc = dev_alloc(v, &L.list_needs, (size_t)d.max_list + 16))) return fail(rc);  // (+16: kf_store_body reads the flags 16 at a time)
     if ((rc = dev_alloc(v, &L.list_quality, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_rows, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.cen, (size_t)3 * kChunkVoxels))) return fail(rc);
@@ -861,7 +862,7 @@ int tf::fused_arm(tf_volume* v) {
 // = the parity used here), or the caller ran launch_dirty_frame over each of its lists (the keyframe unit)
 int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
                       const float* pose_inv16, int32_t frame_id, bool claimed, const FrameCtl* next_ctl, bool ride_filter,
-                      bool sized_xchg, int phase) {
+                      bool sized_xchg, int phase, const KfStoreArgs* store) {
   AtlasState& a = v->atlas;
   if (phase == 2) {
     // second half of a stage whose first half (dirty set + interior meshes) ran before the caller's own exchange
@@ -916,7 +917,8 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
     prof_begin(v, TF_PROF_MESH);
     const bool rode = launch_mesh(d, v->mesh_par, d.work_ids, flat_count, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1,
                                   len_guess, with_hint ? a.h_dirty_len : nullptr, par, v->stream, with_ride ? &prev : nullptr,
-                                  &v->cam, cls);
+                                  &v->cam, cls, store);
+    store = nullptr;  // (once)
     v->mesh_par ^= 1;
     prof_end(v);
     return rode;

@@ -99,8 +99,10 @@ __device__ __forceinline__ uint32_t hash_slot_alive_ent(const VolumeDev& v, unsi
 // Within one launch every key is unique (the visible list has no duplicates), so the payload of
 // a freshly inserted key is only read by later launches.  *is_new = chunk did not exist (absent
 // or parked); *ent = hash entry index.
+// lazy: a parked chunk is NOT revived here (it still counts as new); whoever finalizes the list revives it if it was updated
+// -- so that a dirty-set claim running beside that finalize never sees a chunk alive that is about to be parked again.
 __device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, bool* is_new,
-                                               uint32_t* ent) {
+                                               uint32_t* ent, const bool lazy = false) {
   const unsigned long long key = pack_id(id.x, id.y, id.z);
   uint32_t i = hash_key(key) & v.hmask;
   *is_new = true;
@@ -129,7 +131,7 @@ __device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, b
       *ent = i;
       const uint32_t slot = v.hent[i].slot;
       if (slot == kInvalidSlot) return slot;
-      if (!v.hent[i].alive) v.hent[i].alive = 1;  // parked chunk: revive, still "new"
+      if (!v.hent[i].alive) { if (!lazy) v.hent[i].alive = 1; }  // parked chunk: revive, still "new"
       else *is_new = false;
       return slot;
     }

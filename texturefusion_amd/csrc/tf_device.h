@@ -324,7 +324,8 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
 // list records + centroid tables of a keyframe (into the selection set, as k_pre leaves them) and of its n local frames
 // (into the group scratch, as k_pre_group leaves them) in ONE launch
 void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const float* poses12, float4* pre_scratch,
-                       float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s);
+                       float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s,
+                       int acquire = 0);  // 1: also launch_acquire_emitted's work (the list is k_select<EMIT, plain>'s); 2: ... lazily
 void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
 // the plain list's ids and isNew flags (first min(n_list, cap) entries) into host-visible memory
 void launch_export_list(const VolumeDev& v, int4* h_ids, uint8_t* h_new, uint32_t cap, hipStream_t s);
@@ -374,16 +375,22 @@ void launch_init_meshes(const VolumeDev& v, hipStream_t s);
 // keyframe group: n (<= 6) depth-only frames over the current list in one visit per chunk; scratch = n x (4 x max_list float4 + 1536 floats)
 void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
                             float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s,
-                            bool have_pre = false, int32_t obs_kf = -1);  // obs_kf >= 0: also tf_observations_record of the keyframe
+                            bool have_pre = false, int32_t obs_kf = -1,  // obs_kf >= 0: also tf_observations_record of the keyframe
+                            int fin = 0, uint32_t fin_epoch = 0,         // fin: also launch_finalize(fin_epoch)
+                            int claim_par = -1, uint32_t claim_stamp = 0);  // (with fin) claim_par >= 0: also the dirty-set pass, into the shard lists
 uint32_t mesh_shard_rows(uint32_t max_chunks);
 // len_guess: the list length as far as the host knows (picks the filter's form); len_hint: host-visible word that
 // receives the actual length (may be null)
 // shards_par >= 0: the dirty set is the flat list PLUS the shard lists of that parity (VolumeDev::wl_*)
 // patch != nullptr: the filter launch also carries the patch stage of the PREVIOUS frame (block range ahead of the
 // filter's; tf_patch_body.h) -- returns true when it did (the fused-filter form of the mesher has no such launch)
+// store != nullptr: one more workgroup of the filter launch stores the finalized list of v.sel as a keyframe's validChunks
+// (kf_store_body, tf_kf_store.h: the keyframe unit -- a single-workgroup launch of its own is 11 us at its launch floor)
+struct KfStoreArgs;
 bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, int shards_par,
-                 hipStream_t s, const PatchStage* patch = nullptr, const Cam* cam = nullptr, int cls = 0);  // cls: FilterPatch::cls
+                 hipStream_t s, const PatchStage* patch = nullptr, const Cam* cam = nullptr, int cls = 0,  // cls: FilterPatch::cls
+                 const KfStoreArgs* store = nullptr);
 // per-frame dirty set of the fused flow -> work list of counter set `par` (when K-A did not build it: FrameStage::claim_par)
 void launch_dirty_frame(const VolumeDev& v, int par, uint32_t stamp, hipStream_t s);
 // ... when marks of earlier frames are still waiting for a mesher: everything marked since clear_floor

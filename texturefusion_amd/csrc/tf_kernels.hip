@@ -550,27 +550,28 @@ void launch_acquire(const VolumeDev& v, hipStream_t s) {
 // The same behind k_select<EMIT> with SelectConsts::plain: the list is the unordered one the selection appended (all of it
 // from the front), its length still sits in the append counter -- this launch turns it into a finished plain list
 // (n_list = n_front = length, bounding-box keys re-armed as k_scan does) while it resolves the slots.
-__global__ __launch_bounds__(256) void k_acquire_emitted(VolumeDev v) {
+__device__ __forceinline__ void acquire_emitted_body(const VolumeDev& v, const uint32_t bid, const uint32_t nb, const bool lazy = false) {
   const SelBuf& L = v.sel;
   const unsigned long long pk = L.ctl->emit_pack;
   uint32_t n = (uint32_t)pk;
   if ((pk >> 32) != 0ull || n > v.max_list) n = 0;  // (a list that did not fit was reported by the selection: kStListFull)
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (bid == 0 && threadIdx.x == 0) {
     L.ctl->n_list = n;
     L.ctl->n_front = n;
     for (int a = 0; a < 3; ++a) { L.ctl->bbox_key[a] = f2key(1e8f); L.ctl->bbox_key[3 + a] = f2key(-1e8f); }
   }
-  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+  for (uint32_t e = bid * 256 + threadIdx.x; e < n; e += nb * 256) {
     const int4 id = L.list_id[e];
     bool is_new = false;
     uint32_t ent = 0;
-    const uint32_t slot = chunk_acquire(v, id, &is_new, &ent);
+    const uint32_t slot = chunk_acquire(v, id, &is_new, &ent, lazy);
     L.list_slot[e] = slot;
     L.list_ent[e] = ent;
     L.list_new[e] = is_new ? 1 : 0;
     L.list_needs[e] = 0;
   }
 }
+__global__ __launch_bounds__(256) void k_acquire_emitted(VolumeDev v) { acquire_emitted_body(v, blockIdx.x, gridDim.x); }
 void launch_acquire_emitted(const VolumeDev& v, hipStream_t s) {
   hipLaunchKernelGGL(k_acquire_emitted, dim3(512), dim3(256), 0, s, v);
 }
@@ -700,6 +701,33 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) u32x4* const_u32x4_ptr;
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) u32x8* const_u32x8_ptr;
+
+// The dirty-set claim of one updated chunk (Chisel.h:197-203: the chunk and its six face neighbours, those that exist): lane k
+// < 7 of the wave looks neighbour k up, the per-slot stamp de-duplicates, the winner appends {id, entry, slot} to the shard
+// list of its pool slot (counter set `par`).
+__device__ __forceinline__ void claim_dirty7(const VolumeDev& v, const int4 id, const uint32_t slot, const uint32_t ent, const int lane,
+                                             const uint32_t stamp, const int par) {
+  uint32_t cs = kInvalidSlot, ce = 0;
+  int4 q = id;
+  if (lane < 7) {
+    q = nbr7(id, lane);
+    if (lane == 0) { cs = slot; ce = ent; }
+    else if (part_owned(v, q.x, q.y, q.z)) cs = hash_slot_alive_ent(v, pack_id(q.x, q.y, q.z), &ce);
+    if (cs != kInvalidSlot && !(atomicMax(&v.mesh_rec[cs].stamp, stamp) < stamp)) cs = kInvalidSlot;
+    if (cs != kInvalidSlot) {
+      const uint32_t rows = v.max_chunks / kMeshShards + 258u;  // = mesh_shard_rows()
+      const uint32_t sh = cs & (kMeshShards - 1u);
+      const uint32_t p = atomicAdd(&v.wl_cnt[((par & 1) * kMeshShards + sh) * 16], 1u);
+      if (p < rows) {
+        const size_t at = ((size_t)(par & 1) * kMeshShards + sh) * rows + p;
+        v.wl_ids[at] = make_int4(q.x, q.y, q.z, (int)(ce + 1u));
+        v.wl_slot[at] = cs;
+      } else {
+        atomicOr(&v.vctl->status, kStMeshFull);
+      }
+    }
+  }
+}
 
 template <bool COLOR, bool QUALITY, bool FUSED, bool FLAG, int GP>
 __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameImages& img, const Cam& cam,
@@ -1135,26 +1163,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
           // then updated in this frame and claims itself, or it is parked again and does not exist for the mesher.  A
           // neighbour that is alive now and parked later in this launch stays in the list: the entry carries its hash
           // entry, and the mesher's filter drops chunks that are not alive (RecomputeMeshes' !HasChunk).
-          uint32_t cs = kInvalidSlot, ce = 0;
-          int4 q = id;
-          if (lane < 7) {
-            q = nbr7(id, lane);
-            if (lane == 0) { cs = slot; ce = ent; }
-            else if (part_owned(v, q.x, q.y, q.z)) cs = hash_slot_alive_ent(v, pack_id(q.x, q.y, q.z), &ce);
-            if (cs != kInvalidSlot && !(atomicMax(&v.mesh_rec[cs].stamp, epoch + 1u) < epoch + 1u)) cs = kInvalidSlot;
-            if (cs != kInvalidSlot) {
-              const uint32_t rows = v.max_chunks / kMeshShards + 258u;  // = mesh_shard_rows()
-              const uint32_t sh = cs & (kMeshShards - 1u);
-              const uint32_t p = atomicAdd(&v.wl_cnt[((claim_par & 1) * kMeshShards + sh) * 16], 1u);
-              if (p < rows) {
-                const size_t at = ((size_t)(claim_par & 1) * kMeshShards + sh) * rows + p;
-                v.wl_ids[at] = make_int4(q.x, q.y, q.z, (int)(ce + 1u));
-                v.wl_slot[at] = cs;
-              } else {
-                atomicOr(&v.vctl->status, kStMeshFull);
-              }
-            }
-          }
+          claim_dirty7(v, id, slot, ent, lane, epoch + 1u, claim_par);
         }
       } else if (is_new) {
         if (lane == 0) {
@@ -1227,15 +1236,23 @@ struct GroupPoses {
 // list records and centroid tables of all frames of a group in one launch (blockIdx.y = frame)
 // (with_key: blockIdx.y == 0 is the KEYFRAME -- pose `key`, records into the selection set like k_pre's -- and the local
 // frames follow at y = 1 + f: the keyframe unit computes all seven frames' records in one launch)
+// (acquire: the list is the plain one k_select<EMIT> just appended, its length still in the append counter; the LAST row of
+// blocks is k_acquire_emitted's work -- slots, isNew, the finished list header -- which the record rows do not read.
+// acquire == 2: parked chunks stay parked, chunk_acquire's lazy form -- the list's finalize is k_integrate_group's)
 __global__ __launch_bounds__(256) void k_pre_group(VolumeDev v, GroupPoses gp, Integ ig, float res, float resDiag,
-                                                   float4* pre_scratch, float* cen_scratch, Pose key, int with_key) {
+                                                   float4* pre_scratch, float* cen_scratch, Pose key, int with_key, int acquire) {
   const SelBuf& L = v.sel;
+  if (acquire && blockIdx.y == gridDim.y - 1) { acquire_emitted_body(v, blockIdx.x, gridDim.x, acquire == 2); return; }
   const bool is_key = with_key && blockIdx.y == 0;
   const int f = is_key ? 0 : (int)blockIdx.y - (with_key ? 1 : 0);
   const float* P = is_key ? key.p : gp.P[f].p;
   float4* pre = is_key ? L.list_pre : pre_scratch + (size_t)f * 4 * v.max_list;
   if (blockIdx.x == 0) centroid_table(P, res, is_key ? L.cen : cen_scratch + (size_t)f * 3 * kChunkVoxels);
-  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
+  uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
+  if (acquire) {
+    const unsigned long long pk = L.ctl->emit_pack;
+    n = ((pk >> 32) != 0ull || (uint32_t)pk > v.max_list) ? 0u : (uint32_t)pk;
+  }
   for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
     const int4 id = L.list_id[e];
     const ChunkPre cp = chunk_pre(id, P, ig, res, resDiag);
@@ -1247,8 +1264,13 @@ __global__ __launch_bounds__(256) void k_pre_group(VolumeDev v, GroupPoses gp, I
 // obs_kf >= 0: the launch also records chunk->observations[obs_kf] of the KEYFRAME's integration that ran just before it
 // (Chisel.h:244-247: the list's quality sums and needsUpdate flags as that call left them -- read here before this
 // kernel touches the entry's flag), instead of a launch of its own between the two (k_obs_record: 4.7 us of the unit)
+// fin != 0: the launch is also the list's finalize (k_finalize: FinalizeIntegrateChunks + GarbageCollect, Chisel.h:192-208,
+// :472-477, with epoch fin_epoch) -- each wave finishes its entry behind its last frame, when the entry's needsUpdate flag
+// (the keyframe's call | this visit) is final, as K-A does in a stream (7 us of launch per group less); claim_par >= 0: and the
+// dirty-set pass over the list (k_dirty_frame), into the shard lists of that parity
 template <bool FLAG>
-__global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs ga, Cam cam, IntegrateConsts kc, int32_t obs_kf) {
+__global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs ga, Cam cam, IntegrateConsts kc, int32_t obs_kf,
+                                                         int fin, uint32_t fin_epoch, int claim_par, uint32_t claim_stamp) {
   const SelBuf& L = v.sel;
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
@@ -1387,7 +1409,48 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
       L.list_needs[e] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
       if (part_band(v, id.x, id.y, id.z)) v.hent[L.list_ent[e]].alive = 3u;  // multi-GPU: touched since the last exchange
     }
+    const uint32_t rows_key = fin ? (uint32_t)L.list_rows[e] : 0u;  // the keyframe's own pass: rows_t | rows_c << 8
     if (lane == 0) L.list_rows[e] = (uint16_t)(rows_total < 255u ? rows_total : 255u);  // (statistic; saturates)
+    if (fin) {
+      const bool isnew = L.list_new[e] != 0;
+      if (updated || L.list_needs[e]) {
+        if (lane == 0) {
+          v.mark_epoch[slot] = fin_epoch + 1u;  // meshesToUpdate[id and 6 nbrs] = true, expanded on read
+          // (the list was acquired lazily: a parked chunk that got data is revived here; band chunks carry bit 1 already)
+          if (isnew && !part_band(v, id.x, id.y, id.z)) v.hent[L.list_ent[e]].alive = 1u;
+        }
+        // (a texture stage follows the call's groups: the chunk joins its dirty set here, as K-A's chunks do in a stream)
+        if (claim_par >= 0) claim_dirty7(v, id, slot, L.list_ent[e], lane, claim_stamp, claim_par);
+      } else if (isnew) {
+        // GarbageCollect: RemoveChunk + meshesToUpdate.erase.  Parked storage goes back to the fresh state: colour rows
+        // can have been written by the keyframe's pass (colour band hit with depth outside [near, far]: its row count says);
+        // TSDF rows only when the caller's earlier flags removed a chunk WITH data -- the summary word tells (see k_finalize)
+        const uint32_t ent = L.list_ent[e];
+        if (rows_key >> 8) {
+          uint4* c4 = reinterpret_cast<uint4*>(v.color + (size_t)slot * kChunkVoxels);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) c4[k * 64 + lane] = make_uint4(0, 0, 0, 0);
+        }
+        if (v.hent[ent].alive) {  // (created by this list's acquire: a chunk that was parked before stayed parked)
+          const uint32_t ds = v.summ[slot];
+          if (ds != 0u) {
+            const uint32_t f999 = __float_as_uint(999.0f);
+            uint4* t4 = reinterpret_cast<uint4*>(v.tsdf + (size_t)slot * kChunkVoxels);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t4[k * 64 + lane] = make_uint4(f999, 0u, f999, 0u);
+          }
+          if (lane == 0) {
+            v.hent[ent].alive = 0;
+            if (ds != 0u) {
+              v.summ[slot] = 0u;
+              MeshRec* r = &v.mesh_rec[slot];
+              if (r->state & kMsInMap) { r->state = 0u; r->nv = 0; r->nt = 0; }
+            }
+          }
+        }
+        if (lane == 0) v.erase_epoch[slot] = fin_epoch + 1u;
+      }
+    }
   }
 }
 
@@ -1504,17 +1567,18 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
 }
 
 void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const float* poses12, float4* pre_scratch,
-                       float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s) {
+                       float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s, int acquire) {
   const IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);  // (resDiag does not depend on the flag)
   GroupPoses gp = {};
   for (int f = 0; f < n; ++f)
     for (int q = 0; q < 12; ++q) gp.P[f].p[q] = poses12[12 * f + q];
-  hipLaunchKernelGGL(k_pre_group, dim3(128, n + 1), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch, keyframe, 1);
+  hipLaunchKernelGGL(k_pre_group, dim3(128, n + 1 + (acquire ? 1 : 0)), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch,
+                     cen_scratch, keyframe, 1, acquire);
 }
 
 void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
                             float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s, bool have_pre,
-                            int32_t obs_kf) {
+                            int32_t obs_kf, int fin, uint32_t fin_epoch, int claim_par, uint32_t claim_stamp) {
   IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
   GroupArgs ga = {};
   GroupPoses gp = {};
@@ -1525,11 +1589,11 @@ void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_dep
     ga.pre[f] = pre_scratch + (size_t)f * 4 * v.max_list;
     ga.cen[f] = cen_scratch + (size_t)f * 3 * kChunkVoxels;
   }
-  if (!have_pre) hipLaunchKernelGGL(k_pre_group, dim3(128, n), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch, Pose{}, 0);
+  if (!have_pre) hipLaunchKernelGGL(k_pre_group, dim3(128, n), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch, Pose{}, 0, 0);
   static const int cus = device_cus();
   const dim3 grid(cus * 4), block(256);  // 36 KB of LDS per workgroup: four per CU
-  if (flag) hipLaunchKernelGGL(k_integrate_group<true>, grid, block, 0, s, v, ga, cam, kc, obs_kf);
-  else hipLaunchKernelGGL(k_integrate_group<false>, grid, block, 0, s, v, ga, cam, kc, obs_kf);
+  if (flag) hipLaunchKernelGGL(k_integrate_group<true>, grid, block, 0, s, v, ga, cam, kc, obs_kf, fin, fin_epoch, claim_par, claim_stamp);
+  else hipLaunchKernelGGL(k_integrate_group<false>, grid, block, 0, s, v, ga, cam, kc, obs_kf, fin, fin_epoch, claim_par, claim_stamp);
 }
 
 // One pipelined launch.  Any of the three stages may be absent (pipeline fill / drain):

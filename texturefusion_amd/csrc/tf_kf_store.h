@@ -37,46 +37,51 @@ struct KfStoreArgs {
   int slot, slack;
   uint32_t* fill;
 };
-// (1024 threads)
+// (one workgroup of NT threads, NT = 1024 or 256: the second form is the one that rides on the mesher's filter launch)
+template <int NT = 1024>
 __device__ __forceinline__ void kf_store_body(const VolumeDev& v, KfTab* tab, uint32_t slots, int4* arena, uint32_t cap, int slot,
                                               int slack, uint32_t* fill) {
+  constexpr int NW = NT / 64;                        // waves
+  constexpr uint32_t kStretch = (uint32_t)NT * 16u;  // entries per round of the workgroup: sixteen consecutive ones per thread
   const SelBuf& L = v.sel;
   uint32_t* const t_off = kf_off(tab);
   uint32_t* const t_n = t_off + slots;
   uint32_t* const t_capn = t_n + slots;
   uint32_t* const t_order = t_capn + slots;
   const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
-  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t wsum[NW];
   __shared__ uint32_t base;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // The flags of the first 16 384 entries as ballots (wave w: the 1024 consecutive entries from 1024 w, sixteen coalesced
-  // rounds) -- for a list that short (a room frame has 11 k) these ARE the count, and the compaction below reuses them;
-  // a longer list is counted with a strided pass.  Thread 0 fetches the table's header and the slot's record meanwhile,
-  // so that the serial part between the barriers is arithmetic on registers (it was a chain of ten dependent loads).
-  unsigned long long masks0[16];
-  uint32_t mine0 = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const uint32_t e = (uint32_t)w * 1024u + (uint32_t)r * 64u + (uint32_t)lane;
-    masks0[r] = __ballot(e < n && L.list_needs[e] != 0);
-    mine0 += (uint32_t)__popcll(masks0[r]);
-  }
+  // The flags of a thread's sixteen entries arrive as ONE 16-byte load (list_needs is a byte per entry, allocated with 16
+  // bytes of slack): a room list of 11 k entries is three loads per thread of a 256-thread workgroup, one of a 1024-thread
+  // one -- per-entry loads were a chain of round trips.  Thread 0 fetches the table's header and the slot's record
+  // meanwhile, so that the serial part between the barriers is arithmetic on registers.
+  const uint4* const flags4 = reinterpret_cast<const uint4*>(L.list_needs);
+  auto nz4 = [](const uint32_t x) -> uint32_t {
+    return ((x & 0xFFu) ? 1u : 0u) | ((x & 0xFF00u) ? 2u : 0u) | ((x & 0xFF0000u) ? 4u : 0u) | ((x & 0xFF000000u) ? 8u : 0u);
+  };
+  auto mask16 = [&](const uint32_t s0) -> uint32_t {  // bit k: entry s0 + 16 t + k is flagged
+    const uint32_t e0 = s0 + threadIdx.x * 16u;
+    if (e0 >= n) return 0u;
+    const uint4 f = flags4[e0 >> 4];
+    uint32_t m = nz4(f.x) | (nz4(f.y) << 4) | (nz4(f.z) << 8) | (nz4(f.w) << 12);
+    if (n - e0 < 16u) m &= (1u << (n - e0)) - 1u;
+    return m;
+  };
+  const uint32_t m0 = mask16(0u);
+  uint32_t cnt = (uint32_t)__popc(m0);
+  for (uint32_t s0 = kStretch; s0 < n; s0 += kStretch) cnt += (uint32_t)__popc(mask16(s0));
   KfTab h = {};
   uint32_t capn_s = 0, off_s = 0;
   if (threadIdx.x == 0) { h = *tab; capn_s = t_capn[slot]; off_s = t_off[slot]; }
-  uint32_t cnt = mine0;  // (wave-uniform)
-  if (n > 16384u) {
-    cnt = 0;
-    for (uint32_t e = threadIdx.x; e < n; e += 1024) cnt += L.list_needs[e] ? 1u : 0u;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
-  }
+  for (int o = 32; o >= 1; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
   if (lane == 0) wsum[w] = cnt;
   __syncthreads();
   __shared__ uint32_t s_tot, s_need, s_compact;
   if (threadIdx.x == 0) {
     uint32_t tot = 0;
-    for (int k = 0; k < 16; ++k) tot += wsum[k];
+    for (int k = 0; k < NW; ++k) tot += wsum[k];
     s_tot = tot;
     s_compact = 0;
     if (tot > h.max_tot) h.max_tot = tot;
@@ -105,7 +110,7 @@ __device__ __forceinline__ void kf_store_body(const VolumeDev& v, KfTab* tab, ui
     const uint32_t t = threadIdx.x;
     if (t == 0) s_live = 0;
     __syncthreads();
-    for (uint32_t k = t; k < slots; k += 1024u) {
+    for (uint32_t k = t; k < slots; k += (uint32_t)NT) {
       if (!t_capn[k]) continue;
       const uint32_t my_off = t_off[k];
       uint32_t below = 0;
@@ -122,7 +127,7 @@ __device__ __forceinline__ void kf_store_body(const VolumeDev& v, KfTab* tab, ui
       const uint32_t newcap = roomy < oldcap ? roomy : oldcap;
       __syncthreads();  // (every thread has read the region's old record)
       if (from != to) {
-        for (uint32_t b0 = 0; b0 < len; b0 += 1024u) {  // ascending, a block at a time: target <= source, they may overlap
+        for (uint32_t b0 = 0; b0 < len; b0 += (uint32_t)NT) {  // ascending, a block at a time: target <= source, they may overlap
           int4 val = make_int4(0, 0, 0, 0);
           if (b0 + t < len) val = arena[from + b0 + t];
           __syncthreads();
@@ -159,41 +164,30 @@ __device__ __forceinline__ void kf_store_body(const VolumeDev& v, KfTab* tab, ui
   }
   __syncthreads();
   if (base == 0xFFFFFFFFu) return;
-  // pass 2: ordered compaction in stretches of 16 384 entries -- wave w takes the 1024 consecutive entries
-  // [s0 + 1024 w, s0 + 1024 (w + 1)) as 16 coalesced rounds of 64 whose ballots stay in registers, ONE scan over the 16
-  // wave counts places the waves, and every flagged entry is written behind the flagged entries before it.  (Rounds of
-  // 1024 entries with three barriers each took 13.9 us per keyframe of the room stream, profiles/r4: a list of 11 k
-  // entries is one stretch here.)
-  __shared__ uint32_t wcnt[16];
-  uint32_t run = 0;  // flagged entries of the stretches before this one (block-uniform)
-  for (uint32_t s0 = 0; s0 < n; s0 += 16384u) {
-    const uint32_t w0 = s0 + (uint32_t)w * 1024u;
-    unsigned long long masks[16];
-    uint32_t mine = mine0;
-    if (s0 == 0) {
+  // pass 2: ordered compaction, a round of kStretch entries at a time -- every thread knows the flags of its sixteen
+  // consecutive entries, ONE scan over the threads' counts (shuffles within the wave, the wave totals through LDS) places
+  // them, and every flagged entry is written behind the flagged entries before it.
+  __shared__ uint32_t wcnt[NW];
+  uint32_t run = 0;  // flagged entries of the rounds before this one (block-uniform)
+  for (uint32_t s0 = 0; s0 < n; s0 += kStretch) {
+    const uint32_t m = s0 == 0u ? m0 : mask16(s0);
+    const uint32_t c = (uint32_t)__popc(m);
+    uint32_t incl = c;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) masks[r] = masks0[r];
-    } else {
-      mine = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const uint32_t e = w0 + (uint32_t)r * 64u + (uint32_t)lane;
-        masks[r] = __ballot(e < n && L.list_needs[e] != 0);
-        mine += (uint32_t)__popcll(masks[r]);
-      }
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= o) incl += u;
     }
-    __syncthreads();  // (wcnt of the previous stretch has been read)
-    if (lane == 0) wcnt[w] = mine;
+    __syncthreads();  // (wcnt of the previous round has been read)
+    if (lane == 63) wcnt[w] = incl;
     __syncthreads();
     uint32_t before = run, tot = 0;
-    for (int k = 0; k < 16; ++k) { if (k < w) before += wcnt[k]; tot += wcnt[k]; }
-    uint32_t at = base + before;
+    for (int k = 0; k < NW; ++k) { if (k < w) before += wcnt[k]; tot += wcnt[k]; }
+    uint32_t at = base + before + incl - c;
+    const uint32_t e0 = s0 + threadIdx.x * 16u;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const unsigned long long m = masks[r];
-      if ((m >> lane) & 1ull) arena[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = L.list_id[w0 + (uint32_t)r * 64u + (uint32_t)lane];
-      at += (uint32_t)__popcll(m);
-    }
+    for (int k = 0; k < 16; ++k)
+      if ((m >> k) & 1u) { arena[at] = L.list_id[e0 + (uint32_t)k]; at += 1u; }
     run += tot;
   }
 }

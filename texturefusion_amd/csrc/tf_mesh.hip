@@ -385,6 +385,9 @@ struct FilterPatch {
   // N > 1, exchange overlapped with the interior meshes: 0 = every entry, 1 = only chunks whose 27-neighbourhood is owned
   // (part_interior: nothing of their meshes waits for the ghosts), 2 = only the others
   uint32_t cls;
+  // the keyframe unit: workgroup 0 of the launch is not the filter's, it stores the finalized list of v.sel (kf_store_body)
+  uint32_t n_store;
+  KfStoreArgs store;
   Cam cam;
   KfDev kf;
 };
@@ -395,12 +398,17 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
                                                      uint32_t* __restrict__ cnt, uint32_t cap_sh, int ppar, bool use_summ,
                                                      uint32_t* __restrict__ len_hint, int shards_par, FilterPatch fp) {
-  if (PATCH && blockIdx.x - fp.first < fp.n_patch) {
-    patch_body<true, true, true>(v, fp.cam, fp.par, fp.kf, blockIdx.x - fp.first, fp.n_patch);
+  if (fp.n_store && blockIdx.x == 0) {  // (first: its chain of barriers is the launch's longest)
+    kf_store_body<256>(v, fp.store.tab, fp.store.slots, fp.store.arena, fp.store.cap, fp.store.slot, fp.store.slack, fp.store.fill);
     return;
   }
-  const uint32_t bid = PATCH ? (fp.first ? blockIdx.x : blockIdx.x - fp.n_patch) : blockIdx.x;   // the filter's own block index / grid
-  const uint32_t nblk = PATCH ? gridDim.x - fp.n_patch : gridDim.x;
+  const uint32_t bx = blockIdx.x - fp.n_store, nbx = gridDim.x - fp.n_store;
+  if (PATCH && bx - fp.first < fp.n_patch) {
+    patch_body<true, true, true>(v, fp.cam, fp.par, fp.kf, bx - fp.first, fp.n_patch);
+    return;
+  }
+  const uint32_t bid = PATCH ? (fp.first ? bx : bx - fp.n_patch) : bx;   // the filter's own block index / grid
+  const uint32_t nblk = PATCH ? nbx - fp.n_patch : nbx;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
   uint32_t n_flat = *dcount;
@@ -1002,7 +1010,7 @@ static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries,
 
 bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
                  uint32_t epoch, float res, bool fused, int rearm_set, uint32_t len_guess, uint32_t* len_hint, int shards_par,
-                 hipStream_t s, const PatchStage* patch, const Cam* cam, int cls) {
+                 hipStream_t s, const PatchStage* patch, const Cam* cam, int cls, const KfStoreArgs* store) {
   if (!max_entries) return false;
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshCntWords;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
@@ -1017,6 +1025,7 @@ bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   FilterPatch fp;
   memset(&fp, 0, sizeof(fp));
   fp.cls = (uint32_t)cls;
+  if (store) { fp.n_store = 1u; fp.store = *store; }
   if (patch && cam) {
     // one wave per patch; the range is dispatched AHEAD of the filter's workgroups (its chains are the longer ones)
     fp.defer = 1u;
@@ -1027,7 +1036,7 @@ bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
     fp.kf = patch->kf;
   }
 #define TF_LAUNCH_FILTER(W, P)                                                                                       \
-  hipLaunchKernelGGL((k_mesh_filter<W, P>), dim3(fgrid + fp.n_patch), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, \
+  hipLaunchKernelGGL((k_mesh_filter<W, P>), dim3(fgrid + fp.n_patch + fp.n_store), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, \
                      epoch, v.mesh_nbr, cnt, cap_sh, ppar, use_summ, len_hint, shards_par, fp)
   if (wave_form) { if (fp.n_patch) TF_LAUNCH_FILTER(true, true); else TF_LAUNCH_FILTER(true, false); }
   else { if (fp.n_patch) TF_LAUNCH_FILTER(false, true); else TF_LAUNCH_FILTER(false, false); }

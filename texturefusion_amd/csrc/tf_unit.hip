@@ -108,8 +108,10 @@ static int unit_state(tf_volume* v, UnitState** out) {
 // ReIntegrateKeyframe (MobileFusion.cpp:114-221) for one group with one flag
 // dirty_par >= 0: the group's updated chunks and their face neighbours join the work list of that parity right behind
 // the finalize (launch_dirty_frame over this list), stamped dirty_stamp -- instead of a scan of every chunk's mark later
+// ride_store != nullptr: the group's validChunks are not stored here -- *ride_store receives the arguments and the caller's
+// texture stage takes them along on its filter launch
 static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, int flag, int kf_slot, int dirty_par = -1,
-                           uint32_t dirty_stamp = 0) {
+                           uint32_t dirty_stamp = 0, KfStoreArgs* ride_store = nullptr) {
   hipStream_t s = v->stream;
   VolumeDev& d = v->dev;
   FrameImages img{g->keyframe.d_depth, reinterpret_cast<const uchar4*>(g->keyframe.d_rgba), g->keyframe.d_quality};
@@ -122,7 +124,7 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     v->frame_bound = true;
     // (validChunks = the finalized list in list order; no order of it is observable through this entry point, so the
     // list need not be the reference's: k_select + k_scan would cost 17 us per keyframe more)
-    int rc = launch_prepare_unordered(v, P, s);
+    int rc = launch_prepare_unordered(v, P, s, /*acquire=*/false);  // (the slots: one more row of the records launch below)
     if (rc) return rc;
   } else {
     hipLaunchKernelGGL(k_kf_load, dim3(256), dim3(256), 0, s, d, u->tab, u->slots, u->arena, kf_slot);
@@ -135,22 +137,28 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     dd[f] = g->local[f].d_depth;
     memcpy(poses + 12 * f, flag ? g->local[f].pose : g->old_local_pose[f], 48);
   }
-  launch_pre_frames(d, P, g->n_local, poses, u->group_pre, u->group_cen, v->ig, v->res, v->cam, s);
+  launch_pre_frames(d, P, g->n_local, poses, u->group_pre, u->group_cen, v->ig, v->res, v->cam, s,
+                    /*acquire=*/flag ? (g->n_local > 0 ? 2 : 1) : 0);  // (lazily when the group kernel finalizes the list)
   // the keyframe's own depth + colour (+ quality) ...
   const bool color = img.rgba != nullptr, quality = color && img.quality != nullptr;
   launch_integrate(d, img, v->cam, v->ig, P, v->res, flag, color, quality, 0, s, true);
   // chunk->observations[keyframeID] for BOTH flags (Chisel.h:244-247): recorded by the group kernel's waves ahead of their
   // own work, by a launch of its own when the group has no local frame
   // ... then its local frames depth-only over the same list, one visit per chunk
-  if (g->n_local > 0)
-    launch_integrate_group(d, g->n_local, dd, poses, u->group_pre, u->group_cen, v->cam, v->ig, v->res, flag, s, true, g->kf_id);
-  else
+  // FinalizeIntegrateChunks + GarbageCollect of the list, and (dirty_par >= 0) the dirty-set pass over it: the group
+  // kernel's waves, each behind its entry's last frame (k_finalize + k_dirty_frame were two launches, 7 + 9 us)
+  const bool folded = g->n_local > 0;
+  if (folded) {
+    launch_integrate_group(d, g->n_local, dd, poses, u->group_pre, u->group_cen, v->cam, v->ig, v->res, flag, s, true, g->kf_id,
+                           /*fin=*/1, v->epoch++, dirty_par, dirty_stamp);
+  } else {
     launch_obs_record(d, g->kf_id, s);
-  launch_finalize(d, v->epoch++, s);
+    launch_finalize(d, v->epoch++, s);
+  }
   const int slack = !(getenv("TF_UNIT_NO_SLACK") && atoi(getenv("TF_UNIT_NO_SLACK")));  // test knob (read per call): exact-fit regions
   const KfStoreArgs sa{u->tab, u->slots, u->arena, u->cap, kf_slot, slack, u->h_fill};
   bool stored = false;
-  if (dirty_par >= 0) {
+  if (dirty_par >= 0 && !folded) {
     VolumeDev dd = d;
     dd.work_ids = v->atlas.d_work_ids + (size_t)dirty_par * d.max_chunks;
     dd.work_slot = v->atlas.d_work_slot + (size_t)dirty_par * d.max_chunks;
@@ -158,7 +166,10 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     if (flag) { launch_dirty_frame_store(dd, dirty_par, dirty_stamp, sa, s); stored = true; }
     else launch_dirty_frame(dd, dirty_par, dirty_stamp, s);
   }
-  if (flag && !stored) hipLaunchKernelGGL(k_kf_store, dim3(1), dim3(1024), 0, s, d, sa);
+  if (flag && !stored) {
+    if (ride_store) *ride_store = sa;  // (with the texture stage's filter launch)
+    else hipLaunchKernelGGL(k_kf_store, dim3(1), dim3(1024), 0, s, d, sa);
+  }
   if (!flag) hipLaunchKernelGGL(k_kf_clear, dim3(1), dim3(1), 0, s, u->tab, u->slots, kf_slot);
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
@@ -278,17 +289,23 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
     if ((rc = integrate_group(v, u, &moved[m], 0, slot, dirty_par, dirty_stamp))) return rc;
     if ((rc = integrate_group(v, u, &moved[m], 1, slot, dirty_par, dirty_stamp))) return rc;
   }
+  KfStoreArgs ride_store{};
+  bool have_ride = false;
   if (fresh) {  // :316-323
     const int slot = slot_for(fresh->kf_id, true);
     if (slot < 0) return TF_ERR_HIP;  // (the table could not grow: hipMalloc's message is in tf_last_error)
-    if ((rc = integrate_group(v, u, fresh, 1, slot, dirty_par, dirty_stamp))) return rc;
+    if ((rc = integrate_group(v, u, fresh, 1, slot, dirty_par, dirty_stamp, texture ? &ride_store : nullptr))) return rc;
+    have_ride = texture != 0;
   }
   if (texture) {
     // UpdateMeshes over everything marked since the last CompressMeshes, CompressMeshes, GeneratePatches with the new
     // keyframe as the label of every chunk of chunksToUpdate, UpdateAtlas (the fused texture stage; its patch stage stays
     // pending like a streamed frame's and goes out with the next launch or the next call that looks)
     FrameImages img{fresh->keyframe.d_depth, reinterpret_cast<const uchar4*>(fresh->keyframe.d_rgba), nullptr};
-    return texture_stage(v, v->dev.sel, img, v->epoch - 1u, pose_inv16, fresh->kf_id, dirty_par >= 0, nullptr, true);
+    // (dirty_par >= 0: the set is in the lists of that parity -- shard lists from the group kernels, the flat list from groups
+    // without local frames; the filter walks both)
+    return texture_stage(v, v->dev.sel, img, v->epoch - 1u, pose_inv16, fresh->kf_id, dirty_par >= 0, nullptr, true, false, 0,
+                         have_ride ? &ride_store : nullptr);
   }
   // texture == 0: UpdateMeshes only (asynchronous).  The caller's tf_compress_meshes then returns chunksToUpdate, marks /
   // exchanges the adjacency flags and clears meshesToUpdate (MobileFusion.cpp:343-355), its view selection runs, and

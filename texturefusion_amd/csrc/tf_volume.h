@@ -259,17 +259,18 @@ namespace tf {
 int sync_status(tf_volume* v, uint32_t* n_tmp);
 int ensure_tmp(tf_volume* v, size_t bytes);
 int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hipStream_t s = nullptr);  // tf_capi.cpp
-int launch_prepare_unordered(tf_volume* v, const Pose& pose, hipStream_t s = nullptr);
+int launch_prepare_unordered(tf_volume* v, const Pose& pose, hipStream_t s = nullptr, bool acquire = true);
+struct KfStoreArgs;  // tf_kf_store.h
 // ride_filter: a patch stage still pending when the stage starts rides on its filter launch (the keyframe unit: there is
 // no k_frame launch for it to ride on) instead of going out as a launch of its own
 int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16,
                   int32_t frame_id, bool claimed = false, const FrameCtl* next_ctl = nullptr, bool ride_filter = false,
-                  bool sized_xchg = false, int phase = 0);  // sized_xchg: sel.ctl holds the frame's band counts (fused stream only)
+                  bool sized_xchg = false, int phase = 0,   // sized_xchg: sel.ctl holds the frame's band counts (fused stream only)
+                  const KfStoreArgs* store = nullptr);      // the keyframe unit: the list's validChunks store rides on the filter launch
 int texture_stage_finish(tf_volume* v, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16, int32_t frame_id, int par);
 // the four band counts of the frame whose selection wrote `ctl` (tag = its epoch + 1): waits for the device to publish them
 int xchg_band_counts(tf_volume* v, const FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]);
 int flush_deferred(tf_volume* v);
-struct KfStoreArgs;  // tf_kf_store.h
 void launch_dirty_frame_store(const VolumeDev& v, int par, uint32_t stamp, const KfStoreArgs& a, hipStream_t s);  // tf_mesh.hip
 int patch_flush(tf_volume* v);
 bool host_defer_default();  // !(TF_HOST_DEFER=0 in the environment)
