@@ -456,7 +456,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
     if ((rc = dev_alloc(v, &L.list_slot, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_ent, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_new, (size_t)d.max_list))) return fail(rc);
-    if ((rc = dev_alloc(v, &L.list_needs, (size_t)d.max_list + 16))) return fail(rc);  // (+16: kf_store_body reads the flags 16 at a time)
+    if ((rc = dev_alloc(v, &L.list_needs, (size_t)d.max_list + 64))) return fail(rc);  // (+64: kf_store_body reads the flags in 16-byte words, four per thread)
     if ((rc = dev_alloc(v, &L.list_quality, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_rows, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.cen, (size_t)3 * kChunkVoxels))) return fail(rc);

@@ -42,7 +42,8 @@ template <int NT = 1024>
 __device__ __forceinline__ void kf_store_body(const VolumeDev& v, KfTab* tab, uint32_t slots, int4* arena, uint32_t cap, int slot,
                                               int slack, uint32_t* fill) {
   constexpr int NW = NT / 64;                        // waves
-  constexpr uint32_t kStretch = (uint32_t)NT * 16u;  // entries per round of the workgroup: sixteen consecutive ones per thread
+  constexpr int E = 16384 / NT;          // consecutive entries per thread and round (16 or 64)
+  constexpr uint32_t kStretch = 16384u;  // entries per round of the workgroup (a room list -- 11 k -- is one round)
   const SelBuf& L = v.sel;
   uint32_t* const t_off = kf_off(tab);
   uint32_t* const t_n = t_off + slots;
@@ -52,25 +53,28 @@ __device__ __forceinline__ void kf_store_body(const VolumeDev& v, KfTab* tab, ui
   __shared__ uint32_t wsum[NW];
   __shared__ uint32_t base;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  // The flags of a thread's sixteen entries arrive as ONE 16-byte load (list_needs is a byte per entry, allocated with 16
-  // bytes of slack): a room list of 11 k entries is three loads per thread of a 256-thread workgroup, one of a 1024-thread
-  // one -- per-entry loads were a chain of round trips.  Thread 0 fetches the table's header and the slot's record
-  // meanwhile, so that the serial part between the barriers is arithmetic on registers.
+  // The flags of a thread's E entries arrive as E / 16 independent 16-byte loads (list_needs is a byte per entry, allocated
+  // with 64 bytes of slack) -- per-entry loads were a chain of round trips.  Thread 0 fetches the table's header and the
+  // slot's record meanwhile, so that the serial part between the barriers is arithmetic on registers.
   const uint4* const flags4 = reinterpret_cast<const uint4*>(L.list_needs);
-  auto nz4 = [](const uint32_t x) -> uint32_t {
-    return ((x & 0xFFu) ? 1u : 0u) | ((x & 0xFF00u) ? 2u : 0u) | ((x & 0xFF0000u) ? 4u : 0u) | ((x & 0xFF000000u) ? 8u : 0u);
+  auto nz4 = [](const uint32_t x) -> unsigned long long {
+    return ((x & 0xFFu) ? 1ull : 0ull) | ((x & 0xFF00u) ? 2ull : 0ull) | ((x & 0xFF0000u) ? 4ull : 0ull) | ((x & 0xFF000000u) ? 8ull : 0ull);
   };
-  auto mask16 = [&](const uint32_t s0) -> uint32_t {  // bit k: entry s0 + 16 t + k is flagged
-    const uint32_t e0 = s0 + threadIdx.x * 16u;
-    if (e0 >= n) return 0u;
-    const uint4 f = flags4[e0 >> 4];
-    uint32_t m = nz4(f.x) | (nz4(f.y) << 4) | (nz4(f.z) << 8) | (nz4(f.w) << 12);
-    if (n - e0 < 16u) m &= (1u << (n - e0)) - 1u;
-    return m;
+  auto mask_e = [&](const uint32_t s0) -> unsigned long long {  // bit k: entry s0 + E t + k is flagged
+    const uint32_t e0 = s0 + threadIdx.x * (uint32_t)E;
+    uint4 f[E / 16];
+#pragma unroll
+    for (int q = 0; q < E / 16; ++q) f[q] = (e0 + 16u * q < n) ? flags4[(e0 >> 4) + q] : make_uint4(0, 0, 0, 0);
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int q = 0; q < E / 16; ++q)
+      m |= (nz4(f[q].x) | (nz4(f[q].y) << 4) | (nz4(f[q].z) << 8) | (nz4(f[q].w) << 12)) << (16 * q);
+    if (e0 < n && n - e0 < (uint32_t)E) m &= (1ull << (n - e0)) - 1ull;
+    return e0 < n ? m : 0ull;
   };
-  const uint32_t m0 = mask16(0u);
-  uint32_t cnt = (uint32_t)__popc(m0);
-  for (uint32_t s0 = kStretch; s0 < n; s0 += kStretch) cnt += (uint32_t)__popc(mask16(s0));
+  const unsigned long long m0 = mask_e(0u);
+  uint32_t cnt = (uint32_t)__popcll(m0);
+  for (uint32_t s0 = kStretch; s0 < n; s0 += kStretch) cnt += (uint32_t)__popcll(mask_e(s0));
   KfTab h = {};
   uint32_t capn_s = 0, off_s = 0;
   if (threadIdx.x == 0) { h = *tab; capn_s = t_capn[slot]; off_s = t_off[slot]; }
@@ -164,14 +168,14 @@ __device__ __forceinline__ void kf_store_body(const VolumeDev& v, KfTab* tab, ui
   }
   __syncthreads();
   if (base == 0xFFFFFFFFu) return;
-  // pass 2: ordered compaction, a round of kStretch entries at a time -- every thread knows the flags of its sixteen
-  // consecutive entries, ONE scan over the threads' counts (shuffles within the wave, the wave totals through LDS) places
-  // them, and every flagged entry is written behind the flagged entries before it.
+  // pass 2: ordered compaction, a round of kStretch entries at a time -- every thread knows the flags of its E consecutive
+  // entries, ONE scan over the threads' counts (shuffles within the wave, the wave totals through LDS) places them, and
+  // every flagged entry is written behind the flagged entries before it.
   __shared__ uint32_t wcnt[NW];
   uint32_t run = 0;  // flagged entries of the rounds before this one (block-uniform)
   for (uint32_t s0 = 0; s0 < n; s0 += kStretch) {
-    const uint32_t m = s0 == 0u ? m0 : mask16(s0);
-    const uint32_t c = (uint32_t)__popc(m);
+    const unsigned long long m = s0 == 0u ? m0 : mask_e(s0);
+    const uint32_t c = (uint32_t)__popcll(m);
     uint32_t incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -184,10 +188,10 @@ __device__ __forceinline__ void kf_store_body(const VolumeDev& v, KfTab* tab, ui
     uint32_t before = run, tot = 0;
     for (int k = 0; k < NW; ++k) { if (k < w) before += wcnt[k]; tot += wcnt[k]; }
     uint32_t at = base + before + incl - c;
-    const uint32_t e0 = s0 + threadIdx.x * 16u;
+    const uint32_t e0 = s0 + threadIdx.x * (uint32_t)E;
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if ((m >> k) & 1u) { arena[at] = L.list_id[e0 + (uint32_t)k]; at += 1u; }
+    for (int k = 0; k < E; ++k)
+      if ((m >> k) & 1ull) { arena[at] = L.list_id[e0 + (uint32_t)k]; at += 1u; }
     run += tot;
   }
 }
