@@ -377,7 +377,9 @@ void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_dep
                             float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s,
                             bool have_pre = false, int32_t obs_kf = -1,  // obs_kf >= 0: also tf_observations_record of the keyframe
                             int fin = 0, uint32_t fin_epoch = 0,         // fin: also launch_finalize(fin_epoch)
-                            int claim_par = -1, uint32_t claim_stamp = 0);  // (with fin) claim_par >= 0: also the dirty-set pass, into the shard lists
+                            int claim_par = -1, uint32_t claim_stamp = 0,  // (with fin) claim_par >= 0: also the dirty-set pass, into the shard lists
+                            const FrameImages* key_img = nullptr, const Pose* key_pose = nullptr);  // the keyframe's own depth + colour pass first
+                                                                                                   // (its records: the list's, launch_pre_frames)
 uint32_t mesh_shard_rows(uint32_t max_chunks);
 // len_guess: the list length as far as the host knows (picks the filter's form); len_hint: host-visible word that
 // receives the actual length (may be null)

@@ -1268,9 +1268,19 @@ __global__ __launch_bounds__(256) void k_pre_group(VolumeDev v, GroupPoses gp, I
 // :472-477, with epoch fin_epoch) -- each wave finishes its entry behind its last frame, when the entry's needsUpdate flag
 // (the keyframe's call | this visit) is final, as K-A does in a stream (7 us of launch per group less); claim_par >= 0: and the
 // dirty-set pass over the list (k_dirty_frame), into the shard lists of that parity
-template <bool FLAG>
+// KEY: the visit starts with the KEYFRAME's own depth + colour pass over the entry (k_integrate<COLOR, no quality image, FLAG>,
+// operation for operation: ProjectionIntegrator.cpp:74-341 with the colour band of :202-304) -- its TSDF rows stay in the
+// registers the local frames then work on, instead of a launch of its own that writes them and this one reading them
+// back (31 us of a keyframe's 211).  Its centroids are computed per lane (centroid_table's expression; the workgroup's LDS
+// holds the six local frames' tables), its records are the list's own (k_pre_group's keyframe row).
+struct GroupKey {
+  FrameImages img;  // the keyframe's depth + colour
+  Pose P;           // its pose (centroids)
+};
+template <bool FLAG, bool KEY>
 __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs ga, Cam cam, IntegrateConsts kc, int32_t obs_kf,
-                                                         int fin, uint32_t fin_epoch, int claim_par, uint32_t claim_stamp) {
+                                                         int fin, uint32_t fin_epoch, int claim_par, uint32_t claim_stamp,
+                                                         GroupKey key) {
   const SelBuf& L = v.sel;
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
@@ -1298,7 +1308,7 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
     if (!part_owned(v, id.x, id.y, id.z)) continue;
     const uint32_t slot = L.list_slot[e];
     if (slot == kInvalidSlot) continue;
-    if (obs_kf >= 0 && lane == 0) {
+    if (!KEY && obs_kf >= 0 && lane == 0) {
       const float q = L.list_quality[e];
       if (q > 0.0f && L.list_needs[e]) {
         const uint32_t at = obs_find(v, obs_pack(slot, obs_kf), true);
@@ -1312,6 +1322,171 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
     for (int j = 0; j < 8; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, (j * 64 + lane) * 8, 0, 0);
     uint32_t dirty_rows = 0;   // bit j: the lane's row of slice j was rewritten by some frame
     uint32_t rows_total = 0;
+    uint32_t key_rows_t = 0, key_rows_c = 0;  // rows the keyframe's pass rewrote (wave-uniform)
+    if (KEY) {
+      const float4 r0 = L.list_pre[4 * e], r1 = L.list_pre[4 * e + 1];
+      const float o0 = r0.x, o1 = r0.y, o2 = r0.z, pbx = r0.w, upper = r1.x;
+      const f32x2 o01 = {o0, o1};
+      const float wD = FLAG ? pbx : -pbx;
+      const float band = 32.0f * kc.res;
+      const bool div_safe = (fabsf(o2) > band) && (fabsf(o2) < 1048576.0f) && (fabsf(o0) < 1048576.0f) &&
+                            (fabsf(o1) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
+      const __amdgpu_buffer_rsrc_t rs_depth =
+          __builtin_amdgcn_make_buffer_rsrc((void*)key.img.depth, 0, W * H * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_rgba =
+          __builtin_amdgcn_make_buffer_rsrc((void*)key.img.rgba, 0, W * H * 4, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_C =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+      // centroid of the lane's voxel of slice j, axis a: centroid_table's expression
+      const float khalf = kc.res * 0.5f;
+      const float fx = (float)(lane & 7), fy = (float)vy;
+      float qx[3], qy[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) { qx[a] = key.P.p[a] * fx; qy[a] = key.P.p[4 + a] * fy; }
+      auto cen = [&](const int a, const int j) -> float {
+        const float q2 = key.P.p[8 + a] * (float)j;
+        const float s12 = qy[a] + q2;
+        const float d = qx[a] + s12;
+        return d * kc.res + khalf;
+      };
+      int off_d[8];
+      unsigned long long vm[8];
+      uint32_t R = 64, oob_bits = 0;
+      int oob_any = 0;
+      auto geometry = [&](auto safe_tag) {
+        constexpr bool SAFE = decltype(safe_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const f32x2 pxy = o01 + (f32x2){cen(0, j), cen(1, j)};
+          const float pzv = o2 + cen(2, j);
+          f32x2 q;
+          if (SAFE) {
+            q = div2_by(pxy, recip_refined(pzv));
+          } else {
+            q.x = pxy.x / pzv;
+            q.y = pxy.y / pzv;
+          }
+          const f32x2 uw = q * fxy + cxy;
+          const int X = SAFE ? cvt_rne_hw(uw.x) : cvt_sat_rne(uw.x);
+          const int Y = SAFE ? cvt_rne_hw(uw.y) : cvt_sat_rne(uw.y);
+          const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
+          vm[j] = ballot(valid);
+          int od = (__mul24(Y, W) + X) * 4;
+          asm volatile("" : "+v"(od));
+          off_d[j] = valid ? od : kOOB;
+          // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220); implies !valid
+          oob_bits |= (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1))) ? (1u << j) : 0u;
+        }
+      };
+      if (div_safe) geometry(std::true_type{});
+      else geometry(std::false_type{});
+      unsigned long long all_valid = ~0ull;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) all_valid &= vm[j];
+      if (all_valid != ~0ull) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (R == 64u) {
+            const unsigned long long dead = nonzero_bytes(vm[j]) ^ 0x0101010101010101ull;
+            if (dead) R = (uint32_t)(j * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
+          }
+          const bool live_lane = (uint32_t)(j * 8 + vy) < R;
+          oob_any |= (live_lane && ((oob_bits >> j) & 1u)) ? 1 : 0;  // off-image lanes of processed rows only
+          off_d[j] = live_lane ? off_d[j] : kOOB;
+        }
+      }
+      float dep[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j], 0, 0));
+      // TSDF rows, in the registers the local frames continue with
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if ((uint32_t)(j * 8) >= R) break;  // a stalled row ends the chunk
+        const float d = dep[j];
+        const float sd = d - (o2 + cen(2, j));
+        const bool act = (uint32_t)(j * 8 + vy) < R;
+        const bool dv = (d > cam.nearP) && (cam.farP > d);
+        const bool inside = (sd > kc.lower) && (upper > sd);
+        const bool F = act && dv && inside;
+        const float nw = F ? wD : 0.0f;
+        const bool rf_l = row_any(ballot(F));
+        key_rows_t += (uint32_t)__popcll(ballot(rf_l)) >> 3;
+        if (rf_l) {
+          const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);
+          const float num = ts * tw + sd * nw;
+          const float den = (tw + nw) + kc.sigma;
+          const float ns = num / den;
+          const float nwt = tw + nw;
+          const bool keep = nwt > 0.5f;
+          t[j].x = __float_as_uint(keep ? ns : 999.0f);
+          t[j].y = __float_as_uint(keep ? nwt : 0.0f);
+          dirty_rows |= 1u << j;
+        }
+      }
+      // colour band (-thr < sd < thr, :202-208): which colour rows are rewritten, which pixels feed them -- four slices at
+      // a time (eight would hold 40 registers across the loads)
+      uint32_t lanes_c = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int off_c[4], off_i[4];
+        unsigned long long any_c = 0ull;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = h * 4 + jj;
+          const float sd = dep[j] - (o2 + cen(2, j));
+          const bool upd = (off_d[j] != kOOB) && (fabsf(sd) < kc.thrCol);  // (rows behind a stalled row: off_d is kOOB)
+          off_i[jj] = upd ? off_d[j] : kOOB;
+          const bool ru_l = row_any(ballot(upd));
+          const unsigned long long ru = ballot(ru_l);
+          off_c[jj] = ru_l ? (j * 64 + lane) * 8 : kOOB;
+          lanes_c += (uint32_t)__popcll(ru);
+          any_c |= ru;
+        }
+        if (any_c == 0ull) continue;
+        u32x2 c[4];
+        uint32_t in[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          c[jj] = __builtin_amdgcn_raw_buffer_load_b64(rs_C, off_c[jj], 0, 0);
+          in[jj] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[jj], 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          // colour planes are 4 x u16 {r, g, b, count} per voxel = two packed-u16 dwords (integrate_body, phase 5a)
+          const uint32_t p_rg = __builtin_amdgcn_perm(0u, in[jj], 0x0c010c00u);
+          const uint32_t p_ba = __builtin_amdgcn_perm(0u, in[jj], 0x0c030c02u);
+          const uint32_t w_rg = c[jj].x, w_ba = c[jj].y;
+          const u16x2 in_rg = __builtin_bit_cast(u16x2, p_rg), in_ba = __builtin_bit_cast(u16x2, p_ba);
+          u16x2 c_rg = __builtin_bit_cast(u16x2, w_rg), c_ba = __builtin_bit_cast(u16x2, w_ba);
+          if (FLAG) {  // (:274-292)
+            c_rg += in_rg;
+            c_ba += in_ba;
+            const bool halve = (int)__builtin_bit_cast(uint32_t, c_ba) >= (121 << 16);
+            const u16x2 h_rg = c_rg >> (unsigned short)2, h_ba = c_ba >> (unsigned short)2;
+            c_rg = halve ? h_rg : c_rg;
+            c_ba = halve ? h_ba : c_ba;
+          } else {     // (:293-304)
+            c_rg -= in_rg;
+            c_ba -= in_ba;
+          }
+          c[jj].x = __builtin_bit_cast(uint32_t, c_rg);
+          c[jj].y = __builtin_bit_cast(uint32_t, c_ba);
+          __builtin_amdgcn_raw_buffer_store_b64(c[jj], rs_C, off_c[jj], 0, 0);
+        }
+      }
+      key_rows_c = lanes_c >> 3;
+      // without a quality image nothing is ever added to observationQualitySum: it ends as the out-of-observation
+      // constant iff any processed row had an off-image lane (:221-222)
+      const float qsum = (ballot(oob_any != 0) != 0ull) ? kc.qoob : 0.0f;
+      if (lane == 0) {
+        L.list_quality[e] = qsum;
+        if (obs_kf >= 0 && qsum > 0.0f && key_rows_t != 0u) {  // chunk->observations[keyframe] (Chisel.h:244-247)
+          const uint32_t at = obs_find(v, obs_pack(slot, obs_kf), true);
+          if (at != kInvalidSlot) v.obs_q[at] = qsum;
+        }
+      }
+    }
     for (int f = 0; f < ga.n; ++f) {
       const float4 r0 = ga.pre[f][4 * e], r1 = ga.pre[f][4 * e + 1];
       const float o0 = r0.x, o1 = r0.y, o2 = r0.z, pbx = r0.w, pby = r1.x;
@@ -1404,13 +1579,13 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
     }
     word = wave_or(word);
     if (lane == 0 && word) atomicOr(&v.summ[slot], word);
-    const bool updated = rows_total != 0;
+    const bool updated = (rows_total | key_rows_t) != 0;
     if (updated && lane == 0) {
       L.list_needs[e] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
       if (part_band(v, id.x, id.y, id.z)) v.hent[L.list_ent[e]].alive = 3u;  // multi-GPU: touched since the last exchange
     }
-    const uint32_t rows_key = fin ? (uint32_t)L.list_rows[e] : 0u;  // the keyframe's own pass: rows_t | rows_c << 8
-    if (lane == 0) L.list_rows[e] = (uint16_t)(rows_total < 255u ? rows_total : 255u);  // (statistic; saturates)
+    const uint32_t rows_key = KEY ? (key_rows_c << 8) : (fin ? (uint32_t)L.list_rows[e] : 0u);  // the keyframe's own pass: rows_t | rows_c << 8
+    if (lane == 0) L.list_rows[e] = (uint16_t)(rows_total + key_rows_t < 255u ? rows_total + key_rows_t : 255u);  // (statistic; saturates)
     if (fin) {
       const bool isnew = L.list_new[e] != 0;
       if (updated || L.list_needs[e]) {
@@ -1578,7 +1753,8 @@ void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const fl
 
 void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
                             float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s, bool have_pre,
-                            int32_t obs_kf, int fin, uint32_t fin_epoch, int claim_par, uint32_t claim_stamp) {
+                            int32_t obs_kf, int fin, uint32_t fin_epoch, int claim_par, uint32_t claim_stamp,
+                            const FrameImages* key_img, const Pose* key_pose) {
   IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
   GroupArgs ga = {};
   GroupPoses gp = {};
@@ -1592,8 +1768,13 @@ void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_dep
   if (!have_pre) hipLaunchKernelGGL(k_pre_group, dim3(128, n), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch, Pose{}, 0, 0);
   static const int cus = device_cus();
   const dim3 grid(cus * 4), block(256);  // 36 KB of LDS per workgroup: four per CU
-  if (flag) hipLaunchKernelGGL(k_integrate_group<true>, grid, block, 0, s, v, ga, cam, kc, obs_kf, fin, fin_epoch, claim_par, claim_stamp);
-  else hipLaunchKernelGGL(k_integrate_group<false>, grid, block, 0, s, v, ga, cam, kc, obs_kf, fin, fin_epoch, claim_par, claim_stamp);
+  GroupKey key = {};
+  if (key_img) { key.img = *key_img; key.P = *key_pose; }
+#define TF_LAUNCH_GROUP(F, K) \
+  hipLaunchKernelGGL((k_integrate_group<F, K>), grid, block, 0, s, v, ga, cam, kc, obs_kf, fin, fin_epoch, claim_par, claim_stamp, key)
+  if (key_img) { if (flag) TF_LAUNCH_GROUP(true, true); else TF_LAUNCH_GROUP(false, true); }
+  else { if (flag) TF_LAUNCH_GROUP(true, false); else TF_LAUNCH_GROUP(false, false); }
+#undef TF_LAUNCH_GROUP
 }
 
 // One pipelined launch.  Any of the three stages may be absent (pipeline fill / drain):

@@ -139,9 +139,12 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
   }
   launch_pre_frames(d, P, g->n_local, poses, u->group_pre, u->group_cen, v->ig, v->res, v->cam, s,
                     /*acquire=*/flag ? (g->n_local > 0 ? 2 : 1) : 0);  // (lazily when the group kernel finalizes the list)
-  // the keyframe's own depth + colour (+ quality) ...
+  // the keyframe's own depth + colour (+ quality) ...  With local frames behind it and no quality image the pass is the
+  // first frame of the group kernel's visit (k_integrate_group<., KEY>), not a launch of its own.
   const bool color = img.rgba != nullptr, quality = color && img.quality != nullptr;
-  launch_integrate(d, img, v->cam, v->ig, P, v->res, flag, color, quality, 0, s, true);
+  static const bool key_fold_off = getenv("TF_UNIT_KEY_LAUNCH") && atoi(getenv("TF_UNIT_KEY_LAUNCH"));  // A/B: the keyframe's pass as its own launch
+  const bool key_in_group = g->n_local > 0 && color && !quality && !key_fold_off;
+  if (!key_in_group) launch_integrate(d, img, v->cam, v->ig, P, v->res, flag, color, quality, 0, s, true);
   // chunk->observations[keyframeID] for BOTH flags (Chisel.h:244-247): recorded by the group kernel's waves ahead of their
   // own work, by a launch of its own when the group has no local frame
   // ... then its local frames depth-only over the same list, one visit per chunk
@@ -150,7 +153,7 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
   const bool folded = g->n_local > 0;
   if (folded) {
     launch_integrate_group(d, g->n_local, dd, poses, u->group_pre, u->group_cen, v->cam, v->ig, v->res, flag, s, true, g->kf_id,
-                           /*fin=*/1, v->epoch++, dirty_par, dirty_stamp);
+                           /*fin=*/1, v->epoch++, dirty_par, dirty_stamp, key_in_group ? &img : nullptr, key_in_group ? &P : nullptr);
   } else {
     launch_obs_record(d, g->kf_id, s);
     launch_finalize(d, v->epoch++, s);
