@@ -29,17 +29,22 @@ def _oracle_group(ov, kf_id, key, local, flag, ids=None):
     return ov.finalize(ids, needs, new)
 
 
-def test_keyframe_unit_with_a_moved_keyframe(gpu_required):
+@pytest.mark.parametrize("with_q", [True, False])
+def test_keyframe_unit_with_a_moved_keyframe(gpu_required, with_q):
+    """with_q = False: keyframes without a quality image -- their own depth + colour pass then runs as the first frame of
+    the group kernel's visit (k_integrate_group<., KEY>) instead of a launch of its own"""
     cam = synth.Camera()
     ov = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
     gv = capi.Volume(RES5, cam, max_chunks=1 << 16)
     oa = O.Atlas(RES5)
     fr = [synth.room_frame(k, cam, with_quality=True) for k in range(12)]
-    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1]), HipBuffer(f[2].nbytes).from_host(f[2]))
-            for f in fr]
+    if not with_q:
+        fr = [(f[0], f[1], None, f[3]) for f in fr]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1]),
+             HipBuffer(f[2].nbytes).from_host(f[2]) if with_q else None) for f in fr]
 
     def dev_key(k, pose):
-        return (bufs[k][0].ptr, bufs[k][1].ptr, bufs[k][2].ptr, pose)
+        return (bufs[k][0].ptr, bufs[k][1].ptr, bufs[k][2].ptr if with_q else None, pose)
 
     # ---- keyframe 5 = frame 0 with local frames 1..3; textured with itself
     A_loc = [1, 2, 3]
@@ -59,7 +64,7 @@ def test_keyframe_unit_with_a_moved_keyframe(gpu_required):
     gA2 = capi.Volume.unit_group(5, dev_key(0, newA[0]), [(bufs[k][0].ptr, newA[1 + i]) for i, k in enumerate(A_loc)],
                                  old_keyframe_pose=fr[0][3], old_local_poses=[fr[k][3] for k in A_loc])
     gv.keyframe_unit(fresh=gB, moved=[gA2], texture=True, pose_inv16=synth.pose_inverse16(fr[6][3]))
-    assert ov.retract_observations(5, validA) > 0
+    assert ov.retract_observations(5, validA) > 0 or not with_q  # (no quality image: no observation is ever recorded)
     _oracle_group(ov, 5, fr[0], [(fr[k][0], fr[k][3]) for k in A_loc], 0, ids=validA)
     movedA = (fr[0][0], fr[0][1], fr[0][2], newA[0])
     _oracle_group(ov, 5, movedA, [(fr[k][0], newA[1 + i]) for i, k in enumerate(A_loc)], 1)
@@ -80,7 +85,8 @@ def test_keyframe_unit_with_a_moved_keyframe(gpu_required):
         want[i] = [obs.get(9, 0.0), obs.get(5, 0.0), obs.get(7, 0.0)]
     got = gv.export_datacost(oids, 9, [5, 7])
     assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
-    assert (want[:, 0] > 0).sum() > 500 and (want[:, 1] > 0).sum() > 500
+    if with_q:
+        assert (want[:, 0] > 0).sum() > 500 and (want[:, 1] > 0).sum() > 500
     # ---- meshes, patches, atlas
     mids = sorted_ids(ov.list_meshes())
     assert np.array_equal(mids, sorted_ids(gv.list_meshes())) and len(mids) > 300
@@ -107,7 +113,8 @@ def test_keyframe_unit_with_a_moved_keyframe(gpu_required):
     assert len(gv.dirty()) == 0 and len(ov.dirty()) == 0
     for t in bufs:
         for b in t:
-            b.free()
+            if b is not None:
+                b.free()
     gv.close()
 
 
@@ -266,20 +273,23 @@ def test_keyframe_arena_doubles_when_the_live_lists_fill_it(gpu_required, monkey
         p[0].free(); p[1].free()
 
 
+@pytest.mark.parametrize("with_q", [True, False])
 @pytest.mark.parametrize("n_local", [0, 1, 6])
-def test_keyframe_groups_of_every_size(gpu_required, n_local):
+def test_keyframe_groups_of_every_size(gpu_required, n_local, with_q):
     """a keyframe alone (no local frame), with one, and with the maximum of six (integrateLocalFrameNum): TSDF-only unit
     calls (texture = 0) against the oracle's ReIntegrateKeyframe, two keyframes in a row"""
     cam = synth.Camera()
     ov = O.Volume(RES5, O.camera_from(cam), O.default_integrator())
     gv = capi.Volume(RES5, cam, max_chunks=1 << 16)
     fr = [synth.room_frame(k, cam, with_quality=True) for k in range(2 * (1 + n_local))]
-    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1]), HipBuffer(f[2].nbytes).from_host(f[2]))
-            for f in fr]
+    if not with_q:
+        fr = [(f[0], f[1], None, f[3]) for f in fr]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1]),
+             HipBuffer(f[2].nbytes).from_host(f[2]) if with_q else None) for f in fr]
     for g in range(2):
         k0 = g * (1 + n_local)
         loc = list(range(k0 + 1, k0 + 1 + n_local))
-        grp = capi.Volume.unit_group(20 + g, (bufs[k0][0].ptr, bufs[k0][1].ptr, bufs[k0][2].ptr, fr[k0][3]),
+        grp = capi.Volume.unit_group(20 + g, (bufs[k0][0].ptr, bufs[k0][1].ptr, bufs[k0][2].ptr if with_q else None, fr[k0][3]),
                                      [(bufs[k][0].ptr, fr[k][3]) for k in loc])
         gv.keyframe_unit(fresh=grp, texture=False)
         _oracle_group(ov, 20 + g, fr[k0], [(fr[k][0], fr[k][3]) for k in loc], 1)
@@ -290,5 +300,6 @@ def test_keyframe_groups_of_every_size(gpu_required, n_local):
     assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
     for b in bufs:
         for x in b:
-            x.free()
+            if x is not None:
+                x.free()
     gv.close()
