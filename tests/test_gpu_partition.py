@@ -666,3 +666,62 @@ def test_phase_two_without_phase_one_is_refused(gpu_required):
     v.sync()
     assert len(v.list_meshes()) >= 0
     v.close(); d.free(); c.free()
+
+
+@pytest.mark.parametrize("n_local", [0, 3])
+def test_keyframe_unit_two_partitions_equal_one(gpu_required, n_local):
+    """tf_keyframe_unit_device on two slabs of the chunk-range partition (TSDF-only calls, the band records exchanged by
+    hand between the calls): the keyframe's own pass inside the group kernel (no quality image, local frames behind it),
+    the lazy slot lookup, the finalize and the band flags it leaves for the pack -- the union of the slabs and every ghost
+    copy must carry the single volume's voxels bit for bit, and the same chunks must be dirty."""
+    cam = synth.Camera()
+    axis, split = (1, 1, 1), 35
+    single = capi.Volume(RES5, cam, max_chunks=1 << 16)
+    parts = [capi.Volume(RES5, cam, max_chunks=1 << 16), capi.Volume(RES5, cam, max_chunks=1 << 16)]
+    parts[0].set_partition(-(1 << 31), split, axis)
+    parts[1].set_partition(split, (1 << 31) - 1, axis)
+    cap = 4096
+    xb = [HipBuffer(cap * capi.TF_BOUNDARY_RECORD_BYTES) for _ in range(2)]
+    per = 1 + n_local
+    frames = [synth.room_frame(2 * k, cam, with_quality=False) for k in range(3 * per)]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+    for g in range(3):
+        k0 = g * per
+        grp = capi.Volume.unit_group(40 + g, (bufs[k0][0].ptr, bufs[k0][1].ptr, None, frames[k0][3]),
+                                     [(bufs[k][0].ptr, frames[k][3]) for k in range(k0 + 1, k0 + per)])
+        for v in [single] + parts:
+            v.keyframe_unit(fresh=grp, texture=False)
+            v.sync()
+        n = [parts[r].boundary_pack(xb[r].ptr, cap) for r in range(2)]
+        assert n[0] > 0 and n[1] > 0
+        parts[0].boundary_unpack(xb[1].ptr, n[1])
+        parts[1].boundary_unpack(xb[0].ptr, n[0])
+        for v in parts:
+            v.sync()
+    ref_ids = sorted_ids(single.list_chunks())
+    assert len(ref_ids) > 1500
+    s_ref, w_ref, c_ref = single.get_chunks(ref_ids)
+    key = {tuple(c): i for i, c in enumerate(ref_ids)}
+    seen = set()
+    for r, v in enumerate(parts):
+        ids = v.list_chunks()
+        lo, hi = (-(1 << 31), split) if r == 0 else (split, (1 << 31) - 1)
+        s, w, c = v.get_chunks(ids)
+        for i, cid in enumerate(ids):
+            t = tuple(int(x) for x in cid)
+            if lo <= int(np.dot(cid.astype(np.int64), axis)) < hi:
+                assert t in key, "partition %d holds a chunk the single volume does not" % r
+                seen.add(t)
+            if t in key:  # owned chunks and ghost copies both carry the reference state
+                j = key[t]
+                assert np.array_equal(s[i].view(np.uint32), s_ref[j].view(np.uint32)), (r, t)
+                assert np.array_equal(w[i].view(np.uint32), w_ref[j].view(np.uint32)), (r, t)
+                assert np.array_equal(c[i], c_ref[j]), (r, t)
+    assert seen == set(key)
+    dirty = set(map(tuple, single.dirty()))
+    dparts = set(map(tuple, parts[0].dirty())) | set(map(tuple, parts[1].dirty()))
+    assert dirty == dparts and len(dirty) > 1000
+    for v in [single] + parts:
+        v.close()
+    for b in xb + [x for p in bufs for x in p]:
+        b.free()
