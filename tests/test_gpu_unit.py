@@ -303,3 +303,99 @@ def test_keyframe_groups_of_every_size(gpu_required, n_local, with_q):
             if x is not None:
                 x.free()
     gv.close()
+
+
+def run_unit_sequence(cam, res, frames, plan, with_q, max_chunks=1 << 17, stride=5):
+    """A sequence of tf_keyframe_unit_device calls against the oracle driven call by call.  frames[k] = (depth, rgba,
+    quality, pose); plan = [(kf_id, key_frame_index, [local frame indices], [(moved kf_id, pose shift)])]: every call
+    integrates one new keyframe group, textured with its keyframe, and first moves the listed earlier keyframes -- their
+    frames take the poses of the frames `shift` further along.  Compared at the end: chunk set, voxels (every stride-th
+    chunk), observations, meshes, patches and the atlas fill.  Returns the number of meshes."""
+    ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(res, cam, max_chunks=max_chunks)
+    oa = O.Atlas(res)
+    if not with_q:
+        frames = [(f[0], f[1], None, f[3]) for f in frames]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1]),
+             HipBuffer(f[2].nbytes).from_host(f[2]) if with_q else None) for f in frames]
+
+    def dev_key(k, pose):
+        return (bufs[k][0].ptr, bufs[k][1].ptr, bufs[k][2].ptr if with_q else None, pose)
+
+    state = {}  # kf_id -> {key, loc, poses (current), valid (oracle's validChunks)}
+    kfs = {}
+    for kf_id, key, loc, moves in plan:
+        moved = []
+        for mid, shift in moves:
+            st = state[mid]
+            idx = [st["key"]] + st["loc"]
+            newp = [frames[min(k + shift, len(frames) - 1)][3] for k in idx]
+            moved.append(capi.Volume.unit_group(mid, dev_key(st["key"], newp[0]),
+                                                [(bufs[k][0].ptr, newp[1 + i]) for i, k in enumerate(st["loc"])],
+                                                old_keyframe_pose=st["poses"][0], old_local_poses=st["poses"][1:]))
+            # oracle: retract, de-integrate at the old poses over the stored validChunks, integrate at the new ones
+            ov.retract_observations(mid, st["valid"])
+            fk = frames[st["key"]]
+            _oracle_group(ov, mid, (fk[0], fk[1], fk[2], st["poses"][0]),
+                          [(frames[k][0], st["poses"][1 + i]) for i, k in enumerate(st["loc"])], 0, ids=st["valid"])
+            st["valid"] = _oracle_group(ov, mid, (fk[0], fk[1], fk[2], newp[0]),
+                                        [(frames[k][0], newp[1 + i]) for i, k in enumerate(st["loc"])], 1)
+            st["poses"] = newp
+        fresh = capi.Volume.unit_group(kf_id, dev_key(key, frames[key][3]), [(bufs[k][0].ptr, frames[k][3]) for k in loc])
+        T = synth.pose_inverse16(frames[key][3])
+        gv.keyframe_unit(fresh=fresh, moved=moved, texture=True, pose_inv16=T)
+        valid = _oracle_group(ov, kf_id, frames[key], [(frames[k][0], frames[k][3]) for k in loc], 1)
+        state[kf_id] = dict(key=key, loc=list(loc), poses=[frames[key][3]] + [frames[k][3] for k in loc], valid=valid)
+        ov.update_meshes()
+        ids = ov.compress_meshes()
+        kfs[kf_id] = (np.ascontiguousarray(frames[key][1][..., :3]), frames[key][0], T)
+        ov.generate_patches(oa, ids, np.full(len(ids), kf_id, np.int32), kfs)
+        ov.update_atlas(oa, ids)
+    gv.sync()
+    oids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(oids, sorted_ids(gv.list_chunks())) and len(oids) > 200
+    assert_chunks_equal(ov, gv, oids[::stride], "unit sequence")
+    all_kf = [p[0] for p in plan]
+    want = np.zeros((len(oids), len(all_kf)), np.float32)
+    for i, cid in enumerate(oids):
+        obs = ov.observations(cid)
+        want[i] = [obs.get(k, 0.0) for k in all_kf]
+    got = gv.export_datacost(oids, all_kf[0], all_kf[1:])
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    mids = sorted_ids(ov.list_meshes())
+    assert np.array_equal(mids, sorted_ids(gv.list_meshes()))
+    voff, ioff, V, N, Cc, I, adj, simp = gv.get_meshes(mids)
+    g = gv.get_patches(mids)
+    for i, cid in enumerate(mids):
+        m = ov.get_mesh(cid)
+        assert np.array_equal(V[voff[i]:voff[i + 1]].view(np.uint32), m["verts"].view(np.uint32)), cid
+        assert np.array_equal(I[ioff[i]:ioff[i + 1]], m["indices"]), cid
+        assert bool(simp[i]) == m["simplified"] and np.array_equal(adj[i], m["adj"]), cid
+        o = ov.get_patch(cid)
+        tl = o["texloc"] if o["flags"] & 1 else (1 << 64) - 1
+        assert int(g["texloc"][i]) == tl and g["frameid"][i] == o["frameid"], cid
+        if o["flags"] & 1:
+            a, b = g["voff"][i], g["voff"][i + 1]
+            assert np.array_equal(g["texcoord"][a:b].view(np.uint32), o["texcoord"].view(np.uint32)), cid
+            assert np.array_equal(g["texcolor"][a:b].view(np.uint32), o["texcolor"].view(np.uint32)), cid
+    assert gv.atlas_loc_next() == oa.loc_next()
+    assert len(gv.dirty()) == 0 and len(ov.dirty()) == 0
+    for t in bufs:
+        for b in t:
+            if b is not None:
+                b.free()
+    gv.close()
+    return len(mids)
+
+
+@pytest.mark.parametrize("with_q", [True, False])
+def test_keyframe_unit_sequence_with_repeated_moves(gpu_required, with_q):
+    """four keyframe groups of different sizes in a row (0, 2, 6 and 1 local frames); the first keyframe is moved twice, the
+    second once, a keyframe without local frames is moved too"""
+    cam = synth.Camera(320, 240, 262.5, 262.5, 159.5, 119.5, 0.01, 5.0)
+    frames = [synth.room_frame(3 * k, cam, with_quality=True, wobble=0.05) for k in range(16)]
+    plan = [(3, 0, [], []),
+            (8, 1, [2, 3], [(3, 1)]),
+            (11, 4, [5, 6, 7, 8, 9, 10], [(8, 2)]),
+            (12, 11, [12], [(3, 2), (11, 1)])]
+    assert run_unit_sequence(cam, np.float32(0.008), frames, plan, with_q) > 100

@@ -298,7 +298,7 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
     const int slot = slot_for(fresh->kf_id, true);
     if (slot < 0) return TF_ERR_HIP;  // (the table could not grow: hipMalloc's message is in tf_last_error)
     if ((rc = integrate_group(v, u, fresh, 1, slot, dirty_par, dirty_stamp, texture ? &ride_store : nullptr))) return rc;
-    have_ride = texture != 0;
+    have_ride = ride_store.tab != nullptr;  // (a group without local frames stored with its dirty-set launch)
   }
   if (texture) {
     // UpdateMeshes over everything marked since the last CompressMeshes, CompressMeshes, GeneratePatches with the new
