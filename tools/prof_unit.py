@@ -23,8 +23,8 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-N_LOCAL = 6
-STRIDE = 1 + N_LOCAL
+N_LOCAL = int(os.environ.get("UNIT_N_LOCAL", "6"))  # (experiments: fewer local frames per keyframe, same keyframes)
+STRIDE = 7
 ORBIT = 200
 WARM = 6
 N_KF = 20
