@@ -1652,7 +1652,7 @@ int tf_get_texture_stats(tf_volume* v, tf_texture_stats* out) {
                         hipMemcpyDeviceToHost, v->stream));
   TF_HIP(hipStreamSynchronize(v->stream));
   for (uint32_t k = 0; k < kMeshShards; ++k) {
-    out->n_survivors += mc[k * 16]; out->n_exact += mc[(kMeshShards + k) * 16]; out->n_surface += mc[(kMeshShards + k) * 16 + 1];
+    out->n_survivors += mc[k * 16] + mc[k * 16 + 1]; out->n_exact += mc[(kMeshShards + k) * 16]; out->n_surface += mc[(kMeshShards + k) * 16 + 1];
   }
   out->n_dirty = (int64_t)r[0]; out->n_meshes = (int64_t)r[1]; out->n_vertices = (int64_t)r[2];
   out->n_triangles = (int64_t)r[3]; out->roi_pixels = (int64_t)r[4]; out->n_patches = (int64_t)r[5];

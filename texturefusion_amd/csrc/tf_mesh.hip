@@ -295,6 +295,7 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
   float4 qv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) qv[j] = T4[j * 64 + lane];  // voxels 2 i and 2 i + 1 of the chunk, i = 64 j + lane: {sdf, w, sdf, w}
+  const uint32_t had_mesh = v.mesh_rec[own].state & kMsInMap;  // (travels with the voxels: which end of the row list, below)
   if (lane < 27 && !is_near) {
     const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
     if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
@@ -337,13 +338,20 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
     if (lane == 0) { if (defer) filter_defer_reset(v, cnt, cap_sh, own, id); else filter_reset_record(v, own, id, epoch, ppar); }
     return;
   }
+  // The shard's rows are a two-ended list.  About a quarter of the survivors turn out to have no surface cell (the class
+  // test is necessary, not sufficient) and leave the mesher after its cell pass, at half a chunk's time.  Which ones is
+  // known well enough from the last time they were meshed: a chunk that has a mesh takes a row from the front, one that
+  // has none from the back.  The mesher walks all fronts, then all backs: when the survivors exceed its resident capacity,
+  // the workgroups that start late are the short ones.  (Any order gives the same meshes.)
+  const bool back = !had_mesh;
   uint32_t p = 0;
-  if (lane == 0) p = atomicAdd(&cnt[shard * 16], 1u);
+  if (lane == 0) p = atomicAdd(&cnt[shard * 16 + (back ? 1 : 0)], 1u);
   p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
   if (p >= cap_sh) {  // (cannot happen: at most max_chunks / 32 pool slots share a shard)
     if (lane == 0) atomicOr(&v.vctl->status, kStMeshFull);
     return;
   }
+  if (back) p = cap_sh - 1u - p;
   // [27..29] = the chunk id (the mesher does not go back to the list)
   if (lane >= 27 && lane < 30) nslot = (uint32_t)(lane == 27 ? id.x : (lane == 28 ? id.y : id.z));
   if (lane < 30) surv[32 * ((size_t)shard * cap_sh + p) + lane] = nslot;
@@ -568,25 +576,27 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
   // row b / 32) the busy workgroups reached up to 32 x the LONGEST list; the few beyond the resident capacity started
   // when the first round ended and set the kernel's time (time stamps: last start 18-20 us, last end 34 us of which a
   // chunk takes 20).
+  // (the lists are two-ended, filter_exact: lanes 0..31 hold the shards' front counts, lanes 32..63 their back counts; the
+  // concatenation is every front, then every back; list L = shard L % 32, back end iff L >= 32)
   uint32_t n_rows = 0, excl_l = 0, incl_l = 0;
   {
-    uint32_t my_n = 0;
-    if (lane < (int)kMeshShards) { my_n = cnt[lane * 16]; if (my_n > cap_sh) my_n = cap_sh; }
+    uint32_t my_n = cnt[(lane & 31) * 16 + (lane >> 5)];
+    if (my_n > cap_sh) my_n = cap_sh;
     uint32_t incl = my_n;
 #pragma unroll
-    for (int o = 1; o < (int)kMeshShards; o <<= 1) {
+    for (int o = 1; o < 64; o <<= 1) {
       const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
       if (lane >= o) incl += u;
     }
-    n_rows = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, kMeshShards - 1));  // (wave-uniform: scalar registers)
+    n_rows = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, 63));  // (wave-uniform: scalar registers)
     // this workgroup's first row (the common case: its only one), resolved here so that nothing of the scan stays live
     const uint32_t r0 = blockIdx.x;
-    const uint32_t sh0 = (uint32_t)__popcll(__ballot(lane < (int)kMeshShards && incl <= r0));
-    incl_l = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, (int)(sh0 & 31u)));
-    excl_l = incl_l - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)my_n, (int)(sh0 & 31u)));
-    incl_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh0);  // (reused: the shard of the first row)
+    const uint32_t sh0 = (uint32_t)__popcll(__ballot(incl <= r0));
+    incl_l = (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, (int)(sh0 & 63u)));
+    excl_l = incl_l - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)my_n, (int)(sh0 & 63u)));
+    incl_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh0);  // (reused: the list of the first row)
   }
-  if (blockIdx.x == 0 && t < (int)kMeshShards) { cnt_next[t * 16] = 0u; cnt_next[(kMeshShards + t) * 16] = 0u; cnt_next[(kMeshShards + t) * 16 + 1] = 0u; cnt_next[(2 * kMeshShards + t) * 16] = 0u; }  // the counters of the NEXT launch's filter
+  if (blockIdx.x == 0 && t < (int)kMeshShards) { cnt_next[t * 16] = 0u; cnt_next[t * 16 + 1] = 0u; cnt_next[(kMeshShards + t) * 16] = 0u; cnt_next[(kMeshShards + t) * 16 + 1] = 0u; cnt_next[(2 * kMeshShards + t) * 16] = 0u; }  // the counters of the NEXT launch's filter
   if (blockIdx.x < kMeshShards) {
     // the records the filter wanted emptied (filter_defer_reset): shard b by workgroup b, one thread per record, ahead
     // of the workgroup's own chunk -- nothing in this launch reads another chunk's record
@@ -619,17 +629,18 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
       shard = incl_l;
       uint32_t idx = r - excl_l;
       if (r != blockIdx.x) {  // a further row of this workgroup (lists longer than the grid): scan again
-        uint32_t my_n = 0;
-        if (lane < (int)kMeshShards) { my_n = cnt[lane * 16]; if (my_n > cap_sh) my_n = cap_sh; }
+        uint32_t my_n = cnt[(lane & 31) * 16 + (lane >> 5)];
+        if (my_n > cap_sh) my_n = cap_sh;
         uint32_t incl = my_n;
 #pragma unroll
-        for (int o = 1; o < (int)kMeshShards; o <<= 1) {
+        for (int o = 1; o < 64; o <<= 1) {
           const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
           if (lane >= o) incl += u;
         }
-        shard = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(lane < (int)kMeshShards && incl <= r)));
-        idx = r - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, (int)(shard & 31u)) - __shfl((int)my_n, (int)(shard & 31u)));
+        shard = (uint32_t)__builtin_amdgcn_readfirstlane((int)__popcll(__ballot(incl <= r)));
+        idx = r - (uint32_t)__builtin_amdgcn_readfirstlane(__shfl((int)incl, (int)(shard & 63u)) - __shfl((int)my_n, (int)(shard & 63u)));
       }
+      if (shard >= kMeshShards) { shard -= kMeshShards; idx = cap_sh - 1u - idx; }  // (a row of the list's back end)
       const size_t row = (size_t)shard * cap_sh + idx;
       own = surv[32 * row + 13];    // the chunk's pool slot
       id = make_int4((int)surv[32 * row + 27], (int)surv[32 * row + 28], (int)surv[32 * row + 29], 0);
