@@ -14,10 +14,10 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 # kernel name fragment -> (max VGPRs, max scratch bytes per lane)
 BUDGET = {
-    "tf_kernels.hip": {"k_frameILb1ELb0E": (72, 0), "k_frameILb0ELb0E": (72, 0), "k_frameILb1ELb1E": (80, 40), "k_integrate_groupILb1ELb0E": (96, 0),
-                       "k_integrate_groupILb0ELb0E": (96, 0),
-                       # (with the keyframe's colour pass on board: the LDS tables allow four waves per SIMD = 128 VGPRs)
-                       "k_integrate_groupILb1ELb1E": (128, 0), "k_integrate_groupILb0ELb1E": (128, 0)},
+    "tf_kernels.hip": {"k_frameILb1ELb0E": (72, 0), "k_frameILb0ELb0E": (72, 0), "k_frameILb1ELb1E": (80, 40)},
+    # (with the keyframe's colour pass on board: the LDS tables allow four waves per SIMD = 128 VGPRs)
+    "tf_group.hip": {"k_integrate_groupILb1ELb0E": (96, 0), "k_integrate_groupILb0ELb0E": (96, 0),
+                     "k_integrate_groupILb1ELb1E": (128, 0), "k_integrate_groupILb0ELb1E": (128, 0)},
     # (the filter's two forms -- wave per entry / workgroup batches -- are two kernels: the wave form alone fits the 64 VGPRs
     # that let eight waves per SIMD be resident; the instances that carry the previous frame's patch stage (the keyframe
     # unit) are compiled for 6 waves per SIMD: 80 VGPRs, the patch range spills 28 B/lane)

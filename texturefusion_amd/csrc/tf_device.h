@@ -327,6 +327,7 @@ void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const fl
                        float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s,
                        int acquire = 0);  // 1: also launch_acquire_emitted's work (the list is k_select<EMIT, plain>'s); 2: ... lazily
 void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
+int device_cus();  // compute units of the current device (tf_kernels.hip)
 // the plain list's ids and isNew flags (first min(n_list, cap) entries) into host-visible memory
 void launch_export_list(const VolumeDev& v, int4* h_ids, uint8_t* h_new, uint32_t cap, hipStream_t s);
 // FrameCtl (without the pull counters) followed by VolCtl, as words, into host-visible memory

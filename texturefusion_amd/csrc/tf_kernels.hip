@@ -21,6 +21,7 @@
 #include "tf_devfn.h"
 #include "tf_host_math.h"
 #include "tf_patch_body.h"
+#include "tf_voxel_math.h"
 
 #pragma clang fp contract(off)
 #ifndef TF_KA_GP
@@ -29,76 +30,6 @@
 
 
 namespace tf {
-
-// ---------------------------------------------------------------------------------------
-// helpers
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ int cvt_rne(float x) {
-  return (x >= -2147483648.0f && x < 2147483648.0f) ? (int)rintf(x) : (int)0x80000000;
-}
-
-__device__ __forceinline__ uint32_t f2key(float f) {
-  uint32_t b = __float_as_uint(f);
-  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float key2f(uint32_t k) {
-  uint32_t b = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-  return __uint_as_float(b);
-}
-
-// QuadraticTruncator::GetTruncationDistance (truncation/QuadraticTruncator.h:45-48):
-// |q*pow(z,2) + l*z + c| * s with the pow/sum in double, l*z in float.
-__device__ __forceinline__ float truncation(const Integ& ig, float z) {
-  double zz = (double)z * (double)z;
-  float lz = ig.lin * z;
-  double v = (double)ig.quad * zz + (double)lz + (double)ig.cons;
-  return (float)(fabs(v) * (double)ig.scale);
-}
-
-// Per-chunk scalars of voxelUpdateSIMD (ProjectionIntegrator.cpp:74-101, Chunk.cpp:52) for one list
-// entry.  Computed lane-per-entry where the list is produced (64 chunks per wave instruction
-// instead of one redundant copy per lane inside k_integrate) and read back through scalar loads.
-struct ChunkPre {
-  float4 a;  // o.x, o.y, o.z (origin in camera), truncation
-  float4 b;  // weight / (2 * truncation) (unsigned; the de-integration sign is applied in K-A), upper band
-};
-__device__ __forceinline__ ChunkPre chunk_pre(const int4 id, const float* __restrict__ Pp, const Integ& ig,
-                                              float res, float resDiag) {
-  float dvec[3];
-  dvec[0] = (float)(8 * id.x) * res - Pp[3];
-  dvec[1] = (float)(8 * id.y) * res - Pp[7];
-  dvec[2] = (float)(8 * id.z) * res - Pp[11];
-  float o[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float q0 = Pp[a] * dvec[0], q1 = Pp[4 + a] * dvec[1], q2 = Pp[8 + a] * dvec[2];
-    const float s12 = q1 + q2;
-    o[a] = q0 + s12;
-  }
-  const float trunc = truncation(ig, o[2]);
-  ChunkPre r;
-  r.a = make_float4(o[0], o[1], o[2], trunc);
-  r.b = make_float4(ig.weight / (2.0f * trunc), trunc + resDiag, 0.0f, 0.0f);
-  return r;
-}
-
-
-// Centroid table of a frame (Chisel::bufferIntegratorSIMDCentroids, Structure/Chisel.cpp:52-110):
-// c[a][i] = (R^T (x,y,z))_a * res + res/2, i = (z*8+y)*8+x, summed p0 + (p1 + p2); a function of the
-// pose only.  Written once per frame by one workgroup (ahead of K-A), read by every K-A workgroup.
-__device__ __forceinline__ void centroid_table(const float* __restrict__ Pp, float res, float* __restrict__ cen) {
-  const float half = res * 0.5f;
-  for (int i = threadIdx.x; i < kChunkVoxels; i += 256) {
-    const float fx = (float)(i & 7), fy = (float)((i >> 3) & 7), fz = (float)(i >> 6);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float q0 = Pp[a] * fx, q1 = Pp[4 + a] * fy, q2 = Pp[8 + a] * fz;
-      const float s12 = q1 + q2;
-      const float d = q0 + s12;
-      cen[a * kChunkVoxels + i] = d * res + half;
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------
 // control block reset (create / Reset only; per-frame re-arming rides on k_scan)
@@ -547,30 +478,6 @@ __global__ __launch_bounds__(256) void k_acquire(VolumeDev v) {
 void launch_acquire(const VolumeDev& v, hipStream_t s) {
   hipLaunchKernelGGL(k_acquire, dim3(512), dim3(256), 0, s, v);
 }
-// The same behind k_select<EMIT> with SelectConsts::plain: the list is the unordered one the selection appended (all of it
-// from the front), its length still sits in the append counter -- this launch turns it into a finished plain list
-// (n_list = n_front = length, bounding-box keys re-armed as k_scan does) while it resolves the slots.
-__device__ __forceinline__ void acquire_emitted_body(const VolumeDev& v, const uint32_t bid, const uint32_t nb, const bool lazy = false) {
-  const SelBuf& L = v.sel;
-  const unsigned long long pk = L.ctl->emit_pack;
-  uint32_t n = (uint32_t)pk;
-  if ((pk >> 32) != 0ull || n > v.max_list) n = 0;  // (a list that did not fit was reported by the selection: kStListFull)
-  if (bid == 0 && threadIdx.x == 0) {
-    L.ctl->n_list = n;
-    L.ctl->n_front = n;
-    for (int a = 0; a < 3; ++a) { L.ctl->bbox_key[a] = f2key(1e8f); L.ctl->bbox_key[3 + a] = f2key(-1e8f); }
-  }
-  for (uint32_t e = bid * 256 + threadIdx.x; e < n; e += nb * 256) {
-    const int4 id = L.list_id[e];
-    bool is_new = false;
-    uint32_t ent = 0;
-    const uint32_t slot = chunk_acquire(v, id, &is_new, &ent, lazy);
-    L.list_slot[e] = slot;
-    L.list_ent[e] = ent;
-    L.list_new[e] = is_new ? 1 : 0;
-    L.list_needs[e] = 0;
-  }
-}
 __global__ __launch_bounds__(256) void k_acquire_emitted(VolumeDev v) { acquire_emitted_body(v, blockIdx.x, gridDim.x); }
 void launch_acquire_emitted(const VolumeDev& v, hipStream_t s) {
   hipLaunchKernelGGL(k_acquire_emitted, dim3(512), dim3(256), 0, s, v);
@@ -624,65 +531,12 @@ void launch_lookup(const VolumeDev& v, uint32_t n, hipStream_t s) {
 //   stamps.  FUSED = the per-frame unit (Chisel.h:453-468) in one launch: slot lookup/creation in
 //   front (PrepareIntersectChunks' loop), FinalizeIntegrateChunks + GarbageCollect behind.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long nonzero_bytes(unsigned long long m) {
-  unsigned long long t = m | (m >> 1);
-  t |= t >> 2;
-  t |= t >> 4;
-  return t & 0x0101010101010101ull;
-}
-
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-constexpr int kOOB = 0x7FFFFFF0;  // buffer byte offset that is out of range for every descriptor
 #ifndef TF_KF_WAVES
 #define TF_KF_WAVES 7  // resident waves per SIMD the fused kernel is compiled for (register budget)
 #endif
 #ifndef TF_KFP_WAVES
 #define TF_KFP_WAVES 6  // ... the instance that also carries the patch stage of the previous frame (80 VGPRs)
 #endif
-
-
-// _mm256_cvtps_epi32 for the predicates that consume it: round-to-nearest-even; NaN -> INT_MIN
-// (v_med3 returns the minimum when an operand is NaN); |x| >= 2^31 saturates, which every
-// consumer (`valid`, `out of observation`) classifies exactly like x86's 0x80000000.
-__device__ __forceinline__ int cvt_sat_rne(float x) {
-  return (int)rintf(__builtin_amdgcn_fmed3f(x, -2147483648.0f, 2147483520.0f));
-}
-
-// The same for operands known not to be NaN: v_cvt_i32_f32 saturates by itself (a C++ cast of an
-// out-of-range float would be undefined, hence the instruction is named explicitly).
-__device__ __forceinline__ int cvt_rne_hw(float x) {
-  int r;
-  const float n = rintf(x);
-  asm("v_cvt_i32_f32_e32 %0, %1" : "=v"(r) : "v"(n));
-  return r;
-}
-
-// IEEE-correct f32 quotients with a shared denominator.  This is the instruction sequence hipcc
-// emits for `a / b` (v_rcp, two FMA refinements of the reciprocal, product, three residual FMAs)
-// without v_div_scale / v_div_fmas' scaling / v_div_fixup, which only act on operands or quotients
-// outside the normal exponent range, zeros, infinities and NaNs.  `safe` (wave-uniform) tells
-// whether every lane is inside that range; otherwise the generic division is used, so results are
-// bit-identical to `/` in all cases.  Sharing the reciprocal saves one quarter-rate v_rcp_f32 and
-// two FMAs per voxel in the projection (two quotients over p.z).
-struct Recip { float d, r; };
-__device__ __forceinline__ Recip recip_refined(float d) {
-  Recip R;
-  R.d = d;
-  const float r0 = __builtin_amdgcn_rcpf(d);
-  const float e = __builtin_fmaf(-d, r0, 1.0f);
-  R.r = __builtin_fmaf(e, r0, r0);
-  return R;
-}
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// the same sequence for two numerators at once on the packed-f32 pipe (v_pk_mul / v_pk_fma)
-__device__ __forceinline__ f32x2 div2_by(const f32x2 n, const Recip& R) {
-  const f32x2 d = {-R.d, -R.d}, r = {R.r, R.r};
-  const f32x2 q0 = n * r;
-  const f32x2 e0 = __builtin_elementwise_fma(d, q0, n);
-  const f32x2 q1 = __builtin_elementwise_fma(e0, r, q0);
-  const f32x2 e1 = __builtin_elementwise_fma(d, q1, n);
-  return __builtin_elementwise_fma(e1, r, q1);
-}
 
 // K-A runs per chunk as:   64-B list record + hash entry (scalar loads)  ->  geometry of all 8
 // z-slices  ->  8 depth gathers in flight  ->  slot resolve  ->  RMW passes of GP slices (predicates
@@ -696,38 +550,10 @@ __device__ __forceinline__ f32x2 div2_by(const f32x2 n, const Recip& R) {
 // buffer load/store (out-of-range offset = no memory access, loads return 0), so there is no
 // exec-mask juggling and no lane mask has to live in SGPRs across phases.  Descriptors: the three
 // frame images (kernel arguments) and the chunk's two 4-KiB voxel planes (wave-uniform slot).
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) u32x4* const_u32x4_ptr;
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) u32x8* const_u32x8_ptr;
-
-// The dirty-set claim of one updated chunk (Chisel.h:197-203: the chunk and its six face neighbours, those that exist): lane k
-// < 7 of the wave looks neighbour k up, the per-slot stamp de-duplicates, the winner appends {id, entry, slot} to the shard
-// list of its pool slot (counter set `par`).
-__device__ __forceinline__ void claim_dirty7(const VolumeDev& v, const int4 id, const uint32_t slot, const uint32_t ent, const int lane,
-                                             const uint32_t stamp, const int par) {
-  uint32_t cs = kInvalidSlot, ce = 0;
-  int4 q = id;
-  if (lane < 7) {
-    q = nbr7(id, lane);
-    if (lane == 0) { cs = slot; ce = ent; }
-    else if (part_owned(v, q.x, q.y, q.z)) cs = hash_slot_alive_ent(v, pack_id(q.x, q.y, q.z), &ce);
-    if (cs != kInvalidSlot && !(atomicMax(&v.mesh_rec[cs].stamp, stamp) < stamp)) cs = kInvalidSlot;
-    if (cs != kInvalidSlot) {
-      const uint32_t rows = v.max_chunks / kMeshShards + 258u;  // = mesh_shard_rows()
-      const uint32_t sh = cs & (kMeshShards - 1u);
-      const uint32_t p = atomicAdd(&v.wl_cnt[((par & 1) * kMeshShards + sh) * 16], 1u);
-      if (p < rows) {
-        const size_t at = ((size_t)(par & 1) * kMeshShards + sh) * rows + p;
-        v.wl_ids[at] = make_int4(q.x, q.y, q.z, (int)(ce + 1u));
-        v.wl_slot[at] = cs;
-      } else {
-        atomicOr(&v.vctl->status, kStMeshFull);
-      }
-    }
-  }
-}
 
 template <bool COLOR, bool QUALITY, bool FUSED, bool FLAG, int GP>
 __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameImages& img, const Cam& cam,
@@ -1196,440 +1022,6 @@ __global__ __launch_bounds__(256) void k_integrate(VolumeDev v, FrameImages img,
 }
 
 // ---------------------------------------------------------------------------------------
-// The local frames of a keyframe group in ONE visit per chunk (GCFusion/MobileFusion.cpp:187-203: after the
-// keyframe's own depth + colour, up to six depth-only frames are integrated over the SAME chunk list, each with
-// its own pose).  Frame by frame that is six launches that each read and rewrite the same voxel rows; here a wave
-// loads the chunk's 512 {sdf, weight} pairs once, applies the frames in order while they stay in registers -- the
-// arithmetic of integrate_body<COLOR = false>, operation for operation, including the row-granular rewrite of lanes
-// with weight 0 and the pos-stall of a fully off-image row -- and writes back the rows any frame rewrote.
-// ---------------------------------------------------------------------------------------
-// (Chunk::observations on the device: the table is described with k_obs_record below)
-__device__ __forceinline__ unsigned long long obs_pack(uint32_t slot, int32_t kf) {
-  return ((unsigned long long)slot << 32) | (unsigned long long)(uint32_t)kf;
-}
-__device__ __forceinline__ uint32_t obs_find(const VolumeDev& v, unsigned long long key, bool insert) {
-  uint32_t i = hash_key(key) & v.obs_mask;
-  for (uint32_t probe = 0; probe <= v.obs_mask; ++probe) {
-    unsigned long long cur = v.obs_key[i];
-    if (cur == kEmptyKey) {
-      if (!insert) return kInvalidSlot;
-      cur = atomicCAS(&v.obs_key[i], kEmptyKey, key);
-      if (cur == kEmptyKey) return i;
-    }
-    if (cur == key) return i;
-    i = (i + 1) & v.obs_mask;
-  }
-  if (insert) atomicOr(&v.vctl->status, kStHashFull);
-  return kInvalidSlot;
-}
-constexpr int kGroupMax = 6;
-struct GroupArgs {
-  const float* depth[kGroupMax];   // device depth images
-  const float4* pre[kGroupMax];    // per-frame list records (k_pre)
-  const float* cen[kGroupMax];     // per-frame centroid tables
-  int n;
-};
-
-struct GroupPoses {
-  Pose P[kGroupMax];
-};
-// list records and centroid tables of all frames of a group in one launch (blockIdx.y = frame)
-// (with_key: blockIdx.y == 0 is the KEYFRAME -- pose `key`, records into the selection set like k_pre's -- and the local
-// frames follow at y = 1 + f: the keyframe unit computes all seven frames' records in one launch)
-// (acquire: the list is the plain one k_select<EMIT> just appended, its length still in the append counter; the LAST row of
-// blocks is k_acquire_emitted's work -- slots, isNew, the finished list header -- which the record rows do not read.
-// acquire == 2: parked chunks stay parked, chunk_acquire's lazy form -- the list's finalize is k_integrate_group's)
-__global__ __launch_bounds__(256) void k_pre_group(VolumeDev v, GroupPoses gp, Integ ig, float res, float resDiag,
-                                                   float4* pre_scratch, float* cen_scratch, Pose key, int with_key, int acquire) {
-  const SelBuf& L = v.sel;
-  if (acquire && blockIdx.y == gridDim.y - 1) { acquire_emitted_body(v, blockIdx.x, gridDim.x, acquire == 2); return; }
-  const bool is_key = with_key && blockIdx.y == 0;
-  const int f = is_key ? 0 : (int)blockIdx.y - (with_key ? 1 : 0);
-  const float* P = is_key ? key.p : gp.P[f].p;
-  float4* pre = is_key ? L.list_pre : pre_scratch + (size_t)f * 4 * v.max_list;
-  if (blockIdx.x == 0) centroid_table(P, res, is_key ? L.cen : cen_scratch + (size_t)f * 3 * kChunkVoxels);
-  uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
-  if (acquire) {
-    const unsigned long long pk = L.ctl->emit_pack;
-    n = ((pk >> 32) != 0ull || (uint32_t)pk > v.max_list) ? 0u : (uint32_t)pk;
-  }
-  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-    const int4 id = L.list_id[e];
-    const ChunkPre cp = chunk_pre(id, P, ig, res, resDiag);
-    pre[4 * e] = make_float4(cp.a.x, cp.a.y, cp.a.z, cp.b.x);
-    pre[4 * e + 1] = make_float4(cp.b.y, __int_as_float(id.x), __int_as_float(id.y), __int_as_float(id.z));
-  }
-}
-
-// obs_kf >= 0: the launch also records chunk->observations[obs_kf] of the KEYFRAME's integration that ran just before it
-// (Chisel.h:244-247: the list's quality sums and needsUpdate flags as that call left them -- read here before this
-// kernel touches the entry's flag), instead of a launch of its own between the two (k_obs_record: 4.7 us of the unit)
-// fin != 0: the launch is also the list's finalize (k_finalize: FinalizeIntegrateChunks + GarbageCollect, Chisel.h:192-208,
-// :472-477, with epoch fin_epoch) -- each wave finishes its entry behind its last frame, when the entry's needsUpdate flag
-// (the keyframe's call | this visit) is final, as K-A does in a stream (7 us of launch per group less); claim_par >= 0: and the
-// dirty-set pass over the list (k_dirty_frame), into the shard lists of that parity
-// KEY: the visit starts with the KEYFRAME's own depth + colour pass over the entry (k_integrate<COLOR, no quality image, FLAG>,
-// operation for operation: ProjectionIntegrator.cpp:74-341 with the colour band of :202-304) -- its TSDF rows stay in the
-// registers the local frames then work on, instead of a launch of its own that writes them and this one reading them
-// back (31 us of a keyframe's 211).  Its centroids are computed per lane (centroid_table's expression; the workgroup's LDS
-// holds the six local frames' tables), its records are the list's own (k_pre_group's keyframe row).
-struct GroupKey {
-  FrameImages img;  // the keyframe's depth + colour
-  Pose P;           // its pose (centroids)
-};
-template <bool FLAG, bool KEY>
-__global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs ga, Cam cam, IntegrateConsts kc, int32_t obs_kf,
-                                                         int fin, uint32_t fin_epoch, int claim_par, uint32_t claim_stamp,
-                                                         GroupKey key) {
-  const SelBuf& L = v.sel;
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
-  const uint32_t nwaves = gridDim.x * 4;
-  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
-  const int vy = lane >> 3;
-  const int W = cam.W, H = cam.H;
-  __shared__ float cenT[kGroupMax][3][kChunkVoxels];  // 6 KB per frame
-  for (int f = 0; f < ga.n; ++f) {
-    const float4* src = reinterpret_cast<const float4*>(ga.cen[f]);
-    float4* dst = reinterpret_cast<float4*>(&cenT[f][0][0]);
-    for (int i = threadIdx.x; i < 3 * kChunkVoxels / 4; i += 256) dst[i] = src[i];
-  }
-  __syncthreads();
-  const uint32_t row_lo = lane < 32 ? (0xFFu << (lane & 24)) : 0u;
-  const uint32_t row_hi = lane < 32 ? 0u : (0xFFu << (lane & 24));
-  auto row_any = [&](const unsigned long long m) -> bool {
-    return ((((uint32_t)m) & row_lo) | (((uint32_t)(m >> 32)) & row_hi)) != 0u;
-  };
-  auto ballot = [](const bool b) -> unsigned long long { return __builtin_amdgcn_ballot_w64(b); };
-  const f32x2 fxy = {cam.fxi, cam.fyi}, cxy = {kc.cxs, kc.cys};
-
-  for (uint32_t e = wave; e < n; e += nwaves) {
-    const int4 id = L.list_id[e];
-    if (!part_owned(v, id.x, id.y, id.z)) continue;
-    const uint32_t slot = L.list_slot[e];
-    if (slot == kInvalidSlot) continue;
-    if (!KEY && obs_kf >= 0 && lane == 0) {
-      const float q = L.list_quality[e];
-      if (q > 0.0f && L.list_needs[e]) {
-        const uint32_t at = obs_find(v, obs_pack(slot, obs_kf), true);
-        if (at != kInvalidSlot) v.obs_q[at] = q;
-      }
-    }
-    const __amdgpu_buffer_rsrc_t rs_T =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(v.tsdf + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
-    u32x2 t[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) t[j] = __builtin_amdgcn_raw_buffer_load_b64(rs_T, (j * 64 + lane) * 8, 0, 0);
-    uint32_t dirty_rows = 0;   // bit j: the lane's row of slice j was rewritten by some frame
-    uint32_t rows_total = 0;
-    uint32_t key_rows_t = 0, key_rows_c = 0;  // rows the keyframe's pass rewrote (wave-uniform)
-    if (KEY) {
-      const float4 r0 = L.list_pre[4 * e], r1 = L.list_pre[4 * e + 1];
-      const float o0 = r0.x, o1 = r0.y, o2 = r0.z, pbx = r0.w, upper = r1.x;
-      const f32x2 o01 = {o0, o1};
-      const float wD = FLAG ? pbx : -pbx;
-      const float band = 32.0f * kc.res;
-      const bool div_safe = (fabsf(o2) > band) && (fabsf(o2) < 1048576.0f) && (fabsf(o0) < 1048576.0f) &&
-                            (fabsf(o1) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
-      const __amdgpu_buffer_rsrc_t rs_depth =
-          __builtin_amdgcn_make_buffer_rsrc((void*)key.img.depth, 0, W * H * 4, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_rgba =
-          __builtin_amdgcn_make_buffer_rsrc((void*)key.img.rgba, 0, W * H * 4, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_C =
-          __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
-      // centroid of the lane's voxel of slice j, axis a: centroid_table's expression
-      const float khalf = kc.res * 0.5f;
-      const float fx = (float)(lane & 7), fy = (float)vy;
-      float qx[3], qy[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { qx[a] = key.P.p[a] * fx; qy[a] = key.P.p[4 + a] * fy; }
-      auto cen = [&](const int a, const int j) -> float {
-        const float q2 = key.P.p[8 + a] * (float)j;
-        const float s12 = qy[a] + q2;
-        const float d = qx[a] + s12;
-        return d * kc.res + khalf;
-      };
-      int off_d[8];
-      unsigned long long vm[8];
-      uint32_t R = 64, oob_bits = 0;
-      int oob_any = 0;
-      auto geometry = [&](auto safe_tag) {
-        constexpr bool SAFE = decltype(safe_tag)::value;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const f32x2 pxy = o01 + (f32x2){cen(0, j), cen(1, j)};
-          const float pzv = o2 + cen(2, j);
-          f32x2 q;
-          if (SAFE) {
-            q = div2_by(pxy, recip_refined(pzv));
-          } else {
-            q.x = pxy.x / pzv;
-            q.y = pxy.y / pzv;
-          }
-          const f32x2 uw = q * fxy + cxy;
-          const int X = SAFE ? cvt_rne_hw(uw.x) : cvt_sat_rne(uw.x);
-          const int Y = SAFE ? cvt_rne_hw(uw.y) : cvt_sat_rne(uw.y);
-          const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
-          vm[j] = ballot(valid);
-          int od = (__mul24(Y, W) + X) * 4;
-          asm volatile("" : "+v"(od));
-          off_d[j] = valid ? od : kOOB;
-          // X < 0 || X > W-1 || Y < 0 || Y > H-1 (:212-220); implies !valid
-          oob_bits |= (((unsigned)X > (unsigned)(W - 1)) || ((unsigned)Y > (unsigned)(H - 1))) ? (1u << j) : 0u;
-        }
-      };
-      if (div_safe) geometry(std::true_type{});
-      else geometry(std::false_type{});
-      unsigned long long all_valid = ~0ull;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) all_valid &= vm[j];
-      if (all_valid != ~0ull) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (R == 64u) {
-            const unsigned long long dead = nonzero_bytes(vm[j]) ^ 0x0101010101010101ull;
-            if (dead) R = (uint32_t)(j * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
-          }
-          const bool live_lane = (uint32_t)(j * 8 + vy) < R;
-          oob_any |= (live_lane && ((oob_bits >> j) & 1u)) ? 1 : 0;  // off-image lanes of processed rows only
-          off_d[j] = live_lane ? off_d[j] : kOOB;
-        }
-      }
-      float dep[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j], 0, 0));
-      // TSDF rows, in the registers the local frames continue with
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if ((uint32_t)(j * 8) >= R) break;  // a stalled row ends the chunk
-        const float d = dep[j];
-        const float sd = d - (o2 + cen(2, j));
-        const bool act = (uint32_t)(j * 8 + vy) < R;
-        const bool dv = (d > cam.nearP) && (cam.farP > d);
-        const bool inside = (sd > kc.lower) && (upper > sd);
-        const bool F = act && dv && inside;
-        const float nw = F ? wD : 0.0f;
-        const bool rf_l = row_any(ballot(F));
-        key_rows_t += (uint32_t)__popcll(ballot(rf_l)) >> 3;
-        if (rf_l) {
-          const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);
-          const float num = ts * tw + sd * nw;
-          const float den = (tw + nw) + kc.sigma;
-          const float ns = num / den;
-          const float nwt = tw + nw;
-          const bool keep = nwt > 0.5f;
-          t[j].x = __float_as_uint(keep ? ns : 999.0f);
-          t[j].y = __float_as_uint(keep ? nwt : 0.0f);
-          dirty_rows |= 1u << j;
-        }
-      }
-      // colour band (-thr < sd < thr, :202-208): which colour rows are rewritten, which pixels feed them -- four slices at
-      // a time (eight would hold 40 registers across the loads)
-      uint32_t lanes_c = 0;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        int off_c[4], off_i[4];
-        unsigned long long any_c = 0ull;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int j = h * 4 + jj;
-          const float sd = dep[j] - (o2 + cen(2, j));
-          const bool upd = (off_d[j] != kOOB) && (fabsf(sd) < kc.thrCol);  // (rows behind a stalled row: off_d is kOOB)
-          off_i[jj] = upd ? off_d[j] : kOOB;
-          const bool ru_l = row_any(ballot(upd));
-          const unsigned long long ru = ballot(ru_l);
-          off_c[jj] = ru_l ? (j * 64 + lane) * 8 : kOOB;
-          lanes_c += (uint32_t)__popcll(ru);
-          any_c |= ru;
-        }
-        if (any_c == 0ull) continue;
-        u32x2 c[4];
-        uint32_t in[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          c[jj] = __builtin_amdgcn_raw_buffer_load_b64(rs_C, off_c[jj], 0, 0);
-          in[jj] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[jj], 0, 0);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          // colour planes are 4 x u16 {r, g, b, count} per voxel = two packed-u16 dwords (integrate_body, phase 5a)
-          const uint32_t p_rg = __builtin_amdgcn_perm(0u, in[jj], 0x0c010c00u);
-          const uint32_t p_ba = __builtin_amdgcn_perm(0u, in[jj], 0x0c030c02u);
-          const uint32_t w_rg = c[jj].x, w_ba = c[jj].y;
-          const u16x2 in_rg = __builtin_bit_cast(u16x2, p_rg), in_ba = __builtin_bit_cast(u16x2, p_ba);
-          u16x2 c_rg = __builtin_bit_cast(u16x2, w_rg), c_ba = __builtin_bit_cast(u16x2, w_ba);
-          if (FLAG) {  // (:274-292)
-            c_rg += in_rg;
-            c_ba += in_ba;
-            const bool halve = (int)__builtin_bit_cast(uint32_t, c_ba) >= (121 << 16);
-            const u16x2 h_rg = c_rg >> (unsigned short)2, h_ba = c_ba >> (unsigned short)2;
-            c_rg = halve ? h_rg : c_rg;
-            c_ba = halve ? h_ba : c_ba;
-          } else {     // (:293-304)
-            c_rg -= in_rg;
-            c_ba -= in_ba;
-          }
-          c[jj].x = __builtin_bit_cast(uint32_t, c_rg);
-          c[jj].y = __builtin_bit_cast(uint32_t, c_ba);
-          __builtin_amdgcn_raw_buffer_store_b64(c[jj], rs_C, off_c[jj], 0, 0);
-        }
-      }
-      key_rows_c = lanes_c >> 3;
-      // without a quality image nothing is ever added to observationQualitySum: it ends as the out-of-observation
-      // constant iff any processed row had an off-image lane (:221-222)
-      const float qsum = (ballot(oob_any != 0) != 0ull) ? kc.qoob : 0.0f;
-      if (lane == 0) {
-        L.list_quality[e] = qsum;
-        if (obs_kf >= 0 && qsum > 0.0f && key_rows_t != 0u) {  // chunk->observations[keyframe] (Chisel.h:244-247)
-          const uint32_t at = obs_find(v, obs_pack(slot, obs_kf), true);
-          if (at != kInvalidSlot) v.obs_q[at] = qsum;
-        }
-      }
-    }
-    for (int f = 0; f < ga.n; ++f) {
-      const float4 r0 = ga.pre[f][4 * e], r1 = ga.pre[f][4 * e + 1];
-      const float o0 = r0.x, o1 = r0.y, o2 = r0.z, pbx = r0.w, pby = r1.x;
-      const f32x2 o01 = {o0, o1};
-      const float wD = FLAG ? pbx : -pbx;
-      const float upper = pby;
-      const float band = 32.0f * kc.res;
-      const bool div_safe = (fabsf(o2) > band) && (fabsf(o2) < 1048576.0f) && (fabsf(o0) < 1048576.0f) &&
-                            (fabsf(o1) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
-      const __amdgpu_buffer_rsrc_t rs_depth =
-          __builtin_amdgcn_make_buffer_rsrc((void*)ga.depth[f], 0, W * H * 4, 0x00020000);
-      int off_d[8];
-      unsigned long long vm[8];
-      uint32_t R = 64;
-      auto geometry = [&](auto safe_tag) {
-        constexpr bool SAFE = decltype(safe_tag)::value;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = j * 64 + lane;
-          const f32x2 pxy = o01 + (f32x2){cenT[f][0][k], cenT[f][1][k]};
-          const float pzv = o2 + cenT[f][2][k];
-          f32x2 q;
-          if (SAFE) {
-            q = div2_by(pxy, recip_refined(pzv));
-          } else {
-            q.x = pxy.x / pzv;
-            q.y = pxy.y / pzv;
-          }
-          const f32x2 uw = q * fxy + cxy;
-          const int X = SAFE ? cvt_rne_hw(uw.x) : cvt_sat_rne(uw.x);
-          const int Y = SAFE ? cvt_rne_hw(uw.y) : cvt_sat_rne(uw.y);
-          const bool valid = ((unsigned)(X - 1) < (unsigned)(W - 2)) && ((unsigned)(Y - 1) < (unsigned)(H - 2));
-          vm[j] = ballot(valid);
-          int od = (__mul24(Y, W) + X) * 4;
-          asm volatile("" : "+v"(od));
-          off_d[j] = valid ? od : kOOB;
-        }
-      };
-      if (div_safe) geometry(std::true_type{});
-      else geometry(std::false_type{});
-      unsigned long long all_valid = ~0ull;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) all_valid &= vm[j];
-      if (all_valid != ~0ull) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (R == 64u) {
-            const unsigned long long dead = nonzero_bytes(vm[j]) ^ 0x0101010101010101ull;
-            if (dead) R = (uint32_t)(j * 8) + ((uint32_t)__builtin_ctzll(dead) >> 3);
-          }
-          const bool live_lane = (uint32_t)(j * 8 + vy) < R;
-          off_d[j] = live_lane ? off_d[j] : kOOB;
-        }
-      }
-      float dep[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j)
-        dep[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_depth, off_d[j], 0, 0));
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if ((uint32_t)(j * 8) >= R) break;  // a stalled row ends the chunk
-        const float d = dep[j];
-        const float sd = d - (o2 + cenT[f][2][j * 64 + lane]);
-        const bool act = (uint32_t)(j * 8 + vy) < R;
-        const bool dv = (d > cam.nearP) && (cam.farP > d);
-        const bool inside = (sd > kc.lower) && (upper > sd);
-        const bool F = act && dv && inside;
-        const float nw = F ? wD : 0.0f;
-        const bool rf_l = row_any(ballot(F));
-        rows_total += (uint32_t)__popcll(ballot(rf_l)) >> 3;
-        if (rf_l) {  // every lane of a rewritten row is recomputed, with weight 0 where the voxel itself is not hit
-          const float ts = __uint_as_float(t[j].x), tw = __uint_as_float(t[j].y);
-          const float num = ts * tw + sd * nw;
-          const float den = (tw + nw) + kc.sigma;
-          const float ns = num / den;
-          const float nwt = tw + nw;
-          const bool keep = nwt > 0.5f;
-          t[j].x = __float_as_uint(keep ? ns : 999.0f);
-          t[j].y = __float_as_uint(keep ? nwt : 0.0f);
-          dirty_rows |= 1u << j;
-        }
-      }
-    }
-    uint32_t word = 0;  // VolumeDev::summ: classes of the rewritten rows' final values
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool wr = ((dirty_rows >> j) & 1u) != 0;
-      __builtin_amdgcn_raw_buffer_store_b64(t[j], rs_T, wr ? (j * 64 + lane) * 8 : kOOB, 0, 0);
-      if (wr) word |= chunk_summary_bits(__uint_as_float(t[j].x), __uint_as_float(t[j].y), (uint32_t)(j * 64 + lane));
-    }
-    word = wave_or(word);
-    if (lane == 0 && word) atomicOr(&v.summ[slot], word);
-    const bool updated = (rows_total | key_rows_t) != 0;
-    if (updated && lane == 0) {
-      L.list_needs[e] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
-      if (part_band(v, id.x, id.y, id.z)) v.hent[L.list_ent[e]].alive = 3u;  // multi-GPU: touched since the last exchange
-    }
-    const uint32_t rows_key = KEY ? (key_rows_c << 8) : (fin ? (uint32_t)L.list_rows[e] : 0u);  // the keyframe's own pass: rows_t | rows_c << 8
-    if (lane == 0) L.list_rows[e] = (uint16_t)(rows_total + key_rows_t < 255u ? rows_total + key_rows_t : 255u);  // (statistic; saturates)
-    if (fin) {
-      const bool isnew = L.list_new[e] != 0;
-      if (updated || L.list_needs[e]) {
-        if (lane == 0) {
-          v.mark_epoch[slot] = fin_epoch + 1u;  // meshesToUpdate[id and 6 nbrs] = true, expanded on read
-          // (the list was acquired lazily: a parked chunk that got data is revived here; band chunks carry bit 1 already)
-          if (isnew && !part_band(v, id.x, id.y, id.z)) v.hent[L.list_ent[e]].alive = 1u;
-        }
-        // (a texture stage follows the call's groups: the chunk joins its dirty set here, as K-A's chunks do in a stream)
-        if (claim_par >= 0) claim_dirty7(v, id, slot, L.list_ent[e], lane, claim_stamp, claim_par);
-      } else if (isnew) {
-        // GarbageCollect: RemoveChunk + meshesToUpdate.erase.  Parked storage goes back to the fresh state: colour rows
-        // can have been written by the keyframe's pass (colour band hit with depth outside [near, far]: its row count says);
-        // TSDF rows only when the caller's earlier flags removed a chunk WITH data -- the summary word tells (see k_finalize)
-        const uint32_t ent = L.list_ent[e];
-        if (rows_key >> 8) {
-          uint4* c4 = reinterpret_cast<uint4*>(v.color + (size_t)slot * kChunkVoxels);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) c4[k * 64 + lane] = make_uint4(0, 0, 0, 0);
-        }
-        if (v.hent[ent].alive) {  // (created by this list's acquire: a chunk that was parked before stayed parked)
-          const uint32_t ds = v.summ[slot];
-          if (ds != 0u) {
-            const uint32_t f999 = __float_as_uint(999.0f);
-            uint4* t4 = reinterpret_cast<uint4*>(v.tsdf + (size_t)slot * kChunkVoxels);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) t4[k * 64 + lane] = make_uint4(f999, 0u, f999, 0u);
-          }
-          if (lane == 0) {
-            v.hent[ent].alive = 0;
-            if (ds != 0u) {
-              v.summ[slot] = 0u;
-              MeshRec* r = &v.mesh_rec[slot];
-              if (r->state & kMsInMap) { r->state = 0u; r->nv = 0; r->nt = 0; }
-            }
-          }
-        }
-        if (lane == 0) v.erase_epoch[slot] = fin_epoch + 1u;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------
 // The per-frame unit as ONE launch: independent block ranges form a software pipeline over
 // consecutive frames of a stream --
 //     K-A   of frame f    (reads the list K-C left one launch ago)
@@ -1713,7 +1105,7 @@ static int env_int(const char* name, int dflt) {
 }
 // K-A grid: exactly the resident capacity (TF_KF_WAVES waves per SIMD = that many 256-thread
 // workgroups per CU), so every K-A wave starts at once and walks the list with a fixed stride.
-static int device_cus() {
+int device_cus() {
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     hipDeviceProp_t p;
@@ -1739,42 +1131,6 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
   else if (use_color) TF_LAUNCH_KA(true, false);
   else TF_LAUNCH_KA(false, false);
 #undef TF_LAUNCH_KA
-}
-
-void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const float* poses12, float4* pre_scratch,
-                       float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s, int acquire) {
-  const IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);  // (resDiag does not depend on the flag)
-  GroupPoses gp = {};
-  for (int f = 0; f < n; ++f)
-    for (int q = 0; q < 12; ++q) gp.P[f].p[q] = poses12[12 * f + q];
-  hipLaunchKernelGGL(k_pre_group, dim3(128, n + 1 + (acquire ? 1 : 0)), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch,
-                     cen_scratch, keyframe, 1, acquire);
-}
-
-void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
-                            float* cen_scratch, const Cam& cam, const Integ& ig, float res, int flag, hipStream_t s, bool have_pre,
-                            int32_t obs_kf, int fin, uint32_t fin_epoch, int claim_par, uint32_t claim_stamp,
-                            const FrameImages* key_img, const Pose* key_pose) {
-  IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, flag);
-  GroupArgs ga = {};
-  GroupPoses gp = {};
-  ga.n = n;
-  for (int f = 0; f < n; ++f) {
-    for (int q = 0; q < 12; ++q) gp.P[f].p[q] = poses12[12 * f + q];
-    ga.depth[f] = d_depth[f];
-    ga.pre[f] = pre_scratch + (size_t)f * 4 * v.max_list;
-    ga.cen[f] = cen_scratch + (size_t)f * 3 * kChunkVoxels;
-  }
-  if (!have_pre) hipLaunchKernelGGL(k_pre_group, dim3(128, n), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch, Pose{}, 0, 0);
-  static const int cus = device_cus();
-  const dim3 grid(cus * 4), block(256);  // 36 KB of LDS per workgroup: four per CU
-  GroupKey key = {};
-  if (key_img) { key.img = *key_img; key.P = *key_pose; }
-#define TF_LAUNCH_GROUP(F, K) \
-  hipLaunchKernelGGL((k_integrate_group<F, K>), grid, block, 0, s, v, ga, cam, kc, obs_kf, fin, fin_epoch, claim_par, claim_stamp, key)
-  if (key_img) { if (flag) TF_LAUNCH_GROUP(true, true); else TF_LAUNCH_GROUP(false, true); }
-  else { if (flag) TF_LAUNCH_GROUP(true, false); else TF_LAUNCH_GROUP(false, false); }
-#undef TF_LAUNCH_GROUP
 }
 
 // One pipelined launch.  Any of the three stages may be absent (pipeline fill / drain):
