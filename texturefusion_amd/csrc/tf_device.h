@@ -325,7 +325,8 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
 // (into the group scratch, as k_pre_group leaves them) in ONE launch
 void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const float* poses12, float4* pre_scratch,
                        float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s,
-                       int acquire = 0);  // 1: also launch_acquire_emitted's work (the list is k_select<EMIT, plain>'s); 2: ... lazily
+                       int acquire = 0,   // 1: also launch_acquire_emitted's work (the list is k_select<EMIT, plain>'s); 2: ... lazily
+                       uint32_t* clear_word = nullptr);  // a device word the launch sets to 0 (the unit: kf.validChunks.clear())
 void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
 int device_cus();  // compute units of the current device (tf_kernels.hip)
 // the plain list's ids and isNew flags (first min(n_list, cap) entries) into host-visible memory

@@ -41,8 +41,10 @@ struct GroupPoses {
 // blocks is k_acquire_emitted's work -- slots, isNew, the finished list header -- which the record rows do not read.
 // acquire == 2: parked chunks stay parked, chunk_acquire's lazy form -- the list's finalize is k_integrate_group's)
 __global__ __launch_bounds__(256) void k_pre_group(VolumeDev v, GroupPoses gp, Integ ig, float res, float resDiag,
-                                                   float4* pre_scratch, float* cen_scratch, Pose key, int with_key, int acquire) {
+                                                   float4* pre_scratch, float* cen_scratch, Pose key, int with_key, int acquire,
+                                                   uint32_t* clear_word) {
   const SelBuf& L = v.sel;
+  if (clear_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *clear_word = 0u;  // (the unit: kf.validChunks.clear(), :217)
   if (acquire && blockIdx.y == gridDim.y - 1) { acquire_emitted_body(v, blockIdx.x, gridDim.x, acquire == 2); return; }
   const bool is_key = with_key && blockIdx.y == 0;
   const int f = is_key ? 0 : (int)blockIdx.y - (with_key ? 1 : 0);
@@ -432,13 +434,14 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
 
 
 void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const float* poses12, float4* pre_scratch,
-                       float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s, int acquire) {
+                       float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s, int acquire,
+                       uint32_t* clear_word) {
   const IntegrateConsts kc = make_integrate_consts(cam.cxi, cam.cyi, res, 1);  // (resDiag does not depend on the flag)
   GroupPoses gp = {};
   for (int f = 0; f < n; ++f)
     for (int q = 0; q < 12; ++q) gp.P[f].p[q] = poses12[12 * f + q];
   hipLaunchKernelGGL(k_pre_group, dim3(128, n + 1 + (acquire ? 1 : 0)), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch,
-                     cen_scratch, keyframe, 1, acquire);
+                     cen_scratch, keyframe, 1, acquire, clear_word);
 }
 
 void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_depth, const float* poses12, float4* pre_scratch,
@@ -455,7 +458,7 @@ void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_dep
     ga.pre[f] = pre_scratch + (size_t)f * 4 * v.max_list;
     ga.cen[f] = cen_scratch + (size_t)f * 3 * kChunkVoxels;
   }
-  if (!have_pre) hipLaunchKernelGGL(k_pre_group, dim3(128, n), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch, Pose{}, 0, 0);
+  if (!have_pre) hipLaunchKernelGGL(k_pre_group, dim3(128, n), dim3(256), 0, s, v, gp, ig, res, kc.resDiag, pre_scratch, cen_scratch, Pose{}, 0, 0, (uint32_t*)nullptr);
   static const int cus = device_cus();
   const dim3 grid(cus * 4), block(256);  // 36 KB of LDS per workgroup: four per CU
   GroupKey key = {};

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(1024) void k_kf_store(VolumeDev v, KfStoreArgs a) {
 
 // localChunksIntersecting = kf.validChunks; needsUpdate = true, newChunk = false for every entry (MobileFusion.cpp:135-143);
 // slots resolved like tf_integrate does for a caller's list (a missing chunk is an error: chunks.at() throws)
-__global__ __launch_bounds__(256) void k_kf_load(VolumeDev v, const KfTab* tab, uint32_t slots, const int4* arena, int slot) {
+// ... and MobileFusion::RetractObservations' chunk side over the same entries: observations.erase(frame_id)
+__global__ __launch_bounds__(256) void k_kf_load(VolumeDev v, const KfTab* tab, uint32_t slots, const int4* arena, int slot,
+                                                 int32_t kf_id) {
   const SelBuf& L = v.sel;
   uint32_t n = kf_off(tab)[slots + slot];
   if (n > v.max_list) { n = 0; if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&v.vctl->status, kStListFull); }
@@ -62,16 +64,6 @@ __global__ __launch_bounds__(256) void k_kf_load(VolumeDev v, const KfTab* tab, 
     if (s == kInvalidSlot) atomicOr(&v.vctl->status, kStMissing);
     L.list_slot[e] = s;
     L.list_ent[e] = ent == kInvalidSlot ? 0u : ent;
-  }
-}
-__global__ void k_kf_clear(KfTab* tab, uint32_t slots, int slot) { kf_off(tab)[slots + slot] = 0; }  // kf.validChunks.clear() (:217)
-
-// MobileFusion::RetractObservations' chunk side over the list just loaded: observations.erase(frame_id)
-__global__ __launch_bounds__(256) void k_kf_retract(VolumeDev v, int32_t kf_id) {
-  const SelBuf& L = v.sel;
-  const uint32_t n = L.ctl->n_list <= v.max_list ? L.ctl->n_list : 0u;
-  for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-    const uint32_t s = L.list_slot[e];
     if (s == kInvalidSlot) continue;
     const unsigned long long key = ((unsigned long long)s << 32) | (unsigned long long)(uint32_t)kf_id;
     uint32_t i = hash_key(key) & v.obs_mask;
@@ -124,11 +116,12 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     v->frame_bound = true;
     // (validChunks = the finalized list in list order; no order of it is observable through this entry point, so the
     // list need not be the reference's: k_select + k_scan would cost 17 us per keyframe more)
-    int rc = launch_prepare_unordered(v, P, s, /*acquire=*/false);  // (the slots: one more row of the records launch below)
-    if (rc) return rc;
+    // -- PrepareIntersectChunks without its list ORDER: the selection appends straight to a plain list, no scan / write-out
+    // launch; the slots are one more row of the records launch below
+    launch_bbox(d, img.depth, v->cam, P, s);
+    launch_select(d, img.depth, v->cam, v->ig, P, v->res, /*emit=*/true, s, /*plain=*/true);
   } else {
-    hipLaunchKernelGGL(k_kf_load, dim3(256), dim3(256), 0, s, d, u->tab, u->slots, u->arena, kf_slot);
-    hipLaunchKernelGGL(k_kf_retract, dim3(256), dim3(256), 0, s, d, g->kf_id);
+    hipLaunchKernelGGL(k_kf_load, dim3(256), dim3(256), 0, s, d, u->tab, u->slots, u->arena, kf_slot, g->kf_id);
   }
   // the per-chunk records and centroid tables of all the group's frames in ONE launch (k_pre + k_pre_group were two)
   const float* dd[kGroupFrames];
@@ -138,7 +131,8 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     memcpy(poses + 12 * f, flag ? g->local[f].pose : g->old_local_pose[f], 48);
   }
   launch_pre_frames(d, P, g->n_local, poses, u->group_pre, u->group_cen, v->ig, v->res, v->cam, s,
-                    /*acquire=*/flag ? (g->n_local > 0 ? 2 : 1) : 0);  // (lazily when the group kernel finalizes the list)
+                    /*acquire=*/flag ? (g->n_local > 0 ? 2 : 1) : 0,  // (lazily when the group kernel finalizes the list)
+                    /*clear_word=*/flag ? nullptr : kf_off(u->tab) + u->slots + kf_slot);  // kf.validChunks.clear() (:217): the list is loaded
   // the keyframe's own depth + colour (+ quality) ...  With local frames behind it and no quality image the pass is the
   // first frame of the group kernel's visit (k_integrate_group<., KEY>), not a launch of its own.
   const bool color = img.rgba != nullptr, quality = color && img.quality != nullptr;
@@ -172,7 +166,6 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     if (ride_store) *ride_store = sa;  // (with the texture stage's filter launch)
     else hipLaunchKernelGGL(k_kf_store, dim3(1), dim3(1024), 0, s, d, sa);
   }
-  if (!flag) hipLaunchKernelGGL(k_kf_clear, dim3(1), dim3(1), 0, s, u->tab, u->slots, kf_slot);
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;
   return TF_OK;
