@@ -168,30 +168,52 @@ __device__ __forceinline__ void kf_store_body(const VolumeDev& v, KfTab* tab, ui
   }
   __syncthreads();
   if (base == 0xFFFFFFFFu) return;
-  // pass 2: ordered compaction, a round of kStretch entries at a time -- every thread knows the flags of its E consecutive
-  // entries, ONE scan over the threads' counts (shuffles within the wave, the wave totals through LDS) places them, and
-  // every flagged entry is written behind the flagged entries before it.
+  // pass 2: ordered compaction, a stretch of kStretch entries at a time.  Every thread knows the flags of its E consecutive
+  // entries; a wave owns 64 E consecutive entries and walks them in E rounds of 64 -- the round's 64 flags are the masks of
+  // the 64 / E lanes that own its entries, fetched with lane reads; ids are loaded and stored coalesced, eight rounds in
+  // flight at a time (a thread copying its own E entries one by one was E dependent round trips to 64 different lines).
+  // The waves' totals go through LDS; every flagged entry is written behind the flagged entries before it.
   __shared__ uint32_t wcnt[NW];
-  uint32_t run = 0;  // flagged entries of the rounds before this one (block-uniform)
+  constexpr int LPR = 64 / E;  // lanes whose masks make up one round
+  uint32_t run = 0;  // flagged entries of the stretches before this one (block-uniform)
   for (uint32_t s0 = 0; s0 < n; s0 += kStretch) {
     const unsigned long long m = s0 == 0u ? m0 : mask_e(s0);
-    const uint32_t c = (uint32_t)__popcll(m);
-    uint32_t incl = c;
+    uint32_t c = (uint32_t)__popcll(m);
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t u = (uint32_t)__shfl_up((int)incl, o);
-      if (lane >= o) incl += u;
-    }
-    __syncthreads();  // (wcnt of the previous round has been read)
-    if (lane == 63) wcnt[w] = incl;
+    for (int o = 32; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);  // the wave's total
+    __syncthreads();  // (wcnt of the previous stretch has been read)
+    if (lane == 0) wcnt[w] = c;
     __syncthreads();
-    uint32_t before = run, tot = 0;
-    for (int k = 0; k < NW; ++k) { if (k < w) before += wcnt[k]; tot += wcnt[k]; }
-    uint32_t at = base + before + incl - c;
-    const uint32_t e0 = s0 + threadIdx.x * (uint32_t)E;
+    uint32_t at = base + run, tot = 0;
+    for (int k = 0; k < NW; ++k) { if (k < w) at += wcnt[k]; tot += wcnt[k]; }
+    const uint32_t wave_e0 = s0 + (uint32_t)w * 64u * (uint32_t)E;
+    const uint32_t m_lo = (uint32_t)m, m_hi = (uint32_t)(m >> 32);
+    if (c) {  // (wave-uniform)
 #pragma unroll
-    for (int k = 0; k < E; ++k)
-      if ((m >> k) & 1ull) { arena[at] = L.list_id[e0 + (uint32_t)k]; at += 1u; }
+      for (int rb = 0; rb < E; rb += 8) {
+        unsigned long long mr[8];
+        int4 idv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          unsigned long long x = 0ull;
+#pragma unroll
+          for (int q = 0; q < LPR; ++q) {
+            const int src = (rb + r) * LPR + q;
+            const unsigned long long part = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)m_lo, src) |
+                                            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)m_hi, src) << 32);
+            x |= (E == 64 ? part : (part & ((1ull << (E & 63)) - 1ull))) << ((E * q) & 63);
+          }
+          mr[r] = x;
+          const uint32_t e = wave_e0 + 64u * (uint32_t)(rb + r) + (uint32_t)lane;
+          idv[r] = ((x >> lane) & 1ull) ? L.list_id[e] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          if ((mr[r] >> lane) & 1ull) arena[at + (uint32_t)__popcll(mr[r] & ((1ull << lane) - 1ull))] = idv[r];
+          at += (uint32_t)__popcll(mr[r]);
+        }
+      }
+    }
     run += tot;
   }
 }
