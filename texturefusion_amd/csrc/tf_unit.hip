@@ -98,8 +98,9 @@ static int unit_state(tf_volume* v, UnitState** out) {
 }
 
 // ReIntegrateKeyframe (MobileFusion.cpp:114-221) for one group with one flag
-// dirty_par >= 0: the group's updated chunks and their face neighbours join the work list of that parity right behind
-// the finalize (launch_dirty_frame over this list), stamped dirty_stamp -- instead of a scan of every chunk's mark later
+// dirty_par >= 0: the group's updated chunks and their face neighbours join the dirty set of that parity, stamped
+// dirty_stamp, as they are finalized (the group kernel's claims into the shard lists; launch_dirty_frame into the flat list
+// for a group without local frames) -- instead of a scan of every chunk's mark later
 // ride_store != nullptr: the group's validChunks are not stored here -- *ride_store receives the arguments and the caller's
 // texture stage takes them along on its filter launch
 static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, int flag, int kf_slot, int dirty_par = -1,
@@ -111,13 +112,11 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
   Pose P;
   memcpy(P.p, kpose, sizeof(P.p));
   if (flag) {
-    // PrepareIntersectChunks at the keyframe's pose: the ordered list, chunks created, needsUpdate = false
+    // PrepareIntersectChunks at the keyframe's pose, without its list ORDER: validChunks = the finalized list in list order,
+    // and no order of it is observable through this entry point -- the selection appends straight to a plain list, no scan /
+    // write-out launch (k_scan: 17 us per keyframe); the slots, isNew and needsUpdate = false come with the records launch below
     v->frame = img;
     v->frame_bound = true;
-    // (validChunks = the finalized list in list order; no order of it is observable through this entry point, so the
-    // list need not be the reference's: k_select + k_scan would cost 17 us per keyframe more)
-    // -- PrepareIntersectChunks without its list ORDER: the selection appends straight to a plain list, no scan / write-out
-    // launch; the slots are one more row of the records launch below
     launch_bbox(d, img.depth, v->cam, P, s);
     launch_select(d, img.depth, v->cam, v->ig, P, v->res, /*emit=*/true, s, /*plain=*/true);
   } else {
