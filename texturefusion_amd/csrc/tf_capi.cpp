@@ -251,17 +251,6 @@ int tf::xchg_band_counts(tf_volume* v, const tf::FrameCtl* ctl, uint32_t tag, ui
   for (int q = 0; q < 4; ++q) cnt[q] = w[1 + q];
   return TF_OK;
 }
-// PrepareIntersectChunks without the reference's list ORDER (the keyframe unit: its lists never leave the device and
-// nothing it computes depends on their order): the selection appends straight to the list, no scan / write-out launch
-// (acquire = false: the caller's next launch resolves the slots -- launch_pre_frames(acquire = true))
-int tf::launch_prepare_unordered(tf_volume* v, const tf::Pose& pose, hipStream_t s, bool acquire) {
-  using namespace tf;
-  if (!s) s = v->stream;
-  launch_bbox(v->dev, v->frame.depth, v->cam, pose, s);
-  launch_select(v->dev, v->frame.depth, v->cam, v->ig, pose, v->res, /*emit=*/true, s, /*plain=*/true);
-  if (acquire) launch_acquire_emitted(v->dev, s);
-  return TF_OK;
-}
 int tf::launch_prepare(tf_volume* v, const tf::Pose& pose, bool with_acquire, hipStream_t s) {
   using namespace tf;
   if (!s) s = v->stream;

@@ -315,7 +315,6 @@ void launch_select(const VolumeDev& v, const float* depth, const Cam& cam, const
                    const Pose& pose, float res, bool emit, hipStream_t s, bool plain = false);
 void launch_scan(const VolumeDev& v, int step, hipStream_t s);
 void launch_acquire(const VolumeDev& v, hipStream_t s);
-void launch_acquire_emitted(const VolumeDev& v, hipStream_t s);  // behind launch_select(emit = true, plain = true)
 void launch_lookup(const VolumeDev& v, uint32_t n, hipStream_t s);
 // have_pre: the list records / centroid table of this pose are already there (launch_pre_frames)
 void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam, const Integ& ig,
@@ -325,7 +324,7 @@ void launch_integrate(const VolumeDev& v, const FrameImages& img, const Cam& cam
 // (into the group scratch, as k_pre_group leaves them) in ONE launch
 void launch_pre_frames(const VolumeDev& v, const Pose& keyframe, int n, const float* poses12, float4* pre_scratch,
                        float* cen_scratch, const Integ& ig, float res, const Cam& cam, hipStream_t s,
-                       int acquire = 0,   // 1: also launch_acquire_emitted's work (the list is k_select<EMIT, plain>'s); 2: ... lazily
+                       int acquire = 0,   // 1: the last row of workgroups resolves the slots of the list k_select<EMIT, plain> appended (acquire_emitted_body); 2: ... lazily
                        uint32_t* clear_word = nullptr);  // a device word the launch sets to 0 (the unit: kf.validChunks.clear())
 void launch_finalize(const VolumeDev& v, uint32_t epoch, hipStream_t s);
 int device_cus();  // compute units of the current device (tf_kernels.hip)

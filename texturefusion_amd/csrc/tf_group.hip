@@ -38,7 +38,7 @@ struct GroupPoses {
 // (with_key: blockIdx.y == 0 is the KEYFRAME -- pose `key`, records into the selection set like k_pre's -- and the local
 // frames follow at y = 1 + f: the keyframe unit computes all seven frames' records in one launch)
 // (acquire: the list is the plain one k_select<EMIT> just appended, its length still in the append counter; the LAST row of
-// blocks is k_acquire_emitted's work -- slots, isNew, the finished list header -- which the record rows do not read.
+// blocks is acquire_emitted_body's work (tf_voxel_math.h) -- slots, isNew, the finished list header -- which the record rows do not read.
 // acquire == 2: parked chunks stay parked, chunk_acquire's lazy form -- the list's finalize is k_integrate_group's)
 __global__ __launch_bounds__(256) void k_pre_group(VolumeDev v, GroupPoses gp, Integ ig, float res, float resDiag,
                                                    float4* pre_scratch, float* cen_scratch, Pose key, int with_key, int acquire,

@@ -478,10 +478,6 @@ __global__ __launch_bounds__(256) void k_acquire(VolumeDev v) {
 void launch_acquire(const VolumeDev& v, hipStream_t s) {
   hipLaunchKernelGGL(k_acquire, dim3(512), dim3(256), 0, s, v);
 }
-__global__ __launch_bounds__(256) void k_acquire_emitted(VolumeDev v) { acquire_emitted_body(v, blockIdx.x, gridDim.x); }
-void launch_acquire_emitted(const VolumeDev& v, hipStream_t s) {
-  hipLaunchKernelGGL(k_acquire_emitted, dim3(512), dim3(256), 0, s, v);
-}
 
 // Per-chunk scalars for a list that is integrated with an explicit pose (call-by-call flow: every
 // IntegrateDepthScanColor call brings its own pose, Chisel.h:226).  One thread per entry.

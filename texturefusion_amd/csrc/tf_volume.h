@@ -259,7 +259,6 @@ namespace tf {
 int sync_status(tf_volume* v, uint32_t* n_tmp);
 int ensure_tmp(tf_volume* v, size_t bytes);
 int launch_prepare(tf_volume* v, const Pose& pose, bool with_acquire, hipStream_t s = nullptr);  // tf_capi.cpp
-int launch_prepare_unordered(tf_volume* v, const Pose& pose, hipStream_t s = nullptr, bool acquire = true);
 struct KfStoreArgs;  // tf_kf_store.h
 // ride_filter: a patch stage still pending when the stage starts rides on its filter launch (the keyframe unit: there is
 // no k_frame launch for it to ride on) instead of going out as a launch of its own

@@ -1,12 +1,12 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 R=$PWD
-for cfg in "1 0" "2 0" "6 0"; do   # (second field: TF_UNIT_KEY_LAUNCH, a knob of the experiment build only -- the keyframe's pass as a launch of its own)
+for cfg in "1 0" "2 0" "6 0"; do
   set -- $cfg
   U=$R/gpurun_out/nl_$1_$2; rm -rf $U; mkdir -p $U
-  ( export UNIT_N_LOCAL=$1 TF_UNIT_KEY_LAUNCH=$2; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $U -o t -- python3 $R/tools/prof_unit.py --run > $U/log 2>&1 )
+  ( export UNIT_N_LOCAL=$1; cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $U -o t -- python3 $R/tools/prof_unit.py --run > $U/log 2>&1 )
   S=$(find $U -name "*kernel_stats.csv" | head -1)
-  echo "== n_local=$1 key_launch=$2"; tail -1 $U/log | cut -c1-120
+  echo "== n_local=$1"; tail -1 $U/log | cut -c1-120
   python3 - $S <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
