@@ -264,7 +264,16 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
         // c = candidates with a smaller key = this patch's rank if it is one itself
         const unsigned long long key = pack_id(id.x, id.y, id.z);
         uint32_t c = 0;
-        for (uint32_t i = lane; i < n_cand; i += 64) c += v.cand[i] < key ? 1u : 0u;
+        for (uint32_t i0 = 0; i0 < n_cand; i0 += 256) {  // (four independent loads at a time: one at a time is a chain of round trips)
+          unsigned long long ck[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t i = i0 + 64u * q + (uint32_t)lane;
+            ck[q] = i < n_cand ? v.cand[i] : ~0ull;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) c += ck[q] < key ? 1u : 0u;
+        }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
         // the first failing AddPatch is the candidate of rank `room`; it and every entry behind it are skipped
