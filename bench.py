@@ -606,7 +606,8 @@ def main():
     if multi and not args.no_independent:
         # (the partitioned volume stays open through the replica's run: the library counts registrations of the caller's
         # arrays per process -- and on this ROCm a volume destroyed BEFORE another one streams host frames leaves that one's
-        # uploads at ~10 GB/s instead of ~40, tools/two_volumes_probe.py; cause not found)
+        # uploads at ~10 GB/s instead of ~40 for its first ~100 ms: the freed device pool is wiped in the background by the
+        # DMA engines the uploads use, tools/two_volumes_probe.py)
         try:
             indep = independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses, pinv, a_depth, a_rgba, a_pose,
                                         a_pinv, n_unique, local_rank, world, dist if world > 1 else None, dev, textured, fresh_period)

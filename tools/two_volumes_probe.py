@@ -32,7 +32,9 @@ if mode in ("two", "two_torchstream"):
 else:
     b = mk()
     b.host_register(h_depth); b.host_register(h_rgba)
-for rep in range(3):
+if os.environ.get("SLEEP_AFTER"):
+    time.sleep(float(os.environ["SLEEP_AFTER"]))  # (does the slow-down pass with time?)
+for rep in range(int(os.environ.get("REPS", "3"))):
     b.host_frame_times(reset=True)
     t0 = time.perf_counter()
     for k in range(n):
