@@ -1422,6 +1422,7 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
             "keyframes_per_s": n_kf / dt, "ms_per_keyframe": 1e3 * dt / n_kf, "frame_integrations_per_s": frames / dt,
             "keyframes": n_kf, "moved_groups": n_moved}
         vol.close()
+        time.sleep(0.3)  # (the freed pool is wiped in the background for tens of ms: the next volume's figure should not run into it)
     # ---- the same keyframes through the reference's OWN call sequence (what a caller that only swaps the headers gets,
     # INTEGRATION.md approach A): PrepareIntersectChunks -> IntegrateDepthScanColor (keyframe) -> 6 x IntegrateDepthScanColor
     # (depth only) -> FinalizeIntegrateChunks -> UpdateMeshes -> CompressMeshes -> GeneratePatches -> UpdateAtlas, every call
