@@ -399,3 +399,70 @@ def test_keyframe_unit_sequence_with_repeated_moves(gpu_required, with_q):
             (11, 4, [5, 6, 7, 8, 9, 10], [(8, 2)]),
             (12, 11, [12], [(3, 2), (11, 1)])]
     assert run_unit_sequence(cam, np.float32(0.008), frames, plan, with_q) > 100
+
+
+@pytest.mark.parametrize("with_q", [True, False])
+def test_keyframe_unit_then_the_callers_view_selection(gpu_required, with_q):
+    """The product's own order (MobileFusion::tsdfFusion, :274-406): the unit WITHOUT its texture stage -- integration of
+    the keyframe groups and UpdateMeshes on the device, asynchronous --, then the caller's CompressMeshes, its view
+    selection (host code: here a label per chunk that alternates between the keyframes seen so far), GeneratePatches with
+    those labels and UpdateAtlas through the call-by-call entry points.  chunksToUpdate, meshes, patches and atlas rows must
+    equal the oracle's after every keyframe."""
+    cam = synth.Camera(320, 240, 262.5, 262.5, 159.5, 119.5, 0.01, 5.0)
+    res = np.float32(0.008)
+    frames = [synth.room_frame(k, cam, with_quality=True, wobble=0.02) for k in range(16)]
+    if not with_q:
+        frames = [(f[0], f[1], None, f[3]) for f in frames]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1]),
+             HipBuffer(f[2].nbytes).from_host(f[2]) if with_q else None) for f in frames]
+    ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(res, cam, max_chunks=1 << 16)
+    oa = O.Atlas(res)
+    kfs, seen = {}, []
+    plan = [(4, 0, [1, 2, 3, 4]), (9, 5, [6, 7, 8, 9, 10]), (13, 11, [12, 13]), (14, 14, [15])]
+    for kf_id, key, loc in plan:
+        grp = capi.Volume.unit_group(kf_id, (bufs[key][0].ptr, bufs[key][1].ptr, bufs[key][2].ptr if with_q else None, frames[key][3]),
+                                     [(bufs[k][0].ptr, frames[k][3]) for k in loc])
+        gv.keyframe_unit(fresh=grp, texture=False)
+        _oracle_group(ov, kf_id, frames[key], [(frames[k][0], frames[k][3]) for k in loc], 1)
+        ov.update_meshes()
+        ids = ov.compress_meshes()
+        gids = gv.compress_meshes()
+        assert np.array_equal(ids, gids)
+        T = synth.pose_inverse16(frames[key][3])
+        kfs[kf_id] = (np.ascontiguousarray(frames[key][1][..., :3]), frames[key][0], T)
+        gv.keyframe_cache_device(kf_id, bufs[key][1].ptr, bufs[key][0].ptr, stride=4, pose_inv16=T)
+        seen.append(kf_id)
+        labels = np.array([seen[i % len(seen)] for i in range(len(ids))], np.int32)  # the caller's view selection
+        ov.generate_patches(oa, ids, labels, kfs)
+        ov.update_atlas(oa, ids)
+        rc, hot = gv.generate_patches(ids, labels)
+        assert rc == 0
+        gv.update_atlas(ids)
+    gv.sync()
+    mids = sorted_ids(ov.list_meshes())
+    assert np.array_equal(mids, sorted_ids(gv.list_meshes())) and len(mids) > 100
+    voff, ioff, V, N, Cc, I, adj, simp = gv.get_meshes(mids)
+    g = gv.get_patches(mids)
+    for i, cid in enumerate(mids):
+        m = ov.get_mesh(cid)
+        assert np.array_equal(V[voff[i]:voff[i + 1]].view(np.uint32), m["verts"].view(np.uint32)), cid
+        assert np.array_equal(I[ioff[i]:ioff[i + 1]], m["indices"]), cid
+        o = ov.get_patch(cid)
+        tl = o["texloc"] if o["flags"] & 1 else (1 << 64) - 1
+        assert int(g["texloc"][i]) == tl and g["frameid"][i] == o["frameid"], cid
+        if o["flags"] & 1:
+            a, b = g["voff"][i], g["voff"][i + 1]
+            assert np.array_equal(g["bbox"][i], o["bbox"]), cid
+            assert np.array_equal(g["texcoord"][a:b].view(np.uint32), o["texcoord"].view(np.uint32)), cid
+            assert np.array_equal(g["texcolor"][a:b].view(np.uint32), o["texcolor"].view(np.uint32)), cid
+    assert gv.atlas_loc_next() == oa.loc_next()
+    used = g["texloc"][g["texloc"] != np.uint64((1 << 64) - 1)]
+    hot = oa.hot_range(used)
+    r0, r1 = hot[0] // 13824, hot[1] // 13824
+    assert r1 > r0 and np.array_equal(gv.atlas_rows(r0, r1, 13824), oa.buffer()[r0:r1])
+    for t in bufs:
+        for b in t:
+            if b is not None:
+                b.free()
+    gv.close()
