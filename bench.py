@@ -1423,6 +1423,46 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
             "keyframes": n_kf, "moved_groups": n_moved}
         vol.close()
         time.sleep(0.3)  # (the freed pool is wiped in the background for tens of ms: the next volume's figure should not run into it)
+    # ---- the product's own order (MobileFusion::tsdfFusion with its view selection on the host): the unit WITHOUT its texture
+    # stage (asynchronous), then the caller's CompressMeshes (returns chunksToUpdate: the one synchronisation), its view
+    # selection (here: every chunk labelled with the new keyframe), GeneratePatches and UpdateAtlas through the entry points
+    try:
+        import numpy as np
+        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+                          max_coarse=(1 << 22) if big else (1 << 20), device=device)
+
+        def unit_then_caller(g):
+            k0 = (stride * g) % n_unique
+            loc = [(k0 + 1 + i) % n_unique for i in range(n_local)]
+            grp = capi.Volume.unit_group(1000 + g, (d_depth[k0].data_ptr(), d_rgba[k0].data_ptr(), 0, poses[k0]),
+                                         [(d_depth[k].data_ptr(), poses[k]) for k in loc])
+            vol.keyframe_unit(fresh=grp, moved=[], texture=False)
+            upd = vol.compress_meshes()
+            vol.keyframe_cache_device(1000 + g, d_rgba[k0].data_ptr(), d_depth[k0].data_ptr(), stride=4, pose_inv16=pinv[k0])
+            vol.generate_patches(upd, np.full(len(upd), 1000 + g, np.int32))
+            vol.update_atlas(upd)
+            if g >= 8:
+                vol.keyframe_release(1000 + g - 8)
+
+        for g in range(4):
+            unit_then_caller(g)
+        vol.sync()
+        if cgroup_cpu_quota() is not None:
+            time.sleep(0.12)
+        t0 = time.perf_counter()
+        for g in range(4, 4 + n_kf):
+            unit_then_caller(g)
+        vol.sync()
+        dt = time.perf_counter() - t0
+        res_out["unit_then_callers_view_selection_calls"] = {
+            "keyframes_per_s": n_kf / dt, "ms_per_keyframe": 1e3 * dt / n_kf, "frame_integrations_per_s": n_kf * stride / dt,
+            "keyframes": n_kf,
+            "note": "tf_keyframe_unit_device(texture = 0), then tf_compress_meshes / tf_generate_patches (labels from the caller) / "
+                    "tf_update_atlas: the reference's own order when the view selection stays on the host"}
+        vol.close()
+        time.sleep(0.3)
+    except Exception as e:  # (a diagnostic figure: never fail the bench line for it)
+        res_out["unit_then_callers_view_selection_calls"] = {"error": repr(e)[:300]}
     # ---- the same keyframes through the reference's OWN call sequence (what a caller that only swaps the headers gets,
     # INTEGRATION.md approach A): PrepareIntersectChunks -> IntegrateDepthScanColor (keyframe) -> 6 x IntegrateDepthScanColor
     # (depth only) -> FinalizeIntegrateChunks -> UpdateMeshes -> CompressMeshes -> GeneratePatches -> UpdateAtlas, every call

@@ -555,7 +555,7 @@ class Volume:
         n = C.c_int64(0)
         cap = 1 << 16
         while True:
-            ids = np.zeros((cap, 3), np.int32)
+            ids = np.empty((cap, 3), np.int32)
             rc = self.L.tf_compress_meshes(self.h, _p(ids, C.c_int32), cap, C.byref(n))
             if rc == TF_ERR_CAPACITY and n.value > cap:
                 raise TFError(rc, "compress_meshes: list larger than %d" % cap)
