@@ -466,3 +466,69 @@ def test_keyframe_unit_then_the_callers_view_selection(gpu_required, with_q):
             if b is not None:
                 b.free()
     gv.close()
+
+
+def test_keyframe_pass_inside_the_group_kernel_on_hard_images(gpu_required):
+    """The keyframe's own pass as the first frame of the group kernel's visit (no quality image, local frames behind it) on
+    the images K-A's own tests use against integrate_body: NaN / -Inf / negative / denormal / near- and far-plane depth pixels, a wall
+    35 cm from the camera (chunks near the image border and the near plane: the generic division path, stalled rows,
+    off-image lanes -> the out-of-observation constant), and the same keyframe integrated often enough for the colour
+    counts to be halved at 120 (ProjectionIntegrator.cpp:274-292); then everything de-integrated again (flag 0: the
+    colour subtraction)."""
+    cam = synth.Camera()
+    res = np.float32(0.005)
+    ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    gv = capi.Volume(res, cam, max_chunks=1 << 17)
+    rng = np.random.default_rng(5)
+    frames = []
+    for k in (3, 4, 5, 6):
+        depth, rgba, q, pose = synth.room_frame(k, cam, with_quality=False)
+        depth = depth.copy()
+        H, W = depth.shape
+        # (no +Inf / 1e30 here: one such pixel makes the frame's bounding box overflow the candidate grid and the whole frame
+        # is skipped, on both sides -- tests/test_gpu_parity.py has that case)
+        bad = [np.nan, -np.inf, -1.5, 1e-40, 0.0, 5.0, 4.999, 0.01, 0.0101]
+        ys = rng.integers(0, H, 4000); xs = rng.integers(0, W, 4000)
+        depth[ys, xs] = np.float32(rng.choice(bad, 4000))
+        depth[100:104, 200:260] = np.nan
+        depth[300:303, 50:90] = -1.0
+        frames.append((depth, rgba, None, pose))
+    for s in (1, 2, 3):
+        w = synth.wall_frame(0.35, cam, seed=s)
+        frames.append((w[0], w[1], None, w[3]))
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+
+    def call(kf_id, key, loc, old=None):
+        kw = {}
+        if old is not None:
+            kw = dict(old_keyframe_pose=frames[key][3], old_local_poses=[frames[k][3] for k in loc])
+        return capi.Volume.unit_group(kf_id, (bufs[key][0].ptr, bufs[key][1].ptr, None, frames[key][3]),
+                                      [(bufs[k][0].ptr, frames[k][3]) for k in loc], **kw)
+
+    valid = {}
+    plan = [(1, 0, [1]), (2, 2, [3, 1]), (3, 4, [5, 6])]
+    for kf_id, key, loc in plan:
+        gv.keyframe_unit(fresh=call(kf_id, key, loc), texture=False)
+        valid[kf_id] = _oracle_group(ov, kf_id, frames[key], [(frames[k][0], frames[k][3]) for k in loc], 1)
+    # the wall keyframe again and again: colour counts pass 120 and are quartered
+    for rep in range(130):
+        gv.keyframe_unit(fresh=call(100 + rep, 4, [5]), texture=False)
+        _oracle_group(ov, 100 + rep, frames[4], [(frames[5][0], frames[5][3])], 1)
+    gv.sync()
+    ids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(ids, sorted_ids(gv.list_chunks())) and len(ids) > 1000
+    assert_chunks_equal(ov, gv, ids[::3], "hard images, integrated")
+    assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+    # the three keyframes moved onto themselves: de-integration (flag 0) and re-integration at the same poses
+    for kf_id, key, loc in plan:
+        gv.keyframe_unit(fresh=None, moved=[call(kf_id, key, loc, old=True)], texture=False)
+        ov.retract_observations(kf_id, valid[kf_id])
+        _oracle_group(ov, kf_id, frames[key], [(frames[k][0], frames[k][3]) for k in loc], 0, ids=valid[kf_id])
+        valid[kf_id] = _oracle_group(ov, kf_id, frames[key], [(frames[k][0], frames[k][3]) for k in loc], 1)
+    gv.sync()
+    ids = sorted_ids(ov.list_chunks())
+    assert np.array_equal(ids, sorted_ids(gv.list_chunks()))
+    assert_chunks_equal(ov, gv, ids[::3], "hard images, moved")
+    for b in bufs:
+        b[0].free(); b[1].free()
+    gv.close()
