@@ -1453,11 +1453,14 @@ int tf_compress_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n_o
   TF_DEV(v);
   *n_out = 0;
   int rc = TF_OK;
-  const bool have_list = v->dirty_list_seq + 1 == v->call_seq && v->d_tmp;  // (the call before this one was tf_update_meshes)
+  // (the call before this one was tf_update_meshes -- or a keyframe unit without its texture stage, which leaves the list in the
+  // same place but, being asynchronous, not its length on the host: dirty_list_n == ~0u)
+  const bool have_list = v->dirty_list_seq + 1 == v->call_seq && v->d_tmp;
   if (!have_list) { rc = dirty_list_enqueue(v); if (rc) return rc; }
+  const bool known_n = have_list && v->dirty_list_n != ~0u;
   const uint32_t cap_list = v->dev.max_chunks;
   // room for every listed chunk: known when the list is update_meshes', the whole pool otherwise
-  const size_t cap_host = have_list ? (size_t)v->dirty_list_n : (size_t)cap_list;
+  const size_t cap_host = known_n ? (size_t)v->dirty_list_n : (size_t)cap_list;
   int64_t m = 0;
   if (cap_host) {
     rc = ensure_pinned(v, cap_host * 16);
@@ -1468,7 +1471,7 @@ int tf_compress_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n_o
     launch_compress(v->dev, list, cnt, cap_list, true, v->stream);
     TF_HIP(hipGetLastError());
     TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
-    const uint32_t grid = have_list ? (v->dirty_list_n + 255u) / 256u : 1024u;
+    const uint32_t grid = known_n ? (v->dirty_list_n + 255u) / 256u : 1024u;
     hipLaunchKernelGGL(k_dirty_with_mesh, dim3(grid ? grid : 1u), dim3(256), 0, v->stream, v->dev, list, cnt, cap_list,
                        reinterpret_cast<int4*>(v->h_pinned), (uint32_t)cap_host);
     TF_HIP(hipGetLastError());

@@ -315,6 +315,10 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
               ++v->mesh_epoch, v->res, false, -1, 1u << 30, nullptr, -1, v->stream);
   v->mesh_par ^= 1;
   TF_HIP(hipGetLastError());
+  // (d_tmp holds the dirty list: a tf_compress_meshes right behind this call takes it from there instead of scanning the
+  // chunks' marks again; its length stays on the device -- this call does not wait)
+  v->dirty_list_n = ~0u;
+  v->dirty_list_seq = v->call_seq;
   return TF_OK;
 }
 
