@@ -529,10 +529,15 @@ static int atlas_stage(tf_volume* v, size_t bytes) {
 }
 
 // keyframe table: host mirror -> device (tiny)
+// (the record travels as a kernel ARGUMENT: copied when the launch is enqueued, so the host copy may change right away and
+// nothing waits -- a hipMemcpyAsync out of the pageable table needed a stream synchronisation per keyframe call)
+__global__ void k_kf_set(KfDev* dst, KfDev val) {
+  if (threadIdx.x == 0) *dst = val;
+}
 int kf_push(tf_volume* v, int slot) {
   AtlasState& a = v->atlas;
-  TF_HIP(hipMemcpyAsync(a.d_kf + slot, &a.h_kf[(size_t)slot], sizeof(KfDev), hipMemcpyHostToDevice, v->stream));
-  TF_HIP(hipStreamSynchronize(v->stream));  // the pageable host source must not change under the copy
+  hipLaunchKernelGGL(k_kf_set, dim3(1), dim3(64), 0, v->stream, a.d_kf + slot, a.h_kf[(size_t)slot]);
+  TF_HIP(hipGetLastError());
   return TF_OK;
 }
 static int kf_slot_for(tf_volume* v, int32_t kf_id, bool create, int* out) {
