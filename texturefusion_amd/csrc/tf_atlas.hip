@@ -53,58 +53,88 @@ __global__ __launch_bounds__(256) void k_work_lookup(VolumeDev v, uint32_t n) {
 // workgroup; entry j needs a slot iff its chunk has a mesh without one, the slot number is the number of
 // such entries before it.  The first entry whose hand-out fails ends the call: it and everything behind it
 // stays unprocessed (GeneratePatches returns -1 there).
+// The pool slots of the entries come from k_work_lookup (a launch over the whole chip: the hash probes of one workgroup's
+// threads, three entries each one after the other, were most of this kernel's 36 us).  Here thread t takes entries
+// t, t + 1024, ...: a round of 1024 consecutive entries is one ballot scan, four rounds' loads are in flight together.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_patch_assign(VolumeDev v, uint32_t n) {
-  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t wsum[16], ksum[16];
   __shared__ uint32_t first_fail;
   __shared__ unsigned long long smin, smax;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const uint32_t per = (n + 1023u) / 1024u;
-  const uint32_t b = (uint32_t)t * per < n ? (uint32_t)t * per : n, e = (b + per < n) ? b + per : n;
   if (t == 0) { first_fail = 0xFFFFFFFFu; smin = ~0ull; smax = 0ull; }
-  uint32_t cnt = 0;
-  for (uint32_t i = b; i < e; ++i) {
-    const uint32_t slot = mesh_slot_of(v, v.work_ids[i]);  // !HasMesh -> continue (:157)
-    v.work_slot[i] = slot;
-    if (slot != kInvalidSlot && v.mesh_rec[slot].texloc == kNoTexloc) ++cnt;
-  }
-  uint32_t inc = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t u = __shfl_up(inc, o);
-    if (lane >= o) inc += u;
-  }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  uint32_t before = 0;
-  for (int k = 0; k < w; ++k) before += wsum[k];
   const unsigned long long base = v.actl->n_slots;
-  uint32_t r = before + inc - cnt;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  uint32_t run = 0;     // entries that needed a slot in the rounds before this one (block-uniform)
   uint32_t handed = 0;
-  for (uint32_t i = b; i < e; ++i) {
-    const uint32_t slot = v.work_slot[i];
-    if (slot == kInvalidSlot) continue;
-    MeshRec* rec = &v.mesh_rec[slot];
-    if (rec->texloc != kNoTexloc) continue;
-    unsigned long long tl;
-    if (slot_texloc(v, base + r, &tl)) { rec->texloc = tl; ++handed; }
-    else atomicMin(&first_fail, i);
-    ++r;
+  __syncthreads();
+  for (uint32_t i0 = 0; i0 < n; i0 += 4096u) {
+    uint32_t slot[4];
+    unsigned long long tl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t i = i0 + 1024u * k + (uint32_t)t;
+      slot[k] = i < n ? v.work_slot[i] : kInvalidSlot;  // !HasMesh -> continue (:157)
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) tl[k] = slot[k] != kInvalidSlot ? v.mesh_rec[slot[k]].texloc : 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + 1024u * k >= n) break;  // (block-uniform)
+      const uint32_t i = i0 + 1024u * k + (uint32_t)t;
+      const bool c = slot[k] != kInvalidSlot && tl[k] == kNoTexloc;
+      const unsigned long long m = __ballot(c);
+      __syncthreads();  // (wsum of the previous round has been read)
+      if (lane == 0) wsum[w] = (uint32_t)__popcll(m);
+      __syncthreads();
+      uint32_t before = 0, tot = 0;
+      for (int j = 0; j < 16; ++j) { if (j < w) before += wsum[j]; tot += wsum[j]; }
+      if (c) {
+        const uint32_t r = run + before + (uint32_t)__popcll(m & lt);
+        unsigned long long ntl;
+        if (slot_texloc(v, base + r, &ntl)) { v.mesh_rec[slot[k]].texloc = ntl; ++handed; }
+        else atomicMin(&first_fail, i);
+      }
+      run += tot;
+    }
   }
   __syncthreads();
   const uint32_t ff = first_fail;
   unsigned long long lmin = ~0ull, lmax = 0ull;
   uint32_t kept = 0;
-  for (uint32_t i = b; i < e; ++i) {
-    const uint32_t slot = v.work_slot[i];
-    if (slot == kInvalidSlot) continue;
-    if (i >= ff) { v.work_slot[i] = kInvalidSlot; continue; }
-    MeshRec* rec = &v.mesh_rec[slot];
-    const int kf_slot = v.work_ids[i].w;
-    ++kept;
-    patch_begin(rec, v.kf_tab[kf_slot], kf_slot);
-    lmin = rec->texloc < lmin ? rec->texloc : lmin;
-    lmax = rec->texloc > lmax ? rec->texloc : lmax;
+  for (uint32_t i0 = 0; i0 < n; i0 += 4096u) {
+    uint32_t slot[4];
+    int kfs[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t i = i0 + 1024u * k + (uint32_t)t;
+      slot[k] = i < n ? v.work_slot[i] : kInvalidSlot;
+      kfs[k] = i < n ? v.work_ids[i].w : 0;
+    }
+    unsigned long long tl[4];
+    int32_t kid[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t i = i0 + 1024u * k + (uint32_t)t;
+      const bool live = slot[k] != kInvalidSlot && i < ff;
+      tl[k] = live ? v.mesh_rec[slot[k]].texloc : 0ull;
+      kid[k] = live ? v.kf_tab[kfs[k]].kf_id : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t i = i0 + 1024u * k + (uint32_t)t;
+      if (slot[k] == kInvalidSlot) continue;
+      if (i >= ff) { v.work_slot[i] = kInvalidSlot; continue; }
+      MeshRec* rec = &v.mesh_rec[slot[k]];
+      ++kept;
+      // Patch::clear (Patch.cpp:177-189) + SetFrameid: patch_begin with the keyframe's id fetched above
+      rec->frameid = kid[k];
+      rec->kf_slot = kfs[k];
+      rec->pflags = kPfHasPatch;
+      rec->ratio[0] = 1.0f; rec->ratio[1] = 1.0f;
+      lmin = tl[k] < lmin ? tl[k] : lmin;
+      lmax = tl[k] > lmax ? tl[k] : lmax;
+    }
   }
   atomicMin(&smin, lmin);
   atomicMax(&smax, lmax);
@@ -113,7 +143,6 @@ __global__ __launch_bounds__(1024) void k_patch_assign(VolumeDev v, uint32_t n) 
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) { tot += __shfl_xor(tot, o); tk += __shfl_xor(tk, o); }
   __syncthreads();
-  __shared__ uint32_t ksum[16];
   if (lane == 0) { wsum[w] = tot; ksum[w] = tk; }
   __syncthreads();
   if (t == 0) {
@@ -858,6 +887,7 @@ int tf_generate_patches(tf_volume* v, const int32_t* ids, int64_t n, const int32
   rc = upload_work(v, ids, kfs.data(), n);
   if (rc) return rc;
   a.fused_armed = false;
+  hipLaunchKernelGGL(k_work_lookup, dim3(((uint32_t)n + 255u) / 256u), dim3(256), 0, v->stream, v->dev, (uint32_t)n);
   hipLaunchKernelGGL(k_patch_assign, dim3(1), dim3(1024), 0, v->stream, v->dev, (uint32_t)n);
   prof_begin(v, TF_PROF_PATCH_PROJECT);
   hipLaunchKernelGGL((k_patch<true, false, false>), dim3(1024), dim3(256), 0, v->stream, v->dev, v->cam, 0, KfDev{});
