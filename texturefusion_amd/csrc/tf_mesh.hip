@@ -1011,10 +1011,14 @@ static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries,
   uint32_t* cnt = v.mesh_cnt + (size_t)(cnt_par & 1) * kMeshCntWords;
   uint32_t* cnt_next = v.mesh_cnt + (size_t)((cnt_par & 1) ^ 1) * kMeshCntWords;
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
-  // workgroup b takes row b of the concatenated shard lists and strides by the grid: a few resident rounds at most
-  // (128 threads per chunk: with 12.4 KB of LDS and 80 VGPRs twelve chunks are resident per CU)
+  // workgroup b takes row b of the concatenated shard lists and strides by the grid.  The grid is the RESIDENT capacity
+  // (128 threads per chunk: with 12.4 KB of LDS and 80 VGPRs -- TF_MESH_WAVES waves per SIMD -- twelve chunks per CU): every
+  // workgroup starts at once and walks rows until the lists end.  (Up to round 5 the cap was 4096: the workgroups beyond the
+  // capacity started when the first ones had finished ALL their rows and then walked theirs -- the hall's 12 k survivors
+  // took 175.9 us of filter + mesher per frame instead of 157.3, a room frame's 3 k are the same either way.)
   uint32_t grid = ((max_entries + kMeshShards - 1) / kMeshShards + 1) * kMeshShards;
-  if (grid > 4096u) grid = 4096u;
+  static const uint32_t gmax = (uint32_t)device_cus() * (uint32_t)(TF_MESH_WAVES * 2);
+  if (grid > gmax) grid = gmax;
   hipLaunchKernelGGL((k_mesh<128>), dim3(grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
                      fused ? kMsSimplified : 0u, dbg, rearm_set);
 }
@@ -1027,7 +1031,7 @@ bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
   const uint32_t cap_sh = mesh_shard_rows(v.max_chunks);
   if (max_entries > v.max_chunks) max_entries = v.max_chunks;
   // 2560 workgroups = 1.25 x the wave form's resident capacity: a list of up to 10 k entries runs one entry per wave
-  const uint32_t fmax = 2560u;
+  const uint32_t fmax = 2560u;  // (the workgroup-batch form on the hall's 86 k entries: 1024 / 1536 / 2560 / 3072 / 4608 / 6144 workgroups = 59 / 50 / 43 / 42 / 42 / 44 us)
   const uint32_t fgrid = (max_entries + 3) / 4 < fmax ? (max_entries + 3) / 4 : fmax;
   const uint32_t* dslot = fused ? v.work_slot : nullptr;
   const int ppar = fused ? (rearm_set ^ 1) : -1;
