@@ -194,20 +194,28 @@ def under_profiler():
 
 def visible_gpus():
     """HIP devices this process could use, WITHOUT initialising the GPU (the launcher below must stay a process that
-    never touched it: its children are started with fork + exec).  torch.cuda.device_count() reads the driver's device
-    list on this image and makes no HIP context; the sysfs census of KFD nodes is the fallback."""
+    never touched it: its children are started with fork + exec).  The census of KFD topology nodes in sysfs needs no
+    runtime and no torch import; HIP_/ROCR_VISIBLE_DEVICES narrow it the way the runtime would.  Only when sysfs has no
+    KFD tree at all (not a ROCm host) is torch asked -- device_count() reads the driver's list and makes no context on
+    this image, but that is a property of the image, not a contract."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if nodes:
+        n = 0
+        for p in nodes:
+            try:
+                props = dict(l.split()[:2] for l in open(p).read().splitlines() if len(l.split()) >= 2)
+            except OSError:
+                continue
+            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
+        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+            lst = os.environ.get(var)
+            if lst is not None:
+                n = min(n, len([x for x in lst.split(",") if x.strip() != ""]))
+        return n
     try:
         import torch
         return int(torch.cuda.device_count())
-    except Exception:
-        pass
-    try:
-        import glob
-        n = 0
-        for p in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
-            props = dict(l.split()[:2] for l in open(p).read().splitlines() if len(l.split()) >= 2)
-            n += 1 if int(props.get("simd_count", "0")) > 0 else 0
-        return n
     except Exception:
         return 0
 

@@ -69,8 +69,9 @@ typedef struct {
    * exhausted is the mesh stored empty and reported as TF_ERR_CAPACITY at the next synchronising call. */
   int32_t mesh_max_vertices;
   int32_t mesh_max_triangles;
-  /* blocks of the small pool; 0 = default max(4096, max_chunks / 4) (a quarter of the chunks of a scanned scene lie on a
-   * surface; the rest -- in front of it, behind it, parked -- never own a mesh), at most max_chunks */
+  /* blocks of the small pool; 0 = default max_chunks: every chunk can own a mesh, as in the reference, whose allMeshes never
+   * drops one (ChunkManager.cpp:260-262) -- 20.4 KiB of HBM per pool slot at the default block size.  A caller that knows its
+   * scene can take less (about 30 % of the chunks of a scanned room lie on a surface: DESIGN.md s.2); at most max_chunks */
   int64_t mesh_blocks;
 } tf_config;
 
@@ -133,6 +134,16 @@ TF_API int tf_device_count(void);
  *   the reference kernel hard-codes 512-voxel chunks (ColorVoxel.h:31, Chisel.cpp:81-109). */
 TF_API int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color,
                             const tf_config* cfg, tf_volume** out);
+/* tf_config grows by appended fields and is handed over by pointer: the sized form copies cfg_bytes of it and takes the
+ *   defaults (0) for whatever the caller's header did not know.  C / C++ callers get it through the macro below, so a
+ *   program built against an older header keeps working against a newer library; tf_volume_create itself stays exported
+ *   for bindings that fill the current struct (ctypes, texturefusion_amd/capi.py). */
+TF_API int tf_volume_create_sized(const int32_t chunk_dim[3], float resolution, int use_color, const tf_config* cfg,
+                                  size_t cfg_bytes, tf_volume** out);
+#ifndef TF_NO_SIZED_CREATE
+#define tf_volume_create(chunk_dim, resolution, use_color, cfg, out) \
+  tf_volume_create_sized((chunk_dim), (resolution), (use_color), (cfg), sizeof(tf_config), (out))
+#endif
 TF_API int tf_volume_destroy(tf_volume* v);
 /* Chisel::Reset   Structure/Chisel.cpp:47-50 */
 TF_API int tf_volume_reset(tf_volume* v);
@@ -346,11 +357,18 @@ TF_API int tf_host_frame_times(tf_volume* v, double out[7], int reset);
 TF_API int tf_texture_frame_device(tf_volume* v, const float pose_inv16[16], int32_t frame_id);
 /* The same in two halves around the caller's own boundary exchange, so that the exchange overlaps work: phase 1 builds the
  * frame's dirty set and meshes its INTERIOR chunks (those whose 27-chunk neighbourhood this rank owns: nothing they read
- * comes from another rank); then pack / transport / tf_boundary_unpack_*(join_dirty) -- on any stream the caller orders
- * behind phase 1's launches or, for overlap, next to them: phase 1 reads no ghost chunk and no list the unpack writes --;
- * phase 2 meshes the boundary chunks and everything the arriving ghosts added, and leaves the patch stage pending as
- * tf_texture_frame_device does.  Results equal the one-call form bit for bit.  (With tf_comm_exchange_every_frame the
- * library does exactly this itself, the exchange on a second stream: tf_comm_exchange_overlap(v, 0) switches that off.) */
+ * comes from another rank); phase 2 meshes the boundary chunks and everything the arriving ghosts added, and leaves the
+ * patch stage pending as tf_texture_frame_device does.  Order for the caller's transport:
+ *   - tf_boundary_unpack_*(join_dirty) must run BEHIND phase 1 and ahead of phase 2: phase 1's filter walks the flat work
+ *     list of the frame's parity, the list join_dirty appends to (the library's own overlapped exchange hands its interior
+ *     pass an empty flat list instead; this entry point does not).  The tf_boundary_unpack_* entry points launch on the
+ *     handle's stream, so calling them after phase 1 gives that order;
+ *   - what may overlap phase 1 is the PACK and the TRANSPORT: issue tf_boundary_pack_* before phase 1 (it reads voxels the
+ *     frame's update has finished writing and nothing phase 1 writes) and run the transport on the caller's own stream or
+ *     thread while phase 1's launches execute; a pack issued after phase 1 sits behind it on the handle's stream and
+ *     overlaps nothing.
+ * Results equal the one-call form bit for bit.  (With tf_comm_exchange_every_frame the library does this itself, pack /
+ * send / receive / unpack on a second stream next to the interior pass: tf_comm_exchange_overlap(v, 0) switches that off.) */
 TF_API int tf_texture_frame_device_phase(tf_volume* v, const float pose_inv16[16], int32_t frame_id, int phase);
 TF_API int tf_comm_exchange_overlap(tf_volume* v, int on);
 TF_API int tf_sync(tf_volume* v);
@@ -388,6 +406,13 @@ TF_API int tf_update_meshes(tf_volume* v, int64_t* n_meshed);
  *   chunks whose voxels hold a class the summary lacks (must be 0), *n_stale = chunks whose summary holds a class the
  *   voxels no longer do (allowed: costs time, never changes a result).  Any output may be NULL. */
 TF_API int tf_check_summaries(tf_volume* v, int64_t* n_chunks, int64_t* n_missing, int64_t* n_stale);
+/* Diagnostic of the neighbour table the filter and the patch stage read instead of probing the chunk hash (what
+ *   ChunkManager::GenerateMeshEfficient resolves per call with GetChunk on the neighbour ids, Structure/ChunkManager.cpp:618-632,
+ *   and Chisel::CompressMeshes with allMeshes.find, Structure/Chisel.cpp:134-137): per pool slot the pool slots of the 26
+ *   chunks around it, filled lazily.  out6 = {rows, non-zero words, non-zero words that disagree with the hash (must be 0),
+ *   rows whose "no chunk there" words are currently trusted in full, trusted "none" words whose chunk exists (must be 0),
+ *   the same among the eight words the summary test trusts on their own (must be 0)}. */
+TF_API int tf_check_neighbours(tf_volume* v, int64_t out6[6]);
 /* keys of ChunkManager::GetAllMeshes() (Structure/ChunkManager.h:714) */
 TF_API int tf_list_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n);
 /* Mesh::vertices.size() / indices.size() / adj[6] / simplified of listed chunks (Mesh.h:70-85);

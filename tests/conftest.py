@@ -39,11 +39,13 @@ def _summaries_cover_the_voxels(request, monkeypatch):
     from texturefusion_amd import capi
     real_close = capi.Volume.close
     seen = []
+    nbrs = []
 
     def close(self):
         if getattr(self, "h", None):
             try:
                 seen.append(self.check_summaries())
+                nbrs.append(self.check_neighbours())
             except capi.TFError:
                 pass  # a handle a test has deliberately left in an error state
         real_close(self)
@@ -52,3 +54,5 @@ def _summaries_cover_the_voxels(request, monkeypatch):
     yield
     for n, missing, stale in seen:
         assert missing == 0, "filter summaries lack classes in %d of %d chunks" % (missing, n)
+    for c in nbrs:  # ... and of the neighbour table the filter / patch stage read instead of probing the hash
+        assert c[2] == 0 and c[4] == 0 and c[5] == 0, "neighbour table disagrees with the chunk hash: %s" % (c.tolist(),)

@@ -465,9 +465,18 @@ int main() {
         else if (line.compare(0, 2, "f ") == 0) ++nf;
       }
       CHECK(want_v > 1000 && nv_ == want_v && nvt == want_v && nvn == want_v && nf == want_f);
-      for (const auto& it : chiselMap.GetChunkManager().GetAllMeshes()) {
-        if (!(it.second->m_patch && it.second->m_patch->complete())) continue;
-        const chisel::Patch& p = *it.second->m_patch;
+      {  // (the file lists the meshes in ascending chunk id, like DrawMeshes' stream)
+        const chisel::Mesh* first_mesh = nullptr;
+        for (const auto& it : chiselMap.GetChunkManager().GetAllMeshes()) {
+          if (!(it.second->m_patch && it.second->m_patch->complete()) || it.second->n_vertices == 0) continue;
+          const chisel::ChunkID& a = it.first;
+          if (!first_mesh) { first_mesh = it.second.get(); continue; }
+          const chisel::ChunkID& b = first_mesh->chunkID;
+          if (a(0) < b(0) || (a(0) == b(0) && (a(1) < b(1) || (a(1) == b(1) && a(2) < b(2))))) first_mesh = it.second.get();
+        }
+        CHECK(first_mesh != nullptr);
+        chiselMap.FetchPatchData(first_mesh->chunkID);
+        const chisel::Patch& p = *first_mesh->m_patch;
         chisel::Vec2 tex((float)(p.texloc % 13824), (float)(p.texloc / 13824));
         tex(0) += p.texcoord[0](0) * p.ratio(0);
         tex(1) += p.texcoord[0](1) * p.ratio(1);
@@ -476,7 +485,6 @@ int main() {
         std::ostringstream want;
         want << std::fixed << std::setprecision(6) << "vt " << tex(0) << " " << 1.0f - tex(1);
         CHECK(first_vt == want.str());
-        break;
       }
       std::ifstream mtl((base + "/texture_model.mtl").c_str());
       std::getline(mtl, line);

@@ -29,7 +29,7 @@ PROF_NAMES = ("bbox", "select", "scan", "emit", "integrate", "finalize", "patch_
 
 # every symbol include/tf_fusion.h declares (checked by tests/test_abi.py)
 SYMBOLS = (
-    "tf_last_error", "tf_device_count", "tf_volume_create", "tf_volume_destroy", "tf_volume_reset",
+    "tf_last_error", "tf_device_count", "tf_volume_create", "tf_volume_create_sized", "tf_volume_destroy", "tf_volume_reset",
     "tf_set_stream", "tf_set_camera", "tf_set_truncation", "tf_set_weight", "tf_frame_upload",
     "tf_frame_upload_rgb",
     "tf_frame_bind_device", "tf_prepare", "tf_integrate", "tf_finalize", "tf_integrate_frame",
@@ -44,7 +44,7 @@ SYMBOLS = (
     "tf_host_frame_buffers", "tf_host_frame_deferral", "tf_host_frame_set_deferral", "tf_host_frame_set_async", "tf_host_frame_fence", "tf_texture_frame_device_phase", "tf_comm_exchange_overlap", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_boundary_band_bounds", "tf_boundary_pack_bands2", "tf_boundary_unpack_pair", "tf_comm_exchange_mode", "tf_comm_stats", "tf_comm_stats_ex",
     "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
     "tf_comm_exchange_every_frame",
-    "tf_update_meshes", "tf_check_summaries", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
+    "tf_update_meshes", "tf_check_summaries", "tf_check_neighbours", "tf_list_meshes", "tf_mesh_counts", "tf_meshes_download", "tf_compress_meshes",
     "tf_pre_normal_map", "tf_pre_refine_depth_normal", "tf_pre_color_valid", "tf_pre_color_quality",
     "tf_pre_refine_newframe", "tf_pre_refine_keyframe", "tf_pre_frame_depth", "tf_integrate_depth_group", "tf_integrate_depth_group_host",
 )
@@ -218,6 +218,7 @@ def lib():
     L.tf_update_meshes.argtypes = [vp, i64p]
     L.tf_list_meshes.argtypes = [vp, i32p, C.c_int64, i64p]
     L.tf_check_summaries.argtypes = [vp, i64p, i64p, i64p]
+    L.tf_check_neighbours.argtypes = [vp, i64p]
     L.tf_mesh_counts.argtypes = [vp, i32p, C.c_int64, i32p, i32p, u8p, u8p]
     L.tf_meshes_download.argtypes = [vp, i32p, C.c_int64, i64p, i64p, fp, fp, fp, u32p]
     L.tf_compress_meshes.argtypes = [vp, i32p, C.c_int64, i64p]
@@ -525,6 +526,13 @@ class Volume:
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self._ck(self.L.tf_check_summaries(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def check_neighbours(self):
+        """-> i64[6]: rows, non-zero words, wrong words (must be 0), fully trusted rows, trusted "none" words whose chunk
+        exists (must be 0), the same among the near eight (must be 0) -- the neighbour table against the chunk hash"""
+        out = np.zeros(6, np.int64)
+        self._ck(self.L.tf_check_neighbours(self.h, _p(out, C.c_int64)))
+        return out
 
     def mesh_counts(self, ids):
         """-> (n_vertices i32[n], n_indices i32[n], adj u8[n,6], simplified u8[n])"""

@@ -184,6 +184,8 @@ static int init_device_state(tf_volume* v) {
   TF_HIP(hipMemsetAsync(d.hent, 0xFF, ((size_t)d.hmask + 1) * sizeof(HEntry), s));  // key = empty
   TF_HIP(hipMemsetAsync(d.mark_epoch, 0, (size_t)d.max_chunks * 4, s));
   TF_HIP(hipMemsetAsync(d.erase_epoch, 0, (size_t)d.max_chunks * 4, s));
+  TF_HIP(hipMemsetAsync(d.nbr, 0, (size_t)d.max_chunks * kNbrWords * 4, s));  // nothing known, nothing checked (create_seq = 0: k_reset_ctl)
+  d.seq = 1;
   TF_HIP(hipMemsetAsync(d.phase_buf, 0, (size_t)kPhaseWaves * 16 * 8, s));
   v->clear_floor = 0;
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
@@ -329,8 +331,14 @@ int tf_device_count(void) {
   return n;
 }
 
+#undef tf_volume_create
 int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color,
                      const tf_config* cfg, tf_volume** out) {
+  return tf_volume_create_sized(chunk_dim, resolution, use_color, cfg, sizeof(tf_config), out);
+}
+
+int tf_volume_create_sized(const int32_t chunk_dim[3], float resolution, int use_color, const tf_config* cfg,
+                           size_t cfg_bytes, tf_volume** out) {
   if (!out || !chunk_dim) { set_error("null argument"); return TF_ERR_INVALID; }
   *out = nullptr;
   if (chunk_dim[0] != 8 || chunk_dim[1] != 8 || chunk_dim[2] != 8) {
@@ -346,7 +354,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   tf_volume* v = new tf_volume();
   v->host_defer = tf::host_defer_default();
   memset(&v->cfg, 0, sizeof(v->cfg));
-  if (cfg) v->cfg = *cfg;
+  if (cfg) memcpy(&v->cfg, cfg, std::min(cfg_bytes, sizeof(v->cfg)));  // (fields the caller's header lacks: defaults)
   if (v->cfg.max_chunks <= 0) v->cfg.max_chunks = 1ll << 20;
   v->cfg.max_chunks = (v->cfg.max_chunks + 63) & ~63ll;  // 64 allocation stripes
   if (v->cfg.max_chunks > (1ll << 27)) {
@@ -399,6 +407,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   if ((rc = dev_alloc(v, &d.color, (size_t)d.max_chunks * kChunkVoxels))) return fail(rc);
   if ((rc = dev_alloc(v, &d.hent, hcap))) return fail(rc);
   if ((rc = dev_alloc(v, &d.summ, (size_t)d.max_chunks))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.nbr, (size_t)d.max_chunks * kNbrWords))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mark_epoch, (size_t)d.max_chunks * 2))) return fail(rc);  // mark | erase, one allocation
   d.erase_epoch = d.mark_epoch + d.max_chunks;
   if ((rc = dev_alloc(v, &d.phase_buf, (size_t)kPhaseWaves * 16))) return fail(rc);
@@ -413,7 +422,7 @@ int tf_volume_create(const int32_t chunk_dim[3], float resolution, int use_color
   d.mesh_ct = (uint32_t)v->cfg.mesh_max_triangles;
   {  // the mesh store's small pool: handed out block by block to the chunks that get a mesh (MeshRec::block)
     int64_t nb = v->cfg.mesh_blocks;
-    if (nb <= 0) nb = std::max<int64_t>(4096, v->cfg.max_chunks / 4);
+    if (nb <= 0) nb = v->cfg.max_chunks;  // every chunk can own a mesh (the reference's allMeshes never drops one)
     if (nb > v->cfg.max_chunks) nb = v->cfg.max_chunks;
     v->cfg.mesh_blocks = nb;
     d.mesh_blocks = (uint32_t)nb;
@@ -482,7 +491,7 @@ int tf_volume_destroy(tf_volume* v) {
   if (v->xstream) { hipStreamSynchronize(v->xstream); hipStreamDestroy(v->xstream); v->xstream = nullptr; }
   if (v->ev_fork) { hipEventDestroy(v->ev_fork); v->ev_fork = nullptr; }
   if (v->ev_join) { hipEventDestroy(v->ev_join); v->ev_join = nullptr; }
-  for (const tf_volume::HostRange& r : v->host_ranges) (void)host_range_release(r.p);
+  for (const tf_volume::HostRange& r : v->host_ranges) (void)host_range_release(r.locked);
   v->host_ranges.clear();
   for (int k = 0; k < tf_volume::kHostRing; ++k) {
     if (v->hslot[k].h) hipHostFree(v->hslot[k].h);
@@ -847,6 +856,18 @@ int tf::fused_arm(tf_volume* v) {
   return TF_OK;
 }
 
+// Neighbour table (VolumeDev::nbr): every filter launch carries a seq above that of every launch ahead of it on the
+// stream, so that a row it checks outlives exactly the key insertions that come later (VolCtl::create_seq).  After 2^32
+// launches the table starts over.
+uint32_t tf::nbr_next_seq(tf_volume* v) {
+  if (v->dev.seq >= 0xFFFFFFF0u) {
+    (void)hipMemsetAsync(v->dev.nbr, 0, (size_t)v->dev.max_chunks * kNbrWords * 4, v->stream);
+    (void)hipMemsetAsync(&v->dev.vctl->create_seq, 0, 4, v->stream);
+    v->dev.seq = 1;
+  }
+  return ++v->dev.seq;
+}
+
 // claimed: the dirty set of this frame is already in the lists of the current parity -- K-A built it (FrameStage::claim_par
 // = the parity used here), or the caller ran launch_dirty_frame over each of its lists (the keyframe unit)
 int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
@@ -864,6 +885,7 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
     d.work_ids = a.d_work_ids + (size_t)par * d.max_chunks;
     d.work_slot = a.d_work_slot + (size_t)par * d.max_chunks;
     prof_begin(v, TF_PROF_MESH);
+    d.seq = nbr_next_seq(v);
     launch_mesh(d, v->mesh_par, d.work_ids, &d.actl->set[par].n_work, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1, 0u, nullptr, par,
                 v->stream, nullptr, &v->cam, /*cls=*/2);
     v->mesh_par ^= 1;
@@ -902,8 +924,11 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
   // one filter + mesher pass over the frame's dirty set (cls: every chunk / interior chunks only / boundary chunks only);
   // the shard lists of this parity are walked in any case: empty when K-A did not claim -- the previous frame's mesher
   // re-armed them
-  auto mesh_pass = [&](int cls, const uint32_t* flat_count, bool with_hint, bool with_ride) -> bool {
+  // (new_seq = false: the pass runs NEXT TO the unpack launch of an overlapped exchange, which carries the same seq -- a
+  // key that launch inserts voids what this pass checks of the neighbour table)
+  auto mesh_pass = [&](int cls, const uint32_t* flat_count, bool with_hint, bool with_ride, bool new_seq = true) -> bool {
     prof_begin(v, TF_PROF_MESH);
+    d.seq = new_seq ? nbr_next_seq(v) : v->dev.seq;
     const bool rode = launch_mesh(d, v->mesh_par, d.work_ids, flat_count, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1,
                                   len_guess, with_hint ? a.h_dirty_len : nullptr, par, v->stream, with_ride ? &prev : nullptr,
                                   &v->cam, cls, store);
@@ -944,11 +969,12 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
       TF_HIP(hipStreamWaitEvent(v->xstream, v->ev_fork, 0));
       hipStream_t main_stream = v->stream;
       v->stream = v->xstream;  // (comm_exchange and what it calls enqueue on the handle's stream)
+      (void)nbr_next_seq(v);   // the unpack launch and the interior pass next to it share this seq
       rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u, xc, frame_epoch + 1u, xn);
       v->stream = main_stream;
       if (rc) return rc;
       TF_HIP(hipEventRecord(v->ev_join, v->xstream));
-      rode = mesh_pass(1, &d.vctl->zero_word, true, false);
+      rode = mesh_pass(1, &d.vctl->zero_word, true, false, /*new_seq=*/false);
       prof_begin(v, TF_PROF_XCHG_WAIT);                        // what of the exchange is NOT hidden behind the interior pass
       TF_HIP(hipStreamWaitEvent(v->stream, v->ev_join, 0));
       prof_end(v);
@@ -1296,20 +1322,28 @@ int tf_host_register(tf_volume* v, const void* p, int64_t bytes) {
   const uint8_t* b = static_cast<const uint8_t*>(p);
   for (const tf_volume::HostRange& r : v->host_ranges)
     if (b >= r.p && b + bytes <= r.p + r.n) return TF_OK;  // already inside a range of this handle
+  const uint8_t* locked = b;  // base of the page-locked range that covers [b, b + bytes)
   {
     std::lock_guard<std::mutex> lk(g_locked_mu);
-    auto it = g_locked.find(b);
-    if (it != g_locked.end() && it->second.n >= (size_t)bytes) {
-      it->second.refs += 1;  // another handle of this process locked these pages already
-    } else if (it != g_locked.end()) {
-      set_error("tf_host_register: the buffer is registered with a smaller size by another handle");
-      return TF_ERR_INVALID;
+    // a range some handle of this process locked already may CONTAIN this one (depth / colour views inside one arena):
+    // hipHostRegister on pages that are locked fails, so the containing range is shared instead
+    auto it = g_locked.upper_bound(b);
+    const bool have = it != g_locked.begin() && (--it, b < it->first + it->second.n);  // the range at or below b reaches b
+    if (have && b + bytes <= it->first + it->second.n) {
+      it->second.refs += 1;
+      locked = it->first;
     } else {
+      auto up = g_locked.lower_bound(b);  // the first range that starts at or above b
+      if (have || (up != g_locked.end() && up->first < b + bytes)) {
+        set_error("tf_host_register: the buffer overlaps a range that is page-locked already with a different extent "
+                  "(register the whole arena once, or ranges that do not overlap)");
+        return TF_ERR_INVALID;
+      }
       TF_HIP(hipHostRegister(const_cast<uint8_t*>(b), (size_t)bytes, hipHostRegisterDefault));
       g_locked[b] = LockedRange{(size_t)bytes, 1};
     }
   }
-  v->host_ranges.push_back({b, (size_t)bytes});
+  v->host_ranges.push_back({b, (size_t)bytes, locked});
   return TF_OK;
 }
 int tf_host_unregister(tf_volume* v, const void* p) {
@@ -1318,8 +1352,9 @@ int tf_host_unregister(tf_volume* v, const void* p) {
   TF_HIP(hipStreamSynchronize(v->copy_stream ? v->copy_stream : v->stream));
   for (size_t i = 0; i < v->host_ranges.size(); ++i)
     if (v->host_ranges[i].p == static_cast<const uint8_t*>(p)) {
+      const uint8_t* locked = v->host_ranges[i].locked;
       v->host_ranges.erase(v->host_ranges.begin() + (long)i);
-      return host_range_release(static_cast<const uint8_t*>(p));
+      return host_range_release(locked);
     }
   set_error("not a registered buffer");
   return TF_ERR_INVALID;

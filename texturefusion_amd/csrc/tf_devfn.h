@@ -112,6 +112,7 @@ __device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, b
       cur = atomicCAS(&v.hent[i].key, kEmptyKey, key);
       if (cur == kEmptyKey) {  // inserted: allocate a fresh slot (storage is in the fresh state)
         *ent = i;
+        v.vctl->create_seq = v.seq;  // "no chunk there" words of the neighbour table checked before this launch are void
         const uint32_t stripe = (hash_key(key) >> 7) & (kSlotStripes - 1);
         const uint32_t per = v.max_chunks / kSlotStripes;
         const uint32_t k = atomicAdd(&v.vctl->slot_cnt[stripe], 1u);
@@ -140,6 +141,42 @@ __device__ __forceinline__ uint32_t chunk_acquire(const VolumeDev& v, int4 id, b
   atomicOr(&v.vctl->status, kStHashFull);
   *ent = 0;
   return kInvalidSlot;
+}
+
+// ---- neighbour table (VolumeDev::nbr) ------------------------------------------------------------------------------
+// word of a row for the chunk at id + (dx, dy, dz)
+__device__ __forceinline__ int nbr_word(int dx, int dy, int dz) { return (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1); }
+// what a row stores for a key: pool slot + 1 of the chunk if the hash holds it with a pool slot (alive or parked), else 0.
+// One 16-byte load per probe.  An entry that is being inserted by another wave of the same launch (key there, slot not
+// yet) reads as "none" and is not cached.
+__device__ __forceinline__ uint32_t nbr_probe(const VolumeDev& v, unsigned long long key) {
+  uint32_t i = hash_key(key) & v.hmask;
+  for (uint32_t probe = 0; probe <= v.hmask; ++probe) {
+    const uint4 e = *reinterpret_cast<const uint4*>(&v.hent[i]);  // {key lo, key hi, slot, alive}
+    const unsigned long long cur = ((unsigned long long)e.y << 32) | e.x;
+    if (cur == key) return e.z + 1u;  // (kInvalidSlot + 1 = 0: a chunk the pool had no slot for)
+    if (cur == kEmptyKey) return 0u;
+    i = (i + 1) & v.hmask;
+  }
+  return 0u;
+}
+// The row of pool slot `own` (chunk `id`), lane j < kNbrWords holding word j, with every "none" word among the first
+// n_check (27: the whole row; lanes beyond hold 0) made trustworthy: a row whose check is older than the newest key
+// insertion re-probes its zero words, writes back what it finds and stamps the check (the caller's launch carries a seq
+// above every insertion ahead of it on the stream, launch_mesh).  `w` = the lane's word as loaded (the caller issues the
+// load, next to whatever else it wants in flight); create_seq = VolCtl::create_seq as this launch found it.  Wave-uniform
+// control flow when the lanes of a wave share one row.
+__device__ __forceinline__ uint32_t nbr_row_checked(const VolumeDev& v, const uint32_t own, const int4 id, const int lane,
+                                                   uint32_t w, const uint32_t create_seq) {
+  const uint32_t st = (uint32_t)__shfl((int)w, kNbrFull);
+  if (!(st > create_seq)) {
+    if (lane < 27 && lane != 13 && w == 0u) {
+      w = nbr_probe(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
+      if (w) v.nbr[(size_t)own * kNbrWords + lane] = w;
+    }
+    if (lane == kNbrNear || lane == kNbrFull) v.nbr[(size_t)own * kNbrWords + lane] = v.seq;
+  }
+  return w;
 }
 
 // class of one voxel for the mesher's filter (ChunkManager.cpp:669-722, :776-777): observed (sdf <= 1), observed and

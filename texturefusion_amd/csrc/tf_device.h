@@ -94,7 +94,9 @@ struct VolCtl {
   // workgroup writes the blocks' headers and re-arms the three words (no memset, no header launch per exchange)
   uint32_t xchg_cnt[2];
   uint32_t xchg_ticket;
-  uint32_t xchg_pad2;
+  // neighbour table (VolumeDev::nbr): VolumeDev::seq of the newest launch that INSERTED a key into the chunk hash.  A row's
+  // "no chunk there" entries are trusted only if the row was checked by a launch with a larger seq (kNbrNear / kNbrFull).
+  uint32_t create_seq;
   // Pool slots are handed out from 64 independent stripes (stripe s owns slots
   // [s*max_chunks/64, (s+1)*max_chunks/64)) so that the thousands of chunk creations of a
   // first-touch frame do not serialise on one atomic word.
@@ -210,6 +212,17 @@ struct VolumeDev {
   // it writes in, so a bit may outlive the voxel that set it (never the other way round); k_mesh_filter rewrites
   // the word exactly whenever it reads the chunk's voxels.
   uint32_t* summ;         // [max_chunks]
+  // Neighbour table: per pool slot one 128-byte row.  Words 0..26 = pool slot + 1 of the chunk at id + (dx, dy, dz),
+  // word index (dx + 1) + 3 (dy + 1) + 9 (dz + 1), 0 = no chunk known there (word 13, the chunk itself, is unused);
+  // word kNbrNear / kNbrFull = VolumeDev::seq of the launch that last checked the eight words of the +x / +y / +z corner
+  // (what the filter's summary test reads) / all 27 against the hash.  Pool slots never move and hash entries are never
+  // removed (a garbage-collected chunk is parked: alive = 0, voxels back in the fresh state, summary 0, mesh out of the map
+  // -- which is exactly what every reader by slot assumes of a chunk that does not exist), so a non-zero word is true for
+  // the life of the volume; a zero word is true while no key has been inserted since the check (VolCtl::create_seq).  The
+  // mesher's filter fills rows lazily: ONE coalesced load instead of 8 + 19 hash probes per dirty chunk and frame; the
+  // patch stage reads the six face words for CompressMeshes' flag exchange.
+  uint32_t* nbr;          // [max_chunks][kNbrWords]
+  uint32_t seq;           // launch sequence of the table: the host bumps it ahead of every filter launch (launch_mesh)
   unsigned long long* phase_buf;  // [kPhaseWaves][16] tuning aid: per-wave {start, end, role, XCC} stamps (TF_KA_DBG bit 12)
   uint32_t max_list;
   uint32_t max_coarse;
@@ -299,6 +312,7 @@ struct PatchStage {
   int par;   // counter-set parity of that frame (AtlasCtl::set, patch_list, patch_cnt)
   KfDev kf;  // the frame itself as the keyframe its patches are cut from
 };
+constexpr int kNbrWords = 32, kNbrNear = 27, kNbrFull = 28;  // VolumeDev::nbr
 constexpr uint32_t kSummAny = 0xFFFFu;        // VolumeDev::summ: every class may occur
 constexpr uint32_t kKaCoarseSumm = 16384u;    // IntegrateConsts::dbg bit: FrameStage::coarse_summ
 

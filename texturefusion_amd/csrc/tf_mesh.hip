@@ -247,25 +247,36 @@ __device__ __forceinline__ void filter_defer_reset(const VolumeDev& v, uint32_t*
   // (p >= cap_sh cannot happen: at most max_chunks / 32 pool slots share a shard, each listed once per frame)
 }
 
-// phase A of the filter for the 8-lane group a lane belongs to (k8 = its place in the group): lane k looks up chunk
-// id + (k & 1, (k >> 1) & 1, k >> 2) -- the chunk itself and its seven +x / +y / +z neighbours -- and reads that
-// chunk's class summary.  The summaries are supersets of the classes that occur among a chunk's voxels / on the faces
-// the neighbours contribute (an edge or the corner counts as the whole face it lies in), so a chunk they rule out is
-// ruled out for good.  Returns the lane's pool slot; *own = the chunk's, *maybe = the exact test is needed.
-__device__ __forceinline__ uint32_t filter_near(const VolumeDev& v, const int4 id, int lane, int k8, bool have_own,
-                                                uint32_t own_listed, bool use_summ, uint32_t* own, bool* maybe) {
+// phase A of the filter for the 8-lane group a lane belongs to (k8 = its place in the group): lane k stands for chunk
+// id + (k & 1, (k >> 1) & 1, k >> 2) -- the chunk itself and its seven +x / +y / +z neighbours -- whose pool slots come from
+// the chunk's row of the neighbour table (VolumeDev::nbr: lane 0 fetches the row's check stamp, lanes 1..7 their words; a
+// row whose "none" words may be stale re-probes them), and reads that chunk's class summary.  The summaries are supersets
+// of the classes that occur among a chunk's voxels / on the faces the neighbours contribute (an edge or the corner counts
+// as the whole face it lies in), so a chunk they rule out is ruled out for good.  own_in = the chunk's pool slot as every
+// lane of the group knows it (kInvalidSlot: none; listed: it came with the list entry, whose id.w may name a hash entry).  Returns the lane's pool slot; *own = the chunk's (kInvalidSlot: the
+// chunk is parked), *maybe = the exact test is needed.
+__device__ __forceinline__ uint32_t filter_near(const VolumeDev& v, const int4 id, int lane, int k8, uint32_t own_in, bool listed,
+                                                bool use_summ, uint32_t create_seq, uint32_t* own, bool* maybe) {
   uint32_t nslot = kInvalidSlot;
-  if (k8 == 0 && have_own) {
-    nslot = own_listed;  // the fused flow's list carries the chunk's own pool slot
+  *maybe = true;
+  if (own_in != kInvalidSlot) {
+    const int word = k8 == 0 ? kNbrNear : 13 + (k8 & 1) + 3 * ((k8 >> 1) & 1) + 9 * (k8 >> 2);
+    uint32_t w = v.nbr[(size_t)own_in * kNbrWords + word];
     // an entry K-A claimed (id.w = hash entry + 1) may have been parked later in that launch: RecomputeMeshes skips a
-    // chunk that does not exist (:240-242).  This load travels with the other lanes' hash probes.
-    if (id.w > 0 && !(v.hent[(uint32_t)id.w - 1u].alive & 1u)) nslot = kInvalidSlot;
-  } else {
-    const uint32_t ent = hash_find(v, pack_id(id.x + (k8 & 1), id.y + ((k8 >> 1) & 1), id.z + (k8 >> 2)));
-    if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
+    // chunk that does not exist (:240-242).  This load travels with the row's.
+    uint32_t alive = 1u;
+    if (k8 == 0 && listed && id.w > 0) alive = v.hent[(uint32_t)id.w - 1u].alive & 1u;
+    const uint32_t st = (uint32_t)__shfl((int)w, lane & 56);
+    if (!(st > create_seq)) {  // (group-uniform) the near words may lack a chunk inserted since the last check
+      if (k8 != 0 && w == 0u) {
+        w = nbr_probe(v, pack_id(id.x + (k8 & 1), id.y + ((k8 >> 1) & 1), id.z + (k8 >> 2)));
+        if (w) v.nbr[(size_t)own_in * kNbrWords + word] = w;
+      }
+      if (k8 == 0) v.nbr[(size_t)own_in * kNbrWords + kNbrNear] = v.seq;
+    }
+    nslot = k8 == 0 ? (alive ? own_in : kInvalidSlot) : (w ? w - 1u : kInvalidSlot);
   }
   *own = (uint32_t)__shfl((int)nslot, lane & 56);
-  *maybe = true;
   if (use_summ && *own != kInvalidSlot) {
     const uint32_t sm = nslot != kInvalidSlot ? v.summ[nslot] : 0u;
     // self: whole chunk; +x, +x+y, +x+z, +x+y+z: x = 0 face; +y, +y+z: y = 0 face; +z: z = 0 face
@@ -280,14 +291,14 @@ __device__ __forceinline__ uint32_t filter_near(const VolumeDev& v, const int4 i
 
 // phase B, one wave per entry.  A vertex needs a cell whose 8 corners are all observed with both signs among them,
 // and a corner with weight > 50 (:669-722, :776-777): the exact test reads the chunk's own 4 KiB and, if those do not
-// decide, the 217 corner voxels the +x / +y / +z neighbours contribute.  nslot: lanes 0..26 = neighbourhood index
-// 13 + dx + 3 dy + 9 dz, the near eight filled in by the caller; the far 19 are looked up here, behind the voxel reads
-// (only a survivor's row needs them).  A survivor gets a row of its shard for the mesher's staging.
-__device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, uint32_t nslot, int lane,
+// decide, the 217 corner voxels the +x / +y / +z neighbours contribute.  nslot: lanes 0..26 = pool slot of neighbourhood
+// index 13 + dx + 3 dy + 9 dz (kInvalidSlot: no chunk) -- HAVE_ROW: from the caller, else fetched here from the chunk's row
+// of the neighbour table, next to the voxel reads (own: the chunk's pool slot).  A survivor gets a row of its shard for
+// the mesher's staging.
+template <bool HAVE_ROW>
+__device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, uint32_t nslot, const uint32_t own, int lane,
                                              uint32_t epoch, uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
-                                             uint32_t cap_sh, int ppar, bool use_summ, bool defer) {
-  const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
-  const uint32_t own = (uint32_t)__shfl((int)nslot, 13);
+                                             uint32_t cap_sh, int ppar, bool use_summ, bool defer, uint32_t create_seq) {
   // rows and patch entries go to shard own % 32: pool slots are unique, so a shard never holds more than
   // max_chunks / 32 of them whatever the order of the work
   const uint32_t shard = own & (kMeshShards - 1u);
@@ -296,9 +307,10 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
 #pragma unroll
   for (int j = 0; j < 4; ++j) qv[j] = T4[j * 64 + lane];  // voxels 2 i and 2 i + 1 of the chunk, i = 64 j + lane: {sdf, w, sdf, w}
   const uint32_t had_mesh = v.mesh_rec[own].state & kMsInMap;  // (travels with the voxels: which end of the row list, below)
-  if (lane < 27 && !is_near) {
-    const uint32_t ent = hash_find(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
-    if (ent != kInvalidSlot && (v.hent[ent].alive & 1u)) nslot = v.hent[ent].slot;
+  if (!HAVE_ROW) {
+    uint32_t w = lane < kNbrWords ? v.nbr[(size_t)own * kNbrWords + lane] : 0u;
+    w = nbr_row_checked(v, own, id, lane, w, create_seq);
+    nslot = lane == 13 ? own : ((lane < 27 && w) ? w - 1u : kInvalidSlot);
   }
   uint32_t fl = 0;
 #pragma unroll
@@ -419,6 +431,7 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
   const uint32_t nblk = PATCH ? nbx - fp.n_patch : nbx;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
+  const uint32_t create_seq = v.vctl->create_seq;  // (no launch that inserts keys runs next to a filter over the same chunks)
   uint32_t n_flat = *dcount;
   if (n_flat > max_entries) n_flat = max_entries;
   // shard lists: per-lane inclusive scan of the 32 counters
@@ -443,19 +456,33 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bid * 256 + threadIdx.x) >> 6));
     auto process = [&](const int4 id, const uint32_t own_listed, const bool have_own) {
       if (fp.cls && ((fp.cls == 1u) != part_interior(v, id.x, id.y, id.z))) return;  // (the other pass of this frame takes it)
-      uint32_t own = kInvalidSlot;
-      bool maybe = false;
-      uint32_t near8 = kInvalidSlot;
-      if (lane < 8) near8 = filter_near(v, id, lane, lane, have_own, own_listed, use_summ, &own, &maybe);
-      own = (uint32_t)__shfl((int)own, 0);
-      maybe = __shfl((int)maybe, 0) != 0;
-      if (own == kInvalidSlot) return;  // RecomputeMeshes: !HasChunk -> skip (:240-242)
-      if (!maybe) {
-        if (lane == 0) { if (fp.defer) filter_defer_reset(v, cnt, cap_sh, own, id); else filter_reset_record(v, own, id, epoch, ppar); }
-        return;
+      // the chunk's pool slot: carried by the fused flow's lists, else one hash lookup (call-by-call flow).  RecomputeMeshes
+      // skips a chunk that does not exist (:240-242).
+      const uint32_t own = have_own ? own_listed : hash_slot_alive(v, pack_id(id.x, id.y, id.z));
+      if (own == kInvalidSlot) return;
+      // ONE hop: the chunk's row of the neighbour table (the 27 pool slots around it) and -- for an entry K-A claimed
+      // (id.w = hash entry + 1), which may have been parked later in that launch -- the entry's alive word
+      uint32_t w = lane < kNbrWords ? v.nbr[(size_t)own * kNbrWords + lane] : 0u;
+      uint32_t alive = 1u;
+      if (have_own && id.w > 0) alive = v.hent[(uint32_t)id.w - 1u].alive & 1u;
+      if (!alive) return;
+      w = nbr_row_checked(v, own, id, lane, w, create_seq);
+      const uint32_t nslot = lane == 13 ? own : ((lane < 27 && w) ? w - 1u : kInvalidSlot);
+      if (use_summ) {
+        // class summaries of the chunk and its seven +x / +y / +z neighbours (lanes 13, 14, 16, 17, 22, 23, 25, 26): supersets
+        // of the classes among a chunk's voxels / on the face it contributes, so a chunk they rule out is ruled out for good
+        const uint32_t sm = (is_near && nslot != kInvalidSlot) ? v.summ[nslot] : 0u;
+        // self: whole chunk; +x (with or without +y, +z): x = 0 face; +y, +y+z: y = 0 face; +z: z = 0 face
+        const uint32_t sel = lane == 13 ? 0u : ((lane % 3) == 2 ? 4u : (((lane / 3) % 3) == 2 ? 8u : 12u));
+        const uint32_t u = is_near ? (sm >> sel) & 15u : 0u;
+        const bool so = (__shfl((int)sm, 13) & 1) != 0;
+        const bool maybe = so && __ballot(u & 2u) != 0ull && __ballot(u & 4u) != 0ull && __ballot(u & 8u) != 0ull;
+        if (!maybe) {
+          if (lane == 0) { if (fp.defer) filter_defer_reset(v, cnt, cap_sh, own, id); else filter_reset_record(v, own, id, epoch, ppar); }
+          return;
+        }
       }
-      const uint32_t got = (uint32_t)__shfl((int)near8, is_near ? near_k(lane) : 0);
-      filter_exact(v, id, is_near ? got : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar, use_summ, fp.defer != 0);
+      filter_exact<true>(v, id, nslot, own, lane, epoch, surv, cnt, cap_sh, ppar, use_summ, fp.defer != 0, create_seq);
     };
     // the shard lists K-A filled: wave w walks shard w % 32 from position w / 32 on.  Its first entry is requested TOGETHER
     // with the shard's counter (the entry's address does not depend on the count; a position beyond the count holds an older
@@ -491,7 +518,7 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
   __shared__ uint32_t s_eown[32];  // entries the summaries ruled out: their records are reset behind the barrier, by the
   __shared__ int4 s_eid[32];       // last wave, so that no entry of phase B waits for those round trips
   __shared__ int4 s_id[32];
-  __shared__ uint32_t s_near[32][8];
+  __shared__ uint32_t s_own[32];
   const int grp = threadIdx.x >> 3, k8 = threadIdx.x & 7;
   const uint32_t per = (n + nblk - 1) / nblk;
   const uint32_t first = bid * per;
@@ -502,10 +529,10 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
     const uint32_t entry = base + (uint32_t)grp;
     if (entry < last) {
       int4 id;
-      uint32_t own_listed = kInvalidSlot;
+      uint32_t own_in = kInvalidSlot;  // (every lane of the group: the row loads of phase A hang on it)
       if (entry < n_flat) {
         id = dlist[entry];
-        if (dslot && k8 == 0) own_listed = dslot[entry];
+        own_in = dslot ? dslot[entry] : hash_slot_alive(v, pack_id(id.x, id.y, id.z));
       } else {
         const uint32_t r = entry - n_flat;
         uint32_t shd = 0;
@@ -513,20 +540,17 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
         shd &= kMeshShards - 1u;
         const size_t at = wl_base + (size_t)shd * wl_rows + (r - (s_incl[shd] - s_cnt[shd]));
         id = v.wl_ids[at];
-        if (k8 == 0) own_listed = v.wl_slot[at];
+        own_in = v.wl_slot[at];
       }
       uint32_t own;
       bool maybe;
-      const uint32_t nslot = filter_near(v, id, lane, k8, dslot != nullptr || entry >= n_flat, own_listed, use_summ, &own, &maybe);
+      filter_near(v, id, lane, k8, own_in, dslot != nullptr || entry >= n_flat, use_summ, create_seq, &own, &maybe);
       if (fp.cls && ((fp.cls == 1u) != part_interior(v, id.x, id.y, id.z))) own = kInvalidSlot;  // (group-uniform: the other pass takes it)
-      if (own != kInvalidSlot) {  // RecomputeMeshes: !HasChunk -> skip (:240-242)
+      if (own != kInvalidSlot && k8 == 0) {  // RecomputeMeshes: !HasChunk -> skip (:240-242)
         if (maybe) {
-          uint32_t at = 0;
-          if (k8 == 0) at = atomicAdd(&s_n, 1u);
-          at = (uint32_t)__shfl((int)at, lane & 56);
-          s_near[at][k8] = nslot;
-          if (k8 == 0) s_id[at] = id;
-        } else if (k8 == 0) {
+          const uint32_t at = atomicAdd(&s_n, 1u);
+          s_own[at] = own; s_id[at] = id;
+        } else {
           const uint32_t at = atomicAdd(&s_ne, 1u);
           s_eown[at] = own; s_eid[at] = id;
         }
@@ -539,8 +563,7 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
     }
     const uint32_t nm = s_n;
     for (uint32_t m = (uint32_t)w; m < nm; m += 4u)
-      filter_exact(v, s_id[m], is_near ? s_near[m][near_k(lane)] : kInvalidSlot, lane, epoch, surv, cnt, cap_sh, ppar,
-                   use_summ, fp.defer != 0);
+      filter_exact<false>(v, s_id[m], kInvalidSlot, s_own[m], lane, epoch, surv, cnt, cap_sh, ppar, use_summ, fp.defer != 0, create_seq);
     __syncthreads();  // the parked entries are consumed before the next batch overwrites them
   }
 }
@@ -1304,6 +1327,38 @@ __global__ __launch_bounds__(256) void k_check_summaries(VolumeDev v, unsigned l
   }
 }
 
+// diagnostic (tf_check_neighbours): every row of the neighbour table against the hash.  out[0] rows of chunks with a pool
+// slot, [1] non-zero words, [2] non-zero words that do not name the pool slot the hash holds for that id (must be 0),
+// [3] rows whose last full check is newer than every key insertion, [4] zero words of such rows whose id the hash does hold
+// (must be 0), [5] the same for the near check's eight words (must be 0)
+__global__ __launch_bounds__(256) void k_check_neighbours(VolumeDev v, unsigned long long* out) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * 4;
+  const uint32_t create_seq = v.vctl->create_seq;
+  for (uint32_t e = (blockIdx.x * 256 + threadIdx.x) >> 6; e <= v.hmask; e += nwaves) {
+    const HEntry h = v.hent[e];
+    if (h.key == kEmptyKey || h.slot == kInvalidSlot) continue;
+    const int4 id = unpack_id(h.key);
+    const uint32_t w = lane < kNbrWords ? v.nbr[(size_t)h.slot * kNbrWords + lane] : 0u;
+    const bool full = (uint32_t)__shfl((int)w, kNbrFull) > create_seq, near8 = (uint32_t)__shfl((int)w, kNbrNear) > create_seq;
+    uint32_t truth = 0;
+    const bool nb = lane < 27 && lane != 13;
+    if (nb) truth = nbr_probe(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
+    const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
+    const unsigned long long nz = __ballot(nb && w != 0u), bad = __ballot(nb && w != 0u && w != truth);
+    const unsigned long long miss = __ballot(nb && full && w == 0u && truth != 0u);
+    const unsigned long long miss8 = __ballot(nb && is_near && near8 && w == 0u && truth != 0u);
+    if (lane == 0) {
+      atomicAdd(&out[0], 1ull);
+      if (nz) atomicAdd(&out[1], (unsigned long long)__popcll(nz));
+      if (bad) atomicAdd(&out[2], (unsigned long long)__popcll(bad));
+      if (full) atomicAdd(&out[3], 1ull);
+      if (miss) atomicAdd(&out[4], (unsigned long long)__popcll(miss));
+      if (miss8) atomicAdd(&out[5], (unsigned long long)__popcll(miss8));
+    }
+  }
+}
+
 }  // namespace tf
 
 using namespace tf;
@@ -1319,6 +1374,7 @@ int tf_update_meshes(tf_volume* v, int64_t* n_meshed) {
   // empty list costs two empty launches)
   const uint8_t* db = reinterpret_cast<const uint8_t*>(v->d_tmp);
   prof_begin(v, TF_PROF_MESH);
+  (void)nbr_next_seq(v);
   launch_mesh(v->dev, v->mesh_par, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), v->dev.max_chunks,
               ++v->mesh_epoch, v->res, false, -1, v->dirty_list_n, nullptr, -1, v->stream);
   v->mesh_par ^= 1;
@@ -1536,6 +1592,21 @@ int tf_check_summaries(tf_volume* v, int64_t* n_chunks, int64_t* n_missing, int6
   if (n_chunks) *n_chunks = (int64_t)h[0];
   if (n_missing) *n_missing = (int64_t)h[1];
   if (n_stale) *n_stale = (int64_t)h[2];
+  return TF_OK;
+}
+
+int tf_check_neighbours(tf_volume* v, int64_t out6[6]) {
+  if (!v || !out6) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_DEV(v);
+  int rc = ensure_tmp(v, 64);
+  if (rc) return rc;
+  TF_HIP(hipMemsetAsync(v->d_tmp, 0, 64, v->stream));
+  hipLaunchKernelGGL(k_check_neighbours, dim3(1024), dim3(256), 0, v->stream, v->dev, reinterpret_cast<unsigned long long*>(v->d_tmp));
+  TF_HIP(hipGetLastError());
+  unsigned long long h[6] = {0, 0, 0, 0, 0, 0};
+  TF_HIP(hipMemcpyAsync(h, v->d_tmp, sizeof(h), hipMemcpyDeviceToHost, v->stream));
+  TF_HIP(hipStreamSynchronize(v->stream));
+  for (int k = 0; k < 6; ++k) out6[k] = (int64_t)h[k];
   return TF_OK;
 }
 

@@ -210,6 +210,7 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     room = total > slots_base ? total - slots_base : 0ull;
   }
   const bool overflow = FUSED && (unsigned long long)n_cand > room;  // some AddPatch of this frame throws
+  const uint32_t create_seq = FUSED ? v.vctl->create_seq : 0u;  // (neighbour table: see the flag exchange below)
   const int W = cam.W, H = cam.H;
   const float Wf = (float)W, Hf = (float)H;
   if (FUSED && bid == 0 && threadIdx.x == 0) {
@@ -238,17 +239,27 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     MeshRec R = *rec;  // one 64-B record: counts, flags, slot position, box
     const uint32_t mst = FUSED ? lblk : R.block;  // (the block of the mesh store that holds the mesh)
     stampw(1);
-    if (FUSED && lane < 6) {
+    if (FUSED) {
       // Chisel::CompressMeshes' neighbour exchange (Chisel.cpp:127-145) for this chunk: flag k of the mesh and flag
       // k ^ 1 of its k-th face neighbour's mesh become the OR of the two.  Every mesh of the frame is complete (the
       // mesher ran before this kernel); the pairwise updates are idempotent, so concurrent waves cannot disagree.
+      // The neighbours' pool slots come from the chunk's row of the neighbour table (lanes 0..5: the face words, lane 6:
+      // the stamp of the row's last full check; requested with the record above) -- a mesh lives in the record of its
+      // chunk's pool slot, so nothing else of the neighbour is needed.  A "none" word of a row that has not been checked
+      // in full since the newest key insertion (the filter's batch form checks the +x / +y / +z corner only) falls back
+      // to the hash.
       const int k = lane, m = k ^ 1;
-      int4 q = id;
-      if (k == 0) q.x -= 1; else if (k == 1) q.x += 1; else if (k == 2) q.y -= 1;
-      else if (k == 3) q.y += 1; else if (k == 4) q.z -= 1; else q.z += 1;
-      const uint32_t en = hash_find(v, pack_id(q.x, q.y, q.z));
-      if (en != kInvalidSlot && (v.hent[en].alive & 1u) && v.hent[en].slot != kInvalidSlot) {
-        MeshRec* b = &v.mesh_rec[v.hent[en].slot];
+      const int word = lane < 6 ? 13 + ((k & 1) ? 1 : -1) * (k < 2 ? 1 : (k < 4 ? 3 : 9)) : kNbrFull;
+      uint32_t nw = lane < 7 ? v.nbr[(size_t)slot * kNbrWords + word] : 0u;
+      const bool checked = (uint32_t)__shfl((int)nw, 6) > create_seq;
+      if (lane < 6 && nw == 0u && !checked) {
+        int4 q = id;
+        if (k == 0) q.x -= 1; else if (k == 1) q.x += 1; else if (k == 2) q.y -= 1;
+        else if (k == 3) q.y += 1; else if (k == 4) q.z -= 1; else q.z += 1;
+        nw = nbr_probe(v, pack_id(q.x, q.y, q.z));
+      }
+      if (lane < 6 && nw != 0u) {
+        MeshRec* b = &v.mesh_rec[nw - 1u];
         const uint32_t bs = b->state;
         if ((bs & kMsInMap) && (bs & kMsSimplified)) {
           const uint32_t abit = 1u << (kMsAdjShift + k), bbit = 1u << (kMsAdjShift + m);

@@ -311,6 +311,7 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
   TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
   launch_list_dirty(v->dev, reinterpret_cast<int4*>(db + 16), (uint32_t)cap, v->clear_floor, v->stream);
   TF_HIP(hipMemcpyAsync(db, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));
+  (void)nbr_next_seq(v);
   launch_mesh(v->dev, v->mesh_par, reinterpret_cast<const int4*>(db + 16), reinterpret_cast<const uint32_t*>(db), (uint32_t)cap,
               ++v->mesh_epoch, v->res, false, -1, 1u << 30, nullptr, -1, v->stream);
   v->mesh_par ^= 1;

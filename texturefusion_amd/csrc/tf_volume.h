@@ -178,7 +178,7 @@ struct tf_volume {
   HostSlot hslot[kHostRing];
   // caller buffers registered with tf_host_register (page-locked in place): host frames that lie inside one are uploaded
   // straight out of it -- no staging copy -- and the call returns when that upload is through
-  struct HostRange { const uint8_t* p; size_t n; };
+  struct HostRange { const uint8_t* p; size_t n; const uint8_t* locked; };  // locked: base of the process-wide page-locked range that covers it
   std::vector<HostRange> host_ranges;
   size_t hslot_pixels = 0;
   int hslot_next = 0;
@@ -269,6 +269,7 @@ int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint3
 int texture_stage_finish(tf_volume* v, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16, int32_t frame_id, int par);
 // the four band counts of the frame whose selection wrote `ctl` (tag = its epoch + 1): waits for the device to publish them
 int xchg_band_counts(tf_volume* v, const FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]);
+uint32_t nbr_next_seq(tf_volume* v);  // neighbour table: the seq of the filter launch about to go out (tf_capi.cpp)
 int flush_deferred(tf_volume* v);
 void launch_dirty_frame_store(const VolumeDev& v, int par, uint32_t stamp, const KfStoreArgs& a, hipStream_t s);  // tf_mesh.hip
 int patch_flush(tf_volume* v);

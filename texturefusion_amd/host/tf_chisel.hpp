@@ -471,35 +471,39 @@ class ChunkManager {
   MeshMap allMeshes;
 };
 
-// io/PLY.cpp:29-80 SaveMeshPLYASCII: vertices (+ uchar colours when the mesh has them), one triangle per three
-// consecutive indices; numbers in the stream's default formatting.
-inline bool SaveMeshPLYASCII(const std::string& fileName, const MeshPtr& mesh) {
-  std::ofstream stream(fileName.c_str());
-  if (!stream) return false;
-  const size_t numPoints = mesh->vertices.size();
-  const bool hasColors = !mesh->colors.empty();  // Mesh::HasColors
-  stream << "ply" << std::endl << "format ascii 1.0" << std::endl << "element vertex " << numPoints << std::endl;
-  stream << "property float x" << std::endl << "property float y" << std::endl << "property float z" << std::endl;
-  if (hasColors)
-    stream << "property uchar red" << std::endl << "property uchar green" << std::endl << "property uchar blue" << std::endl;
-  stream << "element face " << numPoints / 3 << std::endl;
-  stream << "property list uchar int vertex_index" << std::endl << "end_header" << std::endl;
-  for (size_t i = 0; i < numPoints; ++i) {
-    const Vec3& vert = mesh->vertices[i];
-    stream << vert(0) << " " << vert(1) << " " << vert(2);
-    if (hasColors) {
-      const Vec3& color = mesh->colors[i];
-      stream << " " << static_cast<int>(color(0) * 255.0f) << " " << static_cast<int>(color(1) * 255.0f) << " "
-             << static_cast<int>(color(2) * 255.0f);
+// ASCII PLY of a triangle soup (what io/PLY.cpp:29-80 SaveMeshPLYASCII leaves on disk for main.cpp:266): a header that
+// declares float x y z (+ uchar red green blue when colours are given) per vertex and one "vertex_index" list per face,
+// then n_corners vertex lines and n_corners / 3 face lines "3 a b c ".  The file declares numPoints / 3 faces, so the soup
+// is written corner by corner: xyz(i) / rgb(i) return the three floats of corner i (rgb may be null: no colour
+// properties); numbers in "%g" = an ostream's default float formatting, colour channels truncated from [0, 1] * 255.
+template <class XyzFn, class RgbFn>
+inline bool WritePlySoup(const std::string& fileName, size_t n_corners, XyzFn xyz, RgbFn rgb, bool with_rgb,
+                         const unsigned int* corner_index, size_t n_index) {
+  std::FILE* f = std::fopen(fileName.c_str(), "w");
+  if (!f) return false;
+  std::fprintf(f, "ply\nformat ascii 1.0\nelement vertex %zu\n", n_corners);
+  for (const char* axis : {"x", "y", "z"}) std::fprintf(f, "property float %s\n", axis);
+  if (with_rgb)
+    for (const char* ch : {"red", "green", "blue"}) std::fprintf(f, "property uchar %s\n", ch);
+  std::fprintf(f, "element face %zu\nproperty list uchar int vertex_index\nend_header\n", n_corners / 3);
+  for (size_t i = 0; i < n_corners; ++i) {
+    const float* p = xyz(i);
+    std::fprintf(f, "%g %g %g", p[0], p[1], p[2]);
+    if (with_rgb) {
+      const float* c = rgb(i);
+      std::fprintf(f, " %d %d %d", (int)(c[0] * 255.0f), (int)(c[1] * 255.0f), (int)(c[2] * 255.0f));
     }
-    stream << std::endl;
+    std::fputc('\n', f);
   }
-  for (size_t i = 0; i + 2 < mesh->indices.size(); i += 3) {
-    stream << "3 ";
-    for (int j = 0; j < 3; j++) stream << mesh->indices[i + j] << " ";
-    stream << std::endl;
-  }
-  return true;
+  for (size_t t = 0; t + 2 < n_index; t += 3)
+    std::fprintf(f, "3 %u %u %u \n", corner_index[t], corner_index[t + 1], corner_index[t + 2]);
+  return std::fclose(f) == 0;
+}
+// the reference's entry point (io/PLY.h): one Mesh, its vertices as they are
+inline bool SaveMeshPLYASCII(const std::string& fileName, const MeshPtr& mesh) {
+  const Mesh& m = *mesh;
+  return WritePlySoup(fileName, m.vertices.size(), [&m](size_t i) { return m.vertices[i].v; },
+                      [&m](size_t i) { return m.colors[i].v; }, !m.colors.empty(), m.indices.data(), m.indices.size());
 }
 
 // A PNG file of an RGB8 image written with stored (uncompressed) deflate blocks -- what cv::imwrite produces for
@@ -582,81 +586,67 @@ class Atlas {
     const std::size_t k = GetPatch(id)->texloc;
     return Vec2((float)(k % MAX_PATCH_WIDTH_), (float)(k / MAX_PATCH_WIDTH_));
   }
-  // Atlas::SaveTexturedModel (Atlas.cpp:93-179): texture_material.png (the whole texture_buffer; RGB, as cv::imwrite
-  // of the BGR-converted buffer stores it), texture_model.obj over every mesh with a complete patch (allMeshes
-  // iteration order, which the reference leaves to std::unordered_map), texture_model.mtl.  Meshes, texcoords and
-  // atlas rows come from the device (fetch(id) = Chisel::FetchPatchData + ChunkManager::FetchMeshData).
-  template <class FetchFn>
-  void SaveTexturedModelWith(std::string const& basepath, FetchFn fetch) {
-    {
-      const std::size_t band = 64;
-      std::vector<unsigned char> rows(band * MAX_PATCH_WIDTH_ * 3);
-      std::size_t have0 = 1, have1 = 0;
-      WritePngRgb(basepath + "/texture_material.png", (uint32_t)MAX_PATCH_WIDTH_, (uint32_t)MAX_PATCH_HEIGHT_, [&](uint32_t y) {
-        if (y < have0 || y >= have1) {
-          have0 = y;
-          have1 = std::min<std::size_t>(MAX_PATCH_HEIGHT_, have0 + band);
-          DownloadRows((int64_t)have0, (int64_t)have1, rows.data());
-        }
-        return (const unsigned char*)&rows[(y - have0) * MAX_PATCH_WIDTH_ * 3];
-      });
-    }
-    Vec3List vertices, normals;
-    Vec2List texcoords;
-    VertIndexList indices, txindices;
-    std::size_t vts = 0;
-    for (auto it : manager->GetAllMeshes()) {
-      MeshPtr mesh = it.second;
-      PatchPtr patch = mesh->m_patch;
-      if (patch == nullptr || !patch->complete()) continue;
-      fetch(mesh->chunkID);
-      for (std::size_t j = 0; j < mesh->indices.size(); j++) {
-        const std::size_t k = mesh->indices[j] + vts;
-        indices.emplace_back((unsigned int)k);
-        txindices.emplace_back((unsigned int)k);
-      }
-      for (std::size_t j = 0; j < mesh->vertices.size(); j++) {
-        vertices.emplace_back(mesh->vertices[j]);
-        normals.emplace_back(mesh->normals[j]);
-        Vec2 tex = GetTexLoc(mesh->chunkID);
-        tex(0) += patch->texcoord[j](0) * patch->ratio(0);
-        tex(1) += patch->texcoord[j](1) * patch->ratio(1);
-        tex(0) /= MAX_PATCH_WIDTH_;
-        tex(1) /= MAX_PATCH_HEIGHT_;
-        texcoords.emplace_back(tex);
-        vts++;
+  // Atlas::SaveTexturedModel (Atlas.cpp:93-179) leaves three files in basepath:
+  //   texture_material.png  the whole texture_buffer (RGB, as cv::imwrite stores the BGR-converted buffer),
+  //   texture_model.obj     Wavefront OBJ: "v" / "vt" / "vn" per vertex of every mesh whose patch is complete(), vt =
+  //                         (slot origin + texcoord * ratio) / atlas size with the v axis flipped, one group + face per
+  //                         triangle with 1-based v/vt/vn triples, numbers with six decimals,
+  //   texture_model.mtl     one material, "demo_texture", that maps the PNG.
+  // Here the geometry is not collected mesh by mesh on the host: it is the packed stream DrawMeshes hands the renderer
+  // (tf_draw_meshes, 12 floats per vertex: position [0..2], atlas uv [6..7], normal [8..10]; triangle corners rebased over
+  // the model; meshes in ascending chunk id where the reference follows its unordered_map).
+  void SaveTexturedModel(std::string const& basepath) {
+    SaveTexturePng(basepath + "/texture_material.png");
+    int64_t cap_v = 0, cap_i = 0;
+    for (const auto& kv : manager->GetAllMeshes())
+      if (kv.second->m_patch && kv.second->m_patch->complete()) { cap_v += kv.second->n_vertices; cap_i += kv.second->n_indices; }
+    std::vector<float> packed((size_t)cap_v * 12 + 12);
+    std::vector<uint32_t> corners((size_t)cap_i + 3);
+    int64_t n_v = 0, n_i = 0;
+    tf_check(tf_draw_meshes(vol, packed.data(), corners.data(), cap_v, cap_i, &n_v, &n_i), "Atlas::SaveTexturedModel");
+    std::FILE* obj = std::fopen((basepath + "/texture_model.obj").c_str(), "w");
+    if (!obj) throw std::runtime_error("Atlas::SaveTexturedModel: cannot write " + basepath + "/texture_model.obj");
+    std::fputs("mtllib texture_model.mtl\n", obj);
+    struct Column { const char* tag; int first, count; };
+    for (const Column& col : {Column{"v", 0, 3}, Column{"vt", 6, 2}, Column{"vn", 8, 3}}) {
+      for (int64_t k = 0; k < n_v; ++k) {
+        const float* rec = &packed[(size_t)k * 12 + col.first];
+        if (col.count == 2) std::fprintf(obj, "%s %.6f %.6f\n", col.tag, rec[0], 1.0f - rec[1]);  // image rows run downwards
+        else std::fprintf(obj, "%s %.6f %.6f %.6f\n", col.tag, rec[0], rec[1], rec[2]);
       }
     }
-    std::ofstream mout((basepath + "/texture_model.obj").c_str());
-    mout << "mtllib " << "texture_model.mtl" << '\n';
-    mout << std::fixed << std::setprecision(6);
-    for (std::size_t i = 0; i < vertices.size(); ++i)
-      mout << "v " << vertices[i](0) << " " << vertices[i](1) << " " << vertices[i](2) << '\n';
-    for (std::size_t i = 0; i < texcoords.size(); ++i) mout << "vt " << texcoords[i](0) << " " << 1.0f - texcoords[i](1) << '\n';
-    for (std::size_t i = 0; i < normals.size(); ++i)
-      mout << "vn " << normals[i](0) << " " << normals[i](1) << " " << normals[i](2) << '\n';
-    mout << "s off" << '\n';
-    mout << "usemtl " << "demo_texture" << '\n';
-    for (std::size_t i = 0; i < indices.size() / 3; ++i) {
-      mout << "g " << "face" << i << '\n';
-      mout << "f";
-      for (std::size_t k = 0; k < 3; ++k)
-        mout << " " << indices[i * 3 + k] + 1 << "/" << txindices[i * 3 + k] + 1 << "/" << indices[i * 3 + k] + 1;
-      mout << '\n';
+    std::fputs("s off\nusemtl demo_texture\n", obj);
+    for (int64_t t = 0; 3 * t + 2 < n_i; ++t) {
+      std::fprintf(obj, "g face%lld\nf", (long long)t);
+      for (int c = 0; c < 3; ++c) {
+        const unsigned long ref = (unsigned long)corners[(size_t)(3 * t + c)] + 1ul;  // OBJ counts from one
+        std::fprintf(obj, " %lu/%lu/%lu", ref, ref, ref);
+      }
+      std::fputc('\n', obj);
     }
-    mout.close();
-    std::ofstream out((basepath + "/texture_model.mtl").c_str());
-    out << "newmtl " << "demo_texture" << '\n'
-        << "Ka 1.000000 1.000000 1.000000" << '\n'
-        << "Kd 1.000000 1.000000 1.000000" << '\n'
-        << "Ks 0.000000 0.000000 0.000000" << '\n'
-        << "Tr 0.000000" << '\n'
-        << "illum 1" << '\n'
-        << "Ns 1.000000" << '\n'
-        << "map_Kd " << "texture_material.png" << std::endl;
-    out.close();
+    std::fclose(obj);
+    std::FILE* mtl = std::fopen((basepath + "/texture_model.mtl").c_str(), "w");
+    if (!mtl) throw std::runtime_error("Atlas::SaveTexturedModel: cannot write " + basepath + "/texture_model.mtl");
+    std::fputs("newmtl demo_texture\n", mtl);
+    for (const char* reflectance : {"Ka 1.000000 1.000000 1.000000", "Kd 1.000000 1.000000 1.000000", "Ks 0.000000 0.000000 0.000000"})
+      std::fprintf(mtl, "%s\n", reflectance);
+    std::fputs("Tr 0.000000\nillum 1\nNs 1.000000\nmap_Kd texture_material.png\n", mtl);
+    std::fclose(mtl);
   }
-  void SaveTexturedModel(std::string const& basepath);  // defined behind Chisel (needs its fetchers)
+  // the atlas as a PNG, downloaded in bands of 64 rows
+  void SaveTexturePng(const std::string& file) {
+    const std::size_t band = 64;
+    std::vector<unsigned char> rows(band * MAX_PATCH_WIDTH_ * 3);
+    std::size_t have0 = 1, have1 = 0;
+    WritePngRgb(file, (uint32_t)MAX_PATCH_WIDTH_, (uint32_t)MAX_PATCH_HEIGHT_, [&](uint32_t y) {
+      if (y < have0 || y >= have1) {
+        have0 = y;
+        have1 = std::min<std::size_t>(MAX_PATCH_HEIGHT_, have0 + band);
+        DownloadRows((int64_t)have0, (int64_t)have1, rows.data());
+      }
+      return (const unsigned char*)&rows[(y - have0) * MAX_PATCH_WIDTH_ * 3];
+    });
+  }
   void BindOwner(class Chisel* c) { owner = c; }
   inline bool HasPatch(const ChunkID& id) const { return manager->HasMesh(id); }            // Atlas.h:55
   inline PatchPtr GetPatch(const ChunkID& id) { return manager->GetMutableMesh(id)->m_patch; }  // :56-58
@@ -979,28 +969,28 @@ class Chisel {
     }
   }
 
-  // Chisel::SaveAllMeshesToPLY (Chisel.cpp:357-379): every mesh of allMeshes un-indexed into one triangle soup
-  // (unordered_map iteration order, as in the reference) and written by SaveMeshPLYASCII.
+  // Chisel::SaveAllMeshesToPLY (Chisel.cpp:357-379; main.cpp:266): the whole map as ONE triangle soup -- every triangle
+  // corner becomes a vertex of its own (position + colour), faces are consecutive triples -- in a PLY file.  Mesh order is
+  // the map's iteration order, as in the reference.
   bool SaveAllMeshesToPLY(const std::string& filename) {
     std::printf("Saving all meshes to PLY file...\n");
-    MeshPtr fullMesh(new Mesh());
-    size_t v = 0;
-    for (const auto& it : chunkManager.GetAllMeshes()) {
-      chunkManager.FetchMeshData(it.first);
-      const Mesh& m = *it.second;
-      for (size_t i = 0; i < m.indices.size(); i++) {
-        const size_t index = m.indices[i];
-        fullMesh->indices.emplace_back((unsigned int)(i + v));
-        fullMesh->vertices.emplace_back(m.vertices[index]);
-        fullMesh->colors.emplace_back(m.colors[index]);
-        fullMesh->normals.emplace_back(m.normals[index]);
+    std::vector<float> soup_xyz, soup_rgb;
+    for (const auto& kv : chunkManager.GetAllMeshes()) {
+      chunkManager.FetchMeshData(kv.first);
+      const Mesh& m = *kv.second;
+      for (const unsigned int corner : m.indices) {
+        soup_xyz.insert(soup_xyz.end(), m.vertices[corner].v, m.vertices[corner].v + 3);
+        soup_rgb.insert(soup_rgb.end(), m.colors[corner].v, m.colors[corner].v + 3);
       }
-      v += m.indices.size();
     }
-    std::printf("Full mesh has %lu verts\n", (unsigned long)v);
-    const bool success = SaveMeshPLYASCII(filename, fullMesh);
-    if (!success) std::printf("Saving failed!\n");
-    return success;
+    const size_t n_corners = soup_xyz.size() / 3;
+    std::vector<unsigned int> ident(n_corners);
+    for (size_t i = 0; i < n_corners; ++i) ident[i] = (unsigned int)i;
+    std::printf("Full mesh has %lu verts\n", (unsigned long)n_corners);
+    const bool ok = WritePlySoup(filename, n_corners, [&](size_t i) { return &soup_xyz[3 * i]; },
+                                 [&](size_t i) { return &soup_rgb[3 * i]; }, true, ident.data(), n_corners);
+    if (!ok) std::printf("Saving failed!\n");
+    return ok;
   }
 
   ChunkID maxChunkID, minChunkID;
@@ -1083,15 +1073,6 @@ class Chisel {
   std::vector<float> qual_buf;
 };
 typedef std::shared_ptr<Chisel> ChiselPtr;
-
-inline void Atlas::SaveTexturedModel(std::string const& basepath) {
-  if (!owner) throw std::runtime_error("Atlas::SaveTexturedModel: atlas not bound to a Chisel");
-  Chisel* c = owner;
-  SaveTexturedModelWith(basepath, [c](const ChunkID& id) {
-    c->GetMutableChunkManager().FetchMeshData(id);
-    c->FetchPatchData(id);
-  });
-}
 
 // Structure/TexMap.{h,cpp}: the bookkeeping of the view selection that consumes this path's outputs -- the chunk
 // graph from the meshes' adjacency flags (update_chunkgraph, TexMap.cpp:50-62) and the data costs from the
