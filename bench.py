@@ -78,6 +78,11 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true",
                     help="skip the rocprofv3 child passes (kernel trace, FETCH_SIZE, WRITE_SIZE)")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="of the rocprofv3 child passes run only the kernel trace (no FETCH_SIZE / WRITE_SIZE passes)")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side runs of the default line: configs[1] (--mode tsdf) and configs[3] (--scene big --hires) as "
+                         "child processes of their own, reported as scalars (side.*, roofline.side_*)")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)  # the timed workload only, run under rocprofv3
     ap.add_argument("--repeats", type=int, default=5, help="N=1: further timed windows on the same orbit positions (median / min / max next to value)")
     ap.add_argument("--no-group", action="store_true", help="skip the keyframe-group (1 colour + 6 depth frames) measurement")
@@ -306,6 +311,16 @@ def main():
         args.no_roofline = args.no_group = True
         args.cpu_frames = 0
     # profiler child passes first, before this process touches the GPU
+    # The other single-GPU configurations of BASELINE.json come FIRST, each a bench.py process of its own (the default line
+    # carries their headline figures as scalars); then the profiler child passes of this line.  All of them before this process
+    # touches the GPU -- and in this order because VRAM a process leaves behind is wiped in the background with the DMA
+    # engines the host-frame uploads use: the hall's tens of GB are wiped while the profiler passes run,
+    # and what is left ahead of this line's own windows is what every earlier round's line had.
+    side = None
+    default_line = (world == 1 and args.mode == "textured" and args.scene == "room" and not args.hires and not args.child
+                    and not args.force_exchange and not args.resident_headline and not args.no_preroll)
+    if default_line and not args.no_side and not args.no_roofline and not under_profiler():
+        side = side_runs(args)
     prof_child = None
     if world == 1 and not (args.no_pmc or args.child or args.no_roofline or args.force_exchange):
         prof_child = {"error": "running under a profiler"} if under_profiler() else child_passes(args)
@@ -346,7 +361,10 @@ def main():
     s_main = torch.cuda.Stream(device=dev) if multi else None
     big = args.scene == "big"
     pool = (1 << args.max_chunks_log2) if args.max_chunks_log2 > 0 else ((1 << 21) if big else (1 << 19))
-    vol = capi.Volume(res, cam, max_chunks=pool, max_list=(1 << 20) if big else (1 << 18),
+    # (mesh_blocks: the library's default gives every pool slot a mesh block, as the reference's allMeshes can hold one per
+    # chunk; the bench knows its scenes -- under a third of a scanned scene's chunks lie on a surface -- and takes a quarter,
+    # which keeps the volumes at the footprint every earlier round measured: 2.7 GB instead of 10.7 GB of store for the room)
+    vol = capi.Volume(res, cam, max_chunks=pool, max_list=(1 << 20) if big else (1 << 18), mesh_blocks=pool // 4,
                       max_coarse=1 << 22 if big else 1 << 20, device=local_rank,
                       stream=s_main.cuda_stream if multi else None)
     # The caller's frame buffers are registered once, as a caller with a fixed set of image buffers does at start-up; host
@@ -544,6 +562,26 @@ def main():
     p0 = pos + Wm  # stream position of the timed window; p0 % ORBIT = its orbit position
     use_host = host_ok and not args.resident_headline
     host_phases = None
+    # VRAM that earlier processes of this job left behind (the profiler child passes, the side runs) is wiped in the background
+    # with the DMA engines the host-frame uploads use: for a while after such a process ends, a 2.46 MB upload takes 250 us
+    # instead of 53 (a window of r6 measured exactly that).  One frame's worth of bytes is uploaded until
+    # the link is back at its rate (at most 3 s), before -- not inside -- the timed region.
+    link_settle = None
+    if use_host and world == 1:
+        probe_h = torch.empty(h_depth[0].nbytes + h_rgba[0].nbytes, dtype=torch.uint8).pin_memory()
+        probe_d = torch.empty_like(probe_h, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best, tries, last = None, 0, None
+        for tries in range(1, 31):
+            e0.record(); probe_d.copy_(probe_h, non_blocking=True); e1.record(); e1.synchronize()
+            last = 1e3 * e0.elapsed_time(e1)
+            best = last if best is None else min(best, last)
+            ok = last <= probe_h.numel() / 25e3  # microseconds at 25 GB/s (the link moves 46 GB/s when nothing else uses it)
+            if tries >= 3 and ok:
+                break
+            time.sleep(0.0 if ok else 0.1)
+        link_settle = {"probes": tries, "last_upload_us": last, "best_upload_us": best, "bytes": int(probe_h.numel())}
+        del probe_h, probe_d
     fresh_period()
     if use_host:
         run_host(pos, Wm)  # (leaves the entry point's four-frame pipeline primed)
@@ -850,6 +888,8 @@ def main():
                                "every %d frames, fixed blocks of %d records" % (args.exchange_every, args.exchange_cap))),
         },
     }
+    if link_settle is not None:
+        out["config"]["link_settle"] = link_settle
     if repeats is not None:
         out["repeats"] = repeats
     if resident is not None:
@@ -899,6 +939,17 @@ def main():
                 pass
         out["cpu_baseline"] = cpu_baseline(args, cam, res, h_depth, h_rgba, h_pose, n_unique, textured)
 
+    if rank == 0 and side is not None:
+        out["side"] = side
+    if rank == 0 and "roofline" in out:
+        # scalar leaves under `roofline` (a consumer that keeps only that dictionary's scalars keeps these): the other
+        # single-GPU configurations and the spread of this line's own repeat windows
+        for k, v in (side or {}).items():
+            if isinstance(v, (int, float)) or v is None:
+                out["roofline"]["side_" + k] = v
+        if repeats is not None:
+            for k in ("ms_per_step_median", "ms_per_step_min", "ms_per_step_max"):
+                out["roofline"]["repeats_" + k] = repeats.get(k)
     if rank == 0:
         print(json.dumps(out))
     vol.close()
@@ -929,7 +980,7 @@ def independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses,
     big = args.scene == "big"
     vol, err = None, None
     try:
-        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), mesh_blocks=(1 << 19) if big else (1 << 17), max_list=(1 << 20) if big else (1 << 18),
                           max_coarse=1 << 22 if big else 1 << 20, device=device)
     except Exception as e:
         err = repr(e)[:200]
@@ -1025,7 +1076,7 @@ def sharded_keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique
     s_main = torch.cuda.Stream(device=dev)
     vol, err = None, None
     try:
-        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), mesh_blocks=(1 << 19) if big else (1 << 17), max_list=(1 << 20) if big else (1 << 18),
                           max_coarse=(1 << 22) if big else (1 << 20), device=device, stream=s_main.cuda_stream)
         vol.set_partition(lo, hi, axis)
     except Exception as e:
@@ -1199,6 +1250,10 @@ def roofline(args, vol, cam, prof, kinds, K, first, n_unique, d_depth, d_rgba, p
     r["k_frame_frac"] = (groups["k_frame"] / t_kframe / 1e3 / HBM_PEAK_GBS) if t_kframe else None
     r["mesh_group_frac"] = (groups["mesh"] / t_mesh / 1e3 / HBM_PEAK_GBS) if textured and t_mesh else None
     r["traffic_ratio"] = (r["traffic"] / bytes_step) if r["traffic"] and bytes_step else None
+    # SURVEY.md s.8(d)'s B to the letter -- voxel rows + images + the atlas term, WITHOUT the meshing term this line's
+    # numerator adds for the f-1 row (the mesher's kernels stay in the denominator: they are part of the step)
+    r["algorithmic_bytes_survey_B"] = (b_tsdf + b_atlas) / K
+    r["frac_survey_B"] = ((b_tsdf + b_atlas) / K / t_step / 1e3 / HBM_PEAK_GBS) if t_step > 0 else None
     r["traffic_detail"] = pmc if pmc else ({"error": prof_child["error"]} if prof_child and "error" in prof_child else None)
     return r
 
@@ -1228,6 +1283,48 @@ def _window(rows, first_frame, K):
     lo = starts[first_frame]
     hi = starts[first_frame + K] if len(starts) > first_frame + K else rows[-1][0] + 1
     return [(d, n, v) for d, n, v in rows if lo <= d < hi]
+
+
+def side_runs(args):
+    """configs[1] (TSDF only, atlas off) and configs[3] (S-hall, 1280x960) with the flags of this run, each as a fresh
+    `bench.py` process started before this one touches the GPU (one process per configuration: each brings its own volume,
+    its own steady-state pre-roll and its own rocprofv3 --kernel-trace child pass).  CPU baseline, keyframe flows and the
+    PMC traffic passes are left out; what comes back are scalars."""
+    import subprocess
+    out = {}
+    hall_steps = min(args.steps, 20)
+    runs = (("tsdf_only", ["--mode", "tsdf", "--steps", str(args.steps), "--warmup", str(args.warmup)],
+             "configs[1]: S-room, 640x480, 5 mm, voxel update only (host frames, H2D inside)"),
+            ("hall", ["--scene", "big", "--hires", "--steps", str(hall_steps), "--warmup", str(min(args.warmup, 5))],
+             "configs[3]: S-hall 8x6x8 m, 1280x960, 5 mm, textured unit (host frames, H2D inside)"))
+    for tag, flags, what in runs:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + flags + ["--no-side", "--no-traffic", "--cpu-frames", "0", "--no-group",
+                                                                         "--repeats", "2", "--res", repr(args.res)]
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=420)
+            line = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[tag + "_error"] = "rc %d: %s" % (r.returncode, r.stderr[-300:])
+                continue
+            d = json.loads(line[-1])
+        except Exception as e:  # a side run must never take the headline down
+            out[tag + "_error"] = "%s: %s" % (type(e).__name__, e)
+            continue
+        rf = d.get("roofline") or {}
+        out[tag + "_workload"] = what
+        out[tag + "_value"] = d.get("value")
+        out[tag + "_ms_per_step"] = d.get("ms_per_step")
+        out[tag + "_steps"] = d.get("steps")
+        out[tag + "_resident_value"] = (d.get("resident") or {}).get("value")
+        out[tag + "_frac"] = rf.get("frac")
+        out[tag + "_kernel_us"] = rf.get("kernel_us_per_step")
+        out[tag + "_algorithmic_bytes"] = rf.get("algorithmic_bytes_per_step")
+        for k in ("k_frame_us", "k_dirty_frame_us", "k_mesh_filter_us", "k_mesh_us"):
+            if rf.get(k) is not None:
+                out[tag + "_" + k] = rf.get(k)
+        out[tag + "_run_s"] = round(time.time() - t0, 1)
+    return out
 
 
 def child_passes(args):
@@ -1299,7 +1396,7 @@ def child_passes(args):
                 out["trace"] = {"kernels": per, "us_per_step": sum(e["us_per_step"] for e in per.values()),
                                 "frames": [first, first + K]}
         pmc = {"kernels": {}}
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for counter in (() if args.no_traffic else ("FETCH_SIZE", "WRITE_SIZE")):
             rows = run_pass(counter, ["--pmc", counter], "*counter_collection.csv", "Kernel_Name",
                             lambda r: float(r["Counter_Value"]), want_counter=counter)
             if isinstance(rows, str):
@@ -1312,6 +1409,8 @@ def child_passes(args):
             for _, n, v in win:
                 e = pmc["kernels"].setdefault(n, {})
                 e[counter] = e.get(counter, 0.0) + PMC_BYTES[counter] * v / K
+        if args.no_traffic:
+            pmc = {"error": "--no-traffic: kernel trace only"}
         if "kernels" in pmc:
             for e in pmc["kernels"].values():
                 e["bytes_per_step"] = e.get("FETCH_SIZE", 0.0) + e.get("WRITE_SIZE", 0.0)
@@ -1339,7 +1438,7 @@ def keyframe_group(args, cam, res, d_depth, d_rgba, poses, n_unique, device):
     from texturefusion_amd import capi
     n_groups, n_local = 8, 6
     big = args.scene == "big"
-    vols = [capi.Volume(res, cam, max_chunks=(1 << 20) if big else (1 << 18), max_list=(1 << 19) if big else (1 << 17),
+    vols = [capi.Volume(res, cam, max_chunks=(1 << 20) if big else (1 << 18), mesh_blocks=(1 << 18) if big else (1 << 16), max_list=(1 << 19) if big else (1 << 17),
                         max_coarse=(1 << 22) if big else (1 << 20), device=device) for _ in range(2)]
     t_loc = [0.0, 0.0]
     t_kf = 0.0
@@ -1393,7 +1492,7 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
     res_out = {}
     big = args.scene == "big"
     for with_moved in (False, True):
-        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), mesh_blocks=(1 << 19) if big else (1 << 17), max_list=(1 << 20) if big else (1 << 18),
                           max_coarse=(1 << 22) if big else (1 << 20), device=device)
 
         def group(g, shift=0, old=False):
@@ -1436,7 +1535,7 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
     # selection (here: every chunk labelled with the new keyframe), GeneratePatches and UpdateAtlas through the entry points
     try:
         import numpy as np
-        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), mesh_blocks=(1 << 19) if big else (1 << 17), max_list=(1 << 20) if big else (1 << 18),
                           max_coarse=(1 << 22) if big else (1 << 20), device=device)
 
         def unit_then_caller(g):
@@ -1477,7 +1576,7 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
     # synchronous with its lists and flags on the host, images device-resident
     try:
         import numpy as np
-        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), max_list=(1 << 20) if big else (1 << 18),
+        vol = capi.Volume(res, cam, max_chunks=(1 << 21) if big else (1 << 19), mesh_blocks=(1 << 19) if big else (1 << 17), max_list=(1 << 20) if big else (1 << 18),
                           max_coarse=(1 << 22) if big else (1 << 20), device=device)
         rgb3 = {}
 

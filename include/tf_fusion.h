@@ -410,8 +410,7 @@ TF_API int tf_check_summaries(tf_volume* v, int64_t* n_chunks, int64_t* n_missin
  *   ChunkManager::GenerateMeshEfficient resolves per call with GetChunk on the neighbour ids, Structure/ChunkManager.cpp:618-632,
  *   and Chisel::CompressMeshes with allMeshes.find, Structure/Chisel.cpp:134-137): per pool slot the pool slots of the 26
  *   chunks around it, filled lazily.  out6 = {rows, non-zero words, non-zero words that disagree with the hash (must be 0),
- *   rows whose "no chunk there" words are currently trusted in full, trusted "none" words whose chunk exists (must be 0),
- *   the same among the eight words the summary test trusts on their own (must be 0)}. */
+ *   rows whose "no chunk there" words are currently trusted, trusted "none" words whose chunk exists (must be 0), 0}. */
 TF_API int tf_check_neighbours(tf_volume* v, int64_t out6[6]);
 /* keys of ChunkManager::GetAllMeshes() (Structure/ChunkManager.h:714) */
 TF_API int tf_list_meshes(tf_volume* v, int32_t* out_ids, int64_t cap, int64_t* n);
@@ -602,6 +601,16 @@ TF_API int tf_patches_download(tf_volume* v, const int32_t* ids, int64_t n, cons
                                float* texcoord, float* texcolor, float* labs);
 /* Atlas::texture_buffer rows [row0,row1) (MobileFusion.h:406-421 uploads the hot rows) */
 TF_API int tf_atlas_download_rows(tf_volume* v, int64_t row0, int64_t row1, uint8_t* dst);
+/* The same rows for a thread OTHER than the one that drives the handle -- the reference's GUI thread reads
+ *   atlas.texture_buffer while the map thread writes it (GCFusion/MobileFusion.h:404-421; SURVEY.md s.8(b) "Threading").
+ *   tf_atlas_download_rows belongs to the driving thread: like every entry point it first brings the handle's deferred work
+ *   onto the stream.  This one touches no state of the pipeline and may run at any time next to the driving thread's calls:
+ *   the rows are copied device-to-device INSIDE the handle's stream, between two of the driving thread's launches, so they
+ *   show ONE moment of the stream -- every atlas write enqueued before it, none enqueued after it -- and travel to dst on a
+ *   stream of the reader's own.  *write_seq = atlas-writing launches ahead of the snapshot (monotonic), *frame_id = the
+ *   label (Patch::frameid) of the newest fused frame among them, -1 = none yet; both may be NULL.  Concurrent readers are
+ *   serialised. */
+TF_API int tf_atlas_snapshot_rows(tf_volume* v, int64_t row0, int64_t row1, uint8_t* dst, int64_t* write_seq, int32_t* frame_id);
 
 /* ---- frame pre-processing that feeds the path ---------------------------------
  * The per-frame image passes main.cpp:117-147 runs before a frame reaches the fusion path, on images resident in

@@ -405,6 +405,12 @@ int main() {
     std::vector<unsigned char> rows((size_t)cfg.atlas_h * 13824 * 3);
     chiselMap.atlas.DownloadRows(0, cfg.atlas_h, rows.data());
     CHECK(std::memcmp(rows.data(), tfo_atlas_buffer(oa), rows.size()) == 0);
+    {  // Atlas::texture_buffer: the hot range the GUI thread uploads (MobileFusion.h:404-421) holds the oracle's texels
+      const chisel::Atlas& at = chiselMap.atlas;
+      CHECK(at.hot_end > at.hot_start && !at.texture_buffer.empty() && at.texture_buffer.cols == 13824);
+      CHECK(std::memcmp(&at.texture_buffer.data[at.hot_start * 3], tfo_atlas_buffer(oa) + at.hot_start * 3,
+                        (at.hot_end - at.hot_start) * 3) == 0);
+    }
     // DrawMeshes: counts, indices and every vertex column but the packed colour delta are identical
     int64_t oni = 0;
     const int64_t onv = tfo_draw_meshes(ov, oa, NULL, NULL, 0, 0, &oni);

@@ -105,7 +105,7 @@ def test_long_orbit_of_the_bench_stream(gpu_required):
     through thousands of updates per chunk."""
     cam = synth.Camera()
     frames = [synth.room_frame(k, cam, with_quality=False) for k in range(90)]
-    assert _run(cam, np.float32(0.005), frames, max_chunks=1 << 18, stride=5) > 5000
+    assert _run(cam, np.float32(0.005), frames, max_chunks=1 << 18, stride=1) > 5000  # EVERY chunk, mesh and patch compared
 
 
 @pytest.mark.parametrize("W,H,f,res", [(320, 240, 262.5, 0.01), (400, 304, 330.0, 0.008)])
@@ -180,7 +180,7 @@ def test_hall_bench_stream_30_frames(gpu_required):
     chunks, and the walls' weights pass the mesher's threshold after a couple of dozen frames"""
     cam = synth.Camera.hires()
     frames = [synth.room_frame(k, cam, half=(4.0, 3.0, 4.0), radius=0.5, with_quality=False) for k in range(30)]
-    n = _run(cam, np.float32(0.005), frames, max_chunks=1 << 20, stride=23)
+    n = _run(cam, np.float32(0.005), frames, max_chunks=1 << 20, stride=1)  # EVERY chunk, mesh and patch compared
     assert n > 2000
 
 

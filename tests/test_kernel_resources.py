@@ -12,18 +12,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "texturefusion_amd", "csrc")
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
-# kernel name fragment -> (max VGPRs, max scratch bytes per lane)
+# kernel name fragment -> (max VGPRs, max scratch bytes per lane); the PRODUCT instances (last template flag false: the
+# tuning instances with time stamps and triage cut-offs are not budgeted)
 BUDGET = {
-    "tf_kernels.hip": {"k_frameILb1ELb0E": (72, 0), "k_frameILb0ELb0E": (72, 0), "k_frameILb1ELb1E": (80, 40)},
+    "tf_kernels.hip": {"k_frameILb1ELb0ELb0E": (72, 0), "k_frameILb0ELb0ELb0E": (72, 0), "k_frameILb1ELb1ELb0E": (80, 0)},
     # (with the keyframe's colour pass on board: the LDS tables allow four waves per SIMD = 128 VGPRs)
     "tf_group.hip": {"k_integrate_groupILb1ELb0E": (96, 0), "k_integrate_groupILb0ELb0E": (96, 0),
                      "k_integrate_groupILb1ELb1E": (128, 0), "k_integrate_groupILb0ELb1E": (128, 0)},
-    # (the filter's two forms -- wave per entry / workgroup batches -- are two kernels: the wave form alone fits the 64 VGPRs
-    # that let eight waves per SIMD be resident; the instances that carry the previous frame's patch stage (the keyframe
-    # unit) are compiled for 6 waves per SIMD: 80 VGPRs, the patch range spills 28 B/lane)
-    "tf_mesh.hip": {"k_meshILi128E": (80, 0), "k_mesh_filterILb1ELb0E": (72, 0),
-                    "k_mesh_filterILb0ELb0E": (80, 0), "k_mesh_filterILb1ELb1E": (80, 40), "k_mesh_filterILb0ELb1E": (80, 40)},
-    "tf_atlas.hip": {"k_patchILb1ELb1ELb1E": (96, 0)},  # one patch per wave, two 64-vertex blocks in registers: 5 waves per SIMD
+    # (the filter's two forms -- wave per entry / workgroup batches -- are two kernels; the instances that carry the previous
+    # frame's patch stage (the keyframe unit) are compiled for 6 waves per SIMD: 80 VGPRs.  Round 6: no instance that carries
+    # the patch stage owns private memory any more -- what they spilled were loop invariants of the patch loop (float / double
+    # / reciprocal forms of the slot and atlas sizes, a lane's byte offsets), now kept opaque so that they are recomputed at
+    # their uses instead of being reloaded -- a dependent round trip each -- from scratch)
+    "tf_mesh.hip": {"k_meshILi128ELb0E": (80, 0), "k_mesh_filterILb1ELb0ELb0E": (72, 0),
+                    "k_mesh_filterILb0ELb0ELb0E": (80, 0), "k_mesh_filterILb1ELb1ELb0E": (80, 0),
+                    # (the batch form with the patch stage on board -- the keyframe unit on hall-sized lists: a 20-byte stack slot the
+                    # compiler reserves and then folds away -- its code holds no scratch instruction)
+                    "k_mesh_filterILb0ELb1ELb0E": (80, 24)},
+    "tf_atlas.hip": {"k_patchILb1ELb1ELb1E": (80, 0)},  # one patch per wave, two 64-vertex blocks in registers: 6 waves per SIMD
 }
 
 

@@ -298,3 +298,55 @@ int main() {
                         "-ltexfusion_hip", "-Wl,-rpath," + os.path.join(ROOT, "texturefusion_amd"), "-Wl,-rpath,/opt/rocm/lib",
                         "-L/opt/rocm/lib"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_gui_texture_upload_compiles_against_the_mirror(tmp_path):
+    """MobileFusion::MobileShow's texture upload (GCFusion/MobileFusion.h:404-421) -- the GUI thread hands the hot rows of
+    `chiselMap->atlas.texture_buffer` to OpenGL -- is cut out of /root/reference AT TEST TIME (the block of the `if` on
+    atlas.hot_end / hot_start), put into a function next to no-op stand-ins for the six GL entry points it calls, compiled
+    against texturefusion_amd/host/tf_chisel.hpp and linked against the C ABI: `atlas.hot_start`, `atlas.hot_end`,
+    `atlas.texture_buffer.data` and MAX_PATCH_WIDTH are what the mirror has to offer for it to compile unchanged.  Nothing
+    of the reference's text is kept in the repository; build container only."""
+    hdr = "/root/reference/GCFusion/MobileFusion.h"
+    if not os.path.exists(hdr):
+        pytest.skip("/root/reference absent")
+    lines = open(hdr).read().splitlines()
+    first = next(i for i, l in enumerate(lines) if "chiselMap->atlas.hot_end > chiselMap->atlas.hot_start" in l)
+    depth, last = 0, None
+    for i in range(first, len(lines)):
+        depth += lines[i].count("{") - lines[i].count("}")
+        if depth == 0 and "{" in "".join(lines[first:i + 1]):
+            last = i
+            break
+    assert last is not None and 12 <= last - first <= 30
+    body = "\n".join(lines[first:last + 1])
+    assert "texture_buffer" in body and ".data[" in body
+    src = tmp_path / "gui_upload.cpp"
+    src.write_text("""
+#include "%s/texturefusion_amd/host/tf_chisel.hpp"
+// stand-ins for what the block calls of OpenGL (this image has no GL): enough for the block to compile as it is
+typedef unsigned int GLuint; typedef int GLint; typedef int GLsizei; typedef unsigned int GLenum; typedef long GLsizeiptr;
+enum { GL_PIXEL_UNPACK_BUFFER = 1, GL_STREAM_COPY_ARB, GL_TEXTURE_2D, GL_RGB, GL_UNSIGNED_BYTE };
+static const void* g_last_upload = nullptr; static long g_last_bytes = 0;
+inline void glBindBufferARB(GLenum, GLuint) {}
+inline void glBufferDataARB(GLenum, GLsizeiptr bytes, const void* p, GLenum) { g_last_upload = p; g_last_bytes = (long)bytes; }
+inline void glBindTexture(GLenum, GLuint) {}
+inline void glTexSubImage2D(GLenum, GLint, GLint, GLint, GLsizei, GLsizei, GLenum, GLenum, const void*) {}
+struct MobileFusion {  // the members the block touches (GCFusion/MobileFusion.h:62-90)
+  chisel::ChiselPtr chiselMap;
+  GLuint pbo = 0, texture_model = 0;
+  void upload() {
+%s
+  }
+};
+int main() {
+  MobileFusion m;
+  (void)m; (void)g_last_upload; (void)g_last_bytes;  // (compiled and linked; running it would need a device volume)
+  return sizeof(&MobileFusion::upload) ? 0 : 1;
+}
+""" % (ROOT, body))
+    exe = tmp_path / "gui_upload"
+    r = subprocess.run(["g++", "-std=c++14", "-O0", "-Wall", str(src), "-o", str(exe), "-L" + os.path.join(ROOT, "texturefusion_amd"),
+                        "-ltexfusion_hip", "-Wl,-rpath," + os.path.join(ROOT, "texturefusion_amd"), "-Wl,-rpath,/opt/rocm/lib",
+                        "-L/opt/rocm/lib"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]

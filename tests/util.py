@@ -20,13 +20,15 @@ def assert_chunks_equal(ov, gv, ids, what=""):
     ids = np.asarray(ids, np.int32).reshape(-1, 3)
     if len(ids) == 0:
         return
-    gs, gw, gc = gv.get_chunks(ids)
-    for i, cid in enumerate(ids):
-        os_, ow, oc = ov.get_chunk(cid)
-        # bit-exact: compare raw bits so that -0.0 / NaN payloads would be caught too
-        assert np.array_equal(os_.view(np.uint32), gs[i].view(np.uint32)), "%s sdf differs in chunk %s" % (what, cid)
-        assert np.array_equal(ow.view(np.uint32), gw[i].view(np.uint32)), "%s weight differs in chunk %s" % (what, cid)
-        assert np.array_equal(oc, gc[i]), "%s colour differs in chunk %s" % (what, cid)
+    for b0 in range(0, len(ids), 8192):  # (in blocks: a hall has 10^5 chunks of 8 KiB)
+        blk = ids[b0:b0 + 8192]
+        gs, gw, gc = gv.get_chunks(blk)
+        for i, cid in enumerate(blk):
+            os_, ow, oc = ov.get_chunk(cid)
+            # bit-exact: compare raw bits so that -0.0 / NaN payloads would be caught too
+            assert np.array_equal(os_.view(np.uint32), gs[i].view(np.uint32)), "%s sdf differs in chunk %s" % (what, cid)
+            assert np.array_equal(ow.view(np.uint32), gw[i].view(np.uint32)), "%s weight differs in chunk %s" % (what, cid)
+            assert np.array_equal(oc, gc[i]), "%s colour differs in chunk %s" % (what, cid)
 
 
 def sorted_ids(ids):

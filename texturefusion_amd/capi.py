@@ -39,7 +39,7 @@ SYMBOLS = (
     "tf_boundary_unpack", "tf_keyframe_cache", "tf_keyframe_cache_device", "tf_keyframe_set_pose",
     "tf_keyframe_release", "tf_atlas_patch_size", "tf_atlas_loc_next", "tf_atlas_size", "tf_meshes_upload",
     "tf_generate_patches", "tf_compensate_color", "tf_update_atlas", "tf_draw_meshes", "tf_draw_meshes_device",
-    "tf_patches_download", "tf_atlas_download_rows", "tf_stream_frames_device",
+    "tf_patches_download", "tf_atlas_download_rows", "tf_atlas_snapshot_rows", "tf_stream_frames_device",
     "tf_stream_frames_textured_device", "tf_get_texture_stats", "tf_integrate_frame_host", "tf_integrate_frame_host_rgb", "tf_host_frame_times", "tf_host_register", "tf_host_unregister",
     "tf_host_frame_buffers", "tf_host_frame_deferral", "tf_host_frame_set_deferral", "tf_host_frame_set_async", "tf_host_frame_fence", "tf_texture_frame_device_phase", "tf_comm_exchange_overlap", "tf_texture_frame_device", "tf_boundary_block_bytes", "tf_boundary_pack_block", "tf_boundary_pack_bands", "tf_boundary_band_bounds", "tf_boundary_pack_bands2", "tf_boundary_unpack_pair", "tf_comm_exchange_mode", "tf_comm_stats", "tf_comm_stats_ex",
     "tf_boundary_unpack_blocks", "tf_comm_unique_id", "tf_comm_init", "tf_comm_destroy", "tf_exchange_boundary",
@@ -214,6 +214,7 @@ def lib():
     L.tf_pre_refine_keyframe.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
     L.tf_comm_exchange_every_frame.argtypes = [vp, C.c_int64]
     L.tf_atlas_download_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p]
+    L.tf_atlas_snapshot_rows.argtypes = [vp, C.c_int64, C.c_int64, u8p, i64p, i32p]
     u32p = C.POINTER(C.c_uint32)
     L.tf_update_meshes.argtypes = [vp, i64p]
     L.tf_list_meshes.argtypes = [vp, i32p, C.c_int64, i64p]
@@ -528,8 +529,8 @@ class Volume:
         return a.value, b.value, c.value
 
     def check_neighbours(self):
-        """-> i64[6]: rows, non-zero words, wrong words (must be 0), fully trusted rows, trusted "none" words whose chunk
-        exists (must be 0), the same among the near eight (must be 0) -- the neighbour table against the chunk hash"""
+        """-> i64[6]: rows, non-zero words, wrong words (must be 0), trusted rows, trusted "none" words whose chunk exists
+        (must be 0), 0 -- the neighbour table against the chunk hash"""
         out = np.zeros(6, np.int64)
         self._ck(self.L.tf_check_neighbours(self.h, _p(out, C.c_int64)))
         return out
@@ -902,3 +903,11 @@ class Volume:
         out = np.zeros((row1 - row0, width, 3), np.uint8)
         self._ck(self.L.tf_atlas_download_rows(self.h, row0, row1, _p(out, C.c_uint8)))
         return out
+
+    def atlas_snapshot_rows(self, row0, row1, width):
+        """-> (rows, write_seq, frame_id): tf_atlas_snapshot_rows -- callable from a thread other than the one that drives
+        the handle (ctypes releases the GIL for the call)"""
+        out = np.zeros((row1 - row0, width, 3), np.uint8)
+        seq, fid = C.c_int64(0), C.c_int32(-1)
+        self._ck(self.L.tf_atlas_snapshot_rows(self.h, row0, row1, _p(out, C.c_uint8), C.byref(seq), C.byref(fid)))
+        return out, seq.value, fid.value

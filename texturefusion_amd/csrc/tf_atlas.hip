@@ -527,7 +527,10 @@ void atlas_destroy(tf_volume* v) {
 
 int atlas_reset(tf_volume* v) {
   AtlasState& a = v->atlas;
-  TF_HIP(hipMemsetAsync(a.buf, 0, (size_t)a.aw * a.ah * 3, v->stream));  // Atlas.cpp:35-36
+  {
+    AtlasWriteScope aw(v, -1);
+    TF_HIP(hipMemsetAsync(a.buf, 0, (size_t)a.aw * a.ah * 3, v->stream));  // Atlas.cpp:35-36
+  }
   AtlasCtl c;
   memset(&c, 0, sizeof(c));
   c.loc_min = ~0ull;
@@ -914,7 +917,10 @@ int tf_update_atlas(tf_volume* v, const int32_t* ids, int64_t n) {
   const uint32_t n32 = (uint32_t)n;
   hipLaunchKernelGGL(k_work_lookup, dim3((n32 + 255) / 256), dim3(256), 0, v->stream, v->dev, n32);
   prof_begin(v, TF_PROF_ATLAS_BLIT);
-  hipLaunchKernelGGL((k_patch<false, true, false>), dim3(1024), dim3(256), 0, v->stream, v->dev, v->cam, 0, KfDev{});
+  {
+    AtlasWriteScope aw(v, INT32_MIN);  // (patches of several keyframes: the label of the last fused frame stays)
+    hipLaunchKernelGGL((k_patch<false, true, false>), dim3(1024), dim3(256), 0, v->stream, v->dev, v->cam, 0, KfDev{});
+  }
   prof_end(v);
   TF_HIP(hipGetLastError());
   return tf_sync(v);
@@ -1116,6 +1122,46 @@ int tf_patches_download(tf_volume* v, const int32_t* ids, int64_t n, const int64
   if (texcoord) memcpy(texcoord, hs + o_tc, (size_t)nv * 8);
   if (texcolor) memcpy(texcolor, hs + o_tcol, (size_t)nv * 12);
   if (labs) memcpy(labs, hs + o_labs, (size_t)nv * 12);
+  return TF_OK;
+}
+
+// Rows [row0, row1) of the atlas as they are behind every atlas-writing launch that is on the handle's stream NOW, for a
+// thread OTHER than the one that drives the handle (no deferred work is flushed, no handle state is touched beyond the
+// reader's own buffers): a device-to-device copy of the rows goes INTO the handle's stream under atlas_mu -- between two of
+// the map thread's launches, never inside one's enqueue -- so the rows are those of ONE moment of the stream, whatever the
+// map thread enqueues meanwhile; an event behind it releases the copy to the host on the reader's own stream.
+int tf_atlas_snapshot_rows(tf_volume* v, int64_t row0, int64_t row1, uint8_t* dst, int64_t* write_seq, int32_t* frame_id) {
+  if (!v || !dst) { set_error("null argument"); return TF_ERR_INVALID; }
+  TF_HIP(hipSetDevice(v->device));
+  AtlasState& a = v->atlas;
+  if (row0 < 0 || row1 > a.ah || row0 > row1) { set_error("row range outside the atlas"); return TF_ERR_INVALID; }
+  const size_t step = (size_t)a.aw * 3, bytes = (size_t)(row1 - row0) * step;
+  std::lock_guard<std::mutex> readers(v->snap_mu);
+  if (!v->read_stream) {
+    TF_HIP(hipStreamCreateWithFlags(&v->read_stream, hipStreamNonBlocking));
+    TF_HIP(hipEventCreateWithFlags(&v->read_ev, hipEventDisableTiming));
+  }
+  if (bytes > v->d_snap_bytes) {  // (grows by doubling; the free waits for the device once per growth)
+    size_t want = std::max<size_t>(64 * step, 1);
+    while (want < bytes) want <<= 1;
+    if (v->d_snap) { TF_HIP(hipStreamSynchronize(v->read_stream)); TF_HIP(hipFree(v->d_snap)); v->d_snap = nullptr; v->d_snap_bytes = 0; }
+    TF_HIP(hipMalloc((void**)&v->d_snap, want));
+    v->d_snap_bytes = want;
+  }
+  uint64_t seq = 0;
+  int32_t fid = -1;
+  {
+    std::lock_guard<std::mutex> lk(v->atlas_mu);
+    if (bytes) TF_HIP(hipMemcpyAsync(v->d_snap, a.buf + (size_t)row0 * step, bytes, hipMemcpyDeviceToDevice, v->stream));
+    TF_HIP(hipEventRecord(v->read_ev, v->stream));
+    seq = v->atlas_seq.load(std::memory_order_acquire);
+    fid = v->atlas_frame.load(std::memory_order_relaxed);
+  }
+  TF_HIP(hipStreamWaitEvent(v->read_stream, v->read_ev, 0));
+  if (bytes) TF_HIP(hipMemcpyAsync(dst, v->d_snap, bytes, hipMemcpyDeviceToHost, v->read_stream));
+  TF_HIP(hipStreamSynchronize(v->read_stream));
+  if (write_seq) *write_seq = (int64_t)seq;
+  if (frame_id) *frame_id = fid;
   return TF_OK;
 }
 

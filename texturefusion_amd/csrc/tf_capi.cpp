@@ -11,6 +11,7 @@
 #include <sched.h>
 #include <limits>
 #include <map>
+#include <memory>
 #include <mutex>
 
 #include "tf_host_math.h"
@@ -222,8 +223,9 @@ static void discard_primed(tf_volume* v) {
 }
 
 }  // namespace tf (the two functions below are shared with tf_unit.hip: declared in tf_volume.h)
-int tf::xchg_band_counts(tf_volume* v, const tf::FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]) {
+int tf::xchg_band_counts(tf_volume* v, const tf::FrameCtl* ctl, uint32_t tag, uint32_t cnt[4], hipStream_t s) {
   using namespace tf;
+  if (!s) s = v->stream;
   if (!v->h_xchg) {
     TF_HIP(hipHostMalloc((void**)&v->h_xchg, 64, hipHostMallocDefault));
     memset(v->h_xchg, 0, 64);
@@ -232,7 +234,7 @@ int tf::xchg_band_counts(tf_volume* v, const tf::FrameCtl* ctl, uint32_t tag, ui
     // (the word the host waits for is a publish SEQUENCE number, never reused: a frame that replaces a discarded selection
     // has the same epoch tag as the frame it replaces, and the old publish may still sit in the pinned word)
     const uint32_t seq = ++v->xchg_seq;
-    launch_xchg_publish(ctl, v->h_xchg, seq, v->stream);
+    launch_xchg_publish(ctl, v->h_xchg, seq, s);
     TF_HIP(hipGetLastError());
     v->xchg_pub_enq = tag;
     v->xchg_pub_seq = seq;
@@ -489,6 +491,9 @@ int tf_volume_destroy(tf_volume* v) {
   if (v->h_xchg) hipHostFree(v->h_xchg);
   v->h_xchg = nullptr;
   if (v->xstream) { hipStreamSynchronize(v->xstream); hipStreamDestroy(v->xstream); v->xstream = nullptr; }
+  if (v->read_stream) { hipStreamSynchronize(v->read_stream); hipStreamDestroy(v->read_stream); v->read_stream = nullptr; }
+  if (v->read_ev) { hipEventDestroy(v->read_ev); v->read_ev = nullptr; }
+  if (v->d_snap) { hipFree(v->d_snap); v->d_snap = nullptr; }
   if (v->ev_fork) { hipEventDestroy(v->ev_fork); v->ev_fork = nullptr; }
   if (v->ev_join) { hipEventDestroy(v->ev_join); v->ev_join = nullptr; }
   for (const tf_volume::HostRange& r : v->host_ranges) (void)host_range_release(r.locked);
@@ -868,6 +873,24 @@ uint32_t tf::nbr_next_seq(tf_volume* v) {
   return ++v->dev.seq;
 }
 
+int tf::boundary_pack_block_on(tf_volume* v, void* d_block, int64_t cap_records, hipStream_t s) {
+  uint8_t* blk = reinterpret_cast<uint8_t*>(d_block);
+  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, s));
+  launch_boundary_pack(v->dev, blk + 16, (uint32_t)cap_records, s);
+  launch_boundary_headers(v->dev, reinterpret_cast<uint32_t*>(blk), (uint32_t)cap_records, nullptr, 0, s);  // the count travels in-band
+  TF_HIP(hipGetLastError());
+  return TF_OK;
+}
+int tf::boundary_pack_bands2_on(tf_volume* v, void* d_block_down, int64_t cap_down, void* d_block_up, int64_t cap_up, hipStream_t s) {
+  // ONE launch: the counters live in VolCtl::xchg_cnt, the last workgroup writes the in-band counts and re-arms them
+  // (round 4: two memsets + the pack + a header launch -- the exchange of a frame was seven stream operations at their
+  // launch floor, 49 us with nothing on the wire; profiles/r5/README.md)
+  launch_boundary_pack_bands(v->dev, reinterpret_cast<uint8_t*>(d_block_down), reinterpret_cast<uint8_t*>(d_block_up),
+                             (uint32_t)cap_down, (uint32_t)cap_up, s);
+  TF_HIP(hipGetLastError());
+  return TF_OK;
+}
+
 // claimed: the dirty set of this frame is already in the lists of the current parity -- K-A built it (FrameStage::claim_par
 // = the parity used here), or the caller ran launch_dirty_frame over each of its lists (the keyframe unit)
 int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint32_t frame_epoch,
@@ -929,9 +952,12 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
   auto mesh_pass = [&](int cls, const uint32_t* flat_count, bool with_hint, bool with_ride, bool new_seq = true) -> bool {
     prof_begin(v, TF_PROF_MESH);
     d.seq = new_seq ? nbr_next_seq(v) : v->dev.seq;
+    std::unique_ptr<AtlasWriteScope> aw;  // (a patch stage riding on the filter launch writes atlas texels)
+    if (with_ride) aw.reset(new AtlasWriteScope(v, prev.kf.kf_id));
     const bool rode = launch_mesh(d, v->mesh_par, d.work_ids, flat_count, d.max_chunks, ++v->mesh_epoch, v->res, true, par ^ 1,
                                   len_guess, with_hint ? a.h_dirty_len : nullptr, par, v->stream, with_ride ? &prev : nullptr,
                                   &v->cam, cls, store);
+    aw.reset();
     store = nullptr;  // (once)
     v->mesh_par ^= 1;
     prof_end(v);
@@ -967,11 +993,8 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
       }
       TF_HIP(hipEventRecord(v->ev_fork, v->stream));          // behind the voxel update of this frame
       TF_HIP(hipStreamWaitEvent(v->xstream, v->ev_fork, 0));
-      hipStream_t main_stream = v->stream;
-      v->stream = v->xstream;  // (comm_exchange and what it calls enqueue on the handle's stream)
       (void)nbr_next_seq(v);   // the unpack launch and the interior pass next to it share this seq
-      rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u, xc, frame_epoch + 1u, xn);
-      v->stream = main_stream;
+      rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u, xc, frame_epoch + 1u, xn, v->xstream);
       if (rc) return rc;
       TF_HIP(hipEventRecord(v->ev_join, v->xstream));
       rode = mesh_pass(1, &d.vctl->zero_word, true, false, /*new_seq=*/false);
@@ -1031,7 +1054,10 @@ namespace tf {
 int patch_flush(tf_volume* v) {  // the pending patch stage as a launch of its own
   AtlasState& a = v->atlas;
   if (!a.pend_patch.on) return TF_OK;
-  launch_patch_fused(v, v->dev, a.pend_patch.st.par, a.pend_patch.st.kf, v->stream);
+  {
+    AtlasWriteScope aw(v, a.pend_patch.st.kf.kf_id);
+    launch_patch_fused(v, v->dev, a.pend_patch.st.par, a.pend_patch.st.kf, v->stream);
+  }
   TF_HIP(hipGetLastError());
   return patch_launched(v);
 }
@@ -1110,8 +1136,14 @@ static int enqueue_frames(tf_volume* v, int64_t n, int64_t n_ahead, const float*
     const bool carry = pp.on && hc && cur.img.rgba != nullptr;
     if (pp.on && hc && !carry) { int rc = patch_flush(v); if (rc) return rc; }
     if (hc) prof_begin(v, TF_PROF_INTEGRATE);
-    launch_frame(v->dev, hc ? &cur : nullptr, hn ? &nxt : nullptr, h2 ? &nx2 : nullptr, carry ? &pp.st : nullptr, v->cam,
-                 v->ig, v->res, v->stream, v->h_progress, &v->progress_seq);
+    if (carry) {  // (the launch writes atlas texels: ordered against tf_atlas_snapshot_rows)
+      AtlasWriteScope aw(v, pp.st.kf.kf_id);
+      launch_frame(v->dev, &cur, hn ? &nxt : nullptr, h2 ? &nx2 : nullptr, &pp.st, v->cam, v->ig, v->res, v->stream, v->h_progress,
+                   &v->progress_seq);
+    } else {
+      launch_frame(v->dev, hc ? &cur : nullptr, hn ? &nxt : nullptr, h2 ? &nx2 : nullptr, nullptr, v->cam, v->ig, v->res, v->stream,
+                   v->h_progress, &v->progress_seq);
+    }
     if (hc) prof_end(v);
     if (carry) { int rc = patch_launched(v); if (rc) return rc; }
     if (hc && tex) {
@@ -2035,26 +2067,14 @@ size_t tf_boundary_block_bytes(int64_t cap_records) { return 16 + (size_t)cap_re
 int tf_boundary_pack_block(tf_volume* v, void* d_block, int64_t cap_records) {
   if (!v || !d_block) { set_error("null argument"); return TF_ERR_INVALID; }
   TF_DEV(v);
-  uint8_t* blk = reinterpret_cast<uint8_t*>(d_block);
-  TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
-  launch_boundary_pack(v->dev, blk + 16, (uint32_t)cap_records, v->stream);
-  launch_boundary_headers(v->dev, reinterpret_cast<uint32_t*>(blk), (uint32_t)cap_records, nullptr, 0, v->stream);  // the count travels in-band
-  TF_HIP(hipGetLastError());
-  return TF_OK;
+  return tf::boundary_pack_block_on(v, d_block, cap_records, v->stream);
 }
 
 int tf_boundary_pack_bands2(tf_volume* v, void* d_block_down, int64_t cap_down, void* d_block_up, int64_t cap_up) {
   if (!v || !d_block_down || !d_block_up) { set_error("null argument"); return TF_ERR_INVALID; }
   if (cap_down < 0 || cap_up < 0) { set_error("negative capacity"); return TF_ERR_INVALID; }
   TF_DEV(v);
-  uint8_t* dn = reinterpret_cast<uint8_t*>(d_block_down);
-  uint8_t* up = reinterpret_cast<uint8_t*>(d_block_up);
-  // ONE launch: the counters live in VolCtl::xchg_cnt, the last workgroup writes the in-band counts and re-arms them
-  // (round 4: two memsets + the pack + a header launch -- the exchange of a frame was seven stream operations at their
-  // launch floor, 49 us with nothing on the wire; profiles/r5/README.md)
-  launch_boundary_pack_bands(v->dev, dn, up, (uint32_t)cap_down, (uint32_t)cap_up, v->stream);
-  TF_HIP(hipGetLastError());
-  return TF_OK;
+  return tf::boundary_pack_bands2_on(v, d_block_down, cap_down, d_block_up, cap_up, v->stream);
 }
 
 int tf_boundary_pack_bands(tf_volume* v, void* d_block_down, void* d_block_up, int64_t cap_records) {

@@ -122,7 +122,7 @@ static int comm_buffers(tf_volume* v, int64_t cap_records) {
   return TF_OK;
 }
 
-// pack -> transport -> unpack on the handle's stream; dirty_par >= 0: the owned face neighbours of every ghost
+// pack -> transport -> unpack on ONE stream (xs, or the handle's); dirty_par >= 0: the owned face neighbours of every ghost
 // chunk that arrives join the fused flow's per-frame dirty list (their neighbour was updated on another rank).
 // ctl != nullptr (the per-frame exchange of the fused flow, neighbour form): the blocks are SIZED by the frame's own
 // selection -- FrameCtl::band_cnt holds, identically on every rank, how many selected chunks lie in this rank's two
@@ -132,8 +132,9 @@ static int comm_buffers(tf_volume* v, int64_t cap_records) {
 // launch of its own) publishes; nothing else synchronises.  Without ctl (tf_exchange_boundary on demand, all-gather
 // form) the blocks have the caller's fixed capacity.
 int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t stamp, const FrameCtl* ctl, uint32_t tag,
-                  const FrameCtl* next_ctl) {
+                  const FrameCtl* next_ctl, hipStream_t xs) {
   CommState& c = v->comm;
+  const hipStream_t s = xs ? xs : v->stream;  // (the overlapped per-frame exchange runs on the handle's second stream)
   if (!c.comm) { set_error("tf_comm_init has not been called"); return TF_ERR_INVALID; }
   int rc = comm_buffers(v, cap_records);
   if (rc) return rc;
@@ -155,21 +156,22 @@ int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t sta
   }
   struct ProfScope {  // HIP events around the whole exchange when tf_profile_enable asked for TF_PROF_XCHG
     tf_volume* v;
-    explicit ProfScope(tf_volume* vv) : v(vv) { prof_begin(v, TF_PROF_XCHG); }
-    ~ProfScope() { prof_end(v); }
-  } prof_scope(v);
+    hipStream_t s;
+    ProfScope(tf_volume* vv, hipStream_t ss) : v(vv), s(ss) { prof_begin(v, TF_PROF_XCHG, s); }
+    ~ProfScope() { prof_end(v, s); }
+  } prof_scope(v, s);
   if (neighbours) {
     // down block -> rank - 1, up block -> rank + 1; from rank - 1 comes ITS up block, from rank + 1 its down block.
     // A missing neighbour's receive slot keeps a zero count.
     uint32_t cap_dn = (uint32_t)c.cap_records, cap_up = cap_dn, cap_lo = cap_dn, cap_hi = cap_dn;
     if (ctl) {
       uint32_t cnt[4];
-      rc = xchg_band_counts(v, ctl, tag, cnt);
+      rc = xchg_band_counts(v, ctl, tag, cnt, s);
       if (rc) return rc;
       cap_dn = xchg_bucket(cnt[0], c.cap_records); cap_up = xchg_bucket(cnt[1], c.cap_records);
       cap_lo = xchg_bucket(cnt[2], c.cap_records); cap_hi = xchg_bucket(cnt[3], c.cap_records);
     }
-    rc = tf_boundary_pack_bands2(v, send, cap_dn, send + block, cap_up);
+    rc = boundary_pack_bands2_on(v, send, cap_dn, send + block, cap_up, s);
     if (rc) return rc;
     const bool lower = c.rank > 0, upper = c.rank + 1 < c.nranks;
     const size_t b_dn = tf_boundary_block_bytes(cap_dn), b_up = tf_boundary_block_bytes(cap_up);
@@ -177,12 +179,12 @@ int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t sta
     if (lower || upper) {
       TF_NCCL(g_rccl.GroupStart());
       if (lower) {
-        TF_NCCL(g_rccl.Send(send, b_dn, ncclUint8, c.rank - 1, comm, v->stream));
-        TF_NCCL(g_rccl.Recv(recv, b_lo, ncclUint8, c.rank - 1, comm, v->stream));
+        TF_NCCL(g_rccl.Send(send, b_dn, ncclUint8, c.rank - 1, comm, s));
+        TF_NCCL(g_rccl.Recv(recv, b_lo, ncclUint8, c.rank - 1, comm, s));
       }
       if (upper) {
-        TF_NCCL(g_rccl.Send(send + block, b_up, ncclUint8, c.rank + 1, comm, v->stream));
-        TF_NCCL(g_rccl.Recv(recv + block, b_hi, ncclUint8, c.rank + 1, comm, v->stream));
+        TF_NCCL(g_rccl.Send(send + block, b_up, ncclUint8, c.rank + 1, comm, s));
+        TF_NCCL(g_rccl.Recv(recv + block, b_hi, ncclUint8, c.rank + 1, comm, s));
       }
       TF_NCCL(g_rccl.GroupEnd());
     }
@@ -198,18 +200,18 @@ int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t sta
       memset(v->h_xchg, 0, 64);
     }
     const uint32_t pub_seq = pub ? ++v->xchg_seq : 0u;  // (a sequence number of its own: see xchg_band_counts)
-    launch_boundary_unpack_blocks(d, recv, 2, -1, cap_lo, dirty_par, stamp, v->stream, recv + block, cap_hi,
+    launch_boundary_unpack_blocks(d, recv, 2, -1, cap_lo, dirty_par, stamp, s, recv + block, cap_hi,
                                   pub ? next_ctl : nullptr, pub ? v->h_xchg : nullptr, pub_seq);
     if (pub) { v->xchg_pub_enq = tag + 1u; v->xchg_pub_seq = pub_seq; }
   } else {
-    rc = tf_boundary_pack_block(v, send, c.cap_records);
+    rc = boundary_pack_block_on(v, send, c.cap_records, s);
     if (rc) return rc;
-    TF_NCCL(g_rccl.AllGather(send, recv, block, ncclUint8, comm, v->stream));
+    TF_NCCL(g_rccl.AllGather(send, recv, block, ncclUint8, comm, s));
     c.bytes_received += (uint64_t)(c.nranks > 1 ? c.nranks - 1 : 0) * block;
     c.bytes_sent += (uint64_t)(c.nranks > 1 ? c.nranks - 1 : 0) * block;
     c.bound_records += (uint64_t)(c.nranks > 1 ? c.cap_records : 0);
     c.exchanges += 1;
-    launch_boundary_unpack_blocks(d, recv, nblocks, skip, (uint32_t)c.cap_records, dirty_par, stamp, v->stream);
+    launch_boundary_unpack_blocks(d, recv, nblocks, skip, (uint32_t)c.cap_records, dirty_par, stamp, s);
   }
   TF_HIP(hipGetLastError());
   v->host_list_n = -1;

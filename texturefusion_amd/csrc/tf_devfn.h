@@ -160,21 +160,20 @@ __device__ __forceinline__ uint32_t nbr_probe(const VolumeDev& v, unsigned long 
   }
   return 0u;
 }
-// The row of pool slot `own` (chunk `id`), lane j < kNbrWords holding word j, with every "none" word among the first
-// n_check (27: the whole row; lanes beyond hold 0) made trustworthy: a row whose check is older than the newest key
+// The row of pool slot `own` (chunk `id`), lane j < kNbrWords holding word j, with every "none" word made trustworthy: a row whose check is older than the newest key
 // insertion re-probes its zero words, writes back what it finds and stamps the check (the caller's launch carries a seq
 // above every insertion ahead of it on the stream, launch_mesh).  `w` = the lane's word as loaded (the caller issues the
 // load, next to whatever else it wants in flight); create_seq = VolCtl::create_seq as this launch found it.  Wave-uniform
 // control flow when the lanes of a wave share one row.
 __device__ __forceinline__ uint32_t nbr_row_checked(const VolumeDev& v, const uint32_t own, const int4 id, const int lane,
                                                    uint32_t w, const uint32_t create_seq) {
-  const uint32_t st = (uint32_t)__shfl((int)w, kNbrFull);
+  const uint32_t st = (uint32_t)__shfl((int)w, kNbrStamp);
   if (!(st > create_seq)) {
     if (lane < 27 && lane != 13 && w == 0u) {
       w = nbr_probe(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
       if (w) v.nbr[(size_t)own * kNbrWords + lane] = w;
     }
-    if (lane == kNbrNear || lane == kNbrFull) v.nbr[(size_t)own * kNbrWords + lane] = v.seq;
+    if (lane == kNbrStamp) v.nbr[(size_t)own * kNbrWords + lane] = v.seq;
   }
   return w;
 }

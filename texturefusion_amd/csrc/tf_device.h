@@ -95,7 +95,7 @@ struct VolCtl {
   uint32_t xchg_cnt[2];
   uint32_t xchg_ticket;
   // neighbour table (VolumeDev::nbr): VolumeDev::seq of the newest launch that INSERTED a key into the chunk hash.  A row's
-  // "no chunk there" entries are trusted only if the row was checked by a launch with a larger seq (kNbrNear / kNbrFull).
+  // "no chunk there" entries are trusted only if the row was checked by a launch with a larger seq (kNbrStamp).
   uint32_t create_seq;
   // Pool slots are handed out from 64 independent stripes (stripe s owns slots
   // [s*max_chunks/64, (s+1)*max_chunks/64)) so that the thousands of chunk creations of a
@@ -214,8 +214,7 @@ struct VolumeDev {
   uint32_t* summ;         // [max_chunks]
   // Neighbour table: per pool slot one 128-byte row.  Words 0..26 = pool slot + 1 of the chunk at id + (dx, dy, dz),
   // word index (dx + 1) + 3 (dy + 1) + 9 (dz + 1), 0 = no chunk known there (word 13, the chunk itself, is unused);
-  // word kNbrNear / kNbrFull = VolumeDev::seq of the launch that last checked the eight words of the +x / +y / +z corner
-  // (what the filter's summary test reads) / all 27 against the hash.  Pool slots never move and hash entries are never
+  // word kNbrStamp = VolumeDev::seq of the launch that last checked the row against the hash.  Pool slots never move and hash entries are never
   // removed (a garbage-collected chunk is parked: alive = 0, voxels back in the fresh state, summary 0, mesh out of the map
   // -- which is exactly what every reader by slot assumes of a chunk that does not exist), so a non-zero word is true for
   // the life of the volume; a zero word is true while no key has been inserted since the check (VolCtl::create_seq).  The
@@ -312,7 +311,7 @@ struct PatchStage {
   int par;   // counter-set parity of that frame (AtlasCtl::set, patch_list, patch_cnt)
   KfDev kf;  // the frame itself as the keyframe its patches are cut from
 };
-constexpr int kNbrWords = 32, kNbrNear = 27, kNbrFull = 28;  // VolumeDev::nbr
+constexpr int kNbrWords = 32, kNbrStamp = 27;  // VolumeDev::nbr
 constexpr uint32_t kSummAny = 0xFFFFu;        // VolumeDev::summ: every class may occur
 constexpr uint32_t kKaCoarseSumm = 16384u;    // IntegrateConsts::dbg bit: FrameStage::coarse_summ
 

@@ -551,7 +551,8 @@ typedef const __attribute__((address_space(4))) u32x4* const_u32x4_ptr;
 typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 typedef const __attribute__((address_space(4))) u32x8* const_u32x8_ptr;
 
-template <bool COLOR, bool QUALITY, bool FUSED, bool FLAG, int GP>
+// TL: the tuning instance (TF_KA_DBG bit 12, tools/timeline.py) -- per-wave time stamps and work counters into the debug table
+template <bool COLOR, bool QUALITY, bool FUSED, bool FLAG, int GP, bool TL = false>
 __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameImages& img, const Cam& cam,
                                                const IntegrateConsts& kc, const uint32_t epoch,
                                                const uint32_t bid, const uint32_t nb, const int claim_par = -1) {
@@ -633,7 +634,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
   float c_near = cam.nearP, c_far = cam.farP, c_thr = kc.thrCol, c_lower = kc.lower, c_sigma = kc.sigma;
   asm volatile("" : "+v"(c_near), "+v"(c_far), "+v"(c_thr), "+v"(c_lower), "+v"(c_sigma));
 
-  if ((kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves)  // timeline aid: prologue end
+  if (TL && (kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves)  // timeline aid: prologue end
   {
     v.phase_buf[wave * 16 + 14] = __builtin_amdgcn_s_memrealtime();
     v.phase_buf[wave * 16 + 8] = 0;
@@ -688,7 +689,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const float band = 32.0f * kc.res;
     const bool div_safe = (fabsf(o2) > band) && (fabsf(o2) < 1048576.0f) && (fabsf(o0) < 1048576.0f) &&
                           (fabsf(o1) < 1048576.0f) && (kc.res > 1e-6f) && (kc.res < 16.0f);
-    if ((kc.dbg & 8192u) && e == e_first && lane == 0 && wave < (uint32_t)kPhaseWaves) {
+    if (TL && (kc.dbg & 8192u) && e == e_first && lane == 0 && wave < (uint32_t)kPhaseWaves) {
       asm volatile("" :: "s"(o0), "s"(o1), "s"(o2), "s"(id.x));
       v.phase_buf[wave * 16 + 15] = __builtin_amdgcn_s_memrealtime();  // timeline aid: first entry loaded
     }
@@ -954,7 +955,7 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
         if (lane == 0 && sword) atomicOr(&v.summ[slot], sword);
       }
     }
-    if ((kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves) {  // timeline aid: work of this wave
+    if (TL && (kc.dbg & 8192u) && lane == 0 && wave < (uint32_t)kPhaseWaves) {  // timeline aid: work of this wave
       v.phase_buf[wave * 16 + 8] += 1;                 // chunks
       v.phase_buf[wave * 16 + 9] += rows_t + rows_c;   // rows rewritten
     }
@@ -1054,25 +1055,27 @@ struct FrameLaunch {
   uint32_t progress_val; // every launch ahead of it on the stream is through (tf_volume::h_progress)
 };
 
-template <bool COLOR, bool PATCH>
+// TL: the tuning instances (TF_KA_DBG / TF_PATCH_DBG set): wave timelines, phase stamps and the triage cut-offs -- the
+// product instances carry none of their branches
+template <bool COLOR, bool PATCH, bool TL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATCH ? TF_KFP_WAVES : TF_KF_WAVES, PATCH ? TF_KFP_WAVES : TF_KF_WAVES))) void k_frame(FrameLaunch a) {
   // Block ranges: K-A [0, n_ka), patches [n_ka, n_ka + n_patch), K-C, K-B behind them.
   // a.rot rotates the dispatch order: 0 = K-A blocks first, n_ka = the other roles first
   const uint32_t total = a.n_ka + a.n_patch + a.n_sel + a.n_bbox;
   const uint32_t b = blockIdx.x + a.rot < total ? blockIdx.x + a.rot : blockIdx.x + a.rot - total;
   // tuning aid (dbg bit 12): per-wave {start, end, role} stamps of the last launch -> phase_buf
-  const bool timeline = (a.kc.dbg & 4096u) != 0 && a.n_sel > 0 && a.n_bbox > 0;  // steady launches only
+  const bool timeline = TL && (a.kc.dbg & 4096u) != 0 && a.n_sel > 0 && a.n_bbox > 0;  // steady launches only
   const unsigned long long t0 = timeline ? __builtin_amdgcn_s_memrealtime() : 0ull;  // 100 MHz, chip-wide
   uint32_t role;
   if (b < a.n_ka) {
     role = 0;
-    integrate_body<COLOR, false, true, true, TF_KA_GP>(a.v, a.img, a.cam, a.kc, a.epoch, b, a.n_ka, a.claim_par);
+    integrate_body<COLOR, false, true, true, TF_KA_GP, TL>(a.v, a.img, a.cam, a.kc, a.epoch, b, a.n_ka, a.claim_par);
   } else if (PATCH && b < a.n_ka + a.n_patch) {
     role = 3;
-    patch_body<true, true, true>(a.v, a.cam, a.patch_par, a.kf_patch, b - a.n_ka, a.n_patch);
+    patch_body<true, true, true, TL>(a.v, a.cam, a.patch_par, a.kf_patch, b - a.n_ka, a.n_patch);
   } else if (b < a.n_ka + a.n_patch + a.n_sel) {
     role = 1;
-    if (!(a.kc.dbg & 512u)) {  // triage switch
+    if (!(TL && (a.kc.dbg & 512u))) {  // triage switch
       VolumeDev v1 = a.v;
       v1.sel = a.sel1;
       select_body<true>(a.depth1, a.cam, a.ig, a.sc1, v1, b - a.n_ka - a.n_patch, a.n_sel);
@@ -1082,7 +1085,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PATCH ? TF_
     // the progress stamp lives in this (lightest) role: next to K-A it cost 36-212 B/lane of private memory
     if (a.progress && b + 1 == total && threadIdx.x == 0)
       __hip_atomic_store(a.progress, a.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (!(a.kc.dbg & 1024u)) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_patch - a.n_sel, a.n_bbox);
+    if (!(TL && (a.kc.dbg & 1024u))) bbox_body(a.depth2, a.cam, a.P2, a.ctl2, b - a.n_ka - a.n_patch - a.n_sel, a.n_bbox);
   }
   if (timeline) {
     const uint32_t gw = (b * 256 + threadIdx.x) >> 6;
@@ -1201,9 +1204,16 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   // frees.  With the patch stage on board that order leaves the stage's 15-us chains to start when K-A's waves end
   // (profiles/r3: span 48 us); patch + selection first, K-A behind them as their waves finish: 44 us.
   a.rot = others_first ? a.n_ka : 0u;
-  if (with_patch) hipLaunchKernelGGL((k_frame<true, true>), dim3(total), dim3(256), 0, s, a);
-  else if (color) hipLaunchKernelGGL((k_frame<true, false>), dim3(total), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_frame<false, false>), dim3(total), dim3(256), 0, s, a);
+  const bool tuning = dbg != 0 || (with_patch && a.kf_patch.pad[0] != 0);  // TF_KA_DBG / TF_PATCH_DBG: the instances with the aids
+  if (with_patch) {
+    if (tuning) hipLaunchKernelGGL((k_frame<true, true, true>), dim3(total), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_frame<true, true>), dim3(total), dim3(256), 0, s, a);
+  } else if (color) {
+    if (tuning) hipLaunchKernelGGL((k_frame<true, false, true>), dim3(total), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_frame<true, false>), dim3(total), dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL((k_frame<false, false>), dim3(total), dim3(256), 0, s, a);
+  }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -247,10 +247,12 @@ __device__ __forceinline__ void filter_defer_reset(const VolumeDev& v, uint32_t*
   // (p >= cap_sh cannot happen: at most max_chunks / 32 pool slots share a shard, each listed once per frame)
 }
 
+// the 19 words of a neighbour-table row that are neither the chunk itself (13) nor one of the eight the summary test reads
+__device__ const uint8_t kFarWord[19] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 15, 18, 19, 20, 21, 24};
 // phase A of the filter for the 8-lane group a lane belongs to (k8 = its place in the group): lane k stands for chunk
 // id + (k & 1, (k >> 1) & 1, k >> 2) -- the chunk itself and its seven +x / +y / +z neighbours -- whose pool slots come from
-// the chunk's row of the neighbour table (VolumeDev::nbr: lane 0 fetches the row's check stamp, lanes 1..7 their words; a
-// row whose "none" words may be stale re-probes them), and reads that chunk's class summary.  The summaries are supersets
+// the chunk's row of the neighbour table (VolumeDev::nbr: lane 0 fetches the stamp of the row's last full check, lanes 1..7 their words; a
+// row whose "none" words may be stale re-probes ALL of them, the group's eight lanes sharing the 25 words), and reads that chunk's class summary.  The summaries are supersets
 // of the classes that occur among a chunk's voxels / on the faces the neighbours contribute (an edge or the corner counts
 // as the whole face it lies in), so a chunk they rule out is ruled out for good.  own_in = the chunk's pool slot as every
 // lane of the group knows it (kInvalidSlot: none; listed: it came with the list entry, whose id.w may name a hash entry).  Returns the lane's pool slot; *own = the chunk's (kInvalidSlot: the
@@ -260,19 +262,28 @@ __device__ __forceinline__ uint32_t filter_near(const VolumeDev& v, const int4 i
   uint32_t nslot = kInvalidSlot;
   *maybe = true;
   if (own_in != kInvalidSlot) {
-    const int word = k8 == 0 ? kNbrNear : 13 + (k8 & 1) + 3 * ((k8 >> 1) & 1) + 9 * (k8 >> 2);
+    const int word = k8 == 0 ? kNbrStamp : 13 + (k8 & 1) + 3 * ((k8 >> 1) & 1) + 9 * (k8 >> 2);
     uint32_t w = v.nbr[(size_t)own_in * kNbrWords + word];
     // an entry K-A claimed (id.w = hash entry + 1) may have been parked later in that launch: RecomputeMeshes skips a
     // chunk that does not exist (:240-242).  This load travels with the row's.
     uint32_t alive = 1u;
     if (k8 == 0 && listed && id.w > 0) alive = v.hent[(uint32_t)id.w - 1u].alive & 1u;
     const uint32_t st = (uint32_t)__shfl((int)w, lane & 56);
-    if (!(st > create_seq)) {  // (group-uniform) the near words may lack a chunk inserted since the last check
+    if (!(st > create_seq)) {  // (group-uniform) the row's "none" words may lack a chunk inserted since the last check
       if (k8 != 0 && w == 0u) {
         w = nbr_probe(v, pack_id(id.x + (k8 & 1), id.y + ((k8 >> 1) & 1), id.z + (k8 >> 2)));
         if (w) v.nbr[(size_t)own_in * kNbrWords + word] = w;
       }
-      if (k8 == 0) v.nbr[(size_t)own_in * kNbrWords + kNbrNear] = v.seq;
+      // ... and the other 19 words, two or three per lane: whoever reads the row of a chunk that went through a
+      // filter launch -- the exact test, the mesher, the patch stage's flag exchange -- finds it checked in full
+      for (int q = k8; q < 19; q += 8) {
+        const int fw = (int)kFarWord[q];
+        if (v.nbr[(size_t)own_in * kNbrWords + fw] == 0u) {
+          const uint32_t got = nbr_probe(v, pack_id(id.x + fw % 3 - 1, id.y + (fw / 3) % 3 - 1, id.z + fw / 9 - 1));
+          if (got) v.nbr[(size_t)own_in * kNbrWords + fw] = got;
+        }
+      }
+      if (k8 == 0) v.nbr[(size_t)own_in * kNbrWords + kNbrStamp] = v.seq;
     }
     nslot = k8 == 0 ? (alive ? own_in : kInvalidSlot) : (w ? w - 1u : kInvalidSlot);
   }
@@ -303,15 +314,12 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
   // max_chunks / 32 of them whatever the order of the work
   const uint32_t shard = own & (kMeshShards - 1u);
   const float4* T4 = reinterpret_cast<const float4*>(v.tsdf + (size_t)own * kChunkVoxels);
+  uint32_t roww = 0u;  // (!HAVE_ROW: the row's word of this lane, requested ahead of the voxels, looked at behind them)
+  if (!HAVE_ROW && lane < kNbrWords) roww = v.nbr[(size_t)own * kNbrWords + lane];
   float4 qv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) qv[j] = T4[j * 64 + lane];  // voxels 2 i and 2 i + 1 of the chunk, i = 64 j + lane: {sdf, w, sdf, w}
   const uint32_t had_mesh = v.mesh_rec[own].state & kMsInMap;  // (travels with the voxels: which end of the row list, below)
-  if (!HAVE_ROW) {
-    uint32_t w = lane < kNbrWords ? v.nbr[(size_t)own * kNbrWords + lane] : 0u;
-    w = nbr_row_checked(v, own, id, lane, w, create_seq);
-    nslot = lane == 13 ? own : ((lane < 27 && w) ? w - 1u : kInvalidSlot);
-  }
   uint32_t fl = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -321,6 +329,10 @@ __device__ __forceinline__ void filter_exact(const VolumeDev& v, const int4 id, 
     fl |= c0 | c1 | ((lane & 3) ? 0u : c0 << 4) | ((lane & 28) ? 0u : (c0 | c1) << 8) | ((j || lane >= 32) ? 0u : (c0 | c1) << 12);
   }
   fl = wave_or(fl);
+  if (!HAVE_ROW) {
+    roww = nbr_row_checked(v, own, id, lane, roww, create_seq);
+    nslot = lane == 13 ? own : ((lane < 27 && roww) ? roww - 1u : kInvalidSlot);
+  }
   if (use_summ && lane == 0) v.summ[own] = fl;  // the chunk's summary is exact again
   if (lane == 0) atomicAdd(&cnt[(kMeshShards + shard) * 16], 1u);  // statistic (tf_texture_stats::n_exact): chunks whose voxels the filter read
   bool empty = !(fl & 1u);
@@ -392,6 +404,12 @@ __device__ __forceinline__ int near_k(int lane) { return (lane % 3 - 1) + 2 * ((
 // blocks, runs behind the launch.  OFF by default (TF_PATCH_IN_FILTER=1): the filter alone is a 15-us latency chain and so
 // are the patch chains, but next to each other they take 26 us -- more than the 9 us the stage costs K-A when it rides on
 // k_frame (profiles/r4/README.md).
+#ifndef TF_FILTER_BATCH_WAVES
+#define TF_FILTER_BATCH_WAVES 6  // ... of the workgroup-batch form
+#endif
+#ifndef TF_FILTER_WAVES
+#define TF_FILTER_WAVES 7  // waves per SIMD of the plain wave-form filter
+#endif
 #ifndef TF_FILTER_PATCH_WAVES
 #define TF_FILTER_PATCH_WAVES 6  // waves per SIMD of the filter instances that carry the patch stage (80 VGPRs)
 #endif
@@ -411,8 +429,10 @@ struct FilterPatch {
   Cam cam;
   KfDev kf;
 };
-template <bool WAVE_FORM, bool PATCH>
-__global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7 : 6)) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
+// TL: the tuning instance (TF_MESH_DBG=10, tools/stamps.py filter): lane 0 of a wave stamps s_memrealtime into the debug
+// table at the phase boundaries of its FIRST entry, row = wave; a phase that ends in loads is closed with a wait
+template <bool WAVE_FORM, bool PATCH, bool TL = false>
+__global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? TF_FILTER_WAVES : TF_FILTER_BATCH_WAVES)) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,
@@ -432,6 +452,16 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
   const uint32_t create_seq = v.vctl->create_seq;  // (no launch that inserts keys runs next to a filter over the same chunks)
+  const uint32_t tl_wave = (bid * 256 + threadIdx.x) >> 6;
+  bool tl_first = true;
+  auto stamp = [&](int k, bool wait) {
+    if (TL && tl_first && tl_wave < (uint32_t)kPhaseWaves) {
+      if (wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) v.phase_buf[tl_wave * 16 + k] = __builtin_amdgcn_s_memrealtime();
+    }
+  };
+  if (TL && lane == 0 && tl_wave < (uint32_t)kPhaseWaves) { for (int k = 1; k < 8; ++k) v.phase_buf[tl_wave * 16 + k] = 0; }
+  stamp(0, false);
   uint32_t n_flat = *dcount;
   if (n_flat > max_entries) n_flat = max_entries;
   // shard lists: per-lane inclusive scan of the 32 counters
@@ -465,6 +495,7 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
       uint32_t w = lane < kNbrWords ? v.nbr[(size_t)own * kNbrWords + lane] : 0u;
       uint32_t alive = 1u;
       if (have_own && id.w > 0) alive = v.hent[(uint32_t)id.w - 1u].alive & 1u;
+      stamp(2, true);
       if (!alive) return;
       w = nbr_row_checked(v, own, id, lane, w, create_seq);
       const uint32_t nslot = lane == 13 ? own : ((lane < 27 && w) ? w - 1u : kInvalidSlot);
@@ -476,13 +507,16 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
         const uint32_t sel = lane == 13 ? 0u : ((lane % 3) == 2 ? 4u : (((lane / 3) % 3) == 2 ? 8u : 12u));
         const uint32_t u = is_near ? (sm >> sel) & 15u : 0u;
         const bool so = (__shfl((int)sm, 13) & 1) != 0;
+        stamp(3, true);
         const bool maybe = so && __ballot(u & 2u) != 0ull && __ballot(u & 4u) != 0ull && __ballot(u & 8u) != 0ull;
         if (!maybe) {
           if (lane == 0) { if (fp.defer) filter_defer_reset(v, cnt, cap_sh, own, id); else filter_reset_record(v, own, id, epoch, ppar); }
+          stamp(4, true);
           return;
         }
       }
       filter_exact<true>(v, id, nslot, own, lane, epoch, surv, cnt, cap_sh, ppar, use_summ, fp.defer != 0, create_seq);
+      stamp(5, true);
     };
     // the shard lists K-A filled: wave w walks shard w % 32 from position w / 32 on.  Its first entry is requested TOGETHER
     // with the shard's counter (the entry's address does not depend on the count; a position beyond the count holds an older
@@ -497,8 +531,11 @@ __global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? 7
       uint32_t own_listed = v.wl_slot[at];
       uint32_t cs = v.wl_cnt[((shards_par & 1) * kMeshShards + sd) * 16];
       if (cs > wl_rows) cs = wl_rows;
+      stamp(1, true);
       while (i < cs) {
         process(id, own_listed, true);
+        stamp(6, false);
+        tl_first = false;
         i += stride;
         if (i < cs) { at = wl_base + (size_t)sd * wl_rows + i; id = v.wl_ids[at]; own_listed = v.wl_slot[at]; }
       }
@@ -583,7 +620,9 @@ __device__ __forceinline__ void mesh_stamp(const VolumeDev& v, uint32_t r, int k
 // (Round 4 measured no gain at 6: its kernel needed 88 VGPRs, and the 80 the compiler was forced to cost more than they gave.)
 #define TF_MESH_WAVES 6
 #endif
-template <int NT>  // threads per chunk
+// DBG: the tuning instance (TF_MESH_DBG: triage cut-offs 1..4 -- results are WRONG with one --, phase stamps 9); the product
+// instance carries none of their branches
+template <int NT, bool DBG = false>  // NT: threads per chunk
 __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const uint32_t* __restrict__ surv, uint32_t* __restrict__ cnt,
                                                  uint32_t* __restrict__ cnt_next, uint32_t cap_sh,
                                                  uint32_t epoch, float res, uint32_t simplified, uint32_t dbg,
@@ -643,7 +682,7 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
     v.patch_cnt[((rearm & 1) * kMeshShards + t) * 16] = 0u;
     v.wl_cnt[((rearm & 1) * kMeshShards + t) * 16] = 0u;  // ... and the shard lists K-A of the next frame appends its dirty set to
   }
-  if (dbg == 9) mesh_stamp(v, blockIdx.x, 0);
+  if (DBG && dbg == 9) mesh_stamp(v, blockIdx.x, 0);
   for (uint32_t r = blockIdx.x; r < n_rows; r += gridDim.x) {
     uint32_t shard, own;
     int4 id;
@@ -683,11 +722,11 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
     unsigned long long htab[(kHalo + NT - 1) / NT];
 #pragma unroll
     for (int j = 0; j < (kHalo + NT - 1) / NT; ++j) htab[j] = (j * NT + t < kHalo) ? d_mesh_tabs.halo[j * NT + t] : ~0ull;
-    if (dbg == 9) mesh_stamp(v, r, 1);
+    if (DBG && dbg == 9) mesh_stamp(v, r, 1);
     if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; sh.ncell = 0; }
     // the record's previous state travels with the first batch of loads, so that the tail of the chunk is stores only
     if (t == NT - 64) { sh.rstate = rec->state; sh.rblock = rec->block; sh.rtexloc = rec->texloc; }
-    if (dbg == 1) continue;  // triage: filter only
+    if (DBG && dbg == 1) continue;  // triage: filter only
     // ---- stage the 11^3 voxels of the neighbourhood (own ones from registers)
 #pragma unroll
     for (int j = 0; j < 512 / NT; ++j) {
@@ -718,7 +757,7 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
       }
     }
     __syncthreads();
-    if (dbg == 9) mesh_stamp(v, r, 3);
+    if (DBG && dbg == 9) mesh_stamp(v, r, 3);
     // ---- per corner: which of its six neighbours are below 1, is its gradient short enough.  A cell asks
     // for the three neighbours OUTSIDE its cube (extractGradientFromCubic fetches those through
     // GetNeighborSDF, :320-447), so the answer per (cell, corner) is three of these bits.
@@ -737,8 +776,8 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
     for (int i = t; i < (kEdgeSlots + 7) / 8; i += NT) sh.ownq[i] = 0u;
     __syncthreads();
 
-    if (dbg == 2) continue;  // triage: + staging and corner flags
-    if (dbg == 9) mesh_stamp(v, r, 4);
+    if (DBG && dbg == 2) continue;  // triage: + staging and corner flags
+    if (DBG && dbg == 9) mesh_stamp(v, r, 4);
     // ---- pass 1: per cell, the MC case, the edges its emitted triangles use, how many triangles.
     // 1a: every cell's case from its 8 corners; the few cells the surface passes through (64 of 512 for a plane) go
     // to a list, so that 1b -- edge validity, triangles, edge ownership: the long part -- runs on dense lanes instead
@@ -812,8 +851,8 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
     }
     __syncthreads();
 
-    if (dbg == 3) continue;  // triage: + cell pass
-    if (dbg == 9) mesh_stamp(v, r, 5);
+    if (DBG && dbg == 3) continue;  // triage: + cell pass
+    if (DBG && dbg == 9) mesh_stamp(v, r, 5);
     // ---- ranks: used edge slots in ascending order (the reference's vertex order, :886-897) and the
     // cells' triangle offsets in cell order (the order of mesh->indices)
     {
@@ -912,8 +951,8 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
     }
     const uint16_t* const gvlist = (ovf & kBlkLarge) ? v.ovf_vlist + (size_t)((ovf & ~kBlkLarge) - 1u) * kOvfCV : nullptr;
 
-    if (dbg == 4) continue;  // triage: + ranking
-    if (dbg == 9) mesh_stamp(v, r, 6);
+    if (DBG && dbg == 4) continue;  // triage: + ranking
+    if (DBG && dbg == 9) mesh_stamp(v, r, 6);
     // a mesh enters allMeshes when it has vertices and stays there afterwards (:260-262).  The patch-list entry does
     // not depend on the vertices: the last wave (it rarely has vertex work) appends it now, so that the round trips
     // of the two counters overlap the vertex pass instead of ending the chunk.
@@ -969,7 +1008,7 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
       }
     }
     if (adj) atomicOr(&sh.adj, adj);
-    if (dbg == 9) mesh_stamp(v, r, 7);
+    if (DBG && dbg == 9) mesh_stamp(v, r, 7);
     // ---- triangles, in cell order; (s2, s1, s0) per triangle (:914-916)
     // (taken from the END of the workgroup: the vertices above keep the first waves busy -- a mesh has 78 of them --
     // while the last ones would otherwise have nothing to do)
@@ -1004,7 +1043,7 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
       rec->state = inmap | (sh.adj << kMsAdjShift) | (inmap ? simplified : 0u);  // (simplified: every mesh of allMeshes, Chisel.cpp:116-126)
     }
     __syncthreads();
-    if (dbg == 9) mesh_stamp(v, r, 8);
+    if (DBG && dbg == 9) mesh_stamp(v, r, 8);
   }
 }
 
@@ -1042,8 +1081,12 @@ static void launch_mesher(const VolumeDev& v, int cnt_par, uint32_t max_entries,
   uint32_t grid = ((max_entries + kMeshShards - 1) / kMeshShards + 1) * kMeshShards;
   static const uint32_t gmax = (uint32_t)device_cus() * (uint32_t)(TF_MESH_WAVES * 2);
   if (grid > gmax) grid = gmax;
-  hipLaunchKernelGGL((k_mesh<128>), dim3(grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
-                     fused ? kMsSimplified : 0u, dbg, rearm_set);
+  if (dbg)
+    hipLaunchKernelGGL((k_mesh<128, true>), dim3(grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
+                       fused ? kMsSimplified : 0u, dbg, rearm_set);
+  else
+    hipLaunchKernelGGL((k_mesh<128>), dim3(grid), dim3(128), v.mesh_cv * sizeof(uint16_t), s, v, surv, cnt, cnt_next, cap_sh, epoch, res,
+                       fused ? kMsSimplified : 0u, 0u, rearm_set);
 }
 
 bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint32_t* dcount, uint32_t max_entries,
@@ -1076,7 +1119,11 @@ bool launch_mesh(const VolumeDev& v, int cnt_par, const int4* dlist, const uint3
 #define TF_LAUNCH_FILTER(W, P)                                                                                       \
   hipLaunchKernelGGL((k_mesh_filter<W, P>), dim3(fgrid + fp.n_patch + fp.n_store), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries, \
                      epoch, v.mesh_nbr, cnt, cap_sh, ppar, use_summ, len_hint, shards_par, fp)
-  if (wave_form) { if (fp.n_patch) TF_LAUNCH_FILTER(true, true); else TF_LAUNCH_FILTER(true, false); }
+  static const bool tl = getenv("TF_MESH_DBG") && atoi(getenv("TF_MESH_DBG")) == 10;
+  if (wave_form && tl && !fp.n_patch)
+    hipLaunchKernelGGL((k_mesh_filter<true, false, true>), dim3(fgrid + fp.n_store), dim3(256), 0, s, v, dlist, dslot, dcount, max_entries,
+                       epoch, v.mesh_nbr, cnt, cap_sh, ppar, use_summ, len_hint, shards_par, fp);
+  else if (wave_form) { if (fp.n_patch) TF_LAUNCH_FILTER(true, true); else TF_LAUNCH_FILTER(true, false); }
   else { if (fp.n_patch) TF_LAUNCH_FILTER(false, true); else TF_LAUNCH_FILTER(false, false); }
 #undef TF_LAUNCH_FILTER
   launch_mesher(v, cnt_par, max_entries, epoch, res, fused, rearm_set, s);
@@ -1329,8 +1376,8 @@ __global__ __launch_bounds__(256) void k_check_summaries(VolumeDev v, unsigned l
 
 // diagnostic (tf_check_neighbours): every row of the neighbour table against the hash.  out[0] rows of chunks with a pool
 // slot, [1] non-zero words, [2] non-zero words that do not name the pool slot the hash holds for that id (must be 0),
-// [3] rows whose last full check is newer than every key insertion, [4] zero words of such rows whose id the hash does hold
-// (must be 0), [5] the same for the near check's eight words (must be 0)
+// [3] rows whose last check is newer than every key insertion, [4] zero words of such rows whose id the hash does hold
+// (must be 0), [5] unused
 __global__ __launch_bounds__(256) void k_check_neighbours(VolumeDev v, unsigned long long* out) {
   const int lane = threadIdx.x & 63;
   const uint32_t nwaves = gridDim.x * 4;
@@ -1340,21 +1387,18 @@ __global__ __launch_bounds__(256) void k_check_neighbours(VolumeDev v, unsigned 
     if (h.key == kEmptyKey || h.slot == kInvalidSlot) continue;
     const int4 id = unpack_id(h.key);
     const uint32_t w = lane < kNbrWords ? v.nbr[(size_t)h.slot * kNbrWords + lane] : 0u;
-    const bool full = (uint32_t)__shfl((int)w, kNbrFull) > create_seq, near8 = (uint32_t)__shfl((int)w, kNbrNear) > create_seq;
+    const bool full = (uint32_t)__shfl((int)w, kNbrStamp) > create_seq;
     uint32_t truth = 0;
     const bool nb = lane < 27 && lane != 13;
     if (nb) truth = nbr_probe(v, pack_id(id.x + lane % 3 - 1, id.y + (lane / 3) % 3 - 1, id.z + lane / 9 - 1));
-    const bool is_near = lane < 27 && (lane % 3) >= 1 && ((lane / 3) % 3) >= 1 && lane / 9 >= 1;
     const unsigned long long nz = __ballot(nb && w != 0u), bad = __ballot(nb && w != 0u && w != truth);
     const unsigned long long miss = __ballot(nb && full && w == 0u && truth != 0u);
-    const unsigned long long miss8 = __ballot(nb && is_near && near8 && w == 0u && truth != 0u);
     if (lane == 0) {
       atomicAdd(&out[0], 1ull);
       if (nz) atomicAdd(&out[1], (unsigned long long)__popcll(nz));
       if (bad) atomicAdd(&out[2], (unsigned long long)__popcll(bad));
       if (full) atomicAdd(&out[3], 1ull);
       if (miss) atomicAdd(&out[4], (unsigned long long)__popcll(miss));
-      if (miss8) atomicAdd(&out[5], (unsigned long long)__popcll(miss8));
     }
   }
 }

@@ -97,7 +97,9 @@ __host__ __device__ inline bool slot_texloc(int atlas_w, int atlas_h, int pw, in
 }
 __device__ __forceinline__ uint32_t mesh_shard_rows_dev(uint32_t max_chunks) { return max_chunks / kMeshShards + 258u; }  // = mesh_shard_rows()
 __device__ __forceinline__ bool slot_texloc(const VolumeDev& v, unsigned long long n, unsigned long long* texloc) {
-  return slot_texloc(v.atlas_w, v.atlas_h, v.patch_w, v.patch_h, n, texloc);
+  int aw = v.atlas_w, pw = v.patch_w;
+  asm volatile("" : "+s"(aw), "+s"(pw));  // (divisors kept opaque: see the blit)
+  return slot_texloc(aw, v.atlas_h, pw, v.patch_h, n, texloc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -122,6 +124,10 @@ __device__ __forceinline__ int cv_round_f(float x) { return (int)rintf(x); }
 // 1 = last row (c1, c2 along x), 2 = last column (c1, c2 along y), 3 = corner / beyond (c1 only).
 struct Taps {
   int i1, i2, i3;  // linear pixel indices, -1 = outside the image (reads 0, see rgb_at)
+};
+// ... and the weights, recomputed from the position when the pixels have arrived (the same expressions give the same values;
+// holding kind + four weights per vertex block across the gathers costs the fused kernel ten registers it does not have)
+struct TapW {
   int kind;
   float ax, bx, ay, by;
 };
@@ -129,17 +135,26 @@ __device__ __forceinline__ int pix_index(int W, int H, int y, int x) {
   const long i = (long)y * W + x;
   return (i < 0 || i >= (long)W * H) ? -1 : (int)i;
 }
+__device__ __forceinline__ int tap_kind(int W, int H, int x, int y) {
+  return (x < W - 1 && y < H - 1) ? 0 : ((x < W - 1 && y == H - 1) ? 1 : ((x == W - 1 && y < H - 1) ? 2 : 3));
+}
 __device__ __forceinline__ Taps make_taps(int W, int H, float lx, float ly) {
   Taps t;
   const int x = (int)floorf(lx), y = (int)floorf(ly);
-  t.ax = (float)(x + 1) - lx; t.bx = lx - (float)x;
-  t.ay = (float)(y + 1) - ly; t.by = ly - (float)y;
+  const int kind = tap_kind(W, H, x, y);
   t.i1 = pix_index(W, H, y, x);
   t.i2 = t.i3 = -1;
-  if (x < W - 1 && y < H - 1) { t.kind = 0; t.i2 = pix_index(W, H, y, x + 1); t.i3 = pix_index(W, H, y + 1, x); }
-  else if (x < W - 1 && y == H - 1) { t.kind = 1; t.i2 = pix_index(W, H, y, x + 1); }
-  else if (x == W - 1 && y < H - 1) { t.kind = 2; t.i2 = pix_index(W, H, y + 1, x); }
-  else t.kind = 3;
+  if (kind == 0) { t.i2 = pix_index(W, H, y, x + 1); t.i3 = pix_index(W, H, y + 1, x); }
+  else if (kind == 1) t.i2 = pix_index(W, H, y, x + 1);
+  else if (kind == 2) t.i2 = pix_index(W, H, y + 1, x);
+  return t;
+}
+__device__ __forceinline__ TapW tap_weights(int W, int H, float lx, float ly) {
+  TapW t;
+  const int x = (int)floorf(lx), y = (int)floorf(ly);
+  t.ax = (float)(x + 1) - lx; t.bx = lx - (float)x;
+  t.ay = (float)(y + 1) - ly; t.by = ly - (float)y;
+  t.kind = tap_kind(W, H, x, y);
   return t;
 }
 // one pixel as r | g << 8 | b << 16 (0 outside the image)
@@ -149,7 +164,7 @@ __device__ __forceinline__ uint32_t load_px(const uint8_t* rgb, int stride, int 
   const uint8_t* p = rgb + 3 * (size_t)i;
   return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16);
 }
-__device__ __forceinline__ float blend(const Taps& t, float c1, float c2, float c3) {
+__device__ __forceinline__ float blend(const TapW& t, float c1, float c2, float c3) {
   if (t.kind == 0) {
     float r = (c1 * t.ax) * t.ay;
     r = r + (c2 * t.bx) * t.ay;
@@ -171,7 +186,9 @@ __device__ __forceinline__ float blend(const Taps& t, float c1, float c2, float 
 constexpr int kVB = TF_PATCH_KVB;  // 64-vertex blocks of a patch kept in registers: one sweep for meshes up to 128 vertices
 
 // bid / nb: this workgroup's index among the nb 256-thread workgroups that run the stage
-template <bool PROJECT, bool BLIT, bool FUSED>
+// TL: the tuning instance (TF_PATCH_DBG, tools/stamps.py patch): phase stamps (3) and the triage cut-offs (1, 2) of
+// KfDev::pad[0]; the product instances carry none of it
+template <bool PROJECT, bool BLIT, bool FUSED, bool TL = false>
 __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, const int par, const KfDev& kf_fused,
                                            const uint32_t bid, const uint32_t nb) {
   const int lane = threadIdx.x & 63;
@@ -180,7 +197,7 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
   AtlasCtl::Set* S = &v.actl->set[par];
   // tuning aid (TF_PATCH_DBG=3, tools/stamps.py): lane 0 of a wave stamps the phases of its patch into the debug table,
   // row = wave; a phase that ends in loads is closed with a wait so that the stamp means "data arrived"
-  const bool tl = FUSED && kf_fused.pad[0] == 3 && wave < (uint32_t)kPhaseWaves;
+  const bool tl = TL && FUSED && kf_fused.pad[0] == 3 && wave < (uint32_t)kPhaseWaves;
   auto stampw = [&](int k) {
     if (tl) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -193,6 +210,12 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
   const uint32_t shard = wave & (kMeshShards - 1u);
   const uint32_t shard_rows = mesh_shard_rows_dev(v.max_chunks);
   const int4* plist = v.patch_list + ((size_t)(par & 1) * kMeshShards + shard) * shard_rows;
+  // the wave's first list entry is requested TOGETHER with the shard's counter and the frame's slot counters (its address does
+  // not depend on the count; a position beyond the count holds an older frame's entry, dropped when the count arrives): one
+  // dependent round trip less per patch -- most waves have exactly one
+  const uint32_t pe0 = FUSED ? wave / kMeshShards : wave;
+  int4 e_first = make_int4(0, 0, 0, 0);
+  if (FUSED) e_first = plist[pe0 < shard_rows ? pe0 : 0u];
   uint32_t n = S->n_work;
   if (FUSED) {
     n = v.patch_cnt[((par & 1) * kMeshShards + shard) * 16];
@@ -210,7 +233,6 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     room = total > slots_base ? total - slots_base : 0ull;
   }
   const bool overflow = FUSED && (unsigned long long)n_cand > room;  // some AddPatch of this frame throws
-  const uint32_t create_seq = FUSED ? v.vctl->create_seq : 0u;  // (neighbour table: see the flag exchange below)
   const int W = cam.W, H = cam.H;
   const float Wf = (float)W, Hf = (float)H;
   if (FUSED && bid == 0 && threadIdx.x == 0) {
@@ -220,13 +242,13 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     v.actl->n_slots = (uint32_t)(slots_base + got);
     if (overflow) atomicOr(&v.vctl->status, kStAtlasFull);
   }
-  for (uint32_t pe = FUSED ? wave / kMeshShards : wave; pe < n; pe += FUSED ? nwaves / kMeshShards : nwaves) {
+  for (uint32_t pe = pe0; pe < n; pe += FUSED ? nwaves / kMeshShards : nwaves) {
     // fused flow: {packed id, pool slot, mesh block} straight from the list (one dependent load less per patch: the vertex
     // loads below need not wait for the record); the call-by-call flow reads the block from the record
     int4 id;
     uint32_t slot, lblk = kBlkNone;
     if (FUSED) {
-      const int4 e = plist[pe];
+      const int4 e = pe == pe0 ? e_first : plist[pe];
       id = unpack_id(((unsigned long long)(uint32_t)e.y << 32) | (uint32_t)e.x);
       slot = (uint32_t)e.z;
       lblk = (uint32_t)e.w;
@@ -239,47 +261,44 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     MeshRec R = *rec;  // one 64-B record: counts, flags, slot position, box
     const uint32_t mst = FUSED ? lblk : R.block;  // (the block of the mesh store that holds the mesh)
     stampw(1);
+    // Chisel::CompressMeshes' neighbour exchange (Chisel.cpp:127-145) for this chunk: flag k of the mesh and flag k ^ 1 of its
+    // k-th face neighbour's mesh become the OR of the two.  Every mesh of the frame is complete (the mesher ran before this
+    // kernel); the pairwise updates are idempotent, so concurrent waves cannot disagree.
+    // The neighbours' pool slots come from the chunk's row of the neighbour table (lanes 0..5: the face words, requested with
+    // the record above) -- a mesh lives in the record of its chunk's pool slot, so nothing else of the neighbour is needed.
+    // The row was checked in full by the filter launch ahead of the mesher that listed this chunk; a chunk inserted since
+    // then has no mesh yet (only a mesher makes one, and this stage runs ahead of the next mesher).  The neighbour's state is
+    // requested here, unconditionally (a lane without a neighbour reads its own record), and looked at behind the vertex
+    // loads of the first sweep: the exchange adds no round trip to the patch's chain.
+    const int xk = lane < 6 ? lane : 0, xm = xk ^ 1;
+    uint32_t x_nw = 0u, x_bs = 0u;
     if (FUSED) {
-      // Chisel::CompressMeshes' neighbour exchange (Chisel.cpp:127-145) for this chunk: flag k of the mesh and flag
-      // k ^ 1 of its k-th face neighbour's mesh become the OR of the two.  Every mesh of the frame is complete (the
-      // mesher ran before this kernel); the pairwise updates are idempotent, so concurrent waves cannot disagree.
-      // The neighbours' pool slots come from the chunk's row of the neighbour table (lanes 0..5: the face words, lane 6:
-      // the stamp of the row's last full check; requested with the record above) -- a mesh lives in the record of its
-      // chunk's pool slot, so nothing else of the neighbour is needed.  A "none" word of a row that has not been checked
-      // in full since the newest key insertion (the filter's batch form checks the +x / +y / +z corner only) falls back
-      // to the hash.
-      const int k = lane, m = k ^ 1;
-      const int word = lane < 6 ? 13 + ((k & 1) ? 1 : -1) * (k < 2 ? 1 : (k < 4 ? 3 : 9)) : kNbrFull;
-      uint32_t nw = lane < 7 ? v.nbr[(size_t)slot * kNbrWords + word] : 0u;
-      const bool checked = (uint32_t)__shfl((int)nw, 6) > create_seq;
-      if (lane < 6 && nw == 0u && !checked) {
-        int4 q = id;
-        if (k == 0) q.x -= 1; else if (k == 1) q.x += 1; else if (k == 2) q.y -= 1;
-        else if (k == 3) q.y += 1; else if (k == 4) q.z -= 1; else q.z += 1;
-        nw = nbr_probe(v, pack_id(q.x, q.y, q.z));
-      }
-      if (lane < 6 && nw != 0u) {
-        MeshRec* b = &v.mesh_rec[nw - 1u];
-        const uint32_t bs = b->state;
-        if ((bs & kMsInMap) && (bs & kMsSimplified)) {
-          const uint32_t abit = 1u << (kMsAdjShift + k), bbit = 1u << (kMsAdjShift + m);
-          const bool fa = (R.state & abit) != 0, fb = (bs & bbit) != 0;
-          if (fa && !fb) atomicOr(&b->state, bbit);
-          if (!fa && fb) atomicOr(&rec->state, abit);
-        }
-      }
+      const int word = 13 + ((xk & 1) ? 1 : -1) * (xk < 2 ? 1 : (xk < 4 ? 3 : 9));
+      x_nw = lane < 6 ? v.nbr[(size_t)slot * kNbrWords + word] : 0u;
+      x_bs = v.mesh_rec[x_nw ? x_nw - 1u : slot].state;
     }
+    auto exchange_flags = [&]() {
+      if (FUSED && x_nw != 0u && (x_bs & kMsInMap) && (x_bs & kMsSimplified)) {
+        const uint32_t abit = 1u << (kMsAdjShift + xk), bbit = 1u << (kMsAdjShift + xm);
+        const bool fa = (R.state & abit) != 0, fb = (x_bs & bbit) != 0;
+        if (fa && !fb) atomicOr(&v.mesh_rec[x_nw - 1u].state, bbit);
+        if (!fa && fb) atomicOr(&rec->state, abit);
+      }
+    };
+    if (!PROJECT) exchange_flags();
     if (FUSED) {
       const bool cand = R.texloc == kNoTexloc;
       if (cand || overflow) {
         // c = candidates with a smaller key = this patch's rank if it is one itself
         const unsigned long long key = pack_id(id.x, id.y, id.z);
         uint32_t c = 0;
+        int l3 = lane;
+        asm volatile("" : "+v"(l3));  // (the lane's address into the candidate list would be hoisted out of the patch loop -- into private memory)
         for (uint32_t i0 = 0; i0 < n_cand; i0 += 256) {  // (four independent loads at a time: one at a time is a chain of round trips)
           unsigned long long ck[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const uint32_t i = i0 + 64u * q + (uint32_t)lane;
+            const uint32_t i = i0 + 64u * q + (uint32_t)l3;
             ck[q] = i < n_cand ? v.cand[i] : ~0ull;
           }
 #pragma unroll
@@ -288,10 +307,14 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
         // the first failing AddPatch is the candidate of rank `room`; it and every entry behind it are skipped
-        if ((unsigned long long)c >= room + (cand ? 0ull : 1ull) && overflow) continue;
+        if ((unsigned long long)c >= room + (cand ? 0ull : 1ull) && overflow) { exchange_flags(); continue; }  // (CompressMeshes ran for it all the same)
         if (cand) {
           unsigned long long tl;
-          if (!slot_texloc(v, slots_base + c, &tl)) continue;  // (cannot happen: c < room)
+          // (the frame's first slot is read again here, by the few patches that are new: held across the patch loop it is two
+          // registers the fused kernel does not have)
+          const AtlasCtl::Set* S2 = S;
+          asm volatile("" : "+v"(S2));
+          if (!slot_texloc(v, S2->slots_base + c, &tl)) { exchange_flags(); continue; }  // (cannot happen: c < room)
           R.texloc = tl;
           if (lane == 0) rec->texloc = tl;
         }
@@ -305,7 +328,7 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     const KfDev kf = FUSED ? kf_fused : v.kf_tab[kf_slot];
     int bx = 0, by = 0, cols = 0, rows = 0;
     bool have_image = false;
-    if (FUSED && kf_fused.pad[0] == 2) continue;  // triage: list walk + record read only
+    if (TL && FUSED && kf_fused.pad[0] == 2) { exchange_flags(); continue; }  // triage: list walk + record read only
     if (PROJECT) {
       float minX = Wf, maxX = 0.0f, minY = Hf, maxY = 0.0f;  // Patch.cpp:46-49
       uint32_t dcmp = 0, ccmp = 0, ncau = 0;
@@ -328,6 +351,7 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
           m0[j] = mesh_plane(v, mst, kMpCol)[ii]; m1[j] = mesh_plane(v, mst, kMpCol + 1)[ii];
           m2[j] = mesh_plane(v, mst, kMpCol + 2)[ii];
         }
+        if (base == 0) exchange_flags();  // (its loads went out with the record; the vertex loads are in flight now)
         stampw(3);
         // ---- projection (:52-66), then every image gather of the sweep in flight at once
         float cX[kVB], cY[kVB], dist[kVB];
@@ -378,14 +402,15 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
             minX = minX < cX[j] ? minX : cX[j]; maxX = maxX > cX[j] ? maxX : cX[j];
             minY = minY < cY[j] ? minY : cY[j]; maxY = maxY > cY[j] ? maxY : cY[j];
             float tc[3];
+            const TapW tw = tap_weights(W, H, cX[j], cY[j]);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
               const float c1 = (float)((q1[j] >> (8 * k)) & 0xFFu), c2 = (float)((q2[j] >> (8 * k)) & 0xFFu),
                           c3 = (float)((q3[j] >> (8 * k)) & 0xFFu);
-              tc[k] = blend(tp[j], c1, c2, c3) / 255.0f;
+              tc[k] = blend(tw, c1, c2, c3) / 255.0f;
               mesh_plane(v, mst, kMpTcol + k)[i] = tc[k];
             }
-            const float dpt = blend(tp[j], d1[j], d2[j], d3[j]);
+            const float dpt = blend(tw, d1[j], d2[j], d3[j]);
             const float e0 = tc[0] - m0[j], e1 = tc[1] - m1[j], e2 = tc[2] - m2[j];
             const float s12 = e1 * e1 + e2 * e2;
             const float nrm = sqrtf(e0 * e0 + s12);
@@ -429,7 +454,9 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
           if (i < nv) { tu[i] = have_box ? keepX[j] - fbx : keepX[j]; tv[i] = have_box ? keepY[j] - fby : keepY[j]; }
         }
       } else if (have_box) {
-        for (uint32_t i = lane; i < nv; i += 64) {  // a lane re-reads what it wrote
+        int l2 = lane;
+        asm volatile("" : "+v"(l2));  // (or the lane's byte offset, hoisted out of the patch loop, is kept in private memory)
+        for (uint32_t i = (uint32_t)l2; i < nv; i += 64) {  // a lane re-reads what it wrote
           tu[i] = tu[i] - fbx;
           tv[i] = tv[i] - fby;
         }
@@ -447,17 +474,22 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     }
     stampw(5);
     if (!BLIT) continue;
-    if (FUSED && kf_fused.pad[0] == 1) continue;  // triage: no blit
+    if (TL && FUSED && kf_fused.pad[0] == 1) continue;  // triage: no blit
     // Patch::complete (Patch.cpp:191-196): vertices, simplified mesh, image, texcoords, frame id
     if (!(nv > 0 && (R.state & kMsSimplified) && have_image && kf.kf_id >= 0)) continue;
     if (cols <= 0 || rows <= 0) continue;  // empty ROI: nothing to copy
-    const int PW = v.patch_w, PH = v.patch_h;
+    // (opaque to the optimiser: float / double / reciprocal forms of the slot size hoisted out of the patch loop cost the
+    // fused kernel 32 bytes of private memory per lane and a reload -- a dependent round trip -- at each of their uses)
+    int PW = v.patch_w, PH = v.patch_h;
+    asm volatile("" : "+s"(PW), "+s"(PH));
     float r0 = 1.0f, r1 = 1.0f;
     if (cols > PW) r0 = (float)PW / (float)cols;  // Atlas.cpp:77-80
     if (rows > PH) r1 = (float)PH / (float)rows;
     if (lane == 0) { rec->ratio[0] = r0; rec->ratio[1] = r1; }
     const unsigned long long tl = R.texloc;
-    const unsigned long long ox = tl % (unsigned long long)v.atlas_w, oy = tl / (unsigned long long)v.atlas_w;
+    int aw_ = v.atlas_w;
+    asm volatile("" : "+s"(aw_));  // (the reciprocal of a loop-invariant divisor is hoisted out of the patch loop -- into private memory)
+    const unsigned long long ox = tl % (unsigned long long)aw_, oy = tl / (unsigned long long)aw_;
     const size_t astep = (size_t)v.atlas_w * 3;
     const int st = kf.stride;
     if (r0 < 1 || r1 < 1) {  // cv::resize(image, texroi, texroi.size()) into the FULL slot

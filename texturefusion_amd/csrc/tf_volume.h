@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -249,12 +251,37 @@ struct tf_volume {
   // the per-frame exchange overlapped with the interior meshes (texture_stage): second stream, fork / join events
   hipStream_t xstream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // tf_atlas_snapshot_rows: a second thread (the reference's GUI thread reads Atlas::texture_buffer while the map thread
+  // writes it, GCFusion/MobileFusion.h:404-421) copies atlas rows out consistently.  atlas_mu orders that thread's
+  // in-stream snapshot against the map thread's atlas-writing launches; atlas_seq counts those launches, atlas_frame is
+  // the label of the newest one; snap_mu serialises readers (one snapshot buffer, one read stream).
+  std::mutex atlas_mu, snap_mu;
+  std::atomic<uint64_t> atlas_seq{0};
+  std::atomic<int32_t> atlas_frame{-1};
+  hipStream_t read_stream = nullptr;
+  hipEvent_t read_ev = nullptr;
+  uint8_t* d_snap = nullptr;
+  size_t d_snap_bytes = 0;
   bool xchg_overlap = true;        // tf_comm_exchange_overlap
   uint64_t xchg_overlapped = 0;    // exchanges that ran next to an interior mesh pass (tf_comm_stats_ex)
   uint32_t xchg_seq = 0;      // publish sequence numbers handed out (monotonic over the handle's life: a stale word never matches)
 };
 
 namespace tf {
+// Around the enqueue of a launch that writes atlas texels: nothing of tf_atlas_snapshot_rows can land between the launch
+// and the bump of the write sequence (label: Patch::frameid of what it writes, INT32_MIN = keep the last one).
+struct AtlasWriteScope {
+  tf_volume* v;
+  int32_t label;
+  AtlasWriteScope(tf_volume* vv, int32_t l) : v(vv), label(l) { v->atlas_mu.lock(); }
+  ~AtlasWriteScope() {
+    if (label != INT32_MIN) v->atlas_frame.store(label, std::memory_order_relaxed);
+    v->atlas_seq.fetch_add(1, std::memory_order_release);
+    v->atlas_mu.unlock();
+  }
+  AtlasWriteScope(const AtlasWriteScope&) = delete;
+  AtlasWriteScope& operator=(const AtlasWriteScope&) = delete;
+};
 // stream synchronisation + control blocks; VolCtl::n_tmp as read (may be NULL); sticky status -> error code
 int sync_status(tf_volume* v, uint32_t* n_tmp);
 int ensure_tmp(tf_volume* v, size_t bytes);
@@ -268,7 +295,7 @@ int texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, uint3
                   const KfStoreArgs* store = nullptr);      // the keyframe unit: the list's validChunks store rides on the filter launch
 int texture_stage_finish(tf_volume* v, const FrameImages& img, uint32_t frame_epoch, const float* pose_inv16, int32_t frame_id, int par);
 // the four band counts of the frame whose selection wrote `ctl` (tag = its epoch + 1): waits for the device to publish them
-int xchg_band_counts(tf_volume* v, const FrameCtl* ctl, uint32_t tag, uint32_t cnt[4]);
+int xchg_band_counts(tf_volume* v, const FrameCtl* ctl, uint32_t tag, uint32_t cnt[4], hipStream_t s = nullptr);
 uint32_t nbr_next_seq(tf_volume* v);  // neighbour table: the seq of the filter launch about to go out (tf_capi.cpp)
 int flush_deferred(tf_volume* v);
 void launch_dirty_frame_store(const VolumeDev& v, int par, uint32_t stamp, const KfStoreArgs& a, hipStream_t s);  // tf_mesh.hip
@@ -282,7 +309,10 @@ int atlas_init(tf_volume* v);
 void atlas_destroy(tf_volume* v);
 int atlas_reset(tf_volume* v);
 int comm_exchange(tf_volume* v, int64_t cap_records, int dirty_par, uint32_t stamp, const FrameCtl* ctl = nullptr,
-                  uint32_t tag = 0, const FrameCtl* next_ctl = nullptr);
+                  uint32_t tag = 0, const FrameCtl* next_ctl = nullptr, hipStream_t xs = nullptr);  // xs: the stream it runs on (null: the handle's)
+// the pack launches of tf_boundary_pack_block / tf_boundary_pack_bands2 on a given stream (no deferred-frame flush: the caller did it)
+int boundary_pack_block_on(tf_volume* v, void* d_block, int64_t cap_records, hipStream_t s);
+int boundary_pack_bands2_on(tf_volume* v, void* d_block_down, int64_t cap_down, void* d_block_up, int64_t cap_up, hipStream_t s);
 void comm_destroy(tf_volume* v);
 int kf_push(tf_volume* v, int slot);
 void launch_patch_fused(tf_volume* v, const VolumeDev& d, int par, const KfDev& kf, hipStream_t s);

@@ -17,11 +17,13 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
 #include <map>
 #include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <algorithm>
@@ -566,9 +568,45 @@ inline bool WritePngRgb(const std::string& fileName, uint32_t w, uint32_t h, Row
 }
 
 // ---- Atlas (Structure/Atlas.h:43-75) -------------------------------------------------------
+// the atlas size as the reference's callers spell it (Atlas.h:29-30; the volume's own size is tf_config.atlas_w / _h)
+#ifndef MAX_PATCH_WIDTH
+#define MAX_PATCH_WIDTH (96 * 72 * 2)
+#endif
+#ifndef MAX_PATCH_HEIGHT
+#define MAX_PATCH_HEIGHT (72 * 96 * 2)
+#endif
 class Atlas {
  public:
   std::size_t loc_next = 0, PATCH_WIDTH = 0, PATCH_HEIGHT = 0, hot_start = 0, hot_end = 0;
+  // Atlas::texture_buffer (Atlas.h:45: a cv::Mat of atlas_h x atlas_w RGB texels that the GUI thread uploads its hot rows
+  // from, GCFusion/MobileFusion.h:404-421: `&chiselMap->atlas.texture_buffer.data[chiselMap->atlas.hot_start * 3]`).  The
+  // texels live in HBM; this is their host mirror with the member the caller dereferences.  Chisel::UpdateAtlas refreshes
+  // the rows [hot_start, hot_end) behind its device call, on the map thread -- so the GUI thread reads plain host memory
+  // under the reference's own protocol (its `vertex_data_updated` flag), with no library call of its own.  Allocated on
+  // first use; pages no hot range ever covered are never touched.
+  struct TextureBuffer {
+    unsigned char* data = nullptr;  // cv::Mat::data
+    int rows = 0, cols = 0;         // cv::Mat::rows / cols
+    std::size_t step = 0;           // bytes per row
+    bool empty() const { return data == nullptr; }
+    ~TextureBuffer() { std::free(data); }
+    TextureBuffer() = default;
+    TextureBuffer(const TextureBuffer&) = delete;
+    TextureBuffer& operator=(const TextureBuffer&) = delete;
+  } texture_buffer;
+  // rows [row0, row1) of the device atlas into texture_buffer (whole rows: hot_start / hot_end are multiples of the width)
+  void RefreshTextureRows(std::size_t row0, std::size_t row1) {
+    if (row1 > MAX_PATCH_HEIGHT_) row1 = MAX_PATCH_HEIGHT_;
+    if (row0 >= row1) return;
+    if (!texture_buffer.data) {
+      texture_buffer.rows = (int)MAX_PATCH_HEIGHT_; texture_buffer.cols = (int)MAX_PATCH_WIDTH_;
+      texture_buffer.step = MAX_PATCH_WIDTH_ * 3;
+      texture_buffer.data = static_cast<unsigned char*>(std::calloc(MAX_PATCH_HEIGHT_ * MAX_PATCH_WIDTH_, 3));  // Atlas.cpp:34-36
+      if (!texture_buffer.data) throw std::bad_alloc();
+    }
+    DownloadRows((int64_t)row0, (int64_t)row1, texture_buffer.data + row0 * texture_buffer.step);
+  }
+  void RefreshHotRows() { RefreshTextureRows(hot_start / MAX_PATCH_WIDTH_, hot_end / MAX_PATCH_WIDTH_); }
   void Bind(tf_volume* v, ChunkManager* m) {
     vol = v;
     manager = m;
@@ -938,6 +976,7 @@ class Chisel {
       for (int a = 0; a < 3; ++a) ids[3 * i + a] = chunksToUpdate[i](a);
     tf_check(tf_update_atlas(vol, ids.data(), (int64_t)n), "UpdateAtlas");
     RefreshPatches(ids, n);  // Patch::ratio is written by Atlas::UpdateBuffer
+    atlas.RefreshHotRows();  // Atlas::texture_buffer: what the GUI thread uploads next (MobileFusion.h:404-421)
   }
 
   // Structure/Chisel.cpp:288-355.  The caller's buffers must hold the whole model, as in the reference
