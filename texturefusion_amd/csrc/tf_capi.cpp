@@ -187,6 +187,7 @@ static int init_device_state(tf_volume* v) {
   TF_HIP(hipMemsetAsync(d.erase_epoch, 0, (size_t)d.max_chunks * 4, s));
   TF_HIP(hipMemsetAsync(d.nbr, 0, (size_t)d.max_chunks * kNbrWords * 4, s));  // nothing known, nothing checked (create_seq = 0: k_reset_ctl)
   d.seq = 1;
+  d.xl_par = 0;  // (the lists' counters: k_reset_ctl)
   TF_HIP(hipMemsetAsync(d.phase_buf, 0, (size_t)kPhaseWaves * 16 * 8, s));
   v->clear_floor = 0;
   for (int k = 0; k < tf_volume::kSelSets; ++k) {
@@ -410,6 +411,7 @@ int tf_volume_create_sized(const int32_t chunk_dim[3], float resolution, int use
   if ((rc = dev_alloc(v, &d.hent, hcap))) return fail(rc);
   if ((rc = dev_alloc(v, &d.summ, (size_t)d.max_chunks))) return fail(rc);
   if ((rc = dev_alloc(v, &d.nbr, (size_t)d.max_chunks * kNbrWords))) return fail(rc);
+  if ((rc = dev_alloc(v, &d.xl_ent, (size_t)d.max_chunks * 2))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mark_epoch, (size_t)d.max_chunks * 2))) return fail(rc);  // mark | erase, one allocation
   d.erase_epoch = d.mark_epoch + d.max_chunks;
   if ((rc = dev_alloc(v, &d.phase_buf, (size_t)kPhaseWaves * 16))) return fail(rc);
@@ -877,6 +879,7 @@ int tf::boundary_pack_block_on(tf_volume* v, void* d_block, int64_t cap_records,
   uint8_t* blk = reinterpret_cast<uint8_t*>(d_block);
   TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, s));
   launch_boundary_pack(v->dev, blk + 16, (uint32_t)cap_records, s);
+  v->dev.xl_par ^= 1u;  // (the voxel kernels list what they touch from now on into the other list)
   launch_boundary_headers(v->dev, reinterpret_cast<uint32_t*>(blk), (uint32_t)cap_records, nullptr, 0, s);  // the count travels in-band
   TF_HIP(hipGetLastError());
   return TF_OK;
@@ -887,6 +890,7 @@ int tf::boundary_pack_bands2_on(tf_volume* v, void* d_block_down, int64_t cap_do
   // launch floor, 49 us with nothing on the wire; profiles/r5/README.md)
   launch_boundary_pack_bands(v->dev, reinterpret_cast<uint8_t*>(d_block_down), reinterpret_cast<uint8_t*>(d_block_up),
                              (uint32_t)cap_down, (uint32_t)cap_up, s);
+  v->dev.xl_par ^= 1u;  // (the voxel kernels list what they touch from now on into the other list)
   TF_HIP(hipGetLastError());
   return TF_OK;
 }
@@ -992,12 +996,15 @@ int tf::texture_stage(tf_volume* v, const SelBuf& sel, const FrameImages& img, u
         TF_HIP(hipEventCreateWithFlags(&v->ev_join, hipEventDisableTiming));
       }
       TF_HIP(hipEventRecord(v->ev_fork, v->stream));          // behind the voxel update of this frame
-      TF_HIP(hipStreamWaitEvent(v->xstream, v->ev_fork, 0));
       (void)nbr_next_seq(v);   // the unpack launch and the interior pass next to it share this seq
+      // the interior pass goes onto the main stream FIRST: the host then spends its time on the exchange's enqueue (band
+      // counts, pack, transport, unpack: ~15 us) while the device already filters and meshes (a kernel trace of the other
+      // order showed the main stream idle for 12 us behind every voxel update)
+      rode = mesh_pass(1, &d.vctl->zero_word, true, false, /*new_seq=*/false);
+      TF_HIP(hipStreamWaitEvent(v->xstream, v->ev_fork, 0));
       rc = comm_exchange(v, v->comm_cap, par, frame_epoch + 1u, xc, frame_epoch + 1u, xn, v->xstream);
       if (rc) return rc;
       TF_HIP(hipEventRecord(v->ev_join, v->xstream));
-      rode = mesh_pass(1, &d.vctl->zero_word, true, false, /*new_seq=*/false);
       prof_begin(v, TF_PROF_XCHG_WAIT);                        // what of the exchange is NOT hidden behind the interior pass
       TF_HIP(hipStreamWaitEvent(v->stream, v->ev_join, 0));
       prof_end(v);
@@ -2043,6 +2050,7 @@ int tf_boundary_pack(tf_volume* v, void* d_records, int64_t cap_records, int64_t
   TF_DEV(v);
   TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
   launch_boundary_pack(v->dev, reinterpret_cast<uint8_t*>(d_records), (uint32_t)cap_records, v->stream);
+  v->dev.xl_par ^= 1u;  // (the voxel kernels list what they touch from now on into the other list)
   TF_HIP(hipGetLastError());
   CtlSnap ctl;
   int rc = fetch_ctl(v, &ctl);
@@ -2057,6 +2065,7 @@ int tf_boundary_pack_async(tf_volume* v, void* d_records, int64_t cap_records, u
   TF_DEV(v);
   TF_HIP(hipMemsetAsync(&v->dev.vctl->n_tmp, 0, 4, v->stream));
   launch_boundary_pack(v->dev, reinterpret_cast<uint8_t*>(d_records), (uint32_t)cap_records, v->stream);
+  v->dev.xl_par ^= 1u;  // (the voxel kernels list what they touch from now on into the other list)
   TF_HIP(hipGetLastError());
   TF_HIP(hipMemcpyAsync(d_count, &v->dev.vctl->n_tmp, 4, hipMemcpyDeviceToDevice, v->stream));
   return TF_OK;

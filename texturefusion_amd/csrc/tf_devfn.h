@@ -178,6 +178,16 @@ __device__ __forceinline__ uint32_t nbr_row_checked(const VolumeDev& v, const ui
   return w;
 }
 
+// multi-GPU: an owned ghost-band chunk was updated -- flag it "touched" (HEntry::alive bit 1) and, if it was not flagged
+// yet, list it for the next boundary pack (VolumeDev::xl_ent).  One thread.
+__device__ __forceinline__ void mark_touched(const VolumeDev& v, const uint32_t ent) {
+  const uint32_t old = atomicOr(&v.hent[ent].alive, 3u);
+  if (!(old & 2u)) {
+    const uint32_t p = atomicAdd(&v.vctl->xl_n[v.xl_par & 1u], 1u);
+    if (p < v.max_chunks) v.xl_ent[(size_t)(v.xl_par & 1u) * v.max_chunks + p] = ent;  // (every flagged chunk is listed once: p < the chunks there are)
+  }
+}
+
 // class of one voxel for the mesher's filter (ChunkManager.cpp:669-722, :776-777): observed (sdf <= 1), observed and
 // positive, negative, weight above the vertex threshold
 __device__ __forceinline__ uint32_t classify_voxel(const float sdf, const float w) {

@@ -94,6 +94,9 @@ struct VolCtl {
   // workgroup writes the blocks' headers and re-arms the three words (no memset, no header launch per exchange)
   uint32_t xchg_cnt[2];
   uint32_t xchg_ticket;
+  // multi-GPU: entries of the two lists of "touched" ghost-band chunks (VolumeDev::xl_ent): the voxel kernels append a chunk
+  // when its touched bit goes 0 -> 1, the pack launch consumes the list of its parity and re-arms it
+  uint32_t xl_n[2];
   // neighbour table (VolumeDev::nbr): VolumeDev::seq of the newest launch that INSERTED a key into the chunk hash.  A row's
   // "no chunk there" entries are trusted only if the row was checked by a launch with a larger seq (kNbrStamp).
   uint32_t create_seq;
@@ -274,6 +277,13 @@ struct VolumeDev {
   unsigned long long* obs_key;  // [obs_mask + 1], kEmptyKey = free
   float* obs_q;
   uint32_t obs_mask;
+  // multi-GPU: the chunks whose "touched" bit (HEntry::alive bit 1: a ghost-band chunk updated since it was last packed) is
+  // set, as hash-entry indices -- two lists: the voxel kernels append to list xl_par, the boundary pack consumes list xl_par
+  // (what does not fit its blocks goes to the other list, still flagged) and the host flips xl_par behind every pack launch.
+  // The pack's cost follows the few hundred chunks a frame touches, not the size of the hash (a scan of the 2^20 entries of
+  // the bench's pool took 35-49 us per frame, more than the slab's voxel update, filter and mesher together).
+  uint32_t* xl_ent;  // [2][max_chunks]
+  uint32_t xl_par;
   SelBuf sel;  // the selection set the launch works on
 };
 // planes of the mesh stored in block `blk` (MeshRec::block; only dereferenced for a mesh with vertices, i.e. blk != kBlkNone)

@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
     const bool updated = (rows_total | key_rows_t) != 0;
     if (updated && lane == 0) {
       L.list_needs[e] = 1;  // needsUpdateFlag[i] |= needsUpdate (Chisel.h:241)
-      if (part_band(v, id.x, id.y, id.z)) v.hent[L.list_ent[e]].alive = 3u;  // multi-GPU: touched since the last exchange
+      if (part_band(v, id.x, id.y, id.z)) mark_touched(v, L.list_ent[e]);  // multi-GPU: touched since the last exchange
     }
     const uint32_t rows_key = KEY ? (key_rows_c << 8) : (fin ? (uint32_t)L.list_rows[e] : 0u);  // the keyframe's own pass: rows_t | rows_c << 8
     if (lane == 0) L.list_rows[e] = (uint16_t)(rows_total + key_rows_t < 255u ? rows_total + key_rows_t : 255u);  // (statistic; saturates)

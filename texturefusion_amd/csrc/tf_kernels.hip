@@ -48,7 +48,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
     for (int k = 0; k < 4; ++k) ctl->band_cnt[k] = 0u;
     if (vctl) {
       vctl->status = 0; vctl->n_tmp = 0; vctl->n_tmp2 = 0; vctl->ovf_next = 0; vctl->xchg_sent = 0; vctl->xchg_recv = 0;
-      vctl->zero_word = 0; vctl->blk_next = 0; vctl->xchg_cnt[0] = vctl->xchg_cnt[1] = 0; vctl->xchg_ticket = 0; vctl->create_seq = 0;
+      vctl->zero_word = 0; vctl->blk_next = 0; vctl->xchg_cnt[0] = vctl->xchg_cnt[1] = 0; vctl->xchg_ticket = 0; vctl->create_seq = 0; vctl->xl_n[0] = vctl->xl_n[1] = 0;
       for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
     }
   }
@@ -969,7 +969,8 @@ __device__ __forceinline__ void integrate_body(const VolumeDev& v, const FrameIm
     const bool face = part_band(v, id.x, id.y, id.z);
     if (updated && lane == 0 && (face || lazy_revive)) {
       const uint32_t en = FUSED ? ent : L.list_ent[pe];
-      v.hent[en].alive = face ? 3u : 1u;  // bit0 alive, bit1 touched
+      if (face) mark_touched(v, en);  // bit0 alive, bit1 touched (+ listed for the next boundary pack)
+      else v.hent[en].alive = 1u;
     }
     if (FUSED) {
       // FinalizeIntegrateChunks (Chisel.h:192-208) + GarbageCollect (:472-477) for this entry

@@ -9,9 +9,10 @@
 namespace tf {
 
 // ---- multi-GPU boundary exchange ------------------------------------------------------
-// Pack every chunk this rank owns whose "touched" bit is set (slab-face chunks updated since the
-// last exchange) and clear the bit.  Record: int4 id | float2[512] | ushort4[512].  One wave scans
-// 64 hash entries at a time and copies the (rare) flagged chunks cooperatively.
+// Pack every chunk this rank owns whose "touched" bit is set (slab-face chunks updated since they were last packed) and
+// clear the bit.  Record: int4 id | float2[512] | ushort4[512].  The flagged chunks are LISTED (VolumeDev::xl_ent, appended
+// by the voxel kernels when the bit goes 0 -> 1): one wave per list entry copies the chunk; the cost of a pack follows what
+// a frame touched, not the size of the hash.
 // BANDS: two blocks instead of one -- `records` takes the chunks the rank BELOW reads as ghosts (key - lo <= a + b + c),
 // `records_up` those the rank ABOVE reads (key == hi - 1); a chunk of a thin slab may go to both.  Slabs are contiguous key
 // ranges, so with every slab at least a + b + c + 1 keys wide these two neighbours are the only readers (part_band).
@@ -21,83 +22,91 @@ __global__ __launch_bounds__(256) void k_boundary_pack(VolumeDev v, uint8_t* rec
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256 + threadIdx.x) >> 6));
   const uint32_t nwaves = gridDim.x * 4;
-  const uint32_t nent = v.hmask + 1;
-  for (uint32_t base = wave * 64; base < nent; base += nwaves * 64) {
-    const uint32_t i = base + lane;
-    HEntry h;
-    h.key = kEmptyKey; h.slot = kInvalidSlot; h.alive = 0;
-    if (i < nent) h = v.hent[i];
-    const bool want = h.key != kEmptyKey && (h.alive & 2u) && h.slot != kInvalidSlot;
-    unsigned long long m = __ballot(want);
-    while (m) {
-      const int src = __builtin_ctzll(m);
-      m &= m - 1;
-      const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)h.slot, src);
-      const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(h.key & 0xFFFFFFFFu), src);
-      const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(h.key >> 32), src);
-      int4 hd = unpack_id(((unsigned long long)khi << 32) | klo);
-      bool down = true, up = false;
-      if (BANDS) {
-        const long long k = part_key(v, hd.x, hd.y, hd.z);
-        down = k >= (long long)v.part_lo && k - (long long)v.part_lo <= (long long)(v.part_a + v.part_b + v.part_c);
-        up = k == (long long)v.part_hi - 1;
+  const uint32_t par = v.xl_par & 1u;
+  const uint32_t* list = v.xl_ent + (size_t)par * v.max_chunks;
+  uint32_t* keep = v.xl_ent + (size_t)(par ^ 1u) * v.max_chunks;  // what does not fit stays flagged: listed for the next pack
+  uint32_t n = v.vctl->xl_n[par];
+  if (n > v.max_chunks) n = v.max_chunks;
+  for (uint32_t e = wave; e < n; e += nwaves) {
+    const uint32_t i = list[e];
+    const HEntry h = v.hent[i];
+    if (h.key == kEmptyKey || !(h.alive & 2u) || h.slot == kInvalidSlot) continue;  // (cannot happen: listed <=> flagged)
+    const uint32_t slot = h.slot;
+    int4 hd = unpack_id(h.key);
+    bool down = true, up = false;
+    if (BANDS) {
+      const long long k = part_key(v, hd.x, hd.y, hd.z);
+      down = k >= (long long)v.part_lo && k - (long long)v.part_lo <= (long long)(v.part_a + v.part_b + v.part_c);
+      up = k == (long long)v.part_hi - 1;
+      if (!down && !up) {  // the partition changed since the chunk was flagged: nobody reads it as a ghost any more
+        if (lane == 0) v.hent[i].alive = h.alive & 5u;
+        continue;
       }
-      uint32_t p = 0, q = 0;
-      if (lane == 0) {
-        if (down) p = atomicAdd(BANDS ? &v.vctl->xchg_cnt[0] : &v.vctl->n_tmp, 1u);
-        if (up) q = atomicAdd(&v.vctl->xchg_cnt[1], 1u);
+    }
+    uint32_t p = 0, q = 0;
+    if (lane == 0) {
+      if (down) p = atomicAdd(BANDS ? &v.vctl->xchg_cnt[0] : &v.vctl->n_tmp, 1u);
+      if (up) q = atomicAdd(&v.vctl->xchg_cnt[1], 1u);
+    }
+    p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+    q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+    // A side that does not fit is skipped on its own (the other block still gets its record); the chunk stays flagged --
+    // and listed -- until every side that wants it has been written: a later exchange with room packs it again (the side
+    // that already has it receives an identical or newer copy).
+    const bool fit_down = down && p < cap, fit_up = up && q < cap_up;
+    if (lane == 0) {
+      if ((fit_down || !down) && (fit_up || !up)) v.hent[i].alive = h.alive & 5u;
+      else {
+        const uint32_t kp = atomicAdd(&v.vctl->xl_n[par ^ 1u], 1u);
+        if (kp < v.max_chunks) keep[kp] = i;
       }
-      p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
-      q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-      // A side that does not fit is skipped on its own (the other block still gets its record); the chunk stays flagged
-      // until every side that wants it has been written -- a later exchange with room packs it again (the side that
-      // already has it receives an identical or newer copy).
-      const bool fit_down = down && p < cap, fit_up = up && q < cap_up;
-      if (!fit_down && !fit_up) continue;
-      if (lane == src && (fit_down || !down) && (fit_up || !up)) v.hent[i].alive = h.alive & 5u;
-      hd.w = (int)v.mark_epoch[slot];  // header: id + the epoch of the chunk's last update (Chisel::meshesToUpdate travels with it)
-      const uint4* st = reinterpret_cast<const uint4*>(v.tsdf + (size_t)slot * kChunkVoxels);
-      const uint4* sc = reinterpret_cast<const uint4*>(v.color + (size_t)slot * kChunkVoxels);
-      uint4 vt[4], vc[4];
+    }
+    if (!fit_down && !fit_up) continue;
+    hd.w = (int)v.mark_epoch[slot];  // header: id + the epoch of the chunk's last update (Chisel::meshesToUpdate travels with it)
+    const uint4* st = reinterpret_cast<const uint4*>(v.tsdf + (size_t)slot * kChunkVoxels);
+    const uint4* sc = reinterpret_cast<const uint4*>(v.color + (size_t)slot * kChunkVoxels);
+    uint4 vt[4], vc[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { vt[k] = st[k * 64 + lane]; vc[k] = sc[k * 64 + lane]; }
+    for (int k = 0; k < 4; ++k) { vt[k] = st[k * 64 + lane]; vc[k] = sc[k * 64 + lane]; }
 #pragma unroll
-      for (int side = 0; side < 2; ++side) {
-        if (side == 0 ? !fit_down : !fit_up) continue;
-        uint8_t* rec = (side == 0 ? records : records_up) + (size_t)(side == 0 ? p : q) * (16 + 4096 + 4096);
-        if (lane == 0) *reinterpret_cast<int4*>(rec) = hd;
-        uint4* dt = reinterpret_cast<uint4*>(rec + 16);
-        uint4* dc = reinterpret_cast<uint4*>(rec + 16 + 4096);
+    for (int side = 0; side < 2; ++side) {
+      if (side == 0 ? !fit_down : !fit_up) continue;
+      uint8_t* rec = (side == 0 ? records : records_up) + (size_t)(side == 0 ? p : q) * (16 + 4096 + 4096);
+      if (lane == 0) *reinterpret_cast<int4*>(rec) = hd;
+      uint4* dt = reinterpret_cast<uint4*>(rec + 16);
+      uint4* dc = reinterpret_cast<uint4*>(rec + 16 + 4096);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { dt[k * 64 + lane] = vt[k]; dc[k * 64 + lane] = vc[k]; }
-      }
+      for (int k = 0; k < 4; ++k) { dt[k * 64 + lane] = vt[k]; dc[k * 64 + lane] = vc[k]; }
     }
   }
-  if (BANDS) {
-    // the last workgroup through writes the two blocks' in-band counts (the first word of the 16-byte header in front of
-    // the records), adds what fitted to the running total and re-arms the counters for the next exchange
-    __shared__ uint32_t s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __threadfence();
-      s_last = atomicAdd(&v.vctl->xchg_ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
-    }
-    __syncthreads();
-    if (s_last && threadIdx.x == 0) {
+  // The last workgroup through re-arms the list it consumed and (BANDS) writes the two blocks' in-band counts (the first
+  // word of the 16-byte header in front of the records), adds what fitted to the running total and re-arms the counters.
+  // (Every count above is a RETURNING atomic -- complete at the L2 before its wave goes on --, and the barrier orders the
+  // workgroup's waves ahead of its ticket; the records only have to be visible to the next launch.  Round 5's form -- a scan
+  // of the whole hash by 1024 workgroups, each with a __threadfence() ahead of its ticket -- took 49 us per frame for ~190
+  // records: the "host-bound exchange" of profiles/r5 was this kernel, tools/gaps.py on its kernel trace.)
+  __shared__ uint32_t s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&v.vctl->xchg_ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    v.vctl->xl_n[par] = 0u;
+    if (BANDS) {
       const uint32_t na = atomicExch(&v.vctl->xchg_cnt[0], 0u), nb = atomicExch(&v.vctl->xchg_cnt[1], 0u);
       *reinterpret_cast<uint32_t*>(records - 16) = na;
       *reinterpret_cast<uint32_t*>(records_up - 16) = nb;
       v.vctl->xchg_sent += (na < cap ? na : cap) + (nb < cap_up ? nb : cap_up);
-      v.vctl->xchg_ticket = 0u;
     }
+    v.vctl->xchg_ticket = 0u;
   }
 }
+// grid: 64 workgroups = 256 waves, one list entry each per round (a frame of the bench's 24-key slab flags ~190 chunks)
 void launch_boundary_pack(const VolumeDev& v, uint8_t* records, uint32_t cap, hipStream_t s) {
-  hipLaunchKernelGGL(k_boundary_pack<false>, dim3(1024), dim3(256), 0, s, v, records, (uint8_t*)nullptr, cap, 0u);
+  hipLaunchKernelGGL(k_boundary_pack<false>, dim3(64), dim3(256), 0, s, v, records, (uint8_t*)nullptr, cap, 0u);
 }
 void launch_boundary_pack_bands(const VolumeDev& v, uint8_t* block_down, uint8_t* block_up, uint32_t cap_down,
                                 uint32_t cap_up, hipStream_t s) {
-  hipLaunchKernelGGL(k_boundary_pack<true>, dim3(1024), dim3(256), 0, s, v, block_down + 16, block_up + 16, cap_down, cap_up);
+  hipLaunchKernelGGL(k_boundary_pack<true>, dim3(64), dim3(256), 0, s, v, block_down + 16, block_up + 16, cap_down, cap_up);
 }
 // The in-band counts of freshly packed blocks (VolCtl::n_tmp / n_tmp2 -> the first word of each block) and the running
 // total of records written (what fitted), for tf_comm_stats_ex.
