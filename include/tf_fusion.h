@@ -58,7 +58,7 @@ typedef struct {
   int32_t atlas_h;       /* default 13824 (Structure/Atlas.h:30) */
   int32_t max_keyframes; /* keyframe image cache slots for the atlas; default 64 */
   /* blocks of the LARGE pool of the mesh store (167 KB each, room for the largest mesh a chunk can have); 0 = default
-   * max(64, max_chunks / 256), at most 65535; -1 = none */
+   * max(256, max_chunks / 64), at most 65535; -1 = none */
   int32_t mesh_overflow_blocks;
   /* device-resident meshes (ChunkManager::allMeshes) live in a store that is allocated ON DEMAND: a chunk-pool slot owns
    * no mesh storage until its chunk first has a mesh with vertices; then it is given a block of mesh_max_vertices /

@@ -436,7 +436,9 @@ int tf_volume_create_sized(const int32_t chunk_dim[3], float resolution, int use
   if ((rc = dev_alloc(v, &d.mesh_rec, (size_t)d.max_chunks))) return fail(rc);
   {  // the large pool, for meshes beyond CV / CT
     int64_t nb = v->cfg.mesh_overflow_blocks;
-    if (nb == 0) nb = std::max<int64_t>(64, v->cfg.max_chunks / 256);
+    // (one full-size block per 64 pool slots: a scene with conflicting surfaces -- walls fused a few centimetres apart -- puts
+    // meshes of a thousand vertices into hundreds of chunks, tests/test_gpu_neighbours.py; max_chunks / 256 lost meshes there)
+    if (nb == 0) nb = std::max<int64_t>(256, v->cfg.max_chunks / 64);
     if (nb < 0) nb = 0;
     if (nb > 65535) nb = 65535;
     d.ovf_blocks = (uint32_t)nb;
