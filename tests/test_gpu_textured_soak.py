@@ -91,6 +91,32 @@ def _run(cam, res, frames, host_frames=False, max_chunks=1 << 17, stride=1):
     return n_meshes
 
 
+def random_case(rng, stride=None):
+    """One randomised case of the textured unit -- image size, focal length, voxel size, orbit stretch, hand-held wobble, entry
+    point -- compared with the oracle by _run (also what tools/soak_random.py loops over); returns (description, meshes)."""
+    W = int(rng.choice([320, 400, 480, 640])); H = int(rng.choice([240, 304, 360, 480]))
+    f = float(rng.uniform(0.7, 1.0) * W * 525.0 / 640.0)
+    res = float(rng.choice([0.005, 0.006, 0.008, 0.01]))
+    cam = synth.Camera(W, H, f, f, W / 2 - 0.5, H / 2 - 0.5, 0.01, 5.0)
+    k0 = int(rng.integers(0, 180)); step = int(rng.integers(1, 4)); n = int(rng.integers(10, 26))
+    wob = float(rng.uniform(0, 0.1)); radius = float(rng.uniform(0.2, 1.2))
+    frames = [synth.room_frame(k0 + step * i, cam, with_quality=False, wobble=wob, radius=radius) for i in range(n)]
+    host = [False, True, "registered", "registered_async", "no_deferral", "rgb"][int(rng.integers(0, 6))]  # entry point / host-frame path
+    st = int(rng.integers(1, 6)) if stride is None else stride
+    nm = _run(cam, np.float32(res), frames, host_frames=host, max_chunks=1 << 18, stride=st)
+    return "%dx%d f %.0f res %.3f frames %d step %d wobble %.2f radius %.2f host %s" % (W, H, f, res, n, step, wob, radius, host), nm
+
+
+@pytest.mark.parametrize("seed", [61, 62])
+def test_randomised_cases(gpu_required, seed):
+    """three cases per seed of tools/soak_random.py's generator, every chunk / mesh / patch compared (the tool itself runs
+    as many as one likes: 46 cases passed at the end of round 2, 24 more in round 6)"""
+    rng = np.random.default_rng(seed)
+    for _ in range(3):
+        what, nm = random_case(rng, stride=1)
+        assert nm > 0, what
+
+
 def test_hand_held_orbit(gpu_required):
     """general rotation matrices (pitch / roll wobble on the orbit): the summation-order-sensitive case"""
     cam = synth.Camera()

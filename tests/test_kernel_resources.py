@@ -15,7 +15,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # kernel name fragment -> (max VGPRs, max scratch bytes per lane); the PRODUCT instances (last template flag false: the
 # tuning instances with time stamps and triage cut-offs are not budgeted)
 BUDGET = {
-    "tf_kernels.hip": {"k_frameILb1ELb0ELb0E": (72, 0), "k_frameILb0ELb0ELb0E": (72, 0), "k_frameILb1ELb1ELb0E": (80, 0)},
+    "tf_kernels.hip": {"k_frameILb1ELb0ELb0E": (72, 0), "k_frameILb0ELb0ELb0E": (72, 0), "k_frameILb1ELb1ELb0E": (72, 8)},
     # (with the keyframe's colour pass on board: the LDS tables allow four waves per SIMD = 128 VGPRs)
     "tf_group.hip": {"k_integrate_groupILb1ELb0E": (96, 0), "k_integrate_groupILb0ELb0E": (96, 0),
                      "k_integrate_groupILb1ELb1E": (128, 0), "k_integrate_groupILb0ELb1E": (128, 0)},
@@ -25,7 +25,7 @@ BUDGET = {
     # / reciprocal forms of the slot and atlas sizes, a lane's byte offsets), now kept opaque so that they are recomputed at
     # their uses instead of being reloaded -- a dependent round trip each -- from scratch)
     "tf_mesh.hip": {"k_meshILi128ELb0E": (80, 0), "k_mesh_filterILb1ELb0ELb0E": (72, 0),
-                    "k_mesh_filterILb0ELb0ELb0E": (80, 0), "k_mesh_filterILb1ELb1ELb0E": (80, 0),
+                    "k_mesh_filterILb0ELb0ELb0E": (80, 0), "k_mesh_filterILb1ELb1ELb0E": (72, 0),
                     # (the batch form with the patch stage on board -- the keyframe unit on hall-sized lists: a 20-byte stack slot the
                     # compiler reserves and then folds away -- its code holds no scratch instruction)
                     "k_mesh_filterILb0ELb1ELb0E": (80, 24)},

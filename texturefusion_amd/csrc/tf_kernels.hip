@@ -530,8 +530,14 @@ void launch_lookup(const VolumeDev& v, uint32_t n, hipStream_t s) {
 #ifndef TF_KF_WAVES
 #define TF_KF_WAVES 7  // resident waves per SIMD the fused kernel is compiled for (register budget)
 #endif
+#ifndef TF_KFP_EXTRA
+#define TF_KFP_EXTRA 1  // K-A workgroups per CU above the residency of the patch-carrying instance (launch_frame)
+#endif
 #ifndef TF_KFP_WAVES
-#define TF_KFP_WAVES 6  // ... the instance that also carries the patch stage of the previous frame (80 VGPRs)
+#define TF_KFP_WAVES 7  // ... the instance that also carries the patch stage of the previous frame.  Round 6: 72 VGPRs like the others
+                        // (the patch stage shed ten registers: tf_patch_body.h) -- 7168 wave slots instead of 6144 for the patch
+                        // stage's 4096 waves + K-A's 7-8 k: k_frame<true,true> 43.0 -> 41.9 us (two A/B pairs, profiles/r6).  Eight
+                        // bytes of private memory remain: the thread index, stored once and reloaded where a non-K-A role starts.
 #endif
 
 // K-A runs per chunk as:   64-B list record + hash entry (scalar loads)  ->  geometry of all 8
@@ -1143,7 +1149,7 @@ void launch_frame(const VolumeDev& v, const FrameStage* cur, const FrameStage* n
   static const int nblocks7 = ka_blocks_default();
   // with the patch stage on board K-A gets one workgroup per CU more than the instance's residency: the patch / selection
   // ranges are dispatched FIRST (below) and K-A's workgroups take the slots they leave as they finish
-  static const int nblocksP = device_cus() * (TF_KFP_WAVES + 1);
+  static const int nblocksP = device_cus() * (TF_KFP_WAVES + TF_KFP_EXTRA);
   const int nblocks = with_patch ? nblocksP : nblocks7;
   FrameLaunch a;
   a.v = v;

@@ -411,7 +411,8 @@ __device__ __forceinline__ int near_k(int lane) { return (lane % 3 - 1) + 2 * ((
 #define TF_FILTER_WAVES 7  // waves per SIMD of the plain wave-form filter
 #endif
 #ifndef TF_FILTER_PATCH_WAVES
-#define TF_FILTER_PATCH_WAVES 6  // waves per SIMD of the filter instances that carry the patch stage (80 VGPRs)
+#define TF_FILTER_PATCH_WAVES 7  // waves per SIMD of the wave-form filter that carries the patch stage (71 VGPRs since round 6; the keyframe
+                                 // unit: 190.2 / 192.7 -> 188.8 / 189.2 us per keyframe against 6); the batch form with the stage: TF_FILTER_BATCH_WAVES
 #endif
 struct FilterPatch {
   uint32_t defer;    // the records the filter wants emptied go to the reset list (a patch stage shares the launch) instead of
@@ -432,7 +433,7 @@ struct FilterPatch {
 // TL: the tuning instance (TF_MESH_DBG=10, tools/stamps.py filter): lane 0 of a wave stamps s_memrealtime into the debug
 // table at the phase boundaries of its FIRST entry, row = wave; a phase that ends in loads is closed with a wait
 template <bool WAVE_FORM, bool PATCH, bool TL = false>
-__global__ __launch_bounds__(256, PATCH ? TF_FILTER_PATCH_WAVES : (WAVE_FORM ? TF_FILTER_WAVES : TF_FILTER_BATCH_WAVES)) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
+__global__ __launch_bounds__(256, PATCH ? (WAVE_FORM ? TF_FILTER_PATCH_WAVES : TF_FILTER_BATCH_WAVES) : (WAVE_FORM ? TF_FILTER_WAVES : TF_FILTER_BATCH_WAVES)) void k_mesh_filter(VolumeDev v, const int4* __restrict__ dlist,
                                                      const uint32_t* __restrict__ dslot,
                                                      const uint32_t* __restrict__ dcount, uint32_t max_entries,
                                                      uint32_t epoch, uint32_t* __restrict__ surv,

@@ -225,13 +225,17 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
   // before this frame, n_cand = patches of this frame that need one.
   const uint32_t n_cand = FUSED ? S->n_cand : 0u;
   const unsigned long long slots_base = FUSED ? S->slots_base : 0ull;
-  unsigned long long room = 0;
-  if (FUSED) {
-    const unsigned long long K = ((unsigned long long)v.atlas_w + v.patch_w - 1) / (unsigned long long)v.patch_w;
-    const unsigned long long bands = ((unsigned long long)v.atlas_h + v.patch_h - 1) / (unsigned long long)v.patch_h;
+  // (a function of the volume's sizes and the frame's first slot: recomputed by the few patches that need it -- as a
+  // 64-bit per-lane value held across the patch loop it is two registers the fused kernel does not have at 72)
+  auto slots_room = [&](const unsigned long long base) -> unsigned long long {
+    int aw = v.atlas_w, ah = v.atlas_h, pw = v.patch_w, ph = v.patch_h;
+    asm volatile("" : "+s"(aw), "+s"(ah), "+s"(pw), "+s"(ph));
+    const unsigned long long K = ((unsigned long long)aw + pw - 1) / (unsigned long long)pw;
+    const unsigned long long bands = ((unsigned long long)ah + ph - 1) / (unsigned long long)ph;
     const unsigned long long total = K * bands;
-    room = total > slots_base ? total - slots_base : 0ull;
-  }
+    return total > base ? total - base : 0ull;
+  };
+  const unsigned long long room = FUSED ? slots_room(slots_base) : 0ull;
   const bool overflow = FUSED && (unsigned long long)n_cand > room;  // some AddPatch of this frame throws
   const int W = cam.W, H = cam.H;
   const float Wf = (float)W, Hf = (float)H;
@@ -270,11 +274,13 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
     // then has no mesh yet (only a mesher makes one, and this stage runs ahead of the next mesher).  The neighbour's state is
     // requested here, unconditionally (a lane without a neighbour reads its own record), and looked at behind the vertex
     // loads of the first sweep: the exchange adds no round trip to the patch's chain.
-    const int xk = lane < 6 ? lane : 0, xm = xk ^ 1;
+    int xlane = lane;
+    asm volatile("" : "+v"(xlane));  // (or the lane's address into the table is hoisted out of the patch loop -- into private memory)
+    const int xk = xlane < 6 ? xlane : 0, xm = xk ^ 1;
     uint32_t x_nw = 0u, x_bs = 0u;
     if (FUSED) {
       const int word = 13 + ((xk & 1) ? 1 : -1) * (xk < 2 ? 1 : (xk < 4 ? 3 : 9));
-      x_nw = lane < 6 ? v.nbr[(size_t)slot * kNbrWords + word] : 0u;
+      x_nw = xlane < 6 ? v.nbr[(size_t)slot * kNbrWords + word] : 0u;
       x_bs = v.mesh_rec[x_nw ? x_nw - 1u : slot].state;
     }
     auto exchange_flags = [&]() {
@@ -307,14 +313,13 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o);
         // the first failing AddPatch is the candidate of rank `room`; it and every entry behind it are skipped
-        if ((unsigned long long)c >= room + (cand ? 0ull : 1ull) && overflow) { exchange_flags(); continue; }  // (CompressMeshes ran for it all the same)
+        const AtlasCtl::Set* S2 = S;
+        asm volatile("" : "+v"(S2));  // (the frame's first slot is read again here: see slots_room)
+        const unsigned long long base2 = S2->slots_base;
+        if (overflow && (unsigned long long)c >= slots_room(base2) + (cand ? 0ull : 1ull)) { exchange_flags(); continue; }  // (CompressMeshes ran for it all the same)
         if (cand) {
           unsigned long long tl;
-          // (the frame's first slot is read again here, by the few patches that are new: held across the patch loop it is two
-          // registers the fused kernel does not have)
-          const AtlasCtl::Set* S2 = S;
-          asm volatile("" : "+v"(S2));
-          if (!slot_texloc(v, S2->slots_base + c, &tl)) { exchange_flags(); continue; }  // (cannot happen: c < room)
+          if (!slot_texloc(v, base2 + c, &tl)) { exchange_flags(); continue; }  // (cannot happen: c < room)
           R.texloc = tl;
           if (lane == 0) rec->texloc = tl;
         }
