@@ -65,8 +65,10 @@ typedef struct {
    * mesh_max_triangles (0 = default 256 / 512: 20.4 KiB; a planar surface through a chunk has 81 / 128) out of
    * mesh_blocks blocks, or -- a mesh has at most 2187 vertices / 2560 triangles (9x9x9x3 edge grid, 512 cells x 5), and
    * the reference emits whatever a chunk produces (Structure/ChunkManager.cpp:856-918) -- a block of the large pool.
-   * Blocks are handed out once per chunk and never returned before tf_volume_reset.  Only when the pool a mesh needs is
-   * exhausted is the mesh stored empty and reported as TF_ERR_CAPACITY at the next synchronising call. */
+   * Once half of a pool has been handed out, a chunk whose mesh comes out empty (Mesh::Clear(), ChunkManager.cpp:254) or
+   * outgrows its small block gives the block back and later meshes reuse it: a pool has to hold the meshes that have
+   * vertices at one time (plus one generation of turnover), not every mesh there ever was.  Only when the pool a mesh needs
+   * is exhausted is the mesh stored empty and reported as TF_ERR_CAPACITY at the next synchronising call. */
   int32_t mesh_max_vertices;
   int32_t mesh_max_triangles;
   /* blocks of the small pool; 0 = default max_chunks: every chunk can own a mesh, as in the reference, whose allMeshes never

@@ -386,22 +386,13 @@ __global__ __launch_bounds__(256) void k_mesh_scatter(VolumeDev v, const int4* _
   // large one for a mesh beyond CV / CT)
   __shared__ uint32_t s_blk;
   if (threadIdx.x == 0) {
-    uint32_t b = v.mesh_rec[slot].block;
-    const bool big = nv > v.mesh_cv || nt > v.mesh_ct;
-    if (nv == 0u && nt == 0u) {
-      // nothing to store
-    } else if (big && !(b & kBlkLarge)) {
-      const uint32_t p = atomicAdd(&v.vctl->ovf_next, 1u);
-      b = p < v.ovf_blocks ? ((p + 1u) | kBlkLarge) : 0x7FFFFFFFu;
-    } else if (!big && b == kBlkNone) {
-      const uint32_t p = atomicAdd(&v.vctl->blk_next, 1u);
-      b = p < v.mesh_blocks ? p + 1u : 0x7FFFFFFFu;
-    }
-    s_blk = b;
+    const uint32_t was = v.mesh_rec[slot].block;
+    s_blk = mesh_block_for(v, was, nv, nt, blk_pressure(v));
+    if (s_blk != kBlkFail) mesh_block_settle(v, was, s_blk);
   }
   __syncthreads();
   const uint32_t mst = s_blk;
-  if (mst == 0x7FFFFFFFu) {
+  if (mst == kBlkFail) {
     if (threadIdx.x == 0) atomicOr(&v.vctl->status, kStMeshFull);
     return;
   }

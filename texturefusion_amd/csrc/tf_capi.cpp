@@ -433,7 +433,6 @@ int tf_volume_create_sized(const int32_t chunk_dim[3], float resolution, int use
   }
   if ((rc = dev_alloc(v, &d.mesh_v, (size_t)d.mesh_blocks * kMeshPlanes * d.mesh_cv))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_t, (size_t)d.mesh_blocks * 3 * d.mesh_ct))) return fail(rc);
-  if ((rc = dev_alloc(v, &d.mesh_rec, (size_t)d.max_chunks))) return fail(rc);
   {  // the large pool, for meshes beyond CV / CT
     int64_t nb = v->cfg.mesh_overflow_blocks;
     // (one full-size block per 64 pool slots: a scene with conflicting surfaces -- walls fused a few centimetres apart -- puts
@@ -448,6 +447,8 @@ int tf_volume_create_sized(const int32_t chunk_dim[3], float resolution, int use
       if ((rc = dev_alloc(v, &d.ovf_vlist, (size_t)nb * kOvfCV))) return fail(rc);
     }
   }
+  // the records, and behind them the free rings of the two pools (one word per block: blk_release / blk_take, tf_devfn.h)
+  if ((rc = dev_alloc(v, &d.mesh_rec, (size_t)d.max_chunks + ((size_t)blk_ring_len(d.mesh_blocks) + blk_ring_len(d.ovf_blocks)) * 4 / sizeof(MeshRec) + 1))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_nbr, (size_t)kMeshShards * mesh_shard_rows(d.max_chunks) * 32))) return fail(rc);
   if ((rc = dev_alloc(v, &d.mesh_cnt, (size_t)2 * kMeshCntWords))) return fail(rc);
   if ((rc = dev_alloc(v, &d.reset_list, (size_t)kMeshShards * mesh_shard_rows(d.max_chunks)))) return fail(rc);

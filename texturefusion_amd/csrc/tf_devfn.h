@@ -178,6 +178,91 @@ __device__ __forceinline__ uint32_t nbr_row_checked(const VolumeDev& v, const ui
   return w;
 }
 
+// ---- the mesh store's blocks (MeshRec::block) ---------------------------------------------------------------------
+// A chunk owns at most one block; the mesher (and tf_mesh_upload) decide per generation where the mesh goes: into the
+// block the chunk owns when it fits there, else into one handed out now -- a released one first, then the pool's bump
+// counter.  A mesh that came out EMPTY gives its block back (the reference's Mesh::Clear() frees the vectors; a surface
+// that moves through a volume would otherwise keep one block per chunk it ever touched), and so does a small block
+// whose mesh outgrew it.  Rings of block words (0 = vacant) behind the records, each a power of two long (blk_ring_len):
+// small, then large.
+// Which block a mesh sits in is not observable.  All of it runs on ONE thread of the workgroup that meshes the chunk.
+constexpr uint32_t kBlkFail = 0x7FFFFFFFu;  // no block left in the pool the mesh needs
+__device__ __forceinline__ uint32_t blk_ring_mask(const VolumeDev& v, const int large) {
+  // (opaque scalars: the masks are loop-invariant in the mesher, and the compiler would otherwise keep them in registers --
+  // spilled ones -- across the whole chunk loop for the sake of this rare path)
+  uint32_t ns = v.mesh_blocks, nl = v.ovf_blocks;
+  asm volatile("" : "+s"(ns), "+s"(nl));
+  const uint32_t ms = ns > 2u ? (0xFFFFFFFFu >> __builtin_clz(ns - 1u)) : 1u;  // = blk_ring_len(blocks) - 1
+  const uint32_t ml = nl > 2u ? (0xFFFFFFFFu >> __builtin_clz(nl - 1u)) : 1u;
+  return large ? ml : ms;
+}
+__device__ __forceinline__ uint32_t* blk_ring(const VolumeDev& v, const int large) {
+  uint32_t* const r = reinterpret_cast<uint32_t*>(v.mesh_rec + v.max_chunks);
+  return large ? r + (blk_ring_mask(v, 0) + 1u) : r;
+}
+__device__ __forceinline__ void blk_release(const VolumeDev& v, const uint32_t b) {  // b != kBlkNone
+  const int large = (b & kBlkLarge) ? 1 : 0;
+  const uint32_t p = atomicAdd(&v.vctl->blk_tail[large], 1u);
+  // (at most `blocks` blocks exist and each is released once while it is free: the ring position is vacant)
+  __hip_atomic_store(&blk_ring(v, large)[p & blk_ring_mask(v, large)], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t blk_take(const VolumeDev& v, const int large) {  // a released block, or kBlkNone
+  uint32_t* const head = &v.vctl->blk_head[large];
+  uint32_t h = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (;;) {
+    const uint32_t tl = __hip_atomic_load(&v.vctl->blk_tail[large], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((int32_t)(tl - h) <= 0) return kBlkNone;
+    const uint32_t old = atomicCAS(head, h, h + 1u);
+    if (old == h) break;
+    h = old;
+  }
+  uint32_t* const e = &blk_ring(v, large)[h & blk_ring_mask(v, large)];
+  // the ticket is ours; its releaser (another workgroup of this launch, at worst) may still be between its ticket and its
+  // store -- a few instructions.  Bounded: giving up loses the block until the ring comes round, never correctness.
+  for (int spin = 0; spin < (1 << 14); ++spin) {
+    const uint32_t b = atomicExch(e, 0u);
+    if (b) return b;
+  }
+  return kBlkNone;
+}
+// the block for a mesh of nv vertices / nt triangles of a chunk that owns `b`: kBlkNone for an empty mesh (under pressure,
+// else the chunk keeps its block), kBlkFail when the
+// pool it needs is exhausted (the chunk then keeps what it had).  The caller writes the mesh and then gives back what the
+// chunk no longer uses: mesh_block_settle.
+// Blocks only go back once their pool has come under pressure -- half of it handed out: a stream whose pool is large
+// enough (the default gives every pool slot a block) never pays the ring's atomics, and a chunk whose surface flickers
+// keeps its block.  Fresh blocks come from the bump counter while it lasts (one atomic, as before); the ring serves the rest.
+// (VolCtl::blk_recycle -- bit 0: the small pool is under pressure, bit 1: the large one; read early, next to the chunk's
+// record, so that the decision does not wait for it)
+__device__ __forceinline__ uint32_t blk_pressure(const VolumeDev& v) { return v.vctl->blk_recycle; }
+__device__ __forceinline__ bool blk_pressed(const uint32_t press, const uint32_t b) { return (press >> ((b & kBlkLarge) ? 1 : 0)) & 1u; }
+__device__ __forceinline__ uint32_t blk_fresh(const VolumeDev& v, const int large) {  // kBlkFail: none left
+  uint32_t* const next = large ? &v.vctl->ovf_next : &v.vctl->blk_next;
+  const uint32_t n = large ? v.ovf_blocks : v.mesh_blocks;
+  const uint32_t p = atomicAdd(next, 1u);
+  if (p + 1u == ((n + 1u) >> 1)) atomicOr(&v.vctl->blk_recycle, large ? 2u : 1u);  // half of the pool is out: recycle from now on
+  if (p < n) return (p + 1u) | (large ? kBlkLarge : 0u);
+  atomicSub(next, 1u);  // (nobody waits for it: the counter stays at about n instead of running towards a wrap-around)
+  const uint32_t b = n ? blk_take(v, large) : kBlkNone;
+  return b != kBlkNone ? b : kBlkFail;
+}
+__device__ __forceinline__ uint32_t mesh_block_for(const VolumeDev& v, uint32_t b, const uint32_t nv, const uint32_t nt, const uint32_t press) {
+  const bool big = nv > v.mesh_cv || nt > v.mesh_ct;
+  if (nv == 0u && nt == 0u) {
+    if (b != kBlkNone && blk_pressed(press, b)) b = kBlkNone;  // nothing to store
+  } else if (big && !(b & kBlkLarge)) {
+    b = blk_fresh(v, 1);
+  } else if (!big && b == kBlkNone) {
+    b = blk_fresh(v, 0);
+  }
+  return b;
+}
+
+// `was`: the block the chunk owned before this generation, `now`: where the generation went (not kBlkFail)
+__device__ __forceinline__ void mesh_block_settle(const VolumeDev& v, const uint32_t was, const uint32_t now) {
+  if (was != kBlkNone && was != now) blk_release(v, was);  // an emptied mesh's block, or the small block a mesh outgrew
+}
+
 // multi-GPU: an owned ghost-band chunk was updated -- flag it "touched" (HEntry::alive bit 1) and, if it was not flagged
 // yet, list it for the next boundary pack (VolumeDev::xl_ent).  One thread.
 __device__ __forceinline__ void mark_touched(const VolumeDev& v, const uint32_t ent) {

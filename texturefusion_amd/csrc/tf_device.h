@@ -100,6 +100,13 @@ struct VolCtl {
   // neighbour table (VolumeDev::nbr): VolumeDev::seq of the newest launch that INSERTED a key into the chunk hash.  A row's
   // "no chunk there" entries are trusted only if the row was checked by a launch with a larger seq (kNbrStamp).
   uint32_t create_seq;
+  // mesh store: blocks that were given back (blk_release: a mesh that became empty, a small block whose mesh moved to the
+  // large pool) wait in one ring per pool -- [0] small, [1] large -- behind VolumeDev::mesh_rec; blk_take hands them out
+  // again before the bump counters above move.  Monotone tickets: head = taken, tail = released.
+  uint32_t blk_head[2], blk_tail[2];
+  // bit 0 / 1: the small / large pool has handed out half of its blocks at some point -- from then on blocks go back to the
+  // rings (sticky until the volume is reset; before that a stream pays nothing for the rings: one read-mostly word)
+  uint32_t blk_recycle;
   // Pool slots are handed out from 64 independent stripes (stripe s owns slots
   // [s*max_chunks/64, (s+1)*max_chunks/64)) so that the thousands of chunk creations of a
   // first-touch frame do not serialise on one atomic word.
@@ -294,6 +301,12 @@ __host__ __device__ inline float* mesh_plane(const VolumeDev& v, uint32_t blk, i
 __host__ __device__ inline uint16_t* tri_plane(const VolumeDev& v, uint32_t blk, int corner) {
   const size_t i = (size_t)((blk & ~kBlkLarge) - 1u);
   return (blk & kBlkLarge) ? v.ovf_t + (i * 3 + corner) * kOvfCT : v.mesh_t + (i * 3 + corner) * v.mesh_ct;
+}
+// length of a pool's ring of released blocks (blk_release / blk_take, tf_devfn.h): the power of two >= blocks (>= 2)
+__host__ __device__ inline uint32_t blk_ring_len(const uint32_t blocks) {
+  uint32_t n = 2;
+  while (n < blocks) n <<= 1;
+  return n;
 }
 __host__ __device__ inline uint32_t mesh_cap_v(const VolumeDev& v, uint32_t blk) { return blk == kBlkNone ? 0u : ((blk & kBlkLarge) ? (uint32_t)kOvfCV : v.mesh_cv); }
 __host__ __device__ inline uint32_t mesh_cap_t(const VolumeDev& v, uint32_t blk) { return blk == kBlkNone ? 0u : ((blk & kBlkLarge) ? (uint32_t)kOvfCT : v.mesh_ct); }

@@ -49,6 +49,7 @@ __global__ void k_reset_ctl(FrameCtl* ctl, VolCtl* vctl) {
     if (vctl) {
       vctl->status = 0; vctl->n_tmp = 0; vctl->n_tmp2 = 0; vctl->ovf_next = 0; vctl->xchg_sent = 0; vctl->xchg_recv = 0;
       vctl->zero_word = 0; vctl->blk_next = 0; vctl->xchg_cnt[0] = vctl->xchg_cnt[1] = 0; vctl->xchg_ticket = 0; vctl->create_seq = 0; vctl->xl_n[0] = vctl->xl_n[1] = 0;
+      vctl->blk_head[0] = vctl->blk_head[1] = vctl->blk_tail[0] = vctl->blk_tail[1] = 0; vctl->blk_recycle = 0;
       for (int k = 0; k < kSlotStripes; ++k) vctl->slot_cnt[k] = 0;
     }
   }

@@ -178,6 +178,7 @@ struct MeshSh {
   uint16_t clist[512];        // ... in no particular order (what is computed per cell is stored per cell)
   uint32_t ovf;               // the chunk's block of the mesh store (MeshRec::block): owned before this pass or handed out in it
   uint32_t rblock;            // MeshRec::block as it was before this pass
+  uint32_t rpress;            // blk_pressure() as read with the record
   uint32_t rstate;            // MeshRec::state as it was before this pass
   unsigned long long rtexloc; // MeshRec::texloc
 };
@@ -236,7 +237,15 @@ __device__ __forceinline__ void filter_reset_record(const VolumeDev& v, uint32_t
   // fused flow (ppar >= 0): CompressMeshes follows in the same frame and its SimplifyByClustering marks EVERY dirty
   // mesh of allMeshes simplified, with or without vertices (Chisel.cpp:116-126, Mesh.cpp:39-48)
   rec->nv = 0; rec->nt = 0; rec->state = inmap | ((ppar >= 0 && inmap) ? kMsSimplified : 0u); rec->epoch = epoch;
-  if (ppar >= 0 && inmap) patch_list_append(v, ppar, own & (kMeshShards - 1u), id, own, rec->texloc, rec->block);  // an emptied mesh keeps its patch
+  if (inmap) {  // (most chunks the filter rules out never had a mesh: they end with the stores above)
+    uint32_t blk = rec->block;
+    const unsigned long long texloc = rec->texloc;
+    if (blk != kBlkNone && blk_pressed(blk_pressure(v), blk)) {  // Mesh::Clear(): the storage goes back to its pool (tf_devfn.h)
+      blk_release(v, blk);
+      rec->block = blk = kBlkNone;
+    }
+    if (ppar >= 0) patch_list_append(v, ppar, own & (kMeshShards - 1u), id, own, texloc, blk);  // an emptied mesh keeps its patch
+  }
 }
 
 // The same, postponed to the mesher launch (VolumeDev::reset_list): one thread
@@ -726,7 +735,7 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
     if (DBG && dbg == 9) mesh_stamp(v, r, 1);
     if (t == 0) { sh.nv = 0; sh.nt = 0; sh.adj = 0; sh.ncell = 0; }
     // the record's previous state travels with the first batch of loads, so that the tail of the chunk is stores only
-    if (t == NT - 64) { sh.rstate = rec->state; sh.rblock = rec->block; sh.rtexloc = rec->texloc; }
+    if (t == NT - 64) { sh.rstate = rec->state; sh.rblock = rec->block; sh.rtexloc = rec->texloc; sh.rpress = blk_pressure(v); }
     if (DBG && dbg == 1) continue;  // triage: filter only
     // ---- stage the 11^3 voxels of the neighbourhood (own ones from registers)
 #pragma unroll
@@ -899,23 +908,9 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
         total += sh.wsum[k];
       }
       // Where does the mesh go?  Into the block the chunk already owns when it fits there; else into a block handed out
-      // now -- of the small pool (CV / CT), or of the large one for a mesh beyond that (one bump allocation per chunk and
-      // pool, ever; a mesh without vertices needs none).  kBlkFail: the pool is exhausted.  Block-uniform.
-      constexpr uint32_t kBlkFail = 0x7FFFFFFFu;
-      if (t == 0) {
-        uint32_t b = sh.rblock;
-        const bool big = (total & 0xFFFFu) > v.mesh_cv || (total >> 16) > v.mesh_ct;
-        if ((total & 0xFFFFu) == 0u && (total >> 16) == 0u) {
-          // nothing to store
-        } else if (big && !(b & kBlkLarge)) {
-          const uint32_t p = atomicAdd(&v.vctl->ovf_next, 1u);
-          b = p < v.ovf_blocks ? ((p + 1u) | kBlkLarge) : kBlkFail;
-        } else if (!big && b == kBlkNone) {
-          const uint32_t p = atomicAdd(&v.vctl->blk_next, 1u);
-          b = p < v.mesh_blocks ? p + 1u : kBlkFail;
-        }
-        sh.ovf = b;
-      }
+      // now -- of the small pool (CV / CT), or of the large one for a mesh beyond that; a mesh without vertices needs none
+      // and gives back what the chunk owned (mesh_block_for, tf_devfn.h).  kBlkFail: the pool is exhausted.  Block-uniform.
+      if (t == 0) sh.ovf = mesh_block_for(v, sh.rblock, total & 0xFFFFu, total >> 16, sh.rpress);
       __syncthreads();
       const uint32_t ovf_blk = sh.ovf;
       uint16_t* const gvl = (ovf_blk != kBlkFail && (ovf_blk & kBlkLarge)) ? v.ovf_vlist + (size_t)((ovf_blk & ~kBlkLarge) - 1u) * kOvfCV : nullptr;
@@ -940,7 +935,7 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
     __syncthreads();
     const uint32_t nv = sh.nv, nt = sh.nt;
     const uint32_t ovf = sh.ovf;
-    if (ovf == 0x7FFFFFFFu) {  // no block left in the pool the mesh needs: reported, stored empty (the chunk keeps what it had)
+    if (ovf == kBlkFail) {  // no block left in the pool the mesh needs: reported, stored empty (the chunk keeps what it had)
       if (t == 0) {
         atomicOr(&v.vctl->status, kStMeshFull);
         const uint32_t was = sh.rstate & kMsInMap;
@@ -958,7 +953,10 @@ __global__ __launch_bounds__(NT, TF_MESH_WAVES) void k_mesh(VolumeDev v, const u
     // not depend on the vertices: the last wave (it rarely has vertex work) appends it now, so that the round trips
     // of the two counters overlap the vertex pass instead of ending the chunk.
     const uint32_t inmap = (sh.rstate & kMsInMap) | (nv ? kMsInMap : 0u);
-    if (t == NT - 64 && rearm >= 0 && inmap) patch_list_append(v, rearm ^ 1, shard, id, own, sh.rtexloc, ovf);
+    if (t == NT - 64) {
+      mesh_block_settle(v, sh.rblock, ovf);  // (what the chunk owned and this generation does not use goes back to its pool)
+      if (rearm >= 0 && inmap) patch_list_append(v, rearm ^ 1, shard, id, own, sh.rtexloc, ovf);
+    }
     // ---- pass 2: the winning cell of every used slot evaluates the vertex; lane = output vertex
     const float org[3] = {(float)(8 * id.x) * res, (float)(8 * id.y) * res, (float)(8 * id.z) * res};  // Chunk.cpp:52
     uint32_t adj = 0;
@@ -1060,6 +1058,7 @@ __global__ __launch_bounds__(256) void k_init_mesh_rec(MeshRec* rec, uint32_t n)
 }
 void launch_init_meshes(const VolumeDev& v, hipStream_t s) {
   hipLaunchKernelGGL(k_init_mesh_rec, dim3(1024), dim3(256), 0, s, v.mesh_rec, v.max_chunks);
+  (void)hipMemsetAsync(v.mesh_rec + v.max_chunks, 0, sizeof(uint32_t) * ((size_t)blk_ring_len(v.mesh_blocks) + blk_ring_len(v.ovf_blocks)), s);  // the free rings: vacant (blk_release)
   (void)hipMemsetAsync(v.mesh_cnt, 0, sizeof(uint32_t) * 2 * kMeshCntWords, s);
 }
 

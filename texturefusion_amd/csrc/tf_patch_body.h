@@ -347,14 +347,17 @@ __device__ __forceinline__ void patch_body(const VolumeDev& v, const Cam& cam, c
         // ---- loads of the sweep: vertex positions and colours
         float px[kVB], py[kVB], pz[kVB], m0[kVB], m1[kVB], m2[kVB];
         const uint32_t lim = base == 0 ? mesh_cap_v(v, mst) : nv;
+        // (a mesh that came out empty gave its block back, mesh_block_for: the unconditional first sweep then reads vertex 0
+        // of block 1 -- any mapped address; every lane is masked by nv = 0 below)
+        const uint32_t mld = mst != kBlkNone ? mst : 1u;
 #pragma unroll
         for (int j = 0; j < kVB; ++j) {
           const uint32_t i = base + 64u * j + lane;
           const uint32_t ii = i < lim ? i : 0u;
-          px[j] = mesh_plane(v, mst, kMpPos)[ii]; py[j] = mesh_plane(v, mst, kMpPos + 1)[ii];
-          pz[j] = mesh_plane(v, mst, kMpPos + 2)[ii];
-          m0[j] = mesh_plane(v, mst, kMpCol)[ii]; m1[j] = mesh_plane(v, mst, kMpCol + 1)[ii];
-          m2[j] = mesh_plane(v, mst, kMpCol + 2)[ii];
+          px[j] = mesh_plane(v, mld, kMpPos)[ii]; py[j] = mesh_plane(v, mld, kMpPos + 1)[ii];
+          pz[j] = mesh_plane(v, mld, kMpPos + 2)[ii];
+          m0[j] = mesh_plane(v, mld, kMpCol)[ii]; m1[j] = mesh_plane(v, mld, kMpCol + 1)[ii];
+          m2[j] = mesh_plane(v, mld, kMpCol + 2)[ii];
         }
         if (base == 0) exchange_flags();  // (its loads went out with the record; the vertex loads are in flight now)
         stampw(3);
