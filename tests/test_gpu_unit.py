@@ -305,7 +305,7 @@ def test_keyframe_groups_of_every_size(gpu_required, n_local, with_q):
     gv.close()
 
 
-def run_unit_sequence(cam, res, frames, plan, with_q, max_chunks=1 << 17, stride=5):
+def run_unit_sequence(cam, res, frames, plan, with_q, max_chunks=1 << 17, stride=5, gpu_ahead=False):
     """A sequence of tf_keyframe_unit_device calls against the oracle driven call by call.  frames[k] = (depth, rgba,
     quality, pose); plan = [(kf_id, key_frame_index, [local frame indices], [(moved kf_id, pose shift)])]: every call
     integrates one new keyframe group, textured with its keyframe, and first moves the listed earlier keyframes -- their
@@ -324,6 +324,13 @@ def run_unit_sequence(cam, res, frames, plan, with_q, max_chunks=1 << 17, stride
 
     state = {}  # kf_id -> {key, loc, poses (current), valid (oracle's validChunks)}
     kfs = {}
+    if gpu_ahead:
+        # every call is enqueued before the oracle starts: the device works through the calls back to back, which is when a
+        # call's front end (selection, records) overlaps the previous call's filter || patch stage and mesher (tf_unit.hip)
+        for kf_id, key, loc, moves in plan:
+            assert not moves
+            fresh = capi.Volume.unit_group(kf_id, dev_key(key, frames[key][3]), [(bufs[k][0].ptr, frames[k][3]) for k in loc])
+            gv.keyframe_unit(fresh=fresh, moved=[], texture=True, pose_inv16=synth.pose_inverse16(frames[key][3]))
     for kf_id, key, loc, moves in plan:
         moved = []
         for mid, shift in moves:
@@ -343,7 +350,8 @@ def run_unit_sequence(cam, res, frames, plan, with_q, max_chunks=1 << 17, stride
             st["poses"] = newp
         fresh = capi.Volume.unit_group(kf_id, dev_key(key, frames[key][3]), [(bufs[k][0].ptr, frames[k][3]) for k in loc])
         T = synth.pose_inverse16(frames[key][3])
-        gv.keyframe_unit(fresh=fresh, moved=moved, texture=True, pose_inv16=T)
+        if not gpu_ahead:
+            gv.keyframe_unit(fresh=fresh, moved=moved, texture=True, pose_inv16=T)
         valid = _oracle_group(ov, kf_id, frames[key], [(frames[k][0], frames[k][3]) for k in loc], 1)
         state[kf_id] = dict(key=key, loc=list(loc), poses=[frames[key][3]] + [frames[k][3] for k in loc], valid=valid)
         ov.update_meshes()
@@ -386,6 +394,16 @@ def run_unit_sequence(cam, res, frames, plan, with_q, max_chunks=1 << 17, stride
                 b.free()
     gv.close()
     return len(mids)
+
+
+def test_keyframe_unit_calls_back_to_back(gpu_required):
+    """Ten keyframe groups (1 + 6 frames each) along the orbit, all ten calls enqueued before anything else happens: the
+    device runs the calls back to back, every call's front end on its own stream beside the previous call's texture
+    stage.  Chunks, voxels, observations, meshes, patches and the atlas fill must equal the oracle's, call by call order."""
+    cam = synth.Camera(320, 240, 262.5, 262.5, 159.5, 119.5, 0.01, 5.0)
+    frames = [synth.room_frame(2 * k, cam, with_quality=False, wobble=0.05) for k in range(70)]
+    plan = [(100 + g, 7 * g, [7 * g + 1 + i for i in range(6)], []) for g in range(10)]
+    assert run_unit_sequence(cam, np.float32(0.008), frames, plan, False, stride=3, gpu_ahead=True) > 300
 
 
 @pytest.mark.parametrize("with_q", [True, False])

@@ -34,6 +34,14 @@ struct UnitState {
   std::unordered_map<int32_t, int> slot_of;
   float4* group_pre = nullptr;  // scratch of the keyframe-group kernel (list records + centroid tables of six frames)
   float* group_cen = nullptr;
+  // The front end of a fresh group (k_bbox -> k_select -> k_pre_group: a pure function of the group's images and poses and of
+  // which chunks exist / are parked) runs on a stream of its own behind the LAST launch that changes chunks -- ev_mut, recorded
+  // at the end of every group -- and into the next selection set of the ring: when unit calls follow each other it overlaps
+  // the previous call's filter || patch stage and mesher (60 us that read voxels, summaries and meshes, and whose kf_store
+  // reads the previous set), instead of 26 us of three small dependent launches between two keyframes.
+  hipStream_t front = nullptr;
+  hipEvent_t ev_mut = nullptr, ev_front = nullptr;
+  uint64_t mut_seq = 0;  // tf_volume::call_seq of the call that recorded ev_mut
 };
 static std::unordered_map<tf_volume*, UnitState> g_units;  // (one per handle; freed by tf_keyframe_unit_release)
 static std::mutex g_units_mu;                              // (handles may live on different threads)
@@ -92,6 +100,11 @@ static int unit_state(tf_volume* v, UnitState** out) {
     memset(u.h_fill, 0, 64);
     TF_HIP(hipMalloc((void**)&u.group_pre, sizeof(float4) * (size_t)kGroupFrames * 4 * v->dev.max_list));
     TF_HIP(hipMalloc((void**)&u.group_cen, sizeof(float) * (size_t)kGroupFrames * 3 * kChunkVoxels));
+    if (!(getenv("TF_UNIT_SERIAL_FRONT") && atoi(getenv("TF_UNIT_SERIAL_FRONT")))) {  // (A/B knob: everything on the handle's stream)
+      TF_HIP(hipStreamCreateWithFlags(&u.front, hipStreamNonBlocking));
+      TF_HIP(hipEventCreateWithFlags(&u.ev_mut, hipEventDisableTiming | hipEventReleaseToDevice));  // (device-scope release: both sides are this GPU)
+      TF_HIP(hipEventCreateWithFlags(&u.ev_front, hipEventDisableTiming | hipEventReleaseToDevice));
+    }
   }
   *out = &u;
   return TF_OK;
@@ -103,22 +116,34 @@ static int unit_state(tf_volume* v, UnitState** out) {
 // for a group without local frames) -- instead of a scan of every chunk's mark later
 // ride_store != nullptr: the group's validChunks are not stored here -- *ride_store receives the arguments and the caller's
 // texture stage takes them along on its filter launch
+// first / last: the group's pass is the first / last one of its tf_keyframe_unit_device call (the front end's own stream)
 static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, int flag, int kf_slot, int dirty_par = -1,
-                           uint32_t dirty_stamp = 0, KfStoreArgs* ride_store = nullptr) {
+                           uint32_t dirty_stamp = 0, KfStoreArgs* ride_store = nullptr, bool first = false, bool last = false) {
   hipStream_t s = v->stream;
   VolumeDev& d = v->dev;
   FrameImages img{g->keyframe.d_depth, reinterpret_cast<const uchar4*>(g->keyframe.d_rgba), g->keyframe.d_quality};
   const float* kpose = flag ? g->keyframe.pose : g->old_keyframe_pose;
   Pose P;
   memcpy(P.p, kpose, sizeof(P.p));
+  hipStream_t fs = s;  // the stream of the front end
+  // Worth it only for the FIRST pass of a call that follows another unit call (ev_mut then stands for "every launch that
+  // changes chunks is done" while that call's texture stage is still on the stream); a later pass of the same call has
+  // nothing to overlap, and the two event edges cost 4 us each (profiles/r6/README.md).
+  if (flag && first && u->front && v->n_primed == 0 && u->mut_seq + 1 == v->call_seq) {
+    // (no selection made ahead by a streaming call sits in the ring: the next set is free)
+    v->cur_sel = (v->cur_sel + 1) % tf_volume::kSelSets;
+    d.sel = v->selbuf[v->cur_sel];
+    TF_HIP(hipStreamWaitEvent(u->front, u->ev_mut, 0));
+    fs = u->front;
+  }
   if (flag) {
     // PrepareIntersectChunks at the keyframe's pose, without its list ORDER: validChunks = the finalized list in list order,
     // and no order of it is observable through this entry point -- the selection appends straight to a plain list, no scan /
     // write-out launch (k_scan: 17 us per keyframe); the slots, isNew and needsUpdate = false come with the records launch below
     v->frame = img;
     v->frame_bound = true;
-    launch_bbox(d, img.depth, v->cam, P, s);
-    launch_select(d, img.depth, v->cam, v->ig, P, v->res, /*emit=*/true, s, /*plain=*/true);
+    launch_bbox(d, img.depth, v->cam, P, fs);
+    launch_select(d, img.depth, v->cam, v->ig, P, v->res, /*emit=*/true, fs, /*plain=*/true);
   } else {
     hipLaunchKernelGGL(k_kf_load, dim3(256), dim3(256), 0, s, d, u->tab, u->slots, u->arena, kf_slot, g->kf_id);
   }
@@ -129,9 +154,13 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     dd[f] = g->local[f].d_depth;
     memcpy(poses + 12 * f, flag ? g->local[f].pose : g->old_local_pose[f], 48);
   }
-  launch_pre_frames(d, P, g->n_local, poses, u->group_pre, u->group_cen, v->ig, v->res, v->cam, s,
+  launch_pre_frames(d, P, g->n_local, poses, u->group_pre, u->group_cen, v->ig, v->res, v->cam, fs,
                     /*acquire=*/flag ? (g->n_local > 0 ? 2 : 1) : 0,  // (lazily when the group kernel finalizes the list)
                     /*clear_word=*/flag ? nullptr : kf_off(u->tab) + u->slots + kf_slot);  // kf.validChunks.clear() (:217): the list is loaded
+  if (fs != s) {  // join: the group's passes wait for its front end
+    TF_HIP(hipEventRecord(u->ev_front, fs));
+    TF_HIP(hipStreamWaitEvent(s, u->ev_front, 0));
+  }
   // the keyframe's own depth + colour (+ quality) ...  With local frames behind it and no quality image the pass is the
   // first frame of the group kernel's visit (k_integrate_group<., KEY>), not a launch of its own.
   const bool color = img.rgba != nullptr, quality = color && img.quality != nullptr;
@@ -166,6 +195,10 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
     else hipLaunchKernelGGL(k_kf_store, dim3(1), dim3(1024), 0, s, d, sa);
   }
   TF_HIP(hipGetLastError());
+  if (u->ev_mut && last) {  // the call's last launch that changes chunks is on the stream
+    TF_HIP(hipEventRecord(u->ev_mut, s));
+    u->mut_seq = v->call_seq;
+  }
   v->host_list_n = -1;
   return TF_OK;
 }
@@ -281,14 +314,14 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
     const int slot = slot_for(moved[m].kf_id, false);
     if (slot < 0) { set_error("a moved keyframe was never integrated through this entry point"); return TF_ERR_INVALID; }
     if ((rc = integrate_group(v, u, &moved[m], 0, slot, dirty_par, dirty_stamp))) return rc;
-    if ((rc = integrate_group(v, u, &moved[m], 1, slot, dirty_par, dirty_stamp))) return rc;
+    if ((rc = integrate_group(v, u, &moved[m], 1, slot, dirty_par, dirty_stamp, nullptr, false, !fresh && m == n_moved - 1))) return rc;
   }
   KfStoreArgs ride_store{};
   bool have_ride = false;
   if (fresh) {  // :316-323
     const int slot = slot_for(fresh->kf_id, true);
     if (slot < 0) return TF_ERR_HIP;  // (the table could not grow: hipMalloc's message is in tf_last_error)
-    if ((rc = integrate_group(v, u, fresh, 1, slot, dirty_par, dirty_stamp, texture ? &ride_store : nullptr))) return rc;
+    if ((rc = integrate_group(v, u, fresh, 1, slot, dirty_par, dirty_stamp, texture ? &ride_store : nullptr, n_moved == 0, true))) return rc;
     have_ride = ride_store.tab != nullptr;  // (a group without local frames stored with its dirty-set launch)
   }
   if (texture) {
@@ -370,6 +403,9 @@ int tf_keyframe_unit_release(tf_volume* v) {
   if (u.h_fill) hipHostFree(u.h_fill);
   if (u.group_pre) hipFree(u.group_pre);
   if (u.group_cen) hipFree(u.group_cen);
+  if (u.front) { hipStreamSynchronize(u.front); hipStreamDestroy(u.front); }
+  if (u.ev_mut) hipEventDestroy(u.ev_mut);
+  if (u.ev_front) hipEventDestroy(u.ev_front);
   g_units.erase(it);
   return TF_OK;
 }

@@ -35,7 +35,7 @@ for step in "$@"; do
             (cd /tmp && rocprofv3 --pmc WRITE_SIZE --output-format csv -d $U/write -o t -- python3 $OLDPWD/tools/prof_unit.py --run $MV > $U/write.log 2>&1)
             T=$(find $U/trace -name "*kernel_trace.csv" | head -1); F=$(find $U/fetch -name "*counter_collection.csv" | head -1); W=$(find $U/write -name "*counter_collection.csv" | head -1)
             S=$(find $U/trace -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $U/kernel_stats.csv
-            python3 tools/prof_unit.py --summarize "$T" "$F" "$W" $U/counts.json > $U/summary.json 2> $U/summary.err
+            python3 tools/prof_unit.py --summarize "$T" "$F" "$W" $U/counts.json --run-line $U/run_line.json > $U/summary.json 2> $U/summary.err
             rc=$?
             rm -rf $U/trace $U/fetch $U/write
             echo "$step rc=$rc"; cat $U/run_line.json; tail -c 1800 $U/summary.json; tail -n 3 $U/summary.err; tail -n 3 $U/count.err ;;

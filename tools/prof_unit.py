@@ -162,10 +162,20 @@ def _window(rows):
     return [(d, n, v) for d, n, v in rows if lo < d < hi]
 
 
-def summarize(trace, fetch, write, counts):
+def summarize(trace, fetch, write, counts, run_line=None):
     cnt = json.loads(open(counts).read().strip().splitlines()[-1])
     K = cnt["keyframes"]
     per = {}
+    # (round 6: a call's front end runs on a stream of its own beside the previous call's texture stage -- the SUM of the
+    # kernel durations counts that time twice; the span of the window and the un-profiled wall time per keyframe do not)
+    se = _window(_rows(trace, lambda r: (int(r["Start_Timestamp"]), int(r["End_Timestamp"]))))
+    span_us = 1e-3 * (max(v[1] for _, _, v in se) - min(v[0] for _, _, v in se)) / K if se else 0.0
+    wall_us = None
+    if run_line and os.path.exists(run_line):
+        try:
+            wall_us = 1e3 * json.loads(open(run_line).read().strip().splitlines()[-1])["ms_per_keyframe"]
+        except Exception:
+            wall_us = None
     for _, n, v in _window(_rows(trace, lambda r: 1e-3 * (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))):
         e = per.setdefault(n, {"us": 0.0, "launches": 0.0, "fetch_B": 0.0, "write_B": 0.0})
         e["us"] += v / K
@@ -180,7 +190,9 @@ def summarize(trace, fetch, write, counts):
     out = {"unit": "per keyframe (1 colour + 6 depth-only frames, meshes, patches, atlas)", "keyframes": K,
            "kernel_us_per_keyframe": tot_us, "algorithmic_bytes_per_keyframe": cnt["algorithmic_bytes_per_keyframe"],
            "roofline": {"bound": "hbm", "achieved_GBs": alg / tot_us / 1e3 if tot_us else 0.0, "peak_GBs": 8000.0,
-                        "frac": alg / tot_us / 1e3 / 8000.0 if tot_us else 0.0, "traffic_bytes_per_keyframe": tot_b or None},
+                        "frac": alg / tot_us / 1e3 / 8000.0 if tot_us else 0.0, "traffic_bytes_per_keyframe": tot_b or None,
+                        "span_us_per_keyframe_profiled": span_us, "frac_span": alg / span_us / 1e3 / 8000.0 if span_us else None,
+                        "wall_us_per_keyframe": wall_us, "frac_wall": alg / wall_us / 1e3 / 8000.0 if wall_us else None},
            "kernels": {k: {kk: round(vv, 3) for kk, vv in e.items()} for k, e in sorted(per.items(), key=lambda kv: -kv[1]["us"])},
            "counts_per_keyframe": cnt["per_keyframe"],
            "pmc": "FETCH_SIZE x 2048 + WRITE_SIZE x 1024 bytes (profiles/r2/README.md calibration), separate passes"}
@@ -193,10 +205,11 @@ if __name__ == "__main__":
     ap.add_argument("--count", action="store_true")
     ap.add_argument("--moved", action="store_true", help="one moved keyframe in every other call")
     ap.add_argument("--summarize", nargs=4, metavar=("TRACE", "FETCH", "WRITE", "COUNTS"))
+    ap.add_argument("--run-line", default=None, help="--summarize: the un-profiled --run output (wall time per keyframe)")
     a = ap.parse_args()
     if a.run:
         run(a.moved)
     elif a.count:
         count(a.moved)
     elif a.summarize:
-        summarize(*a.summarize)
+        summarize(*a.summarize, run_line=a.run_line)
