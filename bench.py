@@ -285,113 +285,137 @@ def spawn_ranks(args):
     return rc
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.child:
-        raise SystemExit(spawn_ranks(args))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if "TF_BENCH_DEVICE" in os.environ:  # test hook: several ranks on one GPU (with TF_BENCH_BACKEND=gloo)
-        local_rank = int(os.environ["TF_BENCH_DEVICE"])
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+class Job:
+    """One rank's run of the benchmark: the synthetic stream (host + HBM copies), the volume, the transport of an N > 1 run, and
+    `pos`, the position in the stream.  main() calls the phases in order; every window of the line (timed, repeats, resident,
+    the other host-frame entry points, events) is one method that starts at the timed window's orbit position."""
 
-    if world > 1:
-        # N ranks share the container's CPU quota (16 CPUs on the 1-GPU boxes): a rank's host thread sleeps between polls of
-        # "is my upload / my staging slot through" instead of spinning, so that eight ranks and their RCCL proxy threads do
-        # not exhaust a period's budget and get the whole job frozen (profiles/r4/README.md, "Host frames")
-        os.environ.setdefault("TF_HOST_POLL_SLEEP_US", "20")
-    orig_affinity, numa_note = pin_to_numa_node(local_rank)  # before any buffer is allocated
-    from texturefusion_amd import synth
-    cam = synth.Camera.hires() if args.hires else synth.Camera()
-    h_depth, h_rgba, h_pose = load_stream(args, cam)  # CPU only: before the child passes, before any GPU use
+    # ---- phase 0: environment, affinity, the stream on the host (CPU only) ------------------------------------------
+    def __init__(self, args):
+        self.args = args
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if "TF_BENCH_DEVICE" in os.environ:  # test hook: several ranks on one GPU (with TF_BENCH_BACKEND=gloo)
+            self.local_rank = int(os.environ["TF_BENCH_DEVICE"])
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, self.world))
+        if self.world > 1:
+            # N ranks share the container's CPU quota (16 CPUs on the 1-GPU boxes): a rank's host thread sleeps between polls of
+            # "is my upload / my staging slot through" instead of spinning, so that eight ranks and their RCCL proxy threads do
+            # not exhaust a period's budget and get the whole job frozen (profiles/r4/README.md, "Host frames")
+            os.environ.setdefault("TF_HOST_POLL_SLEEP_US", "20")
+        self.orig_affinity, self.numa_note = pin_to_numa_node(self.local_rank)  # before any buffer is allocated
+        from texturefusion_amd import synth
+        self.synth = synth
+        self.cam = synth.Camera.hires() if args.hires else synth.Camera()
+        self.h_depth, self.h_rgba, self.h_pose = load_stream(args, self.cam)  # CPU only: before the child passes, before any GPU use
+        if args.child:
+            args.no_roofline = args.no_group = True
+            args.cpu_frames = 0
+        self.side = self.prof_child = None
+        self.pos = 0
 
-    if args.child:
-        args.no_roofline = args.no_group = True
-        args.cpu_frames = 0
-    # profiler child passes first, before this process touches the GPU
-    # The other single-GPU configurations of BASELINE.json come FIRST, each a bench.py process of its own (the default line
-    # carries their headline figures as scalars); then the profiler child passes of this line.  All of them before this process
-    # touches the GPU -- and in this order because VRAM a process leaves behind is wiped in the background with the DMA
-    # engines the host-frame uploads use: the hall's tens of GB are wiped while the profiler passes run,
-    # and what is left ahead of this line's own windows is what every earlier round's line had.
-    side = None
-    default_line = (world == 1 and args.mode == "textured" and args.scene == "room" and not args.hires and not args.child
-                    and not args.force_exchange and not args.resident_headline and not args.no_preroll)
-    if default_line and not args.no_side and not args.no_roofline and not under_profiler():
-        side = side_runs(args)
-    prof_child = None
-    if world == 1 and not (args.no_pmc or args.child or args.no_roofline or args.force_exchange):
-        prof_child = {"error": "running under a profiler"} if under_profiler() else child_passes(args)
+    # ---- phase 1: the processes that must run BEFORE this one touches the GPU ------------------------------------------
+    def children(self):
+        # The other single-GPU configurations of BASELINE.json come FIRST, each a bench.py process of its own (the default line
+        # carries their headline figures as scalars); then the profiler child passes of this line.  All of them before this process
+        # touches the GPU -- and in this order because VRAM a process leaves behind is wiped in the background with the DMA
+        # engines the host-frame uploads use (DESIGN.md s.9 item 3): the hall's tens of GB are wiped while the profiler passes run,
+        # and what is left ahead of this line's own windows is what every earlier round's line had.
+        args, world = self.args, self.world
+        default_line = (world == 1 and args.mode == "textured" and args.scene == "room" and not args.hires and not args.child
+                        and not args.force_exchange and not args.resident_headline and not args.no_preroll)
+        if default_line and not args.no_side and not args.no_roofline and not under_profiler():
+            self.side = side_runs(args)
+        if world == 1 and not (args.no_pmc or args.child or args.no_roofline or args.force_exchange):
+            self.prof_child = {"error": "running under a profiler"} if under_profiler() else child_passes(args)
 
-    import torch  # plumbing: device memory for the frames, barrier/collectives, device sync
-    import torch.distributed as dist
-    torch.set_num_threads(1)  # (no CPU tensor work here; an idle OpenMP pool would only burn the container's CPU quota)
+    # ---- phase 2: the device, the process group, the stream once more in HBM -------------------------------------------
+    def device(self):
+        args = self.args
+        import torch  # plumbing: device memory for the frames, barrier/collectives, device sync
+        import torch.distributed as dist
+        torch.set_num_threads(1)  # (no CPU tensor work here; an idle OpenMP pool would only burn the container's CPU quota)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        self.torch, self.dist = torch, dist
+        self.dev = dev = torch.device("cuda", self.local_rank)
+        self.multi = self.world > 1 or args.force_exchange
+        if self.multi:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29513")
+            backend = os.environ.get("TF_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=self.rank, world_size=self.world)
+        from texturefusion_amd import capi
+        from texturefusion_amd import partition as part
+        self.capi, self.part = capi, part
+        self.res = np.float32(args.res)
+        self.K, self.Wm = args.steps, args.warmup
+        self.ORBIT = self.n_unique = n_unique = args.unique_frames
+        self.textured = args.mode == "textured"
+        # the stream once more in HBM (pre-roll, resident / event / replay passes)
+        self.d_depth = [torch.from_numpy(self.h_depth[k]).to(dev) for k in range(n_unique)]
+        self.d_rgba = [torch.from_numpy(self.h_rgba[k]).to(dev) for k in range(n_unique)]
+        self.poses = self.h_pose.reshape(n_unique, 12).astype(np.float32)
+        self.pinv = np.stack([self.synth.pose_inverse16(self.h_pose[k]) for k in range(n_unique)]).astype(np.float32)
+        torch.cuda.synchronize()
+        # (addresses of the frames' arrays, taken once: the driver loop is Python, and turning four numpy arrays into ctypes
+        # pointers costs ~10 us per call -- a tenth of a step -- that a C++ caller does not pay)
+        self.a_depth = [self.h_depth[i].ctypes.data for i in range(n_unique)]
+        self.a_rgba = [self.h_rgba[i].ctypes.data for i in range(n_unique)]
+        self.a_pose = [self.poses[i].ctypes.data for i in range(n_unique)]
+        self.a_pinv = [self.pinv[i].ctypes.data for i in range(n_unique)]
+        self.quota = cgroup_cpu_quota()
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    multi = world > 1 or args.force_exchange
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29513")
-        backend = os.environ.get("TF_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    # ---- phase 3: the volume, the caller's buffers ------------------------------------------------------------------
+    def volume(self):
+        args, torch = self.args, self.torch
+        self.s_main = torch.cuda.Stream(device=self.dev) if self.multi else None
+        self.big = big = args.scene == "big"
+        pool = (1 << args.max_chunks_log2) if args.max_chunks_log2 > 0 else ((1 << 21) if big else (1 << 19))
+        # (mesh_blocks: the library's default gives every pool slot a mesh block, as the reference's allMeshes can hold one per
+        # chunk; the bench knows its scenes -- under a third of a scanned scene's chunks lie on a surface -- and takes a quarter,
+        # which keeps the volumes at the footprint every earlier round measured: 2.7 GB instead of 10.7 GB of store for the room)
+        self.vol = self.capi.Volume(self.res, self.cam, max_chunks=pool, max_list=(1 << 20) if big else (1 << 18), mesh_blocks=pool // 4,
+                                    max_coarse=1 << 22 if big else 1 << 20, device=self.local_rank,
+                                    stream=self.s_main.cuda_stream if self.multi else None)
+        # The caller's frame buffers are registered once, as a caller with a fixed set of image buffers does at start-up; host
+        # frames then go up straight out of them (no staging copy, ONE host thread, the call returns when the upload is through).
+        # --staged-host-frames: the copy through the library's pinned slots (any caller buffer, nothing registered) -- faster on
+        # a quiet host (its upload is asynchronous), but its eight copy threads must all be scheduled promptly: on the shared
+        # hosts of the GPU boxes (load average 20-40, a CFS quota of 16 CPUs) the same build measured 59-116 us per TSDF-only
+        # frame from box to box, against 80-82 us with registered buffers on every one of them (profiles/r4/README.md).
+        self.host_registered = False
+        if not args.staged_host_frames:
+            try:
+                self.vol.host_register(self.h_depth)  # (the two arrays that hold the orbit's images)
+                self.vol.host_register(self.h_rgba)
+                self.host_registered = True
+            except Exception as e:  # (e.g. a locked-memory limit: the staging path works everywhere)
+                print("bench: tf_host_register failed (%r): host frames take the staging path" % (e,), file=sys.stderr)
+        self.use_rccl = False
+        self.cap = args.exchange_cap
+        self.torch_wire = [0, 0]  # bytes sent / received through the torch transport
+        self.part_spec = None
 
-    from texturefusion_amd import capi
-    from texturefusion_amd import partition as part
-
-    res = np.float32(args.res)
-    K, Wm = args.steps, args.warmup
-    ORBIT = n_unique = args.unique_frames
-    textured = args.mode == "textured"
-
-    # ---- the stream once more in HBM (pre-roll, resident / event / replay passes) -------------
-    d_depth = [torch.from_numpy(h_depth[k]).to(dev) for k in range(n_unique)]
-    d_rgba = [torch.from_numpy(h_rgba[k]).to(dev) for k in range(n_unique)]
-    poses = h_pose.reshape(n_unique, 12).astype(np.float32)
-    pinv = np.stack([synth.pose_inverse16(h_pose[k]) for k in range(n_unique)]).astype(np.float32)
-    torch.cuda.synchronize()
-
-    s_main = torch.cuda.Stream(device=dev) if multi else None
-    big = args.scene == "big"
-    pool = (1 << args.max_chunks_log2) if args.max_chunks_log2 > 0 else ((1 << 21) if big else (1 << 19))
-    # (mesh_blocks: the library's default gives every pool slot a mesh block, as the reference's allMeshes can hold one per
-    # chunk; the bench knows its scenes -- under a third of a scanned scene's chunks lie on a surface -- and takes a quarter,
-    # which keeps the volumes at the footprint every earlier round measured: 2.7 GB instead of 10.7 GB of store for the room)
-    vol = capi.Volume(res, cam, max_chunks=pool, max_list=(1 << 20) if big else (1 << 18), mesh_blocks=pool // 4,
-                      max_coarse=1 << 22 if big else 1 << 20, device=local_rank,
-                      stream=s_main.cuda_stream if multi else None)
-    # The caller's frame buffers are registered once, as a caller with a fixed set of image buffers does at start-up; host
-    # frames then go up straight out of them (no staging copy, ONE host thread, the call returns when the upload is through).
-    # --staged-host-frames: the copy through the library's pinned slots (any caller buffer, nothing registered) -- faster on
-    # a quiet host (its upload is asynchronous), but its eight copy threads must all be scheduled promptly: on the shared
-    # hosts of the GPU boxes (load average 20-40, a CFS quota of 16 CPUs) the same build measured 59-116 us per TSDF-only
-    # frame from box to box, against 80-82 us with registered buffers on every one of them (profiles/r4/README.md).
-    host_registered = False
-    if not args.staged_host_frames:
-        try:
-            vol.host_register(h_depth)  # (the two arrays that hold the orbit's images)
-            vol.host_register(h_rgba)
-            host_registered = True
-        except Exception as e:  # (e.g. a locked-memory limit: the staging path works everywhere)
-            print("bench: tf_host_register failed (%r): host frames take the staging path" % (e,), file=sys.stderr)
-    use_rccl = False
-    if multi:
+    # ---- phase 4 (N > 1, --force-exchange): the partition and the transport ----------------------------------------
+    def partition(self):
+        args, torch, dist, vol, capi, part = self.args, self.torch, self.dist, self.vol, self.capi, self.part
+        rank, world, dev, cap = self.rank, self.world, self.dev, self.cap
         # Ownership key x + y + z: axis-aligned walls and floors are cut diagonally, so no rank holds a
         # whole wall.  Slab edges split the chunk keys of eight sample frames spread over the orbit into
         # equally populated slabs; every rank computes them itself (selection is deterministic), so
         # nothing has to be communicated.
         axis = (1, 1, 1)
         keys = []
-        for i in range(0, ORBIT, max(1, ORBIT // 8)):
-            vol.frame_upload(h_depth[i], None, None)
-            ids_s, _ = vol.prepare(h_pose[i])
+        for i in range(0, self.ORBIT, max(1, self.ORBIT // 8)):
+            vol.frame_upload(self.h_depth[i], None, None)
+            ids_s, _ = vol.prepare(self.h_pose[i])
             keys.append(part.key_of(ids_s, axis))
         vol.reset()
         edges = part.balanced_edges(np.concatenate(keys), max(world, 2) if args.force_exchange and world == 1 else world)
@@ -399,14 +423,14 @@ def main():
         if args.force_exchange and world == 1:
             lo, hi = edges[1] - 12, edges[1] + 12  # a real interior slab so that faces exist and get packed
         vol.set_partition(lo, hi, axis)
+        self.part_spec = (lo, hi, axis)
         # The exchange: fixed-capacity [count | records] blocks, no host round trip.
         # backend nccl: RCCL inside the library (tf_comm_init / tf_exchange_boundary) on the volume's stream;
         # other backends (test hook: several ranks on one GPU over gloo): the same blocks through torch.distributed.
-        cap = args.exchange_cap
         # (--force-exchange with one rank: the in-library path all the same -- RCCL with a single rank: pack, the exchange's
         # second stream, unpack, the interior / boundary mesh passes; nothing travels)
-        use_rccl = (world > 1 or args.force_exchange) and os.environ.get("TF_BENCH_BACKEND", "nccl") == "nccl"
-        if use_rccl:
+        self.use_rccl = (world > 1 or args.force_exchange) and os.environ.get("TF_BENCH_BACKEND", "nccl") == "nccl"
+        if self.use_rccl:
             uid = torch.zeros(128, dtype=torch.uint8, device=dev)
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(capi.comm_unique_id()), dtype=torch.uint8))
@@ -415,161 +439,173 @@ def main():
             vol.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
             # (neighbour send / receive pairs need every slab above the lowest to hold its own ghost band; the library
             # checks that itself at the first exchange and falls back to the all-gather form on every rank otherwise)
-            if textured:
+            if self.textured:
                 vol.comm_exchange_every_frame(cap)
                 if args.no_overlap:
                     vol.comm_exchange_overlap(False)  # (A/B: the exchange in the stream between the voxel update and the mesher)
         else:
             bb = capi.boundary_block_bytes(cap)
-            blk = torch.zeros(bb, dtype=torch.uint8, device=dev)
-            allb = torch.zeros(bb * max(world, 1), dtype=torch.uint8, device=dev)
-            blk_dn = torch.zeros(bb, dtype=torch.uint8, device=dev)
-            blk_up = torch.zeros(bb, dtype=torch.uint8, device=dev)
-            torch_wire = [0, 0]  # bytes sent / received through the torch transport
+            self.blk = torch.zeros(bb, dtype=torch.uint8, device=dev)
+            self.allb = torch.zeros(bb * max(world, 1), dtype=torch.uint8, device=dev)
+            self.blk_dn = torch.zeros(bb, dtype=torch.uint8, device=dev)
+            self.blk_up = torch.zeros(bb, dtype=torch.uint8, device=dev)
 
-    def torch_exchange(join_dirty):
+    # ---- the stream's moving parts ------------------------------------------------------------------------------------
+    def torch_exchange(self, join_dirty):
         """[count | records] blocks through torch.distributed on the volume's stream (no .item(), no host wait)."""
-        with torch.cuda.stream(s_main):
-            vol.boundary_pack_block(blk.data_ptr(), cap)
-            if world > 1:
-                dist.all_gather_into_tensor(allb, blk)
+        torch, dist, vol = self.torch, self.dist, self.vol
+        with torch.cuda.stream(self.s_main):
+            vol.boundary_pack_block(self.blk.data_ptr(), self.cap)
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.allb, self.blk)
             else:
-                allb.copy_(blk)
-            vol.boundary_unpack_blocks(allb.data_ptr(), max(world, 1), rank, cap, join_dirty=join_dirty)
+                self.allb.copy_(self.blk)
+            vol.boundary_unpack_blocks(self.allb.data_ptr(), max(self.world, 1), self.rank, self.cap, join_dirty=join_dirty)
 
-    def torch_exchange_sized():
+    def torch_exchange_sized(self):
         """The per-frame exchange of the textured unit through torch.distributed in its SIZED neighbour form: the four
         block capacities come from the frame's own selection (tf_boundary_band_bounds: the same numbers on both ends of
         every transfer), so a block is as long as what the frame can have changed."""
         from texturefusion_amd import exchange
-        sd, su, rb, ra = vol.boundary_band_bounds(cap)
-        with torch.cuda.stream(s_main):
-            vol.boundary_pack_bands2(blk_dn.data_ptr(), sd, blk_up.data_ptr(), su)
+        torch, vol, capi, rank, world, dev = self.torch, self.vol, self.capi, self.rank, self.world, self.dev
+        sd, su, rb, ra = vol.boundary_band_bounds(self.cap)
+        with torch.cuda.stream(self.s_main):
+            vol.boundary_pack_bands2(self.blk_dn.data_ptr(), sd, self.blk_up.data_ptr(), su)
             nd, nu = capi.boundary_block_bytes(sd), capi.boundary_block_bytes(su)
             if world > 1:
-                s_main.synchronize()  # (gloo moves host copies; RCCL inside the library needs none of this)
-                below, above = exchange.neighbour_exchange_sized(blk_dn[:nd].cpu(), blk_up[:nu].cpu(),
+                self.s_main.synchronize()  # (gloo moves host copies; RCCL inside the library needs none of this)
+                below, above = exchange.neighbour_exchange_sized(self.blk_dn[:nd].cpu(), self.blk_up[:nu].cpu(),
                                                                  capi.boundary_block_bytes(rb), capi.boundary_block_bytes(ra))
                 below, above = below.to(dev), above.to(dev)
-                torch_wire[0] += (nd if rank > 0 else 0) + (nu if rank + 1 < world else 0)
-                torch_wire[1] += (below.numel() if rank > 0 else 0) + (above.numel() if rank + 1 < world else 0)
+                self.torch_wire[0] += (nd if rank > 0 else 0) + (nu if rank + 1 < world else 0)
+                self.torch_wire[1] += (below.numel() if rank > 0 else 0) + (above.numel() if rank + 1 < world else 0)
             else:
                 below = torch.zeros(16, dtype=torch.uint8, device=dev)
                 above = torch.zeros(16, dtype=torch.uint8, device=dev)
             vol.boundary_unpack_pair(below.data_ptr(), rb, above.data_ptr(), ra, join_dirty=True)
-            s_main.synchronize()  # (below / above are temporaries)
+            self.s_main.synchronize()  # (below / above are temporaries)
 
-    def run(first, count, ahead=2):
+    def run(self, first, count, ahead=2):
         """Frames [first, first+count) of the stream (cyclic over the orbit), images already in HBM; the next `ahead`
         frames go through their selection stages too, so that a following run(first + count, ...) starts primed."""
-        idx = [(first + i) % n_unique for i in range(count + ahead)]
+        vol, d_depth, d_rgba, poses, pinv = self.vol, self.d_depth, self.d_rgba, self.poses, self.pinv
+        idx = [(first + i) % self.n_unique for i in range(count + ahead)]
         dd = [d_depth[i].data_ptr() for i in idx]
         dr = [d_rgba[i].data_ptr() for i in idx]
-        if textured and (not multi or use_rccl):
+        if self.textured and (not self.multi or self.use_rccl):
             vol.stream_frames_textured_device(dd, dr, poses[idx], pinv[idx], first, n_ahead=ahead)  # N>1: exchange inside
-        elif not multi:
+        elif not self.multi:
             vol.stream_frames_device(dd, dr, poses[idx], n_ahead=ahead)
-        elif textured:  # torch transport: voxel update, exchange, texture stage -- frame by frame
+        elif self.textured:  # torch transport: voxel update, exchange, texture stage -- frame by frame
             for j in range(count):
                 sub = idx[j:j + 1 + min(2, count + ahead - j - 1)]
                 vol.stream_frames_device([d_depth[i].data_ptr() for i in sub], [d_rgba[i].data_ptr() for i in sub],
                                          poses[sub], n_ahead=len(sub) - 1)
-                torch_exchange_sized()
+                self.torch_exchange_sized()
                 vol.texture_frame_device(pinv[idx[j]], first + j)
         else:  # TSDF only: batches of --exchange-every frames, one exchange behind each
-            for b in range(0, count, args.exchange_every):
-                e = min(b + args.exchange_every, count)
+            every = self.args.exchange_every
+            for b in range(0, count, every):
+                e = min(b + every, count)
                 sub = idx[b:e + (ahead if e == count else 0)]
                 vol.stream_frames_device([d_depth[i].data_ptr() for i in sub], [d_rgba[i].data_ptr() for i in sub],
                                          poses[sub], n_ahead=len(sub) - (e - b))
-                if use_rccl:
-                    vol.exchange_boundary(cap)
+                if self.use_rccl:
+                    vol.exchange_boundary(self.cap)
                 else:
-                    torch_exchange(False)
+                    self.torch_exchange(False)
 
-    # host frames: the reference's calling convention.  Every rank of an N > 1 run is handed every frame.
-    host_ok = (not multi) or (use_rccl and textured)
-
-    def run_host(first, count):
+    def run_host(self, first, count):
         """Frames [first, first+count) as HOST images, one tf_integrate_frame_host call per frame (staging copy into
         pinned memory + H2D inside).  The entry point runs tf_host_frame_deferral() = four frames behind the caller (its
         launch for frame f carries the voxel update of f - 4 next to the selection stages of f - 3 and f - 2), so `count`
         calls put `count` frames' H2D copies and `count` frames' kernels on the device."""
+        vol, a_depth, a_rgba, a_pose, a_pinv, textured, n_unique = (self.vol, self.a_depth, self.a_rgba, self.a_pose, self.a_pinv,
+                                                                    self.textured, self.n_unique)
         for j in range(count):
             i = (first + j) % n_unique
             vol.integrate_frame_host_addr(a_depth[i], a_rgba[i], a_pose[i], a_pinv[i] if textured else 0, first + j)
 
-    # (addresses of the frames' arrays, taken once: the driver loop is Python, and turning four numpy arrays into ctypes
-    # pointers costs ~10 us per call -- a tenth of a step -- that a C++ caller does not pay)
-    a_depth = [h_depth[i].ctypes.data for i in range(n_unique)]
-    a_rgba = [h_rgba[i].ctypes.data for i in range(n_unique)]
-    a_pose = [poses[i].ctypes.data for i in range(n_unique)]
-    a_pinv = [pinv[i].ctypes.data for i in range(n_unique)]
+    def barrier(self):
+        if self.multi:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
 
-    def barrier():
-        if multi:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    quota = cgroup_cpu_quota()
-
-    def fresh_period():
+    def fresh_period(self):
         """The GPU boxes run this process under a CFS quota (cpu.max: e.g. 16 CPUs per 100 ms on a 256-CPU host): a burst of
         many runnable threads ahead of a timed window (image upload, registration, the profiler child passes, the runtime's
         helper threads) can exhaust the period's budget, and the kernel then freezes EVERY thread of the container until the
         period ends -- tens of milliseconds inside a 2-ms window.  A window's own work needs well under the quota; waiting
         out one period before the warm-up frames lets it start with a full budget."""
-        if quota is not None:
-            torch.cuda.synchronize()
+        if self.quota is not None:
+            self.torch.cuda.synchronize()
             time.sleep(0.12)
 
-    # ---- pre-roll (one orbit, untimed), warm-up, then the timed region --------------------------
-    # (the driver loop is Python: a cyclic-GC pass over torch's and numpy's objects takes milliseconds -- longer than the
-    # whole window at the driver's --steps 20 -- and has nothing to do with the path; nothing below builds cycles)
-    import gc
-    gc.collect()
-    gc.freeze()
-    gc.disable()
-    pos = 0
-    if not args.no_preroll:
-        run(0, ORBIT)
-        pos = ORBIT
-    # N > 1: the order of the per-frame exchange -- on the library's second stream next to the interior mesh pass, or in the
-    # main stream between the voxel update and the mesher -- is picked by measurement: the overlapped order costs a second
-    # filter + mesher pass and a stream fork / join per frame and pays only when the wire time exceeds that
-    exchange_order = None
-    if use_rccl and textured and not args.no_overlap and not args.child:
+    def skip_to_window(self):
+        """advance the stream (untimed, resident frames) to the timed window's orbit position in the next turn"""
+        nxt = self.pos + ((self.p0 - self.pos) % self.ORBIT)
+        if nxt > self.pos:
+            self.run(self.pos, nxt - self.pos)
+        self.pos = nxt
+
+    def land_before_window(self):
+        """... to Wm frames ahead of it: a window that warms its own entry point up over those frames"""
+        nxt = self.pos + ((self.p0 - self.Wm - self.pos) % self.ORBIT)
+        if nxt > self.pos:
+            self.run(self.pos, nxt - self.pos)
+        self.pos = nxt
+
+    # ---- phase 5: pre-roll, (N > 1) the order of the exchange, the link --------------------------------------------
+    def preroll(self):
+        # (the driver loop is Python: a cyclic-GC pass over torch's and numpy's objects takes milliseconds -- longer than the
+        # whole window at the driver's --steps 20 -- and has nothing to do with the path; nothing below builds cycles)
+        import gc
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+        self.pos = 0
+        if not self.args.no_preroll:
+            self.run(0, self.ORBIT)
+            self.pos = self.ORBIT
+
+    def pick_exchange_order(self):
+        """N > 1: the order of the per-frame exchange -- on the library's second stream next to the interior mesh pass, or in the
+        main stream between the voxel update and the mesher -- is picked by measurement: the overlapped order costs a second
+        filter + mesher pass and a stream fork / join per frame and pays only when the wire time exceeds that"""
+        args, torch, dist, vol = self.args, self.torch, self.dist, self.vol
+        if not (self.use_rccl and self.textured and not args.no_overlap and not args.child):
+            return None
         t_ord = {}
         for on in (True, False):
             vol.comm_exchange_overlap(on)
-            run(pos, 8)
+            self.run(self.pos, 8)
             vol.sync()
-            barrier()
+            self.barrier()
             tq = time.perf_counter()
-            run(pos + 8, 24)
+            self.run(self.pos + 8, 24)
             vol.sync()
-            barrier()
-            tt = torch.tensor([time.perf_counter() - tq], dtype=torch.float64, device=dev)
-            if world > 1:
+            self.barrier()
+            tt = torch.tensor([time.perf_counter() - tq], dtype=torch.float64, device=self.dev)
+            if self.world > 1:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t_ord[on] = float(tt.item()) / 24
-            pos += 32
+            self.pos += 32
         pick = t_ord[True] <= t_ord[False]
         vol.comm_exchange_overlap(pick)
-        exchange_order = {"picked": "overlapped with the interior mesh pass" if pick else "serial, between voxel update and mesher",
-                          "us_per_frame_overlapped": 1e6 * t_ord[True], "us_per_frame_serial": 1e6 * t_ord[False],
-                          "how": "24 resident frames each way behind 8 warm-up frames, max over ranks; the faster order runs the timed window"}
-    p0 = pos + Wm  # stream position of the timed window; p0 % ORBIT = its orbit position
-    use_host = host_ok and not args.resident_headline
-    host_phases = None
-    # VRAM that earlier processes of this job left behind (the profiler child passes, the side runs) is wiped in the background
-    # with the DMA engines the host-frame uploads use: for a while after such a process ends, a 2.46 MB upload takes 250 us
-    # instead of 53 (DESIGN.md s.9 item 3; a window of r6 measured exactly that).  One frame's worth of bytes is uploaded until
-    # the link is back at its rate (at most 3 s), before -- not inside -- the timed region.
-    link_settle = None
-    if use_host and world == 1:
-        probe_h = torch.empty(h_depth[0].nbytes + h_rgba[0].nbytes, dtype=torch.uint8).pin_memory()
-        probe_d = torch.empty_like(probe_h, device=dev)
+        return {"picked": "overlapped with the interior mesh pass" if pick else "serial, between voxel update and mesher",
+                "us_per_frame_overlapped": 1e6 * t_ord[True], "us_per_frame_serial": 1e6 * t_ord[False],
+                "how": "24 resident frames each way behind 8 warm-up frames, max over ranks; the faster order runs the timed window"}
+
+    def settle_link(self):
+        """VRAM that earlier processes of this job left behind (the profiler child passes, the side runs) is wiped in the background
+        with the DMA engines the host-frame uploads use: for a while after such a process ends, a 2.46 MB upload takes 250 us
+        instead of 53 (a window of r6 measured exactly that).  One frame's worth of bytes is uploaded until
+        the link is back at its rate (at most 3 s), before -- not inside -- the timed region."""
+        torch = self.torch
+        if not (self.use_host and self.world == 1):
+            return None
+        probe_h = torch.empty(self.h_depth[0].nbytes + self.h_rgba[0].nbytes, dtype=torch.uint8).pin_memory()
+        probe_d = torch.empty_like(probe_h, device=self.dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         best, tries, last = None, 0, None
         for tries in range(1, 31):
@@ -580,52 +616,64 @@ def main():
             if tries >= 3 and ok:
                 break
             time.sleep(0.0 if ok else 0.1)
-        link_settle = {"probes": tries, "last_upload_us": last, "best_upload_us": best, "bytes": int(probe_h.numel())}
-        del probe_h, probe_d
-    fresh_period()
-    if use_host:
-        run_host(pos, Wm)  # (leaves the entry point's four-frame pipeline primed)
-        barrier()
-        vol.host_frame_times(reset=True)
-        t0 = time.perf_counter()
-        run_host(p0, K)
-        t_enq = time.perf_counter() - t0
-        barrier()
-        dt = time.perf_counter() - t0
-        host_phases = vol.host_frame_times(reset=True)
-    else:
-        run(pos, Wm)
-        vol.sync()
-        barrier()
-        t0 = time.perf_counter()
-        run(p0, K)
-        t_enq = time.perf_counter() - t0  # host time to enqueue the timed region (launches are asynchronous)
-        barrier()
-        dt = time.perf_counter() - t0
-    vol.sync()  # brings the deferred frames onto the stream; surfaces any device-side capacity error
-    pos = p0 + K
-    per_rank = None
-    if multi:
-        # per rank: its own wall time for the K frames and what the exchange moved (tf_comm_stats_ex: counted since the
-        # volume was made, i.e. over pre-roll + warm-up + timed frames)
+        return {"probes": tries, "last_upload_us": last, "best_upload_us": best, "bytes": int(probe_h.numel())}
+
+    # ---- phase 6: warm-up and THE timed region ----------------------------------------------------------------------
+    def timed_window(self):
+        """W untimed warm-up steps, then exactly K steps between two barrier + device-synchronise pairs -> self.dt (seconds),
+        self.t_enq (host time to enqueue them), self.host_phases."""
+        vol, K, Wm = self.vol, self.K, self.Wm
+        self.p0 = self.pos + Wm  # stream position of the timed window; p0 % ORBIT = its orbit position
+        # host frames: the reference's calling convention.  Every rank of an N > 1 run is handed every frame.
+        host_ok = (not self.multi) or (self.use_rccl and self.textured)
+        self.use_host = host_ok and not self.args.resident_headline
+        self.host_phases = None
+        self.link_settle = self.settle_link()
+        self.fresh_period()
+        if self.use_host:
+            self.run_host(self.pos, Wm)  # (leaves the entry point's four-frame pipeline primed)
+            self.barrier()
+            vol.host_frame_times(reset=True)
+            t0 = time.perf_counter()
+            self.run_host(self.p0, K)
+            self.t_enq = time.perf_counter() - t0
+            self.barrier()
+            self.dt = time.perf_counter() - t0
+            self.host_phases = vol.host_frame_times(reset=True)
+        else:
+            self.run(self.pos, Wm)
+            vol.sync()
+            self.barrier()
+            t0 = time.perf_counter()
+            self.run(self.p0, K)
+            self.t_enq = time.perf_counter() - t0  # host time to enqueue the timed region (launches are asynchronous)
+            self.barrier()
+            self.dt = time.perf_counter() - t0
+        vol.sync()  # brings the deferred frames onto the stream; surfaces any device-side capacity error
+        self.pos = self.p0 + K
+
+    def rank_stats(self):
+        """N > 1: per rank its own wall time for the K frames and what the exchange moved (tf_comm_stats_ex: counted since the
+        volume was made, i.e. over pre-roll + warm-up + timed frames); self.dt becomes the MAX over ranks."""
+        args, torch, dist, vol, K = self.args, self.torch, self.dist, self.vol, self.K
         st = vol.comm_stats_ex()
-        if not use_rccl and textured:
-            st["bytes_sent"], st["bytes_received"] = torch_wire
-        mine = {"rank": rank, "ms_per_step": 1e3 * dt / K, "exchanges": st["exchanges"],
+        if not self.use_rccl and self.textured:
+            st["bytes_sent"], st["bytes_received"] = self.torch_wire
+        mine = {"rank": self.rank, "ms_per_step": 1e3 * self.dt / K, "exchanges": st["exchanges"],
                 "exchange_bytes_sent": st["bytes_sent"], "exchange_bytes_received": st["bytes_received"],
                 "ghost_records_packed": st["records_sent"], "ghost_records_received": st["records_received"],
                 "bytes_received_per_record_received": (st["bytes_received"] / st["records_received"]) if st["records_received"] else None,
                 "exchange_form": "neighbours (sized by the frame's selection)" if st["mode"] == 0 else "all-gather (fixed capacity)",
-                "transport": "RCCL inside the library" if use_rccl else "torch.distributed test hook"}
-        if use_rccl and textured and not args.child:
+                "transport": "RCCL inside the library" if self.use_rccl else "torch.distributed test hook"}
+        if self.use_rccl and self.textured and not args.child:
             # the same window once more with HIP events around every launch and around the exchange (untimed diagnostic)
             vol.sync()
             vol.profile_enable(("integrate", "dirty", "mesh", "xchg", "xchg_wait"))
-            run(pos, K)
+            self.run(self.pos, K)
             vol.sync()
             pr = vol.profile_get(reset=True)
             vol.profile_enable(())
-            pos += K
+            self.pos += K
             mine["event_us_per_step"] = {k: 1e3 * pr[k][0] / K for k in ("integrate", "dirty", "mesh", "xchg", "xchg_wait") if pr[k][1]}
             # the exchange runs on the library's second stream next to the interior mesh pass: what the main stream still
             # waits for it is exposed, the rest hidden (an event pair costs ~6 us by itself: small values are that floor)
@@ -635,274 +683,293 @@ def main():
                 mine["exchange_us_exposed"] = x_wait
                 mine["exchange_us_hidden"] = max(0.0, x_all - x_wait)
         mine["exchanges_overlapped_with_interior_meshes"] = st.get("overlapped", 0)
-        gathered = [None] * world if world > 1 else [mine]
-        if world > 1:
+        gathered = [None] * self.world if self.world > 1 else [mine]
+        if self.world > 1:
             dist.all_gather_object(gathered, mine)
-        per_rank = gathered
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([self.dt], dtype=torch.float64, device=self.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    if args.child:  # profiler child pass: the workload above is all there is
-        vol.close()
-        return
+        self.dt = float(t.item())
+        return gathered
 
-    # ---- N > 1: the same N GPUs as N INDEPENDENT streams (one whole volume per GPU, no partition, no exchange: SURVEY.md
-    # s.8(e)'s stated fallback, "replicas") and the sharded keyframe unit -- printed next to the strong-scaling `value`
-    indep = sharded_unit = None
-    if multi and not args.no_independent:
+    def replicas(self):
+        """N > 1: the same N GPUs as N INDEPENDENT streams (one whole volume per GPU, no partition, no exchange: SURVEY.md
+        s.8(e)'s stated fallback, "replicas") and the sharded keyframe unit -- printed next to the strong-scaling `value`.
+        Closes the partitioned volume."""
+        args = self.args
+        indep = sharded_unit = None
         # (the partitioned volume stays open through the replica's run: the library counts registrations of the caller's
         # arrays per process -- and on this ROCm a volume destroyed BEFORE another one streams host frames leaves that one's
         # uploads at ~10 GB/s instead of ~40 for its first ~100 ms: the freed device pool is wiped in the background by the
         # DMA engines the uploads use, tools/two_volumes_probe.py, DESIGN.md s.9)
         try:
-            indep = independent_streams(args, cam, res, h_depth, h_rgba, d_depth, d_rgba, poses, pinv, a_depth, a_rgba, a_pose,
-                                        a_pinv, n_unique, local_rank, world, dist if world > 1 else None, dev, textured, fresh_period)
+            indep = independent_streams(args, self.cam, self.res, self.h_depth, self.h_rgba, self.d_depth, self.d_rgba, self.poses, self.pinv,
+                                        self.a_depth, self.a_rgba, self.a_pose, self.a_pinv, self.n_unique, self.local_rank, self.world,
+                                        self.dist if self.world > 1 else None, self.dev, self.textured, self.fresh_period)
         except Exception as e:  # (a side figure: never fail the bench line for it)
             indep = {"error": repr(e)[:300]}
-        vol.close()
-        if use_rccl and textured and not args.no_group:
+        self.vol.close()
+        if self.use_rccl and self.textured and not args.no_group:
             try:
-                sharded_unit = sharded_keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, local_rank, rank, world,
-                                                     dist, dev, (lo, hi, axis), args.exchange_cap)
+                sharded_unit = sharded_keyframe_unit(args, self.cam, self.res, self.d_depth, self.d_rgba, self.poses, self.pinv, self.n_unique,
+                                                     self.local_rank, self.rank, self.world, self.dist, self.dev, self.part_spec, args.exchange_cap)
             except Exception as e:
                 sharded_unit = {"error": repr(e)[:300]}
+        return indep, sharded_unit
 
-    def skip_to_window():
-        """advance the stream (untimed, resident frames) to the timed window's orbit position in the next turn"""
-        nonlocal pos
-        nxt = pos + ((p0 - pos) % ORBIT)
-        if nxt > pos:
-            run(pos, nxt - pos)
-        pos = nxt
-
-    # ---- the timed window again (same orbit positions, later turns of the steady-state volume): spread of `value` ----
-    repeats = None
-    if not multi and args.repeats > 0:
-        rep = []
-        for _ in range(args.repeats):
-            # land Wm frames ahead of the window, warm the entry point up over them, time the K frames
-            nxt = pos + ((p0 - Wm - pos) % ORBIT)
-            if nxt > pos:
-                run(pos, nxt - pos)
-            pos = nxt
-            fresh_period()
-            (run_host if use_host else run)(pos, Wm)
-            if not use_host:
-                vol.sync()
-            barrier()
-            t1 = time.perf_counter()
-            (run_host if use_host else run)(pos + Wm, K)
-            barrier()
-            rep.append(1e3 * (time.perf_counter() - t1) / K)
-            vol.sync()
-            pos += Wm + K
-        allw = sorted(rep + [1e3 * dt / K])
-        repeats = {"windows": len(allw), "ms_per_step_median": allw[len(allw) // 2] if len(allw) % 2 else 0.5 * (allw[len(allw) // 2 - 1] + allw[len(allw) // 2]),
-                   "ms_per_step_min": allw[0], "ms_per_step_max": allw[-1],
-                   "value_median": 1e3 / (allw[len(allw) // 2] if len(allw) % 2 else 0.5 * (allw[len(allw) // 2 - 1] + allw[len(allw) // 2])),
-                   "value_min": 1e3 / allw[-1], "value_max": 1e3 / allw[0],
-                   "note": "`value` is the FIRST window (the contract's K timed steps); the others time the same %d orbit positions "
-                           "in later turns, each behind its own %d warm-up frames" % (K, Wm)}
-
-    # ---- the same orbit positions with the frames already in HBM --------------------------------
-    resident = None
-    if use_host and not multi:
-        skip_to_window()
-        vol.sync()
-        barrier()
+    # ---- phase 7 (N = 1): the timed window's orbit positions again, other ways ----------------------------------------
+    def _time_host_window(self, fn):
+        """Wm frames through `fn` (untimed) from Wm frames ahead of the window, then the K frames timed -> seconds"""
+        self.land_before_window()
+        self.fresh_period()
+        fn(self.pos, self.Wm)
+        self.barrier()
+        self.vol.host_frame_times(reset=True)
         t1 = time.perf_counter()
-        run(pos, K)
-        barrier()
+        fn(self.pos + self.Wm, self.K)
+        self.barrier()
+        return time.perf_counter() - t1
+
+    def repeat_windows(self):
+        """the timed window again (same orbit positions, later turns of the steady-state volume): spread of `value`"""
+        K, Wm = self.K, self.Wm
+        rep = []
+        fn = self.run_host if self.use_host else self.run
+        for _ in range(self.args.repeats):
+            # land Wm frames ahead of the window, warm the entry point up over them, time the K frames
+            self.land_before_window()
+            self.fresh_period()
+            fn(self.pos, Wm)
+            if not self.use_host:
+                self.vol.sync()
+            self.barrier()
+            t1 = time.perf_counter()
+            fn(self.pos + Wm, K)
+            self.barrier()
+            rep.append(1e3 * (time.perf_counter() - t1) / K)
+            self.vol.sync()
+            self.pos += Wm + K
+        allw = sorted(rep + [1e3 * self.dt / K])
+        med = allw[len(allw) // 2] if len(allw) % 2 else 0.5 * (allw[len(allw) // 2 - 1] + allw[len(allw) // 2])
+        return {"windows": len(allw), "ms_per_step_median": med, "ms_per_step_min": allw[0], "ms_per_step_max": allw[-1],
+                "value_median": 1e3 / med, "value_min": 1e3 / allw[-1], "value_max": 1e3 / allw[0],
+                "note": "`value` is the FIRST window (the contract's K timed steps); the others time the same %d orbit positions "
+                        "in later turns, each behind its own %d warm-up frames" % (K, Wm)}
+
+    def resident_window(self):
+        """the same orbit positions with the frames already in HBM"""
+        K = self.K
+        self.skip_to_window()
+        self.vol.sync()
+        self.barrier()
+        t1 = time.perf_counter()
+        self.run(self.pos, K)
+        self.barrier()
         dt_res = time.perf_counter() - t1
+        self.vol.sync()
+        self.pos += K
+        return {"value": K / dt_res, "unit": "frames/s", "ms_per_step": 1e3 * dt_res / K,
+                "note": "tf_stream_frames_textured_device on the same %d orbit positions one turn later: images "
+                        "already in HBM, no H2D, one call for all frames" % K}
+
+    def other_host_window(self):
+        """the same positions as HOST frames by the OTHER way in: registered caller buffers <-> the library's staging slots"""
+        vol, K, Wm, n_unique = self.vol, self.K, self.Wm, self.n_unique
+        o_depth = self.h_depth[:n_unique].copy()   # (a second set of caller arrays: outside the registered ranges)
+        o_rgba = self.h_rgba[:n_unique].copy()
+        if not self.host_registered:
+            vol.host_register(o_depth)
+            vol.host_register(o_rgba)
+        ao_depth = [o_depth[i].ctypes.data for i in range(n_unique)]
+        ao_rgba = [o_rgba[i].ctypes.data for i in range(n_unique)]
+        a_pose, a_pinv, textured = self.a_pose, self.a_pinv, self.textured
+
+        def run_host_other(first, count):
+            for j in range(count):
+                i = (first + j) % n_unique
+                vol.integrate_frame_host_addr(ao_depth[i], ao_rgba[i], a_pose[i], a_pinv[i] if textured else 0, first + j)
+
+        dt_o = self._time_host_window(run_host_other)
+        o_ph = vol.host_frame_times(reset=True)
         vol.sync()
-        pos += K
-        resident = {"value": K / dt_res, "unit": "frames/s", "ms_per_step": 1e3 * dt_res / K,
-                    "note": "tf_stream_frames_textured_device on the same %d orbit positions one turn later: images "
-                            "already in HBM, no H2D, one call for all frames" % K}
+        self.pos += Wm + K
+        if not self.host_registered:
+            vol.host_unregister(o_rgba)
+            vol.host_unregister(o_depth)
+        return {"value": K / dt_o, "unit": "frames/s", "ms_per_step": 1e3 * dt_o / K,
+                "host_phases_us_per_step": {k: v for k, v in o_ph.items()},
+                "note": ("tf_integrate_frame_host on the same %d orbit positions " % K) +
+                        ("from arrays that were never registered: a copy into the library's pinned slots by a pool of helper "
+                         "threads, asynchronous upload" if self.host_registered else
+                         "out of caller arrays registered once with tf_host_register: no staging copy, no helper threads, the "
+                         "call returns when its upload is through")}
 
-    # ---- the same positions as HOST frames by the OTHER way in: registered caller buffers <-> the library's staging slots ----
-    other_host = None
-    if use_host and not multi:
-        try:
-            o_depth = h_depth[:n_unique].copy()   # (a second set of caller arrays: outside the registered ranges)
-            o_rgba = h_rgba[:n_unique].copy()
-            if not host_registered:
-                vol.host_register(o_depth)
-                vol.host_register(o_rgba)
+    def async_host_window(self):
+        """the same positions out of the registered arrays WITHOUT waiting for every upload (tf_host_frame_set_async: the
+        caller keeps the "do not touch a buffer before the fence" contract itself -- here: 200 distinct frames, one fence at the end)"""
+        vol, K, Wm = self.vol, self.K, self.Wm
+        self.land_before_window()
+        self.fresh_period()
+        vol.host_frame_set_async(True)
+        self.run_host(self.pos, Wm)
+        vol.host_frame_fence()
+        self.barrier()
+        t1 = time.perf_counter()
+        self.run_host(self.pos + Wm, K)
+        vol.host_frame_fence()
+        self.barrier()
+        dt_a = time.perf_counter() - t1
+        vol.sync()
+        vol.host_frame_set_async(False)
+        self.pos += Wm + K
+        return {"value": K / dt_a, "unit": "frames/s", "ms_per_step": 1e3 * dt_a / K,
+                "note": "the same %d orbit positions out of the registered arrays with tf_host_frame_set_async(1): a call returns "
+                        "when its upload is QUEUED, one tf_host_frame_fence at the end (a caller with a ring of frame buffers); "
+                        "the upload of frame f overlaps the call for f + 1" % K}
 
-            ao_depth = [o_depth[i].ctypes.data for i in range(n_unique)]
-            ao_rgba = [o_rgba[i].ctypes.data for i in range(n_unique)]
+    def rgb_host_window(self):
+        """the same positions as HOST frames with the colour image as the caller holds it (Frame::rgb, 3 B per pixel)"""
+        vol, K, Wm, n_unique, h_depth, h_rgba, poses, pinv, textured = (self.vol, self.K, self.Wm, self.n_unique, self.h_depth, self.h_rgba,
+                                                                        self.poses, self.pinv, self.textured)
+        h_rgb = [np.ascontiguousarray(h_rgba[k][..., :3]) for k in range(n_unique)]
+        all_valid = all(bool(h_rgba[k][..., 3].all()) for k in range(n_unique))
+        h_valid = None if all_valid else [np.ascontiguousarray(h_rgba[k][..., 3]) for k in range(n_unique)]
 
-            def run_host_other(first, count):
-                for j in range(count):
-                    i = (first + j) % n_unique
-                    vol.integrate_frame_host_addr(ao_depth[i], ao_rgba[i], a_pose[i], a_pinv[i] if textured else 0, first + j)
+        def run_host_rgb(first, count):
+            for j in range(count):
+                i = (first + j) % n_unique
+                vol.integrate_frame_host_rgb(h_depth[i], h_rgb[i], None if h_valid is None else h_valid[i], poses[i],
+                                             pinv[i] if textured else None, first + j)
 
-            nxt = pos + ((p0 - Wm - pos) % ORBIT)
-            if nxt > pos:
-                run(pos, nxt - pos)
-            pos = nxt
-            fresh_period()
-            run_host_other(pos, Wm)
-            barrier()
-            vol.host_frame_times(reset=True)
-            t1 = time.perf_counter()
-            run_host_other(pos + Wm, K)
-            barrier()
-            dt_o = time.perf_counter() - t1
-            o_ph = vol.host_frame_times(reset=True)
-            vol.sync()
-            pos += Wm + K
-            if not host_registered:
-                vol.host_unregister(o_rgba)
-                vol.host_unregister(o_depth)
-            other_host = {"value": K / dt_o, "unit": "frames/s", "ms_per_step": 1e3 * dt_o / K,
-                          "host_phases_us_per_step": {k: v for k, v in o_ph.items()},
-                          "note": ("tf_integrate_frame_host on the same %d orbit positions " % K) +
-                                  ("from arrays that were never registered: a copy into the library's pinned slots by a pool of helper "
-                                   "threads, asynchronous upload" if host_registered else
-                                   "out of caller arrays registered once with tf_host_register: no staging copy, no helper threads, the "
-                                   "call returns when its upload is through")}
-            del o_depth, o_rgba
-        except Exception as e:  # (a side figure: never fail the bench line for it)
-            other_host = {"error": repr(e)[:300]}
+        dt_rgb = self._time_host_window(run_host_rgb)
+        vol.sync()
+        self.pos += Wm + K
+        return {"value": K / dt_rgb, "unit": "frames/s", "ms_per_step": 1e3 * dt_rgb / K,
+                "bytes_uploaded_per_frame": self.cam.width * self.cam.height * (7 if h_valid is None else 8),
+                "note": "tf_integrate_frame_host_rgb on the same %d orbit positions: depth + Frame::rgb (3 B per pixel%s) "
+                        "as the reference's caller holds them; its RGBA staging loop (MobileFusion.cpp:232-243) runs on "
+                        "the device behind the upload" % (K, "" if h_valid is None else " + colorValidFlag")}
 
-    # ---- the same positions out of the registered arrays WITHOUT waiting for every upload (tf_host_frame_set_async: the
-    # caller keeps the "do not touch a buffer before the fence" contract itself -- here: 200 distinct frames, one fence at the end)
-    async_host = None
-    if use_host and not multi and host_registered:
-        try:
-            nxt = pos + ((p0 - Wm - pos) % ORBIT)
-            if nxt > pos:
-                run(pos, nxt - pos)
-            pos = nxt
-            fresh_period()
-            vol.host_frame_set_async(True)
-            run_host(pos, Wm)
-            vol.host_frame_fence()
-            barrier()
-            t1 = time.perf_counter()
-            run_host(pos + Wm, K)
-            vol.host_frame_fence()
-            barrier()
-            dt_a = time.perf_counter() - t1
-            vol.sync()
-            vol.host_frame_set_async(False)
-            pos += Wm + K
-            async_host = {"value": K / dt_a, "unit": "frames/s", "ms_per_step": 1e3 * dt_a / K,
-                          "note": "the same %d orbit positions out of the registered arrays with tf_host_frame_set_async(1): a call returns "
-                                  "when its upload is QUEUED, one tf_host_frame_fence at the end (a caller with a ring of frame buffers); "
-                                  "the upload of frame f overlaps the call for f + 1" % K}
-        except Exception as e:  # (a side figure: never fail the bench line for it)
-            async_host = {"error": repr(e)[:300]}
-
-    # ---- the same positions as HOST frames with the colour image as the caller holds it (Frame::rgb, 3 B per pixel) ----
-    rgb_host = None
-    if use_host and not multi:
-        try:
-            h_rgb = [np.ascontiguousarray(h_rgba[k][..., :3]) for k in range(n_unique)]
-            all_valid = all(bool(h_rgba[k][..., 3].all()) for k in range(n_unique))
-            h_valid = None if all_valid else [np.ascontiguousarray(h_rgba[k][..., 3]) for k in range(n_unique)]
-
-            def run_host_rgb(first, count):
-                for j in range(count):
-                    i = (first + j) % n_unique
-                    vol.integrate_frame_host_rgb(h_depth[i], h_rgb[i], None if h_valid is None else h_valid[i], poses[i],
-                                                 pinv[i] if textured else None, first + j)
-
-            nxt = pos + ((p0 - Wm - pos) % ORBIT)
-            if nxt > pos:
-                run(pos, nxt - pos)
-            pos = nxt
-            fresh_period()
-            run_host_rgb(pos, Wm)
-            barrier()
-            t1 = time.perf_counter()
-            run_host_rgb(pos + Wm, K)
-            barrier()
-            dt_rgb = time.perf_counter() - t1
-            vol.sync()
-            pos += Wm + K
-            rgb_host = {"value": K / dt_rgb, "unit": "frames/s", "ms_per_step": 1e3 * dt_rgb / K,
-                        "bytes_uploaded_per_frame": cam.width * cam.height * (7 if h_valid is None else 8),
-                        "note": "tf_integrate_frame_host_rgb on the same %d orbit positions: depth + Frame::rgb (3 B per pixel%s) "
-                                "as the reference's caller holds them; its RGBA staging loop (MobileFusion.cpp:232-243) runs on "
-                                "the device behind the upload" % (K, "" if h_valid is None else " + colorValidFlag")}
-        except Exception as e:  # (a side figure: never fail the bench line for it)
-            rgb_host = {"error": repr(e)[:300]}
-
-    # ---- the same positions again: HIP events (on the handle's stream) around every launch of a step --------
-    prof = None
-    dt_instr = None
-    pair_us = None
-    kinds = STEP_KERNELS if textured else ("integrate",)
-    if not args.no_roofline and not multi:
+    def event_window(self, kinds):
+        """the same positions again: HIP events (on the handle's stream) around every launch of a step -> (prof, seconds, pair_us)"""
+        vol, K = self.vol, self.K
         pair_us = vol.profile_calibrate(200)
-        skip_to_window()
+        self.skip_to_window()
         vol.sync()
         vol.profile_enable(kinds)
-        barrier()
+        self.barrier()
         t1 = time.perf_counter()
-        run(pos, K)
-        barrier()
+        self.run(self.pos, K)
+        self.barrier()
         dt_instr = time.perf_counter() - t1
         prof = vol.profile_get(reset=True)
         vol.profile_enable([])
         vol.sync()
-        pos += K
+        self.pos += K
+        return prof, dt_instr, pair_us
 
-    what = ("TSDF integrate + mesh + atlas update per frame (BASELINE.json configs[%d])" % (4 if world > 1 else (3 if args.hires or big else 2))
-            if textured else "TSDF integrate, atlas off (BASELINE.json configs[%d])" % (4 if world > 1 else (3 if args.hires or big else 1)))
-    out = {
-        "metric": ("RGB-D frames/s (TSDF integrate + atlas update: prepare->integrate->finalize, UpdateMeshes, "
-                   "GeneratePatches + UpdateAtlas over the frame's dirty chunks)" if textured else
-                   "RGB-D frames/s (TSDF integrate, depth+colour, fused prepare->integrate->finalize)"),
-        "value": K / dt,
-        "unit": "frames/s",
-        "n_gpus": world,
-        "steps": K,
-        "warmup": Wm,
-        "ms_per_step": 1e3 * dt / K,
-        "host_enqueue_ms_per_step": 1e3 * t_enq / K,
-        "higher_is_better": True,
-        "scaling": "strong",  # N ranks partition ONE stream by chunk range (total work fixed); the N = 1 line is that series' first point
-        "vs_baseline": None,
-        "dtype": "f32",
-        "data": "synthetic",
-        "config": {
-            "workload": "%s orbit stream, %dx%d RGB-D, %.0f mm voxels, 8^3 chunks, %s; %s"
-                        % ("S-hall 8x6x8 m" if big else "S-room 4x3x4 m", cam.width, cam.height, 1e3 * float(res), what,
-                           "frames handed over as host images, staging + H2D copy (%.2f MB per frame) inside the timed region"
-                           % (8e-6 * cam.width * cam.height) if use_host else "frames resident in HBM"),
-            "h2d_in_timed_region": bool(use_host),
-            "host_affinity": numa_note or "unchanged",
-            "frames_per_orbit": ORBIT,
-            "preroll_frames": 0 if args.no_preroll else ORBIT,
-            "timed_window": {"first_frame": p0, "orbit_position": p0 % ORBIT, "frames": K},
-            "parallelism": ("1 GPU" if world == 1 else
-                            "%d ranks, chunk-range slabs of the key x+y+z of one stream; one RCCL exchange (neighbour send / "
-                            "receive pairs: the band below to rank - 1, the band above to rank + 1) of the updated ghost-band "
-                            "chunks %s"
-                            % (world, "after every voxel update, ahead of the mesher, each block sized by the frame's own "
-                               "selection (8-record buckets, at most %d records of 8 KiB)" % args.exchange_cap if textured else
-                               "every %d frames, fixed blocks of %d records" % (args.exchange_every, args.exchange_cap))),
-        },
-    }
-    if link_settle is not None:
-        out["config"]["link_settle"] = link_settle
+    # ---- phase 8: the line ------------------------------------------------------------------------------------------
+    def line(self):
+        """the contract's keys (metric, value, unit, ... config) from the timed window"""
+        args, world, K, Wm, cam, big, textured = self.args, self.world, self.K, self.Wm, self.cam, self.big, self.textured
+        what = ("TSDF integrate + mesh + atlas update per frame (BASELINE.json configs[%d])" % (4 if world > 1 else (3 if args.hires or big else 2))
+                if textured else "TSDF integrate, atlas off (BASELINE.json configs[%d])" % (4 if world > 1 else (3 if args.hires or big else 1)))
+        out = {
+            "metric": ("RGB-D frames/s (TSDF integrate + atlas update: prepare->integrate->finalize, UpdateMeshes, "
+                       "GeneratePatches + UpdateAtlas over the frame's dirty chunks)" if textured else
+                       "RGB-D frames/s (TSDF integrate, depth+colour, fused prepare->integrate->finalize)"),
+            "value": K / self.dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": Wm,
+            "ms_per_step": 1e3 * self.dt / K,
+            "host_enqueue_ms_per_step": 1e3 * self.t_enq / K,
+            "higher_is_better": True,
+            "scaling": "strong",  # N ranks partition ONE stream by chunk range (total work fixed); the N = 1 line is that series' first point
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s orbit stream, %dx%d RGB-D, %.0f mm voxels, 8^3 chunks, %s; %s"
+                            % ("S-hall 8x6x8 m" if big else "S-room 4x3x4 m", cam.width, cam.height, 1e3 * float(self.res), what,
+                               "frames handed over as host images, staging + H2D copy (%.2f MB per frame) inside the timed region"
+                               % (8e-6 * cam.width * cam.height) if self.use_host else "frames resident in HBM"),
+                "h2d_in_timed_region": bool(self.use_host),
+                "host_affinity": self.numa_note or "unchanged",
+                "frames_per_orbit": self.ORBIT,
+                "preroll_frames": 0 if args.no_preroll else self.ORBIT,
+                "timed_window": {"first_frame": self.p0, "orbit_position": self.p0 % self.ORBIT, "frames": K},
+                "parallelism": ("1 GPU" if world == 1 else
+                                "%d ranks, chunk-range slabs of the key x+y+z of one stream; one RCCL exchange (neighbour send / "
+                                "receive pairs: the band below to rank - 1, the band above to rank + 1) of the updated ghost-band "
+                                "chunks %s"
+                                % (world, "after every voxel update, ahead of the mesher, each block sized by the frame's own "
+                                   "selection (8-record buckets, at most %d records of 8 KiB)" % args.exchange_cap if textured else
+                                   "every %d frames, fixed blocks of %d records" % (args.exchange_every, args.exchange_cap))),
+            },
+        }
+        if self.link_settle is not None:
+            out["config"]["link_settle"] = self.link_settle
+        return out
+
+
+def _side_figure(fn):
+    """a side figure never fails the bench line"""
+    try:
+        return fn()
+    except Exception as e:
+        return {"error": repr(e)[:300]}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.child:
+        raise SystemExit(spawn_ranks(args))
+    job = Job(args)            # environment, affinity, the stream on the host
+    job.children()             # side runs + profiler child passes: before this process touches the GPU
+    job.device()               # torch, process group, the stream in HBM
+    job.volume()
+    if job.multi:
+        job.partition()
+    rank, world, multi, vol = job.rank, job.world, job.multi, job.vol
+    job.preroll()
+    exchange_order = job.pick_exchange_order()
+    job.timed_window()         # warm-up, then THE K timed steps -> job.dt, job.t_enq
+    per_rank = job.rank_stats() if multi else None
+    if args.child:  # profiler child pass: the workload above is all there is
+        vol.close()
+        return
+    indep = sharded_unit = None
+    if multi and not args.no_independent:
+        indep, sharded_unit = job.replicas()
+
+    # ---- N = 1: the timed window's orbit positions again -- its spread, and the other ways a frame can come in ----
+    single_host = job.use_host and not multi
+    repeats = job.repeat_windows() if (not multi and args.repeats > 0) else None
+    resident = job.resident_window() if single_host else None
+    other_host = _side_figure(job.other_host_window) if single_host else None
+    async_host = _side_figure(job.async_host_window) if (single_host and job.host_registered) else None
+    rgb_host = _side_figure(job.rgb_host_window) if single_host else None
+    prof = dt_instr = pair_us = None
+    kinds = STEP_KERNELS if job.textured else ("integrate",)
+    if not args.no_roofline and not multi:
+        prof, dt_instr, pair_us = job.event_window(kinds)
+
+    out = job.line()
     if repeats is not None:
         out["repeats"] = repeats
     if resident is not None:
         out["resident"] = resident
     if other_host is not None:
-        out["staged_host_frames" if host_registered else "registered_host_frames"] = other_host
+        out["staged_host_frames" if job.host_registered else "registered_host_frames"] = other_host
     if rgb_host is not None:
         out["rgb_host_frames"] = rgb_host
     if async_host is not None:
         out["registered_async_host_frames"] = async_host
-    if use_host and host_phases:
+    if job.use_host and job.host_phases:
+        host_phases = job.host_phases
         host_phases["host_buffers"] = ("registered with tf_host_register: uploaded in place, the call returns when the upload is through "
-                                       "(wait_for_upload_us)" if host_registered else "copied into the library's pinned staging slots (staging_copy_us)")
+                                       "(wait_for_upload_us)" if job.host_registered else "copied into the library's pinned staging slots (staging_copy_us)")
         host_phases["note"] = ("host microseconds per call inside the timed window: host_enqueue_ms_per_step includes wait_for_device_us "
                                "(the entry point blocks until the device frees a staging slot -- back-pressure, not host work)")
         out["host_phases_us_per_step"] = host_phases
@@ -915,30 +982,32 @@ def main():
     if sharded_unit is not None:
         out["keyframe_unit_sharded"] = sharded_unit
 
+    cam, res, n_unique = job.cam, job.res, job.n_unique
     # ---- roofline over ALL kernels of a step ------------------------------------------------
     if rank == 0 and prof is not None and not multi:
-        skip_to_window()
-        out["roofline"] = roofline(args, vol, cam, prof, kinds, K, pos, n_unique, d_depth, d_rgba, poses, pinv, textured,
-                                   dt_instr, pair_us, prof_child, 1e6 * dt / K)
-        pos += K
+        job.skip_to_window()
+        out["roofline"] = roofline(args, vol, cam, prof, kinds, job.K, job.pos, n_unique, job.d_depth, job.d_rgba, job.poses, job.pinv, job.textured,
+                                   dt_instr, pair_us, job.prof_child, 1e6 * job.dt / job.K)
+        job.pos += job.K
 
     # ---- the keyframe-group flow of TSDFFusion: 1 colour + 6 depth-only frames over one chunk list -------
     if rank == 0 and not multi and not args.no_group and not args.no_roofline:
-        out["keyframe_group"] = keyframe_group(args, cam, res, d_depth, d_rgba, poses, n_unique, local_rank)
+        out["keyframe_group"] = keyframe_group(args, cam, res, job.d_depth, job.d_rgba, job.poses, n_unique, job.local_rank)
 
     # ---- the keyframe unit: tsdfFusion as one asynchronous call per keyframe -------------------------------
     if rank == 0 and not multi and not args.no_group and not args.no_roofline:
-        out["keyframe_unit"] = keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, local_rank)
+        out["keyframe_unit"] = keyframe_unit(args, cam, res, job.d_depth, job.d_rgba, job.poses, job.pinv, n_unique, job.local_rank)
 
     # ---- CPU baseline: the oracle (C port of the reference path) on the host cores ------------
     if rank == 0 and world == 1 and args.cpu_frames > 0:  # (rank 0 at N = 1 only)
-        if orig_affinity:
+        if job.orig_affinity:
             try:
-                os.sched_setaffinity(0, orig_affinity)  # the CPU port gets every core of the host
+                os.sched_setaffinity(0, job.orig_affinity)  # the CPU port gets every core of the host
             except Exception:
                 pass
-        out["cpu_baseline"] = cpu_baseline(args, cam, res, h_depth, h_rgba, h_pose, n_unique, textured)
+        out["cpu_baseline"] = cpu_baseline(args, cam, res, job.h_depth, job.h_rgba, job.h_pose, n_unique, job.textured)
 
+    side = job.side
     if rank == 0 and side is not None:
         out["side"] = side
     if rank == 0 and "roofline" in out:
@@ -950,11 +1019,21 @@ def main():
         if repeats is not None:
             for k in ("ms_per_step_median", "ms_per_step_min", "ms_per_step_max"):
                 out["roofline"]["repeats_" + k] = repeats.get(k)
-    if rank == 0:
-        print(json.dumps(out))
     vol.close()
+    # the line is the LAST thing on stdout: what C libraries have printed so far (RCCL's version banner sits in the C runtime's
+    # buffer when stdout is a file or a pipe) goes out first -- on every rank, ahead of a last barrier
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
     if multi:
-        dist.destroy_process_group()
+        if world > 1:
+            job.dist.barrier()
+        job.dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def all_ranks_ok(dist, dev, ok):
