@@ -456,6 +456,7 @@ int tf_volume_create_sized(const int32_t chunk_dim[3], float resolution, int use
     SelBuf& L = v->selbuf[k];
     if ((rc = dev_alloc(v, &L.masks, (size_t)d.max_coarse))) return fail(rc);
     if ((rc = dev_alloc(v, &L.offsets, (size_t)d.max_coarse))) return fail(rc);
+    if (hipMemsetAsync(L.offsets, 0, sizeof(uint32_t) * (size_t)d.max_coarse, v->stream) != hipSuccess) { set_error("hipMemsetAsync failed"); return fail(TF_ERR_HIP); }  // k_scan's stamped tile words: no stamp yet
     if ((rc = dev_alloc(v, &L.list_id, (size_t)d.max_list))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_pre, (size_t)d.max_list * 4))) return fail(rc);
     if ((rc = dev_alloc(v, &L.list_slot, (size_t)d.max_list))) return fail(rc);

@@ -117,7 +117,7 @@ struct VolCtl {
 // function of its depth image and pose) can run on a second stream while frame f integrates.
 struct SelBuf {
   unsigned long long* masks;  // [max_coarse]
-  uint32_t* offsets;          // [max_coarse]
+  uint32_t* offsets;          // [max_coarse] k_scan's tile words (64-bit: {launch stamp | kind | entries}, one per 256 coarse blocks)
   int4* list_id;              // [max_list]
   float4* list_pre;           // [4*max_list] 64-B records {o.x,o.y,o.z,wD}, {upper,id.x,id.y,id.z}, spare x2
   uint32_t* list_slot;        // [max_list]

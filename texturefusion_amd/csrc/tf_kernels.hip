@@ -17,6 +17,7 @@
 //               K-C (k_select's body) of frame f+1, K-B (k_bbox's body) of frame f+2 as block ranges
 #include <stdlib.h>
 
+#include <atomic>
 #include "tf_device.h"
 #include "tf_devfn.h"
 #include "tf_host_math.h"
@@ -362,87 +363,31 @@ void launch_select(const VolumeDev& v, const float* depth, const Cam& cam, const
 
 // ---------------------------------------------------------------------------------------
 // exclusive scan of popcount(mask) over the coarse blocks (x-outer .. z-inner order, then lane
-// order i,j,k inside a block = the reference's push_back order) and list write-out; single
-// workgroup.  Also re-arms the bbox keys for the next frame (they were consumed by k_select).
+// order i,j,k inside a block = the reference's push_back order) and list write-out.  Also re-arms
+// the bbox keys for the next frame (they were consumed by k_select).
+// Round 6: a single-pass scan with decoupled look-back over tiles of 256 coarse blocks (one
+// workgroup of four waves per tile, 256 resident workgroups taking tiles in ascending order)
+// instead of ONE workgroup that walked all of them: 17 us of every tf_prepare.  A tile publishes
+// its aggregate, then its inclusive prefix, as one 64-bit word {launch stamp : 30 | kind : 2 |
+// value : 32} in SelBuf::offsets -- stamped, so nothing is cleared between launches; wave 0 of a
+// tile looks back 64 tiles at a time (lane l at tile - 1 - l) until it meets a prefix.  A tile
+// only ever waits for lower tiles, and the lowest unfinished tile waits for nobody.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan(VolumeDev v, int step) {
+constexpr uint32_t kScanTile = 256;  // coarse blocks per tile: one per thread
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x += (uint32_t)__shfl_xor((int)x, o);
+  return x;
+}
+__global__ __launch_bounds__(256) void k_scan(VolumeDev v, int step, uint32_t stamp) {
   FrameCtl* ctl = v.sel.ctl;
   const SelBuf& L = v.sel;
   const uint32_t n = ctl->n_coarse;
-  const uint32_t per = (n + 1023) / 1024;
-  const uint32_t b = threadIdx.x * per;
-  const uint32_t e = (b + per < n) ? b + per : n;
-  uint32_t local = 0;
-  for (uint32_t i = b; i < e; ++i) local += (uint32_t)__popcll(L.masks[i]);
-  // block exclusive scan: wave scan + LDS
-  __shared__ uint32_t wsum[16];
+  const uint32_t n_tiles = (n + kScanTile - 1u) / kScanTile;
+  unsigned long long* const state = reinterpret_cast<unsigned long long*>(L.offsets);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t inc = local;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t t = __shfl_up(inc, o);
-    if (lane >= o) inc += t;
-  }
-  if (lane == 63) wsum[w] = inc;
-  __syncthreads();
-  uint32_t wbase = 0, total = 0;
-  for (int k = 0; k < 16; ++k) {
-    if (k < w) wbase += wsum[k];
-    total += wsum[k];
-  }
-  const bool fits = total <= v.max_list;
-  uint32_t run = wbase + inc - local;
-  for (uint32_t i = b; i < e; ++i) {
-    L.offsets[i] = run;
-    run += (uint32_t)__popcll(L.masks[i]);
-  }
-  __syncthreads();  // offsets[] written above are read by other waves below
-  if (fits) {
-    // list write-out: each wave scans 64 coarse blocks at a time, then expands the non-empty
-    // ones; lane = bit index = (i-x)*16 + (j-y)*4 + (k-z), the reference's inner-loop order
-    // (:508-548), so entry order == push_back order.
-    const uint32_t dz = (uint32_t)ctl->dims[2], dy = (uint32_t)ctl->dims[1];
-    const uint32_t nzny = dz * dy;
-    const int mx = ctl->min_id[0] - 1, my = ctl->min_id[1] - 1, mz = ctl->min_id[2] - 1;
-    // (the masks and offsets of the wave's NEXT 64 blocks are requested before the current ones are expanded: the
-    // loop was a chain of dependent round trips, 17 us of a keyframe's 258 -- profiles/r4/keyframe_unit_*)
-    unsigned long long nmask = ((uint32_t)w * 64 + lane < n) ? L.masks[(uint32_t)w * 64 + lane] : 0ull;
-    uint32_t noff = ((uint32_t)w * 64 + lane < n) ? L.offsets[(uint32_t)w * 64 + lane] : 0u;
-    for (uint32_t base = (uint32_t)w * 64; base < n; base += 16 * 64) {
-      const unsigned long long mymask = nmask;
-      const uint32_t myoff = noff;
-      {
-        const uint32_t nx = base + 16 * 64 + lane;
-        nmask = (nx < n) ? L.masks[nx] : 0ull;
-        noff = (nx < n) ? L.offsets[nx] : 0u;
-      }
-      unsigned long long nonempty = __ballot(mymask != 0ull);
-      while (nonempty) {
-        const int src = __builtin_ctzll(nonempty);
-        nonempty &= nonempty - 1;
-        const uint32_t cb = base + src;
-        const unsigned long long m =
-            ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mymask >> 32), src) << 32) |
-            (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mymask & 0xFFFFFFFFu), src);
-        const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)myoff, src);
-        if ((m >> lane) & 1ull) {
-          const uint32_t pos = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          const uint32_t bx = cb / nzny;
-          const uint32_t brem = cb - bx * nzny;
-          const uint32_t by = brem / dz;
-          const uint32_t bz = brem - by * dz;
-          int4 id;
-          id.x = mx + (int)bx * step + ((step == 4) ? (lane >> 4) : 0);
-          id.y = my + (int)by * step + ((step == 4) ? ((lane >> 2) & 3) : 0);
-          id.z = mz + (int)bz * step + ((step == 4) ? (lane & 3) : 0);
-          id.w = 0;
-          L.list_id[pos] = id;
-        }
-      }
-    }
-  }
-  if (threadIdx.x == 0) {
-    if (!fits) {
+  auto finish = [&](uint32_t total) {  // one thread: the list's header, the bbox keys of the set's next frame
+    if (total > v.max_list) {
       atomicOr(&v.vctl->status, kStListFull);
       total = 0;
     }
@@ -452,10 +397,113 @@ __global__ __launch_bounds__(1024) void k_scan(VolumeDev v, int step) {
       ctl->bbox_key[a] = f2key(1e8f);
       ctl->bbox_key[3 + a] = f2key(-1e8f);
     }
+  };
+  if (n_tiles == 0u) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) finish(0u);
+    return;
+  }
+  auto publish = [&](uint32_t tile, uint32_t kind, uint32_t value) {
+    __hip_atomic_store(&state[tile], ((unsigned long long)stamp << 34) | ((unsigned long long)kind << 32) | value, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  };
+  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t s_base;
+  const uint32_t dz = (uint32_t)ctl->dims[2], dy = (uint32_t)ctl->dims[1];
+  const uint32_t nzny = dz * dy;
+  const int mx = ctl->min_id[0] - 1, my = ctl->min_id[1] - 1, mz = ctl->min_id[2] - 1;
+  for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // lane = coarse block: its mask, the entries ahead of it inside the wave (ex), and where its chunks' ids start
+    const uint32_t cb = tile * kScanTile + (uint32_t)threadIdx.x;
+    const unsigned long long m = cb < n ? L.masks[cb] : 0ull;
+    const uint32_t c = (uint32_t)__popcll(m);
+    uint32_t inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)inc, o);
+      if (lane >= o) inc += t;
+    }
+    const uint32_t ex = inc - c;
+    if (lane == 63) wsum[w] = inc;
+    // (the two divisions per block are done here, 64 blocks at a time, not per block inside the write-out loop)
+    const uint32_t bx = cb / nzny;
+    const uint32_t brem = cb - bx * nzny;
+    const uint32_t by = brem / dz;
+    const uint32_t bz = brem - by * dz;
+    const int ox = mx + (int)bx * step, oy = my + (int)by * step, oz = mz + (int)bz * step;
+    __syncthreads();
+    uint32_t wbase = 0, agg = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < w) wbase += wsum[k];
+      agg += wsum[k];
+    }
+    if (w == 0) {  // the tile's place in the list: entries of all lower tiles
+      uint32_t base = 0;
+      if (tile == 0u) {
+        if (lane == 0) publish(0u, 2u, agg);
+      } else {
+        if (lane == 0) publish(tile, 1u, agg);
+        int look = (int)tile - 1;
+        for (;;) {
+          const int tt = look - lane;
+          uint32_t kind = 2u, val = 0u;  // (below tile 0: an empty prefix -- the walk always ends)
+          if (tt >= 0) {
+            unsigned long long sw;
+            do {
+              sw = __hip_atomic_load(&state[tt], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } while ((uint32_t)(sw >> 34) != stamp || ((uint32_t)(sw >> 32) & 3u) == 0u);
+            kind = (uint32_t)(sw >> 32) & 3u;
+            val = (uint32_t)sw;
+          }
+          const unsigned long long pm = __ballot(kind == 2u);
+          if (pm) {  // the nearest prefix and the aggregates between it and this tile
+            const int first = __builtin_ctzll(pm);
+            base += wave_sum_u32(lane <= first ? val : 0u);
+            break;
+          }
+          base += wave_sum_u32(val);
+          look -= 64;
+        }
+        if (lane == 0) publish(tile, 2u, base + agg);
+      }
+      if (lane == 0) s_base = base;
+    }
+    __syncthreads();
+    const uint32_t tile_base = s_base;
+    const uint32_t tb = tile_base + wbase;
+    // list write-out: the wave expands the non-empty ones of its 64 blocks, lane = bit index = (i-x)*16 + (j-y)*4 + (k-z), the
+    // reference's inner-loop order (:508-548), so entry order == push_back order.  (A list that does not fit is reported by
+    // the last tile; nothing is written past the arrays.)
+    unsigned long long nonempty = __ballot(m != 0ull);
+    while (nonempty) {
+      const int src = __builtin_ctzll(nonempty);
+      nonempty &= nonempty - 1;
+      const unsigned long long mm =
+          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(m >> 32), src) << 32) |
+          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(m & 0xFFFFFFFFu), src);
+      const uint32_t off = tb + (uint32_t)__builtin_amdgcn_readlane((int)ex, src);
+      const int sx = __builtin_amdgcn_readlane(ox, src), sy = __builtin_amdgcn_readlane(oy, src), sz = __builtin_amdgcn_readlane(oz, src);
+      if ((mm >> lane) & 1ull) {
+        const uint32_t pos = off + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+        int4 id;
+        id.x = sx + ((step == 4) ? (lane >> 4) : 0);
+        id.y = sy + ((step == 4) ? ((lane >> 2) & 3) : 0);
+        id.z = sz + ((step == 4) ? (lane & 3) : 0);
+        id.w = 0;
+        if (pos < v.max_list) L.list_id[pos] = id;
+      }
+    }
+    if (tile == n_tiles - 1u && threadIdx.x == 0) finish(tile_base + agg);
+    __syncthreads();  // (wsum / s_base are written again by the workgroup's next tile)
   }
 }
 void launch_scan(const VolumeDev& v, int step, hipStream_t s) {
-  hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, v, step);
+  // (one stamp per launch, process-wide: every selection set has its own state words, all that matters is that a launch
+  // never meets its own stamp from an earlier launch -- 2^30 - 1 launches apart)
+  static std::atomic<uint32_t> g_stamp{0};
+  uint32_t stamp;
+  do { stamp = (g_stamp.fetch_add(1u) + 1u) & 0x3FFFFFFFu; } while (stamp == 0u);
+  hipLaunchKernelGGL(k_scan, dim3(256), dim3(256), 0, s, v, step, stamp);
 }
 
 // ---------------------------------------------------------------------------------------
