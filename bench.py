@@ -807,9 +807,14 @@ class Job:
         """the same positions out of the registered arrays WITHOUT waiting for every upload (tf_host_frame_set_async: the
         caller keeps the "do not touch a buffer before the fence" contract itself -- here: 200 distinct frames, one fence at the end)"""
         vol, K, Wm = self.vol, self.K, self.Wm
+        vol.host_frame_set_async(True)
+        # (the first ~40 calls that run AHEAD of their uploads make the runtime grow its pool of copy resources: four of them
+        # take 8-11 ms each, once per process -- tools/async_probe.py, profiles/r6/README.md; not part of any window)
+        self.run_host(self.pos, 64)
+        vol.host_frame_fence()
+        self.pos += 64
         self.land_before_window()
         self.fresh_period()
-        vol.host_frame_set_async(True)
         self.run_host(self.pos, Wm)
         vol.host_frame_fence()
         self.barrier()
