@@ -129,7 +129,10 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
   // Worth it only for the FIRST pass of a call that follows another unit call (ev_mut then stands for "every launch that
   // changes chunks is done" while that call's texture stage is still on the stream); a later pass of the same call has
   // nothing to overlap, and the two event edges cost 4 us each (profiles/r6/README.md).
-  if (flag && first && u->front && v->n_primed == 0 && u->mut_seq + 1 == v->call_seq) {
+  // (a group WITHOUT local frames acquires its chunks eagerly -- parked ones are revived by the front end itself -- and a
+  // revived chunk is not the same as a parked one to the previous call's filter: such a group stays on the handle's stream;
+  // the lazy form only inserts keys, and a freshly inserted chunk is indistinguishable from an absent one to every reader)
+  if (flag && first && g->n_local > 0 && u->front && v->n_primed == 0 && u->mut_seq + 1 == v->call_seq) {
     // (no selection made ahead by a streaming call sits in the ring: the next set is free)
     v->cur_sel = (v->cur_sel + 1) % tf_volume::kSelSets;
     d.sel = v->selbuf[v->cur_sel];
