@@ -132,7 +132,9 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
   // (a group WITHOUT local frames acquires its chunks eagerly -- parked ones are revived by the front end itself -- and a
   // revived chunk is not the same as a parked one to the previous call's filter: such a group stays on the handle's stream;
   // the lazy form only inserts keys, and a freshly inserted chunk is indistinguishable from an absent one to every reader)
-  if (flag && first && g->n_local > 0 && u->front && v->n_primed == 0 && u->mut_seq + 1 == v->call_seq) {
+  // (... and a handle that runs on a stream of the CALLER's (tf_set_stream) keeps stream order towards whatever the caller put
+  // there itself -- the producers of the group's images, say: no fork)
+  if (flag && first && g->n_local > 0 && u->front && v->own_stream && v->n_primed == 0 && u->mut_seq + 1 == v->call_seq) {
     // (no selection made ahead by a streaming call sits in the ring: the next set is free)
     v->cur_sel = (v->cur_sel + 1) % tf_volume::kSelSets;
     d.sel = v->selbuf[v->cur_sel];
