@@ -1,6 +1,8 @@
 """The textured per-frame unit away from the bench stream: a hand-held orbit (general rotations), other image and
 voxel sizes, the 1280x960 hall of configs[3], the host-frames entry point -- each against the oracle's per-frame
 unit, bit for bit (voxels, meshes, patches, slots, atlas texels).  Every case takes a few seconds."""
+import os
+
 import numpy as np
 import pytest
 
@@ -14,7 +16,9 @@ pytestmark = pytest.mark.gpu
 
 def _run(cam, res, frames, host_frames=False, max_chunks=1 << 17, stride=1):
     ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
-    gv = capi.Volume(res, cam, max_chunks=max_chunks, max_list=1 << 17, max_coarse=1 << 20)
+    # (TF_SOAK_MESH_BLOCKS: a small mesh store -- the runs of tools/soak_random.py then live off recycled blocks)
+    mb = int(os.environ.get("TF_SOAK_MESH_BLOCKS", "0"))
+    gv = capi.Volume(res, cam, max_chunks=max_chunks, max_list=1 << 17, max_coarse=1 << 20, **({"mesh_blocks": mb} if mb else {}))
     oa = O.Atlas(res)
     pinv = [synth.pose_inverse16(f[3]) for f in frames]
     for k, f in enumerate(frames):
