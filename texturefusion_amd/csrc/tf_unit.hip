@@ -102,8 +102,8 @@ static int unit_state(tf_volume* v, UnitState** out) {
     TF_HIP(hipMalloc((void**)&u.group_cen, sizeof(float) * (size_t)kGroupFrames * 3 * kChunkVoxels));
     if (!(getenv("TF_UNIT_SERIAL_FRONT") && atoi(getenv("TF_UNIT_SERIAL_FRONT")))) {  // (A/B knob: everything on the handle's stream)
       TF_HIP(hipStreamCreateWithFlags(&u.front, hipStreamNonBlocking));
-      TF_HIP(hipEventCreateWithFlags(&u.ev_mut, hipEventDisableTiming | hipEventReleaseToDevice));  // (device-scope release: both sides are this GPU)
-      TF_HIP(hipEventCreateWithFlags(&u.ev_front, hipEventDisableTiming | hipEventReleaseToDevice));
+      TF_HIP(hipEventCreateWithFlags(&u.ev_mut, hipEventDisableTiming | hipEventDisableSystemFence));  // (both sides are this GPU: no system-scope writeback / invalidate at the edge)
+      TF_HIP(hipEventCreateWithFlags(&u.ev_front, hipEventDisableTiming | hipEventDisableSystemFence));
     }
   }
   *out = &u;
