@@ -486,8 +486,11 @@ def test_keyframe_unit_then_the_callers_view_selection(gpu_required, with_q):
     gv.close()
 
 
-def test_keyframe_pass_inside_the_group_kernel_on_hard_images(gpu_required):
-    """The keyframe's own pass as the first frame of the group kernel's visit (no quality image, local frames behind it) on
+@pytest.mark.parametrize("with_q", [False, True])
+def test_keyframe_pass_inside_the_group_kernel_on_hard_images(gpu_required, with_q):
+    """with_q: the keyframes carry a quality image (k_integrate_group<., KEY, QUAL>: observationQualitySum kept in row order --
+    random qualities make every sum order-sensitive -- and compared through the observations table).
+    The keyframe's own pass as the first frame of the group kernel's visit (local frames behind it) on
     the images K-A's own tests use against integrate_body: NaN / -Inf / negative / denormal / near- and far-plane depth pixels, a wall
     35 cm from the camera (chunks near the image border and the near plane: the generic division path, stalled rows,
     off-image lanes -> the out-of-observation constant), and the same keyframe integrated often enough for the colour
@@ -514,13 +517,16 @@ def test_keyframe_pass_inside_the_group_kernel_on_hard_images(gpu_required):
     for s in (1, 2, 3):
         w = synth.wall_frame(0.35, cam, seed=s)
         frames.append((w[0], w[1], None, w[3]))
-    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1])) for f in frames]
+    if with_q:
+        frames = [(f[0], f[1], rng.uniform(0.01, 1.0, f[0].shape).astype(np.float32), f[3]) for f in frames]
+    bufs = [(HipBuffer(f[0].nbytes).from_host(f[0]), HipBuffer(f[1].nbytes).from_host(f[1]),
+             HipBuffer(f[2].nbytes).from_host(f[2]) if with_q else None) for f in frames]
 
     def call(kf_id, key, loc, old=None):
         kw = {}
         if old is not None:
             kw = dict(old_keyframe_pose=frames[key][3], old_local_poses=[frames[k][3] for k in loc])
-        return capi.Volume.unit_group(kf_id, (bufs[key][0].ptr, bufs[key][1].ptr, None, frames[key][3]),
+        return capi.Volume.unit_group(kf_id, (bufs[key][0].ptr, bufs[key][1].ptr, bufs[key][2].ptr if with_q else None, frames[key][3]),
                                       [(bufs[k][0].ptr, frames[k][3]) for k in loc], **kw)
 
     valid = {}
@@ -537,6 +543,15 @@ def test_keyframe_pass_inside_the_group_kernel_on_hard_images(gpu_required):
     assert np.array_equal(ids, sorted_ids(gv.list_chunks())) and len(ids) > 1000
     assert_chunks_equal(ov, gv, ids[::3], "hard images, integrated")
     assert np.array_equal(sorted_ids(ov.dirty()), sorted_ids(gv.dirty()))
+    kf_all = [1, 2, 3, 100, 164, 229]  # chunk->observations of these keyframes (Chisel.h:244-247), every chunk
+    want = np.zeros((len(ids), len(kf_all)), np.float32)
+    for i, cid in enumerate(ids):
+        obs = ov.observations(cid)
+        want[i] = [obs.get(k, 0.0) for k in kf_all]
+    got = gv.export_datacost(ids, kf_all[0], kf_all[1:])
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    if with_q:
+        assert (want != 0).sum() > 1000
     # the three keyframes moved onto themselves: de-integration (flag 0) and re-integration at the same poses
     for kf_id, key, loc in plan:
         gv.keyframe_unit(fresh=None, moved=[call(kf_id, key, loc, old=True)], texture=False)
@@ -548,5 +563,7 @@ def test_keyframe_pass_inside_the_group_kernel_on_hard_images(gpu_required):
     assert np.array_equal(ids, sorted_ids(gv.list_chunks()))
     assert_chunks_equal(ov, gv, ids[::3], "hard images, moved")
     for b in bufs:
-        b[0].free(); b[1].free()
+        for x in b:
+            if x is not None:
+                x.free()
     gv.close()

@@ -80,7 +80,10 @@ struct GroupKey {
   FrameImages img;  // the keyframe's depth + colour
   Pose P;           // its pose (centroids)
 };
-template <bool FLAG, bool KEY>
+// QUAL (with KEY): the keyframe has a quality image -- observationQualitySum of the keyframe's pass is kept in row order as
+// integrate_body<COLOR, QUALITY> keeps it (:212-238): reset to the out-of-observation constant by a processed row with an
+// off-image lane, plus the eight qualities of a row that updates colour
+template <bool FLAG, bool KEY, bool QUAL = false>
 __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs ga, Cam cam, IntegrateConsts kc, int32_t obs_kf,
                                                          int fin, uint32_t fin_epoch, int claim_par, uint32_t claim_stamp,
                                                          GroupKey key) {
@@ -140,6 +143,8 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
           __builtin_amdgcn_make_buffer_rsrc((void*)key.img.rgba, 0, W * H * 4, 0x00020000);
       const __amdgpu_buffer_rsrc_t rs_C =
           __builtin_amdgcn_make_buffer_rsrc((void*)(v.color + (size_t)slot * kChunkVoxels), 0, 4096, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_qual =
+          __builtin_amdgcn_make_buffer_rsrc((void*)key.img.quality, 0, QUAL ? W * H * 4 : 0, 0x00020000);
       // centroid of the lane's voxel of slice j, axis a: centroid_table's expression
       const float khalf = kc.res * 0.5f;
       const float fx = (float)(lane & 7), fy = (float)vy;
@@ -230,10 +235,22 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
       // colour band (-thr < sd < thr, :202-208): which colour rows are rewritten, which pixels feed them -- four slices at
       // a time (eight would hold 40 registers across the loads)
       uint32_t lanes_c = 0;
+      float qsum_rows = 0.0f;                       // QUAL: observationQualitySum, row by row
+      const bool some_oob = all_valid != ~0ull;     // (a chunk that projects inside the image has no off-image lane)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         int off_c[4], off_i[4];
         unsigned long long any_c = 0ull;
+        unsigned long long mo[QUAL ? 4 : 1];        // QUAL: off-image lanes of the processed rows of the four slices
+        unsigned long long any_o = 0ull;
+        if (QUAL) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = h * 4 + jj;
+            mo[jj] = some_oob ? ballot(((uint32_t)(j * 8 + vy) < R) && ((oob_bits >> j) & 1u)) : 0ull;
+            any_o |= mo[jj];
+          }
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const int j = h * 4 + jj;
@@ -246,13 +263,22 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
           lanes_c += (uint32_t)__popcll(ru);
           any_c |= ru;
         }
-        if (any_c == 0ull) continue;
+        if (any_c == 0ull) {
+          if (QUAL && any_o) {  // no colour row, but rows with off-image lanes: the sum starts over at the constant
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+              if (mo[jj]) qsum_rows = kc.qoob;
+          }
+          continue;
+        }
         u32x2 c[4];
         uint32_t in[4];
+        float qv[QUAL ? 4 : 1];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           c[jj] = __builtin_amdgcn_raw_buffer_load_b64(rs_C, off_c[jj], 0, 0);
           in[jj] = __builtin_amdgcn_raw_buffer_load_b32(rs_rgba, off_i[jj], 0, 0);
+          if (QUAL) qv[jj] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_qual, off_i[jj], 0, 0));
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -277,11 +303,32 @@ __global__ __launch_bounds__(256) void k_integrate_group(VolumeDev v, GroupArgs 
           c[jj].y = __builtin_bit_cast(uint32_t, c_ba);
           __builtin_amdgcn_raw_buffer_store_b64(c[jj], rs_C, off_c[jj], 0, 0);
         }
+        if (QUAL) {  // observationQualitySum in row order (integrate_body, phase 6)
+          const int rowshift = lane & 56;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = h * 4 + jj;
+            const unsigned long long mu = ballot(off_i[jj] != kOOB);
+            if ((mu | mo[jj]) == 0ull) continue;
+            float rowsum = 0.0f;
+            if (mu) {  // sum += observationQuality[i], i = 0..7 (:233-236)
+#pragma unroll
+              for (int l = 0; l < 8; ++l) rowsum += __shfl(qv[jj], rowshift + l);
+            }
+            const int left = (int)R - j * 8;
+            const int rmax = left < 8 ? left : 8;
+            for (int r = 0; r < rmax; ++r) {
+              if ((mo[jj] >> (8 * r)) & 0xFFull) qsum_rows = kc.qoob;
+              if ((mu >> (8 * r)) & 0xFFull)
+                qsum_rows += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rowsum), 8 * r));
+            }
+          }
+        }
       }
       key_rows_c = lanes_c >> 3;
       // without a quality image nothing is ever added to observationQualitySum: it ends as the out-of-observation
       // constant iff any processed row had an off-image lane (:221-222)
-      const float qsum = (ballot(oob_any != 0) != 0ull) ? kc.qoob : 0.0f;
+      const float qsum = QUAL ? qsum_rows : ((ballot(oob_any != 0) != 0ull) ? kc.qoob : 0.0f);
       if (lane == 0) {
         L.list_quality[e] = qsum;
         if (obs_kf >= 0 && qsum > 0.0f && key_rows_t != 0u) {  // chunk->observations[keyframe] (Chisel.h:244-247)
@@ -463,10 +510,11 @@ void launch_integrate_group(const VolumeDev& v, int n, const float* const* d_dep
   const dim3 grid(cus * 4), block(256);  // 36 KB of LDS per workgroup: four per CU
   GroupKey key = {};
   if (key_img) { key.img = *key_img; key.P = *key_pose; }
-#define TF_LAUNCH_GROUP(F, K) \
-  hipLaunchKernelGGL((k_integrate_group<F, K>), grid, block, 0, s, v, ga, cam, kc, obs_kf, fin, fin_epoch, claim_par, claim_stamp, key)
-  if (key_img) { if (flag) TF_LAUNCH_GROUP(true, true); else TF_LAUNCH_GROUP(false, true); }
-  else { if (flag) TF_LAUNCH_GROUP(true, false); else TF_LAUNCH_GROUP(false, false); }
+#define TF_LAUNCH_GROUP(F, K, Q) \
+  hipLaunchKernelGGL((k_integrate_group<F, K, Q>), grid, block, 0, s, v, ga, cam, kc, obs_kf, fin, fin_epoch, claim_par, claim_stamp, key)
+  if (key_img && key_img->quality) { if (flag) TF_LAUNCH_GROUP(true, true, true); else TF_LAUNCH_GROUP(false, true, true); }
+  else if (key_img) { if (flag) TF_LAUNCH_GROUP(true, true, false); else TF_LAUNCH_GROUP(false, true, false); }
+  else { if (flag) TF_LAUNCH_GROUP(true, false, false); else TF_LAUNCH_GROUP(false, false, false); }
 #undef TF_LAUNCH_GROUP
 }
 

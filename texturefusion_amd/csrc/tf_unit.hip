@@ -169,7 +169,7 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
   // the keyframe's own depth + colour (+ quality) ...  With local frames behind it and no quality image the pass is the
   // first frame of the group kernel's visit (k_integrate_group<., KEY>), not a launch of its own.
   const bool color = img.rgba != nullptr, quality = color && img.quality != nullptr;
-  const bool key_in_group = g->n_local > 0 && color && !quality;
+  const bool key_in_group = g->n_local > 0 && color;  // (round 6: with a quality image too -- k_integrate_group<., KEY, QUAL>)
   if (!key_in_group) launch_integrate(d, img, v->cam, v->ig, P, v->res, flag, color, quality, 0, s, true);
   // chunk->observations[keyframeID] for BOTH flags (Chisel.h:244-247): recorded by the group kernel's waves ahead of their
   // own work, by a launch of its own when the group has no local frame

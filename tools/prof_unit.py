@@ -28,6 +28,7 @@ STRIDE = 7
 ORBIT = 200
 WARM = 6
 N_KF = 20
+QUALITY_PTR = [0]  # --quality: every keyframe carries this quality image (one device image: the figure is the pass's time)
 
 
 def frames_and_volume(moved):
@@ -53,13 +54,18 @@ def group_of(capi, dd, dc, poses, g, shift=0, old=False):
     kw = {}
     if old:
         kw = dict(old_keyframe_pose=poses[k0], old_local_poses=[poses[k] for k in loc])
-    return capi.Volume.unit_group(1000 + g, (dd[k0].data_ptr(), dc[k0].data_ptr(), 0, P(k0)),
+    return capi.Volume.unit_group(1000 + g, (dd[k0].data_ptr(), dc[k0].data_ptr(), QUALITY_PTR[0], P(k0)),
                                   [(dd[k].data_ptr(), P(k)) for k in loc], **kw), k0, loc
 
 
-def run(moved):
+def run(moved, quality=False):
     from texturefusion_amd import capi
     cam, res, fr, dd, dc, poses, pinv, vol = frames_and_volume(moved)
+    if quality:
+        import numpy as np
+        import torch
+        q = torch.from_numpy(np.random.default_rng(3).uniform(0.05, 1.0, fr[0][0].shape).astype(np.float32)).to(dd[0].device)
+        QUALITY_PTR[0] = q.data_ptr()
 
     def call(g):
         fresh, k0, _ = group_of(capi, dd, dc, poses, g)
@@ -205,10 +211,11 @@ if __name__ == "__main__":
     ap.add_argument("--count", action="store_true")
     ap.add_argument("--moved", action="store_true", help="one moved keyframe in every other call")
     ap.add_argument("--summarize", nargs=4, metavar=("TRACE", "FETCH", "WRITE", "COUNTS"))
+    ap.add_argument("--quality", action="store_true", help="--run: keyframes with a quality image")
     ap.add_argument("--run-line", default=None, help="--summarize: the un-profiled --run output (wall time per keyframe)")
     a = ap.parse_args()
     if a.run:
-        run(a.moved)
+        run(a.moved, a.quality)
     elif a.count:
         count(a.moved)
     elif a.summarize:
