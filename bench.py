@@ -1596,7 +1596,9 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
             vol.keyframe_unit(fresh=fresh, moved=moved, texture=True, pose_inv16=pinv[k0])
             return len(moved)
 
-        warm = 4
+        # (one turn of the orbit first, untimed -- the figure is the steady state, like the headline behind its pre-roll; timed
+        # from an empty volume the same keyframes cost 196-201 us instead of 176-178: chunk creation)
+        warm = max(4, n_unique // stride)
         for g in range(warm):
             call(g)
         vol.sync()
@@ -1611,7 +1613,7 @@ def keyframe_unit(args, cam, res, d_depth, d_rgba, poses, pinv, n_unique, device
         frames = n_kf * stride + n_moved * 2 * stride  # a moved group is integrated twice (flag 0, flag 1)
         res_out["with_one_moved_keyframe_every_other_call" if with_moved else "new_keyframes_only"] = {
             "keyframes_per_s": n_kf / dt, "ms_per_keyframe": 1e3 * dt / n_kf, "frame_integrations_per_s": frames / dt,
-            "keyframes": n_kf, "moved_groups": n_moved}
+            "keyframes": n_kf, "moved_groups": n_moved, "untimed_keyframes_ahead": warm}
         vol.close()
         time.sleep(0.3)  # (the freed pool is wiped in the background for tens of ms: the next volume's figure should not run into it)
     # ---- the product's own order (MobileFusion::tsdfFusion with its view selection on the host): the unit WITHOUT its texture
