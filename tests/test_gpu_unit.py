@@ -327,10 +327,18 @@ def run_unit_sequence(cam, res, frames, plan, with_q, max_chunks=1 << 17, stride
     if gpu_ahead:
         # every call is enqueued before the oracle starts: the device works through the calls back to back, which is when a
         # call's front end (selection, records) overlaps the previous call's filter || patch stage and mesher (tf_unit.hip)
+        ahead = {}  # kf_id -> (key, loc, current poses): what the moved groups of later calls need (no oracle result)
         for kf_id, key, loc, moves in plan:
-            assert not moves
+            moved = []
+            for mid, shift in moves:
+                mk, ml, mp = ahead[mid]
+                newp = [frames[min(k + shift, len(frames) - 1)][3] for k in [mk] + ml]
+                moved.append(capi.Volume.unit_group(mid, dev_key(mk, newp[0]), [(bufs[k][0].ptr, newp[1 + i]) for i, k in enumerate(ml)],
+                                                    old_keyframe_pose=mp[0], old_local_poses=mp[1:]))
+                ahead[mid] = (mk, ml, newp)
             fresh = capi.Volume.unit_group(kf_id, dev_key(key, frames[key][3]), [(bufs[k][0].ptr, frames[k][3]) for k in loc])
-            gv.keyframe_unit(fresh=fresh, moved=[], texture=True, pose_inv16=synth.pose_inverse16(frames[key][3]))
+            gv.keyframe_unit(fresh=fresh, moved=moved, texture=True, pose_inv16=synth.pose_inverse16(frames[key][3]))
+            ahead[kf_id] = (key, list(loc), [frames[key][3]] + [frames[k][3] for k in loc])
     for kf_id, key, loc, moves in plan:
         moved = []
         for mid, shift in moves:
@@ -404,6 +412,16 @@ def test_keyframe_unit_calls_back_to_back(gpu_required):
     frames = [synth.room_frame(2 * k, cam, with_quality=False, wobble=0.05) for k in range(56)]
     plan = [(100 + g, 7 * g, [7 * g + 1 + i for i in range(6)], []) for g in range(8)]
     assert run_unit_sequence(cam, np.float32(0.006), frames, plan, False, max_chunks=1 << 18, stride=3, gpu_ahead=True) > 1000
+
+
+def test_keyframe_unit_calls_back_to_back_with_moved_keyframes(gpu_required):
+    """... and with a moved keyframe in every other call (the keyframe integrated two calls earlier takes the poses of the frames
+    one further along): the fresh group's selection then runs on the unit's stream beside the moved keyframe's de- and
+    re-integration."""
+    cam = synth.Camera()
+    frames = [synth.room_frame(2 * k, cam, with_quality=False, wobble=0.05) for k in range(44)]
+    plan = [(100 + g, 7 * g, [7 * g + 1 + i for i in range(6)], [(100 + g - 2, 1)] if g >= 2 and g % 2 == 0 else []) for g in range(6)]
+    assert run_unit_sequence(cam, np.float32(0.006), frames, plan, False, max_chunks=1 << 18, stride=3, gpu_ahead=True) > 800
 
 
 @pytest.mark.parametrize("with_q", [True, False])

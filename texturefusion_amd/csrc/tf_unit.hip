@@ -110,15 +110,48 @@ static int unit_state(tf_volume* v, UnitState** out) {
   return TF_OK;
 }
 
+// May the front end of group g leave the handle's stream in this call?  Only when
+//  - the previous entry point called on the handle was a unit call (ev_mut then stands for "every launch that changes chunks is
+//    done" while that call's texture stage is still on the stream; anything else -> everything in stream order),
+//  - the group has local frames (its acquire is the lazy one: it inserts keys but leaves parked chunks parked -- a chunk the
+//    eager form revives is not the same as a parked one to the previous call's filter, a freshly inserted one is
+//    indistinguishable from an absent one to every reader),
+//  - the handle runs on a stream of its own (on a stream of the CALLER's, tf_set_stream, stream order towards whatever the
+//    caller put there itself -- the producers of the group's images, say -- is kept),
+//  - no selection made ahead by a streaming call sits in the ring of selection sets.
+static bool can_fork(const tf_volume* v, const UnitState* u, const tf_unit_group* g) {
+  return u->front && v->own_stream && v->n_primed == 0 && g->n_local > 0 && u->mut_seq + 1 == v->call_seq;
+}
+// The image part of a fresh group's front end -- bounding box and selection: a function of the keyframe's depth image and
+// pose only -- on the unit's stream, into the NEXT selection set, while the handle's stream works through the call's moved
+// keyframes (18 us of two small dependent launches off the critical path of such a call; the set's last users are at least
+// two calls back, i.e. ahead of ev_mut).  integrate_group(front_mode = 2) joins.
+static int front_ahead(tf_volume* v, UnitState* u, const tf_unit_group* g) {
+  VolumeDev dn = v->dev;
+  dn.sel = v->selbuf[(v->cur_sel + 1) % tf_volume::kSelSets];
+  Pose P;
+  memcpy(P.p, g->keyframe.pose, sizeof(P.p));
+  TF_HIP(hipStreamWaitEvent(u->front, u->ev_mut, 0));
+  launch_bbox(dn, g->keyframe.d_depth, v->cam, P, u->front);
+  launch_select(dn, g->keyframe.d_depth, v->cam, v->ig, P, v->res, /*emit=*/true, u->front, /*plain=*/true);
+  TF_HIP(hipGetLastError());
+  TF_HIP(hipEventRecord(u->ev_front, u->front));
+  return TF_OK;
+}
+
 // ReIntegrateKeyframe (MobileFusion.cpp:114-221) for one group with one flag
 // dirty_par >= 0: the group's updated chunks and their face neighbours join the dirty set of that parity, stamped
 // dirty_stamp, as they are finalized (the group kernel's claims into the shard lists; launch_dirty_frame into the flat list
 // for a group without local frames) -- instead of a scan of every chunk's mark later
 // ride_store != nullptr: the group's validChunks are not stored here -- *ride_store receives the arguments and the caller's
 // texture stage takes them along on its filter launch
-// first / last: the group's pass is the first / last one of its tf_keyframe_unit_device call (the front end's own stream)
+// front_mode (flag 1 only) -- 0: the front end on the handle's stream; 1: all of it on the unit's stream, now, behind ev_mut
+// (the first pass of a call that follows another unit call); 2: its image part (bounding box, selection) is running on the
+// unit's stream already, into the NEXT selection set (front_ahead below: the fresh group of a call with moved keyframes) --
+// this pass switches to that set, joins, and runs the records / acquire launch on the handle's stream.
+// last: the pass is the last one of its tf_keyframe_unit_device call (ev_mut is recorded behind it)
 static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, int flag, int kf_slot, int dirty_par = -1,
-                           uint32_t dirty_stamp = 0, KfStoreArgs* ride_store = nullptr, bool first = false, bool last = false) {
+                           uint32_t dirty_stamp = 0, KfStoreArgs* ride_store = nullptr, int front_mode = 0, bool last = false) {
   hipStream_t s = v->stream;
   VolumeDev& d = v->dev;
   FrameImages img{g->keyframe.d_depth, reinterpret_cast<const uchar4*>(g->keyframe.d_rgba), g->keyframe.d_quality};
@@ -126,22 +159,24 @@ static int integrate_group(tf_volume* v, UnitState* u, const tf_unit_group* g, i
   Pose P;
   memcpy(P.p, kpose, sizeof(P.p));
   hipStream_t fs = s;  // the stream of the front end
-  // Worth it only for the FIRST pass of a call that follows another unit call (ev_mut then stands for "every launch that
-  // changes chunks is done" while that call's texture stage is still on the stream); a later pass of the same call has
-  // nothing to overlap, and the two event edges cost 4 us each (profiles/r6/README.md).
-  // (a group WITHOUT local frames acquires its chunks eagerly -- parked ones are revived by the front end itself -- and a
-  // revived chunk is not the same as a parked one to the previous call's filter: such a group stays on the handle's stream;
-  // the lazy form only inserts keys, and a freshly inserted chunk is indistinguishable from an absent one to every reader)
-  // (... and a handle that runs on a stream of the CALLER's (tf_set_stream) keeps stream order towards whatever the caller put
-  // there itself -- the producers of the group's images, say: no fork)
-  if (flag && first && g->n_local > 0 && u->front && v->own_stream && v->n_primed == 0 && u->mut_seq + 1 == v->call_seq) {
+  // Worth it only for the FIRST pass of a call (a later pass of the same call has nothing of another call to overlap, and
+  // the two event edges cost 3-4 us each, profiles/r6/README.md) -- or, its image part, for the fresh group behind moved ones.
+  // (the conditions are can_fork()'s, checked by the caller)
+  if (flag && front_mode) {
     // (no selection made ahead by a streaming call sits in the ring: the next set is free)
     v->cur_sel = (v->cur_sel + 1) % tf_volume::kSelSets;
     d.sel = v->selbuf[v->cur_sel];
-    TF_HIP(hipStreamWaitEvent(u->front, u->ev_mut, 0));
-    fs = u->front;
+    if (front_mode == 1) {
+      TF_HIP(hipStreamWaitEvent(u->front, u->ev_mut, 0));
+      fs = u->front;
+    } else {
+      TF_HIP(hipStreamWaitEvent(s, u->ev_front, 0));  // front_ahead()'s selection is in this set
+    }
   }
-  if (flag) {
+  if (flag && front_mode == 2) {
+    v->frame = img;
+    v->frame_bound = true;
+  } else if (flag) {
     // PrepareIntersectChunks at the keyframe's pose, without its list ORDER: validChunks = the finalized list in list order,
     // and no order of it is observable through this entry point -- the selection appends straight to a plain list, no scan /
     // write-out launch (k_scan: 17 us per keyframe); the slots, isNew and needsUpdate = false come with the records launch below
@@ -314,19 +349,24 @@ int tf_keyframe_unit_device(tf_volume* v, const tf_unit_group* fresh, const tf_u
     dirty_stamp = v->epoch + (uint32_t)(2 * n_moved + (fresh ? 1 : 0));  // = the stage's frame_epoch + 1
   }
   if ((rc = grow_arena_if_needed(v, u, n_moved + (fresh ? 1 : 0)))) return rc;
+  int fresh_front = 0;
+  if (fresh && can_fork(v, u, fresh)) {
+    fresh_front = n_moved == 0 ? 1 : 2;
+    if (fresh_front == 2 && (rc = front_ahead(v, u, fresh))) return rc;
+  }
   // tsdfFusion's loop over keyframesToUpdate (:296-312): retract, de-integrate at the old poses, integrate at the new
   for (int m = 0; m < n_moved; ++m) {
     const int slot = slot_for(moved[m].kf_id, false);
     if (slot < 0) { set_error("a moved keyframe was never integrated through this entry point"); return TF_ERR_INVALID; }
     if ((rc = integrate_group(v, u, &moved[m], 0, slot, dirty_par, dirty_stamp))) return rc;
-    if ((rc = integrate_group(v, u, &moved[m], 1, slot, dirty_par, dirty_stamp, nullptr, false, !fresh && m == n_moved - 1))) return rc;
+    if ((rc = integrate_group(v, u, &moved[m], 1, slot, dirty_par, dirty_stamp, nullptr, 0, !fresh && m == n_moved - 1))) return rc;
   }
   KfStoreArgs ride_store{};
   bool have_ride = false;
   if (fresh) {  // :316-323
     const int slot = slot_for(fresh->kf_id, true);
     if (slot < 0) return TF_ERR_HIP;  // (the table could not grow: hipMalloc's message is in tf_last_error)
-    if ((rc = integrate_group(v, u, fresh, 1, slot, dirty_par, dirty_stamp, texture ? &ride_store : nullptr, n_moved == 0, true))) return rc;
+    if ((rc = integrate_group(v, u, fresh, 1, slot, dirty_par, dirty_stamp, texture ? &ride_store : nullptr, fresh_front, true))) return rc;
     have_ride = ride_store.tab != nullptr;  // (a group without local frames stored with its dirty-set launch)
   }
   if (texture) {
