@@ -15,7 +15,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # kernel name fragment -> (max VGPRs, max scratch bytes per lane); the PRODUCT instances (last template flag false: the
 # tuning instances with time stamps and triage cut-offs are not budgeted)
 BUDGET = {
-    "tf_kernels.hip": {"k_frameILb1ELb0ELb0E": (72, 0), "k_frameILb0ELb0ELb0E": (72, 0), "k_frameILb1ELb1ELb0E": (72, 8)},
+    "tf_kernels.hip": {"k_frameILb1ELb0ELb0E": (72, 0), "k_frameILb0ELb0ELb0E": (72, 0), "k_frameILb1ELb1ELb0E": (72, 8),
+                       "k_scanENS": (64, 0)},  # (the look-back scan of tf_prepare: eight waves per SIMD)
     # (with the keyframe's colour pass on board: the LDS tables allow four waves per SIMD = 128 VGPRs)
     "tf_group.hip": {"k_integrate_groupILb1ELb0E": (96, 0), "k_integrate_groupILb0ELb0E": (96, 0),
                      "k_integrate_groupILb1ELb1E": (128, 0), "k_integrate_groupILb0ELb1E": (128, 0)},
