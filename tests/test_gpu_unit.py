@@ -305,7 +305,7 @@ def test_keyframe_groups_of_every_size(gpu_required, n_local, with_q):
     gv.close()
 
 
-def run_unit_sequence(cam, res, frames, plan, with_q, max_chunks=1 << 17, stride=5, gpu_ahead=False):
+def run_unit_sequence(cam, res, frames, plan, with_q, max_chunks=1 << 17, stride=5, gpu_ahead=False, junk_then_reset=0):
     """A sequence of tf_keyframe_unit_device calls against the oracle driven call by call.  frames[k] = (depth, rgba,
     quality, pose); plan = [(kf_id, key_frame_index, [local frame indices], [(moved kf_id, pose shift)])]: every call
     integrates one new keyframe group, textured with its keyframe, and first moves the listed earlier keyframes -- their
@@ -324,6 +324,14 @@ def run_unit_sequence(cam, res, frames, plan, with_q, max_chunks=1 << 17, stride
 
     state = {}  # kf_id -> {key, loc, poses (current), valid (oracle's validChunks)}
     kfs = {}
+    if junk_then_reset:
+        # unit calls of another "session" first, then tf_volume_reset: the chain of calls (the unit's own stream, its events, the
+        # ring of selection sets, the keyframe store) starts over -- what follows must equal a fresh volume's results
+        for j in range(junk_then_reset):
+            k = len(frames) - 1 - 7 * j
+            grp = capi.Volume.unit_group(9000 + j, dev_key(k - 6, frames[k - 6][3]), [(bufs[k - 5 + i][0].ptr, frames[k - 5 + i][3]) for i in range(6)])
+            gv.keyframe_unit(fresh=grp, moved=[], texture=True, pose_inv16=synth.pose_inverse16(frames[k - 6][3]))
+        gv.reset()
     if gpu_ahead:
         # every call is enqueued before the oracle starts: the device works through the calls back to back, which is when a
         # call's front end (selection, records) overlaps the previous call's filter || patch stage and mesher (tf_unit.hip)
@@ -412,6 +420,15 @@ def test_keyframe_unit_calls_back_to_back(gpu_required):
     frames = [synth.room_frame(2 * k, cam, with_quality=False, wobble=0.05) for k in range(56)]
     plan = [(100 + g, 7 * g, [7 * g + 1 + i for i in range(6)], []) for g in range(8)]
     assert run_unit_sequence(cam, np.float32(0.006), frames, plan, False, max_chunks=1 << 18, stride=3, gpu_ahead=True) > 1000
+
+
+def test_keyframe_unit_calls_after_a_reset(gpu_required):
+    """three unit calls, tf_volume_reset, then the back-to-back sequence: as on a fresh volume"""
+    cam = synth.Camera()
+    frames = [synth.room_frame(2 * k, cam, with_quality=False, wobble=0.05) for k in range(36)]
+    plan = [(100 + g, 7 * g, [7 * g + 1 + i for i in range(6)], []) for g in range(3)]
+    assert run_unit_sequence(cam, np.float32(0.006), frames, plan, False, max_chunks=1 << 18, stride=3, gpu_ahead=True,
+                             junk_then_reset=2) > 500
 
 
 def test_keyframe_unit_calls_back_to_back_with_moved_keyframes(gpu_required):
