@@ -42,6 +42,19 @@ def test_a_drifting_surface_reuses_the_blocks_it_left(gpu_required):
     gv.close()
 
 
+def test_the_large_pool_recycles_too(gpu_required):
+    """Small blocks of 64 vertices / 64 triangles: a planar wall's meshes (81 / 128) all live in the LARGE pool.  2000 large
+    blocks carry the drifting wall's 2884 meshes the same way."""
+    cam = synth.Camera()
+    res = np.float32(0.005)
+    ov = O.Volume(res, O.camera_from(cam), O.default_integrator())
+    oa = O.Atlas(res)
+    gv = capi.Volume(res, cam, max_chunks=1 << 14, mesh_max_vertices=64, mesh_max_triangles=64, mesh_overflow_blocks=2000)
+    _drift(gv, ov, oa, 14)
+    assert _compare_all(ov, gv, "drifting wall, large pool") > 2500
+    gv.close()
+
+
 def test_the_store_still_reports_exhaustion(gpu_required):
     """Fewer blocks than meshes that hold vertices at ONE moment: TF_ERR_CAPACITY with the message that names the knob."""
     cam = synth.Camera()
